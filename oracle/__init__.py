@@ -1,0 +1,26 @@
+"""CPU oracle for the mlx-audio hot path (TEST INFRASTRUCTURE ONLY).
+
+Nothing under ``oracle/`` is product code.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it,
+and only as the checker / the reported CPU baseline -- never as the thing that
+is measured or shipped.  ``mlx_audio_amd`` must not import this package.
+
+The reference (``/root/reference``, Blaizzy/mlx-audio v0.5.0) is 100 % Python on
+top of the external ``mlx`` runtime (pinned ``mlx 0.31.2``, ``uv.lock:930-931``),
+which is not installed in this image and is not vendored in the reference tree.
+The oracle therefore *restates* the reference's algorithms in numpy (dsp,
+fp64/fp32) and PyTorch-CPU fp32 (model blocks), each function citing the
+reference file:line it follows.
+
+Pinning status
+--------------
+* ``dsp_ref`` (windows / stft / istft / mel_filters / ISTFTCache / mel front
+  ends), ``interp_ref`` and the weight-normed transposed convolution are pinned
+  against every known-answer vector the reference's own tests hold for this
+  path (``tests/golden/*.json``, transcribed with file:line citations; checked
+  in ``tests/test_oracle_golden.py``).
+* ``kokoro_ref`` end-to-end (tokens -> waveform): **parity unpinned** -- the
+  reference holds no golden audio/token/logit fixture for Kokoro and cannot be
+  run here (``import mlx`` fails).  Its building blocks are pinned individually
+  by the vectors above; the composition follows the reference code line by line.
+"""

@@ -1,0 +1,316 @@
+"""numpy restatement of the reference's DSP front/back ends (TEST ORACLE, not product).
+
+Follows ``/root/reference/mlx_audio/dsp.py`` (windows :39-94, stft :385-433,
+istft :436-513, mel_filters :519-609, ISTFTCache :612-752) and the two mel
+front ends that sit directly on top of it
+(``stt/models/whisper/audio.py:41-82``, ``tts/models/qwen3_tts/qwen3_tts.py:64-120``).
+
+The reference delegates the FFT itself to ``mx.fft.rfft/irfft`` (mlx 0.31.2, not
+vendored); here it is ``numpy.fft`` evaluated in float64 and rounded once to
+float32/complex64, which is the correctly-rounded value any fp32 FFT
+approximates.  Everything else mirrors the reference's float32 arithmetic.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Union
+
+import numpy as np
+
+F32 = np.float32
+
+
+# --------------------------------------------------------------------------- windows
+def hanning(size: int, periodic: bool = False) -> np.ndarray:
+    """dsp.py:39-50: 0.5*(1-cos(2*pi*n/denom)), denom=N (periodic) or N-1."""
+    denom = size if periodic else size - 1
+    return np.asarray(
+        [0.5 * (1 - math.cos(2 * math.pi * n / denom)) for n in range(size)], dtype=F32
+    )
+
+
+def hamming(size: int, periodic: bool = False) -> np.ndarray:
+    """dsp.py:53-65."""
+    denom = size if periodic else size - 1
+    return np.asarray(
+        [0.54 - 0.46 * math.cos(2 * math.pi * n / denom) for n in range(size)], dtype=F32
+    )
+
+
+def blackman(size: int, periodic: bool = False) -> np.ndarray:
+    """dsp.py:68-80."""
+    denom = size if periodic else size - 1
+    return np.asarray(
+        [
+            0.42
+            - 0.5 * math.cos(2 * math.pi * n / denom)
+            + 0.08 * math.cos(4 * math.pi * n / denom)
+            for n in range(size)
+        ],
+        dtype=F32,
+    )
+
+
+def bartlett(size: int, periodic: bool = False) -> np.ndarray:
+    """dsp.py:83-87."""
+    denom = size if periodic else size - 1
+    return np.asarray([1 - 2 * abs(n - denom / 2) / denom for n in range(size)], dtype=F32)
+
+
+STR_TO_WINDOW_FN = {
+    "hann": hanning,
+    "hanning": hanning,
+    "hamming": hamming,
+    "blackman": blackman,
+    "bartlett": bartlett,
+}
+
+
+def _resolve_window(window, length: int, for_istft: bool) -> np.ndarray:
+    if isinstance(window, str):
+        fn = STR_TO_WINDOW_FN.get(window.lower())
+        if fn is None:
+            raise ValueError(f"Unknown window function: {window}")
+        # dsp.py:403 (stft: symmetric fn(win_length)) vs dsp.py:472
+        # (istft: fn(win_length+1)[:-1] == periodic)
+        return fn(length + 1)[:-1] if for_istft else fn(length)
+    return np.asarray(window, dtype=F32)
+
+
+# --------------------------------------------------------------------------- stft
+def stft(
+    x,
+    n_fft: int = 800,
+    hop_length: Optional[int] = None,
+    win_length: Optional[int] = None,
+    window: Union[str, np.ndarray] = "hann",
+    center: bool = True,
+    pad_mode: str = "reflect",
+) -> np.ndarray:
+    """dsp.py:385-433.  1-D float32 ``x`` -> complex64 ``[n_frames, n_fft//2+1]``."""
+    x = np.asarray(x, dtype=F32)
+    if hop_length is None:
+        hop_length = n_fft // 4
+    if win_length is None:
+        win_length = n_fft
+    w = _resolve_window(window, win_length, for_istft=False)
+    if w.shape[0] < n_fft:  # right zero-pad the window (dsp.py:408-410)
+        w = np.concatenate([w, np.zeros(n_fft - w.shape[0], dtype=F32)])
+    if center:
+        p = n_fft // 2
+        if pad_mode == "constant":
+            x = np.concatenate([np.zeros(p, F32), x, np.zeros(p, F32)])
+        elif pad_mode == "reflect":
+            x = np.concatenate([x[1 : p + 1][::-1], x, x[-(p + 1) : -1][::-1]])
+        else:
+            raise ValueError(f"Invalid pad_mode {pad_mode}")
+    n_frames = 1 + (x.shape[0] - n_fft) // hop_length
+    if n_frames <= 0:
+        raise ValueError(
+            f"Input is too short (length={x.shape[0]}) for n_fft={n_fft} with "
+            f"hop_length={hop_length} and center={center}."
+        )
+    idx = np.arange(n_frames)[:, None] * hop_length + np.arange(n_fft)[None, :]
+    frames = (x[idx] * w[None, :]).astype(F32)  # fp32 product, as frames*w in fp32
+    return np.fft.rfft(frames.astype(np.float64), axis=-1).astype(np.complex64)
+
+
+# --------------------------------------------------------------------------- istft
+def istft(
+    x,
+    hop_length: Optional[int] = None,
+    win_length: Optional[int] = None,
+    window: Union[str, np.ndarray] = "hann",
+    center: bool = True,
+    length: Optional[int] = None,
+    normalized: bool = False,
+) -> np.ndarray:
+    """dsp.py:436-513.  complex ``[n_fft//2+1, n_frames]`` -> float32 signal."""
+    x = np.asarray(x)
+    if win_length is None:
+        win_length = (x.shape[1] - 1) * 2  # sic: reference uses axis 1 (dsp.py:463)
+    if hop_length is None:
+        hop_length = win_length // 4
+    w = _resolve_window(window, win_length, for_istft=True)
+    if w.shape[0] < win_length:
+        w = np.concatenate([w, np.zeros(win_length - w.shape[0], dtype=F32)])
+    n_frames = x.shape[1]
+    total = (n_frames - 1) * hop_length + win_length
+    frames = np.fft.irfft(x.astype(np.complex128), axis=0).T.astype(F32)  # [frames, n]
+    recon = np.zeros(total, dtype=F32)
+    wsum = np.zeros(total, dtype=F32)
+    wnorm = (w * w).astype(F32) if normalized else w
+    contrib = (frames * w[None, :]).astype(F32)
+    # scatter-add in frame order (dsp.py:499-500); fp32 accumulation
+    for f in range(n_frames):
+        s = f * hop_length
+        recon[s : s + win_length] += contrib[f]
+        wsum[s : s + win_length] += wnorm
+    ok = wsum > 1e-10
+    recon = np.where(ok, recon / np.where(ok, wsum, 1), recon).astype(F32)
+    if center and length is None:
+        recon = recon[win_length // 2 : -win_length // 2]
+    if length is not None:
+        recon = recon[:length]
+    return recon
+
+
+# --------------------------------------------------------------------------- mel filterbank
+def mel_filters(
+    sample_rate: int,
+    n_fft: int,
+    n_mels: int,
+    f_min: float = 0,
+    f_max: Optional[float] = None,
+    norm: Optional[str] = None,
+    mel_scale: Optional[str] = "htk",
+    precise: bool = False,
+) -> np.ndarray:
+    """dsp.py:519-609.  Returns float32 ``[n_mels, n_fft//2+1]``.
+
+    ``mel_scale`` anything other than "htk" (including ``None``) selects Slaney
+    (dsp.py:541).  ``precise`` builds in float64 then casts (dsp.py:605-608).
+    """
+    dt = np.float64 if precise else F32
+
+    def hz_to_mel(freq: float) -> float:
+        if mel_scale == "htk":
+            return 2595.0 * math.log10(1.0 + freq / 700.0)
+        f_sp = 200.0 / 3
+        mels = freq / f_sp
+        if freq >= 1000.0:
+            mels = 1000.0 / f_sp + math.log(freq / 1000.0) / (math.log(6.4) / 27.0)
+        return mels
+
+    def mel_to_hz(m: np.ndarray) -> np.ndarray:
+        if mel_scale == "htk":
+            return (700.0 * (10.0 ** (m / dt(2595.0)) - 1.0)).astype(dt)
+        f_sp = 200.0 / 3
+        min_log_mel = 1000.0 / f_sp
+        logstep = math.log(6.4) / 27.0
+        lin = (dt(f_sp) * m).astype(dt)
+        log = (dt(1000.0) * np.exp(dt(logstep) * (m - dt(min_log_mel)))).astype(dt)
+        return np.where(m >= min_log_mel, log, lin).astype(dt)
+
+    f_max = f_max or sample_rate / 2
+    n_freqs = n_fft // 2 + 1
+    all_freqs = np.linspace(0, sample_rate // 2, n_freqs).astype(dt)
+    m_pts = np.linspace(hz_to_mel(f_min), hz_to_mel(f_max), n_mels + 2).astype(dt)
+    f_pts = mel_to_hz(m_pts)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts[None, :] - all_freqs[:, None]  # [n_freqs, n_mels+2]
+    down = (-slopes[:, :-2]) / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    fb = np.maximum(dt(0), np.minimum(down, up)).astype(dt)
+    if norm == "slaney":
+        enorm = dt(2.0) / (f_pts[2 : n_mels + 2] - f_pts[:n_mels])
+        fb = (fb * enorm[None, :]).astype(dt)
+    return np.ascontiguousarray(fb.T).astype(F32)
+
+
+# --------------------------------------------------------------------------- ISTFTCache
+class ISTFTCache:
+    """dsp.py:612-752: batched irfft + w**2 overlap-add with cached normaliser."""
+
+    def __init__(self):
+        self.norm_buffer_cache = {}
+        self.position_cache = {}
+
+    def get_positions(self, num_frames, frame_length, hop_length):
+        key = (num_frames, frame_length, hop_length)
+        if key not in self.position_cache:
+            pos = np.arange(num_frames)[:, None] * hop_length + np.arange(frame_length)[None, :]
+            self.position_cache[key] = pos.reshape(-1)
+        return self.position_cache[key]
+
+    def get_norm_buffer(self, n_fft, hop_length, win_length, window, num_frames):
+        key = (n_fft, hop_length, win_length, hash(tuple(np.asarray(window).tolist())), num_frames)
+        if key not in self.norm_buffer_cache:
+            flen = window.shape[0]
+            ola = (num_frames - 1) * hop_length + flen
+            buf = np.zeros(ola, dtype=F32)
+            w2 = (window.astype(F32) ** 2).astype(F32)
+            for f in range(num_frames):
+                buf[f * hop_length : f * hop_length + flen] += w2
+            self.norm_buffer_cache[key] = np.maximum(buf, F32(1e-10))
+        return self.norm_buffer_cache[key]
+
+    def istft(
+        self,
+        real_part,
+        imag_part,
+        n_fft,
+        hop_length,
+        win_length,
+        window,
+        center=True,
+        audio_length=None,
+        constrain_value_range=False,
+    ):
+        real_part = np.asarray(real_part, dtype=F32)
+        imag_part = np.asarray(imag_part, dtype=F32)
+        window = np.asarray(window, dtype=F32)
+        if window.shape[0] < n_fft:
+            window = np.concatenate([window, np.zeros(n_fft - window.shape[0], F32)])
+        spec = real_part.astype(np.float64) + 1j * imag_part.astype(np.float64)
+        frames = np.fft.irfft(spec.transpose(0, 2, 1), n=n_fft, axis=-1).astype(F32)
+        if constrain_value_range:
+            frames = np.clip(frames, -window, window)
+        frames = (frames * window).astype(F32)
+        bsz, nfr, flen = frames.shape
+        ola = (nfr - 1) * hop_length + flen
+        norm = self.get_norm_buffer(n_fft, hop_length, win_length, window, nfr)
+        out = np.zeros((bsz, ola), dtype=F32)
+        for f in range(nfr):
+            out[:, f * hop_length : f * hop_length + flen] += frames[:, f]
+        out = (out / norm[None, :]).astype(F32)
+        if center:
+            out = out[:, n_fft // 2 :]
+        if audio_length is not None:
+            out = out[:, :audio_length]
+        return out
+
+    def clear_cache(self):
+        self.norm_buffer_cache.clear()
+        self.position_cache.clear()
+
+
+# --------------------------------------------------------------------------- mel front ends
+def whisper_log_mel(audio, n_mels: int = 80, padding: int = 0) -> np.ndarray:
+    """stt/models/whisper/audio.py:41-82 -> float32 ``[n_frames, n_mels]``."""
+    audio = np.asarray(audio, dtype=F32)
+    if padding > 0:
+        audio = np.concatenate([audio, np.zeros(padding, F32)])
+    spec = stft(audio, window=hanning(400), n_fft=400, hop_length=160)
+    mags = (np.abs(spec[:-1, :]).astype(F32) ** 2).astype(F32)
+    fb = mel_filters(16000, 400, n_mels, norm="slaney", mel_scale=None)
+    mel = (mags @ fb.T).astype(F32)
+    log_spec = np.log10(np.maximum(mel, F32(1e-10))).astype(F32)
+    log_spec = np.maximum(log_spec, log_spec.max() - F32(8.0))
+    return ((log_spec + F32(4.0)) / F32(4.0)).astype(F32)
+
+
+def qwen3_mel_spectrogram(
+    audio,
+    n_fft: int = 1024,
+    num_mels: int = 128,
+    sample_rate: int = 24000,
+    hop_size: int = 256,
+    win_size: int = 1024,
+    fmin: float = 0.0,
+    fmax: float = 12000.0,
+) -> np.ndarray:
+    """tts/models/qwen3_tts/qwen3_tts.py:64-120 -> float32 ``[B, frames, num_mels]``."""
+    audio = np.asarray(audio, dtype=F32)
+    if audio.ndim == 1:
+        audio = audio[None, :]
+    fb = mel_filters(sample_rate, n_fft, num_mels, fmin, fmax, norm="slaney", mel_scale="slaney")
+    pad = (n_fft - hop_size) // 2
+    outs = []
+    for s in audio:
+        s = np.concatenate([s[1 : pad + 1][::-1], s, s[-(pad + 1) : -1][::-1]])
+        spec = stft(s, n_fft=n_fft, hop_length=hop_size, win_length=win_size, window="hann", center=False)
+        mag = np.sqrt((np.abs(spec).astype(F32) ** 2 + F32(1e-9)).astype(F32)).astype(F32)
+        mel = (mag @ fb.T).astype(F32)
+        outs.append(np.log(np.clip(mel, F32(1e-5), None)).astype(F32))
+    return np.stack(outs, axis=0)

@@ -1,0 +1,105 @@
+"""Pins the CPU oracle against every known-answer vector the reference's own tests
+hold for the hot path."""
+import numpy as np
+import torch
+
+from oracle import dsp_ref, interp_ref, kokoro_ref
+
+
+def test_qwen3_mel_golden(golden):
+    g = golden["qwen3_mel_spectrogram"]
+    np.random.seed(42)
+    audio = np.random.randn(12000).astype(np.float32)
+    mel = dsp_ref.qwen3_mel_spectrogram(audio)
+    assert list(mel.shape) == g["shape"]
+    m = mel[0]
+    kw = dict(rtol=g["rtol"], atol=g["atol"])
+    np.testing.assert_allclose(m[0, g["bins"]], g["frame0"], **kw)
+    np.testing.assert_allclose(m[23, g["bins"]], g["frame23"], **kw)
+    np.testing.assert_allclose(m[-1, g["bins"]], g["frame_last"], **kw)
+    np.testing.assert_allclose(mel.mean(), g["mean"], **kw)
+    np.testing.assert_allclose(mel.std(), g["std"], **kw)
+    t = np.arange(12000, dtype=np.float32) / 24000.0
+    s = dsp_ref.qwen3_mel_spectrogram(np.sin(2 * np.pi * 1000 * t).astype(np.float32))[0]
+    np.testing.assert_allclose(s[0, g["sine_1khz"]["bins"]], g["sine_1khz"]["frame0"], **kw)
+
+
+def test_conv_transpose_weight_norm_golden(golden):
+    g = golden["conv_transpose_weight_norm"]
+    w = {"c.weight_v": torch.tensor(g["weight_v"]).view(1, 3, 1),
+         "c.weight_g": torch.tensor([g["weight_g_squared"] ** 0.5]).view(1, 1, 1)}
+    p = kokoro_ref.P(w, "c.", param_dtype=torch.float32)
+    x = torch.tensor(g["x"]).view(1, 1, 4)  # NCL
+    y = kokoro_ref.conv_weighted(p, x, transpose=True, stride=g["stride"], padding=g["padding"])[:, :, g["drop_first"]:]
+    np.testing.assert_allclose(y.reshape(-1).numpy(), g["expected"], rtol=g["rtol"])
+
+
+def test_mlxstft_roundtrip_golden(golden):
+    g = golden["mlxstft_roundtrip"]
+    t = np.arange(g["length"], dtype=np.float32)
+    x = (g["amp"] * np.sin(2 * np.pi * g["freq_hz"] * t / g["sr"])).astype(np.float32)
+    mp = kokoro_ref.stft_mag_phase(x[None], g["n_fft"], g["hop"])  # [1, 22, frames]
+    nb = g["n_fft"] // 2 + 1
+    mag, ph = mp[0, :nb], mp[0, nb:]
+    spec = mag * np.cos(ph) + 1j * mag * np.sin(ph)
+    rec = dsp_ref.istft(spec, hop_length=g["hop"], win_length=g["n_fft"],
+                        window=dsp_ref.hanning(g["n_fft"], periodic=True), center=True, normalized=True)
+    rec = rec[: x.shape[0]]
+    e = g["edge"]
+    np.testing.assert_allclose(rec[e:-e], x[e:-e], atol=g["atol"])
+    # and the plain-window normalisation attenuates by sum(w^2)/sum(w) = 0.75 (istftnet.py:524-531)
+    rec2 = dsp_ref.istft(spec, hop_length=g["hop"], win_length=g["n_fft"],
+                         window=dsp_ref.hanning(g["n_fft"], periodic=True), center=True, normalized=False)
+    np.testing.assert_allclose(rec2[e:-e][: len(x) - 2 * e], 0.75 * x[e:-e], atol=g["atol"])
+
+
+def test_interpolate_golden(golden):
+    g = golden["interpolate"]
+    x = np.array(g["nearest_in"], np.float32)[None, None]
+    np.testing.assert_allclose(interp_ref.interpolate1d(x, 8, "nearest")[0, 0], g["nearest_up8"], rtol=g["rtol"])
+    np.testing.assert_allclose(interp_ref.interpolate1d(x, 2, "nearest")[0, 0], g["nearest_down2"], rtol=g["rtol"])
+    y = np.array(g["linear_in"], np.float32)[None, None]
+    np.testing.assert_allclose(interp_ref.interpolate1d(y, 7, "linear", True)[0, 0], g["linear_ac_true_7"], rtol=g["rtol"])
+    np.testing.assert_allclose(interp_ref.interpolate1d(y, 7, "linear", False)[0, 0], g["linear_ac_false_7"], rtol=g["rtol"])
+    one = np.array([[[5.0]]], np.float32)
+    np.testing.assert_allclose(interp_ref.interpolate1d(one, 4, "linear")[0, 0], [5.0] * 4)
+    assert interp_ref.interpolate(np.zeros((2, 3, 4), np.float32), scale_factor=2).shape == (2, 3, 8)
+
+
+def test_sinegen_shapes_golden(golden):
+    g = golden["sinegen_shapes"]
+    # length-2 f0 at 120 Hz: down-sampling by 300 gives ceil(2/300)=1 coarse step, up-sampling 300
+    # values, truncated back to the f0 length (istftnet.py:620-628)
+    small = interp_ref.output_size(g["length"], scale_factor=1 / g["upsample_scale"])
+    big = interp_ref.output_size(small, scale_factor=g["upsample_scale"])
+    assert small == 1 and big == 300
+
+
+def test_istft_cache_bound_golden(golden):
+    g = golden["istft_cache_bound"]
+    rng = np.random.default_rng(0)
+    real = rng.normal(size=(2, 9, 8)).astype(np.float32) * 8.0
+    imag = rng.normal(size=(2, 9, 8)).astype(np.float32) * 8.0
+    win = dsp_ref.hanning(g["n_fft"], periodic=True)
+    c = dsp_ref.ISTFTCache()
+    a = c.istft(real, imag, g["n_fft"], g["hop"], g["n_fft"], win, center=False)
+    b = c.istft(real, imag, g["n_fft"], g["hop"], g["n_fft"], win, center=False, constrain_value_range=True)
+    assert np.abs(a - b).max() > g["min_diff"]
+    assert np.abs(b).max() <= g["bound"]
+
+
+def test_windows_symmetric_vs_periodic():
+    # stft's "hann" is symmetric, istft's is periodic (dsp.py:403 vs :472)
+    np.testing.assert_allclose(dsp_ref.hanning(8)[-1], 0.0, atol=1e-7)
+    assert dsp_ref.hanning(8, periodic=True)[-1] > 0.1
+    np.testing.assert_allclose(dsp_ref.hanning(9)[:-1], dsp_ref.hanning(8, periodic=True), atol=1e-7)
+
+
+def test_mel_filters_shapes_and_scale():
+    fb = dsp_ref.mel_filters(16000, 400, 80, norm="slaney", mel_scale=None)
+    assert fb.shape == (80, 201) and fb.dtype == np.float32
+    assert dsp_ref.mel_filters(16000, 400, 80, norm="slaney", mel_scale="slaney").tobytes() == fb.tobytes()
+    p = dsp_ref.mel_filters(16000, 400, 80, norm="slaney", mel_scale=None, precise=True)
+    assert np.abs(p - fb).max() < 1e-4
+    w = dsp_ref.whisper_log_mel(np.random.default_rng(0).standard_normal(16000).astype(np.float32), padding=1600)
+    assert w.shape == (110, 80)
