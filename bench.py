@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""Headline benchmark: audio samples/sec + real-time factor, Kokoro-82M TTS on MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` (N>1 under
+``python -m torch.distributed.run``, one rank per GPU, RCCL).  One "step" = one pass of the hot path
+(tokens -> waveform, ``Model.__call__`` of the reference, kokoro.py:111-177) over one batch of
+synthetic utterances per GPU: BASELINE.json config[1], "Kokoro-82M bf16 TTS on 1 MI355X".  Each
+utterance is the canonical short sentence of BASELINE.md: 78 phonemes (T = 80 tokens), durations
+forced to 264 frames -> 158 400 samples = 6.6 s at 24 kHz.  Weights: seeded random, bf16-valued, in
+the exact Kokoro-82M shapes (no network => no checkpoint).  Inputs (token ids, voice rows, SineGen
+noise) are resident in HBM before the timed region.
+
+Rank 0 prints ONE JSON line; see DESIGN.md section "Measurement" for every field.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SAMPLES_PER_UTT = 158400
+T_TOKENS, F_FRAMES = 80, 264
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA
+HBM_PEAK_GBS = 8000.0            # same guide: HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
+    ap.add_argument("--precision", type=int, default=2, help="2 = bf16 hi+lo split MFMA (fp32-grade), 1 = single bf16 pass")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--shape-table", default="", help="write the per-shape conv_gemm timing table (roofline leg) to this file")
+    return ap.parse_args()
+
+
+def make_inputs(S, B, seed, dev):
+    voice = S.make_voice_pack()
+    ids = [S.make_phoneme_ids(T_TOKENS - 2, seed=seed * 1000 + i) for i in range(B)]
+    ref_s = torch.cat([voice[T_TOKENS - 3] for _ in range(B)], 0)
+    fds = [S.forced_durations(T_TOKENS, F_FRAMES, seed=seed * 1000 + i) for i in range(B)]
+    rng = np.random.default_rng(1234 + seed)
+    rand_ini = torch.from_numpy(rng.uniform(size=(B, 9)).astype(np.float32)).to(dev)
+    g = torch.Generator(device=dev).manual_seed(1234 + seed)
+    noise = torch.randn((B, 2 * F_FRAMES * 300, 9), generator=g, device=dev, dtype=torch.float32)
+    return ids, ref_s.to(dev), fds, rand_ini, noise
+
+
+def cpu_baseline(S):
+    """The oracle (restated reference, PyTorch-CPU fp32) on this host's cores: one canonical utterance."""
+    from oracle.kokoro_ref import KokoroRef
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ref = KokoroRef(S.make_kokoro_weights(), S.KOKORO_CONFIG)
+    ids = S.make_phoneme_ids(T_TOKENS - 2, seed=0)
+    ref_s = S.make_voice_pack()[T_TOKENS - 3]
+    fd = S.forced_durations(T_TOKENS, F_FRAMES, seed=0)
+    ref.forward(ids, ref_s, pred_dur=fd)  # warm-up
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ref.forward(ids, ref_s, pred_dur=fd)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": SAMPLES_PER_UTT / med, "unit": "samples/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": "1 utterance (T=80, F=264, 158400 samples), 1 warm-up + median of 3; restated reference "
+                      "(oracle/kokoro_ref.py, PyTorch-CPU fp32), not MLX",
+            "x_realtime": SAMPLES_PER_UTT / 24000.0 / med}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    elif args.gpus > 1:
+        print("bench.py: --gpus > 1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from mlx_audio_amd import ops
+    from mlx_audio_amd.tts.models.kokoro import synthetic as S
+    from mlx_audio_amd.tts.models.kokoro.engine import KokoroEngine
+
+    eng = KokoroEngine(S.make_kokoro_weights(), S.KOKORO_CONFIG, device=dev, precision=args.precision)
+    B = args.batch
+    ids, ref_s, fds, rand_ini, noise = make_inputs(S, B, rank, dev)
+    ids_dev = torch.stack(ids).to(torch.int32).to(dev)
+
+    def step():
+        if world > 1:
+            # utterance sharding: rank 0 owns the request batch -> broadcast ids, compute the local shard,
+            # gather waveforms on rank 0 (RCCL over xGMI; the only collectives of the path)
+            allids = torch.empty((world, B, T_TOKENS), dtype=torch.int32, device=dev)
+            if rank == 0:
+                allids[:] = ids_dev
+            dist.broadcast(allids, 0)
+            mine = [allids[rank, i].long() for i in range(B)]
+        else:
+            mine = ids
+        outs, _ = eng.forward(mine, ref_s, forced_durations=fds, rand_ini=rand_ini, noise=noise)
+        if world > 1:
+            a = torch.stack(outs)
+            gl = [torch.empty_like(a) for _ in range(world)] if rank == 0 else None
+            dist.gather(a, gl, dst=0)
+        return outs
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        outs = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert all(o.numel() == SAMPLES_PER_UTT for o in outs)
+    assert all(bool(torch.isfinite(o).all()) for o in outs)
+
+    res = None
+    if rank == 0:
+        total_samples = SAMPLES_PER_UTT * B * world * args.steps
+        value = total_samples / dt
+        res = {
+            "metric": "audio samples/sec + real-time factor, Kokoro-82M TTS", "value": value, "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 weights x fp32 activations (bf16 hi+lo split MFMA, fp32 accumulate)" if args.precision == 2 else "bf16",
+            "data": "synthetic",
+            "config": {"workload": "Kokoro-82M bf16 TTS, tokens->waveform, canonical short sentence T=80 F=264 (6.6 s @ 24 kHz)",
+                       "utterances_per_gpu": B, "global_batch": B * world, "samples_per_utterance": SAMPLES_PER_UTT,
+                       "parallelism": f"utterance-dp{world}", "precision_mode": args.precision},
+            "x_realtime": value / 24000.0, "rtf_reference_style": 24000.0 / value,
+        }
+    # ---- roofline leg (rank 0, N=1 only): one extra instrumented step, events around every conv_gemm launch
+    if rank == 0 and world == 1 and not args.no_roofline:
+        ops.PROFILE = []
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        step()
+        e1.record()
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        if args.shape_table:
+            agg = {}
+            for fl, by, a0, a1, shp in prof:
+                e = agg.setdefault(shp[:4], [0, 0.0, 0.0, 0])
+                e[0] += 1; e[1] += a0.elapsed_time(a1); e[2] += fl; e[3] = shp[4]
+            with open(args.shape_table, "w") as f:
+                f.write("cin cout k dil rows launches ms gflop tflops\n")
+                for shp, e in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                    f.write(f"{shp[0]} {shp[1]} {shp[2]} {shp[3]} {e[3]} {e[0]} {e[1]:.3f} {e[2] / 1e9:.2f} {e[2] / (e[1] * 1e-3) / 1e12:.1f}\n")
+        flops = sum(p[0] for p in prof)
+        byts = sum(p[1] for p in prof)
+        ms = sum(p[2].elapsed_time(p[3]) for p in prof)
+        res["roofline"] = {
+            "bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv1d/convT/linear, v_mfma_f32_32x32x16_bf16)",
+            "achieved": flops / (ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+            "launches_per_step": len(prof), "algorithmic_gflop_per_step": flops / 1e9,
+            "conv_gemm_ms_per_step": ms, "instrumented_step_ms": e0.elapsed_time(e1),
+            "hbm_view": {"algorithmic_GB_per_step": byts / 1e9, "achieved_GBps": byts / (ms * 1e-3) / 1e9,
+                         "peak_GBps": HBM_PEAK_GBS, "frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "note": "arithmetic intensity of the conv stack (~330-650 FLOP/B) is above the bf16 ridge (~312), so MFMA is the "
+                    "binding roofline; the HBM view is reported alongside (DESIGN.md)",
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(S)
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,309 @@
+/*
+ * mi355audio.h -- C ABI of libmi355audio.so, the MI355X (gfx950 / CDNA4) kernel library
+ * under the mlx-audio hot path (Kokoro-82M TTS: PL-BERT, bi-LSTM prosody predictor,
+ * AdaIN / iSTFTNet vocoder; mlx_audio.dsp STFT / iSTFT / mel).
+ *
+ * The reference (Blaizzy/mlx-audio v0.5.0) has no FFI of its own: its operator boundary is the
+ * Python `mlx.core` API.  Each entry point below therefore names the
+ * `mlx.core` / `mlx.nn` call sites it replaces (file:line relative to the reference tree); the
+ * Python layer `mlx_audio_amd` binds them with ctypes exactly as INTEGRATION.md shows.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the field name ends in `_host`;
+ *   - activations are float32, channels-last: element (b, l, c) of a tensor lives at
+ *     base + b*bstride + l*ld + c   (the NLC layout mx.conv1d uses), ld >= C;
+ *   - `lens` (nullable) holds the valid row count of every batch item (ragged batches are padded
+ *     to a common L; rows >= lens[b] read as zeros and are never written);
+ *   - weights are bfloat16, pre-packed by mi355_pack_* into MFMA fragment order;
+ *   - `stream` is a hipStream_t passed as void*; all functions are asynchronous on it;
+ *   - return value: 0 = ok, negative = error (text via mi355_last_error()); nothing is allocated,
+ *     no global state is kept, distinct streams may be driven from distinct host threads.
+ */
+#ifndef MI355AUDIO_H
+#define MI355AUDIO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_OK 0
+#define MI355_ERR_ARG (-1)
+#define MI355_ERR_LAUNCH (-2)
+#define MI355_ERR_UNSUPPORTED (-3)
+
+const char* mi355_last_error(void);
+/* ABI version of this header; bumped on any struct change. */
+int mi355_abi_version(void);
+/* Name/arch/CU count of device `dev` into caller buffers (used by bench.py). */
+int mi355_device_info(int dev, char* name, int name_cap, int* cu_count, int* lds_bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * conv_gemm: conv1d / linear / polyphase conv_transpose1d as an implicit GEMM on MFMA
+ * (v_mfma_f32_32x32x16_bf16; fp32 activations split on the fly into bf16 hi+lo so that the
+ * result keeps ~16 mantissa bits, weights bf16).
+ * Replaces: mx.conv1d / mx.conv_transpose1d in ConvWeighted (tts/models/kokoro/istftnet.py:
+ * 128-170), nn.Conv1d (istftnet.py:771-786), nn.Linear (modules.py:15,60-90,477-600,
+ * kokoro.py:84), the per-step x-projection mx.addmm of LSTM (modules.py:156-163), and the fused
+ * neighbours the reference runs as separate MLX ops: AdaIN affine + Snake / LeakyReLU in front
+ * (istftnet.py:337,379-380,907-908,818), bias / residual / scaling behind (istftnet.py:394,932,
+ * 822,829).
+ * ------------------------------------------------------------------------------------------ */
+enum { MI355_ACT_NONE = 0, MI355_ACT_LEAKY = 1, MI355_ACT_SNAKE = 2, MI355_ACT_GELU = 3 };
+
+typedef struct {
+  /* input activation */
+  const float* x;      /* [B, Lin, ldx] */
+  int64_t x_bstride;   /* elements between batch items */
+  int32_t ldx;         /* elements between rows (for the flattened strided conv: stride*Cin) */
+  int32_t x_off;       /* element offset added to every row start (flattened conv: -pad*Cin) */
+  int32_t Cin;         /* logical input channels per tap */
+  int32_t Lin;         /* padded input rows */
+  const int32_t* lens_in; /* [B] valid input rows, nullable => Lin */
+  int32_t flat_valid;  /* 0: validity by row; >0: validity by flat element index in
+                          [0, lens_in[b]*flat_valid)  (flat_valid = true channel count) */
+  /* packed weights */
+  const uint16_t* w;   /* from mi355_pack_conv_weight */
+  int32_t Cout;        /* GEMM N (for conv_transpose: up_s * Cout_real) */
+  int32_t K;           /* taps */
+  int32_t dil;         /* dilation */
+  int32_t pad;         /* left zero padding in rows */
+  /* prologue: t = x*pre_scale[b,c] + pre_shift[b,c]; then activation */
+  const float* pre_scale; /* [B, pre_ld] nullable */
+  const float* pre_shift; /* [B, pre_ld] nullable (must be set iff pre_scale is) */
+  int32_t pre_ld;
+  int32_t pre_act;     /* MI355_ACT_NONE / LEAKY / SNAKE */
+  float pre_slope;     /* leaky slope */
+  const float* pre_alpha; /* [Cin padded to 32] snake alpha, nullable unless SNAKE */
+  /* epilogue: y = acc + bias[n]; y = act(y); y += res; y *= out_scale; y += (accumulate? old y) */
+  const float* bias;   /* [Cout] nullable */
+  int32_t post_act;    /* MI355_ACT_NONE / LEAKY / GELU */
+  float post_slope;
+  const float* res;    /* residual [B, *, ldr], row = out_row >> res_shift; nullable */
+  int64_t res_bstride;
+  int32_t ldr;
+  int32_t res_shift;
+  float out_scale;     /* applied after the residual add */
+  int32_t accumulate;  /* 1: y_new = y_old + value (resblock mean, istftnet.py:824-829) */
+  float* y;            /* [B, Lout, ldy] */
+  int64_t y_bstride;
+  int32_t ldy;
+  int32_t Lout;        /* GEMM rows per item (conv: output length; convT: Lin + K - 1) */
+  const int32_t* lens_out; /* [B] valid GEMM rows, nullable => Lout */
+  /* polyphase conv_transpose store: GEMM column n = r*up_cout + co is written to
+     row u*up_s + r - up_p + up_row_off, column co, if 0 <= row < up_Lout (lens_up[b]) */
+  int32_t up_s;        /* 0 = plain store */
+  int32_t up_p;
+  int32_t up_cout;
+  int32_t up_row_off;
+  int32_t up_Lout;
+  const int32_t* lens_up; /* [B] nullable */
+  int32_t B;
+  int32_t precision;   /* 2 = bf16 hi+lo split (default), 1 = single bf16 pass */
+  int32_t tile;        /* 0 = auto, else BM*1000+BN (128128, 64128, 64064) */
+} mi355_conv_gemm_args;
+
+int mi355_conv_gemm(const mi355_conv_gemm_args* a, void* stream);
+/* Host-side packing (CPU, run once at load time).
+ * w: float32 [Cout, K, Cin] in the MLX conv layout (values already weight-normed / bf16 rounded),
+ * out: uint16 buffer of mi355_packed_conv_weight_elems(Cout, K, Cin) elements. */
+int64_t mi355_packed_conv_weight_elems(int32_t Cout, int32_t K, int32_t Cin);
+int mi355_pack_conv_weight_host(const float* w_host, int32_t Cout, int32_t K, int32_t Cin, uint16_t* out_host);
+
+/* ------------------------------------------------------------------------------------------
+ * Instance-norm statistics + AdaIN coefficients.
+ * Replaces InstanceNorm1d / AdaIN1d (istftnet.py:173-338): per (b, c) mean / biased variance over
+ * time, then scale = (1+gamma)*rsqrt(var+eps), shift = beta - mean*scale with
+ * [gamma, beta] = fc(style) (computed by conv_gemm into `gb`).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* x; int64_t x_bstride; int32_t ldx; int32_t C; int32_t L; const int32_t* lens;
+  int32_t B;
+  double* sums;        /* workspace [B, C, 2], zeroed by the call */
+  const float* gb;     /* [B, gb_ld]: gamma at [0,C), beta at [C,2C) */
+  int32_t gb_ld;
+  float eps;
+  float* scale; float* shift; int32_t out_ld; /* [B, out_ld] */
+} mi355_adain_coef_args;
+int mi355_adain_coef(const mi355_adain_coef_args* a, void* stream);
+
+/* LayerNorm over the channel axis of rows, optionally fused with a residual add in front and
+ * (1+gamma)*xhat+beta / weight*xhat+bias and LeakyReLU behind.
+ * Replaces nn.LayerNorm (modules.py:35,445,481,523,537,551), AdaLayerNorm (modules.py:71-90). */
+typedef struct {
+  const float* x; int64_t x_bstride; int32_t ldx;
+  const float* res; int64_t res_bstride; int32_t ldr; /* nullable: normalise x + res */
+  int32_t C; int32_t L; const int32_t* lens; int32_t B;
+  const float* weight; const float* bias;   /* [C] nullable */
+  const float* ada_gb; int32_t ada_ld;      /* [B, ada_ld]: gamma [0,C), beta [C,2C); nullable */
+  float eps;
+  int32_t post_act; float post_slope;
+  float* y; int64_t y_bstride; int32_t ldy;
+} mi355_layernorm_args;
+int mi355_layernorm(const mi355_layernorm_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Bidirectional LSTM recurrence (the x-projection is a conv_gemm).
+ * Replaces the per-time-step Python loops of LSTM._forward_direction/_backward_direction
+ * (modules.py:150-240): gates i,f,g,o; c = f*c + i*g; h = o*tanh(c).
+ * xp: [B, L, ldxp] gate pre-activations x@Wx^T + b_ih + b_hh, forward gates in columns [0,4H),
+ * backward in [4H,8H).  wh: packed by mi355_pack_lstm_wh_host ([2][H/8][4H][8] bf16).
+ * out: [B, L, ldo], forward h in columns [0,H), backward in [H,2H).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* xp; int64_t xp_bstride; int32_t ldxp;
+  const uint16_t* wh; int32_t H;
+  int32_t L; const int32_t* lens; int32_t B;
+  float* out; int64_t out_bstride; int32_t ldo;
+} mi355_lstm_args;
+int mi355_lstm_bidir(const mi355_lstm_args* a, void* stream);
+int mi355_pack_lstm_wh_host(const float* wh_fwd_host, const float* wh_bwd_host, int32_t H, uint16_t* out_host);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-head self-attention over short sequences (PL-BERT, T <= 512), fp32.
+ * Replaces AlbertSelfAttention's QK^T / softmax / PV (modules.py:493-508).
+ * qkv: [B, T, ld] with q at column 0, k at column D, v at 2D (D = heads*dh); keys >= lens[b]
+ * get the reference's additive -10000 mask.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* qkv; int64_t bstride; int32_t ld;
+  int32_t heads; int32_t dh; int32_t T; const int32_t* lens; int32_t B;
+  float* out; int64_t out_bstride; int32_t ldo;
+} mi355_attention_args;
+int mi355_attention(const mi355_attention_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small glue kernels of Kokoro's Model.__call__ (kokoro.py:111-177).
+ * ------------------------------------------------------------------------------------------ */
+/* y[b, l, 0:C] = table[idx[b, l], :] (+ table2[l, :] + row2[:]), rows >= lens[b] zeroed.
+ * nn.Embedding (modules.py:24,429-431, 466-470) and the duration alignment gather that the
+ * reference writes as a one-hot matmul (kokoro.py:161-169). */
+typedef struct {
+  const float* table; int32_t ld_table;          /* [rows, ld_table] or per-batch if table_bstride != 0 */
+  int64_t table_bstride;
+  const float* pos_table; int32_t ld_pos;        /* nullable: + pos_table[l, :] */
+  const float* add_row;                          /* nullable: + add_row[:] */
+  const int32_t* idx; int32_t idx_ld;            /* [B, idx_ld] */
+  int32_t C; int32_t L; const int32_t* lens; int32_t B;
+  float* y; int64_t y_bstride; int32_t ldy;
+} mi355_gather_rows_args;
+int mi355_gather_rows(const mi355_gather_rows_args* a, void* stream);
+
+/* y[b, l, c] = v[b, c] for l < lens[b] (style broadcast, modules.py:393-395). */
+int mi355_broadcast_rows(const float* v, int32_t ldv, int32_t C, float* y, int64_t y_bstride, int32_t ldy,
+                         int32_t L, const int32_t* lens, int32_t B, void* stream);
+
+/* duration head (kokoro.py:140-147): dur = clip(round(sum_j sigmoid(logits[b,t,j]) / speed), 1, 100),
+ * then per item the exclusive scan and the frame->token index (kokoro.py:148-160).
+ * frames[b] = sum of durations; idx[b, f] = token of frame f (f < frames[b], up to idx_ld). */
+typedef struct {
+  const float* logits; int64_t bstride; int32_t ld; int32_t bins;
+  int32_t T; const int32_t* lens; int32_t B; float speed;
+  const int32_t* forced_dur; /* nullable [B, T]: use these instead of the prediction */
+  int32_t* dur;      /* [B, T] */
+  float* dur_raw;    /* [B, T] nullable: pre-round value (tests check the rounding margin) */
+  int32_t* frames;   /* [B] */
+  int32_t* idx; int32_t idx_ld; /* [B, idx_ld], entries >= frames[b] untouched */
+} mi355_duration_args;
+int mi355_duration_align(const mi355_duration_args* a, void* stream);
+
+/* AdaIN + LeakyReLU + depthwise ConvTranspose1d(k3, s2) with the first output dropped
+ * (AdainResBlk1d pool, istftnet.py:879-881,907-915): x [B, L, C] -> y [B, 2L, C]. */
+typedef struct {
+  const float* x; int64_t x_bstride; int32_t ldx; int32_t C; int32_t L; const int32_t* lens; int32_t B;
+  const float* scale; const float* shift; int32_t pre_ld; float slope;
+  const float* w;    /* [C, 3] folded depthwise weight */
+  const float* bias; /* [C] */
+  float* y; int64_t y_bstride; int32_t ldy;
+} mi355_pool_up2_args;
+int mi355_adain_pool_up2(const mi355_pool_up2_args* a, void* stream);
+
+/* Scalar strided conv (1 -> 1 channel, k3, stride 2, pad 1) writing one column of a wider buffer:
+ * Decoder.F0_conv / N_conv (istftnet.py:973-974,983-984).  x [B, Lin], y[b, l, col]. */
+int mi355_conv1d_c1_k3s2(const float* x, int32_t ldx_b, int32_t Lin, const int32_t* lens_in,
+                         float w0, float w1, float w2, float bias, float* y, int64_t y_bstride, int32_t ldy, int32_t col,
+                         int32_t Lout, int32_t B, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Harmonic source + STFT features + iSTFT head of the iSTFTNet Generator.
+ * ------------------------------------------------------------------------------------------ */
+/* SineGen + SourceModuleHnNSF (istftnet.py:548-709, 797-799): f0 [B, L2] at 2 values / frame ->
+ * har_source [B, L2*up].  rand_ini [B, H] uniform, noise [B, L2*up, H] normal (explicit, so that
+ * results are reproducible).  phase_ws: workspace [B, H, L2+1] floats. */
+typedef struct {
+  const float* f0; int32_t ld_f0; int32_t L2; const int32_t* lens2; int32_t B;
+  int32_t up; int32_t H; float sr; float sine_amp; float noise_std; float voiced_thr;
+  const float* rand_ini; const float* noise;
+  const float* lin_w; float lin_b;  /* l_linear [H], bias */
+  float* phase_ws;
+  float* out; int32_t ld_out;
+} mi355_sine_source_args;
+int mi355_sine_source(const mi355_sine_source_args* a, void* stream);
+
+/* MLXSTFT.transform (istftnet.py:473-506) for small n_fft (<= 64): reflect-centred STFT with a
+ * caller-supplied window, magnitude and atan2 phase, written channels-last:
+ * x [B, L] -> y[b, f, 0:nb] = |X|, y[b, f, nb:2nb] = angle(X), f in [0, L/hop], nb = n_fft/2+1. */
+typedef struct {
+  const float* x; int32_t ldx; int32_t L; const int32_t* lens; int32_t B;
+  int32_t n_fft; int32_t hop; const float* window;
+  float* y; int64_t y_bstride; int32_t ldy;
+} mi355_stft_magphase_args;
+int mi355_stft_magphase(const mi355_stft_magphase_args* a, void* stream);
+
+/* Generator tail (istftnet.py:830-835 + MLXSTFT.inverse :508-541 + dsp.istft :436-513 with
+ * normalized=True, center=True): x [B, Fr, 2nb] (conv_post output) -> spec = exp(x[..., :nb]),
+ * phase = sin(x[..., nb:]), irfft, synthesis window, w^2 overlap-add as a gather,
+ * trim n_fft/2 each side -> audio [B, (Fr-1)*hop]. */
+typedef struct {
+  const float* x; int64_t x_bstride; int32_t ldx; int32_t Fr; const int32_t* lens; int32_t B;
+  int32_t n_fft; int32_t hop; const float* window;
+  float* audio; int32_t ld_audio;
+} mi355_istft_head_args;
+int mi355_istft_head(const mi355_istft_head_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * mlx_audio.dsp (dsp.py): batched STFT / iSTFT for arbitrary n_fft (mixed-radix 2/3/4/5 +
+ * generic-prime Stockham FFT staged in LDS) and the fused |X|^2 -> mel -> log front ends.
+ * ------------------------------------------------------------------------------------------ */
+/* dsp.stft (dsp.py:385-433): x [B, L] (already centre-padded by the caller or pad_mode applied
+ * here: 0 none, 1 reflect, 2 constant) -> out complex64 [B, n_frames, n_fft/2+1] interleaved. */
+typedef struct {
+  const float* x; int32_t ldx; int32_t L; int32_t B;
+  int32_t n_fft; int32_t hop; const float* window; /* [n_fft] already zero-padded */
+  int32_t pad_mode; int32_t n_frames;
+  float* out;  /* [B, n_frames, n_fft/2+1, 2] */
+} mi355_stft_args;
+int mi355_stft(const mi355_stft_args* a, void* stream);
+
+/* Fused STFT -> power/magnitude -> mel -> log (whisper/audio.py:41-82; qwen3_tts.py:64-120).
+ * mode 0 (whisper): p = |X|^2, y = log10(max(mel, 1e-10)) (global max clamp + (y+4)/4 by
+ *   mi355_logmel_finish); mode 1 (qwen3): p = sqrt(|X|^2 + 1e-9), y = log(max(mel, 1e-5)).
+ * fb: [n_mels, n_fft/2+1] float32.  out [B, n_frames, n_mels]. */
+typedef struct {
+  const float* x; int32_t ldx; int32_t L; int32_t B;
+  int32_t n_fft; int32_t hop; const float* window; int32_t pad_mode; int32_t n_frames;
+  const float* fb; int32_t n_mels; int32_t mode;
+  float* out;
+  float* gmax;  /* [B] running max for mode 0 (must be -inf initialised by the call), nullable */
+} mi355_logmel_args;
+int mi355_logmel(const mi355_logmel_args* a, void* stream);
+int mi355_logmel_finish(float* y, int64_t n_per_item, const float* gmax, int32_t B, void* stream);
+
+/* dsp.istft / ISTFTCache.istft (dsp.py:436-513, 663-738): spec [B, n_frames, nb, 2] ->
+ * frames irfft(n_fft) * window, overlap-add (gather form), / norm[t] (precomputed window
+ * envelope), out[b, t - trim] for t in [trim, trim+out_len).  clamp: constrain_value_range. */
+typedef struct {
+  const float* spec; int32_t n_frames; int32_t B;
+  int32_t n_fft; int32_t hop; const float* window; const float* norm; /* [ola_len] */
+  int32_t norm_mode;  /* 0: out/norm always (ISTFTCache); 1: divide only where norm > 1e-10 (dsp.istft) */
+  int32_t clamp; int32_t trim; int32_t out_len;
+  float* frames_ws;   /* workspace [B, n_frames rounded up to even, n_fft] floats */
+  float* out; int32_t ld_out;
+} mi355_istft_args;
+int mi355_istft(const mi355_istft_args* a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355AUDIO_H */

@@ -1,0 +1,82 @@
+"""Builds libmi355audio.so (hand-written HIP for gfx950 + the C ABI) in-tree with hipcc.
+
+    python -m mlx_audio_amd.build          # or: from mlx_audio_amd.build import build; build()
+
+The shared library is written to ``mlx_audio_amd/lib/libmi355audio.so`` so that it travels with the
+source snapshot to the GPU box (it is git-ignored, not gpurun-ignored).  hipcc cross-compiles for
+gfx950 without a GPU, so this also runs in the CPU-only authoring container.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIBPATH = os.path.join(LIBDIR, "libmi355audio.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "mi355audio.h")
+SOURCES = ["api.cpp", "conv_gemm.hip", "norm.hip", "lstm.hip", "attention.hip", "glue.hip", "source.hip", "fft.hip"]
+# per-file extra flags: source.hip mirrors the reference's fp32 op order one rounding at a time
+EXTRA_FLAGS = {"source.hip": ["-ffp-contract=off"]}
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC=/path/to/hipcc)")
+
+
+def _fingerprint() -> str:
+    h = hashlib.sha256()
+    for name in SOURCES + ["common.h"]:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+    with open(HEADER, "rb") as f:
+        h.update(f.read())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    stamp = os.path.join(LIBDIR, "libmi355audio.stamp")
+    fp = _fingerprint()
+    if not force and os.path.exists(LIBPATH) and os.path.exists(stamp) and open(stamp).read().strip() == fp:
+        return LIBPATH
+    hipcc = _hipcc()
+    objs = []
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src.rsplit(".", 1)[0] + ".o")
+        objs.append(obj)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c",
+               os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        if verbose and out.strip():
+            print(out)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIBPATH] + objs
+    if verbose:
+        print("[build]", " ".join(link), flush=True)
+    r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    with open(stamp, "w") as f:
+        f.write(fp)
+    return LIBPATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,75 @@
+// Error reporting, ABI version and host-side weight packing for libmi355audio.so.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void mi355_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* mi355_last_error(void) { return g_err; }
+extern "C" int mi355_abi_version(void) { return 1; }
+
+extern "C" int mi355_device_info(int dev, char* name, int name_cap, int* cu_count, int* lds_bytes) {
+  hipDeviceProp_t p;
+  hipError_t e = hipGetDeviceProperties(&p, dev);
+  if (e != hipSuccess) {
+    mi355_set_error("hipGetDeviceProperties: %s", hipGetErrorString(e));
+    return MI355_ERR_LAUNCH;
+  }
+  if (name && name_cap > 0) snprintf(name, name_cap, "%s (%s)", p.name, p.gcnArchName);
+  if (cu_count) *cu_count = p.multiProcessorCount;
+  if (lds_bytes) *lds_bytes = (int)p.sharedMemPerBlock;
+  return MI355_OK;
+}
+
+// ---- conv weight packing: [Cout, K, Cin] fp32 -> MFMA 32x32x16 B-fragment order, bf16.
+// element index = ((((chunk*K + tap)*NTp + nt)*2 + kk)*64 + lane)*8 + j with
+//   n = nt*32 + (lane & 31),  c = chunk*32 + kk*16 + (lane >> 5)*8 + j
+extern "C" int64_t mi355_packed_conv_weight_elems(int32_t Cout, int32_t K, int32_t Cin) {
+  int64_t chunks = (Cin + 31) / 32;
+  int64_t ntp = ((Cout + 127) / 128) * 4;
+  return chunks * K * ntp * 2 * 512;
+}
+
+extern "C" int mi355_pack_conv_weight_host(const float* w, int32_t Cout, int32_t K, int32_t Cin, uint16_t* out) {
+  MI355_REQUIRE(w && out && Cout > 0 && K > 0 && Cin > 0, "pack_conv_weight: bad arguments");
+  const int chunks = (Cin + 31) / 32;
+  const int ntp = ((Cout + 127) / 128) * 4;
+  size_t o = 0;
+  for (int ch = 0; ch < chunks; ++ch)
+    for (int tap = 0; tap < K; ++tap)
+      for (int nt = 0; nt < ntp; ++nt)
+        for (int kk = 0; kk < 2; ++kk)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int n = nt * 32 + (lane & 31);
+            const int c0 = ch * 32 + kk * 16 + (lane >> 5) * 8;
+            for (int j = 0; j < 8; ++j) {
+              const int c = c0 + j;
+              float v = (n < Cout && c < Cin) ? w[((size_t)n * K + tap) * Cin + c] : 0.0f;
+              out[o++] = host_f32_to_bf16(v);
+            }
+          }
+  return MI355_OK;
+}
+
+// ---- LSTM recurrent weight packing: Wh [4H, H] fp32 (fwd, bwd) -> [2][H/8][4H][8] bf16
+extern "C" int mi355_pack_lstm_wh_host(const float* wf, const float* wb, int32_t H, uint16_t* out) {
+  MI355_REQUIRE(wf && wb && out && H > 0 && H % 8 == 0, "pack_lstm_wh: bad arguments");
+  const int G = 4 * H;
+  size_t o = 0;
+  for (int d = 0; d < 2; ++d) {
+    const float* w = d ? wb : wf;
+    for (int k8 = 0; k8 < H / 8; ++k8)
+      for (int r = 0; r < G; ++r)
+        for (int j = 0; j < 8; ++j) out[o++] = host_f32_to_bf16(w[(size_t)r * H + k8 * 8 + j]);
+  }
+  return MI355_OK;
+}

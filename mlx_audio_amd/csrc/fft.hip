@@ -1,0 +1,347 @@
+// mlx_audio.dsp on gfx950: batched STFT / iSTFT for arbitrary n_fft and the fused
+// STFT -> |X|^2 -> mel -> log front ends (dsp.py:385-513, 663-738; whisper/audio.py:41-82;
+// qwen3_tts.py:64-120).
+//
+// FFT: mixed-radix (4, 2, 3, 5, then any odd prime) Stockham autosort, complex fp32, staged entirely
+// in LDS together with its twiddle table (computed once per workgroup in fp64, so every twiddle is
+// correctly rounded).  Two real frames ride one complex transform (even frame -> re, odd frame ->
+// im) and are separated with the Hermitian identities, so an n_fft-point real STFT costs half a
+// complex FFT.  A workgroup transforms several frame pairs at once so that all 256 lanes have
+// butterflies even for n_fft = 400.
+#include "common.h"
+
+namespace {
+
+struct FftPlan { int N; int nrad; int rad[24]; };
+
+bool make_plan(int N, FftPlan& p) {
+  p.N = N; p.nrad = 0;
+  int n = N;
+  const int pref[4] = {4, 2, 3, 5};
+  for (int i = 0; i < 4; ++i)
+    while (n % pref[i] == 0) { if (p.nrad >= 24) return false; p.rad[p.nrad++] = pref[i]; n /= pref[i]; }
+  for (int q = 7; n > 1; q += 2)
+    while (n % q == 0) { if (p.nrad >= 24 || q > 61) return false; p.rad[p.nrad++] = q; n /= q; }
+  return true;
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// forward (conj=false) or inverse-unscaled (conj=true) FFT of `npairs` length-N complex vectors held
+// at src[pair*N + n]; returns the buffer holding the result (src or dst).
+__device__ float2* fft_lds(float2* src, float2* dst, const float2* tw, const FftPlan& pl, int npairs, bool conj) {
+  const int N = pl.N;
+  int Ns = 1;
+  for (int s = 0; s < pl.nrad; ++s) {
+    const int R = pl.rad[s];
+    const int NR = N / R, stride = N / (Ns * R);
+    for (int idx = threadIdx.x; idx < npairs * NR; idx += blockDim.x) {
+      const int pr = idx / NR, j = idx - pr * NR;
+      const int k = j % Ns;
+      const float2* in = src + pr * N;
+      float2* out = dst + pr * N + (j / Ns) * Ns * R + k;
+      if (R == 4) {
+        float2 v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float2 w = tw[(k * stride * t) % N];
+          if (conj) w.y = -w.y;
+          v[t] = cmul(in[j + t * NR], w);
+        }
+        const float2 a0 = make_float2(v[0].x + v[2].x, v[0].y + v[2].y), a1 = make_float2(v[0].x - v[2].x, v[0].y - v[2].y);
+        const float2 b0 = make_float2(v[1].x + v[3].x, v[1].y + v[3].y), b1 = make_float2(v[1].x - v[3].x, v[1].y - v[3].y);
+        // forward: -i * b1 ; inverse: +i * b1
+        const float2 jb = conj ? make_float2(-b1.y, b1.x) : make_float2(b1.y, -b1.x);
+        out[0] = make_float2(a0.x + b0.x, a0.y + b0.y);
+        out[Ns] = make_float2(a1.x + jb.x, a1.y + jb.y);
+        out[2 * Ns] = make_float2(a0.x - b0.x, a0.y - b0.y);
+        out[3 * Ns] = make_float2(a1.x - jb.x, a1.y - jb.y);
+      } else if (R == 2) {
+        float2 w = tw[(k * stride) % N];
+        if (conj) w.y = -w.y;
+        const float2 v0 = in[j], v1 = cmul(in[j + NR], w);
+        out[0] = make_float2(v0.x + v1.x, v0.y + v1.y);
+        out[Ns] = make_float2(v0.x - v1.x, v0.y - v1.y);
+      } else {
+        float2 v[61];
+        for (int t = 0; t < R; ++t) {
+          float2 w = tw[(int)(((long)k * stride * t) % N)];
+          if (conj) w.y = -w.y;
+          v[t] = cmul(in[j + t * NR], w);
+        }
+        for (int q = 0; q < R; ++q) {
+          float2 acc = make_float2(0.f, 0.f);
+          for (int t = 0; t < R; ++t) {
+            float2 w = tw[(int)(((long)NR * t * q) % N)];
+            if (conj) w.y = -w.y;
+            const float2 m = cmul(v[t], w);
+            acc.x += m.x; acc.y += m.y;
+          }
+          out[q * Ns] = acc;
+        }
+      }
+    }
+    __syncthreads();
+    float2* tmp = src; src = dst; dst = tmp;
+    Ns *= R;
+  }
+  return src;
+}
+
+__device__ __forceinline__ void fill_twiddles(float2* tw, int N) {
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    double s, c;
+    sincospi(-2.0 * i / (double)N, &s, &c);
+    tw[i] = make_float2((float)c, (float)s);
+  }
+}
+
+__device__ __forceinline__ void atomic_max_float(float* addr, float v) {
+  if (v >= 0.f) atomicMax((int*)addr, __float_as_int(v));
+  else atomicMin((unsigned int*)addr, __float_as_uint(v));
+}
+
+struct StftCommon {
+  const float* x; int ldx; int L; int n_fft; int hop; const float* window; int pad_mode; int n_frames;
+};
+
+// MODE 0: complex spectrum out [B, n_frames, nb, 2];  MODE 1: log-mel out [B, n_frames, n_mels]
+template <int MODE>
+__global__ __launch_bounds__(256) void stft_kernel(StftCommon c, FftPlan pl, int pairs, float* out, const float* fb, int n_mels,
+                                                   int mel_mode, float* gmax) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int N = c.n_fft, nb = N / 2 + 1;
+  float2* tw = (float2*)smem;
+  float2* buf0 = tw + N;
+  float2* buf1 = buf0 + pairs * N;
+  float* pw = (float*)(buf1 + pairs * N);  // MODE 1: [2*pairs][nb]
+  const int b = blockIdx.y;
+  const int f0 = blockIdx.x * 2 * pairs;
+  fill_twiddles(tw, N);
+  const float* xb = c.x + (int64_t)b * c.ldx;
+  const int off = c.pad_mode ? N / 2 : 0;
+  for (int i = threadIdx.x; i < pairs * N; i += blockDim.x) {
+    const int pr = i / N, n = i - pr * N;
+    float v[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int f = f0 + 2 * pr + h;
+      float s = 0.f;
+      if (f < c.n_frames) {
+        int idx = f * c.hop + n - off;
+        bool ok = true;
+        if (c.pad_mode == 1) {  // reflect
+          if (idx < 0) idx = -idx;
+          if (idx >= c.L) idx = 2 * (c.L - 1) - idx;
+        } else if (idx < 0 || idx >= c.L) ok = false;  // constant pad / out of range
+        if (ok) s = xb[idx] * c.window[n];
+      }
+      v[h] = s;
+    }
+    buf0[i] = make_float2(v[0], v[1]);
+  }
+  __syncthreads();
+  float2* Z = fft_lds(buf0, buf1, tw, pl, pairs, false);
+  // separate the two real transforms: Xa = (Z[k] + conj Z[N-k]) / 2, Xb = (Z[k] - conj Z[N-k]) / (2i)
+  for (int i = threadIdx.x; i < pairs * nb; i += blockDim.x) {
+    const int pr = i / nb, k = i - pr * nb;
+    const float2 z = Z[pr * N + k], zc = Z[pr * N + ((N - k) % N)];
+    float2 xa = make_float2(0.5f * (z.x + zc.x), 0.5f * (z.y - zc.y));
+    float2 xb2 = make_float2(0.5f * (z.y + zc.y), 0.5f * (zc.x - z.x));
+    if (k == 0 || 2 * k == N) { xa.y = 0.f; xb2.y = 0.f; }
+    const int fa = f0 + 2 * pr;
+    if (MODE == 0) {
+      if (fa < c.n_frames) *(float2*)(out + (((int64_t)b * c.n_frames + fa) * nb + k) * 2) = xa;
+      if (fa + 1 < c.n_frames) *(float2*)(out + (((int64_t)b * c.n_frames + fa + 1) * nb + k) * 2) = xb2;
+    } else {
+      float pa = xa.x * xa.x + xa.y * xa.y, pb = xb2.x * xb2.x + xb2.y * xb2.y;
+      if (mel_mode == 1) { pa = sqrtf(pa + 1e-9f); pb = sqrtf(pb + 1e-9f); }
+      pw[(2 * pr) * nb + k] = pa;
+      pw[(2 * pr + 1) * nb + k] = pb;
+    }
+  }
+  if (MODE == 1) {
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float lmax = -INFINITY;
+    for (int task = wv; task < 2 * pairs * n_mels; task += 4) {
+      const int fl = task / n_mels, m = task - fl * n_mels;
+      const int f = f0 + fl;
+      if (f >= c.n_frames) continue;
+      const float* row = fb + (int64_t)m * nb;
+      const float* pr = pw + fl * nb;
+      float s = 0.f;
+      for (int k = lane; k < nb; k += 64) s = fmaf(pr[k], row[k], s);
+      s = wave_sum(s);
+      if (lane == 0) {
+        float y;
+        if (mel_mode == 0) y = log10f(fmaxf(s, 1e-10f));
+        else y = logf(fmaxf(s, 1e-5f));
+        out[((int64_t)b * c.n_frames + f) * n_mels + m] = y;
+        lmax = fmaxf(lmax, y);
+      }
+    }
+    if (gmax && lane == 0 && lmax > -INFINITY) atomic_max_float(gmax + b, lmax);
+  }
+}
+
+__global__ void logmel_finish_kernel(float* y, int64_t n, const float* gmax, int B) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (i >= n) return;
+  float v = y[(int64_t)b * n + i];
+  v = fmaxf(v, gmax[b] - 8.0f);
+  y[(int64_t)b * n + i] = (v + 4.0f) / 4.0f;
+}
+
+// inverse: spectra of two frames -> one complex inverse FFT -> two windowed real frames in frames_ws
+__global__ __launch_bounds__(256) void istft_frames_kernel(const mi355_istft_args a, FftPlan pl, int pairs, int nf_even) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int N = a.n_fft, nb = N / 2 + 1;
+  float2* tw = (float2*)smem;
+  float2* buf0 = tw + N;
+  float2* buf1 = buf0 + pairs * N;
+  const int b = blockIdx.y, f0 = blockIdx.x * 2 * pairs;
+  fill_twiddles(tw, N);
+  const float* sb = a.spec + (int64_t)b * a.n_frames * nb * 2;
+  for (int i = threadIdx.x; i < pairs * N; i += blockDim.x) {
+    const int pr = i / N, n = i - pr * N;
+    const int k = (n <= N / 2) ? n : N - n;
+    const bool mirror = n > N / 2;
+    float2 xa = make_float2(0.f, 0.f), xb = make_float2(0.f, 0.f);
+    const int fa = f0 + 2 * pr;
+    if (fa < a.n_frames) xa = *(const float2*)(sb + ((int64_t)fa * nb + k) * 2);
+    if (fa + 1 < a.n_frames) xb = *(const float2*)(sb + ((int64_t)(fa + 1) * nb + k) * 2);
+    if (k == 0 || 2 * k == N) { xa.y = 0.f; xb.y = 0.f; }  // irfft ignores these imaginary parts
+    if (mirror) { xa.y = -xa.y; xb.y = -xb.y; }
+    buf0[i] = make_float2(xa.x - xb.y, xa.y + xb.x);  // Xa + i*Xb
+  }
+  __syncthreads();
+  float2* z = fft_lds(buf0, buf1, tw, pl, pairs, true);
+  const float invn = 1.0f / (float)N;
+  for (int i = threadIdx.x; i < pairs * N; i += blockDim.x) {
+    const int pr = i / N, n = i - pr * N;
+    const float w = a.window[n];
+    float va = z[i].x * invn, vb = z[i].y * invn;
+    if (a.clamp) { va = fminf(fmaxf(va, -w), w); vb = fminf(fmaxf(vb, -w), w); }
+    const int fa = f0 + 2 * pr;
+    float* ws = a.frames_ws + ((int64_t)b * nf_even + fa) * N + n;
+    if (fa < nf_even) ws[0] = va * w;
+    if (fa + 1 < nf_even) ws[N] = vb * w;
+  }
+}
+
+__global__ __launch_bounds__(256) void istft_ola_kernel(const mi355_istft_args a, int nf_even) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (t >= a.out_len) return;
+  const int N = a.n_fft, hop = a.hop;
+  const int p = t + a.trim;
+  int f_lo = (p - N + hop) / hop; if (p - N + 1 <= 0) f_lo = 0;
+  int f_hi = p / hop; if (f_hi > a.n_frames - 1) f_hi = a.n_frames - 1;
+  const float* ws = a.frames_ws + (int64_t)b * nf_even * N;
+  float acc = 0.f;
+  for (int f = f_lo; f <= f_hi; ++f) {
+    const int n = p - f * hop;
+    if (n >= 0 && n < N) acc += ws[(int64_t)f * N + n];
+  }
+  const float nv = a.norm[p];
+  float o;
+  if (a.norm_mode == 0) o = acc / nv;
+  else o = (nv > 1e-10f) ? acc / nv : acc;
+  a.out[(int64_t)b * a.ld_out + t] = o;
+}
+
+int choose_pairs(int N, int extra_per_frame_bytes) {
+  int pairs = 8;
+  while (pairs > 1 && (size_t)N * 8 + (size_t)pairs * (2 * N * 8 + 2 * extra_per_frame_bytes) > 60 * 1024) pairs >>= 1;
+  return pairs;
+}
+
+template <typename K>
+int set_lds(K kernel, size_t lds, const char* name) {
+  if (lds > 64 * 1024) {
+    MI355_REQUIRE(lds <= 160 * 1024, "%s: n_fft too large for LDS (%zu B)", name, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    MI355_REQUIRE(e == hipSuccess, "%s: cannot reserve %zu B of LDS: %s", name, lds, hipGetErrorString(e));
+  }
+  return MI355_OK;
+}
+
+}  // namespace
+
+extern "C" int mi355_stft(const mi355_stft_args* ap, void* stream) {
+  MI355_REQUIRE(ap && ap->x && ap->window && ap->out, "stft: null tensor");
+  const mi355_stft_args a = *ap;
+  MI355_REQUIRE(a.n_fft >= 2 && a.hop > 0 && a.n_frames > 0 && a.B > 0, "stft: bad shape");
+  MI355_REQUIRE(a.pad_mode >= 0 && a.pad_mode <= 2, "stft: pad_mode must be 0 (none), 1 (reflect) or 2 (constant)");
+  MI355_REQUIRE(a.pad_mode != 1 || a.L > a.n_fft / 2, "stft: input too short for reflect padding");
+  FftPlan pl;
+  MI355_REQUIRE(make_plan(a.n_fft, pl), "stft: n_fft=%d has a prime factor > 61", a.n_fft);
+  const int pairs = choose_pairs(a.n_fft, 0);
+  const size_t lds = (size_t)a.n_fft * 8 * (1 + 2 * pairs);
+  if (int r = set_lds(stft_kernel<0>, lds, "stft")) return r;
+  StftCommon c{a.x, a.ldx, a.L, a.n_fft, a.hop, a.window, a.pad_mode, a.n_frames};
+  const int blocks = (a.n_frames + 2 * pairs - 1) / (2 * pairs);
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(stft_kernel<0>, dim3(blocks, a.B), dim3(256), lds, (hipStream_t)stream, c, pl, pairs, a.out,
+                     (const float*)nullptr, 0, 0, (float*)nullptr);
+  MI355_LAUNCH_CHECK("stft");
+  return MI355_OK;
+}
+
+extern "C" int mi355_logmel(const mi355_logmel_args* ap, void* stream) {
+  MI355_REQUIRE(ap && ap->x && ap->window && ap->fb && ap->out, "logmel: null tensor");
+  const mi355_logmel_args a = *ap;
+  MI355_REQUIRE(a.n_fft >= 2 && a.hop > 0 && a.n_frames > 0 && a.B > 0 && a.n_mels > 0, "logmel: bad shape");
+  MI355_REQUIRE(a.mode == 0 || a.mode == 1, "logmel: mode must be 0 (whisper) or 1 (qwen3)");
+  MI355_REQUIRE(a.pad_mode >= 0 && a.pad_mode <= 2, "logmel: bad pad_mode");
+  MI355_REQUIRE(a.pad_mode != 1 || a.L > a.n_fft / 2, "logmel: input too short for reflect padding");
+  FftPlan pl;
+  MI355_REQUIRE(make_plan(a.n_fft, pl), "logmel: n_fft=%d has a prime factor > 61", a.n_fft);
+  const int nb = a.n_fft / 2 + 1;
+  const int pairs = choose_pairs(a.n_fft, nb * 4);
+  const size_t lds = (size_t)a.n_fft * 8 * (1 + 2 * pairs) + (size_t)2 * pairs * nb * 4;
+  if (int r = set_lds(stft_kernel<1>, lds, "logmel")) return r;
+  hipStream_t st = (hipStream_t)stream;
+  if (a.gmax) {
+    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)a.gmax, (int)0xff800000u, a.B, st);
+    MI355_REQUIRE(e == hipSuccess, "logmel: memset failed: %s", hipGetErrorString(e));
+  }
+  StftCommon c{a.x, a.ldx, a.L, a.n_fft, a.hop, a.window, a.pad_mode, a.n_frames};
+  const int blocks = (a.n_frames + 2 * pairs - 1) / (2 * pairs);
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(stft_kernel<1>, dim3(blocks, a.B), dim3(256), lds, st, c, pl, pairs, a.out, a.fb, a.n_mels, a.mode, a.gmax);
+  MI355_LAUNCH_CHECK("logmel");
+  return MI355_OK;
+}
+
+extern "C" int mi355_logmel_finish(float* y, int64_t n_per_item, const float* gmax, int32_t B, void* stream) {
+  MI355_REQUIRE(y && gmax && n_per_item > 0 && B > 0, "logmel_finish: bad arguments");
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(logmel_finish_kernel, dim3((unsigned)((n_per_item + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, y,
+                     n_per_item, gmax, B);
+  MI355_LAUNCH_CHECK("logmel_finish");
+  return MI355_OK;
+}
+
+extern "C" int mi355_istft(const mi355_istft_args* ap, void* stream) {
+  MI355_REQUIRE(ap && ap->spec && ap->window && ap->norm && ap->frames_ws && ap->out, "istft: null tensor");
+  const mi355_istft_args a = *ap;
+  MI355_REQUIRE(a.n_fft >= 2 && a.n_fft % 2 == 0 && a.hop > 0 && a.n_frames > 0 && a.B > 0 && a.out_len > 0, "istft: bad shape");
+  MI355_REQUIRE(a.trim >= 0 && a.trim + a.out_len <= (a.n_frames - 1) * a.hop + a.n_fft, "istft: trim/out_len outside the overlap-add range");
+  FftPlan pl;
+  MI355_REQUIRE(make_plan(a.n_fft, pl), "istft: n_fft=%d has a prime factor > 61", a.n_fft);
+  const int pairs = choose_pairs(a.n_fft, 0);
+  const size_t lds = (size_t)a.n_fft * 8 * (1 + 2 * pairs);
+  if (int r = set_lds(istft_frames_kernel, lds, "istft")) return r;
+  const int nf_even = (a.n_frames + 1) & ~1;
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (a.n_frames + 2 * pairs - 1) / (2 * pairs);
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(istft_frames_kernel, dim3(blocks, a.B), dim3(256), lds, st, a, pl, pairs, nf_even);
+  MI355_LAUNCH_CHECK("istft_frames");
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(istft_ola_kernel, dim3((a.out_len + 255) / 256, a.B), dim3(256), 0, st, a, nf_even);
+  MI355_LAUNCH_CHECK("istft_ola");
+  return MI355_OK;
+}

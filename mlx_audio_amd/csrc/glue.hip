@@ -1,0 +1,174 @@
+// Small glue kernels of Kokoro's Model.__call__ (tts/models/kokoro/kokoro.py:111-177) that the
+// reference expresses as gathers, one-hot matmuls and Python loops (gfx950).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const mi355_gather_rows_args a) {
+  const int64_t row = blockIdx.x;
+  const int b = (int)(row / a.L), l = (int)(row - (int64_t)b * a.L);
+  const int len = a.lens ? a.lens[b] : a.L;
+  float* yr = a.y + (int64_t)b * a.y_bstride + (int64_t)l * a.ldy;
+  if (l >= len) {
+    for (int c = threadIdx.x; c < a.C; c += blockDim.x) yr[c] = 0.f;
+    return;
+  }
+  const int src = a.idx[(int64_t)b * a.idx_ld + l];
+  const float* tr = a.table + (int64_t)b * a.table_bstride + (int64_t)src * a.ld_table;
+  for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+    float v = tr[c];
+    if (a.pos_table) v += a.pos_table[(int64_t)l * a.ld_pos + c];
+    if (a.add_row) v += a.add_row[c];
+    yr[c] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void broadcast_rows_kernel(const float* v, int ldv, int C, float* y, int64_t ybs, int ldy,
+                                                             int L, const int32_t* lens, int B) {
+  const int64_t row = blockIdx.x;
+  const int b = (int)(row / L), l = (int)(row - (int64_t)b * L);
+  const int len = lens ? lens[b] : L;
+  float* yr = y + (int64_t)b * ybs + (int64_t)l * ldy;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) yr[c] = (l < len) ? v[(int64_t)b * ldv + c] : 0.f;
+}
+
+// one block per utterance: duration head + exclusive scan + frame->token index
+__global__ __launch_bounds__(512) void duration_align_kernel(const mi355_duration_args a) {
+  __shared__ int sdur[512];
+  __shared__ int sstart[513];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int len = a.lens ? a.lens[b] : a.T;
+  int d = 0;
+  if (t < len) {
+    if (a.forced_dur) {
+      d = a.forced_dur[(int64_t)b * a.T + t];
+    } else {
+      const float* lr = a.logits + (int64_t)b * a.bstride + (int64_t)t * a.ld;
+      float s = 0.f;
+      for (int j = 0; j < a.bins; ++j) s += 1.0f / (1.0f + expf(-lr[j]));
+      float v = s / a.speed;
+      if (a.dur_raw) a.dur_raw[(int64_t)b * a.T + t] = v;
+      if (v != v) v = 1.0f;                       // nan -> 1
+      else if (v == INFINITY) v = 100.0f;         // +inf -> max_frames_per_phoneme
+      else if (v == -INFINITY) v = 1.0f;
+      v = fminf(fmaxf(rintf(v), 1.0f), 100.0f);   // mx.round = half-to-even
+      d = (int)v;
+    }
+    a.dur[(int64_t)b * a.T + t] = d;
+  } else if (t < a.T) {
+    a.dur[(int64_t)b * a.T + t] = 0;
+  }
+  sdur[t] = d;
+  __syncthreads();
+  if (t == 0) {
+    int acc = 0;
+    for (int i = 0; i < a.T && i < 512; ++i) { sstart[i] = acc; acc += sdur[i]; }
+    sstart[512] = acc;
+    a.frames[b] = acc;
+  }
+  __syncthreads();
+  if (t < len) {
+    const int s0 = sstart[t];
+    for (int f = 0; f < d; ++f)
+      if (s0 + f < a.idx_ld) a.idx[(int64_t)b * a.idx_ld + s0 + f] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void pool_up2_kernel(const mi355_pool_up2_args a) {
+  // y[b, n, c], n in [0, 2L): position p = n + 1 of the un-trimmed (2L+1)-long transposed conv
+  const int64_t row = blockIdx.x;
+  const int L2 = 2 * a.L;
+  const int b = (int)(row / L2), n = (int)(row - (int64_t)b * L2);
+  const int len = a.lens ? a.lens[b] : a.L;
+  if (n >= 2 * len) return;
+  const int p = n + 1;
+  const float* xb = a.x + (int64_t)b * a.x_bstride;
+  float* yr = a.y + (int64_t)b * a.y_bstride + (int64_t)n * a.ldy;
+  for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+    const float sc = a.scale[(int64_t)b * a.pre_ld + c], sh = a.shift[(int64_t)b * a.pre_ld + c];
+    auto act = [&](int t) {
+      float v = xb[(int64_t)t * a.ldx + c] * sc + sh;
+      return v > 0.f ? v : v * a.slope;
+    };
+    float o;
+    if (p & 1) {
+      o = act((p - 1) >> 1) * a.w[c * 3 + 1];
+    } else {
+      const int t = p >> 1;
+      o = 0.f;
+      if (t < len) o += act(t) * a.w[c * 3 + 0];
+      if (t - 1 >= 0) o += act(t - 1) * a.w[c * 3 + 2];
+    }
+    yr[c] = o + a.bias[c];
+  }
+}
+
+__global__ void conv1d_c1_k3s2_kernel(const float* x, int ldxb, int Lin, const int32_t* lens_in, float w0, float w1, float w2,
+                                      float bias, float* y, int64_t ybs, int ldy, int col, int Lout, int B) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (l >= Lout) return;
+  const int len = lens_in ? lens_in[b] : Lin;
+  const int lout = (len + 2 - 3) / 2 + 1;
+  if (l >= lout) return;
+  const float* xb = x + (int64_t)b * ldxb;
+  float s = 0.f;
+  const int i0 = 2 * l - 1;
+  if (i0 >= 0 && i0 < len) s += w0 * xb[i0];
+  if (i0 + 1 < len) s += w1 * xb[i0 + 1];
+  if (i0 + 2 < len) s += w2 * xb[i0 + 2];
+  y[(int64_t)b * ybs + (int64_t)l * ldy + col] = s + bias;
+}
+
+}  // namespace
+
+extern "C" int mi355_gather_rows(const mi355_gather_rows_args* ap, void* stream) {
+  MI355_REQUIRE(ap && ap->table && ap->idx && ap->y, "gather_rows: null tensor");
+  const mi355_gather_rows_args a = *ap;
+  MI355_REQUIRE(a.B > 0 && a.L > 0 && a.C > 0, "gather_rows: bad shape");
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((int64_t)a.B * a.L)), dim3(256), 0, (hipStream_t)stream, a);
+  MI355_LAUNCH_CHECK("gather_rows");
+  return MI355_OK;
+}
+
+extern "C" int mi355_broadcast_rows(const float* v, int32_t ldv, int32_t C, float* y, int64_t y_bstride, int32_t ldy,
+                                    int32_t L, const int32_t* lens, int32_t B, void* stream) {
+  MI355_REQUIRE(v && y && B > 0 && L > 0 && C > 0, "broadcast_rows: bad arguments");
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(broadcast_rows_kernel, dim3((unsigned)((int64_t)B * L)), dim3(256), 0, (hipStream_t)stream, v, ldv, C,
+                     y, y_bstride, ldy, L, lens, B);
+  MI355_LAUNCH_CHECK("broadcast_rows");
+  return MI355_OK;
+}
+
+extern "C" int mi355_duration_align(const mi355_duration_args* ap, void* stream) {
+  MI355_REQUIRE(ap && ap->dur && ap->frames && ap->idx, "duration_align: null tensor");
+  const mi355_duration_args a = *ap;
+  MI355_REQUIRE(a.forced_dur || a.logits, "duration_align: need logits or forced durations");
+  MI355_REQUIRE(a.T > 0 && a.T <= 512, "duration_align: T must be in [1, 512] (got %d)", a.T);
+  MI355_REQUIRE(a.speed > 0.f || a.forced_dur, "duration_align: speed must be positive");
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(duration_align_kernel, dim3(a.B), dim3(512), 0, (hipStream_t)stream, a);
+  MI355_LAUNCH_CHECK("duration_align");
+  return MI355_OK;
+}
+
+extern "C" int mi355_adain_pool_up2(const mi355_pool_up2_args* ap, void* stream) {
+  MI355_REQUIRE(ap && ap->x && ap->y && ap->scale && ap->shift && ap->w && ap->bias, "adain_pool_up2: null tensor");
+  const mi355_pool_up2_args a = *ap;
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(pool_up2_kernel, dim3((unsigned)((int64_t)a.B * 2 * a.L)), dim3(256), 0, (hipStream_t)stream, a);
+  MI355_LAUNCH_CHECK("adain_pool_up2");
+  return MI355_OK;
+}
+
+extern "C" int mi355_conv1d_c1_k3s2(const float* x, int32_t ldx_b, int32_t Lin, const int32_t* lens_in, float w0, float w1,
+                                    float w2, float bias, float* y, int64_t y_bstride, int32_t ldy, int32_t col, int32_t Lout,
+                                    int32_t B, void* stream) {
+  MI355_REQUIRE(x && y && B > 0 && Lout > 0, "conv1d_c1_k3s2: bad arguments");
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(conv1d_c1_k3s2_kernel, dim3((Lout + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, ldx_b, Lin,
+                     lens_in, w0, w1, w2, bias, y, y_bstride, ldy, col, Lout, B);
+  MI355_LAUNCH_CHECK("conv1d_c1_k3s2");
+  return MI355_OK;
+}

@@ -1,0 +1,154 @@
+// Instance-norm statistics -> AdaIN coefficients, and row LayerNorm (gfx950).
+// Reference call sites: InstanceNorm1d / AdaIN1d (tts/models/kokoro/istftnet.py:173-338),
+// nn.LayerNorm + AdaLayerNorm (tts/models/kokoro/modules.py:35,71-90,445,481,523,537,551).
+#include "common.h"
+
+namespace {
+
+// Partial per-channel sum / sum-of-squares in float64 (robust against cancellation without a second
+// pass over HBM): grid (ceil(C/32), nsplit, B), 256 threads = 32 row groups x 8 float4 lanes, so a
+// wave reads 8 full 128-B row segments per instruction.
+__global__ __launch_bounds__(256) void instnorm_partial_kernel(const mi355_adain_coef_args a, int rows_per_split) {
+  __shared__ double red[2][32][33];
+  const int tid = threadIdx.x, cg = tid & 7, rg = tid >> 3;
+  const int b = blockIdx.z, c = blockIdx.x * 32 + cg * 4;
+  const int len = a.lens ? a.lens[b] : a.L;
+  const int r0 = blockIdx.y * rows_per_split;
+  const int r1 = min(len, r0 + rows_per_split);
+  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  const float* xb = a.x + (int64_t)b * a.x_bstride;
+  if (c < a.C) {
+    for (int l = r0 + rg; l < r1; l += 32) {
+      const float4 v = *(const float4*)(xb + (int64_t)l * a.ldx + c);
+      const float t[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const double d = (double)t[i]; s[i] += d; q[i] += d * d; }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { red[0][rg][cg * 4 + i] = s[i]; red[1][rg][cg * 4 + i] = q[i]; }
+  __syncthreads();
+  if (tid < 64) {
+    const int which = tid >> 5, ch = tid & 31;
+    double t = 0;
+    for (int r = 0; r < 32; ++r) t += red[which][r][ch];
+    const int cc = blockIdx.x * 32 + ch;
+    if (cc < a.C && r0 < len) atomicAdd(a.sums + ((int64_t)b * a.C + cc) * 2 + which, t);
+  }
+}
+
+__global__ void adain_finalize_kernel(const mi355_adain_coef_args a) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (c >= a.out_ld) return;
+  float sc = 0.f, sh = 0.f;
+  if (c < a.C) {
+    const int len = a.lens ? a.lens[b] : a.L;
+    const double n = (double)(len > 0 ? len : 1);
+    const double mean = a.sums[((int64_t)b * a.C + c) * 2] / n;
+    double var = a.sums[((int64_t)b * a.C + c) * 2 + 1] / n - mean * mean;
+    if (var < 0) var = 0;
+    const float rstd = 1.0f / sqrtf((float)var + a.eps);
+    float g = 0.f, be = 0.f;
+    if (a.gb) { g = a.gb[(int64_t)b * a.gb_ld + c]; be = a.gb[(int64_t)b * a.gb_ld + a.C + c]; }
+    sc = (1.0f + g) * rstd;
+    sh = be - (float)mean * sc;
+  }
+  a.scale[(int64_t)b * a.out_ld + c] = sc;
+  a.shift[(int64_t)b * a.out_ld + c] = sh;
+}
+
+// one wave per row, up to 1024 channels held in registers (two-pass mean / variance like mx.var)
+__global__ __launch_bounds__(256) void layernorm_kernel(const mi355_layernorm_args a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)a.B * a.L) return;
+  const int b = (int)(row / a.L), l = (int)(row - (int64_t)b * a.L);
+  const int len = a.lens ? a.lens[b] : a.L;
+  if (l >= len) return;
+  const float* xr = a.x + (int64_t)b * a.x_bstride + (int64_t)l * a.ldx;
+  const float* rr = a.res ? a.res + (int64_t)b * a.res_bstride + (int64_t)l * a.ldr : nullptr;
+  float v[4][4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 256 + lane * 4;
+    if (c < a.C) {
+      float4 t = *(const float4*)(xr + c);
+      if (rr) { const float4 r4 = *(const float4*)(rr + c); t.x += r4.x; t.y += r4.y; t.z += r4.z; t.w += r4.w; }
+      v[i][0] = t.x; v[i][1] = t.y; v[i][2] = t.z; v[i][3] = t.w;
+      s += (t.x + t.y) + (t.z + t.w);
+    } else { v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f; }
+  }
+  const float mean = wave_sum(s) / (float)a.C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 256 + lane * 4;
+    if (c < a.C) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+    }
+  }
+  const float var = wave_sum(q) / (float)a.C;
+  const float rstd = 1.0f / sqrtf(var + a.eps);
+  float* yr = a.y + (int64_t)b * a.y_bstride + (int64_t)l * a.ldy;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 256 + lane * 4;
+    if (c < a.C) {
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t = (v[i][j] - mean) * rstd;
+        if (a.weight) t = t * a.weight[c + j] + (a.bias ? a.bias[c + j] : 0.f);
+        if (a.ada_gb) {
+          const float g = a.ada_gb[(int64_t)b * a.ada_ld + c + j];
+          const float be = a.ada_gb[(int64_t)b * a.ada_ld + a.C + c + j];
+          t = (1.0f + g) * t + be;
+        }
+        if (a.post_act == MI355_ACT_LEAKY) t = t > 0.f ? t : t * a.post_slope;
+        o[j] = t;
+      }
+      *(float4*)(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int mi355_adain_coef(const mi355_adain_coef_args* ap, void* stream) {
+  MI355_REQUIRE(ap && ap->x && ap->sums && ap->scale && ap->shift, "adain_coef: null tensor");
+  const mi355_adain_coef_args a = *ap;
+  MI355_REQUIRE(a.B > 0 && a.C > 0 && a.L > 0, "adain_coef: bad shape");
+  MI355_REQUIRE(a.ldx % 4 == 0 && a.x_bstride % 4 == 0 && a.ldx >= ((a.C + 3) & ~3), "adain_coef: ldx must be a multiple of 4 and cover C rounded up to 4");
+  MI355_REQUIRE(a.out_ld >= a.C, "adain_coef: out_ld < C");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(a.sums, 0, sizeof(double) * 2 * (size_t)a.B * a.C, st);
+  MI355_REQUIRE(e == hipSuccess, "adain_coef: memset failed: %s", hipGetErrorString(e));
+  const int cblocks = (a.C + 31) / 32;
+  int nsplit = (1024 + cblocks * a.B - 1) / (cblocks * a.B);
+  const int max_split = (a.L + 63) / 64;
+  if (nsplit > max_split) nsplit = max_split;
+  if (nsplit < 1) nsplit = 1;
+  const int rows = (a.L + nsplit - 1) / nsplit;
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(instnorm_partial_kernel, dim3(cblocks, nsplit, a.B), dim3(256), 0, st, a, rows);
+  MI355_LAUNCH_CHECK("instnorm_partial");
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(adain_finalize_kernel, dim3((a.out_ld + 127) / 128, a.B), dim3(128), 0, st, a);
+  MI355_LAUNCH_CHECK("adain_finalize");
+  return MI355_OK;
+}
+
+extern "C" int mi355_layernorm(const mi355_layernorm_args* ap, void* stream) {
+  MI355_REQUIRE(ap && ap->x && ap->y, "layernorm: null tensor");
+  const mi355_layernorm_args a = *ap;
+  MI355_REQUIRE(a.C > 0 && a.C <= 1024 && a.C % 4 == 0, "layernorm: C must be a multiple of 4 and <= 1024 (got %d)", a.C);
+  MI355_REQUIRE(a.ldx % 4 == 0 && a.ldy % 4 == 0 && a.x_bstride % 4 == 0 && a.y_bstride % 4 == 0, "layernorm: strides must be multiples of 4");
+  MI355_REQUIRE(!a.res || (a.ldr % 4 == 0 && a.res_bstride % 4 == 0), "layernorm: residual strides must be multiples of 4");
+  const int64_t rows = (int64_t)a.B * a.L;
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  MI355_LAUNCH_CHECK("layernorm");
+  return MI355_OK;
+}

@@ -1,0 +1,276 @@
+// Harmonic source (SineGen + SourceModuleHnNSF), small-n_fft STFT features and the iSTFT head of the
+// iSTFTNet Generator (tts/models/kokoro/istftnet.py:453-709, 797-835; dsp.py:385-513) for gfx950.
+//
+// Numerics notes (why parts of this file are fp64 / contraction-free):
+//  * SineGen's phase reaches 1e5..1e6 rad, so a 1-ulp difference in the x300 interpolation
+//    coordinates or in the cumulative sum is a visible phase error.  The coordinate and blend
+//    arithmetic therefore reproduces the reference's fp32 op sequence one rounding at a time
+//    (no FMA contraction), and the cumulative sum is the same sequential fp32 scan.
+//  * the 20-point DFTs are evaluated in fp64 (cost is nil) and rounded once, so the atan2 phase
+//    features agree with a correctly-rounded rfft; DC / Nyquist imaginary parts are +0 exactly as
+//    pocketfft (numpy, MLX-CPU) produces them.
+#include "common.h"
+
+namespace {
+
+// This translation unit is compiled with -ffp-contract=off (see build.py): HIP's default
+// -ffp-contract=fast would fuse a*b+c into one rounding and break the op-by-op mirror below.
+// (The __fmul_rn/__fadd_rn header intrinsics are plain operators and do NOT prevent contraction.)
+#pragma clang fp contract(off)
+
+__device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
+__device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
+__device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
+
+// torch-semantics linear coordinate (tts/models/interpolate.py:94-110), fp32 op by op
+__device__ __forceinline__ void lin_coord(int i, float scale, float half_scale, int in_w, int& lo, int& hi, float& fr) {
+  float x = mul_rn((float)i, scale);
+  x = add_rn(x, half_scale);
+  x = sub_rn(x, 0.5f);
+  x = fmaxf(x, 0.0f);
+  lo = (int)floorf(x);
+  hi = min(lo + 1, in_w - 1);
+  fr = sub_rn(x, (float)lo);
+}
+
+struct SineDims { int L; int small; int big; float sc_dn, hsc_dn, sc_up, hsc_up; };
+
+// tts/models/interpolate.py:41-50: size = max(1, ceil(float(W) * float(scale))) evaluated in doubles;
+// 600*F*(1/300) overshoots for some F (e.g. F = 7 -> 15 coarse steps), so this must be exact.
+__host__ __device__ inline SineDims sine_dims(int len2, int up) {
+  SineDims d;
+  d.L = len2 * up;
+  const double s_dn = (double)d.L * (1.0 / (double)up);
+  d.small = (int)ceil(s_dn); if (d.small < 1) d.small = 1;
+  d.big = (int)ceil((double)d.small * (double)up); if (d.big < 1) d.big = 1;
+  d.sc_dn = (float)((double)d.L / (double)d.small);
+  d.hsc_dn = (float)(0.5 * ((double)d.L / (double)d.small));
+  d.sc_up = (float)((double)d.small / (double)d.big);
+  d.hsc_up = (float)(0.5 * ((double)d.small / (double)d.big));
+  return d;
+}
+
+// phase_ws[b, h, i] = (cumsum_i(down(rad)) * 2 * pi) * up      -- one thread per (b, h), sequential scan
+__global__ void sine_phase_kernel(const mi355_sine_source_args a) {
+  const int h = threadIdx.x, b = blockIdx.x;
+  if (h >= a.H) return;
+  const int len2 = a.lens2 ? a.lens2[b] : a.L2;
+  const SineDims d = sine_dims(len2, a.up);
+  const int L = d.L;
+  const int small = min(d.small, a.L2 + 1);
+  const float* f0 = a.f0 + (int64_t)b * a.ld_f0;
+  const float mult = (float)(h + 1);
+  const float ini = (h == 0) ? 0.0f : a.rand_ini[(int64_t)b * a.H + h];
+  auto rad = [&](int t) {
+    const float fn = mul_rn(f0[t / a.up], mult);
+    float r = fmodf(fn / a.sr, 1.0f);
+    if (r < 0.f) r = add_rn(r, 1.0f);  // python-style modulo (np.mod / mx %) for negative f0
+    if (t == 0) r = add_rn(r, ini);
+    return r;
+  };
+  float* out = a.phase_ws + ((int64_t)b * a.H + h) * (a.L2 + 1);
+  float cum = 0.f;
+  const float pi_f = 3.14159265358979323846f;
+  for (int i = 0; i < small; ++i) {
+    float v;
+    if (L == 1) {
+      v = rad(0);
+    } else {
+      int lo, hi; float fr;
+      lin_coord(i, d.sc_dn, d.hsc_dn, L, lo, hi, fr);
+      v = add_rn(mul_rn(rad(lo), sub_rn(1.0f, fr)), mul_rn(rad(hi), fr));
+    }
+    cum = add_rn(cum, v);
+    float ph = mul_rn(mul_rn(cum, 2.0f), pi_f);
+    out[i] = mul_rn(ph, (float)a.up);
+  }
+}
+
+__global__ __launch_bounds__(256) void sine_merge_kernel(const mi355_sine_source_args a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const int len2 = a.lens2 ? a.lens2[b] : a.L2;
+  const SineDims d = sine_dims(len2, a.up);
+  const int L = d.L;
+  if (t >= L) return;
+  const int small = min(d.small, a.L2 + 1);
+  const int big = d.big;
+  const float f0v = a.f0[(int64_t)b * a.ld_f0 + t / a.up];
+  const float uv = f0v > a.voiced_thr ? 1.0f : 0.0f;
+  const float namp = add_rn(mul_rn(uv, a.noise_std), mul_rn(sub_rn(1.0f, uv), a.sine_amp) / 3.0f);
+  const float* nz = a.noise + ((int64_t)b * a.L2 * a.up + t) * a.H;
+  float accv = 0.f;
+  for (int h = 0; h < a.H; ++h) {
+    float sv = 0.f;
+    if (t < big) {
+      const float* ph = a.phase_ws + ((int64_t)b * a.H + h) * (a.L2 + 1);
+      float p;
+      if (small == 1) {
+        p = ph[0];
+      } else {
+        int lo, hi; float fr;
+        lin_coord(t, d.sc_up, d.hsc_up, small, lo, hi, fr);
+        p = add_rn(mul_rn(ph[lo], sub_rn(1.0f, fr)), mul_rn(ph[hi], fr));
+      }
+      sv = mul_rn(sinf(p), a.sine_amp);
+    }
+    const float sw = add_rn(mul_rn(sv, uv), mul_rn(namp, nz[h]));
+    accv = add_rn(accv, mul_rn(sw, a.lin_w[h]));
+  }
+  a.out[(int64_t)b * a.ld_out + t] = tanhf(add_rn(accv, a.lin_b));
+}
+
+// ---------------------------------------------------------------- small-n_fft STFT -> |X|, angle(X)
+constexpr int kMaxSmallFft = 64;
+
+__global__ __launch_bounds__(256) void stft_magphase_kernel(const mi355_stft_magphase_args a) {
+  __shared__ double twc[kMaxSmallFft], tws[kMaxSmallFft];
+  __shared__ float win[kMaxSmallFft];
+  const int N = a.n_fft, nb = N / 2 + 1;
+  if (threadIdx.x < N) {
+    double s, c;
+    sincospi(2.0 * threadIdx.x / (double)N, &s, &c);
+    twc[threadIdx.x] = c; tws[threadIdx.x] = s;
+    win[threadIdx.x] = a.window[threadIdx.x];
+  }
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int len = a.lens ? a.lens[b] : a.L;
+  const int nframes = len / a.hop + 1;
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nframes) return;
+  const float* xb = a.x + (int64_t)b * a.ldx;
+  double xw[kMaxSmallFft];
+  for (int n = 0; n < N; ++n) {
+    int i = f * a.hop + n - N / 2;
+    if (i < 0) i = -i;
+    if (i >= len) i = 2 * (len - 1) - i;
+    xw[n] = (double)mul_rn(xb[i], win[n]);  // frames * w is an fp32 product in the reference
+  }
+  float* yr = a.y + (int64_t)b * a.y_bstride + (int64_t)f * a.ldy;
+  for (int k = 0; k < nb; ++k) {
+    double re = 0.0, im = 0.0;
+    int m = 0;
+    for (int n = 0; n < N; ++n) {
+      re += xw[n] * twc[m];
+      im -= xw[n] * tws[m];
+      m += k; if (m >= N) m -= N;
+    }
+    float ref = (float)re, imf = (float)im;
+    if (k == 0 || 2 * k == N) imf = 0.0f;
+    yr[k] = hypotf(ref, imf);
+    yr[nb + k] = atan2f(imf, ref);
+  }
+}
+
+// ---------------------------------------------------------------- iSTFT head
+constexpr int kHeadFrames = 48;  // frames per block (plus overlap halo)
+
+__global__ __launch_bounds__(256) void istft_head_kernel(const mi355_istft_head_args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int N = a.n_fft, nb = N / 2 + 1, hop = a.hop;
+  const int halo = (N + hop - 1) / hop;           // frames overlapping one sample
+  const int FT = kHeadFrames + halo;               // frames staged per block
+  double* twc = (double*)smem;                     // [N]
+  double* tws = twc + N;                           // [N]
+  float* win = (float*)(tws + N);                  // [N]
+  float* spec = win + N;                           // [FT][nb][2]
+  float* td = spec + FT * nb * 2;                  // [FT][N] windowed time frames
+  const int b = blockIdx.y;
+  const int Fr = a.lens ? a.lens[b] : a.Fr;
+  const int fa = blockIdx.x * kHeadFrames - halo;  // first staged frame (may be negative)
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    double s, c;
+    sincospi(2.0 * i / (double)N, &s, &c);
+    twc[i] = c; tws[i] = s; win[i] = a.window[i];
+  }
+  const float* xb = a.x + (int64_t)b * a.x_bstride;
+  for (int i = threadIdx.x; i < FT * nb; i += blockDim.x) {
+    const int j = i / nb, k = i - j * nb, f = fa + j;
+    float re = 0.f, im = 0.f;
+    if (f >= 0 && f < Fr) {
+      const float mag = expf(xb[(int64_t)f * a.ldx + k]);
+      const float ph = sinf(xb[(int64_t)f * a.ldx + nb + k]);
+      re = mul_rn(mag, cosf(ph));
+      im = mul_rn(mag, sinf(ph));
+    }
+    spec[i * 2] = re; spec[i * 2 + 1] = im;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < FT * N; i += blockDim.x) {
+    const int j = i / N, n = i - j * N;
+    const float* sp = spec + j * nb * 2;
+    double acc = (double)sp[0];
+    if ((N & 1) == 0) acc += ((n & 1) ? -1.0 : 1.0) * (double)sp[(nb - 1) * 2];
+    const int kend = (N & 1) ? nb : nb - 1;
+    int m = n;  // (k*n) mod N for k = 1
+    for (int k = 1; k < kend; ++k) {
+      acc += 2.0 * ((double)sp[k * 2] * twc[m] - (double)sp[k * 2 + 1] * tws[m]);
+      m += n; if (m >= N) m -= N;
+    }
+    td[i] = mul_rn((float)(acc / (double)N), win[n]);
+  }
+  __syncthreads();
+  // output samples owned by this block: untrimmed positions p in [blockIdx.x*kHeadFrames*hop, +kHeadFrames*hop)
+  const int total = (Fr - 1) * hop;  // trimmed length
+  for (int i = threadIdx.x; i < kHeadFrames * hop; i += blockDim.x) {
+    const int p = blockIdx.x * kHeadFrames * hop + i;  // untrimmed position
+    const int t = p - N / 2;
+    if (t < 0 || t >= total) continue;
+    int f_lo = (p - N + hop) / hop; if (p - N + 1 <= 0) f_lo = 0;
+    int f_hi = p / hop; if (f_hi > Fr - 1) f_hi = Fr - 1;
+    float rec = 0.f, ws = 0.f;
+    for (int f = f_lo; f <= f_hi; ++f) {
+      const int n = p - f * hop;
+      if (n < 0 || n >= N) continue;
+      rec = add_rn(rec, td[(f - fa) * N + n]);
+      ws = add_rn(ws, mul_rn(win[n], win[n]));
+    }
+    a.audio[(int64_t)b * a.ld_audio + t] = (ws > 1e-10f) ? rec / ws : rec;
+  }
+}
+
+}  // namespace
+
+extern "C" int mi355_sine_source(const mi355_sine_source_args* ap, void* stream) {
+  MI355_REQUIRE(ap && ap->f0 && ap->rand_ini && ap->noise && ap->lin_w && ap->phase_ws && ap->out, "sine_source: null tensor");
+  const mi355_sine_source_args a = *ap;
+  MI355_REQUIRE(a.H > 0 && a.H <= 64 && a.up > 0 && a.L2 > 0 && a.B > 0, "sine_source: bad shape");
+  const SineDims d = sine_dims(a.L2, a.up);
+  MI355_REQUIRE(d.small <= a.L2 + 1, "sine_source: coarse length %d exceeds workspace", d.small);
+  hipStream_t st = (hipStream_t)stream;
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(sine_phase_kernel, dim3(a.B), dim3(64), 0, st, a);
+  MI355_LAUNCH_CHECK("sine_phase");
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(sine_merge_kernel, dim3((d.L + 255) / 256, a.B), dim3(256), 0, st, a);
+  MI355_LAUNCH_CHECK("sine_merge");
+  return MI355_OK;
+}
+
+extern "C" int mi355_stft_magphase(const mi355_stft_magphase_args* ap, void* stream) {
+  MI355_REQUIRE(ap && ap->x && ap->window && ap->y, "stft_magphase: null tensor");
+  const mi355_stft_magphase_args a = *ap;
+  MI355_REQUIRE(a.n_fft >= 2 && a.n_fft <= kMaxSmallFft, "stft_magphase: n_fft must be in [2, %d]", kMaxSmallFft);
+  MI355_REQUIRE(a.hop > 0 && a.L > a.n_fft / 2, "stft_magphase: input too short for reflect padding");
+  const int nframes = a.L / a.hop + 1;
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(stft_magphase_kernel, dim3((nframes + 255) / 256, a.B), dim3(256), 0, (hipStream_t)stream, a);
+  MI355_LAUNCH_CHECK("stft_magphase");
+  return MI355_OK;
+}
+
+extern "C" int mi355_istft_head(const mi355_istft_head_args* ap, void* stream) {
+  MI355_REQUIRE(ap && ap->x && ap->window && ap->audio, "istft_head: null tensor");
+  const mi355_istft_head_args a = *ap;
+  MI355_REQUIRE(a.n_fft >= 2 && a.n_fft <= kMaxSmallFft && a.hop > 0 && a.Fr > 1, "istft_head: bad shape");
+  const int N = a.n_fft, nb = N / 2 + 1;
+  const int halo = (N + a.hop - 1) / a.hop, FT = kHeadFrames + halo;
+  const size_t lds = sizeof(double) * 2 * N + sizeof(float) * N + sizeof(float) * FT * nb * 2 + sizeof(float) * FT * N;
+  // blocks cover untrimmed positions [0, (Fr-1)*hop + N)
+  const int total_untrimmed = (a.Fr - 1) * a.hop + N;
+  const int blocks = (total_untrimmed + kHeadFrames * a.hop - 1) / (kHeadFrames * a.hop);
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(istft_head_kernel, dim3(blocks, a.B), dim3(256), lds, (hipStream_t)stream, a);
+  MI355_LAUNCH_CHECK("istft_head");
+  return MI355_OK;
+}

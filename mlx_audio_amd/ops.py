@@ -1,0 +1,324 @@
+"""Thin torch-tensor front end of the C ABI (include/mi355audio.h).
+
+PyTorch is plumbing only: it owns device memory (caching allocator) and streams; every compute op
+below is a hand-written gfx950 kernel reached through ctypes.  All activations are float32,
+channels-last ``[B, L, C]`` views whose last stride is 1 (slices of wider buffers are fine: that is
+how channel concatenation is fused away).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_LEAKY, ACT_SNAKE, ACT_GELU = 0, 1, 2, 3
+
+# bench.py's roofline leg: when a list is installed here every conv_gemm launch is bracketed by
+# events on the launch stream and (algorithmic flops, algorithmic bytes, start, end) is appended.
+PROFILE = None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _nlc(t: torch.Tensor) -> Tuple[int, int, int, int, int]:
+    """(B, L, C, bstride, ld) of a channels-last view."""
+    assert t.dim() == 3 and t.stride(2) == 1 and t.dtype == torch.float32 and t.is_cuda, (t.shape, t.stride(), t.dtype)
+    return t.shape[0], t.shape[1], t.shape[2], t.stride(0), t.stride(1)
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise _lib.Mi355Error("mlx_audio_amd needs a ROCm device (MI355X / gfx950); there is no CPU fallback")
+    _lib.load()
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# --------------------------------------------------------------------------------------- weights
+@dataclass
+class PackedConv:
+    """bf16 weights of one conv / linear in MFMA fragment order plus its fp32 bias (device)."""
+
+    w: torch.Tensor  # int16 view of the packed bf16 data, on device
+    bias: Optional[torch.Tensor]
+    cout: int
+    k: int
+    cin: int
+
+
+def pack_conv(w: torch.Tensor, bias: Optional[torch.Tensor], device) -> PackedConv:
+    """``w``: float32 CPU tensor ``[Cout, K, Cin]`` (MLX conv layout) or ``[Cout, Cin]`` (linear)."""
+    if w.dim() == 2:
+        w = w[:, None, :]
+    w = w.detach().to(torch.float32).contiguous().cpu()
+    cout, k, cin = w.shape
+    lib = _lib.load()
+    n = lib.mi355_packed_conv_weight_elems(cout, k, cin)
+    out = np.empty(n, dtype=np.uint16)
+    rc = lib.mi355_pack_conv_weight_host(w.numpy().ctypes.data, cout, k, cin, out.ctypes.data)
+    _lib.check(rc, "mi355_pack_conv_weight_host")
+    wd = torch.from_numpy(out.view(np.int16)).to(device)
+    bd = None if bias is None else bias.detach().to(torch.float32).contiguous().to(device)
+    return PackedConv(wd, bd, cout, k, cin)
+
+
+def pack_conv_transpose(w_t: torch.Tensor, bias: Optional[torch.Tensor], stride: int, device) -> PackedConv:
+    """Polyphase repack of a transposed conv.  ``w_t``: ``[Cout, K, Cin]`` as ``mx.conv_transpose1d``
+    takes it (out[n] += x[t] * w_t[:, k, :] for n = t*stride + k - pad); K must be a multiple of
+    stride.  Returns the equivalent stride-1 conv with K/stride taps and ``stride*Cout`` outputs:
+    GEMM row u, column r*Cout+co  ->  out[u*stride + r - pad, co]."""
+    cout, k, cin = w_t.shape
+    assert k % stride == 0, "polyphase conv_transpose needs K % stride == 0"
+    kp = k // stride
+    w = torch.empty((stride * cout, kp, cin), dtype=torch.float32)
+    for r in range(stride):
+        for tp in range(kp):
+            w[r * cout:(r + 1) * cout, tp, :] = w_t[:, r + (kp - 1 - tp) * stride, :]
+    return pack_conv(w, bias, device)
+
+
+def pack_lstm_wh(wh_f: torch.Tensor, wh_b: torch.Tensor, device) -> torch.Tensor:
+    H = wh_f.shape[1]
+    lib = _lib.load()
+    out = np.empty(2 * 4 * H * H, dtype=np.uint16)
+    a = wh_f.detach().to(torch.float32).contiguous().cpu().numpy()
+    b = wh_b.detach().to(torch.float32).contiguous().cpu().numpy()
+    rc = lib.mi355_pack_lstm_wh_host(a.ctypes.data, b.ctypes.data, H, out.ctypes.data)
+    _lib.check(rc, "mi355_pack_lstm_wh_host")
+    return torch.from_numpy(out.view(np.int16)).to(device)
+
+
+# --------------------------------------------------------------------------------------- conv / linear
+def conv_gemm(x: torch.Tensor, pc: PackedConv, y: torch.Tensor, *, dil: int = 1, pad: int = 0,
+              lens_in: Optional[torch.Tensor] = None, lens_out: Optional[torch.Tensor] = None,
+              lout: Optional[int] = None, pre: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+              pre_act: int = ACT_NONE, pre_slope: float = 0.0, pre_alpha: Optional[torch.Tensor] = None,
+              post_act: int = ACT_NONE, post_slope: float = 0.0, res: Optional[torch.Tensor] = None,
+              res_shift: int = 0, out_scale: float = 1.0, accumulate: bool = False,
+              up: Optional[dict] = None, precision: int = 2, tile: int = 0,
+              flat: Optional[dict] = None, use_bias: bool = True):
+    """y = epilogue(conv1d(prologue(x)))  -- see mi355_conv_gemm_args in the header."""
+    B, Lin, Cx, xbs, ldx = _nlc(x)
+    By, Ly, Cy, ybs, ldy = _nlc(y)
+    assert B == By
+    kw = dict(x=_ptr(x), x_bstride=xbs, ldx=ldx, x_off=0, Cin=pc.cin, Lin=Lin, lens_in=_ptr(lens_in), flat_valid=0,
+              w=_ptr(pc.w), Cout=pc.cout, K=pc.k, dil=dil, pad=pad, pre_act=pre_act, pre_slope=pre_slope,
+              pre_alpha=_ptr(pre_alpha), bias=_ptr(pc.bias) if use_bias else None, post_act=post_act,
+              post_slope=post_slope, out_scale=out_scale, accumulate=int(accumulate), y=_ptr(y), y_bstride=ybs, ldy=ldy,
+              Lout=lout if lout is not None else Ly, lens_out=_ptr(lens_out), B=B, precision=precision, tile=tile)
+    if flat is not None:  # flattened strided conv: taps are contiguous in memory (C_in small)
+        kw.update(ldx=flat["ldx"], x_off=flat["x_off"], flat_valid=flat["channels"])
+    else:
+        assert Cx >= pc.cin or ldx >= pc.cin, (Cx, pc.cin)
+    if pre is not None:
+        sc, sh = pre
+        assert sc.dim() == 2 and sc.stride(1) == 1 and sc.stride(0) == sh.stride(0)
+        kw.update(pre_scale=_ptr(sc), pre_shift=_ptr(sh), pre_ld=sc.stride(0))
+    if res is not None:
+        _, _, _, rbs, ldr = _nlc(res)
+        kw.update(res=_ptr(res), res_bstride=rbs, ldr=ldr, res_shift=res_shift)
+    if up is not None:
+        kw.update(up_s=up["s"], up_p=up["p"], up_cout=up["cout"], up_row_off=up.get("row_off", 0),
+                  up_Lout=up["lout"], lens_up=_ptr(up.get("lens")))
+    if PROFILE is not None:
+        rows = (kw["Lout"] * B) if lens_out is None else int(lens_out.sum())
+        flops = 2.0 * rows * pc.cout * pc.k * pc.cin
+        byts = 4.0 * rows * (pc.cin + pc.cout) + 2.0 * pc.cout * pc.k * pc.cin  # fp32 activations in+out, bf16 weights once
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.call_struct("mi355_conv_gemm", "mi355_conv_gemm_args", _stream(), **kw)
+        e1.record()
+        PROFILE.append((flops, byts, e0, e1, (pc.cin, pc.cout, pc.k, dil, rows)))
+        return y
+    _lib.call_struct("mi355_conv_gemm", "mi355_conv_gemm_args", _stream(), **kw)
+    return y
+
+
+def adain_coef(x: torch.Tensor, gb: Optional[torch.Tensor], lens: Optional[torch.Tensor] = None, eps: float = 1e-5):
+    """Instance-norm stats of ``x`` [B, L, C] + AdaIN coefficients -> (scale, shift) each [B, C padded to 32]."""
+    B, L, C, xbs, ldx = _nlc(x)
+    cp = round_up(C, 32)
+    sums = torch.empty(B * C * 2, dtype=torch.float64, device=x.device)
+    scale = torch.empty((B, cp), dtype=torch.float32, device=x.device)
+    shift = torch.empty((B, cp), dtype=torch.float32, device=x.device)
+    _lib.call_struct("mi355_adain_coef", "mi355_adain_coef_args", _stream(), x=_ptr(x), x_bstride=xbs, ldx=ldx, C=C, L=L,
+                     lens=_ptr(lens), B=B, sums=_ptr(sums), gb=_ptr(gb), gb_ld=0 if gb is None else gb.stride(0), eps=eps,
+                     scale=_ptr(scale), shift=_ptr(shift), out_ld=cp)
+    return scale, shift
+
+
+def layernorm(x: torch.Tensor, y: torch.Tensor, *, weight=None, bias=None, ada_gb=None, res=None, eps=1e-5,
+              lens=None, post_act=ACT_NONE, post_slope=0.0):
+    B, L, C, xbs, ldx = _nlc(x)
+    _, _, _, ybs, ldy = _nlc(y)
+    kw = dict(x=_ptr(x), x_bstride=xbs, ldx=ldx, C=C, L=L, lens=_ptr(lens), B=B, weight=_ptr(weight), bias=_ptr(bias),
+              ada_gb=_ptr(ada_gb), ada_ld=0 if ada_gb is None else ada_gb.stride(0), eps=eps, post_act=post_act,
+              post_slope=post_slope, y=_ptr(y), y_bstride=ybs, ldy=ldy)
+    if res is not None:
+        _, _, _, rbs, ldr = _nlc(res)
+        kw.update(res=_ptr(res), res_bstride=rbs, ldr=ldr)
+    _lib.call_struct("mi355_layernorm", "mi355_layernorm_args", _stream(), **kw)
+    return y
+
+
+def lstm_bidir(xp: torch.Tensor, wh: torch.Tensor, H: int, out: torch.Tensor, lens=None):
+    B, L, _, xbs, ldxp = _nlc(xp)
+    _, _, _, obs, ldo = _nlc(out)
+    _lib.call_struct("mi355_lstm_bidir", "mi355_lstm_args", _stream(), xp=_ptr(xp), xp_bstride=xbs, ldxp=ldxp, wh=_ptr(wh),
+                     H=H, L=L, lens=_ptr(lens), B=B, out=_ptr(out), out_bstride=obs, ldo=ldo)
+    return out
+
+
+def attention(qkv: torch.Tensor, heads: int, dh: int, out: torch.Tensor, lens=None):
+    B, T, _, bs, ld = _nlc(qkv)
+    _, _, _, obs, ldo = _nlc(out)
+    _lib.call_struct("mi355_attention", "mi355_attention_args", _stream(), qkv=_ptr(qkv), bstride=bs, ld=ld, heads=heads,
+                     dh=dh, T=T, lens=_ptr(lens), B=B, out=_ptr(out), out_bstride=obs, ldo=ldo)
+    return out
+
+
+def gather_rows(table: torch.Tensor, idx: torch.Tensor, y: torch.Tensor, *, per_batch: bool = False, pos_table=None,
+                add_row=None, lens=None):
+    B, L, C, ybs, ldy = _nlc(y)
+    assert idx.dtype == torch.int32 and idx.dim() == 2 and idx.stride(1) == 1
+    if per_batch:
+        assert table.dim() == 3 and table.stride(2) == 1
+        tbs, ldt = table.stride(0), table.stride(1)
+    else:
+        assert table.dim() == 2 and table.stride(1) == 1
+        tbs, ldt = 0, table.stride(0)
+    _lib.call_struct("mi355_gather_rows", "mi355_gather_rows_args", _stream(), table=_ptr(table), ld_table=ldt,
+                     table_bstride=tbs, pos_table=_ptr(pos_table), ld_pos=0 if pos_table is None else pos_table.stride(0),
+                     add_row=_ptr(add_row), idx=_ptr(idx), idx_ld=idx.stride(0), C=C, L=L, lens=_ptr(lens), B=B, y=_ptr(y),
+                     y_bstride=ybs, ldy=ldy)
+    return y
+
+
+def broadcast_rows(v: torch.Tensor, y: torch.Tensor, lens=None):
+    B, L, C, ybs, ldy = _nlc(y)
+    assert v.dim() == 2 and v.stride(1) == 1
+    lib = _lib.load()
+    rc = lib.mi355_broadcast_rows(_ptr(v), v.stride(0), C, _ptr(y), ybs, ldy, L, _ptr(lens), B, _stream())
+    _lib.check(rc, "mi355_broadcast_rows")
+    return y
+
+
+def duration_align(logits: Optional[torch.Tensor], T: int, B: int, speed: float, idx_cap: int, device, lens=None,
+                   forced: Optional[torch.Tensor] = None, bins: int = 50):
+    dur = torch.empty((B, T), dtype=torch.int32, device=device)
+    raw = torch.zeros((B, T), dtype=torch.float32, device=device)
+    frames = torch.empty((B,), dtype=torch.int32, device=device)
+    idx = torch.zeros((B, idx_cap), dtype=torch.int32, device=device)
+    kw = dict(T=T, lens=_ptr(lens), B=B, speed=speed, forced_dur=_ptr(forced), dur=_ptr(dur), dur_raw=_ptr(raw),
+              frames=_ptr(frames), idx=_ptr(idx), idx_ld=idx_cap, bins=bins)
+    if logits is not None:
+        _, _, _, bs, ld = _nlc(logits)
+        kw.update(logits=_ptr(logits), bstride=bs, ld=ld)
+    _lib.call_struct("mi355_duration_align", "mi355_duration_args", _stream(), **kw)
+    return dur, raw, frames, idx
+
+
+def adain_pool_up2(x: torch.Tensor, scale, shift, slope: float, w: torch.Tensor, bias: torch.Tensor, y: torch.Tensor, lens=None):
+    B, L, C, xbs, ldx = _nlc(x)
+    _, _, _, ybs, ldy = _nlc(y)
+    _lib.call_struct("mi355_adain_pool_up2", "mi355_pool_up2_args", _stream(), x=_ptr(x), x_bstride=xbs, ldx=ldx, C=C, L=L,
+                     lens=_ptr(lens), B=B, scale=_ptr(scale), shift=_ptr(shift), pre_ld=scale.stride(0), slope=slope,
+                     w=_ptr(w), bias=_ptr(bias), y=_ptr(y), y_bstride=ybs, ldy=ldy)
+    return y
+
+
+def conv1d_c1_k3s2(x: torch.Tensor, w3, bias: float, y: torch.Tensor, col: int, lens_in=None):
+    """x [B, Lin] -> y[b, l, col] (Decoder.F0_conv / N_conv)."""
+    assert x.dim() == 2 and x.stride(1) == 1
+    B, Lout, _, ybs, ldy = _nlc(y)
+    lib = _lib.load()
+    rc = lib.mi355_conv1d_c1_k3s2(_ptr(x), x.stride(0), x.shape[1], _ptr(lens_in), float(w3[0]), float(w3[1]), float(w3[2]),
+                                  float(bias), _ptr(y), ybs, ldy, col, Lout, B, _stream())
+    _lib.check(rc, "mi355_conv1d_c1_k3s2")
+    return y
+
+
+# --------------------------------------------------------------------------------------- source / stft heads
+def sine_source(f0: torch.Tensor, rand_ini: torch.Tensor, noise: torch.Tensor, lin_w: torch.Tensor, lin_b: float, up: int,
+                lens2=None, sr: float = 24000.0, sine_amp: float = 0.1, noise_std: float = 0.003, voiced_thr: float = 10.0):
+    B, L2 = f0.shape
+    H = rand_ini.shape[1]
+    assert f0.stride(1) == 1 and noise.is_contiguous() and tuple(noise.shape) == (B, L2 * up, H)
+    ws = torch.empty((B, H, L2 + 1), dtype=torch.float32, device=f0.device)
+    out = torch.zeros((B, L2 * up), dtype=torch.float32, device=f0.device)
+    _lib.call_struct("mi355_sine_source", "mi355_sine_source_args", _stream(), f0=_ptr(f0), ld_f0=f0.stride(0), L2=L2,
+                     lens2=_ptr(lens2), B=B, up=up, H=H, sr=sr, sine_amp=sine_amp, noise_std=noise_std, voiced_thr=voiced_thr,
+                     rand_ini=_ptr(rand_ini), noise=_ptr(noise), lin_w=_ptr(lin_w), lin_b=lin_b, phase_ws=_ptr(ws),
+                     out=_ptr(out), ld_out=out.stride(0))
+    return out
+
+
+def stft_magphase(x: torch.Tensor, n_fft: int, hop: int, window: torch.Tensor, y: torch.Tensor, lens=None):
+    assert x.dim() == 2 and x.stride(1) == 1
+    B, _, _, ybs, ldy = _nlc(y)
+    _lib.call_struct("mi355_stft_magphase", "mi355_stft_magphase_args", _stream(), x=_ptr(x), ldx=x.stride(0), L=x.shape[1],
+                     lens=_ptr(lens), B=B, n_fft=n_fft, hop=hop, window=_ptr(window), y=_ptr(y), y_bstride=ybs, ldy=ldy)
+    return y
+
+
+def istft_head(x: torch.Tensor, n_fft: int, hop: int, window: torch.Tensor, audio: torch.Tensor, lens=None):
+    B, Fr, _, xbs, ldx = _nlc(x)
+    _lib.call_struct("mi355_istft_head", "mi355_istft_head_args", _stream(), x=_ptr(x), x_bstride=xbs, ldx=ldx, Fr=Fr,
+                     lens=_ptr(lens), B=B, n_fft=n_fft, hop=hop, window=_ptr(window), audio=_ptr(audio),
+                     ld_audio=audio.stride(0))
+    return audio
+
+
+# --------------------------------------------------------------------------------------- generic dsp
+def stft_frames(x: torch.Tensor, n_fft: int, hop: int, window: torch.Tensor, pad_mode: int, n_frames: int):
+    """x [B, L] -> complex64 [B, n_frames, n_fft//2+1]."""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32
+    B, L = x.shape
+    out = torch.empty((B, n_frames, n_fft // 2 + 1, 2), dtype=torch.float32, device=x.device)
+    _lib.call_struct("mi355_stft", "mi355_stft_args", _stream(), x=_ptr(x), ldx=x.stride(0), L=L, B=B, n_fft=n_fft, hop=hop,
+                     window=_ptr(window), pad_mode=pad_mode, n_frames=n_frames, out=_ptr(out))
+    return torch.view_as_complex(out)
+
+
+def logmel(x: torch.Tensor, n_fft: int, hop: int, window: torch.Tensor, pad_mode: int, n_frames: int, fb: torch.Tensor,
+           mode: int):
+    assert x.dim() == 2 and x.stride(1) == 1 and fb.is_contiguous()
+    B, L = x.shape
+    n_mels = fb.shape[0]
+    out = torch.empty((B, n_frames, n_mels), dtype=torch.float32, device=x.device)
+    gmax = torch.empty((B,), dtype=torch.float32, device=x.device) if mode == 0 else None
+    _lib.call_struct("mi355_logmel", "mi355_logmel_args", _stream(), x=_ptr(x), ldx=x.stride(0), L=L, B=B, n_fft=n_fft,
+                     hop=hop, window=_ptr(window), pad_mode=pad_mode, n_frames=n_frames, fb=_ptr(fb), n_mels=n_mels,
+                     mode=mode, out=_ptr(out), gmax=_ptr(gmax))
+    if mode == 0:
+        lib = _lib.load()
+        rc = lib.mi355_logmel_finish(_ptr(out), n_frames * n_mels, _ptr(gmax), B, _stream())
+        _lib.check(rc, "mi355_logmel_finish")
+    return out
+
+
+def istft_frames(spec: torch.Tensor, n_fft: int, hop: int, window: torch.Tensor, norm: torch.Tensor, norm_mode: int,
+                 clamp: bool, trim: int, out_len: int):
+    """spec complex64 [B, n_frames, nb] -> [B, out_len]."""
+    sr = torch.view_as_real(spec.contiguous())
+    B, n_frames = spec.shape[0], spec.shape[1]
+    ws = torch.empty((B, (n_frames + 1) // 2 * 2, n_fft), dtype=torch.float32, device=spec.device)
+    out = torch.empty((B, out_len), dtype=torch.float32, device=spec.device)
+    _lib.call_struct("mi355_istft", "mi355_istft_args", _stream(), spec=_ptr(sr), n_frames=n_frames, B=B, n_fft=n_fft,
+                     hop=hop, window=_ptr(window), norm=_ptr(norm), norm_mode=norm_mode, clamp=int(clamp), trim=trim,
+                     out_len=out_len, frames_ws=_ptr(ws), out=_ptr(out), ld_out=out.stride(0))
+    return out

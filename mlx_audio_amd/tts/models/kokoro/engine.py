@@ -1,0 +1,540 @@
+"""Kokoro-82M forward pass on MI355X: the host-side schedule over the HIP kernels.
+
+Mirrors ``Model.__call__`` of the reference (``tts/models/kokoro/kokoro.py:111-177``) and the modules
+it calls (``modules.py``, ``istftnet.py``), but batched over utterances (ragged, padded to the longest)
+and with the reference's op-by-op graph collapsed into fused kernels:
+
+  * weight norm is folded once at load time (the reference recomputes it every call, istftnet.py:130);
+  * all AdaIN / AdaLayerNorm style projections of the whole network are ONE GEMM per style vector;
+  * AdaIN + Snake / LeakyReLU are the prologue of the consuming conv, bias / residual / scaling /
+    resblock averaging its epilogue; channel concatenations are column offsets of wider buffers;
+  * ConvTranspose1d up-samplers run as polyphase stride-1 GEMMs; the alignment "one-hot matmul" is a gather.
+
+Everything here is plumbing (allocation, pointer arithmetic, launch order); all arithmetic on activations
+happens in libmi355audio.so.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .... import ops
+from ....ops import ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_SNAKE, PackedConv, round_up
+
+
+def fold_weight_norm(v: torch.Tensor, g: torch.Tensor, param_dtype: torch.dtype) -> torch.Tensor:
+    """w = g * v / (||v|| + 1e-7) over all axes but 0, evaluated in the parameter dtype exactly like the
+    reference's ``weight_norm`` (istftnet.py:53-93) does on an MLX array of that dtype; returns float32."""
+    v_ = v.to(param_dtype)
+    g_ = g.to(param_dtype)
+    axes = tuple(range(1, v_.dim()))
+    nrm = torch.sqrt((v_ * v_).sum(dim=axes, keepdim=True))
+    w = (v_ / (nrm + torch.tensor(1e-7, dtype=param_dtype))) * g_
+    return w.to(torch.float32)
+
+
+@dataclass
+class _AdaIN:
+    off: int  # column offset of [gamma | beta] in the style-projection output
+    c: int
+
+
+@dataclass
+class _ResBlk1d:  # AdainResBlk1d
+    conv1: PackedConv
+    conv2: PackedConv
+    norm1: _AdaIN
+    norm2: _AdaIN
+    conv1x1: Optional[PackedConv]
+    pool_w: Optional[torch.Tensor]
+    pool_b: Optional[torch.Tensor]
+    din: int
+    dout: int
+
+
+@dataclass
+class _ResBlock1:  # AdaINResBlock1
+    convs1: List[PackedConv]
+    convs2: List[PackedConv]
+    adain1: List[_AdaIN]
+    adain2: List[_AdaIN]
+    alpha1: List[torch.Tensor]
+    alpha2: List[torch.Tensor]
+    k: int
+    dils: Sequence[int]
+    ch: int
+
+
+@dataclass
+class _LSTM:
+    wx: PackedConv
+    wh: torch.Tensor
+    hid: int
+
+
+class _StyleBank:
+    """Collects every ``fc(style)`` of one style vector into a single [sum(2C), style_dim] linear."""
+
+    def __init__(self):
+        self.ws: List[torch.Tensor] = []
+        self.bs: List[torch.Tensor] = []
+        self.n = 0
+
+    def add(self, w: torch.Tensor, b: torch.Tensor) -> int:
+        off = self.n
+        self.ws.append(w.float())
+        self.bs.append(b.float())
+        self.n += round_up(w.shape[0], 4)
+        pad = self.n - off - w.shape[0]
+        if pad:
+            self.ws.append(torch.zeros(pad, w.shape[1]))
+            self.bs.append(torch.zeros(pad))
+        return off
+
+    def pack(self, device) -> PackedConv:
+        return ops.pack_conv(torch.cat(self.ws, 0), torch.cat(self.bs, 0), device)
+
+
+class KokoroEngine:
+    def __init__(self, weights: Dict[str, torch.Tensor], config: dict, device="cuda", param_dtype=torch.bfloat16,
+                 precision: int = 2):
+        ops.require_gpu()
+        self.cfg = config
+        self.dev = torch.device(device)
+        self.pdt = param_dtype
+        self.precision = precision
+        self.w = weights
+        ist = config["istftnet"]
+        self.rates = [int(r) for r in ist["upsample_rates"]]
+        self.kers = [int(k) for k in ist["upsample_kernel_sizes"]]
+        self.n_fft, self.hop = int(ist["gen_istft_n_fft"]), int(ist["gen_istft_hop_size"])
+        self.total_up = int(np.prod(self.rates)) * self.hop
+        self.rk = list(ist["resblock_kernel_sizes"])
+        self.rd = [list(d) for d in ist["resblock_dilation_sizes"]]
+        self.hid = config["hidden_dim"]
+        self.sty = config["style_dim"]
+        self.n_layer = config["n_layer"]
+        self.pb = config["plbert"]
+        self.bank_dec = _StyleBank()
+        self.bank_pred = _StyleBank()
+        self._load()
+
+    # ------------------------------------------------------------------ weight preparation (load time, CPU)
+    def _t(self, name) -> torch.Tensor:
+        return self.w[name].to(torch.float32)
+
+    def _q(self, t: torch.Tensor) -> torch.Tensor:
+        """Parameters live in the checkpoint dtype; compute sees exactly those values."""
+        return t.to(self.pdt).to(torch.float32)
+
+    def _lin(self, pre, bias=True) -> PackedConv:
+        return ops.pack_conv(self._q(self._t(f"{pre}.weight")), self._q(self._t(f"{pre}.bias")) if bias else None, self.dev)
+
+    def _wn(self, pre) -> torch.Tensor:
+        return fold_weight_norm(self.w[f"{pre}.weight_v"], self.w[f"{pre}.weight_g"], self.pdt)
+
+    def _convw(self, pre, bias=True) -> PackedConv:
+        b = self._q(self._t(f"{pre}.bias")) if bias and f"{pre}.bias" in self.w else None
+        return ops.pack_conv(self._wn(pre), b, self.dev)
+
+    def _dvec(self, t: torch.Tensor, pad_to: int = 0) -> torch.Tensor:
+        t = self._q(t.reshape(-1).float())
+        if pad_to and t.numel() < pad_to:
+            t = torch.cat([t, torch.ones(pad_to - t.numel())])
+        return t.contiguous().to(self.dev)
+
+    def _adain(self, bank: _StyleBank, pre, c) -> _AdaIN:
+        return _AdaIN(bank.add(self._q(self._t(f"{pre}.fc.weight")), self._q(self._t(f"{pre}.fc.bias"))), c)
+
+    def _lstm(self, pre) -> _LSTM:
+        wx = torch.cat([self._q(self._t(f"{pre}.Wx_forward")), self._q(self._t(f"{pre}.Wx_backward"))], 0)
+        b = torch.cat([self._q(self._t(f"{pre}.bias_ih_forward")) + self._q(self._t(f"{pre}.bias_hh_forward")),
+                       self._q(self._t(f"{pre}.bias_ih_backward")) + self._q(self._t(f"{pre}.bias_hh_backward"))])
+        whf, whb = self._q(self._t(f"{pre}.Wh_forward")), self._q(self._t(f"{pre}.Wh_backward"))
+        return _LSTM(ops.pack_conv(wx, b, self.dev), ops.pack_lstm_wh(whf, whb, self.dev), whf.shape[1])
+
+    def _resblk1d(self, bank, pre, din, dout) -> _ResBlk1d:
+        up = f"{pre}.pool.weight_v" in self.w
+        pool_w = pool_b = None
+        if up:
+            pool_w = self._wn(f"{pre}.pool")[:, :, 0].contiguous().to(self.dev)  # [C, 3]
+            pool_b = self._q(self._t(f"{pre}.pool.bias")).contiguous().to(self.dev)
+        return _ResBlk1d(self._convw(f"{pre}.conv1"), self._convw(f"{pre}.conv2"), self._adain(bank, f"{pre}.norm1", din),
+                         self._adain(bank, f"{pre}.norm2", dout),
+                         self._convw(f"{pre}.conv1x1", bias=False) if f"{pre}.conv1x1.weight_v" in self.w else None,
+                         pool_w, pool_b, din, dout)
+
+    def _resblock1(self, bank, pre, ch, k, dils) -> _ResBlock1:
+        cp = round_up(ch, 32)
+        return _ResBlock1([self._convw(f"{pre}.convs1.{i}") for i in range(3)], [self._convw(f"{pre}.convs2.{i}") for i in range(3)],
+                          [self._adain(bank, f"{pre}.adain1.{i}", ch) for i in range(3)],
+                          [self._adain(bank, f"{pre}.adain2.{i}", ch) for i in range(3)],
+                          [self._dvec(self._t(f"{pre}.alpha1.{i}"), cp) for i in range(3)],
+                          [self._dvec(self._t(f"{pre}.alpha2.{i}"), cp) for i in range(3)], k, dils, ch)
+
+    def _load(self):
+        d, hid, sty = self.dev, self.hid, self.sty
+        # ---- PL-BERT
+        e = "bert.embeddings"
+        self.word_emb = self._q(self._t(f"{e}.word_embeddings.weight")).contiguous().to(d)
+        self.pos_emb = self._q(self._t(f"{e}.position_embeddings.weight")).contiguous().to(d)
+        self.type_row = self._q(self._t(f"{e}.token_type_embeddings.weight"))[0].contiguous().to(d)
+        self.emb_ln = (self._dvec(self._t(f"{e}.LayerNorm.weight")), self._dvec(self._t(f"{e}.LayerNorm.bias")))
+        self.map_in = self._lin("bert.encoder.embedding_hidden_mapping_in")
+        lay = "bert.encoder.albert_layer_groups.0.albert_layers.0"
+        qkv_w = torch.cat([self._q(self._t(f"{lay}.attention.{n}.weight")) for n in ("query", "key", "value")], 0)
+        qkv_b = torch.cat([self._q(self._t(f"{lay}.attention.{n}.bias")) for n in ("query", "key", "value")], 0)
+        self.qkv = ops.pack_conv(qkv_w, qkv_b, d)
+        self.att_dense = self._lin(f"{lay}.attention.dense")
+        self.att_ln = (self._dvec(self._t(f"{lay}.attention.LayerNorm.weight")), self._dvec(self._t(f"{lay}.attention.LayerNorm.bias")))
+        self.ffn = self._lin(f"{lay}.ffn")
+        self.ffn_out = self._lin(f"{lay}.ffn_output")
+        self.full_ln = (self._dvec(self._t(f"{lay}.full_layer_layer_norm.weight")), self._dvec(self._t(f"{lay}.full_layer_layer_norm.bias")))
+        self.bert_encoder = self._lin("bert_encoder")
+        # ---- prosody predictor
+        self.dur_lstms = [self._lstm(f"predictor.text_encoder.lstms.{2 * i}") for i in range(self.n_layer)]
+        self.dur_adaln = [self._adain(self.bank_pred, f"predictor.text_encoder.lstms.{2 * i + 1}", hid) for i in range(self.n_layer)]
+        self.pred_lstm = self._lstm("predictor.lstm")
+        self.dur_proj = self._lin("predictor.duration_proj.linear_layer")
+        self.shared = self._lstm("predictor.shared")
+        self.f0_blocks, self.n_blocks = [], []
+        dims = [(hid, hid), (hid, hid // 2), (hid // 2, hid // 2)]
+        for i, (a, b) in enumerate(dims):
+            self.f0_blocks.append(self._resblk1d(self.bank_pred, f"predictor.F0.{i}", a, b))
+            self.n_blocks.append(self._resblk1d(self.bank_pred, f"predictor.N.{i}", a, b))
+        self.f0_proj = ops.pack_conv(self._q(self._t("predictor.F0_proj.weight")), self._q(self._t("predictor.F0_proj.bias")), d)
+        self.n_proj = ops.pack_conv(self._q(self._t("predictor.N_proj.weight")), self._q(self._t("predictor.N_proj.bias")), d)
+        # ---- text encoder
+        self.te_emb = self._q(self._t("text_encoder.embedding.weight")).contiguous().to(d)
+        self.te_cnn = []
+        for i in range(self.n_layer):
+            self.te_cnn.append((self._convw(f"text_encoder.cnn.{i}.0"), self._dvec(self._t(f"text_encoder.cnn.{i}.1.weight")),
+                                self._dvec(self._t(f"text_encoder.cnn.{i}.1.bias"))))
+        self.te_k = self.w["text_encoder.cnn.0.0.weight_v"].shape[1]
+        self.te_lstm = self._lstm("text_encoder.lstm")
+        # ---- decoder
+        self.enc_blk = self._resblk1d(self.bank_dec, "decoder.encode", hid + 2, 1024)
+        self.dec_blks = [self._resblk1d(self.bank_dec, f"decoder.decode.{i}", 1024 + 2 + 64, 1024 if i < 3 else 512) for i in range(4)]
+        f0w, nw = self._wn("decoder.F0_conv").reshape(-1), self._wn("decoder.N_conv").reshape(-1)
+        self.f0_conv = ([float(v) for v in f0w], float(self._q(self._t("decoder.F0_conv.bias"))[0]))
+        self.n_conv = ([float(v) for v in nw], float(self._q(self._t("decoder.N_conv.bias"))[0]))
+        self.asr_res = self._convw("decoder.asr_res.0")
+        g = "decoder.generator"
+        self.src_w = self._dvec(self._t(f"{g}.m_source.l_linear.weight"))
+        self.src_b = float(self._q(self._t(f"{g}.m_source.l_linear.bias"))[0])
+        c0 = int(self.cfg["istftnet"]["upsample_initial_channel"])
+        nk = len(self.rk)
+        self.ups, self.noise_convs, self.noise_res, self.resblocks = [], [], [], []
+        for i, (u, k) in enumerate(zip(self.rates, self.kers)):
+            cout = c0 // (2 ** (i + 1))
+            # stored (Cin, K, Cout); mx.conv_transpose1d receives weight.T = (Cout, K, Cin) (istftnet.py:161-166)
+            w_t = self._wn(f"{g}.ups.{i}").permute(2, 1, 0).contiguous()
+            self.ups.append(ops.pack_conv_transpose(w_t, self._q(self._t(f"{g}.ups.{i}.bias")), u, d))
+            ncw = self._q(self._t(f"{g}.noise_convs.{i}.weight"))  # (cout, K, n_fft+2)
+            ncb = self._q(self._t(f"{g}.noise_convs.{i}.bias"))
+            self.noise_convs.append(ops.pack_conv(ncw.reshape(ncw.shape[0], 1, -1), ncb, d))
+            last = i + 1 == len(self.rates)
+            self.noise_res.append(self._resblock1(self.bank_dec, f"{g}.noise_res.{i}", cout, 11 if last else 7, (1, 3, 5)))
+            for j in range(nk):
+                self.resblocks.append(self._resblock1(self.bank_dec, f"{g}.resblocks.{i * nk + j}", cout, self.rk[j], tuple(self.rd[j])))
+        self.conv_post = self._convw(f"{g}.conv_post")
+        self.style_dec = self.bank_dec.pack(d)
+        self.style_pred = self.bank_pred.pack(d)
+        # periodic Hann of MLXSTFT (istftnet.py:466) -- same float32 values as dsp.hanning(n, periodic=True)
+        n = self.n_fft
+        self.window = torch.tensor([0.5 * (1 - math.cos(2 * math.pi * i / n)) for i in range(n)], dtype=torch.float32, device=d)
+        self.w = None  # drop the CPU copy
+
+    # ------------------------------------------------------------------ building blocks (device)
+    def _new(self, *shape, zero=False):
+        return (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=self.dev)
+
+    def _gb(self, gb_all: torch.Tensor, a: _AdaIN) -> torch.Tensor:
+        return gb_all[:, a.off: a.off + 2 * a.c]
+
+    def _conv(self, x, pc, y, **kw):
+        kw.setdefault("precision", self.precision)
+        return ops.conv_gemm(x, pc, y, **kw)
+
+    def _bilstm(self, l: _LSTM, x, out, lens):
+        B, L = x.shape[0], x.shape[1]
+        xp = self._new(B, L, 8 * l.hid)
+        self._conv(x, l.wx, xp, lens_in=lens, lens_out=lens)
+        return ops.lstm_bidir(xp, l.wh, l.hid, out, lens=lens)
+
+    def _resblk1d_fwd(self, blk: _ResBlk1d, x, gb_all, out, lens, lens2=None):
+        """x [B, L, din] -> out [B, L or 2L, dout]."""
+        B, L = x.shape[0], x.shape[1]
+        up = blk.pool_w is not None
+        sc1, sh1 = ops.adain_coef(x, self._gb(gb_all, blk.norm1), lens)
+        lo = lens2 if up else lens
+        Lo = 2 * L if up else L
+        c1 = self._new(B, Lo, blk.dout)
+        if up:
+            pooled = self._new(B, Lo, round_up(blk.din, 32))[:, :, : blk.din]
+            ops.adain_pool_up2(x, sc1, sh1, 0.2, blk.pool_w, blk.pool_b, pooled, lens)
+            self._conv(pooled, blk.conv1, c1, pad=1, lens_in=lo, lens_out=lo)
+        else:
+            self._conv(x, blk.conv1, c1, pad=1, lens_in=lo, lens_out=lo, pre=(sc1, sh1), pre_act=ACT_LEAKY, pre_slope=0.2)
+        sc2, sh2 = ops.adain_coef(c1, self._gb(gb_all, blk.norm2), lo)
+        if blk.conv1x1 is not None:
+            short = self._new(B, L, blk.dout)
+            self._conv(x, blk.conv1x1, short, lens_in=lens, lens_out=lens)
+        else:
+            short = x
+        self._conv(c1, blk.conv2, out, pad=1, lens_in=lo, lens_out=lo, pre=(sc2, sh2), pre_act=ACT_LEAKY, pre_slope=0.2,
+                   res=short, res_shift=1 if up else 0, out_scale=1.0 / math.sqrt(2.0))
+        return out
+
+    def _resblock1_fwd(self, rb: _ResBlock1, x, gb_all, lens, out=None, accumulate=False, out_scale=1.0):
+        """AdaINResBlock1.  ``out`` None: returns a fresh tensor; else the last conv writes (or adds) into ``out``."""
+        B, L, C = x.shape
+        cur = x
+        work = None
+        tmp = self._new(B, L, C)
+        for i, dl in enumerate(rb.dils):
+            sc, sh = ops.adain_coef(cur, self._gb(gb_all, rb.adain1[i]), lens)
+            self._conv(cur, rb.convs1[i], tmp, dil=dl, pad=(rb.k * dl - dl) // 2, lens_in=lens, lens_out=lens, pre=(sc, sh),
+                       pre_act=ACT_SNAKE, pre_alpha=rb.alpha1[i])
+            sc, sh = ops.adain_coef(tmp, self._gb(gb_all, rb.adain2[i]), lens)
+            last = i == len(rb.dils) - 1
+            if last and out is not None:
+                dst, acc, scale = out, accumulate, out_scale
+            else:
+                if work is None:
+                    work = self._new(B, L, C)
+                dst, acc, scale = work, False, 1.0
+            self._conv(tmp, rb.convs2[i], dst, pad=(rb.k - 1) // 2, lens_in=lens, lens_out=lens, pre=(sc, sh),
+                       pre_act=ACT_SNAKE, pre_alpha=rb.alpha2[i], res=cur, accumulate=acc, out_scale=scale)
+            cur = dst
+        return cur
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, input_ids: Sequence[torch.Tensor], ref_s: torch.Tensor, speed: float = 1.0,
+                forced_durations: Optional[Sequence[torch.Tensor]] = None, rand_ini: Optional[torch.Tensor] = None,
+                noise: Optional[torch.Tensor] = None, noise_seed: int = 1234, return_intermediates: bool = False,
+                overrides: Optional[Dict[str, torch.Tensor]] = None):
+        """input_ids: list of B LongTensors (each INCLUDING the 0 BOS/EOS tokens); ref_s [B, 256] float32.
+
+        Returns (audio list of 1-D float32 tensors on device, pred_dur list of int32 tensors).
+        ``rand_ini`` [B, 9] / ``noise`` [B, Lmax, 9] are SineGen's random inputs (generated from
+        ``noise_seed`` when omitted).  ``overrides`` may replace intermediate signals: ``f0`` / ``n``
+        ([B, 2*Fmax] pitch / energy curves: external prosody control) and ``har`` ([B, frames, n_fft+2] harmonic
+        STFT features).  The parity tests use them to teacher-force the vocoder, because SineGen integrates F0
+        into a phase (chaotic in F0 rounding) and the reflect-padded edge frames have rounding-noise phases."""
+        dev, hid, sty = self.dev, self.hid, self.sty
+        B = len(input_ids)
+        Ts = [int(t.numel()) for t in input_ids]
+        Tm = max(Ts)
+        assert Tm <= self.pb["max_position_embeddings"], (Tm, self.pb["max_position_embeddings"])
+        ragged = B > 1
+        ids = torch.zeros((B, Tm), dtype=torch.int32)
+        for b, t in enumerate(input_ids):
+            ids[b, : Ts[b]] = t.to(torch.int32)
+        ids = ids.to(dev)
+        lens_t = torch.tensor(Ts, dtype=torch.int32, device=dev) if ragged else None
+        ref_s = ref_s.to(device=dev, dtype=torch.float32).contiguous()
+        s_dec = ref_s[:, :sty].contiguous()
+        s_pred = ref_s[:, sty:].contiguous()
+        # ---- every style projection of the network: two GEMMs
+        gb_dec = self._new(B, 1, self.style_dec.cout)
+        gb_pred = self._new(B, 1, self.style_pred.cout)
+        self._conv(s_dec[:, None, :], self.style_dec, gb_dec)
+        self._conv(s_pred[:, None, :], self.style_pred, gb_pred)
+        gb_dec, gb_pred = gb_dec[:, 0], gb_pred[:, 0]
+
+        # ---- PL-BERT (CustomAlbert, modules.py:626-655)
+        H = self.pb["hidden_size"]
+        heads = self.pb["num_attention_heads"]
+        E = self.word_emb.shape[1]
+        emb = self._new(B, Tm, E)
+        ops.gather_rows(self.word_emb, ids, emb, pos_table=self.pos_emb, add_row=self.type_row, lens=lens_t)
+        eps = float(self.pb.get("layer_norm_eps", 1e-12))
+        ops.layernorm(emb, emb, weight=self.emb_ln[0], bias=self.emb_ln[1], eps=eps, lens=lens_t)
+        h = self._new(B, Tm, H)
+        self._conv(emb, self.map_in, h, lens_in=lens_t, lens_out=lens_t)
+        qkv = self._new(B, Tm, 3 * H)
+        ctx = self._new(B, Tm, H)
+        tmp = self._new(B, Tm, H)
+        att = self._new(B, Tm, H)
+        inter = self._new(B, Tm, self.pb["intermediate_size"])
+        for _ in range(self.pb["num_hidden_layers"]):
+            self._conv(h, self.qkv, qkv, lens_in=lens_t, lens_out=lens_t)
+            ops.attention(qkv, heads, H // heads, ctx, lens=lens_t)
+            self._conv(ctx, self.att_dense, tmp, lens_in=lens_t, lens_out=lens_t, res=h)
+            ops.layernorm(tmp, att, weight=self.att_ln[0], bias=self.att_ln[1], eps=eps, lens=lens_t)
+            self._conv(att, self.ffn, inter, lens_in=lens_t, lens_out=lens_t, post_act=ACT_GELU)
+            self._conv(inter, self.ffn_out, tmp, lens_in=lens_t, lens_out=lens_t, res=att)
+            ops.layernorm(tmp, h, weight=self.full_ln[0], bias=self.full_ln[1], eps=eps, lens=lens_t)
+
+        # ---- DurationEncoder (modules.py:380-411): [d_en | style] ping-pong buffers
+        da = self._new(B, Tm, hid + sty, zero=True)
+        db = self._new(B, Tm, hid + sty, zero=True)
+        ops.broadcast_rows(s_pred, da[:, :, hid:], lens=lens_t)
+        ops.broadcast_rows(s_pred, db[:, :, hid:], lens=lens_t)
+        self._conv(h, self.bert_encoder, da[:, :, :hid], lens_in=lens_t, lens_out=lens_t)
+        cur, nxt = da, db
+        for i in range(self.n_layer):
+            self._bilstm(self.dur_lstms[i], cur, nxt[:, :, :hid], lens_t)
+            ops.layernorm(nxt[:, :, :hid], nxt[:, :, :hid], ada_gb=self._gb(gb_pred, self.dur_adaln[i]), eps=1e-5, lens=lens_t)
+            cur, nxt = nxt, cur
+        d = cur  # [B, Tm, hid+sty]
+        xl = self._new(B, Tm, hid, zero=True)
+        self._bilstm(self.pred_lstm, d, xl, lens_t)
+        bins = self.dur_proj.cout
+        logits = self._new(B, Tm, round_up(bins, 4))
+        self._conv(xl, self.dur_proj, logits[:, :, :bins], lens_in=lens_t, lens_out=lens_t)
+        forced = None
+        if forced_durations is not None:
+            forced = torch.zeros((B, Tm), dtype=torch.int32)
+            for b, fd in enumerate(forced_durations):
+                forced[b, : Ts[b]] = fd.to(torch.int32)
+            forced = forced.to(dev)
+        idx_cap = Tm * 100
+        dur, dur_raw, frames, idx = ops.duration_align(logits[:, :, :bins], Tm, B, float(speed), idx_cap, dev, lens=lens_t,
+                                                       forced=forced, bins=bins)
+        frames_h = frames.cpu()  # the one host sync of the forward pass (kokoro.py:149-152 syncs per phoneme)
+        Fs = [int(v) for v in frames_h]
+        Fm = max(Fs)
+        if Fm <= 0:
+            return [self._new(1, zero=True) for _ in range(B)], [dur[b, : Ts[b]] for b in range(B)]
+        idx = idx[:, :Fm]
+        lens_f = frames if ragged else None
+        lens_2f = frames * 2 if ragged else None
+
+        # ---- text encoder (modules.py:21-68)
+        x0 = self._new(B, Tm, hid)
+        ops.gather_rows(self.te_emb, ids, x0, lens=lens_t)
+        x1 = self._new(B, Tm, hid)
+        for pc, lw, lb in self.te_cnn:
+            self._conv(x0, pc, x1, pad=(self.te_k - 1) // 2, lens_in=lens_t, lens_out=lens_t)
+            ops.layernorm(x1, x0, weight=lw, bias=lb, eps=1e-5, lens=lens_t, post_act=ACT_LEAKY, post_slope=0.2)
+        t_en = self._new(B, Tm, hid, zero=True)
+        self._bilstm(self.te_lstm, x0, t_en, lens_t)
+
+        # ---- alignment (kokoro.py:148-169): gathers instead of one-hot matmuls
+        en = self._new(B, Fm, hid + sty)
+        ops.gather_rows(d, idx, en, per_batch=True, lens=lens_f)
+        c_in = hid + 2
+        dec_in = self._new(B, Fm, round_up(c_in, 32), zero=True)
+        ops.gather_rows(t_en, idx, dec_in[:, :, :hid], per_batch=True, lens=lens_f)
+        asr = dec_in[:, :, :hid]
+
+        # ---- F0 / N predictor (modules.py:355-377)
+        xs = self._new(B, Fm, hid, zero=True)
+        self._bilstm(self.shared, en, xs, lens_f)
+        curves = []
+        for blocks, proj in ((self.f0_blocks, self.f0_proj), (self.n_blocks, self.n_proj)):
+            y0 = self._new(B, Fm, blocks[0].dout)
+            self._resblk1d_fwd(blocks[0], xs, gb_pred, y0, lens_f)
+            y1 = self._new(B, 2 * Fm, blocks[1].dout)
+            self._resblk1d_fwd(blocks[1], y0, gb_pred, y1, lens_f, lens_2f)
+            y2 = self._new(B, 2 * Fm, blocks[2].dout)
+            self._resblk1d_fwd(blocks[2], y1, gb_pred, y2, lens_2f)
+            curve = self._new(B, 2 * Fm, 1, zero=True)
+            self._conv(y2, proj, curve, lens_in=lens_2f, lens_out=lens_2f)
+            curves.append(curve[:, :, 0])
+        f0_curve, n_curve = curves
+        overrides = overrides or {}
+        if "f0" in overrides:
+            f0_curve = overrides["f0"].to(device=dev, dtype=torch.float32).contiguous()
+            assert tuple(f0_curve.shape) == (B, 2 * Fm)
+        if "n" in overrides:
+            n_curve = overrides["n"].to(device=dev, dtype=torch.float32).contiguous()
+            assert tuple(n_curve.shape) == (B, 2 * Fm)
+
+        # ---- decoder (istftnet.py:981-997)
+        ops.conv1d_c1_k3s2(f0_curve, self.f0_conv[0], self.f0_conv[1], dec_in, hid, lens_in=lens_2f)
+        ops.conv1d_c1_k3s2(n_curve, self.n_conv[0], self.n_conv[1], dec_in, hid + 1, lens_in=lens_2f)
+        c_cat = 1024 + 64 + 2
+        ca = self._new(B, Fm, round_up(c_cat, 32), zero=True)
+        cb = self._new(B, Fm, round_up(c_cat, 32), zero=True)
+        trace = {}
+        self._resblk1d_fwd(self.enc_blk, dec_in[:, :, :c_in], gb_dec, ca[:, :, :1024], lens_f)
+        if return_intermediates:
+            trace.update(dec_in=dec_in[:, :, :c_in].clone(), enc=ca[:, :, :1024].clone())
+        self._conv(asr, self.asr_res, ca[:, :, 1024:1088], lens_in=lens_f, lens_out=lens_f)
+        ca[:, :, 1088:1090].copy_(dec_in[:, :, hid:hid + 2])
+        cb[:, :, 1024:1090].copy_(ca[:, :, 1024:1090])
+        cur, nxt = ca, cb
+        for i in range(3):
+            self._resblk1d_fwd(self.dec_blks[i], cur[:, :, :c_cat], gb_dec, nxt[:, :, :1024], lens_f)
+            cur, nxt = nxt, cur
+            if return_intermediates:
+                trace[f"dec{i}"] = cur[:, :, :1024].clone()
+        xg = self._new(B, 2 * Fm, 512)
+        self._resblk1d_fwd(self.dec_blks[3], cur[:, :, :c_cat], gb_dec, xg, lens_f, lens_2f)
+
+        # ---- generator (istftnet.py:797-835)
+        up = self.total_up
+        L2 = 2 * Fm
+        if rand_ini is None or noise is None:
+            rng = np.random.default_rng(noise_seed)
+            rand_ini = torch.from_numpy(rng.uniform(size=(B, 9)).astype(np.float32))
+            noise = torch.from_numpy(rng.standard_normal((B, L2 * up, 9)).astype(np.float32))
+        rand_ini = rand_ini.to(dev).contiguous()
+        noise = noise.to(dev).contiguous()
+        har_src = ops.sine_source(f0_curve, rand_ini, noise, self.src_w, self.src_b, up, lens2=lens_2f)
+        nb2 = self.n_fft + 2
+        n_har = L2 * up // self.hop + 1
+        har = self._new(B, n_har, nb2)
+        lens_samples = frames * (2 * up) if ragged else None
+        ops.stft_magphase(har_src, self.n_fft, self.hop, self.window, har, lens=lens_samples)
+        if "har" in overrides:
+            har.copy_(overrides["har"].to(device=dev, dtype=torch.float32))
+        lens_har = lens_samples // self.hop + 1 if ragged else None
+        x = xg
+        L = L2
+        lens_x = lens_2f
+        nk = len(self.rk)
+        for i, (u, k) in enumerate(zip(self.rates, self.kers)):
+            last = i + 1 == len(self.rates)
+            cout = self.ups[i].cout // u
+            Lo = L * u + (1 if last else 0)
+            lens_o = (lens_x * u + (1 if last else 0)) if ragged else None
+            # harmonic branch
+            xsrc = self._new(B, Lo, cout)
+            if not last:
+                sf = int(np.prod(self.rates[i + 1:]))
+                self._conv(har, self.noise_convs[i], xsrc, lens_in=lens_har, lens_out=lens_o,
+                           flat=dict(ldx=sf * nb2, x_off=-((sf + 1) // 2) * nb2, channels=nb2))
+            else:
+                self._conv(har, self.noise_convs[i], xsrc, lens_in=lens_har, lens_out=lens_o)
+            if return_intermediates:
+                trace[f"nconv{i}"] = xsrc.clone()
+            xsrc = self._resblock1_fwd(self.noise_res[i], xsrc, gb_dec, lens_o)
+            if return_intermediates:
+                trace[f"nres{i}"] = xsrc.clone()
+            # up-sampler: leaky_relu(0.1) prologue, polyphase GEMM, "+ x_source" epilogue
+            kp = k // u
+            xu = self._new(B, Lo, cout)
+            lens_gemm = (lens_x + (kp - 1)) if ragged else None
+            lens_ct = (lens_x * u) if ragged else None
+            self._conv(x, self.ups[i], xu, pad=kp - 1, lout=L + kp - 1, lens_in=lens_x, lens_out=lens_gemm, pre_act=ACT_LEAKY,
+                       pre_slope=0.1, res=xsrc, up=dict(s=u, p=(k - u) // 2, cout=cout, row_off=1 if last else 0, lout=L * u, lens=lens_ct))
+            if last:
+                xu[:, 0, :].copy_(xsrc[:, 0, :])  # the zero left-pad row of "reflection_pad" + x_source
+            if return_intermediates:
+                trace[f"xu{i}"] = xu.clone()
+            acc = self._new(B, Lo, cout)
+            for j in range(nk):
+                self._resblock1_fwd(self.resblocks[i * nk + j], xu, gb_dec, lens_o, out=acc, accumulate=j > 0,
+                                    out_scale=(1.0 / nk) if j == nk - 1 else 1.0)
+            x, L, lens_x = acc, Lo, lens_o
+            if return_intermediates:
+                trace[f"stage{i}"] = acc.clone()
+        post = self._new(B, L, round_up(nb2, 4))
+        self._conv(x, self.conv_post, post[:, :, :nb2], pad=3, lens_in=lens_x, lens_out=lens_x, pre_act=ACT_LEAKY, pre_slope=0.01)
+        audio = self._new(B, (L - 1) * self.hop, zero=True)
+        ops.istft_head(post[:, :, :nb2], self.n_fft, self.hop, self.window, audio, lens=lens_x)
+        outs = [audio[b, : Fs[b] * 2 * up] for b in range(B)]
+        durs = [dur[b, : Ts[b]] for b in range(B)]
+        if return_intermediates:
+            return outs, durs, dict(d=d, en=en, f0=f0_curve, n=n_curve, asr=asr, t_en=t_en, dur_raw=dur_raw, har_src=har_src,
+                                    har=har, bert=h, xg=xg, post=post[:, :, :nb2], dec3=xg, **trace)
+        return outs, durs

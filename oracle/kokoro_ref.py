@@ -344,14 +344,16 @@ def istft_head(x: Tensor, n_fft: int, hop: int) -> Tensor:
     return torch.from_numpy(np.stack(outs, axis=0))[:, None, :]
 
 
-def generator(p: P, x: Tensor, s: Tensor, f0_curve: Tensor, cfg: dict, rand_ini, noise) -> Tensor:
-    """Generator.__call__ (istftnet.py:797-835)."""
+def generator(p: P, x: Tensor, s: Tensor, f0_curve: Tensor, cfg: dict, rand_ini, noise, trace=None) -> Tensor:
+    """Generator.__call__ (istftnet.py:797-835).  ``trace`` (dict) collects stage outputs for tests."""
     rates, kernels = cfg["upsample_rates"], cfg["upsample_kernel_sizes"]
     rk, rd = cfg["resblock_kernel_sizes"], cfg["resblock_dilation_sizes"]
     n_fft, hop = cfg["gen_istft_n_fft"], cfg["gen_istft_hop_size"]
     total_up = int(np.prod(rates)) * hop
     har_src = sine_source(p, f0_curve, rand_ini, noise, upsample=total_up)
     har = torch.from_numpy(stft_mag_phase(har_src, n_fft, hop)).to(x.dtype)  # [B, 22, frames]
+    if trace is not None:
+        trace.update(har_src=torch.from_numpy(har_src), har=har, xg=x)
     nk = len(rk)
     for i, (u, k) in enumerate(zip(rates, kernels)):
         x = leaky_relu(x, 0.1)
@@ -365,27 +367,40 @@ def generator(p: P, x: Tensor, s: Tensor, f0_curve: Tensor, cfg: dict, rand_ini,
             xs = conv1d_mlx(har, nc("weight"), nc("bias"))
             nres_k = 11
         assert wk == (stride_f0 * 2 if i + 1 < len(rates) else 1)
+        if trace is not None:
+            trace[f"nconv{i}"] = xs
         xs = adain_resblock1(p.sub(f"noise_res.{i}"), xs, s, nres_k, (1, 3, 5))
+        if trace is not None:
+            trace[f"nres{i}"] = xs
         x = conv_weighted(p.sub(f"ups.{i}"), x, transpose=True, stride=u, padding=(k - u) // 2)
         if i == len(rates) - 1:
             x = F.pad(x, (1, 0))  # "ReflectionPad1d" is a constant zero pad (istftnet.py:712-718)
         x = x + xs
+        if trace is not None:
+            trace[f"xu{i}"] = x
         acc = None
         for j in range(nk):
             r = adain_resblock1(p.sub(f"resblocks.{i * nk + j}"), x, s, rk[j], tuple(rd[j]))
             acc = r if acc is None else acc + r
         x = acc / nk
+        if trace is not None:
+            trace[f"stage{i}"] = x
     x = leaky_relu(x, 0.01)
     x = conv_weighted(p.sub("conv_post"), x, padding=3)
+    if trace is not None:
+        trace["post"] = x
     return istft_head(x, n_fft, hop)
 
 
-def decoder(p: P, asr: Tensor, f0_curve: Tensor, n_curve: Tensor, s: Tensor, cfg: dict, rand_ini, noise) -> Tensor:
+def decoder(p: P, asr: Tensor, f0_curve: Tensor, n_curve: Tensor, s: Tensor, cfg: dict, rand_ini, noise, trace=None) -> Tensor:
     """Decoder.__call__ (istftnet.py:981-997) -> [B, 1, samples]."""
     f0 = conv_weighted(p.sub("F0_conv"), f0_curve[:, None, :], stride=2, padding=1)
     n = conv_weighted(p.sub("N_conv"), n_curve[:, None, :], stride=2, padding=1)
     x = torch.cat([asr, f0, n], dim=1)
     x = adain_resblk1d(p.sub("encode"), x, s, upsample=False)
+    if trace is not None:
+        trace["dec_in"] = torch.cat([asr, f0, n], dim=1)
+        trace["enc"] = x
     asr_res = conv_weighted(p.sub("asr_res.0"), asr, padding=0)
     res = True
     for i in range(4):
@@ -393,9 +408,11 @@ def decoder(p: P, asr: Tensor, f0_curve: Tensor, n_curve: Tensor, s: Tensor, cfg
             x = torch.cat([x, asr_res, f0, n], dim=1)
         up = p.has(f"decode.{i}.pool.weight_v")
         x = adain_resblk1d(p.sub(f"decode.{i}"), x, s, upsample=up)
+        if trace is not None:
+            trace[f"dec{i}"] = x
         if up:
             res = False
-    return generator(p.sub("generator"), x, s, f0_curve, cfg, rand_ini, noise)
+    return generator(p.sub("generator"), x, s, f0_curve, cfg, rand_ini, noise, trace)
 
 
 # ------------------------------------------------------------------ full model
@@ -455,7 +472,8 @@ class KokoroRef:
                 up = int(np.prod(cfg["istftnet"]["upsample_rates"])) * cfg["istftnet"]["gen_istft_hop_size"]
                 rand_ini = rng.uniform(size=(1, 9)).astype(np.float32)
                 noise = rng.standard_normal((1, 2 * Fr * up, 9)).astype(np.float32)
-            audio = decoder(p.sub("decoder"), asr, f0, nn_, ref_s[:, :128], cfg["istftnet"], rand_ini, noise)[0]
+            trace = {} if return_intermediates else None
+            audio = decoder(p.sub("decoder"), asr, f0, nn_, ref_s[:, :128], cfg["istftnet"], rand_ini, noise, trace)[0]
             if return_intermediates:
-                return audio, pred_dur, dict(d=d, en=en, f0=f0, n=nn_, asr=asr, raw_dur=raw)
+                return audio, pred_dur, dict(d=d, en=en, f0=f0, n=nn_, asr=asr, raw_dur=raw, **trace)
             return audio, pred_dur

@@ -1,0 +1,436 @@
+"""Parity of every HIP kernel (called through the C ABI) against the CPU oracle / fp64 torch.
+
+All tests here need a real MI355X: run with ``pytest -m gpu``.  Tolerances are stated per test:
+bit-exact for integer/index outputs, fp32-level for everything computed in fp32, and ~2^-16
+relative for the bf16 hi+lo split GEMM (precision=2; precision=1 is the plain bf16 pass).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mlx_audio_amd import ops as _ops
+
+    _ops.require_gpu()
+    return _ops
+
+
+DEV = "cuda"
+
+
+def bf16r(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def ref_conv_nlc(x, w, b, dil, pad):
+    """x [B, L, Cin] fp64, w [Cout, K, Cin] -> [B, Lout, Cout] (zero padding `pad` left, symmetric right)."""
+    y = F.conv1d(x.transpose(1, 2).double(), w.permute(0, 2, 1).double(), None if b is None else b.double(),
+                 padding=pad, dilation=dil)
+    return y.transpose(1, 2)
+
+
+@pytest.mark.parametrize("cin,cout,k,dil,L,B,tile", [
+    (128, 128, 7, 3, 300, 2, 0),
+    (128, 128, 3, 1, 700, 1, 128128),
+    (256, 256, 11, 5, 257, 1, 64128),
+    (256, 256, 11, 5, 257, 1, 128128),
+    (512, 64, 1, 1, 77, 3, 0),
+    (1090, 1024, 3, 1, 45, 1, 0),
+    (514, 200, 3, 1, 33, 2, 64064),
+    (768, 50, 1, 1, 80, 1, 0),
+    (128, 22, 7, 1, 500, 1, 0),
+])
+def test_conv_gemm_plain(ops, cin, cout, k, dil, L, B, tile):
+    g = torch.Generator().manual_seed(cin + cout + k)
+    w = bf16r(torch.randn(cout, k, cin, generator=g) / math.sqrt(k * cin))
+    bias = torch.randn(cout, generator=g) * 0.1
+    ld = ops.round_up(cin, 32)
+    x = torch.randn(B, L, ld, generator=g)
+    pad = (k * dil - dil) // 2
+    pc = ops.pack_conv(w, bias, DEV)
+    xd = x.to(DEV)
+    y = torch.full((B, L, ops.round_up(cout, 4)), float("nan"), device=DEV)
+    for prec, tol in ((2, 3e-5), (1, 1.5e-2)):
+        ops.conv_gemm(xd[:, :, :cin], pc, y[:, :, :cout], dil=dil, pad=pad, precision=prec, tile=tile)
+        torch.cuda.synchronize()
+        ref = ref_conv_nlc(x[:, :, :cin], w, bias, dil, pad)
+        got = y[:, :, :cout].cpu()
+        assert torch.isfinite(got).all()
+        assert rel_err(got, ref) < tol, (prec, rel_err(got, ref))
+
+
+def test_conv_gemm_fused_prologue_epilogue_ragged(ops):
+    """AdaIN affine + Snake in front, bias + residual(row>>1) + scale + accumulate behind, ragged batch."""
+    g = torch.Generator().manual_seed(7)
+    B, L, C, K, dil = 3, 210, 128, 7, 3
+    lens = torch.tensor([210, 64, 131], dtype=torch.int32)
+    w = bf16r(torch.randn(C, K, C, generator=g) / math.sqrt(K * C))
+    bias = torch.randn(C, generator=g) * 0.1
+    x = torch.randn(B, L, C, generator=g)
+    sc = torch.rand(B, C, generator=g) + 0.5
+    sh = torch.randn(B, C, generator=g) * 0.3
+    alpha = torch.rand(C, generator=g) + 0.5
+    res = torch.randn(B, (L + 1) // 2, C, generator=g)
+    y0 = torch.randn(B, L, C, generator=g)
+    pad = (K * dil - dil) // 2
+    pc = ops.pack_conv(w, bias, DEV)
+    lens_d = lens.to(DEV)
+    y = y0.clone().to(DEV)
+    ops.conv_gemm(x.to(DEV), pc, y, dil=dil, pad=pad, lens_in=lens_d, lens_out=lens_d, pre=(sc.to(DEV), sh.to(DEV)),
+                  pre_act=ops.ACT_SNAKE, pre_alpha=alpha.to(DEV), res=res.to(DEV), res_shift=1, out_scale=0.5, accumulate=True)
+    torch.cuda.synchronize()
+    got = y.cpu()
+    for b in range(B):
+        n = int(lens[b])
+        t = x[b:b + 1, :n].double() * sc[b].double() + sh[b].double()
+        t = t + (1.0 / alpha.double()) * torch.sin(alpha.double() * t) ** 2
+        ref = ref_conv_nlc(t, w, bias, dil, pad)[0]
+        ref = (ref + res[b, torch.arange(n) // 2].double() + y0[b, :n].double()) * 0.5
+        assert rel_err(got[b, :n], ref) < 3e-5
+        assert torch.equal(got[b, n:], y0[b, n:])  # rows beyond the item's length are never written
+
+
+@pytest.mark.parametrize("cin,cout,k,s,L,row_off", [(512, 256, 20, 10, 53, 0), (256, 128, 12, 6, 130, 1), (64, 32, 4, 2, 9, 0)])
+def test_conv_transpose_polyphase(ops, cin, cout, k, s, L, row_off):
+    g = torch.Generator().manual_seed(k * s)
+    p = (k - s) // 2
+    w_t = bf16r(torch.randn(cout, k, cin, generator=g) / math.sqrt(k * cin / s))  # mx.conv_transpose1d layout
+    bias = torch.randn(cout, generator=g) * 0.1
+    x = torch.randn(2, L, cin, generator=g)
+    lout = (L - 1) * s - 2 * p + k
+    res = torch.randn(2, lout + row_off, cout, generator=g)
+    pc = ops.pack_conv_transpose(w_t, bias, s, DEV)
+    y = torch.full((2, lout + row_off, cout), float("nan"), device=DEV)
+    kp = k // s
+    ops.conv_gemm(x.to(DEV), pc, y, pad=kp - 1, lout=L + kp - 1, pre_act=ops.ACT_LEAKY, pre_slope=0.1, res=res.to(DEV),
+                  up=dict(s=s, p=p, cout=cout, row_off=row_off, lout=lout))
+    torch.cuda.synchronize()
+    xa = F.leaky_relu(x.double(), 0.1).transpose(1, 2)
+    ref = F.conv_transpose1d(xa, w_t.permute(2, 0, 1).double(), bias.double(), stride=s, padding=p).transpose(1, 2)
+    assert ref.shape[1] == lout
+    ref = ref + res[:, row_off:].double()
+    got = y[:, row_off:].cpu()
+    assert rel_err(got, ref) < 3e-5
+    if row_off:
+        assert torch.isnan(y[:, :row_off]).all()  # the left pad row is the caller's
+
+
+def test_conv_flat_strided_small_cin(ops):
+    """noise_convs[0]: Conv1d(22 -> 256, k=12, stride=6, padding=3) on the contiguous [L, 22] feature map."""
+    g = torch.Generator().manual_seed(3)
+    B, L, cin, cout, k, s, p = 2, 601, 22, 256, 12, 6, 3
+    w = bf16r(torch.randn(cout, k, cin, generator=g) / math.sqrt(k * cin))
+    bias = torch.randn(cout, generator=g) * 0.1
+    x = torch.randn(B, L, cin, generator=g)
+    lout = (L + 2 * p - k) // s + 1
+    pc = ops.pack_conv(w.reshape(cout, 1, k * cin), bias, DEV)
+    y = torch.full((B, lout, cout), float("nan"), device=DEV)
+    lens = torch.tensor([L, 301], dtype=torch.int32)
+    louts = ((lens + 2 * p - k) // s + 1).to(torch.int32)
+    ops.conv_gemm(x.to(DEV), pc, y, lens_in=lens.to(DEV), lens_out=louts.to(DEV),
+                  flat=dict(ldx=s * cin, x_off=-p * cin, channels=cin))
+    torch.cuda.synchronize()
+    for b in range(B):
+        n = int(lens[b])
+        ref = F.conv1d(x[b:b + 1, :n].double().transpose(1, 2), w.permute(0, 2, 1).double(), bias.double(), stride=s, padding=p)
+        ref = ref.transpose(1, 2)[0]
+        assert ref.shape[0] == int(louts[b])
+        assert rel_err(y[b, : ref.shape[0]].cpu(), ref) < 3e-5
+    # K=1, 22 channels, ld=22 (noise_convs[1])
+    w1 = bf16r(torch.randn(128, 1, cin, generator=g))
+    pc1 = ops.pack_conv(w1, None, DEV)
+    y1 = torch.empty((B, L, 128), device=DEV)
+    ops.conv_gemm(x.to(DEV), pc1, y1)
+    torch.cuda.synchronize()
+    assert rel_err(y1.cpu(), x.double() @ w1[:, 0].double().t()) < 3e-5
+
+
+def test_adain_coef(ops):
+    g = torch.Generator().manual_seed(11)
+    B, L, C = 3, 1000, 514
+    lens = torch.tensor([1000, 333, 17], dtype=torch.int32)
+    ld = ops.round_up(C, 32)
+    x = torch.randn(B, L, ld, generator=g) * 3 + 50.0  # large mean: exercises the cancellation-safe path
+    gb = torch.randn(B, 2 * C + 8, generator=g)
+    sc, sh = ops.adain_coef(x.to(DEV)[:, :, :C], gb.to(DEV), lens=lens.to(DEV))
+    torch.cuda.synchronize()
+    for b in range(B):
+        xb = x[b, : int(lens[b]), :C].double()
+        mean, var = xb.mean(0), xb.var(0, unbiased=False)
+        scale = (1 + gb[b, :C].double()) / torch.sqrt(var + 1e-5)
+        shift = gb[b, C:2 * C].double() - mean * scale
+        assert rel_err(sc[b, :C].cpu(), scale) < 2e-5
+        assert float((sh[b, :C].cpu().double() - shift).abs().max() / shift.abs().max()) < 2e-5
+    assert float(sc[:, C:].abs().max()) == 0.0
+
+
+def test_layernorm_variants(ops):
+    g = torch.Generator().manual_seed(5)
+    B, L, C = 2, 37, 768
+    x = torch.randn(B, L, C, generator=g) * 2 + 1
+    r = torch.randn(B, L, C, generator=g)
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    y = torch.empty(B, L, C, device=DEV)
+    ops.layernorm(x.to(DEV), y, weight=w.to(DEV), bias=b.to(DEV), res=r.to(DEV), eps=1e-12)
+    torch.cuda.synchronize()
+    ref = F.layer_norm((x + r).double(), (C,), w.double(), b.double(), 1e-12)
+    assert float((y.cpu().double() - ref).abs().max()) < 2e-5
+    gb = torch.randn(B, 2 * 512, generator=g)
+    x2 = torch.randn(B, L, 640, generator=g)
+    xd = x2.to(DEV)
+    ops.layernorm(xd[:, :, :512], xd[:, :, :512], ada_gb=gb.to(DEV), eps=1e-5, post_act=ops.ACT_LEAKY, post_slope=0.2)
+    torch.cuda.synchronize()
+    ref = F.layer_norm(x2[:, :, :512].double(), (512,), None, None, 1e-5)
+    ref = (1 + gb[:, None, :512].double()) * ref + gb[:, None, 512:].double()
+    ref = torch.where(ref > 0, ref, ref * 0.2)
+    assert float((xd[:, :, :512].cpu().double() - ref).abs().max()) < 2e-5
+    assert torch.equal(xd[:, :, 512:].cpu(), x2[:, :, 512:])
+
+
+@pytest.mark.parametrize("H,In,L,B", [(256, 640, 41, 2), (64, 96, 19, 3)])
+def test_lstm_vs_oracle(ops, H, In, L, B):
+    from oracle import kokoro_ref
+
+    g = torch.Generator().manual_seed(H)
+    s = 1 / math.sqrt(H)
+    wts = {}
+    for d in ("forward", "backward"):
+        wts[f"l.Wx_{d}"] = bf16r((torch.rand(4 * H, In, generator=g) * 2 - 1) * s)
+        wts[f"l.Wh_{d}"] = bf16r((torch.rand(4 * H, H, generator=g) * 2 - 1) * s)
+        wts[f"l.bias_ih_{d}"] = bf16r((torch.rand(4 * H, generator=g) * 2 - 1) * s)
+        wts[f"l.bias_hh_{d}"] = bf16r((torch.rand(4 * H, generator=g) * 2 - 1) * s)
+    x = torch.randn(B, L, In, generator=g)
+    lens = torch.tensor([L, max(1, L // 2), max(1, L - 3)][:B], dtype=torch.int32)
+    wx = torch.cat([wts["l.Wx_forward"], wts["l.Wx_backward"]], 0)
+    bias = torch.cat([wts["l.bias_ih_forward"] + wts["l.bias_hh_forward"], wts["l.bias_ih_backward"] + wts["l.bias_hh_backward"]])
+    pc = ops.pack_conv(wx, bias, DEV)
+    wh = ops.pack_lstm_wh(wts["l.Wh_forward"], wts["l.Wh_backward"], DEV)
+    xp = torch.empty(B, L, 8 * H, device=DEV)
+    lens_d = lens.to(DEV)
+    ops.conv_gemm(x.to(DEV), pc, xp, lens_in=lens_d, lens_out=lens_d)
+    out = torch.zeros(B, L, 2 * H + 32, device=DEV)
+    ops.lstm_bidir(xp, wh, H, out[:, :, : 2 * H], lens=lens_d)
+    torch.cuda.synchronize()
+    p = kokoro_ref.P(wts, "l.", dtype=torch.float64)
+    for b in range(B):
+        n = int(lens[b])
+        ref = kokoro_ref.bilstm(p, x[b:b + 1, :n].double())[0]
+        assert float((out[b, :n, : 2 * H].cpu().double() - ref).abs().max()) < 5e-5
+    assert float(out[:, :, 2 * H:].abs().max()) == 0.0
+
+
+def test_attention(ops):
+    g = torch.Generator().manual_seed(2)
+    B, T, heads, dh = 2, 83, 12, 64
+    D = heads * dh
+    qkv = torch.randn(B, T, 3 * D, generator=g)
+    lens = torch.tensor([83, 40], dtype=torch.int32)
+    out = torch.zeros(B, T, D, device=DEV)
+    ops.attention(qkv.to(DEV), heads, dh, out, lens=lens.to(DEV))
+    torch.cuda.synchronize()
+    for b in range(B):
+        n = int(lens[b])
+        q, k, v = [t.view(n, heads, dh).transpose(0, 1).double() for t in qkv[b, :n].split(D, dim=-1)]
+        ref = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(dh), -1) @ v).transpose(0, 1).reshape(n, D)
+        assert float((out[b, :n].cpu().double() - ref).abs().max()) < 2e-5
+
+
+def test_glue_kernels(ops):
+    g = torch.Generator().manual_seed(9)
+    B, T, C = 2, 20, 96
+    table = torch.randn(50, C, generator=g)
+    pos = torch.randn(T, C, generator=g)
+    row = torch.randn(C, generator=g)
+    idx = torch.randint(0, 50, (B, T), generator=g, dtype=torch.int32)
+    lens = torch.tensor([20, 11], dtype=torch.int32)
+    y = torch.full((B, T, C), float("nan"), device=DEV)
+    ops.gather_rows(table.to(DEV), idx.to(DEV), y, pos_table=pos.to(DEV), add_row=row.to(DEV), lens=lens.to(DEV))
+    torch.cuda.synchronize()
+    ref = table[idx.long()] + pos[None] + row
+    ref[1, 11:] = 0
+    assert torch.equal(y.cpu(), ref)  # exact: same op order as words + position + token_type
+    # duration head + alignment index (bit-exact integer path)
+    logits = torch.randn(B, T, 64, generator=g) * 2
+    dur, raw, frames, aidx = ops.duration_align(logits.to(DEV)[:, :, :50], T, B, 0.9, 2048, DEV, lens=lens.to(DEV))
+    torch.cuda.synchronize()
+    r = (torch.sigmoid(logits[:, :, :50]).sum(-1) / 0.9)
+    margin = (r - torch.floor(r) - 0.5).abs().min()
+    refd = torch.clamp(torch.round(r), 1, 100).to(torch.int32)
+    refd[1, 11:] = 0
+    assert float((raw.cpu() - r)[0].abs().max()) < 1e-4
+    if margin > 1e-3:
+        assert torch.equal(dur.cpu(), refd)
+    d = dur.cpu()
+    for b in range(B):
+        want = torch.repeat_interleave(torch.arange(T), d[b].long())
+        assert int(frames[b]) == want.numel()
+        assert torch.equal(aidx[b, : want.numel()].cpu().long(), want)
+    forced = torch.randint(1, 6, (B, T), generator=g, dtype=torch.int32)
+    d2, _, fr2, idx2 = ops.duration_align(None, T, B, 1.0, 2048, DEV, forced=forced.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(d2.cpu(), forced) and int(fr2[0]) == int(forced[0].sum())
+    # style broadcast
+    v = torch.randn(B, 40, generator=g)
+    yb = torch.zeros(B, T, 128, device=DEV)
+    ops.broadcast_rows(v.to(DEV), yb[:, :, 88:128], lens=lens.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(yb[0, :, 88:].cpu(), v[0].expand(T, 40)) and float(yb[1, 11:].abs().max()) == 0
+    # scalar strided conv
+    x1 = torch.randn(B, 41, generator=g)
+    yc = torch.zeros(B, 21, 8, device=DEV)
+    ops.conv1d_c1_k3s2(x1.to(DEV), [0.3, -1.2, 0.7], 0.05, yc, 5)
+    torch.cuda.synchronize()
+    refc = F.conv1d(x1[:, None], torch.tensor([[[0.3, -1.2, 0.7]]]), torch.tensor([0.05]), stride=2, padding=1)[:, 0]
+    assert float((yc[:, :, 5].cpu() - refc).abs().max()) < 1e-6
+
+
+def test_adain_pool_up2(ops):
+    from oracle import kokoro_ref
+
+    g = torch.Generator().manual_seed(13)
+    B, L, C = 2, 23, 96
+    x = torch.randn(B, L, C, generator=g)
+    sc, sh = torch.rand(B, C, generator=g) + 0.5, torch.randn(B, C, generator=g)
+    w = torch.randn(C, 3, generator=g)
+    bias = torch.randn(C, generator=g)
+    y = torch.empty(B, 2 * L, C, device=DEV)
+    ops.adain_pool_up2(x.to(DEV), sc.to(DEV), sh.to(DEV), 0.2, w.to(DEV), bias.to(DEV), y)
+    torch.cuda.synchronize()
+    a = F.leaky_relu(x.double() * sc[:, None].double() + sh[:, None].double(), 0.2).transpose(1, 2)
+    ref = kokoro_ref.conv_transpose1d_mlx(a, w[:, :, None].double(), bias.double(), stride=2, padding=0, groups=C)[:, :, 1:]
+    assert ref.shape[2] == 2 * L
+    assert float((y.cpu().double() - ref.transpose(1, 2)).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("F2", [14, 3, 80])
+def test_sine_source_and_stft_features(ops, F2):
+    """SineGen path: contraction-free fp32 mirror of the reference's op order -> near bit-exact."""
+    from oracle import kokoro_ref
+
+    rng = np.random.default_rng(F2)
+    B, up, H = 2, 300, 9
+    f0 = (rng.uniform(-40, 400, size=(B, F2))).astype(np.float32)
+    f0[0, : F2 // 3] = 0.0
+    rand_ini = rng.uniform(size=(B, H)).astype(np.float32)
+    noise = rng.standard_normal((B, F2 * up, H)).astype(np.float32)
+    lw = rng.standard_normal((1, H)).astype(np.float32)
+    lb = np.float32(0.03)
+    w = {"m_source.l_linear.weight": torch.from_numpy(lw), "m_source.l_linear.bias": torch.tensor([lb])}
+    ref = kokoro_ref.sine_source(kokoro_ref.P(w), torch.from_numpy(f0), rand_ini, noise, upsample=up)
+    got = ops.sine_source(torch.from_numpy(f0).to(DEV), torch.from_numpy(rand_ini).to(DEV), torch.from_numpy(noise).to(DEV),
+                          torch.from_numpy(lw[0]).to(DEV), float(lb), up)
+    torch.cuda.synchronize()
+    err = np.abs(got.cpu().numpy() - ref)
+    assert err.max() < 2e-4, err.max()
+    assert np.mean(err) < 2e-6
+    # STFT features of the oracle's source (so both sides see identical input)
+    win = torch.from_numpy(__import__("oracle.dsp_ref", fromlist=["x"]).hanning(20, periodic=True))
+    y = torch.empty(B, F2 * up // 5 + 1, 22, device=DEV)
+    ops.stft_magphase(torch.from_numpy(ref).to(DEV), 20, 5, win.to(DEV), y)
+    torch.cuda.synchronize()
+    mp = kokoro_ref.stft_mag_phase(ref, 20, 5).transpose(0, 2, 1)  # [B, frames, 22]
+    g = y.cpu().numpy()
+    assert np.abs(g[:, :, :11] - mp[:, :, :11]).max() < 1e-5
+    dphi = np.abs(g[:, :, 11:] - mp[:, :, 11:])
+    dphi = np.minimum(dphi, 2 * np.pi - dphi)  # +pi / -pi are the same angle
+    big = mp[:, :, :11] > 1e-4
+    assert dphi[big].max() < 1e-3
+
+
+def test_istft_head(ops):
+    from oracle import dsp_ref, kokoro_ref
+
+    rng = np.random.default_rng(4)
+    B, Fr = 2, 233
+    x = rng.standard_normal((B, Fr, 22)).astype(np.float32)
+    x[:, :, :11] = x[:, :, :11] * 0.5 - 1.0
+    win = dsp_ref.hanning(20, periodic=True)
+    audio = torch.full((B, (Fr - 1) * 5), float("nan"), device=DEV)
+    xd = torch.zeros(B, Fr, 24, device=DEV)
+    xd[:, :, :22] = torch.from_numpy(x).to(DEV)
+    ops.istft_head(xd[:, :, :22], 20, 5, torch.from_numpy(win).to(DEV), audio)
+    torch.cuda.synchronize()
+    ref = kokoro_ref.istft_head(torch.from_numpy(x.transpose(0, 2, 1)), 20, 5)[:, 0].numpy()
+    assert ref.shape == (B, (Fr - 1) * 5)
+    assert np.abs(audio.cpu().numpy() - ref).max() < 2e-6
+
+
+def _centered_frames(L, n_fft, hop):
+    return 1 + (L + 2 * (n_fft // 2) - n_fft) // hop
+
+
+@pytest.mark.parametrize("n_fft,hop,L", [(400, 160, 16000), (1024, 256, 12000), (20, 5, 3000), (96, 24, 1000), (56, 14, 700)])
+def test_dsp_stft_istft_roundtrip_and_oracle(ops, n_fft, hop, L):
+    from oracle import dsp_ref
+
+    rng = np.random.default_rng(n_fft)
+    x = rng.standard_normal((2, L)).astype(np.float32)
+    win = dsp_ref.hanning(n_fft)  # symmetric, like stft("hann")
+    nfr = _centered_frames(L, n_fft, hop)
+    spec = ops.stft_frames(torch.from_numpy(x).to(DEV), n_fft, hop, torch.from_numpy(win).to(DEV), 1, nfr)
+    torch.cuda.synchronize()
+    ref = np.stack([dsp_ref.stft(r, n_fft=n_fft, hop_length=hop, window=win) for r in x])
+    scale = np.abs(ref).max()
+    assert np.abs(spec.cpu().numpy() - ref).max() / scale < 2e-6
+    # inverse (dsp.istft semantics: periodic window, w^2 normalisation) of the oracle spectrum
+    wi = dsp_ref.hanning(n_fft + 1)[:-1]
+    ola = (nfr - 1) * hop + n_fft
+    norm = np.zeros(ola, np.float32)
+    for f in range(nfr):
+        norm[f * hop: f * hop + n_fft] += (wi * wi).astype(np.float32)
+    out_len = ola - n_fft
+    rec = ops.istft_frames(torch.from_numpy(ref).to(DEV), n_fft, hop, torch.from_numpy(wi).to(DEV),
+                           torch.from_numpy(norm).to(DEV), 1, False, n_fft // 2, out_len)
+    torch.cuda.synchronize()
+    want = np.stack([dsp_ref.istft(r.T, hop_length=hop, win_length=n_fft, window=wi, normalized=True) for r in ref])
+    assert want.shape[1] == out_len
+    assert np.abs(rec.cpu().numpy() - want).max() < 5e-5
+
+
+def test_logmel_golden_through_gpu(ops, golden):
+    """The reference's own STFT+mel golden vectors (test_qwen3_tts.py:175-353) through the HIP path."""
+    from oracle import dsp_ref
+
+    g = golden["qwen3_mel_spectrogram"]
+    np.random.seed(42)
+    audio = np.random.randn(12000).astype(np.float32)
+    pad = (1024 - 256) // 2
+    padded = np.concatenate([audio[1: pad + 1][::-1], audio, audio[-(pad + 1): -1][::-1]])
+    fb = dsp_ref.mel_filters(24000, 1024, 128, 0.0, 12000.0, norm="slaney", mel_scale="slaney")
+    win = dsp_ref.hanning(1024)
+    nfr = 1 + (len(padded) - 1024) // 256
+    mel = ops.logmel(torch.from_numpy(padded[None].copy()).to(DEV), 1024, 256, torch.from_numpy(win).to(DEV), 0, nfr,
+                     torch.from_numpy(fb).to(DEV), 1)
+    torch.cuda.synchronize()
+    m = mel.cpu().numpy()
+    assert list(m.shape) == g["shape"]
+    kw = dict(rtol=g["rtol"], atol=g["atol"])
+    np.testing.assert_allclose(m[0, 0, g["bins"]], g["frame0"], **kw)
+    np.testing.assert_allclose(m[0, 23, g["bins"]], g["frame23"], **kw)
+    np.testing.assert_allclose(m[0, -1, g["bins"]], g["frame_last"], **kw)
+    np.testing.assert_allclose(m.mean(), g["mean"], **kw)
+    np.testing.assert_allclose(m.std(), g["std"], **kw)
+    assert np.abs(m - dsp_ref.qwen3_mel_spectrogram(audio)).max() < 2e-4
+    # whisper front end: 3 s of noise + 1 s of zero padding
+    a = np.random.default_rng(0).standard_normal(48000).astype(np.float32)
+    ap = np.concatenate([a, np.zeros(16000, np.float32)])
+    fbw = dsp_ref.mel_filters(16000, 400, 80, norm="slaney", mel_scale=None)
+    nf = _centered_frames(len(ap), 400, 160) - 1  # whisper drops the last frame
+    w = ops.logmel(torch.from_numpy(ap[None].copy()).to(DEV), 400, 160, torch.from_numpy(dsp_ref.hanning(400)).to(DEV), 1, nf,
+                   torch.from_numpy(fbw).to(DEV), 0)
+    torch.cuda.synchronize()
+    ref = dsp_ref.whisper_log_mel(a, padding=16000)
+    assert ref.shape == tuple(w.shape[1:])
+    assert np.abs(w.cpu().numpy()[0] - ref).max() < 2e-4

@@ -1,0 +1,183 @@
+"""End-to-end parity of the Kokoro-82M HIP path against the CPU oracle (needs an MI355X).
+
+How parity is stated (DESIGN.md "Parity"):
+  * integer path: predicted durations / alignment are bit-exact whenever the oracle's pre-rounding value is
+    >= 1e-3 away from a .5 boundary (the margin is asserted, not assumed);
+  * front end (PL-BERT, LSTMs, prosody predictor): d, F0, N, asr within 5e-4 relative, free-running;
+  * vocoder (decoder + iSTFTNet generator + iSTFT): waveform max-abs error <= 2e-3 * peak and SNR >= 50 dB
+    against the fp32 oracle (the figures SURVEY.md section 8c proposes; the reference's own numeric tests use
+    rtol = atol = 2e-3), with the oracle's F0 / N curves and harmonic STFT features injected.  The
+    injection is needed because the harmonic source INTEGRATES F0 into a phase: a 1e-5 relative F0 rounding
+    difference moves the 9th harmonic by radians within a second, and the reflect-padded edge frames are
+    exactly symmetric so their phase features are atan2(+-rounding noise, x): sample-wise agreement of the
+    free-running waveform is not a property even two builds of the reference would have;
+  * free-running waveform: checked through the log-mel spectral envelope instead.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from mlx_audio_amd.tts.models.kokoro import synthetic as S
+    from mlx_audio_amd.tts.models.kokoro.engine import KokoroEngine
+    from oracle.kokoro_ref import KokoroRef
+
+    w = S.make_kokoro_weights()
+    eng = KokoroEngine(w, S.KOKORO_CONFIG)
+    ref32 = KokoroRef(S.make_kokoro_weights(), S.KOKORO_CONFIG, dtype=torch.float32)
+    return S, eng, ref32
+
+
+def snr_db(got, ref):
+    err = (got.double() - ref.double())
+    return float(10 * torch.log10(ref.double().pow(2).sum() / err.pow(2).sum().clamp_min(1e-300)))
+
+
+def _noise(F, seed):
+    rng = np.random.default_rng(seed)
+    return rng.uniform(size=(1, 9)).astype(np.float32), rng.standard_normal((1, 2 * F * 300, 9)).astype(np.float32)
+
+
+def _teacher(tr):
+    return dict(f0=tr["f0"], n=tr["n"], har=tr["har"].transpose(1, 2))
+
+
+def test_kokoro_front_end_free_running(setup):
+    S, eng, ref = setup
+    ids = S.make_phoneme_ids(18, seed=5)
+    ref_s = S.make_voice_pack()[len(ids) - 3]
+    pd, d, raw = ref.durations(ids, ref_s, speed=1.3)
+    F = int(pd.sum())
+    ri, nz = _noise(F, 77)
+    audio_ref, _, tr = ref.forward(ids, ref_s, speed=1.3, rand_ini=ri, noise=nz, return_intermediates=True)
+    outs, durs, tg = eng.forward([ids], ref_s, speed=1.3, rand_ini=torch.from_numpy(ri), noise=torch.from_numpy(nz),
+                                 return_intermediates=True)
+    torch.cuda.synchronize()
+    margin = float(((raw - torch.floor(raw)) - 0.5).abs().min())
+    assert float((tg["dur_raw"][0, : len(ids)].cpu() - raw).abs().max()) < 5e-4
+    assert margin > 1e-3, "pick another seed: the oracle itself sits on a rounding boundary"
+    assert torch.equal(durs[0].cpu(), pd)  # bit-exact integer path
+    assert outs[0].shape == audio_ref[0].shape == (600 * F,)
+
+    def rel(a, b):
+        return float((a.cpu().double() - b.double()).abs().max() / b.abs().max())
+
+    assert rel(tg["d"][0], tr["d"][0]) < 5e-4
+    assert rel(tg["f0"][0], tr["f0"][0]) < 5e-4
+    assert rel(tg["n"][0], tr["n"][0]) < 5e-4
+    assert rel(tg["asr"][0], tr["asr"][0].transpose(0, 1)) < 5e-4
+    assert rel(tg["dec3"][0], tr["dec3"][0].transpose(0, 1)) < 1e-3
+    # free-running waveform: same spectral envelope (harmonic phases are not comparable, see module docstring)
+    from oracle import dsp_ref
+
+    fb = dsp_ref.mel_filters(24000, 1024, 80, norm="slaney", mel_scale="slaney")
+
+    def logmel(x):
+        s = np.abs(dsp_ref.stft(x, n_fft=1024, hop_length=256)) ** 2
+        return np.log10(np.maximum(s @ fb.T, 1e-8))
+
+    a, b = logmel(outs[0].cpu().numpy()), logmel(audio_ref[0].numpy())
+    assert a.shape == b.shape
+    env_err = float(np.mean(np.abs(a - b)))
+    print(f"free-running log-mel envelope mean |diff| = {env_err:.3f} (log10 power units)")
+    assert env_err < 0.5  # ~5 dB average; identical models differ by ~2 dB here purely through harmonic phase
+
+
+def test_kokoro_vocoder_teacher_forced(setup):
+    S, eng, ref = setup
+    ids = S.make_phoneme_ids(18, seed=5)
+    ref_s = S.make_voice_pack()[len(ids) - 3]
+    pd, _, _ = ref.durations(ids, ref_s, speed=1.3)
+    F = int(pd.sum())
+    ri, nz = _noise(F, 77)
+    audio_ref, _, tr = ref.forward(ids, ref_s, speed=1.3, rand_ini=ri, noise=nz, return_intermediates=True)
+    outs, _, tg = eng.forward([ids], ref_s, forced_durations=[pd], rand_ini=torch.from_numpy(ri), noise=torch.from_numpy(nz),
+                              overrides=_teacher(tr), return_intermediates=True)
+    torch.cuda.synchronize()
+    got = outs[0].cpu()
+    peak = float(audio_ref.abs().max())
+    err = float((got - audio_ref[0]).abs().max())
+    snr = snr_db(got, audio_ref[0])
+    print(f"kokoro vocoder (teacher-forced): F={F} peak={peak:.3f} max_abs_err={err:.3e} snr={snr:.1f} dB")
+    assert err <= 2e-3 * max(peak, 1.0), err
+    assert snr >= 50.0, snr
+    # with only F0/N injected, the HIP harmonic features agree with the oracle except for +-pi branch flips of
+    # rounding-noise phases; those must be rare and every other feature must match tightly
+    outs2, _, tg2 = eng.forward([ids], ref_s, forced_durations=[pd], rand_ini=torch.from_numpy(ri), noise=torch.from_numpy(nz),
+                                overrides=dict(f0=tr["f0"], n=tr["n"]), return_intermediates=True)
+    torch.cuda.synchronize()
+    assert float((tg2["har_src"].cpu() - tr["har_src"]).abs().max()) < 1e-6
+    hd = (tg2["har"].cpu() - tr["har"].transpose(1, 2)).abs()
+    flips = hd > 1.0
+    assert int(flips.sum()) <= 8, int(flips.sum())
+    assert float(hd[~flips].max()) < 2e-3
+    two_pi = hd[flips]
+    assert bool(((two_pi - 2 * np.pi).abs() < 1e-3).all())
+
+
+def test_kokoro_canonical_short_sentence_forced_durations(setup):
+    """T = 80 tokens, durations forced to 264 frames -> 158 400 samples (6.6 s)."""
+    S, eng, ref = setup
+    ids = S.make_phoneme_ids(78)
+    ref_s = S.make_voice_pack()[len(ids) - 3]
+    fd = S.forced_durations(80, 264)
+    ri, nz = _noise(264, 1234)
+    audio_ref, _, tr = ref.forward(ids, ref_s, pred_dur=fd, rand_ini=ri, noise=nz, return_intermediates=True)
+    outs, durs = eng.forward([ids], ref_s, forced_durations=[fd], rand_ini=torch.from_numpy(ri), noise=torch.from_numpy(nz),
+                             overrides=_teacher(tr))
+    torch.cuda.synchronize()
+    assert torch.equal(durs[0].cpu(), fd)
+    got = outs[0].cpu()
+    assert got.numel() == 158400
+    peak = float(audio_ref.abs().max())
+    err = float((got - audio_ref[0]).abs().max())
+    snr = snr_db(got, audio_ref[0])
+    print(f"kokoro canonical (teacher-forced vocoder): peak={peak:.3f} max_abs_err={err:.3e} snr={snr:.1f} dB")
+    assert err <= 2e-3 * max(peak, 1.0) and snr >= 50.0
+
+
+def test_kokoro_batch_equals_single(setup):
+    """Utterance batching is new (the reference is batch-1): every item of a ragged batch must reproduce
+    its single-utterance result."""
+    S, eng, _ = setup
+    voice = S.make_voice_pack()
+    idl = [S.make_phoneme_ids(n, seed=10 + n) for n in (12, 25, 7)]
+    refs = torch.cat([voice[len(i) - 3] for i in idl], 0)
+    fds = [S.forced_durations(len(i), 3 * len(i), seed=len(i)) for i in idl]
+    Fm = max(int(f.sum()) for f in fds)
+    rng = np.random.default_rng(5)
+    ri = torch.from_numpy(rng.uniform(size=(3, 9)).astype(np.float32))
+    nz = torch.from_numpy(rng.standard_normal((3, 2 * Fm * 300, 9)).astype(np.float32))
+    outs, durs = eng.forward(idl, refs, forced_durations=fds, rand_ini=ri, noise=nz)
+    torch.cuda.synchronize()
+    for b in range(3):
+        Fb = int(fds[b].sum())
+        o1, _ = eng.forward([idl[b]], refs[b:b + 1], forced_durations=[fds[b]], rand_ini=ri[b:b + 1],
+                            noise=nz[b:b + 1, : 2 * Fb * 300].contiguous())
+        torch.cuda.synchronize()
+        assert outs[b].shape == o1[0].shape
+        d = float((outs[b] - o1[0]).abs().max())
+        assert d <= 1e-5 * float(o1[0].abs().max() + 1), (b, d)
+
+
+def test_kokoro_single_pass_bf16_precision_mode(setup):
+    """precision=1 (one bf16 MFMA pass per product) is the fast mode; its error is reported, loosely bounded."""
+    S, eng, ref = setup
+    from mlx_audio_amd.tts.models.kokoro.engine import KokoroEngine
+
+    eng1 = KokoroEngine(S.make_kokoro_weights(), S.KOKORO_CONFIG, precision=1)
+    ids = S.make_phoneme_ids(10, seed=3)
+    ref_s = S.make_voice_pack()[len(ids) - 3]
+    fd = S.forced_durations(len(ids), 30)
+    ri, nz = _noise(30, 9)
+    audio_ref, _, tr = ref.forward(ids, ref_s, pred_dur=fd, rand_ini=ri, noise=nz, return_intermediates=True)
+    outs, _ = eng1.forward([ids], ref_s, forced_durations=[fd], rand_ini=torch.from_numpy(ri), noise=torch.from_numpy(nz),
+                           overrides=_teacher(tr))
+    torch.cuda.synchronize()
+    snr = snr_db(outs[0].cpu(), audio_ref[0])
+    print(f"kokoro precision=1 (single bf16 pass), teacher-forced vocoder: snr={snr:.1f} dB")
+    assert snr >= 25.0
