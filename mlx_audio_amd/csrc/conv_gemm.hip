@@ -16,6 +16,7 @@
 //   accumulate, and either a plain channels-last store or the polyphase conv_transpose scatter.
 //
 // Reference call sites replaced: see include/mi355audio.h (mi355_conv_gemm).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -28,6 +29,74 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* ldst) {
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+
+// Shared epilogue: y = ((acc + bias -> act) + res + y_old) * out_scale, plain or polyphase (conv_transpose) store.
+// All loads of one 32x32 fragment are issued back to back on clamped addresses and only the stores are predicated:
+// a per-element "if (valid) v += res[...]" makes hipcc branch around every load and wait vmcnt(0) each time
+// (64 dependent round trips per wave).  `folded`: res / y_old were already added into the accumulators.
+template <int MF, int NF, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const mi355_conv_gemm_args& a, f32x16 (&acc)[MF][NF], const int b, const int l0,
+                                              const int n0, const int wm, const int wn, const int lane, const int len_out,
+                                              const bool folded) {
+  const int len_up = a.lens_up ? a.lens_up[b] : a.up_Lout;
+  const int len_up_c = len_up > 0 ? len_up : 1;
+  float* yb = a.y + (int64_t)b * a.y_bstride;
+  const float* rb = (a.res && !folded) ? a.res + (int64_t)b * a.res_bstride : nullptr;
+  const bool accum = a.accumulate && !folded;
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      const int n = n0 + wn * WN + nf * 32 + (lane & 31);
+      const bool nok = n < a.Cout;
+      const int ncl = nok ? n : a.Cout - 1;
+      int ocol = ncl, rph = 0;
+      if (a.up_s) { rph = ncl / a.up_cout; ocol = ncl - rph * a.up_cout; }
+      const float bias = a.bias ? a.bias[ocol] : 0.f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {  // 8 accumulator rows at a time keeps the live set small
+        int orows[8];
+        bool ok[8];
+        float rv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int r = h * 8 + q;
+          const int u = l0 + wm * WM + mf * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          bool valid = nok && u < len_out;
+          int orow = u < len_out ? u : len_out - 1;
+          if (a.up_s) {
+            int nc = orow * a.up_s + rph - a.up_p;
+            valid = valid && nc >= 0 && nc < len_up;
+            nc = nc < 0 ? 0 : (nc >= len_up_c ? len_up_c - 1 : nc);
+            orow = nc + a.up_row_off;
+          }
+          ok[q] = valid;
+          orows[q] = orow;
+          rv[q] = 0.f;
+        }
+        if (rb) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) rv[q] = rb[(int64_t)(orows[q] >> a.res_shift) * a.ldr + ocol];
+        }
+        if (accum) {
+          float yv[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) yv[q] = yb[(int64_t)orows[q] * a.ldy + ocol];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) rv[q] += yv[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          float v = acc[mf][nf][h * 8 + q] + bias;
+          if (a.post_act == MI355_ACT_LEAKY) v = v > 0.f ? v : v * a.post_slope;
+          else if (a.post_act == MI355_ACT_GELU) v = gelu_erf(v);
+          v = (v + rv[q]) * a.out_scale;
+          if (ok[q]) yb[(int64_t)orows[q] * a.ldy + ocol] = v;
+        }
+      }
+    }
+}
 
 template <int BM, int BN, int PREC, bool VEC>
 __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_gemm_args a) {
@@ -178,37 +247,330 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_ge
   }
 
   // ---------------------------------------------------------------- epilogue
-  const int len_up = a.lens_up ? a.lens_up[b] : a.up_Lout;
+  conv_epilogue<MF, NF, WM, WN>(a, acc, b, l0, n0, wm, wn, lane, len_out, false);
+}
+
+// =====================================================================================================
+// Wave-specialised variant for the large resblock convs (the bulk of the vocoder's MACs).
+//
+// 512 threads = 8 waves per workgroup, one 128 x 128 output tile:
+//   waves 0-3  CONSUMERS: 2 x 2 over the tile, ds_read_b128 fragments + MFMA only, then the epilogue;
+//   waves 4-7  PRODUCERS: all memory traffic and all VALU prologue math --
+//                * weight slices L2 -> LDS with global_load_lds, TWO steps ahead (3-slot ring, counted vmcnt);
+//                * the activation window of the NEXT 32-channel chunk: 6 x float4 per lane issued at the first
+//                  tap of the current chunk, converted (AdaIN affine, Snake / LeakyReLU, bf16 hi+lo split) and
+//                  written into the other A buffer one tap later, while the consumers keep the matrix cores busy.
+// Each SIMD hosts one consumer and one producer wave per workgroup (MFMA and VALU pipes run concurrently); two
+// workgroups fit per CU (<= 74 KB LDS, <= 128 VGPR), so one workgroup's epilogue / pipeline fill overlaps the
+// other's MFMAs.  One s_barrier per (chunk, tap) step; raw barriers + counted vmcnt so that loads in flight are
+// never drained.  The residual / running-sum operands of the epilogue are folded into the accumulator
+// initialisation (their HBM latency hides under the first chunk), and the 1-D grid is remapped so that the
+// N-tiles sharing one activation window land on the same XCD (same L2).
+// =====================================================================================================
+constexpr int kWsThreads = 512;
+constexpr int kWsNld = 6;  // A-window passes of 32 rows per chunk: R <= 192
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS reads / writes are done
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int PREC>
+__global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355_conv_gemm_args a, const int tiles_per_item,
+                                                                    const int P, const int NT, const int fold) {
+  constexpr int BM = 128, BN = 128, WM = 64, WN = 64, MF = 2, NF = 2;
+  constexpr int BBYTES = (BN / 32) * 2048;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // block id -> (row tile p, N tile ny): ids congruent mod 8 run on one XCD, so the NT column tiles of a row
+  // tile are given ids 8 apart (same XCD, dispatched back to back) and share the activation window in L2.
+  const int id = blockIdx.x;
+  const int kq = id >> 3;
+  const int ny = kq % NT;
+  const int p = (kq / NT) * 8 + (id & 7);
+  if (p >= P) return;
+  const int b = p / tiles_per_item;
+  const int l0 = (p - b * tiles_per_item) * BM, n0 = ny * BN;
+  const int len_out = a.lens_out ? a.lens_out[b] : a.Lout;
+  if (l0 >= len_out) return;
+  const int len_in = a.lens_in ? a.lens_in[b] : a.Lin;
+  const int K = a.K, dil = a.dil;
+  const int R = BM + (K - 1) * dil;
+  const int ABYTES = R * 64;
+  char* Abase = smem;                     // [2 buffers][PREC (hi, lo)][R * 64]
+  char* Bs = smem + 2 * PREC * ABYTES;    // [3 slots][BBYTES]
+  const int nchunks = (a.Cin + 31) >> 5;
+  const int NTp = ((a.Cout + 127) >> 7) << 2;
+  const int nsteps = nchunks * K;
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------------------ producers
+    const int pw = wave - 4;
+    const int ptid = tid - 256;
+    const int c4 = (ptid & 7) * 4;
+    const int prow = ptid >> 3;
+    const float* xb = a.x + (int64_t)b * a.x_bstride + a.x_off;
+    float4 areg[kWsNld];
+
+    auto issue_B = [&](int step, int slot) {
+      const char* src = (const char*)a.w + ((int64_t)step * NTp + (n0 >> 5)) * 2048;
+#pragma unroll
+      for (int i = 0; i < BN / 64; ++i) {
+        const int off = (i * 4 + pw) * 1024;
+        glds16(src + off + lane * 16, Bs + slot * BBYTES + off);
+      }
+    };
+    // always exactly kWsNld vector loads (addresses clamped, masking happens in convert) so that the
+    // counted s_waitcnt below is exact
+    auto loadA = [&](int chunk) {
+      int c = chunk * 32 + c4;
+      if (c >= a.Cin) c = 0;
+#pragma unroll
+      for (int i = 0; i < kWsNld; ++i) {
+        int gl = l0 - a.pad + prow + i * 32;
+        gl = gl < 0 ? 0 : (gl >= a.Lin ? a.Lin - 1 : gl);
+        areg[i] = *(const float4*)(xb + (int64_t)gl * a.ldx + c);
+      }
+    };
+    auto convertA = [&](int chunk, char* A_hi) {
+      char* A_lo = A_hi + ABYTES;
+      const int c = chunk * 32 + c4;
+      float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f}, al[4] = {1.f, 1.f, 1.f, 1.f},
+            ial[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.pre_scale) {
+        const float4 s4 = *(const float4*)(a.pre_scale + (int64_t)b * a.pre_ld + c);
+        const float4 h4 = *(const float4*)(a.pre_shift + (int64_t)b * a.pre_ld + c);
+        sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
+        sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
+      }
+      if (a.pre_act == MI355_ACT_SNAKE) {
+        const float4 a4 = *(const float4*)(a.pre_alpha + c);
+        al[0] = a4.x; al[1] = a4.y; al[2] = a4.z; al[3] = a4.w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ial[i] = 1.0f / al[i];
+      }
+#pragma unroll
+      for (int i = 0; i < kWsNld; ++i) {
+        const int r = prow + i * 32;
+        if (r < R) {
+          const int gl = l0 - a.pad + r;
+          const bool rowok = gl >= 0 && gl < len_in;
+          const float v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
+          float hi[4], lo[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float t = v[j] * sc[j] + sh[j];
+            if (a.pre_act == MI355_ACT_LEAKY) t = t > 0.f ? t : t * a.pre_slope;
+            else if (a.pre_act == MI355_ACT_SNAKE) {
+              const float s = __sinf(al[j] * t);
+              t = t + ial[j] * (s * s);
+            }
+            t = (rowok && (c + j) < a.Cin) ? t : 0.f;
+            const float h = bf16_bits_to_f32(f32_to_bf16_bits(t));
+            hi[j] = h;
+            lo[j] = t - h;
+          }
+          const int addr = r * 64 + ((((c4 >> 3) ^ ((r >> 2) & 3))) << 4) + ((c4 & 4) << 1);
+          uint2 ph;
+          ph.x = pack_bf16x2(hi[0], hi[1]);
+          ph.y = pack_bf16x2(hi[2], hi[3]);
+          *(uint2*)(A_hi + addr) = ph;
+          if (PREC == 2) {
+            uint2 pl;
+            pl.x = pack_bf16x2(lo[0], lo[1]);
+            pl.y = pack_bf16x2(lo[2], lo[3]);
+            *(uint2*)(A_lo + addr) = pl;
+          }
+        }
+      }
+    };
+
+    // Step s = (chunk, tap).  During step s the producers issue weight slice s+2, at tap 0 the loads of the next
+    // chunk's window, at tap 1 its conversion.  At the end of the step slice s+1 must have landed (counted wait:
+    // what was issued after it may stay in flight), then the barrier hands step s+1 to the consumers.
+    // The loop nest is written per chunk, straight-line over taps 0 / 1 / rest, so that no vector load is pending
+    // across a back edge (otherwise hipcc drains vmcnt(0) in front of the next loads).
+    auto end_step = [&](int s, int pend) {
+      if (s + 1 < nsteps) {
+        if (pend == 0) wait_vmcnt<0>();
+        else if (pend == 2) wait_vmcnt<2>();
+        else if (pend == kWsNld) wait_vmcnt<6>();
+        else wait_vmcnt<8>();
+        lds_barrier();
+      }
+    };
+    int slot = 2;
+    auto prefetch_B = [&](int s) -> int {
+      int pend = 0;
+      if (s + 2 < nsteps) {
+        issue_B(s + 2, slot);
+        pend = 2;
+      }
+      slot = slot == 2 ? 0 : slot + 1;
+      asm volatile("" ::: "memory");
+      return pend;
+    };
+    issue_B(0, 0);
+    if (nsteps > 1) issue_B(1, 1);
+    loadA(0);
+    convertA(0, Abase);
+    wait_vmcnt<0>();
+    lds_barrier();  // barrier #0: step 0 (and weight slice 1) staged
+    int s = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      const bool nxt = chunk + 1 < nchunks;
+      char* A_next = Abase + ((chunk + 1) & 1) * PREC * ABYTES;
+      if (K == 1) {
+        const int pend = prefetch_B(s);
+        if (nxt) {
+          loadA(chunk + 1);
+          convertA(chunk + 1, A_next);
+        }
+        end_step(s, pend);
+        ++s;
+      } else {
+        int pend = prefetch_B(s);  // tap 0
+        if (nxt) {
+          loadA(chunk + 1);
+          pend += kWsNld;
+        }
+        asm volatile("" ::: "memory");
+        end_step(s, pend);
+        ++s;
+        if (nxt) convertA(chunk + 1, A_next);  // tap 1: convert first (its waits would also drain a fresh weight DMA)
+        asm volatile("" ::: "memory");
+        pend = prefetch_B(s);
+        end_step(s, pend);
+        ++s;
+        for (int tap = 2; tap < K; ++tap) {
+          pend = prefetch_B(s);
+          end_step(s, pend);
+          ++s;
+        }
+      }
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------------------- consumers
+  const int wm = wave >> 1, wn = wave & 1;
   float* yb = a.y + (int64_t)b * a.y_bstride;
   const float* rb = a.res ? a.res + (int64_t)b * a.res_bstride : nullptr;
+  f32x16 acc[MF][NF];
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
-      const int n = n0 + wn * WN + nf * 32 + (lane & 31);
-      if (n >= a.Cout) continue;
-      int ocol = n, rph = 0;
-      if (a.up_s) { rph = n / a.up_cout; ocol = n - rph * a.up_cout; }
-      const float bias = a.bias ? a.bias[ocol] : 0.f;
+    for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int u = l0 + wm * WM + mf * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (u >= len_out) continue;
-        int orow = u;
-        if (a.up_s) {
-          const int nc = u * a.up_s + rph - a.up_p;
-          if (nc < 0 || nc >= len_up) continue;
-          orow = nc + a.up_row_off;
+      for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+  if (fold) {
+    // residual and running sum go in as the initial accumulator value: issued here, they land while the
+    // producers stage the first chunk.  Clamped addresses + select (never a branch per load).
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const int n = n0 + wn * WN + nf * 32 + (lane & 31);
+        const bool nok = n < a.Cout;
+        const int ncl = nok ? n : a.Cout - 1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float rv[8];
+          int us[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int r = h * 8 + q;
+            us[q] = l0 + wm * WM + mf * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            rv[q] = 0.f;
+          }
+          if (rb) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rv[q] = rb[(int64_t)(us[q] < len_out ? us[q] : len_out - 1) * a.ldr + ncl];
+          }
+          if (a.accumulate) {
+            float yv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) yv[q] = yb[(int64_t)(us[q] < len_out ? us[q] : len_out - 1) * a.ldy + ncl];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rv[q] += yv[q];
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc[mf][nf][h * 8 + q] = (nok && us[q] < len_out) ? rv[q] : 0.f;
         }
-        float v = acc[mf][nf][r] + bias;
-        if (a.post_act == MI355_ACT_LEAKY) v = v > 0.f ? v : v * a.post_slope;
-        else if (a.post_act == MI355_ACT_GELU) v = gelu_erf(v);
-        if (rb) v += rb[(int64_t)(orow >> a.res_shift) * a.ldr + ocol];
-        float* yp = yb + (int64_t)orow * a.ldy + ocol;
-        if (a.accumulate) v += *yp;
-        *yp = v * a.out_scale;
       }
+  }
+
+  lds_barrier();  // barrier #0
+  {
+    int chunk = 0, tap = 0, slot = 0;
+    for (int s = 0; s < nsteps; ++s) {
+      const char* A_hi = Abase + (chunk & 1) * PREC * ABYTES;
+      const char* A_lo = A_hi + ABYTES;
+      const char* Bb = Bs + slot * BBYTES;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 bfr[NF];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+          bfr[nf] = *(const bf16x8*)(Bb + ((((wn * NF + nf) * 2 + kk) * 64 + lane) << 4));
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+          const int row = wm * WM + mf * 32 + (lane & 31) + tap * dil;
+          const int cidx = kk * 2 + (lane >> 5);
+          const int addr = row * 64 + ((cidx ^ ((row >> 2) & 3)) << 4);
+          const bf16x8 ah = *(const bf16x8*)(A_hi + addr);
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf)
+            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bfr[nf], acc[mf][nf], 0, 0, 0);
+          if (PREC == 2) {
+            const bf16x8 alo = *(const bf16x8*)(A_lo + addr);
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+              acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bfr[nf], acc[mf][nf], 0, 0, 0);
+          }
+        }
+      }
+      slot = slot == 2 ? 0 : slot + 1;
+      if (s + 1 < nsteps) lds_barrier();
+      if (++tap == K) { tap = 0; ++chunk; }
     }
+  }
+
+  // epilogue (with `fold` the residual / running sum is already in the accumulators)
+  conv_epilogue<MF, NF, WM, WN>(a, acc, b, l0, n0, wm, wn, lane, len_out, fold != 0);
+}
+
+template <int PREC>
+int launch_ws(const mi355_conv_gemm_args& a, hipStream_t st) {
+  const int R = 128 + (a.K - 1) * a.dil;
+  MI355_REQUIRE(R <= 32 * kWsNld, "conv_gemm(ws): window of %d rows exceeds %d (K=%d dil=%d)", R, 32 * kWsNld, a.K, a.dil);
+  const size_t lds = (size_t)2 * PREC * R * 64 + 3 * 4 * 2048;
+  static bool attr_set = false;  // benign race: the attribute is idempotent
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_ws_kernel<PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    MI355_REQUIRE(e == hipSuccess, "conv_gemm(ws): cannot reserve LDS: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int tiles_per_item = (a.Lout + 127) / 128;
+  const int P = a.B * tiles_per_item;
+  const int NT = (a.Cout + 127) / 128;
+  const int fold = (a.res || a.accumulate) && a.post_act == MI355_ACT_NONE && a.up_s == 0 && a.res_shift == 0;
+  const unsigned grid = (unsigned)(((P + 7) / 8) * 8 * NT);
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL((conv_gemm_ws_kernel<PREC>), dim3(grid), dim3(kWsThreads), lds, st, a, tiles_per_item, P, NT, fold);
+  MI355_LAUNCH_CHECK("conv_gemm(ws)");
+  return MI355_OK;
 }
 
 template <int BM, int BN, int PREC, bool VEC>
@@ -245,11 +607,20 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
   const bool vec = (a.flat_valid == 0) && (a.ldx % 4 == 0) && (a.x_off % 4 == 0) && (a.x_bstride % 4 == 0) &&
                    (((uintptr_t)a.x) % 16 == 0);
   int tile = a.tile;
+  const bool ws_ok = vec && (128 + (a.K - 1) * a.dil) <= 32 * kWsNld && a.Lin > 0;
   if (tile == 0) {
     const int bn = a.Cout <= 64 ? 64 : 128;
     const long wgs128 = (long)a.B * ((a.Lout + 127) / 128) * ((a.Cout + bn - 1) / bn);
     const int bm = (bn == 128 && wgs128 >= 512) ? 128 : 64;
     tile = bm * 1000 + bn;
+    // the wave-specialised kernel once there are enough 128 x 128 tiles to fill the 256 CUs
+    // (MI355_CONV_NO_WS=1 in the environment keeps the auto choice on the 4-wave kernels: an A/B and bisecting aid)
+    static const bool no_ws = getenv("MI355_CONV_NO_WS") != nullptr;
+    if (!no_ws && ws_ok && bn == 128 && wgs128 >= 256 && a.Cin >= 64) tile = 8128128;
+  }
+  if (tile == 8128128) {
+    MI355_REQUIRE(ws_ok, "conv_gemm: the wave-specialised tile needs a 16-B aligned channels-last input and (K-1)*dil <= 64");
+    return a.precision == 2 ? launch_ws<2>(a, st) : launch_ws<1>(a, st);
   }
   if (!vec) {
     a.precision = 2;  // the unaligned (tiny C_in) path always runs the hi+lo split

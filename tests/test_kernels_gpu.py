@@ -51,6 +51,17 @@ def ref_conv_nlc(x, w, b, dil, pad):
     (514, 200, 3, 1, 33, 2, 64064),
     (768, 50, 1, 1, 80, 1, 0),
     (128, 22, 7, 1, 500, 1, 0),
+    # wave-specialised producer / consumer kernel (tile code 8128128): 1, 2 and 3 N-tiles, K = 1 / 2 / odd, dilation,
+    # ragged channel counts, more row tiles than XCDs
+    (128, 128, 7, 3, 300, 2, 8128128),
+    (128, 128, 3, 1, 1500, 3, 8128128),
+    (256, 256, 11, 5, 257, 1, 8128128),
+    (128, 128, 11, 1, 129, 1, 8128128),
+    (96, 200, 2, 1, 131, 2, 8128128),
+    (512, 64, 1, 1, 777, 3, 8128128),
+    (1090, 300, 3, 1, 145, 1, 8128128),
+    (32, 22, 1, 1, 500, 1, 8128128),
+    (64, 128, 5, 16, 260, 1, 8128128),
 ])
 def test_conv_gemm_plain(ops, cin, cout, k, dil, L, B, tile):
     g = torch.Generator().manual_seed(cin + cout + k)
@@ -71,8 +82,11 @@ def test_conv_gemm_plain(ops, cin, cout, k, dil, L, B, tile):
         assert rel_err(got, ref) < tol, (prec, rel_err(got, ref))
 
 
-def test_conv_gemm_fused_prologue_epilogue_ragged(ops):
-    """AdaIN affine + Snake in front, bias + residual(row>>1) + scale + accumulate behind, ragged batch."""
+@pytest.mark.parametrize("tile,res_shift,act", [(0, 1, "snake"), (8128128, 1, "snake"), (8128128, 0, "snake"), (128128, 0, "leaky"),
+                                                 (8128128, 0, "leaky"), (64064, 0, "snake")])
+def test_conv_gemm_fused_prologue_epilogue_ragged(ops, tile, res_shift, act):
+    """AdaIN affine + Snake / LeakyReLU in front, bias + residual(row >> res_shift) + scale + accumulate behind, ragged
+    batch; res_shift == 0 takes the accumulator-initialisation ("fold") path of the wave-specialised kernel."""
     g = torch.Generator().manual_seed(7)
     B, L, C, K, dil = 3, 210, 128, 7, 3
     lens = torch.tensor([210, 64, 131], dtype=torch.int32)
@@ -82,28 +96,33 @@ def test_conv_gemm_fused_prologue_epilogue_ragged(ops):
     sc = torch.rand(B, C, generator=g) + 0.5
     sh = torch.randn(B, C, generator=g) * 0.3
     alpha = torch.rand(C, generator=g) + 0.5
-    res = torch.randn(B, (L + 1) // 2, C, generator=g)
+    res = torch.randn(B, L, C, generator=g)
     y0 = torch.randn(B, L, C, generator=g)
     pad = (K * dil - dil) // 2
     pc = ops.pack_conv(w, bias, DEV)
     lens_d = lens.to(DEV)
     y = y0.clone().to(DEV)
+    kw = dict(pre_act=ops.ACT_SNAKE, pre_alpha=alpha.to(DEV)) if act == "snake" else dict(pre_act=ops.ACT_LEAKY, pre_slope=0.2)
     ops.conv_gemm(x.to(DEV), pc, y, dil=dil, pad=pad, lens_in=lens_d, lens_out=lens_d, pre=(sc.to(DEV), sh.to(DEV)),
-                  pre_act=ops.ACT_SNAKE, pre_alpha=alpha.to(DEV), res=res.to(DEV), res_shift=1, out_scale=0.5, accumulate=True)
+                  res=res.to(DEV), res_shift=res_shift, out_scale=0.5, accumulate=True, tile=tile, **kw)
     torch.cuda.synchronize()
     got = y.cpu()
     for b in range(B):
         n = int(lens[b])
         t = x[b:b + 1, :n].double() * sc[b].double() + sh[b].double()
-        t = t + (1.0 / alpha.double()) * torch.sin(alpha.double() * t) ** 2
+        if act == "snake":
+            t = t + (1.0 / alpha.double()) * torch.sin(alpha.double() * t) ** 2
+        else:
+            t = F.leaky_relu(t, 0.2)
         ref = ref_conv_nlc(t, w, bias, dil, pad)[0]
-        ref = (ref + res[b, torch.arange(n) // 2].double() + y0[b, :n].double()) * 0.5
+        ref = (ref + res[b, torch.arange(n) >> res_shift].double() + y0[b, :n].double()) * 0.5
         assert rel_err(got[b, :n], ref) < 3e-5
         assert torch.equal(got[b, n:], y0[b, n:])  # rows beyond the item's length are never written
 
 
-@pytest.mark.parametrize("cin,cout,k,s,L,row_off", [(512, 256, 20, 10, 53, 0), (256, 128, 12, 6, 130, 1), (64, 32, 4, 2, 9, 0)])
-def test_conv_transpose_polyphase(ops, cin, cout, k, s, L, row_off):
+@pytest.mark.parametrize("cin,cout,k,s,L,row_off,tile", [(512, 256, 20, 10, 53, 0, 0), (256, 128, 12, 6, 130, 1, 0), (64, 32, 4, 2, 9, 0, 0),
+                                                         (512, 256, 20, 10, 153, 0, 8128128), (256, 128, 12, 6, 330, 1, 8128128)])
+def test_conv_transpose_polyphase(ops, cin, cout, k, s, L, row_off, tile):
     g = torch.Generator().manual_seed(k * s)
     p = (k - s) // 2
     w_t = bf16r(torch.randn(cout, k, cin, generator=g) / math.sqrt(k * cin / s))  # mx.conv_transpose1d layout
@@ -115,7 +134,7 @@ def test_conv_transpose_polyphase(ops, cin, cout, k, s, L, row_off):
     y = torch.full((2, lout + row_off, cout), float("nan"), device=DEV)
     kp = k // s
     ops.conv_gemm(x.to(DEV), pc, y, pad=kp - 1, lout=L + kp - 1, pre_act=ops.ACT_LEAKY, pre_slope=0.1, res=res.to(DEV),
-                  up=dict(s=s, p=p, cout=cout, row_off=row_off, lout=lout))
+                  up=dict(s=s, p=p, cout=cout, row_off=row_off, lout=lout), tile=tile)
     torch.cuda.synchronize()
     xa = F.leaky_relu(x.double(), 0.1).transpose(1, 2)
     ref = F.conv_transpose1d(xa, w_t.permute(2, 0, 1).double(), bias.double(), stride=s, padding=p).transpose(1, 2)

@@ -1,0 +1,124 @@
+#!/usr/bin/env python
+"""Within-process A/B of the conv_gemm tile variants on the Kokoro vocoder's dominant conv shapes.
+
+    python tools/bench_conv.py [--batch 32] [--out gpurun_out/conv_ab.txt]
+
+Every (shape, variant) pair is first checked against an fp64 torch conv of the same fused op on a
+slice of the rows (the variants must agree with the reference, not merely with each other), then timed
+interleaved over several rounds with events on the launch stream; the table reports the median.
+Algorithmic FLOPs = 2*rows*Cin*Cout*K (one pass; the bf16 hi+lo split issues twice that on the MFMA
+pipe), algorithmic bytes = fp32 in + out (+ residual) per row, weights once.
+"""
+import argparse
+import math
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--out", default="")
+    ap.add_argument("--precision", type=int, default=2)
+    args = ap.parse_args()
+    from mlx_audio_amd import ops
+
+    ops.require_gpu()
+    dev = "cuda"
+    B = args.batch
+    # (cin, cout, k, dil, L, fused) -- stage-1 (C=128, L=31681) and stage-0 (C=256, L=5280) resblock convs
+    shapes = []
+    for k in (3, 7, 11):
+        for dil in (1, 5):
+            shapes.append((128, 128, k, dil, 31681, "snake+res" if dil == 1 else "snake"))
+    for k in (3, 7, 11):
+        shapes.append((256, 256, k, 1, 5280, "snake+res"))
+    shapes.append((256, 256, 11, 5, 5280, "snake"))
+    shapes.append((1090, 1024, 3, 1, 264, "leaky"))
+    shapes.append((512, 2560, 2, 1, 529, "plain"))
+    variants = [("old128x128", 128128), ("old64x128", 64128), ("ws128x128", 8128128)]
+    lines = ["cin cout k dil rows fused variant ms tflops_alg GBps_alg maxrel"]
+    g = torch.Generator(device=dev).manual_seed(0)
+    for cin, cout, k, dil, L, fused in shapes:
+        w = (torch.randn(cout, k, cin) / math.sqrt(k * cin)).to(torch.bfloat16).float()
+        bias = torch.randn(cout) * 0.1
+        pc = ops.pack_conv(w, bias, dev)
+        ld = ops.round_up(cin, 32)
+        x = torch.randn((B, L, ld), generator=g, device=dev)
+        y = torch.zeros((B, L, cout), device=dev)
+        pad = (k * dil - dil) // 2
+        kw = {}
+        if fused.startswith("snake"):
+            sc = torch.rand((B, ld), generator=g, device=dev) + 0.5
+            sh = torch.randn((B, ld), generator=g, device=dev) * 0.3
+            alpha = torch.rand(ld, generator=g, device=dev) + 0.5
+            kw.update(pre=(sc, sh), pre_act=ops.ACT_SNAKE, pre_alpha=alpha)
+        elif fused == "leaky":
+            sc = torch.rand((B, ld), generator=g, device=dev) + 0.5
+            sh = torch.randn((B, ld), generator=g, device=dev) * 0.3
+            kw.update(pre=(sc, sh), pre_act=ops.ACT_LEAKY, pre_slope=0.2)
+        res = None
+        if fused.endswith("+res"):
+            res = torch.randn((B, L, cout), generator=g, device=dev)
+            kw.update(res=res)
+        rows = B * L
+        flops = 2.0 * rows * cin * cout * k
+        byts = 4.0 * rows * (cin + cout + (cout if res is not None else 0)) + 2.0 * cin * cout * k
+        # reference on the first item's first rows
+        n = min(L, 700)
+        xr = x[0:1, :n, :cin].double().cpu()
+        if "pre" in kw:
+            xr = xr * kw["pre"][0][0, :cin].double().cpu() + kw["pre"][1][0, :cin].double().cpu()
+            if kw["pre_act"] == ops.ACT_SNAKE:
+                al = kw["pre_alpha"][:cin].double().cpu()
+                xr = xr + (1.0 / al) * torch.sin(al * xr) ** 2
+            else:
+                xr = F.leaky_relu(xr, 0.2)
+        ref = F.conv1d(xr.transpose(1, 2), w.permute(0, 2, 1).double(), bias.double(), padding=pad, dilation=dil).transpose(1, 2)[0]
+        if res is not None:
+            ref = ref + res[0, :n].double().cpu()
+        ok_rows = n - pad  # rows whose window stays inside the first n inputs
+        times = {name: [] for name, _ in variants}
+        errs = {}
+        for name, tile in variants:
+            try:
+                ops.conv_gemm(x[:, :, :cin], pc, y, dil=dil, pad=pad, tile=tile, precision=args.precision, **kw)
+                torch.cuda.synchronize()
+                got = y[0, :ok_rows].double().cpu()
+                errs[name] = float((got - ref[:ok_rows]).abs().max() / ref.abs().max())
+            except Exception as e:  # a variant may not support a shape
+                errs[name] = str(e)[:60]
+        for _ in range(args.rounds):
+            for name, tile in variants:
+                if isinstance(errs[name], str):
+                    continue
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                ops.conv_gemm(x[:, :, :cin], pc, y, dil=dil, pad=pad, tile=tile, precision=args.precision, **kw)
+                e1.record()
+                torch.cuda.synchronize()
+                times[name].append(e0.elapsed_time(e1))
+        for name, _ in variants:
+            if isinstance(errs[name], str):
+                lines.append(f"{cin} {cout} {k} {dil} {rows} {fused} {name} n/a - - {errs[name]!r}")
+                continue
+            ms = sorted(times[name])[len(times[name]) // 2]
+            lines.append(f"{cin} {cout} {k} {dil} {rows} {fused} {name} {ms:.4f} {flops / ms / 1e9:.1f} {byts / ms / 1e6:.0f} {errs[name]:.2e}")
+        del x, y, res
+        torch.cuda.empty_cache()
+    txt = "\n".join(lines)
+    print(txt)
+    if args.out:
+        os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+        with open(args.out, "w") as f:
+            f.write(txt + "\n")
+
+
+if __name__ == "__main__":
+    main()
