@@ -81,14 +81,19 @@ def pack_conv_transpose(w_t: torch.Tensor, bias: Optional[torch.Tensor], stride:
     takes it (out[n] += x[t] * w_t[:, k, :] for n = t*stride + k - pad); K must be a multiple of
     stride.  Returns the equivalent stride-1 conv with K/stride taps and ``stride*Cout`` outputs:
     GEMM row u, column r*Cout+co  ->  out[u*stride + r - pad, co]."""
+    return pack_conv(_polyphase_weight(w_t.to(torch.float32), stride), bias, device)
+
+
+def _polyphase_weight(w_t: torch.Tensor, stride: int) -> torch.Tensor:
+    """[Cout, K, Cin] transposed-conv weight -> [stride*Cout, K/stride, Cin] stride-1 conv weight (host logic)."""
     cout, k, cin = w_t.shape
     assert k % stride == 0, "polyphase conv_transpose needs K % stride == 0"
     kp = k // stride
-    w = torch.empty((stride * cout, kp, cin), dtype=torch.float32)
+    w = torch.empty((stride * cout, kp, cin), dtype=w_t.dtype)
     for r in range(stride):
         for tp in range(kp):
             w[r * cout:(r + 1) * cout, tp, :] = w_t[:, r + (kp - 1 - tp) * stride, :]
-    return pack_conv(w, bias, device)
+    return w
 
 
 def pack_lstm_wh(wh_f: torch.Tensor, wh_b: torch.Tensor, device) -> torch.Tensor:

@@ -1,0 +1,173 @@
+"""Host-side mirror of the reference's Python surface for the hot path, CPU-only parts:
+registry, loader error behaviour, Kokoro config / sanitize / pipeline plumbing, dsp constants and import isolation."""
+import json
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dsp_ref
+
+
+def test_registry_is_import_free_and_classifies():
+    code = ("import sys; import mlx_audio_amd.registry as r; "
+            "assert 'torch' not in sys.modules and 'mlx_audio_amd.ops' not in sys.modules; "
+            "print(r.kinds(), r.classify_model('kokoro'), r.classify_model('', 'prince-canuma/Kokoro-82M'), r.classify_model('llama'), "
+            "r.is_supported_model('whisper'))")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout
+    assert out.strip() == "('tts',) tts tts None False"
+    from mlx_audio_amd import registry
+
+    assert "kokoro" in registry.SUPPORTED_MODEL_TYPES["tts"]
+    assert registry.supported_model_types("stt") == frozenset()
+
+
+def test_dsp_imports_without_tts_or_stt():
+    code = ("import sys; import mlx_audio_amd.dsp as d; "
+            "bad = [m for m in sys.modules if m.startswith(('mlx_audio_amd.tts', 'mlx_audio_amd.stt', 'oracle'))]; assert not bad, bad; "
+            "print(sorted(d.STR_TO_WINDOW_FN))")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout
+    assert out.strip() == "['bartlett', 'blackman', 'hamming', 'hann', 'hanning']"
+
+
+@pytest.mark.parametrize("name", ["hanning", "hamming", "blackman", "bartlett"])
+@pytest.mark.parametrize("size,periodic", [(20, True), (400, False), (1024, False), (21, True)])
+def test_dsp_windows_match_oracle(name, size, periodic):
+    from mlx_audio_amd import dsp
+
+    got = getattr(dsp, name)(size, periodic).numpy()
+    assert got.dtype == np.float32 and np.array_equal(got, getattr(dsp_ref, name)(size, periodic))
+
+
+@pytest.mark.parametrize("args,kw", [((16000, 400, 80), dict(norm="slaney", mel_scale=None)),
+                                     ((24000, 1024, 128, 0.0, 12000.0), dict(norm="slaney", mel_scale="slaney")),
+                                     ((16000, 512, 40), dict(mel_scale="htk")),
+                                     ((16000, 400, 80), dict(norm="slaney", mel_scale=None, precise=True))])
+def test_dsp_mel_filters_match_oracle(args, kw):
+    from mlx_audio_amd import dsp
+
+    got = dsp.mel_filters(*args, **kw).numpy()
+    want = dsp_ref.mel_filters(*args, **kw)
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_dsp_argument_errors_match_reference():
+    from mlx_audio_amd import dsp
+
+    with pytest.raises(ValueError, match="Unknown window function"):
+        dsp._resolve_window("kaiser", 16, False)
+    assert dsp._resolve_window("hann", 20, True).shape[0] == 20
+    assert np.array_equal(dsp._resolve_window("hann", 20, True).numpy(), dsp_ref.hanning(21)[:-1])  # periodic in istft
+
+
+def test_kokoro_config_and_sanitize():
+    from mlx_audio_amd.tts.models.kokoro import Model, ModelConfig
+    from mlx_audio_amd.tts.models.kokoro import synthetic as S
+
+    cfg = ModelConfig.from_dict({**S.KOKORO_CONFIG, "unknown_key": 1})
+    assert cfg.sample_rate == 24000 and cfg.n_token == 178
+    m = Model(cfg)
+    assert m.sample_rate == 24000 and m.context_length == 512
+    g = torch.Generator().manual_seed(0)
+    raw = {
+        "bert.embeddings.position_ids": torch.arange(4),
+        "bert.pooler.weight": torch.randn(4, 4, generator=g),
+        "bert_encoder.weight": torch.randn(4, 4, generator=g),
+        "text_encoder.cnn.0.1.gamma": torch.ones(8),
+        "text_encoder.cnn.0.1.beta": torch.zeros(8),
+        "text_encoder.cnn.0.0.weight_v": torch.randn(8, 6, 5, generator=g),        # torch (out, in, K) -> transposed
+        "text_encoder.lstm.weight_ih_l0_reverse": torch.randn(16, 8, generator=g),
+        "predictor.lstm.bias_hh_l0": torch.randn(16, generator=g),
+        "predictor.F0_proj.weight": torch.randn(1, 256, 1, generator=g),
+        "predictor.F0.1.pool.weight_v": torch.randn(512, 1, 3, generator=g),         # depthwise (C, 1, 3) -> (C, 3, 1)
+        "decoder.generator.noise_convs.0.weight": torch.randn(256, 22, 12, generator=g),
+        "decoder.generator.resblocks.0.convs1.0.weight_v": torch.randn(256, 3, 3, generator=g),  # K == in: MLX layout already
+        "decoder.generator.conv_post.weight_g": torch.randn(22, 1, 1, generator=g),
+    }
+    out = m.sanitize(raw)
+    assert "bert.embeddings.position_ids" not in out
+    assert "text_encoder.cnn.0.1.weight" in out and "text_encoder.cnn.0.1.bias" in out
+    assert out["text_encoder.cnn.0.0.weight_v"].shape == (8, 5, 6)
+    assert "text_encoder.lstm.Wx_backward" in out and "predictor.lstm.bias_hh_forward" in out
+    assert out["predictor.F0_proj.weight"].shape == (1, 1, 256)
+    assert out["predictor.F0.1.pool.weight_v"].shape == (512, 3, 1)
+    assert out["decoder.generator.noise_convs.0.weight"].shape == (256, 12, 22)
+    assert out["decoder.generator.resblocks.0.convs1.0.weight_v"].shape == (256, 3, 3)
+    # key set is preserved on an already-converted checkpoint (layouts follow the reference's shape heuristic, which is
+    # only meaningful on PyTorch-layout inputs: e.g. F0_proj.weight is always transposed, kokoro.py:231-243)
+    w = S.make_kokoro_weights(S.tiny_config())
+    assert set(m.sanitize(w)) == set(w)
+    with pytest.raises(RuntimeError, match="no weights"):
+        m("abc", torch.zeros(1, 256))
+    ids = m.phonemes_to_ids("".join(list(cfg.vocab)[:5]) + "?")  # unknown symbols are dropped (kokoro.py:119-121)
+    assert ids.tolist()[0] == 0 and ids.tolist()[-1] == 0 and len(ids) == 7
+
+
+def test_pipeline_chunking_voices_and_errors(tmp_path):
+    from mlx_audio_amd.tts.models.kokoro import KokoroPipeline
+
+    p = KokoroPipeline("en-us", model=False, repo_id=str(tmp_path), g2p=lambda t: t.upper())
+    assert p.lang_code == "a"
+    res = list(p("hello\n\nworld"))
+    assert [(r.graphemes, r.phonemes, r.audio) for r in res] == [("hello", "HELLO", None), ("world", "WORLD", None)]
+    gs, ps, audio = res[0]
+    assert (gs, ps, audio) == ("hello", "HELLO", None)
+    chunks = KokoroPipeline.chunk_phonemes("ab. " * 300)
+    assert all(len(c) <= 510 for c in chunks) and "".join(chunks).replace(" ", "") == ("ab." * 300)
+    assert all(c.endswith(".") for c in chunks[:-1])  # sentence boundaries preferred
+    with pytest.raises(AssertionError):
+        KokoroPipeline("xx", model=False, repo_id="r")
+    with pytest.raises(ValueError, match="repo_id"):
+        KokoroPipeline("a", model=False, repo_id=None)
+    # voices: blend of two packs = mean
+    from safetensors.torch import save_file
+
+    (tmp_path / "voices").mkdir()
+    a, b = torch.randn(510, 1, 256), torch.randn(510, 1, 256)
+    save_file({"voice": a}, str(tmp_path / "voices" / "va.safetensors"))
+    torch.save(b, str(tmp_path / "voices" / "vb.pt"))
+    assert torch.equal(p.load_voice("va"), a)
+    assert torch.allclose(p.load_voice("va,vb"), (a + b) / 2)
+    with pytest.raises(FileNotFoundError):
+        p.load_voice("missing_voice")
+    with pytest.raises(ValueError, match="Specify a voice"):
+        list(KokoroPipeline("a", model=object(), repo_id=str(tmp_path), g2p=str)("hi"))
+    with pytest.raises(ValueError, match="too long"):
+        list(p.generate_from_tokens("a" * 511, voice=None))
+
+
+def test_loader_error_behaviour(tmp_path):
+    from mlx_audio_amd.tts.utils import load_model
+    from mlx_audio_amd.utils import get_model_class, load_config, load_weights
+
+    with pytest.raises(FileNotFoundError):
+        load_model(tmp_path / "nope")
+    with pytest.raises(FileNotFoundError):
+        load_model("./definitely/not/here")
+    d = tmp_path / "Kokoro-82M-bf16"
+    d.mkdir()
+    with pytest.raises(FileNotFoundError, match="Config not found"):
+        load_config(d)
+    (d / "config.json").write_text(json.dumps({"model_type": "does_not_exist"}))
+    with pytest.raises(ValueError, match="not supported for tts"):
+        get_model_class("does_not_exist", None, "tts", {})
+    with pytest.raises(FileNotFoundError, match="No safetensors"):
+        load_weights(d)
+    with pytest.raises(ValueError, match="Invalid model path type"):
+        load_model(123)
+    arch, mt = get_model_class("styletts2", ["kokoro", "82m"], "tts", {"styletts2": "kokoro"})
+    assert mt == "kokoro" and hasattr(arch, "Model") and hasattr(arch, "ModelConfig")
+
+
+def test_generation_result_fields_match_reference():
+    from mlx_audio_amd.tts.models.base import BatchGenerationResult, GenerationResult, check_array_shape, format_duration
+
+    assert [f for f in GenerationResult.__dataclass_fields__] == [
+        "audio", "samples", "sample_rate", "segment_idx", "token_count", "audio_duration", "real_time_factor", "prompt",
+        "audio_samples", "processing_time_seconds", "peak_memory_usage", "is_streaming_chunk", "is_final_chunk"]
+    assert "sequence_idx" in BatchGenerationResult.__dataclass_fields__
+    assert format_duration(6.6) == "00:00:06.599" or format_duration(6.6) == "00:00:06.600"
+    assert format_duration(3725.25) == "01:62:05.250"  # minutes are not wrapped in the reference either (kokoro.py:337-342)
+    assert check_array_shape(torch.zeros(8, 3, 3)) and not check_array_shape(torch.zeros(8, 6, 5)) and not check_array_shape(torch.zeros(2, 3))
