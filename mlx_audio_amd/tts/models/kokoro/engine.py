@@ -474,9 +474,10 @@ class KokoroEngine:
         up = self.total_up
         L2 = 2 * Fm
         if rand_ini is None or noise is None:
-            rng = np.random.default_rng(noise_seed)
-            rand_ini = torch.from_numpy(rng.uniform(size=(B, 9)).astype(np.float32))
-            noise = torch.from_numpy(rng.standard_normal((B, L2 * up, 9)).astype(np.float32))
+            # SineGen's uniform initial phases and gaussian noise (istftnet.py:581,649), drawn on the device
+            gen = torch.Generator(device=dev).manual_seed(noise_seed)
+            rand_ini = torch.rand((B, 9), generator=gen, device=dev, dtype=torch.float32)
+            noise = torch.randn((B, L2 * up, 9), generator=gen, device=dev, dtype=torch.float32)
         rand_ini = rand_ini.to(dev).contiguous()
         noise = noise.to(dev).contiguous()
         har_src = ops.sine_source(f0_curve, rand_ini, noise, self.src_w, self.src_b, up, lens2=lens_2f)

@@ -1,0 +1,130 @@
+"""The reference-shaped Python surface running on the HIP path (needs an MI355X): ``mlx_audio_amd.dsp`` against the
+oracle / the reference's golden vectors, and the Kokoro ``Model`` protocol (load -> sanitize -> __call__ -> generate)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dsp_stft_istft_reference_semantics():
+    from mlx_audio_amd import dsp
+    from oracle import dsp_ref
+
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(5000).astype(np.float32)
+    for n_fft, hop, win, center, pad_mode in [(800, None, "hann", True, "reflect"), (400, 160, "hamming", True, "constant"),
+                                               (512, 128, "blackman", False, "reflect"), (20, 5, "hann", True, "reflect")]:
+        got = dsp.stft(x, n_fft=n_fft, hop_length=hop, window=win, center=center, pad_mode=pad_mode).cpu().numpy()
+        ref = dsp_ref.stft(x, n_fft=n_fft, hop_length=hop, window=win, center=center, pad_mode=pad_mode)
+        assert got.shape == ref.shape and got.dtype == np.complex64
+        assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-6
+    # batched form == per-row form
+    xb = rng.standard_normal((3, 3000)).astype(np.float32)
+    b = dsp.stft(xb, n_fft=400, hop_length=100).cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(b[i], dsp.stft(xb[i], n_fft=400, hop_length=100).cpu().numpy())
+    with pytest.raises(ValueError, match="too short"):
+        dsp.stft(x[:100], n_fft=800, center=False)
+    with pytest.raises(ValueError, match="Unknown window"):
+        dsp.stft(x, window="kaiser")
+    with pytest.raises(ValueError, match="Invalid pad_mode"):
+        dsp.stft(x, pad_mode="edge")
+    # inverse: both normalisations, default hop, explicit length
+    spec = dsp_ref.stft(x, n_fft=400, hop_length=100, window="hann")
+    for normalized in (False, True):
+        got = dsp.istft(spec.T, hop_length=100, win_length=400, normalized=normalized).cpu().numpy()
+        ref = dsp_ref.istft(spec.T, hop_length=100, win_length=400, normalized=normalized)
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 5e-5
+    got = dsp.istft(spec.T, hop_length=100, win_length=400, length=1234).cpu().numpy()
+    ref = dsp_ref.istft(spec.T, hop_length=100, win_length=400, length=1234)
+    assert got.shape == ref.shape == (1234,) and np.abs(got - ref).max() < 5e-5
+    # round trip (MLXSTFT-style: periodic hann 20, hop 5, w^2 normalisation)
+    w = dsp.hanning(21)[:-1]
+    s = dsp.stft(x, n_fft=20, hop_length=5, window=w)
+    back = dsp.istft(s.transpose(0, 1), hop_length=5, win_length=20, window=w, normalized=True).cpu().numpy()
+    assert np.abs(back - x[: back.shape[0]]).max() < 1e-4
+
+
+def test_dsp_istft_cache_and_mel_front_ends(golden):
+    from mlx_audio_amd import dsp
+    from oracle import dsp_ref
+
+    rng = np.random.default_rng(5)
+    B, nb, nf, n_fft, hop = 2, 513, 40, 1024, 256
+    re = rng.standard_normal((B, nb, nf)).astype(np.float32)
+    im = rng.standard_normal((B, nb, nf)).astype(np.float32)
+    win = dsp.hanning(1024, periodic=True)
+    cache, ref_cache = dsp.ISTFTCache(), dsp_ref.ISTFTCache()
+    for clamp, length in ((False, None), (True, 7000)):
+        got = cache.istft(re, im, n_fft, hop, n_fft, win, center=True, audio_length=length, constrain_value_range=clamp).cpu().numpy()
+        ref = ref_cache.istft(re, im, n_fft, hop, n_fft, win.numpy(), center=True, audio_length=length, constrain_value_range=clamp)
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 5e-5 * max(1.0, np.abs(ref).max())
+    assert cache.cache_info()["norm_buffers"] == 1
+    cache.clear_cache()
+    assert cache.cache_info()["total_cached_items"] == 0
+    # reference golden vectors of the Qwen3 mel front end (tts/tests/test_qwen3_tts.py:175-353)
+    g = golden["qwen3_mel_spectrogram"]
+    np.random.seed(42)
+    audio = np.random.randn(12000).astype(np.float32)
+    m = dsp.mel_spectrogram(audio[None]).cpu().numpy()
+    assert list(m.shape) == g["shape"]
+    kw = dict(rtol=g["rtol"], atol=g["atol"])
+    np.testing.assert_allclose(m[0, 0, g["bins"]], g["frame0"], **kw)
+    np.testing.assert_allclose(m[0, -1, g["bins"]], g["frame_last"], **kw)
+    np.testing.assert_allclose(m.mean(), g["mean"], **kw)
+    # whisper front end
+    a = rng.standard_normal(32000).astype(np.float32)
+    w = dsp.log_mel_spectrogram(a, n_mels=80, padding=16000).cpu().numpy()
+    ref = dsp_ref.whisper_log_mel(a, padding=16000)
+    assert w.shape == ref.shape and np.abs(w - ref).max() < 2e-4
+
+
+def test_kokoro_model_protocol_end_to_end(tmp_path):
+    """config.json + safetensors on disk -> load_model (registry, sanitize, engine build) -> __call__ / generate."""
+    from safetensors.torch import save_file
+
+    from mlx_audio_amd.tts.models.kokoro import synthetic as S
+    from mlx_audio_amd.tts.models.kokoro.engine import KokoroEngine
+    from mlx_audio_amd.tts.utils import load_model
+    from mlx_audio_amd.utils import load_model as load_any
+
+    cfg = S.tiny_config()
+    d = tmp_path / "Kokoro-82M-bf16"
+    (d / "voices").mkdir(parents=True)
+    (d / "config.json").write_text(json.dumps(cfg))
+    w = S.make_kokoro_weights(cfg)
+    # write the checkpoint in PyTorch layout / naming for the keys sanitize rewrites, bf16 like the real one
+    raw = {}
+    for k, v in w.items():
+        if k.endswith(("F0_proj.weight", "N_proj.weight")) or ("noise_convs" in k and k.endswith(".weight")):
+            v = v.permute(0, 2, 1)
+        raw[k] = v.contiguous().to(torch.bfloat16)
+    save_file(raw, str(d / "model.safetensors"))
+    voice = S.make_voice_pack()
+    save_file({"voice": voice}, str(d / "voices" / "af_test.safetensors"))
+    model = load_model(d)
+    assert load_any(str(d)).sample_rate == 24000  # kind-agnostic entry point resolves the same model
+    assert model.sample_rate == 24000
+    ps = "".join(list(cfg["vocab"])[3:20])
+    out = model(ps, voice[len(ps) - 1], speed=1.0, return_output=True)
+    ref_eng = KokoroEngine(S.make_kokoro_weights(cfg), cfg)
+    ids = model.phonemes_to_ids(ps)
+    a_ref, d_ref = ref_eng.forward([ids], voice[len(ps) - 1])
+    torch.cuda.synchronize()
+    assert torch.equal(out.pred_dur.cpu(), d_ref[0].cpu())
+    assert out.audio.shape == (1, a_ref[0].numel()) and out.audio.shape[1] == 600 * int(d_ref[0].sum())
+    # SineGen noise is seeded identically in both engines: same checkpoint through the loader == direct engine
+    assert torch.allclose(out.audio[0].cpu(), a_ref[0].cpu(), atol=1e-5)
+    # generate(): phoneme strings through a pluggable G2P (misaki is not part of the hot path)
+    model._get_pipeline("a")._g2p = lambda text: ps
+    results = list(model.generate("two\nsegments", voice="af_test", speed=1.0, lang_code="a", some_cli_kwarg=True))
+    assert len(results) == 2
+    r = results[0]
+    assert r.samples == out.audio.shape[1] == r.audio.numel() and r.sample_rate == 24000 and r.token_count == len(ps)
+    assert r.audio_samples["samples"] == r.samples and r.prompt["tokens"] == len(ps) and r.segment_idx == 0
+    assert r.audio_duration.startswith("00:00:") and r.real_time_factor >= 0
+    br = list(model.batch_generate([ps, ps[:9]], [voice[len(ps) - 1], voice[8]]))
+    assert [b.sequence_idx for b in br] == [0, 1] and br[0].samples == r.samples and br[1].samples < br[0].samples
