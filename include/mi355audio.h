@@ -42,7 +42,7 @@ int mi355_device_info(int dev, char* name, int name_cap, int* cu_count, int* lds
 /* ------------------------------------------------------------------------------------------
  * conv_gemm: conv1d / linear / polyphase conv_transpose1d as an implicit GEMM on MFMA
  * (v_mfma_f32_32x32x16_bf16; fp32 activations split on the fly into bf16 hi+lo so that the
- * result keeps ~16 mantissa bits, weights bf16).
+ * result keeps ~16 mantissa bits, weights bf16; or v_mfma_f32_32x32x16_f16 on fp16-rounded activations).
  * Replaces: mx.conv1d / mx.conv_transpose1d in ConvWeighted (tts/models/kokoro/istftnet.py:
  * 128-170), nn.Conv1d (istftnet.py:771-786), nn.Linear (modules.py:15,60-90,477-600,
  * kokoro.py:84), the per-step x-projection mx.addmm of LSTM (modules.py:156-163), and the fused
@@ -100,7 +100,8 @@ typedef struct {
   int32_t up_Lout;
   const int32_t* lens_up; /* [B] nullable */
   int32_t B;
-  int32_t precision;   /* 2 = bf16 hi+lo split (default), 1 = single bf16 pass */
+  int32_t precision;   /* 2 = bf16 hi+lo split (default; ~16 mantissa bits of the fp32 activation), 1 = single bf16 pass,
+                          3 = single fp16 pass: activations rounded to fp16 (saturating), weights packed with MI355_W_F16 */
   int32_t tile;        /* 0 = auto, else BM*1000+BN (128128, 64128, 64064) */
 } mi355_conv_gemm_args;
 
@@ -110,6 +111,10 @@ int mi355_conv_gemm(const mi355_conv_gemm_args* a, void* stream);
  * out: uint16 buffer of mi355_packed_conv_weight_elems(Cout, K, Cin) elements. */
 int64_t mi355_packed_conv_weight_elems(int32_t Cout, int32_t K, int32_t Cin);
 int mi355_pack_conv_weight_host(const float* w_host, int32_t Cout, int32_t K, int32_t Cin, uint16_t* out_host);
+/* Same with an explicit element type: MI355_W_BF16 (precision 1 / 2) or MI355_W_F16 (precision 3; bf16-valued checkpoint
+ * weights are exactly representable in fp16 down to 2^-17). */
+enum { MI355_W_BF16 = 0, MI355_W_F16 = 1 };
+int mi355_pack_conv_weight_host_dt(const float* w_host, int32_t Cout, int32_t K, int32_t Cin, int32_t dtype, uint16_t* out_host);
 
 /* ------------------------------------------------------------------------------------------
  * Instance-norm statistics + AdaIN coefficients.

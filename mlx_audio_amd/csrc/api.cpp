@@ -15,7 +15,7 @@ void mi355_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* mi355_last_error(void) { return g_err; }
-extern "C" int mi355_abi_version(void) { return 1; }
+extern "C" int mi355_abi_version(void) { return 2; }
 
 extern "C" int mi355_device_info(int dev, char* name, int name_cap, int* cu_count, int* lds_bytes) {
   hipDeviceProp_t p;
@@ -39,8 +39,9 @@ extern "C" int64_t mi355_packed_conv_weight_elems(int32_t Cout, int32_t K, int32
   return chunks * K * ntp * 2 * 512;
 }
 
-extern "C" int mi355_pack_conv_weight_host(const float* w, int32_t Cout, int32_t K, int32_t Cin, uint16_t* out) {
+static int pack_conv_weight(const float* w, int32_t Cout, int32_t K, int32_t Cin, int32_t dtype, uint16_t* out) {
   MI355_REQUIRE(w && out && Cout > 0 && K > 0 && Cin > 0, "pack_conv_weight: bad arguments");
+  MI355_REQUIRE(dtype == MI355_W_BF16 || dtype == MI355_W_F16, "pack_conv_weight: dtype must be MI355_W_BF16 or MI355_W_F16");
   const int chunks = (Cin + 31) / 32;
   const int ntp = ((Cout + 127) / 128) * 4;
   size_t o = 0;
@@ -54,10 +55,18 @@ extern "C" int mi355_pack_conv_weight_host(const float* w, int32_t Cout, int32_t
             for (int j = 0; j < 8; ++j) {
               const int c = c0 + j;
               float v = (n < Cout && c < Cin) ? w[((size_t)n * K + tap) * Cin + c] : 0.0f;
-              out[o++] = host_f32_to_bf16(v);
+              out[o++] = dtype == MI355_W_F16 ? host_f32_to_f16(v) : host_f32_to_bf16(v);
             }
           }
   return MI355_OK;
+}
+
+extern "C" int mi355_pack_conv_weight_host(const float* w, int32_t Cout, int32_t K, int32_t Cin, uint16_t* out) {
+  return pack_conv_weight(w, Cout, K, Cin, MI355_W_BF16, out);
+}
+
+extern "C" int mi355_pack_conv_weight_host_dt(const float* w, int32_t Cout, int32_t K, int32_t Cin, int32_t dtype, uint16_t* out) {
+  return pack_conv_weight(w, Cout, K, Cin, dtype, out);
 }
 
 // ---- LSTM recurrent weight packing: Wh [4H, H] fp32 (fwd, bwd) -> [2][H/8][4H][8] bf16

@@ -29,6 +29,7 @@ void mi355_set_error(const char* fmt, ...);
   } while (0)
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -42,6 +43,33 @@ __device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
 }
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
   return (uint32_t)f32_to_bf16_bits(a) | ((uint32_t)f32_to_bf16_bits(b) << 16);
+}
+
+// round-to-nearest-even fp32 -> fp16 bits, saturating at +-65504 (the conv prologue never produces inf on purpose)
+__device__ __forceinline__ uint32_t pack_f16x2(float a, float b) {
+  a = __builtin_fminf(__builtin_fmaxf(a, -65504.f), 65504.f);
+  b = __builtin_fminf(__builtin_fmaxf(b, -65504.f), 65504.f);
+  const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+  return (uint32_t)__builtin_bit_cast(uint16_t, ha) | ((uint32_t)__builtin_bit_cast(uint16_t, hb) << 16);
+}
+
+// host: fp32 -> IEEE binary16 bits, round-to-nearest-even, saturating to the largest finite value
+static inline uint16_t host_f32_to_f16(float f) {
+  uint32_t u;
+  __builtin_memcpy(&u, &f, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  u &= 0x7fffffffu;
+  if (u > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);           // NaN
+  if (u >= 0x477ff000u) return (uint16_t)(sign | 0x7bffu);          // >= 65520 rounds past the largest finite: saturate
+  if (u < 0x33000001u) return (uint16_t)sign;                       // < 2^-25 (or exactly): rounds to zero
+  const int e = (int)(u >> 23) - 127;
+  uint32_t m = (u & 0x7fffffu) | 0x800000u;                         // 24-bit significand
+  int shift = (e < -14) ? (13 + (-14 - e)) : 13;                    // bits dropped (subnormal: more)
+  uint32_t half = m >> shift;
+  const uint32_t rem = m & ((1u << shift) - 1u), mid = 1u << (shift - 1);
+  if (rem > mid || (rem == mid && (half & 1u))) ++half;
+  if (e < -14) return (uint16_t)(sign | half);                      // subnormal (a carry lands in the exponent correctly)
+  return (uint16_t)(sign | (((uint32_t)(e + 15) << 10) + (half - 0x400u)));
 }
 
 static inline uint16_t host_f32_to_bf16(float f) {

@@ -31,6 +31,19 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* ldst) {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
 
+// one 32x32x16 MFMA on 16-byte A / B fragments: bf16 (PREC 1, 2) or fp16 (PREC 3) inputs, fp32 accumulate
+template <int PREC>
+__device__ __forceinline__ f32x16 mfma16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+  if constexpr (PREC == 3)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// number of LDS images of the activation window: hi + lo for the split, one otherwise
+template <int PREC>
+constexpr int a_images() { return PREC == 2 ? 2 : 1; }
+
+
 // Shared epilogue: y = ((acc + bias -> act) + res + y_old) * out_scale, plain or polyphase (conv_transpose) store.
 // All loads of one 32x32 fragment are issued back to back on clamped addresses and only the stores are predicated:
 // a per-element "if (valid) v += res[...]" makes hipcc branch around every load and wait vmcnt(0) each time
@@ -114,7 +127,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_ge
   const int R = BM + (K - 1) * dil;
   char* A_hi = smem;
   char* A_lo = smem + R * 64;
-  char* Bs = smem + R * 64 * PREC;
+  char* Bs = smem + R * 64 * a_images<PREC>();
   const int nchunks = (a.Cin + 31) >> 5;
   const int NTp = ((a.Cout + 127) >> 7) << 2;
   const int nsteps = nchunks * K;
@@ -187,14 +200,19 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_ge
           t = t + ial[i] * (s * s);
         }
         t = ok[i] ? t : 0.f;
-        const float h = bf16_bits_to_f32(f32_to_bf16_bits(t));
+        const float h = PREC == 3 ? t : bf16_bits_to_f32(f32_to_bf16_bits(t));
         hi[i] = h;
         lo[i] = t - h;
       }
       const int addr = r * 64 + ((((c4 >> 3) ^ ((r >> 2) & 3))) << 4) + ((c4 & 4) << 1);
       uint2 ph;
-      ph.x = pack_bf16x2(hi[0], hi[1]);
-      ph.y = pack_bf16x2(hi[2], hi[3]);
+      if constexpr (PREC == 3) {
+        ph.x = pack_f16x2(hi[0], hi[1]);
+        ph.y = pack_f16x2(hi[2], hi[3]);
+      } else {
+        ph.x = pack_bf16x2(hi[0], hi[1]);
+        ph.y = pack_bf16x2(hi[2], hi[3]);
+      }
       *(uint2*)(A_hi + addr) = ph;
       if (PREC == 2) {
         uint2 pl;
@@ -221,12 +239,12 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_ge
         const bf16x8 ah = *(const bf16x8*)(A_hi + addr);
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf)
-          acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bfr[nf], acc[mf][nf], 0, 0, 0);
+          acc[mf][nf] = mfma16<PREC>(ah, bfr[nf], acc[mf][nf]);
         if (PREC == 2) {
           const bf16x8 alo = *(const bf16x8*)(A_lo + addr);
 #pragma unroll
           for (int nf = 0; nf < NF; ++nf)
-            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bfr[nf], acc[mf][nf], 0, 0, 0);
+            acc[mf][nf] = mfma16<PREC>(alo, bfr[nf], acc[mf][nf]);
         }
       }
     }
@@ -309,7 +327,8 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
   const int R = BM + (K - 1) * dil;
   const int ABYTES = R * 64;
   char* Abase = smem;                     // [2 buffers][PREC (hi, lo)][R * 64]
-  char* Bs = smem + 2 * PREC * ABYTES;    // [3 slots][BBYTES]
+  constexpr int NA = a_images<PREC>();
+  char* Bs = smem + 2 * NA * ABYTES;      // [3 slots][BBYTES]
   const int nchunks = (a.Cin + 31) >> 5;
   const int NTp = ((a.Cout + 127) >> 7) << 2;
   const int nsteps = nchunks * K;
@@ -377,14 +396,19 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
               t = t + ial[j] * (s * s);
             }
             t = (rowok && (c + j) < a.Cin) ? t : 0.f;
-            const float h = bf16_bits_to_f32(f32_to_bf16_bits(t));
+            const float h = PREC == 3 ? t : bf16_bits_to_f32(f32_to_bf16_bits(t));
             hi[j] = h;
             lo[j] = t - h;
           }
           const int addr = r * 64 + ((((c4 >> 3) ^ ((r >> 2) & 3))) << 4) + ((c4 & 4) << 1);
           uint2 ph;
-          ph.x = pack_bf16x2(hi[0], hi[1]);
-          ph.y = pack_bf16x2(hi[2], hi[3]);
+          if constexpr (PREC == 3) {
+            ph.x = pack_f16x2(hi[0], hi[1]);
+            ph.y = pack_f16x2(hi[2], hi[3]);
+          } else {
+            ph.x = pack_bf16x2(hi[0], hi[1]);
+            ph.y = pack_bf16x2(hi[2], hi[3]);
+          }
           *(uint2*)(A_hi + addr) = ph;
           if (PREC == 2) {
             uint2 pl;
@@ -430,7 +454,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
     int s = 0;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
       const bool nxt = chunk + 1 < nchunks;
-      char* A_next = Abase + ((chunk + 1) & 1) * PREC * ABYTES;
+      char* A_next = Abase + ((chunk + 1) & 1) * NA * ABYTES;
       if (K == 1) {
         const int pend = prefetch_B(s);
         if (nxt) {
@@ -515,7 +539,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
   {
     int chunk = 0, tap = 0, slot = 0;
     for (int s = 0; s < nsteps; ++s) {
-      const char* A_hi = Abase + (chunk & 1) * PREC * ABYTES;
+      const char* A_hi = Abase + (chunk & 1) * NA * ABYTES;
       const char* A_lo = A_hi + ABYTES;
       const char* Bb = Bs + slot * BBYTES;
 #pragma unroll
@@ -532,12 +556,12 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
           const bf16x8 ah = *(const bf16x8*)(A_hi + addr);
 #pragma unroll
           for (int nf = 0; nf < NF; ++nf)
-            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bfr[nf], acc[mf][nf], 0, 0, 0);
+            acc[mf][nf] = mfma16<PREC>(ah, bfr[nf], acc[mf][nf]);
           if (PREC == 2) {
             const bf16x8 alo = *(const bf16x8*)(A_lo + addr);
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf)
-              acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bfr[nf], acc[mf][nf], 0, 0, 0);
+              acc[mf][nf] = mfma16<PREC>(alo, bfr[nf], acc[mf][nf]);
           }
         }
       }
@@ -555,7 +579,7 @@ template <int PREC>
 int launch_ws(const mi355_conv_gemm_args& a, hipStream_t st) {
   const int R = 128 + (a.K - 1) * a.dil;
   MI355_REQUIRE(R <= 32 * kWsNld, "conv_gemm(ws): window of %d rows exceeds %d (K=%d dil=%d)", R, 32 * kWsNld, a.K, a.dil);
-  const size_t lds = (size_t)2 * PREC * R * 64 + 3 * 4 * 2048;
+  const size_t lds = (size_t)2 * a_images<PREC>() * R * 64 + 3 * 4 * 2048;
   static bool attr_set = false;  // benign race: the attribute is idempotent
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_ws_kernel<PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
@@ -576,7 +600,7 @@ int launch_ws(const mi355_conv_gemm_args& a, hipStream_t st) {
 template <int BM, int BN, int PREC, bool VEC>
 int launch(const mi355_conv_gemm_args& a, hipStream_t st) {
   const int R = BM + (a.K - 1) * a.dil;
-  const size_t lds = (size_t)R * 64 * PREC + 2 * (BN / 32) * 2048;
+  const size_t lds = (size_t)R * 64 * a_images<PREC>() + 2 * (BN / 32) * 2048;
   MI355_REQUIRE(lds <= 64 * 1024, "conv_gemm: window too large for LDS (K=%d dil=%d)", a.K, a.dil);
   dim3 grid((a.Lout + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.B);
   MI355_CLEAR_ERROR();
@@ -601,7 +625,7 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
   MI355_REQUIRE(!a.up_s || (a.up_cout > 0 && a.Cout % a.up_cout == 0 && a.Cout / a.up_cout == a.up_s),
                 "conv_gemm: polyphase store needs Cout == up_s*up_cout");
   if (a.precision == 0) a.precision = 2;
-  MI355_REQUIRE(a.precision == 1 || a.precision == 2, "conv_gemm: precision must be 1 or 2");
+  MI355_REQUIRE(a.precision >= 1 && a.precision <= 3, "conv_gemm: precision must be 1, 2 or 3");
   if (a.out_scale == 0.f) a.out_scale = 1.f;
   hipStream_t st = (hipStream_t)stream;
   const bool vec = (a.flat_valid == 0) && (a.ldx % 4 == 0) && (a.x_off % 4 == 0) && (a.x_bstride % 4 == 0) &&
@@ -620,10 +644,11 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
   }
   if (tile == 8128128) {
     MI355_REQUIRE(ws_ok, "conv_gemm: the wave-specialised tile needs a 16-B aligned channels-last input and (K-1)*dil <= 64");
-    return a.precision == 2 ? launch_ws<2>(a, st) : launch_ws<1>(a, st);
+    return a.precision == 2 ? launch_ws<2>(a, st) : (a.precision == 3 ? launch_ws<3>(a, st) : launch_ws<1>(a, st));
   }
   if (!vec) {
-    a.precision = 2;  // the unaligned (tiny C_in) path always runs the hi+lo split
+    if (a.precision == 3) return launch<64, 64, 3, false>(a, st);
+    a.precision = 2;  // with bf16 weights the unaligned (tiny C_in) path always runs the hi+lo split
     return launch<64, 64, 2, false>(a, st);
   }
   if (a.precision == 2) {
@@ -631,6 +656,12 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
       case 128128: return launch<128, 128, 2, true>(a, st);
       case 64128: return launch<64, 128, 2, true>(a, st);
       case 64064: return launch<64, 64, 2, true>(a, st);
+    }
+  } else if (a.precision == 3) {
+    switch (tile) {
+      case 128128: return launch<128, 128, 3, true>(a, st);
+      case 64128: return launch<64, 128, 3, true>(a, st);
+      case 64064: return launch<64, 64, 3, true>(a, st);
     }
   } else {
     switch (tile) {

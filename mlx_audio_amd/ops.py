@@ -58,9 +58,10 @@ class PackedConv:
     cout: int
     k: int
     cin: int
+    f16: bool = False  # packed as fp16 for the single-pass fp16 MFMA mode (precision 3)
 
 
-def pack_conv(w: torch.Tensor, bias: Optional[torch.Tensor], device) -> PackedConv:
+def pack_conv(w: torch.Tensor, bias: Optional[torch.Tensor], device, f16: bool = False) -> PackedConv:
     """``w``: float32 CPU tensor ``[Cout, K, Cin]`` (MLX conv layout) or ``[Cout, Cin]`` (linear)."""
     if w.dim() == 2:
         w = w[:, None, :]
@@ -69,19 +70,19 @@ def pack_conv(w: torch.Tensor, bias: Optional[torch.Tensor], device) -> PackedCo
     lib = _lib.load()
     n = lib.mi355_packed_conv_weight_elems(cout, k, cin)
     out = np.empty(n, dtype=np.uint16)
-    rc = lib.mi355_pack_conv_weight_host(w.numpy().ctypes.data, cout, k, cin, out.ctypes.data)
-    _lib.check(rc, "mi355_pack_conv_weight_host")
+    rc = lib.mi355_pack_conv_weight_host_dt(w.numpy().ctypes.data, cout, k, cin, 1 if f16 else 0, out.ctypes.data)
+    _lib.check(rc, "mi355_pack_conv_weight_host_dt")
     wd = torch.from_numpy(out.view(np.int16)).to(device)
     bd = None if bias is None else bias.detach().to(torch.float32).contiguous().to(device)
-    return PackedConv(wd, bd, cout, k, cin)
+    return PackedConv(wd, bd, cout, k, cin, f16)
 
 
-def pack_conv_transpose(w_t: torch.Tensor, bias: Optional[torch.Tensor], stride: int, device) -> PackedConv:
+def pack_conv_transpose(w_t: torch.Tensor, bias: Optional[torch.Tensor], stride: int, device, f16: bool = False) -> PackedConv:
     """Polyphase repack of a transposed conv.  ``w_t``: ``[Cout, K, Cin]`` as ``mx.conv_transpose1d``
     takes it (out[n] += x[t] * w_t[:, k, :] for n = t*stride + k - pad); K must be a multiple of
     stride.  Returns the equivalent stride-1 conv with K/stride taps and ``stride*Cout`` outputs:
     GEMM row u, column r*Cout+co  ->  out[u*stride + r - pad, co]."""
-    return pack_conv(_polyphase_weight(w_t.to(torch.float32), stride), bias, device)
+    return pack_conv(_polyphase_weight(w_t.to(torch.float32), stride), bias, device, f16)
 
 
 def _polyphase_weight(w_t: torch.Tensor, stride: int) -> torch.Tensor:
@@ -120,6 +121,10 @@ def conv_gemm(x: torch.Tensor, pc: PackedConv, y: torch.Tensor, *, dil: int = 1,
     B, Lin, Cx, xbs, ldx = _nlc(x)
     By, Ly, Cy, ybs, ldy = _nlc(y)
     assert B == By
+    if pc.f16:
+        precision = 3  # the weight image decides: fp16-packed weights only fit the fp16 MFMA path
+    elif precision == 3:
+        raise _lib.Mi355Error("conv_gemm: precision 3 needs weights packed with f16=True")
     kw = dict(x=_ptr(x), x_bstride=xbs, ldx=ldx, x_off=0, Cin=pc.cin, Lin=Lin, lens_in=_ptr(lens_in), flat_valid=0,
               w=_ptr(pc.w), Cout=pc.cout, K=pc.k, dil=dil, pad=pad, pre_act=pre_act, pre_slope=pre_slope,
               pre_alpha=_ptr(pre_alpha), bias=_ptr(pc.bias) if use_bias else None, post_act=post_act,

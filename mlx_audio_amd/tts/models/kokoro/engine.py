@@ -139,7 +139,13 @@ class KokoroEngine:
 
     def _convw(self, pre, bias=True) -> PackedConv:
         b = self._q(self._t(f"{pre}.bias")) if bias and f"{pre}.bias" in self.w else None
-        return ops.pack_conv(self._wn(pre), b, self.dev)
+        return ops.pack_conv(self._wn(pre), b, self.dev, f16=self._f16(pre))
+
+    def _f16(self, pre: str) -> bool:
+        """precision 3: the decoder / generator convs (97 % of the FLOPs) run the single-pass fp16 MFMA; the front end
+        (PL-BERT, prosody predictor, text encoder: the bit-exact duration path and the F0 curve the harmonic source
+        integrates) stays on the bf16 hi+lo split."""
+        return self.precision == 3 and pre.startswith("decoder.")
 
     def _dvec(self, t: torch.Tensor, pad_to: int = 0) -> torch.Tensor:
         t = self._q(t.reshape(-1).float())
@@ -233,10 +239,10 @@ class KokoroEngine:
             cout = c0 // (2 ** (i + 1))
             # stored (Cin, K, Cout); mx.conv_transpose1d receives weight.T = (Cout, K, Cin) (istftnet.py:161-166)
             w_t = self._wn(f"{g}.ups.{i}").permute(2, 1, 0).contiguous()
-            self.ups.append(ops.pack_conv_transpose(w_t, self._q(self._t(f"{g}.ups.{i}.bias")), u, d))
+            self.ups.append(ops.pack_conv_transpose(w_t, self._q(self._t(f"{g}.ups.{i}.bias")), u, d, f16=self.precision == 3))
             ncw = self._q(self._t(f"{g}.noise_convs.{i}.weight"))  # (cout, K, n_fft+2)
             ncb = self._q(self._t(f"{g}.noise_convs.{i}.bias"))
-            self.noise_convs.append(ops.pack_conv(ncw.reshape(ncw.shape[0], 1, -1), ncb, d))
+            self.noise_convs.append(ops.pack_conv(ncw.reshape(ncw.shape[0], 1, -1), ncb, d))  # raw phase features: keep hi+lo
             last = i + 1 == len(self.rates)
             self.noise_res.append(self._resblock1(self.bank_dec, f"{g}.noise_res.{i}", cout, 11 if last else 7, (1, 3, 5)))
             for j in range(nk):
@@ -257,7 +263,7 @@ class KokoroEngine:
         return gb_all[:, a.off: a.off + 2 * a.c]
 
     def _conv(self, x, pc, y, **kw):
-        kw.setdefault("precision", self.precision)
+        kw.setdefault("precision", 2 if self.precision == 3 else self.precision)  # fp16-packed weights select 3 themselves
         return ops.conv_gemm(x, pc, y, **kw)
 
     def _bilstm(self, l: _LSTM, x, out, lens):

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.mi355_abi_version() == 1
+    assert lib.mi355_abi_version() == 2
     # and nothing torch-typed crosses the boundary: the header is plain C
     r = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Werror", "-x", "c", HEADER], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -142,3 +142,23 @@ def test_lstm_weight_packing(lib):
         want = _bf16(w).reshape(4 * H, H // 8, 8).transpose(1, 0, 2)
         assert np.array_equal(out[d], want)
     assert lib.mi355_pack_lstm_wh_host(wf.ctypes.data, wb.ctypes.data, 12, out.ctypes.data) == -1  # H % 8 != 0
+
+
+def test_pack_conv_weight_fp16_rounding(lib):
+    """MI355_W_F16 packing: IEEE round-to-nearest-even incl. subnormals (== torch's conversion), saturating at 65504."""
+    rng = np.random.default_rng(7)
+    cout, k, cin = 32, 1, 32
+    mags = np.concatenate([rng.standard_normal(512), rng.standard_normal(256) * 1e-5, rng.standard_normal(128) * 1e-7,
+                           np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e9, -1e9, 2.0 ** -24, 2.0 ** -25, 1.5 * 2.0 ** -25,
+                                     6.1035e-5, 6.0976e-5]), rng.standard_normal(116) * 3e3]).astype(np.float32)
+    w = mags.reshape(cout, k, cin)
+    out = np.empty(lib.mi355_packed_conv_weight_elems(cout, k, cin), dtype=np.uint16)
+    assert lib.mi355_pack_conv_weight_host_dt(w.ctypes.data, cout, k, cin, 1, out.ctypes.data) == 0
+    out = out.reshape(1, 1, 4, 2, 64, 8)
+    want = torch.from_numpy(np.clip(w, -65504.0, 65504.0)).to(torch.float16).view(torch.int16).numpy().view(np.uint16)
+    # values in (65504, 65520) round DOWN to 65504 in IEEE too; >= 65520 would be inf: we saturate instead
+    for n in range(cout):
+        for c in range(cin):
+            nt, lane_lo, kk, hi, j = n // 32, n % 32, c // 16, (c % 16) // 8, c % 8
+            assert out[0, 0, nt, kk, hi * 32 + lane_lo, j] == want[n, 0, c], (w[n, 0, c], hex(out[0, 0, nt, kk, hi * 32 + lane_lo, j]), hex(want[n, 0, c]))
+    assert lib.mi355_pack_conv_weight_host_dt(w.ctypes.data, cout, k, cin, 7, out.ctypes.data) == -1

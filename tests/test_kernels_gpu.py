@@ -73,10 +73,13 @@ def test_conv_gemm_plain(ops, cin, cout, k, dil, L, B, tile):
     pc = ops.pack_conv(w, bias, DEV)
     xd = x.to(DEV)
     y = torch.full((B, L, ops.round_up(cout, 4)), float("nan"), device=DEV)
-    for prec, tol in ((2, 3e-5), (1, 1.5e-2)):
-        ops.conv_gemm(xd[:, :, :cin], pc, y[:, :, :cout], dil=dil, pad=pad, precision=prec, tile=tile)
+    pc16 = ops.pack_conv(w, bias, DEV, f16=True)
+    ref = ref_conv_nlc(x[:, :, :cin], w, bias, dil, pad)
+    # 2: bf16 hi+lo split (~2^-16), 1: single bf16 pass (~2^-8), 3: single fp16 pass (~2^-11; fp16-packed weights)
+    for prec, tol, p in ((2, 3e-5, pc), (1, 1.5e-2, pc), (3, 2e-3, pc16)):
+        y.fill_(float("nan"))
+        ops.conv_gemm(xd[:, :, :cin], p, y[:, :, :cout], dil=dil, pad=pad, precision=prec, tile=tile)
         torch.cuda.synchronize()
-        ref = ref_conv_nlc(x[:, :, :cin], w, bias, dil, pad)
         got = y[:, :, :cout].cpu()
         assert torch.isfinite(got).all()
         assert rel_err(got, ref) < tol, (prec, rel_err(got, ref))

@@ -181,3 +181,35 @@ def test_kokoro_single_pass_bf16_precision_mode(setup):
     snr = snr_db(outs[0].cpu(), audio_ref[0])
     print(f"kokoro precision=1 (single bf16 pass), teacher-forced vocoder: snr={snr:.1f} dB")
     assert snr >= 25.0
+
+
+def test_kokoro_fp16_single_pass_precision_mode(setup):
+    """precision=3: decoder / generator convs as ONE fp16 MFMA pass (activations rounded to fp16, bf16-valued weights
+    held in fp16, fp32 accumulation); the front end stays on the hi+lo split, so the integer path is untouched.
+    Must meet the same waveform bar as the default mode on the canonical sentence: max-abs <= 2e-3 * peak, SNR >= 50 dB."""
+    S, eng, ref = setup
+    from mlx_audio_amd.tts.models.kokoro.engine import KokoroEngine
+
+    eng3 = KokoroEngine(S.make_kokoro_weights(), S.KOKORO_CONFIG, precision=3)
+    # free-running front end: identical integer path and F0 / N curves as the default engine
+    ids = S.make_phoneme_ids(18, seed=5)
+    ref_s = S.make_voice_pack()[len(ids) - 3]
+    _, d3, t3 = eng3.forward([ids], ref_s, speed=1.3, return_intermediates=True)
+    _, d2, t2 = eng.forward([ids], ref_s, speed=1.3, return_intermediates=True)
+    torch.cuda.synchronize()
+    assert torch.equal(d3[0], d2[0]) and torch.equal(t3["f0"], t2["f0"]) and torch.equal(t3["n"], t2["n"])
+    # canonical sentence, vocoder teacher-forced on the oracle's features
+    ids = S.make_phoneme_ids(78)
+    ref_s = S.make_voice_pack()[len(ids) - 3]
+    fd = S.forced_durations(80, 264)
+    ri, nz = _noise(264, 1234)
+    audio_ref, _, tr = ref.forward(ids, ref_s, pred_dur=fd, rand_ini=ri, noise=nz, return_intermediates=True)
+    outs, _ = eng3.forward([ids], ref_s, forced_durations=[fd], rand_ini=torch.from_numpy(ri), noise=torch.from_numpy(nz),
+                           overrides=_teacher(tr))
+    torch.cuda.synchronize()
+    got = outs[0].cpu()
+    peak = float(audio_ref.abs().max())
+    err = float((got - audio_ref[0]).abs().max())
+    snr = snr_db(got, audio_ref[0])
+    print(f"kokoro precision=3 (fp16 single pass, canonical sentence): peak={peak:.3f} max_abs_err={err:.3e} snr={snr:.1f} dB")
+    assert err <= 2e-3 * max(peak, 1.0) and snr >= 50.0, (err, snr)
