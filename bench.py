@@ -36,7 +36,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
-    ap.add_argument("--precision", type=int, default=2, help="2 = bf16 hi+lo split MFMA (fp32-grade), 1 = single bf16 pass")
+    ap.add_argument("--precision", type=int, default=2,
+                    help="2 = bf16 hi+lo split MFMA (fp32-grade), 3 = single fp16 pass in the vocoder, 1 = single bf16 pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--shape-table", default="", help="write the per-shape conv_gemm timing table (roofline leg) to this file")
@@ -99,27 +100,32 @@ def main():
     from mlx_audio_amd.tts.models.kokoro import synthetic as S
     from mlx_audio_amd.tts.models.kokoro.engine import KokoroEngine
 
+    from mlx_audio_amd import shard
+
     eng = KokoroEngine(S.make_kokoro_weights(), S.KOKORO_CONFIG, device=dev, precision=args.precision)
     B = args.batch
-    ids, ref_s, fds, rand_ini, noise = make_inputs(S, B, rank, dev)
-    ids_dev = torch.stack(ids).to(torch.int32).to(dev)
+    n_total = B * world
+    # per-utterance inputs of THIS rank's shard are resident in HBM before the timed region; only the request batch
+    # (token ids, owned by rank 0) and the waveforms cross ranks inside the step
+    requests = [S.make_phoneme_ids(T_TOKENS - 2, seed=i) for i in range(n_total)] if rank == 0 else None
+    _, lens0 = shard.broadcast_requests(requests, dev, dist)
+    mine = shard.my_shard(lens0, dist)            # LPT over token counts: B utterances per rank here
+    assert len(mine) == B, (len(mine), B)
+    voice = S.make_voice_pack()
+    ref_s = torch.cat([voice[T_TOKENS - 3] for _ in mine], 0).to(dev)
+    fds = [S.forced_durations(T_TOKENS, F_FRAMES, seed=i) for i in mine]
+    rng = np.random.default_rng(1234 + rank)
+    rand_ini = torch.from_numpy(rng.uniform(size=(B, 9)).astype(np.float32)).to(dev)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    noise = torch.randn((B, 2 * F_FRAMES * 300, 9), generator=g, device=dev, dtype=torch.float32)
 
     def step():
-        if world > 1:
-            # utterance sharding: rank 0 owns the request batch -> broadcast ids, compute the local shard,
-            # gather waveforms on rank 0 (RCCL over xGMI; the only collectives of the path)
-            allids = torch.empty((world, B, T_TOKENS), dtype=torch.int32, device=dev)
-            if rank == 0:
-                allids[:] = ids_dev
-            dist.broadcast(allids, 0)
-            mine = [allids[rank, i].long() for i in range(B)]
-        else:
-            mine = ids
-        outs, _ = eng.forward(mine, ref_s, forced_durations=fds, rand_ini=rand_ini, noise=noise)
-        if world > 1:
-            a = torch.stack(outs)
-            gl = [torch.empty_like(a) for _ in range(world)] if rank == 0 else None
-            dist.gather(a, gl, dst=0)
+        # utterance sharding (mlx_audio_amd/shard.py): broadcast of the padded token batch from rank 0, local synthesis
+        # of this rank's shard, gather of the waveforms on rank 0 -- over RCCL / xGMI when world > 1
+        ids_pad, lens = shard.broadcast_requests(requests, dev, dist)
+        local = [ids_pad[i, : T_TOKENS].long() for i in mine]
+        outs, _ = eng.forward(local, ref_s, forced_durations=fds, rand_ini=rand_ini, noise=noise)
+        shard.gather_waveforms(outs, mine, n_total, dev, dist)
         return outs
 
     for _ in range(args.warmup):
@@ -151,7 +157,9 @@ def main():
             "metric": "audio samples/sec + real-time factor, Kokoro-82M TTS", "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 weights x fp32 activations (bf16 hi+lo split MFMA, fp32 accumulate)" if args.precision == 2 else "bf16",
+            "dtype": {2: "bf16 weights x fp32 activations (bf16 hi+lo split MFMA, fp32 accumulate)",
+                      3: "fp16 activations x bf16-valued weights in fp16 (single MFMA pass, fp32 accumulate) in the vocoder; hi+lo front end",
+                      1: "bf16"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "Kokoro-82M bf16 TTS, tokens->waveform, canonical short sentence T=80 F=264 (6.6 s @ 24 kHz)",
                        "utterances_per_gpu": B, "global_batch": B * world, "samples_per_utterance": SAMPLES_PER_UTT,

@@ -339,10 +339,13 @@ class KokoroEngine:
         Tm = max(Ts)
         assert Tm <= self.pb["max_position_embeddings"], (Tm, self.pb["max_position_embeddings"])
         ragged = B > 1
-        ids = torch.zeros((B, Tm), dtype=torch.int32)
-        for b, t in enumerate(input_ids):
-            ids[b, : Ts[b]] = t.to(torch.int32)
-        ids = ids.to(dev)
+        if all(t.is_cuda for t in input_ids):  # already resident (sharded serving path): pad on the device, no host sync
+            ids = torch.nn.utils.rnn.pad_sequence([t.to(device=dev, dtype=torch.int32) for t in input_ids], batch_first=True)
+        else:
+            ids = torch.zeros((B, Tm), dtype=torch.int32)
+            for b, t in enumerate(input_ids):
+                ids[b, : Ts[b]] = t.to(torch.int32)
+            ids = ids.to(dev)
         lens_t = torch.tensor(Ts, dtype=torch.int32, device=dev) if ragged else None
         ref_s = ref_s.to(device=dev, dtype=torch.float32).contiguous()
         s_dec = ref_s[:, :sty].contiguous()
