@@ -57,26 +57,36 @@ def make_inputs(S, B, seed, dev):
 
 
 def cpu_baseline(S):
-    """The oracle (restated reference, PyTorch-CPU fp32) on this host's cores: one canonical utterance."""
+    """The oracle (restated reference, PyTorch-CPU fp32) on this host's cores, bounded to ~10-30 s of CPU work:
+    the canonical utterance if one pass takes < 8 s on this host, else a quarter-length one (F = 66)."""
     from oracle.kokoro_ref import KokoroRef
 
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 32))  # intra-op threads beyond ~32 only add synchronisation cost for these conv sizes
     torch.set_num_threads(cores)
     ref = KokoroRef(S.make_kokoro_weights(), S.KOKORO_CONFIG)
     ids = S.make_phoneme_ids(T_TOKENS - 2, seed=0)
     ref_s = S.make_voice_pack()[T_TOKENS - 3]
-    fd = S.forced_durations(T_TOKENS, F_FRAMES, seed=0)
-    ref.forward(ids, ref_s, pred_dur=fd)  # warm-up
-    times = []
-    for _ in range(3):
+
+    def run(frames):
+        fd = S.forced_durations(T_TOKENS, frames, seed=0)
         t0 = time.perf_counter()
         ref.forward(ids, ref_s, pred_dur=fd)
-        times.append(time.perf_counter() - t0)
-    med = sorted(times)[len(times) // 2]
-    return {"value": SAMPLES_PER_UTT / med, "unit": "samples/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": "1 utterance (T=80, F=264, 158400 samples), 1 warm-up + median of 3; restated reference "
-                      "(oracle/kokoro_ref.py, PyTorch-CPU fp32), not MLX",
-            "x_realtime": SAMPLES_PER_UTT / 24000.0 / med}
+        return time.perf_counter() - t0
+
+    probe = run(T_TOKENS)  # F = T = 80: also the warm-up
+    frames = F_FRAMES if probe * F_FRAMES / T_TOKENS < 8.0 else 66
+    reps = 3 if probe * frames / T_TOKENS < 4.0 else 1
+    times = sorted(run(frames) for _ in range(reps))
+    med = times[len(times) // 2]
+    samples = frames * 600
+    return {"value": samples / med, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"1 utterance (T=80, F={frames}, {samples} samples), 1 warm-up (F=80) + median of {reps}; restated "
+                      "reference (oracle/kokoro_ref.py, PyTorch-CPU fp32), not MLX",
+            "x_realtime": samples / 24000.0 / med, "host_cores_available": avail}
 
 
 def main():

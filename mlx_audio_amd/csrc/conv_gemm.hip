@@ -272,18 +272,25 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_ge
 // Wave-specialised variant for the large resblock convs (the bulk of the vocoder's MACs).
 //
 // 512 threads = 8 waves per workgroup, one 128 x 128 output tile:
-//   waves 0-3  CONSUMERS: 2 x 2 over the tile, ds_read_b128 fragments + MFMA only, then the epilogue;
-//   waves 4-7  PRODUCERS: all memory traffic and all VALU prologue math --
-//                * weight slices L2 -> LDS with global_load_lds, TWO steps ahead (3-slot ring, counted vmcnt);
-//                * the activation window of the NEXT 32-channel chunk: 6 x float4 per lane issued at the first
-//                  tap of the current chunk, converted (AdaIN affine, Snake / LeakyReLU, bf16 hi+lo split) and
-//                  written into the other A buffer one tap later, while the consumers keep the matrix cores busy.
+//   waves 0-3  CONSUMERS: 2 x 2 over the tile, ds_read_b128 fragments + MFMA, then the epilogue;
+//   waves 4-7  PRODUCERS: the activation window of the NEXT 32-channel chunk -- 6 x float4 per lane issued at the
+//              first tap of the current chunk (addresses clamped, so always exactly 6 loads), then AdaIN affine,
+//              Snake / LeakyReLU, bf16 hi+lo (or fp16) conversion into the other LDS buffer at the last tap(s), while
+//              the consumers keep the matrix cores busy.
 // Each SIMD hosts one consumer and one producer wave per workgroup (MFMA and VALU pipes run concurrently); two
 // workgroups fit per CU (<= 74 KB LDS, <= 128 VGPR), so one workgroup's epilogue / pipeline fill overlaps the
-// other's MFMAs.  One s_barrier per (chunk, tap) step; raw barriers + counted vmcnt so that loads in flight are
-// never drained.  The residual / running-sum operands of the epilogue are folded into the accumulator
-// initialisation (their HBM latency hides under the first chunk), and the 1-D grid is remapped so that the
-// N-tiles sharing one activation window land on the same XCD (same L2).
+// other's MFMAs.  One raw s_barrier per (chunk, tap) step; weight slices stream L2 -> LDS with global_load_lds two
+// steps ahead through a 3-slot ring behind COUNTED s_waitcnt vmcnt (never a drain):
+//   V2 = false: the producers issue the weight DMA (their vmcnt queue then also holds the activation loads, and
+//               in-order completion makes every weight wait a wait for older activation loads);
+//   V2 = true:  the consumers issue it -- each wave its quarter of the slice, two DMA instructions hidden in the
+//               MFMA shadow -- so the two queues are independent: weights wait on weights only (vmcnt(2)), and the
+//               producers' activation loads fly for K-2 steps before the compiler-counted wait in front of convert.
+// `rot`: workgroups walk the (chunk, tap) steps from different starting points (a rotation by the tile index within
+// its XCD).  Every tile of a layer reads the SAME weight slices; in lockstep that hammers two L2 channels at a
+// time, rotated it spreads over all of them.  (Sums commute: only the fp32 summation order differs per tile.)
+// The residual / running-sum operands of the epilogue are folded into the accumulator initialisation, and the 1-D
+// grid is remapped so that the N-tiles sharing one activation window land on the same XCD (same L2).
 // =====================================================================================================
 constexpr int kWsThreads = 512;
 constexpr int kWsNld = 6;  // A-window passes of 32 rows per chunk: R <= 192
@@ -302,11 +309,12 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
-template <int PREC>
+template <int PREC, bool V2>
 __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355_conv_gemm_args a, const int tiles_per_item,
-                                                                    const int P, const int NT, const int fold) {
+                                                                    const int P, const int NT, const int fold, const int rot) {
   constexpr int BM = 128, BN = 128, WM = 64, WN = 64, MF = 2, NF = 2;
   constexpr int BBYTES = (BN / 32) * 2048;
+  constexpr int NA = a_images<PREC>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -326,12 +334,28 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
   const int K = a.K, dil = a.dil;
   const int R = BM + (K - 1) * dil;
   const int ABYTES = R * 64;
-  char* Abase = smem;                     // [2 buffers][PREC (hi, lo)][R * 64]
-  constexpr int NA = a_images<PREC>();
-  char* Bs = smem + 2 * NA * ABYTES;      // [3 slots][BBYTES]
+  char* Abase = smem;                   // [2 buffers][NA (hi, lo)][R * 64]
+  char* Bs = smem + 2 * NA * ABYTES;    // [3 slots][BBYTES]
   const int nchunks = (a.Cin + 31) >> 5;
   const int NTp = ((a.Cout + 127) >> 7) << 2;
   const int nsteps = nchunks * K;
+  // walk order: iteration (ci, tj) works on chunk (c0 + ci) % nchunks, tap (t0 + tj) % K
+  const int qx = kq / NT;  // index of this row tile among its XCD's tiles
+  const int c0 = rot ? qx % nchunks : 0;
+  const int t0 = rot ? (qx / nchunks) % K : 0;
+  auto chunk_at = [&](int ci) { const int c = c0 + ci; return c >= nchunks ? c - nchunks : c; };
+  auto tap_at = [&](int tj) { const int t = t0 + tj; return t >= K ? t - K : t; };
+
+  // this wave's share of the weight slice of iteration (ci, tj): `part` in 0..3, two 1-KB DMA pieces
+  auto issue_B = [&](int ci, int tj, int slot, int part) {
+    const int slice = chunk_at(ci) * K + tap_at(tj);
+    const char* src = (const char*)a.w + ((int64_t)slice * NTp + (n0 >> 5)) * 2048;
+#pragma unroll
+    for (int i = 0; i < BN / 64; ++i) {
+      const int off = (i * 4 + part) * 1024;
+      glds16(src + off + lane * 16, Bs + slot * BBYTES + off);
+    }
+  };
 
   if (wave >= 4) {
     // ------------------------------------------------------------------------------ producers
@@ -342,16 +366,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
     const float* xb = a.x + (int64_t)b * a.x_bstride + a.x_off;
     float4 areg[kWsNld];
 
-    auto issue_B = [&](int step, int slot) {
-      const char* src = (const char*)a.w + ((int64_t)step * NTp + (n0 >> 5)) * 2048;
-#pragma unroll
-      for (int i = 0; i < BN / 64; ++i) {
-        const int off = (i * 4 + pw) * 1024;
-        glds16(src + off + lane * 16, Bs + slot * BBYTES + off);
-      }
-    };
-    // always exactly kWsNld vector loads (addresses clamped, masking happens in convert) so that the
-    // counted s_waitcnt below is exact
+    // always exactly kWsNld vector loads (addresses clamped, masking happens in convert)
     auto loadA = [&](int chunk) {
       int c = chunk * 32 + c4;
       if (c >= a.Cin) c = 0;
@@ -362,7 +377,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
         areg[i] = *(const float4*)(xb + (int64_t)gl * a.ldx + c);
       }
     };
-    auto convertA = [&](int chunk, char* A_hi) {
+    auto convertA = [&](int chunk, char* A_hi, int i_lo, int i_hi) {
       char* A_lo = A_hi + ABYTES;
       const int c = chunk * 32 + c4;
       float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f}, al[4] = {1.f, 1.f, 1.f, 1.f},
@@ -382,7 +397,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
 #pragma unroll
       for (int i = 0; i < kWsNld; ++i) {
         const int r = prow + i * 32;
-        if (r < R) {
+        if (i >= i_lo && i < i_hi && r < R) {
           const int gl = l0 - a.pad + r;
           const bool rowok = gl >= 0 && gl < len_in;
           const float v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
@@ -420,67 +435,96 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
       }
     };
 
-    // Step s = (chunk, tap).  During step s the producers issue weight slice s+2, at tap 0 the loads of the next
-    // chunk's window, at tap 1 its conversion.  At the end of the step slice s+1 must have landed (counted wait:
-    // what was issued after it may stay in flight), then the barrier hands step s+1 to the consumers.
-    // The loop nest is written per chunk, straight-line over taps 0 / 1 / rest, so that no vector load is pending
-    // across a back edge (otherwise hipcc drains vmcnt(0) in front of the next loads).
-    auto end_step = [&](int s, int pend) {
-      if (s + 1 < nsteps) {
-        if (pend == 0) wait_vmcnt<0>();
-        else if (pend == 2) wait_vmcnt<2>();
-        else if (pend == kWsNld) wait_vmcnt<6>();
-        else wait_vmcnt<8>();
-        lds_barrier();
-      }
-    };
-    int slot = 2;
-    auto prefetch_B = [&](int s) -> int {
-      int pend = 0;
-      if (s + 2 < nsteps) {
-        issue_B(s + 2, slot);
-        pend = 2;
-      }
-      slot = slot == 2 ? 0 : slot + 1;
-      asm volatile("" ::: "memory");
-      return pend;
-    };
-    issue_B(0, 0);
-    if (nsteps > 1) issue_B(1, 1);
-    loadA(0);
-    convertA(0, Abase);
-    wait_vmcnt<0>();
-    lds_barrier();  // barrier #0: step 0 (and weight slice 1) staged
-    int s = 0;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-      const bool nxt = chunk + 1 < nchunks;
-      char* A_next = Abase + ((chunk + 1) & 1) * NA * ABYTES;
-      if (K == 1) {
-        const int pend = prefetch_B(s);
-        if (nxt) {
-          loadA(chunk + 1);
-          convertA(chunk + 1, A_next);
+    if constexpr (V2) {
+      // activation windows only; the compiler counts these loads itself (no DMA in this queue)
+      loadA(chunk_at(0));
+      convertA(chunk_at(0), Abase, 0, kWsNld);
+      lds_barrier();  // barrier #0
+      const int tcA = K >= 4 ? K - 2 : K - 1, tcB = K - 1;  // taps at which the two halves of the next window are converted
+      int s = 0;
+      for (int ci = 0; ci < nchunks; ++ci) {
+        const bool nxt = ci + 1 < nchunks;
+        const int cn = chunk_at(nxt ? ci + 1 : ci);
+        char* A_next = Abase + ((ci + 1) & 1) * NA * ABYTES;
+        for (int tj = 0; tj < K; ++tj) {
+          if (nxt) {
+            if (tj == 0) loadA(cn);
+            if (tcA == tcB) {
+              if (tj == tcB) convertA(cn, A_next, 0, kWsNld);
+            } else {
+              if (tj == tcA) convertA(cn, A_next, 0, kWsNld / 2);
+              if (tj == tcB) convertA(cn, A_next, kWsNld / 2, kWsNld);
+            }
+          }
+          if (s + 1 < nsteps) lds_barrier();
+          ++s;
         }
-        end_step(s, pend);
-        ++s;
-      } else {
-        int pend = prefetch_B(s);  // tap 0
-        if (nxt) {
-          loadA(chunk + 1);
-          pend += kWsNld;
+      }
+    } else {
+      // Step s = iteration (ci, tj).  During step s the producers issue weight slice s+2, at tap 0 the loads of the
+      // next chunk's window, at tap 1 its conversion.  At the end of the step slice s+1 must have landed (counted
+      // wait: what was issued after it may stay in flight), then the barrier hands step s+1 to the consumers.  The
+      // loop nest is straight-line over taps 0 / 1 / rest so that no vector load is pending across a back edge.
+      auto end_step = [&](int s, int pend) {
+        if (s + 1 < nsteps) {
+          if (pend == 0) wait_vmcnt<0>();
+          else if (pend == 2) wait_vmcnt<2>();
+          else if (pend == kWsNld) wait_vmcnt<6>();
+          else wait_vmcnt<8>();
+          lds_barrier();
         }
+      };
+      int slot = 2;
+      auto prefetch_B = [&](int ci, int tj) -> int {  // weight slice two iterations ahead of (ci, tj)
+        int pend = 0;
+        int cj = ci, tt = tj + 2;
+        while (tt >= K) { tt -= K; ++cj; }
+        if (cj < nchunks) {
+          issue_B(cj, tt, slot, pw);
+          pend = 2;
+        }
+        slot = slot == 2 ? 0 : slot + 1;
         asm volatile("" ::: "memory");
-        end_step(s, pend);
-        ++s;
-        if (nxt) convertA(chunk + 1, A_next);  // tap 1: convert first (its waits would also drain a fresh weight DMA)
-        asm volatile("" ::: "memory");
-        pend = prefetch_B(s);
-        end_step(s, pend);
-        ++s;
-        for (int tap = 2; tap < K; ++tap) {
-          pend = prefetch_B(s);
+        return pend;
+      };
+      issue_B(0, 0, 0, pw);
+      if (nsteps > 1) issue_B(K > 1 ? 0 : 1, K > 1 ? 1 : 0, 1, pw);
+      loadA(chunk_at(0));
+      convertA(chunk_at(0), Abase, 0, kWsNld);
+      wait_vmcnt<0>();
+      lds_barrier();  // barrier #0: step 0 (and weight slice 1) staged
+      int s = 0;
+      for (int ci = 0; ci < nchunks; ++ci) {
+        const bool nxt = ci + 1 < nchunks;
+        const int cn = chunk_at(nxt ? ci + 1 : ci);
+        char* A_next = Abase + ((ci + 1) & 1) * NA * ABYTES;
+        if (K == 1) {
+          const int pend = prefetch_B(ci, 0);
+          if (nxt) {
+            loadA(cn);
+            convertA(cn, A_next, 0, kWsNld);
+          }
           end_step(s, pend);
           ++s;
+        } else {
+          int pend = prefetch_B(ci, 0);  // tap 0
+          if (nxt) {
+            loadA(cn);
+            pend += kWsNld;
+          }
+          asm volatile("" ::: "memory");
+          end_step(s, pend);
+          ++s;
+          if (nxt) convertA(cn, A_next, 0, kWsNld);  // tap 1: convert first (its waits would also drain a fresh weight DMA)
+          asm volatile("" ::: "memory");
+          pend = prefetch_B(ci, 1);
+          end_step(s, pend);
+          ++s;
+          for (int tj = 2; tj < K; ++tj) {
+            pend = prefetch_B(ci, tj);
+            end_step(s, pend);
+            ++s;
+          }
         }
       }
     }
@@ -491,6 +535,10 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
   const int wm = wave >> 1, wn = wave & 1;
   float* yb = a.y + (int64_t)b * a.y_bstride;
   const float* rb = a.res ? a.res + (int64_t)b * a.res_bstride : nullptr;
+  if constexpr (V2) {
+    issue_B(0, 0, 0, wave);
+    if (nsteps > 1) issue_B(K > 1 ? 0 : 1, K > 1 ? 1 : 0, 1, wave);
+  }
   f32x16 acc[MF][NF];
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf)
@@ -534,12 +582,25 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
         }
       }
   }
+  if constexpr (V2) wait_vmcnt<0>();  // weight slices 0 and 1 (and the fold operands) have landed
 
   lds_barrier();  // barrier #0
   {
-    int chunk = 0, tap = 0, slot = 0;
+    int ci = 0, tj = 0, slot = 0, slot2 = 2;
     for (int s = 0; s < nsteps; ++s) {
-      const char* A_hi = Abase + (chunk & 1) * NA * ABYTES;
+      bool issued = false;
+      if constexpr (V2) {
+        int cj = ci, tt = tj + 2;
+        while (tt >= K) { tt -= K; ++cj; }
+        if (cj < nchunks) {
+          issue_B(cj, tt, slot2, wave);  // the slot read during step s-1: every consumer is past barrier #s
+          issued = true;
+        }
+        slot2 = slot2 == 2 ? 0 : slot2 + 1;
+        asm volatile("" ::: "memory");
+      }
+      const int tap = tap_at(tj);
+      const char* A_hi = Abase + (ci & 1) * NA * ABYTES;
       const char* A_lo = A_hi + ABYTES;
       const char* Bb = Bs + slot * BBYTES;
 #pragma unroll
@@ -555,19 +616,23 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
           const int addr = row * 64 + ((cidx ^ ((row >> 2) & 3)) << 4);
           const bf16x8 ah = *(const bf16x8*)(A_hi + addr);
 #pragma unroll
-          for (int nf = 0; nf < NF; ++nf)
-            acc[mf][nf] = mfma16<PREC>(ah, bfr[nf], acc[mf][nf]);
+          for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = mfma16<PREC>(ah, bfr[nf], acc[mf][nf]);
           if (PREC == 2) {
             const bf16x8 alo = *(const bf16x8*)(A_lo + addr);
 #pragma unroll
-            for (int nf = 0; nf < NF; ++nf)
-              acc[mf][nf] = mfma16<PREC>(alo, bfr[nf], acc[mf][nf]);
+            for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = mfma16<PREC>(alo, bfr[nf], acc[mf][nf]);
           }
         }
       }
       slot = slot == 2 ? 0 : slot + 1;
-      if (s + 1 < nsteps) lds_barrier();
-      if (++tap == K) { tap = 0; ++chunk; }
+      if (s + 1 < nsteps) {
+        if constexpr (V2) {  // this wave's pieces of slice s+1 have landed; slice s+2 may stay in flight
+          if (issued) wait_vmcnt<2>();
+          else wait_vmcnt<0>();
+        }
+        lds_barrier();
+      }
+      if (++tj == K) { tj = 0; ++ci; }
     }
   }
 
@@ -575,14 +640,14 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
   conv_epilogue<MF, NF, WM, WN>(a, acc, b, l0, n0, wm, wn, lane, len_out, fold != 0);
 }
 
-template <int PREC>
+template <int PREC, bool V2>
 int launch_ws(const mi355_conv_gemm_args& a, hipStream_t st) {
   const int R = 128 + (a.K - 1) * a.dil;
   MI355_REQUIRE(R <= 32 * kWsNld, "conv_gemm(ws): window of %d rows exceeds %d (K=%d dil=%d)", R, 32 * kWsNld, a.K, a.dil);
   const size_t lds = (size_t)2 * a_images<PREC>() * R * 64 + 3 * 4 * 2048;
   static bool attr_set = false;  // benign race: the attribute is idempotent
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_ws_kernel<PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_ws_kernel<PREC, V2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     MI355_REQUIRE(e == hipSuccess, "conv_gemm(ws): cannot reserve LDS: %s", hipGetErrorString(e));
     attr_set = true;
   }
@@ -590,11 +655,17 @@ int launch_ws(const mi355_conv_gemm_args& a, hipStream_t st) {
   const int P = a.B * tiles_per_item;
   const int NT = (a.Cout + 127) / 128;
   const int fold = (a.res || a.accumulate) && a.post_act == MI355_ACT_NONE && a.up_s == 0 && a.res_shift == 0;
+  static const int rot = getenv("MI355_CONV_NO_ROT") ? 0 : 1;  // A/B aid: lockstep walk order
   const unsigned grid = (unsigned)(((P + 7) / 8) * 8 * NT);
   MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL((conv_gemm_ws_kernel<PREC>), dim3(grid), dim3(kWsThreads), lds, st, a, tiles_per_item, P, NT, fold);
+  hipLaunchKernelGGL((conv_gemm_ws_kernel<PREC, V2>), dim3(grid), dim3(kWsThreads), lds, st, a, tiles_per_item, P, NT, fold, rot);
   MI355_LAUNCH_CHECK("conv_gemm(ws)");
   return MI355_OK;
+}
+
+template <bool V2>
+int launch_ws_prec(const mi355_conv_gemm_args& a, hipStream_t st) {
+  return a.precision == 2 ? launch_ws<2, V2>(a, st) : (a.precision == 3 ? launch_ws<3, V2>(a, st) : launch_ws<1, V2>(a, st));
 }
 
 template <int BM, int BN, int PREC, bool VEC>
@@ -640,11 +711,13 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
     // the wave-specialised kernel once there are enough 128 x 128 tiles to fill the 256 CUs
     // (MI355_CONV_NO_WS=1 in the environment keeps the auto choice on the 4-wave kernels: an A/B and bisecting aid)
     static const bool no_ws = getenv("MI355_CONV_NO_WS") != nullptr;
-    if (!no_ws && ws_ok && bn == 128 && wgs128 >= 256 && a.Cin >= 64) tile = 8128128;
+    static const int ws_tile = (getenv("MI355_CONV_WS_VARIANT") && atoi(getenv("MI355_CONV_WS_VARIANT")) == 8) ? 8128128 : 9128128;
+    if (!no_ws && ws_ok && bn == 128 && wgs128 >= 256 && a.Cin >= 64) tile = ws_tile;
+    else if (bn == 128 && wgs128 >= 512) tile = 64128;  // measured: 64-row tiles beat 128-row tiles on the 4-wave kernel
   }
-  if (tile == 8128128) {
+  if (tile == 8128128 || tile == 9128128) {  // 8...: producers stream the weights; 9...: consumers do (see the kernel header)
     MI355_REQUIRE(ws_ok, "conv_gemm: the wave-specialised tile needs a 16-B aligned channels-last input and (K-1)*dil <= 64");
-    return a.precision == 2 ? launch_ws<2>(a, st) : (a.precision == 3 ? launch_ws<3>(a, st) : launch_ws<1>(a, st));
+    return tile == 9128128 ? launch_ws_prec<true>(a, st) : launch_ws_prec<false>(a, st);
   }
   if (!vec) {
     if (a.precision == 3) return launch<64, 64, 3, false>(a, st);

@@ -36,8 +36,9 @@ def rel_err(a, b):
 
 def ref_conv_nlc(x, w, b, dil, pad):
     """x [B, L, Cin] fp64, w [Cout, K, Cin] -> [B, Lout, Cout] (zero padding `pad` left, symmetric right)."""
-    y = F.conv1d(x.transpose(1, 2).double(), w.permute(0, 2, 1).double(), None if b is None else b.double(),
-                 padding=pad, dilation=dil)
+    k = w.shape[1]
+    xp = F.pad(x.transpose(1, 2).double(), (pad, (k - 1) * dil - pad))  # output length == input length, also for even K
+    y = F.conv1d(xp, w.permute(0, 2, 1).double(), None if b is None else b.double(), dilation=dil)
     return y.transpose(1, 2)
 
 
@@ -62,6 +63,17 @@ def ref_conv_nlc(x, w, b, dil, pad):
     (1090, 300, 3, 1, 145, 1, 8128128),
     (32, 22, 1, 1, 500, 1, 8128128),
     (64, 128, 5, 16, 260, 1, 8128128),
+    # ... and its variant in which the consumer waves stream the weight slices (tile code 9128128)
+    (128, 128, 7, 3, 300, 2, 9128128),
+    (128, 128, 3, 1, 1500, 3, 9128128),
+    (256, 256, 11, 5, 257, 1, 9128128),
+    (128, 128, 11, 1, 129, 1, 9128128),
+    (96, 200, 2, 1, 131, 2, 9128128),
+    (512, 64, 1, 1, 777, 3, 9128128),
+    (1090, 300, 3, 1, 145, 1, 9128128),
+    (32, 22, 1, 1, 500, 1, 9128128),
+    (64, 128, 5, 16, 260, 1, 9128128),
+    (128, 128, 4, 2, 2100, 2, 9128128),
 ])
 def test_conv_gemm_plain(ops, cin, cout, k, dil, L, B, tile):
     g = torch.Generator().manual_seed(cin + cout + k)
@@ -86,7 +98,8 @@ def test_conv_gemm_plain(ops, cin, cout, k, dil, L, B, tile):
 
 
 @pytest.mark.parametrize("tile,res_shift,act", [(0, 1, "snake"), (8128128, 1, "snake"), (8128128, 0, "snake"), (128128, 0, "leaky"),
-                                                 (8128128, 0, "leaky"), (64064, 0, "snake")])
+                                                 (8128128, 0, "leaky"), (64064, 0, "snake"), (9128128, 1, "snake"), (9128128, 0, "snake"),
+                                                 (9128128, 0, "leaky")])
 def test_conv_gemm_fused_prologue_epilogue_ragged(ops, tile, res_shift, act):
     """AdaIN affine + Snake / LeakyReLU in front, bias + residual(row >> res_shift) + scale + accumulate behind, ragged
     batch; res_shift == 0 takes the accumulator-initialisation ("fold") path of the wave-specialised kernel."""
@@ -124,7 +137,8 @@ def test_conv_gemm_fused_prologue_epilogue_ragged(ops, tile, res_shift, act):
 
 
 @pytest.mark.parametrize("cin,cout,k,s,L,row_off,tile", [(512, 256, 20, 10, 53, 0, 0), (256, 128, 12, 6, 130, 1, 0), (64, 32, 4, 2, 9, 0, 0),
-                                                         (512, 256, 20, 10, 153, 0, 8128128), (256, 128, 12, 6, 330, 1, 8128128)])
+                                                         (512, 256, 20, 10, 153, 0, 8128128), (256, 128, 12, 6, 330, 1, 8128128),
+                                                         (512, 256, 20, 10, 153, 0, 9128128), (256, 128, 12, 6, 330, 1, 9128128)])
 def test_conv_transpose_polyphase(ops, cin, cout, k, s, L, row_off, tile):
     g = torch.Generator().manual_seed(k * s)
     p = (k - s) // 2

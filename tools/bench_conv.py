@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--out", default="")
     ap.add_argument("--precision", type=int, default=2)
+    ap.add_argument("--quick", action="store_true", help="two shapes, the wave-specialised variants only (for PMC passes)")
     args = ap.parse_args()
     from mlx_audio_amd import ops
 
@@ -42,13 +43,16 @@ def main():
     shapes.append((256, 256, 11, 5, 5280, "snake"))
     shapes.append((1090, 1024, 3, 1, 264, "leaky"))
     shapes.append((512, 2560, 2, 1, 529, "plain"))
-    variants = [("old128x128", 128128), ("old64x128", 64128), ("ws128x128", 8128128)]
+    variants = [("old128x128", 128128), ("old64x128", 64128), ("ws_prodB", 8128128), ("ws_consB", 9128128)]
+    if args.quick:
+        shapes = [(128, 128, 11, 1, 31681, "snake+res"), (128, 128, 3, 1, 31681, "snake+res")]
+        variants = [("old64x128", 64128), ("ws_prodB", 8128128), ("ws_consB", 9128128)]
     lines = ["cin cout k dil rows fused variant ms tflops_alg GBps_alg maxrel"]
     g = torch.Generator(device=dev).manual_seed(0)
     for cin, cout, k, dil, L, fused in shapes:
         w = (torch.randn(cout, k, cin) / math.sqrt(k * cin)).to(torch.bfloat16).float()
         bias = torch.randn(cout) * 0.1
-        pc = ops.pack_conv(w, bias, dev)
+        pc = ops.pack_conv(w, bias, dev, f16=args.precision == 3)
         ld = ops.round_up(cin, 32)
         x = torch.randn((B, L, ld), generator=g, device=dev)
         y = torch.zeros((B, L, cout), device=dev)
@@ -80,10 +84,11 @@ def main():
                 xr = xr + (1.0 / al) * torch.sin(al * xr) ** 2
             else:
                 xr = F.leaky_relu(xr, 0.2)
-        ref = F.conv1d(xr.transpose(1, 2), w.permute(0, 2, 1).double(), bias.double(), padding=pad, dilation=dil).transpose(1, 2)[0]
+        ref = F.conv1d(F.pad(xr.transpose(1, 2), (pad, (k - 1) * dil - pad)), w.permute(0, 2, 1).double(), bias.double(),
+                       dilation=dil).transpose(1, 2)[0]
         if res is not None:
             ref = ref + res[0, :n].double().cpu()
-        ok_rows = n - pad  # rows whose window stays inside the first n inputs
+        ok_rows = n - (k - 1) * dil  # rows whose window stays inside the first n inputs
         times = {name: [] for name, _ in variants}
         errs = {}
         for name, tile in variants:
