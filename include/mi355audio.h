@@ -102,8 +102,15 @@ typedef struct {
   int32_t B;
   int32_t precision;   /* 2 = bf16 hi+lo split (default; ~16 mantissa bits of the fp32 activation), 1 = single bf16 pass,
                           3 = single fp16 pass: activations rounded to fp16 (saturating), weights packed with MI355_W_F16 */
-  int32_t tile;        /* 0 = auto, else BM*1000+BN (128128, 64128, 64064) */
+  int32_t tile;        /* 0 = auto, else BM*1000+BN (128128, 64128, 64064), 8128128 / 9128128 = wave-specialised 8-wave kernels */
+  /* optional instance-norm statistics of the STORED output, fused into the epilogue (plain stores only): per block of
+     MI355_STATS_ROWS output rows and per channel the pair (sum, sum of squared deviations from the block mean), written
+     (never accumulated) to stats_partial[b][row / MI355_STATS_ROWS][c][0..1]; consumed by mi355_adain_from_partials.
+     Saves the separate read pass of InstanceNorm1d over the tensor this conv just produced (istftnet.py:173-338). */
+  float* stats_partial;   /* nullable; [B, ceil(Lout / MI355_STATS_ROWS), Cout, 2] */
+  int64_t stats_bstride;  /* elements between batch items */
 } mi355_conv_gemm_args;
+#define MI355_STATS_ROWS 64
 
 int mi355_conv_gemm(const mi355_conv_gemm_args* a, void* stream);
 /* Host-side packing (CPU, run once at load time).
@@ -132,6 +139,17 @@ typedef struct {
   float* scale; float* shift; int32_t out_ld; /* [B, out_ld] */
 } mi355_adain_coef_args;
 int mi355_adain_coef(const mi355_adain_coef_args* a, void* stream);
+
+/* AdaIN coefficients from the per-block partial statistics a conv_gemm epilogue wrote (see stats_partial): merges the
+ * blocks in float64 (Chan's parallel-variance formula; block row counts follow from lens / L), then the same
+ * scale = (1+gamma)*rsqrt(var+eps), shift = beta - mean*scale as mi355_adain_coef. */
+typedef struct {
+  const float* partials; int64_t bstride;  /* [B, ceil(L / MI355_STATS_ROWS), C, 2] */
+  int32_t C; int32_t L; const int32_t* lens; int32_t B;
+  const float* gb; int32_t gb_ld; float eps;
+  float* scale; float* shift; int32_t out_ld;
+} mi355_adain_partials_args;
+int mi355_adain_from_partials(const mi355_adain_partials_args* a, void* stream);
 
 /* LayerNorm over the channel axis of rows, optionally fused with a residual add in front and
  * (1+gamma)*xhat+beta / weight*xhat+bias and LeakyReLU behind.

@@ -57,6 +57,12 @@ __device__ __forceinline__ void conv_epilogue(const mi355_conv_gemm_args& a, f32
   float* yb = a.y + (int64_t)b * a.y_bstride;
   const float* rb = (a.res && !folded) ? a.res + (int64_t)b * a.res_bstride : nullptr;
   const bool accum = a.accumulate && !folded;
+  const bool want_stats = a.stats_partial != nullptr;
+  // fused statistics (single pass, shifted by the lane's first stored value K so that s2 - s1^2/n does not cancel)
+  float sK[NF], s1[NF], s2[NF];
+  int scnt[NF];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) { sK[nf] = 0.f; s1[nf] = 0.f; s2[nf] = 0.f; scnt[nf] = 0; }
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
@@ -106,9 +112,41 @@ __device__ __forceinline__ void conv_epilogue(const mi355_conv_gemm_args& a, f32
           else if (a.post_act == MI355_ACT_GELU) v = gelu_erf(v);
           v = (v + rv[q]) * a.out_scale;
           if (ok[q]) yb[(int64_t)orows[q] * a.ldy + ocol] = v;
+          if (want_stats && ok[q]) {
+            sK[nf] = scnt[nf] == 0 ? v : sK[nf];
+            const float d = v - sK[nf];
+            s1[nf] += d;
+            s2[nf] += d * d;
+            ++scnt[nf];
+          }
         }
       }
     }
+  // Fused instance-norm statistics of what was just stored: this wave's WM = 64 rows x 32 columns per nf.  Lanes l and
+  // l + 32 hold the same column (rows interleaved): their (count, mean, M2) triples are merged with Chan's formula after
+  // one xor-32 exchange.  (sum, M2 about the block mean) per column goes to stats_partial[b][row block][n]; the float64
+  // merge over row blocks happens in adain_from_partials.
+  if constexpr (WM == MI355_STATS_ROWS) {
+    if (want_stats && a.up_s == 0) {
+      const int row0 = l0 + wm * WM;
+      if (row0 < len_out) {
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          const int n = n0 + wn * WN + nf * 32 + (lane & 31);
+          const float cl = (float)scnt[nf];
+          const float ml = scnt[nf] ? sK[nf] + s1[nf] / cl : 0.f;
+          const float vl = scnt[nf] ? s2[nf] - s1[nf] * s1[nf] / cl : 0.f;
+          const float cp = __shfl_xor(cl, 32, 64), mp = __shfl_xor(ml, 32, 64), vp = __shfl_xor(vl, 32, 64);
+          const float ct = cl + cp;
+          const float dm = mp - ml;
+          const float sum = ml * cl + mp * cp;
+          const float m2 = vl + vp + (ct > 0.f ? dm * dm * cl * cp / ct : 0.f);
+          if (lane < 32 && n < a.Cout)
+            *(float2*)(a.stats_partial + (int64_t)b * a.stats_bstride + ((int64_t)(row0 / MI355_STATS_ROWS) * a.Cout + n) * 2) = make_float2(sum, m2);
+        }
+      }
+    }
+  }
 }
 
 template <int BM, int BN, int PREC, bool VEC>
@@ -640,6 +678,249 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
   conv_epilogue<MF, NF, WM, WN>(a, acc, b, l0, n0, wm, wn, lane, len_out, fold != 0);
 }
 
+// -----------------------------------------------------------------------------------------------------
+// Third wave-specialised variant (tile code 7128128): ONE barrier per 32-channel chunk instead of one per tap.
+// The per-step barrier existed only because the weight slice went through a shared LDS ring.  Here every consumer
+// wave loads its own B fragments straight from L2 into registers -- a fragment is 1 KB contiguous in the packed
+// image, i.e. one coalesced global_load_dwordx4 per (n-tile, kk) -- one step ahead (plain loads: hipcc counts the
+// vmcnt itself, there is no LDS DMA in this kernel).  LDS holds only the two activation-window buffers; the
+// producers hand a converted window over once per chunk and already have the loads of the window after that in
+// flight.  Between two barriers a consumer wave free-runs K x 16 MFMAs.
+// -----------------------------------------------------------------------------------------------------
+template <int PREC>
+__global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws3_kernel(const mi355_conv_gemm_args a, const int tiles_per_item,
+                                                                     const int P, const int NT, const int fold) {
+  constexpr int BM = 128, BN = 128, WM = 64, WN = 64, MF = 2, NF = 2;
+  constexpr int NA = a_images<PREC>();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int id = blockIdx.x;
+  const int kq = id >> 3;
+  const int ny = kq % NT;
+  const int p = (kq / NT) * 8 + (id & 7);
+  if (p >= P) return;
+  const int b = p / tiles_per_item;
+  const int l0 = (p - b * tiles_per_item) * BM, n0 = ny * BN;
+  const int len_out = a.lens_out ? a.lens_out[b] : a.Lout;
+  if (l0 >= len_out) return;
+  const int len_in = a.lens_in ? a.lens_in[b] : a.Lin;
+  const int K = a.K, dil = a.dil;
+  const int R = BM + (K - 1) * dil;
+  const int ABYTES = R * 64;
+  char* Abase = smem;  // [2 buffers][NA (hi, lo)][R * 64]
+  const int nchunks = (a.Cin + 31) >> 5;
+  const int NTp = ((a.Cout + 127) >> 7) << 2;
+  const int nsteps = nchunks * K;
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------------------ producers
+    const int ptid = tid - 256;
+    const int c4 = (ptid & 7) * 4;
+    const int prow = ptid >> 3;
+    const float* xb = a.x + (int64_t)b * a.x_bstride + a.x_off;
+    float4 areg[kWsNld];
+    auto loadA = [&](int chunk) {
+      int c = chunk * 32 + c4;
+      if (c >= a.Cin) c = 0;
+#pragma unroll
+      for (int i = 0; i < kWsNld; ++i) {
+        int gl = l0 - a.pad + prow + i * 32;
+        gl = gl < 0 ? 0 : (gl >= a.Lin ? a.Lin - 1 : gl);
+        areg[i] = *(const float4*)(xb + (int64_t)gl * a.ldx + c);
+      }
+    };
+    auto convertA = [&](int chunk, char* A_hi) {
+      char* A_lo = A_hi + ABYTES;
+      const int c = chunk * 32 + c4;
+      float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f}, al[4] = {1.f, 1.f, 1.f, 1.f},
+            ial[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.pre_scale) {
+        const float4 s4 = *(const float4*)(a.pre_scale + (int64_t)b * a.pre_ld + c);
+        const float4 h4 = *(const float4*)(a.pre_shift + (int64_t)b * a.pre_ld + c);
+        sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
+        sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
+      }
+      if (a.pre_act == MI355_ACT_SNAKE) {
+        const float4 a4 = *(const float4*)(a.pre_alpha + c);
+        al[0] = a4.x; al[1] = a4.y; al[2] = a4.z; al[3] = a4.w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ial[i] = 1.0f / al[i];
+      }
+#pragma unroll
+      for (int i = 0; i < kWsNld; ++i) {
+        const int r = prow + i * 32;
+        if (r < R) {
+          const int gl = l0 - a.pad + r;
+          const bool rowok = gl >= 0 && gl < len_in;
+          const float v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
+          float hi[4], lo[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float t = v[j] * sc[j] + sh[j];
+            if (a.pre_act == MI355_ACT_LEAKY) t = t > 0.f ? t : t * a.pre_slope;
+            else if (a.pre_act == MI355_ACT_SNAKE) {
+              const float s = __sinf(al[j] * t);
+              t = t + ial[j] * (s * s);
+            }
+            t = (rowok && (c + j) < a.Cin) ? t : 0.f;
+            const float h = PREC == 3 ? t : bf16_bits_to_f32(f32_to_bf16_bits(t));
+            hi[j] = h;
+            lo[j] = t - h;
+          }
+          const int addr = r * 64 + ((((c4 >> 3) ^ ((r >> 2) & 3))) << 4) + ((c4 & 4) << 1);
+          uint2 ph;
+          if constexpr (PREC == 3) {
+            ph.x = pack_f16x2(hi[0], hi[1]);
+            ph.y = pack_f16x2(hi[2], hi[3]);
+          } else {
+            ph.x = pack_bf16x2(hi[0], hi[1]);
+            ph.y = pack_bf16x2(hi[2], hi[3]);
+          }
+          *(uint2*)(A_hi + addr) = ph;
+          if (PREC == 2) {
+            uint2 pl;
+            pl.x = pack_bf16x2(lo[0], lo[1]);
+            pl.y = pack_bf16x2(lo[2], lo[3]);
+            *(uint2*)(A_lo + addr) = pl;
+          }
+        }
+      }
+    };
+    loadA(0);
+    convertA(0, Abase);
+    if (nchunks > 1) loadA(1);
+    lds_barrier();  // barrier #0: window 0 staged, window 1 in flight
+    for (int ci = 0; ci + 1 < nchunks; ++ci) {
+      convertA(ci + 1, Abase + ((ci + 1) & 1) * NA * ABYTES);  // buffer last read during chunk ci-1
+      if (ci + 2 < nchunks) loadA(ci + 2);
+      lds_barrier();  // end of chunk ci
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------------------- consumers
+  const int wm = wave >> 1, wn = wave & 1;
+  float* yb = a.y + (int64_t)b * a.y_bstride;
+  const float* rb = a.res ? a.res + (int64_t)b * a.res_bstride : nullptr;
+  // fragment (nf, kk) of weight slice s: 1 KB at wfrag + s * NTp * 2048 + (nf * 2 + kk) * 1024
+  const char* wfrag = (const char*)a.w + ((int64_t)((n0 >> 5) + wn * NF)) * 2048 + lane * 16;
+  const int64_t wstep = (int64_t)NTp * 2048;
+  // two static register sets for the weight fragments: even steps compute from b0 while b1 is being loaded, odd steps
+  // the other way round (no register-to-register hand-over, and hipcc's counted vmcnt stays exact)
+  bf16x8 b0[NF * 2], b1[NF * 2];
+#pragma unroll
+  for (int f = 0; f < NF * 2; ++f) b0[f] = *(const bf16x8*)(wfrag + f * 1024);
+  f32x16 acc[MF][NF];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+  if (fold) {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const int n = n0 + wn * WN + nf * 32 + (lane & 31);
+        const bool nok = n < a.Cout;
+        const int ncl = nok ? n : a.Cout - 1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float rv[8];
+          int us[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int r = h * 8 + q;
+            us[q] = l0 + wm * WM + mf * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            rv[q] = 0.f;
+          }
+          if (rb) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rv[q] = rb[(int64_t)(us[q] < len_out ? us[q] : len_out - 1) * a.ldr + ncl];
+          }
+          if (a.accumulate) {
+            float yv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) yv[q] = yb[(int64_t)(us[q] < len_out ? us[q] : len_out - 1) * a.ldy + ncl];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rv[q] += yv[q];
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc[mf][nf][h * 8 + q] = (nok && us[q] < len_out) ? rv[q] : 0.f;
+        }
+      }
+  }
+
+  lds_barrier();  // barrier #0
+  {
+    int ci = 0, tap = 0;
+    auto compute = [&](const bf16x8 (&bf)[NF * 2]) {
+      const char* A_hi = Abase + (ci & 1) * NA * ABYTES;
+      const char* A_lo = A_hi + ABYTES;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+          const int row = wm * WM + mf * 32 + (lane & 31) + tap * dil;
+          const int cidx = kk * 2 + (lane >> 5);
+          const int addr = row * 64 + ((cidx ^ ((row >> 2) & 3)) << 4);
+          const bf16x8 ah = *(const bf16x8*)(A_hi + addr);
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = mfma16<PREC>(ah, bf[nf * 2 + kk], acc[mf][nf]);
+          if (PREC == 2) {
+            const bf16x8 alo = *(const bf16x8*)(A_lo + addr);
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = mfma16<PREC>(alo, bf[nf * 2 + kk], acc[mf][nf]);
+          }
+        }
+      }
+      if (++tap == K) {  // end of chunk: the next window is staged, this one may be overwritten
+        tap = 0;
+        ++ci;
+        if (ci < nchunks) lds_barrier();
+      }
+    };
+    // The prefetch is unconditional (past the last slice it re-reads the last one): a branch around the loads would make
+    // hipcc assume they may not have been issued and wait for them with vmcnt(3..0) right away.
+    const char* wlast = wfrag + (int64_t)(nsteps - 1) * wstep;
+    for (int s = 0; s < nsteps; s += 2) {
+      const char* w1 = s + 1 < nsteps ? wfrag + (int64_t)(s + 1) * wstep : wlast;
+#pragma unroll
+      for (int f = 0; f < NF * 2; ++f) b1[f] = *(const bf16x8*)(w1 + f * 1024);
+      asm volatile("" ::: "memory");  // keep the prefetch AHEAD of the MFMAs (hipcc otherwise sinks it behind them to save registers)
+      __builtin_amdgcn_sched_barrier(0);
+      compute(b0);
+      if (s + 1 >= nsteps) break;
+      const char* w0 = s + 2 < nsteps ? wfrag + (int64_t)(s + 2) * wstep : wlast;
+#pragma unroll
+      for (int f = 0; f < NF * 2; ++f) b0[f] = *(const bf16x8*)(w0 + f * 1024);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      compute(b1);
+    }
+  }
+  conv_epilogue<MF, NF, WM, WN>(a, acc, b, l0, n0, wm, wn, lane, len_out, fold != 0);
+}
+
+template <int PREC>
+int launch_ws3(const mi355_conv_gemm_args& a, hipStream_t st) {
+  const int R = 128 + (a.K - 1) * a.dil;
+  MI355_REQUIRE(R <= 32 * kWsNld, "conv_gemm(ws3): window of %d rows exceeds %d (K=%d dil=%d)", R, 32 * kWsNld, a.K, a.dil);
+  const size_t lds = (size_t)2 * a_images<PREC>() * R * 64;
+  const int tiles_per_item = (a.Lout + 127) / 128;
+  const int P = a.B * tiles_per_item;
+  const int NT = (a.Cout + 127) / 128;
+  const int fold = (a.res || a.accumulate) && a.post_act == MI355_ACT_NONE && a.up_s == 0 && a.res_shift == 0;
+  const unsigned grid = (unsigned)(((P + 7) / 8) * 8 * NT);
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL((conv_gemm_ws3_kernel<PREC>), dim3(grid), dim3(kWsThreads), lds, st, a, tiles_per_item, P, NT, fold);
+  MI355_LAUNCH_CHECK("conv_gemm(ws3)");
+  return MI355_OK;
+}
+
 template <int PREC, bool V2>
 int launch_ws(const mi355_conv_gemm_args& a, hipStream_t st) {
   const int R = 128 + (a.K - 1) * a.dil;
@@ -701,6 +982,10 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const bool vec = (a.flat_valid == 0) && (a.ldx % 4 == 0) && (a.x_off % 4 == 0) && (a.x_bstride % 4 == 0) &&
                    (((uintptr_t)a.x) % 16 == 0);
+  if (a.stats_partial) {
+    MI355_REQUIRE(a.up_s == 0, "conv_gemm: fused statistics need a plain (non-polyphase) store");
+    MI355_REQUIRE(a.stats_bstride % 2 == 0 && ((uintptr_t)a.stats_partial) % 8 == 0, "conv_gemm: stats_partial must be 8-byte aligned");
+  }
   int tile = a.tile;
   const bool ws_ok = vec && (128 + (a.K - 1) * a.dil) <= 32 * kWsNld && a.Lin > 0;
   if (tile == 0) {
@@ -711,9 +996,18 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
     // the wave-specialised kernel once there are enough 128 x 128 tiles to fill the 256 CUs
     // (MI355_CONV_NO_WS=1 in the environment keeps the auto choice on the 4-wave kernels: an A/B and bisecting aid)
     static const bool no_ws = getenv("MI355_CONV_NO_WS") != nullptr;
-    static const int ws_tile = (getenv("MI355_CONV_WS_VARIANT") && atoi(getenv("MI355_CONV_WS_VARIANT")) == 8) ? 8128128 : 9128128;
+    static const int ws_var = getenv("MI355_CONV_WS_VARIANT") ? atoi(getenv("MI355_CONV_WS_VARIANT")) : 7;
+    static const int ws_tile = ws_var == 8 ? 8128128 : (ws_var == 9 ? 9128128 : 7128128);
     if (!no_ws && ws_ok && bn == 128 && wgs128 >= 256 && a.Cin >= 64) tile = ws_tile;
     else if (bn == 128 && wgs128 >= 512) tile = 64128;  // measured: 64-row tiles beat 128-row tiles on the 4-wave kernel
+  }
+  if (a.stats_partial) {  // statistics are produced per 64-row wave block: only the 128-row kernels have those
+    MI355_REQUIRE(vec, "conv_gemm: fused statistics need the 16-B aligned channels-last input path");
+    if (tile != 8128128 && tile != 9128128 && tile != 7128128) tile = 128128;
+  }
+  if (tile == 7128128) {  // weights through registers, one barrier per chunk
+    MI355_REQUIRE(ws_ok, "conv_gemm: the wave-specialised tile needs a 16-B aligned channels-last input and (K-1)*dil <= 64");
+    return a.precision == 2 ? launch_ws3<2>(a, st) : (a.precision == 3 ? launch_ws3<3>(a, st) : launch_ws3<1>(a, st));
   }
   if (tile == 8128128 || tile == 9128128) {  // 8...: producers stream the weights; 9...: consumers do (see the kernel header)
     MI355_REQUIRE(ws_ok, "conv_gemm: the wave-specialised tile needs a 16-B aligned channels-last input and (K-1)*dil <= 64");

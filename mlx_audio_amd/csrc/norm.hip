@@ -57,6 +57,54 @@ __global__ void adain_finalize_kernel(const mi355_adain_coef_args a) {
   a.shift[(int64_t)b * a.out_ld + c] = sh;
 }
 
+// AdaIN coefficients from the (sum, M2) block partials a conv_gemm epilogue wrote.  256 threads = 16 channels x 16
+// block lanes: every lane merges its share of the row blocks with Chan's parallel-variance update in float64, the 16
+// lanes of a channel are then merged through LDS.  grid (ceil(out_ld / 16), B).
+__global__ __launch_bounds__(256) void adain_from_partials_kernel(const mi355_adain_partials_args a) {
+  __shared__ double red[3][16][17];
+  const int cl = threadIdx.x & 15, eg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl, b = blockIdx.y;
+  const int len = a.lens ? a.lens[b] : a.L;
+  const int nblk = (len + MI355_STATS_ROWS - 1) / MI355_STATS_ROWS;
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  if (c < a.C) {
+    const float* pb = a.partials + (int64_t)b * a.bstride + (int64_t)c * 2;
+    for (int e = eg; e < nblk; e += 16) {
+      const float2 sv = *(const float2*)(pb + (int64_t)e * a.C * 2);
+      const double cnt = (double)min(MI355_STATS_ROWS, len - e * MI355_STATS_ROWS);
+      const double me = (double)sv.x / cnt, d = me - mean, nt = n + cnt;
+      mean += d * cnt / nt;
+      m2 += (double)sv.y + d * d * n * cnt / nt;
+      n = nt;
+    }
+  }
+  red[0][cl][eg] = n; red[1][cl][eg] = mean; red[2][cl][eg] = m2;
+  __syncthreads();
+  if (eg != 0 || c >= a.out_ld) return;
+  float sc = 0.f, sh = 0.f;
+  if (c < a.C) {
+    n = 0.0; mean = 0.0; m2 = 0.0;
+    for (int j = 0; j < 16; ++j) {
+      const double cnt = red[0][cl][j];
+      if (cnt > 0.0) {
+        const double d = red[1][cl][j] - mean, nt = n + cnt;
+        mean += d * cnt / nt;
+        m2 += red[2][cl][j] + d * d * n * cnt / nt;
+        n = nt;
+      }
+    }
+    double var = n > 0.0 ? m2 / n : 0.0;
+    if (var < 0) var = 0;
+    const float rstd = 1.0f / sqrtf((float)var + a.eps);
+    float g = 0.f, be = 0.f;
+    if (a.gb) { g = a.gb[(int64_t)b * a.gb_ld + c]; be = a.gb[(int64_t)b * a.gb_ld + a.C + c]; }
+    sc = (1.0f + g) * rstd;
+    sh = be - (float)mean * sc;
+  }
+  a.scale[(int64_t)b * a.out_ld + c] = sc;
+  a.shift[(int64_t)b * a.out_ld + c] = sh;
+}
+
 // one wave per row, up to 1024 channels held in registers (two-pass mean / variance like mx.var)
 __global__ __launch_bounds__(256) void layernorm_kernel(const mi355_layernorm_args a) {
   const int lane = threadIdx.x & 63;
@@ -137,6 +185,17 @@ extern "C" int mi355_adain_coef(const mi355_adain_coef_args* ap, void* stream) {
   MI355_CLEAR_ERROR();
   hipLaunchKernelGGL(adain_finalize_kernel, dim3((a.out_ld + 127) / 128, a.B), dim3(128), 0, st, a);
   MI355_LAUNCH_CHECK("adain_finalize");
+  return MI355_OK;
+}
+
+extern "C" int mi355_adain_from_partials(const mi355_adain_partials_args* ap, void* stream) {
+  MI355_REQUIRE(ap && ap->partials && ap->scale && ap->shift, "adain_from_partials: null tensor");
+  const mi355_adain_partials_args a = *ap;
+  MI355_REQUIRE(a.B > 0 && a.C > 0 && a.L > 0 && a.out_ld >= a.C, "adain_from_partials: bad shape");
+  MI355_CLEAR_ERROR();
+  MI355_REQUIRE(a.bstride % 2 == 0 && ((uintptr_t)a.partials) % 8 == 0, "adain_from_partials: partials must be 8-byte aligned");
+  hipLaunchKernelGGL(adain_from_partials_kernel, dim3((a.out_ld + 15) / 16, a.B), dim3(256), 0, (hipStream_t)stream, a);
+  MI355_LAUNCH_CHECK("adain_from_partials");
   return MI355_OK;
 }
 

@@ -116,7 +116,7 @@ def conv_gemm(x: torch.Tensor, pc: PackedConv, y: torch.Tensor, *, dil: int = 1,
               post_act: int = ACT_NONE, post_slope: float = 0.0, res: Optional[torch.Tensor] = None,
               res_shift: int = 0, out_scale: float = 1.0, accumulate: bool = False,
               up: Optional[dict] = None, precision: int = 2, tile: int = 0,
-              flat: Optional[dict] = None, use_bias: bool = True):
+              flat: Optional[dict] = None, use_bias: bool = True, stats: Optional[torch.Tensor] = None):
     """y = epilogue(conv1d(prologue(x)))  -- see mi355_conv_gemm_args in the header."""
     B, Lin, Cx, xbs, ldx = _nlc(x)
     By, Ly, Cy, ybs, ldy = _nlc(y)
@@ -144,6 +144,10 @@ def conv_gemm(x: torch.Tensor, pc: PackedConv, y: torch.Tensor, *, dil: int = 1,
     if up is not None:
         kw.update(up_s=up["s"], up_p=up["p"], up_cout=up["cout"], up_row_off=up.get("row_off", 0),
                   up_Lout=up["lout"], lens_up=_ptr(up.get("lens")))
+    if stats is not None:  # [B, ceil(Lout / 64), Cout, 2] float32: per-row-block (sum, M2) of the stored output
+        assert stats.dtype == torch.float32 and stats.dim() == 4 and stats.is_contiguous()
+        assert stats.shape[0] == B and stats.shape[1] >= (kw["Lout"] + STATS_ROWS - 1) // STATS_ROWS and stats.shape[2] == pc.cout
+        kw.update(stats_partial=_ptr(stats), stats_bstride=stats.stride(0))
     if PROFILE is not None:
         rows = (kw["Lout"] * B) if lens_out is None else int(lens_out.sum())
         flops = 2.0 * rows * pc.cout * pc.k * pc.cin
@@ -167,6 +171,26 @@ def adain_coef(x: torch.Tensor, gb: Optional[torch.Tensor], lens: Optional[torch
     shift = torch.empty((B, cp), dtype=torch.float32, device=x.device)
     _lib.call_struct("mi355_adain_coef", "mi355_adain_coef_args", _stream(), x=_ptr(x), x_bstride=xbs, ldx=ldx, C=C, L=L,
                      lens=_ptr(lens), B=B, sums=_ptr(sums), gb=_ptr(gb), gb_ld=0 if gb is None else gb.stride(0), eps=eps,
+                     scale=_ptr(scale), shift=_ptr(shift), out_ld=cp)
+    return scale, shift
+
+
+STATS_ROWS = 64  # MI355_STATS_ROWS
+
+
+def new_stats(B: int, L: int, C: int, device) -> torch.Tensor:
+    """Buffer for the fused instance-norm statistics of a conv output [B, L, C] (see conv_gemm(stats=...))."""
+    return torch.empty((B, (L + STATS_ROWS - 1) // STATS_ROWS, C, 2), dtype=torch.float32, device=device)
+
+
+def adain_from_partials(stats: torch.Tensor, L: int, gb: Optional[torch.Tensor], lens: Optional[torch.Tensor] = None, eps: float = 1e-5):
+    """AdaIN (scale, shift) from the per-row-block partial statistics a conv_gemm epilogue wrote."""
+    B, _, C, _ = stats.shape
+    cp = round_up(C, 32)
+    scale = torch.empty((B, cp), dtype=torch.float32, device=stats.device)
+    shift = torch.empty((B, cp), dtype=torch.float32, device=stats.device)
+    _lib.call_struct("mi355_adain_from_partials", "mi355_adain_partials_args", _stream(), partials=_ptr(stats), bstride=stats.stride(0),
+                     C=C, L=L, lens=_ptr(lens), B=B, gb=_ptr(gb), gb_ld=0 if gb is None else gb.stride(0), eps=eps,
                      scale=_ptr(scale), shift=_ptr(shift), out_ld=cp)
     return scale, shift
 

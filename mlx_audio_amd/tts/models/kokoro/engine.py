@@ -107,6 +107,7 @@ class KokoroEngine:
         self.dev = torch.device(device)
         self.pdt = param_dtype
         self.precision = precision
+        self.fuse_stats = True  # instance-norm statistics out of the producing conv's epilogue (False: separate pass)
         self.w = weights
         ist = config["istftnet"]
         self.rates = [int(r) for r in ist["upsample_rates"]]
@@ -280,13 +281,17 @@ class KokoroEngine:
         lo = lens2 if up else lens
         Lo = 2 * L if up else L
         c1 = self._new(B, Lo, blk.dout)
+        st = ops.new_stats(B, Lo, blk.dout, self.dev) if (self.fuse_stats and Lo >= 128) else None
         if up:
             pooled = self._new(B, Lo, round_up(blk.din, 32))[:, :, : blk.din]
             ops.adain_pool_up2(x, sc1, sh1, 0.2, blk.pool_w, blk.pool_b, pooled, lens)
-            self._conv(pooled, blk.conv1, c1, pad=1, lens_in=lo, lens_out=lo)
+            self._conv(pooled, blk.conv1, c1, pad=1, lens_in=lo, lens_out=lo, stats=st)
         else:
-            self._conv(x, blk.conv1, c1, pad=1, lens_in=lo, lens_out=lo, pre=(sc1, sh1), pre_act=ACT_LEAKY, pre_slope=0.2)
-        sc2, sh2 = ops.adain_coef(c1, self._gb(gb_all, blk.norm2), lo)
+            self._conv(x, blk.conv1, c1, pad=1, lens_in=lo, lens_out=lo, pre=(sc1, sh1), pre_act=ACT_LEAKY, pre_slope=0.2, stats=st)
+        if st is not None:
+            sc2, sh2 = ops.adain_from_partials(st, Lo, self._gb(gb_all, blk.norm2), lo)
+        else:
+            sc2, sh2 = ops.adain_coef(c1, self._gb(gb_all, blk.norm2), lo)
         if blk.conv1x1 is not None:
             short = self._new(B, L, blk.dout)
             self._conv(x, blk.conv1x1, short, lens_in=lens, lens_out=lens)
@@ -296,17 +301,30 @@ class KokoroEngine:
                    res=short, res_shift=1 if up else 0, out_scale=1.0 / math.sqrt(2.0))
         return out
 
-    def _resblock1_fwd(self, rb: _ResBlock1, x, gb_all, lens, out=None, accumulate=False, out_scale=1.0):
-        """AdaINResBlock1.  ``out`` None: returns a fresh tensor; else the last conv writes (or adds) into ``out``."""
+    def _resblock1_fwd(self, rb: _ResBlock1, x, gb_all, lens, out=None, accumulate=False, out_scale=1.0, x_stats=None):
+        """AdaINResBlock1.  ``out`` None: returns a fresh tensor; else the last conv writes (or adds) into ``out``.
+        Instance-norm statistics of every intermediate tensor come out of the producing conv's epilogue (``stats=``);
+        only the block input needs a separate pass, and callers that feed the same input to several blocks pass its
+        raw statistics in (``x_stats`` = (sum/M2 partials) from ``_stats_of``)."""
         B, L, C = x.shape
         cur = x
         work = None
         tmp = self._new(B, L, C)
+        fuse = self.fuse_stats and L >= 128
+        st_cur = x_stats
+        st_tmp = ops.new_stats(B, L, C, self.dev) if fuse else None
+        st_work = ops.new_stats(B, L, C, self.dev) if fuse else None
         for i, dl in enumerate(rb.dils):
-            sc, sh = ops.adain_coef(cur, self._gb(gb_all, rb.adain1[i]), lens)
+            if fuse and st_cur is not None:
+                sc, sh = ops.adain_from_partials(st_cur, L, self._gb(gb_all, rb.adain1[i]), lens)
+            else:
+                sc, sh = ops.adain_coef(cur, self._gb(gb_all, rb.adain1[i]), lens)
             self._conv(cur, rb.convs1[i], tmp, dil=dl, pad=(rb.k * dl - dl) // 2, lens_in=lens, lens_out=lens, pre=(sc, sh),
-                       pre_act=ACT_SNAKE, pre_alpha=rb.alpha1[i])
-            sc, sh = ops.adain_coef(tmp, self._gb(gb_all, rb.adain2[i]), lens)
+                       pre_act=ACT_SNAKE, pre_alpha=rb.alpha1[i], stats=st_tmp)
+            if fuse:
+                sc, sh = ops.adain_from_partials(st_tmp, L, self._gb(gb_all, rb.adain2[i]), lens)
+            else:
+                sc, sh = ops.adain_coef(tmp, self._gb(gb_all, rb.adain2[i]), lens)
             last = i == len(rb.dils) - 1
             if last and out is not None:
                 dst, acc, scale = out, accumulate, out_scale
@@ -315,8 +333,10 @@ class KokoroEngine:
                     work = self._new(B, L, C)
                 dst, acc, scale = work, False, 1.0
             self._conv(tmp, rb.convs2[i], dst, pad=(rb.k - 1) // 2, lens_in=lens, lens_out=lens, pre=(sc, sh),
-                       pre_act=ACT_SNAKE, pre_alpha=rb.alpha2[i], res=cur, accumulate=acc, out_scale=scale)
+                       pre_act=ACT_SNAKE, pre_alpha=rb.alpha2[i], res=cur, accumulate=acc, out_scale=scale,
+                       stats=st_work if (fuse and not last) else None)
             cur = dst
+            st_cur = st_work if (fuse and not last) else None
         return cur
 
     # ------------------------------------------------------------------ forward

@@ -99,8 +99,9 @@ def test_kokoro_model_protocol_end_to_end(tmp_path):
     # write the checkpoint in PyTorch layout / naming for the keys sanitize rewrites, bf16 like the real one
     raw = {}
     for k, v in w.items():
-        if k.endswith(("F0_proj.weight", "N_proj.weight")) or ("noise_convs" in k and k.endswith(".weight")):
-            v = v.permute(0, 2, 1)
+        if k.endswith(("F0_proj.weight", "N_proj.weight")) or ("noise_convs" in k and k.endswith(".weight")) or \
+                (k.endswith("weight_v") and v.dim() == 3):
+            v = v.permute(0, 2, 1)  # PyTorch conv layout (out, in, K): what the HF checkpoint holds and sanitize() undoes
         raw[k] = v.contiguous().to(torch.bfloat16)
     save_file(raw, str(d / "model.safetensors"))
     voice = S.make_voice_pack()

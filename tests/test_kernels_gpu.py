@@ -74,6 +74,18 @@ def ref_conv_nlc(x, w, b, dil, pad):
     (32, 22, 1, 1, 500, 1, 9128128),
     (64, 128, 5, 16, 260, 1, 9128128),
     (128, 128, 4, 2, 2100, 2, 9128128),
+    # ... and the variant with register-streamed weights and one barrier per chunk (tile code 7128128)
+    (128, 128, 7, 3, 300, 2, 7128128),
+    (128, 128, 3, 1, 1500, 3, 7128128),
+    (256, 256, 11, 5, 257, 1, 7128128),
+    (128, 128, 11, 1, 129, 1, 7128128),
+    (96, 200, 2, 1, 131, 2, 7128128),
+    (512, 64, 1, 1, 777, 3, 7128128),
+    (1090, 300, 3, 1, 145, 1, 7128128),
+    (32, 22, 1, 1, 500, 1, 7128128),
+    (64, 128, 5, 16, 260, 1, 7128128),
+    (128, 128, 4, 2, 2100, 2, 7128128),
+    (160, 128, 1, 1, 2100, 1, 7128128),
 ])
 def test_conv_gemm_plain(ops, cin, cout, k, dil, L, B, tile):
     g = torch.Generator().manual_seed(cin + cout + k)
@@ -99,7 +111,7 @@ def test_conv_gemm_plain(ops, cin, cout, k, dil, L, B, tile):
 
 @pytest.mark.parametrize("tile,res_shift,act", [(0, 1, "snake"), (8128128, 1, "snake"), (8128128, 0, "snake"), (128128, 0, "leaky"),
                                                  (8128128, 0, "leaky"), (64064, 0, "snake"), (9128128, 1, "snake"), (9128128, 0, "snake"),
-                                                 (9128128, 0, "leaky")])
+                                                 (9128128, 0, "leaky"), (7128128, 1, "snake"), (7128128, 0, "snake"), (7128128, 0, "leaky")])
 def test_conv_gemm_fused_prologue_epilogue_ragged(ops, tile, res_shift, act):
     """AdaIN affine + Snake / LeakyReLU in front, bias + residual(row >> res_shift) + scale + accumulate behind, ragged
     batch; res_shift == 0 takes the accumulator-initialisation ("fold") path of the wave-specialised kernel."""
@@ -138,7 +150,8 @@ def test_conv_gemm_fused_prologue_epilogue_ragged(ops, tile, res_shift, act):
 
 @pytest.mark.parametrize("cin,cout,k,s,L,row_off,tile", [(512, 256, 20, 10, 53, 0, 0), (256, 128, 12, 6, 130, 1, 0), (64, 32, 4, 2, 9, 0, 0),
                                                          (512, 256, 20, 10, 153, 0, 8128128), (256, 128, 12, 6, 330, 1, 8128128),
-                                                         (512, 256, 20, 10, 153, 0, 9128128), (256, 128, 12, 6, 330, 1, 9128128)])
+                                                         (512, 256, 20, 10, 153, 0, 9128128), (256, 128, 12, 6, 330, 1, 9128128),
+                                                         (512, 256, 20, 10, 153, 0, 7128128), (256, 128, 12, 6, 330, 1, 7128128)])
 def test_conv_transpose_polyphase(ops, cin, cout, k, s, L, row_off, tile):
     g = torch.Generator().manual_seed(k * s)
     p = (k - s) // 2
@@ -191,6 +204,39 @@ def test_conv_flat_strided_small_cin(ops):
     ops.conv_gemm(x.to(DEV), pc1, y1)
     torch.cuda.synchronize()
     assert rel_err(y1.cpu(), x.double() @ w1[:, 0].double().t()) < 3e-5
+
+
+@pytest.mark.parametrize("tile", [0, 128128, 7128128, 8128128, 9128128])
+def test_conv_gemm_fused_instnorm_statistics(ops, tile):
+    """Instance-norm statistics of the conv OUTPUT produced by the epilogue (stats=) + adain_from_partials must equal the
+    separate pass (adain_coef) over the stored tensor: ragged batch, residual + scaling in the epilogue, large mean / std."""
+    g = torch.Generator().manual_seed(21)
+    B, L, C, K = 3, 700, 128, 3
+    lens = torch.tensor([700, 65, 333], dtype=torch.int32).to(DEV)
+    w = bf16r(torch.randn(C, K, C, generator=g) / math.sqrt(K * C))
+    bias = torch.randn(C, generator=g) * 0.1 + 7.0  # mean >> std: the shifted single-pass variance must not cancel
+    x = torch.randn(B, L, C, generator=g).to(DEV)
+    res = torch.randn(B, L, C, generator=g).to(DEV)
+    gb = (torch.randn(B, 2 * C, generator=g) * 0.3).to(DEV)
+    pc = ops.pack_conv(w, bias, DEV)
+    y = torch.zeros(B, L, C, device=DEV)
+    st = ops.new_stats(B, L, C, DEV)
+    st.fill_(float("nan"))
+    ops.conv_gemm(x, pc, y, pad=1, lens_in=lens, lens_out=lens, res=res, out_scale=0.7, tile=tile, stats=st)
+    sc, sh = ops.adain_from_partials(st, L, gb, lens)
+    sc_ref, sh_ref = ops.adain_coef(y, gb, lens)
+    torch.cuda.synchronize()
+    assert torch.isfinite(sc).all() and torch.isfinite(sh).all()
+    assert rel_err(sc[:, :C], sc_ref[:, :C]) < 2e-5, rel_err(sc[:, :C], sc_ref[:, :C])
+    assert rel_err(sh[:, :C], sh_ref[:, :C]) < 2e-5, rel_err(sh[:, :C], sh_ref[:, :C])
+    # and against float64 on the host
+    for b in range(B):
+        n = int(lens[b])
+        v = y[b, :n].double().cpu()
+        mean, var = v.mean(0), v.var(0, unbiased=False)
+        want_sc = (1 + gb[b, :C].double().cpu()) / torch.sqrt(var + 1e-5)
+        assert rel_err(sc[b, :C].cpu(), want_sc) < 2e-5
+        assert rel_err(sh[b, :C].cpu(), gb[b, C:].double().cpu() - mean * want_sc) < 2e-5
 
 
 def test_adain_coef(ops):

@@ -43,10 +43,10 @@ def main():
     shapes.append((256, 256, 11, 5, 5280, "snake"))
     shapes.append((1090, 1024, 3, 1, 264, "leaky"))
     shapes.append((512, 2560, 2, 1, 529, "plain"))
-    variants = [("old128x128", 128128), ("old64x128", 64128), ("ws_prodB", 8128128), ("ws_consB", 9128128)]
+    variants = [("old64x128", 64128), ("ws_prodB", 8128128), ("ws_consB", 9128128), ("ws_regB", 7128128)]
     if args.quick:
         shapes = [(128, 128, 11, 1, 31681, "snake+res"), (128, 128, 3, 1, 31681, "snake+res")]
-        variants = [("old64x128", 64128), ("ws_prodB", 8128128), ("ws_consB", 9128128)]
+        variants = [("old64x128", 64128), ("ws_prodB", 8128128), ("ws_regB", 7128128)]
     lines = ["cin cout k dil rows fused variant ms tflops_alg GBps_alg maxrel"]
     g = torch.Generator(device=dev).manual_seed(0)
     for cin, cout, k, dil, L, fused in shapes:
