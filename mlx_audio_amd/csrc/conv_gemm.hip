@@ -687,7 +687,10 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
 // producers hand a converted window over once per chunk and already have the loads of the window after that in
 // flight.  Between two barriers a consumer wave free-runs K x 16 MFMAs.
 // -----------------------------------------------------------------------------------------------------
-template <int PREC>
+// ABL (ablation bits, timing experiments only -- results are WRONG when non-zero; reachable only through the explicit
+// tile codes ABL*10000000 + 7128128 used by tools/bench_conv.py): 1 = no weight-fragment loads after the first,
+// 2 = no activation-fragment LDS reads, 4 = producers only take part in the barriers, 8 = no epilogue.
+template <int PREC, int ABL = 0>
 __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws3_kernel(const mi355_conv_gemm_args a, const int tiles_per_item,
                                                                      const int P, const int NT, const int fold) {
   constexpr int BM = 128, BN = 128, WM = 64, WN = 64, MF = 2, NF = 2;
@@ -788,6 +791,10 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws3_kernel(const mi35
         }
       }
     };
+    if constexpr ((ABL & 4) != 0) {
+      for (int ci = 0; ci < nchunks; ++ci) lds_barrier();
+      return;
+    }
     loadA(0);
     convertA(0, Abase);
     if (nchunks > 1) loadA(1);
@@ -867,11 +874,15 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws3_kernel(const mi35
           const int row = wm * WM + mf * 32 + (lane & 31) + tap * dil;
           const int cidx = kk * 2 + (lane >> 5);
           const int addr = row * 64 + ((cidx ^ ((row >> 2) & 3)) << 4);
-          const bf16x8 ah = *(const bf16x8*)(A_hi + addr);
+          bf16x8 ah;
+          if constexpr ((ABL & 2) != 0) ah = bf[(mf + kk) & 3];
+          else ah = *(const bf16x8*)(A_hi + addr);
 #pragma unroll
           for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = mfma16<PREC>(ah, bf[nf * 2 + kk], acc[mf][nf]);
           if (PREC == 2) {
-            const bf16x8 alo = *(const bf16x8*)(A_lo + addr);
+            bf16x8 alo;
+            if constexpr ((ABL & 2) != 0) alo = bf[(mf + kk + 1) & 3];
+            else alo = *(const bf16x8*)(A_lo + addr);
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = mfma16<PREC>(alo, bf[nf * 2 + kk], acc[mf][nf]);
           }
@@ -886,6 +897,13 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws3_kernel(const mi35
     // The prefetch is unconditional (past the last slice it re-reads the last one): a branch around the loads would make
     // hipcc assume they may not have been issued and wait for them with vmcnt(3..0) right away.
     const char* wlast = wfrag + (int64_t)(nsteps - 1) * wstep;
+    if constexpr ((ABL & 1) != 0) {
+      for (int s = 0; s < nsteps; ++s) {
+#pragma unroll
+        for (int f = 0; f < NF * 2; ++f) asm volatile("" : "+v"(b0[f]));  // opaque: not hoistable, no loads
+        compute(b0);
+      }
+    } else
     for (int s = 0; s < nsteps; s += 2) {
       const char* w1 = s + 1 < nsteps ? wfrag + (int64_t)(s + 1) * wstep : wlast;
 #pragma unroll
@@ -902,10 +920,21 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws3_kernel(const mi35
       compute(b1);
     }
   }
+  if constexpr ((ABL & 8) != 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[mf][nf][r];
+    if (t == 1.2345e-30f) yb[0] = t;  // keeps the MFMAs alive without an epilogue
+    return;
+  }
   conv_epilogue<MF, NF, WM, WN>(a, acc, b, l0, n0, wm, wn, lane, len_out, fold != 0);
 }
 
-template <int PREC>
+template <int PREC, int ABL = 0>
 int launch_ws3(const mi355_conv_gemm_args& a, hipStream_t st) {
   const int R = 128 + (a.K - 1) * a.dil;
   MI355_REQUIRE(R <= 32 * kWsNld, "conv_gemm(ws3): window of %d rows exceeds %d (K=%d dil=%d)", R, 32 * kWsNld, a.K, a.dil);
@@ -916,7 +945,7 @@ int launch_ws3(const mi355_conv_gemm_args& a, hipStream_t st) {
   const int fold = (a.res || a.accumulate) && a.post_act == MI355_ACT_NONE && a.up_s == 0 && a.res_shift == 0;
   const unsigned grid = (unsigned)(((P + 7) / 8) * 8 * NT);
   MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL((conv_gemm_ws3_kernel<PREC>), dim3(grid), dim3(kWsThreads), lds, st, a, tiles_per_item, P, NT, fold);
+  hipLaunchKernelGGL((conv_gemm_ws3_kernel<PREC, ABL>), dim3(grid), dim3(kWsThreads), lds, st, a, tiles_per_item, P, NT, fold);
   MI355_LAUNCH_CHECK("conv_gemm(ws3)");
   return MI355_OK;
 }
@@ -1004,6 +1033,20 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
   if (a.stats_partial) {  // statistics are produced per 64-row wave block: only the 128-row kernels have those
     MI355_REQUIRE(vec, "conv_gemm: fused statistics need the 16-B aligned channels-last input path");
     if (tile != 8128128 && tile != 9128128 && tile != 7128128) tile = 128128;
+  }
+  if (tile > 10000000 && tile % 10000000 == 7128128) {  // timing ablations of the 7128128 kernel (wrong results by design)
+    MI355_REQUIRE(ws_ok && a.precision == 2, "conv_gemm: ablation tiles need the wave-specialised path at precision 2");
+    switch (tile / 10000000) {
+      case 1: return launch_ws3<2, 1>(a, st);
+      case 2: return launch_ws3<2, 2>(a, st);
+      case 3: return launch_ws3<2, 3>(a, st);
+      case 4: return launch_ws3<2, 4>(a, st);
+      case 8: return launch_ws3<2, 8>(a, st);
+      case 7: return launch_ws3<2, 7>(a, st);
+      case 15: return launch_ws3<2, 15>(a, st);
+    }
+    mi355_set_error("conv_gemm: unknown ablation tile %d", tile);
+    return MI355_ERR_UNSUPPORTED;
   }
   if (tile == 7128128) {  // weights through registers, one barrier per chunk
     MI355_REQUIRE(ws_ok, "conv_gemm: the wave-specialised tile needs a 16-B aligned channels-last input and (K-1)*dil <= 64");

@@ -281,7 +281,7 @@ class KokoroEngine:
         lo = lens2 if up else lens
         Lo = 2 * L if up else L
         c1 = self._new(B, Lo, blk.dout)
-        st = ops.new_stats(B, Lo, blk.dout, self.dev) if (self.fuse_stats and Lo >= 128) else None
+        st = ops.new_stats(B, Lo, blk.dout, self.dev) if self.fuse_stats else None
         if up:
             pooled = self._new(B, Lo, round_up(blk.din, 32))[:, :, : blk.din]
             ops.adain_pool_up2(x, sc1, sh1, 0.2, blk.pool_w, blk.pool_b, pooled, lens)
@@ -310,7 +310,7 @@ class KokoroEngine:
         cur = x
         work = None
         tmp = self._new(B, L, C)
-        fuse = self.fuse_stats and L >= 128
+        fuse = self.fuse_stats  # never by length: a ragged batch and its single utterances must take the same path
         st_cur = x_stats
         st_tmp = ops.new_stats(B, L, C, self.dev) if fuse else None
         st_work = ops.new_stats(B, L, C, self.dev) if fuse else None

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--precision", type=int, default=2)
     ap.add_argument("--quick", action="store_true", help="two shapes, the wave-specialised variants only (for PMC passes)")
+    ap.add_argument("--ablate", action="store_true", help="timing ablations of the 7128128 kernel (their results are wrong by design)")
     args = ap.parse_args()
     from mlx_audio_amd import ops
 
@@ -44,6 +45,10 @@ def main():
     shapes.append((1090, 1024, 3, 1, 264, "leaky"))
     shapes.append((512, 2560, 2, 1, 529, "plain"))
     variants = [("old64x128", 64128), ("ws_prodB", 8128128), ("ws_consB", 9128128), ("ws_regB", 7128128)]
+    if args.ablate:
+        shapes = [(128, 128, 11, 1, 31681, "snake+res"), (128, 128, 3, 1, 31681, "snake+res"), (256, 256, 7, 1, 5280, "snake+res")]
+        variants = [("ws_regB", 7128128), ("abl1_noBload", 17128128), ("abl2_noAread", 27128128), ("abl3_noAB", 37128128),
+                    ("abl4_noProducer", 47128128), ("abl8_noEpilogue", 87128128), ("abl7_noABP", 77128128), ("abl15_mfmaOnly", 157128128)]
     if args.quick:
         shapes = [(128, 128, 11, 1, 31681, "snake+res"), (128, 128, 3, 1, 31681, "snake+res")]
         variants = [("old64x128", 64128), ("ws_prodB", 8128128), ("ws_regB", 7128128)]
