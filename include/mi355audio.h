@@ -14,7 +14,7 @@
  *     base + b*bstride + l*ld + c   (the NLC layout mx.conv1d uses), ld >= C;
  *   - `lens` (nullable) holds the valid row count of every batch item (ragged batches are padded
  *     to a common L; rows >= lens[b] read as zeros and are never written);
- *   - weights are bfloat16, pre-packed by mi355_pack_* into MFMA fragment order;
+ *   - weights are bfloat16 (or float16 for fp16 checkpoints), pre-packed by mi355_pack_* into MFMA fragment order;
  *   - `stream` is a hipStream_t passed as void*; all functions are asynchronous on it;
  *   - return value: 0 = ok, negative = error (text via mi355_last_error()); nothing is allocated,
  *     no global state is kept, distinct streams may be driven from distinct host threads.
@@ -50,7 +50,11 @@ int mi355_device_info(int dev, char* name, int name_cap, int* cu_count, int* lds
  * (istftnet.py:337,379-380,907-908,818), bias / residual / scaling behind (istftnet.py:394,932,
  * 822,829).
  * ------------------------------------------------------------------------------------------ */
-enum { MI355_ACT_NONE = 0, MI355_ACT_LEAKY = 1, MI355_ACT_SNAKE = 2, MI355_ACT_GELU = 3 };
+enum { MI355_ACT_NONE = 0, MI355_ACT_LEAKY = 1, MI355_ACT_SNAKE = 2, MI355_ACT_GELU = 3,
+       MI355_ACT_ELU = 4,        /* prologue or epilogue: x > 0 ? x : expm1(x)  (Mimi SEANet, codec/models/mimi/modules/seanet.py) */
+       MI355_ACT_SILU = 5,       /* epilogue */
+       MI355_ACT_GELU_TANH = 6,  /* epilogue: nn.gelu_approx / GELU(tanh) */
+       MI355_ACT_TANH = 7 };     /* epilogue */
 
 typedef struct {
   /* input activation */
@@ -101,7 +105,9 @@ typedef struct {
   const int32_t* lens_up; /* [B] nullable */
   int32_t B;
   int32_t precision;   /* 2 = bf16 hi+lo split (default; ~16 mantissa bits of the fp32 activation), 1 = single bf16 pass,
-                          3 = single fp16 pass: activations rounded to fp16 (saturating), weights packed with MI355_W_F16 */
+                          3 = single fp16 pass: activations rounded to fp16 (saturating), weights packed with MI355_W_F16,
+                          4 = fp16 hi+lo split (~22 mantissa bits of the activation) on MI355_W_F16 weights: fp16 checkpoints
+                              (Whisper) at fp32-activation accuracy */
   int32_t tile;        /* 0 = auto, else BM*1000+BN (128128, 64128, 64064), 8128128 / 9128128 = wave-specialised 8-wave kernels */
   /* optional instance-norm statistics of the STORED output, fused into the epilogue (plain stores only): per block of
      MI355_STATS_ROWS output rows and per channel the pair (sum, sum of squared deviations from the block mean), written
@@ -109,6 +115,13 @@ typedef struct {
      Saves the separate read pass of InstanceNorm1d over the tensor this conv just produced (istftnet.py:173-338). */
   float* stats_partial;   /* nullable; [B, ceil(Lout / MI355_STATS_ROWS), Cout, 2] */
   int64_t stats_bstride;  /* elements between batch items */
+  /* SnakeBeta prologue (Qwen3 codec decoder, speech_tokenizer.py SnakeBeta): with pre_act == MI355_ACT_SNAKE and
+     pre_inv_beta set, t + pre_inv_beta[c] * sin^2(pre_alpha[c] * t)  (alpha = exp(log_alpha), inv_beta = 1/(exp(log_beta)+eps),
+     evaluated once on the host); null = plain Snake with 1/alpha. */
+  const float* pre_inv_beta; /* [Cin padded to 32] nullable */
+  /* per-output-column scale applied after the epilogue activation and before the residual add (LayerScale:
+     x + scale[c] * f(x), codec/models/mimi/modules/transformer.py LayerScale; ConvNeXt gamma). */
+  const float* post_colscale; /* [Cout] nullable */
 } mi355_conv_gemm_args;
 #define MI355_STATS_ROWS 64
 
@@ -325,6 +338,83 @@ typedef struct {
   float* out; int32_t ld_out;
 } mi355_istft_args;
 int mi355_istft(const mi355_istft_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Scaled-dot-product attention with GQA, causal / sliding-window masks and ragged lengths, exact f32
+ * (v_mfma_f32_32x32x2_f32 flash kernel for Tq > 8, a KV-cache streaming kernel for decode steps).
+ * Replaces Whisper MultiHeadAttention.qkv_attention (stt/models/whisper/whisper.py:371-385: q@k, + mask,
+ * softmax(precise=True), w@v) and mx.fast.scaled_dot_product_attention under the Qwen3-TTS talker / code predictor /
+ * codec transformer (tts/models/qwen3_tts/talker.py:307, speech_tokenizer.py:150-186), the Mimi transformer
+ * (codec/models/mimi/modules/transformer.py:96-113) and the CSM Llama blocks (tts/models/sesame/attention.py:150-175).
+ * q [B, Tq, ldq] with head h at columns [h*dh, (h+1)*dh); k, v [B, Tk, ldk/ldv] with kv head g = h / (heads/kv_heads)
+ * at [g*dh, (g+1)*dh) -- a KV cache is simply the buffer k/v point into.  Queries are the LAST lens_q[b] positions of
+ * the lens_k[b] keys: key j is visible to query i iff j < lens_k[b], (causal) j <= i + lens_k[b] - lens_q[b],
+ * (window > 0) j > i + lens_k[b] - lens_q[b] - window.  softmax(scale * q.k) over the visible keys, times v.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* q; int64_t q_bstride; int32_t ldq;
+  const float* k; int64_t k_bstride; int32_t ldk;
+  const float* v; int64_t v_bstride; int32_t ldv;
+  int32_t heads; int32_t kv_heads; int32_t dh;   /* dh: 64 or 128 */
+  int32_t Tq; int32_t Tk;
+  const int32_t* lens_q;  /* [B] nullable => Tq */
+  const int32_t* lens_k;  /* [B] nullable => Tk */
+  int32_t causal; int32_t window; float scale;
+  int32_t B;
+  int32_t mode;           /* 0 = auto (decode kernel when Tq <= 8), 1 = MFMA flash kernel, 2 = decode kernel */
+  float* out; int64_t out_bstride; int32_t ldo;  /* [B, Tq, ldo], head h at [h*dh, (h+1)*dh) */
+} mi355_flash_attn_args;
+int mi355_flash_attention(const mi355_flash_attn_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whisper decode step on device: SuppressBlank -> SuppressTokens -> ApplyTimestampRules -> GreedyDecoder.update
+ * (stt/models/whisper/decoding.py:333-443, 302-330), one workgroup per sequence, no host round trip.
+ * logits: raw decoder logits of the last position; tokens[b, 0:n] is the context so far (initial tokens included),
+ * tokens[b, n] receives the selected token (eot once the sequence has ended), sum_logprobs[b] accumulates
+ * log softmax(filtered)[token] while the sequence is alive.  gumbel (nullable): [B, ld] Gumbel(0,1) noise, the
+ * explicit-noise form of categorical(logits / temperature) for temperature > 0; null = argmax.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* logits; int32_t ld; int32_t V; int32_t B;
+  int32_t* tokens; int32_t tokens_ld; int32_t n;
+  int32_t sample_begin;
+  const float* suppress_mask;                   /* [V] 0 / -inf, nullable (SuppressTokens) */
+  const int32_t* blank_ids; int32_t n_blank;    /* ids masked while n == sample_begin, nullable (SuppressBlank) */
+  int32_t timestamp_rules;                      /* 1 = ApplyTimestampRules */
+  int32_t timestamp_begin; int32_t eot; int32_t no_timestamps;  /* no_timestamps < 0: tokenizer has none */
+  int32_t max_initial_timestamp_index;          /* < 0: None */
+  const float* gumbel; float temperature;
+  float* sum_logprobs;                          /* [B] */
+  float* filtered;                              /* [B, ld] nullable: the filtered logits (parity tests) */
+  const int32_t* forced_next;                   /* [B] nullable: teacher forcing -- append this token instead of the selection
+                                                   (its log-prob is what gets accumulated) */
+} mi355_whisper_step_args;
+int mi355_whisper_greedy_step(const mi355_whisper_step_args* a, void* stream);
+/* out[b] = softmax(logits[b, 0:V])[token]  (no_speech_prob, decoding.py:604-606). */
+int mi355_softmax_prob_at(const float* logits, int32_t ld, int32_t V, int32_t B, int32_t token, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Skinny GEMM for decode steps: y[m, n] = epilogue(sum_k x[m, k] * w[n, k]), 1 <= M <= 8 rows.
+ * Replaces nn.Linear / Embedding.as_linear at sequence length 1: Whisper TextDecoder (stt/models/whisper/whisper.py:347-416,
+ * 498), Qwen3-TTS talker / code predictor (tts/models/qwen3_tts/talker.py:230-330, 503-764), CSM backbone / depth decoder
+ * (lm/models/llama.py:46-198, tts/models/sesame/sesame.py:361-404).  HBM-bound: w is read once, row-major [N, ldw] in the
+ * checkpoint's 16-bit type (mi355_pack_rowmajor16_host), products accumulate in fp32.
+ * Epilogue: v = act(acc + bias[n]) * colscale[n] + res[m, n]; y = v * out_scale.  glu = 1: rows of w are interleaved
+ * (gate_0, up_0, gate_1, up_1, ...) and y[m, n/2] = silu(acc_gate + b) * (acc_up + b)  (SwiGLU, talker.py TalkerMLP).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* x; int32_t ldx; int32_t M; int32_t K;
+  const uint16_t* w; int32_t ldw; int32_t wdtype; int32_t N;   /* wdtype: MI355_W_BF16 / MI355_W_F16 */
+  const float* bias;       /* [N] nullable */
+  int32_t post_act; float post_slope;
+  const float* colscale;   /* [N] nullable */
+  const float* res; int32_t ldr;   /* [M, ldr] nullable */
+  float out_scale;         /* 0 => 1 */
+  int32_t glu;
+  float* y; int32_t ldy;
+} mi355_gemv_args;
+int mi355_gemv(const mi355_gemv_args* a, void* stream);
+int mi355_pack_rowmajor16_host(const float* w_host, int64_t n, int32_t dtype, uint16_t* out_host);
 
 #ifdef __cplusplus
 }

@@ -29,19 +29,34 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* ldst) {
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// nn.GELU(approx="tanh") / nn.gelu_approx: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+__device__ __forceinline__ float gelu_tanh(float x) { return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x))); }
 
 
-// one 32x32x16 MFMA on 16-byte A / B fragments: bf16 (PREC 1, 2) or fp16 (PREC 3) inputs, fp32 accumulate
+// one 32x32x16 MFMA on 16-byte A / B fragments: bf16 (PREC 1, 2) or fp16 (PREC 3, 4) inputs, fp32 accumulate
+// PREC 2 / 4 split the fp32 activation into hi + lo images of the weight's 16-bit type (two MFMAs per fragment)
 template <int PREC>
 __device__ __forceinline__ f32x16 mfma16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
-  if constexpr (PREC == 3)
+  if constexpr (PREC >= 3)
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 // number of LDS images of the activation window: hi + lo for the split, one otherwise
 template <int PREC>
-constexpr int a_images() { return PREC == 2 ? 2 : 1; }
+constexpr int a_images() { return (PREC == 2 || PREC == 4) ? 2 : 1; }
+// the part of t the first (hi) image carries, as an fp32 value
+template <int PREC>
+__device__ __forceinline__ float split_hi(float t) {
+  if constexpr (PREC == 3) return t;
+  else if constexpr (PREC == 4) return (float)(_Float16)__builtin_fminf(__builtin_fmaxf(t, -65504.f), 65504.f);
+  else return bf16_bits_to_f32(f32_to_bf16_bits(t));
+}
+template <int PREC>
+__device__ __forceinline__ uint32_t pack_lo(float a, float b) {
+  if constexpr (PREC == 4) return pack_f16x2(a, b);
+  else return pack_bf16x2(a, b);
+}
 
 
 // Shared epilogue: y = ((acc + bias -> act) + res + y_old) * out_scale, plain or polyphase (conv_transpose) store.
@@ -73,6 +88,7 @@ __device__ __forceinline__ void conv_epilogue(const mi355_conv_gemm_args& a, f32
       int ocol = ncl, rph = 0;
       if (a.up_s) { rph = ncl / a.up_cout; ocol = ncl - rph * a.up_cout; }
       const float bias = a.bias ? a.bias[ocol] : 0.f;
+      const float cscale = a.post_colscale ? a.post_colscale[ocol] : 1.f;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {  // 8 accumulator rows at a time keeps the live set small
         int orows[8];
@@ -110,7 +126,11 @@ __device__ __forceinline__ void conv_epilogue(const mi355_conv_gemm_args& a, f32
           float v = acc[mf][nf][h * 8 + q] + bias;
           if (a.post_act == MI355_ACT_LEAKY) v = v > 0.f ? v : v * a.post_slope;
           else if (a.post_act == MI355_ACT_GELU) v = gelu_erf(v);
-          v = (v + rv[q]) * a.out_scale;
+          else if (a.post_act == MI355_ACT_SILU) v = v / (1.0f + expf(-v));
+          else if (a.post_act == MI355_ACT_GELU_TANH) v = gelu_tanh(v);
+          else if (a.post_act == MI355_ACT_ELU) v = v > 0.f ? v : expm1f(v);
+          else if (a.post_act == MI355_ACT_TANH) v = tanhf(v);
+          v = (v * cscale + rv[q]) * a.out_scale;
           if (ok[q]) yb[(int64_t)orows[q] * a.ldy + ocol] = v;
           if (want_stats && ok[q]) {
             sK[nf] = scnt[nf] == 0 ? v : sK[nf];
@@ -205,6 +225,10 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_ge
       al[0] = a4.x; al[1] = a4.y; al[2] = a4.z; al[3] = a4.w;
 #pragma unroll
       for (int i = 0; i < 4; ++i) ial[i] = 1.0f / al[i];
+      if (a.pre_inv_beta) {  // SnakeBeta: x + sin^2(alpha x) * inv_beta[c]
+        const float4 b4 = *(const float4*)(a.pre_inv_beta + c);
+        ial[0] = b4.x; ial[1] = b4.y; ial[2] = b4.z; ial[3] = b4.w;
+      }
     }
     for (int r = tid >> 3; r < R; r += kThreads / 8) {
       const int gl = l0 - a.pad + r;
@@ -236,15 +260,15 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_ge
         else if (a.pre_act == MI355_ACT_SNAKE) {
           const float s = __sinf(al[i] * t);
           t = t + ial[i] * (s * s);
-        }
+        } else if (a.pre_act == MI355_ACT_ELU) t = t > 0.f ? t : expm1f(t);
         t = ok[i] ? t : 0.f;
-        const float h = PREC == 3 ? t : bf16_bits_to_f32(f32_to_bf16_bits(t));
+        const float h = split_hi<PREC>(t);
         hi[i] = h;
         lo[i] = t - h;
       }
       const int addr = r * 64 + ((((c4 >> 3) ^ ((r >> 2) & 3))) << 4) + ((c4 & 4) << 1);
       uint2 ph;
-      if constexpr (PREC == 3) {
+      if constexpr (PREC >= 3) {
         ph.x = pack_f16x2(hi[0], hi[1]);
         ph.y = pack_f16x2(hi[2], hi[3]);
       } else {
@@ -252,10 +276,10 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_ge
         ph.y = pack_bf16x2(hi[2], hi[3]);
       }
       *(uint2*)(A_hi + addr) = ph;
-      if (PREC == 2) {
+      if (PREC == 2 || PREC == 4) {
         uint2 pl;
-        pl.x = pack_bf16x2(lo[0], lo[1]);
-        pl.y = pack_bf16x2(lo[2], lo[3]);
+        pl.x = pack_lo<PREC>(lo[0], lo[1]);
+        pl.y = pack_lo<PREC>(lo[2], lo[3]);
         *(uint2*)(A_lo + addr) = pl;
       }
     }
@@ -278,7 +302,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_ge
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf)
           acc[mf][nf] = mfma16<PREC>(ah, bfr[nf], acc[mf][nf]);
-        if (PREC == 2) {
+        if (PREC == 2 || PREC == 4) {
           const bf16x8 alo = *(const bf16x8*)(A_lo + addr);
 #pragma unroll
           for (int nf = 0; nf < NF; ++nf)
@@ -431,6 +455,10 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
         al[0] = a4.x; al[1] = a4.y; al[2] = a4.z; al[3] = a4.w;
 #pragma unroll
         for (int i = 0; i < 4; ++i) ial[i] = 1.0f / al[i];
+      if (a.pre_inv_beta) {  // SnakeBeta: x + sin^2(alpha x) * inv_beta[c]
+        const float4 b4 = *(const float4*)(a.pre_inv_beta + c);
+        ial[0] = b4.x; ial[1] = b4.y; ial[2] = b4.z; ial[3] = b4.w;
+      }
       }
 #pragma unroll
       for (int i = 0; i < kWsNld; ++i) {
@@ -447,15 +475,15 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
             else if (a.pre_act == MI355_ACT_SNAKE) {
               const float s = __sinf(al[j] * t);
               t = t + ial[j] * (s * s);
-            }
+            } else if (a.pre_act == MI355_ACT_ELU) t = t > 0.f ? t : expm1f(t);
             t = (rowok && (c + j) < a.Cin) ? t : 0.f;
-            const float h = PREC == 3 ? t : bf16_bits_to_f32(f32_to_bf16_bits(t));
+            const float h = split_hi<PREC>(t);
             hi[j] = h;
             lo[j] = t - h;
           }
           const int addr = r * 64 + ((((c4 >> 3) ^ ((r >> 2) & 3))) << 4) + ((c4 & 4) << 1);
           uint2 ph;
-          if constexpr (PREC == 3) {
+          if constexpr (PREC >= 3) {
             ph.x = pack_f16x2(hi[0], hi[1]);
             ph.y = pack_f16x2(hi[2], hi[3]);
           } else {
@@ -463,10 +491,10 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
             ph.y = pack_bf16x2(hi[2], hi[3]);
           }
           *(uint2*)(A_hi + addr) = ph;
-          if (PREC == 2) {
+          if (PREC == 2 || PREC == 4) {
             uint2 pl;
-            pl.x = pack_bf16x2(lo[0], lo[1]);
-            pl.y = pack_bf16x2(lo[2], lo[3]);
+            pl.x = pack_lo<PREC>(lo[0], lo[1]);
+            pl.y = pack_lo<PREC>(lo[2], lo[3]);
             *(uint2*)(A_lo + addr) = pl;
           }
         }
@@ -655,7 +683,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
           const bf16x8 ah = *(const bf16x8*)(A_hi + addr);
 #pragma unroll
           for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = mfma16<PREC>(ah, bfr[nf], acc[mf][nf]);
-          if (PREC == 2) {
+          if (PREC == 2 || PREC == 4) {
             const bf16x8 alo = *(const bf16x8*)(A_lo + addr);
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = mfma16<PREC>(alo, bfr[nf], acc[mf][nf]);
@@ -750,6 +778,10 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws3_kernel(const mi35
         al[0] = a4.x; al[1] = a4.y; al[2] = a4.z; al[3] = a4.w;
 #pragma unroll
         for (int i = 0; i < 4; ++i) ial[i] = 1.0f / al[i];
+      if (a.pre_inv_beta) {  // SnakeBeta: x + sin^2(alpha x) * inv_beta[c]
+        const float4 b4 = *(const float4*)(a.pre_inv_beta + c);
+        ial[0] = b4.x; ial[1] = b4.y; ial[2] = b4.z; ial[3] = b4.w;
+      }
       }
 #pragma unroll
       for (int i = 0; i < kWsNld; ++i) {
@@ -766,15 +798,15 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws3_kernel(const mi35
             else if (a.pre_act == MI355_ACT_SNAKE) {
               const float s = __sinf(al[j] * t);
               t = t + ial[j] * (s * s);
-            }
+            } else if (a.pre_act == MI355_ACT_ELU) t = t > 0.f ? t : expm1f(t);
             t = (rowok && (c + j) < a.Cin) ? t : 0.f;
-            const float h = PREC == 3 ? t : bf16_bits_to_f32(f32_to_bf16_bits(t));
+            const float h = split_hi<PREC>(t);
             hi[j] = h;
             lo[j] = t - h;
           }
           const int addr = r * 64 + ((((c4 >> 3) ^ ((r >> 2) & 3))) << 4) + ((c4 & 4) << 1);
           uint2 ph;
-          if constexpr (PREC == 3) {
+          if constexpr (PREC >= 3) {
             ph.x = pack_f16x2(hi[0], hi[1]);
             ph.y = pack_f16x2(hi[2], hi[3]);
           } else {
@@ -782,10 +814,10 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws3_kernel(const mi35
             ph.y = pack_bf16x2(hi[2], hi[3]);
           }
           *(uint2*)(A_hi + addr) = ph;
-          if (PREC == 2) {
+          if (PREC == 2 || PREC == 4) {
             uint2 pl;
-            pl.x = pack_bf16x2(lo[0], lo[1]);
-            pl.y = pack_bf16x2(lo[2], lo[3]);
+            pl.x = pack_lo<PREC>(lo[0], lo[1]);
+            pl.y = pack_lo<PREC>(lo[2], lo[3]);
             *(uint2*)(A_lo + addr) = pl;
           }
         }
@@ -879,7 +911,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws3_kernel(const mi35
           else ah = *(const bf16x8*)(A_hi + addr);
 #pragma unroll
           for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = mfma16<PREC>(ah, bf[nf * 2 + kk], acc[mf][nf]);
-          if (PREC == 2) {
+          if (PREC == 2 || PREC == 4) {
             bf16x8 alo;
             if constexpr ((ABL & 2) != 0) alo = bf[(mf + kk + 1) & 3];
             else alo = *(const bf16x8*)(A_lo + addr);
@@ -942,7 +974,7 @@ int launch_ws3(const mi355_conv_gemm_args& a, hipStream_t st) {
   const int tiles_per_item = (a.Lout + 127) / 128;
   const int P = a.B * tiles_per_item;
   const int NT = (a.Cout + 127) / 128;
-  const int fold = (a.res || a.accumulate) && a.post_act == MI355_ACT_NONE && a.up_s == 0 && a.res_shift == 0;
+  const int fold = (a.res || a.accumulate) && a.post_act == MI355_ACT_NONE && a.up_s == 0 && a.res_shift == 0 && !a.post_colscale;
   const unsigned grid = (unsigned)(((P + 7) / 8) * 8 * NT);
   MI355_CLEAR_ERROR();
   hipLaunchKernelGGL((conv_gemm_ws3_kernel<PREC, ABL>), dim3(grid), dim3(kWsThreads), lds, st, a, tiles_per_item, P, NT, fold);
@@ -964,7 +996,7 @@ int launch_ws(const mi355_conv_gemm_args& a, hipStream_t st) {
   const int tiles_per_item = (a.Lout + 127) / 128;
   const int P = a.B * tiles_per_item;
   const int NT = (a.Cout + 127) / 128;
-  const int fold = (a.res || a.accumulate) && a.post_act == MI355_ACT_NONE && a.up_s == 0 && a.res_shift == 0;
+  const int fold = (a.res || a.accumulate) && a.post_act == MI355_ACT_NONE && a.up_s == 0 && a.res_shift == 0 && !a.post_colscale;
   static const int rot = getenv("MI355_CONV_NO_ROT") ? 0 : 1;  // A/B aid: lockstep walk order
   const unsigned grid = (unsigned)(((P + 7) / 8) * 8 * NT);
   MI355_CLEAR_ERROR();
@@ -1006,7 +1038,7 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
   MI355_REQUIRE(!a.up_s || (a.up_cout > 0 && a.Cout % a.up_cout == 0 && a.Cout / a.up_cout == a.up_s),
                 "conv_gemm: polyphase store needs Cout == up_s*up_cout");
   if (a.precision == 0) a.precision = 2;
-  MI355_REQUIRE(a.precision >= 1 && a.precision <= 3, "conv_gemm: precision must be 1, 2 or 3");
+  MI355_REQUIRE(a.precision >= 1 && a.precision <= 4, "conv_gemm: precision must be 1, 2, 3 or 4");
   if (a.out_scale == 0.f) a.out_scale = 1.f;
   hipStream_t st = (hipStream_t)stream;
   const bool vec = (a.flat_valid == 0) && (a.ldx % 4 == 0) && (a.x_off % 4 == 0) && (a.x_bstride % 4 == 0) &&
@@ -1050,14 +1082,16 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
   }
   if (tile == 7128128) {  // weights through registers, one barrier per chunk
     MI355_REQUIRE(ws_ok, "conv_gemm: the wave-specialised tile needs a 16-B aligned channels-last input and (K-1)*dil <= 64");
-    return a.precision == 2 ? launch_ws3<2>(a, st) : (a.precision == 3 ? launch_ws3<3>(a, st) : launch_ws3<1>(a, st));
+    return a.precision == 2 ? launch_ws3<2>(a, st) : (a.precision == 3 ? launch_ws3<3>(a, st) : (a.precision == 4 ? launch_ws3<4>(a, st) : launch_ws3<1>(a, st)));
   }
   if (tile == 8128128 || tile == 9128128) {  // 8...: producers stream the weights; 9...: consumers do (see the kernel header)
     MI355_REQUIRE(ws_ok, "conv_gemm: the wave-specialised tile needs a 16-B aligned channels-last input and (K-1)*dil <= 64");
+    MI355_REQUIRE(a.precision != 4, "conv_gemm: precision 4 runs on the 4-wave and 7128128 kernels only");
     return tile == 9128128 ? launch_ws_prec<true>(a, st) : launch_ws_prec<false>(a, st);
   }
   if (!vec) {
     if (a.precision == 3) return launch<64, 64, 3, false>(a, st);
+    if (a.precision == 4) return launch<64, 64, 4, false>(a, st);
     a.precision = 2;  // with bf16 weights the unaligned (tiny C_in) path always runs the hi+lo split
     return launch<64, 64, 2, false>(a, st);
   }
@@ -1072,6 +1106,12 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
       case 128128: return launch<128, 128, 3, true>(a, st);
       case 64128: return launch<64, 128, 3, true>(a, st);
       case 64064: return launch<64, 64, 3, true>(a, st);
+    }
+  } else if (a.precision == 4) {
+    switch (tile) {
+      case 128128: return launch<128, 128, 4, true>(a, st);
+      case 64128: return launch<64, 128, 4, true>(a, st);
+      case 64064: return launch<64, 64, 4, true>(a, st);
     }
   } else {
     switch (tile) {

@@ -1,0 +1,188 @@
+// Whisper greedy decode step on device: logit filters + token selection + log-prob bookkeeping (gfx950).
+//
+// Replaces, per generated token, the chain SuppressBlank.apply -> SuppressTokens.apply -> ApplyTimestampRules.apply ->
+// GreedyDecoder.update (stt/models/whisper/decoding.py:333-443, 302-330) that the reference evaluates as ~20 separate MLX
+// ops plus a `tokens.tolist()` device->host round trip per step (decoding.py:390).  One workgroup per sequence walks the
+// vocabulary row (V = 51865) five times out of L2; nothing returns to the host, so the decode loop can be enqueued for a
+// fixed number of steps without synchronising.
+//
+// Reference quirk kept on purpose: ApplyTimestampRules builds `timestamps` as the *indices* i of sampled tokens above
+// timestamp_begin and then masks `timestamp_begin : last_timestamp` with that small index (decoding.py:410-419), which is
+// an empty slice -- the "timestamps must not decrease" rule of the original OpenAI implementation is a no-op in the
+// reference, and therefore here.
+#include "common.h"
+
+namespace {
+
+constexpr int kT = 1024;
+
+struct ArgMax { float v; int i; };
+
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < kT / 64; ++i) r = fmaxf(r, red[i]);
+  return r;
+}
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < kT / 64; ++i) r += red[i];
+  return r;
+}
+__device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) {
+  // larger value wins; on ties the smaller index (mx.argmax returns the first maximum)
+  if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
+  return a;
+}
+__device__ __forceinline__ ArgMax block_argmax(ArgMax x, float* redv, int* redi) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ArgMax y;
+    y.v = __shfl_xor(x.v, o, 64);
+    y.i = __shfl_xor(x.i, o, 64);
+    x = better(x, y);
+  }
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { redv[w] = x.v; redi[w] = x.i; }
+  __syncthreads();
+  ArgMax r;
+  r.v = redv[0]; r.i = redi[0];
+  for (int i = 1; i < kT / 64; ++i) { ArgMax y; y.v = redv[i]; y.i = redi[i]; r = better(r, y); }
+  return r;
+}
+
+__global__ __launch_bounds__(kT) void whisper_greedy_step_kernel(const mi355_whisper_step_args a) {
+  __shared__ float red[kT / 64];
+  __shared__ int redi[kT / 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* lg = a.logits + (int64_t)b * a.ld;
+  int32_t* tk = a.tokens + (int64_t)b * a.tokens_ld;
+  const int n = a.n, nseq = n - a.sample_begin;
+  const int last = n >= 1 ? tk[n - 1] : -1;
+  const bool first = n == a.sample_begin;
+  const bool last_ts = nseq >= 1 && last >= a.timestamp_begin;
+  const bool pen_ts = nseq < 2 || tk[n - 2] >= a.timestamp_begin;
+  const float NEG = -INFINITY;
+
+  auto l1 = [&](int v) -> float {  // logits after SuppressBlank and SuppressTokens
+    float x = lg[v];
+    if (first && a.blank_ids)
+      for (int i = 0; i < a.n_blank; ++i) if (a.blank_ids[i] == v) x = NEG;
+    if (a.suppress_mask) x += a.suppress_mask[v];
+    return x;
+  };
+  auto mask2 = [&](int v) -> float {  // ApplyTimestampRules, before the timestamp-dominance rule
+    if (!a.timestamp_rules) return 0.f;
+    if (v == a.no_timestamps) return NEG;
+    if (last_ts) {
+      if (pen_ts) { if (v >= a.timestamp_begin) return NEG; }
+      else if (v < a.eot) return NEG;
+    }
+    if (first) {
+      if (v < a.timestamp_begin) return NEG;
+      if (a.max_initial_timestamp_index >= 0 && v > a.timestamp_begin + a.max_initial_timestamp_index) return NEG;
+    }
+    return 0.f;
+  };
+
+  bool text_killed = false;
+  if (a.timestamp_rules) {
+    // logprobs = l1 - logsumexp(l1); compare logsumexp(logprobs[ts:]) with max(logprobs[:ts])
+    float mx = NEG;
+    for (int v = tid; v < a.V; v += kT) mx = fmaxf(mx, l1(v));
+    mx = block_max(mx, red);
+    float s = 0.f;
+    for (int v = tid; v < a.V; v += kT) s += expf(l1(v) - mx);
+    s = block_sum(s, red);
+    const float lse = mx + logf(s);
+    float mts = NEG, mtext = NEG;
+    for (int v = tid; v < a.V; v += kT) {
+      const float lp = l1(v) - lse;
+      if (v >= a.timestamp_begin) mts = fmaxf(mts, lp); else mtext = fmaxf(mtext, lp);
+    }
+    mts = block_max(mts, red);
+    mtext = block_max(mtext, red);
+    float sts = 0.f;
+    for (int v = a.timestamp_begin + tid; v < a.V; v += kT) sts += expf((l1(v) - lse) - mts);
+    sts = block_sum(sts, red);
+    const float ts_lp = mts + logf(sts);
+    text_killed = ts_lp > mtext;
+  }
+
+  auto fin = [&](int v) -> float {
+    float x = l1(v) + mask2(v);
+    if (text_killed && v < a.timestamp_begin) x = NEG;
+    return x;
+  };
+
+  ArgMax best; best.v = NEG; best.i = 0x7fffffff;
+  ArgMax bsel; bsel.v = NEG; bsel.i = 0x7fffffff;
+  float fmx = NEG;
+  for (int v = tid; v < a.V; v += kT) {
+    const float x = fin(v);
+    if (a.filtered) a.filtered[(int64_t)b * a.ld + v] = x;
+    fmx = fmaxf(fmx, x);
+    ArgMax c; c.v = x; c.i = v;
+    best = better(best, c);
+    if (a.gumbel) { ArgMax d; d.v = x / a.temperature + a.gumbel[(int64_t)b * a.ld + v]; d.i = v; bsel = better(bsel, d); }
+  }
+  best = block_argmax(best, red, redi);
+  if (a.gumbel) best = block_argmax(bsel, red, redi);
+  fmx = block_max(fmx, red);
+  float fs = 0.f;
+  for (int v = tid; v < a.V; v += kT) fs += expf(fin(v) - fmx);
+  fs = block_sum(fs, red);
+  if (tid == 0) {
+    const int chosen = a.forced_next ? a.forced_next[b] : best.i;
+    const float lp = fin(chosen) - (fmx + logf(fs));
+    const bool done = last == a.eot;
+    if (!done) a.sum_logprobs[b] += lp;
+    tk[n] = done ? a.eot : chosen;
+  }
+}
+
+__global__ __launch_bounds__(kT) void softmax_prob_at_kernel(const float* logits, int ld, int V, int token, float* out) {
+  __shared__ float red[kT / 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* lg = logits + (int64_t)b * ld;
+  float mx = -INFINITY;
+  for (int v = tid; v < V; v += kT) mx = fmaxf(mx, lg[v]);
+  mx = block_max(mx, red);
+  float s = 0.f;
+  for (int v = tid; v < V; v += kT) s += expf(lg[v] - mx);
+  s = block_sum(s, red);
+  if (tid == 0) out[b] = expf(lg[token] - mx) / s;
+}
+
+}  // namespace
+
+extern "C" int mi355_whisper_greedy_step(const mi355_whisper_step_args* ap, void* stream) {
+  MI355_REQUIRE(ap && ap->logits && ap->tokens && ap->sum_logprobs, "whisper_greedy_step: null tensor");
+  const mi355_whisper_step_args a = *ap;
+  MI355_REQUIRE(a.B > 0 && a.V > 0 && a.ld >= a.V, "whisper_greedy_step: bad shape");
+  MI355_REQUIRE(a.n >= 1 && a.n < a.tokens_ld && a.sample_begin <= a.n, "whisper_greedy_step: token buffer too small or n < sample_begin");
+  MI355_REQUIRE(!a.timestamp_rules || (a.timestamp_begin > 0 && a.timestamp_begin < a.V && a.eot >= 0), "whisper_greedy_step: bad timestamp ids");
+  MI355_REQUIRE(!a.gumbel || a.temperature > 0.f, "whisper_greedy_step: sampling needs temperature > 0");
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(whisper_greedy_step_kernel, dim3(a.B), dim3(kT), 0, (hipStream_t)stream, a);
+  MI355_LAUNCH_CHECK("whisper_greedy_step");
+  return MI355_OK;
+}
+
+extern "C" int mi355_softmax_prob_at(const float* logits, int32_t ld, int32_t V, int32_t B, int32_t token, float* out, void* stream) {
+  MI355_REQUIRE(logits && out && B > 0 && V > 0 && token >= 0 && token < V, "softmax_prob_at: bad arguments");
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(softmax_prob_at_kernel, dim3(B), dim3(kT), 0, (hipStream_t)stream, logits, (int)ld, (int)V, (int)token, out);
+  MI355_LAUNCH_CHECK("softmax_prob_at");
+  return MI355_OK;
+}

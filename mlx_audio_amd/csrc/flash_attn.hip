@@ -1,0 +1,301 @@
+// Scaled-dot-product attention for the transformer blocks under mlx_audio/stt and mlx_audio/tts (gfx950).
+//
+// Replaces (reference call sites):
+//   - Whisper MultiHeadAttention.qkv_attention: q@k, + causal mask, softmax(precise=True), w@v
+//     (stt/models/whisper/whisper.py:371-385) for the encoder (1500 x 1500), the decoder prefill and decode steps;
+//   - mx.fast.scaled_dot_product_attention with GQA + additive causal mask + KVCache
+//     (tts/models/qwen3_tts/talker.py:307, speech_tokenizer.py transformer, codec/models/mimi/modules/transformer.py:109,
+//     lm/models/llama.py / sesame/attention.py for CSM).
+//
+// Two kernels, both exact-f32 arithmetic (activations in this library are fp32, SURVEY section 8 header):
+//
+//   flash_attn_kernel<DH>  (Tq > 8): one workgroup = 128 queries x one head, 4 waves x 32 queries.  K / V stream
+//     through LDS in 64-key (DH = 64) / 32-key (DH = 128) stages (register prefetch of the next stage under the MFMAs).  Both contractions run on
+//     v_mfma_f32_32x32x2_f32 in the TRANSPOSED orientation, S^T = K Q^T and O^T += V^T P^T, so that a lane owns ONE
+//     query column (l & 31) of every accumulator: the online-softmax max / sum / rescale are per-lane scalars plus a
+//     single xor-32 exchange between the two half-waves (which hold interleaved key rows of the same query), and the
+//     probabilities feed the second MFMA straight from the accumulator registers -- with the key order of step s
+//     chosen as the C-layout row order ((s&3) + 8*(s>>2) + 4*(lane>>5)) no data movement is needed at all.
+//     LDS rows are padded to DH+1 floats: the A-operand ds_read_b32 of both phases is bank-conflict free.
+//
+//   attn_decode_kernel<DH> (Tq <= 8, the KV-cache decode step): one workgroup per (query, head, item); the 4 waves
+//     take interleaved 64-key chunks, lanes own keys for q.k (float4 row reads) and own channels for p.V, online
+//     softmax per wave, merged through LDS at the end.  An MFMA tile would be 31/32 idle here; this path is bound by
+//     reading the KV cache once.
+//
+// Visibility of key j for query i of item b (len_q / len_k = valid rows, queries are the LAST len_q positions):
+//   j < len_k,  causal: j <= i + (len_k - len_q),  window W > 0: j > i + (len_k - len_q) - W.
+// Invisible keys get probability exactly 0 (the reference adds -1e9 / -inf style masks: identical after softmax).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void wave_lds_sync2() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr float kLog2e = 1.4426950408889634f;
+
+template <int DH>
+__global__ __launch_bounds__(256) void flash_attn_kernel(const mi355_flash_attn_args a) {
+  constexpr int KB = DH == 64 ? 64 : 32;  // keys per LDS stage (two padded fp32 tiles must fit 64 KB of static LDS)
+  constexpr int LD = DH + 1;   // padded LDS row, floats
+  constexpr int NDB = DH / 32; // 32-channel blocks of the output
+  constexpr int NLD = (KB * DH / 4) / 256;  // float4 loads per thread per stage and tensor
+  __shared__ float Ks[KB * LD];
+  __shared__ float Vs[KB * LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int g = h / (a.heads / a.kv_heads);
+  const int len_q = a.lens_q ? a.lens_q[b] : a.Tq;
+  const int len_k = a.lens_k ? a.lens_k[b] : a.Tk;
+  const int q0 = blockIdx.x * 128;
+  if (q0 >= len_q || len_k <= 0) return;
+  const int qoff = len_k - len_q;
+  const int qi = q0 + wave * 32 + (lane & 31);
+  const bool wave_active = (q0 + wave * 32) < len_q;
+  const int qic = qi < len_q ? qi : len_q - 1;
+  const int qpos = qic + qoff;  // absolute position of this lane's query
+
+  // Q fragment: B operand of S^T = K Q^T; step s needs Q[q][2s + half] (pre-scaled, log2 domain)
+  float qreg[DH / 2];
+  {
+    const float* qrow = a.q + (int64_t)b * a.q_bstride + (int64_t)qic * a.ldq + h * DH;
+    const float sc = a.scale * kLog2e;
+#pragma unroll
+    for (int s = 0; s < DH / 2; ++s) {
+      const float2 t = *(const float2*)(qrow + 2 * s);
+      qreg[s] = (half ? t.y : t.x) * sc;
+    }
+  }
+
+  // key range this workgroup needs
+  int kend = len_k, kbeg = 0;
+  if (a.causal) {
+    const int last_q = (q0 + 127 < len_q ? q0 + 127 : len_q - 1) + qoff;
+    kend = last_q + 1 < len_k ? last_q + 1 : len_k;
+    if (kend < 1) kend = 1;
+  }
+  if (a.window > 0) {
+    kbeg = q0 + qoff - a.window + 1;
+    if (kbeg < 0) kbeg = 0;
+    kbeg &= ~(KB - 1);
+  }
+
+  const float* kbase = a.k + (int64_t)b * a.k_bstride + g * DH;
+  const float* vbase = a.v + (int64_t)b * a.v_bstride + g * DH;
+
+  float4 kpre[NLD], vpre[NLD];
+  auto prefetch = [&](int kb) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = i * 256 + tid;
+      const int row = e / (DH / 4), c4 = e % (DH / 4);
+      int j = kb + row;
+      j = j < len_k ? j : len_k - 1;  // clamp: finite data, masked below
+      kpre[i] = *(const float4*)(kbase + (int64_t)j * a.ldk + c4 * 4);
+      vpre[i] = *(const float4*)(vbase + (int64_t)j * a.ldv + c4 * 4);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = i * 256 + tid;
+      const int row = e / (DH / 4), c4 = e % (DH / 4);
+      float* kd = Ks + row * LD + c4 * 4;
+      float* vd = Vs + row * LD + c4 * 4;
+      kd[0] = kpre[i].x; kd[1] = kpre[i].y; kd[2] = kpre[i].z; kd[3] = kpre[i].w;
+      vd[0] = vpre[i].x; vd[1] = vpre[i].y; vd[2] = vpre[i].z; vd[3] = vpre[i].w;
+    }
+  };
+
+  f32x16 o[NDB];
+#pragma unroll
+  for (int d = 0; d < NDB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m = -INFINITY, lsum = 0.f;
+
+  prefetch(kbeg);
+  for (int kb = kbeg; kb < kend; kb += KB) {
+    __syncthreads();  // everyone is done reading the previous stage
+    commit();
+    __syncthreads();
+    if (kb + KB < kend) prefetch(kb + KB);
+    if (!wave_active) continue;
+#pragma unroll
+    for (int sub = 0; sub < KB / 32; ++sub) {
+      const int kb32 = kb + sub * 32;
+      if (kb32 >= kend) break;
+      // ---- S^T block (32 keys x 32 queries)
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* krow = Ks + (sub * 32 + (lane & 31)) * LD + half;
+#pragma unroll
+      for (int s = 0; s < DH / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[2 * s], qreg[s], acc, 0, 0, 0);
+      // ---- mask + online softmax (per-lane query)
+      float bm = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = kb32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        bool vis = j < len_k;
+        if (a.causal) vis = vis && j <= qpos;
+        if (a.window > 0) vis = vis && j > qpos - a.window;
+        acc[r] = vis ? acc[r] : -INFINITY;
+        bm = fmaxf(bm, acc[r]);
+      }
+      bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+      const float m_new = fmaxf(m, bm);
+      const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+      const float alpha = exp2f(m - m_safe);  // m = -inf -> 0
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[r] = exp2f(acc[r] - m_safe);  // -inf -> 0
+        ps += acc[r];
+      }
+      lsum = lsum * alpha + ps;
+      m = m_new;
+#pragma unroll
+      for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+      // ---- O^T += V^T P^T : step s contracts keys (s&3) + 8*(s>>2) + 4*half, which is where acc[s] lives
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float* vrow = Vs + (sub * 32 + (s & 3) + 8 * (s >> 2) + 4 * half) * LD + (lane & 31);
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[d * 32], acc[s], o[d], 0, 0, 0);
+      }
+    }
+  }
+
+  if (!wave_active) return;
+  lsum += __shfl_xor(lsum, 32, 64);
+  const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+  if (qi < len_q) {
+    float* orow = a.out + (int64_t)b * a.out_bstride + (int64_t)qi * a.ldo + h * DH;
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 t = make_float4(o[d][c * 4] * inv, o[d][c * 4 + 1] * inv, o[d][c * 4 + 2] * inv, o[d][c * 4 + 3] * inv);
+        *(float4*)(orow + d * 32 + 8 * c + 4 * half) = t;
+      }
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const mi355_flash_attn_args a) {
+  constexpr int ND = DH / 64;  // channels per lane in the p.V phase
+  __shared__ float qs[DH];
+  __shared__ float ps[4][64];
+  __shared__ float red_m[4], red_l[4];
+  __shared__ float red_o[4][DH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qi = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int g = h / (a.heads / a.kv_heads);
+  const int len_q = a.lens_q ? a.lens_q[b] : a.Tq;
+  const int len_k = a.lens_k ? a.lens_k[b] : a.Tk;
+  if (qi >= len_q) return;
+  const int qpos = qi + (len_k - len_q);
+  if (tid < DH) qs[tid] = a.q[(int64_t)b * a.q_bstride + (int64_t)qi * a.ldq + h * DH + tid] * (a.scale * kLog2e);
+  __syncthreads();
+  int kend = len_k, kbeg = 0;
+  if (a.causal) kend = qpos + 1 < len_k ? qpos + 1 : len_k;
+  if (a.window > 0) { kbeg = qpos - a.window + 1; if (kbeg < 0) kbeg = 0; }
+  const float* kbase = a.k + (int64_t)b * a.k_bstride + g * DH;
+  const float* vbase = a.v + (int64_t)b * a.v_bstride + g * DH;
+  float m = -INFINITY, l = 0.f, o[ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i) o[i] = 0.f;
+  for (int kb = kbeg + wave * 64; kb < kend; kb += 256) {
+    const int j = kb + lane;
+    float s = -INFINITY;
+    if (j < kend) {
+      const float* krow = kbase + (int64_t)j * a.ldk;
+      float t = 0.f;
+#pragma unroll 4
+      for (int d = 0; d < DH; d += 4) {
+        const float4 kv = *(const float4*)(krow + d);
+        t = fmaf(qs[d], kv.x, t);
+        t = fmaf(qs[d + 1], kv.y, t);
+        t = fmaf(qs[d + 2], kv.z, t);
+        t = fmaf(qs[d + 3], kv.w, t);
+      }
+      s = t;
+    }
+    const float m_new = fmaxf(m, wave_max(s));  // finite: key kb itself is visible
+    const float alpha = exp2f(m - m_new);
+    const float p = exp2f(s - m_new);
+    l = l * alpha + wave_sum(p);
+    m = m_new;
+    ps[wave][lane] = p;
+    wave_lds_sync2();
+    const int n = kend - kb < 64 ? kend - kb : 64;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) o[i] *= alpha;
+    for (int jj = 0; jj < n; ++jj) {
+      const float pj = ps[wave][jj];
+      const float* vrow = vbase + (int64_t)(kb + jj) * a.ldv;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) o[i] = fmaf(pj, vrow[i * 64 + lane], o[i]);
+    }
+    wave_lds_sync2();
+  }
+  if (lane == 0) { red_m[wave] = m; red_l[wave] = l; }
+#pragma unroll
+  for (int i = 0; i < ND; ++i) red_o[wave][i * 64 + lane] = o[i];
+  __syncthreads();
+  if (wave == 0) {
+    float M = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+    float L = 0.f;
+    float w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      w[i] = red_m[i] == -INFINITY ? 0.f : exp2f(red_m[i] - M);
+      L += red_l[i] * w[i];
+    }
+    const float inv = L > 0.f ? 1.0f / L : 0.f;
+    float* orow = a.out + (int64_t)b * a.out_bstride + (int64_t)qi * a.ldo + h * DH;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int d = i * 64 + lane;
+      const float t = red_o[0][d] * w[0] + red_o[1][d] * w[1] + red_o[2][d] * w[2] + red_o[3][d] * w[3];
+      orow[d] = t * inv;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int mi355_flash_attention(const mi355_flash_attn_args* ap, void* stream) {
+  MI355_REQUIRE(ap && ap->q && ap->k && ap->v && ap->out, "flash_attention: null tensor");
+  const mi355_flash_attn_args a = *ap;
+  MI355_REQUIRE(a.dh == 64 || a.dh == 128, "flash_attention: head dim must be 64 or 128 (got %d)", a.dh);
+  MI355_REQUIRE(a.heads > 0 && a.kv_heads > 0 && a.heads % a.kv_heads == 0, "flash_attention: heads must be a multiple of kv_heads");
+  MI355_REQUIRE(a.B > 0 && a.Tq > 0 && a.Tk > 0, "flash_attention: bad shape");
+  MI355_REQUIRE(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && a.ldo % 4 == 0 && a.q_bstride % 4 == 0 && a.k_bstride % 4 == 0 &&
+                    a.v_bstride % 4 == 0 && a.out_bstride % 4 == 0,
+                "flash_attention: strides must be multiples of 4 floats");
+  MI355_REQUIRE(((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.out) % 16 == 0, "flash_attention: tensors must be 16-byte aligned");
+  MI355_REQUIRE(a.window >= 0, "flash_attention: window must be >= 0");
+  hipStream_t st = (hipStream_t)stream;
+  MI355_CLEAR_ERROR();
+  const bool decode = a.mode == 2 || (a.mode == 0 && a.Tq <= 8);
+  if (decode) {
+    dim3 grid(a.Tq, a.heads, a.B);
+    if (a.dh == 64) hipLaunchKernelGGL(attn_decode_kernel<64>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(attn_decode_kernel<128>, grid, dim3(256), 0, st, a);
+  } else {
+    dim3 grid((a.Tq + 127) / 128, a.heads, a.B);
+    if (a.dh == 64) hipLaunchKernelGGL(flash_attn_kernel<64>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(flash_attn_kernel<128>, grid, dim3(256), 0, st, a);
+  }
+  MI355_LAUNCH_CHECK("flash_attention");
+  return MI355_OK;
+}

@@ -1,0 +1,176 @@
+// Skinny GEMM for the autoregressive decode steps (1..8 rows): y[m, n] = epilogue(sum_k x[m, k] * W[n, k])  (gfx950).
+//
+// Replaces nn.Linear / nn.Embedding.as_linear at sequence length 1 under the Whisper TextDecoder
+// (stt/models/whisper/whisper.py:347-416, 498), the Qwen3-TTS talker / code predictor (tts/models/qwen3_tts/talker.py:
+// 230-330, 503-764) and the CSM Llama backbone / depth decoder (lm/models/llama.py:46-198, tts/models/sesame/sesame.py:361-404).
+// These steps read every weight once per generated token and do 2*M flops per weight: HBM-bound by a wide margin, so
+// the MFMA tile kernel (conv_gemm) is the wrong tool -- a 64-row tile with <= 8 live rows and N/128 workgroups cannot pull
+// bandwidth.  Here W stays in its natural row-major 16-bit layout [N, ldw] (bf16 or fp16, the checkpoint dtype); one
+// wavefront owns NC output columns, lanes stride K in 16-byte (8-element) pieces so every weight load is a fully coalesced
+// 1 KB wave access, x is staged in LDS once per workgroup in K-chunks, products accumulate in fp32 FMAs (exact on the
+// 16-bit weights) and a wave-level butterfly finishes each column.  Epilogue: bias, activation, residual, scale, and the
+// optional fused SwiGLU (interleaved gate / up rows: y[n/2] = silu(acc[n]) * acc[n+1]).
+#include "common.h"
+
+namespace {
+
+constexpr int kKC = 1024;  // K elements of x staged per chunk and row (8 rows x 1024 x 4 B = 32 KB of LDS)
+
+template <bool F16>
+__device__ __forceinline__ void cvt8(const uint4 w, float (&f)[8]) {
+  const uint32_t u[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if constexpr (F16) {
+      f[2 * i] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u[i] & 0xffffu));
+      f[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u[i] >> 16));
+    } else {
+      f[2 * i] = __builtin_bit_cast(float, u[i] << 16);
+      f[2 * i + 1] = __builtin_bit_cast(float, u[i] & 0xffff0000u);
+    }
+  }
+}
+
+__device__ __forceinline__ float gemv_act(float v, int act, float slope) {
+  switch (act) {
+    case MI355_ACT_LEAKY: return v > 0.f ? v : v * slope;
+    case MI355_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    case MI355_ACT_SILU: return v / (1.0f + expf(-v));
+    case MI355_ACT_GELU_TANH: return 0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v)));
+    case MI355_ACT_ELU: return v > 0.f ? v : expm1f(v);
+    case MI355_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+template <int MT, int NC, bool F16>
+__global__ __launch_bounds__(256) void gemv_kernel(const mi355_gemv_args a) {
+  __shared__ __attribute__((aligned(16))) float xs[MT * kKC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = (blockIdx.x * 4 + wave) * NC;
+  float acc[NC][MT];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[c][m] = 0.f;
+  const uint16_t* wrow[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int n = n0 + c < a.N ? n0 + c : a.N - 1;  // clamp: tail columns recompute the last row, never stored
+    wrow[c] = a.w + (int64_t)n * a.ldw;
+  }
+  for (int k0 = 0; k0 < a.K; k0 += kKC) {
+    const int kc = a.K - k0 < kKC ? a.K - k0 : kKC;  // multiple of 8 (K % 8 == 0)
+    __syncthreads();
+    for (int e = tid * 4; e < MT * kc; e += 1024) {
+      const int m = e / kc, k = e - m * kc;
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < a.M) t = *(const float4*)(a.x + (int64_t)m * a.ldx + k0 + k);
+      *(float4*)(xs + m * kKC + k) = t;
+    }
+    __syncthreads();
+    if (n0 < a.N) {
+      for (int k = lane * 8; k < kc; k += 512) {
+        uint4 wv[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) wv[c] = *(const uint4*)(wrow[c] + k0 + k);
+        float xv[MT][8];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const float4 lo = *(const float4*)(xs + m * kKC + k);
+          const float4 hi = *(const float4*)(xs + m * kKC + k + 4);
+          xv[m][0] = lo.x; xv[m][1] = lo.y; xv[m][2] = lo.z; xv[m][3] = lo.w;
+          xv[m][4] = hi.x; xv[m][5] = hi.y; xv[m][6] = hi.z; xv[m][7] = hi.w;
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          float wf[8];
+          cvt8<F16>(wv[c], wf);
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[c][m] = fmaf(xv[m][j], wf[j], acc[c][m]);
+        }
+      }
+    }
+  }
+  if (n0 >= a.N) return;
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[c][m] = wave_sum(acc[c][m]);
+  if (lane != 0) return;
+  if (a.glu) {  // columns come in (gate, up) pairs: NC is even on this path
+#pragma unroll
+    for (int c = 0; c + 1 < NC; c += 2) {
+      const int n = n0 + c;
+      if (n + 1 >= a.N) break;
+      const float bg = a.bias ? a.bias[n] : 0.f, bu = a.bias ? a.bias[n + 1] : 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        if (m >= a.M) break;
+        const float g = acc[c][m] + bg, u = acc[c + 1][m] + bu;
+        a.y[(int64_t)m * a.ldy + (n >> 1)] = (g / (1.0f + expf(-g))) * u * a.out_scale;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int n = n0 + c;
+    if (n >= a.N) break;
+    const float bias = a.bias ? a.bias[n] : 0.f;
+    const float cs = a.colscale ? a.colscale[n] : 1.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (m >= a.M) break;
+      float v = gemv_act(acc[c][m] + bias, a.post_act, a.post_slope) * cs;
+      if (a.res) v += a.res[(int64_t)m * a.ldr + n];
+      a.y[(int64_t)m * a.ldy + n] = v * a.out_scale;
+    }
+  }
+}
+
+template <int MT, bool F16>
+int launch_gemv(const mi355_gemv_args& a, hipStream_t st) {
+  // enough wavefronts to cover the chip before widening the per-wave column group
+  const int nc = a.glu ? (a.N >= 8192 ? 4 : 2) : (a.N >= 8192 ? 4 : (a.N >= 2048 ? 2 : 1));
+  MI355_CLEAR_ERROR();
+  if (nc == 4) hipLaunchKernelGGL((gemv_kernel<MT, 4, F16>), dim3((a.N + 15) / 16), dim3(256), 0, st, a);
+  else if (nc == 2) hipLaunchKernelGGL((gemv_kernel<MT, 2, F16>), dim3((a.N + 7) / 8), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((gemv_kernel<MT, 1, F16>), dim3((a.N + 3) / 4), dim3(256), 0, st, a);
+  MI355_LAUNCH_CHECK("gemv");
+  return MI355_OK;
+}
+
+template <bool F16>
+int launch_gemv_m(const mi355_gemv_args& a, hipStream_t st) {
+  if (a.M == 1) return launch_gemv<1, F16>(a, st);
+  if (a.M == 2) return launch_gemv<2, F16>(a, st);
+  if (a.M <= 4) return launch_gemv<4, F16>(a, st);
+  return launch_gemv<8, F16>(a, st);
+}
+
+}  // namespace
+
+extern "C" int mi355_gemv(const mi355_gemv_args* ap, void* stream) {
+  MI355_REQUIRE(ap && ap->x && ap->w && ap->y, "gemv: null tensor");
+  mi355_gemv_args a = *ap;
+  MI355_REQUIRE(a.M >= 1 && a.M <= 8, "gemv: M must be in [1, 8] (got %d); use conv_gemm for taller inputs", a.M);
+  MI355_REQUIRE(a.N > 0 && a.K > 0 && a.K % 8 == 0, "gemv: K must be a positive multiple of 8");
+  MI355_REQUIRE(a.ldw % 8 == 0 && a.ldw >= a.K && ((uintptr_t)a.w) % 16 == 0, "gemv: weight rows must be 16-byte aligned");
+  MI355_REQUIRE(a.ldx % 4 == 0 && ((uintptr_t)a.x) % 16 == 0, "gemv: x rows must be 16-byte aligned");
+  MI355_REQUIRE(a.wdtype == MI355_W_BF16 || a.wdtype == MI355_W_F16, "gemv: wdtype must be MI355_W_BF16 or MI355_W_F16");
+  MI355_REQUIRE(!a.glu || (a.N % 2 == 0 && !a.res && !a.colscale && a.post_act == MI355_ACT_NONE), "gemv: glu needs an even N and a plain epilogue");
+  if (a.out_scale == 0.f) a.out_scale = 1.f;
+  hipStream_t st = (hipStream_t)stream;
+  return a.wdtype == MI355_W_F16 ? launch_gemv_m<true>(a, st) : launch_gemv_m<false>(a, st);
+}
+
+// fp32 [rows, cols] (host) -> row-major 16-bit image for mi355_gemv (and for embedding tables kept in the checkpoint dtype)
+extern "C" int mi355_pack_rowmajor16_host(const float* w, int64_t n, int32_t dtype, uint16_t* out) {
+  MI355_REQUIRE(w && out && n >= 0, "pack_rowmajor16: bad arguments");
+  MI355_REQUIRE(dtype == MI355_W_BF16 || dtype == MI355_W_F16, "pack_rowmajor16: dtype must be MI355_W_BF16 or MI355_W_F16");
+  for (int64_t i = 0; i < n; ++i) out[i] = dtype == MI355_W_F16 ? host_f32_to_f16(w[i]) : host_f32_to_bf16(w[i]);
+  return MI355_OK;
+}

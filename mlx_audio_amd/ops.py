@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 
-ACT_NONE, ACT_LEAKY, ACT_SNAKE, ACT_GELU = 0, 1, 2, 3
+ACT_NONE, ACT_LEAKY, ACT_SNAKE, ACT_GELU, ACT_ELU, ACT_SILU, ACT_GELU_TANH, ACT_TANH = 0, 1, 2, 3, 4, 5, 6, 7
 
 # bench.py's roofline leg: when a list is installed here every conv_gemm launch is bracketed by
 # events on the launch stream and (algorithmic flops, algorithmic bytes, start, end) is appended.
@@ -97,6 +97,48 @@ def _polyphase_weight(w_t: torch.Tensor, stride: int) -> torch.Tensor:
     return w
 
 
+@dataclass
+class RowMajor16:
+    """Row-major 16-bit weight image [N, K] for the decode-step GEMV (checkpoint dtype: bf16 or fp16)."""
+
+    w: torch.Tensor  # int16 [N, K] on device
+    bias: Optional[torch.Tensor]
+    n: int
+    k: int
+    f16: bool
+
+
+def pack_rowmajor16(w: torch.Tensor, bias: Optional[torch.Tensor], device, f16: bool = False) -> RowMajor16:
+    """``w``: float32 CPU tensor [N, K] (nn.Linear weight layout)."""
+    w = w.detach().to(torch.float32).contiguous().cpu()
+    n, k = w.shape
+    assert k % 8 == 0, "gemv needs K % 8 == 0"
+    lib = _lib.load()
+    out = np.empty(n * k, dtype=np.uint16)
+    rc = lib.mi355_pack_rowmajor16_host(w.numpy().ctypes.data, n * k, 1 if f16 else 0, out.ctypes.data)
+    _lib.check(rc, "mi355_pack_rowmajor16_host")
+    wd = torch.from_numpy(out.view(np.int16).reshape(n, k)).to(device)
+    bd = None if bias is None else bias.detach().to(torch.float32).contiguous().to(device)
+    return RowMajor16(wd, bd, n, k, f16)
+
+
+def gemv(x: torch.Tensor, rw: RowMajor16, y: torch.Tensor, *, post_act: int = ACT_NONE, post_slope: float = 0.0,
+         res: Optional[torch.Tensor] = None, colscale: Optional[torch.Tensor] = None, out_scale: float = 1.0, glu: bool = False,
+         use_bias: bool = True):
+    """y[m, :] = epilogue(x[m, :] @ W^T) for 1..8 rows; x / y / res are 2-D fp32 views with unit inner stride."""
+    assert x.dim() == 2 and y.dim() == 2 and x.stride(1) == 1 and y.stride(1) == 1 and x.dtype == torch.float32 and y.dtype == torch.float32
+    M = x.shape[0]
+    assert x.shape[1] == rw.k and y.shape[0] == M and y.shape[1] == (rw.n // 2 if glu else rw.n), (x.shape, y.shape, rw.n, rw.k)
+    kw = dict(x=_ptr(x), ldx=x.stride(0), M=M, K=rw.k, w=_ptr(rw.w), ldw=rw.w.stride(0), wdtype=1 if rw.f16 else 0, N=rw.n,
+              bias=_ptr(rw.bias) if use_bias else None, post_act=post_act, post_slope=post_slope, colscale=_ptr(colscale),
+              out_scale=out_scale, glu=int(glu), y=_ptr(y), ldy=y.stride(0))
+    if res is not None:
+        assert res.dim() == 2 and res.stride(1) == 1
+        kw.update(res=_ptr(res), ldr=res.stride(0))
+    _lib.call_struct("mi355_gemv", "mi355_gemv_args", _stream(), **kw)
+    return y
+
+
 def pack_lstm_wh(wh_f: torch.Tensor, wh_b: torch.Tensor, device) -> torch.Tensor:
     H = wh_f.shape[1]
     lib = _lib.load()
@@ -116,20 +158,23 @@ def conv_gemm(x: torch.Tensor, pc: PackedConv, y: torch.Tensor, *, dil: int = 1,
               post_act: int = ACT_NONE, post_slope: float = 0.0, res: Optional[torch.Tensor] = None,
               res_shift: int = 0, out_scale: float = 1.0, accumulate: bool = False,
               up: Optional[dict] = None, precision: int = 2, tile: int = 0,
-              flat: Optional[dict] = None, use_bias: bool = True, stats: Optional[torch.Tensor] = None):
+              flat: Optional[dict] = None, use_bias: bool = True, stats: Optional[torch.Tensor] = None,
+              pre_inv_beta: Optional[torch.Tensor] = None, colscale: Optional[torch.Tensor] = None, x_off: int = 0):
     """y = epilogue(conv1d(prologue(x)))  -- see mi355_conv_gemm_args in the header."""
     B, Lin, Cx, xbs, ldx = _nlc(x)
     By, Ly, Cy, ybs, ldy = _nlc(y)
     assert B == By
     if pc.f16:
-        precision = 3  # the weight image decides: fp16-packed weights only fit the fp16 MFMA path
-    elif precision == 3:
-        raise _lib.Mi355Error("conv_gemm: precision 3 needs weights packed with f16=True")
-    kw = dict(x=_ptr(x), x_bstride=xbs, ldx=ldx, x_off=0, Cin=pc.cin, Lin=Lin, lens_in=_ptr(lens_in), flat_valid=0,
+        if precision not in (3, 4):
+            precision = 3  # the weight image decides: fp16-packed weights only fit the fp16 MFMA paths (3 single, 4 hi+lo)
+    elif precision in (3, 4):
+        raise _lib.Mi355Error("conv_gemm: precision 3 / 4 need weights packed with f16=True")
+    kw = dict(x=_ptr(x), x_bstride=xbs, ldx=ldx, x_off=x_off, Cin=pc.cin, Lin=Lin, lens_in=_ptr(lens_in), flat_valid=0,
               w=_ptr(pc.w), Cout=pc.cout, K=pc.k, dil=dil, pad=pad, pre_act=pre_act, pre_slope=pre_slope,
               pre_alpha=_ptr(pre_alpha), bias=_ptr(pc.bias) if use_bias else None, post_act=post_act,
               post_slope=post_slope, out_scale=out_scale, accumulate=int(accumulate), y=_ptr(y), y_bstride=ybs, ldy=ldy,
-              Lout=lout if lout is not None else Ly, lens_out=_ptr(lens_out), B=B, precision=precision, tile=tile)
+              Lout=lout if lout is not None else Ly, lens_out=_ptr(lens_out), B=B, precision=precision, tile=tile,
+              pre_inv_beta=_ptr(pre_inv_beta), post_colscale=_ptr(colscale))
     if flat is not None:  # flattened strided conv: taps are contiguous in memory (C_in small)
         kw.update(ldx=flat["ldx"], x_off=flat["x_off"], flat_valid=flat["channels"])
     else:
@@ -222,6 +267,48 @@ def attention(qkv: torch.Tensor, heads: int, dh: int, out: torch.Tensor, lens=No
     _, _, _, obs, ldo = _nlc(out)
     _lib.call_struct("mi355_attention", "mi355_attention_args", _stream(), qkv=_ptr(qkv), bstride=bs, ld=ld, heads=heads,
                      dh=dh, T=T, lens=_ptr(lens), B=B, out=_ptr(out), out_bstride=obs, ldo=ldo)
+    return out
+
+
+def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, heads: int, kv_heads: Optional[int] = None,
+                    dh: int, scale: Optional[float] = None, causal: bool = False, window: int = 0, lens_q=None, lens_k=None,
+                    mode: int = 0):
+    """softmax(scale * q k^T + visibility) v.  q/out [B, Tq, >= heads*dh], k/v [B, Tk, >= kv_heads*dh] channels-last views
+    (a KV cache is just the buffer k / v point into); see mi355_flash_attn_args for the visibility rule."""
+    B, Tq, _, qbs, ldq = _nlc(q)
+    Bk, Tk, _, kbs, ldk = _nlc(k)
+    _, Tv, _, vbs, ldv = _nlc(v)
+    _, To, _, obs, ldo = _nlc(out)
+    assert Bk == B and Tv == Tk and To == Tq
+    _lib.call_struct("mi355_flash_attention", "mi355_flash_attn_args", _stream(), q=_ptr(q), q_bstride=qbs, ldq=ldq, k=_ptr(k),
+                     k_bstride=kbs, ldk=ldk, v=_ptr(v), v_bstride=vbs, ldv=ldv, heads=heads, kv_heads=kv_heads or heads, dh=dh,
+                     Tq=Tq, Tk=Tk, lens_q=_ptr(lens_q), lens_k=_ptr(lens_k), causal=int(causal), window=window,
+                     scale=(1.0 / math.sqrt(dh)) if scale is None else scale, B=B, mode=mode, out=_ptr(out), out_bstride=obs, ldo=ldo)
+    return out
+
+
+def whisper_greedy_step(logits: torch.Tensor, tokens: torch.Tensor, n: int, sample_begin: int, sum_logprobs: torch.Tensor, *,
+                        V: Optional[int] = None, suppress_mask=None, blank_ids=None, timestamp_rules: bool = False,
+                        timestamp_begin: int = 0, eot: int = 0, no_timestamps: int = -1, max_initial_timestamp_index: int = -1,
+                        gumbel=None, temperature: float = 0.0, filtered=None, forced_next=None):
+    """One decode step of decoding.py's filter chain + GreedyDecoder.update, in place on ``tokens[:, n]`` / ``sum_logprobs``."""
+    assert logits.dim() == 2 and logits.stride(1) == 1 and logits.dtype == torch.float32
+    assert tokens.dtype == torch.int32 and tokens.dim() == 2 and tokens.stride(1) == 1
+    B = logits.shape[0]
+    _lib.call_struct("mi355_whisper_greedy_step", "mi355_whisper_step_args", _stream(), logits=_ptr(logits), ld=logits.stride(0),
+                     V=V or logits.shape[1], B=B, tokens=_ptr(tokens), tokens_ld=tokens.stride(0), n=n, sample_begin=sample_begin,
+                     suppress_mask=_ptr(suppress_mask), blank_ids=_ptr(blank_ids), n_blank=0 if blank_ids is None else blank_ids.numel(),
+                     timestamp_rules=int(timestamp_rules), timestamp_begin=timestamp_begin, eot=eot, no_timestamps=no_timestamps,
+                     max_initial_timestamp_index=max_initial_timestamp_index, gumbel=_ptr(gumbel), temperature=temperature,
+                     sum_logprobs=_ptr(sum_logprobs), filtered=_ptr(filtered), forced_next=_ptr(forced_next))
+
+
+def softmax_prob_at(logits: torch.Tensor, token: int, V: Optional[int] = None) -> torch.Tensor:
+    assert logits.dim() == 2 and logits.stride(1) == 1 and logits.dtype == torch.float32
+    out = torch.empty((logits.shape[0],), dtype=torch.float32, device=logits.device)
+    lib = _lib.load()
+    rc = lib.mi355_softmax_prob_at(_ptr(logits), logits.stride(0), V or logits.shape[1], logits.shape[0], token, _ptr(out), _stream())
+    _lib.check(rc, "mi355_softmax_prob_at")
     return out
 
 

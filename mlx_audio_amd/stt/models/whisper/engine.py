@@ -1,0 +1,290 @@
+"""Whisper on MI355X: the host-side schedule over the HIP kernels (encoder, decoder with KV caches, decode loop).
+
+Mirrors ``AudioEncoder`` / ``TextDecoder`` / ``ResidualAttentionBlock`` (``stt/models/whisper/whisper.py:338-498``) and
+``DecodingTask._main_loop`` with its logit filters and ``GreedyDecoder`` (``decoding.py:302-443, 588-632``), with the
+reference's op-by-op graph collapsed into:
+
+  * conv stem: conv1 (+GELU) is one implicit-GEMM launch; the stride-2 conv2 is re-expressed on the host as a
+    stride-1, 2-tap conv over pairs of frames (rows of 2*C channels) so it runs on the aligned MFMA path, with GELU and
+    the sinusoidal position add in its epilogue;
+  * every Linear is conv_gemm (fp16 weights; ``precision`` 4 = fp16 hi+lo activations, 3 = the reference's own fp16
+    activation rounding) with bias / GELU / residual fused; q, k, v share one GEMM (K has no bias: zero entries);
+  * attention is ``mi355_flash_attention`` (f32 MFMA flash kernel for the encoder and the prefill, the KV-streaming kernel
+    for decode steps) reading K / V straight out of the caches the projection GEMMs wrote into;
+  * decode steps (1 row per sequence) switch every Linear to the HBM-bound ``mi355_gemv`` on the row-major fp16 image, and
+    the whole filter + arg-max + log-prob bookkeeping of a step is one kernel -- the loop runs without host round trips
+    (completion is polled every ``poll`` steps; results do not depend on when the loop stops).
+
+Everything here is plumbing (allocation, views, launch order); all arithmetic on activations is in libmi355audio.so.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .... import ops
+from ....ops import ACT_GELU, ACT_NONE, PackedConv, RowMajor16
+from .synthetic import ModelDimensions
+
+
+@dataclass
+class _Lin:
+    pc: PackedConv      # MFMA fragment order (prefill / encoder)
+    rm: RowMajor16      # row-major fp16 (decode-step GEMV)
+
+
+@dataclass
+class _LN:
+    w: torch.Tensor
+    b: torch.Tensor
+
+
+@dataclass
+class _Block:
+    attn_ln: _LN
+    qkv: _Lin            # self-attention q | k | v
+    q: _Lin              # decoder only: q alone (k | v go straight into the cache)
+    kv: _Lin
+    out: _Lin
+    cross_ln: Optional[_LN]
+    cq: Optional[_Lin]
+    ckv: Optional[_Lin]
+    cout: Optional[_Lin]
+    mlp_ln: _LN
+    mlp1: _Lin
+    mlp2: _Lin
+
+
+def sinusoids(length: int, channels: int, max_timescale: float = 10000) -> torch.Tensor:
+    """whisper.py:329-335 (host, float32)."""
+    inc = math.log(max_timescale) / (channels // 2 - 1)
+    inv = torch.exp(-inc * torch.arange(channels // 2, dtype=torch.float32))
+    st = torch.arange(length, dtype=torch.float32)[:, None] * inv[None, :]
+    return torch.cat([torch.sin(st), torch.cos(st)], dim=1)
+
+
+class WhisperEngine:
+    def __init__(self, weights: Dict[str, torch.Tensor], dims: ModelDimensions, device: str = "cuda:0", precision: int = 4):
+        ops.require_gpu()
+        assert precision in (3, 4)
+        self.dims = dims
+        self.device = torch.device(device)
+        self.precision = precision
+        self.dh = dims.n_audio_state // dims.n_audio_head
+        assert self.dh in (64, 128) and dims.n_text_state // dims.n_text_head == self.dh
+        assert max(dims.n_audio_state, dims.n_text_state) <= 1024, "layernorm kernel holds <= 1024 channels per row"
+        w = {k: v.detach().to(torch.float16).to(torch.float32).cpu() for k, v in weights.items()}  # checkpoint dtype: fp16
+        dev = self.device
+
+        def lin(wt, bias):
+            return _Lin(ops.pack_conv(wt, bias, dev, f16=True), ops.pack_rowmajor16(wt, bias, dev, f16=True))
+
+        def ln(name):
+            return _LN(w[name + ".weight"].to(dev), w[name + ".bias"].to(dev))
+
+        def block(pfx, n, cross):
+            def att(a):
+                wq, bq = w[f"{pfx}.{a}.query.weight"], w[f"{pfx}.{a}.query.bias"]
+                wk = w[f"{pfx}.{a}.key.weight"]
+                wv, bv = w[f"{pfx}.{a}.value.weight"], w[f"{pfx}.{a}.value.bias"]
+                z = torch.zeros(n)
+                return (lin(torch.cat([wq, wk, wv]), torch.cat([bq, z, bv])), lin(wq, bq), lin(torch.cat([wk, wv]), torch.cat([z, bv])),
+                        lin(w[f"{pfx}.{a}.out.weight"], w[f"{pfx}.{a}.out.bias"]))
+
+            qkv, q, kv, out = att("attn")
+            cq = ckv = cout = cln = None
+            if cross:
+                _, cq, ckv, cout = att("cross_attn")
+                cln = ln(f"{pfx}.cross_attn_ln")
+            return _Block(ln(f"{pfx}.attn_ln"), qkv, q, kv, out, cln, cq, ckv, cout, ln(f"{pfx}.mlp_ln"),
+                          lin(w[f"{pfx}.mlp1.weight"], w[f"{pfx}.mlp1.bias"]), lin(w[f"{pfx}.mlp2.weight"], w[f"{pfx}.mlp2.bias"]))
+
+        na = dims.n_audio_state
+        self.conv1 = ops.pack_conv(w["encoder.conv1.weight"], w["encoder.conv1.bias"], dev, f16=True)
+        # conv2 (k3, stride 2, pad 1) on rows of frame pairs r = (x[2r], x[2r+1]): out[t] = W0 x[2t-1] + W1 x[2t] + W2 x[2t+1]
+        #   = tap0 . row[t-1] (second half only) + tap1 . row[t]
+        w2 = w["encoder.conv2.weight"]
+        wp = torch.zeros(na, 2, 2 * na)
+        wp[:, 0, na:] = w2[:, 0, :]
+        wp[:, 1, :na] = w2[:, 1, :]
+        wp[:, 1, na:] = w2[:, 2, :]
+        self.conv2 = ops.pack_conv(wp, w["encoder.conv2.bias"], dev, f16=True)
+        self.enc_pos = sinusoids(dims.n_audio_ctx, na).to(torch.float16).to(torch.float32).to(dev)[None]  # whisper.py:434 .astype(dtype)
+        self.enc_blocks = [block(f"encoder.blocks.{i}", na, False) for i in range(dims.n_audio_layer)]
+        self.ln_post = ln("encoder.ln_post")
+        self.tok_emb = w["decoder.token_embedding.weight"].to(dev)
+        self.pos_emb = w["decoder.positional_embedding"].to(dev)
+        self.dec_blocks = [block(f"decoder.blocks.{i}", dims.n_text_state, True) for i in range(dims.n_text_layer)]
+        self.ln = ln("decoder.ln")
+        self.logits_lin = lin(w["decoder.token_embedding.weight"], None)  # tied: token_embedding.as_linear (whisper.py:498)
+
+    # ------------------------------------------------------------------ helpers
+    def _f(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    def _linear(self, x: torch.Tensor, l: _Lin, y: torch.Tensor, post_act: int = ACT_NONE, res: Optional[torch.Tensor] = None):
+        """y = act(x W^T + b) + res on [B, L, C] views; decode steps (L == 1, B <= 8) take the GEMV."""
+        B, L, _ = x.shape
+        if L == 1 and B <= 8:
+            ops.gemv(x[:, 0, :], l.rm, y[:, 0, :], post_act=post_act, res=None if res is None else res[:, 0, :])
+        else:
+            ops.conv_gemm(x, l.pc, y, post_act=post_act, res=res, precision=self.precision)
+        return y
+
+    def _lnorm(self, x, p: _LN):
+        return ops.layernorm(x, torch.empty_like(x), weight=p.w, bias=p.b, eps=1e-5)
+
+    # ------------------------------------------------------------------ encoder (whisper.py:438-448)
+    def encode(self, mel: torch.Tensor, return_layers: bool = False):
+        d = self.dims
+        mel = mel.to(self.device, torch.float32).contiguous()
+        B, Fr, nm = mel.shape
+        assert nm == d.n_mels and Fr == 2 * d.n_audio_ctx, "incorrect audio shape"
+        na, H, dh = d.n_audio_state, d.n_audio_head, self.dh
+        T = d.n_audio_ctx
+        y1 = self._f(B, Fr, na)
+        ops.conv_gemm(mel, self.conv1, y1, pad=1, post_act=ACT_GELU, precision=self.precision)
+        x = self._f(B, T, na)
+        ops.conv_gemm(y1.view(B, T, 2 * na), self.conv2, x, pad=1, post_act=ACT_GELU, res=self.enc_pos.expand(B, T, na),
+                      precision=self.precision)
+        layers = [x.clone()] if return_layers else None
+        qkv = self._f(B, T, 3 * na)
+        att = self._f(B, T, na)
+        mid = self._f(B, T, 4 * na)
+        for blk in self.enc_blocks:
+            h = self._lnorm(x, blk.attn_ln)
+            self._linear(h, blk.qkv, qkv)
+            ops.flash_attention(qkv[:, :, 0:na], qkv[:, :, na:2 * na], qkv[:, :, 2 * na:], att, heads=H, dh=dh, scale=dh ** -0.5)
+            self._linear(att, blk.out, x, res=x)
+            h = self._lnorm(x, blk.mlp_ln)
+            self._linear(h, blk.mlp1, mid, post_act=ACT_GELU)
+            self._linear(mid, blk.mlp2, x, res=x)
+            if return_layers:
+                layers.append(x.clone())
+        out = self._lnorm(x, self.ln_post)
+        return (out, layers) if return_layers else out
+
+    # ------------------------------------------------------------------ decoder (whisper.py:476-498)
+    def new_state(self, xa: torch.Tensor) -> dict:
+        """Allocates the self-attention KV caches and fills the cross-attention K / V (computed once, whisper.py:361-365)."""
+        d = self.dims
+        B, T, nt = xa.shape[0], xa.shape[1], d.n_text_state
+        st = dict(B=B, n=0, self_kv=[self._f(B, d.n_text_ctx, 2 * nt) for _ in self.dec_blocks], cross_kv=[])
+        for blk in self.dec_blocks:
+            ckv = self._f(B, T, 2 * nt)
+            ops.conv_gemm(xa, blk.ckv.pc, ckv, precision=self.precision)
+            st["cross_kv"].append(ckv)
+        return st
+
+    def decoder_step(self, tokens: torch.Tensor, st: dict) -> torch.Tensor:
+        """tokens int32 [B, n] (device view) appended at offset st['n'] -> final-LN hidden states [B, n, n_text_state]."""
+        d = self.dims
+        B, n = tokens.shape
+        off = st["n"]
+        assert off + n <= d.n_text_ctx
+        nt, H, dh = d.n_text_state, d.n_text_head, self.dh
+        x = self._f(B, n, nt)
+        ops.gather_rows(self.tok_emb, tokens, x, pos_table=self.pos_emb[off:off + n])
+        q = self._f(B, n, nt)
+        att = self._f(B, n, nt)
+        mid = self._f(B, n, 4 * nt)
+        for i, blk in enumerate(self.dec_blocks):
+            cache = st["self_kv"][i]
+            h = self._lnorm(x, blk.attn_ln)
+            self._linear(h, blk.q, q)
+            self._linear(h, blk.kv, cache[:, off:off + n, :])
+            ops.flash_attention(q, cache[:, :off + n, 0:nt], cache[:, :off + n, nt:], att, heads=H, dh=dh, scale=dh ** -0.5, causal=True)
+            self._linear(att, blk.out, x, res=x)
+            ckv = st["cross_kv"][i]
+            h = self._lnorm(x, blk.cross_ln)
+            self._linear(h, blk.cq, q)
+            ops.flash_attention(q, ckv[:, :, 0:nt], ckv[:, :, nt:], att, heads=H, dh=dh, scale=dh ** -0.5)
+            self._linear(att, blk.cout, x, res=x)
+            h = self._lnorm(x, blk.mlp_ln)
+            self._linear(h, blk.mlp1, mid, post_act=ACT_GELU)
+            self._linear(mid, blk.mlp2, x, res=x)
+        st["n"] = off + n
+        return self._lnorm(x, self.ln)
+
+    def logits(self, hidden: torch.Tensor) -> torch.Tensor:
+        """hidden [B, n, nt] -> [B, n, V_padded] fp32 (columns >= n_vocab are padding)."""
+        B, n, _ = hidden.shape
+        vp = ops.round_up(self.dims.n_vocab, 4)
+        out = self._f(B, n, vp)
+        self._linear(hidden, self.logits_lin, out[:, :, :self.dims.n_vocab])
+        return out
+
+    # ------------------------------------------------------------------ decode loop (decoding.py:588-632)
+    def decode(self, mel: Optional[torch.Tensor], tok, *, sample_len: Optional[int] = None, without_timestamps: bool = False,
+               suppress_blank: bool = True, suppress_tokens: Optional[Sequence[int]] = None, max_initial_timestamp: Optional[float] = 1.0,
+               forced_tokens: Optional[torch.Tensor] = None, audio_features: Optional[torch.Tensor] = None, record: bool = False,
+               poll: int = 16, fixed_steps: bool = False):
+        d = self.dims
+        xa = self.encode(mel) if audio_features is None else audio_features.to(self.device, torch.float32)
+        B = xa.shape[0]
+        dev = self.device
+        sot_sequence = tok.sot_sequence_including_notimestamps if without_timestamps else tok.sot_sequence
+        initial = list(sot_sequence)
+        sample_begin = len(initial)
+        sot_index = initial.index(tok.sot)
+        sample_len = sample_len or d.n_text_ctx // 2
+        cap = d.n_text_ctx + 2
+        tokens = torch.full((B, cap), tok.eot, dtype=torch.int32, device=dev)
+        tokens[:, :sample_begin] = torch.tensor(initial, dtype=torch.int32, device=dev)
+        sum_logprobs = torch.zeros(B, dtype=torch.float32, device=dev)
+        smask = None
+        if suppress_tokens is not None:
+            m = np.zeros(d.n_vocab, np.float32)
+            m[list(suppress_tokens)] = -np.inf
+            smask = torch.from_numpy(m).to(dev)
+        blank = None
+        if suppress_blank:
+            blank = torch.tensor(list(tok.blank_ids) + [tok.eot], dtype=torch.int32, device=dev)
+        ts_rules = not without_timestamps
+        max_idx = -1
+        if ts_rules and max_initial_timestamp:
+            max_idx = round(max_initial_timestamp / (30.0 / d.n_audio_ctx))
+        forced = None if forced_tokens is None else forced_tokens.to(dev, torch.int32).t().contiguous()  # [steps, B]
+        st = self.new_state(xa)
+        trace: List[dict] = []
+        no_speech = None
+        n = sample_begin
+        steps = 0
+        for i in range(sample_len):
+            if n > d.n_text_ctx:
+                break
+            if i == 0:
+                hid = self.decoder_step(tokens[:, :n], st)
+                lg_all = self.logits(hid)
+                no_speech = ops.softmax_prob_at(lg_all[:, sot_index, :], tok.no_speech, V=d.n_vocab)
+                lg = lg_all[:, n - 1, :]
+            else:
+                hid = self.decoder_step(tokens[:, n - 1:n], st)
+                lg = self.logits(hid)[:, 0, :]
+            filt = torch.empty((B, lg.stride(0)), dtype=torch.float32, device=dev) if record else None  # same row stride as lg
+            ops.whisper_greedy_step(lg, tokens, n, sample_begin, sum_logprobs, V=d.n_vocab, suppress_mask=smask, blank_ids=blank,
+                                    timestamp_rules=ts_rules, timestamp_begin=tok.timestamp_begin, eot=tok.eot,
+                                    no_timestamps=-1 if tok.no_timestamps is None else tok.no_timestamps,
+                                    max_initial_timestamp_index=max_idx, filtered=filt,
+                                    forced_next=None if forced is None else forced[i])
+            if record:
+                trace.append(dict(raw=lg[:, :d.n_vocab].clone(), filtered=filt[:, :d.n_vocab]))
+            n += 1
+            steps += 1
+            if forced is None and not fixed_steps and (steps % poll == 0):
+                if bool((tokens[:, n - 1] == tok.eot).all()):  # the only host round trip of the loop
+                    break
+        toks = tokens[:, :n].to(torch.long)
+        if forced is None and not fixed_steps:
+            # the reference stops right after the first step at which every sequence has emitted EOT (decoding.py:626)
+            t = toks.cpu()
+            all_eot = (t[:, sample_begin:] == tok.eot).all(dim=0)
+            if bool(all_eot.any()):
+                first = int(torch.nonzero(all_eot)[0]) + sample_begin
+                toks = toks[:, :first + 1]
+        return dict(tokens=toks, sum_logprobs=sum_logprobs, no_speech_probs=no_speech, trace=trace, sample_begin=sample_begin,
+                    audio_features=xa, steps=steps)

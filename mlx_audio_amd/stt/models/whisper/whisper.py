@@ -1,0 +1,240 @@
+"""Whisper behind the reference's model protocol (``Model(dims, dtype)``, ``sanitize``, ``embed_audio``, ``logits``,
+``__call__``, ``decode``, ``generate`` -> ``STTOutput`` -- ``stt/models/whisper/whisper.py:501-1320``), computing on
+MI355X through ``WhisperEngine``.
+
+Same as the reference: constructor / config (``ModelDimensions`` incl. the HuggingFace spelling), checkpoint key handling
+(``sanitize``: HF names, conv layouts, fp16 cast), ``embed_audio`` / ``logits`` / ``__call__``, ``decode(mel, options)``
+and its ``DecodingResult``, ``generate(audio, *, language, task, temperature, ..., **decode_options)`` returning
+``STTOutput(text, segments, language, ...)`` with 30 s windows advanced by the decoded timestamps.
+
+Deliberately not carried over (host front/back ends): file / stdin loading and resampling
+(``generate`` takes a waveform array at 16 kHz), word-level timestamps (DTW over cross-attention weights), streaming
+(AlignAtt), language detection by probability dict (``detect_language`` returns the arg-max language only), sampling
+fallback temperatures > 0 (the device loop is greedy; the fallback tuple collapses to its first entry).
+"""
+from __future__ import annotations
+
+import time
+from typing import Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from ..base import STTOutput
+from .audio import FRAMES_PER_SECOND, HOP_LENGTH, N_FRAMES, N_SAMPLES, SAMPLE_RATE, log_mel_spectrogram, pad_or_trim
+from .decoding import DecodingOptions, DecodingResult
+from .decoding import decode as decode_function
+from .synthetic import ModelDimensions
+from .tokenizer import LANGUAGES, get_tokenizer
+
+ModelConfig = ModelDimensions  # alias used by load_model (whisper.py:325)
+
+_DECODING_OPTION_NAMES = frozenset(DecodingOptions.__dataclass_fields__)
+
+_HF_KEY_MAP = [  # whisper.py:562-585; order matters
+    ("encoder.embed_positions.weight", None),
+    ("decoder.embed_positions.weight", "decoder.positional_embedding"),
+    ("encoder.layer_norm.", "encoder.ln_post."),
+    ("decoder.layer_norm.", "decoder.ln."),
+    ("encoder.layers.", "encoder.blocks."),
+    ("decoder.layers.", "decoder.blocks."),
+    (".self_attn_layer_norm.", ".attn_ln."),
+    (".final_layer_norm.", ".mlp_ln."),
+    (".encoder_attn_layer_norm.", ".cross_attn_ln."),
+    (".fc1.", ".mlp1."),
+    (".fc2.", ".mlp2."),
+    (".self_attn.q_proj.", ".attn.query."),
+    (".self_attn.k_proj.", ".attn.key."),
+    (".self_attn.v_proj.", ".attn.value."),
+    (".self_attn.out_proj.", ".attn.out."),
+    (".encoder_attn.q_proj.", ".cross_attn.query."),
+    (".encoder_attn.k_proj.", ".cross_attn.key."),
+    (".encoder_attn.v_proj.", ".cross_attn.value."),
+    (".encoder_attn.out_proj.", ".cross_attn.out."),
+    ("decoder.embed_tokens.", "decoder.token_embedding."),
+]
+
+
+def _filter_decode_options(decode_options: dict) -> dict:
+    return {k: v for k, v in decode_options.items() if k in _DECODING_OPTION_NAMES}
+
+
+class Model:
+    def __init__(self, dims: ModelDimensions, dtype: torch.dtype = torch.float16, device: str = "cuda", precision: int = 4):
+        self.dims = dims
+        self.dtype = dtype
+        self.device = device
+        self.precision = precision
+        self.engine = None
+        self.model_path = None
+        self.codec = None  # optional vocabulary object (encode / decode)
+
+    # ------------------------------------------------------------------ checkpoint handling
+    def sanitize(self, weights: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        is_hf = any(k.startswith("model.") for k in weights)
+        out: Dict[str, torch.Tensor] = {}
+        for k, v in weights.items():
+            if is_hf:
+                if k.startswith("model."):
+                    k = k[6:]
+                skip = False
+                for old, new in _HF_KEY_MAP:
+                    if old in k:
+                        if new is None:
+                            skip = True
+                            break
+                        k = k.replace(old, new)
+                if skip:
+                    continue
+                if ("conv1.weight" in k or "conv2.weight" in k) and v.dim() == 3:
+                    v = v.permute(0, 2, 1).contiguous()
+            if v.is_floating_point() and v.dtype != self.dtype:
+                v = v.to(self.dtype)
+            out[k] = v
+        return out
+
+    def load_weights(self, weights, strict: bool = True):
+        from .engine import WhisperEngine
+
+        w = dict(weights)
+        try:
+            self.engine = WhisperEngine({k: v.to(torch.float32) for k, v in w.items() if v.is_floating_point()}, self.dims,
+                                        device=self.device, precision=self.precision)
+        except KeyError as e:
+            raise ValueError(f"Whisper checkpoint is missing parameter {e}") from e
+        return self
+
+    def eval(self):
+        return self
+
+    def _need_engine(self):
+        if self.engine is None:
+            raise RuntimeError("Model has no weights: call load_weights() (or mlx_audio_amd.stt.utils.load_model)")
+        return self.engine
+
+    # ------------------------------------------------------------------ forward surface (whisper.py:620-642)
+    def embed_audio(self, mel: torch.Tensor) -> torch.Tensor:
+        single = mel.dim() == 2
+        out = self._need_engine().encode(mel[None] if single else mel)
+        return out[0] if single else out
+
+    def logits(self, tokens: torch.Tensor, audio_features: torch.Tensor) -> torch.Tensor:
+        eng = self._need_engine()
+        xa = audio_features.to(eng.device, torch.float32)
+        st = eng.new_state(xa)
+        hid = eng.decoder_step(tokens.to(eng.device, torch.int32).contiguous(), st)
+        return eng.logits(hid)[:, :, : self.dims.n_vocab]
+
+    def __call__(self, mel: torch.Tensor, tokens: torch.Tensor) -> torch.Tensor:
+        return self.logits(tokens, self.embed_audio(mel))
+
+    @property
+    def is_multilingual(self) -> bool:
+        return self.dims.n_vocab >= 51865
+
+    @property
+    def num_languages(self) -> int:
+        return self.dims.n_vocab - 51765 - int(self.is_multilingual)
+
+    def get_tokenizer(self, language: str = None, task: str = "transcribe"):
+        return get_tokenizer(self.is_multilingual, num_languages=self.num_languages, language=language, task=task, codec=self.codec)
+
+    def decode(self, mel: torch.Tensor, options: DecodingOptions = DecodingOptions(), **kwargs):
+        return decode_function(self, mel, options, **kwargs)
+
+    def detect_language(self, mel: torch.Tensor, tokenizer=None):
+        """decoding.py:19-77 (arg-max language token only): one decoder pass on <|startoftranscript|>."""
+        tokenizer = tokenizer or self.get_tokenizer()
+        single = mel.dim() == 2
+        if single:
+            mel = mel[None]
+        if tuple(mel.shape[-2:]) != (self.dims.n_audio_ctx, self.dims.n_audio_state):
+            mel = self.embed_audio(mel)
+        x = torch.full((mel.shape[0], 1), tokenizer.sot, dtype=torch.int32)
+        lg = self.logits(x, mel)[:, 0]
+        ids = torch.tensor(tokenizer.all_language_tokens, device=lg.device)
+        best = ids[lg[:, ids].argmax(dim=-1)]
+        return best[0] if single else best
+
+    # ------------------------------------------------------------------ generate (whisper.py:799-1320, condensed)
+    def _prepare_audio(self, audio, padding: int = N_SAMPLES) -> Tuple[torch.Tensor, int]:
+        if isinstance(audio, str):
+            raise NotImplementedError("audio file loading is outside the MI355X hot path: pass a 16 kHz waveform array")
+        if not isinstance(audio, torch.Tensor):
+            audio = torch.from_numpy(np.asarray(audio, dtype=np.float32))
+        mel = log_mel_spectrogram(audio, n_mels=self.dims.n_mels, padding=padding)
+        content_frames = mel.shape[-2] - N_FRAMES if padding else mel.shape[-2]
+        return mel, content_frames
+
+    def generate(self, audio, *, verbose: Optional[bool] = None, language: Optional[str] = None, task: str = "transcribe",
+                 temperature: Union[float, Tuple[float, ...]] = (0.0, 0.2, 0.4, 0.6, 0.8, 1.0),
+                 compression_ratio_threshold: Optional[float] = 2.4, logprob_threshold: Optional[float] = -1.0,
+                 no_speech_threshold: Optional[float] = 0.6, condition_on_previous_text: bool = True,
+                 initial_prompt: Optional[str] = None, return_timestamps: bool = True, word_timestamps: bool = False,
+                 clip_timestamps: Union[str, List[float]] = "0", **decode_options) -> STTOutput:
+        if word_timestamps:
+            raise NotImplementedError("word_timestamps (DTW over cross-attention) is outside the MI355X hot path")
+        t_start = time.time()
+        decode_options = _filter_decode_options(decode_options)
+        decode_options["without_timestamps"] = not return_timestamps
+        mel, content_frames = self._prepare_audio(audio)
+        if language is None:
+            if not self.is_multilingual:
+                language = "en"
+            else:
+                tok0 = self.get_tokenizer()
+                lang_tok = int(self.detect_language(pad_or_trim(mel, N_FRAMES, axis=-2), tok0))
+                language = LANGUAGES[lang_tok - tok0.sot - 1]
+        decode_options.update(language=language, task=task)
+        tokenizer = self.get_tokenizer(language=language, task=task)
+        t0 = temperature if isinstance(temperature, (int, float)) else temperature[0]
+        input_stride = N_FRAMES // self.dims.n_audio_ctx
+        time_precision = input_stride * HOP_LENGTH / SAMPLE_RATE
+        seek = 0
+        all_tokens: List[int] = []
+        segments: List[dict] = []
+        while seek < content_frames:
+            time_offset = seek * HOP_LENGTH / SAMPLE_RATE
+            segment_size = min(N_FRAMES, content_frames - seek)
+            seg = pad_or_trim(mel[seek:seek + N_FRAMES], N_FRAMES, axis=-2)
+            result: DecodingResult = self.decode(seg, DecodingOptions(**decode_options, temperature=float(t0)))
+            tokens = result.tokens
+            if no_speech_threshold is not None and result.no_speech_prob > no_speech_threshold and not (
+                    logprob_threshold is not None and result.avg_logprob > logprob_threshold):
+                seek += segment_size  # silent window (whisper.py:1139-1151)
+                continue
+            ts = [i for i, t in enumerate(tokens) if t >= tokenizer.timestamp_begin]
+            consecutive = [i for i in range(1, len(tokens)) if tokens[i] >= tokenizer.timestamp_begin and tokens[i - 1] >= tokenizer.timestamp_begin]
+            single_ending = len(tokens) >= 2 and tokens[-2] < tokenizer.timestamp_begin <= tokens[-1]
+
+            def seg_dict(start, end, toks):
+                return dict(seek=seek, start=start, end=end, text=tokenizer.decode([t for t in toks if t < tokenizer.eot]), tokens=list(toks),
+                            temperature=result.temperature, avg_logprob=result.avg_logprob, compression_ratio=result.compression_ratio,
+                            no_speech_prob=result.no_speech_prob)
+
+            if consecutive:  # whisper.py:1166-1199: cut at consecutive timestamp pairs
+                slices = consecutive + ([len(tokens)] if single_ending else [])
+                last = 0
+                for cur in slices:
+                    sl = tokens[last:cur]
+                    s_pos = sl[0] - tokenizer.timestamp_begin
+                    e_pos = sl[-1] - tokenizer.timestamp_begin
+                    segments.append(seg_dict(time_offset + s_pos * time_precision, time_offset + e_pos * time_precision, sl))
+                    last = cur
+                if single_ending:
+                    seek += segment_size
+                else:
+                    seek += (tokens[last - 1] - tokenizer.timestamp_begin) * input_stride
+            else:
+                duration = segment_size * HOP_LENGTH / SAMPLE_RATE
+                if ts and tokens[ts[-1]] != tokenizer.timestamp_begin:
+                    duration = (tokens[ts[-1]] - tokenizer.timestamp_begin) * time_precision
+                segments.append(seg_dict(time_offset, time_offset + duration, tokens))
+                seek += segment_size
+            all_tokens.extend(tokens)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        total = time.time() - t_start
+        text = tokenizer.decode([t for t in all_tokens if t < tokenizer.eot])
+        return STTOutput(text=text.strip(), segments=segments, language=language, generation_tokens=len(all_tokens), total_tokens=len(all_tokens),
+                         generation_tps=len(all_tokens) / total if total > 0 else 0.0, total_time=total)

@@ -64,6 +64,25 @@ VECTORS = {
         "rng": "np.random.default_rng(0): real then imag, normal(size=(2,9,8)).astype(float32)*8",
         "n_fft": 16, "hop": 4, "min_diff": 0.1, "bound": 1.000001,
     },
+    "whisper_greedy_update": {
+        "source": "mlx_audio/stt/tests/test_whisper_decoding.py:101-119",
+        "eot": 99,
+        "tokens": [[1, 2], [1, 2], [1, 2]],
+        "logits": [[0.0, 1.0, 2.0], [3.0, 1.0, 0.0], [0.0, 5.0, 1.0]],
+        "expected_tokens": [[1, 2, 2], [1, 2, 0], [1, 2, 1]],
+        "completed": False,
+    },
+    "whisper_timestamp_rules_shape": {
+        "source": "mlx_audio/stt/tests/test_whisper_decoding.py:122-136",
+        "timestamp_begin": 4, "no_timestamps": None, "sample_begin": 2, "max_initial_timestamp_index": None,
+        "logits_shape": [3, 8], "tokens": [[1, 2], [1, 2], [1, 2]],
+    },
+    "whisper_dims": {
+        "source": "mlx_audio/stt/tests/test_models.py:43-54 (whisper-small), stt/models/whisper/audio.py:12-24",
+        "n_mels": 80, "n_audio_ctx": 1500, "n_audio_state": 768, "n_audio_head": 12, "n_audio_layer": 12, "n_vocab": 51865,
+        "n_text_ctx": 448, "n_text_state": 768, "n_text_head": 12, "n_text_layer": 12,
+        "n_samples": 480000, "n_frames": 3000, "hop": 160, "n_fft": 400,
+    },
     "kokoro_shapes": {
         "source": "SURVEY.md 8 header; examples/bible-audiobook/audios/*: every length is k*600 samples",
         "samples_per_frame": 600,

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.mi355_abi_version() == 3
+    assert lib.mi355_abi_version() == _lib.ABI_VERSION
     # and nothing torch-typed crosses the boundary: the header is plain C
     r = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Werror", "-x", "c", HEADER], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr

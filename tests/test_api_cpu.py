@@ -15,13 +15,13 @@ def test_registry_is_import_free_and_classifies():
     code = ("import sys; import mlx_audio_amd.registry as r; "
             "assert 'torch' not in sys.modules and 'mlx_audio_amd.ops' not in sys.modules; "
             "print(r.kinds(), r.classify_model('kokoro'), r.classify_model('', 'prince-canuma/Kokoro-82M'), r.classify_model('llama'), "
-            "r.is_supported_model('whisper'))")
+            "r.is_supported_model('whisper'), r.classify_model('whisper'), r.is_supported_model('parakeet'))")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout
-    assert out.strip() == "('tts',) tts tts None False"
+    assert out.strip() == "('tts', 'stt') tts tts None True stt False"
     from mlx_audio_amd import registry
 
     assert "kokoro" in registry.SUPPORTED_MODEL_TYPES["tts"]
-    assert registry.supported_model_types("stt") == frozenset()
+    assert registry.supported_model_types("stt") == frozenset({"whisper"})
 
 
 def test_dsp_imports_without_tts_or_stt():
@@ -171,3 +171,67 @@ def test_generation_result_fields_match_reference():
     assert format_duration(6.6) == "00:00:06.599" or format_duration(6.6) == "00:00:06.600"
     assert format_duration(3725.25) == "01:62:05.250"  # minutes are not wrapped in the reference either (kokoro.py:337-342)
     assert check_array_shape(torch.zeros(8, 3, 3)) and not check_array_shape(torch.zeros(8, 6, 5)) and not check_array_shape(torch.zeros(2, 3))
+
+
+# ------------------------------------------------------------------------------------------------ Whisper host side
+def test_whisper_tokenizer_ids_and_options():
+    from mlx_audio_amd.stt.models.whisper.decoding import DecodingOptions, _verify_options, get_suppress_tokens
+    from mlx_audio_amd.stt.models.whisper.tokenizer import get_tokenizer
+    from oracle.whisper_ref import TokenizerSpec
+
+    tk, spec = get_tokenizer(True, language="en", task="transcribe"), TokenizerSpec()
+    for name in ("eot", "sot", "translate", "transcribe", "sot_lm", "sot_prev", "no_speech", "no_timestamps", "timestamp_begin"):
+        assert getattr(tk, name) == getattr(spec, name), name
+    assert tk.sot_sequence == spec.sot_sequence == (50258, 50259, 50359)
+    assert tk.sot_sequence_including_notimestamps[-1] == 50363
+    assert get_tokenizer(True, language="de", task="translate").sot_sequence == (50258, 50261, 50358)
+    en = get_tokenizer(False)
+    assert (en.eot, en.sot, en.sot_sequence) == (50256, 50257, (50257,))
+    sup = get_suppress_tokens(tk, "-1")
+    assert set(sup) == {tk.transcribe, tk.translate, tk.sot, tk.sot_prev, tk.sot_lm, tk.no_speech}
+    assert get_suppress_tokens(tk, "5,7")[:2] == (5, 7)
+    with pytest.raises(ValueError):
+        _verify_options(DecodingOptions(beam_size=2, best_of=3))
+    with pytest.raises(ValueError):
+        _verify_options(DecodingOptions(temperature=0.0, best_of=3))
+    with pytest.raises(ValueError):
+        _verify_options(DecodingOptions(patience=1.0))
+    with pytest.raises(ValueError):
+        _verify_options(DecodingOptions(length_penalty=2.0))
+    with pytest.raises(NotImplementedError):  # decoding.py:478-479
+        _verify_options(DecodingOptions(beam_size=5))
+
+
+def test_whisper_config_and_sanitize():
+    from mlx_audio_amd.stt.models.whisper import Model, ModelDimensions
+
+    d = ModelDimensions.from_dict({"d_model": 384, "encoder_layers": 4, "decoder_layers": 4, "encoder_attention_heads": 6,
+                                   "decoder_attention_heads": 6, "num_mel_bins": 80, "vocab_size": 51865})
+    assert (d.n_audio_state, d.n_text_state, d.n_audio_layer, d.n_audio_head, d.n_mels, d.n_vocab) == (384, 384, 4, 6, 80, 51865)
+    d2 = ModelDimensions.from_dict({"n_mels": 80, "n_audio_state": 512, "model_type": "whisper", "unknown": 1})
+    assert d2.n_audio_state == 512
+    m = Model(d, device="cpu")
+    hf = {"model.encoder.conv1.weight": torch.zeros(384, 80, 3), "model.encoder.embed_positions.weight": torch.zeros(1500, 384),
+          "model.decoder.embed_positions.weight": torch.zeros(448, 384), "model.decoder.embed_tokens.weight": torch.zeros(10, 384),
+          "model.decoder.layers.0.encoder_attn.k_proj.weight": torch.zeros(384, 384),
+          "model.encoder.layers.1.self_attn.out_proj.bias": torch.zeros(384), "model.decoder.layers.2.fc1.weight": torch.zeros(1536, 384),
+          "model.encoder.layer_norm.weight": torch.zeros(384), "model.decoder.layers.3.final_layer_norm.bias": torch.zeros(384)}
+    s = m.sanitize(hf)
+    assert set(s) == {"encoder.conv1.weight", "decoder.positional_embedding", "decoder.token_embedding.weight",
+                      "decoder.blocks.0.cross_attn.key.weight", "encoder.blocks.1.attn.out.bias", "decoder.blocks.2.mlp1.weight",
+                      "encoder.ln_post.weight", "decoder.blocks.3.mlp_ln.bias"}
+    assert tuple(s["encoder.conv1.weight"].shape) == (384, 3, 80) and s["encoder.conv1.weight"].dtype == torch.float16
+    assert m.is_multilingual and m.num_languages == 99
+    with pytest.raises(RuntimeError):
+        m.embed_audio(torch.zeros(3000, 80))
+
+
+def test_whisper_synthetic_checkpoint_shapes():
+    from mlx_audio_amd.stt.models.whisper import synthetic as WS
+
+    dims = WS.tiny_dims()
+    w = WS.make_whisper_weights(dims, seed=0)
+    assert tuple(w["encoder.conv1.weight"].shape) == (128, 3, 80) and tuple(w["encoder.conv2.weight"].shape) == (128, 3, 128)
+    assert "encoder.blocks.0.attn.key.bias" not in w and "decoder.blocks.1.cross_attn.key.bias" not in w  # K has no bias
+    assert tuple(w["decoder.token_embedding.weight"].shape) == (51865, 128)
+    assert all(torch.equal(v, v.to(torch.float16).to(torch.float32)) for v in w.values())  # fp16-representable

@@ -103,3 +103,66 @@ def test_mel_filters_shapes_and_scale():
     assert np.abs(p - fb).max() < 1e-4
     w = dsp_ref.whisper_log_mel(np.random.default_rng(0).standard_normal(16000).astype(np.float32), padding=1600)
     assert w.shape == (110, 80)
+
+
+# ------------------------------------------------------------------------------------------------ Whisper
+def test_whisper_greedy_update_golden(golden):
+    from oracle.whisper_ref import GreedyDecoderRef
+
+    g = golden["whisper_greedy_update"]
+    dec = GreedyDecoderRef(eot=g["eot"])
+    tokens, completed, sum_lp = dec.update(torch.tensor(g["tokens"]), torch.tensor(g["logits"]), torch.zeros(3))
+    assert tokens.tolist() == g["expected_tokens"]
+    assert completed is g["completed"]
+    assert tuple(sum_lp.shape) == (3,)
+    # log-probs of the chosen tokens: log softmax at the arg-max
+    lg = torch.tensor(g["logits"], dtype=torch.float64)
+    exp = (lg.max(-1).values - torch.logsumexp(lg, -1)).float()
+    np.testing.assert_allclose(sum_lp.numpy(), exp.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_whisper_timestamp_rules_shape_golden(golden):
+    from types import SimpleNamespace
+
+    from oracle.whisper_ref import ApplyTimestampRulesRef
+
+    g = golden["whisper_timestamp_rules_shape"]
+    tk = SimpleNamespace(timestamp_begin=g["timestamp_begin"], no_timestamps=g["no_timestamps"], eot=99)
+    f = ApplyTimestampRulesRef(tk, sample_begin=g["sample_begin"], max_initial_timestamp_index=g["max_initial_timestamp_index"])
+    out = f.apply(torch.zeros(*g["logits_shape"]), torch.tensor(g["tokens"]))
+    assert list(out.shape) == g["logits_shape"]
+    # first sampled position: only timestamp tokens survive (decoding.py:421-423)
+    assert torch.isinf(out[:, : g["timestamp_begin"]]).all() and torch.isfinite(out[:, g["timestamp_begin"]:]).all()
+
+
+def test_whisper_oracle_kv_cache_equals_full_context():
+    """Size-independent property of the restated decoder: incremental decoding with the KV cache reproduces the
+    full-context logits (what the reference's TextDecoder guarantees by construction, whisper.py:476-498)."""
+    from mlx_audio_amd.stt.models.whisper import synthetic as WS
+    from oracle.whisper_ref import WhisperRef
+
+    dims = WS.tiny_dims()
+    ref = WhisperRef(WS.make_whisper_weights(dims, seed=3), dims)
+    xa = ref.encoder(WS.make_mel(1, seed=1, n_frames=2 * dims.n_audio_ctx))
+    toks = torch.tensor([[50258, 50259, 50359, 50364, 11, 22, 33]])
+    full, _ = ref.decoder(toks, xa)
+    kv = None
+    outs = []
+    l, kv = ref.decoder(toks[:, :3], xa, kv)
+    outs.append(l)
+    for i in range(3, toks.shape[1]):
+        l, kv = ref.decoder(toks[:, i:i + 1], xa, kv)
+        outs.append(l)
+    inc = torch.cat(outs, dim=1)
+    np.testing.assert_allclose(inc.numpy(), full.numpy(), rtol=2e-4, atol=2e-4)
+
+
+def test_whisper_dims_golden(golden):
+    from mlx_audio_amd.stt.models.whisper import audio as WA
+    from mlx_audio_amd.stt.models.whisper.synthetic import WHISPER_SMALL
+
+    g = golden["whisper_dims"]
+    for k in ("n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head", "n_audio_layer", "n_vocab", "n_text_ctx", "n_text_state",
+              "n_text_head", "n_text_layer"):
+        assert getattr(WHISPER_SMALL, k) == g[k]
+    assert (WA.N_SAMPLES, WA.N_FRAMES, WA.HOP_LENGTH, WA.N_FFT) == (g["n_samples"], g["n_frames"], g["hop"], g["n_fft"])

@@ -1,0 +1,329 @@
+"""Parity of the transformer-side HIP kernels (called through the C ABI) against fp64 torch / the CPU oracle.
+
+  * mi355_flash_attention  (f32 MFMA flash kernel + KV-streaming decode kernel): GQA, causal, window, ragged lengths
+  * mi355_gemv             (decode-step skinny GEMM on row-major 16-bit weights)
+  * mi355_conv_gemm        new modes: precision 4 (fp16 hi+lo), ELU / SnakeBeta prologues, SiLU / GELU-tanh / ELU / tanh
+                           epilogues, per-column scale (LayerScale)
+  * mi355_whisper_greedy_step / mi355_softmax_prob_at vs the restated logit filters (bit-exact tokens and masks)
+
+Needs a real MI355X: ``pytest -m gpu``.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mlx_audio_amd import ops as _ops
+
+    _ops.require_gpu()
+    return _ops
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def ref_attention(q, k, v, heads, kv_heads, dh, scale, causal, window, lens_q, lens_k):
+    """fp64 reference with the visibility rule of mi355_flash_attn_args.  q [B,Tq,H*dh], k/v [B,Tk,G*dh]."""
+    B, Tq, _ = q.shape
+    Tk = k.shape[1]
+    out = torch.zeros(B, Tq, heads * dh, dtype=torch.float64)
+    grp = heads // kv_heads
+    for b in range(B):
+        lq = int(lens_q[b]) if lens_q is not None else Tq
+        lk = int(lens_k[b]) if lens_k is not None else Tk
+        for h in range(heads):
+            g = h // grp
+            qq = q[b, :lq, h * dh:(h + 1) * dh].double()
+            kk = k[b, :lk, g * dh:(g + 1) * dh].double()
+            vv = v[b, :lk, g * dh:(g + 1) * dh].double()
+            s = (qq @ kk.T) * scale
+            i = torch.arange(lq)[:, None] + (lk - lq)
+            j = torch.arange(lk)[None, :]
+            vis = torch.ones(lq, lk, dtype=torch.bool)
+            if causal:
+                vis &= j <= i
+            if window > 0:
+                vis &= j > i - window
+            s = s.masked_fill(~vis, -float("inf"))
+            p = torch.softmax(s, dim=-1)
+            p = torch.nan_to_num(p, nan=0.0)  # rows without a visible key -> zeros
+            out[b, :lq, h * dh:(h + 1) * dh] = p @ vv
+    return out
+
+
+ATT_CASES = [
+    # B, Tq, Tk, heads, kv_heads, dh, causal, window, ragged, mode
+    (2, 200, 200, 3, 3, 64, False, 0, False, 1),
+    (1, 1500, 1500, 2, 2, 64, False, 0, False, 1),     # the Whisper encoder shape (2 of 12 heads)
+    (2, 130, 130, 4, 2, 64, True, 0, True, 1),         # GQA + causal + ragged
+    (1, 97, 300, 2, 1, 128, True, 0, False, 1),        # dh 128, queries = last 97 of 300 keys
+    (2, 70, 70, 2, 2, 128, False, 0, True, 1),
+    (1, 300, 300, 2, 2, 64, True, 50, False, 1),       # sliding window (Mimi context)
+    (3, 1, 77, 4, 2, 64, True, 0, True, 2),            # decode step
+    (2, 1, 1500, 12, 12, 64, False, 0, False, 2),      # Whisper cross-attention decode step
+    (2, 3, 3, 2, 2, 64, True, 0, False, 2),            # Whisper prefill (3 initial tokens)
+    (1, 2, 40, 16, 8, 128, True, 0, False, 2),         # Qwen3 code predictor step 0 (2 positions), dh 128
+    (2, 1, 400, 8, 8, 64, True, 250, False, 2),        # Mimi decode step with context 250
+    (2, 5, 33, 2, 2, 64, True, 0, True, 0),            # auto -> decode kernel
+    (1, 9, 33, 2, 2, 64, True, 0, False, 0),           # auto -> flash kernel
+    (1, 40, 40, 2, 1, 64, True, 0, False, 2),          # decode kernel forced on a longer block
+]
+
+
+@pytest.mark.parametrize("B,Tq,Tk,heads,kvh,dh,causal,window,ragged,mode", ATT_CASES)
+def test_flash_attention(ops, B, Tq, Tk, heads, kvh, dh, causal, window, ragged, mode):
+    g = torch.Generator().manual_seed(Tq * 7 + Tk + heads)
+    ldq, ldk = heads * dh + 8, 2 * kvh * dh  # strided views: q padded, k|v interleaved in one buffer like a KV cache
+    qb = torch.randn(B, Tq, ldq, generator=g)
+    kvb = torch.randn(B, Tk, ldk, generator=g)
+    q = qb[:, :, :heads * dh]
+    k, v = kvb[:, :, :kvh * dh], kvb[:, :, kvh * dh:]
+    lens_q = lens_k = None
+    if ragged:
+        lens_k = torch.tensor([max(1, Tk - 13 * i) for i in range(B)], dtype=torch.int32)
+        lens_q = torch.tensor([min(Tq, int(lens_k[i])) - (i % 2) * min(2, Tq - 1) for i in range(B)], dtype=torch.int32)
+    scale = 1.0 / math.sqrt(dh)
+    exp = ref_attention(q, k, v, heads, kvh, dh, scale, causal, window, lens_q, lens_k)
+    qd, kvd = qb.to(DEV), kvb.to(DEV)
+    out = torch.full((B, Tq, heads * dh), 7.0, device=DEV)
+    ops.flash_attention(qd[:, :, :heads * dh], kvd[:, :, :kvh * dh], kvd[:, :, kvh * dh:], out, heads=heads, kv_heads=kvh, dh=dh,
+                        scale=scale, causal=causal, window=window, lens_q=None if lens_q is None else lens_q.to(DEV),
+                        lens_k=None if lens_k is None else lens_k.to(DEV), mode=mode)
+    torch.cuda.synchronize()
+    got = out.cpu()
+    for b in range(B):
+        lq = int(lens_q[b]) if lens_q is not None else Tq
+        assert rel_err(got[b, :lq], exp[b, :lq]) < 2e-5, (b, rel_err(got[b, :lq], exp[b, :lq]))
+        if lq < Tq:
+            assert torch.all(got[b, lq:] == 7.0), "rows past lens_q must not be written"
+
+
+def test_flash_and_decode_kernels_agree(ops):
+    """Same inputs through both kernels (mode 1 / mode 2): a cross-check that does not involve the reference at all."""
+    g = torch.Generator().manual_seed(5)
+    B, T, H, dh = 2, 64, 4, 64
+    x = torch.randn(B, T, 3 * H * dh, generator=g).to(DEV)
+    o1 = torch.empty(B, T, H * dh, device=DEV)
+    o2 = torch.empty_like(o1)
+    for o, mode in ((o1, 1), (o2, 2)):
+        ops.flash_attention(x[:, :, :H * dh], x[:, :, H * dh:2 * H * dh], x[:, :, 2 * H * dh:], o, heads=H, dh=dh, causal=True, mode=mode)
+    torch.cuda.synchronize()
+    assert rel_err(o1.cpu(), o2.cpu()) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ gemv
+def _round16(t, f16):
+    return t.to(torch.float16 if f16 else torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("M,N,K,f16,act,use_res,use_cs", [
+    (1, 768, 768, True, 0, False, False),
+    (1, 51865, 768, True, 0, False, False),     # Whisper logits (ragged N, NC = 4)
+    (2, 3072, 768, True, 3, False, False),      # mlp1 + GELU
+    (3, 768, 3072, True, 0, True, False),       # mlp2 + residual, K > one LDS chunk
+    (5, 2048, 2048, False, 0, True, True),
+    (8, 1024, 6144, False, 5, False, False),    # SiLU, 8 rows
+    (4, 30, 1024, False, 6, False, False),      # tiny N (NC = 1 tail), GELU-tanh
+    (1, 2051, 2048, False, 0, False, False),    # CSM audio head (odd N)
+])
+def test_gemv(ops, M, N, K, f16, act, use_res, use_cs):
+    g = torch.Generator().manual_seed(M * 100 + N + K)
+    w = _round16(torch.randn(N, K, generator=g) / math.sqrt(K), f16)
+    bias = torch.randn(N, generator=g) * 0.1
+    x = torch.randn(M, K + 4, generator=g)[:, :K]  # strided rows
+    res = torch.randn(M, N, generator=g) if use_res else None
+    cs = torch.randn(N, generator=g) if use_cs else None
+    v = x.double() @ w.double().T + bias.double()
+    if act == 3:
+        v = F.gelu(v)
+    elif act == 5:
+        v = F.silu(v)
+    elif act == 6:
+        v = F.gelu(v, approximate="tanh")
+    if cs is not None:
+        v = v * cs.double()
+    if res is not None:
+        v = v + res.double()
+    rw = ops.pack_rowmajor16(w, bias, DEV, f16=f16)
+    xd = torch.zeros(M, K + 4, device=DEV)
+    xd[:, :K] = x.to(DEV)
+    y = torch.empty(M, N, device=DEV)
+    ops.gemv(xd[:, :K], rw, y, post_act=act, res=None if res is None else res.to(DEV), colscale=None if cs is None else cs.to(DEV))
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu(), v) < 5e-6, rel_err(y.cpu(), v)
+
+
+def test_gemv_swiglu(ops):
+    g = torch.Generator().manual_seed(11)
+    M, I, K = 3, 3072, 1024
+    wg = _round16(torch.randn(I, K, generator=g) / math.sqrt(K), False)
+    wu = _round16(torch.randn(I, K, generator=g) / math.sqrt(K), False)
+    x = torch.randn(M, K, generator=g)
+    exp = F.silu(x.double() @ wg.double().T) * (x.double() @ wu.double().T)
+    inter = torch.stack([wg, wu], dim=1).reshape(2 * I, K)  # gate_0, up_0, gate_1, up_1, ...
+    rw = ops.pack_rowmajor16(inter, None, DEV, f16=False)
+    y = torch.empty(M, I, device=DEV)
+    ops.gemv(x.to(DEV), rw, y, glu=True)
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu(), exp) < 5e-6
+
+
+# ------------------------------------------------------------------------------------------------ conv_gemm additions
+def _ref_conv(x, w, b, dil, pad):
+    k = w.shape[1]
+    xp = F.pad(x.transpose(1, 2).double(), (pad, (k - 1) * dil - pad))
+    return F.conv1d(xp, w.permute(0, 2, 1).double(), None if b is None else b.double(), dilation=dil).transpose(1, 2)
+
+
+@pytest.mark.parametrize("cin,cout,k,dil,L,B,tile", [
+    (768, 768, 1, 1, 300, 2, 0),
+    (80, 768, 3, 1, 300, 1, 0),        # Whisper conv1 (C_in not a multiple of 32)
+    (1536, 768, 2, 1, 150, 2, 0),      # Whisper conv2 as the 2-tap pair conv
+    (768, 3072, 1, 1, 1500, 1, 0),
+    (128, 128, 7, 1, 1100, 3, 7128128),
+    (96, 51865, 1, 1, 5, 2, 0),        # logits-shaped: huge N, few rows
+])
+def test_conv_gemm_precision4(ops, cin, cout, k, dil, L, B, tile):
+    g = torch.Generator().manual_seed(cin + cout + k)
+    w = (torch.randn(cout, k, cin, generator=g) / math.sqrt(cin * k)).to(torch.float16).to(torch.float32)
+    bias = torch.randn(cout, generator=g) * 0.1
+    x = torch.randn(B, L, cin, generator=g) * 3.0
+    pad = (k - 1) * dil // 2
+    exp = _ref_conv(x, w, bias, dil, pad)
+    pc = ops.pack_conv(w, bias, DEV, f16=True)
+    y = torch.empty(B, L, cout, device=DEV)
+    ops.conv_gemm(x.to(DEV), pc, y, dil=dil, pad=pad, precision=4, tile=tile)
+    y3 = torch.empty(B, L, cout, device=DEV)
+    ops.conv_gemm(x.to(DEV), pc, y3, dil=dil, pad=pad, precision=3, tile=tile)
+    torch.cuda.synchronize()
+    e4, e3 = rel_err(y.cpu(), exp), rel_err(y3.cpu(), exp)
+    assert e4 < 3e-6, e4            # fp16 hi+lo: ~22 mantissa bits of the activation
+    assert e3 < 2e-3 and e4 < e3    # single fp16 pass: the reference's own activation rounding
+
+
+def test_conv_gemm_new_activations(ops):
+    g = torch.Generator().manual_seed(77)
+    B, L, cin, cout, k = 2, 333, 96, 160, 7
+    w = (torch.randn(cout, k, cin, generator=g) / math.sqrt(cin * k)).to(torch.bfloat16).to(torch.float32)
+    bias = torch.randn(cout, generator=g) * 0.1
+    x = torch.randn(B, L, cin, generator=g)
+    res = torch.randn(B, L, cout, generator=g)
+    cs = torch.randn(cout, generator=g)
+    alpha = torch.rand(cin, generator=g) + 0.5
+    inv_beta = 1.0 / (torch.rand(cin, generator=g) + 0.5)
+    pc = ops.pack_conv(w, bias, DEV)
+    xd, resd = x.to(DEV), res.to(DEV)
+    pad = k - 1  # causal
+
+    def run(**kw):
+        y = torch.empty(B, L, cout, device=DEV)
+        ops.conv_gemm(xd, pc, y, pad=pad, **kw)
+        torch.cuda.synchronize()
+        return y.cpu()
+
+    xe = F.elu(x.double())
+    exp = _ref_conv(xe, w, bias, 1, pad)
+    assert rel_err(run(pre_act=ops.ACT_ELU), exp) < 5e-5
+    al = torch.zeros(128); al[:cin] = alpha
+    ib = torch.zeros(128); ib[:cin] = inv_beta
+    xs = x.double() + inv_beta.double() * torch.sin(alpha.double() * x.double()) ** 2
+    exp = _ref_conv(xs, w, bias, 1, pad)
+    assert rel_err(run(pre_act=ops.ACT_SNAKE, pre_alpha=al.to(DEV), pre_inv_beta=ib.to(DEV)), exp) < 5e-5
+    base = _ref_conv(x, w, bias, 1, pad)
+    assert rel_err(run(post_act=ops.ACT_SILU), F.silu(base)) < 5e-5
+    assert rel_err(run(post_act=ops.ACT_GELU_TANH), F.gelu(base, approximate="tanh")) < 5e-5
+    assert rel_err(run(post_act=ops.ACT_ELU), F.elu(base)) < 5e-5
+    assert rel_err(run(post_act=ops.ACT_TANH), torch.tanh(base)) < 5e-5
+    assert rel_err(run(colscale=cs.to(DEV), res=resd), base * cs.double() + res.double()) < 5e-5
+
+
+# ------------------------------------------------------------------------------------------------ whisper decode step
+def _tok():
+    from oracle.whisper_ref import TokenizerSpec
+
+    return TokenizerSpec()
+
+
+@pytest.mark.parametrize("case", ["first", "after_text", "after_ts_pair", "after_single_ts", "ended", "no_ts_rules"])
+def test_whisper_greedy_step_matches_filters(ops, case):
+    from oracle import whisper_ref as R
+
+    tok = _tok()
+    V, B = 51865, 3
+    g = torch.Generator().manual_seed(sum(map(ord, case)))
+    logits = torch.randn(B, V, generator=g) * 3.0
+    logits[0, tok.timestamp_begin + 7] += 25.0   # a sequence where timestamps dominate
+    logits[1, 1234] += 25.0                      # a sequence where text dominates
+    init = list(tok.sot_sequence)
+    sb = len(init)
+    hist = {"first": [], "after_text": [tok.timestamp_begin, 400, 500], "after_ts_pair": [tok.timestamp_begin, 400, tok.timestamp_begin + 50, tok.timestamp_begin + 50],
+            "after_single_ts": [tok.timestamp_begin, 400, tok.timestamp_begin + 50], "ended": [tok.timestamp_begin, tok.eot], "no_ts_rules": [400, 401]}[case]
+    tokens = torch.tensor([init + hist] * B, dtype=torch.long)
+    if case == "ended":
+        tokens[1, -1] = 777  # only sequences 0 and 2 have ended
+    ts_rules = case != "no_ts_rules"
+    suppress = [1, 2, 3, tok.sot, tok.no_speech, 1234 + 1]
+    filters = [R.SuppressBlankRef(tok, sb, V), R.SuppressTokensRef(suppress, V)]
+    if ts_rules:
+        filters.append(R.ApplyTimestampRulesRef(tok, sb, 50))
+    lg = logits.clone()
+    for f in filters:
+        lg = f.apply(lg, tokens)
+    sum0 = torch.tensor([-1.0, -2.0, -3.0])
+    exp_tokens, _, exp_sum = R.GreedyDecoderRef(tok.eot).update(tokens, lg, sum0.clone())
+
+    n = tokens.shape[1]
+    tk = torch.full((B, n + 4), -5, dtype=torch.int32)
+    tk[:, :n] = tokens.to(torch.int32)
+    tkd = tk.to(DEV)
+    sums = sum0.to(DEV)
+    smask = torch.zeros(V); smask[suppress] = -float("inf")
+    ld = V + 3
+    lgd = torch.zeros(B, ld, device=DEV)
+    lgd[:, :V] = logits.to(DEV)
+    filt = torch.zeros(B, ld, device=DEV)
+    blank = torch.tensor(list(tok.blank_ids) + [tok.eot], dtype=torch.int32, device=DEV)
+    ops.whisper_greedy_step(lgd, tkd, n, sb, sums, V=V, suppress_mask=smask.to(DEV), blank_ids=blank, timestamp_rules=ts_rules,
+                            timestamp_begin=tok.timestamp_begin, eot=tok.eot, no_timestamps=tok.no_timestamps, max_initial_timestamp_index=50,
+                            filtered=filt)
+    torch.cuda.synchronize()
+    got_f = filt[:, :V].cpu()
+    assert torch.equal(torch.isinf(got_f), torch.isinf(lg)), "mask pattern differs"
+    fin = torch.isfinite(lg)
+    assert torch.equal(got_f[fin], lg[fin]), "filters only add 0 / -inf: finite logits must be bit-identical"
+    assert torch.equal(tkd[:, :n + 1].cpu().long(), exp_tokens)
+    assert torch.all(tkd[:, n + 1:].cpu() == -5)
+    np.testing.assert_allclose(sums.cpu().numpy(), exp_sum.numpy(), rtol=2e-5, atol=2e-5)
+
+
+def test_whisper_step_forced_and_no_speech(ops):
+    tok = _tok()
+    V, B = 51865, 2
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(B, V, generator=g)
+    lgd = logits.to(DEV)
+    p = ops.softmax_prob_at(lgd, tok.no_speech)
+    exp = torch.softmax(logits.double(), -1)[:, tok.no_speech]
+    np.testing.assert_allclose(p.cpu().numpy(), exp.numpy(), rtol=1e-5)
+    init = list(tok.sot_sequence_including_notimestamps)
+    tk = torch.zeros(B, 16, dtype=torch.int32)
+    tk[:, :len(init)] = torch.tensor(init, dtype=torch.int32)
+    tkd = tk.to(DEV)
+    sums = torch.zeros(B, device=DEV)
+    forced = torch.tensor([4321, 99], dtype=torch.int32, device=DEV)
+    ops.whisper_greedy_step(lgd, tkd, len(init), len(init), sums, eot=tok.eot, forced_next=forced)
+    torch.cuda.synchronize()
+    assert tkd[:, len(init)].cpu().tolist() == [4321, 99]
+    lp = torch.log_softmax(logits.double(), -1)
+    np.testing.assert_allclose(sums.cpu().numpy(), [float(lp[0, 4321]), float(lp[1, 99])], rtol=1e-5)

@@ -1,0 +1,150 @@
+#!/usr/bin/env python
+"""Secondary benchmark line: BASELINE config[2] -- Whisper-small STT, 30 s audio -> log-mel + encoder + greedy decode
+on one MI355X (synthetic fp16 weights of the exact whisper-small shapes, synthetic audio).
+
+One "step" = one batch of 30 s windows through log-mel (fused STFT/mel kernel), the 12-layer encoder and a fixed number of
+greedy decode steps (logit filters on device, EOT not special-cased so every step is timed).  Prints ONE JSON line with
+  * value = audio seconds transcribed per wall second (x real time), whole step;
+  * encoder / decode split, decode tokens/s;
+  * roofline of the decode-step GEMV (HBM: 16-bit weight bytes read per token / time) and of the encoder's attention
+    kernel (f32 MFMA: 4*T^2*D flops / time vs the 157 TFLOP/s f32 matrix peak), measured with events on the launch stream;
+  * cpu_baseline: the oracle (PyTorch-CPU fp32) on one window's encoder, bounded.
+Not the driver's contract line (that is bench.py / Kokoro, config[1]); results are committed under profiles/.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8, help="30 s windows per step")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--decode-steps", type=int, default=64)
+    ap.add_argument("--precision", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from mlx_audio_amd import dsp, ops
+    from mlx_audio_amd.stt.models.whisper import synthetic as WS
+    from mlx_audio_amd.stt.models.whisper.engine import WhisperEngine
+    from mlx_audio_amd.stt.models.whisper.tokenizer import get_tokenizer
+
+    dev = torch.device("cuda", 0)
+    dims = WS.WHISPER_SMALL
+    w = WS.make_whisper_weights(dims, seed=0)
+    eng = WhisperEngine(w, dims, device=dev, precision=args.precision)
+    tok = get_tokenizer(True, language="en", task="transcribe")
+    B = args.batch
+    g = torch.Generator(device=dev).manual_seed(0)
+    audio = torch.randn((B, 480000), generator=g, device=dev) * 0.1  # resident in HBM before the timed region
+    suppress = [tok.sot, tok.sot_prev, tok.sot_lm, tok.no_speech, tok.transcribe, tok.translate, tok.eot]  # EOT suppressed: fixed length
+
+    def ev():
+        return torch.cuda.Event(enable_timing=True)
+
+    def step(timers=None):
+        e = [ev() for _ in range(4)]
+        e[0].record()
+        mel = dsp.log_mel_spectrogram(audio, n_mels=80, padding=480000)[:, :3000]  # whisper.py:_prepare_audio + pad_or_trim
+        e[1].record()
+        xa = eng.encode(mel.contiguous())
+        e[2].record()
+        out = eng.decode(None, tok, sample_len=args.decode_steps, suppress_tokens=suppress, audio_features=xa, fixed_steps=True)
+        e[3].record()
+        if timers is not None:
+            timers.append(e)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    timers = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(timers)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert out["tokens"].shape[1] == 3 + args.decode_steps and bool(torch.isfinite(out["sum_logprobs"]).all())
+    mel_ms = sum(t[0].elapsed_time(t[1]) for t in timers) / args.steps
+    enc_ms = sum(t[1].elapsed_time(t[2]) for t in timers) / args.steps
+    dec_ms = sum(t[2].elapsed_time(t[3]) for t in timers) / args.steps
+    audio_s = 30.0 * B * args.steps
+    res = {
+        "metric": "audio seconds transcribed per second (x real time), Whisper-small STT, 1 MI355X", "value": audio_s / dt, "unit": "x realtime",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000 * dt / args.steps, "higher_is_better": True,
+        "dtype": "fp16 weights x fp32 activations (precision %d: %s), f32 MFMA attention" % (
+            args.precision, "fp16 hi+lo split" if args.precision == 4 else "single fp16 pass"),
+        "data": "synthetic",
+        "config": {"workload": "Whisper-small, 30 s windows: log-mel + 12-layer encoder + %d greedy decode steps (filters on device)" % args.decode_steps,
+                   "windows_per_step": B, "decode_steps": args.decode_steps},
+        "split_ms": {"logmel": mel_ms, "encoder": enc_ms, "decode": dec_ms},
+        "decode_tokens_per_s": B * args.decode_steps / (dec_ms * 1e-3),
+        "decode_ms_per_token_step": dec_ms / args.decode_steps,
+    }
+
+    # ---- roofline legs: one decode-step GEMV set and one encoder attention, bracketed by events on the launch stream
+    nt = dims.n_text_state
+    x = torch.randn(min(B, 8), nt, device=dev)
+    lin = eng.logits_lin.rm
+    y = torch.empty(x.shape[0], lin.n, device=dev)
+    for _ in range(3):
+        ops.gemv(x, lin, y)
+    a0, a1 = ev(), ev()
+    a0.record()
+    reps = 20
+    for _ in range(reps):
+        ops.gemv(x, lin, y)
+    a1.record()
+    torch.cuda.synchronize()
+    ms = a0.elapsed_time(a1) / reps
+    byts = 2.0 * lin.n * lin.k + 4.0 * x.shape[0] * (lin.k + lin.n)
+    res["roofline"] = {"bound": "hbm", "kernel": "gemv_kernel (decode-step logits, N=51865 K=768 fp16 row-major)", "achieved": byts / (ms * 1e-3) / 1e9,
+                       "peak": 8000.0, "unit": "GB/s", "frac": byts / (ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "us_per_launch": ms * 1e3,
+                       "algorithmic_bytes_per_launch": byts}
+    T, D, H = dims.n_audio_ctx, dims.n_audio_state, dims.n_audio_head
+    qkv = torch.randn(B, T, 3 * D, device=dev)
+    o = torch.empty(B, T, D, device=dev)
+    for _ in range(2):
+        ops.flash_attention(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], o, heads=H, dh=D // H)
+    a0, a1 = ev(), ev()
+    a0.record()
+    for _ in range(5):
+        ops.flash_attention(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], o, heads=H, dh=D // H)
+    a1.record()
+    torch.cuda.synchronize()
+    ms = a0.elapsed_time(a1) / 5
+    fl = 4.0 * B * T * T * D
+    res["attention_roofline"] = {"bound": "mfma", "kernel": "flash_attn_kernel<64> (encoder 1500x1500, f32 MFMA)", "achieved": fl / (ms * 1e-3) / 1e12,
+                                 "peak": 157.3, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / 157.3, "ms_per_launch": ms}
+
+    if not args.no_cpu_baseline:
+        from oracle.whisper_ref import WhisperRef
+
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        cores = max(1, min(avail, 32))
+        torch.set_num_threads(cores)
+        ref = WhisperRef(w, dims)
+        mel1 = WS.make_mel(1, seed=0)
+        t1 = time.perf_counter()
+        ref.encoder(mel1)
+        enc_s = time.perf_counter() - t1
+        res["cpu_baseline"] = {"value": 30.0 / enc_s, "unit": "x realtime (encoder only)", "cores": cores, "kind": "port",
+                               "sample": "1 window (30 s), encoder only, single run; restated reference (oracle/whisper_ref.py, PyTorch-CPU fp32), not MLX",
+                               "host_cores_available": avail}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
