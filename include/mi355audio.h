@@ -416,6 +416,85 @@ typedef struct {
 int mi355_gemv(const mi355_gemv_args* a, void* stream);
 int mi355_pack_rowmajor16_host(const float* w_host, int64_t n, int32_t dtype, uint16_t* out_host);
 
+/* ------------------------------------------------------------------------------------------
+ * Row-wise glue of the decoder-only transformer blocks (Qwen3-TTS talker / code predictor / codec transformer, CSM,
+ * Mimi); see mlx_audio_amd/csrc/transformer.hip for the reference call sites of each.
+ * ------------------------------------------------------------------------------------------ */
+/* nn.RMSNorm over the channel axis: y = x * rsqrt(mean(x^2) + eps) * weight (talker.py:366-369, llama.py:100-104). */
+typedef struct {
+  const float* x; int64_t x_bstride; int32_t ldx;
+  int32_t C; int32_t L; const int32_t* lens; int32_t B;
+  const float* weight;   /* [C] nullable */
+  float eps;
+  float* y; int64_t y_bstride; int32_t ldy;
+} mi355_rmsnorm_args;
+int mi355_rmsnorm(const mi355_rmsnorm_args* a, void* stream);
+
+/* Per-head RMSNorm (q_norm / k_norm, talker.py:264-266) fused with the rotary embedding, out of place: x [B, L, ldx] holds
+ * `heads` heads of dh (64 or 128) channels from column 0; y may be a KV-cache slot.  Angles come from host tables
+ * cos/sin [max_pos, dh/2]; position of row l = pos ? pos[b*pos_ld + l] : pos0 + l.  rope_mode 0 = rotate-half pairs
+ * (i, i + dh/2) (talker.py:14-36), 1 = interleaved pairs (2i, 2i+1) (nn.RoPE(traditional=True), sesame/attention.py:41-105). */
+typedef struct {
+  const float* x; int64_t x_bstride; int32_t ldx;
+  int32_t heads; int32_t dh; int32_t L; const int32_t* lens; int32_t B;
+  const float* norm_weight; float eps;          /* [dh] nullable: no norm */
+  const float* cos_table; const float* sin_table; /* nullable: no rotation */
+  const int32_t* pos; int32_t pos_ld; int32_t pos0;
+  int32_t rope_mode;
+  float* y; int64_t y_bstride; int32_t ldy;
+} mi355_head_rope_args;
+int mi355_head_norm_rope(const mi355_head_rope_args* a, void* stream);
+
+/* y[r, i] = silu(x[r, 2i]) * x[r, 2i+1]  (SwiGLU on interleaved gate / up columns, talker.py:312-330). */
+int mi355_swiglu(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int32_t I, void* stream);
+
+/* y[b, l, :] = scale * (add[b, l, :] + sum_q table[slot_offset[q] + ids[b, l, q], :]); ids < 0 skip the slot.
+ * Codec-embedding sums (qwen3_tts.py:985-1015, sesame.py:361-404) and RVQ decode (codec/models/mimi/modules/quantization.py:
+ * 187-191, speech_tokenizer.py:786-800).  ids element (b, l, q) lives at ids + b*ids_bstride + l*ids_ld + q*ids_qstride. */
+typedef struct {
+  const float* table; int32_t ld_table;
+  const int32_t* slot_offset;   /* [Q] row offset of slot q's table inside `table`, nullable => 0 */
+  const int32_t* ids; int64_t ids_bstride; int32_t ids_ld; int32_t ids_qstride; int32_t Q;
+  const float* add; int64_t add_bstride; int32_t add_ld;   /* nullable */
+  float scale;                  /* 0 => 1 */
+  int32_t C; int32_t L; const int32_t* lens; int32_t B;
+  float* y; int64_t y_bstride; int32_t ldy;
+} mi355_embed_sum_args;
+int mi355_embed_sum(const mi355_embed_sum_args* a, void* stream);
+
+/* Depthwise conv1d (transpose = 0: y[n] = b + sum_k w[c,k] x[n + k - pad]) or depthwise conv_transpose1d (transpose = 1:
+ * y[n] = b + sum over t*stride + k - pad == n of w[c,k] x[t]), channels-last, zero outside [0, lens_in[b]).
+ * ConvNeXt dwconv k7 of the Qwen3 codec decoder (speech_tokenizer.py ConvNeXtBlock), Mimi's depthwise upsampler (mimi.py:296-320). */
+typedef struct {
+  const float* x; int64_t x_bstride; int32_t ldx; int32_t Lin; const int32_t* lens_in;
+  const float* w;      /* [C, K] */
+  const float* bias;   /* [C] nullable */
+  int32_t C; int32_t K; int32_t pad; int32_t stride; int32_t transpose; int32_t B;
+  float* y; int64_t y_bstride; int32_t ldy; int32_t Lout;
+} mi355_dwconv_args;
+int mi355_dwconv(const mi355_dwconv_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Token sampling for the codec-token LMs: suppress -> repetition penalty -> / temperature -> top-k -> top-p / min-p ->
+ * categorical (Gumbel-max on caller-supplied noise).  Replaces Model._sample_token(_batch) (tts/models/qwen3_tts/qwen3_tts.py:
+ * 805-925) and lm/sample_utils.py:130-281.  One workgroup per row, V <= 8192.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* logits; int32_t ld; int32_t V; int32_t B;
+  const float* suppress_mask;     /* [V] 0 / -inf, nullable */
+  const int32_t* history; int32_t hist_ld; int32_t n_hist; const int32_t* hist_len;  /* generated tokens [B, hist_ld]; per-row count
+                                                                                        hist_len[b] (nullable => n_hist) */
+  float repetition_penalty;       /* 1 = off */
+  float temperature;              /* <= 0: arg-max of the penalised logits */
+  int32_t top_k;                  /* <= 0 or >= V: off */
+  float top_p; float min_p;       /* top_p outside (0, 1): off; min_p = 0: off */
+  const float* gumbel;            /* [B, ld] Gumbel(0,1) noise, nullable => arg-max */
+  const int32_t* done; int32_t done_token;  /* nullable: rows with done[b] != 0 emit done_token */
+  int32_t* out; int32_t out_ld;   /* token of row b -> out[b * out_ld] */
+  float* filtered;                /* [B, ld] nullable: logits after all filters (parity tests) */
+} mi355_sample_args;
+int mi355_sample(const mi355_sample_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

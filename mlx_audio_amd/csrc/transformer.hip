@@ -1,0 +1,204 @@
+// Row-wise glue kernels of the decoder-only transformer blocks under mlx_audio/tts (Qwen3-TTS talker / code predictor /
+// codec transformer, CSM Llama backbone + depth decoder) and mlx_audio/codec (Mimi), gfx950.  All HBM-bound, one pass each:
+//
+//   rmsnorm          nn.RMSNorm (talker.py:366-369, llama.py:100-104): one wave per row, x * rsqrt(mean(x^2) + eps) * w
+//   head_norm_rope   per-head q/k RMSNorm (talker.py:264-266, 541-542) fused with the rotary embedding
+//                    (rotate-half: talker.py:14-36; interleaved pairs = nn.RoPE(traditional=True) in Mimi,
+//                    codec/models/mimi/modules/transformer.py:75-77, and CSM's Llama-3 RoPE, sesame/attention.py:41-105),
+//                    reading cos / sin from host-built tables so the angles are the reference's own float32 values;
+//                    the output pointer is separate, so K is rotated straight into its KV-cache slot
+//   swiglu           silu(gate) * up on interleaved (gate, up) columns (talker.py:312-330 TalkerMLP)
+//   embed_sum        sum over slots of embedding rows (+ optional text row): the 16 codec embeddings of a Qwen3 frame
+//                    (qwen3_tts.py:985-1015), the 32 audio-codebook embeddings of CSM (sesame.py:361-404) and RVQ decode
+//                    (quantization.py:187-191 / speech_tokenizer.py:786-800: sum_q codebook_q[codes])
+//   dwconv           depthwise conv1d (ConvNeXt dwconv k7, speech_tokenizer.py ConvNeXtBlock) and depthwise
+//                    conv_transpose1d (Mimi upsample, mimi.py:296-320), causal / streaming-trimmed
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- rmsnorm
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const mi355_rmsnorm_args a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)a.B * a.L) return;
+  const int b = (int)(row / a.L), l = (int)(row - (int64_t)b * a.L);
+  const int len = a.lens ? a.lens[b] : a.L;
+  if (l >= len) return;
+  const float* xr = a.x + (int64_t)b * a.x_bstride + (int64_t)l * a.ldx;
+  float* yr = a.y + (int64_t)b * a.y_bstride + (int64_t)l * a.ldy;
+  float ss = 0.f;
+  for (int c = lane * 4; c < a.C; c += 256) {
+    const float4 t = *(const float4*)(xr + c);
+    ss += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+  }
+  const float r = rsqrtf(wave_sum(ss) / (float)a.C + a.eps);
+  for (int c = lane * 4; c < a.C; c += 256) {
+    const float4 t = *(const float4*)(xr + c);
+    float4 w = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (a.weight) w = *(const float4*)(a.weight + c);
+    *(float4*)(yr + c) = make_float4(t.x * r * w.x, t.y * r * w.y, t.z * r * w.z, t.w * r * w.w);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- head norm + rope
+// one wave per (row, head); dh in {64, 128}: lane p owns the rotation pair p (and p + 64 is not needed: dh/2 <= 64)
+__global__ __launch_bounds__(256) void head_norm_rope_kernel(const mi355_head_rope_args a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t total = (int64_t)a.B * a.L * a.heads;
+  if (wid >= total) return;
+  const int h = (int)(wid % a.heads);
+  const int64_t row = wid / a.heads;
+  const int b = (int)(row / a.L), l = (int)(row - (int64_t)b * a.L);
+  const int len = a.lens ? a.lens[b] : a.L;
+  if (l >= len) return;
+  const int half = a.dh >> 1;
+  const float* xr = a.x + (int64_t)b * a.x_bstride + (int64_t)l * a.ldx + h * a.dh;
+  float* yr = a.y + (int64_t)b * a.y_bstride + (int64_t)l * a.ldy + h * a.dh;
+  const bool act = lane < half;
+  int i0, i1;  // the two elements of this lane's rotation pair
+  if (a.rope_mode == 1) { i0 = 2 * lane; i1 = 2 * lane + 1; }   // interleaved (traditional)
+  else { i0 = lane; i1 = lane + half; }                          // rotate-half
+  float x0 = 0.f, x1 = 0.f;
+  if (act) { x0 = xr[i0]; x1 = xr[i1]; }
+  if (a.norm_weight) {
+    const float ss = wave_sum(x0 * x0 + x1 * x1);
+    const float r = rsqrtf(ss / (float)a.dh + a.eps);
+    if (act) { x0 = x0 * r * a.norm_weight[i0]; x1 = x1 * r * a.norm_weight[i1]; }
+  }
+  if (a.cos_table && act) {
+    const int pos = a.pos ? a.pos[(int64_t)b * a.pos_ld + l] : a.pos0 + l;
+    const float c = a.cos_table[(int64_t)pos * half + lane], s = a.sin_table[(int64_t)pos * half + lane];
+    // (x * cos) + (rotate(x) * sin): pair (x0, x1) -> (x0 c - x1 s, x1 c + x0 s), two roundings per term like the reference
+    const float y0 = x0 * c - x1 * s;
+    const float y1 = x1 * c + x0 * s;
+    x0 = y0; x1 = y1;
+  }
+  if (act) { yr[i0] = x0; yr[i1] = x1; }
+}
+
+// ---------------------------------------------------------------------------------------------- swiglu
+__global__ void swiglu_kernel(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int I) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * I) return;
+  const int64_t r = i / I;
+  const int c = (int)(i - r * I);
+  const float2 gu = *(const float2*)(x + r * ldx + 2 * c);
+  y[r * ldy + c] = (gu.x / (1.0f + expf(-gu.x))) * gu.y;
+}
+
+// ---------------------------------------------------------------------------------------------- embed_sum
+__global__ __launch_bounds__(256) void embed_sum_kernel(const mi355_embed_sum_args a) {
+  const int64_t row = blockIdx.x;  // b * L + l
+  const int b = (int)(row / a.L), l = (int)(row - (int64_t)b * a.L);
+  const int len = a.lens ? a.lens[b] : a.L;
+  if (l >= len) return;
+  const int32_t* ids = a.ids + (int64_t)b * a.ids_bstride + (int64_t)l * a.ids_ld;
+  float* yr = a.y + (int64_t)b * a.y_bstride + (int64_t)l * a.ldy;
+  for (int c = threadIdx.x * 4; c < a.C; c += 1024) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.add) {
+      const float* ar = a.add + (int64_t)b * a.add_bstride + (int64_t)l * a.add_ld;
+      acc = *(const float4*)(ar + c);
+    }
+    for (int q = 0; q < a.Q; ++q) {
+      const int id = ids[(int64_t)q * a.ids_qstride];
+      if (id < 0) continue;  // masked slot
+      const int64_t r = (int64_t)(a.slot_offset ? a.slot_offset[q] : 0) + id;
+      const float4 t = *(const float4*)(a.table + r * a.ld_table + c);
+      acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    }
+    *(float4*)(yr + c) = make_float4(acc.x * a.scale, acc.y * a.scale, acc.z * a.scale, acc.w * a.scale);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- depthwise conv / convT
+// y[b, t, c] = bias[c] + sum_k w[c, k] * x[b, t*1 + k - pad, c]                      (transpose == 0)
+// y[b, n, c] = bias[c] + sum_{t, k: t*stride + k - pad == n} w[c, k] * x[b, t, c]    (transpose == 1)
+__global__ void dwconv_kernel(const mi355_dwconv_args a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)a.B * a.Lout * a.C;
+  if (i >= total) return;
+  const int c = (int)(i % a.C);
+  const int64_t r = i / a.C;
+  const int n = (int)(r % a.Lout), b = (int)(r / a.Lout);
+  const int len_in = a.lens_in ? a.lens_in[b] : a.Lin;
+  const float* xb = a.x + (int64_t)b * a.x_bstride;
+  float acc = a.bias ? a.bias[c] : 0.f;
+  if (!a.transpose) {
+    for (int k = 0; k < a.K; ++k) {
+      const int t = n + k - a.pad;
+      if (t >= 0 && t < len_in) acc = fmaf(a.w[c * a.K + k], xb[(int64_t)t * a.ldx + c], acc);
+    }
+  } else {
+    for (int k = 0; k < a.K; ++k) {
+      const int u = n + a.pad - k;
+      if (u < 0 || u % a.stride) continue;
+      const int t = u / a.stride;
+      if (t < len_in) acc = fmaf(a.w[c * a.K + k], xb[(int64_t)t * a.ldx + c], acc);
+    }
+  }
+  a.y[(int64_t)b * a.y_bstride + (int64_t)n * a.ldy + c] = acc;
+}
+
+}  // namespace
+
+extern "C" int mi355_rmsnorm(const mi355_rmsnorm_args* ap, void* stream) {
+  MI355_REQUIRE(ap && ap->x && ap->y, "rmsnorm: null tensor");
+  const mi355_rmsnorm_args a = *ap;
+  MI355_REQUIRE(a.B > 0 && a.L > 0 && a.C > 0 && a.C % 4 == 0, "rmsnorm: C must be a positive multiple of 4");
+  MI355_REQUIRE(a.ldx % 4 == 0 && a.ldy % 4 == 0 && a.x_bstride % 4 == 0 && a.y_bstride % 4 == 0, "rmsnorm: strides must be multiples of 4");
+  MI355_CLEAR_ERROR();
+  const int64_t rows = (int64_t)a.B * a.L;
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  MI355_LAUNCH_CHECK("rmsnorm");
+  return MI355_OK;
+}
+
+extern "C" int mi355_head_norm_rope(const mi355_head_rope_args* ap, void* stream) {
+  MI355_REQUIRE(ap && ap->x && ap->y, "head_norm_rope: null tensor");
+  const mi355_head_rope_args a = *ap;
+  MI355_REQUIRE(a.dh == 64 || a.dh == 128, "head_norm_rope: head dim must be 64 or 128");
+  MI355_REQUIRE(a.B > 0 && a.L > 0 && a.heads > 0, "head_norm_rope: bad shape");
+  MI355_REQUIRE((a.cos_table == nullptr) == (a.sin_table == nullptr), "head_norm_rope: cos / sin tables come together");
+  MI355_REQUIRE(a.rope_mode == 0 || a.rope_mode == 1, "head_norm_rope: rope_mode must be 0 (rotate-half) or 1 (interleaved)");
+  MI355_CLEAR_ERROR();
+  const int64_t waves = (int64_t)a.B * a.L * a.heads;
+  hipLaunchKernelGGL(head_norm_rope_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  MI355_LAUNCH_CHECK("head_norm_rope");
+  return MI355_OK;
+}
+
+extern "C" int mi355_swiglu(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int32_t I, void* stream) {
+  MI355_REQUIRE(x && y && rows > 0 && I > 0 && ldx % 2 == 0 && ((uintptr_t)x) % 8 == 0, "swiglu: bad arguments");
+  MI355_CLEAR_ERROR();
+  const int64_t n = rows * I;
+  hipLaunchKernelGGL(swiglu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, (int)I);
+  MI355_LAUNCH_CHECK("swiglu");
+  return MI355_OK;
+}
+
+extern "C" int mi355_embed_sum(const mi355_embed_sum_args* ap, void* stream) {
+  MI355_REQUIRE(ap && ap->table && ap->ids && ap->y, "embed_sum: null tensor");
+  mi355_embed_sum_args a = *ap;
+  MI355_REQUIRE(a.B > 0 && a.L > 0 && a.Q > 0 && a.C > 0 && a.C % 4 == 0 && a.ld_table % 4 == 0 && a.ldy % 4 == 0, "embed_sum: bad shape");
+  MI355_REQUIRE(!a.add || (a.add_ld % 4 == 0 && a.add_bstride % 4 == 0), "embed_sum: add strides must be multiples of 4");
+  if (a.scale == 0.f) a.scale = 1.f;
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(embed_sum_kernel, dim3((unsigned)((int64_t)a.B * a.L)), dim3(256), 0, (hipStream_t)stream, a);
+  MI355_LAUNCH_CHECK("embed_sum");
+  return MI355_OK;
+}
+
+extern "C" int mi355_dwconv(const mi355_dwconv_args* ap, void* stream) {
+  MI355_REQUIRE(ap && ap->x && ap->w && ap->y, "dwconv: null tensor");
+  const mi355_dwconv_args a = *ap;
+  MI355_REQUIRE(a.B > 0 && a.Lin > 0 && a.Lout > 0 && a.C > 0 && a.K > 0, "dwconv: bad shape");
+  MI355_REQUIRE(!a.transpose || a.stride >= 1, "dwconv: transposed conv needs stride >= 1");
+  MI355_CLEAR_ERROR();
+  const int64_t n = (int64_t)a.B * a.Lout * a.C;
+  hipLaunchKernelGGL(dwconv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  MI355_LAUNCH_CHECK("dwconv");
+  return MI355_OK;
+}

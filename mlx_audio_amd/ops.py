@@ -312,6 +312,90 @@ def softmax_prob_at(logits: torch.Tensor, token: int, V: Optional[int] = None) -
     return out
 
 
+def rmsnorm(x: torch.Tensor, y: torch.Tensor, weight: Optional[torch.Tensor], eps: float = 1e-6, lens=None):
+    B, L, C, xbs, ldx = _nlc(x)
+    _, _, _, ybs, ldy = _nlc(y)
+    _lib.call_struct("mi355_rmsnorm", "mi355_rmsnorm_args", _stream(), x=_ptr(x), x_bstride=xbs, ldx=ldx, C=C, L=L, lens=_ptr(lens), B=B,
+                     weight=_ptr(weight), eps=eps, y=_ptr(y), y_bstride=ybs, ldy=ldy)
+    return y
+
+
+def head_norm_rope(x: torch.Tensor, y: torch.Tensor, *, heads: int, dh: int, norm_weight: Optional[torch.Tensor] = None, eps: float = 1e-6,
+                   cos: Optional[torch.Tensor] = None, sin: Optional[torch.Tensor] = None, pos: Optional[torch.Tensor] = None, pos0: int = 0,
+                   interleaved: bool = False, lens=None):
+    """Per-head RMSNorm (optional) + RoPE (optional) of ``heads`` heads starting at column 0 of ``x`` into ``y`` (may be a cache slot)."""
+    B, L, _, xbs, ldx = _nlc(x)
+    _, _, _, ybs, ldy = _nlc(y)
+    if cos is not None:
+        assert cos.dim() == 2 and cos.shape[1] == dh // 2 and cos.is_contiguous() and sin.is_contiguous() and cos.shape == sin.shape
+    if pos is not None:
+        assert pos.dtype == torch.int32 and pos.dim() == 2 and pos.stride(1) == 1
+    _lib.call_struct("mi355_head_norm_rope", "mi355_head_rope_args", _stream(), x=_ptr(x), x_bstride=xbs, ldx=ldx, heads=heads, dh=dh, L=L,
+                     lens=_ptr(lens), B=B, norm_weight=_ptr(norm_weight), eps=eps, cos_table=_ptr(cos), sin_table=_ptr(sin), pos=_ptr(pos),
+                     pos_ld=0 if pos is None else pos.stride(0), pos0=pos0, rope_mode=int(interleaved), y=_ptr(y), y_bstride=ybs, ldy=ldy)
+    return y
+
+
+def swiglu(x: torch.Tensor, y: torch.Tensor):
+    """y[..., i] = silu(x[..., 2i]) * x[..., 2i+1] on contiguous-row 3-D views [B, L, 2I] -> [B, L, I] (both dense over B, L)."""
+    B, L, C2, xbs, ldx = _nlc(x)
+    _, _, I, ybs, ldy = _nlc(y)
+    assert C2 == 2 * I and xbs == L * ldx and ybs == L * ldy
+    lib = _lib.load()
+    rc = lib.mi355_swiglu(_ptr(x), ldx, _ptr(y), ldy, B * L, I, _stream())
+    _lib.check(rc, "mi355_swiglu")
+    return y
+
+
+def embed_sum(table: torch.Tensor, ids: torch.Tensor, y: torch.Tensor, *, slot_offset: Optional[torch.Tensor] = None,
+              add: Optional[torch.Tensor] = None, scale: float = 1.0, lens=None):
+    """y[b, l] = scale * (add[b, l] + sum_q table[slot_offset[q] + ids[b, l, q]]); ``ids`` int32 [B, L, Q] (any strides)."""
+    B, L, C, ybs, ldy = _nlc(y)
+    assert ids.dtype == torch.int32 and ids.dim() == 3 and ids.shape[0] == B and ids.shape[1] == L
+    assert table.dim() == 2 and table.stride(1) == 1 and table.dtype == torch.float32
+    kw = dict(table=_ptr(table), ld_table=table.stride(0), slot_offset=_ptr(slot_offset), ids=_ptr(ids), ids_bstride=ids.stride(0),
+              ids_ld=ids.stride(1), ids_qstride=ids.stride(2), Q=ids.shape[2], scale=scale, C=C, L=L, lens=_ptr(lens), B=B, y=_ptr(y),
+              y_bstride=ybs, ldy=ldy)
+    if add is not None:
+        _, _, _, abs_, ald = _nlc(add)
+        kw.update(add=_ptr(add), add_bstride=abs_, add_ld=ald)
+    _lib.call_struct("mi355_embed_sum", "mi355_embed_sum_args", _stream(), **kw)
+    return y
+
+
+def dwconv(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], y: torch.Tensor, *, pad: int = 0, stride: int = 1,
+           transpose: bool = False, lens_in=None):
+    """Depthwise conv / conv_transpose, channels-last; ``w`` [C, K] float32."""
+    B, Lin, C, xbs, ldx = _nlc(x)
+    _, Lout, _, ybs, ldy = _nlc(y)
+    assert w.dim() == 2 and w.shape[0] == C and w.is_contiguous() and w.dtype == torch.float32
+    _lib.call_struct("mi355_dwconv", "mi355_dwconv_args", _stream(), x=_ptr(x), x_bstride=xbs, ldx=ldx, Lin=Lin, lens_in=_ptr(lens_in),
+                     w=_ptr(w), bias=_ptr(bias), C=C, K=w.shape[1], pad=pad, stride=stride, transpose=int(transpose), B=B, y=_ptr(y),
+                     y_bstride=ybs, ldy=ldy, Lout=Lout)
+    return y
+
+
+def sample(logits: torch.Tensor, out: torch.Tensor, *, V: Optional[int] = None, suppress_mask=None, history=None, n_hist: int = 0,
+           hist_len=None, repetition_penalty: float = 1.0, temperature: float = 0.0, top_k: int = 0, top_p: float = 1.0, min_p: float = 0.0,
+           gumbel=None, done=None, done_token: int = 0, filtered=None):
+    """Samples one token per row of ``logits`` [B, ld] into ``out`` (int32 view with B elements, any stride)."""
+    assert logits.dim() == 2 and logits.stride(1) == 1 and logits.dtype == torch.float32 and out.dtype == torch.int32
+    B = logits.shape[0]
+    out_ld = out.stride(0) if out.dim() >= 1 and out.shape[0] == B and B > 1 else 1
+    kw = dict(logits=_ptr(logits), ld=logits.stride(0), V=V or logits.shape[1], B=B, suppress_mask=_ptr(suppress_mask),
+              repetition_penalty=repetition_penalty, temperature=temperature, top_k=top_k, top_p=top_p, min_p=min_p, gumbel=_ptr(gumbel),
+              done=_ptr(done), done_token=done_token, out=_ptr(out), out_ld=out_ld, filtered=_ptr(filtered))
+    if history is not None:
+        assert history.dtype == torch.int32 and history.dim() == 2 and history.stride(1) == 1
+        kw.update(history=_ptr(history), hist_ld=history.stride(0), n_hist=n_hist, hist_len=_ptr(hist_len))
+    if gumbel is not None:
+        assert gumbel.stride(0) == logits.stride(0)
+    if filtered is not None:
+        assert filtered.stride(0) == logits.stride(0)
+    _lib.call_struct("mi355_sample", "mi355_sample_args", _stream(), **kw)
+    return out
+
+
 def gather_rows(table: torch.Tensor, idx: torch.Tensor, y: torch.Tensor, *, per_batch: bool = False, pos_table=None,
                 add_row=None, lens=None):
     B, L, C, ybs, ldy = _nlc(y)

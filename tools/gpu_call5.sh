@@ -19,5 +19,5 @@ cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof_whisper" -o w -- python "$GRAFT_REPO_ROOT/tools/bench_whisper.py" --steps 2 --warmup 1 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_whisper.json" 2> "$GRAFT_REPO_ROOT/gpurun_out/prof_whisper.err"
 echo "rocprof rc=$?" | tee -a "$GRAFT_REPO_ROOT/$R"
 cd "$GRAFT_REPO_ROOT"
-python tools/rocpd_stats.py gpurun_out/prof_whisper > gpurun_out/whisper_kernel_stats.txt 2>&1
+DB=$(find gpurun_out/prof_whisper -name "*_results.db" | head -1); python tools/rocpd_stats.py "$DB" 3 > gpurun_out/whisper_kernel_stats.txt 2>&1; rm -rf gpurun_out/prof_whisper
 cat $R; tail -30 gpurun_out/t_kernels.log; tail -30 gpurun_out/t_whisper.log; tail -8 gpurun_out/t_old.log; cat gpurun_out/bench_whisper.json gpurun_out/bench_whisper_b1.json gpurun_out/bench_whisper_p3.json; tail -5 gpurun_out/bench_whisper.err; head -25 gpurun_out/whisper_kernel_stats.txt
