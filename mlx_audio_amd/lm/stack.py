@@ -1,0 +1,257 @@
+"""Decoder-only transformer stack on MI355X: the host-side schedule over the HIP kernels, shared by every stack on the hot path.
+
+One parametrised engine replaces four separately written reference stacks (file:line relative to /root/reference/mlx_audio):
+  * Qwen3-TTS talker and code predictor   tts/models/qwen3_tts/talker.py:230-400, 503-690
+  * Qwen3-TTS codec transformer           tts/models/qwen3_tts/speech_tokenizer.py:150-420
+  * Mimi transformer                      codec/models/mimi/modules/transformer.py:60-200
+  * CSM Llama backbone / depth decoder    lm/models/llama.py:46-198, tts/models/sesame/attention.py:11-175
+
+Per layer (prefill, L > 1 rows per sequence):      norm -> [q | kv] GEMMs (kv lands in its KV-cache slot) -> per-head RMSNorm + RoPE in place
+  -> flash attention over the cache -> o-proj GEMM with LayerScale + residual in the epilogue -> norm -> gate|up GEMM -> SwiGLU
+  -> down GEMM with LayerScale + residual.   Decode step (1 row per sequence, <= 8 sequences): every GEMM becomes the HBM-bound GEMV on
+  the row-major bf16 image, SwiGLU is fused into the gate|up GEMV, attention is the KV-streaming kernel.
+
+``KVCache`` mirrors lm/models/cache.py:104-176 (capacity grows in steps of 256, in-place slice update, ``offset``, ``trim``) with one
+[B, capacity, 2 * n_kv * dh] fp32 buffer per layer (k | v side by side: one GEMM writes both).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from .. import ops
+from ..ops import ACT_GELU, ACT_GELU_TANH, ACT_NONE, PackedConv, RowMajor16
+
+
+@dataclass
+class StackConfig:
+    d_model: int
+    n_layers: int
+    n_heads: int
+    n_kv_heads: int
+    head_dim: int
+    d_ff: int
+    norm: str = "rms"            # "rms" | "layer"
+    norm_eps: float = 1e-6
+    qk_norm: bool = False
+    rope_theta: Optional[float] = 10000.0
+    rope_interleaved: bool = False
+    rope_llama3_factor: Optional[float] = None
+    max_pos: int = 4096
+    attn_bias: bool = False
+    mlp: str = "swiglu"          # "swiglu" | "gelu" | "gelu_tanh"
+    mlp_bias: bool = False
+    layer_scale: bool = False
+    causal: bool = True
+    window: int = 0
+    final_norm: bool = True
+
+
+def rope_tables(cfg: StackConfig) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Host cos / sin tables [max_pos, head_dim / 2] float32: inv_freq = 1 / theta^(2i/d) (talker.py:85, speech_tokenizer.py:198,
+    nn.RoPE base), optionally Llama-3 scaled (sesame/attention.py:53-66), angle = pos * inv_freq in float32, then cos / sin."""
+    d = cfg.head_dim
+    freqs = 1.0 / (cfg.rope_theta ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+    if cfg.rope_llama3_factor is not None:
+        low_f, high_f, old_ctx = 1, 4, 8192
+        wavelen = 2.0 * math.pi / freqs
+        smooth = torch.clip((old_ctx / wavelen - low_f) / (high_f - low_f), 0.0, 1.0)
+        scaled = freqs / cfg.rope_llama3_factor
+        blended = (1.0 - smooth) * scaled + smooth * freqs
+        freqs = torch.where(wavelen < old_ctx / high_f, freqs, torch.where(wavelen > old_ctx / low_f, scaled, blended))
+    ang = torch.arange(cfg.max_pos, dtype=torch.float32)[:, None] * freqs[None, :]
+    return torch.cos(ang), torch.sin(ang)
+
+
+class KVCache:
+    """lm/models/cache.py:104-176 on the device; ``kv`` is [B, capacity, 2 * n_kv * dh] (k columns first, then v)."""
+    step = 256
+
+    def __init__(self, n_kv_heads: int, head_dim: int, device):
+        self.width = 2 * n_kv_heads * head_dim
+        self.device = device
+        self.kv: Optional[torch.Tensor] = None
+        self.offset = 0
+
+    def reserve(self, batch: int, n_new: int) -> torch.Tensor:
+        """Makes room for ``n_new`` more rows and returns the slot view [B, n_new, width] they must be written to."""
+        prev = self.offset
+        if self.kv is None or prev + n_new > self.kv.shape[1]:
+            n_steps = (self.step + n_new - 1) // self.step
+            new = torch.zeros((batch, n_steps * self.step, self.width), dtype=torch.float32, device=self.device)
+            if self.kv is not None:
+                old = self.kv[:, :prev] if prev % self.step != 0 else self.kv
+                self.kv = torch.cat([old, new], dim=1)
+            else:
+                self.kv = new
+        self.offset = prev + n_new
+        return self.kv[:, prev:self.offset, :]
+
+    @property
+    def keys(self):
+        return None if self.kv is None else self.kv[:, :self.offset, : self.width // 2]
+
+    @property
+    def values(self):
+        return None if self.kv is None else self.kv[:, :self.offset, self.width // 2:]
+
+    def size(self) -> int:
+        return self.offset
+
+    def is_trimmable(self) -> bool:
+        return True
+
+    def trim(self, n: int) -> int:
+        n = min(self.offset, n)
+        self.offset -= n
+        return n
+
+    def reset(self):
+        self.offset = 0
+
+    def empty(self) -> bool:
+        return self.kv is None
+
+    @property
+    def nbytes(self) -> int:
+        return 0 if self.kv is None else self.kv.numel() * 4
+
+
+@dataclass
+class Lin:
+    pc: PackedConv
+    rm: RowMajor16
+
+
+def make_lin(w: torch.Tensor, bias: Optional[torch.Tensor], device, f16: bool = False) -> Lin:
+    return Lin(ops.pack_conv(w, bias, device, f16=f16), ops.pack_rowmajor16(w, bias, device, f16=f16))
+
+
+def linear(x: torch.Tensor, l: Lin, y: torch.Tensor, *, post_act: int = ACT_NONE, res: Optional[torch.Tensor] = None,
+           colscale: Optional[torch.Tensor] = None, glu: bool = False, precision: int = 2):
+    """y = act(x W^T + b) * colscale + res on [B, L, C] views; 1-row-per-sequence inputs with B <= 8 take the GEMV."""
+    B, L, _ = x.shape
+    if L == 1 and B <= 8:
+        ops.gemv(x[:, 0, :], l.rm, y[:, 0, :], post_act=post_act, res=None if res is None else res[:, 0, :], colscale=colscale, glu=glu)
+    else:
+        assert not glu
+        ops.conv_gemm(x, l.pc, y, post_act=post_act, res=res, colscale=colscale, precision=precision)
+    return y
+
+
+@dataclass
+class _Layer:
+    attn_norm: Tuple[torch.Tensor, Optional[torch.Tensor]]
+    wq: Lin
+    wkv: Lin
+    wo: Lin
+    q_norm: Optional[torch.Tensor]
+    k_norm: Optional[torch.Tensor]
+    mlp_norm: Tuple[torch.Tensor, Optional[torch.Tensor]]
+    w_in: Lin            # gate|up interleaved (SwiGLU) or w1
+    w_out: Lin           # down or w2
+    ls1: Optional[torch.Tensor]
+    ls2: Optional[torch.Tensor]
+
+
+class TransformerStack:
+    def __init__(self, weights: Dict[str, torch.Tensor], cfg: StackConfig, device="cuda:0", precision: int = 2, prefix: str = ""):
+        ops.require_gpu()
+        assert cfg.head_dim in (64, 128) and cfg.d_model % 4 == 0
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.precision = precision
+        dev = self.device
+        w = {k[len(prefix):]: v.detach().to(torch.bfloat16).to(torch.float32).cpu() for k, v in weights.items() if k.startswith(prefix)}
+
+        def vec(name):
+            t = w.get(name)
+            return None if t is None else t.to(dev)
+
+        def lin(name, extra_rows=None):
+            return make_lin(w[name + ".weight"], w.get(name + ".bias"), dev)
+
+        self.layers: List[_Layer] = []
+        for i in range(cfg.n_layers):
+            p = f"layers.{i}."
+            wk, wv = w[p + "wk.weight"], w[p + "wv.weight"]
+            bk, bv = w.get(p + "wk.bias"), w.get(p + "wv.bias")
+            kvb = None if bk is None and bv is None else torch.cat([bk if bk is not None else torch.zeros(wk.shape[0]),
+                                                                     bv if bv is not None else torch.zeros(wv.shape[0])])
+            if cfg.mlp == "swiglu":
+                wg, wu = w[p + "w_gate.weight"], w[p + "w_up.weight"]
+                w_in_w = torch.stack([wg, wu], dim=1).reshape(2 * wg.shape[0], wg.shape[1])  # gate_0, up_0, gate_1, up_1, ...
+                bg, bu = w.get(p + "w_gate.bias"), w.get(p + "w_up.bias")
+                w_in_b = None if bg is None else torch.stack([bg, bu], dim=1).reshape(-1)
+                w_in = make_lin(w_in_w, w_in_b, dev)
+                w_out = lin(p + "w_down")
+            else:
+                w_in, w_out = lin(p + "w1"), lin(p + "w2")
+            self.layers.append(_Layer((vec(p + "attn_norm.weight"), vec(p + "attn_norm.bias")), lin(p + "wq"),
+                                      make_lin(torch.cat([wk, wv]), kvb, dev), lin(p + "wo"), vec(p + "q_norm.weight"), vec(p + "k_norm.weight"),
+                                      (vec(p + "mlp_norm.weight"), vec(p + "mlp_norm.bias")), w_in, w_out, vec(p + "ls1"), vec(p + "ls2")))
+        self.final_norm = (vec("final_norm.weight"), vec("final_norm.bias")) if cfg.final_norm else None
+        if cfg.rope_theta is not None:
+            cos, sin = rope_tables(cfg)
+            self.cos, self.sin = cos.contiguous().to(dev), sin.contiguous().to(dev)
+        else:
+            self.cos = self.sin = None
+
+    def make_cache(self) -> List[KVCache]:
+        return [KVCache(self.cfg.n_kv_heads, self.cfg.head_dim, self.device) for _ in range(self.cfg.n_layers)]
+
+    def _norm(self, x: torch.Tensor, p) -> torch.Tensor:
+        y = torch.empty_like(x)
+        if self.cfg.norm == "layer":
+            return ops.layernorm(x, y, weight=p[0], bias=p[1], eps=self.cfg.norm_eps)
+        return ops.rmsnorm(x, y, p[0], eps=self.cfg.norm_eps)
+
+    def __call__(self, x: torch.Tensor, cache: Optional[List[KVCache]] = None, return_layers: bool = False):
+        """x [B, L, d_model] fp32 on the device (modified in place and returned, normalised when ``final_norm``)."""
+        c = self.cfg
+        B, L, D = x.shape
+        assert D == c.d_model and x.is_contiguous()
+        if cache is None:
+            cache = self.make_cache()
+        H, G, dh = c.n_heads, c.n_kv_heads, c.head_dim
+        dev = self.device
+        q = torch.empty((B, L, H * dh), dtype=torch.float32, device=dev)
+        att = torch.empty((B, L, H * dh), dtype=torch.float32, device=dev)
+        ff_w = c.d_ff
+        mid = torch.empty((B, L, ff_w), dtype=torch.float32, device=dev)
+        gu = None
+        decode = L == 1 and B <= 8
+        if c.mlp == "swiglu" and not decode:
+            gu = torch.empty((B, L, 2 * c.d_ff), dtype=torch.float32, device=dev)
+        act = {"gelu": ACT_GELU, "gelu_tanh": ACT_GELU_TANH}.get(c.mlp, ACT_NONE)
+        layers = []
+        for lyr, kvc in zip(self.layers, cache):
+            off = kvc.offset
+            h = self._norm(x, lyr.attn_norm)
+            linear(h, lyr.wq, q, precision=self.precision)
+            slot = kvc.reserve(B, L)
+            linear(h, lyr.wkv, slot, precision=self.precision)
+            if lyr.q_norm is not None or self.cos is not None:
+                ops.head_norm_rope(q, q, heads=H, dh=dh, norm_weight=lyr.q_norm, eps=c.norm_eps, cos=self.cos, sin=self.sin, pos0=off,
+                                   interleaved=c.rope_interleaved)
+                ops.head_norm_rope(slot[:, :, : G * dh], slot[:, :, : G * dh], heads=G, dh=dh, norm_weight=lyr.k_norm, eps=c.norm_eps,
+                                   cos=self.cos, sin=self.sin, pos0=off, interleaved=c.rope_interleaved)
+            ops.flash_attention(q, kvc.keys, kvc.values, att, heads=H, kv_heads=G, dh=dh, causal=c.causal, window=c.window)
+            linear(att, lyr.wo, x, res=x, colscale=lyr.ls1, precision=self.precision)
+            h = self._norm(x, lyr.mlp_norm)
+            if c.mlp == "swiglu":
+                if decode:
+                    linear(h, lyr.w_in, mid, glu=True)
+                else:
+                    linear(h, lyr.w_in, gu, precision=self.precision)
+                    ops.swiglu(gu, mid)
+            else:
+                linear(h, lyr.w_in, mid, post_act=act, precision=self.precision)
+            linear(mid, lyr.w_out, x, res=x, colscale=lyr.ls2, precision=self.precision)
+            if return_layers:
+                layers.append(x.clone())
+        out = self._norm(x, self.final_norm) if self.final_norm is not None else x
+        return (out, layers) if return_layers else out

@@ -1,0 +1,247 @@
+"""Qwen3-TTS talker + code predictor frame loop on MI355X: host schedule over the HIP kernels.
+
+Mirrors the batched generation loop of the reference (``tts/models/qwen3_tts/qwen3_tts.py:1860-1935``) and the modules under it
+(``talker.py:230-822``): per 80 ms frame one talker step, the first-codebook sampling chain (suppress -> repetition penalty -> temperature
+-> top-k -> top-p -> categorical), 15 code-predictor steps on a fresh KV cache, and the next input embedding (text embed or tts_pad + sum of
+the 16 codec embeddings).  Every step is 1 row per sequence: Linear layers run as the HBM-bound ``mi355_gemv`` on row-major bf16 weights
+(SwiGLU fused), attention is the KV-streaming kernel, the whole sampling chain is ONE kernel per token, and the per-frame bookkeeping
+(finished mask, repetition-penalty history, trailing-text index) lives in device tensors -- the reference's per-frame ``mx.eval`` +
+``.tolist()`` round trip (qwen3_tts.py:1911-1914) is gone; completion is polled every ``poll`` frames.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from .... import ops
+from ....lm.stack import Lin, StackConfig, TransformerStack, linear, make_lin
+from ....ops import ACT_SILU
+from .config import Qwen3TTSTalkerConfig
+
+
+def talker_stack_config(c) -> StackConfig:
+    return StackConfig(d_model=c.hidden_size, n_layers=c.num_hidden_layers, n_heads=c.num_attention_heads, n_kv_heads=c.num_key_value_heads,
+                       head_dim=c.head_dim, d_ff=c.intermediate_size, norm="rms", norm_eps=c.rms_norm_eps, qk_norm=True, rope_theta=c.rope_theta,
+                       max_pos=min(c.max_position_embeddings, 8192), attn_bias=c.attention_bias, mlp="swiglu")
+
+
+def canonical(w: Dict[str, torch.Tensor], prefix: str, n_layers: int) -> Dict[str, torch.Tensor]:
+    """``<prefix>layers.N.self_attn.q_proj`` ... (talker.py module paths after sanitize :825-837) -> canonical stack names."""
+    m = {"self_attn.q_proj": "wq", "self_attn.k_proj": "wk", "self_attn.v_proj": "wv", "self_attn.o_proj": "wo", "mlp.gate_proj": "w_gate",
+         "mlp.up_proj": "w_up", "mlp.down_proj": "w_down", "input_layernorm": "attn_norm", "post_attention_layernorm": "mlp_norm",
+         "self_attn.q_norm": "q_norm", "self_attn.k_norm": "k_norm"}
+    out = {}
+    for i in range(n_layers):
+        for src, dst in m.items():
+            for suf in ("weight", "bias"):
+                k = f"{prefix}layers.{i}.{src}.{suf}"
+                if k in w:
+                    out[f"layers.{i}.{dst}.{suf}"] = w[k]
+    out["final_norm.weight"] = w[prefix + "norm.weight"]
+    return out
+
+
+def tiny_talker_config() -> Qwen3TTSTalkerConfig:
+    """Structurally identical (GQA, q/k norm, RoPE, SwiGLU, talker width != predictor width => small_to_mtp_projection, 4 code groups)."""
+    from .config import Qwen3TTSTalkerCodePredictorConfig
+
+    cp = Qwen3TTSTalkerCodePredictorConfig(vocab_size=96, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                                           num_key_value_heads=1, head_dim=64, num_code_groups=4)
+    return Qwen3TTSTalkerConfig(code_predictor_config=cp, vocab_size=1200, hidden_size=256, intermediate_size=384, num_hidden_layers=2,
+                                num_attention_heads=2, num_key_value_heads=1, head_dim=128, num_code_groups=4, text_hidden_size=192,
+                                text_vocab_size=500, codec_eos_token_id=1150)
+
+
+def make_talker_weights(cfg: Qwen3TTSTalkerConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seeded synthetic talker + code-predictor parameters (reference module paths, bf16-representable float32)."""
+    import math
+
+    from ....lm.synthetic import make_stack_weights
+
+    g = torch.Generator().manual_seed(seed)
+    cp = cfg.code_predictor_config
+    w: Dict[str, torch.Tensor] = {}
+
+    def r16(t):
+        return t.to(torch.bfloat16).to(torch.float32)
+
+    def rnd(*shape, std):
+        return r16(torch.randn(*shape, generator=g) * std)
+
+    inv = {"wq": "self_attn.q_proj", "wk": "self_attn.k_proj", "wv": "self_attn.v_proj", "wo": "self_attn.o_proj", "w_gate": "mlp.gate_proj",
+           "w_up": "mlp.up_proj", "w_down": "mlp.down_proj", "attn_norm": "input_layernorm", "mlp_norm": "post_attention_layernorm",
+           "q_norm": "self_attn.q_norm", "k_norm": "self_attn.k_norm"}
+    for prefix, c, sd in (("model.", cfg, seed * 7 + 1), ("code_predictor.model.", cp, seed * 7 + 2)):
+        sw = make_stack_weights(talker_stack_config(c), seed=sd, gain=1.5)
+        for k, v in sw.items():
+            if k.startswith("final_norm"):
+                w[prefix + "norm." + k.split(".", 1)[1]] = v
+            else:
+                _, i, name, suf = k.split(".")
+                w[f"{prefix}layers.{i}.{inv[name]}.{suf}"] = v
+    H = cfg.hidden_size
+    w["model.codec_embedding.weight"] = rnd(cfg.vocab_size, H, std=0.5)
+    w["model.text_embedding.weight"] = rnd(cfg.text_vocab_size, cfg.text_hidden_size, std=0.5)
+    w["text_projection.linear_fc1.weight"] = rnd(cfg.text_hidden_size, cfg.text_hidden_size, std=1.0 / math.sqrt(cfg.text_hidden_size))
+    w["text_projection.linear_fc1.bias"] = rnd(cfg.text_hidden_size, std=0.02)
+    w["text_projection.linear_fc2.weight"] = rnd(H, cfg.text_hidden_size, std=1.0 / math.sqrt(cfg.text_hidden_size))
+    w["text_projection.linear_fc2.bias"] = rnd(H, std=0.02)
+    w["codec_head.weight"] = rnd(cfg.vocab_size, H, std=4.0 / math.sqrt(H))
+    if cp.hidden_size != H:
+        w["code_predictor.small_to_mtp_projection.weight"] = rnd(cp.hidden_size, H, std=1.0 / math.sqrt(H))
+        w["code_predictor.small_to_mtp_projection.bias"] = rnd(cp.hidden_size, std=0.02)
+    for i in range(cfg.num_code_groups - 1):
+        w[f"code_predictor.model.codec_embedding.{i}.weight"] = rnd(cp.vocab_size, H, std=0.5)
+        w[f"code_predictor.lm_head.{i}.weight"] = rnd(cp.vocab_size, cp.hidden_size, std=4.0 / math.sqrt(cp.hidden_size))
+    return w
+
+
+class Qwen3Talker:
+    def __init__(self, weights: Dict[str, torch.Tensor], cfg: Qwen3TTSTalkerConfig, device="cuda:0", precision: int = 2):
+        ops.require_gpu()
+        self.cfg = cfg
+        cp = cfg.code_predictor_config
+        self.device = torch.device(device)
+        self.precision = precision
+        dev = self.device
+        w = {k: v.detach().to(torch.bfloat16).to(torch.float32).cpu() for k, v in weights.items()}
+        self.talker = TransformerStack(canonical(w, "model.", cfg.num_hidden_layers), talker_stack_config(cfg), device=dev, precision=precision)
+        self.cp = TransformerStack(canonical(w, "code_predictor.model.", cp.num_hidden_layers), talker_stack_config(cp), device=dev, precision=precision)
+        self.codec_head = make_lin(w["codec_head.weight"], None, dev)
+        self.lm_heads = [make_lin(w[f"code_predictor.lm_head.{i}.weight"], None, dev) for i in range(cfg.num_code_groups - 1)]
+        self.mtp: Optional[Lin] = None
+        if "code_predictor.small_to_mtp_projection.weight" in w:
+            self.mtp = make_lin(w["code_predictor.small_to_mtp_projection.weight"], w["code_predictor.small_to_mtp_projection.bias"], dev)
+        self.fc1 = make_lin(w["text_projection.linear_fc1.weight"], w["text_projection.linear_fc1.bias"], dev)
+        self.fc2 = make_lin(w["text_projection.linear_fc2.weight"], w["text_projection.linear_fc2.bias"], dev)
+        self.text_embedding = w["model.text_embedding.weight"].to(dev)
+        # one stacked codec-embedding table: slot 0 = talker codec_embedding, slots 1.. = code_predictor.codec_embedding[i]
+        tabs = [w["model.codec_embedding.weight"]] + [w[f"code_predictor.model.codec_embedding.{i}.weight"] for i in range(cfg.num_code_groups - 1)]
+        offs, r = [], 0
+        for t in tabs:
+            offs.append(r)
+            r += t.shape[0]
+        self.codec_table = torch.cat(tabs, 0).contiguous().to(dev)
+        self.codec_offs = torch.tensor(offs, dtype=torch.int32, device=dev)
+        self.codec_offs_host = offs
+        sup = torch.zeros(cfg.vocab_size)
+        sup[[i for i in range(cfg.vocab_size - 1024, cfg.vocab_size) if i != cfg.codec_eos_token_id]] = -float("inf")
+        self.suppress_mask = sup.to(dev)  # qwen3_tts.py:927-933
+
+    def _f(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    def embed_text(self, ids: torch.Tensor) -> torch.Tensor:
+        """text_projection(text_embedding(ids)) (talker.py:333-363, 786-793): int [B, L] -> [B, L, hidden]."""
+        ids = ids.to(self.device, torch.int32).contiguous()
+        B, L = ids.shape
+        e = self._f(B, L, self.cfg.text_hidden_size)
+        ops.gather_rows(self.text_embedding, ids, e)
+        h = self._f(B, L, self.cfg.text_hidden_size)
+        linear(e, self.fc1, h, post_act=ACT_SILU, precision=self.precision)
+        out = self._f(B, L, self.cfg.hidden_size)
+        linear(h, self.fc2, out, precision=self.precision)
+        return out
+
+    def _logits(self, h_last: torch.Tensor, head: Lin) -> torch.Tensor:
+        """h_last [B, 1, C] -> [B, V_padded] fp32."""
+        B = h_last.shape[0]
+        V = head.rm.n
+        out = self._f(B, 1, ops.round_up(V, 4))
+        linear(h_last, head, out[:, :, :V], precision=self.precision)
+        return out[:, 0, :]
+
+    def generate(self, prefill: torch.Tensor, trailing: torch.Tensor, tts_pad: torch.Tensor, max_frames: int, *, temperature: float = 0.9,
+                 top_k: int = 50, top_p: float = 1.0, repetition_penalty: float = 1.05, gumbel0: Optional[torch.Tensor] = None,
+                 gumbel_cp: Optional[torch.Tensor] = None, forced_codes: Optional[torch.Tensor] = None, record: bool = False, poll: int = 16):
+        cfg = self.cfg
+        cp = cfg.code_predictor_config
+        dev = self.device
+        G = cfg.num_code_groups
+        x = prefill.to(dev, torch.float32).contiguous().clone()
+        trailing = trailing.to(dev, torch.float32).contiguous()
+        pad = tts_pad.to(dev, torch.float32).reshape(1, -1)
+        B, _, H = x.shape
+        Tt = trailing.shape[1]
+        cache = self.talker.make_cache()
+        cp_cache = self.cp.make_cache()
+        finished = torch.zeros(B, dtype=torch.int32, device=dev)
+        finished_at = torch.full((B,), -1, dtype=torch.int64, device=dev)
+        hist = torch.full((B, max_frames + 1), -1, dtype=torch.int32, device=dev)
+        hist_len = torch.zeros(B, dtype=torch.int32, device=dev)
+        trailing_idx = torch.zeros(B, dtype=torch.int64, device=dev)
+        codes_all = torch.zeros((B, max_frames, G), dtype=torch.int32, device=dev)
+        ar = torch.arange(B, device=dev)
+        forced = None if forced_codes is None else forced_codes.to(dev, torch.int32)
+        V0, Vc = cfg.vocab_size, cp.vocab_size
+
+        def noise(t, V):
+            if t is None:
+                return None
+            n = torch.zeros((B, ops.round_up(V, 4)), dtype=torch.float32, device=dev)
+            n[:, :V] = t.to(dev, torch.float32)
+            return n
+
+        trace: List[list] = []
+        frames = 0
+        for f in range(max_frames):
+            h = self.talker(x, cache)
+            last = h[:, -1:, :].contiguous()
+            logits = self._logits(last, self.codec_head)
+            tr = [logits[:, :V0].clone()] if record else None
+            row = codes_all[:, f, :]
+            ops.sample(logits, row[:, 0], V=V0, suppress_mask=self.suppress_mask, history=hist, hist_len=hist_len,
+                       repetition_penalty=repetition_penalty, temperature=temperature, top_k=top_k, top_p=top_p,
+                       gumbel=noise(None if gumbel0 is None else gumbel0[f], V0), done=finished, done_token=cfg.codec_eos_token_id)
+            if forced is not None:
+                row[:, 0] = torch.where(finished.bool(), torch.full_like(forced[:, f, 0], cfg.codec_eos_token_id), forced[:, f, 0])
+            tok = row[:, 0]
+            newly = tok == cfg.codec_eos_token_id
+            finished_at = torch.where(newly & (finished == 0), torch.full_like(finished_at, f), finished_at)
+            finished = finished | newly.to(torch.int32)
+            # ---- code predictor: 15 steps on a fresh cache (qwen3_tts.py:941-983)
+            for c in cp_cache:
+                c.reset()
+            for i in range(G - 1):
+                if i == 0:
+                    xin = self._f(B, 2, H)
+                    xin[:, 0:1, :] = last
+                    ops.embed_sum(self.codec_table, row[:, 0:1].unsqueeze(1), xin[:, 1:2, :])
+                else:
+                    xin = self._f(B, 1, H)
+                    ops.embed_sum(self.codec_table, row[:, i:i + 1].unsqueeze(1), xin, slot_offset=self.codec_offs[i:i + 1])
+                if self.mtp is not None:
+                    xp = self._f(B, xin.shape[1], cp.hidden_size)
+                    linear(xin, self.mtp, xp, precision=self.precision)
+                    xin = xp
+                hc = self.cp(xin, cp_cache)
+                lg = self._logits(hc[:, -1:, :].contiguous(), self.lm_heads[i])
+                if record:
+                    tr.append(lg[:, :Vc].clone())
+                ops.sample(lg, row[:, i + 1], V=Vc, temperature=temperature, top_k=top_k, top_p=top_p,
+                           gumbel=noise(None if gumbel_cp is None else gumbel_cp[f][i], Vc))
+                if forced is not None:
+                    row[:, i + 1] = forced[:, f, i + 1]
+            # ---- next input: text embed (or tts_pad once the trailing text is exhausted) + sum of the 16 codec embeddings
+            clamped = torch.clamp(trailing_idx, max=Tt - 1)
+            text = trailing[ar, clamped]
+            text = torch.where((clamped >= Tt - 1)[:, None], pad.expand_as(text), text)
+            nx = self._f(B, 1, H)
+            ops.embed_sum(self.codec_table, row.unsqueeze(1), nx, slot_offset=self.codec_offs, add=text[:, None, :].contiguous())
+            x = nx
+            alive = finished == 0
+            trailing_idx = trailing_idx + alive.to(torch.int64)
+            hist[ar, hist_len.long()] = torch.where(alive, tok, hist[ar, hist_len.long()])
+            hist_len = hist_len + alive.to(torch.int32)
+            frames = f + 1
+            if record:
+                trace.append(tr)
+            if forced is None and frames % poll == 0 and bool((finished != 0).all()):  # the only host round trip of the loop
+                break
+        codes = codes_all[:, :frames].to(torch.int64)
+        if forced is None:
+            fa = finished_at.cpu()
+            if bool((fa >= 0).all()):
+                codes = codes[:, : int(fa.max()) + 1]  # the reference stops at the frame where the last sequence emits EOS
+        return dict(codes=codes, finished_at=finished_at, trace=trace)

@@ -1,0 +1,199 @@
+"""PyTorch-CPU restatement of the decoder-only transformer stacks on the hot path (TEST ORACLE, not product).
+
+One parametrised stack covers the four variants the reference implements separately (reference = /root/reference/mlx_audio):
+  * Qwen3-TTS talker / code predictor      ``tts/models/qwen3_tts/talker.py:230-400, 503-690``: RMSNorm, GQA, per-head q/k RMSNorm,
+                                           rotate-half RoPE (interleaved MRoPE collapses to plain RoPE for the three identical
+                                           text-only position streams, talker.py:139-226,455-467), SwiGLU, no biases
+  * Qwen3-TTS codec transformer            ``tts/models/qwen3_tts/speech_tokenizer.py:150-420``: RMSNorm(1e-5), rotate-half RoPE, SwiGLU,
+                                           LayerScale, input / output projections
+  * Mimi transformer                       ``codec/models/mimi/modules/transformer.py:60-200``: LayerNorm, fused in_proj, traditional
+                                           (interleaved) RoPE, causal + context window, GELU(tanh) MLP, LayerScale
+  * CSM / Llama backbone + depth decoder   ``lm/models/llama.py:46-198``, ``tts/models/sesame/attention.py:11-175``: RMSNorm, GQA,
+                                           Llama-3 scaled interleaved RoPE, SwiGLU
+and ``KVCacheRef`` restates ``lm/models/cache.py:104-176`` (step-256 pre-allocation, in-place slice update, ``[:offset]`` views).
+
+Canonical parameter names (the adapters in ``mlx_audio_amd/lm/adapters.py`` map every reference checkpoint onto them):
+  ``layers.{i}.attn_norm.weight[/bias]``, ``layers.{i}.wq|wk|wv|wo.weight[/bias]``, ``layers.{i}.q_norm.weight``, ``layers.{i}.k_norm.weight``,
+  ``layers.{i}.mlp_norm.weight[/bias]``, ``layers.{i}.w_gate|w_up|w_down.weight`` (SwiGLU) or ``layers.{i}.w1|w2.weight[/bias]``,
+  ``layers.{i}.ls1|ls2`` (LayerScale), ``final_norm.weight[/bias]``.
+
+Precision model: parameters hold bf16-representable values (checkpoint dtype), arithmetic float32 (float64 on request).
+Parity status: **unpinned end to end** (no golden logits exist in the reference for these models); ``vendor_parity`` pins the
+reference's ``lm`` package bit-exactly against ``mlx_lm`` only, which is equally unavailable here.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+@dataclass
+class StackConfig:
+    d_model: int
+    n_layers: int
+    n_heads: int
+    n_kv_heads: int
+    head_dim: int
+    d_ff: int
+    norm: str = "rms"            # "rms" | "layer"
+    norm_eps: float = 1e-6
+    qk_norm: bool = False
+    rope_theta: Optional[float] = 10000.0   # None: no rotary embedding
+    rope_interleaved: bool = False           # True: pairs (2i, 2i+1) ("traditional"); False: rotate-half pairs (i, i + d/2)
+    rope_llama3_factor: Optional[float] = None  # Llama-3 frequency scaling (sesame/attention.py:41-66)
+    max_pos: int = 4096
+    attn_bias: bool = False
+    mlp: str = "swiglu"          # "swiglu" | "gelu" | "gelu_tanh"
+    mlp_bias: bool = False
+    layer_scale: bool = False
+    causal: bool = True
+    window: int = 0              # > 0: keys older than `window` positions are invisible (Mimi context)
+    final_norm: bool = True
+
+
+def rope_inv_freq(cfg: StackConfig) -> Tensor:
+    d = cfg.head_dim
+    freqs = 1.0 / (cfg.rope_theta ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+    if cfg.rope_llama3_factor is not None:  # Llama3ScaledRoPE._apply_scaling with the reference's fixed constants
+        low_f, high_f, old_ctx = 1, 4, 8192
+        wavelen = 2.0 * math.pi / freqs
+        low, high = old_ctx / low_f, old_ctx / high_f
+        smooth = torch.clip((old_ctx / wavelen - low_f) / (high_f - low_f), 0.0, 1.0)
+        scaled = freqs / cfg.rope_llama3_factor
+        blended = (1.0 - smooth) * scaled + smooth * freqs
+        freqs = torch.where(wavelen < high, freqs, torch.where(wavelen > low, scaled, blended))
+    return freqs
+
+
+def rope_tables(cfg: StackConfig) -> Tuple[Tensor, Tensor]:
+    """cos / sin [max_pos, head_dim/2], float32 (talker.py:96-113: inv_freq * pos, then cos / sin)."""
+    ang = torch.arange(cfg.max_pos, dtype=torch.float32)[:, None] * rope_inv_freq(cfg)[None, :]
+    return torch.cos(ang), torch.sin(ang)
+
+
+def apply_rope(x: Tensor, cos: Tensor, sin: Tensor, interleaved: bool) -> Tensor:
+    """x [B, L, H, dh]; cos / sin [L, dh/2]."""
+    c, s = cos[None, :, None, :].to(x.dtype), sin[None, :, None, :].to(x.dtype)
+    if interleaved:  # sesame/attention.py:96-105, nn.RoPE(traditional=True)
+        xe, xo = x[..., 0::2], x[..., 1::2]
+        return torch.stack([xe * c - xo * s, xo * c + xe * s], dim=-1).reshape(x.shape)
+    h = x.shape[-1] // 2  # talker.py:14-36: (q * cos) + (rotate_half(q) * sin) with cos = cat(freqs, freqs)
+    x1, x2 = x[..., :h], x[..., h:]
+    return torch.cat([x1 * c - x2 * s, x2 * c + x1 * s], dim=-1)
+
+
+class KVCacheRef:
+    """lm/models/cache.py:104-176."""
+    step = 256
+
+    def __init__(self):
+        self.keys = None
+        self.values = None
+        self.offset = 0
+
+    def update_and_fetch(self, keys: Tensor, values: Tensor):
+        prev = self.offset
+        if self.keys is None or (prev + keys.shape[2]) > self.keys.shape[2]:
+            B, n_kv, _, dk = keys.shape
+            n_steps = (self.step + keys.shape[2] - 1) // self.step
+            new_k = torch.zeros(B, n_kv, n_steps * self.step, dk, dtype=keys.dtype)
+            new_v = torch.zeros(B, n_kv, n_steps * self.step, values.shape[3], dtype=values.dtype)
+            if self.keys is not None:
+                if prev % self.step != 0:
+                    self.keys, self.values = self.keys[..., :prev, :], self.values[..., :prev, :]
+                self.keys = torch.cat([self.keys, new_k], dim=2)
+                self.values = torch.cat([self.values, new_v], dim=2)
+            else:
+                self.keys, self.values = new_k, new_v
+        self.offset += keys.shape[2]
+        self.keys[..., prev:self.offset, :] = keys
+        self.values[..., prev:self.offset, :] = values
+        return self.keys[..., :self.offset, :], self.values[..., :self.offset, :]
+
+    def trim(self, n: int) -> int:
+        n = min(self.offset, n)
+        self.offset -= n
+        return n
+
+
+class StackRef:
+    def __init__(self, weights: Dict[str, Tensor], cfg: StackConfig, dtype=torch.float32, param_dtype=torch.bfloat16):
+        self.cfg = cfg
+        self.dtype = dtype
+        self.w = {k: v.to(param_dtype).to(dtype) for k, v in weights.items()}
+        if cfg.rope_theta is not None:
+            self.cos, self.sin = rope_tables(cfg)
+
+    def make_cache(self) -> List[KVCacheRef]:
+        return [KVCacheRef() for _ in range(self.cfg.n_layers)]
+
+    def _norm(self, x: Tensor, name: str) -> Tensor:
+        w = self.w[name + ".weight"]
+        if self.cfg.norm == "layer":
+            return F.layer_norm(x, (x.shape[-1],), w, self.w.get(name + ".bias"), self.cfg.norm_eps)
+        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + self.cfg.norm_eps) * w
+
+    def _lin(self, x: Tensor, name: str) -> Tensor:
+        return F.linear(x, self.w[name + ".weight"], self.w.get(name + ".bias"))
+
+    def _attn(self, i: int, x: Tensor, cache: Optional[KVCacheRef]) -> Tensor:
+        c = self.cfg
+        p = f"layers.{i}."
+        B, L, _ = x.shape
+        q = self._lin(x, p + "wq").reshape(B, L, c.n_heads, c.head_dim)
+        k = self._lin(x, p + "wk").reshape(B, L, c.n_kv_heads, c.head_dim)
+        v = self._lin(x, p + "wv").reshape(B, L, c.n_kv_heads, c.head_dim)
+        if c.qk_norm:
+            def hn(t, w):
+                return t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + c.norm_eps) * w
+            q, k = hn(q, self.w[p + "q_norm.weight"]), hn(k, self.w[p + "k_norm.weight"])
+        off = cache.offset if cache is not None else 0
+        if c.rope_theta is not None:
+            cos, sin = self.cos[off:off + L], self.sin[off:off + L]
+            q, k = apply_rope(q, cos, sin, c.rope_interleaved), apply_rope(k, cos, sin, c.rope_interleaved)
+        q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
+        if cache is not None:
+            k, v = cache.update_and_fetch(k, v)
+        Tk = k.shape[2]
+        grp = c.n_heads // c.n_kv_heads
+        kk, vv = k.repeat_interleave(grp, dim=1), v.repeat_interleave(grp, dim=1)
+        s = (q @ kk.transpose(-1, -2)) * (c.head_dim ** -0.5)
+        pos_q = torch.arange(L)[:, None] + (Tk - L)
+        pos_k = torch.arange(Tk)[None, :]
+        allowed = torch.ones(L, Tk, dtype=torch.bool)
+        if c.causal:
+            allowed &= pos_k <= pos_q
+        if c.window > 0:
+            allowed &= (pos_q - pos_k) < c.window  # mimi transformer.py:100-104
+        s = s + torch.where(allowed, 0.0, -1e9).to(s.dtype)
+        o = torch.softmax(s, dim=-1) @ vv
+        return self._lin(o.transpose(1, 2).reshape(B, L, c.n_heads * c.head_dim), p + "wo")
+
+    def _mlp(self, i: int, x: Tensor) -> Tensor:
+        p = f"layers.{i}."
+        if self.cfg.mlp == "swiglu":
+            return self._lin(F.silu(self._lin(x, p + "w_gate")) * self._lin(x, p + "w_up"), p + "w_down")
+        h = self._lin(x, p + "w1")
+        h = F.gelu(h, approximate="tanh") if self.cfg.mlp == "gelu_tanh" else F.gelu(h)
+        return self._lin(h, p + "w2")
+
+    def __call__(self, x: Tensor, cache: Optional[List[KVCacheRef]] = None, return_layers: bool = False):
+        c = self.cfg
+        x = x.to(self.dtype)
+        layers = []
+        for i in range(c.n_layers):
+            p = f"layers.{i}."
+            a = self._attn(i, self._norm(x, p + "attn_norm"), None if cache is None else cache[i])
+            x = x + (a * self.w[p + "ls1"] if c.layer_scale else a)
+            m = self._mlp(i, self._norm(x, p + "mlp_norm"))
+            x = x + (m * self.w[p + "ls2"] if c.layer_scale else m)
+            layers.append(x)
+        if c.final_norm:
+            x = self._norm(x, "final_norm")
+        return (x, layers) if return_layers else x

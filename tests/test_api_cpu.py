@@ -15,9 +15,10 @@ def test_registry_is_import_free_and_classifies():
     code = ("import sys; import mlx_audio_amd.registry as r; "
             "assert 'torch' not in sys.modules and 'mlx_audio_amd.ops' not in sys.modules; "
             "print(r.kinds(), r.classify_model('kokoro'), r.classify_model('', 'prince-canuma/Kokoro-82M'), r.classify_model('llama'), "
-            "r.is_supported_model('whisper'), r.classify_model('whisper'), r.is_supported_model('parakeet'))")
+            "r.is_supported_model('whisper'), r.classify_model('whisper'), r.is_supported_model('parakeet'), r.classify_model('qwen3_tts'), "
+            "r.classify_model('sesame'), r.classify_model('mimi'))")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout
-    assert out.strip() == "('tts', 'stt') tts tts None True stt False"
+    assert out.strip() == "('tts', 'stt', 'codec') tts tts None True stt False tts tts codec"
     from mlx_audio_amd import registry
 
     assert "kokoro" in registry.SUPPORTED_MODEL_TYPES["tts"]

@@ -1,0 +1,156 @@
+"""Qwen3-TTS talker / code predictor frame loop and CSM generate_frame (a28) on the HIP path vs the CPU
+oracles.  Integer path = the sampled codes: compared bit-exactly under teacher forcing wherever the oracle's decision margin exceeds the
+measured logit error (and free-running until the first knife-edge decision); logits <= 2e-3 of their peak.  Needs a real MI355X."""
+from dataclasses import asdict
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _gumbel(g, *shape):
+    return -torch.log(-torch.log(torch.rand(*shape, generator=g).clamp_(1e-9, 1 - 1e-9)))
+
+
+def _check_trace(exp_trace, got_trace, what):
+    worst = 0.0
+    for f, (ef, gf) in enumerate(zip(exp_trace, got_trace)):
+        assert len(ef) == len(gf)
+        for i, (e, g) in enumerate(zip(ef, gf)):
+            err = float((g.cpu() - e).abs().max())
+            peak = float(e.abs().max())
+            assert err <= 2e-3 * peak, (what, f, i, err, peak)
+            worst = max(worst, err / peak)
+            top2 = torch.topk(e, 2, dim=-1).values
+            clear = (top2[:, 0] - top2[:, 1]) > 10 * err
+            if bool(clear.any()):
+                assert torch.equal(g.cpu().argmax(-1)[clear], e.argmax(-1)[clear]), (what, f, i)
+    return worst
+
+
+@pytest.fixture(scope="module")
+def talker():
+    from mlx_audio_amd import ops
+    from mlx_audio_amd.tts.models.qwen3_tts import talker as T
+    from oracle.qwen3_talker_ref import Qwen3TalkerRef
+
+    ops.require_gpu()
+    cfg = T.tiny_talker_config()
+    w = T.make_talker_weights(cfg, seed=1)
+    g = torch.Generator().manual_seed(3)
+    B, H = 3, cfg.hidden_size
+    return dict(cfg=cfg, eng=T.Qwen3Talker(w, cfg, device=DEV), ref=Qwen3TalkerRef(w, cfg), B=B,
+                pre=torch.randn(B, 7, H, generator=g) * 0.5, trail=torch.randn(B, 3, H, generator=g) * 0.5, pad=torch.randn(1, 1, H, generator=g) * 0.5)
+
+
+def test_qwen3_text_projection(talker):
+    ids = torch.randint(0, talker["cfg"].text_vocab_size, (2, 9))
+    exp = talker["ref"].text_projection(talker["ref"].w["model.text_embedding.weight"][ids])
+    got = talker["eng"].embed_text(ids)
+    torch.cuda.synchronize()
+    assert float((got.cpu() - exp).abs().max() / exp.abs().max()) < 2e-4
+
+
+def test_qwen3_frame_loop_teacher_forced(talker):
+    cfg, B = talker["cfg"], talker["B"]
+    g = torch.Generator().manual_seed(5)
+    frames = 6
+    gu0, guc = _gumbel(g, frames, B, cfg.vocab_size), _gumbel(g, frames, cfg.num_code_groups - 1, B, cfg.code_predictor_config.vocab_size)
+    kw = dict(temperature=0.9, top_k=50, top_p=0.95, repetition_penalty=1.05, gumbel0=gu0, gumbel_cp=guc)
+    free = talker["ref"].generate(talker["pre"], talker["trail"], talker["pad"], frames, **kw)
+    forced = free["codes"].clone()
+    forced[1, 3, 0] = cfg.codec_eos_token_id   # sequence 1 ends at frame 3: finished rows keep emitting EOS, its history stops growing
+    exp = talker["ref"].generate(talker["pre"], talker["trail"], talker["pad"], frames, forced_codes=forced, record=True, **kw)
+    got = talker["eng"].generate(talker["pre"], talker["trail"], talker["pad"], frames, forced_codes=forced, record=True, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(got["codes"].cpu(), exp["codes"])
+    assert got["finished_at"].cpu().tolist() == exp["finished_at"].tolist() == [-1, 3, -1]
+    _check_trace(exp["trace"], got["trace"], "qwen3")
+
+
+def test_qwen3_frame_loop_free_running_greedy(talker):
+    frames = 5
+    exp = talker["ref"].generate(talker["pre"], talker["trail"], talker["pad"], frames, temperature=0.0, record=True)
+    got = talker["eng"].generate(talker["pre"], talker["trail"], talker["pad"], frames, temperature=0.0, poll=2)
+    torch.cuda.synchronize()
+    ec, gc = exp["codes"], got["codes"].cpu()
+    for b in range(ec.shape[0]):
+        # walk the decisions in generation order; stop comparing a sequence at its first knife-edge (margin < 1e-2) decision
+        ok = True
+        for f in range(ec.shape[1]):
+            for i in range(ec.shape[2]):
+                if not ok:
+                    break
+                lg = exp["trace"][f][i][b]
+                if i == 0:  # first codebook: decision is taken on the filtered logits; approximate the margin on the raw ones
+                    pass
+                top2 = torch.topk(lg, 2).values
+                if float(top2[0] - top2[1]) < 1e-2:
+                    ok = False
+                    break
+                assert int(gc[b, f, i]) == int(ec[b, f, i]), (b, f, i)
+
+
+@pytest.fixture(scope="module")
+def csm():
+    from mlx_audio_amd import ops
+    from mlx_audio_amd.tts.models.sesame import engine as E
+    from oracle import csm_ref as R
+
+    ops.require_gpu()
+    cfg = E.tiny_csm()
+    w = E.make_csm_weights(cfg, seed=2)
+    rcfg = R.CSMConfig(backbone=R.StackConfig(**asdict(cfg.backbone)), decoder=R.StackConfig(**asdict(cfg.decoder)),
+                       audio_vocab_size=cfg.audio_vocab_size, audio_num_codebooks=cfg.audio_num_codebooks, text_vocab_size=cfg.text_vocab_size)
+    g = torch.Generator().manual_seed(4)
+    B, S, nb = 2, 9, cfg.audio_num_codebooks
+    toks = torch.zeros(B, S, nb + 1, dtype=torch.long)
+    mask = torch.zeros(B, S, nb + 1, dtype=torch.bool)
+    toks[:, :5, -1] = torch.randint(0, cfg.text_vocab_size, (B, 5), generator=g)
+    mask[:, :5, -1] = True
+    toks[:, 5:, :nb] = torch.randint(1, cfg.audio_vocab_size, (B, 4, nb), generator=g)
+    mask[:, 5:, :nb] = True
+    return dict(cfg=cfg, eng=E.CSMEngine(w, cfg, device=DEV), ref=R.CSMRef(w, rcfg), toks=toks, mask=mask, B=B)
+
+
+def test_csm_frames_teacher_forced(csm):
+    cfg, B = csm["cfg"], csm["B"]
+    g = torch.Generator().manual_seed(6)
+    frames = 4
+    gum = _gumbel(g, frames, cfg.audio_num_codebooks, B, cfg.audio_vocab_size)
+    free = csm["ref"].generate(csm["toks"], csm["mask"], frames, gumbel=gum)
+    forced = free["frames"]
+    assert forced.shape[1] == frames
+    exp = csm["ref"].generate(csm["toks"], csm["mask"], frames, gumbel=gum, forced=forced, record=True)
+    got = csm["eng"].generate(csm["toks"], csm["mask"], frames, gumbel=gum, forced=forced, record=True)
+    torch.cuda.synchronize()
+    assert torch.equal(got["frames"].cpu(), exp["frames"])
+    _check_trace(exp["trace"], got["trace"], "csm")
+
+
+def test_csm_free_running_greedy_and_eos(csm):
+    exp = csm["ref"].generate(csm["toks"], csm["mask"], 3, temperature=0.0, record=True)
+    got = csm["eng"].generate(csm["toks"], csm["mask"], 3, temperature=0.0, poll=1)
+    torch.cuda.synchronize()
+    ef, gf = exp["frames"], got["frames"].cpu()
+    assert gf.shape == ef.shape
+    for b in range(ef.shape[0]):
+        ok = True
+        for f in range(ef.shape[1]):
+            for i in range(ef.shape[2]):
+                top2 = torch.topk(exp["trace"][f][i][b], 2).values
+                if float(top2[0] - top2[1]) < 1e-2:
+                    ok = False
+                if not ok:
+                    break
+                assert int(gf[b, f, i]) == int(ef[b, f, i]), (b, f, i)
+            if not ok:
+                break
+    # EOS: an all-zero frame stops the loop and is not returned (sesame.py:828)
+    forced = torch.zeros(csm["B"], 2, csm["cfg"].audio_num_codebooks, dtype=torch.long)
+    forced[:, 0] = 5
+    out = csm["eng"].generate(csm["toks"], csm["mask"], 2, forced=forced)
+    assert out["frames"].shape[1] == 1

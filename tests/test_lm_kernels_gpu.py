@@ -1,0 +1,226 @@
+"""Parity of the decoder-stack glue kernels, the on-device sampler and the generic TransformerStack against fp64 torch / the CPU oracle.
+Needs a real MI355X: ``pytest -m gpu``."""
+import math
+from dataclasses import asdict
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mlx_audio_amd import ops as _ops
+
+    _ops.require_gpu()
+    return _ops
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def test_rmsnorm(ops):
+    g = torch.Generator().manual_seed(0)
+    for C in (128, 1024, 2048, 516):
+        x = torch.randn(3, 7, C + 4, generator=g)[:, :, :C]
+        w = torch.randn(C, generator=g)
+        exp = x.double() * torch.rsqrt(x.double().pow(2).mean(-1, keepdim=True) + 1e-6) * w.double()
+        xd = torch.zeros(3, 7, C + 4, device=DEV)
+        xd[:, :, :C] = x.to(DEV)
+        y = torch.empty(3, 7, C, device=DEV)
+        lens = torch.tensor([7, 3, 5], dtype=torch.int32, device=DEV)
+        y.fill_(9.0)
+        ops.rmsnorm(xd[:, :, :C], y, w.to(DEV), eps=1e-6, lens=lens)
+        torch.cuda.synchronize()
+        for b, n in enumerate((7, 3, 5)):
+            assert rel_err(y[b, :n], exp[b, :n]) < 2e-6
+            assert torch.all(y[b, n:] == 9.0)
+
+
+@pytest.mark.parametrize("dh,heads,interleaved,norm", [(64, 3, False, True), (128, 2, False, True), (64, 4, True, False), (128, 8, True, True),
+                                                         (64, 2, False, False)])
+def test_head_norm_rope(ops, dh, heads, interleaved, norm):
+    from oracle.lm_ref import StackConfig, apply_rope, rope_tables
+
+    g = torch.Generator().manual_seed(dh + heads)
+    B, L, off = 2, 9, 37
+    cfg = StackConfig(d_model=64, n_layers=1, n_heads=heads, n_kv_heads=heads, head_dim=dh, d_ff=64, rope_theta=10000.0, max_pos=128)
+    cos, sin = rope_tables(cfg)
+    x = torch.randn(B, L, heads * dh + 16, generator=g)
+    nw = torch.randn(dh, generator=g) if norm else None
+    xr = x[:, :, :heads * dh].reshape(B, L, heads, dh).double()
+    if norm:
+        xr = xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6) * nw.double()
+    exp = apply_rope(xr, cos[off:off + L].double(), sin[off:off + L].double(), interleaved).reshape(B, L, heads * dh)
+    xd = x.to(DEV)
+    y = torch.zeros(B, L, heads * dh, device=DEV)
+    ops.head_norm_rope(xd[:, :, :heads * dh], y, heads=heads, dh=dh, norm_weight=None if nw is None else nw.to(DEV), eps=1e-6,
+                       cos=cos.to(DEV), sin=sin.to(DEV), pos0=off, interleaved=interleaved)
+    torch.cuda.synchronize()
+    assert rel_err(y, exp) < 3e-6
+    # in place + explicit positions
+    pos = (torch.arange(L, dtype=torch.int32)[None, :] + off).repeat(B, 1).to(DEV)
+    z = xd[:, :, :heads * dh]
+    ops.head_norm_rope(z, z, heads=heads, dh=dh, norm_weight=None if nw is None else nw.to(DEV), eps=1e-6, cos=cos.to(DEV), sin=sin.to(DEV),
+                       pos=pos, interleaved=interleaved)
+    torch.cuda.synchronize()
+    assert rel_err(z, exp) < 3e-6
+
+
+def test_swiglu_embed_sum_dwconv(ops):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 5, 2 * 96, generator=g)
+    y = torch.empty(2, 5, 96, device=DEV)
+    ops.swiglu(x.to(DEV), y)
+    exp = F.silu(x[..., 0::2].double()) * x[..., 1::2].double()
+    assert rel_err(y, exp) < 2e-6
+    # embed_sum: 3 slots of 50-row tables, masked slot, add row, scale
+    table = torch.randn(150, 64, generator=g)
+    ids = torch.randint(0, 50, (2, 3, 7), generator=g, dtype=torch.int32)  # [B, Q, N] like codec codes
+    ids[1, 2, 4] = -1
+    add = torch.randn(2, 7, 64, generator=g)
+    offs = torch.tensor([0, 50, 100], dtype=torch.int32)
+    exp = add.double().clone()
+    for b in range(2):
+        for n in range(7):
+            for q in range(3):
+                if ids[b, q, n] >= 0:
+                    exp[b, n] += table[int(offs[q]) + int(ids[b, q, n])].double()
+    exp *= 0.5
+    out = torch.empty(2, 7, 64, device=DEV)
+    ops.embed_sum(table.to(DEV), ids.to(DEV).permute(0, 2, 1), out, slot_offset=offs.to(DEV), add=add.to(DEV), scale=0.5)
+    assert rel_err(out, exp) < 2e-6
+    # depthwise causal conv k7 and depthwise transposed conv (k4, s2, causal trim)
+    C, L = 40, 33
+    xc = torch.randn(2, L, C, generator=g)
+    w = torch.randn(C, 7, generator=g)
+    bias = torch.randn(C, generator=g)
+    exp = F.conv1d(F.pad(xc.transpose(1, 2).double(), (6, 0)), w.double()[:, None, :], bias.double(), groups=C).transpose(1, 2)
+    yc = torch.empty(2, L, C, device=DEV)
+    ops.dwconv(xc.to(DEV), w.to(DEV), bias.to(DEV), yc, pad=6)
+    assert rel_err(yc, exp) < 2e-6
+    wt = torch.randn(C, 4, generator=g)
+    full = F.conv_transpose1d(xc.transpose(1, 2).double(), wt.double()[:, None, :], None, stride=2, groups=C).transpose(1, 2)
+    yt = torch.empty(2, 2 * L, C, device=DEV)
+    ops.dwconv(xc.to(DEV), wt.to(DEV), None, yt, pad=0, stride=2, transpose=True)
+    torch.cuda.synchronize()
+    assert rel_err(yt, full[:, :2 * L]) < 2e-6
+
+
+SAMPLE_CASES = [
+    dict(temperature=0.9, top_k=50, top_p=1.0, min_p=0.0, repetition_penalty=1.05),     # the reference's defaults (qwen3_tts.py:805-815)
+    dict(temperature=0.9, top_k=50, top_p=0.8, min_p=0.0, repetition_penalty=1.05),
+    dict(temperature=0.7, top_k=0, top_p=0.9, min_p=0.05, repetition_penalty=1.0),
+    dict(temperature=1.0, top_k=5, top_p=1.0, min_p=0.0, repetition_penalty=1.3),
+    dict(temperature=0.0, top_k=50, top_p=0.5, min_p=0.0, repetition_penalty=1.05),      # greedy: arg-max of the penalised logits
+]
+
+
+@pytest.mark.parametrize("case", range(len(SAMPLE_CASES)))
+@pytest.mark.parametrize("V", [3072, 2051])
+def test_sampler_matches_reference_chain(ops, case, V):
+    from oracle import sampling_ref as R
+
+    kw = SAMPLE_CASES[case]
+    g = torch.Generator().manual_seed(100 * case + V)
+    B = 4
+    logits = torch.randn(B, V, generator=g) * 4.0
+    logits[0, 7] = logits[0, 9] = logits[0].max() + 1.0  # a tie at the top
+    suppress = list(range(V - 1024, V - 1000)) if V == 3072 else []
+    hist = [torch.randint(0, V, (n,), generator=g).tolist() for n in (0, 5, 40, 300)]
+    u = torch.rand(B, V, generator=g).clamp_(1e-9, 1 - 1e-9)
+    gum = -torch.log(-torch.log(u))
+    expf = R.filter_logits(logits, generated=hist, suppress_tokens=suppress, **kw)
+    exp_tok = R.sample(logits, gum, generated=hist, suppress_tokens=suppress, **kw)
+    ld = V + 5
+    lgd = torch.zeros(B, ld, device=DEV)
+    lgd[:, :V] = logits.to(DEV)
+    gd = torch.zeros(B, ld, device=DEV)
+    gd[:, :V] = gum.to(DEV)
+    H = 512
+    hd = torch.full((B, H), -1, dtype=torch.int32)
+    for b, h in enumerate(hist):
+        hd[b, :len(h)] = torch.tensor(h, dtype=torch.int32)
+    hl = torch.tensor([len(h) for h in hist], dtype=torch.int32)
+    sm = torch.zeros(V)
+    if suppress:
+        sm[suppress] = -float("inf")
+    out = torch.full((B,), -7, dtype=torch.int32, device=DEV)
+    filt = torch.zeros(B, ld, device=DEV)
+    ops.sample(lgd, out, V=V, suppress_mask=sm.to(DEV), history=hd.to(DEV), hist_len=hl.to(DEV), gumbel=gd, filtered=filt, **kw)
+    torch.cuda.synchronize()
+    got = filt[:, :V].cpu()
+    assert torch.equal(torch.isinf(got), torch.isinf(expf)), "filter pattern differs"
+    fin = torch.isfinite(expf)
+    np.testing.assert_allclose(got[fin].numpy(), expf[fin].numpy(), rtol=2e-6, atol=1e-6)
+    assert out.cpu().tolist() == exp_tok.tolist()
+
+
+def test_sampler_done_rows(ops):
+    logits = torch.randn(3, 64).to(DEV)
+    out = torch.zeros(3, dtype=torch.int32, device=DEV)
+    done = torch.tensor([0, 1, 0], dtype=torch.int32, device=DEV)
+    ops.sample(logits, out, temperature=0.0, done=done, done_token=2150)
+    torch.cuda.synchronize()
+    exp = logits.cpu().argmax(-1).tolist()
+    assert out.cpu().tolist() == [exp[0], 2150, exp[2]]
+
+
+# ------------------------------------------------------------------------------------------------ the generic stack
+def _variants():
+    from oracle.lm_ref import StackConfig
+
+    return {
+        "qwen3_talker": StackConfig(d_model=256, n_layers=2, n_heads=4, n_kv_heads=2, head_dim=128, d_ff=384, norm="rms", norm_eps=1e-6, qk_norm=True,
+                                    rope_theta=1e6, max_pos=512),
+        "qwen3_codec": StackConfig(d_model=128, n_layers=2, n_heads=2, n_kv_heads=2, head_dim=64, d_ff=256, norm="rms", norm_eps=1e-5,
+                                   rope_theta=1e4, max_pos=512, layer_scale=True),
+        "mimi": StackConfig(d_model=128, n_layers=2, n_heads=2, n_kv_heads=2, head_dim=64, d_ff=512, norm="layer", norm_eps=1e-5, rope_theta=1e4,
+                            rope_interleaved=True, max_pos=512, mlp="gelu_tanh", layer_scale=True, window=20, final_norm=False),
+        "csm_llama": StackConfig(d_model=256, n_layers=2, n_heads=4, n_kv_heads=1, head_dim=64, d_ff=512, norm="rms", norm_eps=1e-5,
+                                 rope_theta=5e5, rope_interleaved=True, rope_llama3_factor=32.0, max_pos=512),
+    }
+
+
+@pytest.mark.parametrize("name", ["qwen3_talker", "qwen3_codec", "mimi", "csm_llama"])
+def test_transformer_stack_prefill_and_decode(ops, name):
+    from mlx_audio_amd.lm.stack import StackConfig, TransformerStack
+    from mlx_audio_amd.lm.synthetic import make_stack_weights
+    from oracle.lm_ref import StackRef
+
+    rcfg = _variants()[name]
+    w = make_stack_weights(rcfg, seed=3)
+    ref = StackRef(w, rcfg)
+    eng = TransformerStack(w, StackConfig(**asdict(rcfg)), device=DEV)
+    g = torch.Generator().manual_seed(5)
+    B, L, steps = 2, 37, 5
+    x = torch.randn(B, L + steps, rcfg.d_model, generator=g)
+    # prefill of L positions, then `steps` single-position decode steps through the KV caches
+    rc, ec = ref.make_cache(), eng.make_cache()
+    exp, exp_layers = ref(x[:, :L], rc, return_layers=True)
+    got, layers = eng(x[:, :L].contiguous().to(DEV), ec, return_layers=True)
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(layers, exp_layers)):
+        assert rel_err(a, b) < 2e-4, (i, rel_err(a, b))
+    assert rel_err(got, exp) < 2e-4
+    for s in range(steps):
+        e = ref(x[:, L + s:L + s + 1], rc)
+        o = eng(x[:, L + s:L + s + 1].contiguous().to(DEV), ec)
+        torch.cuda.synchronize()
+        assert rel_err(o, e) < 2e-4, (s, rel_err(o, e))
+    assert ec[0].offset == L + steps == rc[0].offset
+    # the step-256 cache growth (lm/models/cache.py:113-128): capacity is a multiple of 256 and survives a second growth
+    assert ec[0].kv.shape[1] % 256 == 0
+    big = torch.randn(B, 300, rcfg.d_model, generator=g)
+    e = ref(big, rc)
+    o = eng(big.contiguous().to(DEV), ec)
+    torch.cuda.synchronize()
+    assert rel_err(o, e) < 3e-4
+    assert ec[0].offset == L + steps + 300 and ec[0].kv.shape[1] >= ec[0].offset
+    assert ec[0].trim(10) == 10 and ec[0].offset == L + steps + 290
