@@ -412,6 +412,11 @@ typedef struct {
   float out_scale;         /* 0 => 1 */
   int32_t glu;
   float* y; int32_t ldy;
+  /* fused input normalisation over K (the pre-LN of a transformer block, whisper.py:407-415 / talker.py:385-396):
+     norm = 1: LayerNorm (x - mean) * rsqrt(var + eps) * norm_weight + norm_bias;  norm = 2: RMSNorm x * rsqrt(mean(x^2) + eps) * norm_weight */
+  int32_t norm; const float* norm_weight; const float* norm_bias; float norm_eps;
+  /* optional second destination: columns n >= split are written to y2[m, n - split] (q -> y, k|v -> the KV-cache slot) */
+  float* y2; int32_t ldy2; int32_t split;
 } mi355_gemv_args;
 int mi355_gemv(const mi355_gemv_args* a, void* stream);
 int mi355_pack_rowmajor16_host(const float* w_host, int64_t n, int32_t dtype, uint16_t* out_host);

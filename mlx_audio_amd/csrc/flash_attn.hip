@@ -18,8 +18,8 @@
 //     chosen as the C-layout row order ((s&3) + 8*(s>>2) + 4*(lane>>5)) no data movement is needed at all.
 //     LDS rows are padded to DH+1 floats: the A-operand ds_read_b32 of both phases is bank-conflict free.
 //
-//   attn_decode_kernel<DH> (Tq <= 8, the KV-cache decode step): one workgroup per (query, head, item); the 4 waves
-//     take interleaved 64-key chunks, lanes own keys for q.k (float4 row reads) and own channels for p.V, online
+//   attn_decode_kernel<DH> (Tq <= 8, the KV-cache decode step): one workgroup per (query, head, item); its 4 (or, for
+//     more than 256 keys, 16) waves take interleaved 64-key chunks, lanes own keys for q.k (float4 row reads) and own channels for p.V, online
 //     softmax per wave, merged through LDS at the end.  An MFMA tile would be 31/32 idle here; this path is bound by
 //     reading the KV cache once.
 //
@@ -189,13 +189,13 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const mi355_flash_attn_
   }
 }
 
-template <int DH>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const mi355_flash_attn_args a) {
+template <int DH, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_attn_args a) {
   constexpr int ND = DH / 64;  // channels per lane in the p.V phase
   __shared__ float qs[DH];
-  __shared__ float ps[4][64];
-  __shared__ float red_m[4], red_l[4];
-  __shared__ float red_o[4][DH];
+  __shared__ float ps[NW][64];
+  __shared__ float red_m[NW], red_l[NW];
+  __shared__ float red_o[NW][DH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qi = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int g = h / (a.heads / a.kv_heads);
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const mi355_flash_attn
   const int len_k = a.lens_k ? a.lens_k[b] : a.Tk;
   if (qi >= len_q) return;
   const int qpos = qi + (len_k - len_q);
-  if (tid < DH) qs[tid] = a.q[(int64_t)b * a.q_bstride + (int64_t)qi * a.ldq + h * DH + tid] * (a.scale * kLog2e);
+  for (int t = tid; t < DH; t += NW * 64) qs[t] = a.q[(int64_t)b * a.q_bstride + (int64_t)qi * a.ldq + h * DH + t] * (a.scale * kLog2e);
   __syncthreads();
   int kend = len_k, kbeg = 0;
   if (a.causal) kend = qpos + 1 < len_k ? qpos + 1 : len_k;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const mi355_flash_attn
   float m = -INFINITY, l = 0.f, o[ND];
 #pragma unroll
   for (int i = 0; i < ND; ++i) o[i] = 0.f;
-  for (int kb = kbeg + wave * 64; kb < kend; kb += 256) {
+  for (int kb = kbeg + wave * 64; kb < kend; kb += NW * 64) {
     const int j = kb + lane;
     float s = -INFINITY;
     if (j < kend) {
@@ -252,11 +252,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const mi355_flash_attn
   for (int i = 0; i < ND; ++i) red_o[wave][i * 64 + lane] = o[i];
   __syncthreads();
   if (wave == 0) {
-    float M = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
-    float L = 0.f;
-    float w[4];
+    float M = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NW; ++i) M = fmaxf(M, red_m[i]);
+    float L = 0.f;
+    float w[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
       w[i] = red_m[i] == -INFINITY ? 0.f : exp2f(red_m[i] - M);
       L += red_l[i] * w[i];
     }
@@ -265,7 +267,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const mi355_flash_attn
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
       const int d = i * 64 + lane;
-      const float t = red_o[0][d] * w[0] + red_o[1][d] * w[1] + red_o[2][d] * w[2] + red_o[3][d] * w[3];
+      float t = 0.f;
+#pragma unroll
+      for (int j = 0; j < NW; ++j) t += red_o[j][d] * w[j];
       orow[d] = t * inv;
     }
   }
@@ -289,8 +293,16 @@ extern "C" int mi355_flash_attention(const mi355_flash_attn_args* ap, void* stre
   const bool decode = a.mode == 2 || (a.mode == 0 && a.Tq <= 8);
   if (decode) {
     dim3 grid(a.Tq, a.heads, a.B);
-    if (a.dh == 64) hipLaunchKernelGGL(attn_decode_kernel<64>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(attn_decode_kernel<128>, grid, dim3(256), 0, st, a);
+    // long key ranges (Whisper cross-attention: 1500 keys) get 16 waves per (query, head): the per-wave key loop is a dependent
+    // chain of global loads, so more waves in flight is what shortens it; short ranges keep 4 waves
+    const bool wide = a.Tk > 256;
+    if (a.dh == 64) {
+      if (wide) hipLaunchKernelGGL((attn_decode_kernel<64, 16>), grid, dim3(1024), 0, st, a);
+      else hipLaunchKernelGGL((attn_decode_kernel<64, 4>), grid, dim3(256), 0, st, a);
+    } else {
+      if (wide) hipLaunchKernelGGL((attn_decode_kernel<128, 16>), grid, dim3(1024), 0, st, a);
+      else hipLaunchKernelGGL((attn_decode_kernel<128, 4>), grid, dim3(256), 0, st, a);
+    }
   } else {
     dim3 grid((a.Tq + 127) / 128, a.heads, a.B);
     if (a.dh == 64) hipLaunchKernelGGL(flash_attn_kernel<64>, grid, dim3(256), 0, st, a);

@@ -9,7 +9,8 @@
 // wavefront owns NC output columns, lanes stride K in 16-byte (8-element) pieces so every weight load is a fully coalesced
 // 1 KB wave access, x is staged in LDS once per workgroup in K-chunks, products accumulate in fp32 FMAs (exact on the
 // 16-bit weights) and a wave-level butterfly finishes each column.  Epilogue: bias, activation, residual, scale, and the
-// optional fused SwiGLU (interleaved gate / up rows: y[n/2] = silu(acc[n]) * acc[n+1]).
+// optional fused SwiGLU (interleaved gate / up rows: y[n/2] = silu(acc[n]) * acc[n+1]).  Prologue (optional): LayerNorm / RMSNorm of
+// the input rows, recomputed per workgroup; the output columns can be split over two destinations (q | k,v -> buffer | KV-cache slot).
 #include "common.h"
 
 namespace {
@@ -59,13 +60,41 @@ __global__ __launch_bounds__(256) void gemv_kernel(const mi355_gemv_args a) {
     const int n = n0 + c < a.N ? n0 + c : a.N - 1;  // clamp: tail columns recompute the last row, never stored
     wrow[c] = a.w + (int64_t)n * a.ldw;
   }
+  // fused input normalisation (LayerNorm / RMSNorm of the M input rows): every workgroup recomputes the row statistics out of L2
+  // (M * K floats, twice) instead of a separate norm launch writing and re-reading the normalised rows
+  __shared__ float st_mean[8], st_rstd[8];
+  if (a.norm) {
+    for (int m = wave; m < a.M; m += 4) {
+      const float* xr = a.x + (int64_t)m * a.ldx;
+      float s = 0.f;
+      for (int k = lane * 4; k < a.K; k += 256) { const float4 t = *(const float4*)(xr + k); s += (t.x + t.y) + (t.z + t.w); }
+      const float mean = a.norm == 1 ? wave_sum(s) / (float)a.K : 0.f;
+      float q = 0.f;
+      for (int k = lane * 4; k < a.K; k += 256) {
+        const float4 t = *(const float4*)(xr + k);
+        const float d0 = t.x - mean, d1 = t.y - mean, d2 = t.z - mean, d3 = t.w - mean;
+        q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
+      const float var = wave_sum(q) / (float)a.K;
+      if (lane == 0) { st_mean[m] = mean; st_rstd[m] = a.norm == 1 ? 1.0f / sqrtf(var + a.norm_eps) : rsqrtf(var + a.norm_eps); }
+    }
+  }
   for (int k0 = 0; k0 < a.K; k0 += kKC) {
     const int kc = a.K - k0 < kKC ? a.K - k0 : kKC;  // multiple of 8 (K % 8 == 0)
     __syncthreads();
     for (int e = tid * 4; e < MT * kc; e += 1024) {
       const int m = e / kc, k = e - m * kc;
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < a.M) t = *(const float4*)(a.x + (int64_t)m * a.ldx + k0 + k);
+      if (m < a.M) {
+        t = *(const float4*)(a.x + (int64_t)m * a.ldx + k0 + k);
+        if (a.norm) {
+          const float mu = st_mean[m], rs = st_rstd[m];
+          float4 w4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (a.norm_weight) w4 = *(const float4*)(a.norm_weight + k0 + k);
+          if (a.norm_bias) b4 = *(const float4*)(a.norm_bias + k0 + k);
+          t = make_float4((t.x - mu) * rs * w4.x + b4.x, (t.y - mu) * rs * w4.y + b4.y, (t.z - mu) * rs * w4.z + b4.z, (t.w - mu) * rs * w4.w + b4.w);
+        }
+      }
       *(float4*)(xs + m * kKC + k) = t;
     }
     __syncthreads();
@@ -126,7 +155,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(const mi355_gemv_args a) {
       if (m >= a.M) break;
       float v = gemv_act(acc[c][m] + bias, a.post_act, a.post_slope) * cs;
       if (a.res) v += a.res[(int64_t)m * a.ldr + n];
-      a.y[(int64_t)m * a.ldy + n] = v * a.out_scale;
+      if (a.y2 && n >= a.split) a.y2[(int64_t)m * a.ldy2 + (n - a.split)] = v * a.out_scale;  // e.g. q -> y, k|v -> the KV-cache slot
+      else a.y[(int64_t)m * a.ldy + n] = v * a.out_scale;
     }
   }
 }
@@ -161,7 +191,11 @@ extern "C" int mi355_gemv(const mi355_gemv_args* ap, void* stream) {
   MI355_REQUIRE(a.ldw % 8 == 0 && a.ldw >= a.K && ((uintptr_t)a.w) % 16 == 0, "gemv: weight rows must be 16-byte aligned");
   MI355_REQUIRE(a.ldx % 4 == 0 && ((uintptr_t)a.x) % 16 == 0, "gemv: x rows must be 16-byte aligned");
   MI355_REQUIRE(a.wdtype == MI355_W_BF16 || a.wdtype == MI355_W_F16, "gemv: wdtype must be MI355_W_BF16 or MI355_W_F16");
-  MI355_REQUIRE(!a.glu || (a.N % 2 == 0 && !a.res && !a.colscale && a.post_act == MI355_ACT_NONE), "gemv: glu needs an even N and a plain epilogue");
+  MI355_REQUIRE(!a.glu || (a.N % 2 == 0 && !a.res && !a.colscale && a.post_act == MI355_ACT_NONE && !a.y2), "gemv: glu needs an even N and a plain epilogue");
+  MI355_REQUIRE(a.norm >= 0 && a.norm <= 2, "gemv: norm must be 0 (none), 1 (LayerNorm) or 2 (RMSNorm)");
+  MI355_REQUIRE(!a.norm || (a.K % 4 == 0 && (!a.norm_weight || ((uintptr_t)a.norm_weight) % 16 == 0) && (!a.norm_bias || ((uintptr_t)a.norm_bias) % 16 == 0)),
+                "gemv: norm weight / bias must be 16-byte aligned");
+  MI355_REQUIRE(!a.y2 || (a.split > 0 && a.split < a.N), "gemv: split must be inside (0, N) when y2 is given");
   if (a.out_scale == 0.f) a.out_scale = 1.f;
   hipStream_t st = (hipStream_t)stream;
   return a.wdtype == MI355_W_F16 ? launch_gemv_m<true>(a, st) : launch_gemv_m<false>(a, st);

@@ -130,14 +130,21 @@ def make_lin(w: torch.Tensor, bias: Optional[torch.Tensor], device, f16: bool = 
     return Lin(ops.pack_conv(w, bias, device, f16=f16), ops.pack_rowmajor16(w, bias, device, f16=f16))
 
 
+def is_decode(x: torch.Tensor) -> bool:
+    """1 row per sequence and at most 8 sequences: the shape the GEMV / KV-streaming path is built for."""
+    return x.shape[1] == 1 and x.shape[0] <= 8
+
+
 def linear(x: torch.Tensor, l: Lin, y: torch.Tensor, *, post_act: int = ACT_NONE, res: Optional[torch.Tensor] = None,
-           colscale: Optional[torch.Tensor] = None, glu: bool = False, precision: int = 2):
-    """y = act(x W^T + b) * colscale + res on [B, L, C] views; 1-row-per-sequence inputs with B <= 8 take the GEMV."""
-    B, L, _ = x.shape
-    if L == 1 and B <= 8:
-        ops.gemv(x[:, 0, :], l.rm, y[:, 0, :], post_act=post_act, res=None if res is None else res[:, 0, :], colscale=colscale, glu=glu)
+           colscale: Optional[torch.Tensor] = None, glu: bool = False, precision: int = 2, norm: Optional[tuple] = None,
+           y2: Optional[torch.Tensor] = None):
+    """y = act(norm(x) W^T + b) * colscale + res on [B, L, C] views; 1-row-per-sequence inputs with B <= 8 take the GEMV
+    (``norm`` / ``y2`` -- fused input normalisation and split destination -- exist on that path only)."""
+    if is_decode(x):
+        ops.gemv(x[:, 0, :], l.rm, y[:, 0, :], post_act=post_act, res=None if res is None else res[:, 0, :], colscale=colscale, glu=glu,
+                 norm=norm, y2=None if y2 is None else y2[:, 0, :])
     else:
-        assert not glu
+        assert not glu and norm is None and y2 is None
         ops.conv_gemm(x, l.pc, y, post_act=post_act, res=res, colscale=colscale, precision=precision)
     return y
 
@@ -147,6 +154,7 @@ class _Layer:
     attn_norm: Tuple[torch.Tensor, Optional[torch.Tensor]]
     wq: Lin
     wkv: Lin
+    wqkv: Lin            # decode step: one GEMV writes q to its buffer and k | v into the KV-cache slot
     wo: Lin
     q_norm: Optional[torch.Tensor]
     k_norm: Optional[torch.Tensor]
@@ -190,8 +198,12 @@ class TransformerStack:
                 w_out = lin(p + "w_down")
             else:
                 w_in, w_out = lin(p + "w1"), lin(p + "w2")
+            wq_w, bq = w[p + "wq.weight"], w.get(p + "wq.bias")
+            qkvb = None if kvb is None and bq is None else torch.cat([bq if bq is not None else torch.zeros(wq_w.shape[0]),
+                                                                       kvb if kvb is not None else torch.zeros(wk.shape[0] + wv.shape[0])])
+            wqkv = Lin(None, ops.pack_rowmajor16(torch.cat([wq_w, wk, wv]), qkvb, dev))  # GEMV image only
             self.layers.append(_Layer((vec(p + "attn_norm.weight"), vec(p + "attn_norm.bias")), lin(p + "wq"),
-                                      make_lin(torch.cat([wk, wv]), kvb, dev), lin(p + "wo"), vec(p + "q_norm.weight"), vec(p + "k_norm.weight"),
+                                      make_lin(torch.cat([wk, wv]), kvb, dev), wqkv, lin(p + "wo"), vec(p + "q_norm.weight"), vec(p + "k_norm.weight"),
                                       (vec(p + "mlp_norm.weight"), vec(p + "mlp_norm.bias")), w_in, w_out, vec(p + "ls1"), vec(p + "ls2")))
         self.final_norm = (vec("final_norm.weight"), vec("final_norm.bias")) if cfg.final_norm else None
         if cfg.rope_theta is not None:
@@ -223,17 +235,21 @@ class TransformerStack:
         ff_w = c.d_ff
         mid = torch.empty((B, L, ff_w), dtype=torch.float32, device=dev)
         gu = None
-        decode = L == 1 and B <= 8
+        decode = is_decode(x)
         if c.mlp == "swiglu" and not decode:
             gu = torch.empty((B, L, 2 * c.d_ff), dtype=torch.float32, device=dev)
         act = {"gelu": ACT_GELU, "gelu_tanh": ACT_GELU_TANH}.get(c.mlp, ACT_NONE)
         layers = []
+        nmode = "layer" if c.norm == "layer" else "rms"
         for lyr, kvc in zip(self.layers, cache):
             off = kvc.offset
-            h = self._norm(x, lyr.attn_norm)
-            linear(h, lyr.wq, q, precision=self.precision)
             slot = kvc.reserve(B, L)
-            linear(h, lyr.wkv, slot, precision=self.precision)
+            if decode:  # pre-norm fused into the one q | k | v GEMV
+                linear(x, lyr.wqkv, q, norm=(nmode, lyr.attn_norm[0], lyr.attn_norm[1], c.norm_eps), y2=slot)
+            else:
+                h = self._norm(x, lyr.attn_norm)
+                linear(h, lyr.wq, q, precision=self.precision)
+                linear(h, lyr.wkv, slot, precision=self.precision)
             if lyr.q_norm is not None or self.cos is not None:
                 ops.head_norm_rope(q, q, heads=H, dh=dh, norm_weight=lyr.q_norm, eps=c.norm_eps, cos=self.cos, sin=self.sin, pos0=off,
                                    interleaved=c.rope_interleaved)
@@ -241,15 +257,16 @@ class TransformerStack:
                                    cos=self.cos, sin=self.sin, pos0=off, interleaved=c.rope_interleaved)
             ops.flash_attention(q, kvc.keys, kvc.values, att, heads=H, kv_heads=G, dh=dh, causal=c.causal, window=c.window)
             linear(att, lyr.wo, x, res=x, colscale=lyr.ls1, precision=self.precision)
-            h = self._norm(x, lyr.mlp_norm)
-            if c.mlp == "swiglu":
-                if decode:
-                    linear(h, lyr.w_in, mid, glu=True)
-                else:
+            if decode:  # pre-norm (+ SwiGLU) fused into the up-projection GEMV
+                linear(x, lyr.w_in, mid, glu=c.mlp == "swiglu", post_act=ACT_NONE if c.mlp == "swiglu" else act,
+                       norm=(nmode, lyr.mlp_norm[0], lyr.mlp_norm[1], c.norm_eps))
+            else:
+                h = self._norm(x, lyr.mlp_norm)
+                if c.mlp == "swiglu":
                     linear(h, lyr.w_in, gu, precision=self.precision)
                     ops.swiglu(gu, mid)
-            else:
-                linear(h, lyr.w_in, mid, post_act=act, precision=self.precision)
+                else:
+                    linear(h, lyr.w_in, mid, post_act=act, precision=self.precision)
             linear(mid, lyr.w_out, x, res=x, colscale=lyr.ls2, precision=self.precision)
             if return_layers:
                 layers.append(x.clone())

@@ -124,17 +124,25 @@ def pack_rowmajor16(w: torch.Tensor, bias: Optional[torch.Tensor], device, f16: 
 
 def gemv(x: torch.Tensor, rw: RowMajor16, y: torch.Tensor, *, post_act: int = ACT_NONE, post_slope: float = 0.0,
          res: Optional[torch.Tensor] = None, colscale: Optional[torch.Tensor] = None, out_scale: float = 1.0, glu: bool = False,
-         use_bias: bool = True):
-    """y[m, :] = epilogue(x[m, :] @ W^T) for 1..8 rows; x / y / res are 2-D fp32 views with unit inner stride."""
+         use_bias: bool = True, norm: Optional[tuple] = None, y2: Optional[torch.Tensor] = None):
+    """y[m, :] = epilogue(norm(x[m, :]) @ W^T) for 1..8 rows; x / y / res are 2-D fp32 views with unit inner stride.
+    ``norm`` = (mode, weight, bias, eps) with mode "layer" | "rms" fuses the input normalisation; ``y2``: columns >= y.shape[1] go there."""
     assert x.dim() == 2 and y.dim() == 2 and x.stride(1) == 1 and y.stride(1) == 1 and x.dtype == torch.float32 and y.dtype == torch.float32
     M = x.shape[0]
-    assert x.shape[1] == rw.k and y.shape[0] == M and y.shape[1] == (rw.n // 2 if glu else rw.n), (x.shape, y.shape, rw.n, rw.k)
+    n_y = rw.n // 2 if glu else (rw.n if y2 is None else rw.n - y2.shape[1])
+    assert x.shape[1] == rw.k and y.shape[0] == M and y.shape[1] == n_y, (x.shape, y.shape, rw.n, rw.k)
     kw = dict(x=_ptr(x), ldx=x.stride(0), M=M, K=rw.k, w=_ptr(rw.w), ldw=rw.w.stride(0), wdtype=1 if rw.f16 else 0, N=rw.n,
               bias=_ptr(rw.bias) if use_bias else None, post_act=post_act, post_slope=post_slope, colscale=_ptr(colscale),
               out_scale=out_scale, glu=int(glu), y=_ptr(y), ldy=y.stride(0))
     if res is not None:
         assert res.dim() == 2 and res.stride(1) == 1
         kw.update(res=_ptr(res), ldr=res.stride(0))
+    if norm is not None:
+        mode, nw, nb, eps = norm
+        kw.update(norm={"layer": 1, "rms": 2}[mode], norm_weight=_ptr(nw), norm_bias=_ptr(nb), norm_eps=eps)
+    if y2 is not None:
+        assert y2.dim() == 2 and y2.stride(1) == 1 and y2.shape[0] == M
+        kw.update(y2=_ptr(y2), ldy2=y2.stride(0), split=n_y)
     _lib.call_struct("mi355_gemv", "mi355_gemv_args", _stream(), **kw)
     return y
 

@@ -126,12 +126,18 @@ class WhisperEngine:
     def _f(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.device)
 
-    def _linear(self, x: torch.Tensor, l: _Lin, y: torch.Tensor, post_act: int = ACT_NONE, res: Optional[torch.Tensor] = None):
-        """y = act(x W^T + b) + res on [B, L, C] views; decode steps (L == 1, B <= 8) take the GEMV."""
+    def _linear(self, x: torch.Tensor, l: _Lin, y: torch.Tensor, post_act: int = ACT_NONE, res: Optional[torch.Tensor] = None,
+                ln: Optional[_LN] = None, y2: Optional[torch.Tensor] = None):
+        """y = act(LN(x) W^T + b) + res on [B, L, C] views; decode steps (L == 1, B <= 8) take the GEMV, which also fuses the
+        pre-LayerNorm (``ln``) and can split its columns over two destinations (``y2``: q -> y, k | v -> the KV-cache slot)."""
         B, L, _ = x.shape
         if L == 1 and B <= 8:
-            ops.gemv(x[:, 0, :], l.rm, y[:, 0, :], post_act=post_act, res=None if res is None else res[:, 0, :])
+            ops.gemv(x[:, 0, :], l.rm, y[:, 0, :], post_act=post_act, res=None if res is None else res[:, 0, :],
+                     norm=None if ln is None else ("layer", ln.w, ln.b, 1e-5), y2=None if y2 is None else y2[:, 0, :])
         else:
+            assert y2 is None
+            if ln is not None:
+                x = self._lnorm(x, ln)
             ops.conv_gemm(x, l.pc, y, post_act=post_act, res=res, precision=self.precision)
         return y
 
@@ -194,18 +200,19 @@ class WhisperEngine:
         mid = self._f(B, n, 4 * nt)
         for i, blk in enumerate(self.dec_blocks):
             cache = st["self_kv"][i]
-            h = self._lnorm(x, blk.attn_ln)
-            self._linear(h, blk.q, q)
-            self._linear(h, blk.kv, cache[:, off:off + n, :])
+            if n == 1 and B <= 8:  # decode step: LayerNorm + q | k | v in one GEMV, k | v written straight into the cache slot
+                self._linear(x, blk.qkv, q, ln=blk.attn_ln, y2=cache[:, off:off + 1, :])
+            else:
+                h = self._lnorm(x, blk.attn_ln)
+                self._linear(h, blk.q, q)
+                self._linear(h, blk.kv, cache[:, off:off + n, :])
             ops.flash_attention(q, cache[:, :off + n, 0:nt], cache[:, :off + n, nt:], att, heads=H, dh=dh, scale=dh ** -0.5, causal=True)
             self._linear(att, blk.out, x, res=x)
             ckv = st["cross_kv"][i]
-            h = self._lnorm(x, blk.cross_ln)
-            self._linear(h, blk.cq, q)
+            self._linear(x, blk.cq, q, ln=blk.cross_ln)
             ops.flash_attention(q, ckv[:, :, 0:nt], ckv[:, :, nt:], att, heads=H, dh=dh, scale=dh ** -0.5)
             self._linear(att, blk.cout, x, res=x)
-            h = self._lnorm(x, blk.mlp_ln)
-            self._linear(h, blk.mlp1, mid, post_act=ACT_GELU)
+            self._linear(x, blk.mlp1, mid, post_act=ACT_GELU, ln=blk.mlp_ln)
             self._linear(mid, blk.mlp2, x, res=x)
         st["n"] = off + n
         return self._lnorm(x, self.ln)

@@ -78,6 +78,8 @@ ATT_CASES = [
     (2, 5, 33, 2, 2, 64, True, 0, True, 0),            # auto -> decode kernel
     (1, 9, 33, 2, 2, 64, True, 0, False, 0),           # auto -> flash kernel
     (1, 40, 40, 2, 1, 64, True, 0, False, 2),          # decode kernel forced on a longer block
+    (2, 1, 700, 4, 2, 128, True, 0, True, 2),          # 16-wave decode kernel, dh 128, ragged
+    (1, 2, 257, 2, 2, 64, True, 0, False, 2),          # just past the 4 -> 16 wave switch
 ]
 
 
@@ -162,6 +164,32 @@ def test_gemv(ops, M, N, K, f16, act, use_res, use_cs):
     ops.gemv(xd[:, :K], rw, y, post_act=act, res=None if res is None else res.to(DEV), colscale=None if cs is None else cs.to(DEV))
     torch.cuda.synchronize()
     assert rel_err(y.cpu(), v) < 5e-6, rel_err(y.cpu(), v)
+
+
+@pytest.mark.parametrize("mode,M,K", [("layer", 1, 768), ("layer", 5, 3072), ("rms", 8, 2048), ("rms", 2, 1024)])
+def test_gemv_fused_norm_and_split(ops, mode, M, K):
+    g = torch.Generator().manual_seed(K + M)
+    Nq, Nkv = 256, 128
+    w = _round16(torch.randn(Nq + Nkv, K, generator=g) / math.sqrt(K), False)
+    bias = torch.randn(Nq + Nkv, generator=g) * 0.1
+    x = torch.randn(M, K, generator=g) * 2.0 + 0.3
+    nw, nb = torch.randn(K, generator=g), torch.randn(K, generator=g) * 0.1
+    xd = x.double()
+    if mode == "layer":
+        xn = F.layer_norm(xd, (K,), nw.double(), nb.double(), 1e-5)
+    else:
+        nb = None
+        xn = xd * torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + 1e-6) * nw.double()
+    exp = xn @ w.double().T + bias.double()
+    rw = ops.pack_rowmajor16(w, bias, DEV)
+    y = torch.empty(M, Nq, device=DEV)
+    cache = torch.zeros(M, 7, Nkv + 8, device=DEV)          # a strided "KV-cache slot" destination
+    ops.gemv(x.to(DEV), rw, y, norm=(mode, nw.to(DEV), None if nb is None else nb.to(DEV), 1e-5 if mode == "layer" else 1e-6),
+             y2=cache[:, 3, :Nkv])
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu(), exp[:, :Nq]) < 1e-5
+    assert rel_err(cache[:, 3, :Nkv].cpu(), exp[:, Nq:]) < 1e-5
+    assert float(cache[:, 2].abs().max()) == 0.0 and float(cache[:, 3, Nkv:].abs().max()) == 0.0
 
 
 def test_gemv_swiglu(ops):

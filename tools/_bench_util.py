@@ -1,0 +1,56 @@
+"""Helpers shared by the secondary benchmark lines (tools/bench_*.py)."""
+import copy
+import dataclasses
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def ev():
+    return torch.cuda.Event(enable_timing=True)
+
+
+def _clone_obj(o):
+    """Deep copy of a layer record in which every device tensor is a fresh allocation (distinct HBM addresses)."""
+    if isinstance(o, torch.Tensor):
+        return o.clone()
+    if dataclasses.is_dataclass(o):
+        return type(o)(**{f.name: _clone_obj(getattr(o, f.name)) for f in dataclasses.fields(o)})
+    if isinstance(o, tuple):
+        return tuple(_clone_obj(v) for v in o)
+    if isinstance(o, list):
+        return [_clone_obj(v) for v in o]
+    return copy.copy(o)
+
+
+def build_deep_stack(cfg, device, seed=0, precision=2):
+    """A TransformerStack of cfg.n_layers layers whose parameters are packed ONCE (one synthetic layer) and then cloned per layer on
+    the device: identical values, distinct memory, so every layer streams its own weights from HBM exactly like a real checkpoint
+    (host-side random generation + packing of >1e9 parameters would cost minutes of GPU-box time for nothing)."""
+    from mlx_audio_amd.lm.stack import TransformerStack
+    from mlx_audio_amd.lm.synthetic import make_stack_weights
+
+    one = dataclasses.replace(cfg, n_layers=1)
+    st = TransformerStack(make_stack_weights(one, seed=seed, gain=0.5), one, device=device, precision=precision)
+    st.cfg = cfg
+    st.layers = [st.layers[0]] + [_clone_obj(st.layers[0]) for _ in range(cfg.n_layers - 1)]
+    return st
+
+
+def stack_weight_bytes(cfg) -> float:
+    """16-bit weight bytes one decode step of the stack streams (q|k|v, o, gate|up or w1, down or w2 of every layer)."""
+    d, dh = cfg.d_model, cfg.head_dim
+    per = (cfg.n_heads + 2 * cfg.n_kv_heads) * dh * d + d * cfg.n_heads * dh + (2 if cfg.mlp == "swiglu" else 1) * cfg.d_ff * d + d * cfg.d_ff
+    return 2.0 * per * cfg.n_layers
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1

@@ -1,0 +1,106 @@
+#!/usr/bin/env python
+"""Secondary benchmark line: BASELINE config[4] -- CSM-1B (Llama-1B backbone + Llama-100M depth decoder, 32 codebooks x 2051) frame
+generation with Mimi RVQ codec decode on one MI355X, synthetic bf16 weights of the exact shapes (sesame.py:204-264, mimi_202407(32)).
+
+Prints ONE JSON line: value = audio seconds per wall second over (prompt prefill + F frames of generate_frame + Mimi decode); split
+timings; HBM roofline of a frame (16-bit weight bytes of backbone + 31 depth-decoder steps + heads / frame time).  config[4] asks for
+fp8 MFMA GEMMs: at 1 row per step these GEMMs are weight-stream bound GEMVs, measured here on bf16 weights (fp8 weight images are the
+documented next step).  Not the driver's contract line.
+"""
+import argparse
+import json
+import time
+
+import torch
+
+import _bench_util as U
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=32)
+    ap.add_argument("--prompt", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    args = ap.parse_args()
+
+    from mlx_audio_amd.codec.models.mimi import mimi as M
+    from mlx_audio_amd.lm.stack import make_lin
+    from mlx_audio_amd.tts.models.sesame import engine as E
+
+    dev = torch.device("cuda", 0)
+    cfg = E.csm_1b()
+    cfg.text_vocab_size = 4096  # the 128 256-row text table is only gathered from; a small one keeps the setup short
+    tiny = E.tiny_csm()
+    eng = E.CSMEngine(E.make_csm_weights(tiny, seed=0), tiny, device=dev)
+    eng.cfg = cfg
+    eng.backbone = U.build_deep_stack(cfg.backbone, dev, seed=1)
+    eng.decoder = U.build_deep_stack(cfg.decoder, dev, seed=2)
+    eng.backbone_cache = eng.backbone.make_cache()
+    g = torch.Generator().manual_seed(0)
+
+    def rnd(*shape, std):
+        return (torch.randn(*shape, generator=g) * std).to(torch.bfloat16).to(torch.float32)
+
+    D, Dd, V, nb = cfg.backbone.d_model, cfg.decoder.d_model, cfg.audio_vocab_size, cfg.audio_num_codebooks
+    eng.projection = make_lin(rnd(Dd, D, std=1.0 / D ** 0.5), None, dev)
+    eng.c0_head = make_lin(rnd(V, D, std=4.0 / D ** 0.5), None, dev)
+    eng.heads = [make_lin(rnd(V, Dd, std=4.0 / Dd ** 0.5), None, dev) for _ in range(nb - 1)]
+    eng.table = torch.cat([rnd(V * nb, D, std=0.5), rnd(cfg.text_vocab_size, D, std=0.5)], 0).contiguous().to(dev)
+    eng.slot_offs = torch.tensor([i * V for i in range(nb)] + [nb * V], dtype=torch.int32, device=dev)
+    mcfg = M.mimi_202407(32)
+    mimi = M.MimiDecoder(M.make_mimi_decoder_weights(mcfg, seed=0), mcfg, device=dev)
+
+    B, F, S = args.batch, args.frames, args.prompt
+    toks = torch.zeros(B, S, nb + 1, dtype=torch.long)
+    mask = torch.zeros(B, S, nb + 1, dtype=torch.bool)
+    toks[:, :, -1] = torch.randint(0, cfg.text_vocab_size, (B, S), generator=g)
+    mask[:, :, -1] = True
+    toks, mask = toks.to(dev), mask.to(dev)
+
+    def step(timers=None):
+        e = [U.ev() for _ in range(3)]
+        e[0].record()
+        out = eng.generate(toks, mask, F, temperature=0.0, poll=10 ** 9)
+        e[1].record()
+        fr = out["frames"]
+        codes = (fr % mcfg.quantizer_bins).permute(0, 2, 1).contiguous()
+        wav = mimi(codes)
+        e[2].record()
+        if timers is not None:
+            timers.append(e)
+        return fr, wav
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    timers = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fr, wav = step(timers)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = fr.shape[1]
+    assert n >= 1 and wav.shape[-1] == n * 1920 and bool(torch.isfinite(wav).all())
+    lm_ms = sum(t[0].elapsed_time(t[1]) for t in timers) / args.steps
+    dec_ms = sum(t[1].elapsed_time(t[2]) for t in timers) / args.steps
+    frame_ms = lm_ms / n
+    wbytes = U.stack_weight_bytes(cfg.backbone) + (nb - 1) * U.stack_weight_bytes(cfg.decoder) + 2.0 * (V * D + (nb - 1) * (V * Dd + Dd * D))
+    res = {
+        "metric": "audio seconds generated per second (x real time), CSM-1B generate_frame + Mimi decode, 1 MI355X", "value": B * n * 0.08 * args.steps / dt,
+        "unit": "x realtime", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000 * dt / args.steps, "higher_is_better": True,
+        "dtype": "bf16 weights x fp32 activations (GEMV fp32 FMA on bf16 weights)", "data": "synthetic",
+        "config": {"workload": "CSM-1B: prompt %d tokens, %d frames x (backbone step + 31 depth-decoder steps, sampling on device), Mimi decode (32 codebooks)" % (S, n),
+                   "sequences": B, "frames": n, "temperature": 0.0},
+        "split_ms": {"frame_loop": lm_ms, "mimi_decode": dec_ms}, "ms_per_frame": frame_ms, "frames_per_s": B * n / (lm_ms * 1e-3),
+        "mimi_samples_per_s": B * n * 1920 / (dec_ms * 1e-3),
+        "roofline": {"bound": "hbm", "kernel": "gemv_kernel (all decode-step Linear layers of one frame)", "achieved": wbytes / (frame_ms * 1e-3) / 1e9, "peak": 8000.0,
+                     "unit": "GB/s", "frac": wbytes / (frame_ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "algorithmic_bytes_per_frame": wbytes,
+                     "note": "whole-frame figure: includes attention, norms, sampling and launch gaps"},
+    }
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

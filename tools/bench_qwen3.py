@@ -1,0 +1,117 @@
+#!/usr/bin/env python
+"""Secondary benchmark line: BASELINE config[3] -- Qwen3-TTS-1.7B talker + code predictor frame loop and codec decode, per-GPU share of the
+64-utterance batch (8 utterances), synthetic bf16 weights of the 1.7B shapes (talker hidden 2048 / inter 6144 / 28 L / 16-8 heads,
+code predictor config.py:36-52, codec decoder config.py:110-136), temperature 0, on one MI355X.
+
+Prints ONE JSON line: value = audio seconds generated per wall second over (prefill + F frames + codec decode of the F frames);
+split timings; roofline of the decode step against HBM: 16-bit weight bytes every frame must stream (talker + 15 code-predictor steps +
+heads) / measured frame time.  Not the driver's contract line (bench.py / Kokoro); committed under profiles/.
+"""
+import argparse
+import json
+import time
+
+import torch
+
+import _bench_util as U
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--frames", type=int, default=48)
+    ap.add_argument("--prompt", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from mlx_audio_amd import ops
+    from mlx_audio_amd.lm.stack import make_lin
+    from mlx_audio_amd.tts.models.qwen3_tts import synthetic as QS
+    from mlx_audio_amd.tts.models.qwen3_tts import talker as T
+    from mlx_audio_amd.tts.models.qwen3_tts.codec import Qwen3CodecDecoder
+    from mlx_audio_amd.tts.models.qwen3_tts.config import Qwen3TTSTokenizerDecoderConfig, talker_1p7b
+
+    dev = torch.device("cuda", 0)
+    cfg = talker_1p7b()
+    cp = cfg.code_predictor_config
+    # --- build the engine from tiny parameters, then swap in full-size stacks / heads (see _bench_util.build_deep_stack)
+    tiny = T.tiny_talker_config()
+    eng = T.Qwen3Talker(T.make_talker_weights(tiny, seed=0), tiny, device=dev)
+    eng.cfg = cfg
+    eng.talker = U.build_deep_stack(T.talker_stack_config(cfg), dev, seed=1)
+    eng.cp = U.build_deep_stack(T.talker_stack_config(cp), dev, seed=2)
+    g = torch.Generator().manual_seed(0)
+
+    def rnd(n, k, std):
+        return (torch.randn(n, k, generator=g) * std).to(torch.bfloat16).to(torch.float32)
+
+    H = cfg.hidden_size
+    eng.codec_head = make_lin(rnd(cfg.vocab_size, H, 4.0 / H ** 0.5), None, dev)
+    eng.lm_heads = [make_lin(rnd(cp.vocab_size, cp.hidden_size, 4.0 / cp.hidden_size ** 0.5), None, dev) for _ in range(cfg.num_code_groups - 1)]
+    eng.mtp = make_lin(rnd(cp.hidden_size, H, 1.0 / H ** 0.5), torch.zeros(cp.hidden_size), dev)
+    tabs = [rnd(cfg.vocab_size, H, 0.5)] + [rnd(cp.vocab_size, H, 0.5) for _ in range(cfg.num_code_groups - 1)]
+    offs, r = [], 0
+    for t in tabs:
+        offs.append(r)
+        r += t.shape[0]
+    eng.codec_table = torch.cat(tabs, 0).contiguous().to(dev)
+    eng.codec_offs = torch.tensor(offs, dtype=torch.int32, device=dev)
+    sup = torch.zeros(cfg.vocab_size)
+    sup[[i for i in range(cfg.vocab_size - 1024, cfg.vocab_size)]] = -float("inf")  # EOS suppressed too: fixed number of frames
+    eng.suppress_mask = sup.to(dev)
+    ccfg = Qwen3TTSTokenizerDecoderConfig()
+    codec = Qwen3CodecDecoder(QS.make_codec_decoder_weights(ccfg, seed=0), ccfg, device=dev)
+
+    B, F = args.batch, args.frames
+    pre = (torch.randn(B, args.prompt, H, generator=g) * 0.5).to(dev)
+    trail = (torch.randn(B, 16, H, generator=g) * 0.5).to(dev)
+    pad = (torch.randn(1, 1, H, generator=g) * 0.5).to(dev)
+
+    def step(timers=None):
+        e = [U.ev() for _ in range(3)]
+        e[0].record()
+        out = eng.generate(pre, trail, pad, F, temperature=0.0, poll=10 ** 9)
+        e[1].record()
+        codes = (out["codes"] % ccfg.codebook_size).permute(0, 2, 1).contiguous()  # [B, 16, F]
+        wav = codec.chunked_decode(codes, chunk_size=300, left_context_size=25)
+        e[2].record()
+        if timers is not None:
+            timers.append(e)
+        return out, wav
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    timers = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, wav = step(timers)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert out["codes"].shape[1] == F and wav.shape[-1] == F * 1920 and bool(torch.isfinite(wav).all())
+    lm_ms = sum(t[0].elapsed_time(t[1]) for t in timers) / args.steps
+    dec_ms = sum(t[1].elapsed_time(t[2]) for t in timers) / args.steps
+    audio_s = B * F * 0.08 * args.steps
+    frame_ms = lm_ms / F  # includes the (short) prefill
+    wbytes = U.stack_weight_bytes(eng.talker.cfg) + (cfg.num_code_groups - 1) * U.stack_weight_bytes(eng.cp.cfg) + 2.0 * (
+        cfg.vocab_size * H + (cfg.num_code_groups - 1) * (cp.vocab_size * cp.hidden_size + cp.hidden_size * H))
+    res = {
+        "metric": "audio seconds generated per second (x real time), Qwen3-TTS-1.7B talker + code predictor + codec decode, 1 MI355X",
+        "value": audio_s / dt, "unit": "x realtime", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000 * dt / args.steps,
+        "higher_is_better": True, "dtype": "bf16 weights x fp32 activations (GEMV fp32 FMA on bf16 weights; bf16 hi+lo MFMA in the codec)", "data": "synthetic",
+        "config": {"workload": "Qwen3-TTS-1.7B: prefill %d + %d frames x (talker step + 15 code-predictor steps + sampling on device), then codec decode" % (args.prompt, F),
+                   "utterances_per_gpu": B, "frames": F, "temperature": 0.0},
+        "split_ms": {"frame_loop": lm_ms, "codec_decode": dec_ms}, "ms_per_frame": frame_ms, "frames_per_s": B * F / (lm_ms * 1e-3),
+        "codec_samples_per_s": B * F * 1920 / (dec_ms * 1e-3),
+        "roofline": {"bound": "hbm", "kernel": "gemv_kernel (all decode-step Linear layers of one frame)", "achieved": wbytes / (frame_ms * 1e-3) / 1e9,
+                     "peak": 8000.0, "unit": "GB/s", "frac": wbytes / (frame_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                     "algorithmic_bytes_per_frame": wbytes,
+                     "note": "whole-frame figure (weights streamed once per frame / wall time of a frame): includes attention, norms, sampling and launch gaps"},
+    }
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
