@@ -363,6 +363,7 @@ typedef struct {
   int32_t B;
   int32_t mode;           /* 0 = auto (decode kernel when Tq <= 8), 1 = MFMA flash kernel, 2 = decode kernel */
   float* out; int64_t out_bstride; int32_t ldo;  /* [B, Tq, ldo], head h at [h*dh, (h+1)*dh) */
+  const int32_t* k_start; /* [B] nullable: keys j < k_start[b] are left padding (BatchKVCache, lm/models/cache.py:502-560) */
 } mi355_flash_attn_args;
 int mi355_flash_attention(const mi355_flash_attn_args* a, void* stream);
 
@@ -447,6 +448,9 @@ typedef struct {
   const int32_t* pos; int32_t pos_ld; int32_t pos0;
   int32_t rope_mode;
   float* y; int64_t y_bstride; int32_t ldy;
+  /* optional second tensor handled by the same launch with the same positions (q heads -> y, k heads -> the KV-cache slot y2) */
+  const float* x2; int64_t x2_bstride; int32_t ldx2; int32_t heads2; const float* norm_weight2;
+  float* y2; int64_t y2_bstride; int32_t ldy2;
 } mi355_head_rope_args;
 int mi355_head_norm_rope(const mi355_head_rope_args* a, void* stream);
 

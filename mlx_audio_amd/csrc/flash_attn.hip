@@ -24,7 +24,7 @@
 //     reading the KV cache once.
 //
 // Visibility of key j for query i of item b (len_q / len_k = valid rows, queries are the LAST len_q positions):
-//   j < len_k,  causal: j <= i + (len_k - len_q),  window W > 0: j > i + (len_k - len_q) - W.
+//   k_start <= j < len_k,  causal: j <= i + (len_k - len_q),  window W > 0: j > i + (len_k - len_q) - W.
 // Invisible keys get probability exactly 0 (the reference adds -1e9 / -inf style masks: identical after softmax).
 #include "common.h"
 
@@ -82,8 +82,10 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const mi355_flash_attn_
   if (a.window > 0) {
     kbeg = q0 + qoff - a.window + 1;
     if (kbeg < 0) kbeg = 0;
-    kbeg &= ~(KB - 1);
   }
+  const int kstart = a.k_start ? a.k_start[b] : 0;  // left-padded rows: keys before k_start[b] are padding
+  if (kstart > kbeg) kbeg = kstart;
+  kbeg &= ~(KB - 1);
 
   const float* kbase = a.k + (int64_t)b * a.k_bstride + g * DH;
   const float* vbase = a.v + (int64_t)b * a.v_bstride + g * DH;
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const mi355_flash_attn_
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int j = kb32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        bool vis = j < len_k;
+        bool vis = j < len_k && j >= kstart;
         if (a.causal) vis = vis && j <= qpos;
         if (a.window > 0) vis = vis && j > qpos - a.window;
         acc[r] = vis ? acc[r] : -INFINITY;
@@ -208,6 +210,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
   int kend = len_k, kbeg = 0;
   if (a.causal) kend = qpos + 1 < len_k ? qpos + 1 : len_k;
   if (a.window > 0) { kbeg = qpos - a.window + 1; if (kbeg < 0) kbeg = 0; }
+  if (a.k_start && a.k_start[b] > kbeg) kbeg = a.k_start[b];
   const float* kbase = a.k + (int64_t)b * a.k_bstride + g * DH;
   const float* vbase = a.v + (int64_t)b * a.v_bstride + g * DH;
   float m = -INFINITY, l = 0.f, o[ND];

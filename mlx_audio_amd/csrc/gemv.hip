@@ -15,7 +15,6 @@
 
 namespace {
 
-constexpr int kKC = 1024;  // K elements of x staged per chunk and row (8 rows x 1024 x 4 B = 32 KB of LDS)
 
 template <bool F16>
 __device__ __forceinline__ void cvt8(const uint4 w, float (&f)[8]) {
@@ -46,7 +45,10 @@ __device__ __forceinline__ float gemv_act(float v, int act, float slope) {
 
 template <int MT, int NC, bool F16>
 __global__ __launch_bounds__(256) void gemv_kernel(const mi355_gemv_args a) {
-  __shared__ __attribute__((aligned(16))) float xs[MT * kKC];
+  constexpr int KC = MT >= 8 ? 1024 : (MT == 4 ? 2048 : 4096);  // x elements staged per row and chunk: MT * KC * 4 B <= 32 KB of LDS
+  constexpr int IPC = KC / 512;                                  // k-slices per chunk
+  constexpr int D = 4;                                           // weight prefetch depth, in k-slices
+  __shared__ __attribute__((aligned(16))) float xs[MT * KC];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = (blockIdx.x * 4 + wave) * NC;
   float acc[NC][MT];
@@ -79,48 +81,62 @@ __global__ __launch_bounds__(256) void gemv_kernel(const mi355_gemv_args a) {
       if (lane == 0) { st_mean[m] = mean; st_rstd[m] = a.norm == 1 ? 1.0f / sqrtf(var + a.norm_eps) : rsqrtf(var + a.norm_eps); }
     }
   }
-  for (int k0 = 0; k0 < a.K; k0 += kKC) {
-    const int kc = a.K - k0 < kKC ? a.K - k0 : kKC;  // multiple of 8 (K % 8 == 0)
-    __syncthreads();
-    for (int e = tid * 4; e < MT * kc; e += 1024) {
-      const int m = e / kc, k = e - m * kc;
-      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < a.M) {
-        t = *(const float4*)(a.x + (int64_t)m * a.ldx + k0 + k);
-        if (a.norm) {
-          const float mu = st_mean[m], rs = st_rstd[m];
-          float4 w4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (a.norm_weight) w4 = *(const float4*)(a.norm_weight + k0 + k);
-          if (a.norm_bias) b4 = *(const float4*)(a.norm_bias + k0 + k);
-          t = make_float4((t.x - mu) * rs * w4.x + b4.x, (t.y - mu) * rs * w4.y + b4.y, (t.z - mu) * rs * w4.z + b4.z, (t.w - mu) * rs * w4.w + b4.w);
-        }
-      }
-      *(float4*)(xs + m * kKC + k) = t;
-    }
-    __syncthreads();
-    if (n0 < a.N) {
-      for (int k = lane * 8; k < kc; k += 512) {
-        uint4 wv[NC];
+  // The weight stream is a software pipeline of its own: D k-slices (512 elements = 64 lanes x 16 B each) per column are always in
+  // flight, issued before the x chunk they will meet is even staged -- the HBM latency of the weights overlaps the L2 latency of x and
+  // the workgroup barriers around the LDS staging instead of adding to them.
+  const int n_it = (a.K + 511) >> 9;  // (tail waves, n0 >= N, run the same loop on the clamped last row: the barriers stay block-uniform)
+  uint4 ring[D][NC];
+  auto issue = [&](int it, uint4 (&dst)[NC]) {
+    const int k = (it << 9) + lane * 8;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) wv[c] = *(const uint4*)(wrow[c] + k0 + k);
-        float xv[MT][8];
+    for (int c = 0; c < NC; ++c) dst[c] = k < a.K ? *(const uint4*)(wrow[c] + k) : make_uint4(0u, 0u, 0u, 0u);
+  };
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < n_it) issue(d, ring[d]);
+  for (int base = 0; base < n_it; base += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int it = base + d;
+      if (it >= n_it) break;
+      if (it % IPC == 0) {  // next x chunk (block-uniform: every wave walks the same k sequence)
+        const int k0 = (it / IPC) * KC;
+        const int kc = a.K - k0 < KC ? a.K - k0 : KC;  // multiple of 8 (K % 8 == 0)
+        __syncthreads();
+        for (int e = tid * 4; e < MT * kc; e += 1024) {
+          const int m = e / kc, k = e - m * kc;
+          float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (m < a.M) {
+            t = *(const float4*)(a.x + (int64_t)m * a.ldx + k0 + k);
+            if (a.norm) {
+              const float mu = st_mean[m], rs = st_rstd[m];
+              float4 w4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (a.norm_weight) w4 = *(const float4*)(a.norm_weight + k0 + k);
+              if (a.norm_bias) b4 = *(const float4*)(a.norm_bias + k0 + k);
+              t = make_float4((t.x - mu) * rs * w4.x + b4.x, (t.y - mu) * rs * w4.y + b4.y, (t.z - mu) * rs * w4.z + b4.z, (t.w - mu) * rs * w4.w + b4.w);
+            }
+          }
+          *(float4*)(xs + m * KC + k) = t;
+        }
+        __syncthreads();
+      }
+      const int kl = ((it % IPC) << 9) + lane * 8;  // position inside the staged chunk
+      if ((it << 9) + lane * 8 < a.K) {
+        float wf[NC][8];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) cvt8<F16>(ring[d][c], wf[c]);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          const float4 lo = *(const float4*)(xs + m * kKC + k);
-          const float4 hi = *(const float4*)(xs + m * kKC + k + 4);
-          xv[m][0] = lo.x; xv[m][1] = lo.y; xv[m][2] = lo.z; xv[m][3] = lo.w;
-          xv[m][4] = hi.x; xv[m][5] = hi.y; xv[m][6] = hi.z; xv[m][7] = hi.w;
-        }
+          const float4 lo = *(const float4*)(xs + m * KC + kl);
+          const float4 hi = *(const float4*)(xs + m * KC + kl + 4);
+          const float xv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          float wf[8];
-          cvt8<F16>(wv[c], wf);
+          for (int c = 0; c < NC; ++c)
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[c][m] = fmaf(xv[m][j], wf[j], acc[c][m]);
+            for (int j = 0; j < 8; ++j) acc[c][m] = fmaf(xv[j], wf[c][j], acc[c][m]);
         }
       }
+      if (it + D < n_it) issue(it + D, ring[d]);
     }
   }
   if (n0 >= a.N) return;
@@ -163,11 +179,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(const mi355_gemv_args a) {
 
 template <int MT, bool F16>
 int launch_gemv(const mi355_gemv_args& a, hipStream_t st) {
-  // enough wavefronts to cover the chip before widening the per-wave column group
-  const int nc = a.glu ? (a.N >= 8192 ? 4 : 2) : (a.N >= 8192 ? 4 : (a.N >= 2048 ? 2 : 1));
+  // one column per wave keeps the most wavefronts (and weight bytes) in flight; two columns per wave halve the LDS reads of x per weight
+  // byte, which is what binds at 8 rows (16 LDS bytes per weight byte at NC = 1) and for very wide outputs
+  const int nc = (a.glu || MT >= 8 || a.N >= 16384) ? 2 : 1;
   MI355_CLEAR_ERROR();
-  if (nc == 4) hipLaunchKernelGGL((gemv_kernel<MT, 4, F16>), dim3((a.N + 15) / 16), dim3(256), 0, st, a);
-  else if (nc == 2) hipLaunchKernelGGL((gemv_kernel<MT, 2, F16>), dim3((a.N + 7) / 8), dim3(256), 0, st, a);
+  if (nc == 2) hipLaunchKernelGGL((gemv_kernel<MT, 2, F16>), dim3((a.N + 7) / 8), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((gemv_kernel<MT, 1, F16>), dim3((a.N + 3) / 4), dim3(256), 0, st, a);
   MI355_LAUNCH_CHECK("gemv");
   return MI355_OK;

@@ -46,26 +46,32 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const mi355_rmsnorm_args a
 __global__ __launch_bounds__(256) void head_norm_rope_kernel(const mi355_head_rope_args a) {
   const int lane = threadIdx.x & 63;
   const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t total = (int64_t)a.B * a.L * a.heads;
+  const int ht = a.heads + a.heads2;  // second tensor (k heads, written to the KV-cache slot) shares the launch with the first (q heads)
+  const int64_t total = (int64_t)a.B * a.L * ht;
   if (wid >= total) return;
-  const int h = (int)(wid % a.heads);
-  const int64_t row = wid / a.heads;
+  int h = (int)(wid % ht);
+  const int64_t row = wid / ht;
   const int b = (int)(row / a.L), l = (int)(row - (int64_t)b * a.L);
   const int len = a.lens ? a.lens[b] : a.L;
   if (l >= len) return;
   const int half = a.dh >> 1;
-  const float* xr = a.x + (int64_t)b * a.x_bstride + (int64_t)l * a.ldx + h * a.dh;
-  float* yr = a.y + (int64_t)b * a.y_bstride + (int64_t)l * a.ldy + h * a.dh;
+  const bool second = h >= a.heads;
+  if (second) h -= a.heads;
+  const float* xr = second ? a.x2 + (int64_t)b * a.x2_bstride + (int64_t)l * a.ldx2 + h * a.dh
+                           : a.x + (int64_t)b * a.x_bstride + (int64_t)l * a.ldx + h * a.dh;
+  float* yr = second ? a.y2 + (int64_t)b * a.y2_bstride + (int64_t)l * a.ldy2 + h * a.dh
+                     : a.y + (int64_t)b * a.y_bstride + (int64_t)l * a.ldy + h * a.dh;
+  const float* nw = second ? a.norm_weight2 : a.norm_weight;
   const bool act = lane < half;
   int i0, i1;  // the two elements of this lane's rotation pair
   if (a.rope_mode == 1) { i0 = 2 * lane; i1 = 2 * lane + 1; }   // interleaved (traditional)
   else { i0 = lane; i1 = lane + half; }                          // rotate-half
   float x0 = 0.f, x1 = 0.f;
   if (act) { x0 = xr[i0]; x1 = xr[i1]; }
-  if (a.norm_weight) {
+  if (nw) {
     const float ss = wave_sum(x0 * x0 + x1 * x1);
     const float r = rsqrtf(ss / (float)a.dh + a.eps);
-    if (act) { x0 = x0 * r * a.norm_weight[i0]; x1 = x1 * r * a.norm_weight[i1]; }
+    if (act) { x0 = x0 * r * nw[i0]; x1 = x1 * r * nw[i1]; }
   }
   if (a.cos_table && act) {
     const int pos = a.pos ? a.pos[(int64_t)b * a.pos_ld + l] : a.pos0 + l;
@@ -164,7 +170,8 @@ extern "C" int mi355_head_norm_rope(const mi355_head_rope_args* ap, void* stream
   MI355_REQUIRE((a.cos_table == nullptr) == (a.sin_table == nullptr), "head_norm_rope: cos / sin tables come together");
   MI355_REQUIRE(a.rope_mode == 0 || a.rope_mode == 1, "head_norm_rope: rope_mode must be 0 (rotate-half) or 1 (interleaved)");
   MI355_CLEAR_ERROR();
-  const int64_t waves = (int64_t)a.B * a.L * a.heads;
+  MI355_REQUIRE(a.heads2 >= 0 && (a.heads2 == 0 || (a.x2 && a.y2)), "head_norm_rope: second tensor needs x2 / y2");
+  const int64_t waves = (int64_t)a.B * a.L * (a.heads + a.heads2);
   hipLaunchKernelGGL(head_norm_rope_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   MI355_LAUNCH_CHECK("head_norm_rope");
   return MI355_OK;

@@ -72,6 +72,7 @@ class KVCache:
 
     def __init__(self, n_kv_heads: int, head_dim: int, device):
         self.width = 2 * n_kv_heads * head_dim
+        self.n_kv_heads, self.head_dim = n_kv_heads, head_dim
         self.device = device
         self.kv: Optional[torch.Tensor] = None
         self.offset = 0
@@ -251,10 +252,9 @@ class TransformerStack:
                 linear(h, lyr.wq, q, precision=self.precision)
                 linear(h, lyr.wkv, slot, precision=self.precision)
             if lyr.q_norm is not None or self.cos is not None:
+                ks = slot[:, :, : G * dh]
                 ops.head_norm_rope(q, q, heads=H, dh=dh, norm_weight=lyr.q_norm, eps=c.norm_eps, cos=self.cos, sin=self.sin, pos0=off,
-                                   interleaved=c.rope_interleaved)
-                ops.head_norm_rope(slot[:, :, : G * dh], slot[:, :, : G * dh], heads=G, dh=dh, norm_weight=lyr.k_norm, eps=c.norm_eps,
-                                   cos=self.cos, sin=self.sin, pos0=off, interleaved=c.rope_interleaved)
+                                   interleaved=c.rope_interleaved, second=(ks, ks, G, lyr.k_norm))  # q and k heads in one launch
             ops.flash_attention(q, kvc.keys, kvc.values, att, heads=H, kv_heads=G, dh=dh, causal=c.causal, window=c.window)
             linear(att, lyr.wo, x, res=x, colscale=lyr.ls1, precision=self.precision)
             if decode:  # pre-norm (+ SwiGLU) fused into the up-projection GEMV

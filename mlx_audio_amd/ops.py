@@ -280,7 +280,7 @@ def attention(qkv: torch.Tensor, heads: int, dh: int, out: torch.Tensor, lens=No
 
 def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, heads: int, kv_heads: Optional[int] = None,
                     dh: int, scale: Optional[float] = None, causal: bool = False, window: int = 0, lens_q=None, lens_k=None,
-                    mode: int = 0):
+                    mode: int = 0, k_start=None):
     """softmax(scale * q k^T + visibility) v.  q/out [B, Tq, >= heads*dh], k/v [B, Tk, >= kv_heads*dh] channels-last views
     (a KV cache is just the buffer k / v point into); see mi355_flash_attn_args for the visibility rule."""
     B, Tq, _, qbs, ldq = _nlc(q)
@@ -291,7 +291,8 @@ def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torc
     _lib.call_struct("mi355_flash_attention", "mi355_flash_attn_args", _stream(), q=_ptr(q), q_bstride=qbs, ldq=ldq, k=_ptr(k),
                      k_bstride=kbs, ldk=ldk, v=_ptr(v), v_bstride=vbs, ldv=ldv, heads=heads, kv_heads=kv_heads or heads, dh=dh,
                      Tq=Tq, Tk=Tk, lens_q=_ptr(lens_q), lens_k=_ptr(lens_k), causal=int(causal), window=window,
-                     scale=(1.0 / math.sqrt(dh)) if scale is None else scale, B=B, mode=mode, out=_ptr(out), out_bstride=obs, ldo=ldo)
+                     scale=(1.0 / math.sqrt(dh)) if scale is None else scale, B=B, mode=mode, out=_ptr(out), out_bstride=obs, ldo=ldo,
+                     k_start=_ptr(k_start))
     return out
 
 
@@ -330,7 +331,7 @@ def rmsnorm(x: torch.Tensor, y: torch.Tensor, weight: Optional[torch.Tensor], ep
 
 def head_norm_rope(x: torch.Tensor, y: torch.Tensor, *, heads: int, dh: int, norm_weight: Optional[torch.Tensor] = None, eps: float = 1e-6,
                    cos: Optional[torch.Tensor] = None, sin: Optional[torch.Tensor] = None, pos: Optional[torch.Tensor] = None, pos0: int = 0,
-                   interleaved: bool = False, lens=None):
+                   interleaved: bool = False, lens=None, second: Optional[tuple] = None):
     """Per-head RMSNorm (optional) + RoPE (optional) of ``heads`` heads starting at column 0 of ``x`` into ``y`` (may be a cache slot)."""
     B, L, _, xbs, ldx = _nlc(x)
     _, _, _, ybs, ldy = _nlc(y)
@@ -338,9 +339,16 @@ def head_norm_rope(x: torch.Tensor, y: torch.Tensor, *, heads: int, dh: int, nor
         assert cos.dim() == 2 and cos.shape[1] == dh // 2 and cos.is_contiguous() and sin.is_contiguous() and cos.shape == sin.shape
     if pos is not None:
         assert pos.dtype == torch.int32 and pos.dim() == 2 and pos.stride(1) == 1
+    kw = {}
+    if second is not None:  # (x2, y2, heads2, norm_weight2): e.g. the k heads, rotated straight into their KV-cache slot
+        x2, y2, heads2, nw2 = second
+        B2, L2, _, x2bs, ldx2 = _nlc(x2)
+        _, _, _, y2bs, ldy2 = _nlc(y2)
+        assert B2 == B and L2 == L
+        kw = dict(x2=_ptr(x2), x2_bstride=x2bs, ldx2=ldx2, heads2=heads2, norm_weight2=_ptr(nw2), y2=_ptr(y2), y2_bstride=y2bs, ldy2=ldy2)
     _lib.call_struct("mi355_head_norm_rope", "mi355_head_rope_args", _stream(), x=_ptr(x), x_bstride=xbs, ldx=ldx, heads=heads, dh=dh, L=L,
                      lens=_ptr(lens), B=B, norm_weight=_ptr(norm_weight), eps=eps, cos_table=_ptr(cos), sin_table=_ptr(sin), pos=_ptr(pos),
-                     pos_ld=0 if pos is None else pos.stride(0), pos0=pos0, rope_mode=int(interleaved), y=_ptr(y), y_bstride=ybs, ldy=ldy)
+                     pos_ld=0 if pos is None else pos.stride(0), pos0=pos0, rope_mode=int(interleaved), y=_ptr(y), y_bstride=ybs, ldy=ldy, **kw)
     return y
 
 

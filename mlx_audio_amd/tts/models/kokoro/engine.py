@@ -394,7 +394,10 @@ class KokoroEngine:
         inter = self._new(B, Tm, self.pb["intermediate_size"])
         for _ in range(self.pb["num_hidden_layers"]):
             self._conv(h, self.qkv, qkv, lens_in=lens_t, lens_out=lens_t)
-            ops.attention(qkv, heads, H // heads, ctx, lens=lens_t)
+            if H // heads in (64, 128):  # f32-MFMA flash kernel; padded keys are invisible (the reference's additive -10000 mask, modules.py:639)
+                ops.flash_attention(qkv[:, :, :H], qkv[:, :, H:2 * H], qkv[:, :, 2 * H:], ctx, heads=heads, dh=H // heads, lens_q=lens_t, lens_k=lens_t)
+            else:
+                ops.attention(qkv, heads, H // heads, ctx, lens=lens_t)
             self._conv(ctx, self.att_dense, tmp, lens_in=lens_t, lens_out=lens_t, res=h)
             ops.layernorm(tmp, att, weight=self.att_ln[0], bias=self.att_ln[1], eps=eps, lens=lens_t)
             self._conv(att, self.ffn, inter, lens_in=lens_t, lens_out=lens_t, post_act=ACT_GELU)

@@ -204,7 +204,19 @@ class Qwen3Talker:
             for c in cp_cache:
                 c.reset()
             for i in range(G - 1):
-                if i == 0:
+                if i == 0 and B <= 8:
+                    # step 0 feeds two positions, [last_hidden, embed(code0)] (qwen3_tts.py:961-966).  With a causal stack and a KV cache
+                    # that is exactly two single-position steps, and single-position steps run on the GEMV / KV-streaming path instead
+                    # of a 2-row MFMA tile; only the second position's output is used.
+                    x0 = last.clone()
+                    if self.mtp is not None:
+                        xp = self._f(B, 1, cp.hidden_size)
+                        linear(x0, self.mtp, xp, precision=self.precision)
+                        x0 = xp
+                    self.cp(x0, cp_cache)
+                    xin = self._f(B, 1, H)
+                    ops.embed_sum(self.codec_table, row[:, 0:1].unsqueeze(1), xin)
+                elif i == 0:
                     xin = self._f(B, 2, H)
                     xin[:, 0:1, :] = last
                     ops.embed_sum(self.codec_table, row[:, 0:1].unsqueeze(1), xin[:, 1:2, :])

@@ -84,6 +84,7 @@ class CSMEngine:
         nb = cfg.audio_num_codebooks
         self.slot_offs = torch.tensor([i * cfg.audio_vocab_size for i in range(nb)] + [nb * cfg.audio_vocab_size], dtype=torch.int32, device=dev)
         self.backbone_cache = self.backbone.make_cache()
+        self.decoder_cache = self.decoder.make_cache()
 
     def reset_caches(self):
         for c in self.backbone_cache:
@@ -131,10 +132,20 @@ class CSMEngine:
                 sample[:, i] = forced[:, i].to(dev, torch.int32)
 
         draw(self._logits(last, self.c0_head), 0)
-        cache = self.decoder.make_cache()
+        cache = self.decoder_cache  # reset for every frame (sesame.py:385-387): offsets back to 0, buffers reused
+        for c in cache:
+            c.reset()
         Dd = cfg.decoder.d_model
         for i in range(1, nb):
-            if i == 1:
+            if i == 1 and B <= 8:
+                # [last_h, c0_embed] (sesame.py:380) as two single-position steps through the causal depth decoder: same result, and single
+                # positions run on the GEMV / KV-streaming path; only the second position's output is used
+                p0 = self._f(B, 1, Dd)
+                linear(last, self.projection, p0, precision=self.precision)
+                self.decoder(p0, cache)
+                cur = self._f(B, 1, D)
+                ops.embed_sum(self.table, sample[:, 0:1].unsqueeze(1), cur, slot_offset=self.slot_offs[0:1])
+            elif i == 1:
                 cur = self._f(B, 2, D)
                 cur[:, 0:1, :] = last
                 ops.embed_sum(self.table, sample[:, 0:1].unsqueeze(1), cur[:, 1:2, :], slot_offset=self.slot_offs[0:1])

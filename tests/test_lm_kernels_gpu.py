@@ -64,6 +64,21 @@ def test_head_norm_rope(ops, dh, heads, interleaved, norm):
                        cos=cos.to(DEV), sin=sin.to(DEV), pos0=off, interleaved=interleaved)
     torch.cuda.synchronize()
     assert rel_err(y, exp) < 3e-6
+    # q and k in one launch: second tensor with its own head count / norm weight, written to a strided "cache slot"
+    G = max(1, heads // 2)
+    xk = torch.randn(B, L, G * dh, generator=g)
+    nwk = torch.randn(dh, generator=g) if norm else None
+    kr = xk.reshape(B, L, G, dh).double()
+    if norm:
+        kr = kr * torch.rsqrt(kr.pow(2).mean(-1, keepdim=True) + 1e-6) * nwk.double()
+    expk = apply_rope(kr, cos[off:off + L].double(), sin[off:off + L].double(), interleaved).reshape(B, L, G * dh)
+    slot = torch.zeros(B, L, 2 * G * dh, device=DEV)
+    y2 = torch.zeros(B, L, heads * dh, device=DEV)
+    ops.head_norm_rope(xd[:, :, :heads * dh], y2, heads=heads, dh=dh, norm_weight=None if nw is None else nw.to(DEV), eps=1e-6,
+                       cos=cos.to(DEV), sin=sin.to(DEV), pos0=off, interleaved=interleaved,
+                       second=(xk.to(DEV), slot[:, :, :G * dh], G, None if nwk is None else nwk.to(DEV)))
+    torch.cuda.synchronize()
+    assert rel_err(y2, exp) < 3e-6 and rel_err(slot[:, :, :G * dh], expk) < 3e-6 and float(slot[:, :, G * dh:].abs().max()) == 0.0
     # in place + explicit positions
     pos = (torch.arange(L, dtype=torch.int32)[None, :] + off).repeat(B, 1).to(DEV)
     z = xd[:, :, :heads * dh]

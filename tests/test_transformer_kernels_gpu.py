@@ -111,6 +111,26 @@ def test_flash_attention(ops, B, Tq, Tk, heads, kvh, dh, causal, window, ragged,
             assert torch.all(got[b, lq:] == 7.0), "rows past lens_q must not be written"
 
 
+@pytest.mark.parametrize("Tq,mode", [(1, 2), (70, 1)])
+def test_attention_left_padded_batch(ops, Tq, mode):
+    """BatchKVCache layout (lm/models/cache.py:502-560): rows are left-padded, k_start[b] keys of padding are invisible."""
+    g = torch.Generator().manual_seed(17 + Tq)
+    B, Tk, H, dh = 3, 90, 2, 64
+    pad = [0, 13, 41]
+    q = torch.randn(B, Tq, H * dh, generator=g)
+    k = torch.randn(B, Tk, H * dh, generator=g)
+    v = torch.randn(B, Tk, H * dh, generator=g)
+    out = torch.empty(B, Tq, H * dh, device=DEV)
+    ops.flash_attention(q.to(DEV), k.to(DEV), v.to(DEV), out, heads=H, dh=dh, causal=True, mode=mode,
+                        k_start=torch.tensor(pad, dtype=torch.int32, device=DEV))
+    torch.cuda.synchronize()
+    for b in range(B):
+        p = pad[b]
+        nq = min(Tq, Tk - p)  # queries that fall inside the padding have no meaning in the reference either
+        exp = ref_attention(q[b:b + 1, Tq - nq:], k[b:b + 1, p:], v[b:b + 1, p:], H, H, dh, 1.0 / math.sqrt(dh), True, 0, None, None)
+        assert rel_err(out[b, Tq - nq:].cpu(), exp[0]) < 2e-5, b
+
+
 def test_flash_and_decode_kernels_agree(ops):
     """Same inputs through both kernels (mode 1 / mode 2): a cross-check that does not involve the reference at all."""
     g = torch.Generator().manual_seed(5)

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--precision", type=int, default=2)
     ap.add_argument("--quick", action="store_true", help="two shapes, the wave-specialised variants only (for PMC passes)")
     ap.add_argument("--ablate", action="store_true", help="timing ablations of the 7128128 kernel (their results are wrong by design)")
+    ap.add_argument("--small", action="store_true", help="the few-row GEMMs of PL-BERT / predictor (rows = B*80): 4-wave tile shapes A/B")
     args = ap.parse_args()
     from mlx_audio_amd import ops
 
@@ -49,6 +50,11 @@ def main():
         shapes = [(128, 128, 11, 1, 31681, "snake+res"), (128, 128, 3, 1, 31681, "snake+res"), (256, 256, 7, 1, 5280, "snake+res")]
         variants = [("ws_regB", 7128128), ("abl1_noBload", 17128128), ("abl2_noAread", 27128128), ("abl3_noAB", 37128128),
                     ("abl4_noProducer", 47128128), ("abl8_noEpilogue", 87128128), ("abl7_noABP", 77128128), ("abl15_mfmaOnly", 157128128)]
+    if args.small:
+        shapes = [(768, 2304, 1, 1, 80, "plain"), (768, 768, 1, 1, 80, "plain"), (768, 2048, 1, 1, 80, "plain"), (2048, 768, 1, 1, 80, "plain"),
+                  (640, 2048, 1, 1, 264, "plain"), (1090, 1024, 3, 1, 264, "leaky"), (1024, 1024, 3, 1, 264, "leaky"), (512, 512, 3, 1, 528, "leaky"),
+                  (512, 512, 5, 1, 80, "plain")]
+        variants = [("t64x128", 64128), ("t64x64", 64064), ("t128x128", 128128)]
     if args.quick:
         shapes = [(128, 128, 11, 1, 31681, "snake+res"), (128, 128, 3, 1, 31681, "snake+res")]
         variants = [("old64x128", 64128), ("ws_prodB", 8128128), ("ws_regB", 7128128)]

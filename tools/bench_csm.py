@@ -38,6 +38,7 @@ def main():
     eng.backbone = U.build_deep_stack(cfg.backbone, dev, seed=1)
     eng.decoder = U.build_deep_stack(cfg.decoder, dev, seed=2)
     eng.backbone_cache = eng.backbone.make_cache()
+    eng.decoder_cache = eng.decoder.make_cache()
     g = torch.Generator().manual_seed(0)
 
     def rnd(*shape, std):
