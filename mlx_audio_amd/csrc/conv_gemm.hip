@@ -63,7 +63,9 @@ __device__ __forceinline__ uint32_t pack_lo(float a, float b) {
 // All loads of one 32x32 fragment are issued back to back on clamped addresses and only the stores are predicated:
 // a per-element "if (valid) v += res[...]" makes hipcc branch around every load and wait vmcnt(0) each time
 // (64 dependent round trips per wave).  `folded`: res / y_old were already added into the accumulators.
-template <int MF, int NF, int WM, int WN>
+// EXT: the extended epilogue set (SiLU / GELU-tanh / ELU / tanh, per-column scale).  The wave-specialised kernels live at the 128-VGPR
+// limit of two workgroups per CU; their default instantiation leaves the extensions out (they cost spills there).
+template <int MF, int NF, int WM, int WN, bool EXT>
 __device__ __forceinline__ void conv_epilogue(const mi355_conv_gemm_args& a, f32x16 (&acc)[MF][NF], const int b, const int l0,
                                               const int n0, const int wm, const int wn, const int lane, const int len_out,
                                               const bool folded) {
@@ -88,7 +90,8 @@ __device__ __forceinline__ void conv_epilogue(const mi355_conv_gemm_args& a, f32
       int ocol = ncl, rph = 0;
       if (a.up_s) { rph = ncl / a.up_cout; ocol = ncl - rph * a.up_cout; }
       const float bias = a.bias ? a.bias[ocol] : 0.f;
-      const float cscale = a.post_colscale ? a.post_colscale[ocol] : 1.f;
+      float cscale = 1.f;
+      if constexpr (EXT) cscale = a.post_colscale ? a.post_colscale[ocol] : 1.f;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {  // 8 accumulator rows at a time keeps the live set small
         int orows[8];
@@ -126,11 +129,15 @@ __device__ __forceinline__ void conv_epilogue(const mi355_conv_gemm_args& a, f32
           float v = acc[mf][nf][h * 8 + q] + bias;
           if (a.post_act == MI355_ACT_LEAKY) v = v > 0.f ? v : v * a.post_slope;
           else if (a.post_act == MI355_ACT_GELU) v = gelu_erf(v);
-          else if (a.post_act == MI355_ACT_SILU) v = v / (1.0f + expf(-v));
-          else if (a.post_act == MI355_ACT_GELU_TANH) v = gelu_tanh(v);
-          else if (a.post_act == MI355_ACT_ELU) v = v > 0.f ? v : expm1f(v);
-          else if (a.post_act == MI355_ACT_TANH) v = tanhf(v);
-          v = (v * cscale + rv[q]) * a.out_scale;
+          if constexpr (EXT) {
+            if (a.post_act == MI355_ACT_SILU) v = v / (1.0f + expf(-v));
+            else if (a.post_act == MI355_ACT_GELU_TANH) v = gelu_tanh(v);
+            else if (a.post_act == MI355_ACT_ELU) v = v > 0.f ? v : expm1f(v);
+            else if (a.post_act == MI355_ACT_TANH) v = tanhf(v);
+            v = (v * cscale + rv[q]) * a.out_scale;
+          } else {
+            v = (v + rv[q]) * a.out_scale;
+          }
           if (ok[q]) yb[(int64_t)orows[q] * a.ldy + ocol] = v;
           if (want_stats && ok[q]) {
             sK[nf] = scnt[nf] == 0 ? v : sK[nf];
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_ge
   }
 
   // ---------------------------------------------------------------- epilogue
-  conv_epilogue<MF, NF, WM, WN>(a, acc, b, l0, n0, wm, wn, lane, len_out, false);
+  conv_epilogue<MF, NF, WM, WN, true>(a, acc, b, l0, n0, wm, wn, lane, len_out, false);
 }
 
 // =====================================================================================================
@@ -455,10 +462,6 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
         al[0] = a4.x; al[1] = a4.y; al[2] = a4.z; al[3] = a4.w;
 #pragma unroll
         for (int i = 0; i < 4; ++i) ial[i] = 1.0f / al[i];
-      if (a.pre_inv_beta) {  // SnakeBeta: x + sin^2(alpha x) * inv_beta[c]
-        const float4 b4 = *(const float4*)(a.pre_inv_beta + c);
-        ial[0] = b4.x; ial[1] = b4.y; ial[2] = b4.z; ial[3] = b4.w;
-      }
       }
 #pragma unroll
       for (int i = 0; i < kWsNld; ++i) {
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
             else if (a.pre_act == MI355_ACT_SNAKE) {
               const float s = __sinf(al[j] * t);
               t = t + ial[j] * (s * s);
-            } else if (a.pre_act == MI355_ACT_ELU) t = t > 0.f ? t : expm1f(t);
+            }
             t = (rowok && (c + j) < a.Cin) ? t : 0.f;
             const float h = split_hi<PREC>(t);
             hi[j] = h;
@@ -703,7 +706,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
   }
 
   // epilogue (with `fold` the residual / running sum is already in the accumulators)
-  conv_epilogue<MF, NF, WM, WN>(a, acc, b, l0, n0, wm, wn, lane, len_out, fold != 0);
+  conv_epilogue<MF, NF, WM, WN, false>(a, acc, b, l0, n0, wm, wn, lane, len_out, fold != 0);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -718,7 +721,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
 // ABL (ablation bits, timing experiments only -- results are WRONG when non-zero; reachable only through the explicit
 // tile codes ABL*10000000 + 7128128 used by tools/bench_conv.py): 1 = no weight-fragment loads after the first,
 // 2 = no activation-fragment LDS reads, 4 = producers only take part in the barriers, 8 = no epilogue.
-template <int PREC, int ABL = 0>
+template <int PREC, int ABL = 0, bool EXT = false>
 __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws3_kernel(const mi355_conv_gemm_args a, const int tiles_per_item,
                                                                      const int P, const int NT, const int fold) {
   constexpr int BM = 128, BN = 128, WM = 64, WN = 64, MF = 2, NF = 2;
@@ -778,9 +781,11 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws3_kernel(const mi35
         al[0] = a4.x; al[1] = a4.y; al[2] = a4.z; al[3] = a4.w;
 #pragma unroll
         for (int i = 0; i < 4; ++i) ial[i] = 1.0f / al[i];
-      if (a.pre_inv_beta) {  // SnakeBeta: x + sin^2(alpha x) * inv_beta[c]
-        const float4 b4 = *(const float4*)(a.pre_inv_beta + c);
-        ial[0] = b4.x; ial[1] = b4.y; ial[2] = b4.z; ial[3] = b4.w;
+      if constexpr (EXT) {
+        if (a.pre_inv_beta) {  // SnakeBeta: x + sin^2(alpha x) * inv_beta[c]
+          const float4 b4 = *(const float4*)(a.pre_inv_beta + c);
+          ial[0] = b4.x; ial[1] = b4.y; ial[2] = b4.z; ial[3] = b4.w;
+        }
       }
       }
 #pragma unroll
@@ -798,7 +803,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws3_kernel(const mi35
             else if (a.pre_act == MI355_ACT_SNAKE) {
               const float s = __sinf(al[j] * t);
               t = t + ial[j] * (s * s);
-            } else if (a.pre_act == MI355_ACT_ELU) t = t > 0.f ? t : expm1f(t);
+            } else if (EXT && a.pre_act == MI355_ACT_ELU) t = t > 0.f ? t : expm1f(t);
             t = (rowok && (c + j) < a.Cin) ? t : 0.f;
             const float h = split_hi<PREC>(t);
             hi[j] = h;
@@ -963,10 +968,10 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws3_kernel(const mi35
     if (t == 1.2345e-30f) yb[0] = t;  // keeps the MFMAs alive without an epilogue
     return;
   }
-  conv_epilogue<MF, NF, WM, WN>(a, acc, b, l0, n0, wm, wn, lane, len_out, fold != 0);
+  conv_epilogue<MF, NF, WM, WN, EXT>(a, acc, b, l0, n0, wm, wn, lane, len_out, fold != 0);
 }
 
-template <int PREC, int ABL = 0>
+template <int PREC, int ABL = 0, bool EXT = false>
 int launch_ws3(const mi355_conv_gemm_args& a, hipStream_t st) {
   const int R = 128 + (a.K - 1) * a.dil;
   MI355_REQUIRE(R <= 32 * kWsNld, "conv_gemm(ws3): window of %d rows exceeds %d (K=%d dil=%d)", R, 32 * kWsNld, a.K, a.dil);
@@ -977,7 +982,7 @@ int launch_ws3(const mi355_conv_gemm_args& a, hipStream_t st) {
   const int fold = (a.res || a.accumulate) && a.post_act == MI355_ACT_NONE && a.up_s == 0 && a.res_shift == 0 && !a.post_colscale;
   const unsigned grid = (unsigned)(((P + 7) / 8) * 8 * NT);
   MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL((conv_gemm_ws3_kernel<PREC, ABL>), dim3(grid), dim3(kWsThreads), lds, st, a, tiles_per_item, P, NT, fold);
+  hipLaunchKernelGGL((conv_gemm_ws3_kernel<PREC, ABL, EXT>), dim3(grid), dim3(kWsThreads), lds, st, a, tiles_per_item, P, NT, fold);
   MI355_LAUNCH_CHECK("conv_gemm(ws3)");
   return MI355_OK;
 }
@@ -1047,6 +1052,7 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
     MI355_REQUIRE(a.up_s == 0, "conv_gemm: fused statistics need a plain (non-polyphase) store");
     MI355_REQUIRE(a.stats_bstride % 2 == 0 && ((uintptr_t)a.stats_partial) % 8 == 0, "conv_gemm: stats_partial must be 8-byte aligned");
   }
+  const bool ext = a.pre_inv_beta || a.post_colscale || a.pre_act == MI355_ACT_ELU || a.post_act > MI355_ACT_GELU;
   int tile = a.tile;
   const bool ws_ok = vec && (128 + (a.K - 1) * a.dil) <= 32 * kWsNld && a.Lin > 0;
   if (tile == 0) {
@@ -1082,11 +1088,13 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
   }
   if (tile == 7128128) {  // weights through registers, one barrier per chunk
     MI355_REQUIRE(ws_ok, "conv_gemm: the wave-specialised tile needs a 16-B aligned channels-last input and (K-1)*dil <= 64");
+    if (ext)  // SnakeBeta / ELU prologue, extended epilogue: the instantiation that carries them (a few spilled registers)
+      return a.precision == 2 ? launch_ws3<2, 0, true>(a, st) : (a.precision == 3 ? launch_ws3<3, 0, true>(a, st) : (a.precision == 4 ? launch_ws3<4, 0, true>(a, st) : launch_ws3<1, 0, true>(a, st)));
     return a.precision == 2 ? launch_ws3<2>(a, st) : (a.precision == 3 ? launch_ws3<3>(a, st) : (a.precision == 4 ? launch_ws3<4>(a, st) : launch_ws3<1>(a, st)));
   }
   if (tile == 8128128 || tile == 9128128) {  // 8...: producers stream the weights; 9...: consumers do (see the kernel header)
     MI355_REQUIRE(ws_ok, "conv_gemm: the wave-specialised tile needs a 16-B aligned channels-last input and (K-1)*dil <= 64");
-    MI355_REQUIRE(a.precision != 4, "conv_gemm: precision 4 runs on the 4-wave and 7128128 kernels only");
+    MI355_REQUIRE(a.precision != 4 && !ext, "conv_gemm: precision 4 and the extended prologue / epilogue set run on the 4-wave and 7128128 kernels only");
     return tile == 9128128 ? launch_ws_prec<true>(a, st) : launch_ws_prec<false>(a, st);
   }
   if (!vec) {
