@@ -504,6 +504,46 @@ typedef struct {
 } mi355_sample_args;
 int mi355_sample(const mi355_sample_args* a, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Native decode-step runner: one call launches every kernel of a single-position step of a whole decoder stack (<= 8 sequences),
+ * replacing the per-op Python schedule of TalkerDecoderLayer / Qwen3TTSTalkerModel.__call__ (tts/models/qwen3_tts/talker.py:385-500),
+ * CodePredictorModel (talker.py:615-690), LlamaModel (lm/models/llama.py:160-198) and Whisper's TextDecoder blocks with self- and
+ * cross-attention (stt/models/whisper/whisper.py:405-416, 476-498).  All weights are row-major 16-bit images (mi355_pack_rowmajor16_host);
+ * the KV cache of layer i is kv [B, kv_capacity, 2*kv_heads*dh] fp32 (k columns, then v), row `offset` is written by the step.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const uint16_t* wqkv; const float* bqkv;      /* [(heads + 2 kv_heads) dh, d_model]: q | k | v rows */
+  const uint16_t* wo; const float* bo;          /* [d_model, heads dh] */
+  const uint16_t* w_in; const float* b_in;      /* SwiGLU: [2 d_ff, d_model] with gate / up rows interleaved; else [d_ff, d_model] */
+  const uint16_t* w_out; const float* b_out;    /* [d_model, d_ff] */
+  const float* attn_norm_w; const float* attn_norm_b; const float* mlp_norm_w; const float* mlp_norm_b;
+  const float* q_norm; const float* k_norm;     /* [dh] per-head RMSNorm weights, nullable */
+  const float* ls1; const float* ls2;           /* [d_model] LayerScale, nullable */
+  float* kv; int64_t kv_bstride; int32_t kv_capacity;
+  /* optional cross-attention block (Whisper decoder): q projection + pre-norm, K | V precomputed [B, cross_len, 2*kv_heads*dh] */
+  const uint16_t* wcq; const float* bcq; const uint16_t* wco; const float* bco;
+  const float* cross_norm_w; const float* cross_norm_b;
+  const float* cross_kv; int64_t cross_bstride; int32_t cross_len;
+} mi355_layer_desc;
+
+typedef struct {
+  int32_t n_layers; int32_t d_model; int32_t heads; int32_t kv_heads; int32_t dh; int32_t d_ff;
+  int32_t norm;            /* 1 = LayerNorm, 2 = RMSNorm */
+  float eps;
+  int32_t glu;             /* 1 = SwiGLU MLP */
+  int32_t act;             /* MLP activation when glu == 0 (MI355_ACT_GELU, MI355_ACT_GELU_TANH, ...) */
+  int32_t wdtype;          /* MI355_W_BF16 / MI355_W_F16 */
+  int32_t causal; int32_t window;
+  float attn_scale;        /* 0 => dh^-0.5 */
+  int32_t rope_mode; const float* cos; const float* sin;   /* tables [max_pos, dh/2], nullable: no rotary embedding */
+  const mi355_layer_desc* layers;                           /* HOST array of n_layers records */
+  const float* final_norm_w; const float* final_norm_b;     /* nullable */
+} mi355_stack_desc;
+
+/* x [B, d_model] (updated in place: the residual stream), ws: workspace of B * (2 * heads * dh + d_ff) floats, out (nullable) [B, d_model]
+ * receives the final-normed hidden state when final_norm_w is set.  offset = rows already in the KV caches. */
+int mi355_stack_decode_step(const mi355_stack_desc* d, float* x, int32_t B, int32_t offset, float* ws, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

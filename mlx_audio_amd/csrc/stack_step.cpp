@@ -1,0 +1,109 @@
+// Native decode-step runner for the decoder-only transformer stacks (host side of libmi355audio.so, gfx950).
+//
+// One call = one single-position step of a whole stack (all layers) for up to 8 sequences: every kernel of the step is launched from
+// this C++ loop instead of from Python.  The reference drives the same work op by op from Python on MLX's lazy graph
+// (tts/models/qwen3_tts/talker.py:385-500 TalkerDecoderLayer / Qwen3TTSTalkerModel.__call__, lm/models/llama.py:160-198,
+// stt/models/whisper/whisper.py:405-416, 476-498 ResidualAttentionBlock / TextDecoder with the KV cache); at 100-800 kernels per generated
+// frame the per-launch cost of a Python / ctypes call (~15 us) was the whole frame time, so the schedule itself had to become native.
+//
+// Per layer: [pre-norm + q|k|v GEMV, k|v straight into the KV-cache slot] -> [per-head RMSNorm + RoPE of q and k, one launch] ->
+// [KV-streaming attention] -> [o-proj GEMV + LayerScale + residual] -> (cross-attention: [pre-norm + q GEMV] -> [attention over the
+// precomputed cross K|V] -> [o-proj GEMV + residual]) -> [pre-norm + up GEMV with fused SwiGLU / GELU] -> [down GEMV + LayerScale + residual].
+#include <string.h>
+#include "common.h"
+
+namespace {
+
+int gemv_call(const float* x, int ldx, int M, int K, const uint16_t* w, int N, int wdtype, const float* bias, int act, const float* colscale,
+              const float* res, int ldr, int glu, float* y, int ldy, int norm, const float* nw, const float* nb, float eps, float* y2, int ldy2,
+              int split, void* stream) {
+  mi355_gemv_args g;
+  memset(&g, 0, sizeof(g));
+  g.x = x; g.ldx = ldx; g.M = M; g.K = K; g.w = w; g.ldw = K; g.wdtype = wdtype; g.N = N; g.bias = bias; g.post_act = act; g.colscale = colscale;
+  g.res = res; g.ldr = ldr; g.out_scale = 1.f; g.glu = glu; g.y = y; g.ldy = ldy; g.norm = norm; g.norm_weight = nw; g.norm_bias = nb;
+  g.norm_eps = eps; g.y2 = y2; g.ldy2 = ldy2; g.split = split;
+  return mi355_gemv(&g, stream);
+}
+
+int attn_call(const float* q, int ldq, const float* k, const float* v, int64_t kv_bstride, int ldkv, int heads, int kv_heads, int dh, int Tk,
+              int causal, int window, float scale, int B, float* out, int ldo, void* stream) {
+  mi355_flash_attn_args a;
+  memset(&a, 0, sizeof(a));
+  a.q = q; a.q_bstride = ldq; a.ldq = ldq; a.k = k; a.k_bstride = kv_bstride; a.ldk = ldkv; a.v = v; a.v_bstride = kv_bstride; a.ldv = ldkv;
+  a.heads = heads; a.kv_heads = kv_heads; a.dh = dh; a.Tq = 1; a.Tk = Tk; a.causal = causal; a.window = window; a.scale = scale; a.B = B;
+  a.mode = 2; a.out = out; a.out_bstride = ldo; a.ldo = ldo;
+  return mi355_flash_attention(&a, stream);
+}
+
+}  // namespace
+
+extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int32_t B, int32_t offset, float* ws, float* out, void* stream) {
+  MI355_REQUIRE(dp && x && ws && dp->layers, "stack_decode_step: null argument");
+  const mi355_stack_desc d = *dp;
+  MI355_REQUIRE(B >= 1 && B <= 8, "stack_decode_step: 1..8 sequences per step (got %d)", B);
+  MI355_REQUIRE(d.n_layers > 0 && d.d_model % 8 == 0 && d.d_ff % 8 == 0 && (d.dh == 64 || d.dh == 128), "stack_decode_step: bad dimensions");
+  MI355_REQUIRE(d.norm == 1 || d.norm == 2, "stack_decode_step: norm must be 1 (LayerNorm) or 2 (RMSNorm)");
+  MI355_REQUIRE(offset >= 0, "stack_decode_step: negative offset");
+  const int D = d.d_model, H = d.heads, G = d.kv_heads, dh = d.dh;
+  const int nq = H * dh, nkv = 2 * G * dh;
+  float* q = ws;                 // [B, nq]
+  float* att = q + (size_t)B * nq;   // [B, nq]
+  float* mid = att + (size_t)B * nq; // [B, d_ff]
+  const float scale = d.attn_scale > 0.f ? d.attn_scale : 1.0f / sqrtf((float)dh);
+  for (int i = 0; i < d.n_layers; ++i) {
+    const mi355_layer_desc& L = d.layers[i];
+    MI355_REQUIRE(L.wqkv && L.wo && L.w_in && L.w_out && L.kv, "stack_decode_step: layer %d is missing a tensor", i);
+    MI355_REQUIRE(offset < L.kv_capacity, "stack_decode_step: KV cache of layer %d is full (offset %d, capacity %d)", i, offset, L.kv_capacity);
+    float* slot = L.kv + (int64_t)offset * nkv;  // row `offset` of item 0; items are kv_bstride apart
+    // ---- self-attention
+    int rc = gemv_call(x, D, B, D, L.wqkv, nq + nkv, d.wdtype, L.bqkv, MI355_ACT_NONE, nullptr, nullptr, 0, 0, q, nq, d.norm, L.attn_norm_w,
+                       L.attn_norm_b, d.eps, slot, (int)L.kv_bstride, nq, stream);
+    if (rc) return rc;
+    if (L.q_norm || d.cos) {
+      mi355_head_rope_args r;
+      memset(&r, 0, sizeof(r));
+      r.x = q; r.x_bstride = nq; r.ldx = nq; r.heads = H; r.dh = dh; r.L = 1; r.B = B; r.norm_weight = L.q_norm; r.eps = d.eps;
+      r.cos_table = d.cos; r.sin_table = d.sin; r.pos0 = offset; r.rope_mode = d.rope_mode; r.y = q; r.y_bstride = nq; r.ldy = nq;
+      r.x2 = slot; r.x2_bstride = L.kv_bstride; r.ldx2 = nkv; r.heads2 = G; r.norm_weight2 = L.k_norm; r.y2 = slot; r.y2_bstride = L.kv_bstride;
+      r.ldy2 = nkv;
+      rc = mi355_head_norm_rope(&r, stream);
+      if (rc) return rc;
+    }
+    rc = attn_call(q, nq, L.kv, L.kv + G * dh, L.kv_bstride, nkv, H, G, dh, offset + 1, d.causal, d.window, scale, B, att, nq, stream);
+    if (rc) return rc;
+    rc = gemv_call(att, nq, B, nq, L.wo, D, d.wdtype, L.bo, MI355_ACT_NONE, L.ls1, x, D, 0, x, D, 0, nullptr, nullptr, 0.f, nullptr, 0, 0, stream);
+    if (rc) return rc;
+    // ---- cross-attention (Whisper decoder): K | V precomputed once per window
+    if (L.cross_kv) {
+      MI355_REQUIRE(L.wcq && L.wco && L.cross_len > 0, "stack_decode_step: layer %d has cross K|V but no cross projections", i);
+      rc = gemv_call(x, D, B, D, L.wcq, nq, d.wdtype, L.bcq, MI355_ACT_NONE, nullptr, nullptr, 0, 0, q, nq, d.norm, L.cross_norm_w, L.cross_norm_b,
+                     d.eps, nullptr, 0, 0, stream);
+      if (rc) return rc;
+      rc = attn_call(q, nq, L.cross_kv, L.cross_kv + G * dh, L.cross_bstride, nkv, H, G, dh, L.cross_len, 0, 0, scale, B, att, nq, stream);
+      if (rc) return rc;
+      rc = gemv_call(att, nq, B, nq, L.wco, D, d.wdtype, L.bco, MI355_ACT_NONE, nullptr, x, D, 0, x, D, 0, nullptr, nullptr, 0.f, nullptr, 0, 0, stream);
+      if (rc) return rc;
+    }
+    // ---- MLP
+    rc = gemv_call(x, D, B, D, L.w_in, d.glu ? 2 * d.d_ff : d.d_ff, d.wdtype, L.b_in, d.glu ? MI355_ACT_NONE : d.act, nullptr, nullptr, 0, d.glu, mid,
+                   d.d_ff, d.norm, L.mlp_norm_w, L.mlp_norm_b, d.eps, nullptr, 0, 0, stream);
+    if (rc) return rc;
+    rc = gemv_call(mid, d.d_ff, B, d.d_ff, L.w_out, D, d.wdtype, L.b_out, MI355_ACT_NONE, L.ls2, x, D, 0, x, D, 0, nullptr, nullptr, 0.f, nullptr, 0, 0,
+                   stream);
+    if (rc) return rc;
+  }
+  if (out && d.final_norm_w) {
+    if (d.norm == 2) {
+      mi355_rmsnorm_args n;
+      memset(&n, 0, sizeof(n));
+      n.x = x; n.x_bstride = D; n.ldx = D; n.C = D; n.L = 1; n.B = B; n.weight = d.final_norm_w; n.eps = d.eps; n.y = out; n.y_bstride = D; n.ldy = D;
+      return mi355_rmsnorm(&n, stream);
+    }
+    mi355_layernorm_args n;
+    memset(&n, 0, sizeof(n));
+    n.x = x; n.x_bstride = D; n.ldx = D; n.C = D; n.L = 1; n.B = B; n.weight = d.final_norm_w; n.bias = d.final_norm_b; n.eps = d.eps; n.y = out;
+    n.y_bstride = D; n.ldy = D;
+    return mi355_layernorm(&n, stream);
+  }
+  return MI355_OK;
+}

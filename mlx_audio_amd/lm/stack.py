@@ -16,13 +16,14 @@ Per layer (prefill, L > 1 rows per sequence):      norm -> [q | kv] GEMMs (kv la
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
 import torch
 
-from .. import ops
+from .. import _lib, ops
 from ..ops import ACT_GELU, ACT_GELU_TANH, ACT_NONE, PackedConv, RowMajor16
 
 
@@ -173,6 +174,7 @@ class TransformerStack:
         self.cfg = cfg
         self.device = torch.device(device)
         self.precision = precision
+        self.native_decode = True  # single-position steps go through mi355_stack_decode_step (False: the per-op Python schedule)
         dev = self.device
         w = {k[len(prefix):]: v.detach().to(torch.bfloat16).to(torch.float32).cpu() for k, v in weights.items() if k.startswith(prefix)}
 
@@ -216,6 +218,56 @@ class TransformerStack:
     def make_cache(self) -> List[KVCache]:
         return [KVCache(self.cfg.n_kv_heads, self.cfg.head_dim, self.device) for _ in range(self.cfg.n_layers)]
 
+    # ------------------------------------------------------------------ native decode step (mi355_stack_decode_step)
+    def _native_desc(self, cache: List[KVCache]):
+        """Builds (or refreshes after a cache re-allocation) the C descriptor of this stack for the given caches."""
+        key = tuple(c.kv.data_ptr() for c in cache)
+        st = getattr(self, "_native", None)
+        if st is not None and st["key"] == key:
+            return st
+        c = self.cfg
+        LD, SD = _lib.STRUCTS["mi355_layer_desc"], _lib.STRUCTS["mi355_stack_desc"]
+        arr = (LD * c.n_layers)()
+        p = ops._ptr
+        for i, (lyr, kvc) in enumerate(zip(self.layers, cache)):
+            a = arr[i]
+            a.wqkv, a.bqkv = p(lyr.wqkv.rm.w), p(lyr.wqkv.rm.bias)
+            a.wo, a.bo = p(lyr.wo.rm.w), p(lyr.wo.rm.bias)
+            a.w_in, a.b_in = p(lyr.w_in.rm.w), p(lyr.w_in.rm.bias)
+            a.w_out, a.b_out = p(lyr.w_out.rm.w), p(lyr.w_out.rm.bias)
+            a.attn_norm_w, a.attn_norm_b = p(lyr.attn_norm[0]), p(lyr.attn_norm[1])
+            a.mlp_norm_w, a.mlp_norm_b = p(lyr.mlp_norm[0]), p(lyr.mlp_norm[1])
+            a.q_norm, a.k_norm, a.ls1, a.ls2 = p(lyr.q_norm), p(lyr.k_norm), p(lyr.ls1), p(lyr.ls2)
+            a.kv, a.kv_bstride, a.kv_capacity = kvc.kv.data_ptr(), kvc.kv.stride(0), kvc.kv.shape[1]
+        d = SD()
+        d.n_layers, d.d_model, d.heads, d.kv_heads, d.dh, d.d_ff = c.n_layers, c.d_model, c.n_heads, c.n_kv_heads, c.head_dim, c.d_ff
+        d.norm, d.eps, d.glu = (1 if c.norm == "layer" else 2), c.norm_eps, int(c.mlp == "swiglu")
+        d.act = {"gelu": ACT_GELU, "gelu_tanh": ACT_GELU_TANH}.get(c.mlp, ACT_NONE)
+        d.wdtype, d.causal, d.window, d.attn_scale = 0, int(c.causal), c.window, 0.0
+        d.rope_mode, d.cos, d.sin = int(c.rope_interleaved), p(self.cos), p(self.sin)
+        d.layers = ctypes.cast(arr, ctypes.c_void_p)
+        if self.final_norm is not None:
+            d.final_norm_w, d.final_norm_b = p(self.final_norm[0]), p(self.final_norm[1])
+        self._native = dict(key=key, arr=arr, desc=d)
+        return self._native
+
+    def decode_step(self, x: torch.Tensor, cache: List[KVCache]) -> torch.Tensor:
+        """One single-position step for B <= 8 sequences through the native runner: x [B, 1, d_model] (updated in place); returns the
+        final-normed hidden state [B, 1, d_model] (or x itself when the stack has no final norm)."""
+        c = self.cfg
+        B = x.shape[0]
+        off = cache[0].offset
+        for kvc in cache:
+            kvc.reserve(B, 1)
+        st = self._native_desc(cache)
+        ws = torch.empty(B * (2 * c.n_heads * c.head_dim + c.d_ff), dtype=torch.float32, device=self.device)
+        out = torch.empty_like(x) if self.final_norm is not None else None
+        lib = _lib.load()
+        rc = lib.mi355_stack_decode_step(ctypes.byref(st["desc"]), x.data_ptr(), B, off, ws.data_ptr(), None if out is None else out.data_ptr(),
+                                         ops._stream())
+        _lib.check(rc, "mi355_stack_decode_step")
+        return out if out is not None else x
+
     def _norm(self, x: torch.Tensor, p) -> torch.Tensor:
         y = torch.empty_like(x)
         if self.cfg.norm == "layer":
@@ -229,6 +281,8 @@ class TransformerStack:
         assert D == c.d_model and x.is_contiguous()
         if cache is None:
             cache = self.make_cache()
+        if is_decode(x) and not return_layers and self.native_decode:
+            return self.decode_step(x, cache)
         H, G, dh = c.n_heads, c.n_kv_heads, c.head_dim
         dev = self.device
         q = torch.empty((B, L, H * dh), dtype=torch.float32, device=dev)

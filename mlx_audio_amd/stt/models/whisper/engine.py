@@ -19,6 +19,7 @@ Everything here is plumbing (allocation, views, launch order); all arithmetic on
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
@@ -26,7 +27,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 import torch
 
-from .... import ops
+from .... import _lib, ops
 from ....ops import ACT_GELU, ACT_NONE, PackedConv, RowMajor16
 from .synthetic import ModelDimensions
 
@@ -74,6 +75,7 @@ class WhisperEngine:
         self.dims = dims
         self.device = torch.device(device)
         self.precision = precision
+        self.native_decode = True  # single-token decoder steps run through mi355_stack_decode_step
         self.dh = dims.n_audio_state // dims.n_audio_head
         assert self.dh in (64, 128) and dims.n_text_state // dims.n_text_head == self.dh
         assert max(dims.n_audio_state, dims.n_text_state) <= 1024, "layernorm kernel holds <= 1024 channels per row"
@@ -186,6 +188,36 @@ class WhisperEngine:
             st["cross_kv"].append(ckv)
         return st
 
+    def _native_desc(self, st: dict):
+        """C descriptor of the decoder for mi355_stack_decode_step (self-attention, cross-attention over this window's K | V, GELU MLP)."""
+        if "native" in st:
+            return st["native"]
+        d = self.dims
+        LD, SD = _lib.STRUCTS["mi355_layer_desc"], _lib.STRUCTS["mi355_stack_desc"]
+        arr = (LD * d.n_text_layer)()
+        p = ops._ptr
+        for i, blk in enumerate(self.dec_blocks):
+            a = arr[i]
+            a.wqkv, a.bqkv = p(blk.qkv.rm.w), p(blk.qkv.rm.bias)
+            a.wo, a.bo = p(blk.out.rm.w), p(blk.out.rm.bias)
+            a.w_in, a.b_in = p(blk.mlp1.rm.w), p(blk.mlp1.rm.bias)
+            a.w_out, a.b_out = p(blk.mlp2.rm.w), p(blk.mlp2.rm.bias)
+            a.attn_norm_w, a.attn_norm_b = p(blk.attn_ln.w), p(blk.attn_ln.b)
+            a.mlp_norm_w, a.mlp_norm_b = p(blk.mlp_ln.w), p(blk.mlp_ln.b)
+            kv = st["self_kv"][i]
+            a.kv, a.kv_bstride, a.kv_capacity = kv.data_ptr(), kv.stride(0), kv.shape[1]
+            a.wcq, a.bcq, a.wco, a.bco = p(blk.cq.rm.w), p(blk.cq.rm.bias), p(blk.cout.rm.w), p(blk.cout.rm.bias)
+            a.cross_norm_w, a.cross_norm_b = p(blk.cross_ln.w), p(blk.cross_ln.b)
+            ckv = st["cross_kv"][i]
+            a.cross_kv, a.cross_bstride, a.cross_len = ckv.data_ptr(), ckv.stride(0), ckv.shape[1]
+        sd = SD()
+        sd.n_layers, sd.d_model, sd.heads, sd.kv_heads, sd.dh, sd.d_ff = d.n_text_layer, d.n_text_state, d.n_text_head, d.n_text_head, self.dh, 4 * d.n_text_state
+        sd.norm, sd.eps, sd.glu, sd.act, sd.wdtype, sd.causal, sd.window, sd.attn_scale = 1, 1e-5, 0, ACT_GELU, 1, 1, 0, 0.0
+        sd.layers = ctypes.cast(arr, ctypes.c_void_p)
+        sd.final_norm_w, sd.final_norm_b = p(self.ln.w), p(self.ln.b)
+        st["native"] = dict(arr=arr, desc=sd)
+        return st["native"]
+
     def decoder_step(self, tokens: torch.Tensor, st: dict) -> torch.Tensor:
         """tokens int32 [B, n] (device view) appended at offset st['n'] -> final-LN hidden states [B, n, n_text_state]."""
         d = self.dims
@@ -195,6 +227,14 @@ class WhisperEngine:
         nt, H, dh = d.n_text_state, d.n_text_head, self.dh
         x = self._f(B, n, nt)
         ops.gather_rows(self.tok_emb, tokens, x, pos_table=self.pos_emb[off:off + n])
+        if n == 1 and B <= 8 and self.native_decode:  # the whole 12-layer step from the native runner: one call instead of ~100 launches from Python
+            nd = self._native_desc(st)
+            ws = self._f(B * (2 * nt + 4 * nt))
+            out = self._f(B, 1, nt)
+            rc = _lib.load().mi355_stack_decode_step(ctypes.byref(nd["desc"]), x.data_ptr(), B, off, ws.data_ptr(), out.data_ptr(), ops._stream())
+            _lib.check(rc, "mi355_stack_decode_step")
+            st["n"] = off + 1
+            return out
         q = self._f(B, n, nt)
         att = self._f(B, n, nt)
         mid = self._f(B, n, 4 * nt)

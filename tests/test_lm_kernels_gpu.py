@@ -224,11 +224,17 @@ def test_transformer_stack_prefill_and_decode(ops, name):
     for i, (a, b) in enumerate(zip(layers, exp_layers)):
         assert rel_err(a, b) < 2e-4, (i, rel_err(a, b))
     assert rel_err(got, exp) < 2e-4
+    eng_py = TransformerStack(w, StackConfig(**asdict(rcfg)), device=DEV)
+    eng_py.native_decode = False           # the per-op Python schedule of the same kernels: must agree with the native runner
+    pc = eng_py.make_cache()
+    eng_py(x[:, :L].contiguous().to(DEV), pc)
     for s in range(steps):
         e = ref(x[:, L + s:L + s + 1], rc)
         o = eng(x[:, L + s:L + s + 1].contiguous().to(DEV), ec)
+        o2 = eng_py(x[:, L + s:L + s + 1].contiguous().to(DEV), pc)
         torch.cuda.synchronize()
         assert rel_err(o, e) < 2e-4, (s, rel_err(o, e))
+        assert rel_err(o, o2) < 1e-6, (s, rel_err(o, o2))
     assert ec[0].offset == L + steps == rc[0].offset
     # the step-256 cache growth (lm/models/cache.py:113-128): capacity is a multiple of 256 and survives a second growth
     assert ec[0].kv.shape[1] % 256 == 0

@@ -131,6 +131,17 @@ def test_kv_cache_equals_full_context(tiny):
     torch.cuda.synchronize()
     inc = torch.cat(parts, dim=1)
     assert rel_peak(inc, full) < 2e-5
+    # the native step runner (default) against the per-op Python schedule of the same kernels
+    eng.native_decode = False
+    try:
+        st = eng.new_state(xa)
+        py = [eng.logits(eng.decoder_step(toks[:, :3], st))[:, :, :dims.n_vocab]]
+        for i in range(3, toks.shape[1]):
+            py.append(eng.logits(eng.decoder_step(toks[:, i:i + 1], st))[:, :, :dims.n_vocab])
+        torch.cuda.synchronize()
+    finally:
+        eng.native_decode = True
+    assert rel_peak(torch.cat(py, dim=1), inc) < 1e-6
 
 
 def test_whisper_small_full_size():
