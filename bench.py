@@ -197,11 +197,21 @@ def main():
                     f.write(f"{shp[0]} {shp[1]} {shp[2]} {shp[3]} {e[3]} {e[0]} {e[1]:.3f} {e[2] / 1e9:.2f} {e[2] / (e[1] * 1e-3) / 1e12:.1f}\n")
         flops = sum(p[0] for p in prof)
         byts = sum(p[1] for p in prof)
+        # HBM bytes per conv_gemm launch from the PMC counters (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes over this same
+        # command, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py writes the summary that is read back here)
+        traffic, traffic_src = None, os.path.join(ROOT, "profiles", f"r1_hbm_traffic_kokoro_b{B}.json")
+        if os.path.exists(traffic_src):
+            with open(traffic_src) as f:
+                pk = json.load(f)["kernels"]
+            cg = [v for k, v in pk.items() if "conv_gemm" in k]
+            if cg:
+                traffic = sum(v["hbm_bytes_total_corrected"] for v in cg) / max(1, sum(v["dispatches"] for v in cg))
         ms = sum(p[2].elapsed_time(p[3]) for p in prof)
         res["roofline"] = {
             "bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv1d/convT/linear, v_mfma_f32_32x32x16_bf16)",
             "achieved": flops / (ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+            "frac": flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+            "traffic_note": "avg HBM bytes per conv_gemm launch, PMC (2*FETCH_SIZE + WRITE_SIZE)*1024; algorithmic avg = %.3e B" % (byts / max(1, len(prof))),
             "launches_per_step": len(prof), "algorithmic_gflop_per_step": flops / 1e9,
             "conv_gemm_ms_per_step": ms, "instrumented_step_ms": e0.elapsed_time(e1),
             "hbm_view": {"algorithmic_GB_per_step": byts / 1e9, "achieved_GBps": byts / (ms * 1e-3) / 1e9,

@@ -11,6 +11,7 @@
 // 16-bit weights) and a wave-level butterfly finishes each column.  Epilogue: bias, activation, residual, scale, and the
 // optional fused SwiGLU (interleaved gate / up rows: y[n/2] = silu(acc[n]) * acc[n+1]).  Prologue (optional): LayerNorm / RMSNorm of
 // the input rows, recomputed per workgroup; the output columns can be split over two destinations (q | k,v -> buffer | KV-cache slot).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -40,6 +41,46 @@ __device__ __forceinline__ float gemv_act(float v, int act, float slope) {
     case MI355_ACT_ELU: return v > 0.f ? v : expm1f(v);
     case MI355_ACT_TANH: return tanhf(v);
     default: return v;
+  }
+}
+
+// wave-level reduction of the per-lane partial sums + the epilogue (bias, activation, LayerScale, residual, SwiGLU, split destinations)
+template <int MT, int NC>
+__device__ __forceinline__ void gemv_finish(const mi355_gemv_args& a, float (&acc)[NC][MT], const int n0, const int lane) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[c][m] = wave_sum(acc[c][m]);
+  if (lane != 0) return;
+  if (a.glu) {  // columns come in (gate, up) pairs: NC is even on this path
+#pragma unroll
+    for (int c = 0; c + 1 < NC; c += 2) {
+      const int n = n0 + c;
+      if (n + 1 >= a.N) break;
+      const float bg = a.bias ? a.bias[n] : 0.f, bu = a.bias ? a.bias[n + 1] : 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        if (m >= a.M) break;
+        const float g = acc[c][m] + bg, u = acc[c + 1][m] + bu;
+        a.y[(int64_t)m * a.ldy + (n >> 1)] = (g / (1.0f + expf(-g))) * u * a.out_scale;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int n = n0 + c;
+    if (n >= a.N) break;
+    const float bias = a.bias ? a.bias[n] : 0.f;
+    const float cs = a.colscale ? a.colscale[n] : 1.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (m >= a.M) break;
+      float v = gemv_act(acc[c][m] + bias, a.post_act, a.post_slope) * cs;
+      if (a.res) v += a.res[(int64_t)m * a.ldr + n];
+      if (a.y2 && n >= a.split) a.y2[(int64_t)m * a.ldy2 + (n - a.split)] = v * a.out_scale;  // e.g. q -> y, k|v -> the KV-cache slot
+      else a.y[(int64_t)m * a.ldy + n] = v * a.out_scale;
+    }
   }
 }
 
@@ -140,40 +181,100 @@ __global__ __launch_bounds__(256) void gemv_kernel(const mi355_gemv_args a) {
     }
   }
   if (n0 >= a.N) return;
-#pragma unroll
-  for (int c = 0; c < NC; ++c)
-#pragma unroll
-    for (int m = 0; m < MT; ++m) acc[c][m] = wave_sum(acc[c][m]);
-  if (lane != 0) return;
-  if (a.glu) {  // columns come in (gate, up) pairs: NC is even on this path
-#pragma unroll
-    for (int c = 0; c + 1 < NC; c += 2) {
-      const int n = n0 + c;
-      if (n + 1 >= a.N) break;
-      const float bg = a.bias ? a.bias[n] : 0.f, bu = a.bias ? a.bias[n + 1] : 0.f;
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        if (m >= a.M) break;
-        const float g = acc[c][m] + bg, u = acc[c + 1][m] + bu;
-        a.y[(int64_t)m * a.ldy + (n >> 1)] = (g / (1.0f + expf(-g))) * u * a.out_scale;
+  gemv_finish<MT, NC>(a, acc, n0, lane);
+}
+
+// Resident-x variant for 4..8 input rows: at M = 8 the staging of x (M * K * 4 bytes per workgroup) costs more L2 traffic than the weight
+// rows a 4-wave workgroup consumes, so the rows are staged ONCE per workgroup (dynamic LDS, the fused norm applied on the way in) and the
+// waves then walk many column groups (grid-stride) with no barrier inside the loop -- only the weight stream touches memory.
+template <int MT, int NC, bool F16>
+__global__ __launch_bounds__(256) void gemv_res_kernel(const mi355_gemv_args a, const int ngroups) {
+  constexpr int D = 4;
+  extern __shared__ __attribute__((aligned(16))) float xr_s[];  // [MT][K]
+  __shared__ float st_mean[8], st_rstd[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = a.K;
+  if (a.norm) {
+    for (int m = wave; m < a.M; m += 4) {
+      const float* xr = a.x + (int64_t)m * a.ldx;
+      float s = 0.f;
+      for (int k = lane * 4; k < K; k += 256) { const float4 t = *(const float4*)(xr + k); s += (t.x + t.y) + (t.z + t.w); }
+      const float mean = a.norm == 1 ? wave_sum(s) / (float)K : 0.f;
+      float q = 0.f;
+      for (int k = lane * 4; k < K; k += 256) {
+        const float4 t = *(const float4*)(xr + k);
+        const float d0 = t.x - mean, d1 = t.y - mean, d2 = t.z - mean, d3 = t.w - mean;
+        q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
+      const float var = wave_sum(q) / (float)K;
+      if (lane == 0) { st_mean[m] = mean; st_rstd[m] = a.norm == 1 ? 1.0f / sqrtf(var + a.norm_eps) : rsqrtf(var + a.norm_eps); }
+    }
+    __syncthreads();
+  }
+  for (int e = tid * 4; e < MT * K; e += 1024) {
+    const int m = e / K, k = e - m * K;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < a.M) {
+      t = *(const float4*)(a.x + (int64_t)m * a.ldx + k);
+      if (a.norm) {
+        const float mu = st_mean[m], rs = st_rstd[m];
+        float4 w4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.norm_weight) w4 = *(const float4*)(a.norm_weight + k);
+        if (a.norm_bias) b4 = *(const float4*)(a.norm_bias + k);
+        t = make_float4((t.x - mu) * rs * w4.x + b4.x, (t.y - mu) * rs * w4.y + b4.y, (t.z - mu) * rs * w4.z + b4.z, (t.w - mu) * rs * w4.w + b4.w);
       }
     }
-    return;
+    *(float4*)(xr_s + e) = t;
   }
+  __syncthreads();
+  const int n_it = (K + 511) >> 9;
+  for (int g = blockIdx.x * 4 + wave; g < ngroups; g += gridDim.x * 4) {
+    const int n0 = g * NC;
+    float acc[NC][MT];
 #pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const int n = n0 + c;
-    if (n >= a.N) break;
-    const float bias = a.bias ? a.bias[n] : 0.f;
-    const float cs = a.colscale ? a.colscale[n] : 1.f;
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      if (m >= a.M) break;
-      float v = gemv_act(acc[c][m] + bias, a.post_act, a.post_slope) * cs;
-      if (a.res) v += a.res[(int64_t)m * a.ldr + n];
-      if (a.y2 && n >= a.split) a.y2[(int64_t)m * a.ldy2 + (n - a.split)] = v * a.out_scale;  // e.g. q -> y, k|v -> the KV-cache slot
-      else a.y[(int64_t)m * a.ldy + n] = v * a.out_scale;
+      for (int m = 0; m < MT; ++m) acc[c][m] = 0.f;
+    const uint16_t* wrow[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int n = n0 + c < a.N ? n0 + c : a.N - 1;
+      wrow[c] = a.w + (int64_t)n * a.ldw;
     }
+    uint4 ring[D][NC];
+    auto issue = [&](int it, uint4 (&dst)[NC]) {
+      const int k = (it << 9) + lane * 8;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) dst[c] = k < K ? *(const uint4*)(wrow[c] + k) : make_uint4(0u, 0u, 0u, 0u);
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (d < n_it) issue(d, ring[d]);
+    for (int base = 0; base < n_it; base += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int it = base + d;
+        if (it >= n_it) break;
+        const int k = (it << 9) + lane * 8;
+        if (k < K) {
+          float wf[NC][8];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) cvt8<F16>(ring[d][c], wf[c]);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const float4 lo = *(const float4*)(xr_s + m * K + k);
+            const float4 hi = *(const float4*)(xr_s + m * K + k + 4);
+            const float xv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+              for (int j = 0; j < 8; ++j) acc[c][m] = fmaf(xv[j], wf[c][j], acc[c][m]);
+          }
+        }
+        if (it + D < n_it) issue(it + D, ring[d]);
+      }
+    }
+    gemv_finish<MT, NC>(a, acc, n0, lane);
   }
 }
 
@@ -182,6 +283,26 @@ int launch_gemv(const mi355_gemv_args& a, hipStream_t st) {
   // one column per wave keeps the most wavefronts (and weight bytes) in flight; two columns per wave halve the LDS reads of x per weight
   // byte, which is what binds at 8 rows (16 LDS bytes per weight byte at NC = 1) and for very wide outputs
   const int nc = (a.glu || MT >= 8 || a.N >= 16384) ? 2 : 1;
+  if constexpr (MT >= 4) {
+    const size_t lds = (size_t)MT * a.K * sizeof(float);
+    static const bool no_res = getenv("MI355_GEMV_NO_RESIDENT") != nullptr;  // A/B aid
+    if (lds <= 96 * 1024 && !no_res) {
+      static bool attr_set = false;  // benign race: the attribute is idempotent
+      if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemv_res_kernel<MT, 2, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        MI355_REQUIRE(e == hipSuccess, "gemv: cannot reserve LDS: %s", hipGetErrorString(e));
+        attr_set = true;
+      }
+      const int ngroups = (a.N + 1) / 2;
+      const int per_cu = lds <= 24 * 1024 ? 4 : (lds <= 48 * 1024 ? 3 : (lds <= 72 * 1024 ? 2 : 1));
+      int blocks = (ngroups + 3) / 4;
+      if (blocks > 256 * per_cu) blocks = 256 * per_cu;
+      MI355_CLEAR_ERROR();
+      hipLaunchKernelGGL((gemv_res_kernel<MT, 2, F16>), dim3(blocks), dim3(256), lds, st, a, ngroups);
+      MI355_LAUNCH_CHECK("gemv(resident)");
+      return MI355_OK;
+    }
+  }
   MI355_CLEAR_ERROR();
   if (nc == 2) hipLaunchKernelGGL((gemv_kernel<MT, 2, F16>), dim3((a.N + 7) / 8), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((gemv_kernel<MT, 1, F16>), dim3((a.N + 3) / 4), dim3(256), 0, st, a);
