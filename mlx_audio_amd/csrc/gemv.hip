@@ -285,8 +285,11 @@ int launch_gemv(const mi355_gemv_args& a, hipStream_t st) {
   const int nc = (a.glu || MT >= 8 || a.N >= 16384) ? 2 : 1;
   if constexpr (MT >= 4) {
     const size_t lds = (size_t)MT * a.K * sizeof(float);
-    static const bool no_res = getenv("MI355_GEMV_NO_RESIDENT") != nullptr;  // A/B aid
-    if (lds <= 96 * 1024 && !no_res) {
+    // Measured (profiles/r1_kernel_stats_qwen3_1p7b_b8_v4_resident.txt): 22.0 us vs 18.9 us per launch for the chunked kernel at M = 8 -- these
+    // launches are bound by their dependent chain (statistics -> staging -> first weight slice), not by the re-staging of x, and the chunked
+    // kernel overlaps the weight latency with the staging.  Kept as an opt-in (MI355_GEMV_RESIDENT=1) for wide-N shapes.
+    static const bool use_res = getenv("MI355_GEMV_RESIDENT") != nullptr;
+    if (lds <= 96 * 1024 && use_res) {
       static bool attr_set = false;  // benign race: the attribute is idempotent
       if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemv_res_kernel<MT, 2, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
