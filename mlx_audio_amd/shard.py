@@ -1,4 +1,4 @@
-"""Utterance sharding over the GPUs of one node (one process per GPU, ``torch.distributed``).
+"""Utterance / window sharding over the GPUs of one node (one process per GPU, ``torch.distributed``).
 
 The hot path shards naturally: utterances are independent (Kokoro chunks of
 <= 510 phonemes, ``tts/models/kokoro/pipeline.py:266-293``), weights are replicated, and the only
@@ -73,9 +73,29 @@ def my_shard(lens: torch.Tensor, dist=None, cost=None) -> List[int]:
     return lpt_assign(costs, world)[rank]
 
 
+def broadcast_tensor(t: Optional[torch.Tensor], device, dist=None, src: int = 0, dtype=torch.float32) -> torch.Tensor:
+    """Rank ``src`` owns a dense tensor (e.g. the 30 s audio windows of a Whisper request, the prefill embeddings of a Qwen3 batch);
+    afterwards every rank holds it on ``device``.  Shape travels first (one int64 header), then the payload."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return t.to(device=device, dtype=dtype)
+    rank = dist.get_rank()
+    hdr = torch.zeros(8, dtype=torch.int64, device=device)
+    if rank == src:
+        assert t.dim() <= 7
+        hdr[0] = t.dim()
+        for i, n in enumerate(t.shape):
+            hdr[1 + i] = n
+    dist.broadcast(hdr, src)
+    shape = [int(v) for v in hdr[1:1 + int(hdr[0])]]
+    buf = t.to(device=device, dtype=dtype).contiguous() if rank == src else torch.empty(shape, dtype=dtype, device=device)
+    dist.broadcast(buf, src)
+    return buf
+
+
 def gather_waveforms(local_audio: Sequence[torch.Tensor], local_idx: Sequence[int], n_total: int, device, dist=None,
-                     dst: int = 0) -> Optional[List[torch.Tensor]]:
-    """Collects every rank's waveforms on rank ``dst`` in original utterance order.
+                     dst: int = 0, dtype=torch.float32) -> Optional[List[torch.Tensor]]:
+    """Collects every rank's per-item 1-D results (waveforms; with ``dtype=torch.int64`` token / code sequences) on rank ``dst`` in
+    original item order.
 
     One all-gather of the per-utterance sample counts (int64 x n_total), then one padded gather of float32
     samples ``[n_local_max, samples_max]`` per rank.  Returns the list on ``dst`` and ``None`` elsewhere."""
@@ -100,9 +120,9 @@ def gather_waveforms(local_audio: Sequence[torch.Tensor], local_idx: Sequence[in
     idx_pad = torch.full((nmax,), -1, dtype=torch.int64, device=device)
     if local_idx:
         idx_pad[: len(local_idx)] = torch.tensor(list(local_idx), dtype=torch.int64, device=device)
-    payload = torch.zeros((nmax, smax), dtype=torch.float32, device=device)
+    payload = torch.zeros((nmax, smax), dtype=dtype, device=device)
     for j, a in enumerate(local_audio):
-        payload[j, : a.numel()] = a.to(device=device, dtype=torch.float32)
+        payload[j, : a.numel()] = a.reshape(-1).to(device=device, dtype=dtype)
     if rank == dst:
         idx_all = [torch.empty_like(idx_pad) for _ in range(world)]
         pay_all = [torch.empty_like(payload) for _ in range(world)]

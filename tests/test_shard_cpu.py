@@ -85,3 +85,43 @@ def test_single_process_passthrough():
     assert mine == [0, 1, 2]
     out = shard.gather_waveforms([_fake_synth(r) for r in reqs], mine, 3, "cpu", None)
     assert all(torch.equal(o, _fake_synth(r)) for o, r in zip(out, reqs))
+
+
+# ------------------------------------------------------------------ Whisper windows / Qwen3 batch items (dense inputs, integer outputs)
+def _fake_transcribe(window: torch.Tensor) -> torch.Tensor:
+    """Deterministic stand-in for the decoder: a token sequence whose length and content depend on the window."""
+    n = 3 + int(window.abs().sum() * 10) % 7
+    return (torch.arange(n, dtype=torch.int64) * 3 + int(window[0] * 100) % 50)
+
+
+def _worker_dense(rank, world, port, n_items, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(11)
+        windows = torch.randn(n_items, 160, generator=g) if rank == 0 else None
+        w = shard.broadcast_tensor(windows, "cpu", dist)
+        mine = shard.lpt_assign([1] * w.shape[0], world)[rank]          # equal-cost items (30 s windows)
+        toks = [_fake_transcribe(w[i]) for i in mine]
+        out = shard.gather_waveforms(toks, mine, w.shape[0], "cpu", dist, dtype=torch.int64)
+        if rank == 0:
+            q.put(all(torch.equal(o, _fake_transcribe(windows[i])) and o.dtype == torch.int64 for i, o in enumerate(out)) and len(out) == n_items)
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_items", [(2, 5), (3, 3)])
+def test_dense_inputs_integer_outputs_gloo(world, n_items):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dense, args=(r, world, port, n_items, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get()
