@@ -35,7 +35,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
+    ap.add_argument("--batch", type=int, default=64,
+                    help="utterances per GPU per step (SURVEY 8d batch list: 1 / 8 / 64 / 512; 64 per GPU = 512 over the 8-GPU node; measured on one\n"
+                         "MI355X: 122 M samples/s at 32, 140 M at 64, 146 M at 128, 150 M at 256 -- the front end's latency-bound LSTMs amortise)")
     ap.add_argument("--precision", type=int, default=2,
                     help="2 = bf16 hi+lo split MFMA (fp32-grade), 3 = single fp16 pass in the vocoder, 1 = single bf16 pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -221,16 +221,19 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
     float s = -INFINITY;
     if (j < kend) {
       const float* krow = kbase + (int64_t)j * a.ldk;
-      float t = 0.f;
-#pragma unroll 4
-      for (int d = 0; d < DH; d += 4) {
-        const float4 kv = *(const float4*)(krow + d);
-        t = fmaf(qs[d], kv.x, t);
-        t = fmaf(qs[d + 1], kv.y, t);
-        t = fmaf(qs[d + 2], kv.z, t);
-        t = fmaf(qs[d + 3], kv.w, t);
+      // the whole key row in flight at once (DH/4 independent 16-B loads), then four independent FMA chains
+      float4 kv[DH / 4];
+#pragma unroll
+      for (int d = 0; d < DH / 4; ++d) kv[d] = *(const float4*)(krow + 4 * d);
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+      for (int d = 0; d < DH / 4; ++d) {
+        t0 = fmaf(qs[4 * d], kv[d].x, t0);
+        t1 = fmaf(qs[4 * d + 1], kv[d].y, t1);
+        t2 = fmaf(qs[4 * d + 2], kv[d].z, t2);
+        t3 = fmaf(qs[4 * d + 3], kv[d].w, t3);
       }
-      s = t;
+      s = (t0 + t1) + (t2 + t3);
     }
     const float m_new = fmaxf(m, wave_max(s));  // finite: key kb itself is visible
     const float alpha = exp2f(m - m_new);
@@ -242,11 +245,23 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
     const int n = kend - kb < 64 ? kend - kb : 64;
 #pragma unroll
     for (int i = 0; i < ND; ++i) o[i] *= alpha;
-    for (int jj = 0; jj < n; ++jj) {
-      const float pj = ps[wave][jj];
-      const float* vrow = vbase + (int64_t)(kb + jj) * a.ldv;
+    // p.V: 8 value rows in flight per step (a rolled loop keeps ONE load in flight and serialises 64 L2 latencies per chunk: that, not
+    // bandwidth, was what made the 1500-key cross-attention step take 42 us)
+    for (int jj = 0; jj < n; jj += 8) {
+      float vv[8][ND];
 #pragma unroll
-      for (int i = 0; i < ND; ++i) o[i] = fmaf(pj, vrow[i * 64 + lane], o[i]);
+      for (int u = 0; u < 8; ++u) {
+        const int j = jj + u < n ? jj + u : n - 1;
+        const float* vrow = vbase + (int64_t)(kb + j) * a.ldv;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) vv[u][i] = vrow[i * 64 + lane];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float pj = jj + u < n ? ps[wave][jj + u] : 0.f;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) o[i] = fmaf(pj, vv[u][i], o[i]);
+      }
     }
     wave_lds_sync2();
   }

@@ -103,25 +103,6 @@ __global__ __launch_bounds__(256) void gemv_kernel(const mi355_gemv_args a) {
     const int n = n0 + c < a.N ? n0 + c : a.N - 1;  // clamp: tail columns recompute the last row, never stored
     wrow[c] = a.w + (int64_t)n * a.ldw;
   }
-  // fused input normalisation (LayerNorm / RMSNorm of the M input rows): every workgroup recomputes the row statistics out of L2
-  // (M * K floats, twice) instead of a separate norm launch writing and re-reading the normalised rows
-  __shared__ float st_mean[8], st_rstd[8];
-  if (a.norm) {
-    for (int m = wave; m < a.M; m += 4) {
-      const float* xr = a.x + (int64_t)m * a.ldx;
-      float s = 0.f;
-      for (int k = lane * 4; k < a.K; k += 256) { const float4 t = *(const float4*)(xr + k); s += (t.x + t.y) + (t.z + t.w); }
-      const float mean = a.norm == 1 ? wave_sum(s) / (float)a.K : 0.f;
-      float q = 0.f;
-      for (int k = lane * 4; k < a.K; k += 256) {
-        const float4 t = *(const float4*)(xr + k);
-        const float d0 = t.x - mean, d1 = t.y - mean, d2 = t.z - mean, d3 = t.w - mean;
-        q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-      }
-      const float var = wave_sum(q) / (float)a.K;
-      if (lane == 0) { st_mean[m] = mean; st_rstd[m] = a.norm == 1 ? 1.0f / sqrtf(var + a.norm_eps) : rsqrtf(var + a.norm_eps); }
-    }
-  }
   // The weight stream is a software pipeline of its own: D k-slices (512 elements = 64 lanes x 16 B each) per column are always in
   // flight, issued before the x chunk they will meet is even staged -- the HBM latency of the weights overlaps the L2 latency of x and
   // the workgroup barriers around the LDS staging instead of adding to them.
@@ -135,6 +116,45 @@ __global__ __launch_bounds__(256) void gemv_kernel(const mi355_gemv_args a) {
 #pragma unroll
   for (int d = 0; d < D; ++d)
     if (d < n_it) issue(d, ring[d]);
+  // fused input normalisation (LayerNorm / RMSNorm of the M input rows): every workgroup recomputes the row statistics out of L2 instead of
+  // a separate norm launch writing and re-reading the normalised rows.  Rows of up to 2048 elements are read ONCE into registers (mean, then
+  // the centred second moment from the same registers: two-pass numerics, one L2 round trip); longer rows take a second read.
+  __shared__ float st_mean[8], st_rstd[8];
+  if (a.norm) {
+    for (int m = wave; m < a.M; m += 4) {
+      const float* xr = a.x + (int64_t)m * a.ldx;
+      float mean = 0.f, q = 0.f;
+      if (a.K <= 2048) {
+        float4 buf[8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int k = lane * 4 + i * 256;
+          buf[i] = k < a.K ? *(const float4*)(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+          s += (buf[i].x + buf[i].y) + (buf[i].z + buf[i].w);
+        }
+        mean = a.norm == 1 ? wave_sum(s) / (float)a.K : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (lane * 4 + i * 256 < a.K) {
+            const float d0 = buf[i].x - mean, d1 = buf[i].y - mean, d2 = buf[i].z - mean, d3 = buf[i].w - mean;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+          }
+        }
+      } else {
+        float s = 0.f;
+        for (int k = lane * 4; k < a.K; k += 256) { const float4 t = *(const float4*)(xr + k); s += (t.x + t.y) + (t.z + t.w); }
+        mean = a.norm == 1 ? wave_sum(s) / (float)a.K : 0.f;
+        for (int k = lane * 4; k < a.K; k += 256) {
+          const float4 t = *(const float4*)(xr + k);
+          const float d0 = t.x - mean, d1 = t.y - mean, d2 = t.z - mean, d3 = t.w - mean;
+          q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+      }
+      const float var = wave_sum(q) / (float)a.K;
+      if (lane == 0) { st_mean[m] = mean; st_rstd[m] = a.norm == 1 ? 1.0f / sqrtf(var + a.norm_eps) : rsqrtf(var + a.norm_eps); }
+    }
+  }
   for (int base = 0; base < n_it; base += D) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -144,20 +164,37 @@ __global__ __launch_bounds__(256) void gemv_kernel(const mi355_gemv_args a) {
         const int k0 = (it / IPC) * KC;
         const int kc = a.K - k0 < KC ? a.K - k0 : KC;  // multiple of 8 (K % 8 == 0)
         __syncthreads();
-        for (int e = tid * 4; e < MT * kc; e += 1024) {
-          const int m = e / kc, k = e - m * kc;
-          float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (m < a.M) {
-            t = *(const float4*)(a.x + (int64_t)m * a.ldx + k0 + k);
-            if (a.norm) {
-              const float mu = st_mean[m], rs = st_rstd[m];
-              float4 w4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (a.norm_weight) w4 = *(const float4*)(a.norm_weight + k0 + k);
-              if (a.norm_bias) b4 = *(const float4*)(a.norm_bias + k0 + k);
-              t = make_float4((t.x - mu) * rs * w4.x + b4.x, (t.y - mu) * rs * w4.y + b4.y, (t.z - mu) * rs * w4.z + b4.z, (t.w - mu) * rs * w4.w + b4.w);
+        {  // all of this thread's loads of the chunk go out before the first one is consumed (a rolled load -> store loop serialises
+           // one L2 latency per iteration: 8 of them for 8 rows)
+          constexpr int NST = MT * KC / 1024;
+          float4 tb[NST], wb[NST], bb[NST];
+#pragma unroll
+          for (int i = 0; i < NST; ++i) {
+            const int e = tid * 4 + i * 1024;
+            const int m = e / kc, k = e - m * kc;
+            tb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            wb[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+            bb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < MT * kc && m < a.M) {
+              tb[i] = *(const float4*)(a.x + (int64_t)m * a.ldx + k0 + k);
+              if (a.norm && a.norm_weight) wb[i] = *(const float4*)(a.norm_weight + k0 + k);
+              if (a.norm && a.norm_bias) bb[i] = *(const float4*)(a.norm_bias + k0 + k);
             }
           }
-          *(float4*)(xs + m * KC + k) = t;
+#pragma unroll
+          for (int i = 0; i < NST; ++i) {
+            const int e = tid * 4 + i * 1024;
+            if (e < MT * kc) {
+              const int m = e / kc, k = e - m * kc;
+              float4 t = tb[i];
+              if (a.norm && m < a.M) {
+                const float mu = st_mean[m], rs = st_rstd[m];
+                t = make_float4((t.x - mu) * rs * wb[i].x + bb[i].x, (t.y - mu) * rs * wb[i].y + bb[i].y, (t.z - mu) * rs * wb[i].z + bb[i].z,
+                                (t.w - mu) * rs * wb[i].w + bb[i].w);
+              }
+              *(float4*)(xs + m * KC + k) = t;
+            }
+          }
         }
         __syncthreads();
       }

@@ -15,10 +15,10 @@ timeout 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$GRAFT_REPO_ROOT/gpuru
 echo "pmc write rc=$?" | tee -a "$GRAFT_REPO_ROOT/$R"
 cd "$GRAFT_REPO_ROOT"
 DBF=$(find gpurun_out/pmc_f -name "*_results.db" | head -1); DBW=$(find gpurun_out/pmc_w -name "*_results.db" | head -1)
-python tools/pmc_traffic.py "$DBF" "$DBW" > gpurun_out/hbm_traffic_kokoro_b32.json 2> gpurun_out/pmc_traffic.err
+python tools/pmc_traffic.py "$DBF" "$DBW" > gpurun_out/hbm_traffic_kokoro_b64.json 2> gpurun_out/pmc_traffic.err
 echo "pmc summary rc=$?" | tee -a $R
 rm -rf gpurun_out/pmc_f gpurun_out/pmc_w
-mkdir -p profiles; cp gpurun_out/hbm_traffic_kokoro_b32.json profiles/r1_hbm_traffic_kokoro_b32.json
+mkdir -p profiles; cp gpurun_out/hbm_traffic_kokoro_b64.json profiles/r1_hbm_traffic_kokoro_b64.json
 timeout 600 python bench.py > gpurun_out/bench_final11.json 2> gpurun_out/bench_final11.err
 echo "bench rc=$?" | tee -a $R
 cd /tmp
@@ -26,4 +26,4 @@ timeout 500 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/pro
 echo "rocprof kokoro rc=$?" | tee -a "$GRAFT_REPO_ROOT/$R"
 cd "$GRAFT_REPO_ROOT"
 DB=$(find gpurun_out/prof_k -name "*_results.db" | head -1); python tools/rocpd_stats.py "$DB" 4 | cut -c1-200 > gpurun_out/kokoro_kernel_stats_v5.txt 2>&1; rm -rf gpurun_out/prof_k
-cat $R; tail -n 15 gpurun_out/t_full11.log; tail -n 3 gpurun_out/smoke11.log; cat gpurun_out/bench_final11.json; tail -n 3 gpurun_out/bench_final11.err; head -c 1500 gpurun_out/hbm_traffic_kokoro_b32.json; tail -n 5 gpurun_out/pmc_traffic.err gpurun_out/pmc_f.err; head -n 12 gpurun_out/kokoro_kernel_stats_v5.txt
+cat $R; tail -n 15 gpurun_out/t_full11.log; tail -n 3 gpurun_out/smoke11.log; cat gpurun_out/bench_final11.json; tail -n 3 gpurun_out/bench_final11.err; head -c 300 gpurun_out/hbm_traffic_kokoro_b64.json; tail -n 5 gpurun_out/pmc_traffic.err gpurun_out/pmc_f.err; head -n 12 gpurun_out/kokoro_kernel_stats_v5.txt
