@@ -364,6 +364,12 @@ typedef struct {
   int32_t mode;           /* 0 = auto (decode kernel when Tq <= 8), 1 = MFMA flash kernel, 2 = decode kernel */
   float* out; int64_t out_bstride; int32_t ldo;  /* [B, Tq, ldo], head h at [h*dh, (h+1)*dh) */
   const int32_t* k_start; /* [B] nullable: keys j < k_start[b] are left padding (BatchKVCache, lm/models/cache.py:502-560) */
+  /* key-range split for decode steps over long key ranges (flash-decoding): partial (max, sum, out) records in split_ws
+     [B * heads * Tq * 8 * (dh + 2)] floats, tickets in split_cnt [B * heads * Tq] int32 (zero before the first call; left zero by every call).
+     nsplit: 0 = chosen by the library when the workspace is given, 1 = off, 2..8 = forced.  Null workspace = off. */
+  float* split_ws; int32_t* split_cnt; int32_t nsplit;
+  int64_t k_hstride; int64_t v_hstride; /* 0: kv head g at columns [g*dh, (g+1)*dh) of a row; else head-major planes: head g starts at
+                                           g * k_hstride (rows of that head ldk apart, typically ldk = dh) */
 } mi355_flash_attn_args;
 int mi355_flash_attention(const mi355_flash_attn_args* a, void* stream);
 
@@ -523,7 +529,8 @@ typedef struct {
   /* optional cross-attention block (Whisper decoder): q projection + pre-norm, K | V precomputed [B, cross_len, 2*kv_heads*dh] */
   const uint16_t* wcq; const float* bcq; const uint16_t* wco; const float* bco;
   const float* cross_norm_w; const float* cross_norm_b;
-  const float* cross_kv; int64_t cross_bstride; int32_t cross_len;
+  const float* cross_k; const float* cross_v;   /* head-major [B, kv_heads, cross_len, dh] each (a head's keys contiguous) */
+  int64_t cross_bstride; int64_t cross_hstride; int32_t cross_ld; int32_t cross_len;
 } mi355_layer_desc;
 
 typedef struct {
@@ -537,6 +544,7 @@ typedef struct {
   float attn_scale;        /* 0 => dh^-0.5 */
   int32_t rope_mode; const float* cos; const float* sin;   /* tables [max_pos, dh/2], nullable: no rotary embedding */
   const mi355_layer_desc* layers;                           /* HOST array of n_layers records */
+  float* attn_split_ws; int32_t* attn_split_cnt;            /* nullable: workspace of mi355_flash_attn_args.split_* for B <= 8, Tq = 1 */
   const float* final_norm_w; const float* final_norm_b;     /* nullable */
 } mi355_stack_desc;
 

@@ -87,8 +87,10 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const mi355_flash_attn_
   if (kstart > kbeg) kbeg = kstart;
   kbeg &= ~(KB - 1);
 
-  const float* kbase = a.k + (int64_t)b * a.k_bstride + g * DH;
-  const float* vbase = a.v + (int64_t)b * a.v_bstride + g * DH;
+  // heads packed inside a row (g * DH) or head-major planes (k_hstride: a head's keys contiguous -- the layout for long key ranges:
+  // with rows of 2 * heads * DH floats every key of one head sits 6-8 KB from the next and lands on the same one or two L2 channels)
+  const float* kbase = a.k + (int64_t)b * a.k_bstride + (a.k_hstride ? (int64_t)g * a.k_hstride : (int64_t)g * DH);
+  const float* vbase = a.v + (int64_t)b * a.v_bstride + (a.v_hstride ? (int64_t)g * a.v_hstride : (int64_t)g * DH);
 
   float4 kpre[NLD], vpre[NLD];
   auto prefetch = [&](int kb) {
@@ -199,7 +201,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
   __shared__ float red_m[NW], red_l[NW];
   __shared__ float red_o[NW][DH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qi = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int nsplit = a.nsplit > 1 ? a.nsplit : 1;  // key range split over nsplit workgroups (partials merged by the last one to finish)
+  const int qi = blockIdx.x / nsplit, sp = blockIdx.x - qi * nsplit, h = blockIdx.y, b = blockIdx.z;
   const int g = h / (a.heads / a.kv_heads);
   const int len_q = a.lens_q ? a.lens_q[b] : a.Tq;
   const int len_k = a.lens_k ? a.lens_k[b] : a.Tk;
@@ -211,30 +214,52 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
   if (a.causal) kend = qpos + 1 < len_k ? qpos + 1 : len_k;
   if (a.window > 0) { kbeg = qpos - a.window + 1; if (kbeg < 0) kbeg = 0; }
   if (a.k_start && a.k_start[b] > kbeg) kbeg = a.k_start[b];
-  const float* kbase = a.k + (int64_t)b * a.k_bstride + g * DH;
-  const float* vbase = a.v + (int64_t)b * a.v_bstride + g * DH;
+  if (nsplit > 1) {  // this workgroup's share: contiguous, a multiple of 64 keys
+    const int span = kend > kbeg ? kend - kbeg : 0;
+    const int per = (((span + nsplit - 1) / nsplit) + 63) & ~63;
+    kbeg += sp * per;
+    if (kbeg + per < kend) kend = kbeg + per;
+  }
+  // heads packed inside a row (g * DH) or head-major planes (k_hstride: a head's keys contiguous -- the layout for long key ranges:
+  // with rows of 2 * heads * DH floats every key of one head sits 6-8 KB from the next and lands on the same one or two L2 channels)
+  const float* kbase = a.k + (int64_t)b * a.k_bstride + (a.k_hstride ? (int64_t)g * a.k_hstride : (int64_t)g * DH);
+  const float* vbase = a.v + (int64_t)b * a.v_bstride + (a.v_hstride ? (int64_t)g * a.v_hstride : (int64_t)g * DH);
   float m = -INFINITY, l = 0.f, o[ND];
 #pragma unroll
   for (int i = 0; i < ND; ++i) o[i] = 0.f;
   for (int kb = kbeg + wave * 64; kb < kend; kb += NW * 64) {
-    const int j = kb + lane;
-    float s = -INFINITY;
-    if (j < kend) {
-      const float* krow = kbase + (int64_t)j * a.ldk;
-      // the whole key row in flight at once (DH/4 independent 16-B loads), then four independent FMA chains
-      float4 kv[DH / 4];
+    // q.k with FOUR lanes per key: each load instruction then touches 16 keys x 64 contiguous bytes (16 cache lines) instead of 64 keys x
+    // 16 bytes (64 lines) -- the row-per-lane pattern is bound by the address unit (one line per clock), not by bandwidth.  Lane (g, sub) of a
+    // 16-key pass owns floats [i*16 + sub*4, +4) of key g for i = 0 .. DH/16; two xor-shuffles finish the dot product; the 64 scores of the
+    // chunk are redistributed one per lane through LDS.
+    {
+      const int sub = lane & 3, grp = lane >> 2;
 #pragma unroll
-      for (int d = 0; d < DH / 4; ++d) kv[d] = *(const float4*)(krow + 4 * d);
-      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+      for (int p4 = 0; p4 < 4; ++p4) {
+        const int key = kb + p4 * 16 + grp;
+        const bool valid = key < kend;
+        const float* krow = kbase + (int64_t)(valid ? key : kend - 1) * a.ldk + sub * 4;
+        float4 kv[DH / 16];
 #pragma unroll
-      for (int d = 0; d < DH / 4; ++d) {
-        t0 = fmaf(qs[4 * d], kv[d].x, t0);
-        t1 = fmaf(qs[4 * d + 1], kv[d].y, t1);
-        t2 = fmaf(qs[4 * d + 2], kv[d].z, t2);
-        t3 = fmaf(qs[4 * d + 3], kv[d].w, t3);
+        for (int i = 0; i < DH / 16; ++i) kv[i] = *(const float4*)(krow + i * 16);
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < DH / 16; ++i) {
+          const int d = i * 16 + sub * 4;
+          t0 = fmaf(qs[d], kv[i].x, t0);
+          t1 = fmaf(qs[d + 1], kv[i].y, t1);
+          t0 = fmaf(qs[d + 2], kv[i].z, t0);
+          t1 = fmaf(qs[d + 3], kv[i].w, t1);
+        }
+        float t = t0 + t1;
+        t += __shfl_xor(t, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        if (sub == 0) ps[wave][p4 * 16 + grp] = valid ? t : -INFINITY;
       }
-      s = (t0 + t1) + (t2 + t3);
     }
+    wave_lds_sync2();
+    const float s = ps[wave][lane];
+    wave_lds_sync2();  // every lane has its score before ps is overwritten with the probabilities
     const float m_new = fmaxf(m, wave_max(s));  // finite: key kb itself is visible
     const float alpha = exp2f(m - m_new);
     const float p = exp2f(s - m_new);
@@ -280,16 +305,48 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
       w[i] = red_m[i] == -INFINITY ? 0.f : exp2f(red_m[i] - M);
       L += red_l[i] * w[i];
     }
-    const float inv = L > 0.f ? 1.0f / L : 0.f;
     float* orow = a.out + (int64_t)b * a.out_bstride + (int64_t)qi * a.ldo + h * DH;
+    float t[ND];
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
       const int d = i * 64 + lane;
-      float t = 0.f;
+      t[i] = 0.f;
 #pragma unroll
-      for (int j = 0; j < NW; ++j) t += red_o[j][d] * w[j];
-      orow[d] = t * inv;
+      for (int j = 0; j < NW; ++j) t[i] += red_o[j][d] * w[j];
     }
+    if (nsplit > 1) {
+      // publish this workgroup's partial (M, L, O), then take a ticket: the workgroup that draws the last ticket merges all of them.
+      // No workgroup ever waits for another one (no spinning), so there is nothing to deadlock on.
+      const int64_t idx = ((int64_t)b * a.heads + h) * a.Tq + qi;
+      float* rec = a.split_ws + (idx * nsplit + sp) * (DH + 2);
+      if (lane == 0) { rec[0] = M; rec[1] = L; }
+#pragma unroll
+      for (int i = 0; i < ND; ++i) rec[2 + i * 64 + lane] = t[i];
+      __threadfence();
+      int ticket = 0;
+      if (lane == 0) ticket = atomicAdd(a.split_cnt + idx, 1);
+      ticket = __shfl(ticket, 0, 64);
+      if (ticket != nsplit - 1) return;
+      __threadfence();
+      const float* recs = a.split_ws + idx * nsplit * (DH + 2);
+      M = -INFINITY;
+      for (int s2 = 0; s2 < nsplit; ++s2) M = fmaxf(M, __hip_atomic_load(recs + s2 * (DH + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      L = 0.f;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) t[i] = 0.f;
+      for (int s2 = 0; s2 < nsplit; ++s2) {
+        const float* r2 = recs + s2 * (DH + 2);
+        const float ms = __hip_atomic_load(r2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float ws2 = ms == -INFINITY ? 0.f : exp2f(ms - M);
+        L += __hip_atomic_load(r2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * ws2;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) t[i] += __hip_atomic_load(r2 + 2 + i * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * ws2;
+      }
+      if (lane == 0) a.split_cnt[idx] = 0;  // leave the counters zeroed for the next launch
+    }
+    const float inv = L > 0.f ? 1.0f / L : 0.f;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) orow[i * 64 + lane] = t[i] * inv;
   }
 }
 
@@ -297,7 +354,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
 
 extern "C" int mi355_flash_attention(const mi355_flash_attn_args* ap, void* stream) {
   MI355_REQUIRE(ap && ap->q && ap->k && ap->v && ap->out, "flash_attention: null tensor");
-  const mi355_flash_attn_args a = *ap;
+  mi355_flash_attn_args a = *ap;
   MI355_REQUIRE(a.dh == 64 || a.dh == 128, "flash_attention: head dim must be 64 or 128 (got %d)", a.dh);
   MI355_REQUIRE(a.heads > 0 && a.kv_heads > 0 && a.heads % a.kv_heads == 0, "flash_attention: heads must be a multiple of kv_heads");
   MI355_REQUIRE(a.B > 0 && a.Tq > 0 && a.Tk > 0, "flash_attention: bad shape");
@@ -310,7 +367,20 @@ extern "C" int mi355_flash_attention(const mi355_flash_attn_args* ap, void* stre
   MI355_CLEAR_ERROR();
   const bool decode = a.mode == 2 || (a.mode == 0 && a.Tq <= 8);
   if (decode) {
-    dim3 grid(a.Tq, a.heads, a.B);
+    // long key ranges with few (query, head, item) triples leave most CUs idle and each workgroup pulls ~20 GB/s: split the keys
+    // (flash-decoding) when the caller provided the partial-result workspace
+    int nsplit = 1;
+    if (a.split_ws && a.split_cnt && a.nsplit != 1) {
+      const int blocks = a.Tq * a.heads * a.B;
+      // Measured on Whisper's 1500-key cross-attention (96 workgroups): 38.0 us unsplit vs 53.6 us with 3 splits -- the agent-scope fences
+      // around the ticket write back the L2, which costs more than the extra CUs bring.  So the split is opt-in (nsplit >= 2), never automatic.
+      (void)blocks;
+      if (a.nsplit > 1) nsplit = a.nsplit;
+      if (nsplit > 8) nsplit = 8;
+      if (nsplit < 1) nsplit = 1;
+    }
+    a.nsplit = nsplit;
+    dim3 grid(a.Tq * nsplit, a.heads, a.B);
     // long key ranges (Whisper cross-attention: 1500 keys) get 16 waves per (query, head): the per-wave key loop is a dependent
     // chain of global loads, so more waves in flight is what shortens it; short ranges keep 4 waves
     const bool wide = a.Tk > 256;

@@ -26,9 +26,11 @@ int gemv_call(const float* x, int ldx, int M, int K, const uint16_t* w, int N, i
 }
 
 int attn_call(const float* q, int ldq, const float* k, const float* v, int64_t kv_bstride, int ldkv, int heads, int kv_heads, int dh, int Tk,
-              int causal, int window, float scale, int B, float* out, int ldo, void* stream) {
+              int causal, int window, float scale, int B, float* out, int ldo, void* stream, int64_t hstride = 0, float* split_ws = nullptr,
+              int32_t* split_cnt = nullptr) {
   mi355_flash_attn_args a;
   memset(&a, 0, sizeof(a));
+  a.k_hstride = hstride; a.v_hstride = hstride; a.split_ws = split_ws; a.split_cnt = split_cnt;
   a.q = q; a.q_bstride = ldq; a.ldq = ldq; a.k = k; a.k_bstride = kv_bstride; a.ldk = ldkv; a.v = v; a.v_bstride = kv_bstride; a.ldv = ldkv;
   a.heads = heads; a.kv_heads = kv_heads; a.dh = dh; a.Tq = 1; a.Tk = Tk; a.causal = causal; a.window = window; a.scale = scale; a.B = B;
   a.mode = 2; a.out = out; a.out_bstride = ldo; a.ldo = ldo;
@@ -69,17 +71,19 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
       rc = mi355_head_norm_rope(&r, stream);
       if (rc) return rc;
     }
-    rc = attn_call(q, nq, L.kv, L.kv + G * dh, L.kv_bstride, nkv, H, G, dh, offset + 1, d.causal, d.window, scale, B, att, nq, stream);
+    rc = attn_call(q, nq, L.kv, L.kv + G * dh, L.kv_bstride, nkv, H, G, dh, offset + 1, d.causal, d.window, scale, B, att, nq, stream, 0, d.attn_split_ws,
+                   d.attn_split_cnt);
     if (rc) return rc;
     rc = gemv_call(att, nq, B, nq, L.wo, D, d.wdtype, L.bo, MI355_ACT_NONE, L.ls1, x, D, 0, x, D, 0, nullptr, nullptr, 0.f, nullptr, 0, 0, stream);
     if (rc) return rc;
     // ---- cross-attention (Whisper decoder): K | V precomputed once per window
-    if (L.cross_kv) {
-      MI355_REQUIRE(L.wcq && L.wco && L.cross_len > 0, "stack_decode_step: layer %d has cross K|V but no cross projections", i);
+    if (L.cross_k) {
+      MI355_REQUIRE(L.wcq && L.wco && L.cross_v && L.cross_len > 0, "stack_decode_step: layer %d has cross K but no cross projections / V", i);
       rc = gemv_call(x, D, B, D, L.wcq, nq, d.wdtype, L.bcq, MI355_ACT_NONE, nullptr, nullptr, 0, 0, q, nq, d.norm, L.cross_norm_w, L.cross_norm_b,
                      d.eps, nullptr, 0, 0, stream);
       if (rc) return rc;
-      rc = attn_call(q, nq, L.cross_kv, L.cross_kv + G * dh, L.cross_bstride, nkv, H, G, dh, L.cross_len, 0, 0, scale, B, att, nq, stream);
+      rc = attn_call(q, nq, L.cross_k, L.cross_v, L.cross_bstride, L.cross_ld, H, G, dh, L.cross_len, 0, 0, scale, B, att, nq, stream, L.cross_hstride,
+                     d.attn_split_ws, d.attn_split_cnt);
       if (rc) return rc;
       rc = gemv_call(att, nq, B, nq, L.wco, D, d.wdtype, L.bco, MI355_ACT_NONE, nullptr, x, D, 0, x, D, 0, nullptr, nullptr, 0.f, nullptr, 0, 0, stream);
       if (rc) return rc;

@@ -246,6 +246,8 @@ class TransformerStack:
         d.wdtype, d.causal, d.window, d.attn_scale = 0, int(c.causal), c.window, 0.0
         d.rope_mode, d.cos, d.sin = int(c.rope_interleaved), p(self.cos), p(self.sin)
         d.layers = ctypes.cast(arr, ctypes.c_void_p)
+        sws, scnt = ops.attn_split_workspace(self.device, 8 * c.n_heads, c.head_dim)  # key-split decode attention (long key ranges)
+        d.attn_split_ws, d.attn_split_cnt = sws.data_ptr(), scnt.data_ptr()
         if self.final_norm is not None:
             d.final_norm_w, d.final_norm_b = p(self.final_norm[0]), p(self.final_norm[1])
         self._native = dict(key=key, arr=arr, desc=d)

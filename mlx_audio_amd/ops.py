@@ -278,21 +278,46 @@ def attention(qkv: torch.Tensor, heads: int, dh: int, out: torch.Tensor, lens=No
     return out
 
 
+_SPLIT_WS = {}  # (device index, stream) -> (float workspace, zeroed int32 tickets) of the key-split decode attention
+
+
+def attn_split_workspace(device, n_records: int, dh: int):
+    """Persistent workspace for mi355_flash_attn_args.split_ws / split_cnt: ``n_records`` = B * heads * Tq.  The tickets must be zero before
+    the first launch and every launch leaves them zero, so one allocation per (device, stream) serves all calls."""
+    key = (torch.device(device).index or 0, _stream())
+    need_ws, need_cnt = n_records * 8 * (dh + 2), n_records
+    cur = _SPLIT_WS.get(key)
+    if cur is None or cur[0].numel() < need_ws or cur[1].numel() < need_cnt:
+        cur = (torch.empty(max(need_ws, 1 << 16), dtype=torch.float32, device=device),
+               torch.zeros(max(need_cnt, 1 << 10), dtype=torch.int32, device=device))
+        _SPLIT_WS[key] = cur
+    return cur
+
+
 def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, heads: int, kv_heads: Optional[int] = None,
                     dh: int, scale: Optional[float] = None, causal: bool = False, window: int = 0, lens_q=None, lens_k=None,
-                    mode: int = 0, k_start=None):
+                    mode: int = 0, k_start=None, head_major: bool = False, nsplit: int = 0):
     """softmax(scale * q k^T + visibility) v.  q/out [B, Tq, >= heads*dh], k/v [B, Tk, >= kv_heads*dh] channels-last views
     (a KV cache is just the buffer k / v point into); see mi355_flash_attn_args for the visibility rule."""
     B, Tq, _, qbs, ldq = _nlc(q)
-    Bk, Tk, _, kbs, ldk = _nlc(k)
-    _, Tv, _, vbs, ldv = _nlc(v)
     _, To, _, obs, ldo = _nlc(out)
+    khs = vhs = 0
+    if head_major:  # k / v [B, kv_heads, Tk, dh]: a head's keys contiguous (the layout for long key ranges: one L2 channel sweep per head)
+        assert k.dim() == 4 and v.dim() == 4 and k.stride(3) == 1 and v.stride(3) == 1 and k.dtype == torch.float32 and k.shape == v.shape
+        Bk, _, Tk, _ = k.shape
+        Tv, kbs, khs, ldk, vbs, vhs, ldv = Tk, k.stride(0), k.stride(1), k.stride(2), v.stride(0), v.stride(1), v.stride(2)
+    else:
+        Bk, Tk, _, kbs, ldk = _nlc(k)
+        _, Tv, _, vbs, ldv = _nlc(v)
     assert Bk == B and Tv == Tk and To == Tq
+    sws = scnt = None
+    if nsplit > 1 and Tq <= 8 and mode != 1:
+        sws, scnt = attn_split_workspace(q.device, B * heads * Tq, dh)  # key-split decode (flash-decoding), opt-in: measured slower than the unsplit kernel
     _lib.call_struct("mi355_flash_attention", "mi355_flash_attn_args", _stream(), q=_ptr(q), q_bstride=qbs, ldq=ldq, k=_ptr(k),
                      k_bstride=kbs, ldk=ldk, v=_ptr(v), v_bstride=vbs, ldv=ldv, heads=heads, kv_heads=kv_heads or heads, dh=dh,
                      Tq=Tq, Tk=Tk, lens_q=_ptr(lens_q), lens_k=_ptr(lens_k), causal=int(causal), window=window,
                      scale=(1.0 / math.sqrt(dh)) if scale is None else scale, B=B, mode=mode, out=_ptr(out), out_bstride=obs, ldo=ldo,
-                     k_start=_ptr(k_start))
+                     k_start=_ptr(k_start), k_hstride=khs, v_hstride=vhs, split_ws=_ptr(sws), split_cnt=_ptr(scnt), nsplit=nsplit)
     return out
 
 

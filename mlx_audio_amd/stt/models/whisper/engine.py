@@ -181,11 +181,15 @@ class WhisperEngine:
         """Allocates the self-attention KV caches and fills the cross-attention K / V (computed once, whisper.py:361-365)."""
         d = self.dims
         B, T, nt = xa.shape[0], xa.shape[1], d.n_text_state
-        st = dict(B=B, n=0, self_kv=[self._f(B, d.n_text_ctx, 2 * nt) for _ in self.dec_blocks], cross_kv=[])
+        st = dict(B=B, n=0, self_kv=[self._f(B, d.n_text_ctx, 2 * nt) for _ in self.dec_blocks], cross_k=[], cross_v=[])
+        H, dh = d.n_text_head, self.dh
         for blk in self.dec_blocks:
             ckv = self._f(B, T, 2 * nt)
             ops.conv_gemm(xa, blk.ckv.pc, ckv, precision=self.precision)
-            st["cross_kv"].append(ckv)
+            # head-major [B, H, T, dh] copies (layout only, once per window): every decode step streams all 1500 keys of each head, and
+            # with heads packed inside 12 KB rows a head's keys are 6 KB apart -- they all land on the same one or two L2 channels
+            st["cross_k"].append(ckv[:, :, :nt].reshape(B, T, H, dh).permute(0, 2, 1, 3).contiguous())
+            st["cross_v"].append(ckv[:, :, nt:].reshape(B, T, H, dh).permute(0, 2, 1, 3).contiguous())
         return st
 
     def _native_desc(self, st: dict):
@@ -208,12 +212,15 @@ class WhisperEngine:
             a.kv, a.kv_bstride, a.kv_capacity = kv.data_ptr(), kv.stride(0), kv.shape[1]
             a.wcq, a.bcq, a.wco, a.bco = p(blk.cq.rm.w), p(blk.cq.rm.bias), p(blk.cout.rm.w), p(blk.cout.rm.bias)
             a.cross_norm_w, a.cross_norm_b = p(blk.cross_ln.w), p(blk.cross_ln.b)
-            ckv = st["cross_kv"][i]
-            a.cross_kv, a.cross_bstride, a.cross_len = ckv.data_ptr(), ckv.stride(0), ckv.shape[1]
+            ck, cv = st["cross_k"][i], st["cross_v"][i]
+            a.cross_k, a.cross_v = ck.data_ptr(), cv.data_ptr()
+            a.cross_bstride, a.cross_hstride, a.cross_ld, a.cross_len = ck.stride(0), ck.stride(1), ck.stride(2), ck.shape[2]
         sd = SD()
         sd.n_layers, sd.d_model, sd.heads, sd.kv_heads, sd.dh, sd.d_ff = d.n_text_layer, d.n_text_state, d.n_text_head, d.n_text_head, self.dh, 4 * d.n_text_state
         sd.norm, sd.eps, sd.glu, sd.act, sd.wdtype, sd.causal, sd.window, sd.attn_scale = 1, 1e-5, 0, ACT_GELU, 1, 1, 0, 0.0
         sd.layers = ctypes.cast(arr, ctypes.c_void_p)
+        sws, scnt = ops.attn_split_workspace(self.device, 8 * d.n_text_head, self.dh)  # key-split decode attention (long key ranges)
+        sd.attn_split_ws, sd.attn_split_cnt = sws.data_ptr(), scnt.data_ptr()
         sd.final_norm_w, sd.final_norm_b = p(self.ln.w), p(self.ln.b)
         st["native"] = dict(arr=arr, desc=sd)
         return st["native"]
@@ -248,9 +255,8 @@ class WhisperEngine:
                 self._linear(h, blk.kv, cache[:, off:off + n, :])
             ops.flash_attention(q, cache[:, :off + n, 0:nt], cache[:, :off + n, nt:], att, heads=H, dh=dh, scale=dh ** -0.5, causal=True)
             self._linear(att, blk.out, x, res=x)
-            ckv = st["cross_kv"][i]
             self._linear(x, blk.cq, q, ln=blk.cross_ln)
-            ops.flash_attention(q, ckv[:, :, 0:nt], ckv[:, :, nt:], att, heads=H, dh=dh, scale=dh ** -0.5)
+            ops.flash_attention(q, st["cross_k"][i], st["cross_v"][i], att, heads=H, dh=dh, scale=dh ** -0.5, head_major=True)
             self._linear(att, blk.cout, x, res=x)
             self._linear(x, blk.mlp1, mid, post_act=ACT_GELU, ln=blk.mlp_ln)
             self._linear(mid, blk.mlp2, x, res=x)

@@ -131,6 +131,46 @@ def test_attention_left_padded_batch(ops, Tq, mode):
         assert rel_err(out[b, Tq - nq:].cpu(), exp[0]) < 2e-5, b
 
 
+@pytest.mark.parametrize("Tq,mode", [(1, 2), (3, 2), (40, 1)])
+def test_attention_head_major_kv(ops, Tq, mode):
+    """K / V as head-major planes [B, kv_heads, Tk, dh] (Whisper's cross-attention layout) == the packed-row layout."""
+    g = torch.Generator().manual_seed(23 + Tq)
+    B, Tk, H, G, dh = 2, 333, 4, 2, 64
+    q = torch.randn(B, Tq, H * dh, generator=g)
+    k = torch.randn(B, Tk, G * dh, generator=g)
+    v = torch.randn(B, Tk, G * dh, generator=g)
+    exp = ref_attention(q, k, v, H, G, dh, 1.0 / math.sqrt(dh), False, 0, None, None)
+    kh = k.reshape(B, Tk, G, dh).permute(0, 2, 1, 3).contiguous().to(DEV)
+    vh = v.reshape(B, Tk, G, dh).permute(0, 2, 1, 3).contiguous().to(DEV)
+    out = torch.empty(B, Tq, H * dh, device=DEV)
+    ops.flash_attention(q.to(DEV), kh, vh, out, heads=H, kv_heads=G, dh=dh, mode=mode, head_major=True)
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), exp) < 2e-5
+
+
+@pytest.mark.parametrize("Tq,Tk,nsplit,causal,hm", [(1, 1500, 2, False, True), (1, 1500, 4, False, False), (3, 700, 8, True, False), (1, 130, 3, True, False),
+                                                      (2, 64, 8, True, False)])
+def test_attention_key_split_decode(ops, Tq, Tk, nsplit, causal, hm):
+    """Flash-decoding: the key range split over several workgroups, partials merged by the last one; repeated launches reuse the tickets."""
+    g = torch.Generator().manual_seed(31 + Tk + nsplit)
+    B, H, G, dh = 2, 4, 2, 64
+    q = torch.randn(B, Tq, H * dh, generator=g)
+    k = torch.randn(B, Tk, G * dh, generator=g)
+    v = torch.randn(B, Tk, G * dh, generator=g)
+    exp = ref_attention(q, k, v, H, G, dh, 1.0 / math.sqrt(dh), causal, 0, None, None)
+    kd, vd = k.to(DEV), v.to(DEV)
+    if hm:
+        kd = kd.reshape(B, Tk, G, dh).permute(0, 2, 1, 3).contiguous()
+        vd = vd.reshape(B, Tk, G, dh).permute(0, 2, 1, 3).contiguous()
+    for rep in range(3):
+        out = torch.full((B, Tq, H * dh), 5.0, device=DEV)
+        ops.flash_attention(q.to(DEV), kd, vd, out, heads=H, kv_heads=G, dh=dh, causal=causal, mode=2, head_major=hm, nsplit=nsplit)
+        torch.cuda.synchronize()
+        assert rel_err(out.cpu(), exp) < 2e-5, rep
+    ws, cnt = ops.attn_split_workspace(torch.device(DEV), B * H * Tq, dh)
+    assert int(cnt.abs().sum()) == 0  # tickets are left zeroed
+
+
 def test_flash_and_decode_kernels_agree(ops):
     """Same inputs through both kernels (mode 1 / mode 2): a cross-check that does not involve the reference at all."""
     g = torch.Generator().manual_seed(5)
