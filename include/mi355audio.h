@@ -314,7 +314,8 @@ int mi355_stft(const mi355_stft_args* a, void* stream);
 
 /* Fused STFT -> power/magnitude -> mel -> log (whisper/audio.py:41-82; qwen3_tts.py:64-120).
  * mode 0 (whisper): p = |X|^2, y = log10(max(mel, 1e-10)) (global max clamp + (y+4)/4 by
- *   mi355_logmel_finish); mode 1 (qwen3): p = sqrt(|X|^2 + 1e-9), y = log(max(mel, 1e-5)).
+ *   mi355_logmel_finish); mode 1 (qwen3): p = sqrt(|X|^2 + 1e-9), y = log(max(mel, 1e-5)); mode 2 (kaldi fbank): p = |X|^2,
+ *   y = log(max(mel, 1e-8)).
  * fb: [n_mels, n_fft/2+1] float32.  out [B, n_frames, n_mels]. */
 typedef struct {
   const float* x; int32_t ldx; int32_t L; int32_t B;
@@ -325,6 +326,19 @@ typedef struct {
 } mi355_logmel_args;
 int mi355_logmel(const mi355_logmel_args* a, void* stream);
 int mi355_logmel_finish(float* y, int64_t n_per_item, const float* gmax, int32_t B, void* stream);
+
+/* Kaldi framing for dsp.compute_fbank_kaldi (dsp.py:821-975): frame f covers x[f*shift - pad, +win) with Kaldi's edge reflection
+ * (snip_edges=True: pad = 0), + dither * noise (nullable), - frame mean, pre-emphasis inside the frame, * window, zero-padded to n_fft.
+ * frames [n_frames, n_fft] then goes through mi355_logmel with mode 2 (|X|^2 -> mel -> log(max(., 1e-8))), hop = n_fft, window = ones. */
+typedef struct {
+  const float* x; int32_t L;
+  int32_t win; int32_t shift; int32_t pad; int32_t n_fft; int32_t n_frames;
+  const float* window;   /* [win] */
+  const float* noise;    /* [n_frames, win] standard normal, nullable */
+  float dither; float preemph;
+  float* frames;         /* [n_frames, n_fft] */
+} mi355_kaldi_frames_args;
+int mi355_kaldi_frames(const mi355_kaldi_frames_args* a, void* stream);
 
 /* dsp.istft / ISTFTCache.istft (dsp.py:436-513, 663-738): spec [B, n_frames, nb, 2] ->
  * frames irfft(n_fft) * window, overlap-add (gather form), / norm[t] (precomputed window

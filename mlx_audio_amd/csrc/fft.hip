@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256) void stft_kernel(StftCommon c, FftPlan pl, int
       if (lane == 0) {
         float y;
         if (mel_mode == 0) y = log10f(fmaxf(s, 1e-10f));
-        else y = logf(fmaxf(s, 1e-5f));
+        else if (mel_mode == 1) y = logf(fmaxf(s, 1e-5f));
+        else y = logf(fmaxf(s, 1e-8f));  // mode 2: Kaldi fbank (dsp.py:994-995)
         out[((int64_t)b * c.n_frames + f) * n_mels + m] = y;
         lmax = fmaxf(lmax, y);
       }
@@ -267,6 +268,38 @@ int set_lds(K kernel, size_t lds, const char* name) {
   return MI355_OK;
 }
 
+// Kaldi frame extraction for compute_fbank_kaldi (dsp.py:821-975): frame f = x[f*shift, +win) (snip_edges) or the same over the
+// reflected-edge signal (dsp.py:828-838); optional dither noise; DC removal (frame mean); pre-emphasis within the frame (first sample kept);
+// window; zero padding to the FFT size.  One workgroup per frame; the frame mean is a block reduction.
+__global__ __launch_bounds__(256) void kaldi_frames_kernel(const mi355_kaldi_frames_args a) {
+  __shared__ float red[4];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  auto sample = [&](int n) -> float {  // n in [0, win): the (dithered) raw sample of this frame
+    int idx = f * a.shift + n - a.pad;
+    if (idx < 0) idx = -idx;                         // left edge: waveform[1 : pad+1] reversed
+    else if (idx >= a.L) idx = 2 * a.L - 1 - idx;    // right edge: waveform[L-1], waveform[L-2], ...
+    float v = a.x[idx];
+    if (a.noise) v += a.noise[(int64_t)f * a.win + n] * a.dither;
+    return v;
+  };
+  float s = 0.f;
+  for (int n = tid; n < a.win; n += 256) s += sample(n);
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)a.win;
+  float* out = a.frames + (int64_t)f * a.n_fft;
+  for (int n = tid; n < a.n_fft; n += 256) {
+    float v = 0.f;
+    if (n < a.win) {
+      v = sample(n) - mean;
+      if (a.preemph != 0.f && n > 0) v -= a.preemph * (sample(n - 1) - mean);
+      v *= a.window[n];
+    }
+    out[n] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" int mi355_stft(const mi355_stft_args* ap, void* stream) {
@@ -293,7 +326,7 @@ extern "C" int mi355_logmel(const mi355_logmel_args* ap, void* stream) {
   MI355_REQUIRE(ap && ap->x && ap->window && ap->fb && ap->out, "logmel: null tensor");
   const mi355_logmel_args a = *ap;
   MI355_REQUIRE(a.n_fft >= 2 && a.hop > 0 && a.n_frames > 0 && a.B > 0 && a.n_mels > 0, "logmel: bad shape");
-  MI355_REQUIRE(a.mode == 0 || a.mode == 1, "logmel: mode must be 0 (whisper) or 1 (qwen3)");
+  MI355_REQUIRE(a.mode >= 0 && a.mode <= 2, "logmel: mode must be 0 (whisper), 1 (qwen3) or 2 (kaldi fbank)");
   MI355_REQUIRE(a.pad_mode >= 0 && a.pad_mode <= 2, "logmel: bad pad_mode");
   MI355_REQUIRE(a.pad_mode != 1 || a.L > a.n_fft / 2, "logmel: input too short for reflect padding");
   FftPlan pl;
@@ -343,5 +376,16 @@ extern "C" int mi355_istft(const mi355_istft_args* ap, void* stream) {
   MI355_CLEAR_ERROR();
   hipLaunchKernelGGL(istft_ola_kernel, dim3((a.out_len + 255) / 256, a.B), dim3(256), 0, st, a, nf_even);
   MI355_LAUNCH_CHECK("istft_ola");
+  return MI355_OK;
+}
+
+extern "C" int mi355_kaldi_frames(const mi355_kaldi_frames_args* ap, void* stream) {
+  MI355_REQUIRE(ap && ap->x && ap->window && ap->frames, "kaldi_frames: null tensor");
+  const mi355_kaldi_frames_args a = *ap;
+  MI355_REQUIRE(a.L > 0 && a.win > 0 && a.shift > 0 && a.n_fft >= a.win && a.n_frames > 0 && a.pad >= 0, "kaldi_frames: bad shape");
+  MI355_REQUIRE(a.pad < a.L && (int64_t)(a.n_frames - 1) * a.shift + a.win - a.pad <= (int64_t)a.L + a.pad, "kaldi_frames: frames run past the reflected edges");
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(kaldi_frames_kernel, dim3(a.n_frames), dim3(256), 0, (hipStream_t)stream, a);
+  MI355_LAUNCH_CHECK("kaldi_frames");
   return MI355_OK;
 }

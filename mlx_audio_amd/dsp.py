@@ -269,3 +269,89 @@ def mel_spectrogram(audio, n_fft: int = 1024, num_mels: int = 128, sample_rate: 
     fb = mel_filters(sample_rate, n_fft, num_mels, fmin, fmax, norm="slaney", mel_scale="slaney").to(dev).contiguous()
     n_frames = 1 + (x.shape[1] - n_fft) // hop_size
     return ops.logmel(x, n_fft, hop_size, win, 0, n_frames, fb, 1)
+
+
+# ------------------------------------------------------------------------------------------------ Kaldi fbank (dsp.py:806-997)
+def mel_scale_kaldi(freq):
+    return 1127.0 * np.log(1.0 + np.asarray(freq, dtype=np.float32) / np.float32(700.0))
+
+
+def inverse_mel_scale_kaldi(mel_freq):
+    return 700.0 * (np.exp(np.asarray(mel_freq, dtype=np.float32) / np.float32(1127.0)) - 1.0)
+
+
+def _next_power_of_2(x: int) -> int:
+    return 1 if x == 0 else 2 ** (x - 1).bit_length()
+
+
+def get_mel_banks_kaldi(num_bins: int, window_length_padded: int, sample_freq: float, low_freq: float, high_freq: float):
+    """Kaldi mel filterbank (dsp.py:846-895), float32 on the host: (bins [num_bins, n_fft/2], center_freqs [num_bins])."""
+    assert num_bins > 3, "Must have at least 3 mel bins"
+    assert window_length_padded % 2 == 0
+    f32 = np.float32
+    num_fft_bins = window_length_padded // 2
+    nyquist = 0.5 * sample_freq
+    if high_freq <= 0.0:
+        high_freq += nyquist
+    assert (0.0 <= low_freq < nyquist) and (0.0 < high_freq <= nyquist)
+    fft_bin_width = f32(sample_freq / window_length_padded)
+    mel_low, mel_high = float(mel_scale_kaldi(low_freq)), float(mel_scale_kaldi(high_freq))
+    delta = f32((mel_high - mel_low) / (num_bins + 1))
+    idx = np.arange(num_bins, dtype=f32).reshape(-1, 1)
+    left, center, right = f32(mel_low) + idx * delta, f32(mel_low) + (idx + f32(1.0)) * delta, f32(mel_low) + (idx + f32(2.0)) * delta
+    center_freqs = inverse_mel_scale_kaldi(center)
+    mel = mel_scale_kaldi(fft_bin_width * np.arange(num_fft_bins, dtype=f32)).reshape(1, -1)
+    up, down = (mel - left) / (center - left), (right - mel) / (right - center)
+    bins = np.maximum(f32(0.0), np.minimum(up, down)).astype(f32)
+    return torch.from_numpy(bins), torch.from_numpy(center_freqs.squeeze().astype(f32))
+
+
+def compute_fbank_kaldi(waveform, sample_rate: int = 48000, win_len: int = 1920, win_inc: int = 384, num_mels: int = 60, win_type: str = "hamming",
+                        preemphasis: float = 0.97, dither: float = 1.0, snip_edges: bool = True, low_freq: float = 20.0, high_freq: float = 0.0,
+                        noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Kaldi-compatible log mel-filterbank features ``[time, num_mels]`` (``mlx_audio.dsp.compute_fbank_kaldi``, dsp.py:898-997): same
+    arguments and defaults; ``noise`` (extra) supplies the standard-normal dither draws ``[n_frames, window]`` explicitly, otherwise they
+    come from ``torch.randn`` on the device (the reference draws from ``mx.random.normal``: not reproducible across the two either way).
+    Two launches: Kaldi framing (DC removal, pre-emphasis, window, zero pad) and the fused FFT -> |X|^2 -> mel -> log kernel."""
+    from . import ops
+
+    dev = _device()
+    x = torch.as_tensor(waveform, dtype=torch.float32)
+    if x.dim() == 2:
+        x = x[0]
+    x = x.to(dev).contiguous()
+    frame_length_ms, frame_shift_ms = win_len / sample_rate * 1000, win_inc / sample_rate * 1000
+    shift = int(sample_rate * frame_shift_ms * 0.001)
+    win = int(sample_rate * frame_length_ms * 0.001)
+    P = _next_power_of_2(win)
+    L = x.numel()
+    if snip_edges:
+        if L < win:
+            return torch.zeros((0, num_mels), dtype=torch.float32, device=dev)
+        m, pad = 1 + (L - win) // shift, 0
+    else:
+        m = (L + (shift // 2)) // shift
+        pad = win // 2 - shift // 2
+        if pad <= 0:
+            raise NotImplementedError("compute_fbank_kaldi(snip_edges=False) with window <= shift")
+    if m == 0:
+        return torch.zeros((0, num_mels), dtype=torch.float32, device=dev)
+    n = torch.arange(win, dtype=torch.float32)
+    if win_type == "hamming":
+        w = 0.54 - 0.46 * torch.cos(2 * math.pi * n / (win - 1))
+    elif win_type == "hanning":
+        w = 0.5 - 0.5 * torch.cos(2 * math.pi * n / (win - 1))
+    elif win_type == "povey":
+        w = torch.pow(0.5 - 0.5 * torch.cos(2 * math.pi * n / (win - 1)), 0.85)
+    else:
+        w = torch.ones(win)
+    if dither != 0.0 and noise is None:
+        noise = torch.randn((m, win), dtype=torch.float32, device=dev)
+    if dither == 0.0:
+        noise = None
+    frames = ops.kaldi_frames(x, win, shift, pad, P, m, w.to(dev), float(preemphasis),
+                              None if noise is None else torch.as_tensor(noise, dtype=torch.float32).to(dev).contiguous(), float(dither))
+    bins, _ = get_mel_banks_kaldi(num_mels, P, float(sample_rate), low_freq, high_freq)
+    fb = torch.nn.functional.pad(bins, (0, 1)).contiguous().to(dev)           # [num_mels, P/2 + 1] (dsp.py:990)
+    ones = torch.ones(P, dtype=torch.float32, device=dev)
+    return ops.logmel(frames.view(1, m * P), P, P, ones, 0, m, fb, 2)[0]

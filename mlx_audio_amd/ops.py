@@ -557,6 +557,18 @@ def logmel(x: torch.Tensor, n_fft: int, hop: int, window: torch.Tensor, pad_mode
     return out
 
 
+def kaldi_frames(x: torch.Tensor, win: int, shift: int, pad: int, n_fft: int, n_frames: int, window: torch.Tensor, preemph: float,
+                 noise: Optional[torch.Tensor] = None, dither: float = 0.0) -> torch.Tensor:
+    """x [L] -> Kaldi frames [n_frames, n_fft] (DC removed, pre-emphasised, windowed, zero-padded)."""
+    assert x.dim() == 1 and x.is_contiguous() and x.dtype == torch.float32 and window.numel() == win
+    out = torch.empty((n_frames, n_fft), dtype=torch.float32, device=x.device)
+    if noise is not None:
+        assert noise.is_contiguous() and tuple(noise.shape) == (n_frames, win)
+    _lib.call_struct("mi355_kaldi_frames", "mi355_kaldi_frames_args", _stream(), x=_ptr(x), L=x.numel(), win=win, shift=shift, pad=pad, n_fft=n_fft,
+                     n_frames=n_frames, window=_ptr(window), noise=_ptr(noise), dither=dither, preemph=preemph, frames=_ptr(out))
+    return out
+
+
 def istft_frames(spec: torch.Tensor, n_fft: int, hop: int, window: torch.Tensor, norm: torch.Tensor, norm_mode: int,
                  clamp: bool, trim: int, out_len: int):
     """spec complex64 [B, n_frames, nb] -> [B, out_len]."""

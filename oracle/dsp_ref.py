@@ -314,3 +314,88 @@ def qwen3_mel_spectrogram(
         mel = (mag @ fb.T).astype(F32)
         outs.append(np.log(np.clip(mel, F32(1e-5), None)).astype(F32))
     return np.stack(outs, axis=0)
+
+
+# ------------------------------------------------------------------------------------------------ Kaldi fbank (dsp.py:806-997)
+def mel_scale_kaldi(freq):
+    """dsp.py:806-808."""
+    return 1127.0 * np.log(1.0 + np.asarray(freq, dtype=np.float32) / np.float32(700.0))
+
+
+def inverse_mel_scale_kaldi(mel_freq):
+    """dsp.py:811-813."""
+    return 700.0 * (np.exp(np.asarray(mel_freq, dtype=np.float32) / np.float32(1127.0)) - 1.0)
+
+
+def get_strided_kaldi(waveform: np.ndarray, window_size: int, window_shift: int, snip_edges: bool) -> np.ndarray:
+    """dsp.py:821-843."""
+    num_samples = waveform.shape[0]
+    if snip_edges:
+        if num_samples < window_size:
+            return np.zeros((0, 0), np.float32)
+        m = 1 + (num_samples - window_size) // window_shift
+    else:
+        m = (num_samples + (window_shift // 2)) // window_shift
+        pad = window_size // 2 - window_shift // 2
+        if pad > 0:
+            pad_left = waveform[1: pad + 1][::-1]
+            pad_right = waveform[-1: -pad - 1: -1] if pad > 1 else waveform[-1:0:-1]
+            waveform = np.concatenate([pad_left, waveform, pad_right])
+        else:
+            pad_right = waveform[::-1]
+            waveform = np.concatenate([waveform[-pad:], pad_right])
+    return np.lib.stride_tricks.as_strided(waveform, shape=(m, window_size), strides=(window_shift * waveform.itemsize, waveform.itemsize)).copy()
+
+
+def get_mel_banks_kaldi(num_bins: int, window_length_padded: int, sample_freq: float, low_freq: float, high_freq: float):
+    """dsp.py:846-895 (float32 like the reference's mx arrays)."""
+    f32 = np.float32
+    num_fft_bins = window_length_padded // 2
+    nyquist = 0.5 * sample_freq
+    if high_freq <= 0.0:
+        high_freq += nyquist
+    fft_bin_width = f32(sample_freq / window_length_padded)
+    mel_low, mel_high = float(mel_scale_kaldi(low_freq)), float(mel_scale_kaldi(high_freq))
+    delta = f32((mel_high - mel_low) / (num_bins + 1))
+    idx = np.arange(num_bins, dtype=f32).reshape(-1, 1)
+    left, center, right = f32(mel_low) + idx * delta, f32(mel_low) + (idx + f32(1.0)) * delta, f32(mel_low) + (idx + f32(2.0)) * delta
+    mel = mel_scale_kaldi(fft_bin_width * np.arange(num_fft_bins, dtype=f32)).reshape(1, -1)
+    up, down = (mel - left) / (center - left), (right - mel) / (right - center)
+    return np.maximum(f32(0.0), np.minimum(up, down)).astype(f32), inverse_mel_scale_kaldi(center).squeeze()
+
+
+def compute_fbank_kaldi(waveform, sample_rate: int = 48000, win_len: int = 1920, win_inc: int = 384, num_mels: int = 60, win_type: str = "hamming",
+                        preemphasis: float = 0.97, dither: float = 1.0, snip_edges: bool = True, low_freq: float = 20.0, high_freq: float = 0.0,
+                        noise=None) -> np.ndarray:
+    """dsp.py:898-997 statement by statement; ``noise`` [n_frames, window] replaces ``mx.random.normal`` (explicit, reproducible)."""
+    x = np.asarray(waveform, dtype=np.float32)
+    if x.ndim == 2:
+        x = x[0]
+    frame_length_ms, frame_shift_ms = win_len / sample_rate * 1000, win_inc / sample_rate * 1000
+    shift = int(sample_rate * frame_shift_ms * 0.001)
+    win = int(sample_rate * frame_length_ms * 0.001)
+    P = 1 if win == 0 else 2 ** (win - 1).bit_length()
+    fr = get_strided_kaldi(x, win, shift, snip_edges).astype(np.float32)
+    if fr.shape[0] == 0:
+        return np.zeros((0, num_mels), np.float32)
+    if dither != 0.0:
+        fr = fr + (np.asarray(noise, np.float32) if noise is not None else np.random.standard_normal(fr.shape).astype(np.float32)) * np.float32(dither)
+    fr = fr - fr.mean(axis=1, keepdims=True)
+    if preemphasis != 0.0:
+        fr = np.concatenate([fr[:, 0:1], fr[:, 1:] - np.float32(preemphasis) * fr[:, :-1]], axis=1)
+    n = np.arange(win, dtype=np.float32)
+    if win_type == "hamming":
+        w = 0.54 - 0.46 * np.cos(2 * np.pi * n / (win - 1))
+    elif win_type == "hanning":
+        w = 0.5 - 0.5 * np.cos(2 * np.pi * n / (win - 1))
+    elif win_type == "povey":
+        w = np.power(0.5 - 0.5 * np.cos(2 * np.pi * n / (win - 1)), 0.85)
+    else:
+        w = np.ones(win)
+    fr = (fr * w.astype(np.float32)).astype(np.float32)
+    if P != win:
+        fr = np.pad(fr, [(0, 0), (0, P - win)])
+    spec = np.abs(np.fft.rfft(fr.astype(np.float64), n=P, axis=1)) ** 2.0
+    bins, _ = get_mel_banks_kaldi(num_mels, P, float(sample_rate), low_freq, high_freq)
+    bins = np.pad(bins, [(0, 0), (0, 1)])
+    return np.log(np.maximum(spec @ bins.T.astype(np.float64), 1e-8)).astype(np.float32)

@@ -236,3 +236,40 @@ def test_whisper_synthetic_checkpoint_shapes():
     assert "encoder.blocks.0.attn.key.bias" not in w and "decoder.blocks.1.cross_attn.key.bias" not in w  # K has no bias
     assert tuple(w["decoder.token_embedding.weight"].shape) == (51865, 128)
     assert all(torch.equal(v, v.to(torch.float16).to(torch.float32)) for v in w.values())  # fp16-representable
+
+
+def test_kaldi_fbank_oracle_and_host_filterbank():
+    """compute_fbank_kaldi restatement: the reference's own shape pins (sts/tests/test_mossformer2_se.py:134-146, 173-208: [58, 60] for
+    24000 samples, 40 ms / 8 ms frames at 48 kHz), an independent float64 Kaldi statement of one frame, and the host filterbank mirror."""
+    from mlx_audio_amd import dsp
+
+    np.random.seed(42)
+    audio = np.random.randn(24000).astype(np.float32)
+    fb = dsp_ref.compute_fbank_kaldi(audio, sample_rate=48000, win_len=1920, win_inc=384, num_mels=60, dither=0.0)
+    assert fb.shape == (58, 60) and np.isfinite(fb).all()
+    # frame 7 by the textbook (Kaldi feature-window.cc order: DC removal, pre-emphasis with x[-1] := x[0]... the reference keeps x[0]), float64
+    t = 7
+    fr = audio[t * 384: t * 384 + 1920].astype(np.float64)
+    fr = fr - fr.mean()
+    fr = np.concatenate([fr[:1], fr[1:] - 0.97 * fr[:-1]])
+    fr = fr * (0.54 - 0.46 * np.cos(2 * np.pi * np.arange(1920) / 1919))
+    P = np.abs(np.fft.rfft(fr, 2048)) ** 2
+    mel = lambda f: 1127.0 * np.log(1.0 + f / 700.0)
+    lo, hi = mel(20.0), mel(24000.0)
+    d = (hi - lo) / 61
+    want = np.empty(60)
+    fm = mel(48000.0 / 2048 * np.arange(1024))
+    for m in range(60):
+        l, c, r = lo + m * d, lo + (m + 1) * d, lo + (m + 2) * d
+        wgt = np.maximum(0.0, np.minimum((fm - l) / (c - l), (r - fm) / (r - c)))
+        want[m] = np.log(max((P[:1024] * wgt).sum(), 1e-8))
+    assert np.abs(fb[t] - want).max() < 2e-3
+    # host mirror of get_mel_banks_kaldi == oracle, bit for bit; edge cases
+    for args in [(60, 2048, 48000.0, 20.0, 0.0), (80, 512, 16000.0, 20.0, -400.0), (23, 256, 8000.0, 0.0, 0.0)]:
+        b, c = dsp.get_mel_banks_kaldi(*args)
+        bo, co = dsp_ref.get_mel_banks_kaldi(*args)
+        assert np.array_equal(b.numpy(), bo) and np.array_equal(c.numpy(), co.astype(np.float32))
+    assert dsp_ref.compute_fbank_kaldi(audio[:100], dither=0.0).shape == (0, 60)          # shorter than one window (snip_edges)
+    assert dsp_ref.compute_fbank_kaldi(audio, dither=0.0, snip_edges=False).shape == (63, 60)
+    n = np.random.default_rng(1).standard_normal((58, 1920)).astype(np.float32)
+    assert np.abs(dsp_ref.compute_fbank_kaldi(audio, noise=n) - fb).max() > 1e-3        # dither=1.0 default perturbs

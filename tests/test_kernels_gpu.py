@@ -516,3 +516,36 @@ def test_logmel_golden_through_gpu(ops, golden):
     ref = dsp_ref.whisper_log_mel(a, padding=16000)
     assert ref.shape == tuple(w.shape[1:])
     assert np.abs(w.cpu().numpy()[0] - ref).max() < 2e-4
+
+
+@pytest.mark.parametrize("kw", [dict(),
+                                dict(sample_rate=16000, win_len=400, win_inc=160, num_mels=80, win_type="povey", snip_edges=False),
+                                dict(sample_rate=16000, win_len=400, win_inc=160, num_mels=80, win_type="hanning", preemphasis=0.0),
+                                dict(sample_rate=16000, win_len=512, win_inc=128, num_mels=23, win_type="rectangular", low_freq=0.0, high_freq=-200.0,
+                                     snip_edges=False)])
+def test_compute_fbank_kaldi_matches_oracle(ops, kw):
+    """dsp.compute_fbank_kaldi (dsp.py:898-997) on the GPU: framing kernel + fused FFT/power/mel/log vs the numpy restatement; the
+    reference's own pins are the shapes ([58, 60] default case, sts/tests/test_mossformer2_se.py:134-208)."""
+    from mlx_audio_amd import dsp
+    from oracle import dsp_ref
+
+    np.random.seed(42)
+    audio = (np.random.randn(24000) * 3000.0).astype(np.float32)   # int16-range amplitudes as the callers pass them (fireredasr2.py:544)
+    want = dsp_ref.compute_fbank_kaldi(audio, dither=0.0, **kw)
+    got = dsp.compute_fbank_kaldi(torch.from_numpy(audio), dither=0.0, **kw)
+    torch.cuda.synchronize()
+    assert tuple(got.shape) == want.shape
+    if not kw:
+        assert tuple(got.shape) == (58, 60)
+    assert np.abs(got.cpu().numpy() - want).max() < 2e-4
+    # explicit dither noise: same draws on both sides
+    noise = np.random.default_rng(3).standard_normal((want.shape[0], int(kw.get("win_len", 1920)))).astype(np.float32)
+    want_d = dsp_ref.compute_fbank_kaldi(audio, dither=1.0, noise=noise, **kw)
+    got_d = dsp.compute_fbank_kaldi(torch.from_numpy(audio), dither=1.0, noise=torch.from_numpy(noise), **kw)
+    assert np.abs(got_d.cpu().numpy() - want_d).max() < 2e-4
+    # default dither draws on the device: finite, same shape, close to the undithered features at this amplitude
+    d = dsp.compute_fbank_kaldi(torch.from_numpy(audio), **kw)
+    assert tuple(d.shape) == want.shape and torch.isfinite(d).all()
+    # too-short input under snip_edges
+    assert tuple(dsp.compute_fbank_kaldi(torch.from_numpy(audio[:100])).shape) == (0, 60)
+    assert tuple(dsp.compute_fbank_kaldi(torch.from_numpy(audio[None])[:, :4800], dither=0.0).shape) == (8, 60)   # [1, L] input accepted
