@@ -344,6 +344,11 @@ def get_strided_kaldi(waveform: np.ndarray, window_size: int, window_shift: int,
         else:
             pad_right = waveform[::-1]
             waveform = np.concatenate([waveform[-pad:], pad_right])
+    if (m - 1) * window_shift + window_size > waveform.shape[0]:
+        # the reference's mx.as_strided view would run past the padded buffer here (snip_edges=False and num_samples % shift >= shift / 2:
+        # undefined contents); the restatement refuses instead of reading out of bounds, and so does the HIP kernel
+        raise ValueError("get_strided_kaldi: frames run past the reflected edges (out-of-bounds read in the reference)")
+    waveform = np.ascontiguousarray(waveform)
     return np.lib.stride_tricks.as_strided(waveform, shape=(m, window_size), strides=(window_shift * waveform.itemsize, waveform.itemsize)).copy()
 
 
