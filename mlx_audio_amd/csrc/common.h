@@ -41,8 +41,12 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float x) {
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
   return __builtin_bit_cast(float, ((uint32_t)b) << 16);
 }
+typedef __bf16 mi355_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float mi355_f32x2 __attribute__((ext_vector_type(2)));
+// one v_cvt_pk_bf16_f32 (round-to-nearest-even, a in the low half)
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
-  return (uint32_t)f32_to_bf16_bits(a) | ((uint32_t)f32_to_bf16_bits(b) << 16);
+  const mi355_f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, mi355_bf16x2));
 }
 
 // round-to-nearest-even fp32 -> fp16 bits, saturating at +-65504 (the conv prologue never produces inf on purpose)

@@ -17,6 +17,7 @@
 //
 // Reference call sites replaced: see include/mi355audio.h (mi355_conv_gemm).
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -171,6 +172,66 @@ __device__ __forceinline__ void conv_epilogue(const mi355_conv_gemm_args& a, f32
           if (lane < 32 && n < a.Cout)
             *(float2*)(a.stats_partial + (int64_t)b * a.stats_bstride + ((int64_t)(row0 / MI355_STATS_ROWS) * a.Cout + n) * 2) = make_float2(sum, m2);
         }
+      }
+    }
+  }
+}
+
+// Interior-tile epilogue of the wave-specialised kernel: every row and column of the wave's 64 x 64 block is in range, plain store, no
+// epilogue activation, residual / running sum already folded into the accumulators (or absent).  Same arithmetic, in the same order, as
+// conv_epilogue (bias, out_scale, shifted single-pass statistics), so the two paths are bit-identical; what goes away is the per-element
+// clamping, predication and 64-bit address arithmetic: one uniform base pointer + a 32-bit lane offset per store.
+template <int MF, int NF, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue_interior(const mi355_conv_gemm_args& a, f32x16 (&acc)[MF][NF], const int b, const int l0,
+                                                       const int n0, const int wm, const int wn, const int lane) {
+  char* yw = (char*)(a.y + (int64_t)b * a.y_bstride + (int64_t)(l0 + wm * WM) * a.ldy + (n0 + wn * WN));  // wave-uniform base
+  const uint32_t ldb = (uint32_t)a.ldy * 4u;                                                             // row pitch in bytes
+  const uint32_t lane_off = (uint32_t)(4 * (lane >> 5)) * ldb + (uint32_t)(lane & 31) * 4u;            // < 4 GB inside the wave block
+  const bool want_stats = a.stats_partial != nullptr;
+  const float oscale = a.out_scale;
+  float sK[NF], s1[NF], s2[NF];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) { sK[nf] = 0.f; s1[nf] = 0.f; s2[nf] = 0.f; }
+  auto body = [&](auto stats_tag) {
+    constexpr bool STATS = decltype(stats_tag)::value;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const float bias = a.bias ? a.bias[n0 + wn * WN + nf * 32 + (lane & 31)] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t row = mf * 32 + (r & 3) + 8 * (r >> 2);
+          const float v = (acc[mf][nf][r] + bias) * oscale;
+          *(float*)(yw + (lane_off + row * ldb + (uint32_t)(nf * 128))) = v;
+          if constexpr (STATS) {
+            if (mf == 0 && r == 0) sK[nf] = v;
+            const float d = v - sK[nf];
+            s1[nf] += d;
+            s2[nf] += d * d;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one 32 x 32 fragment at a time: keeps the stored values from piling up in registers
+      }
+  };
+  if (want_stats) body(std::true_type{});
+  else body(std::false_type{});
+  if constexpr (WM == MI355_STATS_ROWS) {
+    if (want_stats) {
+      const int row0 = l0 + wm * WM;
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const int n = n0 + wn * WN + nf * 32 + (lane & 31);
+        const float cl = (float)(MF * 16);
+        const float ml = sK[nf] + s1[nf] / cl;
+        const float vl = s2[nf] - s1[nf] * s1[nf] / cl;
+        const float cp = cl, mp = __shfl_xor(ml, 32, 64), vp = __shfl_xor(vl, 32, 64);
+        const float ct = cl + cp;
+        const float dm = mp - ml;
+        const float sum = ml * cl + mp * cp;
+        const float m2 = vl + vp + dm * dm * cl * cp / ct;
+        if (lane < 32)
+          *(float2*)(a.stats_partial + (int64_t)b * a.stats_bstride + ((int64_t)(row0 / MI355_STATS_ROWS) * a.Cout + n) * 2) = make_float2(sum, m2);
       }
     }
   }
@@ -723,17 +784,24 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355
 // 2 = no activation-fragment LDS reads, 4 = producers only take part in the barriers, 8 = no epilogue.
 template <int PREC, int ABL = 0, bool EXT = false>
 __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws3_kernel(const mi355_conv_gemm_args a, const int tiles_per_item,
-                                                                     const int P, const int NT, const int fold) {
+                                                                     const int P, const int NT, const int fold_glog) {
   constexpr int BM = 128, BN = 128, WM = 64, WN = 64, MF = 2, NF = 2;
+  const int fold = fold_glog & 1;
   constexpr int NA = a_images<PREC>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Workgroup ids go round-robin over the 8 XCDs (id & 7 = XCD, each with its own L2).  An XCD owns runs of 8 CONSECUTIVE row tiles
+  // (all NT column tiles of a row tile back to back on it): neighbouring tiles share their (K-1)*dil halo rows through that L2 and
+  // the column tiles re-read the same activation window from it, while runs still interleave over the XCDs (ragged batches balance).
+  // (`fold_glog` = fold | glog << 8.)
   const int id = blockIdx.x;
   const int kq = id >> 3;
   const int ny = kq % NT;
-  const int p = (kq / NT) * 8 + (id & 7);
+  const int pg = kq / NT;
+  const int glog = fold_glog >> 8;  // log2 of the run length (launch_ws3: 8 when there are enough row tiles for several rounds per XCD)
+  const int p = (((((pg >> glog) << 3) + (id & 7)) << glog)) | (pg & ((1 << glog) - 1));
   if (p >= P) return;
   const int b = p / tiles_per_item;
   const int l0 = (p - b * tiles_per_item) * BM, n0 = ny * BN;
@@ -755,16 +823,23 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws3_kernel(const mi35
     const int prow = ptid >> 3;
     const float* xb = a.x + (int64_t)b * a.x_bstride + a.x_off;
     float4 areg[kWsNld];
+    // Row group i of this wave covers rows [wrow0 + 32 i, wrow0 + 32 i + 8): groups entirely past the window (R rows) are neither loaded
+    // nor converted (wave-uniform branches; K = 3, dil = 1 needs 130 of the 192 rows the six groups could hold).
+    const int wrow0 = (wave - 4) * 8;
     auto loadA = [&](int chunk) {
       int c = chunk * 32 + c4;
       if (c >= a.Cin) c = 0;
 #pragma unroll
       for (int i = 0; i < kWsNld; ++i) {
-        int gl = l0 - a.pad + prow + i * 32;
-        gl = gl < 0 ? 0 : (gl >= a.Lin ? a.Lin - 1 : gl);
-        areg[i] = *(const float4*)(xb + (int64_t)gl * a.ldx + c);
+        if (wrow0 + i * 32 < R) {
+          int gl = l0 - a.pad + prow + i * 32;
+          gl = gl < 0 ? 0 : (gl >= a.Lin ? a.Lin - 1 : gl);
+          areg[i] = *(const float4*)(xb + (int64_t)gl * a.ldx + c);
+        }
       }
     };
+    // The prologue activation is selected ONCE per window (ACT is a compile-time tag inside): per-element uniform branches on
+    // a.pre_act cost more issue slots on the SIMDs the consumers' MFMAs share than the arithmetic itself.
     auto convertA = [&](int chunk, char* A_hi) {
       char* A_lo = A_hi + ABYTES;
       const int c = chunk * 32 + c4;
@@ -780,53 +855,76 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws3_kernel(const mi35
         const float4 a4 = *(const float4*)(a.pre_alpha + c);
         al[0] = a4.x; al[1] = a4.y; al[2] = a4.z; al[3] = a4.w;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ial[i] = 1.0f / al[i];
-      if constexpr (EXT) {
-        if (a.pre_inv_beta) {  // SnakeBeta: x + sin^2(alpha x) * inv_beta[c]
-          const float4 b4 = *(const float4*)(a.pre_inv_beta + c);
-          ial[0] = b4.x; ial[1] = b4.y; ial[2] = b4.z; ial[3] = b4.w;
+        for (int i = 0; i < 4; ++i) {  // 1 / alpha: v_rcp_f32 + one Newton step (<= 1 ulp; the IEEE divide is ~12 VALU ops per channel and window)
+          const float r0 = __builtin_amdgcn_rcpf(al[i]);
+          ial[i] = fmaf(fmaf(-al[i], r0, 1.0f), r0, r0);
+          al[i] *= 0.15915494309189535f;  // v_sin_f32 takes revolutions
         }
-      }
-      }
-#pragma unroll
-      for (int i = 0; i < kWsNld; ++i) {
-        const int r = prow + i * 32;
-        if (r < R) {
-          const int gl = l0 - a.pad + r;
-          const bool rowok = gl >= 0 && gl < len_in;
-          const float v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
-          float hi[4], lo[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float t = v[j] * sc[j] + sh[j];
-            if (a.pre_act == MI355_ACT_LEAKY) t = t > 0.f ? t : t * a.pre_slope;
-            else if (a.pre_act == MI355_ACT_SNAKE) {
-              const float s = __sinf(al[j] * t);
-              t = t + ial[j] * (s * s);
-            } else if (EXT && a.pre_act == MI355_ACT_ELU) t = t > 0.f ? t : expm1f(t);
-            t = (rowok && (c + j) < a.Cin) ? t : 0.f;
-            const float h = split_hi<PREC>(t);
-            hi[j] = h;
-            lo[j] = t - h;
-          }
-          const int addr = r * 64 + ((((c4 >> 3) ^ ((r >> 2) & 3))) << 4) + ((c4 & 4) << 1);
-          uint2 ph;
-          if constexpr (PREC >= 3) {
-            ph.x = pack_f16x2(hi[0], hi[1]);
-            ph.y = pack_f16x2(hi[2], hi[3]);
-          } else {
-            ph.x = pack_bf16x2(hi[0], hi[1]);
-            ph.y = pack_bf16x2(hi[2], hi[3]);
-          }
-          *(uint2*)(A_hi + addr) = ph;
-          if (PREC == 2 || PREC == 4) {
-            uint2 pl;
-            pl.x = pack_lo<PREC>(lo[0], lo[1]);
-            pl.y = pack_lo<PREC>(lo[2], lo[3]);
-            *(uint2*)(A_lo + addr) = pl;
+        if constexpr (EXT) {
+          if (a.pre_inv_beta) {  // SnakeBeta: x + sin^2(alpha x) * inv_beta[c]
+            const float4 b4 = *(const float4*)(a.pre_inv_beta + c);
+            ial[0] = b4.x; ial[1] = b4.y; ial[2] = b4.z; ial[3] = b4.w;
           }
         }
       }
+      bool cok[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cok[j] = (c + j) < a.Cin;
+      auto body = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+        const float slope = ACT == MI355_ACT_LEAKY ? a.pre_slope : 1.f;
+#pragma unroll
+        for (int i = 0; i < kWsNld; ++i) {
+          const int r = prow + i * 32;
+          if (r < R) {
+            const int gl = l0 - a.pad + r;
+            const bool rowok = gl >= 0 && gl < len_in;
+            const float v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
+            float t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float u = v[j] * sc[j] + sh[j];
+              if constexpr (ACT == MI355_ACT_LEAKY) {
+                const float m = u * slope;
+                u = u > 0.f ? u : m;
+              } else if constexpr (ACT == MI355_ACT_SNAKE) {
+                const float sn = __builtin_amdgcn_sinf(al[j] * u);
+                u = u + ial[j] * (sn * sn);
+              } else if constexpr (ACT == MI355_ACT_ELU) {
+                u = u > 0.f ? u : expm1f(u);
+              }
+              t[j] = (rowok && cok[j]) ? u : 0.f;
+            }
+            const int addr = r * 64 + ((((c4 >> 3) ^ ((r >> 2) & 3))) << 4) + ((c4 & 4) << 1);
+            uint2 ph;
+            float hi[4];
+            if constexpr (PREC >= 3) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) hi[j] = split_hi<PREC>(t[j]);
+              ph.x = pack_f16x2(hi[0], hi[1]);
+              ph.y = pack_f16x2(hi[2], hi[3]);
+            } else {  // one v_cvt_pk_bf16_f32 per pair; the fp32 value of each half is a shift / mask of the packed word
+              ph.x = pack_bf16x2(t[0], t[1]);
+              ph.y = pack_bf16x2(t[2], t[3]);
+              hi[0] = __builtin_bit_cast(float, ph.x << 16);
+              hi[1] = __builtin_bit_cast(float, ph.x & 0xffff0000u);
+              hi[2] = __builtin_bit_cast(float, ph.y << 16);
+              hi[3] = __builtin_bit_cast(float, ph.y & 0xffff0000u);
+            }
+            *(uint2*)(A_hi + addr) = ph;
+            if (PREC == 2 || PREC == 4) {
+              uint2 pl;
+              pl.x = pack_lo<PREC>(t[0] - hi[0], t[1] - hi[1]);
+              pl.y = pack_lo<PREC>(t[2] - hi[2], t[3] - hi[3]);
+              *(uint2*)(A_lo + addr) = pl;
+            }
+          }
+        }
+      };
+      if (a.pre_act == MI355_ACT_SNAKE) body(std::integral_constant<int, MI355_ACT_SNAKE>{});
+      else if (a.pre_act == MI355_ACT_LEAKY) body(std::integral_constant<int, MI355_ACT_LEAKY>{});
+      else if (EXT && a.pre_act == MI355_ACT_ELU) body(std::integral_constant<int, MI355_ACT_ELU>{});
+      else body(std::integral_constant<int, MI355_ACT_NONE>{});
     };
     if constexpr ((ABL & 4) != 0) {
       for (int ci = 0; ci < nchunks; ++ci) lds_barrier();
@@ -863,7 +961,31 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws3_kernel(const mi35
     for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
-  if (fold) {
+  if (fold && l0 + BM <= len_out && n0 + BN <= a.Cout) {  // interior tile: no clamping, 32-bit lane offsets from wave-uniform bases
+    const char* rw = rb ? (const char*)(rb + (int64_t)(l0 + wm * WM) * a.ldr + (n0 + wn * WN)) : nullptr;
+    const char* yr = (const char*)(yb + (int64_t)(l0 + wm * WM) * a.ldy + (n0 + wn * WN));
+    const uint32_t rpb = (uint32_t)a.ldr * 4u, ypb = (uint32_t)a.ldy * 4u;
+    const uint32_t roff = (uint32_t)(4 * (lane >> 5)) * rpb + (uint32_t)(lane & 31) * 4u;
+    const uint32_t yoff = (uint32_t)(4 * (lane >> 5)) * ypb + (uint32_t)(lane & 31) * 4u;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+        if (rw) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rv[r] = *(const float*)(rw + (roff + (uint32_t)(mf * 32 + (r & 3) + 8 * (r >> 2)) * rpb + (uint32_t)(nf * 128)));
+        }
+        if (a.accumulate) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rv[r] += *(const float*)(yr + (yoff + (uint32_t)(mf * 32 + (r & 3) + 8 * (r >> 2)) * ypb + (uint32_t)(nf * 128)));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mf][nf][r] = rv[r];
+      }
+  } else if (fold) {
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
@@ -968,7 +1090,9 @@ __global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws3_kernel(const mi35
     if (t == 1.2345e-30f) yb[0] = t;  // keeps the MFMAs alive without an epilogue
     return;
   }
-  conv_epilogue<MF, NF, WM, WN, EXT>(a, acc, b, l0, n0, wm, wn, lane, len_out, fold != 0);
+  const bool plain = a.up_s == 0 && a.post_act == MI355_ACT_NONE && (fold || (!a.res && !a.accumulate)) && !(EXT && a.post_colscale);
+  if (plain && l0 + BM <= len_out && n0 + BN <= a.Cout) conv_epilogue_interior<MF, NF, WM, WN>(a, acc, b, l0, n0, wm, wn, lane);
+  else conv_epilogue<MF, NF, WM, WN, EXT>(a, acc, b, l0, n0, wm, wn, lane, len_out, fold != 0);
 }
 
 template <int PREC, int ABL = 0, bool EXT = false>
@@ -980,9 +1104,13 @@ int launch_ws3(const mi355_conv_gemm_args& a, hipStream_t st) {
   const int P = a.B * tiles_per_item;
   const int NT = (a.Cout + 127) / 128;
   const int fold = (a.res || a.accumulate) && a.post_act == MI355_ACT_NONE && a.up_s == 0 && a.res_shift == 0 && !a.post_colscale;
-  const unsigned grid = (unsigned)(((P + 7) / 8) * 8 * NT);
+  // runs of 2^glog consecutive row tiles per XCD: long runs share halos in L2, but every XCD must still get several rounds of runs
+  // (P = 96 with runs of 8 would leave four XCDs with half the work of the others)
+  const int glog = P >= 512 ? 3 : (P >= 256 ? 2 : (P >= 128 ? 1 : 0));
+  const int per = 8 << glog;
+  const unsigned grid = (unsigned)(((P + per - 1) / per) * per * NT);
   MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL((conv_gemm_ws3_kernel<PREC, ABL, EXT>), dim3(grid), dim3(kWsThreads), lds, st, a, tiles_per_item, P, NT, fold);
+  hipLaunchKernelGGL((conv_gemm_ws3_kernel<PREC, ABL, EXT>), dim3(grid), dim3(kWsThreads), lds, st, a, tiles_per_item, P, NT, fold | (glog << 8));
   MI355_LAUNCH_CHECK("conv_gemm(ws3)");
   return MI355_OK;
 }
