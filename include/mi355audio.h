@@ -315,7 +315,7 @@ int mi355_stft(const mi355_stft_args* a, void* stream);
 /* Fused STFT -> power/magnitude -> mel -> log (whisper/audio.py:41-82; qwen3_tts.py:64-120).
  * mode 0 (whisper): p = |X|^2, y = log10(max(mel, 1e-10)) (global max clamp + (y+4)/4 by
  *   mi355_logmel_finish); mode 1 (qwen3): p = sqrt(|X|^2 + 1e-9), y = log(max(mel, 1e-5)); mode 2 (kaldi fbank): p = |X|^2,
- *   y = log(max(mel, 1e-8)).
+ *   y = log(max(mel, 1e-8)); mode 3 (vocos, codec/models/vocos/mel.py:9-33): p = |X|, y = log(max(mel, 1e-5)).
  * fb: [n_mels, n_fft/2+1] float32.  out [B, n_frames, n_mels]. */
 typedef struct {
   const float* x; int32_t ldx; int32_t L; int32_t B;
@@ -339,6 +339,11 @@ typedef struct {
   float* frames;         /* [n_frames, n_fft] */
 } mi355_kaldi_frames_args;
 int mi355_kaldi_frames(const mi355_kaldi_frames_args* a, void* stream);
+/* Vocos ISTFTHead, first half (codec/models/vocos/vocos.py:126-134: mag, p = split(out(x)); mag = clip(exp(mag), max 1e2);
+ * S = mag * (cos p + 1j sin p)): x [B, Fr, 2 nb] float32 (row pitch ldx) -> spec [B, Fr, nb] complex64 (interleaved re, im), which
+ * mi355_istft then inverts (dsp.istft, plain-window overlap-add normalisation). */
+int mi355_polar_spec(const float* x, int64_t x_bstride, int32_t ldx, int32_t Fr, int32_t nb, int32_t B, float clip, float* spec, void* stream);
+
 
 /* dsp.istft / ISTFTCache.istft (dsp.py:436-513, 663-738): spec [B, n_frames, nb, 2] ->
  * frames irfft(n_fft) * window, overlap-add (gather form), / norm[t] (precomputed window

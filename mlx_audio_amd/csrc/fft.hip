@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void stft_kernel(StftCommon c, FftPlan pl, int
     } else {
       float pa = xa.x * xa.x + xa.y * xa.y, pb = xb2.x * xb2.x + xb2.y * xb2.y;
       if (mel_mode == 1) { pa = sqrtf(pa + 1e-9f); pb = sqrtf(pb + 1e-9f); }
+      else if (mel_mode == 3) { pa = sqrtf(pa); pb = sqrtf(pb); }
       pw[(2 * pr) * nb + k] = pa;
       pw[(2 * pr + 1) * nb + k] = pb;
     }
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void stft_kernel(StftCommon c, FftPlan pl, int
       if (lane == 0) {
         float y;
         if (mel_mode == 0) y = log10f(fmaxf(s, 1e-10f));
-        else if (mel_mode == 1) y = logf(fmaxf(s, 1e-5f));
+        else if (mel_mode == 1 || mel_mode == 3) y = logf(fmaxf(s, 1e-5f));
         else y = logf(fmaxf(s, 1e-8f));  // mode 2: Kaldi fbank (dsp.py:994-995)
         out[((int64_t)b * c.n_frames + f) * n_mels + m] = y;
         lmax = fmaxf(lmax, y);
@@ -271,6 +272,22 @@ int set_lds(K kernel, size_t lds, const char* name) {
 // Kaldi frame extraction for compute_fbank_kaldi (dsp.py:821-975): frame f = x[f*shift, +win) (snip_edges) or the same over the
 // reflected-edge signal (dsp.py:828-838); optional dither noise; DC removal (frame mean); pre-emphasis within the frame (first sample kept);
 // window; zero padding to the FFT size.  One workgroup per frame; the frame mean is a block reduction.
+// Vocos ISTFTHead front half (codec/models/vocos/vocos.py:126-134): x [B, Fr, 2 nb] (the head Linear's output: log-magnitude | phase)
+// -> spec [B, Fr, nb] complex64 = min(exp(m), clip) * (cos p + i sin p).  Elementwise, one thread per bin.
+__global__ __launch_bounds__(256) void polar_spec_kernel(const float* x, int64_t x_bstride, int ldx, int Fr, int nb, float clip, float2* spec,
+                                                         int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int k = (int)(i % nb);
+  const int64_t fr = i / nb;
+  const int b = (int)(fr / Fr);
+  const int f = (int)(fr - (int64_t)b * Fr);
+  const float* row = x + (int64_t)b * x_bstride + (int64_t)f * ldx;
+  const float m = fminf(expf(row[k]), clip);
+  const float ph = row[nb + k];
+  spec[i] = make_float2(m * cosf(ph), m * sinf(ph));
+}
+
 __global__ __launch_bounds__(256) void kaldi_frames_kernel(const mi355_kaldi_frames_args a) {
   __shared__ float red[4];
   const int f = blockIdx.x, tid = threadIdx.x;
@@ -326,7 +343,7 @@ extern "C" int mi355_logmel(const mi355_logmel_args* ap, void* stream) {
   MI355_REQUIRE(ap && ap->x && ap->window && ap->fb && ap->out, "logmel: null tensor");
   const mi355_logmel_args a = *ap;
   MI355_REQUIRE(a.n_fft >= 2 && a.hop > 0 && a.n_frames > 0 && a.B > 0 && a.n_mels > 0, "logmel: bad shape");
-  MI355_REQUIRE(a.mode >= 0 && a.mode <= 2, "logmel: mode must be 0 (whisper), 1 (qwen3) or 2 (kaldi fbank)");
+  MI355_REQUIRE(a.mode >= 0 && a.mode <= 3, "logmel: mode must be 0 (whisper), 1 (qwen3), 2 (kaldi fbank) or 3 (vocos)");
   MI355_REQUIRE(a.pad_mode >= 0 && a.pad_mode <= 2, "logmel: bad pad_mode");
   MI355_REQUIRE(a.pad_mode != 1 || a.L > a.n_fft / 2, "logmel: input too short for reflect padding");
   FftPlan pl;
@@ -387,5 +404,17 @@ extern "C" int mi355_kaldi_frames(const mi355_kaldi_frames_args* ap, void* strea
   MI355_CLEAR_ERROR();
   hipLaunchKernelGGL(kaldi_frames_kernel, dim3(a.n_frames), dim3(256), 0, (hipStream_t)stream, a);
   MI355_LAUNCH_CHECK("kaldi_frames");
+  return MI355_OK;
+}
+
+extern "C" int mi355_polar_spec(const float* x, int64_t x_bstride, int32_t ldx, int32_t Fr, int32_t nb, int32_t B, float clip, float* spec,
+                                void* stream) {
+  MI355_REQUIRE(x && spec, "polar_spec: null tensor");
+  MI355_REQUIRE(Fr > 0 && nb > 0 && B > 0 && ldx >= 2 * nb, "polar_spec: bad shape");
+  const int64_t total = (int64_t)B * Fr * nb;
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(polar_spec_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, x_bstride, ldx, Fr, nb, clip,
+                     (float2*)spec, total);
+  MI355_LAUNCH_CHECK("polar_spec");
   return MI355_OK;
 }

@@ -569,6 +569,17 @@ def kaldi_frames(x: torch.Tensor, win: int, shift: int, pad: int, n_fft: int, n_
     return out
 
 
+def polar_spec(x: torch.Tensor, nb: int, clip: float = 1e2) -> torch.Tensor:
+    """x [B, Fr, 2 nb] (log-magnitude | phase) -> complex64 [B, Fr, nb] = min(exp(m), clip) * exp(i p)  (Vocos ISTFTHead)."""
+    B, Fr, C, xbs, ldx = _nlc(x)
+    assert C >= 2 * nb
+    spec = torch.empty((B, Fr, nb), dtype=torch.complex64, device=x.device)
+    lib = _lib.load()
+    rc = lib.mi355_polar_spec(_ptr(x), xbs, ldx, Fr, nb, B, float(clip), _ptr(torch.view_as_real(spec)), _stream())
+    _lib.check(rc, "mi355_polar_spec")
+    return spec
+
+
 def istft_frames(spec: torch.Tensor, n_fft: int, hop: int, window: torch.Tensor, norm: torch.Tensor, norm_mode: int,
                  clamp: bool, trim: int, out_len: int):
     """spec complex64 [B, n_frames, nb] -> [B, out_len]."""

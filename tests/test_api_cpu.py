@@ -275,3 +275,27 @@ def test_kaldi_fbank_oracle_and_host_filterbank():
         dsp_ref.compute_fbank_kaldi(audio, dither=0.0, snip_edges=False)
     n = np.random.default_rng(1).standard_normal((58, 1920)).astype(np.float32)
     assert np.abs(dsp_ref.compute_fbank_kaldi(audio, noise=n) - fb).max() > 1e-3        # dither=1.0 default perturbs
+
+
+def test_vocos_oracle_reference_shape_pins_and_config():
+    """codec/tests/test_vocos.py:60-73: mel model, 120 000 zeros -> (119552,); mel [1, 468, 100]; weight names / shapes of from_hparams."""
+    import torch
+    from mlx_audio_amd.codec.models.vocos.vocos import ISTFTHead, MelSpectrogramFeatures, VocosBackbone, make_vocos_weights
+    from oracle import vocos_ref
+
+    cfg = {"feature_extractor": {"class_path": "vocos.feature_extractors.MelSpectrogramFeatures",
+                                 "init_args": {"sample_rate": 24000, "n_fft": 1024, "hop_length": 256, "n_mels": 100}},
+           "backbone": {"class_path": "vocos.models.VocosBackbone", "init_args": {"input_channels": 100, "dim": 64, "intermediate_dim": 192, "num_layers": 2}},
+           "head": {"class_path": "vocos.heads.ISTFTHead", "init_args": {"dim": 64, "n_fft": 1024, "hop_length": 256}}}
+    w = make_vocos_weights(cfg, seed=0)
+    assert w["backbone.embed.weight"].shape == (64, 7, 100) and w["backbone.convnext.1.dwconv.weight"].shape == (64, 7, 1)
+    assert w["head.out.weight"].shape == (1026, 64) and torch.allclose(w["backbone.convnext.0.gamma"].mean(), torch.tensor(0.5), atol=0.1)
+    ref = vocos_ref.VocosRef(w, cfg)
+    mel = vocos_ref.log_mel_spectrogram(np.zeros(120_000, np.float32))
+    assert mel.shape == (1, 468, 100) and np.allclose(mel, np.log(np.float32(1e-5)))
+    assert ref(np.zeros(120_000, np.float32)).shape == (119552,)
+    assert ref.decode(mel).shape == (119552,)
+    with pytest.raises(ValueError, match="Padding must be"):
+        MelSpectrogramFeatures(padding="valid")
+    bb = VocosBackbone(**cfg["backbone"]["init_args"])
+    assert bb.layer_scale_init_value == 0.5 and not bb.adanorm and ISTFTHead(64, 1024, 256, padding="same").hop_length == 256
