@@ -1,0 +1,1 @@
+from .dac import DAC, make_dac_weights  # noqa: F401

@@ -299,3 +299,20 @@ def test_vocos_oracle_reference_shape_pins_and_config():
         MelSpectrogramFeatures(padding="valid")
     bb = VocosBackbone(**cfg["backbone"]["init_args"])
     assert bb.layer_scale_init_value == 0.5 and not bb.adanorm and ISTFTHead(64, 1024, 256, padding="same").hop_length == 256
+
+
+def test_dac_oracle_reference_length_pins():
+    """codec/tests/test_descript.py:41-42, 74-75, 107-108: the transposed convs' extra sample (groups passed as output_padding)."""
+    import torch
+    from mlx_audio_amd.codec.models.descript.dac import make_dac_weights
+    from oracle.dac_ref import DACDecoderRef
+
+    w = make_dac_weights(32, [8, 5, 4, 2], 16, 2, 32, 8, seed=0)
+    ref = DACDecoderRef(w, [8, 5, 4, 2], 2)
+    z = ref.from_codes(torch.randint(0, 32, (1, 2, 250), generator=torch.Generator().manual_seed(0)))
+    assert tuple(z.shape) == (1, 16, 250)
+    y = ref.decode(z)
+    assert tuple(y.shape) == (1, 80_043, 1) and float(y.abs().max()) <= 1.0
+    assert tuple(ref.decode(z[:, :, :375 - 250 + 125][:, :, :0 + 125]).shape) == (1, 125 * 320 + 43, 1)
+    w2 = make_dac_weights(32, [8, 8, 4, 2], 16, 2, 32, 8, seed=0)
+    assert tuple(DACDecoderRef(w2, [8, 8, 4, 2], 2).decode(torch.zeros(1, 16, 430)).shape) == (1, 220_235, 1)
