@@ -94,6 +94,6 @@ def test_errors_are_loud():
         eng.encode(torch.zeros(1, 1, 800))
     with pytest.raises(NotImplementedError):
         eng(torch.zeros(1, 1, 800))
-    assert tuple(eng.preprocess(torch.zeros(1, 1, 803), 16000).shape) == (1, 1, 1600)   # encoder hop 320 (default encoder_rates)
+    assert tuple(eng.preprocess(torch.zeros(1, 1, 803), 16000).shape) == (1, 1, 960)   # right-pad to a multiple of the encoder hop 320 (dac.py:180-187)
     with pytest.raises(AssertionError):
         eng.preprocess(torch.zeros(1, 1, 800), 8000)
