@@ -571,6 +571,18 @@ typedef struct {
  * receives the final-normed hidden state when final_norm_w is set.  offset = rows already in the KV caches. */
 int mi355_stack_decode_step(const mi355_stack_desc* d, float* x, int32_t B, int32_t offset, float* ws, float* out, void* stream);
 
+/* The same step as ONE launch: a persistent kernel (one or two workgroups per CU) walks the step's phases -- GEMVs with fused norm / SwiGLU /
+ * residual, per-head norm + RoPE, KV-streaming attention, final norm -- separated by grid barriers; activations cross workgroups with
+ * write-through system-scope accesses, the phase list is built once per (stack, B) and cached.  mi355_stack_decode_step dispatches here for
+ * every stack mi355_stack_fused_eligible accepts unless disabled (environment MI355_STEP_FUSED=0, or mi355_stack_fused_set(0), which returns
+ * the previous setting).  The grid barrier's wait is bounded; mi355_stack_fused_check synchronises the stream and fails loudly if a wait was
+ * ever abandoned.  One step kernel at a time per device (it occupies every CU). */
+int mi355_stack_decode_step_fused(const mi355_stack_desc* d, float* x, int32_t B, int32_t offset, float* ws, float* out, void* stream);
+int mi355_stack_fused_eligible(const mi355_stack_desc* d, int32_t B);
+int mi355_stack_fused_set(int32_t enabled);
+int mi355_stack_fused_enabled(void);
+int mi355_stack_fused_check(void* stream);
+
 #ifdef __cplusplus
 }
 #endif

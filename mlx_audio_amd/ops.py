@@ -591,3 +591,17 @@ def istft_frames(spec: torch.Tensor, n_fft: int, hop: int, window: torch.Tensor,
                      hop=hop, window=_ptr(window), norm=_ptr(norm), norm_mode=norm_mode, clamp=int(clamp), trim=trim,
                      out_len=out_len, frames_ws=_ptr(ws), out=_ptr(out), ld_out=out.stride(0))
     return out
+
+
+def fused_step_set(enabled: bool) -> bool:
+    """Enable / disable the one-launch decode-step runner (mega_step.hip); returns the previous setting."""
+    return bool(_lib.load().mi355_stack_fused_set(1 if enabled else 0))
+
+
+def fused_step_enabled() -> bool:
+    return bool(_lib.load().mi355_stack_fused_enabled())
+
+
+def fused_step_check():
+    """Synchronise the stream and raise if a grid barrier of the one-launch step runner was ever abandoned (bounded wait)."""
+    _lib.check(_lib.load().mi355_stack_fused_check(_stream()), "mi355_stack_fused_check")
