@@ -133,7 +133,7 @@ int64_t mi355_packed_conv_weight_elems(int32_t Cout, int32_t K, int32_t Cin);
 int mi355_pack_conv_weight_host(const float* w_host, int32_t Cout, int32_t K, int32_t Cin, uint16_t* out_host);
 /* Same with an explicit element type: MI355_W_BF16 (precision 1 / 2) or MI355_W_F16 (precision 3; bf16-valued checkpoint
  * weights are exactly representable in fp16 down to 2^-17). */
-enum { MI355_W_BF16 = 0, MI355_W_F16 = 1 };
+enum { MI355_W_BF16 = 0, MI355_W_F16 = 1, MI355_W_FP8 = 2 };   /* MI355_W_FP8: row-major GEMV images only (mi355_pack_rowmajor_fp8_host) */
 int mi355_pack_conv_weight_host_dt(const float* w_host, int32_t Cout, int32_t K, int32_t Cin, int32_t dtype, uint16_t* out_host);
 
 /* ------------------------------------------------------------------------------------------
@@ -430,7 +430,7 @@ int mi355_softmax_prob_at(const float* logits, int32_t ld, int32_t V, int32_t B,
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
   const float* x; int32_t ldx; int32_t M; int32_t K;
-  const uint16_t* w; int32_t ldw; int32_t wdtype; int32_t N;   /* wdtype: MI355_W_BF16 / MI355_W_F16 */
+  const uint16_t* w; int32_t ldw; int32_t wdtype; int32_t N;   /* wdtype: MI355_W_BF16 / MI355_W_F16 / MI355_W_FP8 (then w holds bytes; ldw in elements) */
   const float* bias;       /* [N] nullable */
   int32_t post_act; float post_slope;
   const float* colscale;   /* [N] nullable */
@@ -443,9 +443,16 @@ typedef struct {
   int32_t norm; const float* norm_weight; const float* norm_bias; float norm_eps;
   /* optional second destination: columns n >= split are written to y2[m, n - split] (q -> y, k|v -> the KV-cache slot) */
   float* y2; int32_t ldy2; int32_t split;
+  /* MI355_W_FP8 only: per-output-row dequantisation scale [N] (required): acc[n] * wscale[n] precedes the bias */
+  const float* wscale;
 } mi355_gemv_args;
 int mi355_gemv(const mi355_gemv_args* a, void* stream);
 int mi355_pack_rowmajor16_host(const float* w_host, int64_t n, int32_t dtype, uint16_t* out_host);
+/* fp8 weight image for the decode-step GEMVs (BASELINE config[4] names fp8: at <= 8 rows per step a Linear is a weight stream, so the 8-bit
+ * image halves the bytes of a step).  Per output row: scale = 2^ceil(log2(max|w| / 448)) (a power of two: the dequantised value
+ * q * scale is exactly representable in bf16, so the prefill GEMMs run the SAME quantised weights through the bf16 MFMA image), q = OCP e4m3fn
+ * (round-to-nearest-even, max 448).  out_host: rows * cols bytes, scale_host: rows floats; cols % 16 == 0. */
+int mi355_pack_rowmajor_fp8_host(const float* w_host, int64_t rows, int64_t cols, uint8_t* out_host, float* scale_host);
 
 /* ------------------------------------------------------------------------------------------
  * Row-wise glue of the decoder-only transformer blocks (Qwen3-TTS talker / code predictor / codec transformer, CSM,
@@ -550,6 +557,8 @@ typedef struct {
   const float* cross_norm_w; const float* cross_norm_b;
   const float* cross_k; const float* cross_v;   /* head-major [B, kv_heads, cross_len, dh] each (a head's keys contiguous) */
   int64_t cross_bstride; int64_t cross_hstride; int32_t cross_ld; int32_t cross_len;
+  /* wdtype == MI355_W_FP8: per-row scales of the six images (mi355_pack_rowmajor_fp8_host), else null */
+  const float* s_qkv; const float* s_o; const float* s_in; const float* s_out; const float* s_cq; const float* s_co;
 } mi355_layer_desc;
 
 typedef struct {
@@ -558,7 +567,7 @@ typedef struct {
   float eps;
   int32_t glu;             /* 1 = SwiGLU MLP */
   int32_t act;             /* MLP activation when glu == 0 (MI355_ACT_GELU, MI355_ACT_GELU_TANH, ...) */
-  int32_t wdtype;          /* MI355_W_BF16 / MI355_W_F16 */
+  int32_t wdtype;          /* MI355_W_BF16 / MI355_W_F16 / MI355_W_FP8 (every image of the stack, scales in the layer records) */
   int32_t causal; int32_t window;
   float attn_scale;        /* 0 => dh^-0.5 */
   int32_t rope_mode; const float* cos; const float* sin;   /* tables [max_pos, dh/2], nullable: no rotary embedding */

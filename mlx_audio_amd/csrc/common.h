@@ -84,6 +84,62 @@ static inline uint16_t host_f32_to_bf16(float f) {
   return (uint16_t)(u >> 16);
 }
 
+// ---------------------------------------------------------------------------------------------- weight element types of the GEMV images
+// A lane's 16-byte piece of a weight row holds 8 sixteen-bit elements (bf16 / fp16) or 16 fp8 elements (OCP e4m3fn, no inf, max 448).
+template <int WT> struct mi355_wt { static constexpr int EPL = 8; };
+template <> struct mi355_wt<MI355_W_FP8> { static constexpr int EPL = 16; };
+constexpr float kFp8Unbias = 256.0f;  // see cvt_w16<MI355_W_FP8>: the decoded value is the e4m3 value / 2^8
+
+// 16 bytes -> EPL floats.  fp8: a byte s eeee mmm is moved into binary16 position (s 0eeee mmm0000000): the 4-bit exponent lands in the low
+// bits of the 5-bit field and subnormals stay subnormals, so v_cvt_f32_f16 decodes every finite e4m3 code exactly, scaled by
+// 2^(7 - 15) = 2^-8; the caller folds 2^8 into the per-row scale (a power-of-two multiply: exact).
+template <int WT>
+__device__ __forceinline__ void cvt_w16(const uint4 w, float (&f)[mi355_wt<WT>::EPL]) {
+  const uint32_t u[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if constexpr (WT == MI355_W_FP8) {
+      const uint32_t x01 = ((u[i] << 8) & 0x0000ff00u) | ((u[i] << 16) & 0xff000000u);
+      const uint32_t x23 = ((u[i] >> 8) & 0x0000ff00u) | (u[i] & 0xff000000u);
+      const uint32_t h01 = (x01 & 0x80008000u) | ((x01 & 0x7f007f00u) >> 1);
+      const uint32_t h23 = (x23 & 0x80008000u) | ((x23 & 0x7f007f00u) >> 1);
+      f[4 * i] = (float)__builtin_bit_cast(_Float16, (uint16_t)(h01 & 0xffffu));
+      f[4 * i + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(h01 >> 16));
+      f[4 * i + 2] = (float)__builtin_bit_cast(_Float16, (uint16_t)(h23 & 0xffffu));
+      f[4 * i + 3] = (float)__builtin_bit_cast(_Float16, (uint16_t)(h23 >> 16));
+    } else if constexpr (WT == MI355_W_F16) {
+      f[2 * i] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u[i] & 0xffffu));
+      f[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u[i] >> 16));
+    } else {
+      f[2 * i] = __builtin_bit_cast(float, u[i] << 16);
+      f[2 * i + 1] = __builtin_bit_cast(float, u[i] & 0xffff0000u);
+    }
+  }
+}
+
+// host: fp32 -> OCP e4m3fn bits (bias 7, 3 mantissa bits, subnormal quantum 2^-9, max finite 448, no inf), round-to-nearest-even,
+// saturating at +-448; NaN -> 0x7f.  (What torch.float8_e4m3fn's conversion produces for every |x| <= 448.)
+static inline uint8_t host_f32_to_e4m3(float f) {
+  uint32_t u;
+  __builtin_memcpy(&u, &f, 4);
+  const uint8_t sign = (uint8_t)((u >> 24) & 0x80u);
+  u &= 0x7fffffffu;
+  if (u > 0x7f800000u) return (uint8_t)(sign | 0x7fu);
+  float ax;
+  __builtin_memcpy(&ax, &u, 4);
+  if (ax >= 448.0f) return (uint8_t)(sign | 0x7eu);
+  int e = (int)(u >> 23) - 127;
+  if (e < -6) e = -6;                                   // subnormal range: fixed quantum 2^-9
+  const float q = __builtin_ldexpf(1.0f, e - 3);        // spacing of the e4m3 grid around ax
+  const float n = __builtin_rintf(ax / q);              // exact scaling, round-to-nearest-even (default rounding mode)
+  int ni = (int)n;                                      // 0..16: 8..15 = normal mantissas, 16 = carry into the next binade
+  if (ni == 0) return sign;
+  if (ni >= 16) { ni = 8; e += 1; }
+  if (ni < 8) return (uint8_t)(sign | (uint8_t)ni);     // subnormal (only reachable with e == -6)
+  if (e > 8) return (uint8_t)(sign | 0x7eu);
+  return (uint8_t)(sign | (uint8_t)(((e + 7) << 3) | (ni - 8)));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

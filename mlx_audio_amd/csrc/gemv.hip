@@ -17,21 +17,6 @@
 namespace {
 
 
-template <bool F16>
-__device__ __forceinline__ void cvt8(const uint4 w, float (&f)[8]) {
-  const uint32_t u[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if constexpr (F16) {
-      f[2 * i] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u[i] & 0xffffu));
-      f[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u[i] >> 16));
-    } else {
-      f[2 * i] = __builtin_bit_cast(float, u[i] << 16);
-      f[2 * i + 1] = __builtin_bit_cast(float, u[i] & 0xffff0000u);
-    }
-  }
-}
-
 __device__ __forceinline__ float gemv_act(float v, int act, float slope) {
   switch (act) {
     case MI355_ACT_LEAKY: return v > 0.f ? v : v * slope;
@@ -58,10 +43,11 @@ __device__ __forceinline__ void gemv_finish(const mi355_gemv_args& a, float (&ac
       const int n = n0 + c;
       if (n + 1 >= a.N) break;
       const float bg = a.bias ? a.bias[n] : 0.f, bu = a.bias ? a.bias[n + 1] : 0.f;
+      const float wg = a.wscale ? a.wscale[n] * kFp8Unbias : 1.f, wu = a.wscale ? a.wscale[n + 1] * kFp8Unbias : 1.f;  // fp8 images only
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         if (m >= a.M) break;
-        const float g = acc[c][m] + bg, u = acc[c + 1][m] + bu;
+        const float g = acc[c][m] * wg + bg, u = acc[c + 1][m] * wu + bu;
         a.y[(int64_t)m * a.ldy + (n >> 1)] = (g / (1.0f + expf(-g))) * u * a.out_scale;
       }
     }
@@ -73,10 +59,11 @@ __device__ __forceinline__ void gemv_finish(const mi355_gemv_args& a, float (&ac
     if (n >= a.N) break;
     const float bias = a.bias ? a.bias[n] : 0.f;
     const float cs = a.colscale ? a.colscale[n] : 1.f;
+    const float ws = a.wscale ? a.wscale[n] * kFp8Unbias : 1.f;  // fp8 images only (a power of two: exact)
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       if (m >= a.M) break;
-      float v = gemv_act(acc[c][m] + bias, a.post_act, a.post_slope) * cs;
+      float v = gemv_act(acc[c][m] * ws + bias, a.post_act, a.post_slope) * cs;
       if (a.res) v += a.res[(int64_t)m * a.ldr + n];
       if (a.y2 && n >= a.split) a.y2[(int64_t)m * a.ldy2 + (n - a.split)] = v * a.out_scale;  // e.g. q -> y, k|v -> the KV-cache slot
       else a.y[(int64_t)m * a.ldy + n] = v * a.out_scale;
@@ -84,10 +71,13 @@ __device__ __forceinline__ void gemv_finish(const mi355_gemv_args& a, float (&ac
   }
 }
 
-template <int MT, int NC, bool F16>
+template <int MT, int NC, int WT>
 __global__ __launch_bounds__(256) void gemv_kernel(const mi355_gemv_args a) {
+  constexpr int EPL = mi355_wt<WT>::EPL;                         // weight elements per 16-byte lane piece (8, or 16 for fp8)
+  constexpr int ESZ = 16 / EPL;                                  // bytes per weight element
+  constexpr int SL = 64 * EPL;                                   // elements per k-slice (one 1 KB wave load per column)
   constexpr int KC = MT >= 8 ? 1024 : (MT == 4 ? 2048 : 4096);  // x elements staged per row and chunk: MT * KC * 4 B <= 32 KB of LDS
-  constexpr int IPC = KC / 512;                                  // k-slices per chunk
+  constexpr int IPC = KC / SL;                                   // k-slices per chunk
   constexpr int D = 4;                                           // weight prefetch depth, in k-slices
   __shared__ __attribute__((aligned(16))) float xs[MT * KC];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -97,21 +87,21 @@ __global__ __launch_bounds__(256) void gemv_kernel(const mi355_gemv_args a) {
   for (int c = 0; c < NC; ++c)
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[c][m] = 0.f;
-  const uint16_t* wrow[NC];
+  const uint8_t* wrow[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int n = n0 + c < a.N ? n0 + c : a.N - 1;  // clamp: tail columns recompute the last row, never stored
-    wrow[c] = a.w + (int64_t)n * a.ldw;
+    wrow[c] = (const uint8_t*)a.w + (int64_t)n * a.ldw * ESZ;
   }
-  // The weight stream is a software pipeline of its own: D k-slices (512 elements = 64 lanes x 16 B each) per column are always in
+  // The weight stream is a software pipeline of its own: D k-slices (SL elements = 64 lanes x 16 B each) per column are always in
   // flight, issued before the x chunk they will meet is even staged -- the HBM latency of the weights overlaps the L2 latency of x and
   // the workgroup barriers around the LDS staging instead of adding to them.
-  const int n_it = (a.K + 511) >> 9;  // (tail waves, n0 >= N, run the same loop on the clamped last row: the barriers stay block-uniform)
+  const int n_it = (a.K + SL - 1) / SL;  // (tail waves, n0 >= N, run the same loop on the clamped last row: the barriers stay block-uniform)
   uint4 ring[D][NC];
   auto issue = [&](int it, uint4 (&dst)[NC]) {
-    const int k = (it << 9) + lane * 8;
+    const int k = it * SL + lane * EPL;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) dst[c] = k < a.K ? *(const uint4*)(wrow[c] + k) : make_uint4(0u, 0u, 0u, 0u);
+    for (int c = 0; c < NC; ++c) dst[c] = k < a.K ? *(const uint4*)(wrow[c] + (int64_t)k * ESZ) : make_uint4(0u, 0u, 0u, 0u);
   };
 #pragma unroll
   for (int d = 0; d < D; ++d)
@@ -198,20 +188,23 @@ __global__ __launch_bounds__(256) void gemv_kernel(const mi355_gemv_args a) {
         }
         __syncthreads();
       }
-      const int kl = ((it % IPC) << 9) + lane * 8;  // position inside the staged chunk
-      if ((it << 9) + lane * 8 < a.K) {
-        float wf[NC][8];
+      const int kl = (it % IPC) * SL + lane * EPL;  // position inside the staged chunk
+      if (it * SL + lane * EPL < a.K) {
+        float wf[NC][EPL];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) cvt8<F16>(ring[d][c], wf[c]);
+        for (int c = 0; c < NC; ++c) cvt_w16<WT>(ring[d][c], wf[c]);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          const float4 lo = *(const float4*)(xs + m * KC + kl);
-          const float4 hi = *(const float4*)(xs + m * KC + kl + 4);
-          const float xv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          float xv[EPL];
+#pragma unroll
+          for (int j4 = 0; j4 < EPL / 4; ++j4) {
+            const float4 t = *(const float4*)(xs + m * KC + kl + 4 * j4);
+            xv[4 * j4] = t.x; xv[4 * j4 + 1] = t.y; xv[4 * j4 + 2] = t.z; xv[4 * j4 + 3] = t.w;
+          }
 #pragma unroll
           for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[c][m] = fmaf(xv[j], wf[c][j], acc[c][m]);
+            for (int j = 0; j < EPL; ++j) acc[c][m] = fmaf(xv[j], wf[c][j], acc[c][m]);
         }
       }
       if (it + D < n_it) issue(it + D, ring[d]);
@@ -224,8 +217,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(const mi355_gemv_args a) {
 // Resident-x variant for 4..8 input rows: at M = 8 the staging of x (M * K * 4 bytes per workgroup) costs more L2 traffic than the weight
 // rows a 4-wave workgroup consumes, so the rows are staged ONCE per workgroup (dynamic LDS, the fused norm applied on the way in) and the
 // waves then walk many column groups (grid-stride) with no barrier inside the loop -- only the weight stream touches memory.
-template <int MT, int NC, bool F16>
+template <int MT, int NC, int WT>
 __global__ __launch_bounds__(256) void gemv_res_kernel(const mi355_gemv_args a, const int ngroups) {
+  constexpr int EPL = mi355_wt<WT>::EPL, ESZ = 16 / EPL, SL = 64 * EPL;
   constexpr int D = 4;
   extern __shared__ __attribute__((aligned(16))) float xr_s[];  // [MT][K]
   __shared__ float st_mean[8], st_rstd[8];
@@ -264,7 +258,7 @@ __global__ __launch_bounds__(256) void gemv_res_kernel(const mi355_gemv_args a, 
     *(float4*)(xr_s + e) = t;
   }
   __syncthreads();
-  const int n_it = (K + 511) >> 9;
+  const int n_it = (K + SL - 1) / SL;
   for (int g = blockIdx.x * 4 + wave; g < ngroups; g += gridDim.x * 4) {
     const int n0 = g * NC;
     float acc[NC][MT];
@@ -272,17 +266,17 @@ __global__ __launch_bounds__(256) void gemv_res_kernel(const mi355_gemv_args a, 
     for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int m = 0; m < MT; ++m) acc[c][m] = 0.f;
-    const uint16_t* wrow[NC];
+    const uint8_t* wrow[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int n = n0 + c < a.N ? n0 + c : a.N - 1;
-      wrow[c] = a.w + (int64_t)n * a.ldw;
+      wrow[c] = (const uint8_t*)a.w + (int64_t)n * a.ldw * ESZ;
     }
     uint4 ring[D][NC];
     auto issue = [&](int it, uint4 (&dst)[NC]) {
-      const int k = (it << 9) + lane * 8;
+      const int k = it * SL + lane * EPL;
 #pragma unroll
-      for (int c = 0; c < NC; ++c) dst[c] = k < K ? *(const uint4*)(wrow[c] + k) : make_uint4(0u, 0u, 0u, 0u);
+      for (int c = 0; c < NC; ++c) dst[c] = k < K ? *(const uint4*)(wrow[c] + (int64_t)k * ESZ) : make_uint4(0u, 0u, 0u, 0u);
     };
 #pragma unroll
     for (int d = 0; d < D; ++d)
@@ -292,20 +286,23 @@ __global__ __launch_bounds__(256) void gemv_res_kernel(const mi355_gemv_args a, 
       for (int d = 0; d < D; ++d) {
         const int it = base + d;
         if (it >= n_it) break;
-        const int k = (it << 9) + lane * 8;
+        const int k = it * SL + lane * EPL;
         if (k < K) {
-          float wf[NC][8];
+          float wf[NC][EPL];
 #pragma unroll
-          for (int c = 0; c < NC; ++c) cvt8<F16>(ring[d][c], wf[c]);
+          for (int c = 0; c < NC; ++c) cvt_w16<WT>(ring[d][c], wf[c]);
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
-            const float4 lo = *(const float4*)(xr_s + m * K + k);
-            const float4 hi = *(const float4*)(xr_s + m * K + k + 4);
-            const float xv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            float xv[EPL];
+#pragma unroll
+            for (int j4 = 0; j4 < EPL / 4; ++j4) {
+              const float4 t = *(const float4*)(xr_s + m * K + k + 4 * j4);
+              xv[4 * j4] = t.x; xv[4 * j4 + 1] = t.y; xv[4 * j4 + 2] = t.z; xv[4 * j4 + 3] = t.w;
+            }
 #pragma unroll
             for (int c = 0; c < NC; ++c)
 #pragma unroll
-              for (int j = 0; j < 8; ++j) acc[c][m] = fmaf(xv[j], wf[c][j], acc[c][m]);
+              for (int j = 0; j < EPL; ++j) acc[c][m] = fmaf(xv[j], wf[c][j], acc[c][m]);
           }
         }
         if (it + D < n_it) issue(it + D, ring[d]);
@@ -315,7 +312,7 @@ __global__ __launch_bounds__(256) void gemv_res_kernel(const mi355_gemv_args a, 
   }
 }
 
-template <int MT, bool F16>
+template <int MT, int WT>
 int launch_gemv(const mi355_gemv_args& a, hipStream_t st) {
   // one column per wave keeps the most wavefronts (and weight bytes) in flight; two columns per wave halve the LDS reads of x per weight
   // byte, which is what binds at 8 rows (16 LDS bytes per weight byte at NC = 1) and for very wide outputs
@@ -329,7 +326,7 @@ int launch_gemv(const mi355_gemv_args& a, hipStream_t st) {
     if (lds <= 96 * 1024 && use_res) {
       static bool attr_set = false;  // benign race: the attribute is idempotent
       if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemv_res_kernel<MT, 2, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)gemv_res_kernel<MT, 2, WT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         MI355_REQUIRE(e == hipSuccess, "gemv: cannot reserve LDS: %s", hipGetErrorString(e));
         attr_set = true;
       }
@@ -338,24 +335,24 @@ int launch_gemv(const mi355_gemv_args& a, hipStream_t st) {
       int blocks = (ngroups + 3) / 4;
       if (blocks > 256 * per_cu) blocks = 256 * per_cu;
       MI355_CLEAR_ERROR();
-      hipLaunchKernelGGL((gemv_res_kernel<MT, 2, F16>), dim3(blocks), dim3(256), lds, st, a, ngroups);
+      hipLaunchKernelGGL((gemv_res_kernel<MT, 2, WT>), dim3(blocks), dim3(256), lds, st, a, ngroups);
       MI355_LAUNCH_CHECK("gemv(resident)");
       return MI355_OK;
     }
   }
   MI355_CLEAR_ERROR();
-  if (nc == 2) hipLaunchKernelGGL((gemv_kernel<MT, 2, F16>), dim3((a.N + 7) / 8), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((gemv_kernel<MT, 1, F16>), dim3((a.N + 3) / 4), dim3(256), 0, st, a);
+  if (nc == 2) hipLaunchKernelGGL((gemv_kernel<MT, 2, WT>), dim3((a.N + 7) / 8), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((gemv_kernel<MT, 1, WT>), dim3((a.N + 3) / 4), dim3(256), 0, st, a);
   MI355_LAUNCH_CHECK("gemv");
   return MI355_OK;
 }
 
-template <bool F16>
+template <int WT>
 int launch_gemv_m(const mi355_gemv_args& a, hipStream_t st) {
-  if (a.M == 1) return launch_gemv<1, F16>(a, st);
-  if (a.M == 2) return launch_gemv<2, F16>(a, st);
-  if (a.M <= 4) return launch_gemv<4, F16>(a, st);
-  return launch_gemv<8, F16>(a, st);
+  if (a.M == 1) return launch_gemv<1, WT>(a, st);
+  if (a.M == 2) return launch_gemv<2, WT>(a, st);
+  if (a.M <= 4) return launch_gemv<4, WT>(a, st);
+  return launch_gemv<8, WT>(a, st);
 }
 
 }  // namespace
@@ -367,7 +364,9 @@ extern "C" int mi355_gemv(const mi355_gemv_args* ap, void* stream) {
   MI355_REQUIRE(a.N > 0 && a.K > 0 && a.K % 8 == 0, "gemv: K must be a positive multiple of 8");
   MI355_REQUIRE(a.ldw % 8 == 0 && a.ldw >= a.K && ((uintptr_t)a.w) % 16 == 0, "gemv: weight rows must be 16-byte aligned");
   MI355_REQUIRE(a.ldx % 4 == 0 && ((uintptr_t)a.x) % 16 == 0, "gemv: x rows must be 16-byte aligned");
-  MI355_REQUIRE(a.wdtype == MI355_W_BF16 || a.wdtype == MI355_W_F16, "gemv: wdtype must be MI355_W_BF16 or MI355_W_F16");
+  MI355_REQUIRE(a.wdtype == MI355_W_BF16 || a.wdtype == MI355_W_F16 || a.wdtype == MI355_W_FP8, "gemv: wdtype must be MI355_W_BF16, MI355_W_F16 or MI355_W_FP8");
+  MI355_REQUIRE(a.wdtype != MI355_W_FP8 || (a.wscale && a.K % 16 == 0 && a.ldw % 16 == 0), "gemv: fp8 weights need wscale and K, ldw multiples of 16");
+  MI355_REQUIRE(a.wdtype == MI355_W_FP8 || !a.wscale, "gemv: wscale belongs to fp8 weights only");
   MI355_REQUIRE(!a.glu || (a.N % 2 == 0 && !a.res && !a.colscale && a.post_act == MI355_ACT_NONE && !a.y2), "gemv: glu needs an even N and a plain epilogue");
   MI355_REQUIRE(a.norm >= 0 && a.norm <= 2, "gemv: norm must be 0 (none), 1 (LayerNorm) or 2 (RMSNorm)");
   MI355_REQUIRE(!a.norm || (a.K % 4 == 0 && (!a.norm_weight || ((uintptr_t)a.norm_weight) % 16 == 0) && (!a.norm_bias || ((uintptr_t)a.norm_bias) % 16 == 0)),
@@ -375,7 +374,8 @@ extern "C" int mi355_gemv(const mi355_gemv_args* ap, void* stream) {
   MI355_REQUIRE(!a.y2 || (a.split > 0 && a.split < a.N), "gemv: split must be inside (0, N) when y2 is given");
   if (a.out_scale == 0.f) a.out_scale = 1.f;
   hipStream_t st = (hipStream_t)stream;
-  return a.wdtype == MI355_W_F16 ? launch_gemv_m<true>(a, st) : launch_gemv_m<false>(a, st);
+  if (a.wdtype == MI355_W_FP8) return launch_gemv_m<MI355_W_FP8>(a, st);
+  return a.wdtype == MI355_W_F16 ? launch_gemv_m<MI355_W_F16>(a, st) : launch_gemv_m<MI355_W_BF16>(a, st);
 }
 
 // fp32 [rows, cols] (host) -> row-major 16-bit image for mi355_gemv (and for embedding tables kept in the checkpoint dtype)
@@ -383,5 +383,28 @@ extern "C" int mi355_pack_rowmajor16_host(const float* w, int64_t n, int32_t dty
   MI355_REQUIRE(w && out && n >= 0, "pack_rowmajor16: bad arguments");
   MI355_REQUIRE(dtype == MI355_W_BF16 || dtype == MI355_W_F16, "pack_rowmajor16: dtype must be MI355_W_BF16 or MI355_W_F16");
   for (int64_t i = 0; i < n; ++i) out[i] = dtype == MI355_W_F16 ? host_f32_to_f16(w[i]) : host_f32_to_bf16(w[i]);
+  return MI355_OK;
+}
+
+// fp32 [rows, cols] (host) -> fp8 e4m3fn bytes + one power-of-two scale per row (see the header)
+extern "C" int mi355_pack_rowmajor_fp8_host(const float* w, int64_t rows, int64_t cols, uint8_t* out, float* scale) {
+  MI355_REQUIRE(w && out && scale && rows >= 0 && cols > 0 && cols % 16 == 0, "pack_rowmajor_fp8: bad arguments (cols must be a multiple of 16)");
+  for (int64_t r = 0; r < rows; ++r) {
+    const float* wr = w + r * cols;
+    float amax = 0.f;
+    for (int64_t c = 0; c < cols; ++c) {
+      const float a = __builtin_fabsf(wr[c]);
+      MI355_REQUIRE(a == a && a <= 3.0e38f, "pack_rowmajor_fp8: non-finite weight in row %lld", (long long)r);
+      if (a > amax) amax = a;
+    }
+    float s = 1.0f;
+    if (amax > 0.f) {
+      int e;
+      const float m = __builtin_frexpf(amax / 448.0f, &e);  // amax / 448 = m * 2^e, m in [0.5, 1)
+      s = __builtin_ldexpf(1.0f, m == 0.5f ? e - 1 : e);    // 2^ceil(log2(amax / 448))
+    }
+    scale[r] = s;
+    for (int64_t c = 0; c < cols; ++c) out[r * cols + c] = host_f32_to_e4m3(wr[c] / s);  // power-of-two divide: exact
+  }
   return MI355_OK;
 }

@@ -31,7 +31,8 @@ struct Phase {
   int32_t kind;
   // ---- gemv: y[m, n] = epilogue(sum_k norm(x)[m, k] W[n, k])
   int32_t x_id; int32_t ldx; int32_t M; int32_t K;   // activation operands are BUFFER IDS (Bufs below): the pointers change per call
-  const uint16_t* w; int32_t N; int32_t f16;
+  const uint16_t* w; int32_t N; int32_t wt;          // wt: MI355_W_BF16 / MI355_W_F16 / MI355_W_FP8 (bytes + wscale)
+  const float* wscale;
   const float* bias; int32_t act; const float* colscale;
   int32_t res_id; int32_t ldr; int32_t glu;          // res_id < 0: no residual
   int32_t y_id; int32_t ldy;
@@ -93,21 +94,6 @@ __device__ __forceinline__ bool grid_barrier(uint32_t* cnt, const uint32_t targe
   return ok_s != 0;
 }
 
-template <bool F16>
-__device__ __forceinline__ void cvt8m(const uint4 w, float (&f)[8]) {
-  const uint32_t u[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if constexpr (F16) {
-      f[2 * i] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u[i] & 0xffffu));
-      f[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u[i] >> 16));
-    } else {
-      f[2 * i] = __builtin_bit_cast(float, u[i] << 16);
-      f[2 * i + 1] = __builtin_bit_cast(float, u[i] & 0xffff0000u);
-    }
-  }
-}
-
 __device__ __forceinline__ float act_m(float v, int act) {
   switch (act) {
     case MI355_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
@@ -122,20 +108,21 @@ __device__ __forceinline__ float act_m(float v, int act) {
 // ---------------------------------------------------------------------------------------------- GEMV phase
 // Column pairs are dealt round-robin to the 4 * gridDim.x waves of the grid; the input rows are staged (normalised on the way) into LDS once
 // per workgroup when they fit one chunk (the common case: M * K <= 16384), else chunk by chunk per column-pair iteration.
-template <int MT, bool F16>
+template <int MT, int WT>
 __device__ void phase_gemv(const Phase& p, const Bufs& bf, float* xs, float* st, const int offset) {
   constexpr int NC = 2, D = 4;
+  constexpr int EPL = mi355_wt<WT>::EPL, ESZ = 16 / EPL, SL = 64 * EPL;  // elements per lane piece / bytes per element / elements per k-slice
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int W = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
   const int K = p.K, N = p.N, M = p.M;
   const int ngroups = (N + NC - 1) / NC;
   const int iters = (ngroups + W - 1) / W;
-  const int Kp = (K + 511) & ~511;
-  int KC = (kXsCap / MT) & ~511;
+  const int Kp = (K + SL - 1) / SL * SL;
+  int KC = (kXsCap / MT) & ~(SL - 1);
   if (KC > Kp) KC = Kp;
   const int nchunks = (K + KC - 1) / KC;
-  const int IPC = KC >> 9;
-  const int n_it = Kp >> 9;
+  const int IPC = KC / SL;
+  const int n_it = Kp / SL;
   float* y2 = p.y2 ? p.y2 + (int64_t)offset * p.y2_step : nullptr;
   const float* px = bf.p[p.x_id];
   const float* pres = p.res_id >= 0 ? bf.p[p.res_id] : nullptr;
@@ -201,17 +188,17 @@ __device__ void phase_gemv(const Phase& p, const Bufs& bf, float* xs, float* st,
     for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int m = 0; m < MT; ++m) acc[c][m] = 0.f;
-    const uint16_t* wrow[NC];
+    const uint8_t* wrow[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int n = n0 + c < N ? n0 + c : N - 1;
-      wrow[c] = p.w + (int64_t)(valid ? n : 0) * K;
+      wrow[c] = (const uint8_t*)p.w + (int64_t)(valid ? n : 0) * K * ESZ;
     }
     uint4 ring[D][NC];
     auto issue = [&](int it, uint4 (&dst)[NC]) {
-      const int k = (it << 9) + lane * 8;
+      const int k = it * SL + lane * EPL;
 #pragma unroll
-      for (int c = 0; c < NC; ++c) dst[c] = (valid && k < K) ? *(const uint4*)(wrow[c] + k) : make_uint4(0u, 0u, 0u, 0u);
+      for (int c = 0; c < NC; ++c) dst[c] = (valid && k < K) ? *(const uint4*)(wrow[c] + (int64_t)k * ESZ) : make_uint4(0u, 0u, 0u, 0u);
     };
 #pragma unroll
     for (int d = 0; d < D; ++d)
@@ -222,20 +209,23 @@ __device__ void phase_gemv(const Phase& p, const Bufs& bf, float* xs, float* st,
         const int it = base + d;
         if (it >= n_it) break;
         if (it % IPC == 0 && (gi == 0 || nchunks > 1)) stage(it / IPC);  // block-uniform
-        const int kl = ((it % IPC) << 9) + lane * 8;
-        if ((it << 9) + lane * 8 < K) {
-          float wf[NC][8];
+        const int kl = (it % IPC) * SL + lane * EPL;
+        if (it * SL + lane * EPL < K) {
+          float wf[NC][EPL];
 #pragma unroll
-          for (int c = 0; c < NC; ++c) cvt8m<F16>(ring[d][c], wf[c]);
+          for (int c = 0; c < NC; ++c) cvt_w16<WT>(ring[d][c], wf[c]);
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
-            const float4 lo = *(const float4*)(xs + m * KC + kl);
-            const float4 hi = *(const float4*)(xs + m * KC + kl + 4);
-            const float xv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            float xv[EPL];
+#pragma unroll
+            for (int j4 = 0; j4 < EPL / 4; ++j4) {
+              const float4 t = *(const float4*)(xs + m * KC + kl + 4 * j4);
+              xv[4 * j4] = t.x; xv[4 * j4 + 1] = t.y; xv[4 * j4 + 2] = t.z; xv[4 * j4 + 3] = t.w;
+            }
 #pragma unroll
             for (int c = 0; c < NC; ++c)
 #pragma unroll
-              for (int j = 0; j < 8; ++j) acc[c][m] = fmaf(xv[j], wf[c][j], acc[c][m]);
+              for (int j = 0; j < EPL; ++j) acc[c][m] = fmaf(xv[j], wf[c][j], acc[c][m]);
           }
         }
         if (it + D < n_it) issue(it + D, ring[d]);
@@ -250,10 +240,11 @@ __device__ void phase_gemv(const Phase& p, const Bufs& bf, float* xs, float* st,
     if (p.glu) {
       if (n0 + 1 < N) {
         const float bg = p.bias ? p.bias[n0] : 0.f, bu = p.bias ? p.bias[n0 + 1] : 0.f;
+        const float wg = p.wscale ? p.wscale[n0] * kFp8Unbias : 1.f, wu = p.wscale ? p.wscale[n0 + 1] * kFp8Unbias : 1.f;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           if (m >= M) break;
-          const float gg = acc[0][m] + bg, u = acc[1][m] + bu;
+          const float gg = acc[0][m] * wg + bg, u = acc[1][m] * wu + bu;
           st_act(py + (int64_t)m * p.ldy + (n0 >> 1), (gg / (1.0f + expf(-gg))) * u);
         }
       }
@@ -265,10 +256,11 @@ __device__ void phase_gemv(const Phase& p, const Bufs& bf, float* xs, float* st,
       if (n >= N) break;
       const float bias = p.bias ? p.bias[n] : 0.f;
       const float cs = p.colscale ? p.colscale[n] : 1.f;
+      const float ws = p.wscale ? p.wscale[n] * kFp8Unbias : 1.f;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         if (m >= M) break;
-        float v = act_m(acc[c][m] + bias, p.act) * cs;
+        float v = act_m(acc[c][m] * ws + bias, p.act) * cs;
         if (pres) v += ld_act(pres + (int64_t)m * p.ldr + n);
         if (y2 && n >= p.split) st_act(y2 + (int64_t)m * p.ldy2 + (n - p.split), v);
         else st_act(py + (int64_t)m * p.ldy + n, v);
@@ -460,6 +452,12 @@ __global__ __launch_bounds__(256) void step_program_kernel(const Phase* __restri
   extern __shared__ __attribute__((aligned(16))) float xs[];  // kXsCap floats
   __shared__ float st[16];
   __shared__ Phase ph;
+  __shared__ int dead;
+  // an earlier launch of this program abandoned a barrier: its counter is inconsistent until mi355_stack_fused_check resets it -- leave at once
+  // instead of timing out barrier after barrier (the flag is only ever raised, so every workgroup of this launch reads the same value)
+  if (threadIdx.x == 0) dead = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (dead) return;
   for (int i = 0; i < nphases; ++i) {
     __syncthreads();
     {  // the phase record: read-only for the whole launch, plain loads
@@ -470,16 +468,21 @@ __global__ __launch_bounds__(256) void step_program_kernel(const Phase* __restri
     __syncthreads();
     switch (ph.kind) {
       case PH_GEMV:
-        if (ph.f16) {
-          if (ph.M == 1) phase_gemv<1, true>(ph, bf, xs, st, offset);
-          else if (ph.M == 2) phase_gemv<2, true>(ph, bf, xs, st, offset);
-          else if (ph.M <= 4) phase_gemv<4, true>(ph, bf, xs, st, offset);
-          else phase_gemv<8, true>(ph, bf, xs, st, offset);
+        if (ph.wt == MI355_W_FP8) {
+          if (ph.M == 1) phase_gemv<1, MI355_W_FP8>(ph, bf, xs, st, offset);
+          else if (ph.M == 2) phase_gemv<2, MI355_W_FP8>(ph, bf, xs, st, offset);
+          else if (ph.M <= 4) phase_gemv<4, MI355_W_FP8>(ph, bf, xs, st, offset);
+          else phase_gemv<8, MI355_W_FP8>(ph, bf, xs, st, offset);
+        } else if (ph.wt == MI355_W_F16) {
+          if (ph.M == 1) phase_gemv<1, MI355_W_F16>(ph, bf, xs, st, offset);
+          else if (ph.M == 2) phase_gemv<2, MI355_W_F16>(ph, bf, xs, st, offset);
+          else if (ph.M <= 4) phase_gemv<4, MI355_W_F16>(ph, bf, xs, st, offset);
+          else phase_gemv<8, MI355_W_F16>(ph, bf, xs, st, offset);
         } else {
-          if (ph.M == 1) phase_gemv<1, false>(ph, bf, xs, st, offset);
-          else if (ph.M == 2) phase_gemv<2, false>(ph, bf, xs, st, offset);
-          else if (ph.M <= 4) phase_gemv<4, false>(ph, bf, xs, st, offset);
-          else phase_gemv<8, false>(ph, bf, xs, st, offset);
+          if (ph.M == 1) phase_gemv<1, MI355_W_BF16>(ph, bf, xs, st, offset);
+          else if (ph.M == 2) phase_gemv<2, MI355_W_BF16>(ph, bf, xs, st, offset);
+          else if (ph.M <= 4) phase_gemv<4, MI355_W_BF16>(ph, bf, xs, st, offset);
+          else phase_gemv<8, MI355_W_BF16>(ph, bf, xs, st, offset);
         }
         break;
       case PH_ROPE: phase_rope(ph, bf, offset); break;
@@ -520,10 +523,10 @@ uint64_t fnv(const void* data, size_t n, uint64_t h) {
 }
 
 Phase gemv_phase(int x, int ldx, int M, int K, const uint16_t* w, int N, int wdtype, const float* bias, int act, const float* colscale,
-                 int res, int ldr, int glu, int y, int ldy, int norm, const float* nw, const float* nb, float eps) {
+                 int res, int ldr, int glu, int y, int ldy, int norm, const float* nw, const float* nb, float eps, const float* wscale) {
   Phase p;
   memset(&p, 0, sizeof(p));
-  p.kind = PH_GEMV; p.x_id = x; p.ldx = ldx; p.M = M; p.K = K; p.w = w; p.N = N; p.f16 = wdtype == MI355_W_F16; p.bias = bias; p.act = act;
+  p.kind = PH_GEMV; p.x_id = x; p.ldx = ldx; p.M = M; p.K = K; p.w = w; p.N = N; p.wt = wdtype; p.wscale = wdtype == MI355_W_FP8 ? wscale : nullptr; p.bias = bias; p.act = act;
   p.colscale = colscale; p.res_id = res; p.ldr = ldr; p.glu = glu; p.y_id = y; p.ldy = ldy; p.norm = norm; p.nw = nw; p.nb = nb; p.eps = eps;
   return p;
 }
@@ -546,7 +549,8 @@ extern "C" int mi355_stack_fused_eligible(const mi355_stack_desc* dp, int32_t B)
   const mi355_stack_desc& d = *dp;
   if (d.n_layers <= 0 || d.d_model % 8 || d.d_ff % 8 || (d.dh != 64 && d.dh != 128)) return 0;
   if (d.norm != 1 && d.norm != 2) return 0;
-  if (d.wdtype != MI355_W_BF16 && d.wdtype != MI355_W_F16) return 0;
+  if (d.wdtype != MI355_W_BF16 && d.wdtype != MI355_W_F16 && d.wdtype != MI355_W_FP8) return 0;
+  if (d.wdtype == MI355_W_FP8 && (d.d_model % 16 || d.d_ff % 16)) return 0;
   const int MT = B == 1 ? 1 : (B == 2 ? 2 : (B <= 4 ? 4 : 8));
   if (MT * ((d.d_model + 511) & ~511) > kXsCap) return 0;  // the fused pre-norm needs whole rows in one LDS chunk
   if (d.heads % d.kv_heads) return 0;
@@ -580,7 +584,11 @@ extern "C" int mi355_stack_fused_check(void* stream) {
     int32_t v = 0;
     e = hipMemcpy(&v, pr.err, sizeof(v), hipMemcpyDeviceToHost);
     MI355_REQUIRE(e == hipSuccess, "stack_fused_check: %s", hipGetErrorString(e));
-    if (v) { bad = 1; (void)hipMemset(pr.err, 0, sizeof(int32_t)); }
+    if (v) {  // the abandoned barrier left the counter short of its target: start this program's count over
+      bad = 1;
+      (void)hipMemset(pr.cnt, 0, 256);
+      pr.base = 0;
+    }
   }
   MI355_REQUIRE(!bad, "stack_decode_step(fused): a grid barrier timed out (workgroups of the step kernel were not co-resident)");
   return MI355_OK;
@@ -629,7 +637,7 @@ extern "C" int mi355_stack_decode_step_fused(const mi355_stack_desc* dp, float* 
     for (int i = 0; i < d.n_layers; ++i) {
       const mi355_layer_desc& L = d.layers[i];
       Phase g1 = gemv_phase(x_, D, B, D, L.wqkv, nq + nkv, d.wdtype, L.bqkv, MI355_ACT_NONE, nullptr, none, 0, 0, q, nq, d.norm, L.attn_norm_w,
-                            L.attn_norm_b, d.eps);
+                            L.attn_norm_b, d.eps, L.s_qkv);
       g1.y2 = L.kv; g1.ldy2 = (int)L.kv_bstride; g1.split = nq; g1.y2_step = nkv;
       ph.push_back(g1);
       if (L.q_norm || d.cos) {
@@ -640,18 +648,18 @@ extern "C" int mi355_stack_decode_step_fused(const mi355_stack_desc* dp, float* 
         ph.push_back(r);
       }
       ph.push_back(attn_phase(q, nq, L.kv, L.kv + G * dh, L.kv_bstride, nkv, 0, H, G, dh, 1, 1, d.window, scale, B, att, nq));
-      ph.push_back(gemv_phase(att, nq, B, nq, L.wo, D, d.wdtype, L.bo, MI355_ACT_NONE, L.ls1, x_, D, 0, x_, D, 0, nullptr, nullptr, 0.f));
+      ph.push_back(gemv_phase(att, nq, B, nq, L.wo, D, d.wdtype, L.bo, MI355_ACT_NONE, L.ls1, x_, D, 0, x_, D, 0, nullptr, nullptr, 0.f, L.s_o));
       if (L.cross_k) {
         MI355_REQUIRE(L.wcq && L.wco && L.cross_v && L.cross_len > 0, "stack_decode_step(fused): layer %d has cross K but no cross projections / V", i);
         ph.push_back(gemv_phase(x_, D, B, D, L.wcq, nq, d.wdtype, L.bcq, MI355_ACT_NONE, nullptr, none, 0, 0, q, nq, d.norm, L.cross_norm_w,
-                                L.cross_norm_b, d.eps));
+                                L.cross_norm_b, d.eps, L.s_cq));
         ph.push_back(attn_phase(q, nq, L.cross_k, L.cross_v, L.cross_bstride, L.cross_ld, L.cross_hstride, H, G, dh, L.cross_len, 0, 0, scale, B, att,
                                 nq));
-        ph.push_back(gemv_phase(att, nq, B, nq, L.wco, D, d.wdtype, L.bco, MI355_ACT_NONE, nullptr, x_, D, 0, x_, D, 0, nullptr, nullptr, 0.f));
+        ph.push_back(gemv_phase(att, nq, B, nq, L.wco, D, d.wdtype, L.bco, MI355_ACT_NONE, nullptr, x_, D, 0, x_, D, 0, nullptr, nullptr, 0.f, L.s_co));
       }
       ph.push_back(gemv_phase(x_, D, B, D, L.w_in, d.glu ? 2 * d.d_ff : d.d_ff, d.wdtype, L.b_in, d.glu ? MI355_ACT_NONE : d.act, nullptr, none, 0,
-                              d.glu, mid, d.d_ff, d.norm, L.mlp_norm_w, L.mlp_norm_b, d.eps));
-      ph.push_back(gemv_phase(mid, d.d_ff, B, d.d_ff, L.w_out, D, d.wdtype, L.b_out, MI355_ACT_NONE, L.ls2, x_, D, 0, x_, D, 0, nullptr, nullptr, 0.f));
+                              d.glu, mid, d.d_ff, d.norm, L.mlp_norm_w, L.mlp_norm_b, d.eps, L.s_in));
+      ph.push_back(gemv_phase(mid, d.d_ff, B, d.d_ff, L.w_out, D, d.wdtype, L.b_out, MI355_ACT_NONE, L.ls2, x_, D, 0, x_, D, 0, nullptr, nullptr, 0.f, L.s_out));
     }
     if (out && d.final_norm_w) {
       Phase n;
@@ -664,6 +672,7 @@ extern "C" int mi355_stack_decode_step_fused(const mi355_stack_desc* dp, float* 
       if (p.kind != PH_GEMV) continue;
       MI355_REQUIRE(p.K % 8 == 0 && ((uintptr_t)p.w) % 16 == 0 && p.ldx % 2 == 0, "stack_decode_step(fused): misaligned GEMV operand");
       MI355_REQUIRE(!p.glu || p.N % 2 == 0, "stack_decode_step(fused): SwiGLU needs an even N");
+      MI355_REQUIRE(p.wt != MI355_W_FP8 || (p.wscale && p.K % 16 == 0), "stack_decode_step(fused): fp8 image without scales / K not a multiple of 16");
     }
     // slot: reuse the least recently used entry once 32 programs are cached
     if (g_programs.size() < 32) {

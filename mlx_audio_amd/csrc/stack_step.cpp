@@ -16,12 +16,12 @@ namespace {
 
 int gemv_call(const float* x, int ldx, int M, int K, const uint16_t* w, int N, int wdtype, const float* bias, int act, const float* colscale,
               const float* res, int ldr, int glu, float* y, int ldy, int norm, const float* nw, const float* nb, float eps, float* y2, int ldy2,
-              int split, void* stream) {
+              int split, void* stream, const float* wscale = nullptr) {
   mi355_gemv_args g;
   memset(&g, 0, sizeof(g));
   g.x = x; g.ldx = ldx; g.M = M; g.K = K; g.w = w; g.ldw = K; g.wdtype = wdtype; g.N = N; g.bias = bias; g.post_act = act; g.colscale = colscale;
   g.res = res; g.ldr = ldr; g.out_scale = 1.f; g.glu = glu; g.y = y; g.ldy = ldy; g.norm = norm; g.norm_weight = nw; g.norm_bias = nb;
-  g.norm_eps = eps; g.y2 = y2; g.ldy2 = ldy2; g.split = split;
+  g.norm_eps = eps; g.y2 = y2; g.ldy2 = ldy2; g.split = split; g.wscale = wscale;
   return mi355_gemv(&g, stream);
 }
 
@@ -46,6 +46,7 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
   const mi355_stack_desc d = *dp;
   MI355_REQUIRE(B >= 1 && B <= 8, "stack_decode_step: 1..8 sequences per step (got %d)", B);
   MI355_REQUIRE(d.n_layers > 0 && d.d_model % 8 == 0 && d.d_ff % 8 == 0 && (d.dh == 64 || d.dh == 128), "stack_decode_step: bad dimensions");
+  MI355_REQUIRE(d.wdtype != MI355_W_FP8 || (d.d_model % 16 == 0 && d.d_ff % 16 == 0), "stack_decode_step: fp8 images need d_model, d_ff multiples of 16");
   MI355_REQUIRE(d.norm == 1 || d.norm == 2, "stack_decode_step: norm must be 1 (LayerNorm) or 2 (RMSNorm)");
   MI355_REQUIRE(offset >= 0, "stack_decode_step: negative offset");
   const int D = d.d_model, H = d.heads, G = d.kv_heads, dh = d.dh;
@@ -57,11 +58,13 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
   for (int i = 0; i < d.n_layers; ++i) {
     const mi355_layer_desc& L = d.layers[i];
     MI355_REQUIRE(L.wqkv && L.wo && L.w_in && L.w_out && L.kv, "stack_decode_step: layer %d is missing a tensor", i);
+    MI355_REQUIRE(d.wdtype != MI355_W_FP8 || (L.s_qkv && L.s_o && L.s_in && L.s_out && (!L.cross_k || (L.s_cq && L.s_co))),
+                  "stack_decode_step: layer %d has fp8 images but no scales", i);
     MI355_REQUIRE(offset < L.kv_capacity, "stack_decode_step: KV cache of layer %d is full (offset %d, capacity %d)", i, offset, L.kv_capacity);
     float* slot = L.kv + (int64_t)offset * nkv;  // row `offset` of item 0; items are kv_bstride apart
     // ---- self-attention
     int rc = gemv_call(x, D, B, D, L.wqkv, nq + nkv, d.wdtype, L.bqkv, MI355_ACT_NONE, nullptr, nullptr, 0, 0, q, nq, d.norm, L.attn_norm_w,
-                       L.attn_norm_b, d.eps, slot, (int)L.kv_bstride, nq, stream);
+                       L.attn_norm_b, d.eps, slot, (int)L.kv_bstride, nq, stream, L.s_qkv);
     if (rc) return rc;
     if (L.q_norm || d.cos) {
       mi355_head_rope_args r;
@@ -76,26 +79,27 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
     rc = attn_call(q, nq, L.kv, L.kv + G * dh, L.kv_bstride, nkv, H, G, dh, offset + 1, d.causal, d.window, scale, B, att, nq, stream, 0, d.attn_split_ws,
                    d.attn_split_cnt);
     if (rc) return rc;
-    rc = gemv_call(att, nq, B, nq, L.wo, D, d.wdtype, L.bo, MI355_ACT_NONE, L.ls1, x, D, 0, x, D, 0, nullptr, nullptr, 0.f, nullptr, 0, 0, stream);
+    rc = gemv_call(att, nq, B, nq, L.wo, D, d.wdtype, L.bo, MI355_ACT_NONE, L.ls1, x, D, 0, x, D, 0, nullptr, nullptr, 0.f, nullptr, 0, 0, stream, L.s_o);
     if (rc) return rc;
     // ---- cross-attention (Whisper decoder): K | V precomputed once per window
     if (L.cross_k) {
       MI355_REQUIRE(L.wcq && L.wco && L.cross_v && L.cross_len > 0, "stack_decode_step: layer %d has cross K but no cross projections / V", i);
       rc = gemv_call(x, D, B, D, L.wcq, nq, d.wdtype, L.bcq, MI355_ACT_NONE, nullptr, nullptr, 0, 0, q, nq, d.norm, L.cross_norm_w, L.cross_norm_b,
-                     d.eps, nullptr, 0, 0, stream);
+                     d.eps, nullptr, 0, 0, stream, L.s_cq);
       if (rc) return rc;
       rc = attn_call(q, nq, L.cross_k, L.cross_v, L.cross_bstride, L.cross_ld, H, G, dh, L.cross_len, 0, 0, scale, B, att, nq, stream, L.cross_hstride,
                      d.attn_split_ws, d.attn_split_cnt);
       if (rc) return rc;
-      rc = gemv_call(att, nq, B, nq, L.wco, D, d.wdtype, L.bco, MI355_ACT_NONE, nullptr, x, D, 0, x, D, 0, nullptr, nullptr, 0.f, nullptr, 0, 0, stream);
+      rc = gemv_call(att, nq, B, nq, L.wco, D, d.wdtype, L.bco, MI355_ACT_NONE, nullptr, x, D, 0, x, D, 0, nullptr, nullptr, 0.f, nullptr, 0, 0, stream,
+                     L.s_co);
       if (rc) return rc;
     }
     // ---- MLP
     rc = gemv_call(x, D, B, D, L.w_in, d.glu ? 2 * d.d_ff : d.d_ff, d.wdtype, L.b_in, d.glu ? MI355_ACT_NONE : d.act, nullptr, nullptr, 0, d.glu, mid,
-                   d.d_ff, d.norm, L.mlp_norm_w, L.mlp_norm_b, d.eps, nullptr, 0, 0, stream);
+                   d.d_ff, d.norm, L.mlp_norm_w, L.mlp_norm_b, d.eps, nullptr, 0, 0, stream, L.s_in);
     if (rc) return rc;
     rc = gemv_call(mid, d.d_ff, B, d.d_ff, L.w_out, D, d.wdtype, L.b_out, MI355_ACT_NONE, L.ls2, x, D, 0, x, D, 0, nullptr, nullptr, 0.f, nullptr, 0, 0,
-                   stream);
+                   stream, L.s_out);
     if (rc) return rc;
   }
   if (out && d.final_norm_w) {

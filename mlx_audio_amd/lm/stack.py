@@ -128,8 +128,26 @@ class Lin:
     rm: RowMajor16
 
 
-def make_lin(w: torch.Tensor, bias: Optional[torch.Tensor], device, f16: bool = False) -> Lin:
-    return Lin(ops.pack_conv(w, bias, device, f16=f16), ops.pack_rowmajor16(w, bias, device, f16=f16))
+def make_lin(w: torch.Tensor, bias: Optional[torch.Tensor], device, f16: bool = False, fp8: bool = False, gemv_only: bool = False) -> Lin:
+    """MFMA image (prefill) + row-major GEMV image (decode steps) of one Linear.  ``fp8``: the GEMV image is OCP e4m3fn with per-row
+    power-of-two scales (half the bytes of a decode step) and the MFMA image is built from the SAME dequantised values, which bf16 holds
+    exactly -- prefill and decode see one set of weights."""
+    if fp8:
+        rm, wq = ops.pack_rowmajor_fp8(w, bias, device)
+        return Lin(None if gemv_only else ops.pack_conv(wq, bias, device), rm)
+    return Lin(None if gemv_only else ops.pack_conv(w, bias, device, f16=f16), ops.pack_rowmajor16(w, bias, device, f16=f16))
+
+
+def effective_weights(weights: Dict[str, torch.Tensor], cfg: "StackConfig", weight_format: str = "bf16", prefix: str = "") -> Dict[str, torch.Tensor]:
+    """The float32 weights a ``TransformerStack`` built with ``weight_format`` actually computes with (canonical names, prefix stripped):
+    bf16-rounded, and for "fp8" every Linear replaced by its dequantised fp8 image (rows quantised exactly as the engine quantises them: q | k | v
+    and gate | up rows are quantised per row, so fusing them into one image changes nothing).  Parity tests hand these to the oracle."""
+    w = {k[len(prefix):]: v.detach().to(torch.bfloat16).to(torch.float32).cpu() for k, v in weights.items() if k.startswith(prefix)}
+    if weight_format == "fp8":
+        for k in list(w):
+            if k.endswith(".weight") and w[k].dim() == 2 and k.split(".")[-2] in ("wq", "wk", "wv", "wo", "w_gate", "w_up", "w_down", "w1", "w2"):
+                w[k] = ops.dequantize_rows_fp8(*ops.quantize_rows_fp8(w[k]))
+    return w
 
 
 def is_decode(x: torch.Tensor) -> bool:
@@ -168,9 +186,14 @@ class _Layer:
 
 
 class TransformerStack:
-    def __init__(self, weights: Dict[str, torch.Tensor], cfg: StackConfig, device="cuda:0", precision: int = 2, prefix: str = ""):
+    def __init__(self, weights: Dict[str, torch.Tensor], cfg: StackConfig, device="cuda:0", precision: int = 2, prefix: str = "",
+                 weight_format: str = "bf16"):
         ops.require_gpu()
         assert cfg.head_dim in (64, 128) and cfg.d_model % 4 == 0
+        assert weight_format in ("bf16", "fp8"), weight_format
+        fp8 = weight_format == "fp8"
+        assert not fp8 or (cfg.d_model % 16 == 0 and cfg.d_ff % 16 == 0 and (cfg.n_heads * cfg.head_dim) % 16 == 0)
+        self.weight_format = weight_format
         self.cfg = cfg
         self.device = torch.device(device)
         self.precision = precision
@@ -183,7 +206,7 @@ class TransformerStack:
             return None if t is None else t.to(dev)
 
         def lin(name, extra_rows=None):
-            return make_lin(w[name + ".weight"], w.get(name + ".bias"), dev)
+            return make_lin(w[name + ".weight"], w.get(name + ".bias"), dev, fp8=fp8)
 
         self.layers: List[_Layer] = []
         for i in range(cfg.n_layers):
@@ -197,16 +220,16 @@ class TransformerStack:
                 w_in_w = torch.stack([wg, wu], dim=1).reshape(2 * wg.shape[0], wg.shape[1])  # gate_0, up_0, gate_1, up_1, ...
                 bg, bu = w.get(p + "w_gate.bias"), w.get(p + "w_up.bias")
                 w_in_b = None if bg is None else torch.stack([bg, bu], dim=1).reshape(-1)
-                w_in = make_lin(w_in_w, w_in_b, dev)
+                w_in = make_lin(w_in_w, w_in_b, dev, fp8=fp8)
                 w_out = lin(p + "w_down")
             else:
                 w_in, w_out = lin(p + "w1"), lin(p + "w2")
             wq_w, bq = w[p + "wq.weight"], w.get(p + "wq.bias")
             qkvb = None if kvb is None and bq is None else torch.cat([bq if bq is not None else torch.zeros(wq_w.shape[0]),
                                                                        kvb if kvb is not None else torch.zeros(wk.shape[0] + wv.shape[0])])
-            wqkv = Lin(None, ops.pack_rowmajor16(torch.cat([wq_w, wk, wv]), qkvb, dev))  # GEMV image only
+            wqkv = make_lin(torch.cat([wq_w, wk, wv]), qkvb, dev, fp8=fp8, gemv_only=True)
             self.layers.append(_Layer((vec(p + "attn_norm.weight"), vec(p + "attn_norm.bias")), lin(p + "wq"),
-                                      make_lin(torch.cat([wk, wv]), kvb, dev), wqkv, lin(p + "wo"), vec(p + "q_norm.weight"), vec(p + "k_norm.weight"),
+                                      make_lin(torch.cat([wk, wv]), kvb, dev, fp8=fp8), wqkv, lin(p + "wo"), vec(p + "q_norm.weight"), vec(p + "k_norm.weight"),
                                       (vec(p + "mlp_norm.weight"), vec(p + "mlp_norm.bias")), w_in, w_out, vec(p + "ls1"), vec(p + "ls2")))
         self.final_norm = (vec("final_norm.weight"), vec("final_norm.bias")) if cfg.final_norm else None
         if cfg.rope_theta is not None:
@@ -239,11 +262,12 @@ class TransformerStack:
             a.mlp_norm_w, a.mlp_norm_b = p(lyr.mlp_norm[0]), p(lyr.mlp_norm[1])
             a.q_norm, a.k_norm, a.ls1, a.ls2 = p(lyr.q_norm), p(lyr.k_norm), p(lyr.ls1), p(lyr.ls2)
             a.kv, a.kv_bstride, a.kv_capacity = kvc.kv.data_ptr(), kvc.kv.stride(0), kvc.kv.shape[1]
+            a.s_qkv, a.s_o, a.s_in, a.s_out = p(lyr.wqkv.rm.scale), p(lyr.wo.rm.scale), p(lyr.w_in.rm.scale), p(lyr.w_out.rm.scale)
         d = SD()
         d.n_layers, d.d_model, d.heads, d.kv_heads, d.dh, d.d_ff = c.n_layers, c.d_model, c.n_heads, c.n_kv_heads, c.head_dim, c.d_ff
         d.norm, d.eps, d.glu = (1 if c.norm == "layer" else 2), c.norm_eps, int(c.mlp == "swiglu")
         d.act = {"gelu": ACT_GELU, "gelu_tanh": ACT_GELU_TANH}.get(c.mlp, ACT_NONE)
-        d.wdtype, d.causal, d.window, d.attn_scale = 0, int(c.causal), c.window, 0.0
+        d.wdtype, d.causal, d.window, d.attn_scale = self.layers[0].wqkv.rm.wdtype, int(c.causal), c.window, 0.0
         d.rope_mode, d.cos, d.sin = int(c.rope_interleaved), p(self.cos), p(self.sin)
         d.layers = ctypes.cast(arr, ctypes.c_void_p)
         sws, scnt = ops.attn_split_workspace(self.device, 8 * c.n_heads, c.head_dim)  # key-split decode attention (long key ranges)

@@ -101,11 +101,16 @@ def _polyphase_weight(w_t: torch.Tensor, stride: int) -> torch.Tensor:
 class RowMajor16:
     """Row-major 16-bit weight image [N, K] for the decode-step GEMV (checkpoint dtype: bf16 or fp16)."""
 
-    w: torch.Tensor  # int16 [N, K] on device
+    w: torch.Tensor  # int16 [N, K] on device (uint8 [N, K] for the fp8 image)
     bias: Optional[torch.Tensor]
     n: int
     k: int
     f16: bool
+    scale: Optional[torch.Tensor] = None  # fp8 image only: per-row power-of-two dequantisation scale [N] fp32 (device)
+
+    @property
+    def wdtype(self) -> int:
+        return W_FP8 if self.scale is not None else (W_F16 if self.f16 else W_BF16)
 
 
 def pack_rowmajor16(w: torch.Tensor, bias: Optional[torch.Tensor], device, f16: bool = False) -> RowMajor16:
@@ -122,6 +127,36 @@ def pack_rowmajor16(w: torch.Tensor, bias: Optional[torch.Tensor], device, f16: 
     return RowMajor16(wd, bd, n, k, f16)
 
 
+W_BF16, W_F16, W_FP8 = 0, 1, 2  # MI355_W_* of the header
+
+
+def quantize_rows_fp8(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """float32 [N, K] (CPU) -> (uint8 [N, K] OCP e4m3fn codes, float32 [N] power-of-two row scales) through the library's host packer
+    (``mi355_pack_rowmajor_fp8_host``): w ~= decode(code) * scale, and decode(code) * scale is exactly representable in bf16."""
+    w = w.detach().to(torch.float32).contiguous().cpu()
+    n, k = w.shape
+    assert k % 16 == 0, "fp8 GEMV images need K % 16 == 0"
+    lib = _lib.load()
+    codes = np.empty((n, k), dtype=np.uint8)
+    scale = np.empty(n, dtype=np.float32)
+    rc = lib.mi355_pack_rowmajor_fp8_host(w.numpy().ctypes.data, n, k, codes.ctypes.data, scale.ctypes.data)
+    _lib.check(rc, "mi355_pack_rowmajor_fp8_host")
+    return torch.from_numpy(codes), torch.from_numpy(scale)
+
+
+def dequantize_rows_fp8(codes: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """The float32 weights an fp8 image stands for (exact): used to build the bf16 MFMA image of the SAME quantised Linear for prefill."""
+    return codes.view(torch.float8_e4m3fn).to(torch.float32) * scale[:, None]
+
+
+def pack_rowmajor_fp8(w: torch.Tensor, bias: Optional[torch.Tensor], device) -> Tuple[RowMajor16, torch.Tensor]:
+    """fp8 GEMV image of an nn.Linear weight [N, K]; also returns the dequantised float32 weights (CPU) it represents."""
+    codes, scale = quantize_rows_fp8(w)
+    bd = None if bias is None else bias.detach().to(torch.float32).contiguous().to(device)
+    rw = RowMajor16(codes.to(device), bd, codes.shape[0], codes.shape[1], False, scale.to(device))
+    return rw, dequantize_rows_fp8(codes, scale)
+
+
 def gemv(x: torch.Tensor, rw: RowMajor16, y: torch.Tensor, *, post_act: int = ACT_NONE, post_slope: float = 0.0,
          res: Optional[torch.Tensor] = None, colscale: Optional[torch.Tensor] = None, out_scale: float = 1.0, glu: bool = False,
          use_bias: bool = True, norm: Optional[tuple] = None, y2: Optional[torch.Tensor] = None):
@@ -131,7 +166,7 @@ def gemv(x: torch.Tensor, rw: RowMajor16, y: torch.Tensor, *, post_act: int = AC
     M = x.shape[0]
     n_y = rw.n // 2 if glu else (rw.n if y2 is None else rw.n - y2.shape[1])
     assert x.shape[1] == rw.k and y.shape[0] == M and y.shape[1] == n_y, (x.shape, y.shape, rw.n, rw.k)
-    kw = dict(x=_ptr(x), ldx=x.stride(0), M=M, K=rw.k, w=_ptr(rw.w), ldw=rw.w.stride(0), wdtype=1 if rw.f16 else 0, N=rw.n,
+    kw = dict(x=_ptr(x), ldx=x.stride(0), M=M, K=rw.k, w=_ptr(rw.w), ldw=rw.w.stride(0), wdtype=rw.wdtype, wscale=_ptr(rw.scale), N=rw.n,
               bias=_ptr(rw.bias) if use_bias else None, post_act=post_act, post_slope=post_slope, colscale=_ptr(colscale),
               out_scale=out_scale, glu=int(glu), y=_ptr(y), ldy=y.stride(0))
     if res is not None:

@@ -197,3 +197,20 @@ class StackRef:
         if c.final_norm:
             x = self._norm(x, "final_norm")
         return (x, layers) if return_layers else x
+
+
+# ------------------------------------------------------------------------------------------------ fp8 weight images (BASELINE config[4])
+def quantize_rows_fp8_ref(w: Tensor) -> Tuple[Tensor, Tensor]:
+    """Restatement of the build's fp8 weight format (the reference has no fp8 path: BASELINE.json config[4] asks for it, SURVEY 8 row a28
+    "fp8 target is new"), independent of the product packer: per output row ``scale = 2^ceil(log2(max|w| / 448))`` (1 for an all-zero row),
+    ``code = e4m3fn(w / scale)`` with PyTorch's round-to-nearest-even conversion.  Returns (uint8 codes [N, K], float32 scales [N]).
+    The dequantised weights ``decode(code) * scale`` are what every fp8-mode parity test feeds to ``StackRef``."""
+    w = w.detach().to(torch.float32)
+    amax = w.abs().amax(dim=1).to(torch.float64)
+    scale = torch.where(amax > 0, torch.pow(2.0, torch.ceil(torch.log2(amax / 448.0))), torch.ones_like(amax)).to(torch.float32)
+    codes = (w / scale[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)
+    return codes, scale
+
+
+def dequantize_rows_fp8_ref(codes: Tensor, scale: Tensor) -> Tensor:
+    return codes.view(torch.float8_e4m3fn).to(torch.float32) * scale[:, None]

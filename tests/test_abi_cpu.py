@@ -162,3 +162,45 @@ def test_pack_conv_weight_fp16_rounding(lib):
             nt, lane_lo, kk, hi, j = n // 32, n % 32, c // 16, (c % 16) // 8, c % 8
             assert out[0, 0, nt, kk, hi * 32 + lane_lo, j] == want[n, 0, c], (w[n, 0, c], hex(out[0, 0, nt, kk, hi * 32 + lane_lo, j]), hex(want[n, 0, c]))
     assert lib.mi355_pack_conv_weight_host_dt(w.ctypes.data, cout, k, cin, 7, out.ctypes.data) == -1
+
+
+def test_fp8_row_packer_matches_the_restated_format(lib):
+    """mi355_pack_rowmajor_fp8_host against the oracle's restatement (torch.float8_e4m3fn, power-of-two row scales): bit-exact codes and
+    scales, including ties, subnormals, the largest code, an all-zero row; the dequantised values are exactly representable in bf16."""
+    from mlx_audio_amd import ops
+    from oracle.lm_ref import dequantize_rows_fp8_ref, quantize_rows_fp8_ref
+
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(96, 256, generator=g) * 0.02
+    w[3] = 0.0
+    w[5, 7] = 1.5
+    w[6] = torch.linspace(-448.0, 448.0, 256)                     # scale exactly 1: the row walks the whole code range incl. ties
+    w[7, :16] = torch.tensor([2.0 ** -9, 2.0 ** -10, 3 * 2.0 ** -10, 1.5 * 2.0 ** -9, 0.0, -2.0 ** -9, 17.0, 18.0, 19.0, 20.0, 22.0, 26.0, 30.0, 36.0, 44.0, 448.0])
+    codes, scale = ops.quantize_rows_fp8(w)
+    rc, rs = quantize_rows_fp8_ref(w)
+    assert torch.equal(scale, rs)
+    assert torch.equal(codes, rc)
+    assert float(scale[3]) == 1.0 and int(codes[3].max()) == 0
+    assert float(scale[6]) == 1.0 and int(codes[6, -1]) == 0x7E and int(codes[6, 0]) == 0xFE
+    dq = ops.dequantize_rows_fp8(codes, scale)
+    assert torch.equal(dq, dequantize_rows_fp8_ref(rc, rs))
+    assert torch.equal(dq.to(torch.bfloat16).to(torch.float32), dq)   # prefill (bf16 MFMA image) and decode (fp8 GEMV image) see the same weights
+    rel = float((dq - w)[:3].norm() / w[:3].norm())
+    assert rel < 0.04, rel
+    # a fine grid across every binade of the format
+    x = torch.cat([torch.linspace(-448, 448, 100001), torch.linspace(-0.05, 0.05, 100001)])
+    x = torch.cat([x, torch.zeros((-x.numel() - 1) % 16), torch.tensor([448.0])]).reshape(1, -1)
+    c2, s2 = ops.quantize_rows_fp8(x)
+    assert float(s2[0]) == 1.0 and torch.equal(c2, x.to(torch.float8_e4m3fn).view(torch.uint8))
+
+
+def test_fp8_device_decode_identity():
+    """The kernels decode an e4m3fn byte by moving it into binary16 position (csrc/common.h cvt_w16<MI355_W_FP8>) and folding 2^8 into the row
+    scale; the same integer recipe in numpy reproduces every finite code of the format exactly."""
+    b = np.arange(256, dtype=np.uint32)
+    x = b << 8
+    h = (x & 0x8000) | ((x & 0x7F00) >> 1)
+    dec = h.astype(np.uint16).view(np.float16).astype(np.float32) * 256.0
+    ref = torch.arange(256, dtype=torch.uint8).view(torch.float8_e4m3fn).to(torch.float32).numpy()
+    finite = np.isfinite(ref)
+    assert finite.sum() == 254 and np.array_equal(dec[finite], ref[finite])

@@ -287,3 +287,46 @@ def test_fused_step_runner_matches_multi_launch(ops, name, B, L):
         assert torch.allclose(fc[0].kv[:, : L + steps], mc[0].kv[:, : L + steps], rtol=1e-5, atol=1e-6)
     finally:
         ops.fused_step_set(prev)
+
+
+@pytest.mark.parametrize("name,B,L,fused", [("csm_llama", 1, 60, True), ("csm_llama", 4, 250, True), ("qwen3_talker", 8, 60, True),
+                                            ("csm_llama", 2, 60, False), ("mimi", 3, 60, False), ("qwen3_codec", 2, 60, True)])
+def test_stack_fp8_weight_images(ops, name, B, L, fused):
+    """weight_format="fp8" (BASELINE config[4]): decode steps stream OCP e4m3fn weight images (per-row power-of-two scales) through the GEMV
+    phases of both step runners, prefill runs the same dequantised values through the bf16 MFMA image.  Oracle = StackRef on the dequantised
+    weights (oracle/lm_ref.py quantize_rows_fp8_ref restates the format), so the bar is the bf16 stack's; the quantisation itself moves the
+    hidden state by a few percent, which the last assertion records."""
+    from mlx_audio_amd.lm.stack import StackConfig, TransformerStack, effective_weights
+    from mlx_audio_amd.lm.synthetic import make_stack_weights
+    from oracle.lm_ref import StackRef, dequantize_rows_fp8_ref, quantize_rows_fp8_ref
+
+    rcfg = _variants()[name]
+    w = make_stack_weights(rcfg, seed=13)
+    wq = effective_weights(w, StackConfig(**asdict(rcfg)), "fp8")
+    k0 = "layers.0.wq.weight"
+    assert torch.equal(wq[k0], dequantize_rows_fp8_ref(*quantize_rows_fp8_ref(w[k0].to(torch.bfloat16).float())))  # product packer == restated format
+    ref, ref16 = StackRef(wq, rcfg), StackRef(w, rcfg)
+    g = torch.Generator().manual_seed(17)
+    steps = 7
+    x = torch.randn(B, L + steps, rcfg.d_model, generator=g)
+    prev = ops.fused_step_set(fused)
+    try:
+        eng = TransformerStack(w, StackConfig(**asdict(rcfg)), device=DEV, weight_format="fp8")
+        rc, r16, ec = ref.make_cache(), ref16.make_cache(), eng.make_cache()
+        exp = ref(x[:, :L], rc)
+        ref16(x[:, :L], r16)
+        got = eng(x[:, :L].contiguous().to(DEV), ec)
+        torch.cuda.synchronize()
+        assert rel_err(got, exp) < 2e-4, rel_err(got, exp)
+        for s in range(steps):
+            xs = x[:, L + s:L + s + 1].contiguous()
+            e = ref(xs, rc)
+            e16 = ref16(xs, r16)
+            o = eng(xs.to(DEV), ec)
+            torch.cuda.synchronize()
+            assert rel_err(o, e) < 2e-4, (s, rel_err(o, e))
+        ops.fused_step_check()
+        q_err = rel_err(e, e16)
+        assert 1e-4 < q_err < 0.25, q_err   # fp8 is a different model from bf16 by a bounded amount (and not accidentally the same weights)
+    finally:
+        ops.fused_step_set(prev)

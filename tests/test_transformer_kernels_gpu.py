@@ -415,3 +415,36 @@ def test_whisper_step_forced_and_no_speech(ops):
     assert tkd[:, len(init)].cpu().tolist() == [4321, 99]
     lp = torch.log_softmax(logits.double(), -1)
     np.testing.assert_allclose(sums.cpu().numpy(), [float(lp[0, 4321]), float(lp[1, 99])], rtol=1e-5)
+
+
+@pytest.mark.parametrize("M,N,K,act,use_res,glu", [(1, 1000, 1024, 0, False, False), (8, 514, 2048, 3, True, False), (3, 256, 3072, 0, True, False),
+                                                   (5, 2048, 1040, 0, False, True), (2, 130, 16, 5, False, False), (8, 6144, 2048, 0, False, True)])
+def test_gemv_fp8_weights(ops, M, N, K, act, use_res, glu):
+    """mi355_gemv on an fp8 (OCP e4m3fn, power-of-two row scales) image against float64 on the dequantised weights the oracle restates
+    (oracle/lm_ref.py quantize_rows_fp8_ref): the kernel's byte decode and scale fold are exact, so the bar is the bf16 path's."""
+    from oracle.lm_ref import dequantize_rows_fp8_ref, quantize_rows_fp8_ref
+
+    g = torch.Generator().manual_seed(M * 1000 + N + K)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    w[1] = 0.0
+    bias = torch.randn(N, generator=g) * 0.1
+    x = torch.randn(M, K + 4, generator=g)[:, :K]
+    res = torch.randn(M, N, generator=g) if use_res else None
+    wq = dequantize_rows_fp8_ref(*quantize_rows_fp8_ref(w)).double()
+    v = x.double() @ wq.T + bias.double()
+    if glu:
+        v = F.silu(v[:, 0::2]) * v[:, 1::2]
+    elif act == 3:
+        v = F.gelu(v)
+    elif act == 5:
+        v = F.silu(v)
+    if res is not None:
+        v = v + res.double()
+    rw, wdq = ops.pack_rowmajor_fp8(w, bias, DEV)
+    assert rw.wdtype == 2 and torch.equal(wdq.double(), wq)
+    xd = torch.zeros(M, K + 4, device=DEV)
+    xd[:, :K] = x.to(DEV)
+    y = torch.empty(M, N // 2 if glu else N, device=DEV)
+    ops.gemv(xd[:, :K], rw, y, post_act=act, res=None if res is None else res.to(DEV), glu=glu)
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu(), v) < 5e-6, rel_err(y.cpu(), v)

@@ -28,7 +28,7 @@ def _clone_obj(o):
     return copy.copy(o)
 
 
-def build_deep_stack(cfg, device, seed=0, precision=2):
+def build_deep_stack(cfg, device, seed=0, precision=2, weight_format="bf16"):
     """A TransformerStack of cfg.n_layers layers whose parameters are packed ONCE (one synthetic layer) and then cloned per layer on
     the device: identical values, distinct memory, so every layer streams its own weights from HBM exactly like a real checkpoint
     (host-side random generation + packing of >1e9 parameters would cost minutes of GPU-box time for nothing)."""
@@ -36,17 +36,19 @@ def build_deep_stack(cfg, device, seed=0, precision=2):
     from mlx_audio_amd.lm.synthetic import make_stack_weights
 
     one = dataclasses.replace(cfg, n_layers=1)
-    st = TransformerStack(make_stack_weights(one, seed=seed, gain=0.5), one, device=device, precision=precision)
+    st = TransformerStack(make_stack_weights(one, seed=seed, gain=0.5), one, device=device, precision=precision, weight_format=weight_format)
     st.cfg = cfg
     st.layers = [st.layers[0]] + [_clone_obj(st.layers[0]) for _ in range(cfg.n_layers - 1)]
     return st
 
 
-def stack_weight_bytes(cfg) -> float:
-    """16-bit weight bytes one decode step of the stack streams (q|k|v, o, gate|up or w1, down or w2 of every layer)."""
+def stack_weight_bytes(cfg, bytes_per_weight: float = 2.0) -> float:
+    """Weight bytes one decode step of the stack streams (q|k|v, o, gate|up or w1, down or w2 of every layer): 2 per weight for the 16-bit
+    images, 1 for fp8 (+ 4 per output row of scales)."""
     d, dh = cfg.d_model, cfg.head_dim
     per = (cfg.n_heads + 2 * cfg.n_kv_heads) * dh * d + d * cfg.n_heads * dh + (2 if cfg.mlp == "swiglu" else 1) * cfg.d_ff * d + d * cfg.d_ff
-    return 2.0 * per * cfg.n_layers
+    rows = (cfg.n_heads + 2 * cfg.n_kv_heads) * dh + d + (2 if cfg.mlp == "swiglu" else 1) * cfg.d_ff + d
+    return (bytes_per_weight * per + (4.0 * rows if bytes_per_weight < 2.0 else 0.0)) * cfg.n_layers
 
 
 def host_cores():
@@ -54,3 +56,10 @@ def host_cores():
         return len(os.sched_getaffinity(0))
     except AttributeError:
         return os.cpu_count() or 1
+
+
+def step_runner() -> str:
+    """Which decode-step runner mi355_stack_decode_step dispatches to in this process (mega_step.hip unless MI355_STEP_FUSED=0)."""
+    from mlx_audio_amd import ops
+
+    return "one-launch phase program (mega_step.hip)" if ops.fused_step_enabled() else "multi-launch native runner (stack_step.cpp)"

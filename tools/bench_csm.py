@@ -4,8 +4,9 @@ generation with Mimi RVQ codec decode on one MI355X, synthetic bf16 weights of t
 
 Prints ONE JSON line: value = audio seconds per wall second over (prompt prefill + F frames of generate_frame + Mimi decode); split
 timings; HBM roofline of a frame (16-bit weight bytes of backbone + 31 depth-decoder steps + heads / frame time).  config[4] asks for
-fp8 MFMA GEMMs: at 1 row per step these GEMMs are weight-stream bound GEMVs, measured here on bf16 weights (fp8 weight images are the
-documented next step).  Not the driver's contract line.
+fp8 GEMMs: at 1 row per step these GEMMs are weight-stream bound GEMVs, so ``--weights fp8`` switches every Linear of both stacks and the
+heads to OCP e4m3fn weight images with per-row power-of-two scales (half the bytes per step; fp32 FMA on the exactly decoded weights, the
+prompt prefill runs the same dequantised values through the bf16 MFMA image); default bf16 = the reference's dtype.  Not the driver's contract line.
 """
 import argparse
 import json
@@ -23,7 +24,9 @@ def main():
     ap.add_argument("--prompt", type=int, default=64)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--weights", choices=["bf16", "fp8"], default="bf16")
     args = ap.parse_args()
+    fp8 = args.weights == "fp8"
 
     from mlx_audio_amd.codec.models.mimi import mimi as M
     from mlx_audio_amd.lm.stack import make_lin
@@ -35,8 +38,8 @@ def main():
     tiny = E.tiny_csm()
     eng = E.CSMEngine(E.make_csm_weights(tiny, seed=0), tiny, device=dev)
     eng.cfg = cfg
-    eng.backbone = U.build_deep_stack(cfg.backbone, dev, seed=1)
-    eng.decoder = U.build_deep_stack(cfg.decoder, dev, seed=2)
+    eng.backbone = U.build_deep_stack(cfg.backbone, dev, seed=1, weight_format=args.weights)
+    eng.decoder = U.build_deep_stack(cfg.decoder, dev, seed=2, weight_format=args.weights)
     eng.backbone_cache = eng.backbone.make_cache()
     eng.decoder_cache = eng.decoder.make_cache()
     g = torch.Generator().manual_seed(0)
@@ -45,9 +48,9 @@ def main():
         return (torch.randn(*shape, generator=g) * std).to(torch.bfloat16).to(torch.float32)
 
     D, Dd, V, nb = cfg.backbone.d_model, cfg.decoder.d_model, cfg.audio_vocab_size, cfg.audio_num_codebooks
-    eng.projection = make_lin(rnd(Dd, D, std=1.0 / D ** 0.5), None, dev)
-    eng.c0_head = make_lin(rnd(V, D, std=4.0 / D ** 0.5), None, dev)
-    eng.heads = [make_lin(rnd(V, Dd, std=4.0 / Dd ** 0.5), None, dev) for _ in range(nb - 1)]
+    eng.projection = make_lin(rnd(Dd, D, std=1.0 / D ** 0.5), None, dev, fp8=fp8)
+    eng.c0_head = make_lin(rnd(V, D, std=4.0 / D ** 0.5), None, dev, fp8=fp8)
+    eng.heads = [make_lin(rnd(V, Dd, std=4.0 / Dd ** 0.5), None, dev, fp8=fp8) for _ in range(nb - 1)]
     eng.table = torch.cat([rnd(V * nb, D, std=0.5), rnd(cfg.text_vocab_size, D, std=0.5)], 0).contiguous().to(dev)
     eng.slot_offs = torch.tensor([i * V for i in range(nb)] + [nb * V], dtype=torch.int32, device=dev)
     mcfg = M.mimi_202407(32)
@@ -87,14 +90,16 @@ def main():
     lm_ms = sum(t[0].elapsed_time(t[1]) for t in timers) / args.steps
     dec_ms = sum(t[1].elapsed_time(t[2]) for t in timers) / args.steps
     frame_ms = lm_ms / n
-    wbytes = U.stack_weight_bytes(cfg.backbone) + (nb - 1) * U.stack_weight_bytes(cfg.decoder) + 2.0 * (V * D + (nb - 1) * (V * Dd + Dd * D))
+    bpw = 1.0 if fp8 else 2.0
+    wbytes = U.stack_weight_bytes(cfg.backbone, bpw) + (nb - 1) * U.stack_weight_bytes(cfg.decoder, bpw) + bpw * (V * D + (nb - 1) * (V * Dd + Dd * D))
     res = {
         "metric": "audio seconds generated per second (x real time), CSM-1B generate_frame + Mimi decode, 1 MI355X", "value": B * n * 0.08 * args.steps / dt,
         "unit": "x realtime", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000 * dt / args.steps, "higher_is_better": True,
-        "dtype": "bf16 weights x fp32 activations (GEMV fp32 FMA on bf16 weights)", "data": "synthetic",
+        "dtype": ("fp8 e4m3fn weights (per-row 2^k scales) x fp32 activations (GEMV fp32 FMA on exactly decoded weights)" if fp8 else
+                  "bf16 weights x fp32 activations (GEMV fp32 FMA on bf16 weights)"), "data": "synthetic",
         "config": {"workload": "CSM-1B: prompt %d tokens, %d frames x (backbone step + 31 depth-decoder steps, sampling on device), Mimi decode (32 codebooks)" % (S, n),
-                   "sequences": B, "frames": n, "temperature": 0.0},
-        "split_ms": {"frame_loop": lm_ms, "mimi_decode": dec_ms}, "ms_per_frame": frame_ms, "frames_per_s": B * n / (lm_ms * 1e-3),
+                   "sequences": B, "frames": n, "temperature": 0.0, "weights": args.weights},
+        "step_runner": U.step_runner(), "split_ms": {"frame_loop": lm_ms, "mimi_decode": dec_ms}, "ms_per_frame": frame_ms, "frames_per_s": B * n / (lm_ms * 1e-3),
         "mimi_samples_per_s": B * n * 1920 / (dec_ms * 1e-3),
         "roofline": {"bound": "hbm", "kernel": "gemv_kernel (all decode-step Linear layers of one frame)", "achieved": wbytes / (frame_ms * 1e-3) / 1e9, "peak": 8000.0,
                      "unit": "GB/s", "frac": wbytes / (frame_ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "algorithmic_bytes_per_frame": wbytes,

@@ -103,7 +103,7 @@ def main():
         "higher_is_better": True, "dtype": "bf16 weights x fp32 activations (GEMV fp32 FMA on bf16 weights; bf16 hi+lo MFMA in the codec)", "data": "synthetic",
         "config": {"workload": "Qwen3-TTS-1.7B: prefill %d + %d frames x (talker step + 15 code-predictor steps + sampling on device), then codec decode" % (args.prompt, F),
                    "utterances_per_gpu": B, "frames": F, "temperature": 0.0},
-        "split_ms": {"frame_loop": lm_ms, "codec_decode": dec_ms}, "ms_per_frame": frame_ms, "frames_per_s": B * F / (lm_ms * 1e-3),
+        "step_runner": U.step_runner(), "split_ms": {"frame_loop": lm_ms, "codec_decode": dec_ms}, "ms_per_frame": frame_ms, "frames_per_s": B * F / (lm_ms * 1e-3),
         "codec_samples_per_s": B * F * 1920 / (dec_ms * 1e-3),
         "roofline": {"bound": "hbm", "kernel": "gemv_kernel (all decode-step Linear layers of one frame)", "achieved": wbytes / (frame_ms * 1e-3) / 1e9,
                      "peak": 8000.0, "unit": "GB/s", "frac": wbytes / (frame_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
