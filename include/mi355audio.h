@@ -505,13 +505,17 @@ int mi355_embed_sum(const mi355_embed_sum_args* a, void* stream);
 
 /* Depthwise conv1d (transpose = 0: y[n] = b + sum_k w[c,k] x[n + k - pad]) or depthwise conv_transpose1d (transpose = 1:
  * y[n] = b + sum over t*stride + k - pad == n of w[c,k] x[t]), channels-last, zero outside [0, lens_in[b]).
- * ConvNeXt dwconv k7 of the Qwen3 codec decoder (speech_tokenizer.py ConvNeXtBlock), Mimi's depthwise upsampler (mimi.py:296-320). */
+ * ConvNeXt dwconv k7 of the Qwen3 codec decoder (speech_tokenizer.py ConvNeXtBlock), Mimi's depthwise upsampler (mimi.py:296-320),
+ * SNAC's depthwise convs (codec/models/snac/layers.py:170-181, 209-233). */
 typedef struct {
   const float* x; int64_t x_bstride; int32_t ldx; int32_t Lin; const int32_t* lens_in;
   const float* w;      /* [C, K] */
   const float* bias;   /* [C] nullable */
   int32_t C; int32_t K; int32_t pad; int32_t stride; int32_t transpose; int32_t B;
   float* y; int64_t y_bstride; int32_t ldy; int32_t Lout;
+  /* transpose = 0 only: dilation (0 => 1; tap k reads x[n + k * dil - pad]) and an optional Snake prologue per channel,
+     x -> x + pre_inv[c] * sin(pre_alpha[c] * x)^2 -- the depthwise k7 of SNAC's ResidualUnit (codec/models/snac/layers.py:209-233, 298-306) */
+  int32_t dil; const float* pre_alpha; const float* pre_inv;
 } mi355_dwconv_args;
 int mi355_dwconv(const mi355_dwconv_args* a, void* stream);
 
@@ -583,8 +587,8 @@ int mi355_stack_decode_step(const mi355_stack_desc* d, float* x, int32_t B, int3
 /* The same step as ONE launch: a persistent kernel (one or two workgroups per CU) walks the step's phases -- GEMVs with fused norm / SwiGLU /
  * residual, per-head norm + RoPE, KV-streaming attention, final norm -- separated by grid barriers; activations cross workgroups with
  * write-through system-scope accesses, the phase list is built once per (stack, B) and cached.  mi355_stack_decode_step dispatches here for
- * every stack mi355_stack_fused_eligible accepts unless disabled (environment MI355_STEP_FUSED=0, or mi355_stack_fused_set(0), which returns
- * the previous setting).  The grid barrier's wait is bounded; mi355_stack_fused_check synchronises the stream and fails loudly if a wait was
+ * every stack mi355_stack_fused_eligible accepts ONLY when enabled (environment MI355_STEP_FUSED=1, or mi355_stack_fused_set(1), which returns
+ * the previous setting): parity-green but measured 1.7-2x slower than the multi-launch schedule on MI355X, so it is opt-in.  The grid barrier's wait is bounded; mi355_stack_fused_check synchronises the stream and fails loudly if a wait was
  * ever abandoned.  One step kernel at a time per device (it occupies every CU). */
 int mi355_stack_decode_step_fused(const mi355_stack_desc* d, float* x, int32_t B, int32_t offset, float* ws, float* out, void* stream);
 int mi355_stack_fused_eligible(const mi355_stack_desc* d, int32_t B);

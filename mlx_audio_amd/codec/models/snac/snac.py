@@ -1,0 +1,297 @@
+"""SNAC (multi-scale neural audio codec), decode side (codes -> waveform), on MI355X: host schedule over the HIP kernels.
+
+Mirrors ``mlx_audio/codec/models/snac/snac.py`` + ``layers.py`` + ``vq.py`` (constructor arguments, ``preprocess``, ``decode``, ``decode_stream``,
+``quantizer.from_codes``), with the reference's op-by-op graph collapsed into:
+  * ``ResidualVectorQuantize.from_codes`` (vq.py:116-137): ``out_proj(codebook[code])`` is folded once at load into one
+    ``[n_codebooks * codebook_size, latent_dim]`` table; the coarse levels' ``repeat_interleave(stride)`` becomes an index map, so a frame is ONE
+    ``embed_sum`` launch (rows summed in codebook order like the reference's running sum);
+  * every ``Snake1d`` (layers.py:123-129, 298-306) is the PROLOGUE of the conv that consumes it (alpha and 1 / (alpha + 1e-9) precomputed);
+  * ``WNConv1d`` / ``WNConvTranspose1d`` (layers.py:18-120): weight norm folded at load; dense convs are implicit GEMMs (``conv_gemm``), the
+    transposed convs (K = 2 stride) run polyphase as 2-tap stride-1 GEMMs with a strided store; the depthwise k7 convs of the input stage and of
+    every ``ResidualUnit`` (groups = channels, dilation 1 / 3 / 9) run on ``mi355_dwconv`` with the Snake prologue; residual adds and the final
+    ``tanh`` are epilogues;
+  * ``NoiseBlock`` (layers.py:256-267): ``x + noise * linear(x)`` with the per-sample Gaussian noise either supplied (parity tests) or drawn on
+    the device.
+Reference quirk preserved: ``WNConvTranspose1d`` hands ``groups = 1`` to MLX's ``output_padding`` slot (positional order), so each transposed
+conv emits one extra sample: the reference's test pins 59 / 118 / 236 code frames -> 120 907 samples (codec/tests/test_snac.py:24-34).
+
+``attn_window_size`` must be ``None`` (the 24 kHz model, the one Orpheus-style TTS uses); the ``LocalMHA`` variants raise.  The encoder /
+quantiser-search half (``encode``, ``__call__``) is outside the decode hot path and raises.  Weights: float32 checkpoints are held as fp16 MFMA
+images, activations split fp16 hi + lo (``precision = 4``); deviation from the float32 oracle asserted in ``tests/test_snac_gpu.py``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .... import ops
+from ....ops import ACT_NONE, ACT_SNAKE, ACT_TANH, PackedConv, round_up
+
+
+def make_snac_weights(latent_dim: int, decoder_dim: int, decoder_rates: List[int], vq_strides: List[int], codebook_size: int, codebook_dim: int,
+                      noise: bool = True, depthwise: bool = True, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Random float32 decode-side parameters of the shapes ``SNAC(...)`` allocates (reference module paths, MLX layouts)."""
+    g = torch.Generator().manual_seed(seed)
+    w: Dict[str, torch.Tensor] = {}
+
+    def conv(name, cout, k, cin_g, fan_in, transpose=False, gain=1.0, bias=True):
+        scale = math.sqrt(1 / fan_in)
+        shape = (cin_g, k, cout) if transpose else (cout, k, cin_g)   # transposed convs are stored (in, K, out) (layers.py:92-96)
+        v0 = (torch.rand(shape, generator=g) * 2 - 1) * scale * gain
+        gw = torch.sqrt((v0 ** 2).sum(dim=(1, 2), keepdim=True))
+        w[name + ".weight_g"] = gw * (1.0 + 0.1 * torch.randn(gw.shape, generator=g))
+        w[name + ".weight_v"] = v0 / (gw + 1e-12)
+        if bias:
+            w[name + ".bias"] = 0.02 * torch.randn(cout, generator=g)
+
+    def alpha(name, c):
+        w[name + ".alpha"] = (1.0 + 0.3 * torch.randn(1, c, 1, generator=g)).abs() + 0.05
+
+    n_cb = len(vq_strides)
+    for i in range(n_cb):
+        p = f"quantizer.quantizers.{i}."
+        w[p + "codebook.weight"] = torch.randn(codebook_size, codebook_dim, generator=g)
+        conv(p + "out_proj", latent_dim, 1, codebook_dim, codebook_dim, gain=1.0 / math.sqrt(n_cb))
+    m = "decoder.model.layers."
+    if depthwise:
+        conv(m + "0", latent_dim, 7, 1, 7, gain=1.7)
+        conv(m + "1", decoder_dim, 1, latent_dim, latent_dim, gain=1.7)
+        nxt = 2
+    else:
+        conv(m + "0", decoder_dim, 7, latent_dim, 7 * latent_dim, gain=1.7)
+        nxt = 1
+    out_dim = decoder_dim
+    for i, s in enumerate(decoder_rates):
+        in_dim, out_dim = decoder_dim // 2 ** i, decoder_dim // 2 ** (i + 1)
+        p = f"{m}{nxt + i}.block.layers."
+        alpha(p + "0", in_dim)
+        conv(p + "1", out_dim, 2 * s, in_dim, 2 * s * in_dim, transpose=True, gain=1.7 * math.sqrt(s))
+        j0 = 2
+        if noise:
+            conv(p + "2.linear", out_dim, 1, out_dim, out_dim, gain=0.3, bias=False)
+            j0 = 3
+        for j in range(3):
+            q = p + f"{j0 + j}.block.layers."
+            alpha(q + "0", out_dim)
+            if depthwise:
+                conv(q + "1", out_dim, 7, 1, 7, gain=1.2)
+            else:
+                conv(q + "1", out_dim, 7, out_dim, 7 * out_dim, gain=1.2)
+            alpha(q + "2", out_dim)
+            conv(q + "3", out_dim, 1, out_dim, out_dim, gain=0.5)
+    n = nxt + len(decoder_rates)
+    alpha(f"{m}{n}", out_dim)
+    conv(f"{m}{n + 1}", 1, 7, out_dim, 7 * out_dim, gain=0.3)
+    return w
+
+
+class _Snake:
+    """alpha and 1 / (alpha + 1e-9) (layers.py:123-126), padded to a multiple of 32 channels (conv_gemm / dwconv prologue operands)."""
+
+    def __init__(self, alpha: torch.Tensor, device):
+        a = alpha.reshape(-1).float()
+        cp = round_up(a.numel(), 32)
+        al, ib = torch.ones(cp), torch.zeros(cp)
+        al[: a.numel()] = a
+        ib[: a.numel()] = torch.reciprocal(a + 1e-9)
+        self.alpha, self.inv = al.to(device), ib.to(device)
+
+
+def _wn(w: Dict[str, torch.Tensor], name: str) -> torch.Tensor:
+    v, g = w[name + ".weight_v"].double(), w[name + ".weight_g"].double()
+    return (g * v / torch.sqrt((v ** 2).sum(dim=(1, 2), keepdim=True))).float()
+
+
+class _Quantizer:
+    """``ResidualVectorQuantize`` decode side: ``from_codes`` (vq.py:116-137)."""
+
+    def __init__(self, w: Dict[str, torch.Tensor], vq_strides: List[int], codebook_size: int, device):
+        self.vq_strides, self.codebook_size, self.device = list(vq_strides), codebook_size, device
+        self.n_codebooks = len(vq_strides)
+        tabs = []
+        for i in range(self.n_codebooks):
+            p = f"quantizer.quantizers.{i}."
+            wt = _wn(w, p + "out_proj")[:, 0, :].double()  # [D, d]
+            tabs.append((w[p + "codebook.weight"].double() @ wt.t() + w[p + "out_proj.bias"].double()).float())
+        self.table = torch.cat(tabs, 0).contiguous().to(device)
+        self.offs = torch.tensor([i * codebook_size for i in range(self.n_codebooks)], dtype=torch.int32, device=device)
+        self.latent_dim = self.table.shape[1]
+
+    def from_codes(self, codes: List[torch.Tensor]) -> torch.Tensor:
+        """codes[i] int [B, T / stride_i] -> z_q [B, D, T]."""
+        if len(codes) != self.n_codebooks:
+            raise IndexError(f"from_codes: {len(codes)} code tensors given, the model has {self.n_codebooks} quantizers")
+        cs = [torch.as_tensor(c).to(self.device) for c in codes]
+        T = cs[0].shape[1] * self.vq_strides[0]
+        cols = []
+        for c, s in zip(cs, self.vq_strides):
+            if c.shape[1] * s != T:
+                raise ValueError(f"from_codes: level with stride {s} has {c.shape[1]} frames, expected {T // s}")
+            if int(c.min()) < 0 or int(c.max()) >= self.codebook_size:
+                raise IndexError("from_codes: code out of range")
+            cols.append(torch.repeat_interleave(c.to(torch.int32), s, dim=1) if s > 1 else c.to(torch.int32))
+        ids = torch.stack(cols, dim=-1).contiguous()  # [B, T, n]
+        z = torch.empty((ids.shape[0], T, self.latent_dim), dtype=torch.float32, device=self.device)
+        ops.embed_sum(self.table, ids, z, slot_offset=self.offs)
+        return z.transpose(1, 2)
+
+
+class SNAC:
+    def __init__(self, sampling_rate=44100, encoder_dim=64, encoder_rates=[3, 3, 7, 7], latent_dim=None, decoder_dim=1536,
+                 decoder_rates=[7, 7, 3, 3], attn_window_size=32, codebook_size=4096, codebook_dim=8, vq_strides=[8, 4, 2, 1], noise=True,
+                 depthwise=True, weights: Optional[Dict[str, torch.Tensor]] = None, device="cuda:0", seed: int = 0, **kwargs):
+        """Same arguments as the reference (snac.py:16-31) plus ``weights`` (reference parameter names; omitted: random, like a freshly
+        constructed reference model), ``device``, ``seed``."""
+        ops.require_gpu()
+        if attn_window_size is not None:
+            raise NotImplementedError("SNAC with LocalMHA (attn_window_size != None: the 32 / 44 kHz models) is not built; the 24 kHz model has none")
+        self.sampling_rate, self.encoder_dim, self.encoder_rates = sampling_rate, encoder_dim, list(encoder_rates)
+        self.decoder_dim, self.decoder_rates = decoder_dim, list(decoder_rates)
+        self.latent_dim = encoder_dim * (2 ** len(encoder_rates)) if latent_dim is None else latent_dim
+        self.hop_length = int(np.prod(encoder_rates))
+        self.n_codebooks, self.codebook_size, self.codebook_dim = len(vq_strides), codebook_size, codebook_dim
+        self.vq_strides, self.attn_window_size, self.noise, self.depthwise = list(vq_strides), attn_window_size, noise, depthwise
+        self.device = torch.device(device)
+        if weights is None:
+            weights = make_snac_weights(self.latent_dim, decoder_dim, self.decoder_rates, self.vq_strides, codebook_size, codebook_dim, noise, depthwise, seed)
+        self.load_weights(weights)
+
+    # ------------------------------------------------------------------ load
+    def load_weights(self, weights: Dict[str, torch.Tensor]):
+        dev = self.device
+        w = {k: torch.as_tensor(v).detach().float().cpu() for k, v in weights.items() if k.startswith(("decoder.", "quantizer."))}
+
+        def conv(name) -> PackedConv:
+            return ops.pack_conv(_wn(w, name), w.get(name + ".bias"), dev, f16=True)
+
+        def dw(name) -> Tuple[torch.Tensor, torch.Tensor]:
+            return _wn(w, name)[:, :, 0].contiguous().to(dev), w[name + ".bias"].contiguous().to(dev)  # [C, 7], [C]
+
+        def convT(name, stride) -> PackedConv:
+            # stored (in, K, out), normalised over all axes but 0, handed to MLX as weight.swapaxes(0, 2) = (out, K, in) (layers.py:103-117)
+            return ops.pack_conv_transpose(_wn(w, name).permute(2, 1, 0).contiguous(), w.get(name + ".bias"), stride, dev, f16=True)
+
+        def mid(name):
+            return dw(name) if self.depthwise else conv(name)
+
+        self.quantizer = _Quantizer(w, self.vq_strides, self.codebook_size, dev)
+        m = "decoder.model.layers."
+        if self.depthwise:
+            self.in_dw, self.conv_in, nxt = dw(m + "0"), conv(m + "1"), 2
+        else:
+            self.in_dw, self.conv_in, nxt = None, conv(m + "0"), 1
+        self.blocks = []
+        for i, s in enumerate(self.decoder_rates):
+            p = f"{m}{nxt + i}.block.layers."
+            j0 = 3 if self.noise else 2
+            units = []
+            for j, d in enumerate((1, 3, 9)):
+                q = p + f"{j0 + j}.block.layers."
+                units.append(dict(dil=d, s1=_Snake(w[q + "0.alpha"], dev), c1=mid(q + "1"), s2=_Snake(w[q + "2.alpha"], dev), c2=conv(q + "3")))
+            self.blocks.append(dict(stride=s, snake=_Snake(w[p + "0.alpha"], dev), up=convT(p + "1", s), cout=self.decoder_dim // 2 ** (i + 1),
+                                    noise=conv(p + "2.linear") if self.noise else None, units=units))
+        n = nxt + len(self.decoder_rates)
+        self.out_snake = _Snake(w[f"{m}{n}.alpha"], dev)
+        self.conv_out = conv(f"{m}{n + 1}")
+        return self
+
+    # ------------------------------------------------------------------ reference surface
+    def preprocess(self, audio_data):
+        """snac.py:67-86: right-pad to a multiple of hop_length * lcm(vq_strides)."""
+        audio_data = torch.as_tensor(audio_data)
+        length = audio_data.shape[-1]
+        lcm_value = self.vq_strides[0]
+        for s in self.vq_strides[1:]:
+            lcm_value = abs(lcm_value * s) // math.gcd(lcm_value, s)
+        pad_to = self.hop_length * lcm_value
+        right_pad = math.ceil(length / pad_to) * pad_to - length
+        return torch.nn.functional.pad(audio_data, (0, right_pad))
+
+    def encode(self, audio_data):
+        raise NotImplementedError("SNAC.encode (encoder + codebook search) is outside the decode hot path of this build (SURVEY section 8(f).2)")
+
+    def __call__(self, audio_data):
+        raise NotImplementedError("SNAC.__call__ runs the encoder, which this build does not contain; use decode(codes)")
+
+    def _f(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    def _conv(self, x, sn: Optional[_Snake], pc: PackedConv, y, *, dil=1, res=None, post_act=ACT_NONE):
+        kw = dict(dil=dil, pad=(pc.k - 1) * dil // 2, res=res, post_act=post_act, precision=4)
+        if sn is not None:
+            kw.update(pre_act=ACT_SNAKE, pre_alpha=sn.alpha, pre_inv_beta=sn.inv)
+        return ops.conv_gemm(x, pc, y, **kw)
+
+    def _mid(self, x, sn: _Snake, c, y, dil: int):
+        """Snake + the k7 conv of a ResidualUnit: depthwise kernel or dense implicit GEMM."""
+        if self.depthwise:
+            wk, b = c
+            return ops.dwconv(x, wk, b, y, pad=3 * dil, dil=dil, pre_alpha=sn.alpha, pre_inv=sn.inv)
+        return self._conv(x, sn, c, y, dil=dil)
+
+    def decode_latents(self, z, noises: Optional[List[torch.Tensor]] = None, return_stages: bool = False):
+        """z [B, latent_dim, T] -> audio [B, T', 1] (``self.decoder(z.moveaxis(1, 2))``, snac.py:106).  ``noises[i]`` [B, T_i, 1] replaces
+        DecoderBlock i's ``mx.random.normal((B, 1, T))`` (channels-last); omitted: drawn on the device."""
+        z = torch.as_tensor(z, dtype=torch.float32).to(self.device)
+        x = z.transpose(1, 2).contiguous()
+        B, T, _ = x.shape
+        st = {}
+        if self.in_dw is not None:
+            t0 = self._f(B, T, self.latent_dim)
+            ops.dwconv(x, self.in_dw[0], self.in_dw[1], t0, pad=3)
+            x = t0
+        h = self._f(B, T, self.decoder_dim)
+        self._conv(x, None, self.conv_in, h)
+        st["conv_in"] = h
+        for bi, blk in enumerate(self.blocks):
+            s, cout, taps = blk["stride"], blk["cout"], blk["up"].k
+            p = math.ceil(s / 2)
+            Lin = h.shape[1]
+            Lout = (Lin - 1) * s - 2 * p + 2 * s + 1   # + 1: the reference's groups-as-output_padding slip (module docstring)
+            y = self._f(B, Lout, cout)
+            ops.conv_gemm(h, blk["up"], y, pad=taps - 1, lout=Lin + taps - 1, up=dict(s=s, p=p, cout=cout, lout=Lout), pre_act=ACT_SNAKE,
+                          pre_alpha=blk["snake"].alpha, pre_inv_beta=blk["snake"].inv, precision=4)
+            tmp = torch.empty_like(y)
+            if blk["noise"] is not None:
+                if noises is not None:
+                    nz = torch.as_tensor(noises[bi], dtype=torch.float32).to(self.device)
+                    assert nz.shape == (B, Lout, 1), (nz.shape, (B, Lout, 1))
+                else:
+                    nz = torch.randn((B, Lout, 1), dtype=torch.float32, device=self.device)
+                self._conv(y, None, blk["noise"], tmp)
+                y.addcmul_(nz, tmp)                    # x + noise * linear(x): one elementwise pass over [B, Lout, cout]
+            for u in blk["units"]:
+                self._mid(y, u["s1"], u["c1"], tmp, u["dil"])
+                self._conv(tmp, u["s2"], u["c2"], y, res=y)
+            h = y
+            st[f"block{bi}"] = h
+        out = self._f(B, h.shape[1], 1)
+        self._conv(h, self.out_snake, self.conv_out, out, post_act=ACT_TANH)
+        return (out, st) if return_stages else out
+
+    def decode(self, codes: List[torch.Tensor], noises: Optional[List[torch.Tensor]] = None):
+        """codes[i] int [B, T / vq_strides[i]] -> audio [B, T', 1] (snac.py:104-107)."""
+        return self.decode_latents(self.quantizer.from_codes(codes), noises=noises)
+
+    def decode_stream(self, codes: List[torch.Tensor], prev_codes: Optional[List[torch.Tensor]] = None, context_frames: int = 8):
+        """snac.py:109-165: decode with ``context_frames`` of previous codes in front, return only the new samples + the next context."""
+        codes = [torch.as_tensor(c) for c in codes]
+        new_context = [c[:, -context_frames:] if c.shape[1] > context_frames else c for c in codes]
+        if prev_codes is None:
+            return self.decode(codes), new_context
+        combined = []
+        for i, (prev, new) in enumerate(zip(prev_codes, codes)):
+            layer_context = max(1, context_frames // self.vq_strides[i])
+            prev = torch.as_tensor(prev)
+            if prev.shape[1] > layer_context:
+                prev = prev[:, -layer_context:]
+            combined.append(torch.cat([prev.to(new.device), new], dim=1))
+        full_audio = self.decode(combined)
+        context_samples = context_frames * self.hop_length
+        # the reference slices the LAST axis of the [B, T', 1] decoder output (``full_audio[..., context_samples:]``): with one channel that
+        # axis has length 1, so for context_samples >= 1 it returns the whole signal.  Mirrored as is.
+        new_audio = full_audio[..., context_samples:] if full_audio.shape[-1] > context_samples else full_audio
+        return new_audio, new_context

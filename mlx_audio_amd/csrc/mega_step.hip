@@ -568,8 +568,11 @@ extern "C" int mi355_stack_fused_set(int32_t enabled) {
 extern "C" int mi355_stack_fused_enabled(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (g_enabled < 0) {
+    // Opt-in: measured on MI355X (profiles/r1_decode_runner_ab_call21.txt) the phase program is 1.7-2.0x SLOWER than the multi-launch runner
+    // (CSM-1B 14.8 vs 7.4 ms per frame, Qwen3-TTS-1.7B 17.9 vs 10.8, Whisper-small 3.17 vs 1.68 ms per token step): ~17 us per phase
+    // (grid barrier + 4 waves per CU at 384 registers + scalar write-through stores) against ~7.6 us per launch.
     const char* e = getenv("MI355_STEP_FUSED");
-    g_enabled = (e && e[0] == '0') ? 0 : 1;
+    g_enabled = (e && e[0] == '1') ? 1 : 0;
   }
   return g_enabled;
 }

@@ -41,7 +41,7 @@ int attn_call(const float* q, int ldq, const float* k, const float* v, int64_t k
 
 extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int32_t B, int32_t offset, float* ws, float* out, void* stream) {
   MI355_REQUIRE(dp && x && ws && dp->layers, "stack_decode_step: null argument");
-  // the one-launch runner (mega_step.hip) takes every stack it qualifies for; MI355_STEP_FUSED=0 / mi355_stack_fused_set(0) keeps this schedule
+  // the one-launch runner (mega_step.hip) is opt-in (MI355_STEP_FUSED=1 / mi355_stack_fused_set(1)): measured slower than this schedule
   if (mi355_stack_fused_enabled() && mi355_stack_fused_eligible(dp, B)) return mi355_stack_decode_step_fused(dp, x, B, offset, ws, out, stream);
   const mi355_stack_desc d = *dp;
   MI355_REQUIRE(B >= 1 && B <= 8, "stack_decode_step: 1..8 sequences per step (got %d)", B);

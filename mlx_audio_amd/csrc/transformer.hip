@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void embed_sum_kernel(const mi355_embed_sum_ar
 }
 
 // ---------------------------------------------------------------------------------------------- depthwise conv / convT
-// y[b, t, c] = bias[c] + sum_k w[c, k] * x[b, t*1 + k - pad, c]                      (transpose == 0)
+// y[b, t, c] = bias[c] + sum_k w[c, k] * snake(x[b, t + k*dil - pad, c])               (transpose == 0; snake optional)
 // y[b, n, c] = bias[c] + sum_{t, k: t*stride + k - pad == n} w[c, k] * x[b, t, c]    (transpose == 1)
 __global__ void dwconv_kernel(const mi355_dwconv_args a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -133,9 +133,15 @@ __global__ void dwconv_kernel(const mi355_dwconv_args a) {
   const float* xb = a.x + (int64_t)b * a.x_bstride;
   float acc = a.bias ? a.bias[c] : 0.f;
   if (!a.transpose) {
+    const int dil = a.dil > 0 ? a.dil : 1;
+    const float al = a.pre_alpha ? a.pre_alpha[c] : 0.f, inv = a.pre_alpha ? a.pre_inv[c] : 0.f;
     for (int k = 0; k < a.K; ++k) {
-      const int t = n + k - a.pad;
-      if (t >= 0 && t < len_in) acc = fmaf(a.w[c * a.K + k], xb[(int64_t)t * a.ldx + c], acc);
+      const int t = n + k * dil - a.pad;
+      if (t >= 0 && t < len_in) {
+        float v = xb[(int64_t)t * a.ldx + c];
+        if (a.pre_alpha) { const float sn = sinf(al * v); v = v + inv * (sn * sn); }  // Snake of the input element (zero padding stays zero)
+        acc = fmaf(a.w[c * a.K + k], v, acc);
+      }
     }
   } else {
     for (int k = 0; k < a.K; ++k) {
@@ -203,6 +209,8 @@ extern "C" int mi355_dwconv(const mi355_dwconv_args* ap, void* stream) {
   const mi355_dwconv_args a = *ap;
   MI355_REQUIRE(a.B > 0 && a.Lin > 0 && a.Lout > 0 && a.C > 0 && a.K > 0, "dwconv: bad shape");
   MI355_REQUIRE(!a.transpose || a.stride >= 1, "dwconv: transposed conv needs stride >= 1");
+  MI355_REQUIRE(!a.transpose || (a.dil <= 1 && !a.pre_alpha), "dwconv: dilation / Snake prologue exist for the plain depthwise conv only");
+  MI355_REQUIRE(!a.pre_alpha || a.pre_inv, "dwconv: pre_alpha without pre_inv");
   MI355_CLEAR_ERROR();
   const int64_t n = (int64_t)a.B * a.Lout * a.C;
   hipLaunchKernelGGL(dwconv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);

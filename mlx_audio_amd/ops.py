@@ -440,14 +440,15 @@ def embed_sum(table: torch.Tensor, ids: torch.Tensor, y: torch.Tensor, *, slot_o
 
 
 def dwconv(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], y: torch.Tensor, *, pad: int = 0, stride: int = 1,
-           transpose: bool = False, lens_in=None):
-    """Depthwise conv / conv_transpose, channels-last; ``w`` [C, K] float32."""
+           transpose: bool = False, lens_in=None, dil: int = 1, pre_alpha: Optional[torch.Tensor] = None, pre_inv: Optional[torch.Tensor] = None):
+    """Depthwise conv / conv_transpose, channels-last; ``w`` [C, K] float32.  ``dil`` and the per-channel Snake prologue
+    (``pre_alpha``, ``pre_inv`` = 1 / (alpha + 1e-9), each [>= C]) apply to the plain conv."""
     B, Lin, C, xbs, ldx = _nlc(x)
     _, Lout, _, ybs, ldy = _nlc(y)
     assert w.dim() == 2 and w.shape[0] == C and w.is_contiguous() and w.dtype == torch.float32
     _lib.call_struct("mi355_dwconv", "mi355_dwconv_args", _stream(), x=_ptr(x), x_bstride=xbs, ldx=ldx, Lin=Lin, lens_in=_ptr(lens_in),
                      w=_ptr(w), bias=_ptr(bias), C=C, K=w.shape[1], pad=pad, stride=stride, transpose=int(transpose), B=B, y=_ptr(y),
-                     y_bstride=ybs, ldy=ldy, Lout=Lout)
+                     y_bstride=ybs, ldy=ldy, Lout=Lout, dil=dil, pre_alpha=_ptr(pre_alpha), pre_inv=_ptr(pre_inv))
     return y
 
 

@@ -1,0 +1,109 @@
+"""PyTorch-CPU restatement of the SNAC decode path (TEST ORACLE, not product).
+
+Follows /root/reference/mlx_audio/codec/models/snac statement by statement:
+  * ``layers.py:9-60``      WNConv1d: weight = g * v / ||v|| (norm over all axes but 0), ``mx.conv1d(x, w, stride, padding, dilation, groups)``
+  * ``layers.py:63-120``    WNConvTranspose1d: norm over all axes but 0 of the STORED ``(in, K, out)`` tensor, then
+                            ``mx.conv_transpose1d(x, weight.swapaxes(0, 2), stride, padding, dilation, groups)`` -- MLX's positional order is
+                            (..., dilation, output_padding, groups), so ``groups = 1`` lands in ``output_padding`` (the constructor's own
+                            ``output_padding = stride % 2`` is never used): every transposed conv yields ONE MORE sample than its padding formula
+                            says.  The reference's test pins the result: codes of 59 / 118 / 236 frames -> 120 907 samples
+                            (codec/tests/test_snac.py:24-34 = 236 -> 1889 -> 15113 -> 60453 -> 120907 through strides 8, 8, 4, 2).
+  * ``layers.py:123-129, 298-306``  snake(x, alpha) = x + 1 / (alpha + 1e-9) * sin(alpha x)^2, alpha stored ``[1, C, 1]``
+  * ``layers.py:159-206``   Decoder: (depthwise: conv k7 groups = C, conv k1) | conv k7 -> [LocalMHA: not restated, attn_window_size must be None]
+                            -> DecoderBlocks -> snake -> conv k7 -> tanh
+  * ``layers.py:209-233``   ResidualUnit: snake, conv k7 (dilation d, padding 3 d, groups), snake, conv k1, + x
+  * ``layers.py:256-267``   NoiseBlock: x + noise[B, 1, T] * linear(x)  (1x1 conv, no bias); the Gaussian noise is an explicit input here
+  * ``layers.py:270-295``   DecoderBlock: snake, convT K = 2 s (padding ceil(s / 2)), [NoiseBlock], three units with dilations 1 / 3 / 9
+  * ``vq.py:102-137``       ResidualVectorQuantize.from_codes: codebook lookup, out_proj (1x1 WNConv), repeat_interleave(stride), running sum
+  * ``snac.py:104-107``     SNAC.decode(codes) = decoder(from_codes(codes).moveaxis(1, 2))
+
+Parameter names are the reference's module paths (``decoder.model.layers.N...``, ``quantizer.quantizers.N.codebook.weight`` ...), layouts MLX's
+(conv ``[out, K, in / groups]``, transposed conv stored ``[in, K, out]``).  Arithmetic float32 (float64 on request) on the parameters as given.
+Parity status: **unpinned beyond shapes** (the reference's test holds the length pin above only; tests/test_oracle_golden.py reproduces it).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+def wn_weight(g: Tensor, v: Tensor) -> Tensor:
+    """layers.py:9-15: the norm runs over every axis but 0 -- for BOTH conv types (the transposed conv stores ``(in, K, out)``)."""
+    return g * v / torch.sqrt((v ** 2).sum(dim=(1, 2), keepdim=True))
+
+
+def snake(x: Tensor, alpha: Tensor) -> Tensor:
+    """x [B, T, C]; alpha stored [1, C, 1] (layers.py:301-306 swaps it to [1, 1, C])."""
+    a = alpha.reshape(1, 1, -1)
+    return x + torch.reciprocal(a + 1e-9) * torch.sin(a * x) ** 2
+
+
+class SNACDecoderRef:
+    def __init__(self, weights: Dict[str, Tensor], decoder_rates: List[int], vq_strides: List[int], noise: bool = True, depthwise: bool = True,
+                 dtype=torch.float32):
+        self.w = {k: v.to(dtype) if v.is_floating_point() else v for k, v in weights.items()}
+        self.rates, self.vq_strides, self.noise, self.depthwise, self.dtype = list(decoder_rates), list(vq_strides), noise, depthwise, dtype
+
+    def _conv(self, x: Tensor, name: str, dilation: int = 1, padding: int = 0, groups: int = 1) -> Tensor:
+        w = wn_weight(self.w[name + ".weight_g"], self.w[name + ".weight_v"])  # [out, K, in / groups]
+        return F.conv1d(x.transpose(1, 2), w.permute(0, 2, 1), self.w.get(name + ".bias"), padding=padding, dilation=dilation, groups=groups).transpose(1, 2)
+
+    def _convT(self, x: Tensor, name: str, stride: int) -> Tensor:
+        w = wn_weight(self.w[name + ".weight_g"], self.w[name + ".weight_v"])  # stored [in, K, out] = torch's [in, out, K] permuted
+        return F.conv_transpose1d(x.transpose(1, 2), w.permute(0, 2, 1), self.w.get(name + ".bias"), stride=stride, padding=math.ceil(stride / 2),
+                                  output_padding=1).transpose(1, 2)
+
+    def from_codes(self, codes: List[Tensor]) -> Tensor:
+        """codes[i] int [B, T / stride_i] -> z_q [B, D, T] (vq.py:116-137)."""
+        z = 0.0
+        for i, c in enumerate(codes):
+            p = f"quantizer.quantizers.{i}."
+            e = self.w[p + "codebook.weight"][c.long()]                       # [B, T_i, d]
+            zi = self._conv(e, p + "out_proj")                                 # [B, T_i, D]
+            if self.vq_strides[i] > 1:
+                zi = torch.repeat_interleave(zi, self.vq_strides[i], dim=1)    # expanded[..., j::stride] = z_q_i
+            z = z + zi
+        return z.transpose(1, 2)
+
+    def decode(self, z: Tensor, noises: Optional[List[Tensor]] = None, return_stages: bool = False):
+        """z [B, D, T] -> audio [B, T', 1]; ``noises[i]`` [B, T_i, 1] is DecoderBlock i's ``mx.random.normal((B, 1, T))`` (channels-last here)."""
+        x = z.to(self.dtype).transpose(1, 2)
+        st = {}
+        D = x.shape[-1]
+        m = "decoder.model.layers."
+        if self.depthwise:
+            x = self._conv(x, m + "0", padding=3, groups=D)
+            x = self._conv(x, m + "1")
+            nxt = 2
+        else:
+            x = self._conv(x, m + "0", padding=3)
+            nxt = 1
+        st["conv_in"] = x
+        for i, s in enumerate(self.rates):
+            p = f"{m}{nxt + i}.block.layers."
+            x = snake(x, self.w[p + "0.alpha"])
+            x = self._convT(x, p + "1", s)
+            C = x.shape[-1]
+            j0 = 2
+            if self.noise:
+                w = wn_weight(self.w[p + "2.linear.weight_g"], self.w[p + "2.linear.weight_v"])
+                h = F.conv1d(x.transpose(1, 2), w.permute(0, 2, 1)).transpose(1, 2)
+                x = x + noises[i].to(self.dtype) * h
+                j0 = 3
+            for j, d in enumerate((1, 3, 9)):
+                q = p + f"{j0 + j}.block.layers."
+                y = snake(x, self.w[q + "0.alpha"])
+                y = self._conv(y, q + "1", dilation=d, padding=3 * d, groups=C if self.depthwise else 1)
+                y = snake(y, self.w[q + "2.alpha"])
+                y = self._conv(y, q + "3")
+                x = x + y
+            st[f"block{i}"] = x
+        n = nxt + len(self.rates)
+        x = snake(x, self.w[f"{m}{n}.alpha"])
+        x = torch.tanh(self._conv(x, f"{m}{n + 1}", padding=3))
+        return (x, st) if return_stages else x
