@@ -166,3 +166,27 @@ def test_whisper_dims_golden(golden):
               "n_text_head", "n_text_layer"):
         assert getattr(WHISPER_SMALL, k) == g[k]
     assert (WA.N_SAMPLES, WA.N_FRAMES, WA.HOP_LENGTH, WA.N_FFT) == (g["n_samples"], g["n_frames"], g["hop"], g["n_fft"])
+
+
+def test_snac_decode_length_pin():
+    """codec/tests/test_snac.py:24-34: the 24 kHz model decodes codes of 59 / 118 / 236 frames (vq strides 4 / 2 / 1) to 120 907 samples --
+    each transposed conv emits one sample more than its padding formula (groups lands in MLX's output_padding slot).  Lengths do not depend
+    on the channel width, so the pin runs the restated decoder at a reduced width with the reference test's rates / strides."""
+    from mlx_audio_amd.codec.models.snac.snac import make_snac_weights
+    from oracle.snac_ref import SNACDecoderRef
+
+    rates, strides = [8, 8, 4, 2], [4, 2, 1]
+    w = make_snac_weights(16, 32, rates, strides, 64, 8, noise=True, depthwise=True, seed=0)
+    ref = SNACDecoderRef(w, rates, strides, noise=True, depthwise=True)
+    g = torch.Generator().manual_seed(0)
+    codes = [torch.randint(0, 64, (1, 236 // s), generator=g) for s in strides]
+    assert [tuple(c.shape) for c in codes] == [(1, 59), (1, 118), (1, 236)]
+    z = ref.from_codes(codes)
+    assert tuple(z.shape) == (1, 16, 236)
+    # repeat_interleave of the coarse levels (vq.py:124-135): frames 4k .. 4k+3 share level 0's code
+    lv0 = ref.from_codes([codes[0], torch.zeros_like(codes[1]), torch.zeros_like(codes[2])]) - ref.from_codes([torch.zeros_like(c) for c in codes]) \
+        + ref.from_codes([torch.zeros_like(codes[0]), torch.zeros_like(codes[1]), torch.zeros_like(codes[2])]) * 0
+    assert torch.allclose(lv0[:, :, 0::4], lv0[:, :, 3::4])
+    lens = [1889, 15113, 60453, 120907]
+    y = ref.decode(z, [torch.randn(1, n, 1, generator=g) for n in lens])
+    assert tuple(y.shape) == (1, 120_907, 1) and float(y.abs().max()) <= 1.0
