@@ -445,6 +445,7 @@ typedef struct {
   float* y2; int32_t ldy2; int32_t split;
   /* MI355_W_FP8 only: per-output-row dequantisation scale [N] (required): acc[n] * wscale[n] precedes the bias */
   const float* wscale;
+  int32_t norm_two_reads;  /* set by the library (MI355_GEMV_TWO_READS): compute the fused-norm statistics from a separate read of x; callers leave 0 */
 } mi355_gemv_args;
 int mi355_gemv(const mi355_gemv_args* a, void* stream);
 int mi355_pack_rowmajor16_host(const float* w_host, int64_t n, int32_t dtype, uint16_t* out_host);

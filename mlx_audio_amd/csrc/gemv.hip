@@ -110,39 +110,58 @@ __global__ __launch_bounds__(256) void gemv_kernel(const mi355_gemv_args a) {
   // a separate norm launch writing and re-reading the normalised rows.  Rows of up to 2048 elements are read ONCE into registers (mean, then
   // the centred second moment from the same registers: two-pass numerics, one L2 round trip); longer rows take a second read.
   __shared__ float st_mean[8], st_rstd[8];
-  if (a.norm) {
-    for (int m = wave; m < a.M; m += 4) {
-      const float* xr = a.x + (int64_t)m * a.ldx;
-      float mean = 0.f, q = 0.f;
-      if (a.K <= 2048) {
-        float4 buf[8];
-        float s = 0.f;
+  // single = the whole row fits one staged chunk: the statistics are then computed from the LDS copy inside the staging step -- ONE L2 round
+  // trip for x instead of three (two dependent row reads per wave for the statistics at 8 rows, then the staging read).  Decode-step
+  // launches are bound by exactly this dependent chain, not by bytes (profiles/r1_decode_runner_ab_call21.txt).
+  const bool single = a.norm && a.K <= KC && !a.norm_two_reads;
+  if (a.norm && !single) {
+    // both rows of this wave are in flight before the first reduction (rows m and m + 4: one round trip, not two)
+    const int m0 = wave, m1 = wave + 4;
+    constexpr int NR = MT > 4 ? 2 : 1;  // rows per wave
+    if (a.K <= 2048) {
+      float4 buf[NR][8];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int m = r ? m1 : m0;
+        const float* xr = a.x + (int64_t)(m < a.M ? m : 0) * a.ldx;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int k = lane * 4 + i * 256;
-          buf[i] = k < a.K ? *(const float4*)(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-          s += (buf[i].x + buf[i].y) + (buf[i].z + buf[i].w);
+          buf[r][i] = (m < a.M && k < a.K) ? *(const float4*)(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        mean = a.norm == 1 ? wave_sum(s) / (float)a.K : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int m = r ? m1 : m0;
+        if (m >= a.M) continue;  // wave-uniform
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += (buf[r][i].x + buf[r][i].y) + (buf[r][i].z + buf[r][i].w);
+        const float mean = a.norm == 1 ? wave_sum(s) / (float)a.K : 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           if (lane * 4 + i * 256 < a.K) {
-            const float d0 = buf[i].x - mean, d1 = buf[i].y - mean, d2 = buf[i].z - mean, d3 = buf[i].w - mean;
+            const float d0 = buf[r][i].x - mean, d1 = buf[r][i].y - mean, d2 = buf[r][i].z - mean, d3 = buf[r][i].w - mean;
             q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
           }
         }
-      } else {
-        float s = 0.f;
+        const float var = wave_sum(q) / (float)a.K;
+        if (lane == 0) { st_mean[m] = mean; st_rstd[m] = a.norm == 1 ? 1.0f / sqrtf(var + a.norm_eps) : rsqrtf(var + a.norm_eps); }
+      }
+    } else {
+      for (int m = wave; m < a.M; m += 4) {
+        const float* xr = a.x + (int64_t)m * a.ldx;
+        float s = 0.f, q = 0.f;
         for (int k = lane * 4; k < a.K; k += 256) { const float4 t = *(const float4*)(xr + k); s += (t.x + t.y) + (t.z + t.w); }
-        mean = a.norm == 1 ? wave_sum(s) / (float)a.K : 0.f;
+        const float mean = a.norm == 1 ? wave_sum(s) / (float)a.K : 0.f;
         for (int k = lane * 4; k < a.K; k += 256) {
           const float4 t = *(const float4*)(xr + k);
           const float d0 = t.x - mean, d1 = t.y - mean, d2 = t.z - mean, d3 = t.w - mean;
           q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
+        const float var = wave_sum(q) / (float)a.K;
+        if (lane == 0) { st_mean[m] = mean; st_rstd[m] = a.norm == 1 ? 1.0f / sqrtf(var + a.norm_eps) : rsqrtf(var + a.norm_eps); }
       }
-      const float var = wave_sum(q) / (float)a.K;
-      if (lane == 0) { st_mean[m] = mean; st_rstd[m] = a.norm == 1 ? 1.0f / sqrtf(var + a.norm_eps) : rsqrtf(var + a.norm_eps); }
     }
   }
   for (int base = 0; base < n_it; base += D) {
@@ -170,6 +189,28 @@ __global__ __launch_bounds__(256) void gemv_kernel(const mi355_gemv_args a) {
               if (a.norm && a.norm_weight) wb[i] = *(const float4*)(a.norm_weight + k0 + k);
               if (a.norm && a.norm_bias) bb[i] = *(const float4*)(a.norm_bias + k0 + k);
             }
+          }
+          if (single) {  // raw rows -> LDS, statistics from LDS (same summation order as the register path), then normalise below from tb
+#pragma unroll
+            for (int i = 0; i < NST; ++i) {
+              const int e = tid * 4 + i * 1024;
+              if (e < MT * kc) { const int m = e / kc, k = e - m * kc; *(float4*)(xs + m * KC + k) = tb[i]; }
+            }
+            __syncthreads();
+            for (int m = wave; m < a.M; m += 4) {
+              const float* xr = xs + m * KC;
+              float s = 0.f, q = 0.f;
+              for (int k = lane * 4; k < a.K; k += 256) { const float4 t = *(const float4*)(xr + k); s += (t.x + t.y) + (t.z + t.w); }
+              const float mean = a.norm == 1 ? wave_sum(s) / (float)a.K : 0.f;
+              for (int k = lane * 4; k < a.K; k += 256) {
+                const float4 t = *(const float4*)(xr + k);
+                const float d0 = t.x - mean, d1 = t.y - mean, d2 = t.z - mean, d3 = t.w - mean;
+                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+              }
+              const float var = wave_sum(q) / (float)a.K;
+              if (lane == 0) { st_mean[m] = mean; st_rstd[m] = a.norm == 1 ? 1.0f / sqrtf(var + a.norm_eps) : rsqrtf(var + a.norm_eps); }
+            }
+            __syncthreads();
           }
 #pragma unroll
           for (int i = 0; i < NST; ++i) {
@@ -373,6 +414,8 @@ extern "C" int mi355_gemv(const mi355_gemv_args* ap, void* stream) {
                 "gemv: norm weight / bias must be 16-byte aligned");
   MI355_REQUIRE(!a.y2 || (a.split > 0 && a.split < a.N), "gemv: split must be inside (0, N) when y2 is given");
   if (a.out_scale == 0.f) a.out_scale = 1.f;
+  static const bool two_reads = getenv("MI355_GEMV_TWO_READS") != nullptr;  // A/B knob: statistics from a separate read of x (the older schedule)
+  a.norm_two_reads = two_reads ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   if (a.wdtype == MI355_W_FP8) return launch_gemv_m<MI355_W_FP8>(a, st);
   return a.wdtype == MI355_W_F16 ? launch_gemv_m<MI355_W_F16>(a, st) : launch_gemv_m<MI355_W_BF16>(a, st);
