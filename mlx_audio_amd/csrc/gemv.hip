@@ -72,7 +72,7 @@ __device__ __forceinline__ void gemv_finish(const mi355_gemv_args& a, float (&ac
 }
 
 template <int MT, int NC, int WT>
-__global__ __launch_bounds__(256) void gemv_kernel(const mi355_gemv_args a) {
+__global__ __launch_bounds__(256, (MT >= 8 && NC == 2 && WT != MI355_W_FP8) ? 3 : 1) void gemv_kernel(const mi355_gemv_args a) {
   constexpr int EPL = mi355_wt<WT>::EPL;                         // weight elements per 16-byte lane piece (8, or 16 for fp8)
   constexpr int ESZ = 16 / EPL;                                  // bytes per weight element
   constexpr int SL = 64 * EPL;                                   // elements per k-slice (one 1 KB wave load per column)
@@ -173,28 +173,31 @@ __global__ __launch_bounds__(256) void gemv_kernel(const mi355_gemv_args a) {
         const int k0 = (it / IPC) * KC;
         const int kc = a.K - k0 < KC ? a.K - k0 : KC;  // multiple of 8 (K % 8 == 0)
         __syncthreads();
-        {  // all of this thread's loads of the chunk go out before the first one is consumed (a rolled load -> store loop serialises
-           // one L2 latency per iteration: 8 of them for 8 rows)
-          constexpr int NST = MT * KC / 1024;
-          float4 tb[NST], wb[NST], bb[NST];
+        {  // all of this thread's loads of the chunk go out before the first one is consumed (a rolled load -> store loop serialises one
+           // L2 latency per iteration).  A thread owns KQ column positions (k = tid * 4 + j * 1024) of EVERY row: the norm weight / bias of a
+           // column is loaded once for all rows (8 + 1 + 1 float4 at 8 rows instead of 8 + 8 + 8: the staging no longer sets the register
+           // count, and the register count sets how many workgroups a CU keeps in flight across these latency-bound phases).
+          constexpr int KQ = KC / 1024;
+          float4 tb[KQ][MT], wb[KQ], bb[KQ];
 #pragma unroll
-          for (int i = 0; i < NST; ++i) {
-            const int e = tid * 4 + i * 1024;
-            const int m = e / kc, k = e - m * kc;
-            tb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            wb[i] = make_float4(1.f, 1.f, 1.f, 1.f);
-            bb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < MT * kc && m < a.M) {
-              tb[i] = *(const float4*)(a.x + (int64_t)m * a.ldx + k0 + k);
-              if (a.norm && a.norm_weight) wb[i] = *(const float4*)(a.norm_weight + k0 + k);
-              if (a.norm && a.norm_bias) bb[i] = *(const float4*)(a.norm_bias + k0 + k);
-            }
+          for (int j = 0; j < KQ; ++j) {
+            const int k = tid * 4 + j * 1024;
+            wb[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+            bb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < kc && a.norm && a.norm_weight) wb[j] = *(const float4*)(a.norm_weight + k0 + k);
+            if (k < kc && a.norm && a.norm_bias) bb[j] = *(const float4*)(a.norm_bias + k0 + k);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+              tb[j][m] = (k < kc && m < a.M) ? *(const float4*)(a.x + (int64_t)m * a.ldx + k0 + k) : make_float4(0.f, 0.f, 0.f, 0.f);
           }
           if (single) {  // raw rows -> LDS, statistics from LDS (same summation order as the register path), then normalise below from tb
 #pragma unroll
-            for (int i = 0; i < NST; ++i) {
-              const int e = tid * 4 + i * 1024;
-              if (e < MT * kc) { const int m = e / kc, k = e - m * kc; *(float4*)(xs + m * KC + k) = tb[i]; }
+            for (int j = 0; j < KQ; ++j) {
+              const int k = tid * 4 + j * 1024;
+              if (k < kc) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) *(float4*)(xs + m * KC + k) = tb[j][m];
+              }
             }
             __syncthreads();
             for (int m = wave; m < a.M; m += 4) {
@@ -213,17 +216,19 @@ __global__ __launch_bounds__(256) void gemv_kernel(const mi355_gemv_args a) {
             __syncthreads();
           }
 #pragma unroll
-          for (int i = 0; i < NST; ++i) {
-            const int e = tid * 4 + i * 1024;
-            if (e < MT * kc) {
-              const int m = e / kc, k = e - m * kc;
-              float4 t = tb[i];
-              if (a.norm && m < a.M) {
-                const float mu = st_mean[m], rs = st_rstd[m];
-                t = make_float4((t.x - mu) * rs * wb[i].x + bb[i].x, (t.y - mu) * rs * wb[i].y + bb[i].y, (t.z - mu) * rs * wb[i].z + bb[i].z,
-                                (t.w - mu) * rs * wb[i].w + bb[i].w);
+          for (int j = 0; j < KQ; ++j) {
+            const int k = tid * 4 + j * 1024;
+            if (k < kc) {
+#pragma unroll
+              for (int m = 0; m < MT; ++m) {
+                float4 t = tb[j][m];
+                if (a.norm && m < a.M) {
+                  const float mu = st_mean[m], rs = st_rstd[m];
+                  t = make_float4((t.x - mu) * rs * wb[j].x + bb[j].x, (t.y - mu) * rs * wb[j].y + bb[j].y, (t.z - mu) * rs * wb[j].z + bb[j].z,
+                                  (t.w - mu) * rs * wb[j].w + bb[j].w);
+                }
+                *(float4*)(xs + m * KC + k) = t;
               }
-              *(float4*)(xs + m * KC + k) = t;
             }
           }
         }
@@ -357,7 +362,8 @@ template <int MT, int WT>
 int launch_gemv(const mi355_gemv_args& a, hipStream_t st) {
   // one column per wave keeps the most wavefronts (and weight bytes) in flight; two columns per wave halve the LDS reads of x per weight
   // byte, which is what binds at 8 rows (16 LDS bytes per weight byte at NC = 1) and for very wide outputs
-  const int nc = (a.glu || MT >= 8 || a.N >= 16384) ? 2 : 1;
+  static const int nc_env = getenv("MI355_GEMV_NC") ? atoi(getenv("MI355_GEMV_NC")) : 0;  // A/B knob (1 | 2); SwiGLU pairs always need 2
+  const int nc = a.glu ? 2 : (nc_env == 1 || nc_env == 2) ? nc_env : ((MT >= 8 || a.N >= 16384) ? 2 : 1);
   if constexpr (MT >= 4) {
     const size_t lds = (size_t)MT * a.K * sizeof(float);
     // Measured (profiles/r1_kernel_stats_qwen3_1p7b_b8_v4_resident.txt): 22.0 us vs 18.9 us per launch for the chunked kernel at M = 8 -- these
