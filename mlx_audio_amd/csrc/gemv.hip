@@ -404,6 +404,10 @@ int launch_gemv_m(const mi355_gemv_args& a, hipStream_t st) {
 
 }  // namespace
 
+// gemv_mfma.hip: the matrix-pipe kernel for 5..8 rows
+int mi355_gemv_mfma_eligible(const mi355_gemv_args& a);
+int mi355_gemv_mfma_launch(const mi355_gemv_args& a, hipStream_t st);
+
 extern "C" int mi355_gemv(const mi355_gemv_args* ap, void* stream) {
   MI355_REQUIRE(ap && ap->x && ap->w && ap->y, "gemv: null tensor");
   mi355_gemv_args a = *ap;
@@ -423,6 +427,7 @@ extern "C" int mi355_gemv(const mi355_gemv_args* ap, void* stream) {
   static const bool two_reads = getenv("MI355_GEMV_TWO_READS") != nullptr;  // A/B knob: statistics from a separate read of x (the older schedule)
   a.norm_two_reads = two_reads ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
+  if (mi355_gemv_mfma_eligible(a)) return mi355_gemv_mfma_launch(a, st);
   if (a.wdtype == MI355_W_FP8) return launch_gemv_m<MI355_W_FP8>(a, st);
   return a.wdtype == MI355_W_F16 ? launch_gemv_m<MI355_W_F16>(a, st) : launch_gemv_m<MI355_W_BF16>(a, st);
 }

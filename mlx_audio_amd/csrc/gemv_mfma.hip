@@ -1,0 +1,267 @@
+// Skinny GEMM for 5..8 rows per decode step on the matrix pipe (gfx950): y[m, n] = epilogue(sum_k norm(x)[m, k] * W[n, k]).
+//
+// Same contract as mi355_gemv (gemv.hip; replaces nn.Linear at sequence length 1 for batches of 5..8 sequences: Whisper TextDecoder
+// stt/models/whisper/whisper.py:347-416, 498; Qwen3-TTS talker / code predictor tts/models/qwen3_tts/talker.py:230-330, 503-764).  The FMA
+// kernel does 8 fp32 FMAs per weight element at 8 rows and ran the weight stream at ~1 TB/s against ~3.7 TB/s at 1 row: its waves sit in
+// VALU / LDS work and latency-bound staging instead of keeping loads in flight (profiles/r1_gemv_launch_periods_call25.txt).  Here the products
+// go to v_mfma_f32_16x16x32 (bf16 or fp16, the weights' own type):
+//   * A operand = a 16-row tile of W, straight from HBM: lane (i = lane & 15, g = lane >> 4) loads the 32 contiguous bytes W[n0 + i][k0 + 16 g ..
+//     + 16) of a 64-wide k step -- full 128-byte lines per row, no conversion, no LDS -- and feeds its two 16-byte halves to two MFMAs (the
+//     contraction index of an MFMA is a free relabelling as long as A and B agree: half h of group g carries k = k0 + 16 g + 8 h + e);
+//   * B operand = the (normalised) input rows, split ONCE per workgroup into hi + lo images of the weights' 16-bit type (about 16 mantissa bits
+//     for bf16 -- the same split conv_gemm runs prefill with -- and 22 for fp16) and laid out in LDS in fragment order
+//     [k step][half][group][row] x 16 bytes, so every ds_read_b128 of a wave covers 512 contiguous bytes: conflict-free;
+//   * the four waves of a workgroup take interleaved k steps of ONE 16-column tile (split-K: N / 16 workgroups x 4 waves keep enough loads in
+//     flight even for N = 1024) and add their 16 x 16 partial tiles through LDS; thread (n = t & 15, m = t >> 4) finishes one output: bias,
+//     activation, LayerScale, residual, SwiGLU pairs, split destinations (q -> buffer, k | v -> KV-cache slot);
+//   * fused LayerNorm / RMSNorm: statistics from the registers the staging loads already hold (one read of x), two-pass numerics.
+// Rows m >= M of the 16-wide MFMA column space alias rows m & 7: their outputs are never read.
+#include <stdlib.h>
+#include "common.h"
+
+namespace {
+
+constexpr int kKC = 2048;   // input columns staged per chunk: 2 images x 8 rows x 2 bytes x kKC = 64 KB of LDS
+constexpr int kD = 4;       // weight prefetch depth in k steps (4 x 32 bytes per lane = 8 KB per wave in flight)
+
+__device__ __forceinline__ float mfma_act(float v, int act, float slope) {
+  switch (act) {
+    case MI355_ACT_LEAKY: return v > 0.f ? v : v * slope;
+    case MI355_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    case MI355_ACT_SILU: return v / (1.0f + expf(-v));
+    case MI355_ACT_GELU_TANH: return 0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v)));
+    case MI355_ACT_ELU: return v > 0.f ? v : expm1f(v);
+    case MI355_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+// hi + lo images of two fp32 values (low half = first value)
+template <bool F16>
+__device__ __forceinline__ void split2(const float a, const float b, uint32_t& hi, uint32_t& lo) {
+  if constexpr (F16) {
+    hi = pack_f16x2(a, b);
+    const float ha = (float)__builtin_bit_cast(_Float16, (uint16_t)(hi & 0xffffu)), hb = (float)__builtin_bit_cast(_Float16, (uint16_t)(hi >> 16));
+    lo = pack_f16x2(a - ha, b - hb);
+  } else {
+    hi = pack_bf16x2(a, b);
+    const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+    lo = pack_bf16x2(a - ha, b - hb);
+  }
+}
+
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma_16(const uint4 a, const uint4 b, const f32x4 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <bool F16>
+__global__ __launch_bounds__(256) void gemv_mfma_kernel(const mi355_gemv_args a) {
+  extern __shared__ __attribute__((aligned(16))) uint4 planes[];  // [2 images][steps of the chunk][2 halves][4 groups][8 rows] 16-byte pieces
+  __shared__ float red[4][256];
+  __shared__ float st_part[4][8];
+  __shared__ float st_rstd[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * 16;
+  const int K = a.K, M = a.M;
+  const int KC = K < kKC ? K : kKC;            // multiple of 64
+  const int img = KC * 8 / 8;                  // 16-byte pieces per image: 8 rows x KC / 8
+  const int steps_total = K >> 6;
+  const int gi = lane >> 4, li = lane & 15;    // MFMA k group / row of W (A) resp. column = input row (B)
+  const int nrow = n0 + li < a.N ? n0 + li : a.N - 1;   // tail tile: clamped rows recompute the last row, never stored
+  const uint16_t* wrow = a.w + (int64_t)nrow * a.ldw + 16 * gi;
+
+  // ---- weight stream: this wave's k steps are wave, wave + 4, ... ; kD of them are always in flight, issued before x is even staged
+  uint4 ring[kD][2];
+  auto issue = [&](const int s, uint4 (&dst)[2]) {
+    const uint16_t* p = wrow + ((int64_t)s << 6);
+    dst[0] = *(const uint4*)p;
+    dst[1] = *(const uint4*)(p + 8);
+  };
+#pragma unroll
+  for (int d = 0; d < kD; ++d)
+    if (wave + 4 * d < steps_total) issue(wave + 4 * d, ring[d]);
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int it = 0;  // index of this wave's next step: s = wave + 4 * it
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    const int kc = K - k0 < KC ? K - k0 : KC;  // multiple of 64
+    // ---- stage the chunk: thread t owns the 8-column groups q = t, t + 256, ... of EVERY row (norm weight / bias loaded once per column)
+    __syncthreads();  // the previous chunk's readers are done
+    {
+      constexpr int NQ = kKC / 8 / 256;  // 1
+      float4 xa[NQ][8], xb[NQ][8], wa[NQ], wb2[NQ], ba[NQ], bb2[NQ];
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const int q = tid + 256 * j, k = q * 8;
+        wa[j] = wb2[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+        ba[j] = bb2[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < kc && a.norm && a.norm_weight) { wa[j] = *(const float4*)(a.norm_weight + k0 + k); wb2[j] = *(const float4*)(a.norm_weight + k0 + k + 4); }
+        if (k < kc && a.norm && a.norm_bias) { ba[j] = *(const float4*)(a.norm_bias + k0 + k); bb2[j] = *(const float4*)(a.norm_bias + k0 + k + 4); }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          xa[j][m] = xb[j][m] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (k < kc && m < M) {
+            const float* p = a.x + (int64_t)m * a.ldx + k0 + k;
+            xa[j][m] = *(const float4*)p;
+            xb[j][m] = *(const float4*)(p + 4);
+          }
+        }
+      }
+      if (a.norm) {  // whole rows are in this chunk (host-side eligibility: K <= kKC): two-pass statistics from the registers
+        float s[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          s[m] = 0.f;
+#pragma unroll
+          for (int j = 0; j < NQ; ++j) s[m] += ((xa[j][m].x + xa[j][m].y) + (xa[j][m].z + xa[j][m].w)) + ((xb[j][m].x + xb[j][m].y) + (xb[j][m].z + xb[j][m].w));
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) s[m] = wave_sum(s[m]);
+        if (lane < 8) {
+          float v = s[0];
+#pragma unroll
+          for (int m = 1; m < 8; ++m) v = lane == m ? s[m] : v;
+          st_part[wave][lane] = v;
+        }
+        __syncthreads();
+        float mean[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) mean[m] = a.norm == 1 ? ((st_part[0][m] + st_part[1][m]) + (st_part[2][m] + st_part[3][m])) / (float)K : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          float qv = 0.f;
+#pragma unroll
+          for (int j = 0; j < NQ; ++j) {
+            if ((tid + 256 * j) * 8 < kc) {
+              const float d0 = xa[j][m].x - mean[m], d1 = xa[j][m].y - mean[m], d2 = xa[j][m].z - mean[m], d3 = xa[j][m].w - mean[m];
+              const float d4 = xb[j][m].x - mean[m], d5 = xb[j][m].y - mean[m], d6 = xb[j][m].z - mean[m], d7 = xb[j][m].w - mean[m];
+              qv += ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7));
+            }
+          }
+          s[m] = wave_sum(qv);
+        }
+        if (lane < 8) {
+          float v = s[0];
+#pragma unroll
+          for (int m = 1; m < 8; ++m) v = lane == m ? s[m] : v;
+          st_part[wave][lane] = v;
+        }
+        __syncthreads();
+        if (tid < 8) {
+          const float var = ((st_part[0][tid] + st_part[1][tid]) + (st_part[2][tid] + st_part[3][tid])) / (float)K;
+          st_rstd[tid] = a.norm == 1 ? 1.0f / sqrtf(var + a.norm_eps) : rsqrtf(var + a.norm_eps);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const float mu = mean[m], rs = st_rstd[m];
+#pragma unroll
+          for (int j = 0; j < NQ; ++j) {
+            xa[j][m] = make_float4((xa[j][m].x - mu) * rs * wa[j].x + ba[j].x, (xa[j][m].y - mu) * rs * wa[j].y + ba[j].y,
+                                   (xa[j][m].z - mu) * rs * wa[j].z + ba[j].z, (xa[j][m].w - mu) * rs * wa[j].w + ba[j].w);
+            xb[j][m] = make_float4((xb[j][m].x - mu) * rs * wb2[j].x + bb2[j].x, (xb[j][m].y - mu) * rs * wb2[j].y + bb2[j].y,
+                                   (xb[j][m].z - mu) * rs * wb2[j].z + bb2[j].z, (xb[j][m].w - mu) * rs * wb2[j].w + bb2[j].w);
+          }
+        }
+      }
+      // hi / lo images in fragment order: piece (step, half, group, row) = ((step * 2 + half) * 4 + group) * 8 + row
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const int q = tid + 256 * j;
+        if (q * 8 < kc) {
+          const int step = q >> 3, r = q & 7, g = r >> 1, h = r & 1;
+          const int base = ((step * 2 + h) * 4 + g) * 8;
+#pragma unroll
+          for (int m = 0; m < 8; ++m) {
+            uint4 hi, lo;
+            split2<F16>(xa[j][m].x, xa[j][m].y, hi.x, lo.x);
+            split2<F16>(xa[j][m].z, xa[j][m].w, hi.y, lo.y);
+            split2<F16>(xb[j][m].x, xb[j][m].y, hi.z, lo.z);
+            split2<F16>(xb[j][m].z, xb[j][m].w, hi.w, lo.w);
+            planes[base + m] = hi;
+            planes[img + base + m] = lo;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- this wave's k steps inside the chunk
+    const int s_end = (k0 + kc) >> 6;
+    for (;;) {
+      const int s = wave + 4 * it;
+      if (s >= s_end) break;
+      const int slot = it % kD;
+      uint4 w0, w1;
+      // static ring indexing (registers cannot be indexed dynamically): four unrolled cases
+      if (slot == 0) { w0 = ring[0][0]; w1 = ring[0][1]; if (s + 4 * kD < steps_total) issue(s + 4 * kD, ring[0]); }
+      else if (slot == 1) { w0 = ring[1][0]; w1 = ring[1][1]; if (s + 4 * kD < steps_total) issue(s + 4 * kD, ring[1]); }
+      else if (slot == 2) { w0 = ring[2][0]; w1 = ring[2][1]; if (s + 4 * kD < steps_total) issue(s + 4 * kD, ring[2]); }
+      else { w0 = ring[3][0]; w1 = ring[3][1]; if (s + 4 * kD < steps_total) issue(s + 4 * kD, ring[3]); }
+      const int ls = s - (k0 >> 6);                       // step inside the chunk
+      const int p0 = ((ls * 2 + 0) * 4 + gi) * 8 + (li & 7);
+      const int p1 = ((ls * 2 + 1) * 4 + gi) * 8 + (li & 7);
+      const uint4 h0 = planes[p0], h1 = planes[p1], l0 = planes[img + p0], l1 = planes[img + p1];
+      acc = mfma_16<F16>(w0, h0, acc);
+      acc = mfma_16<F16>(w1, h1, acc);
+      acc = mfma_16<F16>(w0, l0, acc);
+      acc = mfma_16<F16>(w1, l1, acc);
+      ++it;
+    }
+  }
+  // ---- split-K: the four waves' 16 x 16 partial tiles through LDS.  D layout: lane holds column (lane & 15) = input row m, rows 4 (lane >> 4) + r = n
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave][(4 * gi + r) * 16 + li] = acc[r];
+  __syncthreads();
+  const int i = tid & 15, m = tid >> 4;  // consecutive threads -> consecutive output columns n of one input row m
+  const int n = n0 + i;
+  if (m >= M || n >= a.N) return;
+  const float v0 = (red[0][i * 16 + m] + red[1][i * 16 + m]) + (red[2][i * 16 + m] + red[3][i * 16 + m]);
+  if (a.glu) {  // rows come in (gate, up) pairs: the even thread of a pair finishes both
+    if (i & 1) return;
+    const float v1 = (red[0][(i + 1) * 16 + m] + red[1][(i + 1) * 16 + m]) + (red[2][(i + 1) * 16 + m] + red[3][(i + 1) * 16 + m]);
+    const float g = v0 + (a.bias ? a.bias[n] : 0.f), u = v1 + (a.bias ? a.bias[n + 1] : 0.f);
+    a.y[(int64_t)m * a.ldy + (n >> 1)] = (g / (1.0f + expf(-g))) * u * a.out_scale;
+    return;
+  }
+  float v = mfma_act(v0 + (a.bias ? a.bias[n] : 0.f), a.post_act, a.post_slope) * (a.colscale ? a.colscale[n] : 1.f);
+  if (a.res) v += a.res[(int64_t)m * a.ldr + n];
+  if (a.y2 && n >= a.split) a.y2[(int64_t)m * a.ldy2 + (n - a.split)] = v * a.out_scale;
+  else a.y[(int64_t)m * a.ldy + n] = v * a.out_scale;
+}
+
+}  // namespace
+
+// 1 = this call qualifies for the matrix-pipe kernel (mi355_gemv dispatches here unless MI355_GEMV_MFMA=0)
+int mi355_gemv_mfma_eligible(const mi355_gemv_args& a) {
+  static const bool off = getenv("MI355_GEMV_MFMA") != nullptr && getenv("MI355_GEMV_MFMA")[0] == '0';
+  if (off) return 0;
+  if (a.M < 5 || a.M > 8) return 0;
+  if (a.wdtype != MI355_W_BF16 && a.wdtype != MI355_W_F16) return 0;
+  if (a.K % 64 || a.K < 64 || a.ldw % 8 || ((uintptr_t)a.w) % 16 || a.ldx % 4 || ((uintptr_t)a.x) % 16) return 0;
+  if (a.norm && a.K > kKC) return 0;
+  if (a.glu && (a.N % 2)) return 0;
+  return 1;
+}
+
+int mi355_gemv_mfma_launch(const mi355_gemv_args& a, hipStream_t st) {
+  static bool attr_set[2] = {false, false};  // benign race: the attribute is idempotent
+  const bool f16 = a.wdtype == MI355_W_F16;
+  const size_t lds = (size_t)(a.K < kKC ? a.K : kKC) * 32;
+  if (!attr_set[f16]) {
+    hipError_t e = f16 ? hipFuncSetAttribute((const void*)gemv_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kKC * 32)
+                       : hipFuncSetAttribute((const void*)gemv_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kKC * 32);
+    MI355_REQUIRE(e == hipSuccess, "gemv(mfma): cannot reserve LDS: %s", hipGetErrorString(e));
+    attr_set[f16] = true;
+  }
+  MI355_CLEAR_ERROR();
+  const dim3 grid((a.N + 15) / 16);
+  if (f16) hipLaunchKernelGGL(gemv_mfma_kernel<true>, grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(gemv_mfma_kernel<false>, grid, dim3(256), lds, st, a);
+  MI355_LAUNCH_CHECK("gemv(mfma)");
+  return MI355_OK;
+}

@@ -282,9 +282,12 @@ def test_fused_step_runner_matches_multi_launch(ops, name, B, L):
             om = eng_m(xs.to(DEV), mc)
             torch.cuda.synchronize()
             assert rel_err(of, e) < 2e-4, (s, rel_err(of, e))
-            assert rel_err(of, om) < 3e-6, (s, rel_err(of, om))
+            # 5..8 sequences: the multi-launch runner's Linear layers run on the matrix pipe (gemv_mfma.hip, hi + lo split of the input rows,
+            # ~16 mantissa bits) while the phase program keeps fp32 FMAs, so the two agree to the split's precision instead of rounding order
+            assert rel_err(of, om) < (1e-4 if B >= 5 else 3e-6), (s, rel_err(of, om))
         ops.fused_step_check()
-        assert torch.allclose(fc[0].kv[:, : L + steps], mc[0].kv[:, : L + steps], rtol=1e-5, atol=1e-6)
+        kv_tol = dict(rtol=1e-3, atol=1e-4) if B >= 5 else dict(rtol=1e-5, atol=1e-6)
+        assert torch.allclose(fc[0].kv[:, : L + steps], mc[0].kv[:, : L + steps], **kv_tol)
     finally:
         ops.fused_step_set(prev)
 
