@@ -22,7 +22,7 @@
 namespace {
 
 constexpr int kKC = 2048;   // input columns staged per chunk: 2 images x 8 rows x 2 bytes x kKC = 64 KB of LDS
-constexpr int kD = 4;       // weight prefetch depth in k steps (4 x 32 bytes per lane = 8 KB per wave in flight)
+constexpr int kD = 8;       // weight prefetch depth in k steps (8 x 32 bytes per lane = 16 KB per wave in flight: a whole K = 2048 slice)
 
 __device__ __forceinline__ float mfma_act(float v, int act, float slope) {
   switch (act) {
@@ -197,11 +197,15 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const mi355_gemv_args a)
       if (s >= s_end) break;
       const int slot = it % kD;
       uint4 w0, w1;
-      // static ring indexing (registers cannot be indexed dynamically): four unrolled cases
-      if (slot == 0) { w0 = ring[0][0]; w1 = ring[0][1]; if (s + 4 * kD < steps_total) issue(s + 4 * kD, ring[0]); }
-      else if (slot == 1) { w0 = ring[1][0]; w1 = ring[1][1]; if (s + 4 * kD < steps_total) issue(s + 4 * kD, ring[1]); }
-      else if (slot == 2) { w0 = ring[2][0]; w1 = ring[2][1]; if (s + 4 * kD < steps_total) issue(s + 4 * kD, ring[2]); }
-      else { w0 = ring[3][0]; w1 = ring[3][1]; if (s + 4 * kD < steps_total) issue(s + 4 * kD, ring[3]); }
+      // static ring indexing (registers cannot be indexed dynamically): one unrolled case per slot
+#pragma unroll
+      for (int d = 0; d < kD; ++d) {
+        if (slot == d) {
+          w0 = ring[d][0];
+          w1 = ring[d][1];
+          if (s + 4 * kD < steps_total) issue(s + 4 * kD, ring[d]);
+        }
+      }
       const int ls = s - (k0 >> 6);                       // step inside the chunk
       const int p0 = ((ls * 2 + 0) * 4 + gi) * 8 + (li & 7);
       const int p1 = ((ls * 2 + 1) * 4 + gi) * 8 + (li & 7);
@@ -243,7 +247,7 @@ int mi355_gemv_mfma_eligible(const mi355_gemv_args& a) {
   if (a.M < 5 || a.M > 8) return 0;
   if (a.wdtype != MI355_W_BF16 && a.wdtype != MI355_W_F16) return 0;
   if (a.K % 64 || a.K < 64 || a.ldw % 8 || ((uintptr_t)a.w) % 16 || a.ldx % 4 || ((uintptr_t)a.x) % 16) return 0;
-  if (a.norm && a.K > kKC) return 0;
+  if (a.K > kKC) return 0;   // one staged chunk only: the chunk loop's workgroup barriers cost more than they save (K = 6144: 25 vs 15 us, call 26)
   if (a.glu && (a.N % 2)) return 0;
   return 1;
 }
