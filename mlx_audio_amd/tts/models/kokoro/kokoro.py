@@ -191,16 +191,60 @@ class Model:
             assert audio is not None and audio.shape[-1] > 0, "No audio generated"
             yield self._result(audio, segment_idx, len(phonemes) if phonemes is not None else 0, seconds)
 
-    def batch_generate(self, phoneme_batches: Sequence[str], voices: Union[torch.Tensor, Sequence[torch.Tensor]], speed: float = 1.0, **kwargs):
-        """All utterances in one launch sequence; yields ``BatchGenerationResult`` in input order."""
-        ids = [self.phonemes_to_ids(p) for p in phoneme_batches]
-        ref = voices if isinstance(voices, torch.Tensor) else torch.cat([v.reshape(1, -1) for v in voices], 0)
+    def batch_generate(self, texts: Sequence[str], voices: Union[None, str, torch.Tensor, Sequence[Union[str, torch.Tensor]]] = None, speed: float = 1.0,
+                       lang_code: str = "a", split_pattern: str = r"\n+", **kwargs):
+        """All utterances in one launch sequence; yields ``BatchGenerationResult`` (tts/models/base.py:88-99) with ``sequence_idx`` = input position.
+
+        Two input forms: (a) ``voices`` are style tensors (one ``[256]`` / ``[1, 256]`` row per utterance, or a ``[B, 256]`` tensor): ``texts`` are
+        PHONEME strings of at most 510 symbols and everything runs as one engine pass, results in input order; (b) ``voices`` are voice names
+        (or ``None`` = "af_heart", one name for all or one per text): ``texts`` go through G2P and chunking and the chunks of all texts are
+        batched step by step through ``KokoroBatchSession`` (results in completion order).  The reference's Kokoro has no batch path
+        (kokoro.py:126 is batch-1); the signature is the one its serving shell probes for (server.py:519-545: ``texts`` / ``voices``)."""
+        tensor_voices = isinstance(voices, torch.Tensor) or (isinstance(voices, (list, tuple)) and len(voices) > 0 and isinstance(voices[0], torch.Tensor))
+        if tensor_voices:
+            ids = [self.phonemes_to_ids(p) for p in texts]
+            ref = voices if isinstance(voices, torch.Tensor) else torch.cat([v.reshape(1, -1) for v in voices], 0)
+            t0 = time.time()
+            outs, _ = self.engine.forward(ids, ref, speed=float(speed))
+            torch.cuda.synchronize()
+            seconds = time.time() - t0
+            for i, a in enumerate(outs):
+                n = int(a.numel())
+                yield BatchGenerationResult(audio=a, sequence_idx=i, samples=n, sample_rate=self.sample_rate, token_count=len(texts[i]),
+                                            audio_duration=format_duration(n / self.sample_rate), processing_time_seconds=seconds,
+                                            peak_memory_usage=torch.cuda.max_memory_allocated() / 1e9)
+            return
+        from ...continuous import TTSBatchItem, TTSBatchOptions
+
+        names = [voices] * len(texts) if voices is None or isinstance(voices, str) else list(voices)
+        if len(names) != len(texts):
+            raise ValueError(f"batch_generate: {len(texts)} texts but {len(names)} voices")
+        session = self.create_tts_batch_session(TTSBatchOptions(lang_code=lang_code, max_batch_size=max(1, len(texts))))
+        session.add([TTSBatchItem(sequence_id=i, text=t, voice=v, speed=speed, extra={"split_pattern": split_pattern}) for i, (t, v) in enumerate(zip(texts, names))])
         t0 = time.time()
-        outs, _ = self.engine.forward(ids, ref, speed=float(speed))
-        torch.cuda.synchronize()
-        seconds = time.time() - t0
-        for i, a in enumerate(outs):
-            n = int(a.numel())
-            yield BatchGenerationResult(audio=a, sequence_idx=i, samples=n, sample_rate=self.sample_rate, token_count=len(phoneme_batches[i]),
-                                        audio_duration=format_duration(n / self.sample_rate), processing_time_seconds=seconds,
-                                        peak_memory_usage=torch.cuda.max_memory_allocated() / 1e9)
+        while not session.idle:
+            for ev in session.step():
+                if ev.error is not None:
+                    raise ev.error
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
+                yield BatchGenerationResult(audio=ev.audio, sequence_idx=ev.sequence_id, samples=ev.samples, sample_rate=self.sample_rate,
+                                            token_count=ev.token_count, audio_duration=format_duration(ev.samples / self.sample_rate),
+                                            processing_time_seconds=time.time() - t0,
+                                            peak_memory_usage=torch.cuda.max_memory_allocated() / 1e9 if torch.cuda.is_available() else 0.0,
+                                            is_final_chunk=True)
+
+    # ------------------------------------------------------------------ continuous batching hooks (tts/continuous.py; probed by server.py:485-600)
+    def supports_tts_batch(self, *, stream: bool = False, voice: Optional[str] = None, instruct: Optional[str] = None, ref_audio=None,
+                           ref_text: Optional[str] = None, speed: Optional[float] = 1.0, pitch: Optional[float] = 1.0, **kwargs) -> bool:
+        """Kokoro has no instruct / reference-audio / pitch controls; any speed and chunk-level streaming batch fine."""
+        del kwargs, stream, voice, speed
+        return not instruct and ref_audio is None and ref_text is None and pitch in (None, 1.0)
+
+    def supports_tts_continuous_batch(self, **kwargs) -> bool:
+        return self.supports_tts_batch(**kwargs)
+
+    def create_tts_batch_session(self, options):
+        from .continuous_batching import KokoroBatchSession
+
+        return KokoroBatchSession(self, options)

@@ -316,3 +316,92 @@ def test_dac_oracle_reference_length_pins():
     assert tuple(ref.decode(z[:, :, :375 - 250 + 125][:, :, :0 + 125]).shape) == (1, 125 * 320 + 43, 1)
     w2 = make_dac_weights(32, [8, 8, 4, 2], 16, 2, 32, 8, seed=0)
     assert tuple(DACDecoderRef(w2, [8, 8, 4, 2], 2).decode(torch.zeros(1, 16, 430)).shape) == (1, 220_235, 1)
+
+
+class _FakeKokoroEngine:
+    """Stands in for the device engine in the host-logic tests of the batch session: 'audio' = 10 samples per token id, valued with the
+    voice row's first element, so batching, ordering, voice-row selection and speed routing are all observable without a GPU."""
+
+    def __init__(self):
+        self.calls = []
+
+    def forward(self, ids, ref_s, speed=1.0):
+        self.calls.append(dict(n=len(ids), speed=speed, lens=[int(i.numel()) for i in ids]))
+        return [torch.full((10 * int(i.numel()),), float(ref_s[b, 0])) for b, i in enumerate(ids)], [None] * len(ids)
+
+
+def _session_model(tmp_path, max_batch=4, stream=False):
+    from mlx_audio_amd.tts.continuous import TTSBatchOptions
+    from mlx_audio_amd.tts.models.kokoro import Model, ModelConfig
+    from mlx_audio_amd.tts.models.kokoro import synthetic as S
+    from mlx_audio_amd.tts.models.kokoro.pipeline import KokoroPipeline
+
+    m = Model(ModelConfig.from_dict(S.KOKORO_CONFIG), repo_id=str(tmp_path))
+    m.engine = _FakeKokoroEngine()
+    pipe = KokoroPipeline("a", model=m, repo_id=str(tmp_path), g2p=lambda t: t)   # texts are already phoneme strings
+    pack = torch.arange(510, dtype=torch.float32).reshape(510, 1, 1).repeat(1, 1, 256)  # row r holds the value r
+    pipe.voices["v"] = pack
+    pipe.voices["w"] = pack + 1000.0
+    m._pipelines["a"] = pipe
+    return m, m.create_tts_batch_session(TTSBatchOptions(max_batch_size=max_batch, stream=stream))
+
+
+def test_kokoro_batch_session_protocol(tmp_path):
+    """tts/continuous.py protocol on the host side: slots, one chunk per active sequence per step, speed groups, completion events with the
+    concatenated waveform, per-request errors, cancel, streaming events."""
+    from mlx_audio_amd.tts import continuous as C
+    from mlx_audio_amd.tts.models.kokoro import synthetic as S
+
+    vocab = [p for p in S.KOKORO_CONFIG["vocab"] if p.strip() and p not in "!.?…:;,— "]
+    short = "".join(vocab[:12])
+    long_text = (" ".join("".join(vocab[i:i + 40]) for i in range(0, 160, 40)) + " ") * 8
+    long_text = long_text[:1200].strip()  # > 510 symbols: three chunks
+    m, s = _session_model(tmp_path, max_batch=3)
+    assert m.supports_tts_batch(voice="v") and m.supports_tts_continuous_batch(speed=1.3) and not m.supports_tts_batch(instruct="x")
+    assert not m.supports_tts_batch(ref_audio=object()) and not m.supports_tts_batch(pitch=1.2)
+    assert s.idle and s.available_slots == 3
+    s.add([C.TTSBatchItem(0, long_text, voice="v"), C.TTSBatchItem(1, short, voice="w"), C.TTSBatchItem(2, short, voice="nope")])
+    assert not s.idle and s.available_slots == 0
+    with pytest.raises(ValueError):
+        s.add([C.TTSBatchItem(3, short, voice="v")])
+    ev = s.step()
+    # the unknown voice fails alone; the short request finishes in the first pass; the long one needs more steps
+    by_id = {e.sequence_id: e for e in ev}
+    assert set(by_id) == {1, 2} and isinstance(by_id[2].error, FileNotFoundError) and by_id[2].done
+    assert by_id[1].done and by_id[1].error is None and by_id[1].samples == 10 * (len(short) + 2) == by_id[1].audio.numel()
+    assert float(by_id[1].audio[0]) == 1000.0 + len(short) - 1          # voice row = chunk length - 1 (pipeline.py:303), pack "w"
+    assert m.engine.calls[0]["n"] == 2 and s.available_slots == 2
+    s.add([C.TTSBatchItem(7, short, voice="v", speed=1.5)])               # joins between steps; its speed group runs after the leader's
+    ev2 = s.step()
+    assert m.engine.calls[1] == dict(n=1, speed=1.0, lens=m.engine.calls[1]["lens"]) and ev2 == []
+    done = {}
+    for _ in range(6):
+        for e in s.step():
+            done[e.sequence_id] = e
+        if s.idle:
+            break
+    assert s.idle and set(done) == {0, 7}
+    n_chunks = done[0].metadata["chunks"]
+    assert n_chunks == 3 and done[0].token_count == sum(len(c) for c in m._pipelines["a"].chunk_phonemes(long_text))
+    assert done[0].samples == done[0].audio.numel() and done[0].is_final_chunk and done[0].sample_rate == 24000
+    assert any(c["speed"] == 1.5 for c in m.engine.calls) and float(done[7].audio[0]) == len(short) - 1
+    # cancel
+    s.add([C.TTSBatchItem(9, long_text, voice="v")])
+    s.step()
+    s.cancel(9)
+    assert s.idle and s.step() == []
+    # streaming: one event per chunk, the last one final
+    m2, st = _session_model(tmp_path, stream=True)
+    st.add([C.TTSBatchItem(0, long_text, voice="v")])
+    evs = []
+    while not st.idle:
+        evs += st.step()
+    assert len(evs) == 3 and all(e.is_streaming_chunk for e in evs) and [e.is_final_chunk for e in evs] == [False, False, True] and evs[-1].done
+    # batch_generate(texts, voices=names): the serving shell's entry point (server.py:519-545 probes the parameter names)
+    import inspect
+
+    assert {"texts", "voices"} <= set(inspect.signature(m2.batch_generate).parameters)
+    res = list(m2.batch_generate([short, long_text], voices=["v", "w"]))
+    assert sorted(r.sequence_idx for r in res) == [0, 1] and all(r.samples == r.audio.numel() for r in res)
+    with pytest.raises(FileNotFoundError):
+        list(m2.batch_generate([short], voices="missing"))

@@ -129,3 +129,23 @@ def test_kokoro_model_protocol_end_to_end(tmp_path):
     assert r.audio_duration.startswith("00:00:") and r.real_time_factor >= 0
     br = list(model.batch_generate([ps, ps[:9]], [voice[len(ps) - 1], voice[8]]))
     assert [b.sequence_idx for b in br] == [0, 1] and br[0].samples == r.samples and br[1].samples < br[0].samples
+    # continuous batching (tts/continuous.py protocol): three requests of different lengths, one chunk per sequence per step; every
+    # sequence equals the same text through generate() (per-utterance parity of the ragged batch: durations exact, waveform to 1e-4)
+    from mlx_audio_amd.tts.continuous import TTSBatchItem, TTSBatchOptions
+
+    model._get_pipeline("a")._g2p = lambda text: text          # texts below are phoneme strings
+    texts = [ps, ps[:9] + "\n" + ps[2:14], ps[4:16]]
+    session = model.create_tts_batch_session(TTSBatchOptions(max_batch_size=4))
+    session.add([TTSBatchItem(i, t, voice="af_test") for i, t in enumerate(texts)])
+    got = {}
+    n_steps = 0
+    while not session.idle:
+        for e in session.step():
+            assert e.error is None and e.done
+            got[e.sequence_id] = e
+        n_steps += 1
+    assert n_steps == 2 and set(got) == {0, 1, 2}              # the two-segment text needs a second pass, the others finish in the first
+    for i, t in enumerate(texts):
+        solo = torch.cat([g.audio for g in model.generate(t, voice="af_test")])
+        assert got[i].samples == solo.numel() == got[i].audio.numel(), (i, got[i].samples, solo.numel())
+        assert float((got[i].audio - solo).abs().max()) < 1e-4 * float(solo.abs().max() + 1e-9) + 1e-5
