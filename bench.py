@@ -187,7 +187,7 @@ def main():
         step()
         e1.record()
         torch.cuda.synchronize()
-        prof, ops.PROFILE = ops.PROFILE, None
+        prof, ops.PROFILE = ops.profile_finalize(ops.PROFILE), None
         if args.shape_table:
             agg = {}
             for fl, by, a0, a1, shp in prof:

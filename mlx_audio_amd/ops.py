@@ -28,6 +28,18 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def profile_finalize(entries):
+    """PROFILE entries -> [(algorithmic flops, algorithmic bytes, start event, end event, (cin, cout, k, dil, rows))] after a synchronize."""
+    torch.cuda.synchronize()
+    out = []
+    for rows, cin, cout, k, dil, e0, e1 in entries:
+        rows = int(rows)
+        flops = 2.0 * rows * cout * k * cin
+        byts = 4.0 * rows * (cin + cout) + 2.0 * cout * k * cin  # fp32 activations in + out, 16-bit weights once
+        out.append((flops, byts, e0, e1, (cin, cout, k, dil, rows)))
+    return out
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -237,14 +249,15 @@ def conv_gemm(x: torch.Tensor, pc: PackedConv, y: torch.Tensor, *, dil: int = 1,
         assert stats.shape[0] == B and stats.shape[1] >= (kw["Lout"] + STATS_ROWS - 1) // STATS_ROWS and stats.shape[2] == pc.cout
         kw.update(stats_partial=_ptr(stats), stats_bstride=stats.stride(0))
     if PROFILE is not None:
-        rows = (kw["Lout"] * B) if lens_out is None else int(lens_out.sum())
-        flops = 2.0 * rows * pc.cout * pc.k * pc.cin
-        byts = 4.0 * rows * (pc.cin + pc.cout) + 2.0 * pc.cout * pc.k * pc.cin  # fp32 activations in+out, bf16 weights once
+        # no host synchronisation here (a .item() on the ragged lengths would drain the queue before every launch: the start event would then
+        # be stamped on an idle GPU and the interval would include the host's submission latency); the row count stays a device scalar and
+        # profile_finalize() resolves it after the step
+        rows = (kw["Lout"] * B) if lens_out is None else lens_out.sum()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         _lib.call_struct("mi355_conv_gemm", "mi355_conv_gemm_args", _stream(), **kw)
         e1.record()
-        PROFILE.append((flops, byts, e0, e1, (pc.cin, pc.cout, pc.k, dil, rows)))
+        PROFILE.append((rows, pc.cin, pc.cout, pc.k, dil, e0, e1))
         return y
     _lib.call_struct("mi355_conv_gemm", "mi355_conv_gemm_args", _stream(), **kw)
     return y
