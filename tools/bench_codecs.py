@@ -1,0 +1,118 @@
+#!/usr/bin/env python
+"""Measurement line for the widened codec rows: Vocos (mel -> waveform, 24 kHz), DAC (44 kHz, 9 codebooks) and SNAC
+(24 kHz, 3 code levels) decode on one MI355X, synthetic weights of the published shapes, inputs resident in HBM before the timed region.
+
+Prints ONE JSON line per codec: value = audio samples decoded per second over the whole batch (and x real time), ms per batch, and a roofline
+object for the conv_gemm launches of one instrumented pass (algorithmic FLOPs / summed launch durations against the dense bf16-class MFMA
+peak; events on the launch stream, no host synchronisation inside the pass).  Not the driver's contract line.
+"""
+import argparse
+import json
+import time
+
+import torch
+
+import _bench_util as U  # noqa: F401  (puts the repo root on sys.path)
+
+MFMA_PEAK_TFLOPS = 2500.0
+
+
+def timed(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = U.ev(), U.ev()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        out = fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return out, 1000.0 * (time.perf_counter() - t0) / steps, e0.elapsed_time(e1) / steps
+
+
+def conv_roofline(fn):
+    from mlx_audio_amd import ops
+
+    ops.PROFILE = []
+    torch.cuda.synchronize()
+    fn()
+    prof, ops.PROFILE = ops.profile_finalize(ops.PROFILE), None
+    ms = sum(p[2].elapsed_time(p[3]) for p in prof)
+    fl, by = sum(p[0] for p in prof), sum(p[1] for p in prof)
+    if not prof or ms <= 0:
+        return None
+    return {"bound": "mfma", "kernel": "conv_gemm (all launches of one decode pass)", "achieved": fl / (ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None, "launches": len(prof), "conv_gemm_ms": ms,
+            "algorithmic_gflop": fl / 1e9, "hbm_view": {"algorithmic_GB": by / 1e9, "achieved_GBps": by / (ms * 1e-3) / 1e9, "frac": by / (ms * 1e-3) / 1e9 / 8000.0}}
+
+
+def line(name, workload, sr, n_samples, B, wall_ms, dev_ms, roof, dtype):
+    total = n_samples * B
+    return {"metric": f"audio samples decoded per second, {name} decode, 1 MI355X", "value": total / (dev_ms * 1e-3), "unit": "samples/s", "n_gpus": 1,
+            "ms_per_step": dev_ms, "wall_ms_per_step": wall_ms, "higher_is_better": True, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": workload, "batch": B, "samples_per_item": n_samples, "sample_rate": sr}, "x_realtime": total / sr / (dev_ms * 1e-3), "roofline": roof}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    B = args.batch
+    g = torch.Generator().manual_seed(0)
+    dt16 = "fp32 checkpoints held as fp16 MFMA images x fp32 activations (fp16 hi+lo split, fp32 accumulate)"
+
+    if args.only in ("", "vocos"):
+        from mlx_audio_amd.codec.models.vocos import Vocos
+
+        cfg = {"feature_extractor": {"class_path": "vocos.feature_extractors.MelSpectrogramFeatures",
+                                     "init_args": {"sample_rate": 24000, "n_fft": 1024, "hop_length": 256, "n_mels": 100}},
+               "backbone": {"class_path": "vocos.models.VocosBackbone", "init_args": {"input_channels": 100, "dim": 512, "intermediate_dim": 1536, "num_layers": 8}},
+               "head": {"class_path": "vocos.heads.ISTFTHead", "init_args": {"dim": 512, "n_fft": 1024, "hop_length": 256}}}
+        eng = Vocos.from_hparams(cfg, device=dev, seed=0)
+        T = int(args.seconds * 24000) // 256
+        mel = (torch.randn(B, T, 100, generator=g) * 2.0 - 4.0).to(dev)
+        fn = lambda: eng.decode(mel)  # noqa: E731
+        out, wall, dms = timed(fn, args.steps, args.warmup)
+        n = int(out.shape[-1])
+        print(json.dumps(line("Vocos (mel-24khz shapes: dim 512, 8 ConvNeXt blocks, iSTFT head n_fft 1024 / hop 256)", f"{B} x {T} mel frames -> waveform", 24000, n, B,
+                              wall, dms, conv_roofline(fn), dt16)))
+
+    if args.only in ("", "dac"):
+        from mlx_audio_amd.codec.models.descript import DAC
+
+        eng = DAC(encoder_dim=64, encoder_rates=[2, 4, 8, 8], decoder_dim=1536, decoder_rates=[8, 8, 4, 2], n_codebooks=9, codebook_size=1024, codebook_dim=8,
+                  sample_rate=44100, device=dev, seed=0)
+        T = int(args.seconds * 44100) // 512
+        codes = torch.randint(0, 1024, (B, 9, T), generator=g).to(dev)
+
+        def fn():
+            z, _, _ = eng.quantizer.from_codes(codes)
+            return eng.decode(z)
+
+        out, wall, dms = timed(fn, args.steps, args.warmup)
+        n = int(out.shape[1])
+        print(json.dumps(line("DAC 44 kHz (decoder_dim 1536, rates 8/8/4/2, 9 codebooks)", f"{B} x {T} code frames -> waveform (from_codes + decoder)", 44100, n, B, wall, dms,
+                              conv_roofline(fn), dt16)))
+
+    if args.only in ("", "snac"):
+        from mlx_audio_amd.codec.models.snac import SNAC
+
+        eng = SNAC(sampling_rate=24000, encoder_dim=48, encoder_rates=[2, 4, 8, 8], decoder_dim=1024, decoder_rates=[8, 8, 4, 2], attn_window_size=None,
+                   codebook_size=4096, codebook_dim=8, vq_strides=[4, 2, 1], noise=True, depthwise=True, device=dev, seed=0)
+        T = (int(args.seconds * 24000) // 512) // 4 * 4
+        codes = [torch.randint(0, 4096, (B, T // s), generator=g).to(dev) for s in (4, 2, 1)]
+        fn = lambda: eng.decode(codes)  # noqa: E731
+        out, wall, dms = timed(fn, args.steps, args.warmup)
+        n = int(out.shape[1])
+        print(json.dumps(line("SNAC 24 kHz (decoder_dim 1024, rates 8/8/4/2, depthwise, noise, 3 code levels)", f"{B} x {T} finest-level code frames -> waveform", 24000, n, B,
+                              wall, dms, conv_roofline(fn), dt16)))
+
+
+if __name__ == "__main__":
+    main()
