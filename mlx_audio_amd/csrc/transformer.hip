@@ -154,6 +154,47 @@ __global__ void dwconv_kernel(const mi355_dwconv_args a) {
   a.y[(int64_t)b * a.y_bstride + (int64_t)n * a.ldy + c] = acc;
 }
 
+// Depthwise k = 7 conv, one "dilated comb" per thread: the J outputs n0 + j * dil (j < J) of one channel share J + 6 input samples, so the
+// optional Snake prologue (v_sin_f32 via __sinf, like conv_gemm's) runs 1.75x per output instead of 7x and every input is loaded once per comb.
+// Threads are adjacent in the channel axis (coalesced 256-byte rows).  SNAC's ResidualUnit convs (dilation 1 / 3 / 9) and ConvNeXt's dwconv.
+template <int J>
+__global__ __launch_bounds__(256) void dwconv7_comb_kernel(const mi355_dwconv_args a, const int dil, const int ncomb) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)a.B * ncomb * dil * a.C;
+  if (i >= total) return;
+  const int c = (int)(i % a.C);
+  int64_t r = i / a.C;
+  const int ph = (int)(r % dil);
+  r /= dil;
+  const int q = (int)(r % ncomb), b = (int)(r / ncomb);
+  const int len_in = a.lens_in ? a.lens_in[b] : a.Lin;
+  const float* xb = a.x + (int64_t)b * a.x_bstride + c;
+  const int n0 = q * J * dil + ph;            // first output of the comb
+  const float al = a.pre_alpha ? a.pre_alpha[c] : 0.f, inv = a.pre_alpha ? a.pre_inv[c] : 0.f;
+  float w[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) w[k] = a.w[c * 7 + k];
+  float v[J + 6];
+#pragma unroll
+  for (int e = 0; e < J + 6; ++e) {
+    const int t = n0 + e * dil - a.pad;
+    float u = (t >= 0 && t < len_in) ? xb[(int64_t)t * a.ldx] : 0.f;
+    if (a.pre_alpha) { const float sn = __sinf(al * u); u = u + inv * (sn * sn); }
+    v[e] = u;
+  }
+  const float bias = a.bias ? a.bias[c] : 0.f;
+  float* yb = a.y + (int64_t)b * a.y_bstride + c;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int n = n0 + j * dil;
+    if (n >= a.Lout) break;
+    float acc = bias;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) acc = fmaf(w[k], v[j + k], acc);
+    yb[(int64_t)n * a.ldy] = acc;
+  }
+}
+
 }  // namespace
 
 extern "C" int mi355_rmsnorm(const mi355_rmsnorm_args* ap, void* stream) {
@@ -212,6 +253,15 @@ extern "C" int mi355_dwconv(const mi355_dwconv_args* ap, void* stream) {
   MI355_REQUIRE(!a.transpose || (a.dil <= 1 && !a.pre_alpha), "dwconv: dilation / Snake prologue exist for the plain depthwise conv only");
   MI355_REQUIRE(!a.pre_alpha || a.pre_inv, "dwconv: pre_alpha without pre_inv");
   MI355_CLEAR_ERROR();
+  if (!a.transpose && a.K == 7 && a.stride <= 1) {  // the k = 7 depthwise convs of ConvNeXt / SNAC: one dilated comb of 8 outputs per thread
+    constexpr int J = 8;
+    const int dil = a.dil > 0 ? a.dil : 1;
+    const int ncomb = (a.Lout + J * dil - 1) / (J * dil);
+    const int64_t nt = (int64_t)a.B * ncomb * dil * a.C;
+    hipLaunchKernelGGL(dwconv7_comb_kernel<J>, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, dil, ncomb);
+    MI355_LAUNCH_CHECK("dwconv(comb)");
+    return MI355_OK;
+  }
   const int64_t n = (int64_t)a.B * a.Lout * a.C;
   hipLaunchKernelGGL(dwconv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   MI355_LAUNCH_CHECK("dwconv");
