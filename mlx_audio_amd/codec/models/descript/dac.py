@@ -77,6 +77,10 @@ class _Snake:
         al[: a.numel()] = a
         ib[: a.numel()] = torch.reciprocal(a + 1e-9)
         self.alpha, self.inv = al.to(device), ib.to(device)
+        # conv_gemm's plain Snake prologue computes 1 / alpha in the kernel (v_rcp_f32 + one Newton step) and is the fast instantiation; the
+        # explicit 1 / (alpha + 1e-9) table selects the extended one (more registers, ~20 % slower).  For |alpha| >= 1e-2 the two coefficients
+        # differ by <= 1e-7 relative (one float32 ulp), far inside the parity bar, so the table is only handed over when an alpha is tiny.
+        self.inv_conv = self.inv if float(a.abs().min()) < 1e-2 else None
 
 
 class _Quantizer:
@@ -182,7 +186,7 @@ class DAC:
     def _conv(self, x, sn: Optional[_Snake], pc: PackedConv, y, *, dil=1, res=None, post_act=ACT_NONE):
         kw = dict(dil=dil, pad=(pc.k - 1) * dil // 2, res=res, post_act=post_act, precision=4)
         if sn is not None:
-            kw.update(pre_act=ACT_SNAKE, pre_alpha=sn.alpha, pre_inv_beta=sn.inv)
+            kw.update(pre_act=ACT_SNAKE, pre_alpha=sn.alpha, pre_inv_beta=sn.inv_conv)
         return ops.conv_gemm(x, pc, y, **kw)
 
     def decode(self, z, return_stages: bool = False):
@@ -201,7 +205,7 @@ class DAC:
             Lout = (Lin - 1) * s - 2 * p + 2 * s + 1   # + 1: the reference's groups-as-output_padding slip (module docstring)
             y = self._f(B, Lout, cout)
             ops.conv_gemm(h, blk["up"], y, pad=taps - 1, lout=Lin + taps - 1, up=dict(s=s, p=p, cout=cout, lout=Lout), pre_act=ACT_SNAKE,
-                          pre_alpha=blk["snake"].alpha, pre_inv_beta=blk["snake"].inv, precision=4)
+                          pre_alpha=blk["snake"].alpha, pre_inv_beta=blk["snake"].inv_conv, precision=4)
             tmp = torch.empty_like(y)
             for u in blk["units"]:
                 self._conv(y, u["s1"], u["c1"], tmp, dil=u["dil"])

@@ -98,6 +98,10 @@ class _Snake:
         al[: a.numel()] = a
         ib[: a.numel()] = torch.reciprocal(a + 1e-9)
         self.alpha, self.inv = al.to(device), ib.to(device)
+        # conv_gemm's plain Snake prologue computes 1 / alpha in the kernel (v_rcp_f32 + one Newton step) and is the fast instantiation; the
+        # explicit 1 / (alpha + 1e-9) table selects the extended one (more registers, ~20 % slower).  For |alpha| >= 1e-2 the two coefficients
+        # differ by <= 1e-7 relative (one float32 ulp), far inside the parity bar, so the table is only handed over when an alpha is tiny.
+        self.inv_conv = self.inv if float(a.abs().min()) < 1e-2 else None
 
 
 def _wn(w: Dict[str, torch.Tensor], name: str) -> torch.Tensor:
@@ -222,7 +226,7 @@ class SNAC:
     def _conv(self, x, sn: Optional[_Snake], pc: PackedConv, y, *, dil=1, res=None, post_act=ACT_NONE):
         kw = dict(dil=dil, pad=(pc.k - 1) * dil // 2, res=res, post_act=post_act, precision=4)
         if sn is not None:
-            kw.update(pre_act=ACT_SNAKE, pre_alpha=sn.alpha, pre_inv_beta=sn.inv)
+            kw.update(pre_act=ACT_SNAKE, pre_alpha=sn.alpha, pre_inv_beta=sn.inv_conv)
         return ops.conv_gemm(x, pc, y, **kw)
 
     def _mid(self, x, sn: _Snake, c, y, dil: int):
@@ -253,7 +257,7 @@ class SNAC:
             Lout = (Lin - 1) * s - 2 * p + 2 * s + 1   # + 1: the reference's groups-as-output_padding slip (module docstring)
             y = self._f(B, Lout, cout)
             ops.conv_gemm(h, blk["up"], y, pad=taps - 1, lout=Lin + taps - 1, up=dict(s=s, p=p, cout=cout, lout=Lout), pre_act=ACT_SNAKE,
-                          pre_alpha=blk["snake"].alpha, pre_inv_beta=blk["snake"].inv, precision=4)
+                          pre_alpha=blk["snake"].alpha, pre_inv_beta=blk["snake"].inv_conv, precision=4)
             tmp = torch.empty_like(y)
             if blk["noise"] is not None:
                 if noises is not None:
