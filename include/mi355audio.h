@@ -424,7 +424,10 @@ int mi355_softmax_prob_at(const float* logits, int32_t ld, int32_t V, int32_t B,
  * Replaces nn.Linear / Embedding.as_linear at sequence length 1: Whisper TextDecoder (stt/models/whisper/whisper.py:347-416,
  * 498), Qwen3-TTS talker / code predictor (tts/models/qwen3_tts/talker.py:230-330, 503-764), CSM backbone / depth decoder
  * (lm/models/llama.py:46-198, tts/models/sesame/sesame.py:361-404).  HBM-bound: w is read once, row-major [N, ldw] in the
- * checkpoint's 16-bit type (mi355_pack_rowmajor16_host), products accumulate in fp32.
+ * checkpoint's 16-bit type (mi355_pack_rowmajor16_host) or as an fp8 image (mi355_pack_rowmajor_fp8_host), products accumulate in fp32.
+ * 1..4 rows (and K > 2048 / fp8 at any row count): fp32 FMAs on the exactly decoded weights.  5..8 rows with 16-bit weights and K <= 2048,
+ * K % 64 == 0: v_mfma_f32_16x16x32 on the weights' own type with the input rows split into hi + lo images (bf16: ~16 mantissa bits of x, the
+ * split the prefill GEMMs use; fp16: ~22) -- environment MI355_GEMV_MFMA=0 keeps the FMA kernel for A/B runs.
  * Epilogue: v = act(acc + bias[n]) * colscale[n] + res[m, n]; y = v * out_scale.  glu = 1: rows of w are interleaved
  * (gate_0, up_0, gate_1, up_1, ...) and y[m, n/2] = silu(acc_gate + b) * (acc_up + b)  (SwiGLU, talker.py TalkerMLP).
  * ------------------------------------------------------------------------------------------ */

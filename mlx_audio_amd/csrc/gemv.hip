@@ -11,6 +11,12 @@
 // 16-bit weights) and a wave-level butterfly finishes each column.  Epilogue: bias, activation, residual, scale, and the
 // optional fused SwiGLU (interleaved gate / up rows: y[n/2] = silu(acc[n]) * acc[n+1]).  Prologue (optional): LayerNorm / RMSNorm of
 // the input rows, recomputed per workgroup; the output columns can be split over two destinations (q | k,v -> buffer | KV-cache slot).
+// Weight element types: bf16, fp16, or fp8 (OCP e4m3fn bytes + one power-of-two scale per row, mi355_pack_rowmajor_fp8_host): a lane's 16-byte
+// piece then carries 16 elements, decoded exactly by moving the byte into binary16 position (common.h cvt_w16).
+// Dispatch: calls with 5..8 rows, 16-bit weights and K <= 2048 (K % 64 == 0) go to the matrix-pipe kernel of gemv_mfma.hip (the FMA kernel runs
+// the weight stream at ~1.4 TB/s at 8 rows against ~3.7 TB/s at 1 row); everything else runs here.  What bounds the small images is the
+// dependent chain inside a launch (x load -> statistics -> staging -> reduction), hence: statistics from the staged LDS copy (one read of x),
+// a staging thread owns columns (norm weight / bias loaded once per column: fewer registers, more waves in flight), weights issued first.
 #include <stdlib.h>
 #include "common.h"
 

@@ -17,6 +17,12 @@
 //   * the grid is exactly the number of co-resident workgroups (occupancy query x CU count), a precondition of any hand-rolled grid barrier.
 // The phase list is built on the host from the same mi355_stack_desc as the multi-launch runner, uploaded once per (stack, buffers, B) and
 // cached; the step index enters as a kernel argument (KV slot = base + offset * row, keys = offset + 1, RoPE position = offset).
+//
+// STATUS (round 1, GPU call 21, profiles/r1_decode_runner_ab_call21.txt): parity-green against the multi-launch runner and the oracle, but 1.7-2.0x
+// SLOWER (CSM-1B 14.8 vs 7.4 ms per frame, Qwen3-TTS-1.7B 17.9 vs 10.8, Whisper-small 3.17 vs 1.68 ms per token step): ~17 us per phase (counter
+// barrier at 256 workgroups + 4 waves per CU at 384 registers + scalar write-through stores) against ~7.6 us per launch.  It is therefore OPT-IN
+// (MI355_STEP_FUSED=1 / mi355_stack_fused_set(1)) and kept as the A/B harness for the next attempt (<= 128 registers for 2 workgroups per CU,
+// the XCD-hierarchical barrier, 16-byte write-through stores).
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
