@@ -449,6 +449,10 @@ typedef struct {
   /* MI355_W_FP8 only: per-output-row dequantisation scale [N] (required): acc[n] * wscale[n] precedes the bias */
   const float* wscale;
   int32_t norm_two_reads;  /* set by the library (MI355_GEMV_TWO_READS): compute the fused-norm statistics from a separate read of x; callers leave 0 */
+  /* optional fused rotary embedding on the first rope_cols output columns (the q | k part of a fused q|k|v projection), interleaved pairs
+     (2i, 2i + 1) inside heads of rope_dh channels -- nn.RoPE(traditional=True) / sesame/attention.py:41-105 at ONE position: rope_cos / rope_sin
+     point at that position's table row [rope_dh / 2].  Plain epilogue only (no activation / colscale / residual / glu); 1..4 rows. */
+  const float* rope_cos; const float* rope_sin; int32_t rope_dh; int32_t rope_cols;
 } mi355_gemv_args;
 int mi355_gemv(const mi355_gemv_args* a, void* stream);
 int mi355_pack_rowmajor16_host(const float* w_host, int64_t n, int32_t dtype, uint16_t* out_host);

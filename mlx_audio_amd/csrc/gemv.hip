@@ -59,6 +59,29 @@ __device__ __forceinline__ void gemv_finish(const mi355_gemv_args& a, float (&ac
     }
     return;
   }
+  if constexpr (NC == 2) {
+    if (a.rope_cos && n0 + 1 < a.N && n0 < a.rope_cols) {  // the wave's two columns are one interleaved rotary pair of a q or k head
+      const int i = (n0 % a.rope_dh) >> 1;
+      const float cs = a.rope_cos[i], sn = a.rope_sin[i];
+      const float b0 = a.bias ? a.bias[n0] : 0.f, b1 = a.bias ? a.bias[n0 + 1] : 0.f;
+      const float w0 = a.wscale ? a.wscale[n0] * kFp8Unbias : 1.f, w1 = a.wscale ? a.wscale[n0 + 1] * kFp8Unbias : 1.f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        if (m >= a.M) break;
+        const float x0 = acc[0][m] * w0 + b0, x1 = acc[1][m] * w1 + b1;
+        const float y0 = x0 * cs - x1 * sn;   // (x * cos) + (rotate(x) * sin), like head_norm_rope_kernel
+        const float y1 = x1 * cs + x0 * sn;
+        if (a.y2 && n0 >= a.split) {
+          a.y2[(int64_t)m * a.ldy2 + (n0 - a.split)] = y0 * a.out_scale;
+          a.y2[(int64_t)m * a.ldy2 + (n0 + 1 - a.split)] = y1 * a.out_scale;
+        } else {
+          a.y[(int64_t)m * a.ldy + n0] = y0 * a.out_scale;
+          a.y[(int64_t)m * a.ldy + n0 + 1] = y1 * a.out_scale;
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int n = n0 + c;
@@ -369,7 +392,7 @@ int launch_gemv(const mi355_gemv_args& a, hipStream_t st) {
   // one column per wave keeps the most wavefronts (and weight bytes) in flight; two columns per wave halve the LDS reads of x per weight
   // byte, which is what binds at 8 rows (16 LDS bytes per weight byte at NC = 1) and for very wide outputs
   static const int nc_env = getenv("MI355_GEMV_NC") ? atoi(getenv("MI355_GEMV_NC")) : 0;  // A/B knob (1 | 2); SwiGLU pairs always need 2
-  const int nc = a.glu ? 2 : (nc_env == 1 || nc_env == 2) ? nc_env : ((MT >= 8 || a.N >= 16384) ? 2 : 1);
+  const int nc = (a.glu || a.rope_cos) ? 2 : (nc_env == 1 || nc_env == 2) ? nc_env : ((MT >= 8 || a.N >= 16384) ? 2 : 1);
   if constexpr (MT >= 4) {
     const size_t lds = (size_t)MT * a.K * sizeof(float);
     // Measured (profiles/r1_kernel_stats_qwen3_1p7b_b8_v4_resident.txt): 22.0 us vs 18.9 us per launch for the chunked kernel at M = 8 -- these
@@ -429,6 +452,9 @@ extern "C" int mi355_gemv(const mi355_gemv_args* ap, void* stream) {
   MI355_REQUIRE(!a.norm || (a.K % 4 == 0 && (!a.norm_weight || ((uintptr_t)a.norm_weight) % 16 == 0) && (!a.norm_bias || ((uintptr_t)a.norm_bias) % 16 == 0)),
                 "gemv: norm weight / bias must be 16-byte aligned");
   MI355_REQUIRE(!a.y2 || (a.split > 0 && a.split < a.N), "gemv: split must be inside (0, N) when y2 is given");
+  MI355_REQUIRE(!a.rope_cos || (a.rope_sin && a.rope_dh > 0 && a.rope_dh % 2 == 0 && a.rope_cols > 0 && a.rope_cols <= a.N && a.rope_cols % a.rope_dh == 0 &&
+                                !a.glu && !a.res && !a.colscale && a.post_act == MI355_ACT_NONE && a.M <= 4 && (!a.y2 || a.split % 2 == 0)),
+                "gemv: fused rope needs a plain epilogue, <= 4 rows, whole heads and an even split");
   if (a.out_scale == 0.f) a.out_scale = 1.f;
   static const bool two_reads = getenv("MI355_GEMV_TWO_READS") != nullptr;  // A/B knob: statistics from a separate read of x (the older schedule)
   a.norm_two_reads = two_reads ? 1 : 0;

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const mi355_gemv_args a)
 int mi355_gemv_mfma_eligible(const mi355_gemv_args& a) {
   static const bool off = getenv("MI355_GEMV_MFMA") != nullptr && getenv("MI355_GEMV_MFMA")[0] == '0';
   if (off) return 0;
-  if (a.M < 5 || a.M > 8) return 0;
+  if (a.M < 5 || a.M > 8 || a.rope_cos) return 0;
   if (a.wdtype != MI355_W_BF16 && a.wdtype != MI355_W_F16) return 0;
   if (a.K % 64 || a.K < 64 || a.ldw % 8 || ((uintptr_t)a.w) % 16 || a.ldx % 4 || ((uintptr_t)a.x) % 16) return 0;
   if (a.K > kKC) return 0;   // one staged chunk only: the chunk loop's workgroup barriers cost more than they save (K = 6144: 25 vs 15 us, call 26)

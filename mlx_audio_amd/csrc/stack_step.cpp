@@ -9,6 +9,7 @@
 // Per layer: [pre-norm + q|k|v GEMV, k|v straight into the KV-cache slot] -> [per-head RMSNorm + RoPE of q and k, one launch] ->
 // [KV-streaming attention] -> [o-proj GEMV + LayerScale + residual] -> (cross-attention: [pre-norm + q GEMV] -> [attention over the
 // precomputed cross K|V] -> [o-proj GEMV + residual]) -> [pre-norm + up GEMV with fused SwiGLU / GELU] -> [down GEMV + LayerScale + residual].
+#include <stdlib.h>
 #include <string.h>
 #include "common.h"
 
@@ -16,12 +17,14 @@ namespace {
 
 int gemv_call(const float* x, int ldx, int M, int K, const uint16_t* w, int N, int wdtype, const float* bias, int act, const float* colscale,
               const float* res, int ldr, int glu, float* y, int ldy, int norm, const float* nw, const float* nb, float eps, float* y2, int ldy2,
-              int split, void* stream, const float* wscale = nullptr) {
+              int split, void* stream, const float* wscale = nullptr, const float* rope_cos = nullptr, const float* rope_sin = nullptr, int rope_dh = 0,
+              int rope_cols = 0) {
   mi355_gemv_args g;
   memset(&g, 0, sizeof(g));
   g.x = x; g.ldx = ldx; g.M = M; g.K = K; g.w = w; g.ldw = K; g.wdtype = wdtype; g.N = N; g.bias = bias; g.post_act = act; g.colscale = colscale;
   g.res = res; g.ldr = ldr; g.out_scale = 1.f; g.glu = glu; g.y = y; g.ldy = ldy; g.norm = norm; g.norm_weight = nw; g.norm_bias = nb;
   g.norm_eps = eps; g.y2 = y2; g.ldy2 = ldy2; g.split = split; g.wscale = wscale;
+  g.rope_cos = rope_cos; g.rope_sin = rope_sin; g.rope_dh = rope_dh; g.rope_cols = rope_cols;
   return mi355_gemv(&g, stream);
 }
 
@@ -63,10 +66,16 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
     MI355_REQUIRE(offset < L.kv_capacity, "stack_decode_step: KV cache of layer %d is full (offset %d, capacity %d)", i, offset, L.kv_capacity);
     float* slot = L.kv + (int64_t)offset * nkv;  // row `offset` of item 0; items are kv_bstride apart
     // ---- self-attention
+    // interleaved RoPE without per-head q / k norms (CSM Llama, Mimi): the rotation of a pair (2i, 2i + 1) is the epilogue of the wave that owns
+    // those two columns of the q | k | v projection -- one launch less per layer (MI355_GEMV_ROPE=0 keeps the separate kernel for A/B runs)
+    static const bool rope_off = getenv("MI355_GEMV_ROPE") != nullptr && getenv("MI355_GEMV_ROPE")[0] == '0';
+    const bool rope_in_gemv = d.cos && d.rope_mode == 1 && !L.q_norm && !L.k_norm && B <= 4 && !rope_off;
+    const float* rc_row = rope_in_gemv ? d.cos + (int64_t)offset * (dh / 2) : nullptr;
+    const float* rs_row = rope_in_gemv ? d.sin + (int64_t)offset * (dh / 2) : nullptr;
     int rc = gemv_call(x, D, B, D, L.wqkv, nq + nkv, d.wdtype, L.bqkv, MI355_ACT_NONE, nullptr, nullptr, 0, 0, q, nq, d.norm, L.attn_norm_w,
-                       L.attn_norm_b, d.eps, slot, (int)L.kv_bstride, nq, stream, L.s_qkv);
+                       L.attn_norm_b, d.eps, slot, (int)L.kv_bstride, nq, stream, L.s_qkv, rc_row, rs_row, dh, rope_in_gemv ? nq + G * dh : 0);
     if (rc) return rc;
-    if (L.q_norm || d.cos) {
+    if (!rope_in_gemv && (L.q_norm || d.cos)) {
       mi355_head_rope_args r;
       memset(&r, 0, sizeof(r));
       r.x = q; r.x_bstride = nq; r.ldx = nq; r.heads = H; r.dh = dh; r.L = 1; r.B = B; r.norm_weight = L.q_norm; r.eps = d.eps;

@@ -171,7 +171,7 @@ def pack_rowmajor_fp8(w: torch.Tensor, bias: Optional[torch.Tensor], device) -> 
 
 def gemv(x: torch.Tensor, rw: RowMajor16, y: torch.Tensor, *, post_act: int = ACT_NONE, post_slope: float = 0.0,
          res: Optional[torch.Tensor] = None, colscale: Optional[torch.Tensor] = None, out_scale: float = 1.0, glu: bool = False,
-         use_bias: bool = True, norm: Optional[tuple] = None, y2: Optional[torch.Tensor] = None):
+         use_bias: bool = True, norm: Optional[tuple] = None, y2: Optional[torch.Tensor] = None, rope: Optional[tuple] = None):
     """y[m, :] = epilogue(norm(x[m, :]) @ W^T) for 1..8 rows; x / y / res are 2-D fp32 views with unit inner stride.
     ``norm`` = (mode, weight, bias, eps) with mode "layer" | "rms" fuses the input normalisation; ``y2``: columns >= y.shape[1] go there."""
     assert x.dim() == 2 and y.dim() == 2 and x.stride(1) == 1 and y.stride(1) == 1 and x.dtype == torch.float32 and y.dtype == torch.float32
@@ -190,6 +190,10 @@ def gemv(x: torch.Tensor, rw: RowMajor16, y: torch.Tensor, *, post_act: int = AC
     if y2 is not None:
         assert y2.dim() == 2 and y2.stride(1) == 1 and y2.shape[0] == M
         kw.update(y2=_ptr(y2), ldy2=y2.stride(0), split=n_y)
+    if rope is not None:  # (cos_row [dh / 2], sin_row [dh / 2], dh, cols): interleaved rotary pairs on the first ``cols`` output columns
+        cos_row, sin_row, dh, cols = rope
+        assert cos_row.is_contiguous() and sin_row.is_contiguous() and cos_row.numel() >= dh // 2
+        kw.update(rope_cos=_ptr(cos_row), rope_sin=_ptr(sin_row), rope_dh=dh, rope_cols=cols)
     _lib.call_struct("mi355_gemv", "mi355_gemv_args", _stream(), **kw)
     return y
 

@@ -509,3 +509,44 @@ def test_gemv_matrix_pipe(ops, M, N, K, f16, mode, glu, act, use_res, split):
     else:
         assert torch.isfinite(y).all()
         assert rel_err(y.cpu(), v) < tol, rel_err(y.cpu(), v)
+
+
+@pytest.mark.parametrize("M,heads,kv_heads,dh,K,fp8", [(1, 4, 1, 64, 256, False), (3, 8, 2, 128, 1024, False), (1, 32, 8, 64, 2048, False), (2, 4, 2, 64, 512, True)])
+def test_gemv_fused_interleaved_rope(ops, M, heads, kv_heads, dh, K, fp8):
+    """q | k | v projection with the interleaved rotary embedding (nn.RoPE(traditional=True), sesame/attention.py:41-105) applied in the GEMV
+    epilogue: q and k columns rotated at one position, v untouched, k | v landing in a strided cache slot; against float64."""
+    g = torch.Generator().manual_seed(M + heads + K)
+    nq, nk = heads * dh, kv_heads * dh
+    N = nq + 2 * nk
+    w = _round16(torch.randn(N, K, generator=g) / math.sqrt(K), False)
+    bias = torch.randn(N, generator=g) * 0.1
+    x = torch.randn(M, K, generator=g)
+    nw = torch.randn(K, generator=g)
+    pos = 37
+    inv = 1.0 / (10000.0 ** (torch.arange(0, dh, 2, dtype=torch.float32) / dh))
+    ang = pos * inv
+    cos_row, sin_row = torch.cos(ang), torch.sin(ang)
+    if fp8:
+        from oracle.lm_ref import dequantize_rows_fp8_ref, quantize_rows_fp8_ref
+
+        rw, _ = ops.pack_rowmajor_fp8(w, bias, DEV)
+        wd = dequantize_rows_fp8_ref(*quantize_rows_fp8_ref(w)).double()
+    else:
+        rw = ops.pack_rowmajor16(w, bias, DEV)
+        wd = w.double()
+    xd = x.double()
+    xn = xd * torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + 1e-5) * nw.double()
+    v = xn @ wd.T + bias.double()
+    exp = v.clone()
+    qk = v[:, : nq + nk].reshape(M, heads + kv_heads, dh // 2, 2)
+    c, s_ = cos_row.double(), sin_row.double()
+    rot = torch.stack([qk[..., 0] * c - qk[..., 1] * s_, qk[..., 1] * c + qk[..., 0] * s_], dim=-1)
+    exp[:, : nq + nk] = rot.reshape(M, nq + nk)
+    y = torch.empty(M, nq, device=DEV)
+    cache = torch.zeros(M, 5, 2 * nk + 8, device=DEV)
+    ops.gemv(x.to(DEV), rw, y, norm=("rms", nw.to(DEV), None, 1e-5), y2=cache[:, 2, : 2 * nk],
+             rope=(cos_row.to(DEV), sin_row.to(DEV), dh, nq + nk))
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu(), exp[:, :nq]) < 1e-5, rel_err(y.cpu(), exp[:, :nq])
+    assert rel_err(cache[:, 2, : 2 * nk].cpu(), exp[:, nq:]) < 1e-5
+    assert float(cache[:, 1].abs().max()) == 0.0 and float(cache[:, 3].abs().max()) == 0.0 and float(cache[:, 2, 2 * nk:].abs().max()) == 0.0
