@@ -238,16 +238,136 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const mi355_gemv_args a)
   else a.y[(int64_t)m * a.ldy + n] = v * a.out_scale;
 }
 
+// ---------------------------------------------------------------------------------------------- streaming variant (no fused norm, any K % 64 == 0)
+// Without a fused norm nothing forces the workgroup to see whole rows, so each WAVE stages only the x columns of ITS OWN k steps, in a private 2 KB
+// LDS window, and there is no workgroup barrier before the final split-K reduction: lane (row = lane >> 3, part = lane & 7) loads the 8 floats
+// x[row][64 s + 8 part .. + 8) of step s (prefetched kDX steps ahead next to the weight ring), splits them into the hi / lo images and writes one
+// 16-byte piece each in the same fragment order as above; the LDS queue of a wave is in order, a wave-level fence separates write and read.
+// Takes the K > 2048 images (down projections: K = 3072 / 6144 / 8192) that the staged kernel's single chunk cannot hold.
+constexpr int kDX = 4;
+
+template <bool F16>
+__global__ __launch_bounds__(256) void gemv_mfma_stream_kernel(const mi355_gemv_args a) {
+  __shared__ __attribute__((aligned(16))) uint4 win[4][2][64];   // [wave][image][piece]
+  __shared__ float red[4][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * 16;
+  const int K = a.K, M = a.M;
+  const int steps_total = K >> 6;
+  const int gi = lane >> 4, li = lane & 15;
+  const int nrow = n0 + li < a.N ? n0 + li : a.N - 1;
+  const uint16_t* wrow = a.w + (int64_t)nrow * a.ldw + 16 * gi;
+  const int xr = lane >> 3, xp = lane & 7;                       // staging role: input row / 8-column part of the step
+  const float* xrow = a.x + (int64_t)(xr < M ? xr : 0) * a.ldx + 8 * xp;
+  const int wpiece = ((xp & 1) * 4 + (xp >> 1)) * 8 + xr;        // (half, group, row) of the piece this lane writes
+
+  uint4 ring[kD][2];
+  float4 xring[kDX][2];
+  auto issue_w = [&](const int s, uint4 (&dst)[2]) {
+    const uint16_t* p = wrow + ((int64_t)s << 6);
+    dst[0] = *(const uint4*)p;
+    dst[1] = *(const uint4*)(p + 8);
+  };
+  auto issue_x = [&](const int s, float4 (&dst)[2]) {
+    if (xr < M) {
+      const float* p = xrow + ((int64_t)s << 6);
+      dst[0] = *(const float4*)p;
+      dst[1] = *(const float4*)(p + 4);
+    } else {
+      dst[0] = dst[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < kD; ++d)
+    if (wave + 4 * d < steps_total) issue_w(wave + 4 * d, ring[d]);
+#pragma unroll
+  for (int d = 0; d < kDX; ++d)
+    if (wave + 4 * d < steps_total) issue_x(wave + 4 * d, xring[d]);
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int it = 0;; ++it) {
+    const int s = wave + 4 * it;
+    if (s >= steps_total) break;
+    uint4 w0, w1;
+    float4 x0, x1;
+    const int slot = it % kD, xslot = it % kDX;
+#pragma unroll
+    for (int d = 0; d < kD; ++d) {
+      if (slot == d) {
+        w0 = ring[d][0];
+        w1 = ring[d][1];
+        if (s + 4 * kD < steps_total) issue_w(s + 4 * kD, ring[d]);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < kDX; ++d) {
+      if (xslot == d) {
+        x0 = xring[d][0];
+        x1 = xring[d][1];
+        if (s + 4 * kDX < steps_total) issue_x(s + 4 * kDX, xring[d]);
+      }
+    }
+    uint4 hi, lo;
+    split2<F16>(x0.x, x0.y, hi.x, lo.x);
+    split2<F16>(x0.z, x0.w, hi.y, lo.y);
+    split2<F16>(x1.x, x1.y, hi.z, lo.z);
+    split2<F16>(x1.z, x1.w, hi.w, lo.w);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the previous step's fragment reads are done (in-order LDS queue of the wave)
+    __builtin_amdgcn_wave_barrier();
+    win[wave][0][wpiece] = hi;
+    win[wave][1][wpiece] = lo;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int p0 = (0 * 4 + gi) * 8 + (li & 7), p1 = (1 * 4 + gi) * 8 + (li & 7);
+    const uint4 h0 = win[wave][0][p0], h1 = win[wave][0][p1], l0 = win[wave][1][p0], l1 = win[wave][1][p1];
+    acc = mfma_16<F16>(w0, h0, acc);
+    acc = mfma_16<F16>(w1, h1, acc);
+    acc = mfma_16<F16>(w0, l0, acc);
+    acc = mfma_16<F16>(w1, l1, acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave][(4 * gi + r) * 16 + li] = acc[r];
+  __syncthreads();
+  const int i = tid & 15, m = tid >> 4;
+  const int n = n0 + i;
+  if (m >= M || n >= a.N) return;
+  const float v0 = (red[0][i * 16 + m] + red[1][i * 16 + m]) + (red[2][i * 16 + m] + red[3][i * 16 + m]);
+  if (a.glu) {
+    if (i & 1) return;
+    const float v1 = (red[0][(i + 1) * 16 + m] + red[1][(i + 1) * 16 + m]) + (red[2][(i + 1) * 16 + m] + red[3][(i + 1) * 16 + m]);
+    const float g = v0 + (a.bias ? a.bias[n] : 0.f), u = v1 + (a.bias ? a.bias[n + 1] : 0.f);
+    a.y[(int64_t)m * a.ldy + (n >> 1)] = (g / (1.0f + expf(-g))) * u * a.out_scale;
+    return;
+  }
+  float v = mfma_act(v0 + (a.bias ? a.bias[n] : 0.f), a.post_act, a.post_slope) * (a.colscale ? a.colscale[n] : 1.f);
+  if (a.res) v += a.res[(int64_t)m * a.ldr + n];
+  if (a.y2 && n >= a.split) a.y2[(int64_t)m * a.ldy2 + (n - a.split)] = v * a.out_scale;
+  else a.y[(int64_t)m * a.ldy + n] = v * a.out_scale;
+}
+
 }  // namespace
 
 // 1 = this call qualifies for the matrix-pipe kernel (mi355_gemv dispatches here unless MI355_GEMV_MFMA=0)
+// MI355_GEMV_MFMA_STREAM: 0 = streaming variant off, 1 (default) = for images the staged kernel cannot take (no fused norm, K > 2048),
+// 2 = for every call without a fused norm (A/B)
+static int stream_mode() {
+  static const int mode = getenv("MI355_GEMV_MFMA_STREAM") ? atoi(getenv("MI355_GEMV_MFMA_STREAM")) : 1;
+  return mode;
+}
+
+static bool use_stream(const mi355_gemv_args& a) {
+  if (a.norm) return false;
+  return stream_mode() == 2 || (stream_mode() == 1 && a.K > kKC);
+}
+
 int mi355_gemv_mfma_eligible(const mi355_gemv_args& a) {
   static const bool off = getenv("MI355_GEMV_MFMA") != nullptr && getenv("MI355_GEMV_MFMA")[0] == '0';
   if (off) return 0;
   if (a.M < 5 || a.M > 8 || a.rope_cos) return 0;
   if (a.wdtype != MI355_W_BF16 && a.wdtype != MI355_W_F16) return 0;
   if (a.K % 64 || a.K < 64 || a.ldw % 8 || ((uintptr_t)a.w) % 16 || a.ldx % 4 || ((uintptr_t)a.x) % 16) return 0;
-  if (a.K > kKC) return 0;   // one staged chunk only: the chunk loop's workgroup barriers cost more than they save (K = 6144: 25 vs 15 us, call 26)
+  if (a.K > kKC && !use_stream(a)) return 0;   // the staged kernel holds one chunk: its chunk loop's workgroup barriers cost more than they save (call 26)
   if (a.glu && (a.N % 2)) return 0;
   return 1;
 }
@@ -255,6 +375,14 @@ int mi355_gemv_mfma_eligible(const mi355_gemv_args& a) {
 int mi355_gemv_mfma_launch(const mi355_gemv_args& a, hipStream_t st) {
   static bool attr_set[2] = {false, false};  // benign race: the attribute is idempotent
   const bool f16 = a.wdtype == MI355_W_F16;
+  const dim3 grid((a.N + 15) / 16);
+  if (use_stream(a)) {
+    MI355_CLEAR_ERROR();
+    if (f16) hipLaunchKernelGGL(gemv_mfma_stream_kernel<true>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(gemv_mfma_stream_kernel<false>, grid, dim3(256), 0, st, a);
+    MI355_LAUNCH_CHECK("gemv(mfma stream)");
+    return MI355_OK;
+  }
   const size_t lds = (size_t)(a.K < kKC ? a.K : kKC) * 32;
   if (!attr_set[f16]) {
     hipError_t e = f16 ? hipFuncSetAttribute((const void*)gemv_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kKC * 32)
@@ -263,7 +391,6 @@ int mi355_gemv_mfma_launch(const mi355_gemv_args& a, hipStream_t st) {
     attr_set[f16] = true;
   }
   MI355_CLEAR_ERROR();
-  const dim3 grid((a.N + 15) / 16);
   if (f16) hipLaunchKernelGGL(gemv_mfma_kernel<true>, grid, dim3(256), lds, st, a);
   else hipLaunchKernelGGL(gemv_mfma_kernel<false>, grid, dim3(256), lds, st, a);
   MI355_LAUNCH_CHECK("gemv(mfma)");
