@@ -11,12 +11,10 @@ echo "gemv tests (stream=2) rc=$?" | tee -a $R
 timeout 120 python tools/bench_csm.py > gpurun_out/bench_csm_35.json 2> gpurun_out/bench_csm_35.err; echo "csm rc=$?" | tee -a $R
 MI355_GEMV_ROPE=0 timeout 120 python tools/bench_csm.py > gpurun_out/bench_csm_35_norope.json 2> gpurun_out/bench_csm_35_norope.err; echo "csm (separate rope) rc=$?" | tee -a $R
 timeout 120 python tools/bench_qwen3.py --no-cpu-baseline > gpurun_out/bench_qwen3_35.json 2> gpurun_out/bench_qwen3_35.err; echo "qwen3 rc=$?" | tee -a $R
-timeout 120 python tools/bench_whisper.py --no-cpu-baseline > gpurun_out/bench_whisper_35.json 2> gpurun_out/bench_whisper_35.err; echo "whisper rc=$?" | tee -a $R
-MI355_GEMV_MFMA_STREAM=2 timeout 120 python tools/bench_qwen3.py --no-cpu-baseline > gpurun_out/bench_qwen3_35_s2.json 2> gpurun_out/bench_qwen3_35_s2.err; echo "qwen3 (stream=2) rc=$?" | tee -a $R
 cat $R; tail -n 15 gpurun_out/t_full35.log | cut -c1-250; tail -n 4 gpurun_out/t_gemv35_stream2.log | cut -c1-200
 python - <<'PY'
 import json
-for n in ("csm_35", "csm_35_norope", "qwen3_35", "qwen3_35_s2", "whisper_35"):
+for n in ("csm_35", "csm_35_norope", "qwen3_35"):
     try:
         d = json.loads(open(f"gpurun_out/bench_{n}.json").read().strip().splitlines()[-1])
         print(n, round(d["value"], 2), d["unit"], {k: round(d[k], 3) for k in d if "ms" in k and not isinstance(d[k], dict)})
