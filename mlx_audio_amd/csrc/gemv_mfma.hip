@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const mi355_gemv_args a)
 // LDS window, and there is no workgroup barrier before the final split-K reduction: lane (row = lane >> 3, part = lane & 7) loads the 8 floats
 // x[row][64 s + 8 part .. + 8) of step s (prefetched kDX steps ahead next to the weight ring), splits them into the hi / lo images and writes one
 // 16-byte piece each in the same fragment order as above; the LDS queue of a wave is in order, a wave-level fence separates write and read.
-// Takes the K > 2048 images (down projections: K = 3072 / 6144 / 8192) that the staged kernel's single chunk cannot hold.
+// Opt-in (MI355_GEMV_MFMA_STREAM, see stream_mode below): measured slower than the FMA kernel on the K > 2048 down projections.
 constexpr int kDX = 4;
 
 template <bool F16>
@@ -349,10 +349,12 @@ __global__ __launch_bounds__(256) void gemv_mfma_stream_kernel(const mi355_gemv_
 }  // namespace
 
 // 1 = this call qualifies for the matrix-pipe kernel (mi355_gemv dispatches here unless MI355_GEMV_MFMA=0)
-// MI355_GEMV_MFMA_STREAM: 0 = streaming variant off, 1 (default) = for images the staged kernel cannot take (no fused norm, K > 2048),
-// 2 = for every call without a fused norm (A/B)
+// MI355_GEMV_MFMA_STREAM: 0 (default) = streaming variant off: K > 2048 stays on the FMA kernel; 1 = for images the staged kernel cannot take
+// (no fused norm, K > 2048); 2 = for every call without a fused norm.  Parity-green in both modes (GPU call 35), but with N / 16 workgroups a wave
+// streams its whole K slice serially: Qwen3-TTS-1.7B ran 8.55 ms per frame with mode 1 against 7.81 with the FMA kernel on those images (24
+// steps per wave at K = 6144), so it is an A/B harness until it splits K over more waves.
 static int stream_mode() {
-  static const int mode = getenv("MI355_GEMV_MFMA_STREAM") ? atoi(getenv("MI355_GEMV_MFMA_STREAM")) : 1;
+  static const int mode = getenv("MI355_GEMV_MFMA_STREAM") ? atoi(getenv("MI355_GEMV_MFMA_STREAM")) : 0;
   return mode;
 }
 
