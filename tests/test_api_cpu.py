@@ -405,3 +405,25 @@ def test_kokoro_batch_session_protocol(tmp_path):
     assert sorted(r.sequence_idx for r in res) == [0, 1] and all(r.samples == r.audio.numel() for r in res)
     with pytest.raises(FileNotFoundError):
         list(m2.batch_generate([short], voices="missing"))
+
+
+def test_codec_package_exports_match_reference_names():
+    """mlx_audio/codec/__init__.py and codec/models/__init__.py: the built decoders resolve under the reference's names (lazily, without a GPU);
+    the codecs outside the scope raise ImportError, unknown names AttributeError."""
+    import mlx_audio_amd.codec as C
+    import mlx_audio_amd.codec.models as CM
+    from mlx_audio_amd.codec.models.descript import DAC
+    from mlx_audio_amd.codec.models.snac import SNAC
+
+    assert C.DAC is DAC and CM.SNAC is SNAC and C.Vocos.__name__ == "Vocos" and CM.Mimi.__name__ == "MimiDecoder"
+    assert set(CM.__all__) == {"DAC", "SNAC", "Vocos", "Mimi"}
+    with pytest.raises(ImportError):
+        CM.Encodec
+    with pytest.raises(AttributeError):
+        CM.NoSuchCodec
+    # constructing an engine without a ROCm device fails loudly (no CPU fallback)
+    if not torch.cuda.is_available():
+        from mlx_audio_amd import _lib
+
+        with pytest.raises(_lib.Mi355Error):
+            SNAC(attn_window_size=None)
