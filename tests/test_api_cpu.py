@@ -427,3 +427,76 @@ def test_codec_package_exports_match_reference_names():
 
         with pytest.raises(_lib.Mi355Error):
             SNAC(attn_window_size=None)
+
+
+def _drain(handle, timeout=10.0):
+    """All chunks of a request up to and including 'done'."""
+    import queue as _q
+
+    out = []
+    while True:
+        try:
+            c = handle.result_queue.get(timeout=timeout)
+        except _q.Empty:
+            raise AssertionError(f"request {handle.context.request_id} never finished: {[x.kind for x in out]}")
+        out.append(c)
+        if c.kind == "done":
+            return out
+
+
+def test_inference_broker_continuous_batching(tmp_path):
+    """mlx_audio/server_inference.py surface over the Kokoro batch session: concurrent requests share engine passes, a failing request gets its own
+    error chunk, a cancelled one is dropped, more requests than slots wait in the backlog, stop_and_join fails what is still active."""
+    from mlx_audio_amd.server_inference import BaseModelExecutionAdapter, InferenceBroker, TTSExecutionAdapter
+    from mlx_audio_amd.tts.models.kokoro import synthetic as S
+
+    vocab = [p for p in S.KOKORO_CONFIG["vocab"] if p.strip() and p not in "!.?…:;,— "]
+    short = "".join(vocab[:12])
+    m, _ = _session_model(tmp_path)
+    broker = InferenceBroker(idle_poll_s=0.01)
+    try:
+        with pytest.raises(ValueError):
+            broker.submit(endpoint_kind="tts", model_name="kokoro", payload={"text": short})
+        broker.register_adapter("tts", TTSExecutionAdapter({"kokoro": m}, max_batch_size=2))
+        hs = [broker.submit(endpoint_kind="tts", model_name="kokoro", payload={"text": short[: 6 + i], "voice": "v"}) for i in range(5)]   # 5 requests, 2 slots
+        bad = broker.submit(endpoint_kind="tts", model_name="kokoro", payload={"text": short, "voice": "nope"})
+        assert hs[0].context.batch_key == ("tts", False, "a") and hs[0].context.endpoint_kind == "tts"
+        for i, h in enumerate(hs):
+            chunks = _drain(h)
+            assert [c.kind for c in chunks] == ["data", "done"], [c.kind for c in chunks]
+            ev = chunks[0].payload
+            assert ev.done and ev.samples == 10 * (6 + i + 2) and float(ev.audio[0]) == 6 + i - 1      # fake engine: 10 samples per id, value = voice row
+        chunks = _drain(bad)
+        assert [c.kind for c in chunks] == ["error", "done"] and isinstance(chunks[0].error, FileNotFoundError)
+        assert max(c["n"] for c in m.engine.calls) == 2 and sum(c["n"] for c in m.engine.calls) == 5   # two slots: passes of <= 2 utterances, 5 in total
+        # unknown model: the session cannot be created -> error + done on that request only
+        chunks = _drain(broker.submit(endpoint_kind="tts", model_name="other", payload={"text": short}))
+        assert [c.kind for c in chunks] == ["error", "done"] and isinstance(chunks[0].error, ValueError)
+        # a cancelled request never reaches the engine
+        n_before = len(m.engine.calls)
+        h = broker.submit(endpoint_kind="tts", model_name="kokoro", payload={"text": short, "voice": "v"})
+        h.cancel()
+        time_limit = 50
+        while time_limit and not broker._inbox.empty():
+            import time as _t
+
+            _t.sleep(0.01)
+            time_limit -= 1
+        # serial fallback for a model without the session hooks
+        class Plain:
+            def generate(self, text, **kw):
+                yield ("seg", text, kw.get("voice"))
+
+        class Serial(BaseModelExecutionAdapter):
+            def run_serial(self, request):
+                for r in Plain().generate(request.payload["text"], voice=request.payload.get("voice")):
+                    request.emit_data(r)
+                request.emit_done()
+
+        broker.register_adapter("plain", Serial())
+        chunks = _drain(broker.submit(endpoint_kind="plain", model_name="x", payload={"text": "abc", "voice": "w"}))
+        assert [c.kind for c in chunks] == ["data", "done"] and chunks[0].payload == ("seg", "abc", "w")
+        assert len(m.engine.calls) in (n_before, n_before + 1)    # the cancelled request was dropped before or right after admission, never synthesised twice
+    finally:
+        broker.stop_and_join(timeout=5.0)
+    assert not broker._worker.is_alive()
