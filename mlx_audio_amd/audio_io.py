@@ -1,0 +1,166 @@
+"""Audio file I/O at the edges of the hot path: ``read`` / ``write`` / ``sf_read`` / ``sf_write`` with the signatures of ``mlx_audio/audio_io.py``
+(``:232-248, 486-491, 605-639``), for the container this build handles itself: RIFF / WAVE (PCM 8 / 16 / 24 / 32 bit, IEEE float 32 / 64,
+``WAVE_FORMAT_EXTENSIBLE``) and headerless PCM16 on the write side.
+
+Conventions kept from the reference: decoded audio passes through signed 16-bit samples (the reference decodes with miniaudio to s16,
+``audio_io.py:339-341``), ``dtype='float32' | 'float64'`` divides by 32768 (``:349-352``), mono comes back 1-D unless ``always_2d`` (``:343-368``),
+``write`` clips floats to [-1, 1] and scales by 32767 with truncation (``:526-531``), integer input other than int16 is cast, the format is taken
+from the extension (WAV for a ``BytesIO``), unknown formats raise ``ValueError`` (``:601-602``).  Not kept: the compressed containers (mp3 / flac /
+ogg / opus / webm / m4a go through ffmpeg or miniaudio in the reference; neither is part of this image) raise ``RuntimeError`` naming the gap, and a
+``sample_rate`` different from the file's is served by ``scipy.signal.resample_poly`` (a Kaiser-windowed polyphase FIR like the reference's
+``resample.py``, but not coefficient-identical: **this module is host convenience, not a parity-pinned path**).
+"""
+from __future__ import annotations
+
+import io
+import struct
+from pathlib import Path
+from typing import Optional, Tuple, Union
+
+import numpy as np
+
+_COMPRESSED = ("flac", "mp3", "ogg", "opus", "vorbis", "webm", "m4a", "aac")
+FileLike = Union[str, Path, io.BytesIO]
+
+
+def _riff_chunks(buf: bytes):
+    if len(buf) < 12 or buf[:4] != b"RIFF" or buf[8:12] != b"WAVE":
+        kind = "Ogg" if buf[:4] == b"OggS" else "MP4 / M4A" if buf[4:8] == b"ftyp" else "FLAC" if buf[:4] == b"fLaC" else "MP3" if buf[:3] == b"ID3" else None
+        if kind:
+            raise RuntimeError(f"{kind} decoding needs ffmpeg / miniaudio, which this build does not contain; convert to WAV first")
+        raise ValueError("Unsupported format: not a RIFF / WAVE stream")
+    pos = 12
+    while pos + 8 <= len(buf):
+        cid, size = buf[pos:pos + 4], struct.unpack("<I", buf[pos + 4:pos + 8])[0]
+        yield cid, buf[pos + 8:pos + 8 + size]
+        pos += 8 + size + (size & 1)
+
+
+def _decode_wav(buf: bytes) -> Tuple[np.ndarray, int, int]:
+    """-> (int16 samples [frames, channels], sample rate, channels)."""
+    fmt = data = None
+    for cid, body in _riff_chunks(buf):
+        if cid == b"fmt ":
+            fmt = body
+        elif cid == b"data":
+            data = body
+    if fmt is None or data is None or len(fmt) < 16:
+        raise ValueError("malformed WAV: missing fmt / data chunk")
+    tag, nch, rate, _, _, bits = struct.unpack("<HHIIHH", fmt[:16])
+    if tag == 0xFFFE and len(fmt) >= 26:   # WAVE_FORMAT_EXTENSIBLE: the sub-format's first two bytes are the real tag
+        tag = struct.unpack("<H", fmt[24:26])[0]
+    if nch <= 0 or rate <= 0:
+        raise ValueError("malformed WAV: bad channel count / sample rate")
+    if tag == 1:
+        if bits == 16:
+            s = np.frombuffer(data[: len(data) // 2 * 2], dtype="<i2").astype(np.int16)
+        elif bits == 8:
+            s = ((np.frombuffer(data, dtype=np.uint8).astype(np.int16) - 128) << 8).astype(np.int16)
+        elif bits == 24:
+            b = np.frombuffer(data[: len(data) // 3 * 3], dtype=np.uint8).reshape(-1, 3)
+            s = ((b[:, 1].astype(np.int32) | (b[:, 2].astype(np.int32) << 8)).astype(np.uint16)).view(np.int16)   # top 16 of 24 bits
+        elif bits == 32:
+            s = (np.frombuffer(data[: len(data) // 4 * 4], dtype="<i4") >> 16).astype(np.int16)
+        else:
+            raise ValueError(f"unsupported PCM width: {bits} bits")
+    elif tag == 3:
+        f = np.frombuffer(data, dtype="<f4" if bits == 32 else "<f8").astype(np.float64)
+        s = np.clip(np.rint(f * 32768.0), -32768, 32767).astype(np.int16)
+    else:
+        raise RuntimeError(f"WAV codec tag {tag:#x} (compressed) needs ffmpeg / miniaudio, which this build does not contain")
+    frames = s.size // nch
+    return s[: frames * nch].reshape(frames, nch), rate, nch
+
+
+def read(file: FileLike, always_2d: bool = False, dtype: str = "float64", sample_rate: Optional[int] = None, nchannels: Optional[int] = None):
+    """Reads a WAV file / buffer -> (samples, sample_rate); see the module docstring for the conventions."""
+    if sample_rate is not None and sample_rate <= 0:
+        raise ValueError(f"sample_rate must be positive, got {sample_rate}")
+    if nchannels is not None and nchannels <= 0:
+        raise ValueError(f"nchannels must be positive, got {nchannels}")
+    if isinstance(file, (str, Path)):
+        ext = Path(file).suffix.lstrip(".").lower()
+        if ext in _COMPRESSED:
+            raise RuntimeError(f"{ext.upper()} decoding needs ffmpeg / miniaudio, which this build does not contain; convert to WAV first")
+        with open(file, "rb") as f:
+            buf = f.read()
+    elif isinstance(file, io.BytesIO):
+        file.seek(0)
+        buf = file.read()
+        file.seek(0)
+    else:
+        raise TypeError(f"Unsupported file type: {type(file)}")
+    pcm, rate, nch = _decode_wav(buf)
+    x = pcm.astype(np.float64) / 32768.0
+    if nchannels is not None and nchannels != nch:
+        if nchannels == 1:
+            x = x.mean(axis=1, keepdims=True)
+        elif nch == 1:
+            x = np.repeat(x, nchannels, axis=1)
+        else:
+            raise ValueError(f"cannot convert {nch} channels to {nchannels}")
+        nch = nchannels
+    if sample_rate is not None and sample_rate != rate:
+        from math import gcd
+
+        from scipy.signal import resample_poly
+
+        g = gcd(int(sample_rate), int(rate))
+        x = resample_poly(x, int(sample_rate) // g, int(rate) // g, axis=0)
+        rate = int(sample_rate)
+    if dtype in ("float32", "float64"):
+        out = x.astype(dtype)
+    else:
+        out = np.clip(np.rint(x * 32768.0), -32768, 32767).astype(np.int16).astype(dtype)
+    if nch == 1 and not always_2d:
+        out = out[:, 0]
+    return out, rate
+
+
+def _to_int16(data) -> np.ndarray:
+    if not isinstance(data, np.ndarray):
+        if hasattr(data, "detach"):   # torch tensor (the engines return device tensors)
+            data = data.detach().cpu().numpy()
+        else:
+            data = np.asarray(data)
+    if data.dtype == np.float16:
+        data = data.astype(np.float32)
+    if data.dtype in (np.float32, np.float64):   # in the array's own precision, like the reference (a float32 product truncates differently from a float64 one)
+        return (np.clip(data, -1.0, 1.0) * 32767).astype(np.int16)
+    return data if data.dtype == np.int16 else data.astype(np.int16)
+
+
+def write(file: FileLike, data, samplerate: int, format: Optional[str] = None) -> None:
+    """Writes 16-bit PCM WAV (or headerless ``pcm`` / ``raw``).  ``data``: ``(samples,)`` or ``(samples, channels)``; numpy array or torch tensor."""
+    if format is None:
+        format = Path(file).suffix.lstrip(".").lower() if isinstance(file, (str, Path)) else "wav"
+    format = format.lower()
+    pcm = _to_int16(data)
+    nch = 1 if pcm.ndim == 1 else int(pcm.shape[1])
+    payload = np.ascontiguousarray(pcm).astype("<i2").tobytes()
+    if format in ("pcm", "raw"):
+        blob = payload
+    elif format == "wav":
+        hdr = struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + len(payload), b"WAVE", b"fmt ", 16, 1, nch, int(samplerate), int(samplerate) * nch * 2, nch * 2, 16,
+                          b"data", len(payload))
+        blob = hdr + payload
+    elif format in _COMPRESSED:
+        raise RuntimeError(f"{format.upper()} encoding needs ffmpeg, which this build does not contain; use WAV")
+    else:
+        raise ValueError(f"Unsupported output format: {format}")
+    if isinstance(file, io.BytesIO):
+        file.write(blob)
+        file.seek(0)
+    else:
+        with open(file, "wb") as f:
+            f.write(blob)
+
+
+def sf_read(file: FileLike, always_2d: bool = False):
+    """soundfile-style alias (audio_io.py:605-620)."""
+    return read(file, always_2d=always_2d, dtype="float64")
+
+
+def sf_write(file: FileLike, data, samplerate: int, format: Optional[str] = None) -> None:
+    """soundfile-style alias (audio_io.py:623-639)."""
+    write(file, data, samplerate, format=format)

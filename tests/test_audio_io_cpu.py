@@ -1,0 +1,102 @@
+"""mlx_audio_amd.audio_io against the behaviour the reference's tests pin for the WAV path (mlx_audio/tests/test_audio_io.py:42-86, 282-350) and
+against Python's own ``wave`` module as an independent RIFF reader / writer.  CPU only."""
+import io
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+from mlx_audio_amd.audio_io import read, sf_read, sf_write, write
+
+
+def _tone(freqs, sr=16000):
+    t = np.linspace(0, 1.0, sr)
+    cols = [np.sin(2 * np.pi * f * t).astype(np.float32) for f in freqs]
+    return cols[0] if len(cols) == 1 else np.column_stack(cols)
+
+
+def test_write_read_wav_mono_and_stereo(tmp_path):
+    for freqs in ((440,), (440, 880)):
+        data = _tone(freqs)
+        f = tmp_path / f"t{len(freqs)}.wav"
+        write(f, data, 16000, format="wav")
+        got, sr = read(f)
+        assert sr == 16000 and got.shape == data.shape and got.dtype == np.float64
+        assert np.abs(got - data).max() < 2.0 / 32767          # one 16-bit step of the truncating write + the 32767 / 32768 scale pair
+        # the file is a plain PCM16 WAV any RIFF reader opens
+        with wave.open(str(f), "rb") as w:
+            assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (len(freqs), 2, 16000, 16000)
+            raw = np.frombuffer(w.readframes(16000), dtype="<i2")
+        assert np.array_equal(raw, (np.clip(data, -1, 1) * 32767).astype(np.int16).reshape(-1))   # audio_io.py:526-531: clip, x 32767, truncate
+
+
+def test_read_dtypes_2d_channels_and_rate(tmp_path):
+    data = _tone((440, 880))
+    f = tmp_path / "s.wav"
+    write(f, data, 16000)
+    i16, _ = read(f, dtype="int16")
+    f32, _ = read(f, dtype="float32", always_2d=True)
+    assert i16.dtype == np.int16 and f32.dtype == np.float32 and f32.shape == (16000, 2)
+    assert np.array_equal((f32 * 32768.0).round().astype(np.int16), i16)         # float = int16 / 32768 (audio_io.py:349-352)
+    mono, sr = read(f, nchannels=1, sample_rate=8000, dtype="float32")            # test_read_wav_target_sample_rate_and_channels
+    assert sr == 8000 and mono.shape == (8000,)
+    m2, _ = read(f, nchannels=1, always_2d=True)
+    assert m2.shape == (16000, 1) and np.allclose(m2[:, 0], read(f)[0].mean(axis=1))
+    up, _ = read(tmp_path / "s.wav", nchannels=2)
+    assert up.shape == (16000, 2)
+    for bad in (dict(sample_rate=0), dict(nchannels=-1)):
+        with pytest.raises(ValueError):
+            read(f, **bad)
+    with pytest.raises(TypeError):
+        read(12345)
+
+
+def test_bytesio_int16_torch_clipping_and_formats(tmp_path):
+    bio = io.BytesIO()
+    write(bio, np.array([1.5, -1.5, 0.5, -0.5], dtype=np.float32), 22050)        # BytesIO defaults to WAV; values outside [-1, 1] are clipped
+    got, sr = read(bio, dtype="int16")
+    assert sr == 22050 and got.tolist() == [32767, -32767, 16383, -16383]
+    write(tmp_path / "i.wav", (np.array([0.0, 0.1, -0.1]) * 32767).astype(np.int16), 8000)   # int16 passes through, short files are fine
+    assert read(tmp_path / "i.wav", dtype="int16")[0].tolist() == [0, 3276, -3276]
+    write(tmp_path / "t.wav", torch.linspace(-1, 1, 101), 24000)                  # engine outputs are torch tensors
+    assert read(tmp_path / "t.wav")[0].shape == (101,)
+    write(tmp_path / "x.pcm", np.array([1, -2, 3], dtype=np.int32), 16000)        # headerless PCM16, other integer types are cast
+    assert (tmp_path / "x.pcm").read_bytes() == np.array([1, -2, 3], dtype="<i2").tobytes()
+    sf_write(tmp_path / "a.wav", _tone((440,)).astype(np.float64), 44100)
+    a, sr = sf_read(tmp_path / "a.wav", always_2d=True)
+    assert sr == 44100 and a.shape == (16000, 1) and a.dtype == np.float64
+    with pytest.raises(RuntimeError):
+        write(tmp_path / "a.mp3", _tone((440,)), 16000)                           # compressed containers need ffmpeg: loud, not silent
+    with pytest.raises(ValueError):
+        write(tmp_path / "a.xyz", _tone((440,)), 16000)
+    with pytest.raises(RuntimeError):
+        read(tmp_path / "missing.ogg")
+    with pytest.raises(RuntimeError):
+        read(io.BytesIO(b"OggS" + b"\0" * 32))
+    with pytest.raises(ValueError):
+        read(io.BytesIO(b"not audio at all"))
+
+
+def test_reads_other_pcm_widths_written_by_the_wave_module(tmp_path):
+    x = (np.sin(np.linspace(0, 20, 4000)) * 0.8)
+    for width, dt, scale in ((1, np.uint8, None), (3, None, None), (4, "<i4", 2 ** 31 - 1)):
+        f = tmp_path / f"w{width}.wav"
+        with wave.open(str(f), "wb") as w:
+            w.setnchannels(1); w.setsampwidth(width); w.setframerate(12000)
+            if width == 1:
+                w.writeframes(((x * 127) + 128).astype(np.uint8).tobytes())
+            elif width == 3:
+                v = (x * (2 ** 23 - 1)).astype(np.int32)
+                w.writeframes(b"".join(int(s).to_bytes(3, "little", signed=True) for s in v))
+            else:
+                w.writeframes((x * scale).astype(dt).tobytes())
+        got, sr = read(f)
+        assert sr == 12000 and got.shape == (4000,) and np.abs(got - x).max() < (0.02 if width == 1 else 1e-4)
+    # IEEE float WAV (tag 3), hand-built header
+    import struct
+
+    pay = x.astype("<f4").tobytes()
+    hdr = struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + len(pay), b"WAVE", b"fmt ", 16, 3, 1, 12000, 48000, 4, 32, b"data", len(pay))
+    got, _ = read(io.BytesIO(hdr + pay))
+    assert np.abs(got - x).max() < 1e-4
