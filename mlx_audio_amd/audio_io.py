@@ -6,9 +6,9 @@ Conventions kept from the reference: decoded audio passes through signed 16-bit 
 ``audio_io.py:339-341``), ``dtype='float32' | 'float64'`` divides by 32768 (``:349-352``), mono comes back 1-D unless ``always_2d`` (``:343-368``),
 ``write`` clips floats to [-1, 1] and scales by 32767 with truncation (``:526-531``), integer input other than int16 is cast, the format is taken
 from the extension (WAV for a ``BytesIO``), unknown formats raise ``ValueError`` (``:601-602``).  Not kept: the compressed containers (mp3 / flac /
-ogg / opus / webm / m4a go through ffmpeg or miniaudio in the reference; neither is part of this image) raise ``RuntimeError`` naming the gap, and a
-``sample_rate`` different from the file's is served by ``scipy.signal.resample_poly`` (a Kaiser-windowed polyphase FIR like the reference's
-``resample.py``, but not coefficient-identical: **this module is host convenience, not a parity-pinned path**).
+ogg / opus / webm / m4a go through ffmpeg or miniaudio in the reference; neither is part of this image) raise ``RuntimeError`` naming the gap.  A
+``sample_rate`` different from the file's goes through ``mlx_audio_amd.resample`` (the reference's ``kaiser_best`` polyphase FIR; the reference uses
+miniaudio's converter for upsampling and this FIR for downsampling, ``audio_io.py:318-330``: here one filter serves both directions).
 """
 from __future__ import annotations
 
@@ -101,12 +101,9 @@ def read(file: FileLike, always_2d: bool = False, dtype: str = "float64", sample
             raise ValueError(f"cannot convert {nch} channels to {nchannels}")
         nch = nchannels
     if sample_rate is not None and sample_rate != rate:
-        from math import gcd
+        from .resample import resample_audio_array
 
-        from scipy.signal import resample_poly
-
-        g = gcd(int(sample_rate), int(rate))
-        x = resample_poly(x, int(sample_rate) // g, int(rate) // g, axis=0)
+        x = resample_audio_array(x, rate, int(sample_rate), axis=0).astype(np.float64)   # the reference's kaiser_best polyphase FIR (resample.py)
         rate = int(sample_rate)
     if dtype in ("float32", "float64"):
         out = x.astype(dtype)

@@ -126,3 +126,11 @@ def load_model(model_name: str, **kwargs):
     if kind is None:
         raise ValueError(f"Model type {cfg.get('model_type')} not supported.")
     return importlib.import_module(f"mlx_audio_amd.{kind}.utils").load_model(Path(path), **kwargs)
+
+
+def resample_audio(audio, orig_sample_rate: int, sample_rate: int, axis: int = -1):
+    """``mlx_audio.utils.resample_audio`` (utils.py:541-578): polyphase resampling with the reference's ``kaiser_best`` filter; the return type matches
+    the input type (numpy array or torch tensor)."""
+    from .resample import resample_audio as _impl
+
+    return _impl(audio, orig_sample_rate, sample_rate, axis=axis)

@@ -100,3 +100,29 @@ def test_reads_other_pcm_widths_written_by_the_wave_module(tmp_path):
     hdr = struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + len(pay), b"WAVE", b"fmt ", 16, 3, 1, 12000, 48000, 4, 32, b"data", len(pay))
     got, _ = read(io.BytesIO(hdr + pay))
     assert np.abs(got - x).max() < 1e-4
+
+
+def test_resample_properties_pinned_by_the_reference_tests():
+    """mlx_audio/tests/test_dsp.py:299-349: a tone 200 Hz above the new Nyquist is removed (RMS < 0.01; scipy's default Kaiser(5) leaves ~0.26), in-band
+    tones keep unit gain up to the band edge (RMS of a full-scale sine 0.70 .. 0.72), the length follows the ratio, equal rates return the input itself;
+    plus the design constants of resample.py:15-26."""
+    from mlx_audio_amd import resample as R
+    from mlx_audio_amd.utils import resample_audio
+
+    orig, target = 24000, 16000
+    t = np.arange(2 * orig) / orig
+    out = np.asarray(resample_audio(np.sin(2 * np.pi * 8200.0 * t).astype(np.float32), orig, target))
+    assert float(np.sqrt(np.mean(out[400:-400] ** 2))) < 0.01
+    for freq in (1000.0, 7000.0):
+        out = np.asarray(resample_audio(np.sin(2 * np.pi * freq * t).astype(np.float32), orig, target))
+        assert 0.70 < float(np.sqrt(np.mean(out[400:-400] ** 2))) < 0.72
+    z = resample_audio(np.zeros(24000, dtype=np.float32), 24000, 16000)
+    assert isinstance(z, np.ndarray) and z.dtype == np.float32 and abs(len(z) - 16000) <= 1
+    zt = resample_audio(torch.zeros(24000), 24000, 16000)
+    assert isinstance(zt, torch.Tensor) and abs(zt.numel() - 16000) <= 1
+    x = np.linspace(-1.0, 1.0, 100, dtype=np.float32)
+    assert resample_audio(x, 16000, 16000) is x
+    up, down, taps = R.polyphase_design(44100, 16000)
+    assert (up, down) == (160, 441) and len(taps) == 2 * 64 * 441 + 1 and abs(float(taps.sum()) - 1.0) < 1e-6
+    st = np.stack([np.sin(2 * np.pi * 440 * t), np.sin(2 * np.pi * 880 * t)], axis=1).astype(np.float32)      # time-first stereo, axis = 0
+    assert R.resample_audio_array(st, orig, target, axis=0).shape == (2 * target, 2)
