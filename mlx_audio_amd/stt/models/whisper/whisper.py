@@ -15,6 +15,7 @@ fallback temperatures > 0 (the device loop is greedy; the fallback tuple collaps
 from __future__ import annotations
 
 import time
+from pathlib import Path
 from typing import Dict, List, Optional, Tuple, Union
 
 import numpy as np
@@ -158,8 +159,10 @@ class Model:
 
     # ------------------------------------------------------------------ generate (whisper.py:799-1320, condensed)
     def _prepare_audio(self, audio, padding: int = N_SAMPLES) -> Tuple[torch.Tensor, int]:
-        if isinstance(audio, str):
-            raise NotImplementedError("audio file loading is outside the MI355X hot path: pass a 16 kHz waveform array")
+        if isinstance(audio, (str, Path)):   # whisper.py:826-829: a path is loaded as a mono 16 kHz waveform (WAV / PCM in this build)
+            from ...utils import load_audio
+
+            audio = load_audio(audio)
         if not isinstance(audio, torch.Tensor):
             audio = torch.from_numpy(np.asarray(audio, dtype=np.float32))
         mel = log_mel_spectrogram(audio, n_mels=self.dims.n_mels, padding=padding)

@@ -126,3 +126,19 @@ def test_resample_properties_pinned_by_the_reference_tests():
     assert (up, down) == (160, 441) and len(taps) == 2 * 64 * 441 + 1 and abs(float(taps.sum()) - 1.0) < 1e-6
     st = np.stack([np.sin(2 * np.pi * 440 * t), np.sin(2 * np.pi * 880 * t)], axis=1).astype(np.float32)      # time-first stereo, axis = 0
     assert R.resample_audio_array(st, orig, target, axis=0).shape == (2 * target, 2)
+
+
+def test_stt_load_audio_mono_16k(tmp_path):
+    """mlx_audio/stt/utils.py:106-130 + tests/test_audio_io.py::test_stt_load_audio_rejects_alias: a 24 kHz stereo file comes back as a mono float32
+    16 kHz waveform, and a tone above the new Nyquist does not alias into it."""
+    from mlx_audio_amd.stt.utils import load_audio
+
+    sr = 24000
+    t = np.arange(2 * sr) / sr
+    st = np.stack([0.5 * np.sin(2 * np.pi * 440 * t), 0.5 * np.sin(2 * np.pi * 440 * t)], axis=1).astype(np.float32)
+    write(tmp_path / "a.wav", st, sr)
+    a = load_audio(tmp_path / "a.wav")
+    assert a.dtype == np.float32 and a.ndim == 1 and abs(len(a) - 32000) <= 1
+    assert 0.34 < float(np.sqrt(np.mean(a[400:-400] ** 2))) < 0.36          # 0.5 / sqrt(2)
+    write(tmp_path / "hi.wav", (0.9 * np.sin(2 * np.pi * 8200.0 * t)).astype(np.float32), sr)
+    assert float(np.sqrt(np.mean(load_audio(tmp_path / "hi.wav")[400:-400] ** 2))) < 0.01
