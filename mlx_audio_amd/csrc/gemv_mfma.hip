@@ -3,7 +3,7 @@
 // Same contract as mi355_gemv (gemv.hip; replaces nn.Linear at sequence length 1 for batches of 5..8 sequences: Whisper TextDecoder
 // stt/models/whisper/whisper.py:347-416, 498; Qwen3-TTS talker / code predictor tts/models/qwen3_tts/talker.py:230-330, 503-764).  The FMA
 // kernel does 8 fp32 FMAs per weight element at 8 rows and ran the weight stream at ~1 TB/s against ~3.7 TB/s at 1 row: its waves sit in
-// VALU / LDS work and latency-bound staging instead of keeping loads in flight (profiles/r1_gemv_launch_periods_call25.txt).  Here the products
+// VALU / LDS work and latency-bound staging instead of keeping loads in flight (profiles/r1_gemv_launch_periods_call23_27.txt).  Here the products
 // go to v_mfma_f32_16x16x32 (bf16 or fp16, the weights' own type):
 //   * A operand = a 16-row tile of W, straight from HBM: lane (i = lane & 15, g = lane >> 4) loads the 32 contiguous bytes W[n0 + i][k0 + 16 g ..
 //     + 16) of a 64-wide k step -- full 128-byte lines per row, no conversion, no LDS -- and feeds its two 16-byte halves to two MFMAs (the
