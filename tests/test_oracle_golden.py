@@ -190,3 +190,23 @@ def test_snac_decode_length_pin():
     lens = [1889, 15113, 60453, 120907]
     y = ref.decode(z, [torch.randn(1, n, 1, generator=g) for n in lens])
     assert tuple(y.shape) == (1, 120_907, 1) and float(y.abs().max()) <= 1.0
+
+
+def test_mimi_decode_shape_pin():
+    """codec/tests/test_mimi.py:11-21: ``mimi_202407(32)`` decodes codes (1, 32, 63) to audio (1, 1, 120960) = 63 frames x 1920 samples; the restated
+    decoder (split RVQ -> depthwise transposed-conv upsampler -> transformer -> SEANet) reproduces the pin at full width, and a shorter code sequence is
+    a sample-exact prefix of a longer one (the decoder is causal / streamable: ``modules/conv.py:245-331``)."""
+    from mlx_audio_amd.codec.models.mimi import mimi as M
+    from oracle.mimi_ref import MimiConfig as RC
+    from oracle.mimi_ref import MimiDecoderRef
+
+    cfg = M.mimi_202407(32)
+    w = M.make_mimi_decoder_weights(cfg, seed=0)
+    ref = MimiDecoderRef(w, RC(**{k: getattr(cfg, k) for k in RC.__dataclass_fields__}))
+    codes = M.make_codes(1, 63, cfg, seed=1)
+    assert tuple(codes.shape) == (1, 32, 63)
+    y = ref(codes)
+    assert tuple(y.shape) == (1, 1, 120_960) and bool(torch.isfinite(y).all())
+    y20 = ref(codes[:, :, :20])
+    assert tuple(y20.shape) == (1, 1, 20 * 1920)
+    np.testing.assert_allclose(y20.numpy(), y[..., : 20 * 1920].numpy(), rtol=0, atol=2e-5 * float(y.abs().max()))
