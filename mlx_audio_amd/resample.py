@@ -6,7 +6,8 @@ sinc with 64 zero crossings per side, roll-off 0.9475937167399596 and beta 14.76
 ``rolloff / max(up, down)`` of that Nyquist (``resample.py:15-26``) -- applied by ``scipy.signal.resample_poly`` with edge padding (``:40-47``).  The
 design constants ARE the algorithm; they are restated here and the properties the reference's tests pin (energy above the new Nyquist removed,
 pass band at unit gain, length, identity at equal rates: ``mlx_audio/tests/test_dsp.py:299-349``) are asserted in ``tests/test_audio_io_cpu.py``.
-A device-side polyphase kernel is the SURVEY 8(f).4 follow-up; the chunked variant (``resample_audio_chunks``) is not built.
+``resample_audio_chunks`` (``resample.py:50-161``) converts a stream of time-first chunks block by block with the SAME samples as one whole-buffer call
+(asserted bit-exactly, like ``test_dsp.py:351-380``).  A device-side polyphase kernel is the SURVEY 8(f).4 follow-up.
 """
 from __future__ import annotations
 
@@ -54,3 +55,89 @@ def resample_audio(audio, orig_sample_rate: int, sample_rate: int, axis: int = -
         out = resample_audio_array(audio.detach().cpu().numpy(), orig_sample_rate, sample_rate, axis=axis)
         return torch.from_numpy(np.ascontiguousarray(out)).to(audio.device)
     return resample_audio_array(np.asarray(audio), orig_sample_rate, sample_rate, axis=axis)
+
+
+class _FrameWindow:
+    """Rolling view over a stream of time-first chunks: ``take(a, b)`` returns frames [a, b) (clipped to what the stream holds), dropping everything
+    before the smallest start it will be asked for again."""
+
+    def __init__(self, chunks, first: np.ndarray):
+        self._it = iter(chunks)
+        self._buf = first
+        self._origin = 0
+        self._eof = False
+        self.trailing = first.shape[1:]
+
+    def _grow_to(self, end: int) -> None:
+        while not self._eof and self._origin + self._buf.shape[0] < end:
+            try:
+                part = np.asarray(next(self._it), dtype=np.float32)
+            except StopIteration:
+                self._eof = True
+                return
+            if part.shape[0] == 0:
+                continue
+            if part.shape[1:] != self.trailing:
+                raise ValueError("all audio chunks must have matching shapes")
+            self._buf = np.concatenate((self._buf, part), axis=0)
+
+    def available(self, end: int) -> int:
+        self._grow_to(end)
+        return self._origin + self._buf.shape[0]
+
+    def take(self, a: int, b: int) -> np.ndarray:
+        return self._buf[a - self._origin:b - self._origin]
+
+    def forget_before(self, a: int) -> None:
+        if a > self._origin:
+            self._buf = self._buf[a - self._origin:].copy()
+            self._origin = a
+
+
+def resample_audio_chunks(chunks, orig_sample_rate: int, sample_rate: int, num_input_frames: int, chunk_duration_seconds: float = 1.0) -> np.ndarray:
+    """Converts time-first audio chunks without materialising the whole input; the result equals ``resample_audio_array(whole, ..., axis=0)`` sample for
+    sample.  The stream is cut into core blocks whose boundaries are multiples of ``down`` input frames (so a block's first output has the same polyphase
+    phase as in the whole-buffer call: ``start * up / down`` is an integer), each block is converted together with a halo that covers the filter's support
+    on both sides, and only the block's own outputs are kept; the edge padding of ``resample_poly`` is therefore only ever seen at the true ends."""
+    if chunk_duration_seconds <= 0:
+        raise ValueError("chunk_duration_seconds must be positive")
+    it = iter(chunks)
+    first = None
+    for c in it:
+        c = np.asarray(c, dtype=np.float32)
+        if c.shape[0] > 0:
+            first = c
+            break
+    if first is None:
+        return np.empty((0,), dtype=np.float32)
+    total = max(0, int(num_input_frames))
+    if total == 0:
+        return np.empty((0, *first.shape[1:]), dtype=np.float32)
+    if orig_sample_rate == sample_rate:
+        return np.concatenate([first] + [np.asarray(c, dtype=np.float32) for c in it], axis=0)[:total]
+    from scipy import signal
+
+    up, down, taps = polyphase_design(int(orig_sample_rate), int(sample_rate))
+    block = max(down, int(chunk_duration_seconds * orig_sample_rate) // down * down)
+    reach = math.ceil(((len(taps) - 1) // 2 + down) / up)          # input frames one output can see on either side (+ the centring shift)
+    halo = math.ceil(reach / down) * down
+    n_out = math.ceil(total * up / down)
+    out = np.empty((n_out, *first.shape[1:]), dtype=np.float32)
+    win = _FrameWindow(it, first)
+    start, written = 0, 0
+    while start < total:
+        stop = min(total, start + block)
+        have = win.available(min(total, stop + halo))
+        if have < stop:                 # the stream ended before num_input_frames
+            stop = have
+            if stop <= start:
+                break
+        lo, hi = max(0, start - halo), min(min(total, stop + halo), have)
+        seg = signal.resample_poly(win.take(lo, hi), up, down, axis=0, window=taps, padtype="edge").astype(np.float32, copy=False)
+        o0, o1 = start * up // down, min(n_out, math.ceil(stop * up / down))
+        shift = o0 - lo * up // down
+        out[o0:o1] = seg[shift:shift + (o1 - o0)]
+        written = o1
+        start = stop
+        win.forget_before(max(0, start - halo))
+    return out[:written]

@@ -142,3 +142,30 @@ def test_stt_load_audio_mono_16k(tmp_path):
     assert 0.34 < float(np.sqrt(np.mean(a[400:-400] ** 2))) < 0.36          # 0.5 / sqrt(2)
     write(tmp_path / "hi.wav", (0.9 * np.sin(2 * np.pi * 8200.0 * t)).astype(np.float32), sr)
     assert float(np.sqrt(np.mean(load_audio(tmp_path / "hi.wav")[400:-400] ** 2))) < 0.01
+
+
+@pytest.mark.parametrize("orig", [24000, 44100, 48000])
+def test_chunked_resample_equals_whole_buffer(orig):
+    """mlx_audio/tests/test_dsp.py:351-380: ragged chunks through ``resample_audio_chunks`` give exactly the samples of one whole-buffer call."""
+    from mlx_audio_amd.resample import resample_audio_array, resample_audio_chunks
+
+    target = 16000
+    rng = np.random.default_rng(orig)
+    audio = rng.normal(0.0, 0.1, size=(2 * orig + 137, 2)).astype(np.float32)
+    sizes = (137, 997, 4096, 53, 1201)
+
+    def chunks():
+        a, i = 0, 0
+        while a < len(audio):
+            b = a + sizes[i % len(sizes)]
+            yield audio[a:b]
+            a, i = b, i + 1
+
+    whole = resample_audio_array(audio, orig, target, axis=0)
+    got = resample_audio_chunks(chunks(), orig, target, len(audio), chunk_duration_seconds=0.025)
+    np.testing.assert_array_equal(got, whole)
+    assert resample_audio_chunks(iter([]), orig, target, 10).shape == (0,)
+    same = resample_audio_chunks(chunks(), orig, orig, len(audio))
+    np.testing.assert_array_equal(same, audio)
+    with pytest.raises(ValueError):
+        resample_audio_chunks(chunks(), orig, target, len(audio), chunk_duration_seconds=0)
