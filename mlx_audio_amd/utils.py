@@ -134,3 +134,16 @@ def resample_audio(audio, orig_sample_rate: int, sample_rate: int, axis: int = -
     from .resample import resample_audio as _impl
 
     return _impl(audio, orig_sample_rate, sample_rate, axis=axis)
+
+
+# ``mlx_audio.utils`` re-exports the dsp entry points (utils.py:31-40; the reference's tests import them from here: tests/test_dsp.py:30-38).  Resolved
+# lazily so that ``import mlx_audio_amd.utils`` (loader, registry users) does not pull the dsp module in.
+_DSP_REEXPORTS = ("STR_TO_WINDOW_FN", "bartlett", "blackman", "hamming", "hanning", "istft", "mel_filters", "stft")
+
+
+def __getattr__(name):
+    if name in _DSP_REEXPORTS:
+        from . import dsp
+
+        return getattr(dsp, name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

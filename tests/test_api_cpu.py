@@ -500,3 +500,22 @@ def test_inference_broker_continuous_batching(tmp_path):
     finally:
         broker.stop_and_join(timeout=5.0)
     assert not broker._worker.is_alive()
+
+
+def test_utils_reexports_dsp_entry_points():
+    """mlx_audio/utils.py:31-40 + tests/test_dsp.py:30-38: the dsp functions are importable from ``utils`` (backward-compatible path), lazily."""
+    import subprocess
+    import sys
+
+    from mlx_audio_amd import dsp
+    from mlx_audio_amd.utils import STR_TO_WINDOW_FN, bartlett, blackman, hamming, hanning, istft, mel_filters, stft
+
+    assert stft is dsp.stft and istft is dsp.istft and mel_filters is dsp.mel_filters and hanning is dsp.hanning
+    assert hamming is dsp.hamming and blackman is dsp.blackman and bartlett is dsp.bartlett and STR_TO_WINDOW_FN is dsp.STR_TO_WINDOW_FN
+    code = "import sys, mlx_audio_amd.utils; assert 'mlx_audio_amd.dsp' not in sys.modules; import mlx_audio_amd.utils as u; u.stft; assert 'mlx_audio_amd.dsp' in sys.modules"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    with pytest.raises(AttributeError):
+        import mlx_audio_amd.utils as u
+
+        u.no_such_name
