@@ -22,7 +22,22 @@ import numpy as np
 import torch
 
 __all__ = ["hanning", "hamming", "blackman", "bartlett", "STR_TO_WINDOW_FN", "stft", "istft", "mel_filters", "ISTFTCache",
-           "log_mel_spectrogram", "mel_spectrogram"]
+           "log_mel_spectrogram", "mel_spectrogram",
+           # host-side level helpers of mlx_audio.dsp (dsp.py:96-382), implemented in .loudness
+           "integrated_loudness", "lfilter", "normalize_loudness", "normalize_peak"]
+
+from .loudness import (  # noqa: E402,F401  (numpy-only; keeps ``from mlx_audio_amd.dsp import integrated_loudness`` working like the reference)
+    _K_WEIGHT_HIGHPASS_FREQ,
+    _K_WEIGHT_HIGHPASS_Q,
+    _K_WEIGHT_SHELF_FREQ,
+    _K_WEIGHT_SHELF_GAIN_DB,
+    _K_WEIGHT_SHELF_Q,
+    _biquad_coefficients,
+    integrated_loudness,
+    lfilter,
+    normalize_loudness,
+    normalize_peak,
+)
 
 
 def _device():

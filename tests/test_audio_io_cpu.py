@@ -169,3 +169,71 @@ def test_chunked_resample_equals_whole_buffer(orig):
     np.testing.assert_array_equal(same, audio)
     with pytest.raises(ValueError):
         resample_audio_chunks(chunks(), orig, target, len(audio), chunk_duration_seconds=0)
+
+
+# ------------------------------------------------------------------------------------------------ loudness (mlx_audio/tests/test_dsp.py:98-296, 381-395)
+def _sine(peak_dbfs, seconds, rate, freq=997.0):
+    n = int(seconds * rate)
+    return 10.0 ** (peak_dbfs / 20.0) * np.sin(2 * np.pi * freq * np.arange(n) / rate)
+
+
+def test_lfilter_and_k_weighting_tables():
+    from mlx_audio_amd.dsp import (_K_WEIGHT_HIGHPASS_FREQ, _K_WEIGHT_HIGHPASS_Q, _K_WEIGHT_SHELF_FREQ, _K_WEIGHT_SHELF_GAIN_DB, _K_WEIGHT_SHELF_Q,
+                                   _biquad_coefficients, lfilter)
+
+    np.testing.assert_allclose(lfilter([1.0, -0.5], [1.0], np.array([1.0, 2.0, 4.0], dtype=np.float32)), [1.0, 1.5, 3.0])
+    np.testing.assert_allclose(lfilter([1.0], [1.0, -0.5], np.array([1.0, 0.0, 0.0, 0.0], dtype=np.float32)), [1.0, 0.5, 0.25, 0.125])
+    sb, sa = _biquad_coefficients(_K_WEIGHT_SHELF_GAIN_DB, _K_WEIGHT_SHELF_Q, _K_WEIGHT_SHELF_FREQ, 48000, "high_shelf")
+    np.testing.assert_allclose(sb, [1.53512485958697, -2.69169618940638, 1.19839281085285], atol=1e-12)     # ITU-R BS.1770 Table 1
+    np.testing.assert_allclose(sa, [1.0, -1.69065929318241, 0.73248077421585], atol=1e-12)
+    pb, pa = _biquad_coefficients(0.0, _K_WEIGHT_HIGHPASS_Q, _K_WEIGHT_HIGHPASS_FREQ, 48000, "high_pass")
+    np.testing.assert_allclose(pb, [1.0, -2.0, 1.0], atol=1e-12)                                              # Table 2
+    np.testing.assert_allclose(pa, [1.0, -1.99004745483398, 0.99007225036621], atol=1e-12)
+    z = np.exp(-2j * np.pi * 997.0 / 48000)
+    g = lambda b, a: 20.0 * np.log10(np.abs((b[0] + b[1] * z + b[2] * z ** 2) / (a[0] + a[1] * z + a[2] * z ** 2)))  # noqa: E731
+    assert g(sb, sa) + g(pb, pa) == pytest.approx(0.691, abs=1e-3)                                            # BS.1770 Note 1
+    with pytest.raises(ValueError):
+        _biquad_coefficients(0.0, 1.0, 100.0, 48000, "low_pass")
+
+
+def test_integrated_loudness_anchors_blocks_and_gating():
+    from mlx_audio_amd.dsp import integrated_loudness
+
+    for peak in (0.0, -20.0, -40.0):                     # a 0 dBFS 997 Hz sine on one channel reads -3.01 LKFS, 1 LKFS per dB
+        assert integrated_loudness(_sine(peak, 2.0, 48000), 48000) == pytest.approx(peak - 3.01, abs=0.01)
+    assert integrated_loudness(_sine(-23.0, 2.0, 11025), 11025) == pytest.approx(-26.01, abs=0.05)     # block 4410, hop round(1102.5) = 1102
+    rate = 24000
+    tone = _sine(-23.0, 0.5, rate)
+    ref = integrated_loudness(tone, rate)
+    hop = int(0.4 * 0.25 * rate)
+    for extra in (1, hop // 2, hop - 1):                 # incomplete gating blocks at the end are not used
+        assert integrated_loudness(np.concatenate([tone, _sine(-23.0, 0.5, rate)[:extra]]), rate) == pytest.approx(ref, abs=1e-12)
+    readings = [integrated_loudness(_sine(-23.0, d, rate), rate) for d in (0.40, 0.45, 0.50, 0.55, 0.60, 0.65, 0.70)]
+    assert max(readings) - min(readings) < 0.01
+    loud, quiet = _sine(-23.0, 8.0, rate), _sine(-60.0, 2.0, rate)
+    assert integrated_loudness(np.concatenate([quiet, loud, quiet]), rate) == pytest.approx(integrated_loudness(loud, rate), abs=0.25)   # relative gate
+    r = [integrated_loudness(np.concatenate([_sine(p, 2.0, rate), loud, _sine(p, 2.0, rate)]), rate) for p in (-100.0, -140.0)]
+    assert r[0] == pytest.approx(r[1], abs=1e-7)                                                                                              # absolute gate
+    st = np.stack([_sine(-23.0, 2.0, 48000), _sine(-23.0, 2.0, 48000)], axis=1)
+    assert integrated_loudness(st, 48000) == pytest.approx(-26.01 + 10 * np.log10(2.0), abs=0.01)                                             # channels sum
+    with pytest.raises(ValueError, match="Data must be floating point."):
+        integrated_loudness(np.arange(10, dtype=np.int16), 24000)
+    with pytest.raises(ValueError, match="Audio must have length greater than the block size."):
+        integrated_loudness(np.zeros(100, dtype=np.float64), 24000)
+    with pytest.raises(ValueError, match="five channels"):
+        integrated_loudness(np.zeros((48000, 6)), 48000)
+
+
+def test_normalize_loudness_and_peak():
+    from mlx_audio_amd.dsp import integrated_loudness, normalize_loudness, normalize_peak
+
+    mono = (np.random.default_rng(0).standard_normal(24000) * 0.02).astype(np.float64)
+    measured = integrated_loudness(mono, 24000)
+    out = normalize_loudness(mono, measured, -18.0)
+    assert integrated_loudness(out, 24000) == pytest.approx(-18.0, abs=1e-9)
+    np.testing.assert_allclose(out, mono * 10.0 ** ((-18.0 - measured) / 20.0), rtol=1e-12)
+    pk = normalize_peak(np.linspace(-0.5, 0.5, 32, dtype=np.float64), -1.0)
+    assert np.max(np.abs(pk)) == pytest.approx(0.8912509381337456, abs=1e-12)
+    np.testing.assert_allclose(pk[:5], [-0.8912509381337456, -0.8337508776089878, -0.77625081708423, -0.7187507565594722, -0.6612506960347144], atol=1e-12, rtol=0.0)
+    with pytest.warns(UserWarning):
+        normalize_peak(np.array([0.1, -0.2]), 0.0)
