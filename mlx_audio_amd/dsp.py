@@ -370,3 +370,34 @@ def compute_fbank_kaldi(waveform, sample_rate: int = 48000, win_len: int = 1920,
     fb = torch.nn.functional.pad(bins, (0, 1)).contiguous().to(dev)           # [num_mels, P/2 + 1] (dsp.py:990)
     ones = torch.ones(P, dtype=torch.float32, device=dev)
     return ops.logmel(frames.view(1, m * P), P, P, ones, 0, m, fb, 2)[0]
+
+
+def compute_deltas_kaldi(specgram, win_length: int = 5, mode: str = "edge") -> torch.Tensor:
+    """Delta coefficients of a spectrogram ``(..., freq, time)`` (``mlx_audio/dsp.py:760-804``, Kaldi / torchaudio ``compute_deltas``):
+    ``d_t = sum_{n=1..N} n (c_{t+n} - c_{t-n}) / (2 sum n^2)`` with ``N = (win_length - 1) // 2`` and edge (or zero) padding in time.  A handful of
+    shifted adds on the tensor's own device (host glue around the fbank kernel, not a hot-path kernel).  The reference multiplies a ``win_length``-wide
+    window by ``2 N + 1`` weights, which only broadcasts for odd ``win_length``; even values are rejected here instead of failing inside."""
+    if win_length < 3:
+        raise ValueError(f"win_length should be >= 3, got {win_length}")
+    if win_length % 2 == 0:
+        raise ValueError(f"win_length must be odd (the reference's window / weight shapes only agree for odd values), got {win_length}")
+    if mode not in ("edge", "constant"):
+        raise ValueError(f"mode must be 'edge' or 'constant', got {mode!r}")
+    x = specgram if isinstance(specgram, torch.Tensor) else torch.as_tensor(np.asarray(specgram))
+    if not x.is_floating_point():
+        x = x.to(torch.float32)
+    n = (win_length - 1) // 2
+    denom = float(n * (n + 1) * (2 * n + 1)) / 3.0
+    flat = x.reshape(-1, x.shape[-1])
+    T = flat.shape[1]
+    if mode == "edge":
+        padded = torch.cat([flat[:, :1].expand(-1, n), flat, flat[:, -1:].expand(-1, n)], dim=1)
+    else:
+        padded = torch.nn.functional.pad(flat, (n, n))
+    out = torch.zeros_like(flat)
+    for k in range(1, n + 1):
+        out = out + float(k) * (padded[:, n + k:n + k + T] - padded[:, n - k:n - k + T])
+    return (out / denom).reshape(x.shape)
+
+
+__all__ += ["compute_deltas_kaldi", "mel_scale_kaldi", "inverse_mel_scale_kaldi", "get_mel_banks_kaldi", "compute_fbank_kaldi"]  # the rest of mlx_audio.dsp.__all__

@@ -237,3 +237,25 @@ def test_normalize_loudness_and_peak():
     np.testing.assert_allclose(pk[:5], [-0.8912509381337456, -0.8337508776089878, -0.77625081708423, -0.7187507565594722, -0.6612506960347144], atol=1e-12, rtol=0.0)
     with pytest.warns(UserWarning):
         normalize_peak(np.array([0.1, -0.2]), 0.0)
+
+
+def test_compute_deltas_kaldi_matches_the_definition():
+    """dsp.py:760-804: d_t = sum_n n (c_{t+n} - c_{t-n}) / (2 sum n^2), edge / constant padding; a linear ramp has delta 1 in the interior."""
+    from mlx_audio_amd.dsp import compute_deltas_kaldi
+
+    g = np.random.default_rng(3)
+    x = g.standard_normal((2, 4, 17)).astype(np.float32)
+    for win, mode in ((5, "edge"), (3, "edge"), (9, "constant")):
+        n = (win - 1) // 2
+        pad = np.pad(x, [(0, 0), (0, 0), (n, n)], mode="edge" if mode == "edge" else "constant")
+        want = np.zeros_like(x)
+        for t in range(x.shape[-1]):
+            want[..., t] = sum(k * (pad[..., t + n + k] - pad[..., t + n - k]) for k in range(1, n + 1)) / (2 * sum(k * k for k in range(1, n + 1)))
+        got = compute_deltas_kaldi(torch.from_numpy(x), win_length=win, mode=mode)
+        assert got.shape == x.shape and np.abs(got.numpy() - want).max() < 1e-5
+    ramp = torch.arange(20, dtype=torch.float32)[None, :]
+    assert torch.allclose(compute_deltas_kaldi(ramp)[:, 2:-2], torch.ones(1, 16))
+    assert compute_deltas_kaldi(x).shape == x.shape          # numpy in -> tensor out
+    for bad in (dict(win_length=2), dict(win_length=4), dict(mode="reflect")):
+        with pytest.raises(ValueError):
+            compute_deltas_kaldi(ramp, **bad)
