@@ -31,6 +31,13 @@ def load_audio(file: Union[str, Path], sr: int = SAMPLE_RATE, from_stdin: bool =
     return audio.astype(dtype, copy=False)
 
 
+def resample_audio(audio: np.ndarray, orig_sr: int, target_sr: int) -> np.ndarray:
+    """Time-first resampling with the package resampler (``mlx_audio/stt/utils.py:100-103``)."""
+    from ..utils import resample_audio as _resample_audio
+
+    return _resample_audio(audio, orig_sr, target_sr, axis=0)
+
+
 def load_model(model_path: Union[str, Path], lazy: bool = False, strict: bool = False, **kwargs: Any):
     return base_load_model(model_path=model_path, category="stt", model_remapping=MODEL_REMAPPING, lazy=lazy, strict=strict, **kwargs)
 

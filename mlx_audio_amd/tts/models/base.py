@@ -65,3 +65,21 @@ class BatchGenerationResult:
     peak_memory_usage: float
     is_streaming_chunk: bool = False
     is_final_chunk: bool = False
+
+
+def adjust_speed(audio_array, speed_factor: float) -> torch.Tensor:
+    """Changes the speed of ``audio_array`` ``[samples]`` or ``[samples, channels]`` by linear-interpolation resampling (``tts/models/base.py:37-68``):
+    ``int(n / speed_factor)`` output points spread evenly over ``[0, n - 1]`` (both end points kept), each a weighted mean of its two neighbours.
+    ``speed_factor`` > 1 is faster.  Runs on the tensor's own device."""
+    x = audio_array if isinstance(audio_array, torch.Tensor) else torch.as_tensor(audio_array)
+    if not x.is_floating_point():
+        x = x.to(torch.float32)
+    n = x.shape[0]
+    m = int(n / speed_factor)
+    pos = torch.linspace(0, n - 1, m, device=x.device, dtype=torch.float32)
+    lo = torch.floor(pos).to(torch.long)
+    hi = torch.clamp(lo + 1, max=n - 1)
+    w_hi = (pos - lo.to(torch.float32)).to(x.dtype)
+    if x.dim() > 1:
+        w_hi = w_hi.reshape(-1, *([1] * (x.dim() - 1)))
+    return (1.0 - w_hi) * x[lo] + w_hi * x[hi]

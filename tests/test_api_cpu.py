@@ -519,3 +519,17 @@ def test_utils_reexports_dsp_entry_points():
         import mlx_audio_amd.utils as u
 
         u.no_such_name
+
+
+def test_adjust_speed_and_stt_resample_helpers():
+    """tts/models/base.py:37-68 (linear-interpolation speed change, both end points kept) and stt/utils.py:100-103 (time-first resample)."""
+    from mlx_audio_amd.stt.utils import resample_audio
+    from mlx_audio_amd.tts.models.base import adjust_speed
+
+    x = torch.arange(11, dtype=torch.float32)
+    y = adjust_speed(x, 2.0)
+    assert y.shape == (5,) and torch.allclose(y, torch.tensor([0.0, 2.5, 5.0, 7.5, 10.0]))
+    z = adjust_speed(np.stack([np.arange(9.0), -np.arange(9.0)], axis=1), 0.5)
+    assert z.shape == (18, 2) and float(z[0, 0]) == 0.0 and float(z[-1, 0]) == 8.0 and torch.allclose(z[:, 0], -z[:, 1])
+    a = resample_audio(np.zeros((24000, 2), dtype=np.float32), 24000, 16000)
+    assert a.shape == (16000, 2) and a.dtype == np.float32
