@@ -468,7 +468,8 @@ def test_inference_broker_continuous_batching(tmp_path):
             assert ev.done and ev.samples == 10 * (6 + i + 2) and float(ev.audio[0]) == 6 + i - 1      # fake engine: 10 samples per id, value = voice row
         chunks = _drain(bad)
         assert [c.kind for c in chunks] == ["error", "done"] and isinstance(chunks[0].error, FileNotFoundError)
-        assert max(c["n"] for c in m.engine.calls) == 2 and sum(c["n"] for c in m.engine.calls) == 5   # two slots: passes of <= 2 utterances, 5 in total
+        assert max(c["n"] for c in m.engine.calls) <= 2 and sum(c["n"] for c in m.engine.calls) == 5   # two slots: passes of <= 2 utterances, 5 in total
+        # (how many passes actually carried 2 depends on how the submitting thread and the worker interleave: not asserted)
         # unknown model: the session cannot be created -> error + done on that request only
         chunks = _drain(broker.submit(endpoint_kind="tts", model_name="other", payload={"text": short}))
         assert [c.kind for c in chunks] == ["error", "done"] and isinstance(chunks[0].error, ValueError)
