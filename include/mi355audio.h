@@ -108,7 +108,7 @@ typedef struct {
                           3 = single fp16 pass: activations rounded to fp16 (saturating), weights packed with MI355_W_F16,
                           4 = fp16 hi+lo split (~22 mantissa bits of the activation) on MI355_W_F16 weights: fp16 checkpoints
                               (Whisper) at fp32-activation accuracy */
-  int32_t tile;        /* 0 = auto, else BM*1000+BN (128128, 64128, 64064), 8128128 / 9128128 = wave-specialised 8-wave kernels */
+  int32_t tile;        /* 0 = auto, else BM*1000+BN (128128, 64128, 64064), 6128128 / 7128128 = wave-specialised 8-wave kernels (ws4 / ws3) */
   /* optional instance-norm statistics of the STORED output, fused into the epilogue (plain stores only): per block of
      MI355_STATS_ROWS output rows and per channel the pair (sum, sum of squared deviations from the block mean), written
      (never accumulated) to stats_partial[b][row / MI355_STATS_ROWS][c][0..1]; consumed by mi355_adain_from_partials.

@@ -16,49 +16,13 @@
 //   accumulate, and either a plain channels-last store or the polyphase conv_transpose scatter.
 //
 // Reference call sites replaced: see include/mi355audio.h (mi355_conv_gemm).
-#include <stdlib.h>
-#include <type_traits>
-#include "common.h"
+#include "conv_common.h"
+
+using namespace mi355conv;
 
 namespace {
 
 constexpr int kThreads = 256;
-
-__device__ __forceinline__ void glds16(const void* gsrc, void* ldst) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
-}
-
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-// nn.GELU(approx="tanh") / nn.gelu_approx: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
-__device__ __forceinline__ float gelu_tanh(float x) { return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x))); }
-
-
-// one 32x32x16 MFMA on 16-byte A / B fragments: bf16 (PREC 1, 2) or fp16 (PREC 3, 4) inputs, fp32 accumulate
-// PREC 2 / 4 split the fp32 activation into hi + lo images of the weight's 16-bit type (two MFMAs per fragment)
-template <int PREC>
-__device__ __forceinline__ f32x16 mfma16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
-  if constexpr (PREC >= 3)
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  else
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-// number of LDS images of the activation window: hi + lo for the split, one otherwise
-template <int PREC>
-constexpr int a_images() { return (PREC == 2 || PREC == 4) ? 2 : 1; }
-// the part of t the first (hi) image carries, as an fp32 value
-template <int PREC>
-__device__ __forceinline__ float split_hi(float t) {
-  if constexpr (PREC == 3) return t;
-  else if constexpr (PREC == 4) return (float)(_Float16)__builtin_fminf(__builtin_fmaxf(t, -65504.f), 65504.f);
-  else return bf16_bits_to_f32(f32_to_bf16_bits(t));
-}
-template <int PREC>
-__device__ __forceinline__ uint32_t pack_lo(float a, float b) {
-  if constexpr (PREC == 4) return pack_f16x2(a, b);
-  else return pack_bf16x2(a, b);
-}
-
 
 // Shared epilogue: y = ((acc + bias -> act) + res + y_old) * out_scale, plain or polyphase (conv_transpose) store.
 // All loads of one 32x32 fragment are issued back to back on clamped addresses and only the stores are predicated:
@@ -398,377 +362,8 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_ge
   conv_epilogue<MF, NF, WM, WN, true>(a, acc, b, l0, n0, wm, wn, lane, len_out, false);
 }
 
-// =====================================================================================================
-// Wave-specialised variant for the large resblock convs (the bulk of the vocoder's MACs).
-//
-// 512 threads = 8 waves per workgroup, one 128 x 128 output tile:
-//   waves 0-3  CONSUMERS: 2 x 2 over the tile, ds_read_b128 fragments + MFMA, then the epilogue;
-//   waves 4-7  PRODUCERS: the activation window of the NEXT 32-channel chunk -- 6 x float4 per lane issued at the
-//              first tap of the current chunk (addresses clamped, so always exactly 6 loads), then AdaIN affine,
-//              Snake / LeakyReLU, bf16 hi+lo (or fp16) conversion into the other LDS buffer at the last tap(s), while
-//              the consumers keep the matrix cores busy.
-// Each SIMD hosts one consumer and one producer wave per workgroup (MFMA and VALU pipes run concurrently); two
-// workgroups fit per CU (<= 74 KB LDS, <= 128 VGPR), so one workgroup's epilogue / pipeline fill overlaps the
-// other's MFMAs.  One raw s_barrier per (chunk, tap) step; weight slices stream L2 -> LDS with global_load_lds two
-// steps ahead through a 3-slot ring behind COUNTED s_waitcnt vmcnt (never a drain):
-//   V2 = false: the producers issue the weight DMA (their vmcnt queue then also holds the activation loads, and
-//               in-order completion makes every weight wait a wait for older activation loads);
-//   V2 = true:  the consumers issue it -- each wave its quarter of the slice, two DMA instructions hidden in the
-//               MFMA shadow -- so the two queues are independent: weights wait on weights only (vmcnt(2)), and the
-//               producers' activation loads fly for K-2 steps before the compiler-counted wait in front of convert.
-// `rot`: workgroups walk the (chunk, tap) steps from different starting points (a rotation by the tile index within
-// its XCD).  Every tile of a layer reads the SAME weight slices; in lockstep that hammers two L2 channels at a
-// time, rotated it spreads over all of them.  (Sums commute: only the fp32 summation order differs per tile.)
-// The residual / running-sum operands of the epilogue are folded into the accumulator initialisation, and the 1-D
-// grid is remapped so that the N-tiles sharing one activation window land on the same XCD (same L2).
-// =====================================================================================================
 constexpr int kWsThreads = 512;
 constexpr int kWsNld = 6;  // A-window passes of 32 rows per chunk: R <= 192
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-}
-
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS reads / writes are done
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
-
-template <int PREC, bool V2>
-__global__ __launch_bounds__(kWsThreads, 4) void conv_gemm_ws_kernel(const mi355_conv_gemm_args a, const int tiles_per_item,
-                                                                    const int P, const int NT, const int fold, const int rot) {
-  constexpr int BM = 128, BN = 128, WM = 64, WN = 64, MF = 2, NF = 2;
-  constexpr int BBYTES = (BN / 32) * 2048;
-  constexpr int NA = a_images<PREC>();
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // block id -> (row tile p, N tile ny): ids congruent mod 8 run on one XCD, so the NT column tiles of a row
-  // tile are given ids 8 apart (same XCD, dispatched back to back) and share the activation window in L2.
-  const int id = blockIdx.x;
-  const int kq = id >> 3;
-  const int ny = kq % NT;
-  const int p = (kq / NT) * 8 + (id & 7);
-  if (p >= P) return;
-  const int b = p / tiles_per_item;
-  const int l0 = (p - b * tiles_per_item) * BM, n0 = ny * BN;
-  const int len_out = a.lens_out ? a.lens_out[b] : a.Lout;
-  if (l0 >= len_out) return;
-  const int len_in = a.lens_in ? a.lens_in[b] : a.Lin;
-  const int K = a.K, dil = a.dil;
-  const int R = BM + (K - 1) * dil;
-  const int ABYTES = R * 64;
-  char* Abase = smem;                   // [2 buffers][NA (hi, lo)][R * 64]
-  char* Bs = smem + 2 * NA * ABYTES;    // [3 slots][BBYTES]
-  const int nchunks = (a.Cin + 31) >> 5;
-  const int NTp = ((a.Cout + 127) >> 7) << 2;
-  const int nsteps = nchunks * K;
-  // walk order: iteration (ci, tj) works on chunk (c0 + ci) % nchunks, tap (t0 + tj) % K
-  const int qx = kq / NT;  // index of this row tile among its XCD's tiles
-  const int c0 = rot ? qx % nchunks : 0;
-  const int t0 = rot ? (qx / nchunks) % K : 0;
-  auto chunk_at = [&](int ci) { const int c = c0 + ci; return c >= nchunks ? c - nchunks : c; };
-  auto tap_at = [&](int tj) { const int t = t0 + tj; return t >= K ? t - K : t; };
-
-  // this wave's share of the weight slice of iteration (ci, tj): `part` in 0..3, two 1-KB DMA pieces
-  auto issue_B = [&](int ci, int tj, int slot, int part) {
-    const int slice = chunk_at(ci) * K + tap_at(tj);
-    const char* src = (const char*)a.w + ((int64_t)slice * NTp + (n0 >> 5)) * 2048;
-#pragma unroll
-    for (int i = 0; i < BN / 64; ++i) {
-      const int off = (i * 4 + part) * 1024;
-      glds16(src + off + lane * 16, Bs + slot * BBYTES + off);
-    }
-  };
-
-  if (wave >= 4) {
-    // ------------------------------------------------------------------------------ producers
-    const int pw = wave - 4;
-    const int ptid = tid - 256;
-    const int c4 = (ptid & 7) * 4;
-    const int prow = ptid >> 3;
-    const float* xb = a.x + (int64_t)b * a.x_bstride + a.x_off;
-    float4 areg[kWsNld];
-
-    // always exactly kWsNld vector loads (addresses clamped, masking happens in convert)
-    auto loadA = [&](int chunk) {
-      int c = chunk * 32 + c4;
-      if (c >= a.Cin) c = 0;
-#pragma unroll
-      for (int i = 0; i < kWsNld; ++i) {
-        int gl = l0 - a.pad + prow + i * 32;
-        gl = gl < 0 ? 0 : (gl >= a.Lin ? a.Lin - 1 : gl);
-        areg[i] = *(const float4*)(xb + (int64_t)gl * a.ldx + c);
-      }
-    };
-    auto convertA = [&](int chunk, char* A_hi, int i_lo, int i_hi) {
-      char* A_lo = A_hi + ABYTES;
-      const int c = chunk * 32 + c4;
-      float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f}, al[4] = {1.f, 1.f, 1.f, 1.f},
-            ial[4] = {1.f, 1.f, 1.f, 1.f};
-      if (a.pre_scale) {
-        const float4 s4 = *(const float4*)(a.pre_scale + (int64_t)b * a.pre_ld + c);
-        const float4 h4 = *(const float4*)(a.pre_shift + (int64_t)b * a.pre_ld + c);
-        sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
-        sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
-      }
-      if (a.pre_act == MI355_ACT_SNAKE) {
-        const float4 a4 = *(const float4*)(a.pre_alpha + c);
-        al[0] = a4.x; al[1] = a4.y; al[2] = a4.z; al[3] = a4.w;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ial[i] = 1.0f / al[i];
-      }
-#pragma unroll
-      for (int i = 0; i < kWsNld; ++i) {
-        const int r = prow + i * 32;
-        if (i >= i_lo && i < i_hi && r < R) {
-          const int gl = l0 - a.pad + r;
-          const bool rowok = gl >= 0 && gl < len_in;
-          const float v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
-          float hi[4], lo[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float t = v[j] * sc[j] + sh[j];
-            if (a.pre_act == MI355_ACT_LEAKY) t = t > 0.f ? t : t * a.pre_slope;
-            else if (a.pre_act == MI355_ACT_SNAKE) {
-              const float s = __sinf(al[j] * t);
-              t = t + ial[j] * (s * s);
-            }
-            t = (rowok && (c + j) < a.Cin) ? t : 0.f;
-            const float h = split_hi<PREC>(t);
-            hi[j] = h;
-            lo[j] = t - h;
-          }
-          const int addr = r * 64 + ((((c4 >> 3) ^ ((r >> 2) & 3))) << 4) + ((c4 & 4) << 1);
-          uint2 ph;
-          if constexpr (PREC >= 3) {
-            ph.x = pack_f16x2(hi[0], hi[1]);
-            ph.y = pack_f16x2(hi[2], hi[3]);
-          } else {
-            ph.x = pack_bf16x2(hi[0], hi[1]);
-            ph.y = pack_bf16x2(hi[2], hi[3]);
-          }
-          *(uint2*)(A_hi + addr) = ph;
-          if (PREC == 2 || PREC == 4) {
-            uint2 pl;
-            pl.x = pack_lo<PREC>(lo[0], lo[1]);
-            pl.y = pack_lo<PREC>(lo[2], lo[3]);
-            *(uint2*)(A_lo + addr) = pl;
-          }
-        }
-      }
-    };
-
-    if constexpr (V2) {
-      // activation windows only; the compiler counts these loads itself (no DMA in this queue)
-      loadA(chunk_at(0));
-      convertA(chunk_at(0), Abase, 0, kWsNld);
-      lds_barrier();  // barrier #0
-      const int tcA = K >= 4 ? K - 2 : K - 1, tcB = K - 1;  // taps at which the two halves of the next window are converted
-      int s = 0;
-      for (int ci = 0; ci < nchunks; ++ci) {
-        const bool nxt = ci + 1 < nchunks;
-        const int cn = chunk_at(nxt ? ci + 1 : ci);
-        char* A_next = Abase + ((ci + 1) & 1) * NA * ABYTES;
-        for (int tj = 0; tj < K; ++tj) {
-          if (nxt) {
-            if (tj == 0) loadA(cn);
-            if (tcA == tcB) {
-              if (tj == tcB) convertA(cn, A_next, 0, kWsNld);
-            } else {
-              if (tj == tcA) convertA(cn, A_next, 0, kWsNld / 2);
-              if (tj == tcB) convertA(cn, A_next, kWsNld / 2, kWsNld);
-            }
-          }
-          if (s + 1 < nsteps) lds_barrier();
-          ++s;
-        }
-      }
-    } else {
-      // Step s = iteration (ci, tj).  During step s the producers issue weight slice s+2, at tap 0 the loads of the
-      // next chunk's window, at tap 1 its conversion.  At the end of the step slice s+1 must have landed (counted
-      // wait: what was issued after it may stay in flight), then the barrier hands step s+1 to the consumers.  The
-      // loop nest is straight-line over taps 0 / 1 / rest so that no vector load is pending across a back edge.
-      auto end_step = [&](int s, int pend) {
-        if (s + 1 < nsteps) {
-          if (pend == 0) wait_vmcnt<0>();
-          else if (pend == 2) wait_vmcnt<2>();
-          else if (pend == kWsNld) wait_vmcnt<6>();
-          else wait_vmcnt<8>();
-          lds_barrier();
-        }
-      };
-      int slot = 2;
-      auto prefetch_B = [&](int ci, int tj) -> int {  // weight slice two iterations ahead of (ci, tj)
-        int pend = 0;
-        int cj = ci, tt = tj + 2;
-        while (tt >= K) { tt -= K; ++cj; }
-        if (cj < nchunks) {
-          issue_B(cj, tt, slot, pw);
-          pend = 2;
-        }
-        slot = slot == 2 ? 0 : slot + 1;
-        asm volatile("" ::: "memory");
-        return pend;
-      };
-      issue_B(0, 0, 0, pw);
-      if (nsteps > 1) issue_B(K > 1 ? 0 : 1, K > 1 ? 1 : 0, 1, pw);
-      loadA(chunk_at(0));
-      convertA(chunk_at(0), Abase, 0, kWsNld);
-      wait_vmcnt<0>();
-      lds_barrier();  // barrier #0: step 0 (and weight slice 1) staged
-      int s = 0;
-      for (int ci = 0; ci < nchunks; ++ci) {
-        const bool nxt = ci + 1 < nchunks;
-        const int cn = chunk_at(nxt ? ci + 1 : ci);
-        char* A_next = Abase + ((ci + 1) & 1) * NA * ABYTES;
-        if (K == 1) {
-          const int pend = prefetch_B(ci, 0);
-          if (nxt) {
-            loadA(cn);
-            convertA(cn, A_next, 0, kWsNld);
-          }
-          end_step(s, pend);
-          ++s;
-        } else {
-          int pend = prefetch_B(ci, 0);  // tap 0
-          if (nxt) {
-            loadA(cn);
-            pend += kWsNld;
-          }
-          asm volatile("" ::: "memory");
-          end_step(s, pend);
-          ++s;
-          if (nxt) convertA(cn, A_next, 0, kWsNld);  // tap 1: convert first (its waits would also drain a fresh weight DMA)
-          asm volatile("" ::: "memory");
-          pend = prefetch_B(ci, 1);
-          end_step(s, pend);
-          ++s;
-          for (int tj = 2; tj < K; ++tj) {
-            pend = prefetch_B(ci, tj);
-            end_step(s, pend);
-            ++s;
-          }
-        }
-      }
-    }
-    return;
-  }
-
-  // -------------------------------------------------------------------------------- consumers
-  const int wm = wave >> 1, wn = wave & 1;
-  float* yb = a.y + (int64_t)b * a.y_bstride;
-  const float* rb = a.res ? a.res + (int64_t)b * a.res_bstride : nullptr;
-  if constexpr (V2) {
-    issue_B(0, 0, 0, wave);
-    if (nsteps > 1) issue_B(K > 1 ? 0 : 1, K > 1 ? 1 : 0, 1, wave);
-  }
-  f32x16 acc[MF][NF];
-#pragma unroll
-  for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-    for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
-  if (fold) {
-    // residual and running sum go in as the initial accumulator value: issued here, they land while the
-    // producers stage the first chunk.  Clamped addresses + select (never a branch per load).
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-      for (int nf = 0; nf < NF; ++nf) {
-        const int n = n0 + wn * WN + nf * 32 + (lane & 31);
-        const bool nok = n < a.Cout;
-        const int ncl = nok ? n : a.Cout - 1;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          float rv[8];
-          int us[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const int r = h * 8 + q;
-            us[q] = l0 + wm * WM + mf * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            rv[q] = 0.f;
-          }
-          if (rb) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) rv[q] = rb[(int64_t)(us[q] < len_out ? us[q] : len_out - 1) * a.ldr + ncl];
-          }
-          if (a.accumulate) {
-            float yv[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) yv[q] = yb[(int64_t)(us[q] < len_out ? us[q] : len_out - 1) * a.ldy + ncl];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) rv[q] += yv[q];
-          }
-#pragma unroll
-          for (int q = 0; q < 8; ++q) acc[mf][nf][h * 8 + q] = (nok && us[q] < len_out) ? rv[q] : 0.f;
-        }
-      }
-  }
-  if constexpr (V2) wait_vmcnt<0>();  // weight slices 0 and 1 (and the fold operands) have landed
-
-  lds_barrier();  // barrier #0
-  {
-    int ci = 0, tj = 0, slot = 0, slot2 = 2;
-    for (int s = 0; s < nsteps; ++s) {
-      bool issued = false;
-      if constexpr (V2) {
-        int cj = ci, tt = tj + 2;
-        while (tt >= K) { tt -= K; ++cj; }
-        if (cj < nchunks) {
-          issue_B(cj, tt, slot2, wave);  // the slot read during step s-1: every consumer is past barrier #s
-          issued = true;
-        }
-        slot2 = slot2 == 2 ? 0 : slot2 + 1;
-        asm volatile("" ::: "memory");
-      }
-      const int tap = tap_at(tj);
-      const char* A_hi = Abase + (ci & 1) * NA * ABYTES;
-      const char* A_lo = A_hi + ABYTES;
-      const char* Bb = Bs + slot * BBYTES;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 bfr[NF];
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf)
-          bfr[nf] = *(const bf16x8*)(Bb + ((((wn * NF + nf) * 2 + kk) * 64 + lane) << 4));
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf) {
-          const int row = wm * WM + mf * 32 + (lane & 31) + tap * dil;
-          const int cidx = kk * 2 + (lane >> 5);
-          const int addr = row * 64 + ((cidx ^ ((row >> 2) & 3)) << 4);
-          const bf16x8 ah = *(const bf16x8*)(A_hi + addr);
-#pragma unroll
-          for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = mfma16<PREC>(ah, bfr[nf], acc[mf][nf]);
-          if (PREC == 2 || PREC == 4) {
-            const bf16x8 alo = *(const bf16x8*)(A_lo + addr);
-#pragma unroll
-            for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = mfma16<PREC>(alo, bfr[nf], acc[mf][nf]);
-          }
-        }
-      }
-      slot = slot == 2 ? 0 : slot + 1;
-      if (s + 1 < nsteps) {
-        if constexpr (V2) {  // this wave's pieces of slice s+1 have landed; slice s+2 may stay in flight
-          if (issued) wait_vmcnt<2>();
-          else wait_vmcnt<0>();
-        }
-        lds_barrier();
-      }
-      if (++tj == K) { tj = 0; ++ci; }
-    }
-  }
-
-  // epilogue (with `fold` the residual / running sum is already in the accumulators)
-  conv_epilogue<MF, NF, WM, WN, false>(a, acc, b, l0, n0, wm, wn, lane, len_out, fold != 0);
-}
 
 // -----------------------------------------------------------------------------------------------------
 // Third wave-specialised variant (tile code 7128128): ONE barrier per 32-channel chunk instead of one per tap.
@@ -1115,34 +710,6 @@ int launch_ws3(const mi355_conv_gemm_args& a, hipStream_t st) {
   return MI355_OK;
 }
 
-template <int PREC, bool V2>
-int launch_ws(const mi355_conv_gemm_args& a, hipStream_t st) {
-  const int R = 128 + (a.K - 1) * a.dil;
-  MI355_REQUIRE(R <= 32 * kWsNld, "conv_gemm(ws): window of %d rows exceeds %d (K=%d dil=%d)", R, 32 * kWsNld, a.K, a.dil);
-  const size_t lds = (size_t)2 * a_images<PREC>() * R * 64 + 3 * 4 * 2048;
-  static bool attr_set = false;  // benign race: the attribute is idempotent
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_ws_kernel<PREC, V2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    MI355_REQUIRE(e == hipSuccess, "conv_gemm(ws): cannot reserve LDS: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
-  const int tiles_per_item = (a.Lout + 127) / 128;
-  const int P = a.B * tiles_per_item;
-  const int NT = (a.Cout + 127) / 128;
-  const int fold = (a.res || a.accumulate) && a.post_act == MI355_ACT_NONE && a.up_s == 0 && a.res_shift == 0 && !a.post_colscale;
-  static const int rot = getenv("MI355_CONV_NO_ROT") ? 0 : 1;  // A/B aid: lockstep walk order
-  const unsigned grid = (unsigned)(((P + 7) / 8) * 8 * NT);
-  MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL((conv_gemm_ws_kernel<PREC, V2>), dim3(grid), dim3(kWsThreads), lds, st, a, tiles_per_item, P, NT, fold, rot);
-  MI355_LAUNCH_CHECK("conv_gemm(ws)");
-  return MI355_OK;
-}
-
-template <bool V2>
-int launch_ws_prec(const mi355_conv_gemm_args& a, hipStream_t st) {
-  return a.precision == 2 ? launch_ws<2, V2>(a, st) : (a.precision == 3 ? launch_ws<3, V2>(a, st) : launch_ws<1, V2>(a, st));
-}
-
 template <int BM, int BN, int PREC, bool VEC>
 int launch(const mi355_conv_gemm_args& a, hipStream_t st) {
   const int R = BM + (a.K - 1) * a.dil;
@@ -1191,39 +758,31 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
     // the wave-specialised kernel once there are enough 128 x 128 tiles to fill the 256 CUs
     // (MI355_CONV_NO_WS=1 in the environment keeps the auto choice on the 4-wave kernels: an A/B and bisecting aid)
     static const bool no_ws = getenv("MI355_CONV_NO_WS") != nullptr;
-    static const int ws_var = getenv("MI355_CONV_WS_VARIANT") ? atoi(getenv("MI355_CONV_WS_VARIANT")) : 7;
-    static const int ws_tile = ws_var == 8 ? 8128128 : (ws_var == 9 ? 9128128 : 7128128);
-    if (!no_ws && ws_ok && bn == 128 && wgs128 >= 256 && a.Cin >= 64) tile = ws_tile;
+    // MI355_CONV_WS_VARIANT=7 keeps the previous wave-specialised kernel (A/B aid); MI355_CONV_WS_MIN_TILES overrides the fill threshold
+    static const int ws_var = getenv("MI355_CONV_WS_VARIANT") ? atoi(getenv("MI355_CONV_WS_VARIANT")) : 4;
+    static const int ws_feat = getenv("MI355_CONV_WS_FEAT") ? atoi(getenv("MI355_CONV_WS_FEAT")) : 0;
+    static const long ws_min = getenv("MI355_CONV_WS_MIN_TILES") ? atol(getenv("MI355_CONV_WS_MIN_TILES")) : 256;
+    if (!no_ws && ws_var == 4 && bn == 128 && wgs128 >= ws_min && a.Cin >= 64 && mi355_conv_ws4_eligible(a, vec)) {
+      const int rc = mi355_conv_ws4_launch(a, st, ws_feat);
+      if (rc != MI355_ERR_UNSUPPORTED) return rc;  // no instantiation for this prologue / epilogue pair: fall through to the older kernels
+    }
+    if (!no_ws && ws_ok && bn == 128 && wgs128 >= ws_min && a.Cin >= 64) tile = 7128128;
     else if (bn == 128 && wgs128 >= 512) tile = 64128;  // measured: 64-row tiles beat 128-row tiles on the 4-wave kernel
+  }
+  if (tile % 10000000 == 6128128) {  // ws4, explicit: 6128128 + 10000000 * feature bits
+    MI355_REQUIRE(mi355_conv_ws4_eligible(a, vec), "conv_gemm: the ws4 tile needs 16-B aligned channels-last input / output / residual rows, "
+                  "Cout %% 4 == 0, a window of <= 256 rows and precision 2 or 4");
+    return mi355_conv_ws4_launch(a, st, tile / 10000000);
   }
   if (a.stats_partial) {  // statistics are produced per 64-row wave block: only the 128-row kernels have those
     MI355_REQUIRE(vec, "conv_gemm: fused statistics need the 16-B aligned channels-last input path");
-    if (tile != 8128128 && tile != 9128128 && tile != 7128128) tile = 128128;
-  }
-  if (tile > 10000000 && tile % 10000000 == 7128128) {  // timing ablations of the 7128128 kernel (wrong results by design)
-    MI355_REQUIRE(ws_ok && a.precision == 2, "conv_gemm: ablation tiles need the wave-specialised path at precision 2");
-    switch (tile / 10000000) {
-      case 1: return launch_ws3<2, 1>(a, st);
-      case 2: return launch_ws3<2, 2>(a, st);
-      case 3: return launch_ws3<2, 3>(a, st);
-      case 4: return launch_ws3<2, 4>(a, st);
-      case 8: return launch_ws3<2, 8>(a, st);
-      case 7: return launch_ws3<2, 7>(a, st);
-      case 15: return launch_ws3<2, 15>(a, st);
-    }
-    mi355_set_error("conv_gemm: unknown ablation tile %d", tile);
-    return MI355_ERR_UNSUPPORTED;
+    if (tile != 7128128) tile = 128128;
   }
   if (tile == 7128128) {  // weights through registers, one barrier per chunk
     MI355_REQUIRE(ws_ok, "conv_gemm: the wave-specialised tile needs a 16-B aligned channels-last input and (K-1)*dil <= 64");
     if (ext)  // SnakeBeta / ELU prologue, extended epilogue: the instantiation that carries them (a few spilled registers)
       return a.precision == 2 ? launch_ws3<2, 0, true>(a, st) : (a.precision == 3 ? launch_ws3<3, 0, true>(a, st) : (a.precision == 4 ? launch_ws3<4, 0, true>(a, st) : launch_ws3<1, 0, true>(a, st)));
     return a.precision == 2 ? launch_ws3<2>(a, st) : (a.precision == 3 ? launch_ws3<3>(a, st) : (a.precision == 4 ? launch_ws3<4>(a, st) : launch_ws3<1>(a, st)));
-  }
-  if (tile == 8128128 || tile == 9128128) {  // 8...: producers stream the weights; 9...: consumers do (see the kernel header)
-    MI355_REQUIRE(ws_ok, "conv_gemm: the wave-specialised tile needs a 16-B aligned channels-last input and (K-1)*dil <= 64");
-    MI355_REQUIRE(a.precision != 4 && !ext, "conv_gemm: precision 4 and the extended prologue / epilogue set run on the 4-wave and 7128128 kernels only");
-    return tile == 9128128 ? launch_ws_prec<true>(a, st) : launch_ws_prec<false>(a, st);
   }
   if (!vec) {
     if (a.precision == 3) return launch<64, 64, 3, false>(a, st);

@@ -218,8 +218,21 @@ def conv_gemm(x: torch.Tensor, pc: PackedConv, y: torch.Tensor, *, dil: int = 1,
               res_shift: int = 0, out_scale: float = 1.0, accumulate: bool = False,
               up: Optional[dict] = None, precision: int = 2, tile: int = 0,
               flat: Optional[dict] = None, use_bias: bool = True, stats: Optional[torch.Tensor] = None,
-              pre_inv_beta: Optional[torch.Tensor] = None, colscale: Optional[torch.Tensor] = None, x_off: int = 0):
-    """y = epilogue(conv1d(prologue(x)))  -- see mi355_conv_gemm_args in the header."""
+              pre_inv_beta: Optional[torch.Tensor] = None, colscale: Optional[torch.Tensor] = None, x_off: int = 0,
+              flatten: bool = False):
+    """y = epilogue(conv1d(prologue(x)))  -- see mi355_conv_gemm_args in the header.
+
+    ``flatten``: the caller states that this is a per-row linear layer (K == 1) whose padding rows (rows >= lens[b]) may be
+    computed and written like any other row (nothing downstream reads them as valid): ``[B, L, C]`` operands whose items are
+    row-contiguous are then handed over as ONE item of B*L rows, so the 128-row tiles are full instead of one partly
+    filled tile per utterance (PL-BERT at T = 80: 62 % -> 100 % useful rows)."""
+    if flatten and pc.k == 1 and up is None and flat is None and res_shift == 0 and stats is None and pre is None and x.shape[0] > 1:
+        ts = [x, y] + ([res] if res is not None else [])
+        if all(t.dim() == 3 and t.shape[:2] == x.shape[:2] and t.stride(0) == t.shape[1] * t.stride(1) for t in ts):
+            fl = lambda t: t.as_strided((1, t.shape[0] * t.shape[1], t.shape[2]), (t.shape[0] * t.shape[1] * t.stride(1), t.stride(1), 1))
+            return conv_gemm(fl(x), pc, fl(y), pre_act=pre_act, pre_slope=pre_slope, pre_alpha=pre_alpha, post_act=post_act,
+                             post_slope=post_slope, res=None if res is None else fl(res), out_scale=out_scale, accumulate=accumulate,
+                             precision=precision, tile=tile, use_bias=use_bias, pre_inv_beta=pre_inv_beta, colscale=colscale, x_off=x_off)
     B, Lin, Cx, xbs, ldx = _nlc(x)
     By, Ly, Cy, ybs, ldy = _nlc(y)
     assert B == By

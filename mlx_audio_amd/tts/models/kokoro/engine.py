@@ -270,7 +270,7 @@ class KokoroEngine:
     def _bilstm(self, l: _LSTM, x, out, lens):
         B, L = x.shape[0], x.shape[1]
         xp = self._new(B, L, 8 * l.hid)
-        self._conv(x, l.wx, xp, lens_in=lens, lens_out=lens)
+        self._conv(x, l.wx, xp, lens_in=lens, lens_out=lens, flatten=True)
         return ops.lstm_bidir(xp, l.wh, l.hid, out, lens=lens)
 
     def _resblk1d_fwd(self, blk: _ResBlk1d, x, gb_all, out, lens, lens2=None):
@@ -294,7 +294,7 @@ class KokoroEngine:
             sc2, sh2 = ops.adain_coef(c1, self._gb(gb_all, blk.norm2), lo)
         if blk.conv1x1 is not None:
             short = self._new(B, L, blk.dout)
-            self._conv(x, blk.conv1x1, short, lens_in=lens, lens_out=lens)
+            self._conv(x, blk.conv1x1, short, lens_in=lens, lens_out=lens, flatten=True)
         else:
             short = x
         self._conv(c1, blk.conv2, out, pad=1, lens_in=lo, lens_out=lo, pre=(sc2, sh2), pre_act=ACT_LEAKY, pre_slope=0.2,
@@ -386,22 +386,22 @@ class KokoroEngine:
         eps = float(self.pb.get("layer_norm_eps", 1e-12))
         ops.layernorm(emb, emb, weight=self.emb_ln[0], bias=self.emb_ln[1], eps=eps, lens=lens_t)
         h = self._new(B, Tm, H)
-        self._conv(emb, self.map_in, h, lens_in=lens_t, lens_out=lens_t)
+        self._conv(emb, self.map_in, h, lens_in=lens_t, lens_out=lens_t, flatten=True)
         qkv = self._new(B, Tm, 3 * H)
         ctx = self._new(B, Tm, H)
         tmp = self._new(B, Tm, H)
         att = self._new(B, Tm, H)
         inter = self._new(B, Tm, self.pb["intermediate_size"])
         for _ in range(self.pb["num_hidden_layers"]):
-            self._conv(h, self.qkv, qkv, lens_in=lens_t, lens_out=lens_t)
+            self._conv(h, self.qkv, qkv, lens_in=lens_t, lens_out=lens_t, flatten=True)
             if H // heads in (64, 128):  # f32-MFMA flash kernel; padded keys are invisible (the reference's additive -10000 mask, modules.py:639)
                 ops.flash_attention(qkv[:, :, :H], qkv[:, :, H:2 * H], qkv[:, :, 2 * H:], ctx, heads=heads, dh=H // heads, lens_q=lens_t, lens_k=lens_t)
             else:
                 ops.attention(qkv, heads, H // heads, ctx, lens=lens_t)
-            self._conv(ctx, self.att_dense, tmp, lens_in=lens_t, lens_out=lens_t, res=h)
+            self._conv(ctx, self.att_dense, tmp, lens_in=lens_t, lens_out=lens_t, res=h, flatten=True)
             ops.layernorm(tmp, att, weight=self.att_ln[0], bias=self.att_ln[1], eps=eps, lens=lens_t)
-            self._conv(att, self.ffn, inter, lens_in=lens_t, lens_out=lens_t, post_act=ACT_GELU)
-            self._conv(inter, self.ffn_out, tmp, lens_in=lens_t, lens_out=lens_t, res=att)
+            self._conv(att, self.ffn, inter, lens_in=lens_t, lens_out=lens_t, post_act=ACT_GELU, flatten=True)
+            self._conv(inter, self.ffn_out, tmp, lens_in=lens_t, lens_out=lens_t, res=att, flatten=True)
             ops.layernorm(tmp, h, weight=self.full_ln[0], bias=self.full_ln[1], eps=eps, lens=lens_t)
 
         # ---- DurationEncoder (modules.py:380-411): [d_en | style] ping-pong buffers
@@ -409,7 +409,7 @@ class KokoroEngine:
         db = self._new(B, Tm, hid + sty, zero=True)
         ops.broadcast_rows(s_pred, da[:, :, hid:], lens=lens_t)
         ops.broadcast_rows(s_pred, db[:, :, hid:], lens=lens_t)
-        self._conv(h, self.bert_encoder, da[:, :, :hid], lens_in=lens_t, lens_out=lens_t)
+        self._conv(h, self.bert_encoder, da[:, :, :hid], lens_in=lens_t, lens_out=lens_t, flatten=True)
         cur, nxt = da, db
         for i in range(self.n_layer):
             self._bilstm(self.dur_lstms[i], cur, nxt[:, :, :hid], lens_t)
@@ -490,7 +490,7 @@ class KokoroEngine:
         self._resblk1d_fwd(self.enc_blk, dec_in[:, :, :c_in], gb_dec, ca[:, :, :1024], lens_f)
         if return_intermediates:
             trace.update(dec_in=dec_in[:, :, :c_in].clone(), enc=ca[:, :, :1024].clone())
-        self._conv(asr, self.asr_res, ca[:, :, 1024:1088], lens_in=lens_f, lens_out=lens_f)
+        self._conv(asr, self.asr_res, ca[:, :, 1024:1088], lens_in=lens_f, lens_out=lens_f, flatten=True)
         ca[:, :, 1088:1090].copy_(dec_in[:, :, hid:hid + 2])
         cb[:, :, 1024:1090].copy_(ca[:, :, 1024:1090])
         cur, nxt = ca, cb

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--quick", action="store_true", help="two shapes, the wave-specialised variants only (for PMC passes)")
     ap.add_argument("--ablate", action="store_true", help="timing ablations of the 7128128 kernel (their results are wrong by design)")
     ap.add_argument("--small", action="store_true", help="the few-row GEMMs of PL-BERT / predictor (rows = B*80): 4-wave tile shapes A/B")
+    ap.add_argument("--flat", action="store_true", help="with --small: hand the batch over as ONE item of B*L rows (ops.conv_gemm(flatten=True))")
     args = ap.parse_args()
     from mlx_audio_amd import ops
 
@@ -45,7 +46,7 @@ def main():
     shapes.append((256, 256, 11, 5, 5280, "snake"))
     shapes.append((1090, 1024, 3, 1, 264, "leaky"))
     shapes.append((512, 2560, 2, 1, 529, "plain"))
-    variants = [("old64x128", 64128), ("ws_prodB", 8128128), ("ws_consB", 9128128), ("ws_regB", 7128128)]
+    variants = [("old64x128", 64128), ("ws3", 7128128), ("ws4", 6128128), ("ws4_prio", 16128128)]
     if args.ablate:
         shapes = [(128, 128, 11, 1, 31681, "snake+res"), (128, 128, 3, 1, 31681, "snake+res"), (256, 256, 7, 1, 5280, "snake+res")]
         variants = [("ws_regB", 7128128), ("abl1_noBload", 17128128), ("abl2_noAread", 27128128), ("abl3_noAB", 37128128),
@@ -54,13 +55,15 @@ def main():
         shapes = [(768, 2304, 1, 1, 80, "plain"), (768, 768, 1, 1, 80, "plain"), (768, 2048, 1, 1, 80, "plain"), (2048, 768, 1, 1, 80, "plain"),
                   (640, 2048, 1, 1, 264, "plain"), (1090, 1024, 3, 1, 264, "leaky"), (1024, 1024, 3, 1, 264, "leaky"), (512, 512, 3, 1, 528, "leaky"),
                   (512, 512, 5, 1, 80, "plain")]
-        variants = [("t64x128", 64128), ("t64x64", 64064), ("t128x128", 128128)]
+        variants = [("t64x128", 64128), ("t64x64", 64064), ("ws3", 7128128), ("ws4", 6128128), ("ws4_prio", 16128128)]
     if args.quick:
         shapes = [(128, 128, 11, 1, 31681, "snake+res"), (128, 128, 3, 1, 31681, "snake+res")]
-        variants = [("old64x128", 64128), ("ws_prodB", 8128128), ("ws_regB", 7128128)]
+        variants = [("ws3", 7128128), ("ws4", 6128128)]
     lines = ["cin cout k dil rows fused variant ms tflops_alg GBps_alg maxrel"]
     g = torch.Generator(device=dev).manual_seed(0)
     for cin, cout, k, dil, L, fused in shapes:
+        if args.flat:
+            L, B = L * args.batch, 1
         w = (torch.randn(cout, k, cin) / math.sqrt(k * cin)).to(torch.bfloat16).float()
         bias = torch.randn(cout) * 0.1
         pc = ops.pack_conv(w, bias, dev, f16=args.precision == 3)
