@@ -126,6 +126,9 @@ typedef struct {
 #define MI355_STATS_ROWS 64
 
 int mi355_conv_gemm(const mi355_conv_gemm_args* a, void* stream);
+/* Timeline probe of the wave-specialised kernel (tile code 46128128, tools/conv_timeline.py): device buffer of
+ * [ceil(grid / 16)][2][48] uint64 s_memtime stamps (consumer wave 0, producer wave 4 of every 16th workgroup); NULL = off. */
+int mi355_conv_ws4_debug_buffer(void* device_buffer);
 /* Host-side packing (CPU, run once at load time).
  * w: float32 [Cout, K, Cin] in the MLX conv layout (values already weight-normed / bf16 rounded),
  * out: uint16 buffer of mi355_packed_conv_weight_elems(Cout, K, Cin) elements. */

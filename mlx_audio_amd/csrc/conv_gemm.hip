@@ -24,183 +24,6 @@ namespace {
 
 constexpr int kThreads = 256;
 
-// Shared epilogue: y = ((acc + bias -> act) + res + y_old) * out_scale, plain or polyphase (conv_transpose) store.
-// All loads of one 32x32 fragment are issued back to back on clamped addresses and only the stores are predicated:
-// a per-element "if (valid) v += res[...]" makes hipcc branch around every load and wait vmcnt(0) each time
-// (64 dependent round trips per wave).  `folded`: res / y_old were already added into the accumulators.
-// EXT: the extended epilogue set (SiLU / GELU-tanh / ELU / tanh, per-column scale).  The wave-specialised kernels live at the 128-VGPR
-// limit of two workgroups per CU; their default instantiation leaves the extensions out (they cost spills there).
-template <int MF, int NF, int WM, int WN, bool EXT>
-__device__ __forceinline__ void conv_epilogue(const mi355_conv_gemm_args& a, f32x16 (&acc)[MF][NF], const int b, const int l0,
-                                              const int n0, const int wm, const int wn, const int lane, const int len_out,
-                                              const bool folded) {
-  const int len_up = a.lens_up ? a.lens_up[b] : a.up_Lout;
-  const int len_up_c = len_up > 0 ? len_up : 1;
-  float* yb = a.y + (int64_t)b * a.y_bstride;
-  const float* rb = (a.res && !folded) ? a.res + (int64_t)b * a.res_bstride : nullptr;
-  const bool accum = a.accumulate && !folded;
-  const bool want_stats = a.stats_partial != nullptr;
-  // fused statistics (single pass, shifted by the lane's first stored value K so that s2 - s1^2/n does not cancel)
-  float sK[NF], s1[NF], s2[NF];
-  int scnt[NF];
-#pragma unroll
-  for (int nf = 0; nf < NF; ++nf) { sK[nf] = 0.f; s1[nf] = 0.f; s2[nf] = 0.f; scnt[nf] = 0; }
-#pragma unroll
-  for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
-      const int n = n0 + wn * WN + nf * 32 + (lane & 31);
-      const bool nok = n < a.Cout;
-      const int ncl = nok ? n : a.Cout - 1;
-      int ocol = ncl, rph = 0;
-      if (a.up_s) { rph = ncl / a.up_cout; ocol = ncl - rph * a.up_cout; }
-      const float bias = a.bias ? a.bias[ocol] : 0.f;
-      float cscale = 1.f;
-      if constexpr (EXT) cscale = a.post_colscale ? a.post_colscale[ocol] : 1.f;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {  // 8 accumulator rows at a time keeps the live set small
-        int orows[8];
-        bool ok[8];
-        float rv[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int r = h * 8 + q;
-          const int u = l0 + wm * WM + mf * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          bool valid = nok && u < len_out;
-          int orow = u < len_out ? u : len_out - 1;
-          if (a.up_s) {
-            int nc = orow * a.up_s + rph - a.up_p;
-            valid = valid && nc >= 0 && nc < len_up;
-            nc = nc < 0 ? 0 : (nc >= len_up_c ? len_up_c - 1 : nc);
-            orow = nc + a.up_row_off;
-          }
-          ok[q] = valid;
-          orows[q] = orow;
-          rv[q] = 0.f;
-        }
-        if (rb) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) rv[q] = rb[(int64_t)(orows[q] >> a.res_shift) * a.ldr + ocol];
-        }
-        if (accum) {
-          float yv[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) yv[q] = yb[(int64_t)orows[q] * a.ldy + ocol];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) rv[q] += yv[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          float v = acc[mf][nf][h * 8 + q] + bias;
-          if (a.post_act == MI355_ACT_LEAKY) v = v > 0.f ? v : v * a.post_slope;
-          else if (a.post_act == MI355_ACT_GELU) v = gelu_erf(v);
-          if constexpr (EXT) {
-            if (a.post_act == MI355_ACT_SILU) v = v / (1.0f + expf(-v));
-            else if (a.post_act == MI355_ACT_GELU_TANH) v = gelu_tanh(v);
-            else if (a.post_act == MI355_ACT_ELU) v = v > 0.f ? v : expm1f(v);
-            else if (a.post_act == MI355_ACT_TANH) v = tanhf(v);
-            v = (v * cscale + rv[q]) * a.out_scale;
-          } else {
-            v = (v + rv[q]) * a.out_scale;
-          }
-          if (ok[q]) yb[(int64_t)orows[q] * a.ldy + ocol] = v;
-          if (want_stats && ok[q]) {
-            sK[nf] = scnt[nf] == 0 ? v : sK[nf];
-            const float d = v - sK[nf];
-            s1[nf] += d;
-            s2[nf] += d * d;
-            ++scnt[nf];
-          }
-        }
-      }
-    }
-  // Fused instance-norm statistics of what was just stored: this wave's WM = 64 rows x 32 columns per nf.  Lanes l and
-  // l + 32 hold the same column (rows interleaved): their (count, mean, M2) triples are merged with Chan's formula after
-  // one xor-32 exchange.  (sum, M2 about the block mean) per column goes to stats_partial[b][row block][n]; the float64
-  // merge over row blocks happens in adain_from_partials.
-  if constexpr (WM == MI355_STATS_ROWS) {
-    if (want_stats && a.up_s == 0) {
-      const int row0 = l0 + wm * WM;
-      if (row0 < len_out) {
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) {
-          const int n = n0 + wn * WN + nf * 32 + (lane & 31);
-          const float cl = (float)scnt[nf];
-          const float ml = scnt[nf] ? sK[nf] + s1[nf] / cl : 0.f;
-          const float vl = scnt[nf] ? s2[nf] - s1[nf] * s1[nf] / cl : 0.f;
-          const float cp = __shfl_xor(cl, 32, 64), mp = __shfl_xor(ml, 32, 64), vp = __shfl_xor(vl, 32, 64);
-          const float ct = cl + cp;
-          const float dm = mp - ml;
-          const float sum = ml * cl + mp * cp;
-          const float m2 = vl + vp + (ct > 0.f ? dm * dm * cl * cp / ct : 0.f);
-          if (lane < 32 && n < a.Cout)
-            *(float2*)(a.stats_partial + (int64_t)b * a.stats_bstride + ((int64_t)(row0 / MI355_STATS_ROWS) * a.Cout + n) * 2) = make_float2(sum, m2);
-        }
-      }
-    }
-  }
-}
-
-// Interior-tile epilogue of the wave-specialised kernel: every row and column of the wave's 64 x 64 block is in range, plain store, no
-// epilogue activation, residual / running sum already folded into the accumulators (or absent).  Same arithmetic, in the same order, as
-// conv_epilogue (bias, out_scale, shifted single-pass statistics), so the two paths are bit-identical; what goes away is the per-element
-// clamping, predication and 64-bit address arithmetic: one uniform base pointer + a 32-bit lane offset per store.
-template <int MF, int NF, int WM, int WN>
-__device__ __forceinline__ void conv_epilogue_interior(const mi355_conv_gemm_args& a, f32x16 (&acc)[MF][NF], const int b, const int l0,
-                                                       const int n0, const int wm, const int wn, const int lane) {
-  char* yw = (char*)(a.y + (int64_t)b * a.y_bstride + (int64_t)(l0 + wm * WM) * a.ldy + (n0 + wn * WN));  // wave-uniform base
-  const uint32_t ldb = (uint32_t)a.ldy * 4u;                                                             // row pitch in bytes
-  const uint32_t lane_off = (uint32_t)(4 * (lane >> 5)) * ldb + (uint32_t)(lane & 31) * 4u;            // < 4 GB inside the wave block
-  const bool want_stats = a.stats_partial != nullptr;
-  const float oscale = a.out_scale;
-  float sK[NF], s1[NF], s2[NF];
-#pragma unroll
-  for (int nf = 0; nf < NF; ++nf) { sK[nf] = 0.f; s1[nf] = 0.f; s2[nf] = 0.f; }
-  auto body = [&](auto stats_tag) {
-    constexpr bool STATS = decltype(stats_tag)::value;
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-      for (int nf = 0; nf < NF; ++nf) {
-        const float bias = a.bias ? a.bias[n0 + wn * WN + nf * 32 + (lane & 31)] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const uint32_t row = mf * 32 + (r & 3) + 8 * (r >> 2);
-          const float v = (acc[mf][nf][r] + bias) * oscale;
-          *(float*)(yw + (lane_off + row * ldb + (uint32_t)(nf * 128))) = v;
-          if constexpr (STATS) {
-            if (mf == 0 && r == 0) sK[nf] = v;
-            const float d = v - sK[nf];
-            s1[nf] += d;
-            s2[nf] += d * d;
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);  // one 32 x 32 fragment at a time: keeps the stored values from piling up in registers
-      }
-  };
-  if (want_stats) body(std::true_type{});
-  else body(std::false_type{});
-  if constexpr (WM == MI355_STATS_ROWS) {
-    if (want_stats) {
-      const int row0 = l0 + wm * WM;
-#pragma unroll
-      for (int nf = 0; nf < NF; ++nf) {
-        const int n = n0 + wn * WN + nf * 32 + (lane & 31);
-        const float cl = (float)(MF * 16);
-        const float ml = sK[nf] + s1[nf] / cl;
-        const float vl = s2[nf] - s1[nf] * s1[nf] / cl;
-        const float cp = cl, mp = __shfl_xor(ml, 32, 64), vp = __shfl_xor(vl, 32, 64);
-        const float ct = cl + cp;
-        const float dm = mp - ml;
-        const float sum = ml * cl + mp * cp;
-        const float m2 = vl + vp + dm * dm * cl * cp / ct;
-        if (lane < 32)
-          *(float2*)(a.stats_partial + (int64_t)b * a.stats_bstride + ((int64_t)(row0 / MI355_STATS_ROWS) * a.Cout + n) * 2) = make_float2(sum, m2);
-      }
-    }
-  }
-}
-
 template <int BM, int BN, int PREC, bool VEC>
 __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_gemm_args a) {
   constexpr int WM = BM / 2, WN = BN / 2, MF = WM / 32, NF = WN / 32;
@@ -761,7 +584,7 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
     // MI355_CONV_WS_VARIANT=7 keeps the previous wave-specialised kernel (A/B aid); MI355_CONV_WS_MIN_TILES overrides the fill threshold
     static const int ws_var = getenv("MI355_CONV_WS_VARIANT") ? atoi(getenv("MI355_CONV_WS_VARIANT")) : 4;
     static const int ws_feat = getenv("MI355_CONV_WS_FEAT") ? atoi(getenv("MI355_CONV_WS_FEAT")) : 0;
-    static const long ws_min = getenv("MI355_CONV_WS_MIN_TILES") ? atol(getenv("MI355_CONV_WS_MIN_TILES")) : 256;
+    static const long ws_min = getenv("MI355_CONV_WS_MIN_TILES") ? atol(getenv("MI355_CONV_WS_MIN_TILES")) : 128;
     if (!no_ws && ws_var == 4 && bn == 128 && wgs128 >= ws_min && a.Cin >= 64 && mi355_conv_ws4_eligible(a, vec)) {
       const int rc = mi355_conv_ws4_launch(a, st, ws_feat);
       if (rc != MI355_ERR_UNSUPPORTED) return rc;  // no instantiation for this prologue / epilogue pair: fall through to the older kernels
