@@ -127,7 +127,8 @@ typedef struct {
 
 int mi355_conv_gemm(const mi355_conv_gemm_args* a, void* stream);
 /* Timeline probe of the wave-specialised kernel (tile code 46128128, tools/conv_timeline.py): device buffer of
- * [ceil(grid / 16)][2][48] uint64 s_memtime stamps (consumer wave 0, producer wave 4 of every 16th workgroup); NULL = off. */
+ * [ceil(grid / 16)][8][4] uint64 s_memtime stamps (consumer wave 0 of every 16th workgroup, its first 8 tiles: tile start, first window
+ * staged, main loop done, stores issued); NULL = off. */
 int mi355_conv_ws4_debug_buffer(void* device_buffer);
 /* Host-side packing (CPU, run once at load time).
  * w: float32 [Cout, K, Cin] in the MLX conv layout (values already weight-normed / bf16 rounded),

@@ -30,18 +30,46 @@ enum { P_NONE = 0, P_LEAKY = 1, P_SNAKE = 2, P_SNAKEBETA = 3, P_ELU = 4 };
 
 struct ws4_geom {
   int tiles_per_item, P, NT, glog, fold;
-  int nch;       // chunks per tile (GEMM mode: 64-channel super-chunks)
-  int keff;      // taps per chunk (GEMM mode: 2 sub-chunks)
-  int tap_rows;  // LDS row shift per tap (conv: dilation; GEMM mode: 128)
-  int R;         // window rows (conv: 128 + (K-1)*dil; GEMM mode: 256)
+  int nch;        // chunks per tile (GEMM mode: 64-channel super-chunks)
+  int keff;       // taps per chunk (GEMM mode: 2 sub-chunks)
+  int tap_rows;   // LDS row shift per tap (conv: dilation; GEMM mode: 128)
+  int R;          // window rows (conv: 128 + (K-1)*dil; GEMM mode: 256)
   int gemm;
-  int nslices;   // weight slices of the packed image = ceil(Cin / 32) * K
-  int feat;      // bit 0: consumers at s_setprio 1 (A/B aid)
+  int nslices;    // weight slices of the packed image = ceil(Cin / 32) * K
+  int feat;       // bit 0: consumers at s_setprio 1 (A/B aid)
+  int total_ids;  // virtual workgroup ids (tile slots incl. the XCD-run padding); a workgroup walks ids blockIdx.x + i * gridDim.x
 };
 
-// timeline probe (DBG instantiation only): s_memtime stamps of one consumer and one producer wave of every 16th workgroup
+// timeline probe (DBG instantiation only): s_memtime stamps of consumer wave 0 of every 16th workgroup, 4 per tile for its first 8 tiles
 __device__ unsigned long long* g_ws4_dbg = nullptr;
-constexpr int kDbgSlots = 48;
+constexpr int kDbgSlots = 32;
+
+struct tile_t { int b, l0, n0, len_out, len_in; };
+
+// Virtual workgroup ids go round-robin over the 8 XCDs (id & 7 = XCD, each with its own L2; gridDim.x is a multiple of 8, so a workgroup's ids all
+// map to its own XCD).  An XCD owns runs of 2^glog CONSECUTIVE row tiles (all NT column tiles of a row tile back to back on it): neighbouring
+// tiles share their halo rows through that L2 and the column tiles re-read the same activation window from it.
+__device__ __forceinline__ bool decode_tile(const mi355_conv_gemm_args& a, const ws4_geom& q, const int id, tile_t& t) {
+  const int kq = id >> 3;
+  const int ny = kq % q.NT;
+  const int pg = kq / q.NT;
+  const int glog = q.glog;
+  const int p = (((((pg >> glog) << 3) + (id & 7)) << glog)) | (pg & ((1 << glog) - 1));
+  if (p >= q.P) return false;
+  t.b = p / q.tiles_per_item;
+  t.l0 = (p - t.b * q.tiles_per_item) * 128;
+  t.n0 = ny * 128;
+  t.len_out = a.lens_out ? a.lens_out[t.b] : a.Lout;
+  if (t.l0 >= t.len_out) return false;
+  t.len_in = a.lens_in ? a.lens_in[t.b] : a.Lin;
+  return true;
+}
+// the next id of this workgroup (after `id`) that has work, or -1
+__device__ __forceinline__ int next_work(const mi355_conv_gemm_args& a, const ws4_geom& q, int id, tile_t& t) {
+  for (id += (int)gridDim.x; id < q.total_ids; id += (int)gridDim.x)
+    if (decode_tile(a, q, id, t)) return id;
+  return -1;
+}
 
 template <int PREC, int PRE, bool EXT, bool GEMM, bool DBG = false>
 __global__ __launch_bounds__(kThreads, 4) void conv_ws4_kernel(const mi355_conv_gemm_args a, const ws4_geom q) {
@@ -50,41 +78,42 @@ __global__ __launch_bounds__(kThreads, 4) void conv_ws4_kernel(const mi355_conv_
   constexpr int NA = a_images<PREC>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane_k = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // Workgroup ids go round-robin over the 8 XCDs (id & 7 = XCD, each with its own L2).  An XCD owns runs of 2^glog CONSECUTIVE row tiles (all NT
-  // column tiles of a row tile back to back on it): neighbouring tiles share their halo rows through that L2 and the column tiles re-read the
-  // same activation window from it, while runs still interleave over the XCDs.
-  const int id = blockIdx.x;
-  const int kq = id >> 3;
-  const int ny = kq % q.NT;
-  const int pg = kq / q.NT;
-  const int glog = q.glog;
-  const int p = (((((pg >> glog) << 3) + (id & 7)) << glog)) | (pg & ((1 << glog) - 1));
-  if (p >= q.P) return;
-  const int b = p / q.tiles_per_item;
-  const int l0 = (p - b * q.tiles_per_item) * BM, n0 = ny * BN;
-  const int len_out = a.lens_out ? a.lens_out[b] : a.Lout;
-  if (l0 >= len_out) return;
-  const int len_in = a.lens_in ? a.lens_in[b] : a.Lin;
   const int R = q.R;
   const int ABYTES = R * 64;
   char* Abase = smem;  // [2 buffers][NA (hi, lo)][R * 64]
   const int nch = q.nch, keff = q.keff;
+  // PERSISTENT: the workgroup walks its tiles; the (tile, chunk) items form one stream.  Item j is staged in LDS buffer j & 1; one s_barrier per
+  // item: the producers arrive when item j is converted, the consumers when they are done with item j - 1 (and with the previous tile's epilogue
+  // and the next tile's fold loads), so the window of a tile's first chunk is already waiting when its MFMAs may start.
+  tile_t t0;
+  int id0 = (int)blockIdx.x - (int)gridDim.x;
+  id0 = next_work(a, q, id0, t0);
+  if (id0 < 0) return;
 
   if (wave >= 4) {
     // ------------------------------------------------------------------------------ producers
     const int ptid = tid - 256;
     const int c4 = (ptid & 7) * 4;
     const int prow = ptid >> 3;
-    const float* xb = a.x + (int64_t)b * a.x_bstride + a.x_off;
+    const float* xbase = a.x + a.x_off;
     const int wrow0 = (wave - 4) * 8;  // pass i of this wave covers window rows [wrow0 + 32 i, +8): passes entirely past R are skipped
     constexpr int cstride = GEMM ? 64 : 32;
-    float4 s0[NLD], s1[NLD];  // two windows in flight: s0 carries the even chunks, s1 the odd ones
+    float4 s0[NLD], s1[NLD];  // two windows in flight: s0 carries the even items, s1 the odd ones
+    struct item_t { int id, ci, b, l0, len_in; };
+    auto advance = [&](item_t& it) {  // next (tile, chunk) item of this workgroup; id = -1 past the end
+      if (it.ci + 1 < nch) { ++it.ci; return; }
+      tile_t t;
+      it.id = next_work(a, q, it.id, t);
+      it.ci = 0; it.b = t.b; it.l0 = t.l0; it.len_in = t.len_in;
+    };
 
     // window row r = prow + 32 i of a chunk: conv mode = input row l0 - pad + r, channels [32 chunk, +32);
     // GEMM mode = input row l0 + (r & 127), channels [64 chunk + 32 (r >> 7), +32)
-    auto loadA = [&](float4 (&areg)[NLD], const int chunk) {
+    auto loadA = [&](float4 (&areg)[NLD], const item_t& it) {
+      const int chunk = it.ci, l0 = it.l0;
+      const float* xb = xbase + (int64_t)it.b * a.x_bstride;
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
         if (GEMM || wrow0 + i * 32 < R) {
@@ -96,7 +125,8 @@ __global__ __launch_bounds__(kThreads, 4) void conv_ws4_kernel(const mi355_conv_
         }
       }
     };
-    auto convertA = [&](const float4 (&areg)[NLD], const int chunk, char* A_hi) {
+    auto convertA = [&](const float4 (&areg)[NLD], const item_t& it, char* A_hi) {
+      const int chunk = it.ci, l0 = it.l0, b = it.b, len_in = it.len_in;
       char* A_lo = A_hi + ABYTES;
       const int c = chunk * cstride + c4;  // GEMM mode (no prologue coefficients): passes 4..7 carry channels c + 32
       float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f}, al[4] = {1.f, 1.f, 1.f, 1.f}, ial[4] = {1.f, 1.f, 1.f, 1.f};
@@ -180,37 +210,27 @@ __global__ __launch_bounds__(kThreads, 4) void conv_ws4_kernel(const mi355_conv_
 
     // chunk ci is converted into buffer ci & 1 while the consumers work on chunk ci - 1 (they left that buffer at the barrier that ended
     // chunk ci - 2); the loads of chunk ci + 2 are issued right behind the conversion, i.e. two windows are always in flight
-    unsigned long long* dbg = nullptr;
-    int dslot = 0;
-    auto stamp = [&]() {
-      if constexpr (DBG) {
-        if (dbg && lane == 0 && dslot < kDbgSlots) dbg[dslot] = __builtin_amdgcn_s_memtime();
-        ++dslot;
-      }
-    };
-    if constexpr (DBG) {
-      if (wave == 4 && (blockIdx.x & 15) == 0 && g_ws4_dbg) dbg = g_ws4_dbg + ((size_t)(blockIdx.x >> 4) * 2 + 1) * kDbgSlots;
-    }
-    stamp();  // slot 0: start
-    loadA(s0, 0);
-    if (nch > 1) loadA(s1, 1);
-    for (int ci = 0; ci < nch; ci += 2) {
-      if constexpr (DBG) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // (probe only) s0's loads have landed, s1's may be in flight
-      stamp();  // loads of chunk ci landed
-      convertA(s0, ci, Abase);
-      if (ci + 2 < nch) loadA(s0, ci + 2);
-      stamp();  // converted
-      lds_barrier();  // window ci staged (= the consumers' end-of-chunk barrier of chunk ci - 1)
-      stamp();  // barrier passed
-      if (ci + 1 < nch) {
-        if constexpr (DBG) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        stamp();
-        convertA(s1, ci + 1, Abase + NA * ABYTES);
-        if (ci + 3 < nch) loadA(s1, ci + 3);
-        stamp();
-        lds_barrier();
-        stamp();
-      }
+
+    item_t ia{id0, 0, t0.b, t0.l0, t0.len_in};
+    item_t ib = ia;
+    advance(ib);
+    loadA(s0, ia);
+    if (ib.id >= 0) loadA(s1, ib);
+    while (true) {
+      convertA(s0, ia, Abase);
+      item_t na = ib;
+      if (na.id >= 0) advance(na);
+      if (na.id >= 0) loadA(s0, na);
+      lds_barrier();  // even item staged
+      if (ib.id < 0) break;
+      convertA(s1, ib, Abase + NA * ABYTES);
+      item_t nb = na;
+      if (nb.id >= 0) advance(nb);
+      if (nb.id >= 0) loadA(s1, nb);
+      lds_barrier();  // odd item staged
+      if (na.id < 0) break;
+      ia = na;
+      ib = nb;
     }
     return;
   }
@@ -218,190 +238,185 @@ __global__ __launch_bounds__(kThreads, 4) void conv_ws4_kernel(const mi355_conv_
   // -------------------------------------------------------------------------------- consumers
   constexpr int WM = 64, WN = 64, MF = 2, NF = 2;
   const int wm = wave >> 1, wn = wave & 1;
-  const int hl = lane & 31, hh = lane >> 5;
   if (q.feat & 1) __builtin_amdgcn_s_setprio(1);
-  // fragment (nf, kk) of weight slice s: 1 KB at wfrag + s * wstep + (nf * 2 + kk) * 1024
   const int NTp = ((a.Cout + 127) >> 7) << 2;
-  const char* wfrag = (const char*)a.w + ((int64_t)((n0 >> 5) + wn * NF)) * 2048 + lane * 16;
   const int64_t wstep = (int64_t)NTp * 2048;
   const int nsteps = nch * keff;
   const int last_slice = q.nslices - 1;
-  auto wptr = [&](const int s) { return wfrag + (int64_t)(s < last_slice ? s : last_slice) * wstep; };
-  bf16x8 b0[4], b1[4];
-#pragma unroll
-  for (int f = 0; f < 4; ++f) b0[f] = *(const bf16x8*)(wfrag + f * 1024);
-
-  f32x16 acc[MF][NF];
-#pragma unroll
-  for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-    for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
-
-  float* yb = a.y + (int64_t)b * a.y_bstride;
-  const float* rb = a.res ? a.res + (int64_t)b * a.res_bstride : nullptr;
-  const bool interior = l0 + BM <= len_out && n0 + BN <= a.Cout;
   const int fold = q.fold;
-  // residual and running sum go in as the initial accumulator value (their latency hides under the staging of the first window)
-  if (fold && interior) {  // no clamping, 32-bit lane offsets from wave-uniform bases
-    const char* rw = rb ? (const char*)(rb + (int64_t)(l0 + wm * WM) * a.ldr + (n0 + wn * WN)) : nullptr;
-    const char* yr = (const char*)(yb + (int64_t)(l0 + wm * WM) * a.ldy + (n0 + wn * WN));
-    const uint32_t rpb = (uint32_t)a.ldr * 4u, ypb = (uint32_t)a.ldy * 4u;
-    const uint32_t roff = (uint32_t)(4 * hh) * rpb + (uint32_t)hl * 4u;
-    const uint32_t yoff = (uint32_t)(4 * hh) * ypb + (uint32_t)hl * 4u;
+  unsigned long long* dbg = nullptr;
+  if constexpr (DBG) {
+    if (wave == 0 && (blockIdx.x & 15) == 0 && g_ws4_dbg) dbg = g_ws4_dbg + (size_t)(blockIdx.x >> 4) * kDbgSlots;
+  }
+  int jbuf = 0;   // parity of the item stream = LDS buffer of the current chunk
+  int ntile = 0;
+  tile_t t = t0;
+  for (int id = id0; id >= 0; id = next_work(a, q, id, t), ++ntile) {
+    const int b = t.b, l0 = t.l0, n0 = t.n0, len_out = t.len_out;
+    // an opaque per-tile copy of the lane id: without it LICM hoists the ~200 lane-constant 64-bit fold / store offsets out of the tile loop and
+    // parks them in scratch (a persistent kernel's classic: recompute per tile instead, it is a handful of VALU ops)
+    int lane = lane_k;
+    asm volatile("" : "+v"(lane));
+    const int hl = lane & 31, hh = lane >> 5;
+    if constexpr (DBG) {
+      if (dbg && lane == 0 && ntile < 8) dbg[4 * ntile] = __builtin_amdgcn_s_memtime();  // tile start
+    }
+    // fragment (nf, kk) of weight slice s: 1 KB at wfrag + s * wstep + (nf * 2 + kk) * 1024
+    const char* wfrag = (const char*)a.w + ((int64_t)((n0 >> 5) + wn * NF)) * 2048 + lane * 16;
+    auto wptr = [&](const int s) { return wfrag + (int64_t)(s < last_slice ? s : last_slice) * wstep; };
+    bf16x8 b0[4], b1[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) b0[f] = *(const bf16x8*)(wfrag + f * 1024);
+
+    f32x16 acc[MF][NF];
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf) {
-        float rv[16];
+      for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rv[r] = 0.f;
-        if (rw) {
+        for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+
+    float* yb = a.y + (int64_t)b * a.y_bstride;
+    const float* rb = a.res ? a.res + (int64_t)b * a.res_bstride : nullptr;
+    const bool interior = l0 + BM <= len_out && n0 + BN <= a.Cout;
+    // residual and running sum go in as the initial accumulator value
+    if (fold && interior) {  // no clamping, 32-bit lane offsets from wave-uniform bases
+      const char* rw = rb ? (const char*)(rb + (int64_t)(l0 + wm * WM) * a.ldr + (n0 + wn * WN)) : nullptr;
+      const char* yr = (const char*)(yb + (int64_t)(l0 + wm * WM) * a.ldy + (n0 + wn * WN));
+      const uint32_t rpb = (uint32_t)a.ldr * 4u, ypb = (uint32_t)a.ldy * 4u;
+      const uint32_t roff = (uint32_t)(4 * hh) * rpb + (uint32_t)hl * 4u;
+      const uint32_t yoff = (uint32_t)(4 * hh) * ypb + (uint32_t)hl * 4u;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) rv[r] = *(const float*)(rw + (roff + (uint32_t)(mf * 32 + (r & 3) + 8 * (r >> 2)) * rpb + (uint32_t)(nf * 128)));
-        }
-        if (a.accumulate) {
+      for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) rv[r] += *(const float*)(yr + (yoff + (uint32_t)(mf * 32 + (r & 3) + 8 * (r >> 2)) * ypb + (uint32_t)(nf * 128)));
-        }
+        for (int nf = 0; nf < NF; ++nf) {
+          float rv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mf][nf][r] = rv[r];
-      }
-  } else if (fold) {
+          for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+          if (rw) {
 #pragma unroll
-    for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-      for (int nf = 0; nf < NF; ++nf) {
-        const int n = n0 + wn * WN + nf * 32 + hl;
-        const bool nok = n < a.Cout;
-        const int ncl = nok ? n : a.Cout - 1;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          float rv[8];
-          int us[8];
-#pragma unroll
-          for (int qq = 0; qq < 8; ++qq) {
-            const int r = h * 8 + qq;
-            us[qq] = l0 + wm * WM + mf * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            rv[qq] = 0.f;
-          }
-          if (rb) {
-#pragma unroll
-            for (int qq = 0; qq < 8; ++qq) rv[qq] = rb[(int64_t)(us[qq] < len_out ? us[qq] : len_out - 1) * a.ldr + ncl];
+            for (int r = 0; r < 16; ++r) rv[r] = *(const float*)(rw + (roff + (uint32_t)(mf * 32 + (r & 3) + 8 * (r >> 2)) * rpb + (uint32_t)(nf * 128)));
           }
           if (a.accumulate) {
-            float yv[8];
 #pragma unroll
-            for (int qq = 0; qq < 8; ++qq) yv[qq] = yb[(int64_t)(us[qq] < len_out ? us[qq] : len_out - 1) * a.ldy + ncl];
-#pragma unroll
-            for (int qq = 0; qq < 8; ++qq) rv[qq] += yv[qq];
+            for (int r = 0; r < 16; ++r) rv[r] += *(const float*)(yr + (yoff + (uint32_t)(mf * 32 + (r & 3) + 8 * (r >> 2)) * ypb + (uint32_t)(nf * 128)));
           }
 #pragma unroll
-          for (int qq = 0; qq < 8; ++qq) acc[mf][nf][h * 8 + qq] = (nok && us[qq] < len_out) ? rv[qq] : 0.f;
+          for (int r = 0; r < 16; ++r) acc[mf][nf][r] = rv[r];
         }
-      }
-  }
-
-  unsigned long long* dbg = nullptr;
-  int dslot = 0;
-  if constexpr (DBG) {
-    if (wave == 0 && (blockIdx.x & 15) == 0 && g_ws4_dbg) dbg = g_ws4_dbg + (size_t)(blockIdx.x >> 4) * 2 * kDbgSlots;
-    if (dbg && lane == 0) dbg[dslot] = __builtin_amdgcn_s_memtime();  // slot 0: fold loads issued
-    ++dslot;
-  }
-  lds_barrier();  // barrier #0
-  if constexpr (DBG) {
-    if (dbg && lane == 0) dbg[dslot] = __builtin_amdgcn_s_memtime();  // slot 1: window 0 staged
-    ++dslot;
-  }
-  {
-    int ci = 0, tap = 0;
-    bf16x8 ah0, al0, ah1, al1;  // two static activation-fragment sets (al*: the lo image, unused for the single-pass precisions)
-    // group g of a tap: kk = g >> 1 (16-channel half of the chunk), mf = g & 1 (32-row half of the wave's rows)
-    auto rdA = [&](bf16x8& h, bf16x8& l, const int g, const int tp) {
-      const int kk = g >> 1, mf = g & 1;
-      const int row = wm * WM + mf * 32 + hl + tp * q.tap_rows;
-      const int cidx = kk * 2 + hh;
-      const int addr = row * 64 + ((cidx ^ ((row >> 2) & 3)) << 4);
-      const char* A_hi = Abase + (ci & 1) * NA * ABYTES;
-      h = *(const bf16x8*)(A_hi + addr);
-      if constexpr (NA == 2) l = *(const bf16x8*)(A_hi + ABYTES + addr);
-    };
-    auto mm = [&](const bf16x8& h, const bf16x8& l, const int g, const bf16x8 (&bf)[4]) {
-      const int kk = g >> 1, mf = g & 1;
-      acc[mf][0] = mfma16<PREC>(h, bf[kk], acc[mf][0]);
-      acc[mf][1] = mfma16<PREC>(h, bf[2 + kk], acc[mf][1]);
-      if constexpr (NA == 2) {
-        acc[mf][0] = mfma16<PREC>(l, bf[kk], acc[mf][0]);
-        acc[mf][1] = mfma16<PREC>(l, bf[2 + kk], acc[mf][1]);
-      }
-    };
-    // one tap = four groups; the fragments of group g+1 are requested before the MFMAs of group g are issued
-    auto tap_body = [&](const bf16x8 (&bf)[4]) {
-      rdA(ah1, al1, 1, tap);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(ah0, al0, 0, bf);
-      rdA(ah0, al0, 2, tap);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(ah1, al1, 1, bf);
-      rdA(ah1, al1, 3, tap);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(ah0, al0, 2, bf);
-      if (tap + 1 < keff) rdA(ah0, al0, 0, tap + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(ah1, al1, 3, bf);
-      if (++tap == keff) {  // end of chunk: the next window is staged behind the barrier, this one may be overwritten
-        tap = 0;
-        ++ci;
-        if (ci < nch) {
-          if constexpr (DBG) {
-            if (dbg && lane == 0 && dslot < kDbgSlots - 4) dbg[dslot] = __builtin_amdgcn_s_memtime();  // chunk done, before the barrier
-            ++dslot;
+    } else if (fold) {
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          const int n = n0 + wn * WN + nf * 32 + hl;
+          const bool nok = n < a.Cout;
+          const int ncl = nok ? n : a.Cout - 1;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float rv[8];
+            int us[8];
+#pragma unroll
+            for (int qq = 0; qq < 8; ++qq) {
+              const int r = h * 8 + qq;
+              us[qq] = l0 + wm * WM + mf * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+              rv[qq] = 0.f;
+            }
+            if (rb) {
+#pragma unroll
+              for (int qq = 0; qq < 8; ++qq) rv[qq] = rb[(int64_t)(us[qq] < len_out ? us[qq] : len_out - 1) * a.ldr + ncl];
+            }
+            if (a.accumulate) {
+              float yv[8];
+#pragma unroll
+              for (int qq = 0; qq < 8; ++qq) yv[qq] = yb[(int64_t)(us[qq] < len_out ? us[qq] : len_out - 1) * a.ldy + ncl];
+#pragma unroll
+              for (int qq = 0; qq < 8; ++qq) rv[qq] += yv[qq];
+            }
+#pragma unroll
+            for (int qq = 0; qq < 8; ++qq) acc[mf][nf][h * 8 + qq] = (nok && us[qq] < len_out) ? rv[qq] : 0.f;
           }
+        }
+    }
+
+    {
+      int tap = 0;
+      bf16x8 ah0, al0, ah1, al1;  // two static activation-fragment sets (al*: the lo image, unused for the single-pass precisions)
+      // group g of a tap: kk = g >> 1 (16-channel half of the chunk), mf = g & 1 (32-row half of the wave's rows)
+      auto rdA = [&](bf16x8& h, bf16x8& l, const int g, const int tp) {
+        const int kk = g >> 1, mf = g & 1;
+        const int row = wm * WM + mf * 32 + hl + tp * q.tap_rows;
+        const int cidx = kk * 2 + hh;
+        const int addr = row * 64 + ((cidx ^ ((row >> 2) & 3)) << 4);
+        const char* A_hi = Abase + jbuf * NA * ABYTES;
+        h = *(const bf16x8*)(A_hi + addr);
+        if constexpr (NA == 2) l = *(const bf16x8*)(A_hi + ABYTES + addr);
+      };
+      auto mm = [&](const bf16x8& h, const bf16x8& l, const int g, const bf16x8 (&bf)[4]) {
+        const int kk = g >> 1, mf = g & 1;
+        acc[mf][0] = mfma16<PREC>(h, bf[kk], acc[mf][0]);
+        acc[mf][1] = mfma16<PREC>(h, bf[2 + kk], acc[mf][1]);
+        if constexpr (NA == 2) {
+          acc[mf][0] = mfma16<PREC>(l, bf[kk], acc[mf][0]);
+          acc[mf][1] = mfma16<PREC>(l, bf[2 + kk], acc[mf][1]);
+        }
+      };
+      // one tap = four groups; the fragments of group g+1 are requested before the MFMAs of group g are issued
+      auto tap_body = [&](const bf16x8 (&bf)[4], const bool first) {
+        if (tap == 0) {  // new chunk: its window is staged behind this barrier (and the producers may refill the buffer just left)
           lds_barrier();
           if constexpr (DBG) {
-            if (dbg && lane == 0 && dslot < kDbgSlots - 4) dbg[dslot] = __builtin_amdgcn_s_memtime();  // barrier passed
-            ++dslot;
+            if (first && dbg && lane == 0 && ntile < 8) dbg[4 * ntile + 1] = __builtin_amdgcn_s_memtime();  // first window staged
           }
           rdA(ah0, al0, 0, 0);
         }
+        rdA(ah1, al1, 1, tap);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(ah0, al0, 0, bf);
+        rdA(ah0, al0, 2, tap);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(ah1, al1, 1, bf);
+        rdA(ah1, al1, 3, tap);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(ah0, al0, 2, bf);
+        if (tap + 1 < keff) rdA(ah0, al0, 0, tap + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(ah1, al1, 3, bf);
+        if (++tap == keff) {  // end of chunk
+          tap = 0;
+          jbuf ^= 1;
+        }
+      };
+      // The weight prefetch is unconditional (past the last slice it re-reads the last one): a branch around the loads would make hipcc assume
+      // they may not have been issued and wait for them right away.
+      for (int s = 0; s < nsteps; s += 2) {
+        const char* w1 = wptr(s + 1);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) b1[f] = *(const bf16x8*)(w1 + f * 1024);
+        asm volatile("" ::: "memory");  // keep the prefetch AHEAD of the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        tap_body(b0, s == 0);
+        if (s + 1 >= nsteps) break;
+        const char* w0 = wptr(s + 2);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) b0[f] = *(const bf16x8*)(w0 + f * 1024);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        tap_body(b1, false);
       }
-    };
-    rdA(ah0, al0, 0, 0);
-    // The weight prefetch is unconditional (past the last slice it re-reads the last one): a branch around the loads would make hipcc assume
-    // they may not have been issued and wait for them right away.
-    for (int s = 0; s < nsteps; s += 2) {
-      const char* w1 = wptr(s + 1);
-#pragma unroll
-      for (int f = 0; f < 4; ++f) b1[f] = *(const bf16x8*)(w1 + f * 1024);
-      asm volatile("" ::: "memory");  // keep the prefetch AHEAD of the MFMAs
-      __builtin_amdgcn_sched_barrier(0);
-      tap_body(b0);
-      if (s + 1 >= nsteps) break;
-      const char* w0 = wptr(s + 2);
-#pragma unroll
-      for (int f = 0; f < 4; ++f) b0[f] = *(const bf16x8*)(w0 + f * 1024);
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      tap_body(b1);
+    }
+    if constexpr (DBG) {
+      if (dbg && lane == 0 && ntile < 8) dbg[4 * ntile + 2] = __builtin_amdgcn_s_memtime();  // main loop done
+    }
+
+    const bool plain = a.up_s == 0 && a.post_act == MI355_ACT_NONE && (fold || (!a.res && !a.accumulate)) && !(EXT && a.post_colscale);
+    if (plain && interior) conv_epilogue_interior<MF, NF, WM, WN>(a, acc, b, l0, n0, wm, wn, lane);
+    else conv_epilogue<MF, NF, WM, WN, EXT>(a, acc, b, l0, n0, wm, wn, lane, len_out, fold != 0);
+    if constexpr (DBG) {
+      if (dbg && lane == 0 && ntile < 8) dbg[4 * ntile + 3] = __builtin_amdgcn_s_memtime();  // stores issued
     }
   }
   if (q.feat & 1) __builtin_amdgcn_s_setprio(0);
-  if constexpr (DBG) {
-    if (dbg && lane == 0) dbg[kDbgSlots - 3] = __builtin_amdgcn_s_memtime();  // main loop done
-  }
-
-  const bool plain = a.up_s == 0 && a.post_act == MI355_ACT_NONE && (fold || (!a.res && !a.accumulate)) && !(EXT && a.post_colscale);
-  if (plain && interior) conv_epilogue_interior<MF, NF, WM, WN>(a, acc, b, l0, n0, wm, wn, lane);
-  else conv_epilogue<MF, NF, WM, WN, EXT>(a, acc, b, l0, n0, wm, wn, lane, len_out, fold != 0);
-  if constexpr (DBG) {
-    if (dbg && lane == 0) {
-      dbg[kDbgSlots - 2] = __builtin_amdgcn_s_memtime();  // stores issued
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      dbg[kDbgSlots - 1] = __builtin_amdgcn_s_memtime();  // stores retired
-    }
-  }
 }
 
 // GEMM mode: pure linear layers (K == 1, no prologue) with at least two 32-channel chunks
@@ -434,7 +449,18 @@ int launch_ws4(const mi355_conv_gemm_args& a, hipStream_t st, const int feat) {
   q.glog = q.P >= 512 ? 3 : (q.P >= 256 ? 2 : (q.P >= 128 ? 1 : 0));
   q.feat = feat;
   const int per = 8 << q.glog;
-  const unsigned grid = (unsigned)(((q.P + per - 1) / per) * per * q.NT);
+  q.total_ids = ((q.P + per - 1) / per) * per * q.NT;
+  // persistent: two resident workgroups per CU (128 VGPRs x 8 waves each) walk the tile list; small problems launch one workgroup per tile
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  static const int wg_per_cu = getenv("MI355_CONV_WS_WG_PER_CU") ? atoi(getenv("MI355_CONV_WS_WG_PER_CU")) : 2;
+  const int resident = ((cus * wg_per_cu) / 8) * 8;
+  const unsigned grid = (unsigned)((feat & 8) || q.total_ids <= resident ? q.total_ids : resident);  // feat bit 3: one workgroup per tile (A/B aid)
   MI355_CLEAR_ERROR();
   hipLaunchKernelGGL((conv_ws4_kernel<PREC, PRE, EXT, GEMM, DBG>), dim3(grid), dim3(kThreads), lds, st, a, q);
   MI355_LAUNCH_CHECK("conv_gemm(ws4)");

@@ -46,7 +46,7 @@ def main():
     shapes.append((256, 256, 11, 5, 5280, "snake"))
     shapes.append((1090, 1024, 3, 1, 264, "leaky"))
     shapes.append((512, 2560, 2, 1, 529, "plain"))
-    variants = [("old64x128", 64128), ("ws3", 7128128), ("ws4", 6128128), ("ws4_prio", 16128128)]
+    variants = [("ws3", 7128128), ("ws4_1tile", 86128128), ("ws4", 6128128), ("ws4_prio", 16128128)]
     if args.ablate:
         shapes = [(128, 128, 11, 1, 31681, "snake+res"), (128, 128, 3, 1, 31681, "snake+res"), (256, 256, 7, 1, 5280, "snake+res")]
         variants = [("ws_regB", 7128128), ("abl1_noBload", 17128128), ("abl2_noAread", 27128128), ("abl3_noAB", 37128128),
@@ -55,7 +55,7 @@ def main():
         shapes = [(768, 2304, 1, 1, 80, "plain"), (768, 768, 1, 1, 80, "plain"), (768, 2048, 1, 1, 80, "plain"), (2048, 768, 1, 1, 80, "plain"),
                   (640, 2048, 1, 1, 264, "plain"), (1090, 1024, 3, 1, 264, "leaky"), (1024, 1024, 3, 1, 264, "leaky"), (512, 512, 3, 1, 528, "leaky"),
                   (512, 512, 5, 1, 80, "plain")]
-        variants = [("t64x128", 64128), ("t64x64", 64064), ("ws3", 7128128), ("ws4", 6128128), ("ws4_prio", 16128128)]
+        variants = [("t64x128", 64128), ("t64x64", 64064), ("ws3", 7128128), ("ws4_1tile", 86128128), ("ws4", 6128128)]
     if args.quick:
         shapes = [(128, 128, 11, 1, 31681, "snake+res"), (128, 128, 3, 1, 31681, "snake+res")]
         variants = [("ws3", 7128128), ("ws4", 6128128)]
