@@ -592,10 +592,10 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
     if (!no_ws && ws_ok && bn == 128 && wgs128 >= ws_min && a.Cin >= 64) tile = 7128128;
     else if (bn == 128 && wgs128 >= 512) tile = 64128;  // measured: 64-row tiles beat 128-row tiles on the 4-wave kernel
   }
-  if (tile % 10000000 == 6128128) {  // ws4, explicit: 6128128 + 10000000 * feature bits
+  if (tile % 10000000 == 6128128) {  // ws4, explicit: 6128128 + 10000000 * feature bits (+ 100000000 * ablation bits)
     MI355_REQUIRE(mi355_conv_ws4_eligible(a, vec), "conv_gemm: the ws4 tile needs 16-B aligned channels-last input / output / residual rows, "
                   "Cout %% 4 == 0, a window of <= 256 rows and precision 2 or 4");
-    return mi355_conv_ws4_launch(a, st, tile / 10000000);
+    return mi355_conv_ws4_launch(a, st, ((tile / 10000000) % 10) | ((tile / 100000000) << 4));
   }
   if (a.stats_partial) {  // statistics are produced per 64-row wave block: only the 128-row kernels have those
     MI355_REQUIRE(vec, "conv_gemm: fused statistics need the 16-B aligned channels-last input path");

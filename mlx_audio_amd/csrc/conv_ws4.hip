@@ -42,7 +42,7 @@ struct ws4_geom {
 
 // timeline probe (DBG instantiation only): s_memtime stamps of consumer wave 0 of every 16th workgroup, 4 per tile for its first 8 tiles
 __device__ unsigned long long* g_ws4_dbg = nullptr;
-constexpr int kDbgSlots = 32;
+constexpr int kDbgSlots = 34;
 
 struct tile_t { int b, l0, n0, len_out, len_in; };
 
@@ -71,7 +71,10 @@ __device__ __forceinline__ int next_work(const mi355_conv_gemm_args& a, const ws
   return -1;
 }
 
-template <int PREC, int PRE, bool EXT, bool GEMM, bool DBG = false>
+// ABL (ablation bits, timing experiments only -- results are WRONG when non-zero; reachable only through the explicit tile codes
+// ABL * 100000000 + 6128128 of tools/bench_conv.py --ablate): 1 = no weight-fragment loads after the first, 2 = no activation-fragment LDS
+// reads, 4 = the producers only take part in the barriers, 8 = no residual fold and no epilogue.
+template <int PREC, int PRE, bool EXT, bool GEMM, bool DBG = false, int ABL = 0>
 __global__ __launch_bounds__(kThreads, 4) void conv_ws4_kernel(const mi355_conv_gemm_args a, const ws4_geom q) {
   constexpr int BM = 128, BN = 128;
   constexpr int NLD = GEMM ? 8 : 6;  // window passes of 32 rows per chunk (conv: R <= 192; GEMM mode: R = 256)
@@ -214,19 +217,20 @@ __global__ __launch_bounds__(kThreads, 4) void conv_ws4_kernel(const mi355_conv_
     item_t ia{id0, 0, t0.b, t0.l0, t0.len_in};
     item_t ib = ia;
     advance(ib);
-    loadA(s0, ia);
-    if (ib.id >= 0) loadA(s1, ib);
+    constexpr bool work = (ABL & 4) == 0;
+    if (work) loadA(s0, ia);
+    if (work && ib.id >= 0) loadA(s1, ib);
     while (true) {
-      convertA(s0, ia, Abase);
+      if (work) convertA(s0, ia, Abase);
       item_t na = ib;
       if (na.id >= 0) advance(na);
-      if (na.id >= 0) loadA(s0, na);
+      if (work && na.id >= 0) loadA(s0, na);
       lds_barrier();  // even item staged
       if (ib.id < 0) break;
-      convertA(s1, ib, Abase + NA * ABYTES);
+      if (work) convertA(s1, ib, Abase + NA * ABYTES);
       item_t nb = na;
       if (nb.id >= 0) advance(nb);
-      if (nb.id >= 0) loadA(s1, nb);
+      if (work && nb.id >= 0) loadA(s1, nb);
       lds_barrier();  // odd item staged
       if (na.id < 0) break;
       ia = na;
@@ -260,6 +264,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv_ws4_kernel(const mi355_conv_
     const int hl = lane & 31, hh = lane >> 5;
     if constexpr (DBG) {
       if (dbg && lane == 0 && ntile < 8) dbg[4 * ntile] = __builtin_amdgcn_s_memtime();  // tile start
+      if (dbg && lane == 0 && (ntile == 0 || ntile == 7)) dbg[32 + (ntile == 7)] = wall_clock64();  // 100 MHz constant-rate counter: gives the shader clock
     }
     // fragment (nf, kk) of weight slice s: 1 KB at wfrag + s * wstep + (nf * 2 + kk) * 1024
     const char* wfrag = (const char*)a.w + ((int64_t)((n0 >> 5) + wn * NF)) * 2048 + lane * 16;
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv_ws4_kernel(const mi355_conv_
     const float* rb = a.res ? a.res + (int64_t)b * a.res_bstride : nullptr;
     const bool interior = l0 + BM <= len_out && n0 + BN <= a.Cout;
     // residual and running sum go in as the initial accumulator value
-    if (fold && interior) {  // no clamping, 32-bit lane offsets from wave-uniform bases
+    if ((ABL & 8) == 0 && fold && interior) {  // no clamping, 32-bit lane offsets from wave-uniform bases
       const char* rw = rb ? (const char*)(rb + (int64_t)(l0 + wm * WM) * a.ldr + (n0 + wn * WN)) : nullptr;
       const char* yr = (const char*)(yb + (int64_t)(l0 + wm * WM) * a.ldy + (n0 + wn * WN));
       const uint32_t rpb = (uint32_t)a.ldr * 4u, ypb = (uint32_t)a.ldy * 4u;
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv_ws4_kernel(const mi355_conv_
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[mf][nf][r] = rv[r];
         }
-    } else if (fold) {
+    } else if ((ABL & 8) == 0 && fold) {
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv_ws4_kernel(const mi355_conv_
 
     {
       int tap = 0;
-      bf16x8 ah0, al0, ah1, al1;  // two static activation-fragment sets (al*: the lo image, unused for the single-pass precisions)
+      bf16x8 ah0 = b0[0], al0 = b0[1], ah1 = b0[2], al1 = b0[3];  // two static activation-fragment sets (al*: the lo image, unused for the single-pass precisions)
       // group g of a tap: kk = g >> 1 (16-channel half of the chunk), mf = g & 1 (32-row half of the wave's rows)
       auto rdA = [&](bf16x8& h, bf16x8& l, const int g, const int tp) {
         const int kk = g >> 1, mf = g & 1;
@@ -349,8 +354,12 @@ __global__ __launch_bounds__(kThreads, 4) void conv_ws4_kernel(const mi355_conv_
         const int cidx = kk * 2 + hh;
         const int addr = row * 64 + ((cidx ^ ((row >> 2) & 3)) << 4);
         const char* A_hi = Abase + jbuf * NA * ABYTES;
-        h = *(const bf16x8*)(A_hi + addr);
-        if constexpr (NA == 2) l = *(const bf16x8*)(A_hi + ABYTES + addr);
+        if constexpr ((ABL & 2) != 0) {
+          asm volatile("" : "+v"(h), "+v"(l) : "v"(addr));  // opaque: no LDS read
+        } else {
+          h = *(const bf16x8*)(A_hi + addr);
+          if constexpr (NA == 2) l = *(const bf16x8*)(A_hi + ABYTES + addr);
+        }
       };
       auto mm = [&](const bf16x8& h, const bf16x8& l, const int g, const bf16x8 (&bf)[4]) {
         const int kk = g >> 1, mf = g & 1;
@@ -392,14 +401,20 @@ __global__ __launch_bounds__(kThreads, 4) void conv_ws4_kernel(const mi355_conv_
       for (int s = 0; s < nsteps; s += 2) {
         const char* w1 = wptr(s + 1);
 #pragma unroll
-        for (int f = 0; f < 4; ++f) b1[f] = *(const bf16x8*)(w1 + f * 1024);
+        for (int f = 0; f < 4; ++f) {
+          if constexpr ((ABL & 1) != 0) { b1[f] = b0[f]; asm volatile("" : "+v"(b1[f]) : "v"(w1)); }
+          else b1[f] = *(const bf16x8*)(w1 + f * 1024);
+        }
         asm volatile("" ::: "memory");  // keep the prefetch AHEAD of the MFMAs
         __builtin_amdgcn_sched_barrier(0);
         tap_body(b0, s == 0);
         if (s + 1 >= nsteps) break;
         const char* w0 = wptr(s + 2);
 #pragma unroll
-        for (int f = 0; f < 4; ++f) b0[f] = *(const bf16x8*)(w0 + f * 1024);
+        for (int f = 0; f < 4; ++f) {
+          if constexpr ((ABL & 1) != 0) { b0[f] = b1[f]; asm volatile("" : "+v"(b0[f]) : "v"(w0)); }
+          else b0[f] = *(const bf16x8*)(w0 + f * 1024);
+        }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         tap_body(b1, false);
@@ -409,6 +424,17 @@ __global__ __launch_bounds__(kThreads, 4) void conv_ws4_kernel(const mi355_conv_
       if (dbg && lane == 0 && ntile < 8) dbg[4 * ntile + 2] = __builtin_amdgcn_s_memtime();  // main loop done
     }
 
+    if constexpr ((ABL & 8) != 0) {
+      float tsum = 0.f;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tsum += acc[mf][nf][r];
+      if (tsum == 1.2345e-30f) yb[0] = tsum;  // keeps the MFMAs alive without an epilogue
+      continue;
+    }
     const bool plain = a.up_s == 0 && a.post_act == MI355_ACT_NONE && (fold || (!a.res && !a.accumulate)) && !(EXT && a.post_colscale);
     if (plain && interior) conv_epilogue_interior<MF, NF, WM, WN>(a, acc, b, l0, n0, wm, wn, lane);
     else conv_epilogue<MF, NF, WM, WN, EXT>(a, acc, b, l0, n0, wm, wn, lane, len_out, fold != 0);
@@ -422,7 +448,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv_ws4_kernel(const mi355_conv_
 // GEMM mode: pure linear layers (K == 1, no prologue) with at least two 32-channel chunks
 bool gemm_mode(const mi355_conv_gemm_args& a) { return a.K == 1 && a.Cin >= 64 && a.pre_act == MI355_ACT_NONE && !a.pre_scale; }
 
-template <int PREC, int PRE, bool EXT, bool GEMM, bool DBG = false>
+template <int PREC, int PRE, bool EXT, bool GEMM, bool DBG = false, int ABL = 0>
 int launch_ws4(const mi355_conv_gemm_args& a, hipStream_t st, const int feat) {
   ws4_geom q;
   q.gemm = GEMM ? 1 : 0;
@@ -462,7 +488,7 @@ int launch_ws4(const mi355_conv_gemm_args& a, hipStream_t st, const int feat) {
   const int resident = ((cus * wg_per_cu) / 8) * 8;
   const unsigned grid = (unsigned)((feat & 8) || q.total_ids <= resident ? q.total_ids : resident);  // feat bit 3: one workgroup per tile (A/B aid)
   MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL((conv_ws4_kernel<PREC, PRE, EXT, GEMM, DBG>), dim3(grid), dim3(kThreads), lds, st, a, q);
+  hipLaunchKernelGGL((conv_ws4_kernel<PREC, PRE, EXT, GEMM, DBG, ABL>), dim3(grid), dim3(kThreads), lds, st, a, q);
   MI355_LAUNCH_CHECK("conv_gemm(ws4)");
   return MI355_OK;
 }
@@ -508,6 +534,20 @@ int mi355_conv_ws4_launch(const mi355_conv_gemm_args& a, hipStream_t st, int fea
   const int pre = pre_kind(a);
   const bool ext = ext_epilogue(a), gemm = gemm_mode(a);
   if ((feat & 4) && a.precision == 2 && pre == P_SNAKE && !ext && !gemm) return launch_ws4<2, P_SNAKE, false, false, true>(a, st, feat);
+  if (const int abl = feat >> 4) {  // timing ablations (wrong results by design)
+    MI355_REQUIRE(a.precision == 2 && pre == P_SNAKE && !ext && !gemm, "conv_gemm(ws4): ablation tiles exist for the precision-2 Snake kernel only");
+    switch (abl) {
+      case 1: return launch_ws4<2, P_SNAKE, false, false, false, 1>(a, st, feat & 15);
+      case 2: return launch_ws4<2, P_SNAKE, false, false, false, 2>(a, st, feat & 15);
+      case 3: return launch_ws4<2, P_SNAKE, false, false, false, 3>(a, st, feat & 15);
+      case 4: return launch_ws4<2, P_SNAKE, false, false, false, 4>(a, st, feat & 15);
+      case 8: return launch_ws4<2, P_SNAKE, false, false, false, 8>(a, st, feat & 15);
+      case 7: return launch_ws4<2, P_SNAKE, false, false, false, 7>(a, st, feat & 15);
+      case 15: return launch_ws4<2, P_SNAKE, false, false, false, 15>(a, st, feat & 15);
+    }
+    mi355_set_error("conv_gemm(ws4): unknown ablation %d", abl);
+    return MI355_ERR_UNSUPPORTED;
+  }
   // Kokoro (bf16 checkpoints): AdaIN resblocks (Snake), AdainResBlk1d / upsamplers (LeakyReLU), plain linears (+ GELU: PL-BERT FFN)
   WS4_CASE(2, P_NONE, false);
   WS4_CASE(2, P_LEAKY, false);

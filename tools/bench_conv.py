@@ -48,9 +48,11 @@ def main():
     shapes.append((512, 2560, 2, 1, 529, "plain"))
     variants = [("ws3", 7128128), ("ws4_1tile", 86128128), ("ws4", 6128128), ("ws4_prio", 16128128)]
     if args.ablate:
-        shapes = [(128, 128, 11, 1, 31681, "snake+res"), (128, 128, 3, 1, 31681, "snake+res"), (256, 256, 7, 1, 5280, "snake+res")]
-        variants = [("ws_regB", 7128128), ("abl1_noBload", 17128128), ("abl2_noAread", 27128128), ("abl3_noAB", 37128128),
-                    ("abl4_noProducer", 47128128), ("abl8_noEpilogue", 87128128), ("abl7_noABP", 77128128), ("abl15_mfmaOnly", 157128128)]
+        shapes = [(128, 128, 11, 1, 31681, "snake+res"), (128, 128, 11, 5, 31681, "snake"), (128, 128, 3, 1, 31681, "snake+res"), (256, 256, 7, 1, 5280, "snake+res")]
+        W = 6128128
+        variants = [("ws4", W), ("abl1_noBload", 100000000 + W), ("abl2_noAread", 200000000 + W), ("abl3_noAB", 300000000 + W),
+                    ("abl4_noProducer", 400000000 + W), ("abl8_noFoldEpilogue", 800000000 + W), ("abl7_noABP", 700000000 + W),
+                    ("abl15_mfmaOnly", 1500000000 + W)]
     if args.small:
         shapes = [(768, 2304, 1, 1, 80, "plain"), (768, 768, 1, 1, 80, "plain"), (768, 2048, 1, 1, 80, "plain"), (2048, 768, 1, 1, 80, "plain"),
                   (640, 2048, 1, 1, 264, "plain"), (1090, 1024, 3, 1, 264, "leaky"), (1024, 1024, 3, 1, 264, "leaky"), (512, 512, 3, 1, 528, "leaky"),

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-SLOTS = 32
+SLOTS = 34
 
 
 def main():
@@ -56,13 +56,17 @@ def main():
                 ms_plain = e0.elapsed_time(e1)
             ms = e0.elapsed_time(e1)
         _lib.check(lib.mi355_conv_ws4_debug_buffer(ctypes.c_void_p(0)), "debug_buffer")
-        t = buf.cpu().numpy().astype(np.int64).reshape(nrec, 8, 4)  # [workgroup, tile, (start, window staged, main loop done, stores issued)]
+        raw = buf.cpu().numpy().astype(np.int64)
+        wc = raw[:, 32:34]
+        t = raw[:, :32].reshape(nrec, 8, 4)
+        okc = (wc[:, 1] > wc[:, 0]) & (t[:, 7, 0] > 0)
+        ghz = float(np.median((t[okc, 7, 0] - t[okc, 0, 0]) / ((wc[okc, 1] - wc[okc, 0]) * 10.0))) if okc.any() else float("nan")  # [workgroup, tile, (start, window staged, main loop done, stores issued)]
         t = t[t[:, 0, 0] > 0]
         nch = (cin + 31) // 32
         mfma_cyc = k * 16 * 32 * nch
         med = lambda v: float(np.median(v))
         lines.append(f"## cin={cin} cout={cout} k={k} dil={dil} rows={B * L} res={int(res_on)}: kernel {ms_plain * 1e3:.1f} us (probe build {ms * 1e3:.1f} us), grid {grid}, "
-                     f"{len(t)} probed workgroups; one consumer wave issues {mfma_cyc} MFMA pipe cycles per tile (2 waves share a SIMD: {2 * mfma_cyc})")
+                     f"{len(t)} probed workgroups, shader clock {ghz:.2f} GHz (s_memtime ticks per wall_clock64 tick); one consumer wave issues {mfma_cyc} MFMA pipe cycles per tile (2 waves share a SIMD: {2 * mfma_cyc})")
         lines.append("tile#  wait-for-window  main-loop  epilogue  tile-period   [shader cycles, medians over the probed workgroups]")
         for i in range(8):
             ok = t[:, i, 3] > 0
