@@ -51,9 +51,11 @@ __device__ __forceinline__ void lds_barrier() {
 // All loads of one 32x32 fragment are issued back to back on clamped addresses and only the stores are predicated:
 // a per-element "if (valid) v += res[...]" makes hipcc branch around every load and wait vmcnt(0) each time
 // (64 dependent round trips per wave).  `folded`: res / y_old were already added into the accumulators.
-// EXT: the extended epilogue set (SiLU / GELU-tanh / ELU / tanh, per-column scale).  The wave-specialised kernels live at the 128-VGPR
-// limit of two workgroups per CU; their default instantiation leaves the extensions out (they cost spills there).
-template <int MF, int NF, int WM, int WN, bool EXT>
+// EPI: which epilogue activation this instantiation carries: -1 = all of them behind runtime branches (the 4-wave kernels), 0 = none /
+// LeakyReLU, 1 = GELU (erf), 2 = SiLU, 3 = GELU-tanh.  The wave-specialised kernel is instantiated per activation: every activation body is
+// inlined once per accumulator element (~14 KB of code each), and the instantiation that carried all of them was 2x the code of the plain one
+// and did not fit the instruction cache (profiles/r1_static_code_size_conv_gemm.txt; now profiles/r2_static_code_size_conv.txt).
+template <int MF, int NF, int WM, int WN, int EPI>
 __device__ __forceinline__ void conv_epilogue(const mi355_conv_gemm_args& a, f32x16 (&acc)[MF][NF], const int b, const int l0,
                                               const int n0, const int wm, const int wn, const int lane, const int len_out,
                                               const bool folded) {
@@ -78,8 +80,7 @@ __device__ __forceinline__ void conv_epilogue(const mi355_conv_gemm_args& a, f32
       int ocol = ncl, rph = 0;
       if (a.up_s) { rph = ncl / a.up_cout; ocol = ncl - rph * a.up_cout; }
       const float bias = a.bias ? a.bias[ocol] : 0.f;
-      float cscale = 1.f;
-      if constexpr (EXT) cscale = a.post_colscale ? a.post_colscale[ocol] : 1.f;
+      const float cscale = a.post_colscale ? a.post_colscale[ocol] : 1.f;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {  // 8 accumulator rows at a time keeps the live set small
         int orows[8];
@@ -115,17 +116,25 @@ __device__ __forceinline__ void conv_epilogue(const mi355_conv_gemm_args& a, f32
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           float v = acc[mf][nf][h * 8 + q] + bias;
-          if (a.post_act == MI355_ACT_LEAKY) v = v > 0.f ? v : v * a.post_slope;
-          else if (a.post_act == MI355_ACT_GELU) v = gelu_erf(v);
-          if constexpr (EXT) {
+          if constexpr (EPI == -1 || EPI == 0) {
+            if (a.post_act == MI355_ACT_LEAKY) v = v > 0.f ? v : v * a.post_slope;
+          }
+          if constexpr (EPI == -1) {
+            if (a.post_act == MI355_ACT_GELU) v = gelu_erf(v);
+          } else if constexpr (EPI == 1) {
+            v = gelu_erf(v);
+          }
+          if constexpr (EPI == -1) {
             if (a.post_act == MI355_ACT_SILU) v = v / (1.0f + expf(-v));
             else if (a.post_act == MI355_ACT_GELU_TANH) v = gelu_tanh(v);
             else if (a.post_act == MI355_ACT_ELU) v = v > 0.f ? v : expm1f(v);
             else if (a.post_act == MI355_ACT_TANH) v = tanhf(v);
-            v = (v * cscale + rv[q]) * a.out_scale;
-          } else {
-            v = (v + rv[q]) * a.out_scale;
+          } else if constexpr (EPI == 2) {
+            v = v / (1.0f + expf(-v));
+          } else if constexpr (EPI == 3) {
+            v = gelu_tanh(v);
           }
+          v = (v * cscale + rv[q]) * a.out_scale;
           if (ok[q]) yb[(int64_t)orows[q] * a.ldy + ocol] = v;
           if (want_stats && ok[q]) {
             sK[nf] = scnt[nf] == 0 ? v : sK[nf];
@@ -226,8 +235,9 @@ __device__ __forceinline__ void conv_epilogue_interior(const mi355_conv_gemm_arg
 
 }  // namespace mi355conv
 
-// conv_ws4.hip: wave-specialised kernel (tile code 6128128 [+ 10000000 * feature bits for A/B runs]).  `feat` bit 0: consumers run at
-// s_setprio 1; bit 1: the producers keep two activation windows in flight.  Returns MI355_ERR_UNSUPPORTED (and sets the error text) for
-// argument combinations it has no instantiation for; `min_tiles_ok` tells the auto dispatcher whether the launch would fill the chip.
+// conv_ws4.hip: wave-specialised kernel (tile code 6128128 [+ 10000000 * feature bits for A/B runs]).  `feat` bit 0: consumers at default
+// priority (A/B aid; they run at s_setprio 1 otherwise), bit 2: timeline probe build, bit 3: one workgroup per tile instead of persistent
+// workgroups, bits 4..: timing ablations.  Returns MI355_ERR_UNSUPPORTED (and sets the error text) for argument combinations it has no
+// instantiation for.
 int mi355_conv_ws4_launch(const mi355_conv_gemm_args& a, hipStream_t st, int feat);
 bool mi355_conv_ws4_eligible(const mi355_conv_gemm_args& a, bool vec);

@@ -1,0 +1,529 @@
+// conv_ws4: the wave-specialised implicit-GEMM conv1d / linear / polyphase conv_transpose kernel (gfx950 only).
+//
+// 512 threads = 8 waves per workgroup, one 128 x 128 output tile, two workgroups per CU (<= 128 VGPRs, <= 64 KB LDS):
+//   waves 4-7  PRODUCERS  stream the fp32 activation window of one 32-channel chunk HBM -> registers (float4 per lane, up to two windows in
+//              flight), apply the fused prologue once per input element (AdaIN affine, Snake / SnakeBeta / LeakyReLU / ELU), split the value
+//              into hi + lo images of the weights' 16-bit type and write them to LDS (64-B rows, 16-B pieces XOR-swizzled by (row >> 2) & 3:
+//              the 32x32x16 fragment ds_read_b128 is conflict free for every tap shift);
+//   waves 0-3  CONSUMERS  2 x 2 over the tile (64 x 64 each = four 32x32 accumulators).  Weight fragments come straight from L2 into registers
+//              (1 KB contiguous per fragment in the packed image, one tap ahead, two static register sets); activation fragments are read
+//              from LDS ONE GROUP OF FOUR MFMAs AHEAD (two static register sets), so the matrix pipe never waits for an LDS round trip.
+//              One s_barrier per chunk.
+// The epilogue is the row-per-register one shared with the 4-wave kernels (conv_common.h): a half wave stores 128 contiguous bytes of one
+// output row per instruction.  (Measured, profiles/r2_conv_ab_call1_*.txt: the transposed MFMA orientation -- a lane owning one row and four
+// consecutive channels, 16-B loads / stores at a 512-B row pitch -- needs 4x fewer memory instructions but touches 32 cache lines per
+// instruction instead of 2; the residual fold got 7-11 % slower and WRITE_SIZE grew 15 % from partially written lines.)
+//
+// GEMM mode (K == 1, the nn.Linear layers: PL-BERT, LSTM x-projections, 1x1 shortcuts): a "chunk" is 64 channels staged as two 128-row
+// blocks of the window and the "taps" walk the blocks, so there are 32 MFMAs per wave between barriers instead of 16.
+//
+// Reference call sites replaced: see include/mi355audio.h (mi355_conv_gemm).
+#pragma once
+#include "conv_common.h"
+
+namespace mi355conv {
+
+constexpr int kWs4Threads = 512;
+
+enum { P_NONE = 0, P_LEAKY = 1, P_SNAKE = 2, P_SNAKEBETA = 3, P_ELU = 4 };
+
+struct ws4_geom {
+  int tiles_per_item, P, NT, glog, fold;
+  int nch;        // chunks per tile (GEMM mode: 64-channel super-chunks)
+  int keff;       // taps per chunk (GEMM mode: 2 sub-chunks)
+  int tap_rows;   // LDS row shift per tap (conv: dilation; GEMM mode: 128)
+  int R;          // window rows (conv: 128 + (K-1)*dil; GEMM mode: 256)
+  int gemm;
+  int nslices;    // weight slices of the packed image = ceil(Cin / 32) * K
+  int feat;       // bit 0: consumers at default priority (A/B aid)
+  int total_ids;  // virtual workgroup ids (tile slots incl. the XCD-run padding); a workgroup walks ids blockIdx.x + i * gridDim.x
+  unsigned long long* dbg;  // timeline probe buffer (DBG instantiation only)
+};
+
+// timeline probe (DBG instantiation only): s_memtime stamps of consumer wave 0 of every 16th workgroup, 4 per tile for its first 8 tiles
+constexpr int kDbgSlots = 34;
+
+struct tile_t { int b, l0, n0, len_out, len_in; };
+
+// Virtual workgroup ids go round-robin over the 8 XCDs (id & 7 = XCD, each with its own L2; gridDim.x is a multiple of 8, so a workgroup's ids all
+// map to its own XCD).  An XCD owns runs of 2^glog CONSECUTIVE row tiles (all NT column tiles of a row tile back to back on it): neighbouring
+// tiles share their halo rows through that L2 and the column tiles re-read the same activation window from it.
+__device__ __forceinline__ bool decode_tile(const mi355_conv_gemm_args& a, const ws4_geom& q, const int id, tile_t& t) {
+  const int kq = id >> 3;
+  const int ny = kq % q.NT;
+  const int pg = kq / q.NT;
+  const int glog = q.glog;
+  const int p = (((((pg >> glog) << 3) + (id & 7)) << glog)) | (pg & ((1 << glog) - 1));
+  if (p >= q.P) return false;
+  t.b = p / q.tiles_per_item;
+  t.l0 = (p - t.b * q.tiles_per_item) * 128;
+  t.n0 = ny * 128;
+  t.len_out = a.lens_out ? a.lens_out[t.b] : a.Lout;
+  if (t.l0 >= t.len_out) return false;
+  t.len_in = a.lens_in ? a.lens_in[t.b] : a.Lin;
+  return true;
+}
+// the next id of this workgroup (after `id`) that has work, or -1
+__device__ __forceinline__ int next_work(const mi355_conv_gemm_args& a, const ws4_geom& q, int id, tile_t& t) {
+  for (id += (int)gridDim.x; id < q.total_ids; id += (int)gridDim.x)
+    if (decode_tile(a, q, id, t)) return id;
+  return -1;
+}
+
+// ABL (ablation bits, timing experiments only -- results are WRONG when non-zero; reachable only through the explicit tile codes
+// ABL * 100000000 + 6128128 of tools/bench_conv.py --ablate): 1 = no weight-fragment loads after the first, 2 = no activation-fragment LDS
+// reads, 4 = the producers only take part in the barriers, 8 = no residual fold and no epilogue.
+template <int PREC, int PRE, int EPI, bool GEMM, bool DBG = false, int ABL = 0>
+__global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_conv_gemm_args a, const ws4_geom q) {
+  constexpr int BM = 128, BN = 128;
+  constexpr int NLD = GEMM ? 8 : 6;  // window passes of 32 rows per chunk (conv: R <= 192; GEMM mode: R = 256)
+  constexpr int NA = a_images<PREC>();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane_k = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int R = q.R;
+  const int ABYTES = R * 64;
+  char* Abase = smem;  // [2 buffers][NA (hi, lo)][R * 64]
+  const int nch = q.nch, keff = q.keff;
+  // PERSISTENT: the workgroup walks its tiles; the (tile, chunk) items form one stream.  Item j is staged in LDS buffer j & 1; one s_barrier per
+  // item: the producers arrive when item j is converted, the consumers when they are done with item j - 1 (and with the previous tile's epilogue
+  // and the next tile's fold loads), so the window of a tile's first chunk is already waiting when its MFMAs may start.
+  tile_t t0;
+  int id0 = (int)blockIdx.x - (int)gridDim.x;
+  id0 = next_work(a, q, id0, t0);
+  if (id0 < 0) return;
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------------------ producers
+    const int ptid = tid - 256;
+    const int c4 = (ptid & 7) * 4;
+    const int prow = ptid >> 3;
+    const float* xbase = a.x + a.x_off;
+    const int wrow0 = (wave - 4) * 8;  // pass i of this wave covers window rows [wrow0 + 32 i, +8): passes entirely past R are skipped
+    constexpr int cstride = GEMM ? 64 : 32;
+    float4 s0[NLD], s1[NLD];  // two windows in flight: s0 carries the even items, s1 the odd ones
+    struct item_t { int id, ci, b, l0, len_in; };
+    auto advance = [&](item_t& it) {  // next (tile, chunk) item of this workgroup; id = -1 past the end
+      if (it.ci + 1 < nch) { ++it.ci; return; }
+      tile_t t;
+      it.id = next_work(a, q, it.id, t);
+      it.ci = 0; it.b = t.b; it.l0 = t.l0; it.len_in = t.len_in;
+    };
+
+    // window row r = prow + 32 i of a chunk: conv mode = input row l0 - pad + r, channels [32 chunk, +32);
+    // GEMM mode = input row l0 + (r & 127), channels [64 chunk + 32 (r >> 7), +32)
+    auto loadA = [&](float4 (&areg)[NLD], const item_t& it) {
+      const int chunk = it.ci, l0 = it.l0;
+      const float* xb = xbase + (int64_t)it.b * a.x_bstride;
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        if (GEMM || wrow0 + i * 32 < R) {
+          int gl = GEMM ? l0 + prow + 32 * (i & 3) : l0 - a.pad + prow + 32 * i;
+          int c = chunk * cstride + (GEMM ? 32 * (i >> 2) : 0) + c4;
+          gl = gl < 0 ? 0 : (gl >= a.Lin ? a.Lin - 1 : gl);
+          if (c >= a.Cin) c = 0;
+          areg[i] = *(const float4*)(xb + (int64_t)gl * a.ldx + c);
+        }
+      }
+    };
+    auto convertA = [&](const float4 (&areg)[NLD], const item_t& it, char* A_hi) {
+      const int chunk = it.ci, l0 = it.l0, b = it.b, len_in = it.len_in;
+      char* A_lo = A_hi + ABYTES;
+      const int c = chunk * cstride + c4;  // GEMM mode (no prologue coefficients): passes 4..7 carry channels c + 32
+      float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f}, al[4] = {1.f, 1.f, 1.f, 1.f}, ial[4] = {1.f, 1.f, 1.f, 1.f};
+      if constexpr (!GEMM) {
+        if (a.pre_scale) {
+          const float4 s4 = *(const float4*)(a.pre_scale + (int64_t)b * a.pre_ld + c);
+          const float4 h4 = *(const float4*)(a.pre_shift + (int64_t)b * a.pre_ld + c);
+          sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
+          sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
+        }
+      }
+      if constexpr (PRE == P_SNAKE || PRE == P_SNAKEBETA) {
+        const float4 a4 = *(const float4*)(a.pre_alpha + c);
+        al[0] = a4.x; al[1] = a4.y; al[2] = a4.z; al[3] = a4.w;
+        if constexpr (PRE == P_SNAKEBETA) {  // x + sin^2(alpha x) * inv_beta[c]
+          const float4 b4 = *(const float4*)(a.pre_inv_beta + c);
+          ial[0] = b4.x; ial[1] = b4.y; ial[2] = b4.z; ial[3] = b4.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (PRE == P_SNAKE) {  // 1 / alpha: v_rcp_f32 + one Newton step (<= 1 ulp)
+            const float r0 = __builtin_amdgcn_rcpf(al[j]);
+            ial[j] = fmaf(fmaf(-al[j], r0, 1.0f), r0, r0);
+          }
+          al[j] *= 0.15915494309189535f;  // v_sin_f32 takes revolutions
+        }
+      }
+      const float slope = a.pre_slope;
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        if (GEMM || wrow0 + i * 32 < R) {
+          const int r = prow + i * 32;
+          if (GEMM || r < R) {
+            const int gl = GEMM ? l0 + prow + 32 * (i & 3) : l0 - a.pad + r;
+            const bool rowok = gl >= 0 && gl < len_in;
+            const int cb = c + (GEMM ? 32 * (i >> 2) : 0);
+            const float v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
+            float tt[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float u = v[j];
+              if constexpr (!GEMM) u = u * sc[j] + sh[j];
+              if constexpr (PRE == P_LEAKY) {
+                const float m = u * slope;
+                u = u > 0.f ? u : m;
+              } else if constexpr (PRE == P_SNAKE || PRE == P_SNAKEBETA) {
+                const float sn = __builtin_amdgcn_sinf(al[j] * u);
+                u = u + ial[j] * (sn * sn);
+              } else if constexpr (PRE == P_ELU) {
+                u = u > 0.f ? u : expm1f(u);
+              }
+              tt[j] = (rowok && (cb + j) < a.Cin) ? u : 0.f;
+            }
+            const int addr = r * 64 + ((((c4 >> 3) ^ ((r >> 2) & 3))) << 4) + ((c4 & 4) << 1);
+            uint2 ph;
+            float hi[4];
+            if constexpr (PREC >= 3) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) hi[j] = split_hi<PREC>(tt[j]);
+              ph.x = pack_f16x2(hi[0], hi[1]);
+              ph.y = pack_f16x2(hi[2], hi[3]);
+            } else {  // one v_cvt_pk_bf16_f32 per pair; the fp32 value of each half is a shift / mask of the packed word
+              ph.x = pack_bf16x2(tt[0], tt[1]);
+              ph.y = pack_bf16x2(tt[2], tt[3]);
+              hi[0] = __builtin_bit_cast(float, ph.x << 16);
+              hi[1] = __builtin_bit_cast(float, ph.x & 0xffff0000u);
+              hi[2] = __builtin_bit_cast(float, ph.y << 16);
+              hi[3] = __builtin_bit_cast(float, ph.y & 0xffff0000u);
+            }
+            *(uint2*)(A_hi + addr) = ph;
+            if constexpr (NA == 2) {
+              uint2 pl;
+              pl.x = pack_lo<PREC>(tt[0] - hi[0], tt[1] - hi[1]);
+              pl.y = pack_lo<PREC>(tt[2] - hi[2], tt[3] - hi[3]);
+              *(uint2*)(A_lo + addr) = pl;
+            }
+          }
+        }
+      }
+    };
+
+    // chunk ci is converted into buffer ci & 1 while the consumers work on chunk ci - 1 (they left that buffer at the barrier that ended
+    // chunk ci - 2); the loads of chunk ci + 2 are issued right behind the conversion, i.e. two windows are always in flight
+
+    item_t ia{id0, 0, t0.b, t0.l0, t0.len_in};
+    item_t ib = ia;
+    advance(ib);
+    constexpr bool work = (ABL & 4) == 0;
+    if (work) loadA(s0, ia);
+    if (work && ib.id >= 0) loadA(s1, ib);
+    while (true) {
+      if (work) convertA(s0, ia, Abase);
+      item_t na = ib;
+      if (na.id >= 0) advance(na);
+      if (work && na.id >= 0) loadA(s0, na);
+      lds_barrier();  // even item staged
+      if (ib.id < 0) break;
+      if (work) convertA(s1, ib, Abase + NA * ABYTES);
+      item_t nb = na;
+      if (nb.id >= 0) advance(nb);
+      if (work && nb.id >= 0) loadA(s1, nb);
+      lds_barrier();  // odd item staged
+      if (na.id < 0) break;
+      ia = na;
+      ib = nb;
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------------------- consumers
+  constexpr int WM = 64, WN = 64, MF = 2, NF = 2;
+  const int wm = wave >> 1, wn = wave & 1;
+  if (!(q.feat & 1)) __builtin_amdgcn_s_setprio(1);  // MFMA issuers outrank the producers' VALU work (measured +1..8 %)
+  const int NTp = ((a.Cout + 127) >> 7) << 2;
+  const int64_t wstep = (int64_t)NTp * 2048;
+  const int nsteps = nch * keff;
+  const int last_slice = q.nslices - 1;
+  const int fold = q.fold;
+  unsigned long long* dbg = nullptr;
+  if constexpr (DBG) {
+    if (wave == 0 && (blockIdx.x & 15) == 0 && q.dbg) dbg = q.dbg + (size_t)(blockIdx.x >> 4) * kDbgSlots;
+  }
+  int jbuf = 0;   // parity of the item stream = LDS buffer of the current chunk
+  int ntile = 0;
+  tile_t t = t0;
+  for (int id = id0; id >= 0; id = next_work(a, q, id, t), ++ntile) {
+    const int b = t.b, l0 = t.l0, n0 = t.n0, len_out = t.len_out;
+    // an opaque per-tile copy of the lane id: without it LICM hoists the ~200 lane-constant 64-bit fold / store offsets out of the tile loop and
+    // parks them in scratch (a persistent kernel's classic: recompute per tile instead, it is a handful of VALU ops)
+    int lane = lane_k;
+    asm volatile("" : "+v"(lane));
+    const int hl = lane & 31, hh = lane >> 5;
+    if constexpr (DBG) {
+      if (dbg && lane == 0 && ntile < 8) dbg[4 * ntile] = __builtin_amdgcn_s_memtime();  // tile start
+      if (dbg && lane == 0 && (ntile == 0 || ntile == 7)) dbg[32 + (ntile == 7)] = wall_clock64();  // 100 MHz constant-rate counter: gives the shader clock
+    }
+    // fragment (nf, kk) of weight slice s: 1 KB at wfrag + s * wstep + (nf * 2 + kk) * 1024
+    const char* wfrag = (const char*)a.w + ((int64_t)((n0 >> 5) + wn * NF)) * 2048 + lane * 16;
+    auto wptr = [&](const int s) { return wfrag + (int64_t)(s < last_slice ? s : last_slice) * wstep; };
+    bf16x8 b0[4], b1[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) b0[f] = *(const bf16x8*)(wfrag + f * 1024);
+
+    f32x16 acc[MF][NF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+
+    float* yb = a.y + (int64_t)b * a.y_bstride;
+    const float* rb = a.res ? a.res + (int64_t)b * a.res_bstride : nullptr;
+    const bool interior = l0 + BM <= len_out && n0 + BN <= a.Cout;
+    // residual and running sum go in as the initial accumulator value
+    if ((ABL & 8) == 0 && fold && interior) {  // no clamping, 32-bit lane offsets from wave-uniform bases
+      const char* rw = rb ? (const char*)(rb + (int64_t)(l0 + wm * WM) * a.ldr + (n0 + wn * WN)) : nullptr;
+      const char* yr = (const char*)(yb + (int64_t)(l0 + wm * WM) * a.ldy + (n0 + wn * WN));
+      const uint32_t rpb = (uint32_t)a.ldr * 4u, ypb = (uint32_t)a.ldy * 4u;
+      const uint32_t roff = (uint32_t)(4 * hh) * rpb + (uint32_t)hl * 4u;
+      const uint32_t yoff = (uint32_t)(4 * hh) * ypb + (uint32_t)hl * 4u;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          float rv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+          if (rw) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = *(const float*)(rw + (roff + (uint32_t)(mf * 32 + (r & 3) + 8 * (r >> 2)) * rpb + (uint32_t)(nf * 128)));
+          }
+          if (a.accumulate) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] += *(const float*)(yr + (yoff + (uint32_t)(mf * 32 + (r & 3) + 8 * (r >> 2)) * ypb + (uint32_t)(nf * 128)));
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mf][nf][r] = rv[r];
+        }
+    } else if ((ABL & 8) == 0 && fold) {
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          const int n = n0 + wn * WN + nf * 32 + hl;
+          const bool nok = n < a.Cout;
+          const int ncl = nok ? n : a.Cout - 1;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float rv[8];
+            int us[8];
+#pragma unroll
+            for (int qq = 0; qq < 8; ++qq) {
+              const int r = h * 8 + qq;
+              us[qq] = l0 + wm * WM + mf * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+              rv[qq] = 0.f;
+            }
+            if (rb) {
+#pragma unroll
+              for (int qq = 0; qq < 8; ++qq) rv[qq] = rb[(int64_t)(us[qq] < len_out ? us[qq] : len_out - 1) * a.ldr + ncl];
+            }
+            if (a.accumulate) {
+              float yv[8];
+#pragma unroll
+              for (int qq = 0; qq < 8; ++qq) yv[qq] = yb[(int64_t)(us[qq] < len_out ? us[qq] : len_out - 1) * a.ldy + ncl];
+#pragma unroll
+              for (int qq = 0; qq < 8; ++qq) rv[qq] += yv[qq];
+            }
+#pragma unroll
+            for (int qq = 0; qq < 8; ++qq) acc[mf][nf][h * 8 + qq] = (nok && us[qq] < len_out) ? rv[qq] : 0.f;
+          }
+        }
+    }
+
+    {
+      int tap = 0;
+      bf16x8 ah0 = b0[0], al0 = b0[1], ah1 = b0[2], al1 = b0[3];  // two static activation-fragment sets (al*: the lo image, unused for the single-pass precisions)
+      // group g of a tap: kk = g >> 1 (16-channel half of the chunk), mf = g & 1 (32-row half of the wave's rows)
+      auto rdA = [&](bf16x8& h, bf16x8& l, const int g, const int tp) {
+        const int kk = g >> 1, mf = g & 1;
+        const int row = wm * WM + mf * 32 + hl + tp * q.tap_rows;
+        const int cidx = kk * 2 + hh;
+        const int addr = row * 64 + ((cidx ^ ((row >> 2) & 3)) << 4);
+        const char* A_hi = Abase + jbuf * NA * ABYTES;
+        if constexpr ((ABL & 2) != 0) {
+          asm volatile("" : "+v"(h), "+v"(l) : "v"(addr));  // opaque: no LDS read
+        } else {
+          h = *(const bf16x8*)(A_hi + addr);
+          if constexpr (NA == 2) l = *(const bf16x8*)(A_hi + ABYTES + addr);
+        }
+      };
+      auto mm = [&](const bf16x8& h, const bf16x8& l, const int g, const bf16x8 (&bf)[4]) {
+        const int kk = g >> 1, mf = g & 1;
+        acc[mf][0] = mfma16<PREC>(h, bf[kk], acc[mf][0]);
+        acc[mf][1] = mfma16<PREC>(h, bf[2 + kk], acc[mf][1]);
+        if constexpr (NA == 2) {
+          acc[mf][0] = mfma16<PREC>(l, bf[kk], acc[mf][0]);
+          acc[mf][1] = mfma16<PREC>(l, bf[2 + kk], acc[mf][1]);
+        }
+      };
+      // one tap = four groups; the fragments of group g+1 are requested before the MFMAs of group g are issued
+      auto tap_body = [&](const bf16x8 (&bf)[4], const bool first) {
+        if (tap == 0) {  // new chunk: its window is staged behind this barrier (and the producers may refill the buffer just left)
+          lds_barrier();
+          if constexpr (DBG) {
+            if (first && dbg && lane == 0 && ntile < 8) dbg[4 * ntile + 1] = __builtin_amdgcn_s_memtime();  // first window staged
+          }
+          rdA(ah0, al0, 0, 0);
+        }
+        rdA(ah1, al1, 1, tap);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(ah0, al0, 0, bf);
+        rdA(ah0, al0, 2, tap);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(ah1, al1, 1, bf);
+        rdA(ah1, al1, 3, tap);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(ah0, al0, 2, bf);
+        if (tap + 1 < keff) rdA(ah0, al0, 0, tap + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(ah1, al1, 3, bf);
+        if (++tap == keff) {  // end of chunk
+          tap = 0;
+          jbuf ^= 1;
+        }
+      };
+      // The weight prefetch is unconditional (past the last slice it re-reads the last one): a branch around the loads would make hipcc assume
+      // they may not have been issued and wait for them right away.
+      for (int s = 0; s < nsteps; s += 2) {
+        const char* w1 = wptr(s + 1);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          if constexpr ((ABL & 1) != 0) { b1[f] = b0[f]; asm volatile("" : "+v"(b1[f]) : "v"(w1)); }
+          else b1[f] = *(const bf16x8*)(w1 + f * 1024);
+        }
+        asm volatile("" ::: "memory");  // keep the prefetch AHEAD of the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        tap_body(b0, s == 0);
+        if (s + 1 >= nsteps) break;
+        const char* w0 = wptr(s + 2);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          if constexpr ((ABL & 1) != 0) { b0[f] = b1[f]; asm volatile("" : "+v"(b0[f]) : "v"(w0)); }
+          else b0[f] = *(const bf16x8*)(w0 + f * 1024);
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        tap_body(b1, false);
+      }
+    }
+    if constexpr (DBG) {
+      if (dbg && lane == 0 && ntile < 8) dbg[4 * ntile + 2] = __builtin_amdgcn_s_memtime();  // main loop done
+    }
+
+    if constexpr ((ABL & 8) != 0) {
+      float tsum = 0.f;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tsum += acc[mf][nf][r];
+      if (tsum == 1.2345e-30f) yb[0] = tsum;  // keeps the MFMAs alive without an epilogue
+      continue;
+    }
+    const bool plain = a.up_s == 0 && a.post_act == MI355_ACT_NONE && (fold || (!a.res && !a.accumulate)) && !a.post_colscale;
+    if (plain && interior) conv_epilogue_interior<MF, NF, WM, WN>(a, acc, b, l0, n0, wm, wn, lane);
+    else conv_epilogue<MF, NF, WM, WN, EPI>(a, acc, b, l0, n0, wm, wn, lane, len_out, fold != 0);
+    if constexpr (DBG) {
+      if (dbg && lane == 0 && ntile < 8) dbg[4 * ntile + 3] = __builtin_amdgcn_s_memtime();  // stores issued
+    }
+  }
+  if (!(q.feat & 1)) __builtin_amdgcn_s_setprio(0);
+}
+
+// GEMM mode: pure linear layers (K == 1, no prologue) with at least two 32-channel chunks
+inline bool gemm_mode(const mi355_conv_gemm_args& a) { return a.K == 1 && a.Cin >= 64 && a.pre_act == MI355_ACT_NONE && !a.pre_scale; }
+
+template <int PREC, int PRE, int EPI, bool GEMM, bool DBG = false, int ABL = 0>
+int launch_ws4(const mi355_conv_gemm_args& a, hipStream_t st, const int feat, unsigned long long* dbg = nullptr) {
+  ws4_geom q;
+  q.gemm = GEMM ? 1 : 0;
+  const int chunks32 = (a.Cin + 31) >> 5;
+  q.nslices = chunks32 * a.K;
+  if (q.gemm) {
+    q.nch = (chunks32 + 1) >> 1;
+    q.keff = 2;
+    q.tap_rows = 128;
+    q.R = 256;
+  } else {
+    q.nch = chunks32;
+    q.keff = a.K;
+    q.tap_rows = a.dil;
+    q.R = 128 + (a.K - 1) * a.dil;
+  }
+  MI355_REQUIRE(q.R <= (GEMM ? 256 : 192), "conv_gemm(ws4): window of %d rows exceeds %d (K=%d dil=%d)", q.R, GEMM ? 256 : 192, a.K, a.dil);
+  const size_t lds = (size_t)2 * a_images<PREC>() * q.R * 64;
+  q.tiles_per_item = (a.Lout + 127) / 128;
+  q.P = a.B * q.tiles_per_item;
+  q.NT = (a.Cout + 127) / 128;
+  q.fold = ((a.res || a.accumulate) && a.post_act == MI355_ACT_NONE && a.up_s == 0 && a.res_shift == 0 && !a.post_colscale) ? 1 : 0;
+  // runs of 2^glog consecutive row tiles per XCD: long runs share halos in L2, but every XCD must still get several rounds of runs
+  q.glog = q.P >= 512 ? 3 : (q.P >= 256 ? 2 : (q.P >= 128 ? 1 : 0));
+  q.feat = feat;
+  q.dbg = dbg;
+  const int per = 8 << q.glog;
+  q.total_ids = ((q.P + per - 1) / per) * per * q.NT;
+  // persistent: two resident workgroups per CU (128 VGPRs x 8 waves each) walk the tile list; small problems launch one workgroup per tile
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  static const int wg_per_cu = getenv("MI355_CONV_WS_WG_PER_CU") ? atoi(getenv("MI355_CONV_WS_WG_PER_CU")) : 2;
+  const int resident = ((cus * wg_per_cu) / 8) * 8;
+  const unsigned grid = (unsigned)((feat & 8) || q.total_ids <= resident ? q.total_ids : resident);  // feat bit 3: one workgroup per tile (A/B aid)
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL((conv_ws4_kernel<PREC, PRE, EPI, GEMM, DBG, ABL>), dim3(grid), dim3(kWs4Threads), lds, st, a, q);
+  MI355_LAUNCH_CHECK("conv_gemm(ws4)");
+  return MI355_OK;
+}
+
+// epilogue family of a launch: 0 = none / LeakyReLU, 1 = GELU (erf), 2 = SiLU, 3 = GELU-tanh; -1 = ELU / tanh epilogues (the one-column final
+// convs of DAC / SNAC: never this kernel's shapes, they stay on the 4-wave kernels).  One instantiation per activation: the transcendental
+// bodies are inlined 64 times per wave, and a kernel carrying all of them no longer fits the instruction cache.
+inline int epi_family(const mi355_conv_gemm_args& a) {
+  switch (a.post_act) {
+    case MI355_ACT_NONE:
+    case MI355_ACT_LEAKY: return 0;
+    case MI355_ACT_GELU: return 1;
+    case MI355_ACT_SILU: return 2;
+    case MI355_ACT_GELU_TANH: return 3;
+  }
+  return -1;
+}
+inline int pre_kind(const mi355_conv_gemm_args& a) {
+  switch (a.pre_act) {
+    case MI355_ACT_NONE: return P_NONE;
+    case MI355_ACT_LEAKY: return P_LEAKY;
+    case MI355_ACT_SNAKE: return a.pre_inv_beta ? P_SNAKEBETA : P_SNAKE;
+    case MI355_ACT_ELU: return P_ELU;
+  }
+  return -1;
+}
+
+#define WS4_CASE(PREC, PRE, EPI) \
+  if (pre == PRE && epi == EPI && !gemm) return launch_ws4<PREC, PRE, EPI, false>(a, st, feat)
+#define WS4_GEMM(PREC, EPI) \
+  if (epi == EPI && gemm) return launch_ws4<PREC, P_NONE, EPI, true>(a, st, feat)
+
+}  // namespace mi355conv
+
+// per-precision instantiation sets (one translation unit each: they compile in parallel); MI355_ERR_UNSUPPORTED = no such instantiation
+int mi355_conv_ws4_p2(const mi355_conv_gemm_args& a, hipStream_t st, int feat, unsigned long long* dbg);
+int mi355_conv_ws4_p4(const mi355_conv_gemm_args& a, hipStream_t st, int feat);
+int mi355_conv_ws4_p13(const mi355_conv_gemm_args& a, hipStream_t st, int feat);

@@ -52,20 +52,9 @@ def ref_conv_nlc(x, w, b, dil, pad):
     (514, 200, 3, 1, 33, 2, 64064),
     (768, 50, 1, 1, 80, 1, 0),
     (128, 22, 7, 1, 500, 1, 0),
-    # the previous wave-specialised producer / consumer kernel (tile code 7128128: kept as the A/B baseline): 1, 2 and 3 N-tiles,
-    # K = 1 / 2 / odd, dilation, ragged channel counts, more row tiles than XCDs
-    (128, 128, 7, 3, 300, 2, 7128128),
-    (128, 128, 3, 1, 1500, 3, 7128128),
-    (256, 256, 11, 5, 257, 1, 7128128),
-    (128, 128, 11, 1, 129, 1, 7128128),
-    (96, 200, 2, 1, 131, 2, 7128128),
-    (512, 64, 1, 1, 777, 3, 7128128),
-    (1090, 300, 3, 1, 145, 1, 7128128),
-    (32, 22, 1, 1, 500, 1, 7128128),
-    (64, 128, 5, 16, 260, 1, 7128128),
-    (128, 128, 4, 2, 2100, 2, 7128128),
-    (160, 128, 1, 1, 2100, 1, 7128128),
-    # ws4 (tile code 6128128; +10000000 = consumers at s_setprio 1): conv mode ...
+    # the wave-specialised producer / consumer kernel (tile code 6128128; +10000000 = consumers at default priority, +80000000 = one
+    # workgroup per tile instead of persistent workgroups): conv mode with 1, 2 and 3 N-tiles, K = 1 / 2 / odd, dilation, ragged channel
+    # counts, more row tiles than XCDs ...
     (128, 128, 7, 3, 300, 2, 6128128),
     (128, 128, 3, 1, 1500, 3, 6128128),
     (256, 256, 11, 5, 257, 1, 6128128),
@@ -75,6 +64,9 @@ def ref_conv_nlc(x, w, b, dil, pad):
     (32, 24, 1, 1, 500, 1, 6128128),
     (64, 128, 5, 16, 260, 1, 6128128),
     (128, 128, 4, 2, 2100, 2, 16128128),
+    (128, 128, 7, 3, 300, 2, 86128128),
+    (256, 256, 11, 5, 1200, 3, 86128128),
+    (128, 128, 3, 1, 70000, 1, 6128128),
     # ... and GEMM mode (K = 1: 64-channel super-chunks; odd / ragged chunk counts, one row tile, many row tiles)
     (512, 64, 1, 1, 777, 3, 6128128),
     (160, 128, 1, 1, 2100, 1, 6128128),
@@ -96,9 +88,8 @@ def test_conv_gemm_plain(ops, cin, cout, k, dil, L, B, tile):
     pc16 = ops.pack_conv(w, bias, DEV, f16=True)
     ref = ref_conv_nlc(x[:, :, :cin], w, bias, dil, pad)
     # 2: bf16 hi+lo split (~2^-16), 1: single bf16 pass (~2^-8), 3: single fp16 pass (~2^-11; fp16-packed weights),
-    # 4: fp16 hi+lo split (~2^-22); ws4 carries the two split precisions only
-    ws4 = tile % 10000000 == 6128128
-    for prec, tol, p in (((2, 3e-5, pc), (4, 3e-6, pc16)) if ws4 else ((2, 3e-5, pc), (1, 1.5e-2, pc), (3, 2e-3, pc16))):
+    # 4: fp16 hi+lo split (~2^-22)
+    for prec, tol, p in ((2, 3e-5, pc), (1, 1.5e-2, pc), (3, 2e-3, pc16), (4, 3e-6, pc16)):
         y.fill_(float("nan"))
         ops.conv_gemm(xd[:, :, :cin], p, y[:, :, :cout], dil=dil, pad=pad, precision=prec, tile=tile)
         torch.cuda.synchronize()
@@ -109,7 +100,7 @@ def test_conv_gemm_plain(ops, cin, cout, k, dil, L, B, tile):
 
 @pytest.mark.parametrize("tile,res_shift,act", [(0, 1, "snake"), (6128128, 1, "snake"), (6128128, 0, "snake"), (128128, 0, "leaky"),
                                                  (6128128, 0, "leaky"), (64064, 0, "snake"), (16128128, 0, "snake"),
-                                                 (7128128, 1, "snake"), (7128128, 0, "snake"), (7128128, 0, "leaky")])
+                                                 (86128128, 1, "snake"), (86128128, 0, "snake"), (86128128, 0, "leaky")])
 def test_conv_gemm_fused_prologue_epilogue_ragged(ops, tile, res_shift, act):
     """AdaIN affine + Snake / LeakyReLU in front, bias + residual(row >> res_shift) + scale + accumulate behind, ragged
     batch; res_shift == 0 takes the accumulator-initialisation ("fold") path of the wave-specialised kernel."""
@@ -148,7 +139,7 @@ def test_conv_gemm_fused_prologue_epilogue_ragged(ops, tile, res_shift, act):
 
 @pytest.mark.parametrize("cin,cout,k,s,L,row_off,tile", [(512, 256, 20, 10, 53, 0, 0), (256, 128, 12, 6, 130, 1, 0), (64, 32, 4, 2, 9, 0, 0),
                                                          (512, 256, 20, 10, 153, 0, 6128128), (256, 128, 12, 6, 330, 1, 6128128),
-                                                         (512, 256, 20, 10, 153, 0, 7128128), (256, 128, 12, 6, 330, 1, 7128128)])
+                                                         (512, 256, 20, 10, 153, 0, 86128128), (256, 128, 12, 6, 330, 1, 86128128)])
 def test_conv_transpose_polyphase(ops, cin, cout, k, s, L, row_off, tile):
     g = torch.Generator().manual_seed(k * s)
     p = (k - s) // 2
@@ -203,7 +194,7 @@ def test_conv_flat_strided_small_cin(ops):
     assert rel_err(y1.cpu(), x.double() @ w1[:, 0].double().t()) < 3e-5
 
 
-@pytest.mark.parametrize("tile", [0, 128128, 7128128, 6128128])
+@pytest.mark.parametrize("tile", [0, 128128, 6128128, 86128128])
 def test_conv_gemm_fused_instnorm_statistics(ops, tile):
     """Instance-norm statistics of the conv OUTPUT produced by the epilogue (stats=) + adain_from_partials must equal the
     separate pass (adain_coef) over the stored tensor: ragged batch, residual + scaling in the epilogue, large mean / std."""

@@ -286,7 +286,8 @@ def _ref_conv(x, w, b, dil, pad):
     (80, 768, 3, 1, 300, 1, 0),        # Whisper conv1 (C_in not a multiple of 32)
     (1536, 768, 2, 1, 150, 2, 0),      # Whisper conv2 as the 2-tap pair conv
     (768, 3072, 1, 1, 1500, 1, 0),
-    (128, 128, 7, 1, 1100, 3, 7128128),
+    (128, 128, 7, 1, 1100, 3, 6128128),
+    (768, 3072, 1, 1, 1500, 1, 6128128),
     (96, 51865, 1, 1, 5, 2, 0),        # logits-shaped: huge N, few rows
 ])
 def test_conv_gemm_precision4(ops, cin, cout, k, dil, L, B, tile):
@@ -307,7 +308,10 @@ def test_conv_gemm_precision4(ops, cin, cout, k, dil, L, B, tile):
     assert e3 < 2e-3 and e4 < e3    # single fp16 pass: the reference's own activation rounding
 
 
-def test_conv_gemm_new_activations(ops):
+@pytest.mark.parametrize("tile", [0, 6128128])
+def test_conv_gemm_new_activations(ops, tile):
+    """ELU / SnakeBeta prologues, SiLU / GELU-tanh / ELU / tanh epilogues and the per-column scale, on the 4-wave kernels (auto) and on the
+    per-family instantiations of the wave-specialised kernel (tile code 6128128)."""
     g = torch.Generator().manual_seed(77)
     B, L, cin, cout, k = 2, 333, 96, 160, 7
     w = (torch.randn(cout, k, cin, generator=g) / math.sqrt(cin * k)).to(torch.bfloat16).to(torch.float32)
@@ -323,7 +327,7 @@ def test_conv_gemm_new_activations(ops):
 
     def run(**kw):
         y = torch.empty(B, L, cout, device=DEV)
-        ops.conv_gemm(xd, pc, y, pad=pad, **kw)
+        ops.conv_gemm(xd, pc, y, pad=pad, tile=tile, **kw)
         torch.cuda.synchronize()
         return y.cpu()
 

@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--precision", type=int, default=2)
     ap.add_argument("--quick", action="store_true", help="two shapes, the wave-specialised variants only (for PMC passes)")
-    ap.add_argument("--ablate", action="store_true", help="timing ablations of the 7128128 kernel (their results are wrong by design)")
+    ap.add_argument("--ablate", action="store_true", help="timing ablations of the wave-specialised kernel (their results are wrong by design)")
     ap.add_argument("--small", action="store_true", help="the few-row GEMMs of PL-BERT / predictor (rows = B*80): 4-wave tile shapes A/B")
     ap.add_argument("--flat", action="store_true", help="with --small: hand the batch over as ONE item of B*L rows (ops.conv_gemm(flatten=True))")
     args = ap.parse_args()
@@ -46,21 +46,20 @@ def main():
     shapes.append((256, 256, 11, 5, 5280, "snake"))
     shapes.append((1090, 1024, 3, 1, 264, "leaky"))
     shapes.append((512, 2560, 2, 1, 529, "plain"))
-    variants = [("ws3", 7128128), ("ws4_1tile", 86128128), ("ws4", 6128128), ("ws4_prio", 16128128)]
+    variants = [("old64x128", 64128), ("ws4_1tile", 86128128), ("ws4_noprio", 16128128), ("ws4", 6128128)]
     if args.ablate:
         shapes = [(128, 128, 11, 1, 31681, "snake+res"), (128, 128, 11, 5, 31681, "snake"), (128, 128, 3, 1, 31681, "snake+res"), (256, 256, 7, 1, 5280, "snake+res")]
         W = 6128128
         variants = [("ws4", W), ("abl1_noBload", 100000000 + W), ("abl2_noAread", 200000000 + W), ("abl3_noAB", 300000000 + W),
-                    ("abl4_noProducer", 400000000 + W), ("abl8_noFoldEpilogue", 800000000 + W), ("abl7_noABP", 700000000 + W),
-                    ("abl15_mfmaOnly", 1500000000 + W)]
+                    ("abl4_noProducer", 400000000 + W), ("abl7_noABP", 700000000 + W)]
     if args.small:
         shapes = [(768, 2304, 1, 1, 80, "plain"), (768, 768, 1, 1, 80, "plain"), (768, 2048, 1, 1, 80, "plain"), (2048, 768, 1, 1, 80, "plain"),
                   (640, 2048, 1, 1, 264, "plain"), (1090, 1024, 3, 1, 264, "leaky"), (1024, 1024, 3, 1, 264, "leaky"), (512, 512, 3, 1, 528, "leaky"),
                   (512, 512, 5, 1, 80, "plain")]
-        variants = [("t64x128", 64128), ("t64x64", 64064), ("ws3", 7128128), ("ws4_1tile", 86128128), ("ws4", 6128128)]
+        variants = [("t64x128", 64128), ("t64x64", 64064), ("ws4_1tile", 86128128), ("ws4", 6128128)]
     if args.quick:
         shapes = [(128, 128, 11, 1, 31681, "snake+res"), (128, 128, 3, 1, 31681, "snake+res")]
-        variants = [("ws3", 7128128), ("ws4", 6128128)]
+        variants = [("old64x128", 64128), ("ws4", 6128128)]
     lines = ["cin cout k dil rows fused variant ms tflops_alg GBps_alg maxrel"]
     g = torch.Generator(device=dev).manual_seed(0)
     for cin, cout, k, dil, L, fused in shapes:
