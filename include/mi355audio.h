@@ -482,7 +482,7 @@ int mi355_rmsnorm(const mi355_rmsnorm_args* a, void* stream);
 
 /* Per-head RMSNorm (q_norm / k_norm, talker.py:264-266) fused with the rotary embedding, out of place: x [B, L, ldx] holds
  * `heads` heads of dh (64 or 128) channels from column 0; y may be a KV-cache slot.  Angles come from host tables
- * cos/sin [max_pos, dh/2]; position of row l = pos ? pos[b*pos_ld + l] : pos0 + l.  rope_mode 0 = rotate-half pairs
+ * cos/sin [rope_rows, dh/2]; position of row l = (pos ? pos[b*pos_ld + l] : pos0 + l) - (pos_sub ? pos_sub[b] : 0).  rope_mode 0 = rotate-half pairs
  * (i, i + dh/2) (talker.py:14-36), 1 = interleaved pairs (2i, 2i+1) (nn.RoPE(traditional=True), sesame/attention.py:41-105). */
 typedef struct {
   const float* x; int64_t x_bstride; int32_t ldx;
@@ -490,6 +490,8 @@ typedef struct {
   const float* norm_weight; float eps;          /* [dh] nullable: no norm */
   const float* cos_table; const float* sin_table; /* nullable: no rotation */
   const int32_t* pos; int32_t pos_ld; int32_t pos0;
+  const int32_t* pos_sub;  /* [B] nullable: subtracted from the row's position (left padding of a BatchKVCache row: its first real token is position 0) */
+  int32_t rope_rows;       /* rows of cos_table / sin_table; positions are checked (pos0 + L <= rope_rows) or, for device-side positions, clamped */
   int32_t rope_mode;
   float* y; int64_t y_bstride; int32_t ldy;
   /* optional second tensor handled by the same launch with the same positions (q heads -> y, k heads -> the KV-cache slot y2) */
@@ -586,7 +588,10 @@ typedef struct {
   int32_t wdtype;          /* MI355_W_BF16 / MI355_W_F16 / MI355_W_FP8 (every image of the stack, scales in the layer records) */
   int32_t causal; int32_t window;
   float attn_scale;        /* 0 => dh^-0.5 */
-  int32_t rope_mode; const float* cos; const float* sin;   /* tables [max_pos, dh/2], nullable: no rotary embedding */
+  int32_t rope_mode; const float* cos; const float* sin;   /* tables [rope_rows, dh/2], nullable: no rotary embedding */
+  int32_t rope_rows;       /* table rows: a step at offset >= rope_rows is refused (sesame.py:817-820 raises for the same reason) */
+  const int32_t* k_start;  /* [B] nullable: left padding of each sequence (lm/models/cache.py:502-560 BatchKVCache): keys before it are invisible,
+                              RoPE positions count from it */
   const mi355_layer_desc* layers;                           /* HOST array of n_layers records */
   float* attn_split_ws; int32_t* attn_split_cnt;            /* nullable: workspace of mi355_flash_attn_args.split_* for B <= 8, Tq = 1 */
   const float* final_norm_w; const float* final_norm_b;     /* nullable */
@@ -595,18 +600,6 @@ typedef struct {
 /* x [B, d_model] (updated in place: the residual stream), ws: workspace of B * (2 * heads * dh + d_ff) floats, out (nullable) [B, d_model]
  * receives the final-normed hidden state when final_norm_w is set.  offset = rows already in the KV caches. */
 int mi355_stack_decode_step(const mi355_stack_desc* d, float* x, int32_t B, int32_t offset, float* ws, float* out, void* stream);
-
-/* The same step as ONE launch: a persistent kernel (one or two workgroups per CU) walks the step's phases -- GEMVs with fused norm / SwiGLU /
- * residual, per-head norm + RoPE, KV-streaming attention, final norm -- separated by grid barriers; activations cross workgroups with
- * write-through system-scope accesses, the phase list is built once per (stack, B) and cached.  mi355_stack_decode_step dispatches here for
- * every stack mi355_stack_fused_eligible accepts ONLY when enabled (environment MI355_STEP_FUSED=1, or mi355_stack_fused_set(1), which returns
- * the previous setting): parity-green but measured 1.7-2x slower than the multi-launch schedule on MI355X, so it is opt-in.  The grid barrier's wait is bounded; mi355_stack_fused_check synchronises the stream and fails loudly if a wait was
- * ever abandoned.  One step kernel at a time per device (it occupies every CU). */
-int mi355_stack_decode_step_fused(const mi355_stack_desc* d, float* x, int32_t B, int32_t offset, float* ws, float* out, void* stream);
-int mi355_stack_fused_eligible(const mi355_stack_desc* d, int32_t B);
-int mi355_stack_fused_set(int32_t enabled);
-int mi355_stack_fused_enabled(void);
-int mi355_stack_fused_check(void* stream);
 
 #ifdef __cplusplus
 }

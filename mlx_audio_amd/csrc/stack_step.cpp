@@ -30,13 +30,13 @@ int gemv_call(const float* x, int ldx, int M, int K, const uint16_t* w, int N, i
 
 int attn_call(const float* q, int ldq, const float* k, const float* v, int64_t kv_bstride, int ldkv, int heads, int kv_heads, int dh, int Tk,
               int causal, int window, float scale, int B, float* out, int ldo, void* stream, int64_t hstride = 0, float* split_ws = nullptr,
-              int32_t* split_cnt = nullptr) {
+              int32_t* split_cnt = nullptr, const int32_t* k_start = nullptr) {
   mi355_flash_attn_args a;
   memset(&a, 0, sizeof(a));
   a.k_hstride = hstride; a.v_hstride = hstride; a.split_ws = split_ws; a.split_cnt = split_cnt;
   a.q = q; a.q_bstride = ldq; a.ldq = ldq; a.k = k; a.k_bstride = kv_bstride; a.ldk = ldkv; a.v = v; a.v_bstride = kv_bstride; a.ldv = ldkv;
   a.heads = heads; a.kv_heads = kv_heads; a.dh = dh; a.Tq = 1; a.Tk = Tk; a.causal = causal; a.window = window; a.scale = scale; a.B = B;
-  a.mode = 2; a.out = out; a.out_bstride = ldo; a.ldo = ldo;
+  a.mode = 2; a.out = out; a.out_bstride = ldo; a.ldo = ldo; a.k_start = k_start;
   return mi355_flash_attention(&a, stream);
 }
 
@@ -44,14 +44,14 @@ int attn_call(const float* q, int ldq, const float* k, const float* v, int64_t k
 
 extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int32_t B, int32_t offset, float* ws, float* out, void* stream) {
   MI355_REQUIRE(dp && x && ws && dp->layers, "stack_decode_step: null argument");
-  // the one-launch runner (mega_step.hip) is opt-in (MI355_STEP_FUSED=1 / mi355_stack_fused_set(1)): measured slower than this schedule
-  if (mi355_stack_fused_enabled() && mi355_stack_fused_eligible(dp, B)) return mi355_stack_decode_step_fused(dp, x, B, offset, ws, out, stream);
   const mi355_stack_desc d = *dp;
   MI355_REQUIRE(B >= 1 && B <= 8, "stack_decode_step: 1..8 sequences per step (got %d)", B);
   MI355_REQUIRE(d.n_layers > 0 && d.d_model % 8 == 0 && d.d_ff % 8 == 0 && (d.dh == 64 || d.dh == 128), "stack_decode_step: bad dimensions");
   MI355_REQUIRE(d.wdtype != MI355_W_FP8 || (d.d_model % 16 == 0 && d.d_ff % 16 == 0), "stack_decode_step: fp8 images need d_model, d_ff multiples of 16");
   MI355_REQUIRE(d.norm == 1 || d.norm == 2, "stack_decode_step: norm must be 1 (LayerNorm) or 2 (RMSNorm)");
   MI355_REQUIRE(offset >= 0, "stack_decode_step: negative offset");
+  MI355_REQUIRE(!d.cos || (d.rope_rows > 0 && offset < d.rope_rows), "stack_decode_step: position %d is past the %d-row rotary tables", offset,
+                d.rope_rows);
   const int D = d.d_model, H = d.heads, G = d.kv_heads, dh = d.dh;
   const int nq = H * dh, nkv = 2 * G * dh;
   float* q = ws;                 // [B, nq]
@@ -69,7 +69,7 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
     // interleaved RoPE without per-head q / k norms (CSM Llama, Mimi): the rotation of a pair (2i, 2i + 1) is the epilogue of the wave that owns
     // those two columns of the q | k | v projection -- one launch less per layer (MI355_GEMV_ROPE=0 keeps the separate kernel for A/B runs)
     static const bool rope_off = getenv("MI355_GEMV_ROPE") != nullptr && getenv("MI355_GEMV_ROPE")[0] == '0';
-    const bool rope_in_gemv = d.cos && d.rope_mode == 1 && !L.q_norm && !L.k_norm && B <= 4 && !rope_off;
+    const bool rope_in_gemv = d.cos && d.rope_mode == 1 && !L.q_norm && !L.k_norm && B <= 4 && !rope_off && !d.k_start;  // one table row for all rows
     const float* rc_row = rope_in_gemv ? d.cos + (int64_t)offset * (dh / 2) : nullptr;
     const float* rs_row = rope_in_gemv ? d.sin + (int64_t)offset * (dh / 2) : nullptr;
     int rc = gemv_call(x, D, B, D, L.wqkv, nq + nkv, d.wdtype, L.bqkv, MI355_ACT_NONE, nullptr, nullptr, 0, 0, q, nq, d.norm, L.attn_norm_w,
@@ -79,14 +79,15 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
       mi355_head_rope_args r;
       memset(&r, 0, sizeof(r));
       r.x = q; r.x_bstride = nq; r.ldx = nq; r.heads = H; r.dh = dh; r.L = 1; r.B = B; r.norm_weight = L.q_norm; r.eps = d.eps;
-      r.cos_table = d.cos; r.sin_table = d.sin; r.pos0 = offset; r.rope_mode = d.rope_mode; r.y = q; r.y_bstride = nq; r.ldy = nq;
+      r.cos_table = d.cos; r.sin_table = d.sin; r.pos0 = offset; r.pos_sub = d.k_start; r.rope_rows = d.rope_rows; r.rope_mode = d.rope_mode;
+      r.y = q; r.y_bstride = nq; r.ldy = nq;
       r.x2 = slot; r.x2_bstride = L.kv_bstride; r.ldx2 = nkv; r.heads2 = G; r.norm_weight2 = L.k_norm; r.y2 = slot; r.y2_bstride = L.kv_bstride;
       r.ldy2 = nkv;
       rc = mi355_head_norm_rope(&r, stream);
       if (rc) return rc;
     }
     rc = attn_call(q, nq, L.kv, L.kv + G * dh, L.kv_bstride, nkv, H, G, dh, offset + 1, d.causal, d.window, scale, B, att, nq, stream, 0, d.attn_split_ws,
-                   d.attn_split_cnt);
+                   d.attn_split_cnt, d.k_start);
     if (rc) return rc;
     rc = gemv_call(att, nq, B, nq, L.wo, D, d.wdtype, L.bo, MI355_ACT_NONE, L.ls1, x, D, 0, x, D, 0, nullptr, nullptr, 0.f, nullptr, 0, 0, stream, L.s_o);
     if (rc) return rc;

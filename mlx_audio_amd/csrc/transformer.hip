@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void head_norm_rope_kernel(const mi355_head_ro
     if (act) { x0 = x0 * r * nw[i0]; x1 = x1 * r * nw[i1]; }
   }
   if (a.cos_table && act) {
-    const int pos = a.pos ? a.pos[(int64_t)b * a.pos_ld + l] : a.pos0 + l;
+    int pos = (a.pos ? a.pos[(int64_t)b * a.pos_ld + l] : a.pos0 + l) - (a.pos_sub ? a.pos_sub[b] : 0);
+    pos = pos < 0 ? 0 : (pos >= a.rope_rows ? a.rope_rows - 1 : pos);  // left-padding rows sit before position 0; host-known ranges are checked at the entry point
     const float c = a.cos_table[(int64_t)pos * half + lane], s = a.sin_table[(int64_t)pos * half + lane];
     // (x * cos) + (rotate(x) * sin): pair (x0, x1) -> (x0 c - x1 s, x1 c + x0 s), two roundings per term like the reference
     const float y0 = x0 * c - x1 * s;
@@ -218,6 +219,9 @@ extern "C" int mi355_head_norm_rope(const mi355_head_rope_args* ap, void* stream
   MI355_REQUIRE(a.rope_mode == 0 || a.rope_mode == 1, "head_norm_rope: rope_mode must be 0 (rotate-half) or 1 (interleaved)");
   MI355_CLEAR_ERROR();
   MI355_REQUIRE(a.heads2 >= 0 && (a.heads2 == 0 || (a.x2 && a.y2)), "head_norm_rope: second tensor needs x2 / y2");
+  MI355_REQUIRE(!a.cos_table || a.rope_rows > 0, "head_norm_rope: rope_rows (rows of the cos / sin tables) must be set");
+  MI355_REQUIRE(!a.cos_table || a.pos || a.pos0 + a.L <= a.rope_rows, "head_norm_rope: positions %d..%d run past the %d-row rotary tables", a.pos0,
+                a.pos0 + a.L - 1, a.rope_rows);
   const int64_t waves = (int64_t)a.B * a.L * (a.heads + a.heads2);
   hipLaunchKernelGGL(head_norm_rope_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   MI355_LAUNCH_CHECK("head_norm_rope");

@@ -242,9 +242,10 @@ class TransformerStack:
         return [KVCache(self.cfg.n_kv_heads, self.cfg.head_dim, self.device) for _ in range(self.cfg.n_layers)]
 
     # ------------------------------------------------------------------ native decode step (mi355_stack_decode_step)
-    def _native_desc(self, cache: List[KVCache]):
-        """Builds (or refreshes after a cache re-allocation) the C descriptor of this stack for the given caches."""
-        key = tuple(c.kv.data_ptr() for c in cache)
+    def _native_desc(self, cache: List[KVCache], k_start: Optional[torch.Tensor] = None):
+        """Builds (or refreshes after a cache re-allocation) the C descriptor of this stack for the given caches.  The key carries everything the
+        descriptor stores about a cache: the caching allocator may hand a later, differently sized cache the same addresses."""
+        key = tuple((c.kv.data_ptr(), c.kv.shape[0], c.kv.shape[1], c.kv.stride(0)) for c in cache) + (None if k_start is None else k_start.data_ptr(),)
         st = getattr(self, "_native", None)
         if st is not None and st["key"] == key:
             return st
@@ -269,23 +270,31 @@ class TransformerStack:
         d.act = {"gelu": ACT_GELU, "gelu_tanh": ACT_GELU_TANH}.get(c.mlp, ACT_NONE)
         d.wdtype, d.causal, d.window, d.attn_scale = self.layers[0].wqkv.rm.wdtype, int(c.causal), c.window, 0.0
         d.rope_mode, d.cos, d.sin = int(c.rope_interleaved), p(self.cos), p(self.sin)
+        d.rope_rows = 0 if self.cos is None else self.cos.shape[0]
+        d.k_start = p(k_start)
         d.layers = ctypes.cast(arr, ctypes.c_void_p)
         sws, scnt = ops.attn_split_workspace(self.device, 8 * c.n_heads, c.head_dim)  # key-split decode attention (long key ranges)
         d.attn_split_ws, d.attn_split_cnt = sws.data_ptr(), scnt.data_ptr()
         if self.final_norm is not None:
             d.final_norm_w, d.final_norm_b = p(self.final_norm[0]), p(self.final_norm[1])
-        self._native = dict(key=key, arr=arr, desc=d)
+        self._native = dict(key=key, arr=arr, desc=d, k_start=k_start)
         return self._native
 
-    def decode_step(self, x: torch.Tensor, cache: List[KVCache]) -> torch.Tensor:
+    def _check_positions(self, offset: int, n_new: int):
+        """RoPE tables have ``max_pos`` rows (CSM: 2048, talker: <= 8192): running past them must raise, not read garbage (sesame.py:817-820)."""
+        if self.cos is not None and offset + n_new > self.cos.shape[0]:
+            raise ValueError(f"sequence position {offset + n_new - 1} is past the {self.cos.shape[0]}-row rotary tables (max_pos) of this stack")
+
+    def decode_step(self, x: torch.Tensor, cache: List[KVCache], k_start: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One single-position step for B <= 8 sequences through the native runner: x [B, 1, d_model] (updated in place); returns the
-        final-normed hidden state [B, 1, d_model] (or x itself when the stack has no final norm)."""
+        final-normed hidden state [B, 1, d_model] (or x itself when the stack has no final norm).  ``k_start`` int32 [B]: left padding."""
         c = self.cfg
         B = x.shape[0]
         off = cache[0].offset
+        self._check_positions(off, 1)
         for kvc in cache:
             kvc.reserve(B, 1)
-        st = self._native_desc(cache)
+        st = self._native_desc(cache, k_start)
         ws = torch.empty(B * (2 * c.n_heads * c.head_dim + c.d_ff), dtype=torch.float32, device=self.device)
         out = torch.empty_like(x) if self.final_norm is not None else None
         lib = _lib.load()
@@ -300,15 +309,21 @@ class TransformerStack:
             return ops.layernorm(x, y, weight=p[0], bias=p[1], eps=self.cfg.norm_eps)
         return ops.rmsnorm(x, y, p[0], eps=self.cfg.norm_eps)
 
-    def __call__(self, x: torch.Tensor, cache: Optional[List[KVCache]] = None, return_layers: bool = False):
-        """x [B, L, d_model] fp32 on the device (modified in place and returned, normalised when ``final_norm``)."""
+    def __call__(self, x: torch.Tensor, cache: Optional[List[KVCache]] = None, return_layers: bool = False, k_start: Optional[torch.Tensor] = None):
+        """x [B, L, d_model] fp32 on the device (modified in place and returned, normalised when ``final_norm``).
+        ``k_start`` int32 [B] (device): row b of the batch is LEFT-padded by k_start[b] positions (BatchKVCache, lm/models/cache.py:502-560;
+        the reference's batched talker builds the same thing from its attention mask, talker.py:443-470): its keys before k_start[b] are
+        invisible and its rotary positions count from k_start[b].  Outputs at padding positions are meaningless."""
         c = self.cfg
         B, L, D = x.shape
         assert D == c.d_model and x.is_contiguous()
         if cache is None:
             cache = self.make_cache()
+        if k_start is not None:
+            assert k_start.dtype == torch.int32 and k_start.shape == (B,) and k_start.is_cuda
         if is_decode(x) and not return_layers and self.native_decode:
-            return self.decode_step(x, cache)
+            return self.decode_step(x, cache, k_start)
+        self._check_positions(cache[0].offset, L)
         H, G, dh = c.n_heads, c.n_kv_heads, c.head_dim
         dev = self.device
         q = torch.empty((B, L, H * dh), dtype=torch.float32, device=dev)
@@ -334,8 +349,8 @@ class TransformerStack:
             if lyr.q_norm is not None or self.cos is not None:
                 ks = slot[:, :, : G * dh]
                 ops.head_norm_rope(q, q, heads=H, dh=dh, norm_weight=lyr.q_norm, eps=c.norm_eps, cos=self.cos, sin=self.sin, pos0=off,
-                                   interleaved=c.rope_interleaved, second=(ks, ks, G, lyr.k_norm))  # q and k heads in one launch
-            ops.flash_attention(q, kvc.keys, kvc.values, att, heads=H, kv_heads=G, dh=dh, causal=c.causal, window=c.window)
+                                   interleaved=c.rope_interleaved, second=(ks, ks, G, lyr.k_norm), pos_sub=k_start)  # q and k heads in one launch
+            ops.flash_attention(q, kvc.keys, kvc.values, att, heads=H, kv_heads=G, dh=dh, causal=c.causal, window=c.window, k_start=k_start)
             linear(att, lyr.wo, x, res=x, colscale=lyr.ls1, precision=self.precision)
             if decode:  # pre-norm (+ SwiGLU) fused into the up-projection GEMV
                 linear(x, lyr.w_in, mid, glu=c.mlp == "swiglu", post_act=ACT_NONE if c.mlp == "swiglu" else act,

@@ -421,14 +421,17 @@ def rmsnorm(x: torch.Tensor, y: torch.Tensor, weight: Optional[torch.Tensor], ep
 
 def head_norm_rope(x: torch.Tensor, y: torch.Tensor, *, heads: int, dh: int, norm_weight: Optional[torch.Tensor] = None, eps: float = 1e-6,
                    cos: Optional[torch.Tensor] = None, sin: Optional[torch.Tensor] = None, pos: Optional[torch.Tensor] = None, pos0: int = 0,
-                   interleaved: bool = False, lens=None, second: Optional[tuple] = None):
-    """Per-head RMSNorm (optional) + RoPE (optional) of ``heads`` heads starting at column 0 of ``x`` into ``y`` (may be a cache slot)."""
+                   interleaved: bool = False, lens=None, second: Optional[tuple] = None, pos_sub: Optional[torch.Tensor] = None):
+    """Per-head RMSNorm (optional) + RoPE (optional) of ``heads`` heads starting at column 0 of ``x`` into ``y`` (may be a cache slot).
+    ``pos_sub`` int32 [B]: left padding of each row, subtracted from its positions (its first real token is position 0)."""
     B, L, _, xbs, ldx = _nlc(x)
     _, _, _, ybs, ldy = _nlc(y)
     if cos is not None:
         assert cos.dim() == 2 and cos.shape[1] == dh // 2 and cos.is_contiguous() and sin.is_contiguous() and cos.shape == sin.shape
     if pos is not None:
         assert pos.dtype == torch.int32 and pos.dim() == 2 and pos.stride(1) == 1
+    elif cos is not None and pos0 + L > cos.shape[0]:
+        raise ValueError(f"head_norm_rope: positions {pos0}..{pos0 + L - 1} run past the {cos.shape[0]}-row rotary tables")
     kw = {}
     if second is not None:  # (x2, y2, heads2, norm_weight2): e.g. the k heads, rotated straight into their KV-cache slot
         x2, y2, heads2, nw2 = second
@@ -438,7 +441,8 @@ def head_norm_rope(x: torch.Tensor, y: torch.Tensor, *, heads: int, dh: int, nor
         kw = dict(x2=_ptr(x2), x2_bstride=x2bs, ldx2=ldx2, heads2=heads2, norm_weight2=_ptr(nw2), y2=_ptr(y2), y2_bstride=y2bs, ldy2=ldy2)
     _lib.call_struct("mi355_head_norm_rope", "mi355_head_rope_args", _stream(), x=_ptr(x), x_bstride=xbs, ldx=ldx, heads=heads, dh=dh, L=L,
                      lens=_ptr(lens), B=B, norm_weight=_ptr(norm_weight), eps=eps, cos_table=_ptr(cos), sin_table=_ptr(sin), pos=_ptr(pos),
-                     pos_ld=0 if pos is None else pos.stride(0), pos0=pos0, rope_mode=int(interleaved), y=_ptr(y), y_bstride=ybs, ldy=ldy, **kw)
+                     pos_ld=0 if pos is None else pos.stride(0), pos0=pos0, pos_sub=_ptr(pos_sub), rope_rows=0 if cos is None else cos.shape[0],
+                     rope_mode=int(interleaved), y=_ptr(y), y_bstride=ybs, ldy=ldy, **kw)
     return y
 
 
@@ -657,17 +661,3 @@ def istft_frames(spec: torch.Tensor, n_fft: int, hop: int, window: torch.Tensor,
                      hop=hop, window=_ptr(window), norm=_ptr(norm), norm_mode=norm_mode, clamp=int(clamp), trim=trim,
                      out_len=out_len, frames_ws=_ptr(ws), out=_ptr(out), ld_out=out.stride(0))
     return out
-
-
-def fused_step_set(enabled: bool) -> bool:
-    """Enable / disable the one-launch decode-step runner (mega_step.hip); returns the previous setting."""
-    return bool(_lib.load().mi355_stack_fused_set(1 if enabled else 0))
-
-
-def fused_step_enabled() -> bool:
-    return bool(_lib.load().mi355_stack_fused_enabled())
-
-
-def fused_step_check():
-    """Synchronise the stream and raise if a grid barrier of the one-launch step runner was ever abandoned (bounded wait)."""
-    _lib.check(_lib.load().mi355_stack_fused_check(_stream()), "mi355_stack_fused_check")

@@ -25,15 +25,33 @@ def _is_pkg_dir(p: Path) -> bool:
 
 @lru_cache(maxsize=None)
 def kinds() -> Tuple[str, ...]:
-    found = sorted(p.name for p in _PKG.iterdir() if _is_pkg_dir(p) and (p / "models").is_dir())
+    """A kind is loadable only when ``<kind>/utils.py`` (its ``load_model``) exists: ``codec`` ships decoder engines but no loader."""
+    found = sorted(p.name for p in _PKG.iterdir() if _is_pkg_dir(p) and (p / "models").is_dir() and (p / "utils.py").is_file())
     head = [k for k in _VOICE_KINDS_FIRST if k in found]
     return tuple(head + [k for k in found if k not in head])
+
+
+def _exports_model(pkg: Path) -> bool:
+    """True when the family's ``__init__.py`` binds the name ``Model`` (import, class or assignment), read with ``ast``: a family directory
+    without a ``Model`` cannot be loaded, so it must not be advertised."""
+    try:
+        tree = ast.parse((pkg / "__init__.py").read_text())
+    except (OSError, SyntaxError):
+        return False
+    for node in tree.body:
+        if isinstance(node, (ast.Import, ast.ImportFrom)) and any((a.asname or a.name) == "Model" for a in node.names):
+            return True
+        if isinstance(node, ast.ClassDef) and node.name == "Model":
+            return True
+        if isinstance(node, ast.Assign) and any(isinstance(t, ast.Name) and t.id == "Model" for t in node.targets):
+            return True
+    return False
 
 
 @lru_cache(maxsize=None)
 def _families(kind: str) -> FrozenSet[str]:
     root = _PKG / kind / "models"
-    return frozenset(p.name for p in root.iterdir() if _is_pkg_dir(p)) if root.is_dir() else frozenset()
+    return frozenset(p.name for p in root.iterdir() if _is_pkg_dir(p) and _exports_model(p)) if root.is_dir() else frozenset()
 
 
 @lru_cache(maxsize=None)
@@ -54,8 +72,9 @@ def _remapping(kind: str) -> Dict[str, str]:
 
 @lru_cache(maxsize=None)
 def supported_model_types(kind: str) -> FrozenSet[str]:
-    remap = _remapping(kind)
-    return _families(kind) | frozenset(remap) | frozenset(remap.values())
+    fams = _families(kind)
+    remap = {k: v for k, v in _remapping(kind).items() if v in fams}  # an alias of a family that cannot load is not supported either
+    return fams | frozenset(remap) | frozenset(remap.values())
 
 
 def _name_parts(name: str) -> List[str]:

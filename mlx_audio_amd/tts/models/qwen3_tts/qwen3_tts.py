@@ -1,0 +1,397 @@
+"""Qwen3-TTS behind the reference's model protocol (``Model(config)``, ``sanitize``, ``post_load_hook``, ``generate``, ``batch_generate`` --
+``tts/models/qwen3_tts/qwen3_tts.py:168-2937``), computing on MI355X through ``Qwen3Talker`` (talker + code predictor frame loop) and
+``Qwen3TTSSpeechTokenizer`` (codec decoder).
+
+Same as the reference: constructor / config records, checkpoint key handling, the chat-template prompt construction
+(``_prepare_generation_inputs`` :326-484) and its left-padded batch form (``_prepare_batch_inputs`` :486-604), the sampling defaults, the
+generator protocol and every field of ``GenerationResult`` / ``BatchGenerationResult``, chunked codec decode (15-frame chunks + 5 frames of
+left context, :1050-1083).
+
+Not in this build (raise, never silently degrade): in-context voice cloning (``ref_audio`` + ``ref_text``: needs the speech-tokenizer ENCODER and
+the ECAPA speaker encoder), streaming chunk decode with carried codec state (``stream=True`` decodes each chunk with left context).
+"""
+from __future__ import annotations
+
+import json
+import time
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Dict, Generator, List, Optional, Tuple, Union
+
+import torch
+
+from ..base import BatchGenerationResult, GenerationResult
+from .config import ModelConfig, Qwen3TTSTokenizerConfig, filter_dict_for_dataclass
+from .speech_tokenizer import Qwen3TTSSpeechTokenizer, check_array_shape_qwen3
+
+
+def format_duration(seconds: float) -> str:
+    """HH:MM:SS.mmm (qwen3_tts.py:160-165)."""
+    return f"{int(seconds // 3600):02d}:{int((seconds % 3600) // 60):02d}:{seconds % 60:06.3f}"
+
+
+@dataclass
+class Qwen3BatchInputs:
+    """``qwen3_tts.py:36-44``."""
+    input_embeds: torch.Tensor
+    trailing_text_hidden: torch.Tensor
+    tts_pad_embed: torch.Tensor
+    attention_mask: torch.Tensor
+    left_padding: List[int]
+    prefill_lens: List[int]
+    trailing_lens: List[int]
+    ref_codes: Optional[torch.Tensor] = None
+
+
+class Model:
+    def __init__(self, config: ModelConfig, device: str = "cuda", precision: int = 2):
+        self.config = config
+        self._sample_rate = config.sample_rate
+        self.device = device
+        self.precision = precision
+        self.talker = None            # Qwen3Talker (engine), built by load_weights
+        self.speaker_encoder = None   # not part of this build
+        self.speech_tokenizer: Optional[Qwen3TTSSpeechTokenizer] = None
+        self.tokenizer = None
+        self.generate_config = None
+        tc = config.talker_config
+        self.supported_speakers = list(tc.spk_id.keys()) if tc.spk_id else []
+        self.supported_languages = ["auto"] + [k for k in (tc.codec_language_id or {}) if "dialect" not in k]
+        self.model_path = None
+
+    # ------------------------------------------------------------------ protocol
+    @property
+    def sample_rate(self) -> int:
+        return self._sample_rate
+
+    @property
+    def model_type(self) -> str:
+        return "qwen3_tts"
+
+    def eval(self):
+        return self
+
+    def supports_tts_batch(self, *, stream: bool = False, voice: Optional[str] = None, instruct: Optional[str] = None, ref_audio=None,
+                           ref_text: Optional[str] = None, speed: Optional[float] = 1.0, pitch: Optional[float] = 1.0, **kwargs) -> bool:
+        """``qwen3_tts.py:215-252`` (reference audio never batches here: no encoder)."""
+        del kwargs
+        if stream or speed not in (None, 1.0) or pitch not in (None, 1.0):
+            return False
+        if ref_audio is not None or ref_text is not None:
+            return False
+        kind = getattr(self.config, "tts_model_type", "base")
+        if kind not in {"base", "custom_voice"}:
+            return False
+        if kind == "base" and instruct:
+            return False
+        if kind == "custom_voice" and not voice:
+            return False
+        return True
+
+    def supports_tts_continuous_batch(self, **kwargs) -> bool:
+        return False  # continuous_batching.py:37-360 (per-request KV merge / extract) is not wired to the engine yet
+
+    def load_speech_tokenizer(self, speech_tokenizer: Qwen3TTSSpeechTokenizer):
+        self.speech_tokenizer = speech_tokenizer
+
+    def load_generate_config(self, generate_config: dict):
+        self.generate_config = generate_config
+
+    def get_supported_speakers(self) -> List[str]:
+        return self.supported_speakers
+
+    def get_supported_languages(self) -> List[str]:
+        return self.supported_languages
+
+    def model_quant_predicate(self, path: str, module) -> bool:
+        return not any(p in path for p in ("codec_embedding", "text_embedding", "speech_tokenizer", "speaker_encoder"))
+
+    # ------------------------------------------------------------------ checkpoint handling
+    @staticmethod
+    def sanitize(weights: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """``qwen3_tts.py:2914-2937``: drop ``position_ids``, PyTorch conv layouts (out, in, K) -> (out, K, in) for every 3-D "conv" weight
+        (and ``speaker_encoder.fc``) unless the shape heuristic says it already is."""
+        out = {}
+        for k, v in weights.items():
+            if "position_ids" in k:
+                continue
+            if ("conv" in k or "speaker_encoder.fc" in k) and "weight" in k and v.dim() == 3:
+                v = v if check_array_shape_qwen3(v) else v.permute(0, 2, 1).contiguous()
+            out[k] = v
+        return out
+
+    def load_weights(self, weights, strict: bool = True):
+        """``weights``: sanitized dict / pair list with the reference's module paths (``talker.model.layers...``, ``talker.codec_head...``,
+        ``talker.code_predictor...``, ``speaker_encoder...``); builds the device engine of the talker."""
+        from .talker import Qwen3Talker
+
+        w = dict(weights)
+        tw = {k[len("talker."):]: v for k, v in w.items() if k.startswith("talker.")}
+        if not tw:
+            raise ValueError("Qwen3-TTS checkpoint has no talker.* parameters")
+        try:
+            self.talker = Qwen3Talker(tw, self.config.talker_config, device=self.device, precision=self.precision)
+        except KeyError as e:
+            raise ValueError(f"Qwen3-TTS checkpoint is missing parameter talker.{e.args[0]}") from e
+        return self
+
+    @classmethod
+    def post_load_hook(cls, model: "Model", model_path) -> "Model":
+        """``qwen3_tts.py:2818-2911``: text tokenizer (``AutoTokenizer`` on the model directory), speech tokenizer from ``speech_tokenizer/``
+        (its own config.json + safetensors), generation_config.json."""
+        model_path = Path(model_path)
+        if model.tokenizer is None:
+            try:
+                from transformers import AutoTokenizer
+
+                model.tokenizer = AutoTokenizer.from_pretrained(str(model_path))
+            except Exception as e:  # same behaviour as the reference: warn, fail later in generate()
+                print(f"Warning: Could not load tokenizer: {e}")
+        st_path = model_path / "speech_tokenizer"
+        if st_path.exists():
+            from safetensors.torch import load_file
+
+            with open(st_path / "config.json") as f:
+                d = json.load(f)
+            tcfg = Qwen3TTSTokenizerConfig(**filter_dict_for_dataclass(Qwen3TTSTokenizerConfig, d))
+            st = Qwen3TTSSpeechTokenizer(tcfg, device=model.device, precision=model.precision)
+            tw: Dict[str, torch.Tensor] = {}
+            for wf in sorted(st_path.glob("*.safetensors")):
+                tw.update(load_file(str(wf)))
+            if tw:
+                st.load_weights(Qwen3TTSSpeechTokenizer.sanitize(tw))
+                model.load_speech_tokenizer(st)
+        gen = model_path / "generation_config.json"
+        if gen.exists():
+            with open(gen) as f:
+                model.load_generate_config(json.load(f))
+        return model
+
+    # ------------------------------------------------------------------ prompt construction
+    def _text_embed(self, ids: List[int]) -> torch.Tensor:
+        return self.talker.embed_text(torch.tensor([ids], dtype=torch.int32))
+
+    def _codec_embed(self, ids: List[int]) -> torch.Tensor:
+        idx = torch.tensor(ids, dtype=torch.long, device=self.talker.device)
+        return self.talker.codec_table[idx][None]  # slot 0 of the stacked table = the talker's codec_embedding
+
+    def extract_speaker_embedding(self, audio, sr: int = 24000):
+        raise NotImplementedError("voice cloning needs the ECAPA speaker encoder (tts/models/qwen3_tts/speaker_encoder.py), which this build does not ship")
+
+    def _prepare_generation_inputs(self, text: str, language: str = "auto", speaker: Optional[str] = None, ref_audio=None,
+                                   ref_text: Optional[str] = None, instruct: Optional[str] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """``qwen3_tts.py:326-484``: (input_embeds [1, L, H], trailing_text_hidden [1, T, H], tts_pad_embed [1, 1, H])."""
+        if self.tokenizer is None:
+            raise ValueError("Tokenizer not loaded. Call post_load_hook first.")
+        if ref_audio is not None:
+            self.extract_speaker_embedding(ref_audio)
+        cfg = self.config.talker_config
+        chat = f"<|im_start|>assistant\n{text}<|im_end|>\n<|im_start|>assistant\n"
+        text_embed = self._text_embed(list(self.tokenizer.encode(chat)))
+        tts = self._text_embed([self.config.tts_bos_token_id, self.config.tts_eos_token_id, self.config.tts_pad_token_id])
+        tts_bos, tts_eos, tts_pad = tts[:, 0:1], tts[:, 1:2], tts[:, 2:3]
+        speaker_embed = None
+        if speaker and speaker.lower() in (cfg.spk_id or {}):
+            sid = cfg.spk_id[speaker.lower()]
+            speaker_embed = self._codec_embed([sid[0] if isinstance(sid, (list, tuple)) else sid])
+        language_id = None
+        if language.lower() != "auto" and cfg.codec_language_id and language.lower() in cfg.codec_language_id:
+            language_id = cfg.codec_language_id[language.lower()]
+        if language.lower() in ("chinese", "auto") and speaker and (cfg.spk_is_dialect or {}).get(speaker.lower()):
+            dialect = cfg.spk_is_dialect[speaker.lower()]
+            if dialect in (cfg.codec_language_id or {}):
+                language_id = cfg.codec_language_id[dialect]
+        if language_id is None:
+            prefill = [cfg.codec_nothink_id, cfg.codec_think_bos_id, cfg.codec_think_eos_id]
+        else:
+            prefill = [cfg.codec_think_id, cfg.codec_think_bos_id, language_id, cfg.codec_think_eos_id]
+        codec_embed = self._codec_embed(prefill)
+        suffix = self._codec_embed([cfg.codec_pad_id, cfg.codec_bos_id])
+        codec_embed = torch.cat([codec_embed] + ([speaker_embed.reshape(1, 1, -1)] if speaker_embed is not None else []) + [suffix], dim=1)
+        instruct_embed = None
+        if instruct:
+            instruct_embed = self._text_embed(list(self.tokenizer.encode(f"<|im_start|>user\n{instruct}<|im_end|>\n")))
+        role = text_embed[:, :3]
+        pad_count = codec_embed.shape[1] - 2
+        combined = torch.cat([tts_pad.expand(1, pad_count, -1), tts_bos], dim=1) + codec_embed[:, :-1]
+        parts = ([instruct_embed] if instruct_embed is not None else []) + [role, combined, text_embed[:, 3:4] + codec_embed[:, -1:]]
+        input_embeds = torch.cat(parts, dim=1)
+        trailing = torch.cat([text_embed[:, 4:-5], tts_eos], dim=1)
+        return input_embeds.contiguous(), trailing.contiguous(), tts_pad.contiguous()
+
+    def _prepare_batch_inputs(self, texts: List[str], language: str = "auto", speakers: Optional[List[Optional[str]]] = None,
+                              instructs: Optional[List[Optional[str]]] = None, ref_audio=None, ref_text: Optional[str] = None,
+                              return_metadata: bool = False):
+        """``qwen3_tts.py:486-604``: per-sequence inputs, input_embeds LEFT-padded with zeros, trailing text RIGHT-padded with tts_pad."""
+        if ref_audio is not None or ref_text is not None:
+            raise NotImplementedError("in-context voice cloning needs the speech-tokenizer encoder, which this build does not ship")
+        embeds, trailings, pad = [], [], None
+        for i, t in enumerate(texts):
+            e, tr, p = self._prepare_generation_inputs(t, language=language, speaker=speakers[i] if speakers else None,
+                                                       instruct=instructs[i] if instructs else None)
+            embeds.append(e)
+            trailings.append(tr)
+            pad = p if pad is None else pad
+        H = embeds[0].shape[-1]
+        plens = [e.shape[1] for e in embeds]
+        mp = max(plens)
+        left = [mp - n for n in plens]
+        dev = embeds[0].device
+        x = torch.cat([torch.cat([torch.zeros((1, l, H), device=dev), e], dim=1) for e, l in zip(embeds, left)], dim=0)
+        mask = torch.cat([torch.cat([torch.zeros((1, l), device=dev), torch.ones((1, n), device=dev)], dim=1) for n, l in zip(plens, left)], dim=0)
+        tlens = [t.shape[1] for t in trailings]
+        mt = max(tlens)
+        tr = torch.cat([torch.cat([t, pad.expand(1, mt - t.shape[1], H)], dim=1) for t in trailings], dim=0)
+        bi = Qwen3BatchInputs(input_embeds=x.contiguous(), trailing_text_hidden=tr.contiguous(), tts_pad_embed=pad, attention_mask=mask,
+                              left_padding=left, prefill_lens=plens, trailing_lens=tlens)
+        return bi if return_metadata else (bi.input_embeds, bi.trailing_text_hidden, bi.tts_pad_embed, bi.attention_mask)
+
+    # ------------------------------------------------------------------ decode
+    def _decode_generated_codes(self, codes: torch.Tensor, *, decode_chunk: int = 15, decode_ctx: int = 5) -> torch.Tensor:
+        """codes int [T, num_code_groups] of ONE sequence -> waveform [samples] with bounded decoder memory (``qwen3_tts.py:1050-1083``): chunks
+        of ``decode_chunk`` frames with ``decode_ctx`` frames of left context whose audio is trimmed."""
+        dec = self.speech_tokenizer.decoder
+        if codes.numel() == 0:
+            return torch.zeros(0, dtype=torch.float32, device=dec.device)
+        up = dec.total_upsample
+        tr = codes.t()[None].contiguous()  # [1, groups, T]
+        parts, start, n = [], 0, tr.shape[-1]
+        while start < n:
+            end = min(start + decode_chunk, n)
+            ctx = decode_ctx if start > decode_ctx else start
+            wav = dec(tr[..., start - ctx:end]).squeeze(1)[0]
+            parts.append(wav[ctx * up:] if ctx > 0 else wav)
+            start = end
+        return torch.cat(parts) if len(parts) > 1 else parts[0]
+
+    def _result(self, audio: torch.Tensor, segment_idx: int, token_count: int, elapsed: float, **extra) -> GenerationResult:
+        samples = int(audio.shape[0])
+        dur = samples / self.sample_rate
+        return GenerationResult(
+            audio=audio, samples=samples, sample_rate=self.sample_rate, segment_idx=segment_idx, token_count=token_count,
+            audio_duration=format_duration(dur), real_time_factor=dur / elapsed if elapsed > 0 else 0,
+            prompt={"tokens": token_count, "tokens-per-sec": token_count / elapsed if elapsed > 0 else 0},
+            audio_samples={"samples": samples, "samples-per-sec": samples / elapsed if elapsed > 0 else 0},
+            processing_time_seconds=elapsed, peak_memory_usage=torch.cuda.max_memory_allocated() / 1e9 if torch.cuda.is_available() else 0.0, **extra)
+
+    def _frame_loop(self, input_embeds, trailing, tts_pad, max_tokens, *, temperature, top_k, top_p, repetition_penalty, left_pad=None, seed=None,
+                    **engine_kw):
+        gen = None
+        if temperature > 0 and "gumbel0" not in engine_kw:
+            gen = torch.Generator(device=self.talker.device)
+            gen.manual_seed(int(seed) if seed is not None else int(torch.seed() % (2 ** 31)))
+        cap = self.talker.talker.cos.shape[0] - input_embeds.shape[1]
+        return self.talker.generate(input_embeds, trailing, tts_pad, min(max_tokens, cap), temperature=temperature, top_k=top_k, top_p=top_p,
+                                    repetition_penalty=repetition_penalty, left_pad=left_pad, generator=gen, **engine_kw)
+
+    # ------------------------------------------------------------------ generate
+    def generate(self, text: str, voice: Optional[str] = None, instruct: Optional[str] = None, temperature: float = 0.9, speed: float = 1.0,
+                 lang_code: str = "auto", ref_audio=None, ref_text: Optional[str] = None, split_pattern: str = "\n", max_tokens: int = 4096,
+                 verbose: bool = False, stream: bool = False, streaming_interval: float = 2.0, streaming_context_size: int = 25, top_k: int = 50,
+                 top_p: float = 1.0, repetition_penalty: float = 1.05, **kwargs) -> Generator[GenerationResult, None, None]:
+        """``qwen3_tts.py:1122-1575``: one ``GenerationResult`` per text segment (``stream=True``: one per ``streaming_interval`` of audio plus the
+        final chunk).  Routing by ``config.tts_model_type`` as in the reference: ``voice_design`` needs ``instruct``, ``custom_voice`` needs
+        ``voice``; ``base`` accepts an optional preset ``voice``.  Engine-level keyword arguments (``seed``, ``gumbel0``, ``gumbel_cp``,
+        ``forced_codes``) pass through for deterministic runs; other unknown keyword arguments are ignored like the reference does."""
+        if self.talker is None:
+            raise RuntimeError("Model has no weights: call load_weights() (or mlx_audio_amd.tts.utils.load_model)")
+        if self.speech_tokenizer is None:
+            raise ValueError("Speech tokenizer not loaded")
+        if ref_audio is not None or ref_text is not None:
+            raise NotImplementedError("voice cloning (ref_audio / ref_text) needs the speech-tokenizer encoder and the speaker encoder, which this build does not ship")
+        kind = getattr(self.config, "tts_model_type", "base")
+        if kind == "voice_design" and not instruct:
+            raise ValueError("VoiceDesign model requires 'instruct' to describe the voice (e.g., 'A cheerful young female voice with high pitch')")
+        if kind == "custom_voice" and not voice:
+            raise ValueError(f"CustomVoice model requires 'voice' (speaker name) (e.g., {self.supported_speakers})")
+        if kind == "base":
+            if voice is not None and voice.lower() not in [s.lower() for s in self.supported_speakers]:
+                raise ValueError(f"Voice '{voice}' is not supported by this Base model. Base models have no built-in preset voices — clone a voice by "
+                                 "passing ref_audio and ref_text instead."
+                                 + (f" Available preset voices: {self.supported_speakers}" if self.supported_speakers else ""))
+            instruct = None
+        engine_kw = {k: kwargs[k] for k in ("gumbel0", "gumbel_cp", "forced_codes") if k in kwargs}
+        segments = [s.strip() for s in text.split(split_pattern) if s.strip()] if split_pattern else [text]
+        for segment_idx, seg in enumerate(segments):
+            t0 = time.time()
+            x, trailing, pad = self._prepare_generation_inputs(seg, language=lang_code, speaker=voice if kind != "voice_design" else None, instruct=instruct)
+            out = self._frame_loop(x, trailing, pad, max_tokens, temperature=temperature, top_k=top_k, top_p=top_p, repetition_penalty=repetition_penalty,
+                                   seed=kwargs.get("seed"), pad_when_index_clamped=False, **engine_kw)
+            codes = out["codes"][0]
+            fa = int(out["finished_at"][0])
+            codes = codes[:fa] if fa >= 0 else codes  # the EOS frame itself is not decoded (qwen3_tts.py:1408-1412)
+            if codes.shape[0] == 0:
+                continue
+            if stream:
+                chunk = max(1, int(streaming_interval * 12.5))
+                done = 0
+                up = self.speech_tokenizer.decode_upsample_rate
+                while done < codes.shape[0]:
+                    end = min(done + chunk, codes.shape[0])
+                    ctx = min(streaming_context_size, done)
+                    wav = self.speech_tokenizer.decoder(codes[done - ctx:end].t()[None].contiguous()).squeeze(1)[0][ctx * up:]
+                    torch.cuda.synchronize()
+                    yield self._result(wav, segment_idx, end - done, time.time() - t0, is_streaming_chunk=True, is_final_chunk=end == codes.shape[0])
+                    done, t0 = end, time.time()
+                continue
+            audio, lengths = self.speech_tokenizer.decode(codes[None])
+            audio = audio[0]
+            valid = int(lengths[0])
+            if 0 < valid < audio.shape[0]:
+                audio = audio[:valid]
+            torch.cuda.synchronize()
+            yield self._result(audio, segment_idx, int(codes.shape[0]), time.time() - t0)
+
+    def generate_custom_voice(self, text: str, speaker: str, language: str = "auto", instruct: Optional[str] = None, **kw):
+        """``qwen3_tts.py:2062-2137``."""
+        if getattr(self.config, "tts_model_type", "base") != "custom_voice":
+            raise ValueError("generate_custom_voice needs a CustomVoice checkpoint")
+        yield from self.generate(text, voice=speaker, instruct=instruct, lang_code=language, **kw)
+
+    def generate_voice_design(self, text: str, instruct: str, language: str = "auto", **kw):
+        """``qwen3_tts.py:2139-2198``."""
+        if getattr(self.config, "tts_model_type", "base") != "voice_design":
+            raise ValueError("generate_voice_design needs a VoiceDesign checkpoint")
+        yield from self.generate(text, instruct=instruct, lang_code=language, **kw)
+
+    def batch_generate(self, texts: List[str], voices: Optional[List[Optional[str]]] = None, instructs: Optional[List[Optional[str]]] = None,
+                       ref_audio=None, ref_text: Optional[str] = None, ref_audios=None, ref_texts=None, temperature: float = 0.9,
+                       lang_code: str = "auto", max_tokens: int = 4096, top_k: int = 50, top_p: float = 1.0, repetition_penalty: float = 1.05,
+                       stream: bool = False, streaming_interval: float = 2.0, streaming_context_size: int = 25, verbose: bool = False,
+                       **kwargs) -> Generator[BatchGenerationResult, None, None]:
+        """All texts in ONE batched frame loop (``qwen3_tts.py:1651-2060``): left-padded prompts, finished rows emit EOS, per-sequence chunked
+        codec decode; yields one ``BatchGenerationResult`` per sequence in input order."""
+        if self.speech_tokenizer is None:
+            raise ValueError("Speech tokenizer not loaded")
+        if any(v is not None for v in (ref_audio, ref_text, ref_audios, ref_texts)):
+            raise NotImplementedError("in-context voice cloning needs the speech-tokenizer encoder, which this build does not ship")
+        if stream:
+            raise NotImplementedError("batch_generate(stream=True) is not wired to the engine yet")
+        if not texts:
+            return
+        for name, lst in (("voices", voices), ("instructs", instructs)):
+            if lst is not None and len(lst) != len(texts):
+                raise ValueError(f"{name} length ({len(lst)}) must match texts length ({len(texts)})")
+        t0 = time.time()
+        bi = self._prepare_batch_inputs(texts, language=lang_code, speakers=voices, instructs=instructs, return_metadata=True)
+        left = torch.tensor(bi.left_padding, dtype=torch.int32) if len(texts) > 1 else None
+        engine_kw = {k: kwargs[k] for k in ("gumbel0", "gumbel_cp", "forced_codes") if k in kwargs}
+        out = self._frame_loop(bi.input_embeds, bi.trailing_text_hidden, bi.tts_pad_embed, max_tokens, temperature=temperature, top_k=top_k, top_p=top_p,
+                               repetition_penalty=repetition_penalty, left_pad=left, seed=kwargs.get("seed"), **engine_kw)
+        torch.cuda.synchronize()
+        elapsed = time.time() - t0
+        fa = out["finished_at"].cpu()
+        for b in range(len(texts)):
+            n = int(fa[b]) if int(fa[b]) >= 0 else out["codes"].shape[1]
+            if n == 0:
+                continue
+            audio = self._decode_generated_codes(out["codes"][b, :n])
+            yield BatchGenerationResult(audio=audio, sequence_idx=b, samples=int(audio.shape[0]), sample_rate=self.sample_rate, token_count=n,
+                                        audio_duration=format_duration(audio.shape[0] / self.sample_rate), processing_time_seconds=elapsed,
+                                        peak_memory_usage=torch.cuda.max_memory_allocated() / 1e9)
+
+    @classmethod
+    def from_pretrained(cls, path: Union[str, Path]) -> "Model":
+        from ...utils import load
+
+        return load(path)

@@ -154,7 +154,16 @@ class Qwen3Talker:
 
     def generate(self, prefill: torch.Tensor, trailing: torch.Tensor, tts_pad: torch.Tensor, max_frames: int, *, temperature: float = 0.9,
                  top_k: int = 50, top_p: float = 1.0, repetition_penalty: float = 1.05, gumbel0: Optional[torch.Tensor] = None,
-                 gumbel_cp: Optional[torch.Tensor] = None, forced_codes: Optional[torch.Tensor] = None, record: bool = False, poll: int = 16):
+                 gumbel_cp: Optional[torch.Tensor] = None, forced_codes: Optional[torch.Tensor] = None, record: bool = False, poll: int = 16,
+                 left_pad: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None, pad_when_index_clamped: bool = True):
+        """The frame loop (qwen3_tts.py:1860-1935).  ``prefill`` [B, L, H] may be LEFT-padded (``left_pad`` int [B] = padding positions of each
+        row, qwen3_tts.py:536-560): padded keys are invisible and positions count from the first real token, exactly what the reference's
+        attention-mask / cumsum position ids do (talker.py:443-470).  Sampling noise: explicit Gumbel tensors (``gumbel0`` / ``gumbel_cp``, the
+        parity tests), else -- for temperature > 0 -- Gumbel noise drawn on the device from ``generator`` (``mx.random.categorical`` in the
+        reference, qwen3_tts.py:805-925: a different RNG stream, the same distribution); neither = greedy.
+        ``pad_when_index_clamped``: the batched loop's rule for the trailing text (qwen3_tts.py:993-1015, 1894-1900): the LAST trailing position
+        already reads as tts_pad (True, ``batch_generate``); the single-utterance loop feeds every trailing position and pads after it (False,
+        ``generate`` :1388-1394)."""
         cfg = self.cfg
         cp = cfg.code_predictor_config
         dev = self.device
@@ -166,6 +175,9 @@ class Qwen3Talker:
         Tt = trailing.shape[1]
         cache = self.talker.make_cache()
         cp_cache = self.cp.make_cache()
+        k_start = None if left_pad is None else left_pad.to(dev, torch.int32).contiguous()
+        if x.shape[1] + max_frames > self.talker.cos.shape[0]:
+            raise ValueError(f"prompt ({x.shape[1]} positions) + max_frames ({max_frames}) exceeds the talker's {self.talker.cos.shape[0]} rotary positions")
         finished = torch.zeros(B, dtype=torch.int32, device=dev)
         finished_at = torch.full((B,), -1, dtype=torch.int64, device=dev)
         hist = torch.full((B, max_frames + 1), -1, dtype=torch.int32, device=dev)
@@ -176,9 +188,14 @@ class Qwen3Talker:
         forced = None if forced_codes is None else forced_codes.to(dev, torch.int32)
         V0, Vc = cfg.vocab_size, cp.vocab_size
 
+        draw = generator is not None and temperature > 0
+
         def noise(t, V):
             if t is None:
-                return None
+                if not draw:
+                    return None
+                e = torch.empty((B, ops.round_up(V, 4)), dtype=torch.float32, device=dev).exponential_(generator=generator)
+                return -torch.log(e)  # -log(Exp(1)) is Gumbel(0, 1)
             n = torch.zeros((B, ops.round_up(V, 4)), dtype=torch.float32, device=dev)
             n[:, :V] = t.to(dev, torch.float32)
             return n
@@ -186,7 +203,7 @@ class Qwen3Talker:
         trace: List[list] = []
         frames = 0
         for f in range(max_frames):
-            h = self.talker(x, cache)
+            h = self.talker(x, cache, k_start=k_start)
             last = h[:, -1:, :].contiguous()
             logits = self._logits(last, self.codec_head)
             tr = [logits[:, :V0].clone()] if record else None
@@ -238,7 +255,8 @@ class Qwen3Talker:
             # ---- next input: text embed (or tts_pad once the trailing text is exhausted) + sum of the 16 codec embeddings
             clamped = torch.clamp(trailing_idx, max=Tt - 1)
             text = trailing[ar, clamped]
-            text = torch.where((clamped >= Tt - 1)[:, None], pad.expand_as(text), text)
+            exhausted = (clamped >= Tt - 1) if pad_when_index_clamped else (trailing_idx >= Tt)
+            text = torch.where(exhausted[:, None], pad.expand_as(text), text)
             nx = self._f(B, 1, H)
             ops.embed_sum(self.codec_table, row.unsqueeze(1), nx, slot_offset=self.codec_offs, add=text[:, None, :].contiguous())
             x = nx

@@ -102,7 +102,7 @@ class CSMEngine:
 
     def generate_frame(self, tokens: torch.Tensor, tokens_mask: torch.Tensor, *, temperature: float = 0.9, top_k: int = 50,
                        gumbel: Optional[torch.Tensor] = None, forced: Optional[torch.Tensor] = None, trace: Optional[list] = None,
-                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       out: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None) -> torch.Tensor:
         """tokens int [B, S, n_cb + 1], tokens_mask bool [B, S, n_cb + 1] -> sample int32 [B, n_cb] (device)."""
         cfg = self.cfg
         dev = self.device
@@ -119,7 +119,10 @@ class CSMEngine:
 
         def noise(i):
             if gumbel is None:
-                return None
+                if generator is None or temperature <= 0:
+                    return None  # greedy
+                # make_sampler(temp, top_k) -> mx.random.categorical in the reference (sesame.py:767): Gumbel-max with device-drawn noise here
+                return -torch.log(torch.empty((B, Vp), dtype=torch.float32, device=dev).exponential_(generator=generator))
             n = torch.zeros((B, Vp), dtype=torch.float32, device=dev)
             n[:, :V] = gumbel[i].to(dev, torch.float32)
             return n
@@ -159,11 +162,15 @@ class CSMEngine:
         return sample
 
     def generate(self, prompt_tokens: torch.Tensor, prompt_mask: torch.Tensor, max_frames: int, *, temperature: float = 0.9, top_k: int = 50,
-                 gumbel: Optional[torch.Tensor] = None, forced: Optional[torch.Tensor] = None, record: bool = False, poll: int = 16):
+                 gumbel: Optional[torch.Tensor] = None, forced: Optional[torch.Tensor] = None, record: bool = False, poll: int = 16,
+                 generator: Optional[torch.Generator] = None):
         """Frame loop (sesame.py:813-846): frames int64 [B, n, n_cb]; stops at the first all-zero frame (EOS)."""
         cfg = self.cfg
         dev = self.device
         self.reset_caches()
+        max_pos = self.backbone.cos.shape[0]
+        if prompt_tokens.shape[1] + max_frames > max_pos:  # sesame.py:817-820
+            raise ValueError(f"Inputs too long, must be below max_seq_len - max_audio_frames: {max_pos - max_frames}")
         nb = cfg.audio_num_codebooks
         B = prompt_tokens.shape[0]
         frames = torch.zeros((B, max_frames, nb), dtype=torch.int32, device=dev)
@@ -174,7 +181,7 @@ class CSMEngine:
         for f in range(max_frames):
             tr = [] if record else None
             s = self.generate_frame(toks, mask, temperature=temperature, top_k=top_k, gumbel=None if gumbel is None else gumbel[f],
-                                    forced=None if forced is None else forced[:, f], trace=tr, out=frames[:, f, :])
+                                    forced=None if forced is None else forced[:, f], trace=tr, out=frames[:, f, :], generator=generator)
             traces.append(tr)
             toks = torch.cat([s, torch.zeros((B, 1), dtype=torch.int32, device=dev)], dim=1)[:, None, :]
             mask = next_mask

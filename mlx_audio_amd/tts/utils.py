@@ -11,6 +11,10 @@ MODEL_REMAPPING = {
     "kokoro": "kokoro",
     "kokoro_82m": "kokoro",
     "styletts2": "kokoro",
+    "qwen3_tts": "qwen3_tts",
+    "csm": "sesame",
+    "marvis": "sesame",
+    "sesame": "sesame",
 }
 
 

@@ -80,6 +80,10 @@ def get_model_class(model_type: str, model_name: Optional[List[str]], category: 
         msg = f"Model type {model_type} not supported for {category}."
         logging.error(msg)
         raise ValueError(msg)
+    if not hasattr(arch, "Model"):  # a family directory that ships engines but no Model: the reference's error for an unknown type
+        msg = f"Model type {model_type} not supported for {category}."
+        logging.error(msg)
+        raise ValueError(msg)
     return arch, model_type
 
 

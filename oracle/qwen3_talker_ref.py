@@ -95,7 +95,7 @@ class Qwen3TalkerRef:
         return e
 
     def generate(self, prefill: Tensor, trailing: Tensor, tts_pad: Tensor, max_frames: int, *, temperature=0.9, top_k=50, top_p=1.0,
-                 repetition_penalty=1.05, gumbel0=None, gumbel_cp=None, forced_codes=None, record=False):
+                 repetition_penalty=1.05, gumbel0=None, gumbel_cp=None, forced_codes=None, record=False, pad_when_index_clamped=True):
         """prefill [B, L, H] embeddings; trailing [B, Tt, H] text embeddings consumed one per frame, then ``tts_pad`` [1, 1, H].
         gumbel0 [frames, B, V], gumbel_cp [frames, n_groups-1, B, Vcp] (None => arg-max).  Returns dict(codes [B, frames, n_groups],
         finished_at [B] (frame index of the EOS, or -1), trace)."""
@@ -128,7 +128,8 @@ class Qwen3TalkerRef:
             Tt = trailing.shape[1]
             clamped = torch.clamp(trailing_idx, max=Tt - 1)
             text = trailing[torch.arange(B), clamped]
-            exhausted = clamped >= Tt - 1  # pad_when_index_clamped=True (qwen3_tts.py:1006-1011)
+            # qwen3_tts.py:1006-1011: the batched loop pads from the LAST trailing position on; the single-utterance loop (:1388-1394) after it
+            exhausted = (clamped >= Tt - 1) if pad_when_index_clamped else (trailing_idx >= Tt)
             text = torch.where(exhausted[:, None], tts_pad.reshape(1, -1).expand_as(text), text)
             x = (text + self.codec_embeds(codes))[:, None, :]
             trailing_idx = trailing_idx + (~finished).long()

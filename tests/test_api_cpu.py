@@ -18,10 +18,17 @@ def test_registry_is_import_free_and_classifies():
             "r.is_supported_model('whisper'), r.classify_model('whisper'), r.is_supported_model('parakeet'), r.classify_model('qwen3_tts'), "
             "r.classify_model('sesame'), r.classify_model('mimi'))")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout
-    assert out.strip() == "('tts', 'stt', 'codec') tts tts None True stt False tts tts codec"
+    # only loadable things are advertised: a kind needs its utils.py (codec ships decoder engines, no loader), a family its Model
+    assert out.strip() == "('tts', 'stt') tts tts None True stt False tts tts None"
     from mlx_audio_amd import registry
 
     assert "kokoro" in registry.SUPPORTED_MODEL_TYPES["tts"]
+    assert {"qwen3_tts", "sesame", "csm", "marvis"} <= registry.SUPPORTED_MODEL_TYPES["tts"]
+    import importlib
+
+    for kind, fams in registry.SUPPORTED_MODEL_TYPES.items():  # every advertised family really exposes Model (AST-level check, no import of torch)
+        for fam in registry._families(kind):
+            assert registry._exports_model(registry._PKG / kind / "models" / fam), (kind, fam)
     assert registry.supported_model_types("stt") == frozenset({"whisper"})
 
 

@@ -340,6 +340,21 @@ def test_conv_gemm_new_activations(ops, tile):
     exp = _ref_conv(xs, w, bias, 1, pad)
     assert rel_err(run(pre_act=ops.ACT_SNAKE, pre_alpha=al.to(DEV), pre_inv_beta=ib.to(DEV)), exp) < 5e-5
     base = _ref_conv(x, w, bias, 1, pad)
+    assert rel_err(run(colscale=cs.to(DEV), res=resd), base * cs.double() + res.double()) < 5e-5
+    if tile:
+        # the wave-specialised kernel carries one epilogue activation per instantiation, SiLU and GELU-tanh for the linear layers (K = 1:
+        # GEMM mode) that use them (text projection, Mimi / codec transformer MLPs); ELU / tanh epilogues only exist on the 4-wave kernels
+        w1 = (torch.randn(cout, 1, cin, generator=g) / math.sqrt(cin)).to(torch.bfloat16).to(torch.float32)
+        pc1 = ops.pack_conv(w1, bias, DEV)
+        base1 = _ref_conv(x, w1, bias, 1, 0)
+        for act, fn in ((ops.ACT_SILU, F.silu), (ops.ACT_GELU_TANH, lambda t: F.gelu(t, approximate="tanh")), (ops.ACT_GELU, F.gelu)):
+            y = torch.empty(B, L, cout, device=DEV)
+            ops.conv_gemm(xd, pc1, y, tile=tile, post_act=act, colscale=cs.to(DEV), res=resd)
+            torch.cuda.synchronize()
+            assert rel_err(y.cpu(), fn(base1) * cs.double() + res.double()) < 5e-5
+        with pytest.raises(Exception):
+            run(post_act=ops.ACT_TANH)
+        return
     assert rel_err(run(post_act=ops.ACT_SILU), F.silu(base)) < 5e-5
     assert rel_err(run(post_act=ops.ACT_GELU_TANH), F.gelu(base, approximate="tanh")) < 5e-5
     assert rel_err(run(post_act=ops.ACT_ELU), F.elu(base)) < 5e-5

@@ -59,7 +59,5 @@ def host_cores():
 
 
 def step_runner() -> str:
-    """Which decode-step runner mi355_stack_decode_step dispatches to in this process (stack_step.cpp unless MI355_STEP_FUSED=1)."""
-    from mlx_audio_amd import ops
-
-    return "one-launch phase program (mega_step.hip)" if ops.fused_step_enabled() else "multi-launch native runner (stack_step.cpp)"
+    """The decode-step runner behind mi355_stack_decode_step."""
+    return "multi-launch native runner (stack_step.cpp)"

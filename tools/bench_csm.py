@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--prompt", type=int, default=64)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="accepted for symmetry with the other bench lines")
     ap.add_argument("--weights", choices=["bf16", "fp8"], default="bf16")
     args = ap.parse_args()
     fp8 = args.weights == "fp8"

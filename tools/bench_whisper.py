@@ -86,7 +86,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": "Whisper-small, 30 s windows: log-mel + 12-layer encoder + %d greedy decode steps (filters on device)" % args.decode_steps,
                    "windows_per_step": B, "decode_steps": args.decode_steps},
-        "step_runner": ("one-launch phase program (mega_step.hip)" if ops.fused_step_enabled() else "multi-launch native runner (stack_step.cpp)"),
+        "step_runner": "multi-launch native runner (stack_step.cpp)",
         "split_ms": {"logmel": mel_ms, "encoder": enc_ms, "decode": dec_ms},
         "decode_tokens_per_s": B * args.decode_steps / (dec_ms * 1e-3),
         "decode_ms_per_token_step": dec_ms / args.decode_steps,
