@@ -259,6 +259,17 @@ typedef struct {
 } mi355_pool_up2_args;
 int mi355_adain_pool_up2(const mi355_pool_up2_args* a, void* stream);
 
+/* interpolate1d (tts/models/interpolate.py:61-132): x [rows, W] -> y [rows, size] (rows = N * C of the reference's [N, C, W]).
+ * mode 0 = nearest: source index floor(i * scale) with scale = float32(W / size); mode 1 = linear with torch semantics: source coordinate
+ * i * scale + half_scale - 0.5 clamped at 0 (scale = float32(W / size), half_scale = float32(0.5 * W / size)), or i * scale with
+ * scale = float32((W - 1) / (size - 1)) when align_corners; every step rounded to float32 like the MLX op sequence. */
+typedef struct {
+  const float* x; int64_t x_rstride; int32_t W; int64_t rows;
+  int32_t size; int32_t mode; int32_t align_corners; float scale; float half_scale;
+  float* y; int64_t y_rstride;
+} mi355_interp1d_args;
+int mi355_interpolate1d(const mi355_interp1d_args* a, void* stream);
+
 /* Scalar strided conv (1 -> 1 channel, k3, stride 2, pad 1) writing one column of a wider buffer:
  * Decoder.F0_conv / N_conv (istftnet.py:973-974,983-984).  x [B, Lin], y[b, l, col]. */
 int mi355_conv1d_c1_k3s2(const float* x, int32_t ldx_b, int32_t Lin, const int32_t* lens_in,

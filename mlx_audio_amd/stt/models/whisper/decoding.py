@@ -77,15 +77,35 @@ def _verify_options(options: DecodingOptions) -> DecodingOptions:
         raise ValueError("length_penalty (alpha) should be a value between 0 and 1")
     if options.beam_size is not None:
         raise NotImplementedError("Beam search decoder is not yet implemented")  # decoding.py:478-479
-    if options.temperature != 0:
-        raise NotImplementedError("temperature > 0 needs explicit noise: use WhisperEngine.decode(gumbel=...)")
-    if options.prompt or options.prefix:
-        raise NotImplementedError("prompt / prefix conditioning is not wired to the device loop yet")
     return options
 
 
-def decode(model, mel: torch.Tensor, options: DecodingOptions = DecodingOptions(), **kwargs):
-    """decoding.py:702-735: mel ``[n_frames, n_mels]`` or ``[*, n_frames, n_mels]`` (or already-encoded features)."""
+def initial_tokens(tok, options: DecodingOptions, n_ctx: int, sample_len: int) -> List[int]:
+    """decoding.py:525-551: ``[sot_prev] + prompt[-(n_ctx // 2 - 1):] + sot_sequence + prefix[-(n_ctx // 2 - sample_len):]``."""
+    tokens = list(tok.sot_sequence_including_notimestamps if options.without_timestamps else tok.sot_sequence)
+    if options.prefix:
+        prefix = tok.encode(" " + options.prefix.strip()) if isinstance(options.prefix, str) else list(options.prefix)
+        tokens = tokens + prefix[-(n_ctx // 2 - sample_len):]
+    if options.prompt:
+        prompt = tok.encode(" " + options.prompt.strip()) if isinstance(options.prompt, str) else list(options.prompt)
+        tokens = [tok.sot_prev] + prompt[-(n_ctx // 2 - 1):] + tokens
+    return [int(t) for t in tokens]
+
+
+def rank_group(tokens: List[List[int]], sum_logprobs: List[float], length_penalty: Optional[float]) -> int:
+    """MaximumLikelihoodRanker (decoding.py:212-235): highest sum-logprob over length (or over the Google-NMT penalty)."""
+    scores = []
+    for t, lp in zip(tokens, sum_logprobs):
+        length = len(t)
+        penalty = length if length_penalty is None else ((5 + length) / 6) ** length_penalty
+        with np.errstate(divide="ignore", invalid="ignore"):
+            scores.append(np.float64(lp) / penalty)
+    return int(np.argmax(scores))
+
+
+def decode(model, mel: torch.Tensor, options: DecodingOptions = DecodingOptions(), generator: Optional[torch.Generator] = None, **kwargs):
+    """decoding.py:702-735: mel ``[n_frames, n_mels]`` or ``[*, n_frames, n_mels]`` (or already-encoded features).  ``generator`` seeds the
+    device noise of ``temperature > 0`` sampling (the reference draws from MLX's global key)."""
     if single := mel.dim() == 2:
         mel = mel[None]
     if kwargs:
@@ -93,22 +113,29 @@ def decode(model, mel: torch.Tensor, options: DecodingOptions = DecodingOptions(
     options = _verify_options(options)
     tok = model.get_tokenizer(language=options.language or "en", task=options.task)
     d = model.dims
-    feats = None
-    if tuple(mel.shape[-2:]) == (d.n_audio_ctx, d.n_audio_state):
-        feats, mel = mel, None
+    sample_len = options.sample_len or d.n_text_ctx // 2
+    initial = initial_tokens(tok, options, d.n_text_ctx, sample_len)
+    n_group = options.best_of or 1
+    feats = mel if tuple(mel.shape[-2:]) == (d.n_audio_ctx, d.n_audio_state) else model.engine.encode(mel.to(model.engine.device))
+    n_audio = feats.shape[0]
+    run_feats = feats.repeat_interleave(n_group, dim=0) if n_group > 1 else feats
     suppress = get_suppress_tokens(tok, options.suppress_tokens) if options.suppress_tokens else None
-    out = model.engine.decode(mel, tok, sample_len=options.sample_len, without_timestamps=options.without_timestamps,
+    out = model.engine.decode(None, tok, sample_len=sample_len, without_timestamps=options.without_timestamps,
                               suppress_blank=options.suppress_blank, suppress_tokens=suppress,
-                              max_initial_timestamp=options.max_initial_timestamp, audio_features=feats)
+                              max_initial_timestamp=options.max_initial_timestamp, audio_features=run_feats, initial_tokens=initial,
+                              temperature=float(options.temperature), generator=generator)
     sb = out["sample_begin"]
     toks = torch.nn.functional.pad(out["tokens"], (0, 1), value=tok.eot)[:, sb:].cpu().tolist()  # GreedyDecoder.finalize
+    toks = [t[: t.index(tok.eot)] for t in toks]
     sums = out["sum_logprobs"].cpu().tolist()
     nsp = out["no_speech_probs"].cpu().tolist()
     results = []
-    for i, t in enumerate(toks):
-        t = t[: t.index(tok.eot)]
+    for a in range(n_audio):
+        grp = slice(a * n_group, (a + 1) * n_group)
+        sel = a * n_group + (rank_group(toks[grp], sums[grp], options.length_penalty) if n_group > 1 else 0)
+        t = toks[sel]
         text = tok.decode(t).strip()
-        results.append(DecodingResult(audio_features=out["audio_features"][i], language=options.language or "en", tokens=t, text=text,
-                                      avg_logprob=sums[i] / (len(t) + 1), no_speech_prob=nsp[i], temperature=options.temperature,
+        results.append(DecodingResult(audio_features=feats[a], language=options.language or "en", tokens=t, text=text,
+                                      avg_logprob=sums[sel] / (len(t) + 1), no_speech_prob=nsp[a * n_group], temperature=options.temperature,
                                       compression_ratio=compression_ratio(text)))
     return results[0] if single else results

@@ -275,13 +275,17 @@ class WhisperEngine:
     def decode(self, mel: Optional[torch.Tensor], tok, *, sample_len: Optional[int] = None, without_timestamps: bool = False,
                suppress_blank: bool = True, suppress_tokens: Optional[Sequence[int]] = None, max_initial_timestamp: Optional[float] = 1.0,
                forced_tokens: Optional[torch.Tensor] = None, audio_features: Optional[torch.Tensor] = None, record: bool = False,
-               poll: int = 16, fixed_steps: bool = False):
+               poll: int = 16, fixed_steps: bool = False, initial_tokens: Optional[Sequence[int]] = None, temperature: float = 0.0,
+               generator: Optional[torch.Generator] = None):
+        """``initial_tokens``: the full initial sequence (``[sot_prev] + prompt + sot_sequence + prefix``, decoding.py:525-551) when the caller
+        conditions on a prompt; ``temperature`` > 0 samples ``categorical(logits / T)`` (decoding.py:266-269) as an arg-max over
+        ``logits / T + Gumbel(0, 1)`` with the noise drawn on the device from ``generator``."""
         d = self.dims
         xa = self.encode(mel) if audio_features is None else audio_features.to(self.device, torch.float32)
         B = xa.shape[0]
         dev = self.device
         sot_sequence = tok.sot_sequence_including_notimestamps if without_timestamps else tok.sot_sequence
-        initial = list(sot_sequence)
+        initial = list(sot_sequence) if initial_tokens is None else [int(t) for t in initial_tokens]
         sample_begin = len(initial)
         sot_index = initial.index(tok.sot)
         sample_len = sample_len or d.n_text_ctx // 2
@@ -318,11 +322,17 @@ class WhisperEngine:
             else:
                 hid = self.decoder_step(tokens[:, n - 1:n], st)
                 lg = self.logits(hid)[:, 0, :]
+            gumbel = None
+            if temperature > 0:
+                if lg.stride(0) != lg.shape[1]:
+                    lg = lg.contiguous()  # the noise shares the logits' row stride: do not draw it for the whole prompt block
+                u = torch.rand(lg.shape, dtype=torch.float32, device=dev, generator=generator).clamp_(1e-20, 1.0 - 1e-7)
+                gumbel = u.log_().neg_().log_().neg_()
             filt = torch.empty((B, lg.stride(0)), dtype=torch.float32, device=dev) if record else None  # same row stride as lg
             ops.whisper_greedy_step(lg, tokens, n, sample_begin, sum_logprobs, V=d.n_vocab, suppress_mask=smask, blank_ids=blank,
                                     timestamp_rules=ts_rules, timestamp_begin=tok.timestamp_begin, eot=tok.eot,
                                     no_timestamps=-1 if tok.no_timestamps is None else tok.no_timestamps,
-                                    max_initial_timestamp_index=max_idx, filtered=filt,
+                                    max_initial_timestamp_index=max_idx, filtered=filt, gumbel=gumbel, temperature=float(temperature),
                                     forced_next=None if forced is None else forced[i])
             if record:
                 trace.append(dict(raw=lg[:, :d.n_vocab].clone(), filtered=filt[:, :d.n_vocab]))

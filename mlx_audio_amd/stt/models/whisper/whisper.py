@@ -7,10 +7,14 @@ Same as the reference: constructor / config (``ModelDimensions`` incl. the Huggi
 and its ``DecodingResult``, ``generate(audio, *, language, task, temperature, ..., **decode_options)`` returning
 ``STTOutput(text, segments, language, ...)`` with 30 s windows advanced by the decoded timestamps.
 
-Deliberately not carried over (host front/back ends): file / stdin loading and resampling
-(``generate`` takes a waveform array at 16 kHz), word-level timestamps (DTW over cross-attention weights), streaming
-(AlignAtt), language detection by probability dict (``detect_language`` returns the arg-max language only), sampling
-fallback temperatures > 0 (the device loop is greedy; the fallback tuple collapses to its first entry).
+``generate`` follows the reference's window loop: each 30 s window holds only its own frames (zero-padded in the log-mel domain),
+temperature fallback over the ``temperature`` tuple (sampling = arg-max of ``logits / T`` + device Gumbel noise in the decode-rules kernel,
+``best_of`` groups ranked like ``MaximumLikelihoodRanker``), prompt conditioning on the previous windows / ``initial_prompt`` / ``hotwords``,
+``clip_timestamps``, segment cutting at consecutive timestamps.
+
+Deliberately not carried over (host front/back ends): resampling of non-16 kHz files, word-level timestamps and
+``hallucination_silence_threshold`` (DTW over cross-attention weights), streaming (AlignAtt) -- these raise ``NotImplementedError`` --
+and language detection by probability dict (``detect_language`` returns the arg-max language only).
 """
 from __future__ import annotations
 
@@ -174,10 +178,20 @@ class Model:
                  compression_ratio_threshold: Optional[float] = 2.4, logprob_threshold: Optional[float] = -1.0,
                  no_speech_threshold: Optional[float] = 0.6, condition_on_previous_text: bool = True,
                  initial_prompt: Optional[str] = None, return_timestamps: bool = True, word_timestamps: bool = False,
-                 clip_timestamps: Union[str, List[float]] = "0", **decode_options) -> STTOutput:
-        if word_timestamps:
-            raise NotImplementedError("word_timestamps (DTW over cross-attention) is outside the MI355X hot path")
+                 clip_timestamps: Union[str, List[float]] = "0", hallucination_silence_threshold: Optional[float] = None,
+                 hotwords: Optional[List[str]] = None, stream: bool = False, generator: Optional[torch.Generator] = None,
+                 **decode_options) -> STTOutput:
+        """whisper.py:799-1320.  Windows, temperature fallback, prompt conditioning and segment cutting follow the reference; the options that
+        need word-level alignment (``word_timestamps``, ``hallucination_silence_threshold``) and ``stream`` raise instead of being ignored."""
+        if word_timestamps or hallucination_silence_threshold is not None:
+            raise NotImplementedError("word_timestamps / hallucination_silence_threshold (DTW over cross-attention) are outside the MI355X hot path")
+        if stream:
+            raise NotImplementedError("generate(stream=True) is outside the MI355X hot path")
         t_start = time.time()
+        if hotwords:  # stt/utils.py:15-34: the vocabulary list is folded into the prompt
+            terms = ", ".join(str(t).strip() for t in hotwords if t is not None and str(t).strip())
+            if terms:
+                initial_prompt = f"{initial_prompt}\n{terms}" if initial_prompt else terms
         decode_options = _filter_decode_options(decode_options)
         decode_options["without_timestamps"] = not return_timestamps
         mel, content_frames = self._prepare_audio(audio)
@@ -190,54 +204,114 @@ class Model:
                 language = LANGUAGES[lang_tok - tok0.sot - 1]
         decode_options.update(language=language, task=task)
         tokenizer = self.get_tokenizer(language=language, task=task)
-        t0 = temperature if isinstance(temperature, (int, float)) else temperature[0]
+
+        if isinstance(clip_timestamps, str):  # whisper.py:937-950
+            clip_timestamps = [float(ts) for ts in (clip_timestamps.split(",") if clip_timestamps else [])]
+        seek_points = [round(ts * FRAMES_PER_SECOND) for ts in clip_timestamps]
+        if len(seek_points) == 0:
+            seek_points.append(0)
+        if len(seek_points) % 2 == 1:
+            seek_points.append(content_frames)
+        else:
+            seek_points[-1] = min(content_frames, seek_points[-1])
+        seek_clips = list(zip(seek_points[::2], seek_points[1::2]))
+
+        def decode_with_fallback(segment: torch.Tensor) -> DecodingResult:
+            """whisper.py:957-996: retry at the next temperature while the text is too repetitive or too unlikely, unless it is silence."""
+            temperatures = [temperature] if isinstance(temperature, (int, float)) else list(temperature)
+            result = None
+            for t in temperatures:
+                kw = dict(decode_options)
+                if t > 0:
+                    kw.pop("beam_size", None)
+                    kw.pop("patience", None)
+                else:
+                    kw.pop("best_of", None)
+                result = self.decode(segment, DecodingOptions(**kw, temperature=float(t)), generator=generator)
+                needs_fallback = False
+                if compression_ratio_threshold is not None and result.compression_ratio > compression_ratio_threshold:
+                    needs_fallback = True
+                if logprob_threshold is not None and result.avg_logprob < logprob_threshold:
+                    needs_fallback = True
+                if no_speech_threshold is not None and result.no_speech_prob > no_speech_threshold:
+                    needs_fallback = False
+                if not needs_fallback:
+                    break
+            return result
+
         input_stride = N_FRAMES // self.dims.n_audio_ctx
         time_precision = input_stride * HOP_LENGTH / SAMPLE_RATE
-        seek = 0
         all_tokens: List[int] = []
         segments: List[dict] = []
-        while seek < content_frames:
-            time_offset = seek * HOP_LENGTH / SAMPLE_RATE
-            segment_size = min(N_FRAMES, content_frames - seek)
-            seg = pad_or_trim(mel[seek:seek + N_FRAMES], N_FRAMES, axis=-2)
-            result: DecodingResult = self.decode(seg, DecodingOptions(**decode_options, temperature=float(t0)))
-            tokens = result.tokens
-            if no_speech_threshold is not None and result.no_speech_prob > no_speech_threshold and not (
-                    logprob_threshold is not None and result.avg_logprob > logprob_threshold):
-                seek += segment_size  # silent window (whisper.py:1139-1151)
-                continue
-            ts = [i for i, t in enumerate(tokens) if t >= tokenizer.timestamp_begin]
-            consecutive = [i for i in range(1, len(tokens)) if tokens[i] >= tokenizer.timestamp_begin and tokens[i - 1] >= tokenizer.timestamp_begin]
-            single_ending = len(tokens) >= 2 and tokens[-2] < tokenizer.timestamp_begin <= tokens[-1]
+        prompt_reset_since = 0
+        initial_prompt_tokens: List[int] = []
+        if initial_prompt is not None:
+            initial_prompt_tokens = list(tokenizer.encode(" " + initial_prompt.strip()))
+            all_tokens.extend(initial_prompt_tokens)
+        seek = seek_clips[0][0]
+        for _, seek_clip_end in seek_clips:
+            while seek < seek_clip_end:
+                time_offset = float(seek * HOP_LENGTH / SAMPLE_RATE)
+                segment_size = min(N_FRAMES, content_frames - seek, seek_clip_end - seek)
+                # whisper.py:1046-1050: only THIS window's frames, padded with 0.0 in the log-mel domain (not the audio that follows)
+                seg = pad_or_trim(mel[seek:seek + segment_size], N_FRAMES, axis=-2)
+                decode_options["prompt"] = all_tokens[prompt_reset_since:]
+                result: DecodingResult = decode_with_fallback(seg)
+                tokens = list(result.tokens)
+                if no_speech_threshold is not None:
+                    should_skip = result.no_speech_prob > no_speech_threshold
+                    if logprob_threshold is not None and result.avg_logprob > logprob_threshold:
+                        should_skip = False
+                    if should_skip:
+                        seek += segment_size  # silent window (whisper.py:1056-1069)
+                        continue
+                current: List[dict] = []
+                ts = [i for i, t in enumerate(tokens) if t >= tokenizer.timestamp_begin]
+                consecutive = [i for i in range(1, len(tokens))
+                               if tokens[i] >= tokenizer.timestamp_begin and tokens[i - 1] >= tokenizer.timestamp_begin]
+                single_ending = len(tokens) >= 2 and tokens[-2] < tokenizer.timestamp_begin <= tokens[-1]
 
-            def seg_dict(start, end, toks):
-                return dict(seek=seek, start=start, end=end, text=tokenizer.decode([t for t in toks if t < tokenizer.eot]), tokens=list(toks),
-                            temperature=result.temperature, avg_logprob=result.avg_logprob, compression_ratio=result.compression_ratio,
-                            no_speech_prob=result.no_speech_prob)
+                def seg_dict(start, end, toks, _seek=seek, _result=result):
+                    return dict(seek=_seek, start=float(start), end=float(end), text=tokenizer.decode([t for t in toks if t < tokenizer.eot]),
+                                tokens=list(toks), temperature=_result.temperature, avg_logprob=_result.avg_logprob,
+                                compression_ratio=_result.compression_ratio, no_speech_prob=_result.no_speech_prob)
 
-            if consecutive:  # whisper.py:1166-1199: cut at consecutive timestamp pairs
-                slices = consecutive + ([len(tokens)] if single_ending else [])
-                last = 0
-                for cur in slices:
-                    sl = tokens[last:cur]
-                    s_pos = sl[0] - tokenizer.timestamp_begin
-                    e_pos = sl[-1] - tokenizer.timestamp_begin
-                    segments.append(seg_dict(time_offset + s_pos * time_precision, time_offset + e_pos * time_precision, sl))
-                    last = cur
-                if single_ending:
-                    seek += segment_size
+                if consecutive:  # whisper.py:1144-1170: cut at consecutive timestamp pairs
+                    slices = consecutive + ([len(tokens)] if single_ending else [])
+                    last = 0
+                    for cur in slices:
+                        sl = tokens[last:cur]
+                        s_pos = sl[0] - tokenizer.timestamp_begin
+                        e_pos = sl[-1] - tokenizer.timestamp_begin
+                        current.append(seg_dict(time_offset + s_pos * time_precision, time_offset + e_pos * time_precision, sl))
+                        last = cur
+                    if single_ending:
+                        seek += segment_size
+                    else:
+                        seek += (tokens[last - 1] - tokenizer.timestamp_begin) * input_stride
                 else:
-                    seek += (tokens[last - 1] - tokenizer.timestamp_begin) * input_stride
-            else:
-                duration = segment_size * HOP_LENGTH / SAMPLE_RATE
-                if ts and tokens[ts[-1]] != tokenizer.timestamp_begin:
-                    duration = (tokens[ts[-1]] - tokenizer.timestamp_begin) * time_precision
-                segments.append(seg_dict(time_offset, time_offset + duration, tokens))
-                seek += segment_size
-            all_tokens.extend(tokens)
+                    duration = segment_size * HOP_LENGTH / SAMPLE_RATE
+                    if ts and tokens[ts[-1]] != tokenizer.timestamp_begin:
+                        duration = (tokens[ts[-1]] - tokenizer.timestamp_begin) * time_precision
+                    current.append(seg_dict(time_offset, time_offset + duration, tokens))
+                    seek += segment_size
+                if verbose:
+                    for sgm in current:
+                        print(f"[{sgm['start']:.3f} --> {sgm['end']:.3f}] {sgm['text']}")
+                for sgm in current:  # whisper.py:1269-1277: instantaneous or empty segments are cleared
+                    if sgm["start"] == sgm["end"] or sgm["text"].strip() == "":
+                        sgm["text"] = ""
+                        sgm["tokens"] = []
+                        sgm["words"] = []
+                segments.extend({"id": i, **sgm} for i, sgm in enumerate(current, start=len(segments)))
+                all_tokens.extend(t for sgm in current for t in sgm["tokens"])
+                if not condition_on_previous_text or result.temperature > 0.5:
+                    prompt_reset_since = len(all_tokens)  # whisper.py:1298-1300
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         total = time.time() - t_start
-        text = tokenizer.decode([t for t in all_tokens if t < tokenizer.eot])
-        return STTOutput(text=text.strip(), segments=segments, language=language, generation_tokens=len(all_tokens), total_tokens=len(all_tokens),
-                         generation_tps=len(all_tokens) / total if total > 0 else 0.0, total_time=total)
+        out_tokens = all_tokens[len(initial_prompt_tokens):]
+        text = tokenizer.decode([t for t in out_tokens if t < tokenizer.eot])
+        n_gen = len(out_tokens)
+        return STTOutput(text=text.strip(), segments=segments, language=language, generation_tokens=n_gen, total_tokens=len(all_tokens),
+                         generation_tps=n_gen / total if total > 0 else 0.0, total_time=total)

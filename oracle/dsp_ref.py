@@ -290,6 +290,26 @@ def whisper_log_mel(audio, n_mels: int = 80, padding: int = 0) -> np.ndarray:
     return ((log_spec + F32(4.0)) / F32(4.0)).astype(F32)
 
 
+def whisper_log_mel_f64(audio, n_mels: int = 80, padding: int = 0) -> np.ndarray:
+    """The same chain evaluated entirely in float64 (window, framing, DFT, power, filterbank, log10, clamp): the value both the reference's
+    float32 pipeline and the device kernel approximate.  Used as the yardstick on the speech fixture (tests/golden/*.wav)."""
+    audio = np.asarray(audio, dtype=np.float64)
+    if padding > 0:
+        audio = np.concatenate([audio, np.zeros(padding)])
+    n_fft, hop = 400, 160
+    w = 0.5 * (1.0 - np.cos(2.0 * np.pi * np.arange(n_fft) / (n_fft - 1)))  # audio.py:72: hanning(N_FFT), the symmetric form (dsp.py:40-50)
+    x = np.pad(audio, n_fft // 2, mode="reflect")
+    n = 1 + (len(x) - n_fft) // hop
+    idx = np.arange(n)[:, None] * hop + np.arange(n_fft)[None, :]
+    spec = np.fft.rfft(x[idx] * w[None, :], axis=-1)
+    mags = np.abs(spec[:-1]) ** 2
+    fb = mel_filters(16000, 400, n_mels, norm="slaney", mel_scale=None).astype(np.float64)
+    log_spec = np.log10(np.maximum(mags @ fb.T, 1e-10))
+    log_spec = np.maximum(log_spec, log_spec.max() - 8.0)
+    return (log_spec + 4.0) / 4.0
+
+
+
 def qwen3_mel_spectrogram(
     audio,
     n_fft: int = 1024,

@@ -182,8 +182,12 @@ class WhisperRef:
     def decode(self, mel: Tensor, tok: TokenizerSpec, *, sample_len: Optional[int] = None, without_timestamps: bool = False,
                suppress_blank: bool = True, suppress_tokens: Optional[Sequence[int]] = None,
                max_initial_timestamp: Optional[float] = 1.0, forced_tokens: Optional[Tensor] = None, audio_features=None,
-               record: bool = False):
-        """DecodingTask.run / _main_loop (decoding.py:588-632, 634-700) for temperature 0, no prefix / prompt.
+               record: bool = False, initial_tokens: Optional[Sequence[int]] = None, temperature: float = 0.0, gumbel=None):
+        """DecodingTask.run / _main_loop (decoding.py:588-632, 634-700).
+
+        ``initial_tokens``: the initial sequence when a prompt / prefix is given (decoding.py:525-551; default = the sot sequence).
+        ``temperature`` > 0 with ``gumbel`` (callable step -> [B, V] Gumbel(0, 1) noise): ``categorical(logits / T)`` (decoding.py:266-269)
+        drawn as ``argmax(logits / T + g)``, so that a test can hand both implementations the same noise.
 
         ``forced_tokens`` [B, steps] (optional): teacher forcing -- the tokens appended at each step are taken from
         here instead of the arg-max (the filters and log-probs are still evaluated), which lets a test compare the
@@ -194,7 +198,7 @@ class WhisperRef:
         xa = self.encoder(mel) if audio_features is None else audio_features.to(self.dtype)
         B = xa.shape[0]
         sot_sequence = tok.sot_sequence_including_notimestamps if without_timestamps else tok.sot_sequence
-        initial = tuple(sot_sequence)
+        initial = tuple(sot_sequence) if initial_tokens is None else tuple(int(t) for t in initial_tokens)
         sample_begin = len(initial)
         sot_index = initial.index(tok.sot)
         sample_len = sample_len or d.n_text_ctx // 2
@@ -227,6 +231,8 @@ class WhisperRef:
             for f in filters:
                 logits = f.apply(logits, tokens)
             forced = None if forced_tokens is None else forced_tokens[:, i]
+            if forced is None and temperature > 0:
+                forced = (logits / temperature + gumbel(i).to(logits.dtype)).argmax(dim=-1)
             tokens, completed, sum_logprobs = dec.update(tokens, logits, sum_logprobs, forced)
             if record:
                 trace.append(dict(raw=raw, filtered=logits.clone()))

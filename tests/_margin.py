@@ -1,0 +1,37 @@
+"""The "margin rule" of the free-running decode parity tests, in one place, with its cost made visible.
+
+Two float32 builds of the same network (device kernels vs the CPU oracle) differ by ~1e-4 in the logits, so an arg-max / Gumbel-max decision
+whose top-2 gap is below ``thr`` may legitimately fall either way -- and every later decision of that sequence then runs on a different
+context.  ``walk`` therefore compares a sequence's decisions in generation order up to (not including) its first knife-edge decision, records how
+many decisions that left uncompared, and the session prints the totals (tests/conftest.py: ``pytest_terminal_summary``) so that the fraction of
+free-running steps hidden behind the rule is a reported number with a bound, not an unknown.  Teacher-forced tests compare every step.
+"""
+from typing import Dict, List, Sequence
+
+REPORT: Dict[str, List[int]] = {}  # family -> [compared, skipped, knife_edges_hit, sequences]
+
+
+def walk(family: str, got: Sequence[int], exp: Sequence[int], margins: Sequence[float], thr: float = 1e-2, where=None) -> int:
+    """Asserts ``got[i] == exp[i]`` for every decision before the first one with ``margins[i] < thr``; returns the number compared."""
+    n = min(len(got), len(exp), len(margins))
+    compared = n
+    for i in range(n):
+        if float(margins[i]) < thr:
+            compared = i
+            break
+        assert int(got[i]) == int(exp[i]), (family, where, i, int(got[i]), int(exp[i]))
+    r = REPORT.setdefault(family, [0, 0, 0, 0])
+    r[0] += compared
+    r[1] += n - compared
+    r[2] += int(compared < n)
+    r[3] += 1
+    return compared
+
+
+def summary_lines() -> List[str]:
+    out = []
+    for fam, (c, s, k, n) in sorted(REPORT.items()):
+        tot = max(c + s, 1)
+        out.append(f"margin rule [{fam}]: {c}/{c + s} free-running decisions compared bit-exactly ({100.0 * c / tot:.1f} %), "
+                   f"{s} after a knife edge ({100.0 * s / tot:.1f} %), {k}/{n} sequences hit one")
+    return out

@@ -8,6 +8,13 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+import _margin  # noqa: E402  (tests/_margin.py: the knife-edge rule and its accounting)
+
+
+def _gap(logits):
+    top2 = torch.topk(logits, 2).values
+    return top2[0] - top2[1]
 DEV = "cuda"
 
 
@@ -77,21 +84,11 @@ def test_qwen3_frame_loop_free_running_greedy(talker):
     got = talker["eng"].generate(talker["pre"], talker["trail"], talker["pad"], frames, temperature=0.0, poll=2)
     torch.cuda.synchronize()
     ec, gc = exp["codes"], got["codes"].cpu()
+    nf = min(ec.shape[1], gc.shape[1])
     for b in range(ec.shape[0]):
-        # walk the decisions in generation order; stop comparing a sequence at its first knife-edge (margin < 1e-2) decision
-        ok = True
-        for f in range(ec.shape[1]):
-            for i in range(ec.shape[2]):
-                if not ok:
-                    break
-                lg = exp["trace"][f][i][b]
-                if i == 0:  # first codebook: decision is taken on the filtered logits; approximate the margin on the raw ones
-                    pass
-                top2 = torch.topk(lg, 2).values
-                if float(top2[0] - top2[1]) < 1e-2:
-                    ok = False
-                    break
-                assert int(gc[b, f, i]) == int(ec[b, f, i]), (b, f, i)
+        # decisions in generation order; a sequence is compared up to its first knife-edge (top-2 gap < 1e-2) decision (tests/_margin.py)
+        margins = [float(_gap(exp["trace"][f][i][b])) for f in range(nf) for i in range(ec.shape[2])]
+        _margin.walk("qwen3_tts", gc[b, :nf].flatten().tolist(), ec[b, :nf].flatten().tolist(), margins, where=("talker", b))
 
 
 @pytest.fixture(scope="module")
@@ -138,17 +135,8 @@ def test_csm_free_running_greedy_and_eos(csm):
     ef, gf = exp["frames"], got["frames"].cpu()
     assert gf.shape == ef.shape
     for b in range(ef.shape[0]):
-        ok = True
-        for f in range(ef.shape[1]):
-            for i in range(ef.shape[2]):
-                top2 = torch.topk(exp["trace"][f][i][b], 2).values
-                if float(top2[0] - top2[1]) < 1e-2:
-                    ok = False
-                if not ok:
-                    break
-                assert int(gf[b, f, i]) == int(ef[b, f, i]), (b, f, i)
-            if not ok:
-                break
+        margins = [float(_gap(exp["trace"][f][i][b])) for f in range(ef.shape[1]) for i in range(ef.shape[2])]
+        _margin.walk("csm", gf[b].flatten().tolist(), ef[b].flatten().tolist(), margins, where=("csm", b))
     # EOS: an all-zero frame stops the loop and is not returned (sesame.py:828)
     forced = torch.zeros(csm["B"], 2, csm["cfg"].audio_num_codebooks, dtype=torch.long)
     forced[:, 0] = 5

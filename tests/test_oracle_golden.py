@@ -210,3 +210,22 @@ def test_mimi_decode_shape_pin():
     y20 = ref(codes[:, :, :20])
     assert tuple(y20.shape) == (1, 1, 20 * 1920)
     np.testing.assert_allclose(y20.numpy(), y[..., : 20 * 1920].numpy(), rtol=0, atol=2e-5 * float(y.abs().max()))
+
+
+def test_whisper_log_mel_oracle_on_speech_fixture():
+    """tests/golden/genesis_1_1_af_heart_16k.wav (made by tests/golden/make_wav_fixture.py from a clip the reference ships): the float32
+    restatement of audio.py:41-82 stays within 5e-5 of the all-float64 evaluation on real speech with 30 s of padding -- the yardstick the device
+    kernel is held to in tests/test_whisper_gpu.py."""
+    import os
+
+    import scipy.io.wavfile as wavfile
+
+    sr, x = wavfile.read(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "genesis_1_1_af_heart_16k.wav"))
+    assert sr == 16000 and x.dtype == np.int16 and x.shape == (105600,)
+    a = (x / 32768.0).astype(np.float32)
+    m32 = dsp_ref.whisper_log_mel(a, padding=480000)
+    m64 = dsp_ref.whisper_log_mel_f64(a, padding=480000)
+    assert m32.shape == m64.shape == (3660, 80)
+    assert np.abs(m32 - m64).max() < 5e-5
+    assert abs(float(m64.max()) - float(m64.min()) - 2.0) < 1e-9          # the (max - 8) floor is active: padding frames sit on it
+    assert 0.05 < float((m64 > m64.min() + 1e-9).mean()) < 0.5            # and the speech frames are above it
