@@ -119,45 +119,6 @@ __global__ void conv1d_c1_k3s2_kernel(const float* x, int ldxb, int Lin, const i
   y[(int64_t)b * ybs + (int64_t)l * ldy + col] = s + bias;
 }
 
-// ---------------------------------------------------------------------------------------------- interpolate1d
-// tts/models/interpolate.py:61-132: nearest = floor(i * W/size) clipped; linear with torch semantics (half-pixel source coordinate clamped at 0,
-// or align_corners).  The coordinate arithmetic is float32 with one rounding per operation, exactly the MLX op sequence (arange * scalar, + scalar,
-// - 0.5, maximum): the intrinsics keep hipcc from contracting it into FMAs (SineGen multiplies these index roundings by phase slopes of hundreds
-// of radians).  One thread per output element, rows = N * C.
-__global__ __launch_bounds__(256) void interpolate1d_kernel(const mi355_interp1d_args a) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.rows * (int64_t)a.size) return;
-  const int64_t r = i / a.size;
-  const int o = (int)(i - r * a.size);
-  const float* xr = a.x + r * a.x_rstride;
-  float* yr = a.y + r * a.y_rstride;
-  const int W = a.W;
-  if (a.mode == 0) {  // nearest
-    int idx = a.size == 1 ? 0 : (int)floorf(__fmul_rn((float)o, a.scale));
-    idx = idx < 0 ? 0 : (idx > W - 1 ? W - 1 : idx);
-    yr[o] = xr[idx];
-    return;
-  }
-  if (W == 1) { yr[o] = xr[0]; return; }
-  float x;
-  if (a.align_corners && a.size > 1) x = __fmul_rn((float)o, a.scale);
-  else if (a.size == 1) x = 0.f;
-  else {
-    x = __fmul_rn((float)o, a.scale);
-    if (!a.align_corners) {
-      x = __fadd_rn(x, a.half_scale);
-      x = __fsub_rn(x, 0.5f);
-      x = fmaxf(x, 0.f);
-    }
-  }
-  const int lo = (int)floorf(x);
-  const int hi = lo + 1 < W - 1 ? lo + 1 : W - 1;
-  const float frac = __fsub_rn(x, (float)lo);
-  const float lo_term = __fmul_rn(xr[lo < W ? lo : W - 1], __fsub_rn(1.0f, frac));
-  const float hi_term = __fmul_rn(xr[hi], frac);
-  yr[o] = __fadd_rn(lo_term, hi_term);
-}
-
 }  // namespace
 
 extern "C" int mi355_gather_rows(const mi355_gather_rows_args* ap, void* stream) {
@@ -209,16 +170,5 @@ extern "C" int mi355_conv1d_c1_k3s2(const float* x, int32_t ldx_b, int32_t Lin, 
   hipLaunchKernelGGL(conv1d_c1_k3s2_kernel, dim3((Lout + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, ldx_b, Lin,
                      lens_in, w0, w1, w2, bias, y, y_bstride, ldy, col, Lout, B);
   MI355_LAUNCH_CHECK("conv1d_c1_k3s2");
-  return MI355_OK;
-}
-
-extern "C" int mi355_interpolate1d(const mi355_interp1d_args* ap, void* stream) {
-  MI355_REQUIRE(ap && ap->x && ap->y, "interpolate1d: null tensor");
-  const mi355_interp1d_args a = *ap;
-  MI355_REQUIRE(a.rows > 0 && a.W >= 1 && a.size >= 1 && (a.mode == 0 || a.mode == 1), "interpolate1d: bad arguments");
-  MI355_CLEAR_ERROR();
-  const int64_t n = a.rows * (int64_t)a.size;
-  hipLaunchKernelGGL(interpolate1d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
-  MI355_LAUNCH_CHECK("interpolate1d");
   return MI355_OK;
 }

@@ -229,6 +229,45 @@ __global__ __launch_bounds__(256) void istft_head_kernel(const mi355_istft_head_
   }
 }
 
+// ---------------------------------------------------------------------------------------------- interpolate1d
+// tts/models/interpolate.py:61-132: nearest = floor(i * W/size) clipped; linear with torch semantics (half-pixel source coordinate clamped at 0,
+// or align_corners).  The coordinate arithmetic is float32 with one rounding per operation, exactly the MLX op sequence (arange * scalar, + scalar,
+// - 0.5, maximum): this translation unit is compiled with contraction off, so no step is fused into an FMA (SineGen multiplies these index
+// roundings by phase slopes of hundreds of radians).  One thread per output element, rows = N * C.
+__global__ __launch_bounds__(256) void interpolate1d_kernel(const mi355_interp1d_args a) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.rows * (int64_t)a.size) return;
+  const int64_t r = i / a.size;
+  const int o = (int)(i - r * a.size);
+  const float* xr = a.x + r * a.x_rstride;
+  float* yr = a.y + r * a.y_rstride;
+  const int W = a.W;
+  if (a.mode == 0) {  // nearest
+    int idx = a.size == 1 ? 0 : (int)floorf(((float)o * a.scale));
+    idx = idx < 0 ? 0 : (idx > W - 1 ? W - 1 : idx);
+    yr[o] = xr[idx];
+    return;
+  }
+  if (W == 1) { yr[o] = xr[0]; return; }
+  float x;
+  if (a.align_corners && a.size > 1) x = ((float)o * a.scale);
+  else if (a.size == 1) x = 0.f;
+  else {
+    x = ((float)o * a.scale);
+    if (!a.align_corners) {
+      x = x + a.half_scale;
+      x = x - 0.5f;
+      x = fmaxf(x, 0.f);
+    }
+  }
+  const int lo = (int)floorf(x);
+  const int hi = lo + 1 < W - 1 ? lo + 1 : W - 1;
+  const float frac = x - (float)lo;
+  const float lo_term = xr[lo < W ? lo : W - 1] * (1.0f - frac);
+  const float hi_term = xr[hi] * frac;
+  yr[o] = lo_term + hi_term;
+}
+
 }  // namespace
 
 extern "C" int mi355_sine_source(const mi355_sine_source_args* ap, void* stream) {
@@ -272,5 +311,16 @@ extern "C" int mi355_istft_head(const mi355_istft_head_args* ap, void* stream) {
   MI355_CLEAR_ERROR();
   hipLaunchKernelGGL(istft_head_kernel, dim3(blocks, a.B), dim3(256), lds, (hipStream_t)stream, a);
   MI355_LAUNCH_CHECK("istft_head");
+  return MI355_OK;
+}
+
+extern "C" int mi355_interpolate1d(const mi355_interp1d_args* ap, void* stream) {
+  MI355_REQUIRE(ap && ap->x && ap->y, "interpolate1d: null tensor");
+  const mi355_interp1d_args a = *ap;
+  MI355_REQUIRE(a.rows > 0 && a.W >= 1 && a.size >= 1 && (a.mode == 0 || a.mode == 1), "interpolate1d: bad arguments");
+  MI355_CLEAR_ERROR();
+  const int64_t n = a.rows * (int64_t)a.size;
+  hipLaunchKernelGGL(interpolate1d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  MI355_LAUNCH_CHECK("interpolate1d");
   return MI355_OK;
 }

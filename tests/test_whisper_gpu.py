@@ -269,6 +269,6 @@ def test_model_surface(tiny):
     gen = torch.Generator(device=DEV).manual_seed(5)
     res = model.decode(mel, DecodingOptions(language="en", sample_len=5, temperature=0.7, best_of=3, prompt=[7, 8, 9], prefix=[21, 22]),
                        generator=gen)
-    assert len(res.tokens) <= 5 + 2 and res.tokens[:2] == [21, 22] and res.temperature == 0.7 and np.isfinite(res.avg_logprob)
+    assert len(res.tokens) <= 5 and res.temperature == 0.7 and np.isfinite(res.avg_logprob)  # the prefix sits before sample_begin
     with pytest.raises(ValueError):
         model.decode(mel, DecodingOptions(beam_size=2, best_of=2))
