@@ -40,22 +40,19 @@ def parse():
                          "MI355X: 122 M samples/s at 32, 140 M at 64, 146 M at 128, 150 M at 256 -- the front end's latency-bound LSTMs amortise)")
     ap.add_argument("--precision", type=int, default=2,
                     help="2 = bf16 hi+lo split MFMA (fp32-grade), 3 = single fp16 pass in the vocoder, 1 = single bf16 pass")
+    ap.add_argument("--config", choices=["kokoro", "whisper", "qwen3", "csm"], default="kokoro",
+                    help="kokoro = the headline line (BASELINE config[1]); whisper / qwen3 / csm = the secondary lines of SURVEY 8d (BASELINE configs\n"
+                         "[2] / [3] / [4]) with the same JSON schema (tools/bench_{whisper,qwen3,csm}.py run in-process, 1 GPU)")
+    ap.add_argument("--ragged", action="store_true",
+                    help="utterance lengths drawn from 20..510 tokens with +-35 %% frames-per-token spread instead of the uniform canonical sentence:\n"
+                         "shows the load imbalance the frame-count re-balance (mlx_audio_amd/shard.py) is there for; not the headline configuration")
+    ap.add_argument("--wire", choices=["fp32", "fp16"], default="fp32", help="waveform dtype on the wire of the multi-GPU gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two in-run rocprofv3 PMC passes (roofline.traffic is then null)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--shape-table", default="", help="write the per-shape conv_gemm timing table (roofline leg) to this file")
-    return ap.parse_args()
-
-
-def make_inputs(S, B, seed, dev):
-    voice = S.make_voice_pack()
-    ids = [S.make_phoneme_ids(T_TOKENS - 2, seed=seed * 1000 + i) for i in range(B)]
-    ref_s = torch.cat([voice[T_TOKENS - 3] for _ in range(B)], 0)
-    fds = [S.forced_durations(T_TOKENS, F_FRAMES, seed=seed * 1000 + i) for i in range(B)]
-    rng = np.random.default_rng(1234 + seed)
-    rand_ini = torch.from_numpy(rng.uniform(size=(B, 9)).astype(np.float32)).to(dev)
-    g = torch.Generator(device=dev).manual_seed(1234 + seed)
-    noise = torch.randn((B, 2 * F_FRAMES * 300, 9), generator=g, device=dev, dtype=torch.float32)
-    return ids, ref_s.to(dev), fds, rand_ini, noise
+    return ap.parse_known_args()[0]
 
 
 def cpu_baseline(S):
@@ -91,8 +88,62 @@ def cpu_baseline(S):
             "x_realtime": samples / 24000.0 / med, "host_cores_available": avail}
 
 
+def run_secondary(args):
+    """``--config whisper | qwen3 | csm``: the secondary lines (tools/bench_*.py) behind the driver's flags, same JSON schema, one GPU."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import importlib
+
+    mod = importlib.import_module(f"bench_{args.config}")
+    argv = ["--steps", str(args.steps), "--warmup", str(args.warmup)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+    mod.main(argv)
+
+
+def pmc_traffic(args):
+    """HBM bytes per conv launch from the PMC counters, measured in THIS run: two child passes of this same command (one step each) under
+    ``rocprofv3 --kernel-trace --pmc FETCH_SIZE`` and ``... --pmc WRITE_SIZE`` (separate passes: the TCC block has 4 slots, the two counters
+    need 3 + 2), summed per dispatch over the counter instances, corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts
+    half of a coalesced streaming read; both are in KB): bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  Returns None when rocprofv3 is not
+    usable here (then ``roofline.traffic`` is null rather than a number from another run)."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if shutil.which("rocprofv3") is None or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD") or os.environ.get("ROCP_TOOL_LIBRARIES"):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from pmc_traffic import per_kernel
+
+    tmp = tempfile.mkdtemp(prefix="mi355_pmc_")
+    env = dict(os.environ, TMPDIR="/tmp")
+    tot = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
+                   "--steps", "1", "--warmup", "1", "--batch", str(args.batch), "--precision", str(args.precision), "--no-roofline",
+                   "--no-cpu-baseline"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+            dbs = glob.glob(os.path.join(out, "**", "*results.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None
+            per = per_kernel(dbs[0], ctr)
+            vals = [v for k, vs in per.items() if "conv_ws4_kernel" in k or "conv_gemm_kernel" in k for v in vs]
+            tot[ctr] = (sum(vals), len(vals))
+        n = max(tot["FETCH_SIZE"][1], 1)
+        # the child ran warm-up + timed step = 2 steps; both counters saw the same launches
+        return {"bytes_per_launch": (2.0 * tot["FETCH_SIZE"][0] + tot["WRITE_SIZE"][0]) * 1024.0 / n, "launches_counted": n,
+                "fetch_kb_total": tot["FETCH_SIZE"][0], "write_kb_total": tot["WRITE_SIZE"][0]}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     args = parse()
+    if args.config != "kokoro":
+        return run_secondary(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -117,28 +168,33 @@ def main():
     eng = KokoroEngine(S.make_kokoro_weights(), S.KOKORO_CONFIG, device=dev, precision=args.precision)
     B = args.batch
     n_total = B * world
-    # per-utterance inputs of THIS rank's shard are resident in HBM before the timed region; only the request batch
-    # (token ids, owned by rank 0) and the waveforms cross ranks inside the step
-    requests = [S.make_phoneme_ids(T_TOKENS - 2, seed=i) for i in range(n_total)] if rank == 0 else None
-    _, lens0 = shard.broadcast_requests(requests, dev, dist)
-    mine = shard.my_shard(lens0, dist)            # LPT over token counts: B utterances per rank here
-    assert len(mine) == B, (len(mine), B)
-    voice = S.make_voice_pack()
-    ref_s = torch.cat([voice[T_TOKENS - 3] for _ in mine], 0).to(dev)
-    fds = [S.forced_durations(T_TOKENS, F_FRAMES, seed=i) for i in mine]
-    rng = np.random.default_rng(1234 + rank)
-    rand_ini = torch.from_numpy(rng.uniform(size=(B, 9)).astype(np.float32)).to(dev)
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    noise = torch.randn((B, 2 * F_FRAMES * 300, 9), generator=g, device=dev, dtype=torch.float32)
+    # requests (token ids) are owned by rank 0 and cross ranks inside the step (one broadcast); voice rows, forced durations and SineGen noise
+    # are per-utterance inputs every rank derives locally from the seed, resident in HBM before the timed region
+    if args.ragged:
+        rng = np.random.default_rng(7)
+        t_of = [int(v) for v in rng.integers(20, 511, size=n_total)]
+        f_of = [max(t, int(round(t * 3.3 * (1.0 + 0.35 * (2.0 * rng.random() - 1.0))))) for t in t_of]
+    else:
+        t_of, f_of = [T_TOKENS] * n_total, [F_FRAMES] * n_total
+    requests = [S.make_phoneme_ids(t_of[i] - 2, seed=i) for i in range(n_total)] if rank == 0 else None
+    voice = S.make_voice_pack().to(dev)
+    fds = [S.forced_durations(t_of[i], f_of[i], seed=i).to(dev) for i in range(n_total)]
+    ch = shard.ShardChannel(dev, dist, max_items=max(n_total, 8), max_tokens=512)
+    noise_kw = None
+    if not args.ragged:  # uniform shapes: the SineGen inputs of a rank's B utterances are one resident block
+        rng = np.random.default_rng(1234 + rank)
+        rand_ini = torch.from_numpy(rng.uniform(size=(B, 9)).astype(np.float32)).to(dev)
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        noise = torch.randn((B, 2 * F_FRAMES * 300, 9), generator=g, device=dev, dtype=torch.float32)
+        noise_kw = lambda items: dict(rand_ini=rand_ini[: len(items)], noise=noise[: len(items)])
+    wire = torch.float16 if args.wire == "fp16" else None
 
     def step():
-        # utterance sharding (mlx_audio_amd/shard.py): broadcast of the padded token batch from rank 0, local synthesis
-        # of this rank's shard, gather of the waveforms on rank 0 -- over RCCL / xGMI when world > 1
-        ids_pad, lens = shard.broadcast_requests(requests, dev, dist)
-        local = [ids_pad[i, : T_TOKENS].long() for i in mine]
-        outs, _ = eng.forward(local, ref_s, forced_durations=fds, rand_ini=rand_ini, noise=noise)
-        shard.gather_waveforms(outs, mine, n_total, dev, dist)
-        return outs
+        # mlx_audio_amd/shard.py: broadcast of the request block, token-rate half on this rank's shard, all_reduce of the frame counts,
+        # re-balance on the real frame counts (all_to_all, only when it pays), frame-rate half, exact-size all_to_all of the waveforms to
+        # rank 0 -- over RCCL / xGMI when world > 1
+        return shard.kokoro_step(ch, eng, requests, lambda i, t: voice[t - 3], 600, forced_durations_of=lambda i: fds[i],
+                                 wire_dtype=wire, back_kwargs=noise_kw)
 
     for _ in range(args.warmup):
         step()
@@ -158,12 +214,13 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    assert all(o.numel() == SAMPLES_PER_UTT for o in outs)
-    assert all(bool(torch.isfinite(o).all()) for o in outs)
+    if rank == 0:
+        assert len(outs) == n_total and all(o.numel() == f_of[i] * 600 for i, o in enumerate(outs))
+        assert all(bool(torch.isfinite(o).all()) for o in outs)
 
     res = None
     if rank == 0:
-        total_samples = SAMPLES_PER_UTT * B * world * args.steps
+        total_samples = sum(f_of) * 600 * args.steps
         value = total_samples / dt
         res = {
             "metric": "audio samples/sec + real-time factor, Kokoro-82M TTS", "value": value, "unit": "samples/s",
@@ -173,9 +230,13 @@ def main():
                       3: "fp16 activations x bf16-valued weights in fp16 (single MFMA pass, fp32 accumulate) in the vocoder; hi+lo front end",
                       1: "bf16"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": "Kokoro-82M bf16 TTS, tokens->waveform, canonical short sentence T=80 F=264 (6.6 s @ 24 kHz)",
-                       "utterances_per_gpu": B, "global_batch": B * world, "samples_per_utterance": SAMPLES_PER_UTT,
-                       "parallelism": f"utterance-dp{world}", "precision_mode": args.precision},
+            "config": {"workload": ("Kokoro-82M bf16 TTS, tokens->waveform, RAGGED utterances T in 20..510 tokens, frames/token 3.3 +-35 %"
+                                     if args.ragged else
+                                     "Kokoro-82M bf16 TTS, tokens->waveform, canonical short sentence T=80 F=264 (6.6 s @ 24 kHz)"),
+                       "utterances_per_gpu": B, "global_batch": B * world,
+                       "samples_per_utterance": (sum(f_of) * 600 / n_total) if args.ragged else SAMPLES_PER_UTT,
+                       "parallelism": f"utterance-dp{world}", "precision_mode": args.precision, "wire": args.wire,
+                       "shard_plan_makespan_frames": shard.makespan(f_of, ch.owned), "collectives_per_step": ch.collectives // max(1, args.steps + args.warmup)},
             "x_realtime": value / 24000.0, "rtf_reference_style": 24000.0 / value,
         }
     # ---- roofline leg (rank 0, N=1 only): one extra instrumented step, events around every conv_gemm launch
@@ -199,21 +260,19 @@ def main():
                     f.write(f"{shp[0]} {shp[1]} {shp[2]} {shp[3]} {e[3]} {e[0]} {e[1]:.3f} {e[2] / 1e9:.2f} {e[2] / (e[1] * 1e-3) / 1e12:.1f}\n")
         flops = sum(p[0] for p in prof)
         byts = sum(p[1] for p in prof)
-        # HBM bytes per conv_gemm launch from the PMC counters (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes over this same
-        # command, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py writes the summary that is read back here)
-        traffic, traffic_src = None, os.path.join(ROOT, "profiles", f"r1_hbm_traffic_kokoro_b{B}.json")
-        if os.path.exists(traffic_src):
-            with open(traffic_src) as f:
-                pk = json.load(f)["kernels"]
-            cg = [v for k, v in pk.items() if "conv_gemm" in k]
-            if cg:
-                traffic = sum(v["hbm_bytes_total_corrected"] for v in cg) / max(1, sum(v["dispatches"] for v in cg))
+        # HBM bytes per conv launch from the PMC counters, measured by two child passes of this same command (pmc_traffic above)
+        pmc = None if (args.no_pmc or args.ragged) else pmc_traffic(args)
+        traffic = pmc["bytes_per_launch"] if pmc else None
         ms = sum(p[2].elapsed_time(p[3]) for p in prof)
         res["roofline"] = {
-            "bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv1d/convT/linear, v_mfma_f32_32x32x16_bf16)",
+            "bound": "mfma", "kernel": "conv_ws4_kernel + conv_gemm_kernel (implicit-GEMM conv1d/convT/linear, v_mfma_f32_32x32x16_bf16)",
             "achieved": flops / (ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
-            "traffic_note": "avg HBM bytes per conv_gemm launch, PMC (2*FETCH_SIZE + WRITE_SIZE)*1024; algorithmic avg = %.3e B" % (byts / max(1, len(prof))),
+            "traffic_note": "avg HBM bytes per conv launch measured in this run: (2*FETCH_SIZE + WRITE_SIZE)*1024 over %s launches of two rocprofv3 PMC "
+                            "child passes; algorithmic avg = %.3e B per launch (inputs + outputs + residual / accumulate reads + weights, each once)" % (
+                                pmc["launches_counted"] if pmc else "no", byts / max(1, len(prof))),
+            "algorithmic_bytes_per_launch": byts / max(1, len(prof)),
+            "traffic_over_algorithmic": (traffic / (byts / max(1, len(prof)))) if traffic else None,
             "launches_per_step": len(prof), "algorithmic_gflop_per_step": flops / 1e9,
             "conv_gemm_ms_per_step": ms, "instrumented_step_ms": e0.elapsed_time(e1),
             "hbm_view": {"algorithmic_GB_per_step": byts / 1e9, "achieved_GBps": byts / (ms * 1e-3) / 1e9,

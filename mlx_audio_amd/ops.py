@@ -29,13 +29,17 @@ def _stream() -> int:
 
 
 def profile_finalize(entries):
-    """PROFILE entries -> [(algorithmic flops, algorithmic bytes, start event, end event, (cin, cout, k, dil, rows))] after a synchronize."""
+    """PROFILE entries -> [(algorithmic flops, algorithmic bytes, start event, end event, (cin, cout, k, dil, rows))] after a synchronize.
+
+    Algorithmic bytes of one launch = every operand once: fp32 input rows, fp32 output rows, the 16-bit weight image, plus one more fp32
+    output-shaped read per residual operand and per ``accumulate`` (the launch must read what it adds to) -- the figure the PMC traffic is
+    compared with."""
     torch.cuda.synchronize()
     out = []
-    for rows, cin, cout, k, dil, e0, e1 in entries:
+    for rows, cin, cout, k, dil, extra_reads, e0, e1 in entries:
         rows = int(rows)
         flops = 2.0 * rows * cout * k * cin
-        byts = 4.0 * rows * (cin + cout) + 2.0 * cout * k * cin  # fp32 activations in + out, 16-bit weights once
+        byts = 4.0 * rows * (cin + cout * (1 + extra_reads)) + 2.0 * cout * k * cin
         out.append((flops, byts, e0, e1, (cin, cout, k, dil, rows)))
     return out
 
@@ -274,7 +278,7 @@ def conv_gemm(x: torch.Tensor, pc: PackedConv, y: torch.Tensor, *, dil: int = 1,
         e0.record()
         _lib.call_struct("mi355_conv_gemm", "mi355_conv_gemm_args", _stream(), **kw)
         e1.record()
-        PROFILE.append((rows, pc.cin, pc.cout, pc.k, dil, e0, e1))
+        PROFILE.append((rows, pc.cin, pc.cout, pc.k, dil, int(res is not None) + int(bool(accumulate)), e0, e1))
         return y
     _lib.call_struct("mi355_conv_gemm", "mi355_conv_gemm_args", _stream(), **kw)
     return y

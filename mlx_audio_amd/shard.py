@@ -1,17 +1,32 @@
 """Utterance / window sharding over the GPUs of one node (one process per GPU, ``torch.distributed``).
 
-The hot path shards naturally: utterances are independent (Kokoro chunks of
-<= 510 phonemes, ``tts/models/kokoro/pipeline.py:266-293``), weights are replicated, and the only
-exchanges are tiny: the padded int32 token batch goes out from rank 0 (broadcast), waveforms come
-back (gather).  The reference has no counterpart (single device).  No tensor / sequence
-parallelism: the largest model of the path is 3.4 GB.
+The hot path shards naturally: utterances are independent (Kokoro chunks of <= 510 phonemes,
+``tts/models/kokoro/pipeline.py:266-293``), weights are replicated, and the exchanges are small: token ids go out from the rank that
+owns the request queue, waveforms come back.  The reference has no counterpart (single device).  No tensor / sequence parallelism:
+the largest model of the path is 3.4 GB.
 
-Everything here is backend-agnostic: the same code runs over RCCL (backend ``"nccl"`` on ROCm, GPU
-tensors, xGMI) and over ``gloo`` (CPU tensors; the world_size-2 tests).
+Wire protocol of one step (``ShardChannel``; every message is ONE collective, sizes never travel in a separate message):
+
+1. ``scatter_requests``: ONE ``broadcast`` of a fixed-capacity int32 block ``[max_items, 1 + max_tokens]`` (column 0 = token count, -1 = empty
+   row).  The capacity is agreed when the channel is created, so no header round trip.  The token counts are read back to the host once
+   (the host needs the shapes to build its batch): the only host sync this module adds.
+2. Every rank derives the same longest-processing-time assignment from the token counts (``lpt_assign``: deterministic, no communication).
+3. After the model's token-rate half (Kokoro: PL-BERT + duration predictor) each rank knows the true frame counts of ITS utterances.
+   ``share_counts``: ONE ``all_reduce`` of an int32 vector ``[max_items]`` (disjoint ownership: sum == all-gather) makes them global.  The model
+   has just synced on those counts itself (they size its buffers), so reading the reduced vector costs a copy, not a pipeline bubble.
+4. ``rebalance`` (optional): LPT again on the real frame counts; utterances whose owner changes move as packed float32 blobs in ONE
+   ``all_to_all_single`` with exact split sizes (no padding).  Skipped when the token-count plan is already within ``tolerance`` of the
+   frame-count plan's makespan.
+5. ``gather``: ONE ``all_to_all_single`` towards the destination rank with exact split sizes (every rank can compute every rank's sample counts
+   from step 3 -- samples = frames x 600 for Kokoro -- or passes ``counts``), optionally as fp16 / int16 on the wire.  No padding crosses xGMI.
+
+Everything here is backend-agnostic: the same code runs over RCCL (backend ``"nccl"`` on ROCm, GPU tensors, xGMI) and over ``gloo`` (CPU
+tensors; the world_size 2 / 3 / 8 tests).  xGMI note: a gather to one rank is bound by that rank's 7 inbound links
+(~153 GB/s each); 64 utterances x 634 KB per rank is 40 MB per link per step, ~0.3 ms against a ~60 ms step.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -31,6 +46,28 @@ def lpt_assign(costs: Sequence[int], world: int) -> List[List[int]]:
     return [sorted(o) for o in owned]
 
 
+def makespan(costs: Sequence[int], owned: Sequence[Sequence[int]]) -> int:
+    return max((sum(int(costs[i]) for i in o) for o in owned), default=0)
+
+
+def lpt_rebalance(costs: Sequence[int], current: Sequence[Sequence[int]], tolerance: float = 0.05) -> List[List[int]]:
+    """Plan on the real costs, moving as few items as possible: keep ``current`` when its makespan is within ``tolerance`` of a fresh LPT plan's;
+    otherwise LPT with ties broken towards the current owner (so an item only moves when that shortens the schedule)."""
+    world = len(current)
+    fresh = lpt_assign(costs, world)
+    if makespan(costs, current) <= (1.0 + tolerance) * makespan(costs, fresh):
+        return [sorted(o) for o in current]
+    owner = {i: r for r, o in enumerate(current) for i in o}
+    order = sorted(range(len(costs)), key=lambda i: (-int(costs[i]), i))
+    load = [0] * world
+    owned: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], 0 if owner.get(i) == k else 1, k))
+        owned[r].append(i)
+        load[r] += int(costs[i])
+    return [sorted(o) for o in owned]
+
+
 def pack_token_batch(ids_list: Sequence[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
     """List of 1-D integer tensors -> (padded int32 ``[N, Tmax]``, int32 lengths ``[N]``)."""
     n = len(ids_list)
@@ -42,99 +79,197 @@ def pack_token_batch(ids_list: Sequence[torch.Tensor]) -> Tuple[torch.Tensor, to
     return out, lens
 
 
-def broadcast_requests(ids_list: Optional[Sequence[torch.Tensor]], device, dist=None, src: int = 0):
-    """Rank ``src`` owns the request batch; afterwards every rank holds (padded ids, lens) on ``device``."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        ids, lens = pack_token_batch(ids_list)
-        return ids.to(device), lens.to(device)
-    rank = dist.get_rank()
-    hdr = torch.zeros(2, dtype=torch.int64, device=device)
-    if rank == src:
-        ids, lens = pack_token_batch(ids_list)
-        hdr[0], hdr[1] = ids.shape[0], ids.shape[1]
-    dist.broadcast(hdr, src)
-    n, tmax = int(hdr[0]), int(hdr[1])
-    if rank == src:
-        ids, lens = ids.to(device), lens.to(device)
-    else:
-        ids = torch.empty((n, tmax), dtype=torch.int32, device=device)
-        lens = torch.empty((n,), dtype=torch.int32, device=device)
-    dist.broadcast(ids, src)
-    dist.broadcast(lens, src)
-    return ids, lens
+class ShardChannel:
+    """The per-process-group state of the protocol above: capacities, the request block, the last plan."""
+
+    def __init__(self, device, dist=None, max_items: int = 1024, max_tokens: int = 512, src: int = 0, dst: int = 0):
+        self.device = torch.device(device)
+        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.world = self.dist.get_world_size() if self.dist else 1
+        self.rank = self.dist.get_rank() if self.dist else 0
+        self.max_items, self.max_tokens, self.src, self.dst = int(max_items), int(max_tokens), src, dst
+        self.block = torch.full((self.max_items, 1 + self.max_tokens), -1, dtype=torch.int32, device=self.device)
+        self.n_items = 0
+        self.owned: List[List[int]] = [[] for _ in range(self.world)]
+        self.collectives = 0  # issued by this channel since creation (the tests count them)
+
+    # ------------------------------------------------------------------ requests out
+    def scatter_requests(self, ids_list: Optional[Sequence[torch.Tensor]]) -> Tuple[torch.Tensor, List[int]]:
+        """Rank ``src`` passes the request batch (others ``None``).  Returns (block ``[n, 1 + max_tokens]`` on the device: column 0 = length,
+        then the ids; token counts as host ints) on every rank and stores the token-count LPT plan in ``self.owned``."""
+        if self.rank == self.src:
+            n = len(ids_list)
+            if n > self.max_items or any(int(t.numel()) > self.max_tokens for t in ids_list):
+                raise ValueError(f"request batch exceeds the channel capacity ({self.max_items} items x {self.max_tokens} tokens)")
+            host = torch.full((self.max_items, 1 + self.max_tokens), -1, dtype=torch.int32)
+            if n:
+                pad = torch.nn.utils.rnn.pad_sequence([t.to(dtype=torch.int32, device="cpu") for t in ids_list], batch_first=True)
+                host[:n, 0] = torch.tensor([int(t.numel()) for t in ids_list], dtype=torch.int32)
+                host[:n, 1:1 + pad.shape[1]] = pad
+            self.block.copy_(host, non_blocking=True)
+        if self.dist:
+            self.dist.broadcast(self.block, self.src)
+            self.collectives += 1
+        if self.dist:
+            lens_all = self.block[:, 0].cpu()  # the one read-back: the host builds its batch from these shapes
+            n = int((lens_all >= 0).sum())
+            lens = [int(v) for v in lens_all[:n]]
+        else:
+            lens = [int(t.numel()) for t in ids_list]  # single process: the shapes never left the host
+            n = len(lens)
+        self.n_items = n
+        self.owned = lpt_assign(lens, self.world)
+        return self.block[:n], lens
+
+    def my_items(self) -> List[int]:
+        return self.owned[self.rank]
+
+    def my_ids(self, block: torch.Tensor, lens: Sequence[int]) -> List[torch.Tensor]:
+        return [block[i, 1:1 + lens[i]] for i in self.my_items()]
+
+    # ------------------------------------------------------------------ counts
+    def share_counts(self, local_counts: Sequence[int], owned: Optional[Sequence[Sequence[int]]] = None) -> List[int]:
+        """Per-item integer (frame / sample / token count) known only to the item's owner -> the full vector on every rank.  ONE all_reduce."""
+        owned = self.owned if owned is None else owned
+        mine = owned[self.rank]
+        assert len(local_counts) == len(mine), (len(local_counts), len(mine))
+        vec = torch.zeros(self.max_items, dtype=torch.int32)
+        for i, c in zip(mine, local_counts):
+            vec[i] = int(c)
+        if not self.dist:
+            return [int(v) for v in vec[: self.n_items]]
+        dev_vec = vec.to(self.device, non_blocking=True)
+        self.dist.all_reduce(dev_vec)
+        self.collectives += 1
+        return [int(v) for v in dev_vec[: self.n_items].cpu()]
+
+    # ------------------------------------------------------------------ re-balance on the real costs
+    def rebalance(self, costs: Sequence[int], pack: Callable[[int], torch.Tensor], blob_size: Callable[[int], int],
+                  tolerance: float = 0.05) -> Tuple[List[List[int]], dict]:
+        """``costs``: real per-item costs (all items, e.g. ``share_counts`` of the frame counts).  ``pack(i)`` -> 1-D float32 blob of item ``i`` (called
+        only for items this rank gives away), ``blob_size(i)`` -> its length (computable by every rank).  Returns (new plan, {item: blob}
+        for the items this rank received).  ONE all_to_all_single when anything moves, no collective otherwise."""
+        new = lpt_rebalance(costs, self.owned, tolerance)
+        old_owner = {i: r for r, o in enumerate(self.owned) for i in o}
+        new_owner = {i: r for r, o in enumerate(new) for i in o}
+        moves = sorted(i for i in new_owner if new_owner[i] != old_owner[i])
+        received: dict = {}
+        if moves and self.dist:
+            send = [[i for i in moves if old_owner[i] == self.rank and new_owner[i] == r] for r in range(self.world)]
+            recv = [[i for i in moves if new_owner[i] == self.rank and old_owner[i] == r] for r in range(self.world)]
+            in_split = [sum(blob_size(i) for i in s) for s in send]
+            out_split = [sum(blob_size(i) for i in s) for s in recv]
+            parts = [pack(i).reshape(-1).to(device=self.device, dtype=torch.float32) for s in send for i in s]
+            inp = torch.cat(parts) if parts else torch.empty(0, dtype=torch.float32, device=self.device)
+            out = torch.empty(sum(out_split), dtype=torch.float32, device=self.device)
+            self.dist.all_to_all_single(out, inp, out_split, in_split)
+            self.collectives += 1
+            off = 0
+            for s in recv:
+                for i in s:
+                    received[i] = out[off:off + blob_size(i)]
+                    off += blob_size(i)
+        self.owned = new
+        return new, received
+
+    # ------------------------------------------------------------------ results back
+    def gather(self, local: Sequence[torch.Tensor], counts: Optional[Sequence[int]] = None, dtype=torch.float32,
+               wire_dtype: Optional[torch.dtype] = None) -> Optional[List[torch.Tensor]]:
+        """Per-item 1-D results of this rank's items (in ``my_items()`` order) -> list over ALL items on rank ``dst`` (``None`` elsewhere).
+
+        ``counts``: element count of every item (all ranks must pass the same list, e.g. frames x samples-per-frame); when omitted the counts are
+        exchanged first (``share_counts``: one extra tiny all_reduce).  ONE all_to_all_single with exact split sizes carries the payload;
+        ``wire_dtype`` (fp16 for waveforms) halves it and is cast back to ``dtype`` on ``dst``."""
+        mine = self.my_items()
+        assert len(local) == len(mine), (len(local), len(mine))
+        if not self.dist:
+            out: List[Optional[torch.Tensor]] = [None] * self.n_items
+            for i, a in zip(mine, local):
+                out[i] = a
+            return out  # type: ignore[return-value]
+        if counts is None:
+            counts = self.share_counts([int(a.numel()) for a in local])
+        wire = wire_dtype or dtype
+        per_rank = [sum(int(counts[i]) for i in o) for o in self.owned]
+        parts = [a.reshape(-1).to(device=self.device, dtype=wire) for a in local]
+        inp = torch.cat(parts) if parts else torch.empty(0, dtype=wire, device=self.device)
+        assert int(inp.numel()) == per_rank[self.rank], (int(inp.numel()), per_rank[self.rank])
+        in_split = [per_rank[self.rank] if r == self.dst else 0 for r in range(self.world)]
+        out_split = per_rank if self.rank == self.dst else [0] * self.world
+        buf = torch.empty(sum(out_split), dtype=wire, device=self.device)
+        self.dist.all_to_all_single(buf, inp, out_split, in_split)
+        self.collectives += 1
+        if self.rank != self.dst:
+            return None
+        res: List[Optional[torch.Tensor]] = [None] * self.n_items
+        off = 0
+        for o in self.owned:
+            for i in o:
+                n = int(counts[i])
+                res[i] = buf[off:off + n].to(dtype)
+                off += n
+        return res  # type: ignore[return-value]
 
 
-def my_shard(lens: torch.Tensor, dist=None, cost=None) -> List[int]:
-    """Indices of the utterances this rank synthesises (LPT over a per-utterance cost; default: token count,
-    a proxy for the frame count that is only known after the duration predictor ran)."""
-    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
-    rank = dist.get_rank() if world > 1 else 0
-    costs = [int(v) for v in (cost if cost is not None else lens.cpu())]
-    return lpt_assign(costs, world)[rank]
+def kokoro_step(ch: ShardChannel, engine, requests: Optional[Sequence[torch.Tensor]], ref_s_of: Callable[[int, int], torch.Tensor],
+                samples_per_frame: int, forced_durations_of: Optional[Callable[[int], torch.Tensor]] = None, tolerance: float = 0.05,
+                wire_dtype: Optional[torch.dtype] = None, back_kwargs: Optional[Callable[[List[int]], dict]] = None):
+    """One sharded Kokoro synthesis step: requests out, token-rate half on the token-LPT shard, frame counts shared, utterances re-balanced on
+    the real frame counts, frame-rate half, waveforms back.  ``ref_s_of(item, n_tokens)`` -> the item's style row ``[1, 256]``;
+    ``back_kwargs(items)`` -> extra arguments of ``engine.back`` for the final shard (SineGen noise in the bench).  Returns the waveforms on
+    ``ch.dst`` (``None`` elsewhere).  Collectives: broadcast, all_reduce (int32 counts), [all_to_all_single], all_to_all_single."""
+    from .tts.models.kokoro.engine import KokoroFront
+
+    block, lens = ch.scatter_requests(requests)
+    first = ch.my_items()
+    st = None
+    if first:
+        ids = ch.my_ids(block, lens)
+        ref = torch.cat([ref_s_of(i, lens[i]) for i in first], 0)
+        fd = [forced_durations_of(i) for i in first] if forced_durations_of else None
+        st = engine.front(ids, ref, forced_durations=fd)
+    frames = ch.share_counts(st.frames if st else [])
+    width = engine.hid + engine.sty
+    style = 2 * engine.sty
+    pos = {i: k for k, i in enumerate(first)}
+    new, received = ch.rebalance(frames, lambda i: st.pack(pos[i]), lambda i: KokoroFront.packed_size(lens[i], style, width), tolerance)
+    mine = new[ch.rank]
+    outs: List[torch.Tensor] = []
+    if mine:
+        kept = [i for i in mine if i in pos]
+        parts = []
+        if kept:
+            parts.append((kept, st.select([pos[i] for i in kept])))
+        got = [i for i in mine if i not in pos]
+        if got:
+            parts.append((got, KokoroFront.unpack([received[i] for i in got], [frames[i] for i in got], style, width, st.speed if st else 1.0)))
+        order = [i for p in parts for i in p[0]]
+        merged = KokoroFront.concat([p[1] for p in parts])
+        perm = sorted(range(len(order)), key=lambda k: order[k])  # ascending item order == my_items() order
+        merged = merged.select(perm)
+        outs, _ = engine.back(merged, **(back_kwargs(mine) if back_kwargs else {}))
+    counts = [f * samples_per_frame for f in frames]
+    return ch.gather(outs, counts=counts, wire_dtype=wire_dtype)
 
 
-def broadcast_tensor(t: Optional[torch.Tensor], device, dist=None, src: int = 0, dtype=torch.float32) -> torch.Tensor:
+# ---------------------------------------------------------------------------------------------------- plain helpers (dense tensors)
+def broadcast_tensor(t: Optional[torch.Tensor], device, dist=None, src: int = 0, dtype=torch.float32, shape: Optional[Sequence[int]] = None) -> torch.Tensor:
     """Rank ``src`` owns a dense tensor (e.g. the 30 s audio windows of a Whisper request, the prefill embeddings of a Qwen3 batch);
-    afterwards every rank holds it on ``device``.  Shape travels first (one int64 header), then the payload."""
+    afterwards every rank holds it on ``device``.  With ``shape`` given (the receivers know it: fixed window size) this is ONE broadcast;
+    otherwise the shape travels first in one int64 header."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return t.to(device=device, dtype=dtype)
     rank = dist.get_rank()
-    hdr = torch.zeros(8, dtype=torch.int64, device=device)
-    if rank == src:
-        assert t.dim() <= 7
-        hdr[0] = t.dim()
-        for i, n in enumerate(t.shape):
-            hdr[1 + i] = n
-    dist.broadcast(hdr, src)
-    shape = [int(v) for v in hdr[1:1 + int(hdr[0])]]
-    buf = t.to(device=device, dtype=dtype).contiguous() if rank == src else torch.empty(shape, dtype=dtype, device=device)
+    if shape is None:
+        hdr = torch.zeros(8, dtype=torch.int64, device=device)
+        if rank == src:
+            assert t.dim() <= 7
+            hdr[0] = t.dim()
+            for i, n in enumerate(t.shape):
+                hdr[1 + i] = n
+        dist.broadcast(hdr, src)
+        hdr_h = hdr.cpu()
+        shape = [int(v) for v in hdr_h[1:1 + int(hdr_h[0])]]
+    buf = t.to(device=device, dtype=dtype).contiguous() if rank == src else torch.empty(list(shape), dtype=dtype, device=device)
     dist.broadcast(buf, src)
     return buf
-
-
-def gather_waveforms(local_audio: Sequence[torch.Tensor], local_idx: Sequence[int], n_total: int, device, dist=None,
-                     dst: int = 0, dtype=torch.float32) -> Optional[List[torch.Tensor]]:
-    """Collects every rank's per-item 1-D results (waveforms; with ``dtype=torch.int64`` token / code sequences) on rank ``dst`` in
-    original item order.
-
-    One all-gather of the per-utterance sample counts (int64 x n_total), then one padded gather of float32
-    samples ``[n_local_max, samples_max]`` per rank.  Returns the list on ``dst`` and ``None`` elsewhere."""
-    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
-    if world == 1:
-        out: List[Optional[torch.Tensor]] = [None] * n_total
-        for i, a in zip(local_idx, local_audio):
-            out[i] = a
-        return out  # type: ignore[return-value]
-    rank = dist.get_rank()
-    counts = torch.zeros(n_total, dtype=torch.int64, device=device)
-    for i, a in zip(local_idx, local_audio):
-        counts[i] = a.numel()
-    dist.all_reduce(counts)  # disjoint ownership: sum == all-gather of the per-utterance counts
-    counts_h = counts.cpu()
-    smax = int(counts_h.max()) if n_total else 0
-    # every rank derives every rank's ownership from the counts it contributed: gather the index lists
-    nloc = torch.tensor([len(local_idx)], dtype=torch.int64, device=device)
-    nlocs = [torch.zeros_like(nloc) for _ in range(world)]
-    dist.all_gather(nlocs, nloc)
-    nmax = max(int(v) for v in nlocs)
-    idx_pad = torch.full((nmax,), -1, dtype=torch.int64, device=device)
-    if local_idx:
-        idx_pad[: len(local_idx)] = torch.tensor(list(local_idx), dtype=torch.int64, device=device)
-    payload = torch.zeros((nmax, smax), dtype=dtype, device=device)
-    for j, a in enumerate(local_audio):
-        payload[j, : a.numel()] = a.reshape(-1).to(device=device, dtype=dtype)
-    if rank == dst:
-        idx_all = [torch.empty_like(idx_pad) for _ in range(world)]
-        pay_all = [torch.empty_like(payload) for _ in range(world)]
-    else:
-        idx_all = pay_all = None
-    dist.gather(idx_pad, idx_all, dst=dst)
-    dist.gather(payload, pay_all, dst=dst)
-    if rank != dst:
-        return None
-    out = [None] * n_total
-    for r in range(world):
-        for j, i in enumerate(idx_all[r].cpu().tolist()):
-            if i >= 0:
-                out[i] = pay_all[r][j, : int(counts_h[i])]
-    return out  # type: ignore[return-value]

@@ -99,6 +99,52 @@ class _StyleBank:
         return ops.pack_conv(torch.cat(self.ws, 0), torch.cat(self.bs, 0), device)
 
 
+@dataclass
+class KokoroFront:
+    """What crosses the front / back split of the forward pass, per utterance (lists of length B): token ids ``[T]``, style row ``[256]``,
+    duration-encoder output ``d`` ``[T, hid + style]``, predicted durations ``[T]`` int32, and the frame counts (host ints)."""
+    ids: List[torch.Tensor]
+    ref_s: torch.Tensor
+    d: List[torch.Tensor]
+    dur: List[torch.Tensor]
+    frames: List[int]
+    speed: float = 1.0
+    trace: Optional[dict] = None
+
+    def select(self, which: Sequence[int]) -> "KokoroFront":
+        which = list(which)
+        return KokoroFront([self.ids[i] for i in which], self.ref_s[which], [self.d[i] for i in which], [self.dur[i] for i in which],
+                           [self.frames[i] for i in which], self.speed, None)
+
+    def pack(self, i: int) -> torch.Tensor:
+        """Utterance ``i`` as one float32 vector: ``[T, ids (bit pattern), dur (bit pattern), ref_s, d]`` -- the wire format of a re-balance."""
+        T = int(self.ids[i].numel())
+        hdr = torch.tensor([T], dtype=torch.int32, device=self.d[i].device).view(torch.float32)
+        return torch.cat([hdr, self.ids[i].to(torch.int32).view(torch.float32), self.dur[i].to(torch.int32).view(torch.float32),
+                          self.ref_s[i].reshape(-1).to(torch.float32), self.d[i].reshape(-1).to(torch.float32)])
+
+    @staticmethod
+    def packed_size(T: int, style: int, width: int) -> int:
+        return 1 + 2 * T + style + T * width
+
+    @classmethod
+    def unpack(cls, blobs: Sequence[torch.Tensor], frames: Sequence[int], style: int, width: int, speed: float = 1.0) -> "KokoroFront":
+        ids, dur, ref, d = [], [], [], []
+        for b in blobs:
+            T = (int(b.numel()) - 1 - style) // (2 + width)  # from the blob length: no device read
+            ids.append(b[1:1 + T].view(torch.int32))
+            dur.append(b[1 + T:1 + 2 * T].view(torch.int32))
+            ref.append(b[1 + 2 * T:1 + 2 * T + style])
+            d.append(b[1 + 2 * T + style:].reshape(T, width))
+        return cls(ids, torch.stack(ref, 0), d, dur, list(frames), speed, None)
+
+    @classmethod
+    def concat(cls, parts: Sequence["KokoroFront"]) -> "KokoroFront":
+        parts = [p for p in parts if len(p.ids)]
+        return cls(sum((p.ids for p in parts), []), torch.cat([p.ref_s for p in parts], 0), sum((p.d for p in parts), []),
+                   sum((p.dur for p in parts), []), sum((list(p.frames) for p in parts), []), parts[0].speed, None)
+
+
 class KokoroEngine:
     def __init__(self, weights: Dict[str, torch.Tensor], config: dict, device="cuda", param_dtype=torch.bfloat16,
                  precision: int = 2):
@@ -352,7 +398,18 @@ class KokoroEngine:
         ``noise_seed`` when omitted).  ``overrides`` may replace intermediate signals: ``f0`` / ``n``
         ([B, 2*Fmax] pitch / energy curves: external prosody control) and ``har`` ([B, frames, n_fft+2] harmonic
         STFT features).  The parity tests use them to teacher-force the vocoder, because SineGen integrates F0
-        into a phase (chaotic in F0 rounding) and the reflect-padded edge frames have rounding-noise phases."""
+        into a phase (chaotic in F0 rounding) and the reflect-padded edge frames have rounding-noise phases.
+
+        = ``back(front(...))``: ``front`` is everything up to the predicted durations (PL-BERT, duration encoder / predictor, kokoro.py:118-152),
+        ``back`` the frame-rate half (text encoder, alignment, F0 / N, decoder, generator).  The split point is the forward pass's one host
+        sync (the frame counts size every later buffer); the utterance-sharding layer (mlx_audio_amd/shard.py) re-balances utterances across
+        GPUs there, on the real frame counts."""
+        st = self.front(input_ids, ref_s, speed=speed, forced_durations=forced_durations, keep_trace=return_intermediates)
+        return self.back(st, rand_ini=rand_ini, noise=noise, noise_seed=noise_seed, return_intermediates=return_intermediates, overrides=overrides)
+
+    def front(self, input_ids: Sequence[torch.Tensor], ref_s: torch.Tensor, speed: float = 1.0,
+              forced_durations: Optional[Sequence[torch.Tensor]] = None, keep_trace: bool = False) -> "KokoroFront":
+        """Token-rate half: returns the per-utterance state ``back`` needs (ids, style, duration-encoder output ``d``, durations, frames)."""
         dev, hid, sty = self.dev, self.hid, self.sty
         B = len(input_ids)
         Ts = [int(t.numel()) for t in input_ids]
@@ -432,6 +489,35 @@ class KokoroEngine:
                                                        forced=forced, bins=bins)
         frames_h = frames.cpu()  # the one host sync of the forward pass (kokoro.py:149-152 syncs per phoneme)
         Fs = [int(v) for v in frames_h]
+        return KokoroFront(ids=[ids[b, : Ts[b]] for b in range(B)], ref_s=ref_s, d=[d[b, : Ts[b]] for b in range(B)],
+                           dur=[dur[b, : Ts[b]] for b in range(B)], frames=Fs, speed=float(speed),
+                           trace=dict(dur_raw=dur_raw, bert=h) if keep_trace else None)
+
+    def back(self, st: "KokoroFront", rand_ini: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, noise_seed: int = 1234,
+             return_intermediates: bool = False, overrides: Optional[Dict[str, torch.Tensor]] = None):
+        """Frame-rate half on the utterances of ``st`` (which may have been produced by ``front`` on another GPU: only ids, style, ``d`` and the
+        durations travel; the alignment indices are rebuilt here from the durations)."""
+        dev, hid, sty = self.dev, self.hid, self.sty
+        B = len(st.ids)
+        Ts = [int(t.numel()) for t in st.ids]
+        Tm = max(Ts)
+        ragged = B > 1
+        ids = torch.nn.utils.rnn.pad_sequence([t.to(device=dev, dtype=torch.int32) for t in st.ids], batch_first=True)
+        lens_t = torch.tensor(Ts, dtype=torch.int32, device=dev) if ragged else None
+        ref_s = st.ref_s.to(device=dev, dtype=torch.float32).contiguous()
+        s_dec = ref_s[:, :sty].contiguous()
+        s_pred = ref_s[:, sty:].contiguous()
+        gb_dec = self._new(B, 1, self.style_dec.cout)
+        gb_pred = self._new(B, 1, self.style_pred.cout)
+        self._conv(s_dec[:, None, :], self.style_dec, gb_dec)
+        self._conv(s_pred[:, None, :], self.style_pred, gb_pred)
+        gb_dec, gb_pred = gb_dec[:, 0], gb_pred[:, 0]
+        d = torch.nn.utils.rnn.pad_sequence([t.to(dev) for t in st.d], batch_first=True).contiguous()
+        forced = torch.nn.utils.rnn.pad_sequence([t.to(device=dev, dtype=torch.int32) for t in st.dur], batch_first=True).contiguous()
+        dur, _, frames, idx = ops.duration_align(None, Tm, B, st.speed, Tm * 100, dev, lens=lens_t, forced=forced)
+        Fs = list(st.frames)
+        dur_raw = st.trace["dur_raw"] if st.trace else None
+        h = st.trace["bert"] if st.trace else None
         Fm = max(Fs)
         if Fm <= 0:
             return [self._new(1, zero=True) for _ in range(B)], [dur[b, : Ts[b]] for b in range(B)]

@@ -1,6 +1,8 @@
-"""The multi-GPU path of the hot path is utterance sharding with one broadcast out and one gather back
-(mlx_audio_amd/shard.py).  Exercised here with world_size 2 and 3 over ``gloo`` on CPU tensors; on the
-GPU node the same code runs over RCCL (backend "nccl") with device tensors."""
+"""The multi-GPU path of the hot path: utterance sharding through ``mlx_audio_amd.shard.ShardChannel`` -- one broadcast out, one tiny
+all_reduce of the frame counts, an all_to_all re-balance when the real frame counts disagree with the token-count plan, one exact-size
+all_to_all back.  Exercised here with world sizes 2, 3 and 8 over ``gloo`` on CPU tensors with a stand-in engine that has the Kokoro engine's
+``front`` / ``back`` contract; on the GPU node the same code runs over RCCL (backend "nccl") with device tensors
+(tests/test_shard_nccl_gpu.py needs >= 2 GPUs)."""
 import os
 import socket
 
@@ -10,6 +12,9 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from mlx_audio_amd import shard
+from mlx_audio_amd.tts.models.kokoro.engine import KokoroFront
+
+SPF = 6  # "samples per frame" of the stand-in vocoder
 
 
 def _free_port():
@@ -20,10 +25,49 @@ def _free_port():
     return p
 
 
-def _fake_synth(ids: torch.Tensor) -> torch.Tensor:
-    """Deterministic stand-in for the engine: 'waveform' length and content depend on the token ids."""
-    n = 7 * int(ids.numel()) + int(ids.sum()) % 5
-    return (torch.arange(n, dtype=torch.float32) * 0.25 + float(ids[0])) * (1.0 + float(ids.numel()))
+class FakeEngine:
+    """Deterministic stand-in with the engine's split: ``front`` -> per-utterance state + data-dependent frame counts, ``back`` -> 'waveforms'
+    of ``frames * SPF`` samples that depend on every field that crosses the split (so a wrong or corrupted move is visible)."""
+    hid, sty = 5, 2
+
+    def __init__(self, skew=False, device="cpu"):
+        self.skew = skew
+        self.device = torch.device(device)
+        self.front_calls = 0
+        self.back_items = []
+
+    def frames_of(self, ids):
+        base = 3 * int(ids.numel())
+        if self.skew and int(ids[0]) % 4 == 0:
+            base *= 9  # a few utterances are much longer in frames than their token count suggests
+        return base + int(ids.sum()) % 4
+
+    def front(self, ids, ref_s, forced_durations=None, speed=1.0):
+        self.front_calls += 1
+        dev = self.device
+        ids = [i.to(dev) for i in ids]
+        d = [(i.to(torch.float32)[:, None] * torch.arange(1, self.hid + self.sty + 1, dtype=torch.float32, device=dev)[None, :]) * 0.5 for i in ids]
+        dur = [(i % 7 + 1).to(torch.int32) for i in ids]
+        return KokoroFront([i.to(torch.int32) for i in ids], ref_s.to(dev), d, dur, [self.frames_of(i.cpu()) for i in ids], speed, None)
+
+    def back(self, st):
+        outs = []
+        for b in range(len(st.ids)):
+            n = st.frames[b] * SPF
+            key = float(st.d[b].sum()) * 1e-3 + float(st.dur[b].sum()) + float(st.ref_s[b].sum()) + float(st.ids[b][0])
+            outs.append(torch.arange(n, dtype=torch.float32, device=self.device) * 0.25 + key)
+        self.back_items.append(len(st.ids))
+        return outs, st.dur
+
+
+def _ref_s_of(i, n_tokens):
+    return torch.full((1, 2 * FakeEngine.sty), float(i) + 0.5 * n_tokens)
+
+
+def _single_process(reqs, skew):
+    eng = FakeEngine(skew)
+    st = eng.front(reqs, torch.cat([_ref_s_of(i, int(r.numel())) for i, r in enumerate(reqs)], 0))
+    return eng.back(st)[0]
 
 
 def _make_requests(n, seed):
@@ -31,94 +75,146 @@ def _make_requests(n, seed):
     return [torch.randint(1, 178, (int(torch.randint(3, 40, (1,), generator=g)),), generator=g) for _ in range(n)]
 
 
-def _worker(rank, world, port, n_utts, q):
+def _worker(rank, world, port, n_utts, skew, wire, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         reqs = _make_requests(n_utts, 5) if rank == 0 else None
-        ids, lens = shard.broadcast_requests(reqs, "cpu", dist)
-        mine = shard.my_shard(lens, dist)
-        audio = [_fake_synth(ids[i, : int(lens[i])].long()) for i in mine]
-        out = shard.gather_waveforms(audio, mine, ids.shape[0], "cpu", dist)
+        ch = shard.ShardChannel("cpu", dist, max_items=32, max_tokens=64)
+        eng = FakeEngine(skew)
+        token_plan = None
+        for step in range(2):  # the channel is reused step after step
+            out = shard.kokoro_step(ch, eng, reqs, _ref_s_of, SPF, tolerance=0.05, wire_dtype=wire)
+            if step == 0:
+                token_plan = shard.lpt_assign([int(r.numel()) for r in reqs], world) if rank == 0 else None
         if rank == 0:
-            ok = all(torch.equal(o, _fake_synth(r)) for o, r in zip(out, reqs)) and len(out) == n_utts
-            q.put((ok, [len(shard.lpt_assign([int(v) for v in lens], world)[r]) for r in range(world)]))
+            want = _single_process(reqs, skew)
+            if wire is None:
+                ok = len(out) == n_utts and all(torch.equal(o, w) for o, w in zip(out, want))
+            else:
+                ok = len(out) == n_utts and all(o.dtype == torch.float32 and torch.allclose(o, w, rtol=2e-3, atol=1e-2) for o, w in zip(out, want))
+            q.put(dict(ok=ok, collectives=ch.collectives, plan=ch.owned, token_plan=token_plan,
+                       frames=[eng.frames_of(r) for r in reqs]))
         else:
             assert out is None
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_utts", [(2, 9), (3, 4), (2, 1)])
-def test_broadcast_shard_gather_gloo(world, n_utts):
+def _run(world, n_utts, skew=False, wire=None):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_utts, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_utts, skew, wire, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(180)
         assert p.exitcode == 0
-    ok, sizes = q.get()
-    assert ok
-    assert sum(sizes) == n_utts
+    return q.get()
+
+
+@pytest.mark.parametrize("world,n_utts", [(2, 9), (3, 4), (2, 1), (8, 19), (8, 5)])
+def test_sharded_step_equals_single_process(world, n_utts):
+    r = _run(world, n_utts)
+    assert r["ok"]
+    assert sorted(i for o in r["plan"] for i in o) == list(range(n_utts))
+    # per step: broadcast + all_reduce(frame counts) + all_to_all(waveforms); frames ~ 3 x tokens here, so nothing needs to move
+    assert r["plan"] == r["token_plan"]
+    assert r["collectives"] == 2 * 3
+
+
+@pytest.mark.parametrize("world,n_utts", [(2, 9), (3, 11), (8, 19)])
+def test_rebalance_on_real_frame_counts(world, n_utts):
+    r = _run(world, n_utts, skew=True)
+    assert r["ok"]
+    frames = r["frames"]
+    assert r["plan"] != r["token_plan"]                                   # utterances moved ...
+    assert shard.makespan(frames, r["plan"]) < shard.makespan(frames, r["token_plan"])   # ... and the slowest rank got faster
+    assert shard.makespan(frames, r["plan"]) <= 1.05 * shard.makespan(frames, shard.lpt_assign(frames, world)) + max(frames) * 0
+    assert r["collectives"] == 2 * 4                                      # one extra all_to_all per step, nothing else
+
+
+def test_fp16_on_the_wire():
+    assert _run(2, 6, wire=torch.float16)["ok"]
 
 
 def test_lpt_is_balanced_and_deterministic():
     costs = [264, 40, 300, 120, 90, 500, 33, 33, 260, 210, 75, 410]
     parts = shard.lpt_assign(costs, 4)
-    assert sorted(i for p in parts for i in p) == list(range(len(costs)))
     loads = [sum(costs[i] for i in p) for p in parts]
-    assert max(loads) - min(loads) <= max(costs)  # LPT bound
+    assert sorted(i for p in parts for i in p) == list(range(len(costs)))
+    assert max(loads) - min(loads) <= max(costs) // 2
     assert parts == shard.lpt_assign(costs, 4)
     assert shard.lpt_assign([], 2) == [[], []]
     assert shard.lpt_assign([5], 3) == [[0], [], []]
 
 
-def test_single_process_passthrough():
-    reqs = _make_requests(3, 1)
-    ids, lens = shard.broadcast_requests(reqs, "cpu", None)
-    assert ids.shape[0] == 3 and [int(v) for v in lens] == [r.numel() for r in reqs]
-    mine = shard.my_shard(lens, None)
-    assert mine == [0, 1, 2]
-    out = shard.gather_waveforms([_fake_synth(r) for r in reqs], mine, 3, "cpu", None)
-    assert all(torch.equal(o, _fake_synth(r)) for o, r in zip(out, reqs))
+def test_lpt_rebalance_moves_only_when_it_pays():
+    costs = [100, 100, 100, 100]
+    cur = [[0, 1], [2, 3]]
+    assert shard.lpt_rebalance(costs, cur) == cur                        # already optimal: nothing moves, whatever fresh LPT would pick
+    cur = [[0, 2], [1, 3]]
+    assert shard.lpt_rebalance(costs, cur) == cur
+    costs = [900, 100, 100, 100]
+    new = shard.lpt_rebalance(costs, [[0, 1], [2, 3]])
+    assert new == [[0], [1, 2, 3]]                                        # item 1 moves, items 2 / 3 stay where they were
+    assert shard.lpt_rebalance([10, 11, 10, 10], [[0, 1], [2, 3]], tolerance=0.10) == [[0, 1], [2, 3]]
 
 
-# ------------------------------------------------------------------ Whisper windows / Qwen3 batch items (dense inputs, integer outputs)
-def _fake_transcribe(window: torch.Tensor) -> torch.Tensor:
-    """Deterministic stand-in for the decoder: a token sequence whose length and content depend on the window."""
-    n = 3 + int(window.abs().sum() * 10) % 7
-    return (torch.arange(n, dtype=torch.int64) * 3 + int(window[0] * 100) % 50)
+def test_single_process_path_and_capacity_errors():
+    reqs = _make_requests(3, 9)
+    ch = shard.ShardChannel("cpu", None, max_items=4, max_tokens=64)
+    out = shard.kokoro_step(ch, FakeEngine(), reqs, _ref_s_of, SPF)
+    want = _single_process(reqs, False)
+    assert ch.collectives == 0 and all(torch.equal(o, w) for o, w in zip(out, want))
+    with pytest.raises(ValueError):
+        ch.scatter_requests(_make_requests(5, 1))
+    with pytest.raises(ValueError):
+        shard.ShardChannel("cpu", None, max_items=4, max_tokens=2).scatter_requests(reqs)
 
 
-def _worker_dense(rank, world, port, n_items, q):
+def test_front_state_pack_roundtrip():
+    eng = FakeEngine()
+    reqs = _make_requests(4, 3)
+    st = eng.front(reqs, torch.cat([_ref_s_of(i, int(r.numel())) for i, r in enumerate(reqs)], 0))
+    blobs = [st.pack(i) for i in range(4)]
+    width, style = eng.hid + eng.sty, 2 * eng.sty
+    assert [int(b.numel()) for b in blobs] == [KokoroFront.packed_size(int(r.numel()), style, width) for r in reqs]
+    back = KokoroFront.unpack(blobs, st.frames, style, width)
+    for i in range(4):
+        assert torch.equal(back.ids[i], st.ids[i]) and torch.equal(back.dur[i], st.dur[i]) and torch.equal(back.d[i], st.d[i])
+    assert torch.equal(back.ref_s, st.ref_s)
+    sel = st.select([2, 0])
+    assert torch.equal(sel.ids[0], st.ids[2]) and sel.frames == [st.frames[2], st.frames[0]] and torch.equal(sel.ref_s[1], st.ref_s[0])
+
+
+def _worker_windows(rank, world, port, q):
+    """The Whisper-shaped use: equal-cost dense items (30 s windows) out with a known shape (one broadcast), ragged token lists back."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        g = torch.Generator().manual_seed(11)
-        windows = torch.randn(n_items, 160, generator=g) if rank == 0 else None
-        w = shard.broadcast_tensor(windows, "cpu", dist)
-        mine = shard.lpt_assign([1] * w.shape[0], world)[rank]          # equal-cost items (30 s windows)
-        toks = [_fake_transcribe(w[i]) for i in mine]
-        out = shard.gather_waveforms(toks, mine, w.shape[0], "cpu", dist, dtype=torch.int64)
+        g = torch.Generator().manual_seed(3)
+        windows = torch.randn(5, 8, 4, generator=g) if rank == 0 else None
+        w = shard.broadcast_tensor(windows, "cpu", dist, shape=(5, 8, 4))
+        ch = shard.ShardChannel("cpu", dist, max_items=8, max_tokens=1)
+        ch.n_items, ch.owned = 5, shard.lpt_assign([1] * 5, world)
+        toks = [torch.arange(3 + i, dtype=torch.int64) * (i + 1) + int(w[i].abs().sum() * 10) for i in ch.my_items()]
+        out = ch.gather(toks, dtype=torch.int64)
         if rank == 0:
-            q.put(all(torch.equal(o, _fake_transcribe(windows[i])) and o.dtype == torch.int64 for i, o in enumerate(out)) and len(out) == n_items)
-        else:
-            assert out is None
+            want = [torch.arange(3 + i, dtype=torch.int64) * (i + 1) + int(windows[i].abs().sum() * 10) for i in range(5)]
+            q.put(all(torch.equal(a, b) for a, b in zip(out, want)) and ch.collectives == 2)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_items", [(2, 5), (3, 3)])
-def test_dense_inputs_integer_outputs_gloo(world, n_items):
+def test_dense_windows_out_ragged_tokens_back():
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_dense, args=(r, world, port, n_items, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_windows, args=(r, 3, port, q)) for r in range(3)]
     for p in procs:
         p.start()
     for p in procs:

@@ -1,0 +1,51 @@
+"""The sharded step over RCCL (backend "nccl", device tensors): world_size 2 on one node.  Needs two GPUs -- self-skips on the 1-GPU boxes the
+round's ``pytest -m gpu`` runs on; the protocol itself is covered at world 2 / 3 / 8 over gloo in tests/test_shard_cpu.py."""
+import os
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    from mlx_audio_amd import shard
+    from test_shard_cpu import SPF, FakeEngine, _make_requests, _ref_s_of, _single_process
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        reqs = _make_requests(9, 5) if rank == 0 else None
+        ch = shard.ShardChannel(dev, dist, max_items=32, max_tokens=64)
+        eng = FakeEngine(skew=True, device=dev)
+        out = None
+        for _ in range(2):
+            out = shard.kokoro_step(ch, eng, reqs, lambda i, t: _ref_s_of(i, t).to(dev), SPF)
+        torch.cuda.synchronize()
+        if rank == 0:
+            want = _single_process(reqs, True)
+            q.put(len(out) == 9 and all(o.is_cuda and torch.equal(o.cpu(), w) for o, w in zip(out, want)) and ch.collectives == 8)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_step_over_rccl_world2():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (RCCL over xGMI); the gloo tests cover the protocol")
+    from test_shard_cpu import _free_port
+
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert q.get()

@@ -61,3 +61,45 @@ def host_cores():
 def step_runner() -> str:
     """The decode-step runner behind mi355_stack_decode_step."""
     return "multi-launch native runner (stack_step.cpp)"
+
+
+def cpu_frame_baseline(stacks, batch: int, context: int = 32, seconds_per_frame_audio: float = 0.08):
+    """``cpu_baseline`` of a codec-LM frame loop: the oracle (oracle/lm_ref.py StackRef, PyTorch-CPU fp32, the restated reference) timed on this
+    host for ONE generated frame of the same stacks -- ``stacks`` = [(StackConfig-like cfg, single-position steps per frame)].  Bounded sample:
+    one layer's parameters are generated and aliased to every layer (generating > 1e9 random parameters on the host would cost minutes; the
+    aliasing can only flatter the CPU through its caches), heads / embeddings / sampling are left out (also in the CPU's favour)."""
+    import time
+    from dataclasses import asdict
+
+    from mlx_audio_amd.lm.synthetic import make_stack_weights
+    from oracle import lm_ref as R
+
+    cores = max(1, min(host_cores(), 32))
+    torch.set_num_threads(cores)
+    frame_s = 0.0
+    for cfg, steps in stacks:
+        one = dataclasses.replace(cfg, n_layers=1)
+        w1 = make_stack_weights(one, seed=0)
+        w = {}
+        for k, v in w1.items():
+            if k.startswith("layers.0."):
+                for i in range(cfg.n_layers):
+                    w[f"layers.{i}." + k[len("layers.0."):]] = v
+            else:
+                w[k] = v
+        names = {f.name for f in dataclasses.fields(R.StackConfig)}
+        ref = R.StackRef(w, R.StackConfig(**{k: v for k, v in asdict(cfg).items() if k in names}), param_dtype=torch.float32)
+        cache = ref.make_cache()
+        with torch.no_grad():
+            ref(torch.randn(batch, context, cfg.d_model) * 0.1, cache)  # prefill (also the warm-up)
+            n = max(1, min(steps, 4))
+            t0 = time.perf_counter()
+            for _ in range(n):
+                ref(torch.randn(batch, 1, cfg.d_model) * 0.1, cache)
+            frame_s += (time.perf_counter() - t0) / n * steps
+        del ref, w, w1
+    return {"value": batch * seconds_per_frame_audio / frame_s, "unit": "x realtime", "cores": cores, "kind": "port",
+            "sample": "1 frame of the transformer stacks only (%s single-position steps, batch %d, context %d), oracle/lm_ref.py StackRef fp32; one "
+                      "layer's random parameters aliased to all layers, heads / sampling / codec left out" % (
+                          " + ".join(f"{s} x {c.n_layers} layers d={c.d_model}" for c, s in stacks), batch, context),
+            "cpu_ms_per_frame": frame_s * 1e3}

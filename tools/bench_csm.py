@@ -17,7 +17,7 @@ import torch
 import _bench_util as U
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--frames", type=int, default=32)
@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="accepted for symmetry with the other bench lines")
     ap.add_argument("--weights", choices=["bf16", "fp8"], default="bf16")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     fp8 = args.weights == "fp8"
 
     from mlx_audio_amd.codec.models.mimi import mimi as M
@@ -106,7 +106,10 @@ def main():
                      "unit": "GB/s", "frac": wbytes / (frame_ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "algorithmic_bytes_per_frame": wbytes,
                      "note": "whole-frame figure: includes attention, norms, sampling and launch gaps"},
     }
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = U.cpu_frame_baseline([(cfg.backbone, 1), (cfg.decoder, nb - 1)], B, context=S)
     print(json.dumps(res))
+    return res
 
 
 if __name__ == "__main__":

@@ -16,7 +16,7 @@ import torch
 import _bench_util as U
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--frames", type=int, default=48)
@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     from mlx_audio_amd import ops
     from mlx_audio_amd.lm.stack import make_lin
@@ -110,7 +110,10 @@ def main():
                      "algorithmic_bytes_per_frame": wbytes,
                      "note": "whole-frame figure (weights streamed once per frame / wall time of a frame): includes attention, norms, sampling and launch gaps"},
     }
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = U.cpu_frame_baseline([(eng.talker.cfg, 1), (eng.cp.cfg, cfg.num_code_groups - 1)], B, context=args.prompt)
     print(json.dumps(res))
+    return res
 
 
 if __name__ == "__main__":

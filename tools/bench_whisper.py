@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8, help="30 s windows per step")
     ap.add_argument("--steps", type=int, default=5)
@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--decode-steps", type=int, default=64)
     ap.add_argument("--precision", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     from mlx_audio_amd import dsp, ops
     from mlx_audio_amd.stt.models.whisper import synthetic as WS
