@@ -189,11 +189,26 @@ def main():
         noise_kw = lambda items: dict(rand_ini=rand_ini[: len(items)], noise=noise[: len(items)])
     wire = torch.float16 if args.wire == "fp16" else None
 
+    class VoiceRows:  # style row of an utterance = voice pack row (n_phonemes - 1), kokoro.py:223-226; one device gather per step
+        def __init__(self):
+            self.cache = {}
+
+        def __call__(self, i, t):
+            return voice[t - 3]
+
+        def rows(self, items, lens):
+            key = tuple(items)
+            if key not in self.cache:
+                self.cache[key] = torch.tensor([lens[i] - 3 for i in items], dtype=torch.long, device=dev)
+            return voice[self.cache[key], 0]
+
+    voice_rows = VoiceRows()
+
     def step():
         # mlx_audio_amd/shard.py: broadcast of the request block, token-rate half on this rank's shard, all_reduce of the frame counts,
         # re-balance on the real frame counts (all_to_all, only when it pays), frame-rate half, exact-size all_to_all of the waveforms to
         # rank 0 -- over RCCL / xGMI when world > 1
-        return shard.kokoro_step(ch, eng, requests, lambda i, t: voice[t - 3], 600, forced_durations_of=lambda i: fds[i],
+        return shard.kokoro_step(ch, eng, requests, voice_rows, 600, forced_durations_of=lambda i: fds[i],
                                  wire_dtype=wire, back_kwargs=noise_kw)
 
     for _ in range(args.warmup):

@@ -50,67 +50,100 @@ __host__ __device__ inline SineDims sine_dims(int len2, int up) {
   return d;
 }
 
-// phase_ws[b, h, i] = (cumsum_i(down(rad)) * 2 * pi) * up      -- one thread per (b, h), sequential scan
-__global__ void sine_phase_kernel(const mi355_sine_source_args a) {
-  const int h = threadIdx.x, b = blockIdx.x;
-  if (h >= a.H) return;
+// phase_ws[b, h, i] = (cumsum_i(down(rad)) * 2 * pi) * up.  One workgroup per utterance.  The cumulative sum is the reference's sequential fp32
+// scan (its rounding feeds a phase that is multiplied by hundreds of radians), but only the additions are sequential: the terms -- the
+// down-sampled, harmonic-scaled, wrapped instantaneous frequencies (an fmodf and an interpolation each) -- are computed by all 256 threads into
+// LDS a chunk at a time, then one lane per harmonic adds them up out of LDS.
+constexpr int kPhaseChunk = 1024;
+
+__global__ __launch_bounds__(256) void sine_phase_kernel(const mi355_sine_source_args a) {
+  extern __shared__ __attribute__((aligned(16))) float vterm[];  // [H][kPhaseChunk]
+  const int b = blockIdx.x, tid = threadIdx.x;
   const int len2 = a.lens2 ? a.lens2[b] : a.L2;
   const SineDims d = sine_dims(len2, a.up);
   const int L = d.L;
   const int small = min(d.small, a.L2 + 1);
   const float* f0 = a.f0 + (int64_t)b * a.ld_f0;
-  const float mult = (float)(h + 1);
-  const float ini = (h == 0) ? 0.0f : a.rand_ini[(int64_t)b * a.H + h];
-  auto rad = [&](int t) {
+  auto rad = [&](int t, float mult, float ini) {
     const float fn = mul_rn(f0[t / a.up], mult);
     float r = fmodf(fn / a.sr, 1.0f);
     if (r < 0.f) r = add_rn(r, 1.0f);  // python-style modulo (np.mod / mx %) for negative f0
     if (t == 0) r = add_rn(r, ini);
     return r;
   };
-  float* out = a.phase_ws + ((int64_t)b * a.H + h) * (a.L2 + 1);
-  float cum = 0.f;
   const float pi_f = 3.14159265358979323846f;
-  for (int i = 0; i < small; ++i) {
-    float v;
-    if (L == 1) {
-      v = rad(0);
-    } else {
-      int lo, hi; float fr;
-      lin_coord(i, d.sc_dn, d.hsc_dn, L, lo, hi, fr);
-      v = add_rn(mul_rn(rad(lo), sub_rn(1.0f, fr)), mul_rn(rad(hi), fr));
+  float cum = 0.f;
+  for (int c0 = 0; c0 < small; c0 += kPhaseChunk) {
+    const int cn = min(kPhaseChunk, small - c0);
+    for (int idx = tid; idx < a.H * cn; idx += 256) {
+      const int h = idx / cn, i = c0 + (idx - h * cn);
+      const float mult = (float)(h + 1);
+      const float ini = (h == 0) ? 0.0f : a.rand_ini[(int64_t)b * a.H + h];
+      float v;
+      if (L == 1) {
+        v = rad(0, mult, ini);
+      } else {
+        int lo, hi; float fr;
+        lin_coord(i, d.sc_dn, d.hsc_dn, L, lo, hi, fr);
+        v = add_rn(mul_rn(rad(lo, mult, ini), sub_rn(1.0f, fr)), mul_rn(rad(hi, mult, ini), fr));
+      }
+      vterm[h * kPhaseChunk + (i - c0)] = v;
     }
-    cum = add_rn(cum, v);
-    float ph = mul_rn(mul_rn(cum, 2.0f), pi_f);
-    out[i] = mul_rn(ph, (float)a.up);
+    __syncthreads();
+    if (tid < a.H) {
+      float* out = a.phase_ws + ((int64_t)b * a.H + tid) * (a.L2 + 1) + c0;
+      const float* vt = vterm + tid * kPhaseChunk;
+      for (int i = 0; i < cn; ++i) {
+        cum = add_rn(cum, vt[i]);
+        out[i] = mul_rn(mul_rn(mul_rn(cum, 2.0f), pi_f), (float)a.up);
+      }
+    }
+    __syncthreads();
   }
 }
 
+constexpr int kMergeMaxH = 16;
+
 __global__ __launch_bounds__(256) void sine_merge_kernel(const mi355_sine_source_args a) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  // the gaussian noise [B, L, H] is the bulk of this kernel's bytes (H floats per sample against one float out): a workgroup's 256 x H block is
+  // contiguous, so it comes in as 16-byte loads and is read back per sample at stride H (H = 9: odd, conflict-free)
+  __shared__ __attribute__((aligned(16))) float nzs[256 * kMergeMaxH];
+  const int t0 = blockIdx.x * 256, tid = threadIdx.x, b = blockIdx.y;
+  const int t = t0 + tid;
   const int len2 = a.lens2 ? a.lens2[b] : a.L2;
   const SineDims d = sine_dims(len2, a.up);
   const int L = d.L;
+  if (t0 >= L) return;
+  {
+    const int64_t item = (int64_t)a.L2 * a.up * a.H;            // floats per utterance
+    const float* src = a.noise + (int64_t)b * item + (int64_t)t0 * a.H;
+    const int nfl = (int)min((int64_t)256 * a.H, item - (int64_t)t0 * a.H);
+    if ((((uintptr_t)src) & 15) == 0) {
+      for (int i = tid * 4; i < nfl; i += 1024) {
+        if (i + 4 <= nfl) *(float4*)(nzs + i) = *(const float4*)(src + i);
+        else for (int j = i; j < nfl; ++j) nzs[j] = src[j];
+      }
+    } else {
+      for (int i = tid; i < nfl; i += 256) nzs[i] = src[i];
+    }
+  }
+  __syncthreads();
   if (t >= L) return;
   const int small = min(d.small, a.L2 + 1);
   const int big = d.big;
   const float f0v = a.f0[(int64_t)b * a.ld_f0 + t / a.up];
   const float uv = f0v > a.voiced_thr ? 1.0f : 0.0f;
   const float namp = add_rn(mul_rn(uv, a.noise_std), mul_rn(sub_rn(1.0f, uv), a.sine_amp) / 3.0f);
-  const float* nz = a.noise + ((int64_t)b * a.L2 * a.up + t) * a.H;
+  const float* nz = nzs + tid * a.H;
+  int lo = 0, hi = 0; float fr = 0.f;
+  if (small > 1) lin_coord(t, d.sc_up, d.hsc_up, small, lo, hi, fr);
+  const float omf = sub_rn(1.0f, fr);
   float accv = 0.f;
   for (int h = 0; h < a.H; ++h) {
     float sv = 0.f;
     if (t < big) {
       const float* ph = a.phase_ws + ((int64_t)b * a.H + h) * (a.L2 + 1);
-      float p;
-      if (small == 1) {
-        p = ph[0];
-      } else {
-        int lo, hi; float fr;
-        lin_coord(t, d.sc_up, d.hsc_up, small, lo, hi, fr);
-        p = add_rn(mul_rn(ph[lo], sub_rn(1.0f, fr)), mul_rn(ph[hi], fr));
-      }
+      const float p = small == 1 ? ph[0] : add_rn(mul_rn(ph[lo], omf), mul_rn(ph[hi], fr));
       sv = mul_rn(sinf(p), a.sine_amp);
     }
     const float sw = add_rn(mul_rn(sv, uv), mul_rn(namp, nz[h]));
@@ -229,6 +262,143 @@ __global__ __launch_bounds__(256) void istft_head_kernel(const mi355_istft_head_
   }
 }
 
+// ---------------------------------------------------------------- compile-time (n_fft, hop) variants of the two kernels above
+// Kokoro's generator runs n_fft = 20, hop = 5 over 31 681 frames per 6.6 s utterance.  The generic kernels rebuild an fp64 twiddle table with
+// sincospi in every workgroup (tens of microseconds of latency on 20 lanes), index it with a runtime (k n) mod N and keep the frame in a
+// runtime-indexed array; here the table arrives as a kernel argument (built once on the host), every loop is unrolled so each twiddle is a scalar
+// operand, the real-input symmetry x[n] +- x[N-n] halves the products, a workgroup's samples / rows are staged through LDS with coalesced
+// accesses and the results leave the same way.  Sums stay in fp64 (rounded once to fp32, like the oracle's rfft / irfft in double).
+struct SmallTw { double c[32]; double s[32]; };
+
+template <int N, int HOP>
+__global__ __launch_bounds__(256) void stft_magphase_fast_kernel(const mi355_stft_magphase_args a, const SmallTw tw) {
+  constexpr int nb = N / 2 + 1, FB = 256, SPAN = (FB - 1) * HOP + N, YS = 2 * nb + 1;
+  __shared__ float xs[SPAN];
+  __shared__ float ys[FB * YS];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int len = a.lens ? a.lens[b] : a.L;
+  const int nframes = len / HOP + 1;
+  const int f0 = blockIdx.x * FB;
+  if (f0 >= nframes) return;
+  const float* xb = a.x + (int64_t)b * a.ldx;
+  for (int j = tid; j < SPAN; j += 256) {
+    int i = f0 * HOP + j - N / 2;
+    if (i < 0) i = -i;
+    if (i >= len) i = 2 * (len - 1) - i;
+    i = i < 0 ? 0 : (i >= len ? len - 1 : i);   // only reached by frames past the end, which are not stored
+    xs[j] = xb[i];
+  }
+  __syncthreads();
+  double xw[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) xw[n] = (double)mul_rn(xs[tid * HOP + n], a.window[n]);  // frames * w is an fp32 product in the reference
+  double sp[N / 2], sm[N / 2];
+#pragma unroll
+  for (int n = 1; n < N / 2; ++n) { sp[n] = xw[n] + xw[N - n]; sm[n] = xw[n] - xw[N - n]; }
+  float* yrow = ys + tid * YS;
+#pragma unroll
+  for (int k = 0; k < nb; ++k) {
+    double re = (k & 1) ? xw[0] - xw[N / 2] : xw[0] + xw[N / 2];
+    double im = 0.0;
+#pragma unroll
+    for (int n = 1; n < N / 2; ++n) {
+      const int m = (k * n) % N;
+      re = fma(sp[n], tw.c[m], re);
+      im = fma(-sm[n], tw.s[m], im);
+    }
+    const float ref = (float)re;
+    const float imf = (k == 0 || 2 * k == N) ? 0.0f : (float)im;
+    yrow[k] = hypotf(ref, imf);
+    yrow[nb + k] = atan2f(imf, ref);
+  }
+  __syncthreads();
+  float* yb = a.y + (int64_t)b * a.y_bstride;
+  const int nrows = min(FB, nframes - f0);
+  for (int i = tid; i < nrows * 2 * nb; i += 256) {
+    const int r = i / (2 * nb), c = i - r * (2 * nb);
+    yb[(int64_t)(f0 + r) * a.ldy + c] = ys[r * YS + c];
+  }
+}
+
+template <int N, int HOP>
+__global__ __launch_bounds__(256) void istft_head_fast_kernel(const mi355_istft_head_args a, const SmallTw tw) {
+  constexpr int nb = N / 2 + 1, HALO = (N + HOP - 1) / HOP, FT = 256, FO = FT - HALO, XS = 2 * nb + 1, TS = N + 1;
+  __shared__ float xin[FT * XS];
+  __shared__ float td[FT * TS];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int Fr = a.lens ? a.lens[b] : a.Fr;
+  const int fa = blockIdx.x * FO - HALO;  // first staged frame (may be negative)
+  const float* xb = a.x + (int64_t)b * a.x_bstride;
+  for (int i = tid; i < FT * 2 * nb; i += 256) {
+    const int j = i / (2 * nb), c = i - j * (2 * nb), f = fa + j;
+    xin[j * XS + c] = (f >= 0 && f < Fr) ? xb[(int64_t)f * a.ldx + c] : 0.f;
+  }
+  __syncthreads();
+  {
+    const int f = fa + tid;
+    const bool valid = f >= 0 && f < Fr;
+    const float* xr = xin + tid * XS;
+    double re[nb], im[nb];
+#pragma unroll
+    for (int k = 0; k < nb; ++k) {
+      const float mag = expf(xr[k]);
+      const float ph = sinf(xr[nb + k]);
+      re[k] = valid ? (double)mul_rn(mag, cosf(ph)) : 0.0;
+      im[k] = valid ? (double)mul_rn(mag, sinf(ph)) : 0.0;
+    }
+    float* tr = td + tid * TS;
+#pragma unroll
+    for (int n = 0; n <= N / 2; ++n) {
+      const double base = (n & 1) ? re[0] - re[nb - 1] : re[0] + re[nb - 1];
+      double A = 0.0, Bs = 0.0;
+#pragma unroll
+      for (int k = 1; k < nb - 1; ++k) {
+        const int m = (k * n) % N;
+        A = fma(re[k], tw.c[m], A);
+        Bs = fma(im[k], tw.s[m], Bs);
+      }
+      tr[n] = mul_rn((float)((base + 2.0 * (A - Bs)) / (double)N), a.window[n]);
+      if (n > 0 && n < N / 2) tr[N - n] = mul_rn((float)((base + 2.0 * (A + Bs)) / (double)N), a.window[N - n]);
+    }
+  }
+  __syncthreads();
+  const int total = (Fr - 1) * HOP;  // trimmed length
+  for (int i = tid; i < FO * HOP; i += 256) {
+    const int p = blockIdx.x * FO * HOP + i;  // untrimmed position
+    const int t = p - N / 2;
+    if (t < 0 || t >= total) continue;
+    int f_lo = (p - N + HOP) / HOP; if (p - N + 1 <= 0) f_lo = 0;
+    int f_hi = p / HOP; if (f_hi > Fr - 1) f_hi = Fr - 1;
+    float rec = 0.f, ws = 0.f;
+    for (int f = f_lo; f <= f_hi; ++f) {
+      const int n = p - f * HOP;
+      if (n < 0 || n >= N) continue;
+      rec = add_rn(rec, td[(f - fa) * TS + n]);
+      const float w = a.window[n];
+      ws = add_rn(ws, mul_rn(w, w));
+    }
+    a.audio[(int64_t)b * a.ld_audio + t] = (ws > 1e-10f) ? rec / ws : rec;
+  }
+}
+
+SmallTw make_small_tw(int N) {
+  SmallTw tw;
+  for (int m = 0; m < 32; ++m) {
+    const long double ang = 2.0L * 3.14159265358979323846264338327950288L * (long double)(m % N) / (long double)N;
+    tw.c[m] = (double)cosl(ang);
+    tw.s[m] = (double)sinl(ang);
+  }
+  // the exact values at the quarter points (cosl / sinl of a rounded multiple of pi leave ~1e-20 there; the generic kernels' sincospi is exact)
+  for (int m = 0; m < N; ++m) {
+    if ((4 * m) % N == 0) {
+      const int q = (4 * m) / N;
+      tw.c[m] = q == 0 ? 1.0 : (q == 2 ? -1.0 : 0.0);
+      tw.s[m] = q == 1 ? 1.0 : (q == 3 ? -1.0 : 0.0);
+    }
+  }
+  return tw;
+}
+
 // ---------------------------------------------------------------------------------------------- interpolate1d
 // tts/models/interpolate.py:61-132: nearest = floor(i * W/size) clipped; linear with torch semantics (half-pixel source coordinate clamped at 0,
 // or align_corners).  The coordinate arithmetic is float32 with one rounding per operation, exactly the MLX op sequence (arange * scalar, + scalar,
@@ -278,7 +448,8 @@ extern "C" int mi355_sine_source(const mi355_sine_source_args* ap, void* stream)
   MI355_REQUIRE(d.small <= a.L2 + 1, "sine_source: coarse length %d exceeds workspace", d.small);
   hipStream_t st = (hipStream_t)stream;
   MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL(sine_phase_kernel, dim3(a.B), dim3(64), 0, st, a);
+  MI355_REQUIRE(a.H <= kMergeMaxH, "sine_source: at most %d harmonics", kMergeMaxH);
+  hipLaunchKernelGGL(sine_phase_kernel, dim3(a.B), dim3(256), sizeof(float) * a.H * kPhaseChunk, st, a);
   MI355_LAUNCH_CHECK("sine_phase");
   MI355_CLEAR_ERROR();
   hipLaunchKernelGGL(sine_merge_kernel, dim3((d.L + 255) / 256, a.B), dim3(256), 0, st, a);
@@ -293,6 +464,12 @@ extern "C" int mi355_stft_magphase(const mi355_stft_magphase_args* ap, void* str
   MI355_REQUIRE(a.hop > 0 && a.L > a.n_fft / 2, "stft_magphase: input too short for reflect padding");
   const int nframes = a.L / a.hop + 1;
   MI355_CLEAR_ERROR();
+  if (a.n_fft == 20 && a.hop == 5) {
+    static const SmallTw tw20 = make_small_tw(20);
+    hipLaunchKernelGGL((stft_magphase_fast_kernel<20, 5>), dim3((nframes + 255) / 256, a.B), dim3(256), 0, (hipStream_t)stream, a, tw20);
+    MI355_LAUNCH_CHECK("stft_magphase");
+    return MI355_OK;
+  }
   hipLaunchKernelGGL(stft_magphase_kernel, dim3((nframes + 255) / 256, a.B), dim3(256), 0, (hipStream_t)stream, a);
   MI355_LAUNCH_CHECK("stft_magphase");
   return MI355_OK;
@@ -303,6 +480,15 @@ extern "C" int mi355_istft_head(const mi355_istft_head_args* ap, void* stream) {
   const mi355_istft_head_args a = *ap;
   MI355_REQUIRE(a.n_fft >= 2 && a.n_fft <= kMaxSmallFft && a.hop > 0 && a.Fr > 1, "istft_head: bad shape");
   const int N = a.n_fft, nb = N / 2 + 1;
+  if (N == 20 && a.hop == 5) {
+    static const SmallTw tw20 = make_small_tw(20);
+    constexpr int FO = 256 - (20 + 5 - 1) / 5;
+    const int total_untrimmed = (a.Fr - 1) * 5 + 20;
+    MI355_CLEAR_ERROR();
+    hipLaunchKernelGGL((istft_head_fast_kernel<20, 5>), dim3((total_untrimmed + FO * 5 - 1) / (FO * 5), a.B), dim3(256), 0, (hipStream_t)stream, a, tw20);
+    MI355_LAUNCH_CHECK("istft_head");
+    return MI355_OK;
+  }
   const int halo = (N + a.hop - 1) / a.hop, FT = kHeadFrames + halo;
   const size_t lds = sizeof(double) * 2 * N + sizeof(float) * N + sizeof(float) * FT * nb * 2 + sizeof(float) * FT * N;
   // blocks cover untrimmed positions [0, (Fr-1)*hop + N)

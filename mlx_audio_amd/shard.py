@@ -211,11 +211,12 @@ class ShardChannel:
         return res  # type: ignore[return-value]
 
 
-def kokoro_step(ch: ShardChannel, engine, requests: Optional[Sequence[torch.Tensor]], ref_s_of: Callable[[int, int], torch.Tensor],
+def kokoro_step(ch: ShardChannel, engine, requests: Optional[Sequence[torch.Tensor]], ref_s_of: Callable,
                 samples_per_frame: int, forced_durations_of: Optional[Callable[[int], torch.Tensor]] = None, tolerance: float = 0.05,
                 wire_dtype: Optional[torch.dtype] = None, back_kwargs: Optional[Callable[[List[int]], dict]] = None):
     """One sharded Kokoro synthesis step: requests out, token-rate half on the token-LPT shard, frame counts shared, utterances re-balanced on
-    the real frame counts, frame-rate half, waveforms back.  ``ref_s_of(item, n_tokens)`` -> the item's style row ``[1, 256]``;
+    the real frame counts, frame-rate half, waveforms back.  ``ref_s_of(item, n_tokens)`` -> the item's style row ``[1, 256]`` (or, when it has
+    a ``rows`` attribute, ``ref_s_of.rows(items, lens)`` -> all rows ``[n, 256]`` in one device gather);
     ``back_kwargs(items)`` -> extra arguments of ``engine.back`` for the final shard (SineGen noise in the bench).  Returns the waveforms on
     ``ch.dst`` (``None`` elsewhere).  Collectives: broadcast, all_reduce (int32 counts), [all_to_all_single], all_to_all_single."""
     from .tts.models.kokoro.engine import KokoroFront
@@ -225,7 +226,7 @@ def kokoro_step(ch: ShardChannel, engine, requests: Optional[Sequence[torch.Tens
     st = None
     if first:
         ids = ch.my_ids(block, lens)
-        ref = torch.cat([ref_s_of(i, lens[i]) for i in first], 0)
+        ref = ref_s_of.rows(first, lens) if hasattr(ref_s_of, "rows") else torch.cat([ref_s_of(i, lens[i]) for i in first], 0)
         fd = [forced_durations_of(i) for i in first] if forced_durations_of else None
         st = engine.front(ids, ref, forced_durations=fd)
     frames = ch.share_counts(st.frames if st else [])
@@ -236,17 +237,20 @@ def kokoro_step(ch: ShardChannel, engine, requests: Optional[Sequence[torch.Tens
     mine = new[ch.rank]
     outs: List[torch.Tensor] = []
     if mine:
-        kept = [i for i in mine if i in pos]
-        parts = []
-        if kept:
-            parts.append((kept, st.select([pos[i] for i in kept])))
-        got = [i for i in mine if i not in pos]
-        if got:
-            parts.append((got, KokoroFront.unpack([received[i] for i in got], [frames[i] for i in got], style, width, st.speed if st else 1.0)))
-        order = [i for p in parts for i in p[0]]
-        merged = KokoroFront.concat([p[1] for p in parts])
-        perm = sorted(range(len(order)), key=lambda k: order[k])  # ascending item order == my_items() order
-        merged = merged.select(perm)
+        if mine == first:
+            merged = st  # nothing moved: the state goes on as it is (its padded device tensors included)
+        else:
+            kept = [i for i in mine if i in pos]
+            parts = []
+            if kept:
+                parts.append((kept, st.select([pos[i] for i in kept])))
+            got = [i for i in mine if i not in pos]
+            if got:
+                parts.append((got, KokoroFront.unpack([received[i] for i in got], [frames[i] for i in got], style, width, st.speed if st else 1.0)))
+            order = [i for p in parts for i in p[0]]
+            merged = KokoroFront.concat([p[1] for p in parts])
+            perm = sorted(range(len(order)), key=lambda k: order[k])  # ascending item order == my_items() order
+            merged = merged.select(perm)
         outs, _ = engine.back(merged, **(back_kwargs(mine) if back_kwargs else {}))
     counts = [f * samples_per_frame for f in frames]
     return ch.gather(outs, counts=counts, wire_dtype=wire_dtype)

@@ -110,6 +110,7 @@ class KokoroFront:
     frames: List[int]
     speed: float = 1.0
     trace: Optional[dict] = None
+    padded: Optional[dict] = None  # front()'s own padded device tensors: back() on the same, unmoved state skips the re-padding
 
     def select(self, which: Sequence[int]) -> "KokoroFront":
         which = list(which)
@@ -480,10 +481,16 @@ class KokoroEngine:
         self._conv(xl, self.dur_proj, logits[:, :, :bins], lens_in=lens_t, lens_out=lens_t)
         forced = None
         if forced_durations is not None:
-            forced = torch.zeros((B, Tm), dtype=torch.int32)
-            for b, fd in enumerate(forced_durations):
-                forced[b, : Ts[b]] = fd.to(torch.int32)
-            forced = forced.to(dev)
+            if all(fd.is_cuda for fd in forced_durations):  # resident: pad on the device (a host-side fill would read every row back)
+                forced = torch.nn.utils.rnn.pad_sequence([fd.to(torch.int32) for fd in forced_durations], batch_first=True)
+                if forced.shape[1] < Tm:
+                    forced = torch.nn.functional.pad(forced, (0, Tm - forced.shape[1]))
+                forced = forced.contiguous()
+            else:
+                forced = torch.zeros((B, Tm), dtype=torch.int32)
+                for b, fd in enumerate(forced_durations):
+                    forced[b, : Ts[b]] = fd.to(torch.int32)
+                forced = forced.to(dev)
         idx_cap = Tm * 100
         dur, dur_raw, frames, idx = ops.duration_align(logits[:, :, :bins], Tm, B, float(speed), idx_cap, dev, lens=lens_t,
                                                        forced=forced, bins=bins)
@@ -491,7 +498,8 @@ class KokoroEngine:
         Fs = [int(v) for v in frames_h]
         return KokoroFront(ids=[ids[b, : Ts[b]] for b in range(B)], ref_s=ref_s, d=[d[b, : Ts[b]] for b in range(B)],
                            dur=[dur[b, : Ts[b]] for b in range(B)], frames=Fs, speed=float(speed),
-                           trace=dict(dur_raw=dur_raw, bert=h) if keep_trace else None)
+                           trace=dict(dur_raw=dur_raw, bert=h) if keep_trace else None,
+                           padded=dict(ids=ids, lens_t=lens_t, d=d, dur=dur, frames=frames, idx=idx, gb_dec=gb_dec, gb_pred=gb_pred))
 
     def back(self, st: "KokoroFront", rand_ini: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, noise_seed: int = 1234,
              return_intermediates: bool = False, overrides: Optional[Dict[str, torch.Tensor]] = None):
@@ -502,19 +510,23 @@ class KokoroEngine:
         Ts = [int(t.numel()) for t in st.ids]
         Tm = max(Ts)
         ragged = B > 1
-        ids = torch.nn.utils.rnn.pad_sequence([t.to(device=dev, dtype=torch.int32) for t in st.ids], batch_first=True)
-        lens_t = torch.tensor(Ts, dtype=torch.int32, device=dev) if ragged else None
-        ref_s = st.ref_s.to(device=dev, dtype=torch.float32).contiguous()
-        s_dec = ref_s[:, :sty].contiguous()
-        s_pred = ref_s[:, sty:].contiguous()
-        gb_dec = self._new(B, 1, self.style_dec.cout)
-        gb_pred = self._new(B, 1, self.style_pred.cout)
-        self._conv(s_dec[:, None, :], self.style_dec, gb_dec)
-        self._conv(s_pred[:, None, :], self.style_pred, gb_pred)
-        gb_dec, gb_pred = gb_dec[:, 0], gb_pred[:, 0]
-        d = torch.nn.utils.rnn.pad_sequence([t.to(dev) for t in st.d], batch_first=True).contiguous()
-        forced = torch.nn.utils.rnn.pad_sequence([t.to(device=dev, dtype=torch.int32) for t in st.dur], batch_first=True).contiguous()
-        dur, _, frames, idx = ops.duration_align(None, Tm, B, st.speed, Tm * 100, dev, lens=lens_t, forced=forced)
+        if st.padded is not None:
+            pd = st.padded
+            ids, lens_t, d, dur, frames, idx, gb_dec, gb_pred = (pd[k] for k in ("ids", "lens_t", "d", "dur", "frames", "idx", "gb_dec", "gb_pred"))
+        else:
+            ids = torch.nn.utils.rnn.pad_sequence([t.to(device=dev, dtype=torch.int32) for t in st.ids], batch_first=True)
+            lens_t = torch.tensor(Ts, dtype=torch.int32, device=dev) if ragged else None
+            ref_s = st.ref_s.to(device=dev, dtype=torch.float32).contiguous()
+            s_dec = ref_s[:, :sty].contiguous()
+            s_pred = ref_s[:, sty:].contiguous()
+            gb_dec = self._new(B, 1, self.style_dec.cout)
+            gb_pred = self._new(B, 1, self.style_pred.cout)
+            self._conv(s_dec[:, None, :], self.style_dec, gb_dec)
+            self._conv(s_pred[:, None, :], self.style_pred, gb_pred)
+            gb_dec, gb_pred = gb_dec[:, 0], gb_pred[:, 0]
+            d = torch.nn.utils.rnn.pad_sequence([t.to(dev) for t in st.d], batch_first=True).contiguous()
+            forced = torch.nn.utils.rnn.pad_sequence([t.to(device=dev, dtype=torch.int32) for t in st.dur], batch_first=True).contiguous()
+            dur, _, frames, idx = ops.duration_align(None, Tm, B, st.speed, Tm * 100, dev, lens=lens_t, forced=forced)
         Fs = list(st.frames)
         dur_raw = st.trace["dur_raw"] if st.trace else None
         h = st.trace["bert"] if st.trace else None
