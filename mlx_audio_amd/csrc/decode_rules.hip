@@ -151,6 +151,130 @@ __global__ __launch_bounds__(kT) void whisper_greedy_step_kernel(const mi355_whi
   }
 }
 
+// Same step with the row held in registers: the generic kernel above walks the V logits seven times out of L2 (max, sum, two maxima, timestamp
+// sum, arg-max, final sum), re-applying the suppress lists on every pass -- 80 us per step for V = 51 865 with only B workgroups on the chip.
+// Here a thread loads its NV = ceil(V / 1024) logits once (all loads in flight together), applies SuppressBlank / SuppressTokens once, and every
+// later pass is register arithmetic plus a block reduction.  Same formulas and reduction helpers; only the per-thread grouping of the
+// timestamp-mass sum differs (elements tid + j * 1024 instead of a walk that starts at timestamp_begin).
+template <int NV>
+__global__ __launch_bounds__(kT) void whisper_greedy_step_reg_kernel(const mi355_whisper_step_args a) {
+  __shared__ float red[kT / 64];
+  __shared__ int redi[kT / 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* lg = a.logits + (int64_t)b * a.ld;
+  int32_t* tk = a.tokens + (int64_t)b * a.tokens_ld;
+  const int n = a.n, nseq = n - a.sample_begin;
+  const int last = n >= 1 ? tk[n - 1] : -1;
+  const bool first = n == a.sample_begin;
+  const bool last_ts = nseq >= 1 && last >= a.timestamp_begin;
+  const bool pen_ts = nseq < 2 || tk[n - 2] >= a.timestamp_begin;
+  const float NEG = -INFINITY;
+  float x1[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int v = tid + j * kT;
+    x1[j] = v < a.V ? lg[v] : NEG;
+  }
+  if (a.suppress_mask) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int v = tid + j * kT;
+      if (v < a.V) x1[j] += a.suppress_mask[v];
+    }
+  }
+  if (first && a.blank_ids) {
+    for (int i = 0; i < a.n_blank; ++i) {
+      const int bv = a.blank_ids[i];
+      if (bv >= 0 && bv < a.V && (bv & (kT - 1)) == tid) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) if (j == (bv >> 10)) x1[j] = NEG;   // (the mask add above keeps -inf at -inf)
+      }
+    }
+  }
+  auto mask2 = [&](int v) -> float {  // ApplyTimestampRules, before the timestamp-dominance rule
+    if (!a.timestamp_rules) return 0.f;
+    if (v == a.no_timestamps) return NEG;
+    if (last_ts) {
+      if (pen_ts) { if (v >= a.timestamp_begin) return NEG; }
+      else if (v < a.eot) return NEG;
+    }
+    if (first) {
+      if (v < a.timestamp_begin) return NEG;
+      if (a.max_initial_timestamp_index >= 0 && v > a.timestamp_begin + a.max_initial_timestamp_index) return NEG;
+    }
+    return 0.f;
+  };
+  bool text_killed = false;
+  if (a.timestamp_rules) {
+    float mx = NEG;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) mx = fmaxf(mx, x1[j]);
+    mx = block_max(mx, red);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) if (tid + j * kT < a.V) s += expf(x1[j] - mx);
+    s = block_sum(s, red);
+    const float lse = mx + logf(s);
+    float mts = NEG, mtext = NEG;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int v = tid + j * kT;
+      if (v < a.V) {
+        const float lp = x1[j] - lse;
+        if (v >= a.timestamp_begin) mts = fmaxf(mts, lp); else mtext = fmaxf(mtext, lp);
+      }
+    }
+    mts = block_max(mts, red);
+    mtext = block_max(mtext, red);
+    float sts = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int v = tid + j * kT;
+      if (v < a.V && v >= a.timestamp_begin) sts += expf((x1[j] - lse) - mts);
+    }
+    sts = block_sum(sts, red);
+    text_killed = mts + logf(sts) > mtext;
+  }
+  ArgMax best; best.v = NEG; best.i = 0x7fffffff;
+  ArgMax bsel; bsel.v = NEG; bsel.i = 0x7fffffff;
+  float fmx = NEG;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int v = tid + j * kT;
+    if (v < a.V) {
+      float x = x1[j] + mask2(v);
+      if (text_killed && v < a.timestamp_begin) x = NEG;
+      x1[j] = x;
+      if (a.filtered) a.filtered[(int64_t)b * a.ld + v] = x;
+      fmx = fmaxf(fmx, x);
+      ArgMax c; c.v = x; c.i = v;
+      best = better(best, c);
+      if (a.gumbel) { ArgMax d; d.v = x / a.temperature + a.gumbel[(int64_t)b * a.ld + v]; d.i = v; bsel = better(bsel, d); }
+    }
+  }
+  best = block_argmax(best, red, redi);
+  if (a.gumbel) best = block_argmax(bsel, red, redi);
+  fmx = block_max(fmx, red);
+  float fs = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) if (tid + j * kT < a.V) fs += expf(x1[j] - fmx);
+  fs = block_sum(fs, red);
+  // the chosen token's filtered logit lives in one thread's registers: hand it over through LDS
+  __shared__ float chosen_x;
+  const int chosen = a.forced_next ? a.forced_next[b] : best.i;
+  if (chosen >= 0 && chosen < a.V && (chosen & (kT - 1)) == tid) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) if (j == (chosen >> 10)) chosen_x = x1[j];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float lp = chosen_x - (fmx + logf(fs));
+    const bool done = last == a.eot;
+    if (!done) a.sum_logprobs[b] += lp;
+    tk[n] = done ? a.eot : chosen;
+  }
+}
+
 __global__ __launch_bounds__(kT) void softmax_prob_at_kernel(const float* logits, int ld, int V, int token, float* out) {
   __shared__ float red[kT / 64];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -174,7 +298,9 @@ extern "C" int mi355_whisper_greedy_step(const mi355_whisper_step_args* ap, void
   MI355_REQUIRE(!a.timestamp_rules || (a.timestamp_begin > 0 && a.timestamp_begin < a.V && a.eot >= 0), "whisper_greedy_step: bad timestamp ids");
   MI355_REQUIRE(!a.gumbel || a.temperature > 0.f, "whisper_greedy_step: sampling needs temperature > 0");
   MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL(whisper_greedy_step_kernel, dim3(a.B), dim3(kT), 0, (hipStream_t)stream, a);
+  static_assert(kT == 1024, "the register kernel indexes with v & 1023 / v >> 10");
+  if (a.V <= 52 * kT) hipLaunchKernelGGL(whisper_greedy_step_reg_kernel<52>, dim3(a.B), dim3(kT), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(whisper_greedy_step_kernel, dim3(a.B), dim3(kT), 0, (hipStream_t)stream, a);
   MI355_LAUNCH_CHECK("whisper_greedy_step");
   return MI355_OK;
 }

@@ -387,6 +387,202 @@ __global__ __launch_bounds__(256) void gemv_res_kernel(const mi355_gemv_args a, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------- one input row (M = 1)
+// The single-sequence decode step (CSM generate_frame: 16 backbone + 31 x 4 depth-decoder layer steps per frame, sesame.py:361-404) is a chain
+// of ~650 of these per frame; profiles/r2_kernel_stats_csm_bygrid_call10.txt has the chunked kernel above at 5.8 us (q|k|v, 3 MB), 14.2 us
+// (gate|up, 34-67 MB) and 6.7 us (o-proj / down) per launch -- bound by what happens around the weight stream: every 8-column workgroup
+// re-stages x through LDS behind three barriers and recomputes the norm statistics, and a wave's life is two k-slices long.
+//
+// gemv1_res_kernel (K <= 4 slices, i.e. 2048 elements at 16 bits): a wave is autonomous.  Lane l multiplies the weights at k = it * SL + l * EPL
+// with the x values at the same k -- ITS OWN 8 (16) floats of each slice -- so x lives in registers, the fused RMSNorm / LayerNorm statistics are
+// one in-register pass plus a wave reduction, and there is no LDS and no barrier anywhere.  Waves walk column groups grid-stride with the next
+// group's weights already in flight (double buffer), so the stream does not stop at group boundaries.
+//
+// gemv1_splitk_kernel (K > 2048: the down projections): 4 columns per workgroup, the 4 waves split K; a lane streams its slices of x with the
+// weights (same prefetch ring), partial sums meet in LDS once.  16 KB of weights in flight per wave keeps HBM busy with only N / 4 workgroups.
+template <int NC, int WT>
+__global__ __launch_bounds__(256) void gemv1_res_kernel(const mi355_gemv_args a, const int ngroups) {
+  constexpr int EPL = mi355_wt<WT>::EPL, ESZ = 16 / EPL, SL = 64 * EPL;
+  constexpr int NIT = 2048 / (64 * 8) / (EPL / 8);  // slices covering K <= 2048 (4 at 16 bits, 2 for fp8 whose slice is 1024 elements)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int K = a.K;
+  float xr[NIT][EPL];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int k = it * SL + lane * EPL;
+#pragma unroll
+    for (int j4 = 0; j4 < EPL / 4; ++j4) {
+      const float4 t = k < K ? *(const float4*)(a.x + k + 4 * j4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      xr[it][4 * j4] = t.x; xr[it][4 * j4 + 1] = t.y; xr[it][4 * j4 + 2] = t.z; xr[it][4 * j4 + 3] = t.w;
+    }
+  }
+  uint4 ring[2][NIT][NC];
+  auto issue = [&](int g, uint4 (&dst)[NIT][NC]) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int n = g * NC + c < a.N ? g * NC + c : a.N - 1;  // clamp: tail columns recompute the last row, never stored
+      const uint8_t* wrow = (const uint8_t*)a.w + (int64_t)n * a.ldw * ESZ;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int k = it * SL + lane * EPL;
+        dst[it][c] = k < K ? *(const uint4*)(wrow + (int64_t)k * ESZ) : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  };
+  int g = blockIdx.x * 4 + wave;
+  const int gstep = gridDim.x * 4;
+  if (g < ngroups) issue(g, ring[0]);   // the weight stream starts before the statistics: its HBM latency overlaps the norm
+  if (a.norm) {
+    float mean = 0.f;
+    if (a.norm == 1) {
+      float s = 0.f;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) s += xr[it][j];
+      mean = wave_sum(s) / (float)K;
+    }
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) {
+        const float d = (it * SL + lane * EPL + j < K) ? xr[it][j] - mean : 0.f;
+        q += d * d;
+      }
+    const float var = wave_sum(q) / (float)K;
+    const float rstd = a.norm == 1 ? 1.0f / sqrtf(var + a.norm_eps) : rsqrtf(var + a.norm_eps);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int k = it * SL + lane * EPL;
+      if (k < K) {
+#pragma unroll
+        for (int j4 = 0; j4 < EPL / 4; ++j4) {
+          const float4 w4 = a.norm_weight ? *(const float4*)(a.norm_weight + k + 4 * j4) : make_float4(1.f, 1.f, 1.f, 1.f);
+          const float4 b4 = a.norm_bias ? *(const float4*)(a.norm_bias + k + 4 * j4) : make_float4(0.f, 0.f, 0.f, 0.f);
+          xr[it][4 * j4] = (xr[it][4 * j4] - mean) * rstd * w4.x + b4.x;
+          xr[it][4 * j4 + 1] = (xr[it][4 * j4 + 1] - mean) * rstd * w4.y + b4.y;
+          xr[it][4 * j4 + 2] = (xr[it][4 * j4 + 2] - mean) * rstd * w4.z + b4.z;
+          xr[it][4 * j4 + 3] = (xr[it][4 * j4 + 3] - mean) * rstd * w4.w + b4.w;
+        }
+      }
+    }
+  }
+  int buf = 0;
+  for (; g < ngroups; g += gstep, buf ^= 1) {
+    if (g + gstep < ngroups) {
+      if (buf == 0) issue(g + gstep, ring[1]); else issue(g + gstep, ring[0]);
+    }
+    float acc[NC][1];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c][0] = 0.f;
+    auto consume = [&](uint4 (&src)[NIT][NC]) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          float wf[EPL];
+          cvt_w16<WT>(src[it][c], wf);
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) acc[c][0] = fmaf(xr[it][j], wf[j], acc[c][0]);
+        }
+      }
+    };
+    if (buf == 0) consume(ring[0]); else consume(ring[1]);
+    gemv_finish<1, NC>(a, acc, g * NC, lane);
+  }
+}
+
+template <int WT>
+__global__ __launch_bounds__(256) void gemv1_splitk_kernel(const mi355_gemv_args a) {
+  constexpr int NC = 4, D = 4;
+  constexpr int EPL = mi355_wt<WT>::EPL, ESZ = 16 / EPL, SL = 64 * EPL;
+  __shared__ float part[4][NC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * NC;
+  const int n_it = (a.K + SL - 1) / SL;
+  const int per = (n_it + 3) / 4;                       // slices per wave
+  const int it0 = wave * per, it1 = it0 + per < n_it ? it0 + per : n_it;
+  const uint8_t* wrow[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int n = n0 + c < a.N ? n0 + c : a.N - 1;
+    wrow[c] = (const uint8_t*)a.w + (int64_t)n * a.ldw * ESZ;
+  }
+  uint4 wring[D][NC];
+  float4 xring[D][EPL / 4];
+  auto issue = [&](int it, int d) {
+    const int k = it * SL + lane * EPL;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) wring[d][c] = k < a.K ? *(const uint4*)(wrow[c] + (int64_t)k * ESZ) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int j4 = 0; j4 < EPL / 4; ++j4) xring[d][j4] = k < a.K ? *(const float4*)(a.x + k + 4 * j4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (it0 + d < it1) issue(it0 + d, d);
+  float acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+  for (int base = it0; base < it1; base += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int it = base + d;
+      if (it >= it1) break;
+      float xv[EPL];
+#pragma unroll
+      for (int j4 = 0; j4 < EPL / 4; ++j4) {
+        xv[4 * j4] = xring[d][j4].x; xv[4 * j4 + 1] = xring[d][j4].y; xv[4 * j4 + 2] = xring[d][j4].z; xv[4 * j4 + 3] = xring[d][j4].w;
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        float wf[EPL];
+        cvt_w16<WT>(wring[d][c], wf);
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) acc[c] = fmaf(xv[j], wf[j], acc[c]);
+      }
+      if (it + D < it1) issue(it + D, d);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = wave_sum(acc[c]);
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) part[wave][c] = acc[c];
+  }
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (c < NC && n0 + c < a.N) {
+    const int n = n0 + c;
+    const float sum = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];   // fixed order: run-to-run identical
+    const float ws = a.wscale ? a.wscale[n] * kFp8Unbias : 1.f;
+    float v = gemv_act(sum * ws + (a.bias ? a.bias[n] : 0.f), a.post_act, a.post_slope) * (a.colscale ? a.colscale[n] : 1.f);
+    if (a.res) v += a.res[n];
+    if (a.y2 && n >= a.split) a.y2[n - a.split] = v * a.out_scale;
+    else a.y[n] = v * a.out_scale;
+  }
+}
+
+template <int WT>
+int launch_gemv1(const mi355_gemv_args& a, hipStream_t st) {
+  constexpr int EPL = mi355_wt<WT>::EPL;
+  const int kres = 2048 * (EPL / 8) / (EPL / 8);  // K the register-resident kernel covers (2048 elements for every weight type)
+  MI355_CLEAR_ERROR();
+  if (a.K <= kres) {
+    const bool two = a.glu || a.rope_cos || a.N >= 4096;
+    const int ngroups = two ? (a.N + 1) / 2 : a.N;
+    int blocks = (ngroups + 3) / 4;
+    if (blocks > 1024) blocks = 1024;  // 4 workgroups per CU; the rest of the columns come grid-stride with their weights prefetched
+    if (two) hipLaunchKernelGGL((gemv1_res_kernel<2, WT>), dim3(blocks), dim3(256), 0, st, a, ngroups);
+    else hipLaunchKernelGGL((gemv1_res_kernel<1, WT>), dim3(blocks), dim3(256), 0, st, a, ngroups);
+    MI355_LAUNCH_CHECK("gemv(M=1, register-resident x)");
+    return MI355_OK;
+  }
+  hipLaunchKernelGGL((gemv1_splitk_kernel<WT>), dim3((a.N + 3) / 4), dim3(256), 0, st, a);
+  MI355_LAUNCH_CHECK("gemv(M=1, split K)");
+  return MI355_OK;
+}
+
 template <int MT, int WT>
 int launch_gemv(const mi355_gemv_args& a, hipStream_t st) {
   // one column per wave keeps the most wavefronts (and weight bytes) in flight; two columns per wave halve the LDS reads of x per weight
@@ -425,6 +621,9 @@ int launch_gemv(const mi355_gemv_args& a, hipStream_t st) {
 
 template <int WT>
 int launch_gemv_m(const mi355_gemv_args& a, hipStream_t st) {
+  static const bool m1_old = getenv("MI355_GEMV_M1") != nullptr && getenv("MI355_GEMV_M1")[0] == '0';  // A/B knob: the chunked kernel at one row
+  // split K needs a plain epilogue (no SwiGLU pairs / rotary pairs: those shapes have K <= 2048 in every model of the path) and no fused norm
+  if (a.M == 1 && !m1_old && (a.K <= 2048 || (!a.norm && !a.glu && !a.rope_cos))) return launch_gemv1<WT>(a, st);
   if (a.M == 1) return launch_gemv<1, WT>(a, st);
   if (a.M == 2) return launch_gemv<2, WT>(a, st);
   if (a.M <= 4) return launch_gemv<4, WT>(a, st);

@@ -32,6 +32,11 @@ def setup():
     return S, eng, ref32
 
 
+# Free-running spectral-envelope bar (log10 power, mean |diff| over the 80-band log-mel of the whole utterance).  Measured on MI355X in round 2:
+# see the value printed by test_kokoro_front_end_free_running (profiles/r2_kokoro_free_running_call11.txt); the bar is 2x that measurement.
+ENV_BAR = 0.5
+
+
 def snr_db(got, ref):
     err = (got.double() - ref.double())
     return float(10 * torch.log10(ref.double().pow(2).sum() / err.pow(2).sum().clamp_min(1e-300)))
@@ -83,8 +88,8 @@ def test_kokoro_front_end_free_running(setup):
     a, b = logmel(outs[0].cpu().numpy()), logmel(audio_ref[0].numpy())
     assert a.shape == b.shape
     env_err = float(np.mean(np.abs(a - b)))
-    print(f"free-running log-mel envelope mean |diff| = {env_err:.3f} (log10 power units)")
-    assert env_err < 0.5  # ~5 dB average; identical models differ by ~2 dB here purely through harmonic phase
+    print(f"free-running log-mel envelope mean |diff| = {env_err:.4f} (log10 power units)")
+    assert env_err < ENV_BAR
 
 
 def test_kokoro_vocoder_teacher_forced(setup):
@@ -117,6 +122,49 @@ def test_kokoro_vocoder_teacher_forced(setup):
     assert float(hd[~flips].max()) < 2e-3
     two_pi = hd[flips]
     assert bool(((two_pi - 2 * np.pi).abs() < 1e-3).all())
+
+
+def test_kokoro_vocoder_free_running_f0n_only(setup):
+    """The vocoder FREE-RUNNING from the pitch / energy curves: only F0 / N are injected; SineGen (phase integration, noise, tanh), the n_fft = 20
+    STFT, decoder, generator and iSTFT head all run on their own HIP outputs.  Bar: 2e-3 * peak and 50 dB against the fp32 oracle, after
+    restoring the <= 8 harmonic-phase entries whose value is a +-pi branch of atan2(+-rounding noise, x) (reflect-padded edge frames are exactly
+    symmetric, so their imaginary parts are pure rounding noise; which branch comes out is not a property of the algorithm).
+
+    Why F0 / N themselves must be injected -- the F0-error -> phase budget: the source phase of harmonic h is 2 pi h * sum(f0) / sr, so a relative
+    F0 error eps becomes a phase error 2 pi h f0 eps t after t seconds.  A waveform error of 2e-3 * peak needs that phase error below ~2e-3 rad at
+    the top harmonic (h = 9): for f0 = 200 Hz over the canonical 6.6 s utterance that is eps < 2e-3 / (2 pi * 9 * 200 * 6.6) -- asserted below to be under fp32's
+    own rounding step (2^-24), i.e. no fp32 implementation of the front end, the reference's included, could deliver F0 to that precision:
+    the measured front-end agreement (5e-4 relative, test above) is 4 orders of magnitude away from it."""
+    S, eng, ref = setup
+    ids = S.make_phoneme_ids(18, seed=5)
+    ref_s = S.make_voice_pack()[len(ids) - 3]
+    pd, _, _ = ref.durations(ids, ref_s, speed=1.3)
+    F = int(pd.sum())
+    ri, nz = _noise(F, 77)
+    audio_ref, _, tr = ref.forward(ids, ref_s, speed=1.3, rand_ini=ri, noise=nz, return_intermediates=True)
+    kw = dict(forced_durations=[pd], rand_ini=torch.from_numpy(ri), noise=torch.from_numpy(nz), return_intermediates=True)
+    outs, _, tg = eng.forward([ids], ref_s, overrides=dict(f0=tr["f0"], n=tr["n"]), **kw)
+    torch.cuda.synchronize()
+    har_hip, har_ref = tg["har"].cpu(), tr["har"].transpose(1, 2)
+    flips = (har_hip - har_ref).abs() > 1.0
+    n_flips = int(flips.sum())
+    assert n_flips <= 8, n_flips
+    peak = float(audio_ref.abs().max())
+    raw_err = float((outs[0].cpu() - audio_ref[0]).abs().max())
+    if n_flips:
+        patched = torch.where(flips, har_ref, har_hip)   # the HIP features, with only the branch-ambiguous entries set to the oracle's branch
+        outs, _, _ = eng.forward([ids], ref_s, overrides=dict(f0=tr["f0"], n=tr["n"], har=patched), **kw)
+        torch.cuda.synchronize()
+    got = outs[0].cpu()
+    err = float((got - audio_ref[0]).abs().max())
+    snr = snr_db(got, audio_ref[0])
+    print(f"kokoro vocoder (free-running from F0 / N): F={F} peak={peak:.3f} branch flips={n_flips} max_abs_err={err:.3e} "
+          f"(before restoring the flips {raw_err:.3e}) snr={snr:.1f} dB")
+    assert err <= 2e-3 * max(peak, 1.0), err
+    assert snr >= 50.0, snr
+    t_s = 6.6  # the canonical utterance of the benchmark (BASELINE.md); this test's own utterance is shorter
+    eps_needed = 2e-3 / (2 * np.pi * 9 * 200.0 * t_s)
+    assert eps_needed < 2.0 ** -24, eps_needed   # the budget is below one fp32 rounding of F0: injection is a property of the problem
 
 
 def test_kokoro_canonical_short_sentence_forced_durations(setup):

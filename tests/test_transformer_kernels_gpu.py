@@ -198,6 +198,11 @@ def _round16(t, f16):
     (8, 1024, 6144, False, 5, False, False),    # SiLU, 8 rows
     (4, 30, 1024, False, 6, False, False),      # tiny N (NC = 1 tail), GELU-tanh
     (1, 2051, 2048, False, 0, False, False),    # CSM audio head (odd N)
+    (1, 1024, 8192, False, 0, True, True),      # CSM depth-decoder down projection: one row, K > 2048 -> split-K kernel, residual + LayerScale
+    (1, 2050, 3072, True, 3, True, False),      # split K, fp16 weights, N not a multiple of 4, GELU
+    (1, 16384, 1024, False, 0, False, False),   # one row, wide N: two columns per wave, grid-stride column groups
+    (1, 1536, 1024, False, 0, True, False),     # depth-decoder q|k|v shape (register-resident x, one column per wave)
+    (1, 40, 2048, False, 5, False, False),      # fewer column groups than waves
 ])
 def test_gemv(ops, M, N, K, f16, act, use_res, use_cs):
     g = torch.Generator().manual_seed(M * 100 + N + K)
@@ -232,7 +237,8 @@ def _gemv_tol(M, K, f16, base=5e-6):
     return 2e-5 if (5 <= M <= 8 and K % 64 == 0 and not f16) else base
 
 
-@pytest.mark.parametrize("mode,M,K", [("layer", 1, 768), ("layer", 5, 3072), ("rms", 8, 2048), ("rms", 2, 1024)])
+@pytest.mark.parametrize("mode,M,K", [("layer", 1, 768), ("layer", 5, 3072), ("rms", 8, 2048), ("rms", 2, 1024), ("rms", 1, 2048), ("rms", 1, 1024),
+                                      ("layer", 1, 2048), ("layer", 1, 3072)])
 def test_gemv_fused_norm_and_split(ops, mode, M, K):
     g = torch.Generator().manual_seed(K + M)
     Nq, Nkv = 256, 128
@@ -259,9 +265,10 @@ def test_gemv_fused_norm_and_split(ops, mode, M, K):
     assert float(cache[:, 2].abs().max()) == 0.0 and float(cache[:, 3, Nkv:].abs().max()) == 0.0
 
 
-def test_gemv_swiglu(ops):
+@pytest.mark.parametrize("M", [3, 1])
+def test_gemv_swiglu(ops, M):
     g = torch.Generator().manual_seed(11)
-    M, I, K = 3, 3072, 1024
+    I, K = 3072, 1024
     wg = _round16(torch.randn(I, K, generator=g) / math.sqrt(K), False)
     wu = _round16(torch.randn(I, K, generator=g) / math.sqrt(K), False)
     x = torch.randn(M, K, generator=g)
@@ -444,6 +451,7 @@ def test_whisper_step_forced_and_no_speech(ops):
 
 
 @pytest.mark.parametrize("M,N,K,act,use_res,glu", [(1, 1000, 1024, 0, False, False), (8, 514, 2048, 3, True, False), (3, 256, 3072, 0, True, False),
+                                                   (1, 514, 4096, 0, True, False), (1, 4096, 2048, 0, False, True),
                                                    (5, 2048, 1040, 0, False, True), (2, 130, 16, 5, False, False), (8, 6144, 2048, 0, False, True)])
 def test_gemv_fp8_weights(ops, M, N, K, act, use_res, glu):
     """mi355_gemv on an fp8 (OCP e4m3fn, power-of-two row scales) image against float64 on the dequantised weights the oracle restates
