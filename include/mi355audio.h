@@ -385,6 +385,7 @@ int mi355_istft(const mi355_istft_args* a, void* stream);
  * the lens_k[b] keys: key j is visible to query i iff j < lens_k[b], (causal) j <= i + lens_k[b] - lens_q[b],
  * (window > 0) j > i + lens_k[b] - lens_q[b] - window.  softmax(scale * q.k) over the visible keys, times v.
  * ------------------------------------------------------------------------------------------ */
+enum { MI355_KV_F32 = 0, MI355_KV_BF16 = 1, MI355_KV_F16 = 2 };
 typedef struct {
   const float* q; int64_t q_bstride; int32_t ldq;
   const float* k; int64_t k_bstride; int32_t ldk;
@@ -404,6 +405,8 @@ typedef struct {
   float* split_ws; int32_t* split_cnt; int32_t nsplit;
   int64_t k_hstride; int64_t v_hstride; /* 0: kv head g at columns [g*dh, (g+1)*dh) of a row; else head-major planes: head g starts at
                                            g * k_hstride (rows of that head ldk apart, typically ldk = dh) */
+  int32_t kv_dtype;       /* element type of k and v: MI355_KV_F32 (0: k / v are float*), MI355_KV_BF16, MI355_KV_F16 (16-bit: the checkpoint dtype the
+                             reference keeps its caches in, whisper.py:360-361, lm/models/cache.py:104-176); every k / v stride is in ELEMENTS */
 } mi355_flash_attn_args;
 int mi355_flash_attention(const mi355_flash_attn_args* a, void* stream);
 
@@ -586,6 +589,7 @@ typedef struct {
   const float* cross_norm_w; const float* cross_norm_b;
   const float* cross_k; const float* cross_v;   /* head-major [B, kv_heads, cross_len, dh] each (a head's keys contiguous) */
   int64_t cross_bstride; int64_t cross_hstride; int32_t cross_ld; int32_t cross_len;
+  int32_t cross_kv_dtype;   /* MI355_KV_F32 / MI355_KV_BF16 / MI355_KV_F16: element type of cross_k / cross_v (strides in elements) */
   /* wdtype == MI355_W_FP8: per-row scales of the six images (mi355_pack_rowmajor_fp8_host), else null */
   const float* s_qkv; const float* s_o; const float* s_in; const float* s_out; const float* s_cq; const float* s_co;
 } mi355_layer_desc;

@@ -38,8 +38,34 @@ __device__ __forceinline__ void wave_lds_sync2() {
 
 constexpr float kLog2e = 1.4426950408889634f;
 
-template <int DH>
+// K / V element types: KVT 0 = float32, 1 = bfloat16, 2 = float16 (mi355_flash_attn_args.kv_dtype = MI355_KV_F32 / MI355_KV_BF16 / MI355_KV_F16).  A 16-bit cache
+// is what the reference keeps (K / V live in the checkpoint dtype: whisper.py:360-361, lm/models/cache.py:104-176) and halves the bytes of the
+// decode-step attention, which is bound by reading the cache once.  Strides are in ELEMENTS for every type.
+template <int KVT> struct kv_t { using type = float; };
+template <> struct kv_t<1> { using type = uint16_t; };
+template <> struct kv_t<2> { using type = uint16_t; };
+
+template <int KVT>
+__device__ __forceinline__ float kv_f32(const uint16_t u) {
+  if constexpr (KVT == 1) return __builtin_bit_cast(float, (uint32_t)u << 16);
+  else return (float)__builtin_bit_cast(_Float16, u);
+}
+
+// four consecutive elements at p (16-byte aligned for float32, 8-byte aligned for the 16-bit types)
+template <int KVT>
+__device__ __forceinline__ float4 kv_load4(const typename kv_t<KVT>::type* p) {
+  if constexpr (KVT == 0) {
+    return *(const float4*)p;
+  } else {
+    const uint2 u = *(const uint2*)p;
+    return make_float4(kv_f32<KVT>((uint16_t)(u.x & 0xffffu)), kv_f32<KVT>((uint16_t)(u.x >> 16)), kv_f32<KVT>((uint16_t)(u.y & 0xffffu)),
+                       kv_f32<KVT>((uint16_t)(u.y >> 16)));
+  }
+}
+
+template <int DH, int KVT>
 __global__ __launch_bounds__(256) void flash_attn_kernel(const mi355_flash_attn_args a) {
+  using kvp = const typename kv_t<KVT>::type*;
   constexpr int KB = DH == 64 ? 64 : 32;  // keys per LDS stage (two padded fp32 tiles must fit 64 KB of static LDS)
   constexpr int LD = DH + 1;   // padded LDS row, floats
   constexpr int NDB = DH / 32; // 32-channel blocks of the output
@@ -89,8 +115,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const mi355_flash_attn_
 
   // heads packed inside a row (g * DH) or head-major planes (k_hstride: a head's keys contiguous -- the layout for long key ranges:
   // with rows of 2 * heads * DH floats every key of one head sits 6-8 KB from the next and lands on the same one or two L2 channels)
-  const float* kbase = a.k + (int64_t)b * a.k_bstride + (a.k_hstride ? (int64_t)g * a.k_hstride : (int64_t)g * DH);
-  const float* vbase = a.v + (int64_t)b * a.v_bstride + (a.v_hstride ? (int64_t)g * a.v_hstride : (int64_t)g * DH);
+  kvp kbase = (kvp)a.k + (int64_t)b * a.k_bstride + (a.k_hstride ? (int64_t)g * a.k_hstride : (int64_t)g * DH);
+  kvp vbase = (kvp)a.v + (int64_t)b * a.v_bstride + (a.v_hstride ? (int64_t)g * a.v_hstride : (int64_t)g * DH);
 
   float4 kpre[NLD], vpre[NLD];
   auto prefetch = [&](int kb) {
@@ -100,8 +126,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const mi355_flash_attn_
       const int row = e / (DH / 4), c4 = e % (DH / 4);
       int j = kb + row;
       j = j < len_k ? j : len_k - 1;  // clamp: finite data, masked below
-      kpre[i] = *(const float4*)(kbase + (int64_t)j * a.ldk + c4 * 4);
-      vpre[i] = *(const float4*)(vbase + (int64_t)j * a.ldv + c4 * 4);
+      kpre[i] = kv_load4<KVT>(kbase + (int64_t)j * a.ldk + c4 * 4);
+      vpre[i] = kv_load4<KVT>(vbase + (int64_t)j * a.ldv + c4 * 4);
     }
   };
   auto commit = [&]() {
@@ -193,8 +219,9 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const mi355_flash_attn_
   }
 }
 
-template <int DH, int NW>
+template <int DH, int NW, int KVT>
 __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_attn_args a) {
+  using kvp = const typename kv_t<KVT>::type*;
   constexpr int ND = DH / 64;  // channels per lane in the p.V phase
   __shared__ float qs[DH];
   __shared__ float ps[NW][64];
@@ -222,8 +249,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
   }
   // heads packed inside a row (g * DH) or head-major planes (k_hstride: a head's keys contiguous -- the layout for long key ranges:
   // with rows of 2 * heads * DH floats every key of one head sits 6-8 KB from the next and lands on the same one or two L2 channels)
-  const float* kbase = a.k + (int64_t)b * a.k_bstride + (a.k_hstride ? (int64_t)g * a.k_hstride : (int64_t)g * DH);
-  const float* vbase = a.v + (int64_t)b * a.v_bstride + (a.v_hstride ? (int64_t)g * a.v_hstride : (int64_t)g * DH);
+  kvp kbase = (kvp)a.k + (int64_t)b * a.k_bstride + (a.k_hstride ? (int64_t)g * a.k_hstride : (int64_t)g * DH);
+  kvp vbase = (kvp)a.v + (int64_t)b * a.v_bstride + (a.v_hstride ? (int64_t)g * a.v_hstride : (int64_t)g * DH);
   float m = -INFINITY, l = 0.f, o[ND];
 #pragma unroll
   for (int i = 0; i < ND; ++i) o[i] = 0.f;
@@ -238,10 +265,10 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
       for (int p4 = 0; p4 < 4; ++p4) {
         const int key = kb + p4 * 16 + grp;
         const bool valid = key < kend;
-        const float* krow = kbase + (int64_t)(valid ? key : kend - 1) * a.ldk + sub * 4;
+        kvp krow = kbase + (int64_t)(valid ? key : kend - 1) * a.ldk + sub * 4;
         float4 kv[DH / 16];
 #pragma unroll
-        for (int i = 0; i < DH / 16; ++i) kv[i] = *(const float4*)(krow + i * 16);
+        for (int i = 0; i < DH / 16; ++i) kv[i] = kv_load4<KVT>(krow + i * 16);
         float t0 = 0.f, t1 = 0.f;
 #pragma unroll
         for (int i = 0; i < DH / 16; ++i) {
@@ -272,20 +299,57 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
     for (int i = 0; i < ND; ++i) o[i] *= alpha;
     // p.V: 8 value rows in flight per step (a rolled loop keeps ONE load in flight and serialises 64 L2 latencies per chunk: that, not
     // bandwidth, was what made the 1500-key cross-attention step take 42 us)
-    for (int jj = 0; jj < n; jj += 8) {
-      float vv[8][ND];
+    if constexpr (KVT == 0) {
+      for (int jj = 0; jj < n; jj += 8) {
+        float vv[8][ND];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int j = jj + u < n ? jj + u : n - 1;
-        const float* vrow = vbase + (int64_t)(kb + j) * a.ldv;
+        for (int u = 0; u < 8; ++u) {
+          const int j = jj + u < n ? jj + u : n - 1;
+          const float* vrow = vbase + (int64_t)(kb + j) * a.ldv;
 #pragma unroll
-        for (int i = 0; i < ND; ++i) vv[u][i] = vrow[i * 64 + lane];
+          for (int i = 0; i < ND; ++i) vv[u][i] = vrow[i * 64 + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float pj = jj + u < n ? ps[wave][jj + u] : 0.f;
+#pragma unroll
+          for (int i = 0; i < ND; ++i) o[i] = fmaf(pj, vv[u][i], o[i]);
+        }
       }
+    } else {
+      // 16-bit values: a lane loads one 4-byte PAIR of channels, so a wave load covers KPL = 128 / DH whole rows (two 128-byte rows at DH = 64,
+      // one 256-byte row at DH = 128).  Lane (r = lane / PR, c = lane % PR) accumulates channels 2c, 2c + 1 over the keys j = r (mod KPL);
+      // the KPL partial sums are folded once per chunk and handed back to the channel-per-lane layout of `o` through LDS.
+      constexpr int PR = DH / 2, KPL = 64 / PR;
+      const int r = lane / PR, c = lane - r * PR;
+      float o2[2] = {0.f, 0.f};
+      for (int jj = 0; jj < n; jj += 8 * KPL) {
+        uint32_t vv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float pj = jj + u < n ? ps[wave][jj + u] : 0.f;
+        for (int u = 0; u < 8; ++u) {
+          int j = jj + u * KPL + r;
+          j = j < n ? j : n - 1;
+          vv[u] = *(const uint32_t*)(vbase + (int64_t)(kb + j) * a.ldv + 2 * c);
+        }
 #pragma unroll
-        for (int i = 0; i < ND; ++i) o[i] = fmaf(pj, vv[u][i], o[i]);
+        for (int u = 0; u < 8; ++u) {
+          const int j = jj + u * KPL + r;
+          const float pj = j < n ? ps[wave][j] : 0.f;
+          o2[0] = fmaf(pj, kv_f32<KVT>((uint16_t)(vv[u] & 0xffffu)), o2[0]);
+          o2[1] = fmaf(pj, kv_f32<KVT>((uint16_t)(vv[u] >> 16)), o2[1]);
+        }
+      }
+      if constexpr (KPL == 2) {
+        o2[0] += __shfl_xor(o2[0], 32, 64);
+        o2[1] += __shfl_xor(o2[1], 32, 64);
+      }
+      // the probabilities in ps[wave] have been consumed: reuse the row to go from pair-per-lane back to channel-per-lane (64 channels a round)
+#pragma unroll
+      for (int h2 = 0; h2 < ND; ++h2) {
+        wave_lds_sync2();
+        if (r == 0 && c >= 32 * h2 && c < 32 * h2 + 32) { ps[wave][2 * (c - 32 * h2)] = o2[0]; ps[wave][2 * (c - 32 * h2) + 1] = o2[1]; }
+        wave_lds_sync2();
+        o[h2] += ps[wave][lane];
       }
     }
     wave_lds_sync2();
@@ -363,6 +427,9 @@ extern "C" int mi355_flash_attention(const mi355_flash_attn_args* ap, void* stre
                 "flash_attention: strides must be multiples of 4 floats");
   MI355_REQUIRE(((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.out) % 16 == 0, "flash_attention: tensors must be 16-byte aligned");
   MI355_REQUIRE(a.window >= 0, "flash_attention: window must be >= 0");
+  MI355_REQUIRE(a.kv_dtype >= MI355_KV_F32 && a.kv_dtype <= MI355_KV_F16, "flash_attention: kv_dtype must be MI355_KV_F32, MI355_KV_BF16 or MI355_KV_F16");
+  const int kvt = a.kv_dtype;
+  MI355_REQUIRE(kvt == 0 || (((uintptr_t)a.k | (uintptr_t)a.v) % 8 == 0), "flash_attention: 16-bit K / V must be 8-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   MI355_CLEAR_ERROR();
   const bool decode = a.mode == 2 || (a.mode == 0 && a.Tq <= 8);
@@ -384,17 +451,23 @@ extern "C" int mi355_flash_attention(const mi355_flash_attn_args* ap, void* stre
     // long key ranges (Whisper cross-attention: 1500 keys) get 16 waves per (query, head): the per-wave key loop is a dependent
     // chain of global loads, so more waves in flight is what shortens it; short ranges keep 4 waves
     const bool wide = a.Tk > 256;
-    if (a.dh == 64) {
-      if (wide) hipLaunchKernelGGL((attn_decode_kernel<64, 16>), grid, dim3(1024), 0, st, a);
-      else hipLaunchKernelGGL((attn_decode_kernel<64, 4>), grid, dim3(256), 0, st, a);
-    } else {
-      if (wide) hipLaunchKernelGGL((attn_decode_kernel<128, 16>), grid, dim3(1024), 0, st, a);
-      else hipLaunchKernelGGL((attn_decode_kernel<128, 4>), grid, dim3(256), 0, st, a);
+#define MI355_DECODE_CASE(KVT)                                                                                   \
+    if (a.dh == 64) {                                                                                            \
+      if (wide) hipLaunchKernelGGL((attn_decode_kernel<64, 16, KVT>), grid, dim3(1024), 0, st, a);               \
+      else hipLaunchKernelGGL((attn_decode_kernel<64, 4, KVT>), grid, dim3(256), 0, st, a);                      \
+    } else {                                                                                                     \
+      if (wide) hipLaunchKernelGGL((attn_decode_kernel<128, 16, KVT>), grid, dim3(1024), 0, st, a);              \
+      else hipLaunchKernelGGL((attn_decode_kernel<128, 4, KVT>), grid, dim3(256), 0, st, a);                     \
     }
+    if (kvt == 0) { MI355_DECODE_CASE(0) } else if (kvt == 1) { MI355_DECODE_CASE(1) } else { MI355_DECODE_CASE(2) }
+#undef MI355_DECODE_CASE
   } else {
     dim3 grid((a.Tq + 127) / 128, a.heads, a.B);
-    if (a.dh == 64) hipLaunchKernelGGL(flash_attn_kernel<64>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(flash_attn_kernel<128>, grid, dim3(256), 0, st, a);
+#define MI355_FLASH_CASE(KVT)                                                                   \
+    if (a.dh == 64) hipLaunchKernelGGL((flash_attn_kernel<64, KVT>), grid, dim3(256), 0, st, a); \
+    else hipLaunchKernelGGL((flash_attn_kernel<128, KVT>), grid, dim3(256), 0, st, a);
+    if (kvt == 0) { MI355_FLASH_CASE(0) } else if (kvt == 1) { MI355_FLASH_CASE(1) } else { MI355_FLASH_CASE(2) }
+#undef MI355_FLASH_CASE
   }
   MI355_LAUNCH_CHECK("flash_attention");
   return MI355_OK;

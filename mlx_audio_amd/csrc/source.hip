@@ -343,8 +343,10 @@ __global__ __launch_bounds__(256) void istft_head_fast_kernel(const mi355_istft_
     for (int k = 0; k < nb; ++k) {
       const float mag = expf(xr[k]);
       const float ph = sinf(xr[nb + k]);
-      re[k] = valid ? (double)mul_rn(mag, cosf(ph)) : 0.0;
-      im[k] = valid ? (double)mul_rn(mag, sinf(ph)) : 0.0;
+      float sn, cs;
+      sincosf(ph, &sn, &cs);   // one argument reduction for both (|ph| <= 1); same values as sinf / cosf
+      re[k] = valid ? (double)mul_rn(mag, cs) : 0.0;
+      im[k] = valid ? (double)mul_rn(mag, sn) : 0.0;
     }
     float* tr = td + tid * TS;
 #pragma unroll
@@ -357,8 +359,9 @@ __global__ __launch_bounds__(256) void istft_head_fast_kernel(const mi355_istft_
         A = fma(re[k], tw.c[m], A);
         Bs = fma(im[k], tw.s[m], Bs);
       }
-      tr[n] = mul_rn((float)((base + 2.0 * (A - Bs)) / (double)N), a.window[n]);
-      if (n > 0 && n < N / 2) tr[N - n] = mul_rn((float)((base + 2.0 * (A + Bs)) / (double)N), a.window[N - n]);
+      constexpr double inv_n = 1.0 / (double)N;   // (a multiply instead of 20 fp64 divisions per frame; the fp32 rounding below hides the last bit)
+      tr[n] = mul_rn((float)((base + 2.0 * (A - Bs)) * inv_n), a.window[n]);
+      if (n > 0 && n < N / 2) tr[N - n] = mul_rn((float)((base + 2.0 * (A + Bs)) * inv_n), a.window[N - n]);
     }
   }
   __syncthreads();

@@ -30,13 +30,13 @@ int gemv_call(const float* x, int ldx, int M, int K, const uint16_t* w, int N, i
 
 int attn_call(const float* q, int ldq, const float* k, const float* v, int64_t kv_bstride, int ldkv, int heads, int kv_heads, int dh, int Tk,
               int causal, int window, float scale, int B, float* out, int ldo, void* stream, int64_t hstride = 0, float* split_ws = nullptr,
-              int32_t* split_cnt = nullptr, const int32_t* k_start = nullptr) {
+              int32_t* split_cnt = nullptr, const int32_t* k_start = nullptr, int kv_dtype = MI355_KV_F32) {
   mi355_flash_attn_args a;
   memset(&a, 0, sizeof(a));
   a.k_hstride = hstride; a.v_hstride = hstride; a.split_ws = split_ws; a.split_cnt = split_cnt;
   a.q = q; a.q_bstride = ldq; a.ldq = ldq; a.k = k; a.k_bstride = kv_bstride; a.ldk = ldkv; a.v = v; a.v_bstride = kv_bstride; a.ldv = ldkv;
   a.heads = heads; a.kv_heads = kv_heads; a.dh = dh; a.Tq = 1; a.Tk = Tk; a.causal = causal; a.window = window; a.scale = scale; a.B = B;
-  a.mode = 2; a.out = out; a.out_bstride = ldo; a.ldo = ldo; a.k_start = k_start;
+  a.mode = 2; a.out = out; a.out_bstride = ldo; a.ldo = ldo; a.k_start = k_start; a.kv_dtype = kv_dtype;
   return mi355_flash_attention(&a, stream);
 }
 
@@ -98,7 +98,7 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
                      d.eps, nullptr, 0, 0, stream, L.s_cq);
       if (rc) return rc;
       rc = attn_call(q, nq, L.cross_k, L.cross_v, L.cross_bstride, L.cross_ld, H, G, dh, L.cross_len, 0, 0, scale, B, att, nq, stream, L.cross_hstride,
-                     d.attn_split_ws, d.attn_split_cnt);
+                     d.attn_split_ws, d.attn_split_cnt, nullptr, L.cross_kv_dtype);
       if (rc) return rc;
       rc = gemv_call(att, nq, B, nq, L.wco, D, d.wdtype, L.bco, MI355_ACT_NONE, nullptr, x, D, 0, x, D, 0, nullptr, nullptr, 0.f, nullptr, 0, 0, stream,
                      L.s_co);

@@ -363,6 +363,9 @@ def attn_split_workspace(device, n_records: int, dh: int):
     return cur
 
 
+KV_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}  # MI355_KV_F32 / MI355_KV_BF16 / MI355_KV_F16
+
+
 def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, heads: int, kv_heads: Optional[int] = None,
                     dh: int, scale: Optional[float] = None, causal: bool = False, window: int = 0, lens_q=None, lens_k=None,
                     mode: int = 0, k_start=None, head_major: bool = False, nsplit: int = 0):
@@ -372,13 +375,15 @@ def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torc
     _, To, _, obs, ldo = _nlc(out)
     khs = vhs = 0
     if head_major:  # k / v [B, kv_heads, Tk, dh]: a head's keys contiguous (the layout for long key ranges: one L2 channel sweep per head)
-        assert k.dim() == 4 and v.dim() == 4 and k.stride(3) == 1 and v.stride(3) == 1 and k.dtype == torch.float32 and k.shape == v.shape
+        assert k.dim() == 4 and v.dim() == 4 and k.stride(3) == 1 and v.stride(3) == 1 and k.shape == v.shape
         Bk, _, Tk, _ = k.shape
         Tv, kbs, khs, ldk, vbs, vhs, ldv = Tk, k.stride(0), k.stride(1), k.stride(2), v.stride(0), v.stride(1), v.stride(2)
     else:
-        Bk, Tk, _, kbs, ldk = _nlc(k)
-        _, Tv, _, vbs, ldv = _nlc(v)
+        assert k.dim() == 3 and v.dim() == 3 and k.stride(2) == 1 and v.stride(2) == 1 and k.is_cuda and v.is_cuda
+        Bk, Tk, kbs, ldk = k.shape[0], k.shape[1], k.stride(0), k.stride(1)
+        Tv, vbs, ldv = v.shape[1], v.stride(0), v.stride(1)
     assert Bk == B and Tv == Tk and To == Tq
+    assert k.dtype == v.dtype and k.dtype in KV_DTYPES, "k / v must both be float32, bfloat16 or float16"
     sws = scnt = None
     if nsplit > 1 and Tq <= 8 and mode != 1:
         sws, scnt = attn_split_workspace(q.device, B * heads * Tq, dh)  # key-split decode (flash-decoding), opt-in: measured slower than the unsplit kernel
@@ -386,7 +391,8 @@ def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torc
                      k_bstride=kbs, ldk=ldk, v=_ptr(v), v_bstride=vbs, ldv=ldv, heads=heads, kv_heads=kv_heads or heads, dh=dh,
                      Tq=Tq, Tk=Tk, lens_q=_ptr(lens_q), lens_k=_ptr(lens_k), causal=int(causal), window=window,
                      scale=(1.0 / math.sqrt(dh)) if scale is None else scale, B=B, mode=mode, out=_ptr(out), out_bstride=obs, ldo=ldo,
-                     k_start=_ptr(k_start), k_hstride=khs, v_hstride=vhs, split_ws=_ptr(sws), split_cnt=_ptr(scnt), nsplit=nsplit)
+                     k_start=_ptr(k_start), k_hstride=khs, v_hstride=vhs, split_ws=_ptr(sws), split_cnt=_ptr(scnt), nsplit=nsplit,
+                     kv_dtype=KV_DTYPES[k.dtype])
     return out
 
 

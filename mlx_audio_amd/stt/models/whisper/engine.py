@@ -69,9 +69,12 @@ def sinusoids(length: int, channels: int, max_timescale: float = 10000) -> torch
 
 
 class WhisperEngine:
-    def __init__(self, weights: Dict[str, torch.Tensor], dims: ModelDimensions, device: str = "cuda:0", precision: int = 4):
+    def __init__(self, weights: Dict[str, torch.Tensor], dims: ModelDimensions, device: str = "cuda:0", precision: int = 4,
+                 kv_dtype: torch.dtype = torch.float16):
         ops.require_gpu()
         assert precision in (3, 4)
+        assert kv_dtype in ops.KV_DTYPES
+        self.kv_dtype = kv_dtype  # cross-attention K | V cache: the checkpoint dtype (fp16), like the reference; float32 keeps the wider copy
         self.dims = dims
         self.device = torch.device(device)
         self.precision = precision
@@ -188,8 +191,10 @@ class WhisperEngine:
             ops.conv_gemm(xa, blk.ckv.pc, ckv, precision=self.precision)
             # head-major [B, H, T, dh] copies (layout only, once per window): every decode step streams all 1500 keys of each head, and
             # with heads packed inside 12 KB rows a head's keys are 6 KB apart -- they all land on the same one or two L2 channels
-            st["cross_k"].append(ckv[:, :, :nt].reshape(B, T, H, dh).permute(0, 2, 1, 3).contiguous())
-            st["cross_v"].append(ckv[:, :, nt:].reshape(B, T, H, dh).permute(0, 2, 1, 3).contiguous())
+            # ... and in the checkpoint's 16-bit type, as the reference keeps them (whisper.py:360-361: k, v of the cross-attention are computed
+            # once in the model dtype and cached): the decode step is bound by streaming these 2 x B x 1500 x n_state values per layer
+            st["cross_k"].append(ckv[:, :, :nt].reshape(B, T, H, dh).permute(0, 2, 1, 3).to(self.kv_dtype).contiguous())
+            st["cross_v"].append(ckv[:, :, nt:].reshape(B, T, H, dh).permute(0, 2, 1, 3).to(self.kv_dtype).contiguous())
         return st
 
     def _native_desc(self, st: dict):
@@ -215,6 +220,7 @@ class WhisperEngine:
             ck, cv = st["cross_k"][i], st["cross_v"][i]
             a.cross_k, a.cross_v = ck.data_ptr(), cv.data_ptr()
             a.cross_bstride, a.cross_hstride, a.cross_ld, a.cross_len = ck.stride(0), ck.stride(1), ck.stride(2), ck.shape[2]
+            a.cross_kv_dtype = ops.KV_DTYPES[ck.dtype]
         sd = SD()
         sd.n_layers, sd.d_model, sd.heads, sd.kv_heads, sd.dh, sd.d_ff = d.n_text_layer, d.n_text_state, d.n_text_head, d.n_text_head, self.dh, 4 * d.n_text_state
         sd.norm, sd.eps, sd.glu, sd.act, sd.wdtype, sd.causal, sd.window, sd.attn_scale = 1, 1e-5, 0, ACT_GELU, 1, 1, 0, 0.0

@@ -89,9 +89,13 @@ def gelu(x: Tensor) -> Tensor:
 
 
 class WhisperRef:
-    def __init__(self, weights: Dict[str, Tensor], dims: Dims, dtype=torch.float32, param_dtype=torch.float16):
+    def __init__(self, weights: Dict[str, Tensor], dims: Dims, dtype=torch.float32, param_dtype=torch.float16, cross_kv_dtype=torch.float16):
+        """``cross_kv_dtype``: the cross-attention K / V are computed once per window and CACHED in the model dtype (whisper.py:360-365: fp16 for
+        the released checkpoints); the restatement keeps float32 activations everywhere else, so that one rounding is applied explicitly where
+        the reference stores them (None = keep float32)."""
         self.dims = dims
         self.dtype = dtype
+        self.cross_kv_dtype = cross_kv_dtype
         self.w = {k: v.to(param_dtype).to(dtype) for k, v in weights.items()}
         # whisper.py:434: sinusoids(...).astype(dtype) -- the positional table is rounded to the model dtype
         self.enc_pos = sinusoids(dims.n_audio_ctx, dims.n_audio_state).to(param_dtype).to(dtype)
@@ -115,6 +119,8 @@ class WhisperRef:
         elif kv_cache is None:
             k = self._lin(xa, pfx + ".key", bias=False)
             v = self._lin(xa, pfx + ".value")
+            if self.cross_kv_dtype is not None:
+                k, v = k.to(self.cross_kv_dtype).to(self.dtype), v.to(self.cross_kv_dtype).to(self.dtype)
         else:
             k, v = kv_cache
         B, n_ctx, n_state = q.shape

@@ -148,6 +148,33 @@ def test_attention_head_major_kv(ops, Tq, mode):
     assert rel_err(out.cpu(), exp) < 2e-5
 
 
+@pytest.mark.parametrize("kvd", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Tq,Tk,dh,G,hm,causal", [(1, 1500, 64, 4, True, False), (1, 31, 128, 2, False, True), (3, 333, 64, 2, False, True),
+                                                   (1, 700, 128, 4, True, False), (40, 333, 64, 2, False, True), (150, 260, 128, 1, True, False)])
+def test_attention_16bit_kv(ops, kvd, Tq, Tk, dh, G, hm, causal):
+    """K / V held in the checkpoint's 16-bit type (mi355_flash_attn_args.kv_dtype; the reference caches them in the model dtype, whisper.py:360-361,
+    lm/models/cache.py:104-176): decode kernel (4 and 16 waves, both head sizes, packed rows and head-major planes) and prefill kernel against
+    float64 attention over the SAME rounded K / V -- the kernels only change how the bytes are read, so the fp32 bar stays."""
+    g = torch.Generator().manual_seed(101 + Tq + Tk + dh)
+    B, H = 2, 4
+    q = torch.randn(B, Tq, H * dh, generator=g)
+    k = torch.randn(B, Tk, G * dh, generator=g).to(kvd)
+    v = torch.randn(B, Tk, G * dh, generator=g).to(kvd)
+    exp = ref_attention(q, k.float(), v.float(), H, G, dh, 1.0 / math.sqrt(dh), causal, 0, None, None)
+    if hm:
+        kd = k.reshape(B, Tk, G, dh).permute(0, 2, 1, 3).contiguous().to(DEV)
+        vd = v.reshape(B, Tk, G, dh).permute(0, 2, 1, 3).contiguous().to(DEV)
+    else:  # a strided "cache": rows of k | v side by side, capacity beyond Tk
+        cache = torch.zeros(B, Tk + 5, 2 * G * dh, dtype=kvd, device=DEV)
+        cache[:, :Tk, : G * dh] = k.to(DEV)
+        cache[:, :Tk, G * dh:] = v.to(DEV)
+        kd, vd = cache[:, :Tk, : G * dh], cache[:, :Tk, G * dh:]
+    out = torch.empty(B, Tq, H * dh, device=DEV)
+    ops.flash_attention(q.to(DEV), kd, vd, out, heads=H, kv_heads=G, dh=dh, causal=causal, head_major=hm)
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), exp) < 2e-5, rel_err(out.cpu(), exp)
+
+
 @pytest.mark.parametrize("Tq,Tk,nsplit,causal,hm", [(1, 1500, 2, False, True), (1, 1500, 4, False, False), (3, 700, 8, True, False), (1, 130, 3, True, False),
                                                       (2, 64, 8, True, False)])
 def test_attention_key_split_decode(ops, Tq, Tk, nsplit, causal, hm):
