@@ -219,6 +219,211 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const mi355_flash_attn_
   }
 }
 
+// ---------------------------------------------------------------------------------------------------- 16-bit K / V on the 16-bit matrix pipe
+// flash_attn16_kernel<DH, KVT>: the prefill / encoder kernel when K and V are held in the checkpoint's 16-bit type.  Same tiling, visibility
+// rule and online softmax as flash_attn_kernel, but both contractions run on v_mfma_f32_32x32x16_{bf16,f16} (16 k per instruction at half the
+// issue cost of the fp32 32x32x2: 16x the MACs per cycle):
+//   * K tile [64 keys][DH] goes global -> LDS untouched (16-byte pieces; rows padded by 16 bytes so the A-operand ds_read_b128 is conflict free);
+//     V goes in TRANSPOSED ([DH][64 keys]) because the second contraction is over keys: its A operand needs 8 keys of one channel per lane.
+//   * Q (fp32, pre-scaled) is split once into hi + lo images of the K / V type and lives in registers as the B operand of S^T = K Q^T; the
+//     probabilities come out of the accumulator in C layout, are split hi + lo and are already in B-operand order for O^T += V^T P^T when the
+//     keys of a step are taken in C-row order {0..3, 8..11} + 4 * (lane >> 5) (+16 for the second step) -- the V^T fragment is read in that order.
+//   So K and V enter exactly (they ARE 16-bit), Q and P carry ~16 (bf16) / ~22 (fp16) mantissa bits: fp32-grade results at 4 MFMAs per product pair.
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma32_16(const uint4 a, const uint4 b, const f32x16 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <bool F16>
+__device__ __forceinline__ void split_pair(const float x, const float y, uint32_t& hi, uint32_t& lo) {
+  if constexpr (F16) {
+    hi = pack_f16x2(x, y);
+    const float hx = (float)__builtin_bit_cast(_Float16, (uint16_t)(hi & 0xffffu)), hy = (float)__builtin_bit_cast(_Float16, (uint16_t)(hi >> 16));
+    lo = pack_f16x2(x - hx, y - hy);
+  } else {
+    hi = pack_bf16x2(x, y);
+    const float hx = __builtin_bit_cast(float, hi << 16), hy = __builtin_bit_cast(float, hi & 0xffff0000u);
+    lo = pack_bf16x2(x - hx, y - hy);
+  }
+}
+
+template <int DH, int KVT>
+__global__ __launch_bounds__(256) void flash_attn16_kernel(const mi355_flash_attn_args a) {
+  constexpr bool F16 = KVT == 2;
+  constexpr int KB = 64;            // keys per LDS stage
+  constexpr int KLD = DH + 8;       // K row stride (halves): 144 / 272 bytes
+  constexpr int VLD = KB + 8;       // V^T row stride (halves): 144 bytes
+  constexpr int NDB = DH / 32;      // 32-channel blocks of the output
+  constexpr int NST = DH / 16;      // k steps of S^T = K Q^T
+  constexpr int NLD = (KB * DH / 8) / 256;  // 16-byte pieces per thread per stage and tensor
+  __shared__ __attribute__((aligned(16))) uint16_t Ks[KB * KLD];
+  __shared__ __attribute__((aligned(16))) uint16_t Vt[DH * VLD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g2 = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int g = h / (a.heads / a.kv_heads);
+  const int len_q = a.lens_q ? a.lens_q[b] : a.Tq;
+  const int len_k = a.lens_k ? a.lens_k[b] : a.Tk;
+  const int q0 = blockIdx.x * 128;
+  if (q0 >= len_q || len_k <= 0) return;
+  const int qoff = len_k - len_q;
+  const int qi = q0 + wave * 32 + (lane & 31);
+  const bool wave_active = (q0 + wave * 32) < len_q;
+  const int qic = qi < len_q ? qi : len_q - 1;
+  const int qpos = qic + qoff;
+
+  // Q fragments (B operand): step s holds Q[q][16 s + 8 g2 .. + 8], pre-scaled into the log2 domain, as hi + lo images
+  uint4 qh[NST], ql[NST];
+  {
+    const float* qrow = a.q + (int64_t)b * a.q_bstride + (int64_t)qic * a.ldq + h * DH;
+    const float sc = a.scale * kLog2e;
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+      const float4 t0 = *(const float4*)(qrow + 16 * s + 8 * g2), t1 = *(const float4*)(qrow + 16 * s + 8 * g2 + 4);
+      split_pair<F16>(t0.x * sc, t0.y * sc, qh[s].x, ql[s].x);
+      split_pair<F16>(t0.z * sc, t0.w * sc, qh[s].y, ql[s].y);
+      split_pair<F16>(t1.x * sc, t1.y * sc, qh[s].z, ql[s].z);
+      split_pair<F16>(t1.z * sc, t1.w * sc, qh[s].w, ql[s].w);
+    }
+  }
+
+  int kend = len_k, kbeg = 0;
+  if (a.causal) {
+    const int last_q = (q0 + 127 < len_q ? q0 + 127 : len_q - 1) + qoff;
+    kend = last_q + 1 < len_k ? last_q + 1 : len_k;
+    if (kend < 1) kend = 1;
+  }
+  if (a.window > 0) {
+    kbeg = q0 + qoff - a.window + 1;
+    if (kbeg < 0) kbeg = 0;
+  }
+  const int kstart = a.k_start ? a.k_start[b] : 0;
+  if (kstart > kbeg) kbeg = kstart;
+  kbeg &= ~(KB - 1);
+
+  const uint16_t* kbase = (const uint16_t*)a.k + (int64_t)b * a.k_bstride + (a.k_hstride ? (int64_t)g * a.k_hstride : (int64_t)g * DH);
+  const uint16_t* vbase = (const uint16_t*)a.v + (int64_t)b * a.v_bstride + (a.v_hstride ? (int64_t)g * a.v_hstride : (int64_t)g * DH);
+
+  uint4 kpre[NLD], vpre[NLD];
+  auto prefetch = [&](int kb) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = i * 256 + tid;
+      const int row = e / (DH / 8), c8 = e % (DH / 8);
+      int j = kb + row;
+      j = j < len_k ? j : len_k - 1;  // clamp: finite data, masked below
+      kpre[i] = *(const uint4*)(kbase + (int64_t)j * a.ldk + c8 * 8);
+      vpre[i] = *(const uint4*)(vbase + (int64_t)j * a.ldv + c8 * 8);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = i * 256 + tid;
+      const int row = e / (DH / 8), c8 = e % (DH / 8);
+      *(uint4*)(Ks + row * KLD + c8 * 8) = kpre[i];
+      uint16_t* vd = Vt + (c8 * 8) * VLD + row;
+      vd[0 * VLD] = (uint16_t)(vpre[i].x & 0xffffu); vd[1 * VLD] = (uint16_t)(vpre[i].x >> 16);
+      vd[2 * VLD] = (uint16_t)(vpre[i].y & 0xffffu); vd[3 * VLD] = (uint16_t)(vpre[i].y >> 16);
+      vd[4 * VLD] = (uint16_t)(vpre[i].z & 0xffffu); vd[5 * VLD] = (uint16_t)(vpre[i].z >> 16);
+      vd[6 * VLD] = (uint16_t)(vpre[i].w & 0xffffu); vd[7 * VLD] = (uint16_t)(vpre[i].w >> 16);
+    }
+  };
+
+  f32x16 o[NDB];
+#pragma unroll
+  for (int d = 0; d < NDB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m = -INFINITY, lsum = 0.f;
+
+  prefetch(kbeg);
+  for (int kb = kbeg; kb < kend; kb += KB) {
+    __syncthreads();  // everyone is done reading the previous stage
+    commit();
+    __syncthreads();
+    if (kb + KB < kend) prefetch(kb + KB);
+    if (!wave_active) continue;
+#pragma unroll
+    for (int sub = 0; sub < KB / 32; ++sub) {
+      const int kb32 = kb + sub * 32;
+      if (kb32 >= kend) break;
+      // ---- S^T block (32 keys x 32 queries): A = K rows, B = Q hi / lo
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const uint16_t* krow = Ks + (sub * 32 + (lane & 31)) * KLD + 8 * g2;
+#pragma unroll
+      for (int s = 0; s < NST; ++s) {
+        const uint4 kf = *(const uint4*)(krow + 16 * s);
+        acc = mfma32_16<F16>(kf, qh[s], acc);
+        acc = mfma32_16<F16>(kf, ql[s], acc);
+      }
+      // ---- mask + online softmax (per-lane query)
+      float bm = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = kb32 + (r & 3) + 8 * (r >> 2) + 4 * g2;
+        bool vis = j < len_k && j >= kstart;
+        if (a.causal) vis = vis && j <= qpos;
+        if (a.window > 0) vis = vis && j > qpos - a.window;
+        acc[r] = vis ? acc[r] : -INFINITY;
+        bm = fmaxf(bm, acc[r]);
+      }
+      bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+      const float m_new = fmaxf(m, bm);
+      const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+      const float alpha = exp2f(m - m_safe);  // m = -inf -> 0
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[r] = exp2f(acc[r] - m_safe);  // -inf -> 0
+        ps += acc[r];
+      }
+      lsum = lsum * alpha + ps;
+      m = m_new;
+#pragma unroll
+      for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+      // ---- O^T += V^T P^T: step s2 contracts the keys 16 s2 + {0..3, 8..11} + 4 g2, which is where acc[8 s2 .. 8 s2 + 7] live
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        uint4 ph, pl;
+        split_pair<F16>(acc[8 * s2 + 0], acc[8 * s2 + 1], ph.x, pl.x);
+        split_pair<F16>(acc[8 * s2 + 2], acc[8 * s2 + 3], ph.y, pl.y);
+        split_pair<F16>(acc[8 * s2 + 4], acc[8 * s2 + 5], ph.z, pl.z);
+        split_pair<F16>(acc[8 * s2 + 6], acc[8 * s2 + 7], ph.w, pl.w);
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) {
+          const uint16_t* vrow = Vt + (d * 32 + (lane & 31)) * VLD + sub * 32 + 16 * s2 + 4 * g2;
+          const uint2 v0 = *(const uint2*)vrow, v1 = *(const uint2*)(vrow + 8);
+          const uint4 vf = make_uint4(v0.x, v0.y, v1.x, v1.y);
+          o[d] = mfma32_16<F16>(vf, ph, o[d]);
+          o[d] = mfma32_16<F16>(vf, pl, o[d]);
+        }
+      }
+    }
+  }
+
+  if (!wave_active) return;
+  lsum += __shfl_xor(lsum, 32, 64);
+  const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+  if (qi < len_q) {
+    float* orow = a.out + (int64_t)b * a.out_bstride + (int64_t)qi * a.ldo + h * DH;
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 t = make_float4(o[d][c * 4] * inv, o[d][c * 4 + 1] * inv, o[d][c * 4 + 2] * inv, o[d][c * 4 + 3] * inv);
+        *(float4*)(orow + d * 32 + 8 * c + 4 * g2) = t;
+      }
+  }
+}
+
 template <int DH, int NW, int KVT>
 __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_attn_args a) {
   using kvp = const typename kv_t<KVT>::type*;
@@ -463,10 +668,19 @@ extern "C" int mi355_flash_attention(const mi355_flash_attn_args* ap, void* stre
 #undef MI355_DECODE_CASE
   } else {
     dim3 grid((a.Tq + 127) / 128, a.heads, a.B);
-#define MI355_FLASH_CASE(KVT)                                                                   \
-    if (a.dh == 64) hipLaunchKernelGGL((flash_attn_kernel<64, KVT>), grid, dim3(256), 0, st, a); \
-    else hipLaunchKernelGGL((flash_attn_kernel<128, KVT>), grid, dim3(256), 0, st, a);
-    if (kvt == 0) { MI355_FLASH_CASE(0) } else if (kvt == 1) { MI355_FLASH_CASE(1) } else { MI355_FLASH_CASE(2) }
+    if (kvt == 0) {
+      if (a.dh == 64) hipLaunchKernelGGL((flash_attn_kernel<64, 0>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((flash_attn_kernel<128, 0>), grid, dim3(256), 0, st, a);
+    } else {
+      MI355_REQUIRE(a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.k_bstride % 8 == 0 && a.v_bstride % 8 == 0 && a.k_hstride % 8 == 0 && a.v_hstride % 8 == 0 &&
+                        (((uintptr_t)a.k | (uintptr_t)a.v) % 16 == 0),
+                    "flash_attention: 16-bit K / V rows must be 16-byte aligned for the prefill kernel");
+#define MI355_FLASH16_CASE(KVT)                                                                    \
+      if (a.dh == 64) hipLaunchKernelGGL((flash_attn16_kernel<64, KVT>), grid, dim3(256), 0, st, a); \
+      else hipLaunchKernelGGL((flash_attn16_kernel<128, KVT>), grid, dim3(256), 0, st, a);
+      if (kvt == 1) { MI355_FLASH16_CASE(1) } else { MI355_FLASH16_CASE(2) }
+#undef MI355_FLASH16_CASE
+    }
 #undef MI355_FLASH_CASE
   }
   MI355_LAUNCH_CHECK("flash_attention");

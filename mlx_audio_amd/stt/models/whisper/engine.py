@@ -164,12 +164,17 @@ class WhisperEngine:
                       precision=self.precision)
         layers = [x.clone()] if return_layers else None
         qkv = self._f(B, T, 3 * na)
+        kv16 = torch.empty((B, T, 2 * na), dtype=self.kv_dtype, device=self.device) if self.kv_dtype != torch.float32 else None
         att = self._f(B, T, na)
         mid = self._f(B, T, 4 * na)
         for blk in self.enc_blocks:
             h = self._lnorm(x, blk.attn_ln)
             self._linear(h, blk.qkv, qkv)
-            ops.flash_attention(qkv[:, :, 0:na], qkv[:, :, na:2 * na], qkv[:, :, 2 * na:], att, heads=H, dh=dh, scale=dh ** -0.5)
+            if self.kv_dtype == torch.float32:
+                ops.flash_attention(qkv[:, :, 0:na], qkv[:, :, na:2 * na], qkv[:, :, 2 * na:], att, heads=H, dh=dh, scale=dh ** -0.5)
+            else:  # K | V in the checkpoint's 16-bit type: both contractions on the 16-bit matrix pipe (flash_attn16_kernel)
+                kv16.copy_(qkv[:, :, na:])
+                ops.flash_attention(qkv[:, :, 0:na], kv16[:, :, :na], kv16[:, :, na:], att, heads=H, dh=dh, scale=dh ** -0.5)
             self._linear(att, blk.out, x, res=x)
             h = self._lnorm(x, blk.mlp_ln)
             self._linear(h, blk.mlp1, mid, post_act=ACT_GELU)

@@ -96,6 +96,9 @@ class WhisperRef:
         self.dims = dims
         self.dtype = dtype
         self.cross_kv_dtype = cross_kv_dtype
+        # the encoder's self-attention reads its K / V operands in the same 16-bit type (in the reference every activation is fp16: this
+        # restatement keeps float32 everywhere except the K / V operands of attention, which are the values the reference would hold in fp16 too)
+        self.enc_kv_dtype = cross_kv_dtype
         self.w = {k: v.to(param_dtype).to(dtype) for k, v in weights.items()}
         # whisper.py:434: sinusoids(...).astype(dtype) -- the positional table is rounded to the model dtype
         self.enc_pos = sinusoids(dims.n_audio_ctx, dims.n_audio_state).to(param_dtype).to(dtype)
@@ -113,6 +116,8 @@ class WhisperRef:
         if xa is None:
             k = self._lin(x, pfx + ".key", bias=False)
             v = self._lin(x, pfx + ".value")
+            if pfx.startswith("encoder.") and self.enc_kv_dtype is not None:
+                k, v = k.to(self.enc_kv_dtype).to(self.dtype), v.to(self.enc_kv_dtype).to(self.dtype)
             if kv_cache is not None:
                 k = torch.cat([kv_cache[0], k], dim=1)
                 v = torch.cat([kv_cache[1], v], dim=1)

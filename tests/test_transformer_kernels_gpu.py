@@ -172,7 +172,8 @@ def test_attention_16bit_kv(ops, kvd, Tq, Tk, dh, G, hm, causal):
     out = torch.empty(B, Tq, H * dh, device=DEV)
     ops.flash_attention(q.to(DEV), kd, vd, out, heads=H, kv_heads=G, dh=dh, causal=causal, head_major=hm)
     torch.cuda.synchronize()
-    assert rel_err(out.cpu(), exp) < 2e-5, rel_err(out.cpu(), exp)
+    # prefill (Tq > 8) runs both contractions on the 16-bit matrix pipe with Q and P split hi + lo: ~16 mantissa bits for bf16 (the conv path's bar)
+    assert rel_err(out.cpu(), exp) < (3e-5 if (Tq > 8 and kvd == torch.bfloat16) else 2e-5), rel_err(out.cpu(), exp)
 
 
 @pytest.mark.parametrize("Tq,Tk,nsplit,causal,hm", [(1, 1500, 2, False, True), (1, 1500, 4, False, False), (3, 700, 8, True, False), (1, 130, 3, True, False),
