@@ -240,9 +240,13 @@ __device__ __forceinline__ f32x16 mfma32_16(const uint4 a, const uint4 b, const 
 template <bool F16>
 __device__ __forceinline__ void split_pair(const float x, const float y, uint32_t& hi, uint32_t& lo) {
   if constexpr (F16) {
-    hi = pack_f16x2(x, y);
-    const float hx = (float)__builtin_bit_cast(_Float16, (uint16_t)(hi & 0xffffu)), hy = (float)__builtin_bit_cast(_Float16, (uint16_t)(hi >> 16));
-    lo = pack_f16x2(x - hx, y - hy);
+    // round-toward-zero pack (one v_cvt_pkrtz_f16_f32 for two values): hi need not be the NEAREST half, only a half whose remainder the lo
+    // image can hold -- x - hi is exact in fp32 and |x - hi| < 1 ulp_half(x), so hi + lo carries the same ~22 bits
+    typedef __attribute__((ext_vector_type(2))) __fp16 h2;
+    const h2 hv = __builtin_amdgcn_cvt_pkrtz(x, y);
+    hi = __builtin_bit_cast(uint32_t, hv);
+    const h2 lv = __builtin_amdgcn_cvt_pkrtz(x - (float)hv[0], y - (float)hv[1]);
+    lo = __builtin_bit_cast(uint32_t, lv);
   } else {
     hi = pack_bf16x2(x, y);
     const float hx = __builtin_bit_cast(float, hi << 16), hy = __builtin_bit_cast(float, hi & 0xffff0000u);
@@ -362,33 +366,48 @@ __global__ __launch_bounds__(256) void flash_attn16_kernel(const mi355_flash_att
         acc = mfma32_16<F16>(kf, qh[s], acc);
         acc = mfma32_16<F16>(kf, ql[s], acc);
       }
-      // ---- mask + online softmax (per-lane query)
+      // ---- mask + online softmax (per-lane query).  The VALU work of this section, not the MFMAs, is what bounds the kernel at DH = 64
+      // (~10 lane-instructions per (query, key) against one MFMA cycle), so everything that is not needed on an interior block is skipped
+      // wave-uniformly: the visibility mask (only blocks that touch len_k / k_start / the causal diagonal / the window edge), the rescale of
+      // O (only when some lane's running maximum moved), and exp2 is the bare v_exp_f32 (arguments <= 0: no range handling needed).
+      const int wq0 = q0 + wave * 32 + qoff;   // positions of this wave's first / last query
+      const int wq1 = (q0 + wave * 32 + 31 < len_q ? q0 + wave * 32 + 31 : len_q - 1) + qoff;
+      const bool interior = kb32 + 32 <= len_k && kb32 >= kstart && (!a.causal || kb32 + 31 <= wq0) && (a.window <= 0 || kb32 > wq1 - a.window);
       float bm = -INFINITY;
+      if (interior) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = kb32 + (r & 3) + 8 * (r >> 2) + 4 * g2;
-        bool vis = j < len_k && j >= kstart;
-        if (a.causal) vis = vis && j <= qpos;
-        if (a.window > 0) vis = vis && j > qpos - a.window;
-        acc[r] = vis ? acc[r] : -INFINITY;
-        bm = fmaxf(bm, acc[r]);
+        for (int r = 0; r < 16; ++r) bm = fmaxf(bm, acc[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = kb32 + (r & 3) + 8 * (r >> 2) + 4 * g2;
+          bool vis = j < len_k && j >= kstart;
+          if (a.causal) vis = vis && j <= qpos;
+          if (a.window > 0) vis = vis && j > qpos - a.window;
+          acc[r] = vis ? acc[r] : -INFINITY;
+          bm = fmaxf(bm, acc[r]);
+        }
       }
       bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
       const float m_new = fmaxf(m, bm);
       const float m_safe = m_new == -INFINITY ? 0.f : m_new;
-      const float alpha = exp2f(m - m_safe);  // m = -inf -> 0
       float ps = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        acc[r] = exp2f(acc[r] - m_safe);  // -inf -> 0
+        acc[r] = __builtin_amdgcn_exp2f(acc[r] - m_safe);  // -inf -> 0
         ps += acc[r];
       }
-      lsum = lsum * alpha + ps;
+      if (__builtin_amdgcn_ballot_w64(m_new != m) != 0) {   // some query's maximum moved: rescale (wave-uniform branch)
+        const float alpha = __builtin_amdgcn_exp2f(m - m_safe);  // m = -inf -> 0
+        lsum = lsum * alpha + ps;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+      } else {
+        lsum += ps;
+      }
       m = m_new;
-#pragma unroll
-      for (int d = 0; d < NDB; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
       // ---- O^T += V^T P^T: step s2 contracts the keys 16 s2 + {0..3, 8..11} + 4 g2, which is where acc[8 s2 .. 8 s2 + 7] live
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
