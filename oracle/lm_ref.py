@@ -12,7 +12,8 @@ One parametrised stack covers the four variants the reference implements separat
                                            Llama-3 scaled interleaved RoPE, SwiGLU
 and ``KVCacheRef`` restates ``lm/models/cache.py:104-176`` (step-256 pre-allocation, in-place slice update, ``[:offset]`` views).
 
-Canonical parameter names (the adapters in ``mlx_audio_amd/lm/adapters.py`` map every reference checkpoint onto them):
+Canonical parameter names (each model maps its checkpoint onto them: ``tts/models/qwen3_tts/talker.py::canonical``, ``tts/models/sesame/sesame.py::_canonical``,
+``codec/models/mimi/mimi.py`` and ``tts/models/qwen3_tts/codec.py`` for the codec transformers):
   ``layers.{i}.attn_norm.weight[/bias]``, ``layers.{i}.wq|wk|wv|wo.weight[/bias]``, ``layers.{i}.q_norm.weight``, ``layers.{i}.k_norm.weight``,
   ``layers.{i}.mlp_norm.weight[/bias]``, ``layers.{i}.w_gate|w_up|w_down.weight`` (SwiGLU) or ``layers.{i}.w1|w2.weight[/bias]``,
   ``layers.{i}.ls1|ls2`` (LayerScale), ``final_norm.weight[/bias]``.
