@@ -204,11 +204,26 @@ def main():
 
     voice_rows = VoiceRows()
 
+    class ForcedRows:  # forced durations of a shard as one padded int32 block (resident; built once per plan)
+        def __init__(self):
+            self.cache = {}
+
+        def __call__(self, i):
+            return fds[i]
+
+        def rows(self, items, lens):
+            key = tuple(items)
+            if key not in self.cache:
+                self.cache[key] = torch.nn.utils.rnn.pad_sequence([fds[i].to(torch.int32) for i in items], batch_first=True).contiguous()
+            return self.cache[key]
+
+    forced_rows = ForcedRows()
+
     def step():
         # mlx_audio_amd/shard.py: broadcast of the request block, token-rate half on this rank's shard, all_reduce of the frame counts,
         # re-balance on the real frame counts (all_to_all, only when it pays), frame-rate half, exact-size all_to_all of the waveforms to
         # rank 0 -- over RCCL / xGMI when world > 1
-        return shard.kokoro_step(ch, eng, requests, voice_rows, 600, forced_durations_of=lambda i: fds[i],
+        return shard.kokoro_step(ch, eng, requests, voice_rows, 600, forced_durations_of=forced_rows,
                                  wire_dtype=wire, back_kwargs=noise_kw)
 
     for _ in range(args.warmup):

@@ -227,8 +227,14 @@ def kokoro_step(ch: ShardChannel, engine, requests: Optional[Sequence[torch.Tens
     if first:
         ids = ch.my_ids(block, lens)
         ref = ref_s_of.rows(first, lens) if hasattr(ref_s_of, "rows") else torch.cat([ref_s_of(i, lens[i]) for i in first], 0)
-        fd = [forced_durations_of(i) for i in first] if forced_durations_of else None
-        st = engine.front(ids, ref, forced_durations=fd)
+        kw = {}
+        if hasattr(engine, "pb"):  # the real engine takes the batch as the block already holds it (rows of the request block, zero-padded)
+            rows = torch.tensor(first, dtype=torch.long, device=block.device)
+            kw["ids_padded"] = block[rows, 1:].clamp_min(0)
+            if forced_durations_of is not None and hasattr(forced_durations_of, "rows"):
+                kw["forced_padded"] = forced_durations_of.rows(first, lens)
+        fd = [forced_durations_of(i) for i in first] if forced_durations_of and "forced_padded" not in kw else None
+        st = engine.front(ids, ref, forced_durations=fd, **kw)
     frames = ch.share_counts(st.frames if st else [])
     width = engine.hid + engine.sty
     style = 2 * engine.sty

@@ -409,15 +409,21 @@ class KokoroEngine:
         return self.back(st, rand_ini=rand_ini, noise=noise, noise_seed=noise_seed, return_intermediates=return_intermediates, overrides=overrides)
 
     def front(self, input_ids: Sequence[torch.Tensor], ref_s: torch.Tensor, speed: float = 1.0,
-              forced_durations: Optional[Sequence[torch.Tensor]] = None, keep_trace: bool = False) -> "KokoroFront":
-        """Token-rate half: returns the per-utterance state ``back`` needs (ids, style, duration-encoder output ``d``, durations, frames)."""
+              forced_durations: Optional[Sequence[torch.Tensor]] = None, keep_trace: bool = False,
+              ids_padded: Optional[torch.Tensor] = None, forced_padded: Optional[torch.Tensor] = None) -> "KokoroFront":
+        """Token-rate half: returns the per-utterance state ``back`` needs (ids, style, duration-encoder output ``d``, durations, frames).
+        ``ids_padded`` / ``forced_padded`` (int32 ``[B, >= Tmax]`` on the device, rows zero-padded): the batch as the caller already holds it
+        (the shard channel's request block) -- skips the per-utterance re-padding (one small copy kernel per utterance)."""
         dev, hid, sty = self.dev, self.hid, self.sty
         B = len(input_ids)
         Ts = [int(t.numel()) for t in input_ids]
         Tm = max(Ts)
         assert Tm <= self.pb["max_position_embeddings"], (Tm, self.pb["max_position_embeddings"])
         ragged = B > 1
-        if all(t.is_cuda for t in input_ids):  # already resident (sharded serving path): pad on the device, no host sync
+        if ids_padded is not None:
+            assert ids_padded.is_cuda and ids_padded.dtype == torch.int32 and ids_padded.shape[0] == B and ids_padded.shape[1] >= Tm
+            ids = ids_padded[:, :Tm].contiguous()
+        elif all(t.is_cuda for t in input_ids):  # already resident (sharded serving path): pad on the device, no host sync
             ids = torch.nn.utils.rnn.pad_sequence([t.to(device=dev, dtype=torch.int32) for t in input_ids], batch_first=True)
         else:
             ids = torch.zeros((B, Tm), dtype=torch.int32)
@@ -480,7 +486,10 @@ class KokoroEngine:
         logits = self._new(B, Tm, round_up(bins, 4))
         self._conv(xl, self.dur_proj, logits[:, :, :bins], lens_in=lens_t, lens_out=lens_t)
         forced = None
-        if forced_durations is not None:
+        if forced_padded is not None:
+            assert forced_padded.is_cuda and forced_padded.dtype == torch.int32 and forced_padded.shape[0] == B and forced_padded.shape[1] >= Tm
+            forced = forced_padded[:, :Tm].contiguous()
+        elif forced_durations is not None:
             if all(fd.is_cuda for fd in forced_durations):  # resident: pad on the device (a host-side fill would read every row back)
                 forced = torch.nn.utils.rnn.pad_sequence([fd.to(torch.int32) for fd in forced_durations], batch_first=True)
                 if forced.shape[1] < Tm:
