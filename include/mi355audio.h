@@ -407,6 +407,14 @@ typedef struct {
                                            g * k_hstride (rows of that head ldk apart, typically ldk = dh) */
   int32_t kv_dtype;       /* element type of k and v: MI355_KV_F32 (0: k / v are float*), MI355_KV_BF16, MI355_KV_F16 (16-bit: the checkpoint dtype the
                              reference keeps its caches in, whisper.py:360-361, lm/models/cache.py:104-176); every k / v stride is in ELEMENTS */
+  /* Fused single-query decode step (Tq == 1, causal; talker.py:264-307 q_norm / k_norm / apply_rotary_pos_emb / cache update / sdpa in one launch):
+     q holds the RAW projection output; new_k / new_v [B, kv_heads * dh] (items new_bstride floats apart) hold the raw k, v of the new position
+     Tk - 1, which is NOT in the cache yet.  The kernel applies the per-head RMSNorm (q_norm_w / k_norm_w [dh], nullable) and the rotary
+     embedding (rope_cos / rope_sin [rope_rows, dh / 2], nullable; rope_mode as in mi355_head_rope_args; position rope_pos - k_start[b]) to q and
+     to the new k, attends over the cache rows [.., Tk - 1) plus the new pair, and writes the processed k and the v into cache row Tk - 1. */
+  const float* new_k; const float* new_v; int64_t new_bstride;
+  const float* q_norm_w; const float* k_norm_w; float norm_eps;
+  const float* rope_cos; const float* rope_sin; int32_t rope_rows; int32_t rope_mode; int32_t rope_pos;
 } mi355_flash_attn_args;
 int mi355_flash_attention(const mi355_flash_attn_args* a, void* stream);
 

@@ -210,29 +210,24 @@ __global__ __launch_bounds__(kT) void whisper_greedy_step_reg_kernel(const mi355
 #pragma unroll
     for (int j = 0; j < NV; ++j) mx = fmaxf(mx, x1[j]);
     mx = block_max(mx, red);
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) if (tid + j * kT < a.V) s += expf(x1[j] - mx);
-    s = block_sum(s, red);
-    const float lse = mx + logf(s);
-    float mts = NEG, mtext = NEG;
+    // ONE exponential pass feeds both sums: the total (-> logsumexp) and the timestamp mass.  logsumexp(logprobs[ts:]) =
+    // log(sum_ts exp(x - mx)) + mx - lse, the same quantity the generic kernel forms around the timestamp maximum (decoding.py:428-436).
+    float s = 0.f, s_ts = 0.f, mtext = NEG;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int v = tid + j * kT;
       if (v < a.V) {
-        const float lp = x1[j] - lse;
-        if (v >= a.timestamp_begin) mts = fmaxf(mts, lp); else mtext = fmaxf(mtext, lp);
+        const float e = expf(x1[j] - mx);
+        s += e;
+        if (v >= a.timestamp_begin) s_ts += e; else mtext = fmaxf(mtext, x1[j]);
       }
     }
-    mts = block_max(mts, red);
+    s = block_sum(s, red);
+    s_ts = block_sum(s_ts, red);
     mtext = block_max(mtext, red);
-    float sts = 0.f;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int v = tid + j * kT;
-      if (v < a.V && v >= a.timestamp_begin) sts += expf((x1[j] - lse) - mts);
-    }
-    sts = block_sum(sts, red);
+    const float lse = mx + logf(s);
+    const float mts = mx - lse, sts = s_ts;   // (names of the generic kernel: ts_lp = mts + log(sts))
+    mtext -= lse;
     text_killed = mts + logf(sts) > mtext;
   }
   ArgMax best; best.v = NEG; best.i = 0x7fffffff;

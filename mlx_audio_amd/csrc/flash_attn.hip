@@ -459,10 +459,54 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
   const int len_k = a.lens_k ? a.lens_k[b] : a.Tk;
   if (qi >= len_q) return;
   const int qpos = qi + (len_k - len_q);
-  for (int t = tid; t < DH; t += NW * 64) qs[t] = a.q[(int64_t)b * a.q_bstride + (int64_t)qi * a.ldq + h * DH + t] * (a.scale * kLog2e);
+  // Fused decode step (new_k != null; Tq == 1): q arrives RAW from the q|k|v projection and gets its per-head RMSNorm + rotary embedding here;
+  // the new position's k and v arrive raw in new_k / new_v (NOT in the cache), k gets the same treatment, both enter the softmax as one more
+  // online-softmax update after the cached keys, and the first query head of each kv group stores them into the cache row Tk - 1 -- which
+  // nobody reads in this launch.  One launch less per layer than projection -> head_norm_rope -> attention (talker.py:264-307).
+  __shared__ float ks_new[DH], vs_new[DH];
+  const bool fused = a.new_k != nullptr;
+  const float qsc = a.scale * kLog2e;
+  if (!fused) {
+    for (int t = tid; t < DH; t += NW * 64) qs[t] = a.q[(int64_t)b * a.q_bstride + (int64_t)qi * a.ldq + h * DH + t] * qsc;
+  } else {
+    for (int t = tid; t < DH; t += NW * 64) {
+      qs[t] = a.q[(int64_t)b * a.q_bstride + (int64_t)qi * a.ldq + h * DH + t];
+      ks_new[t] = a.new_k[(int64_t)b * a.new_bstride + g * DH + t];
+      vs_new[t] = a.new_v[(int64_t)b * a.new_bstride + g * DH + t];
+    }
+    __syncthreads();
+    if (wave < 2) {  // wave 0: q, wave 1: k -- the arithmetic of head_norm_rope_kernel (transformer.hip), same order
+      float* vec = wave == 0 ? qs : ks_new;
+      const float* nw = wave == 0 ? a.q_norm_w : a.k_norm_w;
+      constexpr int half = DH / 2;
+      const bool act = lane < half;
+      const int i0 = a.rope_mode == 1 ? 2 * lane : lane, i1 = a.rope_mode == 1 ? 2 * lane + 1 : lane + half;
+      float x0 = 0.f, x1 = 0.f;
+      if (act) { x0 = vec[i0]; x1 = vec[i1]; }
+      if (nw) {
+        const float ss = wave_sum(x0 * x0 + x1 * x1);
+        const float r = rsqrtf(ss / (float)DH + a.norm_eps);
+        if (act) { x0 = x0 * r * nw[i0]; x1 = x1 * r * nw[i1]; }
+      }
+      if (a.rope_cos && act) {
+        int pos = a.rope_pos - (a.k_start ? a.k_start[b] : 0);
+        pos = pos < 0 ? 0 : (pos >= a.rope_rows ? a.rope_rows - 1 : pos);
+        const float c = a.rope_cos[(int64_t)pos * half + lane], sn = a.rope_sin[(int64_t)pos * half + lane];
+        const float y0 = x0 * c - x1 * sn;
+        const float y1 = x1 * c + x0 * sn;
+        x0 = y0; x1 = y1;
+      }
+      wave_lds_sync2();
+      if (act) {
+        if (wave == 0) { vec[i0] = x0 * qsc; vec[i1] = x1 * qsc; }
+        else { vec[i0] = x0; vec[i1] = x1; }
+      }
+    }
+  }
   __syncthreads();
   int kend = len_k, kbeg = 0;
   if (a.causal) kend = qpos + 1 < len_k ? qpos + 1 : len_k;
+  if (fused) kend = len_k - 1;   // the cached keys; the new one (position len_k - 1 = the query's own) is added from ks_new / vs_new below
   if (a.window > 0) { kbeg = qpos - a.window + 1; if (kbeg < 0) kbeg = 0; }
   if (a.k_start && a.k_start[b] > kbeg) kbeg = a.k_start[b];
   if (nsplit > 1) {  // this workgroup's share: contiguous, a multiple of 64 keys
@@ -578,6 +622,31 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
     }
     wave_lds_sync2();
   }
+  if (fused && wave == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) t = fmaf(qs[i * 64 + lane], ks_new[i * 64 + lane], t);
+    const float s_new = wave_sum(t);
+    const float m_new = fmaxf(m, s_new);
+    const float alpha = exp2f(m - m_new);   // m = -inf (no cached key visible) -> 0
+    const float p = exp2f(s_new - m_new);
+    l = l * alpha + p;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) o[i] = o[i] * alpha + p * vs_new[i * 64 + lane];
+    m = m_new;
+  }
+  if (fused && wave == 1 && h % (a.heads / a.kv_heads) == 0) {   // one writer per (item, kv head): the processed k and the raw v go into the cache
+    using kvw = typename kv_t<KVT>::type;
+    kvw* kdst = (kvw*)a.k + (int64_t)b * a.k_bstride + (a.k_hstride ? (int64_t)g * a.k_hstride : (int64_t)g * DH) + (int64_t)(len_k - 1) * a.ldk;
+    kvw* vdst = (kvw*)a.v + (int64_t)b * a.v_bstride + (a.v_hstride ? (int64_t)g * a.v_hstride : (int64_t)g * DH) + (int64_t)(len_k - 1) * a.ldv;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int d = i * 64 + lane;
+      if constexpr (KVT == 0) { kdst[d] = ks_new[d]; vdst[d] = vs_new[d]; }
+      else if constexpr (KVT == 1) { kdst[d] = (uint16_t)(pack_bf16x2(ks_new[d], 0.f) & 0xffffu); vdst[d] = (uint16_t)(pack_bf16x2(vs_new[d], 0.f) & 0xffffu); }
+      else { kdst[d] = (uint16_t)(pack_f16x2(ks_new[d], 0.f) & 0xffffu); vdst[d] = (uint16_t)(pack_f16x2(vs_new[d], 0.f) & 0xffffu); }
+    }
+  }
   if (lane == 0) { red_m[wave] = m; red_l[wave] = l; }
 #pragma unroll
   for (int i = 0; i < ND; ++i) red_o[wave][i * 64 + lane] = o[i];
@@ -654,8 +723,12 @@ extern "C" int mi355_flash_attention(const mi355_flash_attn_args* ap, void* stre
   MI355_REQUIRE(a.kv_dtype >= MI355_KV_F32 && a.kv_dtype <= MI355_KV_F16, "flash_attention: kv_dtype must be MI355_KV_F32, MI355_KV_BF16 or MI355_KV_F16");
   const int kvt = a.kv_dtype;
   MI355_REQUIRE(kvt == 0 || (((uintptr_t)a.k | (uintptr_t)a.v) % 8 == 0), "flash_attention: 16-bit K / V must be 8-byte aligned");
+  MI355_REQUIRE(!a.new_k || (a.new_v && a.Tq == 1 && !a.lens_q && !a.lens_k && a.mode != 1 && a.nsplit <= 1 && a.causal),
+                "flash_attention: the fused norm / rope step is a causal single-query decode step without ragged lengths or key split");
+  MI355_REQUIRE(!a.new_k || !a.rope_cos || (a.rope_sin && a.rope_rows > 0), "flash_attention: rope tables incomplete");
   hipStream_t st = (hipStream_t)stream;
   MI355_CLEAR_ERROR();
+  if (a.new_k) { a.nsplit = 1; a.split_ws = nullptr; }
   const bool decode = a.mode == 2 || (a.mode == 0 && a.Tq <= 8);
   if (decode) {
     // long key ranges with few (query, head, item) triples leave most CUs idle and each workgroup pulls ~20 GB/s: split the keys

@@ -72,9 +72,27 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
     const bool rope_in_gemv = d.cos && d.rope_mode == 1 && !L.q_norm && !L.k_norm && B <= 4 && !rope_off && !d.k_start;  // one table row for all rows
     const float* rc_row = rope_in_gemv ? d.cos + (int64_t)offset * (dh / 2) : nullptr;
     const float* rs_row = rope_in_gemv ? d.sin + (int64_t)offset * (dh / 2) : nullptr;
+    // per-head q / k norms and / or rotate-half RoPE (Qwen3 talker / code predictor / codec transformer): the attention kernel applies them to q
+    // and to the new k itself and files k, v into the cache (mi355_flash_attn_args.new_k) -- the raw k | v of this step go to a scratch row (the
+    // MLP's hidden buffer, free until the MLP runs) instead of the cache slot.  MI355_ATTN_FUSE_ROPE=0 keeps the separate head_norm_rope launch.
+    static const bool fuse_off = getenv("MI355_ATTN_FUSE_ROPE") != nullptr && getenv("MI355_ATTN_FUSE_ROPE")[0] == '0';
+    const bool rope_in_attn = !rope_in_gemv && (L.q_norm || d.cos) && !fuse_off && d.causal && d.d_ff >= nkv;
+    float* kvtmp = mid;  // [B, nkv]
     int rc = gemv_call(x, D, B, D, L.wqkv, nq + nkv, d.wdtype, L.bqkv, MI355_ACT_NONE, nullptr, nullptr, 0, 0, q, nq, d.norm, L.attn_norm_w,
-                       L.attn_norm_b, d.eps, slot, (int)L.kv_bstride, nq, stream, L.s_qkv, rc_row, rs_row, dh, rope_in_gemv ? nq + G * dh : 0);
+                       L.attn_norm_b, d.eps, rope_in_attn ? kvtmp : slot, rope_in_attn ? nkv : (int)L.kv_bstride, nq, stream, L.s_qkv, rc_row, rs_row, dh,
+                       rope_in_gemv ? nq + G * dh : 0);
     if (rc) return rc;
+    if (rope_in_attn) {
+      mi355_flash_attn_args a;
+      memset(&a, 0, sizeof(a));
+      a.q = q; a.q_bstride = nq; a.ldq = nq; a.k = L.kv; a.k_bstride = L.kv_bstride; a.ldk = nkv; a.v = L.kv + G * dh; a.v_bstride = L.kv_bstride; a.ldv = nkv;
+      a.heads = H; a.kv_heads = G; a.dh = dh; a.Tq = 1; a.Tk = offset + 1; a.causal = 1; a.window = d.window; a.scale = scale; a.B = B; a.mode = 2;
+      a.out = att; a.out_bstride = nq; a.ldo = nq; a.k_start = d.k_start; a.nsplit = 1;
+      a.new_k = kvtmp; a.new_v = kvtmp + G * dh; a.new_bstride = nkv; a.q_norm_w = L.q_norm; a.k_norm_w = L.k_norm; a.norm_eps = d.eps;
+      a.rope_cos = d.cos; a.rope_sin = d.sin; a.rope_rows = d.rope_rows; a.rope_mode = d.rope_mode; a.rope_pos = offset;
+      rc = mi355_flash_attention(&a, stream);
+      if (rc) return rc;
+    } else {
     if (!rope_in_gemv && (L.q_norm || d.cos)) {
       mi355_head_rope_args r;
       memset(&r, 0, sizeof(r));
@@ -89,6 +107,7 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
     rc = attn_call(q, nq, L.kv, L.kv + G * dh, L.kv_bstride, nkv, H, G, dh, offset + 1, d.causal, d.window, scale, B, att, nq, stream, 0, d.attn_split_ws,
                    d.attn_split_cnt, d.k_start);
     if (rc) return rc;
+    }
     rc = gemv_call(att, nq, B, nq, L.wo, D, d.wdtype, L.bo, MI355_ACT_NONE, L.ls1, x, D, 0, x, D, 0, nullptr, nullptr, 0.f, nullptr, 0, 0, stream, L.s_o);
     if (rc) return rc;
     // ---- cross-attention (Whisper decoder): K | V precomputed once per window

@@ -368,9 +368,11 @@ KV_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}  # MI355_KV_
 
 def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, heads: int, kv_heads: Optional[int] = None,
                     dh: int, scale: Optional[float] = None, causal: bool = False, window: int = 0, lens_q=None, lens_k=None,
-                    mode: int = 0, k_start=None, head_major: bool = False, nsplit: int = 0):
+                    mode: int = 0, k_start=None, head_major: bool = False, nsplit: int = 0, fused: Optional[dict] = None):
     """softmax(scale * q k^T + visibility) v.  q/out [B, Tq, >= heads*dh], k/v [B, Tk, >= kv_heads*dh] channels-last views
-    (a KV cache is just the buffer k / v point into); see mi355_flash_attn_args for the visibility rule."""
+    (a KV cache is just the buffer k / v point into); see mi355_flash_attn_args for the visibility rule.
+    ``fused`` (single-query decode step): dict(new_k, new_v [B, kv_heads * dh] raw projections of the new position, q_norm_w, k_norm_w, eps,
+    cos, sin [rows, dh / 2], rope_mode, pos) -- q / k norms, rotary embedding and the cache store of row Tk - 1 happen inside the attention kernel."""
     B, Tq, _, qbs, ldq = _nlc(q)
     _, To, _, obs, ldo = _nlc(out)
     khs = vhs = 0
@@ -384,6 +386,14 @@ def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torc
         Tv, vbs, ldv = v.shape[1], v.stride(0), v.stride(1)
     assert Bk == B and Tv == Tk and To == Tq
     assert k.dtype == v.dtype and k.dtype in KV_DTYPES, "k / v must both be float32, bfloat16 or float16"
+    fkw = {}
+    if fused is not None:
+        nk, nv = fused["new_k"], fused["new_v"]
+        assert nk.dim() == 2 and nv.dim() == 2 and nk.stride(1) == 1 and nv.stride(1) == 1 and nk.stride(0) == nv.stride(0) and nk.dtype == torch.float32
+        cos, sin = fused.get("cos"), fused.get("sin")
+        fkw = dict(new_k=_ptr(nk), new_v=_ptr(nv), new_bstride=nk.stride(0), q_norm_w=_ptr(fused.get("q_norm_w")), k_norm_w=_ptr(fused.get("k_norm_w")),
+                   norm_eps=fused.get("eps", 1e-6), rope_cos=_ptr(cos), rope_sin=_ptr(sin), rope_rows=0 if cos is None else cos.shape[0],
+                   rope_mode=fused.get("rope_mode", 0), rope_pos=fused.get("pos", Tk - 1))
     sws = scnt = None
     if nsplit > 1 and Tq <= 8 and mode != 1:
         sws, scnt = attn_split_workspace(q.device, B * heads * Tq, dh)  # key-split decode (flash-decoding), opt-in: measured slower than the unsplit kernel
@@ -392,7 +402,7 @@ def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torc
                      Tq=Tq, Tk=Tk, lens_q=_ptr(lens_q), lens_k=_ptr(lens_k), causal=int(causal), window=window,
                      scale=(1.0 / math.sqrt(dh)) if scale is None else scale, B=B, mode=mode, out=_ptr(out), out_bstride=obs, ldo=ldo,
                      k_start=_ptr(k_start), k_hstride=khs, v_hstride=vhs, split_ws=_ptr(sws), split_cnt=_ptr(scnt), nsplit=nsplit,
-                     kv_dtype=KV_DTYPES[k.dtype])
+                     kv_dtype=KV_DTYPES[k.dtype], **fkw)
     return out
 
 

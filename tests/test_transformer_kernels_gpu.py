@@ -176,6 +176,47 @@ def test_attention_16bit_kv(ops, kvd, Tq, Tk, dh, G, hm, causal):
     assert rel_err(out.cpu(), exp) < (3e-5 if (Tq > 8 and kvd == torch.bfloat16) else 2e-5), rel_err(out.cpu(), exp)
 
 
+@pytest.mark.parametrize("dh,H,G,Tk,mode,norms,kvd", [(128, 16, 8, 37, 0, True, torch.float32), (128, 8, 2, 1, 0, True, torch.float32),
+                                                      (64, 8, 8, 300, 1, False, torch.float32), (128, 4, 2, 700, 0, True, torch.bfloat16),
+                                                      (64, 4, 1, 65, 0, True, torch.float16)])
+def test_decode_attention_with_fused_norm_rope_and_cache_store(ops, dh, H, G, Tk, mode, norms, kvd):
+    """The fused decode step (mi355_flash_attn_args.new_k): q / k per-head RMSNorm + rotary embedding + cache store + attention in one launch ==
+    head_norm_rope (q in place, k into the cache slot) followed by the plain decode attention, for both rope modes, with and without the norms,
+    left padding, float32 and 16-bit caches.  The cache row written by the fused kernel must equal the one the separate kernel writes."""
+    g = torch.Generator().manual_seed(7 + dh + Tk)
+    B = 3
+    nq, nkv = H * dh, 2 * G * dh
+    q_raw = torch.randn(B, nq, generator=g).to(DEV)
+    kv_raw = torch.randn(B, nkv, generator=g).to(DEV)
+    cache0 = torch.randn(B, Tk + 3, nkv, generator=g).to(kvd).to(DEV)
+    k_start = torch.tensor([0, min(2, Tk - 1), 0], dtype=torch.int32, device=DEV)
+    qw = (1.0 + 0.1 * torch.randn(dh, generator=g)).to(DEV) if norms else None
+    kw = (1.0 + 0.1 * torch.randn(dh, generator=g)).to(DEV) if norms else None
+    pos = Tk - 1
+    inv = 1.0 / (10000.0 ** (torch.arange(0, dh, 2, dtype=torch.float32) / dh))
+    ang = torch.arange(Tk + 4, dtype=torch.float32)[:, None] * inv[None, :]
+    cos, sin = ang.cos().to(DEV).contiguous(), ang.sin().to(DEV).contiguous()
+    # ---- separate kernels: norm + rope of q (in place) and of k (float32 scratch), v untouched, then the store and the attention
+    q_ref = q_raw.clone()[:, None, :]
+    kv_ref = kv_raw.clone()[:, None, :]
+    ops.head_norm_rope(q_ref, q_ref, heads=H, dh=dh, norm_weight=qw, eps=1e-6, cos=cos, sin=sin, pos0=pos, interleaved=(mode == 1), pos_sub=k_start,
+                       second=(kv_ref[:, :, : G * dh], kv_ref[:, :, : G * dh], G, kw))
+    cache_ref = cache0.clone()
+    cache_ref[:, Tk - 1] = kv_ref[:, 0].to(kvd)
+    out_ref = torch.empty(B, 1, nq, device=DEV)
+    ops.flash_attention(q_ref, cache_ref[:, :Tk, : G * dh], cache_ref[:, :Tk, G * dh:], out_ref, heads=H, kv_heads=G, dh=dh, causal=True, k_start=k_start, mode=2)
+    # ---- fused
+    cache = cache0.clone()
+    out = torch.empty(B, 1, nq, device=DEV)
+    ops.flash_attention(q_raw[:, None, :], cache[:, :Tk, : G * dh], cache[:, :Tk, G * dh:], out, heads=H, kv_heads=G, dh=dh, causal=True, k_start=k_start, mode=2,
+                        fused=dict(new_k=kv_raw[:, : G * dh], new_v=kv_raw[:, G * dh:], q_norm_w=qw, k_norm_w=kw, eps=1e-6, cos=cos, sin=sin,
+                                   rope_mode=mode, pos=pos))
+    torch.cuda.synchronize()
+    assert torch.equal(cache[:, Tk - 1], cache_ref[:, Tk - 1])            # same arithmetic, same rounding into the cache dtype
+    assert torch.equal(cache[:, :Tk - 1], cache0[:, :Tk - 1]) and torch.equal(cache[:, Tk:], cache0[:, Tk:])   # nothing else touched
+    assert rel_err(out.cpu(), out_ref.cpu()) < (2e-5 if kvd == torch.float32 else 2e-3), rel_err(out.cpu(), out_ref.cpu())
+
+
 @pytest.mark.parametrize("Tq,Tk,nsplit,causal,hm", [(1, 1500, 2, False, True), (1, 1500, 4, False, False), (3, 700, 8, True, False), (1, 130, 3, True, False),
                                                       (2, 64, 8, True, False)])
 def test_attention_key_split_decode(ops, Tq, Tk, nsplit, causal, hm):
