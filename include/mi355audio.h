@@ -479,6 +479,10 @@ typedef struct {
      (2i, 2i + 1) inside heads of rope_dh channels -- nn.RoPE(traditional=True) / sesame/attention.py:41-105 at ONE position: rope_cos / rope_sin
      point at that position's table row [rope_dh / 2].  Plain epilogue only (no activation / colscale / residual / glu); 1..4 rows. */
   const float* rope_cos; const float* rope_sin; int32_t rope_dh; int32_t rope_cols;
+  /* optional gathered input (M == 1 only): the input row is row (x_ids[0] + x_id_offset) of the table x points at (rows ldx floats apart) -- an
+     embedding lookup fused into the projection that consumes it (sesame.py:392-396: embed the code just sampled, project it to the decoder width);
+     the id is read on the device, so the sampler's output feeds the next GEMV without a host round trip or a separate gather launch */
+  const int32_t* x_ids; int32_t x_id_offset;
 } mi355_gemv_args;
 int mi355_gemv(const mi355_gemv_args* a, void* stream);
 int mi355_pack_rowmajor16_host(const float* w_host, int64_t n, int32_t dtype, uint16_t* out_host);

@@ -406,13 +406,14 @@ __global__ __launch_bounds__(256) void gemv1_res_kernel(const mi355_gemv_args a,
   constexpr int NIT = 2048 / (64 * 8) / (EPL / 8);  // slices covering K <= 2048 (4 at 16 bits, 2 for fp8 whose slice is 1024 elements)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int K = a.K;
+  const float* xrow = a.x_ids ? a.x + ((int64_t)a.x_ids[0] + a.x_id_offset) * a.ldx : a.x;   // optional fused embedding lookup
   float xr[NIT][EPL];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int k = it * SL + lane * EPL;
 #pragma unroll
     for (int j4 = 0; j4 < EPL / 4; ++j4) {
-      const float4 t = k < K ? *(const float4*)(a.x + k + 4 * j4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 t = k < K ? *(const float4*)(xrow + k + 4 * j4) : make_float4(0.f, 0.f, 0.f, 0.f);
       xr[it][4 * j4] = t.x; xr[it][4 * j4 + 1] = t.y; xr[it][4 * j4 + 2] = t.z; xr[it][4 * j4 + 3] = t.w;
     }
   }
@@ -509,6 +510,7 @@ __global__ __launch_bounds__(256) void gemv1_splitk_kernel(const mi355_gemv_args
     const int n = n0 + c < a.N ? n0 + c : a.N - 1;
     wrow[c] = (const uint8_t*)a.w + (int64_t)n * a.ldw * ESZ;
   }
+  const float* xrow = a.x_ids ? a.x + ((int64_t)a.x_ids[0] + a.x_id_offset) * a.ldx : a.x;
   uint4 wring[D][NC];
   float4 xring[D][EPL / 4];
   auto issue = [&](int it, int d) {
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(256) void gemv1_splitk_kernel(const mi355_gemv_args
 #pragma unroll
     for (int c = 0; c < NC; ++c) wring[d][c] = k < a.K ? *(const uint4*)(wrow[c] + (int64_t)k * ESZ) : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-    for (int j4 = 0; j4 < EPL / 4; ++j4) xring[d][j4] = k < a.K ? *(const float4*)(a.x + k + 4 * j4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j4 = 0; j4 < EPL / 4; ++j4) xring[d][j4] = k < a.K ? *(const float4*)(xrow + k + 4 * j4) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
 #pragma unroll
   for (int d = 0; d < D; ++d)
@@ -623,7 +625,7 @@ template <int WT>
 int launch_gemv_m(const mi355_gemv_args& a, hipStream_t st) {
   static const bool m1_old = getenv("MI355_GEMV_M1") != nullptr && getenv("MI355_GEMV_M1")[0] == '0';  // A/B knob: the chunked kernel at one row
   // split K needs a plain epilogue (no SwiGLU pairs / rotary pairs: those shapes have K <= 2048 in every model of the path) and no fused norm
-  if (a.M == 1 && !m1_old && (a.K <= 2048 || (!a.norm && !a.glu && !a.rope_cos))) return launch_gemv1<WT>(a, st);
+  if (a.M == 1 && (!m1_old || a.x_ids) && (a.K <= 2048 || (!a.norm && !a.glu && !a.rope_cos))) return launch_gemv1<WT>(a, st);
   if (a.M == 1) return launch_gemv<1, WT>(a, st);
   if (a.M == 2) return launch_gemv<2, WT>(a, st);
   if (a.M <= 4) return launch_gemv<4, WT>(a, st);
@@ -640,6 +642,7 @@ extern "C" int mi355_gemv(const mi355_gemv_args* ap, void* stream) {
   MI355_REQUIRE(ap && ap->x && ap->w && ap->y, "gemv: null tensor");
   mi355_gemv_args a = *ap;
   MI355_REQUIRE(a.M >= 1 && a.M <= 8, "gemv: M must be in [1, 8] (got %d); use conv_gemm for taller inputs", a.M);
+  MI355_REQUIRE(!a.x_ids || (a.M == 1 && (a.K <= 2048 || (!a.norm && !a.glu && !a.rope_cos))), "gemv: the gathered input exists for one row on the M = 1 kernels");
   MI355_REQUIRE(a.N > 0 && a.K > 0 && a.K % 8 == 0, "gemv: K must be a positive multiple of 8");
   MI355_REQUIRE(a.ldw % 8 == 0 && a.ldw >= a.K && ((uintptr_t)a.w) % 16 == 0, "gemv: weight rows must be 16-byte aligned");
   MI355_REQUIRE(a.ldx % 4 == 0 && ((uintptr_t)a.x) % 16 == 0, "gemv: x rows must be 16-byte aligned");

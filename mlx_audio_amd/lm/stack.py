@@ -285,9 +285,11 @@ class TransformerStack:
         if self.cos is not None and offset + n_new > self.cos.shape[0]:
             raise ValueError(f"sequence position {offset + n_new - 1} is past the {self.cos.shape[0]}-row rotary tables (max_pos) of this stack")
 
-    def decode_step(self, x: torch.Tensor, cache: List[KVCache], k_start: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def decode_step(self, x: torch.Tensor, cache: List[KVCache], k_start: Optional[torch.Tensor] = None, defer_final_norm: bool = False) -> torch.Tensor:
         """One single-position step for B <= 8 sequences through the native runner: x [B, 1, d_model] (updated in place); returns the
-        final-normed hidden state [B, 1, d_model] (or x itself when the stack has no final norm).  ``k_start`` int32 [B]: left padding."""
+        final-normed hidden state [B, 1, d_model] (or x itself when the stack has no final norm).  ``k_start`` int32 [B]: left padding.
+        ``defer_final_norm``: return the UN-normalised residual stream; the caller fuses the final norm into the GEMV that consumes it
+        (``final_norm_arg()`` is the ``norm=`` tuple for ``linear``): one launch less per step."""
         c = self.cfg
         B = x.shape[0]
         off = cache[0].offset
@@ -296,12 +298,18 @@ class TransformerStack:
             kvc.reserve(B, 1)
         st = self._native_desc(cache, k_start)
         ws = torch.empty(B * (2 * c.n_heads * c.head_dim + c.d_ff), dtype=torch.float32, device=self.device)
-        out = torch.empty_like(x) if self.final_norm is not None else None
+        out = torch.empty_like(x) if (self.final_norm is not None and not defer_final_norm) else None
         lib = _lib.load()
         rc = lib.mi355_stack_decode_step(ctypes.byref(st["desc"]), x.data_ptr(), B, off, ws.data_ptr(), None if out is None else out.data_ptr(),
                                          ops._stream())
         _lib.check(rc, "mi355_stack_decode_step")
         return out if out is not None else x
+
+    def final_norm_arg(self) -> Optional[tuple]:
+        """``norm=`` argument of ``linear`` / ``ops.gemv`` that applies this stack's final norm inside the consuming GEMV."""
+        if self.final_norm is None:
+            return None
+        return ("layer" if self.cfg.norm == "layer" else "rms", self.final_norm[0], self.final_norm[1], self.cfg.norm_eps)
 
     def _norm(self, x: torch.Tensor, p) -> torch.Tensor:
         y = torch.empty_like(x)
@@ -309,7 +317,8 @@ class TransformerStack:
             return ops.layernorm(x, y, weight=p[0], bias=p[1], eps=self.cfg.norm_eps)
         return ops.rmsnorm(x, y, p[0], eps=self.cfg.norm_eps)
 
-    def __call__(self, x: torch.Tensor, cache: Optional[List[KVCache]] = None, return_layers: bool = False, k_start: Optional[torch.Tensor] = None):
+    def __call__(self, x: torch.Tensor, cache: Optional[List[KVCache]] = None, return_layers: bool = False, k_start: Optional[torch.Tensor] = None,
+                 defer_final_norm: bool = False):
         """x [B, L, d_model] fp32 on the device (modified in place and returned, normalised when ``final_norm``).
         ``k_start`` int32 [B] (device): row b of the batch is LEFT-padded by k_start[b] positions (BatchKVCache, lm/models/cache.py:502-560;
         the reference's batched talker builds the same thing from its attention mask, talker.py:443-470): its keys before k_start[b] are
@@ -322,7 +331,8 @@ class TransformerStack:
         if k_start is not None:
             assert k_start.dtype == torch.int32 and k_start.shape == (B,) and k_start.is_cuda
         if is_decode(x) and not return_layers and self.native_decode:
-            return self.decode_step(x, cache, k_start)
+            return self.decode_step(x, cache, k_start, defer_final_norm)
+        assert not defer_final_norm, "defer_final_norm exists on the single-position decode path only"
         self._check_positions(cache[0].offset, L)
         H, G, dh = c.n_heads, c.n_kv_heads, c.head_dim
         dev = self.device

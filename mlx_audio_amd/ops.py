@@ -175,11 +175,12 @@ def pack_rowmajor_fp8(w: torch.Tensor, bias: Optional[torch.Tensor], device) -> 
 
 def gemv(x: torch.Tensor, rw: RowMajor16, y: torch.Tensor, *, post_act: int = ACT_NONE, post_slope: float = 0.0,
          res: Optional[torch.Tensor] = None, colscale: Optional[torch.Tensor] = None, out_scale: float = 1.0, glu: bool = False,
-         use_bias: bool = True, norm: Optional[tuple] = None, y2: Optional[torch.Tensor] = None, rope: Optional[tuple] = None):
+         use_bias: bool = True, norm: Optional[tuple] = None, y2: Optional[torch.Tensor] = None, rope: Optional[tuple] = None,
+         x_ids: Optional[torch.Tensor] = None, x_id_offset: int = 0):
     """y[m, :] = epilogue(norm(x[m, :]) @ W^T) for 1..8 rows; x / y / res are 2-D fp32 views with unit inner stride.
     ``norm`` = (mode, weight, bias, eps) with mode "layer" | "rms" fuses the input normalisation; ``y2``: columns >= y.shape[1] go there."""
     assert x.dim() == 2 and y.dim() == 2 and x.stride(1) == 1 and y.stride(1) == 1 and x.dtype == torch.float32 and y.dtype == torch.float32
-    M = x.shape[0]
+    M = x.shape[0] if x_ids is None else 1   # x_ids int32 [1] (device): x is then a TABLE and the input row is x[x_ids[0] + x_id_offset]
     n_y = rw.n // 2 if glu else (rw.n if y2 is None else rw.n - y2.shape[1])
     assert x.shape[1] == rw.k and y.shape[0] == M and y.shape[1] == n_y, (x.shape, y.shape, rw.n, rw.k)
     kw = dict(x=_ptr(x), ldx=x.stride(0), M=M, K=rw.k, w=_ptr(rw.w), ldw=rw.w.stride(0), wdtype=rw.wdtype, wscale=_ptr(rw.scale), N=rw.n,
@@ -194,6 +195,9 @@ def gemv(x: torch.Tensor, rw: RowMajor16, y: torch.Tensor, *, post_act: int = AC
     if y2 is not None:
         assert y2.dim() == 2 and y2.stride(1) == 1 and y2.shape[0] == M
         kw.update(y2=_ptr(y2), ldy2=y2.stride(0), split=n_y)
+    if x_ids is not None:
+        assert x_ids.dtype == torch.int32 and x_ids.numel() == 1 and x_ids.is_cuda
+        kw.update(x_ids=_ptr(x_ids), x_id_offset=int(x_id_offset))
     if rope is not None:  # (cos_row [dh / 2], sin_row [dh / 2], dh, cols): interleaved rotary pairs on the first ``cols`` output columns
         cos_row, sin_row, dh, cols = rope
         assert cos_row.is_contiguous() and sin_row.is_contiguous() and cos_row.numel() >= dh // 2

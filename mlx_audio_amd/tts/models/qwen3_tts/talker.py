@@ -144,12 +144,12 @@ class Qwen3Talker:
         linear(h, self.fc2, out, precision=self.precision)
         return out
 
-    def _logits(self, h_last: torch.Tensor, head: Lin) -> torch.Tensor:
-        """h_last [B, 1, C] -> [B, V_padded] fp32."""
+    def _logits(self, h_last: torch.Tensor, head: Lin, norm=None) -> torch.Tensor:
+        """h_last [B, 1, C] -> [B, V_padded] fp32 (``norm``: the producing stack's deferred final norm, applied in the GEMV prologue)."""
         B = h_last.shape[0]
         V = head.rm.n
         out = self._f(B, 1, ops.round_up(V, 4))
-        linear(h_last, head, out[:, :, :V], precision=self.precision)
+        linear(h_last, head, out[:, :, :V], precision=self.precision, norm=norm)
         return out[:, 0, :]
 
     def generate(self, prefill: torch.Tensor, trailing: torch.Tensor, tts_pad: torch.Tensor, max_frames: int, *, temperature: float = 0.9,
@@ -244,8 +244,13 @@ class Qwen3Talker:
                     xp = self._f(B, xin.shape[1], cp.hidden_size)
                     linear(xin, self.mtp, xp, precision=self.precision)
                     xin = xp
-                hc = self.cp(xin, cp_cache)
-                lg = self._logits(hc[:, -1:, :].contiguous(), self.lm_heads[i])
+                if xin.shape[1] == 1 and B <= 8 and self.cp.native_decode and self.cp.cfg.d_model <= 2048:
+                    # the code predictor's final RMSNorm runs inside the lm_head GEMV (fused-norm prologue): one launch less per code group
+                    hc = self.cp(xin, cp_cache, defer_final_norm=True)
+                    lg = self._logits(hc, self.lm_heads[i], norm=self.cp.final_norm_arg())
+                else:
+                    hc = self.cp(xin, cp_cache)
+                    lg = self._logits(hc[:, -1:, :].contiguous(), self.lm_heads[i])
                 if record:
                     tr.append(lg[:, :Vc].clone())
                 ops.sample(lg, row[:, i + 1], V=Vc, temperature=temperature, top_k=top_k, top_p=top_p,

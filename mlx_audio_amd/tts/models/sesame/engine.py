@@ -72,6 +72,7 @@ class CSMEngine:
         self.cfg = cfg
         self.device = torch.device(device)
         self.precision = precision
+        self.fuse_embed = True  # one sequence: the depth decoder's input embedding lookup runs inside the projection GEMV (False: embed_sum + GEMV)
         dev = self.device
         w = {k: v.detach().to(torch.bfloat16).to(torch.float32).cpu() for k, v in weights.items()}
         self.backbone = TransformerStack(w, cfg.backbone, device=dev, precision=precision, prefix="backbone.")
@@ -93,11 +94,11 @@ class CSMEngine:
     def _f(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.device)
 
-    def _logits(self, h_last, head):
+    def _logits(self, h_last, head, norm=None):
         B = h_last.shape[0]
         V = head.rm.n
         out = self._f(B, 1, ops.round_up(V, 4))
-        linear(h_last, head, out[:, :, :V], precision=self.precision)
+        linear(h_last, head, out[:, :, :V], precision=self.precision, norm=norm)
         return out[:, 0, :]
 
     def generate_frame(self, tokens: torch.Tensor, tokens_mask: torch.Tensor, *, temperature: float = 0.9, top_k: int = 50,
@@ -146,19 +147,32 @@ class CSMEngine:
                 p0 = self._f(B, 1, Dd)
                 linear(last, self.projection, p0, precision=self.precision)
                 self.decoder(p0, cache)
-                cur = self._f(B, 1, D)
-                ops.embed_sum(self.table, sample[:, 0:1].unsqueeze(1), cur, slot_offset=self.slot_offs[0:1])
+                if B == 1 and self.fuse_embed:
+                    cur = None
+                else:
+                    cur = self._f(B, 1, D)
+                    ops.embed_sum(self.table, sample[:, 0:1].unsqueeze(1), cur, slot_offset=self.slot_offs[0:1])
             elif i == 1:
                 cur = self._f(B, 2, D)
                 cur[:, 0:1, :] = last
                 ops.embed_sum(self.table, sample[:, 0:1].unsqueeze(1), cur[:, 1:2, :], slot_offset=self.slot_offs[0:1])
+            elif B == 1 and self.fuse_embed:
+                cur = None
             else:
                 cur = self._f(B, 1, D)
                 ops.embed_sum(self.table, sample[:, i - 1:i].unsqueeze(1), cur, slot_offset=self.slot_offs[i - 1:i])
-            p = self._f(B, cur.shape[1], Dd)
-            linear(cur, self.projection, p, precision=self.precision)
-            dh = self.decoder(p, cache)
-            draw(self._logits(dh[:, -1:, :].contiguous(), self.heads[i - 1]), i)
+            p = self._f(B, cur.shape[1] if cur is not None else 1, Dd)
+            if cur is None:  # one sequence: embedding lookup of the code just sampled fused into the projection GEMV (mi355_gemv_args.x_ids)
+                ops.gemv(self.table, self.projection.rm, p[:, 0, :], x_ids=sample[0, i - 1:i], x_id_offset=(i - 1) * V)
+            else:
+                linear(cur, self.projection, p, precision=self.precision)
+            if p.shape[1] == 1 and B <= 8 and self.decoder.native_decode:
+                # the depth decoder's final RMSNorm runs inside the head GEMV (its fused-norm prologue): one launch less per codebook
+                dh = self.decoder(p, cache, defer_final_norm=True)
+                draw(self._logits(dh, self.heads[i - 1], norm=self.decoder.final_norm_arg()), i)
+            else:
+                dh = self.decoder(p, cache)
+                draw(self._logits(dh[:, -1:, :].contiguous(), self.heads[i - 1]), i)
         return sample
 
     def generate(self, prompt_tokens: torch.Tensor, prompt_mask: torch.Tensor, max_frames: int, *, temperature: float = 0.9, top_k: int = 50,

@@ -300,6 +300,24 @@ def test_gemv(ops, M, N, K, f16, act, use_res, use_cs):
     assert rel_err(y.cpu(), v) < _gemv_tol(M, K, f16), rel_err(y.cpu(), v)
 
 
+@pytest.mark.parametrize("N,K,idx,off", [(1024, 2048, 7, 100), (512, 4096, 0, 3)])
+def test_gemv_gathered_input_row(ops, N, K, idx, off):
+    """mi355_gemv_args.x_ids: the input row is row (ids[0] + offset) of a table, read on the device (embedding lookup fused into the projection,
+    sesame.py:392-396) == the GEMV on that row."""
+    g = torch.Generator().manual_seed(N + K)
+    table = torch.randn(200, K, generator=g).to(DEV)
+    w = _round16(torch.randn(N, K, generator=g) / math.sqrt(K), False)
+    rw = ops.pack_rowmajor16(w, None, DEV)
+    ids = torch.tensor([idx], dtype=torch.int32, device=DEV)
+    y = torch.empty(1, N, device=DEV)
+    ops.gemv(table, rw, y, x_ids=ids, x_id_offset=off)
+    y2 = torch.empty(1, N, device=DEV)
+    ops.gemv(table[idx + off: idx + off + 1], rw, y2)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+    assert rel_err(y.cpu(), table[idx + off].cpu().double() @ w.double().T) < 5e-6
+
+
 def _gemv_tol(M, K, f16, base=5e-6):
     """5..8 rows with K % 64 == 0 run on the matrix pipe (gemv_mfma.hip): the input rows are split into hi + lo images of the weights' type,
     ~16 mantissa bits for bf16 weights (the split conv_gemm precision 2 runs prefill with; its tests allow 3e-5), ~22 for fp16."""
