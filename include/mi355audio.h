@@ -483,6 +483,8 @@ typedef struct {
      embedding lookup fused into the projection that consumes it (sesame.py:392-396: embed the code just sampled, project it to the decoder width);
      the id is read on the device, so the sampler's output feeds the next GEMV without a host round trip or a separate gather launch */
   const int32_t* x_ids; int32_t x_id_offset;
+  int32_t y2_dtype;   /* element type of y2: MI355_KV_F32 (0) / MI355_KV_BF16 / MI355_KV_F16 -- a 16-bit KV-cache slot (the reference's cache dtype);
+                         y2 is then a uint16_t* in disguise and ldy2 counts 16-bit elements */
 } mi355_gemv_args;
 int mi355_gemv(const mi355_gemv_args* a, void* stream);
 int mi355_pack_rowmajor16_host(const float* w_host, int64_t n, int32_t dtype, uint16_t* out_host);
@@ -595,7 +597,7 @@ typedef struct {
   const float* attn_norm_w; const float* attn_norm_b; const float* mlp_norm_w; const float* mlp_norm_b;
   const float* q_norm; const float* k_norm;     /* [dh] per-head RMSNorm weights, nullable */
   const float* ls1; const float* ls2;           /* [d_model] LayerScale, nullable */
-  float* kv; int64_t kv_bstride; int32_t kv_capacity;
+  float* kv; int64_t kv_bstride; int32_t kv_capacity;   /* element type = mi355_stack_desc.kv_dtype (then kv is a uint16_t* in disguise); strides in elements */
   /* optional cross-attention block (Whisper decoder): q projection + pre-norm, K | V precomputed [B, cross_len, 2*kv_heads*dh] */
   const uint16_t* wcq; const float* bcq; const uint16_t* wco; const float* bco;
   const float* cross_norm_w; const float* cross_norm_b;
@@ -622,9 +624,12 @@ typedef struct {
   const mi355_layer_desc* layers;                           /* HOST array of n_layers records */
   float* attn_split_ws; int32_t* attn_split_cnt;            /* nullable: workspace of mi355_flash_attn_args.split_* for B <= 8, Tq = 1 */
   const float* final_norm_w; const float* final_norm_b;     /* nullable */
+  int32_t kv_dtype;        /* MI355_KV_F32 / MI355_KV_BF16 / MI355_KV_F16: element type of every layer's kv buffer (the reference keeps its caches in the
+                              checkpoint dtype, lm/models/cache.py:104-176).  16-bit caches need the stores that exist: q|k|v GEMV with the rotary pairs in its
+                              epilogue, the fused norm / rope attention step, or no rotary embedding at all */
 } mi355_stack_desc;
 
-/* x [B, d_model] (updated in place: the residual stream), ws: workspace of B * (2 * heads * dh + d_ff) floats, out (nullable) [B, d_model]
+/* x [B, d_model] (updated in place: the residual stream), ws: workspace of B * (2 * heads * dh + d_ff + 2 * kv_heads * dh) floats, out (nullable) [B, d_model]
  * receives the final-normed hidden state when final_norm_w is set.  offset = rows already in the KV caches. */
 int mi355_stack_decode_step(const mi355_stack_desc* d, float* x, int32_t B, int32_t offset, float* ws, float* out, void* stream);
 

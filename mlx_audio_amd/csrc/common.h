@@ -140,6 +140,13 @@ static inline uint8_t host_f32_to_e4m3(float f) {
   return (uint8_t)(sign | (uint8_t)(((e + 7) << 3) | (ni - 8)));
 }
 
+// one value into a buffer of element type MI355_KV_F32 / MI355_KV_BF16 / MI355_KV_F16 (index in elements); round to nearest even
+__device__ __forceinline__ void store_kv_elem(void* base, int64_t idx, float v, int dtype) {
+  if (dtype == MI355_KV_F32) ((float*)base)[idx] = v;
+  else if (dtype == MI355_KV_BF16) ((uint16_t*)base)[idx] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffffu);
+  else ((uint16_t*)base)[idx] = (uint16_t)(pack_f16x2(v, 0.f) & 0xffffu);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

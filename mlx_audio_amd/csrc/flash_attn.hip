@@ -51,6 +51,14 @@ __device__ __forceinline__ float kv_f32(const uint16_t u) {
   else return (float)__builtin_bit_cast(_Float16, u);
 }
 
+// the value a cache of this type would hand back (round to nearest even into the 16-bit type and back; identity for float32)
+template <int KVT>
+__device__ __forceinline__ float kv_round(const float v) {
+  if constexpr (KVT == 0) return v;
+  else if constexpr (KVT == 1) return kv_f32<1>((uint16_t)(pack_bf16x2(v, 0.f) & 0xffffu));
+  else return kv_f32<2>((uint16_t)(pack_f16x2(v, 0.f) & 0xffffu));
+}
+
 // four consecutive elements at p (16-byte aligned for float32, 8-byte aligned for the 16-bit types)
 template <int KVT>
 __device__ __forceinline__ float4 kv_load4(const typename kv_t<KVT>::type* p) {
@@ -472,7 +480,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
     for (int t = tid; t < DH; t += NW * 64) {
       qs[t] = a.q[(int64_t)b * a.q_bstride + (int64_t)qi * a.ldq + h * DH + t];
       ks_new[t] = a.new_k[(int64_t)b * a.new_bstride + g * DH + t];
-      vs_new[t] = a.new_v[(int64_t)b * a.new_bstride + g * DH + t];
+      vs_new[t] = kv_round<KVT>(a.new_v[(int64_t)b * a.new_bstride + g * DH + t]);   // as the cache will hold it (the reference attends over the cache)
     }
     __syncthreads();
     if (wave < 2) {  // wave 0: q, wave 1: k -- the arithmetic of head_norm_rope_kernel (transformer.hip), same order
@@ -499,7 +507,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
       wave_lds_sync2();
       if (act) {
         if (wave == 0) { vec[i0] = x0 * qsc; vec[i1] = x1 * qsc; }
-        else { vec[i0] = x0; vec[i1] = x1; }
+        else { vec[i0] = kv_round<KVT>(x0); vec[i1] = kv_round<KVT>(x1); }
       }
     }
   }

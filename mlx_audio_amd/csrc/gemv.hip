@@ -72,8 +72,8 @@ __device__ __forceinline__ void gemv_finish(const mi355_gemv_args& a, float (&ac
         const float y0 = x0 * cs - x1 * sn;   // (x * cos) + (rotate(x) * sin), like head_norm_rope_kernel
         const float y1 = x1 * cs + x0 * sn;
         if (a.y2 && n0 >= a.split) {
-          a.y2[(int64_t)m * a.ldy2 + (n0 - a.split)] = y0 * a.out_scale;
-          a.y2[(int64_t)m * a.ldy2 + (n0 + 1 - a.split)] = y1 * a.out_scale;
+          store_kv_elem(a.y2, (int64_t)m * a.ldy2 + (n0 - a.split), y0 * a.out_scale, a.y2_dtype);
+          store_kv_elem(a.y2, (int64_t)m * a.ldy2 + (n0 + 1 - a.split), y1 * a.out_scale, a.y2_dtype);
         } else {
           a.y[(int64_t)m * a.ldy + n0] = y0 * a.out_scale;
           a.y[(int64_t)m * a.ldy + n0 + 1] = y1 * a.out_scale;
@@ -94,7 +94,7 @@ __device__ __forceinline__ void gemv_finish(const mi355_gemv_args& a, float (&ac
       if (m >= a.M) break;
       float v = gemv_act(acc[c][m] * ws + bias, a.post_act, a.post_slope) * cs;
       if (a.res) v += a.res[(int64_t)m * a.ldr + n];
-      if (a.y2 && n >= a.split) a.y2[(int64_t)m * a.ldy2 + (n - a.split)] = v * a.out_scale;  // e.g. q -> y, k|v -> the KV-cache slot
+      if (a.y2 && n >= a.split) store_kv_elem(a.y2, (int64_t)m * a.ldy2 + (n - a.split), v * a.out_scale, a.y2_dtype);  // e.g. q -> y, k|v -> the KV-cache slot
       else a.y[(int64_t)m * a.ldy + n] = v * a.out_scale;
     }
   }
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(256) void gemv1_splitk_kernel(const mi355_gemv_args
     const float ws = a.wscale ? a.wscale[n] * kFp8Unbias : 1.f;
     float v = gemv_act(sum * ws + (a.bias ? a.bias[n] : 0.f), a.post_act, a.post_slope) * (a.colscale ? a.colscale[n] : 1.f);
     if (a.res) v += a.res[n];
-    if (a.y2 && n >= a.split) a.y2[n - a.split] = v * a.out_scale;
+    if (a.y2 && n >= a.split) store_kv_elem(a.y2, n - a.split, v * a.out_scale, a.y2_dtype);
     else a.y[n] = v * a.out_scale;
   }
 }
@@ -634,9 +634,11 @@ int launch_gemv_m(const mi355_gemv_args& a, hipStream_t st) {
 
 }  // namespace
 
-// gemv_mfma.hip: the matrix-pipe kernel for 5..8 rows
+// gemv_mfma.hip / gemv_mfma_fp8.hip: the matrix-pipe kernels for 5..8 rows (16-bit and fp8 weight images)
 int mi355_gemv_mfma_eligible(const mi355_gemv_args& a);
 int mi355_gemv_mfma_launch(const mi355_gemv_args& a, hipStream_t st);
+int mi355_gemv_mfma_fp8_eligible(const mi355_gemv_args& a);
+int mi355_gemv_mfma_fp8_launch(const mi355_gemv_args& a, hipStream_t st);
 
 extern "C" int mi355_gemv(const mi355_gemv_args* ap, void* stream) {
   MI355_REQUIRE(ap && ap->x && ap->w && ap->y, "gemv: null tensor");
@@ -654,6 +656,7 @@ extern "C" int mi355_gemv(const mi355_gemv_args* ap, void* stream) {
   MI355_REQUIRE(!a.norm || (a.K % 4 == 0 && (!a.norm_weight || ((uintptr_t)a.norm_weight) % 16 == 0) && (!a.norm_bias || ((uintptr_t)a.norm_bias) % 16 == 0)),
                 "gemv: norm weight / bias must be 16-byte aligned");
   MI355_REQUIRE(!a.y2 || (a.split > 0 && a.split < a.N), "gemv: split must be inside (0, N) when y2 is given");
+  MI355_REQUIRE(a.y2_dtype >= MI355_KV_F32 && a.y2_dtype <= MI355_KV_F16, "gemv: y2_dtype must be MI355_KV_F32, MI355_KV_BF16 or MI355_KV_F16");
   MI355_REQUIRE(!a.rope_cos || (a.rope_sin && a.rope_dh > 0 && a.rope_dh % 2 == 0 && a.rope_cols > 0 && a.rope_cols <= a.N && a.rope_cols % a.rope_dh == 0 &&
                                 !a.glu && !a.res && !a.colscale && a.post_act == MI355_ACT_NONE && a.M <= 4 && (!a.y2 || a.split % 2 == 0)),
                 "gemv: fused rope needs a plain epilogue, <= 4 rows, whole heads and an even split");
@@ -662,6 +665,7 @@ extern "C" int mi355_gemv(const mi355_gemv_args* ap, void* stream) {
   a.norm_two_reads = two_reads ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   if (mi355_gemv_mfma_eligible(a)) return mi355_gemv_mfma_launch(a, st);
+  if (mi355_gemv_mfma_fp8_eligible(a)) return mi355_gemv_mfma_fp8_launch(a, st);
   if (a.wdtype == MI355_W_FP8) return launch_gemv_m<MI355_W_FP8>(a, st);
   return a.wdtype == MI355_W_F16 ? launch_gemv_m<MI355_W_F16>(a, st) : launch_gemv_m<MI355_W_BF16>(a, st);
 }

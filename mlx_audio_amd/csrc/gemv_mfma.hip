@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const mi355_gemv_args a)
   }
   float v = mfma_act(v0 + (a.bias ? a.bias[n] : 0.f), a.post_act, a.post_slope) * (a.colscale ? a.colscale[n] : 1.f);
   if (a.res) v += a.res[(int64_t)m * a.ldr + n];
-  if (a.y2 && n >= a.split) a.y2[(int64_t)m * a.ldy2 + (n - a.split)] = v * a.out_scale;
+  if (a.y2 && n >= a.split) store_kv_elem(a.y2, (int64_t)m * a.ldy2 + (n - a.split), v * a.out_scale, a.y2_dtype);
   else a.y[(int64_t)m * a.ldy + n] = v * a.out_scale;
 }
 
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void gemv_mfma_stream_kernel(const mi355_gemv_
   }
   float v = mfma_act(v0 + (a.bias ? a.bias[n] : 0.f), a.post_act, a.post_slope) * (a.colscale ? a.colscale[n] : 1.f);
   if (a.res) v += a.res[(int64_t)m * a.ldr + n];
-  if (a.y2 && n >= a.split) a.y2[(int64_t)m * a.ldy2 + (n - a.split)] = v * a.out_scale;
+  if (a.y2 && n >= a.split) store_kv_elem(a.y2, (int64_t)m * a.ldy2 + (n - a.split), v * a.out_scale, a.y2_dtype);
   else a.y[(int64_t)m * a.ldy + n] = v * a.out_scale;
 }
 

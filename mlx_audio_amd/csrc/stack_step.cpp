@@ -18,13 +18,13 @@ namespace {
 int gemv_call(const float* x, int ldx, int M, int K, const uint16_t* w, int N, int wdtype, const float* bias, int act, const float* colscale,
               const float* res, int ldr, int glu, float* y, int ldy, int norm, const float* nw, const float* nb, float eps, float* y2, int ldy2,
               int split, void* stream, const float* wscale = nullptr, const float* rope_cos = nullptr, const float* rope_sin = nullptr, int rope_dh = 0,
-              int rope_cols = 0) {
+              int rope_cols = 0, int y2_dtype = MI355_KV_F32) {
   mi355_gemv_args g;
   memset(&g, 0, sizeof(g));
   g.x = x; g.ldx = ldx; g.M = M; g.K = K; g.w = w; g.ldw = K; g.wdtype = wdtype; g.N = N; g.bias = bias; g.post_act = act; g.colscale = colscale;
   g.res = res; g.ldr = ldr; g.out_scale = 1.f; g.glu = glu; g.y = y; g.ldy = ldy; g.norm = norm; g.norm_weight = nw; g.norm_bias = nb;
   g.norm_eps = eps; g.y2 = y2; g.ldy2 = ldy2; g.split = split; g.wscale = wscale;
-  g.rope_cos = rope_cos; g.rope_sin = rope_sin; g.rope_dh = rope_dh; g.rope_cols = rope_cols;
+  g.rope_cos = rope_cos; g.rope_sin = rope_sin; g.rope_dh = rope_dh; g.rope_cols = rope_cols; g.y2_dtype = y2_dtype;
   return mi355_gemv(&g, stream);
 }
 
@@ -50,6 +50,7 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
   MI355_REQUIRE(d.wdtype != MI355_W_FP8 || (d.d_model % 16 == 0 && d.d_ff % 16 == 0), "stack_decode_step: fp8 images need d_model, d_ff multiples of 16");
   MI355_REQUIRE(d.norm == 1 || d.norm == 2, "stack_decode_step: norm must be 1 (LayerNorm) or 2 (RMSNorm)");
   MI355_REQUIRE(offset >= 0, "stack_decode_step: negative offset");
+  MI355_REQUIRE(d.kv_dtype >= MI355_KV_F32 && d.kv_dtype <= MI355_KV_F16, "stack_decode_step: bad kv_dtype");
   MI355_REQUIRE(!d.cos || (d.rope_rows > 0 && offset < d.rope_rows), "stack_decode_step: position %d is past the %d-row rotary tables", offset,
                 d.rope_rows);
   const int D = d.d_model, H = d.heads, G = d.kv_heads, dh = d.dh;
@@ -64,7 +65,9 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
     MI355_REQUIRE(d.wdtype != MI355_W_FP8 || (L.s_qkv && L.s_o && L.s_in && L.s_out && (!L.cross_k || (L.s_cq && L.s_co))),
                   "stack_decode_step: layer %d has fp8 images but no scales", i);
     MI355_REQUIRE(offset < L.kv_capacity, "stack_decode_step: KV cache of layer %d is full (offset %d, capacity %d)", i, offset, L.kv_capacity);
-    float* slot = L.kv + (int64_t)offset * nkv;  // row `offset` of item 0; items are kv_bstride apart
+    const int kvsz = d.kv_dtype == MI355_KV_F32 ? 4 : 2;   // bytes per cache element
+    float* slot = (float*)((char*)L.kv + (int64_t)offset * nkv * kvsz);  // row `offset` of item 0; items are kv_bstride elements apart
+    const float* vbase = (const float*)((const char*)L.kv + (int64_t)G * dh * kvsz);  // the v columns of row 0
     // ---- self-attention
     // interleaved RoPE without per-head q / k norms (CSM Llama, Mimi): the rotation of a pair (2i, 2i + 1) is the epilogue of the wave that owns
     // those two columns of the q | k | v projection -- one launch less per layer (MI355_GEMV_ROPE=0 keeps the separate kernel for A/B runs)
@@ -74,18 +77,21 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
     const float* rs_row = rope_in_gemv ? d.sin + (int64_t)offset * (dh / 2) : nullptr;
     // per-head q / k norms and / or rotate-half RoPE (Qwen3 talker / code predictor / codec transformer): the attention kernel applies them to q
     // and to the new k itself and files k, v into the cache (mi355_flash_attn_args.new_k) -- the raw k | v of this step go to a scratch row (the
-    // MLP's hidden buffer, free until the MLP runs) instead of the cache slot.  MI355_ATTN_FUSE_ROPE=0 keeps the separate head_norm_rope launch.
+    // tail of the workspace) instead of the cache slot.  MI355_ATTN_FUSE_ROPE=0 keeps the separate head_norm_rope launch.
     static const bool fuse_off = getenv("MI355_ATTN_FUSE_ROPE") != nullptr && getenv("MI355_ATTN_FUSE_ROPE")[0] == '0';
-    const bool rope_in_attn = !rope_in_gemv && (L.q_norm || d.cos) && !fuse_off && d.causal && d.d_ff >= nkv;
-    float* kvtmp = mid;  // [B, nkv]
+    const bool rope_in_attn = !rope_in_gemv && (L.q_norm || d.cos) && (!fuse_off || d.kv_dtype != MI355_KV_F32) && d.causal;
+    MI355_REQUIRE(d.kv_dtype == MI355_KV_F32 || rope_in_gemv || rope_in_attn || !(L.q_norm || d.cos),
+                  "stack_decode_step: a 16-bit KV cache needs the rotary embedding inside the q|k|v GEMV or inside the attention step");
+    float* kvtmp = mid + (size_t)B * d.d_ff;  // [B, nkv]: the tail of the workspace
     int rc = gemv_call(x, D, B, D, L.wqkv, nq + nkv, d.wdtype, L.bqkv, MI355_ACT_NONE, nullptr, nullptr, 0, 0, q, nq, d.norm, L.attn_norm_w,
                        L.attn_norm_b, d.eps, rope_in_attn ? kvtmp : slot, rope_in_attn ? nkv : (int)L.kv_bstride, nq, stream, L.s_qkv, rc_row, rs_row, dh,
-                       rope_in_gemv ? nq + G * dh : 0);
+                       rope_in_gemv ? nq + G * dh : 0, rope_in_attn ? MI355_KV_F32 : d.kv_dtype);
     if (rc) return rc;
     if (rope_in_attn) {
       mi355_flash_attn_args a;
       memset(&a, 0, sizeof(a));
-      a.q = q; a.q_bstride = nq; a.ldq = nq; a.k = L.kv; a.k_bstride = L.kv_bstride; a.ldk = nkv; a.v = L.kv + G * dh; a.v_bstride = L.kv_bstride; a.ldv = nkv;
+      a.q = q; a.q_bstride = nq; a.ldq = nq; a.k = L.kv; a.k_bstride = L.kv_bstride; a.ldk = nkv; a.v = vbase; a.v_bstride = L.kv_bstride; a.ldv = nkv;
+      a.kv_dtype = d.kv_dtype;
       a.heads = H; a.kv_heads = G; a.dh = dh; a.Tq = 1; a.Tk = offset + 1; a.causal = 1; a.window = d.window; a.scale = scale; a.B = B; a.mode = 2;
       a.out = att; a.out_bstride = nq; a.ldo = nq; a.k_start = d.k_start; a.nsplit = 1;
       a.new_k = kvtmp; a.new_v = kvtmp + G * dh; a.new_bstride = nkv; a.q_norm_w = L.q_norm; a.k_norm_w = L.k_norm; a.norm_eps = d.eps;
@@ -104,8 +110,8 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
       rc = mi355_head_norm_rope(&r, stream);
       if (rc) return rc;
     }
-    rc = attn_call(q, nq, L.kv, L.kv + G * dh, L.kv_bstride, nkv, H, G, dh, offset + 1, d.causal, d.window, scale, B, att, nq, stream, 0, d.attn_split_ws,
-                   d.attn_split_cnt, d.k_start);
+    rc = attn_call(q, nq, L.kv, vbase, L.kv_bstride, nkv, H, G, dh, offset + 1, d.causal, d.window, scale, B, att, nq, stream, 0, d.attn_split_ws,
+                   d.attn_split_cnt, d.k_start, d.kv_dtype);
     if (rc) return rc;
     }
     rc = gemv_call(att, nq, B, nq, L.wo, D, d.wdtype, L.bo, MI355_ACT_NONE, L.ls1, x, D, 0, x, D, 0, nullptr, nullptr, 0.f, nullptr, 0, 0, stream, L.s_o);

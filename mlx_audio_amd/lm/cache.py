@@ -22,7 +22,8 @@ from .stack import KVCache
 class BatchKVCache:
     step = 256
 
-    def __init__(self, left_padding: Sequence[int], n_kv_heads: int, head_dim: int, device="cpu"):
+    def __init__(self, left_padding: Sequence[int], n_kv_heads: int, head_dim: int, device="cpu", dtype: torch.dtype = torch.float32):
+        self.dtype = dtype
         self.width = 2 * n_kv_heads * head_dim
         self.n_kv_heads, self.head_dim = n_kv_heads, head_dim
         self.device = torch.device(device)
@@ -50,7 +51,7 @@ class BatchKVCache:
         prev = self._idx
         if self.kv is None or prev + n_new > self.kv.shape[1]:
             n_steps = (self.step + n_new - 1) // self.step
-            new = torch.zeros((B, n_steps * self.step, self.width), dtype=torch.float32, device=self.device)
+            new = torch.zeros((B, n_steps * self.step, self.width), dtype=self.dtype, device=self.device)
             if self.kv is not None:
                 old = self.kv[:, :prev] if prev % self.step != 0 else self.kv
                 self.kv = torch.cat([old, new], dim=1)
@@ -84,7 +85,7 @@ class BatchKVCache:
 
     @property
     def nbytes(self) -> int:
-        return 0 if self.kv is None else self.kv.numel() * 4
+        return 0 if self.kv is None else self.kv.numel() * self.kv.element_size()
 
     # ------------------------------------------------------------------ continuous batching (cache.py:606-717)
     def filter(self, batch_indices):
@@ -113,7 +114,7 @@ class BatchKVCache:
         def pad(c: "BatchKVCache"):
             kv = c.kv
             if kv is None:
-                kv = torch.zeros((c.offset.shape[0], 0, self.width), dtype=torch.float32, device=self.device)
+                kv = torch.zeros((c.offset.shape[0], 0, self.width), dtype=self.dtype, device=self.device)
             left = max_idx - c._idx
             right = max_size - kv.shape[1] - left
             if right < 0:
@@ -130,7 +131,7 @@ class BatchKVCache:
         self._idx = max_idx
 
     def extract(self, idx: int) -> KVCache:
-        c = KVCache(self.n_kv_heads, self.head_dim, self.device)
+        c = KVCache(self.n_kv_heads, self.head_dim, self.device, self.dtype)
         p = int(self.left_padding[idx])
         c.kv = self.kv[idx:idx + 1, p:self._idx].contiguous()
         c.offset = c.kv.shape[1]
@@ -142,11 +143,12 @@ class BatchKVCache:
         max_length = max(lengths)
         ref = next((c for c in caches if c.kv is not None), caches[0])
         n_kv, dh, dev = ref.width // 2 // _dh(ref), _dh(ref), ref.device
+        dt = getattr(ref, "dtype", torch.float32)
         if max_length == 0:
-            return cls([0] * len(caches), n_kv, dh, dev)
+            return cls([0] * len(caches), n_kv, dh, dev, dt)
         padding = [max_length - l for l in lengths]
-        out = cls(padding, n_kv, dh, dev)
-        out.kv = torch.zeros((len(caches), max_length, ref.width), dtype=torch.float32, device=dev)
+        out = cls(padding, n_kv, dh, dev, dt)
+        out.kv = torch.zeros((len(caches), max_length, ref.width), dtype=dt, device=dev)
         for i, (p, c) in enumerate(zip(padding, caches)):
             if c.kv is not None:
                 out.kv[i, p:p + c.offset] = c.kv[0, :c.offset]

@@ -71,10 +71,11 @@ class KVCache:
     """lm/models/cache.py:104-176 on the device; ``kv`` is [B, capacity, 2 * n_kv * dh] (k columns first, then v)."""
     step = 256
 
-    def __init__(self, n_kv_heads: int, head_dim: int, device):
+    def __init__(self, n_kv_heads: int, head_dim: int, device, dtype: torch.dtype = torch.float32):
         self.width = 2 * n_kv_heads * head_dim
         self.n_kv_heads, self.head_dim = n_kv_heads, head_dim
         self.device = device
+        self.dtype = dtype   # float32, or the checkpoint's 16-bit type like the reference's caches (lm/models/cache.py:104-176)
         self.kv: Optional[torch.Tensor] = None
         self.offset = 0
 
@@ -83,7 +84,7 @@ class KVCache:
         prev = self.offset
         if self.kv is None or prev + n_new > self.kv.shape[1]:
             n_steps = (self.step + n_new - 1) // self.step
-            new = torch.zeros((batch, n_steps * self.step, self.width), dtype=torch.float32, device=self.device)
+            new = torch.zeros((batch, n_steps * self.step, self.width), dtype=self.dtype, device=self.device)
             if self.kv is not None:
                 old = self.kv[:, :prev] if prev % self.step != 0 else self.kv
                 self.kv = torch.cat([old, new], dim=1)
@@ -119,7 +120,7 @@ class KVCache:
 
     @property
     def nbytes(self) -> int:
-        return 0 if self.kv is None else self.kv.numel() * 4
+        return 0 if self.kv is None else self.kv.numel() * self.kv.element_size()
 
 
 @dataclass
@@ -187,8 +188,10 @@ class _Layer:
 
 class TransformerStack:
     def __init__(self, weights: Dict[str, torch.Tensor], cfg: StackConfig, device="cuda:0", precision: int = 2, prefix: str = "",
-                 weight_format: str = "bf16"):
+                 weight_format: str = "bf16", kv_dtype: torch.dtype = torch.float32):
         ops.require_gpu()
+        assert kv_dtype in ops.KV_DTYPES
+        self.kv_dtype = kv_dtype  # element type of the KV caches make_cache() builds (bfloat16 = the reference's cache dtype for bf16 checkpoints)
         assert cfg.head_dim in (64, 128) and cfg.d_model % 4 == 0
         assert weight_format in ("bf16", "fp8"), weight_format
         fp8 = weight_format == "fp8"
@@ -239,7 +242,7 @@ class TransformerStack:
             self.cos = self.sin = None
 
     def make_cache(self) -> List[KVCache]:
-        return [KVCache(self.cfg.n_kv_heads, self.cfg.head_dim, self.device) for _ in range(self.cfg.n_layers)]
+        return [KVCache(self.cfg.n_kv_heads, self.cfg.head_dim, self.device, self.kv_dtype) for _ in range(self.cfg.n_layers)]
 
     # ------------------------------------------------------------------ native decode step (mi355_stack_decode_step)
     def _native_desc(self, cache: List[KVCache], k_start: Optional[torch.Tensor] = None):
@@ -272,6 +275,7 @@ class TransformerStack:
         d.rope_mode, d.cos, d.sin = int(c.rope_interleaved), p(self.cos), p(self.sin)
         d.rope_rows = 0 if self.cos is None else self.cos.shape[0]
         d.k_start = p(k_start)
+        d.kv_dtype = ops.KV_DTYPES[cache[0].kv.dtype]
         d.layers = ctypes.cast(arr, ctypes.c_void_p)
         sws, scnt = ops.attn_split_workspace(self.device, 8 * c.n_heads, c.head_dim)  # key-split decode attention (long key ranges)
         d.attn_split_ws, d.attn_split_cnt = sws.data_ptr(), scnt.data_ptr()
@@ -297,7 +301,7 @@ class TransformerStack:
         for kvc in cache:
             kvc.reserve(B, 1)
         st = self._native_desc(cache, k_start)
-        ws = torch.empty(B * (2 * c.n_heads * c.head_dim + c.d_ff), dtype=torch.float32, device=self.device)
+        ws = torch.empty(B * (2 * c.n_heads * c.head_dim + c.d_ff + 2 * c.n_kv_heads * c.head_dim), dtype=torch.float32, device=self.device)
         out = torch.empty_like(x) if (self.final_norm is not None and not defer_final_norm) else None
         lib = _lib.load()
         rc = lib.mi355_stack_decode_step(ctypes.byref(st["desc"]), x.data_ptr(), B, off, ws.data_ptr(), None if out is None else out.data_ptr(),
@@ -349,7 +353,9 @@ class TransformerStack:
         nmode = "layer" if c.norm == "layer" else "rms"
         for lyr, kvc in zip(self.layers, cache):
             off = kvc.offset
-            slot = kvc.reserve(B, L)
+            cache_slot = kvc.reserve(B, L)
+            # a 16-bit cache receives its rows through a float32 scratch block: projection and norm / rope run in float32, ONE rounding into the cache
+            slot = cache_slot if cache_slot.dtype == torch.float32 else torch.empty(cache_slot.shape, dtype=torch.float32, device=dev)
             if decode:  # pre-norm fused into the one q | k | v GEMV
                 linear(x, lyr.wqkv, q, norm=(nmode, lyr.attn_norm[0], lyr.attn_norm[1], c.norm_eps), y2=slot)
             else:
@@ -360,6 +366,8 @@ class TransformerStack:
                 ks = slot[:, :, : G * dh]
                 ops.head_norm_rope(q, q, heads=H, dh=dh, norm_weight=lyr.q_norm, eps=c.norm_eps, cos=self.cos, sin=self.sin, pos0=off,
                                    interleaved=c.rope_interleaved, second=(ks, ks, G, lyr.k_norm), pos_sub=k_start)  # q and k heads in one launch
+            if slot is not cache_slot:
+                cache_slot.copy_(slot)
             ops.flash_attention(q, kvc.keys, kvc.values, att, heads=H, kv_heads=G, dh=dh, causal=c.causal, window=c.window, k_start=k_start)
             linear(att, lyr.wo, x, res=x, colscale=lyr.ls1, precision=self.precision)
             if decode:  # pre-norm (+ SwiGLU) fused into the up-projection GEMV

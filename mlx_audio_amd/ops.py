@@ -193,8 +193,8 @@ def gemv(x: torch.Tensor, rw: RowMajor16, y: torch.Tensor, *, post_act: int = AC
         mode, nw, nb, eps = norm
         kw.update(norm={"layer": 1, "rms": 2}[mode], norm_weight=_ptr(nw), norm_bias=_ptr(nb), norm_eps=eps)
     if y2 is not None:
-        assert y2.dim() == 2 and y2.stride(1) == 1 and y2.shape[0] == M
-        kw.update(y2=_ptr(y2), ldy2=y2.stride(0), split=n_y)
+        assert y2.dim() == 2 and y2.stride(1) == 1 and y2.shape[0] == M and y2.dtype in KV_DTYPES
+        kw.update(y2=_ptr(y2), ldy2=y2.stride(0), split=n_y, y2_dtype=KV_DTYPES[y2.dtype])
     if x_ids is not None:
         assert x_ids.dtype == torch.int32 and x_ids.numel() == 1 and x_ids.is_cuda
         kw.update(x_ids=_ptr(x_ids), x_id_offset=int(x_id_offset))

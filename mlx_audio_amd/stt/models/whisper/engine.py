@@ -247,7 +247,7 @@ class WhisperEngine:
         ops.gather_rows(self.tok_emb, tokens, x, pos_table=self.pos_emb[off:off + n])
         if n == 1 and B <= 8 and self.native_decode:  # the whole 12-layer step from the native runner: one call instead of ~100 launches from Python
             nd = self._native_desc(st)
-            ws = self._f(B * (2 * nt + 4 * nt))
+            ws = self._f(B * (2 * nt + 4 * nt + 2 * nt))
             out = self._f(B, 1, nt)
             rc = _lib.load().mi355_stack_decode_step(ctypes.byref(nd["desc"]), x.data_ptr(), B, off, ws.data_ptr(), out.data_ptr(), ops._stream())
             _lib.check(rc, "mi355_stack_decode_step")

@@ -93,12 +93,15 @@ class KVCacheRef:
     """lm/models/cache.py:104-176."""
     step = 256
 
-    def __init__(self):
+    def __init__(self, dtype=None):
         self.keys = None
         self.values = None
         self.offset = 0
+        self.dtype = dtype  # e.g. torch.bfloat16: the cache holds keys / values in the checkpoint dtype (cache.py:113-118 allocates k.dtype)
 
     def update_and_fetch(self, keys: Tensor, values: Tensor):
+        if self.dtype is not None:  # the rounding a 16-bit cache applies; arithmetic on the fetched views stays in the caller's float32
+            keys, values = keys.to(self.dtype).to(keys.dtype), values.to(self.dtype).to(values.dtype)
         prev = self.offset
         if self.keys is None or (prev + keys.shape[2]) > self.keys.shape[2]:
             B, n_kv, _, dk = keys.shape
@@ -124,15 +127,16 @@ class KVCacheRef:
 
 
 class StackRef:
-    def __init__(self, weights: Dict[str, Tensor], cfg: StackConfig, dtype=torch.float32, param_dtype=torch.bfloat16):
+    def __init__(self, weights: Dict[str, Tensor], cfg: StackConfig, dtype=torch.float32, param_dtype=torch.bfloat16, kv_dtype=None):
         self.cfg = cfg
         self.dtype = dtype
+        self.kv_dtype = kv_dtype
         self.w = {k: v.to(param_dtype).to(dtype) for k, v in weights.items()}
         if cfg.rope_theta is not None:
             self.cos, self.sin = rope_tables(cfg)
 
     def make_cache(self) -> List[KVCacheRef]:
-        return [KVCacheRef() for _ in range(self.cfg.n_layers)]
+        return [KVCacheRef(self.kv_dtype) for _ in range(self.cfg.n_layers)]
 
     def _norm(self, x: Tensor, name: str) -> Tensor:
         w = self.w[name + ".weight"]

@@ -247,6 +247,46 @@ def test_transformer_stack_prefill_and_decode(ops, name):
     assert ec[0].trim(10) == 10 and ec[0].offset == L + steps + 290
 
 
+@pytest.mark.parametrize("name,kvd,B", [("qwen3_talker", torch.bfloat16, 2), ("csm_llama", torch.bfloat16, 1), ("csm_llama", torch.bfloat16, 6),
+                                        ("mimi", torch.float16, 2), ("qwen3_codec", torch.bfloat16, 3)])
+def test_transformer_stack_16bit_kv_cache(ops, name, kvd, B):
+    """KV caches in the checkpoint's 16-bit type (the reference's cache dtype, lm/models/cache.py:104-176: k.dtype): prefill, then decode steps through the
+    native runner (16-bit store in the q|k|v GEMV epilogue with the rotary pairs, or in the fused norm / rope attention step), then a per-op decode
+    step, against the oracle whose cache applies the same rounding.  Everything except the stored k | v stays float32, so the bar only widens by the
+    chance that a value lands on the other side of a 16-bit rounding boundary in one of the two implementations (a handful of elements per layer)."""
+    from mlx_audio_amd.lm.stack import StackConfig, TransformerStack
+    from mlx_audio_amd.lm.synthetic import make_stack_weights
+    from oracle.lm_ref import StackRef
+
+    rcfg = _variants()[name]
+    w = make_stack_weights(rcfg, seed=5)
+    ref = StackRef(w, rcfg, kv_dtype=kvd)
+    cfg = StackConfig(**asdict(rcfg))
+    eng = TransformerStack(w, cfg, device=DEV, kv_dtype=kvd)
+    g = torch.Generator().manual_seed(12)
+    L = 37
+    x = torch.randn(B, L, cfg.d_model, generator=g)
+    rc, ec = ref.make_cache(), eng.make_cache()
+    assert ec[0].dtype == kvd
+    exp = ref(x.clone(), rc)
+    got = eng(x.clone().to(DEV), ec)
+    assert ec[0].kv.dtype == kvd and ec[0].nbytes == ec[0].kv.numel() * 2
+    assert rel_err(got, exp) < 5e-4
+    for step in range(4):
+        x1 = torch.randn(B, 1, cfg.d_model, generator=g)
+        exp = ref(x1.clone(), rc)
+        if step == 3:
+            eng.native_decode = False   # the per-op schedule writes the cache through a float32 scratch row
+        got = eng(x1.clone().to(DEV), ec)
+        assert rel_err(got, exp) < 5e-4, (step, rel_err(got, exp))
+    eng.native_decode = True
+    assert ec[0].offset == rc[0].offset == L + 4
+    # the cache itself: same values as the oracle's (up to the rare boundary flips), stored in 16 bits
+    k_ref = rc[0].keys[:, :, : L + 4].transpose(1, 2).reshape(B, L + 4, -1)
+    k_got = ec[0].keys.float().cpu()
+    assert rel_err(k_got, k_ref) < 1e-2 and float((k_got - k_ref).abs().mean() / k_ref.abs().mean()) < 1e-4
+
+
 @pytest.mark.parametrize("name,B,L", [("csm_llama", 1, 60), ("csm_llama", 4, 250), ("qwen3_talker", 8, 60), ("mimi", 3, 60), ("qwen3_codec", 2, 60)])
 def test_stack_fp8_weight_images(ops, name, B, L):
     """weight_format="fp8" (BASELINE config[4]): decode steps stream OCP e4m3fn weight images (per-row power-of-two scales) through the GEMVs

@@ -214,7 +214,7 @@ def test_decode_attention_with_fused_norm_rope_and_cache_store(ops, dh, H, G, Tk
     torch.cuda.synchronize()
     assert torch.equal(cache[:, Tk - 1], cache_ref[:, Tk - 1])            # same arithmetic, same rounding into the cache dtype
     assert torch.equal(cache[:, :Tk - 1], cache0[:, :Tk - 1]) and torch.equal(cache[:, Tk:], cache0[:, Tk:])   # nothing else touched
-    assert rel_err(out.cpu(), out_ref.cpu()) < (2e-5 if kvd == torch.float32 else 2e-3), rel_err(out.cpu(), out_ref.cpu())
+    assert rel_err(out.cpu(), out_ref.cpu()) < 2e-5, rel_err(out.cpu(), out_ref.cpu())   # (the new k | v enter the softmax as the cache will hold them)
 
 
 @pytest.mark.parametrize("Tq,Tk,nsplit,causal,hm", [(1, 1500, 2, False, True), (1, 1500, 4, False, False), (3, 700, 8, True, False), (1, 130, 3, True, False),
@@ -538,7 +538,8 @@ def test_whisper_step_forced_and_no_speech(ops):
 
 
 @pytest.mark.parametrize("M,N,K,act,use_res,glu", [(1, 1000, 1024, 0, False, False), (8, 514, 2048, 3, True, False), (3, 256, 3072, 0, True, False),
-                                                   (1, 514, 4096, 0, True, False), (1, 4096, 2048, 0, False, True),
+                                                   (1, 514, 4096, 0, True, False), (1, 4096, 2048, 0, False, True), (5, 1000, 1024, 5, False, False),
+                                                   (7, 64, 64, 0, True, False), (6, 2050, 1536, 0, False, True),
                                                    (5, 2048, 1040, 0, False, True), (2, 130, 16, 5, False, False), (8, 6144, 2048, 0, False, True)])
 def test_gemv_fp8_weights(ops, M, N, K, act, use_res, glu):
     """mi355_gemv on an fp8 (OCP e4m3fn, power-of-two row scales) image against float64 on the dequantised weights the oracle restates
@@ -568,7 +569,10 @@ def test_gemv_fp8_weights(ops, M, N, K, act, use_res, glu):
     y = torch.empty(M, N // 2 if glu else N, device=DEV)
     ops.gemv(xd[:, :K], rw, y, post_act=act, res=None if res is None else res.to(DEV), glu=glu)
     torch.cuda.synchronize()
-    assert rel_err(y.cpu(), v) < 5e-6, rel_err(y.cpu(), v)
+    # 5..8 rows with K % 64 == 0, K <= 2048 run on the fp8 matrix pipe: the input rows are split into four e4m3 terms (~16 significant bits, the
+    # accuracy of the bf16 hi + lo split: same bar as the 16-bit matrix-pipe kernel)
+    tol = 2e-5 if (5 <= M <= 8 and K % 64 == 0 and K <= 2048) else 5e-6
+    assert rel_err(y.cpu(), v) < tol, rel_err(y.cpu(), v)
 
 
 @pytest.mark.parametrize("M,N,K,f16,mode,glu,act,use_res,split", [

@@ -28,7 +28,7 @@ def _clone_obj(o):
     return copy.copy(o)
 
 
-def build_deep_stack(cfg, device, seed=0, precision=2, weight_format="bf16"):
+def build_deep_stack(cfg, device, seed=0, precision=2, weight_format="bf16", kv_dtype=torch.float32):
     """A TransformerStack of cfg.n_layers layers whose parameters are packed ONCE (one synthetic layer) and then cloned per layer on
     the device: identical values, distinct memory, so every layer streams its own weights from HBM exactly like a real checkpoint
     (host-side random generation + packing of >1e9 parameters would cost minutes of GPU-box time for nothing)."""
@@ -36,7 +36,8 @@ def build_deep_stack(cfg, device, seed=0, precision=2, weight_format="bf16"):
     from mlx_audio_amd.lm.synthetic import make_stack_weights
 
     one = dataclasses.replace(cfg, n_layers=1)
-    st = TransformerStack(make_stack_weights(one, seed=seed, gain=0.5), one, device=device, precision=precision, weight_format=weight_format)
+    st = TransformerStack(make_stack_weights(one, seed=seed, gain=0.5), one, device=device, precision=precision, weight_format=weight_format,
+                          kv_dtype=kv_dtype)
     st.cfg = cfg
     st.layers = [st.layers[0]] + [_clone_obj(st.layers[0]) for _ in range(cfg.n_layers - 1)]
     return st

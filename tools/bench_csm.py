@@ -26,6 +26,7 @@ def main(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="accepted for symmetry with the other bench lines")
     ap.add_argument("--weights", choices=["bf16", "fp8"], default="bf16")
+    ap.add_argument("--kv16", action="store_true", help="bf16 KV caches (the reference's cache dtype) instead of float32")
     args = ap.parse_args(argv)
     fp8 = args.weights == "fp8"
 
@@ -39,8 +40,9 @@ def main(argv=None):
     tiny = E.tiny_csm()
     eng = E.CSMEngine(E.make_csm_weights(tiny, seed=0), tiny, device=dev)
     eng.cfg = cfg
-    eng.backbone = U.build_deep_stack(cfg.backbone, dev, seed=1, weight_format=args.weights)
-    eng.decoder = U.build_deep_stack(cfg.decoder, dev, seed=2, weight_format=args.weights)
+    kvd = torch.bfloat16 if args.kv16 else torch.float32
+    eng.backbone = U.build_deep_stack(cfg.backbone, dev, seed=1, weight_format=args.weights, kv_dtype=kvd)
+    eng.decoder = U.build_deep_stack(cfg.decoder, dev, seed=2, weight_format=args.weights, kv_dtype=kvd)
     eng.backbone_cache = eng.backbone.make_cache()
     eng.decoder_cache = eng.decoder.make_cache()
     g = torch.Generator().manual_seed(0)
@@ -97,9 +99,10 @@ def main(argv=None):
         "metric": "audio seconds generated per second (x real time), CSM-1B generate_frame + Mimi decode, 1 MI355X", "value": B * n * 0.08 * args.steps / dt,
         "unit": "x realtime", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000 * dt / args.steps, "higher_is_better": True,
         "dtype": ("fp8 e4m3fn weights (per-row 2^k scales) x fp32 activations (GEMV fp32 FMA on exactly decoded weights)" if fp8 else
-                  "bf16 weights x fp32 activations (GEMV fp32 FMA on bf16 weights)"), "data": "synthetic",
+                  "bf16 weights x fp32 activations (GEMV fp32 FMA on bf16 weights)") + ("; 5..8 sequences: v_mfma_f32_16x16x32 on the weights' own type" if B >= 5 else ""),
+        "data": "synthetic",
         "config": {"workload": "CSM-1B: prompt %d tokens, %d frames x (backbone step + 31 depth-decoder steps, sampling on device), Mimi decode (32 codebooks)" % (S, n),
-                   "sequences": B, "frames": n, "temperature": 0.0, "weights": args.weights},
+                   "sequences": B, "frames": n, "temperature": 0.0, "weights": args.weights, "kv_cache": "bf16" if args.kv16 else "fp32"},
         "step_runner": U.step_runner(), "split_ms": {"frame_loop": lm_ms, "mimi_decode": dec_ms}, "ms_per_frame": frame_ms, "frames_per_s": B * n / (lm_ms * 1e-3),
         "mimi_samples_per_s": B * n * 1920 / (dec_ms * 1e-3),
         "roofline": {"bound": "hbm", "kernel": "gemv_kernel (all decode-step Linear layers of one frame)", "achieved": wbytes / (frame_ms * 1e-3) / 1e9, "peak": 8000.0,
