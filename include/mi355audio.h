@@ -440,6 +440,10 @@ typedef struct {
   float* filtered;                              /* [B, ld] nullable: the filtered logits (parity tests) */
   const int32_t* forced_next;                   /* [B] nullable: teacher forcing -- append this token instead of the selection
                                                    (its log-prob is what gets accumulated) */
+  /* optional: spread each row over 16 workgroups (two launches: partial statistics, then filter + selection with the last workgroup of a row
+     merging).  split_ws: [B * 16 * 12] floats scratch, split_cnt: [B] int32, zero before the first call and left zero by every call.  Null = one
+     workgroup per row. */
+  float* split_ws; int32_t* split_cnt;
 } mi355_whisper_step_args;
 int mi355_whisper_greedy_step(const mi355_whisper_step_args* a, void* stream);
 /* out[b] = softmax(logits[b, 0:V])[token]  (no_speech_prob, decoding.py:604-606). */

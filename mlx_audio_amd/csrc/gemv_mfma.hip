@@ -369,7 +369,10 @@ int mi355_gemv_mfma_eligible(const mi355_gemv_args& a) {
   if (a.M < 5 || a.M > 8 || a.rope_cos) return 0;
   if (a.wdtype != MI355_W_BF16 && a.wdtype != MI355_W_F16) return 0;
   if (a.K % 64 || a.K < 64 || a.ldw % 8 || ((uintptr_t)a.w) % 16 || a.ldx % 4 || ((uintptr_t)a.x) % 16) return 0;
-  if (a.K > kKC && !use_stream(a)) return 0;   // the staged kernel holds one chunk: its chunk loop's workgroup barriers cost more than they save (call 26)
+  // the staged kernel holds one chunk: its chunk loop's workgroup barriers were measured to cost more than they save (r1 call 26);
+  // MI355_GEMV_MFMA_CHUNKED=1 lets no-norm images with K > 2048 take the chunk loop anyway (A/B knob)
+  static const bool chunked = getenv("MI355_GEMV_MFMA_CHUNKED") != nullptr && getenv("MI355_GEMV_MFMA_CHUNKED")[0] == '1';
+  if (a.K > kKC && !use_stream(a) && !(chunked && !a.norm)) return 0;
   if (a.glu && (a.N % 2)) return 0;
   return 1;
 }

@@ -413,7 +413,7 @@ def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torc
 def whisper_greedy_step(logits: torch.Tensor, tokens: torch.Tensor, n: int, sample_begin: int, sum_logprobs: torch.Tensor, *,
                         V: Optional[int] = None, suppress_mask=None, blank_ids=None, timestamp_rules: bool = False,
                         timestamp_begin: int = 0, eot: int = 0, no_timestamps: int = -1, max_initial_timestamp_index: int = -1,
-                        gumbel=None, temperature: float = 0.0, filtered=None, forced_next=None):
+                        gumbel=None, temperature: float = 0.0, filtered=None, forced_next=None, split_ws=None):
     """One decode step of decoding.py's filter chain + GreedyDecoder.update, in place on ``tokens[:, n]`` / ``sum_logprobs``."""
     assert logits.dim() == 2 and logits.stride(1) == 1 and logits.dtype == torch.float32
     assert tokens.dtype == torch.int32 and tokens.dim() == 2 and tokens.stride(1) == 1
@@ -423,7 +423,13 @@ def whisper_greedy_step(logits: torch.Tensor, tokens: torch.Tensor, n: int, samp
                      suppress_mask=_ptr(suppress_mask), blank_ids=_ptr(blank_ids), n_blank=0 if blank_ids is None else blank_ids.numel(),
                      timestamp_rules=int(timestamp_rules), timestamp_begin=timestamp_begin, eot=eot, no_timestamps=no_timestamps,
                      max_initial_timestamp_index=max_initial_timestamp_index, gumbel=_ptr(gumbel), temperature=temperature,
-                     sum_logprobs=_ptr(sum_logprobs), filtered=_ptr(filtered), forced_next=_ptr(forced_next))
+                     sum_logprobs=_ptr(sum_logprobs), filtered=_ptr(filtered), forced_next=_ptr(forced_next),
+                     split_ws=None if split_ws is None else _ptr(split_ws[0]), split_cnt=None if split_ws is None else _ptr(split_ws[1]))
+
+
+def whisper_step_workspace(device, B: int):
+    """(float32 [B * 16 * 12], int32 [B] zeroed): the scratch of the multi-workgroup decode-rules step (mi355_whisper_step_args.split_ws / split_cnt)."""
+    return (torch.empty(B * 16 * 12, dtype=torch.float32, device=device), torch.zeros(B, dtype=torch.int32, device=device))
 
 
 def softmax_prob_at(logits: torch.Tensor, token: int, V: Optional[int] = None) -> torch.Tensor:

@@ -318,6 +318,7 @@ class WhisperEngine:
             max_idx = round(max_initial_timestamp / (30.0 / d.n_audio_ctx))
         forced = None if forced_tokens is None else forced_tokens.to(dev, torch.int32).t().contiguous()  # [steps, B]
         st = self.new_state(xa)
+        step_ws = ops.whisper_step_workspace(dev, B)   # each row of the decode-rules step spread over 16 workgroups
         trace: List[dict] = []
         no_speech = None
         n = sample_begin
@@ -343,7 +344,7 @@ class WhisperEngine:
             ops.whisper_greedy_step(lg, tokens, n, sample_begin, sum_logprobs, V=d.n_vocab, suppress_mask=smask, blank_ids=blank,
                                     timestamp_rules=ts_rules, timestamp_begin=tok.timestamp_begin, eot=tok.eot,
                                     no_timestamps=-1 if tok.no_timestamps is None else tok.no_timestamps,
-                                    max_initial_timestamp_index=max_idx, filtered=filt, gumbel=gumbel, temperature=float(temperature),
+                                    max_initial_timestamp_index=max_idx, filtered=filt, gumbel=gumbel, temperature=float(temperature), split_ws=step_ws,
                                     forced_next=None if forced is None else forced[i])
             if record:
                 trace.append(dict(raw=lg[:, :d.n_vocab].clone(), filtered=filt[:, :d.n_vocab]))

@@ -464,7 +464,9 @@ def _tok():
 
 
 @pytest.mark.parametrize("case", ["first", "after_text", "after_ts_pair", "after_single_ts", "ended", "no_ts_rules"])
-def test_whisper_greedy_step_matches_filters(ops, case):
+@pytest.mark.parametrize("split", [False, True])
+def test_whisper_greedy_step_matches_filters(ops, case, split):
+    """``split``: the row spread over 16 workgroups (two launches, the last workgroup of a row merges): same filtered logits, tokens, log-probs."""
     from oracle import whisper_ref as R
 
     tok = _tok()
@@ -504,7 +506,7 @@ def test_whisper_greedy_step_matches_filters(ops, case):
     blank = torch.tensor(list(tok.blank_ids) + [tok.eot], dtype=torch.int32, device=DEV)
     ops.whisper_greedy_step(lgd, tkd, n, sb, sums, V=V, suppress_mask=smask.to(DEV), blank_ids=blank, timestamp_rules=ts_rules,
                             timestamp_begin=tok.timestamp_begin, eot=tok.eot, no_timestamps=tok.no_timestamps, max_initial_timestamp_index=50,
-                            filtered=filt)
+                            filtered=filt, split_ws=ops.whisper_step_workspace(DEV, B) if split else None)
     torch.cuda.synchronize()
     got_f = filt[:, :V].cpu()
     assert torch.equal(torch.isinf(got_f), torch.isinf(lg)), "mask pattern differs"
