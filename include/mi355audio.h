@@ -154,6 +154,8 @@ typedef struct {
   int32_t gb_ld;
   float eps;
   float* scale; float* shift; int32_t out_ld; /* [B, out_ld] */
+  int32_t reuse_sums;  /* 1: `sums` already holds the statistics of this x (a previous call with the same x, lens): only the coefficients are
+                          recomputed from another gb -- the three AdaINResBlock1 of a generator stage normalise the SAME input (istftnet.py:822-829) */
 } mi355_adain_coef_args;
 int mi355_adain_coef(const mi355_adain_coef_args* a, void* stream);
 

@@ -5,23 +5,17 @@
 // columns in LDS ([k/8][row][8] so that consecutive lanes read consecutive 16 B), the rest streamed
 // from L2 with coalesced 16-B loads.  h lives in LDS (fp32) and is broadcast-read; c lives in the
 // registers of the first H threads.
-#include <stdlib.h>
 #include "common.h"
 
 namespace {
 
-// DOT2: the products run on v_dot2c_f32_bf16 (two bf16 x bf16 products accumulated into fp32 per instruction) with the weights as they are stored
-// (no unpack) against hi + lo bf16 images of h (~16 significant bits of h; the fp32-FMA variant keeps h exact): 2 instructions per 2 MACs instead
-// of 4 -- the recurrence is VALU-bound (16 waves on one CU: 3.7 us per time step with FMAs).
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-
-template <int H, int KREG, int KLDS, bool DOT2>
+template <int H, int KREG, int KLDS>
 __global__ __launch_bounds__(4 * H) void lstm_kernel(const mi355_lstm_args a) {
   constexpr int G = 4 * H;
   constexpr int NREG = KREG / 8, NLDS = KLDS / 8, NGLB = (H - KREG - KLDS) / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* wl = (uint4*)smem;                              // [NLDS][G] 16-B weight groups
-  float* hbuf = (float*)(smem + (size_t)NLDS * G * 16);  // [H] fp32, or (DOT2) [H / 2] hi pairs followed by [H / 2] lo pairs of packed bf16
+  float* hbuf = (float*)(smem + (size_t)NLDS * G * 16);  // [H]
   float* gates = hbuf + H;                               // [G]
   const int r = threadIdx.x, dir = blockIdx.x, b = blockIdx.y;
   const int len = a.lens ? a.lens[b] : a.L;
@@ -39,20 +33,6 @@ __global__ __launch_bounds__(4 * H) void lstm_kernel(const mi355_lstm_args a) {
   const int gate = r / H;
 
   auto dot8 = [&](const uint4 w, const float* h8, float acc) {
-    if constexpr (DOT2) {
-      const int k8 = (int)(h8 - hbuf) / 8;                       // group of 8 consecutive k
-      const uint4 hh = ((const uint4*)hbuf)[k8];                  // 8 hi values (4 packed pairs)
-      const uint4 hl = ((const uint4*)hbuf)[H / 8 + k8];          // 8 lo values
-      acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.x), __builtin_bit_cast(bf16x2_t, hh.x), acc, false);
-      acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.x), __builtin_bit_cast(bf16x2_t, hl.x), acc, false);
-      acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.y), __builtin_bit_cast(bf16x2_t, hh.y), acc, false);
-      acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.y), __builtin_bit_cast(bf16x2_t, hl.y), acc, false);
-      acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.z), __builtin_bit_cast(bf16x2_t, hh.z), acc, false);
-      acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.z), __builtin_bit_cast(bf16x2_t, hl.z), acc, false);
-      acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.w), __builtin_bit_cast(bf16x2_t, hh.w), acc, false);
-      acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.w), __builtin_bit_cast(bf16x2_t, hl.w), acc, false);
-      return acc;
-    }
     const float4 h0 = *(const float4*)(h8);
     const float4 h1 = *(const float4*)(h8 + 4);
     acc = fmaf(__builtin_bit_cast(float, w.x << 16), h0.x, acc);
@@ -104,27 +84,21 @@ __global__ __launch_bounds__(4 * H) void lstm_kernel(const mi355_lstm_args a) {
       const float ig = gates[r], fg = gates[H + r], gg = gates[2 * H + r], og = gates[3 * H + r];
       c = fg * c + ig * gg;
       const float h = og * tanhf(c);
-      if constexpr (DOT2) {
-        const uint32_t hi = pack_bf16x2(h, 0.f) & 0xffffu;
-        ((uint16_t*)hbuf)[r] = (uint16_t)hi;
-        ((uint16_t*)hbuf)[H + r] = (uint16_t)(pack_bf16x2(h - __builtin_bit_cast(float, hi << 16), 0.f) & 0xffffu);
-      } else {
-        hbuf[r] = h;
-      }
+      hbuf[r] = h;
       ob[(int64_t)t * a.ldo + r] = h;
     }
     __syncthreads();
   }
 }
 
-template <int H, int KREG, int KLDS, bool DOT2 = false>
+template <int H, int KREG, int KLDS>
 int launch_lstm(const mi355_lstm_args& a, hipStream_t st) {
   constexpr int G = 4 * H;
   const size_t lds = (size_t)(KLDS / 8) * G * 16 + (size_t)H * 4 + (size_t)G * 4;
-  hipError_t e = hipFuncSetAttribute((const void*)lstm_kernel<H, KREG, KLDS, DOT2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute((const void*)lstm_kernel<H, KREG, KLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   MI355_REQUIRE(e == hipSuccess, "lstm: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
   MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL((lstm_kernel<H, KREG, KLDS, DOT2>), dim3(2, a.B), dim3(G), lds, st, a);
+  hipLaunchKernelGGL((lstm_kernel<H, KREG, KLDS>), dim3(2, a.B), dim3(G), lds, st, a);
   MI355_LAUNCH_CHECK("lstm_bidir");
   return MI355_OK;
 }
@@ -138,10 +112,7 @@ extern "C" int mi355_lstm_bidir(const mi355_lstm_args* ap, void* stream) {
   MI355_REQUIRE(a.ldxp >= 8 * a.H && a.ldo >= 2 * a.H, "lstm: ldxp/ldo too small");
   hipStream_t st = (hipStream_t)stream;
   switch (a.H) {
-    case 256: {
-      static const bool fma = getenv("MI355_LSTM_FMA") != nullptr && getenv("MI355_LSTM_FMA")[0] == '1';  // A/B knob: exact-h fp32 FMAs
-      return fma ? launch_lstm<256, 192, 64, false>(a, st) : launch_lstm<256, 192, 64, true>(a, st);
-    }
+    case 256: return launch_lstm<256, 192, 64>(a, st);
     case 128: return launch_lstm<128, 128, 0>(a, st);
     case 64: return launch_lstm<64, 64, 0>(a, st);
     case 32: return launch_lstm<32, 32, 0>(a, st);

@@ -171,17 +171,19 @@ extern "C" int mi355_adain_coef(const mi355_adain_coef_args* ap, void* stream) {
   MI355_REQUIRE(a.ldx % 4 == 0 && a.x_bstride % 4 == 0 && a.ldx >= ((a.C + 3) & ~3), "adain_coef: ldx must be a multiple of 4 and cover C rounded up to 4");
   MI355_REQUIRE(a.out_ld >= a.C, "adain_coef: out_ld < C");
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(a.sums, 0, sizeof(double) * 2 * (size_t)a.B * a.C, st);
-  MI355_REQUIRE(e == hipSuccess, "adain_coef: memset failed: %s", hipGetErrorString(e));
-  const int cblocks = (a.C + 31) / 32;
-  int nsplit = (1024 + cblocks * a.B - 1) / (cblocks * a.B);
-  const int max_split = (a.L + 63) / 64;
-  if (nsplit > max_split) nsplit = max_split;
-  if (nsplit < 1) nsplit = 1;
-  const int rows = (a.L + nsplit - 1) / nsplit;
-  MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL(instnorm_partial_kernel, dim3(cblocks, nsplit, a.B), dim3(256), 0, st, a, rows);
-  MI355_LAUNCH_CHECK("instnorm_partial");
+  if (!a.reuse_sums) {
+    hipError_t e = hipMemsetAsync(a.sums, 0, sizeof(double) * 2 * (size_t)a.B * a.C, st);
+    MI355_REQUIRE(e == hipSuccess, "adain_coef: memset failed: %s", hipGetErrorString(e));
+    const int cblocks = (a.C + 31) / 32;
+    int nsplit = (1024 + cblocks * a.B - 1) / (cblocks * a.B);
+    const int max_split = (a.L + 63) / 64;
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    const int rows = (a.L + nsplit - 1) / nsplit;
+    MI355_CLEAR_ERROR();
+    hipLaunchKernelGGL(instnorm_partial_kernel, dim3(cblocks, nsplit, a.B), dim3(256), 0, st, a, rows);
+    MI355_LAUNCH_CHECK("instnorm_partial");
+  }
   MI355_CLEAR_ERROR();
   hipLaunchKernelGGL(adain_finalize_kernel, dim3((a.out_ld + 127) / 128, a.B), dim3(128), 0, st, a);
   MI355_LAUNCH_CHECK("adain_finalize");

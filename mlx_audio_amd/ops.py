@@ -288,16 +288,21 @@ def conv_gemm(x: torch.Tensor, pc: PackedConv, y: torch.Tensor, *, dil: int = 1,
     return y
 
 
-def adain_coef(x: torch.Tensor, gb: Optional[torch.Tensor], lens: Optional[torch.Tensor] = None, eps: float = 1e-5):
-    """Instance-norm stats of ``x`` [B, L, C] + AdaIN coefficients -> (scale, shift) each [B, C padded to 32]."""
+def adain_coef(x: torch.Tensor, gb: Optional[torch.Tensor], lens: Optional[torch.Tensor] = None, eps: float = 1e-5, sums: Optional[torch.Tensor] = None,
+               reuse: bool = False):
+    """Instance-norm stats of ``x`` [B, L, C] + AdaIN coefficients -> (scale, shift) each [B, C padded to 32].
+    ``sums`` (float64 [B * C * 2]) + ``reuse=True``: the statistics of this same ``x`` are already in ``sums`` (an earlier call): only the coefficients
+    for another ``gb`` are computed -- one statistics pass for all blocks that normalise the same input."""
     B, L, C, xbs, ldx = _nlc(x)
     cp = round_up(C, 32)
-    sums = torch.empty(B * C * 2, dtype=torch.float64, device=x.device)
+    if sums is None:
+        assert not reuse
+        sums = torch.empty(B * C * 2, dtype=torch.float64, device=x.device)
     scale = torch.empty((B, cp), dtype=torch.float32, device=x.device)
     shift = torch.empty((B, cp), dtype=torch.float32, device=x.device)
     _lib.call_struct("mi355_adain_coef", "mi355_adain_coef_args", _stream(), x=_ptr(x), x_bstride=xbs, ldx=ldx, C=C, L=L,
                      lens=_ptr(lens), B=B, sums=_ptr(sums), gb=_ptr(gb), gb_ld=0 if gb is None else gb.stride(0), eps=eps,
-                     scale=_ptr(scale), shift=_ptr(shift), out_ld=cp)
+                     scale=_ptr(scale), shift=_ptr(shift), out_ld=cp, reuse_sums=int(reuse))
     return scale, shift
 
 

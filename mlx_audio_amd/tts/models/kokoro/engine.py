@@ -348,11 +348,11 @@ class KokoroEngine:
                    res=short, res_shift=1 if up else 0, out_scale=1.0 / math.sqrt(2.0))
         return out
 
-    def _resblock1_fwd(self, rb: _ResBlock1, x, gb_all, lens, out=None, accumulate=False, out_scale=1.0, x_stats=None):
+    def _resblock1_fwd(self, rb: _ResBlock1, x, gb_all, lens, out=None, accumulate=False, out_scale=1.0, x_stats=None, x_sums=None):
         """AdaINResBlock1.  ``out`` None: returns a fresh tensor; else the last conv writes (or adds) into ``out``.
         Instance-norm statistics of every intermediate tensor come out of the producing conv's epilogue (``stats=``);
-        only the block input needs a separate pass, and callers that feed the same input to several blocks pass its
-        raw statistics in (``x_stats`` = (sum/M2 partials) from ``_stats_of``)."""
+        only the block input needs a separate pass, and callers that feed the same input to several blocks share it:
+        ``x_sums`` = (float64 sums buffer, already_filled) -- the first block of a stage fills it, the other two only recompute their coefficients."""
         B, L, C = x.shape
         cur = x
         work = None
@@ -364,6 +364,8 @@ class KokoroEngine:
         for i, dl in enumerate(rb.dils):
             if fuse and st_cur is not None:
                 sc, sh = ops.adain_from_partials(st_cur, L, self._gb(gb_all, rb.adain1[i]), lens)
+            elif i == 0 and x_sums is not None:
+                sc, sh = ops.adain_coef(cur, self._gb(gb_all, rb.adain1[i]), lens, sums=x_sums[0], reuse=x_sums[1])
             else:
                 sc, sh = ops.adain_coef(cur, self._gb(gb_all, rb.adain1[i]), lens)
             self._conv(cur, rb.convs1[i], tmp, dil=dl, pad=(rb.k * dl - dl) // 2, lens_in=lens, lens_out=lens, pre=(sc, sh),
@@ -662,9 +664,10 @@ class KokoroEngine:
             if return_intermediates:
                 trace[f"xu{i}"] = xu.clone()
             acc = self._new(B, Lo, cout)
+            xu_sums = torch.empty(B * cout * 2, dtype=torch.float64, device=dev)  # instance-norm statistics of xu: one pass for the nk resblocks
             for j in range(nk):
                 self._resblock1_fwd(self.resblocks[i * nk + j], xu, gb_dec, lens_o, out=acc, accumulate=j > 0,
-                                    out_scale=(1.0 / nk) if j == nk - 1 else 1.0)
+                                    out_scale=(1.0 / nk) if j == nk - 1 else 1.0, x_sums=(xu_sums, j > 0))
             x, L, lens_x = acc, Lo, lens_o
             if return_intermediates:
                 trace[f"stage{i}"] = acc.clone()
