@@ -541,7 +541,8 @@ def test_whisper_step_forced_and_no_speech(ops):
 
 @pytest.mark.parametrize("M,N,K,act,use_res,glu", [(1, 1000, 1024, 0, False, False), (8, 514, 2048, 3, True, False), (3, 256, 3072, 0, True, False),
                                                    (1, 514, 4096, 0, True, False), (1, 4096, 2048, 0, False, True), (5, 1000, 1024, 5, False, False),
-                                                   (7, 64, 64, 0, True, False), (6, 2050, 1536, 0, False, True),
+                                                   (7, 64, 64, 0, True, False), (6, 2050, 1536, 0, False, True), (8, 16384, 1024, 0, False, True),
+                                                   (5, 8200, 2048, 5, True, False), (8, 1024, 8192, 0, True, False), (6, 520, 4160, 3, False, False),
                                                    (5, 2048, 1040, 0, False, True), (2, 130, 16, 5, False, False), (8, 6144, 2048, 0, False, True)])
 def test_gemv_fp8_weights(ops, M, N, K, act, use_res, glu):
     """mi355_gemv on an fp8 (OCP e4m3fn, power-of-two row scales) image against float64 on the dequantised weights the oracle restates
@@ -571,9 +572,10 @@ def test_gemv_fp8_weights(ops, M, N, K, act, use_res, glu):
     y = torch.empty(M, N // 2 if glu else N, device=DEV)
     ops.gemv(xd[:, :K], rw, y, post_act=act, res=None if res is None else res.to(DEV), glu=glu)
     torch.cuda.synchronize()
-    # 5..8 rows with K % 64 == 0, K <= 2048 run on the fp8 matrix pipe: the input rows are split into four e4m3 terms (~16 significant bits, the
+    # 5..8 rows with K % 64 == 0 run on the fp8 matrix pipe (1, 2 or 4 column tiles per workgroup, 2048-column chunks of K): the input rows are split into four e4m3 terms (~16 significant bits, the
     # accuracy of the bf16 hi + lo split: same bar as the 16-bit matrix-pipe kernel)
-    tol = 2e-5 if (5 <= M <= 8 and K % 64 == 0 and K <= 2048) else 5e-6
+    # (four e4m3 terms = ~16 significant bits of the input rows; a SwiGLU output multiplies two such results: 3e-5, the conv path's hi + lo bar)
+    tol = 3e-5 if (5 <= M <= 8 and K % 64 == 0) else 5e-6
     assert rel_err(y.cpu(), v) < tol, rel_err(y.cpu(), v)
 
 
