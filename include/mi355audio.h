@@ -489,6 +489,10 @@ typedef struct {
      embedding lookup fused into the projection that consumes it (sesame.py:392-396: embed the code just sampled, project it to the decoder width);
      the id is read on the device, so the sampler's output feeds the next GEMV without a host round trip or a separate gather launch */
   const int32_t* x_ids; int32_t x_id_offset;
+  /* optional scratch for splitting K over workgroups (5..8 rows, K > 2048, no fused norm: the down projections): split_ws holds
+     ceil(N / 16) * ceil(K / 2048) * 256 floats, split_cnt ceil(N / 16) int32 tickets (zero before the first call, left zero by every call).  Null =
+     the single-workgroup-per-column-group kernels. */
+  float* split_ws; int32_t* split_cnt;
   int32_t y2_dtype;   /* element type of y2: MI355_KV_F32 (0) / MI355_KV_BF16 / MI355_KV_F16 -- a 16-bit KV-cache slot (the reference's cache dtype);
                          y2 is then a uint16_t* in disguise and ldy2 counts 16-bit elements */
 } mi355_gemv_args;
@@ -629,6 +633,7 @@ typedef struct {
                               RoPE positions count from it */
   const mi355_layer_desc* layers;                           /* HOST array of n_layers records */
   float* attn_split_ws; int32_t* attn_split_cnt;            /* nullable: workspace of mi355_flash_attn_args.split_* for B <= 8, Tq = 1 */
+  float* gemv_split_ws; int32_t* gemv_split_cnt;            /* nullable: mi355_gemv_args.split_ws / split_cnt sized for the largest projection of the stack */
   const float* final_norm_w; const float* final_norm_b;     /* nullable */
   int32_t kv_dtype;        /* MI355_KV_F32 / MI355_KV_BF16 / MI355_KV_F16: element type of every layer's kv buffer (the reference keeps its caches in the
                               checkpoint dtype, lm/models/cache.py:104-176).  16-bit caches need the stores that exist: q|k|v GEMV with the rotary pairs in its

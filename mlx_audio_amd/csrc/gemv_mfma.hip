@@ -346,6 +346,101 @@ __global__ __launch_bounds__(256) void gemv_mfma_stream_kernel(const mi355_gemv_
   else a.y[(int64_t)m * a.ldy + n] = v * a.out_scale;
 }
 
+// ---------------------------------------------------------------------------------------------- K split over workgroups (no fused norm, K > 2048)
+// The down projections (N = 1024 .. 2048, K = 3072 .. 8192) have few column tiles and a long K: N / 16 workgroups walking 2-4 chunks one after the
+// other leave the chip empty (measured: slower than the FMA kernel, call 24).  Here a workgroup owns ONE (tile, 2048-column chunk) pair -- the grid is
+// tiles x chunks -- and the chunks of a tile meet through a scratch record and a ticket: the workgroup that draws the last ticket adds the records
+// in chunk order (deterministic) and runs the epilogue.  Nobody waits for anybody.
+template <bool F16>
+__global__ __launch_bounds__(256) void gemv_mfma_ksplit_kernel(const mi355_gemv_args a, const int nch) {
+  __shared__ __attribute__((aligned(16))) uint4 planes[2 * kKC * 8 / 8];  // [2 images][32 steps][2 halves][4 groups][8 rows] 16-byte pieces: 64 KB
+  __shared__ float red[4][256];
+  __shared__ int ticket_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x, c = blockIdx.y;
+  const int n0 = tile * 16;
+  const int K = a.K, M = a.M;
+  const int k0 = c * kKC;
+  const int kc = K - k0 < kKC ? K - k0 : kKC;   // multiple of 64
+  const int steps = kc >> 6;
+  constexpr int img = kKC;                      // 16-byte pieces per image
+  const int gi = lane >> 4, li = lane & 15;
+  const int nrow = n0 + li < a.N ? n0 + li : a.N - 1;
+  const uint16_t* wrow = a.w + (int64_t)nrow * a.ldw + k0 + 16 * gi;
+  uint4 ring[kD][2];
+#pragma unroll
+  for (int d = 0; d < kD; ++d) {
+    ring[d][0] = ring[d][1] = make_uint4(0u, 0u, 0u, 0u);
+    if (wave + 4 * d < steps) {
+      const uint16_t* p = wrow + ((int64_t)(wave + 4 * d) << 6);
+      ring[d][0] = *(const uint4*)p;
+      ring[d][1] = *(const uint4*)(p + 8);
+    }
+  }
+  {  // stage the chunk: thread t owns the 8-column group q = t of every row
+    const int q = tid, k = q * 8;
+    if (k < kc) {
+      const int step = q >> 3, r = q & 7, g = r >> 1, h = r & 1;
+      const int base = ((step * 2 + h) * 4 + g) * 8;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), xb = xa;
+        if (m < M) {
+          const float* p = a.x + (int64_t)m * a.ldx + k0 + k;
+          xa = *(const float4*)p;
+          xb = *(const float4*)(p + 4);
+        }
+        uint4 hi, lo;
+        split2<F16>(xa.x, xa.y, hi.x, lo.x);
+        split2<F16>(xa.z, xa.w, hi.y, lo.y);
+        split2<F16>(xb.x, xb.y, hi.z, lo.z);
+        split2<F16>(xb.z, xb.w, hi.w, lo.w);
+        planes[base + m] = hi;
+        planes[img + base + m] = lo;
+      }
+    }
+  }
+  __syncthreads();
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int d = 0; d < kD; ++d) {
+    const int sl = wave + 4 * d;
+    if (sl < steps) {
+      const int p0 = ((sl * 2 + 0) * 4 + gi) * 8 + (li & 7);
+      const int p1 = ((sl * 2 + 1) * 4 + gi) * 8 + (li & 7);
+      acc = mfma_16<F16>(ring[d][0], planes[p0], acc);
+      acc = mfma_16<F16>(ring[d][1], planes[p1], acc);
+      acc = mfma_16<F16>(ring[d][0], planes[img + p0], acc);
+      acc = mfma_16<F16>(ring[d][1], planes[img + p1], acc);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave][(4 * gi + r) * 16 + li] = acc[r];
+  __syncthreads();
+  const int i = tid & 15, m = tid >> 4;   // consecutive threads -> consecutive output columns n of one input row m
+  const int n = n0 + i;
+  float v0 = (red[0][i * 16 + m] + red[1][i * 16 + m]) + (red[2][i * 16 + m] + red[3][i * 16 + m]);
+  if (nch > 1) {
+    float* rec = a.split_ws + ((int64_t)tile * nch + c) * 256;
+    rec[tid] = v0;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) ticket_s = atomicAdd(a.split_cnt + tile, 1);
+    __syncthreads();
+    if (ticket_s != nch - 1) return;
+    __threadfence();
+    const float* recs = a.split_ws + (int64_t)tile * nch * 256;
+    v0 = 0.f;
+    for (int cc = 0; cc < nch; ++cc) v0 += __hip_atomic_load(recs + cc * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) a.split_cnt[tile] = 0;   // leave the ticket zeroed for the next launch
+  }
+  if (m >= M || n >= a.N) return;
+  float v = mfma_act(v0 + (a.bias ? a.bias[n] : 0.f), a.post_act, a.post_slope) * (a.colscale ? a.colscale[n] : 1.f);
+  if (a.res) v += a.res[(int64_t)m * a.ldr + n];
+  if (a.y2 && n >= a.split) store_kv_elem(a.y2, (int64_t)m * a.ldy2 + (n - a.split), v * a.out_scale, a.y2_dtype);
+  else a.y[(int64_t)m * a.ldy + n] = v * a.out_scale;
+}
+
 }  // namespace
 
 // 1 = this call qualifies for the matrix-pipe kernel (mi355_gemv dispatches here unless MI355_GEMV_MFMA=0)
@@ -356,6 +451,11 @@ __global__ __launch_bounds__(256) void gemv_mfma_stream_kernel(const mi355_gemv_
 static int stream_mode() {
   static const int mode = getenv("MI355_GEMV_MFMA_STREAM") ? atoi(getenv("MI355_GEMV_MFMA_STREAM")) : 0;
   return mode;
+}
+
+static bool ksplit_on() {
+  static const bool on = getenv("MI355_GEMV_KSPLIT") != nullptr && getenv("MI355_GEMV_KSPLIT")[0] == '1';
+  return on;
 }
 
 static bool use_stream(const mi355_gemv_args& a) {
@@ -372,6 +472,10 @@ int mi355_gemv_mfma_eligible(const mi355_gemv_args& a) {
   // the staged kernel holds one chunk: its chunk loop's workgroup barriers were measured to cost more than they save (r1 call 26);
   // MI355_GEMV_MFMA_CHUNKED=1 lets no-norm images with K > 2048 take the chunk loop anyway (A/B knob)
   static const bool chunked = getenv("MI355_GEMV_MFMA_CHUNKED") != nullptr && getenv("MI355_GEMV_MFMA_CHUNKED")[0] == '1';
+  // K split over workgroups (gemv_mfma_ksplit_kernel): OPT-IN (MI355_GEMV_KSPLIT=1).  Measured in call 29: 19.7 / 43.5 us per launch on the Qwen3
+  // down projections against 13.9 / 20.1 us for the FMA kernel -- the agent-scope fence in front of the ticket writes the L2 back, which costs
+  // more than the extra workgroups bring (the same finding as the key-split attention of round 1)
+  if (ksplit_on() && a.K > kKC && !a.norm && !a.glu && a.split_ws && a.split_cnt) return 1;
   if (a.K > kKC && !use_stream(a) && !(chunked && !a.norm)) return 0;
   if (a.glu && (a.N % 2)) return 0;
   return 1;
@@ -381,6 +485,14 @@ int mi355_gemv_mfma_launch(const mi355_gemv_args& a, hipStream_t st) {
   static bool attr_set[2] = {false, false};  // benign race: the attribute is idempotent
   const bool f16 = a.wdtype == MI355_W_F16;
   const dim3 grid((a.N + 15) / 16);
+  if (ksplit_on() && a.K > kKC && !a.norm && !a.glu && a.split_ws && a.split_cnt && !use_stream(a)) {
+    const int nch = (a.K + kKC - 1) / kKC;
+    MI355_CLEAR_ERROR();
+    if (f16) hipLaunchKernelGGL(gemv_mfma_ksplit_kernel<true>, dim3(grid.x, nch), dim3(256), 0, st, a, nch);
+    else hipLaunchKernelGGL(gemv_mfma_ksplit_kernel<false>, dim3(grid.x, nch), dim3(256), 0, st, a, nch);
+    MI355_LAUNCH_CHECK("gemv(mfma, K split over workgroups)");
+    return MI355_OK;
+  }
   if (use_stream(a)) {
     MI355_CLEAR_ERROR();
     if (f16) hipLaunchKernelGGL(gemv_mfma_stream_kernel<true>, grid, dim3(256), 0, st, a);

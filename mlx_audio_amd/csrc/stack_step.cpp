@@ -18,13 +18,14 @@ namespace {
 int gemv_call(const float* x, int ldx, int M, int K, const uint16_t* w, int N, int wdtype, const float* bias, int act, const float* colscale,
               const float* res, int ldr, int glu, float* y, int ldy, int norm, const float* nw, const float* nb, float eps, float* y2, int ldy2,
               int split, void* stream, const float* wscale = nullptr, const float* rope_cos = nullptr, const float* rope_sin = nullptr, int rope_dh = 0,
-              int rope_cols = 0, int y2_dtype = MI355_KV_F32) {
+              int rope_cols = 0, int y2_dtype = MI355_KV_F32, float* split_ws = nullptr, int32_t* split_cnt = nullptr) {
   mi355_gemv_args g;
   memset(&g, 0, sizeof(g));
   g.x = x; g.ldx = ldx; g.M = M; g.K = K; g.w = w; g.ldw = K; g.wdtype = wdtype; g.N = N; g.bias = bias; g.post_act = act; g.colscale = colscale;
   g.res = res; g.ldr = ldr; g.out_scale = 1.f; g.glu = glu; g.y = y; g.ldy = ldy; g.norm = norm; g.norm_weight = nw; g.norm_bias = nb;
   g.norm_eps = eps; g.y2 = y2; g.ldy2 = ldy2; g.split = split; g.wscale = wscale;
   g.rope_cos = rope_cos; g.rope_sin = rope_sin; g.rope_dh = rope_dh; g.rope_cols = rope_cols; g.y2_dtype = y2_dtype;
+  g.split_ws = split_ws; g.split_cnt = split_cnt;
   return mi355_gemv(&g, stream);
 }
 
@@ -134,7 +135,7 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
                    d.d_ff, d.norm, L.mlp_norm_w, L.mlp_norm_b, d.eps, nullptr, 0, 0, stream, L.s_in);
     if (rc) return rc;
     rc = gemv_call(mid, d.d_ff, B, d.d_ff, L.w_out, D, d.wdtype, L.b_out, MI355_ACT_NONE, L.ls2, x, D, 0, x, D, 0, nullptr, nullptr, 0.f, nullptr, 0, 0,
-                   stream, L.s_out);
+                   stream, L.s_out, nullptr, nullptr, 0, 0, MI355_KV_F32, d.gemv_split_ws, d.gemv_split_cnt);
     if (rc) return rc;
   }
   if (out && d.final_norm_w) {

@@ -279,6 +279,8 @@ class TransformerStack:
         d.layers = ctypes.cast(arr, ctypes.c_void_p)
         sws, scnt = ops.attn_split_workspace(self.device, 8 * c.n_heads, c.head_dim)  # key-split decode attention (long key ranges)
         d.attn_split_ws, d.attn_split_cnt = sws.data_ptr(), scnt.data_ptr()
+        gws, gcnt = ops.gemv_split_workspace(self.device, c.d_model, c.d_ff)   # K split over workgroups for the down projection (5..8 rows)
+        d.gemv_split_ws, d.gemv_split_cnt = gws.data_ptr(), gcnt.data_ptr()
         if self.final_norm is not None:
             d.final_norm_w, d.final_norm_b = p(self.final_norm[0]), p(self.final_norm[1])
         self._native = dict(key=key, arr=arr, desc=d, k_start=k_start)

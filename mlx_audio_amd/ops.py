@@ -195,6 +195,9 @@ def gemv(x: torch.Tensor, rw: RowMajor16, y: torch.Tensor, *, post_act: int = AC
     if y2 is not None:
         assert y2.dim() == 2 and y2.stride(1) == 1 and y2.shape[0] == M and y2.dtype in KV_DTYPES
         kw.update(y2=_ptr(y2), ldy2=y2.stride(0), split=n_y, y2_dtype=KV_DTYPES[y2.dtype])
+    if 5 <= M <= 8 and rw.k > 2048 and norm is None and not glu and rw.wdtype != 2:  # K split over workgroups for the long-K projections
+        sws, scnt = gemv_split_workspace(x.device, rw.n, rw.k)
+        kw.update(split_ws=_ptr(sws), split_cnt=_ptr(scnt))
     if x_ids is not None:
         assert x_ids.dtype == torch.int32 and x_ids.numel() == 1 and x_ids.is_cuda
         kw.update(x_ids=_ptr(x_ids), x_id_offset=int(x_id_offset))
@@ -369,6 +372,24 @@ def attn_split_workspace(device, n_records: int, dh: int):
         cur = (torch.empty(max(need_ws, 1 << 16), dtype=torch.float32, device=device),
                torch.zeros(max(need_cnt, 1 << 10), dtype=torch.int32, device=device))
         _SPLIT_WS[key] = cur
+    return cur
+
+
+_GEMV_SPLIT_WS = {}
+
+
+def gemv_split_workspace(device, n: int, k: int):
+    """(float32 scratch, zeroed int32 tickets) for mi355_gemv_args.split_ws / split_cnt, grown on demand and shared by every launch on ``device``
+    (launches on one stream are ordered; the tickets are left zero by every call)."""
+    tiles, nch = (n + 15) // 16, (k + 2047) // 2048
+    need = tiles * nch * 256
+    key = str(device)
+    cur = _GEMV_SPLIT_WS.get(key)
+    if cur is None:  # allocated ONCE per device and never re-allocated: C descriptors keep raw pointers to it
+        cur = (torch.empty(1 << 22, dtype=torch.float32, device=device), torch.zeros(1 << 13, dtype=torch.int32, device=device))
+        _GEMV_SPLIT_WS[key] = cur
+    if need > cur[0].numel() or tiles > cur[1].numel():
+        raise _lib.Mi355Error(f"gemv split workspace too small for N={n}, K={k}")
     return cur
 
 

@@ -232,6 +232,8 @@ class WhisperEngine:
         sd.layers = ctypes.cast(arr, ctypes.c_void_p)
         sws, scnt = ops.attn_split_workspace(self.device, 8 * d.n_text_head, self.dh)  # key-split decode attention (long key ranges)
         sd.attn_split_ws, sd.attn_split_cnt = sws.data_ptr(), scnt.data_ptr()
+        gws, gcnt = ops.gemv_split_workspace(self.device, d.n_text_state, 4 * d.n_text_state)   # mlp2 (K = 4 n_state): K split over workgroups
+        sd.gemv_split_ws, sd.gemv_split_cnt = gws.data_ptr(), gcnt.data_ptr()
         sd.final_norm_w, sd.final_norm_b = p(self.ln.w), p(self.ln.b)
         st["native"] = dict(arr=arr, desc=sd)
         return st["native"]
