@@ -7,8 +7,10 @@ Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` (N>1 under
 synthetic utterances per GPU: BASELINE.json config[1], "Kokoro-82M bf16 TTS on 1 MI355X".  Each
 utterance is the canonical short sentence of BASELINE.md: 78 phonemes (T = 80 tokens), durations
 forced to 264 frames -> 158 400 samples = 6.6 s at 24 kHz.  Weights: seeded random, bf16-valued, in
-the exact Kokoro-82M shapes (no network => no checkpoint).  Inputs (token ids, voice rows, SineGen
-noise) are resident in HBM before the timed region.
+the exact Kokoro-82M shapes (no network => no checkpoint).  Per-utterance inputs (voice rows, forced durations,
+SineGen noise) are resident in HBM before the timed region; the request block itself (int32 token ids, 131 KB for 64
+utterances) travels inside the step because that IS the first message of the sharded step (mlx_audio_amd/shard.py: rank 0
+owns the request queue; one broadcast).  ``--config whisper | qwen3 | csm`` run the secondary lines with the same schema.
 
 Rank 0 prints ONE JSON line; see DESIGN.md section "Measurement" for every field.
 """

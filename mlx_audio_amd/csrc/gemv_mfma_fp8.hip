@@ -8,11 +8,11 @@
 //   * B operand = the (normalised) input rows.  fp8 has 4 significant bits, so a row is scaled by a power of two into [-240, 240] and split into
 //     NT = 4 e4m3 TERMS of decreasing weight: x / s = h0 + h1 / 16 + h2 / 256 + h3 / 4096 (each remainder is exact in fp32 and is re-scaled by 16 before
 //     it is rounded again), ~16 significant bits in total -- the accuracy of the bf16 hi + lo split the 16-bit kernel uses.  Each term has its own
-//     accumulator (the terms differ by a power of two that cannot ride inside an e4m3 operand); they are combined in the epilogue together with the
-//     row scale of x and the row scale of W.  The images live in LDS in fragment order [term][k step][half][group][row] x 8 bytes;
+//     accumulator (the terms differ by a power of two that cannot ride inside an e4m3 operand); they are combined per 2048-column chunk together with
+//     the chunk's row scale of x, and the row scale of W is applied in the epilogue.  The images live in LDS in fragment order [term][k step][half][group][row] x 8 bytes;
 //   * split-K over the four waves of a workgroup, fused LayerNorm / RMSNorm, bias / activation / LayerScale / residual / SwiGLU / split destinations
 //     exactly as gemv_mfma.hip.
-// Same contract and dispatch rules as the 16-bit matrix-pipe kernel (5..8 rows, K <= 2048, K % 64 == 0); MI355_GEMV_MFMA_FP8=0 keeps the FMA kernel.
+// Same contract as the 16-bit matrix-pipe kernel (5..8 rows, K % 64 == 0; a fused norm needs K <= 2048); MI355_GEMV_MFMA_FP8=0 keeps the FMA kernel.
 #include <stdlib.h>
 #include "common.h"
 
