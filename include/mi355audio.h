@@ -198,6 +198,8 @@ typedef struct {
   const uint16_t* wh; int32_t H;
   int32_t L; const int32_t* lens; int32_t B;
   float* out; int64_t out_bstride; int32_t ldo;
+  int32_t quant_h;  /* 1: the recurrent product sees fake_quant_dynamic_u8(h) of each step's hidden vector; the emitted h is not quantised
+                     * (KittenTTS LSTM with activation_quant, kitten_tts/modules.py:178,224) */
 } mi355_lstm_args;
 int mi355_lstm_bidir(const mi355_lstm_args* a, void* stream);
 int mi355_pack_lstm_wh_host(const float* wh_fwd_host, const float* wh_bwd_host, int32_t H, uint16_t* out_host);
@@ -247,8 +249,23 @@ typedef struct {
   float* dur_raw;    /* [B, T] nullable: pre-round value (tests check the rounding margin) */
   int32_t* frames;   /* [B] */
   int32_t* idx; int32_t idx_ld; /* [B, idx_ld], entries >= frames[b] untouched */
+  int32_t max_frames; /* upper clip of one duration: 0 = 100 (Kokoro, kokoro.py:145-147); < 0 = none (KittenTTS, kitten_tts.py:398) */
 } mi355_duration_args;
 int mi355_duration_align(const mi355_duration_args* a, void* stream);
+
+/* Dynamic per-tensor uint8 fake quantisation of one activation tensor per utterance (tts/models/kitten_tts/quant.py:4-24, the
+ * ``maybe_fake_quant`` the KittenTTS modules apply to their inputs): y[b] = fq(act(scale[b,c] * x[b] + shift[b,c])) over the valid rows
+ * of x [B, L, C] (rows >= lens[b] are neither read nor written).  The optional affine + activation prologue is what the consuming conv
+ * would otherwise have fused (AdaIN + LeakyReLU / Snake): a quantised input has to exist in memory, because its extrema are needed first.
+ * x == y is allowed.  ``minmax`` [B, 2] float32 is scratch (overwritten: {-min, max} per utterance). */
+typedef struct {
+  const float* x; int64_t x_bstride; int32_t ldx; int32_t C; int32_t L; const int32_t* lens; int32_t B;
+  const float* pre_scale; const float* pre_shift; int32_t pre_ld;   /* nullable pair [B, pre_ld] */
+  int32_t pre_act; float pre_slope; const float* pre_alpha;          /* MI355_ACT_NONE / LEAKY / SNAKE (alpha [C]) */
+  float* y; int64_t y_bstride; int32_t ldy;
+  float* minmax;
+} mi355_fake_quant_args;
+int mi355_fake_quant_u8(const mi355_fake_quant_args* a, void* stream);
 
 /* AdaIN + LeakyReLU + depthwise ConvTranspose1d(k3, s2) with the first output dropped
  * (AdainResBlk1d pool, istftnet.py:879-881,907-915): x [B, L, C] -> y [B, 2L, C]. */
@@ -291,6 +308,8 @@ typedef struct {
   const float* lin_w; float lin_b;  /* l_linear [H], bias */
   float* phase_ws;
   float* out; int32_t ld_out;
+  float* quant_ws;  /* nullable [B, 2] scratch: when given, sine_wavs [L, H] goes through fake_quant_dynamic_u8 (per utterance) before l_linear
+                     * (KittenTTS with activation_quant on m_source.l_linear, kitten_tts/istftnet.py:711-713) */
 } mi355_sine_source_args;
 int mi355_sine_source(const mi355_sine_source_args* a, void* stream);
 

@@ -147,6 +147,22 @@ __device__ __forceinline__ void store_kv_elem(void* base, int64_t idx, float v, 
   else ((uint16_t*)base)[idx] = (uint16_t)(pack_f16x2(v, 0.f) & 0xffffu);
 }
 
+// Dynamic per-tensor uint8 fake quantisation (tts/models/kitten_tts/quant.py:4-20), float32 op by op: mn <= 0 <= mx are the tensor's
+// extrema joined with 0.  scale == 0 (constant-zero tensor) -> every output is 0.
+struct FakeQuant {
+  float scale, zp;
+  __device__ __forceinline__ FakeQuant(float mn, float mx) {
+    scale = (mx - mn) / 255.0f;
+    const float safe = scale == 0.f ? 1.0f : scale;
+    zp = fminf(fmaxf(rintf(-mn / safe), 0.0f), 255.0f);
+  }
+  __device__ __forceinline__ float operator()(float x) const {
+    if (scale == 0.f) return 0.f;
+    const float q = fminf(fmaxf(rintf(x / scale + zp), 0.0f), 255.0f);
+    return (q - zp) * scale;
+  }
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(512) void duration_align_kernel(const mi355_duratio
       if (v != v) v = 1.0f;                       // nan -> 1
       else if (v == INFINITY) v = 100.0f;         // +inf -> max_frames_per_phoneme
       else if (v == -INFINITY) v = 1.0f;
-      v = fminf(fmaxf(rintf(v), 1.0f), 100.0f);   // mx.round = half-to-even
+      v = fmaxf(rintf(v), 1.0f);                  // mx.round = half-to-even
+      if (a.max_frames >= 0) v = fminf(v, a.max_frames ? (float)a.max_frames : 100.0f);
       d = (int)v;
     }
     a.dur[(int64_t)b * a.T + t] = d;

@@ -17,6 +17,7 @@ __global__ __launch_bounds__(4 * H) void lstm_kernel(const mi355_lstm_args a) {
   uint4* wl = (uint4*)smem;                              // [NLDS][G] 16-B weight groups
   float* hbuf = (float*)(smem + (size_t)NLDS * G * 16);  // [H]
   float* gates = hbuf + H;                               // [G]
+  __shared__ float wext[2 * ((H + 63) / 64)];            // quant_h: per-wave {-min, max} of the step's hidden vector
   const int r = threadIdx.x, dir = blockIdx.x, b = blockIdx.y;
   const int len = a.lens ? a.lens[b] : a.L;
   const uint4* wg = (const uint4*)a.wh + (size_t)dir * (H / 8) * G;  // [H/8][G]
@@ -80,12 +81,28 @@ __global__ __launch_bounds__(4 * H) void lstm_kernel(const mi355_lstm_args a) {
     else gv = 1.0f / (1.0f + expf(-pre));
     gates[r] = gv;
     __syncthreads();
+    float h = 0.f;
     if (r < H) {
       const float ig = gates[r], fg = gates[H + r], gg = gates[2 * H + r], og = gates[3 * H + r];
       c = fg * c + ig * gg;
-      const float h = og * tanhf(c);
-      hbuf[r] = h;
+      h = og * tanhf(c);
       ob[(int64_t)t * a.ldo + r] = h;
+      if (!a.quant_h) hbuf[r] = h;
+    }
+    if (a.quant_h) {  // the next step's recurrent product sees fq(h): extrema over the H values of this utterance and direction
+      constexpr int NWV = (H + 63) / 64;
+      if (r < NWV * 64) {
+        const float nmn = wave_max(fmaxf(-h, 0.f)), mx = wave_max(fmaxf(h, 0.f));  // lanes >= H carry h = 0
+        if ((r & 63) == 0) { wext[2 * (r >> 6)] = nmn; wext[2 * (r >> 6) + 1] = mx; }
+      }
+      __syncthreads();
+      if (r < H) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) { a0 = fmaxf(a0, wext[2 * w]); a1 = fmaxf(a1, wext[2 * w + 1]); }
+        const FakeQuant fq(-a0, a1);
+        hbuf[r] = fq(h);
+      }
     }
     __syncthreads();
   }

@@ -104,6 +104,10 @@ __global__ __launch_bounds__(256) void sine_phase_kernel(const mi355_sine_source
 
 constexpr int kMergeMaxH = 16;
 
+// EXTREMA = true is the first pass of the KittenTTS variant (l_linear carries activation_quant, kitten_tts/istftnet.py:711-713): only the
+// extrema of sine_wavs [L, H] per utterance are produced ({-min, max} in a.quant_ws, integer atomicMax on non-negative floats); the second,
+// ordinary pass then quantises each term before the 9-term product.
+template <bool EXTREMA>
 __global__ __launch_bounds__(256) void sine_merge_kernel(const mi355_sine_source_args a) {
   // the gaussian noise [B, L, H] is the bulk of this kernel's bytes (H floats per sample against one float out): a workgroup's 256 x H block is
   // contiguous, so it comes in as 16-byte loads and is read back per sample at stride H (H = 9: odd, conflict-free)
@@ -128,7 +132,11 @@ __global__ __launch_bounds__(256) void sine_merge_kernel(const mi355_sine_source
     }
   }
   __syncthreads();
-  if (t >= L) return;
+  float nmn = 0.f, mxv = 0.f;
+  const bool live = t < L;
+  if (!EXTREMA && !live) return;
+  const FakeQuant fq = (!EXTREMA && a.quant_ws) ? FakeQuant(-a.quant_ws[2 * b], a.quant_ws[2 * b + 1]) : FakeQuant(0.f, 0.f);
+  if (live) {
   const int small = min(d.small, a.L2 + 1);
   const int big = d.big;
   const float f0v = a.f0[(int64_t)b * a.ld_f0 + t / a.up];
@@ -146,10 +154,21 @@ __global__ __launch_bounds__(256) void sine_merge_kernel(const mi355_sine_source
       const float p = small == 1 ? ph[0] : add_rn(mul_rn(ph[lo], omf), mul_rn(ph[hi], fr));
       sv = mul_rn(sinf(p), a.sine_amp);
     }
-    const float sw = add_rn(mul_rn(sv, uv), mul_rn(namp, nz[h]));
+    float sw = add_rn(mul_rn(sv, uv), mul_rn(namp, nz[h]));
+    if (EXTREMA) { nmn = fmaxf(nmn, -sw); mxv = fmaxf(mxv, sw); }
+    else if (a.quant_ws) sw = fq(sw);
     accv = add_rn(accv, mul_rn(sw, a.lin_w[h]));
   }
-  a.out[(int64_t)b * a.ld_out + t] = tanhf(add_rn(accv, a.lin_b));
+  if (!EXTREMA) a.out[(int64_t)b * a.ld_out + t] = tanhf(add_rn(accv, a.lin_b));
+  }
+  if (EXTREMA) {
+    nmn = wave_max(nmn);
+    mxv = wave_max(mxv);
+    if ((tid & 63) == 0) {
+      atomicMax((int*)a.quant_ws + 2 * b, __float_as_int(nmn));
+      atomicMax((int*)a.quant_ws + 2 * b + 1, __float_as_int(mxv));
+    }
+  }
 }
 
 // ---------------------------------------------------------------- small-n_fft STFT -> |X|, angle(X)
@@ -441,7 +460,78 @@ __global__ __launch_bounds__(256) void interpolate1d_kernel(const mi355_interp1d
   yr[o] = lo_term + hi_term;
 }
 
+// ---- dynamic uint8 fake quantisation of a module input (tts/models/kitten_tts/quant.py:4-24) ----
+// pass 1: y = act(scale * x + shift) (what the consuming conv would have fused) and the tensor's extrema per utterance; min / max are
+// order-independent, so the atomics are deterministic.  Both extrema are joined with 0 like the reference, hence {-min, max} >= 0 and
+// an integer atomicMax on the float bit patterns orders them.
+__global__ __launch_bounds__(256) void fq_prepare_kernel(const mi355_fake_quant_args a) {
+  const int b = blockIdx.y;
+  const int len = a.lens ? a.lens[b] : a.L;
+  const float* xb = a.x + (int64_t)b * a.x_bstride;
+  float* yb = a.y + (int64_t)b * a.y_bstride;
+  const int64_t n = (int64_t)len * a.C;
+  float nmn = 0.f, mx = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int l = (int)(i / a.C), c = (int)(i - (int64_t)l * a.C);
+    float t = xb[(int64_t)l * a.ldx + c];
+    if (a.pre_scale) t = t * a.pre_scale[(int64_t)b * a.pre_ld + c] + a.pre_shift[(int64_t)b * a.pre_ld + c];
+    if (a.pre_act == MI355_ACT_LEAKY) t = t > 0.f ? t : t * a.pre_slope;
+    else if (a.pre_act == MI355_ACT_SNAKE) {
+      const float al = a.pre_alpha[c];
+      const float sn = sinf(al * t);
+      t = t + (1.0f / al) * (sn * sn);
+    }
+    yb[(int64_t)l * a.ldy + c] = t;
+    nmn = fmaxf(nmn, -t);
+    mx = fmaxf(mx, t);
+  }
+  nmn = wave_max(nmn);
+  mx = wave_max(mx);
+  __shared__ float red[8];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[2 * w] = nmn; red[2 * w + 1] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 4; ++i) { nmn = fmaxf(nmn, red[2 * i]); mx = fmaxf(mx, red[2 * i + 1]); }
+    atomicMax((int*)a.minmax + 2 * b, __float_as_int(nmn));
+    atomicMax((int*)a.minmax + 2 * b + 1, __float_as_int(mx));
+  }
+}
+
+__global__ __launch_bounds__(256) void fq_apply_kernel(const mi355_fake_quant_args a) {
+  const int b = blockIdx.y;
+  const int len = a.lens ? a.lens[b] : a.L;
+  float* yb = a.y + (int64_t)b * a.y_bstride;
+  const int64_t n = (int64_t)len * a.C;
+  const FakeQuant fq(-a.minmax[2 * b], a.minmax[2 * b + 1]);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int l = (int)(i / a.C), c = (int)(i - (int64_t)l * a.C);
+    float* p = yb + (int64_t)l * a.ldy + c;
+    *p = fq(*p);
+  }
+}
+
 }  // namespace
+
+extern "C" int mi355_fake_quant_u8(const mi355_fake_quant_args* ap, void* stream) {
+  MI355_REQUIRE(ap && ap->x && ap->y && ap->minmax, "fake_quant_u8: null tensor");
+  const mi355_fake_quant_args a = *ap;
+  MI355_REQUIRE(a.B > 0 && a.L > 0 && a.C > 0 && a.ldx >= a.C && a.ldy >= a.C, "fake_quant_u8: bad shape");
+  MI355_REQUIRE(!a.pre_scale == !a.pre_shift, "fake_quant_u8: pre_scale and pre_shift go together");
+  MI355_REQUIRE(a.pre_act == MI355_ACT_NONE || a.pre_act == MI355_ACT_LEAKY || a.pre_act == MI355_ACT_SNAKE, "fake_quant_u8: unsupported prologue activation %d", a.pre_act);
+  MI355_REQUIRE(a.pre_act != MI355_ACT_SNAKE || a.pre_alpha, "fake_quant_u8: snake needs pre_alpha");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(a.minmax, 0, sizeof(float) * 2 * a.B, st);
+  MI355_REQUIRE(e == hipSuccess, "fake_quant_u8: memset failed: %s", hipGetErrorString(e));
+  const int64_t n = (int64_t)a.L * a.C;
+  const unsigned nblk = (unsigned)std::min<int64_t>((n + 1023) / 1024, 1024);
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(fq_prepare_kernel, dim3(nblk, a.B), dim3(256), 0, st, a);
+  MI355_LAUNCH_CHECK("fake_quant_u8 (prepare)");
+  hipLaunchKernelGGL(fq_apply_kernel, dim3(nblk, a.B), dim3(256), 0, st, a);
+  MI355_LAUNCH_CHECK("fake_quant_u8 (apply)");
+  return MI355_OK;
+}
 
 extern "C" int mi355_sine_source(const mi355_sine_source_args* ap, void* stream) {
   MI355_REQUIRE(ap && ap->f0 && ap->rand_ini && ap->noise && ap->lin_w && ap->phase_ws && ap->out, "sine_source: null tensor");
@@ -455,7 +545,13 @@ extern "C" int mi355_sine_source(const mi355_sine_source_args* ap, void* stream)
   hipLaunchKernelGGL(sine_phase_kernel, dim3(a.B), dim3(256), sizeof(float) * a.H * kPhaseChunk, st, a);
   MI355_LAUNCH_CHECK("sine_phase");
   MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL(sine_merge_kernel, dim3((d.L + 255) / 256, a.B), dim3(256), 0, st, a);
+  if (a.quant_ws) {
+    hipError_t e = hipMemsetAsync(a.quant_ws, 0, sizeof(float) * 2 * a.B, st);
+    MI355_REQUIRE(e == hipSuccess, "sine_source: memset failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(sine_merge_kernel<true>, dim3((d.L + 255) / 256, a.B), dim3(256), 0, st, a);
+    MI355_LAUNCH_CHECK("sine_merge (extrema)");
+  }
+  hipLaunchKernelGGL(sine_merge_kernel<false>, dim3((d.L + 255) / 256, a.B), dim3(256), 0, st, a);
   MI355_LAUNCH_CHECK("sine_merge");
   return MI355_OK;
 }

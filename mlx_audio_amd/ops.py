@@ -343,12 +343,28 @@ def layernorm(x: torch.Tensor, y: torch.Tensor, *, weight=None, bias=None, ada_g
     return y
 
 
-def lstm_bidir(xp: torch.Tensor, wh: torch.Tensor, H: int, out: torch.Tensor, lens=None):
+def lstm_bidir(xp: torch.Tensor, wh: torch.Tensor, H: int, out: torch.Tensor, lens=None, quant_h: bool = False):
     B, L, _, xbs, ldxp = _nlc(xp)
     _, _, _, obs, ldo = _nlc(out)
     _lib.call_struct("mi355_lstm_bidir", "mi355_lstm_args", _stream(), xp=_ptr(xp), xp_bstride=xbs, ldxp=ldxp, wh=_ptr(wh),
-                     H=H, L=L, lens=_ptr(lens), B=B, out=_ptr(out), out_bstride=obs, ldo=ldo)
+                     H=H, L=L, lens=_ptr(lens), B=B, out=_ptr(out), out_bstride=obs, ldo=ldo, quant_h=int(bool(quant_h)))
     return out
+
+
+def fake_quant_u8(x: torch.Tensor, y: Optional[torch.Tensor] = None, *, lens=None, pre=None, pre_act: int = ACT_NONE, pre_slope: float = 0.0,
+                  pre_alpha: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``fake_quant_dynamic_u8`` (tts/models/kitten_tts/quant.py) of ``act(scale * x + shift)`` per utterance: x [B, L, C] -> y (a fresh
+    tensor unless given; ``y is x`` quantises in place)."""
+    B, L, C, xbs, ldx = _nlc(x)
+    if y is None:  # channel-padded like every conv input of the engines (rows past lens[b] and the pad columns stay zero)
+        y = torch.zeros((B, L, round_up(C, 32)), dtype=torch.float32, device=x.device)[:, :, :C]
+    _, _, _, ybs, ldy = _nlc(y)
+    mm = torch.empty((B, 2), dtype=torch.float32, device=x.device)
+    sc, sh = pre if pre is not None else (None, None)
+    _lib.call_struct("mi355_fake_quant_u8", "mi355_fake_quant_args", _stream(), x=_ptr(x), x_bstride=xbs, ldx=ldx, C=C, L=L, lens=_ptr(lens), B=B,
+                     pre_scale=_ptr(sc), pre_shift=_ptr(sh), pre_ld=sc.stride(0) if sc is not None else 0, pre_act=pre_act, pre_slope=pre_slope,
+                     pre_alpha=_ptr(pre_alpha), y=_ptr(y), y_bstride=ybs, ldy=ldy, minmax=_ptr(mm))
+    return y
 
 
 def attention(qkv: torch.Tensor, heads: int, dh: int, out: torch.Tensor, lens=None):
@@ -590,13 +606,13 @@ def broadcast_rows(v: torch.Tensor, y: torch.Tensor, lens=None):
 
 
 def duration_align(logits: Optional[torch.Tensor], T: int, B: int, speed: float, idx_cap: int, device, lens=None,
-                   forced: Optional[torch.Tensor] = None, bins: int = 50):
+                   forced: Optional[torch.Tensor] = None, bins: int = 50, max_frames: int = 0):
     dur = torch.empty((B, T), dtype=torch.int32, device=device)
     raw = torch.zeros((B, T), dtype=torch.float32, device=device)
     frames = torch.empty((B,), dtype=torch.int32, device=device)
     idx = torch.zeros((B, idx_cap), dtype=torch.int32, device=device)
     kw = dict(T=T, lens=_ptr(lens), B=B, speed=speed, forced_dur=_ptr(forced), dur=_ptr(dur), dur_raw=_ptr(raw),
-              frames=_ptr(frames), idx=_ptr(idx), idx_ld=idx_cap, bins=bins)
+              frames=_ptr(frames), idx=_ptr(idx), idx_ld=idx_cap, bins=bins, max_frames=max_frames)
     if logits is not None:
         _, _, _, bs, ld = _nlc(logits)
         kw.update(logits=_ptr(logits), bstride=bs, ld=ld)
@@ -626,7 +642,7 @@ def conv1d_c1_k3s2(x: torch.Tensor, w3, bias: float, y: torch.Tensor, col: int, 
 
 # --------------------------------------------------------------------------------------- source / stft heads
 def sine_source(f0: torch.Tensor, rand_ini: torch.Tensor, noise: torch.Tensor, lin_w: torch.Tensor, lin_b: float, up: int,
-                lens2=None, sr: float = 24000.0, sine_amp: float = 0.1, noise_std: float = 0.003, voiced_thr: float = 10.0):
+                lens2=None, sr: float = 24000.0, sine_amp: float = 0.1, noise_std: float = 0.003, voiced_thr: float = 10.0, quant: bool = False):
     B, L2 = f0.shape
     H = rand_ini.shape[1]
     assert f0.stride(1) == 1 and noise.is_contiguous() and tuple(noise.shape) == (B, L2 * up, H)
@@ -635,7 +651,8 @@ def sine_source(f0: torch.Tensor, rand_ini: torch.Tensor, noise: torch.Tensor, l
     _lib.call_struct("mi355_sine_source", "mi355_sine_source_args", _stream(), f0=_ptr(f0), ld_f0=f0.stride(0), L2=L2,
                      lens2=_ptr(lens2), B=B, up=up, H=H, sr=sr, sine_amp=sine_amp, noise_std=noise_std, voiced_thr=voiced_thr,
                      rand_ini=_ptr(rand_ini), noise=_ptr(noise), lin_w=_ptr(lin_w), lin_b=lin_b, phase_ws=_ptr(ws),
-                     out=_ptr(out), ld_out=out.stride(0))
+                     out=_ptr(out), ld_out=out.stride(0),
+                     quant_ws=_ptr(torch.empty((B, 2), dtype=torch.float32, device=f0.device)) if quant else None)
     return out
 
 

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from .... import ops
-from ....ops import ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_SNAKE, PackedConv, round_up
+from ....ops import ACT_GELU, ACT_GELU_TANH, ACT_LEAKY, ACT_NONE, ACT_SNAKE, PackedConv, round_up
 
 
 def fold_weight_norm(v: torch.Tensor, g: torch.Tensor, param_dtype: torch.dtype) -> torch.Tensor:
@@ -41,6 +41,14 @@ def fold_weight_norm(v: torch.Tensor, g: torch.Tensor, param_dtype: torch.dtype)
 class _AdaIN:
     off: int  # column offset of [gamma | beta] in the style-projection output
     c: int
+    q: bool = False  # KittenTTS: fc sees the fake-quantised style vector (kitten_tts/istftnet.py:336, modules.py:80)
+
+
+@dataclass
+class _StyleProj:
+    """Every style projection of one style vector, from the plain and (KittenTTS, when any AdaIN is flagged) the fake-quantised vector."""
+    plain: torch.Tensor
+    quant: Optional[torch.Tensor] = None
 
 
 @dataclass
@@ -54,6 +62,7 @@ class _ResBlk1d:  # AdainResBlk1d
     pool_b: Optional[torch.Tensor]
     din: int
     dout: int
+    name: str = ""
 
 
 @dataclass
@@ -67,6 +76,7 @@ class _ResBlock1:  # AdaINResBlock1
     k: int
     dils: Sequence[int]
     ch: int
+    name: str = ""
 
 
 @dataclass
@@ -74,6 +84,7 @@ class _LSTM:
     wx: PackedConv
     wh: torch.Tensor
     hid: int
+    q: bool = False  # KittenTTS: fake-quantised input and per-step hidden vector (kitten_tts/modules.py:155,178)
 
 
 class _StyleBank:
@@ -83,6 +94,7 @@ class _StyleBank:
         self.ws: List[torch.Tensor] = []
         self.bs: List[torch.Tensor] = []
         self.n = 0
+        self.any_q = False  # some AdaIN of this bank wants the fake-quantised style vector (KittenTTS)
 
     def add(self, w: torch.Tensor, b: torch.Tensor) -> int:
         off = self.n
@@ -147,10 +159,22 @@ class KokoroFront:
 
 
 class KokoroEngine:
+    # what KittenTTS (tts/models/kitten_tts/engine.py) changes: decoder widths, ALBERT activation, Snake parameter names, the duration clip
+    # and the list of modules whose inputs are fake-quantised
+    ffn_act = ACT_GELU        # nn.GELU (modules.py:571)
+    alpha_name = "alpha{w}.{i}"
+    max_frames = 0            # clip(round(dur), 1, 100) (kokoro.py:145-147)
+
+    def _decoder_dims(self, config: dict):
+        """(width of the decoder blocks, generator input width, asr_res width): fixed in Kokoro (istftnet.py:948-975)."""
+        return 1024, 512, 64
+
     def __init__(self, weights: Dict[str, torch.Tensor], config: dict, device="cuda", param_dtype=torch.bfloat16,
-                 precision: int = 2):
+                 precision: int = 2, quant_modules: Sequence[str] = ()):
         ops.require_gpu()
         self.cfg = config
+        self.qmods = tuple(quant_modules)
+        self.cdim, self.gdim, self.adim = self._decoder_dims(config)
         self.dev = torch.device(device)
         self.pdt = param_dtype
         self.precision = precision
@@ -201,15 +225,22 @@ class KokoroEngine:
             t = torch.cat([t, torch.ones(pad_to - t.numel())])
         return t.contiguous().to(self.dev)
 
+    def _isq(self, name: str) -> bool:
+        """Does module ``name`` carry ``activation_quant``?  A module is flagged when a listed name is the module itself or lies below it
+        (kitten_tts/kitten_tts.py:291-299); Kokoro lists none."""
+        return any(q == name or q.startswith(name + ".") for q in self.qmods)
+
     def _adain(self, bank: _StyleBank, pre, c) -> _AdaIN:
-        return _AdaIN(bank.add(self._q(self._t(f"{pre}.fc.weight")), self._q(self._t(f"{pre}.fc.bias"))), c)
+        q = self._isq(pre)
+        bank.any_q = bank.any_q or q
+        return _AdaIN(bank.add(self._q(self._t(f"{pre}.fc.weight")), self._q(self._t(f"{pre}.fc.bias"))), c, q)
 
     def _lstm(self, pre) -> _LSTM:
         wx = torch.cat([self._q(self._t(f"{pre}.Wx_forward")), self._q(self._t(f"{pre}.Wx_backward"))], 0)
         b = torch.cat([self._q(self._t(f"{pre}.bias_ih_forward")) + self._q(self._t(f"{pre}.bias_hh_forward")),
                        self._q(self._t(f"{pre}.bias_ih_backward")) + self._q(self._t(f"{pre}.bias_hh_backward"))])
         whf, whb = self._q(self._t(f"{pre}.Wh_forward")), self._q(self._t(f"{pre}.Wh_backward"))
-        return _LSTM(ops.pack_conv(wx, b, self.dev), ops.pack_lstm_wh(whf, whb, self.dev), whf.shape[1])
+        return _LSTM(ops.pack_conv(wx, b, self.dev), ops.pack_lstm_wh(whf, whb, self.dev), whf.shape[1], self._isq(pre))
 
     def _resblk1d(self, bank, pre, din, dout) -> _ResBlk1d:
         up = f"{pre}.pool.weight_v" in self.w
@@ -220,15 +251,15 @@ class KokoroEngine:
         return _ResBlk1d(self._convw(f"{pre}.conv1"), self._convw(f"{pre}.conv2"), self._adain(bank, f"{pre}.norm1", din),
                          self._adain(bank, f"{pre}.norm2", dout),
                          self._convw(f"{pre}.conv1x1", bias=False) if f"{pre}.conv1x1.weight_v" in self.w else None,
-                         pool_w, pool_b, din, dout)
+                         pool_w, pool_b, din, dout, pre)
 
     def _resblock1(self, bank, pre, ch, k, dils) -> _ResBlock1:
         cp = round_up(ch, 32)
         return _ResBlock1([self._convw(f"{pre}.convs1.{i}") for i in range(3)], [self._convw(f"{pre}.convs2.{i}") for i in range(3)],
                           [self._adain(bank, f"{pre}.adain1.{i}", ch) for i in range(3)],
                           [self._adain(bank, f"{pre}.adain2.{i}", ch) for i in range(3)],
-                          [self._dvec(self._t(f"{pre}.alpha1.{i}"), cp) for i in range(3)],
-                          [self._dvec(self._t(f"{pre}.alpha2.{i}"), cp) for i in range(3)], k, dils, ch)
+                          [self._dvec(self._t(f"{pre}.{self.alpha_name.format(w=1, i=i)}"), cp) for i in range(3)],
+                          [self._dvec(self._t(f"{pre}.{self.alpha_name.format(w=2, i=i)}"), cp) for i in range(3)], k, dils, ch, pre)
 
     def _load(self):
         d, hid, sty = self.dev, self.hid, self.sty
@@ -271,8 +302,9 @@ class KokoroEngine:
         self.te_k = self.w["text_encoder.cnn.0.0.weight_v"].shape[1]
         self.te_lstm = self._lstm("text_encoder.lstm")
         # ---- decoder
-        self.enc_blk = self._resblk1d(self.bank_dec, "decoder.encode", hid + 2, 1024)
-        self.dec_blks = [self._resblk1d(self.bank_dec, f"decoder.decode.{i}", 1024 + 2 + 64, 1024 if i < 3 else 512) for i in range(4)]
+        cd, gd, ad = self.cdim, self.gdim, self.adim
+        self.enc_blk = self._resblk1d(self.bank_dec, "decoder.encode", hid + 2, cd)
+        self.dec_blks = [self._resblk1d(self.bank_dec, f"decoder.decode.{i}", cd + 2 + ad, cd if i < 3 else gd) for i in range(4)]
         f0w, nw = self._wn("decoder.F0_conv").reshape(-1), self._wn("decoder.N_conv").reshape(-1)
         self.f0_conv = ([float(v) for v in f0w], float(self._q(self._t("decoder.F0_conv.bias"))[0]))
         self.n_conv = ([float(v) for v in nw], float(self._q(self._t("decoder.N_conv.bias"))[0]))
@@ -298,6 +330,7 @@ class KokoroEngine:
         self.conv_post = self._convw(f"{g}.conv_post")
         self.style_dec = self.bank_dec.pack(d)
         self.style_pred = self.bank_pred.pack(d)
+        self.q_style_dec, self.q_style_pred = self.bank_dec.any_q, self.bank_pred.any_q
         # periodic Hann of MLXSTFT (istftnet.py:466) -- same float32 values as dsp.hanning(n, periodic=True)
         n = self.n_fft
         self.window = torch.tensor([0.5 * (1 - math.cos(2 * math.pi * i / n)) for i in range(n)], dtype=torch.float32, device=d)
@@ -307,18 +340,46 @@ class KokoroEngine:
     def _new(self, *shape, zero=False):
         return (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=self.dev)
 
-    def _gb(self, gb_all: torch.Tensor, a: _AdaIN) -> torch.Tensor:
-        return gb_all[:, a.off: a.off + 2 * a.c]
+    def _gb(self, gb_all: _StyleProj, a: _AdaIN) -> torch.Tensor:
+        return (gb_all.quant if a.q else gb_all.plain)[:, a.off: a.off + 2 * a.c]
+
+    def _style_proj(self, s: torch.Tensor, pc: PackedConv, quant: bool) -> _StyleProj:
+        """Every ``fc(style)`` of one style vector: one GEMM, and one more from the fake-quantised vector when an AdaIN wants that."""
+        B = s.shape[0]
+        plain = self._new(B, 1, pc.cout)
+        self._conv(s[:, None, :], pc, plain)
+        q = None
+        if quant:
+            q = self._new(B, 1, pc.cout)
+            self._conv(ops.fake_quant_u8(s[:, None, :]), pc, q)
+            q = q[:, 0]
+        return _StyleProj(plain[:, 0], q)
 
     def _conv(self, x, pc, y, **kw):
         kw.setdefault("precision", 2 if self.precision == 3 else self.precision)  # fp16-packed weights select 3 themselves
         return ops.conv_gemm(x, pc, y, **kw)
 
+    def _convq(self, name: str, x, pc, y, *, lens_in=None, pre=None, pre_act=ACT_NONE, pre_slope=0.0, pre_alpha=None, **kw):
+        """``_conv`` of module ``name``.  When the module is flagged for activation quantisation (KittenTTS) its input -- INCLUDING the
+        AdaIN / activation prologue the conv would have fused -- is materialised and fake-quantised first (kitten_tts/istftnet.py:131)."""
+        if self.qmods and self._isq(name):
+            xq = ops.fake_quant_u8(x, lens=lens_in, pre=pre, pre_act=pre_act, pre_slope=pre_slope, pre_alpha=pre_alpha)
+            return self._conv(xq, pc, y, lens_in=lens_in, **kw)
+        if pre is not None or pre_act != ACT_NONE:
+            kw.update(pre=pre, pre_act=pre_act, pre_slope=pre_slope, pre_alpha=pre_alpha)
+        return self._conv(x, pc, y, lens_in=lens_in, **kw)
+
+    def _dur_cap(self, bins: int, speed: float) -> int:
+        """Upper bound of one predicted duration: the clip (Kokoro), else the sum of ``bins`` sigmoids over the speed (KittenTTS, unclipped)."""
+        return 100 if self.max_frames == 0 else (self.max_frames if self.max_frames > 0 else max(100, int(math.ceil(bins / speed)) + 1))
+
     def _bilstm(self, l: _LSTM, x, out, lens):
         B, L = x.shape[0], x.shape[1]
         xp = self._new(B, L, 8 * l.hid)
+        if l.q:
+            x = ops.fake_quant_u8(x, lens=lens)
         self._conv(x, l.wx, xp, lens_in=lens, lens_out=lens, flatten=True)
-        return ops.lstm_bidir(xp, l.wh, l.hid, out, lens=lens)
+        return ops.lstm_bidir(xp, l.wh, l.hid, out, lens=lens, quant_h=l.q)
 
     def _resblk1d_fwd(self, blk: _ResBlk1d, x, gb_all, out, lens, lens2=None):
         """x [B, L, din] -> out [B, L or 2L, dout]."""
@@ -329,23 +390,31 @@ class KokoroEngine:
         Lo = 2 * L if up else L
         c1 = self._new(B, Lo, blk.dout)
         st = ops.new_stats(B, Lo, blk.dout, self.dev) if self.fuse_stats else None
+        nm = blk.name
         if up:
-            pooled = self._new(B, Lo, round_up(blk.din, 32))[:, :, : blk.din]
-            ops.adain_pool_up2(x, sc1, sh1, 0.2, blk.pool_w, blk.pool_b, pooled, lens)
-            self._conv(pooled, blk.conv1, c1, pad=1, lens_in=lo, lens_out=lo, stats=st)
+            pooled = self._new(B, Lo, round_up(blk.din, 32), zero=bool(self.qmods))[:, :, : blk.din]
+            if self.qmods and self._isq(f"{nm}.pool"):  # the depthwise transposed conv is a ConvWeighted too: it sees fq(leaky(adain(x)))
+                xq = ops.fake_quant_u8(x, lens=lens, pre=(sc1, sh1), pre_act=ACT_LEAKY, pre_slope=0.2)
+                one, zero = torch.ones_like(sc1), torch.zeros_like(sh1)
+                ops.adain_pool_up2(xq, one, zero, 1.0, blk.pool_w, blk.pool_b, pooled, lens)
+            else:
+                ops.adain_pool_up2(x, sc1, sh1, 0.2, blk.pool_w, blk.pool_b, pooled, lens)
+            self._convq(f"{nm}.conv1", pooled, blk.conv1, c1, pad=1, lens_in=lo, lens_out=lo, stats=st)
         else:
-            self._conv(x, blk.conv1, c1, pad=1, lens_in=lo, lens_out=lo, pre=(sc1, sh1), pre_act=ACT_LEAKY, pre_slope=0.2, stats=st)
+            self._convq(f"{nm}.conv1", x, blk.conv1, c1, pad=1, lens_in=lo, lens_out=lo, pre=(sc1, sh1), pre_act=ACT_LEAKY, pre_slope=0.2, stats=st)
         if st is not None:
             sc2, sh2 = ops.adain_from_partials(st, Lo, self._gb(gb_all, blk.norm2), lo)
         else:
             sc2, sh2 = ops.adain_coef(c1, self._gb(gb_all, blk.norm2), lo)
         if blk.conv1x1 is not None:
             short = self._new(B, L, blk.dout)
-            self._conv(x, blk.conv1x1, short, lens_in=lens, lens_out=lens, flatten=True)
+            # the reference up-samples the shortcut before conv1x1; k = 1, so conv-then-repeat is the same values, and the fake-quantised
+            # input has the same extrema either way (nearest repeat adds no new values)
+            self._convq(f"{nm}.conv1x1", x, blk.conv1x1, short, lens_in=lens, lens_out=lens, flatten=True)
         else:
             short = x
-        self._conv(c1, blk.conv2, out, pad=1, lens_in=lo, lens_out=lo, pre=(sc2, sh2), pre_act=ACT_LEAKY, pre_slope=0.2,
-                   res=short, res_shift=1 if up else 0, out_scale=1.0 / math.sqrt(2.0))
+        self._convq(f"{nm}.conv2", c1, blk.conv2, out, pad=1, lens_in=lo, lens_out=lo, pre=(sc2, sh2), pre_act=ACT_LEAKY, pre_slope=0.2,
+                    res=short, res_shift=1 if up else 0, out_scale=1.0 / math.sqrt(2.0))
         return out
 
     def _resblock1_fwd(self, rb: _ResBlock1, x, gb_all, lens, out=None, accumulate=False, out_scale=1.0, x_stats=None, x_sums=None):
@@ -368,8 +437,8 @@ class KokoroEngine:
                 sc, sh = ops.adain_coef(cur, self._gb(gb_all, rb.adain1[i]), lens, sums=x_sums[0], reuse=x_sums[1])
             else:
                 sc, sh = ops.adain_coef(cur, self._gb(gb_all, rb.adain1[i]), lens)
-            self._conv(cur, rb.convs1[i], tmp, dil=dl, pad=(rb.k * dl - dl) // 2, lens_in=lens, lens_out=lens, pre=(sc, sh),
-                       pre_act=ACT_SNAKE, pre_alpha=rb.alpha1[i], stats=st_tmp)
+            self._convq(f"{rb.name}.convs1.{i}", cur, rb.convs1[i], tmp, dil=dl, pad=(rb.k * dl - dl) // 2, lens_in=lens, lens_out=lens, pre=(sc, sh),
+                        pre_act=ACT_SNAKE, pre_alpha=rb.alpha1[i], stats=st_tmp)
             if fuse:
                 sc, sh = ops.adain_from_partials(st_tmp, L, self._gb(gb_all, rb.adain2[i]), lens)
             else:
@@ -381,9 +450,9 @@ class KokoroEngine:
                 if work is None:
                     work = self._new(B, L, C)
                 dst, acc, scale = work, False, 1.0
-            self._conv(tmp, rb.convs2[i], dst, pad=(rb.k - 1) // 2, lens_in=lens, lens_out=lens, pre=(sc, sh),
-                       pre_act=ACT_SNAKE, pre_alpha=rb.alpha2[i], res=cur, accumulate=acc, out_scale=scale,
-                       stats=st_work if (fuse and not last) else None)
+            self._convq(f"{rb.name}.convs2.{i}", tmp, rb.convs2[i], dst, pad=(rb.k - 1) // 2, lens_in=lens, lens_out=lens, pre=(sc, sh),
+                        pre_act=ACT_SNAKE, pre_alpha=rb.alpha2[i], res=cur, accumulate=acc, out_scale=scale,
+                        stats=st_work if (fuse and not last) else None)
             cur = dst
             st_cur = st_work if (fuse and not last) else None
         return cur
@@ -437,11 +506,8 @@ class KokoroEngine:
         s_dec = ref_s[:, :sty].contiguous()
         s_pred = ref_s[:, sty:].contiguous()
         # ---- every style projection of the network: two GEMMs
-        gb_dec = self._new(B, 1, self.style_dec.cout)
-        gb_pred = self._new(B, 1, self.style_pred.cout)
-        self._conv(s_dec[:, None, :], self.style_dec, gb_dec)
-        self._conv(s_pred[:, None, :], self.style_pred, gb_pred)
-        gb_dec, gb_pred = gb_dec[:, 0], gb_pred[:, 0]
+        gb_dec = self._style_proj(s_dec, self.style_dec, self.q_style_dec)
+        gb_pred = self._style_proj(s_pred, self.style_pred, self.q_style_pred)
 
         # ---- PL-BERT (CustomAlbert, modules.py:626-655)
         H = self.pb["hidden_size"]
@@ -452,22 +518,26 @@ class KokoroEngine:
         eps = float(self.pb.get("layer_norm_eps", 1e-12))
         ops.layernorm(emb, emb, weight=self.emb_ln[0], bias=self.emb_ln[1], eps=eps, lens=lens_t)
         h = self._new(B, Tm, H)
-        self._conv(emb, self.map_in, h, lens_in=lens_t, lens_out=lens_t, flatten=True)
+        enc_n, lay_n = "bert.encoder", "bert.encoder.albert_layer_groups.0.albert_layers.0"
+        att_n = f"{lay_n}.attention"
+        # (KittenTTS: the encoder / layer / attention MODULES quantise at fixed points of their own forward, kitten_tts.py:108-133,255-268,296-298;
+        #  _convq keys on the module that owns the quantisation point, not on the linear layer)
+        self._convq(enc_n, emb, self.map_in, h, lens_in=lens_t, lens_out=lens_t, flatten=True)
         qkv = self._new(B, Tm, 3 * H)
         ctx = self._new(B, Tm, H)
         tmp = self._new(B, Tm, H)
         att = self._new(B, Tm, H)
         inter = self._new(B, Tm, self.pb["intermediate_size"])
         for _ in range(self.pb["num_hidden_layers"]):
-            self._conv(h, self.qkv, qkv, lens_in=lens_t, lens_out=lens_t, flatten=True)
+            self._convq(att_n, h, self.qkv, qkv, lens_in=lens_t, lens_out=lens_t, flatten=True)
             if H // heads in (64, 128):  # f32-MFMA flash kernel; padded keys are invisible (the reference's additive -10000 mask, modules.py:639)
                 ops.flash_attention(qkv[:, :, :H], qkv[:, :, H:2 * H], qkv[:, :, 2 * H:], ctx, heads=heads, dh=H // heads, lens_q=lens_t, lens_k=lens_t)
             else:
                 ops.attention(qkv, heads, H // heads, ctx, lens=lens_t)
-            self._conv(ctx, self.att_dense, tmp, lens_in=lens_t, lens_out=lens_t, res=h, flatten=True)
+            self._convq(att_n, ctx, self.att_dense, tmp, lens_in=lens_t, lens_out=lens_t, res=h, flatten=True)
             ops.layernorm(tmp, att, weight=self.att_ln[0], bias=self.att_ln[1], eps=eps, lens=lens_t)
-            self._conv(att, self.ffn, inter, lens_in=lens_t, lens_out=lens_t, post_act=ACT_GELU, flatten=True)
-            self._conv(inter, self.ffn_out, tmp, lens_in=lens_t, lens_out=lens_t, res=att, flatten=True)
+            self._convq(lay_n, att, self.ffn, inter, lens_in=lens_t, lens_out=lens_t, post_act=self.ffn_act, flatten=True)
+            self._convq(lay_n, inter, self.ffn_out, tmp, lens_in=lens_t, lens_out=lens_t, res=att, flatten=True)
             ops.layernorm(tmp, h, weight=self.full_ln[0], bias=self.full_ln[1], eps=eps, lens=lens_t)
 
         # ---- DurationEncoder (modules.py:380-411): [d_en | style] ping-pong buffers
@@ -475,7 +545,7 @@ class KokoroEngine:
         db = self._new(B, Tm, hid + sty, zero=True)
         ops.broadcast_rows(s_pred, da[:, :, hid:], lens=lens_t)
         ops.broadcast_rows(s_pred, db[:, :, hid:], lens=lens_t)
-        self._conv(h, self.bert_encoder, da[:, :, :hid], lens_in=lens_t, lens_out=lens_t, flatten=True)
+        self._convq("bert_encoder", h, self.bert_encoder, da[:, :, :hid], lens_in=lens_t, lens_out=lens_t, flatten=True)
         cur, nxt = da, db
         for i in range(self.n_layer):
             self._bilstm(self.dur_lstms[i], cur, nxt[:, :, :hid], lens_t)
@@ -486,7 +556,7 @@ class KokoroEngine:
         self._bilstm(self.pred_lstm, d, xl, lens_t)
         bins = self.dur_proj.cout
         logits = self._new(B, Tm, round_up(bins, 4))
-        self._conv(xl, self.dur_proj, logits[:, :, :bins], lens_in=lens_t, lens_out=lens_t)
+        self._convq("predictor.duration_proj", xl, self.dur_proj, logits[:, :, :bins], lens_in=lens_t, lens_out=lens_t)
         forced = None
         if forced_padded is not None:
             assert forced_padded.is_cuda and forced_padded.dtype == torch.int32 and forced_padded.shape[0] == B and forced_padded.shape[1] >= Tm
@@ -502,9 +572,9 @@ class KokoroEngine:
                 for b, fd in enumerate(forced_durations):
                     forced[b, : Ts[b]] = fd.to(torch.int32)
                 forced = forced.to(dev)
-        idx_cap = Tm * 100
+        idx_cap = Tm * self._dur_cap(bins, float(speed))
         dur, dur_raw, frames, idx = ops.duration_align(logits[:, :, :bins], Tm, B, float(speed), idx_cap, dev, lens=lens_t,
-                                                       forced=forced, bins=bins)
+                                                       forced=forced, bins=bins, max_frames=self.max_frames)
         frames_h = frames.cpu()  # the one host sync of the forward pass (kokoro.py:149-152 syncs per phoneme)
         Fs = [int(v) for v in frames_h]
         return KokoroFront(ids=[ids[b, : Ts[b]] for b in range(B)], ref_s=ref_s, d=[d[b, : Ts[b]] for b in range(B)],
@@ -530,14 +600,12 @@ class KokoroEngine:
             ref_s = st.ref_s.to(device=dev, dtype=torch.float32).contiguous()
             s_dec = ref_s[:, :sty].contiguous()
             s_pred = ref_s[:, sty:].contiguous()
-            gb_dec = self._new(B, 1, self.style_dec.cout)
-            gb_pred = self._new(B, 1, self.style_pred.cout)
-            self._conv(s_dec[:, None, :], self.style_dec, gb_dec)
-            self._conv(s_pred[:, None, :], self.style_pred, gb_pred)
-            gb_dec, gb_pred = gb_dec[:, 0], gb_pred[:, 0]
+            gb_dec = self._style_proj(s_dec, self.style_dec, self.q_style_dec)
+            gb_pred = self._style_proj(s_pred, self.style_pred, self.q_style_pred)
             d = torch.nn.utils.rnn.pad_sequence([t.to(dev) for t in st.d], batch_first=True).contiguous()
             forced = torch.nn.utils.rnn.pad_sequence([t.to(device=dev, dtype=torch.int32) for t in st.dur], batch_first=True).contiguous()
-            dur, _, frames, idx = ops.duration_align(None, Tm, B, st.speed, Tm * 100, dev, lens=lens_t, forced=forced)
+            cap = max(100, max((int(f) for f in st.frames), default=0) // max(Tm, 1) + 1)
+            dur, _, frames, idx = ops.duration_align(None, Tm, B, st.speed, Tm * cap, dev, lens=lens_t, forced=forced)
         Fs = list(st.frames)
         dur_raw = st.trace["dur_raw"] if st.trace else None
         h = st.trace["bert"] if st.trace else None
@@ -552,8 +620,8 @@ class KokoroEngine:
         x0 = self._new(B, Tm, hid)
         ops.gather_rows(self.te_emb, ids, x0, lens=lens_t)
         x1 = self._new(B, Tm, hid)
-        for pc, lw, lb in self.te_cnn:
-            self._conv(x0, pc, x1, pad=(self.te_k - 1) // 2, lens_in=lens_t, lens_out=lens_t)
+        for i, (pc, lw, lb) in enumerate(self.te_cnn):
+            self._convq(f"text_encoder.cnn.{i}.0", x0, pc, x1, pad=(self.te_k - 1) // 2, lens_in=lens_t, lens_out=lens_t)
             ops.layernorm(x1, x0, weight=lw, bias=lb, eps=1e-5, lens=lens_t, post_act=ACT_LEAKY, post_slope=0.2)
         t_en = self._new(B, Tm, hid, zero=True)
         self._bilstm(self.te_lstm, x0, t_en, lens_t)
@@ -570,7 +638,7 @@ class KokoroEngine:
         xs = self._new(B, Fm, hid, zero=True)
         self._bilstm(self.shared, en, xs, lens_f)
         curves = []
-        for blocks, proj in ((self.f0_blocks, self.f0_proj), (self.n_blocks, self.n_proj)):
+        for blocks, proj, proj_n in ((self.f0_blocks, self.f0_proj, "predictor.F0_proj"), (self.n_blocks, self.n_proj, "predictor.N_proj")):
             y0 = self._new(B, Fm, blocks[0].dout)
             self._resblk1d_fwd(blocks[0], xs, gb_pred, y0, lens_f)
             y1 = self._new(B, 2 * Fm, blocks[1].dout)
@@ -578,7 +646,7 @@ class KokoroEngine:
             y2 = self._new(B, 2 * Fm, blocks[2].dout)
             self._resblk1d_fwd(blocks[2], y1, gb_pred, y2, lens_2f)
             curve = self._new(B, 2 * Fm, 1, zero=True)
-            self._conv(y2, proj, curve, lens_in=lens_2f, lens_out=lens_2f)
+            self._convq(proj_n, y2, proj, curve, lens_in=lens_2f, lens_out=lens_2f)
             curves.append(curve[:, :, 0])
         f0_curve, n_curve = curves
         overrides = overrides or {}
@@ -590,25 +658,31 @@ class KokoroEngine:
             assert tuple(n_curve.shape) == (B, 2 * Fm)
 
         # ---- decoder (istftnet.py:981-997)
-        ops.conv1d_c1_k3s2(f0_curve, self.f0_conv[0], self.f0_conv[1], dec_in, hid, lens_in=lens_2f)
-        ops.conv1d_c1_k3s2(n_curve, self.n_conv[0], self.n_conv[1], dec_in, hid + 1, lens_in=lens_2f)
-        c_cat = 1024 + 64 + 2
+        f0_in, n_in = f0_curve, n_curve
+        if self.qmods and self._isq("decoder.F0_conv"):
+            f0_in = ops.fake_quant_u8(f0_curve[:, :, None], y=torch.zeros_like(f0_curve)[:, :, None], lens=lens_2f)[:, :, 0]
+        if self.qmods and self._isq("decoder.N_conv"):
+            n_in = ops.fake_quant_u8(n_curve[:, :, None], y=torch.zeros_like(n_curve)[:, :, None], lens=lens_2f)[:, :, 0]
+        ops.conv1d_c1_k3s2(f0_in, self.f0_conv[0], self.f0_conv[1], dec_in, hid, lens_in=lens_2f)
+        ops.conv1d_c1_k3s2(n_in, self.n_conv[0], self.n_conv[1], dec_in, hid + 1, lens_in=lens_2f)
+        cd, gd, ad = self.cdim, self.gdim, self.adim
+        c_cat = cd + ad + 2
         ca = self._new(B, Fm, round_up(c_cat, 32), zero=True)
         cb = self._new(B, Fm, round_up(c_cat, 32), zero=True)
         trace = {}
-        self._resblk1d_fwd(self.enc_blk, dec_in[:, :, :c_in], gb_dec, ca[:, :, :1024], lens_f)
+        self._resblk1d_fwd(self.enc_blk, dec_in[:, :, :c_in], gb_dec, ca[:, :, :cd], lens_f)
         if return_intermediates:
-            trace.update(dec_in=dec_in[:, :, :c_in].clone(), enc=ca[:, :, :1024].clone())
-        self._conv(asr, self.asr_res, ca[:, :, 1024:1088], lens_in=lens_f, lens_out=lens_f, flatten=True)
-        ca[:, :, 1088:1090].copy_(dec_in[:, :, hid:hid + 2])
-        cb[:, :, 1024:1090].copy_(ca[:, :, 1024:1090])
+            trace.update(dec_in=dec_in[:, :, :c_in].clone(), enc=ca[:, :, :cd].clone())
+        self._convq("decoder.asr_res.0", asr, self.asr_res, ca[:, :, cd:cd + ad], lens_in=lens_f, lens_out=lens_f, flatten=True)
+        ca[:, :, cd + ad:c_cat].copy_(dec_in[:, :, hid:hid + 2])
+        cb[:, :, cd:c_cat].copy_(ca[:, :, cd:c_cat])
         cur, nxt = ca, cb
         for i in range(3):
-            self._resblk1d_fwd(self.dec_blks[i], cur[:, :, :c_cat], gb_dec, nxt[:, :, :1024], lens_f)
+            self._resblk1d_fwd(self.dec_blks[i], cur[:, :, :c_cat], gb_dec, nxt[:, :, :cd], lens_f)
             cur, nxt = nxt, cur
             if return_intermediates:
-                trace[f"dec{i}"] = cur[:, :, :1024].clone()
-        xg = self._new(B, 2 * Fm, 512)
+                trace[f"dec{i}"] = cur[:, :, :cd].clone()
+        xg = self._new(B, 2 * Fm, gd)
         self._resblk1d_fwd(self.dec_blks[3], cur[:, :, :c_cat], gb_dec, xg, lens_f, lens_2f)
 
         # ---- generator (istftnet.py:797-835)
@@ -621,7 +695,9 @@ class KokoroEngine:
             noise = torch.randn((B, L2 * up, 9), generator=gen, device=dev, dtype=torch.float32)
         rand_ini = rand_ini.to(dev).contiguous()
         noise = noise.to(dev).contiguous()
-        har_src = ops.sine_source(f0_curve, rand_ini, noise, self.src_w, self.src_b, up, lens2=lens_2f)
+        g_n = "decoder.generator"
+        har_src = ops.sine_source(f0_curve, rand_ini, noise, self.src_w, self.src_b, up, lens2=lens_2f,
+                                  quant=bool(self.qmods) and self._isq(f"{g_n}.m_source.l_linear"))
         nb2 = self.n_fft + 2
         n_har = L2 * up // self.hop + 1
         har = self._new(B, n_har, nb2)
@@ -641,12 +717,15 @@ class KokoroEngine:
             lens_o = (lens_x * u + (1 if last else 0)) if ragged else None
             # harmonic branch
             xsrc = self._new(B, Lo, cout)
+            har_i = har
+            if self.qmods and self._isq(f"{g_n}.noise_convs.{i}"):  # contiguous copy: the strided noise conv reads its taps as one flat run
+                har_i = ops.fake_quant_u8(har, y=torch.zeros_like(har), lens=lens_har)
             if not last:
                 sf = int(np.prod(self.rates[i + 1:]))
-                self._conv(har, self.noise_convs[i], xsrc, lens_in=lens_har, lens_out=lens_o,
+                self._conv(har_i, self.noise_convs[i], xsrc, lens_in=lens_har, lens_out=lens_o,
                            flat=dict(ldx=sf * nb2, x_off=-((sf + 1) // 2) * nb2, channels=nb2))
             else:
-                self._conv(har, self.noise_convs[i], xsrc, lens_in=lens_har, lens_out=lens_o)
+                self._conv(har_i, self.noise_convs[i], xsrc, lens_in=lens_har, lens_out=lens_o)
             if return_intermediates:
                 trace[f"nconv{i}"] = xsrc.clone()
             xsrc = self._resblock1_fwd(self.noise_res[i], xsrc, gb_dec, lens_o)
@@ -657,8 +736,8 @@ class KokoroEngine:
             xu = self._new(B, Lo, cout)
             lens_gemm = (lens_x + (kp - 1)) if ragged else None
             lens_ct = (lens_x * u) if ragged else None
-            self._conv(x, self.ups[i], xu, pad=kp - 1, lout=L + kp - 1, lens_in=lens_x, lens_out=lens_gemm, pre_act=ACT_LEAKY,
-                       pre_slope=0.1, res=xsrc, up=dict(s=u, p=(k - u) // 2, cout=cout, row_off=1 if last else 0, lout=L * u, lens=lens_ct))
+            self._convq(f"{g_n}.ups.{i}", x, self.ups[i], xu, pad=kp - 1, lout=L + kp - 1, lens_in=lens_x, lens_out=lens_gemm, pre_act=ACT_LEAKY,
+                        pre_slope=0.1, res=xsrc, up=dict(s=u, p=(k - u) // 2, cout=cout, row_off=1 if last else 0, lout=L * u, lens=lens_ct))
             if last:
                 xu[:, 0, :].copy_(xsrc[:, 0, :])  # the zero left-pad row of "reflection_pad" + x_source
             if return_intermediates:
@@ -672,7 +751,7 @@ class KokoroEngine:
             if return_intermediates:
                 trace[f"stage{i}"] = acc.clone()
         post = self._new(B, L, round_up(nb2, 4))
-        self._conv(x, self.conv_post, post[:, :, :nb2], pad=3, lens_in=lens_x, lens_out=lens_x, pre_act=ACT_LEAKY, pre_slope=0.01)
+        self._convq(f"{g_n}.conv_post", x, self.conv_post, post[:, :, :nb2], pad=3, lens_in=lens_x, lens_out=lens_x, pre_act=ACT_LEAKY, pre_slope=0.01)
         audio = self._new(B, (L - 1) * self.hop, zero=True)
         ops.istft_head(post[:, :, :nb2], self.n_fft, self.hop, self.window, audio, lens=lens_x)
         outs = [audio[b, : Fs[b] * 2 * up] for b in range(B)]

@@ -64,9 +64,10 @@ def _bf16(t: torch.Tensor) -> torch.Tensor:
 
 
 class _Gen:
-    def __init__(self, seed: int):
+    def __init__(self, seed: int, alpha_sep: str = "."):
         self.g = torch.Generator().manual_seed(seed)
         self.w: Dict[str, torch.Tensor] = {}
+        self.alpha_sep = alpha_sep  # "." = Kokoro's list (alpha1.0); "_" = KittenTTS's attributes (alpha1_0)
 
     def normal(self, name, shape, std=1.0, mean=0.0):
         self.w[name] = _bf16(torch.randn(shape, generator=self.g) * std + mean)
@@ -125,13 +126,16 @@ class _Gen:
             self.conv_weighted(f"{pre}.convs2.{i}", ch, k, ch)
             self.adain(f"{pre}.adain1.{i}", style, ch)
             self.adain(f"{pre}.adain2.{i}", style, ch)
-            self.normal(f"{pre}.alpha1.{i}", (1, ch, 1), 0.15, 1.0)
-            self.normal(f"{pre}.alpha2.{i}", (1, ch, 1), 0.15, 1.0)
+            self.normal(f"{pre}.alpha1{self.alpha_sep}{i}", (1, ch, 1), 0.15, 1.0)
+            self.normal(f"{pre}.alpha2{self.alpha_sep}{i}", (1, ch, 1), 0.15, 1.0)
 
 
-def make_kokoro_weights(config: dict = None, seed: int = 0) -> Dict[str, torch.Tensor]:
+def make_kokoro_weights(config: dict = None, seed: int = 0, decoder_dims=(1024, 512, 64), alpha_sep: str = ".") -> Dict[str, torch.Tensor]:
+    """``decoder_dims`` = (decoder block width, generator input width, asr_res width): Kokoro's constants (istftnet.py:948-975);
+    KittenTTS reads them from its config (mlx_audio_amd/tts/models/kitten_tts/synthetic.py)."""
     cfg = config or KOKORO_CONFIG
-    g = _Gen(seed)
+    g = _Gen(seed, alpha_sep)
+    cd, gd, ad = decoder_dims
     pb, hid, sty = cfg["plbert"], cfg["hidden_dim"], cfg["style_dim"]
     H, emb = pb["hidden_size"], pb.get("embedding_size", 128)
     # ---- PL-BERT (CustomAlbert)
@@ -175,13 +179,13 @@ def make_kokoro_weights(config: dict = None, seed: int = 0) -> Dict[str, torch.T
     g.lstm("text_encoder.lstm", hid, hid // 2)
     # ---- decoder
     ist = cfg["istftnet"]
-    g.adain_resblk1d("decoder.encode", hid + 2, 1024, sty)
+    g.adain_resblk1d("decoder.encode", hid + 2, cd, sty)
     for i in range(3):
-        g.adain_resblk1d(f"decoder.decode.{i}", 1024 + 2 + 64, 1024, sty)
-    g.adain_resblk1d("decoder.decode.3", 1024 + 2 + 64, 512, sty, upsample=True)
+        g.adain_resblk1d(f"decoder.decode.{i}", cd + 2 + ad, cd, sty)
+    g.adain_resblk1d("decoder.decode.3", cd + 2 + ad, gd, sty, upsample=True)
     g.conv_weighted("decoder.F0_conv", 1, 3, 1, gain=0.02)   # keeps the F0 channel O(1)
     g.conv_weighted("decoder.N_conv", 1, 3, 1)
-    g.conv_weighted("decoder.asr_res.0", 64, 1, 512)
+    g.conv_weighted("decoder.asr_res.0", ad, 1, hid)
     gen = "decoder.generator"
     g.normal(f"{gen}.m_source.l_linear.weight", (1, 9), 1.0)
     g.normal(f"{gen}.m_source.l_linear.bias", (1,), 0.02)

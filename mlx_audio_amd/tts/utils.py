@@ -11,6 +11,8 @@ MODEL_REMAPPING = {
     "kokoro": "kokoro",
     "kokoro_82m": "kokoro",
     "styletts2": "kokoro",
+    "kitten": "kitten_tts",
+    "kitten_tts": "kitten_tts",
     "qwen3_tts": "qwen3_tts",
     "csm": "sesame",
     "marvis": "sesame",

@@ -83,15 +83,47 @@ def conv_transpose1d_mlx(x: Tensor, w: Tensor, b: Optional[Tensor], stride=1, pa
     return y
 
 
+FQ_MARGINS: Optional[list] = None  # a test may bind a list here: every fake-quant call then records its smallest rounding margin
+
+
+def fake_quant_dynamic_u8(x: Tensor) -> Tensor:
+    """Per-tensor dynamic uint8 fake quantisation (kitten_tts/quant.py:4-20), float32 like the reference (``x.astype(mx.float32)``)."""
+    dt = x.dtype
+    xf = x.to(torch.float32)
+    zero = torch.zeros((), dtype=torch.float32)
+    x_min = torch.minimum(xf.min(), zero)
+    x_max = torch.maximum(xf.max(), zero)
+    scale = (x_max - x_min) / 255.0
+    if float(scale) == 0.0:
+        return torch.zeros_like(x)
+    zp = torch.clamp(torch.round(-x_min / scale), 0.0, 255.0)
+    pos = xf / scale + zp
+    if FQ_MARGINS is not None:  # distance of the closest element from a rounding boundary, in grid steps (tests: margin rule)
+        FQ_MARGINS.append(float(((pos - torch.floor(pos)) - 0.5).abs().min()))
+    q = torch.clamp(torch.round(pos), 0.0, 255.0)
+    return ((q - zp) * scale).to(dt)
+
+
 class P:
     """Flat parameter dictionary with prefix navigation (MLX post-``sanitize`` names)."""
 
     def __init__(self, weights: Dict[str, Tensor], prefix: str = "", dtype=torch.float32,
-                 param_dtype=torch.bfloat16):
+                 param_dtype=torch.bfloat16, quant_modules=()):
         self.w, self.prefix, self.dtype, self.param_dtype = weights, prefix, dtype, param_dtype
+        self.quant_modules = tuple(quant_modules)
 
     def sub(self, name) -> "P":
-        return P(self.w, f"{self.prefix}{name}.", self.dtype, self.param_dtype)
+        return P(self.w, f"{self.prefix}{name}.", self.dtype, self.param_dtype, self.quant_modules)
+
+    @property
+    def quant(self) -> bool:
+        """KittenTTS only: does the module at this prefix carry ``activation_quant``?  The reference flags a module when a listed name is
+        the module itself or lies below it (kitten_tts.py:291-299); Kokoro never lists any."""
+        name = self.prefix[:-1]
+        return bool(name) and any(q == name or q.startswith(name + ".") for q in self.quant_modules)
+
+    def fq(self, x: Tensor) -> Tensor:
+        return fake_quant_dynamic_u8(x) if self.quant else x
 
     def has(self, name) -> bool:
         return f"{self.prefix}{name}" in self.w
@@ -113,6 +145,7 @@ class P:
 def conv_weighted(p: P, x: Tensor, transpose: bool = False, **kw) -> Tensor:
     """ConvWeighted.__call__ (istftnet.py:128-170) on NCL input."""
     w = p.wn()
+    x = p.fq(x)  # kitten_tts/istftnet.py:131
     groups = kw.get("groups", 1)
     if transpose:
         if groups == 1:
@@ -145,7 +178,7 @@ def leaky_relu(x: Tensor, slope: float) -> Tensor:
 # ------------------------------------------------------------------ AdaIN blocks
 def adain1d(p: P, x: Tensor, s: Tensor) -> Tensor:
     """AdaIN1d (istftnet.py:326-338): (1+gamma)*InstanceNorm(x)+beta, biased var, eps 1e-5."""
-    h = linear(p.sub("fc"), s).unsqueeze(2)
+    h = linear(p.sub("fc"), p.fq(s)).unsqueeze(2)  # kitten_tts/istftnet.py:336
     gamma, beta = h.chunk(2, dim=1)
     mean = x.mean(dim=2, keepdim=True)
     var = x.var(dim=2, keepdim=True, unbiased=False)
@@ -157,14 +190,19 @@ def snake(x: Tensor, alpha: Tensor) -> Tensor:
     return x + (1 / alpha) * (torch.sin(alpha * x) ** 2)
 
 
+def _alpha(p: P, which: int, i: int) -> Tensor:
+    """Snake parameters: a list in Kokoro (``alpha1.0``, istftnet.py:374), per-index attributes in KittenTTS (``alpha1_0``, kitten_tts/istftnet.py:379-384)."""
+    return p(f"alpha{which}.{i}") if p.has(f"alpha{which}.{i}") else p(f"alpha{which}_{i}")
+
+
 def adain_resblock1(p: P, x: Tensor, s: Tensor, kernel: int, dilations=(1, 3, 5)) -> Tensor:
     """AdaINResBlock1 (istftnet.py:341-396)."""
     for i, d in enumerate(dilations):
         xt = adain1d(p.sub(f"adain1.{i}"), x, s)
-        xt = snake(xt, p(f"alpha1.{i}"))
+        xt = snake(xt, _alpha(p, 1, i))
         xt = conv_weighted(p.sub(f"convs1.{i}"), xt, padding=(kernel * d - d) // 2, dilation=d)
         xt = adain1d(p.sub(f"adain2.{i}"), xt, s)
-        xt = snake(xt, p(f"alpha2.{i}"))
+        xt = snake(xt, _alpha(p, 2, i))
         xt = conv_weighted(p.sub(f"convs2.{i}"), xt, padding=(kernel - 1) // 2, dilation=1)
         x = xt + x
     return x
@@ -194,7 +232,7 @@ def bilstm(p: P, x: Tensor) -> Tensor:
     for direction in ("forward", "backward"):
         wx, wh = p(f"Wx_{direction}"), p(f"Wh_{direction}")
         bias = p(f"bias_ih_{direction}") + p(f"bias_hh_{direction}")
-        xp = x @ wx.t() + bias
+        xp = p.fq(x) @ wx.t() + bias  # kitten_tts/modules.py:155,201
         bsz, L, _ = x.shape
         hdim = wh.shape[1]
         h = x.new_zeros(bsz, hdim)
@@ -202,7 +240,7 @@ def bilstm(p: P, x: Tensor) -> Tensor:
         seq = [None] * L
         order = range(L) if direction == "forward" else range(L - 1, -1, -1)
         for t in order:
-            gates = xp[:, t, :] + h @ wh.t()
+            gates = xp[:, t, :] + p.fq(h) @ wh.t()  # kitten_tts/modules.py:178,224 (the emitted h stays unquantised)
             i, f, g, o = gates.chunk(4, dim=-1)
             i, f, g, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
             c = f * c + i * g
@@ -256,7 +294,7 @@ def text_encoder(p: P, input_ids: Tensor, n_layer: int) -> Tensor:
 
 def ada_layer_norm(p: P, x: Tensor, s: Tensor) -> Tensor:
     """AdaLayerNorm (modules.py:71-90): x [B, T, C], s [B, style]."""
-    h = linear(p.sub("fc"), s)
+    h = linear(p.sub("fc"), p.fq(s))  # kitten_tts/modules.py:80
     gamma, beta = h.chunk(2, dim=1)
     xn = layer_norm(x, None, None, 1e-5)
     return (1 + gamma[:, None, :]) * xn + beta[:, None, :]
@@ -310,6 +348,8 @@ def sine_source(p: P, f0_frames: Tensor, rand_ini: np.ndarray, noise: np.ndarray
     noise_amp = (uv * f32(noise_std) + (f32(1) - uv) * f32(sine_amp) / f32(3)).astype(f32)
     nz = (noise_amp * np.asarray(noise, dtype=f32)).astype(f32)
     sw = (sines * uv + nz).astype(f32)
+    if p.sub("m_source.l_linear").quant:  # kitten_tts/istftnet.py:711-713
+        sw = np.stack([fake_quant_dynamic_u8(torch.from_numpy(row)).numpy() for row in sw], axis=0)
     w = p("m_source.l_linear.weight").to(torch.float32).numpy()  # [1, H]
     b = p("m_source.l_linear.bias").to(torch.float32).numpy()
     merged = np.tanh((sw @ w.T.astype(f32) + b.astype(f32)).astype(f32)).astype(f32)
@@ -361,10 +401,10 @@ def generator(p: P, x: Tensor, s: Tensor, f0_curve: Tensor, cfg: dict, rand_ini,
         wk = nc.raw("weight").shape[1]
         if i + 1 < len(rates):
             stride_f0 = int(np.prod(rates[i + 1:]))
-            xs = conv1d_mlx(har, nc("weight"), nc("bias"), stride=stride_f0, padding=(stride_f0 + 1) // 2)
+            xs = conv1d_mlx(nc.fq(har), nc("weight"), nc("bias"), stride=stride_f0, padding=(stride_f0 + 1) // 2)  # fq: kitten_tts/istftnet.py:815-818
             nres_k = 7
         else:
-            xs = conv1d_mlx(har, nc("weight"), nc("bias"))
+            xs = conv1d_mlx(nc.fq(har), nc("weight"), nc("bias"))
             nres_k = 11
         assert wk == (stride_f0 * 2 if i + 1 < len(rates) else 1)
         if trace is not None:
