@@ -42,7 +42,7 @@ def parse():
                          "MI355X: 122 M samples/s at 32, 140 M at 64, 146 M at 128, 150 M at 256 -- the front end's latency-bound LSTMs amortise)")
     ap.add_argument("--precision", type=int, default=2,
                     help="2 = bf16 hi+lo split MFMA (fp32-grade), 3 = single fp16 pass in the vocoder, 1 = single bf16 pass")
-    ap.add_argument("--config", choices=["kokoro", "whisper", "qwen3", "csm"], default="kokoro",
+    ap.add_argument("--config", choices=["kokoro", "whisper", "qwen3", "csm", "kitten"], default="kokoro",
                     help="kokoro = the headline line (BASELINE config[1]); whisper / qwen3 / csm = the secondary lines of SURVEY 8d (BASELINE configs\n"
                          "[2] / [3] / [4]) with the same JSON schema (tools/bench_{whisper,qwen3,csm}.py run in-process, 1 GPU)")
     ap.add_argument("--ragged", action="store_true",

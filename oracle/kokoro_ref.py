@@ -84,12 +84,17 @@ def conv_transpose1d_mlx(x: Tensor, w: Tensor, b: Optional[Tensor], stride=1, pa
 
 
 FQ_MARGINS: Optional[list] = None  # a test may bind a list here: every fake-quant call then records its smallest rounding margin
+FQ_JITTER: Optional[tuple] = None  # (relative amplitude, torch.Generator): tests perturb every quantiser input by that much gaussian noise to
+#                                    measure how far ordinary rounding noise of that size moves the network's outputs (grid steps flip)
 
 
 def fake_quant_dynamic_u8(x: Tensor) -> Tensor:
     """Per-tensor dynamic uint8 fake quantisation (kitten_tts/quant.py:4-20), float32 like the reference (``x.astype(mx.float32)``)."""
     dt = x.dtype
     xf = x.to(torch.float32)
+    if FQ_JITTER is not None:
+        amp, gen = FQ_JITTER
+        xf = xf * (1.0 + amp * torch.randn(xf.shape, generator=gen))
     zero = torch.zeros((), dtype=torch.float32)
     x_min = torch.minimum(xf.min(), zero)
     x_max = torch.maximum(xf.max(), zero)

@@ -7,8 +7,9 @@ Two regimes:
   * with the converter's module list (every conv / linear / LSTM input goes through ``fake_quant_dynamic_u8``): quantisation ROUNDS, so an fp32
     rounding difference upstream flips a grid step (1/255 of the tensor's range) in a few elements and the flips feed the next layer.  The
     kernels themselves are held to exact statements (bit-exact quantiser; LSTM under the margin rule); the network is held to the oracle's own
-    sensitivity: the fp32 oracle and the same oracle with float64 activations differ by ~1 % relative RMS at the decoder output for exactly
-    this reason (measured in the test), and the HIP path has to be as close to the fp32 oracle as a small multiple of that.
+    sensitivity to rounding noise of the HIP path's size (1e-6 relative at every quantiser input): that alone moves the oracle's decoder output
+    by a few per cent relative RMS (measured in the test), and the HIP path has to be as close to the un-perturbed oracle as a small multiple
+    of that.
 """
 import json
 
@@ -257,47 +258,61 @@ def quant():
     cfg = KS.tiny_config()
     w = KS.make_kitten_weights(cfg, seed=11)
     cfg = dict(cfg, activation_quant_modules=KS.converter_quant_modules(w))
-    return cfg, w, KittenEngine(w, cfg), KittenRef(w, cfg, dtype=torch.float32), KittenRef(w, cfg, dtype=torch.float64)
+    return cfg, w, KittenEngine(w, cfg), KittenRef(w, cfg, dtype=torch.float32)
 
 
 def test_kitten_with_activation_quantisation(quant):
+    """Network-level statement under dynamic quantisation.  Reference point: the fp32 oracle.  Yardstick: the same oracle with every quantiser
+    input perturbed by 1e-6 relative gaussian noise (``oracle.kokoro_ref.FQ_JITTER``) -- the size of the HIP path's per-layer rounding error
+    (bf16 hi+lo split products, fp32 accumulation; the un-quantised tests above hold it to 5e-4 end to end).  Such noise is invisible without
+    quantisation (1e-6) but flips grid steps with it: the jittered oracles land anywhere between 1e-7 and a few 1e-2 of the un-jittered one,
+    depending on whether a flip happened upstream (printed).  The HIP path must be within 4x the worst of four jittered oracles (+ a floor)."""
     from mlx_audio_amd.tts.models.kokoro import synthetic as S
+    from oracle import kokoro_ref as K
 
-    cfg, w, eng, r32, r64 = quant
+    cfg, w, eng, r32 = quant
     assert eng.q_style_dec and eng.q_style_pred and eng.te_lstm.q and eng._isq("bert.encoder") and not eng._isq("bert.embeddings")
     ids = S.make_phoneme_ids(14, seed=5)
     ref_s = S.make_voice_pack()[len(ids) - 3]
     pd, d, raw = r32.durations(ids, ref_s)
-    pd64, _, raw64 = r64.durations(ids, ref_s)
     F = int(pd.sum())
     ri, nz = _noise(F, 7)
     a32, _, t32 = r32.forward(ids, ref_s, rand_ini=ri, noise=nz, pred_dur=pd, return_intermediates=True)
-    a64, _, t64 = r64.forward(ids, ref_s, rand_ini=ri, noise=nz, pred_dur=pd, return_intermediates=True, f0_override=t32["f0"], n_override=t32["n"])
+    ens = []
+    try:
+        for seed in range(4):
+            K.FQ_JITTER = (1e-6, torch.Generator().manual_seed(seed))
+            dj = r32.durations(ids, ref_s)
+            aj, _, tj = r32.forward(ids, ref_s, rand_ini=ri, noise=nz, pred_dur=pd, return_intermediates=True, f0_override=t32["f0"], n_override=t32["n"])
+            ens.append(dict(tj, audio=aj, d_free=dj[1], raw=dj[2]))
+    finally:
+        K.FQ_JITTER = None
     # free-running front end
     outs, durs, tg = eng.forward([ids], ref_s, rand_ini=torch.from_numpy(ri), noise=torch.from_numpy(nz), return_intermediates=True)
     torch.cuda.synchronize()
     raw_err = float((tg["dur_raw"][0, : len(ids)].cpu() - raw).abs().max())
+    raw_own = max(float((e["raw"] - raw).abs().max()) for e in ens)
     clear = ((raw - torch.floor(raw)) - 0.5).abs() > max(5 * raw_err, 1e-3)
-    print(f"kitten quantised: raw duration err {raw_err:.2e} (oracle fp32 vs fp64: {float((raw - raw64).abs().max()):.2e}), "
-          f"{int(clear.sum())}/{len(ids)} durations clear of a boundary")
-    assert raw_err < 0.05 and torch.equal(durs[0].cpu()[clear], pd[clear])
+    print(f"kitten quantised: raw duration err {raw_err:.2e} (jittered oracles: {raw_own:.2e}), {int(clear.sum())}/{len(ids)} durations clear of a boundary")
+    assert raw_err <= 4 * raw_own + 0.02 and torch.equal(durs[0].cpu()[clear], pd[clear])
 
-    def bar(key, a, b32, b64, floor):
-        mine, own = rel_rms(a, b32), rel_rms(b64, b32)
-        print(f"  {key:8s} HIP vs fp32 oracle {mine:.3e}   fp64 vs fp32 oracle {own:.3e}")
-        assert mine <= 4 * own + floor, (key, mine, own)
+    def bar(key, a, b32, own_key, floor, tr=lambda t: t):
+        mine = rel_rms(a, b32)
+        own = [rel_rms(tr(e[own_key]), b32) for e in ens]
+        print(f"  {key:8s} HIP vs fp32 oracle {mine:.3e}   jittered oracles vs fp32 oracle {' '.join(f'{o:.1e}' for o in own)}")
+        assert mine <= 4 * max(own) + floor, (key, mine, own)
 
-    if torch.equal(durs[0].cpu(), pd):
-        bar("d", tg["d"][0], t32["d"][0], r64.durations(ids, ref_s)[1][0], 2e-3)
-    # frame-rate half on the oracle's durations, F0 / N / harmonic features injected (both oracles saw the same ones)
+    bar("d", tg["d"][0], t32["d"][0], "d_free", 5e-3, lambda t: t[0])
+    # frame-rate half on the oracle's durations, F0 / N / harmonic features injected (every oracle run saw the same ones)
     outs, _, tg = eng.forward([ids], ref_s, forced_durations=[pd], rand_ini=torch.from_numpy(ri), noise=torch.from_numpy(nz),
                               overrides=dict(f0=t32["f0"], n=t32["n"], har=t32["har"].transpose(1, 2)), return_intermediates=True)
     torch.cuda.synchronize()
-    bar("asr", tg["asr"][0], t32["asr"][0].transpose(0, 1), t64["asr"][0].transpose(0, 1), 2e-3)
-    bar("dec3", tg["dec3"][0], t32["dec3"][0].transpose(0, 1), t64["dec3"][0].transpose(0, 1), 5e-3)
-    bar("stage0", tg["stage0"][0], t32["stage0"][0].transpose(0, 1), t64["stage0"][0].transpose(0, 1), 5e-3)
-    bar("post", tg["post"][0], t32["post"][0].transpose(0, 1), t64["post"][0].transpose(0, 1), 5e-3)
-    bar("audio", outs[0], a32[0], a64[0], 1e-2)
+    nlc = lambda t: t[0].transpose(0, 1)
+    bar("asr", tg["asr"][0], nlc(t32["asr"]), "asr", 5e-3, nlc)
+    bar("dec3", tg["dec3"][0], nlc(t32["dec3"]), "dec3", 5e-3, nlc)
+    bar("stage0", tg["stage0"][0], nlc(t32["stage0"]), "stage0", 5e-3, nlc)
+    bar("post", tg["post"][0], nlc(t32["post"]), "post", 5e-3, nlc)
+    bar("audio", outs[0], a32[0], "audio", 1e-2, lambda t: t[0])
 
 
 def test_kitten_quantised_batch_equals_single(quant):
@@ -306,7 +321,7 @@ def test_kitten_quantised_batch_equals_single(quant):
     statement is statistical: durations equal, waveforms within 2 % relative RMS."""
     from mlx_audio_amd.tts.models.kokoro import synthetic as S
 
-    cfg, w, eng, r32, _ = quant
+    cfg, w, eng, r32 = quant
     voice = S.make_voice_pack()
     idl = [S.make_phoneme_ids(n, seed=20 + n) for n in (9, 17, 5)]
     refs = torch.cat([voice[len(i) - 3] for i in idl], 0)
