@@ -310,6 +310,8 @@ typedef struct {
   float* out; int32_t ld_out;
   float* quant_ws;  /* nullable [B, 2] scratch: when given, sine_wavs [L, H] goes through fake_quant_dynamic_u8 (per utterance) before l_linear
                      * (KittenTTS with activation_quant on m_source.l_linear, kitten_tts/istftnet.py:711-713) */
+  int32_t coarse_f32; /* 1: coarse-grid length = ceil(L * float32(1 / up)) = L2 + 1 (KittenTTS hands interpolate() a float32 scale factor,
+                       * kitten_tts/istftnet.py:572,595-599); 0: ceil(L * (1.0 / up)) in doubles (Kokoro, istftnet.py:567,590-594) */
 } mi355_sine_source_args;
 int mi355_sine_source(const mi355_sine_source_args* a, void* stream);
 

@@ -37,10 +37,13 @@ struct SineDims { int L; int small; int big; float sc_dn, hsc_dn, sc_up, hsc_up;
 
 // tts/models/interpolate.py:41-50: size = max(1, ceil(float(W) * float(scale))) evaluated in doubles;
 // 600*F*(1/300) overshoots for some F (e.g. F = 7 -> 15 coarse steps), so this must be exact.
-__host__ __device__ inline SineDims sine_dims(int len2, int up) {
+// coarse_f32 (KittenTTS): its SineGen keeps upsample_scale as an mx.array, so the scale factor 1 / upsample_scale reaches interpolate() as a
+// float32 (0.0033333334 for 300) and float(W) * float(scale) lands just above 2F: the coarse grid ALWAYS has 2F + 1 points there
+// (kitten_tts/istftnet.py:572,595-599), against 2F (mostly) with Kokoro's python double.
+__host__ __device__ inline SineDims sine_dims(int len2, int up, int coarse_f32) {
   SineDims d;
   d.L = len2 * up;
-  const double s_dn = (double)d.L * (1.0 / (double)up);
+  const double s_dn = (double)d.L * (coarse_f32 ? (double)(1.0f / (float)up) : (1.0 / (double)up));
   d.small = (int)ceil(s_dn); if (d.small < 1) d.small = 1;
   d.big = (int)ceil((double)d.small * (double)up); if (d.big < 1) d.big = 1;
   d.sc_dn = (float)((double)d.L / (double)d.small);
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(256) void sine_phase_kernel(const mi355_sine_source
   extern __shared__ __attribute__((aligned(16))) float vterm[];  // [H][kPhaseChunk]
   const int b = blockIdx.x, tid = threadIdx.x;
   const int len2 = a.lens2 ? a.lens2[b] : a.L2;
-  const SineDims d = sine_dims(len2, a.up);
+  const SineDims d = sine_dims(len2, a.up, a.coarse_f32);
   const int L = d.L;
   const int small = min(d.small, a.L2 + 1);
   const float* f0 = a.f0 + (int64_t)b * a.ld_f0;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256) void sine_merge_kernel(const mi355_sine_source
   const int t0 = blockIdx.x * 256, tid = threadIdx.x, b = blockIdx.y;
   const int t = t0 + tid;
   const int len2 = a.lens2 ? a.lens2[b] : a.L2;
-  const SineDims d = sine_dims(len2, a.up);
+  const SineDims d = sine_dims(len2, a.up, a.coarse_f32);
   const int L = d.L;
   if (t0 >= L) return;
   {
@@ -537,7 +540,7 @@ extern "C" int mi355_sine_source(const mi355_sine_source_args* ap, void* stream)
   MI355_REQUIRE(ap && ap->f0 && ap->rand_ini && ap->noise && ap->lin_w && ap->phase_ws && ap->out, "sine_source: null tensor");
   const mi355_sine_source_args a = *ap;
   MI355_REQUIRE(a.H > 0 && a.H <= 64 && a.up > 0 && a.L2 > 0 && a.B > 0, "sine_source: bad shape");
-  const SineDims d = sine_dims(a.L2, a.up);
+  const SineDims d = sine_dims(a.L2, a.up, a.coarse_f32);
   MI355_REQUIRE(d.small <= a.L2 + 1, "sine_source: coarse length %d exceeds workspace", d.small);
   hipStream_t st = (hipStream_t)stream;
   MI355_CLEAR_ERROR();

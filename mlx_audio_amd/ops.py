@@ -642,7 +642,8 @@ def conv1d_c1_k3s2(x: torch.Tensor, w3, bias: float, y: torch.Tensor, col: int, 
 
 # --------------------------------------------------------------------------------------- source / stft heads
 def sine_source(f0: torch.Tensor, rand_ini: torch.Tensor, noise: torch.Tensor, lin_w: torch.Tensor, lin_b: float, up: int,
-                lens2=None, sr: float = 24000.0, sine_amp: float = 0.1, noise_std: float = 0.003, voiced_thr: float = 10.0, quant: bool = False):
+                lens2=None, sr: float = 24000.0, sine_amp: float = 0.1, noise_std: float = 0.003, voiced_thr: float = 10.0, quant: bool = False,
+                coarse_f32: bool = False):
     B, L2 = f0.shape
     H = rand_ini.shape[1]
     assert f0.stride(1) == 1 and noise.is_contiguous() and tuple(noise.shape) == (B, L2 * up, H)
@@ -652,7 +653,7 @@ def sine_source(f0: torch.Tensor, rand_ini: torch.Tensor, noise: torch.Tensor, l
                      lens2=_ptr(lens2), B=B, up=up, H=H, sr=sr, sine_amp=sine_amp, noise_std=noise_std, voiced_thr=voiced_thr,
                      rand_ini=_ptr(rand_ini), noise=_ptr(noise), lin_w=_ptr(lin_w), lin_b=lin_b, phase_ws=_ptr(ws),
                      out=_ptr(out), ld_out=out.stride(0),
-                     quant_ws=_ptr(torch.empty((B, 2), dtype=torch.float32, device=f0.device)) if quant else None)
+                     quant_ws=_ptr(torch.empty((B, 2), dtype=torch.float32, device=f0.device)) if quant else None, coarse_f32=int(bool(coarse_f32)))
     return out
 
 

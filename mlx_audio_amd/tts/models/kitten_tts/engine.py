@@ -6,7 +6,10 @@ The reference's KittenTTS (``tts/models/kitten_tts/``) is its Kokoro port re-par
     fixed 1024 / 512 / 64 (kokoro/istftnet.py:948-975); the LSTMs are ``hidden_dim // 2`` wide (the 32 / 64 / 128 / 256 instantiations of
     ``mi355_lstm_bidir``);
   * ALBERT's FFN uses the ONNX tanh-GELU (kitten_tts.py:244-263), the Snake parameters are per-index attributes ``alpha1_0`` ...
-    (kitten_tts/istftnet.py:379-384), predicted durations are clipped from below only (kitten_tts.py:398);
+    (kitten_tts/istftnet.py:379-384), predicted durations are clipped from below only (kitten_tts.py:398); the harmonic source's coarse phase
+    grid has 2F + 1 points instead of Kokoro's 2F, because ``SineGen.upsample_scale`` stays an mx.array there and ``1 / upsample_scale`` reaches
+    ``interpolate`` as the float32 0.0033333334 (kitten_tts/istftnet.py:572,595-599) -- found by running the reference's own files
+    (tests/golden/make_reference_fixtures.py);
   * the modules listed in ``activation_quant_modules`` see ``fake_quant_dynamic_u8`` of their input (kitten_tts/quant.py): per-tensor min / max ->
     uint8 grid -> back to float.  That needs the tensor's extrema before its first use, so a flagged conv cannot fuse its AdaIN / Snake
     prologue: ``KokoroEngine._convq`` materialises and quantises the input with ``mi355_fake_quant_u8`` and runs the conv without prologue;
@@ -31,6 +34,7 @@ class KittenEngine(KokoroEngine):
     ffn_act = ACT_GELU_TANH
     alpha_name = "alpha{w}_{i}"
     max_frames = -1  # mx.clip(mx.round(duration), a_min=1, a_max=None)
+    coarse_f32 = True  # SineGen.upsample_scale stays an mx.array: 1 / upsample_scale is a float32 -> the coarse phase grid has 2F + 1 points
 
     def _decoder_dims(self, config: dict):
         cd = int(config["max_conv_dim"])

@@ -164,6 +164,7 @@ class KokoroEngine:
     ffn_act = ACT_GELU        # nn.GELU (modules.py:571)
     alpha_name = "alpha{w}.{i}"
     max_frames = 0            # clip(round(dur), 1, 100) (kokoro.py:145-147)
+    coarse_f32 = False        # SineGen's coarse phase grid: ceil(L * (1 / up)) in doubles (istftnet.py:567,590-594)
 
     def _decoder_dims(self, config: dict):
         """(width of the decoder blocks, generator input width, asr_res width): fixed in Kokoro (istftnet.py:948-975)."""
@@ -697,7 +698,7 @@ class KokoroEngine:
         noise = noise.to(dev).contiguous()
         g_n = "decoder.generator"
         har_src = ops.sine_source(f0_curve, rand_ini, noise, self.src_w, self.src_b, up, lens2=lens_2f,
-                                  quant=bool(self.qmods) and self._isq(f"{g_n}.m_source.l_linear"))
+                                  quant=bool(self.qmods) and self._isq(f"{g_n}.m_source.l_linear"), coarse_f32=self.coarse_f32)
         nb2 = self.n_fft + 2
         n_har = L2 * up // self.hop + 1
         har = self._new(B, n_har, nb2)

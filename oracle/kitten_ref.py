@@ -9,7 +9,8 @@ fake quantisation* of the inputs of the modules listed in ``activation_quant_mod
   * ``tts/models/kitten_tts/quant.py:4-24``          fake_quant_dynamic_u8 (oracle.kokoro_ref.fake_quant_dynamic_u8)
   * ``tts/models/kitten_tts/modules.py``             quant sites :19 (LinearNorm), :80 (AdaLayerNorm), :155/:178/:201/:224 (LSTM), :371/:380 (F0 / N proj)
   * ``tts/models/kitten_tts/istftnet.py``            quant sites :131 (ConvWeighted), :336 (AdaIN1d), :711 (l_linear), :815 (noise_convs);
-                                                     per-index Snake parameters :379-384; no phase unwrap :524-527 (the identity for |phase| <= 1)
+                                                     per-index Snake parameters :379-384; no phase unwrap :524-527 (the identity for |phase| <= 1);
+                                                     SineGen keeps ``upsample_scale`` as an mx.array :572, so its coarse phase grid has 2F + 1 points
 
 Everything that is the same module as Kokoro's is ``oracle.kokoro_ref``'s function, called with a parameter view that carries the quantised-module
 list (``P.quant`` implements the reference's flag rule); the quantisation hooks there are inert for Kokoro.
@@ -136,7 +137,7 @@ class KittenRef:
                 rand_ini = rng.uniform(size=(1, 9)).astype(np.float32)
                 noise = rng.standard_normal((1, 2 * Fr * up, 9)).astype(np.float32)
             trace = {} if return_intermediates else None
-            audio = K.decoder(p.sub("decoder"), asr, f0, nn_, ref_s[:, :128], cfg["istftnet"], rand_ini, noise, trace)[0]
+            audio = K.decoder(p.sub("decoder"), asr, f0, nn_, ref_s[:, :128], cfg["istftnet"], rand_ini, noise, trace, coarse_f32=True)[0]
             if return_intermediates:
                 return audio, pred_dur, dict(d=d, en=en, f0=f0, n=nn_, asr=asr, raw_dur=raw, **trace)
             return audio, pred_dur

@@ -320,7 +320,7 @@ def duration_encoder(p: P, d_en: Tensor, s: Tensor, n_layer: int) -> Tensor:
 # ------------------------------------------------------------------ source module / STFT head
 def sine_source(p: P, f0_frames: Tensor, rand_ini: np.ndarray, noise: np.ndarray,
                 upsample: int = 300, sr: int = 24000, harmonics: int = 9,
-                sine_amp: float = 0.1, noise_std: float = 0.003, voiced_thr: float = 10.0) -> np.ndarray:
+                sine_amp: float = 0.1, noise_std: float = 0.003, voiced_thr: float = 10.0, coarse_f32: bool = False) -> np.ndarray:
     """f0 nearest-upsample + SineGen + tanh(Linear) (istftnet.py:548-709,797-799).
 
     f0_frames [B, 2F] -> har_source [B, L=2F*upsample] (float32, numpy).
@@ -337,7 +337,9 @@ def sine_source(p: P, f0_frames: Tensor, rand_ini: np.ndarray, noise: np.ndarray
     ini[:, 0] = 0
     rad[:, 0, :] = (rad[:, 0, :] + ini).astype(f32)
     rad_t = rad.transpose(0, 2, 1)
-    small = interp_ref.output_size(L, scale_factor=1 / upsample)
+    # KittenTTS keeps upsample_scale as an mx.array: ``1 / upsample_scale`` is then a float32 (0.0033333334 for 300) and the coarse grid always has
+    # 2F + 1 points (kitten_tts/istftnet.py:572,595-599); Kokoro casts to int first and divides in python doubles (istftnet.py:567)
+    small = interp_ref.output_size(L, scale_factor=float(np.float32(1.0) / np.float32(upsample)) if coarse_f32 else 1 / upsample)
     rad_ds = interp_ref.interpolate1d(rad_t, small, "linear")  # [B, H, small]
     phase = (np.cumsum(rad_ds, axis=2, dtype=f32) * f32(2.0)).astype(f32)
     phase = (phase * f32(np.pi)).astype(f32)  # (cumsum * 2) * mx.pi, left to right
@@ -389,13 +391,13 @@ def istft_head(x: Tensor, n_fft: int, hop: int) -> Tensor:
     return torch.from_numpy(np.stack(outs, axis=0))[:, None, :]
 
 
-def generator(p: P, x: Tensor, s: Tensor, f0_curve: Tensor, cfg: dict, rand_ini, noise, trace=None) -> Tensor:
+def generator(p: P, x: Tensor, s: Tensor, f0_curve: Tensor, cfg: dict, rand_ini, noise, trace=None, coarse_f32: bool = False) -> Tensor:
     """Generator.__call__ (istftnet.py:797-835).  ``trace`` (dict) collects stage outputs for tests."""
     rates, kernels = cfg["upsample_rates"], cfg["upsample_kernel_sizes"]
     rk, rd = cfg["resblock_kernel_sizes"], cfg["resblock_dilation_sizes"]
     n_fft, hop = cfg["gen_istft_n_fft"], cfg["gen_istft_hop_size"]
     total_up = int(np.prod(rates)) * hop
-    har_src = sine_source(p, f0_curve, rand_ini, noise, upsample=total_up)
+    har_src = sine_source(p, f0_curve, rand_ini, noise, upsample=total_up, coarse_f32=coarse_f32)
     har = torch.from_numpy(stft_mag_phase(har_src, n_fft, hop)).to(x.dtype)  # [B, 22, frames]
     if trace is not None:
         trace.update(har_src=torch.from_numpy(har_src), har=har, xg=x)
@@ -437,7 +439,7 @@ def generator(p: P, x: Tensor, s: Tensor, f0_curve: Tensor, cfg: dict, rand_ini,
     return istft_head(x, n_fft, hop)
 
 
-def decoder(p: P, asr: Tensor, f0_curve: Tensor, n_curve: Tensor, s: Tensor, cfg: dict, rand_ini, noise, trace=None) -> Tensor:
+def decoder(p: P, asr: Tensor, f0_curve: Tensor, n_curve: Tensor, s: Tensor, cfg: dict, rand_ini, noise, trace=None, coarse_f32: bool = False) -> Tensor:
     """Decoder.__call__ (istftnet.py:981-997) -> [B, 1, samples]."""
     f0 = conv_weighted(p.sub("F0_conv"), f0_curve[:, None, :], stride=2, padding=1)
     n = conv_weighted(p.sub("N_conv"), n_curve[:, None, :], stride=2, padding=1)
@@ -457,7 +459,7 @@ def decoder(p: P, asr: Tensor, f0_curve: Tensor, n_curve: Tensor, s: Tensor, cfg
             trace[f"dec{i}"] = x
         if up:
             res = False
-    return generator(p.sub("generator"), x, s, f0_curve, cfg, rand_ini, noise, trace)
+    return generator(p.sub("generator"), x, s, f0_curve, cfg, rand_ini, noise, trace, coarse_f32=coarse_f32)
 
 
 # ------------------------------------------------------------------ full model
@@ -488,8 +490,10 @@ class KokoroRef:
 
     def forward(self, input_ids: Tensor, ref_s: Tensor, speed: float = 1.0,
                 rand_ini: Optional[np.ndarray] = None, noise: Optional[np.ndarray] = None,
-                pred_dur: Optional[Tensor] = None, noise_seed: int = 1234, return_intermediates=False):
-        """input_ids: LongTensor [T] INCLUDING the leading/trailing 0 tokens; ref_s [1, 256]."""
+                pred_dur: Optional[Tensor] = None, noise_seed: int = 1234, return_intermediates=False,
+                f0_override: Optional[Tensor] = None, n_override: Optional[Tensor] = None):
+        """input_ids: LongTensor [T] INCLUDING the leading/trailing 0 tokens; ref_s [1, 256].  ``f0_override`` / ``n_override`` [1, 2F] replace the
+        predicted pitch / energy curves (tests: the harmonic source integrates F0 into a phase, so vocoder comparisons inject the other side's curves)."""
         cfg, p = self.cfg, self.p
         with torch.no_grad():
             ids = input_ids.view(1, -1)
@@ -510,6 +514,10 @@ class KokoroRef:
                 nn_ = adain_resblk1d(pr.sub(f"N.{i}"), nn_, s_pred, upsample=pr.has(f"N.{i}.pool.weight_v"))
             f0 = conv1d_mlx(f0, pr("F0_proj.weight"), pr("F0_proj.bias"))[:, 0, :]
             nn_ = conv1d_mlx(nn_, pr("N_proj.weight"), pr("N_proj.bias"))[:, 0, :]
+            if f0_override is not None:
+                f0 = f0_override.to(self.dtype)
+            if n_override is not None:
+                nn_ = n_override.to(self.dtype)
             t_en = text_encoder(p.sub("text_encoder"), ids, cfg["n_layer"])
             asr = t_en[:, :, idx]
             if rand_ini is None or noise is None:

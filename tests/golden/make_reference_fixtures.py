@@ -1,0 +1,280 @@
+#!/usr/bin/env python
+"""Runs the reference's OWN Kokoro / KittenTTS source files (``/root/reference/mlx_audio/...``, imported from where they lie, unmodified) on
+synthetic checkpoints and stores what they compute under ``tests/golden/ref_*.npz``.  ``tests/test_reference_fixtures_cpu.py`` pins the oracle
+(``oracle/kokoro_ref.py``, ``oracle/kitten_ref.py``) to these files, so the oracle is no longer a restatement checked only against itself.
+
+MLX is not installable here (no network; ``uv.lock`` pins mlx 0.31.2): the array library underneath the reference's code is the numpy stand-in
+``tests/golden/mlx_shim.py`` (read its header for what that does and does not prove).  Before anything is written, the stand-in itself is
+checked against every known-answer vector the reference's tests hold for this path (``tts/tests/test_istftnet_fidelity.py``,
+``tts/tests/test_interpolate.py``, ``tts/tests/test_sinegen_length_alignment.py``) by running those assertions through it.
+
+Only runs in the build container (needs /root/reference): ``python tests/golden/make_reference_fixtures.py``.  The synthetic checkpoints are
+regenerated from their seeds by the test, so the fixtures hold inputs' seeds + the reference's outputs only.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/mlx_audio"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import mlx_shim  # noqa: E402
+
+mx, nn = mlx_shim.install()
+
+
+def _pkg(name, path):
+    m = types.ModuleType(name)
+    m.__path__ = [path]
+    m.__package__ = name
+    sys.modules[name] = m
+    return m
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def import_reference():
+    """The reference's modules under their real names, without executing the package ``__init__`` chains (those pull in the HF hub, the CLI ...)."""
+    _pkg("mlx_audio", REF)
+    _pkg("mlx_audio.tts", f"{REF}/tts")
+    _pkg("mlx_audio.tts.models", f"{REF}/tts/models")
+    dsp = _load("mlx_audio.dsp", f"{REF}/dsp.py")
+    utils = types.ModuleType("mlx_audio.utils")  # mlx_audio/utils.py:31-40 re-exports these two from dsp
+    utils.stft, utils.istft = dsp.stft, dsp.istft
+    sys.modules["mlx_audio.utils"] = utils
+    _load("mlx_audio.tts.models.base", f"{REF}/tts/models/base.py")
+    interp = _load("mlx_audio.tts.models.interpolate", f"{REF}/tts/models/interpolate.py")
+    _pkg("mlx_audio.tts.models.kokoro", f"{REF}/tts/models/kokoro")
+    pipe = types.ModuleType("mlx_audio.tts.models.kokoro.pipeline")  # G2P front end (misaki): not on this path
+    pipe.KokoroPipeline = type("KokoroPipeline", (), {})
+    sys.modules["mlx_audio.tts.models.kokoro.pipeline"] = pipe
+    k_ist = _load("mlx_audio.tts.models.kokoro.istftnet", f"{REF}/tts/models/kokoro/istftnet.py")
+    _load("mlx_audio.tts.models.kokoro.modules", f"{REF}/tts/models/kokoro/modules.py")
+    kokoro = _load("mlx_audio.tts.models.kokoro.kokoro", f"{REF}/tts/models/kokoro/kokoro.py")
+    _pkg("mlx_audio.tts.models.kitten_tts", f"{REF}/tts/models/kitten_tts")
+    _load("mlx_audio.tts.models.kitten_tts.quant", f"{REF}/tts/models/kitten_tts/quant.py")
+    t_ist = _load("mlx_audio.tts.models.kitten_tts.istftnet", f"{REF}/tts/models/kitten_tts/istftnet.py")
+    _load("mlx_audio.tts.models.kitten_tts.modules", f"{REF}/tts/models/kitten_tts/modules.py")
+    _load("mlx_audio.tts.models.kitten_tts.preprocess", f"{REF}/tts/models/kitten_tts/preprocess.py")
+    kitten = _load("mlx_audio.tts.models.kitten_tts.kitten_tts", f"{REF}/tts/models/kitten_tts/kitten_tts.py")
+    return dict(dsp=dsp, interp=interp, k_ist=k_ist, t_ist=t_ist, kokoro=kokoro, kitten=kitten)
+
+
+def check_shim_against_reference_vectors(R):
+    """The reference's own known-answer assertions for this path, run through the stand-in (same numbers as the test files cited)."""
+    for ist in (R["k_ist"], R["t_ist"]):
+        # tts/tests/test_istftnet_fidelity.py:18-31
+        conv = ist.ConvWeighted(1, 1, kernel_size=3, stride=2, padding=0)
+        conv.weight_v = mx.array([1.0, 2.0, 3.0]).reshape(1, 3, 1)
+        conv.weight_g = mx.array([float(np.sqrt(14.0))]).reshape(1, 1, 1)
+        out = conv(mx.array([1.0, 2.0, 3.0, 4.0]).reshape(1, 4, 1), mx.conv_transpose1d)[:, 1:, :]
+        np.testing.assert_allclose(np.array(out).reshape(-1), [2.0, 5.0, 4.0, 9.0, 6.0, 13.0, 8.0, 12.0], rtol=1e-4)
+        # :34-47 MLXSTFT round trip at unity gain
+        stft = ist.MLXSTFT(filter_length=20, hop_length=5, win_length=20)
+        t = np.arange(2000, dtype=np.float32)
+        x = (0.5 * np.sin(2 * np.pi * 220 * t / 24000)).astype(np.float32)
+        rec = np.array(stft.inverse(*stft.transform(mx.array(x)[None, :]))).reshape(-1)[: x.shape[0]]
+        np.testing.assert_allclose(rec[20:-20], x[20:-20], atol=1e-3)
+    # tts/tests/test_interpolate.py:40-97 and tts/tests/test_sinegen_length_alignment.py:8-17 (vectors transcribed in reference_vectors.json)
+    import json
+
+    vec = json.load(open(os.path.join(HERE, "reference_vectors.json")))
+    iv = vec["interpolate"]
+    f = R["interp"].interpolate
+    x = mx.array(np.asarray(iv["nearest_in"], dtype=np.float32).reshape(1, 1, -1))
+    np.testing.assert_allclose(np.array(f(x, size=8, mode="nearest")).reshape(-1), iv["nearest_up8"], rtol=iv["rtol"])
+    np.testing.assert_allclose(np.array(f(x, size=2, mode="nearest")).reshape(-1), iv["nearest_down2"], rtol=iv["rtol"])
+    x = mx.array(np.asarray(iv["linear_in"], dtype=np.float32).reshape(1, 1, -1))
+    np.testing.assert_allclose(np.array(f(x, size=7, mode="linear", align_corners=True)).reshape(-1), iv["linear_ac_true_7"], rtol=iv["rtol"])
+    np.testing.assert_allclose(np.array(f(x, size=7, mode="linear", align_corners=False)).reshape(-1), iv["linear_ac_false_7"], rtol=iv["rtol"])
+    sg = vec["sinegen_shapes"]
+    for ist in (R["k_ist"], R["t_ist"]):
+        gen = ist.SineGen(24000, upsample_scale=sg["upsample_scale"], harmonic_num=sg["harmonic_num"])
+        sine, uv, _ = gen(mx.full((1, sg["length"], 1), sg["f0"]))
+        assert list(sine.shape) == sg["sine_shape"] and list(uv.shape) == [1, sg["length"], 1]
+    return 4
+
+
+class Recorder:
+    """Wraps bound methods of reference modules to keep their inputs / outputs."""
+
+    def __init__(self):
+        self.data = {}
+
+    def wrap(self, obj, attr, name, pick=lambda args, out: out):
+        fn = getattr(obj, attr)
+
+        def g(*a, **k):
+            out = fn(*a, **k)
+            self.data[name] = pick(a, out)
+            return out
+
+        setattr(obj, attr, g)
+
+
+def _np(x):
+    return np.asarray(x, dtype=np.float32 if np.asarray(x).dtype.kind == "f" else None)
+
+
+def run_kokoro(R, seed_w, n_phon, seed_ids, speed, seed_rng):
+    from mlx_audio_amd.tts.models.kokoro import synthetic as S
+
+    cfg = S.tiny_config()
+    w = S.make_kokoro_weights(cfg, seed=seed_w)
+    K = R["kokoro"]
+    model = K.Model(K.ModelConfig.from_dict(cfg), repo_id="none")
+    model.load_weights([(k, v.numpy()) for k, v in w.items()])
+    missing, unexpected, mism = model._load_report
+    # every parameter the reference's modules own is in the synthetic checkpoint and vice versa (bert.pooler is constructed by CustomAlbert)
+    assert not missing and not unexpected, (missing[:5], unexpected[:5])
+    model.eval()  # the reference's loader does (utils.py: base_load_model)
+    ids = S.make_phoneme_ids(n_phon, seed=seed_ids)
+    inv = {v: k for k, v in cfg["vocab"].items()}
+    phonemes = "".join(inv[int(i)] for i in ids[1:-1])
+    ref_s = S.make_voice_pack()[len(ids) - 3].numpy()
+    rec = Recorder()
+    rec.wrap(model.predictor, "F0Ntrain", "f0n", lambda a, out: (np.array(a[0]), np.array(out[0]), np.array(out[1])))
+    dec = model.decoder
+    rec.wrap(dec, "__call__", "dec_in", lambda a, out: tuple(np.array(v) for v in a))
+    # Decoder is invoked as ``decoder(asr, F0, N, s)`` through type(obj).__call__, so patch the class-level entry instead
+    cls_call = type(dec).__call__
+
+    def dec_call(self, asr, f0, n, s):
+        rec.data["dec_in"] = (np.array(asr), np.array(f0), np.array(n))
+        return cls_call(self, asr, f0, n, s)
+
+    type(dec).__call__ = dec_call
+    gen = dec.generator
+    gcall = type(gen).__call__
+
+    def gen_call(self, x, s, f0):
+        rec.data["xg"] = np.array(x)
+        return gcall(self, x, s, f0)
+
+    type(gen).__call__ = gen_call
+    src = gen.m_source
+    scall = type(src).__call__
+
+    def src_call(self, x):
+        out = scall(self, x)
+        rec.data["har_src"] = np.array(out[0])
+        return out
+
+    type(src).__call__ = src_call
+    lstm_cls = type(model.predictor.lstm)
+    lcall = lstm_cls.__call__
+    dur_in = {}
+
+    def lstm_call(self, x, *a, **k):
+        if self is model.predictor.lstm:
+            dur_in["d"] = np.array(x)
+        return lcall(self, x, *a, **k)
+
+    lstm_cls.__call__ = lstm_call
+    mx.random.seed(seed_rng)
+    try:
+        out = model(phonemes, mx.array(ref_s), speed=speed, return_output=True)
+    finally:
+        type(dec).__call__, type(gen).__call__, type(src).__call__, lstm_cls.__call__ = cls_call, gcall, scall, lcall
+    draws = list(mx.random.log)
+    uni = [v for kind, shp, v in draws if kind == "uniform"]
+    nor = [v for kind, shp, v in draws if kind == "normal"]
+    # SineGen: rand_ini [1, 9], noise [1, L, 9]; the third draw [1, L, 1] is SourceModuleHnNSF's unused noise branch (istftnet.py:707-708)
+    assert len(uni) == 1 and nor[0].shape[-1] == 9 and len(nor) == 2, [(k, s) for k, s, _ in draws]
+    asr, f0, n = rec.data["dec_in"]
+    return dict(cfg_kind="kokoro_tiny", seed_w=seed_w, n_phon=n_phon, seed_ids=seed_ids, speed=np.float32(speed),
+                pred_dur=np.asarray(out.pred_dur, dtype=np.int32), d=dur_in["d"].astype(np.float32), f0=f0.astype(np.float32), n=n.astype(np.float32),
+                asr=asr.astype(np.float32), xg_every8=rec.data["xg"][:, ::8].astype(np.float32), har_src=rec.data["har_src"].astype(np.float32),
+                seed_rng=seed_rng, rand_ini=uni[0].astype(np.float32), noise_head=nor[0][0, :4].astype(np.float32),  # the draws are re-made from seed_rng
+                audio=np.asarray(out.audio, dtype=np.float32))
+
+
+def run_kitten(R, seed_w, n_phon, seed_ids, speed, seed_rng, quant):
+    from mlx_audio_amd.tts.models.kitten_tts import synthetic as KS
+    from mlx_audio_amd.tts.models.kokoro import synthetic as S
+
+    cfg = KS.tiny_config()
+    w = KS.make_kitten_weights(cfg, seed=seed_w)
+    qm = KS.converter_quant_modules(w) if quant else None
+    cfg = dict(cfg, activation_quant_modules=qm)
+    T = R["kitten"]
+    model = T.Model(T.ModelConfig.from_dict(cfg))
+    model.load_weights([(k, v.numpy()) for k, v in model.sanitize({k: v for k, v in w.items()}).items()])
+    missing, unexpected, mism = model._load_report
+    assert not missing and not unexpected, (missing[:5], unexpected[:5])
+    model.eval()
+    flagged = sorted(name for name, m in model.named_modules() if getattr(m, "activation_quant", False))
+    all_modules = sorted(name for name, m in model.named_modules() if name)
+    ids = S.make_phoneme_ids(n_phon, seed=seed_ids)
+    ref_s = S.make_voice_pack()[len(ids) - 3].numpy()
+    rec = {}
+    dec = model.decoder
+    dcall = type(dec).__call__
+
+    def dec_call(self, asr, f0, n, s):
+        rec["dec_in"] = (np.array(asr), np.array(f0), np.array(n))
+        return dcall(self, asr, f0, n, s)
+
+    type(dec).__call__ = dec_call
+    gen = dec.generator
+    gcall = type(gen).__call__
+
+    def gen_call(self, x, s, f0):
+        rec["xg"] = np.array(x)
+        return gcall(self, x, s, f0)
+
+    type(gen).__call__ = gen_call
+    lstm_cls = type(model.predictor.lstm)
+    lcall = lstm_cls.__call__
+
+    def lstm_call(self, x, *a, **k):
+        if self is model.predictor.lstm:
+            rec["d"] = np.array(x)
+        return lcall(self, x, *a, **k)
+
+    lstm_cls.__call__ = lstm_call
+    mx.random.seed(seed_rng)
+    try:
+        out = model(mx.array(ids.numpy()[None, :], dtype=mx.int32), mx.array(ref_s), speed=speed, return_output=True)
+    finally:
+        type(dec).__call__, type(gen).__call__, lstm_cls.__call__ = dcall, gcall, lcall
+    draws = list(mx.random.log)
+    uni = [v for kind, shp, v in draws if kind == "uniform"]
+    nor = [v for kind, shp, v in draws if kind == "normal"]
+    assert len(uni) == 1 and nor[0].shape[-1] == 9 and len(nor) == 2, [(k, s) for k, s, _ in draws]
+    asr, f0, n = rec["dec_in"]
+    return dict(cfg_kind="kitten_tiny", seed_w=seed_w, n_phon=n_phon, seed_ids=seed_ids, speed=np.float32(speed), quant=np.int32(bool(quant)),
+                flagged_modules=np.array(flagged), all_modules=np.array(all_modules), pred_dur=np.asarray(out.pred_dur, dtype=np.int32), d=rec["d"].astype(np.float32),
+                f0=f0.astype(np.float32), n=n.astype(np.float32), asr=asr.astype(np.float32), xg=rec["xg"].astype(np.float32),
+                seed_rng=seed_rng, rand_ini=uni[0].astype(np.float32), noise_head=nor[0][0, :4].astype(np.float32),
+                audio=np.asarray(out.audio, dtype=np.float32))
+
+
+def main():
+    R = import_reference()
+    n = check_shim_against_reference_vectors(R)
+    print(f"stand-in passes the reference's ConvTranspose / MLXSTFT vectors (both model families) and {n} interpolate vectors")
+    k = run_kokoro(R, seed_w=21, n_phon=10, seed_ids=4, speed=1.0, seed_rng=5)
+    np.savez_compressed(os.path.join(HERE, "ref_kokoro_tiny.npz"), **k)
+    print("kokoro:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in k.items()})
+    for quant in (False, True):
+        t = run_kitten(R, seed_w=22, n_phon=9, seed_ids=6, speed=1.1, seed_rng=8, quant=quant)
+        np.savez_compressed(os.path.join(HERE, f"ref_kitten_tiny_{'quant' if quant else 'plain'}.npz"), **t)
+        print("kitten quant" if quant else "kitten plain", {a: (v.shape if hasattr(v, "shape") else v) for a, v in t.items() if a not in ("flagged_modules", "all_modules")},
+              len(t["flagged_modules"]), "flagged modules")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,110 @@
+"""The oracle against the reference's OWN code.
+
+``tests/golden/ref_*.npz`` hold what the reference's Kokoro / KittenTTS source files compute on seeded synthetic checkpoints -- the files under
+``/root/reference/mlx_audio/tts/models/{kokoro,kitten_tts}/``, ``dsp.py`` and ``interpolate.py`` imported from where they lie and executed
+unmodified, with a numpy stand-in for the MLX array library underneath (``tests/golden/mlx_shim.py``; generator script
+``tests/golden/make_reference_fixtures.py``, which first runs the reference's own known-answer vectors for this path through the stand-in).
+These tests rebuild the same checkpoints and inputs from their seeds and require ``oracle/kokoro_ref.py`` / ``oracle/kitten_ref.py`` to
+reproduce the reference's intermediates and waveform.  The harmonic source integrates F0 into a phase (chaotic in F0 rounding), so the vocoder
+half is compared with the reference's own F0 / N curves injected -- the harmonic source itself is then required to be BIT-EXACT.
+
+History worth keeping: the first run of this test found (a) a weak-scalar promotion slip in the stand-in (fixed there) and (b) a real quirk of the
+reference the restated oracle had missed -- KittenTTS's SineGen keeps ``upsample_scale`` as an mx.array, so its coarse phase grid has 2F + 1
+points where Kokoro's has 2F (oracle, HIP kernel and engine now carry ``coarse_f32``).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel_max(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+def rel_rms(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean()))
+
+
+def _draws(fx, L):
+    """The stand-in's logged SineGen draws, re-made from the seed (uniform [1, 9] first, then normal [1, L, 9]: make_reference_fixtures.py)."""
+    rng = np.random.default_rng(int(fx["seed_rng"]))
+    ri = rng.uniform(size=(1, 9)).astype(np.float32)
+    nz = rng.standard_normal((1, L, 9)).astype(np.float32)
+    assert np.array_equal(ri[:, 1:], fx["rand_ini"][:, 1:]) and np.array_equal(nz[0, :4], fx["noise_head"])  # column 0 is zeroed in place by SineGen
+    return ri, nz
+
+
+def test_kokoro_oracle_reproduces_the_reference_modules():
+    from mlx_audio_amd.tts.models.kokoro import synthetic as S
+    from oracle.kokoro_ref import KokoroRef
+
+    fx = np.load(os.path.join(GOLD, "ref_kokoro_tiny.npz"))
+    cfg = S.tiny_config()
+    w = S.make_kokoro_weights(cfg, seed=int(fx["seed_w"]))
+    ids = S.make_phoneme_ids(int(fx["n_phon"]), seed=int(fx["seed_ids"]))
+    ref_s = S.make_voice_pack()[len(ids) - 3]
+    ref = KokoroRef(w, cfg, param_dtype=torch.float32)  # the fixture run held the (bf16-valued) parameters in float32
+    sp = float(fx["speed"])
+    pd, d, raw = ref.durations(ids, ref_s, sp)
+    assert np.array_equal(pd.numpy(), fx["pred_dur"])                      # integer path: exact
+    assert rel_max(d.numpy(), fx["d"]) < 2e-5                               # PL-BERT + duration encoder
+    L = fx["audio"].shape[1]
+    ri, nz = _draws(fx, L)
+    _, _, tr = ref.forward(ids, ref_s, speed=sp, rand_ini=ri, noise=nz, return_intermediates=True)
+    assert rel_max(tr["f0"].numpy(), fx["f0"]) < 5e-5 and rel_max(tr["n"].numpy(), fx["n"]) < 5e-5    # prosody predictor
+    assert rel_max(tr["asr"].numpy(), fx["asr"]) < 2e-5                                               # text encoder + alignment
+    audio, _, tr = ref.forward(ids, ref_s, speed=sp, rand_ini=ri, noise=nz, return_intermediates=True,
+                               f0_override=torch.from_numpy(fx["f0"]), n_override=torch.from_numpy(fx["n"]))
+    assert np.array_equal(tr["har_src"].numpy(), fx["har_src"][..., 0])     # SineGen + l_linear + tanh: bit-exact on the same F0
+    assert rel_max(tr["xg"].numpy()[:, ::8], fx["xg_every8"]) < 5e-5        # decoder (AdainResBlk1d stack) output
+    err = float(np.abs(audio.numpy() - fx["audio"]).max())
+    peak = float(np.abs(fx["audio"]).max())
+    snr = 10 * np.log10((fx["audio"].astype(np.float64) ** 2).sum() / ((audio.numpy() - fx["audio"]).astype(np.float64) ** 2).sum())
+    print(f"kokoro oracle vs reference modules: waveform max-abs {err:.2e} (peak {peak:.2f}), SNR {snr:.1f} dB")
+    assert err < 2e-4 * peak and snr > 90.0                                 # generator + iSTFT head (measured 3.2e-5 / 105.9 dB)
+
+
+@pytest.mark.parametrize("kind", ["plain", "quant"])
+def test_kitten_oracle_reproduces_the_reference_modules(kind):
+    from mlx_audio_amd.tts.models.kitten_tts import synthetic as KS
+    from mlx_audio_amd.tts.models.kokoro import synthetic as S
+    from oracle.kitten_ref import KittenRef
+    from oracle.kokoro_ref import P
+
+    fx = np.load(os.path.join(GOLD, f"ref_kitten_tiny_{kind}.npz"))
+    cfg = KS.tiny_config()
+    w = KS.make_kitten_weights(cfg, seed=int(fx["seed_w"]))
+    qm = KS.converter_quant_modules(w) if kind == "quant" else ()
+    assert bool(int(fx["quant"])) == (kind == "quant")
+    # the flag rule (kitten_tts.py:291-299) as the reference applied it to its own module tree: all 423 modules agree
+    flagged = set(fx["flagged_modules"].tolist())
+    p = P({}, "", quant_modules=qm)
+    assert len(fx["all_modules"]) > 400 and all(p.sub(m).quant == (m in flagged) for m in fx["all_modules"].tolist())
+    ids = S.make_phoneme_ids(int(fx["n_phon"]), seed=int(fx["seed_ids"]))
+    ref_s = S.make_voice_pack()[len(ids) - 3]
+    ref = KittenRef(w, cfg, param_dtype=torch.float32, quant_modules=qm)
+    sp = float(fx["speed"])
+    pd, d, raw = ref.durations(ids, ref_s, sp)
+    clear = ((raw - torch.floor(raw)) - 0.5).abs() > 1e-2
+    assert np.array_equal(pd.numpy()[clear.numpy()], fx["pred_dur"][clear.numpy()]) and int(np.abs(pd.numpy() - fx["pred_dur"]).max()) <= 1
+    L = fx["audio"].shape[1]
+    ri, nz = _draws(fx, L)
+    fd = torch.from_numpy(fx["pred_dur"])
+    _, _, tr = ref.forward(ids, ref_s, speed=sp, rand_ini=ri, noise=nz, pred_dur=fd, return_intermediates=True)
+    audio, _, tr2 = ref.forward(ids, ref_s, speed=sp, rand_ini=ri, noise=nz, pred_dur=fd, return_intermediates=True,
+                                f0_override=torch.from_numpy(fx["f0"]), n_override=torch.from_numpy(fx["n"]))
+    got = dict(d=d.numpy(), f0=tr["f0"].numpy(), n=tr["n"].numpy(), asr=tr["asr"].numpy(), xg=tr2["xg"].numpy(), audio=audio.numpy())
+    errs = {k: rel_rms(v, fx[k]) for k, v in got.items()}
+    print(f"kitten ({kind}) oracle vs reference modules, relative RMS: " + "  ".join(f"{k} {e:.1e}" for k, e in errs.items()))
+    if kind == "plain":
+        assert max(errs[k] for k in ("d", "f0", "n", "asr", "xg")) < 2e-5 and errs["audio"] < 1e-4       # measured 2e-7 .. 2e-6, waveform 3.2e-6
+    else:
+        # quantisation rounds: two fp32 builds differ by flipped grid steps (here: numpy vs torch kernels).  Measured: 1e-7 where nothing flipped
+        # (d, F0, asr, xg), 1.2e-2 in the N branch (one flip), 3.1e-2 on the waveform -- tests/test_kitten_gpu.py measures the same band by jitter
+        assert max(errs[k] for k in ("d", "f0", "n", "asr", "xg")) < 5e-2 and errs["audio"] < 0.15
