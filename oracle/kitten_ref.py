@@ -15,10 +15,13 @@ fake quantisation* of the inputs of the modules listed in ``activation_quant_mod
 Everything that is the same module as Kokoro's is ``oracle.kokoro_ref``'s function, called with a parameter view that carries the quantised-module
 list (``P.quant`` implements the reference's flag rule); the quantisation hooks there are inert for Kokoro.
 
-Parity status: **unpinned** end to end (the reference holds no KittenTTS output vector and its tests only construct the model,
-tts/tests/test_models.py:416-492); pinned pieces are the ones shared with Kokoro (weight-normed transposed conv, MLXSTFT round trip --
-tts/tests/test_istftnet_fidelity.py runs both model families through the same assertions) and ``fake_quant_dynamic_u8`` against hand-computed
-vectors (tests/test_oracle_golden.py).
+Parity status: **pinned to the reference's own modules**: ``tests/golden/make_reference_fixtures.py`` runs the reference's KittenTTS source
+files (imported from /root/reference, unmodified) on a seeded synthetic checkpoint -- once without and once with the converter's
+``activation_quant_modules`` -- over a numpy stand-in for MLX (``tests/golden/mlx_shim.py``), and ``tests/test_reference_fixtures_cpu.py`` holds this
+oracle to those fixtures: durations exact, the quantisation flag rule identical on all 423 modules of the reference's module tree, intermediates
+2e-7..2e-6 and waveform 3e-6 relative RMS without quantisation; with it, 1e-7 where no grid step flips and the flip-noise band otherwise.  The
+reference's own tests only construct the model (tts/tests/test_models.py:416-492; reproduced in tests/test_kitten_cpu.py); MLX's kernels
+themselves are not exercised by the stand-in.
 """
 from __future__ import annotations
 

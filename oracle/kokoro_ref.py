@@ -26,9 +26,14 @@ path's rounding error.
 Stochastic inputs (SineGen's uniform initial phase and gaussian noise,
 istftnet.py:581,649) are explicit arguments so results are reproducible.
 
-End-to-end parity status: **unpinned** (no golden Kokoro output exists in the
-reference; see oracle/__init__.py).  Pinned pieces: weight-normed transposed conv,
-MLXSTFT round trip, interpolate, stft/istft/mel (tests/test_oracle_golden.py).
+End-to-end parity status: **pinned to the reference's own modules** (round 2): the reference ships no golden Kokoro
+output, so ``tests/golden/make_reference_fixtures.py`` imports the reference's Kokoro source files from where they lie and
+runs them, unmodified, on a seeded synthetic checkpoint over a numpy stand-in for MLX (``tests/golden/mlx_shim.py``: MLX itself
+is not installable here); ``tests/test_reference_fixtures_cpu.py`` requires this oracle to reproduce those fixtures (durations
+exact, harmonic source bit-exact, intermediates 1e-6..5e-6, waveform 3.2e-5 max-abs / 106 dB with the reference's F0 / N
+injected).  What that cannot cover is MLX's own kernels (the stand-in follows their documented semantics).  Pinned pieces from
+the reference's known-answer tests: weight-normed transposed conv, MLXSTFT round trip, interpolate, stft/istft/mel
+(tests/test_oracle_golden.py).
 """
 from __future__ import annotations
 

@@ -167,16 +167,18 @@ def test_harmonic_source_with_quantised_terms():
     nz = rng.standard_normal((2, F2 * up, 9)).astype(np.float32)
     w = {"m_source.l_linear.weight": torch.randn(1, 9, generator=g), "m_source.l_linear.bias": torch.tensor([0.03])}
     lens2 = torch.tensor([F2, 14], dtype=torch.int32)
-    for quant in (False, True):
+    for quant, coarse in ((False, False), (False, True), (True, True)):  # coarse: KittenTTS's 2F + 1-point phase grid (kitten_tts/istftnet.py:572)
         p = K.P(w, "", quant_modules=("m_source.l_linear",) if quant else ())
-        want0 = K.sine_source(p, f0[0:1], ri[0:1], nz[0:1], upsample=up)
-        want1 = K.sine_source(p, f0[1:2, :14], ri[1:2], nz[1:2, : 14 * up], upsample=up)
+        want0 = K.sine_source(p, f0[0:1], ri[0:1], nz[0:1], upsample=up, coarse_f32=coarse)
+        want1 = K.sine_source(p, f0[1:2, :14], ri[1:2], nz[1:2, : 14 * up], upsample=up, coarse_f32=coarse)
         got = ops.sine_source(f0.to(DEV), torch.from_numpy(ri).to(DEV), torch.from_numpy(nz).to(DEV), w["m_source.l_linear.weight"].reshape(-1).to(DEV),
-                              0.03, up, lens2=lens2.to(DEV), quant=quant).cpu()
+                              0.03, up, lens2=lens2.to(DEV), quant=quant, coarse_f32=coarse).cpu()
         torch.cuda.synchronize()
         e0 = np.abs(got[0].numpy() - want0[0])
         e1 = np.abs(got[1, : 14 * up].numpy() - want1[0])
-        print(f"sine source quant={quant}: max err {e0.max():.2e} / {e1.max():.2e}")
+        print(f"sine source quant={quant} coarse_f32={coarse}: max err {e0.max():.2e} / {e1.max():.2e}")
+        if coarse and not quant:
+            assert np.abs(want0 - K.sine_source(p, f0[0:1], ri[0:1], nz[0:1], upsample=up)).max() > 1e-3  # the two grids do differ
         if not quant:
             assert e0.max() < 2e-6 and e1.max() < 2e-6
         else:  # a flipped term moves the pre-tanh sum by one grid step x |w|: rare, bounded
