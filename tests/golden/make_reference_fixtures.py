@@ -262,6 +262,89 @@ def run_kitten(R, seed_w, n_phon, seed_ids, speed, seed_rng, quant):
                 audio=np.asarray(out.audio, dtype=np.float32))
 
 
+class FakeWhisperTokenizer:
+    """What DecodingTask reads from a tokenizer (decoding.py:455-510), with the multilingual vocabulary's special ids (oracle.whisper_ref.TokenizerSpec)."""
+    eot, sot, translate, transcribe, sot_lm, sot_prev, no_speech, no_timestamps, timestamp_begin = 50257, 50258, 50358, 50359, 50360, 50361, 50362, 50363, 50364
+    language_token = 50259
+    non_speech_tokens = (1, 2, 7, 8, 9, 10, 14, 25)
+    language = "en"
+
+    @property
+    def sot_sequence(self):
+        return (self.sot, self.language_token, self.transcribe)
+
+    @property
+    def sot_sequence_including_notimestamps(self):
+        return self.sot_sequence + (self.no_timestamps,)
+
+    def encode(self, text):
+        assert text == " "
+        return [220]
+
+    def decode(self, tokens):
+        return " ".join(str(t) for t in tokens)
+
+
+def import_whisper():
+    _pkg("mlx_audio.stt", f"{REF}/stt")
+    _pkg("mlx_audio.stt.models", f"{REF}/stt/models")
+    _pkg("mlx_audio.stt.models.whisper", f"{REF}/stt/models/whisper")
+    su = types.ModuleType("mlx_audio.stt.utils")
+    su.load_audio = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("no audio files here"))
+    sys.modules["mlx_audio.stt.utils"] = su
+    dsp = sys.modules["mlx_audio.dsp"]
+    u = sys.modules["mlx_audio.utils"]
+    u.hanning, u.mel_filters = dsp.hanning, dsp.mel_filters
+    base = "mlx_audio.stt.models.whisper"
+    _load(f"{base}.audio", f"{REF}/stt/models/whisper/audio.py")
+    _load(f"{base}.tokenizer", f"{REF}/stt/models/whisper/tokenizer.py")
+    dec = _load(f"{base}.decoding", f"{REF}/stt/models/whisper/decoding.py")
+    _load(f"{base}.timing", f"{REF}/stt/models/whisper/timing.py")
+    wh = _load(f"{base}.whisper", f"{REF}/stt/models/whisper/whisper.py")
+    return wh, dec
+
+
+def run_whisper(seed_w, seed_mel, sample_len):
+    """The reference's Whisper ``Model`` (encoder, decoder with its KV cache) and ``DecodingTask`` (greedy, all three logit filters) on a tiny
+    synthetic checkpoint, float32 (the composition is what is pinned; the fp16 roundings of the released checkpoints are the oracle's own model)."""
+    from mlx_audio_amd.stt.models.whisper import synthetic as WS
+
+    wh, dec = import_whisper()
+    dims = WS.tiny_dims()
+    w = WS.make_whisper_weights(dims, seed=seed_w)
+    rd = wh.ModelDimensions(**{k: getattr(dims, k) for k in ("n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head", "n_audio_layer", "n_vocab",
+                                                               "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer")})
+    model = wh.Model(rd, dtype=mx.float32)
+    model.load_weights([(k, v.numpy()) for k, v in w.items()])
+    missing, unexpected, mism = model._load_report
+    assert not missing and not unexpected and not mism, (missing[:5], unexpected[:5], mism[:5])
+    model.eval()
+    model.get_tokenizer = lambda language=None, task="transcribe": FakeWhisperTokenizer()
+    mel = WS.make_mel(2, seed=seed_mel, n_frames=2 * dims.n_audio_ctx).numpy()
+    xa = model.encoder(mx.array(mel))
+    tok = FakeWhisperTokenizer()
+    # teacher-forced decoder logits: full context, then one cached step
+    ctx = np.array([list(tok.sot_sequence) + [50364, 400, 1200, 31]] * 2, dtype=np.int32)
+    logits_full, kv, _ = model.decoder(mx.array(ctx), xa)
+    step_tok = np.array([[805], [17]], dtype=np.int32)
+    logits_step, kv, _ = model.decoder(mx.array(step_tok), xa, kv_cache=kv)
+    out = {}
+    for name, kw in (("ts", dict()), ("nots", dict(without_timestamps=True))):
+        opts = dec.DecodingOptions(language="en", fp16=False, temperature=0.0, sample_len=sample_len, suppress_tokens="-1", **kw)
+        res = dec.decode(model, mx.array(mel), opts)
+        ntok = max(len(r.tokens) for r in res)
+        toks = np.full((2, ntok), -1, dtype=np.int32)
+        for i, r in enumerate(res):
+            toks[i, : len(r.tokens)] = r.tokens
+        out[f"{name}_tokens"] = toks
+        out[f"{name}_avg_logprob"] = np.array([r.avg_logprob for r in res], dtype=np.float64)
+        out[f"{name}_no_speech"] = np.array([r.no_speech_prob for r in res], dtype=np.float64)
+    return dict(seed_w=seed_w, seed_mel=seed_mel, sample_len=sample_len, non_speech_tokens=np.array(tok.non_speech_tokens, dtype=np.int32),
+                xa_every4=np.asarray(xa)[:, :, ::4].astype(np.float32), ctx=ctx, step_tok=step_tok,
+                logits_full_last=np.asarray(logits_full)[:, -1, ::16].astype(np.float32), logits_step=np.asarray(logits_step)[:, -1, ::16].astype(np.float32),
+                logits_full_argmax=np.asarray(logits_full).argmax(-1).astype(np.int32), **out)
+
+
 def main():
     R = import_reference()
     n = check_shim_against_reference_vectors(R)
@@ -274,6 +357,9 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"ref_kitten_tiny_{'quant' if quant else 'plain'}.npz"), **t)
         print("kitten quant" if quant else "kitten plain", {a: (v.shape if hasattr(v, "shape") else v) for a, v in t.items() if a not in ("flagged_modules", "all_modules")},
               len(t["flagged_modules"]), "flagged modules")
+    wfx = run_whisper(seed_w=3, seed_mel=2, sample_len=24)
+    np.savez_compressed(os.path.join(HERE, "ref_whisper_tiny.npz"), **wfx)
+    print("whisper:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in wfx.items()}, wfx["ts_tokens"].tolist(), wfx["nots_tokens"].tolist())
 
 
 if __name__ == "__main__":

@@ -13,6 +13,7 @@ Nothing in the product, ``oracle/``, ``bench.py`` or the GPU tests imports this 
 """
 from __future__ import annotations
 
+import builtins as _b
 import math
 import sys
 import types
@@ -28,7 +29,9 @@ bool_ = np.bool_
 complex64 = np.complex64
 pi = math.pi
 inf = math.inf
+nan = math.nan
 newaxis = None
+Dtype = type  # ``mx.Dtype`` only appears in annotations
 
 _DOWN = {np.dtype(np.float64): np.float32, np.dtype(np.complex128): np.complex64, np.dtype(np.int64): np.int32}
 
@@ -64,9 +67,9 @@ class array(np.ndarray):
         self._wide = getattr(obj, "_wide", False)
 
     def __array_ufunc__(self, ufunc, method, *inputs, out=None, **kw):
-        wide = any(isinstance(i, np.ndarray) and i.dtype == np.float64 and getattr(i, "_wide", False) for i in inputs)
+        wide = _b.any(isinstance(i, np.ndarray) and i.dtype == np.float64 and getattr(i, "_wide", False) for i in inputs)
         raw = [np.asarray(i) if isinstance(i, array) else i for i in inputs]
-        if any(isinstance(i, float) for i in raw):
+        if _b.any(isinstance(i, float) for i in raw):
             # MLX: a python float is a WEAK scalar -- against an integer array the result is float32 and the scalar is rounded to float32 first
             # (numpy would compute in float64 with the unrounded double: visible in interpolate's ``arange(size) * (W / size)``)
             raw = [np.float32(i) if isinstance(i, float) else (i.astype(np.float32) if isinstance(i, np.ndarray) and i.dtype.kind in "iub" else i)
@@ -101,6 +104,9 @@ class array(np.ndarray):
 
     def square(self):
         return self * self
+
+    def logsumexp(self, axis=None, keepdims=False):
+        return logsumexp(self, axis=axis, keepdims=keepdims)
 
     def abs(self):
         return np.abs(self)
@@ -225,7 +231,7 @@ def pad(a, pad_width, mode="constant", constant_values=0, stream=None):
     a = np.asarray(a)
     if isinstance(pad_width, int):
         pad_width = [(pad_width, pad_width)] * a.ndim
-    elif isinstance(pad_width, tuple) and len(pad_width) == 2 and all(isinstance(p, (int, np.integer)) for p in pad_width):
+    elif isinstance(pad_width, tuple) and len(pad_width) == 2 and _b.all(isinstance(p, (int, np.integer)) for p in pad_width):
         pad_width = [tuple(pad_width)] * a.ndim
     if mode == "constant":
         return _wrap(np.pad(a, pad_width, mode="constant", constant_values=constant_values))
@@ -235,7 +241,7 @@ def pad(a, pad_width, mode="constant", constant_values=0, stream=None):
 def where(c, x, y, stream=None):
     x, y = _as(x), _as(y)
     r = np.where(np.asarray(c), np.asarray(x), np.asarray(y))
-    if not any(isinstance(v, np.ndarray) and v.dtype == np.float64 for v in (x, y)) and r.dtype in _DOWN:
+    if not _b.any(isinstance(v, np.ndarray) and v.dtype == np.float64 for v in (x, y)) and r.dtype in _DOWN:
         r = r.astype(_DOWN[r.dtype])
     return _wrap(r)
 
@@ -365,7 +371,32 @@ def conv_transpose1d(x, w, stride=1, padding=0, dilation=1, output_padding=0, gr
     return _wrap(y.permute(0, 2, 1).contiguous().numpy())
 
 
+def logsumexp(a, axis=None, keepdims=False, stream=None):
+    a = np.asarray(a)
+    m = a.max(axis=axis, keepdims=True)
+    m = np.where(np.isfinite(m), m, 0.0).astype(a.dtype)
+    r = np.log(np.exp(a - m).sum(axis=axis, keepdims=True)) + m
+    return _wrap((r if keepdims else np.squeeze(r, axis=axis)).astype(a.dtype))
+
+
+def argmax(a, axis=None, keepdims=False, stream=None):
+    r = np.argmax(np.asarray(a), axis=axis, keepdims=keepdims)
+    return _wrap(np.asarray(r).astype(np.uint32))
+
+
+def all(a, axis=None, keepdims=False, stream=None):  # noqa: A001
+    return _wrap(np.asarray(np.all(np.asarray(a), axis=axis, keepdims=keepdims)))
+
+
+def any(a, axis=None, keepdims=False, stream=None):  # noqa: A001
+    return _wrap(np.asarray(np.any(np.asarray(a), axis=axis, keepdims=keepdims)))
+
+
 def eval(*a, **k):  # noqa: A001
+    return None
+
+
+def async_eval(*a, **k):
     return None
 
 
@@ -402,6 +433,8 @@ def dropout(x, p=0.5, *a, **k):
 
 class _Random:
     """``mx.random``: seeded draws, every draw logged (kind, shape, values) so that the oracle can be fed the very same numbers."""
+
+    state: list = []  # ``mx.random.state`` (only passed to mx.compile by the reference)
 
     def __init__(self):
         self.rng = np.random.default_rng(0)
@@ -490,7 +523,7 @@ class Module:
                 continue
             if isinstance(v, array):
                 names.append(f"{prefix}{k}")
-            elif isinstance(v, (list, tuple)) and v and all(isinstance(e, array) for e in v):
+            elif isinstance(v, (list, tuple)) and v and _b.all(isinstance(e, array) for e in v):
                 names.extend(f"{prefix}{k}.{i}" for i in range(len(v)))
         for k, c in self._children():
             names.extend(c.parameter_names(f"{prefix}{k}."))
@@ -543,6 +576,9 @@ class Embedding(Module):
 
     def __call__(self, x):
         return _wrap(np.asarray(self.weight)[np.asarray(x)])
+
+    def as_linear(self, x):
+        return matmul(x, self.weight.T)
 
 
 class LayerNorm(Module):
@@ -627,6 +663,16 @@ class Upsample(Module):
         return _wrap(x)
 
 
+class MultiHeadAttention(Module):
+    """Only the static helper the reference's Whisper uses (whisper.py:468)."""
+
+    @staticmethod
+    def create_additive_causal_mask(N, dtype=np.float32):
+        idx = np.arange(N)
+        # MLX: (indices[:, None] < indices[None]) * finfo(dtype).min
+        return _wrap(((idx[:, None] < idx[None]).astype(np.float32) * np.finfo(np.float32).min).astype(dtype))
+
+
 def leaky_relu(x, negative_slope=0.01):
     x = np.asarray(x)
     return _wrap(np.maximum(np.float32(negative_slope) * x, x))
@@ -677,15 +723,25 @@ def install():
     core = types.ModuleType("mlx.core")
     for k, v in vars(me).items():
         if not k.startswith("_") and k not in ("Module", "Linear", "Embedding", "LayerNorm", "InstanceNorm", "Conv1d", "Dropout", "Identity", "Upsample",
-                                               "LeakyReLU", "GELU", "leaky_relu", "gelu", "nn_tanh", "relu", "silu", "install"):
+                                               "LeakyReLU", "GELU", "leaky_relu", "gelu", "nn_tanh", "relu", "silu", "install", "MultiHeadAttention"):
             setattr(core, k, v)
     nn = types.ModuleType("mlx.nn")
     for k in ("Module", "Linear", "Embedding", "LayerNorm", "InstanceNorm", "Conv1d", "Dropout", "Identity", "Upsample", "LeakyReLU", "GELU", "leaky_relu",
-              "gelu", "relu", "silu", "sigmoid"):
+              "gelu", "relu", "silu", "sigmoid", "MultiHeadAttention"):
         setattr(nn, k, getattr(me, k))
     nn.tanh = nn_tanh
     utils = types.ModuleType("mlx.utils")
     utils.tree_flatten = lambda tree: []
+
+    def tree_map(fn, tree, *rest):
+        if isinstance(tree, (list, tuple)):
+            return type(tree)(tree_map(fn, t, *[r[i] for r in rest]) for i, t in enumerate(tree))
+        if isinstance(tree, dict):
+            return {k: tree_map(fn, v, *[r[k] for r in rest]) for k, v in tree.items()}
+        return fn(tree, *rest)
+
+    utils.tree_map = tree_map
+    utils.tree_unflatten = lambda pairs: dict(pairs)
     root = types.ModuleType("mlx")
     root._IS_SHIM = True
     root.core, root.nn, root.utils = core, nn, utils

@@ -108,3 +108,40 @@ def test_kitten_oracle_reproduces_the_reference_modules(kind):
         # quantisation rounds: two fp32 builds differ by flipped grid steps (here: numpy vs torch kernels).  Measured: 1e-7 where nothing flipped
         # (d, F0, asr, xg), 1.2e-2 in the N branch (one flip), 3.1e-2 on the waveform -- tests/test_kitten_gpu.py measures the same band by jitter
         assert max(errs[k] for k in ("d", "f0", "n", "asr", "xg")) < 5e-2 and errs["audio"] < 0.15
+
+
+def test_whisper_oracle_reproduces_the_reference_modules():
+    """The reference's Whisper ``Model`` (conv stem, encoder, decoder with its KV cache: whisper.py:336-520) and ``DecodingTask`` (greedy decoder,
+    SuppressBlank / SuppressTokens / ApplyTimestampRules, no-speech probability: decoding.py:302-700) executed on a tiny float32 checkpoint; the
+    oracle has to reproduce the features, the teacher-forced logits, and -- integer path -- the decoded token sequences of both decoding modes."""
+    from mlx_audio_amd.stt.models.whisper import synthetic as WS
+    from oracle.whisper_ref import Dims, TokenizerSpec, WhisperRef
+
+    fx = np.load(os.path.join(GOLD, "ref_whisper_tiny.npz"))
+    dims = WS.tiny_dims()
+    w = WS.make_whisper_weights(dims, seed=int(fx["seed_w"]))
+    ref = WhisperRef(w, Dims(**{k: getattr(dims, k) for k in Dims.__dataclass_fields__}), dtype=torch.float32, param_dtype=torch.float32, cross_kv_dtype=None)
+    mel = WS.make_mel(2, seed=int(fx["seed_mel"]), n_frames=2 * dims.n_audio_ctx)
+    xa = ref.encoder(mel)
+    assert rel_max(xa.numpy()[:, :, ::4], fx["xa_every4"]) < 2e-5
+    ctx = torch.from_numpy(fx["ctx"]).long()
+    logits, kv = ref.decoder(ctx, xa)
+    assert np.array_equal(logits.argmax(-1).numpy(), fx["logits_full_argmax"])
+    assert rel_max(logits[:, -1, ::16].numpy(), fx["logits_full_last"]) < 2e-5
+    step, kv = ref.decoder(torch.from_numpy(fx["step_tok"]).long(), xa, kv)
+    assert rel_max(step[:, -1, ::16].numpy(), fx["logits_step"]) < 2e-5
+    tok = TokenizerSpec(non_speech_tokens=tuple(int(t) for t in fx["non_speech_tokens"]))
+    # decoding.py:80-112 with suppress_tokens = "-1"
+    suppress = sorted(set(list(tok.non_speech_tokens) + [tok.transcribe, tok.translate, tok.sot, tok.sot_prev, tok.sot_lm, tok.no_speech]))
+    for name, kw in (("ts", {}), ("nots", dict(without_timestamps=True))):
+        out = ref.decode(mel, tok, sample_len=int(fx["sample_len"]), suppress_tokens=suppress, **kw)
+        want = fx[f"{name}_tokens"]
+        got = out["tokens"][:, out["sample_begin"]:].numpy()
+        for b in range(2):
+            n = int((want[b] >= 0).sum())
+            row = got[b].tolist()
+            row = row[: row.index(tok.eot)] if tok.eot in row else row
+            assert row[:n] == want[b, :n].tolist(), (name, b, row, want[b].tolist())
+            avg = float(out["sum_logprobs"][b]) / (n + 1)
+            assert abs(avg - float(fx[f"{name}_avg_logprob"][b])) < 1e-4 * max(1.0, abs(avg))
+        assert np.allclose(out["no_speech_probs"].numpy(), fx[f"{name}_no_speech"], rtol=1e-4, atol=1e-9)
