@@ -345,6 +345,62 @@ def run_whisper(seed_w, seed_mel, sample_len):
                 logits_full_argmax=np.asarray(logits_full).argmax(-1).astype(np.int32), **out)
 
 
+def import_lm_and_mimi():
+    """lm/models/{base,cache,...} and codec/models/mimi/** under their real names (package __init__ chains skipped as above)."""
+    if "mlx_audio.codec.models.mimi.mimi" in sys.modules:
+        return sys.modules["mlx_audio.codec.models.mimi.mimi"]
+    _pkg("mlx_audio.lm", f"{REF}/lm")
+    _pkg("mlx_audio.lm.models", f"{REF}/lm/models")
+    for m in ("base", "cache", "activations", "rope_utils"):
+        _load(f"mlx_audio.lm.models.{m}", f"{REF}/lm/models/{m}.py")
+    _pkg("mlx_audio.codec", f"{REF}/codec")
+    _pkg("mlx_audio.codec.models", f"{REF}/codec/models")
+    _pkg("mlx_audio.codec.models.mimi", f"{REF}/codec/models/mimi")
+    mods = _pkg("mlx_audio.codec.models.mimi.modules", f"{REF}/codec/models/mimi/modules")
+    base = "mlx_audio.codec.models.mimi.modules"
+    for m in ("conv", "quantization", "seanet", "transformer"):
+        mod = _load(f"{base}.{m}", f"{REF}/codec/models/mimi/modules/{m}.py")
+        for k, v in vars(mod).items():  # modules/__init__.py re-exports the public classes
+            if not k.startswith("_") and isinstance(v, type):
+                setattr(mods, k, v)
+    return _load("mlx_audio.codec.models.mimi.mimi", f"{REF}/codec/models/mimi/mimi.py")
+
+
+def run_mimi(seed_w, seed_codes, n_frames):
+    """The reference's ``Mimi.decode`` (quantizer.decode -> ConvTrUpsample1d -> ProjectedTransformer with its KV cache -> SeanetDecoder,
+    mimi.py:155-161) on a tiny synthetic checkpoint: one whole-utterance call, and the same codes frame by frame through ``decode_step``."""
+    from mlx_audio_amd.codec.models.mimi import mimi as M
+
+    rm = import_lm_and_mimi()
+    mods = sys.modules["mlx_audio.codec.models.mimi.modules"]
+    c = M.tiny_mimi_config()
+    w = M.make_mimi_decoder_weights(c, seed=seed_w)
+    ref_cfg = rm.mimi_202407(c.quantizer_nq)
+    sc, tc = ref_cfg.seanet, ref_cfg.transformer
+    sc.dimension, sc.nfilters, sc.ratios, sc.ksize, sc.residual_ksize, sc.last_ksize, sc.compress = (c.dimension, c.nfilters, list(c.ratios), c.ksize,
+                                                                                                    c.residual_ksize, c.last_ksize, c.compress)
+    tc.d_model, tc.num_heads, tc.num_layers, tc.dim_feedforward, tc.context, tc.max_seq_len = (c.dimension, c.num_heads, c.num_layers, c.dim_feedforward,
+                                                                                                c.context, c.max_seq_len)
+    ref_cfg.quantizer_bins, ref_cfg.quantizer_dim = c.quantizer_bins, c.quantizer_dim
+    model = rm.Mimi(ref_cfg)
+    model.load_weights([(k, v.numpy()) for k, v in w.items()])
+    missing, unexpected, mism = model._load_report
+    # decode-side parameters only: the encoder half, the quantizer's input projections and its ``initialized`` flag (a training buffer) are not on the path
+    dec_missing = [m for m in missing if not m.startswith(("encoder", "downsample", "quantizer.rvq_first.input_proj", "quantizer.rvq_rest.input_proj"))
+                   and not m.endswith(".codebook.initialized")]
+    assert not unexpected and not dec_missing and not mism, (dec_missing[:8], unexpected[:8], mism[:4])
+    for _, m in model.named_modules():  # what load_pytorch_weights does after load_weights (mimi.py:252-260): derived tensors of codebooks / conv-transposes
+        if isinstance(m, (mods.EuclideanCodebook, sys.modules["mlx_audio.codec.models.mimi.modules.conv"].ConvTranspose1d)):
+            m.update_in_place()
+    model.eval()
+    codes = M.make_codes(2, n_frames, c, seed=seed_codes).numpy()
+    pcm = np.asarray(model.decode(mx.array(codes.astype(np.int32))))
+    model.reset_state()
+    steps = [np.asarray(model.decode_step(mx.array(codes[:, :, t:t + 1].astype(np.int32)))) for t in range(n_frames)]
+    pcm_steps = np.concatenate(steps, axis=-1)
+    return dict(seed_w=seed_w, seed_codes=seed_codes, n_frames=n_frames, pcm=pcm.astype(np.float32), pcm_steps=pcm_steps.astype(np.float32))
+
+
 def main():
     R = import_reference()
     n = check_shim_against_reference_vectors(R)
@@ -357,6 +413,10 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"ref_kitten_tiny_{'quant' if quant else 'plain'}.npz"), **t)
         print("kitten quant" if quant else "kitten plain", {a: (v.shape if hasattr(v, "shape") else v) for a, v in t.items() if a not in ("flagged_modules", "all_modules")},
               len(t["flagged_modules"]), "flagged modules")
+    mfx = run_mimi(seed_w=5, seed_codes=1, n_frames=30)
+    np.savez_compressed(os.path.join(HERE, "ref_mimi_tiny.npz"), **mfx)
+    print("mimi:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in mfx.items()},
+          "decode vs decode_step max diff", float(np.abs(mfx["pcm"] - mfx["pcm_steps"]).max()), "peak", float(np.abs(mfx["pcm"]).max()))
     wfx = run_whisper(seed_w=3, seed_mel=2, sample_len=24)
     np.savez_compressed(os.path.join(HERE, "ref_whisper_tiny.npz"), **wfx)
     print("whisper:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in wfx.items()}, wfx["ts_tokens"].tolist(), wfx["nots_tokens"].tolist())

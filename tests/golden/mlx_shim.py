@@ -392,6 +392,136 @@ def any(a, axis=None, keepdims=False, stream=None):  # noqa: A001
     return _wrap(np.asarray(np.any(np.asarray(a), axis=axis, keepdims=keepdims)))
 
 
+def triu(a, k=0, stream=None):
+    return _wrap(np.triu(np.asarray(a), k))
+
+
+def tril(a, k=0, stream=None):
+    return _wrap(np.tril(np.asarray(a), k))
+
+
+def take(a, indices, axis=None, stream=None):
+    return _wrap(np.take(np.asarray(a), np.asarray(indices), axis=axis))
+
+
+def take_along_axis(a, indices, axis=None, stream=None):
+    return _wrap(np.take_along_axis(np.asarray(a), np.asarray(indices).astype(np.int64), axis=axis))
+
+
+def contiguous(a, stream=None):
+    return _wrap(np.ascontiguousarray(np.asarray(a)))
+
+
+def concat(arrays, axis=0, stream=None):
+    return concatenate(arrays, axis=axis)
+
+
+def argsort(a, axis=-1, stream=None):
+    return _wrap(np.argsort(np.asarray(a), axis=axis, kind="stable").astype(np.uint32))
+
+
+def sort(a, axis=-1, stream=None):
+    return _wrap(np.sort(np.asarray(a), axis=axis, kind="stable"))
+
+
+def argpartition(a, kth, axis=-1, stream=None):
+    return _wrap(np.argpartition(np.asarray(a), kth, axis=axis).astype(np.uint32))
+
+
+def put_along_axis(a, indices, values, axis=None, stream=None):
+    out = np.array(np.asarray(a), copy=True)
+    np.put_along_axis(out, np.asarray(indices).astype(np.int64), np.asarray(values), axis=axis)
+    return _wrap(out)
+
+
+class _Fast:
+    """``mx.fast``: the fused ops, as their definitions (float32 accumulation, output in the input dtype)."""
+
+    @staticmethod
+    def scaled_dot_product_attention(q, k, v, *, scale, mask=None, sinks=None, stream=None):
+        assert sinks is None
+        q, k, v = (np.asarray(t, dtype=np.float32) for t in (q, k, v))
+        B, Hq, Tq, D = q.shape
+        Hk = k.shape[1]
+        if Hk != Hq:  # grouped-query attention: head h reads kv head h // (Hq / Hk)
+            k = np.repeat(k, Hq // Hk, axis=1)
+            v = np.repeat(v, Hq // Hk, axis=1)
+        sc = np.matmul(q * np.float32(scale), np.swapaxes(k, -1, -2))
+        Tk = k.shape[2]
+        if isinstance(mask, str):
+            assert mask == "causal"
+            qi = np.arange(Tk - Tq, Tk)[:, None]
+            sc = np.where(qi >= np.arange(Tk)[None, :], sc, -np.inf)
+        elif mask is not None:
+            m = np.asarray(mask)
+            sc = np.where(m, sc, -np.inf) if m.dtype == np.bool_ else sc + m.astype(np.float32)
+        e = np.exp(sc - sc.max(axis=-1, keepdims=True))
+        w = e / e.sum(axis=-1, keepdims=True)
+        return _wrap(np.matmul(w, v).astype(np.float32))
+
+    @staticmethod
+    def rms_norm(x, weight, eps, stream=None):
+        x = np.asarray(x, dtype=np.float32)
+        y = x * (1.0 / np.sqrt((x * x).mean(axis=-1, keepdims=True) + np.float32(eps)))
+        return _wrap(y if weight is None else y * np.asarray(weight, dtype=np.float32))
+
+    @staticmethod
+    def layer_norm(x, weight, bias, eps, stream=None):
+        x = np.asarray(x, dtype=np.float32)
+        y = (x - x.mean(axis=-1, keepdims=True)) * (1.0 / np.sqrt(x.var(axis=-1, keepdims=True) + np.float32(eps)))
+        if weight is not None:
+            y = y * np.asarray(weight)
+        if bias is not None:
+            y = y + np.asarray(bias)
+        return _wrap(y.astype(np.float32))
+
+    @staticmethod
+    def rope(x, dims, *, traditional, base, scale, offset, freqs=None, stream=None):
+        """x [..., T, D]: position t + offset rotates the first ``dims`` features; angle = pos * scale * base^(-2i / dims), or pos * scale / freqs[i].
+        traditional: pairs (2i, 2i + 1); otherwise (i, i + dims / 2)."""
+        x = np.asarray(x, dtype=np.float32)
+        T = x.shape[-2]
+        half = dims // 2
+        if freqs is None:
+            inv = np.float32(base) ** (-np.arange(0, half, dtype=np.float32) * np.float32(2.0 / dims))
+        else:
+            inv = (1.0 / np.asarray(freqs, dtype=np.float32)).astype(np.float32)
+        off = np.asarray(offset)
+        pos = (np.arange(T, dtype=np.float32) + np.float32(off.item() if off.ndim == 0 else 0)) * np.float32(scale)
+        if off.ndim > 0:  # per-sequence offsets [B]
+            pos = (np.arange(T, dtype=np.float32)[None, :] + off.astype(np.float32)[:, None]) * np.float32(scale)
+            ang = pos[..., None] * inv
+            ang = ang.reshape(ang.shape[0], *([1] * (x.ndim - 3)), T, half)
+        else:
+            ang = pos[:, None] * inv[None, :]
+        c, s_ = np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+        out = np.array(x, copy=True)
+        if traditional:
+            a, b = x[..., 0:dims:2], x[..., 1:dims:2]
+            out[..., 0:dims:2] = a * c - b * s_
+            out[..., 1:dims:2] = a * s_ + b * c
+        else:
+            a, b = x[..., :half], x[..., half:dims]
+            out[..., :half] = a * c - b * s_
+            out[..., half:dims] = a * s_ + b * c
+        return _wrap(out)
+
+
+fast = _Fast()
+
+
+class _Distributed:
+    class Group:  # noqa: D106
+        pass
+
+    @staticmethod
+    def init(*a, **k):
+        return None
+
+
+distributed = _Distributed()
+
+
 def eval(*a, **k):  # noqa: A001
     return None
 
@@ -663,6 +793,49 @@ class Upsample(Module):
         return _wrap(x)
 
 
+class RMSNorm(Module):
+    def __init__(self, dims, eps=1e-5):
+        super().__init__()
+        self.weight = ones((dims,))
+        self.eps = eps
+
+    def __call__(self, x):
+        return fast.rms_norm(x, self.weight, self.eps)
+
+
+class RoPE(Module):
+    def __init__(self, dims, traditional=False, base=10000, scale=1.0):
+        super().__init__()
+        self.dims, self.traditional, self.base, self.scale = dims, traditional, base, scale
+
+    def __call__(self, x, offset=0):
+        return fast.rope(x, self.dims, traditional=self.traditional, base=self.base, scale=self.scale, offset=offset)
+
+
+class ConvTranspose1d(Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, output_padding=0, bias=True):
+        super().__init__()
+        s = math.sqrt(1.0 / (in_channels * kernel_size))
+        self.weight = random.uniform(-s, s, (out_channels, kernel_size, in_channels))
+        if bias:
+            self.bias = zeros((out_channels,))
+        self.stride, self.padding, self.dilation, self.output_padding = stride, padding, dilation, output_padding
+
+    def __call__(self, x):
+        y = conv_transpose1d(x, self.weight, self.stride, self.padding, self.dilation, self.output_padding)
+        return y + self.bias if "bias" in self.__dict__ else y
+
+
+def elu(x, alpha=1.0):
+    x = np.asarray(x)
+    return _wrap(np.where(x > 0, x, np.float32(alpha) * (np.exp(np.minimum(x, 0)) - 1)).astype(x.dtype))
+
+
+def gelu_approx(x):
+    torch = _t()
+    return _wrap(torch.nn.functional.gelu(torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float32))), approximate="tanh").numpy())
+
+
 class MultiHeadAttention(Module):
     """Only the static helper the reference's Whisper uses (whisper.py:468)."""
 
@@ -723,11 +896,11 @@ def install():
     core = types.ModuleType("mlx.core")
     for k, v in vars(me).items():
         if not k.startswith("_") and k not in ("Module", "Linear", "Embedding", "LayerNorm", "InstanceNorm", "Conv1d", "Dropout", "Identity", "Upsample",
-                                               "LeakyReLU", "GELU", "leaky_relu", "gelu", "nn_tanh", "relu", "silu", "install", "MultiHeadAttention"):
+                                               "LeakyReLU", "GELU", "leaky_relu", "gelu", "nn_tanh", "relu", "silu", "install", "MultiHeadAttention", "RMSNorm", "RoPE", "ConvTranspose1d", "elu", "gelu_approx"):
             setattr(core, k, v)
     nn = types.ModuleType("mlx.nn")
     for k in ("Module", "Linear", "Embedding", "LayerNorm", "InstanceNorm", "Conv1d", "Dropout", "Identity", "Upsample", "LeakyReLU", "GELU", "leaky_relu",
-              "gelu", "relu", "silu", "sigmoid", "MultiHeadAttention"):
+              "gelu", "relu", "silu", "sigmoid", "MultiHeadAttention", "RMSNorm", "RoPE", "ConvTranspose1d", "elu", "gelu_approx"):
         setattr(nn, k, getattr(me, k))
     nn.tanh = nn_tanh
     utils = types.ModuleType("mlx.utils")
@@ -746,5 +919,12 @@ def install():
     root._IS_SHIM = True
     root.core, root.nn, root.utils = core, nn, utils
     root.__path__ = []
-    sys.modules.update({"mlx": root, "mlx.core": core, "mlx.nn": nn, "mlx.utils": utils})
+    layers = types.ModuleType("mlx.nn.layers")
+    dist_l = types.ModuleType("mlx.nn.layers.distributed")
+    dist_l.shard_linear = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("tensor parallel sharding is not part of the fixtures"))
+    layers.distributed = dist_l
+    nn.layers = layers
+    nn.__path__ = []
+    layers.__path__ = []
+    sys.modules.update({"mlx": root, "mlx.core": core, "mlx.nn": nn, "mlx.utils": utils, "mlx.nn.layers": layers, "mlx.nn.layers.distributed": dist_l})
     return core, nn

@@ -145,3 +145,26 @@ def test_whisper_oracle_reproduces_the_reference_modules():
             avg = float(out["sum_logprobs"][b]) / (n + 1)
             assert abs(avg - float(fx[f"{name}_avg_logprob"][b])) < 1e-4 * max(1.0, abs(avg))
         assert np.allclose(out["no_speech_probs"].numpy(), fx[f"{name}_no_speech"], rtol=1e-4, atol=1e-9)
+
+
+def test_mimi_oracle_reproduces_the_reference_modules():
+    """The reference's ``Mimi.decode`` and, frame by frame, ``Mimi.decode_step`` (codec/models/mimi/mimi.py:155-176 with modules/{quantization,conv,
+    transformer,seanet}.py and the rotating KV cache of lm/models/cache.py) on a tiny synthetic checkpoint, 30 frames against an attention context of 20."""
+    from dataclasses import asdict
+
+    from mlx_audio_amd.codec.models.mimi import mimi as M
+    from oracle.mimi_ref import MimiConfig as RC
+    from oracle.mimi_ref import MimiDecoderRef
+
+    fx = np.load(os.path.join(GOLD, "ref_mimi_tiny.npz"))
+    cfg = M.tiny_mimi_config()
+    w = M.make_mimi_decoder_weights(cfg, seed=int(fx["seed_w"]))
+    ref = MimiDecoderRef(w, RC(**{k: v for k, v in asdict(cfg).items() if k in RC.__dataclass_fields__}), param_dtype=torch.float32)
+    codes = M.make_codes(2, int(fx["n_frames"]), cfg, seed=int(fx["seed_codes"]))
+    got = ref(codes).numpy()
+    assert got.shape == fx["pcm"].shape
+    for name in ("pcm", "pcm_steps"):
+        err = float(np.abs(got - fx[name]).max())
+        peak = float(np.abs(fx[name]).max())
+        print(f"mimi oracle vs reference {name}: max-abs {err:.2e} (peak {peak:.3f})")
+        assert err < 2e-5 * max(peak, 1e-3) + 1e-7
