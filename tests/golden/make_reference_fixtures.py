@@ -401,6 +401,63 @@ def run_mimi(seed_w, seed_codes, n_frames):
     return dict(seed_w=seed_w, seed_codes=seed_codes, n_frames=n_frames, pcm=pcm.astype(np.float32), pcm_steps=pcm_steps.astype(np.float32))
 
 
+def run_qwen3_talker(seed_w, seed_in):
+    """The reference's ``Qwen3TTSTalkerForConditionalGeneration`` (talker stack with MRoPE position ids, q / k norms, GQA, KV cache, ``codec_head``;
+    talker.py:229-500, 767-822) and ``Qwen3TTSTalkerCodePredictor`` (talker.py:503-764) stepped exactly like ``_predict_code_tokens``
+    (qwen3_tts.py:941-983) with forced codes, on a tiny synthetic checkpoint: prefill of 11 positions, then two single-position steps."""
+    from dataclasses import asdict
+
+    from mlx_audio_amd.tts.models.qwen3_tts import talker as T
+
+    import_lm_and_mimi()
+    _pkg("mlx_audio.tts.models.qwen3_tts", f"{REF}/tts/models/qwen3_tts")
+    rc = _load("mlx_audio.tts.models.qwen3_tts.config", f"{REF}/tts/models/qwen3_tts/config.py")
+    rt = _load("mlx_audio.tts.models.qwen3_tts.talker", f"{REF}/tts/models/qwen3_tts/talker.py")
+    cfg = T.tiny_talker_config()
+    w = T.make_talker_weights(cfg, seed=seed_w)
+    d = asdict(cfg)
+    cpd = d.pop("code_predictor_config")
+    known = set(rc.Qwen3TTSTalkerConfig.__dataclass_fields__)
+    cp_known = set(rc.Qwen3TTSTalkerCodePredictorConfig.__dataclass_fields__)
+    rcfg = rc.Qwen3TTSTalkerConfig(code_predictor_config=rc.Qwen3TTSTalkerCodePredictorConfig(**{k: v for k, v in cpd.items() if k in cp_known}),
+                                   **{k: v for k, v in d.items() if k in known})
+    model = rt.Qwen3TTSTalkerForConditionalGeneration(rcfg)
+    model.load_weights([(k, v.numpy()) for k, v in w.items()])
+    missing, unexpected, mism = model._load_report
+    assert not missing and not unexpected and not mism, (missing[:8], unexpected[:8], mism[:4])
+    model.eval()
+    g = np.random.default_rng(seed_in)
+    B, L, H = 2, 11, cfg.hidden_size
+    prefill = (g.standard_normal((B, L, H)) * 0.5).astype(np.float32)
+    steps = (g.standard_normal((2, B, 1, H)) * 0.5).astype(np.float32)
+    cache = model.make_cache()
+    logits0, hid0 = model(mx.array(prefill), cache=cache)
+    outs = [(np.asarray(logits0)[:, -1], np.asarray(hid0)[:, -1])]
+    for s_ in steps:
+        lg, hd = model(mx.array(s_), cache=cache)
+        outs.append((np.asarray(lg)[:, -1], np.asarray(hd)[:, -1]))
+    # code predictor, teacher-forced on fixed codes, from the hidden state of the last talker step
+    ng = cfg.num_code_groups
+    forced = g.integers(0, cfg.code_predictor_config.vocab_size, size=(B, ng)).astype(np.int32)
+    forced[:, 0] = g.integers(0, cfg.vocab_size - 1024, size=B)
+    cp_cache = model.code_predictor.make_cache()
+    hidden = mx.array(outs[-1][1][:, None, :])
+    cp_logits = []
+    for i in range(ng - 1):
+        if i == 0:
+            e0 = model.get_input_embeddings()(mx.array(forced[:, 0:1]))
+            inp = mx.concatenate([hidden, e0], axis=1)
+        else:
+            inp = model.code_predictor.codec_embedding[i - 1](mx.array(forced[:, i:i + 1]))
+        lg, cp_cache, _ = model.code_predictor(inp, cache=cp_cache, generation_step=i)
+        cp_logits.append(np.asarray(lg)[:, -1])
+    text_ids = g.integers(0, cfg.text_vocab_size, size=(B, 5)).astype(np.int32)
+    tproj = np.asarray(model.text_projection(model.get_text_embeddings()(mx.array(text_ids))))
+    return dict(seed_w=seed_w, seed_in=seed_in, prefill=prefill, steps=steps, forced=forced, text_ids=text_ids, text_projection=tproj.astype(np.float32),
+                logits=np.stack([o[0] for o in outs]).astype(np.float32), hidden=np.stack([o[1] for o in outs]).astype(np.float32),
+                cp_logits=np.stack(cp_logits).astype(np.float32))
+
+
 def main():
     R = import_reference()
     n = check_shim_against_reference_vectors(R)
@@ -417,6 +474,9 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_mimi_tiny.npz"), **mfx)
     print("mimi:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in mfx.items()},
           "decode vs decode_step max diff", float(np.abs(mfx["pcm"] - mfx["pcm_steps"]).max()), "peak", float(np.abs(mfx["pcm"]).max()))
+    qfx = run_qwen3_talker(seed_w=1, seed_in=4)
+    np.savez_compressed(os.path.join(HERE, "ref_qwen3_talker_tiny.npz"), **qfx)
+    print("qwen3 talker:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in qfx.items()})
     wfx = run_whisper(seed_w=3, seed_mel=2, sample_len=24)
     np.savez_compressed(os.path.join(HERE, "ref_whisper_tiny.npz"), **wfx)
     print("whisper:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in wfx.items()}, wfx["ts_tokens"].tolist(), wfx["nots_tokens"].tolist())

@@ -168,3 +168,31 @@ def test_mimi_oracle_reproduces_the_reference_modules():
         peak = float(np.abs(fx[name]).max())
         print(f"mimi oracle vs reference {name}: max-abs {err:.2e} (peak {peak:.3f})")
         assert err < 2e-5 * max(peak, 1e-3) + 1e-7
+
+
+def test_qwen3_talker_oracle_reproduces_the_reference_modules():
+    """The reference's talker stack (MRoPE position ids, q / k RMSNorm, GQA, SwiGLU, KV cache: talker.py:229-500) with ``codec_head`` and
+    ``text_projection``, and its code predictor stepped like ``_predict_code_tokens`` (qwen3_tts.py:941-983) on forced codes: prefill + 2 cached steps."""
+    import torch.nn.functional as F
+
+    from mlx_audio_amd.tts.models.qwen3_tts import talker as T
+    from oracle.qwen3_talker_ref import Qwen3TalkerRef
+
+    fx = np.load(os.path.join(GOLD, "ref_qwen3_talker_tiny.npz"))
+    cfg = T.tiny_talker_config()
+    w = T.make_talker_weights(cfg, seed=int(fx["seed_w"]))
+    ref = Qwen3TalkerRef(w, cfg, param_dtype=torch.float32)
+    cache = ref.talker.make_cache()
+    xs = [torch.from_numpy(fx["prefill"])] + [torch.from_numpy(s) for s in fx["steps"]]
+    for i, x in enumerate(xs):
+        h = ref.talker(x, cache)[:, -1]
+        logits = F.linear(h, ref.w["codec_head.weight"])
+        assert rel_max(h.numpy(), fx["hidden"][i]) < 2e-5 and rel_max(logits.numpy(), fx["logits"][i]) < 2e-5, i
+    trace = []
+    forced = torch.from_numpy(fx["forced"]).long()
+    codes = ref.predict_codes(forced[:, 0], h, temperature=0.0, top_k=0, top_p=1.0, forced=forced, trace=trace)
+    assert torch.equal(codes, forced) and len(trace) == cfg.num_code_groups - 1
+    for i, lg in enumerate(trace):
+        assert rel_max(lg.numpy(), fx["cp_logits"][i]) < 2e-5, i
+    tp = ref.text_projection(ref.w["model.text_embedding.weight"][torch.from_numpy(fx["text_ids"]).long()])
+    assert rel_max(tp.numpy(), fx["text_projection"]) < 2e-5
