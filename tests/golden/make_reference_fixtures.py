@@ -458,6 +458,38 @@ def run_qwen3_talker(seed_w, seed_in):
                 cp_logits=np.stack(cp_logits).astype(np.float32))
 
 
+def run_qwen3_codec(seed_w, seed_codes, n_frames):
+    """The reference's ``Qwen3TTSSpeechTokenizerDecoder`` (split RVQ decode, pre_conv, 8-layer-style transformer with LayerScale and sliding window,
+    ConvNeXt up-samplers, SnakeBeta decoder blocks: speech_tokenizer.py:32-955), whole-utterance ``__call__`` and ``chunked_decode``."""
+    from dataclasses import asdict
+
+    from mlx_audio_amd.tts.models.qwen3_tts import synthetic as QS
+
+    import_lm_and_mimi()
+    if "mlx_audio.tts.models.qwen3_tts.config" not in sys.modules:
+        _pkg("mlx_audio.tts.models.qwen3_tts", f"{REF}/tts/models/qwen3_tts")
+        _load("mlx_audio.tts.models.qwen3_tts.config", f"{REF}/tts/models/qwen3_tts/config.py")
+    rc = sys.modules["mlx_audio.tts.models.qwen3_tts.config"]
+    st = _load("mlx_audio.tts.models.qwen3_tts.speech_tokenizer", f"{REF}/tts/models/qwen3_tts/speech_tokenizer.py")
+    cfg = QS.tiny_codec_config()
+    w = QS.make_codec_decoder_weights(cfg, seed=seed_w)
+    known = set(rc.Qwen3TTSTokenizerDecoderConfig.__dataclass_fields__)
+    rcfg = rc.Qwen3TTSTokenizerDecoderConfig(**{k: v for k, v in asdict(cfg).items() if k in known})
+    model = st.Qwen3TTSSpeechTokenizerDecoder(rcfg)
+    model.load_weights([(k, v.numpy()) for k, v in w.items()])
+    missing, unexpected, mism = model._load_report
+    assert not unexpected and not mism, (unexpected[:8], mism[:4])
+    model.eval()
+    for _, m in model.named_modules():
+        if hasattr(m, "update_in_place"):
+            m.update_in_place()
+    codes = QS.make_codes(2, n_frames, cfg, seed=seed_codes).numpy().astype(np.int32)
+    audio = np.asarray(model(mx.array(codes)))
+    chunked = np.asarray(model.chunked_decode(mx.array(codes), chunk_size=12, left_context_size=5))
+    return dict(seed_w=seed_w, seed_codes=seed_codes, n_frames=n_frames, missing=np.array(missing), audio=audio.astype(np.float32),
+                chunked=chunked.astype(np.float32))
+
+
 def main():
     R = import_reference()
     n = check_shim_against_reference_vectors(R)
@@ -477,6 +509,10 @@ def main():
     qfx = run_qwen3_talker(seed_w=1, seed_in=4)
     np.savez_compressed(os.path.join(HERE, "ref_qwen3_talker_tiny.npz"), **qfx)
     print("qwen3 talker:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in qfx.items()})
+    cfx = run_qwen3_codec(seed_w=2, seed_codes=3, n_frames=40)
+    np.savez_compressed(os.path.join(HERE, "ref_qwen3_codec_tiny.npz"), **cfx)
+    print("qwen3 codec:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in cfx.items() if a != "missing"}, "missing", cfx["missing"].tolist()[:6],
+          "peak", float(np.abs(cfx["audio"]).max()))
     wfx = run_whisper(seed_w=3, seed_mel=2, sample_len=24)
     np.savez_compressed(os.path.join(HERE, "ref_whisper_tiny.npz"), **wfx)
     print("whisper:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in wfx.items()}, wfx["ts_tokens"].tolist(), wfx["nots_tokens"].tolist())

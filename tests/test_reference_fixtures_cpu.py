@@ -196,3 +196,25 @@ def test_qwen3_talker_oracle_reproduces_the_reference_modules():
         assert rel_max(lg.numpy(), fx["cp_logits"][i]) < 2e-5, i
     tp = ref.text_projection(ref.w["model.text_embedding.weight"][torch.from_numpy(fx["text_ids"]).long()])
     assert rel_max(tp.numpy(), fx["text_projection"]) < 2e-5
+
+
+def test_qwen3_codec_oracle_reproduces_the_reference_modules():
+    """The reference's ``Qwen3TTSSpeechTokenizerDecoder`` (speech_tokenizer.py:786-955): codes -> waveform in one call and through ``chunked_decode``
+    (chunks of 12 frames with 5 frames of left context); the only parameters of the reference's decoder that the synthetic checkpoint does not
+    carry are the quantizer's encode-side ``input_proj`` weights."""
+    from mlx_audio_amd.tts.models.qwen3_tts import synthetic as QS
+    from oracle.qwen3_codec_ref import Qwen3CodecDecoderRef
+
+    fx = np.load(os.path.join(GOLD, "ref_qwen3_codec_tiny.npz"))
+    assert all(m.endswith("input_proj.weight") for m in fx["missing"].tolist())
+    cfg = QS.tiny_codec_config()
+    w = QS.make_codec_decoder_weights(cfg, seed=int(fx["seed_w"]))
+    ref = Qwen3CodecDecoderRef(w, cfg, param_dtype=torch.float32)
+    codes = QS.make_codes(2, int(fx["n_frames"]), cfg, seed=int(fx["seed_codes"]))
+    got = ref(codes).numpy()
+    peak = float(np.abs(fx["audio"]).max())
+    err = float(np.abs(got - fx["audio"]).max())
+    print(f"qwen3 codec oracle vs reference: max-abs {err:.2e} (peak {peak:.3f})")
+    assert got.shape == fx["audio"].shape and err < 2e-5 * peak
+    ch = ref.chunked_decode(codes, chunk_size=12, left_context_size=5).numpy()
+    assert ch.shape == fx["chunked"].shape and float(np.abs(ch - fx["chunked"]).max()) < 2e-5 * peak
