@@ -19,17 +19,19 @@ Pinning status
   against every known-answer vector the reference's own tests hold for this
   path (``tests/golden/*.json``, transcribed with file:line citations; checked
   in ``tests/test_oracle_golden.py``).
-* ``kokoro_ref`` and ``kitten_ref`` end-to-end (tokens -> waveform): **pinned to the
-  reference's own modules** since round 2.  The reference holds no golden audio /
-  token / logit fixture for them and real MLX cannot be installed, so
-  ``tests/golden/make_reference_fixtures.py`` imports the reference's source files
-  from ``/root/reference`` (unmodified) over a numpy stand-in for the MLX array
-  library (``tests/golden/mlx_shim.py``), runs them on seeded synthetic checkpoints
-  and commits what they compute (``tests/golden/ref_*.npz``);
-  ``tests/test_reference_fixtures_cpu.py`` holds the oracle to those files.  The
-  stand-in is itself checked against the reference's known-answer vectors before
-  anything is written.  Not covered by this: MLX's own kernels.
-* the other model oracles (``whisper_ref``, ``qwen3_*_ref``, ``csm_ref``, ``mimi_ref``,
-  codec decoders) remain **parity unpinned** end to end (their headers say what the
-  reference does pin).
+* every model oracle -- ``kokoro_ref``, ``kitten_ref``, ``whisper_ref``, ``qwen3_talker_ref``,
+  ``qwen3_codec_ref``, ``csm_ref``, ``mimi_ref`` (and through them ``lm_ref.StackRef``'s
+  Qwen3 / Llama-3 / Mimi variants) -- is **pinned to the reference's own modules**
+  since round 2.  The reference holds no golden audio / token / logit fixture for
+  them and real MLX cannot be installed, so ``tests/golden/make_reference_fixtures.py``
+  imports the reference's source files from ``/root/reference`` (unmodified) over a
+  numpy stand-in for the MLX array library (``tests/golden/mlx_shim.py``), runs them
+  on seeded synthetic checkpoints and commits what they compute
+  (``tests/golden/ref_*.npz``); ``tests/test_reference_fixtures_cpu.py`` holds the
+  oracles to those files (1e-6 .. 3e-5; integer paths exact).  The stand-in is itself
+  checked against the reference's known-answer vectors before anything is written,
+  and its ``load_weights`` reports parameter names the reference's modules own but
+  the synthetic checkpoints lack (none on the decode paths).  Not covered: MLX's own
+  kernels, and the codec oracles of SURVEY section 8(f) (``dac_ref``, ``snac_ref``,
+  ``vocos_ref``), which remain unpinned end to end.
 """

@@ -10,7 +10,10 @@ Follows ``tts/models/sesame/sesame.py`` of the reference:
   * :406-425  _embed_audio / _embed_tokens
   * :767      sampler = make_sampler(temp=0.9, top_k=50) (lm/sample_utils.py) -- via oracle.sampling_ref with explicit Gumbel noise
 Stacks: oracle.lm_ref.StackRef (interleaved RoPE, lm/models/llama.py:46-198 + sesame/attention.py:11-175).
-Parity status: unpinned end to end (no golden frames in the reference).
+Parity status: **pinned to the reference's own modules** (round 2): tests/golden/make_reference_fixtures.py runs the reference's source files for
+CSM (imported from /root/reference, unmodified, over the numpy stand-in for MLX in tests/golden/mlx_shim.py) on a seeded tiny checkpoint, and
+tests/test_reference_fixtures_cpu.py holds this oracle to the result -- ``SesameModel.generate_frame`` for three frames with a forcing sampler (backbone + depth decoder logits): 3e-5.
+The reference's own tests pin shapes / token-rule cases only (reproduced in tests/test_oracle_golden.py); MLX's kernels are not exercised by the stand-in.
 """
 from __future__ import annotations
 

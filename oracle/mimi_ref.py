@@ -13,8 +13,10 @@ Follows ``codec/models/mimi`` of the reference:
   * ``modules/seanet.py:54-110, 206-300``  SeanetResnetBlock (ELU -> conv k3 -> ELU -> conv k1, true skip), DecoderLayer, SeanetDecoder
 The non-streaming ``decode`` is restated; the streaming ``decode_step`` (one frame per call, CSM's usage) produces the same samples for
 causal convolutions, which is what the product computes in one batch per utterance (state reset per utterance).
-Parity status: shape pins of the reference reproduce (``codec/tests/test_mimi.py:11-21``: codes (1, 32, 63) -> audio (1, 1, 120960));
-values are unpinned (the reference test decodes random weights and asserts shapes only).
+Parity status: **pinned to the reference's own modules** (round 2): tests/golden/make_reference_fixtures.py runs the reference's source files for
+Mimi (imported from /root/reference, unmodified, over the numpy stand-in for MLX in tests/golden/mlx_shim.py) on a seeded tiny checkpoint, and
+tests/test_reference_fixtures_cpu.py holds this oracle to the result -- ``Mimi.decode`` and frame-by-frame ``decode_step`` (30 frames, attention context 20): 1e-6 of the waveform.
+The reference's own tests pin shapes / token-rule cases only (reproduced in tests/test_oracle_golden.py); MLX's kernels are not exercised by the stand-in.
 """
 from __future__ import annotations
 

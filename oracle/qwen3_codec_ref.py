@@ -11,7 +11,10 @@ Follows ``tts/models/qwen3_tts/speech_tokenizer.py`` of the reference:
   * :786-880  Qwen3TTSSpeechTokenizerDecoder.__call__ and chunked_decode (:930-954)
 Parameter names are the reference's module paths (``decoder.`` prefix dropped), conv weights in the MLX layout (C_out, K, C_in/groups);
 ConvTranspose1d weights (C_out, K, C_in) as ``mx.conv_transpose1d`` takes them.
-Parity status: unpinned end to end (no golden codes -> audio fixture exists in the reference).
+Parity status: **pinned to the reference's own modules** (round 2): tests/golden/make_reference_fixtures.py runs the reference's source files for
+the Qwen3-TTS codec decoder (imported from /root/reference, unmodified, over the numpy stand-in for MLX in tests/golden/mlx_shim.py) on a seeded tiny checkpoint, and
+tests/test_reference_fixtures_cpu.py holds this oracle to the result -- ``Qwen3TTSSpeechTokenizerDecoder.__call__`` and ``chunked_decode``: 9e-7 of the waveform.
+The reference's own tests pin shapes / token-rule cases only (reproduced in tests/test_oracle_golden.py); MLX's kernels are not exercised by the stand-in.
 """
 from __future__ import annotations
 

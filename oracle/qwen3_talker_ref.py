@@ -11,7 +11,10 @@ Follows ``tts/models/qwen3_tts`` of the reference:
                                     penalty, suppress ids [vocab-1024, vocab) except EOS :927-933)
 Sampling is ``oracle.sampling_ref`` with explicit Gumbel noise.  Prompt construction (:359-604) is tokenizer-side host logic and not part of
 this restatement: the loop starts from prefill embeddings.
-Parity status: unpinned end to end (no golden codes in the reference).
+Parity status: **pinned to the reference's own modules** (round 2): tests/golden/make_reference_fixtures.py runs the reference's source files for
+the Qwen3-TTS talker (imported from /root/reference, unmodified, over the numpy stand-in for MLX in tests/golden/mlx_shim.py) on a seeded tiny checkpoint, and
+tests/test_reference_fixtures_cpu.py holds this oracle to the result -- talker stack (prefill + cached steps), ``codec_head``, ``text_projection`` and the code predictor stepped like ``_predict_code_tokens`` on forced codes: 2e-5.
+The reference's own tests pin shapes / token-rule cases only (reproduced in tests/test_oracle_golden.py); MLX's kernels are not exercised by the stand-in.
 """
 from __future__ import annotations
 

@@ -18,9 +18,10 @@ The reference itself rounds every activation to fp16; that rounding noise (2^-11
 logit tolerance of the parity tests is 2e-3 and token equality is asserted only where the oracle's top-2 logit
 margin exceeds the tolerance.
 
-Parity status: **unpinned end to end** -- the reference holds no golden Whisper logits or tokens that can be
-reproduced here (its greedy-decoder test, ``stt/tests/test_models.py``, runs on mocked logits: the same mocked-logit
-cases are replayed against ``GreedyDecoderRef`` / the filters in ``tests/test_oracle_golden.py``).
+Parity status: **pinned to the reference's own modules** (round 2): tests/golden/make_reference_fixtures.py runs the reference's source files for
+Whisper (imported from /root/reference, unmodified, over the numpy stand-in for MLX in tests/golden/mlx_shim.py) on a seeded tiny checkpoint, and
+tests/test_reference_fixtures_cpu.py holds this oracle to the result -- ``Model`` (encoder, decoder + KV cache) and ``DecodingTask`` (greedy, all three logit filters, no-speech probability) in float32: features / logits 2e-5, decoded tokens of both decoding modes exact.
+The reference's own tests pin shapes / token-rule cases only (reproduced in tests/test_oracle_golden.py); MLX's kernels are not exercised by the stand-in.
 """
 from __future__ import annotations
 

@@ -490,6 +490,105 @@ def run_qwen3_codec(seed_w, seed_codes, n_frames):
                 chunked=chunked.astype(np.float32))
 
 
+def run_csm(seed_w, seed_in, n_frames):
+    """The reference's ``SesameModel`` (sesame.py:301-425: two ``LlamaModel`` stacks of lm/models/llama.py with the ``Llama3ScaledRoPE`` attention of
+    sesame/attention.py, summed audio + text embeddings, ``codebook0_head``, depth decoder with ``audio_head``) -- ``generate_frame`` called
+    ``n_frames`` times on a prompt, with a sampler that returns forced codes and records the logits it was handed."""
+    from mlx_audio_amd.tts.models.sesame import engine as E
+
+    import_lm_and_mimi()
+    _load("mlx_audio.lm.models.llama", f"{REF}/lm/models/llama.py")
+    _pkg("mlx_audio.tts.models.sesame", f"{REF}/tts/models/sesame")
+    aio = types.ModuleType("mlx_audio.audio_io")
+    aio.read = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("no audio files here"))
+    sys.modules["mlx_audio.audio_io"] = aio
+    mimi_pkg = sys.modules["mlx_audio.codec.models.mimi"]
+    mimi_pkg.Mimi = sys.modules["mlx_audio.codec.models.mimi.mimi"].Mimi
+    mimi_pkg.MimiStreamingDecoder = type("MimiStreamingDecoder", (), {})
+    _load("mlx_audio.tts.models.sesame.attention", f"{REF}/tts/models/sesame/attention.py")
+    # sesame.py imports the HF tokenizer stack at module level (text tokenisation, not on this path); ``transformers`` probes for a real ``mlx``
+    # and trips over the stand-in, so both names are stubbed for the duration of this one import
+    u = sys.modules["mlx_audio.utils"]
+    u.load_audio = u.resample_audio = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("no audio files here"))
+    saved = {k: sys.modules.get(k) for k in ("transformers", "tokenizers", "tokenizers.processors")}
+    tf = types.ModuleType("transformers")
+    tf.AutoTokenizer = None
+    tk, tkp = types.ModuleType("tokenizers"), types.ModuleType("tokenizers.processors")
+    tkp.TemplateProcessing = None
+    tk.processors = tkp
+    sys.modules.update({"transformers": tf, "tokenizers": tk, "tokenizers.processors": tkp})
+    try:
+        rs = _load("mlx_audio.tts.models.sesame.sesame", f"{REF}/tts/models/sesame/sesame.py")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    cfg = E.tiny_csm()
+    w = E.make_csm_weights(cfg, seed=seed_w)
+
+    def llama_fields(sc):
+        return dict(num_hidden_layers=sc.n_layers, num_attention_heads=sc.n_heads, num_key_value_heads=sc.n_kv_heads, head_dim=sc.head_dim,
+                    hidden_size=sc.d_model, intermediate_size=sc.d_ff, rms_norm_eps=sc.norm_eps, max_position_embeddings=sc.max_pos,
+                    attention_bias=False, mlp_bias=False, rope_theta=sc.rope_theta,
+                    rope_scaling={"factor": sc.rope_llama3_factor, "high_freq_factor": 4.0, "low_freq_factor": 1.0,
+                                  "original_max_position_embeddings": 8192, "rope_type": "llama3"})
+
+    b, d_ = cfg.backbone, cfg.decoder
+    config = dict(model_type="csm", backbone_flavor="none", decoder_flavor="none", text_vocab_size=cfg.text_vocab_size, audio_vocab_size=cfg.audio_vocab_size,
+                  audio_num_codebooks=cfg.audio_num_codebooks, attention_dropout=0.0, audio_eos_token_id=0, audio_token_id=0, bos_token_id=0,
+                  codebook_eos_token_id=0, codebook_pad_token_id=0, hidden_act="silu", initializer_range=0.02, num_codebooks=cfg.audio_num_codebooks,
+                  pad_token_id=0, tie_codebooks_embeddings=True, tie_word_embeddings=False, use_cache=True, vocab_size=cfg.text_vocab_size,
+                  depth_decoder_config=dict(attention_dropout=0.0, backbone_hidden_size=b.d_model, hidden_act="silu", initializer_range=0.02,
+                                            model_type="csm_depth_decoder_model", num_codebooks=cfg.audio_num_codebooks, use_cache=True,
+                                            vocab_size=cfg.audio_vocab_size, **llama_fields(d_)),
+                  **llama_fields(b))
+    model = rs.SesameModel(config)
+    names = {"wq": "self_attn.q_proj", "wk": "self_attn.k_proj", "wv": "self_attn.v_proj", "wo": "self_attn.o_proj", "w_gate": "mlp.gate_proj",
+             "w_up": "mlp.up_proj", "w_down": "mlp.down_proj", "attn_norm": "input_layernorm", "mlp_norm": "post_attention_layernorm"}
+    ref_w = {}
+    for k, v in w.items():  # canonical stack names (mlx_audio_amd/lm/stack.py) -> the reference's module paths
+        parts = k.split(".")
+        if parts[0] in ("backbone", "decoder") and parts[1] == "layers":
+            ref_w[".".join([parts[0], "layers", parts[2], names[parts[3]], parts[4]])] = v
+        elif parts[0] in ("backbone", "decoder") and parts[1] == "final_norm":
+            ref_w[f"{parts[0]}.norm.{parts[2]}"] = v
+        else:
+            ref_w[k] = v
+    model.load_weights([(k, v.numpy()) for k, v in ref_w.items()])
+    missing, unexpected, mism = model._load_report
+    assert not missing and not unexpected and not mism, (missing[:8], unexpected[:8], mism[:4])
+    model.eval()
+    model.setup_caches(2)
+    g = np.random.default_rng(seed_in)
+    B, S, ncb = 2, 7, cfg.audio_num_codebooks
+    toks = np.zeros((B, S, ncb + 1), dtype=np.int32)
+    mask = np.zeros((B, S, ncb + 1), dtype=bool)
+    toks[:, :4, -1] = g.integers(1, cfg.text_vocab_size, size=(B, 4))      # text rows
+    mask[:, :4, -1] = True
+    toks[:, 4:, :-1] = g.integers(1, cfg.audio_vocab_size, size=(B, S - 4, ncb))   # audio rows
+    mask[:, 4:, :-1] = True
+    forced = g.integers(1, cfg.audio_vocab_size, size=(n_frames, B, ncb)).astype(np.int32)
+    logits = []
+    cur_t, cur_m = toks, mask
+    for f in range(n_frames):
+        rec = []
+
+        def sampler(lg, rec=rec, f=f):
+            rec.append(np.asarray(lg))
+            return mx.array(forced[f][:, len(rec) - 1])
+
+        pos = np.broadcast_to(np.arange(cur_t.shape[1])[None, :], (B, cur_t.shape[1]))
+        out = np.asarray(model.generate_frame(mx.array(cur_t), mx.array(cur_m.astype(np.float32)), mx.array(pos), sampler))
+        assert np.array_equal(out, forced[f])
+        logits.append(np.stack(rec))
+        cur_t = np.concatenate([out, np.zeros((B, 1), np.int32)], axis=1)[:, None, :]
+        cur_m = np.concatenate([np.ones((B, ncb), bool), np.zeros((B, 1), bool)], axis=1)[:, None, :]
+    return dict(seed_w=seed_w, seed_in=seed_in, n_frames=n_frames, prompt_tokens=toks, prompt_mask=mask, forced=forced,
+                logits=np.stack(logits).astype(np.float32))
+
+
 def main():
     R = import_reference()
     n = check_shim_against_reference_vectors(R)
@@ -513,6 +612,9 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_qwen3_codec_tiny.npz"), **cfx)
     print("qwen3 codec:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in cfx.items() if a != "missing"}, "missing", cfx["missing"].tolist()[:6],
           "peak", float(np.abs(cfx["audio"]).max()))
+    sfx = run_csm(seed_w=2, seed_in=6, n_frames=3)
+    np.savez_compressed(os.path.join(HERE, "ref_csm_tiny.npz"), **sfx)
+    print("csm:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in sfx.items()})
     wfx = run_whisper(seed_w=3, seed_mel=2, sample_len=24)
     np.savez_compressed(os.path.join(HERE, "ref_whisper_tiny.npz"), **wfx)
     print("whisper:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in wfx.items()}, wfx["ts_tokens"].tolist(), wfx["nots_tokens"].tolist())

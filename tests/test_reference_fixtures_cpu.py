@@ -218,3 +218,28 @@ def test_qwen3_codec_oracle_reproduces_the_reference_modules():
     assert got.shape == fx["audio"].shape and err < 2e-5 * peak
     ch = ref.chunked_decode(codes, chunk_size=12, left_context_size=5).numpy()
     assert ch.shape == fx["chunked"].shape and float(np.abs(ch - fx["chunked"]).max()) < 2e-5 * peak
+
+
+def test_csm_oracle_reproduces_the_reference_modules():
+    """The reference's ``SesameModel.generate_frame`` (sesame.py:361-404) -- backbone and depth decoder are its ``LlamaModel`` (lm/models/llama.py) with
+    the Llama-3-scaled RoPE attention of sesame/attention.py and the KV caches of lm/models/cache.py -- called for three frames with a sampler that
+    hands back forced codes: the logits every sampler call received (codebook 0 head, then the depth decoder's per-codebook heads)."""
+    from mlx_audio_amd.tts.models.sesame import engine as E
+    from oracle import csm_ref as R
+
+    fx = np.load(os.path.join(GOLD, "ref_csm_tiny.npz"))
+    cfg = E.tiny_csm()
+    w = E.make_csm_weights(cfg, seed=int(fx["seed_w"]))
+    rcfg = R.CSMConfig(backbone=R.llama_stack(cfg.backbone.d_model, cfg.backbone.n_layers, cfg.backbone.n_heads, cfg.backbone.n_kv_heads,
+                                              cfg.backbone.head_dim, cfg.backbone.d_ff),
+                       decoder=R.llama_stack(cfg.decoder.d_model, cfg.decoder.n_layers, cfg.decoder.n_heads, cfg.decoder.n_kv_heads,
+                                             cfg.decoder.head_dim, cfg.decoder.d_ff),
+                       audio_vocab_size=cfg.audio_vocab_size, audio_num_codebooks=cfg.audio_num_codebooks, text_vocab_size=cfg.text_vocab_size)
+    ref = R.CSMRef(w, rcfg, param_dtype=torch.float32)
+    forced = torch.from_numpy(fx["forced"]).long()              # [frames, B, n_cb]
+    out = ref.generate(torch.from_numpy(fx["prompt_tokens"]).long(), torch.from_numpy(fx["prompt_mask"]), int(fx["n_frames"]),
+                       forced=forced.permute(1, 0, 2), record=True, temperature=0.0)
+    assert torch.equal(out["frames"], forced.permute(1, 0, 2))
+    for f, tr in enumerate(out["trace"]):
+        for i, lg in enumerate(tr):
+            assert rel_max(lg.numpy(), fx["logits"][f, i]) < 3e-5, (f, i)
