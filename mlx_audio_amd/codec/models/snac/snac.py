@@ -10,8 +10,10 @@ Mirrors ``mlx_audio/codec/models/snac/snac.py`` + ``layers.py`` + ``vq.py`` (con
     transposed convs (K = 2 stride) run polyphase as 2-tap stride-1 GEMMs with a strided store; the depthwise k7 convs of the input stage and of
     every ``ResidualUnit`` (groups = channels, dilation 1 / 3 / 9) run on ``mi355_dwconv`` with the Snake prologue; residual adds and the final
     ``tanh`` are epilogues;
-  * ``NoiseBlock`` (layers.py:256-267): ``x + noise * linear(x)`` with the per-sample Gaussian noise either supplied (parity tests) or drawn on
-    the device.
+  * ``NoiseBlock`` (layers.py:256-267): ``x + noise * linear(x)`` with the Gaussian noise either supplied (parity tests) or drawn on the device.
+    Reference quirk preserved: the block unpacks ``B, C, T = x.shape`` from a channels-LAST tensor, so its ``mx.random.normal((B, 1, T))`` is one
+    draw per CHANNEL, constant over time (the PyTorch original draws one per time step) -- found by running the reference's own file
+    (tests/golden/make_reference_fixtures.py); ``noises[i]`` is therefore ``[B, 1, channels_i]``.
 Reference quirk preserved: ``WNConvTranspose1d`` hands ``groups = 1`` to MLX's ``output_padding`` slot (positional order), so each transposed
 conv emits one extra sample: the reference's test pins 59 / 118 / 236 code frames -> 120 907 samples (codec/tests/test_snac.py:24-34).
 
@@ -237,8 +239,9 @@ class SNAC:
         return self._conv(x, sn, c, y, dil=dil)
 
     def decode_latents(self, z, noises: Optional[List[torch.Tensor]] = None, return_stages: bool = False):
-        """z [B, latent_dim, T] -> audio [B, T', 1] (``self.decoder(z.moveaxis(1, 2))``, snac.py:106).  ``noises[i]`` [B, T_i, 1] replaces
-        DecoderBlock i's ``mx.random.normal((B, 1, T))`` (channels-last); omitted: drawn on the device."""
+        """z [B, latent_dim, T] -> audio [B, T', 1] (``self.decoder(z.moveaxis(1, 2))``, snac.py:106).  ``noises[i]`` [B, 1, channels_i] replaces
+        DecoderBlock i's ``mx.random.normal((B, 1, T))`` -- whose "T" is the channel count of the channels-last activation (module docstring);
+        omitted: drawn on the device."""
         z = torch.as_tensor(z, dtype=torch.float32).to(self.device)
         x = z.transpose(1, 2).contiguous()
         B, T, _ = x.shape
@@ -262,9 +265,9 @@ class SNAC:
             if blk["noise"] is not None:
                 if noises is not None:
                     nz = torch.as_tensor(noises[bi], dtype=torch.float32).to(self.device)
-                    assert nz.shape == (B, Lout, 1), (nz.shape, (B, Lout, 1))
+                    assert nz.shape == (B, 1, cout), (nz.shape, (B, 1, cout))
                 else:
-                    nz = torch.randn((B, Lout, 1), dtype=torch.float32, device=self.device)
+                    nz = torch.randn((B, 1, cout), dtype=torch.float32, device=self.device)
                 self._conv(y, None, blk["noise"], tmp)
                 y.addcmul_(nz, tmp)                    # x + noise * linear(x): one elementwise pass over [B, Lout, cout]
             for u in blk["units"]:

@@ -20,8 +20,8 @@ Pinning status
   path (``tests/golden/*.json``, transcribed with file:line citations; checked
   in ``tests/test_oracle_golden.py``).
 * every model oracle -- ``kokoro_ref``, ``kitten_ref``, ``whisper_ref``, ``qwen3_talker_ref``,
-  ``qwen3_codec_ref``, ``csm_ref``, ``mimi_ref`` (and through them ``lm_ref.StackRef``'s
-  Qwen3 / Llama-3 / Mimi variants) -- is **pinned to the reference's own modules**
+  ``qwen3_codec_ref``, ``csm_ref``, ``mimi_ref``, ``dac_ref``, ``snac_ref``, ``vocos_ref`` (and through
+  them ``lm_ref.StackRef``'s Qwen3 / Llama-3 / Mimi variants) -- is **pinned to the reference's own modules**
   since round 2.  The reference holds no golden audio / token / logit fixture for
   them and real MLX cannot be installed, so ``tests/golden/make_reference_fixtures.py``
   imports the reference's source files from ``/root/reference`` (unmodified) over a
@@ -32,6 +32,7 @@ Pinning status
   checked against the reference's known-answer vectors before anything is written,
   and its ``load_weights`` reports parameter names the reference's modules own but
   the synthetic checkpoints lack (none on the decode paths).  Not covered: MLX's own
-  kernels, and the codec oracles of SURVEY section 8(f) (``dac_ref``, ``snac_ref``,
-  ``vocos_ref``), which remain unpinned end to end.
+  kernels.  Two reference quirks the restatements had missed were found this way and
+  are now reproduced: KittenTTS's 2F + 1-point coarse phase grid and SNAC's
+  per-channel NoiseBlock noise.
 """

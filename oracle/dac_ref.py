@@ -16,7 +16,10 @@ Follows /root/reference/mlx_audio/codec/models/descript statement by statement:
 
 Parameter names are the reference's module paths (``decoder.model.layers.N...``, ``quantizer.quantizers.N.codebook.weight`` ...), layouts MLX's
 (conv ``[out, K, in]``).  Arithmetic float32 (float64 on request) on the parameters as given (the published checkpoints are float32).
-Parity status: **unpinned beyond shapes** (the reference's tests hold the length pins above only).
+Parity status: **pinned to the reference's own modules** (round 2): tests/golden/make_reference_fixtures.py runs the reference's source files
+(imported from /root/reference, unmodified, over the numpy stand-in for MLX in tests/golden/mlx_shim.py) and tests/test_reference_fixtures_cpu.py holds
+this oracle to the result -- ``DAC.quantizer.from_codes`` + ``DAC.decode`` on a small seeded checkpoint (all four rates): latents 1e-5, waveform 2e-5.  The reference's own tests hold shape / length pins only
+(reproduced in tests/test_oracle_golden.py and the GPU tests); MLX's kernels are not exercised by the stand-in.
 """
 from __future__ import annotations
 

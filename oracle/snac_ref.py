@@ -12,14 +12,19 @@ Follows /root/reference/mlx_audio/codec/models/snac statement by statement:
   * ``layers.py:159-206``   Decoder: (depthwise: conv k7 groups = C, conv k1) | conv k7 -> [LocalMHA: not restated, attn_window_size must be None]
                             -> DecoderBlocks -> snake -> conv k7 -> tanh
   * ``layers.py:209-233``   ResidualUnit: snake, conv k7 (dilation d, padding 3 d, groups), snake, conv k1, + x
-  * ``layers.py:256-267``   NoiseBlock: x + noise[B, 1, T] * linear(x)  (1x1 conv, no bias); the Gaussian noise is an explicit input here
+  * ``layers.py:256-267``   NoiseBlock: x + noise * linear(x)  (1x1 conv, no bias); the Gaussian noise is an explicit input here.  The block reads
+                            ``B, C, T = x.shape`` off a channels-LAST tensor, so ``mx.random.normal((B, 1, T))`` is [B, 1, channels]: one draw per
+                            channel, constant over time (pinned by tests/test_reference_fixtures_cpu.py against the reference's own file)
   * ``layers.py:270-295``   DecoderBlock: snake, convT K = 2 s (padding ceil(s / 2)), [NoiseBlock], three units with dilations 1 / 3 / 9
   * ``vq.py:102-137``       ResidualVectorQuantize.from_codes: codebook lookup, out_proj (1x1 WNConv), repeat_interleave(stride), running sum
   * ``snac.py:104-107``     SNAC.decode(codes) = decoder(from_codes(codes).moveaxis(1, 2))
 
 Parameter names are the reference's module paths (``decoder.model.layers.N...``, ``quantizer.quantizers.N.codebook.weight`` ...), layouts MLX's
 (conv ``[out, K, in / groups]``, transposed conv stored ``[in, K, out]``).  Arithmetic float32 (float64 on request) on the parameters as given.
-Parity status: **unpinned beyond shapes** (the reference's test holds the length pin above only; tests/test_oracle_golden.py reproduces it).
+Parity status: **pinned to the reference's own modules** (round 2): tests/golden/make_reference_fixtures.py runs the reference's source files
+(imported from /root/reference, unmodified, over the numpy stand-in for MLX in tests/golden/mlx_shim.py) and tests/test_reference_fixtures_cpu.py holds
+this oracle to the result -- ``SNAC.quantizer.from_codes`` + ``SNAC.decoder`` with the NoiseBlock draws the reference made: waveform 2e-5 (this run exposed the NoiseBlock's per-channel noise).  The reference's own tests hold shape / length pins only
+(reproduced in tests/test_oracle_golden.py and the GPU tests); MLX's kernels are not exercised by the stand-in.
 """
 from __future__ import annotations
 
@@ -71,7 +76,7 @@ class SNACDecoderRef:
         return z.transpose(1, 2)
 
     def decode(self, z: Tensor, noises: Optional[List[Tensor]] = None, return_stages: bool = False):
-        """z [B, D, T] -> audio [B, T', 1]; ``noises[i]`` [B, T_i, 1] is DecoderBlock i's ``mx.random.normal((B, 1, T))`` (channels-last here)."""
+        """z [B, D, T] -> audio [B, T', 1]; ``noises[i]`` [B, 1, C_i] is DecoderBlock i's ``mx.random.normal((B, 1, T))`` (its "T" is the channel count)."""
         x = z.to(self.dtype).transpose(1, 2)
         st = {}
         D = x.shape[-1]
@@ -93,6 +98,7 @@ class SNACDecoderRef:
             if self.noise:
                 w = wn_weight(self.w[p + "2.linear.weight_g"], self.w[p + "2.linear.weight_v"])
                 h = F.conv1d(x.transpose(1, 2), w.permute(0, 2, 1)).transpose(1, 2)
+                assert tuple(noises[i].shape) == (x.shape[0], 1, x.shape[2]), (tuple(noises[i].shape), tuple(x.shape))
                 x = x + noises[i].to(self.dtype) * h
                 j0 = 3
             for j, d in enumerate((1, 3, 9)):

@@ -15,8 +15,10 @@ Parameter names are the reference's after its own load-time transposes (``vocos.
 ``backbone.convnext.{i}.dwconv.weight`` [dim, K, 1], ``...pwconv1.weight`` [inter, dim], ``...gamma`` [dim], ``head.out.weight`` [n_fft+2, dim].
 Arithmetic float32 (float64 on request) on the parameters as given (the published checkpoints are float32).
 
-Parity status: **unpinned beyond shapes**: the reference's tests hold shape pins only (codec/tests/test_vocos.py:60-98: 120 000 zeros ->
-(119552,) through the mel model); those are asserted in tests/test_api_cpu.py.
+Parity status: **pinned to the reference's own modules** (round 2): tests/golden/make_reference_fixtures.py runs the reference's source files
+(imported from /root/reference, unmodified, over the numpy stand-in for MLX in tests/golden/mlx_shim.py) and tests/test_reference_fixtures_cpu.py holds
+this oracle to the result -- mel ``Vocos``: features 2e-5, waveform 5e-5.  The reference's own tests hold shape / length pins only
+(reproduced in tests/test_oracle_golden.py and the GPU tests); MLX's kernels are not exercised by the stand-in.
 """
 from __future__ import annotations
 

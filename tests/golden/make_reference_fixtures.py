@@ -589,6 +589,104 @@ def run_csm(seed_w, seed_in, n_frames):
                 logits=np.stack(logits).astype(np.float32))
 
 
+def _codec_pkgs():
+    if "mlx_audio.codec.models" not in sys.modules:
+        _pkg("mlx_audio.codec", f"{REF}/codec")
+        _pkg("mlx_audio.codec.models", f"{REF}/codec/models")
+
+
+def run_dac(seed_w, seed_codes, n_frames):
+    """The reference's ``DAC.quantizer.from_codes`` + ``DAC.decode`` (codec/models/descript/{dac.py, nn/layers.py, nn/quantize.py}), small widths, all four rates."""
+    from mlx_audio_amd.codec.models.descript import make_dac_weights
+
+    _codec_pkgs()
+    base = "mlx_audio.codec.models.descript"
+    _pkg(base, f"{REF}/codec/models/descript")
+    _pkg(f"{base}.nn", f"{REF}/codec/models/descript/nn")
+    _load(f"{base}.base", f"{REF}/codec/models/descript/base.py")
+    _load(f"{base}.nn.layers", f"{REF}/codec/models/descript/nn/layers.py")
+    _load(f"{base}.nn.quantize", f"{REF}/codec/models/descript/nn/quantize.py")
+    rd = _load(f"{base}.dac", f"{REF}/codec/models/descript/dac.py")
+    rates, dim, latent, nq, csize, cdim = [8, 5, 4, 2], 64, 32, 3, 128, 8
+    w = make_dac_weights(dim, rates, latent, nq, csize, cdim, seed=seed_w)
+    model = rd.DAC(encoder_dim=16, encoder_rates=[2, 4, 5, 8], latent_dim=latent, decoder_dim=dim, decoder_rates=rates, n_codebooks=nq,
+                   codebook_size=csize, codebook_dim=cdim, sample_rate=16000)
+    model.load_weights([(k, v.numpy()) for k, v in w.items()])
+    missing, unexpected, mism = model._load_report
+    dec_missing = [m for m in missing if not m.startswith("encoder.") and ".in_proj." not in m]
+    assert not unexpected and not dec_missing and not mism, (dec_missing[:8], unexpected[:8], mism[:4])
+    model.eval()
+    codes = np.random.default_rng(seed_codes).integers(0, csize, size=(2, nq, n_frames)).astype(np.int32)
+    z, zp, _ = model.quantizer.from_codes(mx.array(codes))
+    audio = np.asarray(model.decode(z))
+    return dict(seed_w=seed_w, codes=codes, z=np.asarray(z).astype(np.float32), audio=audio.astype(np.float32))
+
+
+def run_snac(seed_w, seed_codes, n_frames):
+    """The reference's ``SNAC.quantizer.from_codes`` + ``SNAC.decoder`` (codec/models/snac/{snac,layers,vq}.py), depthwise convs, no attention, with the
+    NoiseBlock's gaussian draws logged."""
+    from mlx_audio_amd.codec.models.snac import make_snac_weights
+
+    _codec_pkgs()
+    base = "mlx_audio.codec.models.snac"
+    _pkg(base, f"{REF}/codec/models/snac")
+    _load(f"{base}.attention", f"{REF}/codec/models/snac/attention.py")
+    _load(f"{base}.layers", f"{REF}/codec/models/snac/layers.py")
+    _load(f"{base}.vq", f"{REF}/codec/models/snac/vq.py")
+    rsn = _load(f"{base}.snac", f"{REF}/codec/models/snac/snac.py")
+    cfg = dict(sampling_rate=24000, encoder_dim=8, encoder_rates=[2, 4, 8], decoder_dim=64, decoder_rates=[8, 4, 2], attn_window_size=None,
+               codebook_size=64, codebook_dim=8, vq_strides=[4, 2, 1], noise=True, depthwise=True)
+    latent = cfg["encoder_dim"] * 2 ** len(cfg["encoder_rates"])
+    w = make_snac_weights(latent, cfg["decoder_dim"], cfg["decoder_rates"], cfg["vq_strides"], cfg["codebook_size"], cfg["codebook_dim"], True, True, seed=seed_w)
+    model = rsn.SNAC(**cfg)
+    model.load_weights([(k, v.numpy()) for k, v in w.items()])
+    missing, unexpected, mism = model._load_report
+    dec_missing = [m for m in missing if not m.startswith("encoder.") and ".in_proj." not in m]
+    assert not unexpected and not dec_missing and not mism, (dec_missing[:8], unexpected[:8], mism[:4])
+    model.eval()
+    g = np.random.default_rng(seed_codes)
+    codes = [g.integers(0, cfg["codebook_size"], size=(2, n_frames // s_)).astype(np.int32) for s_ in cfg["vq_strides"]]
+    mx.random.seed(seed_codes)
+    z = model.quantizer.from_codes([mx.array(c) for c in codes])
+    audio = np.asarray(model.decoder(z.moveaxis(1, 2)))  # SNAC.decode (snac.py:101-104)
+    noises = [v for kind, shp, v in mx.random.log if kind == "normal"]
+    out = dict(seed_w=seed_w, z=np.asarray(z).astype(np.float32), audio=audio.astype(np.float32), n_noise=len(noises))
+    out.update({f"codes{i}": c for i, c in enumerate(codes)})
+    out.update({f"noise{i}": n.astype(np.float32) for i, n in enumerate(noises)})
+    return out, cfg
+
+
+def run_vocos(seed_w, seed_audio):
+    """The reference's ``Vocos`` mel model: ``MelSpectrogramFeatures`` -> ``VocosBackbone`` (ConvNeXt blocks) -> ``ISTFTHead`` (codec/models/vocos/{vocos,mel}.py)."""
+    from mlx_audio_amd.codec.models.vocos import make_vocos_weights
+
+    _codec_pkgs()
+    base = "mlx_audio.codec.models.vocos"
+    _pkg(base, f"{REF}/codec/models/vocos")
+    enc = types.ModuleType("mlx_audio.codec.models.encodec")   # EnCodec features are another model (LSTM): not built, not on this path
+    enc.Encodec = type("Encodec", (), {})
+    sys.modules["mlx_audio.codec.models.encodec"] = enc
+    u = sys.modules["mlx_audio.utils"]
+    dsp = sys.modules["mlx_audio.dsp"]
+    u.hanning, u.istft, u.mel_filters, u.stft = dsp.hanning, dsp.istft, dsp.mel_filters, dsp.stft
+    _load(f"{base}.mel", f"{REF}/codec/models/vocos/mel.py")
+    rv = _load(f"{base}.vocos", f"{REF}/codec/models/vocos/vocos.py")
+    cfg = {"feature_extractor": {"class_path": "vocos.feature_extractors.MelSpectrogramFeatures",
+                                 "init_args": {"sample_rate": 24000, "n_fft": 1024, "hop_length": 256, "n_mels": 100}},
+           "backbone": {"class_path": "vocos.models.VocosBackbone", "init_args": {"input_channels": 100, "dim": 64, "intermediate_dim": 128, "num_layers": 2}},
+           "head": {"class_path": "vocos.heads.ISTFTHead", "init_args": {"dim": 64, "n_fft": 1024, "hop_length": 256}}}
+    w = make_vocos_weights(cfg, seed=seed_w)
+    model = rv.Vocos.from_hparams(cfg)
+    model.load_weights([(k, v.numpy()) for k, v in w.items()])
+    missing, unexpected, mism = model._load_report
+    assert not missing and not unexpected and not mism, (missing[:8], unexpected[:8], mism[:4])
+    model.eval()
+    audio = np.random.default_rng(seed_audio).standard_normal(12_000).astype(np.float32)
+    feats = np.asarray(model.feature_extractor(mx.array(audio)))
+    out = np.asarray(model(mx.array(audio)))
+    return dict(seed_w=seed_w, seed_audio=seed_audio, features=feats.astype(np.float32), audio=out.astype(np.float32)), cfg
+
+
 def main():
     R = import_reference()
     n = check_shim_against_reference_vectors(R)
@@ -615,6 +713,17 @@ def main():
     sfx = run_csm(seed_w=2, seed_in=6, n_frames=3)
     np.savez_compressed(os.path.join(HERE, "ref_csm_tiny.npz"), **sfx)
     print("csm:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in sfx.items()})
+    import json
+
+    dfx = run_dac(seed_w=11, seed_codes=5, n_frames=37)
+    np.savez_compressed(os.path.join(HERE, "ref_dac_tiny.npz"), **dfx)
+    print("dac:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in dfx.items()}, "peak", float(np.abs(dfx["audio"]).max()))
+    nfx, ncfg = run_snac(seed_w=4, seed_codes=9, n_frames=24)
+    np.savez_compressed(os.path.join(HERE, "ref_snac_tiny.npz"), config=json.dumps(ncfg), **nfx)
+    print("snac:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in nfx.items()}, "peak", float(np.abs(nfx["audio"]).max()))
+    vfx, vcfg = run_vocos(seed_w=3, seed_audio=1)
+    np.savez_compressed(os.path.join(HERE, "ref_vocos_tiny.npz"), config=json.dumps(vcfg), **vfx)
+    print("vocos:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in vfx.items()}, "peak", float(np.abs(vfx["audio"]).max()))
     wfx = run_whisper(seed_w=3, seed_mel=2, sample_len=24)
     np.savez_compressed(os.path.join(HERE, "ref_whisper_tiny.npz"), **wfx)
     print("whisper:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in wfx.items()}, wfx["ts_tokens"].tolist(), wfx["nots_tokens"].tolist())

@@ -108,6 +108,33 @@ class array(np.ndarray):
     def logsumexp(self, axis=None, keepdims=False):
         return logsumexp(self, axis=axis, keepdims=keepdims)
 
+    def log(self):
+        return log(self)
+
+    def exp(self):
+        return exp(self)
+
+    def sqrt(self):
+        return sqrt(self)
+
+    def sin(self):
+        return sin(self)
+
+    def cos(self):
+        return cos(self)
+
+    def split(self, indices_or_sections, axis=0):
+        return split(self, indices_or_sections, axis=axis)
+
+    def moveaxis(self, source, destination):
+        return np.moveaxis(np.asarray(self), source, destination).view(array)
+
+    def flatten(self, start_axis=0, end_axis=-1):
+        a = np.asarray(self)
+        nd = a.ndim
+        s0, e0 = start_axis % _b.max(nd, 1), end_axis % _b.max(nd, 1)
+        return a.reshape(a.shape[:s0] + (-1,) + a.shape[e0 + 1:]).view(array)
+
     def abs(self):
         return np.abs(self)
 
@@ -392,6 +419,22 @@ def any(a, axis=None, keepdims=False, stream=None):  # noqa: A001
     return _wrap(np.asarray(np.any(np.asarray(a), axis=axis, keepdims=keepdims)))
 
 
+def moveaxis(a, source, destination, stream=None):
+    return _wrap(np.moveaxis(np.asarray(a), source, destination))
+
+
+def einsum(subscripts, *operands, stream=None):
+    return _wrap(np.einsum(subscripts, *[np.asarray(o) for o in operands]))
+
+
+def reciprocal(a, stream=None):
+    return _wrap(1.0 / np.asarray(a))
+
+
+def log10(a, stream=None):
+    return _wrap(np.log10(np.asarray(a)))
+
+
 def triu(a, k=0, stream=None):
     return _wrap(np.triu(np.asarray(a), k))
 
@@ -616,6 +659,16 @@ class Module:
     def __call__(self, *a, **k):
         raise NotImplementedError
 
+    # MLX modules are dicts of their parameters / children
+    def __contains__(self, key):
+        return key in self.__dict__
+
+    def __getitem__(self, key):
+        return self.__dict__[key]
+
+    def __setitem__(self, key, value):
+        setattr(self, key, value)
+
     def train(self, mode=True):
         for m in self.modules():
             m.training = bool(mode)
@@ -836,6 +889,22 @@ def gelu_approx(x):
     return _wrap(torch.nn.functional.gelu(torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float32))), approximate="tanh").numpy())
 
 
+class Sequential(Module):
+    def __init__(self, *modules):
+        super().__init__()
+        self.layers = list(modules)
+
+    def __call__(self, x):
+        for m in self.layers:
+            x = m(x)
+        return x
+
+
+class Tanh(Module):
+    def __call__(self, x):
+        return tanh(x)
+
+
 class MultiHeadAttention(Module):
     """Only the static helper the reference's Whisper uses (whisper.py:468)."""
 
@@ -896,11 +965,11 @@ def install():
     core = types.ModuleType("mlx.core")
     for k, v in vars(me).items():
         if not k.startswith("_") and k not in ("Module", "Linear", "Embedding", "LayerNorm", "InstanceNorm", "Conv1d", "Dropout", "Identity", "Upsample",
-                                               "LeakyReLU", "GELU", "leaky_relu", "gelu", "nn_tanh", "relu", "silu", "install", "MultiHeadAttention", "RMSNorm", "RoPE", "ConvTranspose1d", "elu", "gelu_approx"):
+                                               "LeakyReLU", "GELU", "leaky_relu", "gelu", "nn_tanh", "relu", "silu", "install", "MultiHeadAttention", "RMSNorm", "RoPE", "ConvTranspose1d", "elu", "gelu_approx", "Sequential", "Tanh"):
             setattr(core, k, v)
     nn = types.ModuleType("mlx.nn")
     for k in ("Module", "Linear", "Embedding", "LayerNorm", "InstanceNorm", "Conv1d", "Dropout", "Identity", "Upsample", "LeakyReLU", "GELU", "leaky_relu",
-              "gelu", "relu", "silu", "sigmoid", "MultiHeadAttention", "RMSNorm", "RoPE", "ConvTranspose1d", "elu", "gelu_approx"):
+              "gelu", "relu", "silu", "sigmoid", "MultiHeadAttention", "RMSNorm", "RoPE", "ConvTranspose1d", "elu", "gelu_approx", "Sequential", "Tanh"):
         setattr(nn, k, getattr(me, k))
     nn.tanh = nn_tanh
     utils = types.ModuleType("mlx.utils")

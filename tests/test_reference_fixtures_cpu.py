@@ -243,3 +243,59 @@ def test_csm_oracle_reproduces_the_reference_modules():
     for f, tr in enumerate(out["trace"]):
         for i, lg in enumerate(tr):
             assert rel_max(lg.numpy(), fx["logits"][f, i]) < 3e-5, (f, i)
+
+
+def test_dac_oracle_reproduces_the_reference_modules():
+    """The reference's ``DAC.quantizer.from_codes`` + ``DAC.decode`` (codec/models/descript/dac.py:204-205, nn/quantize.py:122-131)."""
+    from mlx_audio_amd.codec.models.descript import make_dac_weights
+    from oracle.dac_ref import DACDecoderRef
+
+    fx = np.load(os.path.join(GOLD, "ref_dac_tiny.npz"))
+    rates, dim, latent, nq, csize, cdim = [8, 5, 4, 2], 64, 32, 3, 128, 8
+    w = make_dac_weights(dim, rates, latent, nq, csize, cdim, seed=int(fx["seed_w"]))
+    ref = DACDecoderRef(w, rates, nq)
+    z = ref.from_codes(torch.from_numpy(fx["codes"]).long())
+    assert rel_max(z.numpy(), fx["z"]) < 1e-5
+    audio = ref.decode(z).numpy()
+    assert audio.shape == fx["audio"].shape and rel_max(audio, fx["audio"]) < 2e-5
+
+
+def test_snac_oracle_reproduces_the_reference_modules():
+    """The reference's ``SNAC.decode`` (snac.py:101-104) with the NoiseBlock draws the reference made: this is where the channels-last unpacking slip of
+    ``NoiseBlock`` (one draw per channel, layers.py:261-263) was found."""
+    import json
+
+    from mlx_audio_amd.codec.models.snac import make_snac_weights
+    from oracle.snac_ref import SNACDecoderRef
+
+    fx = np.load(os.path.join(GOLD, "ref_snac_tiny.npz"))
+    cfg = json.loads(str(fx["config"]))
+    latent = cfg["encoder_dim"] * 2 ** len(cfg["encoder_rates"])
+    w = make_snac_weights(latent, cfg["decoder_dim"], cfg["decoder_rates"], cfg["vq_strides"], cfg["codebook_size"], cfg["codebook_dim"], True, True,
+                          seed=int(fx["seed_w"]))
+    ref = SNACDecoderRef(w, cfg["decoder_rates"], cfg["vq_strides"], True, True)
+    codes = [torch.from_numpy(fx[f"codes{i}"]).long() for i in range(len(cfg["vq_strides"]))]
+    z = ref.from_codes(codes)
+    assert rel_max(z.numpy(), fx["z"]) < 1e-5
+    noises = [torch.from_numpy(fx[f"noise{i}"]) for i in range(int(fx["n_noise"]))]
+    assert [tuple(n.shape) for n in noises] == [(2, 1, cfg["decoder_dim"] >> (i + 1)) for i in range(len(noises))]
+    audio = ref.decode(z, noises).numpy()
+    assert audio.shape == fx["audio"].shape and rel_max(audio, fx["audio"]) < 2e-5
+
+
+def test_vocos_oracle_reproduces_the_reference_modules():
+    """The reference's mel ``Vocos``: ``MelSpectrogramFeatures`` -> ``VocosBackbone`` -> ``ISTFTHead`` (codec/models/vocos/vocos.py:25-52, 119-141, 217-276)."""
+    import json
+
+    from mlx_audio_amd.codec.models.vocos import make_vocos_weights
+    from oracle import vocos_ref
+
+    fx = np.load(os.path.join(GOLD, "ref_vocos_tiny.npz"))
+    cfg = json.loads(str(fx["config"]))
+    w = make_vocos_weights(cfg, seed=int(fx["seed_w"]))
+    ref = vocos_ref.VocosRef(w, cfg)
+    audio = np.random.default_rng(int(fx["seed_audio"])).standard_normal(12_000).astype(np.float32)
+    mel = vocos_ref.log_mel_spectrogram(audio)
+    assert rel_max(np.asarray(mel).reshape(fx["features"].shape), fx["features"]) < 2e-5
+    out = np.asarray(ref(audio))
+    assert out.shape == fx["audio"].shape and rel_max(out, fx["audio"]) < 5e-5

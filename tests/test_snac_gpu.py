@@ -60,7 +60,8 @@ def test_from_codes_and_decode_stages_vs_oracle(depthwise, noise):
         for s in cfg["decoder_rates"]:
             L = (L - 1) * s - 2 * ((s + 1) // 2) + 2 * s + 1
             lens.append(L)
-        noises = [torch.randn(2, n, 1, generator=g) for n in lens]
+        # NoiseBlock noise is [B, 1, channels] (the reference's quirk: oracle/snac_ref.py); the block widths halve from decoder_dim
+        noises = [torch.randn(2, 1, cfg["decoder_dim"] >> (i + 1), generator=g) for i in range(len(lens))]
         want, wst = ref.decode(z_ref, noises, return_stages=True)
         got, gst = eng.decode_latents(z, noises, return_stages=True)
         torch.cuda.synchronize()
@@ -94,7 +95,7 @@ def test_reference_length_pin_full_width():
         L = L * s + 1
         lens.append(L)
     g = torch.Generator().manual_seed(3)
-    noises = [torch.randn(1, n, 1, generator=g) for n in lens]
+    noises = [torch.randn(1, 1, CFG_24K["decoder_dim"] >> (i + 1), generator=g) for i in range(len(lens))]
     want = ref.decode(ref.from_codes(short), noises)
     got = eng.decode(short, noises)
     assert tuple(got.shape) == tuple(want.shape) == (1, lens[-1], 1)
