@@ -102,8 +102,8 @@ def make_mimi_decoder_weights(cfg: MimiConfig, seed: int = 0) -> Dict[str, torch
     D = cfg.dimension
     for pfx, n in (("quantizer.rvq_first", 1), ("quantizer.rvq_rest", cfg.quantizer_nq - 1)):
         for i in range(n):
-            w[f"{pfx}.vq.layers.{i}.codebook.embedding_sum"] = torch.randn(cfg.quantizer_bins, cfg.quantizer_dim, generator=g) * 3.0
-            w[f"{pfx}.vq.layers.{i}.codebook.cluster_usage"] = torch.rand(cfg.quantizer_bins, generator=g) * 5.0 + 0.5
+            w[f"{pfx}.vq.layers.{i}.codebook.embedding_sum"] = r16(torch.randn(cfg.quantizer_bins, cfg.quantizer_dim, generator=g) * 3.0)
+            w[f"{pfx}.vq.layers.{i}.codebook.cluster_usage"] = r16(torch.rand(cfg.quantizer_bins, generator=g) * 5.0 + 0.5)
         conv(pfx + ".output_proj", D, 1, cfg.quantizer_dim, bias=False, gain=1.0 / math.sqrt(max(n, 1)))
     conv("upsample.convtr.convtr.convtr", D, 2 * cfg.upsample_stride, 1, bias=False, gain=1.5)
     for i in range(cfg.num_layers):
