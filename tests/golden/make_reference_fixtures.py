@@ -687,6 +687,48 @@ def run_vocos(seed_w, seed_audio):
     return dict(seed_w=seed_w, seed_audio=seed_audio, features=feats.astype(np.float32), audio=out.astype(np.float32)), cfg
 
 
+def run_sampler(seed):
+    """The reference's sampling chain: ``Model._sample_token_batch`` of Qwen3-TTS (suppress ids, per-sequence repetition penalty, temperature, top-k,
+    top-p / min-p through ``lm/sample_utils.py``; qwen3_tts.py:862-925) with the final ``categorical_sampling`` replaced by a probe that records the
+    filtered logits it was handed -- i.e. everything up to the random draw, for five parameter sets."""
+    import_lm_and_mimi()
+    _load("mlx_audio.lm.sample_utils", f"{REF}/lm/sample_utils.py")
+    cont = _load("mlx_audio.tts.continuous", f"{REF}/tts/continuous.py")
+    if "mlx_audio.tts.models.qwen3_tts.config" not in sys.modules:
+        _pkg("mlx_audio.tts.models.qwen3_tts", f"{REF}/tts/models/qwen3_tts")
+        _load("mlx_audio.tts.models.qwen3_tts.config", f"{REF}/tts/models/qwen3_tts/config.py")
+    for m in ("talker", "speech_tokenizer", "speaker_encoder"):
+        if f"mlx_audio.tts.models.qwen3_tts.{m}" not in sys.modules:
+            _load(f"mlx_audio.tts.models.qwen3_tts.{m}", f"{REF}/tts/models/qwen3_tts/{m}.py")
+    u = sys.modules["mlx_audio.utils"]
+    u.load_audio = lambda *a, **k: None
+    q = _load("mlx_audio.tts.models.qwen3_tts.qwen3_tts", f"{REF}/tts/models/qwen3_tts/qwen3_tts.py")
+    g = np.random.default_rng(seed)
+    B, V = 3, 257
+    logits = (g.standard_normal((B, 1, V)) * 3).astype(np.float32)
+    hist = [list(map(int, g.integers(0, V, size=n))) for n in (0, 5, 40)]
+    sup = [V - 7, V - 3, 11]
+    cases = [dict(temperature=0.9, top_k=50, top_p=1.0, repetition_penalty=1.05), dict(temperature=0.7, top_k=0, top_p=0.8, repetition_penalty=1.0),
+             dict(temperature=1.0, top_k=20, top_p=0.6, repetition_penalty=1.3), dict(temperature=1.3, top_k=0, top_p=1.0, repetition_penalty=1.1, min_p=0.05),
+             dict(temperature=0.0, top_k=50, top_p=1.0, repetition_penalty=1.5)]
+    out = {}
+    seen = []
+    orig = q.categorical_sampling
+    q.categorical_sampling = lambda lg, temp: (seen.append(np.asarray(lg)), mx.argmax(lg, axis=-1))[1]
+    try:
+        for i, kw in enumerate(cases):
+            seen.clear()
+            tok = q.Model._sample_token_batch(None, mx.array(logits), generated_tokens_per_seq=hist, suppress_tokens=sup, **kw)
+            out[f"tok{i}"] = np.asarray(tok).astype(np.int32)
+            if seen:
+                out[f"filtered{i}"] = seen[0].astype(np.float32)
+    finally:
+        q.categorical_sampling = orig
+    import json
+
+    return dict(seed=seed, logits=logits, hist=json.dumps(hist), suppress=np.array(sup, dtype=np.int32), cases=json.dumps(cases), **out)
+
+
 def main():
     R = import_reference()
     n = check_shim_against_reference_vectors(R)
@@ -724,6 +766,9 @@ def main():
     vfx, vcfg = run_vocos(seed_w=3, seed_audio=1)
     np.savez_compressed(os.path.join(HERE, "ref_vocos_tiny.npz"), config=json.dumps(vcfg), **vfx)
     print("vocos:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in vfx.items()}, "peak", float(np.abs(vfx["audio"]).max()))
+    pfx = run_sampler(seed=12)
+    np.savez_compressed(os.path.join(HERE, "ref_sampler.npz"), **pfx)
+    print("sampler:", sorted(pfx.keys()))
     wfx = run_whisper(seed_w=3, seed_mel=2, sample_len=24)
     np.savez_compressed(os.path.join(HERE, "ref_whisper_tiny.npz"), **wfx)
     print("whisper:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in wfx.items()}, wfx["ts_tokens"].tolist(), wfx["nots_tokens"].tolist())

@@ -905,6 +905,12 @@ class Tanh(Module):
         return tanh(x)
 
 
+def log_softmax(x, axis=-1):
+    x = np.asarray(x)
+    m = x.max(axis=axis, keepdims=True)
+    return _wrap((x - m - np.log(np.exp(x - m).sum(axis=axis, keepdims=True))).astype(x.dtype))
+
+
 class MultiHeadAttention(Module):
     """Only the static helper the reference's Whisper uses (whisper.py:468)."""
 
@@ -965,11 +971,11 @@ def install():
     core = types.ModuleType("mlx.core")
     for k, v in vars(me).items():
         if not k.startswith("_") and k not in ("Module", "Linear", "Embedding", "LayerNorm", "InstanceNorm", "Conv1d", "Dropout", "Identity", "Upsample",
-                                               "LeakyReLU", "GELU", "leaky_relu", "gelu", "nn_tanh", "relu", "silu", "install", "MultiHeadAttention", "RMSNorm", "RoPE", "ConvTranspose1d", "elu", "gelu_approx", "Sequential", "Tanh"):
+                                               "LeakyReLU", "GELU", "leaky_relu", "gelu", "nn_tanh", "relu", "silu", "install", "MultiHeadAttention", "RMSNorm", "RoPE", "ConvTranspose1d", "elu", "gelu_approx", "Sequential", "Tanh", "log_softmax"):
             setattr(core, k, v)
     nn = types.ModuleType("mlx.nn")
     for k in ("Module", "Linear", "Embedding", "LayerNorm", "InstanceNorm", "Conv1d", "Dropout", "Identity", "Upsample", "LeakyReLU", "GELU", "leaky_relu",
-              "gelu", "relu", "silu", "sigmoid", "MultiHeadAttention", "RMSNorm", "RoPE", "ConvTranspose1d", "elu", "gelu_approx", "Sequential", "Tanh"):
+              "gelu", "relu", "silu", "sigmoid", "MultiHeadAttention", "RMSNorm", "RoPE", "ConvTranspose1d", "elu", "gelu_approx", "Sequential", "Tanh", "log_softmax"):
         setattr(nn, k, getattr(me, k))
     nn.tanh = nn_tanh
     utils = types.ModuleType("mlx.utils")

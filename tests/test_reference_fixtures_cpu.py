@@ -299,3 +299,25 @@ def test_vocos_oracle_reproduces_the_reference_modules():
     assert rel_max(np.asarray(mel).reshape(fx["features"].shape), fx["features"]) < 2e-5
     out = np.asarray(ref(audio))
     assert out.shape == fx["audio"].shape and rel_max(out, fx["audio"]) < 5e-5
+
+
+def test_sampling_oracle_reproduces_the_reference_chain():
+    """The reference's ``_sample_token_batch`` (qwen3_tts.py:862-925) through ``lm/sample_utils.py`` (top-k :131-153, min-p :156-203, top-p :206-239), with the
+    categorical draw replaced by a probe: the filtered logits (which entries survive, and their values) for four parameter sets, the arg-max for the
+    greedy one.  Same vectors feed the HIP sampler's test (tests/test_reference_fixtures_gpu.py)."""
+    import json
+
+    from oracle import sampling_ref
+
+    fx = np.load(os.path.join(GOLD, "ref_sampler.npz"))
+    logits = torch.from_numpy(fx["logits"])[:, -1]
+    hist = json.loads(str(fx["hist"]))
+    sup = [int(t) for t in fx["suppress"]]
+    for i, kw in enumerate(json.loads(str(fx["cases"]))):
+        got = sampling_ref.filter_logits(logits, generated=hist, suppress_tokens=sup, **kw)
+        if f"filtered{i}" in fx:
+            want = fx[f"filtered{i}"]
+            assert np.array_equal(np.isneginf(got.numpy()), np.isneginf(want)), i
+            keep = ~np.isneginf(want)
+            assert np.allclose(got.numpy()[keep], want[keep], rtol=2e-6, atol=1e-6), i
+        assert np.array_equal(got.argmax(-1).numpy(), fx[f"tok{i}"][:, 0]), i

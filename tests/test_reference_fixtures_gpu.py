@@ -156,3 +156,33 @@ def test_float32_codec_engines_vs_reference_run(name):
     snr = _snr(got, fx["audio"])
     print(f"{name} HIP vs reference run: max-abs {err:.2e} (peak {peak:.3f}), SNR {snr:.1f} dB")
     assert err <= 2e-3 * max(peak, 1.0) and snr >= 50.0
+
+
+def test_sampler_kernel_vs_reference_chain():
+    """``mi355_sample`` against what the reference's ``_sample_token_batch`` + ``lm/sample_utils.py`` handed to its categorical draw (ref_sampler.npz):
+    the same surviving entries, their values, and -- with zero Gumbel noise -- the same arg-max."""
+    from mlx_audio_amd import ops
+
+    fx = np.load(os.path.join(GOLD, "ref_sampler.npz"))
+    logits = torch.from_numpy(fx["logits"])[:, -1]
+    B, V = logits.shape
+    hist = json.loads(str(fx["hist"]))
+    hd = torch.full((B, 64), -1, dtype=torch.int32)
+    for b, h in enumerate(hist):
+        hd[b, : len(h)] = torch.tensor(h, dtype=torch.int32)
+    hl = torch.tensor([len(h) for h in hist], dtype=torch.int32)
+    sm = torch.zeros(V)
+    sm[[int(t) for t in fx["suppress"]]] = -float("inf")
+    for i, kw in enumerate(json.loads(str(fx["cases"]))):
+        out = torch.full((B,), -7, dtype=torch.int32, device=DEV)
+        filt = torch.zeros(B, V, device=DEV)
+        ops.sample(logits.to(DEV).contiguous(), out, V=V, suppress_mask=sm.to(DEV), history=hd.to(DEV), hist_len=hl.to(DEV),
+                   gumbel=torch.zeros(B, V, device=DEV), filtered=filt, **kw)
+        torch.cuda.synchronize()
+        if f"filtered{i}" in fx:
+            want = fx[f"filtered{i}"]
+            got = filt.cpu().numpy()
+            assert np.array_equal(np.isneginf(got), np.isneginf(want)), i
+            keep = ~np.isneginf(want)
+            assert np.allclose(got[keep], want[keep], rtol=2e-6, atol=1e-6), i
+        assert out.cpu().tolist() == fx[f"tok{i}"][:, 0].tolist(), i
