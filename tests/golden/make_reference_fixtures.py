@@ -339,7 +339,13 @@ def run_whisper(seed_w, seed_mel, sample_len):
         out[f"{name}_tokens"] = toks
         out[f"{name}_avg_logprob"] = np.array([r.avg_logprob for r in res], dtype=np.float64)
         out[f"{name}_no_speech"] = np.array([r.no_speech_prob for r in res], dtype=np.float64)
+    # the log-mel front end on 1.5 s of noise + tones (stt/models/whisper/audio.py:41-82 over dsp.stft / mel_filters)
+    ga = np.random.default_rng(seed_mel)
+    t = np.arange(24000) / 16000.0
+    wave = (0.1 * ga.standard_normal(24000) + 0.3 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 3100 * t)).astype(np.float32)
+    logmel = np.asarray(sys.modules["mlx_audio.stt.models.whisper.audio"].log_mel_spectrogram(wave, n_mels=80, padding=8000))
     return dict(seed_w=seed_w, seed_mel=seed_mel, sample_len=sample_len, non_speech_tokens=np.array(tok.non_speech_tokens, dtype=np.int32),
+                logmel=logmel.astype(np.float32),
                 xa_every4=np.asarray(xa)[:, :, ::4].astype(np.float32), ctx=ctx, step_tok=step_tok,
                 logits_full_last=np.asarray(logits_full)[:, -1, ::16].astype(np.float32), logits_step=np.asarray(logits_step)[:, -1, ::16].astype(np.float32),
                 logits_full_argmax=np.asarray(logits_full).argmax(-1).astype(np.int32), **out)

@@ -111,6 +111,9 @@ class array(np.ndarray):
     def log(self):
         return log(self)
 
+    def log10(self):
+        return log10(self)
+
     def exp(self):
         return exp(self)
 

@@ -130,6 +130,13 @@ def test_whisper_oracle_reproduces_the_reference_modules():
     assert rel_max(logits[:, -1, ::16].numpy(), fx["logits_full_last"]) < 2e-5
     step, kv = ref.decoder(torch.from_numpy(fx["step_tok"]).long(), xa, kv)
     assert rel_max(step[:, -1, ::16].numpy(), fx["logits_step"]) < 2e-5
+    # the log-mel front end (stt/models/whisper/audio.py:41-82) on 1.5 s of noise + two tones, 0.5 s of zero padding
+    from oracle import dsp_ref
+
+    ga = np.random.default_rng(int(fx["seed_mel"]))
+    t = np.arange(24000) / 16000.0
+    wave = (0.1 * ga.standard_normal(24000) + 0.3 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 3100 * t)).astype(np.float32)
+    assert float(np.abs(dsp_ref.whisper_log_mel(wave, 80, padding=8000) - fx["logmel"]).max()) < 1e-6
     tok = TokenizerSpec(non_speech_tokens=tuple(int(t) for t in fx["non_speech_tokens"]))
     # decoding.py:80-112 with suppress_tokens = "-1"
     suppress = sorted(set(list(tok.non_speech_tokens) + [tok.transcribe, tok.translate, tok.sot, tok.sot_prev, tok.sot_lm, tok.no_speech]))

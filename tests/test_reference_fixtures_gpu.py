@@ -111,6 +111,14 @@ def test_whisper_engine_vs_reference_run():
     err, peak = _peak_err(xa.float().cpu().numpy()[:, :, ::4], fx["xa_every4"])
     print(f"whisper HIP vs reference run: encoder features {err / peak:.2e} of peak")
     assert err <= 1e-2 * peak
+    # fused STFT / mel kernel against the reference's own log_mel_spectrogram
+    from mlx_audio_amd import dsp
+
+    ga = np.random.default_rng(int(fx["seed_mel"]))
+    t = np.arange(24000) / 16000.0
+    wave = (0.1 * ga.standard_normal(24000) + 0.3 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 3100 * t)).astype(np.float32)
+    lm = dsp.log_mel_spectrogram(torch.from_numpy(wave).to(DEV), n_mels=80, padding=8000).cpu().numpy()
+    assert lm.shape == fx["logmel"].shape and float(np.abs(lm - fx["logmel"]).max()) < 5e-5
     tok = TokenizerSpec(non_speech_tokens=tuple(int(t) for t in fx["non_speech_tokens"]))
     suppress = sorted(set([int(t) for t in fx["non_speech_tokens"]] + [tok.transcribe, tok.translate, tok.sot, tok.sot_prev, tok.sot_lm, tok.no_speech]))
     want = fx["nots_tokens"]
