@@ -467,26 +467,51 @@ __global__ __launch_bounds__(256) void interpolate1d_kernel(const mi355_interp1d
 // pass 1: y = act(scale * x + shift) (what the consuming conv would have fused) and the tensor's extrema per utterance; min / max are
 // order-independent, so the atomics are deterministic.  Both extrema are joined with 0 like the reference, hence {-min, max} >= 0 and
 // an integer atomicMax on the float bit patterns orders them.
+__device__ __forceinline__ float fq_prologue(const mi355_fake_quant_args& a, float t, int b, int c) {
+  if (a.pre_scale) t = t * a.pre_scale[(int64_t)b * a.pre_ld + c] + a.pre_shift[(int64_t)b * a.pre_ld + c];
+  if (a.pre_act == MI355_ACT_LEAKY) t = t > 0.f ? t : t * a.pre_slope;
+  else if (a.pre_act == MI355_ACT_SNAKE) {
+    const float al = a.pre_alpha[c];
+    const float sn = sinf(al * t);
+    t = t + (1.0f / al) * (sn * sn);
+  }
+  return t;
+}
+
+// VEC: C, ldx, ldy multiples of 4 and 16-byte aligned bases: the workgroup walks (rows, channel quads) with 16-byte accesses
+template <bool VEC>
 __global__ __launch_bounds__(256) void fq_prepare_kernel(const mi355_fake_quant_args a) {
   const int b = blockIdx.y;
   const int len = a.lens ? a.lens[b] : a.L;
   const float* xb = a.x + (int64_t)b * a.x_bstride;
   float* yb = a.y + (int64_t)b * a.y_bstride;
-  const int64_t n = (int64_t)len * a.C;
   float nmn = 0.f, mx = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int l = (int)(i / a.C), c = (int)(i - (int64_t)l * a.C);
-    float t = xb[(int64_t)l * a.ldx + c];
-    if (a.pre_scale) t = t * a.pre_scale[(int64_t)b * a.pre_ld + c] + a.pre_shift[(int64_t)b * a.pre_ld + c];
-    if (a.pre_act == MI355_ACT_LEAKY) t = t > 0.f ? t : t * a.pre_slope;
-    else if (a.pre_act == MI355_ACT_SNAKE) {
-      const float al = a.pre_alpha[c];
-      const float sn = sinf(al * t);
-      t = t + (1.0f / al) * (sn * sn);
+  if (VEC) {
+    // 256 threads = rps rows x C4 channel quads (rps = 256 / C4 when a row is narrower than the workgroup): one division per thread, none per element
+    const int C4 = a.C >> 2, rps = C4 >= 256 ? 1 : 256 / C4, span = C4 >= 256 ? 256 : C4;
+    const int ty = C4 >= 256 ? 0 : (int)threadIdx.x / C4, tx = (int)threadIdx.x - ty * span;
+    for (int l = blockIdx.x * rps + ty; l < len && ty < rps; l += gridDim.x * rps) {
+      for (int c4 = tx; c4 < C4; c4 += span) {
+        const float4 v = *(const float4*)(xb + (int64_t)l * a.ldx + 4 * c4);
+        float4 t;
+        t.x = fq_prologue(a, v.x, b, 4 * c4);
+        t.y = fq_prologue(a, v.y, b, 4 * c4 + 1);
+        t.z = fq_prologue(a, v.z, b, 4 * c4 + 2);
+        t.w = fq_prologue(a, v.w, b, 4 * c4 + 3);
+        *(float4*)(yb + (int64_t)l * a.ldy + 4 * c4) = t;
+        nmn = fmaxf(fmaxf(nmn, -t.x), fmaxf(fmaxf(-t.y, -t.z), -t.w));
+        mx = fmaxf(fmaxf(mx, t.x), fmaxf(fmaxf(t.y, t.z), t.w));
+      }
     }
-    yb[(int64_t)l * a.ldy + c] = t;
-    nmn = fmaxf(nmn, -t);
-    mx = fmaxf(mx, t);
+  } else {
+    const int64_t n = (int64_t)len * a.C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+      const int l = (int)(i / a.C), c = (int)(i - (int64_t)l * a.C);
+      const float t = fq_prologue(a, xb[(int64_t)l * a.ldx + c], b, c);
+      yb[(int64_t)l * a.ldy + c] = t;
+      nmn = fmaxf(nmn, -t);
+      mx = fmaxf(mx, t);
+    }
   }
   nmn = wave_max(nmn);
   mx = wave_max(mx);
@@ -501,16 +526,30 @@ __global__ __launch_bounds__(256) void fq_prepare_kernel(const mi355_fake_quant_
   }
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void fq_apply_kernel(const mi355_fake_quant_args a) {
   const int b = blockIdx.y;
   const int len = a.lens ? a.lens[b] : a.L;
   float* yb = a.y + (int64_t)b * a.y_bstride;
-  const int64_t n = (int64_t)len * a.C;
   const FakeQuant fq(-a.minmax[2 * b], a.minmax[2 * b + 1]);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int l = (int)(i / a.C), c = (int)(i - (int64_t)l * a.C);
-    float* p = yb + (int64_t)l * a.ldy + c;
-    *p = fq(*p);
+  if (VEC) {
+    const int C4 = a.C >> 2, rps = C4 >= 256 ? 1 : 256 / C4, span = C4 >= 256 ? 256 : C4;
+    const int ty = C4 >= 256 ? 0 : (int)threadIdx.x / C4, tx = (int)threadIdx.x - ty * span;
+    for (int l = blockIdx.x * rps + ty; l < len && ty < rps; l += gridDim.x * rps) {
+      for (int c4 = tx; c4 < C4; c4 += span) {
+        float4* p = (float4*)(yb + (int64_t)l * a.ldy + 4 * c4);
+        float4 v = *p;
+        v.x = fq(v.x); v.y = fq(v.y); v.z = fq(v.z); v.w = fq(v.w);
+        *p = v;
+      }
+    }
+  } else {
+    const int64_t n = (int64_t)len * a.C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+      const int l = (int)(i / a.C), c = (int)(i - (int64_t)l * a.C);
+      float* p = yb + (int64_t)l * a.ldy + c;
+      *p = fq(*p);
+    }
   }
 }
 
@@ -527,11 +566,23 @@ extern "C" int mi355_fake_quant_u8(const mi355_fake_quant_args* ap, void* stream
   hipError_t e = hipMemsetAsync(a.minmax, 0, sizeof(float) * 2 * a.B, st);
   MI355_REQUIRE(e == hipSuccess, "fake_quant_u8: memset failed: %s", hipGetErrorString(e));
   const int64_t n = (int64_t)a.L * a.C;
-  const unsigned nblk = (unsigned)std::min<int64_t>((n + 1023) / 1024, 1024);
+  const bool vec = (a.C % 4 == 0) && (a.ldx % 4 == 0) && (a.ldy % 4 == 0) && (a.x_bstride % 4 == 0) && (a.y_bstride % 4 == 0) &&
+                   (((uintptr_t)a.x | (uintptr_t)a.y) & 15) == 0;
   MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL(fq_prepare_kernel, dim3(nblk, a.B), dim3(256), 0, st, a);
+  if (vec) {
+    // a workgroup covers rps = max(1, 256 / (C / 4)) rows per sweep; ~4096 workgroups over the batch, each with several sweeps when the tensor is large
+    const int c4 = a.C / 4, rps = c4 >= 256 ? 1 : 256 / c4;
+    const unsigned nblk = (unsigned)std::max<int64_t>(1, std::min<int64_t>(((int64_t)a.L + 8 * rps - 1) / (8 * rps), 4096 / std::max(1, a.B) + 1));
+    hipLaunchKernelGGL(fq_prepare_kernel<true>, dim3(nblk, a.B), dim3(256), 0, st, a);
+    MI355_LAUNCH_CHECK("fake_quant_u8 (prepare)");
+    hipLaunchKernelGGL(fq_apply_kernel<true>, dim3(nblk, a.B), dim3(256), 0, st, a);
+    MI355_LAUNCH_CHECK("fake_quant_u8 (apply)");
+    return MI355_OK;
+  }
+  const unsigned nblk = (unsigned)std::min<int64_t>((n + 1023) / 1024, 1024);
+  hipLaunchKernelGGL(fq_prepare_kernel<false>, dim3(nblk, a.B), dim3(256), 0, st, a);
   MI355_LAUNCH_CHECK("fake_quant_u8 (prepare)");
-  hipLaunchKernelGGL(fq_apply_kernel, dim3(nblk, a.B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(fq_apply_kernel<false>, dim3(nblk, a.B), dim3(256), 0, st, a);
   MI355_LAUNCH_CHECK("fake_quant_u8 (apply)");
   return MI355_OK;
 }
