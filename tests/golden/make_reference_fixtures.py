@@ -735,6 +735,36 @@ def run_sampler(seed):
     return dict(seed=seed, logits=logits, hist=json.dumps(hist), suppress=np.array(sup, dtype=np.int32), cases=json.dumps(cases), **out)
 
 
+def run_dsp(R, seed):
+    """The reference's ``dsp.py`` entry points of the path (stft / istft with both normalisations / mel_filters / ISTFTCache.istft / compute_fbank_kaldi with
+    dither 0) and Qwen3-TTS's ``mel_spectrogram`` (qwen3_tts.py:64-120), on seeded noise + tones."""
+    dsp = R["dsp"]
+    g = np.random.default_rng(seed)
+    t = np.arange(12000) / 24000.0
+    x = (0.2 * g.standard_normal(12000) + 0.4 * np.sin(2 * np.pi * 330 * t) + 0.1 * np.sin(2 * np.pi * 5000 * t)).astype(np.float32)
+    out = dict(seed=seed)
+    s1 = dsp.stft(mx.array(x), n_fft=400, hop_length=160, window=dsp.hanning(400))
+    out["stft_400_160"] = np.asarray(s1).astype(np.complex64)
+    s2 = dsp.stft(mx.array(x), n_fft=1024, hop_length=256, win_length=1024, window="hann", center=True, pad_mode="constant")
+    out["stft_1024_256_constant"] = np.asarray(s2).astype(np.complex64)
+    for norm in (False, True):
+        y = dsp.istft(s2.T if hasattr(s2, "T") else s2.transpose(1, 0), hop_length=256, win_length=1024, window="hann", center=True, length=12000, normalized=norm)
+        out[f"istft_norm{int(norm)}"] = np.asarray(y).astype(np.float32)
+    out["mel_slaney"] = np.asarray(dsp.mel_filters(16000, 400, 80, norm="slaney", mel_scale=None)).astype(np.float32)
+    out["mel_htk"] = np.asarray(dsp.mel_filters(24000, 1024, 128, f_min=0, f_max=12000, norm=None, mel_scale="htk")).astype(np.float32)
+    cache = dsp.ISTFTCache()
+    spec = np.asarray(s2).T[None]  # [1, bins, frames]
+    w = dsp.hanning(1024 + 1)[:-1]
+    yc = cache.istft(mx.array(spec.real.astype(np.float32)), mx.array(spec.imag.astype(np.float32)), 1024, 256, 1024, w, center=True, audio_length=12000)
+    out["istft_cache"] = np.asarray(yc).astype(np.float32)
+    x48 = np.concatenate([x, x, x, x])[:40000]
+    fb = dsp.compute_fbank_kaldi(mx.array(x48[None, :]), sample_rate=48000, win_len=1920, win_inc=384, num_mels=60, win_type="hamming", dither=0.0)
+    out["fbank"] = np.asarray(fb).astype(np.float32)
+    q = sys.modules["mlx_audio.tts.models.qwen3_tts.qwen3_tts"]
+    out["qwen3_mel"] = np.asarray(q.mel_spectrogram(mx.array(x))).astype(np.float32)
+    return out
+
+
 def main():
     R = import_reference()
     n = check_shim_against_reference_vectors(R)
@@ -775,6 +805,9 @@ def main():
     pfx = run_sampler(seed=12)
     np.savez_compressed(os.path.join(HERE, "ref_sampler.npz"), **pfx)
     print("sampler:", sorted(pfx.keys()))
+    xfx = run_dsp(R, seed=21)
+    np.savez_compressed(os.path.join(HERE, "ref_dsp.npz"), **xfx)
+    print("dsp:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in xfx.items()})
     wfx = run_whisper(seed_w=3, seed_mel=2, sample_len=24)
     np.savez_compressed(os.path.join(HERE, "ref_whisper_tiny.npz"), **wfx)
     print("whisper:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in wfx.items()}, wfx["ts_tokens"].tolist(), wfx["nots_tokens"].tolist())

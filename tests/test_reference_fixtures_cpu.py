@@ -328,3 +328,35 @@ def test_sampling_oracle_reproduces_the_reference_chain():
             keep = ~np.isneginf(want)
             assert np.allclose(got.numpy()[keep], want[keep], rtol=2e-6, atol=1e-6), i
         assert np.array_equal(got.argmax(-1).numpy(), fx[f"tok{i}"][:, 0]), i
+
+
+def _dsp_wave(fx):
+    g = np.random.default_rng(int(fx["seed"]))
+    t = np.arange(12000) / 24000.0
+    return (0.2 * g.standard_normal(12000) + 0.4 * np.sin(2 * np.pi * 330 * t) + 0.1 * np.sin(2 * np.pi * 5000 * t)).astype(np.float32)
+
+
+def test_dsp_oracle_reproduces_the_reference_functions():
+    """``dsp.py`` run as is (stft :385-433, istft :436-513 both normalisations, mel_filters :520-609, ISTFTCache.istft :663-738, compute_fbank_kaldi
+    :898-997 with dither 0) and Qwen3-TTS's ``mel_spectrogram`` (qwen3_tts.py:64-120): the numpy restatement is bit-identical on the forward transforms
+    and filter banks and within 2e-7 on the inverses.  With ``length=`` given the reference does not trim the centre padding, so the first samples sit
+    where the summed squared window is ~1e-9: the quotient there is rounding noise on both sides and is left out of the comparison."""
+    from oracle import dsp_ref as D
+
+    fx = np.load(os.path.join(GOLD, "ref_dsp.npz"))
+    x = _dsp_wave(fx)
+    assert np.array_equal(D.stft(x, n_fft=400, hop_length=160, window=D.hanning(400)), fx["stft_400_160"])
+    s2 = D.stft(x, n_fft=1024, hop_length=256, win_length=1024, window="hann", center=True, pad_mode="constant")
+    assert np.array_equal(s2, fx["stft_1024_256_constant"])
+    for n in (0, 1):
+        y = D.istft(s2.T, hop_length=256, win_length=1024, window="hann", center=True, length=12000, normalized=bool(n))
+        assert rel_max(y[64:], fx[f"istft_norm{n}"][64:]) < 1e-6, n
+    assert np.array_equal(D.mel_filters(16000, 400, 80, norm="slaney", mel_scale=None), fx["mel_slaney"])
+    assert np.array_equal(D.mel_filters(24000, 1024, 128, f_min=0, f_max=12000, norm=None, mel_scale="htk"), fx["mel_htk"])
+    sp = s2.T[None]
+    yc = D.ISTFTCache().istft(sp.real.astype(np.float32), sp.imag.astype(np.float32), 1024, 256, 1024, D.hanning(1025)[:-1], center=True, audio_length=12000)
+    assert rel_max(yc, fx["istft_cache"]) < 1e-6
+    x48 = np.concatenate([x, x, x, x])[:40000]
+    fb = D.compute_fbank_kaldi(x48[None, :], sample_rate=48000, win_len=1920, win_inc=384, num_mels=60, win_type="hamming", dither=0.0)
+    assert fb.shape == fx["fbank"].shape and float(np.abs(fb - fx["fbank"]).max()) < 5e-6
+    assert np.array_equal(D.qwen3_mel_spectrogram(x), fx["qwen3_mel"])
