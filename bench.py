@@ -182,13 +182,9 @@ def main():
     voice = S.make_voice_pack().to(dev)
     fds = [S.forced_durations(t_of[i], f_of[i], seed=i).to(dev) for i in range(n_total)]
     ch = shard.ShardChannel(dev, dist, max_items=max(n_total, 8), max_tokens=512)
+    # SineGen's uniform initial phases and gaussian noise are drawn on the device INSIDE every step (engine default, like the reference's
+    # mx.random calls inside its forward pass, istftnet.py:581,649): nothing of a step is precomputed except the inputs
     noise_kw = None
-    if not args.ragged:  # uniform shapes: the SineGen inputs of a rank's B utterances are one resident block
-        rng = np.random.default_rng(1234 + rank)
-        rand_ini = torch.from_numpy(rng.uniform(size=(B, 9)).astype(np.float32)).to(dev)
-        g = torch.Generator(device=dev).manual_seed(1234 + rank)
-        noise = torch.randn((B, 2 * F_FRAMES * 300, 9), generator=g, device=dev, dtype=torch.float32)
-        noise_kw = lambda items: dict(rand_ini=rand_ini[: len(items)], noise=noise[: len(items)])
     wire = torch.float16 if args.wire == "fp16" else None
 
     class VoiceRows:  # style row of an utterance = voice pack row (n_phonemes - 1), kokoro.py:223-226; one device gather per step
