@@ -44,8 +44,11 @@ class KittenEngine(KokoroEngine):
                              f"{config['istftnet']['upsample_initial_channel']} (the generator's input width, kitten_tts.py:139-156)")
         return cd, gd, int(config["asr_res_dim"])
 
-    def __init__(self, weights: Dict[str, torch.Tensor], config: dict, device="cuda", param_dtype=torch.float32, precision: int = 2,
+    def __init__(self, weights: Dict[str, torch.Tensor], config: dict, device="cuda", param_dtype=torch.float32, precision: int = None,
                  quant_modules: Sequence[str] = None):
+        if precision is None:
+            # float32 checkpoints (what the ONNX converter writes): fp16 weight images + fp16 hi / lo activations; 16-bit checkpoints are exact in mode 2
+            precision = 4 if param_dtype == torch.float32 else 2
         pb = config["plbert"]
         if int(pb.get("num_hidden_groups", 1)) != 1 or int(pb.get("inner_group_num", 1)) != 1:
             raise NotImplementedError("KittenTTS engine: ALBERT with more than one layer group / inner layer is not supported")

@@ -107,7 +107,7 @@ class Model:
         audio: torch.Tensor
         pred_dur: Optional[torch.Tensor] = None
 
-    def __init__(self, config: ModelConfig, device: str = "cuda", precision: int = 2):
+    def __init__(self, config: ModelConfig, device: str = "cuda", precision: Optional[int] = None):
         self.config = config
         self.speed_priors = config.speed_priors or {}
         self.voice_aliases = config.voice_aliases or {}

@@ -107,8 +107,8 @@ class _StyleBank:
             self.bs.append(torch.zeros(pad))
         return off
 
-    def pack(self, device) -> PackedConv:
-        return ops.pack_conv(torch.cat(self.ws, 0), torch.cat(self.bs, 0), device)
+    def pack(self, device, f16: bool = False) -> PackedConv:
+        return ops.pack_conv(torch.cat(self.ws, 0), torch.cat(self.bs, 0), device, f16=f16)
 
 
 @dataclass
@@ -175,6 +175,11 @@ class KokoroEngine:
         ops.require_gpu()
         self.cfg = config
         self.qmods = tuple(quant_modules)
+        # precision 4: EVERY conv / linear weight as an fp16 image (11 significant bits instead of bf16's 8) with fp16 hi + lo activations -- the mode
+        # for float32 checkpoints, whose values a bf16 image would round at 2^-9 (measured against the reference run on a float32 checkpoint:
+        # 35-40 dB with bf16 images).  bf16 checkpoints (Kokoro-82M-bf16, BASELINE config[1]) are exact in the default mode 2.  The recurrent LSTM
+        # weights stay bf16 images in every mode (persistent-kernel layout).
+        self.all_f16 = precision == 4
         self.cdim, self.gdim, self.adim = self._decoder_dims(config)
         self.dev = torch.device(device)
         self.pdt = param_dtype
@@ -205,7 +210,7 @@ class KokoroEngine:
         return t.to(self.pdt).to(torch.float32)
 
     def _lin(self, pre, bias=True) -> PackedConv:
-        return ops.pack_conv(self._q(self._t(f"{pre}.weight")), self._q(self._t(f"{pre}.bias")) if bias else None, self.dev)
+        return ops.pack_conv(self._q(self._t(f"{pre}.weight")), self._q(self._t(f"{pre}.bias")) if bias else None, self.dev, f16=self.all_f16)
 
     def _wn(self, pre) -> torch.Tensor:
         return fold_weight_norm(self.w[f"{pre}.weight_v"], self.w[f"{pre}.weight_g"], self.pdt)
@@ -218,7 +223,7 @@ class KokoroEngine:
         """precision 3: the decoder / generator convs (97 % of the FLOPs) run the single-pass fp16 MFMA; the front end
         (PL-BERT, prosody predictor, text encoder: the bit-exact duration path and the F0 curve the harmonic source
         integrates) stays on the bf16 hi+lo split."""
-        return self.precision == 3 and pre.startswith("decoder.")
+        return self.all_f16 or (self.precision == 3 and pre.startswith("decoder."))
 
     def _dvec(self, t: torch.Tensor, pad_to: int = 0) -> torch.Tensor:
         t = self._q(t.reshape(-1).float())
@@ -241,7 +246,7 @@ class KokoroEngine:
         b = torch.cat([self._q(self._t(f"{pre}.bias_ih_forward")) + self._q(self._t(f"{pre}.bias_hh_forward")),
                        self._q(self._t(f"{pre}.bias_ih_backward")) + self._q(self._t(f"{pre}.bias_hh_backward"))])
         whf, whb = self._q(self._t(f"{pre}.Wh_forward")), self._q(self._t(f"{pre}.Wh_backward"))
-        return _LSTM(ops.pack_conv(wx, b, self.dev), ops.pack_lstm_wh(whf, whb, self.dev), whf.shape[1], self._isq(pre))
+        return _LSTM(ops.pack_conv(wx, b, self.dev, f16=self.all_f16), ops.pack_lstm_wh(whf, whb, self.dev), whf.shape[1], self._isq(pre))
 
     def _resblk1d(self, bank, pre, din, dout) -> _ResBlk1d:
         up = f"{pre}.pool.weight_v" in self.w
@@ -274,7 +279,7 @@ class KokoroEngine:
         lay = "bert.encoder.albert_layer_groups.0.albert_layers.0"
         qkv_w = torch.cat([self._q(self._t(f"{lay}.attention.{n}.weight")) for n in ("query", "key", "value")], 0)
         qkv_b = torch.cat([self._q(self._t(f"{lay}.attention.{n}.bias")) for n in ("query", "key", "value")], 0)
-        self.qkv = ops.pack_conv(qkv_w, qkv_b, d)
+        self.qkv = ops.pack_conv(qkv_w, qkv_b, d, f16=self.all_f16)
         self.att_dense = self._lin(f"{lay}.attention.dense")
         self.att_ln = (self._dvec(self._t(f"{lay}.attention.LayerNorm.weight")), self._dvec(self._t(f"{lay}.attention.LayerNorm.bias")))
         self.ffn = self._lin(f"{lay}.ffn")
@@ -292,8 +297,8 @@ class KokoroEngine:
         for i, (a, b) in enumerate(dims):
             self.f0_blocks.append(self._resblk1d(self.bank_pred, f"predictor.F0.{i}", a, b))
             self.n_blocks.append(self._resblk1d(self.bank_pred, f"predictor.N.{i}", a, b))
-        self.f0_proj = ops.pack_conv(self._q(self._t("predictor.F0_proj.weight")), self._q(self._t("predictor.F0_proj.bias")), d)
-        self.n_proj = ops.pack_conv(self._q(self._t("predictor.N_proj.weight")), self._q(self._t("predictor.N_proj.bias")), d)
+        self.f0_proj = ops.pack_conv(self._q(self._t("predictor.F0_proj.weight")), self._q(self._t("predictor.F0_proj.bias")), d, f16=self.all_f16)
+        self.n_proj = ops.pack_conv(self._q(self._t("predictor.N_proj.weight")), self._q(self._t("predictor.N_proj.bias")), d, f16=self.all_f16)
         # ---- text encoder
         self.te_emb = self._q(self._t("text_encoder.embedding.weight")).contiguous().to(d)
         self.te_cnn = []
@@ -320,17 +325,17 @@ class KokoroEngine:
             cout = c0 // (2 ** (i + 1))
             # stored (Cin, K, Cout); mx.conv_transpose1d receives weight.T = (Cout, K, Cin) (istftnet.py:161-166)
             w_t = self._wn(f"{g}.ups.{i}").permute(2, 1, 0).contiguous()
-            self.ups.append(ops.pack_conv_transpose(w_t, self._q(self._t(f"{g}.ups.{i}.bias")), u, d, f16=self.precision == 3))
+            self.ups.append(ops.pack_conv_transpose(w_t, self._q(self._t(f"{g}.ups.{i}.bias")), u, d, f16=self.precision == 3 or self.all_f16))
             ncw = self._q(self._t(f"{g}.noise_convs.{i}.weight"))  # (cout, K, n_fft+2)
             ncb = self._q(self._t(f"{g}.noise_convs.{i}.bias"))
-            self.noise_convs.append(ops.pack_conv(ncw.reshape(ncw.shape[0], 1, -1), ncb, d))  # raw phase features: keep hi+lo
+            self.noise_convs.append(ops.pack_conv(ncw.reshape(ncw.shape[0], 1, -1), ncb, d, f16=self.all_f16))  # raw phase features: keep hi+lo
             last = i + 1 == len(self.rates)
             self.noise_res.append(self._resblock1(self.bank_dec, f"{g}.noise_res.{i}", cout, 11 if last else 7, (1, 3, 5)))
             for j in range(nk):
                 self.resblocks.append(self._resblock1(self.bank_dec, f"{g}.resblocks.{i * nk + j}", cout, self.rk[j], tuple(self.rd[j])))
         self.conv_post = self._convw(f"{g}.conv_post")
-        self.style_dec = self.bank_dec.pack(d)
-        self.style_pred = self.bank_pred.pack(d)
+        self.style_dec = self.bank_dec.pack(d, self.all_f16)
+        self.style_pred = self.bank_pred.pack(d, self.all_f16)
         self.q_style_dec, self.q_style_pred = self.bank_dec.any_q, self.bank_pred.any_q
         # periodic Hann of MLXSTFT (istftnet.py:466) -- same float32 values as dsp.hanning(n, periodic=True)
         n = self.n_fft

@@ -68,7 +68,7 @@ class Model:
         audio: torch.Tensor
         pred_dur: Optional[torch.Tensor] = None
 
-    def __init__(self, config: ModelConfig, repo_id: str = None, device: str = "cuda", precision: int = 2):
+    def __init__(self, config: ModelConfig, repo_id: str = None, device: str = "cuda", precision: Optional[int] = None):
         self.repo_id = repo_id
         self.config = config
         self.vocab = config.vocab
@@ -127,8 +127,11 @@ class Model:
         pdt = torch.bfloat16 if torch.bfloat16 in dtypes else (torch.float16 if torch.float16 in dtypes else torch.float32)
         cfg = self.config if isinstance(self.config, dict) else self.config.__dict__
         try:
+            # bf16 / fp16 checkpoints are held exactly by the default mode (2); a float32 checkpoint gets fp16 weight images + fp16 hi / lo
+            # activations (4) unless the caller chose a mode
+            prec = self.precision if self.precision is not None else (4 if pdt == torch.float32 else 2)
             self.engine = KokoroEngine({k: v.to(torch.float32) for k, v in w.items()}, cfg, device=self.device,
-                                       param_dtype=pdt, precision=self.precision)
+                                       param_dtype=pdt, precision=prec)
         except KeyError as e:
             if strict:
                 raise ValueError(f"Kokoro checkpoint is missing parameter {e}") from e
