@@ -200,9 +200,12 @@ typedef struct {
   float* out; int64_t out_bstride; int32_t ldo;
   int32_t quant_h;  /* 1: the recurrent product sees fake_quant_dynamic_u8(h) of each step's hidden vector; the emitted h is not quantised
                      * (KittenTTS LSTM with activation_quant, kitten_tts/modules.py:178,224) */
+  int32_t wh_f16;   /* 1: wh holds IEEE half values (mi355_pack_lstm_wh16_host with f16 = 1: float32 checkpoints, 11 significant bits); 0: bf16 */
 } mi355_lstm_args;
 int mi355_lstm_bidir(const mi355_lstm_args* a, void* stream);
 int mi355_pack_lstm_wh_host(const float* wh_fwd_host, const float* wh_bwd_host, int32_t H, uint16_t* out_host);
+/* same layout, element type chosen by f16 (0 = bf16 like mi355_pack_lstm_wh_host, 1 = IEEE half, round to nearest even) */
+int mi355_pack_lstm_wh16_host(const float* wh_fwd_host, const float* wh_bwd_host, int32_t H, int32_t f16, uint16_t* out_host);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-head self-attention over short sequences (PL-BERT, T <= 512), fp32.

@@ -15,7 +15,7 @@ void mi355_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* mi355_last_error(void) { return g_err; }
-extern "C" int mi355_abi_version(void) { return 16; }
+extern "C" int mi355_abi_version(void) { return 17; }
 
 extern "C" int mi355_device_info(int dev, char* name, int name_cap, int* cu_count, int* lds_bytes) {
   hipDeviceProp_t p;
@@ -79,6 +79,20 @@ extern "C" int mi355_pack_lstm_wh_host(const float* wf, const float* wb, int32_t
     for (int k8 = 0; k8 < H / 8; ++k8)
       for (int r = 0; r < G; ++r)
         for (int j = 0; j < 8; ++j) out[o++] = host_f32_to_bf16(w[(size_t)r * H + k8 * 8 + j]);
+  }
+  return MI355_OK;
+}
+
+extern "C" int mi355_pack_lstm_wh16_host(const float* wf, const float* wb, int32_t H, int32_t f16, uint16_t* out) {
+  if (!f16) return mi355_pack_lstm_wh_host(wf, wb, H, out);
+  MI355_REQUIRE(wf && wb && out && H > 0 && H % 8 == 0, "pack_lstm_wh16: bad arguments");
+  const int G = 4 * H;
+  size_t o = 0;
+  for (int d = 0; d < 2; ++d) {
+    const float* w = d ? wb : wf;
+    for (int k8 = 0; k8 < H / 8; ++k8)
+      for (int r = 0; r < G; ++r)
+        for (int j = 0; j < 8; ++j) out[o++] = host_f32_to_f16(w[(size_t)r * H + k8 * 8 + j]);
   }
   return MI355_OK;
 }

@@ -9,7 +9,19 @@
 
 namespace {
 
-template <int H, int KREG, int KLDS>
+// 16-bit weight pair -> two floats: bf16 is the high half of a float; F16 = IEEE half (float32 checkpoints, precision 4)
+template <bool F16>
+__device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi) {
+  if constexpr (F16) {
+    lo = (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu));
+    hi = (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
+  } else {
+    lo = __builtin_bit_cast(float, w << 16);
+    hi = __builtin_bit_cast(float, w & 0xffff0000u);
+  }
+}
+
+template <int H, int KREG, int KLDS, bool F16>
 __global__ __launch_bounds__(4 * H) void lstm_kernel(const mi355_lstm_args a) {
   constexpr int G = 4 * H;
   constexpr int NREG = KREG / 8, NLDS = KLDS / 8, NGLB = (H - KREG - KLDS) / 8;
@@ -36,14 +48,11 @@ __global__ __launch_bounds__(4 * H) void lstm_kernel(const mi355_lstm_args a) {
   auto dot8 = [&](const uint4 w, const float* h8, float acc) {
     const float4 h0 = *(const float4*)(h8);
     const float4 h1 = *(const float4*)(h8 + 4);
-    acc = fmaf(__builtin_bit_cast(float, w.x << 16), h0.x, acc);
-    acc = fmaf(__builtin_bit_cast(float, w.x & 0xffff0000u), h0.y, acc);
-    acc = fmaf(__builtin_bit_cast(float, w.y << 16), h0.z, acc);
-    acc = fmaf(__builtin_bit_cast(float, w.y & 0xffff0000u), h0.w, acc);
-    acc = fmaf(__builtin_bit_cast(float, w.z << 16), h1.x, acc);
-    acc = fmaf(__builtin_bit_cast(float, w.z & 0xffff0000u), h1.y, acc);
-    acc = fmaf(__builtin_bit_cast(float, w.w << 16), h1.z, acc);
-    acc = fmaf(__builtin_bit_cast(float, w.w & 0xffff0000u), h1.w, acc);
+    float w0, w1;
+    unpack2<F16>(w.x, w0, w1); acc = fmaf(w0, h0.x, acc); acc = fmaf(w1, h0.y, acc);
+    unpack2<F16>(w.y, w0, w1); acc = fmaf(w0, h0.z, acc); acc = fmaf(w1, h0.w, acc);
+    unpack2<F16>(w.z, w0, w1); acc = fmaf(w0, h1.x, acc); acc = fmaf(w1, h1.y, acc);
+    unpack2<F16>(w.w, w0, w1); acc = fmaf(w0, h1.z, acc); acc = fmaf(w1, h1.w, acc);
     return acc;
   };
 
@@ -108,16 +117,21 @@ __global__ __launch_bounds__(4 * H) void lstm_kernel(const mi355_lstm_args a) {
   }
 }
 
-template <int H, int KREG, int KLDS>
-int launch_lstm(const mi355_lstm_args& a, hipStream_t st) {
+template <int H, int KREG, int KLDS, bool F16>
+int launch_lstm_t(const mi355_lstm_args& a, hipStream_t st) {
   constexpr int G = 4 * H;
   const size_t lds = (size_t)(KLDS / 8) * G * 16 + (size_t)H * 4 + (size_t)G * 4;
-  hipError_t e = hipFuncSetAttribute((const void*)lstm_kernel<H, KREG, KLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute((const void*)lstm_kernel<H, KREG, KLDS, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   MI355_REQUIRE(e == hipSuccess, "lstm: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
   MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL((lstm_kernel<H, KREG, KLDS>), dim3(2, a.B), dim3(G), lds, st, a);
+  hipLaunchKernelGGL((lstm_kernel<H, KREG, KLDS, F16>), dim3(2, a.B), dim3(G), lds, st, a);
   MI355_LAUNCH_CHECK("lstm_bidir");
   return MI355_OK;
+}
+
+template <int H, int KREG, int KLDS>
+int launch_lstm(const mi355_lstm_args& a, hipStream_t st) {
+  return a.wh_f16 ? launch_lstm_t<H, KREG, KLDS, true>(a, st) : launch_lstm_t<H, KREG, KLDS, false>(a, st);
 }
 
 }  // namespace

@@ -209,14 +209,16 @@ def gemv(x: torch.Tensor, rw: RowMajor16, y: torch.Tensor, *, post_act: int = AC
     return y
 
 
-def pack_lstm_wh(wh_f: torch.Tensor, wh_b: torch.Tensor, device) -> torch.Tensor:
+def pack_lstm_wh(wh_f: torch.Tensor, wh_b: torch.Tensor, device, f16: bool = False) -> torch.Tensor:
+    """Recurrent weights of both directions in the persistent kernel's layout; ``f16``: IEEE half instead of bf16 values (float32 checkpoints; pass
+    ``wh_f16=True`` to ``lstm_bidir``)."""
     H = wh_f.shape[1]
     lib = _lib.load()
     out = np.empty(2 * 4 * H * H, dtype=np.uint16)
     a = wh_f.detach().to(torch.float32).contiguous().cpu().numpy()
     b = wh_b.detach().to(torch.float32).contiguous().cpu().numpy()
-    rc = lib.mi355_pack_lstm_wh_host(a.ctypes.data, b.ctypes.data, H, out.ctypes.data)
-    _lib.check(rc, "mi355_pack_lstm_wh_host")
+    rc = lib.mi355_pack_lstm_wh16_host(a.ctypes.data, b.ctypes.data, H, int(bool(f16)), out.ctypes.data)
+    _lib.check(rc, "mi355_pack_lstm_wh16_host")
     return torch.from_numpy(out.view(np.int16)).to(device)
 
 
@@ -343,11 +345,11 @@ def layernorm(x: torch.Tensor, y: torch.Tensor, *, weight=None, bias=None, ada_g
     return y
 
 
-def lstm_bidir(xp: torch.Tensor, wh: torch.Tensor, H: int, out: torch.Tensor, lens=None, quant_h: bool = False):
+def lstm_bidir(xp: torch.Tensor, wh: torch.Tensor, H: int, out: torch.Tensor, lens=None, quant_h: bool = False, wh_f16: bool = False):
     B, L, _, xbs, ldxp = _nlc(xp)
     _, _, _, obs, ldo = _nlc(out)
     _lib.call_struct("mi355_lstm_bidir", "mi355_lstm_args", _stream(), xp=_ptr(xp), xp_bstride=xbs, ldxp=ldxp, wh=_ptr(wh),
-                     H=H, L=L, lens=_ptr(lens), B=B, out=_ptr(out), out_bstride=obs, ldo=ldo, quant_h=int(bool(quant_h)))
+                     H=H, L=L, lens=_ptr(lens), B=B, out=_ptr(out), out_bstride=obs, ldo=ldo, quant_h=int(bool(quant_h)), wh_f16=int(bool(wh_f16)))
     return out
 
 

@@ -85,6 +85,7 @@ class _LSTM:
     wh: torch.Tensor
     hid: int
     q: bool = False  # KittenTTS: fake-quantised input and per-step hidden vector (kitten_tts/modules.py:155,178)
+    f16: bool = False  # recurrent weights held as IEEE half (precision 4)
 
 
 class _StyleBank:
@@ -178,7 +179,7 @@ class KokoroEngine:
         # precision 4: EVERY conv / linear weight as an fp16 image (11 significant bits instead of bf16's 8) with fp16 hi + lo activations -- the mode
         # for float32 checkpoints, whose values a bf16 image would round at 2^-9 (measured against the reference run on a float32 checkpoint:
         # 35-40 dB with bf16 images).  bf16 checkpoints (Kokoro-82M-bf16, BASELINE config[1]) are exact in the default mode 2.  The recurrent LSTM
-        # weights stay bf16 images in every mode (persistent-kernel layout).
+        # weights follow: IEEE half in mode 4 (``mi355_lstm_args.wh_f16``), bf16 otherwise.
         self.all_f16 = precision == 4
         self.cdim, self.gdim, self.adim = self._decoder_dims(config)
         self.dev = torch.device(device)
@@ -246,7 +247,8 @@ class KokoroEngine:
         b = torch.cat([self._q(self._t(f"{pre}.bias_ih_forward")) + self._q(self._t(f"{pre}.bias_hh_forward")),
                        self._q(self._t(f"{pre}.bias_ih_backward")) + self._q(self._t(f"{pre}.bias_hh_backward"))])
         whf, whb = self._q(self._t(f"{pre}.Wh_forward")), self._q(self._t(f"{pre}.Wh_backward"))
-        return _LSTM(ops.pack_conv(wx, b, self.dev, f16=self.all_f16), ops.pack_lstm_wh(whf, whb, self.dev), whf.shape[1], self._isq(pre))
+        return _LSTM(ops.pack_conv(wx, b, self.dev, f16=self.all_f16), ops.pack_lstm_wh(whf, whb, self.dev, f16=self.all_f16), whf.shape[1],
+                     self._isq(pre), self.all_f16)
 
     def _resblk1d(self, bank, pre, din, dout) -> _ResBlk1d:
         up = f"{pre}.pool.weight_v" in self.w
@@ -385,7 +387,7 @@ class KokoroEngine:
         if l.q:
             x = ops.fake_quant_u8(x, lens=lens)
         self._conv(x, l.wx, xp, lens_in=lens, lens_out=lens, flatten=True)
-        return ops.lstm_bidir(xp, l.wh, l.hid, out, lens=lens, quant_h=l.q)
+        return ops.lstm_bidir(xp, l.wh, l.hid, out, lens=lens, quant_h=l.q, wh_f16=l.f16)
 
     def _resblk1d_fwd(self, blk: _ResBlk1d, x, gb_all, out, lens, lens2=None):
         """x [B, L, din] -> out [B, L or 2L, dout]."""

@@ -218,6 +218,14 @@ def make_kokoro_weights(config: dict = None, seed: int = 0, decoder_dims=(1024, 
     return g.w
 
 
+def as_float32_checkpoint(weights: Dict[str, torch.Tensor], seed: int = 0) -> Dict[str, torch.Tensor]:
+    """The same checkpoint with every value moved off the bf16 grid (x (1 + u 2^-9), u uniform in [-1, 1)): what a genuinely float32 checkpoint looks
+    like to the engines' 16-bit weight images (tests of precision 4)."""
+    g = torch.Generator().manual_seed(7000 + seed)
+    return {k: (v * (1.0 + (torch.rand(v.shape, generator=g) * 2 - 1) * 2.0 ** -9)).to(torch.float32) if v.is_floating_point() else v
+            for k, v in sorted(weights.items())}
+
+
 def make_voice_pack(seed: int = 1, rows: int = 510) -> torch.Tensor:
     """Voice pack [rows, 1, 256] ~ N(0, 0.1) (fp32), indexed by ``len(phonemes) - 1``."""
     gen = torch.Generator().manual_seed(seed)

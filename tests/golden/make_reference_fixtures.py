@@ -128,11 +128,13 @@ def _np(x):
     return np.asarray(x, dtype=np.float32 if np.asarray(x).dtype.kind == "f" else None)
 
 
-def run_kokoro(R, seed_w, n_phon, seed_ids, speed, seed_rng):
+def run_kokoro(R, seed_w, n_phon, seed_ids, speed, seed_rng, off_grid=False):
     from mlx_audio_amd.tts.models.kokoro import synthetic as S
 
     cfg = S.tiny_config()
     w = S.make_kokoro_weights(cfg, seed=seed_w)
+    if off_grid:  # a genuinely float32 checkpoint: no value is bf16-representable
+        w = S.as_float32_checkpoint(w, seed=seed_w)
     K = R["kokoro"]
     model = K.Model(K.ModelConfig.from_dict(cfg), repo_id="none")
     model.load_weights([(k, v.numpy()) for k, v in w.items()])
@@ -771,6 +773,8 @@ def main():
     print(f"stand-in passes the reference's ConvTranspose / MLXSTFT vectors (both model families) and {n} interpolate vectors")
     k = run_kokoro(R, seed_w=21, n_phon=10, seed_ids=4, speed=1.0, seed_rng=5)
     np.savez_compressed(os.path.join(HERE, "ref_kokoro_tiny.npz"), **k)
+    k32 = run_kokoro(R, seed_w=23, n_phon=8, seed_ids=7, speed=1.0, seed_rng=6, off_grid=True)
+    np.savez_compressed(os.path.join(HERE, "ref_kokoro_tiny_f32.npz"), **{a: v for a, v in k32.items() if a not in ("xg_every8", "har_src")})
     print("kokoro:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in k.items()})
     for quant in (False, True):
         t = run_kitten(R, seed_w=22, n_phon=9, seed_ids=6, speed=1.1, seed_rng=8, quant=quant)

@@ -299,6 +299,19 @@ def test_lstm_vs_oracle(ops, H, In, L, B):
         ref = kokoro_ref.bilstm(p, x[b:b + 1, :n].double())[0]
         assert float((out[b, :n, : 2 * H].cpu().double() - ref).abs().max()) < 5e-5
     assert float(out[:, :, 2 * H:].abs().max()) == 0.0
+    # recurrent weights as IEEE half (precision 4 of the StyleTTS engines: float32 checkpoints): fp16-representable Wh, same bars
+    wts16 = dict(wts)
+    for d in ("forward", "backward"):
+        wts16[f"l.Wh_{d}"] = ((torch.rand(4 * H, H, generator=g) * 2 - 1) * s).half().float()
+    wh16 = ops.pack_lstm_wh(wts16["l.Wh_forward"], wts16["l.Wh_backward"], DEV, f16=True)
+    out16 = torch.zeros(B, L, 2 * H, device=DEV)
+    ops.lstm_bidir(xp, wh16, H, out16, lens=lens_d, wh_f16=True)
+    torch.cuda.synchronize()
+    p16 = kokoro_ref.P(wts16, "l.", dtype=torch.float64, param_dtype=torch.float32)
+    for b in range(B):
+        n = int(lens[b])
+        ref = kokoro_ref.bilstm(p16, x[b:b + 1, :n].double())[0]
+        assert float((out16[b, :n].cpu().double() - ref).abs().max()) < 5e-5
 
 
 def test_attention(ops):

@@ -360,3 +360,24 @@ def test_dsp_oracle_reproduces_the_reference_functions():
     fb = D.compute_fbank_kaldi(x48[None, :], sample_rate=48000, win_len=1920, win_inc=384, num_mels=60, win_type="hamming", dither=0.0)
     assert fb.shape == fx["fbank"].shape and float(np.abs(fb - fx["fbank"]).max()) < 5e-6
     assert np.array_equal(D.qwen3_mel_spectrogram(x), fx["qwen3_mel"])
+
+
+def test_kokoro_oracle_on_a_genuinely_float32_checkpoint():
+    """Same reference run on a checkpoint whose values are all OFF the bf16 grid (synthetic.as_float32_checkpoint): the oracle with float32 parameters
+    reproduces it like the on-grid one; the GPU engines are held to this file in precision 4 (tests/test_reference_fixtures_gpu.py)."""
+    from mlx_audio_amd.tts.models.kokoro import synthetic as S
+    from oracle.kokoro_ref import KokoroRef
+
+    fx = np.load(os.path.join(GOLD, "ref_kokoro_tiny_f32.npz"))
+    cfg = S.tiny_config()
+    w = S.as_float32_checkpoint(S.make_kokoro_weights(cfg, seed=int(fx["seed_w"])), seed=int(fx["seed_w"]))
+    ids = S.make_phoneme_ids(int(fx["n_phon"]), seed=int(fx["seed_ids"]))
+    ref_s = S.make_voice_pack()[len(ids) - 3]
+    ref = KokoroRef(w, cfg, param_dtype=torch.float32)
+    pd, d, _ = ref.durations(ids, ref_s, float(fx["speed"]))
+    assert np.array_equal(pd.numpy(), fx["pred_dur"]) and rel_max(d.numpy(), fx["d"]) < 2e-5
+    ri, nz = _draws(fx, fx["audio"].shape[1])
+    audio, _, tr = ref.forward(ids, ref_s, speed=float(fx["speed"]), rand_ini=ri, noise=nz, return_intermediates=True,
+                               f0_override=torch.from_numpy(fx["f0"]), n_override=torch.from_numpy(fx["n"]))
+    assert rel_max(tr["asr"].numpy(), fx["asr"]) < 2e-5
+    assert float(np.abs(audio.numpy() - fx["audio"]).max()) < 2e-4 * float(np.abs(fx["audio"]).max())

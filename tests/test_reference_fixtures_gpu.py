@@ -229,7 +229,7 @@ def test_dsp_api_vs_reference_functions():
     assert qm.shape == fx["qwen3_mel"].shape and float(np.abs(qm - fx["qwen3_mel"]).max()) < 2e-4
 
 
-@pytest.mark.parametrize("family", ["kokoro", "kitten"])
+@pytest.mark.parametrize("family", ["kokoro", "kitten", "kokoro_off_grid"])
 def test_styletts_engines_vs_reference_run_on_a_float32_checkpoint(family):
     """Kokoro / KittenTTS engines against the reference's own modules' outputs on a float32 checkpoint (the fixture run evaluates weight norm in float32):
     precision 4 = every conv / linear weight as an fp16 image, fp16 hi + lo activations.  Durations exact; F0 / N / asr within 2e-3 relative RMS; with the
@@ -238,12 +238,14 @@ def test_styletts_engines_vs_reference_run_on_a_float32_checkpoint(family):
     checkpoints exactly and reaches 35-40 dB on a float32 one (tools/debug_fp32_checkpoint_vs_reference_run.py)."""
     from mlx_audio_amd.tts.models.kokoro import synthetic as S
 
-    if family == "kokoro":
+    if family.startswith("kokoro"):
         from mlx_audio_amd.tts.models.kokoro.engine import KokoroEngine as E
 
-        fx = np.load(os.path.join(GOLD, "ref_kokoro_tiny.npz"))
+        fx = np.load(os.path.join(GOLD, "ref_kokoro_tiny.npz" if family == "kokoro" else "ref_kokoro_tiny_f32.npz"))
         cfg = S.tiny_config()
         w = S.make_kokoro_weights(cfg, seed=int(fx["seed_w"]))
+        if family == "kokoro_off_grid":  # every value (LSTM, linear, conv) off the bf16 grid: also exercises the fp16 recurrent weights
+            w = S.as_float32_checkpoint(w, seed=int(fx["seed_w"]))
     else:
         from mlx_audio_amd.tts.models.kitten_tts import synthetic as KS
         from mlx_audio_amd.tts.models.kitten_tts.engine import KittenEngine as E
