@@ -276,4 +276,7 @@ def test_styletts_engines_vs_reference_run_on_a_float32_checkpoint(family):
     got, want = outs[0].cpu().numpy(), fx["audio"][0]
     err, peak = _peak_err(got, want)
     print(f"{family} HIP (precision 4) vs reference run on a float32 checkpoint: {errs}, waveform max-abs {err:.2e} (peak {peak:.2f}), SNR {_snr(got, want):.1f} dB")
-    assert max(errs.values()) < 2e-3 and err <= 4e-3 * peak and _snr(got, want) >= 50.0
+    # on-grid checkpoints (LSTM / linear weights bf16-representable, only the weight-normed convs are not): 5e-4; all values off the grid: every
+    # weight carries the fp16 image's 2^-12 rounding and it accumulates over ~25 sequential layers to 1e-3 on d and 3-5e-3 on F0 / N (measured)
+    bar = 1e-2 if family == "kokoro_off_grid" else 2e-3
+    assert max(errs.values()) < bar and err <= 4e-3 * peak and _snr(got, want) >= 50.0
