@@ -1,5 +1,7 @@
 """The sharded step over RCCL (backend "nccl", device tensors): world_size 2 on one node.  Needs two GPUs -- self-skips on the 1-GPU boxes the
-round's ``pytest -m gpu`` runs on; the protocol itself is covered at world 2 / 3 / 8 over gloo in tests/test_shard_cpu.py."""
+round's ``pytest -m gpu`` runs on; the protocol itself is covered at world 2 / 3 / 8 over gloo in tests/test_shard_cpu.py.  A one-rank RCCL group
+(runs on every box) sends the same collectives -- broadcast, int32 all_reduce, exact-size all_to_all_single on device tensors -- through the
+"nccl" backend, so the calls themselves (dtypes, split lists, device placement) are exercised on RCCL even where no second GPU exists."""
 import os
 
 import pytest
@@ -29,7 +31,8 @@ def _worker(rank, world, port, q):
         torch.cuda.synchronize()
         if rank == 0:
             want = _single_process(reqs, True)
-            q.put(len(out) == 9 and all(o.is_cuda and torch.equal(o.cpu(), w) for o, w in zip(out, want)) and ch.collectives == 8)
+            # per step: broadcast + all_reduce + all_to_all back, + the re-balance all_to_all when another rank exists to take work
+            q.put(len(out) == 9 and all(o.is_cuda and torch.equal(o.cpu(), w) for o, w in zip(out, want)) and ch.collectives == (8 if world > 1 else 6))
     finally:
         dist.destroy_process_group()
 
@@ -49,3 +52,14 @@ def test_sharded_step_over_rccl_world2():
         p.join(300)
         assert p.exitcode == 0
     assert q.get()
+
+
+def test_collectives_go_through_rccl_on_a_one_rank_group():
+    from test_shard_cpu import _free_port
+
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), q))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0 and q.get()
