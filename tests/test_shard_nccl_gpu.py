@@ -55,14 +55,38 @@ def test_sharded_step_over_rccl_world2():
     assert q.get() == (True, 8)
 
 
+def _worker_calls(port, q):
+    """The exact collective calls ShardChannel issues (mlx_audio_amd/shard.py), on a one-rank RCCL group: request-block broadcast (int32), frame-count
+    all_reduce (int32), exact-size all_to_all_single of float32 and float16 payloads with explicit split lists."""
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        block = torch.arange(4 * 64, dtype=torch.int32, device=dev).reshape(4, 64)
+        dist.broadcast(block, src=0)
+        counts = torch.tensor([3, 0, 7, 11], dtype=torch.int32, device=dev)
+        dist.all_reduce(counts)
+        ok = counts.tolist() == [3, 0, 7, 11] and int(block[3, 63]) == 255
+        for dt in (torch.float32, torch.float16):
+            src = torch.arange(1000, dtype=torch.float32, device=dev).to(dt)
+            dst = torch.empty(1000, dtype=dt, device=dev)
+            dist.all_to_all_single(dst, src, output_split_sizes=[1000], input_split_sizes=[1000])
+            ok = ok and torch.equal(dst, src)
+        torch.cuda.synchronize()
+        q.put(ok)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_collectives_go_through_rccl_on_a_one_rank_group():
     from test_shard_cpu import _free_port
 
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), q))
+    p = ctx.Process(target=_worker_calls, args=(_free_port(), q))
     p.start()
     p.join(300)
-    assert p.exitcode == 0
-    ok, n = q.get()
-    assert ok and n in (4, 6), (ok, n)   # two steps of broadcast + (all_reduce) + all_to_all; no re-balance with one rank
+    assert p.exitcode == 0 and q.get()
