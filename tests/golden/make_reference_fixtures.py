@@ -767,6 +767,33 @@ def run_dsp(R, seed):
     return out
 
 
+def run_sanitize(R):
+    """The reference's ``sanitize`` of Kokoro (kokoro.py:178-275 + istftnet.py:998-1011) and CSM (sesame.py:577-604) on checkpoints in their published
+    on-disk form (tests/golden/pt_layouts.py): resulting key -> [shape, sum, sum of squares]."""
+    import json
+
+    import pt_layouts as PT
+    import torch
+
+    from mlx_audio_amd.tts.models.kokoro import synthetic as S
+    from mlx_audio_amd.tts.models.sesame import engine as E
+
+    out = {}
+    cfg = S.tiny_config()
+    K = R["kokoro"]
+    model = K.Model(K.ModelConfig.from_dict(cfg), repo_id="none")
+    ck = PT.kokoro_checkpoint(S.make_kokoro_weights(cfg, seed=1))
+    san = model.sanitize({k: mx.array(v.numpy()) for k, v in ck.items()})
+    out["kokoro"] = PT.summary({k: torch.from_numpy(np.asarray(v)) for k, v in san.items()})
+    rs = sys.modules["mlx_audio.tts.models.sesame.sesame"]
+    ck = PT.csm_checkpoint(E.make_csm_weights(E.tiny_csm(), seed=5))
+    san = rs.Model.sanitize(None, {k: mx.array(v.numpy()) for k, v in ck.items()})
+    out["csm"] = PT.summary({k: torch.from_numpy(np.asarray(v)) for k, v in san.items()})
+    with open(os.path.join(HERE, "ref_sanitize.json"), "w") as f:
+        json.dump(out, f)
+    return {k: len(v) for k, v in out.items()}
+
+
 def main():
     R = import_reference()
     n = check_shim_against_reference_vectors(R)
@@ -812,6 +839,7 @@ def main():
     xfx = run_dsp(R, seed=21)
     np.savez_compressed(os.path.join(HERE, "ref_dsp.npz"), **xfx)
     print("dsp:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in xfx.items()})
+    print("sanitize:", run_sanitize(R))
     wfx = run_whisper(seed_w=3, seed_mel=2, sample_len=24)
     np.savez_compressed(os.path.join(HERE, "ref_whisper_tiny.npz"), **wfx)
     print("whisper:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in wfx.items()}, wfx["ts_tokens"].tolist(), wfx["nots_tokens"].tolist())

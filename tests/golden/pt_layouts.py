@@ -1,0 +1,49 @@
+"""Synthetic checkpoints in the form the published ones have on disk (PyTorch / torchtune key names and conv layouts), i.e. what ``Model.sanitize`` of
+each family receives.  Shared by tests/golden/make_reference_fixtures.py (feeds them to the reference's own ``sanitize``) and the tests that feed them to
+this package's ``sanitize`` (tests/test_reference_fixtures_cpu.py; the loader tests build the same forms inline)."""
+import re
+
+import torch
+
+
+def kokoro_checkpoint(w):
+    """mlx_audio_amd.tts.models.kokoro.synthetic weights -> the HF checkpoint's form: PyTorch conv layout (out, in, K) for the keys sanitize transposes,
+    torch LSTM names, LayerNorm gamma / beta in the text encoder, plus a ``position_ids`` buffer that sanitize drops."""
+    names = {"Wx_forward": "weight_ih_l0", "Wh_forward": "weight_hh_l0", "bias_ih_forward": "bias_ih_l0", "bias_hh_forward": "bias_hh_l0",
+             "Wx_backward": "weight_ih_l0_reverse", "Wh_backward": "weight_hh_l0_reverse", "bias_ih_backward": "bias_ih_l0_reverse",
+             "bias_hh_backward": "bias_hh_l0_reverse"}
+    out = {}
+    for k, v in w.items():
+        base, _, suf = k.rpartition(".")
+        if suf in names and k.startswith(("text_encoder", "predictor")):
+            out[f"{base}.{names[suf]}"] = v
+        elif k.startswith("text_encoder.cnn") and re.search(r"\.1\.(weight|bias)$", k):
+            out[base + (".gamma" if suf == "weight" else ".beta")] = v
+        elif k.endswith(("F0_proj.weight", "N_proj.weight")) or ("noise_convs" in k and k.endswith(".weight")) or (k.endswith("weight_v") and v.dim() == 3):
+            out[k] = v.permute(0, 2, 1).contiguous()
+        else:
+            out[k] = v
+    out["bert.embeddings.position_ids"] = torch.arange(8)[None]
+    return out
+
+
+def csm_checkpoint(w):
+    """mlx_audio_amd.tts.models.sesame.engine.make_csm_weights (canonical stack names) -> torchtune names as sesame/csm-1b stores them."""
+    tt = {"wq": "attn.q_proj", "wk": "attn.k_proj", "wv": "attn.v_proj", "wo": "attn.output_proj", "w_gate": "mlp.w1", "w_down": "mlp.w2", "w_up": "mlp.w3"}
+    ck = {}
+    for k, v in w.items():
+        m = re.match(r"^(backbone|decoder)\.layers\.(\d+)\.(\w+)\.weight$", k)
+        if m and m.group(3) in tt:
+            ck[f"{m.group(1)}.layers.{m.group(2)}.{tt[m.group(3)]}.weight"] = v
+        elif m and m.group(3) in ("attn_norm", "mlp_norm"):
+            ck[f"{m.group(1)}.layers.{m.group(2)}.{'sa_norm' if m.group(3) == 'attn_norm' else 'mlp_norm'}.scale"] = v
+        elif k.endswith("final_norm.weight"):
+            ck[k.replace("final_norm.weight", "norm.scale")] = v
+        else:
+            ck[k] = v
+    return ck
+
+
+def summary(d):
+    """key -> [shape, sum, sum of squares] (float64): enough to tell two sanitized dicts apart, small enough to commit."""
+    return {k: [list(v.shape), float(torch.as_tensor(v).double().sum()), float((torch.as_tensor(v).double() ** 2).sum())] for k, v in sorted(d.items())}

@@ -381,3 +381,32 @@ def test_kokoro_oracle_on_a_genuinely_float32_checkpoint():
                                f0_override=torch.from_numpy(fx["f0"]), n_override=torch.from_numpy(fx["n"]))
     assert rel_max(tr["asr"].numpy(), fx["asr"]) < 2e-5
     assert float(np.abs(audio.numpy() - fx["audio"]).max()) < 2e-4 * float(np.abs(fx["audio"]).max())
+
+
+def test_sanitize_matches_the_reference_sanitize():
+    """The loader boundary: this package's ``Model.sanitize`` against the reference's own ``sanitize`` (Kokoro: kokoro.py:178-275 with the decoder's
+    istftnet.py:998-1011; CSM: sesame.py:577-604), both fed a checkpoint in its published on-disk form (PyTorch conv layouts, torch LSTM names,
+    gamma / beta, position_ids; torchtune names): the same keys, shapes and values come out (ref_sanitize.json holds key -> shape / sum / sum of squares)."""
+    import json
+    import sys
+
+    sys.path.insert(0, GOLD)
+    import pt_layouts as PT
+
+    from mlx_audio_amd.tts.models.kokoro import synthetic as S
+    from mlx_audio_amd.tts.models.kokoro.kokoro import Model, ModelConfig
+    from mlx_audio_amd.tts.models.sesame import engine as E
+
+    want = json.load(open(os.path.join(GOLD, "ref_sanitize.json")))
+    cfg = S.tiny_config()
+    got = PT.summary(Model(ModelConfig.from_dict(cfg)).sanitize(PT.kokoro_checkpoint(S.make_kokoro_weights(cfg, seed=1))))
+    assert set(got) == set(want["kokoro"])
+    for k, (shape, s1, s2) in want["kokoro"].items():
+        assert got[k][0] == shape and abs(got[k][1] - s1) <= 1e-9 * (1 + abs(s1)) and abs(got[k][2] - s2) <= 1e-9 * (1 + s2), k
+
+    from mlx_audio_amd.tts.models.sesame.sesame import Model as CSM
+
+    got = PT.summary(CSM.sanitize(None, PT.csm_checkpoint(E.make_csm_weights(E.tiny_csm(), seed=5))))
+    assert set(got) == set(want["csm"])
+    for k, (shape, s1, s2) in want["csm"].items():
+        assert got[k][0] == shape and abs(got[k][1] - s1) <= 1e-9 * (1 + abs(s1)) and abs(got[k][2] - s2) <= 1e-9 * (1 + s2), k
