@@ -789,6 +789,14 @@ def run_sanitize(R):
     ck = PT.csm_checkpoint(E.make_csm_weights(E.tiny_csm(), seed=5))
     san = rs.Model.sanitize(None, {k: mx.array(v.numpy()) for k, v in ck.items()})
     out["csm"] = PT.summary({k: torch.from_numpy(np.asarray(v)) for k, v in san.items()})
+    from mlx_audio_amd.tts.models.qwen3_tts import synthetic as QS
+
+    if "mlx_audio.tts.models.qwen3_tts.qwen3_tts" not in sys.modules:
+        run_sampler(0)  # loads the qwen3_tts modules
+    st = sys.modules["mlx_audio.tts.models.qwen3_tts.speech_tokenizer"]
+    ck = PT.qwen3_codec_checkpoint(QS.make_codec_decoder_weights(QS.tiny_codec_config(), seed=4))
+    san = st.Qwen3TTSSpeechTokenizer.sanitize({k: mx.array(v.numpy()) for k, v in ck.items()})
+    out["qwen3_codec"] = PT.summary({k: torch.from_numpy(np.asarray(v)) for k, v in san.items()})
     with open(os.path.join(HERE, "ref_sanitize.json"), "w") as f:
         json.dump(out, f)
     return {k: len(v) for k, v in out.items()}

@@ -44,6 +44,24 @@ def csm_checkpoint(w):
     return ck
 
 
+def qwen3_codec_checkpoint(cw):
+    """mlx_audio_amd.tts.models.qwen3_tts.synthetic.make_codec_decoder_weights -> the speech_tokenizer/model.safetensors form: ``decoder.`` prefix, codebooks as
+    embedding_sum / cluster_usage, PyTorch Conv1d (out, in, K) and ConvTranspose1d (in, out, K) layouts, plus an encoder key that sanitize has to place."""
+    ck = {}
+    for k, v in cw.items():
+        if k.endswith("codebook.embed.weight"):
+            base = k[: -len(".codebook.embed.weight")]
+            ck[f"decoder.{base}._codebook.cluster_usage"] = torch.full((v.shape[0],), 2.0)
+            ck[f"decoder.{base}._codebook.embedding_sum"] = 2.0 * v
+        elif v.dim() == 3 and (("upsample" in k and ".0.conv.weight" in k) or re.search(r"decoder\.\d+\.block\.1\.conv\.weight", k)):
+            ck["decoder." + k] = v.permute(2, 0, 1).contiguous()
+        elif v.dim() == 3:
+            ck["decoder." + k] = v.permute(0, 2, 1).contiguous()
+        else:
+            ck["decoder." + k] = v
+    return ck
+
+
 def summary(d):
     """key -> [shape, sum, sum of squares] (float64): enough to tell two sanitized dicts apart, small enough to commit."""
     return {k: [list(v.shape), float(torch.as_tensor(v).double().sum()), float((torch.as_tensor(v).double() ** 2).sum())] for k, v in sorted(d.items())}

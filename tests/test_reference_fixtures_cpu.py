@@ -410,3 +410,12 @@ def test_sanitize_matches_the_reference_sanitize():
     assert set(got) == set(want["csm"])
     for k, (shape, s1, s2) in want["csm"].items():
         assert got[k][0] == shape and abs(got[k][1] - s1) <= 1e-9 * (1 + abs(s1)) and abs(got[k][2] - s2) <= 1e-9 * (1 + s2), k
+
+    from mlx_audio_amd.tts.models.qwen3_tts import synthetic as QS
+    from mlx_audio_amd.tts.models.qwen3_tts.speech_tokenizer import Qwen3TTSSpeechTokenizer as Tok
+
+    # speech_tokenizer.py:1220-1460: decoder keys (codebooks from embedding_sum / cluster_usage, Conv1d / ConvTranspose1d layouts)
+    got = PT.summary(Tok.sanitize(PT.qwen3_codec_checkpoint(QS.make_codec_decoder_weights(QS.tiny_codec_config(), seed=4))))
+    assert set(got) == set(want["qwen3_codec"]), (sorted(set(got) ^ set(want["qwen3_codec"]))[:6])
+    for k, (shape, s1, s2) in want["qwen3_codec"].items():
+        assert got[k][0] == shape and abs(got[k][1] - s1) <= 1e-6 * (1 + abs(s1)) and abs(got[k][2] - s2) <= 1e-6 * (1 + s2), k
