@@ -270,6 +270,19 @@ typedef struct {
 } mi355_fake_quant_args;
 int mi355_fake_quant_u8(const mi355_fake_quant_args* a, void* stream);
 
+/* Anti-aliased activation of BigVGAN (codec/models/bigvgan/resample.py:157-177 ``Activation1d`` with SnakeBeta, activation.py:27-51):
+ * x [B, L, C] channels-last -> y [B, L, C]:  2x up-sampling (edge pad 5, depthwise transposed conv with the 12-tap Kaiser-sinc filter, x 2, trimmed
+ * to 2L: resample.py:101-136), a = u + inv_beta[c] * sin^2(alpha[c] * u), 2x down-sampling (edge pad 5 / 6, the 12-tap low-pass at stride 2:
+ * resample.py:49-98, 139-154).  Ratio 2 and 12 taps only (the only configuration the reference builds).  up_filter / down_filter: 12 floats each on
+ * the device (they are module buffers of the checkpoint); alpha, inv_beta: [C] (exp() of the log-scale parameters and 1 / (beta + 1e-9), applied at load). */
+typedef struct {
+  const float* x; int64_t x_bstride; int32_t ldx; int32_t C; int32_t L; const int32_t* lens; int32_t B;
+  const float* up_filter; const float* down_filter;
+  const float* alpha; const float* inv_beta;
+  float* y; int64_t y_bstride; int32_t ldy;
+} mi355_aa_act_args;
+int mi355_aa_activation(const mi355_aa_act_args* a, void* stream);
+
 /* AdaIN + LeakyReLU + depthwise ConvTranspose1d(k3, s2) with the first output dropped
  * (AdainResBlk1d pool, istftnet.py:879-881,907-915): x [B, L, C] -> y [B, 2L, C]. */
 typedef struct {

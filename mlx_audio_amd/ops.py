@@ -631,6 +631,16 @@ def adain_pool_up2(x: torch.Tensor, scale, shift, slope: float, w: torch.Tensor,
     return y
 
 
+def aa_activation(x: torch.Tensor, y: torch.Tensor, up_filter: torch.Tensor, down_filter: torch.Tensor, alpha: torch.Tensor, inv_beta: torch.Tensor, lens=None):
+    """BigVGAN's anti-aliased SnakeBeta (``Activation1d``, codec/models/bigvgan/resample.py:157-177): x [B, L, C] -> y [B, L, C]."""
+    B, L, C, xbs, ldx = _nlc(x)
+    _, _, _, ybs, ldy = _nlc(y)
+    assert up_filter.numel() == 12 and down_filter.numel() == 12 and alpha.numel() >= C and inv_beta.numel() >= C
+    _lib.call_struct("mi355_aa_activation", "mi355_aa_act_args", _stream(), x=_ptr(x), x_bstride=xbs, ldx=ldx, C=C, L=L, lens=_ptr(lens), B=B,
+                     up_filter=_ptr(up_filter), down_filter=_ptr(down_filter), alpha=_ptr(alpha), inv_beta=_ptr(inv_beta), y=_ptr(y), y_bstride=ybs, ldy=ldy)
+    return y
+
+
 def conv1d_c1_k3s2(x: torch.Tensor, w3, bias: float, y: torch.Tensor, col: int, lens_in=None):
     """x [B, Lin] -> y[b, l, col] (Decoder.F0_conv / N_conv)."""
     assert x.dim() == 2 and x.stride(1) == 1

@@ -802,6 +802,36 @@ def run_sanitize(R):
     return {k: len(v) for k, v in out.items()}
 
 
+BIGVGAN_TINY = dict(num_mels=20, upsample_rates=[4, 2], upsample_kernel_sizes=[8, 4], upsample_initial_channel=64, resblock="1",
+                    resblock_kernel_sizes=[3, 7], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5]], activation="snakebeta", snake_logscale=True,
+                    use_bias_at_final=True, use_tanh_at_final=True)
+
+
+def run_bigvgan(seed_w, seed_mel, n_frames):
+    """The reference's ``BigVGAN`` (codec/models/bigvgan/{bigvgan,amp,resample,activation,conv}.py): mel -> waveform, AMPBlock1 and AMPBlock2 variants."""
+    from mlx_audio_amd.codec.models.bigvgan import BigVGANConfig, make_bigvgan_weights
+
+    _codec_pkgs()
+    base = "mlx_audio.codec.models.bigvgan"
+    if base not in sys.modules:
+        _pkg(base, f"{REF}/codec/models/bigvgan")
+        for m in ("activation", "conv", "resample", "amp", "bigvgan"):
+            _load(f"{base}.{m}", f"{REF}/codec/models/bigvgan/{m}.py")
+    rb = sys.modules[f"{base}.bigvgan"]
+    out = dict(seed_w=seed_w, seed_mel=seed_mel, n_frames=n_frames)
+    mel = (np.random.default_rng(seed_mel).standard_normal((2, BIGVGAN_TINY["num_mels"], n_frames)) * 0.8).astype(np.float32)
+    for kind in ("1", "2"):
+        cfgd = dict(BIGVGAN_TINY, resblock=kind)
+        w = make_bigvgan_weights(BigVGANConfig(**cfgd), seed=seed_w)
+        model = rb.BigVGAN(rb.BigVGANConfig(**cfgd))
+        model.load_weights([(k, v.numpy()) for k, v in w.items()])
+        missing, unexpected, mism = model._load_report
+        assert not missing and not unexpected and not mism, (missing[:8], unexpected[:8], mism[:4])
+        model.eval()
+        out[f"audio{kind}"] = np.asarray(model(mx.array(mel))).astype(np.float32)
+    return out
+
+
 def main():
     R = import_reference()
     n = check_shim_against_reference_vectors(R)
@@ -848,6 +878,9 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_dsp.npz"), **xfx)
     print("dsp:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in xfx.items()})
     print("sanitize:", run_sanitize(R))
+    bfx = run_bigvgan(seed_w=6, seed_mel=2, n_frames=50)
+    np.savez_compressed(os.path.join(HERE, "ref_bigvgan_tiny.npz"), config=json.dumps(BIGVGAN_TINY), **bfx)
+    print("bigvgan:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in bfx.items()}, "peak", float(np.abs(bfx["audio1"]).max()))
     wfx = run_whisper(seed_w=3, seed_mel=2, sample_len=24)
     np.savez_compressed(os.path.join(HERE, "ref_whisper_tiny.npz"), **wfx)
     print("whisper:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in wfx.items()}, wfx["ts_tokens"].tolist(), wfx["nots_tokens"].tolist())

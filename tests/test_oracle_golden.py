@@ -229,3 +229,19 @@ def test_whisper_log_mel_oracle_on_speech_fixture():
     assert np.abs(m32 - m64).max() < 5e-5
     assert abs(float(m64.max()) - float(m64.min()) - 2.0) < 1e-9          # the (max - 8) floor is active: padding frames sit on it
     assert 0.05 < float((m64 > m64.min() + 1e-9).mean()) < 0.5            # and the speech frames are above it
+
+
+def test_bigvgan_shape_pins():
+    """codec/tests/test_bigvgan.py:10-49: 800 mel frames -> 800 x prod(upsample_rates) samples for the 22 kHz / 80-band (x256) and 44 kHz / 128-band (x512)
+    rate / kernel tables; lengths do not depend on the channel width, so the pin runs the restated model at a reduced width and 40 frames."""
+    import math
+
+    from mlx_audio_amd.codec.models.bigvgan import BigVGANConfig, make_bigvgan_weights
+    from oracle.bigvgan_ref import BigVGANRef
+
+    for mels, rates, kers, tanh, bias in ((80, [4, 4, 2, 2, 2, 2], [8, 8, 4, 4, 4, 4], True, True), (128, [8, 4, 2, 2, 2, 2], [16, 8, 4, 4, 4, 4], False, False)):
+        cfg = dict(num_mels=mels, upsample_rates=rates, upsample_kernel_sizes=kers, upsample_initial_channel=64, resblock="1", resblock_kernel_sizes=[3],
+                   resblock_dilation_sizes=[[1, 3, 5]], activation="snakebeta", snake_logscale=True, use_bias_at_final=bias, use_tanh_at_final=tanh)
+        ref = BigVGANRef(make_bigvgan_weights(BigVGANConfig(**cfg), seed=0), cfg)
+        y = ref(torch.zeros(1, mels, 40))
+        assert tuple(y.shape) == (1, 1, 40 * math.prod(rates)) and float(y.abs().max()) <= 1.0

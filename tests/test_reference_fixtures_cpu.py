@@ -419,3 +419,21 @@ def test_sanitize_matches_the_reference_sanitize():
     assert set(got) == set(want["qwen3_codec"]), (sorted(set(got) ^ set(want["qwen3_codec"]))[:6])
     for k, (shape, s1, s2) in want["qwen3_codec"].items():
         assert got[k][0] == shape and abs(got[k][1] - s1) <= 1e-6 * (1 + abs(s1)) and abs(got[k][2] - s2) <= 1e-6 * (1 + s2), k
+
+
+def test_bigvgan_oracle_reproduces_the_reference_modules():
+    """The reference's ``BigVGAN`` (codec/models/bigvgan/*.py) with AMPBlock1 and AMPBlock2, SnakeBeta in log scale, anti-aliased activations."""
+    import json
+
+    from mlx_audio_amd.codec.models.bigvgan import BigVGANConfig, make_bigvgan_weights
+    from oracle.bigvgan_ref import BigVGANRef
+
+    fx = np.load(os.path.join(GOLD, "ref_bigvgan_tiny.npz"))
+    cfg = json.loads(str(fx["config"]))
+    mel = torch.from_numpy((np.random.default_rng(int(fx["seed_mel"])).standard_normal((2, cfg["num_mels"], int(fx["n_frames"]))) * 0.8).astype(np.float32))
+    for kind in ("1", "2"):
+        c = dict(cfg, resblock=kind)
+        ref = BigVGANRef(make_bigvgan_weights(BigVGANConfig(**c), seed=int(fx["seed_w"])), c)
+        got = ref(mel).numpy()
+        want = fx[f"audio{kind}"]
+        assert got.shape == want.shape and rel_max(got, want) < 2e-5, kind
