@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Measurement line for the widened codec rows: Vocos (mel -> waveform, 24 kHz), DAC (44 kHz, 9 codebooks) and SNAC
-(24 kHz, 3 code levels) decode on one MI355X, synthetic weights of the published shapes, inputs resident in HBM before the timed region.
+"""Measurement line for the widened codec rows: Vocos (mel -> waveform, 24 kHz), DAC (44 kHz, 9 codebooks), SNAC
+(24 kHz, 3 code levels) decode and the BigVGAN vocoder (22 kHz, 80 bands) on one MI355X, synthetic weights of the published shapes, inputs resident in HBM before the timed region.
 
 Prints ONE JSON line per codec: value = audio samples decoded per second over the whole batch (and x real time), ms per batch, and a roofline
 object for the conv_gemm launches of one instrumented pass (algorithmic FLOPs / summed launch durations against the dense bf16-class MFMA
@@ -112,6 +112,21 @@ def main():
         n = int(out.shape[1])
         print(json.dumps(line("SNAC 24 kHz (decoder_dim 1024, rates 8/8/4/2, depthwise, noise, 3 code levels)", f"{B} x {T} finest-level code frames -> waveform", 24000, n, B,
                               wall, dms, conv_roofline(fn), dt16)))
+
+    if args.only in ("", "bigvgan"):
+        from mlx_audio_amd.codec.models.bigvgan import BigVGAN, BigVGANConfig
+
+        cfg = BigVGANConfig(num_mels=80, upsample_rates=[4, 4, 2, 2, 2, 2], upsample_kernel_sizes=[8, 8, 4, 4, 4, 4], upsample_initial_channel=1536, resblock="1",
+                            resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3, activation="snakebeta", snake_logscale=True)
+        eng = BigVGAN(cfg, device=dev, seed=0)
+        T = int(args.seconds * 22050) // 256
+        Bb = max(1, B // 4)  # the 22 kHz / 80-band model is ~14 x the FLOPs per sample of the codecs above
+        mel = (torch.randn(Bb, 80, T, generator=g) * 0.8).to(dev)
+        fn = lambda: eng(mel)  # noqa: E731
+        out, wall, dms = timed(fn, args.steps, args.warmup)
+        n = int(out.shape[-1])
+        print(json.dumps(line("BigVGAN 22 kHz / 80 bands (1536 channels, rates 4/4/2/2/2/2, AMPBlock1 k 3/7/11, SnakeBeta, anti-aliased activations)",
+                              f"{Bb} x {T} mel frames -> waveform", 22050, n, Bb, wall, dms, conv_roofline(fn), dt16)))
 
 
 if __name__ == "__main__":
