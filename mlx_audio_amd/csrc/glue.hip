@@ -120,26 +120,30 @@ __global__ void conv1d_c1_k3s2_kernel(const float* x, int ldxb, int Lin, const i
   y[(int64_t)b * ybs + (int64_t)l * ldy + col] = s + bias;
 }
 
-// ---- BigVGAN anti-aliased activation (one workgroup = 64 outputs x 64 channels; x window and the activated 2x signal live in LDS) ----
-constexpr int kAaT = 64;   // outputs per workgroup
+// ---- BigVGAN anti-aliased activation: one workgroup = T outputs x CT channels (T * CT = 4096); the x window and the activated 2x signal live in
+// LDS, so the double-rate tensor never reaches HBM.  CT is the widest power of two (<= 64) that divides C: the late stages are narrow (24 .. 96
+// channels) and a fixed 64-lane channel tile would idle up to 62 % of the lanes there.
+template <int CT>
 __global__ __launch_bounds__(256) void aa_act_kernel(const mi355_aa_act_args a) {
-  __shared__ float xs[(kAaT + 11) * 64];       // x rows t0 - 6 .. t0 + T + 4 (edge-clamped)
-  __shared__ float as_[(2 * kAaT + 10) * 64];  // a[m], m = 2 t0 - 5 .. 2 t0 + 2 T + 4 (edge-clamped)
+  constexpr int T = 4096 / CT, RG = 256 / CT;
+  __shared__ float xs[(T + 11) * CT];       // x rows t0 - 6 .. t0 + T + 4 (edge-clamped)
+  __shared__ float as_[(2 * T + 10) * CT];  // a[m], m = 2 t0 - 5 .. 2 t0 + 2 T + 4 (edge-clamped)
   __shared__ float fu[12], fd[12];
-  const int b = blockIdx.z, c0 = blockIdx.y * 64, t0 = blockIdx.x * kAaT;
+  const int b = blockIdx.z, c0 = blockIdx.y * CT, t0 = blockIdx.x * T;
   const int len = a.lens ? a.lens[b] : a.L;
   if (t0 >= len) return;
-  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = c0 + cl;
+  const int cl = threadIdx.x % CT, rg = threadIdx.x / CT, c = c0 + cl;
   const bool cok = c < a.C;
   if (threadIdx.x < 12) { fu[threadIdx.x] = a.up_filter[threadIdx.x]; fd[threadIdx.x] = a.down_filter[threadIdx.x]; }
   const float* xb = a.x + (int64_t)b * a.x_bstride;
-  for (int r = rg; r < kAaT + 11; r += 4) {
+  const int nrows = min(T, len - t0);
+  for (int r = rg; r < nrows + 11; r += RG) {
     const int t = min(max(t0 - 6 + r, 0), len - 1);
-    xs[r * 64 + cl] = cok ? xb[(int64_t)t * a.ldx + c] : 0.f;
+    xs[r * CT + cl] = cok ? xb[(int64_t)t * a.ldx + c] : 0.f;
   }
   __syncthreads();
   const float al = cok ? a.alpha[c] : 1.f, ib = cok ? a.inv_beta[c] : 0.f;
-  for (int j = rg; j < 2 * kAaT + 10; j += 4) {
+  for (int j = rg; j < 2 * nrows + 10; j += RG) {
     const int m = min(max(2 * t0 - 5 + j, 0), 2 * len - 1);  // edge padding of the activated signal = its first / last sample
     // u[m] = 2 * sum_k f[k] * xp[(m + 15 - k) / 2] over k of the parity of m + 15; xp[i] = x[clamp(i - 5)]
     const int p = (m + 15) & 1;
@@ -148,22 +152,27 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const mi355_aa_act_args a) 
     for (int q = 0; q < 6; ++q) {
       const int k = p + 2 * q;
       const int xi = min(max((m + 15 - k) / 2 - 5, 0), len - 1);
-      u += fu[k] * xs[(xi - (t0 - 6)) * 64 + cl];
+      u += fu[k] * xs[(xi - (t0 - 6)) * CT + cl];
     }
     u *= 2.0f;
     const float sn = sinf(al * u);
-    as_[j * 64 + cl] = u + ib * (sn * sn);
+    as_[j * CT + cl] = u + ib * (sn * sn);
   }
   __syncthreads();
   float* yb = a.y + (int64_t)b * a.y_bstride;
-  for (int r = rg; r < kAaT; r += 4) {
-    const int t = t0 + r;
-    if (t >= len || !cok) continue;
+  for (int r = rg; r < nrows; r += RG) {
+    if (!cok) continue;
     float acc = 0.f;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) acc += fd[k] * as_[(2 * r + k) * 64 + cl];
-    yb[(int64_t)t * a.ldy + c] = acc;
+    for (int k = 0; k < 12; ++k) acc += fd[k] * as_[(2 * r + k) * CT + cl];
+    yb[(int64_t)(t0 + r) * a.ldy + c] = acc;
   }
+}
+
+template <int CT>
+void launch_aa(const mi355_aa_act_args& a, hipStream_t st) {
+  constexpr int T = 4096 / CT;
+  hipLaunchKernelGGL(aa_act_kernel<CT>, dim3((a.L + T - 1) / T, (a.C + CT - 1) / CT, a.B), dim3(256), 0, st, a);
 }
 
 }  // namespace
@@ -174,7 +183,12 @@ extern "C" int mi355_aa_activation(const mi355_aa_act_args* ap, void* stream) {
   MI355_REQUIRE(a.B > 0 && a.L > 0 && a.C > 0 && a.ldx >= a.C && a.ldy >= a.C, "aa_activation: bad shape");
   MI355_REQUIRE(a.x != a.y, "aa_activation: in-place operation is not supported (every output reads 12 neighbours)");
   MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL(aa_act_kernel, dim3((a.L + kAaT - 1) / kAaT, (a.C + 63) / 64, a.B), dim3(256), 0, (hipStream_t)stream, a);
+  hipStream_t st = (hipStream_t)stream;
+  if (a.C % 64 == 0 || a.C > 128) launch_aa<64>(a, st);        // wide tensors: at most one partly filled channel tile
+  else if (a.C % 32 == 0) launch_aa<32>(a, st);
+  else if (a.C % 16 == 0) launch_aa<16>(a, st);
+  else if (a.C % 8 == 0 || a.C < 8) launch_aa<8>(a, st);
+  else launch_aa<64>(a, st);
   MI355_LAUNCH_CHECK("aa_activation");
   return MI355_OK;
 }
