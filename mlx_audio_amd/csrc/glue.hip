@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const mi355_aa_act_args a) 
       u += fu[k] * xs[(xi - (t0 - 6)) * CT + cl];
     }
     u *= 2.0f;
-    const float sn = sinf(al * u);
+    const float sn = __sinf(al * u);  // hardware sine (|al * u| stays far below its 256-revolution range); ~1e-6 absolute, as in the conv prologues
     as_[j * CT + cl] = u + ib * (sn * sn);
   }
   __syncthreads();
