@@ -832,6 +832,76 @@ def run_bigvgan(seed_w, seed_mel, n_frames):
     return out
 
 
+def run_cache():
+    """The reference's own ``KVCache`` / ``BatchKVCache`` (lm/models/cache.py:104-176, 502-717) through the operation sequences tests/test_cache_cpu.py
+    runs on this package's device-layout mirrors: offsets, capacities, left paddings and the fetched contents (as checksums)."""
+    import json
+
+    import_lm_and_mimi()
+    C = sys.modules["mlx_audio.lm.models.cache"]
+    G, DH = 2, 4
+    W = G * DH
+
+    def kv(B, n, seed):  # the same draws as tests/test_cache_cpu.py::_kv, in the reference's [B, heads, n, dh] layout
+        import torch
+
+        g = torch.Generator().manual_seed(seed)
+        k, v = torch.randn(B, n, W, generator=g), torch.randn(B, n, W, generator=g)
+        to = lambda t: mx.array(t.reshape(B, n, G, DH).transpose(1, 2).contiguous().numpy())  # noqa: E731
+        return to(k), to(v)
+
+    def chk(a):
+        a = np.asarray(a, dtype=np.float64)
+        return [list(a.shape), float(a.sum()), float((a ** 2).sum())]
+
+    out = {}
+    c = C.KVCache()
+    rows = []
+    for i, n in enumerate((3, 1, 1, 260, 1, 300)):
+        k, v = kv(2, n, i)
+        rk, rv = c.update_and_fetch(k, v)
+        rows.append(dict(offset=int(c.offset), capacity=int(c.keys.shape[2]), keys=chk(rk), values=chk(rv)))
+    t1 = int(c.trim(5))
+    o1 = int(c.offset)
+    t2 = int(c.trim(10 ** 6))
+    out["kvcache"] = dict(rows=rows, trim5=t1, offset_after=o1, trim_all=t2, offset_end=int(c.offset))
+    # merge -> step -> extract
+    singles = []
+    for i, n in enumerate((5, 2, 9)):
+        s_ = C.KVCache()
+        k, v = kv(1, n, 10 + i)
+        s_.update_and_fetch(k, v)
+        singles.append(s_)
+    b = C.BatchKVCache.merge(singles)
+    m = dict(left_padding=[int(x) for x in np.asarray(b.left_padding)], offset=[int(x) for x in np.asarray(b.offset)], size=int(b.size()))
+    k, v = kv(3, 1, 99)
+    keys, vals = b.update_and_fetch(k, v)
+    m.update(step_keys=chk(keys), step_offset=[int(x) for x in np.asarray(b.offset)],
+             extracted=[dict(offset=int(b.extract(i).offset), keys=chk(b.extract(i).state[0])) for i in range(3)])
+    out["merge"] = m
+    # filter / extend / trim
+    b = C.BatchKVCache([1, 3, 0])
+    k, v = kv(3, 4, 1)
+    b.update_and_fetch(k, v)
+    f = dict(offset0=[int(x) for x in np.asarray(b.offset)], idx0=int(b._idx))
+    b.filter(mx.array([0, 1]))
+    f.update(left_padding1=[int(x) for x in np.asarray(b.left_padding)], idx1=int(b._idx), keys1=chk(b.keys[..., : b._idx, :]))
+    other = C.BatchKVCache([0])
+    k2, v2 = kv(1, 6, 2)
+    other.update_and_fetch(k2, v2)
+    b.extend(other)
+    f.update(idx2=int(b._idx), left_padding2=[int(x) for x in np.asarray(b.left_padding)], offset2=[int(x) for x in np.asarray(b.offset)],
+             keys2=chk(b.keys[..., : b._idx, :]))
+    f.update(trim=int(b.trim(2)), idx3=int(b._idx), offset3=[int(x) for x in np.asarray(b.offset)])
+    e1, e2 = C.BatchKVCache([2]), C.BatchKVCache([0, 1])
+    e1.extend(e2)
+    f.update(empty_extend_left_padding=[int(x) for x in np.asarray(e1.left_padding)], empty=bool(e1.empty()))
+    out["filter_extend"] = f
+    with open(os.path.join(HERE, "ref_cache.json"), "w") as fh:
+        json.dump(out, fh)
+    return {k: (len(v) if isinstance(v, (list, dict)) else v) for k, v in out.items()}
+
+
 def main():
     R = import_reference()
     n = check_shim_against_reference_vectors(R)
@@ -878,6 +948,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_dsp.npz"), **xfx)
     print("dsp:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in xfx.items()})
     print("sanitize:", run_sanitize(R))
+    print("cache:", run_cache())
     bfx = run_bigvgan(seed_w=6, seed_mel=2, n_frames=50)
     np.savez_compressed(os.path.join(HERE, "ref_bigvgan_tiny.npz"), config=json.dumps(BIGVGAN_TINY), **bfx)
     print("bigvgan:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in bfx.items()}, "peak", float(np.abs(bfx["audio1"]).max()))

@@ -74,3 +74,65 @@ def test_batch_cache_filter_and_extend():
     e1, e2 = BatchKVCache([2], G, DH), BatchKVCache([0, 1], G, DH)
     e1.extend(e2)
     assert e1.left_padding.tolist() == [2, 0, 1] and e1.empty()
+
+
+def _chk(t):
+    t = t.double()
+    return [list(t.shape), float(t.sum()), float((t ** 2).sum())]
+
+
+def _same(a, b, tol=1e-9):
+    return a[0] == b[0] and abs(a[1] - b[1]) <= tol * (1 + abs(b[1])) and abs(a[2] - b[2]) <= tol * (1 + b[2])
+
+
+def test_caches_against_the_reference_classes_own_run():
+    """tests/golden/ref_cache.json = the reference's OWN ``KVCache`` / ``BatchKVCache`` (lm/models/cache.py, executed over the numpy stand-in for MLX by
+    tests/golden/make_reference_fixtures.py) through the operation sequences of this file: this package's device-layout mirrors reproduce every offset,
+    capacity, left padding, trim count and the fetched contents."""
+    import json
+    import os
+
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_cache.json")))
+    c = KVCache(G, DH, "cpu")
+    for i, (n, row) in enumerate(zip((3, 1, 1, 260, 1, 300), want["kvcache"]["rows"])):
+        k, v = _kv(2, n, i)
+        slot = c.reserve(2, n)
+        slot[:, :, :W], slot[:, :, W:] = k, v
+        assert c.offset == row["offset"] and c.kv.shape[1] == row["capacity"]
+        assert _same(_chk(_to_ref(c.keys)), row["keys"]) and _same(_chk(_to_ref(c.values)), row["values"])
+    kw = want["kvcache"]
+    assert c.trim(5) == kw["trim5"] and c.offset == kw["offset_after"] and c.trim(10 ** 6) == kw["trim_all"] and c.offset == kw["offset_end"]
+
+    singles = []
+    for i, n in enumerate((5, 2, 9)):
+        s = KVCache(G, DH, "cpu")
+        k, v = _kv(1, n, 10 + i)
+        sl = s.reserve(1, n)
+        sl[:, :, :W], sl[:, :, W:] = k, v
+        singles.append(s)
+    b = BatchKVCache.merge(singles)
+    m = want["merge"]
+    assert b.left_padding.tolist() == m["left_padding"] and b.offset.tolist() == m["offset"] and b.size() == m["size"]
+    k, v = _kv(3, 1, 99)
+    keys, _ = b.update_and_fetch(k, v)
+    assert _same(_chk(_to_ref(keys)), m["step_keys"]) and b.offset.tolist() == m["step_offset"]
+    for i, e in enumerate(m["extracted"]):
+        x = b.extract(i)
+        assert x.offset == e["offset"] and _same(_chk(_to_ref(x.keys)), e["keys"])
+
+    f = want["filter_extend"]
+    b = BatchKVCache([1, 3, 0], G, DH)
+    k, v = _kv(3, 4, 1)
+    b.update_and_fetch(k, v)
+    assert b.offset.tolist() == f["offset0"] and b._idx == f["idx0"]
+    b.filter([0, 1])
+    assert b.left_padding.tolist() == f["left_padding1"] and b._idx == f["idx1"] and _same(_chk(_to_ref(b.keys)), f["keys1"])
+    other = BatchKVCache([0], G, DH)
+    k2, v2 = _kv(1, 6, 2)
+    other.update_and_fetch(k2, v2)
+    b.extend(other)
+    assert b._idx == f["idx2"] and b.left_padding.tolist() == f["left_padding2"] and b.offset.tolist() == f["offset2"] and _same(_chk(_to_ref(b.keys)), f["keys2"])
+    assert b.trim(2) == f["trim"] and b._idx == f["idx3"] and b.offset.tolist() == f["offset3"]
+    e1, e2 = BatchKVCache([2], G, DH), BatchKVCache([0, 1], G, DH)
+    e1.extend(e2)
+    assert e1.left_padding.tolist() == f["empty_extend_left_padding"] and e1.empty() == f["empty"]
