@@ -902,6 +902,52 @@ def run_cache():
     return {k: (len(v) if isinstance(v, (list, dict)) else v) for k, v in out.items()}
 
 
+def run_kitten_generate(R):
+    """The reference's ``Model.generate`` of KittenTTS (kitten_tts.py:419-751: chunking, voice alias / speed prior, cross-fade between chunks, tail trim,
+    fade-out, trailing silence, GenerationResult bookkeeping) with the network call replaced by a deterministic waveform (pt_layouts.fake_kitten_wave)
+    and espeak by a stand-in phonemizer: what ``generate`` does with the audio it is handed."""
+    import json
+
+    import pt_layouts as PT
+
+    from mlx_audio_amd.tts.models.kitten_tts import synthetic as KS
+
+    T = R["kitten"]
+    cfg = dict(KS.tiny_config(), voice_aliases={"kiki": "expr-voice-2-f"}, speed_priors={"expr-voice-2-f": 0.8})
+    model = T.Model(T.ModelConfig.from_dict(cfg))
+    model.voices = {"expr-voice-2-f": np.zeros((40, 256), dtype=np.float32)}
+
+    class Phonemizer:
+        def phonemize(self, texts):
+            return [t.lower() for t in texts]
+
+    model._phonemizer = Phonemizer()
+    orig = T.Model.__call__
+    calls = []
+
+    def fake(self, input_ids, ref_s, speed=1.0, return_output=False):
+        n = int(input_ids.shape[-1])
+        calls.append((n, float(speed)))
+        return mx.array(PT.fake_kitten_wave(n, float(speed)))[None, :]
+
+    T.Model.__call__ = fake
+    out = []
+    try:
+        for case in PT.KITTEN_GENERATE_CASES:
+            calls.clear()
+            res = list(model.generate(case["text"], voice="kiki", clean_text=False, **case["kw"]))
+            out.append(dict(calls=list(calls), results=[dict(samples=int(r.samples), segment_idx=int(r.segment_idx), token_count=int(r.token_count),
+                                                             n=int(np.asarray(r.audio).shape[0]), sum=float(np.asarray(r.audio, dtype=np.float64).sum()),
+                                                             sq=float((np.asarray(r.audio, dtype=np.float64) ** 2).sum()),
+                                                             head=[float(x) for x in np.asarray(r.audio)[:3]], tail=[float(x) for x in np.asarray(r.audio)[-3:]])
+                                                        for r in res]))
+    finally:
+        T.Model.__call__ = orig
+    with open(os.path.join(HERE, "ref_kitten_generate.json"), "w") as f:
+        json.dump(out, f)
+    return [(len(c["calls"]), [r["n"] for r in c["results"]]) for c in out]
+
+
 def main():
     R = import_reference()
     n = check_shim_against_reference_vectors(R)
@@ -949,6 +995,7 @@ def main():
     print("dsp:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in xfx.items()})
     print("sanitize:", run_sanitize(R))
     print("cache:", run_cache())
+    print("kitten generate:", run_kitten_generate(R))
     bfx = run_bigvgan(seed_w=6, seed_mel=2, n_frames=50)
     np.savez_compressed(os.path.join(HERE, "ref_bigvgan_tiny.npz"), config=json.dumps(BIGVGAN_TINY), **bfx)
     print("bigvgan:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in bfx.items()}, "peak", float(np.abs(bfx["audio1"]).max()))

@@ -65,3 +65,25 @@ def qwen3_codec_checkpoint(cw):
 def summary(d):
     """key -> [shape, sum, sum of squares] (float64): enough to tell two sanitized dicts apart, small enough to commit."""
     return {k: [list(v.shape), float(torch.as_tensor(v).double().sum()), float((torch.as_tensor(v).double() ** 2).sum())] for k, v in sorted(d.items())}
+
+
+def fake_kitten_wave(n_tokens: int, speed: float):
+    """A deterministic stand-in for a synthesised chunk (float32 numpy, 24 kHz): speech-like noise, then 50 ms of near-silence and a short spurt at the
+    end -- the pattern the tail trimmer of KittenTTS's ``generate`` looks for -- with length and seed depending on the inputs."""
+    import numpy as np
+
+    rng = np.random.default_rng(1000 + n_tokens)
+    n = int(24000 * (0.4 + 0.01 * n_tokens) / max(speed, 0.25))
+    env = np.minimum(1.0, np.arange(n) / 2400.0) * (0.6 + 0.4 * np.sin(np.arange(n) / 3000.0) ** 2)
+    body = (0.2 * rng.standard_normal(n) * env).astype(np.float32)
+    gap = (1e-4 * rng.standard_normal(1200)).astype(np.float32)
+    spurt = (0.15 * rng.standard_normal(700)).astype(np.float32)
+    return np.concatenate([body, gap, spurt]).astype(np.float32)
+
+
+KITTEN_GENERATE_CASES = [
+    dict(text="Hello there, this is a test", kw=dict()),
+    dict(text="The quick brown fox jumps. Over the lazy dog! And then it sleeps for a while", kw=dict(chunk_size=30)),
+    dict(text="One two three. Four five six? Seven eight", kw=dict(chunk_size=16, crossfade_ms=0, fade_out_ms=0, tail_silence_ms=0)),
+    dict(text="Short one. Another short one", kw=dict(chunk_size=12, crossfade_ms=50, fade_out_ms=600, tail_silence_ms=100, speed=1.3)),
+]

@@ -134,3 +134,48 @@ def test_oracle_without_quantisation_is_kokoro_with_other_widths():
     assert not torch.equal(kit.durations(ids, ref_s)[1], dk)
     q = kitten_ref.KittenRef(w, dict(cfg, activation_quant_modules=KS.converter_quant_modules(w)), param_dtype=torch.bfloat16)
     assert not torch.equal(q.durations(ids, ref_s)[1], kit.durations(ids, ref_s)[1])
+
+
+def test_generate_host_logic_matches_the_reference_generate():
+    """tests/golden/ref_kitten_generate.json = the reference's own ``Model.generate`` (kitten_tts.py:419-751, run by tests/golden/make_reference_fixtures.py
+    over the numpy stand-in for MLX) with the network call replaced by a deterministic waveform and espeak by a stand-in: chunking, alias and compounding
+    speed prior (the (tokens, speed) of every network call), cross-fade, tail trim (the waveforms end in silence + a spurt), fade-out, trailing silence,
+    segment / token bookkeeping.  This package's ``generate`` -- same stand-ins -- yields the same audio, sample for sample."""
+    import json
+    import os
+    import sys
+
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gold)
+    import pt_layouts as PT
+
+    from mlx_audio_amd.tts.models.kitten_tts import Model, ModelConfig
+    from mlx_audio_amd.tts.models.kitten_tts import synthetic as KS
+
+    want = json.load(open(os.path.join(gold, "ref_kitten_generate.json")))
+    calls = []
+
+    class Probe(Model):
+        def __call__(self, input_ids, ref_s, speed=1.0, return_output=False):
+            n = int(input_ids.shape[-1])
+            calls.append([n, float(speed)])
+            return torch.from_numpy(PT.fake_kitten_wave(n, float(speed)))[None, :]
+
+    class Phonemizer:
+        def phonemize(self, texts):
+            return [t.lower() for t in texts]
+
+    cfg = dict(KS.tiny_config(), voice_aliases={"kiki": "expr-voice-2-f"}, speed_priors={"expr-voice-2-f": 0.8})
+    model = Probe(ModelConfig.from_dict(cfg))
+    model.voices = {"expr-voice-2-f": np.zeros((40, 256), dtype=np.float32)}
+    model._phonemizer = Phonemizer()
+    for case, exp in zip(PT.KITTEN_GENERATE_CASES, want):
+        calls.clear()
+        res = list(model.generate(case["text"], voice="kiki", clean_text=False, **case["kw"]))
+        assert [[c[0], round(c[1], 6)] for c in calls] == [[c[0], round(c[1], 6)] for c in exp["calls"]], (calls, exp["calls"])
+        assert len(res) == len(exp["results"])
+        for r, e in zip(res, exp["results"]):
+            a = r.audio.double().numpy()
+            assert r.samples == e["samples"] == a.shape[0] == e["n"] and r.segment_idx == e["segment_idx"] and r.token_count == e["token_count"]
+            assert abs(a.sum() - e["sum"]) <= 1e-4 * (1 + abs(e["sum"])) and abs((a ** 2).sum() - e["sq"]) <= 1e-5 * (1 + e["sq"])
+            assert np.allclose(a[:3], e["head"], atol=1e-6) and np.allclose(a[-3:], e["tail"], atol=1e-6)
