@@ -948,6 +948,68 @@ def run_kitten_generate(R):
     return [(len(c["calls"]), [r["n"] for r in c["results"]]) for c in out]
 
 
+def run_whisper_generate():
+    """The reference's ``Model.generate`` of Whisper (whisper.py:799-1320: 30 s windows, temperature fallback, no-speech skipping, segment cutting at
+    consecutive timestamps, seek advance, prompt conditioning and its reset, clip timestamps) with ``_prepare_audio`` replaced by a ramp mel and ``decode``
+    by a script of DecodingResults (pt_layouts.WHISPER_GENERATE_CASES): every decode call's window / temperature / prompt, and the resulting segments."""
+    import json
+
+    import pt_layouts as PT
+
+    from mlx_audio_amd.stt.models.whisper import synthetic as WS
+
+    wh, dec = import_whisper()
+    u = sys.modules["mlx_audio.utils"]
+    for n in ("base_load_model", "get_model_path", "load_config"):
+        setattr(u, n, None)
+    su = _load("mlx_audio.stt.utils", f"{REF}/stt/utils.py")
+    dims = WS.tiny_dims()
+    rd = wh.ModelDimensions(n_mels=80, n_audio_ctx=1500, n_audio_state=64, n_audio_head=2, n_audio_layer=1, n_vocab=51865, n_text_ctx=448, n_text_state=64,
+                            n_text_head=2, n_text_layer=1)
+    codec = PT.WhisperCodec()
+
+    class Tok(FakeWhisperTokenizer):
+        def encode(self, text):
+            return codec.encode(text)
+
+        def decode(self, tokens):  # as HFTokenizerWrapper.decode (whisper.py:74-82): timestamp tokens are dropped
+            return codec.decode([t for t in tokens if t < self.timestamp_begin])
+
+    out = []
+    for case in PT.WHISPER_GENERATE_CASES:
+        model = wh.Model(rd, dtype=mx.float32)
+        model.get_tokenizer = lambda language=None, task="transcribe": Tok()
+        n = case["frames"] + 3000
+        mel = mx.array(np.broadcast_to(np.arange(1, n + 1, dtype=np.float32)[:, None], (n, 80)).copy())
+        model._prepare_audio = lambda audio, padding=0, mel=mel, case=case: (mel, case["frames"])
+        script = list(case["script"])
+        calls = []
+
+        def decode(segment, options, script=script, calls=calls):
+            spec = script.pop(0)
+            if "tokens" not in spec:           # {temperature: spec}: stay on this entry until a temperature is accepted
+                table = spec
+                key = min(table, key=lambda t: abs(float(t) - float(options.temperature)))
+                spec = table[key]
+                if float(key) != max(float(t) for t in table):
+                    script.insert(0, table)
+            col = np.asarray(segment)[:, 0]
+            calls.append(dict(first=float(col[0]), nonzero=int((col != 0).sum()), last_nonzero=float(col[col != 0][-1]) if (col != 0).any() else 0.0,
+                              temperature=float(options.temperature), prompt=[int(t) for t in (options.prompt or [])]))
+            return dec.DecodingResult(audio_features=None, language="en", tokens=list(spec["tokens"]), text=codec.decode(spec["tokens"]),
+                                      avg_logprob=spec.get("avg_logprob", -0.1), no_speech_prob=spec.get("no_speech_prob", 0.0),
+                                      temperature=float(options.temperature), compression_ratio=spec.get("compression_ratio", 1.0))
+
+        model.decode = decode
+        res = model.generate(np.zeros(16000, np.float32), language="en", **case["kw"])
+        segs = [dict(id=s["id"], seek=int(s["seek"]), start=float(s["start"]), end=float(s["end"]), tokens=[int(t) for t in s["tokens"]], text=s["text"],
+                     temperature=float(s["temperature"])) for s in res.segments]
+        out.append(dict(name=case["name"], calls=calls, segments=segs, text=res.text, unused_script=len(script)))
+    with open(os.path.join(HERE, "ref_whisper_generate.json"), "w") as f:
+        json.dump(out, f)
+    return [(c["name"], len(c["calls"]), len(c["segments"])) for c in out]
+
+
 def main():
     R = import_reference()
     n = check_shim_against_reference_vectors(R)
@@ -1000,6 +1062,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_bigvgan_tiny.npz"), config=json.dumps(BIGVGAN_TINY), **bfx)
     print("bigvgan:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in bfx.items()}, "peak", float(np.abs(bfx["audio1"]).max()))
     wfx = run_whisper(seed_w=3, seed_mel=2, sample_len=24)
+    print("whisper generate:", run_whisper_generate())
     np.savez_compressed(os.path.join(HERE, "ref_whisper_tiny.npz"), **wfx)
     print("whisper:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in wfx.items()}, wfx["ts_tokens"].tolist(), wfx["nots_tokens"].tolist())
 

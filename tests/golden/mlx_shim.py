@@ -600,6 +600,9 @@ def stream(s):
     return _Stream()
 
 
+Stream = _Stream
+
+
 cpu = gpu = object()
 
 
@@ -993,6 +996,7 @@ def install():
 
     utils.tree_map = tree_map
     utils.tree_unflatten = lambda pairs: dict(pairs)
+    utils.tree_reduce = lambda fn, tree, init=None: init
     root = types.ModuleType("mlx")
     root._IS_SHIM = True
     root.core, root.nn, root.utils = core, nn, utils

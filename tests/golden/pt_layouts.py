@@ -87,3 +87,42 @@ KITTEN_GENERATE_CASES = [
     dict(text="One two three. Four five six? Seven eight", kw=dict(chunk_size=16, crossfade_ms=0, fade_out_ms=0, tail_silence_ms=0)),
     dict(text="Short one. Another short one", kw=dict(chunk_size=12, crossfade_ms=50, fade_out_ms=600, tail_silence_ms=100, speed=1.3)),
 ]
+
+
+class WhisperCodec:
+    """Deterministic text <-> token stand-in shared by the reference-side tokenizer stub and this package's ``get_tokenizer(codec=...)``."""
+
+    def encode(self, text):
+        return [100 + (ord(c) % 50) for c in text]
+
+    def decode(self, toks):
+        return "".join(chr(ord("a") + (int(t) % 26)) for t in toks)
+
+
+TB = 50364  # timestamp_begin of the multilingual vocabulary
+
+# Scripts for ``Model.generate`` with ``decode`` stubbed: every entry of "script" is the DecodingResult of one decode call, either a dict or a
+# {temperature: dict} table (temperature fallback).  "frames" = content frames of the (ramp) mel, "kw" = generate() options.
+WHISPER_GENERATE_CASES = [
+    dict(name="two_windows", frames=4000, kw=dict(temperature=0.0),
+         script=[dict(tokens=[TB, 200, 201, TB + 1500]), dict(tokens=[TB, 300, TB + 100])]),
+    dict(name="fallback", frames=3000, kw=dict(),
+         script=[{0.0: dict(tokens=[TB, 200, TB + 1500], compression_ratio=3.0), 0.2: dict(tokens=[TB, 210, TB + 1500], avg_logprob=-1.5),
+                  0.4: dict(tokens=[TB, 220, 221, TB + 1500], avg_logprob=-0.3)}] * 1),
+    dict(name="no_speech_skip", frames=6000, kw=dict(temperature=0.0),
+         script=[dict(tokens=[TB, 200, TB + 1500], no_speech_prob=0.9, avg_logprob=-2.0), dict(tokens=[TB, 300, 301, TB + 1500])]),
+    dict(name="consecutive_timestamps", frames=3000, kw=dict(temperature=0.0),
+         script=[dict(tokens=[TB, 100, 101, TB + 200, TB + 200, 102, TB + 400, TB + 400, 103, 104, TB + 900]),
+                 dict(tokens=[TB, 105, TB + 600])]),
+    dict(name="consecutive_ending_pair", frames=3000, kw=dict(temperature=0.0),
+         script=[dict(tokens=[TB, 100, TB + 200, TB + 200, 102, TB + 400, TB + 400]), dict(tokens=[TB, 105, TB + 1100])]),
+    dict(name="prompt_and_no_conditioning", frames=5000, kw=dict(temperature=0.0, condition_on_previous_text=False, initial_prompt="hello there"),
+         script=[dict(tokens=[TB, 200, TB + 1500]), dict(tokens=[TB, 300, TB + 1000])]),
+    dict(name="conditioning_resets_at_high_temperature", frames=7000, kw=dict(temperature=(0.0, 0.8)),
+         script=[{0.0: dict(tokens=[TB, 200, TB + 1500], avg_logprob=-3.0), 0.8: dict(tokens=[TB, 201, TB + 1500])}, dict(tokens=[TB, 300, TB + 1500]),
+                 dict(tokens=[TB, 400, TB + 500])]),
+    dict(name="clip_timestamps", frames=4000, kw=dict(temperature=0.0, clip_timestamps="5,12,20,26"),
+         script=[dict(tokens=[TB, 200, TB + 350]), dict(tokens=[TB, 300, TB + 300])]),
+    dict(name="no_timestamps", frames=3500, kw=dict(temperature=0.0, return_timestamps=False),
+         script=[dict(tokens=[200, 201, 202]), dict(tokens=[300])]),
+]

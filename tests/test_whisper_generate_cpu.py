@@ -166,3 +166,70 @@ def test_initial_tokens_and_group_ranking():
     # MaximumLikelihoodRanker (decoding.py:212-235)
     assert rank_group([[1, 2, 3, 4], [1, 2]], [-4.0, -3.0], None) == 0
     assert rank_group([[1, 2, 3, 4], [1, 2]], [-4.0, -3.0], 0.0) == 1
+
+
+def test_generate_host_loop_matches_the_reference_generate():
+    """tests/golden/ref_whisper_generate.json = the reference's own ``Model.generate`` (whisper.py:799-1320, executed over the numpy stand-in for MLX by
+    tests/golden/make_reference_fixtures.py) with ``_prepare_audio`` replaced by a ramp mel and ``decode`` by scripts of DecodingResults: nine scenarios
+    (plain windows, temperature fallback, no-speech skip, segment cutting at consecutive timestamps with and without a trailing pair, prompt conditioning and
+    its resets, clip timestamps, no timestamps).  This package's ``generate`` -- same stubs -- issues the same decode calls (window contents, temperature,
+    prompt tokens) and returns the same segments and text."""
+    import json
+    import os
+    import sys
+
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gold)
+    import pt_layouts as PT
+
+    want = json.load(open(os.path.join(gold, "ref_whisper_generate.json")))
+    codec = PT.WhisperCodec()
+
+    class Replay(Model):
+        def __init__(self, case):
+            super().__init__(dims(), device="cpu")
+            self.codec = codec
+            self.case = case
+            self.script = list(case["script"])
+            self.calls = []
+
+        def _prepare_audio(self, audio, padding=0):
+            n = self.case["frames"] + N_FRAMES
+            return torch.arange(1, n + 1, dtype=torch.float32)[:, None].expand(n, 80).clone(), self.case["frames"]
+
+        def decode(self, mel, options=DecodingOptions(), **kw):
+            spec = self.script.pop(0)
+            if "tokens" not in spec:
+                table = spec
+                key = min(table, key=lambda t: abs(float(t) - float(options.temperature)))
+                spec = table[key]
+                if float(key) != max(float(t) for t in table):
+                    self.script.insert(0, table)
+            col = mel[:, 0].numpy()
+            nz = col[col != 0]
+            self.calls.append(dict(first=float(col[0]), nonzero=int((col != 0).sum()), last_nonzero=float(nz[-1]) if nz.size else 0.0,
+                                   temperature=float(options.temperature), prompt=[int(t) for t in (options.prompt or [])]))
+            return DecodingResult(audio_features=None, language="en", tokens=list(spec["tokens"]), text=codec.decode(spec["tokens"]),
+                                  avg_logprob=spec.get("avg_logprob", -0.1), no_speech_prob=spec.get("no_speech_prob", 0.0),
+                                  temperature=float(options.temperature), compression_ratio=spec.get("compression_ratio", 1.0))
+
+        def get_tokenizer(self, language=None, task="transcribe"):
+            return get_tokenizer(True, language=language or "en", task=task, codec=codec)
+
+    assert len(want) == len(PT.WHISPER_GENERATE_CASES)
+    for case, exp in zip(PT.WHISPER_GENERATE_CASES, want):
+        # json turned the temperature keys of the fallback tables into strings on the reference side only; the scripts here are the python objects
+        m = Replay(case)
+        out = m.generate(np.zeros(16000, np.float32), language="en", **case["kw"])
+        assert len(m.calls) == len(exp["calls"]), (case["name"], len(m.calls), len(exp["calls"]))
+        for a, b in zip(m.calls, exp["calls"]):
+            assert a["first"] == b["first"] and a["nonzero"] == b["nonzero"] and a["last_nonzero"] == b["last_nonzero"], (case["name"], a, b)
+            assert abs(a["temperature"] - b["temperature"]) < 1e-9 and a["prompt"] == b["prompt"], (case["name"], a, b)
+        assert len(m.script) == exp["unused_script"], case["name"]
+        got = [dict(id=s["id"], seek=int(s["seek"]), start=float(s["start"]), end=float(s["end"]), tokens=[int(t) for t in s["tokens"]], text=s["text"],
+                    temperature=float(s["temperature"])) for s in out.segments]
+        assert len(got) == len(exp["segments"]), (case["name"], got, exp["segments"])
+        for g, e in zip(got, exp["segments"]):
+            assert g["id"] == e["id"] and g["seek"] == e["seek"] and g["tokens"] == e["tokens"] and g["text"] == e["text"], (case["name"], g, e)
+            assert abs(g["start"] - e["start"]) < 1e-9 and abs(g["end"] - e["end"]) < 1e-9 and abs(g["temperature"] - e["temperature"]) < 1e-9, (case["name"], g, e)
+        assert out.text == exp["text"], (case["name"], out.text, exp["text"])
