@@ -283,6 +283,20 @@ typedef struct {
 } mi355_aa_act_args;
 int mi355_aa_activation(const mi355_aa_act_args* a, void* stream);
 
+/* Polyphase FIR sample-rate conversion (mlx_audio/resample.py:29-47 ``resample_audio_array`` = scipy.signal.resample_poly(x, up, down, window=taps,
+ * padtype="edge") with the kaiser_best taps of resample.py:15-26; also utils.py:541-578 ``resample_audio``):  x [rows, n_in] -> y [rows, n_out],
+ *   y[r][n] = sum_k table[k][p] * x[r][clamp(q - k, 0, n_in - 1)],   t = (n + first) * down,  p = t % up,  q = t / up.
+ * table [K, up] float64 on the device (tap-major) = the taps x up, shifted right by (down - half % down) zeros (half = (len(taps) - 1) / 2; resample_poly
+ * centres its output this way), split by phase: table[k][p] = padded[p + k * up], zero where that runs past the end; first = (half + shift) / down =
+ * the outputs resample_poly drops at the front; n_out = ceil(n_in * up / down).  Sums are float64 like scipy's.  The input window of 256 outputs,
+ * (255 * down / up + K + 1) float64 samples, must fit 64 KB of LDS (any pair of the usual rates does; 384 kHz -> 8 kHz does not and is refused). */
+typedef struct {
+  const float* x; int64_t x_bstride; int32_t n_in; int32_t rows;
+  const double* table; int32_t up; int32_t down; int32_t K; int32_t first;
+  float* y; int64_t y_bstride; int32_t n_out;
+} mi355_resample_args;
+int mi355_resample_poly(const mi355_resample_args* a, void* stream);
+
 /* AdaIN + LeakyReLU + depthwise ConvTranspose1d(k3, s2) with the first output dropped
  * (AdainResBlk1d pool, istftnet.py:879-881,907-915): x [B, L, C] -> y [B, 2L, C]. */
 typedef struct {

@@ -641,6 +641,19 @@ def aa_activation(x: torch.Tensor, y: torch.Tensor, up_filter: torch.Tensor, dow
     return y
 
 
+def resample_poly(x: torch.Tensor, table: torch.Tensor, up: int, down: int, first: int, n_out: int, y: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Polyphase FIR rate conversion of the rows of x [rows, n_in] (``scipy.signal.resample_poly(..., padtype="edge")`` as ``mlx_audio/resample.py:40-47``
+    calls it) with the tap-major float64 table [K, up] of ``mlx_audio_amd.resample.polyphase_table``."""
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1 and table.dtype == torch.float64 and table.is_contiguous() and table.shape[1] == up
+    rows, n_in = x.shape
+    if y is None:
+        y = torch.empty(rows, n_out, device=x.device, dtype=torch.float32)
+    assert y.shape == (rows, n_out) and y.stride(1) == 1 and y.dtype == torch.float32
+    _lib.call_struct("mi355_resample_poly", "mi355_resample_args", _stream(), x=_ptr(x), x_bstride=x.stride(0), n_in=n_in, rows=rows, table=_ptr(table),
+                     up=up, down=down, K=table.shape[0], first=first, y=_ptr(y), y_bstride=y.stride(0), n_out=n_out)
+    return y
+
+
 def conv1d_c1_k3s2(x: torch.Tensor, w3, bias: float, y: torch.Tensor, col: int, lens_in=None):
     """x [B, Lin] -> y[b, l, col] (Decoder.F0_conv / N_conv)."""
     assert x.dim() == 2 and x.stride(1) == 1

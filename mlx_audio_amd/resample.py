@@ -7,7 +7,11 @@ sinc with 64 zero crossings per side, roll-off 0.9475937167399596 and beta 14.76
 design constants ARE the algorithm; they are restated here and the properties the reference's tests pin (energy above the new Nyquist removed,
 pass band at unit gain, length, identity at equal rates: ``mlx_audio/tests/test_dsp.py:299-349``) are asserted in ``tests/test_audio_io_cpu.py``.
 ``resample_audio_chunks`` (``resample.py:50-161``) converts a stream of time-first chunks block by block with the SAME samples as one whole-buffer call
-(asserted bit-exactly, like ``test_dsp.py:351-380``).  A device-side polyphase kernel is the SURVEY 8(f).4 follow-up.
+(asserted bit-exactly, like ``test_dsp.py:351-380``).
+
+Tensors that already live on the GPU are converted there: ``resample_audio`` hands a CUDA tensor to ``mi355_resample_poly`` (the same
+taps as a float64 table split by phase, float64 sums, edge padding: ``polyphase_table`` / ``resample_on_device``), so audio between two device stages never
+crosses PCIe; numpy input keeps the reference's host path.
 """
 from __future__ import annotations
 
@@ -33,6 +37,55 @@ def polyphase_design(orig_sample_rate: int, sample_rate: int):
     return up, down, taps
 
 
+def polyphase_table(orig_sample_rate: int, sample_rate: int, n_in: int):
+    """What ``scipy.signal.resample_poly(x, up, down, window=taps, padtype="edge")`` does to ``n_in`` samples, as data for ``mi355_resample_poly``:
+    (up, down, table [K, up] float64 -- tap-major --, first, n_out).  resample_poly scales the taps by ``up``, prepends ``down - half % down`` zeros so that output
+    ``first = (half + zeros) // down`` is the one centred on input 0, appends zeros until the filter output is long enough, runs upfirdn and keeps
+    outputs ``first .. first + n_out``; output m of upfirdn only meets the taps of phase ``m * down % up``: ``table[k][p] = padded[p + k * up]``."""
+    up, down, taps = polyphase_design(int(orig_sample_rate), int(sample_rate))
+    half = (len(taps) - 1) // 2
+    n_out = -(-n_in * up // down)
+    lead = down - half % down
+    first = (half + lead) // down
+    tail = 0
+    while ((n_in - 1) * up + len(taps) + lead + tail - 1) // down + 1 < n_out + first:
+        tail += 1
+    padded = np.concatenate((np.zeros(lead), np.asarray(taps, dtype=np.float64) * up, np.zeros(tail)))
+    K = -(-len(padded) // up)
+    table = np.zeros(K * up, dtype=np.float64)
+    table[:len(padded)] = padded
+    return up, down, table.reshape(K, up), first, n_out
+
+
+_DEVICE_TABLES: dict = {}
+
+
+def resample_on_device(audio, orig_sample_rate: int, sample_rate: int, axis: int = -1):
+    """CUDA tensor in -> CUDA float32 tensor out through the HIP polyphase kernel (no host copy); same samples as ``resample_audio_array``."""
+    import torch
+
+    from . import ops
+
+    if not audio.is_cuda:
+        raise ValueError("resample_on_device expects a tensor on the GPU; use resample_audio_array for host arrays")
+    ops.require_gpu()
+    if orig_sample_rate == sample_rate:
+        return audio
+    x = audio.to(torch.float32).movedim(axis, -1)
+    lead_shape, n_in = x.shape[:-1], x.shape[-1]
+    if n_in == 0:
+        raise ValueError("cannot resample an empty signal")
+    up, down, table, first, n_out = polyphase_table(orig_sample_rate, sample_rate, n_in)
+    key = (up, down, table.shape[0], first, str(audio.device))
+    if key not in _DEVICE_TABLES:
+        _DEVICE_TABLES[key] = torch.from_numpy(table).to(audio.device)
+    rows = x.reshape(-1, n_in).contiguous()
+    out = torch.empty(rows.shape[0], n_out, device=audio.device, dtype=torch.float32)
+    for r0 in range(0, rows.shape[0], 65535):
+        ops.resample_poly(rows[r0:r0 + 65535], _DEVICE_TABLES[key], up, down, first, n_out, out[r0:r0 + 65535])
+    return out.reshape(*lead_shape, n_out).movedim(-1, axis)
+
+
 def resample_audio_array(audio: np.ndarray, orig_sample_rate: int, sample_rate: int, axis: int = -1) -> np.ndarray:
     """In-memory array through the polyphase FIR; float32 out, the input itself when the rates are equal."""
     if orig_sample_rate == sample_rate:
@@ -51,6 +104,8 @@ def resample_audio(audio, orig_sample_rate: int, sample_rate: int, axis: int = -
         import torch
     except ImportError:  # pragma: no cover
         torch = None
+    if torch is not None and isinstance(audio, torch.Tensor) and audio.is_cuda:
+        return resample_on_device(audio, orig_sample_rate, sample_rate, axis=axis)
     if torch is not None and isinstance(audio, torch.Tensor):
         out = resample_audio_array(audio.detach().cpu().numpy(), orig_sample_rate, sample_rate, axis=axis)
         return torch.from_numpy(np.ascontiguousarray(out)).to(audio.device)

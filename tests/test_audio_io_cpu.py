@@ -259,3 +259,26 @@ def test_compute_deltas_kaldi_matches_the_definition():
     for bad in (dict(win_length=2), dict(win_length=4), dict(mode="reflect")):
         with pytest.raises(ValueError):
             compute_deltas_kaldi(ramp, **bad)
+
+
+@pytest.mark.parametrize("orig,target,n", [(24000, 16000, 1000), (16000, 24000, 777), (44100, 16000, 5000), (22050, 24000, 3000), (48000, 16000, 501),
+                                           (8000, 16000, 64), (16000, 8000, 3), (24000, 16000, 1), (8000, 48000, 100)])
+def test_polyphase_table_restates_resample_poly(orig, target, n):
+    """``polyphase_table`` (the data ``mi355_resample_poly`` runs on) against ``scipy.signal.resample_poly(..., padtype="edge")`` -- the call the reference
+    makes (resample.py:40-47): the kernel's formula y[n] = sum_k table[k][p] x[clamp(q - k)], evaluated here with numpy in float64, gives the same
+    float32 samples, the same output length and start."""
+    from scipy import signal
+
+    from mlx_audio_amd.resample import polyphase_design, polyphase_table
+
+    up, down, table, first, n_out = polyphase_table(orig, target, n)
+    _, _, taps = polyphase_design(orig, target)
+    x = (np.random.default_rng(n).standard_normal(n) + 0.7).astype(np.float32)   # the offset makes the edge padding visible
+    want = signal.resample_poly(x, up, down, window=taps, padtype="edge").astype(np.float32)
+    assert n_out == len(want) and table.shape[1] == up and table.dtype == np.float64
+    K = table.shape[0]
+    t = (np.arange(n_out) + first) * down
+    idx = np.clip((t // up)[:, None] - np.arange(K)[None, :], 0, n - 1)
+    got = np.einsum("nk,nk->n", table[:, t % up].T, x[idx].astype(np.float64)).astype(np.float32)
+    assert np.abs(got - want).max() <= 1.2e-7 * max(1.0, float(np.abs(want).max()))
+    assert ((255 * down) // up + K + 1) * 8 <= 64 * 1024      # the kernel's LDS window
