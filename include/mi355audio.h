@@ -288,8 +288,9 @@ int mi355_aa_activation(const mi355_aa_act_args* a, void* stream);
  *   y[r][n] = sum_k table[k][p] * x[r][clamp(q - k, 0, n_in - 1)],   t = (n + first) * down,  p = t % up,  q = t / up.
  * table [K, up] float64 on the device (tap-major) = the taps x up, shifted right by (down - half % down) zeros (half = (len(taps) - 1) / 2; resample_poly
  * centres its output this way), split by phase: table[k][p] = padded[p + k * up], zero where that runs past the end; first = (half + shift) / down =
- * the outputs resample_poly drops at the front; n_out = ceil(n_in * up / down).  Sums are float64 like scipy's.  The input window of 256 outputs,
- * (255 * down / up + K + 1) float64 samples, must fit 64 KB of LDS (any pair of the usual rates does; 384 kHz -> 8 kHz does not and is refused). */
+ * the outputs resample_poly drops at the front; n_out = ceil(n_in * up / down).  Sums are float64 like scipy's.  Two kernels: four same-phase outputs per
+ * thread with a float32 input window in LDS when that window fits 64 KB (every pair of the usual rates), else one output per thread with a float64
+ * window of (255 * down / up + K + 1) samples; a conversion that fits neither (384 kHz -> 8 kHz) is refused. */
 typedef struct {
   const float* x; int64_t x_bstride; int32_t n_in; int32_t rows;
   const double* table; int32_t up; int32_t down; int32_t K; int32_t first;

@@ -222,6 +222,42 @@ __global__ __launch_bounds__(256) void resample_poly_kernel(const mi355_resample
   a.y[(int64_t)row * a.y_bstride + n] = (float)acc;
 }
 
+// The same conversion with R = 4 outputs per thread that share a phase (n, n + up, n + 2 up, n + 3 up: their taps are the same table column and
+// their inputs lie `down` apart), which is what the one-output kernel above is bound by: it issues an 8-byte table read and an 8-byte LDS read per
+// float64 multiply-add (2.3 - 4.8 TFLOP/s measured, call 47).  Here a table value feeds four multiply-adds and the window sits in LDS as float32
+// (half the LDS bytes; the conversion is a second float64-rate instruction).  Thread u of the launch owns outputs (u / up) * 4 up + u % up + j up:
+// consecutive threads still write consecutive samples for each j.  A workgroup's 256 threads touch at most 256 / up + 2 groups of 4 up outputs.
+constexpr int RS_R = 4;
+
+__device__ __forceinline__ int64_t rs_base(int64_t u, int up) { return (u / up) * (RS_R * (int64_t)up) + u % up; }
+
+__global__ __launch_bounds__(256) void resample_poly4_kernel(const mi355_resample_args a) {
+  extern __shared__ float xf[];
+  const int row = blockIdx.y;
+  const int64_t u0 = (int64_t)blockIdx.x * 256;
+  const float* x = a.x + (int64_t)row * a.x_bstride;
+  const int64_t n_min = rs_base(u0, a.up), n_max = rs_base(u0 + 255, a.up) + (RS_R - 1) * (int64_t)a.up;
+  const int64_t q_lo = ((n_min + a.first) * a.down) / a.up - (a.K - 1);
+  const int len = (int)(((n_max + a.first) * a.down) / a.up - q_lo + 1);
+  for (int i = threadIdx.x; i < len; i += 256) xf[i] = x[min(max(q_lo + i, (int64_t)0), (int64_t)a.n_in - 1)];
+  __syncthreads();
+  const int64_t nb = rs_base(u0 + threadIdx.x, a.up);
+  if (nb >= a.n_out) return;
+  const int64_t t = (nb + a.first) * a.down;
+  const double* h = a.table + (int)(t % a.up);
+  const float* xp = xf + (int)(t / a.up - q_lo);   // output j, tap k reads xp[j * down - k]
+  double acc[RS_R] = {0.0, 0.0, 0.0, 0.0};
+  for (int k = 0; k < a.K; ++k) {
+    const double hk = h[(int64_t)k * a.up];
+#pragma unroll
+    for (int j = 0; j < RS_R; ++j) acc[j] += hk * (double)xp[j * a.down - k];
+  }
+  float* y = a.y + (int64_t)row * a.y_bstride;
+#pragma unroll
+  for (int j = 0; j < RS_R; ++j)
+    if (nb + j * (int64_t)a.up < a.n_out) y[nb + j * (int64_t)a.up] = (float)acc[j];
+}
+
 }  // namespace
 
 extern "C" int mi355_resample_poly(const mi355_resample_args* ap, void* stream) {
@@ -229,13 +265,22 @@ extern "C" int mi355_resample_poly(const mi355_resample_args* ap, void* stream) 
   const mi355_resample_args a = *ap;
   MI355_REQUIRE(a.rows > 0 && a.n_in > 0 && a.n_out > 0 && a.up > 0 && a.down > 0 && a.K > 0 && a.first >= 0, "resample_poly: bad shape");
   MI355_REQUIRE(a.rows <= 65535, "resample_poly: at most 65535 rows per call");
-  // inputs one workgroup reads: from (n0 + first) * down / up - (K - 1) to (n0 + 255 + first) * down / up
-  const int64_t span = (255 * (int64_t)a.down) / a.up + 2 + (a.K - 1);
-  MI355_REQUIRE(span * 8 <= 64 * 1024, "resample_poly: the input window of 256 outputs (%lld float64 samples) exceeds the 64 KB LDS budget",
-                (long long)span);
-  MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL(resample_poly_kernel, dim3((unsigned)((a.n_out + 255) / 256), (unsigned)a.rows), dim3(256), (size_t)span * 8, (hipStream_t)stream, a,
-                     (int)span);
+  hipStream_t st = (hipStream_t)stream;
+  // four-outputs-per-thread kernel: the 256 threads of a workgroup span at most (255 / up + 1) * 4 up + up - 1 + 3 up outputs (see rs_base)
+  const int64_t dn = (255 / (int64_t)a.up + 1) * RS_R * a.up + a.up - 1 + (RS_R - 1) * (int64_t)a.up;
+  const int64_t span4 = (dn * a.down) / a.up + 2 + (a.K - 1);
+  if (span4 * 4 <= 64 * 1024) {
+    MI355_CLEAR_ERROR();
+    const int64_t threads = ((a.n_out + RS_R * (int64_t)a.up - 1) / (RS_R * (int64_t)a.up)) * a.up;
+    hipLaunchKernelGGL(resample_poly4_kernel, dim3((unsigned)((threads + 255) / 256), (unsigned)a.rows), dim3(256), (size_t)span4 * 4, st, a);
+  } else {
+    // one output per thread: inputs from (n0 + first) * down / up - (K - 1) to (n0 + 255 + first) * down / up
+    const int64_t span = (255 * (int64_t)a.down) / a.up + 2 + (a.K - 1);
+    MI355_REQUIRE(span * 8 <= 64 * 1024, "resample_poly: the input window of 256 outputs (%lld float64 samples) exceeds the 64 KB LDS budget",
+                  (long long)span);
+    MI355_CLEAR_ERROR();
+    hipLaunchKernelGGL(resample_poly_kernel, dim3((unsigned)((a.n_out + 255) / 256), (unsigned)a.rows), dim3(256), (size_t)span * 8, st, a, (int)span);
+  }
   MI355_LAUNCH_CHECK("resample_poly");
   return MI355_OK;
 }

@@ -17,7 +17,8 @@ def _host(x, orig, target, axis=-1):
 
 
 @pytest.mark.parametrize("orig,target,n", [(24000, 16000, 24000), (16000, 24000, 7777), (44100, 16000, 44100), (22050, 24000, 30001), (48000, 16000, 501),
-                                           (8000, 16000, 64), (16000, 8000, 3), (24000, 16000, 1), (48000, 8000, 100000), (8000, 48000, 999)])
+                                           (8000, 16000, 64), (16000, 8000, 3), (24000, 16000, 1), (48000, 8000, 100000), (8000, 48000, 999), (96000, 8000, 50000),
+                                           (128000, 8000, 64000)])   # the last one takes the one-output-per-thread kernel (its 4-output window exceeds LDS)
 def test_resample_kernel_equals_the_host_polyphase_filter(orig, target, n):
     from mlx_audio_amd.resample import resample_on_device
 
