@@ -14,6 +14,7 @@ per utterance (the reference's non-streaming path inherits state from the previo
 """
 from __future__ import annotations
 
+import os
 import re
 import time
 import warnings
@@ -178,9 +179,26 @@ class Model:
         return frame, mask
 
     def _tokenize_audio(self, audio, add_eos: bool = True):
-        raise NotImplementedError("audio context needs the Mimi encoder (codec/models/mimi encode side), which this build does not ship")
+        """``sesame.py:527-559``: codes (K, T) of the audio tokenizer's ``encode`` -> (tokens int32 [T (+1), 33], mask) with the codes in the first K
+        columns and, with ``add_eos``, one all-zero frame appended.  The Mimi *encoder* is not part of this build: the method works with any object that
+        offers ``encode(audio[1, 1, samples]) -> [1, K, T]`` as ``_audio_tokenizer`` (the reference's contract) and says so otherwise."""
+        enc = getattr(self._audio_tokenizer, "encode", None)
+        if enc is None:
+            raise NotImplementedError("audio context needs the Mimi encoder (codec/models/mimi encode side), which this build does not ship")
+        codes = torch.as_tensor(enc(audio[None, None, ...]))[0].to(torch.int32).cpu()
+        K = self._frame_size - 1
+        if codes.shape[0] != K:
+            raise ValueError(f"Audio tokenizer returned {codes.shape[0]} codebooks, expected {K}")
+        if add_eos:
+            codes = torch.cat([codes, torch.zeros((K, 1), dtype=codes.dtype)], dim=1)
+        frame = torch.zeros((codes.shape[1], self._frame_size), dtype=torch.int32)
+        mask = torch.zeros((codes.shape[1], self._frame_size), dtype=torch.bool)
+        frame[:, :-1] = codes.t()
+        mask[:, :-1] = True
+        return frame, mask
 
     def _tokenize_segment(self, segment: Segment, add_eos: bool = True):
+        """``sesame.py:561-575``; a segment without audio (an extension: the reference's segments always carry audio) contributes its text frames only."""
         t, tm = self._tokenize_text_segment(segment.text, segment.speaker)
         if segment.audio is None:
             return t, tm
@@ -226,9 +244,18 @@ class Model:
         if sampler is not None:
             raise NotImplementedError("custom sampler callables run on the host; pass temperature= / top_k= instead")
         context = list(context or [])
-        if ref_audio is not None or voice is not None or any(s.audio is not None for s in context):
+        has_encoder = getattr(self._audio_tokenizer, "encode", None) is not None
+        if ref_audio is not None and not has_encoder or any(s.audio is not None for s in context) and not has_encoder:
             raise NotImplementedError("voice prompts / reference audio need the Mimi encoder, which this build does not ship")
-        if not context and self._use_default_voice_prompt:
+        if ref_audio is not None and isinstance(ref_audio, (str, os.PathLike)):
+            from ....utils import load_audio
+
+            ref_audio = load_audio(ref_audio, sample_rate=self.sample_rate)
+        if not context and ref_audio is not None and ref_text is not None:   # sesame.py:753-755: the reference clip is the first segment
+            context = [Segment(speaker=speaker, text=ref_text, audio=ref_audio)]
+        elif ref_audio is None and not context and self._use_default_voice_prompt:
+            if voice is not None:
+                raise NotImplementedError("named voice prompts are downloaded from the hub and need the Mimi encoder; pass context= / ref_audio=")
             warnings.warn("CSM: the default voice prompt needs the hub and the Mimi encoder; generating without a voice prompt", stacklevel=2)
         if voice_match is None:
             voice_match = self._default_voice_match
@@ -243,14 +270,18 @@ class Model:
             gen.manual_seed(int(kwargs["seed"]) if kwargs.get("seed") is not None else int(torch.seed() % (2 ** 31)))
         for prompt in text:
             t0 = time.perf_counter()
+            current = list(context)
+            if voice_match and current:   # sesame.py:776-783: the text continues the FIRST segment's text, its audio is left open (no EOS frame)
+                current = [Segment(speaker=speaker, text=(context[0].text + " " + prompt).strip(), audio=context[0].audio)]
             toks, masks = [], []
-            for seg in context:
+            for seg in current:
                 st, sm = self._tokenize_segment(seg, add_eos=not voice_match)
                 toks.append(st)
                 masks.append(sm)
-            gt, gm = self._tokenize_text_segment(prompt, speaker)
-            toks.append(gt)
-            masks.append(gm)
+            if not voice_match or not current:
+                gt, gm = self._tokenize_text_segment(prompt, speaker)
+                toks.append(gt)
+                masks.append(gm)
             prompt_tokens, prompt_mask = torch.cat(toks, 0), torch.cat(masks, 0)
             max_seq_len = 2048 - max_audio_frames
             if prompt_tokens.shape[0] >= max_seq_len:

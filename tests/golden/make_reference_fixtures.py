@@ -498,12 +498,11 @@ def run_qwen3_codec(seed_w, seed_codes, n_frames):
                 chunked=chunked.astype(np.float32))
 
 
-def run_csm(seed_w, seed_in, n_frames):
-    """The reference's ``SesameModel`` (sesame.py:301-425: two ``LlamaModel`` stacks of lm/models/llama.py with the ``Llama3ScaledRoPE`` attention of
-    sesame/attention.py, summed audio + text embeddings, ``codebook0_head``, depth decoder with ``audio_head``) -- ``generate_frame`` called
-    ``n_frames`` times on a prompt, with a sampler that returns forced codes and records the logits it was handed."""
-    from mlx_audio_amd.tts.models.sesame import engine as E
-
+def import_sesame():
+    """The reference's ``tts/models/sesame/sesame.py`` under its real name."""
+    name = "mlx_audio.tts.models.sesame.sesame"
+    if name in sys.modules:
+        return sys.modules[name]
     import_lm_and_mimi()
     _load("mlx_audio.lm.models.llama", f"{REF}/lm/models/llama.py")
     _pkg("mlx_audio.tts.models.sesame", f"{REF}/tts/models/sesame")
@@ -533,6 +532,83 @@ def run_csm(seed_w, seed_in, n_frames):
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+    return rs
+
+
+def run_csm_generate():
+    """The reference's CSM ``Model.generate`` (sesame.py:730-866) with its prompt-frame builders (``_tokenize_text_segment`` / ``_tokenize_audio`` /
+    ``_tokenize_segment``, :502-575) on scripted parts: the text tokenizer is one id per character, ``Mimi.encode`` is ``pt_layouts.csm_fake_codes``,
+    ``generate_frame`` replays scripted frames and records what it is handed, ``generate_result`` records the frames it is given.  Cases:
+    ``pt_layouts.CSM_GENERATE_CASES`` (speaker prefix with / without space, prompt splitting, context with and without voice matching, reference audio,
+    streaming chunks, the frame budget, a list of prompts)."""
+    import json
+
+    import pt_layouts as PT
+
+    rs = import_sesame()
+    K = PT.CSM_CODEBOOKS
+    tok = PT.CsmCharTokenizer()
+    saved_load = rs.load_audio
+    rs.load_audio = lambda a, sample_rate=None, **k: a
+    out = []
+    try:
+        for case in PT.CSM_GENERATE_CASES:
+            prompts = []
+
+            class Engine:
+                args = types.SimpleNamespace(audio_num_codebooks=K)
+
+                def reset_caches(self):
+                    prompts.append(dict(calls=[]))
+
+                def generate_frame(self, tokens, mask, pos, sampler):
+                    i, calls = len(prompts) - 1, prompts[-1]["calls"]
+                    j = len(calls)
+                    calls.append(dict(tokens=np.asarray(tokens)[0].astype(int).tolist(), mask=np.asarray(mask)[0].astype(int).tolist(),
+                                      pos=np.asarray(pos)[0].astype(int).tolist()))
+                    frame = PT.csm_frame(i, j) if j < case["frames"][i] else [0] * K
+                    return mx.array(np.array([frame], dtype=np.int32))
+
+            class Host:
+                _tokenize_text_segment = rs.Model._tokenize_text_segment
+                _tokenize_audio = rs.Model._tokenize_audio
+                _tokenize_segment = rs.Model._tokenize_segment
+                generate = rs.Model.generate
+                sample_rate = 24000
+                tokenizer_repo = None
+                _frame_size = K + 1
+                _speaker_prefix_space = case["cfg"]["speaker_prefix_space"]
+                _default_voice_match = case["cfg"]["voice_match"]
+                _use_default_voice_prompt = False
+                model = Engine()
+                _text_tokenizer = types.SimpleNamespace(encode=lambda text, return_tensors=None: mx.array(np.array([tok.ids(text)], dtype=np.int32)))
+                _audio_tokenizer = types.SimpleNamespace(encode=lambda x: mx.array(PT.csm_fake_codes(np.asarray(x)[0, 0]))[None])
+                _streaming_decoder = types.SimpleNamespace(reset=lambda: None)
+
+                def generate_result(self, samples, start_time, stream=False):
+                    return dict(n=len(samples), stream=bool(stream), frames=[np.asarray(f)[0].astype(int).tolist() for f in samples])
+
+            kw = dict(case["kw"])
+            if "context" in kw:
+                kw["context"] = [rs.Segment(speaker=sp, text=t, audio=mx.array(PT.csm_audio(*au))) for sp, t, au in kw["context"]]
+            if "ref_audio" in kw:
+                kw["ref_audio"] = mx.array(PT.csm_audio(*kw["ref_audio"]))
+            results = list(Host().generate(case["text"], sampler=object(), **kw))
+            out.append(dict(name=case["name"], prompts=prompts, results=results))
+    finally:
+        rs.load_audio = saved_load
+    with open(os.path.join(HERE, "ref_csm_generate.json"), "w") as f:
+        json.dump(out, f)
+    return [(c["name"], [len(p["calls"]) for p in c["prompts"]], [(r["n"], r["stream"]) for r in c["results"]]) for c in out]
+
+
+def run_csm(seed_w, seed_in, n_frames):
+    """The reference's ``SesameModel`` (sesame.py:301-425: two ``LlamaModel`` stacks of lm/models/llama.py with the ``Llama3ScaledRoPE`` attention of
+    sesame/attention.py, summed audio + text embeddings, ``codebook0_head``, depth decoder with ``audio_head``) -- ``generate_frame`` called
+    ``n_frames`` times on a prompt, with a sampler that returns forced codes and records the logits it was handed."""
+    from mlx_audio_amd.tts.models.sesame import engine as E
+
+    rs = import_sesame()
     cfg = E.tiny_csm()
     w = E.make_csm_weights(cfg, seed=seed_w)
 
@@ -695,13 +771,14 @@ def run_vocos(seed_w, seed_audio):
     return dict(seed_w=seed_w, seed_audio=seed_audio, features=feats.astype(np.float32), audio=out.astype(np.float32)), cfg
 
 
-def run_sampler(seed):
-    """The reference's sampling chain: ``Model._sample_token_batch`` of Qwen3-TTS (suppress ids, per-sequence repetition penalty, temperature, top-k,
-    top-p / min-p through ``lm/sample_utils.py``; qwen3_tts.py:862-925) with the final ``categorical_sampling`` replaced by a probe that records the
-    filtered logits it was handed -- i.e. everything up to the random draw, for five parameter sets."""
+def import_qwen3_model():
+    """The reference's ``tts/models/qwen3_tts/qwen3_tts.py`` (``Model``) under its real name."""
+    name = "mlx_audio.tts.models.qwen3_tts.qwen3_tts"
+    if name in sys.modules:
+        return sys.modules[name]
     import_lm_and_mimi()
     _load("mlx_audio.lm.sample_utils", f"{REF}/lm/sample_utils.py")
-    cont = _load("mlx_audio.tts.continuous", f"{REF}/tts/continuous.py")
+    _load("mlx_audio.tts.continuous", f"{REF}/tts/continuous.py")
     if "mlx_audio.tts.models.qwen3_tts.config" not in sys.modules:
         _pkg("mlx_audio.tts.models.qwen3_tts", f"{REF}/tts/models/qwen3_tts")
         _load("mlx_audio.tts.models.qwen3_tts.config", f"{REF}/tts/models/qwen3_tts/config.py")
@@ -710,7 +787,58 @@ def run_sampler(seed):
             _load(f"mlx_audio.tts.models.qwen3_tts.{m}", f"{REF}/tts/models/qwen3_tts/{m}.py")
     u = sys.modules["mlx_audio.utils"]
     u.load_audio = lambda *a, **k: None
-    q = _load("mlx_audio.tts.models.qwen3_tts.qwen3_tts", f"{REF}/tts/models/qwen3_tts/qwen3_tts.py")
+    return _load(name, f"{REF}/tts/models/qwen3_tts/qwen3_tts.py")
+
+
+def run_qwen3_inputs(seed):
+    """The reference's prompt assembly of Qwen3-TTS -- ``Model._prepare_generation_inputs`` (qwen3_tts.py:326-484: chat template slices, tts pad / bos /
+    eos embeddings, the codec prefix with / without a language id, dialect override, speaker embedding, instruct prefix, first text token, trailing text)
+    and ``_prepare_batch_inputs`` (:486-604: left-padded prefill, tts_pad-padded trailing text, mask and padding metadata) -- with the talker's embedding
+    tables replaced by seeded lookup tables and the tokenizer by ``pt_layouts.QwenCharTokenizer``; cases in ``pt_layouts.QWEN3_INPUT_CASES``."""
+    import pt_layouts as PT
+
+    q = import_qwen3_model()
+    g = np.random.default_rng(seed)
+    H = 8
+    text_table = g.standard_normal((PT.QWEN3_TEXT_VOCAB, H)).astype(np.float32)
+    codec_table = g.standard_normal((PT.QWEN3_CODEC_VOCAB, H)).astype(np.float32)
+
+    class Talker:
+        def get_text_embeddings(self):
+            return lambda ids: mx.array(text_table)[ids]
+
+        def text_projection(self, x):
+            return x
+
+        def get_input_embeddings(self):
+            return lambda ids: mx.array(codec_table)[ids]
+
+    class Host:
+        _prepare_generation_inputs = q.Model._prepare_generation_inputs
+        _prepare_batch_inputs = q.Model._prepare_batch_inputs
+        tokenizer = PT.QwenCharTokenizer()
+        config = PT.qwen3_input_config()
+        talker = Talker()
+        speaker_encoder = None
+
+    host = Host()
+    out = dict(seed=seed, text_table=text_table, codec_table=codec_table)
+    for i, c in enumerate(PT.QWEN3_INPUT_CASES):
+        e, tr, pad = host._prepare_generation_inputs(c["text"], language=c["language"], speaker=c["speaker"], instruct=c["instruct"])
+        out[f"embeds{i}"], out[f"trailing{i}"], out[f"pad{i}"] = (np.asarray(v).astype(np.float32) for v in (e, tr, pad))
+    b = PT.QWEN3_BATCH_CASE
+    bi = host._prepare_batch_inputs(b["texts"], language=b["language"], speakers=b["speakers"], instructs=b["instructs"], return_metadata=True)
+    out.update(batch_embeds=np.asarray(bi.input_embeds).astype(np.float32), batch_trailing=np.asarray(bi.trailing_text_hidden).astype(np.float32),
+               batch_pad=np.asarray(bi.tts_pad_embed).astype(np.float32), batch_mask=np.asarray(bi.attention_mask).astype(np.float32),
+               left_padding=np.array(bi.left_padding), prefill_lens=np.array(bi.prefill_lens), trailing_lens=np.array(bi.trailing_lens))
+    return out
+
+
+def run_sampler(seed):
+    """The reference's sampling chain: ``Model._sample_token_batch`` of Qwen3-TTS (suppress ids, per-sequence repetition penalty, temperature, top-k,
+    top-p / min-p through ``lm/sample_utils.py``; qwen3_tts.py:862-925) with the final ``categorical_sampling`` replaced by a probe that records the
+    filtered logits it was handed -- i.e. everything up to the random draw, for five parameter sets."""
+    q = import_qwen3_model()
     g = np.random.default_rng(seed)
     B, V = 3, 257
     logits = (g.standard_normal((B, 1, V)) * 3).astype(np.float32)
@@ -1061,6 +1189,10 @@ def main():
     bfx = run_bigvgan(seed_w=6, seed_mel=2, n_frames=50)
     np.savez_compressed(os.path.join(HERE, "ref_bigvgan_tiny.npz"), config=json.dumps(BIGVGAN_TINY), **bfx)
     print("bigvgan:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in bfx.items()}, "peak", float(np.abs(bfx["audio1"]).max()))
+    print("csm generate:", run_csm_generate())
+    qfx = run_qwen3_inputs(seed=17)
+    np.savez_compressed(os.path.join(HERE, "ref_qwen3_inputs.npz"), **qfx)
+    print("qwen3 inputs:", {a: v.shape for a, v in qfx.items() if hasattr(v, "shape") and a.startswith(("embeds", "batch"))})
     wfx = run_whisper(seed_w=3, seed_mel=2, sample_len=24)
     print("whisper generate:", run_whisper_generate())
     np.savez_compressed(os.path.join(HERE, "ref_whisper_tiny.npz"), **wfx)

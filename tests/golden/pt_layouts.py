@@ -126,3 +126,85 @@ WHISPER_GENERATE_CASES = [
     dict(name="no_timestamps", frames=3500, kw=dict(temperature=0.0, return_timestamps=False),
          script=[dict(tokens=[200, 201, 202]), dict(tokens=[300])]),
 ]
+
+
+# ---- Qwen3-TTS prompt assembly (make_reference_fixtures.run_qwen3_inputs and tests/test_tts_prompt_assembly_cpu.py share these)
+QWEN3_TEXT_VOCAB, QWEN3_CODEC_VOCAB = 400, 120
+
+
+class QwenCharTokenizer:
+    """One id per character: the assembly only slices the id list ([:3] role, [3:4] first text token, [4:-5] trailing), so any tokenizer exercises it."""
+
+    def encode(self, text):
+        return [7 + (ord(c) * 31) % (QWEN3_TEXT_VOCAB - 10) for c in text]
+
+
+def qwen3_input_config():
+    from types import SimpleNamespace
+
+    talker = SimpleNamespace(spk_id={"vivian": 101, "dylan": 102, "eric": 103}, spk_is_dialect={"vivian": False, "dylan": "beijing_dialect", "eric": "martian"},
+                             codec_language_id={"english": 50, "chinese": 55, "beijing_dialect": 74}, codec_nothink_id=40, codec_think_id=41,
+                             codec_think_bos_id=42, codec_think_eos_id=43, codec_pad_id=44, codec_bos_id=45, codec_eos_token_id=46)
+    return SimpleNamespace(talker_config=talker, tts_bos_token_id=391, tts_eos_token_id=392, tts_pad_token_id=393)
+
+
+QWEN3_INPUT_CASES = [
+    dict(text="Hello world.", language="auto", speaker=None, instruct=None),
+    dict(text="Hello.", language="English", speaker="Vivian", instruct=None),
+    dict(text="Ni hao ma", language="auto", speaker="dylan", instruct=None),                       # dialect override of the language id
+    dict(text="Ni hao", language="chinese", speaker="Dylan", instruct="Speak slowly and warmly"),
+    dict(text="Hi there", language="klingon", speaker=None, instruct=None),                       # unknown language: no-think prefix
+    dict(text="Hi", language="english", speaker="nobody", instruct="Whisper"),                    # unknown speaker: no speaker slot
+    dict(text="Guten Tag", language="english", speaker="eric", instruct=None),                    # dialect name without a language id: ignored
+    dict(text="Bonjour", language="auto", speaker="vivian", instruct=None),                       # spk_is_dialect False
+]
+QWEN3_BATCH_CASE = dict(texts=["Hello world, this is the long one.", "Hi", "Ni hao ma"], language="auto", speakers=["vivian", None, "dylan"],
+                        instructs=[None, "Be brief", None])
+
+
+# ---- CSM prompt frames + generate bookkeeping (make_reference_fixtures.run_csm_generate and tests/test_tts_prompt_assembly_cpu.py)
+CSM_CODEBOOKS = 4
+
+
+class CsmCharTokenizer:
+    def ids(self, text):
+        return [3 + (ord(c) * 17) % 200 for c in text]
+
+
+def csm_fake_codes(audio_1d):
+    """Stand-in for ``Mimi.encode``: (K, T) codes that depend on the samples, T = len // 5."""
+    import numpy as _np
+
+    a = _np.asarray(audio_1d, dtype=_np.float64).reshape(-1)
+    T = len(a) // 5
+    base = _np.floor(_np.abs(a[:T * 5].reshape(T, 5)).sum(1) * 100).astype(_np.int64)
+    return _np.stack([(base + 7 * k) % 50 + 1 for k in range(CSM_CODEBOOKS)], 0).astype(_np.int32)
+
+
+def csm_audio(n, seed):
+    import numpy as _np
+
+    return _np.random.default_rng(seed).standard_normal(n).astype(_np.float32)
+
+
+# "frames": how many non-EOS frames the scripted model emits per prompt (then an all-zero frame unless the frame budget ends the loop first)
+CSM_GENERATE_CASES = [
+    dict(name="plain", text="Hello there.", kw=dict(speaker=0), cfg=dict(speaker_prefix_space=False, voice_match=True), frames=[5]),
+    dict(name="prefix_space_two_prompts", text="  First line.\n\nSecond line.", kw=dict(speaker=3), cfg=dict(speaker_prefix_space=True, voice_match=True),
+         frames=[4, 2]),
+    dict(name="context_voice_match", text="And then more.", kw=dict(speaker=1, context=[(1, "I said this", (23, 1)), (0, "ignored second", (11, 2))]),
+         cfg=dict(speaker_prefix_space=False, voice_match=True), frames=[3]),
+    dict(name="context_no_voice_match", text="A reply.", kw=dict(speaker=1, context=[(1, "I said this", (23, 1)), (0, "You said that", (11, 2))], voice_match=False),
+         cfg=dict(speaker_prefix_space=False, voice_match=True), frames=[3]),
+    dict(name="ref_audio", text="Clone me.", kw=dict(speaker=2, ref_audio=(31, 5), ref_text="Reference words"), cfg=dict(speaker_prefix_space=True, voice_match=False),
+         frames=[2]),
+    dict(name="stream", text="Streaming output.", kw=dict(speaker=0, stream=True, streaming_interval=0.5), cfg=dict(speaker_prefix_space=False, voice_match=True),
+         frames=[15]),
+    dict(name="budget", text="Cut short.", kw=dict(speaker=0, max_audio_length_ms=400), cfg=dict(speaker_prefix_space=False, voice_match=True), frames=[50]),
+    dict(name="list_of_prompts_no_split", text=["One\nstill one", "Two"], kw=dict(speaker=0), cfg=dict(speaker_prefix_space=False, voice_match=True), frames=[1, 0]),
+]
+
+
+def csm_frame(i, j):
+    """Scripted frame j (non-zero) of prompt i."""
+    return [1 + (5 * i + 3 * j + k) % 40 for k in range(CSM_CODEBOOKS)]
