@@ -276,4 +276,9 @@ def test_csm_load_model_and_generate(csm_ckpt):
     with pytest.raises(ValueError):
         list(model.generate("x" * 50, max_audio_length_ms=80 * 2040))
     with pytest.raises(NotImplementedError):
+        list(model.generate(text, ref_audio=torch.zeros(100), ref_text="x"))
+    # this checkpoint sets use_default_voice_prompt=False: like the reference (sesame.py:756) a voice name is then not looked at
+    assert len(list(model.generate(text, voice="conversational_a", temperature=0.0, max_audio_length_ms=frames * 80))) == 1
+    model._use_default_voice_prompt = True
+    with pytest.raises(NotImplementedError):
         list(model.generate(text, voice="conversational_a"))
