@@ -97,6 +97,17 @@ class Qwen3TalkerRef:
             e = e + self.w[f"code_predictor.model.codec_embedding.{i - 1}.weight"][codes[:, i]]
         return e
 
+    def next_input(self, trailing: Tensor, trailing_idx: Tensor, tts_pad: Tensor, codes: Tensor, pad_when_index_clamped: bool) -> Tensor:
+        """``_next_batch_input_embeds`` (qwen3_tts.py:993-1015): the next position's input [B, 1, H] = trailing text at ``trailing_idx`` (or ``tts_pad`` once
+        the text is exhausted) + the summed embeddings of the frame's codes.  The batched loop pads from the LAST trailing position on
+        (``pad_when_index_clamped``), the single-utterance loop (:1388-1394) after it."""
+        B, Tt = trailing.shape[0], trailing.shape[1]
+        clamped = torch.clamp(trailing_idx, max=Tt - 1)
+        text = trailing[torch.arange(B), clamped]
+        exhausted = (clamped >= Tt - 1) if pad_when_index_clamped else (trailing_idx >= Tt)
+        text = torch.where(exhausted[:, None], tts_pad.reshape(1, -1).expand_as(text), text)
+        return (text + self.codec_embeds(codes))[:, None, :]
+
     def generate(self, prefill: Tensor, trailing: Tensor, tts_pad: Tensor, max_frames: int, *, temperature=0.9, top_k=50, top_p=1.0,
                  repetition_penalty=1.05, gumbel0=None, gumbel_cp=None, forced_codes=None, record=False, pad_when_index_clamped=True):
         """prefill [B, L, H] embeddings; trailing [B, Tt, H] text embeddings consumed one per frame, then ``tts_pad`` [1, 1, H].
@@ -128,13 +139,7 @@ class Qwen3TalkerRef:
             codes = self.predict_codes(tok, last, temperature=temperature, top_k=top_k, top_p=top_p,
                                        gumbel=None if gumbel_cp is None else gumbel_cp[f],
                                        forced=None if forced_codes is None else forced_codes[:, f], trace=tr)
-            Tt = trailing.shape[1]
-            clamped = torch.clamp(trailing_idx, max=Tt - 1)
-            text = trailing[torch.arange(B), clamped]
-            # qwen3_tts.py:1006-1011: the batched loop pads from the LAST trailing position on; the single-utterance loop (:1388-1394) after it
-            exhausted = (clamped >= Tt - 1) if pad_when_index_clamped else (trailing_idx >= Tt)
-            text = torch.where(exhausted[:, None], tts_pad.reshape(1, -1).expand_as(text), text)
-            x = (text + self.codec_embeds(codes))[:, None, :]
+            x = self.next_input(trailing, trailing_idx, tts_pad, codes, pad_when_index_clamped)
             trailing_idx = trailing_idx + (~finished).long()
             for b in range(B):
                 if not bool(finished[b]):

@@ -409,18 +409,20 @@ def run_mimi(seed_w, seed_codes, n_frames):
     return dict(seed_w=seed_w, seed_codes=seed_codes, n_frames=n_frames, pcm=pcm.astype(np.float32), pcm_steps=pcm_steps.astype(np.float32))
 
 
-def run_qwen3_talker(seed_w, seed_in):
-    """The reference's ``Qwen3TTSTalkerForConditionalGeneration`` (talker stack with MRoPE position ids, q / k norms, GQA, KV cache, ``codec_head``;
-    talker.py:229-500, 767-822) and ``Qwen3TTSTalkerCodePredictor`` (talker.py:503-764) stepped exactly like ``_predict_code_tokens``
-    (qwen3_tts.py:941-983) with forced codes, on a tiny synthetic checkpoint: prefill of 11 positions, then two single-position steps."""
+def ref_qwen3_talker(seed_w):
+    """The reference's ``Qwen3TTSTalkerForConditionalGeneration`` on the tiny synthetic checkpoint of this package's generator: (model, cfg, reference cfg)."""
     from dataclasses import asdict
 
     from mlx_audio_amd.tts.models.qwen3_tts import talker as T
 
     import_lm_and_mimi()
-    _pkg("mlx_audio.tts.models.qwen3_tts", f"{REF}/tts/models/qwen3_tts")
-    rc = _load("mlx_audio.tts.models.qwen3_tts.config", f"{REF}/tts/models/qwen3_tts/config.py")
-    rt = _load("mlx_audio.tts.models.qwen3_tts.talker", f"{REF}/tts/models/qwen3_tts/talker.py")
+    if "mlx_audio.tts.models.qwen3_tts.config" not in sys.modules:
+        _pkg("mlx_audio.tts.models.qwen3_tts", f"{REF}/tts/models/qwen3_tts")
+        _load("mlx_audio.tts.models.qwen3_tts.config", f"{REF}/tts/models/qwen3_tts/config.py")
+    rc = sys.modules["mlx_audio.tts.models.qwen3_tts.config"]
+    if "mlx_audio.tts.models.qwen3_tts.talker" not in sys.modules:
+        _load("mlx_audio.tts.models.qwen3_tts.talker", f"{REF}/tts/models/qwen3_tts/talker.py")
+    rt = sys.modules["mlx_audio.tts.models.qwen3_tts.talker"]
     cfg = T.tiny_talker_config()
     w = T.make_talker_weights(cfg, seed=seed_w)
     d = asdict(cfg)
@@ -434,6 +436,95 @@ def run_qwen3_talker(seed_w, seed_in):
     missing, unexpected, mism = model._load_report
     assert not missing and not unexpected and not mism, (missing[:8], unexpected[:8], mism[:4])
     model.eval()
+    return model, cfg, rcfg
+
+
+def run_qwen3_generate_loop(seed_w):
+    """The reference's single-utterance ``Model.generate`` loop (qwen3_tts.py:1268-1420: prefill, suppressed + repetition-penalised arg-max of the first
+    code, code predictor, next input = trailing text or tts_pad + the sum of the 16 code embeddings, EOS test before the frame is kept) on the tiny
+    reference talker, greedy, with a character tokenizer and the speech tokenizer replaced by a recorder -- and ``_next_batch_input_embeds``
+    (:993-1015), the batched loop's trailing-text rule, in both of its modes.  Two runs: a frame budget of 7, then the same text with the EOS id set to
+    the first code the budget run chose at frame 4 (so the EOS branch is taken there)."""
+    import pt_layouts as PT
+
+    q = import_qwen3_model()
+    model, cfg, rcfg = ref_qwen3_talker(seed_w)
+    tok = PT.QwenCharTokenizer(vocab=cfg.text_vocab_size)
+    seen = {}
+    for name, value in PT.QWEN3_LOOP_CODEC_IDS.items():   # the special codec ids of the real checkpoint lie beyond the tiny vocabulary
+        setattr(rcfg, name, value)
+
+    class Host:
+        generate = q.Model.generate
+        _prepare_generation_inputs = q.Model._prepare_generation_inputs
+        _sample_token = q.Model._sample_token
+        _next_batch_input_embeds = q.Model._next_batch_input_embeds
+        _codec_embeds_for_tokens = q.Model._codec_embeds_for_tokens
+        tokenizer = tok
+        talker = model
+        speaker_encoder = None
+        sample_rate = 24000
+        supported_speakers = []
+        config = types.SimpleNamespace(talker_config=rcfg, tts_model_type="base", tts_bos_token_id=cfg.text_vocab_size - 3,
+                                       tts_eos_token_id=cfg.text_vocab_size - 2, tts_pad_token_id=cfg.text_vocab_size - 1)
+        speech_tokenizer = types.SimpleNamespace(has_encoder=False, decode=lambda codes: (seen.__setitem__("codes", np.asarray(codes)[0].astype(np.int32)),
+                                                                                           (mx.zeros((1, codes.shape[1] * 8)), mx.array([codes.shape[1] * 8])))[1])
+
+    host = Host()
+    text = "Hi, how are you?"
+    logits_seen = []
+    orig_sample = Host._sample_token
+
+    def spy(self, logits, **kw):
+        if kw.get("suppress_tokens"):
+            logits_seen.append(np.asarray(logits)[0, -1].astype(np.float32))
+        return orig_sample(self, logits, **kw)
+
+    Host._sample_token = spy
+    ex, etr, epad = host._prepare_generation_inputs(text, language="auto", speaker=None)
+    res = list(host.generate(text, temperature=0.0, max_tokens=7, lang_code="auto"))
+    budget_codes, budget_logits = seen["codes"].copy(), np.stack(logits_seen)
+    assert len(res) == 1 and budget_codes.shape == (7, cfg.num_code_groups) and res[0].token_count == 7
+    eos_saved = rcfg.codec_eos_token_id
+    eos_new = int(budget_codes[4, 0])
+    assert eos_new not in budget_codes[:4, 0].tolist()
+    rcfg.codec_eos_token_id = eos_new
+    logits_seen.clear()
+    try:
+        res2 = list(host.generate(text, temperature=0.0, max_tokens=7, lang_code="auto"))
+    finally:
+        rcfg.codec_eos_token_id = eos_saved
+    eos_codes = seen["codes"].copy()
+    assert res2[0].token_count == 4 and np.array_equal(eos_codes, budget_codes[:4])
+    # a prompt whose trailing text (2 tokens + tts_eos) runs out after three frames: the tts_pad branch of the loop
+    Host.tokenizer = types.SimpleNamespace(encode=lambda t: [11 + (7 * i + len(t)) % 300 for i in range(11)])
+    logits_seen.clear()
+    sx, strl, spad = host._prepare_generation_inputs(text, language="auto", speaker=None)
+    res3 = list(host.generate(text, temperature=0.0, max_tokens=7, lang_code="auto"))
+    short_codes, short_logits = seen["codes"].copy(), np.stack(logits_seen)
+    assert np.asarray(strl).shape[1] == 3 and short_codes.shape[0] == 7 and len(res3) == 1
+    Host.tokenizer = tok
+    # the batched loop's trailing-text rule
+    g = np.random.default_rng(seed_w + 1)
+    H = cfg.hidden_size
+    tr = (g.standard_normal((3, 4, H)) * 0.5).astype(np.float32)
+    pad = (g.standard_normal((1, 1, H)) * 0.5).astype(np.float32)
+    idx = np.array([[1], [3], [6]], dtype=np.int32)
+    codes = [mx.array(budget_codes[f:f + 1, i:i + 1].repeat(3, 0)) for f, i in ((0, 0),)] + \
+            [mx.array(budget_codes[0:1, i:i + 1].repeat(3, 0)) for i in range(1, cfg.num_code_groups)]
+    nxt = {str(int(flag)): np.asarray(host._next_batch_input_embeds(mx.array(tr), mx.array(pad), mx.array(idx), codes, pad_when_index_clamped=flag))
+           .astype(np.float32) for flag in (False, True)}
+    return dict(seed_w=seed_w, text=text, prefill=np.asarray(ex).astype(np.float32), trailing=np.asarray(etr).astype(np.float32), pad=np.asarray(epad).astype(np.float32),
+                short_prefill=np.asarray(sx).astype(np.float32), short_trailing=np.asarray(strl).astype(np.float32), short_codes=short_codes,
+                short_logits=short_logits, budget_codes=budget_codes, budget_logits=budget_logits, eos_id=eos_new, eos_codes=eos_codes, eos_logits=np.stack(logits_seen),
+                next_trailing=tr, next_pad=pad, next_idx=idx, next_codes=budget_codes[0], next_embeds_unclamped=nxt["0"], next_embeds_clamped=nxt["1"])
+
+
+def run_qwen3_talker(seed_w, seed_in):
+    """The reference's ``Qwen3TTSTalkerForConditionalGeneration`` (talker stack with MRoPE position ids, q / k norms, GQA, KV cache, ``codec_head``;
+    talker.py:229-500, 767-822) and ``Qwen3TTSTalkerCodePredictor`` (talker.py:503-764) stepped exactly like ``_predict_code_tokens``
+    (qwen3_tts.py:941-983) with forced codes, on a tiny synthetic checkpoint: prefill of 11 positions, then two single-position steps."""
+    model, cfg, rcfg = ref_qwen3_talker(seed_w)
     g = np.random.default_rng(seed_in)
     B, L, H = 2, 11, cfg.hidden_size
     prefill = (g.standard_normal((B, L, H)) * 0.5).astype(np.float32)
@@ -1190,6 +1281,9 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_bigvgan_tiny.npz"), config=json.dumps(BIGVGAN_TINY), **bfx)
     print("bigvgan:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in bfx.items()}, "peak", float(np.abs(bfx["audio1"]).max()))
     print("csm generate:", run_csm_generate())
+    lfx = run_qwen3_generate_loop(seed_w=7)
+    np.savez_compressed(os.path.join(HERE, "ref_qwen3_generate_loop.npz"), **lfx)
+    print("qwen3 generate loop:", lfx["budget_codes"][:, 0].tolist(), "eos", lfx["eos_id"], lfx["eos_codes"].shape)
     qfx = run_qwen3_inputs(seed=17)
     np.savez_compressed(os.path.join(HERE, "ref_qwen3_inputs.npz"), **qfx)
     print("qwen3 inputs:", {a: v.shape for a, v in qfx.items() if hasattr(v, "shape") and a.startswith(("embeds", "batch"))})

@@ -135,8 +135,11 @@ QWEN3_TEXT_VOCAB, QWEN3_CODEC_VOCAB = 400, 120
 class QwenCharTokenizer:
     """One id per character: the assembly only slices the id list ([:3] role, [3:4] first text token, [4:-5] trailing), so any tokenizer exercises it."""
 
+    def __init__(self, vocab=None):
+        self.vocab = vocab or QWEN3_TEXT_VOCAB
+
     def encode(self, text):
-        return [7 + (ord(c) * 31) % (QWEN3_TEXT_VOCAB - 10) for c in text]
+        return [7 + (ord(c) * 31) % (self.vocab - 10) for c in text]
 
 
 def qwen3_input_config():
@@ -208,3 +211,6 @@ CSM_GENERATE_CASES = [
 def csm_frame(i, j):
     """Scripted frame j (non-zero) of prompt i."""
     return [1 + (5 * i + 3 * j + k) % 40 for k in range(CSM_CODEBOOKS)]
+
+# special codec ids inside the tiny talker's 1200-entry vocabulary (run_qwen3_generate_loop and its test)
+QWEN3_LOOP_CODEC_IDS = dict(codec_think_id=1154, codec_nothink_id=1155, codec_think_bos_id=1156, codec_think_eos_id=1157, codec_pad_id=1148, codec_bos_id=1149)

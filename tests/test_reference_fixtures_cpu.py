@@ -205,6 +205,51 @@ def test_qwen3_talker_oracle_reproduces_the_reference_modules():
     assert rel_max(tp.numpy(), fx["text_projection"]) < 2e-5
 
 
+def test_qwen3_generate_loop_oracle_reproduces_the_reference_loop():
+    """``ref_qwen3_generate_loop.npz`` = the reference's single-utterance ``Model.generate`` loop (qwen3_tts.py:1268-1420) run greedy on the tiny talker:
+    the oracle's ``generate`` -- the loop the HIP engine is held to on the GPU -- produces the same frames from the same inputs (first-code logits to
+    2e-5, every code equal), consumes the trailing text and switches to ``tts_pad`` at the same frame, and stops at the same frame when the EOS id
+    comes up, without keeping that frame.  ``next_input`` reproduces ``_next_batch_input_embeds`` (:993-1015) in both padding modes."""
+    import dataclasses
+    import sys
+
+    from mlx_audio_amd.tts.models.qwen3_tts import talker as T
+    from oracle.qwen3_talker_ref import Qwen3TalkerRef
+
+    sys.path.insert(0, GOLD)
+    import pt_layouts as PT
+
+    fx = np.load(os.path.join(GOLD, "ref_qwen3_generate_loop.npz"))
+    cfg = dataclasses.replace(T.tiny_talker_config(), **PT.QWEN3_LOOP_CODEC_IDS)
+    w = T.make_talker_weights(cfg, seed=int(fx["seed_w"]))
+    pad = torch.from_numpy(fx["pad"])
+
+    def run(c, prefill, trailing):
+        ref = Qwen3TalkerRef(w, c, param_dtype=torch.float32)
+        return ref, ref.generate(torch.from_numpy(prefill), torch.from_numpy(trailing), pad, 7, temperature=0.0, record=True, pad_when_index_clamped=False)
+
+    for tag, prefill, trailing in (("budget", fx["prefill"], fx["trailing"]), ("short", fx["short_prefill"], fx["short_trailing"])):
+        ref, out = run(cfg, prefill, trailing)
+        codes, want = out["codes"][0].numpy(), fx[f"{tag}_codes"]
+        assert int(out["finished_at"][0]) == -1 and codes.shape == want.shape == (7, cfg.num_code_groups)
+        for f in range(7):
+            lg = out["trace"][f][0][0].numpy()
+            assert rel_max(lg, fx[f"{tag}_logits"][f]) < 2e-5, (tag, f)
+            top2 = np.sort(fx[f"{tag}_logits"][f][:cfg.vocab_size - 1024])[-2:]
+            assert top2[1] - top2[0] > 1e-3, (tag, f, "the fixture sits on a knife edge: pick another seed")
+        assert np.array_equal(codes, want), (tag, codes.tolist(), want.tolist())
+    # EOS: the frame that draws the EOS id is not kept and nothing follows it
+    eos_cfg = dataclasses.replace(cfg, codec_eos_token_id=int(fx["eos_id"]))
+    ref, out = run(eos_cfg, fx["prefill"], fx["trailing"])
+    assert int(out["finished_at"][0]) == 4 and out["codes"].shape[1] == 5
+    assert np.array_equal(out["codes"][0, :4].numpy(), fx["eos_codes"]) and fx["eos_codes"].shape[0] == 4
+    # the batched loop's next input
+    codes = torch.from_numpy(fx["next_codes"]).long()[None].expand(3, -1)
+    for flag, key in ((False, "next_embeds_unclamped"), (True, "next_embeds_clamped")):
+        got = ref.next_input(torch.from_numpy(fx["next_trailing"]), torch.from_numpy(fx["next_idx"])[:, 0].long(), torch.from_numpy(fx["next_pad"]), codes, flag)
+        assert got.shape == fx[key].shape and rel_max(got.numpy(), fx[key]) < 1e-6, key
+
+
 def test_qwen3_codec_oracle_reproduces_the_reference_modules():
     """The reference's ``Qwen3TTSSpeechTokenizerDecoder`` (speech_tokenizer.py:786-955): codes -> waveform in one call and through ``chunked_decode``
     (chunks of 12 frames with 5 frames of left context); the only parameters of the reference's decoder that the synthetic checkpoint does not
