@@ -107,7 +107,7 @@ class KokoroBatchSession:
             pipeline = self.model._get_pipeline(lang)
             pack = pipeline.load_voice(item.voice or "af_heart")
             parts = re.split(item.extra.get("split_pattern", r"\n+"), item.text.strip()) if item.text else []
-            chunks = [ps for g in parts if g.strip() for ps in pipeline.chunk_phonemes(pipeline.g2p(g) or "")]
+            chunks = [ps for g in parts if g.strip() for _, ps, _ in pipeline.phoneme_chunks(g)]
             # symbols outside the vocabulary are dropped by phonemes_to_ids (kokoro.py:123-125); a chunk left empty is skipped
             chunks = [ps for ps in chunks if any(self.model.vocab.get(p) is not None for p in ps)]
             return _Seq(item.sequence_id, chunks, pack, float(item.speed) if item.speed else 1.0)

@@ -4,13 +4,16 @@ Mirrors the surface of the reference's ``KokoroPipeline`` (``tts/models/kokoro/p
 codes and aliases, ``load_voice`` (single names, ``a,b`` blends, ``.pt`` / ``.safetensors`` files), the 510-phoneme
 chunk limit, ``Result`` records that unpack as ``(graphemes, phonemes, audio)``.  The G2P itself is the external
 ``misaki`` package in the reference (pipeline.py:27-59); it is not part of the hot path,
-so it is a pluggable callable here: ``KokoroPipeline(..., g2p=fn)`` with ``fn(text) -> phoneme string`` (or
-``(phonemes, tokens)``).  When none is given ``misaki`` is imported lazily and, if it is missing, the same
+so it is a pluggable callable here: ``KokoroPipeline(..., g2p=fn)`` with ``fn(text) -> (phonemes, tokens)`` like ``misaki.en.G2P``
+(tokens: objects with ``text`` / ``phonemes`` / ``whitespace``; English then takes the reference's token-level chunking, ``en_tokenize`` +
+``waterfall_last``, pipeline.py:231-294, and gets word timestamps, ``join_timestamps``, :360-399) or ``fn(text) -> phoneme string`` (other
+languages: the reference's 400-character text chunks, :473-528; for English a plain string is cut by ``chunk_phonemes``, an extension).  When none is given ``misaki`` is imported lazily and, if it is missing, the same
 ``ImportError`` + pip hint the reference's loader produces is raised at first use.  Text already in phonemes can
 be synthesised without any G2P through ``generate_from_tokens``.
 """
 from __future__ import annotations
 
+import logging
 import os
 import re
 from dataclasses import dataclass
@@ -49,11 +52,7 @@ def _default_g2p(lang_code: str) -> Callable:
     except ImportError as e:  # same wording as the reference's loader (utils.py:305-312)
         raise ImportError(f"\nMissing dependency while loading kokoro: {e}\nPlease install it using: pip install {e.name}") from e
 
-    def run(text):
-        out = g(text)
-        return out[0] if isinstance(out, tuple) else out
-
-    return run
+    return g
 
 
 class KokoroPipeline:
@@ -135,8 +134,8 @@ class KokoroPipeline:
     # ------------------------------------------------------------------ chunking + synthesis
     @staticmethod
     def chunk_phonemes(ps: str, limit: int = MAX_PHONEMES) -> List[str]:
-        """Splits a phoneme string into pieces of at most ``limit`` symbols, preferring the latest sentence, then
-        clause, then word boundary before the limit (the reference's ``waterfall_last`` order, pipeline.py:236-262)."""
+        """For a G2P that returns a bare phoneme string for English (no tokens to chunk by): pieces of at most ``limit`` symbols, preferring the
+        latest sentence, then clause, then word boundary before the limit (the order of ``waterfall_last``)."""
         out = []
         ps = ps.strip()
         while len(ps) > limit:
@@ -154,21 +153,153 @@ class KokoroPipeline:
         return out
 
     @classmethod
+    def tokens_to_ps(cls, tokens) -> str:
+        return "".join(t.phonemes + (" " if t.whitespace else "") for t in tokens).strip()
+
+    @classmethod
+    def tokens_to_text(cls, tokens) -> str:
+        return "".join(t.text + t.whitespace for t in tokens).strip()
+
+    @classmethod
+    def waterfall_last(cls, tokens, next_count: int, waterfall=("!.?…", ":;", ",—"), bumps=(")", "”")) -> int:
+        """Where to cut ``tokens`` so that what stays behind fits: after the LAST sentence mark if that leaves at most 510 phonemes for the next
+        chunk, else after the last clause mark, else the last comma / dash, else everything (pipeline.py:236-261).  A closing bracket / quote that
+        follows the mark goes with it."""
+        for marks in waterfall:
+            z = next((i for i in range(len(tokens) - 1, -1, -1) if tokens[i].phonemes in set(marks)), None)
+            if z is None:
+                continue
+            z += 1
+            if z < len(tokens) and tokens[z].phonemes in bumps:
+                z += 1
+            if next_count - len(cls.tokens_to_ps(tokens[:z])) <= MAX_PHONEMES:
+                return z
+        return len(tokens)
+
+    def en_tokenize(self, tokens) -> Generator[tuple, None, None]:
+        """English tokens -> (text, phonemes, tokens) chunks of at most 510 phonemes, cut by ``waterfall_last`` (pipeline.py:266-294).  As in the
+        reference the flap is rewritten (ɾ -> T) and a missing pronunciation becomes the empty string, in place."""
+        held, count = [], 0
+        for t in tokens:
+            t.phonemes = "" if t.phonemes is None else t.phonemes.replace("ɾ", "T")
+            piece = t.phonemes + (" " if t.whitespace else "")
+            ahead = count + len(piece.rstrip())
+            if ahead > MAX_PHONEMES:
+                z = KokoroPipeline.waterfall_last(held, ahead)
+                yield KokoroPipeline.tokens_to_text(held[:z]), KokoroPipeline.tokens_to_ps(held[:z]), held[:z]
+                held = held[z:]
+                count = len(KokoroPipeline.tokens_to_ps(held))
+                if not held:
+                    piece = piece.lstrip()
+            held.append(t)
+            count += len(piece)
+        if held:
+            yield KokoroPipeline.tokens_to_text(held).strip(), KokoroPipeline.tokens_to_ps(held).strip(), held
+
+    @classmethod
+    def join_timestamps(cls, tokens, pred_dur) -> None:
+        """Word start / end times from the predicted durations (pipeline.py:360-399): positions are counted in half frames (80 per second) so that the
+        frame of a space can be split between its neighbours; ``pred_dur[0]`` is <bos> (all but 3 of its frames count as lead-in)."""
+        if not tokens or len(pred_dur) < 3:
+            return
+        dur = [int(d) for d in (pred_dur.tolist() if hasattr(pred_dur, "tolist") else pred_dur)]
+        left = right = 2 * max(0, dur[0] - 3)
+        i = 1
+        for t in tokens:
+            if i >= len(dur) - 1:
+                break
+            if not t.phonemes:
+                if t.whitespace:
+                    i += 1
+                    left = right + dur[i]
+                    right = left + dur[i]
+                    i += 1
+                continue
+            j = i + len(t.phonemes)
+            if j >= len(dur):
+                break
+            t.start_ts = left / 80
+            space = dur[j] if t.whitespace else 0
+            left = right + 2 * sum(dur[i:j]) + space
+            t.end_ts = left / 80
+            right = left + space
+            i = j + (1 if t.whitespace else 0)
+
+    @staticmethod
+    def text_chunks(graphemes: str, chunk_size: int = 400) -> List[str]:
+        """Non-English text -> pieces of roughly ``chunk_size`` characters on sentence boundaries (pipeline.py:473-503); without any sentence mark the
+        text stays one piece (the reference's character-count fallback cannot trigger: a non-empty text always yields one piece)."""
+        parts = re.split(r"([.!?]+)", graphemes)
+        chunks, current = [], ""
+        for i in range(0, len(parts), 2):
+            sentence = parts[i] + (parts[i + 1] if i + 1 < len(parts) else "")
+            if len(current) + len(sentence) <= chunk_size:
+                current += sentence
+            else:
+                if current:
+                    chunks.append(current.strip())
+                current = sentence
+        if current:
+            chunks.append(current.strip())
+        if not chunks:
+            chunks = [graphemes[i:i + chunk_size] for i in range(0, len(graphemes), chunk_size)]
+        return chunks
+
+    def phoneme_chunks(self, graphemes: str) -> Generator[tuple, None, None]:
+        """(graphemes, phonemes, tokens or None) per synthesis call for one text segment, as ``__call__`` of the reference cuts it (pipeline.py:444-528)."""
+        if self.lang_code in "ab":
+            out = self.g2p(graphemes)
+            tokens = out[1] if isinstance(out, tuple) and len(out) > 1 else None
+            if tokens is None:   # a G2P that only returns the phoneme string
+                for ps in self.chunk_phonemes((out[0] if isinstance(out, tuple) else out) or ""):
+                    yield graphemes, ps, None
+                return
+            for gs, ps, tks in self.en_tokenize(tokens):
+                if not ps:
+                    continue
+                if len(ps) > MAX_PHONEMES:
+                    logging.warning(f"Unexpected len(ps) == {len(ps)} > {MAX_PHONEMES} and ps == '{ps}'")
+                    ps = ps[:MAX_PHONEMES]
+                yield gs, ps, tks
+            return
+        for chunk in self.text_chunks(graphemes):
+            if not chunk.strip():
+                continue
+            out = self.g2p(chunk)
+            ps = out[0] if isinstance(out, tuple) else out
+            if not ps:
+                continue
+            if len(ps) > MAX_PHONEMES:
+                logging.warning(f"Truncating len(ps) == {len(ps)} > {MAX_PHONEMES}")
+                ps = ps[:MAX_PHONEMES]
+            yield chunk, ps, None
+
+    @classmethod
     def infer(cls, model, ps: str, pack: torch.Tensor, speed: Number = 1):
         return model(ps, pack[len(ps) - 1], speed, return_output=True)
 
     def generate_from_tokens(self, tokens: Union[str, list], voice, speed: Number = 1, model=None) -> Generator["KokoroPipeline.Result", None, None]:
-        """Audio from a raw phoneme string (no G2P).  Raises ``ValueError`` for a missing voice or > 510 phonemes,
-        like the reference (pipeline.py:348-373)."""
+        """Audio from a raw phoneme string (no G2P; ``ValueError`` beyond 510 phonemes) or from pre-processed tokens (chunked like text), as
+        pipeline.py:305-358; ``ValueError`` for a missing voice."""
         model = model or self.model
         if model and voice is None:
             raise ValueError('Specify a voice: pipeline.generate_from_tokens(..., voice="af_heart")')
         pack = self.load_voice(voice) if model else None
-        if not isinstance(tokens, str):
-            tokens = "".join(getattr(t, "phonemes", "") + (" " if getattr(t, "whitespace", "") else "") for t in tokens).strip()
-        if len(tokens) > MAX_PHONEMES:
-            raise ValueError(f"Phoneme string too long: {len(tokens)} > {MAX_PHONEMES}")
-        yield self.Result(graphemes="", phonemes=tokens, output=KokoroPipeline.infer(model, tokens, pack, speed) if model else None)
+        if isinstance(tokens, str):
+            if len(tokens) > MAX_PHONEMES:
+                raise ValueError(f"Phoneme string too long: {len(tokens)} > {MAX_PHONEMES}")
+            yield self.Result(graphemes="", phonemes=tokens, output=KokoroPipeline.infer(model, tokens, pack, speed) if model else None)
+            return
+        for gs, ps, tks in self.en_tokenize(tokens):
+            if not ps:
+                continue
+            if len(ps) > MAX_PHONEMES:
+                logging.warning(f"Unexpected len(ps) == {len(ps)} > {MAX_PHONEMES} and ps == '{ps}'; truncating")
+                ps = ps[:MAX_PHONEMES]
+            output = KokoroPipeline.infer(model, ps, pack, speed) if model else None
+            if output is not None and output.pred_dur is not None:
+                KokoroPipeline.join_timestamps(tks, output.pred_dur)
+            yield self.Result(graphemes=gs, phonemes=ps, tokens=tks, output=output)
 
     def __call__(self, text: Union[str, List[str]], voice=None, speed: Number = 1, split_pattern: Optional[str] = r"\n+", model=None):
         model = model or self.model
@@ -180,6 +311,8 @@ class KokoroPipeline:
         for index, graphemes in enumerate(text):
             if not graphemes.strip():
                 continue
-            for ps in self.chunk_phonemes(self.g2p(graphemes) or ""):
+            for gs, ps, tks in self.phoneme_chunks(graphemes):
                 out = KokoroPipeline.infer(model, ps, pack, speed) if model else None
-                yield self.Result(graphemes=graphemes, phonemes=ps, output=out, text_index=index)
+                if tks is not None and out is not None and out.pred_dur is not None:
+                    KokoroPipeline.join_timestamps(tks, out.pred_dur)
+                yield self.Result(graphemes=gs, phonemes=ps, tokens=tks, output=out, text_index=index)

@@ -925,6 +925,54 @@ def run_qwen3_inputs(seed):
     return out
 
 
+def run_kokoro_pipeline():
+    """The reference's ``KokoroPipeline`` (tts/models/kokoro/pipeline.py) with the G2P and the model replaced by stand-ins: ``__call__`` on English
+    token streams (``en_tokenize`` / ``waterfall_last`` / ``tokens_to_ps`` / ``tokens_to_text``, ``join_timestamps`` on the stand-in's durations,
+    :231-294, 360-399, 444-470) and on other languages (400-character text chunks, truncation at 510 phonemes, :473-528), and ``generate_from_tokens``
+    on a token list; cases in ``pt_layouts.KOKORO_PIPELINE_CASES``."""
+    import json
+
+    import pt_layouts as PT
+
+    _pkg("mlx_audio.tts.models.kokoro", f"{REF}/tts/models/kokoro")
+    if "mlx_audio.tts.models.kokoro.voice" not in sys.modules:
+        _load("mlx_audio.tts.models.kokoro.voice", f"{REF}/tts/models/kokoro/voice.py")
+    hub = sys.modules.get("huggingface_hub")
+    rp = _load("mlx_audio.tts.models.kokoro.pipeline", f"{REF}/tts/models/kokoro/pipeline.py")
+    out = []
+    for case in PT.KOKORO_PIPELINE_CASES:
+        calls = []
+
+        def model(ps, ref_s, speed, return_output=True, calls=calls):
+            calls.append(dict(ps=ps, row=int(np.asarray(ref_s)[0]), speed=float(speed)))
+            return types.SimpleNamespace(audio=mx.zeros((len(ps) * 10,)), pred_dur=mx.array(np.array(PT.kokoro_fake_durations(ps), dtype=np.int32)))
+
+        pipe = rp.KokoroPipeline.__new__(rp.KokoroPipeline)
+        pipe.lang_code, pipe.repo_id, pipe.model = case["lang"], "repo", model
+        pipe.voices = {"v": mx.array(np.arange(512, dtype=np.float32)[:, None] * np.ones((1, 4), dtype=np.float32))}
+        if "tokens" in case:
+            toks = PT.kokoro_token_stream(*case["tokens"])
+            pipe.g2p = lambda text, toks=toks: ("", toks)
+            results = list(pipe("some text", voice="v", speed=1.25))
+        else:
+            pipe.g2p = PT.kokoro_spanish_g2p
+            kw = {"split_pattern": case["split_pattern"]} if "split_pattern" in case else {}
+            results = list(pipe(case["text"], voice="v", speed=0.9, **kw))
+        rec = [dict(graphemes=r.graphemes, phonemes=r.phonemes, text_index=r.text_index,
+                    tokens=None if r.tokens is None else [[t.text, t.phonemes, t.start_ts, t.end_ts] for t in r.tokens]) for r in results]
+        entry = dict(name=case["name"], results=rec, calls=calls)
+        if case["name"] == "en_mixed":   # the same stream through generate_from_tokens (fresh tokens: en_tokenize rewrites them in place)
+            calls2 = []
+            pipe.model = lambda ps, ref_s, speed, return_output=True: model(ps, ref_s, speed, calls=calls2)
+            res2 = list(pipe.generate_from_tokens(PT.kokoro_token_stream(*case["tokens"]), voice="v", speed=1.0))
+            entry["from_tokens"] = [dict(graphemes=r.graphemes, phonemes=r.phonemes, n_tokens=len(r.tokens), last_end=r.tokens[-1].end_ts) for r in res2]
+            entry["from_tokens_calls"] = calls2
+        out.append(entry)
+    with open(os.path.join(HERE, "ref_kokoro_pipeline.json"), "w") as f:
+        json.dump(out, f)
+    return [(e["name"], [len(r["phonemes"]) for r in e["results"]]) for e in out]
+
+
 def run_sampler(seed):
     """The reference's sampling chain: ``Model._sample_token_batch`` of Qwen3-TTS (suppress ids, per-sequence repetition penalty, temperature, top-k,
     top-p / min-p through ``lm/sample_utils.py``; qwen3_tts.py:862-925) with the final ``categorical_sampling`` replaced by a probe that records the
@@ -1280,6 +1328,7 @@ def main():
     bfx = run_bigvgan(seed_w=6, seed_mel=2, n_frames=50)
     np.savez_compressed(os.path.join(HERE, "ref_bigvgan_tiny.npz"), config=json.dumps(BIGVGAN_TINY), **bfx)
     print("bigvgan:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in bfx.items()}, "peak", float(np.abs(bfx["audio1"]).max()))
+    print("kokoro pipeline:", run_kokoro_pipeline())
     print("csm generate:", run_csm_generate())
     lfx = run_qwen3_generate_loop(seed_w=7)
     np.savez_compressed(os.path.join(HERE, "ref_qwen3_generate_loop.npz"), **lfx)

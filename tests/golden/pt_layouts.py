@@ -214,3 +214,65 @@ def csm_frame(i, j):
 
 # special codec ids inside the tiny talker's 1200-entry vocabulary (run_qwen3_generate_loop and its test)
 QWEN3_LOOP_CODEC_IDS = dict(codec_think_id=1154, codec_nothink_id=1155, codec_think_bos_id=1156, codec_think_eos_id=1157, codec_pad_id=1148, codec_bos_id=1149)
+
+
+# ---- Kokoro pipeline chunking (make_reference_fixtures.run_kokoro_pipeline and tests/test_kokoro_pipeline_cpu.py)
+class FakeMToken:
+    """What the pipeline reads from a ``misaki.en.MToken``."""
+
+    def __init__(self, text, phonemes, whitespace):
+        self.text, self.phonemes, self.whitespace = text, phonemes, whitespace
+        self.start_ts = self.end_ts = None
+
+
+def kokoro_token_stream(kind, n_words):
+    """A deterministic English token list: words with 1..9 phonemes (some with a flap, some unpronounceable), punctuation per ``kind``."""
+    toks = []
+    for i in range(n_words):
+        ph = "".join("aɾbdefgik"[(i * 7 + j * 3) % 9] for j in range(1 + (i * 5) % 9))
+        if i % 23 == 11:
+            ph = None                                   # out-of-dictionary word without fallback
+        mark = None
+        if kind == "sentences" and i % 17 == 16:
+            mark = ".!?…"[(i // 17) % 4]
+        elif kind == "clauses" and i % 13 == 12:
+            mark = ":;"[(i // 13) % 2]
+        elif kind == "commas" and i % 9 == 8:
+            mark = ",—"[(i // 9) % 2]
+        elif kind == "mixed":
+            if i % 41 == 40:
+                mark = "."
+            elif i % 11 == 10:
+                mark = ","
+        elif kind == "quoted" and i % 19 == 18:
+            mark = "!"
+        toks.append(FakeMToken(f"w{i}", ph, "" if mark else " "))
+        if mark:
+            toks.append(FakeMToken(mark, mark, "" if kind == "quoted" else " "))
+            if kind == "quoted":
+                toks.append(FakeMToken("”", "”", " "))
+    return toks
+
+
+def kokoro_fake_durations(ps):
+    return [5] + [1 + (ord(c) * 7) % 4 for c in ps] + [3]
+
+
+def kokoro_spanish_g2p(text):
+    """Stand-in for an espeak G2P: one phoneme per letter, doubled vowels (so that long sentences exceed 510 phonemes); some calls return a tuple."""
+    ps = "".join(c + c if c in "aeiou" else c for c in text.lower())
+    return (ps, None) if len(text) % 2 else ps
+
+
+KOKORO_PIPELINE_CASES = [
+    dict(name="en_sentences", lang="a", tokens=("sentences", 420)),
+    dict(name="en_clauses", lang="a", tokens=("clauses", 330)),
+    dict(name="en_commas", lang="b", tokens=("commas", 300)),
+    dict(name="en_no_marks", lang="a", tokens=("none", 260)),
+    dict(name="en_mixed", lang="a", tokens=("mixed", 500)),
+    dict(name="en_quoted", lang="a", tokens=("quoted", 300)),
+    dict(name="en_short", lang="a", tokens=("sentences", 9)),
+    dict(name="es_sentences", lang="e", text="Hola mundo. " * 60 + "\n\n" + "Una frase muy larga sin puntos " * 25 + "\n \n" + "Fin!"),
+    dict(name="es_no_split", lang="e", text="Buenos dias. Como estas? " * 30, split_pattern=None),
+    dict(name="ja_list", lang="j", text=["Primero. Segundo! Tercero?", "", "Otro"]),
+]
