@@ -973,6 +973,19 @@ def run_kokoro_pipeline():
     return [(e["name"], [len(r["phonemes"]) for r in e["results"]]) for e in out]
 
 
+def run_broker():
+    """The reference's ``InferenceBroker`` (server_inference.py:129-358) driven by ``pt_layouts.broker_scenario``."""
+    import json
+
+    import pt_layouts as PT
+
+    mod = _load("mlx_audio.server_inference", f"{REF}/server_inference.py")
+    out = PT.broker_scenario(mod)
+    with open(os.path.join(HERE, "ref_broker.json"), "w") as f:
+        json.dump(out, f)
+    return out["trace"]
+
+
 def run_sampler(seed):
     """The reference's sampling chain: ``Model._sample_token_batch`` of Qwen3-TTS (suppress ids, per-sequence repetition penalty, temperature, top-k,
     top-p / min-p through ``lm/sample_utils.py``; qwen3_tts.py:862-925) with the final ``categorical_sampling`` replaced by a probe that records the
@@ -1328,6 +1341,7 @@ def main():
     bfx = run_bigvgan(seed_w=6, seed_mel=2, n_frames=50)
     np.savez_compressed(os.path.join(HERE, "ref_bigvgan_tiny.npz"), config=json.dumps(BIGVGAN_TINY), **bfx)
     print("bigvgan:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in bfx.items()}, "peak", float(np.abs(bfx["audio1"]).max()))
+    print("broker:", run_broker())
     print("kokoro pipeline:", run_kokoro_pipeline())
     print("csm generate:", run_csm_generate())
     lfx = run_qwen3_generate_loop(seed_w=7)

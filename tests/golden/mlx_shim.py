@@ -606,6 +606,14 @@ Stream = _Stream
 cpu = gpu = object()
 
 
+def new_stream(device=None):
+    return _Stream()
+
+
+def set_default_stream(s):
+    return None
+
+
 def dropout(x, p=0.5, *a, **k):
     raise RuntimeError("mx.dropout is not an MLX function; the reference never reaches this line in inference")
 

@@ -276,3 +276,115 @@ KOKORO_PIPELINE_CASES = [
     dict(name="es_no_split", lang="e", text="Buenos dias. Como estas? " * 30, split_pattern=None),
     dict(name="ja_list", lang="j", text=["Primero. Segundo! Tercero?", "", "Otro"]),
 ]
+
+
+# ---- serving shell: one scripted scenario run through a broker module (the reference's server_inference.py or this package's)
+def broker_scenario(mod):
+    """Submits a fixed set of requests to ``mod.InferenceBroker`` while its worker is held inside the first request, so that the worker then sees them all
+    at once: continuous sessions (two keys, one session whose step raises, one request the session refuses), fixed-window batches (key A: more requests
+    than ``max_batch_size``, one cancelled while waiting; key B alone), serial requests (one raising), a request whose adapter disappears.  Returns the
+    adapter / session call trace and every request's result chunks."""
+    import threading
+
+    trace, gate, started = [], threading.Event(), threading.Event()
+
+    class Session:
+        def __init__(self, key):
+            self.key, self.active = key, []
+            trace.append(["create", key])
+
+        @property
+        def idle(self):
+            return not self.active
+
+        def submit(self, req):
+            trace.append(["submit", self.key, req.payload["id"]])
+            if req.payload.get("reject"):
+                raise RuntimeError("session refuses this request")
+            self.active.append([req, req.payload["steps"]])
+
+        def step(self):
+            trace.append(["step", self.key, [r.payload["id"] for r, _ in self.active]])
+            if any(r.payload.get("explode") for r, _ in self.active):
+                raise RuntimeError("boom")
+            for item in list(self.active):
+                item[0].emit_data(["chunk", item[0].payload["id"], item[1]])
+                item[1] -= 1
+                if item[1] == 0:
+                    item[0].emit_done()
+                    self.active.remove(item)
+
+        def fail(self, err):
+            trace.append(["fail", self.key, str(err)])
+            for r, _ in self.active:
+                r.emit_error(err)
+                r.emit_done()
+            self.active = []
+
+    class Adapter:
+        max_batch_size = 3
+
+        def supports_batch(self, r):
+            return bool(r.payload.get("batch"))
+
+        def batch_key(self, r):
+            return r.payload.get("key")
+
+        def supports_continuous_batch(self, r):
+            return "ckey" in r.payload
+
+        def continuous_batch_key(self, r):
+            return r.payload["ckey"]
+
+        def create_continuous_batch_session(self, r):
+            return Session(r.payload["ckey"])
+
+        def run_serial(self, r):
+            trace.append(["serial", r.payload["id"]])
+            if r.payload.get("gate"):
+                started.set()
+                gate.wait(10)
+            if r.payload.get("raise"):
+                raise ValueError("bad request")
+            r.emit_data(["out", r.payload["id"]])
+            r.emit_done()
+
+        def run_batch(self, reqs):
+            trace.append(["batch", [r.payload["id"] for r in reqs]])
+            for r in reqs:
+                r.emit_data(["out", r.payload["id"]])
+                r.emit_done()
+
+    broker = mod.InferenceBroker(idle_poll_s=0.01)
+    broker.register_adapter("tts", Adapter())
+    broker.register_adapter("gone", Adapter())
+    unknown = None
+    try:
+        broker.submit(endpoint_kind="nope", model_name="m", payload={"id": -1})
+    except ValueError as e:
+        unknown = str(e)
+    payloads = [dict(id=0, gate=True), dict(id=1, batch=True, key="A"), dict(id=2), dict(id=3, batch=True, key="A"), dict(id=4, batch=True, key="B"),
+                dict(id=5, batch=True, key="A"), dict(id=6, batch=True, key="A"), dict(id=7, batch=True, key="A"), dict(id=8, ckey="X", steps=2),
+                dict(id=9, ckey="X", steps=3), dict(id=10, ckey="Y", steps=1), dict(id=11, endpoint="gone"), dict(id=12, batch=True, key="A"),
+                dict(id=13, ckey="Z", steps=2, explode=True), dict(id=14, ckey="X", steps=1, reject=True), dict(id=15, **{"raise": True}),
+                dict(id=16, batch=True, key="A", model="other")]
+    handles = []
+    for i, pl in enumerate(payloads):
+        handles.append(broker.submit(endpoint_kind=pl.get("endpoint", "tts"), model_name=pl.get("model", "m"), payload=pl))
+        if i == 0:
+            assert started.wait(10)
+    handles[7].cancel()
+    broker._adapters.pop("gone")
+    gate.set()
+    chunks = {}
+    for pl, h in zip(payloads, handles):
+        got = []
+        if pl["id"] != 7:                       # the cancelled request is dropped without a word
+            while True:
+                c = h.result_queue.get(timeout=10)
+                got.append([c.kind, c.payload if c.kind == "data" else (str(c.error) if c.kind == "error" else None)])
+                if c.kind == "done":
+                    break
+        chunks[str(pl["id"])] = got
+    broker.stop_and_join()
+    return dict(unknown_endpoint=unknown, trace=trace, chunks=chunks)
