@@ -13,8 +13,8 @@ temperature fallback over the ``temperature`` tuple (sampling = arg-max of ``log
 ``clip_timestamps``, segment cutting at consecutive timestamps.
 
 Deliberately not carried over (host front/back ends): resampling of non-16 kHz files, word-level timestamps and
-``hallucination_silence_threshold`` (DTW over cross-attention weights), streaming (AlignAtt) -- these raise ``NotImplementedError`` --
-and language detection by probability dict (``detect_language`` returns the arg-max language only).
+``hallucination_silence_threshold`` (DTW over cross-attention weights), streaming (AlignAtt) -- these raise ``NotImplementedError``.
+``detect_language`` returns the reference's (language tokens, probability dicts) pair.
 """
 from __future__ import annotations
 
@@ -148,18 +148,25 @@ class Model:
         return decode_function(self, mel, options, **kwargs)
 
     def detect_language(self, mel: torch.Tensor, tokenizer=None):
-        """decoding.py:19-77 (arg-max language token only): one decoder pass on <|startoftranscript|>."""
+        """``decoding.py:20-77``: one decoder pass on <|startoftranscript|>, every token but the language tokens masked out.  Returns
+        ``(language_tokens, language_probs)``: the most probable language token per clip (a 0-d tensor for a single [frames, mels] input) and one
+        ``{language code: probability}`` dict per clip (a single dict for a single input), like the reference."""
         tokenizer = tokenizer or self.get_tokenizer()
+        if tokenizer.language is None or tokenizer.language_token not in tokenizer.sot_sequence:
+            raise ValueError("This model doesn't have language tokens so it can't perform lang id")
         single = mel.dim() == 2
         if single:
             mel = mel[None]
         if tuple(mel.shape[-2:]) != (self.dims.n_audio_ctx, self.dims.n_audio_state):
             mel = self.embed_audio(mel)
         x = torch.full((mel.shape[0], 1), tokenizer.sot, dtype=torch.int32)
-        lg = self.logits(x, mel)[:, 0]
+        lg = self.logits(x, mel)[:, 0].float()
         ids = torch.tensor(tokenizer.all_language_tokens, device=lg.device)
-        best = ids[lg[:, ids].argmax(dim=-1)]
-        return best[0] if single else best
+        lang_logits = lg[:, ids]                                   # the mask of the reference leaves exactly these columns
+        tokens = ids[lang_logits.argmax(dim=-1)]
+        probs = torch.softmax(lang_logits, dim=-1).cpu()
+        dicts = [{c: float(probs[i, j]) for j, c in enumerate(tokenizer.all_language_codes)} for i in range(probs.shape[0])]
+        return (tokens[0], dicts[0]) if single else (tokens, dicts)
 
     # ------------------------------------------------------------------ generate (whisper.py:799-1320, condensed)
     def _prepare_audio(self, audio, padding: int = N_SAMPLES) -> Tuple[torch.Tensor, int]:
@@ -200,8 +207,8 @@ class Model:
                 language = "en"
             else:
                 tok0 = self.get_tokenizer()
-                lang_tok = int(self.detect_language(pad_or_trim(mel, N_FRAMES, axis=-2), tok0))
-                language = LANGUAGES[lang_tok - tok0.sot - 1]
+                _, probs = self.detect_language(pad_or_trim(mel, N_FRAMES, axis=-2), tok0)   # whisper.py:897-905
+                language = max(probs, key=probs.get)
         decode_options.update(language=language, task=task)
         tokenizer = self.get_tokenizer(language=language, task=task)
 

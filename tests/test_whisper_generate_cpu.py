@@ -233,3 +233,19 @@ def test_generate_host_loop_matches_the_reference_generate():
             assert g["id"] == e["id"] and g["seek"] == e["seek"] and g["tokens"] == e["tokens"] and g["text"] == e["text"], (case["name"], g, e)
             assert abs(g["start"] - e["start"]) < 1e-9 and abs(g["end"] - e["end"]) < 1e-9 and abs(g["temperature"] - e["temperature"]) < 1e-9, (case["name"], g, e)
         assert out.text == exp["text"], (case["name"], out.text, exp["text"])
+
+
+def test_generate_detects_the_language_from_the_probability_dict():
+    """whisper.py:897-905: with ``language=None`` a multilingual model asks ``detect_language`` (-> tokens, {code: probability}) and decodes in the most
+    probable language; the first 30 s window is what it is shown."""
+    seen = {}
+    tb = tok().timestamp_begin
+
+    class M(Stub):
+        def detect_language(self, mel, tokenizer=None):
+            seen["shape"] = tuple(mel.shape)
+            return torch.tensor(50261), {"en": 0.2, "de": 0.7, "fr": 0.1}
+
+    m = M(3000, [dict(tokens=[tb, 100, tb + 1500])])
+    out = m.generate(np.zeros(16000, np.float32), temperature=0.0)
+    assert [c["options"].language for c in m.calls] == ["de"] and out.language == "de" and seen["shape"][0] == N_FRAMES

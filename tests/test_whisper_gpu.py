@@ -272,3 +272,33 @@ def test_model_surface(tiny):
     assert len(res.tokens) <= 5 and res.temperature == 0.7 and np.isfinite(res.avg_logprob)  # the prefix sits before sample_begin
     with pytest.raises(ValueError):
         model.decode(mel, DecodingOptions(beam_size=2, best_of=2))
+
+
+def test_detect_language_contract(tiny):
+    """decoding.py:20-77: (language tokens, {code: probability}) from one decoder pass on <|startoftranscript|> with everything but the language tokens
+    masked: the probabilities are the soft-max over the language columns of the oracle's logits, the token is their arg-max; single clip -> scalars."""
+    from mlx_audio_amd.stt.models.whisper import Model
+
+    dims, WS = tiny["dims"], tiny["WS"]
+    model = Model(dims, device=DEV)
+    model.load_weights(model.sanitize(WS.make_whisper_weights(dims, seed=1)))
+    mel = WS.make_mel(2, seed=9, n_frames=2 * dims.n_audio_ctx)
+    tokens, probs = model.detect_language(mel)
+    tok = model.get_tokenizer()
+    ids = list(tok.all_language_tokens)
+    feats = tiny["ref"].encoder(mel)
+    ref_logits = tiny["ref"].decoder(torch.full((2, 1), tok.sot, dtype=torch.long), feats)[0][:, 0, ids].double()
+    want = torch.softmax(ref_logits, dim=-1)
+    assert tokens.shape == (2,) and len(probs) == 2 and list(probs[0]) == list(tok.all_language_codes)
+    for b in range(2):
+        got = torch.tensor([probs[b][c] for c in tok.all_language_codes], dtype=torch.float64)
+        assert abs(float(got.sum()) - 1.0) < 1e-5 and float((got - want[b]).abs().max()) < 2e-3 * float(want[b].max())
+        top2 = torch.topk(ref_logits[b], 2).values
+        if float(top2[0] - top2[1]) > 1e-2:
+            assert int(tokens[b]) == ids[int(ref_logits[b].argmax())] and max(probs[b], key=probs[b].get) == tok.all_language_codes[int(ref_logits[b].argmax())]
+    t1, p1 = model.detect_language(mel[0])
+    assert t1.dim() == 0 and int(t1) == int(tokens[0]) and isinstance(p1, dict) and abs(p1["en"] - probs[0]["en"]) < 1e-6
+    english_only = model.get_tokenizer()
+    english_only.language = None
+    with pytest.raises(ValueError, match="language tokens"):
+        model.detect_language(mel, english_only)
