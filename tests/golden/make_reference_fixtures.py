@@ -1228,6 +1228,44 @@ def run_kitten_generate(R):
     return [(len(c["calls"]), [r["n"] for r in c["results"]]) for c in out]
 
 
+def run_whisper_host():
+    """Host helpers of the reference's Whisper decode (decoding.py): ``DecodingTask._get_initial_tokens`` (:525-551: sot sequence, prefix and prompt
+    truncation), ``get_suppress_tokens`` (:80-112), ``MaximumLikelihoodRanker.rank`` (:212-235) and ``compression_ratio`` (:15-17) on
+    ``pt_layouts.WHISPER_HOST_CASES``."""
+    import json
+
+    import pt_layouts as PT
+
+    wh, dec = import_whisper()
+    codec = PT.WhisperCodec()
+
+    class Tok(FakeWhisperTokenizer):
+        def encode(self, text):
+            return codec.encode(text)
+
+    tok = Tok()
+    C = PT.WHISPER_HOST_CASES
+    out = dict(initial=[], suppress=[], rank=[], ratio=[])
+    for kw in C["initial"]:
+        kw = dict(kw)
+        sample_len = kw.pop("sample_len", None)
+        opts = dec.DecodingOptions(language="en", **kw)
+        task = dec.DecodingTask.__new__(dec.DecodingTask)
+        task.options, task.tokenizer, task.n_ctx = opts, tok, PT.WHISPER_HOST_N_CTX
+        task.sample_len = sample_len or PT.WHISPER_HOST_N_CTX // 2
+        task.sot_sequence = tok.sot_sequence_including_notimestamps if opts.without_timestamps else tok.sot_sequence
+        out["initial"].append([int(t) for t in task._get_initial_tokens()])
+    for sup in C["suppress"]:
+        out["suppress"].append([int(t) for t in dec.get_suppress_tokens(tok, sup)])
+    for r in C["rank"]:
+        out["rank"].append(int(dec.MaximumLikelihoodRanker(r["length_penalty"]).rank([r["tokens"]], [r["sum_logprobs"]])[0]))
+    for t in C["text"]:
+        out["ratio"].append(float(dec.compression_ratio(t)))
+    with open(os.path.join(HERE, "ref_whisper_host.json"), "w") as f:
+        json.dump(out, f)
+    return {k: len(v) for k, v in out.items()}
+
+
 def run_whisper_generate():
     """The reference's ``Model.generate`` of Whisper (whisper.py:799-1320: 30 s windows, temperature fallback, no-speech skipping, segment cutting at
     consecutive timestamps, seek advance, prompt conditioning and its reset, clip timestamps) with ``_prepare_audio`` replaced by a ramp mel and ``decode``
@@ -1342,6 +1380,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_bigvgan_tiny.npz"), config=json.dumps(BIGVGAN_TINY), **bfx)
     print("bigvgan:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in bfx.items()}, "peak", float(np.abs(bfx["audio1"]).max()))
     print("broker:", run_broker())
+    print("whisper host helpers:", run_whisper_host())
     print("kokoro pipeline:", run_kokoro_pipeline())
     print("csm generate:", run_csm_generate())
     lfx = run_qwen3_generate_loop(seed_w=7)

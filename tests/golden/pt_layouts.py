@@ -388,3 +388,18 @@ def broker_scenario(mod):
         chunks[str(pl["id"])] = got
     broker.stop_and_join()
     return dict(unknown_endpoint=unknown, trace=trace, chunks=chunks)
+
+
+# ---- Whisper decode host helpers (make_reference_fixtures.run_whisper_host and tests/test_whisper_generate_cpu.py)
+WHISPER_HOST_CASES = dict(
+    initial=[dict(), dict(without_timestamps=True), dict(prefix=list(range(300, 340))), dict(prompt=list(range(400, 460))),
+             dict(prompt=list(range(400, 460)), prefix=[9, 8, 7], without_timestamps=True), dict(prompt="hello there", prefix=" well "),
+             dict(prefix=list(range(300, 340)), sample_len=30), dict(prompt=[5], sample_len=3)],
+    suppress=["-1", "1,2,-1", [5, 6], "7", None, [-1, 50300]],
+    rank=[dict(tokens=[[1, 2, 3], [1, 2], [4, 5, 6, 7]], sum_logprobs=[-3.0, -2.5, -3.2], length_penalty=None),
+          dict(tokens=[[1, 2, 3], [1, 2], [4, 5, 6, 7]], sum_logprobs=[-3.0, -2.5, -3.2], length_penalty=0.6),
+          dict(tokens=[[1], [2]], sum_logprobs=[-1.0, -1.0], length_penalty=None),
+          dict(tokens=[[1, 2, 3, 4, 5, 6], [1]], sum_logprobs=[-6.6, -1.2], length_penalty=1.0)],
+    text=["hello hello hello hello hello", "The quick brown fox jumps over the lazy dog.", "a", "ĉu vi ŝatas ĝin? " * 7],
+)
+WHISPER_HOST_N_CTX = 64

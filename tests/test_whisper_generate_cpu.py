@@ -249,3 +249,34 @@ def test_generate_detects_the_language_from_the_probability_dict():
     m = M(3000, [dict(tokens=[tb, 100, tb + 1500])])
     out = m.generate(np.zeros(16000, np.float32), temperature=0.0)
     assert [c["options"].language for c in m.calls] == ["de"] and out.language == "de" and seen["shape"][0] == N_FRAMES
+
+
+def test_decode_host_helpers_match_the_reference():
+    """``ref_whisper_host.json`` = the reference's ``DecodingTask._get_initial_tokens`` (decoding.py:525-551), ``get_suppress_tokens`` (:80-112),
+    ``MaximumLikelihoodRanker.rank`` (:212-235) and ``compression_ratio`` (:15-17) on ``pt_layouts.WHISPER_HOST_CASES``; this package's
+    ``initial_tokens`` / ``get_suppress_tokens`` / ``rank_group`` / ``compression_ratio`` give the same."""
+    import json
+    import os
+    import sys
+
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gold)
+    import pt_layouts as PT
+
+    from mlx_audio_amd.stt.models.whisper import decoding as D
+
+    want = json.load(open(os.path.join(gold, "ref_whisper_host.json")))
+    C = PT.WHISPER_HOST_CASES
+    t = get_tokenizer(True, language="en", task="transcribe", codec=PT.WhisperCodec())
+    t.non_speech_tokens = (1, 2, 7, 8, 9, 10, 14, 25)         # the stand-in vocabulary of the reference-side tokenizer
+    for kw, exp in zip(C["initial"], want["initial"]):
+        kw = dict(kw)
+        sample_len = kw.pop("sample_len", None) or PT.WHISPER_HOST_N_CTX // 2
+        got = D.initial_tokens(t, DecodingOptions(language="en", **kw), PT.WHISPER_HOST_N_CTX, sample_len)
+        assert got == exp, (kw, got, exp)
+    for sup, exp in zip(C["suppress"], want["suppress"]):
+        assert list(D.get_suppress_tokens(t, sup)) == exp, sup
+    for r, exp in zip(C["rank"], want["rank"]):
+        assert D.rank_group(r["tokens"], r["sum_logprobs"], r["length_penalty"]) == exp, r
+    for text, exp in zip(C["text"], want["ratio"]):
+        assert abs(D.compression_ratio(text) - exp) < 1e-12
