@@ -1065,7 +1065,7 @@ def run_sanitize(R):
     ck = PT.kokoro_checkpoint(S.make_kokoro_weights(cfg, seed=1))
     san = model.sanitize({k: mx.array(v.numpy()) for k, v in ck.items()})
     out["kokoro"] = PT.summary({k: torch.from_numpy(np.asarray(v)) for k, v in san.items()})
-    rs = sys.modules["mlx_audio.tts.models.sesame.sesame"]
+    rs = import_sesame()
     ck = PT.csm_checkpoint(E.make_csm_weights(E.tiny_csm(), seed=5))
     san = rs.Model.sanitize(None, {k: mx.array(v.numpy()) for k, v in ck.items()})
     out["csm"] = PT.summary({k: torch.from_numpy(np.asarray(v)) for k, v in san.items()})
@@ -1077,6 +1077,20 @@ def run_sanitize(R):
     ck = PT.qwen3_codec_checkpoint(QS.make_codec_decoder_weights(QS.tiny_codec_config(), seed=4))
     san = st.Qwen3TTSSpeechTokenizer.sanitize({k: mx.array(v.numpy()) for k, v in ck.items()})
     out["qwen3_codec"] = PT.summary({k: torch.from_numpy(np.asarray(v)) for k, v in san.items()})
+    # Whisper from the HF hub (whisper.py:551-617), Qwen3-TTS Model.sanitize with its layout heuristic (qwen3_tts.py:123-157, 2914-2937), KittenTTS's
+    # Snake parameter names (kitten_tts.py:394-404)
+    from mlx_audio_amd.stt.models.whisper import synthetic as WS
+
+    wh, _ = import_whisper()
+    ck = PT.whisper_hf_checkpoint(WS.make_whisper_weights(WS.tiny_dims(), seed=1))
+    san = wh.Model.sanitize(types.SimpleNamespace(dtype=mx.float32), {k: mx.array(v.numpy()) for k, v in ck.items()})
+    out["whisper_hf"] = PT.summary({k: torch.from_numpy(np.asarray(v)) for k, v in san.items()})
+    q = import_qwen3_model()
+    san = q.Model.sanitize({k: mx.array(v.numpy()) for k, v in PT.qwen3_model_checkpoint(3).items()})
+    out["qwen3_model"] = PT.summary({k: torch.from_numpy(np.asarray(v)) for k, v in san.items()})
+    for i, ck in enumerate(PT.kitten_alpha_checkpoints()):
+        san = R["kitten"].Model.sanitize(None, {k: mx.array(v.numpy()) for k, v in ck.items()})
+        out[f"kitten_alpha{i}"] = PT.summary({k: torch.from_numpy(np.asarray(v)) for k, v in san.items()})
     with open(os.path.join(HERE, "ref_sanitize.json"), "w") as f:
         json.dump(out, f)
     return {k: len(v) for k, v in out.items()}

@@ -403,3 +403,46 @@ WHISPER_HOST_CASES = dict(
     text=["hello hello hello hello hello", "The quick brown fox jumps over the lazy dog.", "a", "ĉu vi ŝatas ĝin? " * 7],
 )
 WHISPER_HOST_N_CTX = 64
+
+
+# ---- more checkpoints in their published form for the sanitize pins (Whisper from the HF hub, Qwen3-TTS, KittenTTS exports)
+_WHISPER_TO_HF = [("decoder.positional_embedding", "decoder.embed_positions.weight"), ("encoder.ln_post.", "encoder.layer_norm."), ("decoder.ln.", "decoder.layer_norm."),
+                  ("encoder.blocks.", "encoder.layers."), ("decoder.blocks.", "decoder.layers."), (".cross_attn_ln.", ".encoder_attn_layer_norm."),
+                  (".attn_ln.", ".self_attn_layer_norm."), (".mlp_ln.", ".final_layer_norm."), (".mlp1.", ".fc1."), (".mlp2.", ".fc2."),
+                  (".cross_attn.query.", ".encoder_attn.q_proj."), (".cross_attn.key.", ".encoder_attn.k_proj."), (".cross_attn.value.", ".encoder_attn.v_proj."),
+                  (".cross_attn.out.", ".encoder_attn.out_proj."), (".attn.query.", ".self_attn.q_proj."), (".attn.key.", ".self_attn.k_proj."),
+                  (".attn.value.", ".self_attn.v_proj."), (".attn.out.", ".self_attn.out_proj."), ("decoder.token_embedding.", "decoder.embed_tokens.")]
+
+
+def whisper_hf_checkpoint(w):
+    """This package's Whisper weights (MLX names, conv (out, K, in)) under the HuggingFace names with the ``model.`` prefix, PyTorch conv layout, plus the
+    sinusoid table HF checkpoints carry for the encoder (dropped by sanitize)."""
+    out = {}
+    for k, v in w.items():
+        for mlx_name, hf_name in _WHISPER_TO_HF:
+            if mlx_name in k:
+                k = k.replace(mlx_name, hf_name)
+        if ("conv1.weight" in k or "conv2.weight" in k) and v.dim() == 3:
+            v = v.permute(0, 2, 1).contiguous()
+        out["model." + k] = v
+    out["model.encoder.embed_positions.weight"] = torch.zeros(4, 4)
+    return out
+
+
+def qwen3_model_checkpoint(seed=0):
+    """Keys / shapes that walk every branch of Qwen3-TTS ``Model.sanitize`` and its layout heuristic (qwen3_tts.py:123-157, 2914-2937)."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *shape: torch.randn(*shape, generator=g)
+    return {"talker.model.layers.0.self_attn.q_proj.weight": r(8, 8), "talker.model.rotary.position_ids": torch.arange(6)[None],
+            "speaker_encoder.blocks.0.conv.weight": r(64, 80, 5), "speaker_encoder.blocks.0.conv.bias": r(64), "speaker_encoder.asp.conv.weight": r(128, 1, 200),
+            "speaker_encoder.blocks.1.conv.weight": r(128, 1, 7), "speech_tokenizer.decoder.pre_conv.conv.weight": r(32, 100, 1),
+            "speech_tokenizer.decoder.x.conv.weight": r(32, 3, 1), "speech_tokenizer.decoder.y.conv.weight": r(16, 4, 9), "speaker_encoder.fc.weight": r(8, 20, 1),
+            "speaker_encoder.fc.bias": r(8), "talker.other.weight": r(3, 9, 2), "speech_tokenizer.decoder.upconv.weight": r(6, 12, 12)}
+
+
+def kitten_alpha_checkpoints():
+    r = lambda n: torch.arange(n, dtype=torch.float32)
+    return [{"decoder.generator.resblocks.0.alpha1.0": r(3), "decoder.generator.resblocks.0.alpha2.1": r(4), "bert.embeddings.word_embeddings.weight": r(5)},
+            {"decoder.generator.resblocks.0.alpha1_0": r(3), "decoder.generator.resblocks.0.alpha2_1": r(4)},
+            {"decoder.generator.resblocks.0.alpha1.0": r(3), "decoder.generator.resblocks.1.alpha1_0": r(2)},
+            {"text_encoder.lstm.weight_ih_l0": r(6)}]

@@ -430,7 +430,7 @@ def test_kokoro_oracle_on_a_genuinely_float32_checkpoint():
 
 def test_sanitize_matches_the_reference_sanitize():
     """The loader boundary: this package's ``Model.sanitize`` against the reference's own ``sanitize`` (Kokoro: kokoro.py:178-275 with the decoder's
-    istftnet.py:998-1011; CSM: sesame.py:577-604), both fed a checkpoint in its published on-disk form (PyTorch conv layouts, torch LSTM names,
+    istftnet.py:998-1011; CSM: sesame.py:577-604; Qwen3-TTS speech tokenizer and model; Whisper from the HF hub; KittenTTS), both fed a checkpoint in its published on-disk form (PyTorch conv layouts, torch LSTM names,
     gamma / beta, position_ids; torchtune names): the same keys, shapes and values come out (ref_sanitize.json holds key -> shape / sum / sum of squares)."""
     import json
     import sys
@@ -464,6 +464,28 @@ def test_sanitize_matches_the_reference_sanitize():
     assert set(got) == set(want["qwen3_codec"]), (sorted(set(got) ^ set(want["qwen3_codec"]))[:6])
     for k, (shape, s1, s2) in want["qwen3_codec"].items():
         assert got[k][0] == shape and abs(got[k][1] - s1) <= 1e-6 * (1 + abs(s1)) and abs(got[k][2] - s2) <= 1e-6 * (1 + s2), k
+
+    # Whisper in the HuggingFace layout (whisper.py:551-617), Qwen3-TTS Model.sanitize with its conv layout heuristic (qwen3_tts.py:123-157, 2914-2937),
+    # KittenTTS's Snake parameter names (kitten_tts.py:394-404)
+    from types import SimpleNamespace
+
+    from mlx_audio_amd.stt.models.whisper import synthetic as WS
+    from mlx_audio_amd.stt.models.whisper.whisper import Model as Whisper
+    from mlx_audio_amd.tts.models.kitten_tts.kitten_tts import Model as Kitten
+    from mlx_audio_amd.tts.models.qwen3_tts.qwen3_tts import Model as Qwen3
+
+    def same(got, exp, tag):
+        assert set(got) == set(exp), (tag, sorted(set(got) ^ set(exp))[:6])
+        for k, (shape, s1, s2) in exp.items():
+            assert got[k][0] == shape and abs(got[k][1] - s1) <= 1e-6 * (1 + abs(s1)) and abs(got[k][2] - s2) <= 1e-6 * (1 + s2), (tag, k)
+
+    w = WS.make_whisper_weights(WS.tiny_dims(), seed=1)
+    got = Whisper.sanitize(SimpleNamespace(dtype=torch.float32), PT.whisper_hf_checkpoint(w))
+    same(PT.summary(got), want["whisper_hf"], "whisper_hf")
+    assert set(got) == set(w) and all(torch.equal(got[k], w[k].to(torch.float32)) for k in w)      # and it is the inverse of the HF renaming
+    same(PT.summary(Qwen3.sanitize(PT.qwen3_model_checkpoint(3))), want["qwen3_model"], "qwen3_model")
+    for i, ck in enumerate(PT.kitten_alpha_checkpoints()):
+        same(PT.summary(Kitten.sanitize(None, ck)), want[f"kitten_alpha{i}"], f"kitten_alpha{i}")
 
 
 def test_bigvgan_oracle_reproduces_the_reference_modules():
