@@ -986,6 +986,36 @@ def run_broker():
     return out["trace"]
 
 
+def run_dataclasses(R):
+    """Field names and defaults of the record types that cross the boundary: ``GenerationResult`` / ``BatchGenerationResult`` (tts/models/base.py),
+    ``TTSBatchOptions / Item / Event`` (tts/continuous.py), the broker's request / context / chunk records (server_inference.py), Whisper's
+    ``DecodingOptions`` / ``DecodingResult`` (decoding.py), ``STTOutput`` (stt/models/base.py)."""
+    import dataclasses
+    import json
+
+    def fields(cls):
+        out = []
+        for f in dataclasses.fields(cls):
+            d = f.default if f.default is not dataclasses.MISSING else ("<factory>" if f.default_factory is not dataclasses.MISSING else "<required>")
+            out.append([f.name, d if isinstance(d, (int, float, str, bool, type(None))) else repr(d)])
+        return out
+
+    import_qwen3_model()
+    _, dec = import_whisper()
+    base = sys.modules["mlx_audio.tts.models.base"]
+    cont = sys.modules["mlx_audio.tts.continuous"]
+    srv = sys.modules.get("mlx_audio.server_inference") or _load("mlx_audio.server_inference", f"{REF}/server_inference.py")
+    stt = sys.modules.get("mlx_audio.stt.models.base") or _load("mlx_audio.stt.models.base", f"{REF}/stt/models/base.py")
+    out = {"GenerationResult": fields(base.GenerationResult), "BatchGenerationResult": fields(base.BatchGenerationResult),
+           "TTSBatchOptions": fields(cont.TTSBatchOptions), "TTSBatchItem": fields(cont.TTSBatchItem), "TTSBatchEvent": fields(cont.TTSBatchEvent),
+           "InferenceResultChunk": fields(srv.InferenceResultChunk), "InferenceContext": fields(srv.InferenceContext),
+           "InferenceRequest": [f for f in fields(srv.InferenceRequest)], "DecodingOptions": fields(dec.DecodingOptions),
+           "DecodingResult": fields(dec.DecodingResult), "STTOutput": fields(stt.STTOutput)}
+    with open(os.path.join(HERE, "ref_dataclasses.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    return {k: len(v) for k, v in out.items()}
+
+
 def run_sampler(seed):
     """The reference's sampling chain: ``Model._sample_token_batch`` of Qwen3-TTS (suppress ids, per-sequence repetition penalty, temperature, top-k,
     top-p / min-p through ``lm/sample_utils.py``; qwen3_tts.py:862-925) with the final ``categorical_sampling`` replaced by a probe that records the
@@ -1393,6 +1423,7 @@ def main():
     bfx = run_bigvgan(seed_w=6, seed_mel=2, n_frames=50)
     np.savez_compressed(os.path.join(HERE, "ref_bigvgan_tiny.npz"), config=json.dumps(BIGVGAN_TINY), **bfx)
     print("bigvgan:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in bfx.items()}, "peak", float(np.abs(bfx["audio1"]).max()))
+    print("dataclasses:", run_dataclasses(R))
     print("broker:", run_broker())
     print("whisper host helpers:", run_whisper_host())
     print("kokoro pipeline:", run_kokoro_pipeline())
