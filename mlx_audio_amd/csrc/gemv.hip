@@ -639,11 +639,17 @@ int mi355_gemv_mfma_eligible(const mi355_gemv_args& a);
 int mi355_gemv_mfma_launch(const mi355_gemv_args& a, hipStream_t st);
 int mi355_gemv_mfma_fp8_eligible(const mi355_gemv_args& a);
 int mi355_gemv_mfma_fp8_launch(const mi355_gemv_args& a, hipStream_t st);
+// gemm_rows.hip: 9..64 rows (a batch of sequences per decode step), 16-bit weight images
+int mi355_gemm_rows_eligible(const mi355_gemv_args& a);
+int mi355_gemm_rows_launch(const mi355_gemv_args& a, hipStream_t st);
 
 extern "C" int mi355_gemv(const mi355_gemv_args* ap, void* stream) {
   MI355_REQUIRE(ap && ap->x && ap->w && ap->y, "gemv: null tensor");
   mi355_gemv_args a = *ap;
-  MI355_REQUIRE(a.M >= 1 && a.M <= 8, "gemv: M must be in [1, 8] (got %d); use conv_gemm for taller inputs", a.M);
+  MI355_REQUIRE(a.M >= 1 && a.M <= 64, "gemv: M must be in [1, 64] (got %d); use conv_gemm for taller inputs", a.M);
+  MI355_REQUIRE(a.M <= 8 || mi355_gemm_rows_eligible(a),
+                "gemv: 9..64 rows need 16-bit weights, K %% 64 == 0, 16-byte aligned rows and no fused rope / gathered input (M = %d, K = %d, wdtype = %d)",
+                a.M, a.K, a.wdtype);
   MI355_REQUIRE(!a.x_ids || (a.M == 1 && (a.K <= 2048 || (!a.norm && !a.glu && !a.rope_cos))), "gemv: the gathered input exists for one row on the M = 1 kernels");
   MI355_REQUIRE(a.N > 0 && a.K > 0 && a.K % 8 == 0, "gemv: K must be a positive multiple of 8");
   MI355_REQUIRE(a.ldw % 8 == 0 && a.ldw >= a.K && ((uintptr_t)a.w) % 16 == 0, "gemv: weight rows must be 16-byte aligned");
@@ -664,6 +670,7 @@ extern "C" int mi355_gemv(const mi355_gemv_args* ap, void* stream) {
   static const bool two_reads = getenv("MI355_GEMV_TWO_READS") != nullptr;  // A/B knob: statistics from a separate read of x (the older schedule)
   a.norm_two_reads = two_reads ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
+  if (a.M > 8) return mi355_gemm_rows_launch(a, st);
   if (mi355_gemv_mfma_eligible(a)) return mi355_gemv_mfma_launch(a, st);
   if (mi355_gemv_mfma_fp8_eligible(a)) return mi355_gemv_mfma_fp8_launch(a, st);
   if (a.wdtype == MI355_W_FP8) return launch_gemv_m<MI355_W_FP8>(a, st);

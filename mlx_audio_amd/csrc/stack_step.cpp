@@ -1,6 +1,6 @@
 // Native decode-step runner for the decoder-only transformer stacks (host side of libmi355audio.so, gfx950).
 //
-// One call = one single-position step of a whole stack (all layers) for up to 8 sequences: every kernel of the step is launched from
+// One call = one single-position step of a whole stack (all layers) for up to 64 sequences (1..8: the GEMV kernels, 9..64: gemm_rows.hip): every kernel of the step is launched from
 // this C++ loop instead of from Python.  The reference drives the same work op by op from Python on MLX's lazy graph
 // (tts/models/qwen3_tts/talker.py:385-500 TalkerDecoderLayer / Qwen3TTSTalkerModel.__call__, lm/models/llama.py:160-198,
 // stt/models/whisper/whisper.py:405-416, 476-498 ResidualAttentionBlock / TextDecoder with the KV cache); at 100-800 kernels per generated
@@ -46,7 +46,9 @@ int attn_call(const float* q, int ldq, const float* k, const float* v, int64_t k
 extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int32_t B, int32_t offset, float* ws, float* out, void* stream) {
   MI355_REQUIRE(dp && x && ws && dp->layers, "stack_decode_step: null argument");
   const mi355_stack_desc d = *dp;
-  MI355_REQUIRE(B >= 1 && B <= 8, "stack_decode_step: 1..8 sequences per step (got %d)", B);
+  MI355_REQUIRE(B >= 1 && B <= 64, "stack_decode_step: 1..64 sequences per step (got %d)", B);
+  MI355_REQUIRE(B <= 8 || (d.wdtype != MI355_W_FP8 && d.d_model % 64 == 0 && d.d_ff % 64 == 0 && (d.heads * d.dh) % 64 == 0),
+                "stack_decode_step: 9..64 sequences per step need 16-bit weight images and widths that are multiples of 64");
   MI355_REQUIRE(d.n_layers > 0 && d.d_model % 8 == 0 && d.d_ff % 8 == 0 && (d.dh == 64 || d.dh == 128), "stack_decode_step: bad dimensions");
   MI355_REQUIRE(d.wdtype != MI355_W_FP8 || (d.d_model % 16 == 0 && d.d_ff % 16 == 0), "stack_decode_step: fp8 images need d_model, d_ff multiples of 16");
   MI355_REQUIRE(d.norm == 1 || d.norm == 2, "stack_decode_step: norm must be 1 (LayerNorm) or 2 (RMSNorm)");

@@ -8,8 +8,8 @@ One parametrised engine replaces four separately written reference stacks (file:
 
 Per layer (prefill, L > 1 rows per sequence):      norm -> [q | kv] GEMMs (kv lands in its KV-cache slot) -> per-head RMSNorm + RoPE in place
   -> flash attention over the cache -> o-proj GEMM with LayerScale + residual in the epilogue -> norm -> gate|up GEMM -> SwiGLU
-  -> down GEMM with LayerScale + residual.   Decode step (1 row per sequence, <= 8 sequences): every GEMM becomes the HBM-bound GEMV on
-  the row-major bf16 image, SwiGLU is fused into the gate|up GEMV, attention is the KV-streaming kernel.
+  -> down GEMM with LayerScale + residual.   Decode step (1 row per sequence, <= 64 sequences): every GEMM becomes the weight-streaming GEMV on
+  the row-major bf16 image (1..8 rows: FMA / MFMA GEMV kernels, 9..64 rows: the matrix-pipe kernel of gemm_rows.hip), SwiGLU is fused into the gate|up GEMV, attention is the KV-streaming kernel.
 
 ``KVCache`` mirrors lm/models/cache.py:104-176 (capacity grows in steps of 256, in-place slice update, ``offset``, ``trim``) with one
 [B, capacity, 2 * n_kv * dh] fp32 buffer per layer (k | v side by side: one GEMM writes both).
@@ -151,9 +151,17 @@ def effective_weights(weights: Dict[str, torch.Tensor], cfg: "StackConfig", weig
     return w
 
 
-def is_decode(x: torch.Tensor) -> bool:
-    """1 row per sequence and at most 8 sequences: the shape the GEMV / KV-streaming path is built for."""
-    return x.shape[1] == 1 and x.shape[0] <= 8
+MAX_DECODE_ROWS = 64   # mi355_gemv: 1..8 rows on the GEMV kernels, 9..64 rows on the matrix-pipe kernel of gemm_rows.hip
+
+
+def decode_rows(l: "Lin") -> int:
+    """Most sequences a single-position step through ``l`` may carry on the GEMV path: 64 for 16-bit images with K % 64 == 0, else 8."""
+    return MAX_DECODE_ROWS if (l.rm.wdtype != 2 and l.rm.k % 64 == 0) else 8
+
+
+def is_decode(x: torch.Tensor, l: Optional["Lin"] = None) -> bool:
+    """1 row per sequence and few enough sequences for the weight-streaming GEMV path (``decode_rows``; 8 when no image is named)."""
+    return x.shape[1] == 1 and x.shape[0] <= (8 if l is None else decode_rows(l))
 
 
 def linear(x: torch.Tensor, l: Lin, y: torch.Tensor, *, post_act: int = ACT_NONE, res: Optional[torch.Tensor] = None,
@@ -161,7 +169,7 @@ def linear(x: torch.Tensor, l: Lin, y: torch.Tensor, *, post_act: int = ACT_NONE
            y2: Optional[torch.Tensor] = None):
     """y = act(norm(x) W^T + b) * colscale + res on [B, L, C] views; 1-row-per-sequence inputs with B <= 8 take the GEMV
     (``norm`` / ``y2`` -- fused input normalisation and split destination -- exist on that path only)."""
-    if is_decode(x):
+    if is_decode(x, l):
         ops.gemv(x[:, 0, :], l.rm, y[:, 0, :], post_act=post_act, res=None if res is None else res[:, 0, :], colscale=colscale, glu=glu,
                  norm=norm, y2=None if y2 is None else y2[:, 0, :])
     else:
@@ -201,6 +209,8 @@ class TransformerStack:
         self.device = torch.device(device)
         self.precision = precision
         self.native_decode = True  # single-position steps go through mi355_stack_decode_step (False: the per-op Python schedule)
+        # sequences per single-position step on the weight-streaming path: 9..64 need 16-bit images and widths that are multiples of 64
+        self.max_decode_rows = MAX_DECODE_ROWS if (not fp8 and cfg.d_model % 64 == 0 and cfg.d_ff % 64 == 0 and (cfg.n_heads * cfg.head_dim) % 64 == 0) else 8
         dev = self.device
         w = {k[len(prefix):]: v.detach().to(torch.bfloat16).to(torch.float32).cpu() for k, v in weights.items() if k.startswith(prefix)}
 
@@ -292,7 +302,7 @@ class TransformerStack:
             raise ValueError(f"sequence position {offset + n_new - 1} is past the {self.cos.shape[0]}-row rotary tables (max_pos) of this stack")
 
     def decode_step(self, x: torch.Tensor, cache: List[KVCache], k_start: Optional[torch.Tensor] = None, defer_final_norm: bool = False) -> torch.Tensor:
-        """One single-position step for B <= 8 sequences through the native runner: x [B, 1, d_model] (updated in place); returns the
+        """One single-position step for B <= ``max_decode_rows`` sequences through the native runner: x [B, 1, d_model] (updated in place); returns the
         final-normed hidden state [B, 1, d_model] (or x itself when the stack has no final norm).  ``k_start`` int32 [B]: left padding.
         ``defer_final_norm``: return the UN-normalised residual stream; the caller fuses the final norm into the GEMV that consumes it
         (``final_norm_arg()`` is the ``norm=`` tuple for ``linear``): one launch less per step."""
@@ -336,7 +346,8 @@ class TransformerStack:
             cache = self.make_cache()
         if k_start is not None:
             assert k_start.dtype == torch.int32 and k_start.shape == (B,) and k_start.is_cuda
-        if is_decode(x) and not return_layers and self.native_decode:
+        decode = L == 1 and B <= self.max_decode_rows
+        if decode and not return_layers and self.native_decode:
             return self.decode_step(x, cache, k_start, defer_final_norm)
         assert not defer_final_norm, "defer_final_norm exists on the single-position decode path only"
         self._check_positions(cache[0].offset, L)
@@ -347,7 +358,6 @@ class TransformerStack:
         ff_w = c.d_ff
         mid = torch.empty((B, L, ff_w), dtype=torch.float32, device=dev)
         gu = None
-        decode = is_decode(x)
         if c.mlp == "swiglu" and not decode:
             gu = torch.empty((B, L, 2 * c.d_ff), dtype=torch.float32, device=dev)
         act = {"gelu": ACT_GELU, "gelu_tanh": ACT_GELU_TANH}.get(c.mlp, ACT_NONE)

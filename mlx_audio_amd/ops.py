@@ -177,7 +177,7 @@ def gemv(x: torch.Tensor, rw: RowMajor16, y: torch.Tensor, *, post_act: int = AC
          res: Optional[torch.Tensor] = None, colscale: Optional[torch.Tensor] = None, out_scale: float = 1.0, glu: bool = False,
          use_bias: bool = True, norm: Optional[tuple] = None, y2: Optional[torch.Tensor] = None, rope: Optional[tuple] = None,
          x_ids: Optional[torch.Tensor] = None, x_id_offset: int = 0):
-    """y[m, :] = epilogue(norm(x[m, :]) @ W^T) for 1..8 rows; x / y / res are 2-D fp32 views with unit inner stride.
+    """y[m, :] = epilogue(norm(x[m, :]) @ W^T) for 1..8 rows (any weight image) or 9..64 rows (16-bit images, K % 64 == 0); x / y / res are 2-D fp32 views with unit inner stride.
     ``norm`` = (mode, weight, bias, eps) with mode "layer" | "rms" fuses the input normalisation; ``y2``: columns >= y.shape[1] go there."""
     assert x.dim() == 2 and y.dim() == 2 and x.stride(1) == 1 and y.stride(1) == 1 and x.dtype == torch.float32 and y.dtype == torch.float32
     M = x.shape[0] if x_ids is None else 1   # x_ids int32 [1] (device): x is then a TABLE and the input row is x[x_ids[0] + x_id_offset]

@@ -221,7 +221,7 @@ class Qwen3Talker:
             for c in cp_cache:
                 c.reset()
             for i in range(G - 1):
-                if i == 0 and B <= 8:
+                if i == 0 and B <= self.cp.max_decode_rows:
                     # step 0 feeds two positions, [last_hidden, embed(code0)] (qwen3_tts.py:961-966).  With a causal stack and a KV cache
                     # that is exactly two single-position steps, and single-position steps run on the GEMV / KV-streaming path instead
                     # of a 2-row MFMA tile; only the second position's output is used.
@@ -244,7 +244,7 @@ class Qwen3Talker:
                     xp = self._f(B, xin.shape[1], cp.hidden_size)
                     linear(xin, self.mtp, xp, precision=self.precision)
                     xin = xp
-                if xin.shape[1] == 1 and B <= 8 and self.cp.native_decode and self.cp.cfg.d_model <= 2048:
+                if xin.shape[1] == 1 and B <= self.cp.max_decode_rows and self.cp.native_decode and (B > 8 or self.cp.cfg.d_model <= 2048):
                     # the code predictor's final RMSNorm runs inside the lm_head GEMV (fused-norm prologue): one launch less per code group
                     hc = self.cp(xin, cp_cache, defer_final_norm=True)
                     lg = self._logits(hc, self.lm_heads[i], norm=self.cp.final_norm_arg())

@@ -141,7 +141,7 @@ class CSMEngine:
             c.reset()
         Dd = cfg.decoder.d_model
         for i in range(1, nb):
-            if i == 1 and B <= 8:
+            if i == 1 and B <= self.decoder.max_decode_rows:
                 # [last_h, c0_embed] (sesame.py:380) as two single-position steps through the causal depth decoder: same result, and single
                 # positions run on the GEMV / KV-streaming path; only the second position's output is used
                 p0 = self._f(B, 1, Dd)
@@ -166,7 +166,7 @@ class CSMEngine:
                 ops.gemv(self.table, self.projection.rm, p[:, 0, :], x_ids=sample[0, i - 1:i], x_id_offset=(i - 1) * V)
             else:
                 linear(cur, self.projection, p, precision=self.precision)
-            if p.shape[1] == 1 and B <= 8 and self.decoder.native_decode:
+            if p.shape[1] == 1 and B <= self.decoder.max_decode_rows and self.decoder.native_decode:
                 # the depth decoder's final RMSNorm runs inside the head GEMV (its fused-norm prologue): one launch less per codebook
                 dh = self.decoder(p, cache, defer_final_norm=True)
                 draw(self._logits(dh, self.heads[i - 1], norm=self.decoder.final_norm_arg()), i)

@@ -323,3 +323,67 @@ def test_stack_fp8_weight_images(ops, name, B, L):
             assert rel_err(o, e) < 2e-4, (s, rel_err(o, e))
         q_err = rel_err(e, e16)
         assert 1e-4 < q_err < 0.25, q_err   # fp8 is a different model from bf16 by a bounded amount (and not accidentally the same weights)
+
+
+# ------------------------------------------------------------------------------------------------ the stacks of BASELINE configs [3] / [4] at their real widths
+def _real_width_configs():
+    """Layer shapes of Qwen3-TTS-1.7B (talker, code predictor: config.py:36-73) and CSM-1B (Llama backbone, depth decoder: sesame.py:204-299), built by
+    the product's own config functions; DEPTH is cut to 3 layers -- kernel dispatch (K > 2048 split-K, the 50 MB gate | up image, FMA / MFMA / 9..64-row
+    kernels) depends on the widths and the row count, not on how many layers repeat them -- so the CPU oracle finishes in seconds."""
+    from dataclasses import replace
+
+    from mlx_audio_amd.tts.models.qwen3_tts import talker as T
+    from mlx_audio_amd.tts.models.qwen3_tts.config import talker_1p7b
+    from mlx_audio_amd.tts.models.sesame.engine import csm_1b
+
+    q, c = talker_1p7b(), csm_1b()
+    assert (q.hidden_size, q.intermediate_size, q.num_attention_heads, q.num_key_value_heads, q.head_dim) == (2048, 6144, 16, 8, 128)
+    assert (c.backbone.d_model, c.backbone.d_ff, c.decoder.d_model, c.decoder.d_ff) == (2048, 8192, 1024, 8192)
+    return {
+        "qwen3_talker_1p7b": replace(T.talker_stack_config(q), n_layers=3, max_pos=256),
+        "qwen3_code_predictor": replace(T.talker_stack_config(q.code_predictor_config), n_layers=3, max_pos=256),
+        "csm_backbone_1b": replace(c.backbone, n_layers=3, max_pos=256),
+        "csm_decoder_100m": replace(c.decoder, n_layers=3, max_pos=256),
+    }
+
+
+_REAL_CACHE = {}
+
+
+def _real_stack(name):
+    if name not in _REAL_CACHE:
+        from mlx_audio_amd.lm.stack import TransformerStack
+        from mlx_audio_amd.lm.synthetic import make_stack_weights
+        from oracle.lm_ref import StackConfig as RefConfig, StackRef
+
+        _REAL_CACHE.clear()   # one set of full-width weights at a time (host memory)
+        cfg = _real_width_configs()[name]
+        w = make_stack_weights(cfg, seed=21)
+        _REAL_CACHE[name] = (cfg, StackRef(w, RefConfig(**asdict(cfg))), TransformerStack(w, cfg, device=DEV))
+    return _REAL_CACHE[name]
+
+
+@pytest.mark.parametrize("B", [1, 8, 64])
+@pytest.mark.parametrize("name", ["qwen3_talker_1p7b", "qwen3_code_predictor", "csm_backbone_1b", "csm_decoder_100m"])
+def test_stack_real_widths_prefill_and_decode(ops, name, B):
+    """Engine-level parity at the widths of Qwen3-TTS-1.7B and CSM-1B: one prefill (5 positions) + 3 single-position decode steps through the
+    native step runner, teacher-forced inputs, B = 1 (M = 1 GEMVs, K > 2048 split-K), 8 (matrix-pipe GEMV / FMA on the long-K images) and 64 (gemm_rows.hip:
+    BASELINE config[3]'s batch), against the CPU oracle; bar 2e-4 of the peak of the hidden state."""
+    cfg, ref, eng = _real_stack(name)
+    assert eng.max_decode_rows == 64
+    g = torch.Generator().manual_seed(31 + B)
+    L, steps = 5, 3
+    x = torch.randn(B, L + steps, cfg.d_model, generator=g)
+    rc, ec = ref.make_cache(), eng.make_cache()
+    exp = ref(x[:, :L], rc)
+    got = eng(x[:, :L].contiguous().to(DEV), ec)
+    torch.cuda.synchronize()
+    assert rel_err(got, exp) < 2e-4, rel_err(got, exp)
+    for s in range(steps):
+        xs = x[:, L + s:L + s + 1].contiguous()
+        e = ref(xs, rc)
+        o = eng(xs.to(DEV), ec)
+        torch.cuda.synchronize()
+        assert o.shape == (B, 1, cfg.d_model) and bool(torch.isfinite(o).all())
+        assert rel_err(o, e) < 2e-4, (s, rel_err(o, e))
+    assert ec[0].offset == L + steps

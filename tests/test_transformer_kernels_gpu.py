@@ -588,9 +588,24 @@ def test_gemv_fp8_weights(ops, M, N, K, act, use_res, glu):
     (6, 2048, 6144, False, None, False, 0, True, 0),          # talker down + residual, three k chunks, 6 rows
     (5, 1040, 1024, False, "rms", False, 5, False, 0),        # N not a multiple of 16, SiLU
     (7, 30, 64, False, None, False, 0, False, 0),             # one k step, tiny N
+    # ---- 9..64 rows: gemm_rows.hip (a batch of sequences per decode step; BASELINE config[3] = 64 utterances)
+    (64, 4096, 2048, False, "rms", False, 0, False, 2048),    # talker q | k | v at 64 rows: fused RMSNorm, k | v into a strided cache slot
+    (64, 12288, 2048, False, "rms", True, 0, False, 0),       # talker gate | up: fused RMSNorm + SwiGLU, 768 tiles over 512 workgroups
+    (64, 2048, 6144, False, None, False, 0, True, 0),         # talker down + residual, 24 chunks of K
+    (64, 2048, 2048, False, None, False, 0, True, 0),         # talker o-proj + residual
+    (33, 1024, 3072, False, None, False, 5, True, 0),         # code predictor down, 33 rows (3 row groups of the 64-row kernel), SiLU
+    (32, 6144, 1024, False, "rms", True, 0, False, 0),        # code predictor gate | up at 32 rows (the 32-row kernel)
+    (17, 3072, 2048, False, "rms", False, 0, False, 0),       # codec head with the deferred final norm, 17 rows
+    (16, 2051, 2048, False, None, False, 0, False, 0),        # 16 rows (the 16-row kernel), N not a multiple of 16
+    (9, 1040, 1024, False, "rms", False, 5, False, 0),        # 9 rows, ragged last tile
+    (12, 51865, 768, True, "layer", False, 0, False, 0),      # Whisper logits at 12 rows: LayerNorm with bias, fp16 weights, 7 tile groups
+    (24, 2304, 768, True, "layer", False, 0, False, 768),     # Whisper q | k | v at 24 rows
+    (40, 768, 3072, True, None, False, 3, True, 0),           # Whisper mlp2 at 40 rows, GELU + residual
+    (64, 48, 64, False, None, False, 0, False, 0),            # one k step, 3 tiles
+    (10, 30, 128, False, "layer", False, 0, False, 0),        # tiny
 ])
 def test_gemv_matrix_pipe(ops, M, N, K, f16, mode, glu, act, use_res, split):
-    """gemv_mfma.hip (5..8 rows): every epilogue / prologue combination the decode steps use, against float64."""
+    """gemv_mfma.hip (5..8 rows) and gemm_rows.hip (9..64 rows): every epilogue / prologue combination the decode steps use, against float64."""
     g = torch.Generator().manual_seed(M + N + K)
     w = _round16(torch.randn(N, K, generator=g) / math.sqrt(K), f16)
     bias = torch.randn(N, generator=g) * 0.1

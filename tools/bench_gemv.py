@@ -31,6 +31,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=300)
     ap.add_argument("--tag", default="")
+    ap.add_argument("--rows", type=int, default=0, help="override M of every Qwen3 / Whisper shape (9..64: the gemm_rows.hip kernel)")
     args = ap.parse_args()
     from mlx_audio_amd import ops
 
@@ -38,6 +39,10 @@ def main():
     g = torch.Generator().manual_seed(0)
     rows = []
     for label, M, N, K, norm, glu, f16 in SHAPES:
+        if args.rows:
+            if label.startswith("csm"):
+                continue
+            M = args.rows
         w = (torch.randn(N, K, generator=g) / K ** 0.5)
         w = w.half().float() if f16 else w.bfloat16().float()
         rw = ops.pack_rowmajor16(w, torch.zeros(N), dev, f16=f16)
