@@ -469,6 +469,13 @@ typedef struct {
   const float* new_k; const float* new_v; int64_t new_bstride;
   const float* q_norm_w; const float* k_norm_w; float norm_eps;
   const float* rope_cos; const float* rope_sin; int32_t rope_rows; int32_t rope_mode; int32_t rope_pos;
+  /* the fused step inside the rows pipeline (steps of 9..64 sequences): in_kgroups > 1: q / new_k / new_v point into slab 0 of mi355_rows_gemm's
+     partial sums and the kernel adds the in_kgroups slabs (in_kg_stride floats apart, fixed order) plus the projection bias (q_bias [heads dh],
+     k_bias / v_bias [kv_heads dh], nullable) itself -- the q | k | v projection needs no separate row epilogue.  out_planes (nullable): the output
+     rows additionally (out may then be null) leave as planes of planes_R rows in planes_dtype (MI355_W_BF16 / MI355_W_F16) for the o-proj GEMM;
+     item b is row b.  Both need Tq == 1. */
+  int32_t in_kgroups; int64_t in_kg_stride; const float* q_bias; const float* k_bias; const float* v_bias;
+  uint16_t* out_planes; int32_t planes_R; int32_t planes_dtype;
 } mi355_flash_attn_args;
 int mi355_flash_attention(const mi355_flash_attn_args* a, void* stream);
 
@@ -645,7 +652,8 @@ typedef struct {
 int mi355_sample(const mi355_sample_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Native decode-step runner: one call launches every kernel of a single-position step of a whole decoder stack (<= 8 sequences),
+ * Native decode-step runner: one call launches every kernel of a single-position step of a whole decoder stack (<= 64 sequences; 9..64 run
+ * the rows pipeline -- mi355_rows_gemm / mi355_rows_finish -- on the tile images of the layer records),
  * replacing the per-op Python schedule of TalkerDecoderLayer / Qwen3TTSTalkerModel.__call__ (tts/models/qwen3_tts/talker.py:385-500),
  * CodePredictorModel (talker.py:615-690), LlamaModel (lm/models/llama.py:160-198) and Whisper's TextDecoder blocks with self- and
  * cross-attention (stt/models/whisper/whisper.py:405-416, 476-498).  All weights are row-major 16-bit images (mi355_pack_rowmajor16_host);
@@ -668,6 +676,8 @@ typedef struct {
   int32_t cross_kv_dtype;   /* MI355_KV_F32 / MI355_KV_BF16 / MI355_KV_F16: element type of cross_k / cross_v (strides in elements) */
   /* wdtype == MI355_W_FP8: per-row scales of the six images (mi355_pack_rowmajor_fp8_host), else null */
   const float* s_qkv; const float* s_o; const float* s_in; const float* s_out; const float* s_cq; const float* s_co;
+  /* steps for 9..64 sequences: tile images (mi355_pack_tiles16_host) of the four projections; null = this layer only runs steps of <= 8 sequences */
+  const uint16_t* wqkv_t; const uint16_t* wo_t; const uint16_t* w_in_t; const uint16_t* w_out_t;
 } mi355_layer_desc;
 
 typedef struct {
@@ -690,11 +700,55 @@ typedef struct {
   int32_t kv_dtype;        /* MI355_KV_F32 / MI355_KV_BF16 / MI355_KV_F16: element type of every layer's kv buffer (the reference keeps its caches in the
                               checkpoint dtype, lm/models/cache.py:104-176).  16-bit caches need the stores that exist: q|k|v GEMV with the rotary pairs in its
                               epilogue, the fused norm / rope attention step, or no rotary embedding at all */
+  void* rows_ws; int64_t rows_ws_bytes;   /* steps for 9..64 sequences: planes + partial slabs, mi355_stack_rows_ws_bytes(d, B) bytes (nullable otherwise) */
 } mi355_stack_desc;
+
+/* ------------------------------------------------------------------------------------------
+ * Decode steps for a batch of 9..64 sequences (BASELINE config[3]: 64 utterances; the reference's batched generation
+ * tts/models/qwen3_tts/qwen3_tts.py:1651-2060 over talker.py:229-336, 385-500): nn.Linear at sequence length 1 as
+ *   mi355_rows_gemm   (pure matrix-pipe GEMM: tile image of W x pre-split input planes -> fp32 partial slabs, one per K group)
+ *   mi355_rows_finish (row epilogue: sum of the slabs in a fixed order, then the epilogue of mi355_gemv, optional normalisation of the
+ *                      finished row, optional output as planes for the next mi355_rows_gemm; kgroups = 1: converter fp32 rows -> planes).
+ * Planes: the input rows as hi + lo images of the weights' 16-bit type (x ~= hi + lo: ~16 mantissa bits for bf16, ~22 for fp16) in MFMA fragment
+ * order: 16-byte piece ((((s * 2 + image) * 2 + half) * 4 + group) * R + row) holds x[row][64 s + 16 group + 8 half .. + 8), R = 16 / 32 / 64 rows;
+ * 4 * R * K bytes for K columns.  Rows >= M of the planes are never read into a stored result.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const uint16_t* wt;       /* tile image of W [N, K] from mi355_pack_tiles16_host */
+  int32_t wdtype;           /* MI355_W_BF16 / MI355_W_F16 (planes must hold the same type) */
+  int32_t N; int32_t K;     /* K % 64 == 0 */
+  const uint16_t* planes;   /* the input rows (written by mi355_rows_finish) */
+  int32_t M; int32_t R;     /* rows in use / rows of the planes (16, 32 or 64) */
+  float* part;              /* slab g at part + g * kg_stride: [M, ldp] fp32 partial sums over the g-th range of k steps */
+  int32_t ldp; int64_t kg_stride;
+  int32_t kgroups;          /* mi355_rows_kgroups(N, K) (or any count that leaves no K group empty) */
+} mi355_rows_gemm_args;
+int mi355_rows_gemm(const mi355_rows_gemm_args* a, void* stream);
+int32_t mi355_rows_kgroups(int32_t N, int32_t K);
+/* fp32 [N, K] (host) -> tile image: element e of (tile t, k step s, group g, row i) = W[16 t + i][64 s + 16 g + e], stored
+ * [ceil(N / 16)][K / 64][4][16][16]; rows past N are zero.  out: ceil(N / 16) * 16 * K 16-bit elements.  dtype: MI355_W_BF16 / MI355_W_F16 */
+int mi355_pack_tiles16_host(const float* w_host, int64_t N, int64_t K, int32_t dtype, uint16_t* out_host);
+
+typedef struct {
+  const float* part; int32_t kgroups; int64_t kg_stride; int32_t ldp;   /* input: sum over g of part[g * kg_stride + m * ldp + n]; kgroups = 1: a plain fp32 matrix */
+  int32_t M; int32_t N;
+  /* epilogue of mi355_gemv: v = act(sum + bias[n]) * colscale[n] + res[m, n]; v *= out_scale;  glu = 1: columns are (gate, up) pairs and
+     v[m, n / 2] = silu(gate + b) * (up + b) * out_scale */
+  const float* bias; int32_t post_act; float post_slope; const float* colscale; const float* res; int32_t ldr; float out_scale; int32_t glu;
+  float* y; int32_t ldy;    /* nullable: the finished row as fp32 (may alias res) */
+  float* y2; int32_t ldy2; int32_t split; int32_t y2_dtype;   /* nullable: columns >= split go to y2[m, n - split] (the KV-cache slot, MI355_KV_*) */
+  /* optional normalisation of the finished row over its N (glu: N / 2) outputs, feeding yn / planes: 1 = LayerNorm, 2 = RMSNorm */
+  int32_t norm; const float* norm_weight; const float* norm_bias; float norm_eps;
+  float* yn; int32_t ldyn;  /* nullable: the (normalised) row as fp32 (a stack's final norm) */
+  uint16_t* planes; int32_t R; int32_t planes_dtype;   /* nullable: the (normalised) row as planes of R rows in MI355_W_BF16 / MI355_W_F16 (row length % 64 == 0) */
+} mi355_rows_finish_args;
+int mi355_rows_finish(const mi355_rows_finish_args* a, void* stream);
 
 /* x [B, d_model] (updated in place: the residual stream), ws: workspace of B * (2 * heads * dh + d_ff + 2 * kv_heads * dh) floats, out (nullable) [B, d_model]
  * receives the final-normed hidden state when final_norm_w is set.  offset = rows already in the KV caches. */
 int mi355_stack_decode_step(const mi355_stack_desc* d, float* x, int32_t B, int32_t offset, float* ws, float* out, void* stream);
+/* bytes of mi355_stack_desc.rows_ws a step of B (9..64) sequences needs (planes of the three GEMM inputs + the largest set of partial slabs) */
+int64_t mi355_stack_rows_ws_bytes(const mi355_stack_desc* d, int32_t B);
 
 #ifdef __cplusplus
 }

@@ -478,9 +478,19 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
     for (int t = tid; t < DH; t += NW * 64) qs[t] = a.q[(int64_t)b * a.q_bstride + (int64_t)qi * a.ldq + h * DH + t] * qsc;
   } else {
     for (int t = tid; t < DH; t += NW * 64) {
-      qs[t] = a.q[(int64_t)b * a.q_bstride + (int64_t)qi * a.ldq + h * DH + t];
-      ks_new[t] = a.new_k[(int64_t)b * a.new_bstride + g * DH + t];
-      vs_new[t] = kv_round<KVT>(a.new_v[(int64_t)b * a.new_bstride + g * DH + t]);   // as the cache will hold it (the reference attends over the cache)
+      const int64_t iq = (int64_t)b * a.q_bstride + (int64_t)qi * a.ldq + h * DH + t, ik = (int64_t)b * a.new_bstride + g * DH + t;
+      float q0 = a.q[iq], k0 = a.new_k[ik], v0 = a.new_v[ik];
+      for (int sl = 1; sl < a.in_kgroups; ++sl) {   // rows pipeline: the projection arrives as K-group slabs (summed in slab order: deterministic)
+        q0 += a.q[iq + sl * a.in_kg_stride];
+        k0 += a.new_k[ik + sl * a.in_kg_stride];
+        v0 += a.new_v[ik + sl * a.in_kg_stride];
+      }
+      if (a.q_bias) q0 += a.q_bias[h * DH + t];
+      if (a.k_bias) k0 += a.k_bias[g * DH + t];
+      if (a.v_bias) v0 += a.v_bias[g * DH + t];
+      qs[t] = q0;
+      ks_new[t] = k0;
+      vs_new[t] = kv_round<KVT>(v0);   // as the cache will hold it (the reference attends over the cache)
     }
     __syncthreads();
     if (wave < 2) {  // wave 0: q, wave 1: k -- the arithmetic of head_norm_rope_kernel (transformer.hip), same order
@@ -710,15 +720,48 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
       if (lane == 0) a.split_cnt[idx] = 0;  // leave the counters zeroed for the next launch
     }
     const float inv = L > 0.f ? 1.0f / L : 0.f;
+    if (a.out) {
 #pragma unroll
-    for (int i = 0; i < ND; ++i) orow[i * 64 + lane] = t[i] * inv;
+      for (int i = 0; i < ND; ++i) orow[i * 64 + lane] = t[i] * inv;
+    }
+    if (a.out_planes) {   // the row also leaves as hi + lo planes (fragment order of mi355_rows_gemm): lane c < DH / 8 builds the piece of channels 8 c .. 8 c + 7
+#pragma unroll
+      for (int i = 0; i < ND; ++i) red_o[0][i * 64 + lane] = t[i] * inv;
+      wave_lds_sync2();
+      if (lane < DH / 8) {
+        float e[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) e[u] = red_o[0][8 * lane + u];
+        uint4 hi, lo;
+        if (a.planes_dtype == MI355_W_F16) {
+          auto sp2 = [](float x, float y, uint32_t& hh, uint32_t& ll) {
+            hh = pack_f16x2(x, y);
+            const float hx = (float)__builtin_bit_cast(_Float16, (uint16_t)(hh & 0xffffu)), hy = (float)__builtin_bit_cast(_Float16, (uint16_t)(hh >> 16));
+            ll = pack_f16x2(x - hx, y - hy);
+          };
+          sp2(e[0], e[1], hi.x, lo.x); sp2(e[2], e[3], hi.y, lo.y); sp2(e[4], e[5], hi.z, lo.z); sp2(e[6], e[7], hi.w, lo.w);
+        } else {
+          auto sp2 = [](float x, float y, uint32_t& hh, uint32_t& ll) {
+            hh = pack_bf16x2(x, y);
+            const float hx = __builtin_bit_cast(float, hh << 16), hy = __builtin_bit_cast(float, hh & 0xffff0000u);
+            ll = pack_bf16x2(x - hx, y - hy);
+          };
+          sp2(e[0], e[1], hi.x, lo.x); sp2(e[2], e[3], hi.y, lo.y); sp2(e[4], e[5], hi.z, lo.z); sp2(e[6], e[7], hi.w, lo.w);
+        }
+        const int k = h * DH + 8 * lane;   // column of the attention output row
+        const int s = k >> 6, gq = (k & 63) >> 4, hh = (k >> 3) & 1;
+        uint4* const pl = (uint4*)a.out_planes;
+        pl[(((s * 2 + 0) * 2 + hh) * 4 + gq) * a.planes_R + b] = hi;
+        pl[(((s * 2 + 1) * 2 + hh) * 4 + gq) * a.planes_R + b] = lo;
+      }
+    }
   }
 }
 
 }  // namespace
 
 extern "C" int mi355_flash_attention(const mi355_flash_attn_args* ap, void* stream) {
-  MI355_REQUIRE(ap && ap->q && ap->k && ap->v && ap->out, "flash_attention: null tensor");
+  MI355_REQUIRE(ap && ap->q && ap->k && ap->v && (ap->out || ap->out_planes), "flash_attention: null tensor");
   mi355_flash_attn_args a = *ap;
   MI355_REQUIRE(a.dh == 64 || a.dh == 128, "flash_attention: head dim must be 64 or 128 (got %d)", a.dh);
   MI355_REQUIRE(a.heads > 0 && a.kv_heads > 0 && a.heads % a.kv_heads == 0, "flash_attention: heads must be a multiple of kv_heads");
@@ -726,7 +769,12 @@ extern "C" int mi355_flash_attention(const mi355_flash_attn_args* ap, void* stre
   MI355_REQUIRE(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && a.ldo % 4 == 0 && a.q_bstride % 4 == 0 && a.k_bstride % 4 == 0 &&
                     a.v_bstride % 4 == 0 && a.out_bstride % 4 == 0,
                 "flash_attention: strides must be multiples of 4 floats");
-  MI355_REQUIRE(((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.out) % 16 == 0, "flash_attention: tensors must be 16-byte aligned");
+  MI355_REQUIRE(((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.out | (uintptr_t)a.out_planes) % 16 == 0, "flash_attention: tensors must be 16-byte aligned");
+  MI355_REQUIRE(a.in_kgroups <= 1 || (a.new_k && a.in_kg_stride > 0), "flash_attention: slab inputs exist for the fused decode step only");
+  MI355_REQUIRE(!a.out_planes || (a.Tq == 1 && a.mode != 1 && a.nsplit <= 1 && (a.planes_R == 16 || a.planes_R == 32 || a.planes_R == 64) && a.B <= a.planes_R &&
+                                  (a.planes_dtype == MI355_W_BF16 || a.planes_dtype == MI355_W_F16)),
+                "flash_attention: a planes output needs a single-query decode step of at most planes_R (16 / 32 / 64) items");
+  MI355_REQUIRE(a.out || a.out_planes, "flash_attention: no destination");
   MI355_REQUIRE(a.window >= 0, "flash_attention: window must be >= 0");
   MI355_REQUIRE(a.kv_dtype >= MI355_KV_F32 && a.kv_dtype <= MI355_KV_F16, "flash_attention: kv_dtype must be MI355_KV_F32, MI355_KV_BF16 or MI355_KV_F16");
   const int kvt = a.kv_dtype;

@@ -73,7 +73,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 template <int MR, bool F16>
-__global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mi355_gemv_args a, const int ntiles) {
+__global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mi355_gemv_args a, const int ntiles, const int dbg) {
   using C = rows_cfg<MR>;
   constexpr int R = C::R, KC = C::KC, SPW = C::SPW, T = C::T, P = C::P;
   constexpr int IMGW = SPW * 8 * R;     // 16-byte pieces per image of ONE wave's window
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mi355_gemv_args
   uint4* const win = planes + wave * (2 * IMGW);
 
   // ---- fused norm: statistics of every row (wave w takes rows w, w + 4, ...), fp64 sums of one pass
-  if (a.norm) {
+  if (a.norm && !(dbg & 32)) {
     for (int m = wave; m < M; m += 4) {
       const float* xr = a.x + (int64_t)m * a.ldx;
       double s = 0.0, ss = 0.0;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mi355_gemv_args
 #pragma unroll
         for (int u = 0; u < SPW; ++u) {
           const int k = c * KC + (wave + 4 * u) * 64;
-          if (tv[j] && k < K) {
+          if (tv[j] && k < K && !(dbg & 16)) {
             const uint16_t* p = wrow[j] + k;
             dst[j][u][0] = *(const uint4*)p;
             dst[j][u][1] = *(const uint4*)(p + 8);
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mi355_gemv_args
         for (int rb = 0; rb < 2 * MR; ++rb) {
           const int m = 8 * rb + srow;
           xr[u][rb][0] = xr[u][rb][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (m < M && k < K) {
+          if (m < M && k < K && !(dbg & 1)) {
             const float* p = a.x + (int64_t)m * a.ldx + k;
             xr[u][rb][0] = *(const float4*)p;
             xr[u][rb][1] = *(const float4*)(p + 4);
@@ -180,12 +180,18 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mi355_gemv_args
             if (m >= M) v0 = v1 = make_float4(0.f, 0.f, 0.f, 0.f);
           }
           uint4 hi, lo;
+          if (dbg & 2) {
+            hi = __builtin_bit_cast(uint4, v0); lo = __builtin_bit_cast(uint4, v1);
+          } else {
           rows_split2<F16>(v0.x, v0.y, hi.x, lo.x);
           rows_split2<F16>(v0.z, v0.w, hi.y, lo.y);
           rows_split2<F16>(v1.x, v1.y, hi.z, lo.z);
           rows_split2<F16>(v1.z, v1.w, hi.w, lo.w);
+          }
+          if (!(dbg & 4)) {
           win[base + m] = hi;
           win[IMGW + base + m] = lo;
+          }
         }
       }
     };
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mi355_gemv_args
           wave_lds_fence();
 #pragma unroll
           for (int u = 0; u < SPW; ++u) {
-            if (c * KC + (wave + 4 * u) * 64 < K) {
+            if (c * KC + (wave + 4 * u) * 64 < K && !(dbg & 8)) {
               uint4 w0[T], w1[T];
 #pragma unroll
               for (int j = 0; j < T; ++j) { w0[j] = ring[p][j][u][0]; w1[j] = ring[p][j][u][1]; }
@@ -285,7 +291,8 @@ int launch_rows(const mi355_gemv_args& a, hipStream_t st) {
   const int cap = wgs_env > 0 ? wgs_env : 512;   // two 64 KB workgroups per CU
   const int grid = ntiles < cap ? ntiles : cap;
   MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL((gemm_rows_kernel<MR, F16>), dim3(grid), dim3(256), lds, st, a, ntiles);
+  static const int dbg = getenv("MI355_GEMM_ROWS_DBG") ? atoi(getenv("MI355_GEMM_ROWS_DBG")) : 0;   // ablation bits (timing experiments only)
+  hipLaunchKernelGGL((gemm_rows_kernel<MR, F16>), dim3(grid), dim3(256), lds, st, a, ntiles, dbg);
   MI355_LAUNCH_CHECK("gemv(9..64 rows, matrix pipe)");
   return MI355_OK;
 }

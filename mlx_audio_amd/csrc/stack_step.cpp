@@ -41,7 +41,169 @@ int attn_call(const float* q, int ldq, const float* k, const float* v, int64_t k
   return mi355_flash_attention(&a, stream);
 }
 
+
+// ---------------------------------------------------------------------------------------------- steps for 9..64 sequences: the rows pipeline (rows_pipe.hip)
+struct RowsWs {
+  uint16_t* px; uint16_t* pa; uint16_t* pm; float* part; int64_t part_floats; int64_t bytes;
+};
+
+int rows_R(int B) { return B <= 16 ? 16 : (B <= 32 ? 32 : 64); }
+int round8(int n) { return (n + 7) / 8 * 8; }
+
+RowsWs rows_layout(const mi355_stack_desc& d, int B, void* base) {
+  const int R = rows_R(B), D = d.d_model, nq = d.heads * d.dh, nkv = 2 * d.kv_heads * d.dh, n_in = d.glu ? 2 * d.d_ff : d.d_ff;
+  RowsWs w;
+  w.px = (uint16_t*)base;
+  w.pa = w.px + (int64_t)2 * R * D;
+  w.pm = w.pa + (int64_t)2 * R * nq;
+  w.part = (float*)(w.pm + (int64_t)2 * R * d.d_ff);
+  const int64_t f_qkv = (int64_t)mi355_rows_kgroups(nq + nkv, D) * B * round8(nq + nkv), f_o = (int64_t)mi355_rows_kgroups(D, nq) * B * round8(D);
+  const int64_t f_in = (int64_t)mi355_rows_kgroups(n_in, D) * B * round8(n_in), f_out = (int64_t)mi355_rows_kgroups(D, d.d_ff) * B * round8(D);
+  w.part_floats = f_qkv > f_o ? f_qkv : f_o;
+  if (f_in > w.part_floats) w.part_floats = f_in;
+  if (f_out > w.part_floats) w.part_floats = f_out;
+  w.bytes = ((char*)w.part - (char*)base) + w.part_floats * 4;
+  return w;
+}
+
+int rows_gemm_call(const uint16_t* planes, const uint16_t* wt, int wdtype, int N, int K, int B, int R, float* part, int* kg, void* stream) {
+  mi355_rows_gemm_args g;
+  memset(&g, 0, sizeof(g));
+  *kg = mi355_rows_kgroups(N, K);
+  g.wt = wt; g.wdtype = wdtype; g.N = N; g.K = K; g.planes = planes; g.M = B; g.R = R; g.part = part; g.ldp = round8(N);
+  g.kg_stride = (int64_t)B * g.ldp; g.kgroups = *kg;
+  return mi355_rows_gemm(&g, stream);
+}
+
+int tall_step(const mi355_stack_desc& d, float* x, int B, int offset, float* ws, float* out, void* stream) {
+  MI355_REQUIRE(d.wdtype == MI355_W_BF16 || d.wdtype == MI355_W_F16, "stack_decode_step: 9..64 sequences per step need 16-bit weight images");
+  MI355_REQUIRE(d.d_model % 64 == 0 && d.d_ff % 64 == 0 && (d.heads * d.dh) % 64 == 0, "stack_decode_step: 9..64 sequences per step need widths that are multiples of 64");
+  MI355_REQUIRE(d.rows_ws && ((uintptr_t)d.rows_ws) % 16 == 0, "stack_decode_step: 9..64 sequences per step need the rows workspace (mi355_stack_rows_ws_bytes)");
+  const int D = d.d_model, H = d.heads, G = d.kv_heads, dh = d.dh, R = rows_R(B);
+  const int nq = H * dh, nkv = 2 * G * dh, n_in = d.glu ? 2 * d.d_ff : d.d_ff;
+  const RowsWs w = rows_layout(d, B, d.rows_ws);
+  MI355_REQUIRE(w.bytes <= d.rows_ws_bytes, "stack_decode_step: rows workspace too small (%lld bytes, need %lld)", (long long)d.rows_ws_bytes, (long long)w.bytes);
+  float* q = ws;                       // [B, nq]
+  float* att = q + (size_t)B * nq;     // [B, nq]
+  const float scale = d.attn_scale > 0.f ? d.attn_scale : 1.0f / sqrtf((float)dh);
+  const int kvsz = d.kv_dtype == MI355_KV_F32 ? 4 : 2;
+  auto finish = [&](mi355_rows_finish_args& f, int N, int kg) {
+    f.part = w.part; f.kgroups = kg; f.ldp = round8(N); f.kg_stride = kg > 1 ? (int64_t)B * f.ldp : 0; f.M = B; f.N = N; f.out_scale = 1.f;
+    f.R = R; f.planes_dtype = d.wdtype;
+    return mi355_rows_finish(&f, stream);
+  };
+  int rc, kg;
+  {  // the step input as planes, normalised by layer 0's attention norm
+    mi355_rows_finish_args f;
+    memset(&f, 0, sizeof(f));
+    f.part = x; f.kgroups = 1; f.ldp = D; f.M = B; f.N = D; f.out_scale = 1.f; f.norm = d.norm; f.norm_weight = d.layers[0].attn_norm_w;
+    f.norm_bias = d.layers[0].attn_norm_b; f.norm_eps = d.eps; f.planes = w.px; f.R = R; f.planes_dtype = d.wdtype;
+    rc = mi355_rows_finish(&f, stream);
+    if (rc) return rc;
+  }
+  for (int i = 0; i < d.n_layers; ++i) {
+    const mi355_layer_desc& L = d.layers[i];
+    MI355_REQUIRE(L.wqkv_t && L.wo_t && L.w_in_t && L.w_out_t && L.kv, "stack_decode_step: layer %d has no tile images (steps of 9..64 sequences)", i);
+    MI355_REQUIRE(!L.cross_k, "stack_decode_step: cross-attention layers run steps of <= 8 sequences");
+    MI355_REQUIRE(offset < L.kv_capacity, "stack_decode_step: KV cache of layer %d is full (offset %d, capacity %d)", i, offset, L.kv_capacity);
+    float* slot = (float*)((char*)L.kv + (int64_t)offset * nkv * kvsz);
+    const float* vbase = (const float*)((const char*)L.kv + (int64_t)G * dh * kvsz);
+    const bool rope_in_attn = (L.q_norm || d.cos) && d.causal;
+    MI355_REQUIRE(d.kv_dtype == MI355_KV_F32 || rope_in_attn || !(L.q_norm || d.cos),
+                  "stack_decode_step: a 16-bit KV cache needs the rotary embedding inside the attention step");
+    // ---- q | k | v
+    rc = rows_gemm_call(w.px, L.wqkv_t, d.wdtype, nq + nkv, D, B, R, w.part, &kg, stream);
+    if (rc) return rc;
+    if (rope_in_attn) {
+      // the fused attention step adds the K-group slabs of its own head itself (+ bias), applies the per-head norms / rotary embedding, files k, v
+      // into the cache and leaves its output row as planes for the o-proj GEMM: no row epilogue and no converter launch around it
+      const int ld = round8(nq + nkv);
+      mi355_flash_attn_args a;
+      memset(&a, 0, sizeof(a));
+      a.q = w.part; a.q_bstride = ld; a.ldq = ld; a.k = L.kv; a.k_bstride = L.kv_bstride; a.ldk = nkv; a.v = vbase; a.v_bstride = L.kv_bstride; a.ldv = nkv;
+      a.kv_dtype = d.kv_dtype;
+      a.heads = H; a.kv_heads = G; a.dh = dh; a.Tq = 1; a.Tk = offset + 1; a.causal = 1; a.window = d.window; a.scale = scale; a.B = B; a.mode = 2;
+      a.out_planes = w.pa; a.planes_R = R; a.planes_dtype = d.wdtype; a.out_bstride = nq; a.ldo = nq; a.k_start = d.k_start; a.nsplit = 1;
+      a.new_k = w.part + nq; a.new_v = w.part + nq + G * dh; a.new_bstride = ld;
+      a.in_kgroups = kg; a.in_kg_stride = (int64_t)B * ld;
+      if (L.bqkv) { a.q_bias = L.bqkv; a.k_bias = L.bqkv + nq; a.v_bias = L.bqkv + nq + G * dh; }
+      a.q_norm_w = L.q_norm; a.k_norm_w = L.k_norm; a.norm_eps = d.eps;
+      a.rope_cos = d.cos; a.rope_sin = d.sin; a.rope_rows = d.rope_rows; a.rope_mode = d.rope_mode; a.rope_pos = offset;
+      rc = mi355_flash_attention(&a, stream);
+      if (rc) return rc;
+    } else {
+      {
+        mi355_rows_finish_args f;
+        memset(&f, 0, sizeof(f));
+        f.bias = L.bqkv; f.y = q; f.ldy = nq; f.split = nq; f.y2 = slot; f.ldy2 = (int)L.kv_bstride; f.y2_dtype = d.kv_dtype;
+        rc = finish(f, nq + nkv, kg);
+        if (rc) return rc;
+      }
+      if (L.q_norm || d.cos) {
+        mi355_head_rope_args r;
+        memset(&r, 0, sizeof(r));
+        r.x = q; r.x_bstride = nq; r.ldx = nq; r.heads = H; r.dh = dh; r.L = 1; r.B = B; r.norm_weight = L.q_norm; r.eps = d.eps;
+        r.cos_table = d.cos; r.sin_table = d.sin; r.pos0 = offset; r.pos_sub = d.k_start; r.rope_rows = d.rope_rows; r.rope_mode = d.rope_mode;
+        r.y = q; r.y_bstride = nq; r.ldy = nq;
+        r.x2 = slot; r.x2_bstride = L.kv_bstride; r.ldx2 = nkv; r.heads2 = G; r.norm_weight2 = L.k_norm; r.y2 = slot; r.y2_bstride = L.kv_bstride;
+        r.ldy2 = nkv;
+        rc = mi355_head_norm_rope(&r, stream);
+        if (rc) return rc;
+      }
+      rc = attn_call(q, nq, L.kv, vbase, L.kv_bstride, nkv, H, G, dh, offset + 1, d.causal, d.window, scale, B, att, nq, stream, 0, nullptr, nullptr, d.k_start,
+                     d.kv_dtype);
+      if (rc) return rc;
+      mi355_rows_finish_args f;   // attention output -> planes
+      memset(&f, 0, sizeof(f));
+      f.part = att; f.kgroups = 1; f.ldp = nq; f.M = B; f.N = nq; f.out_scale = 1.f; f.planes = w.pa; f.R = R; f.planes_dtype = d.wdtype;
+      rc = mi355_rows_finish(&f, stream);
+      if (rc) return rc;
+    }
+    // ---- o-proj + LayerScale + residual; the new residual stream also leaves as planes normalised for the MLP
+    rc = rows_gemm_call(w.pa, L.wo_t, d.wdtype, D, nq, B, R, w.part, &kg, stream);
+    if (rc) return rc;
+    {
+      mi355_rows_finish_args f;
+      memset(&f, 0, sizeof(f));
+      f.bias = L.bo; f.colscale = L.ls1; f.res = x; f.ldr = D; f.y = x; f.ldy = D;
+      f.norm = d.norm; f.norm_weight = L.mlp_norm_w; f.norm_bias = L.mlp_norm_b; f.norm_eps = d.eps; f.planes = w.px;
+      rc = finish(f, D, kg);
+      if (rc) return rc;
+    }
+    // ---- MLP
+    rc = rows_gemm_call(w.px, L.w_in_t, d.wdtype, n_in, D, B, R, w.part, &kg, stream);
+    if (rc) return rc;
+    {
+      mi355_rows_finish_args f;
+      memset(&f, 0, sizeof(f));
+      f.bias = L.b_in; f.glu = d.glu; f.post_act = d.glu ? MI355_ACT_NONE : d.act; f.planes = w.pm;
+      rc = finish(f, n_in, kg);
+      if (rc) return rc;
+    }
+    rc = rows_gemm_call(w.pm, L.w_out_t, d.wdtype, D, d.d_ff, B, R, w.part, &kg, stream);
+    if (rc) return rc;
+    {
+      mi355_rows_finish_args f;
+      memset(&f, 0, sizeof(f));
+      f.bias = L.b_out; f.colscale = L.ls2; f.res = x; f.ldr = D; f.y = x; f.ldy = D;
+      if (i + 1 < d.n_layers) {   // the next layer's input planes
+        f.norm = d.norm; f.norm_weight = d.layers[i + 1].attn_norm_w; f.norm_bias = d.layers[i + 1].attn_norm_b; f.norm_eps = d.eps; f.planes = w.px;
+      } else if (out && d.final_norm_w) {
+        f.norm = d.norm; f.norm_weight = d.final_norm_w; f.norm_bias = d.final_norm_b; f.norm_eps = d.eps; f.yn = out; f.ldyn = D;
+      }
+      rc = finish(f, D, kg);
+      if (rc) return rc;
+    }
+  }
+  return MI355_OK;
+}
+
 }  // namespace
+
+extern "C" int64_t mi355_stack_rows_ws_bytes(const mi355_stack_desc* dp, int32_t B) {
+  if (!dp || B < 1 || B > 64 || dp->d_model % 64 || dp->d_ff % 64 || (dp->heads * dp->dh) % 64) return 0;
+  return rows_layout(*dp, B, nullptr).bytes;
+}
 
 extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int32_t B, int32_t offset, float* ws, float* out, void* stream) {
   MI355_REQUIRE(dp && x && ws && dp->layers, "stack_decode_step: null argument");
@@ -49,6 +211,7 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
   MI355_REQUIRE(B >= 1 && B <= 64, "stack_decode_step: 1..64 sequences per step (got %d)", B);
   MI355_REQUIRE(B <= 8 || (d.wdtype != MI355_W_FP8 && d.d_model % 64 == 0 && d.d_ff % 64 == 0 && (d.heads * d.dh) % 64 == 0),
                 "stack_decode_step: 9..64 sequences per step need 16-bit weight images and widths that are multiples of 64");
+  static const bool rows_off = getenv("MI355_ROWS_PIPE") != nullptr && getenv("MI355_ROWS_PIPE")[0] == '0';   // A/B knob: 9..64 rows through mi355_gemv (gemm_rows.hip)
   MI355_REQUIRE(d.n_layers > 0 && d.d_model % 8 == 0 && d.d_ff % 8 == 0 && (d.dh == 64 || d.dh == 128), "stack_decode_step: bad dimensions");
   MI355_REQUIRE(d.wdtype != MI355_W_FP8 || (d.d_model % 16 == 0 && d.d_ff % 16 == 0), "stack_decode_step: fp8 images need d_model, d_ff multiples of 16");
   MI355_REQUIRE(d.norm == 1 || d.norm == 2, "stack_decode_step: norm must be 1 (LayerNorm) or 2 (RMSNorm)");
@@ -56,6 +219,7 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
   MI355_REQUIRE(d.kv_dtype >= MI355_KV_F32 && d.kv_dtype <= MI355_KV_F16, "stack_decode_step: bad kv_dtype");
   MI355_REQUIRE(!d.cos || (d.rope_rows > 0 && offset < d.rope_rows), "stack_decode_step: position %d is past the %d-row rotary tables", offset,
                 d.rope_rows);
+  if (B > 8 && !rows_off && d.layers[0].wqkv_t) return tall_step(d, x, B, offset, ws, out, stream);
   const int D = d.d_model, H = d.heads, G = d.kv_heads, dh = d.dh;
   const int nq = H * dh, nkv = 2 * G * dh;
   float* q = ws;                 // [B, nq]

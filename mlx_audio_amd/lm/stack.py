@@ -127,6 +127,12 @@ class KVCache:
 class Lin:
     pc: PackedConv
     rm: RowMajor16
+    tl: Optional["ops.Tiles16"] = None   # tile image for steps of 9..64 sequences (rows_pipe.hip), built on first use
+
+    def tiles(self) -> "ops.Tiles16":
+        if self.tl is None:
+            self.tl = ops.tiles16_from_rowmajor(self.rm)
+        return self.tl
 
 
 def make_lin(w: torch.Tensor, bias: Optional[torch.Tensor], device, f16: bool = False, fp8: bool = False, gemv_only: bool = False) -> Lin:
@@ -164,11 +170,45 @@ def is_decode(x: torch.Tensor, l: Optional["Lin"] = None) -> bool:
     return x.shape[1] == 1 and x.shape[0] <= (8 if l is None else decode_rows(l))
 
 
+ROWS_PIPE = True   # single-position Linear layers of 9..64 sequences outside the native runner: rows pipeline (False: mi355_gemv's 9..64-row kernel)
+_ROWS_WS: Dict[tuple, torch.Tensor] = {}
+
+
+def _rows_ws(device, kind: str, nbytes: int) -> torch.Tensor:
+    """Grow-only scratch of the rows pipeline per (device, stream, kind): launches on one stream are ordered, so one buffer per kind serves all calls."""
+    key = (str(device), ops._stream(), kind)
+    cur = _ROWS_WS.get(key)
+    if cur is None or cur.numel() < nbytes:
+        cur = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ROWS_WS[key] = cur
+    return cur
+
+
+def linear_rows(x: torch.Tensor, l: Lin, y: torch.Tensor, *, post_act: int = ACT_NONE, res: Optional[torch.Tensor] = None,
+                colscale: Optional[torch.Tensor] = None, glu: bool = False, norm: Optional[tuple] = None, y2: Optional[torch.Tensor] = None):
+    """``linear`` for 9..64 single-position rows through the rows pipeline: converter (fused input norm) -> mi355_rows_gemm -> row epilogue."""
+    B = x.shape[0]
+    tl = l.tiles()
+    R = ops.rows_R(B)
+    f16 = l.rm.f16
+    planes = _rows_ws(x.device, "planes", 4 * R * tl.k)
+    kg = ops.rows_kgroups(tl.n, tl.k)
+    ld = ops.round_up(tl.n, 8)
+    part = _rows_ws(x.device, "part", 4 * kg * B * ld).view(torch.float32)[: kg * B * ld].view(kg, B, ld)
+    ops.rows_finish(x[:, 0, :], B, tl.k, norm=norm, planes=planes, R=R, f16=f16)
+    ops.rows_gemm(planes, tl, part, B, R, kgroups=kg)
+    ops.rows_finish(part, B, tl.n, kg, bias=l.rm.bias, post_act=post_act, res=None if res is None else res[:, 0, :], colscale=colscale, glu=glu,
+                    y=y[:, 0, :], y2=None if y2 is None else y2[:, 0, :])
+    return y
+
+
 def linear(x: torch.Tensor, l: Lin, y: torch.Tensor, *, post_act: int = ACT_NONE, res: Optional[torch.Tensor] = None,
            colscale: Optional[torch.Tensor] = None, glu: bool = False, precision: int = 2, norm: Optional[tuple] = None,
            y2: Optional[torch.Tensor] = None):
     """y = act(norm(x) W^T + b) * colscale + res on [B, L, C] views; 1-row-per-sequence inputs with B <= 8 take the GEMV
     (``norm`` / ``y2`` -- fused input normalisation and split destination -- exist on that path only)."""
+    if is_decode(x, l) and x.shape[0] > 8 and ROWS_PIPE and l.rm.wdtype != 2:
+        return linear_rows(x, l, y, post_act=post_act, res=res, colscale=colscale, glu=glu, norm=norm, y2=y2)
     if is_decode(x, l):
         ops.gemv(x[:, 0, :], l.rm, y[:, 0, :], post_act=post_act, res=None if res is None else res[:, 0, :], colscale=colscale, glu=glu,
                  norm=norm, y2=None if y2 is None else y2[:, 0, :])
@@ -209,6 +249,7 @@ class TransformerStack:
         self.device = torch.device(device)
         self.precision = precision
         self.native_decode = True  # single-position steps go through mi355_stack_decode_step (False: the per-op Python schedule)
+        self.rows_pipe = True      # native steps of 9..64 sequences run the rows pipeline (rows_pipe.hip); False: mi355_gemv's 9..64-row kernel
         # sequences per single-position step on the weight-streaming path: 9..64 need 16-bit images and widths that are multiples of 64
         self.max_decode_rows = MAX_DECODE_ROWS if (not fp8 and cfg.d_model % 64 == 0 and cfg.d_ff % 64 == 0 and (cfg.n_heads * cfg.head_dim) % 64 == 0) else 8
         dev = self.device
@@ -255,10 +296,12 @@ class TransformerStack:
         return [KVCache(self.cfg.n_kv_heads, self.cfg.head_dim, self.device, self.kv_dtype) for _ in range(self.cfg.n_layers)]
 
     # ------------------------------------------------------------------ native decode step (mi355_stack_decode_step)
-    def _native_desc(self, cache: List[KVCache], k_start: Optional[torch.Tensor] = None):
+    def _native_desc(self, cache: List[KVCache], k_start: Optional[torch.Tensor] = None, tall: bool = False):
         """Builds (or refreshes after a cache re-allocation) the C descriptor of this stack for the given caches.  The key carries everything the
-        descriptor stores about a cache: the caching allocator may hand a later, differently sized cache the same addresses."""
-        key = tuple((c.kv.data_ptr(), c.kv.shape[0], c.kv.shape[1], c.kv.stride(0)) for c in cache) + (None if k_start is None else k_start.data_ptr(),)
+        descriptor stores about a cache: the caching allocator may hand a later, differently sized cache the same addresses.  ``tall``: the step
+        carries 9..64 sequences -- the descriptor then also names the tile images and the rows workspace (built on first use, kept)."""
+        tall = self.rows_pipe and (tall or getattr(self, "_rows_ws", None) is not None)
+        key = tuple((c.kv.data_ptr(), c.kv.shape[0], c.kv.shape[1], c.kv.stride(0)) for c in cache) + (None if k_start is None else k_start.data_ptr(), tall)
         st = getattr(self, "_native", None)
         if st is not None and st["key"] == key:
             return st
@@ -277,6 +320,8 @@ class TransformerStack:
             a.q_norm, a.k_norm, a.ls1, a.ls2 = p(lyr.q_norm), p(lyr.k_norm), p(lyr.ls1), p(lyr.ls2)
             a.kv, a.kv_bstride, a.kv_capacity = kvc.kv.data_ptr(), kvc.kv.stride(0), kvc.kv.shape[1]
             a.s_qkv, a.s_o, a.s_in, a.s_out = p(lyr.wqkv.rm.scale), p(lyr.wo.rm.scale), p(lyr.w_in.rm.scale), p(lyr.w_out.rm.scale)
+            if tall:
+                a.wqkv_t, a.wo_t, a.w_in_t, a.w_out_t = p(lyr.wqkv.tiles().w), p(lyr.wo.tiles().w), p(lyr.w_in.tiles().w), p(lyr.w_out.tiles().w)
         d = SD()
         d.n_layers, d.d_model, d.heads, d.kv_heads, d.dh, d.d_ff = c.n_layers, c.d_model, c.n_heads, c.n_kv_heads, c.head_dim, c.d_ff
         d.norm, d.eps, d.glu = (1 if c.norm == "layer" else 2), c.norm_eps, int(c.mlp == "swiglu")
@@ -293,6 +338,12 @@ class TransformerStack:
         d.gemv_split_ws, d.gemv_split_cnt = gws.data_ptr(), gcnt.data_ptr()
         if self.final_norm is not None:
             d.final_norm_w, d.final_norm_b = p(self.final_norm[0]), p(self.final_norm[1])
+        if tall:
+            if getattr(self, "_rows_ws", None) is None:
+                need = int(_lib.load().mi355_stack_rows_ws_bytes(ctypes.byref(d), MAX_DECODE_ROWS))
+                assert need > 0
+                self._rows_ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
+            d.rows_ws, d.rows_ws_bytes = self._rows_ws.data_ptr(), self._rows_ws.numel()
         self._native = dict(key=key, arr=arr, desc=d, k_start=k_start)
         return self._native
 
@@ -312,7 +363,7 @@ class TransformerStack:
         self._check_positions(off, 1)
         for kvc in cache:
             kvc.reserve(B, 1)
-        st = self._native_desc(cache, k_start)
+        st = self._native_desc(cache, k_start, tall=B > 8 and self.rows_pipe)
         ws = torch.empty(B * (2 * c.n_heads * c.head_dim + c.d_ff + 2 * c.n_kv_heads * c.head_dim), dtype=torch.float32, device=self.device)
         out = torch.empty_like(x) if (self.final_norm is not None and not defer_final_norm) else None
         lib = _lib.load()

@@ -209,6 +209,100 @@ def gemv(x: torch.Tensor, rw: RowMajor16, y: torch.Tensor, *, post_act: int = AC
     return y
 
 
+# --------------------------------------------------------------------------------------- decode steps for 9..64 sequences (rows_pipe.hip)
+@dataclass
+class Tiles16:
+    """Tile image of a [N, K] Linear for ``mi355_rows_gemm``: [ceil(N / 16)][K / 64][4 groups][16 rows][16 elements] 16-bit elements."""
+
+    w: torch.Tensor  # int16, flat, on the device
+    n: int
+    k: int
+    f16: bool
+
+    @property
+    def wdtype(self) -> int:
+        return W_F16 if self.f16 else W_BF16
+
+
+def tiles16_from_rowmajor(rm: RowMajor16) -> Tiles16:
+    """The tile image of a row-major 16-bit image, permuted on the device (== ``mi355_pack_tiles16_host`` of the same weights, element for element)."""
+    assert rm.scale is None and rm.k % 64 == 0, "tile images exist for 16-bit weights with K % 64 == 0"
+    nt = (rm.n + 15) // 16
+    w = rm.w[:, : rm.k]
+    if nt * 16 != rm.n:
+        w = torch.cat([w, torch.zeros((nt * 16 - rm.n, rm.k), dtype=w.dtype, device=w.device)], 0)
+    t = w.reshape(nt, 16, rm.k // 64, 4, 16).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
+    return Tiles16(t, rm.n, rm.k, rm.f16)
+
+
+def pack_tiles16_host(w: torch.Tensor, f16: bool = False) -> np.ndarray:
+    """``mi355_pack_tiles16_host`` on float32 CPU weights [N, K]: uint16 [ceil(N / 16) * 16 * K]."""
+    w = w.detach().to(torch.float32).contiguous().cpu()
+    n, k = w.shape
+    out = np.empty(((n + 15) // 16) * 16 * k, dtype=np.uint16)
+    rc = _lib.load().mi355_pack_tiles16_host(w.numpy().ctypes.data, n, k, 1 if f16 else 0, out.ctypes.data)
+    _lib.check(rc, "mi355_pack_tiles16_host")
+    return out
+
+
+def rows_R(M: int) -> int:
+    """Rows of the planes that carry ``M`` sequences: 16, 32 or 64."""
+    assert 1 <= M <= 64
+    return 16 if M <= 16 else (32 if M <= 32 else 64)
+
+
+def rows_kgroups(n: int, k: int) -> int:
+    return int(_lib.load().mi355_rows_kgroups(n, k))
+
+
+def rows_planes(R: int, k: int, device) -> torch.Tensor:
+    """Storage of the planes of R rows x k columns (hi + lo images: 4 bytes per element)."""
+    return torch.zeros(2 * R * k, dtype=torch.int16, device=device)
+
+
+def rows_gemm(planes: torch.Tensor, tl: Tiles16, part: torch.Tensor, M: int, R: int, kgroups: Optional[int] = None):
+    """part[g, :M, :N] = partial products of the g-th range of k steps; ``part`` is fp32 [kgroups, rows >= M, ld >= N] (contiguous slabs)."""
+    kg = rows_kgroups(tl.n, tl.k) if kgroups is None else kgroups
+    assert part.dtype == torch.float32 and part.dim() == 3 and part.shape[0] >= kg and part.shape[1] >= M and part.shape[2] >= tl.n and part.stride(2) == 1
+    assert planes.numel() * planes.element_size() >= 4 * R * tl.k
+    _lib.call_struct("mi355_rows_gemm", "mi355_rows_gemm_args", _stream(), wt=_ptr(tl.w), wdtype=tl.wdtype, N=tl.n, K=tl.k, planes=_ptr(planes), M=M, R=R,
+                     part=_ptr(part), ldp=part.stride(1), kg_stride=part.stride(0), kgroups=kg)
+    return kg
+
+
+def rows_finish(part: torch.Tensor, M: int, N: int, kgroups: int = 1, *, bias=None, post_act: int = ACT_NONE, post_slope: float = 0.0, colscale=None,
+                res: Optional[torch.Tensor] = None, out_scale: float = 1.0, glu: bool = False, y: Optional[torch.Tensor] = None,
+                y2: Optional[torch.Tensor] = None, norm: Optional[tuple] = None, yn: Optional[torch.Tensor] = None,
+                planes: Optional[torch.Tensor] = None, R: int = 0, f16: bool = False):
+    """Row epilogue of ``rows_gemm`` (see ``mi355_rows_finish_args``).  ``part``: fp32 [kgroups, rows, ld] slabs, or a 2-D fp32 matrix (kgroups = 1:
+    the converter rows -> planes).  ``y`` / ``y2`` / ``yn`` are 2-D views with unit inner stride; ``norm`` = (mode, weight, bias, eps)."""
+    if part.dim() == 2:
+        part = part.unsqueeze(0)
+    assert part.dtype == torch.float32 and part.stride(2) == 1 and part.shape[0] >= kgroups
+    kw = dict(part=_ptr(part), kgroups=kgroups, kg_stride=part.stride(0) if kgroups > 1 else 0, ldp=part.stride(1), M=M, N=N, bias=_ptr(bias),
+              post_act=post_act, post_slope=post_slope, colscale=_ptr(colscale), out_scale=out_scale, glu=int(glu))
+    n_out = N // 2 if glu else N
+    if res is not None:
+        assert res.dim() == 2 and res.stride(1) == 1
+        kw.update(res=_ptr(res), ldr=res.stride(0))
+    if y2 is not None:
+        assert y is not None and y2.dim() == 2 and y2.stride(1) == 1 and y2.dtype in KV_DTYPES
+        kw.update(y2=_ptr(y2), ldy2=y2.stride(0), split=n_out - y2.shape[1], y2_dtype=KV_DTYPES[y2.dtype])
+    if y is not None:
+        assert y.dim() == 2 and y.stride(1) == 1 and y.dtype == torch.float32
+        kw.update(y=_ptr(y), ldy=y.stride(0))
+    if norm is not None:
+        mode, nw, nb, eps = norm
+        kw.update(norm={"layer": 1, "rms": 2}[mode], norm_weight=_ptr(nw), norm_bias=_ptr(nb), norm_eps=eps)
+    if yn is not None:
+        assert yn.dim() == 2 and yn.stride(1) == 1 and yn.dtype == torch.float32
+        kw.update(yn=_ptr(yn), ldyn=yn.stride(0))
+    if planes is not None:
+        assert R in (16, 32, 64) and planes.numel() * planes.element_size() >= 4 * R * n_out
+        kw.update(planes=_ptr(planes), R=R, planes_dtype=W_F16 if f16 else W_BF16)
+    _lib.call_struct("mi355_rows_finish", "mi355_rows_finish_args", _stream(), **kw)
+
+
 def pack_lstm_wh(wh_f: torch.Tensor, wh_b: torch.Tensor, device, f16: bool = False) -> torch.Tensor:
     """Recurrent weights of both directions in the persistent kernel's layout; ``f16``: IEEE half instead of bf16 values (float32 checkpoints; pass
     ``wh_f16=True`` to ``lstm_bidir``)."""

@@ -78,6 +78,28 @@ def test_qwen3_frame_loop_teacher_forced(talker):
     _check_trace(exp["trace"], got["trace"], "qwen3")
 
 
+def test_qwen3_frame_loop_teacher_forced_tall_batch(talker):
+    """The same frame loop with 12 sequences per step: every single-position Linear (both stacks through the native runner's rows pipeline, the
+    heads / projections through ``linear_rows``) runs mi355_rows_gemm / mi355_rows_finish, the fused attention step reads the projection slabs and
+    writes planes.  Same oracle, same bars as the 3-sequence test."""
+    cfg = talker["cfg"]
+    g = torch.Generator().manual_seed(17)
+    B, H, frames = 12, cfg.hidden_size, 4
+    assert talker["eng"].talker.max_decode_rows == 64 and talker["eng"].cp.max_decode_rows == 64
+    pre, trail = torch.randn(B, 7, H, generator=g) * 0.5, torch.randn(B, 3, H, generator=g) * 0.5
+    gu0, guc = _gumbel(g, frames, B, cfg.vocab_size), _gumbel(g, frames, cfg.num_code_groups - 1, B, cfg.code_predictor_config.vocab_size)
+    kw = dict(temperature=0.9, top_k=50, top_p=0.95, repetition_penalty=1.05, gumbel0=gu0, gumbel_cp=guc)
+    free = talker["ref"].generate(pre, trail, talker["pad"], frames, **kw)
+    forced = free["codes"].clone()
+    forced[5, 2, 0] = cfg.codec_eos_token_id
+    exp = talker["ref"].generate(pre, trail, talker["pad"], frames, forced_codes=forced, record=True, **kw)
+    got = talker["eng"].generate(pre, trail, talker["pad"], frames, forced_codes=forced, record=True, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(got["codes"].cpu(), exp["codes"])
+    assert got["finished_at"].cpu().tolist() == exp["finished_at"].tolist()
+    _check_trace(exp["trace"], got["trace"], "qwen3 (12 sequences)")
+
+
 def test_qwen3_frame_loop_free_running_greedy(talker):
     frames = 5
     exp = talker["ref"].generate(talker["pre"], talker["trail"], talker["pad"], frames, temperature=0.0, record=True)

@@ -387,3 +387,13 @@ def test_stack_real_widths_prefill_and_decode(ops, name, B):
         assert o.shape == (B, 1, cfg.d_model) and bool(torch.isfinite(o).all())
         assert rel_err(o, e) < 2e-4, (s, rel_err(o, e))
     assert ec[0].offset == L + steps
+    if B > 8:   # the same step through mi355_gemv's 9..64-row kernel (gemm_rows.hip) instead of the rows pipeline: two implementations, one result
+        xs = torch.randn(B, 1, cfg.d_model, generator=g)
+        e = ref(xs, rc)
+        eng.rows_pipe = False
+        try:
+            o = eng(xs.to(DEV), ec)
+        finally:
+            eng.rows_pipe = True
+        torch.cuda.synchronize()
+        assert rel_err(o, e) < 2e-4, rel_err(o, e)

@@ -687,3 +687,119 @@ def test_gemv_fused_interleaved_rope(ops, M, heads, kv_heads, dh, K, fp8):
     assert rel_err(y.cpu(), exp[:, :nq]) < 1e-5, rel_err(y.cpu(), exp[:, :nq])
     assert rel_err(cache[:, 2, : 2 * nk].cpu(), exp[:, nq:]) < 1e-5
     assert float(cache[:, 1].abs().max()) == 0.0 and float(cache[:, 3].abs().max()) == 0.0 and float(cache[:, 2, 2 * nk:].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ rows pipeline (9..64 sequences per decode step)
+def test_tile_image_matches_host_packer(ops):
+    """The device-side permutation that builds tile images == mi355_pack_tiles16_host, element for element (ragged last tile, both 16-bit types)."""
+    g = torch.Generator().manual_seed(3)
+    for n, k, f16 in [(37, 128, False), (64, 64, True), (2051, 192, False)]:
+        w = _round16(torch.randn(n, k, generator=g), f16)
+        t = ops.tiles16_from_rowmajor(ops.pack_rowmajor16(w, None, DEV, f16=f16))
+        assert np.array_equal(t.w.cpu().numpy().view(np.uint16), ops.pack_tiles16_host(w, f16=f16))
+
+
+@pytest.mark.parametrize("M,N,K,f16,mode,glu,act,use_res,split,kg", [
+    (64, 4096, 2048, False, "rms", False, 0, False, 2048, None),   # talker q | k | v: RMSNorm in the converter, k | v into a strided cache slot
+    (64, 12288, 2048, False, "rms", True, 0, False, 0, None),      # talker gate | up + SwiGLU
+    (64, 2048, 6144, False, None, False, 0, True, 0, None),        # talker down + residual (10 K groups)
+    (64, 2048, 2048, False, None, False, 0, True, 0, None),        # talker o-proj + residual
+    (33, 1024, 3072, False, None, False, 5, True, 0, None),        # code predictor down at 33 rows (R = 64), SiLU
+    (32, 6144, 1024, False, "rms", True, 0, False, 0, None),       # code predictor gate | up at 32 rows (R = 32)
+    (17, 3072, 2048, False, "rms", False, 0, False, 0, None),      # codec head (R = 32)
+    (16, 2051, 2048, False, None, False, 0, False, 0, None),       # R = 16, ragged last tile (T = 2)
+    (9, 1040, 1024, False, "rms", False, 5, False, 0, 1),          # one K group
+    (12, 51865, 768, True, "layer", False, 0, False, 0, None),     # Whisper logits: LayerNorm with bias, fp16, 3242 tiles
+    (24, 2304, 768, True, "layer", False, 0, False, 768, 2),       # Whisper q | k | v, two K groups
+    (40, 768, 3072, True, None, False, 3, True, 0, None),          # Whisper mlp2, GELU + residual
+    (64, 48, 64, False, None, False, 0, False, 0, None),           # one k step, T = 1
+    (10, 30, 128, False, "layer", False, 0, False, 0, None),       # tiny
+])
+def test_rows_pipeline(ops, M, N, K, f16, mode, glu, act, use_res, split, kg):
+    """fp32 rows -> (norm) -> planes [mi355_rows_finish as converter] -> mi355_rows_gemm -> slabs -> mi355_rows_finish (epilogue), against float64."""
+    g = torch.Generator().manual_seed(M + N + K)
+    w = _round16(torch.randn(N, K, generator=g) / math.sqrt(K), f16)
+    bias = torch.randn(N, generator=g) * 0.1
+    x = torch.randn(M, K + 8, generator=g)[:, :K] * 1.5 + 0.2
+    res = torch.randn(M, N, generator=g) if use_res else None
+    xd = x.double()
+    nw = nb = None
+    if mode == "layer":
+        nw, nb = torch.randn(K, generator=g), torch.randn(K, generator=g) * 0.1
+        xd = F.layer_norm(xd, (K,), nw.double(), nb.double(), 1e-5)
+    elif mode == "rms":
+        nw = torch.randn(K, generator=g)
+        xd = xd * torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + 1e-6) * nw.double()
+    v = xd @ w.double().T + bias.double()
+    if glu:
+        v = F.silu(v[:, 0::2]) * v[:, 1::2]
+    elif act == 3:
+        v = F.gelu(v)
+    elif act == 5:
+        v = F.silu(v)
+    if res is not None:
+        v = v + res.double()
+    tl = ops.tiles16_from_rowmajor(ops.pack_rowmajor16(w, None, DEV, f16=f16))
+    R = ops.rows_R(M)
+    xdev = torch.zeros(M, K + 8, device=DEV)
+    xdev[:, :K] = x.to(DEV)
+    planes = ops.rows_planes(R, K, DEV)
+    planes.fill_(0x7fc0 if not f16 else 0x7e00)   # NaN in every row: rows >= M must never reach a stored result
+    norm = None if mode is None else (mode, nw.to(DEV), None if nb is None else nb.to(DEV), 1e-5 if mode == "layer" else 1e-6)
+    ops.rows_finish(xdev[:, :K], M, K, norm=norm, planes=planes, R=R, f16=f16)
+    kgroups = ops.rows_kgroups(N, K) if kg is None else kg
+    ld = ops.round_up(N, 8)
+    part = torch.full((kgroups, M, ld), float("nan"), device=DEV)
+    assert ops.rows_gemm(planes, tl, part, M, R, kgroups=kgroups) == kgroups
+    n_out = N // 2 if glu else (split if split else N)
+    y = torch.full((M, n_out), float("nan"), device=DEV)
+    cache = torch.zeros(M, 3, (N - split) + 8, device=DEV) if split else None
+    ops.rows_finish(part, M, N, kgroups, bias=bias.to(DEV), post_act=act, res=None if res is None else res.to(DEV), glu=glu, y=y,
+                    y2=None if not split else cache[:, 1, : N - split])
+    torch.cuda.synchronize()
+    tol = 3e-6 if f16 else 2e-5
+    if split:
+        assert rel_err(y.cpu(), v[:, :split]) < tol, rel_err(y.cpu(), v[:, :split])
+        assert rel_err(cache[:, 1, : N - split].cpu(), v[:, split:]) < tol
+        assert float(cache[:, 0].abs().max()) == 0.0 and float(cache[:, 2].abs().max()) == 0.0 and float(cache[:, 1, N - split:].abs().max()) == 0.0
+    else:
+        assert torch.isfinite(y).all()
+        assert rel_err(y.cpu(), v) < tol, rel_err(y.cpu(), v)
+
+
+@pytest.mark.parametrize("M,mode,kvd", [(64, "rms", torch.bfloat16), (20, "layer", torch.float16)])
+def test_rows_finish_outputs(ops, M, mode, kvd):
+    """The row epilogue's other destinations: in-place residual (y aliases res), LayerScale, the normalised row as fp32 (yn) and as planes feeding a
+    second GEMM (checked through that GEMM), and a 16-bit KV-cache slot."""
+    g = torch.Generator().manual_seed(M)
+    K, N, N2 = 256, 512, 192
+    w1 = _round16(torch.randn(N, K, generator=g) / math.sqrt(K), False)
+    w2 = _round16(torch.randn(N2, N, generator=g) / math.sqrt(N), False)
+    x, res, cs = torch.randn(M, K, generator=g), torch.randn(M, N, generator=g), torch.randn(N, generator=g)
+    nw, nb = torch.randn(N, generator=g), (torch.randn(N, generator=g) * 0.1 if mode == "layer" else None)
+    h = (x.double() @ w1.double().T) * cs.double() + res.double()
+    hn = F.layer_norm(h, (N,), nw.double(), nb.double(), 1e-5) if mode == "layer" else h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + 1e-5) * nw.double()
+    out = hn @ w2.double().T
+    R = ops.rows_R(M)
+    t1 = ops.tiles16_from_rowmajor(ops.pack_rowmajor16(w1, None, DEV))
+    t2 = ops.tiles16_from_rowmajor(ops.pack_rowmajor16(w2, None, DEV))
+    p1, p2 = ops.rows_planes(R, K, DEV), ops.rows_planes(R, N, DEV)
+    ops.rows_finish(x.to(DEV), M, K, planes=p1, R=R)
+    kg1 = ops.rows_kgroups(N, K)
+    part = torch.empty(kg1, M, N, device=DEV)
+    ops.rows_gemm(p1, t1, part, M, R)
+    stream = res.to(DEV).clone()   # the residual stream, updated in place
+    yn = torch.empty(M, N, device=DEV)
+    ops.rows_finish(part, M, N, kg1, colscale=cs.to(DEV), res=stream, y=stream, norm=(mode, nw.to(DEV), None if nb is None else nb.to(DEV), 1e-5), yn=yn,
+                    planes=p2, R=R)
+    kg2 = ops.rows_kgroups(N2, N)
+    part2 = torch.empty(kg2, M, N2, device=DEV)
+    ops.rows_gemm(p2, t2, part2, M, R)
+    y = torch.empty(M, 64, device=DEV)
+    slot = torch.zeros(M, 2, N2 - 64 + 8, dtype=kvd, device=DEV)
+    ops.rows_finish(part2, M, N2, kg2, y=y, y2=slot[:, 1, : N2 - 64])
+    torch.cuda.synchronize()
+    assert rel_err(stream.cpu(), h) < 2e-5 and rel_err(yn.cpu(), hn) < 3e-5
+    assert rel_err(y.cpu(), out[:, :64]) < 4e-5
+    exp_slot = out[:, 64:].to(torch.float32).to(kvd).double()
+    assert rel_err(slot[:, 1, : N2 - 64].double().cpu(), exp_slot) < 1e-2 and float(slot[:, 0].abs().max()) == 0.0
