@@ -722,6 +722,9 @@ typedef struct {
   float* part;              /* slab g at part + g * kg_stride: [M, ldp] fp32 partial sums over the g-th range of k steps */
   int32_t ldp; int64_t kg_stride;
   int32_t kgroups;          /* mi355_rows_kgroups(N, K) (or any count that leaves no K group empty) */
+  /* kgroups == 1 only (a workgroup then holds complete sums): fused SwiGLU epilogue -- columns are (gate, up) pairs, planes_out receives
+     silu(gate + bias) * (up + bias) [M, N / 2] as planes of R rows (N % 128 == 0), nothing is written to part (which may then be null) */
+  uint16_t* glu_planes_out; const float* glu_bias;
 } mi355_rows_gemm_args;
 int mi355_rows_gemm(const mi355_rows_gemm_args* a, void* stream);
 int32_t mi355_rows_kgroups(int32_t N, int32_t K);

@@ -480,7 +480,20 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
     for (int t = tid; t < DH; t += NW * 64) {
       const int64_t iq = (int64_t)b * a.q_bstride + (int64_t)qi * a.ldq + h * DH + t, ik = (int64_t)b * a.new_bstride + g * DH + t;
       float q0 = a.q[iq], k0 = a.new_k[ik], v0 = a.new_v[ik];
-      for (int sl = 1; sl < a.in_kgroups; ++sl) {   // rows pipeline: the projection arrives as K-group slabs (summed in slab order: deterministic)
+      // rows pipeline: the projection arrives as K-group slabs (summed in slab order: deterministic); four slabs' loads in flight at a time
+      int sl = 1;
+      for (; sl + 4 <= a.in_kgroups; sl += 4) {
+        float tq[4], tk[4], tv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          tq[u] = a.q[iq + (sl + u) * a.in_kg_stride];
+          tk[u] = a.new_k[ik + (sl + u) * a.in_kg_stride];
+          tv[u] = a.new_v[ik + (sl + u) * a.in_kg_stride];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { q0 += tq[u]; k0 += tk[u]; v0 += tv[u]; }
+      }
+      for (; sl < a.in_kgroups; ++sl) {
         q0 += a.q[iq + sl * a.in_kg_stride];
         k0 += a.new_k[ik + sl * a.in_kg_stride];
         v0 += a.new_v[ik + sl * a.in_kg_stride];

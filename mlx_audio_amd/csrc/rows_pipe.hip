@@ -127,6 +127,35 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(const mi355_rows_gemm
 #pragma unroll
       for (int e = 0; e < 4; ++e) red[((wave * T + j) * MR + r) * 256 + (4 * gi + e) * 16 + li] = acc[j][r][e];
   __syncthreads();
+  if (a.glu_planes_out) {   // complete sums (one K group): SwiGLU here, the result leaves as planes -- thread (row m, tile j) builds the piece of outputs 8 (t0 + j) .. + 8
+    for (int u = tid; u < a.M * T; u += 256) {
+      const int m = u / T, j = u - m * T, tile = t0 + j;
+      if (tile >= ntiles) continue;
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float gv = 0.f, uv = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const int b = ((w * T + j) * MR + (m >> 4)) * 256 + (m & 15);
+          gv += red[b + (2 * e) * 16];
+          uv += red[b + (2 * e + 1) * 16];
+        }
+        if (a.glu_bias) { gv += a.glu_bias[tile * 16 + 2 * e]; uv += a.glu_bias[tile * 16 + 2 * e + 1]; }
+        o[e] = (gv / (1.0f + expf(-gv))) * uv;
+      }
+      uint4 hi, lo;
+      pipe_split2<F16>(o[0], o[1], hi.x, lo.x);
+      pipe_split2<F16>(o[2], o[3], hi.y, lo.y);
+      pipe_split2<F16>(o[4], o[5], hi.z, lo.z);
+      pipe_split2<F16>(o[6], o[7], hi.w, lo.w);
+      const int p = tile, s = p >> 3, g = (p & 7) >> 1, h = p & 1;
+      uint4* const po = (uint4*)a.glu_planes_out;
+      po[(((s * 2 + 0) * 2 + h) * 4 + g) * R + m] = hi;
+      po[(((s * 2 + 1) * 2 + h) * 4 + g) * R + m] = lo;
+    }
+    return;
+  }
   constexpr int CW = 16 * T;            // columns of the workgroup
   constexpr int RSTEP = 256 / CW;       // rows written per pass
   const int c = tid % CW, r0 = tid / CW;
@@ -166,8 +195,11 @@ int launch_rows_gemm_t(const mi355_rows_gemm_args& a, hipStream_t st, const int 
 int tiles_per_wg(const int N) {
   static const int t_env = getenv("MI355_ROWS_T") ? atoi(getenv("MI355_ROWS_T")) : 0;   // A/B knob
   if (t_env == 1 || t_env == 2 || t_env == 4) return t_env;
+  // measured (profiles/r3_rows_sweep_call4.txt): two tiles per workgroup (132 registers: three workgroups per CU) beat four (200 registers) on every
+  // decode shape of the Qwen3-TTS stacks although the input planes are then read by twice as many workgroups -- latency hiding, not L2 traffic, binds;
+  // very wide outputs (vocabulary heads) keep four tiles
   const int ntiles = (N + 15) / 16;
-  return ntiles >= 256 ? 4 : (ntiles >= 64 ? 2 : 1);
+  return ntiles >= 2048 ? 4 : (ntiles >= 32 ? 2 : 1);
 }
 
 // ---------------------------------------------------------------------------------------------- the row epilogue
@@ -341,7 +373,7 @@ extern "C" int32_t mi355_rows_kgroups(int32_t N, int32_t K) {
   static const int wg_env = getenv("MI355_ROWS_WGS") ? atoi(getenv("MI355_ROWS_WGS")) : 0;
   const int steps = K / 64, T = tiles_per_wg(N);
   const int ng = ((N + 15) / 16 + T - 1) / T;
-  int kg = ((wg_env > 0 ? wg_env : 640) + ng / 2) / ng;
+  int kg = ((wg_env > 0 ? wg_env : 512) + ng / 2) / ng;
   if (kg_env > 0) kg = kg_env;
   const int cap = steps / 4 > 0 ? steps / 4 : 1;   // at least one k step per wave
   if (kg > cap) kg = cap;
@@ -351,14 +383,16 @@ extern "C" int32_t mi355_rows_kgroups(int32_t N, int32_t K) {
 }
 
 extern "C" int mi355_rows_gemm(const mi355_rows_gemm_args* ap, void* stream) {
-  MI355_REQUIRE(ap && ap->wt && ap->planes && ap->part, "rows_gemm: null tensor");
+  MI355_REQUIRE(ap && ap->wt && ap->planes && (ap->part || ap->glu_planes_out), "rows_gemm: null tensor");
+  MI355_REQUIRE(!ap->glu_planes_out || (ap->kgroups == 1 && ap->N % 128 == 0 && ((uintptr_t)ap->glu_planes_out) % 16 == 0),
+                "rows_gemm: the fused SwiGLU epilogue needs one K group and N %% 128 == 0");
   const mi355_rows_gemm_args a = *ap;
   MI355_REQUIRE(a.wdtype == MI355_W_BF16 || a.wdtype == MI355_W_F16, "rows_gemm: wdtype must be MI355_W_BF16 or MI355_W_F16");
   MI355_REQUIRE(a.N > 0 && a.K >= 64 && a.K % 64 == 0, "rows_gemm: K must be a positive multiple of 64 (got %d)", a.K);
   MI355_REQUIRE(a.R == 16 || a.R == 32 || a.R == 64, "rows_gemm: planes hold 16, 32 or 64 rows (got %d)", a.R);
   MI355_REQUIRE(a.M >= 1 && a.M <= a.R, "rows_gemm: M must be in [1, R] (got %d, R = %d)", a.M, a.R);
   MI355_REQUIRE(((uintptr_t)a.wt) % 16 == 0 && ((uintptr_t)a.planes) % 16 == 0, "rows_gemm: images must be 16-byte aligned");
-  MI355_REQUIRE(a.ldp >= a.N && a.kgroups >= 1 && a.kgroups <= a.K / 64, "rows_gemm: bad slab geometry (ldp %d, kgroups %d)", a.ldp, a.kgroups);
+  MI355_REQUIRE((a.glu_planes_out || a.ldp >= a.N) && a.kgroups >= 1 && a.kgroups <= a.K / 64, "rows_gemm: bad slab geometry (ldp %d, kgroups %d)", a.ldp, a.kgroups);
   MI355_REQUIRE(a.kgroups == 1 || a.kg_stride >= (int64_t)a.M * a.ldp, "rows_gemm: slabs overlap");
   const int steps = a.K / 64, ntiles = (a.N + 15) / 16, T = tiles_per_wg(a.N);
   const int spg = (steps + a.kgroups - 1) / a.kgroups;

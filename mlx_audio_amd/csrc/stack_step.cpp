@@ -171,6 +171,16 @@ int tall_step(const mi355_stack_desc& d, float* x, int B, int offset, float* ws,
       if (rc) return rc;
     }
     // ---- MLP
+    // SwiGLU in the GEMM's own epilogue (one K group: a workgroup holds complete sums) saves the row-epilogue launch; worth it whenever the column
+    // tiles alone fill the chip (n_in >= 4096: >= 128 workgroups of two tiles) -- measured on the code predictor's 6144 x 1024 image (call 7)
+    if (d.glu && n_in % 128 == 0 && (mi355_rows_kgroups(n_in, D) == 1 || n_in >= 4096)) {
+      mi355_rows_gemm_args g;
+      memset(&g, 0, sizeof(g));
+      g.wt = L.w_in_t; g.wdtype = d.wdtype; g.N = n_in; g.K = D; g.planes = w.px; g.M = B; g.R = R; g.kgroups = 1;
+      g.glu_planes_out = w.pm; g.glu_bias = L.b_in;
+      rc = mi355_rows_gemm(&g, stream);
+      if (rc) return rc;
+    } else {
     rc = rows_gemm_call(w.px, L.w_in_t, d.wdtype, n_in, D, B, R, w.part, &kg, stream);
     if (rc) return rc;
     {
@@ -179,6 +189,7 @@ int tall_step(const mi355_stack_desc& d, float* x, int B, int offset, float* ws,
       f.bias = L.b_in; f.glu = d.glu; f.post_act = d.glu ? MI355_ACT_NONE : d.act; f.planes = w.pm;
       rc = finish(f, n_in, kg);
       if (rc) return rc;
+    }
     }
     rc = rows_gemm_call(w.pm, L.w_out_t, d.wdtype, D, d.d_ff, B, R, w.part, &kg, stream);
     if (rc) return rc;

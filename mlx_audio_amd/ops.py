@@ -260,9 +260,16 @@ def rows_planes(R: int, k: int, device) -> torch.Tensor:
     return torch.zeros(2 * R * k, dtype=torch.int16, device=device)
 
 
-def rows_gemm(planes: torch.Tensor, tl: Tiles16, part: torch.Tensor, M: int, R: int, kgroups: Optional[int] = None):
-    """part[g, :M, :N] = partial products of the g-th range of k steps; ``part`` is fp32 [kgroups, rows >= M, ld >= N] (contiguous slabs)."""
+def rows_gemm(planes: torch.Tensor, tl: Tiles16, part: Optional[torch.Tensor], M: int, R: int, kgroups: Optional[int] = None, *,
+              glu_planes_out: Optional[torch.Tensor] = None, glu_bias: Optional[torch.Tensor] = None):
+    """part[g, :M, :N] = partial products of the g-th range of k steps; ``part`` is fp32 [kgroups, rows >= M, ld >= N] (contiguous slabs).
+    ``glu_planes_out`` (one K group): silu(gate + b) * (up + b) of the (gate, up) column pairs leaves as planes instead."""
     kg = rows_kgroups(tl.n, tl.k) if kgroups is None else kgroups
+    if glu_planes_out is not None:
+        assert kg == 1 and glu_planes_out.numel() * glu_planes_out.element_size() >= 4 * R * (tl.n // 2)
+        _lib.call_struct("mi355_rows_gemm", "mi355_rows_gemm_args", _stream(), wt=_ptr(tl.w), wdtype=tl.wdtype, N=tl.n, K=tl.k, planes=_ptr(planes), M=M, R=R,
+                         kgroups=1, glu_planes_out=_ptr(glu_planes_out), glu_bias=_ptr(glu_bias))
+        return 1
     assert part.dtype == torch.float32 and part.dim() == 3 and part.shape[0] >= kg and part.shape[1] >= M and part.shape[2] >= tl.n and part.stride(2) == 1
     assert planes.numel() * planes.element_size() >= 4 * R * tl.k
     _lib.call_struct("mi355_rows_gemm", "mi355_rows_gemm_args", _stream(), wt=_ptr(tl.w), wdtype=tl.wdtype, N=tl.n, K=tl.k, planes=_ptr(planes), M=M, R=R,

@@ -803,3 +803,30 @@ def test_rows_finish_outputs(ops, M, mode, kvd):
     assert rel_err(y.cpu(), out[:, :64]) < 4e-5
     exp_slot = out[:, 64:].to(torch.float32).to(kvd).double()
     assert rel_err(slot[:, 1, : N2 - 64].double().cpu(), exp_slot) < 1e-2 and float(slot[:, 0].abs().max()) == 0.0
+
+
+def _decode_planes(planes, R, K, f16):
+    """hi + lo planes (fragment order, see mi355audio.h) -> float64 [R, K]."""
+    raw = planes[: 2 * R * K].cpu().view(torch.float16 if f16 else torch.bfloat16).double().reshape(K // 64, 2, 2, 4, R, 8)
+    x = raw[:, 0] + raw[:, 1]                      # [step, half, group, row, 8]
+    return x.permute(3, 0, 2, 1, 4).reshape(R, K)  # column = 64 step + 16 group + 8 half + e
+
+
+@pytest.mark.parametrize("M,N,K,use_bias", [(64, 12288, 2048, False), (20, 512, 128, True), (9, 256, 64, True)])
+def test_rows_gemm_fused_swiglu_epilogue(ops, M, N, K, use_bias):
+    """One K group: mi355_rows_gemm applies SwiGLU itself and writes the result as planes (no row-epilogue launch); against float64, and the planes
+    written by the converter decode back to the input (the layout the header documents)."""
+    g = torch.Generator().manual_seed(M + N)
+    w = _round16(torch.randn(N, K, generator=g) / math.sqrt(K), False)
+    bias = torch.randn(N, generator=g) * 0.1 if use_bias else None
+    x = torch.randn(M, K, generator=g)
+    v = x.double() @ w.double().T + (bias.double() if use_bias else 0.0)
+    exp = F.silu(v[:, 0::2]) * v[:, 1::2]
+    R = ops.rows_R(M)
+    tl = ops.tiles16_from_rowmajor(ops.pack_rowmajor16(w, None, DEV))
+    pin, pout = ops.rows_planes(R, K, DEV), ops.rows_planes(R, N // 2, DEV)
+    ops.rows_finish(x.to(DEV), M, K, planes=pin, R=R)
+    ops.rows_gemm(pin, tl, None, M, R, kgroups=1, glu_planes_out=pout, glu_bias=None if bias is None else bias.to(DEV))
+    torch.cuda.synchronize()
+    assert rel_err(_decode_planes(pin, R, K, False)[:M], x.double()) < 1e-5
+    assert rel_err(_decode_planes(pout, R, N // 2, False)[:M], exp) < 3e-5
