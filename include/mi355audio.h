@@ -80,7 +80,8 @@ typedef struct {
   int32_t pre_act;     /* MI355_ACT_NONE / LEAKY / SNAKE */
   float pre_slope;     /* leaky slope */
   const float* pre_alpha; /* [Cin padded to 32] snake alpha, nullable unless SNAKE */
-  /* epilogue: y = acc + bias[n]; y = act(y); y += res; y *= out_scale; y += (accumulate? old y) */
+  /* epilogue, in this order: v = act(acc + bias[n]) * colscale[n]; v += res; v += (accumulate ? old y : 0); y = v * out_scale
+     (out_scale multiplies the accumulated value too: the BigVGAN / iSTFTNet stage mean sets out_scale = 1 / num_kernels on the LAST accumulating block only) */
   const float* bias;   /* [Cout] nullable */
   int32_t post_act;    /* MI355_ACT_NONE / LEAKY / GELU */
   float post_slope;

@@ -257,6 +257,8 @@ __global__ __launch_bounds__(kT) void whisper_greedy_step_reg_kernel(const mi355
   // the chosen token's filtered logit lives in one thread's registers: hand it over through LDS
   __shared__ float chosen_x;
   const int chosen = a.forced_next ? a.forced_next[b] : best.i;
+  if (tid == 0) chosen_x = -INFINITY;   // an out-of-range forced id contributes log p = -inf instead of uninitialised shared memory
+  __syncthreads();
   if (chosen >= 0 && chosen < a.V && (chosen & (kT - 1)) == tid) {
 #pragma unroll
     for (int j = 0; j < NV; ++j) if (j == (chosen >> 10)) chosen_x = x1[j];
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(kTS) void whisper_step_split_b_kernel(const mi355_w
       if (m_i > NEG) FS += __hip_atomic_load(recs + i * 12 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * expf(m_i - FM);
     }
     const int chosen = a.forced_next ? a.forced_next[b] : (a.gumbel ? B2.i : B1.i);
-    float xc = step_l1(a, c, chosen) + step_mask2(a, c, chosen);
+    float xc = (chosen >= 0 && chosen < a.V) ? step_l1(a, c, chosen) + step_mask2(a, c, chosen) : -INFINITY;   // out-of-range forced id: no read
     if (text_killed && chosen < a.timestamp_begin) xc = NEG;
     const bool done = c.last == a.eot;
     if (!done) a.sum_logprobs[b] += xc - (FM + logf(FS));

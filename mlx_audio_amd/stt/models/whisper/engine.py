@@ -74,7 +74,7 @@ class WhisperEngine:
         ops.require_gpu()
         assert precision in (3, 4)
         assert kv_dtype in ops.KV_DTYPES
-        self.kv_dtype = kv_dtype  # cross-attention K | V cache: the checkpoint dtype (fp16), like the reference; float32 keeps the wider copy
+        self.kv_dtype = kv_dtype  # K | V caches: Model.load_weights passes the checkpoint's floating dtype (the reference's cache dtype); default fp16 = the published checkpoints
         self.dims = dims
         self.device = torch.device(device)
         self.precision = precision

@@ -103,8 +103,13 @@ class Model:
 
         w = dict(weights)
         try:
+            # the K / V caches live in the checkpoint's floating dtype like the reference's (whisper.py:360-361): fp16 -> fp16, bf16 -> bf16, fp32 -> fp32
+            fdt = [v.dtype for v in w.values() if v.is_floating_point()]
+            kv_dtype = max(set(fdt), key=fdt.count) if fdt else torch.float16
+            if kv_dtype not in (torch.float16, torch.bfloat16, torch.float32):
+                kv_dtype = torch.float32
             self.engine = WhisperEngine({k: v.to(torch.float32) for k, v in w.items() if v.is_floating_point()}, self.dims,
-                                        device=self.device, precision=self.precision)
+                                        device=self.device, precision=self.precision, kv_dtype=kv_dtype)
         except KeyError as e:
             raise ValueError(f"Whisper checkpoint is missing parameter {e}") from e
         return self

@@ -183,10 +183,16 @@ class Model:
         if voice in self.speed_priors:
             speed = speed * self.speed_priors[voice]
         if clean_text:
-            if self.text_preprocessor is None:
-                raise NotImplementedError("KittenTTS.generate(clean_text=True): text normalisation runs on the host and is not part of this package; "
-                                          "set model.text_preprocessor to a callable (the reference's TextPreprocessor) or pass clean_text=False")
-            text = self.text_preprocessor(text)
+            if self.text_preprocessor is not None:
+                text = self.text_preprocessor(text)
+            elif not getattr(self, "_warned_no_preprocessor", False):
+                # the reference's TextPreprocessor (number / currency / unit expansion, kitten_tts.py:30-330) is host-side text normalisation outside
+                # the hot path; a default generate() call must still work out of the box, so without one the text goes to the phonemizer as it is
+                import warnings
+
+                warnings.warn("KittenTTS.generate(clean_text=True) without model.text_preprocessor: the text is phonemized un-normalised "
+                              "(set model.text_preprocessor to a callable for the reference's number / unit expansion)", stacklevel=3)
+                self._warned_no_preprocessor = True
         phonemes = " ".join(basic_english_tokenize(self._get_phonemizer().phonemize([text])[0]))
         tokens = [0, *self._text_cleaner(phonemes), 0]
         rows = self.voices[voice]

@@ -44,15 +44,17 @@ class Segment:
 
 def csm_config_from_dict(config: Dict) -> CSMConfig:
     """Explicit sizes (``create_llama_model_args_for_backbone / _for_decoder``, sesame.py:165-201) when the config carries them, else the flavor
-    presets.  RoPE: theta / Llama-3 factor from ``rope_scaling`` (defaults 5e5 / 32), 2048 positions."""
+    presets.  RoPE: theta (default 5e5) and the Llama-3 factor from ``rope_scaling`` (no ``factor`` key = 1.0 = unscaled, as attention.py:132), 2048 positions."""
     def stack(d: Dict, flavor: Optional[str]):
-        if "hidden_size" in d and "num_hidden_layers" in d:
+        # explicit sizes need a rope_scaling dict (sesame.py:165-201 reads cfg.rope_scaling; attention.py:132 ``.get("factor", 1.0)``); without one the
+        # reference's constructor fails and its caller falls back to the flavor presets
+        if "hidden_size" in d and "num_hidden_layers" in d and (isinstance(d.get("rope_scaling"), dict) or flavor not in _FLAVORS):
             hd = d.get("head_dim") or d["hidden_size"] // d["num_attention_heads"]
             sc = llama_stack(d["hidden_size"], d["num_hidden_layers"], d["num_attention_heads"], d.get("num_key_value_heads", d["num_attention_heads"]),
                              hd, d["intermediate_size"])
             sc.norm_eps = float(d.get("rms_norm_eps", 1e-5))
             sc.rope_theta = float(d.get("rope_theta", 500000.0))
-            sc.rope_llama3_factor = float((d.get("rope_scaling") or {}).get("factor", 32.0))
+            sc.rope_llama3_factor = float((d.get("rope_scaling") or {}).get("factor", 1.0))   # attention.py:132: no factor = no scaling
             sc.max_pos = int(d.get("max_position_embeddings", 2048))
             return sc
         if flavor not in _FLAVORS:

@@ -98,6 +98,22 @@ def test_conv_gemm_plain(ops, cin, cout, k, dil, L, B, tile):
         assert rel_err(got, ref) < tol, (prec, rel_err(got, ref))
 
 
+@pytest.mark.parametrize("tile", [0, 6128128])
+def test_conv_gemm_accumulate_then_out_scale(ops, tile):
+    """The epilogue order the header states: y = (act(acc + bias) + res + old y) * out_scale -- out_scale multiplies the accumulated value too (the
+    resblock-stage mean of iSTFTNet / BigVGAN: blocks j > 0 accumulate, the last one carries out_scale = 1 / num_kernels)."""
+    g = torch.Generator().manual_seed(5)
+    cin, cout, k, L, B = 128, 128, 3, 300, 2
+    w = bf16r(torch.randn(cout, k, cin, generator=g) / math.sqrt(k * cin))
+    bias = torch.randn(cout, generator=g) * 0.1
+    x, res, old = torch.randn(B, L, cin, generator=g), torch.randn(B, L, cout, generator=g), torch.randn(B, L, cout, generator=g)
+    ref = (ref_conv_nlc(x, w, bias, 1, 1) + res.double() + old.double()) / 3.0
+    y = old.to(DEV).clone()
+    ops.conv_gemm(x.to(DEV), ops.pack_conv(w, bias, DEV), y, dil=1, pad=1, res=res.to(DEV), accumulate=True, out_scale=1.0 / 3.0, tile=tile)
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu(), ref) < 3e-5, rel_err(y.cpu(), ref)
+
+
 @pytest.mark.parametrize("tile,res_shift,act", [(0, 1, "snake"), (6128128, 1, "snake"), (6128128, 0, "snake"), (128128, 0, "leaky"),
                                                  (6128128, 0, "leaky"), (64064, 0, "snake"), (16128128, 0, "snake"),
                                                  (86128128, 1, "snake"), (86128128, 0, "snake"), (86128128, 0, "leaky")])

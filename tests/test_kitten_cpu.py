@@ -169,6 +169,22 @@ def test_generate_host_logic_matches_the_reference_generate():
     model = Probe(ModelConfig.from_dict(cfg))
     model.voices = {"expr-voice-2-f": np.zeros((40, 256), dtype=np.float32)}
     model._phonemizer = Phonemizer()
+    # default arguments (clean_text=True) with no text_preprocessor installed: works out of the box (one warning), same result as clean_text=False
+    import warnings
+
+    with warnings.catch_warnings(record=True) as wlog:
+        warnings.simplefilter("always")
+        res_default = list(model.generate(PT.KITTEN_GENERATE_CASES[0]["text"], voice="kiki"))
+        list(model.generate(PT.KITTEN_GENERATE_CASES[0]["text"], voice="kiki"))
+    assert len([w for w in wlog if "text_preprocessor" in str(w.message)]) == 1
+    calls_default = [list(c) for c in calls]
+    calls.clear()
+    res_plain = list(model.generate(PT.KITTEN_GENERATE_CASES[0]["text"], voice="kiki", clean_text=False))
+    assert calls_default[: len(calls)] == calls and len(res_default) == len(res_plain) and torch.equal(res_default[0].audio, res_plain[0].audio)
+    model.text_preprocessor = lambda t: t.upper()   # an installed preprocessor is applied
+    calls.clear()
+    list(model.generate("ab", voice="kiki"))
+    model.text_preprocessor = None
     for case, exp in zip(PT.KITTEN_GENERATE_CASES, want):
         calls.clear()
         res = list(model.generate(case["text"], voice="kiki", clean_text=False, **case["kw"]))

@@ -233,7 +233,7 @@ def test_kitten_front_end_and_vocoder_without_quantisation(plain):
     err = float((got - audio_ref[0]).abs().max())
     snr = snr_db(got, audio_ref[0])
     print(f"kitten (no quantisation) vocoder teacher-forced: F={F} peak={peak:.3f} max_abs_err={err:.3e} snr={snr:.1f} dB")
-    assert err <= 2e-3 * max(peak, 1.0) and snr >= 50.0
+    assert err <= 2e-3 * peak and snr >= 50.0
 
 
 def test_kitten_durations_are_not_clipped_at_100(plain):

@@ -10,6 +10,7 @@ kernel, the log-mel front end and the dsp API are held to the reference's own fu
 """
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -17,6 +18,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -39,7 +41,7 @@ def test_mimi_engine_vs_reference_run():
     got = eng(M.make_codes(2, int(fx["n_frames"]), cfg, seed=int(fx["seed_codes"]))).cpu().numpy()
     err, peak = _peak_err(got, fx["pcm"])
     print(f"mimi HIP vs reference run: max-abs {err:.2e} (peak {peak:.2f}), SNR {_snr(got, fx['pcm']):.1f} dB")
-    assert got.shape == fx["pcm"].shape and err <= 2e-3 * max(peak, 1.0) and _snr(got, fx["pcm"]) >= 50.0
+    assert got.shape == fx["pcm"].shape and err <= 2e-3 * peak and _snr(got, fx["pcm"]) >= 50.0
 
 
 def test_qwen3_codec_engine_vs_reference_run():
@@ -52,7 +54,7 @@ def test_qwen3_codec_engine_vs_reference_run():
     got = eng(QS.make_codes(2, int(fx["n_frames"]), cfg, seed=int(fx["seed_codes"]))).cpu().numpy()
     err, peak = _peak_err(got, fx["audio"])
     print(f"qwen3 codec HIP vs reference run: max-abs {err:.2e} (peak {peak:.2f}), SNR {_snr(got, fx['audio']):.1f} dB")
-    assert got.shape == fx["audio"].shape and err <= 2e-3 * max(peak, 1.0) and _snr(got, fx["audio"]) >= 50.0
+    assert got.shape == fx["audio"].shape and err <= 2e-3 * peak and _snr(got, fx["audio"]) >= 50.0
 
 
 def test_csm_engine_vs_reference_run():
@@ -124,12 +126,22 @@ def test_whisper_engine_vs_reference_run():
     tok = TokenizerSpec(non_speech_tokens=tuple(int(t) for t in fx["non_speech_tokens"]))
     suppress = sorted(set([int(t) for t in fx["non_speech_tokens"]] + [tok.transcribe, tok.translate, tok.sot, tok.sot_prev, tok.sot_lm, tok.no_speech]))
     want = fx["nots_tokens"]
-    out = eng.decode(mel.to(DEV), tok, sample_len=int(fx["sample_len"]), without_timestamps=True, suppress_tokens=suppress)
+    out = eng.decode(mel.to(DEV), tok, sample_len=int(fx["sample_len"]), without_timestamps=True, suppress_tokens=suppress, record=True)
     torch.cuda.synchronize()
     got = out["tokens"][:, out["sample_begin"]:].cpu().numpy()
     same = int((got[:, : want.shape[1]] == want).sum())
     print(f"whisper HIP vs reference run: {same}/{want.size} free-running tokens equal")
-    assert (got[:, :3] == want[:, :3]).all()  # the first decisions; later ones follow the margin rule of tests/test_whisper_gpu.py
+    # every free-running token of the reference run, under the margin rule (tests/_margin.py): a sequence is compared in generation order up to its
+    # first decision whose top-2 gap of the filtered logits is below 1e-2; at least 90 % of the fixture's decisions must have been compared
+    import _margin as margin_rule
+
+    compared = 0
+    for b in range(want.shape[0]):
+        n = min(got.shape[1], want.shape[1])
+        top2 = [torch.topk(t["filtered"][b].float(), 2).values for t in out["trace"][:n]]
+        margins = [float(v[0] - v[1]) for v in top2]
+        compared += margin_rule.walk("whisper_fixture", got[b, :n].tolist(), want[b, :n].tolist(), margins, where=("fixture", b))
+    assert compared >= 0.9 * want.size, (compared, want.size)
 
 
 @pytest.mark.parametrize("name", ["dac", "snac", "vocos"])
@@ -165,7 +177,7 @@ def test_float32_codec_engines_vs_reference_run(name):
     err, peak = _peak_err(got, fx["audio"])
     snr = _snr(got, fx["audio"])
     print(f"{name} HIP vs reference run: max-abs {err:.2e} (peak {peak:.3f}), SNR {snr:.1f} dB")
-    assert err <= 2e-3 * max(peak, 1.0) and snr >= 50.0
+    assert err <= 2e-3 * peak and snr >= 50.0
 
 
 def test_sampler_kernel_vs_reference_chain():

@@ -1,0 +1,26 @@
+"""Floors on the margin rule's coverage, asserted at the END of a GPU session (this module sorts last): the rule (tests/_margin.py) lets a free-running
+sequence stop being compared at its first knife-edge decision, so the fraction it hides must be a bounded, failing number -- not only a printed one.
+Families with fewer than 20 decisions in this session (a partial run) are skipped."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _margin  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+# measured on MI355X (rounds 2-3): whisper 100 %, whisper_fixture 100 %, csm 100 %, qwen3_tts 81.5-100 %
+FLOORS = {"whisper": 0.90, "whisper_fixture": 0.90, "csm": 0.90, "qwen3_tts": 0.70}
+
+
+def test_margin_rule_coverage_floors():
+    seen = 0
+    for fam, (compared, skipped, _edges, _seqs) in _margin.REPORT.items():
+        if compared + skipped < 20:
+            continue
+        seen += 1
+        frac = compared / (compared + skipped)
+        assert frac >= FLOORS.get(fam, 0.6), (fam, compared, skipped, frac)
+    print(f"margin-rule floors checked for {seen} famil{'y' if seen == 1 else 'ies'}")
