@@ -466,7 +466,8 @@ typedef struct {
      q holds the RAW projection output; new_k / new_v [B, kv_heads * dh] (items new_bstride floats apart) hold the raw k, v of the new position
      Tk - 1, which is NOT in the cache yet.  The kernel applies the per-head RMSNorm (q_norm_w / k_norm_w [dh], nullable) and the rotary
      embedding (rope_cos / rope_sin [rope_rows, dh / 2], nullable; rope_mode as in mi355_head_rope_args; position rope_pos - k_start[b]) to q and
-     to the new k, attends over the cache rows [.., Tk - 1) plus the new pair, and writes the processed k and the v into cache row Tk - 1. */
+     to the new k, attends over the cache rows [.., Tk - 1) plus the new pair, and writes the processed k and the v into cache row Tk - 1.
+     With lens_k (slot caches of a continuous-batching session) item b's Tk is lens_k[b]: its new row and its rotary position are lens_k[b] - 1. */
   const float* new_k; const float* new_v; int64_t new_bstride;
   const float* q_norm_w; const float* k_norm_w; float norm_eps;
   const float* rope_cos; const float* rope_sin; int32_t rope_rows; int32_t rope_mode; int32_t rope_pos;
@@ -702,6 +703,10 @@ typedef struct {
                               checkpoint dtype, lm/models/cache.py:104-176).  16-bit caches need the stores that exist: q|k|v GEMV with the rotary pairs in its
                               epilogue, the fused norm / rope attention step, or no rotary embedding at all */
   void* rows_ws; int64_t rows_ws_bytes;   /* steps for 9..64 sequences: planes + partial slabs, mi355_stack_rows_ws_bytes(d, B) bytes (nullable otherwise) */
+  const int32_t* slot_lens_k;  /* [B] nullable (device): SLOT caches of a continuous-batching session -- sequence b holds slot_lens_k[b] - 1 cached positions
+                                  and this step appends position slot_lens_k[b] - 1 to ITS row of every kv buffer (rotary position = that index); `offset`
+                                  is then only the host's upper bound of the positions (capacity / table checks).  Needs the fused attention step
+                                  (per-head norms and / or rotary embedding, causal). */
 } mi355_stack_desc;
 
 /* ------------------------------------------------------------------------------------------

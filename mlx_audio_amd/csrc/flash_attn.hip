@@ -520,7 +520,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
         if (act) { x0 = x0 * r * nw[i0]; x1 = x1 * r * nw[i1]; }
       }
       if (a.rope_cos && act) {
-        int pos = a.rope_pos - (a.k_start ? a.k_start[b] : 0);
+        int pos = (a.lens_k ? len_k - 1 : a.rope_pos) - (a.k_start ? a.k_start[b] : 0);   // slot caches: every item is at its own position
         pos = pos < 0 ? 0 : (pos >= a.rope_rows ? a.rope_rows - 1 : pos);
         const float c = a.rope_cos[(int64_t)pos * half + lane], sn = a.rope_sin[(int64_t)pos * half + lane];
         const float y0 = x0 * c - x1 * sn;
@@ -792,8 +792,8 @@ extern "C" int mi355_flash_attention(const mi355_flash_attn_args* ap, void* stre
   MI355_REQUIRE(a.kv_dtype >= MI355_KV_F32 && a.kv_dtype <= MI355_KV_F16, "flash_attention: kv_dtype must be MI355_KV_F32, MI355_KV_BF16 or MI355_KV_F16");
   const int kvt = a.kv_dtype;
   MI355_REQUIRE(kvt == 0 || (((uintptr_t)a.k | (uintptr_t)a.v) % 8 == 0), "flash_attention: 16-bit K / V must be 8-byte aligned");
-  MI355_REQUIRE(!a.new_k || (a.new_v && a.Tq == 1 && !a.lens_q && !a.lens_k && a.mode != 1 && a.nsplit <= 1 && a.causal),
-                "flash_attention: the fused norm / rope step is a causal single-query decode step without ragged lengths or key split");
+  MI355_REQUIRE(!a.new_k || (a.new_v && a.Tq == 1 && !a.lens_q && a.mode != 1 && a.nsplit <= 1 && a.causal),
+                "flash_attention: the fused norm / rope step is a causal single-query decode step without ragged query lengths or key split");
   MI355_REQUIRE(!a.new_k || !a.rope_cos || (a.rope_sin && a.rope_rows > 0), "flash_attention: rope tables incomplete");
   hipStream_t st = (hipStream_t)stream;
   MI355_CLEAR_ERROR();

@@ -111,6 +111,7 @@ int tall_step(const mi355_stack_desc& d, float* x, int B, int offset, float* ws,
     const bool rope_in_attn = (L.q_norm || d.cos) && d.causal;
     MI355_REQUIRE(d.kv_dtype == MI355_KV_F32 || rope_in_attn || !(L.q_norm || d.cos),
                   "stack_decode_step: a 16-bit KV cache needs the rotary embedding inside the attention step");
+    MI355_REQUIRE(!d.slot_lens_k || rope_in_attn, "stack_decode_step: slot caches need the fused attention step (per-head norms / rotary embedding, causal)");
     // ---- q | k | v
     rc = rows_gemm_call(w.px, L.wqkv_t, d.wdtype, nq + nkv, D, B, R, w.part, &kg, stream);
     if (rc) return rc;
@@ -124,6 +125,7 @@ int tall_step(const mi355_stack_desc& d, float* x, int B, int offset, float* ws,
       a.kv_dtype = d.kv_dtype;
       a.heads = H; a.kv_heads = G; a.dh = dh; a.Tq = 1; a.Tk = offset + 1; a.causal = 1; a.window = d.window; a.scale = scale; a.B = B; a.mode = 2;
       a.out_planes = w.pa; a.planes_R = R; a.planes_dtype = d.wdtype; a.out_bstride = nq; a.ldo = nq; a.k_start = d.k_start; a.nsplit = 1;
+      a.lens_k = d.slot_lens_k;
       a.new_k = w.part + nq; a.new_v = w.part + nq + G * dh; a.new_bstride = ld;
       a.in_kgroups = kg; a.in_kg_stride = (int64_t)B * ld;
       if (L.bqkv) { a.q_bias = L.bqkv; a.k_bias = L.bqkv + nq; a.v_bias = L.bqkv + nq + G * dh; }
@@ -250,14 +252,15 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
     // interleaved RoPE without per-head q / k norms (CSM Llama, Mimi): the rotation of a pair (2i, 2i + 1) is the epilogue of the wave that owns
     // those two columns of the q | k | v projection -- one launch less per layer (MI355_GEMV_ROPE=0 keeps the separate kernel for A/B runs)
     static const bool rope_off = getenv("MI355_GEMV_ROPE") != nullptr && getenv("MI355_GEMV_ROPE")[0] == '0';
-    const bool rope_in_gemv = d.cos && d.rope_mode == 1 && !L.q_norm && !L.k_norm && B <= 4 && !rope_off && !d.k_start;  // one table row for all rows
+    const bool rope_in_gemv = d.cos && d.rope_mode == 1 && !L.q_norm && !L.k_norm && B <= 4 && !rope_off && !d.k_start && !d.slot_lens_k;  // one table row for all rows
     const float* rc_row = rope_in_gemv ? d.cos + (int64_t)offset * (dh / 2) : nullptr;
     const float* rs_row = rope_in_gemv ? d.sin + (int64_t)offset * (dh / 2) : nullptr;
     // per-head q / k norms and / or rotate-half RoPE (Qwen3 talker / code predictor / codec transformer): the attention kernel applies them to q
     // and to the new k itself and files k, v into the cache (mi355_flash_attn_args.new_k) -- the raw k | v of this step go to a scratch row (the
     // tail of the workspace) instead of the cache slot.  MI355_ATTN_FUSE_ROPE=0 keeps the separate head_norm_rope launch.
     static const bool fuse_off = getenv("MI355_ATTN_FUSE_ROPE") != nullptr && getenv("MI355_ATTN_FUSE_ROPE")[0] == '0';
-    const bool rope_in_attn = !rope_in_gemv && (L.q_norm || d.cos) && (!fuse_off || d.kv_dtype != MI355_KV_F32) && d.causal;
+    const bool rope_in_attn = !rope_in_gemv && (L.q_norm || d.cos) && (!fuse_off || d.kv_dtype != MI355_KV_F32 || d.slot_lens_k) && d.causal;
+    MI355_REQUIRE(!d.slot_lens_k || rope_in_attn, "stack_decode_step: slot caches need the fused attention step (per-head norms / rotary embedding, causal)");
     MI355_REQUIRE(d.kv_dtype == MI355_KV_F32 || rope_in_gemv || rope_in_attn || !(L.q_norm || d.cos),
                   "stack_decode_step: a 16-bit KV cache needs the rotary embedding inside the q|k|v GEMV or inside the attention step");
     float* kvtmp = mid + (size_t)B * d.d_ff;  // [B, nkv]: the tail of the workspace
@@ -271,7 +274,7 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
       a.q = q; a.q_bstride = nq; a.ldq = nq; a.k = L.kv; a.k_bstride = L.kv_bstride; a.ldk = nkv; a.v = vbase; a.v_bstride = L.kv_bstride; a.ldv = nkv;
       a.kv_dtype = d.kv_dtype;
       a.heads = H; a.kv_heads = G; a.dh = dh; a.Tq = 1; a.Tk = offset + 1; a.causal = 1; a.window = d.window; a.scale = scale; a.B = B; a.mode = 2;
-      a.out = att; a.out_bstride = nq; a.ldo = nq; a.k_start = d.k_start; a.nsplit = 1;
+      a.out = att; a.out_bstride = nq; a.ldo = nq; a.k_start = d.k_start; a.nsplit = 1; a.lens_k = d.slot_lens_k;
       a.new_k = kvtmp; a.new_v = kvtmp + G * dh; a.new_bstride = nkv; a.q_norm_w = L.q_norm; a.k_norm_w = L.k_norm; a.norm_eps = d.eps;
       a.rope_cos = d.cos; a.rope_sin = d.sin; a.rope_rows = d.rope_rows; a.rope_mode = d.rope_mode; a.rope_pos = offset;
       rc = mi355_flash_attention(&a, stream);

@@ -296,12 +296,13 @@ class TransformerStack:
         return [KVCache(self.cfg.n_kv_heads, self.cfg.head_dim, self.device, self.kv_dtype) for _ in range(self.cfg.n_layers)]
 
     # ------------------------------------------------------------------ native decode step (mi355_stack_decode_step)
-    def _native_desc(self, cache: List[KVCache], k_start: Optional[torch.Tensor] = None, tall: bool = False):
+    def _native_desc(self, cache: List[KVCache], k_start: Optional[torch.Tensor] = None, tall: bool = False, slot_lens_k: Optional[torch.Tensor] = None):
         """Builds (or refreshes after a cache re-allocation) the C descriptor of this stack for the given caches.  The key carries everything the
         descriptor stores about a cache: the caching allocator may hand a later, differently sized cache the same addresses.  ``tall``: the step
         carries 9..64 sequences -- the descriptor then also names the tile images and the rows workspace (built on first use, kept)."""
         tall = self.rows_pipe and (tall or getattr(self, "_rows_ws", None) is not None)
-        key = tuple((c.kv.data_ptr(), c.kv.shape[0], c.kv.shape[1], c.kv.stride(0)) for c in cache) + (None if k_start is None else k_start.data_ptr(), tall)
+        key = tuple((c.kv.data_ptr(), c.kv.shape[0], c.kv.shape[1], c.kv.stride(0)) for c in cache) + (None if k_start is None else k_start.data_ptr(), tall,
+                                                                                                           None if slot_lens_k is None else slot_lens_k.data_ptr())
         st = getattr(self, "_native", None)
         if st is not None and st["key"] == key:
             return st
@@ -330,6 +331,7 @@ class TransformerStack:
         d.rope_mode, d.cos, d.sin = int(c.rope_interleaved), p(self.cos), p(self.sin)
         d.rope_rows = 0 if self.cos is None else self.cos.shape[0]
         d.k_start = p(k_start)
+        d.slot_lens_k = p(slot_lens_k)
         d.kv_dtype = ops.KV_DTYPES[cache[0].kv.dtype]
         d.layers = ctypes.cast(arr, ctypes.c_void_p)
         sws, scnt = ops.attn_split_workspace(self.device, 8 * c.n_heads, c.head_dim)  # key-split decode attention (long key ranges)
@@ -344,7 +346,7 @@ class TransformerStack:
                 assert need > 0
                 self._rows_ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
             d.rows_ws, d.rows_ws_bytes = self._rows_ws.data_ptr(), self._rows_ws.numel()
-        self._native = dict(key=key, arr=arr, desc=d, k_start=k_start)
+        self._native = dict(key=key, arr=arr, desc=d, k_start=k_start, slot_lens_k=slot_lens_k)
         return self._native
 
     def _check_positions(self, offset: int, n_new: int):
@@ -352,7 +354,8 @@ class TransformerStack:
         if self.cos is not None and offset + n_new > self.cos.shape[0]:
             raise ValueError(f"sequence position {offset + n_new - 1} is past the {self.cos.shape[0]}-row rotary tables (max_pos) of this stack")
 
-    def decode_step(self, x: torch.Tensor, cache: List[KVCache], k_start: Optional[torch.Tensor] = None, defer_final_norm: bool = False) -> torch.Tensor:
+    def decode_step(self, x: torch.Tensor, cache: List[KVCache], k_start: Optional[torch.Tensor] = None, defer_final_norm: bool = False,
+                    slot_lens_k: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One single-position step for B <= ``max_decode_rows`` sequences through the native runner: x [B, 1, d_model] (updated in place); returns the
         final-normed hidden state [B, 1, d_model] (or x itself when the stack has no final norm).  ``k_start`` int32 [B]: left padding.
         ``defer_final_norm``: return the UN-normalised residual stream; the caller fuses the final norm into the GEMV that consumes it
@@ -363,7 +366,9 @@ class TransformerStack:
         self._check_positions(off, 1)
         for kvc in cache:
             kvc.reserve(B, 1)
-        st = self._native_desc(cache, k_start, tall=B > 8 and self.rows_pipe)
+        if slot_lens_k is not None:   # slot caches (continuous batching): int32 [B] device, item b appends position slot_lens_k[b] - 1 to its own row
+            assert slot_lens_k.dtype == torch.int32 and slot_lens_k.is_cuda and slot_lens_k.numel() >= B and k_start is None
+        st = self._native_desc(cache, k_start, tall=B > 8 and self.rows_pipe, slot_lens_k=slot_lens_k)
         ws = torch.empty(B * (2 * c.n_heads * c.head_dim + c.d_ff + 2 * c.n_kv_heads * c.head_dim), dtype=torch.float32, device=self.device)
         out = torch.empty_like(x) if (self.final_norm is not None and not defer_final_norm) else None
         lib = _lib.load()

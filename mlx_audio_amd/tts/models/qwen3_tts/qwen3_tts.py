@@ -89,7 +89,16 @@ class Model:
         return True
 
     def supports_tts_continuous_batch(self, **kwargs) -> bool:
-        return False  # continuous_batching.py:37-360 (per-request KV merge / extract) is not wired to the engine yet
+        """``qwen3_tts.py:254-257``."""
+        if kwargs.get("ref_audio") is not None or kwargs.get("ref_text") is not None:
+            return False
+        return self.supports_tts_batch(**kwargs)
+
+    def create_tts_batch_session(self, options, **kw):
+        """``qwen3_tts.py:1114-1120``: the step-wise session the serving shell drives (``add`` / ``cancel`` / ``step``), here on slot KV caches."""
+        from .continuous_batching import Qwen3TTSBatchSession
+
+        return Qwen3TTSBatchSession(self, options, **kw)
 
     def load_speech_tokenizer(self, speech_tokenizer: Qwen3TTSSpeechTokenizer):
         self.speech_tokenizer = speech_tokenizer

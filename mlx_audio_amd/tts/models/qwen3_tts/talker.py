@@ -280,3 +280,221 @@ class Qwen3Talker:
             if bool((fa >= 0).all()):
                 codes = codes[:, : int(fa.max()) + 1]  # the reference stops at the frame where the last sequence emits EOS
         return dict(codes=codes, finished_at=finished_at, trace=trace)
+
+
+class Qwen3TalkerSlots:
+    """Device-resident state of a continuous-batching session (``tts/models/qwen3_tts/continuous_batching.py:37-360``) over SLOT KV caches.
+
+    The reference keeps one KV cache per request and, at EVERY step, merges the active requests' caches into a left-padded batch cache
+    (``KVCache.merge``) and splits it again afterwards (``extract``): O(KV) copies twice per generated frame.  Here a request owns a
+    slot = one row of every layer's ``[slots, capacity, 2 * kv_heads * dh]`` buffer for its whole life: admission prefills the newcomers as one
+    left-padded batch and files each prompt's keys / values into its slot once; every later step appends in place -- the native step runner takes
+    the per-slot lengths (``mi355_stack_desc.slot_lens_k``), so sequences of different lengths share one launch sequence without any padding,
+    merging or extraction.  Slots without a request are carried as finished rows (their sampler emits EOS, nothing of their state moves).
+    The per-frame arithmetic is ``Qwen3Talker.generate``'s (one talker step, the first-codebook sampling chain with the request's own history,
+    15 code-predictor steps on a fresh cache, next input = trailing text or tts_pad + the 16 codec embeddings)."""
+
+    def __init__(self, eng: "Qwen3Talker", n_slots: int, max_frames: int, *, temperature: float = 0.9, top_k: int = 50, top_p: float = 1.0,
+                 repetition_penalty: float = 1.05, generator: Optional[torch.Generator] = None):
+        assert 1 <= n_slots <= eng.talker.max_decode_rows, f"at most {eng.talker.max_decode_rows} slots per step"
+        self.eng, self.S, self.max_frames = eng, n_slots, max_frames
+        self.kw = dict(temperature=temperature, top_k=top_k, top_p=top_p, repetition_penalty=repetition_penalty)
+        self.generator = generator
+        dev, cfg = eng.device, eng.cfg
+        S, H, G = n_slots, cfg.hidden_size, cfg.num_code_groups
+        self.lens = torch.zeros(S, dtype=torch.int32, device=dev)        # cached positions of each slot
+        self.lens_k = torch.ones(S, dtype=torch.int32, device=dev)       # lens + 1: what the step runner reads
+        self.x_next = torch.zeros((S, 1, H), dtype=torch.float32, device=dev)
+        self.trailing = torch.zeros((S, 1, H), dtype=torch.float32, device=dev)
+        self.trailing_idx = torch.zeros(S, dtype=torch.int64, device=dev)
+        self.pad = torch.zeros((1, H), dtype=torch.float32, device=dev)
+        self.hist = torch.full((S, max_frames + 1), -1, dtype=torch.int32, device=dev)
+        self.hist_len = torch.zeros(S, dtype=torch.int32, device=dev)
+        self.finished = torch.ones(S, dtype=torch.int32, device=dev)     # a free slot is a finished row
+        self.codes = torch.zeros((S, max_frames, G), dtype=torch.int32, device=dev)
+        self.fidx = torch.zeros(S, dtype=torch.int64, device=dev)        # frames generated per slot
+        self.cache = eng.talker.make_cache()
+        self.occupied = torch.zeros(S, dtype=torch.int32, device=dev)    # 1 while the slot holds a request (free slots stay at position 0)
+        self.hlens = [0] * S                                             # host copy of lens for the occupied slots (capacity / table bounds)
+        self.limit = [0] * S                                             # frames a slot's request may still generate in total
+        self.max_len = 0                                                 # max(hlens)
+        self._cp_caches: Dict[int, list] = {}
+        self._ar = torch.arange(S, device=dev)
+
+    # ------------------------------------------------------------------ storage
+    def _ensure_capacity(self, positions: int):
+        """Every layer's slot buffer holds ``positions`` rows per slot (grown in steps of 256, contents kept)."""
+        need = ops.round_up(max(positions, 1), 256)
+        for c in self.cache:
+            if c.kv is None:
+                c.kv = torch.zeros((self.S, need, c.width), dtype=c.dtype, device=c.device)
+            elif c.kv.shape[1] < need:
+                new = torch.zeros((self.S, need, c.width), dtype=c.dtype, device=c.device)
+                new[:, : c.kv.shape[1]] = c.kv
+                c.kv = new
+
+    def _cp_cache(self, B: int):
+        if B not in self._cp_caches:
+            self._cp_caches[B] = self.eng.cp.make_cache()
+        return self._cp_caches[B]
+
+    def _noise(self, B: int, V: int):
+        if self.generator is None or self.kw["temperature"] <= 0:
+            return None
+        e = torch.empty((B, ops.round_up(V, 4)), dtype=torch.float32, device=self.eng.device).exponential_(generator=self.generator)
+        return -torch.log(e)
+
+    # ------------------------------------------------------------------ one frame for B rows (the body of Qwen3Talker.generate's loop)
+    def _frame(self, last: torch.Tensor, hist, hist_len, finished, trailing, trailing_idx):
+        """``last`` [B, 1, H] final-normed talker output.  Updates hist / hist_len / finished / trailing_idx in place for the rows still alive.
+        Returns (codes of the frame [B, G] int32, next input embedding [B, 1, H], alive mask before this frame's EOS took effect)."""
+        eng, cfg = self.eng, self.eng.cfg
+        cp = cfg.code_predictor_config
+        B, H, G = last.shape[0], cfg.hidden_size, cfg.num_code_groups
+        V0, Vc = cfg.vocab_size, cp.vocab_size
+        kw = self.kw
+        ar = self._ar[:B]
+        row = torch.zeros((B, G), dtype=torch.int32, device=eng.device)
+        logits = eng._logits(last, eng.codec_head)
+        ops.sample(logits, row[:, 0], V=V0, suppress_mask=eng.suppress_mask, history=hist, hist_len=hist_len, repetition_penalty=kw["repetition_penalty"],
+                   temperature=kw["temperature"], top_k=kw["top_k"], top_p=kw["top_p"], gumbel=self._noise(B, V0), done=finished,
+                   done_token=cfg.codec_eos_token_id)
+        tok = row[:, 0]
+        finished |= (tok == cfg.codec_eos_token_id).to(torch.int32)
+        cp_cache = self._cp_cache(B)
+        for c in cp_cache:
+            c.reset()
+        tall = B <= eng.cp.max_decode_rows
+        for i in range(G - 1):
+            if i == 0 and tall:
+                x0 = last.clone()
+                if eng.mtp is not None:
+                    xp = eng._f(B, 1, cp.hidden_size)
+                    linear(x0, eng.mtp, xp, precision=eng.precision)
+                    x0 = xp
+                eng.cp(x0, cp_cache)
+                xin = eng._f(B, 1, H)
+                ops.embed_sum(eng.codec_table, row[:, 0:1].unsqueeze(1), xin)
+            elif i == 0:
+                xin = eng._f(B, 2, H)
+                xin[:, 0:1, :] = last
+                ops.embed_sum(eng.codec_table, row[:, 0:1].unsqueeze(1), xin[:, 1:2, :])
+            else:
+                xin = eng._f(B, 1, H)
+                ops.embed_sum(eng.codec_table, row[:, i:i + 1].unsqueeze(1), xin, slot_offset=eng.codec_offs[i:i + 1])
+            if eng.mtp is not None:
+                xp = eng._f(B, xin.shape[1], cp.hidden_size)
+                linear(xin, eng.mtp, xp, precision=eng.precision)
+                xin = xp
+            if xin.shape[1] == 1 and tall and eng.cp.native_decode and (B > 8 or eng.cp.cfg.d_model <= 2048):
+                hc = eng.cp(xin, cp_cache, defer_final_norm=True)
+                lg = eng._logits(hc, eng.lm_heads[i], norm=eng.cp.final_norm_arg())
+            else:
+                hc = eng.cp(xin, cp_cache)
+                lg = eng._logits(hc[:, -1:, :].contiguous(), eng.lm_heads[i])
+            ops.sample(lg, row[:, i + 1], V=Vc, temperature=kw["temperature"], top_k=kw["top_k"], top_p=kw["top_p"], gumbel=self._noise(B, Vc))
+        # next input: the request's next trailing-text position (tts_pad once it is exhausted; rows are right-padded with tts_pad, so the
+        # per-request rule of continuous_batching.py:266-283 and the padded-batch rule of qwen3_tts.py:993-1015 coincide) + the 16 codec embeddings
+        Tt = trailing.shape[1]
+        clamped = torch.clamp(trailing_idx, max=Tt - 1)
+        text = trailing[ar, clamped]
+        text = torch.where((trailing_idx >= Tt)[:, None], self.pad.expand_as(text), text)
+        nx = eng._f(B, 1, H)
+        ops.embed_sum(eng.codec_table, row.unsqueeze(1), nx, slot_offset=eng.codec_offs, add=text[:, None, :].contiguous())
+        alive = finished == 0
+        trailing_idx += alive.to(torch.int64)
+        hist[ar, hist_len.long()] = torch.where(alive, tok, hist[ar, hist_len.long()])
+        hist_len += alive.to(torch.int32)
+        return row, nx, alive
+
+    # ------------------------------------------------------------------ admission (continuous_batching.py:109-189)
+    def admit(self, slots: List[int], input_embeds: torch.Tensor, left_pad: List[int], trailing: torch.Tensor, tts_pad: torch.Tensor) -> List[bool]:
+        """Prefills the newcomers as ONE left-padded batch, files every prompt into its slot, samples their first frame.  ``trailing`` [n, Tt, H]
+        right-padded with ``tts_pad``.  Returns, per newcomer, whether its first token was already EOS."""
+        eng, dev = self.eng, self.eng.device
+        n, L = input_embeds.shape[0], input_embeds.shape[1]
+        assert n == len(slots) == len(left_pad) and len(set(slots)) == n and all(0 <= s < self.S for s in slots)
+        x = input_embeds.to(dev, torch.float32).contiguous().clone()
+        trailing = trailing.to(dev, torch.float32)
+        self.pad = tts_pad.to(dev, torch.float32).reshape(1, -1)
+        plens = [L - int(p) for p in left_pad]
+        rows = eng.talker.cos.shape[0]
+        if max(plens) >= rows:
+            raise ValueError(f"prompt of {max(plens)} positions does not fit the talker's {rows} rotary positions")
+        self._ensure_capacity(max(max(plens), self.max_len) + 2)
+        tmp = eng.talker.make_cache()
+        ks = torch.tensor([int(p) for p in left_pad], dtype=torch.int32, device=dev) if n > 1 or left_pad[0] else None
+        h = eng.talker(x, tmp, k_start=ks)
+        last = h[:, -1:, :].contiguous()
+        for c, t in zip(self.cache, tmp):   # each prompt's keys / values into its slot, ONCE (positions count from the first real token)
+            for r, s in enumerate(slots):
+                c.kv[s, : plens[r]] = t.kv[r, int(left_pad[r]):L]
+        sl = torch.tensor(slots, dtype=torch.long, device=dev)
+        hist = torch.full((n, self.max_frames + 1), -1, dtype=torch.int32, device=dev)
+        hist_len = torch.zeros(n, dtype=torch.int32, device=dev)
+        fin = torch.zeros(n, dtype=torch.int32, device=dev)
+        tidx = torch.zeros(n, dtype=torch.int64, device=dev)
+        row, nx, alive = self._frame(last, hist, hist_len, fin, trailing, tidx)
+        Tt = trailing.shape[1]
+        if Tt > self.trailing.shape[1]:   # widen the slot rows, padding with tts_pad (what the exhausted rule reads)
+            wide = self.pad.expand(self.S, Tt, -1).clone()
+            wide[:, : self.trailing.shape[1]] = self.trailing
+            self.trailing = wide
+        self.trailing[sl] = self.pad.expand(n, self.trailing.shape[1], -1).clone()
+        self.trailing[sl, :Tt] = trailing
+        self.lens[sl] = torch.tensor(plens, dtype=torch.int32, device=dev)
+        self.x_next[sl] = nx
+        self.hist[sl] = hist
+        self.hist_len[sl] = hist_len
+        self.finished[sl] = fin
+        self.trailing_idx[sl] = tidx
+        self.codes[sl, 0] = row
+        self.fidx[sl] = alive.to(torch.int64)
+        self.occupied[sl] = 1
+        for r, sidx in enumerate(slots):
+            self.hlens[sidx] = plens[r]
+            self.limit[sidx] = min(self.max_frames, rows - plens[r])   # a request stops where the rotary tables end (the reference's are unbounded)
+        self.max_len = max(self.hlens)
+        return [bool(v) for v in fin.cpu().tolist()]
+
+    # ------------------------------------------------------------------ one step of every occupied slot (continuous_batching.py:191-239)
+    def advance(self, n_rows: int) -> List[bool]:
+        """One talker step for slots [0, n_rows) (free slots among them ride along as finished rows).  Returns the finished flag of each row."""
+        eng = self.eng
+        n = n_rows
+        torch.add(self.lens[:n], 1, out=self.lens_k[:n])
+        self._ensure_capacity(self.max_len + 2)
+        for c in self.cache:
+            c.offset = self.max_len
+        x = self.x_next[:n].clone()
+        h = eng.talker.decode_step(x, self.cache, slot_lens_k=self.lens_k)
+        row, nx, alive = self._frame(h, self.hist[:n], self.hist_len[:n], self.finished[:n], self.trailing[:n], self.trailing_idx[:n])
+        ar = self._ar[:n]
+        f = torch.clamp(self.fidx[:n], max=self.max_frames - 1)
+        self.codes[ar, f] = torch.where(alive[:, None], row, self.codes[ar, f])
+        self.fidx[:n] += alive.to(torch.int64)
+        # every occupied row appended one position (a row that just emitted EOS too: its request leaves with this step)
+        self.lens[:n] += self.occupied[:n]
+        self.x_next[:n] = nx
+        for sidx in range(n):
+            if self.hlens[sidx] > 0:
+                self.hlens[sidx] += 1
+        self.max_len = max(self.hlens)
+        return [bool(v) for v in self.finished[:n].cpu().tolist()]
+
+    def frames(self, slot: int) -> int:
+        return int(self.fidx[slot])
+
+    def take_codes(self, slot: int, n_frames: int) -> torch.Tensor:
+        """The ``n_frames`` generated code frames of a slot ([n, G] int64) -- the slot can be released afterwards."""
+        return self.codes[slot, :n_frames].to(torch.int64).clone()
+
+    def release(self, slot: int):
+        self.finished[slot] = 1
+        self.occupied[slot] = 0
+        self.hlens[slot] = 0
+        self.max_len = max(self.hlens)
+        self.lens[slot] = 0
+        self.fidx[slot] = 0
+        self.hist_len[slot] = 0
+        self.trailing_idx[slot] = 0

@@ -986,6 +986,105 @@ def run_broker():
     return out["trace"]
 
 
+def run_qwen3_session():
+    """The reference's ``Qwen3TTSBatchSession`` (continuous_batching.py:37-360) over a SCRIPTED model (every request's EOS frame is fixed by
+    ``pt_layouts.QWEN3_SESSION``; the talker only moves the reference's own KV caches along): which requests each ``step()`` advances and admits,
+    and the events it returns, for arrivals / cancellations in the middle of other requests' utterances."""
+    import json
+    from types import SimpleNamespace
+
+    import pt_layouts as PT
+
+    if "mlx_audio" not in sys.modules:
+        import_reference()
+    import_lm_and_mimi()   # lm/models/cache.py: the session's KVCache / BatchKVCache
+    if "mlx_audio.tts.continuous" not in sys.modules:
+        _load("mlx_audio.tts.continuous", f"{REF}/tts/continuous.py")
+    if "mlx_audio.tts.models.qwen3_tts" not in sys.modules:
+        _pkg("mlx_audio.tts.models.qwen3_tts", f"{REF}/tts/models/qwen3_tts")
+    mod = _load("mlx_audio.tts.models.qwen3_tts.continuous_batching", f"{REF}/tts/models/qwen3_tts/continuous_batching.py")
+    cont = sys.modules["mlx_audio.tts.continuous"]
+    cfg = PT.QWEN3_SESSION
+    EOS, script = cfg["eos"], cfg["script"]
+
+    def ids_of(x):  # channel 0 of the last position carries the sequence id
+        return [int(round(float(v))) for v in np.asarray(x)[:, -1, 0]]
+
+    def embed_for_tokens(code_tokens):
+        tok = np.asarray(code_tokens[0]).reshape(-1)
+        e = np.zeros((tok.shape[0], 1, 4), dtype=np.float32)
+        e[:, 0, 0] = tok // 1000
+        return mx.array(e)
+
+    class Model:
+        sample_rate = 24000
+        speech_tokenizer = object()
+        config = SimpleNamespace(talker_config=SimpleNamespace(codec_eos_token_id=EOS, num_hidden_layers=1, vocab_size=3000))
+
+        def _suppress_codec_tokens(self, eos):
+            return []
+
+        def _prepare_batch_inputs(self, texts, language="auto", speakers=None, instructs=None, return_metadata=False):
+            ids = [int(t) for t in texts]
+            plens = [2 + (i % 3) for i in ids]
+            L = max(plens)
+            x = np.zeros((len(ids), L, 4), dtype=np.float32)
+            mask = np.zeros((len(ids), L), dtype=np.float32)
+            for b, (i, n) in enumerate(zip(ids, plens)):
+                x[b, L - n:, 0] = i
+                mask[b, L - n:] = 1
+            tl = [1 + (i % 2) for i in ids]
+            return SimpleNamespace(input_embeds=mx.array(x), attention_mask=mx.array(mask), left_padding=[L - n for n in plens],
+                                   trailing_text_hidden=mx.zeros((len(ids), max(tl), 4)), tts_pad_embed=mx.zeros((1, 1, 4)), trailing_lens=tl)
+
+        def talker(self, x, cache=None, attention_mask=None):
+            B, L, _ = x.shape
+            for c in cache:
+                c.update_and_fetch(mx.zeros((B, 1, L, 2)), mx.zeros((B, 1, L, 2)))
+            return x[:, -1:, :2], x[:, -1:, :]
+
+        def _sample_token_batch(self, logits, temperature=0.9, top_k=50, top_p=1.0, repetition_penalty=1.05, generated_tokens_per_seq=None,
+                                suppress_tokens=None, min_p=0.0):
+            out = []
+            for b, i in enumerate(ids_of(logits)):
+                f = len(generated_tokens_per_seq[b])
+                out.append([EOS if f >= script[i] else 1000 * i + f])
+            return mx.array(np.asarray(out, dtype=np.int32))
+
+        def _predict_code_tokens(self, first_token, hidden, *, temperature, top_k, top_p, code_cache=None):
+            return [first_token], first_token
+
+        def _next_batch_input_embeds(self, trailing, pad, indices, code_tokens, *, pad_when_index_clamped=False):
+            return embed_for_tokens(code_tokens)
+
+        def _codec_embeds_for_tokens(self, code_tokens):
+            return embed_for_tokens(code_tokens)
+
+        def _decode_generated_codes(self, codes):
+            return mx.zeros((10 * len(codes),))
+
+    session = mod.Qwen3TTSBatchSession(Model(), cont.TTSBatchOptions(temperature=0.0, max_tokens=cfg["max_tokens"], max_batch_size=cfg["max_batch"]))
+    trace = []
+    adv, adm = session._advance_active, session._take_pending_batch
+
+    def advance():
+        trace.append(["advance", [st.sequence_id for st in session._active]])
+        return adv()
+
+    def take():
+        batch = adm()
+        if batch:
+            trace.append(["admit", [it.sequence_id for it in batch]])
+        return batch
+
+    session._advance_active, session._take_pending_batch = advance, take
+    rows = PT.qwen3_session_drive(session, lambda i: cont.TTSBatchItem(sequence_id=i, text=str(i)))
+    out = dict(rows=rows, trace=trace)
+    with open(os.path.join(HERE, "ref_qwen3_session.json"), "w") as f:
+        json.dump(out, f)
+    return dict(steps=len(rows), calls=len(trace))
+
+
 def run_dataclasses(R):
     """Field names and defaults of the record types that cross the boundary: ``GenerationResult`` / ``BatchGenerationResult`` (tts/models/base.py),
     ``TTSBatchOptions / Item / Event`` (tts/continuous.py), the broker's request / context / chunk records (server_inference.py), Whisper's
@@ -1425,6 +1524,7 @@ def main():
     print("bigvgan:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in bfx.items()}, "peak", float(np.abs(bfx["audio1"]).max()))
     print("dataclasses:", run_dataclasses(R))
     print("broker:", run_broker())
+    print("qwen3 session:", run_qwen3_session())
     print("whisper host helpers:", run_whisper_host())
     print("kokoro pipeline:", run_kokoro_pipeline())
     print("csm generate:", run_csm_generate())

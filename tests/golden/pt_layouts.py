@@ -446,3 +446,30 @@ def kitten_alpha_checkpoints():
             {"decoder.generator.resblocks.0.alpha1_0": r(3), "decoder.generator.resblocks.0.alpha2_1": r(4)},
             {"decoder.generator.resblocks.0.alpha1.0": r(3), "decoder.generator.resblocks.1.alpha1_0": r(2)},
             {"text_encoder.lstm.weight_ih_l0": r(6)}]
+
+
+# ---- Qwen3-TTS continuous batching: one scripted scenario driven through a session object (the reference's Qwen3TTSBatchSession over a scripted
+# model, or this package's over a scripted slot engine): who is advanced / admitted at every step, which events come out, in which order
+QWEN3_SESSION = dict(
+    max_batch=3, max_tokens=6, eos=2999,
+    # sequence id -> first-codebook tokens it samples before EOS (0: EOS on its first frame = empty event; >= max_tokens: cut by max_tokens)
+    script={1: 3, 2: 0, 3: 9, 4: 2, 5: 1, 6: 4, 7: 6, 8: 2},
+    arrivals={0: [1, 2, 3, 4], 3: [5], 4: [6, 7, 8]},
+    cancels={5: [8], 6: [7]},        # step -> sequence ids cancelled BEFORE that step runs (8 while still pending, 7 while active)
+)
+
+
+def qwen3_session_drive(session, make_item, cfg=QWEN3_SESSION, max_steps=60):
+    """Feeds the scripted arrivals / cancellations to ``session`` and steps it until idle.  Returns [[step, [[sequence id, token_count, samples], ...],
+    available_slots after the step, idle after the step], ...]."""
+    rows, step = [], 0
+    last = max(list(cfg["arrivals"]) + list(cfg["cancels"]))
+    while step < max_steps and (step <= last or not session.idle):
+        if step in cfg["arrivals"]:
+            session.add([make_item(i) for i in cfg["arrivals"][step]])
+        for sid in cfg["cancels"].get(step, []):
+            session.cancel(sid)
+        ev = session.step()
+        rows.append([step, [[int(e.sequence_id), int(e.token_count), int(e.samples)] for e in ev], int(session.available_slots), bool(session.idle)])
+        step += 1
+    return rows

@@ -196,6 +196,73 @@ def test_qwen3_tts_batch_generate_left_padded(qwen3_ckpt):
     assert all(r.samples == r.token_count * c["up"] == r.audio.shape[0] for r in res)
 
 
+@pytest.mark.parametrize("max_batch", [3, 12])
+def test_qwen3_tts_continuous_batching_session(qwen3_ckpt, max_batch):
+    """``create_tts_batch_session`` (continuous_batching.py:37-360) on slot KV caches: requests arrive while others are mid-utterance, are admitted as
+    slots free up, leave when they hit EOS / max_tokens -- and every request's codes equal ITS OWN single-sequence oracle run under the margin
+    rule (sharing a step with sequences of other lengths, riding in a recycled slot, being prefilled next to other prompts: all invisible).
+    max_batch 12: the steps run the rows pipeline (9..64 sequences per step)."""
+    from mlx_audio_amd.tts.continuous import TTSBatchEvent, TTSBatchItem, TTSBatchOptions
+    from mlx_audio_amd.tts.utils import load_model
+    from oracle.qwen3_talker_ref import Qwen3TalkerRef
+
+    c = qwen3_ckpt
+    model = load_model(c["path"], device=DEV)
+    tok = FakeTokenizer(c["tc"].text_vocab_size)
+    model.tokenizer = tok
+    ref = Qwen3TalkerRef(c["tw"], c["tc"])
+    assert model.supports_tts_continuous_batch(voice=None) and not model.supports_tts_continuous_batch(ref_audio=torch.zeros(8))
+    frames = 7
+    texts = ["a short one", "a noticeably longer sentence than the first", "mid sized text", "four", "the fifth request arrives late and is long enough",
+             "six", "seven is here", "eight", "nine nine nine", "ten", "eleven comes", "twelve", "thirteen is unlucky", "fourteen"]
+    n_req = 7 if max_batch == 3 else len(texts)
+    items = [TTSBatchItem(sequence_id=100 + i, text=texts[i], voice="vivian" if i % 3 == 1 else None) for i in range(n_req)]
+    session = model.create_tts_batch_session(TTSBatchOptions(temperature=0.0, max_tokens=frames, max_batch_size=max_batch))
+    session.trace, session.codes_log = [], {}
+    assert session.idle and session.available_slots == max_batch
+    arrivals = {0: items[:2], 2: items[2:5], 3: items[5:]} if max_batch == 3 else {0: items[:5], 1: items[5:11], 4: items[11:]}
+    events, step = [], 0
+    while step < 200 and (step <= max(arrivals) or not session.idle):
+        if step in arrivals:
+            session.add(arrivals[step])
+        ev = session.step()
+        assert len(session._active) <= max_batch and all(isinstance(e, TTSBatchEvent) and e.done for e in ev)
+        events.extend(ev)
+        step += 1
+    torch.cuda.synchronize()
+    assert session.idle and sorted(e.sequence_id for e in events) == [it.sequence_id for it in items]
+    admits = [t for t in session.trace if t[0] == "admit"]
+    assert admits[0][1] == [it.sequence_id for it in arrivals[0]][:max_batch]
+    assert any(t[0] == "advance" and len(t[1]) > 1 for t in session.trace)
+    if max_batch == 3:   # more requests than slots: later ones wait for a free slot and reuse it
+        assert any(t[0] == "admit" and 1 <= len(t[1]) < 3 for t in session.trace[2:])
+    for e in events:
+        it = items[e.sequence_id - 100]
+        ex, etr, epad = _qwen3_ref_inputs(ref, c["tc"], tok, it.text, speaker=it.voice)
+        exp = ref.generate(ex, etr, epad, frames, temperature=0.0, record=True, pad_when_index_clamped=False)
+        fa = int(exp["finished_at"][0])
+        n_exp = fa if fa >= 0 else exp["codes"].shape[1]
+        got = session.codes_log.get(e.sequence_id)
+        gc = got.cpu() if got is not None else torch.zeros((0, exp["codes"].shape[2]), dtype=torch.long)
+        nf = min(gc.shape[0], n_exp)
+        margins = [float(_gap(exp["trace"][f][i][0])) for f in range(nf) for i in range(exp["codes"].shape[2])]
+        done = _margin.walk("qwen3_tts", gc[:nf].flatten().tolist(), exp["codes"][0, :nf].flatten().tolist(), margins, where=("session", e.sequence_id))
+        if done == nf * exp["codes"].shape[2]:   # no knife edge on the way: the lengths agree too
+            assert e.token_count == n_exp, (e.sequence_id, e.token_count, n_exp)
+        assert e.samples == e.token_count * c["up"] == int(e.audio.shape[0]) and e.sample_rate == 24000
+    # cancel: a pending and an active request disappear without an event; max_tokens <= 0 answers with empty events
+    s2 = model.create_tts_batch_session(TTSBatchOptions(temperature=0.0, max_tokens=50, max_batch_size=2))
+    s2.add([TTSBatchItem(sequence_id=1, text="one"), TTSBatchItem(sequence_id=2, text="two"), TTSBatchItem(sequence_id=3, text="three")])
+    s2.step()
+    s2.cancel(1)
+    s2.cancel(3)
+    assert [st.sequence_id for st in s2._active] == [2] and not s2._pending
+    s3 = model.create_tts_batch_session(TTSBatchOptions(max_tokens=0, max_batch_size=2))
+    s3.add([TTSBatchItem(sequence_id=9, text="nothing")])
+    ev = s3.step()
+    assert len(ev) == 1 and ev[0].samples == 0 and ev[0].token_count == 0 and ev[0].done and s3.idle
+
+
 # ------------------------------------------------------------------------------------------------ CSM
 @pytest.fixture(scope="module")
 def csm_ckpt(tmp_path_factory):
