@@ -49,6 +49,8 @@ def parse():
                     help="utterance lengths drawn from 20..510 tokens with +-35 %% frames-per-token spread instead of the uniform canonical sentence:\n"
                          "shows the load imbalance the frame-count re-balance (mlx_audio_amd/shard.py) is there for; not the headline configuration")
     ap.add_argument("--wire", choices=["fp32", "fp16"], default="fp32", help="waveform dtype on the wire of the multi-GPU gather")
+    ap.add_argument("--gather", choices=["rank0", "none"], default="rank0",
+                    help="--config whisper | qwen3 | csm on several GPUs: results (token / code sequences) back to rank 0, or kept on the rank that made them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two in-run rocprofv3 PMC passes (roofline.traffic is then null)")
@@ -96,7 +98,14 @@ def run_secondary(args):
     import importlib
 
     mod = importlib.import_module(f"bench_{args.config}")
+    # --gpus N: launched like the headline line (torch.distributed.run, one rank per GPU); the tools read RANK / WORLD_SIZE themselves and shard
+    # their batch over the ranks through mlx_audio_amd.shard.ShardChannel (requests out in one broadcast, ragged integer results back)
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        print("bench.py: --gpus > 1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
     argv = ["--steps", str(args.steps), "--warmup", str(args.warmup)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+    if args.config != "kitten":
+        argv += ["--gather", args.gather]
     mod.main(argv)
 
 

@@ -211,6 +211,54 @@ class ShardChannel:
         return res  # type: ignore[return-value]
 
 
+def scatter_dense(ch: ShardChannel, x: Optional[torch.Tensor], item_shape: Sequence[int]) -> Tuple[torch.Tensor, List[int]]:
+    """Dense float32 requests (Whisper: log-mel windows) from rank ``src`` to every rank: ONE broadcast of a fixed-capacity buffer
+    ``[max_items, 1 + prod(item_shape)]`` (column 0 = 1 for a valid row, -1 for an empty one).  Returns (this rank's items ``[n_mine, *item_shape]``,
+    their global indices); every item costs the same, so the LPT plan is a round-robin by index.  The plan is stored in ``ch.owned``."""
+    width = 1
+    for d in item_shape:
+        width *= int(d)
+    buf = getattr(ch, "_dense_buf", None)
+    if buf is None or buf.shape[1] != 1 + width:
+        buf = torch.full((ch.max_items, 1 + width), -1.0, dtype=torch.float32, device=ch.device)
+        ch._dense_buf = buf
+    if ch.rank == ch.src:
+        n = int(x.shape[0])
+        if n > ch.max_items or tuple(x.shape[1:]) != tuple(int(d) for d in item_shape):
+            raise ValueError(f"dense request batch {tuple(x.shape)} exceeds / mismatches the channel ({ch.max_items} items of {tuple(item_shape)})")
+        buf[:, 0] = -1.0
+        buf[:n, 0] = 1.0
+        buf[:n, 1:] = x.reshape(n, -1).to(device=ch.device, dtype=torch.float32)
+    if ch.dist:
+        ch.dist.broadcast(buf, ch.src)
+        ch.collectives += 1
+        n = int((buf[:, 0] > 0).sum())
+    ch.n_items = n
+    ch.owned = lpt_assign([1] * n, ch.world)
+    mine = ch.my_items()
+    idx = torch.tensor(mine, dtype=torch.long, device=ch.device)
+    return buf[idx, 1:].reshape(len(mine), *[int(d) for d in item_shape]), mine
+
+
+def sharded_decode(ch: ShardChannel, requests: Optional[Sequence[torch.Tensor]], run_local: Callable[[List[int], List[torch.Tensor]], List[torch.Tensor]],
+                   dtype: torch.dtype = torch.int64, gather: str = "rank0"):
+    """The autoregressive configs (Qwen3-TTS, CSM, Whisper decode): sequences are independent, so a step is ``scatter_requests`` (one broadcast of
+    the token block; the LPT plan on the prompt lengths) -> ``run_local(my global indices, my token ids)`` = the unchanged single-GPU engine on
+    this rank's share -> the RAGGED results (one 1-D tensor per sequence: code frames, token ids, ...) back.
+    ``gather="rank0"``: one tiny all_reduce of the result lengths + ONE exact-size all_to_all_single towards ``ch.dst`` (returns the list over all
+    sequences there, ``None`` elsewhere) -- fine for code / token sequences (64 utterances x 48 frames x 16 codes x 8 B = 393 KB per step in
+    total); ``gather="none"``: every rank keeps its own results (a serving shell streams each sequence from the rank that made it, rank 0 is no
+    hot spot); returns ``(my indices, my results)``."""
+    block, lens = ch.scatter_requests(requests)
+    mine = ch.my_items()
+    local = run_local(mine, ch.my_ids(block, lens))
+    assert len(local) == len(mine)
+    if gather == "none":
+        return mine, local
+    assert gather == "rank0", gather
+    return ch.gather([a.reshape(-1) for a in local], dtype=dtype)
+
+
 def kokoro_step(ch: ShardChannel, engine, requests: Optional[Sequence[torch.Tensor]], ref_s_of: Callable,
                 samples_per_frame: int, forced_durations_of: Optional[Callable[[int], torch.Tensor]] = None, tolerance: float = 0.05,
                 wire_dtype: Optional[torch.dtype] = None, back_kwargs: Optional[Callable[[List[int]], dict]] = None):

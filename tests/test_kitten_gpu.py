@@ -380,8 +380,9 @@ def test_kitten_load_model_call_and_generate(tmp_path):
             return [t.lower() for t in texts]
 
     model._phonemizer = Phonemizer()
-    with pytest.raises(NotImplementedError):
-        next(model.generate("Hello there.", voice="kiki"))
+    with pytest.warns(UserWarning, match="text_preprocessor"):   # default clean_text=True without a preprocessor: works, un-normalised, one warning
+        first = next(model.generate("Hello there.", voice="kiki"))
+    assert torch.equal(first.audio, next(model.generate("Hello there.", voice="kiki", clean_text=False)).audio)
     with pytest.raises(ValueError):
         next(model.generate("Hello there.", voice="nobody", clean_text=False))
     text = "The quick brown fox jumps. Over the lazy dog! And then it sleeps"

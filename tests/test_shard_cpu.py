@@ -221,3 +221,59 @@ def test_dense_windows_out_ragged_tokens_back():
         p.join(120)
         assert p.exitcode == 0
     assert q.get()
+
+
+# ------------------------------------------------------------------------------------------------ the autoregressive configs: ragged integer results
+def _decode_worker(rank, world, port, n_seq, gather, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ch = shard.ShardChannel("cpu", dist, max_items=64, max_tokens=40)
+        g = torch.Generator().manual_seed(3)
+        reqs = [torch.randint(1, 400, (int(torch.randint(3, 30, (1,), generator=g)),), generator=g) for _ in range(n_seq)]
+
+        def run_local(items, ids):   # "code frames" of a sequence: ragged [frames, 4] int64 that depend on its ids and on its GLOBAL index
+            return [(torch.arange((int(t.sum()) % 7 + 1) * 4, dtype=torch.int64) + 1000 * i + int(t[0])) for i, t in zip(items, ids)]
+
+        want = run_local(list(range(n_seq)), [t.to(torch.int32) for t in reqs])
+        out = shard.sharded_decode(ch, reqs if rank == 0 else None, run_local, dtype=torch.int64, gather=gather)
+        if gather == "none":
+            mine, local = out
+            ok = mine == ch.my_items() and all(torch.equal(a, want[i]) for i, a in zip(mine, local))
+            got = dict(rank=rank, mine=mine, ok=bool(ok), collectives=ch.collectives)
+            allg = [None] * world
+            dist.all_gather_object(allg, got)
+            if rank == 0:
+                q.put(dict(ok=all(x["ok"] for x in allg), items=sorted(i for x in allg for i in x["mine"]), collectives=allg[0]["collectives"]))
+        else:
+            if rank == 0:
+                ok = len(out) == n_seq and all(o.dtype == torch.int64 and torch.equal(o, w) for o, w in zip(out, want))
+                q.put(dict(ok=bool(ok), items=list(range(n_seq)), collectives=ch.collectives))
+            else:
+                assert out is None
+        # dense requests (Whisper windows): one broadcast, round-robin plan, every rank sees exactly its rows
+        x = torch.arange(n_seq * 6, dtype=torch.float32).reshape(n_seq, 2, 3) if rank == 0 else None
+        mine_x, idx = shard.scatter_dense(ch, x, (2, 3))
+        full = torch.arange(n_seq * 6, dtype=torch.float32).reshape(n_seq, 2, 3)
+        assert idx == ch.my_items() and torch.equal(mine_x, full[idx])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_seq,gather", [(2, 9, "rank0"), (8, 19, "rank0"), (8, 5, "rank0"), (2, 9, "none"), (8, 19, "none")])
+def test_sharded_decode_ragged_integer_results(world, n_seq, gather):
+    """``shard.sharded_decode``: code / token sequences of different lengths come back bit-exact and in request order (rank0), or stay on the rank
+    that made them (none: no result collective at all)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_decode_worker, args=(r, world, port, n_seq, gather, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    r = q.get()
+    assert r["ok"] and r["items"] == list(range(n_seq))
+    # broadcast + (rank0: all_reduce of the result lengths + all_to_all of the payload)
+    assert r["collectives"] == (3 if gather == "rank0" else 1)

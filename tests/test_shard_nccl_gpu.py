@@ -75,6 +75,17 @@ def _worker_calls(port, q):
             dst = torch.empty(1000, dtype=dt, device=dev)
             dist.all_to_all_single(dst, src, output_split_sizes=[1000], input_split_sizes=[1000])
             ok = ok and torch.equal(dst, src)
+        # the autoregressive configs (shard.sharded_decode / scatter_dense): ragged int64 code sequences back, dense float32 requests out
+        from mlx_audio_amd import shard
+
+        ch = shard.ShardChannel(dev, None, max_items=8, max_tokens=16)
+        ch.dist, ch.world, ch.rank = dist, 1, 0   # a one-rank group still issues every collective
+        reqs = [torch.arange(3 + i, dtype=torch.int64) + i for i in range(4)]
+        got = shard.sharded_decode(ch, reqs, lambda items, ids: [torch.arange(5 * (i + 1), dtype=torch.int64, device=dev) + 7 * i for i in items], dtype=torch.int64)
+        ok = ok and len(got) == 4 and all(g.dtype == torch.int64 and torch.equal(g.cpu(), torch.arange(5 * (i + 1)) + 7 * i) for i, g in enumerate(got))
+        x = torch.arange(3 * 10, dtype=torch.float32, device=dev).reshape(3, 10)
+        mine, idx = shard.scatter_dense(ch, x, (10,))
+        ok = ok and idx == [0, 1, 2] and torch.equal(mine, x) and ch.collectives == 4
         torch.cuda.synchronize()
         q.put(ok)
     finally:

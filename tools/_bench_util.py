@@ -104,3 +104,41 @@ def cpu_frame_baseline(stacks, batch: int, context: int = 32, seconds_per_frame_
                       "layer's random parameters aliased to all layers, heads / sampling / codec left out" % (
                           " + ".join(f"{s} x {c.n_layers} layers d={c.d_model}" for c, s in stacks), batch, context),
             "cpu_ms_per_frame": frame_s * 1e3}
+
+
+class Dist:
+    """One process per GPU (launched by ``python -m torch.distributed.run`` exactly like bench.py): RANK / LOCAL_RANK / WORLD_SIZE from the environment,
+    backend "nccl" (= RCCL on ROCm).  A single process is world 1 with no process group."""
+
+    def __init__(self):
+        import os
+
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        self.dev = torch.device("cuda", self.local)
+        torch.cuda.set_device(self.dev)
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.init_process_group("nccl", device_id=self.dev)
+            self.dist = dist
+
+    def fence(self):
+        torch.cuda.synchronize()
+        if self.dist:
+            self.dist.barrier()
+            torch.cuda.synchronize()
+
+    def max_over_ranks(self, v: float) -> float:
+        if not self.dist:
+            return v
+        t = torch.tensor([v], device=self.dev, dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.dist:
+            self.dist.barrier()
+            self.dist.destroy_process_group()

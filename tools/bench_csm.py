@@ -27,6 +27,7 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true", help="accepted for symmetry with the other bench lines")
     ap.add_argument("--weights", choices=["bf16", "fp8"], default="bf16")
     ap.add_argument("--kv16", action="store_true", help="bf16 KV caches (the reference's cache dtype) instead of float32")
+    ap.add_argument("--gather", choices=["rank0", "none"], default="rank0", help="multi-GPU runs: code frames back to rank 0, or kept on the rank that made them")
     args = ap.parse_args(argv)
     fp8 = args.weights == "fp8"
 
@@ -34,7 +35,10 @@ def main(argv=None):
     from mlx_audio_amd.lm.stack import make_lin
     from mlx_audio_amd.tts.models.sesame import engine as E
 
-    dev = torch.device("cuda", 0)
+    from mlx_audio_amd import shard
+
+    D_ = U.Dist()   # one process per GPU; --batch sequences sharded over the ranks
+    dev = D_.dev
     cfg = E.csm_1b()
     cfg.text_vocab_size = 4096  # the 128 256-row text table is only gathered from; a small one keeps the setup short
     tiny = E.tiny_csm()
@@ -60,34 +64,48 @@ def main(argv=None):
     mimi = M.MimiDecoder(M.make_mimi_decoder_weights(mcfg, seed=0), mcfg, device=dev)
 
     B, F, S = args.batch, args.frames, args.prompt
-    toks = torch.zeros(B, S, nb + 1, dtype=torch.long)
-    mask = torch.zeros(B, S, nb + 1, dtype=torch.bool)
-    toks[:, :, -1] = torch.randint(0, cfg.text_vocab_size, (B, S), generator=g)
-    mask[:, :, -1] = True
-    toks, mask = toks.to(dev), mask.to(dev)
+    requests = [torch.randint(0, cfg.text_vocab_size, (S,), generator=g) for _ in range(B)]   # text token ids, owned by rank 0
+    ch = shard.ShardChannel(dev, D_.dist, max_items=max(B, 8), max_tokens=max(S, 8))
+    last = {}
+
+    def run_local(items, ids):
+        if not items:
+            last.update(fr=None, wav=None)
+            return []
+        b = len(items)
+        toks = torch.zeros(b, S, nb + 1, dtype=torch.long, device=dev)
+        mask = torch.zeros(b, S, nb + 1, dtype=torch.bool, device=dev)
+        toks[:, :, -1] = torch.stack([i.long() for i in ids])
+        mask[:, :, -1] = True
+        out = eng.generate(toks, mask, F, temperature=0.0, poll=10 ** 9)
+        last["ev"].record()
+        fr = out["frames"]
+        codes = (fr % mcfg.quantizer_bins).permute(0, 2, 1).contiguous()
+        last.update(fr=fr, wav=mimi(codes))
+        return [f.reshape(-1) for f in fr]
 
     def step(timers=None):
         e = [U.ev() for _ in range(3)]
+        last["ev"] = e[1]
         e[0].record()
-        out = eng.generate(toks, mask, F, temperature=0.0, poll=10 ** 9)
-        e[1].record()
-        fr = out["frames"]
-        codes = (fr % mcfg.quantizer_bins).permute(0, 2, 1).contiguous()
-        wav = mimi(codes)
+        got = shard.sharded_decode(ch, requests if D_.rank == 0 else None, run_local, dtype=torch.int64, gather=args.gather)
         e[2].record()
         if timers is not None:
             timers.append(e)
-        return fr, wav
+        return last.get("fr"), last.get("wav")
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    D_.fence()
     timers = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         fr, wav = step(timers)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    D_.fence()
+    dt = D_.max_over_ranks(time.perf_counter() - t0)
+    if D_.rank != 0:
+        D_.close()
+        return None
     n = fr.shape[1]
     assert n >= 1 and wav.shape[-1] == n * 1920 and bool(torch.isfinite(wav).all())
     lm_ms = sum(t[0].elapsed_time(t[1]) for t in timers) / args.steps
@@ -96,13 +114,13 @@ def main(argv=None):
     bpw = 1.0 if fp8 else 2.0
     wbytes = U.stack_weight_bytes(cfg.backbone, bpw) + (nb - 1) * U.stack_weight_bytes(cfg.decoder, bpw) + bpw * (V * D + (nb - 1) * (V * Dd + Dd * D))
     res = {
-        "metric": "audio seconds generated per second (x real time), CSM-1B generate_frame + Mimi decode, 1 MI355X", "value": B * n * 0.08 * args.steps / dt,
-        "unit": "x realtime", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000 * dt / args.steps, "higher_is_better": True,
+        "metric": "audio seconds generated per second (x real time), CSM-1B generate_frame + Mimi decode, %d MI355X" % D_.world, "value": B * n * 0.08 * args.steps / dt,
+        "unit": "x realtime", "n_gpus": D_.world, "scaling": "strong", "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000 * dt / args.steps, "higher_is_better": True,
         "dtype": ("fp8 e4m3fn weights (per-row 2^k scales) x fp32 activations (GEMV fp32 FMA on exactly decoded weights)" if fp8 else
                   "bf16 weights x fp32 activations (GEMV fp32 FMA on bf16 weights)") + ("; 5..8 sequences: v_mfma_f32_16x16x32 on the weights' own type" if B >= 5 else ""),
         "data": "synthetic",
         "config": {"workload": "CSM-1B: prompt %d tokens, %d frames x (backbone step + 31 depth-decoder steps, sampling on device), Mimi decode (32 codebooks)" % (S, n),
-                   "sequences": B, "frames": n, "temperature": 0.0, "weights": args.weights, "kv_cache": "bf16" if args.kv16 else "fp32"},
+                   "sequences": B, "sequences_on_rank0": len(ch.my_items()), "parallelism": f"sequence-dp{D_.world}", "gather": args.gather, "frames": n, "temperature": 0.0, "weights": args.weights, "kv_cache": "bf16" if args.kv16 else "fp32"},
         "step_runner": U.step_runner(), "split_ms": {"frame_loop": lm_ms, "mimi_decode": dec_ms}, "ms_per_frame": frame_ms, "frames_per_s": B * n / (lm_ms * 1e-3),
         "mimi_samples_per_s": B * n * 1920 / (dec_ms * 1e-3),
         "roofline": {"bound": "hbm", "kernel": "gemv_kernel (all decode-step Linear layers of one frame)", "achieved": wbytes / (frame_ms * 1e-3) / 1e9, "peak": 8000.0,
@@ -112,6 +130,7 @@ def main(argv=None):
     if not args.no_cpu_baseline:
         res["cpu_baseline"] = U.cpu_frame_baseline([(cfg.backbone, 1), (cfg.decoder, nb - 1)], B, context=S)
     print(json.dumps(res))
+    D_.close()
     return res
 
 

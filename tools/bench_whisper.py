@@ -31,21 +31,28 @@ def main(argv=None):
     ap.add_argument("--decode-steps", type=int, default=64)
     ap.add_argument("--precision", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", choices=["rank0", "none"], default="rank0", help="multi-GPU runs: token sequences back to rank 0, or kept on the rank that made them")
     args = ap.parse_args(argv)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import _bench_util as U
 
     from mlx_audio_amd import dsp, ops
     from mlx_audio_amd.stt.models.whisper import synthetic as WS
     from mlx_audio_amd.stt.models.whisper.engine import WhisperEngine
     from mlx_audio_amd.stt.models.whisper.tokenizer import get_tokenizer
 
-    dev = torch.device("cuda", 0)
+    from mlx_audio_amd import shard
+
+    D_ = U.Dist()   # one process per GPU; the --batch windows are sharded over the ranks (audio out in ONE dense broadcast, token ids back)
+    dev = D_.dev
     dims = WS.WHISPER_SMALL
     w = WS.make_whisper_weights(dims, seed=0)
     eng = WhisperEngine(w, dims, device=dev, precision=args.precision)
     tok = get_tokenizer(True, language="en", task="transcribe")
     B = args.batch
     g = torch.Generator(device=dev).manual_seed(0)
-    audio = torch.randn((B, 480000), generator=g, device=dev) * 0.1  # resident in HBM before the timed region
+    audio = torch.randn((B, 480000), generator=g, device=dev) * 0.1  # resident in HBM (on rank 0: the owner of the requests) before the timed region
+    ch = shard.ShardChannel(dev, D_.dist, max_items=max(B, 8), max_tokens=8)
     suppress = [tok.sot, tok.sot_prev, tok.sot_lm, tok.no_speech, tok.transcribe, tok.translate, tok.eot]  # EOT suppressed: fixed length
 
     def ev():
@@ -54,38 +61,51 @@ def main(argv=None):
     def step(timers=None):
         e = [ev() for _ in range(4)]
         e[0].record()
-        mel = dsp.log_mel_spectrogram(audio, n_mels=80, padding=480000)[:, :3000]  # whisper.py:_prepare_audio + pad_or_trim
+        mine, items = shard.scatter_dense(ch, audio if D_.rank == 0 else None, (480000,)) if D_.dist else (audio, list(range(B)))
+        if not items:
+            for k in (1, 2, 3):
+                e[k].record()
+            ch.gather([], dtype=torch.int64) if (D_.dist and args.gather == "rank0") else None
+            return None
+        mel = dsp.log_mel_spectrogram(mine, n_mels=80, padding=480000)[:, :3000]  # whisper.py:_prepare_audio + pad_or_trim
         e[1].record()
         xa = eng.encode(mel.contiguous())
         e[2].record()
         out = eng.decode(None, tok, sample_len=args.decode_steps, suppress_tokens=suppress, audio_features=xa, fixed_steps=True)
         e[3].record()
+        if D_.dist and args.gather == "rank0":
+            out["gathered"] = ch.gather([t.reshape(-1) for t in out["tokens"]], counts=[int(out["tokens"].shape[1])] * ch.n_items, dtype=torch.int64)
         if timers is not None:
             timers.append(e)
         return out
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    D_.fence()
     timers = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step(timers)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    D_.fence()
+    dt = D_.max_over_ranks(time.perf_counter() - t0)
+    if D_.rank != 0:
+        D_.close()
+        return None
     assert out["tokens"].shape[1] == 3 + args.decode_steps and bool(torch.isfinite(out["sum_logprobs"]).all())
+    assert not (D_.dist and args.gather == "rank0") or (len(out["gathered"]) == B and all(t.numel() == 3 + args.decode_steps for t in out["gathered"]))
     mel_ms = sum(t[0].elapsed_time(t[1]) for t in timers) / args.steps
     enc_ms = sum(t[1].elapsed_time(t[2]) for t in timers) / args.steps
     dec_ms = sum(t[2].elapsed_time(t[3]) for t in timers) / args.steps
     audio_s = 30.0 * B * args.steps
     res = {
-        "metric": "audio seconds transcribed per second (x real time), Whisper-small STT, 1 MI355X", "value": audio_s / dt, "unit": "x realtime",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000 * dt / args.steps, "higher_is_better": True,
+        "metric": "audio seconds transcribed per second (x real time), Whisper-small STT, %d MI355X" % D_.world, "value": audio_s / dt, "unit": "x realtime",
+        "n_gpus": D_.world, "scaling": "strong", "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000 * dt / args.steps, "higher_is_better": True,
         "dtype": "fp16 weights x fp32 activations (precision %d: %s), f32 MFMA attention" % (
             args.precision, "fp16 hi+lo split" if args.precision == 4 else "single fp16 pass"),
         "data": "synthetic",
         "config": {"workload": "Whisper-small, 30 s windows: log-mel + 12-layer encoder + %d greedy decode steps (filters on device)" % args.decode_steps,
-                   "windows_per_step": B, "decode_steps": args.decode_steps},
+                   "windows_per_step": B, "windows_on_rank0": len(ch.my_items()) if D_.dist else B, "parallelism": f"window-dp{D_.world}", "gather": args.gather,
+                   "decode_steps": args.decode_steps},
         "step_runner": "multi-launch native runner (stack_step.cpp)",
         "split_ms": {"logmel": mel_ms, "encoder": enc_ms, "decode": dec_ms},
         "decode_tokens_per_s": B * args.decode_steps / (dec_ms * 1e-3),
@@ -153,6 +173,8 @@ def main(argv=None):
                                "sample": "1 window (30 s), encoder only, single run; restated reference (oracle/whisper_ref.py, PyTorch-CPU fp32), not MLX",
                                "host_cores_available": avail}
     print(json.dumps(res))
+    D_.close()
+    return res
 
 
 if __name__ == "__main__":
