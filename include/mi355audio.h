@@ -710,6 +710,21 @@ typedef struct {
 } mi355_stack_desc;
 
 /* ------------------------------------------------------------------------------------------
+ * Unidirectional LSTM over a whole sequence, any hidden size (EnCodec's two 512-wide layers, codec/models/encodec/encodec.py:89-167: the
+ * reference's Metal `lstm` kernel + one matmul per step).  xproj [B, T, 4H] = x @ Wx^T + bias for all steps (the caller's GEMM), gate chunks in the
+ * order i | f | g | o; wh: row-major 16-bit image [4H, H] (mi355_pack_rowmajor16_host); h, c [B, H] fp32 state (in: initial, normally zeros; out:
+ * final); pre [B, 4H] scratch; out [B, T, H].  Two launches per time step (mi355_gemv with the x-projection row as residual, then the gates).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* xproj; int64_t xproj_bstride; int32_t ld_xproj;
+  const uint16_t* wh; int32_t wdtype;   /* MI355_W_BF16 / MI355_W_F16 */
+  float* h; float* c; float* pre;
+  float* out; int64_t out_bstride; int32_t ld_out;
+  int32_t B; int32_t T; int32_t H;
+} mi355_lstm_seq_args;
+int mi355_lstm_seq(const mi355_lstm_seq_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Decode steps for a batch of 9..64 sequences (BASELINE config[3]: 64 utterances; the reference's batched generation
  * tts/models/qwen3_tts/qwen3_tts.py:1651-2060 over talker.py:229-336, 385-500): nn.Linear at sequence length 1 as
  *   mi355_rows_gemm   (pure matrix-pipe GEMM: tile image of W x pre-split input planes -> fp32 partial slabs, one per K group)

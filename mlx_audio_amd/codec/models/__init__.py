@@ -1,6 +1,6 @@
 """Codec models of the decode hot path, under the reference's names (``mlx_audio/codec/models/__init__.py``): ``DAC``, ``SNAC``, ``Vocos`` are the
 decode-side engines of this build (same constructor arguments as the reference classes); ``Mimi`` is exposed as its decoder engine
-(``MimiDecoder``: codes -> waveform).  The remaining reference exports (Encodec, EcapaTdnnBackbone, MossAudioTokenizer, NemotronVoiceChatCodec,
+(``MimiDecoder``: codes -> waveform); ``Encodec`` is the decode side of EnCodec (``Encodec(config).decode``).  The remaining reference exports (EcapaTdnnBackbone, MossAudioTokenizer, NemotronVoiceChatCodec,
 StepAudio2Token2Wav) are outside SURVEY section 8 and raise ``ImportError`` naming that fact instead of an ``AttributeError``.  Resolved lazily so
 that ``import mlx_audio_amd.codec`` stays import-light."""
 import importlib
@@ -10,8 +10,9 @@ _BUILT = {
     "SNAC": (".snac", "SNAC"),
     "Vocos": (".vocos", "Vocos"),
     "Mimi": (".mimi", "MimiDecoder"),
+    "Encodec": (".encodec", "Encodec"),
 }
-_NOT_BUILT = ("EcapaTdnnBackbone", "Encodec", "MossAudioTokenizer", "NemotronVoiceChatCodec", "StepAudio2Token2Wav")
+_NOT_BUILT = ("EcapaTdnnBackbone", "MossAudioTokenizer", "NemotronVoiceChatCodec", "StepAudio2Token2Wav")
 
 __all__ = sorted(_BUILT)
 

@@ -1,0 +1,1 @@
+from .encodec import Encodec, EncodecConfig, make_encodec_weights, preprocess_audio  # noqa: F401

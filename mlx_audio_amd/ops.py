@@ -323,6 +323,21 @@ def pack_lstm_wh(wh_f: torch.Tensor, wh_b: torch.Tensor, device, f16: bool = Fal
     return torch.from_numpy(out.view(np.int16)).to(device)
 
 
+def lstm_seq(xproj: torch.Tensor, wh: RowMajor16, out: torch.Tensor, h0: Optional[torch.Tensor] = None, c0: Optional[torch.Tensor] = None):
+    """Unidirectional LSTM recurrence of any hidden size (``mi355_lstm_seq``): ``xproj`` [B, T, 4H] = x @ Wx^T + b (gate order i | f | g | o), ``wh`` the
+    row-major 16-bit image of Wh [4H, H], ``out`` [B, T, H].  Returns (h_T, c_T)."""
+    B, T, H4 = xproj.shape
+    H = H4 // 4
+    assert wh.n == H4 and wh.k == H and wh.scale is None and out.shape == (B, T, H) and xproj.stride(2) == 1 and out.stride(2) == 1
+    h = torch.zeros((B, H), dtype=torch.float32, device=xproj.device) if h0 is None else h0.to(torch.float32).contiguous().clone()
+    c = torch.zeros((B, H), dtype=torch.float32, device=xproj.device) if c0 is None else c0.to(torch.float32).contiguous().clone()
+    pre = torch.empty((B, H4), dtype=torch.float32, device=xproj.device)
+    _lib.call_struct("mi355_lstm_seq", "mi355_lstm_seq_args", _stream(), xproj=_ptr(xproj), xproj_bstride=xproj.stride(0), ld_xproj=xproj.stride(1),
+                     wh=_ptr(wh.w), wdtype=wh.wdtype, h=_ptr(h), c=_ptr(c), pre=_ptr(pre), out=_ptr(out), out_bstride=out.stride(0), ld_out=out.stride(1),
+                     B=B, T=T, H=H)
+    return h, c
+
+
 # --------------------------------------------------------------------------------------- conv / linear
 def conv_gemm(x: torch.Tensor, pc: PackedConv, y: torch.Tensor, *, dil: int = 1, pad: int = 0,
               lens_in: Optional[torch.Tensor] = None, lens_out: Optional[torch.Tensor] = None,

@@ -12,6 +12,7 @@ Only runs in the build container (needs /root/reference): ``python tests/golden/
 regenerated from their seeds by the test, so the fixtures hold inputs' seeds + the reference's outputs only.
 """
 import importlib.util
+import json
 import os
 import sys
 import types
@@ -1085,6 +1086,39 @@ def run_qwen3_session():
     return dict(steps=len(rows), calls=len(trace))
 
 
+ENCODEC_TINY = dict(audio_channels=1, num_filters=8, kernel_size=7, num_residual_layers=1, dilation_growth_rate=2, codebook_size=64, codebook_dim=32,
+                    hidden_size=32, num_lstm_layers=2, residual_kernel_size=3, use_causal_conv=True, normalize=False, pad_mode="reflect",
+                    norm_type="weight_norm", last_kernel_size=7, trim_right_ratio=1.0, compress=2, upsampling_ratios=[4, 2, 2],
+                    target_bandwidths=[15.0, 60.0], sampling_rate=24000)
+
+
+def run_encodec(seed_w, seed_codes, n_frames):
+    """The reference's ``Encodec.decode`` (codec/models/encodec/encodec.py:740-777 -> _decode_frame -> RVQ decode -> EncodecDecoder with its LSTM) on a
+    seeded checkpoint of a small config (causal, reflect padding, three upsampling stages, two LSTM layers), batch 1 (see mlx_shim._metal_kernel)."""
+    if "mlx_audio" not in sys.modules:
+        import_reference()
+    if "mlx_audio.codec" not in sys.modules:
+        _pkg("mlx_audio.codec", f"{REF}/codec")
+        _pkg("mlx_audio.codec.models", f"{REF}/codec/models")
+    _pkg("mlx_audio.codec.models.encodec", f"{REF}/codec/models/encodec")
+    E = _load("mlx_audio.codec.models.encodec.encodec", f"{REF}/codec/models/encodec/encodec.py")
+    sys.path.insert(0, ROOT)
+    from mlx_audio_amd.codec.models.encodec.encodec import make_encodec_weights
+
+    cfg = E.EncodecConfig(**ENCODEC_TINY)
+    model = E.Encodec(cfg)
+    w = make_encodec_weights(ENCODEC_TINY, seed=seed_w)
+    missing = model.load_weights([(k, mx.array(v.numpy())) for k, v in w.items() if k.startswith(("decoder.", "quantizer."))], strict=False)
+    nq = model.quantizer.num_quantizers
+    g = np.random.default_rng(seed_codes)
+    codes = g.integers(0, ENCODEC_TINY["codebook_size"], size=(1, 1, nq, n_frames)).astype(np.int32)   # [B, chunks = 1, nq, T]
+    audio = model.decode(mx.array(codes), [None])
+    emb = model.quantizer.decode(mx.array(codes[:, 0]))
+    np.savez_compressed(os.path.join(HERE, "ref_encodec_tiny.npz"), seed_w=seed_w, seed_codes=seed_codes, n_frames=n_frames, codes=codes,
+                        config=json.dumps(ENCODEC_TINY), audio=_np(audio), embeddings=_np(emb))
+    return dict(audio=list(np.asarray(audio).shape), nq=int(nq), peak=float(np.abs(np.asarray(audio)).max()), missing=str(missing)[:80])
+
+
 def run_dataclasses(R):
     """Field names and defaults of the record types that cross the boundary: ``GenerationResult`` / ``BatchGenerationResult`` (tts/models/base.py),
     ``TTSBatchOptions / Item / Event`` (tts/continuous.py), the broker's request / context / chunk records (server_inference.py), Whisper's
@@ -1523,6 +1557,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_bigvgan_tiny.npz"), config=json.dumps(BIGVGAN_TINY), **bfx)
     print("bigvgan:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in bfx.items()}, "peak", float(np.abs(bfx["audio1"]).max()))
     print("dataclasses:", run_dataclasses(R))
+    print("encodec:", run_encodec(3, 5, 23))
     print("broker:", run_broker())
     print("qwen3 session:", run_qwen3_session())
     print("whisper host helpers:", run_whisper_host())

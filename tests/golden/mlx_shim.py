@@ -553,6 +553,33 @@ class _Fast:
         return _wrap(out)
 
 
+def _metal_kernel(name, input_names, output_names, header="", source="", **kw):
+    """``mx.fast.metal_kernel``: custom Metal kernels cannot run here; the ONE kernel on the path (codec/models/encodec/encodec.py:89-123, ``lstm``) is
+    restated from its Metal source: gate chunks i | f | g | o of h_in + x[:, t], sigmoid(x) = 1 / (1 + exp(-|x|)) mirrored for x < 0, precise tanh,
+    cell = f * cell + i * g, hidden = o * tanh(cell).  The source's thread indexing (elem = b * 4H + y) is only consistent for one sequence per
+    launch; that case is what is restated (and asserted)."""
+    if name != "lstm":
+        raise NotImplementedError(f"metal kernel {name!r} has no stand-in")
+
+    def sig(x):
+        y = 1.0 / (1.0 + np.exp(-np.abs(x)))
+        return np.where(x < 0, 1.0 - y, y)
+
+    def call(inputs, output_shapes, output_dtypes, grid, threadgroup, **k2):
+        x, h_in, cell, hidden_size, time_step, num_time_steps = inputs
+        x, h_in, cell = (np.asarray(t, dtype=np.float32) for t in (x, h_in, cell))
+        assert x.shape[0] == 1 and x.shape[1] == int(num_time_steps), "the Metal kernel's indexing is only consistent for batch 1"
+        H = int(hidden_size)
+        g = h_in + x[:, int(time_step), :]
+        i, f, gg, o = sig(g[:, :H]), sig(g[:, H:2 * H]), np.tanh(g[:, 2 * H:3 * H]), sig(g[:, 3 * H:])
+        c = (f * cell + i * gg).astype(np.float32)
+        h = (o * np.tanh(c)).astype(np.float32)
+        return _wrap(h), _wrap(c)
+
+    return call
+
+
+_Fast.metal_kernel = staticmethod(_metal_kernel)
 fast = _Fast()
 
 
@@ -898,6 +925,15 @@ def elu(x, alpha=1.0):
     return _wrap(np.where(x > 0, x, np.float32(alpha) * (np.exp(np.minimum(x, 0)) - 1)).astype(x.dtype))
 
 
+class ELU(Module):
+    def __init__(self, alpha=1.0):
+        super().__init__()
+        self._alpha = alpha
+
+    def __call__(self, x):
+        return elu(x, self._alpha)
+
+
 def gelu_approx(x):
     torch = _t()
     return _wrap(torch.nn.functional.gelu(torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float32))), approximate="tanh").numpy())
@@ -985,11 +1021,11 @@ def install():
     core = types.ModuleType("mlx.core")
     for k, v in vars(me).items():
         if not k.startswith("_") and k not in ("Module", "Linear", "Embedding", "LayerNorm", "InstanceNorm", "Conv1d", "Dropout", "Identity", "Upsample",
-                                               "LeakyReLU", "GELU", "leaky_relu", "gelu", "nn_tanh", "relu", "silu", "install", "MultiHeadAttention", "RMSNorm", "RoPE", "ConvTranspose1d", "elu", "gelu_approx", "Sequential", "Tanh", "log_softmax"):
+                                               "LeakyReLU", "GELU", "leaky_relu", "gelu", "nn_tanh", "relu", "silu", "install", "MultiHeadAttention", "RMSNorm", "RoPE", "ConvTranspose1d", "elu", "gelu_approx", "Sequential", "Tanh", "log_softmax", "ELU"):
             setattr(core, k, v)
     nn = types.ModuleType("mlx.nn")
     for k in ("Module", "Linear", "Embedding", "LayerNorm", "InstanceNorm", "Conv1d", "Dropout", "Identity", "Upsample", "LeakyReLU", "GELU", "leaky_relu",
-              "gelu", "relu", "silu", "sigmoid", "MultiHeadAttention", "RMSNorm", "RoPE", "ConvTranspose1d", "elu", "gelu_approx", "Sequential", "Tanh", "log_softmax"):
+              "gelu", "relu", "silu", "sigmoid", "MultiHeadAttention", "RMSNorm", "RoPE", "ConvTranspose1d", "elu", "gelu_approx", "Sequential", "Tanh", "log_softmax", "ELU"):
         setattr(nn, k, getattr(me, k))
     nn.tanh = nn_tanh
     utils = types.ModuleType("mlx.utils")

@@ -423,9 +423,9 @@ def test_codec_package_exports_match_reference_names():
     from mlx_audio_amd.codec.models.snac import SNAC
 
     assert C.DAC is DAC and CM.SNAC is SNAC and C.Vocos.__name__ == "Vocos" and CM.Mimi.__name__ == "MimiDecoder"
-    assert set(CM.__all__) == {"DAC", "SNAC", "Vocos", "Mimi"}
+    assert set(CM.__all__) == {"DAC", "SNAC", "Vocos", "Mimi", "Encodec"} and CM.Encodec.__name__ == "Encodec"
     with pytest.raises(ImportError):
-        CM.Encodec
+        CM.EcapaTdnnBackbone
     with pytest.raises(AttributeError):
         CM.NoSuchCodec
     # constructing an engine without a ROCm device fails loudly (no CPU fallback)

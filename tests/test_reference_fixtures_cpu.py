@@ -312,6 +312,25 @@ def test_dac_oracle_reproduces_the_reference_modules():
     assert audio.shape == fx["audio"].shape and rel_max(audio, fx["audio"]) < 2e-5
 
 
+def test_encodec_oracle_reproduces_the_reference_modules():
+    """The reference's ``Encodec.decode`` (codec/models/encodec/encodec.py:740-777: RVQ decode, SEANet decoder with causal reflect-padded convs, trimmed
+    transposed convs, resnet blocks, and the two-layer LSTM whose gates are the reference's own Metal kernel -- restated in the stand-in from its source)."""
+    import json
+
+    from mlx_audio_amd.codec.models.encodec.encodec import make_encodec_weights
+    from oracle.encodec_ref import EncodecDecoderRef
+
+    fx = np.load(os.path.join(GOLD, "ref_encodec_tiny.npz"))
+    cfg = json.loads(str(fx["config"]))
+    ref = EncodecDecoderRef(make_encodec_weights(cfg, seed=int(fx["seed_w"])), cfg)
+    codes = torch.from_numpy(fx["codes"]).long()
+    assert np.array_equal(ref.quantizer_decode(codes[:, 0]).numpy(), fx["embeddings"])
+    audio = ref.decode(codes, [None]).numpy()
+    peak = float(np.abs(fx["audio"]).max())
+    assert audio.shape == fx["audio"].shape == (1, 23 * 16, 1) and peak > 0.5
+    assert float(np.abs(audio - fx["audio"]).max()) <= 2e-5 * peak
+
+
 def test_snac_oracle_reproduces_the_reference_modules():
     """The reference's ``SNAC.decode`` (snac.py:101-104) with the NoiseBlock draws the reference made: this is where the channels-last unpacking slip of
     ``NoiseBlock`` (one draw per channel, layers.py:261-263) was found."""

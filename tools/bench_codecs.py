@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Measurement line for the widened codec rows: Vocos (mel -> waveform, 24 kHz), DAC (44 kHz, 9 codebooks), SNAC
+"""Measurement line for the widened codec rows: Vocos (mel -> waveform, 24 kHz), DAC (44 kHz, 9 codebooks), EnCodec (24 kHz, 6 kbps), SNAC
 (24 kHz, 3 code levels) decode and the BigVGAN vocoder (22 kHz, 80 bands) on one MI355X, synthetic weights of the published shapes, inputs resident in HBM before the timed region.
 
 Prints ONE JSON line per codec: value = audio samples decoded per second over the whole batch (and x real time), ms per batch, and a roofline
@@ -112,6 +112,19 @@ def main():
         n = int(out.shape[1])
         print(json.dumps(line("SNAC 24 kHz (decoder_dim 1024, rates 8/8/4/2, depthwise, noise, 3 code levels)", f"{B} x {T} finest-level code frames -> waveform", 24000, n, B,
                               wall, dms, conv_roofline(fn), dt16)))
+
+    if args.only in ("", "encodec"):
+        from mlx_audio_amd.codec.models.encodec import Encodec
+
+        eng = Encodec(dict(upsampling_ratios=[8, 5, 4, 2], target_bandwidths=[1.5, 3.0, 6.0, 12.0, 24.0]), device=dev, seed=0)
+        T = int(args.seconds * 24000) // 320
+        codes = torch.randint(0, 1024, (B, 1, 8, T), generator=g).to(dev)   # 6 kbps: 8 codebooks
+        fn = lambda: eng.decode(codes, [None])  # noqa: E731
+        out, wall, dms = timed(fn, args.steps, args.warmup)
+        n = int(out.shape[1])
+        print(json.dumps(line("EnCodec 24 kHz (32 filters, rates 8/5/4/2, two 512-wide LSTM layers, 8 of 32 codebooks = 6 kbps)",
+                              f"{B} x {T} code frames -> waveform (RVQ decode + SEANet decoder; LSTM = {2 * T} per-step launch pairs)", 24000, n, B, wall, dms,
+                              conv_roofline(fn), dt16)))
 
     if args.only in ("", "bigvgan"):
         from mlx_audio_amd.codec.models.bigvgan import BigVGAN, BigVGANConfig
