@@ -477,6 +477,7 @@ typedef struct {
      rows additionally (out may then be null) leave as planes of planes_R rows in planes_dtype (MI355_W_BF16 / MI355_W_F16) for the o-proj GEMM;
      item b is row b.  Both need Tq == 1. */
   int32_t in_kgroups; int64_t in_kg_stride; const float* q_bias; const float* k_bias; const float* v_bias;
+  const float* q_wscale; const float* k_wscale; const float* v_wscale;   /* nullable: per-column scales of the slab sums (fp8 images), indexed like the biases */
   uint16_t* out_planes; int32_t planes_R; int32_t planes_dtype;
 } mi355_flash_attn_args;
 int mi355_flash_attention(const mi355_flash_attn_args* a, void* stream);
@@ -735,8 +736,9 @@ int mi355_lstm_seq(const mi355_lstm_seq_args* a, void* stream);
  * 4 * R * K bytes for K columns.  Rows >= M of the planes are never read into a stored result.
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
-  const uint16_t* wt;       /* tile image of W [N, K] from mi355_pack_tiles16_host */
-  int32_t wdtype;           /* MI355_W_BF16 / MI355_W_F16 (planes must hold the same type) */
+  const uint16_t* wt;       /* tile image of W [N, K] from mi355_pack_tiles16_host (MI355_W_FP8: the byte image of mi355_pack_tiles8_host) */
+  int32_t wdtype;           /* MI355_W_BF16 / MI355_W_F16 (planes must hold the same type) / MI355_W_FP8 (OCP e4m3fn bytes, decoded to bf16 in registers: exact;
+                               planes hold bf16; the per-row scales are applied by the row epilogue: mi355_rows_finish_args.wscale) */
   int32_t N; int32_t K;     /* K % 64 == 0 */
   const uint16_t* planes;   /* the input rows (written by mi355_rows_finish) */
   int32_t M; int32_t R;     /* rows in use / rows of the planes (16, 32 or 64) */
@@ -746,12 +748,15 @@ typedef struct {
   /* kgroups == 1 only (a workgroup then holds complete sums): fused SwiGLU epilogue -- columns are (gate, up) pairs, planes_out receives
      silu(gate + bias) * (up + bias) [M, N / 2] as planes of R rows (N % 128 == 0), nothing is written to part (which may then be null) */
   uint16_t* glu_planes_out; const float* glu_bias;
+  const float* wscale;      /* fused SwiGLU epilogue of an fp8 image only: per-row scales [N] (applied to the sums before the bias) */
 } mi355_rows_gemm_args;
 int mi355_rows_gemm(const mi355_rows_gemm_args* a, void* stream);
 int32_t mi355_rows_kgroups(int32_t N, int32_t K);
 /* fp32 [N, K] (host) -> tile image: element e of (tile t, k step s, group g, row i) = W[16 t + i][64 s + 16 g + e], stored
  * [ceil(N / 16)][K / 64][4][16][16]; rows past N are zero.  out: ceil(N / 16) * 16 * K 16-bit elements.  dtype: MI355_W_BF16 / MI355_W_F16 */
 int mi355_pack_tiles16_host(const float* w_host, int64_t N, int64_t K, int32_t dtype, uint16_t* out_host);
+/* uint8 [N, K] e4m3 codes (mi355_pack_rowmajor_fp8_host) -> the fp8 tile image, same order, one byte per element; out: ceil(N / 16) * 16 * K bytes */
+int mi355_pack_tiles8_host(const uint8_t* codes_host, int64_t N, int64_t K, uint8_t* out_host);
 
 typedef struct {
   const float* part; int32_t kgroups; int64_t kg_stride; int32_t ldp;   /* input: sum over g of part[g * kg_stride + m * ldp + n]; kgroups = 1: a plain fp32 matrix */
@@ -759,6 +764,7 @@ typedef struct {
   /* epilogue of mi355_gemv: v = act(sum + bias[n]) * colscale[n] + res[m, n]; v *= out_scale;  glu = 1: columns are (gate, up) pairs and
      v[m, n / 2] = silu(gate + b) * (up + b) * out_scale */
   const float* bias; int32_t post_act; float post_slope; const float* colscale; const float* res; int32_t ldr; float out_scale; int32_t glu;
+  const float* wscale;      /* nullable: per-column scale of the SUM, before the bias (the per-row dequantisation scales of an fp8 image) */
   float* y; int32_t ldy;    /* nullable: the finished row as fp32 (may alias res) */
   float* y2; int32_t ldy2; int32_t split; int32_t y2_dtype;   /* nullable: columns >= split go to y2[m, n - split] (the KV-cache slot, MI355_KV_*) */
   /* optional normalisation of the finished row over its N (glu: N / 2) outputs, feeding yn / planes: 1 = LayerNorm, 2 = RMSNorm */

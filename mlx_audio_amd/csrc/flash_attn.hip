@@ -498,6 +498,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
         k0 += a.new_k[ik + sl * a.in_kg_stride];
         v0 += a.new_v[ik + sl * a.in_kg_stride];
       }
+      if (a.q_wscale) { q0 *= a.q_wscale[h * DH + t]; k0 *= a.k_wscale[g * DH + t]; v0 *= a.v_wscale[g * DH + t]; }
       if (a.q_bias) q0 += a.q_bias[h * DH + t];
       if (a.k_bias) k0 += a.k_bias[g * DH + t];
       if (a.v_bias) v0 += a.v_bias[g * DH + t];

@@ -59,8 +59,18 @@ __device__ __forceinline__ f32x4 pipe_mfma(const uint4 a, const uint4 b, const f
 
 // ---------------------------------------------------------------------------------------------- the GEMM
 // MR = row groups of 16 in the planes (R = 16 MR rows), T = adjacent column tiles per workgroup.
-template <int MR, int T, bool F16>
+// eight OCP e4m3fn bytes -> eight bf16 values (exact: 4 significant bits, the exponent range of bf16 covers e4m3's)
+__device__ __forceinline__ uint4 fp8x8_to_bf16x8(const uint2 v) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.x, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.x, true);
+  const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.y, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.y, true);
+  return make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(b[0], b[1]), pack_bf16x2(c[0], c[1]), pack_bf16x2(d[0], d[1]));
+}
+
+// WT: element type of the tile image: MI355_W_BF16 / MI355_W_F16 (planes of the same type) / MI355_W_FP8 (e4m3 bytes decoded to bf16 in registers, bf16 planes)
+template <int MR, int T, int WT>
 __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(const mi355_rows_gemm_args a, const int ntiles, const int steps_total, const int spg) {
+  constexpr bool F16 = WT == MI355_W_F16, FP8 = WT == MI355_W_FP8;
   constexpr int R = 16 * MR;
   extern __shared__ __attribute__((aligned(16))) float red[];   // [wave][tile][row group][256]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -82,10 +92,14 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(const mi355_rows_gemm
     for (int r = 0; r < MR; ++r) acc[j][r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   uint4 A[T][2];              // the weights of a step: [tile][half]; a half is reloaded for the next step as soon as its MFMAs are issued
+  uint2 A8[T][2];             // fp8 image: the raw bytes of a half (decoded right before use)
   uint4 B0[2][MR], B1[2][MR]; // the two halves of a step of the input rows: [image][row group]
   auto load_a = [&](const int s, const int h) {
 #pragma unroll
-    for (int j = 0; j < T; ++j) A[j][h] = wt[abase[j] + (int64_t)s * 128 + h];
+    for (int j = 0; j < T; ++j) {
+      if constexpr (FP8) A8[j][h] = ((const uint2*)a.wt)[abase[j] + (int64_t)s * 128 + h];   // 16 bytes per lane and step: the same index arithmetic in 8-byte units
+      else A[j][h] = wt[abase[j] + (int64_t)s * 128 + h];
+    }
   };
   auto load_b = [&](const int s, const int h, uint4 (&dst)[2][MR]) {
 #pragma unroll
@@ -94,6 +108,10 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(const mi355_rows_gemm
       for (int r = 0; r < MR; ++r) dst[im][r] = pl[(((s * 2 + im) * 2 + h) * 4) * R + bbase + 16 * r];
   };
   auto mfma_half = [&](const int h, const uint4 (&B)[2][MR]) {
+    if constexpr (FP8) {
+#pragma unroll
+      for (int j = 0; j < T; ++j) A[j][h] = fp8x8_to_bf16x8(A8[j][h]);
+    }
 #pragma unroll
     for (int im = 0; im < 2; ++im)
 #pragma unroll
@@ -141,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(const mi355_rows_gemm
           gv += red[b + (2 * e) * 16];
           uv += red[b + (2 * e + 1) * 16];
         }
+        if (a.wscale) { gv *= a.wscale[tile * 16 + 2 * e]; uv *= a.wscale[tile * 16 + 2 * e + 1]; }
         if (a.glu_bias) { gv += a.glu_bias[tile * 16 + 2 * e]; uv += a.glu_bias[tile * 16 + 2 * e + 1]; }
         o[e] = (gv / (1.0f + expf(-gv))) * uv;
       }
@@ -169,27 +188,34 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(const mi355_rows_gemm
   }
 }
 
-template <int MR, int T, bool F16>
+template <int MR, int T, int WT>
 int launch_rows_gemm(const mi355_rows_gemm_args& a, hipStream_t st, const int ntiles, const int steps_total, const int spg) {
   static bool attr_set = false;  // benign race: the attribute is idempotent
   constexpr size_t lds = (size_t)4 * T * MR * 256 * sizeof(float);
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)rows_gemm_kernel<MR, T, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)rows_gemm_kernel<MR, T, WT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     MI355_REQUIRE(e == hipSuccess, "rows_gemm: cannot reserve LDS: %s", hipGetErrorString(e));
     attr_set = true;
   }
   const dim3 grid((ntiles + T - 1) / T, a.kgroups);
   MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL((rows_gemm_kernel<MR, T, F16>), grid, dim3(256), lds, st, a, ntiles, steps_total, spg);
+  hipLaunchKernelGGL((rows_gemm_kernel<MR, T, WT>), grid, dim3(256), lds, st, a, ntiles, steps_total, spg);
   MI355_LAUNCH_CHECK("rows_gemm");
   return MI355_OK;
 }
 
-template <int MR, bool F16>
+template <int MR, int WT>
 int launch_rows_gemm_t(const mi355_rows_gemm_args& a, hipStream_t st, const int T, const int ntiles, const int steps_total, const int spg) {
-  if (T == 4) return launch_rows_gemm<MR, 4, F16>(a, st, ntiles, steps_total, spg);
-  if (T == 2) return launch_rows_gemm<MR, 2, F16>(a, st, ntiles, steps_total, spg);
-  return launch_rows_gemm<MR, 1, F16>(a, st, ntiles, steps_total, spg);
+  if (T == 4) return launch_rows_gemm<MR, 4, WT>(a, st, ntiles, steps_total, spg);
+  if (T == 2) return launch_rows_gemm<MR, 2, WT>(a, st, ntiles, steps_total, spg);
+  return launch_rows_gemm<MR, 1, WT>(a, st, ntiles, steps_total, spg);
+}
+
+template <int MR>
+int launch_rows_gemm_w(const mi355_rows_gemm_args& a, hipStream_t st, const int T, const int ntiles, const int steps_total, const int spg) {
+  if (a.wdtype == MI355_W_FP8) return launch_rows_gemm_t<MR, MI355_W_FP8>(a, st, T, ntiles, steps_total, spg);
+  if (a.wdtype == MI355_W_F16) return launch_rows_gemm_t<MR, MI355_W_F16>(a, st, T, ntiles, steps_total, spg);
+  return launch_rows_gemm_t<MR, MI355_W_BF16>(a, st, T, ntiles, steps_total, spg);
 }
 
 int tiles_per_wg(const int N) {
@@ -235,7 +261,8 @@ __global__ __launch_bounds__(256) void rows_finish_kernel(const mi355_rows_finis
       const float gu[16] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w, s3.x, s3.y, s3.z, s3.w};
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float g = gu[2 * e] + (a.bias ? a.bias[2 * (n0 + e)] : 0.f), u = gu[2 * e + 1] + (a.bias ? a.bias[2 * (n0 + e) + 1] : 0.f);
+        const float sg = a.wscale ? a.wscale[2 * (n0 + e)] : 1.f, su = a.wscale ? a.wscale[2 * (n0 + e) + 1] : 1.f;
+        const float g = gu[2 * e] * sg + (a.bias ? a.bias[2 * (n0 + e)] : 0.f), u = gu[2 * e + 1] * su + (a.bias ? a.bias[2 * (n0 + e) + 1] : 0.f);
         w[e] = (g / (1.0f + expf(-g))) * u * a.out_scale;
       }
     } else {
@@ -260,7 +287,7 @@ __global__ __launch_bounds__(256) void rows_finish_kernel(const mi355_rows_finis
         const int n = n0 + e;
         float t = 0.f;
         if (n < No) {
-          t = pipe_act(sv[e] + (a.bias ? a.bias[n] : 0.f), a.post_act, a.post_slope) * (a.colscale ? a.colscale[n] : 1.f);
+          t = pipe_act(sv[e] * (a.wscale ? a.wscale[n] : 1.f) + (a.bias ? a.bias[n] : 0.f), a.post_act, a.post_slope) * (a.colscale ? a.colscale[n] : 1.f);
           if (a.res) t += a.res[(int64_t)m * a.ldr + n];
           t *= a.out_scale;
         }
@@ -387,7 +414,7 @@ extern "C" int mi355_rows_gemm(const mi355_rows_gemm_args* ap, void* stream) {
   MI355_REQUIRE(!ap->glu_planes_out || (ap->kgroups == 1 && ap->N % 128 == 0 && ((uintptr_t)ap->glu_planes_out) % 16 == 0),
                 "rows_gemm: the fused SwiGLU epilogue needs one K group and N %% 128 == 0");
   const mi355_rows_gemm_args a = *ap;
-  MI355_REQUIRE(a.wdtype == MI355_W_BF16 || a.wdtype == MI355_W_F16, "rows_gemm: wdtype must be MI355_W_BF16 or MI355_W_F16");
+  MI355_REQUIRE(a.wdtype == MI355_W_BF16 || a.wdtype == MI355_W_F16 || a.wdtype == MI355_W_FP8, "rows_gemm: wdtype must be MI355_W_BF16, MI355_W_F16 or MI355_W_FP8");
   MI355_REQUIRE(a.N > 0 && a.K >= 64 && a.K % 64 == 0, "rows_gemm: K must be a positive multiple of 64 (got %d)", a.K);
   MI355_REQUIRE(a.R == 16 || a.R == 32 || a.R == 64, "rows_gemm: planes hold 16, 32 or 64 rows (got %d)", a.R);
   MI355_REQUIRE(a.M >= 1 && a.M <= a.R, "rows_gemm: M must be in [1, R] (got %d, R = %d)", a.M, a.R);
@@ -398,10 +425,9 @@ extern "C" int mi355_rows_gemm(const mi355_rows_gemm_args* ap, void* stream) {
   const int spg = (steps + a.kgroups - 1) / a.kgroups;
   MI355_REQUIRE((steps + spg - 1) / spg == a.kgroups, "rows_gemm: %d K groups leave empty slabs for %d k steps (use mi355_rows_kgroups)", a.kgroups, steps);
   hipStream_t st = (hipStream_t)stream;
-  const bool f16 = a.wdtype == MI355_W_F16;
-  if (a.R == 16) return f16 ? launch_rows_gemm_t<1, true>(a, st, T, ntiles, steps, spg) : launch_rows_gemm_t<1, false>(a, st, T, ntiles, steps, spg);
-  if (a.R == 32) return f16 ? launch_rows_gemm_t<2, true>(a, st, T, ntiles, steps, spg) : launch_rows_gemm_t<2, false>(a, st, T, ntiles, steps, spg);
-  return f16 ? launch_rows_gemm_t<4, true>(a, st, T, ntiles, steps, spg) : launch_rows_gemm_t<4, false>(a, st, T, ntiles, steps, spg);
+  if (a.R == 16) return launch_rows_gemm_w<1>(a, st, T, ntiles, steps, spg);
+  if (a.R == 32) return launch_rows_gemm_w<2>(a, st, T, ntiles, steps, spg);
+  return launch_rows_gemm_w<4>(a, st, T, ntiles, steps, spg);
 }
 
 extern "C" int mi355_rows_finish(const mi355_rows_finish_args* ap, void* stream) {
@@ -430,6 +456,21 @@ extern "C" int mi355_rows_finish(const mi355_rows_finish_args* ap, void* stream)
   if (a.planes && a.planes_dtype == MI355_W_F16) hipLaunchKernelGGL(rows_finish_kernel<true>, dim3(a.M, cb), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(rows_finish_kernel<false>, dim3(a.M, cb), dim3(256), 0, (hipStream_t)stream, a);
   MI355_LAUNCH_CHECK("rows_finish");
+  return MI355_OK;
+}
+
+// uint8 [N, K] (host: the e4m3 codes of mi355_pack_rowmajor_fp8_host) -> the fp8 tile image: the same permutation as mi355_pack_tiles16_host, one byte per element
+extern "C" int mi355_pack_tiles8_host(const uint8_t* codes, int64_t N, int64_t K, uint8_t* out) {
+  MI355_REQUIRE(codes && out && N > 0 && K > 0 && K % 64 == 0, "pack_tiles8: bad arguments (K must be a multiple of 64)");
+  const int64_t ntiles = (N + 15) / 16, steps = K / 64;
+  for (int64_t t = 0; t < ntiles; ++t)
+    for (int64_t s = 0; s < steps; ++s)
+      for (int g = 0; g < 4; ++g)
+        for (int i = 0; i < 16; ++i) {
+          uint8_t* o = out + (((t * steps + s) * 4 + g) * 16 + i) * 16;
+          const int64_t n = 16 * t + i;
+          for (int e = 0; e < 16; ++e) o[e] = n < N ? codes[n * K + 64 * s + 16 * g + e] : 0;
+        }
   return MI355_OK;
 }
 

@@ -76,12 +76,13 @@ int rows_gemm_call(const uint16_t* planes, const uint16_t* wt, int wdtype, int N
 }
 
 int tall_step(const mi355_stack_desc& d, float* x, int B, int offset, float* ws, float* out, void* stream) {
-  MI355_REQUIRE(d.wdtype == MI355_W_BF16 || d.wdtype == MI355_W_F16, "stack_decode_step: 9..64 sequences per step need 16-bit weight images");
   MI355_REQUIRE(d.d_model % 64 == 0 && d.d_ff % 64 == 0 && (d.heads * d.dh) % 64 == 0, "stack_decode_step: 9..64 sequences per step need widths that are multiples of 64");
   MI355_REQUIRE(d.rows_ws && ((uintptr_t)d.rows_ws) % 16 == 0, "stack_decode_step: 9..64 sequences per step need the rows workspace (mi355_stack_rows_ws_bytes)");
   const int D = d.d_model, H = d.heads, G = d.kv_heads, dh = d.dh, R = rows_R(B);
   const int nq = H * dh, nkv = 2 * G * dh, n_in = d.glu ? 2 * d.d_ff : d.d_ff;
   const RowsWs w = rows_layout(d, B, d.rows_ws);
+  const int pdt = d.wdtype == MI355_W_F16 ? MI355_W_F16 : MI355_W_BF16;   // element type of the planes (an fp8 image is decoded to bf16)
+  const bool fp8 = d.wdtype == MI355_W_FP8;
   MI355_REQUIRE(w.bytes <= d.rows_ws_bytes, "stack_decode_step: rows workspace too small (%lld bytes, need %lld)", (long long)d.rows_ws_bytes, (long long)w.bytes);
   float* q = ws;                       // [B, nq]
   float* att = q + (size_t)B * nq;     // [B, nq]
@@ -89,7 +90,7 @@ int tall_step(const mi355_stack_desc& d, float* x, int B, int offset, float* ws,
   const int kvsz = d.kv_dtype == MI355_KV_F32 ? 4 : 2;
   auto finish = [&](mi355_rows_finish_args& f, int N, int kg) {
     f.part = w.part; f.kgroups = kg; f.ldp = round8(N); f.kg_stride = kg > 1 ? (int64_t)B * f.ldp : 0; f.M = B; f.N = N; f.out_scale = 1.f;
-    f.R = R; f.planes_dtype = d.wdtype;
+    f.R = R; f.planes_dtype = pdt;
     return mi355_rows_finish(&f, stream);
   };
   int rc, kg;
@@ -97,7 +98,7 @@ int tall_step(const mi355_stack_desc& d, float* x, int B, int offset, float* ws,
     mi355_rows_finish_args f;
     memset(&f, 0, sizeof(f));
     f.part = x; f.kgroups = 1; f.ldp = D; f.M = B; f.N = D; f.out_scale = 1.f; f.norm = d.norm; f.norm_weight = d.layers[0].attn_norm_w;
-    f.norm_bias = d.layers[0].attn_norm_b; f.norm_eps = d.eps; f.planes = w.px; f.R = R; f.planes_dtype = d.wdtype;
+    f.norm_bias = d.layers[0].attn_norm_b; f.norm_eps = d.eps; f.planes = w.px; f.R = R; f.planes_dtype = pdt;
     rc = mi355_rows_finish(&f, stream);
     if (rc) return rc;
   }
@@ -124,7 +125,8 @@ int tall_step(const mi355_stack_desc& d, float* x, int B, int offset, float* ws,
       a.q = w.part; a.q_bstride = ld; a.ldq = ld; a.k = L.kv; a.k_bstride = L.kv_bstride; a.ldk = nkv; a.v = vbase; a.v_bstride = L.kv_bstride; a.ldv = nkv;
       a.kv_dtype = d.kv_dtype;
       a.heads = H; a.kv_heads = G; a.dh = dh; a.Tq = 1; a.Tk = offset + 1; a.causal = 1; a.window = d.window; a.scale = scale; a.B = B; a.mode = 2;
-      a.out_planes = w.pa; a.planes_R = R; a.planes_dtype = d.wdtype; a.out_bstride = nq; a.ldo = nq; a.k_start = d.k_start; a.nsplit = 1;
+      a.out_planes = w.pa; a.planes_R = R; a.planes_dtype = pdt; a.out_bstride = nq; a.ldo = nq; a.k_start = d.k_start; a.nsplit = 1;
+      if (fp8) { a.q_wscale = L.s_qkv; a.k_wscale = L.s_qkv + nq; a.v_wscale = L.s_qkv + nq + G * dh; }
       a.lens_k = d.slot_lens_k;
       a.new_k = w.part + nq; a.new_v = w.part + nq + G * dh; a.new_bstride = ld;
       a.in_kgroups = kg; a.in_kg_stride = (int64_t)B * ld;
@@ -137,7 +139,7 @@ int tall_step(const mi355_stack_desc& d, float* x, int B, int offset, float* ws,
       {
         mi355_rows_finish_args f;
         memset(&f, 0, sizeof(f));
-        f.bias = L.bqkv; f.y = q; f.ldy = nq; f.split = nq; f.y2 = slot; f.ldy2 = (int)L.kv_bstride; f.y2_dtype = d.kv_dtype;
+        f.bias = L.bqkv; f.y = q; f.ldy = nq; f.split = nq; f.y2 = slot; f.ldy2 = (int)L.kv_bstride; f.y2_dtype = d.kv_dtype; f.wscale = fp8 ? L.s_qkv : nullptr;
         rc = finish(f, nq + nkv, kg);
         if (rc) return rc;
       }
@@ -157,7 +159,7 @@ int tall_step(const mi355_stack_desc& d, float* x, int B, int offset, float* ws,
       if (rc) return rc;
       mi355_rows_finish_args f;   // attention output -> planes
       memset(&f, 0, sizeof(f));
-      f.part = att; f.kgroups = 1; f.ldp = nq; f.M = B; f.N = nq; f.out_scale = 1.f; f.planes = w.pa; f.R = R; f.planes_dtype = d.wdtype;
+      f.part = att; f.kgroups = 1; f.ldp = nq; f.M = B; f.N = nq; f.out_scale = 1.f; f.planes = w.pa; f.R = R; f.planes_dtype = pdt;
       rc = mi355_rows_finish(&f, stream);
       if (rc) return rc;
     }
@@ -167,7 +169,7 @@ int tall_step(const mi355_stack_desc& d, float* x, int B, int offset, float* ws,
     {
       mi355_rows_finish_args f;
       memset(&f, 0, sizeof(f));
-      f.bias = L.bo; f.colscale = L.ls1; f.res = x; f.ldr = D; f.y = x; f.ldy = D;
+      f.bias = L.bo; f.colscale = L.ls1; f.res = x; f.ldr = D; f.y = x; f.ldy = D; f.wscale = fp8 ? L.s_o : nullptr;
       f.norm = d.norm; f.norm_weight = L.mlp_norm_w; f.norm_bias = L.mlp_norm_b; f.norm_eps = d.eps; f.planes = w.px;
       rc = finish(f, D, kg);
       if (rc) return rc;
@@ -179,7 +181,7 @@ int tall_step(const mi355_stack_desc& d, float* x, int B, int offset, float* ws,
       mi355_rows_gemm_args g;
       memset(&g, 0, sizeof(g));
       g.wt = L.w_in_t; g.wdtype = d.wdtype; g.N = n_in; g.K = D; g.planes = w.px; g.M = B; g.R = R; g.kgroups = 1;
-      g.glu_planes_out = w.pm; g.glu_bias = L.b_in;
+      g.glu_planes_out = w.pm; g.glu_bias = L.b_in; g.wscale = fp8 ? L.s_in : nullptr;
       rc = mi355_rows_gemm(&g, stream);
       if (rc) return rc;
     } else {
@@ -188,7 +190,7 @@ int tall_step(const mi355_stack_desc& d, float* x, int B, int offset, float* ws,
     {
       mi355_rows_finish_args f;
       memset(&f, 0, sizeof(f));
-      f.bias = L.b_in; f.glu = d.glu; f.post_act = d.glu ? MI355_ACT_NONE : d.act; f.planes = w.pm;
+      f.bias = L.b_in; f.glu = d.glu; f.post_act = d.glu ? MI355_ACT_NONE : d.act; f.planes = w.pm; f.wscale = fp8 ? L.s_in : nullptr;
       rc = finish(f, n_in, kg);
       if (rc) return rc;
     }
@@ -198,7 +200,7 @@ int tall_step(const mi355_stack_desc& d, float* x, int B, int offset, float* ws,
     {
       mi355_rows_finish_args f;
       memset(&f, 0, sizeof(f));
-      f.bias = L.b_out; f.colscale = L.ls2; f.res = x; f.ldr = D; f.y = x; f.ldy = D;
+      f.bias = L.b_out; f.colscale = L.ls2; f.res = x; f.ldr = D; f.y = x; f.ldy = D; f.wscale = fp8 ? L.s_out : nullptr;
       if (i + 1 < d.n_layers) {   // the next layer's input planes
         f.norm = d.norm; f.norm_weight = d.layers[i + 1].attn_norm_w; f.norm_bias = d.layers[i + 1].attn_norm_b; f.norm_eps = d.eps; f.planes = w.px;
       } else if (out && d.final_norm_w) {
@@ -222,8 +224,8 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
   MI355_REQUIRE(dp && x && ws && dp->layers, "stack_decode_step: null argument");
   const mi355_stack_desc d = *dp;
   MI355_REQUIRE(B >= 1 && B <= 64, "stack_decode_step: 1..64 sequences per step (got %d)", B);
-  MI355_REQUIRE(B <= 8 || (d.wdtype != MI355_W_FP8 && d.d_model % 64 == 0 && d.d_ff % 64 == 0 && (d.heads * d.dh) % 64 == 0),
-                "stack_decode_step: 9..64 sequences per step need 16-bit weight images and widths that are multiples of 64");
+  MI355_REQUIRE(B <= 8 || (d.d_model % 64 == 0 && d.d_ff % 64 == 0 && (d.heads * d.dh) % 64 == 0),
+                "stack_decode_step: 9..64 sequences per step need widths that are multiples of 64");
   static const bool rows_off = getenv("MI355_ROWS_PIPE") != nullptr && getenv("MI355_ROWS_PIPE")[0] == '0';   // A/B knob: 9..64 rows through mi355_gemv (gemm_rows.hip)
   MI355_REQUIRE(d.n_layers > 0 && d.d_model % 8 == 0 && d.d_ff % 8 == 0 && (d.dh == 64 || d.dh == 128), "stack_decode_step: bad dimensions");
   MI355_REQUIRE(d.wdtype != MI355_W_FP8 || (d.d_model % 16 == 0 && d.d_ff % 16 == 0), "stack_decode_step: fp8 images need d_model, d_ff multiples of 16");
@@ -232,7 +234,9 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
   MI355_REQUIRE(d.kv_dtype >= MI355_KV_F32 && d.kv_dtype <= MI355_KV_F16, "stack_decode_step: bad kv_dtype");
   MI355_REQUIRE(!d.cos || (d.rope_rows > 0 && offset < d.rope_rows), "stack_decode_step: position %d is past the %d-row rotary tables", offset,
                 d.rope_rows);
-  if (B > 8 && !rows_off && d.layers[0].wqkv_t) return tall_step(d, x, B, offset, ws, out, stream);
+  // the rows pipeline also serves 5..8 sequences (16-row planes): measured faster than the 5..8-row matrix-pipe GEMV it replaces there (MI355_ROWS_MIN=9: old split)
+  static const int rows_min = getenv("MI355_ROWS_MIN") ? atoi(getenv("MI355_ROWS_MIN")) : 5;
+  if ((B > 8 || B >= rows_min) && !rows_off && d.layers[0].wqkv_t && !d.layers[0].cross_k) return tall_step(d, x, B, offset, ws, out, stream);
   const int D = d.d_model, H = d.heads, G = d.kv_heads, dh = d.dh;
   const int nq = H * dh, nkv = 2 * G * dh;
   float* q = ws;                 // [B, nq]

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -161,8 +162,8 @@ MAX_DECODE_ROWS = 64   # mi355_gemv: 1..8 rows on the GEMV kernels, 9..64 rows o
 
 
 def decode_rows(l: "Lin") -> int:
-    """Most sequences a single-position step through ``l`` may carry on the GEMV path: 64 for 16-bit images with K % 64 == 0, else 8."""
-    return MAX_DECODE_ROWS if (l.rm.wdtype != 2 and l.rm.k % 64 == 0) else 8
+    """Most sequences a single-position step through ``l`` may carry on the weight-streaming path: 64 when K % 64 == 0 (tile images), else 8."""
+    return MAX_DECODE_ROWS if l.rm.k % 64 == 0 else 8
 
 
 def is_decode(x: torch.Tensor, l: Optional["Lin"] = None) -> bool:
@@ -170,7 +171,8 @@ def is_decode(x: torch.Tensor, l: Optional["Lin"] = None) -> bool:
     return x.shape[1] == 1 and x.shape[0] <= (8 if l is None else decode_rows(l))
 
 
-ROWS_PIPE = True   # single-position Linear layers of 9..64 sequences outside the native runner: rows pipeline (False: mi355_gemv's 9..64-row kernel)
+ROWS_PIPE = True   # single-position Linear layers of ROWS_MIN..64 sequences outside the native runner: rows pipeline (False: mi355_gemv's kernels)
+ROWS_MIN = int(os.environ.get("MI355_ROWS_MIN", "5"))   # fewest sequences per step the rows pipeline takes (5..8 were the matrix-pipe GEMV's; 9 = the old split)
 _ROWS_WS: Dict[tuple, torch.Tensor] = {}
 
 
@@ -195,10 +197,10 @@ def linear_rows(x: torch.Tensor, l: Lin, y: torch.Tensor, *, post_act: int = ACT
     kg = ops.rows_kgroups(tl.n, tl.k)
     ld = ops.round_up(tl.n, 8)
     part = _rows_ws(x.device, "part", 4 * kg * B * ld).view(torch.float32)[: kg * B * ld].view(kg, B, ld)
-    ops.rows_finish(x[:, 0, :], B, tl.k, norm=norm, planes=planes, R=R, f16=f16)
+    ops.rows_finish(x[:, 0, :], B, tl.k, norm=norm, planes=planes, R=R, f16=f16 and tl.scale is None)
     ops.rows_gemm(planes, tl, part, B, R, kgroups=kg)
     ops.rows_finish(part, B, tl.n, kg, bias=l.rm.bias, post_act=post_act, res=None if res is None else res[:, 0, :], colscale=colscale, glu=glu,
-                    y=y[:, 0, :], y2=None if y2 is None else y2[:, 0, :])
+                    wscale=tl.scale, y=y[:, 0, :], y2=None if y2 is None else y2[:, 0, :])
     return y
 
 
@@ -207,7 +209,7 @@ def linear(x: torch.Tensor, l: Lin, y: torch.Tensor, *, post_act: int = ACT_NONE
            y2: Optional[torch.Tensor] = None):
     """y = act(norm(x) W^T + b) * colscale + res on [B, L, C] views; 1-row-per-sequence inputs with B <= 8 take the GEMV
     (``norm`` / ``y2`` -- fused input normalisation and split destination -- exist on that path only)."""
-    if is_decode(x, l) and x.shape[0] > 8 and ROWS_PIPE and l.rm.wdtype != 2:
+    if is_decode(x, l) and x.shape[0] >= min(ROWS_MIN, 9) and ROWS_PIPE and l.rm.k % 64 == 0 and not (glu and (l.rm.n % 16)):
         return linear_rows(x, l, y, post_act=post_act, res=res, colscale=colscale, glu=glu, norm=norm, y2=y2)
     if is_decode(x, l):
         ops.gemv(x[:, 0, :], l.rm, y[:, 0, :], post_act=post_act, res=None if res is None else res[:, 0, :], colscale=colscale, glu=glu,
@@ -251,7 +253,7 @@ class TransformerStack:
         self.native_decode = True  # single-position steps go through mi355_stack_decode_step (False: the per-op Python schedule)
         self.rows_pipe = True      # native steps of 9..64 sequences run the rows pipeline (rows_pipe.hip); False: mi355_gemv's 9..64-row kernel
         # sequences per single-position step on the weight-streaming path: 9..64 need 16-bit images and widths that are multiples of 64
-        self.max_decode_rows = MAX_DECODE_ROWS if (not fp8 and cfg.d_model % 64 == 0 and cfg.d_ff % 64 == 0 and (cfg.n_heads * cfg.head_dim) % 64 == 0) else 8
+        self.max_decode_rows = MAX_DECODE_ROWS if (cfg.d_model % 64 == 0 and cfg.d_ff % 64 == 0 and (cfg.n_heads * cfg.head_dim) % 64 == 0) else 8
         dev = self.device
         w = {k[len(prefix):]: v.detach().to(torch.bfloat16).to(torch.float32).cpu() for k, v in weights.items() if k.startswith(prefix)}
 
@@ -368,7 +370,7 @@ class TransformerStack:
             kvc.reserve(B, 1)
         if slot_lens_k is not None:   # slot caches (continuous batching): int32 [B] device, item b appends position slot_lens_k[b] - 1 to its own row
             assert slot_lens_k.dtype == torch.int32 and slot_lens_k.is_cuda and slot_lens_k.numel() >= B and k_start is None
-        st = self._native_desc(cache, k_start, tall=B > 8 and self.rows_pipe, slot_lens_k=slot_lens_k)
+        st = self._native_desc(cache, k_start, tall=B >= min(ROWS_MIN, 9) and self.rows_pipe and self.max_decode_rows > 8, slot_lens_k=slot_lens_k)
         ws = torch.empty(B * (2 * c.n_heads * c.head_dim + c.d_ff + 2 * c.n_kv_heads * c.head_dim), dtype=torch.float32, device=self.device)
         out = torch.empty_like(x) if (self.final_norm is not None and not defer_final_norm) else None
         lib = _lib.load()

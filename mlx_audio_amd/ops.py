@@ -214,25 +214,36 @@ def gemv(x: torch.Tensor, rw: RowMajor16, y: torch.Tensor, *, post_act: int = AC
 class Tiles16:
     """Tile image of a [N, K] Linear for ``mi355_rows_gemm``: [ceil(N / 16)][K / 64][4 groups][16 rows][16 elements] 16-bit elements."""
 
-    w: torch.Tensor  # int16, flat, on the device
+    w: torch.Tensor  # int16 (fp8 image: uint8), flat, on the device
     n: int
     k: int
     f16: bool
+    scale: Optional[torch.Tensor] = None  # fp8 image only: per-row power-of-two dequantisation scale [N] fp32 (device)
 
     @property
     def wdtype(self) -> int:
-        return W_F16 if self.f16 else W_BF16
+        return W_FP8 if self.scale is not None else (W_F16 if self.f16 else W_BF16)
 
 
 def tiles16_from_rowmajor(rm: RowMajor16) -> Tiles16:
     """The tile image of a row-major 16-bit image, permuted on the device (== ``mi355_pack_tiles16_host`` of the same weights, element for element)."""
-    assert rm.scale is None and rm.k % 64 == 0, "tile images exist for 16-bit weights with K % 64 == 0"
+    assert rm.k % 64 == 0, "tile images need K % 64 == 0"   # an fp8 image (uint8 codes + per-row scales) is permuted the same way, one byte per element
     nt = (rm.n + 15) // 16
     w = rm.w[:, : rm.k]
     if nt * 16 != rm.n:
         w = torch.cat([w, torch.zeros((nt * 16 - rm.n, rm.k), dtype=w.dtype, device=w.device)], 0)
     t = w.reshape(nt, 16, rm.k // 64, 4, 16).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
-    return Tiles16(t, rm.n, rm.k, rm.f16)
+    return Tiles16(t, rm.n, rm.k, rm.f16, rm.scale)
+
+
+def pack_tiles8_host(codes: torch.Tensor) -> np.ndarray:
+    """``mi355_pack_tiles8_host`` on uint8 e4m3 codes [N, K] (CPU): uint8 [ceil(N / 16) * 16 * K]."""
+    c = codes.detach().to(torch.uint8).contiguous().cpu()
+    n, k = c.shape
+    out = np.empty(((n + 15) // 16) * 16 * k, dtype=np.uint8)
+    rc = _lib.load().mi355_pack_tiles8_host(c.numpy().ctypes.data, n, k, out.ctypes.data)
+    _lib.check(rc, "mi355_pack_tiles8_host")
+    return out
 
 
 def pack_tiles16_host(w: torch.Tensor, f16: bool = False) -> np.ndarray:
@@ -268,7 +279,7 @@ def rows_gemm(planes: torch.Tensor, tl: Tiles16, part: Optional[torch.Tensor], M
     if glu_planes_out is not None:
         assert kg == 1 and glu_planes_out.numel() * glu_planes_out.element_size() >= 4 * R * (tl.n // 2)
         _lib.call_struct("mi355_rows_gemm", "mi355_rows_gemm_args", _stream(), wt=_ptr(tl.w), wdtype=tl.wdtype, N=tl.n, K=tl.k, planes=_ptr(planes), M=M, R=R,
-                         kgroups=1, glu_planes_out=_ptr(glu_planes_out), glu_bias=_ptr(glu_bias))
+                         kgroups=1, glu_planes_out=_ptr(glu_planes_out), glu_bias=_ptr(glu_bias), wscale=_ptr(tl.scale))
         return 1
     assert part.dtype == torch.float32 and part.dim() == 3 and part.shape[0] >= kg and part.shape[1] >= M and part.shape[2] >= tl.n and part.stride(2) == 1
     assert planes.numel() * planes.element_size() >= 4 * R * tl.k
@@ -278,8 +289,8 @@ def rows_gemm(planes: torch.Tensor, tl: Tiles16, part: Optional[torch.Tensor], M
 
 
 def rows_finish(part: torch.Tensor, M: int, N: int, kgroups: int = 1, *, bias=None, post_act: int = ACT_NONE, post_slope: float = 0.0, colscale=None,
-                res: Optional[torch.Tensor] = None, out_scale: float = 1.0, glu: bool = False, y: Optional[torch.Tensor] = None,
-                y2: Optional[torch.Tensor] = None, norm: Optional[tuple] = None, yn: Optional[torch.Tensor] = None,
+                res: Optional[torch.Tensor] = None, out_scale: float = 1.0, glu: bool = False, wscale: Optional[torch.Tensor] = None,
+                y: Optional[torch.Tensor] = None, y2: Optional[torch.Tensor] = None, norm: Optional[tuple] = None, yn: Optional[torch.Tensor] = None,
                 planes: Optional[torch.Tensor] = None, R: int = 0, f16: bool = False):
     """Row epilogue of ``rows_gemm`` (see ``mi355_rows_finish_args``).  ``part``: fp32 [kgroups, rows, ld] slabs, or a 2-D fp32 matrix (kgroups = 1:
     the converter rows -> planes).  ``y`` / ``y2`` / ``yn`` are 2-D views with unit inner stride; ``norm`` = (mode, weight, bias, eps)."""
@@ -287,7 +298,7 @@ def rows_finish(part: torch.Tensor, M: int, N: int, kgroups: int = 1, *, bias=No
         part = part.unsqueeze(0)
     assert part.dtype == torch.float32 and part.stride(2) == 1 and part.shape[0] >= kgroups
     kw = dict(part=_ptr(part), kgroups=kgroups, kg_stride=part.stride(0) if kgroups > 1 else 0, ldp=part.stride(1), M=M, N=N, bias=_ptr(bias),
-              post_act=post_act, post_slope=post_slope, colscale=_ptr(colscale), out_scale=out_scale, glu=int(glu))
+              post_act=post_act, post_slope=post_slope, colscale=_ptr(colscale), out_scale=out_scale, glu=int(glu), wscale=_ptr(wscale))
     n_out = N // 2 if glu else N
     if res is not None:
         assert res.dim() == 2 and res.stride(1) == 1

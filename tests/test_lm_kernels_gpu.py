@@ -287,7 +287,8 @@ def test_transformer_stack_16bit_kv_cache(ops, name, kvd, B):
     assert rel_err(k_got, k_ref) < 1e-2 and float((k_got - k_ref).abs().mean() / k_ref.abs().mean()) < 1e-4
 
 
-@pytest.mark.parametrize("name,B,L", [("csm_llama", 1, 60), ("csm_llama", 4, 250), ("qwen3_talker", 8, 60), ("mimi", 3, 60), ("qwen3_codec", 2, 60)])
+@pytest.mark.parametrize("name,B,L", [("csm_llama", 1, 60), ("csm_llama", 4, 250), ("qwen3_talker", 8, 60), ("mimi", 3, 60), ("qwen3_codec", 2, 60),
+                                      ("csm_llama", 6, 40), ("qwen3_talker", 20, 30)])   # 5..64 sequences: the rows pipeline on fp8 tile images
 def test_stack_fp8_weight_images(ops, name, B, L):
     """weight_format="fp8" (BASELINE config[4]): decode steps stream OCP e4m3fn weight images (per-row power-of-two scales) through the GEMVs
     of the native step runner, prefill runs the same dequantised values through the bf16 MFMA image.  Oracle = StackRef on the dequantised

@@ -830,3 +830,36 @@ def test_rows_gemm_fused_swiglu_epilogue(ops, M, N, K, use_bias):
     torch.cuda.synchronize()
     assert rel_err(_decode_planes(pin, R, K, False)[:M], x.double()) < 1e-5
     assert rel_err(_decode_planes(pout, R, N // 2, False)[:M], exp) < 3e-5
+
+
+@pytest.mark.parametrize("M,N,K,glu,fused", [(8, 4096, 1024, False, False), (64, 2048, 2048, False, False), (8, 16384, 1024, True, True), (20, 512, 256, True, False)])
+def test_rows_pipeline_fp8_tile_image(ops, M, N, K, glu, fused):
+    """fp8 tile images (BASELINE config[4]: fp8 GEMMs): the e4m3 bytes of ``mi355_pack_rowmajor_fp8_host`` in tile order are decoded to bf16 in registers
+    (exact) and multiplied on the bf16 matrix pipe with hi + lo input planes; the per-row power-of-two scales are applied to the sums by the row
+    epilogue (or by the fused SwiGLU epilogue).  Oracle: float64 on the DEQUANTISED weights, the bf16 pipeline's bar."""
+    g = torch.Generator().manual_seed(M + N + K)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K) * (1.0 + torch.rand(N, 1, generator=g) * 3.0)
+    bias = torch.randn(N, generator=g) * 0.1
+    x = torch.randn(M, K, generator=g)
+    rm, wq = ops.pack_rowmajor_fp8(w, bias, DEV)
+    tl = ops.tiles16_from_rowmajor(rm)
+    assert tl.wdtype == 2 and np.array_equal(tl.w.cpu().numpy(), ops.pack_tiles8_host(rm.w.cpu()))
+    v = x.double() @ wq.double().T + bias.double()
+    exp = F.silu(v[:, 0::2]) * v[:, 1::2] if glu else v
+    R = ops.rows_R(M)
+    planes = ops.rows_planes(R, K, DEV)
+    ops.rows_finish(x.to(DEV), M, K, planes=planes, R=R)
+    if fused:
+        po = ops.rows_planes(R, N // 2, DEV)
+        ops.rows_gemm(planes, tl, None, M, R, kgroups=1, glu_planes_out=po, glu_bias=rm.bias)
+        torch.cuda.synchronize()
+        got = _decode_planes(po, R, N // 2, False)[:M]
+    else:
+        kg = ops.rows_kgroups(N, K)
+        part = torch.empty(kg, M, N, device=DEV)
+        ops.rows_gemm(planes, tl, part, M, R, kgroups=kg)
+        y = torch.empty(M, N // 2 if glu else N, device=DEV)
+        ops.rows_finish(part, M, N, kg, bias=rm.bias, glu=glu, wscale=rm.scale, y=y)
+        torch.cuda.synchronize()
+        got = y.cpu()
+    assert rel_err(got, exp) < 3e-5, rel_err(got, exp)
