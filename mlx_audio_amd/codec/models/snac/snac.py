@@ -17,7 +17,10 @@ Mirrors ``mlx_audio/codec/models/snac/snac.py`` + ``layers.py`` + ``vq.py`` (con
 Reference quirk preserved: ``WNConvTranspose1d`` hands ``groups = 1`` to MLX's ``output_padding`` slot (positional order), so each transposed
 conv emits one extra sample: the reference's test pins 59 / 118 / 236 code frames -> 120 907 samples (codec/tests/test_snac.py:24-34).
 
-``attn_window_size`` must be ``None`` (the 24 kHz model, the one Orpheus-style TTS uses); the ``LocalMHA`` variants raise.  The encoder /
+``attn_window_size`` = ``None`` is the 24 kHz model (the one Orpheus-style TTS uses).  The 32 / 44 kHz models' ``LocalMHA`` (windowed attention between the
+input convs and the first decoder block, attention.py:5-53) is LayerNorm + two GEMMs around one attention launch whose batch items are the windows -- built
+to what the module MEANS: the reference's own transcription expects [B, C, T] data but receives channels-last [B, T, C] and raises (recorded in
+tests/golden/ref_snac_local_mha_probe.json), so this path has no reference output and is held to the oracle's restatement only (PARITY UNPINNED).  The encoder /
 quantiser-search half (``encode``, ``__call__``) is outside the decode hot path and raises.  Weights: float32 checkpoints are held as fp16 MFMA
 images, activations split fp16 hi + lo (``precision = 4``); deviation from the float32 oracle asserted in ``tests/test_snac_gpu.py``.
 """
@@ -34,7 +37,7 @@ from ....ops import ACT_NONE, ACT_SNAKE, ACT_TANH, PackedConv, round_up
 
 
 def make_snac_weights(latent_dim: int, decoder_dim: int, decoder_rates: List[int], vq_strides: List[int], codebook_size: int, codebook_dim: int,
-                      noise: bool = True, depthwise: bool = True, seed: int = 0) -> Dict[str, torch.Tensor]:
+                      noise: bool = True, depthwise: bool = True, seed: int = 0, attn: bool = False) -> Dict[str, torch.Tensor]:
     """Random float32 decode-side parameters of the shapes ``SNAC(...)`` allocates (reference module paths, MLX layouts)."""
     g = torch.Generator().manual_seed(seed)
     w: Dict[str, torch.Tensor] = {}
@@ -65,6 +68,13 @@ def make_snac_weights(latent_dim: int, decoder_dim: int, decoder_rates: List[int
     else:
         conv(m + "0", decoder_dim, 7, latent_dim, 7 * latent_dim, gain=1.7)
         nxt = 1
+    if attn:  # LocalMHA (attention.py:5-18): LayerNorm, to_qkv / to_out without bias
+        a = f"{m}{nxt}."
+        w[a + "norm.weight"] = 1.0 + 0.1 * torch.randn(decoder_dim, generator=g)
+        w[a + "norm.bias"] = 0.05 * torch.randn(decoder_dim, generator=g)
+        w[a + "to_qkv.weight"] = (torch.rand(3 * decoder_dim, decoder_dim, generator=g) * 2 - 1) * math.sqrt(3.0 / decoder_dim)
+        w[a + "to_out.weight"] = (torch.rand(decoder_dim, decoder_dim, generator=g) * 2 - 1) * math.sqrt(1.5 / decoder_dim)
+        nxt += 1
     out_dim = decoder_dim
     for i, s in enumerate(decoder_rates):
         in_dim, out_dim = decoder_dim // 2 ** i, decoder_dim // 2 ** (i + 1)
@@ -152,8 +162,6 @@ class SNAC:
         """Same arguments as the reference (snac.py:16-31) plus ``weights`` (reference parameter names; omitted: random, like a freshly
         constructed reference model), ``device``, ``seed``."""
         ops.require_gpu()
-        if attn_window_size is not None:
-            raise NotImplementedError("SNAC with LocalMHA (attn_window_size != None: the 32 / 44 kHz models) is not built; the 24 kHz model has none")
         self.sampling_rate, self.encoder_dim, self.encoder_rates = sampling_rate, encoder_dim, list(encoder_rates)
         self.decoder_dim, self.decoder_rates = decoder_dim, list(decoder_rates)
         self.latent_dim = encoder_dim * (2 ** len(encoder_rates)) if latent_dim is None else latent_dim
@@ -162,7 +170,8 @@ class SNAC:
         self.vq_strides, self.attn_window_size, self.noise, self.depthwise = list(vq_strides), attn_window_size, noise, depthwise
         self.device = torch.device(device)
         if weights is None:
-            weights = make_snac_weights(self.latent_dim, decoder_dim, self.decoder_rates, self.vq_strides, codebook_size, codebook_dim, noise, depthwise, seed)
+            weights = make_snac_weights(self.latent_dim, decoder_dim, self.decoder_rates, self.vq_strides, codebook_size, codebook_dim, noise, depthwise, seed,
+                                        attn=attn_window_size is not None)
         self.load_weights(weights)
 
     # ------------------------------------------------------------------ load
@@ -189,6 +198,19 @@ class SNAC:
             self.in_dw, self.conv_in, nxt = dw(m + "0"), conv(m + "1"), 2
         else:
             self.in_dw, self.conv_in, nxt = None, conv(m + "0"), 1
+        self.attn = None
+        if self.attn_window_size is not None:   # LocalMHA (attention.py:5-53) between the input convs and the first DecoderBlock (layers.py:185-186)
+            a = f"{m}{nxt}."
+            dh = 64
+            if self.decoder_dim % dh:
+                raise ValueError(f"LocalMHA needs decoder_dim ({self.decoder_dim}) to be a multiple of its head size 64")
+            inv = 1.0 / (10000 ** (torch.arange(0, dh, 2, dtype=torch.float32) / dh))
+            ang = torch.arange(self.attn_window_size, dtype=torch.float32)[:, None] * inv[None, :]
+            self.attn = dict(nw=w[a + "norm.weight"].to(dev), nb=w[a + "norm.bias"].to(dev), dh=dh, heads=self.decoder_dim // dh,
+                             qkv=ops.pack_conv(w[a + "to_qkv.weight"][:, None, :], None, dev, f16=True),
+                             out=ops.pack_conv(w[a + "to_out.weight"][:, None, :], None, dev, f16=True),
+                             cos=torch.cos(ang).contiguous().to(dev), sin=torch.sin(ang).contiguous().to(dev))
+            nxt += 1
         self.blocks = []
         for i, s in enumerate(self.decoder_rates):
             p = f"{m}{nxt + i}.block.layers."
@@ -253,6 +275,9 @@ class SNAC:
         h = self._f(B, T, self.decoder_dim)
         self._conv(x, None, self.conv_in, h)
         st["conv_in"] = h
+        if self.attn is not None:
+            h = self._local_mha(h)
+            st["attn"] = h
         for bi, blk in enumerate(self.blocks):
             s, cout, taps = blk["stride"], blk["cout"], blk["up"].k
             p = math.ceil(s / 2)
@@ -278,6 +303,28 @@ class SNAC:
         out = self._f(B, h.shape[1], 1)
         self._conv(h, self.out_snake, self.conv_out, out, post_act=ACT_TANH)
         return (out, st) if return_stages else out
+
+    def _local_mha(self, h: torch.Tensor) -> torch.Tensor:
+        """``LocalMHA.__call__`` (attention.py:19-53) on channels-last [B, T, C]: LayerNorm -> to_qkv -> heads of 64 channels, attention INSIDE
+        windows of ``attn_window_size`` positions (rotate-half rotary embedding with the position inside the window, no mask) -> to_out + x.  The
+        windows are the batch items of one attention launch (a window's rows are contiguous: [B, T, 3C] viewed as [B * windows, window, 3C])."""
+        a, ws = self.attn, self.attn_window_size
+        B, T, C = h.shape
+        if T % ws:
+            raise ValueError(f"LocalMHA: {T} positions are not a whole number of windows of {ws} (the reference's reshape fails the same way)")
+        H, dh = a["heads"], a["dh"]
+        xn = self._f(B, T, C)
+        ops.layernorm(h, xn, weight=a["nw"], bias=a["nb"], eps=1e-5)
+        qkv = self._f(B, T, 3 * C)
+        ops.conv_gemm(xn, a["qkv"], qkv, precision=4, flatten=True)
+        win = qkv.view(B * (T // ws), ws, 3 * C)
+        q, k, v = win[:, :, :C], win[:, :, C:2 * C], win[:, :, 2 * C:]
+        ops.head_norm_rope(q, q, heads=H, dh=dh, cos=a["cos"], sin=a["sin"], pos0=0, interleaved=False, second=(k, k, H, None))
+        att = self._f(B * (T // ws), ws, C)
+        ops.flash_attention(q, k, v, att, heads=H, kv_heads=H, dh=dh, causal=False, mode=1)
+        out = self._f(B, T, C)
+        ops.conv_gemm(att.view(B, T, C), a["out"], out, res=h, precision=4, flatten=True)
+        return out
 
     def decode(self, codes: List[torch.Tensor], noises: Optional[List[torch.Tensor]] = None):
         """codes[i] int [B, T / vq_strides[i]] -> audio [B, T', 1] (snac.py:104-107)."""

@@ -1,0 +1,110 @@
+"""The OpenAI-style speech endpoint of the reference's serving shell (``mlx_audio/server.py:959-987``: ``POST /v1/audio/speech``) over this package's
+``InferenceBroker`` -- the thinnest shell that lets a client of the reference switch: the request model (``SpeechRequest``, server.py:167-186: same fields and
+defaults), submission to the broker (endpoint kind "tts": continuous-batching sessions for Kokoro / Qwen3-TTS, serial ``generate`` otherwise), and a streaming
+response that carries each result chunk as audio bytes.  ``GET /v1/models`` lists what is loaded.
+
+Deliberately NOT here (control plane of the reference, out of scope of the hot path: SURVEY section 8 / DESIGN section 8): model download / hot loading, the
+web UI, CORS / auth, STT / separation endpoints, mp3 / flac / opus containers (``response_format`` "wav" and "pcm" only: the reference encodes the others with
+ffmpeg-backed writers).  Models are handed in already loaded (``create_app({"name": model})``).
+
+Multi-GPU: one server process per GPU (``mlx_audio_amd.shard``): a front process shards a batch of requests with ``shard.sharded_decode`` / ``kokoro_step``;
+inside one process the broker's session batches whatever requests are in flight.
+"""
+from __future__ import annotations
+
+import io
+from typing import Any, Dict, Optional
+
+from .server_inference import InferenceBroker, TTSExecutionAdapter
+
+
+from pydantic import BaseModel  # noqa: E402  (fastapi's dependency; the endpoint parameter's annotation must resolve at module level)
+
+
+class SpeechRequest(BaseModel):   # server.py:167-186
+    model: str
+    input: str
+    instruct: Optional[str] = None
+    voice: Optional[str] = None
+    speed: Optional[float] = 1.0
+    gender: Optional[str] = "male"
+    pitch: Optional[float] = 1.0
+    lang_code: Optional[str] = "a"
+    ref_audio: Optional[str] = None
+    ref_text: Optional[str] = None
+    temperature: Optional[float] = 0.7
+    top_p: Optional[float] = 0.95
+    top_k: Optional[int] = 40
+    repetition_penalty: Optional[float] = 1.0
+    response_format: Optional[str] = "mp3"
+    stream: bool = False
+    streaming_interval: float = 2.0
+    max_tokens: int = 1200
+    verbose: bool = False
+
+
+
+def _pcm16(audio) -> bytes:
+    import numpy as np
+    import torch
+
+    a = audio.detach().to(torch.float32).cpu().numpy() if isinstance(audio, torch.Tensor) else np.asarray(audio, dtype=np.float32)
+    return (np.clip(a.reshape(-1), -1.0, 1.0) * 32767.0).astype("<i2").tobytes()
+
+
+def _wav_header(sample_rate: int, n_bytes: int = 0xFFFFFFFF - 36) -> bytes:
+    """RIFF header of a 16-bit mono stream; with the size unknown up front (streaming) the placeholder length players accept."""
+    import struct
+
+    return b"RIFF" + struct.pack("<I", (36 + n_bytes) & 0xFFFFFFFF) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, sample_rate, sample_rate * 2, 2, 16) + \
+        b"data" + struct.pack("<I", n_bytes & 0xFFFFFFFF)
+
+
+def create_app(models: Dict[str, Any], *, max_batch_size: int = 8, broker: Optional[InferenceBroker] = None):
+    """FastAPI app serving ``models`` (name -> loaded model with the reference's ``generate`` / ``create_tts_batch_session`` surface)."""
+    from fastapi import FastAPI, HTTPException
+    from fastapi.responses import StreamingResponse
+
+    app = FastAPI(title="mlx_audio_amd")
+    brk = broker or InferenceBroker()
+    brk.register_adapter("tts", TTSExecutionAdapter(models, max_batch_size=max_batch_size))
+    app.state.broker = brk
+
+    @app.get("/v1/models")
+    def list_models():
+        return {"object": "list", "data": [{"id": name, "object": "model"} for name in sorted(models)]}
+
+    @app.post("/v1/audio/speech")
+    def tts_speech(payload: SpeechRequest):
+        if payload.model not in models:
+            raise HTTPException(status_code=404, detail=f"Model '{payload.model}' is not loaded")
+        fmt = (payload.response_format or "wav").lower()
+        if fmt not in ("wav", "pcm"):
+            raise HTTPException(status_code=400, detail=f"response_format '{fmt}' is not built here (wav | pcm); the reference encodes it through its audio writers")
+        body = payload.model_dump(exclude={"model", "input", "response_format"}, exclude_none=True)
+        body["text"] = payload.input
+        handle = brk.submit(endpoint_kind="tts", model_name=payload.model, payload=body, normalized_kwargs=body, stream=payload.stream)
+        sr = int(getattr(models[payload.model], "sample_rate", 24000))
+
+        def chunks():
+            first = True
+            while True:
+                chunk = handle.result_queue.get()
+                if chunk.kind == "done":
+                    break
+                if chunk.kind == "error":
+                    raise RuntimeError(str(chunk.error))
+                audio = getattr(chunk.payload, "audio", chunk.payload)
+                if audio is None:
+                    continue
+                data = _pcm16(audio)
+                if first and fmt == "wav":
+                    yield _wav_header(sr)
+                first = False
+                yield data
+            if first and fmt == "wav":
+                yield _wav_header(sr, 0)
+
+        return StreamingResponse(chunks(), media_type=f"audio/{fmt}", headers={"Content-Disposition": f"attachment; filename=speech.{fmt}"})
+
+    return app

@@ -368,7 +368,12 @@ class TTSExecutionAdapter(BaseModelExecutionAdapter):
         from .tts.continuous import TTSBatchOptions
 
         p = request.payload if isinstance(request.payload, dict) else {}
-        opts = TTSBatchOptions(lang_code=p.get("lang_code", "a"), stream=request.stream, max_batch_size=self.max_batch_size)
+        # server.py:456-469: the session is created with the FIRST request's sampling options (requests of one session share a batch key)
+        defaults = TTSBatchOptions()
+        opts = TTSBatchOptions(temperature=p.get("temperature", defaults.temperature), top_p=p.get("top_p", defaults.top_p), top_k=p.get("top_k", defaults.top_k),
+                               repetition_penalty=p.get("repetition_penalty", defaults.repetition_penalty), max_tokens=p.get("max_tokens", defaults.max_tokens),
+                               lang_code=p.get("lang_code", "a"), stream=request.stream, streaming_interval=p.get("streaming_interval", defaults.streaming_interval),
+                               max_batch_size=self.max_batch_size, verbose=bool(p.get("verbose", False)))
         return _SpeechSession(self._model(request).create_tts_batch_session(opts))
 
     def run_serial(self, request: InferenceRequest) -> None:

@@ -9,7 +9,7 @@ Follows /root/reference/mlx_audio/codec/models/snac statement by statement:
                             says.  The reference's test pins the result: codes of 59 / 118 / 236 frames -> 120 907 samples
                             (codec/tests/test_snac.py:24-34 = 236 -> 1889 -> 15113 -> 60453 -> 120907 through strides 8, 8, 4, 2).
   * ``layers.py:123-129, 298-306``  snake(x, alpha) = x + 1 / (alpha + 1e-9) * sin(alpha x)^2, alpha stored ``[1, C, 1]``
-  * ``layers.py:159-206``   Decoder: (depthwise: conv k7 groups = C, conv k1) | conv k7 -> [LocalMHA: not restated, attn_window_size must be None]
+  * ``layers.py:159-206``   Decoder: (depthwise: conv k7 groups = C, conv k1) | conv k7 -> [LocalMHA (attention.py:5-53) when attn_window_size is set: ``local_mha``]
                             -> DecoderBlocks -> snake -> conv k7 -> tanh
   * ``layers.py:209-233``   ResidualUnit: snake, conv k7 (dilation d, padding 3 d, groups), snake, conv k1, + x
   * ``layers.py:256-267``   NoiseBlock: x + noise * linear(x)  (1x1 conv, no bias); the Gaussian noise is an explicit input here.  The block reads
@@ -50,7 +50,8 @@ def snake(x: Tensor, alpha: Tensor) -> Tensor:
 
 class SNACDecoderRef:
     def __init__(self, weights: Dict[str, Tensor], decoder_rates: List[int], vq_strides: List[int], noise: bool = True, depthwise: bool = True,
-                 dtype=torch.float32):
+                 dtype=torch.float32, attn_window_size: Optional[int] = None):
+        self.attn_window_size = attn_window_size
         self.w = {k: v.to(dtype) if v.is_floating_point() else v for k, v in weights.items()}
         self.rates, self.vq_strides, self.noise, self.depthwise, self.dtype = list(decoder_rates), list(vq_strides), noise, depthwise, dtype
 
@@ -62,6 +63,33 @@ class SNACDecoderRef:
         w = wn_weight(self.w[name + ".weight_g"], self.w[name + ".weight_v"])  # stored [in, K, out] = torch's [in, out, K] permuted
         return F.conv_transpose1d(x.transpose(1, 2), w.permute(0, 2, 1), self.w.get(name + ".bias"), stride=stride, padding=math.ceil(stride / 2),
                                   output_padding=1).transpose(1, 2)
+
+    def local_mha(self, x: Tensor, p: str) -> Tensor:
+        """PARITY UNPINNED (the reference's module raises in this layout: tests/golden/ref_snac_local_mha_probe.json) -- what ``LocalMHA.__call__``
+        (attention.py:19-53) MEANS, on channels-last x [B, T, C]: LayerNorm, to_qkv (no bias), heads of 64, windows of
+        ``attn_window_size`` positions, rotary embedding with the position INSIDE the window (``SinusoidalEmbeddings`` without xpos: freqs =
+        [t * inv_freq | t * inv_freq], scale 1; ``apply_rotary_pos_emb``: q cos + rotate_half(q) sin, rotate_half = [-x2, x1]), scores / sqrt(64),
+        softmax, to_out, + residual."""
+        ws, dh = self.attn_window_size, 64
+        B, T, C = x.shape
+        H, W = C // dh, T // ws
+        xn = F.layer_norm(x, (C,), self.w[p + "norm.weight"], self.w[p + "norm.bias"], 1e-5)
+        qkv = xn @ self.w[p + "to_qkv.weight"].t()
+        q, k, v = [t.reshape(B, W, ws, H, dh).permute(0, 3, 1, 2, 4) for t in qkv.split(C, dim=-1)]
+        inv = 1.0 / (10000 ** (torch.arange(0, dh, 2, dtype=torch.float32) / dh))
+        fr = torch.arange(ws, dtype=torch.float32)[:, None] * inv[None, :]
+        fr = torch.cat([fr, fr], dim=-1).to(x.dtype)
+
+        def rot(t):
+            x1, x2 = t[..., : dh // 2], t[..., dh // 2:]
+            return torch.cat([-x2, x1], dim=-1)
+
+        q = q * torch.cos(fr) + rot(q) * torch.sin(fr)
+        k = k * torch.cos(fr) + rot(k) * torch.sin(fr)
+        sc = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
+        out = torch.softmax(sc, dim=-1) @ v
+        out = out.permute(0, 2, 3, 1, 4).reshape(B, T, C)
+        return out @ self.w[p + "to_out.weight"].t() + x
 
     def from_codes(self, codes: List[Tensor]) -> Tensor:
         """codes[i] int [B, T / stride_i] -> z_q [B, D, T] (vq.py:116-137)."""
@@ -89,6 +117,10 @@ class SNACDecoderRef:
             x = self._conv(x, m + "0", padding=3)
             nxt = 1
         st["conv_in"] = x
+        if self.attn_window_size is not None:
+            x = self.local_mha(x, f"{m}{nxt}.")
+            st["attn"] = x
+            nxt += 1
         for i, s in enumerate(self.rates):
             p = f"{m}{nxt + i}.block.layers."
             x = snake(x, self.w[p + "0.alpha"])

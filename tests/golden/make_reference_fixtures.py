@@ -789,7 +789,7 @@ def run_dac(seed_w, seed_codes, n_frames):
                    codebook_size=csize, codebook_dim=cdim, sample_rate=16000)
     model.load_weights([(k, v.numpy()) for k, v in w.items()])
     missing, unexpected, mism = model._load_report
-    dec_missing = [m for m in missing if not m.startswith("encoder.") and ".in_proj." not in m]
+    dec_missing = [m for m in missing if not m.startswith("encoder.") and ".in_proj." not in m and ".rel_pos.inv_freq" not in m]  # inv_freq: a constant the module builds itself
     assert not unexpected and not dec_missing and not mism, (dec_missing[:8], unexpected[:8], mism[:4])
     model.eval()
     codes = np.random.default_rng(seed_codes).integers(0, csize, size=(2, nq, n_frames)).astype(np.int32)
@@ -798,7 +798,7 @@ def run_dac(seed_w, seed_codes, n_frames):
     return dict(seed_w=seed_w, codes=codes, z=np.asarray(z).astype(np.float32), audio=audio.astype(np.float32))
 
 
-def run_snac(seed_w, seed_codes, n_frames):
+def run_snac(seed_w, seed_codes, n_frames, attn_window_size=None):
     """The reference's ``SNAC.quantizer.from_codes`` + ``SNAC.decoder`` (codec/models/snac/{snac,layers,vq}.py), depthwise convs, no attention, with the
     NoiseBlock's gaussian draws logged."""
     from mlx_audio_amd.codec.models.snac import make_snac_weights
@@ -810,14 +810,15 @@ def run_snac(seed_w, seed_codes, n_frames):
     _load(f"{base}.layers", f"{REF}/codec/models/snac/layers.py")
     _load(f"{base}.vq", f"{REF}/codec/models/snac/vq.py")
     rsn = _load(f"{base}.snac", f"{REF}/codec/models/snac/snac.py")
-    cfg = dict(sampling_rate=24000, encoder_dim=8, encoder_rates=[2, 4, 8], decoder_dim=64, decoder_rates=[8, 4, 2], attn_window_size=None,
-               codebook_size=64, codebook_dim=8, vq_strides=[4, 2, 1], noise=True, depthwise=True)
+    cfg = dict(sampling_rate=24000, encoder_dim=8, encoder_rates=[2, 4, 8], decoder_dim=128 if attn_window_size else 64, decoder_rates=[8, 4, 2],
+               attn_window_size=attn_window_size, codebook_size=64, codebook_dim=8, vq_strides=[4, 2, 1], noise=True, depthwise=True)
     latent = cfg["encoder_dim"] * 2 ** len(cfg["encoder_rates"])
-    w = make_snac_weights(latent, cfg["decoder_dim"], cfg["decoder_rates"], cfg["vq_strides"], cfg["codebook_size"], cfg["codebook_dim"], True, True, seed=seed_w)
+    w = make_snac_weights(latent, cfg["decoder_dim"], cfg["decoder_rates"], cfg["vq_strides"], cfg["codebook_size"], cfg["codebook_dim"], True, True, seed=seed_w,
+                          attn=attn_window_size is not None)
     model = rsn.SNAC(**cfg)
     model.load_weights([(k, v.numpy()) for k, v in w.items()])
     missing, unexpected, mism = model._load_report
-    dec_missing = [m for m in missing if not m.startswith("encoder.") and ".in_proj." not in m]
+    dec_missing = [m for m in missing if not m.startswith("encoder.") and ".in_proj." not in m and ".rel_pos.inv_freq" not in m]  # inv_freq: a constant the module builds itself
     assert not unexpected and not dec_missing and not mism, (dec_missing[:8], unexpected[:8], mism[:4])
     model.eval()
     g = np.random.default_rng(seed_codes)
@@ -830,6 +831,21 @@ def run_snac(seed_w, seed_codes, n_frames):
     out.update({f"codes{i}": c for i, c in enumerate(codes)})
     out.update({f"noise{i}": n.astype(np.float32) for i, n in enumerate(noises)})
     return out, cfg
+
+
+def run_snac_local_mha_probe():
+    """The reference's SNAC with ``attn_window_size`` set (the 32 / 44 kHz models) CANNOT run its decoder: ``LocalMHA.__call__`` (attention.py:19-23) is a
+    line-by-line transcription of the PyTorch module for [B, C, T] data (``B, C, T = x.shape``, ``x.moveaxis(1, 2)``) but the MLX decoder hands it
+    channels-last [B, T, C] data, so its LayerNorm([C]) meets a last axis of length T.  Recorded here as evidence (the error the reference raises),
+    because this package's LocalMHA implements what the module MEANS and therefore has no reference output to be pinned to."""
+    try:
+        run_snac(seed_w=6, seed_codes=2, n_frames=16, attn_window_size=4)
+        out = dict(raised=False)
+    except Exception as e:  # noqa: BLE001
+        out = dict(raised=True, error_type=type(e).__name__, message=str(e)[:200], where="mlx_audio/codec/models/snac/attention.py:22 (self.norm(x.moveaxis(1, 2)))")
+    with open(os.path.join(HERE, "ref_snac_local_mha_probe.json"), "w") as f:
+        json.dump(out, f)
+    return out
 
 
 def run_vocos(seed_w, seed_audio):
@@ -1541,6 +1557,7 @@ def main():
     nfx, ncfg = run_snac(seed_w=4, seed_codes=9, n_frames=24)
     np.savez_compressed(os.path.join(HERE, "ref_snac_tiny.npz"), config=json.dumps(ncfg), **nfx)
     print("snac:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in nfx.items()}, "peak", float(np.abs(nfx["audio"]).max()))
+    print("snac (LocalMHA) probe:", run_snac_local_mha_probe())
     vfx, vcfg = run_vocos(seed_w=3, seed_audio=1)
     np.savez_compressed(os.path.join(HERE, "ref_vocos_tiny.npz"), config=json.dumps(vcfg), **vfx)
     print("vocos:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in vfx.items()}, "peak", float(np.abs(vfx["audio"]).max()))

@@ -331,7 +331,16 @@ def test_encodec_oracle_reproduces_the_reference_modules():
     assert float(np.abs(audio - fx["audio"]).max()) <= 2e-5 * peak
 
 
-def test_snac_oracle_reproduces_the_reference_modules():
+def test_snac_local_mha_has_no_reference_output_to_pin_to():
+    """Evidence behind "parity unpinned" for SNAC's ``LocalMHA`` variants: the reference's own module raises in its decoder (channels-last data into a
+    [B, C, T] transcription, attention.py:19-23) -- recorded by tests/golden/make_reference_fixtures.py::run_snac_local_mha_probe."""
+    import json
+
+    probe = json.load(open(os.path.join(GOLD, "ref_snac_local_mha_probe.json")))
+    assert probe["raised"] and probe["error_type"] == "ValueError" and "broadcast" in probe["message"]
+
+
+def test_snac_oracle_reproduces_the_reference_modules(fixture="ref_snac_tiny.npz"):
     """The reference's ``SNAC.decode`` (snac.py:101-104) with the NoiseBlock draws the reference made: this is where the channels-last unpacking slip of
     ``NoiseBlock`` (one draw per channel, layers.py:261-263) was found."""
     import json
@@ -339,12 +348,12 @@ def test_snac_oracle_reproduces_the_reference_modules():
     from mlx_audio_amd.codec.models.snac import make_snac_weights
     from oracle.snac_ref import SNACDecoderRef
 
-    fx = np.load(os.path.join(GOLD, "ref_snac_tiny.npz"))
+    fx = np.load(os.path.join(GOLD, fixture))
     cfg = json.loads(str(fx["config"]))
     latent = cfg["encoder_dim"] * 2 ** len(cfg["encoder_rates"])
     w = make_snac_weights(latent, cfg["decoder_dim"], cfg["decoder_rates"], cfg["vq_strides"], cfg["codebook_size"], cfg["codebook_dim"], True, True,
-                          seed=int(fx["seed_w"]))
-    ref = SNACDecoderRef(w, cfg["decoder_rates"], cfg["vq_strides"], True, True)
+                          seed=int(fx["seed_w"]), attn=cfg["attn_window_size"] is not None)
+    ref = SNACDecoderRef(w, cfg["decoder_rates"], cfg["vq_strides"], True, True, attn_window_size=cfg["attn_window_size"])
     codes = [torch.from_numpy(fx[f"codes{i}"]).long() for i in range(len(cfg["vq_strides"]))]
     z = ref.from_codes(codes)
     assert rel_max(z.numpy(), fx["z"]) < 1e-5

@@ -26,14 +26,15 @@ def _pair(cfg, seed, fp16_exact):
 
     latent = cfg["encoder_dim"] * 2 ** len(cfg["encoder_rates"])
     w = make_snac_weights(latent, cfg["decoder_dim"], cfg["decoder_rates"], cfg["vq_strides"], cfg["codebook_size"], cfg["codebook_dim"], cfg["noise"],
-                          cfg["depthwise"], seed=seed)
+                          cfg["depthwise"], seed=seed, attn=cfg["attn_window_size"] is not None)
     if fp16_exact:  # make the FOLDED conv weights fp16-representable: v := folded weight rounded, g := its norm
         for k in [k for k in w if k.endswith("weight_v") and k.startswith("decoder.")]:
             base = k[: -len(".weight_v")]
             folded = wn_weight(w[base + ".weight_g"], w[k]).half().float()
             w[base + ".weight_g"] = torch.sqrt((folded.double() ** 2).sum(dim=(1, 2), keepdim=True)).float()
             w[k] = folded
-    return SNAC(**cfg, weights=w, device=DEV), SNACDecoderRef(w, cfg["decoder_rates"], cfg["vq_strides"], cfg["noise"], cfg["depthwise"])
+    return SNAC(**cfg, weights=w, device=DEV), SNACDecoderRef(w, cfg["decoder_rates"], cfg["vq_strides"], cfg["noise"], cfg["depthwise"],
+                                                              attn_window_size=cfg["attn_window_size"])
 
 
 def _codes(cfg, B, T, seed):
@@ -80,6 +81,26 @@ def test_from_codes_and_decode_stages_vs_oracle(depthwise, noise):
         assert torch.equal(full, got)
 
 
+def test_local_mha_variant_vs_oracle():
+    """The 32 / 44 kHz models' ``LocalMHA`` (attention.py:5-53: LayerNorm, to_qkv, windows of 32 positions, rotate-half rotary embedding inside the window,
+    softmax, to_out, + x) between the input convs and the first decoder block.  PARITY UNPINNED: the reference's own module raises in its decoder
+    (tests/golden/ref_snac_local_mha_probe.json), so this is held to the oracle's restatement of what the module means."""
+    cfg = dict(sampling_rate=32000, encoder_dim=4, encoder_rates=[2, 4, 8, 8], decoder_dim=256, decoder_rates=[8, 5, 4, 2], attn_window_size=32,
+               codebook_size=512, codebook_dim=8, vq_strides=[4, 2, 1], noise=True, depthwise=True)
+    eng, ref = _pair(cfg, 5, False)
+    codes = _codes(cfg, 2, 64, 7)   # 64 positions = two windows
+    z_ref = ref.from_codes(codes)
+    z = eng.quantizer.from_codes(codes)
+    g = torch.Generator().manual_seed(2)
+    noises = [torch.randn(2, 1, cfg["decoder_dim"] >> (i + 1), generator=g) for i in range(4)]
+    want, wst = ref.decode(z_ref, noises, return_stages=True)
+    got, gst = eng.decode_latents(z, noises, return_stages=True)
+    torch.cuda.synchronize()
+    assert "attn" in gst and rel_peak(gst["attn"], wst["attn"]) < 1e-3, rel_peak(gst["attn"], wst["attn"])
+    assert rel_peak(gst["attn"], wst["conv_in"]) > 1e-2          # the block is not a no-op
+    assert snr_db(got, want) >= 50.0 and float((got.cpu() - want).abs().max()) <= 2e-3 * float(want.abs().max())
+
+
 def test_reference_length_pin_full_width():
     """The 24 kHz model of the reference test: codes of 59 / 118 / 236 frames -> (1, 120907, 1); a short prefix against the oracle, including
     the tail samples produced by the groups-as-output_padding slip."""
@@ -119,8 +140,8 @@ def test_surface_and_errors_are_loud():
         eng.encode(torch.zeros(1, 1, 800))
     with pytest.raises(NotImplementedError):
         eng(torch.zeros(1, 1, 800))
-    with pytest.raises(NotImplementedError):
-        SNAC(**{**cfg, "attn_window_size": 32}, device=DEV)
+    with pytest.raises(ValueError):   # LocalMHA: positions must be a whole number of windows
+        SNAC(**{**cfg, "attn_window_size": 32}, device=DEV).decode([torch.zeros((1, 2), dtype=torch.long), torch.zeros((1, 4), dtype=torch.long)])
     assert tuple(eng.preprocess(torch.zeros(1, 1, 1000)).shape) == (1, 1, 1024)   # right-pad to hop 512 * lcm(2, 1) (snac.py:67-86)
     # decode_stream (snac.py:109-165): first call decodes as is and keeps the last context_frames codes per level
     codes = [torch.zeros((1, 6), dtype=torch.long), torch.zeros((1, 12), dtype=torch.long)]
