@@ -109,7 +109,8 @@ typedef struct {
                           3 = single fp16 pass: activations rounded to fp16 (saturating), weights packed with MI355_W_F16,
                           4 = fp16 hi+lo split (~22 mantissa bits of the activation) on MI355_W_F16 weights: fp16 checkpoints
                               (Whisper) at fp32-activation accuracy */
-  int32_t tile;        /* 0 = auto, else BM*1000+BN (128128, 64128, 64064), 6128128 / 7128128 = wave-specialised 8-wave kernels (ws4 / ws3) */
+  int32_t tile;        /* 0 = auto, else BM*1000+BN (128128, 64128, 64064), 6128128 / 7128128 = wave-specialised 8-wave kernels (ws4 / ws3),
+                          2064128 / 2064064 (+ 10000000 * groups) = split-K on 64-row tiles (needs split_ws) */
   /* optional instance-norm statistics of the STORED output, fused into the epilogue (plain stores only): per block of
      MI355_STATS_ROWS output rows and per channel the pair (sum, sum of squared deviations from the block mean), written
      (never accumulated) to stats_partial[b][row / MI355_STATS_ROWS][c][0..1]; consumed by mi355_adain_from_partials.
@@ -123,6 +124,11 @@ typedef struct {
   /* per-output-column scale applied after the epilogue activation and before the residual add (LayerScale:
      x + scale[c] * f(x), codec/models/mimi/modules/transformer.py LayerScale; ConvNeXt gamma). */
   const float* post_colscale; /* [Cout] nullable */
+  /* optional workspace for launches of few output tiles (one utterance per call): with it the dispatcher may cut the input-channel range of a
+     tile over several workgroups (fp32 partial tiles [B][groups][Lout][Cout] in the workspace) and apply the epilogue above in a second kernel
+     that sums the groups in a fixed order.  NULL = never split.  The workspace is scratch of this call only (stream-ordered reuse is safe). */
+  void* split_ws;
+  int64_t split_ws_bytes;
 } mi355_conv_gemm_args;
 #define MI355_STATS_ROWS 64
 

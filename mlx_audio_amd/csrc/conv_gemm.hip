@@ -24,15 +24,22 @@ namespace {
 
 constexpr int kThreads = 256;
 
-template <int BM, int BN, int PREC, bool VEC>
-__global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_gemm_args a) {
+// Split-K geometry (SPLIT instantiations): blockIdx.z = b * ksplit + kz; the workgroup covers chunks [kz * cpz, min(nchunks, (kz + 1) * cpz)) and
+// stores its raw partial tile (the host hands it args whose y is the slab workspace [B][ksplit][Lout][Cout] and whose epilogue is switched off);
+// conv_split_finish_kernel sums the slabs in a fixed order and applies the epilogue of the original call.
+struct split_geom {
+  int ksplit, cpz;
+};
+
+template <int BM, int BN, int PREC, bool VEC, bool SPLIT = false>
+__global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_gemm_args a, const split_geom sg) {
   constexpr int WM = BM / 2, WN = BN / 2, MF = WM / 32, NF = WN / 32;
   constexpr int BBYTES = (BN / 32) * 2048;  // one (chunk, tap) weight slice of this block
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int b = blockIdx.z, l0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int b = SPLIT ? (int)blockIdx.z / sg.ksplit : (int)blockIdx.z, l0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int len_out = a.lens_out ? a.lens_out[b] : a.Lout;
   if (l0 >= len_out) return;
   const int len_in = a.lens_in ? a.lens_in[b] : a.Lin;
@@ -43,7 +50,12 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_ge
   char* Bs = smem + R * 64 * a_images<PREC>();
   const int nchunks = (a.Cin + 31) >> 5;
   const int NTp = ((a.Cout + 127) >> 7) << 2;
-  const int nsteps = nchunks * K;
+  int c_begin = 0, c_end = nchunks;
+  if constexpr (SPLIT) {
+    c_begin = ((int)blockIdx.z - b * sg.ksplit) * sg.cpz;
+    c_end = c_begin + sg.cpz < nchunks ? c_begin + sg.cpz : nchunks;
+  }
+  const int s_begin = c_begin * K, s_end = c_end * K;
   const float* xb = a.x + (int64_t)b * a.x_bstride;
   const int64_t flat_hi = (int64_t)len_in * a.flat_valid;
 
@@ -167,22 +179,22 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_ge
     }
   };
 
-  issue_B(0, 0);
-  int chunk = 0, tap = 0;
-  for (int s = 0; s < nsteps; ++s) {
+  issue_B(s_begin, 0);
+  int chunk = c_begin, tap = 0;
+  for (int s = s_begin; s < s_end; ++s) {
     if (tap == 0) {
-      if (s) __syncthreads();  // every wave is done reading the previous chunk's window
+      if (s != s_begin) __syncthreads();  // every wave is done reading the previous chunk's window
       stage_A(chunk);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this step's weight slice has landed in LDS
     __syncthreads();
-    if (s + 1 < nsteps) issue_B(s + 1, (s + 1) & 1);
-    compute(tap, s & 1);
+    if (s + 1 < s_end) issue_B(s + 1, (s + 1 - s_begin) & 1);
+    compute(tap, (s - s_begin) & 1);
     if (++tap == K) { tap = 0; ++chunk; }
   }
 
-  // ---------------------------------------------------------------- epilogue
-  conv_epilogue<MF, NF, WM, WN, -1>(a, acc, b, l0, n0, wm, wn, lane, len_out, false);
+  // ---------------------------------------------------------------- epilogue (SPLIT: a plain store of the partial tile into slab blockIdx.z)
+  conv_epilogue<MF, NF, WM, WN, SPLIT ? 0 : -1>(a, acc, SPLIT ? (int)blockIdx.z : b, l0, n0, wm, wn, lane, len_out, false);
 }
 
 template <int BM, int BN, int PREC, bool VEC>
@@ -192,9 +204,190 @@ int launch(const mi355_conv_gemm_args& a, hipStream_t st) {
   MI355_REQUIRE(lds <= 64 * 1024, "conv_gemm: window too large for LDS (K=%d dil=%d)", a.K, a.dil);
   dim3 grid((a.Lout + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.B);
   MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, PREC, VEC>), grid, dim3(kThreads), lds, st, a);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, PREC, VEC>), grid, dim3(kThreads), lds, st, a, split_geom{1, 0});
   MI355_LAUNCH_CHECK("conv_gemm");
   return MI355_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- split-K for launches of few tiles
+// One utterance per call (the latency configuration) leaves most convs of the network with 2..90 output tiles and 24..100 dependent
+// (chunk, tap) steps each: the kernel then runs at the latency of its serial K loop on a fraction of the CUs (profiles/r3_kernel_stats_b1_call14.txt:
+// 60 us for an 80 x 768 x 768 PL-BERT projection on 12 workgroups).  With a workspace in the args the dispatcher cuts the chunk range over
+// ksplit workgroups per tile (grid z) and a second kernel sums the partial tiles in slab order and applies the epilogue of the call -- bias,
+// activation, LayerScale, residual (row >> res_shift), running sum, out_scale, plain or polyphase store and the fused instance-norm statistics
+// of the stored rows -- so every feature of mi355_conv_gemm keeps its meaning.  Sums are in a fixed order (deterministic), but not the order
+// of the unsplit kernel: results differ from it by fp32 rounding of the accumulation.
+// One workgroup per 64 x 64 block of GEMM outputs; thread (r16, c4) owns rows r16 + 16 i (i < 4) and columns 4 c4 .. + 4: every slab read is a
+// 16-byte load, the four rows and the groups are independent loads in flight.  ldp = slab row pitch (C_out padded to 4).
+__global__ __launch_bounds__(256) void conv_split_finish_kernel(const mi355_conv_gemm_args a, const float* __restrict__ part, const int ksplit,
+                                                                const int64_t slab, const int ldp) {
+  __shared__ float sst[16][64][3];
+  const int tid = threadIdx.x, c4 = tid & 15, r16 = tid >> 4;
+  const int b = blockIdx.z, nb = blockIdx.y * 64 + 4 * c4, row0 = blockIdx.x * 64;
+  const int len_out = a.lens_out ? a.lens_out[b] : a.Lout;
+  if (row0 >= len_out) return;
+  const int len_up = a.lens_up ? a.lens_up[b] : a.up_Lout;
+  int ocol[4], rph[4];
+  float bias[4], cscale[4];
+  bool nok[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int n = nb + e;
+    nok[e] = n < a.Cout;
+    ocol[e] = nok[e] ? n : 0;
+    rph[e] = 0;
+    if (a.up_s) { rph[e] = ocol[e] / a.up_cout; ocol[e] -= rph[e] * a.up_cout; }
+    bias[e] = (a.bias && nok[e]) ? a.bias[ocol[e]] : 0.f;
+    cscale[e] = (a.post_colscale && nok[e]) ? a.post_colscale[ocol[e]] : 1.f;
+  }
+  float* const yb = a.y + (int64_t)b * a.y_bstride;
+  const float* const rb = a.res ? a.res + (int64_t)b * a.res_bstride : nullptr;
+  const float* const pb = part + (int64_t)b * ksplit * slab + nb;
+  const bool colok = nb < ldp;   // the 16-byte piece lies inside the slab row
+  float4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool rok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rok[i] = colok && (row0 + r16 + 16 * i) < len_out;
+  auto add4 = [](float4& s, const float4 t) { s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; };
+  int g = 0;
+  for (; g + 2 <= ksplit; g += 2) {   // eight independent loads in flight, added in slab order
+    float4 t[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        t[u][i] = rok[i] ? *(const float4*)(pb + (int64_t)(g + u) * slab + (int64_t)(row0 + r16 + 16 * i) * ldp) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) add4(acc[i], t[u][i]);
+  }
+  for (; g < ksplit; ++g) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (rok[i]) add4(acc[i], *(const float4*)(pb + (int64_t)g * slab + (int64_t)(row0 + r16 + 16 * i) * ldp));
+  }
+  float sK[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  int cnt[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int u = row0 + r16 + 16 * i;
+    const float av[4] = {acc[i].x, acc[i].y, acc[i].z, acc[i].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      bool valid = nok[e] && u < len_out;
+      int orow = u;
+      if (a.up_s) {
+        const int nc = u * a.up_s + rph[e] - a.up_p;
+        valid = valid && nc >= 0 && nc < len_up;
+        orow = nc + a.up_row_off;
+      }
+      if (!valid) continue;
+      float v = av[e] + bias[e];
+      switch (a.post_act) {
+        case MI355_ACT_LEAKY: v = v > 0.f ? v : v * a.post_slope; break;
+        case MI355_ACT_GELU: v = gelu_erf(v); break;
+        case MI355_ACT_SILU: v = v / (1.0f + expf(-v)); break;
+        case MI355_ACT_GELU_TANH: v = gelu_tanh(v); break;
+        case MI355_ACT_ELU: v = v > 0.f ? v : expm1f(v); break;
+        case MI355_ACT_TANH: v = tanhf(v); break;
+        default: break;
+      }
+      float rv = rb ? rb[(int64_t)(orow >> a.res_shift) * a.ldr + ocol[e]] : 0.f;
+      float* const dst = yb + (int64_t)orow * a.ldy + ocol[e];
+      if (a.accumulate) rv += *dst;
+      v = (v * cscale[e] + rv) * a.out_scale;
+      *dst = v;
+      sK[e] = cnt[e] == 0 ? v : sK[e];
+      const float d = v - sK[e];
+      s1[e] += d;
+      s2[e] += d * d;
+      ++cnt[e];
+    }
+  }
+  if (!a.stats_partial) return;
+  // (count, mean, M2) of this thread's <= 4 stored rows per column; the 16 row threads of a column merge with Chan's formula in thread order
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float cl = (float)cnt[e];
+    sst[r16][4 * c4 + e][0] = cl;
+    sst[r16][4 * c4 + e][1] = cnt[e] ? sK[e] + s1[e] / cl : 0.f;
+    sst[r16][4 * c4 + e][2] = cnt[e] ? s2[e] - s1[e] * s1[e] / cl : 0.f;
+  }
+  __syncthreads();
+  const int n = blockIdx.y * 64 + tid;
+  if (tid < 64 && n < a.Cout) {
+    float ct = sst[0][tid][0], mt = sst[0][tid][1], vt = sst[0][tid][2];
+    for (int j = 1; j < 16; ++j) {
+      const float cj = sst[j][tid][0], mj = sst[j][tid][1], vj = sst[j][tid][2];
+      if (cj > 0.f) {
+        const float cn = ct + cj, dm = mj - mt;
+        vt = vt + vj + (ct > 0.f ? dm * dm * ct * cj / cn : 0.f);
+        mt = (mt * ct + mj * cj) / cn;
+        ct = cn;
+      }
+    }
+    *(float2*)(a.stats_partial + (int64_t)b * a.stats_bstride + ((int64_t)blockIdx.x * a.Cout + n) * 2) = make_float2(mt * ct, vt);
+  }
+}
+
+// chunk groups for a launch of `wgs` tiles (0 = do not split): enough workgroups for two per CU, at least `min_steps` (chunk, tap) steps per group
+int split_groups(const long wgs, const int nchunks, const int K, const long rows_total, const int Cout, const int64_t ws_bytes, const int forced) {
+  if (nchunks < 2) return 0;
+  static const int off = getenv("MI355_CONV_SPLIT") ? atoi(getenv("MI355_CONV_SPLIT")) : -1;   // 0 = never split (A/B aid)
+  if (off == 0 && !forced) return 0;
+  static const int min_steps = getenv("MI355_CONV_SPLIT_MINSTEPS") ? atoi(getenv("MI355_CONV_SPLIT_MINSTEPS")) : 4;   // A/B knob
+  const int min_chunks = K >= min_steps ? 1 : (min_steps + K - 1) / K;       // >= min_steps (chunk, tap) steps per group
+  int ks = forced;                                            // > 0: that many groups; -1: the rule's count whatever the tile count; 0: the rule
+  if (ks <= 0) {
+    if (forced == 0 && (wgs >= 256 || (long)nchunks * K < 8)) return 0;
+    ks = (int)((512 + wgs - 1) / wgs);
+    if (ks < 2) ks = 2;
+  }
+  if (ks > nchunks / min_chunks) ks = nchunks / min_chunks;
+  const int64_t per = rows_total * ((Cout + 3) & ~3) * 4;     // one slab of every item
+  if (per <= 0 || ws_bytes / per < 2) return 0;
+  if (ks > ws_bytes / per) ks = (int)(ws_bytes / per);
+  if (ks < 2) return 0;
+  const int cpz = (nchunks + ks - 1) / ks;
+  ks = (nchunks + cpz - 1) / cpz;                             // groups that actually hold chunks
+  return ks >= 2 ? ks : 0;
+}
+
+template <int BM, int BN, int PREC>
+int launch_split(const mi355_conv_gemm_args& a, hipStream_t st, const int ks) {
+  const int R = BM + (a.K - 1) * a.dil;
+  const size_t lds = (size_t)R * 64 * a_images<PREC>() + 2 * (BN / 32) * 2048;
+  MI355_REQUIRE(lds <= 64 * 1024, "conv_gemm: window too large for LDS (K=%d dil=%d)", a.K, a.dil);
+  const int nchunks = (a.Cin + 31) >> 5;
+  const split_geom sg{ks, (nchunks + ks - 1) / ks};
+  const int ldp = (a.Cout + 3) & ~3;
+  const int64_t slab = (int64_t)a.Lout * ldp;
+  mi355_conv_gemm_args p = a;   // the partial pass: same input side, raw store into slab (b, kz)
+  p.y = (float*)a.split_ws;
+  p.y_bstride = slab;
+  p.ldy = ldp;
+  p.bias = nullptr; p.post_act = MI355_ACT_NONE; p.post_colscale = nullptr;
+  p.res = nullptr; p.accumulate = 0; p.out_scale = 1.f;
+  p.up_s = 0; p.lens_up = nullptr; p.stats_partial = nullptr;
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, PREC, true, true>), dim3((a.Lout + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.B * ks), dim3(kThreads), lds, st, p, sg);
+  MI355_LAUNCH_CHECK("conv_gemm (split)");
+  hipLaunchKernelGGL(conv_split_finish_kernel, dim3((a.Lout + 63) / 64, (a.Cout + 63) / 64, a.B), dim3(256), 0, st, a, (const float*)a.split_ws, ks, slab, ldp);
+  MI355_LAUNCH_CHECK("conv_gemm (split finish)");
+  return MI355_OK;
+}
+
+template <int BM, int BN>
+int launch_split_p(const mi355_conv_gemm_args& a, hipStream_t st, const int ks) {
+  switch (a.precision) {
+    case 1: return launch_split<BM, BN, 1>(a, st, ks);
+    case 3: return launch_split<BM, BN, 3>(a, st, ks);
+    case 4: return launch_split<BM, BN, 4>(a, st, ks);
+    default: return launch_split<BM, BN, 2>(a, st, ks);
+  }
 }
 
 }  // namespace
@@ -239,6 +432,19 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
       if (rc != MI355_ERR_UNSUPPORTED) return rc;  // no instantiation for this prologue / epilogue pair: fall through to the 4-wave kernels
     }
     if (bn == 128 && wgs128 >= 512) tile = 64128;  // measured: 64-row tiles beat 128-row tiles on the 4-wave kernel
+    if (a.split_ws && vec) {   // few tiles and a deep K loop: cut the chunk range over several workgroups per tile (64-row tiles)
+      const long wgs64 = (long)a.B * ((a.Lout + 63) / 64) * ((a.Cout + bn - 1) / bn);
+      const int ks = split_groups(wgs64, (a.Cin + 31) >> 5, a.K, (long)a.B * a.Lout, a.Cout, a.split_ws_bytes, 0);
+      if (ks) return bn == 128 ? launch_split_p<64, 128>(a, st, ks) : launch_split_p<64, 64>(a, st, ks);
+    }
+  }
+  if (tile % 10000000 == 2064128 || tile % 10000000 == 2064064) {  // split-K, explicit: + 10000000 * groups (0 = as many as the rule gives)
+    MI355_REQUIRE(vec && a.split_ws, "conv_gemm: the split-K tiles need the 16-B aligned channels-last input path and a workspace (split_ws)");
+    const bool wide = tile % 10000000 == 2064128;
+    const long wgs64 = (long)a.B * ((a.Lout + 63) / 64) * ((a.Cout + (wide ? 127 : 63)) / (wide ? 128 : 64));
+    const int ks = split_groups(wgs64, (a.Cin + 31) >> 5, a.K, (long)a.B * a.Lout, a.Cout, a.split_ws_bytes, tile / 10000000 ? tile / 10000000 : -1);
+    MI355_REQUIRE(ks >= 2, "conv_gemm: nothing to split (C_in %d, K %d, workspace %lld bytes)", a.Cin, a.K, (long long)a.split_ws_bytes);
+    return wide ? launch_split_p<64, 128>(a, st, ks) : launch_split_p<64, 64>(a, st, ks);
   }
   if (tile % 10000000 == 6128128) {  // ws4, explicit: 6128128 + 10000000 * feature bits (+ 100000000 * ablation bits)
     MI355_REQUIRE(mi355_conv_ws4_eligible(a, vec), "conv_gemm: the wave-specialised tile needs 16-B aligned channels-last input rows and a window of <= 192 rows");

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -405,6 +406,9 @@ def conv_gemm(x: torch.Tensor, pc: PackedConv, y: torch.Tensor, *, dil: int = 1,
         assert stats.dtype == torch.float32 and stats.dim() == 4 and stats.is_contiguous()
         assert stats.shape[0] == B and stats.shape[1] >= (kw["Lout"] + STATS_ROWS - 1) // STATS_ROWS and stats.shape[2] == pc.cout
         kw.update(stats_partial=_ptr(stats), stats_bstride=stats.stride(0))
+    if SPLIT_WS_BYTES and B * kw["Lout"] <= 65536:   # only small launches can split: do not even create the scratch for a large batch
+        st = _stream()
+        kw.update(split_ws=_split_ws(x.device, st).data_ptr(), split_ws_bytes=SPLIT_WS_BYTES)
     if PROFILE is not None:
         # no host synchronisation here (a .item() on the ragged lengths would drain the queue before every launch: the start event would then
         # be stamped on an idle GPU and the interval would include the host's submission latency); the row count stays a device scalar and
@@ -439,6 +443,19 @@ def adain_coef(x: torch.Tensor, gb: Optional[torch.Tensor], lens: Optional[torch
 
 
 STATS_ROWS = 64  # MI355_STATS_ROWS
+
+# scratch of mi355_conv_gemm's split-K path (launches of few output tiles: one utterance per call), one per (device, stream): launches on a stream
+# are ordered, so consecutive convs can share it
+SPLIT_WS_BYTES = int(os.environ.get("MI355_CONV_SPLIT_WS_MB", "96")) << 20
+_SPLIT_WS = {}
+
+
+def _split_ws(device: torch.device, stream: int) -> torch.Tensor:
+    key = (device.index, stream)
+    ws = _SPLIT_WS.get(key)
+    if ws is None:
+        ws = _SPLIT_WS[key] = torch.empty(SPLIT_WS_BYTES, dtype=torch.uint8, device=device)
+    return ws
 
 
 def new_stats(B: int, L: int, C: int, device) -> torch.Tensor:

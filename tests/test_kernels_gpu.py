@@ -74,6 +74,17 @@ def ref_conv_nlc(x, w, b, dil, pad):
     (1090, 1024, 1, 1, 264, 2, 6128128),
     (2048, 768, 1, 1, 5000, 1, 16128128),
     (64, 128, 1, 1, 130, 1, 6128128),
+    # split-K (tile codes 2064128 / 2064064 + 10000000 * groups; tile 0 with few tiles and a deep K loop takes it by itself): the launches of a
+    # single utterance -- PL-BERT projections, frame-level convs, the first generator stage
+    (768, 768, 1, 1, 80, 1, 2064128),
+    (3072, 768, 1, 1, 80, 1, 2064128),
+    (768, 2304, 1, 1, 80, 1, 52064128),
+    (256, 256, 11, 5, 5281, 1, 2064128),
+    (256, 256, 11, 5, 257, 1, 42064128),
+    (1090, 1024, 3, 1, 264, 1, 2064128),
+    (514, 200, 3, 1, 33, 2, 22064128),
+    (512, 64, 1, 1, 77, 3, 2064064),
+    (96, 50, 7, 2, 130, 1, 32064064),
 ])
 def test_conv_gemm_plain(ops, cin, cout, k, dil, L, B, tile):
     g = torch.Generator().manual_seed(cin + cout + k)
@@ -98,7 +109,7 @@ def test_conv_gemm_plain(ops, cin, cout, k, dil, L, B, tile):
         assert rel_err(got, ref) < tol, (prec, rel_err(got, ref))
 
 
-@pytest.mark.parametrize("tile", [0, 6128128])
+@pytest.mark.parametrize("tile", [0, 6128128, 2064128])
 def test_conv_gemm_accumulate_then_out_scale(ops, tile):
     """The epilogue order the header states: y = (act(acc + bias) + res + old y) * out_scale -- out_scale multiplies the accumulated value too (the
     resblock-stage mean of iSTFTNet / BigVGAN: blocks j > 0 accumulate, the last one carries out_scale = 1 / num_kernels)."""
@@ -116,7 +127,8 @@ def test_conv_gemm_accumulate_then_out_scale(ops, tile):
 
 @pytest.mark.parametrize("tile,res_shift,act", [(0, 1, "snake"), (6128128, 1, "snake"), (6128128, 0, "snake"), (128128, 0, "leaky"),
                                                  (6128128, 0, "leaky"), (64064, 0, "snake"), (16128128, 0, "snake"),
-                                                 (86128128, 1, "snake"), (86128128, 0, "snake"), (86128128, 0, "leaky")])
+                                                 (86128128, 1, "snake"), (86128128, 0, "snake"), (86128128, 0, "leaky"),
+                                                 (2064128, 1, "snake"), (32064128, 0, "leaky"), (2064064, 0, "snake")])
 def test_conv_gemm_fused_prologue_epilogue_ragged(ops, tile, res_shift, act):
     """AdaIN affine + Snake / LeakyReLU in front, bias + residual(row >> res_shift) + scale + accumulate behind, ragged
     batch; res_shift == 0 takes the accumulator-initialisation ("fold") path of the wave-specialised kernel."""
@@ -155,7 +167,8 @@ def test_conv_gemm_fused_prologue_epilogue_ragged(ops, tile, res_shift, act):
 
 @pytest.mark.parametrize("cin,cout,k,s,L,row_off,tile", [(512, 256, 20, 10, 53, 0, 0), (256, 128, 12, 6, 130, 1, 0), (64, 32, 4, 2, 9, 0, 0),
                                                          (512, 256, 20, 10, 153, 0, 6128128), (256, 128, 12, 6, 330, 1, 6128128),
-                                                         (512, 256, 20, 10, 153, 0, 86128128), (256, 128, 12, 6, 330, 1, 86128128)])
+                                                         (512, 256, 20, 10, 153, 0, 86128128), (256, 128, 12, 6, 330, 1, 86128128),
+                                                         (512, 256, 20, 10, 53, 0, 2064128), (256, 128, 12, 6, 130, 1, 42064128)])
 def test_conv_transpose_polyphase(ops, cin, cout, k, s, L, row_off, tile):
     g = torch.Generator().manual_seed(k * s)
     p = (k - s) // 2
@@ -210,7 +223,7 @@ def test_conv_flat_strided_small_cin(ops):
     assert rel_err(y1.cpu(), x.double() @ w1[:, 0].double().t()) < 3e-5
 
 
-@pytest.mark.parametrize("tile", [0, 128128, 6128128, 86128128])
+@pytest.mark.parametrize("tile", [0, 128128, 6128128, 86128128, 2064128, 32064128])
 def test_conv_gemm_fused_instnorm_statistics(ops, tile):
     """Instance-norm statistics of the conv OUTPUT produced by the epilogue (stats=) + adain_from_partials must equal the
     separate pass (adain_coef) over the stored tensor: ragged batch, residual + scaling in the epilogue, large mean / std."""
