@@ -137,6 +137,10 @@ int mi355_conv_gemm(const mi355_conv_gemm_args* a, void* stream);
  * [ceil(grid / 16)][8][4] uint64 s_memtime stamps (consumer wave 0 of every 16th workgroup, its first 8 tiles: tile start, first window
  * staged, main loop done, stores issued); NULL = off. */
 int mi355_conv_ws4_debug_buffer(void* device_buffer);
+/* Persistent workgroups the wave-specialised kernel's NEXT launches may take (process-wide, read on the host at launch time; 0 = default, two per
+ * CU): lets independent convs of one stage run side by side on separate streams, each on a share of the CUs (the three resblocks of an MRF stage:
+ * istftnet.py:797-835 loops over them one after the other). */
+int mi355_conv_ws4_resident(int wgs);
 /* Host-side packing (CPU, run once at load time).
  * w: float32 [Cout, K, Cin] in the MLX conv layout (values already weight-normed / bf16 rounded),
  * out: uint16 buffer of mi355_packed_conv_weight_elems(Cout, K, Cin) elements. */

@@ -23,6 +23,8 @@
 
 namespace mi355conv {
 
+extern int g_ws4_resident;   // conv_ws4.hip; 0 = two workgroups per CU
+
 constexpr int kWs4Threads = 512;
 
 enum { P_NONE = 0, P_LEAKY = 1, P_SNAKE = 2, P_SNAKEBETA = 3, P_ELU = 4 };
@@ -485,7 +487,8 @@ int launch_ws4(const mi355_conv_gemm_args& a, hipStream_t st, const int feat, un
     if (cus <= 0) cus = 256;
   }
   static const int wg_per_cu = getenv("MI355_CONV_WS_WG_PER_CU") ? atoi(getenv("MI355_CONV_WS_WG_PER_CU")) : 2;
-  const int resident = ((cus * wg_per_cu) / 8) * 8;
+  // mi355_conv_ws4_resident(n): the next launches take at most n persistent workgroups (a share of the chip: several convs on separate streams)
+  const int resident = g_ws4_resident > 0 ? ((g_ws4_resident + 7) / 8) * 8 : ((cus * wg_per_cu) / 8) * 8;
   const unsigned grid = (unsigned)((feat & 8) || q.total_ids <= resident ? q.total_ids : resident);  // feat bit 3: one workgroup per tile (A/B aid)
   MI355_CLEAR_ERROR();
   hipLaunchKernelGGL((conv_ws4_kernel<PREC, PRE, EPI, GEMM, DBG, ABL>), dim3(grid), dim3(kWs4Threads), lds, st, a, q);

@@ -8,6 +8,18 @@ namespace {
 unsigned long long* g_dbg_buffer = nullptr;  // host copy of the probe buffer pointer (handed to the DBG instantiation through its geometry record)
 }
 
+namespace mi355conv {
+int g_ws4_resident = 0;
+}
+
+// Process-wide, host-side setting read at launch time: persistent workgroups of the wave-specialised kernel's next launches (0 = the default, two
+// per CU).  For running independent convs side by side on several streams, each on a share of the chip (tools/bench_conv_concurrent.py).
+extern "C" int mi355_conv_ws4_resident(int wgs) {
+  MI355_REQUIRE(wgs >= 0, "conv_ws4_resident: negative count");
+  mi355conv::g_ws4_resident = wgs;
+  return MI355_OK;
+}
+
 bool mi355_conv_ws4_eligible(const mi355_conv_gemm_args& a, bool vec) {
   if (!vec || a.Lin <= 0) return false;
   if (!gemm_mode(a) && 128 + (a.K - 1) * a.dil > 192) return false;

@@ -408,7 +408,7 @@ def conv_gemm(x: torch.Tensor, pc: PackedConv, y: torch.Tensor, *, dil: int = 1,
         kw.update(stats_partial=_ptr(stats), stats_bstride=stats.stride(0))
     if SPLIT_WS_BYTES and B * kw["Lout"] <= 65536:   # only small launches can split: do not even create the scratch for a large batch
         st = _stream()
-        kw.update(split_ws=_split_ws(x.device, st).data_ptr(), split_ws_bytes=SPLIT_WS_BYTES)
+        kw.update(split_ws=_conv_split_ws(x.device, st).data_ptr(), split_ws_bytes=SPLIT_WS_BYTES)
     if PROFILE is not None:
         # no host synchronisation here (a .item() on the ragged lengths would drain the queue before every launch: the start event would then
         # be stamped on an idle GPU and the interval would include the host's submission latency); the row count stays a device scalar and
@@ -447,14 +447,14 @@ STATS_ROWS = 64  # MI355_STATS_ROWS
 # scratch of mi355_conv_gemm's split-K path (launches of few output tiles: one utterance per call), one per (device, stream): launches on a stream
 # are ordered, so consecutive convs can share it
 SPLIT_WS_BYTES = int(os.environ.get("MI355_CONV_SPLIT_WS_MB", "96")) << 20
-_SPLIT_WS = {}
+_CONV_SPLIT_WS = {}
 
 
-def _split_ws(device: torch.device, stream: int) -> torch.Tensor:
+def _conv_split_ws(device: torch.device, stream: int) -> torch.Tensor:
     key = (device.index, stream)
-    ws = _SPLIT_WS.get(key)
+    ws = _CONV_SPLIT_WS.get(key)
     if ws is None:
-        ws = _SPLIT_WS[key] = torch.empty(SPLIT_WS_BYTES, dtype=torch.uint8, device=device)
+        ws = _CONV_SPLIT_WS[key] = torch.empty(SPLIT_WS_BYTES, dtype=torch.uint8, device=device)
     return ws
 
 

