@@ -239,5 +239,5 @@ __device__ __forceinline__ void conv_epilogue_interior(const mi355_conv_gemm_arg
 // priority (A/B aid; they run at s_setprio 1 otherwise), bit 2: timeline probe build, bit 3: one workgroup per tile instead of persistent
 // workgroups, bits 4..: timing ablations.  Returns MI355_ERR_UNSUPPORTED (and sets the error text) for argument combinations it has no
 // instantiation for.
-int mi355_conv_ws4_launch(const mi355_conv_gemm_args& a, hipStream_t st, int feat);
+int mi355_conv_ws4_launch(const mi355_conv_gemm_args& a, hipStream_t st, int feat, int bn = 128);
 bool mi355_conv_ws4_eligible(const mi355_conv_gemm_args& a, bool vec);

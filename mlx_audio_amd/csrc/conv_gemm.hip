@@ -431,6 +431,12 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
       const int rc = mi355_conv_ws4_launch(a, st, ws_feat);
       if (rc != MI355_ERR_UNSUPPORTED) return rc;  // no instantiation for this prologue / epilogue pair: fall through to the 4-wave kernels
     }
+    // thin outputs (C_out <= 64): the same kernel on 128 x 64 tiles (MI355_CONV_NO_WS64=1 keeps them on the 4-wave 64 x 64 kernel: A/B aid)
+    static const bool no_ws64 = getenv("MI355_CONV_NO_WS64") != nullptr;
+    if (!no_ws && !no_ws64 && bn == 64 && wgs128 >= ws_min && a.Cin >= 32 && mi355_conv_ws4_eligible(a, vec)) {
+      const int rc = mi355_conv_ws4_launch(a, st, ws_feat & 3, 64);
+      if (rc != MI355_ERR_UNSUPPORTED) return rc;
+    }
     if (bn == 128 && wgs128 >= 512) tile = 64128;  // measured: 64-row tiles beat 128-row tiles on the 4-wave kernel
     if (a.split_ws && vec) {   // few tiles and a deep K loop: cut the chunk range over several workgroups per tile (64-row tiles)
       const long wgs64 = (long)a.B * ((a.Lout + 63) / 64) * ((a.Cout + bn - 1) / bn);
@@ -445,6 +451,10 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
     const int ks = split_groups(wgs64, (a.Cin + 31) >> 5, a.K, (long)a.B * a.Lout, a.Cout, a.split_ws_bytes, tile / 10000000 ? tile / 10000000 : -1);
     MI355_REQUIRE(ks >= 2, "conv_gemm: nothing to split (C_in %d, K %d, workspace %lld bytes)", a.Cin, a.K, (long long)a.split_ws_bytes);
     return wide ? launch_split_p<64, 128>(a, st, ks) : launch_split_p<64, 64>(a, st, ks);
+  }
+  if (tile % 10000000 == 6128064) {  // ws4 on 128 x 64 tiles, explicit (+ 10000000 * feature bits 0..3)
+    MI355_REQUIRE(mi355_conv_ws4_eligible(a, vec), "conv_gemm: the wave-specialised tile needs 16-B aligned channels-last input rows and a window of <= 192 rows");
+    return mi355_conv_ws4_launch(a, st, (tile / 10000000) & 11, 64);
   }
   if (tile % 10000000 == 6128128) {  // ws4, explicit: 6128128 + 10000000 * feature bits (+ 100000000 * ablation bits)
     MI355_REQUIRE(mi355_conv_ws4_eligible(a, vec), "conv_gemm: the wave-specialised tile needs 16-B aligned channels-last input rows and a window of <= 192 rows");

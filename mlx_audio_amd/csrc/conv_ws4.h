@@ -37,6 +37,7 @@ struct ws4_geom {
   int R;          // window rows (conv: 128 + (K-1)*dil; GEMM mode: 256)
   int gemm;
   int nslices;    // weight slices of the packed image = ceil(Cin / 32) * K
+  int bn;         // tile columns: 128, or 64 (the BN = 64 instantiations: C_out <= 64 per tile column, 2 x 2 consumer waves of 64 x 32)
   int feat;       // bit 0: consumers at default priority (A/B aid)
   int total_ids;  // virtual workgroup ids (tile slots incl. the XCD-run padding); a workgroup walks ids blockIdx.x + i * gridDim.x
   unsigned long long* dbg;  // timeline probe buffer (DBG instantiation only)
@@ -59,7 +60,7 @@ __device__ __forceinline__ bool decode_tile(const mi355_conv_gemm_args& a, const
   if (p >= q.P) return false;
   t.b = p / q.tiles_per_item;
   t.l0 = (p - t.b * q.tiles_per_item) * 128;
-  t.n0 = ny * 128;
+  t.n0 = ny * q.bn;
   t.len_out = a.lens_out ? a.lens_out[t.b] : a.Lout;
   if (t.l0 >= t.len_out) return false;
   t.len_in = a.lens_in ? a.lens_in[t.b] : a.Lin;
@@ -75,9 +76,10 @@ __device__ __forceinline__ int next_work(const mi355_conv_gemm_args& a, const ws
 // ABL (ablation bits, timing experiments only -- results are WRONG when non-zero; reachable only through the explicit tile codes
 // ABL * 100000000 + 6128128 of tools/bench_conv.py --ablate): 1 = no weight-fragment loads after the first, 2 = no activation-fragment LDS
 // reads, 4 = the producers only take part in the barriers, 8 = no residual fold and no epilogue.
-template <int PREC, int PRE, int EPI, bool GEMM, bool DBG = false, int ABL = 0>
+template <int PREC, int PRE, int EPI, bool GEMM, bool DBG = false, int ABL = 0, int BN = 128>
 __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_conv_gemm_args a, const ws4_geom q) {
-  constexpr int BM = 128, BN = 128;
+  constexpr int BM = 128;
+  static_assert(BN == 128 || BN == 64, "tile columns");
   constexpr int NLD = GEMM ? 8 : 6;  // window passes of 32 rows per chunk (conv: R <= 192; GEMM mode: R = 256)
   constexpr int NA = a_images<PREC>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -241,7 +243,8 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
   }
 
   // -------------------------------------------------------------------------------- consumers
-  constexpr int WM = 64, WN = 64, MF = 2, NF = 2;
+  constexpr int WM = 64, WN = BN / 2, MF = 2, NF = WN / 32;   // BN = 64: every activation fragment feeds one 32-column fragment instead of two
+  constexpr int NB = 2 * NF;                                  // weight fragments of a wave per slice: (nf, kk)
   const int wm = wave >> 1, wn = wave & 1;
   if (!(q.feat & 1)) __builtin_amdgcn_s_setprio(1);  // MFMA issuers outrank the producers' VALU work (measured +1..8 %)
   const int NTp = ((a.Cout + 127) >> 7) << 2;
@@ -270,9 +273,9 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
     // fragment (nf, kk) of weight slice s: 1 KB at wfrag + s * wstep + (nf * 2 + kk) * 1024
     const char* wfrag = (const char*)a.w + ((int64_t)((n0 >> 5) + wn * NF)) * 2048 + lane * 16;
     auto wptr = [&](const int s) { return wfrag + (int64_t)(s < last_slice ? s : last_slice) * wstep; };
-    bf16x8 b0[4], b1[4];
+    bf16x8 b0[NB], b1[NB];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) b0[f] = *(const bf16x8*)(wfrag + f * 1024);
+    for (int f = 0; f < NB; ++f) b0[f] = *(const bf16x8*)(wfrag + f * 1024);
 
     f32x16 acc[MF][NF];
 #pragma unroll
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
 
     {
       int tap = 0;
-      bf16x8 ah0 = b0[0], al0 = b0[1], ah1 = b0[2], al1 = b0[3];  // two static activation-fragment sets (al*: the lo image, unused for the single-pass precisions)
+      bf16x8 ah0 = b0[0], al0 = b0[1], ah1 = b0[0], al1 = b0[1];  // two static activation-fragment sets (al*: the lo image, unused for the single-pass precisions)
       // group g of a tap: kk = g >> 1 (16-channel half of the chunk), mf = g & 1 (32-row half of the wave's rows)
       auto rdA = [&](bf16x8& h, bf16x8& l, const int g, const int tp) {
         const int kk = g >> 1, mf = g & 1;
@@ -362,17 +365,17 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
           if constexpr (NA == 2) l = *(const bf16x8*)(A_hi + ABYTES + addr);
         }
       };
-      auto mm = [&](const bf16x8& h, const bf16x8& l, const int g, const bf16x8 (&bf)[4]) {
+      auto mm = [&](const bf16x8& h, const bf16x8& l, const int g, const bf16x8 (&bf)[NB]) {
         const int kk = g >> 1, mf = g & 1;
-        acc[mf][0] = mfma16<PREC>(h, bf[kk], acc[mf][0]);
-        acc[mf][1] = mfma16<PREC>(h, bf[2 + kk], acc[mf][1]);
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = mfma16<PREC>(h, bf[2 * nf + kk], acc[mf][nf]);
         if constexpr (NA == 2) {
-          acc[mf][0] = mfma16<PREC>(l, bf[kk], acc[mf][0]);
-          acc[mf][1] = mfma16<PREC>(l, bf[2 + kk], acc[mf][1]);
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = mfma16<PREC>(l, bf[2 * nf + kk], acc[mf][nf]);
         }
       };
       // one tap = four groups; the fragments of group g+1 are requested before the MFMAs of group g are issued
-      auto tap_body = [&](const bf16x8 (&bf)[4], const bool first) {
+      auto tap_body = [&](const bf16x8 (&bf)[NB], const bool first) {
         if (tap == 0) {  // new chunk: its window is staged behind this barrier (and the producers may refill the buffer just left)
           lds_barrier();
           if constexpr (DBG) {
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
       for (int s = 0; s < nsteps; s += 2) {
         const char* w1 = wptr(s + 1);
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
+        for (int f = 0; f < NB; ++f) {
           if constexpr ((ABL & 1) != 0) { b1[f] = b0[f]; asm volatile("" : "+v"(b1[f]) : "v"(w1)); }
           else b1[f] = *(const bf16x8*)(w1 + f * 1024);
         }
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
         if (s + 1 >= nsteps) break;
         const char* w0 = wptr(s + 2);
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
+        for (int f = 0; f < NB; ++f) {
           if constexpr ((ABL & 1) != 0) { b0[f] = b1[f]; asm volatile("" : "+v"(b0[f]) : "v"(w0)); }
           else b0[f] = *(const bf16x8*)(w0 + f * 1024);
         }
@@ -449,9 +452,10 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
 // GEMM mode: pure linear layers (K == 1, no prologue) with at least two 32-channel chunks
 inline bool gemm_mode(const mi355_conv_gemm_args& a) { return a.K == 1 && a.Cin >= 64 && a.pre_act == MI355_ACT_NONE && !a.pre_scale; }
 
-template <int PREC, int PRE, int EPI, bool GEMM, bool DBG = false, int ABL = 0>
+template <int PREC, int PRE, int EPI, bool GEMM, bool DBG = false, int ABL = 0, int BN = 128>
 int launch_ws4(const mi355_conv_gemm_args& a, hipStream_t st, const int feat, unsigned long long* dbg = nullptr) {
   ws4_geom q;
+  q.bn = BN;
   q.gemm = GEMM ? 1 : 0;
   const int chunks32 = (a.Cin + 31) >> 5;
   q.nslices = chunks32 * a.K;
@@ -470,7 +474,7 @@ int launch_ws4(const mi355_conv_gemm_args& a, hipStream_t st, const int feat, un
   const size_t lds = (size_t)2 * a_images<PREC>() * q.R * 64;
   q.tiles_per_item = (a.Lout + 127) / 128;
   q.P = a.B * q.tiles_per_item;
-  q.NT = (a.Cout + 127) / 128;
+  q.NT = (a.Cout + BN - 1) / BN;
   q.fold = ((a.res || a.accumulate) && a.post_act == MI355_ACT_NONE && a.up_s == 0 && a.res_shift == 0 && !a.post_colscale) ? 1 : 0;
   // runs of 2^glog consecutive row tiles per XCD: long runs share halos in L2, but every XCD must still get several rounds of runs
   q.glog = q.P >= 512 ? 3 : (q.P >= 256 ? 2 : (q.P >= 128 ? 1 : 0));
@@ -491,7 +495,7 @@ int launch_ws4(const mi355_conv_gemm_args& a, hipStream_t st, const int feat, un
   const int resident = g_ws4_resident > 0 ? ((g_ws4_resident + 7) / 8) * 8 : ((cus * wg_per_cu) / 8) * 8;
   const unsigned grid = (unsigned)((feat & 8) || q.total_ids <= resident ? q.total_ids : resident);  // feat bit 3: one workgroup per tile (A/B aid)
   MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL((conv_ws4_kernel<PREC, PRE, EPI, GEMM, DBG, ABL>), dim3(grid), dim3(kWs4Threads), lds, st, a, q);
+  hipLaunchKernelGGL((conv_ws4_kernel<PREC, PRE, EPI, GEMM, DBG, ABL, BN>), dim3(grid), dim3(kWs4Threads), lds, st, a, q);
   MI355_LAUNCH_CHECK("conv_gemm(ws4)");
   return MI355_OK;
 }
@@ -520,13 +524,18 @@ inline int pre_kind(const mi355_conv_gemm_args& a) {
 }
 
 #define WS4_CASE(PREC, PRE, EPI) \
-  if (pre == PRE && epi == EPI && !gemm) return launch_ws4<PREC, PRE, EPI, false>(a, st, feat)
+  if (bn == 128 && pre == PRE && epi == EPI && !gemm) return launch_ws4<PREC, PRE, EPI, false>(a, st, feat)
 #define WS4_GEMM(PREC, EPI) \
-  if (epi == EPI && gemm) return launch_ws4<PREC, P_NONE, EPI, true>(a, st, feat)
+  if (bn == 128 && epi == EPI && gemm) return launch_ws4<PREC, P_NONE, EPI, true>(a, st, feat)
+// the 64-column tile (bn == 64: asked for by the dispatcher when the last 128-column tile would be at most half full)
+#define WS4_CASE_N64(PREC, PRE, EPI) \
+  if (bn == 64 && pre == PRE && epi == EPI && !gemm) return launch_ws4<PREC, PRE, EPI, false, false, 0, 64>(a, st, feat & 15)
+#define WS4_GEMM_N64(PREC, EPI) \
+  if (bn == 64 && epi == EPI && gemm) return launch_ws4<PREC, P_NONE, EPI, true, false, 0, 64>(a, st, feat & 15)
 
 }  // namespace mi355conv
 
 // per-precision instantiation sets (one translation unit each: they compile in parallel); MI355_ERR_UNSUPPORTED = no such instantiation
-int mi355_conv_ws4_p2(const mi355_conv_gemm_args& a, hipStream_t st, int feat, unsigned long long* dbg);
-int mi355_conv_ws4_p4(const mi355_conv_gemm_args& a, hipStream_t st, int feat);
-int mi355_conv_ws4_p13(const mi355_conv_gemm_args& a, hipStream_t st, int feat);
+int mi355_conv_ws4_p2(const mi355_conv_gemm_args& a, hipStream_t st, int feat, unsigned long long* dbg, int bn);
+int mi355_conv_ws4_p4(const mi355_conv_gemm_args& a, hipStream_t st, int feat, int bn);
+int mi355_conv_ws4_p13(const mi355_conv_gemm_args& a, hipStream_t st, int feat, int bn);

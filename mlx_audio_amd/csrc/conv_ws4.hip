@@ -32,11 +32,11 @@ extern "C" int mi355_conv_ws4_debug_buffer(void* p) {
   return MI355_OK;
 }
 
-int mi355_conv_ws4_p2(const mi355_conv_gemm_args& a, hipStream_t st, int feat, unsigned long long* dbg) {
+int mi355_conv_ws4_p2(const mi355_conv_gemm_args& a, hipStream_t st, int feat, unsigned long long* dbg, int bn) {
   const int pre = pre_kind(a), epi = epi_family(a);
   const bool gemm = gemm_mode(a);
-  if ((feat & 4) && pre == P_SNAKE && epi == 0 && !gemm) return launch_ws4<2, P_SNAKE, 0, false, true>(a, st, feat, dbg);
-  if (const int abl = feat >> 4) {  // timing ablations (wrong results by design)
+  if (bn == 128 && (feat & 4) && pre == P_SNAKE && epi == 0 && !gemm) return launch_ws4<2, P_SNAKE, 0, false, true>(a, st, feat, dbg);
+  if (const int abl = bn == 128 ? feat >> 4 : 0) {  // timing ablations (wrong results by design)
     MI355_REQUIRE(pre == P_SNAKE && epi == 0 && !gemm, "conv_gemm(ws4): ablation tiles exist for the precision-2 Snake kernel only");
     switch (abl) {
       case 1: return launch_ws4<2, P_SNAKE, 0, false, false, 1>(a, st, feat & 15);
@@ -60,15 +60,21 @@ int mi355_conv_ws4_p2(const mi355_conv_gemm_args& a, hipStream_t st, int feat, u
   WS4_GEMM(2, 1);
   WS4_GEMM(2, 2);
   WS4_GEMM(2, 3);
+  // 64-column tiles: thin tensors (KittenTTS: 64-channel generator stage; codec decoders' late stages)
+  WS4_CASE_N64(2, P_NONE, 0);
+  WS4_CASE_N64(2, P_LEAKY, 0);
+  WS4_CASE_N64(2, P_SNAKE, 0);
+  WS4_CASE_N64(2, P_ELU, 0);
+  WS4_GEMM_N64(2, 0);
   return MI355_ERR_UNSUPPORTED;
 }
 
-int mi355_conv_ws4_launch(const mi355_conv_gemm_args& a, hipStream_t st, int feat) {
+int mi355_conv_ws4_launch(const mi355_conv_gemm_args& a, hipStream_t st, int feat, int bn) {
   int rc = MI355_ERR_UNSUPPORTED;
-  if (a.precision == 2) rc = mi355_conv_ws4_p2(a, st, feat, g_dbg_buffer);
-  else if (a.precision == 4) rc = mi355_conv_ws4_p4(a, st, feat & 3);
-  else if (a.precision == 1 || a.precision == 3) rc = mi355_conv_ws4_p13(a, st, feat & 3);
+  if (a.precision == 2) rc = mi355_conv_ws4_p2(a, st, feat, g_dbg_buffer, bn);
+  else if (a.precision == 4) rc = mi355_conv_ws4_p4(a, st, feat & 3, bn);
+  else if (a.precision == 1 || a.precision == 3) rc = mi355_conv_ws4_p13(a, st, feat & 3, bn);
   if (rc == MI355_ERR_UNSUPPORTED)
-    mi355_set_error("conv_gemm(ws4): no instantiation for precision %d, prologue %d, epilogue family %d", a.precision, pre_kind(a), epi_family(a));
+    mi355_set_error("conv_gemm(ws4): no instantiation for precision %d, prologue %d, epilogue family %d, %d-column tiles", a.precision, pre_kind(a), epi_family(a), bn);
   return rc;
 }

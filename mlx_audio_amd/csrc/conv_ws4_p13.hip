@@ -3,7 +3,7 @@
 
 using namespace mi355conv;
 
-int mi355_conv_ws4_p13(const mi355_conv_gemm_args& a, hipStream_t st, int feat) {
+int mi355_conv_ws4_p13(const mi355_conv_gemm_args& a, hipStream_t st, int feat, int bn) {
   const int pre = pre_kind(a), epi = epi_family(a);
   const bool gemm = gemm_mode(a);
   if (a.precision == 1) {
@@ -12,6 +12,10 @@ int mi355_conv_ws4_p13(const mi355_conv_gemm_args& a, hipStream_t st, int feat) 
     WS4_CASE(1, P_SNAKE, 0);
     WS4_GEMM(1, 0);
     WS4_GEMM(1, 1);
+    WS4_CASE_N64(1, P_NONE, 0);
+    WS4_CASE_N64(1, P_LEAKY, 0);
+    WS4_CASE_N64(1, P_SNAKE, 0);
+    WS4_GEMM_N64(1, 0);
   } else {
     WS4_CASE(3, P_NONE, 0);
     WS4_CASE(3, P_LEAKY, 0);
@@ -19,6 +23,10 @@ int mi355_conv_ws4_p13(const mi355_conv_gemm_args& a, hipStream_t st, int feat) 
     WS4_CASE(3, P_NONE, 1);
     WS4_GEMM(3, 0);
     WS4_GEMM(3, 1);
+    WS4_CASE_N64(3, P_NONE, 0);
+    WS4_CASE_N64(3, P_LEAKY, 0);
+    WS4_CASE_N64(3, P_SNAKE, 0);
+    WS4_GEMM_N64(3, 0);
   }
   return MI355_ERR_UNSUPPORTED;
 }

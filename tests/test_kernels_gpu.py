@@ -85,6 +85,18 @@ def ref_conv_nlc(x, w, b, dil, pad):
     (514, 200, 3, 1, 33, 2, 22064128),
     (512, 64, 1, 1, 77, 3, 2064064),
     (96, 50, 7, 2, 130, 1, 32064064),
+    # the wave-specialised kernel on 128 x 64 tiles (tile code 6128064; tile 0 takes it for C_out <= 64 once there are >= 128 row tiles):
+    # conv mode, GEMM mode, ragged channel counts, one and many row tiles
+    (64, 64, 7, 3, 300, 2, 6128064),
+    (64, 64, 11, 5, 2100, 2, 6128064),
+    (128, 64, 3, 1, 1500, 1, 6128064),
+    (64, 50, 11, 1, 129, 1, 6128064),
+    (256, 22, 7, 1, 500, 1, 6128064),
+    (512, 64, 1, 1, 777, 3, 6128064),
+    (64, 64, 1, 1, 130, 1, 6128064),
+    (160, 40, 1, 1, 2100, 1, 16128064),
+    (64, 64, 3, 1, 20000, 1, 0),
+    (64, 64, 3, 1, 70000, 1, 86128064),
 ])
 def test_conv_gemm_plain(ops, cin, cout, k, dil, L, B, tile):
     g = torch.Generator().manual_seed(cin + cout + k)
@@ -165,7 +177,47 @@ def test_conv_gemm_fused_prologue_epilogue_ragged(ops, tile, res_shift, act):
         assert torch.equal(got[b, n:], y0[b, n:])  # rows beyond the item's length are never written
 
 
-@pytest.mark.parametrize("cin,cout,k,s,L,row_off,tile", [(512, 256, 20, 10, 53, 0, 0), (256, 128, 12, 6, 130, 1, 0), (64, 32, 4, 2, 9, 0, 0),
+@pytest.mark.parametrize("tile", [0, 6128064, 86128064, 64064])
+def test_conv_gemm_thin_tiles_fused(ops, tile):
+    """C = 64 (KittenTTS's last generator stage): AdaIN + Snake prologue, bias + residual + out_scale, fused instance-norm statistics, ragged batch,
+    through the 128 x 64 tiles of the wave-specialised kernel (6128064) and through the 4-wave kernel it replaces (64064; no fused statistics there)."""
+    g = torch.Generator().manual_seed(31)
+    B, L, C, K, dil = 3, 1900, 64, 7, 3
+    lens = torch.tensor([1900, 64, 1031], dtype=torch.int32)
+    w = bf16r(torch.randn(C, K, C, generator=g) / math.sqrt(K * C))
+    bias = torch.randn(C, generator=g) * 0.1 + 3.0
+    x = torch.randn(B, L, C, generator=g)
+    sc = torch.rand(B, C, generator=g) + 0.5
+    sh = torch.randn(B, C, generator=g) * 0.3
+    alpha = torch.rand(C, generator=g) + 0.5
+    res = torch.randn(B, L, C, generator=g)
+    gb = (torch.randn(B, 2 * C, generator=g) * 0.3).to(DEV)
+    pad = (K * dil - dil) // 2
+    pc = ops.pack_conv(w, bias, DEV)
+    lens_d = lens.to(DEV)
+    y = torch.full((B, L, C), float("nan"), device=DEV)
+    want_stats = tile != 64064
+    st = ops.new_stats(B, L, C, DEV) if want_stats else None
+    ops.conv_gemm(x.to(DEV), pc, y, dil=dil, pad=pad, lens_in=lens_d, lens_out=lens_d, pre=(sc.to(DEV), sh.to(DEV)), pre_act=ops.ACT_SNAKE,
+                  pre_alpha=alpha.to(DEV), res=res.to(DEV), out_scale=0.5, tile=tile, stats=st)
+    torch.cuda.synchronize()
+    got = y.cpu()
+    for b in range(B):
+        n = int(lens[b])
+        t = x[b:b + 1, :n].double() * sc[b].double() + sh[b].double()
+        t = t + (1.0 / alpha.double()) * torch.sin(alpha.double() * t) ** 2
+        ref = (ref_conv_nlc(t, w, bias, dil, pad)[0] + res[b, :n].double()) * 0.5
+        assert rel_err(got[b, :n], ref) < 3e-5
+        assert torch.isnan(got[b, n:]).all()  # rows beyond the item's length are never written
+    if want_stats:
+        ysafe = torch.nan_to_num(y)
+        s1, h1 = ops.adain_from_partials(st, L, gb, lens_d)
+        s2, h2 = ops.adain_coef(ysafe, gb, lens_d)
+        torch.cuda.synchronize()
+        assert rel_err(s1[:, :C], s2[:, :C]) < 2e-5 and rel_err(h1[:, :C], h2[:, :C]) < 2e-5
+
+
+@pytest.mark.parametrize("cin,cout,k,s,L,row_off,tile", [(128, 16, 8, 4, 700, 0, 6128064), (128, 16, 8, 4, 700, 1, 0), (512, 256, 20, 10, 53, 0, 0), (256, 128, 12, 6, 130, 1, 0), (64, 32, 4, 2, 9, 0, 0),
                                                          (512, 256, 20, 10, 153, 0, 6128128), (256, 128, 12, 6, 330, 1, 6128128),
                                                          (512, 256, 20, 10, 153, 0, 86128128), (256, 128, 12, 6, 330, 1, 86128128),
                                                          (512, 256, 20, 10, 53, 0, 2064128), (256, 128, 12, 6, 130, 1, 42064128)])
