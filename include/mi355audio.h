@@ -129,6 +129,10 @@ typedef struct {
      that sums the groups in a fixed order.  NULL = never split.  The workspace is scratch of this call only (stream-ordered reuse is safe). */
   void* split_ws;
   int64_t split_ws_bytes;
+  /* fake-quantised module input (KittenTTS activation_quant_modules, kitten_tts/quant.py:4-24): [B][2] = {-min, max} of the PROLOGUE'S OUTPUT over
+     the utterance, both joined with 0, as mi355_fake_quant_extrema leaves them; the prologue then ends with the reference's dynamic uint8
+     quantise / dequantise of every value (float32 op by op), so the quantised tensor is never materialised.  NULL = no quantisation. */
+  const float* pre_fq;
 } mi355_conv_gemm_args;
 #define MI355_STATS_ROWS 64
 
@@ -280,6 +284,10 @@ typedef struct {
   float* minmax;
 } mi355_fake_quant_args;
 int mi355_fake_quant_u8(const mi355_fake_quant_args* a, void* stream);
+/* Extrema pass alone for a conv that quantises in its prologue (mi355_conv_gemm_args.pre_fq): minmax[b] = {-min, max} of act(scale x + shift)
+ * over utterance b's valid rows, joined with 0; y is not touched (may be NULL).  The prologue value is evaluated exactly as the conv prologues
+ * evaluate it (fmaf, v_sin, v_rcp + Newton), not with the libm calls of mi355_fake_quant_u8. */
+int mi355_fake_quant_extrema(const mi355_fake_quant_args* a, void* stream);
 
 /* Anti-aliased activation of BigVGAN (codec/models/bigvgan/resample.py:157-177 ``Activation1d`` with SnakeBeta, activation.py:27-51):
  * x [B, L, C] channels-last -> y [B, L, C]:  2x up-sampling (edge pad 5, depthwise transposed conv with the 12-tap Kaiser-sinc filter, x 2, trimmed

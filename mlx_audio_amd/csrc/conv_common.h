@@ -41,6 +41,36 @@ __device__ __forceinline__ uint32_t pack_lo(float a, float b) {
   else return pack_bf16x2(a, b);
 }
 
+// ---- fake-quantised conv inputs (KittenTTS: tts/models/kitten_tts/quant.py:4-24, istftnet.py:131) -------------------------------------------
+// The module input that is quantised is the PROLOGUE'S OUTPUT t = act(scale x + shift).  The extrema pass (conv_quant.hip) and every conv
+// prologue that applies the quantiser evaluate t with this one function, operation by operation (explicit fmaf, v_sin on revolutions, v_rcp +
+// one Newton step: TU-independent, nothing left for the compiler to contract), so the extrema are the extrema of exactly the values the conv
+// quantises.  al_rev = alpha / 2 pi, ial = 1 / alpha.
+struct fq_coef { float sc, sh, al_rev, ial; };
+__device__ __forceinline__ fq_coef fq_load_coef(const float* pre_scale, const float* pre_shift, const int64_t pre_off, const int pre_act,
+                                                const float* pre_alpha, const int c) {
+  fq_coef k{1.f, 0.f, 1.f, 1.f};
+  if (pre_scale) { k.sc = pre_scale[pre_off + c]; k.sh = pre_shift[pre_off + c]; }
+  if (pre_act == MI355_ACT_SNAKE) {
+    const float al = pre_alpha[c];
+    const float r0 = __builtin_amdgcn_rcpf(al);
+    k.ial = fmaf(fmaf(-al, r0, 1.0f), r0, r0);
+    k.al_rev = al * 0.15915494309189535f;
+  }
+  return k;
+}
+__device__ __forceinline__ float fq_pre_value(const float x, const fq_coef& k, const bool affine, const int pre_act, const float slope) {
+  float u = affine ? fmaf(x, k.sc, k.sh) : x;
+  if (pre_act == MI355_ACT_LEAKY) {
+    const float m = u * slope;
+    u = u > 0.f ? u : m;
+  } else if (pre_act == MI355_ACT_SNAKE) {
+    const float sn = __builtin_amdgcn_sinf(k.al_rev * u);
+    u = fmaf(k.ial, sn * sn, u);
+  }
+  return u;
+}
+
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS reads / writes are done
   __builtin_amdgcn_s_barrier();

@@ -97,6 +97,14 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_ge
         ial[0] = b4.x; ial[1] = b4.y; ial[2] = b4.z; ial[3] = b4.w;
       }
     }
+    // quantising prologue (a.pre_fq): the value of conv_common.h's fq_pre_value, then the utterance's dynamic uint8 quantise / dequantise
+    const bool fqon = a.pre_fq != nullptr;
+    const FakeQuant fq = fqon ? FakeQuant(-a.pre_fq[2 * b], a.pre_fq[2 * b + 1]) : FakeQuant(0.f, 0.f);
+    fq_coef fk[4];
+    if (fqon) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fk[i] = fq_load_coef(a.pre_scale, a.pre_shift, (int64_t)b * a.pre_ld, a.pre_act, a.pre_alpha, (c + i) < a.Cin ? c + i : 0);
+    }
     for (int r = tid >> 3; r < R; r += kThreads / 8) {
       const int gl = l0 - a.pad + r;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -123,7 +131,8 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_ge
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float t = v[i] * sc[i] + sh[i];
-        if (a.pre_act == MI355_ACT_LEAKY) t = t > 0.f ? t : t * a.pre_slope;
+        if (fqon) t = fq(fq_pre_value(v[i], fk[i], a.pre_scale != nullptr, a.pre_act, a.pre_slope));
+        else if (a.pre_act == MI355_ACT_LEAKY) t = t > 0.f ? t : t * a.pre_slope;
         else if (a.pre_act == MI355_ACT_SNAKE) {
           const float s = __sinf(al[i] * t);
           t = t + ial[i] * (s * s);
@@ -407,6 +416,8 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
                 "conv_gemm: polyphase store needs Cout == up_s*up_cout");
   if (a.precision == 0) a.precision = 2;
   MI355_REQUIRE(a.precision >= 1 && a.precision <= 4, "conv_gemm: precision must be 1, 2, 3 or 4");
+  MI355_REQUIRE(!a.pre_fq || a.pre_act == MI355_ACT_NONE || a.pre_act == MI355_ACT_LEAKY || (a.pre_act == MI355_ACT_SNAKE && !a.pre_inv_beta),
+                "conv_gemm: a quantising prologue (pre_fq) takes no activation, LeakyReLU or Snake");
   if (a.out_scale == 0.f) a.out_scale = 1.f;
   hipStream_t st = (hipStream_t)stream;
   const bool vec = (a.flat_valid == 0) && (a.ldx % 4 == 0) && (a.x_off % 4 == 0) && (a.x_bstride % 4 == 0) &&

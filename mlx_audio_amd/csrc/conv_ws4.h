@@ -76,8 +76,11 @@ __device__ __forceinline__ int next_work(const mi355_conv_gemm_args& a, const ws
 // ABL (ablation bits, timing experiments only -- results are WRONG when non-zero; reachable only through the explicit tile codes
 // ABL * 100000000 + 6128128 of tools/bench_conv.py --ablate): 1 = no weight-fragment loads after the first, 2 = no activation-fragment LDS
 // reads, 4 = the producers only take part in the barriers, 8 = no residual fold and no epilogue.
-template <int PREC, int PRE, int EPI, bool GEMM, bool DBG = false, int ABL = 0, int BN = 128>
+// FQ: the prologue ends with the dynamic uint8 fake quantisation of its value (a.pre_fq: the utterance's extrema); the prologue value is then
+// conv_common.h's fq_pre_value, the function the extrema pass evaluated.
+template <int PREC, int PRE, int EPI, bool GEMM, bool DBG = false, int ABL = 0, int BN = 128, bool FQ = false>
 __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_conv_gemm_args a, const ws4_geom q) {
+  static_assert(!FQ || (!GEMM && (PRE == P_NONE || PRE == P_LEAKY || PRE == P_SNAKE)), "quantising prologues: conv mode, none / LeakyReLU / Snake");
   constexpr int BM = 128;
   static_assert(BN == 128 || BN == 64, "tile columns");
   constexpr int NLD = GEMM ? 8 : 6;  // window passes of 32 rows per chunk (conv: R <= 192; GEMM mode: R = 256)
@@ -161,6 +164,14 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
         }
       }
       const float slope = a.pre_slope;
+      // FQ: this utterance's quantiser and the channel coefficients in the form fq_pre_value takes
+      const FakeQuant fq = FQ ? FakeQuant(-a.pre_fq[2 * b], a.pre_fq[2 * b + 1]) : FakeQuant(0.f, 0.f);
+      fq_coef fk[4];
+      if constexpr (FQ) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          fk[j] = fq_load_coef(a.pre_scale, a.pre_shift, (int64_t)b * a.pre_ld, PRE == P_SNAKE ? MI355_ACT_SNAKE : MI355_ACT_NONE, a.pre_alpha, c + j);
+      }
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
         if (GEMM || wrow0 + i * 32 < R) {
@@ -174,6 +185,11 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               float u = v[j];
+              if constexpr (FQ) {
+                u = fq(fq_pre_value(u, fk[j], a.pre_scale != nullptr, PRE == P_SNAKE ? MI355_ACT_SNAKE : (PRE == P_LEAKY ? MI355_ACT_LEAKY : MI355_ACT_NONE), slope));
+                tt[j] = (rowok && (cb + j) < a.Cin) ? u : 0.f;
+                continue;
+              }
               if constexpr (!GEMM) u = u * sc[j] + sh[j];
               if constexpr (PRE == P_LEAKY) {
                 const float m = u * slope;
@@ -450,9 +466,9 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
 }
 
 // GEMM mode: pure linear layers (K == 1, no prologue) with at least two 32-channel chunks
-inline bool gemm_mode(const mi355_conv_gemm_args& a) { return a.K == 1 && a.Cin >= 64 && a.pre_act == MI355_ACT_NONE && !a.pre_scale; }
+inline bool gemm_mode(const mi355_conv_gemm_args& a) { return a.K == 1 && a.Cin >= 64 && a.pre_act == MI355_ACT_NONE && !a.pre_scale && !a.pre_fq; }
 
-template <int PREC, int PRE, int EPI, bool GEMM, bool DBG = false, int ABL = 0, int BN = 128>
+template <int PREC, int PRE, int EPI, bool GEMM, bool DBG = false, int ABL = 0, int BN = 128, bool FQ = false>
 int launch_ws4(const mi355_conv_gemm_args& a, hipStream_t st, const int feat, unsigned long long* dbg = nullptr) {
   ws4_geom q;
   q.bn = BN;
@@ -495,7 +511,7 @@ int launch_ws4(const mi355_conv_gemm_args& a, hipStream_t st, const int feat, un
   const int resident = g_ws4_resident > 0 ? ((g_ws4_resident + 7) / 8) * 8 : ((cus * wg_per_cu) / 8) * 8;
   const unsigned grid = (unsigned)((feat & 8) || q.total_ids <= resident ? q.total_ids : resident);  // feat bit 3: one workgroup per tile (A/B aid)
   MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL((conv_ws4_kernel<PREC, PRE, EPI, GEMM, DBG, ABL, BN>), dim3(grid), dim3(kWs4Threads), lds, st, a, q);
+  hipLaunchKernelGGL((conv_ws4_kernel<PREC, PRE, EPI, GEMM, DBG, ABL, BN, FQ>), dim3(grid), dim3(kWs4Threads), lds, st, a, q);
   MI355_LAUNCH_CHECK("conv_gemm(ws4)");
   return MI355_OK;
 }
@@ -539,3 +555,4 @@ inline int pre_kind(const mi355_conv_gemm_args& a) {
 int mi355_conv_ws4_p2(const mi355_conv_gemm_args& a, hipStream_t st, int feat, unsigned long long* dbg, int bn);
 int mi355_conv_ws4_p4(const mi355_conv_gemm_args& a, hipStream_t st, int feat, int bn);
 int mi355_conv_ws4_p13(const mi355_conv_gemm_args& a, hipStream_t st, int feat, int bn);
+int mi355_conv_ws4_fq(const mi355_conv_gemm_args& a, hipStream_t st, int feat, int bn);   // quantising prologues (pre_fq), precision 2

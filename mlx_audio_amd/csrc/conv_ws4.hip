@@ -71,7 +71,8 @@ int mi355_conv_ws4_p2(const mi355_conv_gemm_args& a, hipStream_t st, int feat, u
 
 int mi355_conv_ws4_launch(const mi355_conv_gemm_args& a, hipStream_t st, int feat, int bn) {
   int rc = MI355_ERR_UNSUPPORTED;
-  if (a.precision == 2) rc = mi355_conv_ws4_p2(a, st, feat, g_dbg_buffer, bn);
+  if (a.pre_fq) rc = a.precision == 2 ? mi355_conv_ws4_fq(a, st, feat & 3, bn) : MI355_ERR_UNSUPPORTED;
+  else if (a.precision == 2) rc = mi355_conv_ws4_p2(a, st, feat, g_dbg_buffer, bn);
   else if (a.precision == 4) rc = mi355_conv_ws4_p4(a, st, feat & 3, bn);
   else if (a.precision == 1 || a.precision == 3) rc = mi355_conv_ws4_p13(a, st, feat & 3, bn);
   if (rc == MI355_ERR_UNSUPPORTED)

@@ -360,14 +360,14 @@ def conv_gemm(x: torch.Tensor, pc: PackedConv, y: torch.Tensor, *, dil: int = 1,
               up: Optional[dict] = None, precision: int = 2, tile: int = 0,
               flat: Optional[dict] = None, use_bias: bool = True, stats: Optional[torch.Tensor] = None,
               pre_inv_beta: Optional[torch.Tensor] = None, colscale: Optional[torch.Tensor] = None, x_off: int = 0,
-              flatten: bool = False):
+              flatten: bool = False, pre_fq: Optional[torch.Tensor] = None):
     """y = epilogue(conv1d(prologue(x)))  -- see mi355_conv_gemm_args in the header.
 
     ``flatten``: the caller states that this is a per-row linear layer (K == 1) whose padding rows (rows >= lens[b]) may be
     computed and written like any other row (nothing downstream reads them as valid): ``[B, L, C]`` operands whose items are
     row-contiguous are then handed over as ONE item of B*L rows, so the 128-row tiles are full instead of one partly
     filled tile per utterance (PL-BERT at T = 80: 62 % -> 100 % useful rows)."""
-    if flatten and pc.k == 1 and up is None and flat is None and res_shift == 0 and stats is None and pre is None and x.shape[0] > 1:
+    if flatten and pc.k == 1 and up is None and flat is None and res_shift == 0 and stats is None and pre is None and pre_fq is None and x.shape[0] > 1:
         ts = [x, y] + ([res] if res is not None else [])
         if all(t.dim() == 3 and t.shape[:2] == x.shape[:2] and t.stride(0) == t.shape[1] * t.stride(1) for t in ts):
             fl = lambda t: t.as_strided((1, t.shape[0] * t.shape[1], t.shape[2]), (t.shape[0] * t.shape[1] * t.stride(1), t.stride(1), 1))
@@ -388,6 +388,9 @@ def conv_gemm(x: torch.Tensor, pc: PackedConv, y: torch.Tensor, *, dil: int = 1,
               post_slope=post_slope, out_scale=out_scale, accumulate=int(accumulate), y=_ptr(y), y_bstride=ybs, ldy=ldy,
               Lout=lout if lout is not None else Ly, lens_out=_ptr(lens_out), B=B, precision=precision, tile=tile,
               pre_inv_beta=_ptr(pre_inv_beta), post_colscale=_ptr(colscale))
+    if pre_fq is not None:  # [B, 2] from fake_quant_extrema (same prologue arguments): the prologue ends with the dynamic uint8 fake quantisation
+        assert pre_fq.dtype == torch.float32 and pre_fq.shape == (B, 2) and pre_fq.is_contiguous()
+        kw.update(pre_fq=_ptr(pre_fq))
     if flat is not None:  # flattened strided conv: taps are contiguous in memory (C_in small)
         kw.update(ldx=flat["ldx"], x_off=flat["x_off"], flat_valid=flat["channels"])
     else:
@@ -511,6 +514,19 @@ def fake_quant_u8(x: torch.Tensor, y: Optional[torch.Tensor] = None, *, lens=Non
                      pre_scale=_ptr(sc), pre_shift=_ptr(sh), pre_ld=sc.stride(0) if sc is not None else 0, pre_act=pre_act, pre_slope=pre_slope,
                      pre_alpha=_ptr(pre_alpha), y=_ptr(y), y_bstride=ybs, ldy=ldy, minmax=_ptr(mm))
     return y
+
+
+def fake_quant_extrema(x: torch.Tensor, *, lens=None, pre=None, pre_act: int = ACT_NONE, pre_slope: float = 0.0,
+                       pre_alpha: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Extrema pass alone: ``[B, 2]`` = {-min, max} of ``act(scale * x + shift)`` per utterance (joined with 0) for ``conv_gemm(pre_fq=...)``,
+    which quantises inside its prologue -- the quantised tensor is never written."""
+    B, L, C, xbs, ldx = _nlc(x)
+    mm = torch.empty((B, 2), dtype=torch.float32, device=x.device)
+    sc, sh = pre if pre is not None else (None, None)
+    _lib.call_struct("mi355_fake_quant_extrema", "mi355_fake_quant_args", _stream(), x=_ptr(x), x_bstride=xbs, ldx=ldx, C=C, L=L, lens=_ptr(lens), B=B,
+                     pre_scale=_ptr(sc), pre_shift=_ptr(sh), pre_ld=sc.stride(0) if sc is not None else 0, pre_act=pre_act, pre_slope=pre_slope,
+                     pre_alpha=_ptr(pre_alpha), minmax=_ptr(mm))
+    return mm
 
 
 def attention(qkv: torch.Tensor, heads: int, dh: int, out: torch.Tensor, lens=None):

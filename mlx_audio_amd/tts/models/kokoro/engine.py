@@ -16,6 +16,7 @@ happens in libmi355audio.so.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
 
@@ -186,6 +187,9 @@ class KokoroEngine:
         self.pdt = param_dtype
         self.precision = precision
         self.fuse_stats = True  # instance-norm statistics out of the producing conv's epilogue (False: separate pass)
+        # KittenTTS activation quantisation: extrema pass + quantiser inside the consuming conv's prologue (False: materialise the quantised tensor
+        # with mi355_fake_quant_u8 first -- the round-2 path, kept for A/B runs: MI355_FOLD_QUANT=0)
+        self.fold_quant = os.environ.get("MI355_FOLD_QUANT", "1") != "0"
         self.w = weights
         ist = config["istftnet"]
         self.rates = [int(r) for r in ist["upsample_rates"]]
@@ -371,6 +375,10 @@ class KokoroEngine:
         """``_conv`` of module ``name``.  When the module is flagged for activation quantisation (KittenTTS) its input -- INCLUDING the
         AdaIN / activation prologue the conv would have fused -- is materialised and fake-quantised first (kitten_tts/istftnet.py:131)."""
         if self.qmods and self._isq(name):
+            if self.fold_quant and "flat" not in kw:
+                # one read-only extrema pass; the conv quantises inside its prologue (no materialised tensor)
+                mm = ops.fake_quant_extrema(x, lens=lens_in, pre=pre, pre_act=pre_act, pre_slope=pre_slope, pre_alpha=pre_alpha)
+                return self._conv(x, pc, y, lens_in=lens_in, pre=pre, pre_act=pre_act, pre_slope=pre_slope, pre_alpha=pre_alpha, pre_fq=mm, **kw)
             xq = ops.fake_quant_u8(x, lens=lens_in, pre=pre, pre_act=pre_act, pre_slope=pre_slope, pre_alpha=pre_alpha)
             return self._conv(xq, pc, y, lens_in=lens_in, **kw)
         if pre is not None or pre_act != ACT_NONE:

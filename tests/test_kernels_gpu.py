@@ -217,6 +217,76 @@ def test_conv_gemm_thin_tiles_fused(ops, tile):
         assert rel_err(s1[:, :C], s2[:, :C]) < 2e-5 and rel_err(h1[:, :C], h2[:, :C]) < 2e-5
 
 
+def _fq_ref(t, nmn, mx):
+    """kitten_tts/quant.py:4-20 in float32, op by op (t float32 [L, C]; nmn = -min, mx = max, both joined with 0)."""
+    mn = -np.float32(nmn)
+    scale = (np.float32(mx) - mn) / np.float32(255.0)
+    if scale == 0:
+        return torch.zeros_like(t)
+    zp = np.clip(np.rint(-mn / scale), 0, 255).astype(np.float32)
+    tn = t.numpy().astype(np.float32)
+    q = np.clip(np.rint(tn / scale + zp), 0, 255).astype(np.float32)
+    return torch.from_numpy(((q - zp) * scale).astype(np.float32))
+
+
+@pytest.mark.parametrize("tile", [0, 6128128, 6128064, 64128, 64064, 2064128])
+@pytest.mark.parametrize("act", ["none", "leaky", "snake"])
+def test_conv_gemm_quantising_prologue(ops, tile, act):
+    """mi355_conv_gemm_args.pre_fq: extrema pass + the dynamic uint8 fake quantisation inside the conv prologue == quantising the prologue's output
+    first and convolving that.  Without a prologue the quantised values are the reference's bit for bit (the conv must then agree with the conv of
+    the materialised mi355_fake_quant_u8 tensor at conv accuracy); with AdaIN + LeakyReLU / Snake the prologue value carries ~1e-6 of its own, so a
+    value within that distance of a rounding boundary may land in the neighbouring bin: bounded below by the bin width it can move."""
+    g = torch.Generator().manual_seed(41)
+    C = 64 if tile in (6128064, 64064) else 128
+    B, L, K, dil = 3, 2100, 7, 3
+    lens = torch.tensor([2100, 64, 1031], dtype=torch.int32)
+    w = bf16r(torch.randn(C, K, C, generator=g) / math.sqrt(K * C))
+    bias = torch.randn(C, generator=g) * 0.1
+    x = torch.randn(B, L, C, generator=g) * 2.0 + 0.3
+    sc = torch.rand(B, C, generator=g) + 0.5
+    sh = torch.randn(B, C, generator=g) * 0.3
+    alpha = torch.rand(C, generator=g) + 0.5
+    pad = (K * dil - dil) // 2
+    pc = ops.pack_conv(w, bias, DEV)
+    lens_d, xd = lens.to(DEV), x.to(DEV)
+    kw = {}
+    if act != "none":
+        kw.update(pre=(sc.to(DEV), sh.to(DEV)))
+        kw.update(dict(pre_act=ops.ACT_SNAKE, pre_alpha=alpha.to(DEV)) if act == "snake" else dict(pre_act=ops.ACT_LEAKY, pre_slope=0.2))
+    mm = ops.fake_quant_extrema(xd, lens=lens_d, **kw)
+    y = torch.full((B, L, C), float("nan"), device=DEV)
+    ops.conv_gemm(xd, pc, y, dil=dil, pad=pad, lens_in=lens_d, lens_out=lens_d, tile=tile, pre_fq=mm, **kw)
+    torch.cuda.synchronize()
+    got, mmc = y.cpu(), mm.cpu()
+    for b in range(B):
+        n = int(lens[b])
+        t = x[b, :n].double()
+        if act != "none":
+            t = t * sc[b].double() + sh[b].double()
+            t = t + (1.0 / alpha.double()) * torch.sin(alpha.double() * t) ** 2 if act == "snake" else F.leaky_relu(t, 0.2)
+        # the extrema: those of the prologue output (joined with 0) at fp32 accuracy of the prologue
+        assert abs(float(mmc[b, 0]) - max(0.0, float(-t.min()))) <= 2e-5 * float(t.abs().max())
+        assert abs(float(mmc[b, 1]) - max(0.0, float(t.max()))) <= 2e-5 * float(t.abs().max())
+        q = _fq_ref(t.float(), mmc[b, 0], mmc[b, 1])
+        ref = ref_conv_nlc(q[None].double(), w, bias, dil, pad)[0]
+        err = (got[b, :n].double() - ref).abs()
+        peak = float(ref.abs().max())
+        step = (float(mmc[b, 1]) + float(mmc[b, 0])) / 255.0
+        if act == "none":
+            assert float(err.max()) < 3e-5 * peak
+        else:  # a few inputs one bin off: each moves an output by at most step * |w|; the bulk stays at conv accuracy
+            assert float(err.max()) <= 3e-5 * peak + 3 * step * float(w.abs().max()) and float(err.median()) < 3e-5 * peak
+        assert torch.isnan(got[b, n:]).all()
+    if act == "none":  # the materialised path on the same values
+        xq = ops.fake_quant_u8(xd, lens=lens_d)
+        y2 = torch.zeros((B, L, C), device=DEV)
+        ops.conv_gemm(xq, pc, y2, dil=dil, pad=pad, lens_in=lens_d, lens_out=lens_d, tile=tile)
+        torch.cuda.synchronize()
+        for b in range(B):
+            n = int(lens[b])
+            assert rel_err(got[b, :n], y2[b, :n].cpu()) < 1e-6
+
+
 @pytest.mark.parametrize("cin,cout,k,s,L,row_off,tile", [(128, 16, 8, 4, 700, 0, 6128064), (128, 16, 8, 4, 700, 1, 0), (512, 256, 20, 10, 53, 0, 0), (256, 128, 12, 6, 130, 1, 0), (64, 32, 4, 2, 9, 0, 0),
                                                          (512, 256, 20, 10, 153, 0, 6128128), (256, 128, 12, 6, 330, 1, 6128128),
                                                          (512, 256, 20, 10, 153, 0, 86128128), (256, 128, 12, 6, 330, 1, 86128128),
