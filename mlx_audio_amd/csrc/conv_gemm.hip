@@ -351,7 +351,9 @@ int split_groups(const long wgs, const int nchunks, const int K, const long rows
   const int min_chunks = K >= min_steps ? 1 : (min_steps + K - 1) / K;       // >= min_steps (chunk, tap) steps per group
   int ks = forced;                                            // > 0: that many groups; -1: the rule's count whatever the tile count; 0: the rule
   if (ks <= 0) {
-    if (forced == 0 && (wgs >= 256 || (long)nchunks * K < 8)) return 0;
+    // measured (profiles/r3_bench_codecs_b1_call22): between ~130 and 256 tiles two or three groups do not pay for the slab traffic and the second
+    // launch (EnCodec's 512 -> 8 x 256 transposed conv at one utterance: 192 tiles, +19 % with the split) -- split only when at least half the CUs idle
+    if (forced == 0 && (wgs > 128 || (long)nchunks * K < 8)) return 0;
     ks = (int)((512 + wgs - 1) / wgs);
     if (ks < 2) ks = 2;
   }

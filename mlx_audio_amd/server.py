@@ -7,8 +7,11 @@ Deliberately NOT here (control plane of the reference, out of scope of the hot p
 web UI, CORS / auth, STT / separation endpoints, mp3 / flac / opus containers (``response_format`` "wav" and "pcm" only: the reference encodes the others with
 ffmpeg-backed writers).  Models are handed in already loaded (``create_app({"name": model})``).
 
-Multi-GPU: one server process per GPU (``mlx_audio_amd.shard``): a front process shards a batch of requests with ``shard.sharded_decode`` / ``kokoro_step``;
-inside one process the broker's session batches whatever requests are in flight.
+Multi-GPU (one process per GPU, ``torch.distributed`` over RCCL): ``attach_sharded_engine(model, dist)`` on every rank.  Rank 0 then serves
+``create_app({...: model})`` as on one GPU -- the broker's ``KokoroBatchSession`` calls ``model.engine.forward`` for whatever requests are in flight, and that
+call is now ``shard.ShardedKokoro.forward``: request block and style rows out, token-rate half on the token-LPT shard, re-balance on the real frame counts,
+frame-rate half, waveforms back -- while the other ranks block in the returned object's ``worker_loop()`` until rank 0 calls ``close()``
+(tests/test_shard_serving_cpu.py: the endpoint over gloo at world 2).  The autoregressive families shard by sequence with ``shard.sharded_decode``.
 """
 from __future__ import annotations
 
@@ -108,3 +111,17 @@ def create_app(models: Dict[str, Any], *, max_batch_size: int = 8, broker: Optio
         return StreamingResponse(chunks(), media_type=f"audio/{fmt}", headers={"Content-Disposition": f"attachment; filename=speech.{fmt}"})
 
     return app
+
+
+def attach_sharded_engine(model, dist, *, max_items: int = 1024, max_tokens: int = 512, wire_dtype=None):
+    """Every rank calls this with its own loaded copy of a Kokoro-family ``model`` (engine with ``front`` / ``back``).  Replaces ``model.engine`` by a
+    ``shard.ShardedKokoro`` over all ranks and returns it: rank 0 goes on to ``create_app`` / ``uvicorn.run`` and calls ``.close()`` at shutdown, the other
+    ranks call ``.worker_loop()``."""
+    from . import shard
+
+    eng = model.engine
+    ch = shard.ShardChannel(eng.dev if hasattr(eng, "dev") else "cpu", dist, max_items=max_items, max_tokens=max_tokens)
+    spf = 2 * int(eng.total_up)   # samples per duration frame: 2 x prod(upsample rates) x iSTFT hop (Kokoro: 600)
+    sk = shard.ShardedKokoro(eng, ch, spf, wire_dtype=wire_dtype)
+    model.engine = sk
+    return sk

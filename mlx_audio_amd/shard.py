@@ -261,7 +261,7 @@ def sharded_decode(ch: ShardChannel, requests: Optional[Sequence[torch.Tensor]],
 
 def kokoro_step(ch: ShardChannel, engine, requests: Optional[Sequence[torch.Tensor]], ref_s_of: Callable,
                 samples_per_frame: int, forced_durations_of: Optional[Callable[[int], torch.Tensor]] = None, tolerance: float = 0.05,
-                wire_dtype: Optional[torch.dtype] = None, back_kwargs: Optional[Callable[[List[int]], dict]] = None):
+                wire_dtype: Optional[torch.dtype] = None, back_kwargs: Optional[Callable[[List[int]], dict]] = None, speed: Optional[float] = None):
     """One sharded Kokoro synthesis step: requests out, token-rate half on the token-LPT shard, frame counts shared, utterances re-balanced on
     the real frame counts, frame-rate half, waveforms back.  ``ref_s_of(item, n_tokens)`` -> the item's style row ``[1, 256]`` (or, when it has
     a ``rows`` attribute, ``ref_s_of.rows(items, lens)`` -> all rows ``[n, 256]`` in one device gather);
@@ -282,6 +282,8 @@ def kokoro_step(ch: ShardChannel, engine, requests: Optional[Sequence[torch.Tens
             if forced_durations_of is not None and hasattr(forced_durations_of, "rows"):
                 kw["forced_padded"] = forced_durations_of.rows(first, lens)
         fd = [forced_durations_of(i) for i in first] if forced_durations_of and "forced_padded" not in kw else None
+        if speed is not None:
+            kw["speed"] = float(speed)
         st = engine.front(ids, ref, forced_durations=fd, **kw)
     frames = ch.share_counts(st.frames if st else [])
     width = engine.hid + engine.sty
@@ -331,3 +333,75 @@ def broadcast_tensor(t: Optional[torch.Tensor], device, dist=None, src: int = 0,
     buf = t.to(device=device, dtype=dtype).contiguous() if rank == src else torch.empty(list(shape), dtype=dtype, device=device)
     dist.broadcast(buf, src)
     return buf
+
+
+# ---------------------------------------------------------------------------------------------------- the serving shell on N GPUs
+class _RefRows:
+    """``ref_s_of`` for ``kokoro_step`` when the style rows of the whole request batch are already on every rank."""
+
+    def __init__(self, rows: torch.Tensor):
+        self._rows = rows
+
+    def __call__(self, i: int, n_tokens: int) -> torch.Tensor:
+        return self._rows[i:i + 1]
+
+    def rows(self, items: Sequence[int], lens: Sequence[int]) -> torch.Tensor:
+        return self._rows[torch.tensor(list(items), dtype=torch.long, device=self._rows.device)]
+
+
+class ShardedKokoro:
+    """``engine.forward`` of the serving shell over every rank of a ``ShardChannel`` ("InferenceBroker / TTSBatchSession wired to the
+    multi-GPU engine").  The HTTP front end, the ``InferenceBroker`` and the ``KokoroBatchSession`` live on rank ``ch.src`` and call ``forward`` exactly
+    as they call the single-GPU engine; every other rank sits in ``worker_loop()``.  One call = one header broadcast (command, batch size, speed),
+    one broadcast of the style rows ``[n, 2 * style]``, then ``kokoro_step`` (request block out, token-rate half on the token-LPT shard, frame counts
+    shared, re-balance on the real frame counts, frame-rate half, waveforms back to ``ch.dst == ch.src``).  ``close()`` releases the workers."""
+
+    CMD_STOP, CMD_RUN = 0, 1
+
+    def __init__(self, engine, ch: ShardChannel, samples_per_frame: int, wire_dtype: Optional[torch.dtype] = None, tolerance: float = 0.05):
+        assert ch.src == ch.dst, "the rank that submits the batch receives the waveforms"
+        self.engine, self.ch, self.spf, self.wire_dtype, self.tolerance = engine, ch, int(samples_per_frame), wire_dtype, tolerance
+        self.steps = 0
+
+    def _header(self, cmd: int = 0, n: int = 0, speed: float = 1.0) -> Tuple[int, int, float]:
+        ch = self.ch
+        hdr = torch.zeros(3, dtype=torch.float64, device=ch.device)
+        if ch.rank == ch.src:
+            hdr = torch.tensor([float(cmd), float(n), float(speed)], dtype=torch.float64, device=ch.device)
+        if ch.dist:
+            ch.dist.broadcast(hdr, ch.src)
+            ch.collectives += 1
+        h = hdr.cpu()
+        return int(h[0]), int(h[1]), float(h[2])
+
+    def _run(self, input_ids, ref_s, n: int, speed: float):
+        ch = self.ch
+        width = 2 * self.engine.sty
+        rows = broadcast_tensor(ref_s, ch.device, ch.dist, ch.src, shape=(n, width))
+        if ch.dist:
+            ch.collectives += 1
+        self.steps += 1
+        return kokoro_step(ch, self.engine, input_ids, _RefRows(rows), self.spf, tolerance=self.tolerance, wire_dtype=self.wire_dtype, speed=speed)
+
+    # rank ch.src: the engine interface the sessions use
+    def forward(self, input_ids: Sequence[torch.Tensor], ref_s: torch.Tensor, speed: float = 1.0, **kw):
+        assert self.ch.rank == self.ch.src, "forward() is the submitting rank's call; the other ranks run worker_loop()"
+        if kw:
+            raise TypeError(f"ShardedKokoro.forward: unsupported arguments {sorted(kw)} (the sharded step takes ids, style rows and speed)")
+        n = len(input_ids)
+        self._header(self.CMD_RUN, n, speed)
+        outs = self._run(input_ids, ref_s.reshape(n, -1), n, float(speed))
+        return outs, None
+
+    def worker_loop(self) -> int:
+        """Every rank but ``ch.src``: serve steps until ``close()``.  Returns the number of steps served."""
+        assert self.ch.rank != self.ch.src
+        while True:
+            cmd, n, speed = self._header()
+            if cmd == self.CMD_STOP:
+                return self.steps
+            self._run(None, None, n, speed)
+
+    def close(self) -> None:
+        if self.ch.rank == self.ch.src:
+            self._header(self.CMD_STOP)
