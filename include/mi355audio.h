@@ -289,6 +289,20 @@ int mi355_fake_quant_u8(const mi355_fake_quant_args* a, void* stream);
  * evaluate it (fmaf, v_sin, v_rcp + Newton), not with the libm calls of mi355_fake_quant_u8. */
 int mi355_fake_quant_extrema(const mi355_fake_quant_args* a, void* stream);
 
+/* Residual vector quantisation, encode side (codec/models/mimi/modules/quantization.py:37-45, 84-96: per layer argmin_b (|e_b|^2 / 2 - x . e_b),
+ * first minimum, then x -= e_idx in float32): the quantiser of Mimi.encode (mimi.py:146-153; CSM audio context, sesame.py:527-559) and of the
+ * Qwen3-TTS speech tokenizer's encoder (speech_tokenizer.py:1037-1058).  x is the PROJECTED input (after input_proj). */
+typedef struct {
+  const float* x; int64_t rows; int32_t ldx; int32_t D;      /* [rows, D] float32 */
+  const float* tables;    /* [n_layers, bins, D]  embedding = embedding_sum / max(cluster_usage, 1e-5) */
+  const float* tables_t;  /* [n_layers, D, bins]  the same values transposed (the search reads these) */
+  const float* c2;        /* [n_layers, bins]     |e|^2 / 2 */
+  int32_t bins; int32_t n_layers;
+  int32_t* codes; int32_t ld_codes;   /* [rows, ld_codes >= n_layers] */
+  float* margins;                     /* nullable, same layout as codes: second-best score - best score of every decision */
+} mi355_rvq_encode_args;
+int mi355_rvq_encode(const mi355_rvq_encode_args* a, void* stream);
+
 /* Anti-aliased activation of BigVGAN (codec/models/bigvgan/resample.py:157-177 ``Activation1d`` with SnakeBeta, activation.py:27-51):
  * x [B, L, C] channels-last -> y [B, L, C]:  2x up-sampling (edge pad 5, depthwise transposed conv with the 12-tap Kaiser-sinc filter, x 2, trimmed
  * to 2L: resample.py:101-136), a = u + inv_beta[c] * sin^2(alpha[c] * u), 2x down-sampling (edge pad 5 / 6, the 12-tap low-pass at stride 2:

@@ -1,1 +1,1 @@
-from .mimi import MimiConfig, MimiDecoder, mimi_202407  # noqa: F401
+from .mimi import Mimi, MimiConfig, MimiDecoder, MimiEncoder, mimi_202407  # noqa: F401

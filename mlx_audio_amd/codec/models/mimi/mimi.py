@@ -1,4 +1,12 @@
-"""Mimi codec decode path (RVQ codes -> 24 kHz waveform) on MI355X: host schedule over the HIP kernels.
+"""Mimi codec on MI355X: decode (RVQ codes -> 24 kHz waveform) and encode (waveform -> codes): host schedules over the HIP kernels.
+
+ENCODE (``Mimi.encode``, mimi.py:146-153; round 3 -- what CSM's audio context / ``ref_audio`` and the Qwen3-TTS tokenizer's encoder need): SeanetEncoder
+(seanet.py:118-205) -> encoder_transformer -> ConvDownsample1d -> SplitResidualVectorQuantizer.encode.  Every strided causal conv has K = 2 * stride
+(conv.py: left pad K - stride, right pad up to a whole frame), so it runs as a 2-tap conv over rows regrouped ``[L / s, s * C]`` -- a free view of a
+buffer whose length is a multiple of the stride (zero tail = the reference's "constant" right padding; ELU(0) = 0 keeps it zero through the prologue);
+the 1-channel first conv is the flattened conv of the noise convs; the quantiser is ``mi355_rvq_encode`` (residual on chip across layers).
+
+DECODE:
 
 Mirrors ``Mimi.decode`` (``codec/models/mimi/mimi.py:155-161``) -- quantizer.decode -> ConvTrUpsample1d -> decoder transformer -> SEANet
 decoder -- and the ``mimi_202407`` configuration (:36-91).  Kernel mapping:
@@ -130,6 +138,60 @@ def make_mimi_decoder_weights(cfg: MimiConfig, seed: int = 0) -> Dict[str, torch
     return w
 
 
+def make_mimi_encoder_weights(cfg: MimiConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seeded synthetic ENCODE-side parameters under the reference's module paths (SeanetEncoder, encoder_transformer, downsample, the quantiser's
+    input projections); the codebooks are the decode side's (``make_mimi_decoder_weights`` with the same seed: merge the two dicts)."""
+    g = torch.Generator().manual_seed(7000 + seed)
+    w: Dict[str, torch.Tensor] = {}
+
+    def r16(t):
+        return t.to(torch.bfloat16).to(torch.float32)
+
+    def rnd(*shape, std):
+        return r16(torch.randn(*shape, generator=g) * std)
+
+    def conv(name, cout, k, cin, bias=True, gain=1.0):
+        w[name + ".weight"] = rnd(cout, k, cin, std=gain / math.sqrt(k * cin))
+        if bias:
+            w[name + ".bias"] = rnd(cout, std=0.02)
+
+    D = cfg.dimension
+    mult = 1
+    conv("encoder.init_conv1d.conv.conv", cfg.nfilters, cfg.ksize, 1, gain=2.0)
+    for i, ratio in enumerate(reversed(cfg.ratios)):
+        dim = mult * cfg.nfilters
+        p = f"encoder.layers.{i}"
+        conv(p + ".residuals.0.block.0.conv.conv", dim // cfg.compress, cfg.residual_ksize, dim, gain=0.7)
+        conv(p + ".residuals.0.block.1.conv.conv", dim, 1, dim // cfg.compress, gain=0.7)
+        conv(p + ".downsample.conv.conv", 2 * dim, 2 * ratio, dim, gain=1.4)
+        mult *= 2
+    conv("encoder.final_conv1d.conv.conv", D, cfg.last_ksize, mult * cfg.nfilters, gain=1.4)
+    for i in range(cfg.num_layers):
+        p = f"encoder_transformer.transformer.layers.{i}."
+        w[p + "self_attn.in_proj.weight"] = rnd(3 * D, D, std=1.0 / math.sqrt(D))
+        w[p + "self_attn.out_proj.weight"] = rnd(D, D, std=1.0 / math.sqrt(D))
+        for nm in ("norm1", "norm2"):
+            w[p + nm + ".weight"] = r16(1.0 + 0.1 * torch.randn(D, generator=g))
+            w[p + nm + ".bias"] = rnd(D, std=0.05)
+        w[p + "gating.linear1.weight"] = rnd(cfg.dim_feedforward, D, std=1.0 / math.sqrt(D))
+        w[p + "gating.linear2.weight"] = rnd(D, cfg.dim_feedforward, std=1.0 / math.sqrt(cfg.dim_feedforward))
+        w[p + "layer_scale_1.scale"] = r16(0.3 + 0.05 * torch.randn(D, generator=g))
+        w[p + "layer_scale_2.scale"] = r16(0.3 + 0.05 * torch.randn(D, generator=g))
+    conv("downsample.conv.conv.conv", D, 2 * cfg.upsample_stride, D, bias=False, gain=1.0)
+    for pfx in ("quantizer.rvq_first", "quantizer.rvq_rest"):
+        conv(pfx + ".input_proj", cfg.quantizer_dim, 1, D, bias=False, gain=3.0 * math.sqrt(cfg.quantizer_dim))   # latents on the codebooks' scale
+    return w
+
+
+def make_pcm(batch: int, n_samples: int, seed: int = 0) -> torch.Tensor:
+    """A seeded clip [B, 1, S]: a few partials + noise, amplitude ~0.3."""
+    g = torch.Generator().manual_seed(9000 + seed)
+    t = torch.arange(n_samples, dtype=torch.float32) / 24000.0
+    f = 110.0 + 400.0 * torch.rand(batch, 4, generator=g)
+    x = (torch.sin(2 * math.pi * f[:, :, None] * t[None, None, :]) * torch.tensor([0.2, 0.1, 0.05, 0.03])[None, :, None]).sum(1)
+    return (x + 0.02 * torch.randn(batch, n_samples, generator=g))[:, None, :].contiguous()
+
+
 def make_codes(batch: int, n_frames: int, cfg: MimiConfig, seed: int = 0) -> torch.Tensor:
     g = torch.Generator().manual_seed(3000 + seed)
     return torch.randint(0, cfg.quantizer_bins, (batch, cfg.quantizer_nq, n_frames), generator=g, dtype=torch.int64)
@@ -227,3 +289,130 @@ class MimiDecoder:
         self._conv(x, self.final_conv, out, elu=True)
         audio = out.transpose(1, 2)
         return (audio, st) if return_stages else audio
+
+
+class MimiEncoder:
+    """``Mimi.encode`` (mimi.py:146-153): pcm [B, 1, S] float -> codes int64 [B, nq, ceil(S / 1920)].  ``return_margins=True`` adds the gap between the best and
+    the second-best codeword score of every decision ([B, nq, T] float32: a code whose gap is at float32 rounding level is a knife edge)."""
+
+    def __init__(self, weights: Dict[str, torch.Tensor], cfg: MimiConfig, device="cuda:0", precision: int = 2):
+        ops.require_gpu()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.precision = precision
+        dev = self.device
+        w = {k: v.detach().to(torch.float32).cpu().to(torch.bfloat16).to(torch.float32) for k, v in weights.items() if v.is_floating_point()}
+
+        def conv(name):
+            return ops.pack_conv(w[name + ".weight"], w.get(name + ".bias"), dev)
+
+        def strided(name, stride):  # K = 2 * stride taps of C channels -> 2 taps of stride * C channels (rows regrouped)
+            wt = w[name + ".weight"]
+            cout, k, cin = wt.shape
+            assert k == 2 * stride, (name, k, stride)
+            return ops.pack_conv(wt.reshape(cout, 2, stride * cin).contiguous(), w.get(name + ".bias"), dev)
+
+        w0 = w["encoder.init_conv1d.conv.conv.weight"]  # (nfilters, K, 1): flattened conv over the contiguous samples
+        self.init_k = w0.shape[1]
+        self.init_conv = ops.pack_conv(w0.reshape(w0.shape[0], 1, self.init_k).contiguous(), w.get("encoder.init_conv1d.conv.conv.bias"), dev)
+        self.layers = []
+        for i, ratio in enumerate(reversed(cfg.ratios)):
+            p = f"encoder.layers.{i}"
+            self.layers.append(dict(ratio=ratio, c0=conv(p + ".residuals.0.block.0.conv.conv"), c1=conv(p + ".residuals.0.block.1.conv.conv"),
+                                    down=strided(p + ".downsample.conv.conv", ratio)))
+        self.final_conv = conv("encoder.final_conv1d.conv.conv")
+        self.stack = TransformerStack(canonical_stack_weights(w, "encoder_transformer.transformer.", cfg), mimi_stack_config(cfg), device=dev,
+                                      precision=precision)
+        self.down = strided("downsample.conv.conv.conv", cfg.upsample_stride)
+        self.rvq = []
+        for pfx, n in (("quantizer.rvq_first", 1), ("quantizer.rvq_rest", cfg.quantizer_nq - 1)):
+            if n <= 0:
+                continue
+            tabs = []
+            for i in range(n):
+                c = f"{pfx}.vq.layers.{i}.codebook"
+                tabs.append(w[c + ".embedding_sum"] / torch.clamp(w[c + ".cluster_usage"], min=1e-5)[:, None])  # quantization.py:26-30
+            t = torch.stack(tabs, 0).contiguous()
+            self.rvq.append((t.to(dev), t.transpose(1, 2).contiguous().to(dev), ((t * t).sum(-1) / 2).contiguous().to(dev), conv(pfx + ".input_proj"), n))
+
+    def _z(self, *shape):
+        return torch.zeros(shape, dtype=torch.float32, device=self.device)
+
+    def latent(self, pcm: torch.Tensor, return_stages: bool = False):
+        cfg, prec = self.cfg, self.precision
+        x0 = pcm.to(self.device, torch.float32).reshape(pcm.shape[0], -1).contiguous()
+        B, S = x0.shape
+        st = {}
+        up = lambda n, m: (n + m - 1) // m * m
+        ratios = list(reversed(cfg.ratios))
+        L = S
+        x = self._z(B, up(L, ratios[0]), cfg.nfilters)   # rows past L stay zero: the right padding of the strided conv that reads this buffer
+        ops.conv_gemm(x0[:, :, None], self.init_conv, x, lout=L, flat=dict(ldx=1, x_off=-(self.init_k - 1), channels=1), precision=prec)
+        for i, lyr in enumerate(self.layers):
+            r, C = lyr["ratio"], x.shape[2]
+            h = self._z(B, x.shape[1], lyr["c0"].cout)
+            ops.conv_gemm(x, lyr["c0"], h, pad=lyr["c0"].k - 1, lout=L, pre_act=ACT_ELU, precision=prec)
+            ops.conv_gemm(h, lyr["c1"], x, lout=L, pre_act=ACT_ELU, res=x, precision=prec)
+            Ln = x.shape[1] // r
+            nxt_r = ratios[i + 1] if i + 1 < len(ratios) else 1
+            y = self._z(B, up(Ln, nxt_r), lyr["down"].cout)
+            ops.conv_gemm(x.view(B, Ln, r * C), lyr["down"], y, pad=1, lout=Ln, pre_act=ACT_ELU, precision=prec)   # K = 2 r, stride r as 2 taps of r rows
+            x, L = y, Ln
+            if return_stages:
+                st[f"layer{i}"] = x[:, :L].clone()   # the next resblock updates this buffer in place
+        t = self._z(B, L, cfg.dimension)
+        ops.conv_gemm(x, self.final_conv, t, pad=self.final_conv.k - 1, lout=L, pre_act=ACT_ELU, precision=prec)
+        st["seanet"] = t
+        t = self.stack(t.clone() if return_stages else t)
+        st["transformer"] = t
+        # ConvDownsample1d (conv.py:333-355): K = 2 s, stride s, "edge" padding: K - s copies of the first row in front, copies of the last row up to a whole frame
+        s = cfg.upsample_stride
+        T2 = (L + s - 1) // s
+        buf = torch.empty((B, s * (T2 + 1), cfg.dimension), dtype=torch.float32, device=self.device)
+        buf[:, :s] = t[:, :1]
+        buf[:, s:s + L] = t
+        if s + L < buf.shape[1]:
+            buf[:, s + L:] = t[:, L - 1:L]
+        z = self._z(B, T2, cfg.dimension)
+        ops.conv_gemm(buf.view(B, T2 + 1, s * cfg.dimension), self.down, z, pad=0, lout=T2, precision=prec)
+        st["latent"] = z
+        return (z, st) if return_stages else z
+
+    def quantize(self, z: torch.Tensor, return_margins: bool = False):
+        B, T, _ = z.shape
+        codes, margins = [], []
+        for tables, tables_t, c2, proj, n in self.rvq:
+            zp = torch.empty((B, T, proj.cout), dtype=torch.float32, device=self.device)
+            ops.conv_gemm(z, proj, zp, precision=self.precision)
+            out = ops.rvq_encode(zp.view(B * T, proj.cout), tables, tables_t, c2, margins=return_margins)
+            c, m = out if return_margins else (out, None)
+            codes.append(c.view(B, T, n).permute(0, 2, 1))
+            if return_margins:
+                margins.append(m.view(B, T, n).permute(0, 2, 1))
+        codes = torch.cat(codes, 1).to(torch.int64)
+        return (codes, torch.cat(margins, 1)) if return_margins else codes
+
+    def __call__(self, pcm: torch.Tensor, return_margins: bool = False):
+        return self.quantize(self.latent(pcm), return_margins)
+
+
+class Mimi:
+    """Both halves behind the reference's surface (``encode`` / ``decode`` / ``sample_rate`` / ``frame_rate``, mimi.py:146-161, 184-190): the object CSM
+    holds as ``_audio_tokenizer``.  Calling it decodes (the decode-only object's contract in this package)."""
+
+    def __init__(self, weights: Dict[str, torch.Tensor], cfg: MimiConfig, device="cuda:0", precision: int = 2):
+        self.cfg = cfg
+        self.decoder = MimiDecoder(weights, cfg, device=device, precision=precision)
+        self.encoder = MimiEncoder(weights, cfg, device=device, precision=precision) if "encoder.init_conv1d.conv.conv.weight" in weights else None
+        self.sample_rate, self.frame_rate = cfg.sample_rate, cfg.frame_rate
+        if self.encoder is None:
+            self.encode = None   # a checkpoint without the encoder half: callers probe ``getattr(tokenizer, "encode", None)``
+
+    def encode(self, pcm: torch.Tensor) -> torch.Tensor:
+        return self.encoder(pcm)
+
+    def decode(self, codes: torch.Tensor) -> torch.Tensor:
+        return self.decoder(codes)
+
+    def __call__(self, codes: torch.Tensor, **kw):
+        return self.decoder(codes, **kw)

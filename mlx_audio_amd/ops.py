@@ -516,6 +516,20 @@ def fake_quant_u8(x: torch.Tensor, y: Optional[torch.Tensor] = None, *, lens=Non
     return y
 
 
+def rvq_encode(x: torch.Tensor, tables: torch.Tensor, tables_t: torch.Tensor, c2: torch.Tensor, margins: bool = False):
+    """Residual VQ encode of the projected frames ``x`` [rows, D] over ``tables`` [n, bins, D] (+ transposed copy [n, D, bins] and |e|^2 / 2 [n, bins]):
+    codes int32 [rows, n] (and the best-vs-second score gaps when ``margins``)."""
+    assert x.dim() == 2 and x.stride(1) == 1 and tables.is_contiguous() and tables_t.is_contiguous() and c2.is_contiguous()
+    rows, D = x.shape
+    n, bins, D2 = tables.shape
+    assert D2 == D and tuple(tables_t.shape) == (n, D, bins) and tuple(c2.shape) == (n, bins)
+    codes = torch.empty((rows, n), dtype=torch.int32, device=x.device)
+    mg = torch.empty((rows, n), dtype=torch.float32, device=x.device) if margins else None
+    _lib.call_struct("mi355_rvq_encode", "mi355_rvq_encode_args", _stream(), x=_ptr(x), rows=rows, ldx=x.stride(0), D=D, tables=_ptr(tables), tables_t=_ptr(tables_t),
+                     c2=_ptr(c2), bins=bins, n_layers=n, codes=_ptr(codes), ld_codes=n, margins=_ptr(mg))
+    return (codes, mg) if margins else codes
+
+
 def fake_quant_extrema(x: torch.Tensor, *, lens=None, pre=None, pre_act: int = ACT_NONE, pre_slope: float = 0.0,
                        pre_alpha: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Extrema pass alone: ``[B, 2]`` = {-min, max} of ``act(scale * x + shift)`` per utterance (joined with 0) for ``conv_gemm(pre_fq=...)``,

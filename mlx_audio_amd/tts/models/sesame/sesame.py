@@ -7,9 +7,10 @@ presets, sesame.py:165-299), checkpoint key handling (``sanitize`` :577-604), th
 [n, 33] tokens + mask, text in the last column), the 2048-position guard, sampler defaults (temperature 0.9, top-k 50), the generator protocol
 and ``GenerationResult`` fields.
 
-Not in this build (raise, never silently degrade): audio context (``context`` segments with audio, ``ref_audio``, named voices / the default
-voice prompt) -- they need the Mimi ENCODER and the hub; watermarking (``silentcipher`` is an optional dependency the
-reference also skips when it is missing, sesame.py:471-474).  Without context the model speaks in an unprompted voice.  The Mimi decoder is reset
+Audio context (``context`` segments with audio, ``ref_audio`` + ``ref_text``) runs through the Mimi ENCODER (``codec.models.mimi.MimiEncoder``, round 3)
+when the Mimi checkpoint carries the encoder half (``encoder.*``, ``encoder_transformer.*``, ``downsample.*``, the quantiser's ``input_proj``); a
+decode-only checkpoint raises.  Not in this build (raise, never silently degrade): named voices / the default voice prompt (they are downloaded from
+the hub); watermarking (``silentcipher`` is an optional dependency the reference also skips when it is missing, sesame.py:471-474).  The Mimi decoder is reset
 per utterance (the reference's non-streaming path inherits state from the previous call, sesame.py:786-788: documented difference).
 """
 from __future__ import annotations
@@ -97,7 +98,7 @@ class Model:
         self._default_voice_match = bool(config.get("voice_match", True))
         self.tokenizer_repo = config.get("text_tokenizer")
         self._text_tokenizer = None   # post_load_hook / first use: AutoTokenizer on config["text_tokenizer"] or the model directory
-        self._audio_tokenizer = None  # MimiDecoder (decode side only)
+        self._audio_tokenizer = None  # codec.models.mimi.Mimi (decode; encode when the checkpoint has the encoder half)
         self._watermarker = None
         self._sample_rate = 24000
         self.model = None             # CSMEngine, built by load_weights
@@ -156,14 +157,15 @@ class Model:
         if model._audio_tokenizer is None and mimi_dir.exists():
             from safetensors.torch import load_file
 
-            from ....codec.models.mimi.mimi import MimiConfig, MimiDecoder, mimi_202407
+            from ....codec.models.mimi.mimi import Mimi, MimiConfig, mimi_202407
 
             w: Dict[str, torch.Tensor] = {}
             for f in sorted(mimi_dir.glob("*.safetensors")):
                 w.update(load_file(str(f)))
             mcfg = model.config.get("audio_tokenizer_config")  # optional explicit sizes; the reference always loads mimi_202407(32) (mimi.py:36-91)
             mcfg = MimiConfig(**mcfg) if mcfg else mimi_202407(model.cfg.audio_num_codebooks)
-            model._audio_tokenizer = MimiDecoder(w, mcfg, device=model.device, precision=model.precision)
+            # both halves when the checkpoint carries the encoder (audio context / ref_audio need ``encode``); calling the object decodes
+            model._audio_tokenizer = Mimi(w, mcfg, device=model.device, precision=model.precision)
         return model
 
     # ------------------------------------------------------------------ prompt frames
@@ -182,11 +184,11 @@ class Model:
 
     def _tokenize_audio(self, audio, add_eos: bool = True):
         """``sesame.py:527-559``: codes (K, T) of the audio tokenizer's ``encode`` -> (tokens int32 [T (+1), 33], mask) with the codes in the first K
-        columns and, with ``add_eos``, one all-zero frame appended.  The Mimi *encoder* is not part of this build: the method works with any object that
-        offers ``encode(audio[1, 1, samples]) -> [1, K, T]`` as ``_audio_tokenizer`` (the reference's contract) and says so otherwise."""
+        columns and, with ``add_eos``, one all-zero frame appended.  ``_audio_tokenizer`` is any object with the reference's contract
+        ``encode(audio[1, 1, samples]) -> [1, K, T]`` (``codec.models.mimi.Mimi`` when the checkpoint has the encoder half)."""
         enc = getattr(self._audio_tokenizer, "encode", None)
         if enc is None:
-            raise NotImplementedError("audio context needs the Mimi encoder (codec/models/mimi encode side), which this build does not ship")
+            raise NotImplementedError("audio context needs the Mimi encoder: the loaded Mimi checkpoint has no encoder half (encoder.* / encoder_transformer.* / downsample.*)")
         codes = torch.as_tensor(enc(audio[None, None, ...]))[0].to(torch.int32).cpu()
         K = self._frame_size - 1
         if codes.shape[0] != K:
@@ -248,7 +250,7 @@ class Model:
         context = list(context or [])
         has_encoder = getattr(self._audio_tokenizer, "encode", None) is not None
         if ref_audio is not None and not has_encoder or any(s.audio is not None for s in context) and not has_encoder:
-            raise NotImplementedError("voice prompts / reference audio need the Mimi encoder, which this build does not ship")
+            raise NotImplementedError("voice prompts / reference audio need the Mimi encoder: the loaded Mimi checkpoint has no encoder half")
         if ref_audio is not None and isinstance(ref_audio, (str, os.PathLike)):
             from ....utils import load_audio
 

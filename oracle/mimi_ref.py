@@ -1,4 +1,4 @@
-"""PyTorch-CPU restatement of the Mimi codec DECODE path (TEST ORACLE, not product).
+"""PyTorch-CPU restatement of the Mimi codec DECODE and ENCODE paths (TEST ORACLE, not product).
 
 Follows ``codec/models/mimi`` of the reference:
   * ``mimi.py:36-91``            mimi_202407 configuration (SEANet ratios [8,6,5,4], 64 filters, 8-layer transformer d 512 / 8 heads /
@@ -16,6 +16,10 @@ causal convolutions, which is what the product computes in one batch per utteran
 Parity status: **pinned to the reference's own modules** (round 2): tests/golden/make_reference_fixtures.py runs the reference's source files for
 Mimi (imported from /root/reference, unmodified, over the numpy stand-in for MLX in tests/golden/mlx_shim.py) on a seeded tiny checkpoint, and
 tests/test_reference_fixtures_cpu.py holds this oracle to the result -- ``Mimi.decode`` and frame-by-frame ``decode_step`` (30 frames, attention context 20): 1e-6 of the waveform.
+The ENCODE path (``MimiEncoderRef``: mimi.py:146-153 ``Mimi.encode`` = SeanetEncoder (seanet.py:118-205: strided causal convs K = 2 * ratio) ->
+encoder_transformer -> ConvDownsample1d (conv.py:333-355: K = 2 * stride, "edge" left padding, no bias) -> SplitResidualVectorQuantizer.encode
+(quantization.py:37-45, 84-96, 125-128, 174-179: per layer argmin of |e|^2 / 2 - x . e, residual in float32)) is pinned the same way:
+``ref_mimi_encode.npz`` holds the reference's own codes and pre-quantiser latent for a seeded clip (round 3).
 The reference's own tests pin shapes / token-rule cases only (reproduced in tests/test_oracle_golden.py); MLX's kernels are not exercised by the stand-in.
 """
 from __future__ import annotations
@@ -149,3 +153,77 @@ class MimiDecoderRef:
         x = self._conv(x, "decoder.final_conv1d.conv.conv", elu=True)
         out = x.transpose(1, 2)
         return (out, st) if return_stages else out
+
+
+class MimiEncoderRef:
+    """``Mimi.encode`` (mimi.py:146-153): pcm [B, 1, S] -> codes int64 [B, nq, ceil(S / (prod(ratios) * stride))]."""
+
+    def __init__(self, weights: Dict[str, Tensor], cfg: MimiConfig, dtype=torch.float32, param_dtype=torch.bfloat16):
+        self.cfg = cfg
+        self.dtype = dtype
+        self.w = {k: v.to(param_dtype).to(dtype) for k, v in weights.items()}
+        self.stack = StackRef(canonical_stack_weights(weights, "encoder_transformer.transformer.", cfg), mimi_stack_config(cfg), dtype, param_dtype)
+
+    def _sconv(self, x: Tensor, name: str, stride: int = 1, dil: int = 1, elu: bool = False, pad_mode: str = "constant") -> Tensor:
+        """StreamableConv1d.__call__ (conv.py:213-236), causal: x [B, L, C] -> [B, ceil(L / stride), C_out]."""
+        w = self.w[name + ".weight"]  # (C_out, K, C_in)
+        k = (w.shape[1] - 1) * dil + 1
+        if elu:
+            x = F.elu(x)
+        L = x.shape[1]
+        total = k - stride
+        nframes = max(L + total - k, 0) / stride + 1.0
+        import math
+        ideal = (int(math.ceil(nframes)) - 1) * stride + k - total
+        extra = max(0, ideal - L)
+        xt = x.transpose(1, 2)
+        xp = F.pad(xt, (total, extra), mode="replicate" if pad_mode == "edge" else "constant")
+        return F.conv1d(xp, w.permute(0, 2, 1), self.w.get(name + ".bias"), stride=stride, dilation=dil).transpose(1, 2)
+
+    def _embedding(self, pfx: str) -> Tensor:
+        usage = torch.clamp(self.w[pfx + ".cluster_usage"], min=1e-5)[:, None]
+        return self.w[pfx + ".embedding_sum"] / usage
+
+    def latent(self, pcm: Tensor, return_stages: bool = False):
+        """Everything in front of the quantiser: [B, 1, S] -> [B, T, dimension]."""
+        cfg = self.cfg
+        st = {}
+        x = self._sconv(pcm.to(self.dtype).transpose(1, 2), "encoder.init_conv1d.conv.conv")
+        for i, ratio in enumerate(reversed(cfg.ratios)):
+            p = f"encoder.layers.{i}"
+            y = self._sconv(x, p + ".residuals.0.block.0.conv.conv", elu=True)
+            y = self._sconv(y, p + ".residuals.0.block.1.conv.conv", elu=True)
+            x = y + x
+            x = self._sconv(x, p + ".downsample.conv.conv", stride=ratio, elu=True)
+            st[f"layer{i}"] = x
+        x = self._sconv(x, "encoder.final_conv1d.conv.conv", elu=True)
+        st["seanet"] = x
+        x = self.stack(x)
+        st["transformer"] = x
+        x = self._sconv(x, "downsample.conv.conv.conv", stride=cfg.upsample_stride, pad_mode="edge")
+        st["latent"] = x
+        return (x, st) if return_stages else x
+
+    def quantize(self, z: Tensor, return_margins: bool = False):
+        """SplitResidualVectorQuantizer.encode on z [B, T, dimension] -> codes [B, nq, T] (and, for the margin rule of the tests, the gap between the
+        best and the second-best score of every decision)."""
+        cfg = self.cfg
+        codes, margins = [], []
+        for pfx, n in (("quantizer.rvq_first", 1), ("quantizer.rvq_rest", cfg.quantizer_nq - 1)):
+            if n <= 0:
+                continue
+            r = F.conv1d(z.transpose(1, 2), self.w[pfx + ".input_proj.weight"].permute(0, 2, 1)).transpose(1, 2).to(torch.float32)
+            for i in range(n):
+                e = self._embedding(f"{pfx}.vq.layers.{i}.codebook").to(torch.float32)
+                c2 = (e * e).sum(-1) / 2
+                score = c2[None, None, :] - r @ e.t()
+                top2 = torch.topk(score, 2, dim=-1, largest=False)
+                idx = score.argmin(-1)   # the first minimum, like mx.argmin
+                codes.append(idx)
+                margins.append(top2.values[..., 1] - top2.values[..., 0])
+                r = r - e[idx]
+        out = torch.stack(codes, 1)
+        return (out, torch.stack(margins, 1)) if return_margins else out
+
+    def __call__(self, pcm: Tensor) -> Tensor:
+        return self.quantize(self.latent(pcm))

@@ -410,6 +410,46 @@ def run_mimi(seed_w, seed_codes, n_frames):
     return dict(seed_w=seed_w, seed_codes=seed_codes, n_frames=n_frames, pcm=pcm.astype(np.float32), pcm_steps=pcm_steps.astype(np.float32))
 
 
+def run_mimi_encode(seed_w, seed_audio, n_samples):
+    """The reference's ``Mimi.encode`` (SeanetEncoder -> encoder_transformer with its KV cache -> ConvDownsample1d -> SplitResidualVectorQuantizer.encode,
+    mimi.py:146-153) on a tiny synthetic checkpoint and a seeded clip whose length is NOT a multiple of the frame size (the extra right padding of
+    every strided conv, conv.py:163-173, is on the path); also the latent in front of the quantiser and the decode of the codes (round trip)."""
+    from mlx_audio_amd.codec.models.mimi import mimi as M
+
+    rm = import_lm_and_mimi()
+    mods = sys.modules["mlx_audio.codec.models.mimi.modules"]
+    c = M.tiny_mimi_config()
+    w = {**M.make_mimi_decoder_weights(c, seed=seed_w), **M.make_mimi_encoder_weights(c, seed=seed_w)}
+    ref_cfg = rm.mimi_202407(c.quantizer_nq)
+    sc, tc = ref_cfg.seanet, ref_cfg.transformer
+    sc.dimension, sc.nfilters, sc.ratios, sc.ksize, sc.residual_ksize, sc.last_ksize, sc.compress = (c.dimension, c.nfilters, list(c.ratios), c.ksize,
+                                                                                                    c.residual_ksize, c.last_ksize, c.compress)
+    tc.d_model, tc.num_heads, tc.num_layers, tc.dim_feedforward, tc.context, tc.max_seq_len = (c.dimension, c.num_heads, c.num_layers, c.dim_feedforward,
+                                                                                                c.context, c.max_seq_len)
+    ref_cfg.quantizer_bins, ref_cfg.quantizer_dim = c.quantizer_bins, c.quantizer_dim
+    model = rm.Mimi(ref_cfg)
+    model.load_weights([(k, v.numpy()) for k, v in w.items()])
+    missing, unexpected, mism = model._load_report
+    missing = [m for m in missing if not m.endswith(".codebook.initialized")]   # a training buffer
+    assert not unexpected and not missing and not mism, (missing[:8], unexpected[:8], mism[:4])
+    for _, m in model.named_modules():
+        if isinstance(m, (mods.EuclideanCodebook, sys.modules["mlx_audio.codec.models.mimi.modules.conv"].ConvTranspose1d)):
+            m.update_in_place()
+    model.eval()
+    pcm = M.make_pcm(2, n_samples, seed=seed_audio).numpy()
+    codes = np.asarray(model.encode(mx.array(pcm)))
+    # the same three stages by hand, for the latent (encode() resets the state itself)
+    model.encoder.reset_state()
+    for cch in model.encoder_cache:
+        cch.reset() if hasattr(cch, "reset") else None
+    model.reset_state()
+    xs = model.encoder(mx.array(pcm))
+    xs = model.encoder_transformer(xs, cache=model.encoder_cache)[0]
+    z = np.asarray(model.downsample(xs))
+    back = np.asarray(model.decode(mx.array(codes.astype(np.int32))))
+    return dict(seed_w=seed_w, seed_audio=seed_audio, n_samples=n_samples, codes=codes.astype(np.int64), latent=z.astype(np.float32), decoded=back.astype(np.float32))
+
+
 def ref_qwen3_talker(seed_w):
     """The reference's ``Qwen3TTSTalkerForConditionalGeneration`` on the tiny synthetic checkpoint of this package's generator: (model, cfg, reference cfg)."""
     from dataclasses import asdict
@@ -1539,6 +1579,9 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_mimi_tiny.npz"), **mfx)
     print("mimi:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in mfx.items()},
           "decode vs decode_step max diff", float(np.abs(mfx["pcm"] - mfx["pcm_steps"]).max()), "peak", float(np.abs(mfx["pcm"]).max()))
+    mefx = run_mimi_encode(seed_w=5, seed_audio=2, n_samples=1920 * 9 + 700)
+    np.savez_compressed(os.path.join(HERE, "ref_mimi_encode.npz"), **mefx)
+    print("mimi encode:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in mefx.items()})
     qfx = run_qwen3_talker(seed_w=1, seed_in=4)
     np.savez_compressed(os.path.join(HERE, "ref_qwen3_talker_tiny.npz"), **qfx)
     print("qwen3 talker:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in qfx.items()})

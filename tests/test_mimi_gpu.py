@@ -62,3 +62,37 @@ def test_mimi_202407_reference_shape_pin_and_values():
         assert rel_peak(gst[k], est[k]) < 3e-4, (k, rel_peak(gst[k], est[k]))
     peak = float(exp.abs().max())
     assert float((got.cpu() - exp).abs().max()) <= 2e-3 * peak and snr_db(got, exp) >= 50.0
+
+
+def test_mimi_202407_encode_shape_pin_and_stages():
+    """ENCODE at the real sizes: the reference's own shape pin (codec/tests/test_mimi.py:13-18: 120 000 samples -> codes (1, 32, 63) -> audio
+    (1, 1, 120 960)) and, on a 1.2 s clip, every stage in front of the quantiser against the oracle (3e-4 of the stage's peak) + the codes under the
+    margin rule (2048-entry codebooks: near ties exist)."""
+    import _margin
+    from mlx_audio_amd.codec.models.mimi import mimi as M
+    from oracle.mimi_ref import MimiConfig as RC
+    from oracle.mimi_ref import MimiEncoderRef
+
+    cfg = M.mimi_202407(32)
+    w = {**M.make_mimi_decoder_weights(cfg, seed=0), **M.make_mimi_encoder_weights(cfg, seed=0)}
+    both = M.Mimi(w, cfg, device=DEV)
+    codes = both.encode(torch.zeros(1, 1, 120_000))
+    torch.cuda.synchronize()
+    assert tuple(codes.shape) == (1, 32, 63) and codes.dtype == torch.int64
+    assert tuple(both.decode(codes).shape) == (1, 1, 120_960)
+    pcm = M.make_pcm(2, 28_800 + 333, seed=3)
+    ref = MimiEncoderRef(w, RC(**{k: getattr(cfg, k) for k in RC.__dataclass_fields__}))
+    zr, est = ref.latent(pcm, return_stages=True)
+    z, gst = both.encoder.latent(pcm, return_stages=True)
+    torch.cuda.synchronize()
+    for k in est:
+        assert rel_peak(gst[k], est[k]) < 3e-4, (k, rel_peak(gst[k], est[k]))
+    want, wm = ref.quantize(zr, return_margins=True)
+    got, gm = both.encoder.quantize(z, return_margins=True)
+    torch.cuda.synchronize()
+    got, gm = got.cpu(), gm.cpu()
+    thr = 2e-3 * float(zr.abs().max()) * 3.0   # a latent error of 3e-4 of peak moves a score by about |e| times that
+    for b in range(got.shape[0]):
+        for t in range(got.shape[2]):
+            _margin.walk("mimi_encode", got[b, :1, t].tolist(), want[b, :1, t].tolist(), torch.minimum(gm, wm)[b, :1, t].tolist(), thr=thr, where=(b, t, 0))
+            _margin.walk("mimi_encode", got[b, 1:, t].tolist(), want[b, 1:, t].tolist(), torch.minimum(gm, wm)[b, 1:, t].tolist(), thr=thr, where=(b, t))

@@ -177,6 +177,35 @@ def test_mimi_oracle_reproduces_the_reference_modules():
         assert err < 2e-5 * max(peak, 1e-3) + 1e-7
 
 
+def test_mimi_encode_oracle_reproduces_the_reference_modules():
+    """The reference's ``Mimi.encode`` (mimi.py:146-153: SeanetEncoder with its strided causal convs, encoder_transformer, ConvDownsample1d with "edge"
+    padding, SplitResidualVectorQuantizer.encode) on a tiny synthetic checkpoint and a clip of 9 frames + 700 samples: the latent in front of the
+    quantiser to 1e-5 of its peak, every code equal (the smallest best-vs-second gap of the fixture's decisions is printed)."""
+    from dataclasses import asdict
+
+    from mlx_audio_amd.codec.models.mimi import mimi as M
+    from oracle.mimi_ref import MimiConfig as RC
+    from oracle.mimi_ref import MimiDecoderRef, MimiEncoderRef
+
+    fx = np.load(os.path.join(GOLD, "ref_mimi_encode.npz"))
+    cfg = M.tiny_mimi_config()
+    w = {**M.make_mimi_decoder_weights(cfg, seed=int(fx["seed_w"])), **M.make_mimi_encoder_weights(cfg, seed=int(fx["seed_w"]))}
+    rc = RC(**{k: v for k, v in asdict(cfg).items() if k in RC.__dataclass_fields__})
+    enc = MimiEncoderRef(w, rc, param_dtype=torch.float32)
+    pcm = M.make_pcm(2, int(fx["n_samples"]), seed=int(fx["seed_audio"]))
+    z = enc.latent(pcm)
+    want = torch.from_numpy(fx["latent"]).transpose(1, 2)
+    assert z.shape == want.shape == (2, -(-int(fx["n_samples"]) // 1920), cfg.dimension)
+    err, peak = float((z - want).abs().max()), float(want.abs().max())
+    codes, margins = enc.quantize(z, return_margins=True)
+    print(f"mimi encode oracle vs reference: latent max-abs {err:.2e} (peak {peak:.2f}), smallest decision gap {float(margins.min()):.3f}")
+    assert err < 1e-5 * peak
+    assert np.array_equal(codes.numpy(), fx["codes"])
+    # and the round trip through the decode oracle equals the reference's decode of its own codes
+    back = MimiDecoderRef(w, rc, param_dtype=torch.float32)(codes).numpy()
+    assert float(np.abs(back - fx["decoded"]).max()) < 2e-5 * max(float(np.abs(fx["decoded"]).max()), 1e-3) + 1e-7
+
+
 def test_qwen3_talker_oracle_reproduces_the_reference_modules():
     """The reference's talker stack (MRoPE position ids, q / k RMSNorm, GQA, SwiGLU, KV cache: talker.py:229-500) with ``codec_head`` and
     ``text_projection``, and its code predictor stepped like ``_predict_code_tokens`` (qwen3_tts.py:941-983) on forced codes: prefill + 2 cached steps."""

@@ -32,6 +32,54 @@ def _snr(got, want):
     return float(10 * np.log10((want ** 2).sum() / max(((got - want) ** 2).sum(), 1e-300)))
 
 
+def test_mimi_encoder_engine_vs_reference_run():
+    """``MimiEncoder`` (HIP) against the reference's own ``Mimi.encode`` run: the latent in front of the quantiser within 2e-4 of its peak (bf16 hi + lo
+    convs, 16 significant bits), the codes under the margin rule -- per frame the residual layers are walked in order and compared up to the first
+    decision whose best-vs-second gap (from the device kernel itself) is at rounding level -- and ``mi355_rvq_encode`` alone on the oracle's latent
+    (every code, same rule)."""
+    from dataclasses import asdict
+
+    import _margin
+    from mlx_audio_amd.codec.models.mimi import mimi as M
+    from oracle.mimi_ref import MimiConfig as RC
+    from oracle.mimi_ref import MimiEncoderRef
+
+    fx = np.load(os.path.join(GOLD, "ref_mimi_encode.npz"))
+    cfg = M.tiny_mimi_config()
+    w = {**M.make_mimi_decoder_weights(cfg, seed=int(fx["seed_w"])), **M.make_mimi_encoder_weights(cfg, seed=int(fx["seed_w"]))}
+    eng = M.MimiEncoder(w, cfg, device=DEV)
+    pcm = M.make_pcm(2, int(fx["n_samples"]), seed=int(fx["seed_audio"]))
+    z, st = eng.latent(pcm, return_stages=True)
+    torch.cuda.synchronize()
+    want = torch.from_numpy(fx["latent"]).transpose(1, 2)
+    err, peak = float((z.cpu() - want).abs().max()), float(want.abs().max())
+    print(f"mimi encoder HIP vs reference run: latent max-abs {err:.2e} (peak {peak:.2f})")
+    assert z.shape == want.shape and err <= 2e-4 * peak
+    codes, margins = eng(pcm, return_margins=True)
+    torch.cuda.synchronize()
+    codes, margins = codes.cpu(), margins.cpu()
+    assert codes.dtype == torch.int64 and tuple(codes.shape) == fx["codes"].shape
+    for b in range(codes.shape[0]):
+        for t in range(codes.shape[2]):
+            _margin.walk("mimi_encode", codes[b, 1:, t].tolist(), fx["codes"][b, 1:, t].tolist(), margins[b, 1:, t].tolist(), thr=1e-2 * peak, where=(b, t))
+            _margin.walk("mimi_encode", codes[b, :1, t].tolist(), fx["codes"][b, :1, t].tolist(), margins[b, :1, t].tolist(), thr=1e-2 * peak, where=(b, t, "first"))
+    # the search kernel alone, fed the oracle's latent: no conv error in front of it
+    rc = RC(**{k: v for k, v in asdict(cfg).items() if k in RC.__dataclass_fields__})
+    zr = MimiEncoderRef(w, rc, param_dtype=torch.float32).latent(pcm)
+    c2, m2 = eng.quantize(zr.to(DEV), return_margins=True)
+    torch.cuda.synchronize()
+    clear = m2.cpu() > 1e-3
+    assert bool(clear.float().mean() > 0.9) and bool((c2.cpu()[clear] == torch.from_numpy(fx["codes"])[clear]).all())
+    # Mimi (both halves): encode -> decode round trip has the clip's length rounded up to whole frames
+    both = M.Mimi(w, cfg, device=DEV)
+    audio = both.decode(both.encode(pcm))
+    torch.cuda.synchronize()
+    assert tuple(audio.shape) == (2, 1, 1920 * codes.shape[2]) and bool(torch.isfinite(audio).all())
+    got, ref = audio.cpu().numpy(), fx["decoded"]
+    if np.array_equal(codes.numpy(), fx["codes"]):
+        assert float(np.abs(got - ref).max()) <= 2e-3 * float(np.abs(ref).max())
+
+
 def test_mimi_engine_vs_reference_run():
     from mlx_audio_amd.codec.models.mimi import mimi as M
 

@@ -349,3 +349,39 @@ def test_csm_load_model_and_generate(csm_ckpt):
     model._use_default_voice_prompt = True
     with pytest.raises(NotImplementedError):
         list(model.generate(text, voice="conversational_a"))
+
+
+def test_csm_audio_context_through_the_mimi_encoder(csm_ckpt, tmp_path):
+    """A Mimi checkpoint WITH the encoder half: ``_tokenize_audio`` (sesame.py:527-559) encodes the clip on the device (``codec.models.mimi.MimiEncoder``),
+    its codes equal the oracle's ``Mimi.encode`` under the margin rule, and ``generate(ref_audio=..., ref_text=...)`` / ``context=[Segment(audio=...)]``
+    run with the clip's frames in the prompt (the decode-only checkpoint of the test above refuses)."""
+    import shutil
+
+    from mlx_audio_amd.codec.models.mimi import mimi as M
+    from mlx_audio_amd.tts.models.sesame.sesame import Segment
+    from mlx_audio_amd.tts.utils import load_model
+    from oracle.mimi_ref import MimiConfig as RMimiConfig, MimiEncoderRef
+
+    c = csm_ckpt
+    root = tmp_path / "csm_enc"
+    shutil.copytree(c["path"], root)
+    mw = {**c["mw"], **M.make_mimi_encoder_weights(c["mcfg"], seed=6)}
+    save_file({k: v.contiguous() for k, v in mw.items()}, str(root / "mimi" / "model.safetensors"))
+    model = load_model(root, device=DEV)
+    model._text_tokenizer = FakeTokenizer(c["cfg"].text_vocab_size)
+    K = c["cfg"].audio_num_codebooks
+    clip = M.make_pcm(1, 1920 * 3 + 500, seed=4)[0, 0]
+    frame, mask = model._tokenize_audio(clip.to(DEV))
+    assert frame.shape == (5, K + 1) and mask.shape == frame.shape            # 4 frames (3 whole + 1 padded) + the all-zero EOS frame
+    assert bool(mask[:, :K].all()) and not bool(mask[:, K].any()) and int(frame[-1].abs().sum()) == 0
+    names = set(RMimiConfig.__dataclass_fields__)
+    enc = MimiEncoderRef(mw, RMimiConfig(**{k: v for k, v in asdict(c["mcfg"]).items() if k in names}))
+    want, margins = enc.quantize(enc.latent(clip[None, None]), return_margins=True)
+    for t in range(4):
+        _margin.walk("mimi_encode", frame[t, :1].tolist(), want[0, :1, t].tolist(), margins[0, :1, t].tolist(), thr=0.05, where=("csm ctx", t, 0))
+        _margin.walk("mimi_encode", frame[t, 1:K].tolist(), want[0, 1:, t].tolist(), margins[0, 1:, t].tolist(), thr=0.05, where=("csm ctx", t))
+    frames = 3
+    a = list(model.generate("hi there", speaker=0, temperature=0.0, max_audio_length_ms=frames * 80, ref_audio=clip.to(DEV), ref_text="before"))
+    b = list(model.generate("hi there", speaker=0, temperature=0.0, max_audio_length_ms=frames * 80,
+                            context=[Segment(speaker=0, text="before", audio=clip.to(DEV))]))
+    assert len(a) == len(b) == 1 and a[0].samples == a[0].audio.shape[0] > 0 and torch.equal(a[0].audio, b[0].audio)   # ref_audio IS the first segment (sesame.py:753-755)
