@@ -713,6 +713,7 @@ typedef struct {
   const float* s_qkv; const float* s_o; const float* s_in; const float* s_out; const float* s_cq; const float* s_co;
   /* steps for 9..64 sequences: tile images (mi355_pack_tiles16_host) of the four projections; null = this layer only runs steps of <= 8 sequences */
   const uint16_t* wqkv_t; const uint16_t* wo_t; const uint16_t* w_in_t; const uint16_t* w_out_t;
+  const uint16_t* wcq_t; const uint16_t* wco_t;   /* ... and of the cross-attention projections (Whisper decoder at 9..64 windows per step) */
 } mi355_layer_desc;
 
 typedef struct {

@@ -105,11 +105,14 @@ int tall_step(const mi355_stack_desc& d, float* x, int B, int offset, float* ws,
   for (int i = 0; i < d.n_layers; ++i) {
     const mi355_layer_desc& L = d.layers[i];
     MI355_REQUIRE(L.wqkv_t && L.wo_t && L.w_in_t && L.w_out_t && L.kv, "stack_decode_step: layer %d has no tile images (steps of 9..64 sequences)", i);
-    MI355_REQUIRE(!L.cross_k, "stack_decode_step: cross-attention layers run steps of <= 8 sequences");
+    MI355_REQUIRE(!L.cross_k || (L.wcq_t && L.wco_t && L.cross_v && L.cross_len > 0),
+                  "stack_decode_step: layer %d has cross K but no tile images of its cross projections / no V (steps of 9..64 sequences)", i);
     MI355_REQUIRE(offset < L.kv_capacity, "stack_decode_step: KV cache of layer %d is full (offset %d, capacity %d)", i, offset, L.kv_capacity);
     float* slot = (float*)((char*)L.kv + (int64_t)offset * nkv * kvsz);
     const float* vbase = (const float*)((const char*)L.kv + (int64_t)G * dh * kvsz);
-    const bool rope_in_attn = (L.q_norm || d.cos) && d.causal;
+    // causal stacks take the fused attention step (slab sums + bias + optional per-head norms / rotary embedding + cache store inside the attention
+    // launch, output as planes); a stack without norms / rotary embedding (Whisper's decoder) simply has nothing applied there
+    const bool rope_in_attn = d.causal != 0;
     MI355_REQUIRE(d.kv_dtype == MI355_KV_F32 || rope_in_attn || !(L.q_norm || d.cos),
                   "stack_decode_step: a 16-bit KV cache needs the rotary embedding inside the attention step");
     MI355_REQUIRE(!d.slot_lens_k || rope_in_attn, "stack_decode_step: slot caches need the fused attention step (per-head norms / rotary embedding, causal)");
@@ -170,9 +173,43 @@ int tall_step(const mi355_stack_desc& d, float* x, int B, int offset, float* ws,
       mi355_rows_finish_args f;
       memset(&f, 0, sizeof(f));
       f.bias = L.bo; f.colscale = L.ls1; f.res = x; f.ldr = D; f.y = x; f.ldy = D; f.wscale = fp8 ? L.s_o : nullptr;
-      f.norm = d.norm; f.norm_weight = L.mlp_norm_w; f.norm_bias = L.mlp_norm_b; f.norm_eps = d.eps; f.planes = w.px;
+      f.norm = d.norm; f.norm_eps = d.eps; f.planes = w.px;
+      f.norm_weight = L.cross_k ? L.cross_norm_w : L.mlp_norm_w;   // the planes feed the cross-attention's q projection when there is one
+      f.norm_bias = L.cross_k ? L.cross_norm_b : L.mlp_norm_b;
       rc = finish(f, D, kg);
       if (rc) return rc;
+    }
+    // ---- cross-attention (Whisper decoder): K | V precomputed once per window; q projection, attention over all cross_len keys, o-proj + residual
+    if (L.cross_k) {
+      rc = rows_gemm_call(w.px, L.wcq_t, d.wdtype, nq, D, B, R, w.part, &kg, stream);
+      if (rc) return rc;
+      {
+        mi355_rows_finish_args f;
+        memset(&f, 0, sizeof(f));
+        f.bias = L.bcq; f.y = q; f.ldy = nq; f.wscale = fp8 ? L.s_cq : nullptr;
+        rc = finish(f, nq, kg);
+        if (rc) return rc;
+      }
+      {  // >= 5 x heads (query, head) items: no key split; the output row leaves as planes for the o-proj GEMM (no converter launch)
+        mi355_flash_attn_args a;
+        memset(&a, 0, sizeof(a));
+        a.k_hstride = L.cross_hstride; a.v_hstride = L.cross_hstride;
+        a.q = q; a.q_bstride = nq; a.ldq = nq; a.k = L.cross_k; a.k_bstride = L.cross_bstride; a.ldk = L.cross_ld; a.v = L.cross_v; a.v_bstride = L.cross_bstride;
+        a.ldv = L.cross_ld; a.heads = H; a.kv_heads = G; a.dh = dh; a.Tq = 1; a.Tk = L.cross_len; a.scale = scale; a.B = B; a.mode = 2; a.nsplit = 1;
+        a.out_planes = w.pa; a.planes_R = R; a.planes_dtype = pdt; a.out_bstride = nq; a.ldo = nq; a.kv_dtype = L.cross_kv_dtype;
+        rc = mi355_flash_attention(&a, stream);
+        if (rc) return rc;
+      }
+      rc = rows_gemm_call(w.pa, L.wco_t, d.wdtype, D, nq, B, R, w.part, &kg, stream);
+      if (rc) return rc;
+      {
+        mi355_rows_finish_args f;
+        memset(&f, 0, sizeof(f));
+        f.bias = L.bco; f.res = x; f.ldr = D; f.y = x; f.ldy = D; f.wscale = fp8 ? L.s_co : nullptr;
+        f.norm = d.norm; f.norm_weight = L.mlp_norm_w; f.norm_bias = L.mlp_norm_b; f.norm_eps = d.eps; f.planes = w.px;
+        rc = finish(f, D, kg);
+        if (rc) return rc;
+      }
     }
     // ---- MLP
     // SwiGLU in the GEMM's own epilogue (one K group: a workgroup holds complete sums) saves the row-epilogue launch; worth it whenever the column
@@ -236,7 +273,7 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
                 d.rope_rows);
   // the rows pipeline also serves 5..8 sequences (16-row planes): measured faster than the 5..8-row matrix-pipe GEMV it replaces there (MI355_ROWS_MIN=9: old split)
   static const int rows_min = getenv("MI355_ROWS_MIN") ? atoi(getenv("MI355_ROWS_MIN")) : 5;
-  if ((B > 8 || B >= rows_min) && !rows_off && d.layers[0].wqkv_t && !d.layers[0].cross_k) return tall_step(d, x, B, offset, ws, out, stream);
+  if ((B > 8 || B >= rows_min) && !rows_off && d.layers[0].wqkv_t && (!d.layers[0].cross_k || d.layers[0].wcq_t)) return tall_step(d, x, B, offset, ws, out, stream);
   const int D = d.d_model, H = d.heads, G = d.kv_heads, dh = d.dh;
   const int nq = H * dh, nkv = 2 * G * dh;
   float* q = ws;                 // [B, nq]

@@ -20,6 +20,7 @@ Everything here is plumbing (allocation, views, launch order); all arithmetic on
 from __future__ import annotations
 
 import ctypes
+import os
 import math
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
@@ -79,6 +80,11 @@ class WhisperEngine:
         self.device = torch.device(device)
         self.precision = precision
         self.native_decode = True  # single-token decoder steps run through mi355_stack_decode_step
+        # windows per step from which the decoder runs on the rows pipeline (tile images x input planes; stack_step.cpp tall_step); below: the
+        # one-row-per-wave / 5..8-row matrix-pipe GEMV kernels.  MI355_WHISPER_ROWS_MIN: A/B knob
+        self.rows_min = int(os.environ.get("MI355_WHISPER_ROWS_MIN", "9"))
+        self._rows_ws = None
+        self._tile_images = {}
         self.dh = dims.n_audio_state // dims.n_audio_head
         assert self.dh in (64, 128) and dims.n_text_state // dims.n_text_head == self.dh
         assert max(dims.n_audio_state, dims.n_text_state) <= 1024, "layernorm kernel holds <= 1024 channels per row"
@@ -133,10 +139,11 @@ class WhisperEngine:
 
     def _linear(self, x: torch.Tensor, l: _Lin, y: torch.Tensor, post_act: int = ACT_NONE, res: Optional[torch.Tensor] = None,
                 ln: Optional[_LN] = None, y2: Optional[torch.Tensor] = None):
-        """y = act(LN(x) W^T + b) + res on [B, L, C] views; decode steps (L == 1, B <= 8) take the GEMV, which also fuses the
-        pre-LayerNorm (``ln``) and can split its columns over two destinations (``y2``: q -> y, k | v -> the KV-cache slot)."""
+        """y = act(LN(x) W^T + b) + res on [B, L, C] views; decode steps (L == 1, B <= 64) take the GEMV (1..8 rows: one row per wave / matrix-pipe
+        kernels, 9..64 rows: gemm_rows.hip), which also fuses the pre-LayerNorm (``ln``) and can split its columns over two destinations
+        (``y2``: q -> y, k | v -> the KV-cache slot)."""
         B, L, _ = x.shape
-        if L == 1 and B <= 8:
+        if L == 1 and B <= 64:
             ops.gemv(x[:, 0, :], l.rm, y[:, 0, :], post_act=post_act, res=None if res is None else res[:, 0, :],
                      norm=None if ln is None else ("layer", ln.w, ln.b, 1e-5), y2=None if y2 is None else y2[:, 0, :])
         else:
@@ -203,9 +210,11 @@ class WhisperEngine:
         return st
 
     def _native_desc(self, st: dict):
-        """C descriptor of the decoder for mi355_stack_decode_step (self-attention, cross-attention over this window's K | V, GELU MLP)."""
+        """C descriptor of the decoder for mi355_stack_decode_step (self-attention, cross-attention over this window's K | V, GELU MLP).  Steps of
+        ``rows_min`` .. 64 windows also name the tile images and the rows workspace (the rows pipeline of rows_pipe.hip)."""
         if "native" in st:
             return st["native"]
+        tall = st["B"] >= self.rows_min
         d = self.dims
         LD, SD = _lib.STRUCTS["mi355_layer_desc"], _lib.STRUCTS["mi355_stack_desc"]
         arr = (LD * d.n_text_layer)()
@@ -226,6 +235,9 @@ class WhisperEngine:
             a.cross_k, a.cross_v = ck.data_ptr(), cv.data_ptr()
             a.cross_bstride, a.cross_hstride, a.cross_ld, a.cross_len = ck.stride(0), ck.stride(1), ck.stride(2), ck.shape[2]
             a.cross_kv_dtype = ops.KV_DTYPES[ck.dtype]
+            if tall:   # tile images for the rows pipeline (steps of 5..64 windows), built once per engine
+                tl = lambda l: ops._ptr(self._tiles(l).w)
+                a.wqkv_t, a.wo_t, a.w_in_t, a.w_out_t, a.wcq_t, a.wco_t = tl(blk.qkv), tl(blk.out), tl(blk.mlp1), tl(blk.mlp2), tl(blk.cq), tl(blk.cout)
         sd = SD()
         sd.n_layers, sd.d_model, sd.heads, sd.kv_heads, sd.dh, sd.d_ff = d.n_text_layer, d.n_text_state, d.n_text_head, d.n_text_head, self.dh, 4 * d.n_text_state
         sd.norm, sd.eps, sd.glu, sd.act, sd.wdtype, sd.causal, sd.window, sd.attn_scale = 1, 1e-5, 0, ACT_GELU, 1, 1, 0, 0.0
@@ -235,8 +247,20 @@ class WhisperEngine:
         gws, gcnt = ops.gemv_split_workspace(self.device, d.n_text_state, 4 * d.n_text_state)   # mlp2 (K = 4 n_state): K split over workgroups
         sd.gemv_split_ws, sd.gemv_split_cnt = gws.data_ptr(), gcnt.data_ptr()
         sd.final_norm_w, sd.final_norm_b = p(self.ln.w), p(self.ln.b)
+        if tall:
+            if self._rows_ws is None:
+                need = int(_lib.load().mi355_stack_rows_ws_bytes(ctypes.byref(sd), 64))
+                assert need > 0
+                self._rows_ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
+            sd.rows_ws, sd.rows_ws_bytes = self._rows_ws.data_ptr(), self._rows_ws.numel()
         st["native"] = dict(arr=arr, desc=sd)
         return st["native"]
+
+    def _tiles(self, l: _Lin):
+        t = self._tile_images.get(id(l))
+        if t is None:
+            t = self._tile_images[id(l)] = ops.tiles16_from_rowmajor(l.rm)
+        return t
 
     def decoder_step(self, tokens: torch.Tensor, st: dict) -> torch.Tensor:
         """tokens int32 [B, n] (device view) appended at offset st['n'] -> final-LN hidden states [B, n, n_text_state]."""
@@ -247,7 +271,7 @@ class WhisperEngine:
         nt, H, dh = d.n_text_state, d.n_text_head, self.dh
         x = self._f(B, n, nt)
         ops.gather_rows(self.tok_emb, tokens, x, pos_table=self.pos_emb[off:off + n])
-        if n == 1 and B <= 8 and self.native_decode:  # the whole 12-layer step from the native runner: one call instead of ~100 launches from Python
+        if n == 1 and B <= 64 and self.native_decode:  # the whole 12-layer step from the native runner: one call instead of ~100 launches from Python
             nd = self._native_desc(st)
             ws = self._f(B * (2 * nt + 4 * nt + 2 * nt))
             out = self._f(B, 1, nt)
@@ -260,7 +284,7 @@ class WhisperEngine:
         mid = self._f(B, n, 4 * nt)
         for i, blk in enumerate(self.dec_blocks):
             cache = st["self_kv"][i]
-            if n == 1 and B <= 8:  # decode step: LayerNorm + q | k | v in one GEMV, k | v written straight into the cache slot
+            if n == 1 and B <= 64:  # decode step: LayerNorm + q | k | v in one GEMV, k | v written straight into the cache slot
                 self._linear(x, blk.qkv, q, ln=blk.attn_ln, y2=cache[:, off:off + 1, :])
             else:
                 h = self._lnorm(x, blk.attn_ln)

@@ -193,6 +193,74 @@ def test_kv_cache_equals_full_context(tiny):
     assert rel_peak(torch.cat(py, dim=1), inc) < 1e-6
 
 
+@pytest.mark.parametrize("B,rows_min", [(12, 9), (6, 5)])
+def test_tiny_decode_tall_batch_on_the_rows_pipeline(tiny, B, rows_min):
+    """Steps of 9..64 windows (and, with ``rows_min`` lowered, of 5..8) run the decoder on the rows pipeline -- tile images x input planes, the
+    cross-attention block included (stack_step.cpp tall_step) -- teacher-forced against the oracle like the <= 8-window test, and against the same
+    windows decoded in groups of <= 4 through the one-row kernels."""
+    from mlx_audio_amd.stt.models.whisper.engine import WhisperEngine
+
+    dims, tok = tiny["dims"], tiny["tok"]
+    eng = tiny["eng"]
+    if rows_min != eng.rows_min:
+        eng = WhisperEngine(tiny["WS"].make_whisper_weights(dims, seed=1), dims, device=DEV)
+        eng.rows_min = rows_min
+    mel = tiny["WS"].make_mel(B, seed=15, n_frames=2 * dims.n_audio_ctx)
+    suppress = [1, 2, 3, tok.sot, tok.sot_prev, tok.sot_lm, tok.no_speech, tok.transcribe, tok.translate]
+    kw = dict(sample_len=8, suppress_tokens=suppress)
+    free = tiny["ref"].decode(mel, tok, **kw, record=True)
+    sb = free["sample_begin"]
+    forced = free["tokens"][:, sb:]
+    steps = forced.shape[1]
+    exp = tiny["ref"].decode(mel, tok, **kw, forced_tokens=forced, record=True)
+    got = eng.decode(mel, tok, **kw, forced_tokens=forced[:, :steps], record=True)
+    torch.cuda.synchronize()
+    assert eng._rows_ws is not None                     # the tall path ran (it allocates the rows workspace)
+    assert torch.equal(got["tokens"].cpu(), exp["tokens"][:, :got["tokens"].shape[1]])
+    for i in range(steps):
+        e, g = exp["trace"][i], got["trace"][i]
+        err = float((g["raw"].cpu() - e["raw"]).abs().max())
+        peak = float(e["raw"].abs().max())
+        assert err <= 2e-3 * peak, (i, err, peak)
+        m = _margin(e["filtered"])
+        clear = m > 10 * err
+        if bool(clear.any()):
+            assert torch.equal(g["filtered"].cpu().argmax(-1)[clear], e["filtered"].argmax(-1)[clear]), f"step {i}"
+    np.testing.assert_allclose(got["sum_logprobs"].cpu().numpy(), exp["sum_logprobs"].numpy(), atol=1e-3 * steps)
+    # the same windows four at a time on the short path: logits of the last step agree to fp32 rounding of a different summation order
+    for b0 in range(0, B, 4):
+        part = tiny["eng"].decode(mel[b0:b0 + 4], tok, **kw, forced_tokens=forced[b0:b0 + 4, :steps], record=True)
+        torch.cuda.synchronize()
+        assert rel_peak(part["trace"][steps - 1]["raw"], got["trace"][steps - 1]["raw"][b0:b0 + 4]) < 2e-5
+
+
+def test_whisper_small_tall_batch_full_size():
+    """Whisper-small widths, 16 windows per step: three teacher-forced decode steps on the rows pipeline against the oracle."""
+    from mlx_audio_amd.stt.models.whisper import synthetic as WS
+    from mlx_audio_amd.stt.models.whisper.engine import WhisperEngine
+    from oracle.whisper_ref import TokenizerSpec, WhisperRef
+
+    dims = WS.WHISPER_SMALL
+    w = WS.make_whisper_weights(dims, seed=0)
+    eng = WhisperEngine(w, dims, device=DEV)
+    ref = WhisperRef(w, dims)
+    tok = TokenizerSpec()
+    mel1 = WS.make_mel(2, seed=9)
+    mel = mel1.repeat(8, 1, 1)                          # 16 windows: two distinct ones (the oracle encodes two)
+    kw = dict(sample_len=3, suppress_tokens=[tok.sot, tok.no_speech])
+    free = ref.decode(mel1, tok, **kw, record=True)
+    forced = free["tokens"][:, free["sample_begin"]:]
+    steps = forced.shape[1]
+    got = eng.decode(mel, tok, **kw, forced_tokens=forced.repeat(8, 1), record=True)
+    torch.cuda.synchronize()
+    assert eng._rows_ws is not None
+    for i in range(steps):
+        e, g = free["trace"][i], got["trace"][i]
+        for r in range(16):
+            err = float((g["raw"][r].cpu() - e["raw"][r % 2]).abs().max())
+            assert err <= 2e-3 * float(e["raw"].abs().max()), (i, r, err)
+
+
 def test_whisper_small_full_size():
     """BASELINE config[2] at full size (whisper-small dims, one 30 s window): encoder output and 6 teacher-forced decode
     steps against the oracle."""

@@ -25,7 +25,8 @@ sys.path.insert(0, ROOT)
 
 def main(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--batch", type=int, default=8, help="30 s windows per step")
+    ap.add_argument("--batch", type=int, default=64, help="30 s windows per step (64 = 32 minutes of audio per step; <= 8: the one-row / 5..8-row kernels, "
+                    "9..64: the rows pipeline)")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--decode-steps", type=int, default=64)
@@ -131,6 +132,29 @@ def main(argv=None):
     res["roofline"] = {"bound": "hbm", "kernel": "gemv_kernel (decode-step logits, N=51865 K=768 fp16 row-major)", "achieved": byts / (ms * 1e-3) / 1e9,
                        "peak": 8000.0, "unit": "GB/s", "frac": byts / (ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "us_per_launch": ms * 1e3,
                        "algorithmic_bytes_per_launch": byts}
+    if B > 8:
+        # the dominant kernel of a tall decode step: cross-attention of B windows x heads over 1500 cached keys (K | V in the checkpoint's 16-bit type,
+        # head-major): every step streams 2 x B x 1500 x n_state values per layer -- bytes that no batching amortises
+        Hh, dh, Tc = dims.n_text_head, nt // dims.n_text_head, dims.n_audio_ctx
+        ck = torch.randn(B, Hh, Tc, dh, device=dev).to(eng.kv_dtype)
+        cv = torch.randn(B, Hh, Tc, dh, device=dev).to(eng.kv_dtype)
+        qx = torch.randn(B, 1, nt, device=dev)
+        ax = torch.empty(B, 1, nt, device=dev)
+        for _ in range(3):
+            ops.flash_attention(qx, ck, cv, ax, heads=Hh, dh=dh, scale=dh ** -0.5, head_major=True)
+        c0, c1 = ev(), ev()
+        c0.record()
+        for _ in range(reps):
+            ops.flash_attention(qx, ck, cv, ax, heads=Hh, dh=dh, scale=dh ** -0.5, head_major=True)
+        c1.record()
+        torch.cuda.synchronize()
+        cms = c0.elapsed_time(c1) / reps
+        cb = 2.0 * B * Tc * nt * ck.element_size() + 8.0 * B * nt
+        res["logits_roofline"] = res["roofline"]
+        res["roofline"] = {"bound": "hbm", "kernel": "attn_decode_kernel<64, 16, 16-bit K|V> (decode-step cross-attention: %d windows x %d heads x %d keys)" % (B, Hh, Tc),
+                           "achieved": cb / (cms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": cb / (cms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                           "us_per_launch": cms * 1e3, "algorithmic_bytes_per_launch": cb,
+                           "share_of_decode_step": 12 * cms / max(dec_ms / args.decode_steps, 1e-9) if dims.n_text_layer == 12 else None}
     T, D, H = dims.n_audio_ctx, dims.n_audio_state, dims.n_audio_head
     qkv = torch.randn(B, T, 3 * D, device=dev)
     o = torch.empty(B, T, D, device=dev)
