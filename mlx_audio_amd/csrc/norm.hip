@@ -57,43 +57,48 @@ __global__ void adain_finalize_kernel(const mi355_adain_coef_args a) {
   a.shift[(int64_t)b * a.out_ld + c] = sh;
 }
 
-// AdaIN coefficients from the (sum, M2) block partials a conv_gemm epilogue wrote.  256 threads = 16 channels x 16
-// block lanes: every lane merges its share of the row blocks with Chan's parallel-variance update in float64, the 16
-// lanes of a channel are then merged through LDS.  grid (ceil(out_ld / 16), B).
+// AdaIN coefficients from the (sum, M2) block partials a conv_gemm epilogue wrote.  256 threads = 16 channels x 16 block lanes, float64
+// throughout, two sweeps over the partials (they are L2-resident: 8 bytes per block and channel): first the total sum -> the mean, then
+// M2 = sum_e [M2_e + cnt_e (mean_e - mean)^2] -- the exact decomposition of the sum of squared deviations over row blocks; no division inside
+// the sweeps (the per-block Chan update of the first version spent its time in three float64 divisions per block).  grid (ceil(out_ld / 16), B).
 __global__ __launch_bounds__(256) void adain_from_partials_kernel(const mi355_adain_partials_args a) {
-  __shared__ double red[3][16][17];
+  __shared__ double red[16][17];
   const int cl = threadIdx.x & 15, eg = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl, b = blockIdx.y;
   const int len = a.lens ? a.lens[b] : a.L;
   const int nblk = (len + MI355_STATS_ROWS - 1) / MI355_STATS_ROWS;
-  double n = 0.0, mean = 0.0, m2 = 0.0;
-  if (c < a.C) {
-    const float* pb = a.partials + (int64_t)b * a.bstride + (int64_t)c * 2;
+  const bool cok = c < a.C;
+  const float* pb = a.partials + (int64_t)b * a.bstride + (int64_t)(cok ? c : 0) * 2;
+  double s = 0.0;
+  if (cok)
+    for (int e = eg; e < nblk; e += 16) s += (double)pb[(int64_t)e * a.C * 2];
+  red[cl][eg] = s;
+  __syncthreads();
+  double tot = 0.0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) tot += red[cl][j];   // every lane of a channel adds the 16 shares in the same order: one value per channel
+  const double mean = len > 0 ? tot / (double)len : 0.0;
+  __syncthreads();
+  double m2 = 0.0;
+  if (cok) {
+    const double inv_full = 1.0 / (double)MI355_STATS_ROWS;
     for (int e = eg; e < nblk; e += 16) {
       const float2 sv = *(const float2*)(pb + (int64_t)e * a.C * 2);
-      const double cnt = (double)min(MI355_STATS_ROWS, len - e * MI355_STATS_ROWS);
-      const double me = (double)sv.x / cnt, d = me - mean, nt = n + cnt;
-      mean += d * cnt / nt;
-      m2 += (double)sv.y + d * d * n * cnt / nt;
-      n = nt;
+      const int cnt = min(MI355_STATS_ROWS, len - e * MI355_STATS_ROWS);
+      const double me = cnt == MI355_STATS_ROWS ? (double)sv.x * inv_full : (double)sv.x / (double)cnt;
+      const double d = me - mean;
+      m2 += (double)sv.y + d * d * (double)cnt;
     }
   }
-  red[0][cl][eg] = n; red[1][cl][eg] = mean; red[2][cl][eg] = m2;
+  red[cl][eg] = m2;
   __syncthreads();
   if (eg != 0 || c >= a.out_ld) return;
   float sc = 0.f, sh = 0.f;
-  if (c < a.C) {
-    n = 0.0; mean = 0.0; m2 = 0.0;
-    for (int j = 0; j < 16; ++j) {
-      const double cnt = red[0][cl][j];
-      if (cnt > 0.0) {
-        const double d = red[1][cl][j] - mean, nt = n + cnt;
-        mean += d * cnt / nt;
-        m2 += red[2][cl][j] + d * d * n * cnt / nt;
-        n = nt;
-      }
-    }
-    double var = n > 0.0 ? m2 / n : 0.0;
+  if (cok) {
+    double q = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) q += red[cl][j];
+    double var = len > 0 ? q / (double)len : 0.0;
     if (var < 0) var = 0;
     const float rstd = 1.0f / sqrtf((float)var + a.eps);
     float g = 0.f, be = 0.f;
