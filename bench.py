@@ -53,6 +53,7 @@ def parse():
                     help="--config whisper | qwen3 | csm on several GPUs: results (token / code sequences) back to rank 0, or kept on the rank that made them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the one-utterance-per-call leg (latency_b1): a kernel trace of the run then holds the batch's launches only")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two in-run rocprofv3 PMC passes (roofline.traffic is then null)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--shape-table", default="", help="write the per-shape conv_gemm timing table (roofline leg) to this file")
@@ -319,7 +320,7 @@ def main():
         }
     # ---- latency leg (rank 0, N=1 only): ONE canonical utterance at a time, the reference's own configuration (config[0] / [1] synthesise a single
     # sentence); median wall time of the whole request: ids -> waveform on the device, SineGen noise drawn inside, synchronised
-    if rank == 0 and world == 1 and not args.ragged:
+    if rank == 0 and world == 1 and not args.ragged and not args.no_latency and not args.pmc_child:
         ids1 = S.make_phoneme_ids(T_TOKENS - 2, seed=0)
         ref1 = voice[T_TOKENS - 3]
         fd1 = [fds[0]]
