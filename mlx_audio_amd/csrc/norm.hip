@@ -70,8 +70,15 @@ __global__ __launch_bounds__(256) void adain_from_partials_kernel(const mi355_ad
   const bool cok = c < a.C;
   const float* pb = a.partials + (int64_t)b * a.bstride + (int64_t)(cok ? c : 0) * 2;
   double s = 0.0;
-  if (cok)
-    for (int e = eg; e < nblk; e += 16) s += (double)pb[(int64_t)e * a.C * 2];
+  const int64_t estride = (int64_t)a.C * 2;
+  if (cok) {   // four independent loads in flight per lane (the sweeps are latency-bound: 8 bytes per block and channel, blocks C * 8 bytes apart)
+    int e = eg;
+    for (; e + 48 < nblk; e += 64) {
+      const float v0 = pb[(int64_t)e * estride], v1 = pb[(int64_t)(e + 16) * estride], v2 = pb[(int64_t)(e + 32) * estride], v3 = pb[(int64_t)(e + 48) * estride];
+      s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+    }
+    for (; e < nblk; e += 16) s += (double)pb[(int64_t)e * estride];
+  }
   red[cl][eg] = s;
   __syncthreads();
   double tot = 0.0;
@@ -82,13 +89,19 @@ __global__ __launch_bounds__(256) void adain_from_partials_kernel(const mi355_ad
   double m2 = 0.0;
   if (cok) {
     const double inv_full = 1.0 / (double)MI355_STATS_ROWS;
-    for (int e = eg; e < nblk; e += 16) {
-      const float2 sv = *(const float2*)(pb + (int64_t)e * a.C * 2);
+    auto term = [&](const float2 sv, const int e) {
       const int cnt = min(MI355_STATS_ROWS, len - e * MI355_STATS_ROWS);
       const double me = cnt == MI355_STATS_ROWS ? (double)sv.x * inv_full : (double)sv.x / (double)cnt;
       const double d = me - mean;
-      m2 += (double)sv.y + d * d * (double)cnt;
+      return (double)sv.y + d * d * (double)cnt;
+    };
+    int e = eg;
+    for (; e + 48 < nblk; e += 64) {
+      const float2 v0 = *(const float2*)(pb + (int64_t)e * estride), v1 = *(const float2*)(pb + (int64_t)(e + 16) * estride);
+      const float2 v2 = *(const float2*)(pb + (int64_t)(e + 32) * estride), v3 = *(const float2*)(pb + (int64_t)(e + 48) * estride);
+      m2 += (term(v0, e) + term(v1, e + 16)) + (term(v2, e + 32) + term(v3, e + 48));
     }
+    for (; e < nblk; e += 16) m2 += term(*(const float2*)(pb + (int64_t)e * estride), e);
   }
   red[cl][eg] = m2;
   __syncthreads();

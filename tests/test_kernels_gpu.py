@@ -290,7 +290,9 @@ def test_conv_gemm_quantising_prologue(ops, tile, act):
 @pytest.mark.parametrize("cin,cout,k,s,L,row_off,tile", [(128, 16, 8, 4, 700, 0, 6128064), (128, 16, 8, 4, 700, 1, 0), (512, 256, 20, 10, 53, 0, 0), (256, 128, 12, 6, 130, 1, 0), (64, 32, 4, 2, 9, 0, 0),
                                                          (512, 256, 20, 10, 153, 0, 6128128), (256, 128, 12, 6, 330, 1, 6128128),
                                                          (512, 256, 20, 10, 153, 0, 86128128), (256, 128, 12, 6, 330, 1, 86128128),
-                                                         (512, 256, 20, 10, 53, 0, 2064128), (256, 128, 12, 6, 130, 1, 42064128)])
+                                                         (512, 256, 20, 10, 53, 0, 2064128), (256, 128, 12, 6, 130, 1, 42064128),
+                                                         # long enough for interior tiles: the polyphase fast epilogue (conv_epilogue_interior_up)
+                                                         (512, 256, 20, 10, 700, 0, 6128128), (256, 128, 12, 6, 1500, 1, 0), (128, 64, 8, 4, 900, 0, 6128128)])
 def test_conv_transpose_polyphase(ops, cin, cout, k, s, L, row_off, tile):
     g = torch.Generator().manual_seed(k * s)
     p = (k - s) // 2
