@@ -216,6 +216,10 @@ typedef struct {
   int32_t quant_h;  /* 1: the recurrent product sees fake_quant_dynamic_u8(h) of each step's hidden vector; the emitted h is not quantised
                      * (KittenTTS LSTM with activation_quant, kitten_tts/modules.py:178,224) */
   int32_t wh_f16;   /* 1: wh holds IEEE half values (mi355_pack_lstm_wh16_host with f16 = 1: float32 checkpoints, 11 significant bits); 0: bf16 */
+  float wh_scale;   /* with wh_f16: the packed values are W / wh_scale (wh_scale a power of two; 0 = 1): the recurrent sum is multiplied by it.  A bf16
+                     * checkpoint scaled by 2^k into the normal range of IEEE half is held EXACTLY (8 significant bits), every fp32 product and sum is
+                     * the unscaled one times 2^k, so the result is bit-identical to the bf16 image's -- at half the VALU work (v_fma_mix_f32 reads a
+                     * half operand directly; a bf16 pair costs a shift / mask per weight on top of the FMA) */
 } mi355_lstm_args;
 int mi355_lstm_bidir(const mi355_lstm_args* a, void* stream);
 int mi355_pack_lstm_wh_host(const float* wh_fwd_host, const float* wh_bwd_host, int32_t H, uint16_t* out_host);

@@ -44,6 +44,7 @@ __global__ __launch_bounds__(4 * H) void lstm_kernel(const mi355_lstm_args a) {
   const float* xpb = a.xp + (int64_t)b * a.xp_bstride + (size_t)dir * G + r;
   float* ob = a.out + (int64_t)b * a.out_bstride + dir * H;
   const int gate = r / H;
+  const float wsc = (F16 && a.wh_scale != 0.f) ? a.wh_scale : 1.0f;   // power of two: exact
 
   auto dot8 = [&](const uint4 w, const float* h8, float acc) {
     const float4 h0 = *(const float4*)(h8);
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(4 * H) void lstm_kernel(const mi355_lstm_args a) {
       if (i & 1) acc1 = dot8(wglb[i], hbuf + (NREG + NLDS + i) * 8, acc1);
       else acc0 = dot8(wglb[i], hbuf + (NREG + NLDS + i) * 8, acc0);
     }
-    const float pre = xpv + (acc0 + acc1);
+    const float pre = xpv + (acc0 + acc1) * wsc;
     float gv;
     if (gate == 2) gv = tanhf(pre);
     else gv = 1.0f / (1.0f + expf(-pre));

@@ -335,6 +335,25 @@ def pack_lstm_wh(wh_f: torch.Tensor, wh_b: torch.Tensor, device, f16: bool = Fal
     return torch.from_numpy(out.view(np.int16)).to(device)
 
 
+def pack_lstm_wh_scaled(wh_f: torch.Tensor, wh_b: torch.Tensor, device):
+    """bf16-valued recurrent weights as an IEEE-half image scaled by a power of two into half's normal range: (image, wh_scale) for
+    ``lstm_bidir(wh_f16=True, wh_scale=...)``, or ``None`` when some value would not be held exactly (then use the bf16 image).  Exact because a bf16
+    value has 8 significant bits and half holds 11 in its normal range; the kernel's fp32 sums then equal the bf16 image's times 2^k, bit for bit."""
+    w = torch.cat([wh_f.detach().to(torch.float32).reshape(-1), wh_b.detach().to(torch.float32).reshape(-1)]).cpu()
+    amax = float(w.abs().max())
+    if amax == 0.0 or not math.isfinite(amax):
+        return None
+    k = int(math.floor(math.log2(32768.0 / amax)))
+    ws = w * (2.0 ** k)
+    if not bool((ws.to(torch.float16).to(torch.float32) == ws).all()) or float(ws.abs().max()) > 65504.0:
+        return None
+    nz = ws[ws != 0].abs()
+    if nz.numel() and float(nz.min()) < 2.0 ** -14:      # a subnormal half would still be exact here, but fma_mix may flush it: stay in the normal range
+        return None
+    img = pack_lstm_wh(wh_f.detach().to(torch.float32) * (2.0 ** k), wh_b.detach().to(torch.float32) * (2.0 ** k), device, f16=True)
+    return img, 2.0 ** -k
+
+
 def lstm_seq(xproj: torch.Tensor, wh: RowMajor16, out: torch.Tensor, h0: Optional[torch.Tensor] = None, c0: Optional[torch.Tensor] = None):
     """Unidirectional LSTM recurrence of any hidden size (``mi355_lstm_seq``): ``xproj`` [B, T, 4H] = x @ Wx^T + b (gate order i | f | g | o), ``wh`` the
     row-major 16-bit image of Wh [4H, H], ``out`` [B, T, H].  Returns (h_T, c_T)."""
@@ -492,11 +511,13 @@ def layernorm(x: torch.Tensor, y: torch.Tensor, *, weight=None, bias=None, ada_g
     return y
 
 
-def lstm_bidir(xp: torch.Tensor, wh: torch.Tensor, H: int, out: torch.Tensor, lens=None, quant_h: bool = False, wh_f16: bool = False):
+def lstm_bidir(xp: torch.Tensor, wh: torch.Tensor, H: int, out: torch.Tensor, lens=None, quant_h: bool = False, wh_f16: bool = False,
+               wh_scale: float = 0.0):
     B, L, _, xbs, ldxp = _nlc(xp)
     _, _, _, obs, ldo = _nlc(out)
     _lib.call_struct("mi355_lstm_bidir", "mi355_lstm_args", _stream(), xp=_ptr(xp), xp_bstride=xbs, ldxp=ldxp, wh=_ptr(wh),
-                     H=H, L=L, lens=_ptr(lens), B=B, out=_ptr(out), out_bstride=obs, ldo=ldo, quant_h=int(bool(quant_h)), wh_f16=int(bool(wh_f16)))
+                     H=H, L=L, lens=_ptr(lens), B=B, out=_ptr(out), out_bstride=obs, ldo=ldo, quant_h=int(bool(quant_h)), wh_f16=int(bool(wh_f16)),
+                     wh_scale=float(wh_scale))
     return out
 
 

@@ -87,6 +87,8 @@ class _LSTM:
     hid: int
     q: bool = False  # KittenTTS: fake-quantised input and per-step hidden vector (kitten_tts/modules.py:155,178)
     f16: bool = False  # recurrent weights held as IEEE half (precision 4)
+    wh_f16: bool = False   # the image handed to the kernel is IEEE half: f16 checkpoints, or a bf16 checkpoint scaled exactly into half's normal range
+    wh_scale: float = 0.0  # ... then: the power of two the recurrent sum is multiplied by
 
 
 class _StyleBank:
@@ -251,8 +253,13 @@ class KokoroEngine:
         b = torch.cat([self._q(self._t(f"{pre}.bias_ih_forward")) + self._q(self._t(f"{pre}.bias_hh_forward")),
                        self._q(self._t(f"{pre}.bias_ih_backward")) + self._q(self._t(f"{pre}.bias_hh_backward"))])
         whf, whb = self._q(self._t(f"{pre}.Wh_forward")), self._q(self._t(f"{pre}.Wh_backward"))
+        # bf16 checkpoints: the recurrent weights as an exactly scaled IEEE-half image (v_fma_mix_f32 reads a half operand directly: half the VALU
+        # work of the bf16 image's shift / mask + FMA, bit-identical sums; MI355_LSTM_BF16=1 keeps the bf16 image: A/B aid)
+        scaled = None if (self.all_f16 or os.environ.get("MI355_LSTM_BF16")) else ops.pack_lstm_wh_scaled(whf, whb, self.dev)
+        if scaled is not None:
+            return _LSTM(ops.pack_conv(wx, b, self.dev, f16=self.all_f16), scaled[0], whf.shape[1], self._isq(pre), self.all_f16, True, scaled[1])
         return _LSTM(ops.pack_conv(wx, b, self.dev, f16=self.all_f16), ops.pack_lstm_wh(whf, whb, self.dev, f16=self.all_f16), whf.shape[1],
-                     self._isq(pre), self.all_f16)
+                     self._isq(pre), self.all_f16, self.all_f16, 0.0)
 
     def _resblk1d(self, bank, pre, din, dout) -> _ResBlk1d:
         up = f"{pre}.pool.weight_v" in self.w
@@ -395,7 +402,7 @@ class KokoroEngine:
         if l.q:
             x = ops.fake_quant_u8(x, lens=lens)
         self._conv(x, l.wx, xp, lens_in=lens, lens_out=lens, flatten=True)
-        return ops.lstm_bidir(xp, l.wh, l.hid, out, lens=lens, quant_h=l.q, wh_f16=l.f16)
+        return ops.lstm_bidir(xp, l.wh, l.hid, out, lens=lens, quant_h=l.q, wh_f16=l.wh_f16, wh_scale=l.wh_scale)
 
     def _resblk1d_fwd(self, blk: _ResBlk1d, x, gb_all, out, lens, lens2=None):
         """x [B, L, din] -> out [B, L or 2L, dout]."""

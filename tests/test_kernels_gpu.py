@@ -452,6 +452,17 @@ def test_lstm_vs_oracle(ops, H, In, L, B):
         ref = kokoro_ref.bilstm(p, x[b:b + 1, :n].double())[0]
         assert float((out[b, :n, : 2 * H].cpu().double() - ref).abs().max()) < 5e-5
     assert float(out[:, :, 2 * H:].abs().max()) == 0.0
+    # the same bf16 weights as an IEEE-half image scaled by a power of two (what the engines hand over: half the VALU work): every fp32 product and
+    # sum is the bf16 image's times 2^k, so the output must be IDENTICAL, bit for bit, quantised hidden state or not
+    scaled = ops.pack_lstm_wh_scaled(wts["l.Wh_forward"], wts["l.Wh_backward"], DEV)
+    assert scaled is not None and scaled[1] > 0 and math.log2(scaled[1]) == round(math.log2(scaled[1]))
+    for qh in (False, True):
+        a = torch.zeros(B, L, 2 * H, device=DEV)
+        bb = torch.zeros(B, L, 2 * H, device=DEV)
+        ops.lstm_bidir(xp, wh, H, a, lens=lens_d, quant_h=qh)
+        ops.lstm_bidir(xp, scaled[0], H, bb, lens=lens_d, quant_h=qh, wh_f16=True, wh_scale=scaled[1])
+        torch.cuda.synchronize()
+        assert torch.equal(a, bb), (qh, float((a - bb).abs().max()))
     # recurrent weights as IEEE half (precision 4 of the StyleTTS engines: float32 checkpoints): fp16-representable Wh, same bars
     wts16 = dict(wts)
     for d in ("forward", "backward"):
