@@ -57,33 +57,32 @@ __global__ void adain_finalize_kernel(const mi355_adain_coef_args a) {
   a.shift[(int64_t)b * a.out_ld + c] = sh;
 }
 
-// AdaIN coefficients from the (sum, M2) block partials a conv_gemm epilogue wrote.  256 threads = 16 channels x 16 block lanes, float64
+// AdaIN coefficients from the (sum, M2) block partials a conv_gemm epilogue wrote.  256 threads = CPW channels x (256 / CPW) block lanes, float64
 // throughout, two sweeps over the partials (they are L2-resident: 8 bytes per block and channel): first the total sum -> the mean, then
 // M2 = sum_e [M2_e + cnt_e (mean_e - mean)^2] -- the exact decomposition of the sum of squared deviations over row blocks; no division inside
-// the sweeps (the per-block Chan update of the first version spent its time in three float64 divisions per block).  grid (ceil(out_ld / 16), B).
+// the sweeps.  The sweeps are latency-bound (one 8-byte read per block, blocks C * 8 bytes apart), so a workgroup takes only CPW = 4 channels and
+// spreads their blocks over 64 lanes each: 8 dependent rounds for the 495 blocks of a 31 681-row utterance instead of 31 with 16 lanes per
+// channel (17.7 -> 7 us at one utterance).  grid (ceil(out_ld / CPW), B).
+constexpr int kAdainCPW = 4, kAdainLanes = 256 / kAdainCPW;
 __global__ __launch_bounds__(256) void adain_from_partials_kernel(const mi355_adain_partials_args a) {
-  __shared__ double red[16][17];
-  const int cl = threadIdx.x & 15, eg = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl, b = blockIdx.y;
+  __shared__ double red[kAdainCPW][kAdainLanes + 1];
+  const int cl = threadIdx.x % kAdainCPW, eg = threadIdx.x / kAdainCPW;
+  const int c = blockIdx.x * kAdainCPW + cl, b = blockIdx.y;
   const int len = a.lens ? a.lens[b] : a.L;
   const int nblk = (len + MI355_STATS_ROWS - 1) / MI355_STATS_ROWS;
   const bool cok = c < a.C;
   const float* pb = a.partials + (int64_t)b * a.bstride + (int64_t)(cok ? c : 0) * 2;
-  double s = 0.0;
   const int64_t estride = (int64_t)a.C * 2;
-  if (cok) {   // four independent loads in flight per lane (the sweeps are latency-bound: 8 bytes per block and channel, blocks C * 8 bytes apart)
+  double s = 0.0;
+  if (cok) {   // two independent loads in flight per lane
     int e = eg;
-    for (; e + 48 < nblk; e += 64) {
-      const float v0 = pb[(int64_t)e * estride], v1 = pb[(int64_t)(e + 16) * estride], v2 = pb[(int64_t)(e + 32) * estride], v3 = pb[(int64_t)(e + 48) * estride];
-      s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
-    }
-    for (; e < nblk; e += 16) s += (double)pb[(int64_t)e * estride];
+    for (; e + kAdainLanes < nblk; e += 2 * kAdainLanes) s += (double)pb[(int64_t)e * estride] + (double)pb[(int64_t)(e + kAdainLanes) * estride];
+    for (; e < nblk; e += kAdainLanes) s += (double)pb[(int64_t)e * estride];
   }
   red[cl][eg] = s;
   __syncthreads();
   double tot = 0.0;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) tot += red[cl][j];   // every lane of a channel adds the 16 shares in the same order: one value per channel
+  for (int j = 0; j < kAdainLanes; ++j) tot += red[cl][j];   // every lane of a channel adds the shares in the same order: one value per channel
   const double mean = len > 0 ? tot / (double)len : 0.0;
   __syncthreads();
   double m2 = 0.0;
@@ -96,12 +95,11 @@ __global__ __launch_bounds__(256) void adain_from_partials_kernel(const mi355_ad
       return (double)sv.y + d * d * (double)cnt;
     };
     int e = eg;
-    for (; e + 48 < nblk; e += 64) {
-      const float2 v0 = *(const float2*)(pb + (int64_t)e * estride), v1 = *(const float2*)(pb + (int64_t)(e + 16) * estride);
-      const float2 v2 = *(const float2*)(pb + (int64_t)(e + 32) * estride), v3 = *(const float2*)(pb + (int64_t)(e + 48) * estride);
-      m2 += (term(v0, e) + term(v1, e + 16)) + (term(v2, e + 32) + term(v3, e + 48));
+    for (; e + kAdainLanes < nblk; e += 2 * kAdainLanes) {
+      const float2 v0 = *(const float2*)(pb + (int64_t)e * estride), v1 = *(const float2*)(pb + (int64_t)(e + kAdainLanes) * estride);
+      m2 += term(v0, e) + term(v1, e + kAdainLanes);
     }
-    for (; e < nblk; e += 16) m2 += term(*(const float2*)(pb + (int64_t)e * estride), e);
+    for (; e < nblk; e += kAdainLanes) m2 += term(*(const float2*)(pb + (int64_t)e * estride), e);
   }
   red[cl][eg] = m2;
   __syncthreads();
@@ -109,8 +107,7 @@ __global__ __launch_bounds__(256) void adain_from_partials_kernel(const mi355_ad
   float sc = 0.f, sh = 0.f;
   if (cok) {
     double q = 0.0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) q += red[cl][j];
+    for (int j = 0; j < kAdainLanes; ++j) q += red[cl][j];
     double var = len > 0 ? q / (double)len : 0.0;
     if (var < 0) var = 0;
     const float rstd = 1.0f / sqrtf((float)var + a.eps);
@@ -214,7 +211,7 @@ extern "C" int mi355_adain_from_partials(const mi355_adain_partials_args* ap, vo
   MI355_REQUIRE(a.B > 0 && a.C > 0 && a.L > 0 && a.out_ld >= a.C, "adain_from_partials: bad shape");
   MI355_CLEAR_ERROR();
   MI355_REQUIRE(a.bstride % 2 == 0 && ((uintptr_t)a.partials) % 8 == 0, "adain_from_partials: partials must be 8-byte aligned");
-  hipLaunchKernelGGL(adain_from_partials_kernel, dim3((a.out_ld + 15) / 16, a.B), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(adain_from_partials_kernel, dim3((a.out_ld + kAdainCPW - 1) / kAdainCPW, a.B), dim3(256), 0, (hipStream_t)stream, a);
   MI355_LAUNCH_CHECK("adain_from_partials");
   return MI355_OK;
 }
