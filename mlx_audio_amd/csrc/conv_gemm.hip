@@ -353,8 +353,9 @@ int split_groups(const long wgs, const int nchunks, const int K, const long rows
   if (ks <= 0) {
     // measured (profiles/r3_bench_codecs_b1_call22): between ~130 and 256 tiles two or three groups do not pay for the slab traffic and the second
     // launch (EnCodec's 512 -> 8 x 256 transposed conv at one utterance: 192 tiles, +19 % with the split) -- split only when at least half the CUs idle
-    // ... unless the K loop is deep (Kokoro's first generator stage at one utterance: 166 tiles x 88 steps, 79.5 -> 38.5 us with three groups)
-    if (forced == 0 && ((wgs > 128 && !(wgs < 256 && (long)nchunks * K >= 64)) || (long)nchunks * K < 8)) return 0;
+    // ... unless the K loop is deep enough for the cut to pay (Kokoro's first generator stage at one utterance: 166 tiles x 24 / 56 / 88 steps,
+    // 79.5 -> 38.5 us with three groups at 88 steps; the same-box A/B of call 27 showed the 192-tile / 32-step case within noise, not slower)
+    if (forced == 0 && ((wgs > 128 && !(wgs < 256 && (long)nchunks * K >= 24)) || (long)nchunks * K < 8)) return 0;
     ks = (int)((512 + wgs - 1) / wgs);
     if (ks < 2) ks = 2;
   }

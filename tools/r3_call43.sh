@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3 call 43: adain_from_partials with 64 block lanes per channel: parity of its users, one utterance per call, per-kernel time at one utterance
+# round 3 calls 43-44: adain_from_partials with 64 block lanes per channel; 44: split rule from 24 steps for 129..255 tiles
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; O=$GRAFT_REPO_ROOT/gpurun_out
 timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_kokoro_gpu.py tests/test_kitten_gpu.py tests/test_edge_cases_gpu.py -q -m gpu > $O/t_k.log 2>&1; echo "tests rc=$?" > $O/rc.txt
 timeout 900 python bench.py --no-cpu-baseline --no-pmc --no-roofline > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/rc.txt
