@@ -55,6 +55,8 @@ class MimiConfig:
     upsample_stride: int = 2
     sample_rate: int = 24000
     frame_rate: float = 12.5
+    rope_interleaved: bool = True    # Mimi: nn.RoPE(traditional=True); the Qwen3-TTS tokenizer's encoder builds the same modules with traditional=False
+    attn_window: int = -1            # -1: the ``context`` window; 0: plain causal attention (Qwen3-TTS encode passes an explicit causal mask, speech_tokenizer.py:1046-1053)
 
 
 def mimi_202407(num_codebooks: int) -> MimiConfig:
@@ -69,8 +71,8 @@ def tiny_mimi_config() -> MimiConfig:
 def mimi_stack_config(cfg: MimiConfig) -> StackConfig:
     return StackConfig(d_model=cfg.dimension, n_layers=cfg.num_layers, n_heads=cfg.num_heads, n_kv_heads=cfg.num_heads,
                        head_dim=cfg.dimension // cfg.num_heads, d_ff=cfg.dim_feedforward, norm="layer", norm_eps=1e-5, rope_theta=cfg.max_period,
-                       rope_interleaved=True, max_pos=cfg.max_seq_len, attn_bias=False, mlp="gelu_tanh", mlp_bias=False, layer_scale=True,
-                       causal=True, window=cfg.context, final_norm=False)
+                       rope_interleaved=bool(getattr(cfg, "rope_interleaved", True)), max_pos=cfg.max_seq_len, attn_bias=False, mlp="gelu_tanh", mlp_bias=False,
+                       layer_scale=True, causal=True, window=cfg.context if getattr(cfg, "attn_window", -1) < 0 else int(cfg.attn_window), final_norm=False)
 
 
 def canonical_stack_weights(w: Dict[str, torch.Tensor], prefix: str, cfg: MimiConfig) -> Dict[str, torch.Tensor]:

@@ -56,13 +56,15 @@ class MimiConfig:
     quantizer_dim: int = 256
     upsample_stride: int = 2      # encoder frame rate 25 Hz / codec frame rate 12.5 Hz
     sample_rate: int = 24000
+    rope_interleaved: bool = True   # nn.RoPE(traditional=...) (transformer.py:38, 76); the Qwen3-TTS tokenizer encoder: False
+    attn_window: int = -1           # -1: ``context``; 0: plain causal (speech_tokenizer.py:1046-1053 hands the transformer an explicit causal mask)
 
 
 def mimi_stack_config(cfg) -> StackConfig:
     return StackConfig(d_model=cfg.dimension, n_layers=cfg.num_layers, n_heads=cfg.num_heads, n_kv_heads=cfg.num_heads,
                        head_dim=cfg.dimension // cfg.num_heads, d_ff=cfg.dim_feedforward, norm="layer", norm_eps=1e-5, rope_theta=cfg.max_period,
-                       rope_interleaved=True, max_pos=cfg.max_seq_len, attn_bias=False, mlp="gelu_tanh", mlp_bias=False, layer_scale=True,
-                       causal=True, window=cfg.context, final_norm=False)
+                       rope_interleaved=bool(getattr(cfg, "rope_interleaved", True)), max_pos=cfg.max_seq_len, attn_bias=False, mlp="gelu_tanh", mlp_bias=False,
+                       layer_scale=True, causal=True, window=cfg.context if getattr(cfg, "attn_window", -1) < 0 else int(cfg.attn_window), final_norm=False)
 
 
 def canonical_stack_weights(w: Dict[str, Tensor], prefix: str, cfg) -> Dict[str, Tensor]:

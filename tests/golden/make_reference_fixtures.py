@@ -450,6 +450,41 @@ def run_mimi_encode(seed_w, seed_audio, n_samples):
     return dict(seed_w=seed_w, seed_audio=seed_audio, n_samples=n_samples, codes=codes.astype(np.int64), latent=z.astype(np.float32), decoded=back.astype(np.float32))
 
 
+def run_qwen3_tokenizer_encode(seed_w, seed_audio, n_samples):
+    """The reference's ``Qwen3TTSSpeechTokenizerEncoder.encode`` (speech_tokenizer.py:957-1058: the Mimi modules under the tokenizer's configuration --
+    non-traditional RoPE, an explicit causal mask, ``codes[:, :valid_num_quantizers]``) on a tiny synthetic checkpoint handed over in the HuggingFace
+    form and passed through the reference's own ``sanitize``."""
+    from mlx_audio_amd.codec.models.mimi import mimi as M
+
+    if "mlx_audio.tts.models.qwen3_tts.qwen3_tts" not in sys.modules:
+        run_sampler(0)  # loads the qwen3_tts modules
+    st = sys.modules["mlx_audio.tts.models.qwen3_tts.speech_tokenizer"]
+    cfgm = sys.modules["mlx_audio.tts.models.qwen3_tts.config"]
+    import pt_layouts as PT
+
+    c = M.tiny_mimi_config()
+    mw = {**M.make_mimi_decoder_weights(c, seed=seed_w), **M.make_mimi_encoder_weights(c, seed=seed_w)}
+    ec = cfgm.Qwen3TTSTokenizerEncoderConfig(hidden_size=c.dimension, num_filters=c.nfilters, upsampling_ratios=list(c.ratios), kernel_size=c.ksize,
+                                             residual_kernel_size=c.residual_ksize, last_kernel_size=c.last_ksize, compress=c.compress,
+                                             num_attention_heads=c.num_heads, num_key_value_heads=c.num_heads, head_dim=c.dimension // c.num_heads,
+                                             num_hidden_layers=c.num_layers, intermediate_size=c.dim_feedforward, sliding_window=c.context,
+                                             max_position_embeddings=c.max_seq_len, num_quantizers=c.quantizer_nq, codebook_size=c.quantizer_bins,
+                                             codebook_dim=c.quantizer_dim, vector_quantization_hidden_dimension=c.quantizer_dim)
+    enc = st.Qwen3TTSSpeechTokenizerEncoder(ec)
+    san = st.Qwen3TTSSpeechTokenizer.sanitize({k: mx.array(v.numpy()) for k, v in PT.qwen3_tokenizer_encoder_checkpoint(mw, c.num_layers, c.quantizer_nq).items()})
+    enc.load_weights([(k[len("encoder_model."):], v) for k, v in san.items() if k.startswith("encoder_model.")])
+    missing, unexpected, mism = enc._load_report
+    missing = [m for m in missing if not m.endswith(".codebook.initialized")]
+    assert not unexpected and not missing and not mism, (missing[:8], unexpected[:8], mism[:4])
+    mods = sys.modules["mlx_audio.codec.models.mimi.modules"]
+    for _, m in enc.named_modules():
+        if isinstance(m, mods.EuclideanCodebook):
+            m.update_in_place()
+    pcm = M.make_pcm(2, n_samples, seed=seed_audio).numpy()
+    codes = np.asarray(enc.encode(mx.array(pcm)))
+    return dict(seed_w=seed_w, seed_audio=seed_audio, n_samples=n_samples, codes=codes.astype(np.int64), valid=int(enc.valid_num_quantizers))
+
+
 def ref_qwen3_talker(seed_w):
     """The reference's ``Qwen3TTSTalkerForConditionalGeneration`` on the tiny synthetic checkpoint of this package's generator: (model, cfg, reference cfg)."""
     from dataclasses import asdict
@@ -1296,6 +1331,14 @@ def run_sanitize(R):
     ck = PT.qwen3_codec_checkpoint(QS.make_codec_decoder_weights(QS.tiny_codec_config(), seed=4))
     san = st.Qwen3TTSSpeechTokenizer.sanitize({k: mx.array(v.numpy()) for k, v in ck.items()})
     out["qwen3_codec"] = PT.summary({k: torch.from_numpy(np.asarray(v)) for k, v in san.items()})
+    # ... and the ENCODER half of the same checkpoint (speech_tokenizer.py:1229-1381, 1418-1441): SeanetEncoder layer indices, q | k | v -> in_proj, embed_sum codebooks
+    from mlx_audio_amd.codec.models.mimi import mimi as MM
+
+    mc = MM.tiny_mimi_config()
+    mw = {**MM.make_mimi_decoder_weights(mc, seed=8), **MM.make_mimi_encoder_weights(mc, seed=8)}
+    ck = PT.qwen3_tokenizer_encoder_checkpoint(mw, mc.num_layers, mc.quantizer_nq)
+    san = st.Qwen3TTSSpeechTokenizer.sanitize({k: mx.array(v.numpy()) for k, v in ck.items()})
+    out["qwen3_tokenizer_encoder"] = PT.summary({k: torch.from_numpy(np.asarray(v)) for k, v in san.items()})
     # Whisper from the HF hub (whisper.py:551-617), Qwen3-TTS Model.sanitize with its layout heuristic (qwen3_tts.py:123-157, 2914-2937), KittenTTS's
     # Snake parameter names (kitten_tts.py:394-404)
     from mlx_audio_amd.stt.models.whisper import synthetic as WS
@@ -1582,6 +1625,9 @@ def main():
     mefx = run_mimi_encode(seed_w=5, seed_audio=2, n_samples=1920 * 9 + 700)
     np.savez_compressed(os.path.join(HERE, "ref_mimi_encode.npz"), **mefx)
     print("mimi encode:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in mefx.items()})
+    qefx = run_qwen3_tokenizer_encode(seed_w=9, seed_audio=3, n_samples=1920 * 8 + 1001)
+    np.savez_compressed(os.path.join(HERE, "ref_qwen3_tokenizer_encode.npz"), **qefx)
+    print("qwen3 tokenizer encode:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in qefx.items()})
     qfx = run_qwen3_talker(seed_w=1, seed_in=4)
     np.savez_compressed(os.path.join(HERE, "ref_qwen3_talker_tiny.npz"), **qfx)
     print("qwen3 talker:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in qfx.items()})

@@ -62,6 +62,44 @@ def qwen3_codec_checkpoint(cw):
     return ck
 
 
+def qwen3_tokenizer_encoder_checkpoint(mw, n_layers, nq):
+    """Mimi-named ENCODER weights (mlx_audio_amd.codec.models.mimi.make_mimi_encoder_weights + the codebooks of make_mimi_decoder_weights) -> the
+    HuggingFace form of the Qwen3-TTS speech tokenizer's encoder half (``encoder.`` prefix: SeanetEncoder layers by index with ``block.1`` / ``block.3``,
+    separate q / k / v projections, ``embed_sum`` codebooks, PyTorch Conv1d layouts, plus an ``initialized`` buffer and an unused layer that sanitize drops)."""
+    ck = {}
+    pt = lambda v: v.permute(0, 2, 1).contiguous() if v.dim() == 3 else v
+    seanet = {"encoder.init_conv1d.conv.conv": "encoder.encoder.layers.0.conv", "encoder.final_conv1d.conv.conv": "encoder.encoder.layers.14.conv"}
+    for i in range(4):
+        seanet[f"encoder.layers.{i}.residuals.0.block.0.conv.conv"] = f"encoder.encoder.layers.{1 + 3 * i}.block.1.conv"
+        seanet[f"encoder.layers.{i}.residuals.0.block.1.conv.conv"] = f"encoder.encoder.layers.{1 + 3 * i}.block.3.conv"
+        seanet[f"encoder.layers.{i}.downsample.conv.conv"] = f"encoder.encoder.layers.{3 + 3 * i}.conv"
+    for src, dst in seanet.items():
+        for suf in ("weight", "bias"):
+            if f"{src}.{suf}" in mw:
+                ck[f"{dst}.{suf}"] = pt(mw[f"{src}.{suf}"])
+    tr = {"self_attn.out_proj.weight": "self_attn.o_proj.weight", "gating.linear1.weight": "mlp.fc1.weight", "gating.linear2.weight": "mlp.fc2.weight",
+          "norm1.weight": "input_layernorm.weight", "norm1.bias": "input_layernorm.bias", "norm2.weight": "post_attention_layernorm.weight",
+          "norm2.bias": "post_attention_layernorm.bias", "layer_scale_1.scale": "self_attn_layer_scale.scale", "layer_scale_2.scale": "mlp_layer_scale.scale"}
+    for i in range(n_layers):
+        p = f"encoder_transformer.transformer.layers.{i}."
+        ip = mw[p + "self_attn.in_proj.weight"]
+        d = ip.shape[0] // 3
+        for j, nm in enumerate(("q", "k", "v")):
+            ck[f"encoder.encoder_transformer.layers.{i}.self_attn.{nm}_proj.weight"] = ip[j * d:(j + 1) * d].contiguous()
+        for src, dst in tr.items():
+            ck[f"encoder.encoder_transformer.layers.{i}.{dst}"] = mw[p + src]
+    ck["encoder.downsample.conv.weight"] = pt(mw["downsample.conv.conv.conv.weight"])
+    for half, hf, n in (("rvq_first", "semantic_residual_vector_quantizer", 1), ("rvq_rest", "acoustic_residual_vector_quantizer", nq - 1)):
+        ck[f"encoder.quantizer.{hf}.input_proj.weight"] = pt(mw[f"quantizer.{half}.input_proj.weight"])
+        ck[f"encoder.quantizer.{hf}.output_proj.weight"] = pt(mw[f"quantizer.{half}.output_proj.weight"])
+        for i in range(n):
+            ck[f"encoder.quantizer.{hf}.layers.{i}.codebook.embed_sum"] = mw[f"quantizer.{half}.vq.layers.{i}.codebook.embedding_sum"]
+            ck[f"encoder.quantizer.{hf}.layers.{i}.codebook.cluster_usage"] = mw[f"quantizer.{half}.vq.layers.{i}.codebook.cluster_usage"]
+            ck[f"encoder.quantizer.{hf}.layers.{i}.codebook.initialized"] = torch.ones(1)
+    ck["encoder.encoder.layers.2.conv.weight"] = torch.zeros(3, 3, 3)   # an index the map does not name (ELU in the HF module list): dropped
+    return ck
+
+
 def summary(d):
     """key -> [shape, sum, sum of squares] (float64): enough to tell two sanitized dicts apart, small enough to commit."""
     return {k: [list(v.shape), float(torch.as_tensor(v).double().sum()), float((torch.as_tensor(v).double() ** 2).sum())] for k, v in sorted(d.items())}

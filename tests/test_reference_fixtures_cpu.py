@@ -206,6 +206,27 @@ def test_mimi_encode_oracle_reproduces_the_reference_modules():
     assert float(np.abs(back - fx["decoded"]).max()) < 2e-5 * max(float(np.abs(fx["decoded"]).max()), 1e-3) + 1e-7
 
 
+def test_qwen3_tokenizer_encode_oracle_reproduces_the_reference_modules():
+    """The reference's ``Qwen3TTSSpeechTokenizerEncoder.encode`` (speech_tokenizer.py:957-1058) = the Mimi encode modules with non-traditional RoPE and a
+    plain causal mask: the oracle with those two switches gives the reference's codes, with Mimi's own settings it does not."""
+    from dataclasses import asdict
+
+    from mlx_audio_amd.codec.models.mimi import mimi as M
+    from oracle.mimi_ref import MimiConfig as RC
+    from oracle.mimi_ref import MimiEncoderRef
+
+    fx = np.load(os.path.join(GOLD, "ref_qwen3_tokenizer_encode.npz"))
+    cfg = M.tiny_mimi_config()
+    w = {**M.make_mimi_decoder_weights(cfg, seed=int(fx["seed_w"])), **M.make_mimi_encoder_weights(cfg, seed=int(fx["seed_w"]))}
+    pcm = M.make_pcm(2, int(fx["n_samples"]), seed=int(fx["seed_audio"]))
+    base = {k: v for k, v in asdict(cfg).items() if k in RC.__dataclass_fields__}
+    codes, margins = MimiEncoderRef(w, RC(**{**base, "rope_interleaved": False, "attn_window": 0}), param_dtype=torch.float32).quantize(
+        MimiEncoderRef(w, RC(**{**base, "rope_interleaved": False, "attn_window": 0}), param_dtype=torch.float32).latent(pcm), return_margins=True)
+    print(f"qwen3 tokenizer encode oracle vs reference: smallest decision gap {float(margins.min()):.3f}")
+    assert np.array_equal(codes.numpy(), fx["codes"])
+    assert not np.array_equal(MimiEncoderRef(w, RC(**base), param_dtype=torch.float32)(pcm).numpy(), fx["codes"])
+
+
 def test_qwen3_talker_oracle_reproduces_the_reference_modules():
     """The reference's talker stack (MRoPE position ids, q / k RMSNorm, GQA, SwiGLU, KV cache: talker.py:229-500) with ``codec_head`` and
     ``text_projection``, and its code predictor stepped like ``_predict_code_tokens`` (qwen3_tts.py:941-983) on forced codes: prefill + 2 cached steps."""
@@ -521,6 +542,19 @@ def test_sanitize_matches_the_reference_sanitize():
     assert set(got) == set(want["qwen3_codec"]), (sorted(set(got) ^ set(want["qwen3_codec"]))[:6])
     for k, (shape, s1, s2) in want["qwen3_codec"].items():
         assert got[k][0] == shape and abs(got[k][1] - s1) <= 1e-6 * (1 + abs(s1)) and abs(got[k][2] - s2) <= 1e-6 * (1 + s2), k
+
+    # ... and the encoder half (speech_tokenizer.py:1229-1381, 1418-1441): SeanetEncoder layer indices, q | k | v -> in_proj, embed_sum codebooks
+    from mlx_audio_amd.codec.models.mimi import mimi as MM
+
+    mc = MM.tiny_mimi_config()
+    mw = {**MM.make_mimi_decoder_weights(mc, seed=8), **MM.make_mimi_encoder_weights(mc, seed=8)}
+    got = PT.summary(Tok.sanitize(PT.qwen3_tokenizer_encoder_checkpoint(mw, mc.num_layers, mc.quantizer_nq)))
+    assert set(got) == set(want["qwen3_tokenizer_encoder"]), (sorted(set(got) ^ set(want["qwen3_tokenizer_encoder"]))[:6])
+    for k, (shape, s1, s2) in want["qwen3_tokenizer_encoder"].items():
+        assert got[k][0] == shape and abs(got[k][1] - s1) <= 1e-6 * (1 + abs(s1)) and abs(got[k][2] - s2) <= 1e-6 * (1 + s2), k
+    # the sanitized encoder keys are exactly what the Mimi engine's encoder reads (prefix stripped)
+    enc = {k[len("encoder_model."):] for k in got}
+    assert {k for k in mw if k.startswith(("encoder.", "encoder_transformer.", "downsample.", "quantizer."))} <= enc | {k for k in mw if "initialized" in k}
 
     # Whisper in the HuggingFace layout (whisper.py:551-617), Qwen3-TTS Model.sanitize with its conv layout heuristic (qwen3_tts.py:123-157, 2914-2937),
     # KittenTTS's Snake parameter names (kitten_tts.py:394-404)

@@ -105,6 +105,53 @@ def test_qwen3_codec_engine_vs_reference_run():
     assert got.shape == fx["audio"].shape and err <= 2e-3 * peak and _snr(got, fx["audio"]) >= 50.0
 
 
+def test_qwen3_tokenizer_encoder_vs_reference_run():
+    """``Qwen3TTSSpeechTokenizer.encode`` (the Mimi engine under the tokenizer's configuration: non-traditional RoPE, plain causal attention, the first 16
+    codebooks) from a HuggingFace-form checkpoint -- decoder AND encoder halves through this package's ``sanitize`` / ``load_weights`` -- against the
+    reference's own ``Qwen3TTSSpeechTokenizerEncoder.encode`` run, codes under the margin rule (the gaps come from the device kernel)."""
+    from dataclasses import asdict
+
+    import _margin
+    sys.path.insert(0, GOLD)
+    import pt_layouts as PT
+    from mlx_audio_amd.codec.models.mimi import mimi as M
+    from mlx_audio_amd.tts.models.qwen3_tts import synthetic as QS
+    from mlx_audio_amd.tts.models.qwen3_tts.config import Qwen3TTSTokenizerConfig
+    from mlx_audio_amd.tts.models.qwen3_tts.speech_tokenizer import Qwen3TTSSpeechTokenizer as Tok
+
+    fx = np.load(os.path.join(GOLD, "ref_qwen3_tokenizer_encode.npz"))
+    c = M.tiny_mimi_config()
+    mw = {**M.make_mimi_decoder_weights(c, seed=int(fx["seed_w"])), **M.make_mimi_encoder_weights(c, seed=int(fx["seed_w"]))}
+    dcfg = QS.tiny_codec_config()
+    ck = {**PT.qwen3_codec_checkpoint(QS.make_codec_decoder_weights(dcfg, seed=4)), **PT.qwen3_tokenizer_encoder_checkpoint(mw, c.num_layers, c.quantizer_nq)}
+    ec = dict(hidden_size=c.dimension, num_filters=c.nfilters, upsampling_ratios=list(c.ratios), kernel_size=c.ksize, residual_kernel_size=c.residual_ksize,
+              last_kernel_size=c.last_ksize, compress=c.compress, num_attention_heads=c.num_heads, num_key_value_heads=c.num_heads, num_hidden_layers=c.num_layers,
+              intermediate_size=c.dim_feedforward, sliding_window=c.context, max_position_embeddings=c.max_seq_len, num_quantizers=c.quantizer_nq,
+              codebook_size=c.quantizer_bins, codebook_dim=c.quantizer_dim)
+    tok = Tok(Qwen3TTSTokenizerConfig(encoder_config=ec, decoder_config=dcfg), device=DEV)
+    assert not tok.has_encoder
+    tok.load_weights(Tok.sanitize(ck))
+    assert tok.has_encoder and tok.encoder_model.cfg.rope_interleaved is False and tok.encoder_model.cfg.attn_window == 0
+    pcm = M.make_pcm(2, int(fx["n_samples"]), seed=int(fx["seed_audio"]))
+    codes = tok.encode(pcm.to(DEV))
+    _, margins = tok.encoder_model(pcm, return_margins=True)
+    torch.cuda.synchronize()
+    codes, margins = codes.cpu(), margins.cpu()
+    assert codes.dtype == torch.int64 and tuple(codes.shape) == fx["codes"].shape      # 4 codebooks < valid_num_quantizers = 16: all of them
+    for b in range(codes.shape[0]):
+        for t in range(codes.shape[2]):
+            _margin.walk("mimi_encode", codes[b, :1, t].tolist(), fx["codes"][b, :1, t].tolist(), margins[b, :1, t].tolist(), thr=0.05, where=("qwen3 tok", b, t, 0))
+            _margin.walk("mimi_encode", codes[b, 1:, t].tolist(), fx["codes"][b, 1:, t].tolist(), margins[b, 1:, t].tolist(), thr=0.05, where=("qwen3 tok", b, t))
+    # a decoder-only checkpoint keeps the reference's contract: no encoder, encode raises
+    tok2 = Tok(Qwen3TTSTokenizerConfig(encoder_config=ec, decoder_config=dcfg), device=DEV)
+    tok2.load_weights(Tok.sanitize(PT.qwen3_codec_checkpoint(QS.make_codec_decoder_weights(dcfg, seed=4))))
+    assert not tok2.has_encoder
+    import pytest
+
+    with pytest.raises(ValueError):
+        tok2.encode(pcm)
+
+
 def test_csm_engine_vs_reference_run():
     """Three frames of ``generate_frame`` teacher-forced on the codes the fixture run forced: every logits tensor the reference's sampler saw."""
     from mlx_audio_amd.tts.models.sesame import engine as E
