@@ -7,8 +7,10 @@ Same as the reference: constructor / config records, checkpoint key handling, th
 generator protocol and every field of ``GenerationResult`` / ``BatchGenerationResult``, chunked codec decode (15-frame chunks + 5 frames of
 left context, :1050-1083).
 
-Not in this build (raise, never silently degrade): in-context voice cloning (``ref_audio`` + ``ref_text``: needs the speech-tokenizer ENCODER and
-the ECAPA speaker encoder), streaming chunk decode with carried codec state (``stream=True`` decodes each chunk with left context).
+Not in this build (raise, never silently degrade): in-context voice cloning (``ref_audio`` + ``ref_text``, ``_prepare_icl_generation_inputs``
+:606-803): Base checkpoints always carry the ECAPA speaker encoder (``speaker_encoder.py``) whose x-vector enters the ICL prompt, and that network is
+not built; the other half ICL needs -- the speech tokenizer's ENCODER -- is (``speech_tokenizer.encode``, round 3).  Streaming chunk decode with
+carried codec state (``stream=True`` decodes each chunk with left context).
 """
 from __future__ import annotations
 
@@ -233,7 +235,7 @@ class Model:
                               return_metadata: bool = False):
         """``qwen3_tts.py:486-604``: per-sequence inputs, input_embeds LEFT-padded with zeros, trailing text RIGHT-padded with tts_pad."""
         if ref_audio is not None or ref_text is not None:
-            raise NotImplementedError("in-context voice cloning needs the speech-tokenizer encoder, which this build does not ship")
+            raise NotImplementedError("in-context voice cloning needs the ECAPA speaker encoder, which this build does not ship")
         embeds, trailings, pad = [], [], None
         for i, t in enumerate(texts):
             e, tr, p = self._prepare_generation_inputs(t, language=language, speaker=speakers[i] if speakers else None,
@@ -307,7 +309,8 @@ class Model:
         if self.speech_tokenizer is None:
             raise ValueError("Speech tokenizer not loaded")
         if ref_audio is not None or ref_text is not None:
-            raise NotImplementedError("voice cloning (ref_audio / ref_text) needs the speech-tokenizer encoder and the speaker encoder, which this build does not ship")
+            raise NotImplementedError("voice cloning (ref_audio / ref_text) needs the ECAPA speaker encoder (speaker_encoder.py), which this build does not ship "
+                                      "(the speech tokenizer's encoder half is built: speech_tokenizer.encode)")
         kind = getattr(self.config, "tts_model_type", "base")
         if kind == "voice_design" and not instruct:
             raise ValueError("VoiceDesign model requires 'instruct' to describe the voice (e.g., 'A cheerful young female voice with high pitch')")
@@ -373,7 +376,7 @@ class Model:
         if self.speech_tokenizer is None:
             raise ValueError("Speech tokenizer not loaded")
         if any(v is not None for v in (ref_audio, ref_text, ref_audios, ref_texts)):
-            raise NotImplementedError("in-context voice cloning needs the speech-tokenizer encoder, which this build does not ship")
+            raise NotImplementedError("in-context voice cloning needs the ECAPA speaker encoder, which this build does not ship")
         if stream:
             raise NotImplementedError("batch_generate(stream=True) is not wired to the engine yet")
         if not texts:
