@@ -307,6 +307,38 @@ typedef struct {
 } mi355_rvq_encode_args;
 int mi355_rvq_encode(const mi355_rvq_encode_args* a, void* stream);
 
+/* ECAPA-TDNN speaker encoder of Qwen3-TTS (tts/models/qwen3_tts/speaker_encoder.py), the row-wise pieces between its convolutions (which are
+ * mi355_conv_gemm launches).  mi355_ecapa_rows: y[b, r, c] = f(x[b, s, c]) * sigmoid(gate[b, c]) + res[b, s, c] with s = reflect(r - pad) for
+ * r in [0, T + 2 pad): reflect_pad_1d (:11-26: mirror without repeating the edge row; needs pad < T), the Res2Net input "chunk + previous
+ * output" (:98-101), the tanh in front of the attention conv (:213), SqueezeExcitationBlock's x * sigmoid(.) (:138-141) + the block residual (:180). */
+typedef struct {
+  const float* x; int64_t x_bstride; int32_t ldx;        /* [B, T, C] float32, any row stride (a channel slice of a wider buffer) */
+  const float* gate; int32_t gate_ld;                    /* nullable [B, C] LOGITS of the gate */
+  const float* res; int64_t res_bstride; int32_t ldr;    /* nullable [B, T, C] */
+  int32_t pre_tanh;                                      /* 1: f = tanh, 0: identity */
+  float* y; int64_t y_bstride; int32_t ldy;              /* [B, T + 2 pad, C] */
+  int32_t B; int32_t T; int32_t C; int32_t pad;
+} mi355_ecapa_rows_args;
+int mi355_ecapa_rows(const mi355_ecapa_rows_args* a, void* stream);
+/* mean[b, c] = mean_t x[b, t, c];  std[b, c] (nullable) = sqrt(biased variance + eps)  (speaker_encoder.py:133, 201-202) */
+typedef struct {
+  const float* x; int64_t x_bstride; int32_t ldx;
+  int32_t B; int32_t T; int32_t C;
+  float eps;
+  float* mean; float* std; int32_t out_ld;               /* [B, out_ld >= C] each */
+} mi355_time_moments_args;
+int mi355_time_moments(const mi355_time_moments_args* a, void* stream);
+/* AttentiveStatisticsPooling's tail (speaker_encoder.py:219-228): w = softmax over TIME of logits[b, :, c];  out[b, c] = sum_t w x;
+ * out[b, C + c] = sqrt(max(sum_t w (x - mean)^2, eps)). */
+typedef struct {
+  const float* x; int64_t x_bstride; int32_t ldx;        /* [B, T, C] */
+  const float* logits; int64_t l_bstride; int32_t ldl;   /* [B, T, C] */
+  int32_t B; int32_t T; int32_t C;
+  float eps;
+  float* out; int32_t out_ld;                            /* [B, out_ld >= 2 C] */
+} mi355_attentive_pool_args;
+int mi355_attentive_pool(const mi355_attentive_pool_args* a, void* stream);
+
 /* Anti-aliased activation of BigVGAN (codec/models/bigvgan/resample.py:157-177 ``Activation1d`` with SnakeBeta, activation.py:27-51):
  * x [B, L, C] channels-last -> y [B, L, C]:  2x up-sampling (edge pad 5, depthwise transposed conv with the 12-tap Kaiser-sinc filter, x 2, trimmed
  * to 2L: resample.py:101-136), a = u + inv_beta[c] * sin^2(alpha[c] * u), 2x down-sampling (edge pad 5 / 6, the 12-tap low-pass at stride 2:

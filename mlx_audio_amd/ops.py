@@ -551,6 +551,46 @@ def rvq_encode(x: torch.Tensor, tables: torch.Tensor, tables_t: torch.Tensor, c2
     return (codes, mg) if margins else codes
 
 
+def ecapa_rows(x: torch.Tensor, y: torch.Tensor, *, pad: int = 0, gate: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
+               pre_tanh: bool = False) -> torch.Tensor:
+    """``y[b, r] = f(x[b, s]) * sigmoid(gate[b]) + res[b, s]``, ``s = reflect(r - pad)``: x / res [B, T, C] (channel slices of wider buffers are fine),
+    gate [B, C] logits, y [B, T + 2 * pad, C] -- see mi355_ecapa_rows_args."""
+    B, T, C, xbs, ldx = _nlc(x)
+    By, Ty, Cy, ybs, ldy = _nlc(y)
+    assert (By, Ty, Cy) == (B, T + 2 * pad, C), ((By, Ty, Cy), (B, T, C), pad)
+    kw = dict(x=_ptr(x), x_bstride=xbs, ldx=ldx, pre_tanh=int(pre_tanh), y=_ptr(y), y_bstride=ybs, ldy=ldy, B=B, T=T, C=C, pad=pad)
+    if gate is not None:
+        assert gate.dtype == torch.float32 and gate.shape == (B, C) and gate.stride(1) == 1
+        kw.update(gate=_ptr(gate), gate_ld=gate.stride(0))
+    if res is not None:
+        Br, Tr, Cr, rbs, ldr = _nlc(res)
+        assert (Br, Tr, Cr) == (B, T, C)
+        kw.update(res=_ptr(res), res_bstride=rbs, ldr=ldr)
+    _lib.call_struct("mi355_ecapa_rows", "mi355_ecapa_rows_args", _stream(), **kw)
+    return y
+
+
+def time_moments(x: torch.Tensor, eps: float = 0.0, want_std: bool = True):
+    """(mean [B, C], sqrt(biased variance + eps) [B, C] or None) over the time axis of ``x`` [B, T, C]."""
+    B, T, C, xbs, ldx = _nlc(x)
+    mean = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    std = torch.empty((B, C), dtype=torch.float32, device=x.device) if want_std else None
+    _lib.call_struct("mi355_time_moments", "mi355_time_moments_args", _stream(), x=_ptr(x), x_bstride=xbs, ldx=ldx, B=B, T=T, C=C, eps=eps,
+                     mean=_ptr(mean), std=_ptr(std), out_ld=C)
+    return mean, std
+
+
+def attentive_pool(x: torch.Tensor, logits: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    """Softmax over time of ``logits`` per channel; [B, 2C] = (weighted mean | sqrt(max(weighted variance, eps))) of ``x`` -- mi355_attentive_pool_args."""
+    B, T, C, xbs, ldx = _nlc(x)
+    Bl, Tl, Cl, lbs, ldl = _nlc(logits)
+    assert (Bl, Tl, Cl) == (B, T, C)
+    out = torch.empty((B, 2 * C), dtype=torch.float32, device=x.device)
+    _lib.call_struct("mi355_attentive_pool", "mi355_attentive_pool_args", _stream(), x=_ptr(x), x_bstride=xbs, ldx=ldx, logits=_ptr(logits), l_bstride=lbs,
+                     ldl=ldl, B=B, T=T, C=C, eps=eps, out=_ptr(out), out_ld=2 * C)
+    return out
+
+
 def fake_quant_extrema(x: torch.Tensor, *, lens=None, pre=None, pre_act: int = ACT_NONE, pre_slope: float = 0.0,
                        pre_alpha: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Extrema pass alone: ``[B, 2]`` = {-min, max} of ``act(scale * x + shift)`` per utterance (joined with 0) for ``conv_gemm(pre_fq=...)``,

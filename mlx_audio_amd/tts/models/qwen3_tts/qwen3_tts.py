@@ -7,9 +7,11 @@ Same as the reference: constructor / config records, checkpoint key handling, th
 generator protocol and every field of ``GenerationResult`` / ``BatchGenerationResult``, chunked codec decode (15-frame chunks + 5 frames of
 left context, :1050-1083).
 
-Not in this build (raise, never silently degrade): in-context voice cloning (``ref_audio`` + ``ref_text``, ``_prepare_icl_generation_inputs``
-:606-803): Base checkpoints always carry the ECAPA speaker encoder (``speaker_encoder.py``) whose x-vector enters the ICL prompt, and that network is
-not built; the other half ICL needs -- the speech tokenizer's ENCODER -- is (``speech_tokenizer.encode``, round 3).  Streaming chunk decode with
+Voice cloning (round 3): ``ref_audio`` alone adds the clip's x-vector to the codec prefix (:383-384); ``ref_audio`` + ``ref_text`` is the in-context
+path (``_prepare_icl_generation_inputs`` :606-803, ``_generate_icl`` :2200-2510, the shared-reference batch :1724-2045): the clip's codes from the
+speech tokenizer's ENCODER, its transcript and the x-vector of the ECAPA speaker encoder (``speaker_encoder.py``) in the prefill, the reference codes
+in front of the generated ones at decode time, the reference's share of the waveform cut off proportionally.
+Not in this build (raise, never silently degrade): streaming chunk decode with
 carried codec state (``stream=True`` decodes each chunk with left context).
 """
 from __future__ import annotations
@@ -52,7 +54,8 @@ class Model:
         self.device = device
         self.precision = precision
         self.talker = None            # Qwen3Talker (engine), built by load_weights
-        self.speaker_encoder = None   # not part of this build
+        self.speaker_encoder = None   # Qwen3TTSSpeakerEncoder (engine), built by load_weights when a Base checkpoint carries speaker_encoder.*
+        self._icl_cache: Dict = {}
         self.speech_tokenizer: Optional[Qwen3TTSSpeechTokenizer] = None
         self.tokenizer = None
         self.generate_config = None
@@ -75,13 +78,14 @@ class Model:
 
     def supports_tts_batch(self, *, stream: bool = False, voice: Optional[str] = None, instruct: Optional[str] = None, ref_audio=None,
                            ref_text: Optional[str] = None, speed: Optional[float] = 1.0, pitch: Optional[float] = 1.0, **kwargs) -> bool:
-        """``qwen3_tts.py:215-252`` (reference audio never batches here: no encoder)."""
+        """``qwen3_tts.py:215-252``."""
         del kwargs
         if stream or speed not in (None, 1.0) or pitch not in (None, 1.0):
             return False
-        if ref_audio is not None or ref_text is not None:
-            return False
         kind = getattr(self.config, "tts_model_type", "base")
+        if ref_audio is not None or ref_text is not None:
+            return (kind == "base" and ref_audio is not None and ref_text is not None and voice is None and instruct is None
+                    and self.speech_tokenizer is not None and self.speech_tokenizer.has_encoder)
         if kind not in {"base", "custom_voice"}:
             return False
         if kind == "base" and instruct:
@@ -144,6 +148,13 @@ class Model:
             self.talker = Qwen3Talker(tw, self.config.talker_config, device=self.device, precision=self.precision)
         except KeyError as e:
             raise ValueError(f"Qwen3-TTS checkpoint is missing parameter talker.{e.args[0]}") from e
+        # the reference builds the speaker encoder for every Base model (qwen3_tts.py:179-182); here it exists when the checkpoint carries its parameters
+        sw = {k[len("speaker_encoder."):]: v for k, v in w.items() if k.startswith("speaker_encoder.")}
+        if sw and getattr(self.config, "tts_model_type", "base") == "base":
+            from .speaker_encoder import Qwen3TTSSpeakerEncoder
+
+            self.speaker_encoder = Qwen3TTSSpeakerEncoder(self.config.speaker_encoder_config, device=self.device, precision=self.precision)
+            self.speaker_encoder.load_weights(sw, strict=strict)
         return self
 
     @classmethod
@@ -186,23 +197,36 @@ class Model:
         idx = torch.tensor(ids, dtype=torch.long, device=self.talker.device)
         return self.talker.codec_table[idx][None]  # slot 0 of the stacked table = the talker's codec_embedding
 
-    def extract_speaker_embedding(self, audio, sr: int = 24000):
-        raise NotImplementedError("voice cloning needs the ECAPA speaker encoder (tts/models/qwen3_tts/speaker_encoder.py), which this build does not ship")
+    def _codes_embed(self, codes: torch.Tensor) -> torch.Tensor:
+        """Whole frames ``[1, T, num_code_groups]`` -> the sum of their codec embeddings ``[1, T, H]`` (qwen3_tts.py:701-709)."""
+        return self.talker.embed_codes(codes)
+
+    def extract_speaker_embedding(self, audio, sr: int = 24000) -> torch.Tensor:
+        """``qwen3_tts.py:285-324``: 24 kHz samples ``[n]`` (or ``[B, n]``) -> x-vector ``[B, enc_dim]``: the fused mel front end
+        (``dsp.mel_spectrogram``: n_fft 1024, hop 256, 128 Slaney mels up to 12 kHz) then the ECAPA encoder, all on the device."""
+        if sr != 24000:
+            raise ValueError("Only 24kHz audio is supported for speaker embedding extraction")
+        if self.speaker_encoder is None:
+            raise ValueError("Speaker encoder not available for this model type")
+        from ....dsp import mel_spectrogram
+
+        mels = mel_spectrogram(audio, n_fft=1024, num_mels=128, sample_rate=24000, hop_size=256, win_size=1024, fmin=0, fmax=12000)
+        return self.speaker_encoder(mels)
 
     def _prepare_generation_inputs(self, text: str, language: str = "auto", speaker: Optional[str] = None, ref_audio=None,
                                    ref_text: Optional[str] = None, instruct: Optional[str] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """``qwen3_tts.py:326-484``: (input_embeds [1, L, H], trailing_text_hidden [1, T, H], tts_pad_embed [1, 1, H])."""
         if self.tokenizer is None:
             raise ValueError("Tokenizer not loaded. Call post_load_hook first.")
-        if ref_audio is not None:
-            self.extract_speaker_embedding(ref_audio)
         cfg = self.config.talker_config
         chat = f"<|im_start|>assistant\n{text}<|im_end|>\n<|im_start|>assistant\n"
         text_embed = self._text_embed(list(self.tokenizer.encode(chat)))
         tts = self._text_embed([self.config.tts_bos_token_id, self.config.tts_eos_token_id, self.config.tts_pad_token_id])
         tts_bos, tts_eos, tts_pad = tts[:, 0:1], tts[:, 1:2], tts[:, 2:3]
         speaker_embed = None
-        if speaker and speaker.lower() in (cfg.spk_id or {}):
+        if ref_audio is not None and self.speaker_encoder is not None:   # x-vector cloning without a transcript (:383-384)
+            speaker_embed = self.extract_speaker_embedding(ref_audio).to(torch.float32)
+        elif speaker and speaker.lower() in (cfg.spk_id or {}):
             sid = cfg.spk_id[speaker.lower()]
             speaker_embed = self._codec_embed([sid[0] if isinstance(sid, (list, tuple)) else sid])
         language_id = None
@@ -230,16 +254,59 @@ class Model:
         trailing = torch.cat([text_embed[:, 4:-5], tts_eos], dim=1)
         return input_embeds.contiguous(), trailing.contiguous(), tts_pad.contiguous()
 
+    def _prepare_icl_generation_inputs(self, text: str, ref_audio, ref_text: str, language: str = "auto"):
+        """``qwen3_tts.py:606-803`` (the official ``generate_icl_prompt`` in its non-streaming form): (input_embeds, trailing_text_hidden = tts_pad,
+        tts_pad_embed, ref_codes [1, groups, ref_time]).  Prefill = role (3 tokens) | codec prefix (think / no-think, language id, x-vector, pad, bos)
+        under tts_pad ... tts_bos | all text (reference transcript + target text + tts_eos) over codec_pad | codec_bos + the reference clip's frames
+        (sum of the codec embeddings of all groups) over tts_pad.  Codes and transcript ids of a clip are cached by (transcript, clip fingerprint)."""
+        if self.tokenizer is None:
+            raise ValueError("Tokenizer not loaded. Call post_load_hook first.")
+        cfg = self.config.talker_config
+        ref_audio = torch.as_tensor(ref_audio)
+        key = (ref_text, (int(ref_audio.numel()), float(ref_audio.sum())))
+        ref_codes, ref_text_ids = self._icl_cache.get(key, (None, None))
+        audio_for_spk = ref_audio
+        if ref_codes is None:
+            a = ref_audio[None, None, :] if ref_audio.dim() == 1 else (ref_audio[None, :] if ref_audio.dim() == 2 else ref_audio)
+            ref_codes = self.speech_tokenizer.encode(a)                          # [1, groups, ref_time]
+            ref_text_ids = list(self.tokenizer.encode(f"<|im_start|>assistant\n{ref_text}<|im_end|>\n"))[3:-2]
+            self._icl_cache[key] = (ref_codes, ref_text_ids)
+        target_ids = list(self.tokenizer.encode(f"<|im_start|>assistant\n{text}<|im_end|>\n<|im_start|>assistant\n"))
+        text_ids = target_ids[3:-5]
+        tts = self._text_embed([self.config.tts_bos_token_id, self.config.tts_eos_token_id, self.config.tts_pad_token_id])
+        tts_bos, tts_eos, tts_pad = tts[:, 0:1], tts[:, 1:2], tts[:, 2:3]
+        text_embed = torch.cat([self._text_embed(list(ref_text_ids) + text_ids), tts_eos], dim=1)
+        codes_t = torch.as_tensor(ref_codes).permute(0, 2, 1)                    # [1, ref_time, groups]
+        codec_icl = torch.cat([self._codec_embed([cfg.codec_bos_id]), self._codes_embed(codes_t)], dim=1)
+        icl = torch.cat([text_embed + self._codec_embed([cfg.codec_pad_id]), codec_icl + tts_pad], dim=1)
+        language_id = None
+        if language.lower() != "auto" and cfg.codec_language_id and language.lower() in cfg.codec_language_id:
+            language_id = cfg.codec_language_id[language.lower()]
+        speaker_embed = self.extract_speaker_embedding(audio_for_spk) if self.speaker_encoder is not None else None   # ICL still uses the x-vector (:743-746)
+        if language_id is None:
+            prefill = [cfg.codec_nothink_id, cfg.codec_think_bos_id, cfg.codec_think_eos_id]
+        else:
+            prefill = [cfg.codec_think_id, cfg.codec_think_bos_id, language_id, cfg.codec_think_eos_id]
+        prefix = torch.cat([self._codec_embed(prefill)] + ([speaker_embed.to(torch.float32).reshape(1, 1, -1)] if speaker_embed is not None else [])
+                           + [self._codec_embed([cfg.codec_pad_id, cfg.codec_bos_id])], dim=1)
+        role = self._text_embed(target_ids[:3])
+        combined = torch.cat([tts_pad.expand(1, prefix.shape[1] - 2, -1), tts_bos], dim=1) + prefix[:, :-1]
+        input_embeds = torch.cat([role, combined, icl], dim=1)
+        return input_embeds.contiguous(), tts_pad.contiguous(), tts_pad.contiguous(), ref_codes
+
     def _prepare_batch_inputs(self, texts: List[str], language: str = "auto", speakers: Optional[List[Optional[str]]] = None,
                               instructs: Optional[List[Optional[str]]] = None, ref_audio=None, ref_text: Optional[str] = None,
                               return_metadata: bool = False):
         """``qwen3_tts.py:486-604``: per-sequence inputs, input_embeds LEFT-padded with zeros, trailing text RIGHT-padded with tts_pad."""
-        if ref_audio is not None or ref_text is not None:
-            raise NotImplementedError("in-context voice cloning needs the ECAPA speaker encoder, which this build does not ship")
-        embeds, trailings, pad = [], [], None
+        use_icl = ref_audio is not None and ref_text is not None
+        embeds, trailings, pad, shared_ref_codes = [], [], None, None
         for i, t in enumerate(texts):
-            e, tr, p = self._prepare_generation_inputs(t, language=language, speaker=speakers[i] if speakers else None,
-                                                       instruct=instructs[i] if instructs else None)
+            if use_icl:   # one shared reference clip for the whole batch
+                e, tr, p, rc = self._prepare_icl_generation_inputs(t, ref_audio=ref_audio, ref_text=ref_text, language=language)
+                shared_ref_codes = rc if shared_ref_codes is None else shared_ref_codes
+            else:
+                e, tr, p = self._prepare_generation_inputs(t, language=language, speaker=speakers[i] if speakers else None,
+                                                           instruct=instructs[i] if instructs else None)
             embeds.append(e)
             trailings.append(tr)
             pad = p if pad is None else pad
@@ -254,7 +321,7 @@ class Model:
         mt = max(tlens)
         tr = torch.cat([torch.cat([t, pad.expand(1, mt - t.shape[1], H)], dim=1) for t in trailings], dim=0)
         bi = Qwen3BatchInputs(input_embeds=x.contiguous(), trailing_text_hidden=tr.contiguous(), tts_pad_embed=pad, attention_mask=mask,
-                              left_padding=left, prefill_lens=plens, trailing_lens=tlens)
+                              left_padding=left, prefill_lens=plens, trailing_lens=tlens, ref_codes=shared_ref_codes)
         return bi if return_metadata else (bi.input_embeds, bi.trailing_text_hidden, bi.tts_pad_embed, bi.attention_mask)
 
     # ------------------------------------------------------------------ decode
@@ -274,6 +341,25 @@ class Model:
             parts.append(wav[ctx * up:] if ctx > 0 else wav)
             start = end
         return torch.cat(parts) if len(parts) > 1 else parts[0]
+
+    def _decode_icl_generated_codes(self, codes: torch.Tensor, ref_codes: torch.Tensor) -> torch.Tensor:
+        """``qwen3_tts.py:1085-1112``: generated frames ``[T, groups]`` decoded BEHIND the reference clip's frames (the codec decoder is causal: the
+        clip is the acoustic left context of the new audio), then the clip's share of the samples -- ``ref_len / total_len`` of them -- is cut off."""
+        dec_dev = self.speech_tokenizer.decoder.device
+        if codes.numel() == 0:
+            return torch.zeros(0, dtype=torch.float32, device=dec_dev)
+        ref_t = torch.as_tensor(ref_codes).permute(0, 2, 1).to(codes.device, codes.dtype)     # [1, ref_len, groups]
+        full = torch.cat([ref_t, codes[None]], dim=1).contiguous()
+        ref_len, total_len = int(ref_t.shape[1]), int(full.shape[1])
+        audio, lengths = self.speech_tokenizer.decode(full)
+        audio = audio[0]
+        valid = int(lengths[0])
+        if 0 < valid < audio.shape[0]:
+            audio = audio[:valid]
+        cut = int(ref_len / max(total_len, 1) * audio.shape[0])
+        if 0 < cut < audio.shape[0]:
+            audio = audio[cut:]
+        return audio
 
     def _result(self, audio: torch.Tensor, segment_idx: int, token_count: int, elapsed: float, **extra) -> GenerationResult:
         samples = int(audio.shape[0])
@@ -308,25 +394,34 @@ class Model:
             raise RuntimeError("Model has no weights: call load_weights() (or mlx_audio_amd.tts.utils.load_model)")
         if self.speech_tokenizer is None:
             raise ValueError("Speech tokenizer not loaded")
-        if ref_audio is not None or ref_text is not None:
-            raise NotImplementedError("voice cloning (ref_audio / ref_text) needs the ECAPA speaker encoder (speaker_encoder.py), which this build does not ship "
-                                      "(the speech tokenizer's encoder half is built: speech_tokenizer.encode)")
+        if ref_audio is not None and isinstance(ref_audio, (str, Path)):
+            from ....utils import load_audio
+
+            ref_audio = load_audio(str(ref_audio), sample_rate=self.sample_rate)
         kind = getattr(self.config, "tts_model_type", "base")
         if kind == "voice_design" and not instruct:
             raise ValueError("VoiceDesign model requires 'instruct' to describe the voice (e.g., 'A cheerful young female voice with high pitch')")
         if kind == "custom_voice" and not voice:
             raise ValueError(f"CustomVoice model requires 'voice' (speaker name) (e.g., {self.supported_speakers})")
         if kind == "base":
-            if voice is not None and voice.lower() not in [s.lower() for s in self.supported_speakers]:
-                raise ValueError(f"Voice '{voice}' is not supported by this Base model. Base models have no built-in preset voices — clone a voice by "
-                                 "passing ref_audio and ref_text instead."
-                                 + (f" Available preset voices: {self.supported_speakers}" if self.supported_speakers else ""))
             instruct = None
         engine_kw = {k: kwargs[k] for k in ("gumbel0", "gumbel_cp", "forced_codes") if k in kwargs}
+        if kind == "base" and ref_audio is not None and ref_text is not None and self.speech_tokenizer.has_encoder:
+            # in-context cloning (:1227-1250); the stronger repetition penalty keeps long reference prefills from degenerating
+            yield from self._generate_icl(text, ref_audio, ref_text, language=lang_code, temperature=temperature, max_tokens=max_tokens, top_k=top_k,
+                                          top_p=top_p, repetition_penalty=max(repetition_penalty, 1.5), stream=stream, streaming_interval=streaming_interval,
+                                          streaming_context_size=streaming_context_size, seed=kwargs.get("seed"), **engine_kw)
+            return
+        if kind == "base" and voice is not None and voice.lower() not in [s.lower() for s in self.supported_speakers]:
+            raise ValueError(f"Voice '{voice}' is not supported by this Base model. Base models have no built-in preset voices — clone a voice by "
+                             "passing ref_audio and ref_text instead."
+                             + (f" Available preset voices: {self.supported_speakers}" if self.supported_speakers else ""))
+        clip = ref_audio if kind == "base" else None   # only the Base route hands the clip on (x-vector cloning, :1290-1297)
         segments = [s.strip() for s in text.split(split_pattern) if s.strip()] if split_pattern else [text]
         for segment_idx, seg in enumerate(segments):
             t0 = time.time()
-            x, trailing, pad = self._prepare_generation_inputs(seg, language=lang_code, speaker=voice if kind != "voice_design" else None, instruct=instruct)
+            x, trailing, pad = self._prepare_generation_inputs(seg, language=lang_code, speaker=voice if kind != "voice_design" else None, ref_audio=clip,
+                                                               ref_text=ref_text if kind == "base" else None, instruct=instruct)
             out = self._frame_loop(x, trailing, pad, max_tokens, temperature=temperature, top_k=top_k, top_p=top_p, repetition_penalty=repetition_penalty,
                                    seed=kwargs.get("seed"), pad_when_index_clamped=False, **engine_kw)
             codes = out["codes"][0]
@@ -354,6 +449,39 @@ class Model:
             torch.cuda.synchronize()
             yield self._result(audio, segment_idx, int(codes.shape[0]), time.time() - t0)
 
+    def _generate_icl(self, text: str, ref_audio, ref_text: str, language: str = "auto", temperature: float = 0.9, max_tokens: int = 4096, top_k: int = 50,
+                      top_p: float = 1.0, repetition_penalty: float = 1.5, stream: bool = False, streaming_interval: float = 2.0,
+                      streaming_context_size: int = 25, seed=None, **engine_kw) -> Generator[GenerationResult, None, None]:
+        """``qwen3_tts.py:2200-2510``: the whole text as ONE segment behind the in-context prompt; the frame loop is the engine's (prefill of the
+        prompt, then a talker step + 15 code-predictor steps per frame); decode behind the reference codes and cut them off.  ``stream=True``
+        yields chunks of the NEW audio only, each decoded with ``streaming_context_size`` frames of left context (the reference carries decoder
+        state across chunks instead)."""
+        t0 = time.time()
+        x, trailing, pad, ref_codes = self._prepare_icl_generation_inputs(text, ref_audio=ref_audio, ref_text=ref_text, language=language)
+        out = self._frame_loop(x, trailing, pad, max_tokens, temperature=temperature, top_k=top_k, top_p=top_p, repetition_penalty=repetition_penalty,
+                               seed=seed, pad_when_index_clamped=False, **engine_kw)
+        codes = out["codes"][0]
+        fa = int(out["finished_at"][0])
+        codes = codes[:fa] if fa >= 0 else codes
+        if codes.shape[0] == 0:
+            return
+        if stream:
+            chunk = max(1, int(streaming_interval * 12.5))
+            done = 0
+            up = self.speech_tokenizer.decode_upsample_rate
+            while done < codes.shape[0]:
+                end = min(done + chunk, codes.shape[0])
+                ctx = min(streaming_context_size, done)
+                wav = self.speech_tokenizer.decoder(codes[done - ctx:end].t()[None].contiguous()).squeeze(1)[0][ctx * up:]
+                torch.cuda.synchronize()
+                yield self._result(wav, 0, end - done, time.time() - t0, is_streaming_chunk=True, is_final_chunk=end == codes.shape[0])
+                done, t0 = end, time.time()
+            return
+        audio = self._decode_icl_generated_codes(codes, ref_codes)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        yield self._result(audio, 0, int(codes.shape[0]), time.time() - t0)
+
     def generate_custom_voice(self, text: str, speaker: str, language: str = "auto", instruct: Optional[str] = None, **kw):
         """``qwen3_tts.py:2062-2137``."""
         if getattr(self.config, "tts_model_type", "base") != "custom_voice":
@@ -366,6 +494,50 @@ class Model:
             raise ValueError("generate_voice_design needs a VoiceDesign checkpoint")
         yield from self.generate(text, instruct=instruct, lang_code=language, **kw)
 
+    @staticmethod
+    def _same_shared_ref_value(left, right) -> bool:
+        if isinstance(left, (str, Path)) and isinstance(right, (str, Path)):
+            return str(left) == str(right)
+        return left is right
+
+    def _normalize_shared_batch_refs(self, batch_size: int, *, ref_audio=None, ref_text: Optional[str] = None, ref_audios=None, ref_texts=None):
+        """``qwen3_tts.py:1582-1649``: ONE shared (clip, transcript) pair for a whole batch, given directly or as per-item lists that must all name
+        the same reference; both halves or neither."""
+        def shared_from_list(name, values):
+            if values is None:
+                return None
+            if len(values) != batch_size:
+                raise ValueError(f"{name} length ({len(values)}) must match texts length ({batch_size})")
+            present = [v for v in values if v is not None]
+            if not present:
+                return None
+            if len(present) != batch_size:
+                raise ValueError(f"Qwen3-TTS batch_generate requires {name} for every text when using reference cloning")
+            shared = present[0]
+            for v in present[1:]:
+                if not self._same_shared_ref_value(shared, v):
+                    raise ValueError(f"Qwen3-TTS batch_generate currently supports only one shared {name[:-1]} across the whole batch")
+            return shared
+
+        list_audio, list_text = shared_from_list("ref_audios", ref_audios), shared_from_list("ref_texts", ref_texts)
+        if list_audio is not None:
+            if ref_audio is not None and not self._same_shared_ref_value(ref_audio, list_audio):
+                raise ValueError("ref_audio and ref_audios must refer to the same shared reference")
+            ref_audio = list_audio
+        if list_text is not None:
+            if ref_text is not None and ref_text != list_text:
+                raise ValueError("ref_text and ref_texts must refer to the same shared reference")
+            ref_text = list_text
+        if ref_audio is None and ref_text is None:
+            return None, None
+        if ref_audio is None or ref_text is None:
+            raise ValueError("Qwen3-TTS batch reference cloning requires both ref_audio and ref_text")
+        if isinstance(ref_audio, (str, Path)):
+            from ....utils import load_audio
+
+            ref_audio = load_audio(str(ref_audio), sample_rate=self.sample_rate)
+        return ref_audio, ref_text
+
     def batch_generate(self, texts: List[str], voices: Optional[List[Optional[str]]] = None, instructs: Optional[List[Optional[str]]] = None,
                        ref_audio=None, ref_text: Optional[str] = None, ref_audios=None, ref_texts=None, temperature: float = 0.9,
                        lang_code: str = "auto", max_tokens: int = 4096, top_k: int = 50, top_p: float = 1.0, repetition_penalty: float = 1.05,
@@ -375,8 +547,6 @@ class Model:
         codec decode; yields one ``BatchGenerationResult`` per sequence in input order."""
         if self.speech_tokenizer is None:
             raise ValueError("Speech tokenizer not loaded")
-        if any(v is not None for v in (ref_audio, ref_text, ref_audios, ref_texts)):
-            raise NotImplementedError("in-context voice cloning needs the ECAPA speaker encoder, which this build does not ship")
         if stream:
             raise NotImplementedError("batch_generate(stream=True) is not wired to the engine yet")
         if not texts:
@@ -384,20 +554,34 @@ class Model:
         for name, lst in (("voices", voices), ("instructs", instructs)):
             if lst is not None and len(lst) != len(texts):
                 raise ValueError(f"{name} length ({len(lst)}) must match texts length ({len(texts)})")
+        ref_audio, ref_text = self._normalize_shared_batch_refs(len(texts), ref_audio=ref_audio, ref_text=ref_text, ref_audios=ref_audios, ref_texts=ref_texts)
+        use_icl = ref_audio is not None and ref_text is not None
+        caps = [max_tokens] * len(texts)
+        if use_icl:   # one shared reference clip in front of every sequence (:1724-1741, :1823-1827)
+            if not self.speech_tokenizer.has_encoder:
+                raise ValueError("Qwen3-TTS batch reference cloning requires a speech tokenizer encoder")
+            if any(v is not None for v in (voices or [])):
+                raise ValueError("Qwen3-TTS batch reference cloning does not support voices")
+            if any(v is not None for v in (instructs or [])):
+                raise ValueError("Qwen3-TTS batch reference cloning does not support instructs")
+            repetition_penalty = max(repetition_penalty, 1.5)
+            caps = [min(max_tokens, max(75, len(self.tokenizer.encode(t)) * 6)) for t in texts]
         t0 = time.time()
-        bi = self._prepare_batch_inputs(texts, language=lang_code, speakers=voices, instructs=instructs, return_metadata=True)
+        bi = self._prepare_batch_inputs(texts, language=lang_code, speakers=voices, instructs=instructs, ref_audio=ref_audio, ref_text=ref_text,
+                                        return_metadata=True)
         left = torch.tensor(bi.left_padding, dtype=torch.int32) if len(texts) > 1 else None
         engine_kw = {k: kwargs[k] for k in ("gumbel0", "gumbel_cp", "forced_codes") if k in kwargs}
-        out = self._frame_loop(bi.input_embeds, bi.trailing_text_hidden, bi.tts_pad_embed, max_tokens, temperature=temperature, top_k=top_k, top_p=top_p,
+        out = self._frame_loop(bi.input_embeds, bi.trailing_text_hidden, bi.tts_pad_embed, max(caps), temperature=temperature, top_k=top_k, top_p=top_p,
                                repetition_penalty=repetition_penalty, left_pad=left, seed=kwargs.get("seed"), **engine_kw)
         torch.cuda.synchronize()
         elapsed = time.time() - t0
         fa = out["finished_at"].cpu()
         for b in range(len(texts)):
             n = int(fa[b]) if int(fa[b]) >= 0 else out["codes"].shape[1]
+            n = min(n, caps[b])   # a row that reaches its own budget is finished there (rows never influence each other)
             if n == 0:
                 continue
-            audio = self._decode_generated_codes(out["codes"][b, :n])
+            audio = (self._decode_icl_generated_codes(out["codes"][b, :n], bi.ref_codes) if use_icl else self._decode_generated_codes(out["codes"][b, :n]))
             yield BatchGenerationResult(audio=audio, sequence_idx=b, samples=int(audio.shape[0]), sample_rate=self.sample_rate, token_count=n,
                                         audio_duration=format_duration(audio.shape[0] / self.sample_rate), processing_time_seconds=elapsed,
                                         peak_memory_usage=torch.cuda.max_memory_allocated() / 1e9)

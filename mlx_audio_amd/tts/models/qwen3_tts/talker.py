@@ -144,6 +144,17 @@ class Qwen3Talker:
         linear(h, self.fc2, out, precision=self.precision)
         return out
 
+    def embed_codes(self, codes: torch.Tensor) -> torch.Tensor:
+        """Sum over the code groups of the codec embeddings of whole frames (group 0: the talker's ``codec_embedding``, group i >= 1:
+        ``code_predictor.codec_embedding[i - 1]``): int ``[B, T, G]`` -> ``[B, T, hidden]`` -- the reference-clip half of an in-context prompt
+        (qwen3_tts.py:701-709), one gather-and-sum launch."""
+        ids = codes.to(self.device, torch.int32).contiguous()
+        B, T, G = ids.shape
+        assert G == self.cfg.num_code_groups, (G, self.cfg.num_code_groups)
+        out = self._f(B, T, self.cfg.hidden_size)
+        ops.embed_sum(self.codec_table, ids, out, slot_offset=self.codec_offs)
+        return out
+
     def _logits(self, h_last: torch.Tensor, head: Lin, norm=None) -> torch.Tensor:
         """h_last [B, 1, C] -> [B, V_padded] fp32 (``norm``: the producing stack's deferred final norm, applied in the GEMV prologue)."""
         B = h_last.shape[0]

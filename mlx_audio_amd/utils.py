@@ -140,6 +140,82 @@ def resample_audio(audio, orig_sample_rate: int, sample_rate: int, axis: int = -
     return _impl(audio, orig_sample_rate, sample_rate, axis=axis)
 
 
+def audio_volume_normalize(audio, coeff: float = 0.2):
+    """``mlx_audio.utils.audio_volume_normalize`` (utils.py:477-516): quiet clips (peak < 0.1) are first scaled to a peak of 0.1; then the mean of the
+    90th..99th percentile magnitudes above 0.01 is brought to ``coeff`` (gain clipped to [0.1, 10]) and the result to a peak of at most 1.  numpy in,
+    numpy out."""
+    import numpy as np
+
+    temp = np.sort(np.abs(audio))
+    if temp[-1] < 0.1:
+        audio = audio / max(temp[-1], 1e-3) * 0.1
+    temp = temp[temp > 0.01]
+    L = temp.shape[0]
+    if L <= 10:
+        return audio
+    volume = np.mean(temp[int(0.9 * L): int(0.99 * L)])
+    audio = audio * np.clip(coeff / volume, a_min=0.1, a_max=10)
+    peak = np.max(np.abs(audio))
+    return audio / peak if peak > 1 else audio
+
+
+def random_select_audio_segment(audio, length: int):
+    """``mlx_audio.utils.random_select_audio_segment`` (utils.py:519-538): a random window of ``length`` samples (zero-padded when the clip is shorter)."""
+    import random
+
+    import numpy as np
+
+    if audio.shape[0] < length:
+        audio = np.pad(audio, (0, int(length - audio.shape[0])))
+    start = random.randint(0, audio.shape[0] - length)
+    return audio[start: int(start + length)]
+
+
+def trim_silence(audio, top_db: float = 20, frame_length: int = 2048, hop_length: int = 512):
+    """``mlx_audio.utils.trim_silence`` (utils.py:580-617): frames whose RMS is within ``top_db`` of the loudest frame bound the kept span."""
+    import numpy as np
+    import torch
+
+    a = audio.detach().cpu().numpy() if isinstance(audio, torch.Tensor) else np.asarray(audio)
+    n_frames = 1 + (len(a) - frame_length) // hop_length
+    if n_frames <= 0:
+        return audio
+    rms = np.array([np.sqrt(np.mean(a[i * hop_length: i * hop_length + frame_length] ** 2)) for i in range(n_frames)])
+    rms_db = 20 * np.log10(np.maximum(rms, 1e-10))
+    keep = np.where(rms_db >= np.max(rms_db) - top_db)[0]
+    if len(keep) == 0:
+        return audio
+    out = a[int(keep[0]) * hop_length: min((int(keep[-1]) + 1) * hop_length + frame_length, len(a))].astype(np.float32, copy=False)
+    return torch.from_numpy(np.ascontiguousarray(out)).to(audio.device) if isinstance(audio, torch.Tensor) else out
+
+
+def load_audio(audio, sample_rate: int = 24000, length: Optional[int] = None, volume_normalize: bool = False, segment_duration: Optional[int] = None):
+    """``mlx_audio.utils.load_audio`` (utils.py:620-676): a path is read (mono, resampled to ``sample_rate``, float32), optionally cut to a random
+    segment, volume-normalised, padded / truncated to ``length``; a tensor (the reference: an ``mx.array``) is returned as is.  Returns a float32
+    ``torch.Tensor`` on the host; the engines move it to the device."""
+    import os
+
+    import numpy as np
+    import torch
+
+    if isinstance(audio, torch.Tensor):
+        return audio
+    if not isinstance(audio, str):
+        raise TypeError(f"audio must be str or torch.Tensor, got {type(audio)}")
+    from .audio_io import read as audio_read
+
+    if not os.path.exists(audio):
+        raise FileNotFoundError(f"Audio file not found: {audio}")
+    samples, _ = audio_read(audio, dtype="float32", sample_rate=sample_rate, nchannels=1)
+    if segment_duration is not None:
+        samples = random_select_audio_segment(samples, int(sample_rate * segment_duration))
+    if volume_normalize:
+        samples = audio_volume_normalize(samples)
+    if length is not None:
+        samples = samples[:length] if samples.shape[0] > length else np.pad(samples, (0, int(length - samples.shape[0])))
+    return torch.from_numpy(np.ascontiguousarray(samples, dtype=np.float32))
+
+
 # ``mlx_audio.utils`` re-exports the dsp entry points (utils.py:31-40; the reference's tests import them from here: tests/test_dsp.py:30-38).  Resolved
 # lazily so that ``import mlx_audio_amd.utils`` (loader, registry users) does not pull the dsp module in.
 _DSP_REEXPORTS = ("STR_TO_WINDOW_FN", "bartlett", "blackman", "hamming", "hanning", "istft", "mel_filters", "stft")

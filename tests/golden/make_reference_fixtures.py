@@ -1017,6 +1017,137 @@ def run_qwen3_inputs(seed):
     return out
 
 
+def run_qwen3_speaker_encoder(seed_w, seed_mel, frames):
+    """The reference's ``Qwen3TTSSpeakerEncoder`` (speaker_encoder.py:232-313: TDNN -> three SE-Res2Net blocks -> MFA -> attentive statistics pooling ->
+    fc) on a seeded tiny checkpoint (loaded in the module's own layout) and a seeded mel batch; also the reference's ``sanitize`` of the same
+    parameters in their PyTorch form at widths where its shape heuristic is unambiguous (``ref_sanitize``-style summary)."""
+    import pt_layouts as PT
+    import torch
+
+    from mlx_audio_amd.tts.models.qwen3_tts import speaker_encoder as SE
+
+    import_qwen3_model()
+    rs = sys.modules["mlx_audio.tts.models.qwen3_tts.speaker_encoder"]
+    rc = sys.modules["mlx_audio.tts.models.qwen3_tts.config"]
+    c = SE.tiny_speaker_encoder_config()
+    w = SE.make_speaker_encoder_weights(c, seed=seed_w)
+    from dataclasses import asdict
+
+    model = rs.Qwen3TTSSpeakerEncoder(rc.Qwen3TTSSpeakerEncoderConfig(**asdict(c)))
+    model.load_weights([(k, v.numpy()) for k, v in w.items()])
+    missing, unexpected, mism = model._load_report
+    assert not missing and not unexpected and not mism, (missing[:8], unexpected[:8], mism[:4])
+    mels = SE.make_mels(2, frames, c.mel_dim, seed=seed_mel).numpy()
+    emb = np.asarray(model(mx.array(mels))).astype(np.float32)
+    # sanitize: widths > 64 so that (out, in, 1) kernels are recognised as PyTorch-form (qwen3_tts.py:123-157)
+    c2 = SE.Qwen3TTSSpeakerEncoderConfig(mel_dim=80, enc_dim=72, enc_channels=[96, 96, 96, 192], enc_kernel_sizes=[5, 3, 3, 1], enc_dilations=[1, 2, 3, 1],
+                                         enc_attention_channels=80, enc_res2net_scale=4, enc_se_channels=72)
+    w2 = SE.make_speaker_encoder_weights(c2, seed=seed_w + 1)
+    ck = {"speaker_encoder." + k: (v.permute(0, 2, 1).contiguous() if v.dim() == 3 else v) for k, v in w2.items()}
+    ck["talker.model.norm.weight"] = torch.ones(4)   # dropped: not a speaker-encoder key
+    san = rs.Qwen3TTSSpeakerEncoder.sanitize({k: mx.array(v.numpy()) for k, v in ck.items()})
+    import json
+
+    return dict(seed_w=seed_w, seed_mel=seed_mel, frames=frames, embedding=emb,
+                sanitize=json.dumps(PT.summary({k: torch.from_numpy(np.asarray(v)) for k, v in san.items()})))
+
+
+def run_qwen3_icl(seed):
+    """The reference's voice-cloning host logic of Qwen3-TTS on scripted parts (``pt_layouts``: character tokenizer, seeded embedding tables, stand-ins for
+    the speech tokenizer's encode / decode and for the x-vector): ``_prepare_icl_generation_inputs`` (qwen3_tts.py:606-803), the in-context branch of
+    ``_prepare_batch_inputs`` (:509-527), ``_prepare_generation_inputs`` with a clip but no transcript (:383-384), ``_decode_icl_generated_codes``
+    (:1085-1112), ``_normalize_shared_batch_refs`` (:1582-1649) and ``supports_tts_batch`` with references (:233-244)."""
+    import json
+
+    import pt_layouts as PT
+
+    q = import_qwen3_model()
+    g = np.random.default_rng(seed)
+    H = 8
+    text_table = g.standard_normal((PT.QWEN3_TEXT_VOCAB, H)).astype(np.float32)
+    codec_table = g.standard_normal((PT.QWEN3_CODEC_VOCAB, H)).astype(np.float32)
+    cp_tables = g.standard_normal((PT.QWEN3_ICL_GROUPS - 1, PT.QWEN3_ICL_CP_VOCAB, H)).astype(np.float32)
+
+    class CodePredictor:
+        codec_embedding = [(lambda ids, i=i: mx.array(cp_tables[i])[ids]) for i in range(PT.QWEN3_ICL_GROUPS - 1)]
+
+    class Talker:
+        code_predictor = CodePredictor()
+
+        def get_text_embeddings(self):
+            return lambda ids: mx.array(text_table)[ids]
+
+        def text_projection(self, x):
+            return x
+
+        def get_input_embeddings(self):
+            return lambda ids: mx.array(codec_table)[ids]
+
+    class SpeechTokenizer:
+        has_encoder = True
+
+        def encode(self, audio):
+            return mx.array(PT.qwen3_fake_codes(np.asarray(audio)))
+
+        def decode(self, codes):
+            a, n = PT.qwen3_fake_decode(np.asarray(codes))
+            return mx.array(a), mx.array(n)
+
+    class Host:
+        _prepare_generation_inputs = q.Model._prepare_generation_inputs
+        _prepare_icl_generation_inputs = q.Model._prepare_icl_generation_inputs
+        _prepare_batch_inputs = q.Model._prepare_batch_inputs
+        _decode_icl_generated_codes = q.Model._decode_icl_generated_codes
+        _normalize_shared_batch_refs = q.Model._normalize_shared_batch_refs
+        _same_shared_ref_value = staticmethod(q.Model._same_shared_ref_value)
+        supports_tts_batch = q.Model.supports_tts_batch
+        tokenizer = PT.QwenCharTokenizer()
+        talker = Talker()
+        sample_rate = 24000
+
+        def __init__(self, xvec=True, kind="base", enc=True):
+            self.config = PT.qwen3_icl_config(kind)
+            self.speaker_encoder = object() if xvec else None
+            self.speech_tokenizer = None if enc is None else SpeechTokenizer()
+            if enc is False:
+                self.speech_tokenizer.has_encoder = False
+            self._icl_cache = {}
+
+        def extract_speaker_embedding(self, audio, sr=24000):
+            return mx.array(PT.qwen3_fake_xvector(np.asarray(audio), H))
+
+    def clip(spec):
+        n, s, lead = spec
+        a = PT.qwen3_fake_clip(n, s)
+        return mx.array(a.reshape((1,) * lead + (n,)))
+
+    out = dict(seed=seed, text_table=text_table, codec_table=codec_table, cp_tables=cp_tables)
+    hosts = {True: Host(True), False: Host(False)}
+    for i, c in enumerate(PT.QWEN3_ICL_CASES):
+        e, tr, pad, rc_ = hosts[c["xvec"]]._prepare_icl_generation_inputs(c["text"], ref_audio=clip(c["clip"]), ref_text=c["ref_text"], language=c["language"])
+        out[f"icl_embeds{i}"], out[f"icl_trailing{i}"], out[f"icl_pad{i}"] = (np.asarray(v).astype(np.float32) for v in (e, tr, pad))
+        out[f"icl_codes{i}"] = np.asarray(rc_).astype(np.int64)
+    out["cache_entries"] = np.array([len(hosts[True]._icl_cache), len(hosts[False]._icl_cache)])
+    b = PT.QWEN3_ICL_BATCH
+    bi = Host(True)._prepare_batch_inputs(b["texts"], language=b["language"], ref_audio=clip(b["clip"]), ref_text=b["ref_text"], return_metadata=True)
+    out.update(batch_embeds=np.asarray(bi.input_embeds).astype(np.float32), batch_trailing=np.asarray(bi.trailing_text_hidden).astype(np.float32),
+               batch_mask=np.asarray(bi.attention_mask).astype(np.float32), left_padding=np.array(bi.left_padding), prefill_lens=np.array(bi.prefill_lens),
+               trailing_lens=np.array(bi.trailing_lens), batch_ref_codes=np.asarray(bi.ref_codes).astype(np.int64))
+    for i, c in enumerate(PT.QWEN3_XVEC_CASES):
+        e, tr, pad = Host(c["xvec"])._prepare_generation_inputs(c["text"], language=c["language"], speaker=c["speaker"], ref_audio=clip(c["clip"]))
+        out[f"xvec_embeds{i}"], out[f"xvec_trailing{i}"] = np.asarray(e).astype(np.float32), np.asarray(tr).astype(np.float32)
+    h = Host(True)
+    for i, (n_gen, n_ref) in enumerate(PT.QWEN3_ICL_DECODE_CASES):
+        gen, ref = PT.qwen3_icl_decode_case(n_gen, n_ref)
+        audio = h._decode_icl_generated_codes([mx.array(gen[j:j + 1]) for j in range(n_gen)], mx.array(ref))
+        out[f"decoded{i}"] = np.asarray(audio).astype(np.float32)
+    q.load_audio = lambda path, sample_rate=None: "loaded:" + str(path)
+    tables = dict(shared=[PT.qwen3_shared_ref_outcome(h._normalize_shared_batch_refs, c) for c in PT.QWEN3_SHARED_REF_CASES],
+                  supports=[bool(Host(True, c["kind"], c["enc"]).supports_tts_batch(**c["kw"])) for c in PT.QWEN3_SUPPORTS_BATCH_CASES])
+    out["tables"] = json.dumps(tables)
+    return out
+
+
 def run_kokoro_pipeline():
     """The reference's ``KokoroPipeline`` (tts/models/kokoro/pipeline.py) with the G2P and the model replaced by stand-ins: ``__call__`` on English
     token streams (``en_tokenize`` / ``waterfall_last`` / ``tokens_to_ps`` / ``tokens_to_text``, ``join_timestamps`` on the stand-in's durations,
@@ -1606,6 +1737,15 @@ def run_whisper_generate():
 
 def main():
     R = import_reference()
+    if "qwen3_clone" in sys.argv[1:]:   # only the voice-cloning fixtures (round 3)
+        sfx = run_qwen3_speaker_encoder(seed_w=13, seed_mel=5, frames=37)
+        np.savez_compressed(os.path.join(HERE, "ref_qwen3_speaker_encoder.npz"), **sfx)
+        print("qwen3 speaker encoder:", sfx["embedding"].shape, "peak", float(np.abs(sfx["embedding"]).max()))
+        ifx = run_qwen3_icl(seed=19)
+        np.savez_compressed(os.path.join(HERE, "ref_qwen3_icl.npz"), **ifx)
+        print("qwen3 icl:", {a: v.shape for a, v in ifx.items() if hasattr(v, "shape") and a.startswith(("icl_embeds", "batch_embeds", "xvec_embeds", "decoded"))})
+        print(ifx["tables"])
+        return
     n = check_shim_against_reference_vectors(R)
     print(f"stand-in passes the reference's ConvTranspose / MLXSTFT vectors (both model families) and {n} interpolate vectors")
     k = run_kokoro(R, seed_w=21, n_phon=10, seed_ids=4, speed=1.0, seed_rng=5)
@@ -1672,6 +1812,11 @@ def main():
     lfx = run_qwen3_generate_loop(seed_w=7)
     np.savez_compressed(os.path.join(HERE, "ref_qwen3_generate_loop.npz"), **lfx)
     print("qwen3 generate loop:", lfx["budget_codes"][:, 0].tolist(), "eos", lfx["eos_id"], lfx["eos_codes"].shape)
+    sfx = run_qwen3_speaker_encoder(seed_w=13, seed_mel=5, frames=37)
+    np.savez_compressed(os.path.join(HERE, "ref_qwen3_speaker_encoder.npz"), **sfx)
+    ifx = run_qwen3_icl(seed=19)
+    np.savez_compressed(os.path.join(HERE, "ref_qwen3_icl.npz"), **ifx)
+    print("qwen3 clone:", sfx["embedding"].shape, len(ifx))
     qfx = run_qwen3_inputs(seed=17)
     np.savez_compressed(os.path.join(HERE, "ref_qwen3_inputs.npz"), **qfx)
     print("qwen3 inputs:", {a: v.shape for a, v in qfx.items() if hasattr(v, "shape") and a.startswith(("embeds", "batch"))})

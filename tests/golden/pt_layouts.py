@@ -203,6 +203,122 @@ QWEN3_BATCH_CASE = dict(texts=["Hello world, this is the long one.", "Hi", "Ni h
                         instructs=[None, "Be brief", None])
 
 
+# ---- Qwen3-TTS voice cloning: in-context prompts, x-vector prompts, decode behind the reference codes, the batch's shared-reference rules
+# (make_reference_fixtures.run_qwen3_icl and tests/test_tts_prompt_assembly_cpu.py share these stand-ins and case tables)
+QWEN3_ICL_GROUPS, QWEN3_ICL_CP_VOCAB, QWEN3_ICL_UP = 4, 64, 8
+
+
+def qwen3_fake_clip(n, seed):
+    import numpy as _np
+
+    return (_np.random.default_rng(seed).standard_normal(n) * 0.1).astype(_np.float32)
+
+
+def qwen3_fake_codes(audio):
+    """Stand-in for ``speech_tokenizer.encode``: [1, 1, n] (any leading ones) -> codes [1, groups, n // 50], values < 40, some first codes 0."""
+    import numpy as _np
+
+    a = _np.asarray(audio, dtype=_np.float64).reshape(-1)
+    T = len(a) // 50
+    base = _np.floor(_np.abs(a[:T * 50].reshape(T, 50)).sum(1) * 40).astype(_np.int64)
+    return _np.stack([(base + 11 * g) % 40 for g in range(QWEN3_ICL_GROUPS)], 0)[None].astype(_np.int64)
+
+
+def qwen3_fake_xvector(audio, H):
+    import numpy as _np
+
+    a = _np.asarray(audio, dtype=_np.float64).reshape(-1)
+    return _np.cos(_np.arange(1, H + 1) * (1.0 + float(_np.abs(a).sum())))[None].astype(_np.float32)
+
+
+def qwen3_fake_decode(codes):
+    """Stand-in for ``speech_tokenizer.decode``: codes [1, T, groups] -> (audio [1, T * up] that depends on every code, valid sample counts [1])."""
+    import numpy as _np
+
+    c = _np.asarray(codes, dtype=_np.int64)
+    per_frame = (c * _np.arange(1, c.shape[2] + 1)).sum(2).astype(_np.float32) / 100.0          # [1, T]
+    audio = (per_frame[:, :, None] + _np.arange(QWEN3_ICL_UP, dtype=_np.float32) / 1000.0).reshape(1, -1)
+    return audio.astype(_np.float32), ((c[..., 0] > 0).sum(1) * QWEN3_ICL_UP).astype(_np.int64)
+
+
+def qwen3_icl_config(kind="base"):
+    c = qwen3_input_config()
+    c.talker_config.num_code_groups = QWEN3_ICL_GROUPS
+    c.tts_model_type = kind
+    return c
+
+
+# clip: (samples, seed, leading axes added before the call); xvec: whether the model has a speaker encoder
+QWEN3_ICL_CASES = [
+    dict(text="Hello there.", ref_text="Reference words", language="auto", clip=(400, 1, 0), xvec=True),
+    dict(text="Bonjour", ref_text="Reference words", language="English", clip=(400, 1, 0), xvec=True),      # same clip + transcript: cache hit; language id
+    dict(text="A", ref_text="Other transcript", language="klingon", clip=(650, 2, 1), xvec=True),            # [1, n] clip; unknown language
+    dict(text="No x-vector here", ref_text="Ref", language="chinese", clip=(300, 3, 0), xvec=False),
+]
+QWEN3_ICL_BATCH = dict(texts=["First sentence of the batch.", "Two", "And a third one"], ref_text="Shared reference", language="auto", clip=(500, 4, 0))
+# plain prompts with a clip but no transcript: the x-vector takes the speaker slot (also over a named speaker); ignored without a speaker encoder
+QWEN3_XVEC_CASES = [
+    dict(text="Hello world.", language="auto", speaker=None, clip=(400, 1, 0), xvec=True),
+    dict(text="Hello.", language="English", speaker="Vivian", clip=(350, 5, 0), xvec=True),
+    dict(text="Hello.", language="English", speaker="Vivian", clip=(350, 5, 0), xvec=False),
+]
+# (generated frames, reference frames): decode behind the reference codes, trim to the valid length, cut the reference's share
+QWEN3_ICL_DECODE_CASES = [(5, 3), (1, 9), (7, 1), (0, 4)]
+
+
+def qwen3_icl_decode_case(n_gen, n_ref):
+    import numpy as _np
+
+    g = _np.random.default_rng(100 * n_gen + n_ref)
+    gen = g.integers(0, 3, size=(n_gen, QWEN3_ICL_GROUPS)).astype(_np.int64)        # zeros among the first codes: "invalid" frames
+    ref = g.integers(1, 40, size=(1, QWEN3_ICL_GROUPS, n_ref)).astype(_np.int64)
+    return gen, ref
+
+
+_A, _B = "clip-a.wav", "clip-b.wav"
+QWEN3_SHARED_REF_CASES = [
+    dict(n=2),
+    dict(n=2, ref_audio=_A, ref_text="t"),
+    dict(n=2, ref_audio=_A),
+    dict(n=2, ref_text="t"),
+    dict(n=2, ref_audios=[_A, _A], ref_texts=["t", "t"]),
+    dict(n=2, ref_audios=[_A, _B], ref_texts=["t", "t"]),
+    dict(n=2, ref_audios=[_A, _A], ref_texts=["t", "u"]),
+    dict(n=2, ref_audios=[_A, None], ref_texts=["t", "t"]),
+    dict(n=2, ref_audios=[_A], ref_texts=["t", "t"]),
+    dict(n=2, ref_audios=[None, None], ref_texts=[None, None]),
+    dict(n=2, ref_audio=_B, ref_audios=[_A, _A], ref_texts=["t", "t"]),
+    dict(n=2, ref_audio=_A, ref_text="u", ref_audios=[_A, _A], ref_texts=["t", "t"]),
+    dict(n=3, ref_audio=_A, ref_texts=["t", "t", "t"]),
+]
+
+
+def qwen3_shared_ref_outcome(fn, case):
+    kw = {k: v for k, v in case.items() if k != "n"}
+    try:
+        a, t = fn(case["n"], **kw)
+        return ["ok", a, t]     # the caller patches load_audio to return "loaded:<path>"
+    except ValueError as e:
+        return ["error", str(e)]
+
+
+QWEN3_SUPPORTS_BATCH_CASES = [
+    dict(kind="base", enc=True, kw=dict(ref_audio="x", ref_text="t")),
+    dict(kind="base", enc=False, kw=dict(ref_audio="x", ref_text="t")),
+    dict(kind="base", enc=True, kw=dict(ref_audio="x")),
+    dict(kind="base", enc=True, kw=dict(ref_text="t")),
+    dict(kind="base", enc=True, kw=dict(ref_audio="x", ref_text="t", voice="vivian")),
+    dict(kind="base", enc=True, kw=dict(ref_audio="x", ref_text="t", instruct="slow")),
+    dict(kind="base", enc=True, kw=dict(ref_audio="x", ref_text="t", stream=True)),
+    dict(kind="base", enc=True, kw=dict(ref_audio="x", ref_text="t", speed=1.2)),
+    dict(kind="custom_voice", enc=True, kw=dict(ref_audio="x", ref_text="t", voice="vivian")),
+    dict(kind="custom_voice", enc=True, kw=dict(voice="vivian")),
+    dict(kind="voice_design", enc=True, kw=dict(instruct="deep")),
+    dict(kind="base", enc=True, kw=dict()),
+    dict(kind="base", enc=None, kw=dict(ref_audio="x", ref_text="t")),     # no speech tokenizer at all
+]
+
+
 # ---- CSM prompt frames + generate bookkeeping (make_reference_fixtures.run_csm_generate and tests/test_tts_prompt_assembly_cpu.py)
 CSM_CODEBOOKS = 4
 

@@ -282,3 +282,48 @@ def test_polyphase_table_restates_resample_poly(orig, target, n):
     got = np.einsum("nk,nk->n", table[:, t % up].T, x[idx].astype(np.float64)).astype(np.float32)
     assert np.abs(got - want).max() <= 1.2e-7 * max(1.0, float(np.abs(want).max()))
     assert ((255 * down) // up + K + 1) * 8 <= 64 * 1024      # the kernel's LDS window
+
+
+def test_load_audio_and_level_helpers(tmp_path):
+    """``mlx_audio.utils.load_audio`` (utils.py:620-676) and the helpers it uses (``audio_volume_normalize`` :477-516, ``random_select_audio_segment``
+    :519-538, ``trim_silence`` :580-617), against a direct numpy statement of each rule: a 48 kHz stereo file comes back mono float32 at the asked
+    rate; tensors pass through; ``length`` pads / truncates; errors keep the reference's types."""
+    import pytest
+
+    from mlx_audio_amd.audio_io import write
+    from mlx_audio_amd.utils import audio_volume_normalize, load_audio, random_select_audio_segment, trim_silence
+
+    t = np.arange(48000) / 48000.0
+    st = np.stack([0.5 * np.sin(2 * np.pi * 440 * t), 0.25 * np.sin(2 * np.pi * 440 * t)], axis=1).astype(np.float32)
+    write(str(tmp_path / "a.wav"), st, 48000)
+    a = load_audio(str(tmp_path / "a.wav"), sample_rate=24000)
+    assert isinstance(a, torch.Tensor) and a.dtype == torch.float32 and a.dim() == 1 and abs(a.numel() - 24000) <= 1
+    assert abs(float(a[2000:-2000].abs().max()) - 0.375) < 5e-3                      # channel mean of the two amplitudes
+    assert load_audio(a) is a
+    assert load_audio(str(tmp_path / "a.wav"), length=30000).numel() == 30000 and float(load_audio(str(tmp_path / "a.wav"), length=30000)[-100:].abs().max()) == 0.0
+    assert load_audio(str(tmp_path / "a.wav"), length=500).numel() == 500
+    assert load_audio(str(tmp_path / "a.wav"), segment_duration=0.25).numel() == 6000
+    with pytest.raises(FileNotFoundError):
+        load_audio(str(tmp_path / "missing.wav"))
+    with pytest.raises(TypeError):
+        load_audio(np.zeros(4, dtype=np.float32))
+    # volume rule: loud enough clip -> the 90..99th percentile magnitudes (> 0.01) average to coeff; peak never above 1
+    g = np.random.default_rng(0)
+    x = (g.standard_normal(5000) * 0.05).astype(np.float32)
+    y = audio_volume_normalize(x.copy())
+    mags = np.sort(np.abs(x))
+    mags = mags[mags > 0.01]
+    gain = np.clip(0.2 / np.mean(mags[int(0.9 * len(mags)): int(0.99 * len(mags))]), 0.1, 10)
+    assert np.allclose(y, x * gain / max(1.0, float(np.abs(x * gain).max())), rtol=1e-6) and float(np.abs(y).max()) <= 1.0
+    q = audio_volume_normalize(np.full(100, 1e-4, dtype=np.float32))                  # quiet: peak raised to 0.1 * (1e-4 / 1e-3), no second stage
+    assert np.allclose(q, 1e-4 / 1e-3 * 0.1)
+    vn = load_audio(str(tmp_path / "a.wav"), sample_rate=24000, volume_normalize=True)
+    assert float(vn.abs().max()) <= 1.0 and not torch.allclose(vn, a)
+    seg = random_select_audio_segment(np.arange(10, dtype=np.float32), 4)
+    assert len(seg) == 4 and np.all(np.diff(seg) == 1)
+    assert len(random_select_audio_segment(np.ones(3, dtype=np.float32), 8)) == 8
+    sil = np.concatenate([np.zeros(8192), 0.5 * np.sin(np.arange(16384) * 0.05), np.zeros(8192)]).astype(np.float32)
+    tr = trim_silence(sil)
+    assert 16384 <= len(tr) < len(sil) and isinstance(tr, np.ndarray)
+    assert isinstance(trim_silence(torch.from_numpy(sil)), torch.Tensor) and trim_silence(torch.from_numpy(sil)).numel() == len(tr)
+    assert trim_silence(sil[:100]) is not None and len(trim_silence(sil[:100])) == 100   # shorter than a frame: returned as is

@@ -13,6 +13,7 @@ reference the restated oracle had missed -- KittenTTS's SineGen keeps ``upsample
 points where Kokoro's has 2F (oracle, HIP kernel and engine now carry ``coarse_f32``).
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -225,6 +226,46 @@ def test_qwen3_tokenizer_encode_oracle_reproduces_the_reference_modules():
     print(f"qwen3 tokenizer encode oracle vs reference: smallest decision gap {float(margins.min()):.3f}")
     assert np.array_equal(codes.numpy(), fx["codes"])
     assert not np.array_equal(MimiEncoderRef(w, RC(**base), param_dtype=torch.float32)(pcm).numpy(), fx["codes"])
+
+
+def test_qwen3_speaker_encoder_oracle_and_sanitize_reproduce_the_reference_module():
+    """``ref_qwen3_speaker_encoder.npz`` = the reference's own ``Qwen3TTSSpeakerEncoder`` (speaker_encoder.py:232-313) run on a seeded tiny checkpoint and a
+    seeded mel batch: the restatement gives its embedding; and this package's ``Qwen3TTSSpeakerEncoder.sanitize`` returns what the reference's returns
+    (:315-340: prefix stripped, other keys dropped, PyTorch conv layouts transposed) for the same PyTorch-form checkpoint."""
+    import json
+
+    from mlx_audio_amd.tts.models.qwen3_tts import speaker_encoder as SE
+    from oracle.ecapa_ref import EcapaRef
+
+    fx = np.load(os.path.join(GOLD, "ref_qwen3_speaker_encoder.npz"))
+    c = SE.tiny_speaker_encoder_config()
+    w = SE.make_speaker_encoder_weights(c, seed=int(fx["seed_w"]))
+    mels = SE.make_mels(2, int(fx["frames"]), c.mel_dim, seed=int(fx["seed_mel"]))
+    want = fx["embedding"]
+    got = EcapaRef(w, c)(mels).numpy()
+    err, peak = float(np.abs(got - want).max()), float(np.abs(want).max())
+    err64 = float(np.abs(EcapaRef(w, c, dtype=torch.float64)(mels).numpy() - want).max())
+    print(f"ecapa oracle vs reference: max-abs {err:.2e} (float64 restatement {err64:.2e}, peak {peak:.2f})")
+    assert got.shape == want.shape == (2, c.enc_dim) and peak > 1.0
+    assert err < 1e-5 * peak and err64 < 1e-5 * peak
+    # the two utterances differ, and the attention is not uniform (the pooled statistics are not the plain moments)
+    assert float(np.abs(want[0] - want[1]).max()) > 0.05 * peak
+
+    c2 = SE.Qwen3TTSSpeakerEncoderConfig(mel_dim=80, enc_dim=72, enc_channels=[96, 96, 96, 192], enc_kernel_sizes=[5, 3, 3, 1], enc_dilations=[1, 2, 3, 1],
+                                         enc_attention_channels=80, enc_res2net_scale=4, enc_se_channels=72)
+    w2 = SE.make_speaker_encoder_weights(c2, seed=int(fx["seed_w"]) + 1)
+    ck = {"speaker_encoder." + k: (v.permute(0, 2, 1).contiguous() if v.dim() == 3 else v) for k, v in w2.items()}
+    ck["talker.model.norm.weight"] = torch.ones(4)
+    sys.path.insert(0, GOLD)
+    import pt_layouts as PT
+
+    san = SE.Qwen3TTSSpeakerEncoder.sanitize(ck)
+    exp = json.loads(str(fx["sanitize"]))
+    got_s = PT.summary(san)
+    assert set(got_s) == set(exp) == set(w2)
+    for k, (shape, s1, s2) in exp.items():
+        assert got_s[k][0] == shape and abs(got_s[k][1] - s1) <= 1e-6 * (1 + abs(s1)) and abs(got_s[k][2] - s2) <= 1e-6 * (1 + s2), k
+        assert torch.equal(san[k], w2[k]), k     # i.e. the module's own layout comes back
 
 
 def test_qwen3_talker_oracle_reproduces_the_reference_modules():
