@@ -1,0 +1,292 @@
+"""Qwen3-TTS voice cloning on the device (VERDICT r2 "missing 6": the speaker encoder and the encode sides gate ``ref_audio`` / in-context prompts):
+the ECAPA-TDNN speaker encoder against the reference's own module run (tests/golden/ref_qwen3_speaker_encoder.npz) and against the float64
+restatement at the published widths; its three row kernels against their definitions; the in-context prompt, generation and decode of ``Model`` on a
+synthetic Base checkpoint that carries all four parts (talker, speaker encoder, tokenizer encoder + decoder).  Needs an MI355X."""
+import os
+import sys
+from dataclasses import asdict
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _rel(got, want):
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    return float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
+
+
+def test_ecapa_row_kernels_against_their_definitions():
+    from mlx_audio_amd import ops
+
+    ops.require_gpu()
+    g = torch.Generator().manual_seed(0)
+    B, T, C = 3, 37, 64
+    big = torch.randn(B, T, 96, generator=g)
+    res_big = torch.randn(B, T, 80, generator=g)
+    gate = torch.randn(B, C, generator=g) * 2
+    x, res = big[:, :, 16:80], res_big[:, :, 8:72]                       # channel slices: row strides 96 / 80
+    xd, rd, gd = big.to(DEV)[:, :, 16:80], res_big.to(DEV)[:, :, 8:72], gate.to(DEV)
+    for pad in (0, 1, 4):
+        idx = torch.arange(-pad, T + pad).abs()
+        idx = torch.where(idx >= T, 2 * (T - 1) - idx, idx)
+        yb = torch.full((B, T + 2 * pad, 128), 7.0, device=DEV)
+        ops.ecapa_rows(xd, yb[:, :, 32:96], pad=pad, gate=gd, res=rd, pre_tanh=True)
+        want = torch.tanh(x.double()[:, idx]) * torch.sigmoid(gate.double())[:, None, :] + res.double()[:, idx]
+        assert _rel(yb[:, :, 32:96], want) < 2e-6, pad
+        assert float((yb[:, :, :32] - 7.0).abs().max()) == 0.0 and float((yb[:, :, 96:] - 7.0).abs().max()) == 0.0   # nothing outside the slice
+        y2 = torch.empty((B, T + 2 * pad, C), device=DEV)
+        ops.ecapa_rows(xd, y2, pad=pad)
+        assert torch.equal(y2.cpu(), x[:, idx])                                                                        # the plain reflect-padded copy is exact
+        y3 = torch.empty((B, T + 2 * pad, C), device=DEV)
+        ops.ecapa_rows(xd, y3, pad=pad, res=rd)
+        assert torch.equal(y3.cpu(), (x + res)[:, idx])
+    with pytest.raises(Exception):
+        ops.ecapa_rows(xd[:, :3], torch.empty((B, 3 + 6, C), device=DEV), pad=3)                                       # reflect needs pad < T
+    # moments and attentive pooling: 70 channels (a partly filled 64-channel group), short and long clips
+    for T2 in (1, 5, 37, 1000):
+        x2 = (torch.randn(2, T2, 70, generator=g) * 2 + 1)
+        lg = torch.randn(2, T2, 70, generator=g) * 3
+        mean, std = ops.time_moments(x2.to(DEV), eps=1e-12)
+        xd2 = x2.double()
+        assert _rel(mean, xd2.mean(1)) < 2e-6 and _rel(std, torch.sqrt(xd2.var(1, unbiased=False) + 1e-12)) < 1e-5, T2
+        m_only, none = ops.time_moments(x2.to(DEV), want_std=False)
+        assert none is None and torch.equal(m_only, mean)
+        out = ops.attentive_pool(x2.to(DEV), lg.to(DEV), eps=1e-12)
+        w = torch.softmax(lg.double(), 1)
+        wm = (w * xd2).sum(1)
+        ws = torch.sqrt(((w * (xd2 - wm[:, None]) ** 2).sum(1)).clamp_min(1e-12))
+        assert tuple(out.shape) == (2, 140)
+        assert _rel(out[:, :70], wm) < 5e-6 and float((out[:, 70:].double().cpu() - ws).abs().max()) < 1e-5 * float(ws.max()) + 2e-6, T2
+
+
+def test_speaker_encoder_engine_vs_reference_run():
+    """The device engine against the reference's own ``Qwen3TTSSpeakerEncoder`` run (tiny widths: 16-channel Res2Net chunks, every stage on the path),
+    stage by stage against the float64 restatement.  Bar: 2e-3 of the peak (bf16-exact weights, hi + lo split activations, as for every conv here)."""
+    from mlx_audio_amd.tts.models.qwen3_tts import speaker_encoder as SE
+    from oracle.ecapa_ref import EcapaRef
+
+    fx = np.load(os.path.join(GOLD, "ref_qwen3_speaker_encoder.npz"))
+    c = SE.tiny_speaker_encoder_config()
+    w = SE.make_speaker_encoder_weights(c, seed=int(fx["seed_w"]))
+    mels = SE.make_mels(2, int(fx["frames"]), c.mel_dim, seed=int(fx["seed_mel"]))
+    enc = SE.Qwen3TTSSpeakerEncoder(c, w, device=DEV)
+    st = {}
+    emb = enc(mels.to(DEV), stages=st)
+    torch.cuda.synchronize()
+    want = torch.from_numpy(fx["embedding"])
+    ost = {}
+    EcapaRef(w, c, dtype=torch.float64)(mels, ost)
+    for k in ("block1", "block2", "block3", "mfa", "asp_logits", "pooled"):
+        e = ost[k] if k != "pooled" else ost[k][:, 0]
+        assert tuple(st[k].shape) == tuple(e.shape), (k, tuple(st[k].shape), tuple(e.shape))
+        assert _rel(st[k], e) < 2e-3, (k, _rel(st[k], e))
+    print(f"speaker encoder vs the reference run: {_rel(emb, want):.2e} of the peak")
+    assert tuple(emb.shape) == tuple(want.shape) and _rel(emb, want) < 2e-3
+    # one clip alone gives the same row (nothing leaks across the batch)
+    solo = enc(mels[1:2].to(DEV))
+    assert _rel(solo, want[1:2]) < 2e-3 and float((solo - emb[1:2]).abs().max()) < 2e-3 * float(want.abs().max())
+    with pytest.raises(ValueError):
+        enc(mels[:, :3].to(DEV))            # fewer frames than the widest reflect padding
+    with pytest.raises(ValueError):
+        SE.Qwen3TTSSpeakerEncoder(c, {k: v for k, v in w.items() if not k.startswith("mfa.")}, device=DEV)
+
+
+@pytest.mark.parametrize("batch,frames", [(1, 280), (3, 97)])
+def test_speaker_encoder_at_the_published_widths(batch, frames):
+    """``Qwen3TTSSpeakerEncoderConfig()`` defaults = the shipped Base checkpoints (config.py:8-33: 128 mels, 512-wide blocks of 8 x 64-channel chunks,
+    dilations 2 / 3 / 4, 1536-wide MFA and pooling, 1024-d embedding): seeded parameters, ~3 s and ~1 s clips, against the float64 restatement."""
+    from mlx_audio_amd.tts.models.qwen3_tts import speaker_encoder as SE
+    from mlx_audio_amd.tts.models.qwen3_tts.config import Qwen3TTSSpeakerEncoderConfig
+    from oracle.ecapa_ref import EcapaRef
+
+    c = Qwen3TTSSpeakerEncoderConfig()
+    w = SE.make_speaker_encoder_weights(c, seed=2)
+    mels = SE.make_mels(batch, frames, c.mel_dim, seed=7)
+    enc = SE.Qwen3TTSSpeakerEncoder(c, w, device=DEV)
+    emb = enc(mels.to(DEV))
+    torch.cuda.synchronize()
+    want = EcapaRef(w, c, dtype=torch.float64)(mels)
+    print(f"speaker encoder, published widths, {batch} x {frames} frames: {_rel(emb, want):.2e} of the peak")
+    assert tuple(emb.shape) == (batch, c.enc_dim) and bool(torch.isfinite(emb).all())
+    assert _rel(emb, want) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------ Model: x-vector and in-context cloning
+class _Tok:
+    """Chat-template specials get fixed ids, every other character its own id (tests/test_tts_model_protocol_gpu.py uses the same rule)."""
+    SPECIAL = {"<|im_start|>": 1, "assistant": 2, "user": 5, "\n": 3, "<|im_end|>": 4}
+
+    def __init__(self, vocab):
+        self.vocab = vocab
+
+    def encode(self, text, **kw):
+        import re
+
+        ids = []
+        for piece in re.split("(" + "|".join(re.escape(k) for k in self.SPECIAL) + ")", text):
+            if piece in self.SPECIAL:
+                ids.append(self.SPECIAL[piece])
+            else:
+                ids.extend(10 + (ord(ch) * 7) % (self.vocab - 20) for ch in piece)
+        return ids
+
+
+@pytest.fixture(scope="module")
+def clone_model():
+    sys.path.insert(0, GOLD)
+    import pt_layouts as PT
+    from mlx_audio_amd.codec.models.mimi import mimi as M
+    from mlx_audio_amd.tts.models.qwen3_tts import speaker_encoder as SE
+    from mlx_audio_amd.tts.models.qwen3_tts import synthetic as QS
+    from mlx_audio_amd.tts.models.qwen3_tts import talker as T
+    from mlx_audio_amd.tts.models.qwen3_tts.config import ModelConfig, Qwen3TTSSpeakerEncoderConfig, Qwen3TTSTokenizerConfig
+    from mlx_audio_amd.tts.models.qwen3_tts.qwen3_tts import Model
+    from mlx_audio_amd.tts.models.qwen3_tts.speech_tokenizer import Qwen3TTSSpeechTokenizer as Tok
+
+    tc = T.tiny_talker_config()          # codec vocabulary 1200, EOS 1150: the special ids below sit in its suppressed tail like the real ones do
+    tc.codec_think_id, tc.codec_nothink_id, tc.codec_think_bos_id, tc.codec_think_eos_id, tc.codec_pad_id, tc.codec_bos_id = 1154, 1155, 1156, 1157, 1148, 1149
+    tc.codec_language_id = {"english": 1160}
+    tw = T.make_talker_weights(tc, seed=3)
+    sc = Qwen3TTSSpeakerEncoderConfig(mel_dim=128, enc_dim=tc.hidden_size, enc_channels=[64, 64, 64, 64, 192], enc_attention_channels=32,
+                                      enc_res2net_scale=4, enc_se_channels=32)
+    sw = SE.make_speaker_encoder_weights(sc, seed=5)
+    cfg = ModelConfig(talker_config=tc, speaker_encoder_config=sc, tts_model_type="base", tts_pad_token_id=497, tts_bos_token_id=498, tts_eos_token_id=499)
+    model = Model(cfg, device=DEV)
+    model.load_weights({**{"talker." + k: v for k, v in tw.items()}, **{"speaker_encoder." + k: v for k, v in sw.items()}})
+    mc = M.tiny_mimi_config()
+    mw = {**M.make_mimi_decoder_weights(mc, seed=9), **M.make_mimi_encoder_weights(mc, seed=9)}
+    dcfg = QS.tiny_codec_config()
+    cw = QS.make_codec_decoder_weights(dcfg, seed=4)
+    ck = {**PT.qwen3_codec_checkpoint(cw), **PT.qwen3_tokenizer_encoder_checkpoint(mw, mc.num_layers, mc.quantizer_nq)}
+    ec = dict(hidden_size=mc.dimension, num_filters=mc.nfilters, upsampling_ratios=list(mc.ratios), kernel_size=mc.ksize, residual_kernel_size=mc.residual_ksize,
+              last_kernel_size=mc.last_ksize, compress=mc.compress, num_attention_heads=mc.num_heads, num_key_value_heads=mc.num_heads,
+              num_hidden_layers=mc.num_layers, intermediate_size=mc.dim_feedforward, sliding_window=mc.context, max_position_embeddings=mc.max_seq_len,
+              num_quantizers=mc.quantizer_nq, codebook_size=mc.quantizer_bins, codebook_dim=mc.quantizer_dim)
+    tok = Tok(Qwen3TTSTokenizerConfig(encoder_config=ec, decoder_config=dcfg), device=DEV)
+    tok.load_weights(Tok.sanitize(ck))
+    model.load_speech_tokenizer(tok)
+    model.tokenizer = _Tok(tc.text_vocab_size)
+    clip = M.make_pcm(1, 12000, seed=11)[0, 0]           # half a second at 24 kHz: 7 codec frames, 46 mel frames
+    return dict(model=model, tc=tc, tw=tw, sc=sc, sw=sw, dcfg=dcfg, cw=cw, clip=clip)
+
+
+def test_talker_embed_codes_is_the_sum_of_the_group_embeddings(clone_model):
+    m, tc, tw = clone_model["model"], clone_model["tc"], clone_model["tw"]
+    g = torch.Generator().manual_seed(1)
+    codes = torch.randint(0, 64, (2, 5, tc.num_code_groups), generator=g)
+    got = m.talker.embed_codes(codes)
+    r16 = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    want = r16(tw["model.codec_embedding.weight"])[codes[..., 0]]
+    for i in range(tc.num_code_groups - 1):
+        want = want + r16(tw[f"code_predictor.model.codec_embedding.{i}.weight"])[codes[..., i + 1]]
+    assert tuple(got.shape) == (2, 5, tc.hidden_size) and _rel(got, want) < 1e-6
+
+
+def test_qwen3_x_vector_and_in_context_cloning(clone_model):
+    """``extract_speaker_embedding`` = fused mel front end + ECAPA engine (against the restatement fed the same mel); the in-context prompt against an
+    independent restatement of qwen3_tts.py:606-803 on the oracle's tensors; ``generate(ref_audio, ref_text)``: audio = the codec oracle's decode of
+    [reference codes | generated codes] with the reference's share cut off; the transcript-less route puts the x-vector in the speaker slot."""
+    from mlx_audio_amd import dsp
+    from mlx_audio_amd.tts.models.base import GenerationResult
+    from oracle.ecapa_ref import EcapaRef
+    from oracle.qwen3_codec_ref import Qwen3CodecDecoderRef
+    from oracle.qwen3_talker_ref import Qwen3TalkerRef
+
+    c = clone_model
+    m, tc, clip = c["model"], c["tc"], c["clip"]
+    assert m.speaker_encoder is not None and m.speech_tokenizer.has_encoder
+    assert m.supports_tts_batch(ref_audio=clip, ref_text="x") and not m.supports_tts_continuous_batch(ref_audio=clip, ref_text="x")
+    # ---- x-vector
+    xv = m.extract_speaker_embedding(clip)
+    mels = dsp.mel_spectrogram(clip, n_fft=1024, num_mels=128, sample_rate=24000, hop_size=256, win_size=1024, fmin=0, fmax=12000)
+    torch.cuda.synchronize()
+    assert tuple(mels.shape) == (1, 46, 128) and tuple(xv.shape) == (1, tc.hidden_size)
+    want_xv = EcapaRef(c["sw"], c["sc"], dtype=torch.float64)(mels.cpu())
+    assert _rel(xv, want_xv) < 2e-3
+    with pytest.raises(ValueError):
+        m.extract_speaker_embedding(clip, sr=16000)
+    # ---- in-context prompt, restated on the oracle's tensors
+    ref = Qwen3TalkerRef(c["tw"], tc)
+    W, tok = ref.w, m.tokenizer
+    emb = lambda ids: ref.text_projection(W["model.text_embedding.weight"][torch.tensor([ids])])
+    cod = lambda ids: W["model.codec_embedding.weight"][torch.tensor([ids])]
+    text, ref_text = "clone this voice", "what the clip says"
+    x, tr, pad, codes = m._prepare_icl_generation_inputs(text, ref_audio=clip, ref_text=ref_text, language="english")
+    torch.cuda.synchronize()
+    codes = torch.as_tensor(codes).cpu()
+    assert tuple(codes.shape) == (1, tc.num_code_groups, 7) and tuple(tr.shape) == (1, 1, tc.hidden_size) and torch.equal(tr, pad)
+    tts = emb([498, 499, 497])
+    bos, eos, tpad = tts[:, 0:1], tts[:, 1:2], tts[:, 2:3]
+    ids_t = tok.encode(f"<|im_start|>assistant\n{text}<|im_end|>\n<|im_start|>assistant\n")
+    ids_r = tok.encode(f"<|im_start|>assistant\n{ref_text}<|im_end|>\n")
+    text_embed = torch.cat([emb(ids_r[3:-2] + ids_t[3:-5]), eos], dim=1)
+    frames = W["model.codec_embedding.weight"][codes[:, 0]]
+    for i in range(tc.num_code_groups - 1):
+        frames = frames + W[f"code_predictor.model.codec_embedding.{i}.weight"][codes[:, i + 1]]
+    icl = torch.cat([text_embed + cod([tc.codec_pad_id]), torch.cat([cod([tc.codec_bos_id]), frames], dim=1) + tpad], dim=1)
+    prefix = torch.cat([cod([tc.codec_think_id, tc.codec_think_bos_id, tc.codec_language_id["english"], tc.codec_think_eos_id]),
+                        want_xv.float().reshape(1, 1, -1), cod([tc.codec_pad_id, tc.codec_bos_id])], dim=1)
+    combined = torch.cat([tpad.expand(1, prefix.shape[1] - 2, -1), bos], dim=1) + prefix[:, :-1]
+    ex = torch.cat([emb(ids_t[:3]), combined, icl], dim=1)
+    slot = 3 + 4                                                                          # role (3) + think prefix with a language id (4): the x-vector's position
+    rest = [i for i in range(ex.shape[1]) if i != slot]
+    assert x.shape == ex.shape and _rel(x[:, rest], ex[:, rest]) < 3e-4 and _rel(x[:, slot], ex[:, slot]) < 2e-3 and _rel(pad, tpad) < 3e-4
+    # the second call takes codes and transcript ids from the cache (one encoder pass per clip)
+    assert len(m._icl_cache) == 1
+    x2, _, _, codes2 = m._prepare_icl_generation_inputs("other words", ref_audio=clip, ref_text=ref_text)
+    assert len(m._icl_cache) == 1 and codes2 is not None and torch.equal(torch.as_tensor(codes2).cpu(), codes) and x2.shape[1] != x.shape[1]
+    # ---- generate(): one result; its audio = decode of [reference | generated] codes minus the reference's share.  The generated frames are forced
+    # (engine keyword): the decode path is what is under test here, the frame loop has its own tests
+    frames_n = 6
+    g = torch.Generator().manual_seed(5)
+    forced = torch.randint(1, 64, (1, frames_n, tc.num_code_groups), generator=g)
+    forced[0, 2, 0] = 0                                                                   # first code 0: not counted as valid audio (speech_tokenizer.py:1112-1116)
+    res = list(m.generate(text, ref_audio=clip, ref_text=ref_text, lang_code="english", temperature=0.0, max_tokens=frames_n, verbose=False, forced_codes=forced))
+    assert len(res) == 1 and isinstance(res[0], GenerationResult) and res[0].segment_idx == 0 and res[0].token_count == frames_n
+    gen = forced[0]
+    full = torch.cat([codes[0].t(), gen.long()], dim=0)                                   # [ref + gen, groups]
+    cref = Qwen3CodecDecoderRef(c["cw"], c["dcfg"])
+    wav = cref.chunked_decode(full.t()[None].long())[0, 0]
+    valid = int((full[:, 0] > 0).sum()) * 1920
+    assert 0 < valid < wav.shape[0]
+    wav = wav[:valid]
+    cut = int(7 / full.shape[0] * wav.shape[0])
+    wav = wav[cut:] if 0 < cut < wav.shape[0] else wav
+    got = res[0].audio.cpu()
+    assert got.shape == wav.shape and res[0].samples == got.shape[0]
+    assert float((got - wav).abs().max()) <= 2e-3 * max(1.0, float(wav.abs().max()))
+    # streaming: chunks of the NEW audio only
+    chunks = list(m.generate(text, ref_audio=clip, ref_text=ref_text, lang_code="english", temperature=0.0, max_tokens=frames_n, stream=True, streaming_interval=0.16,
+                             forced_codes=forced))
+    assert len(chunks) == 3 and all(r.is_streaming_chunk for r in chunks) and chunks[-1].is_final_chunk and not chunks[0].is_final_chunk
+    assert sum(r.samples for r in chunks) == frames_n * 1920 and sum(r.token_count for r in chunks) == frames_n
+    # ---- a clip without a transcript: the x-vector sits in the speaker slot of the plain prompt (qwen3_tts.py:383-384)
+    xa, tra, _ = m._prepare_generation_inputs(text, language="english", ref_audio=clip)
+    xb, trb, _ = m._prepare_generation_inputs(text, language="english")
+    torch.cuda.synchronize()
+    assert xa.shape[1] == xb.shape[1] + 1 and torch.equal(tra, trb)
+    assert _rel(xa[:, slot], (tpad[:, 0] + want_xv.float())) < 2e-3
+    assert torch.equal(xa[:, :slot], xb[:, :slot])
+    r = list(m.generate(text, ref_audio=clip, lang_code="english", temperature=0.0, max_tokens=3, forced_codes=forced[:, :3]))
+    assert len(r) == 1 and r[0].token_count == 3 and r[0].samples == 2 * 1920 and bool(torch.isfinite(r[0].audio).all())   # frame 2 is the "invalid" one
+    # ---- the shared-reference batch: one result per text, in order, each decoded behind the same reference codes
+    texts = ["first one", "and a second, longer sentence"]
+    fb = torch.randint(1, 64, (2, 5, tc.num_code_groups), generator=g)
+    br = list(m.batch_generate(texts, ref_audio=clip, ref_text=ref_text, temperature=0.0, max_tokens=5, forced_codes=fb))
+    assert [b.sequence_idx for b in br] == [0, 1]
+    for b in br:
+        fullb = torch.cat([codes[0].t(), fb[b.sequence_idx].long()], dim=0)
+        wb = cref.chunked_decode(fullb.t()[None].long())[0, 0]
+        wb = wb[int(7 / fullb.shape[0] * wb.shape[0]):]
+        assert b.token_count == 5 and b.samples == b.audio.shape[0] == wb.shape[0]
+        assert float((b.audio.cpu() - wb).abs().max()) <= 2e-3 * max(1.0, float(wb.abs().max()))
+    with pytest.raises(ValueError):
+        list(m.batch_generate(texts, ref_audio=clip, ref_text=ref_text, voices=["vivian", None]))
+    with pytest.raises(ValueError):
+        list(m.batch_generate(texts, ref_audio=clip))

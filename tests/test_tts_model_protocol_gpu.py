@@ -152,8 +152,13 @@ def test_qwen3_tts_load_model_and_generate(qwen3_ckpt):
     # ---- routing errors of the reference
     with pytest.raises(ValueError):
         list(model.generate(text, voice="nobody"))
-    with pytest.raises(NotImplementedError):
-        list(model.generate(text, ref_audio=torch.zeros(100), ref_text="x"))
+    # this checkpoint has neither the speaker encoder nor the tokenizer's encoder half: like the reference (qwen3_tts.py:383, 1227-1231) a reference
+    # clip then changes nothing (the cloning paths are covered by tests/test_qwen3_clone_gpu.py)
+    assert model.speaker_encoder is None
+    xa, tra, _ = model._prepare_generation_inputs(text, language="english", ref_audio=torch.zeros(100), ref_text="x")
+    xb, trb, _ = model._prepare_generation_inputs(text, language="english")
+    assert torch.equal(xa, xb) and torch.equal(tra, trb)
+    assert not model.supports_tts_batch(ref_audio=torch.zeros(100), ref_text="x")
 
 
 def test_qwen3_tts_batch_generate_left_padded(qwen3_ckpt):
