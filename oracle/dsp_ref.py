@@ -9,6 +9,13 @@ The reference delegates the FFT itself to ``mx.fft.rfft/irfft`` (mlx 0.31.2, not
 vendored); here it is ``numpy.fft`` evaluated in float64 and rounded once to
 float32/complex64, which is the correctly-rounded value any fp32 FFT
 approximates.  Everything else mirrors the reference's float32 arithmetic.
+
+Parity status: **pinned twice**.  (1) The reference's own golden vectors and known-answer tests for this path (SURVEY section 8c:
+``tts/tests/test_qwen3_tts.py:175-353`` STFT + mel vectors, ``tts/tests/test_istftnet_fidelity.py:18-46`` MLXSTFT round trip, ``mlx_audio/tests/test_dsp.py:62-95`` ISTFTCache bound), transcribed
+into tests/golden/reference_vectors.json and checked by tests/test_oracle_golden.py.  (2) The reference's ``dsp.py`` and ``mel_spectrogram``
+executed as they are (imported from /root/reference over the numpy stand-in for MLX, tests/golden/make_reference_fixtures.py ``run_dsp``) on seeded
+noise + tones: ``ref_dsp.npz``, against which tests/test_reference_fixtures_cpu.py finds this restatement bit-identical on the forward transforms
+and filter banks and within 2e-7 on the inverses.
 """
 from __future__ import annotations
 

@@ -4,6 +4,11 @@ Index arithmetic is done in float32 exactly as the reference's MLX ops do it
 (``mx.arange(size)`` int32 times a Python-float scalar -> float32, one rounding
 per op); this matters for SineGen, whose x300 up-sampling multiplies index
 rounding errors by phase slopes of hundreds of radians.
+
+Parity status: **pinned** to the reference's own interpolate vectors (``tts/tests/test_interpolate.py:40-97``: nearest / linear, align_corners on and
+off, scale factors and sizes; transcribed into tests/golden/reference_vectors.json, tests/test_oracle_golden.py::test_interpolate_golden); the
+reference's ``interpolate.py`` itself, executed over the numpy stand-in for MLX, reproduces the same vectors (``check_shim_against_reference_vectors``
+in tests/golden/make_reference_fixtures.py) and runs inside every Kokoro / KittenTTS reference fixture this oracle's callers are held to.
 """
 from __future__ import annotations
 

@@ -19,8 +19,17 @@ Canonical parameter names (each model maps its checkpoint onto them: ``tts/model
   ``layers.{i}.ls1|ls2`` (LayerScale), ``final_norm.weight[/bias]``.
 
 Precision model: parameters hold bf16-representable values (checkpoint dtype), arithmetic float32 (float64 on request).
-Parity status: **unpinned end to end** (no golden logits exist in the reference for these models); ``vendor_parity`` pins the
-reference's ``lm`` package bit-exactly against ``mlx_lm`` only, which is equally unavailable here.
+Parity status: **pinned to the reference's own modules through every model that uses it** (rounds 2-3; this header said "unpinned" until then): the
+reference ships no golden logits, so tests/golden/make_reference_fixtures.py executes the reference's source files (imported from /root/reference,
+unmodified, over the numpy stand-in for MLX in tests/golden/mlx_shim.py) on seeded tiny checkpoints, and tests/test_reference_fixtures_cpu.py holds
+``StackRef`` to the results in each of its four configurations: the Qwen3-TTS talker + code predictor (``ref_qwen3_talker_tiny.npz``: prefill and two
+cached steps, hidden states and logits 2e-5 of the peak; ``ref_qwen3_generate_loop.npz``: the greedy ``generate`` loop's codes), the Qwen3 codec transformer
+(``ref_qwen3_codec_tiny.npz``), the Mimi transformers of both directions (``ref_mimi_tiny.npz`` decode and frame-by-frame ``decode_step``;
+``ref_mimi_encode.npz`` and ``ref_qwen3_tokenizer_encode.npz``: encoder transformer under both RoPE conventions, all codes equal) and the CSM
+backbone + depth decoder (``ref_csm_tiny.npz``).  ``KVCacheRef`` is held to the reference's own ``KVCache`` / ``BatchKVCache`` operation sequences
+(``ref_cache.json``, tests/test_cache_cpu.py).  What stays unpinned: MLX's kernels themselves (the stand-in implements their documented semantics and
+passes the reference's own ConvTranspose / MLXSTFT / interpolate vectors), and ``vendor_parity`` (bit-exactness of the reference's ``lm`` package
+against ``mlx_lm``, which is equally unavailable here).
 """
 from __future__ import annotations
 

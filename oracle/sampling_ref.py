@@ -6,6 +6,12 @@ over the set of generated tokens -> temperature -> top-k -> probability filters 
 ``mx.random.categorical(logits)`` draws arg-max(logits + Gumbel noise); the noise is an explicit argument here so that two
 implementations can be compared draw by draw.  Ties inside top-k (``mx.argpartition`` leaves them unspecified) resolve to the lower
 index, like the device kernel.
+
+Parity status: **pinned to the reference's own chain**: tests/golden/make_reference_fixtures.py ``run_sampler`` executes the reference's
+``_sample_token_batch`` and ``lm/sample_utils.py`` (imported from /root/reference over the numpy stand-in for MLX) with the final categorical draw
+replaced by a probe; ``ref_sampler.npz`` holds which logits survive the filters (and their values) for four parameter sets and the greedy arg-max;
+tests/test_reference_fixtures_cpu.py::test_sampling_oracle_reproduces_the_reference_chain holds this file to them, and the same vectors feed the
+device sampler's test.
 """
 from __future__ import annotations
 
