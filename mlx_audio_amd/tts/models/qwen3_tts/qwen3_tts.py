@@ -11,8 +11,8 @@ Voice cloning (round 3): ``ref_audio`` alone adds the clip's x-vector to the cod
 path (``_prepare_icl_generation_inputs`` :606-803, ``_generate_icl`` :2200-2510, the shared-reference batch :1724-2045): the clip's codes from the
 speech tokenizer's ENCODER, its transcript and the x-vector of the ECAPA speaker encoder (``speaker_encoder.py``) in the prefill, the reference codes
 in front of the generated ones at decode time, the reference's share of the waveform cut off proportionally.
-Not in this build (raise, never silently degrade): streaming chunk decode with
-carried codec state (``stream=True`` decodes each chunk with left context).
+Not in this build: streaming chunk decode with carried codec state (``stream=True`` decodes each chunk behind left context instead, which is also
+what the reference's ``batch_generate(stream=True)`` does).
 """
 from __future__ import annotations
 
@@ -547,8 +547,6 @@ class Model:
         codec decode; yields one ``BatchGenerationResult`` per sequence in input order."""
         if self.speech_tokenizer is None:
             raise ValueError("Speech tokenizer not loaded")
-        if stream:
-            raise NotImplementedError("batch_generate(stream=True) is not wired to the engine yet")
         if not texts:
             return
         for name, lst in (("voices", voices), ("instructs", instructs)):
@@ -569,6 +567,11 @@ class Model:
         t0 = time.time()
         bi = self._prepare_batch_inputs(texts, language=lang_code, speakers=voices, instructs=instructs, ref_audio=ref_audio, ref_text=ref_text,
                                         return_metadata=True)
+        if stream:
+            yield from self._batch_generate_stream(bi, caps, t0, temperature=temperature, top_k=top_k, top_p=top_p, repetition_penalty=repetition_penalty,
+                                                   streaming_interval=streaming_interval, seed=kwargs.get("seed"), use_icl=use_icl,
+                                                   slots=kwargs.get("slots"), codes_log=kwargs.get("codes_log"))
+            return
         left = torch.tensor(bi.left_padding, dtype=torch.int32) if len(texts) > 1 else None
         engine_kw = {k: kwargs[k] for k in ("gumbel0", "gumbel_cp", "forced_codes") if k in kwargs}
         out = self._frame_loop(bi.input_embeds, bi.trailing_text_hidden, bi.tts_pad_embed, max(caps), temperature=temperature, top_k=top_k, top_p=top_p,
@@ -585,6 +588,76 @@ class Model:
             yield BatchGenerationResult(audio=audio, sequence_idx=b, samples=int(audio.shape[0]), sample_rate=self.sample_rate, token_count=n,
                                         audio_duration=format_duration(audio.shape[0] / self.sample_rate), processing_time_seconds=elapsed,
                                         peak_memory_usage=torch.cuda.max_memory_allocated() / 1e9)
+
+    def _batch_generate_stream(self, bi: Qwen3BatchInputs, caps: List[int], t0: float, *, temperature: float, top_k: int, top_p: float,
+                               repetition_penalty: float, streaming_interval: float, seed=None, use_icl: bool = False, slots=None,
+                               codes_log: Optional[dict] = None):
+        """The streaming half of ``batch_generate`` (``qwen3_tts.py:1845-1853, 1935-2010``): every sequence owns a slot of the step-wise engine
+        (``Qwen3TalkerSlots``: one prefill for the whole batch, then one talker step + the code-predictor steps per frame for all rows); whenever a
+        sequence has ``int(streaming_interval * 12.5)`` new frames they are decoded behind up to 25 frames of its own left context (none for its first
+        chunk), the context's samples are cut off and the chunk is yielded; what is left when every row is finished (EOS, its frame budget, the end
+        of the rotary tables) goes out flagged ``is_final_chunk`` -- like the reference, a sequence that ends exactly on a chunk boundary gets no
+        final flag, except in the in-context batch when the step that exhausts the last open budget also completes a chunk (the reference leaves
+        its loop before the emission there, :1926-1933).  ``slots`` / ``codes_log``: test hooks (a scripted engine; sequence index -> all frames)."""
+        B = bi.input_embeds.shape[0]
+        if slots is None:
+            from .talker import Qwen3TalkerSlots
+
+            if B > self.talker.talker.max_decode_rows:
+                raise NotImplementedError(f"batch_generate(stream=True) steps at most {self.talker.talker.max_decode_rows} sequences at once")
+            gen = None
+            if temperature > 0:
+                gen = torch.Generator(device=self.talker.device)
+                gen.manual_seed(int(seed) if seed is not None else int(torch.seed() % (2 ** 31)))
+            rows = self.talker.talker.cos.shape[0]
+            slots = Qwen3TalkerSlots(self.talker, B, max(1, min(max(caps), rows - 1)), temperature=temperature, top_k=top_k, top_p=top_p,
+                                     repetition_penalty=repetition_penalty, generator=gen)
+        chunk = max(1, int(streaming_interval * 12.5))
+        ctx_max = 25                                   # the vocoder's left context (qwen3_tts.py:1846-1847: the argument is not consulted)
+        up = self.speech_tokenizer.decode_upsample_rate
+        frames, decoded = [0] * B, [0] * B
+
+        def emit(b: int, final: bool):
+            new = frames[b] - decoded[b]
+            ctx = 0 if decoded[b] == 0 else min(ctx_max, decoded[b])
+            codes = slots.take_codes(b, frames[b])[decoded[b] - ctx:]
+            wav = self.speech_tokenizer.decoder.chunked_decode(codes.t()[None].contiguous()).squeeze(1)[0]
+            if ctx > 0 and ctx * up < wav.shape[0]:
+                wav = wav[ctx * up:]
+            decoded[b] = frames[b]
+            extra = dict(is_final_chunk=True) if final else {}
+            return BatchGenerationResult(audio=wav, sequence_idx=b, samples=int(wav.shape[0]), sample_rate=self.sample_rate, token_count=new,
+                                         audio_duration=format_duration(wav.shape[0] / self.sample_rate), processing_time_seconds=time.time() - t0,
+                                         peak_memory_usage=torch.cuda.max_memory_allocated() / 1e9 if torch.cuda.is_available() else 0.0,
+                                         is_streaming_chunk=True, **extra)
+
+        fin = slots.admit(list(range(B)), bi.input_embeds, bi.left_padding, bi.trailing_text_hidden, bi.tts_pad_embed)
+        done = [False] * B
+        for b in range(B):
+            frames[b] = 0 if fin[b] else 1
+            done[b] = bool(fin[b]) or frames[b] >= min(caps[b], slots.limit[b])
+        while True:
+            if not (use_icl and all(done)):
+                for b in range(B):
+                    if frames[b] - decoded[b] >= chunk:
+                        yield emit(b, False)
+            if all(done):
+                break
+            fin = slots.advance(B)
+            for b in range(B):
+                if done[b]:
+                    continue
+                if not fin[b]:
+                    frames[b] += 1
+                done[b] = bool(fin[b]) or frames[b] >= min(caps[b], slots.limit[b])
+        for b in range(B):
+            if frames[b] > decoded[b]:
+                yield emit(b, True)
+        if codes_log is not None:
+            for b in range(B):
+                codes_log[b] = slots.take_codes(b, frames[b])
+        for b in range(B):
+            slots.release(b)
 
     @classmethod
     def from_pretrained(cls, path: Union[str, Path]) -> "Model":

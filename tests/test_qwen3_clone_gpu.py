@@ -161,7 +161,9 @@ def clone_model():
     model.load_weights({**{"talker." + k: v for k, v in tw.items()}, **{"speaker_encoder." + k: v for k, v in sw.items()}})
     mc = M.tiny_mimi_config()
     mw = {**M.make_mimi_decoder_weights(mc, seed=9), **M.make_mimi_encoder_weights(mc, seed=9)}
-    dcfg = QS.tiny_codec_config()
+    from dataclasses import replace
+
+    dcfg = replace(QS.tiny_codec_config(), codebook_size=256)   # every code the free-running talker (176 first codes) and code predictor (96) can emit has an entry
     cw = QS.make_codec_decoder_weights(dcfg, seed=4)
     # the decoder half in the module's own layout (what ``sanitize`` returns at the published widths; at these tiny widths its shape heuristic cannot tell
     # (out, in, 1) from (out, K, 1), qwen3_tts.py:123-157), the encoder half from its HuggingFace form through ``sanitize``
@@ -293,3 +295,33 @@ def test_qwen3_x_vector_and_in_context_cloning(clone_model):
         list(m.batch_generate(texts, ref_audio=clip, ref_text=ref_text, voices=["vivian", None]))
     with pytest.raises(ValueError):
         list(m.batch_generate(texts, ref_audio=clip))
+
+
+@pytest.mark.parametrize("cloned", [False, True])
+def test_qwen3_batch_generate_streams_chunks_from_the_slot_engine(clone_model, cloned):
+    """``batch_generate(stream=True)`` (qwen3_tts.py:1845-1853, 1935-2010) on ``Qwen3TalkerSlots``: per sequence, chunks of 3 frames as they
+    become available, each = the codec oracle's decode of the window behind its left context with the context's samples cut off; the frames behind the
+    chunks are the engine's own (``codes_log``); plain and shared-reference batches."""
+    from oracle.qwen3_codec_ref import Qwen3CodecDecoderRef
+
+    c = clone_model
+    m = c["model"]
+    cref = Qwen3CodecDecoderRef(c["cw"], c["dcfg"])
+    texts = ["first one", "and a second, longer sentence", "x"]
+    ref = dict(ref_audio=c["clip"], ref_text="what the clip says") if cloned else {}
+    log = {}
+    out = list(m.batch_generate(texts, temperature=0.0, max_tokens=8, stream=True, streaming_interval=0.24, codes_log=log, **ref))
+    assert sorted(log) == [0, 1, 2] and all(r.is_streaming_chunk for r in out)
+    pos = [0, 0, 0]
+    for r in out:
+        b = r.sequence_idx
+        new = r.token_count
+        assert new == 3 or r.is_final_chunk or pos[b] + new == 8                      # whole chunks, except the tail
+        ctx = min(25, pos[b])
+        win = log[b][pos[b] - ctx: pos[b] + new].cpu()
+        wav = cref.chunked_decode(win.t()[None].long())[0, 0][ctx * 1920:]
+        got = r.audio.cpu()
+        assert got.shape == wav.shape and r.samples == new * 1920
+        assert float((got - wav).abs().max()) <= 2e-3 * max(float(wav.abs().max()), 1e-3), (b, pos[b])
+        pos[b] += new
+    assert pos == [int(log[b].shape[0]) for b in range(3)] and max(pos) >= 1 and all(p <= 8 for p in pos)

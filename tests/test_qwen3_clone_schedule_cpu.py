@@ -290,3 +290,94 @@ def test_batch_generate_with_a_shared_reference(monkeypatch):
     m.speech_tokenizer.has_encoder = False
     with pytest.raises(ValueError, match="requires a speech tokenizer encoder"):
         list(m.batch_generate(texts, ref_audio=clip, ref_text="w"))
+
+
+# ------------------------------------------------------------------------------------------------ batch_generate(stream=True) on a scripted slot engine
+class _ScriptedSlots:
+    """The interface of ``Qwen3TalkerSlots`` with every row's life fixed in advance: row b produces ``n[b]`` frames, then EOS."""
+
+    def __init__(self, n):
+        self.n, self.f = list(n), [0] * len(n)
+        self.limit = [10 ** 9] * len(n)
+        self.released = []
+
+    def admit(self, slots, input_embeds, left_pad, trailing, tts_pad):
+        assert slots == list(range(len(self.n))) and input_embeds.shape[0] == len(self.n)
+        out = []
+        for b in slots:
+            fin = self.n[b] <= 0
+            self.f[b] = 0 if fin else 1
+            out.append(fin)
+        return out
+
+    def advance(self, n_rows):
+        out = []
+        for b in range(n_rows):
+            fin = self.f[b] >= self.n[b]
+            if not fin:
+                self.f[b] += 1
+            out.append(fin)
+        return out
+
+    def take_codes(self, b, n):
+        assert n <= self.f[b]
+        return (1 + (torch.arange(n)[:, None] * 3 + torch.arange(PT.QWEN3_ICL_GROUPS)[None] + 5 * b) % 30).to(torch.int64)
+
+    def release(self, b):
+        self.released.append(b)
+
+
+def _reference_stream_events(n, caps, max_tokens, chunk, use_icl):
+    """qwen3_tts.py:1860-2010 restated as bookkeeping only: (sequence, new frames, context frames, final flag) in emission order."""
+    B = len(n)
+    gen, dec, fin, ev = [0] * B, [0] * B, [False] * B, []
+    for _ in range(max_tokens):
+        fin = [fin[b] or gen[b] >= n[b] for b in range(B)]           # the sampled token is EOS once the row has said everything
+        if all(fin):
+            break
+        for b in range(B):
+            if not fin[b]:
+                gen[b] += 1
+        if use_icl:
+            fin = [fin[b] or gen[b] >= caps[b] for b in range(B)]
+            if all(fin):
+                break
+        for b in range(B):
+            if gen[b] and gen[b] - dec[b] >= chunk:
+                ev.append((b, gen[b] - dec[b], 0 if dec[b] == 0 else min(25, dec[b]), False))
+                dec[b] = gen[b]
+    for b in range(B):
+        if gen[b] and gen[b] > dec[b]:
+            ev.append((b, gen[b] - dec[b], min(25, dec[b]), True))
+            dec[b] = gen[b]
+    return ev, gen
+
+
+@pytest.mark.parametrize("n,max_tokens,interval,use_icl", [
+    ([7, 0, 3, 64], 40, 0.16, False),      # chunk 2: a row silent from the start, one ending on a chunk boundary, one cut by max_tokens with context 25
+    ([5, 9], 9, 0.4, False),               # chunk 5: both end exactly on boundaries / the budget
+    ([200, 30, 200], 150, 0.3, True),      # in-context budgets (75 .. 150 frames): rows stop at their own caps; chunk 3
+    ([1], 4, 2.0, False),                  # one frame, one final chunk
+])
+def test_batch_generate_streaming_follows_the_reference_loop(monkeypatch, n, max_tokens, interval, use_icl):
+    texts = ["Short.", "A considerably longer second sentence for the batch.", "Mid length text", "four"][: len(n)]
+    m, _ = _scripted_model(monkeypatch, lambda b, L: 0)
+    m.speech_tokenizer.decoder = type("Dec", (), {"device": "cpu", "chunked_decode": staticmethod(
+        lambda codes: torch.from_numpy(PT.qwen3_fake_decode(codes.permute(0, 2, 1).numpy())[0])[:, None, :])})()
+    clip = torch.from_numpy(PT.qwen3_fake_clip(500, 4))
+    ref = dict(ref_audio=clip, ref_text="words") if use_icl else {}
+    caps = [min(max_tokens, max(75, len(m.tokenizer.encode(t)) * 6)) for t in texts] if use_icl else [max_tokens] * len(n)
+    slots, log = _ScriptedSlots(n), {}
+    out = list(m.batch_generate(texts, max_tokens=max_tokens, stream=True, streaming_interval=interval, slots=slots, codes_log=log, **ref))
+    chunk = max(1, int(interval * 12.5))
+    want, gen = _reference_stream_events(n, caps, max_tokens, chunk, use_icl)
+    assert [(r.sequence_idx, r.token_count, r.is_final_chunk) for r in out] == [(b, new, final) for b, new, _, final in want]
+    assert all(r.is_streaming_chunk for r in out) and sorted(slots.released) == list(range(len(n)))
+    assert [log[b].shape[0] for b in range(len(n))] == gen
+    pos = [0] * len(n)
+    for r, (b, new, ctx, _) in zip(out, want):                          # the audio: the window decoded behind its context, the context's samples cut off
+        codes = slots.take_codes(b, pos[b] + new)[pos[b] - ctx:]
+        wav = PT.qwen3_fake_decode(codes[None].numpy())[0][0][ctx * PT.QWEN3_ICL_UP:]
+        assert r.samples == new * PT.QWEN3_ICL_UP and np.array_equal(r.audio.numpy(), wav), (b, pos[b], new, ctx)
+        pos[b] += new
+    assert pos == gen
