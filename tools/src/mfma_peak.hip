@@ -16,6 +16,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 template <int SHAPE, int NACC>
 __global__ __launch_bounds__(256) void mfma_loop(const uint4* __restrict__ src, float* __restrict__ sink, int iters) {
@@ -45,6 +48,44 @@ __global__ __launch_bounds__(256) void mfma_loop(const uint4* __restrict__ src, 
     for (int i = 0; i < NACC; ++i)
 #pragma unroll
       for (int j = 0; j < 16; ++j) total += acc[i][j];
+  } else if constexpr (SHAPE == 3) {  // 32x32x64 fp8 (e4m3) on the block-scaled pipe with unit scales (E8M0 127): the only 2x-rate fp8 form of gfx950
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    i32x8 a8[2], b8[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a8[0][j] = ((const int*)&ra[0])[j]; a8[0][j + 4] = ((const int*)&ra[1])[j];
+      a8[1][j] = ((const int*)&ra[1])[j]; a8[1][j + 4] = ((const int*)&rb[0])[j];
+      b8[0][j] = ((const int*)&rb[0])[j]; b8[0][j + 4] = ((const int*)&rb[1])[j];
+      b8[1][j] = ((const int*)&rb[1])[j]; b8[1][j + 4] = ((const int*)&ra[0])[j];
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < NACC; ++i)
+        acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i & 1], b8[(i >> 1) & 1], acc[i], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    }
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) total += acc[i][j];
+  } else if constexpr (SHAPE == 4) {  // 32x32x32 int8
+    i32x16 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[i][j] = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < NACC; ++i)
+        acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, ra[i & 1]), __builtin_bit_cast(i32x4, rb[(i >> 1) & 1]), acc[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) total += (float)acc[i][j];
   } else {  // 16x16x32 bf16
     f32x4 acc[NACC];
 #pragma unroll
@@ -86,9 +127,22 @@ int main(int argc, char** argv) {
     h[i] = zero ? 0 : bf;
   }
   hipMemcpy(src, h, nsrc * 16, hipMemcpyHostToDevice);
-  const Shape shapes[3] = {{"v_mfma_f32_32x32x16_bf16", 0, 2.0 * 32 * 32 * 16, 32},
+  // a second operand pool of random BYTES for the 8-bit shapes: finite e4m3 values of mid-range exponent (never the NaN pattern 0x7f), which as int8 are
+  // ordinary signed values
+  uint4* src8;
+  hipMalloc(&src8, nsrc * sizeof(uint4));
+  uint8_t* h8 = (uint8_t*)malloc(nsrc * 16);
+  for (size_t i = 0; i < nsrc * 16; ++i) {
+    s = s * 1664525u + 1013904223u;
+    h8[i] = zero ? 0 : (uint8_t)(((s >> 31) << 7) | ((5 + ((s >> 9) % 6)) << 3) | ((s >> 13) & 7));
+  }
+  hipMemcpy(src8, h8, nsrc * 16, hipMemcpyHostToDevice);
+  // cycles of the two 8-bit shapes = what a 2x-rate pipe would need (K = 64 fp8: 64; K = 32 int8: 32); "implied_clock_ghz" for them is that assumption's clock
+  const Shape shapes[5] = {{"v_mfma_f32_32x32x16_bf16", 0, 2.0 * 32 * 32 * 16, 32},
                            {"v_mfma_f32_16x16x32_bf16", 1, 2.0 * 16 * 16 * 32, 16},
-                           {"v_mfma_f32_32x32x16_f16", 2, 2.0 * 32 * 32 * 16, 32}};
+                           {"v_mfma_f32_32x32x16_f16", 2, 2.0 * 32 * 32 * 16, 32},
+                           {"v_mfma_scale_f32_32x32x64_f8f6f4(e4m3, unit scales)", 3, 2.0 * 32 * 32 * 64, 64},
+                           {"v_mfma_i32_32x32x32_i8", 4, 2.0 * 32 * 32 * 32, 32}};
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
@@ -97,7 +151,7 @@ int main(int argc, char** argv) {
   constexpr int NACC = 4;
   int ntargets = argc > 1 ? argc - 1 : 3;
   double targets_default[3] = {2.0, 50.0, 1000.0};
-  for (int si = 0; si < 3; ++si) {
+  for (int si = 0; si < 5; ++si) {
     for (int ti = 0; ti < ntargets; ++ti) {
       const double target_ms = argc > 1 ? atof(argv[1 + ti]) : targets_default[ti];
       // iterations for the target duration at a nominal 2.0 GHz: per SIMD, waves x iters x NACC x cycles
@@ -109,6 +163,8 @@ int main(int argc, char** argv) {
         if (si == 0) mfma_loop<0, NACC><<<grid, block>>>(src, sink, iters);
         if (si == 1) mfma_loop<1, NACC><<<grid, block>>>(src, sink, iters);
         if (si == 2) mfma_loop<2, NACC><<<grid, block>>>(src, sink, iters);
+        if (si == 3) mfma_loop<3, NACC><<<grid, block>>>(src8, sink, iters);
+        if (si == 4) mfma_loop<4, NACC><<<grid, block>>>(src8, sink, iters);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         hipEventElapsedTime(&last, e0, e1);
