@@ -266,7 +266,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {2: "bf16 weights x fp32 activations (bf16 hi+lo split MFMA, fp32 accumulate)",
                       3: "fp16 activations x bf16-valued weights in fp16 (single MFMA pass, fp32 accumulate) in the vocoder; hi+lo front end",
-                      1: "bf16", 4: "fp16-valued weights x fp32 activations (fp16 hi+lo split MFMA)"}[args.precision],
+                      1: "bf16", 4: "fp16-valued weights x fp32 activations (fp16 hi+lo split MFMA)",
+                      5: "bf16 weights x fp32 activations: vocoder convs = fp16 hi pass (v_mfma_f32_32x32x16_f16) + block-scaled e4m3 lo pass "
+                         "(v_mfma_scale_f32_32x32x64_f8f6f4, OCP MX: E8M0 scale per row x 32 channels / per output column), fp32 accumulate; "
+                         "front end bf16 hi+lo split"}[args.precision],
             "data": "synthetic",
             "config": {"workload": ("Kokoro-82M bf16 TTS, tokens->waveform, RAGGED utterances T in 20..510 tokens, frames/token 3.3 +-35 %"
                                      if args.ragged else
@@ -303,7 +306,9 @@ def main():
         traffic = pmc["bytes_per_launch"] if pmc else None
         ms = sum(p[2].elapsed_time(p[3]) for p in prof)
         res["roofline"] = {
-            "bound": "mfma", "kernel": "conv_ws4_kernel + conv_gemm_kernel (implicit-GEMM conv1d/convT/linear, v_mfma_f32_32x32x16_bf16)",
+            "bound": "mfma", "kernel": ("conv_ws4_kernel<5, ...> (fp16 hi taps on v_mfma_f32_32x32x16_f16 + e4m3 lo tap pairs on v_mfma_scale_f32_32x32x64_f8f6f4) + "
+                                        "conv_ws4_kernel<2 / 4, ...> + conv_gemm_kernel (implicit-GEMM conv1d/convT/linear)" if args.precision == 5 else
+                                        "conv_ws4_kernel + conv_gemm_kernel (implicit-GEMM conv1d/convT/linear, v_mfma_f32_32x32x16_bf16)"),
             "achieved": flops / (ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
             "traffic_note": "avg HBM bytes per conv launch measured in this run: (2*FETCH_SIZE + WRITE_SIZE)*1024 over %s launches of two rocprofv3 PMC "

@@ -108,7 +108,13 @@ typedef struct {
   int32_t precision;   /* 2 = bf16 hi+lo split (default; ~16 mantissa bits of the fp32 activation), 1 = single bf16 pass,
                           3 = single fp16 pass: activations rounded to fp16 (saturating), weights packed with MI355_W_F16,
                           4 = fp16 hi+lo split (~22 mantissa bits of the activation) on MI355_W_F16 weights: fp16 checkpoints
-                              (Whisper) at fp32-activation accuracy */
+                              (Whisper) at fp32-activation accuracy,
+                          5 = fp16 hi pass + block-scaled e4m3 lo pass on an MX image (mi355_pack_conv_weight_mx_host): the residual
+                              t - fp16(t) (2^-11 of the value) and a second, e4m3 copy of the weights go through
+                              v_mfma_scale_f32_32x32x64_f8f6f4 at twice the 16-bit rate, two taps per instruction, E8M0 scale per window
+                              row and 32 channels / per output column: ~15 significant bits of the activation (conv sweep: <= 2e-5 of
+                              the peak).  Launches the wave-specialised kernel does not take (few tiles, K % 4 != 3, thin outputs) run
+                              the precision-4 arithmetic on the image's fp16 slices */
   int32_t tile;        /* 0 = auto, else BM*1000+BN (128128, 64128, 64064), 6128128 / 7128128 = wave-specialised 8-wave kernels (ws4 / ws3),
                           2064128 / 2064064 (+ 10000000 * groups) = split-K on 64-row tiles (needs split_ws) */
   /* optional instance-norm statistics of the STORED output, fused into the epilogue (plain stores only): per block of
@@ -154,6 +160,10 @@ int mi355_pack_conv_weight_host(const float* w_host, int32_t Cout, int32_t K, in
  * weights are exactly representable in fp16 down to 2^-17). */
 enum { MI355_W_BF16 = 0, MI355_W_F16 = 1, MI355_W_FP8 = 2 };   /* MI355_W_FP8: row-major GEMV images only (mi355_pack_rowmajor_fp8_host) */
 int mi355_pack_conv_weight_host_dt(const float* w_host, int32_t Cout, int32_t K, int32_t Cin, int32_t dtype, uint16_t* out_host);
+/* The MX image of precision 5 (bf16-valued checkpoint weights are exact in its fp16 part): per 32-channel chunk K fp16 tap slices followed
+ * by ceil(K / 2) e4m3 tap-pair slices, then one E8M0 scale byte per (padded) output column.  out_host: mi355_packed_conv_weight_mx_bytes bytes. */
+int64_t mi355_packed_conv_weight_mx_bytes(int32_t Cout, int32_t K, int32_t Cin);
+int mi355_pack_conv_weight_mx_host(const float* w_host, int32_t Cout, int32_t K, int32_t Cin, uint8_t* out_host);
 
 /* ------------------------------------------------------------------------------------------
  * Instance-norm statistics + AdaIN coefficients.

@@ -3,6 +3,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <math.h>
+#include <vector>
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -15,7 +17,7 @@ void mi355_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* mi355_last_error(void) { return g_err; }
-extern "C" int mi355_abi_version(void) { return 28; }
+extern "C" int mi355_abi_version(void) { return 29; }
 
 extern "C" int mi355_device_info(int dev, char* name, int name_cap, int* cu_count, int* lds_bytes) {
   hipDeviceProp_t p;
@@ -58,6 +60,77 @@ static int pack_conv_weight(const float* w, int32_t Cout, int32_t K, int32_t Cin
               out[o++] = dtype == MI355_W_F16 ? host_f32_to_f16(v) : host_f32_to_bf16(v);
             }
           }
+  return MI355_OK;
+}
+
+// ---- MX image (precision 5: fp16 hi pass + block-scaled e4m3 lo pass).  Per 32-channel chunk: K fp16 tap slices in the layout above, then
+// NP = ceil(K / 2) e4m3 tap-PAIR slices of the same size (NTp x 2 KB): byte index within a pair slice = ((nt * 2 + h) * 64 + lane) * 16 + j with
+//   n = nt*32 + (lane & 31),  tap = 2 p + h,  c = chunk*32 + (lane >> 5)*16 + j      (h = K block of v_mfma_scale_f32_32x32x64_f8f6f4),
+// value = e4m3(w / 2^e[n]), zero for tap >= K or padding.  After the last slice: NTp*32 E8M0 bytes, one per output column:
+// e[n] = floor(log2(max |w[n, :, :]|)) - 7 (the scaled column maximum lies in [128, 256) < 448), byte = e + 127; 127 for an all-zero column.
+extern "C" int64_t mi355_packed_conv_weight_mx_bytes(int32_t Cout, int32_t K, int32_t Cin) {
+  const int64_t chunks = (Cin + 31) / 32;
+  const int64_t ntp = ((Cout + 127) / 128) * 4;
+  return chunks * (K + (K + 1) / 2) * ntp * 2048 + ntp * 32;
+}
+
+extern "C" int mi355_pack_conv_weight_mx_host(const float* w, int32_t Cout, int32_t K, int32_t Cin, uint8_t* out) {
+  MI355_REQUIRE(w && out && Cout > 0 && K > 0 && Cin > 0, "pack_conv_weight_mx: bad arguments");
+  const int chunks = (Cin + 31) / 32;
+  const int ntp = ((Cout + 127) / 128) * 4;
+  const int np = (K + 1) / 2;
+  uint8_t* scales = out + (size_t)chunks * (K + np) * ntp * 2048;
+  std::vector<float> inv(ntp * 32, 1.0f);
+  for (int n = 0; n < ntp * 32; ++n) {
+    float amax = 0.f;
+    if (n < Cout)
+      for (size_t e = 0; e < (size_t)K * Cin; ++e) {
+        const float v = fabsf(w[(size_t)n * K * Cin + e]);
+        MI355_REQUIRE(v == v && v <= 3.0e38f, "pack_conv_weight_mx: non-finite weight in output channel %d", n);
+        amax = v > amax ? v : amax;
+      }
+    int e = 0;
+    if (amax > 0.f) {
+      (void)frexpf(amax, &e);   // amax = m * 2^e, m in [0.5, 1): floor(log2(amax)) = e - 1
+      e = e - 1 - 7;
+      if (e < -127) e = -127;
+      if (e > 120) e = 120;
+    }
+    scales[n] = (uint8_t)(e + 127);
+    inv[n] = ldexpf(1.0f, -e);
+  }
+  size_t o = 0;
+  uint16_t* o16 = (uint16_t*)out;
+  for (int ch = 0; ch < chunks; ++ch) {
+    for (int tap = 0; tap < K; ++tap)
+      for (int nt = 0; nt < ntp; ++nt)
+        for (int kk = 0; kk < 2; ++kk)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int n = nt * 32 + (lane & 31);
+            const int c0 = ch * 32 + kk * 16 + (lane >> 5) * 8;
+            for (int j = 0; j < 8; ++j) {
+              const int c = c0 + j;
+              const float v = (n < Cout && c < Cin) ? w[((size_t)n * K + tap) * Cin + c] : 0.0f;
+              o16[o++] = host_f32_to_f16(v);
+            }
+          }
+    uint8_t* o8 = out + o * 2;
+    size_t b = 0;
+    for (int p = 0; p < np; ++p)
+      for (int nt = 0; nt < ntp; ++nt)
+        for (int h = 0; h < 2; ++h)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int n = nt * 32 + (lane & 31);
+            const int tap = 2 * p + h;
+            const int c0 = ch * 32 + (lane >> 5) * 16;
+            for (int j = 0; j < 16; ++j) {
+              const int c = c0 + j;
+              const float v = (n < Cout && c < Cin && tap < K) ? w[((size_t)n * K + tap) * Cin + c] : 0.0f;
+              o8[b++] = host_f32_to_e4m3(v * inv[n]);   // power-of-two scaling: exact
+            }
+          }
+    o += b / 2;
+  }
   return MI355_OK;
 }
 

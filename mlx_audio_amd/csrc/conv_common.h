@@ -25,14 +25,23 @@ __device__ __forceinline__ f32x16 mfma16(const bf16x8 a, const bf16x8 b, const f
   else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
-// number of LDS images of the activation window: hi + lo for the split, one otherwise
+// number of 16-bit LDS images of the activation window: hi + lo for the 16-bit splits, one otherwise (PREC 5 keeps its lo residual as an
+// 8-bit block-scaled plane behind the hi image: window_bytes)
 template <int PREC>
 constexpr int a_images() { return (PREC == 2 || PREC == 4) ? 2 : 1; }
+// PREC 5 = fp16 hi pass + MX lo pass: the lo residual t - fp16(t) as OCP e4m3 bytes with one E8M0 scale byte per window row and 32-channel chunk,
+// multiplied by a second, e4m3 image of the weights (one E8M0 scale per output column) on v_mfma_scale_f32_32x32x64_f8f6f4, which pairs two taps
+// per instruction (K block b of the instruction = the 32 channels of tap 2 p + b) and runs at twice the 16-bit rate.
+// LDS bytes of one staged window of R rows: [hi image R x 64][lo image R x 32][R scale bytes, padded to 16]
+template <int PREC>
+__host__ __device__ constexpr int window_bytes(const int R) {
+  return PREC == 5 ? R * 96 + ((R + 15) & ~15) : a_images<PREC>() * R * 64;
+}
 // the part of t the first (hi) image carries, as an fp32 value
 template <int PREC>
 __device__ __forceinline__ float split_hi(float t) {
   if constexpr (PREC == 3) return t;
-  else if constexpr (PREC == 4) return (float)(_Float16)__builtin_fminf(__builtin_fmaxf(t, -65504.f), 65504.f);
+  else if constexpr (PREC == 4 || PREC == 5) return (float)(_Float16)__builtin_fminf(__builtin_fmaxf(t, -65504.f), 65504.f);
   else return bf16_bits_to_f32(f32_to_bf16_bits(t));
 }
 template <int PREC>

@@ -29,6 +29,7 @@ constexpr int kThreads = 256;
 // conv_split_finish_kernel sums the slabs in a fixed order and applies the epilogue of the original call.
 struct split_geom {
   int ksplit, cpz;
+  int lo_slices;   // MX images (precision 5): e4m3 tap-pair slices that follow a chunk's K fp16 tap slices (skipped here), 0 otherwise
 };
 
 template <int BM, int BN, int PREC, bool VEC, bool SPLIT = false>
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_ge
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   auto issue_B = [&](int step, int buf) {
-    const char* src = (const char*)a.w + ((int64_t)step * NTp + (n0 >> 5)) * 2048;
+    const int wslice = sg.lo_slices ? step + (step / K) * sg.lo_slices : step;
+    const char* src = (const char*)a.w + ((int64_t)wslice * NTp + (n0 >> 5)) * 2048;
 #pragma unroll
     for (int i = 0; i < BN / 64; ++i) {
       const int off = (i * 4 + wave) * 1024;
@@ -206,6 +208,10 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_ge
   conv_epilogue<MF, NF, WM, WN, SPLIT ? 0 : -1>(a, acc, SPLIT ? (int)blockIdx.z : b, l0, n0, wm, wn, lane, len_out, false);
 }
 
+// e4m3 tap-pair slices per chunk of the weight image of the call being dispatched (MX images handed to these kernels: they run the precision-4
+// arithmetic on the fp16 slices and skip the rest); set by mi355_conv_gemm for the duration of one call
+thread_local int t_mx_lo_slices = 0;
+
 template <int BM, int BN, int PREC, bool VEC>
 int launch(const mi355_conv_gemm_args& a, hipStream_t st) {
   const int R = BM + (a.K - 1) * a.dil;
@@ -213,7 +219,7 @@ int launch(const mi355_conv_gemm_args& a, hipStream_t st) {
   MI355_REQUIRE(lds <= 64 * 1024, "conv_gemm: window too large for LDS (K=%d dil=%d)", a.K, a.dil);
   dim3 grid((a.Lout + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.B);
   MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, PREC, VEC>), grid, dim3(kThreads), lds, st, a, split_geom{1, 0});
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, PREC, VEC>), grid, dim3(kThreads), lds, st, a, split_geom{1, 0, t_mx_lo_slices});
   MI355_LAUNCH_CHECK("conv_gemm");
   return MI355_OK;
 }
@@ -375,7 +381,7 @@ int launch_split(const mi355_conv_gemm_args& a, hipStream_t st, const int ks) {
   const size_t lds = (size_t)R * 64 * a_images<PREC>() + 2 * (BN / 32) * 2048;
   MI355_REQUIRE(lds <= 64 * 1024, "conv_gemm: window too large for LDS (K=%d dil=%d)", a.K, a.dil);
   const int nchunks = (a.Cin + 31) >> 5;
-  const split_geom sg{ks, (nchunks + ks - 1) / ks};
+  const split_geom sg{ks, (nchunks + ks - 1) / ks, t_mx_lo_slices};
   const int ldp = (a.Cout + 3) & ~3;
   const int64_t slab = (int64_t)a.Lout * ldp;
   mi355_conv_gemm_args p = a;   // the partial pass: same input side, raw store into slab (b, kz)
@@ -419,7 +425,8 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
   MI355_REQUIRE(!a.up_s || (a.up_cout > 0 && a.Cout % a.up_cout == 0 && a.Cout / a.up_cout == a.up_s),
                 "conv_gemm: polyphase store needs Cout == up_s*up_cout");
   if (a.precision == 0) a.precision = 2;
-  MI355_REQUIRE(a.precision >= 1 && a.precision <= 4, "conv_gemm: precision must be 1, 2, 3 or 4");
+  MI355_REQUIRE(a.precision >= 1 && a.precision <= 5, "conv_gemm: precision must be 1 .. 5");
+  MI355_REQUIRE(a.precision != 5 || !a.pre_fq, "conv_gemm: precision 5 has no quantising prologue");
   MI355_REQUIRE(!a.pre_fq || a.pre_act == MI355_ACT_NONE || a.pre_act == MI355_ACT_LEAKY || (a.pre_act == MI355_ACT_SNAKE && !a.pre_inv_beta),
                 "conv_gemm: a quantising prologue (pre_fq) takes no activation, LeakyReLU or Snake");
   if (a.out_scale == 0.f) a.out_scale = 1.f;
@@ -431,6 +438,24 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
     MI355_REQUIRE(a.stats_bstride % 2 == 0 && ((uintptr_t)a.stats_partial) % 8 == 0, "conv_gemm: stats_partial must be 8-byte aligned");
   }
   int tile = a.tile;
+  t_mx_lo_slices = 0;
+  if (a.precision == 5) {
+    // the wave-specialised kernel takes the launch when it fills the chip (the same rule as the auto choice below) or when asked for by tile
+    // code; everything else runs the precision-4 arithmetic of the 4-wave kernels on the image's fp16 slices
+    static const long ws_min5 = getenv("MI355_CONV_WS_MIN_TILES") ? atol(getenv("MI355_CONV_WS_MIN_TILES")) : 128;
+    static const bool no_ws5 = getenv("MI355_CONV_NO_WS") != nullptr;
+    const long wgs128 = (long)a.B * ((a.Lout + 127) / 128) * ((a.Cout + 127) / 128);
+    const bool want = tile % 10000000 == 6128128 || (tile == 0 && !no_ws5 && a.Cout > 64 && wgs128 >= ws_min5 && a.Cin >= 64);
+    if (want && mi355_conv_ws4_eligible(a, vec)) {
+      const int rc = mi355_conv_ws4_launch(a, st, tile == 0 ? 0 : (tile / 10000000) & 3);
+      if (rc != MI355_ERR_UNSUPPORTED) return rc;
+    }
+    MI355_REQUIRE(tile % 10000000 != 6128128, "conv_gemm: precision 5 on the wave-specialised tile needs K = 3 (mod 4), a plain / LeakyReLU / Snake prologue, "
+                  "no epilogue activation beyond LeakyReLU and 16-B aligned channels-last rows");
+    t_mx_lo_slices = (a.K + 1) >> 1;
+    a.precision = 4;   // (the precision-4 instantiations of the wave-specialised kernel do not know the MX slice layout: mx_image below)
+  }
+  const bool mx_image = t_mx_lo_slices != 0;
   if (tile == 0) {
     const int bn = a.Cout <= 64 ? 64 : 128;
     const long wgs128 = (long)a.B * ((a.Lout + 127) / 128) * ((a.Cout + bn - 1) / bn);
@@ -442,13 +467,13 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
     static const bool no_ws = getenv("MI355_CONV_NO_WS") != nullptr;
     static const int ws_feat = getenv("MI355_CONV_WS_FEAT") ? atoi(getenv("MI355_CONV_WS_FEAT")) : 0;
     static const long ws_min = getenv("MI355_CONV_WS_MIN_TILES") ? atol(getenv("MI355_CONV_WS_MIN_TILES")) : 128;
-    if (!no_ws && bn == 128 && wgs128 >= ws_min && a.Cin >= 64 && mi355_conv_ws4_eligible(a, vec)) {
+    if (!no_ws && !mx_image && bn == 128 && wgs128 >= ws_min && a.Cin >= 64 && mi355_conv_ws4_eligible(a, vec)) {
       const int rc = mi355_conv_ws4_launch(a, st, ws_feat);
       if (rc != MI355_ERR_UNSUPPORTED) return rc;  // no instantiation for this prologue / epilogue pair: fall through to the 4-wave kernels
     }
     // thin outputs (C_out <= 64): the same kernel on 128 x 64 tiles (MI355_CONV_NO_WS64=1 keeps them on the 4-wave 64 x 64 kernel: A/B aid)
     static const bool no_ws64 = getenv("MI355_CONV_NO_WS64") != nullptr;
-    if (!no_ws && !no_ws64 && bn == 64 && wgs128 >= ws_min && a.Cin >= 32 && mi355_conv_ws4_eligible(a, vec)) {
+    if (!no_ws && !no_ws64 && !mx_image && bn == 64 && wgs128 >= ws_min && a.Cin >= 32 && mi355_conv_ws4_eligible(a, vec)) {
       const int rc = mi355_conv_ws4_launch(a, st, ws_feat & 3, 64);
       if (rc != MI355_ERR_UNSUPPORTED) return rc;
     }
@@ -468,6 +493,7 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
     return wide ? launch_split_p<64, 128>(a, st, ks) : launch_split_p<64, 64>(a, st, ks);
   }
   if (tile % 10000000 == 6128064) {  // ws4 on 128 x 64 tiles, explicit (+ 10000000 * feature bits 0..3)
+    MI355_REQUIRE(!mx_image, "conv_gemm: MX images (precision 5) have no 128 x 64 wave-specialised tile");
     MI355_REQUIRE(mi355_conv_ws4_eligible(a, vec), "conv_gemm: the wave-specialised tile needs 16-B aligned channels-last input rows and a window of <= 192 rows");
     return mi355_conv_ws4_launch(a, st, (tile / 10000000) & 11, 64);
   }

@@ -17,6 +17,11 @@
 // GEMM mode (K == 1, the nn.Linear layers: PL-BERT, LSTM x-projections, 1x1 shortcuts): a "chunk" is 64 channels staged as two 128-row
 // blocks of the window and the "taps" walk the blocks, so there are 32 MFMAs per wave between barriers instead of 16.
 //
+// PREC 5 (fp16 hi pass + block-scaled e4m3 lo pass, conv mode only): the producers keep the lo residual t - fp16(t) as e4m3 bytes (32-byte rows,
+// 16-byte halves XOR-swizzled by (row >> 3) & 1) with one E8M0 scale byte per window row; the weight stream of a chunk is K fp16 tap slices followed
+// by ceil(K / 2) e4m3 tap-PAIR slices of the same size, so the consumers see ONE stream of 16-register items: K hi items (16 MFMAs of 32x32x16 each)
+// and then ceil(K / 2) lo items (4 x v_mfma_scale_f32_32x32x64_f8f6f4: K block b of the instruction = tap 2 p + b) into the same accumulators.
+//
 // Reference call sites replaced: see include/mi355audio.h (mi355_conv_gemm).
 #pragma once
 #include "conv_common.h"
@@ -83,6 +88,7 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
   static_assert(!FQ || (!GEMM && (PRE == P_NONE || PRE == P_LEAKY || PRE == P_SNAKE)), "quantising prologues: conv mode, none / LeakyReLU / Snake");
   constexpr int BM = 128;
   static_assert(BN == 128 || BN == 64, "tile columns");
+  static_assert(PREC != 5 || (!GEMM && !FQ && !DBG && ABL == 0 && BN == 128), "precision 5: conv mode, 128-column tiles");
   constexpr int NLD = GEMM ? 8 : 6;  // window passes of 32 rows per chunk (conv: R <= 192; GEMM mode: R = 256)
   constexpr int NA = a_images<PREC>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -91,7 +97,8 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int R = q.R;
   const int ABYTES = R * 64;
-  char* Abase = smem;  // [2 buffers][NA (hi, lo)][R * 64]
+  const int WBYTES = window_bytes<PREC>(R);  // one staged window: NA 16-bit images (PREC 5: hi image, e4m3 lo image, scale bytes)
+  char* Abase = smem;  // [2 buffers][WBYTES]
   const int nch = q.nch, keff = q.keff;
   // PERSISTENT: the workgroup walks its tiles; the (tile, chunk) items form one stream.  Item j is staged in LDS buffer j & 1; one s_barrier per
   // item: the producers arrive when item j is converted, the consumers when they are done with item j - 1 (and with the previous tile's epilogue
@@ -205,7 +212,17 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
             const int addr = r * 64 + ((((c4 >> 3) ^ ((r >> 2) & 3))) << 4) + ((c4 & 4) << 1);
             uint2 ph;
             float hi[4];
-            if constexpr (PREC >= 3) {
+            if constexpr (PREC == 5) {  // v_cvt_pk_f16_f32 on the clamped value, v_cvt_f32_f16 back
+              typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+              typedef float f2_t __attribute__((ext_vector_type(2)));
+              float cl[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) cl[j] = __builtin_fminf(__builtin_fmaxf(tt[j], -65504.f), 65504.f);
+              const h2_t ha = __builtin_convertvector((f2_t){cl[0], cl[1]}, h2_t), hb = __builtin_convertvector((f2_t){cl[2], cl[3]}, h2_t);
+              ph.x = __builtin_bit_cast(uint32_t, ha);
+              ph.y = __builtin_bit_cast(uint32_t, hb);
+              hi[0] = (float)ha[0]; hi[1] = (float)ha[1]; hi[2] = (float)hb[0]; hi[3] = (float)hb[1];
+            } else if constexpr (PREC >= 3) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) hi[j] = split_hi<PREC>(tt[j]);
               ph.x = pack_f16x2(hi[0], hi[1]);
@@ -224,6 +241,24 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
               pl.x = pack_lo<PREC>(tt[0] - hi[0], tt[1] - hi[1]);
               pl.y = pack_lo<PREC>(tt[2] - hi[2], tt[3] - hi[3]);
               *(uint2*)(A_lo + addr) = pl;
+            }
+            if constexpr (PREC == 5) {
+              // MX block = the 32 channels of this window row (the 8 lanes ptid & 7): shared exponent = floor(log2(max |lo|)) - 7, so the scaled
+              // elements stay below 256 < 448 (no saturation); E8M0 byte 0 (2^-127) for an all-zero / denormal-sized row
+              const float l0 = tt[0] - hi[0], l1 = tt[1] - hi[1], l2 = tt[2] - hi[2], l3 = tt[3] - hi[3];
+              const float m4 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(l0), __builtin_fabsf(l1)), __builtin_fmaxf(__builtin_fabsf(l2), __builtin_fabsf(l3)));
+              uint32_t mb = __builtin_bit_cast(uint32_t, m4);  // non-negative floats order like unsigned integers
+              mb = max(mb, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mb, 0xB1, 0xf, 0xf, true));   // quad_perm [1, 0, 3, 2]
+              mb = max(mb, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mb, 0x4E, 0xf, 0xf, true));   // quad_perm [2, 3, 0, 1]
+              mb = max(mb, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mb, 0x141, 0xf, 0xf, true));  // row_half_mirror: the other quad of the 8 lanes
+              const int sb = max((int)(mb >> 23) - 7, 0);
+              const float mul = __builtin_bit_cast(float, (uint32_t)(254 - sb) << 23);  // 2^(127 - sb): exact
+              int pk = 0;
+              pk = __builtin_amdgcn_cvt_pk_fp8_f32(l0 * mul, l1 * mul, pk, false);
+              pk = __builtin_amdgcn_cvt_pk_fp8_f32(l2 * mul, l3 * mul, pk, true);
+              char* A_l8 = A_hi + ABYTES;
+              *(int*)(A_l8 + r * 32 + ((((c4 >> 4) ^ ((r >> 3) & 1))) << 4) + (c4 & 15)) = pk;
+              if ((ptid & 7) == 0) *(uint8_t*)(A_l8 + R * 32 + r) = (uint8_t)sb;
             }
           }
         }
@@ -246,7 +281,7 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
       if (work && na.id >= 0) loadA(s0, na);
       lds_barrier();  // even item staged
       if (ib.id < 0) break;
-      if (work) convertA(s1, ib, Abase + NA * ABYTES);
+      if (work) convertA(s1, ib, Abase + WBYTES);
       item_t nb = na;
       if (nb.id >= 0) advance(nb);
       if (work && nb.id >= 0) loadA(s1, nb);
@@ -290,8 +325,10 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
     const char* wfrag = (const char*)a.w + ((int64_t)((n0 >> 5) + wn * NF)) * 2048 + lane * 16;
     auto wptr = [&](const int s) { return wfrag + (int64_t)(s < last_slice ? s : last_slice) * wstep; };
     bf16x8 b0[NB], b1[NB];
+    if constexpr (PREC != 5) {
 #pragma unroll
-    for (int f = 0; f < NB; ++f) b0[f] = *(const bf16x8*)(wfrag + f * 1024);
+      for (int f = 0; f < NB; ++f) b0[f] = *(const bf16x8*)(wfrag + f * 1024);
+    }
 
     f32x16 acc[MF][NF];
 #pragma unroll
@@ -364,7 +401,160 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
         }
     }
 
-    {
+    if constexpr (PREC == 5) {
+      // ---- fp16 hi taps, then the e4m3 lo tap pairs of the chunk: one stream of 16-register weight items, one s_barrier per chunk.
+      // Register plan (128 per lane, 64 of them accumulators): two weight items as 8-register tuples w[nf] (hi item: low half = the kk 0 fragment,
+      // high half = kk 1; lo item: the 32-byte e4m3 operand of column fragment nf), ONE 8-register activation set `qa` shared by the two phases
+      // (hi: its low half is fragment set 0; lo: the whole e4m3 operand) and a 4-register second hi set.
+      typedef int i32x4 __attribute__((ext_vector_type(4)));
+      typedef int i32x8 __attribute__((ext_vector_type(8)));
+      // An "a" constraint anywhere in the kernel makes hipcc split the 128 registers into 64 VGPRs + 64 AGPRs and keep the MFMA accumulators in
+      // the AGPR half: two bins (4 x 16 accumulator registers | the 8-register operand tuples), instead of one in which the tuples fragment.
+      // { int agpr_hint; asm volatile("" : "=a"(agpr_hint)); }
+      const int K = keff, NP = (K + 1) >> 1, dil = q.tap_rows;   // K = 3 (mod 4): K odd, NP even (the dispatcher's eligibility rule)
+      // E8M0 scales of this wave's two 32-column fragments (one per output column, after the last slice of the image): bytes 0 / 1 = nf 0 / 1
+      const uint8_t* wsc = (const uint8_t*)a.w + (int64_t)q.nslices * wstep + (n0 + wn * WN) + hl;
+      const int bsc = (int)wsc[0] | ((int)wsc[32] << 8);
+      // weight item s: a wave-uniform base (SGPR pair) + the lane's 32-bit offset: no 64-bit VALU address arithmetic, no pointer VGPRs
+      const char* wtile = (const char*)a.w + ((int64_t)((n0 >> 5) + wn * NF)) * 2048;
+      const uint32_t wlane = (uint32_t)lane * 16u;
+      auto ldW = [&](i32x8 (&w)[2], const int s) {
+        const char* src = wtile + (int64_t)(s < last_slice ? s : last_slice) * wstep;
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+          const i32x4 lo4 = *(const i32x4*)(src + (2 * nf) * 1024 + wlane), hi4 = *(const i32x4*)(src + (2 * nf + 1) * 1024 + wlane);
+          w[nf] = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+      };
+      i32x8 w0[2], w1[2];
+      ldW(w0, 0);
+      i32x8 qa;   // hi phase: fragment set 0 = low half, set 1 = high half; lo phase: the whole e4m3 operand
+      int sa = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qa[e] = 0;
+      // per-item opaque copies of the lane coordinates: LICM otherwise parks ~12 partly computed LDS addresses in VGPRs across the whole tile and
+      // the allocator pays for them with an accumulator in scratch; recomputing them costs a handful of VALU operations per 8 MFMAs
+      int hlx = hl, hhx = hh;
+      auto fresh = [&]() { asm volatile("" : "+v"(hlx), "+v"(hhx)); };
+      auto lo4 = [](const i32x8& v) { return __builtin_bit_cast(bf16x8, (i32x4)__builtin_shufflevector(v, v, 0, 1, 2, 3)); };
+      auto hi4 = [](const i32x8& v) { return __builtin_bit_cast(bf16x8, (i32x4)__builtin_shufflevector(v, v, 4, 5, 6, 7)); };
+      auto rdH = [&](const int g, const int tp) {
+        const int kk = g >> 1, mf = g & 1;
+        const int row = wm * WM + mf * 32 + hlx + tp * dil;
+        const int cidx = kk * 2 + hhx;
+        return *(const i32x4*)(Abase + jbuf * WBYTES + row * 64 + ((cidx ^ ((row >> 2) & 3)) << 4));
+      };
+      auto rdH0 = [&](const int g, const int tp) {  // into the low half of qa
+        const i32x4 v = rdH(g, tp);
+        qa = __builtin_shufflevector(v, (i32x4)__builtin_shufflevector(qa, qa, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7);
+      };
+      auto rdH1 = [&](const int g, const int tp) {  // into the high half of qa
+        const i32x4 v = rdH(g, tp);
+        qa = __builtin_shufflevector((i32x4)__builtin_shufflevector(qa, qa, 0, 1, 2, 3), v, 0, 1, 2, 3, 4, 5, 6, 7);
+      };
+      // lo operand of rows [mf * 32, +32) for tap pair p: bytes 0..15 = channels [16 hh, +16) of the row under tap 2 p, bytes 16..31 = the same
+      // channels under tap 2 p + 1 (K is odd: the last pair takes its last tap twice, that half of the weight item is zero, the data stay
+      // finite); scale byte: lanes 0..31 carry K block 0 (tap 2 p), lanes 32..63 K block 1
+      auto rdL0 = [&](const int mf, const int p) {  // K block 0 (tap 2 p) -> low half
+        const int r0 = wm * WM + mf * 32 + hlx + 2 * p * dil;
+        const char* L8 = Abase + jbuf * WBYTES + ABYTES;
+        const i32x4 x0 = *(const i32x4*)(L8 + r0 * 32 + ((hhx ^ ((r0 >> 3) & 1)) << 4));
+        qa = __builtin_shufflevector(x0, (i32x4)__builtin_shufflevector(qa, qa, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7);
+      };
+      auto rdL1 = [&](const int mf, const int p) {  // K block 1 (tap 2 p + 1) -> high half, and the lane's scale byte
+        const int t1 = 2 * p + 1 < K ? 2 * p + 1 : K - 1;
+        const int rb = wm * WM + mf * 32 + hlx;
+        const int r0 = rb + 2 * p * dil, r1 = rb + t1 * dil;
+        const char* L8 = Abase + jbuf * WBYTES + ABYTES;
+        const i32x4 x1 = *(const i32x4*)(L8 + r1 * 32 + ((hhx ^ ((r1 >> 3) & 1)) << 4));
+        qa = __builtin_shufflevector((i32x4)__builtin_shufflevector(qa, qa, 0, 1, 2, 3), x1, 0, 1, 2, 3, 4, 5, 6, 7);
+        sa = (int)*(const uint8_t*)(L8 + R * 32 + (hhx ? r1 : r0));
+      };
+      auto rdL = [&](const int mf, const int p) { rdL0(mf, p); rdL1(mf, p); };
+      auto mmH = [&](const bf16x8 h, const int g, const i32x8 (&w)[2]) {
+        const int kk = g >> 1, mf = g & 1;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = mfma16<PREC>(h, kk ? hi4(w[nf]) : lo4(w[nf]), acc[mf][nf]);
+      };
+      auto mmL = [&](const int mf, const i32x8 (&w)[2]) {
+        // (inline asm, accumulator tied in place: with the builtin hipcc picks the three-address form under register pressure -- D in 16 OTHER
+        // registers -- and then shuffles whole accumulators through scratch.  Hazards, which hipcc does not pad for an asm statement: a VALU
+        // result as an operand (the scale byte's mask) wants two wait states = the leading s_nop 1; the next reader of D is always another
+        // MFMA taking it whole as C (0 wait states) until the pad in front of the fold / epilogue below.)
+        asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc[mf][0]) : "v"(qa), "v"(w[0]), "v"(sa), "v"(bsc));
+        asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[0,1,0] op_sel_hi:[0,0,0]" : "+v"(acc[mf][1]) : "v"(qa), "v"(w[1]), "v"(sa), "v"(bsc));
+      };
+      // hi tap tp on weight item w: four groups, the fragment of group g + 1 requested before the MFMAs of group g; `last`: the chunk's last
+      // hi tap requests the first lo operand instead of the next tap's first fragment
+      auto hi_tap = [&](const int tp, const i32x8 (&w)[2], auto last) {
+        fresh();
+        rdH1(1, tp);
+        __builtin_amdgcn_sched_barrier(0);
+        mmH(lo4(qa), 0, w);
+        rdH0(2, tp);
+        __builtin_amdgcn_sched_barrier(0);
+        mmH(hi4(qa), 1, w);
+        rdH1(3, tp);
+        __builtin_amdgcn_sched_barrier(0);
+        mmH(lo4(qa), 2, w);
+        if constexpr (decltype(last)::value) rdL0(0, 0);   // the first lo operand arrives in two halves, each behind the last MFMA that reads
+        else rdH0(0, tp + 1);                               // the hi fragment it replaces
+        __builtin_amdgcn_sched_barrier(0);
+        mmH(hi4(qa), 3, w);
+        if constexpr (decltype(last)::value) rdL1(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      // lo tap pair p on weight item w: ONE operand set (the register budget), refilled between the two row halves
+      auto lo_pair = [&](const int p, const i32x8 (&w)[2], const bool more) {
+        fresh();
+        mmL(0, w);
+        __builtin_amdgcn_sched_barrier(0);
+        rdL(1, p);
+        __builtin_amdgcn_sched_barrier(0);
+        mmL(1, w);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) rdL(0, p + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto prefetch = [&](i32x8 (&w)[2], const int s) {
+        ldW(w, s);
+        asm volatile("" ::: "memory");  // keep the prefetch AHEAD of the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      // One chunk: K hi items, then NP lo items; wa holds item s on entry, wb holds the next chunk's first item on exit (K odd, NP even: the
+      // roles of the two register sets swap from chunk to chunk, hence the two instances below).
+      int s = 0;
+      auto chunk_body = [&](i32x8 (&wa)[2], i32x8 (&wb)[2]) {
+        lds_barrier();  // the chunk's window is staged behind this barrier (and the producers may refill the buffer just left)
+        rdH0(0, 0);
+        int tp = 0;
+        for (; tp + 1 < K; tp += 2) {
+          prefetch(wb, s + 1);
+          hi_tap(tp, wa, std::false_type{});
+          prefetch(wa, s + 2);
+          hi_tap(tp + 1, wb, std::false_type{});
+          s += 2;
+        }
+        prefetch(wb, s + 1);
+        hi_tap(tp, wa, std::true_type{});
+        s += 1;
+        for (int p = 0; p < NP; p += 2) {
+          prefetch(wa, s + 1);
+          lo_pair(p, wb, true);
+          prefetch(wb, s + 2);
+          lo_pair(p + 1, wa, p + 2 < NP);
+          s += 2;
+        }
+        jbuf ^= 1;
+      };
+      for (int c = 0; c < nch; c += 2) {
+        chunk_body(w0, w1);
+        if (c + 1 >= nch) break;
+        chunk_body(w1, w0);
+      }
+      // the tile's last MFMAs are asm statements: 16 passes -> 19 wait states before anything but an MFMA may touch their D
+      asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+    } else {
       int tap = 0;
       bf16x8 ah0 = b0[0], al0 = b0[1], ah1 = b0[0], al1 = b0[1];  // two static activation-fragment sets (al*: the lo image, unused for the single-pass precisions)
       // group g of a tap: kk = g >> 1 (16-channel half of the chunk), mf = g & 1 (32-row half of the wave's rows)
@@ -373,7 +563,7 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
         const int row = wm * WM + mf * 32 + hl + tp * q.tap_rows;
         const int cidx = kk * 2 + hh;
         const int addr = row * 64 + ((cidx ^ ((row >> 2) & 3)) << 4);
-        const char* A_hi = Abase + jbuf * NA * ABYTES;
+        const char* A_hi = Abase + jbuf * WBYTES;
         if constexpr ((ABL & 2) != 0) {
           asm volatile("" : "+v"(h), "+v"(l) : "v"(addr));  // opaque: no LDS read
         } else {
@@ -474,7 +664,7 @@ int launch_ws4(const mi355_conv_gemm_args& a, hipStream_t st, const int feat, un
   q.bn = BN;
   q.gemm = GEMM ? 1 : 0;
   const int chunks32 = (a.Cin + 31) >> 5;
-  q.nslices = chunks32 * a.K;
+  q.nslices = chunks32 * (PREC == 5 ? a.K + ((a.K + 1) >> 1) : a.K);
   if (q.gemm) {
     q.nch = (chunks32 + 1) >> 1;
     q.keff = 2;
@@ -487,7 +677,7 @@ int launch_ws4(const mi355_conv_gemm_args& a, hipStream_t st, const int feat, un
     q.R = 128 + (a.K - 1) * a.dil;
   }
   MI355_REQUIRE(q.R <= (GEMM ? 256 : 192), "conv_gemm(ws4): window of %d rows exceeds %d (K=%d dil=%d)", q.R, GEMM ? 256 : 192, a.K, a.dil);
-  const size_t lds = (size_t)2 * a_images<PREC>() * q.R * 64;
+  const size_t lds = (size_t)2 * window_bytes<PREC>(q.R);
   q.tiles_per_item = (a.Lout + 127) / 128;
   q.P = a.B * q.tiles_per_item;
   q.NT = (a.Cout + BN - 1) / BN;
@@ -556,3 +746,4 @@ int mi355_conv_ws4_p2(const mi355_conv_gemm_args& a, hipStream_t st, int feat, u
 int mi355_conv_ws4_p4(const mi355_conv_gemm_args& a, hipStream_t st, int feat, int bn);
 int mi355_conv_ws4_p13(const mi355_conv_gemm_args& a, hipStream_t st, int feat, int bn);
 int mi355_conv_ws4_fq(const mi355_conv_gemm_args& a, hipStream_t st, int feat, int bn);   // quantising prologues (pre_fq), precision 2
+int mi355_conv_ws4_p5(const mi355_conv_gemm_args& a, hipStream_t st, int feat, int bn);   // fp16 hi + MX e4m3 lo (conv mode, 128-column tiles)

@@ -76,15 +76,29 @@ class PackedConv:
     k: int
     cin: int
     f16: bool = False  # packed as fp16 for the single-pass fp16 MFMA mode (precision 3)
+    mx: bool = False   # MX image: fp16 tap slices + e4m3 tap-pair slices + E8M0 column scales (precision 5)
 
 
-def pack_conv(w: torch.Tensor, bias: Optional[torch.Tensor], device, f16: bool = False) -> PackedConv:
-    """``w``: float32 CPU tensor ``[Cout, K, Cin]`` (MLX conv layout) or ``[Cout, Cin]`` (linear)."""
+def mx_eligible(cout: int, k: int, cin: int) -> bool:
+    """Shapes the wave-specialised kernel takes at precision 5 (``mi355_conv_ws4_eligible``): K = 3 (mod 4), more than 64 outputs, >= 64 inputs."""
+    return k % 4 == 3 and cout > 64 and cin >= 64
+
+
+def pack_conv(w: torch.Tensor, bias: Optional[torch.Tensor], device, f16: bool = False, mx: bool = False) -> PackedConv:
+    """``w``: float32 CPU tensor ``[Cout, K, Cin]`` (MLX conv layout) or ``[Cout, Cin]`` (linear).  ``mx``: the image of precision 5."""
     if w.dim() == 2:
         w = w[:, None, :]
     w = w.detach().to(torch.float32).contiguous().cpu()
     cout, k, cin = w.shape
     lib = _lib.load()
+    if mx:
+        nb = lib.mi355_packed_conv_weight_mx_bytes(cout, k, cin)
+        out8 = np.empty(nb, dtype=np.uint8)
+        rc = lib.mi355_pack_conv_weight_mx_host(w.numpy().ctypes.data, cout, k, cin, out8.ctypes.data)
+        _lib.check(rc, "mi355_pack_conv_weight_mx_host")
+        wd = torch.from_numpy(out8).to(device)
+        bd = None if bias is None else bias.detach().to(torch.float32).contiguous().to(device)
+        return PackedConv(wd, bd, cout, k, cin, True, True)
     n = lib.mi355_packed_conv_weight_elems(cout, k, cin)
     out = np.empty(n, dtype=np.uint16)
     rc = lib.mi355_pack_conv_weight_host_dt(w.numpy().ctypes.data, cout, k, cin, 1 if f16 else 0, out.ctypes.data)
@@ -396,11 +410,13 @@ def conv_gemm(x: torch.Tensor, pc: PackedConv, y: torch.Tensor, *, dil: int = 1,
     B, Lin, Cx, xbs, ldx = _nlc(x)
     By, Ly, Cy, ybs, ldy = _nlc(y)
     assert B == By
-    if pc.f16:
+    if pc.mx:
+        precision = 5  # the weight image decides
+    elif pc.f16:
         if precision not in (3, 4):
-            precision = 3  # the weight image decides: fp16-packed weights only fit the fp16 MFMA paths (3 single, 4 hi+lo)
-    elif precision in (3, 4):
-        raise _lib.Mi355Error("conv_gemm: precision 3 / 4 need weights packed with f16=True")
+            precision = 4 if precision == 5 else 3  # fp16-packed weights only fit the fp16 MFMA paths (3 single, 4 hi+lo; mode 5 = hi+lo where no MX image exists)
+    elif precision in (3, 4, 5):
+        raise _lib.Mi355Error("conv_gemm: precision 3 / 4 need weights packed with f16=True, precision 5 with mx=True")
     kw = dict(x=_ptr(x), x_bstride=xbs, ldx=ldx, x_off=x_off, Cin=pc.cin, Lin=Lin, lens_in=_ptr(lens_in), flat_valid=0,
               w=_ptr(pc.w), Cout=pc.cout, K=pc.k, dil=dil, pad=pad, pre_act=pre_act, pre_slope=pre_slope,
               pre_alpha=_ptr(pre_alpha), bias=_ptr(pc.bias) if use_bias else None, post_act=post_act,

@@ -224,13 +224,16 @@ class KokoroEngine:
 
     def _convw(self, pre, bias=True) -> PackedConv:
         b = self._q(self._t(f"{pre}.bias")) if bias and f"{pre}.bias" in self.w else None
-        return ops.pack_conv(self._wn(pre), b, self.dev, f16=self._f16(pre))
+        w = self._wn(pre)
+        mx = self.precision == 5 and pre.startswith("decoder.") and w.dim() == 3 and ops.mx_eligible(w.shape[0], w.shape[1], w.shape[2])
+        return ops.pack_conv(w, b, self.dev, f16=self._f16(pre), mx=mx)
 
     def _f16(self, pre: str) -> bool:
         """precision 3: the decoder / generator convs (97 % of the FLOPs) run the single-pass fp16 MFMA; the front end
         (PL-BERT, prosody predictor, text encoder: the bit-exact duration path and the F0 curve the harmonic source
-        integrates) stays on the bf16 hi+lo split."""
-        return self.all_f16 or (self.precision == 3 and pre.startswith("decoder."))
+        integrates) stays on the bf16 hi+lo split.  precision 5: the same split of the network, the decoder / generator convs on the fp16 hi +
+        block-scaled e4m3 lo pass (MX images) where the wave-specialised kernel takes the shape, fp16 hi + lo (precision 4) elsewhere."""
+        return self.all_f16 or (self.precision in (3, 5) and pre.startswith("decoder."))
 
     def _dvec(self, t: torch.Tensor, pad_to: int = 0) -> torch.Tensor:
         t = self._q(t.reshape(-1).float())
@@ -338,7 +341,7 @@ class KokoroEngine:
             cout = c0 // (2 ** (i + 1))
             # stored (Cin, K, Cout); mx.conv_transpose1d receives weight.T = (Cout, K, Cin) (istftnet.py:161-166)
             w_t = self._wn(f"{g}.ups.{i}").permute(2, 1, 0).contiguous()
-            self.ups.append(ops.pack_conv_transpose(w_t, self._q(self._t(f"{g}.ups.{i}.bias")), u, d, f16=self.precision == 3 or self.all_f16))
+            self.ups.append(ops.pack_conv_transpose(w_t, self._q(self._t(f"{g}.ups.{i}.bias")), u, d, f16=self.precision in (3, 5) or self.all_f16))
             ncw = self._q(self._t(f"{g}.noise_convs.{i}.weight"))  # (cout, K, n_fft+2)
             ncb = self._q(self._t(f"{g}.noise_convs.{i}.bias"))
             self.noise_convs.append(ops.pack_conv(ncw.reshape(ncw.shape[0], 1, -1), ncb, d, f16=self.all_f16))  # raw phase features: keep hi+lo
@@ -375,7 +378,8 @@ class KokoroEngine:
         return _StyleProj(plain[:, 0], q)
 
     def _conv(self, x, pc, y, **kw):
-        kw.setdefault("precision", 2 if self.precision == 3 else self.precision)  # fp16-packed weights select 3 themselves
+        # the weight image decides: fp16-packed weights select 3 themselves (4 in mode 5), MX images 5; bf16 images of modes 3 / 5 (front end) run 2
+        kw.setdefault("precision", 2 if (self.precision == 3 or (self.precision == 5 and not pc.f16)) else self.precision)
         return ops.conv_gemm(x, pc, y, **kw)
 
     def _convq(self, name: str, x, pc, y, *, lens_in=None, pre=None, pre_act=ACT_NONE, pre_slope=0.0, pre_alpha=None, **kw):

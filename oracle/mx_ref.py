@@ -1,0 +1,133 @@
+"""numpy statement of the arithmetic of conv precision 5 and of its weight image (TEST ORACLE, not product).
+
+Precision 5 (include/mi355audio.h, ``mi355_conv_gemm_args.precision``) is this repository's own number format for the vocoder convs -- the
+reference (``/root/reference/mlx_audio/tts/models/kokoro/istftnet.py:128-170`` ``ConvWeighted``) computes ``mx.conv1d`` in the checkpoint dtype
+and knows nothing of it -- so what is pinned here is (a) that the HIP kernel performs exactly the arithmetic it documents and (b) how far that
+arithmetic is from the exact product:
+
+    y = sum fp16(t) * w                                   (fp16 hi pass; bf16-valued weights are exact in fp16)
+      + sum q8(t - fp16(t)) * q8(w)                       (OCP MX: e4m3 elements, one E8M0 scale per window row and 32-channel chunk for the
+                                                           activations, one per output column for the weights)
+
+``t`` = the conv input AFTER its prologue.  OCP e4m3fn: 4 exponent bits (bias 7), 3 mantissa bits, subnormal quantum 2^-9, max finite 448,
+round to nearest even; E8M0: scale = 2^(byte - 127).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def e4m3_round(v: np.ndarray) -> np.ndarray:
+    """Nearest e4m3fn value (ties to even), saturating at +-448; float64 in, float64 out."""
+    v = np.asarray(v, dtype=np.float64)
+    a = np.abs(v)
+    with np.errstate(divide="ignore"):
+        e = np.floor(np.log2(np.where(a > 0, a, 1.0)))
+    e = np.maximum(e, -6.0)                      # below the smallest normal 2^-6 the grid is the subnormal one: quantum 2^-9
+    q = np.exp2(e - 3.0)
+    r = np.rint(a / q) * q                       # np.rint: ties to even
+    r = np.minimum(r, 448.0)
+    return np.sign(v) * r
+
+
+def e4m3_bits(v: np.ndarray) -> np.ndarray:
+    """e4m3fn code (uint8) of values that already lie on the grid."""
+    v = np.asarray(v, dtype=np.float64)
+    a = np.abs(v)
+    s = (np.signbit(v)).astype(np.uint8) << 7
+    with np.errstate(divide="ignore"):
+        e = np.floor(np.log2(np.where(a > 0, a, 1.0)))
+    sub = a < 2.0 ** -6
+    ee = np.where(sub, 0, e + 7).astype(np.int64)
+    m = np.where(sub, a / 2.0 ** -9, (a / np.exp2(e) - 1.0) * 8.0)
+    m = np.rint(m).astype(np.int64)
+    assert ((m >= 0) & (m <= 7)).all()
+    return (s | (ee.astype(np.uint8) << 3) | m.astype(np.uint8)).astype(np.uint8)
+
+
+def column_scale_exponents(w: np.ndarray) -> np.ndarray:
+    """E8M0 exponent e[n] of every output column of w [Cout, K, Cin]: floor(log2(max |w[n]|)) - 7 (0 for an all-zero column)."""
+    amax = np.abs(w.reshape(w.shape[0], -1)).max(axis=1).astype(np.float64)
+    e = np.zeros(w.shape[0], dtype=np.int64)
+    nz = amax > 0
+    e[nz] = np.floor(np.log2(amax[nz])).astype(np.int64) - 7
+    return np.clip(e, -127, 120)
+
+
+def quantise_weights(w: np.ndarray) -> np.ndarray:
+    """The values the lo pass multiplies by: e4m3(w / 2^e[n]) * 2^e[n]."""
+    e = column_scale_exponents(w)
+    sc = np.exp2(e.astype(np.float64))[:, None, None]
+    return e4m3_round(w.astype(np.float64) / sc) * sc
+
+
+def split_activation(t: np.ndarray):
+    """t [..., C] float32 (C a multiple of 32, zero padded) -> (hi, lo_q) float64: hi = fp16(clamp(t)), lo_q = the MX-quantised residual with one
+    shared exponent per row and 32-channel chunk: floor(log2(max |lo|)) - 7 (byte 0 = 2^-127 when that would go below)."""
+    t = np.asarray(t, dtype=np.float32)
+    hi = np.clip(t, -65504.0, 65504.0).astype(np.float16).astype(np.float32)
+    lo = (t - hi).astype(np.float32)                        # exact in float32
+    C = t.shape[-1]
+    assert C % 32 == 0
+    blk = lo.reshape(*t.shape[:-1], C // 32, 32)
+    amax = np.abs(blk).max(axis=-1)
+    ef = (amax.view(np.uint32) >> 23).astype(np.int64)      # biased float32 exponent of the block maximum
+    sb = np.maximum(ef - 7, 0)
+    scale = np.exp2((sb - 127).astype(np.float64))[..., None]
+    q = e4m3_round(blk.astype(np.float64) / scale) * scale
+    return hi.astype(np.float64), q.reshape(t.shape)
+
+
+def conv_mx(t: np.ndarray, w: np.ndarray, dil: int, pad: int) -> np.ndarray:
+    """t [L, Cin] float32 (prologue output), w [Cout, K, Cin] (bf16-valued) -> [L, Cout] float64 by the precision-5 arithmetic, 'same' length."""
+    L, cin = t.shape
+    cout, K, _ = w.shape
+    cp = (cin + 31) // 32 * 32
+    tp = np.zeros((L, cp), dtype=np.float32)
+    tp[:, :cin] = t
+    hi, lo = split_activation(tp)
+    w16 = w.astype(np.float16).astype(np.float64)
+    wq = quantise_weights(w)
+    y = np.zeros((L, cout), dtype=np.float64)
+    for k in range(K):
+        off = k * dil - pad
+        lo_r, hi_r = max(0, -off), min(L, L - off)
+        if hi_r <= lo_r:
+            continue
+        rows = slice(lo_r + off, hi_r + off)
+        y[lo_r:hi_r] += hi[rows, :cin] @ w16[:, k, :].T + lo[rows, :cin] @ wq[:, k, :].T
+    return y
+
+
+def pack_mx_image(w: np.ndarray) -> np.ndarray:
+    """Independent restatement of ``mi355_pack_conv_weight_mx_host`` (csrc/api.cpp): uint8 image of w [Cout, K, Cin] float32."""
+    cout, K, cin = w.shape
+    chunks, ntp, npair = (cin + 31) // 32, (cout + 127) // 128 * 4, (K + 1) // 2
+    e = column_scale_exponents(w)
+    wp = np.zeros((ntp * 32, 2 * npair, chunks * 32), dtype=np.float64)
+    wp[:cout, :K, :cin] = w
+    ep = np.zeros(ntp * 32, dtype=np.int64)
+    ep[:cout] = e
+    codes = e4m3_bits(e4m3_round(wp / np.exp2(ep.astype(np.float64))[:, None, None]))      # [N, 2 NP, C]
+    h16 = wp[:, :K, :].astype(np.float16).view(np.uint16)                                   # [N, K, C]
+    out = np.zeros(chunks * (K + npair) * ntp * 2048 + ntp * 32, dtype=np.uint8)
+    lane = np.arange(64)
+    n_of = lane & 31
+    for ch in range(chunks):
+        base = ch * (K + npair) * ntp * 2048
+        for tap in range(K):
+            for nt in range(ntp):
+                for kk in range(2):
+                    c0 = ch * 32 + kk * 16 + (lane >> 5) * 8
+                    frag = h16[nt * 32 + n_of][:, tap][np.arange(64)[:, None], c0[:, None] + np.arange(8)[None, :]]       # [64, 8]
+                    o = base + ((tap * ntp + nt) * 2 + kk) * 1024
+                    out[o:o + 1024] = frag.astype(np.uint16).reshape(-1).view(np.uint8)
+        for p in range(npair):
+            for nt in range(ntp):
+                for h in range(2):
+                    c0 = ch * 32 + (lane >> 5) * 16
+                    frag = codes[nt * 32 + n_of][:, 2 * p + h][np.arange(64)[:, None], c0[:, None] + np.arange(16)[None, :]]  # [64, 16]
+                    o = base + K * ntp * 2048 + ((p * ntp + nt) * 2 + h) * 1024
+                    out[o:o + 1024] = frag.reshape(-1)
+    out[chunks * (K + npair) * ntp * 2048:] = (ep + 127).astype(np.uint8)
+    return out

@@ -265,3 +265,46 @@ def test_kokoro_fp16_single_pass_precision_mode(setup):
     snr = snr_db(got, audio_ref[0])
     print(f"kokoro precision=3 (fp16 single pass, canonical sentence): peak={peak:.3f} max_abs_err={err:.3e} snr={snr:.1f} dB")
     assert err <= 3e-3 * peak and snr >= 50.0, (err, snr)
+
+
+def test_kokoro_precision5_mx_lo_pass_mode(setup):
+    """precision=5: decoder / generator convs as the fp16 hi pass + block-scaled e4m3 lo pass (MX images, v_mfma_scale_f32_32x32x64_f8f6f4) where the
+    wave-specialised kernel takes the shape, fp16 hi + lo elsewhere; the front end stays on the bf16 hi+lo split (integer path and F0 / N curves
+    bit-identical to the default engine).  Same bars as the default mode: 2e-3 * peak and 50 dB, teacher-forced on the oracle's features, on the
+    canonical sentence -- as a batch of four so that BOTH generator stages fill the chip and run the MX kernel (one utterance leaves stage 0 on the
+    4-wave kernels)."""
+    S, eng, ref = setup
+    from mlx_audio_amd.tts.models.kokoro.engine import KokoroEngine
+
+    eng5 = KokoroEngine(S.make_kokoro_weights(), S.KOKORO_CONFIG, precision=5)
+    ids = S.make_phoneme_ids(18, seed=5)
+    ref_s = S.make_voice_pack()[len(ids) - 3]
+    _, d5, t5 = eng5.forward([ids], ref_s, speed=1.3, return_intermediates=True)
+    _, d2, t2 = eng.forward([ids], ref_s, speed=1.3, return_intermediates=True)
+    torch.cuda.synchronize()
+    assert torch.equal(d5[0], d2[0]) and torch.equal(t5["f0"], t2["f0"]) and torch.equal(t5["n"], t2["n"])
+    ids = S.make_phoneme_ids(78)
+    ref_s = S.make_voice_pack()[len(ids) - 3]
+    fd = S.forced_durations(80, 264)
+    ri, nz = _noise(264, 1234)
+    audio_ref, _, tr = ref.forward(ids, ref_s, pred_dur=fd, rand_ini=ri, noise=nz, return_intermediates=True)
+    nb = 4
+    tea = {k: torch.cat([torch.as_tensor(v)] * nb, dim=0) for k, v in _teacher(tr).items()}
+    outs, _ = eng5.forward([ids] * nb, ref_s, forced_durations=[fd] * nb, rand_ini=torch.from_numpy(np.repeat(ri, nb, axis=0)),
+                           noise=torch.from_numpy(np.repeat(nz, nb, axis=0)), overrides=tea)
+    torch.cuda.synchronize()
+    peak = float(audio_ref.abs().max())
+    worst_err, worst_snr = 0.0, 1e9
+    for b in range(nb):
+        got = outs[b].cpu()
+        worst_err = max(worst_err, float((got - audio_ref[0]).abs().max()))
+        worst_snr = min(worst_snr, snr_db(got, audio_ref[0]))
+    print(f"kokoro precision=5 (fp16 hi + MX e4m3 lo, canonical sentence x {nb}): peak={peak:.3f} max_abs_err={worst_err:.3e} ({worst_err / peak:.2e} of peak) snr={worst_snr:.1f} dB")
+    assert worst_err <= 2e-3 * peak and worst_snr >= 50.0, (worst_err, worst_snr)
+    # single utterance: stage 0 on the 4-wave kernels (precision-4 arithmetic on the same images), stage 1 on the MX kernel
+    outs1, _ = eng5.forward([ids], ref_s, forced_durations=[fd], rand_ini=torch.from_numpy(ri), noise=torch.from_numpy(nz), overrides=_teacher(tr))
+    torch.cuda.synchronize()
+    got = outs1[0].cpu()
+    err1, snr1 = float((got - audio_ref[0]).abs().max()), snr_db(got, audio_ref[0])
+    print(f"kokoro precision=5, one utterance: max_abs_err={err1:.3e} snr={snr1:.1f} dB")
+    assert err1 <= 2e-3 * peak and snr1 >= 50.0, (err1, snr1)

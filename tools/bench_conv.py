@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--quick", action="store_true", help="two shapes, the wave-specialised variants only (for PMC passes)")
     ap.add_argument("--ablate", action="store_true", help="timing ablations of the wave-specialised kernel (their results are wrong by design)")
     ap.add_argument("--small", action="store_true", help="the few-row GEMMs of PL-BERT / predictor (rows = B*80): 4-wave tile shapes A/B")
+    ap.add_argument("--prec-ab", action="store_true", help="the wave-specialised kernel under precisions 2 (bf16 hi+lo), 3 (one fp16 pass), 4 (fp16 hi+lo) and 5 (fp16 hi + MX e4m3 lo)")
     ap.add_argument("--flat", action="store_true", help="with --small: hand the batch over as ONE item of B*L rows (ops.conv_gemm(flatten=True))")
     args = ap.parse_args()
     from mlx_audio_amd import ops
@@ -60,6 +61,9 @@ def main():
     if args.quick:
         shapes = [(128, 128, 11, 1, 31681, "snake+res"), (128, 128, 3, 1, 31681, "snake+res")]
         variants = [("old64x128", 64128), ("ws4", 6128128)]
+    if args.prec_ab:
+        shapes = [s for s in shapes if s[2] % 4 == 3]
+        variants = [("p2_bf16_hi_lo", 6128128), ("p3_fp16_one_pass", 6128128), ("p4_fp16_hi_lo", 6128128), ("p5_fp16_hi_mx8_lo", 6128128)]
     lines = ["cin cout k dil rows fused variant ms tflops_alg GBps_alg maxrel"]
     g = torch.Generator(device=dev).manual_seed(0)
     for cin, cout, k, dil, L, fused in shapes:
@@ -68,6 +72,12 @@ def main():
         w = (torch.randn(cout, k, cin) / math.sqrt(k * cin)).to(torch.bfloat16).float()
         bias = torch.randn(cout) * 0.1
         pc = ops.pack_conv(w, bias, dev, f16=args.precision == 3)
+        vprec = {name: args.precision for name, _ in variants}
+        vpc = {name: pc for name, _ in variants}
+        if args.prec_ab:
+            pc16, pcmx = ops.pack_conv(w, bias, dev, f16=True), ops.pack_conv(w, bias, dev, mx=True)
+            vprec = {"p2_bf16_hi_lo": 2, "p3_fp16_one_pass": 3, "p4_fp16_hi_lo": 4, "p5_fp16_hi_mx8_lo": 5}
+            vpc = {"p2_bf16_hi_lo": pc, "p3_fp16_one_pass": pc16, "p4_fp16_hi_lo": pc16, "p5_fp16_hi_mx8_lo": pcmx}
         ld = ops.round_up(cin, 32)
         x = torch.randn((B, L, ld), generator=g, device=dev)
         y = torch.zeros((B, L, cout), device=dev)
@@ -108,7 +118,7 @@ def main():
         errs = {}
         for name, tile in variants:
             try:
-                ops.conv_gemm(x[:, :, :cin], pc, y, dil=dil, pad=pad, tile=tile, precision=args.precision, **kw)
+                ops.conv_gemm(x[:, :, :cin], vpc[name], y, dil=dil, pad=pad, tile=tile, precision=vprec[name], **kw)
                 torch.cuda.synchronize()
                 got = y[0, :ok_rows].double().cpu()
                 errs[name] = float((got - ref[:ok_rows]).abs().max() / ref.abs().max())
@@ -120,7 +130,7 @@ def main():
                     continue
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                ops.conv_gemm(x[:, :, :cin], pc, y, dil=dil, pad=pad, tile=tile, precision=args.precision, **kw)
+                ops.conv_gemm(x[:, :, :cin], vpc[name], y, dil=dil, pad=pad, tile=tile, precision=vprec[name], **kw)
                 e1.record()
                 torch.cuda.synchronize()
                 times[name].append(e0.elapsed_time(e1))
