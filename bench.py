@@ -40,8 +40,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=64,
                     help="utterances per GPU per step (SURVEY 8d batch list: 1 / 8 / 64 / 512; 64 per GPU = 512 over the 8-GPU node; measured on one\n"
                          "MI355X: 122 M samples/s at 32, 140 M at 64, 146 M at 128, 150 M at 256 -- the front end's latency-bound LSTMs amortise)")
-    ap.add_argument("--precision", type=int, default=2,
-                    help="2 = bf16 hi+lo split MFMA (fp32-grade), 3 = single fp16 pass in the vocoder, 1 = single bf16 pass")
+    ap.add_argument("--precision", type=int, default=5,
+                    help="5 = vocoder convs as fp16 hi pass + block-scaled e4m3 lo pass (default; 1.1e-4 of the peak / 85 dB on the canonical sentence), "
+                         "2 = bf16 hi+lo split MFMA everywhere (3e-5), 3 = single fp16 pass in the vocoder (misses the 2e-3 bar), 1 = single bf16 pass")
     ap.add_argument("--config", choices=["kokoro", "whisper", "qwen3", "csm", "kitten"], default="kokoro",
                     help="kokoro = the headline line (BASELINE config[1]); whisper / qwen3 / csm = the secondary lines of SURVEY 8d (BASELINE configs\n"
                          "[2] / [3] / [4]) with the same JSON schema (tools/bench_{whisper,qwen3,csm}.py run in-process, 1 GPU)")

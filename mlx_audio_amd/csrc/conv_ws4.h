@@ -428,51 +428,49 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
       };
       i32x8 w0[2], w1[2];
       ldW(w0, 0);
-      i32x8 qa;   // hi phase: fragment set 0 = low half, set 1 = high half; lo phase: the whole e4m3 operand
-      int sa = 0;
+      // Activation operands: two 8-register tuples.  hi phase: four fragment sets (qa low / high half, qb low / high half = groups 0..3 of a tap), each
+      // refilled with the NEXT tap's fragment right behind the MFMAs that read it: a read is four groups (8 MFMAs) ahead of its use.  lo phase:
+      // qa = the e4m3 operand of rows 0..31 of the wave's block, qb = rows 32..63, each refilled for the next tap pair behind its two MFMAs.
+      i32x8 qa, qb;
+      int sa = 0, sb2 = 0;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) qa[e] = 0;
+      for (int e = 0; e < 8; ++e) { qa[e] = 0; qb[e] = 0; }
       // per-item opaque copies of the lane coordinates: LICM otherwise parks ~12 partly computed LDS addresses in VGPRs across the whole tile and
       // the allocator pays for them with an accumulator in scratch; recomputing them costs a handful of VALU operations per 8 MFMAs
       int hlx = hl, hhx = hh;
       auto fresh = [&]() { asm volatile("" : "+v"(hlx), "+v"(hhx)); };
       auto lo4 = [](const i32x8& v) { return __builtin_bit_cast(bf16x8, (i32x4)__builtin_shufflevector(v, v, 0, 1, 2, 3)); };
       auto hi4 = [](const i32x8& v) { return __builtin_bit_cast(bf16x8, (i32x4)__builtin_shufflevector(v, v, 4, 5, 6, 7)); };
+      auto set_lo = [](i32x8& q8, const i32x4 v) { q8 = __builtin_shufflevector(v, (i32x4)__builtin_shufflevector(q8, q8, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7); };
+      auto set_hi = [](i32x8& q8, const i32x4 v) { q8 = __builtin_shufflevector((i32x4)__builtin_shufflevector(q8, q8, 0, 1, 2, 3), v, 0, 1, 2, 3, 4, 5, 6, 7); };
+      // fragment of group g (kk = g >> 1: 16-channel half of the chunk, mf = g & 1: 32-row half of the wave's rows) under tap tp
       auto rdH = [&](const int g, const int tp) {
         const int kk = g >> 1, mf = g & 1;
         const int row = wm * WM + mf * 32 + hlx + tp * dil;
         const int cidx = kk * 2 + hhx;
-        return *(const i32x4*)(Abase + jbuf * WBYTES + row * 64 + ((cidx ^ ((row >> 2) & 3)) << 4));
-      };
-      auto rdH0 = [&](const int g, const int tp) {  // into the low half of qa
-        const i32x4 v = rdH(g, tp);
-        qa = __builtin_shufflevector(v, (i32x4)__builtin_shufflevector(qa, qa, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7);
-      };
-      auto rdH1 = [&](const int g, const int tp) {  // into the high half of qa
-        const i32x4 v = rdH(g, tp);
-        qa = __builtin_shufflevector((i32x4)__builtin_shufflevector(qa, qa, 0, 1, 2, 3), v, 0, 1, 2, 3, 4, 5, 6, 7);
+        const i32x4 v = *(const i32x4*)(Abase + jbuf * WBYTES + row * 64 + ((cidx ^ ((row >> 2) & 3)) << 4));
+        if (g == 0) set_lo(qa, v);
+        else if (g == 1) set_hi(qa, v);
+        else if (g == 2) set_lo(qb, v);
+        else set_hi(qb, v);
       };
       // lo operand of rows [mf * 32, +32) for tap pair p: bytes 0..15 = channels [16 hh, +16) of the row under tap 2 p, bytes 16..31 = the same
       // channels under tap 2 p + 1 (K is odd: the last pair takes its last tap twice, that half of the weight item is zero, the data stay
       // finite); scale byte: lanes 0..31 carry K block 0 (tap 2 p), lanes 32..63 K block 1
-      auto rdL0 = [&](const int mf, const int p) {  // K block 0 (tap 2 p) -> low half
-        const int r0 = wm * WM + mf * 32 + hlx + 2 * p * dil;
-        const char* L8 = Abase + jbuf * WBYTES + ABYTES;
-        const i32x4 x0 = *(const i32x4*)(L8 + r0 * 32 + ((hhx ^ ((r0 >> 3) & 1)) << 4));
-        qa = __builtin_shufflevector(x0, (i32x4)__builtin_shufflevector(qa, qa, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7);
-      };
-      auto rdL1 = [&](const int mf, const int p) {  // K block 1 (tap 2 p + 1) -> high half, and the lane's scale byte
+      auto rdL = [&](const int mf, const int p) {
         const int t1 = 2 * p + 1 < K ? 2 * p + 1 : K - 1;
         const int rb = wm * WM + mf * 32 + hlx;
         const int r0 = rb + 2 * p * dil, r1 = rb + t1 * dil;
         const char* L8 = Abase + jbuf * WBYTES + ABYTES;
+        const i32x4 x0 = *(const i32x4*)(L8 + r0 * 32 + ((hhx ^ ((r0 >> 3) & 1)) << 4));
         const i32x4 x1 = *(const i32x4*)(L8 + r1 * 32 + ((hhx ^ ((r1 >> 3) & 1)) << 4));
-        qa = __builtin_shufflevector((i32x4)__builtin_shufflevector(qa, qa, 0, 1, 2, 3), x1, 0, 1, 2, 3, 4, 5, 6, 7);
-        sa = (int)*(const uint8_t*)(L8 + R * 32 + (hhx ? r1 : r0));
+        const int sc = (int)*(const uint8_t*)(L8 + R * 32 + (hhx ? r1 : r0));
+        if (mf == 0) { qa = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7); sa = sc; }
+        else { qb = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7); sb2 = sc; }
       };
-      auto rdL = [&](const int mf, const int p) { rdL0(mf, p); rdL1(mf, p); };
-      auto mmH = [&](const bf16x8 h, const int g, const i32x8 (&w)[2]) {
+      auto mmH = [&](const int g, const i32x8 (&w)[2]) {
         const int kk = g >> 1, mf = g & 1;
+        const bf16x8 h = g == 0 ? lo4(qa) : (g == 1 ? hi4(qa) : (g == 2 ? lo4(qb) : hi4(qb)));
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = mfma16<PREC>(h, kk ? hi4(w[nf]) : lo4(w[nf]), acc[mf][nf]);
       };
@@ -481,39 +479,42 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
         // registers -- and then shuffles whole accumulators through scratch.  Hazards, which hipcc does not pad for an asm statement: a VALU
         // result as an operand (the scale byte's mask) wants two wait states = the leading s_nop 1; the next reader of D is always another
         // MFMA taking it whole as C (0 wait states) until the pad in front of the fold / epilogue below.)
-        asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc[mf][0]) : "v"(qa), "v"(w[0]), "v"(sa), "v"(bsc));
-        asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[0,1,0] op_sel_hi:[0,0,0]" : "+v"(acc[mf][1]) : "v"(qa), "v"(w[1]), "v"(sa), "v"(bsc));
+        if (mf == 0) {
+          asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc[0][0]) : "v"(qa), "v"(w[0]), "v"(sa), "v"(bsc));
+          asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[0,1,0] op_sel_hi:[0,0,0]" : "+v"(acc[0][1]) : "v"(qa), "v"(w[1]), "v"(sa), "v"(bsc));
+        } else {
+          asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc[1][0]) : "v"(qb), "v"(w[0]), "v"(sb2), "v"(bsc));
+          asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[0,1,0] op_sel_hi:[0,0,0]" : "+v"(acc[1][1]) : "v"(qb), "v"(w[1]), "v"(sb2), "v"(bsc));
+        }
       };
-      // hi tap tp on weight item w: four groups, the fragment of group g + 1 requested before the MFMAs of group g; `last`: the chunk's last
-      // hi tap requests the first lo operand instead of the next tap's first fragment
+      // hi tap tp on weight item w (its four fragments are in flight or landed); `last`: the chunk's last hi tap requests the two operands of the
+      // first lo tap pair instead of the next tap's fragments
       auto hi_tap = [&](const int tp, const i32x8 (&w)[2], auto last) {
+        constexpr bool LAST = decltype(last)::value;
         fresh();
-        rdH1(1, tp);
+        mmH(0, w);
+        if constexpr (!LAST) rdH(0, tp + 1);
         __builtin_amdgcn_sched_barrier(0);
-        mmH(lo4(qa), 0, w);
-        rdH0(2, tp);
+        mmH(1, w);
+        if constexpr (LAST) rdL(0, 0);
+        else rdH(1, tp + 1);
         __builtin_amdgcn_sched_barrier(0);
-        mmH(hi4(qa), 1, w);
-        rdH1(3, tp);
+        mmH(2, w);
+        if constexpr (!LAST) rdH(2, tp + 1);
         __builtin_amdgcn_sched_barrier(0);
-        mmH(lo4(qa), 2, w);
-        if constexpr (decltype(last)::value) rdL0(0, 0);   // the first lo operand arrives in two halves, each behind the last MFMA that reads
-        else rdH0(0, tp + 1);                               // the hi fragment it replaces
-        __builtin_amdgcn_sched_barrier(0);
-        mmH(hi4(qa), 3, w);
-        if constexpr (decltype(last)::value) rdL1(0, 0);
+        mmH(3, w);
+        if constexpr (LAST) rdL(1, 0);
+        else rdH(3, tp + 1);
         __builtin_amdgcn_sched_barrier(0);
       };
-      // lo tap pair p on weight item w: ONE operand set (the register budget), refilled between the two row halves
+      // lo tap pair p on weight item w
       auto lo_pair = [&](const int p, const i32x8 (&w)[2], const bool more) {
         fresh();
         mmL(0, w);
-        __builtin_amdgcn_sched_barrier(0);
-        rdL(1, p);
+        if (more) rdL(0, p + 1);
         __builtin_amdgcn_sched_barrier(0);
         mmL(1, w);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) rdL(0, p + 1);
+        if (more) rdL(1, p + 1);
         __builtin_amdgcn_sched_barrier(0);
       };
       auto prefetch = [&](i32x8 (&w)[2], const int s) {
@@ -526,7 +527,11 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
       int s = 0;
       auto chunk_body = [&](i32x8 (&wa)[2], i32x8 (&wb)[2]) {
         lds_barrier();  // the chunk's window is staged behind this barrier (and the producers may refill the buffer just left)
-        rdH0(0, 0);
+        fresh();
+        rdH(0, 0);
+        rdH(1, 0);
+        rdH(2, 0);
+        rdH(3, 0);
         int tp = 0;
         for (; tp + 1 < K; tp += 2) {
           prefetch(wb, s + 1);

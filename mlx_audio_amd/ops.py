@@ -84,6 +84,12 @@ def mx_eligible(cout: int, k: int, cin: int) -> bool:
     return k % 4 == 3 and cout > 64 and cin >= 64
 
 
+def mx_pays(cout: int, k: int, cin: int) -> bool:
+    """... and for which it is the faster arithmetic (profiles/r4_conv_prec_ab_b32_call3.txt): from 7 taps on.  The 3-tap convs are bound by HBM and
+    by the producers' VALU work, where the bf16 split is the cheapest prologue (cvt_pk + shift / mask): they stay on the bf16 hi + lo pass."""
+    return mx_eligible(cout, k, cin) and k >= 7
+
+
 def pack_conv(w: torch.Tensor, bias: Optional[torch.Tensor], device, f16: bool = False, mx: bool = False) -> PackedConv:
     """``w``: float32 CPU tensor ``[Cout, K, Cin]`` (MLX conv layout) or ``[Cout, Cin]`` (linear).  ``mx``: the image of precision 5."""
     if w.dim() == 2:

@@ -225,7 +225,10 @@ class KokoroEngine:
     def _convw(self, pre, bias=True) -> PackedConv:
         b = self._q(self._t(f"{pre}.bias")) if bias and f"{pre}.bias" in self.w else None
         w = self._wn(pre)
-        mx = self.precision == 5 and pre.startswith("decoder.") and w.dim() == 3 and ops.mx_eligible(w.shape[0], w.shape[1], w.shape[2])
+        dec5 = self.precision == 5 and pre.startswith("decoder.") and w.dim() == 3
+        mx = dec5 and ops.mx_pays(w.shape[0], w.shape[1], w.shape[2])
+        if dec5 and not mx and w.shape[1] == 3 and ops.mx_eligible(w.shape[0], w.shape[1], w.shape[2]):
+            return ops.pack_conv(w, b, self.dev)   # the HBM / VALU-bound 3-tap convs: bf16 hi + lo (exact weights, cheapest prologue)
         return ops.pack_conv(w, b, self.dev, f16=self._f16(pre), mx=mx)
 
     def _f16(self, pre: str) -> bool:
@@ -530,6 +533,8 @@ class KokoroEngine:
             ids = ids.to(dev)
         lens_t = torch.tensor(Ts, dtype=torch.int32, device=dev) if ragged else None
         ref_s = ref_s.to(device=dev, dtype=torch.float32).contiguous()
+        if ref_s.dim() != 2 or ref_s.shape[0] != B or ref_s.shape[1] != 2 * sty:
+            raise ValueError(f"ref_s must be [{B}, {2 * sty}] (one style row per utterance), got {tuple(ref_s.shape)}")
         s_dec = ref_s[:, :sty].contiguous()
         s_pred = ref_s[:, sty:].contiguous()
         # ---- every style projection of the network: two GEMMs

@@ -140,7 +140,7 @@ def test_conv_precision5_saturating_input(ops):
     got = y.cpu()
     assert torch.isfinite(got).all()
     ref = ref_conv_nlc(x, w, None, 1, 1)
-    assert peak_err(got, ref) < 2e-2
+    assert peak_err(got, ref) < 8e-2   # the rows under the spikes: |lo| = |t| - 65504 carried with 3 significant bits
     far = torch.ones(L, dtype=torch.bool)
     far[96:106] = False
     assert peak_err(got[0, far], ref[0, far]) < 3e-5

@@ -290,7 +290,7 @@ def test_kokoro_precision5_mx_lo_pass_mode(setup):
     audio_ref, _, tr = ref.forward(ids, ref_s, pred_dur=fd, rand_ini=ri, noise=nz, return_intermediates=True)
     nb = 4
     tea = {k: torch.cat([torch.as_tensor(v)] * nb, dim=0) for k, v in _teacher(tr).items()}
-    outs, _ = eng5.forward([ids] * nb, ref_s, forced_durations=[fd] * nb, rand_ini=torch.from_numpy(np.repeat(ri, nb, axis=0)),
+    outs, _ = eng5.forward([ids] * nb, ref_s.repeat(nb, 1), forced_durations=[fd] * nb, rand_ini=torch.from_numpy(np.repeat(ri, nb, axis=0)),
                            noise=torch.from_numpy(np.repeat(nz, nb, axis=0)), overrides=tea)
     torch.cuda.synchronize()
     peak = float(audio_ref.abs().max())
