@@ -635,6 +635,16 @@ typedef struct {
   float* split_ws; int32_t* split_cnt;
   int32_t y2_dtype;   /* element type of y2: MI355_KV_F32 (0) / MI355_KV_BF16 / MI355_KV_F16 -- a 16-bit KV-cache slot (the reference's cache dtype);
                          y2 is then a uint16_t* in disguise and ldy2 counts 16-bit elements */
+  int32_t w_policy;   /* cache policy of the weight stream (one-row kernels): 0 = default loads, 1 = non-temporal (`nt`): images that are streamed once
+                         per step and should not displace what the step re-reads -- a 2.4 GB backbone in front of a 220 MB depth decoder that runs
+                         31 times per frame and fits the 256 MB Infinity Cache (sesame.py:361-404) */
+  /* optional attention PROLOGUE (M == 1, K = attn_heads * attn_dh <= 2048, attn_Tk <= 64 cached positions): x is the step's query row (rotated,
+     head-major) and the row that enters the product is softmax(q K^T * attn_scale) V over the cache rows 0 .. attn_Tk - 1 (the step's own k | v
+     already filed by the q|k|v launch) -- mx.fast.scaled_dot_product_attention + o_proj of lm/models/llama.py:80-96 at one position, one launch
+     instead of two where the context is short (CSM's depth decoder: <= 32 positions, sesame.py:385-404).  attn_k / attn_v: row t of kv head g at
+     element t * attn_ld + g * attn_dh, element type attn_kv_dtype (MI355_KV_*).  No fused norm / glu / rope / gathered input. */
+  const void* attn_k; const void* attn_v; int32_t attn_ld; int32_t attn_Tk; int32_t attn_heads; int32_t attn_kv_heads; int32_t attn_dh;
+  float attn_scale; int32_t attn_kv_dtype;
 } mi355_gemv_args;
 int mi355_gemv(const mi355_gemv_args* a, void* stream);
 int mi355_pack_rowmajor16_host(const float* w_host, int64_t n, int32_t dtype, uint16_t* out_host);
@@ -787,6 +797,7 @@ typedef struct {
                                   and this step appends position slot_lens_k[b] - 1 to ITS row of every kv buffer (rotary position = that index); `offset`
                                   is then only the host's upper bound of the positions (capacity / table checks).  Needs the fused attention step
                                   (per-head norms and / or rotary embedding, causal). */
+  int32_t w_policy;        /* mi355_gemv_args.w_policy of every projection of the stack (steps of 1 sequence) */
 } mi355_stack_desc;
 
 /* ------------------------------------------------------------------------------------------

@@ -41,7 +41,7 @@ __device__ __forceinline__ void gemv_finish(const mi355_gemv_args& a, float (&ac
 #pragma unroll
   for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[c][m] = wave_sum(acc[c][m]);
+    for (int m = 0; m < MT; ++m) acc[c][m] = wave_sum_fast(acc[c][m]);   // called by whole waves
   if (lane != 0) return;
   if (a.glu) {  // columns come in (gate, up) pairs: NC is even on this path
 #pragma unroll
@@ -400,10 +400,24 @@ __global__ __launch_bounds__(256) void gemv_res_kernel(const mi355_gemv_args a, 
 //
 // gemv1_splitk_kernel (K > 2048: the down projections): 4 columns per workgroup, the 4 waves split K; a lane streams its slices of x with the
 // weights (same prefetch ring), partial sums meet in LDS once.  16 KB of weights in flight per wave keeps HBM busy with only N / 4 workgroups.
-template <int NC, int WT>
+// 16 bytes of the weight stream under the launch's cache policy (NT: global_load_dwordx4 ... nt)
+template <bool NT>
+__device__ __forceinline__ uint4 ldw16(const void* p) {
+  if constexpr (NT) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+  } else {
+    return *(const uint4*)p;
+  }
+}
+
+// HALF: K <= 1024 (half the slices: half the weight ring and x registers -- the 1024-wide depth decoder / code predictor then keep 4 waves per SIMD
+// resident instead of 2, see launch_gemv1)
+template <int NC, int WT, bool NT = false, bool HALF = false>
 __global__ __launch_bounds__(256) void gemv1_res_kernel(const mi355_gemv_args a, const int ngroups) {
   constexpr int EPL = mi355_wt<WT>::EPL, ESZ = 16 / EPL, SL = 64 * EPL;
-  constexpr int NIT = 2048 / (64 * 8) / (EPL / 8);  // slices covering K <= 2048 (4 at 16 bits, 2 for fp8 whose slice is 1024 elements)
+  constexpr int NIT = 2048 / (64 * 8) / (EPL / 8) / (HALF ? 2 : 1);  // slices covering K <= 2048 (4 at 16 bits, 2 for fp8 whose slice is 1024 elements)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int K = a.K;
   const float* xrow = a.x_ids ? a.x + ((int64_t)a.x_ids[0] + a.x_id_offset) * a.ldx : a.x;   // optional fused embedding lookup
@@ -426,13 +440,24 @@ __global__ __launch_bounds__(256) void gemv1_res_kernel(const mi355_gemv_args a,
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int k = it * SL + lane * EPL;
-        dst[it][c] = k < K ? *(const uint4*)(wrow + (int64_t)k * ESZ) : make_uint4(0u, 0u, 0u, 0u);
+        dst[it][c] = k < K ? ldw16<NT>(wrow + (int64_t)k * ESZ) : make_uint4(0u, 0u, 0u, 0u);
       }
     }
   };
   int g = blockIdx.x * 4 + wave;
   const int gstep = gridDim.x * 4;
   if (g < ngroups) issue(g, ring[0]);   // the weight stream starts before the statistics: its HBM latency overlaps the norm
+  // the norm weights are requested before the statistics too (one L2 round trip less on the kernel's dependent chain)
+  float4 nwq[NIT][EPL / 4];
+  if (a.norm) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int k = it * SL + lane * EPL;
+#pragma unroll
+      for (int j4 = 0; j4 < EPL / 4; ++j4)
+        nwq[it][j4] = (a.norm_weight && k < K) ? *(const float4*)(a.norm_weight + k + 4 * j4) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+  }
   if (a.norm) {
     float mean = 0.f;
     if (a.norm == 1) {
@@ -441,7 +466,7 @@ __global__ __launch_bounds__(256) void gemv1_res_kernel(const mi355_gemv_args a,
       for (int it = 0; it < NIT; ++it)
 #pragma unroll
         for (int j = 0; j < EPL; ++j) s += xr[it][j];
-      mean = wave_sum(s) / (float)K;
+      mean = wave_sum_fast(s) / (float)K;
     }
     float q = 0.f;
 #pragma unroll
@@ -451,7 +476,7 @@ __global__ __launch_bounds__(256) void gemv1_res_kernel(const mi355_gemv_args a,
         const float d = (it * SL + lane * EPL + j < K) ? xr[it][j] - mean : 0.f;
         q += d * d;
       }
-    const float var = wave_sum(q) / (float)K;
+    const float var = wave_sum_fast(q) / (float)K;
     const float rstd = a.norm == 1 ? 1.0f / sqrtf(var + a.norm_eps) : rsqrtf(var + a.norm_eps);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -459,7 +484,7 @@ __global__ __launch_bounds__(256) void gemv1_res_kernel(const mi355_gemv_args a,
       if (k < K) {
 #pragma unroll
         for (int j4 = 0; j4 < EPL / 4; ++j4) {
-          const float4 w4 = a.norm_weight ? *(const float4*)(a.norm_weight + k + 4 * j4) : make_float4(1.f, 1.f, 1.f, 1.f);
+          const float4 w4 = nwq[it][j4];
           const float4 b4 = a.norm_bias ? *(const float4*)(a.norm_bias + k + 4 * j4) : make_float4(0.f, 0.f, 0.f, 0.f);
           xr[it][4 * j4] = (xr[it][4 * j4] - mean) * rstd * w4.x + b4.x;
           xr[it][4 * j4 + 1] = (xr[it][4 * j4 + 1] - mean) * rstd * w4.y + b4.y;
@@ -494,7 +519,146 @@ __global__ __launch_bounds__(256) void gemv1_res_kernel(const mi355_gemv_args a,
   }
 }
 
-template <int WT>
+
+// gemv1_attn_kernel: the o-proj of a decode step with the attention of that step as its PROLOGUE (M == 1, K = heads * dh <= 2048, at most 64 cached
+// positions: the depth decoder of CSM attends over <= 32 positions, 124 times per frame).  Every workgroup recomputes the whole attention row -- a
+// few thousand multiply-adds on K | V rows that sit in L2 -- while its slice of the weight stream is already in flight, and then runs the
+// register-resident GEMV of gemv1_res_kernel on it: one launch per layer less, and the scores never touch memory.  x = the (rotated) query row.
+template <int WT, bool NT>
+__global__ __launch_bounds__(256) void gemv1_attn_kernel(const mi355_gemv_args a, const int ngroups) {
+  constexpr int NC = 1;
+  constexpr int EPL = mi355_wt<WT>::EPL, ESZ = 16 / EPL, SL = 64 * EPL;
+  constexpr int NIT = 2048 / (64 * 8) / (EPL / 8);
+  __shared__ float s_q[2048];        // query, then (same storage) the attention output
+  __shared__ float s_p[32 * 64];     // scores / probabilities [heads][64]
+  __shared__ float s_o[4 * 2048];    // partial outputs of the position shares
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = a.K, H = a.attn_heads, G = a.attn_kv_heads, dh = a.attn_dh, Tk = a.attn_Tk, rep = H / G;
+  uint4 ring[2][NIT][NC];
+  auto issue = [&](int g, uint4 (&dst)[NIT][NC]) {
+    const int n = g < a.N ? g : a.N - 1;
+    const uint8_t* wrow = (const uint8_t*)a.w + (int64_t)n * a.ldw * ESZ;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int k = it * SL + lane * EPL;
+      dst[it][0] = k < K ? ldw16<NT>(wrow + (int64_t)k * ESZ) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  int g = blockIdx.x * 4 + wave;
+  const int gstep = gridDim.x * 4;
+  if (g < ngroups) issue(g, ring[0]);   // the weight stream starts first: its HBM latency covers the attention prologue
+  // four consecutive cache elements as floats (16-byte / 8-byte load by element type)
+  auto kv4 = [&](const void* base, const int64_t idx) -> float4 {
+    if (a.attn_kv_dtype == MI355_KV_F32) return *(const float4*)((const float*)base + idx);
+    const uint2 u = *(const uint2*)((const uint16_t*)base + idx);
+    if (a.attn_kv_dtype == MI355_KV_BF16)
+      return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u), __builtin_bit_cast(float, u.y << 16),
+                         __builtin_bit_cast(float, u.y & 0xffff0000u));
+    return make_float4((float)__builtin_bit_cast(_Float16, (uint16_t)(u.x & 0xffffu)), (float)__builtin_bit_cast(_Float16, (uint16_t)(u.x >> 16)),
+                       (float)__builtin_bit_cast(_Float16, (uint16_t)(u.y & 0xffffu)), (float)__builtin_bit_cast(_Float16, (uint16_t)(u.y >> 16)));
+  };
+  for (int i = tid; i < K; i += 256) s_q[i] = a.x[i];
+  __syncthreads();
+  // scores: one cache row (t, g) per quad of lanes, each lane a quarter of the dh channels; the quad's partial dots with the rep query heads of kv
+  // head g meet through two xor steps.  All of a pass's loads are in flight together: one L2 round trip per 64 rows.
+  {
+    const int qd = tid & 3, rowi = tid >> 2, seg = dh >> 2;   // seg = channels per lane (16 or 32)
+    for (int r0 = 0; r0 < Tk * G; r0 += 64) {
+      const int r = r0 + rowi;
+      const bool ok = r < Tk * G;
+      const int t = ok ? r / G : 0, gk = ok ? r - t * G : 0;
+      const int64_t kb = (int64_t)t * a.attn_ld + gk * dh + qd * seg;
+      float4 kk[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (4 * j < seg) kk[j] = kv4(a.attn_k, kb + 4 * j);
+      for (int rr = 0; rr < rep; ++rr) {
+        const int h = gk * rep + rr;
+        const float* qp = s_q + h * dh + qd * seg;
+        float sc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (4 * j < seg) {
+            sc = fmaf(qp[4 * j], kk[j].x, sc); sc = fmaf(qp[4 * j + 1], kk[j].y, sc);
+            sc = fmaf(qp[4 * j + 2], kk[j].z, sc); sc = fmaf(qp[4 * j + 3], kk[j].w, sc);
+          }
+        sc += __shfl_xor(sc, 1, 64);
+        sc += __shfl_xor(sc, 2, 64);
+        if (ok && qd == 0) s_p[h * 64 + t] = sc * a.attn_scale;
+      }
+    }
+  }
+  __syncthreads();
+  // softmax per head: one wave per head round, lane = key position (Tk <= 64)
+  for (int h = wave; h < H; h += 4) {
+    const float v = lane < Tk ? s_p[h * 64 + lane] : -INFINITY;
+    const float m = wave_max(v);
+    const float e = lane < Tk ? expf(v - m) : 0.f;
+    const float den = wave_sum(e);
+    if (lane < Tk) s_p[h * 64 + lane] = e / den;
+  }
+  __syncthreads();
+  // out[h, d] = sum_t p[h, t] v[t, h / rep, d]: a thread owns four channels of one kv head for a share of the positions (TS shares so that all 256
+  // threads work); the shares meet in s_o, the result overwrites the query
+  {
+    const int items = G * (dh >> 2);              // (g, d4) items: 64 (depth decoder) .. 128
+    const int TS = 256 / items >= 4 ? 4 : (256 / items >= 1 ? 256 / items : 1);   // <= 4 shares: s_o holds four rows
+    const int it = tid % items, ts = tid / items;
+    const int gk = it / (dh >> 2), d4 = (it - gk * (dh >> 2)) * 4;
+    float4 o[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) o[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ts < TS) {
+      for (int t = ts; t < Tk; t += TS) {
+        const float4 vv = kv4(a.attn_v, (int64_t)t * a.attn_ld + gk * dh + d4);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr)
+          if (rr < rep) {
+            const float pw = s_p[(gk * rep + rr) * 64 + t];
+            o[rr].x = fmaf(pw, vv.x, o[rr].x); o[rr].y = fmaf(pw, vv.y, o[rr].y); o[rr].z = fmaf(pw, vv.z, o[rr].z); o[rr].w = fmaf(pw, vv.w, o[rr].w);
+          }
+      }
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr)
+        if (rr < rep) *(float4*)(s_o + ts * 2048 + (gk * rep + rr) * dh + d4) = o[rr];
+    }
+    __syncthreads();
+    for (int i = tid; i < K; i += 256) {
+      float sum = s_o[i];
+      for (int u = 1; u < TS; ++u) sum += s_o[u * 2048 + i];
+      s_q[i] = sum;
+    }
+  }
+  __syncthreads();
+  float xr[NIT][EPL];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int k = it * SL + lane * EPL;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) xr[it][j] = k + j < K ? s_q[k + j] : 0.f;
+  }
+  int buf = 0;
+  for (; g < ngroups; g += gstep, buf ^= 1) {
+    if (g + gstep < ngroups) {
+      if (buf == 0) issue(g + gstep, ring[1]); else issue(g + gstep, ring[0]);
+    }
+    float acc[NC][1];
+    acc[0][0] = 0.f;
+    auto consume = [&](uint4 (&src)[NIT][NC]) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        float wf[EPL];
+        cvt_w16<WT>(src[it][0], wf);
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) acc[0][0] = fmaf(xr[it][j], wf[j], acc[0][0]);
+      }
+    };
+    if (buf == 0) consume(ring[0]); else consume(ring[1]);
+    gemv_finish<1, NC>(a, acc, g, lane);
+  }
+}
+
+template <int WT, bool NT = false>
 __global__ __launch_bounds__(256) void gemv1_splitk_kernel(const mi355_gemv_args a) {
   constexpr int NC = 4, D = 4;
   constexpr int EPL = mi355_wt<WT>::EPL, ESZ = 16 / EPL, SL = 64 * EPL;
@@ -516,7 +680,7 @@ __global__ __launch_bounds__(256) void gemv1_splitk_kernel(const mi355_gemv_args
   auto issue = [&](int it, int d) {
     const int k = it * SL + lane * EPL;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) wring[d][c] = k < a.K ? *(const uint4*)(wrow[c] + (int64_t)k * ESZ) : make_uint4(0u, 0u, 0u, 0u);
+    for (int c = 0; c < NC; ++c) wring[d][c] = k < a.K ? ldw16<NT>(wrow[c] + (int64_t)k * ESZ) : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
     for (int j4 = 0; j4 < EPL / 4; ++j4) xring[d][j4] = k < a.K ? *(const float4*)(xrow + k + 4 * j4) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
@@ -547,7 +711,7 @@ __global__ __launch_bounds__(256) void gemv1_splitk_kernel(const mi355_gemv_args
     }
   }
 #pragma unroll
-  for (int c = 0; c < NC; ++c) acc[c] = wave_sum(acc[c]);
+  for (int c = 0; c < NC; ++c) acc[c] = wave_sum_fast(acc[c]);
   if (lane == 0) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) part[wave][c] = acc[c];
@@ -570,17 +734,61 @@ int launch_gemv1(const mi355_gemv_args& a, hipStream_t st) {
   constexpr int EPL = mi355_wt<WT>::EPL;
   const int kres = 2048 * (EPL / 8) / (EPL / 8);  // K the register-resident kernel covers (2048 elements for every weight type)
   MI355_CLEAR_ERROR();
+  if (a.attn_k) {   // attention prologue: validated by mi355_gemv
+    int blocks = (a.N + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    static const int nt_env0 = getenv("MI355_GEMV_NT") ? atoi(getenv("MI355_GEMV_NT")) : -1;
+    if (nt_env0 >= 0 ? nt_env0 != 0 : a.w_policy == 1) hipLaunchKernelGGL((gemv1_attn_kernel<WT, true>), dim3(blocks), dim3(256), 0, st, a, a.N);
+    else hipLaunchKernelGGL((gemv1_attn_kernel<WT, false>), dim3(blocks), dim3(256), 0, st, a, a.N);
+    MI355_LAUNCH_CHECK("gemv(M=1, attention prologue)");
+    return MI355_OK;
+  }
   if (a.K <= kres) {
     const bool two = a.glu || a.rope_cos || a.N >= 4096;
     const int ngroups = two ? (a.N + 1) / 2 : a.N;
-    int blocks = (ngroups + 3) / 4;
-    if (blocks > 1024) blocks = 1024;  // 4 workgroups per CU; the rest of the columns come grid-stride with their weights prefetched
-    if (two) hipLaunchKernelGGL((gemv1_res_kernel<2, WT>), dim3(blocks), dim3(256), 0, st, a, ngroups);
-    else hipLaunchKernelGGL((gemv1_res_kernel<1, WT>), dim3(blocks), dim3(256), 0, st, a, ngroups);
+    static const int nt_env = getenv("MI355_GEMV_NT") ? atoi(getenv("MI355_GEMV_NT")) : -1;   // A/B knob: 0 / 1 overrides every launch's policy
+    const bool nt = nt_env >= 0 ? nt_env != 0 : a.w_policy == 1;
+    const bool half = a.K <= 1024;
+    // ONE resident round: the grid is what the chip holds at this instantiation's register count (the two-column kernel at K = 2048 takes 224
+    // registers = 2 workgroups per CU; launched as 1024 workgroups it ran two full rounds, each with its own x load -> statistics -> first HBM
+    // round trip: 13.9 us for the 33.5 MB gate|up image of the depth decoder, profiles/r2_kernel_stats_csm_bygrid_call11_m1_kernels.txt); the rest
+    // of the columns come grid-stride with their weights prefetched
+    auto go = [&](auto kern) {
+      static int resident = 0;   // per instantiation (the lambda's body is instantiated per kernel type)
+      if (resident == 0) {
+        // 256-thread workgroups = one wave per SIMD: workgroups per CU = waves per SIMD = floor(512 / registers allocated in granules of 8), at most 8
+        // (the occupancy API answered 4 for the 224-register instantiation, which the hardware runs at 2: call 5)
+        int per_cu = 2, dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, (const void*)kern) == hipSuccess && fa.numRegs > 0) {
+          per_cu = 512 / (((fa.numRegs + 7) / 8) * 8);
+          per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+        }
+        resident = per_cu * cus;
+      }
+      int blocks = (ngroups + 3) / 4;
+      if (blocks > resident) blocks = resident;
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, st, a, ngroups);
+    };
+    if (half) {
+      if (two && nt) go(gemv1_res_kernel<2, WT, true, true>);
+      else if (two) go(gemv1_res_kernel<2, WT, false, true>);
+      else if (nt) go(gemv1_res_kernel<1, WT, true, true>);
+      else go(gemv1_res_kernel<1, WT, false, true>);
+    } else {
+      if (two && nt) go(gemv1_res_kernel<2, WT, true>);
+      else if (two) go(gemv1_res_kernel<2, WT>);
+      else if (nt) go(gemv1_res_kernel<1, WT, true>);
+      else go(gemv1_res_kernel<1, WT>);
+    }
     MI355_LAUNCH_CHECK("gemv(M=1, register-resident x)");
     return MI355_OK;
   }
-  hipLaunchKernelGGL((gemv1_splitk_kernel<WT>), dim3((a.N + 3) / 4), dim3(256), 0, st, a);
+  static const int nt_env2 = getenv("MI355_GEMV_NT") ? atoi(getenv("MI355_GEMV_NT")) : -1;
+  if (nt_env2 >= 0 ? nt_env2 != 0 : a.w_policy == 1) hipLaunchKernelGGL((gemv1_splitk_kernel<WT, true>), dim3((a.N + 3) / 4), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((gemv1_splitk_kernel<WT>), dim3((a.N + 3) / 4), dim3(256), 0, st, a);
   MI355_LAUNCH_CHECK("gemv(M=1, split K)");
   return MI355_OK;
 }
@@ -666,6 +874,14 @@ extern "C" int mi355_gemv(const mi355_gemv_args* ap, void* stream) {
   MI355_REQUIRE(!a.rope_cos || (a.rope_sin && a.rope_dh > 0 && a.rope_dh % 2 == 0 && a.rope_cols > 0 && a.rope_cols <= a.N && a.rope_cols % a.rope_dh == 0 &&
                                 !a.glu && !a.res && !a.colscale && a.post_act == MI355_ACT_NONE && a.M <= 4 && (!a.y2 || a.split % 2 == 0)),
                 "gemv: fused rope needs a plain epilogue, <= 4 rows, whole heads and an even split");
+  MI355_REQUIRE(!a.attn_k || (a.attn_v && a.M == 1 && a.K <= 2048 && !a.norm && !a.glu && !a.rope_cos && !a.x_ids && a.attn_Tk >= 1 && a.attn_Tk <= 64 &&
+                               a.attn_heads >= 1 && a.attn_heads <= 32 && a.attn_kv_heads >= 1 && a.attn_heads % a.attn_kv_heads == 0 &&
+                               a.attn_heads * a.attn_dh == a.K && a.attn_ld >= a.attn_kv_heads * a.attn_dh && a.attn_ld % 4 == 0 &&
+                               (a.attn_dh == 64 || a.attn_dh == 128) && a.attn_heads / a.attn_kv_heads <= 8 && a.attn_kv_heads * (a.attn_dh / 4) <= 256 &&
+                               ((uintptr_t)a.attn_k) % 16 == 0 && ((uintptr_t)a.attn_v) % 8 == 0 &&
+                               a.attn_kv_dtype >= MI355_KV_F32 && a.attn_kv_dtype <= MI355_KV_F16),
+                "gemv: the attention prologue needs one row, K = heads * dh <= 2048, <= 32 heads, 1..64 cached positions and a plain input side");
+  MI355_REQUIRE(a.w_policy == 0 || a.w_policy == 1, "gemv: w_policy must be 0 (default) or 1 (non-temporal)");
   if (a.out_scale == 0.f) a.out_scale = 1.f;
   static const bool two_reads = getenv("MI355_GEMV_TWO_READS") != nullptr;  // A/B knob: statistics from a separate read of x (the older schedule)
   a.norm_two_reads = two_reads ? 1 : 0;

@@ -15,6 +15,8 @@
 
 namespace {
 
+thread_local int t_w_policy = 0;   // mi355_stack_desc.w_policy of the step being enqueued
+
 int gemv_call(const float* x, int ldx, int M, int K, const uint16_t* w, int N, int wdtype, const float* bias, int act, const float* colscale,
               const float* res, int ldr, int glu, float* y, int ldy, int norm, const float* nw, const float* nb, float eps, float* y2, int ldy2,
               int split, void* stream, const float* wscale = nullptr, const float* rope_cos = nullptr, const float* rope_sin = nullptr, int rope_dh = 0,
@@ -26,6 +28,7 @@ int gemv_call(const float* x, int ldx, int M, int K, const uint16_t* w, int N, i
   g.norm_eps = eps; g.y2 = y2; g.ldy2 = ldy2; g.split = split; g.wscale = wscale;
   g.rope_cos = rope_cos; g.rope_sin = rope_sin; g.rope_dh = rope_dh; g.rope_cols = rope_cols; g.y2_dtype = y2_dtype;
   g.split_ws = split_ws; g.split_cnt = split_cnt;
+  g.w_policy = t_w_policy;
   return mi355_gemv(&g, stream);
 }
 
@@ -276,6 +279,8 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
   if ((B > 8 || B >= rows_min) && !rows_off && d.layers[0].wqkv_t && (!d.layers[0].cross_k || d.layers[0].wcq_t)) return tall_step(d, x, B, offset, ws, out, stream);
   const int D = d.d_model, H = d.heads, G = d.kv_heads, dh = d.dh;
   const int nq = H * dh, nkv = 2 * G * dh;
+  MI355_REQUIRE(d.w_policy == 0 || d.w_policy == 1, "stack_decode_step: w_policy must be 0 or 1");
+  t_w_policy = d.w_policy;
   float* q = ws;                 // [B, nq]
   float* att = q + (size_t)B * nq;   // [B, nq]
   float* mid = att + (size_t)B * nq; // [B, d_ff]
@@ -304,6 +309,13 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
     MI355_REQUIRE(!d.slot_lens_k || rope_in_attn, "stack_decode_step: slot caches need the fused attention step (per-head norms / rotary embedding, causal)");
     MI355_REQUIRE(d.kv_dtype == MI355_KV_F32 || rope_in_gemv || rope_in_attn || !(L.q_norm || d.cos),
                   "stack_decode_step: a 16-bit KV cache needs the rotary embedding inside the q|k|v GEMV or inside the attention step");
+    // one sequence, rotary pairs already applied by the q|k|v GEMV, at most 64 cached positions, no window / left padding: attention as the
+    // prologue of the o-proj GEMV
+    // Measured (profiles/r4_kernel_stats_csm_attn_prologue_call5.txt): the fused launch takes 13.3 us against 5.7 + 4.4 us for the two it replaces --
+    // 256 workgroups re-reading the same 64 KB of K | V at the same moment queue on the same L2 lines -- so it is OPT-IN: MI355_ATTN_IN_OPROJ=1.
+    static const bool aio_off = getenv("MI355_ATTN_IN_OPROJ") == nullptr || getenv("MI355_ATTN_IN_OPROJ")[0] != '1';
+    const bool attn_in_oproj = !aio_off && B == 1 && (rope_in_gemv || !(L.q_norm || d.cos)) && !rope_in_attn && offset + 1 <= 64 && nq <= 2048 && H <= 32 && d.causal &&
+                               !d.window && !d.k_start && !d.slot_lens_k && !L.cross_k;
     float* kvtmp = mid + (size_t)B * d.d_ff;  // [B, nkv]: the tail of the workspace
     int rc = gemv_call(x, D, B, D, L.wqkv, nq + nkv, d.wdtype, L.bqkv, MI355_ACT_NONE, nullptr, nullptr, 0, 0, q, nq, d.norm, L.attn_norm_w,
                        L.attn_norm_b, d.eps, rope_in_attn ? kvtmp : slot, rope_in_attn ? nkv : (int)L.kv_bstride, nq, stream, L.s_qkv, rc_row, rs_row, dh,
@@ -320,6 +332,8 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
       a.rope_cos = d.cos; a.rope_sin = d.sin; a.rope_rows = d.rope_rows; a.rope_mode = d.rope_mode; a.rope_pos = offset;
       rc = mi355_flash_attention(&a, stream);
       if (rc) return rc;
+    } else if (attn_in_oproj) {
+      // short context, one sequence: the attention row is recomputed by every workgroup of the o-proj GEMV as its prologue (mi355_gemv_args.attn_*)
     } else {
     if (!rope_in_gemv && (L.q_norm || d.cos)) {
       mi355_head_rope_args r;
@@ -336,7 +350,17 @@ extern "C" int mi355_stack_decode_step(const mi355_stack_desc* dp, float* x, int
                    d.attn_split_cnt, d.k_start, d.kv_dtype);
     if (rc) return rc;
     }
-    rc = gemv_call(att, nq, B, nq, L.wo, D, d.wdtype, L.bo, MI355_ACT_NONE, L.ls1, x, D, 0, x, D, 0, nullptr, nullptr, 0.f, nullptr, 0, 0, stream, L.s_o);
+    if (attn_in_oproj) {
+      mi355_gemv_args g;
+      memset(&g, 0, sizeof(g));
+      g.x = q; g.ldx = nq; g.M = 1; g.K = nq; g.w = L.wo; g.ldw = nq; g.wdtype = d.wdtype; g.N = D; g.bias = L.bo; g.post_act = MI355_ACT_NONE; g.colscale = L.ls1;
+      g.res = x; g.ldr = D; g.out_scale = 1.f; g.y = x; g.ldy = D; g.wscale = L.s_o; g.w_policy = t_w_policy;
+      g.attn_k = L.kv; g.attn_v = vbase; g.attn_ld = nkv; g.attn_Tk = offset + 1; g.attn_heads = H; g.attn_kv_heads = G; g.attn_dh = dh; g.attn_scale = scale;
+      g.attn_kv_dtype = d.kv_dtype;
+      rc = mi355_gemv(&g, stream);
+    } else {
+      rc = gemv_call(att, nq, B, nq, L.wo, D, d.wdtype, L.bo, MI355_ACT_NONE, L.ls1, x, D, 0, x, D, 0, nullptr, nullptr, 0.f, nullptr, 0, 0, stream, L.s_o);
+    }
     if (rc) return rc;
     // ---- cross-attention (Whisper decoder): K | V precomputed once per window
     if (L.cross_k) {

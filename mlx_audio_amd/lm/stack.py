@@ -206,14 +206,14 @@ def linear_rows(x: torch.Tensor, l: Lin, y: torch.Tensor, *, post_act: int = ACT
 
 def linear(x: torch.Tensor, l: Lin, y: torch.Tensor, *, post_act: int = ACT_NONE, res: Optional[torch.Tensor] = None,
            colscale: Optional[torch.Tensor] = None, glu: bool = False, precision: int = 2, norm: Optional[tuple] = None,
-           y2: Optional[torch.Tensor] = None):
+           y2: Optional[torch.Tensor] = None, w_policy: int = 0):
     """y = act(norm(x) W^T + b) * colscale + res on [B, L, C] views; 1-row-per-sequence inputs with B <= 8 take the GEMV
     (``norm`` / ``y2`` -- fused input normalisation and split destination -- exist on that path only)."""
     if is_decode(x, l) and x.shape[0] >= min(ROWS_MIN, 9) and ROWS_PIPE and l.rm.k % 64 == 0 and not (glu and (l.rm.n % 16)):
         return linear_rows(x, l, y, post_act=post_act, res=res, colscale=colscale, glu=glu, norm=norm, y2=y2)
     if is_decode(x, l):
         ops.gemv(x[:, 0, :], l.rm, y[:, 0, :], post_act=post_act, res=None if res is None else res[:, 0, :], colscale=colscale, glu=glu,
-                 norm=norm, y2=None if y2 is None else y2[:, 0, :])
+                 norm=norm, y2=None if y2 is None else y2[:, 0, :], w_policy=w_policy)
     else:
         assert not glu and norm is None and y2 is None
         ops.conv_gemm(x, l.pc, y, post_act=post_act, res=res, colscale=colscale, precision=precision)
@@ -335,6 +335,7 @@ class TransformerStack:
         d.k_start = p(k_start)
         d.slot_lens_k = p(slot_lens_k)
         d.kv_dtype = ops.KV_DTYPES[cache[0].kv.dtype]
+        d.w_policy = int(getattr(self, "w_policy", 0))   # 1: the stack's weight images stream past the caches (non-temporal loads) in one-sequence steps
         d.layers = ctypes.cast(arr, ctypes.c_void_p)
         sws, scnt = ops.attn_split_workspace(self.device, 8 * c.n_heads, c.head_dim)  # key-split decode attention (long key ranges)
         d.attn_split_ws, d.attn_split_cnt = sws.data_ptr(), scnt.data_ptr()

@@ -197,7 +197,7 @@ def pack_rowmajor_fp8(w: torch.Tensor, bias: Optional[torch.Tensor], device) -> 
 def gemv(x: torch.Tensor, rw: RowMajor16, y: torch.Tensor, *, post_act: int = ACT_NONE, post_slope: float = 0.0,
          res: Optional[torch.Tensor] = None, colscale: Optional[torch.Tensor] = None, out_scale: float = 1.0, glu: bool = False,
          use_bias: bool = True, norm: Optional[tuple] = None, y2: Optional[torch.Tensor] = None, rope: Optional[tuple] = None,
-         x_ids: Optional[torch.Tensor] = None, x_id_offset: int = 0):
+         x_ids: Optional[torch.Tensor] = None, x_id_offset: int = 0, w_policy: int = 0):
     """y[m, :] = epilogue(norm(x[m, :]) @ W^T) for 1..8 rows (any weight image) or 9..64 rows (16-bit images, K % 64 == 0); x / y / res are 2-D fp32 views with unit inner stride.
     ``norm`` = (mode, weight, bias, eps) with mode "layer" | "rms" fuses the input normalisation; ``y2``: columns >= y.shape[1] go there."""
     assert x.dim() == 2 and y.dim() == 2 and x.stride(1) == 1 and y.stride(1) == 1 and x.dtype == torch.float32 and y.dtype == torch.float32
@@ -206,7 +206,7 @@ def gemv(x: torch.Tensor, rw: RowMajor16, y: torch.Tensor, *, post_act: int = AC
     assert x.shape[1] == rw.k and y.shape[0] == M and y.shape[1] == n_y, (x.shape, y.shape, rw.n, rw.k)
     kw = dict(x=_ptr(x), ldx=x.stride(0), M=M, K=rw.k, w=_ptr(rw.w), ldw=rw.w.stride(0), wdtype=rw.wdtype, wscale=_ptr(rw.scale), N=rw.n,
               bias=_ptr(rw.bias) if use_bias else None, post_act=post_act, post_slope=post_slope, colscale=_ptr(colscale),
-              out_scale=out_scale, glu=int(glu), y=_ptr(y), ldy=y.stride(0))
+              out_scale=out_scale, glu=int(glu), y=_ptr(y), ldy=y.stride(0), w_policy=int(w_policy))
     if res is not None:
         assert res.dim() == 2 and res.stride(1) == 1
         kw.update(res=_ptr(res), ldr=res.stride(0))

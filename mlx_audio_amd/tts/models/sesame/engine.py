@@ -73,10 +73,14 @@ class CSMEngine:
         self.device = torch.device(device)
         self.precision = precision
         self.fuse_embed = True  # one sequence: the depth decoder's input embedding lookup runs inside the projection GEMV (False: embed_sum + GEMV)
+        # Cache policy of the weight streams in one-sequence steps (mi355_gemv_args.w_policy): the 2.4 GB backbone and the 32 heads (each read once per
+        # frame) stream past the caches; the 220 MB depth decoder runs 31 times per frame and keeps the default policy.  set_stream_policy() applies it.
+        self.head_policy = 1
         dev = self.device
         w = {k: v.detach().to(torch.bfloat16).to(torch.float32).cpu() for k, v in weights.items()}
         self.backbone = TransformerStack(w, cfg.backbone, device=dev, precision=precision, prefix="backbone.")
         self.decoder = TransformerStack(w, cfg.decoder, device=dev, precision=precision, prefix="decoder.")
+        self.backbone.w_policy, self.decoder.w_policy = 1, 0   # measured: 5.35 -> 5.10 ms per frame (profiles/r4_bench_csm_*_call6.json); nt on the decoder too: slower
         self.projection = make_lin(w["projection.weight"], None, dev)
         self.c0_head = make_lin(w["codebook0_head.weight"], None, dev)
         self.heads = [make_lin(w["audio_head"][i].t().contiguous(), None, dev) for i in range(cfg.audio_num_codebooks - 1)]
@@ -86,6 +90,11 @@ class CSMEngine:
         self.slot_offs = torch.tensor([i * cfg.audio_vocab_size for i in range(nb)] + [nb * cfg.audio_vocab_size], dtype=torch.int32, device=dev)
         self.backbone_cache = self.backbone.make_cache()
         self.decoder_cache = self.decoder.make_cache()
+
+    def set_stream_policy(self, backbone: int = 1, heads: int = 1, decoder: int = 0):
+        self.backbone.w_policy, self.decoder.w_policy, self.head_policy = int(backbone), int(decoder), int(heads)
+        for st in (self.backbone, self.decoder):
+            st._native = None   # descriptors are rebuilt with the new policy
 
     def reset_caches(self):
         for c in self.backbone_cache:
@@ -98,7 +107,7 @@ class CSMEngine:
         B = h_last.shape[0]
         V = head.rm.n
         out = self._f(B, 1, ops.round_up(V, 4))
-        linear(h_last, head, out[:, :, :V], precision=self.precision, norm=norm)
+        linear(h_last, head, out[:, :, :V], precision=self.precision, norm=norm, w_policy=self.head_policy)
         return out[:, 0, :]
 
     def generate_frame(self, tokens: torch.Tensor, tokens_mask: torch.Tensor, *, temperature: float = 0.9, top_k: int = 50,
@@ -163,7 +172,7 @@ class CSMEngine:
                 ops.embed_sum(self.table, sample[:, i - 1:i].unsqueeze(1), cur, slot_offset=self.slot_offs[i - 1:i])
             p = self._f(B, cur.shape[1] if cur is not None else 1, Dd)
             if cur is None:  # one sequence: embedding lookup of the code just sampled fused into the projection GEMV (mi355_gemv_args.x_ids)
-                ops.gemv(self.table, self.projection.rm, p[:, 0, :], x_ids=sample[0, i - 1:i], x_id_offset=(i - 1) * V)
+                ops.gemv(self.table, self.projection.rm, p[:, 0, :], x_ids=sample[0, i - 1:i], x_id_offset=(i - 1) * V)   # (4 MB, re-read 31 x per frame: default policy)
             else:
                 linear(cur, self.projection, p, precision=self.precision)
             if p.shape[1] == 1 and B <= self.decoder.max_decode_rows and self.decoder.native_decode:

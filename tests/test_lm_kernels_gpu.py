@@ -398,3 +398,37 @@ def test_stack_real_widths_prefill_and_decode(ops, name, B):
             eng.rows_pipe = True
         torch.cuda.synchronize()
         assert rel_err(o, e) < 2e-4, rel_err(o, e)
+
+
+@pytest.mark.parametrize("H,G,dh,Tk,kvd,nt", [(8, 2, 128, 1, torch.float32, 0), (8, 2, 128, 17, torch.float32, 1), (8, 2, 128, 32, torch.bfloat16, 0),
+                                                (32, 8, 64, 64, torch.float32, 0), (32, 8, 64, 33, torch.float16, 1), (4, 4, 64, 5, torch.float32, 0)])
+def test_gemv_attention_prologue(ops, H, G, dh, Tk, kvd, nt):
+    """mi355_gemv_args.attn_*: the o-proj GEMV of a one-sequence decode step with the step's attention as its prologue (short contexts: CSM's depth
+    decoder) against softmax(q K^T / sqrt(dh)) V followed by the projection in float64 -- and both weight-stream policies (w_policy 0 / 1)."""
+    from mlx_audio_amd import _lib
+
+    g = torch.Generator().manual_seed(H * 1000 + Tk)
+    nq, nkv, D = H * dh, 2 * G * dh, 1024
+    q = torch.randn(1, nq, generator=g)
+    kv = torch.randn(80, nkv, generator=g).to(kvd)            # cache rows: k columns, then v columns
+    w = (torch.randn(D, nq, generator=g) / nq ** 0.5).bfloat16().float()
+    bias = torch.randn(D, generator=g) * 0.1
+    res = torch.randn(1, D, generator=g)
+    rw = ops.pack_rowmajor16(w, bias, DEV)
+    kvf = kv.float().double()
+    k, v = kvf[:Tk, : G * dh].view(Tk, G, dh), kvf[:Tk, G * dh:].view(Tk, G, dh)
+    qh = q.double().view(H, dh)
+    rep = H // G
+    att = torch.empty(H, dh, dtype=torch.float64)
+    for h in range(H):
+        p = torch.softmax((k[:, h // rep, :] @ qh[h]) / dh ** 0.5, dim=0)
+        att[h] = p @ v[:, h // rep, :]
+    want = att.view(1, nq) @ w.double().t() + bias.double() + res.double()
+    qd, kvdv, y = q.to(DEV), kv.to(DEV), res.to(DEV).clone()
+    _lib.call_struct("mi355_gemv", "mi355_gemv_args", ops._stream(), x=qd.data_ptr(), ldx=nq, M=1, K=nq, w=rw.w.data_ptr(), ldw=nq, wdtype=rw.wdtype, N=D,
+                     bias=rw.bias.data_ptr(), res=y.data_ptr(), ldr=D, out_scale=1.0, y=y.data_ptr(), ldy=D, w_policy=nt,
+                     attn_k=kvdv.data_ptr(), attn_v=kvdv.data_ptr() + G * dh * kv.element_size(), attn_ld=nkv, attn_Tk=Tk, attn_heads=H, attn_kv_heads=G,
+                     attn_dh=dh, attn_scale=1.0 / dh ** 0.5, attn_kv_dtype=ops.KV_DTYPES[kvd])
+    torch.cuda.synchronize()
+    err = float((y.cpu().double() - want).abs().max() / want.abs().max())
+    assert err < 2e-6, err

@@ -26,6 +26,7 @@ def main(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="accepted for symmetry with the other bench lines")
     ap.add_argument("--weights", choices=["bf16", "fp8"], default="bf16")
+    ap.add_argument("--nt", default="", help="weight-stream cache policy: comma list of backbone, heads, decoder that load non-temporally (default: the engine's)")
     ap.add_argument("--kv16", action="store_true", help="bf16 KV caches (the reference's cache dtype) instead of float32")
     ap.add_argument("--gather", choices=["rank0", "none"], default="rank0", help="multi-GPU runs: code frames back to rank 0, or kept on the rank that made them")
     args = ap.parse_args(argv)
@@ -47,6 +48,9 @@ def main(argv=None):
     kvd = torch.bfloat16 if args.kv16 else torch.float32
     eng.backbone = U.build_deep_stack(cfg.backbone, dev, seed=1, weight_format=args.weights, kv_dtype=kvd)
     eng.decoder = U.build_deep_stack(cfg.decoder, dev, seed=2, weight_format=args.weights, kv_dtype=kvd)
+    if args.nt:
+        nts = set(args.nt.split(","))
+        eng.set_stream_policy(backbone=int("backbone" in nts), heads=int("heads" in nts), decoder=int("decoder" in nts))
     eng.backbone_cache = eng.backbone.make_cache()
     eng.decoder_cache = eng.decoder.make_cache()
     g = torch.Generator().manual_seed(0)
@@ -120,7 +124,7 @@ def main(argv=None):
                   "bf16 weights x fp32 activations (GEMV fp32 FMA on bf16 weights)") + ("; 5..8 sequences: v_mfma_f32_16x16x32 on the weights' own type" if B >= 5 else ""),
         "data": "synthetic",
         "config": {"workload": "CSM-1B: prompt %d tokens, %d frames x (backbone step + 31 depth-decoder steps, sampling on device), Mimi decode (32 codebooks)" % (S, n),
-                   "sequences": B, "sequences_on_rank0": len(ch.my_items()), "parallelism": f"sequence-dp{D_.world}", "gather": args.gather, "frames": n, "temperature": 0.0, "weights": args.weights, "kv_cache": "bf16" if args.kv16 else "fp32"},
+                   "sequences": B, "sequences_on_rank0": len(ch.my_items()), "parallelism": f"sequence-dp{D_.world}", "gather": args.gather, "frames": n, "temperature": 0.0, "weights": args.weights, "nt": args.nt or "engine default", "kv_cache": "bf16" if args.kv16 else "fp32"},
         "step_runner": U.step_runner(), "split_ms": {"frame_loop": lm_ms, "mimi_decode": dec_ms}, "ms_per_frame": frame_ms, "frames_per_s": B * n / (lm_ms * 1e-3),
         "mimi_samples_per_s": B * n * 1920 / (dec_ms * 1e-3),
         "roofline": {"bound": "hbm", "kernel": "gemv_kernel (all decode-step Linear layers of one frame)", "achieved": wbytes / (frame_ms * 1e-3) / 1e9, "peak": 8000.0,

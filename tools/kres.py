@@ -21,5 +21,5 @@ for ln in p.stderr.splitlines():
 print("%-5s %-5s %-5s %-8s %-7s %-7s %-6s %s" % ("VGPR", "AGPR", "SGPR", "scratch", "vspill", "sspill", "occ", "kernel"))
 for r in rows:
     print("%-5s %-5s %-5s %-8s %-7s %-7s %-6s %s" % (r.get("VGPRs"), r.get("AGPRs"), r.get("TotalSGPRs"), r.get("ScratchSize [bytes/lane]"), r.get("VGPRs Spill"), r.get("SGPRs Spill"),
-                                               r.get("Occupancy [waves/SIMD]"), re.sub(r"\(.*", "", r["name"])[:150]))
+                                               r.get("Occupancy [waves/SIMD]"), r["name"].replace("(anonymous namespace)::", "")[:110]))
 sys.exit(p.returncode)
