@@ -222,7 +222,7 @@ class MimiDecoder:
             tabs = []
             for i in range(n):
                 c = f"{pfx}.vq.layers.{i}.codebook"
-                tabs.append(w[c + ".embedding_sum"] / torch.clamp(w[c + ".cluster_usage"], min=1e-5)[:, None])  # quantization.py:26-30
+                tabs.append(raw[c + ".embedding_sum"] / torch.clamp(raw[c + ".cluster_usage"], min=1e-5)[:, None])  # quantization.py:26-30 (checkpoint values)
             table = torch.cat(tabs, 0).contiguous().to(dev)
             offs = torch.tensor([i * cfg.quantizer_bins for i in range(n)], dtype=torch.int32, device=dev)
             self.rvq.append((table, offs, conv(pfx + ".output_proj"), n))
@@ -303,7 +303,11 @@ class MimiEncoder:
         self.device = torch.device(device)
         self.precision = precision
         dev = self.device
-        w = {k: v.detach().to(torch.float32).cpu().to(torch.bfloat16).to(torch.float32) for k, v in weights.items() if v.is_floating_point()}
+        # conv / linear weights enter bf16 MFMA images; the RVQ codebook statistics (embedding_sum, cluster_usage) do NOT: EuclideanCodebook.encode
+        # (quantization.py:26-47) works in the checkpoint dtype -- float32 for the kyutai / Qwen3 tokenizer checkpoints -- and a 2^-9 rounding of the
+        # codewords flips arg-min decisions (the rvq kernel takes float32 tables anyway)
+        w = {k: (v.detach().to(torch.float32).cpu() if ".codebook." in k else v.detach().to(torch.float32).cpu().to(torch.bfloat16).to(torch.float32))
+             for k, v in weights.items() if v.is_floating_point()}
 
         def conv(name):
             return ops.pack_conv(w[name + ".weight"], w.get(name + ".bias"), dev)

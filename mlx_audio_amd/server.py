@@ -81,34 +81,77 @@ def create_app(models: Dict[str, Any], *, max_batch_size: int = 8, broker: Optio
     def tts_speech(payload: SpeechRequest):
         if payload.model not in models:
             raise HTTPException(status_code=404, detail=f"Model '{payload.model}' is not loaded")
-        fmt = (payload.response_format or "wav").lower()
-        if fmt not in ("wav", "pcm"):
-            raise HTTPException(status_code=400, detail=f"response_format '{fmt}' is not built here (wav | pcm); the reference encodes it through its audio writers")
+        asked = (payload.response_format or "wav").lower()
+        # the schema keeps the reference's default "mp3" (server.py:959 of the reference), but no compressed encoder is built here: a request
+        # for mp3 / opus / aac / flac -- including every OpenAI-style call that simply omits response_format -- is answered as WAV, with the substitution
+        # named in a response header, instead of failing
+        compressed = ("mp3", "opus", "aac", "flac")
+        if asked not in ("wav", "pcm") + compressed:
+            raise HTTPException(status_code=400, detail=f"unknown response_format '{asked}' (wav | pcm; {' | '.join(compressed)} are served as wav)")
+        fmt = "wav" if asked in compressed else asked
         body = payload.model_dump(exclude={"model", "input", "response_format"}, exclude_none=True)
         body["text"] = payload.input
         handle = brk.submit(endpoint_kind="tts", model_name=payload.model, payload=body, normalized_kwargs=body, stream=payload.stream)
         sr = int(getattr(models[payload.model], "sample_rate", 24000))
 
-        def chunks():
-            first = True
-            while True:
-                chunk = handle.result_queue.get()
-                if chunk.kind == "done":
-                    break
-                if chunk.kind == "error":
-                    raise RuntimeError(str(chunk.error))
-                audio = getattr(chunk.payload, "audio", chunk.payload)
-                if audio is None:
-                    continue
-                data = _pcm16(audio)
-                if first and fmt == "wav":
-                    yield _wav_header(sr)
-                first = False
-                yield data
-            if first and fmt == "wav":
-                yield _wav_header(sr, 0)
+        headers = {"Content-Disposition": f"attachment; filename=speech.{fmt}"}
+        if fmt != asked:
+            headers["X-Response-Format-Fallback"] = f"{asked} -> wav (no {asked} encoder in this build)"
 
-        return StreamingResponse(chunks(), media_type=f"audio/{fmt}", headers={"Content-Disposition": f"attachment; filename=speech.{fmt}"})
+        def cancel():
+            c = getattr(handle, "cancel", None)
+            if callable(c):
+                c()
+
+        if not payload.stream:
+            # nothing has been sent yet: collect the audio first, so that a failure is an HTTP 5xx and not a 200 with a truncated body
+            parts = []
+            try:
+                while True:
+                    chunk = handle.result_queue.get()
+                    if chunk.kind == "done":
+                        break
+                    if chunk.kind == "error":
+                        raise HTTPException(status_code=500, detail=f"synthesis failed: {chunk.error}")
+                    audio = getattr(chunk.payload, "audio", chunk.payload)
+                    if audio is not None:
+                        parts.append(_pcm16(audio))
+            except BaseException:
+                cancel()
+                raise
+            body_bytes = b"".join(parts)
+            if fmt == "wav":
+                body_bytes = _wav_header(sr, len(body_bytes)) + body_bytes
+            from fastapi.responses import Response
+
+            return Response(content=body_bytes, media_type=f"audio/{fmt}", headers=headers)
+
+        def chunks():
+            first, finished = True, False
+            try:
+                while True:
+                    chunk = handle.result_queue.get()
+                    if chunk.kind == "done":
+                        finished = True
+                        break
+                    if chunk.kind == "error":
+                        finished = True
+                        raise RuntimeError(str(chunk.error))   # bytes may already be out: the connection is dropped mid-body, the slot is released below
+                    audio = getattr(chunk.payload, "audio", chunk.payload)
+                    if audio is None:
+                        continue
+                    data = _pcm16(audio)
+                    if first and fmt == "wav":
+                        yield _wav_header(sr)
+                    first = False
+                    yield data
+                if first and fmt == "wav":
+                    yield _wav_header(sr, 0)
+            finally:
+                if not finished:   # client went away (generator closed) or the stream broke: do not keep the batch slot busy
+                    cancel()
+
+        return StreamingResponse(chunks(), media_type=f"audio/{fmt}", headers=headers)
 
     return app
 

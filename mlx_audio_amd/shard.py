@@ -143,6 +143,15 @@ class ShardChannel:
         self.collectives += 1
         return [int(v) for v in dev_vec[: self.n_items].cpu()]
 
+    def any_failed(self, failed: bool) -> bool:
+        """Did the step fail on ANY rank?  One int32 all_reduce (a rank that raised keeps taking part in the protocol until every rank knows)."""
+        if not self.dist:
+            return bool(failed)
+        flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=self.device)
+        self.dist.all_reduce(flag)
+        self.collectives += 1
+        return bool(int(flag.cpu()[0]) > 0)
+
     # ------------------------------------------------------------------ re-balance on the real costs
     def rebalance(self, costs: Sequence[int], pack: Callable[[int], torch.Tensor], blob_size: Callable[[int], int],
                   tolerance: float = 0.05) -> Tuple[List[List[int]], dict]:
@@ -259,6 +268,14 @@ def sharded_decode(ch: ShardChannel, requests: Optional[Sequence[torch.Tensor]],
     return ch.gather([a.reshape(-1) for a in local], dtype=dtype)
 
 
+class ShardStepFailed(RuntimeError):
+    """A sharded step failed on some rank.  Raised on EVERY rank at the same point of the protocol (after the collective that spread the news), so the
+    group's collectives stay matched and the next step can run; ``__cause__`` holds the local exception on the rank(s) that failed."""
+
+
+_FAILED_COUNT = -(1 << 28)   # a rank whose token-rate half raised reports this "frame count" for its items: the sum stays negative on every rank
+
+
 def kokoro_step(ch: ShardChannel, engine, requests: Optional[Sequence[torch.Tensor]], ref_s_of: Callable,
                 samples_per_frame: int, forced_durations_of: Optional[Callable[[int], torch.Tensor]] = None, tolerance: float = 0.05,
                 wire_dtype: Optional[torch.dtype] = None, back_kwargs: Optional[Callable[[List[int]], dict]] = None, speed: Optional[float] = None):
@@ -272,7 +289,9 @@ def kokoro_step(ch: ShardChannel, engine, requests: Optional[Sequence[torch.Tens
     block, lens = ch.scatter_requests(requests)
     first = ch.my_items()
     st = None
+    err: Optional[BaseException] = None
     if first:
+      try:   # a failure on this rank must not leave the others waiting in the next collective: it travels with the frame counts
         ids = ch.my_ids(block, lens)
         ref = ref_s_of.rows(first, lens) if hasattr(ref_s_of, "rows") else torch.cat([ref_s_of(i, lens[i]) for i in first], 0)
         kw = {}
@@ -285,7 +304,11 @@ def kokoro_step(ch: ShardChannel, engine, requests: Optional[Sequence[torch.Tens
         if speed is not None:
             kw["speed"] = float(speed)
         st = engine.front(ids, ref, forced_durations=fd, **kw)
-    frames = ch.share_counts(st.frames if st else [])
+      except Exception as e:  # noqa: BLE001
+        err, st = e, None
+    frames = ch.share_counts(st.frames if st else [_FAILED_COUNT] * len(first if err else []))
+    if any(f < 0 for f in frames):
+        raise ShardStepFailed("the token-rate half of a sharded step failed on rank%s" % (" %d: %r" % (ch.rank, err) if err else " (another rank)")) from err
     width = engine.hid + engine.sty
     style = 2 * engine.sty
     pos = {i: k for k, i in enumerate(first)}
@@ -293,6 +316,7 @@ def kokoro_step(ch: ShardChannel, engine, requests: Optional[Sequence[torch.Tens
     mine = new[ch.rank]
     outs: List[torch.Tensor] = []
     if mine:
+      try:
         if mine == first:
             merged = st  # nothing moved: the state goes on as it is (its padded device tensors included)
         else:
@@ -308,6 +332,10 @@ def kokoro_step(ch: ShardChannel, engine, requests: Optional[Sequence[torch.Tens
             perm = sorted(range(len(order)), key=lambda k: order[k])  # ascending item order == my_items() order
             merged = merged.select(perm)
         outs, _ = engine.back(merged, **(back_kwargs(mine) if back_kwargs else {}))
+      except Exception as e:  # noqa: BLE001
+        err, outs = e, []
+    if ch.any_failed(err is not None):
+        raise ShardStepFailed("the frame-rate half of a sharded step failed on rank%s" % (" %d: %r" % (ch.rank, err) if err else " (another rank)")) from err
     counts = [f * samples_per_frame for f in frames]
     return ch.gather(outs, counts=counts, wire_dtype=wire_dtype)
 
@@ -389,8 +417,21 @@ class ShardedKokoro:
         if kw:
             raise TypeError(f"ShardedKokoro.forward: unsupported arguments {sorted(kw)} (the sharded step takes ids, style rows and speed)")
         n = len(input_ids)
+        # everything that can be checked is checked BEFORE the header goes out: once the workers have left their header wait they are inside the
+        # step's collectives, and a rank-0 exception in front of those would strand them there
+        ch = self.ch
+        if n < 1 or n > ch.max_items:
+            raise ValueError(f"ShardedKokoro.forward: {n} requests (the channel carries 1..{ch.max_items})")
+        too_long = [int(t.numel()) for t in input_ids if int(t.numel()) > ch.max_tokens or int(t.numel()) < 1]
+        if too_long:
+            raise ValueError(f"ShardedKokoro.forward: request lengths {too_long} outside 1..{ch.max_tokens} tokens")
+        width = 2 * self.engine.sty
+        if ref_s.numel() != n * width:
+            raise ValueError(f"ShardedKokoro.forward: ref_s must hold {n} style rows of {width} values, got shape {tuple(ref_s.shape)}")
+        if not (speed > 0.0 and speed == speed and speed != float("inf")):
+            raise ValueError(f"ShardedKokoro.forward: speed must be positive and finite (got {speed})")
         self._header(self.CMD_RUN, n, speed)
-        outs = self._run(input_ids, ref_s.reshape(n, -1), n, float(speed))
+        outs = self._run(input_ids, ref_s.reshape(n, width), n, float(speed))   # ShardStepFailed: every rank left the step together; the group stays usable
         return outs, None
 
     def worker_loop(self) -> int:
@@ -400,7 +441,10 @@ class ShardedKokoro:
             cmd, n, speed = self._header()
             if cmd == self.CMD_STOP:
                 return self.steps
-            self._run(None, None, n, speed)
+            try:
+                self._run(None, None, n, speed)
+            except ShardStepFailed:
+                self.failed_steps = getattr(self, "failed_steps", 0) + 1   # reported to the caller on the submitting rank; this rank serves the next step
 
     def close(self) -> None:
         if self.ch.rank == self.ch.src:

@@ -222,8 +222,9 @@ class Qwen3Talker:
             ops.sample(logits, row[:, 0], V=V0, suppress_mask=self.suppress_mask, history=hist, hist_len=hist_len,
                        repetition_penalty=repetition_penalty, temperature=temperature, top_k=top_k, top_p=top_p,
                        gumbel=noise(None if gumbel0 is None else gumbel0[f], V0), done=finished, done_token=cfg.codec_eos_token_id)
-            if forced is not None:
-                row[:, 0] = torch.where(finished.bool(), torch.full_like(forced[:, f, 0], cfg.codec_eos_token_id), forced[:, f, 0])
+            if forced is not None:   # teacher forcing; a negative entry keeps the step's own selection (partial forcing: tests re-synchronise at knife edges)
+                row[:, 0] = torch.where(finished.bool(), torch.full_like(forced[:, f, 0], cfg.codec_eos_token_id),
+                                        torch.where(forced[:, f, 0] >= 0, forced[:, f, 0], row[:, 0]))
             tok = row[:, 0]
             newly = tok == cfg.codec_eos_token_id
             finished_at = torch.where(newly & (finished == 0), torch.full_like(finished_at, f), finished_at)
@@ -267,7 +268,7 @@ class Qwen3Talker:
                 ops.sample(lg, row[:, i + 1], V=Vc, temperature=temperature, top_k=top_k, top_p=top_p,
                            gumbel=noise(None if gumbel_cp is None else gumbel_cp[f][i], Vc))
                 if forced is not None:
-                    row[:, i + 1] = forced[:, f, i + 1]
+                    row[:, i + 1] = torch.where(forced[:, f, i + 1] >= 0, forced[:, f, i + 1], row[:, i + 1])
             # ---- next input: text embed (or tts_pad once the trailing text is exhausted) + sum of the 16 codec embeddings
             clamped = torch.clamp(trailing_idx, max=Tt - 1)
             text = trailing[ar, clamped]

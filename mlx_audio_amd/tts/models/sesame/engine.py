@@ -141,8 +141,9 @@ class CSMEngine:
             if trace is not None:
                 trace.append(logits[:, :V].clone())
             ops.sample(logits, sample[:, i], V=V, temperature=temperature, top_k=top_k, gumbel=noise(i))
-            if forced is not None:
-                sample[:, i] = forced[:, i].to(dev, torch.int32)
+            if forced is not None:   # teacher forcing; a negative entry keeps the step's own selection
+                fo = forced[:, i].to(dev, torch.int32)
+                sample[:, i] = torch.where(fo >= 0, fo, sample[:, i])
 
         draw(self._logits(last, self.c0_head), 0)
         cache = self.decoder_cache  # reset for every frame (sesame.py:385-387): offsets back to 0, buffers reused

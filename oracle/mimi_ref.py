@@ -90,7 +90,7 @@ class MimiDecoderRef:
     def __init__(self, weights: Dict[str, Tensor], cfg: MimiConfig, dtype=torch.float32, param_dtype=torch.bfloat16):
         self.cfg = cfg
         self.dtype = dtype
-        self.w = {k: v.to(param_dtype).to(dtype) for k, v in weights.items()}
+        self.w = {k: (v.to(dtype) if ".codebook." in k else v.to(param_dtype).to(dtype)) for k, v in weights.items()}   # codebook statistics: never cast (quantization.py:26-30)
         self.stack = StackRef(canonical_stack_weights(weights, "decoder_transformer.transformer.", cfg), mimi_stack_config(cfg), dtype, param_dtype)
         self.total_upsample = cfg.upsample_stride
         for r in cfg.ratios:
@@ -163,7 +163,8 @@ class MimiEncoderRef:
     def __init__(self, weights: Dict[str, Tensor], cfg: MimiConfig, dtype=torch.float32, param_dtype=torch.bfloat16):
         self.cfg = cfg
         self.dtype = dtype
-        self.w = {k: v.to(param_dtype).to(dtype) for k, v in weights.items()}
+        # (codebook statistics stay in the checkpoint's own values: quantization.py:26-47 never casts them)
+        self.w = {k: (v.to(dtype) if ".codebook." in k else v.to(param_dtype).to(dtype)) for k, v in weights.items()}
         self.stack = StackRef(canonical_stack_weights(weights, "encoder_transformer.transformer.", cfg), mimi_stack_config(cfg), dtype, param_dtype)
 
     def _sconv(self, x: Tensor, name: str, stride: int = 1, dil: int = 1, elu: bool = False, pad_mode: str = "constant") -> Tensor:

@@ -103,14 +103,26 @@ def test_qwen3_frame_loop_teacher_forced_tall_batch(talker):
 def test_qwen3_frame_loop_free_running_greedy(talker):
     frames = 5
     exp = talker["ref"].generate(talker["pre"], talker["trail"], talker["pad"], frames, temperature=0.0, record=True)
-    got = talker["eng"].generate(talker["pre"], talker["trail"], talker["pad"], frames, temperature=0.0, poll=2)
+    ec = exp["codes"]
+    nf, G = ec.shape[1], ec.shape[2]
+    # the oracle's token is forced at its knife-edge decisions (top-2 gap < _margin.THR) and nowhere else: the engine free-runs between them on a
+    # re-synchronised context, so EVERY other decision of every sequence is compared (tests/_margin.py: walk_resync)
+    margins = torch.tensor([[[float(_gap(exp["trace"][f][i][b])) for i in range(G)] for f in range(nf)] for b in range(ec.shape[0])])
+    forced = torch.where(margins < _margin.THR, ec[:, :nf], torch.full_like(ec[:, :nf], -1))
+    got = talker["eng"].generate(talker["pre"], talker["trail"], talker["pad"], nf, temperature=0.0, forced_codes=forced)
     torch.cuda.synchronize()
-    ec, gc = exp["codes"], got["codes"].cpu()
-    nf = min(ec.shape[1], gc.shape[1])
+    gc = got["codes"].cpu()
+    assert gc.shape[1] == nf
     for b in range(ec.shape[0]):
-        # decisions in generation order; a sequence is compared up to its first knife-edge (top-2 gap < 1e-2) decision (tests/_margin.py)
-        margins = [float(_gap(exp["trace"][f][i][b])) for f in range(nf) for i in range(ec.shape[2])]
-        _margin.walk("qwen3_tts", gc[b, :nf].flatten().tolist(), ec[b, :nf].flatten().tolist(), margins, where=("talker", b))
+        _margin.walk_resync("qwen3_tts", gc[b].flatten().tolist(), ec[b].flatten().tolist(), margins[b].flatten().tolist(), where=("talker", b))
+    # ... and the unforced loop (the EOS poll and the stop rule) reproduces the oracle wherever no knife edge precedes
+    free = talker["eng"].generate(talker["pre"], talker["trail"], talker["pad"], frames, temperature=0.0, poll=2)
+    fc = free["codes"].cpu()
+    for b in range(ec.shape[0]):
+        n = min(nf, fc.shape[1]) * G
+        ke = _margin.knife_edges(margins[b].flatten().tolist())
+        stop = ke[0] if ke else n
+        assert fc[b].flatten().tolist()[:min(stop, n)] == ec[b].flatten().tolist()[:min(stop, n)]
 
 
 @pytest.fixture(scope="module")
@@ -152,13 +164,21 @@ def test_csm_frames_teacher_forced(csm):
 
 def test_csm_free_running_greedy_and_eos(csm):
     exp = csm["ref"].generate(csm["toks"], csm["mask"], 3, temperature=0.0, record=True)
-    got = csm["eng"].generate(csm["toks"], csm["mask"], 3, temperature=0.0, poll=1)
+    ef = exp["frames"]
+    margins = torch.tensor([[[float(_gap(exp["trace"][f][i][b])) for i in range(ef.shape[2])] for f in range(ef.shape[1])] for b in range(ef.shape[0])])
+    forced = torch.where(margins < _margin.THR, ef, torch.full_like(ef, -1))   # the oracle's token at its knife edges only (tests/_margin.py)
+    got = csm["eng"].generate(csm["toks"], csm["mask"], ef.shape[1], temperature=0.0, forced=forced)
     torch.cuda.synchronize()
-    ef, gf = exp["frames"], got["frames"].cpu()
+    gf = got["frames"].cpu()
     assert gf.shape == ef.shape
     for b in range(ef.shape[0]):
-        margins = [float(_gap(exp["trace"][f][i][b])) for f in range(ef.shape[1]) for i in range(ef.shape[2])]
-        _margin.walk("csm", gf[b].flatten().tolist(), ef[b].flatten().tolist(), margins, where=("csm", b))
+        _margin.walk_resync("csm", gf[b].flatten().tolist(), ef[b].flatten().tolist(), margins[b].flatten().tolist(), where=("csm", b))
+    free = csm["eng"].generate(csm["toks"], csm["mask"], 3, temperature=0.0, poll=1)["frames"].cpu()   # the unforced loop, up to the first knife edge
+    for b in range(ef.shape[0]):
+        ke = _margin.knife_edges(margins[b].flatten().tolist())
+        n = min(free.shape[1], ef.shape[1]) * ef.shape[2]
+        stop = min(ke[0] if ke else n, n)
+        assert free[b].flatten().tolist()[:stop] == ef[b].flatten().tolist()[:stop]
     # EOS: an all-zero frame stops the loop and is not returned (sesame.py:828)
     forced = torch.zeros(csm["B"], 2, csm["cfg"].audio_num_codebooks, dtype=torch.long)
     forced[:, 0] = 5

@@ -75,6 +75,13 @@ def test_mimi_202407_encode_shape_pin_and_stages():
 
     cfg = M.mimi_202407(32)
     w = {**M.make_mimi_decoder_weights(cfg, seed=0), **M.make_mimi_encoder_weights(cfg, seed=0)}
+    # float32 codebook statistics that are NOT bf16 values (real checkpoints: kyutai Mimi, the Qwen3 speech tokenizer): the encoder must build its
+    # tables from the checkpoint values -- rounding them to bf16 first moves codewords by 2^-9 and flips arg-min decisions (round-3 advisor finding)
+    gq = torch.Generator().manual_seed(99)
+    for k in list(w):
+        if ".codebook.embedding_sum" in k and k.startswith("quantizer."):
+            w[k] = (w[k].float() * (1.0 + 3e-3 * torch.randn(w[k].shape, generator=gq))).float()
+    assert any((w[k].float() != w[k].to(torch.bfloat16).float()).any() for k in w if ".codebook.embedding_sum" in k and k.startswith("quantizer."))
     both = M.Mimi(w, cfg, device=DEV)
     codes = both.encode(torch.zeros(1, 1, 120_000))
     torch.cuda.synchronize()

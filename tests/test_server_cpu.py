@@ -102,7 +102,34 @@ def test_speech_endpoint_serial_and_session_paths():
         assert {k: len(v) // 2 for k, v in out.items()} == {"aa": 100, "bbbb": 200, "cccccc": 300}
         # errors of the shell itself
         assert client.post("/v1/audio/speech", json={"model": "nope", "input": "x"}).status_code == 404
-        assert client.post("/v1/audio/speech", json={"model": "serial", "input": "x"}).status_code == 400          # default response_format mp3: not built
+        # the schema's default response_format is the reference's "mp3", for which no encoder is built: served as WAV, the substitution named in a header
+        r = client.post("/v1/audio/speech", json={"model": "serial", "input": "x"})
+        assert r.status_code == 200 and r.headers["content-type"].startswith("audio/wav") and r.headers["x-response-format-fallback"].startswith("mp3 -> wav")
+        assert r.content[:4] == b"RIFF" and struct.unpack("<I", r.content[40:44])[0] == len(r.content) - 44    # non-streaming: a complete header
+        assert client.post("/v1/audio/speech", json={"model": "serial", "input": "x", "response_format": "xyz"}).status_code == 400
         assert client.post("/v1/audio/speech", json={"model": "serial"}).status_code == 422                       # pydantic validation like the reference
+    finally:
+        app.state.broker.stop_and_join()
+
+
+class FailingModel(SerialModel):
+    def generate(self, text, **kw):
+        from types import SimpleNamespace
+
+        yield SimpleNamespace(audio=torch.full((100,), 0.25), samples=100, sample_rate=24000)
+        raise RuntimeError("vocoder fell over")
+
+
+def test_speech_endpoint_failures_are_5xx_when_nothing_was_sent():
+    """A synthesis error of a non-streaming request must be an HTTP error, not a 200 with a truncated body (round-3 advisor finding)."""
+    from mlx_audio_amd.server import create_app
+
+    app = create_app({"bad": FailingModel(), "good": SerialModel()}, max_batch_size=2)
+    client = TestClient(app, raise_server_exceptions=False)
+    try:
+        r = client.post("/v1/audio/speech", json={"model": "bad", "input": "hello", "response_format": "wav"})
+        assert r.status_code == 500 and "vocoder fell over" in r.text
+        r = client.post("/v1/audio/speech", json={"model": "good", "input": "hi", "response_format": "pcm"})   # the broker keeps serving
+        assert r.status_code == 200 and len(r.content) == 2 * 200
     finally:
         app.state.broker.stop_and_join()

@@ -120,9 +120,9 @@ def test_sharded_step_equals_single_process(world, n_utts):
     r = _run(world, n_utts)
     assert r["ok"]
     assert sorted(i for o in r["plan"] for i in o) == list(range(n_utts))
-    # per step: broadcast + all_reduce(frame counts) + all_to_all(waveforms); frames ~ 3 x tokens here, so nothing needs to move
+    # per step: broadcast + all_reduce(frame counts) + all_reduce(failure flag) + all_to_all(waveforms); frames ~ 3 x tokens here, so nothing needs to move
     assert r["plan"] == r["token_plan"]
-    assert r["collectives"] == 2 * 3
+    assert r["collectives"] == 2 * 4
 
 
 @pytest.mark.parametrize("world,n_utts", [(2, 9), (3, 11), (8, 19)])
@@ -133,7 +133,7 @@ def test_rebalance_on_real_frame_counts(world, n_utts):
     assert r["plan"] != r["token_plan"]                                   # utterances moved ...
     assert shard.makespan(frames, r["plan"]) < shard.makespan(frames, r["token_plan"])   # ... and the slowest rank got faster
     assert shard.makespan(frames, r["plan"]) <= 1.05 * shard.makespan(frames, shard.lpt_assign(frames, world)) + max(frames) * 0
-    assert r["collectives"] == 2 * 4                                      # one extra all_to_all per step, nothing else
+    assert r["collectives"] == 2 * 5                                      # one extra all_to_all per step, nothing else
 
 
 def test_fp16_on_the_wire():
@@ -277,3 +277,78 @@ def test_sharded_decode_ragged_integer_results(world, n_seq, gather):
     assert r["ok"] and r["items"] == list(range(n_seq))
     # broadcast + (rank0: all_reduce of the result lengths + all_to_all of the payload)
     assert r["collectives"] == (3 if gather == "rank0" else 1)
+
+
+# ---- a step that fails on one rank: every rank leaves it together and the group stays usable (round-3 advisor finding: a rank-0 exception between
+# two collectives used to strand the workers inside the step)
+class _FlakyEngine(FakeEngine):
+    def __init__(self, fail_front_on=None, fail_back_on=None):
+        super().__init__(False)
+        self.calls = 0
+        self.fail_front_on, self.fail_back_on = fail_front_on, fail_back_on
+
+    def front(self, *a, **k):
+        self.calls += 1
+        if self.fail_front_on == self.calls:
+            raise RuntimeError("front exploded")
+        return super().front(*a, **k)
+
+    def back(self, *a, **k):
+        if self.fail_back_on == self.calls:
+            raise RuntimeError("back exploded")
+        return super().back(*a, **k)
+
+
+def _failing_worker(rank, world, port, bad_rank, where, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        reqs = _make_requests(7, 5) if rank == 0 else None
+        ch = shard.ShardChannel("cpu", dist, max_items=32, max_tokens=64)
+        eng = _FlakyEngine(**({("fail_front_on" if where == "front" else "fail_back_on"): 2} if rank == bad_rank else {}))
+        results = []
+        for step in range(3):   # step 2 (the engine's second call) fails on bad_rank; steps 1 and 3 must be served normally
+            try:
+                out = shard.kokoro_step(ch, eng, reqs, _ref_s_of, SPF)
+                results.append("ok" if (rank != 0 or all(torch.equal(o, w) for o, w in zip(out, _single_process(reqs, False)))) else "wrong")
+            except shard.ShardStepFailed as e:
+                results.append("failed-local" if e.__cause__ is not None else "failed-remote")
+        q.put((rank, results))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bad_rank,where", [(0, "front"), (1, "front"), (1, "back"), (0, "back")])
+def test_failed_step_is_left_by_every_rank_and_the_group_survives(bad_rank, where):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, bad_rank, where, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0   # nobody hangs in a collective, nobody dies
+    got = dict(q.get() for _ in range(world))
+    for r in range(world):
+        assert got[r] == ["ok", "failed-local" if r == bad_rank else "failed-remote", "ok"], got
+
+
+def test_sharded_forward_validates_before_the_header():
+    """Everything checkable is refused BEFORE the CMD_RUN header: no collective has been issued when the exception leaves forward()."""
+    ch = shard.ShardChannel("cpu", None, max_items=4, max_tokens=16)
+    sk = shard.ShardedKokoro(FakeEngine(False), ch, SPF)
+    ok_ids = [torch.randint(1, 100, (5,)) for _ in range(2)]
+    style = torch.zeros(2, 2 * FakeEngine.sty)
+    for ids, ref, speed in (([torch.randint(1, 100, (5,)) for _ in range(5)], torch.zeros(5, 2 * FakeEngine.sty), 1.0),   # too many requests
+                            ([torch.randint(1, 100, (17,))], torch.zeros(1, 2 * FakeEngine.sty), 1.0),                      # too long
+                            (ok_ids, torch.zeros(3, 2 * FakeEngine.sty), 1.0),                                              # style rows != requests
+                            (ok_ids, style, 0.0), ([], torch.zeros(0, 2 * FakeEngine.sty), 1.0)):
+        before = ch.collectives
+        with pytest.raises(ValueError):
+            sk.forward(ids, ref, speed=speed)
+        assert ch.collectives == before and sk.steps == 0
+    outs, _ = sk.forward(ok_ids, style)
+    assert len(outs) == 2 and sk.steps == 1

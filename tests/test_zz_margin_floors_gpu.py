@@ -12,7 +12,9 @@ import _margin  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 # measured on MI355X (rounds 2-3): whisper 100 %, whisper_fixture 100 %, csm 100 %, qwen3_tts 81.5-100 %, mimi_encode 98.6 %
-FLOORS = {"whisper": 0.90, "whisper_fixture": 0.90, "csm": 0.90, "qwen3_tts": 0.70, "mimi_encode": 0.90}
+# round 4: threshold 1e-2 -> 1e-3 and re-synchronisation at the knife edges of the autoregressive engines (tests/_margin.py): what stays uncompared
+# there is the knife-edge decisions themselves
+FLOORS = {"whisper": 0.95, "whisper_fixture": 0.95, "csm": 0.95, "qwen3_tts": 0.95, "mimi_encode": 0.95}
 
 
 def test_margin_rule_coverage_floors():
