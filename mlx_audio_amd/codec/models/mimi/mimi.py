@@ -259,6 +259,78 @@ class MimiDecoder:
             q0 += n
         return out
 
+    # ------------------------------------------------------------------ incremental decode (carried state)
+    def new_stream(self, batch: int = 1) -> MimiDecodeStream:
+        return MimiDecodeStream(self.stack.make_cache(), batch)
+
+    def _conv_step(self, st: MimiDecodeStream, key: str, x, pc: PackedConv, y, *, elu: bool, dil: int = 1, res=None):
+        """``_conv`` on a chunk: the conv's (K - 1) * dil left-context rows come from the stream (zeros before the first chunk = the one-shot pass's
+        causal zero padding: ELU(0) = 0) and are refreshed from this chunk's input."""
+        h = (pc.k - 1) * dil
+        if h == 0:
+            return self._conv(x, pc, y, elu=elu, dil=dil, res=res)
+        B, L, C = x.shape
+        hist = st.hist.get(key)
+        ext = torch.empty((B, h + L, C), dtype=torch.float32, device=self.device)
+        if hist is None:
+            ext[:, :h].zero_()
+        else:
+            ext[:, :h].copy_(hist)
+        ext[:, h:].copy_(x)
+        ops.conv_gemm(ext, pc, y, dil=dil, pad=0, lout=L, pre_act=ACT_ELU if elu else ACT_NONE, res=res, precision=self.precision)
+        st.hist[key] = ext[:, L:, :].clone()   # the last h rows
+        return y
+
+    def decode_step(self, codes: torch.Tensor, st: MimiDecodeStream, return_stages: bool = False):
+        """codes int [B, nq, n] (the NEXT n frames of the stream, n >= 1) -> their audio [B, 1, n * 1920].  Concatenating the outputs of successive calls
+        gives what ``__call__`` returns for the concatenated codes (same arithmetic per output row; kernels chosen by launch size may sum in a
+        different order: <= 1e-6 of the peak, tests/test_mimi_gpu.py)."""
+        cfg = self.cfg
+        codes = codes.to(self.device, torch.int32).contiguous()
+        B, Q, N = codes.shape
+        assert Q == cfg.quantizer_nq and B == st.batch and N >= 1
+        stages = {}
+        h = self.dequantize(codes)
+        stages["dequant"] = h
+        s = cfg.upsample_stride
+        # depthwise transposed conv, K = 2 s: output rows [t s, (t + 1) s) read frames t - 1 and t -> one frame of history
+        ext = torch.zeros((B, N + 1, cfg.dimension), dtype=torch.float32, device=self.device)
+        if "upsample" in st.hist:
+            ext[:, :1].copy_(st.hist["upsample"])
+        ext[:, 1:].copy_(h)
+        u_ext = self._f(B, (N + 1) * s, cfg.dimension)
+        ops.dwconv(ext, self.up_w, None, u_ext, pad=0, stride=s, transpose=True)
+        st.hist["upsample"] = h[:, -1:, :].clone()
+        u = u_ext[:, s:, :].contiguous()
+        stages["upsample"] = u
+        t = self.stack(u.clone() if return_stages else u, st.caches)   # appends the chunk's positions to the stream's KV caches
+        stages["transformer"] = t
+        x = self._f(B, t.shape[1], self.init_conv.cout)
+        self._conv_step(st, "init", t, self.init_conv, x, elu=False)
+        for i, lyr in enumerate(self.layers):
+            Lin, ratio, cout = x.shape[1], lyr["ratio"], lyr["cout"]
+            taps = lyr["up"].k
+            assert taps == 2, "streaming decode: transposed convs with K = 2 * stride"
+            ext = torch.zeros((B, Lin + 1, x.shape[2]), dtype=torch.float32, device=self.device)
+            if f"up{i}" in st.hist:
+                ext[:, :1].copy_(st.hist[f"up{i}"])
+            ext[:, 1:].copy_(x)
+            st.hist[f"up{i}"] = x[:, -1:, :].clone()
+            y_ext = self._f(B, (Lin + 1) * ratio, cout)
+            ops.conv_gemm(ext, lyr["up"], y_ext, pad=taps - 1, lout=Lin + 1 + taps - 1, pre_act=ACT_ELU, precision=self.precision,
+                          up=dict(s=ratio, p=0, cout=cout, lout=(Lin + 1) * ratio))
+            y = y_ext[:, ratio:, :]   # the first `ratio` rows belong to the previous chunk's last frame (recomputed without ITS history: dropped)
+            hmid = self._f(B, Lin * ratio, lyr["c0"].cout)
+            self._conv_step(st, f"c0_{i}", y, lyr["c0"], hmid, elu=True)
+            self._conv_step(st, f"c1_{i}", hmid, lyr["c1"], y, elu=True, res=y)
+            x = y
+            stages[f"layer{i}"] = x
+        out = self._f(B, x.shape[1], 1)
+        self._conv_step(st, "final", x, self.final_conv, out, elu=True)
+        st.frames += N
+        audio = out.transpose(1, 2)
+        return (audio, stages) if return_stages else audio
+
     def __call__(self, codes: torch.Tensor, return_stages: bool = False):
         """codes int [B, nq, N] -> audio [B, 1, N * 1920]."""
         cfg = self.cfg
@@ -291,6 +363,38 @@ class MimiDecoder:
         self._conv(x, self.final_conv, out, elu=True)
         audio = out.transpose(1, 2)
         return (audio, st) if return_stages else audio
+
+
+class MimiDecodeStream:
+    """Carried state of an incremental decode (``Mimi.decode_step``, mimi.py:171-176; ``StreamableConv1d.step`` / ``StreamableConvTranspose1d.step``,
+    modules/conv.py:245-331): the decoder transformer's KV caches, the last input frame of the depthwise upsampler and, for every causal conv of the
+    SEANet decoder, the (K - 1) * dilation input rows that precede the next chunk (a transposed conv of stride s with K = 2 s taps: one row)."""
+
+    def __init__(self, caches, batch: int):
+        self.caches, self.batch = caches, batch
+        self.hist: Dict[str, torch.Tensor] = {}
+        self.frames = 0
+
+
+class MimiStreamingDecoder:
+    """``MimiStreamingDecoder`` (mimi.py:278-321): keeps the codec's decode state across calls; ``decode_frames(tokens [B, C, T] | [C, T])`` returns
+    the waveform of exactly those frames.  (The reference loops ``decode_step`` frame by frame; here a call decodes its frames in one pass over the
+    carried state -- every operator is causal, so the samples are the same.)"""
+
+    def __init__(self, mimi) -> None:
+        self._mimi = mimi
+        self._stream = None
+
+    def reset(self) -> None:
+        self._stream = None
+
+    def decode_frames(self, tokens: torch.Tensor) -> torch.Tensor:
+        if tokens.dim() == 2:
+            tokens = tokens[None]
+        dec = self._mimi.decoder if hasattr(self._mimi, "decoder") else self._mimi
+        if self._stream is None or self._stream.batch != tokens.shape[0]:
+            self._stream = dec.new_stream(tokens.shape[0])
+        return dec.decode_step(tokens, self._stream)
 
 
 class MimiEncoder:
@@ -419,6 +523,16 @@ class Mimi:
 
     def decode(self, codes: torch.Tensor) -> torch.Tensor:
         return self.decoder(codes)
+
+    # incremental decode (mimi.py:138-144, 171-176): one carried state per object, like the reference's module-held caches
+    def reset_state(self) -> None:
+        self._stream = None
+
+    def decode_step(self, codes: torch.Tensor) -> torch.Tensor:
+        st = getattr(self, "_stream", None)
+        if st is None or st.batch != codes.shape[0]:
+            st = self._stream = self.decoder.new_stream(codes.shape[0])
+        return self.decoder.decode_step(codes, st)
 
     def __call__(self, codes: torch.Tensor, **kw):
         return self.decoder(codes, **kw)

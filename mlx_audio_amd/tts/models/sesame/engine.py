@@ -185,6 +185,42 @@ class CSMEngine:
                 draw(self._logits(dh[:, -1:, :].contiguous(), self.heads[i - 1]), i)
         return sample
 
+    def generate_chunks(self, prompt_tokens: torch.Tensor, prompt_mask: torch.Tensor, max_frames: int, *, chunk: int, temperature: float = 0.9,
+                        top_k: int = 50, gumbel: Optional[torch.Tensor] = None, forced: Optional[torch.Tensor] = None,
+                        generator: Optional[torch.Generator] = None):
+        """The frame loop as a generator (sesame.py:813-860 with ``stream=True``): yields int64 [B, n, n_cb] blocks of the frames generated since the last
+        yield, every ``chunk`` frames, WHILE the loop runs -- the caller decodes and hands on a block before the next frame is computed.  The
+        all-zero EOS frame ends the loop and is not yielded; one host read-back per block (the reference reads back every frame, sesame.py:828).
+        ``self.frames_generated`` counts the frames computed so far (what a test reads to see that a block left before the loop ended)."""
+        cfg, dev = self.cfg, self.device
+        self.reset_caches()
+        max_pos = self.backbone.cos.shape[0]
+        if prompt_tokens.shape[1] + max_frames > max_pos:  # sesame.py:817-820
+            raise ValueError(f"Inputs too long, must be below max_seq_len - max_audio_frames: {max_pos - max_frames}")
+        nb = cfg.audio_num_codebooks
+        B = prompt_tokens.shape[0]
+        frames = torch.zeros((B, max_frames, nb), dtype=torch.int32, device=dev)
+        toks, mask = prompt_tokens, prompt_mask
+        next_mask = torch.cat([torch.ones(B, 1, nb, dtype=torch.bool), torch.zeros(B, 1, 1, dtype=torch.bool)], dim=2).to(dev)
+        sent = 0
+        self.frames_generated = 0
+        for f in range(max_frames):
+            s = self.generate_frame(toks, mask, temperature=temperature, top_k=top_k, gumbel=None if gumbel is None else gumbel[f],
+                                    forced=None if forced is None else forced[:, f], out=frames[:, f, :], generator=generator)
+            self.frames_generated = f + 1
+            toks = torch.cat([s, torch.zeros((B, 1), dtype=torch.int32, device=dev)], dim=1)[:, None, :]
+            mask = next_mask
+            if f + 1 - sent >= chunk or f + 1 == max_frames:
+                blk = frames[:, sent:f + 1].to(torch.int64)
+                zero = (blk == 0).all(dim=2).all(dim=0).cpu()
+                if bool(zero.any()):
+                    first = int(torch.nonzero(zero)[0])
+                    if first > 0:
+                        yield blk[:, :first]
+                    return
+                yield blk
+                sent = f + 1
+
     def generate(self, prompt_tokens: torch.Tensor, prompt_mask: torch.Tensor, max_frames: int, *, temperature: float = 0.9, top_k: int = 50,
                  gumbel: Optional[torch.Tensor] = None, forced: Optional[torch.Tensor] = None, record: bool = False, poll: int = 16,
                  generator: Optional[torch.Generator] = None):

@@ -290,17 +290,24 @@ class Model:
             max_seq_len = 2048 - max_audio_frames
             if prompt_tokens.shape[0] >= max_seq_len:
                 raise ValueError(f"Inputs too long, must be below max_seq_len - max_audio_frames: {max_seq_len}")
+            if stream:
+                # sesame.py:825-860: a partial result every ``streaming_interval`` seconds of frames, decoded by the Mimi streaming decoder (carried conv
+                # / transformer state: codec/models/mimi/mimi.py:171-176, 278-321) and yielded WHILE the frame loop runs
+                if self._audio_tokenizer is None:
+                    raise ValueError("Mimi decoder not loaded (expected <model_path>/mimi/*.safetensors or config['audio_tokenizer_path'])")
+                from ....codec.models.mimi.mimi import MimiStreamingDecoder
+
+                sd = MimiStreamingDecoder(self._audio_tokenizer)
+                for blk in self.model.generate_chunks(prompt_tokens[None], prompt_mask[None], max_audio_frames, chunk=interval, temperature=temperature,
+                                                      top_k=top_k, gumbel=kwargs.get("gumbel"), forced=kwargs.get("forced"), generator=gen):
+                    fr = blk[0]
+                    audio = sd.decode_frames(fr.t()[None].contiguous())[0, 0]
+                    yield self.generate_result(fr, t0, stream=True, audio=audio)
+                    t0 = time.perf_counter()
+                continue
             out = self.model.generate(prompt_tokens[None], prompt_mask[None], max_audio_frames, temperature=temperature, top_k=top_k,
                                       gumbel=kwargs.get("gumbel"), forced=kwargs.get("forced"), generator=gen)
             frames = out["frames"][0]
             if frames.shape[0] == 0:
                 continue
-            if not stream:
-                yield self.generate_result(frames, t0)
-                continue
-            audio = self._decode_frames(frames)  # one causal pass; the chunks below are slices of it (identical to chunked streaming decode)
-            up = audio.shape[0] // frames.shape[0]
-            for s in range(0, frames.shape[0], interval):
-                e = min(s + interval, frames.shape[0])
-                yield self.generate_result(frames[s:e], t0, stream=True, audio=audio[s * up:e * up])
-                t0 = time.perf_counter()
+            yield self.generate_result(frames, t0)

@@ -103,3 +103,42 @@ def test_mimi_202407_encode_shape_pin_and_stages():
         for t in range(got.shape[2]):
             _margin.walk("mimi_encode", got[b, :1, t].tolist(), want[b, :1, t].tolist(), torch.minimum(gm, wm)[b, :1, t].tolist(), thr=thr, where=(b, t, 0))
             _margin.walk("mimi_encode", got[b, 1:, t].tolist(), want[b, 1:, t].tolist(), torch.minimum(gm, wm)[b, 1:, t].tolist(), thr=thr, where=(b, t))
+
+
+@pytest.mark.parametrize("full", [False, True])
+def test_streaming_decode_equals_one_shot(full):
+    """``decode_step`` with carried state (mimi.py:171-176, modules/conv.py:245-331): the concatenation of the chunks' audio is the one-shot decode of
+    the concatenated codes -- every stage, chunk sizes 1 .. 7, more transformer positions than the attention window (tiny config: context 20)."""
+    from mlx_audio_amd.codec.models.mimi import mimi as M
+
+    cfg = M.mimi_202407(32) if full else M.tiny_mimi_config()
+    eng, _, _ = _pair(cfg, 3)
+    n = 23 if full else 41
+    codes = M.make_codes(2, n, cfg, seed=5)
+    want, wst = eng(codes, return_stages=True)
+    st = eng.new_stream(2)
+    pieces, stages, pos = [], {}, 0
+    for size in [1, 4, 3, 7, 2, 1, 5, 100]:
+        if pos >= n:
+            break
+        a, g = eng.decode_step(codes[:, :, pos:pos + size], st, return_stages=True)
+        assert a.shape[-1] == min(size, n - pos) * (want.shape[-1] // n)
+        pieces.append(a)
+        for k, v in g.items():
+            stages.setdefault(k, []).append(v)
+        pos += size
+    torch.cuda.synchronize()
+    assert st.frames == n
+    for k, v in stages.items():
+        assert rel_peak(torch.cat(v, 1), wst[k]) < 2e-6, (k, rel_peak(torch.cat(v, 1), wst[k]))
+    got = torch.cat(pieces, -1)
+    assert got.shape == want.shape
+    assert rel_peak(got, want) < 1e-6, rel_peak(got, want)
+    # the reference's wrapper (MimiStreamingDecoder.decode_frames) over the same state machine
+    both = M.Mimi({**M.make_mimi_decoder_weights(cfg, seed=3)}, cfg, device=DEV)
+    sd = M.MimiStreamingDecoder(both)
+    a1, a2 = sd.decode_frames(codes[:, :, :9]), sd.decode_frames(codes[:, :, 9:])
+    torch.cuda.synchronize()
+    assert rel_peak(torch.cat([a1, a2], -1), want) < 1e-6
+    sd.reset()
+    assert rel_peak(sd.decode_frames(codes[0, :, :6]), want[:1, :, : 6 * (want.shape[-1] // n)]) < 1e-6   # [C, T] input, fresh state

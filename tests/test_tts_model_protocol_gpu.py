@@ -341,9 +341,15 @@ def test_csm_load_model_and_generate(csm_ckpt):
     wav = mref(gf.t()[None].long())[0, 0]
     got = res[0].audio.cpu()
     assert got.shape == wav.shape and float((got - wav).abs().max()) <= 2e-3 * max(1.0, float(wav.abs().max()))
-    # streaming chunks are slices of the same causal decode
-    chunks = list(model.generate(text, speaker=0, temperature=0.0, max_audio_length_ms=frames * 80, stream=True, streaming_interval=0.16))
-    assert all(r.is_streaming_chunk for r in chunks) and torch.equal(torch.cat([r.audio for r in chunks]).cpu(), got)
+    # stream=True (sesame.py:825-860): chunks are decoded by the Mimi streaming decoder (carried state) and leave WHILE the frame loop runs -- the first
+    # chunk (0.16 s = 2 frames) is in hand when only 2 of the 5 frames have been computed; the concatenation is the one-shot waveform
+    it = model.generate(text, speaker=0, temperature=0.0, max_audio_length_ms=frames * 80, stream=True, streaming_interval=0.16)
+    first = next(it)
+    assert first.is_streaming_chunk and first.token_count == 2 and first.samples == 2 * 1920 and model.model.frames_generated == 2 < gf.shape[0]
+    chunks = [first] + list(it)
+    assert model.model.frames_generated == gf.shape[0] and [r.token_count for r in chunks] == [2, 2, 1][: len(chunks)] and sum(r.token_count for r in chunks) == gf.shape[0]
+    cat = torch.cat([r.audio for r in chunks]).cpu()
+    assert all(r.is_streaming_chunk for r in chunks) and cat.shape == got.shape and float((cat - got).abs().max()) <= 1e-6 * float(got.abs().max())
     # the 2048-position guard (sesame.py:817-820) and the audio-context refusals
     with pytest.raises(ValueError):
         list(model.generate("x" * 50, max_audio_length_ms=80 * 2040))
