@@ -67,6 +67,16 @@ class _Snake:
         self.alpha, self.inv_beta = a.to(device), b.to(device)
 
 
+class Qwen3CodecStream:
+    """Carried state of ``streaming_step``: the pre-transformer's KV caches and the left-context rows of every causal conv / transposed conv
+    (the reference keeps them inside its modules: ``CausalConv1d._buffer``, the transformer cache; speech_tokenizer.py:871-930)."""
+
+    def __init__(self, caches, batch: int):
+        self.caches, self.batch = caches, batch
+        self.hist: Dict[str, torch.Tensor] = {}
+        self.frames = 0
+
+
 class Qwen3CodecDecoder:
     def __init__(self, weights: Dict[str, torch.Tensor], cfg: Qwen3TTSTokenizerDecoderConfig, device="cuda:0", precision: int = 2):
         ops.require_gpu()
@@ -200,6 +210,107 @@ class Qwen3CodecDecoder:
         self._snake_conv(wav, self.out_snake, self.out_conv, out)
         audio = out.transpose(1, 2).clamp_(-1.0, 1.0)
         return (audio, st) if return_stages else audio
+
+    # ------------------------------------------------------------------ incremental decode (speech_tokenizer.py:882-930)
+    def reset_streaming_state(self) -> None:
+        self._stream = None
+
+    def new_stream(self, batch: int = 1) -> "Qwen3CodecStream":
+        return Qwen3CodecStream(self.stack.make_cache(), batch)
+
+    def _ctx_conv(self, st: "Qwen3CodecStream", key: str, x, sn: Optional[_Snake], pc: PackedConv, y, *, dil=1, res=None):
+        """``_snake_conv`` on a chunk: the (K - 1) * dil left-context rows come from the stream (zeros before the first chunk = the causal zero padding of
+        the one-shot pass: SnakeBeta(0) = 0) and are refreshed from this chunk's input (``CausalConv1d.step``, speech_tokenizer.py)."""
+        h = (pc.k - 1) * dil
+        if h == 0:
+            return self._snake_conv(x, sn, pc, y, dil=dil, res=res)
+        B, L, C = x.shape
+        ext = torch.empty((B, h + L, C), dtype=torch.float32, device=self.device)
+        hist = st.hist.get(key)
+        if hist is None:
+            ext[:, :h].zero_()
+        else:
+            ext[:, :h].copy_(hist)
+        ext[:, h:].copy_(x)
+        kw = dict(dil=dil, pad=0, lout=L, res=res, precision=self.precision)
+        if sn is not None:
+            kw.update(pre_act=ACT_SNAKE, pre_alpha=sn.alpha, pre_inv_beta=sn.inv_beta)
+        ops.conv_gemm(ext, pc, y, **kw)
+        st.hist[key] = ext[:, L:, :].clone()
+        return y
+
+    def _ctx_convT(self, st: "Qwen3CodecStream", key: str, x, sn: Optional[_Snake], pc: PackedConv, stride: int, cout: int):
+        """``_convT`` on a chunk: a transposed conv with ``taps`` = K / stride taps reads taps - 1 earlier input rows (none when K == stride)."""
+        taps = pc.k
+        if taps == 1:
+            return self._convT(x, sn, pc, stride, cout)
+        B, L, C = x.shape
+        h = taps - 1
+        ext = torch.zeros((B, h + L, C), dtype=torch.float32, device=self.device)
+        if key in st.hist:
+            ext[:, :h].copy_(st.hist[key])
+        ext[:, h:].copy_(x)
+        st.hist[key] = ext[:, L:, :].clone()
+        y_ext = self._convT(ext, sn, pc, stride, cout)
+        return y_ext[:, h * stride:, :]   # the first rows belong to earlier chunks (recomputed without THEIR history: dropped)
+
+    def streaming_step(self, codes: torch.Tensor, st: Optional["Qwen3CodecStream"] = None, return_stages: bool = False):
+        """codes int [B, num_quantizers, n]: the NEXT n frames of the stream -> their audio [B, 1, n * total_upsample].  The concatenation of successive
+        calls is the one-shot decode of the concatenated codes (every operator is causal; tests/test_qwen3_codec_gpu.py).  ``st`` = a state from
+        ``new_stream`` (default: the object-held one, reset by ``reset_streaming_state`` -- the reference's calling convention)."""
+        cfg = self.cfg
+        if st is None:
+            st = getattr(self, "_stream", None)
+            if st is None or st.batch != codes.shape[0]:
+                st = self._stream = self.new_stream(codes.shape[0])
+        if codes.shape[1] != cfg.num_quantizers:
+            raise ValueError(f"Expected {cfg.num_quantizers} layers of codes, got {codes.shape[1]}")
+        codes = codes.to(self.device, torch.int32).contiguous()
+        B, _, N = codes.shape
+        assert B == st.batch and N >= 1
+        stg = {}
+        h = self.dequantize(codes)
+        stg["dequant"] = h
+        x = self._f(B, N, cfg.latent_dim)
+        self._ctx_conv(st, "pre_conv", h, None, self.pre_conv, x)
+        stg["pre_conv"] = x
+        t = self._f(B, N, cfg.hidden_size)
+        ops.conv_gemm(x, self.in_proj.pc, t, precision=self.precision)
+        t = self.stack(t, st.caches)    # appends the chunk's positions to the stream's KV caches
+        h = self._f(B, N, cfg.latent_dim)
+        ops.conv_gemm(t, self.out_proj.pc, h, precision=self.precision)
+        stg["transformer"] = h
+        for i, up in enumerate(self.ups):
+            h = self._ctx_convT(st, f"upT{i}", h, None, up["convT"], up["f"], cfg.latent_dim)
+            Bh, Lh, C = h.shape
+            kd = up["dw_w"].shape[1] - 1   # depthwise causal conv, K = 7: six rows of history
+            ext = torch.zeros((Bh, kd + Lh, C), dtype=torch.float32, device=self.device)
+            if f"dw{i}" in st.hist:
+                ext[:, :kd].copy_(st.hist[f"dw{i}"])
+            ext[:, kd:].copy_(h)
+            st.hist[f"dw{i}"] = ext[:, Lh:, :].clone()
+            d = self._f(Bh, Lh, C)
+            ops.dwconv(ext, up["dw_w"], up["dw_b"], d, pad=0)
+            ops.layernorm(d, d, weight=up["ln_w"], bias=up["ln_b"], eps=1e-6)
+            m = self._f(Bh, Lh, 4 * C)
+            ops.conv_gemm(d, up["pw1"], m, post_act=ACT_GELU, precision=self.precision)
+            h = h.contiguous()
+            ops.conv_gemm(m, up["pw2"], h, colscale=up["gamma"], res=h, precision=self.precision)
+        stg["upsampled"] = h
+        wav = self._f(B, h.shape[1], cfg.decoder_dim)
+        self._ctx_conv(st, "init", h, None, self.init_conv, wav)
+        for bi, blk in enumerate(self.blocks):
+            wav = self._ctx_convT(st, f"blkT{bi}", wav, blk["snake"], blk["up"], blk["rate"], blk["cout"]).contiguous()
+            tmp = torch.empty_like(wav)
+            for ui, u in enumerate(blk["units"]):
+                self._ctx_conv(st, f"b{bi}u{ui}c1", wav, u["s1"], u["c1"], tmp, dil=u["dil"])
+                self._ctx_conv(st, f"b{bi}u{ui}c2", tmp, u["s2"], u["c2"], wav, res=wav)
+            stg[f"block{bi}"] = wav
+        out = self._f(B, wav.shape[1], 1)
+        self._ctx_conv(st, "out", wav, self.out_snake, self.out_conv, out)
+        st.frames += N
+        audio = out.transpose(1, 2).clamp_(-1.0, 1.0)
+        return (audio, stg) if return_stages else audio
 
     def chunked_decode(self, codes: torch.Tensor, chunk_size: int = 300, left_context_size: int = 25) -> torch.Tensor:
         """speech_tokenizer.py:930-954: chunks of ``chunk_size`` code frames with ``left_context_size`` frames of context."""

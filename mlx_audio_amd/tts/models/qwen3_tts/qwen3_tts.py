@@ -378,8 +378,29 @@ class Model:
             gen = torch.Generator(device=self.talker.device)
             gen.manual_seed(int(seed) if seed is not None else int(torch.seed() % (2 ** 31)))
         cap = self.talker.talker.cos.shape[0] - input_embeds.shape[1]
+        if engine_kw.get("chunk"):   # streaming: the generator itself (blocks of frames while the loop runs, then the final dict)
+            return self.talker.generate_iter(input_embeds, trailing, tts_pad, min(max_tokens, cap), temperature=temperature, top_k=top_k, top_p=top_p,
+                                             repetition_penalty=repetition_penalty, left_pad=left_pad, generator=gen, **engine_kw)
         return self.talker.generate(input_embeds, trailing, tts_pad, min(max_tokens, cap), temperature=temperature, top_k=top_k, top_p=top_p,
                                     repetition_penalty=repetition_penalty, left_pad=left_pad, generator=gen, **engine_kw)
+
+    def _stream_blocks(self, blocks, segment_idx: int, prime_codes: Optional[torch.Tensor] = None):
+        """qwen3_tts.py:1426-1465: every block of new frames goes through ``decoder.streaming_step`` (conv buffers + transformer KV cache carried from
+        block to block: speech_tokenizer.py:882-930) and leaves as a ``GenerationResult`` WHILE the frame loop runs.  ``prime_codes`` [n, G]: frames
+        that precede the stream (the reference clip of in-context cloning): decoded into the state, their audio dropped."""
+        dec = self.speech_tokenizer.decoder
+        st = dec.new_stream(1)
+        if prime_codes is not None and prime_codes.shape[0] > 0:
+            dec.streaming_step(prime_codes.t()[None].contiguous(), st)
+        t0 = time.time()
+        for item in blocks:
+            if "block" not in item:
+                continue
+            blk = item["block"][0]
+            wav = dec.streaming_step(blk.t()[None].contiguous(), st).squeeze(1)[0]
+            torch.cuda.synchronize()
+            yield self._result(wav, segment_idx, int(blk.shape[0]), time.time() - t0, is_streaming_chunk=True, is_final_chunk=bool(item.get("last")))
+            t0 = time.time()
 
     # ------------------------------------------------------------------ generate
     def generate(self, text: str, voice: Optional[str] = None, instruct: Optional[str] = None, temperature: float = 0.9, speed: float = 1.0,
@@ -422,24 +443,17 @@ class Model:
             t0 = time.time()
             x, trailing, pad = self._prepare_generation_inputs(seg, language=lang_code, speaker=voice if kind != "voice_design" else None, ref_audio=clip,
                                                                ref_text=ref_text if kind == "base" else None, instruct=instruct)
+            if stream:
+                blocks = self._frame_loop(x, trailing, pad, max_tokens, temperature=temperature, top_k=top_k, top_p=top_p, repetition_penalty=repetition_penalty,
+                                          seed=kwargs.get("seed"), pad_when_index_clamped=False, chunk=max(1, int(streaming_interval * 12.5)), **engine_kw)
+                yield from self._stream_blocks(blocks, segment_idx)
+                continue
             out = self._frame_loop(x, trailing, pad, max_tokens, temperature=temperature, top_k=top_k, top_p=top_p, repetition_penalty=repetition_penalty,
                                    seed=kwargs.get("seed"), pad_when_index_clamped=False, **engine_kw)
             codes = out["codes"][0]
             fa = int(out["finished_at"][0])
             codes = codes[:fa] if fa >= 0 else codes  # the EOS frame itself is not decoded (qwen3_tts.py:1408-1412)
             if codes.shape[0] == 0:
-                continue
-            if stream:
-                chunk = max(1, int(streaming_interval * 12.5))
-                done = 0
-                up = self.speech_tokenizer.decode_upsample_rate
-                while done < codes.shape[0]:
-                    end = min(done + chunk, codes.shape[0])
-                    ctx = min(streaming_context_size, done)
-                    wav = self.speech_tokenizer.decoder(codes[done - ctx:end].t()[None].contiguous()).squeeze(1)[0][ctx * up:]
-                    torch.cuda.synchronize()
-                    yield self._result(wav, segment_idx, end - done, time.time() - t0, is_streaming_chunk=True, is_final_chunk=end == codes.shape[0])
-                    done, t0 = end, time.time()
                 continue
             audio, lengths = self.speech_tokenizer.decode(codes[None])
             audio = audio[0]
@@ -454,28 +468,21 @@ class Model:
                       streaming_context_size: int = 25, seed=None, **engine_kw) -> Generator[GenerationResult, None, None]:
         """``qwen3_tts.py:2200-2510``: the whole text as ONE segment behind the in-context prompt; the frame loop is the engine's (prefill of the
         prompt, then a talker step + 15 code-predictor steps per frame); decode behind the reference codes and cut them off.  ``stream=True``
-        yields chunks of the NEW audio only, each decoded with ``streaming_context_size`` frames of left context (the reference carries decoder
-        state across chunks instead)."""
+        yields chunks of the NEW audio only, decoded by ``streaming_step`` on a state primed with the reference clip's codes."""
         t0 = time.time()
         x, trailing, pad, ref_codes = self._prepare_icl_generation_inputs(text, ref_audio=ref_audio, ref_text=ref_text, language=language)
+        if stream:
+            blocks = self._frame_loop(x, trailing, pad, max_tokens, temperature=temperature, top_k=top_k, top_p=top_p, repetition_penalty=repetition_penalty,
+                                      seed=seed, pad_when_index_clamped=False, chunk=max(1, int(streaming_interval * 12.5)), **engine_kw)
+            rc = None if ref_codes is None else torch.as_tensor(ref_codes)[0].t()   # [1, groups, ref_time] -> frames [ref_time, groups]
+            yield from self._stream_blocks(blocks, 0, prime_codes=rc)
+            return
         out = self._frame_loop(x, trailing, pad, max_tokens, temperature=temperature, top_k=top_k, top_p=top_p, repetition_penalty=repetition_penalty,
                                seed=seed, pad_when_index_clamped=False, **engine_kw)
         codes = out["codes"][0]
         fa = int(out["finished_at"][0])
         codes = codes[:fa] if fa >= 0 else codes
         if codes.shape[0] == 0:
-            return
-        if stream:
-            chunk = max(1, int(streaming_interval * 12.5))
-            done = 0
-            up = self.speech_tokenizer.decode_upsample_rate
-            while done < codes.shape[0]:
-                end = min(done + chunk, codes.shape[0])
-                ctx = min(streaming_context_size, done)
-                wav = self.speech_tokenizer.decoder(codes[done - ctx:end].t()[None].contiguous()).squeeze(1)[0][ctx * up:]
-                torch.cuda.synchronize()
-                yield self._result(wav, 0, end - done, time.time() - t0, is_streaming_chunk=True, is_final_chunk=end == codes.shape[0])
-                done, t0 = end, time.time()
             return
         audio = self._decode_icl_generated_codes(codes, ref_codes)
         if torch.cuda.is_available():

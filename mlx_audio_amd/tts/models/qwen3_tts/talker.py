@@ -163,11 +163,24 @@ class Qwen3Talker:
         linear(h_last, head, out[:, :, :V], precision=self.precision, norm=norm)
         return out[:, 0, :]
 
-    def generate(self, prefill: torch.Tensor, trailing: torch.Tensor, tts_pad: torch.Tensor, max_frames: int, *, temperature: float = 0.9,
-                 top_k: int = 50, top_p: float = 1.0, repetition_penalty: float = 1.05, gumbel0: Optional[torch.Tensor] = None,
-                 gumbel_cp: Optional[torch.Tensor] = None, forced_codes: Optional[torch.Tensor] = None, record: bool = False, poll: int = 16,
-                 left_pad: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None, pad_when_index_clamped: bool = True):
-        """The frame loop (qwen3_tts.py:1860-1935).  ``prefill`` [B, L, H] may be LEFT-padded (``left_pad`` int [B] = padding positions of each
+    def generate(self, prefill: torch.Tensor, trailing: torch.Tensor, tts_pad: torch.Tensor, max_frames: int, **kw):
+        """The frame loop run to its end: the last item of ``generate_iter`` (dict codes / finished_at / trace)."""
+        out = None
+        for out in self.generate_iter(prefill, trailing, tts_pad, max_frames, **kw):
+            pass
+        return out
+
+    def generate_iter(self, prefill: torch.Tensor, trailing: torch.Tensor, tts_pad: torch.Tensor, max_frames: int, *, temperature: float = 0.9,
+                      top_k: int = 50, top_p: float = 1.0, repetition_penalty: float = 1.05, gumbel0: Optional[torch.Tensor] = None,
+                      gumbel_cp: Optional[torch.Tensor] = None, forced_codes: Optional[torch.Tensor] = None, record: bool = False, poll: int = 16,
+                      left_pad: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None, pad_when_index_clamped: bool = True,
+                      chunk: int = 0):
+        """The frame loop as a generator.  ``chunk`` > 0 (one sequence: qwen3_tts.py:1426-1465 ``stream=True``): every ``chunk`` frames a dict
+        ``block`` = int64 [1, n, G] (the frames generated since the last block, the EOS frame excluded) is yielded WHILE the loop runs, so the caller
+        decodes and hands on audio before the next frame exists (one host read-back per block; ``self.frames_generated`` = frames computed so far).
+        The LAST item is always the final dict (``codes`` / ``finished_at`` / ``trace``) ``generate`` returns.
+
+        The frame loop (qwen3_tts.py:1860-1935).  ``prefill`` [B, L, H] may be LEFT-padded (``left_pad`` int [B] = padding positions of each
         row, qwen3_tts.py:536-560): padded keys are invisible and positions count from the first real token, exactly what the reference's
         attention-mask / cumsum position ids do (talker.py:443-470).  Sampling noise: explicit Gumbel tensors (``gumbel0`` / ``gumbel_cp``, the
         parity tests), else -- for temperature > 0 -- Gumbel noise drawn on the device from ``generator`` (``mx.random.categorical`` in the
@@ -213,6 +226,9 @@ class Qwen3Talker:
 
         trace: List[list] = []
         frames = 0
+        sent = 0
+        self.frames_generated = 0
+        assert chunk == 0 or B == 1, "chunked (streaming) frame loop: one sequence"
         for f in range(max_frames):
             h = self.talker(x, cache, k_start=k_start)
             last = h[:, -1:, :].contiguous()
@@ -282,16 +298,31 @@ class Qwen3Talker:
             hist[ar, hist_len.long()] = torch.where(alive, tok, hist[ar, hist_len.long()])
             hist_len = hist_len + alive.to(torch.int32)
             frames = f + 1
+            self.frames_generated = frames
             if record:
                 trace.append(tr)
-            if forced is None and frames % poll == 0 and bool((finished != 0).all()):  # the only host round trip of the loop
+            if chunk and frames - sent >= chunk:   # streaming: hand the finished frames on now (one read-back per block)
+                fa0 = int(finished_at[0])
+                end = frames if fa0 < 0 else fa0
+                if end > sent:
+                    yield dict(block=codes_all[:, sent:end].to(torch.int64), first_frame=sent, last=fa0 >= 0 or frames == max_frames)
+                sent = end
+                if fa0 >= 0:
+                    break
+                continue
+            if not chunk and forced is None and frames % poll == 0 and bool((finished != 0).all()):  # the only host round trip of the loop
                 break
         codes = codes_all[:, :frames].to(torch.int64)
+        if chunk:   # the tail of a streamed sequence
+            fa0 = int(finished_at[0])
+            end = frames if fa0 < 0 else fa0
+            if end > sent:
+                yield dict(block=codes_all[:, sent:end].to(torch.int64), first_frame=sent, last=True)
         if forced is None:
             fa = finished_at.cpu()
             if bool((fa >= 0).all()):
                 codes = codes[:, : int(fa.max()) + 1]  # the reference stops at the frame where the last sequence emits EOS
-        return dict(codes=codes, finished_at=finished_at, trace=trace)
+        yield dict(codes=codes, finished_at=finished_at, trace=trace)
 
 
 class Qwen3TalkerSlots:

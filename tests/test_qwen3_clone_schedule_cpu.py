@@ -172,6 +172,21 @@ def _scripted_model(monkeypatch, frames_of, xvec=True):
                               left_pad=None if left_pad is None else left_pad.tolist(), kw=sorted(kw)))
             return dict(codes=codes, finished_at=torch.tensor([x if x < max_frames else -1 for x in n]))
 
+        def generate_iter(self, prefill, trailing, tts_pad, max_frames, *, chunk=0, **kw):
+            """the engine's streaming contract: blocks of ``chunk`` frames (EOS frame excluded) while the loop runs, then the final dict"""
+            out = self.generate(prefill, trailing, tts_pad, max_frames, **kw)
+            calls[-1]["chunk"] = chunk
+            fa = int(out["finished_at"][0])
+            n = fa if fa >= 0 else out["codes"].shape[1]
+            if chunk:
+                for s0 in range(0, n, chunk):
+                    e = min(s0 + chunk, n)
+                    streamed.append((s0, e))
+                    yield dict(block=out["codes"][:, s0:e], first_frame=s0, last=e == n)
+            yield out
+
+    streamed = []
+
     class Tok:
         has_encoder = True
         decode_upsample_rate = PT.QWEN3_ICL_UP
@@ -188,8 +203,19 @@ def _scripted_model(monkeypatch, frames_of, xvec=True):
         a, _ = PT.qwen3_fake_decode(codes.permute(0, 2, 1).numpy())
         return torch.from_numpy(a)[:, None, :]
 
+    class Dec:   # the codec decoder's surface: one-shot call + the carried-state streaming pair (the stand-in codec has no memory, so the state only counts)
+        device = "cpu"
+        __call__ = staticmethod(decoder)
+
+        def new_stream(self, batch=1):
+            return SimpleNamespace(frames=0, batch=batch)
+
+        def streaming_step(self, codes, st):
+            st.frames += codes.shape[2]
+            return decoder(codes)
+
     tok = Tok()
-    tok.decoder = type("Dec", (), {"device": "cpu", "__call__": staticmethod(decoder)})()
+    tok.decoder = Dec()
     m = Model.__new__(Model)
     m.config = PT.qwen3_icl_config("base")
     m._sample_rate = 24000
@@ -235,6 +261,7 @@ def test_generate_routes_a_clip_with_transcript_through_the_in_context_path(monk
     chunks = list(m.generate("Say this.", ref_audio=clip, ref_text="the clip's words", max_tokens=40, stream=True, streaming_interval=0.16))
     assert [r.token_count for r in chunks] == [2, 2, 1] and [r.is_final_chunk for r in chunks] == [False, False, True]
     assert all(r.is_streaming_chunk and r.samples == r.token_count * PT.QWEN3_ICL_UP for r in chunks)
+    assert calls[-1]["chunk"] == 2     # the frame loop itself ran in streaming mode: blocks left it while it ran (qwen3_tts.py:1426-1465)
     # no frames at all (EOS on the first one): nothing is yielded
     m0, _ = _scripted_model(monkeypatch, lambda b, L: 0)
     assert list(m0.generate("x", ref_audio=clip, ref_text="t", max_tokens=4)) == []

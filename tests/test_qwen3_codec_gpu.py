@@ -85,3 +85,37 @@ def test_full_size_decoder():
     for k in est:
         assert rel_peak(gst[k], est[k]) < 3e-4, (k, rel_peak(gst[k], est[k]))
     assert float((got.cpu() - exp).abs().max()) <= 2e-3 and snr_db(got, exp) >= 50.0
+
+
+def test_streaming_step_equals_one_shot(tiny):
+    """``streaming_step`` (speech_tokenizer.py:882-930: conv buffers + transformer KV cache carried across calls): the concatenated chunks are the
+    one-shot decode of the concatenated codes, stage by stage, for chunk sizes 1 .. 9 and more positions than the sliding attention window."""
+    eng, cfg = tiny["eng"], tiny["cfg"]
+    n = 37
+    codes = tiny["QS"].make_codes(2, n, cfg, seed=11)
+    want, wst = eng(codes, return_stages=True)
+    st = eng.new_stream(2)
+    pieces, stages, pos = [], {}, 0
+    for size in [1, 2, 9, 4, 1, 6, 100]:
+        if pos >= n:
+            break
+        a, g = eng.streaming_step(codes[:, :, pos:pos + size], st, return_stages=True)
+        pieces.append(a)
+        for k, v in g.items():
+            stages.setdefault(k, []).append(v)
+        pos += size
+    torch.cuda.synchronize()
+    assert st.frames == n
+    for k, v in stages.items():
+        got = torch.cat(v, 1).double().cpu()
+        ref = wst[k].double().cpu()
+        assert got.shape == ref.shape and float((got - ref).abs().max() / ref.abs().max()) < 2e-5, k
+    got = torch.cat(pieces, -1)
+    # float32-rounding-level differences only (kernels are picked by launch size and sum in different orders; measured 2-4e-6)
+    print(f"qwen3 codec streaming vs one-shot: {float((got - want).abs().max()) / max(1.0, float(want.abs().max())):.2e}")
+    assert got.shape == want.shape and float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    # the object-held state of the reference's calling convention: reset_streaming_state() + streaming_step(codes)
+    eng.reset_streaming_state()
+    a1, a2 = eng.streaming_step(codes[:, :, :10]), eng.streaming_step(codes[:, :, 10:])
+    torch.cuda.synchronize()
+    assert float((torch.cat([a1, a2], -1) - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
