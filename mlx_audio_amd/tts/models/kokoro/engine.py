@@ -225,18 +225,17 @@ class KokoroEngine:
     def _convw(self, pre, bias=True) -> PackedConv:
         b = self._q(self._t(f"{pre}.bias")) if bias and f"{pre}.bias" in self.w else None
         w = self._wn(pre)
-        dec5 = self.precision == 5 and pre.startswith("decoder.") and w.dim() == 3
-        mx = dec5 and ops.mx_pays(w.shape[0], w.shape[1], w.shape[2])
-        if dec5 and not mx and w.shape[1] == 3 and ops.mx_eligible(w.shape[0], w.shape[1], w.shape[2]):
-            return ops.pack_conv(w, b, self.dev)   # the HBM / VALU-bound 3-tap convs: bf16 hi + lo (exact weights, cheapest prologue)
+        # precision 5: MX images where the fp16 hi + e4m3 lo arithmetic is the faster one (>= 7 taps on the wave-specialised kernel); every other
+        # conv keeps the default mode's bf16 image (exact weights, the cheapest prologue: the 3-tap convs are HBM / VALU bound)
+        mx = self.precision == 5 and pre.startswith("decoder.") and w.dim() == 3 and ops.mx_pays(w.shape[0], w.shape[1], w.shape[2])
         return ops.pack_conv(w, b, self.dev, f16=self._f16(pre), mx=mx)
 
     def _f16(self, pre: str) -> bool:
         """precision 3: the decoder / generator convs (97 % of the FLOPs) run the single-pass fp16 MFMA; the front end
         (PL-BERT, prosody predictor, text encoder: the bit-exact duration path and the F0 curve the harmonic source
-        integrates) stays on the bf16 hi+lo split.  precision 5: the same split of the network, the decoder / generator convs on the fp16 hi +
-        block-scaled e4m3 lo pass (MX images) where the wave-specialised kernel takes the shape, fp16 hi + lo (precision 4) elsewhere."""
-        return self.all_f16 or (self.precision in (3, 5) and pre.startswith("decoder."))
+        integrates) stays on the bf16 hi+lo split.  precision 5: the decoder / generator convs of >= 7 taps on the fp16 hi + block-scaled e4m3 lo
+        pass (MX images, ``_convw``), everything else exactly as the default mode."""
+        return self.all_f16 or (self.precision == 3 and pre.startswith("decoder."))
 
     def _dvec(self, t: torch.Tensor, pad_to: int = 0) -> torch.Tensor:
         t = self._q(t.reshape(-1).float())
@@ -344,7 +343,7 @@ class KokoroEngine:
             cout = c0 // (2 ** (i + 1))
             # stored (Cin, K, Cout); mx.conv_transpose1d receives weight.T = (Cout, K, Cin) (istftnet.py:161-166)
             w_t = self._wn(f"{g}.ups.{i}").permute(2, 1, 0).contiguous()
-            self.ups.append(ops.pack_conv_transpose(w_t, self._q(self._t(f"{g}.ups.{i}.bias")), u, d, f16=self.precision in (3, 5) or self.all_f16))
+            self.ups.append(ops.pack_conv_transpose(w_t, self._q(self._t(f"{g}.ups.{i}.bias")), u, d, f16=self.precision == 3 or self.all_f16))
             ncw = self._q(self._t(f"{g}.noise_convs.{i}.weight"))  # (cout, K, n_fft+2)
             ncb = self._q(self._t(f"{g}.noise_convs.{i}.bias"))
             self.noise_convs.append(ops.pack_conv(ncw.reshape(ncw.shape[0], 1, -1), ncb, d, f16=self.all_f16))  # raw phase features: keep hi+lo

@@ -138,6 +138,28 @@ def main(argv=None):
                      "algorithmic_bytes_per_frame": wbytes,
                      "note": "whole-frame figure (weights streamed once per frame / wall time of a frame): includes attention, norms, sampling and launch gaps"},
     }
+    if D.world == 1:
+        # time to first audio of ONE streamed utterance (qwen3_tts.py:1426-1465; the reference's published metric: 84.8 ms TTFB at batch 1 on Apple silicon,
+        # 6-bit model): prefill + k frames (talker step + 15 code-predictor steps each) + decoder.streaming_step of those frames
+        pre1 = table[requests[0].long()[None].to(dev)]
+        ttfb = {}
+        for k in (1, 25):   # one frame (80 ms of audio), and the reference's default streaming_interval 2.0 s = 25 frames
+            best = None
+            for _ in range(3):
+                st = codec.new_stream(1)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                it = eng.generate_iter(pre1, trail_all[:1], pad, max(F, k), temperature=0.0, chunk=k)
+                blk = next(it)["block"]
+                wav1 = codec.streaming_step((blk % ccfg.codebook_size).permute(0, 2, 1).contiguous(), st)
+                torch.cuda.synchronize()
+                dt1 = time.perf_counter() - t1
+                it.close()
+                assert wav1.shape[-1] == k * 1920 and eng.frames_generated == k
+                best = dt1 if best is None else min(best, dt1)
+            ttfb["%d_frame%s" % (k, "" if k == 1 else "s")] = 1000.0 * best
+        res["ttfb_ms"] = ttfb
+        res["ttfb_note"] = "one utterance: prefill (%d positions) + k frames + codec streaming_step of those frames, best of 3; audio leaves while the frame loop runs" % args.prompt
     if not args.no_cpu_baseline:
         res["cpu_baseline"] = U.cpu_frame_baseline([(eng.talker.cfg, 1), (eng.cp.cfg, cfg.num_code_groups - 1)], B, context=args.prompt)
     print(json.dumps(res))
