@@ -32,10 +32,10 @@ constexpr int a_images() { return (PREC == 2 || PREC == 4) ? 2 : 1; }
 // PREC 5 = fp16 hi pass + MX lo pass: the lo residual t - fp16(t) as OCP e4m3 bytes with one E8M0 scale byte per window row and 32-channel chunk,
 // multiplied by a second, e4m3 image of the weights (one E8M0 scale per output column) on v_mfma_scale_f32_32x32x64_f8f6f4, which pairs two taps
 // per instruction (K block b of the instruction = the 32 channels of tap 2 p + b) and runs at twice the 16-bit rate.
-// LDS bytes of one staged window of R rows: [hi image R x 64][lo image R x 32][R scale bytes, padded to 16]
+// LDS bytes of one staged window of R rows: [hi image R x 80][lo image R x 48][R scale bytes, padded to 16] (padded pitches instead of a swizzle)
 template <int PREC>
 __host__ __device__ constexpr int window_bytes(const int R) {
-  return PREC == 5 ? R * 96 + ((R + 15) & ~15) : a_images<PREC>() * R * 64;
+  return PREC == 5 ? R * 128 + ((R + 15) & ~15) : a_images<PREC>() * R * 64;   // PREC 5: 80-byte hi rows + 48-byte lo rows (unswizzled, conv_ws4.h)
 }
 // the part of t the first (hi) image carries, as an fp32 value
 template <int PREC>

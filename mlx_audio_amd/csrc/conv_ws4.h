@@ -96,7 +96,11 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
   const int tid = threadIdx.x, lane_k = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int R = q.R;
-  const int ABYTES = R * 64;
+  // PREC 5 keeps its planes UNSWIZZLED at padded pitches -- 80-byte hi rows, 48-byte lo rows: 20 r mod 64 / 12 r mod 64 walk the 4-bank groups
+  // bijectively over any 16 consecutive row residues, so the 16 lanes of a ds_read_b128 group (rows covering all residues mod 16, one 16-byte piece
+  // each) never meet -- and an address is then base + row * pitch: one add per read instead of the ~10 VALU operations of the XOR swizzle
+  constexpr int HP = PREC == 5 ? 80 : 64, LP = 48;
+  const int ABYTES = R * HP;
   const int WBYTES = window_bytes<PREC>(R);  // one staged window: NA 16-bit images (PREC 5: hi image, e4m3 lo image, scale bytes)
   char* Abase = smem;  // [2 buffers][WBYTES]
   const int nch = q.nch, keff = q.keff;
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
               }
               tt[j] = (rowok && (cb + j) < a.Cin) ? u : 0.f;
             }
-            const int addr = r * 64 + ((((c4 >> 3) ^ ((r >> 2) & 3))) << 4) + ((c4 & 4) << 1);
+            const int addr = PREC == 5 ? r * HP + c4 * 2 : r * 64 + ((((c4 >> 3) ^ ((r >> 2) & 3))) << 4) + ((c4 & 4) << 1);
             uint2 ph;
             float hi[4];
             if constexpr (PREC == 5) {  // v_cvt_pk_f16_f32 on the clamped value, v_cvt_f32_f16 back
@@ -257,8 +261,8 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
               pk = __builtin_amdgcn_cvt_pk_fp8_f32(l0 * mul, l1 * mul, pk, false);
               pk = __builtin_amdgcn_cvt_pk_fp8_f32(l2 * mul, l3 * mul, pk, true);
               char* A_l8 = A_hi + ABYTES;
-              *(int*)(A_l8 + r * 32 + ((((c4 >> 4) ^ ((r >> 3) & 1))) << 4) + (c4 & 15)) = pk;
-              if ((ptid & 7) == 0) *(uint8_t*)(A_l8 + R * 32 + r) = (uint8_t)sb;
+              *(int*)(A_l8 + r * LP + c4) = pk;
+              if ((ptid & 7) == 0) *(uint8_t*)(A_l8 + R * LP + r) = (uint8_t)sb;
             }
           }
         }
@@ -438,7 +442,13 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
       // per-item opaque copies of the lane coordinates: LICM otherwise parks ~12 partly computed LDS addresses in VGPRs across the whole tile and
       // the allocator pays for them with an accumulator in scratch; recomputing them costs a handful of VALU operations per 8 MFMAs
       int hlx = hl, hhx = hh;
-      auto fresh = [&]() { asm volatile("" : "+v"(hlx), "+v"(hhx)); };
+      int lbH = 0, lbL = 0, lbS = 0;   // the lane's byte offsets into the hi / lo planes and the scale bytes; everything else of an address is wave-uniform
+      auto fresh = [&]() {
+        asm volatile("" : "+v"(hlx), "+v"(hhx));
+        lbH = (wm * WM + hlx) * HP + hhx * 16;
+        lbL = (wm * WM + hlx) * LP + hhx * 16;
+        lbS = wm * WM + hlx;
+      };
       auto lo4 = [](const i32x8& v) { return __builtin_bit_cast(bf16x8, (i32x4)__builtin_shufflevector(v, v, 0, 1, 2, 3)); };
       auto hi4 = [](const i32x8& v) { return __builtin_bit_cast(bf16x8, (i32x4)__builtin_shufflevector(v, v, 4, 5, 6, 7)); };
       auto set_lo = [](i32x8& q8, const i32x4 v) { q8 = __builtin_shufflevector(v, (i32x4)__builtin_shufflevector(q8, q8, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7); };
@@ -446,9 +456,10 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
       // fragment of group g (kk = g >> 1: 16-channel half of the chunk, mf = g & 1: 32-row half of the wave's rows) under tap tp
       auto rdH = [&](const int g, const int tp) {
         const int kk = g >> 1, mf = g & 1;
-        const int row = wm * WM + mf * 32 + hlx + tp * dil;
-        const int cidx = kk * 2 + hhx;
-        const i32x4 v = *(const i32x4*)(Abase + jbuf * WBYTES + row * 64 + ((cidx ^ ((row >> 2) & 3)) << 4));
+        const int uoff = jbuf * WBYTES + (mf * 32 + tp * dil) * HP + kk * 32;   // wave-uniform
+        int la = lbH;
+        asm volatile("" : "+v"(la));   // one add per read, recomputed: a shared (hoisted) address per (group, tap) costs a register each
+        const i32x4 v = *(const i32x4*)(Abase + (la + uoff));
         if (g == 0) set_lo(qa, v);
         else if (g == 1) set_hi(qa, v);
         else if (g == 2) set_lo(qb, v);
@@ -459,12 +470,13 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
       // finite); scale byte: lanes 0..31 carry K block 0 (tap 2 p), lanes 32..63 K block 1
       auto rdL = [&](const int mf, const int p) {
         const int t1 = 2 * p + 1 < K ? 2 * p + 1 : K - 1;
-        const int rb = wm * WM + mf * 32 + hlx;
-        const int r0 = rb + 2 * p * dil, r1 = rb + t1 * dil;
-        const char* L8 = Abase + jbuf * WBYTES + ABYTES;
-        const i32x4 x0 = *(const i32x4*)(L8 + r0 * 32 + ((hhx ^ ((r0 >> 3) & 1)) << 4));
-        const i32x4 x1 = *(const i32x4*)(L8 + r1 * 32 + ((hhx ^ ((r1 >> 3) & 1)) << 4));
-        const int sc = (int)*(const uint8_t*)(L8 + R * 32 + (hhx ? r1 : r0));
+        const int u0 = mf * 32 + 2 * p * dil, u1 = mf * 32 + t1 * dil;          // wave-uniform row offsets of the two taps
+        const int ubase = jbuf * WBYTES + ABYTES;
+        int la = lbL, ls = lbS;
+        asm volatile("" : "+v"(la), "+v"(ls));
+        const i32x4 x0 = *(const i32x4*)(Abase + (la + (ubase + u0 * LP)));
+        const i32x4 x1 = *(const i32x4*)(Abase + (la + (ubase + u1 * LP)));
+        const int sc = (int)*(const uint8_t*)(Abase + (ls + (ubase + R * LP + (hhx ? u1 : u0))));
         if (mf == 0) { qa = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7); sa = sc; }
         else { qb = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7); sb2 = sc; }
       };

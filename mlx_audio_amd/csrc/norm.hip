@@ -63,26 +63,43 @@ __global__ void adain_finalize_kernel(const mi355_adain_coef_args a) {
 // the sweeps.  The sweeps are latency-bound (one 8-byte read per block, blocks C * 8 bytes apart), so a workgroup takes only CPW = 4 channels and
 // spreads their blocks over 64 lanes each: 8 dependent rounds for the 495 blocks of a 31 681-row utterance instead of 31 with 16 lanes per
 // channel (17.7 -> 7 us at one utterance).  grid (ceil(out_ld / CPW), B).
-constexpr int kAdainCPW = 4, kAdainLanes = 256 / kAdainCPW;
+// Batches (B >= 8) are bandwidth problems instead (64 utterances: 32 MB of partials per call): CPW = 16 -- the 16 channel lanes of a block row read 128
+// contiguous bytes, a full line per request instead of a quarter -- and ONE sweep: a lane keeps its <= kAdainKeep partials in registers between the mean
+// and the M2 passes (longer utterances fall back to the second read).  Round 4: 28.8 -> us per call in the 64-utterance step (profiles/r4_*).
+constexpr int kAdainKeep = 32;
+template <int CPW>
 __global__ __launch_bounds__(256) void adain_from_partials_kernel(const mi355_adain_partials_args a) {
-  __shared__ double red[kAdainCPW][kAdainLanes + 1];
-  const int cl = threadIdx.x % kAdainCPW, eg = threadIdx.x / kAdainCPW;
-  const int c = blockIdx.x * kAdainCPW + cl, b = blockIdx.y;
+  constexpr int LPC = 256 / CPW;   // block lanes per channel
+  __shared__ double red[CPW][LPC + 1];
+  const int cl = threadIdx.x % CPW, eg = threadIdx.x / CPW;
+  const int c = blockIdx.x * CPW + cl, b = blockIdx.y;
   const int len = a.lens ? a.lens[b] : a.L;
   const int nblk = (len + MI355_STATS_ROWS - 1) / MI355_STATS_ROWS;
   const bool cok = c < a.C;
   const float* pb = a.partials + (int64_t)b * a.bstride + (int64_t)(cok ? c : 0) * 2;
   const int64_t estride = (int64_t)a.C * 2;
+  const bool keep = CPW > 4 && nblk <= kAdainKeep * LPC;   // wave-uniform (per utterance)
+  float2 kept[CPW > 4 ? kAdainKeep : 1];
   double s = 0.0;
-  if (cok) {   // two independent loads in flight per lane
-    int e = eg;
-    for (; e + kAdainLanes < nblk; e += 2 * kAdainLanes) s += (double)pb[(int64_t)e * estride] + (double)pb[(int64_t)(e + kAdainLanes) * estride];
-    for (; e < nblk; e += kAdainLanes) s += (double)pb[(int64_t)e * estride];
+  if (cok) {
+    if (keep) {
+#pragma unroll
+      for (int j = 0; j < (CPW > 4 ? kAdainKeep : 1); ++j) {
+        const int e = eg + j * LPC;
+        kept[j] = e < nblk ? *(const float2*)(pb + (int64_t)e * estride) : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < (CPW > 4 ? kAdainKeep : 1); ++j) s += (double)kept[j].x;
+    } else {   // two independent loads in flight per lane
+      int e = eg;
+      for (; e + LPC < nblk; e += 2 * LPC) s += (double)pb[(int64_t)e * estride] + (double)pb[(int64_t)(e + LPC) * estride];
+      for (; e < nblk; e += LPC) s += (double)pb[(int64_t)e * estride];
+    }
   }
   red[cl][eg] = s;
   __syncthreads();
   double tot = 0.0;
-  for (int j = 0; j < kAdainLanes; ++j) tot += red[cl][j];   // every lane of a channel adds the shares in the same order: one value per channel
+  for (int j = 0; j < LPC; ++j) tot += red[cl][j];   // every lane of a channel adds the shares in the same order: one value per channel
   const double mean = len > 0 ? tot / (double)len : 0.0;
   __syncthreads();
   double m2 = 0.0;
@@ -94,12 +111,20 @@ __global__ __launch_bounds__(256) void adain_from_partials_kernel(const mi355_ad
       const double d = me - mean;
       return (double)sv.y + d * d * (double)cnt;
     };
-    int e = eg;
-    for (; e + kAdainLanes < nblk; e += 2 * kAdainLanes) {
-      const float2 v0 = *(const float2*)(pb + (int64_t)e * estride), v1 = *(const float2*)(pb + (int64_t)(e + kAdainLanes) * estride);
-      m2 += term(v0, e) + term(v1, e + kAdainLanes);
+    if (keep) {
+#pragma unroll
+      for (int j = 0; j < (CPW > 4 ? kAdainKeep : 1); ++j) {
+        const int e = eg + j * LPC;
+        if (e < nblk) m2 += term(kept[j], e);
+      }
+    } else {
+      int e = eg;
+      for (; e + LPC < nblk; e += 2 * LPC) {
+        const float2 v0 = *(const float2*)(pb + (int64_t)e * estride), v1 = *(const float2*)(pb + (int64_t)(e + LPC) * estride);
+        m2 += term(v0, e) + term(v1, e + LPC);
+      }
+      for (; e < nblk; e += LPC) m2 += term(*(const float2*)(pb + (int64_t)e * estride), e);
     }
-    for (; e < nblk; e += kAdainLanes) m2 += term(*(const float2*)(pb + (int64_t)e * estride), e);
   }
   red[cl][eg] = m2;
   __syncthreads();
@@ -107,7 +132,7 @@ __global__ __launch_bounds__(256) void adain_from_partials_kernel(const mi355_ad
   float sc = 0.f, sh = 0.f;
   if (cok) {
     double q = 0.0;
-    for (int j = 0; j < kAdainLanes; ++j) q += red[cl][j];
+    for (int j = 0; j < LPC; ++j) q += red[cl][j];
     double var = len > 0 ? q / (double)len : 0.0;
     if (var < 0) var = 0;
     const float rstd = 1.0f / sqrtf((float)var + a.eps);
@@ -211,7 +236,10 @@ extern "C" int mi355_adain_from_partials(const mi355_adain_partials_args* ap, vo
   MI355_REQUIRE(a.B > 0 && a.C > 0 && a.L > 0 && a.out_ld >= a.C, "adain_from_partials: bad shape");
   MI355_CLEAR_ERROR();
   MI355_REQUIRE(a.bstride % 2 == 0 && ((uintptr_t)a.partials) % 8 == 0, "adain_from_partials: partials must be 8-byte aligned");
-  hipLaunchKernelGGL(adain_from_partials_kernel, dim3((a.out_ld + kAdainCPW - 1) / kAdainCPW, a.B), dim3(256), 0, (hipStream_t)stream, a);
+  // (MI355_ADAIN_CPW=4 keeps the latency-shaped kernel at every batch size: A/B aid)
+  static const int cpw_env = getenv("MI355_ADAIN_CPW") ? atoi(getenv("MI355_ADAIN_CPW")) : 0;
+  if (a.B >= 8 && cpw_env != 4) hipLaunchKernelGGL(adain_from_partials_kernel<16>, dim3((a.out_ld + 15) / 16, a.B), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(adain_from_partials_kernel<4>, dim3((a.out_ld + 3) / 4, a.B), dim3(256), 0, (hipStream_t)stream, a);
   MI355_LAUNCH_CHECK("adain_from_partials");
   return MI355_OK;
 }

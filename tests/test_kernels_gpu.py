@@ -380,6 +380,33 @@ def test_conv_gemm_fused_instnorm_statistics(ops, tile):
         assert rel_err(sh[b, :C].cpu(), gb[b, C:].double().cpu() - mean * want_sc) < 2e-5
 
 
+@pytest.mark.parametrize("B,L,C", [(9, 2100, 128), (8, 40000, 200), (16, 70, 64)])
+def test_adain_from_partials_batch_kernel(ops, B, L, C):
+    """B >= 8 takes the bandwidth-shaped instantiation (16 channels per workgroup, the partials kept in registers between the mean and the M2 pass;
+    L = 40 000 -> 625 blocks > 32 x 16 lanes: the re-reading fallback): same coefficients as float64 on the host, ragged lengths included."""
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    lens = torch.randint(max(1, L // 3), L + 1, (B,), generator=g).to(torch.int32)
+    lens[0] = L
+    y = (torch.randn(B, L, C, generator=g) * 2.0 + 5.0)
+    gb = torch.randn(B, 2 * C, generator=g) * 0.3
+    nblk = (L + 63) // 64
+    st = torch.full((B, nblk, C, 2), float("nan"))
+    for b in range(B):
+        n = int(lens[b])
+        for e in range((n + 63) // 64):
+            blk = y[b, e * 64:min(n, (e + 1) * 64)].double()
+            st[b, e, :, 0] = blk.sum(0).float()
+            st[b, e, :, 1] = ((blk - blk.mean(0)) ** 2).sum(0).float()
+    sc, sh = ops.adain_from_partials(st.to(DEV), L, gb.to(DEV), lens.to(DEV))
+    torch.cuda.synchronize()
+    for b in range(B):
+        v = y[b, : int(lens[b])].double()
+        mean, var = v.mean(0), v.var(0, unbiased=False)
+        want_sc = (1 + gb[b, :C].double()) / torch.sqrt(var + 1e-5)
+        assert rel_err(sc[b, :C].cpu(), want_sc) < 2e-6
+        assert rel_err(sh[b, :C].cpu(), gb[b, C:].double() - mean * want_sc) < 2e-6
+
+
 def test_adain_coef(ops):
     g = torch.Generator().manual_seed(11)
     B, L, C = 3, 1000, 514
