@@ -113,7 +113,9 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_ge
       bool ok[4] = {false, false, false, false};
       const int64_t base = (int64_t)a.x_off + (int64_t)gl * a.ldx + c;
       if (VEC) {
-        if (gl >= 0 && gl < len_in && c < a.Cin) {
+        // flattened strided conv on 16-byte aligned runs (flat_valid > 0: validity by flat element index; every bound is a multiple of 4 there)
+        const bool rin = a.flat_valid > 0 ? (base >= 0 && base + 3 < flat_hi) : (gl >= 0 && gl < len_in);
+        if (rin && c < a.Cin) {
           const float4 t = *(const float4*)(xb + base);
           v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
 #pragma unroll
@@ -431,7 +433,8 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
                 "conv_gemm: a quantising prologue (pre_fq) takes no activation, LeakyReLU or Snake");
   if (a.out_scale == 0.f) a.out_scale = 1.f;
   hipStream_t st = (hipStream_t)stream;
-  const bool vec = (a.flat_valid == 0) && (a.ldx % 4 == 0) && (a.x_off % 4 == 0) && (a.x_bstride % 4 == 0) &&
+  // 16-byte loads of four channels: aligned rows; a flattened strided conv (flat_valid > 0) qualifies when its run bounds are multiples of 4 too
+  const bool vec = (a.flat_valid % 4 == 0) && (a.ldx % 4 == 0) && (a.x_off % 4 == 0) && (a.x_bstride % 4 == 0) &&
                    (((uintptr_t)a.x) % 16 == 0);
   if (a.stats_partial) {
     MI355_REQUIRE(a.up_s == 0, "conv_gemm: fused statistics need a plain (non-polyphase) store");

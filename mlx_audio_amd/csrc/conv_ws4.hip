@@ -21,7 +21,7 @@ extern "C" int mi355_conv_ws4_resident(int wgs) {
 }
 
 bool mi355_conv_ws4_eligible(const mi355_conv_gemm_args& a, bool vec) {
-  if (!vec || a.Lin <= 0) return false;
+  if (!vec || a.Lin <= 0 || a.flat_valid != 0) return false;   // (flattened strided convs: the producers mask by row, not by flat element index)
   if (a.precision == 5)   // conv mode only (K == 1 layers included), K odd with an even number of tap pairs, 128-column tiles
     return a.K % 4 == 3 && 128 + (a.K - 1) * a.dil <= 192 && a.Cout > 64 && !a.pre_fq && (pre_kind(a) == P_NONE || pre_kind(a) == P_LEAKY || pre_kind(a) == P_SNAKE) &&
            epi_family(a) == 0;

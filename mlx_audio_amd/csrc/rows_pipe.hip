@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void rows_finish_kernel(const mi355_rows_finis
   float mean = 0.f, rstd = 1.f;
   if (a.norm) {   // two-pass statistics of the finished row
     if (a.norm == 1) {
-      const float s = wave_sum(lsum);
+      const float s = wave_sum_fast(lsum);   // every lane is here (no early exit above): the DPP reduction
       if (lane == 0) sred[wave] = s;
       __syncthreads();
       mean = ((sred[0] + sred[1]) + (sred[2] + sred[3])) / (float)No;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void rows_finish_kernel(const mi355_rows_finis
       for (int e = 0; e < 8; ++e)
         if (p < npieces && 8 * p + e < No) { const float d = v[it][e] - mean; q += d * d; }
     }
-    q = wave_sum(q);
+    q = wave_sum_fast(q);
     if (lane == 0) sred[4 + wave] = q;
     __syncthreads();
     const float var = ((sred[4] + sred[5]) + (sred[6] + sred[7])) / (float)No;

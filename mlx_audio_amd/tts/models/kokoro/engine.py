@@ -346,7 +346,12 @@ class KokoroEngine:
             self.ups.append(ops.pack_conv_transpose(w_t, self._q(self._t(f"{g}.ups.{i}.bias")), u, d, f16=self.precision == 3 or self.all_f16))
             ncw = self._q(self._t(f"{g}.noise_convs.{i}.weight"))  # (cout, K, n_fft+2)
             ncb = self._q(self._t(f"{g}.noise_convs.{i}.bias"))
-            self.noise_convs.append(ops.pack_conv(ncw.reshape(ncw.shape[0], 1, -1), ncb, d, f16=self.all_f16))  # raw phase features: keep hi+lo
+            # the harmonic features live in rows of round_up(n_fft + 2, 4) floats (22 -> 24: 16-byte aligned rows, so the strided noise conv reads its
+            # taps as float4 runs instead of scalars); the pad columns are zero on both sides
+            nbp = ops.round_up(ncw.shape[2], 4)
+            ncwp = torch.zeros((ncw.shape[0], ncw.shape[1], nbp), dtype=ncw.dtype)
+            ncwp[:, :, : ncw.shape[2]] = ncw
+            self.noise_convs.append(ops.pack_conv(ncwp.reshape(ncw.shape[0], 1, -1) if ncw.shape[1] > 1 else ncw, ncb, d, f16=self.all_f16))  # raw phase features: keep hi+lo
             last = i + 1 == len(self.rates)
             self.noise_res.append(self._resblock1(self.bank_dec, f"{g}.noise_res.{i}", cout, 11 if last else 7, (1, 3, 5)))
             for j in range(nk):
@@ -730,8 +735,9 @@ class KokoroEngine:
         har_src = ops.sine_source(f0_curve, rand_ini, noise, self.src_w, self.src_b, up, lens2=lens_2f,
                                   quant=bool(self.qmods) and self._isq(f"{g_n}.m_source.l_linear"), coarse_f32=self.coarse_f32)
         nb2 = self.n_fft + 2
+        nbp = ops.round_up(nb2, 4)
         n_har = L2 * up // self.hop + 1
-        har = self._new(B, n_har, nb2)
+        har = self._new(B, n_har, nbp, zero=True)[:, :, :nb2]   # rows of nbp floats, pad columns zero (see the noise convs' weight images)
         lens_samples = frames * (2 * up) if ragged else None
         ops.stft_magphase(har_src, self.n_fft, self.hop, self.window, har, lens=lens_samples)
         if "har" in overrides:
@@ -749,12 +755,12 @@ class KokoroEngine:
             # harmonic branch
             xsrc = self._new(B, Lo, cout)
             har_i = har
-            if self.qmods and self._isq(f"{g_n}.noise_convs.{i}"):  # contiguous copy: the strided noise conv reads its taps as one flat run
-                har_i = ops.fake_quant_u8(har, y=torch.zeros_like(har), lens=lens_har)
+            if self.qmods and self._isq(f"{g_n}.noise_convs.{i}"):  # a copy in the same padded row layout: the strided noise conv reads its taps as one flat run
+                har_i = ops.fake_quant_u8(har, y=self._new(B, n_har, nbp, zero=True)[:, :, :nb2], lens=lens_har)
             if not last:
                 sf = int(np.prod(self.rates[i + 1:]))
                 self._conv(har_i, self.noise_convs[i], xsrc, lens_in=lens_har, lens_out=lens_o,
-                           flat=dict(ldx=sf * nb2, x_off=-((sf + 1) // 2) * nb2, channels=nb2))
+                           flat=dict(ldx=sf * nbp, x_off=-((sf + 1) // 2) * nbp, channels=nbp))
             else:
                 self._conv(har_i, self.noise_convs[i], xsrc, lens_in=lens_har, lens_out=lens_o)
             if return_intermediates:
