@@ -181,6 +181,21 @@ __device__ __forceinline__ float wave_sum_fast(float v) {
   const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
   return (r0 + r1) + (r2 + r3);
 }
+// The rotary pair and the per-head sum of squares with their roundings PINNED (no fp contraction): three kernels apply them (head_norm_rope_kernel,
+// the fused decode-attention prologue, the q|k|v GEMV epilogue) and the tests hold their cache rows bit-equal -- with contraction left to the compiler
+// the choice of which product joins the fma followed the code around the expression (it changed when the operands' loads were moved, round 4).
+// (x * cos) + (rotate(x) * sin): each term rounded like the reference's separate multiplies and add.
+__device__ __forceinline__ void rope_pair(const float x0, const float x1, const float c, const float s, float& y0, float& y1) {
+#pragma clang fp contract(off)
+  const float p0 = x0 * c, p1 = x1 * s, p2 = x1 * c, p3 = x0 * s;
+  y0 = p0 - p1;
+  y1 = p2 + p3;
+}
+__device__ __forceinline__ float sumsq2(const float x0, const float x1) {
+#pragma clang fp contract(off)
+  const float p0 = x0 * x0, p1 = x1 * x1;
+  return p0 + p1;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -350,6 +350,134 @@ __global__ __launch_bounds__(256) void conv_split_finish_kernel(const mi355_conv
   }
 }
 
+// conv_split_finish_lean_kernel: the same sums, epilogue and statistics for the plain store (no polyphase upsampling) with C_out a multiple of 4
+// and 16-byte aligned operands -- every linear / conv of the one-utterance configuration except the generator's two transposed convs -- as
+// straight-line code.  In conv_split_finish_kernel every guarded load (`rok ? *p : 0`, `a.bias ? ... : 0`, `rb ? rb[...] : 0`, the accumulate
+// read) compiles to a branch with its own s_waitcnt vmcnt(0): ~70 serial round trips in the generated code, 11-14 us per launch for a 64 x 64
+// block, 116 launches = 1.36 ms of the 7.6 ms one-utterance pass (profiles/r3_kernel_stats_b1_bygrid_call44.txt).  Here every load is
+// unconditional (rows / columns past the block clamp to valid ones, null operands read the slab instead) and 16 bytes wide, all requested before
+// the first use; only the stores are predicated.
+__global__ __launch_bounds__(256) void conv_split_finish_lean_kernel(const mi355_conv_gemm_args a, const float* __restrict__ part, const int ksplit,
+                                                                     const int64_t slab, const int ldp) {
+  __shared__ float sst[16][64][3];
+  const int tid = threadIdx.x, c4 = tid & 15, r16 = tid >> 4;
+  const int b = blockIdx.z, nb = blockIdx.y * 64 + 4 * c4, row0 = blockIdx.x * 64;
+  const int len_out = a.lens_out ? a.lens_out[b] : a.Lout;
+  if (row0 >= len_out) return;   // workgroup-uniform
+  const bool colok = nb < a.Cout;                       // C_out % 4 == 0: the piece is whole or absent
+  const int nbc = colok ? nb : a.Cout - 4;
+  const float* const pb = part + (int64_t)b * ksplit * slab + nbc;
+  const bool has_bias = a.bias != nullptr, has_cs = a.post_colscale != nullptr, has_res = a.res != nullptr;
+  int urow[4];
+  bool rok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int u = row0 + r16 + 16 * i;
+    rok[i] = colok && u < len_out;
+    urow[i] = u < len_out ? u : len_out - 1;
+  }
+  const float4 bias4 = *(const float4*)(has_bias ? a.bias + nbc : pb + (int64_t)urow[0] * ldp);
+  const float4 cs4 = *(const float4*)(has_cs ? a.post_colscale + nbc : pb + (int64_t)urow[0] * ldp);
+  float* const yb = a.y + (int64_t)b * a.y_bstride + nbc;
+  float4 res4[4], old4[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float* const dummy = pb + (int64_t)urow[i] * ldp;
+    res4[i] = *(const float4*)(has_res ? a.res + (int64_t)b * a.res_bstride + (int64_t)(urow[i] >> a.res_shift) * a.ldr + nbc : dummy);
+    old4[i] = *(const float4*)(a.accumulate ? yb + (int64_t)urow[i] * a.ldy : dummy);
+  }
+  float4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto add4 = [](float4& s, const float4 t) { s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; };
+  int g = 0;
+  for (; g + 2 <= ksplit; g += 2) {   // eight loads in flight, added in slab order
+    float4 t[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[u][i] = *(const float4*)(pb + (int64_t)(g + u) * slab + (int64_t)urow[i] * ldp);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) add4(acc[i], t[u][i]);
+  }
+  for (; g < ksplit; ++g) {
+    float4 t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = *(const float4*)(pb + (int64_t)g * slab + (int64_t)urow[i] * ldp);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) add4(acc[i], t[i]);
+  }
+  const float bias[4] = {bias4.x, bias4.y, bias4.z, bias4.w}, cscale[4] = {cs4.x, cs4.y, cs4.z, cs4.w};
+  float pv[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    pv[i][0] = acc[i].x + (has_bias ? bias[0] : 0.f); pv[i][1] = acc[i].y + (has_bias ? bias[1] : 0.f);
+    pv[i][2] = acc[i].z + (has_bias ? bias[2] : 0.f); pv[i][3] = acc[i].w + (has_bias ? bias[3] : 0.f);
+  }
+  auto each = [&](auto f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pv[i][e] = f(pv[i][e]);
+  };
+  switch (a.post_act) {   // one switch around the 16 values, not 16 switches
+    case MI355_ACT_LEAKY: each([&](float v) { return v > 0.f ? v : v * a.post_slope; }); break;
+    case MI355_ACT_GELU: each([](float v) { return gelu_erf(v); }); break;
+    case MI355_ACT_SILU: each([](float v) { return v / (1.0f + expf(-v)); }); break;
+    case MI355_ACT_GELU_TANH: each([](float v) { return gelu_tanh(v); }); break;
+    case MI355_ACT_ELU: each([](float v) { return v > 0.f ? v : expm1f(v); }); break;
+    case MI355_ACT_TANH: each([](float v) { return tanhf(v); }); break;
+    default: break;
+  }
+  float sK[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  int cnt[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float rv4[4] = {res4[i].x, res4[i].y, res4[i].z, res4[i].w}, ov4[4] = {old4[i].x, old4[i].y, old4[i].z, old4[i].w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float rv = has_res ? rv4[e] : 0.f;
+      if (a.accumulate) rv += ov4[e];
+      const float v = (pv[i][e] * (has_cs ? cscale[e] : 1.f) + rv) * a.out_scale;
+      o[e] = v;
+      if (rok[i]) {   // the running statistics of conv_split_finish_kernel, same order
+        sK[e] = cnt[e] == 0 ? v : sK[e];
+        const float d = v - sK[e];
+        s1[e] += d;
+        s2[e] += d * d;
+        ++cnt[e];
+      }
+    }
+    if (rok[i]) *(float4*)(yb + (int64_t)urow[i] * a.ldy) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  if (!a.stats_partial) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float cl = (float)cnt[e];
+    sst[r16][4 * c4 + e][0] = cl;
+    sst[r16][4 * c4 + e][1] = cnt[e] ? sK[e] + s1[e] / cl : 0.f;
+    sst[r16][4 * c4 + e][2] = cnt[e] ? s2[e] - s1[e] * s1[e] / cl : 0.f;
+  }
+  __syncthreads();
+  const int n = blockIdx.y * 64 + tid;
+  if (tid < 64 && n < a.Cout) {
+    float ct = sst[0][tid][0], mt = sst[0][tid][1], vt = sst[0][tid][2];
+    for (int j = 1; j < 16; ++j) {
+      const float cj = sst[j][tid][0], mj = sst[j][tid][1], vj = sst[j][tid][2];
+      if (cj > 0.f) {
+        const float cn = ct + cj, dm = mj - mt;
+        vt = vt + vj + (ct > 0.f ? dm * dm * ct * cj / cn : 0.f);
+        mt = (mt * ct + mj * cj) / cn;
+        ct = cn;
+      }
+    }
+    *(float2*)(a.stats_partial + (int64_t)b * a.stats_bstride + ((int64_t)blockIdx.x * a.Cout + n) * 2) = make_float2(mt * ct, vt);
+  }
+}
+
 // chunk groups for a launch of `wgs` tiles (0 = do not split): enough workgroups for two per CU, at least `min_steps` (chunk, tap) steps per group
 int split_groups(const long wgs, const int nchunks, const int K, const long rows_total, const int Cout, const int64_t ws_bytes, const int forced) {
   if (nchunks < 2) return 0;
@@ -396,7 +524,12 @@ int launch_split(const mi355_conv_gemm_args& a, hipStream_t st, const int ks) {
   MI355_CLEAR_ERROR();
   hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, PREC, true, true>), dim3((a.Lout + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.B * ks), dim3(kThreads), lds, st, p, sg);
   MI355_LAUNCH_CHECK("conv_gemm (split)");
-  hipLaunchKernelGGL(conv_split_finish_kernel, dim3((a.Lout + 63) / 64, (a.Cout + 63) / 64, a.B), dim3(256), 0, st, a, (const float*)a.split_ws, ks, slab, ldp);
+  static const bool lean_off = getenv("MI355_CONV_FINISH_OLD") != nullptr && getenv("MI355_CONV_FINISH_OLD")[0] == '1';   // A/B knob
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  const bool lean = !lean_off && !a.up_s && a.Cout % 4 == 0 && al16(a.bias) && al16(a.post_colscale) && al16(a.res) && al16(a.y) && al16(a.split_ws) &&
+                    a.ldy % 4 == 0 && a.y_bstride % 4 == 0 && (!a.res || (a.ldr % 4 == 0 && a.res_bstride % 4 == 0));
+  if (lean) hipLaunchKernelGGL(conv_split_finish_lean_kernel, dim3((a.Lout + 63) / 64, (a.Cout + 63) / 64, a.B), dim3(256), 0, st, a, (const float*)a.split_ws, ks, slab, ldp);
+  else hipLaunchKernelGGL(conv_split_finish_kernel, dim3((a.Lout + 63) / 64, (a.Cout + 63) / 64, a.B), dim3(256), 0, st, a, (const float*)a.split_ws, ks, slab, ldp);
   MI355_LAUNCH_CHECK("conv_gemm (split finish)");
   return MI355_OK;
 }
@@ -434,8 +567,9 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
   if (a.out_scale == 0.f) a.out_scale = 1.f;
   hipStream_t st = (hipStream_t)stream;
   // 16-byte loads of four channels: aligned rows; a flattened strided conv (flat_valid > 0) qualifies when its run bounds are multiples of 4 too
+  static const bool novec_flat = getenv("MI355_CONV_NOVEC_FLAT") != nullptr && getenv("MI355_CONV_NOVEC_FLAT")[0] == '1';   // A/B knob
   const bool vec = (a.flat_valid % 4 == 0) && (a.ldx % 4 == 0) && (a.x_off % 4 == 0) && (a.x_bstride % 4 == 0) &&
-                   (((uintptr_t)a.x) % 16 == 0);
+                   (((uintptr_t)a.x) % 16 == 0) && !(novec_flat && a.flat_valid > 0);
   if (a.stats_partial) {
     MI355_REQUIRE(a.up_s == 0, "conv_gemm: fused statistics need a plain (non-polyphase) store");
     MI355_REQUIRE(a.stats_bstride % 2 == 0 && ((uintptr_t)a.stats_partial) % 8 == 0, "conv_gemm: stats_partial must be 8-byte aligned");

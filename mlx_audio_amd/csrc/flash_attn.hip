@@ -474,6 +474,23 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
   __shared__ float ks_new[DH], vs_new[DH];
   const bool fused = a.new_k != nullptr;
   const float qsc = a.scale * kLog2e;
+  // The per-head norm weights and the rotary table entries of this lane's pair are requested HERE, with the raw q | k | v loads, and
+  // unconditionally (a missing operand reads the q row instead -- valid memory -- and is dropped by a select): behind the first barrier they were
+  // two more dependent L2 round trips of a launch whose whole work is a few of them (one decode step of CSM's depth decoder: 8 workgroups).
+  constexpr int half_dh = DH / 2;
+  const bool pf_act = lane < half_dh;
+  const int pf_i0 = pf_act ? (a.rope_mode == 1 ? 2 * lane : lane) : 0, pf_i1 = pf_act ? (a.rope_mode == 1 ? 2 * lane + 1 : lane + half_dh) : 0;
+  const float* const pf_dummy = a.q + (int64_t)b * a.q_bstride + (int64_t)qi * a.ldq + h * DH;
+  const float* const pf_nwp = fused ? (wave == 0 ? a.q_norm_w : a.k_norm_w) : nullptr;
+  const bool pf_has_nw = pf_nwp != nullptr, pf_has_rope = fused && a.rope_cos != nullptr;
+  int pf_pos = 0;
+  if (pf_has_rope) {
+    pf_pos = (a.lens_k ? len_k - 1 : a.rope_pos) - (a.k_start ? a.k_start[b] : 0);   // slot caches: every item is at its own position
+    pf_pos = pf_pos < 0 ? 0 : (pf_pos >= a.rope_rows ? a.rope_rows - 1 : pf_pos);
+  }
+  const float pf_nw0 = (pf_has_nw ? pf_nwp : pf_dummy)[pf_i0], pf_nw1 = (pf_has_nw ? pf_nwp : pf_dummy)[pf_i1];
+  const float pf_cos = (pf_has_rope ? a.rope_cos + (int64_t)pf_pos * half_dh : pf_dummy)[pf_act ? lane : 0];
+  const float pf_sin = (pf_has_rope ? a.rope_sin + (int64_t)pf_pos * half_dh : pf_dummy)[pf_act ? lane : 0];
   if (!fused) {
     for (int t = tid; t < DH; t += NW * 64) qs[t] = a.q[(int64_t)b * a.q_bstride + (int64_t)qi * a.ldq + h * DH + t] * qsc;
   } else {
@@ -516,16 +533,14 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
       float x0 = 0.f, x1 = 0.f;
       if (act) { x0 = vec[i0]; x1 = vec[i1]; }
       if (nw) {
-        const float ss = wave_sum(x0 * x0 + x1 * x1);
+        const float ss = wave_sum(sumsq2(x0, x1));
         const float r = rsqrtf(ss / (float)DH + a.norm_eps);
-        if (act) { x0 = x0 * r * nw[i0]; x1 = x1 * r * nw[i1]; }
+        if (act) { x0 = x0 * r * pf_nw0; x1 = x1 * r * pf_nw1; }
       }
       if (a.rope_cos && act) {
-        int pos = (a.lens_k ? len_k - 1 : a.rope_pos) - (a.k_start ? a.k_start[b] : 0);   // slot caches: every item is at its own position
-        pos = pos < 0 ? 0 : (pos >= a.rope_rows ? a.rope_rows - 1 : pos);
-        const float c = a.rope_cos[(int64_t)pos * half + lane], sn = a.rope_sin[(int64_t)pos * half + lane];
-        const float y0 = x0 * c - x1 * sn;
-        const float y1 = x1 * c + x0 * sn;
+        const float c = pf_cos, sn = pf_sin;
+        float y0, y1;
+        rope_pair(x0, x1, c, sn, y0, y1);
         x0 = y0; x1 = y1;
       }
       wave_lds_sync2();
@@ -559,29 +574,60 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
     // 16 bytes (64 lines) -- the row-per-lane pattern is bound by the address unit (one line per clock), not by bandwidth.  Lane (g, sub) of a
     // 16-key pass owns floats [i*16 + sub*4, +4) of key g for i = 0 .. DH/16; two xor-shuffles finish the dot product; the 64 scores of the
     // chunk are redistributed one per lane through LDS.
+    // fp32 caches: the chunk's first 16 value rows are requested together with its keys (their addresses depend on neither the scores nor the
+    // softmax): a short key range -- a decode step of CSM's depth decoder attends over <= 32 positions -- then costs one round trip, not three
+    constexpr int VB = (NW == 16 && DH == 128) ? 8 : 16;   // the 1024-thread instantiation has 128 registers per lane
+    float vpre[VB][ND];
+    if constexpr (KVT == 0) {
+      const int nn = kend - kb < 64 ? kend - kb : 64;
+#pragma unroll
+      for (int u = 0; u < VB; ++u) {
+        const float* vrow = vbase + (int64_t)(kb + (u < nn ? u : nn - 1)) * a.ldv;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) vpre[u][i] = vrow[i * 64 + lane];
+      }
+    }
     {
+      // The four 16-key passes of a chunk go in groups of PG whose loads are ALL requested before the first is used (as one rolled sequence the
+      // passes shared their registers and every pass waited for its own loads: four serial round trips per chunk); a group with no visible key
+      // is skipped (wave-uniform) and scores -inf.
+      constexpr int PG = DH == 64 ? 4 : 2;
       const int sub = lane & 3, grp = lane >> 2;
 #pragma unroll
-      for (int p4 = 0; p4 < 4; ++p4) {
-        const int key = kb + p4 * 16 + grp;
-        const bool valid = key < kend;
-        kvp krow = kbase + (int64_t)(valid ? key : kend - 1) * a.ldk + sub * 4;
-        float4 kv[DH / 16];
+      for (int pg = 0; pg < 4; pg += PG) {
+        if (kb + pg * 16 >= kend) {
+          if (sub == 0) {
 #pragma unroll
-        for (int i = 0; i < DH / 16; ++i) kv[i] = kv_load4<KVT>(krow + i * 16);
-        float t0 = 0.f, t1 = 0.f;
-#pragma unroll
-        for (int i = 0; i < DH / 16; ++i) {
-          const int d = i * 16 + sub * 4;
-          t0 = fmaf(qs[d], kv[i].x, t0);
-          t1 = fmaf(qs[d + 1], kv[i].y, t1);
-          t0 = fmaf(qs[d + 2], kv[i].z, t0);
-          t1 = fmaf(qs[d + 3], kv[i].w, t1);
+            for (int u = 0; u < PG; ++u) ps[wave][(pg + u) * 16 + grp] = -INFINITY;
+          }
+          continue;
         }
-        float t = t0 + t1;
-        t += __shfl_xor(t, 1, 64);
-        t += __shfl_xor(t, 2, 64);
-        if (sub == 0) ps[wave][p4 * 16 + grp] = valid ? t : -INFINITY;
+        float4 kv[PG][DH / 16];
+        bool valid[PG];
+#pragma unroll
+        for (int u = 0; u < PG; ++u) {
+          const int key = kb + (pg + u) * 16 + grp;
+          valid[u] = key < kend;
+          kvp krow = kbase + (int64_t)(valid[u] ? key : kend - 1) * a.ldk + sub * 4;
+#pragma unroll
+          for (int i = 0; i < DH / 16; ++i) kv[u][i] = kv_load4<KVT>(krow + i * 16);
+        }
+#pragma unroll
+        for (int u = 0; u < PG; ++u) {
+          float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+          for (int i = 0; i < DH / 16; ++i) {
+            const int d = i * 16 + sub * 4;
+            t0 = fmaf(qs[d], kv[u][i].x, t0);
+            t1 = fmaf(qs[d + 1], kv[u][i].y, t1);
+            t0 = fmaf(qs[d + 2], kv[u][i].z, t0);
+            t1 = fmaf(qs[d + 3], kv[u][i].w, t1);
+          }
+          float t = t0 + t1;
+          t += __shfl_xor(t, 1, 64);
+          t += __shfl_xor(t, 2, 64);
+          if (sub == 0) ps[wave][(pg + u) * 16 + grp] = valid[u] ? t : -INFINITY;
+        }
       }
     }
     wave_lds_sync2();
@@ -600,17 +646,23 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
     // p.V: 8 value rows in flight per step (a rolled loop keeps ONE load in flight and serialises 64 L2 latencies per chunk: that, not
     // bandwidth, was what made the 1500-key cross-attention step take 42 us)
     if constexpr (KVT == 0) {
-      for (int jj = 0; jj < n; jj += 8) {
-        float vv[8][ND];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < VB; ++u) {   // the rows requested with the keys
+        const float pj = u < n ? ps[wave][u] : 0.f;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) o[i] = fmaf(pj, vpre[u][i], o[i]);
+      }
+      for (int jj = VB; jj < n; jj += VB) {
+        float vv[VB][ND];
+#pragma unroll
+        for (int u = 0; u < VB; ++u) {
           const int j = jj + u < n ? jj + u : n - 1;
           const float* vrow = vbase + (int64_t)(kb + j) * a.ldv;
 #pragma unroll
           for (int i = 0; i < ND; ++i) vv[u][i] = vrow[i * 64 + lane];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < VB; ++u) {
           const float pj = jj + u < n ? ps[wave][jj + u] : 0.f;
 #pragma unroll
           for (int i = 0; i < ND; ++i) o[i] = fmaf(pj, vv[u][i], o[i]);

@@ -35,14 +35,10 @@ __device__ __forceinline__ float gemv_act(float v, int act, float slope) {
   }
 }
 
-// wave-level reduction of the per-lane partial sums + the epilogue (bias, activation, LayerScale, residual, SwiGLU, split destinations)
+// the epilogue of NC complete column sums starting at column n0 (bias, activation, LayerScale, residual, SwiGLU, rotary pair, split destinations),
+// executed by whichever lane holds them
 template <int MT, int NC>
-__device__ __forceinline__ void gemv_finish(const mi355_gemv_args& a, float (&acc)[NC][MT], const int n0, const int lane) {
-#pragma unroll
-  for (int c = 0; c < NC; ++c)
-#pragma unroll
-    for (int m = 0; m < MT; ++m) acc[c][m] = wave_sum_fast(acc[c][m]);   // called by whole waves
-  if (lane != 0) return;
+__device__ __forceinline__ void gemv_epilogue(const mi355_gemv_args& a, float (&acc)[NC][MT], const int n0) {
   if (a.glu) {  // columns come in (gate, up) pairs: NC is even on this path
 #pragma unroll
     for (int c = 0; c + 1 < NC; c += 2) {
@@ -69,8 +65,8 @@ __device__ __forceinline__ void gemv_finish(const mi355_gemv_args& a, float (&ac
       for (int m = 0; m < MT; ++m) {
         if (m >= a.M) break;
         const float x0 = acc[0][m] * w0 + b0, x1 = acc[1][m] * w1 + b1;
-        const float y0 = x0 * cs - x1 * sn;   // (x * cos) + (rotate(x) * sin), like head_norm_rope_kernel
-        const float y1 = x1 * cs + x0 * sn;
+        float y0, y1;
+        rope_pair(x0, x1, cs, sn, y0, y1);    // (x * cos) + (rotate(x) * sin), the roundings of head_norm_rope_kernel
         if (a.y2 && n0 >= a.split) {
           store_kv_elem(a.y2, (int64_t)m * a.ldy2 + (n0 - a.split), y0 * a.out_scale, a.y2_dtype);
           store_kv_elem(a.y2, (int64_t)m * a.ldy2 + (n0 + 1 - a.split), y1 * a.out_scale, a.y2_dtype);
@@ -98,6 +94,17 @@ __device__ __forceinline__ void gemv_finish(const mi355_gemv_args& a, float (&ac
       else a.y[(int64_t)m * a.ldy + n] = v * a.out_scale;
     }
   }
+}
+
+// wave-level reduction of the per-lane partial sums + the epilogue in lane 0
+template <int MT, int NC>
+__device__ __forceinline__ void gemv_finish(const mi355_gemv_args& a, float (&acc)[NC][MT], const int n0, const int lane) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[c][m] = wave_sum_fast(acc[c][m]);   // called by whole waves
+  if (lane != 0) return;
+  gemv_epilogue<MT, NC>(a, acc, n0);
 }
 
 template <int MT, int NC, int WT>
@@ -520,6 +527,150 @@ __global__ __launch_bounds__(256) void gemv1_res_kernel(const mi355_gemv_args a,
 }
 
 
+// gemv1_stream_kernel: gemv1_res_kernel's arithmetic with a memory schedule that has ONE dependent round trip.  The old loop's loads sat under
+// `k < K` / `g + gstep < ngroups` branches; at every control-flow join the compiler's wait-count pass has to assume the path with the fewest
+// younger loads, so each group's data was awaited with s_waitcnt vmcnt(0) -- the prefetched NEXT group included -- and every group then paid its
+// own epilogue round trip (bias / residual loads -> store) in lane 0: ~3.5 us per 8 KB group and wave, whatever the bandwidth.  Here
+//  * every load is unconditional (out-of-range k / groups are clamped to a valid address, x is zeroed instead): the loop body is straight-line
+//    code and the waits are exact (vmcnt = the loads of the younger group);
+//  * a wave owns a CONTIGUOUS run of <= 64 groups and parks group i's finished sums in lane i; after the last group the lanes run the
+//    epilogue side by side: its loads and stores are coalesced over the run and are awaited once per wave, not once per group.
+template <int NC, int WT, bool NT, bool HALF>
+__global__ __launch_bounds__(256) void gemv1_stream_kernel(const mi355_gemv_args a, const int ngroups, const int gpw) {
+  constexpr int EPL = mi355_wt<WT>::EPL, ESZ = 16 / EPL, SL = 64 * EPL;
+  constexpr int NIT = 2048 / (64 * 8) / (EPL / 8) / (HALF ? 2 : 1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int K = a.K;
+  const int g0 = (blockIdx.x * 4 + wave) * gpw;
+  if (g0 >= ngroups) return;                     // wave-uniform; the kernel has no barrier
+  const int G = ngroups - g0 < gpw ? ngroups - g0 : gpw;
+  const float* xrow = a.x_ids ? a.x + ((int64_t)a.x_ids[0] + a.x_id_offset) * a.ldx : a.x;
+  int koff[NIT];          // element offset of this lane's piece of slice it (clamped into the row), and whether it is real
+  bool kin[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int k = it * SL + lane * EPL;
+    kin[it] = k < K;
+    koff[it] = kin[it] ? k : 0;
+  }
+  float xr[NIT][EPL];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+#pragma unroll
+    for (int j4 = 0; j4 < EPL / 4; ++j4) {
+      const float4 t = *(const float4*)(xrow + koff[it] + 4 * j4);
+      xr[it][4 * j4] = t.x; xr[it][4 * j4 + 1] = t.y; xr[it][4 * j4 + 2] = t.z; xr[it][4 * j4 + 3] = t.w;
+    }
+  }
+  float4 nwq[NIT][EPL / 4];
+  // the norm weights are requested with x, UNCONDITIONALLY (a launch without them re-reads x instead and never uses the values): a load under a
+  // branch whose other side supplies constants compiles to register copies inside the branch, i.e. an s_waitcnt before the weight stream starts
+  const bool has_nw = a.norm && a.norm_weight;
+  const float* nwp = has_nw ? a.norm_weight : xrow;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+#pragma unroll
+    for (int j4 = 0; j4 < EPL / 4; ++j4) nwq[it][j4] = *(const float4*)(nwp + koff[it] + 4 * j4);
+  uint4 ring0[NIT][NC], ring1[NIT][NC];
+  auto issue = [&](int gi, uint4 (&dst)[NIT][NC]) {
+    const int g = g0 + (gi < G ? gi : G - 1);    // past the run: the last group again (an L1 / L2 hit), never a branch
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int n = g * NC + c < a.N ? g * NC + c : a.N - 1;
+      const uint8_t* wrow = (const uint8_t*)a.w + (int64_t)n * a.ldw * ESZ;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) dst[it][c] = ldw16<NT>(wrow + (int64_t)koff[it] * ESZ);
+    }
+  };
+  issue(0, ring0);
+  issue(1, ring1);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+    if (!kin[it]) {
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) xr[it][j] = 0.f;
+    }
+  if (a.norm) {
+    float mean = 0.f;
+    if (a.norm == 1) {
+      float s = 0.f;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) s += xr[it][j];
+      mean = wave_sum_fast(s) / (float)K;
+    }
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) {
+        const float d = kin[it] ? xr[it][j] - mean : 0.f;
+        q += d * d;
+      }
+    const float var = wave_sum_fast(q) / (float)K;
+    const float rstd = a.norm == 1 ? 1.0f / sqrtf(var + a.norm_eps) : rsqrtf(var + a.norm_eps);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+#pragma unroll
+      for (int j4 = 0; j4 < EPL / 4; ++j4) {
+        const float4 w4 = has_nw ? nwq[it][j4] : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        xr[it][4 * j4] = kin[it] ? (xr[it][4 * j4] - mean) * rstd * w4.x + b4.x : 0.f;
+        xr[it][4 * j4 + 1] = kin[it] ? (xr[it][4 * j4 + 1] - mean) * rstd * w4.y + b4.y : 0.f;
+        xr[it][4 * j4 + 2] = kin[it] ? (xr[it][4 * j4 + 2] - mean) * rstd * w4.z + b4.z : 0.f;
+        xr[it][4 * j4 + 3] = kin[it] ? (xr[it][4 * j4 + 3] - mean) * rstd * w4.w + b4.w : 0.f;
+      }
+    }
+    if (a.norm_bias) {   // a LayerNorm's bias comes late, under one branch (loads behind the stream's first two groups: that stack's first wait is vmcnt(0))
+      float4 nb[NIT][EPL / 4];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int j4 = 0; j4 < EPL / 4; ++j4) nb[it][j4] = *(const float4*)(a.norm_bias + koff[it] + 4 * j4);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int j4 = 0; j4 < EPL / 4; ++j4) {
+          xr[it][4 * j4] += kin[it] ? nb[it][j4].x : 0.f;
+          xr[it][4 * j4 + 1] += kin[it] ? nb[it][j4].y : 0.f;
+          xr[it][4 * j4 + 2] += kin[it] ? nb[it][j4].z : 0.f;
+          xr[it][4 * j4 + 3] += kin[it] ? nb[it][j4].w : 0.f;
+        }
+    }
+  }
+  float mine[NC][1];      // lane i: the sums of group g0 + i
+#pragma unroll
+  for (int c = 0; c < NC; ++c) mine[c][0] = 0.f;
+  auto consume = [&](uint4 (&src)[NIT][NC], int gi) {
+    float acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        float wf[EPL];
+        cvt_w16<WT>(src[it][c], wf);
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) acc[c] = fmaf(xr[it][j], wf[j], acc[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float t = wave_sum_fast(acc[c]);
+      mine[c][0] = lane == gi ? t : mine[c][0];
+    }
+  };
+  for (int gi = 0; gi < G; gi += 2) {
+    consume(ring0, gi);
+    issue(gi + 2, ring0);
+    consume(ring1, gi + 1);     // gi + 1 == G: a repeat of the last group, parked in a lane the epilogue does not run
+    issue(gi + 3, ring1);
+  }
+  if (lane < G) gemv_epilogue<1, NC>(a, mine, (g0 + lane) * NC);
+}
+
 // gemv1_attn_kernel: the o-proj of a decode step with the attention of that step as its PROLOGUE (M == 1, K = heads * dh <= 2048, at most 64 cached
 // positions: the depth decoder of CSM attends over <= 32 positions, 124 times per frame).  Every workgroup recomputes the whole attention row -- a
 // few thousand multiply-adds on K | V rows that sit in L2 -- while its slice of the weight stream is already in flight, and then runs the
@@ -659,7 +810,7 @@ __global__ __launch_bounds__(256) void gemv1_attn_kernel(const mi355_gemv_args a
 }
 
 template <int WT, bool NT = false>
-__global__ __launch_bounds__(256) void gemv1_splitk_kernel(const mi355_gemv_args a) {
+__global__ __launch_bounds__(256) void gemv1_splitk_old_kernel(const mi355_gemv_args a) {
   constexpr int NC = 4, D = 4;
   constexpr int EPL = mi355_wt<WT>::EPL, ESZ = 16 / EPL, SL = 64 * EPL;
   __shared__ float part[4][NC];
@@ -729,6 +880,96 @@ __global__ __launch_bounds__(256) void gemv1_splitk_kernel(const mi355_gemv_args
   }
 }
 
+// gemv1_splitk_kernel, second form: the first one's `k < K ? load : 0` guards compiled to a branch per load, several of them with their own
+// s_waitcnt vmcnt(0) -- up to eight SERIAL HBM round trips before the first multiply (7.0-8.7 us for the 16.8 MB down projection of the CSM depth
+// decoder, whose bytes are 2.7 us at the chip's rate).  Here every load is unconditional (clamped address, x zeroed instead), the epilogue's
+// operands are requested first, and the slice loop is straight-line code: one round trip.
+template <int WT, bool NT = false>
+__global__ __launch_bounds__(256) void gemv1_splitk_kernel(const mi355_gemv_args a) {
+  constexpr int NC = 4, D = 4;
+  constexpr int EPL = mi355_wt<WT>::EPL, ESZ = 16 / EPL, SL = 64 * EPL;
+  __shared__ float part[4][NC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * NC;
+  const int ec = threadIdx.x < NC && n0 + (int)threadIdx.x < a.N ? n0 + (int)threadIdx.x : -1;   // the column this thread finishes
+  // its operands are requested first, by every thread for a clamped column (no lane-divergent branch in front of the stream)
+  const int el = n0 + (lane & 3) < a.N ? n0 + (lane & 3) : a.N - 1;
+  const float e_bias = a.bias ? a.bias[el] : 0.f;
+  const float e_cs = a.colscale ? a.colscale[el] : 1.f;
+  const float e_res = a.res ? a.res[el] : 0.f;
+  const float e_ws = a.wscale ? a.wscale[el] : 1.0f / kFp8Unbias;
+  const int n_it = (a.K + SL - 1) / SL;
+  const int per = (n_it + 3) / 4;                       // slices per wave
+  const int it0 = wave * per, it1 = it0 + per < n_it ? it0 + per : n_it;
+  const uint8_t* wrow[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int n = n0 + c < a.N ? n0 + c : a.N - 1;
+    wrow[c] = (const uint8_t*)a.w + (int64_t)n * a.ldw * ESZ;
+  }
+  const float* xrow = a.x_ids ? a.x + ((int64_t)a.x_ids[0] + a.x_id_offset) * a.ldx : a.x;
+  uint4 wring[D][NC];
+  float4 xring[D][EPL / 4];
+  bool okring[D];
+  auto issue = [&](int it, int d) {
+    const int k = it * SL + lane * EPL;
+    okring[d] = it < it1 && k < a.K;
+    const int kc = okring[d] ? k : 0;                   // past the wave's slices / the row: a valid address, the product is zeroed through x
+#pragma unroll
+    for (int c = 0; c < NC; ++c) wring[d][c] = ldw16<NT>(wrow[c] + (int64_t)kc * ESZ);
+#pragma unroll
+    for (int j4 = 0; j4 < EPL / 4; ++j4) xring[d][j4] = *(const float4*)(xrow + kc + 4 * j4);
+  };
+#pragma unroll
+  for (int d = 0; d < D; ++d) issue(it0 + d, d);
+  float acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+  auto consume = [&](int d) {
+    float xv[EPL];
+#pragma unroll
+    for (int j4 = 0; j4 < EPL / 4; ++j4) {
+      xv[4 * j4] = okring[d] ? xring[d][j4].x : 0.f; xv[4 * j4 + 1] = okring[d] ? xring[d][j4].y : 0.f;
+      xv[4 * j4 + 2] = okring[d] ? xring[d][j4].z : 0.f; xv[4 * j4 + 3] = okring[d] ? xring[d][j4].w : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      float wf[EPL];
+      cvt_w16<WT>(wring[d][c], wf);
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) acc[c] = fmaf(xv[j], wf[j], acc[c]);
+    }
+  };
+  int base = it0;
+  for (; base + D < it1; base += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      consume(d);
+      issue(base + D + d, d);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) consume(d);               // the last block: nothing left to request
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = wave_sum_fast(acc[c]);
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) part[wave][c] = acc[c];
+  }
+  __syncthreads();
+  if (ec >= 0) {
+    const int c = threadIdx.x;
+    const float sum = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];   // fixed order: run-to-run identical
+    float ews = e_ws;
+    asm volatile("" : "+v"(ews));   // keeps the scale's multiply (and with it the load's s_waitcnt) down here instead of hoisted in front of the stream
+    const float ws = a.wscale ? ews * kFp8Unbias : 1.f;
+    float v = gemv_act(sum * ws + e_bias, a.post_act, a.post_slope) * e_cs;
+    if (a.res) v += e_res;
+    if (a.y2 && ec >= a.split) store_kv_elem(a.y2, ec - a.split, v * a.out_scale, a.y2_dtype);
+    else a.y[ec] = v * a.out_scale;
+  }
+}
+
 template <int WT>
 int launch_gemv1(const mi355_gemv_args& a, hipStream_t st) {
   constexpr int EPL = mi355_wt<WT>::EPL;
@@ -772,6 +1013,41 @@ int launch_gemv1(const mi355_gemv_args& a, hipStream_t st) {
       if (blocks > resident) blocks = resident;
       hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, st, a, ngroups);
     };
+    static const bool old1 = getenv("MI355_GEMV1_OLD") != nullptr && getenv("MI355_GEMV1_OLD")[0] == '1';   // A/B knob: the grid-stride kernel
+    auto gs = [&](auto kern) {
+      static int resident = 0;
+      if (resident == 0) {
+        int per_cu = 2, dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, (const void*)kern) == hipSuccess && fa.numRegs > 0) {
+          per_cu = 512 / (((fa.numRegs + 7) / 8) * 8);
+          per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+        }
+        resident = per_cu * cus;
+      }
+      // one resident round of waves, every wave the same contiguous run of groups (<= 64: one lane per group for the epilogue)
+      int gpw = (ngroups + resident * 4 - 1) / (resident * 4);
+      if (gpw > 64) gpw = 64;
+      const int blocks = (ngroups + 4 * gpw - 1) / (4 * gpw);
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, st, a, ngroups, gpw);
+    };
+    if (!old1) {
+      if (half) {
+        if (two && nt) gs(gemv1_stream_kernel<2, WT, true, true>);
+        else if (two) gs(gemv1_stream_kernel<2, WT, false, true>);
+        else if (nt) gs(gemv1_stream_kernel<1, WT, true, true>);
+        else gs(gemv1_stream_kernel<1, WT, false, true>);
+      } else {
+        if (two && nt) gs(gemv1_stream_kernel<2, WT, true, false>);
+        else if (two) gs(gemv1_stream_kernel<2, WT, false, false>);
+        else if (nt) gs(gemv1_stream_kernel<1, WT, true, false>);
+        else gs(gemv1_stream_kernel<1, WT, false, false>);
+      }
+      MI355_LAUNCH_CHECK("gemv(M=1, register-resident x, streamed groups)");
+      return MI355_OK;
+    }
     if (half) {
       if (two && nt) go(gemv1_res_kernel<2, WT, true, true>);
       else if (two) go(gemv1_res_kernel<2, WT, false, true>);
@@ -787,7 +1063,11 @@ int launch_gemv1(const mi355_gemv_args& a, hipStream_t st) {
     return MI355_OK;
   }
   static const int nt_env2 = getenv("MI355_GEMV_NT") ? atoi(getenv("MI355_GEMV_NT")) : -1;
-  if (nt_env2 >= 0 ? nt_env2 != 0 : a.w_policy == 1) hipLaunchKernelGGL((gemv1_splitk_kernel<WT, true>), dim3((a.N + 3) / 4), dim3(256), 0, st, a);
+  static const bool old2 = getenv("MI355_GEMV1_OLD") != nullptr && getenv("MI355_GEMV1_OLD")[0] == '1';
+  const bool nt2 = nt_env2 >= 0 ? nt_env2 != 0 : a.w_policy == 1;
+  if (old2 && nt2) hipLaunchKernelGGL((gemv1_splitk_old_kernel<WT, true>), dim3((a.N + 3) / 4), dim3(256), 0, st, a);
+  else if (old2) hipLaunchKernelGGL((gemv1_splitk_old_kernel<WT>), dim3((a.N + 3) / 4), dim3(256), 0, st, a);
+  else if (nt2) hipLaunchKernelGGL((gemv1_splitk_kernel<WT, true>), dim3((a.N + 3) / 4), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((gemv1_splitk_kernel<WT>), dim3((a.N + 3) / 4), dim3(256), 0, st, a);
   MI355_LAUNCH_CHECK("gemv(M=1, split K)");
   return MI355_OK;

@@ -85,8 +85,17 @@ __global__ __launch_bounds__(256) void adain_from_partials_kernel(const mi355_ad
     if (keep) {
 #pragma unroll
       for (int j = 0; j < (CPW > 4 ? kAdainKeep : 1); ++j) {
+        // unconditional (clamped) loads, zeroed by a select: as `e < nblk ? load : 0` each of the 32 compiled to a branch with its own
+        // s_waitcnt vmcnt(0) -- 32 SERIAL round trips per lane (tools/scan_serial_waits.py)
         const int e = eg + j * LPC;
-        kept[j] = e < nblk ? *(const float2*)(pb + (int64_t)e * estride) : make_float2(0.f, 0.f);
+        const int ec = e < nblk ? e : (nblk > 0 ? nblk - 1 : 0);
+        kept[j] = *(const float2*)(pb + (int64_t)ec * estride);
+      }
+#pragma unroll
+      for (int j = 0; j < (CPW > 4 ? kAdainKeep : 1); ++j) {
+        const bool in = eg + j * LPC < nblk;
+        kept[j].x = in ? kept[j].x : 0.f;
+        kept[j].y = in ? kept[j].y : 0.f;
       }
 #pragma unroll
       for (int j = 0; j < (CPW > 4 ? kAdainKeep : 1); ++j) s += (double)kept[j].x;

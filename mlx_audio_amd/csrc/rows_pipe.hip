@@ -391,6 +391,143 @@ __global__ __launch_bounds__(256) void rows_finish_kernel(const mi355_rows_finis
   }
 }
 
+// rows_finish_lean_kernel: the row epilogue of the decode stacks (o-proj / down-proj / step input: slab sums + bias + LayerScale + residual ->
+// y, norm -> planes / yn) as STRAIGHT-LINE code.  rows_finish_kernel answers every flag of mi355_rows_finish_args at run time; hipcc compiles each
+// `ptr ? ptr[n] : c` of it to a branch around a load with its own s_waitcnt vmcnt(0), so a launch was a chain of serial L2 round trips (6.9 us in
+// situ for 2 MB of slabs, 370 launches per Qwen3-TTS frame: tools/scan_serial_waits.py counts them) in 24 000 instructions of generated code.
+// Here: whole 8-column pieces, NP of them per thread; EVERY operand is loaded unconditionally before the first use (a null operand is replaced by
+// the slab row -- valid memory -- and dropped by a select), threads past the row clamp to its last piece and only their stores are predicated.
+// mi355_rows_finish dispatches here when the call has this shape (no GLU, no activation, no split destination, aligned operands, <= 4096 outputs).
+template <bool F16, int NP>
+__global__ __launch_bounds__(256) void rows_finish_lean_kernel(const mi355_rows_finish_args a) {
+  __shared__ float sred[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = blockIdx.x;
+  const int No = a.N, npieces = No >> 3;
+  const float* const prow = a.part + (int64_t)m * a.ldp;
+  const bool has_ws = a.wscale != nullptr, has_b = a.bias != nullptr, has_cs = a.colscale != nullptr, has_res = a.res != nullptr;
+  const bool has_nw = a.norm_weight != nullptr, has_nb = a.norm_bias != nullptr;
+  auto ld8 = [](const float* q, float (&d)[8]) {
+    const float4 t0 = *(const float4*)q, t1 = *(const float4*)(q + 4);
+    d[0] = t0.x; d[1] = t0.y; d[2] = t0.z; d[3] = t0.w; d[4] = t1.x; d[5] = t1.y; d[6] = t1.z; d[7] = t1.w;
+  };
+  int pc[NP];
+  bool live[NP];
+  float wsv[NP][8], bv[NP][8], cv[NP][8], rv[NP][8], nwv[NP][8], nbv[NP][8];
+#pragma unroll
+  for (int it = 0; it < NP; ++it) {
+    const int p = tid + 256 * it;
+    live[it] = p < npieces;
+    pc[it] = live[it] ? p : npieces - 1;
+    const int n0 = 8 * pc[it];
+    const float* dummy = prow + n0;
+    ld8(has_ws ? a.wscale + n0 : dummy, wsv[it]);
+    ld8(has_b ? a.bias + n0 : dummy, bv[it]);
+    ld8(has_cs ? a.colscale + n0 : dummy, cv[it]);
+    ld8(has_res ? a.res + (int64_t)m * a.ldr + n0 : dummy, rv[it]);
+    ld8(has_nw ? a.norm_weight + n0 : dummy, nwv[it]);
+    ld8(has_nb ? a.norm_bias + n0 : dummy, nbv[it]);
+  }
+  float v[NP][8];
+#pragma unroll
+  for (int it = 0; it < NP; ++it)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[it][e] = 0.f;
+  int g = 0;
+  for (; g + 4 <= a.kgroups; g += 4) {   // four slabs' loads in flight per piece, added in slab order (deterministic)
+    float t[NP][4][8];
+#pragma unroll
+    for (int it = 0; it < NP; ++it)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ld8(prow + (int64_t)(g + u) * a.kg_stride + 8 * pc[it], t[it][u]);
+#pragma unroll
+    for (int it = 0; it < NP; ++it)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[it][e] += t[it][u][e];
+  }
+  for (; g < a.kgroups; ++g) {
+    float t[NP][8];
+#pragma unroll
+    for (int it = 0; it < NP; ++it) ld8(prow + (int64_t)g * a.kg_stride + 8 * pc[it], t[it]);
+#pragma unroll
+    for (int it = 0; it < NP; ++it)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[it][e] += t[it][e];
+  }
+  float lsum = 0.f;
+#pragma unroll
+  for (int it = 0; it < NP; ++it) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = (v[it][e] * (has_ws ? wsv[it][e] : 1.f) + (has_b ? bv[it][e] : 0.f)) * (has_cs ? cv[it][e] : 1.f);
+      t += has_res ? rv[it][e] : 0.f;
+      t *= a.out_scale;
+      v[it][e] = live[it] ? t : 0.f;
+      lsum += v[it][e];
+    }
+  }
+  float mean = 0.f, rstd = 1.f;
+  if (a.norm) {   // two-pass statistics of the finished row, the arithmetic of rows_finish_kernel
+    if (a.norm == 1) {
+      const float s = wave_sum_fast(lsum);
+      if (lane == 0) sred[wave] = s;
+      __syncthreads();
+      mean = ((sred[0] + sred[1]) + (sred[2] + sred[3])) / (float)No;
+    }
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < NP; ++it)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = live[it] ? v[it][e] - mean : 0.f;
+        q += d * d;
+      }
+    q = wave_sum_fast(q);
+    if (lane == 0) sred[4 + wave] = q;
+    __syncthreads();
+    const float var = ((sred[4] + sred[5]) + (sred[6] + sred[7])) / (float)No;
+    rstd = a.norm == 1 ? 1.0f / sqrtf(var + a.norm_eps) : rsqrtf(var + a.norm_eps);
+  }
+  uint4* const pl = (uint4*)a.planes;
+  // every load has long landed; an opaque use makes the compiler say so HERE -- behind the conditional y stores its wait-count bookkeeping can no
+  // longer tell loads from stores and would wait for the stores (vmcnt(0)) in front of the plane stores
+#pragma unroll
+  for (int it = 0; it < NP; ++it)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(nwv[it][e]), "+v"(nbv[it][e]));
+#pragma unroll
+  for (int it = 0; it < NP; ++it) {
+    if (!live[it]) continue;
+    const int p = pc[it];
+    if (a.y) {   // stored down here: a store in front of the statistics would sit in every later s_waitcnt vmcnt(0) of the generated code
+      float* yp = a.y + (int64_t)m * a.ldy + 8 * p;
+      *(float4*)yp = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
+      *(float4*)(yp + 4) = make_float4(v[it][4], v[it][5], v[it][6], v[it][7]);
+    }
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      t[e] = a.norm ? (v[it][e] - mean) * rstd * (has_nw ? nwv[it][e] : 1.f) + (has_nb ? nbv[it][e] : 0.f) : v[it][e];
+    if (a.yn) {
+      float* yp = a.yn + (int64_t)m * a.ldyn + 8 * p;
+      *(float4*)yp = make_float4(t[0], t[1], t[2], t[3]);
+      *(float4*)(yp + 4) = make_float4(t[4], t[5], t[6], t[7]);
+    }
+    if (pl) {
+      uint4 hi, lo;
+      pipe_split2<F16>(t[0], t[1], hi.x, lo.x);
+      pipe_split2<F16>(t[2], t[3], hi.y, lo.y);
+      pipe_split2<F16>(t[4], t[5], hi.z, lo.z);
+      pipe_split2<F16>(t[6], t[7], hi.w, lo.w);
+      const int s = p >> 3, gg = (p & 7) >> 1, h = p & 1;
+      pl[(((s * 2 + 0) * 2 + h) * 4 + gg) * a.R + m] = hi;
+      pl[(((s * 2 + 1) * 2 + h) * 4 + gg) * a.R + m] = lo;
+    }
+  }
+}
+
 }  // namespace
 
 // K groups mi355_rows_gemm splits a [N, K] projection into (what the caller must size the slab workspace for and hand to mi355_rows_finish)
@@ -451,6 +588,22 @@ extern "C" int mi355_rows_finish(const mi355_rows_finish_args* ap, void* stream)
   MI355_REQUIRE(a.y || a.y2 || a.planes || a.yn, "rows_finish: no destination");
   if (a.out_scale == 0.f) a.out_scale = 1.f;
   MI355_CLEAR_ERROR();
+  {   // the straight-line kernel for the shape the decode stacks use (see rows_finish_lean_kernel)
+    static const bool lean_off = getenv("MI355_ROWS_FINISH_OLD") != nullptr && getenv("MI355_ROWS_FINISH_OLD")[0] == '1';   // A/B knob
+    auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+    const bool lean = !lean_off && !a.glu && a.post_act == MI355_ACT_NONE && !a.y2 && No % 8 == 0 && No <= 4096 && al16(a.wscale) && al16(a.bias) &&
+                      al16(a.colscale) && al16(a.res) && al16(a.norm_weight) && al16(a.norm_bias) && (!a.res || a.ldr % 4 == 0) &&
+                      (!a.y || (al16(a.y) && a.ldy % 4 == 0)) && (!a.yn || (al16(a.yn) && a.ldyn % 4 == 0));
+    if (lean) {
+      const bool f16 = a.planes && a.planes_dtype == MI355_W_F16, two = No > 2048;
+      if (f16 && two) hipLaunchKernelGGL((rows_finish_lean_kernel<true, 2>), dim3(a.M), dim3(256), 0, (hipStream_t)stream, a);
+      else if (f16) hipLaunchKernelGGL((rows_finish_lean_kernel<true, 1>), dim3(a.M), dim3(256), 0, (hipStream_t)stream, a);
+      else if (two) hipLaunchKernelGGL((rows_finish_lean_kernel<false, 2>), dim3(a.M), dim3(256), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((rows_finish_lean_kernel<false, 1>), dim3(a.M), dim3(256), 0, (hipStream_t)stream, a);
+      MI355_LAUNCH_CHECK("rows_finish (lean)");
+      return MI355_OK;
+    }
+  }
   int cb = 1;   // column blocks of a row: only a normalised row needs one workgroup to see all of it
   if (!a.norm) { cb = ((No + 7) / 8 + 255) / 256; if (cb > 16) cb = 16; }
   if (a.planes && a.planes_dtype == MI355_W_F16) hipLaunchKernelGGL(rows_finish_kernel<true>, dim3(a.M, cb), dim3(256), 0, (hipStream_t)stream, a);

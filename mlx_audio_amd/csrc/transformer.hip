@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void head_norm_rope_kernel(const mi355_head_ro
   float x0 = 0.f, x1 = 0.f;
   if (act) { x0 = xr[i0]; x1 = xr[i1]; }
   if (nw) {
-    const float ss = wave_sum(x0 * x0 + x1 * x1);
+    const float ss = wave_sum(sumsq2(x0, x1));
     const float r = rsqrtf(ss / (float)a.dh + a.eps);
     if (act) { x0 = x0 * r * nw[i0]; x1 = x1 * r * nw[i1]; }
   }
@@ -78,8 +78,8 @@ __global__ __launch_bounds__(256) void head_norm_rope_kernel(const mi355_head_ro
     pos = pos < 0 ? 0 : (pos >= a.rope_rows ? a.rope_rows - 1 : pos);  // left-padding rows sit before position 0; host-known ranges are checked at the entry point
     const float c = a.cos_table[(int64_t)pos * half + lane], s = a.sin_table[(int64_t)pos * half + lane];
     // (x * cos) + (rotate(x) * sin): pair (x0, x1) -> (x0 c - x1 s, x1 c + x0 s), two roundings per term like the reference
-    const float y0 = x0 * c - x1 * s;
-    const float y1 = x1 * c + x0 * s;
+    float y0, y1;
+    rope_pair(x0, x1, c, s, y0, y1);
     x0 = y0; x1 = y1;
   }
   if (act) { yr[i0] = x0; yr[i1] = x1; }
