@@ -81,24 +81,44 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_ge
   auto stage_A = [&](int chunk) {
     const int c4 = (tid & 7) * 4;
     const int c = chunk * 32 + c4;
-    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f}, al[4] = {1.f, 1.f, 1.f, 1.f},
-          ial[4] = {1.f, 1.f, 1.f, 1.f};
-    if (a.pre_scale) {
-      const float4 s4 = *(const float4*)(a.pre_scale + (int64_t)b * a.pre_ld + c);
-      const float4 h4 = *(const float4*)(a.pre_shift + (int64_t)b * a.pre_ld + c);
-      sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
-      sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
-    }
-    if (a.pre_act == MI355_ACT_SNAKE) {
-      const float4 a4 = *(const float4*)(a.pre_alpha + c);
-      al[0] = a4.x; al[1] = a4.y; al[2] = a4.z; al[3] = a4.w;
+    // the prologue's per-channel operands, requested together and unconditionally (an absent one reads the weight image -- valid, 16-byte aligned --
+    // and is dropped by a select): as loads under `if (ptr)` with constants on the other side each was its own round trip in front of the window
+    const float* const safe = (const float*)a.w;
+    const bool has_aff = a.pre_scale != nullptr, has_snake = a.pre_act == MI355_ACT_SNAKE, has_beta = has_snake && a.pre_inv_beta != nullptr;
+    const float4 s4 = *(const float4*)(has_aff ? a.pre_scale + (int64_t)b * a.pre_ld + c : safe);
+    const float4 h4 = *(const float4*)(has_aff ? a.pre_shift + (int64_t)b * a.pre_ld + c : safe);
+    const float4 a4 = *(const float4*)(has_snake ? a.pre_alpha + c : safe);
+    const float4 b4 = *(const float4*)(has_beta ? a.pre_inv_beta + c : safe);
+    // ... and the first four window rows of this thread with them (VEC): one round trip per chunk for windows of <= 128 rows
+    constexpr int NR = 4, RS = kThreads / 8;
+    const int cc = c < a.Cin ? c : 0;
+    auto load_rows = [&](const int rb, float4 (&t)[NR], bool (&rin)[NR]) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ial[i] = 1.0f / al[i];
-      if (a.pre_inv_beta) {  // SnakeBeta: x + sin^2(alpha x) * inv_beta[c]
-        const float4 b4 = *(const float4*)(a.pre_inv_beta + c);
-        ial[0] = b4.x; ial[1] = b4.y; ial[2] = b4.z; ial[3] = b4.w;
+      for (int u = 0; u < NR; ++u) {
+        const int r = rb + u * RS;
+        const int gl = l0 - a.pad + r;
+        int64_t base = (int64_t)a.x_off + (int64_t)gl * a.ldx + cc;
+        if (a.flat_valid > 0) {   // flattened strided conv on 16-byte aligned runs: validity by flat element index, every bound a multiple of 4
+          rin[u] = r < R && c < a.Cin && base >= 0 && base + 3 < flat_hi;
+          base = base < 0 ? 0 : (base + 3 < flat_hi ? base : flat_hi - 4);
+        } else {
+          rin[u] = r < R && c < a.Cin && gl >= 0 && gl < len_in;
+          const int glc = gl < 0 ? 0 : (gl < len_in ? gl : len_in - 1);
+          base = (int64_t)a.x_off + (int64_t)glc * a.ldx + cc;
+        }
+        t[u] = *(const float4*)(xb + base);
       }
-    }
+    };
+    float4 t0[NR];
+    bool rin0[NR];
+    if constexpr (VEC) load_rows(tid >> 3, t0, rin0);
+    float sc[4], sh[4], al[4], ial[4];
+    sc[0] = has_aff ? s4.x : 1.f; sc[1] = has_aff ? s4.y : 1.f; sc[2] = has_aff ? s4.z : 1.f; sc[3] = has_aff ? s4.w : 1.f;
+    sh[0] = has_aff ? h4.x : 0.f; sh[1] = has_aff ? h4.y : 0.f; sh[2] = has_aff ? h4.z : 0.f; sh[3] = has_aff ? h4.w : 0.f;
+    al[0] = has_snake ? a4.x : 1.f; al[1] = has_snake ? a4.y : 1.f; al[2] = has_snake ? a4.z : 1.f; al[3] = has_snake ? a4.w : 1.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ial[i] = 1.0f / al[i];
+    if (has_beta) { ial[0] = b4.x; ial[1] = b4.y; ial[2] = b4.z; ial[3] = b4.w; }   // SnakeBeta: x + sin^2(alpha x) * inv_beta[c]
     // quantising prologue (a.pre_fq): the value of conv_common.h's fq_pre_value, then the utterance's dynamic uint8 quantise / dequantise
     const bool fqon = a.pre_fq != nullptr;
     const FakeQuant fq = fqon ? FakeQuant(-a.pre_fq[2 * b], a.pre_fq[2 * b + 1]) : FakeQuant(0.f, 0.f);
@@ -107,30 +127,8 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_ge
 #pragma unroll
       for (int i = 0; i < 4; ++i) fk[i] = fq_load_coef(a.pre_scale, a.pre_shift, (int64_t)b * a.pre_ld, a.pre_act, a.pre_alpha, (c + i) < a.Cin ? c + i : 0);
     }
-    for (int r = tid >> 3; r < R; r += kThreads / 8) {
-      const int gl = l0 - a.pad + r;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      bool ok[4] = {false, false, false, false};
-      const int64_t base = (int64_t)a.x_off + (int64_t)gl * a.ldx + c;
-      if (VEC) {
-        // flattened strided conv on 16-byte aligned runs (flat_valid > 0: validity by flat element index; every bound is a multiple of 4 there)
-        const bool rin = a.flat_valid > 0 ? (base >= 0 && base + 3 < flat_hi) : (gl >= 0 && gl < len_in);
-        if (rin && c < a.Cin) {
-          const float4 t = *(const float4*)(xb + base);
-          v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) ok[i] = (c + i) < a.Cin;
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          bool o = (c + i) < a.Cin;
-          if (a.flat_valid > 0) o = o && (base + i) >= 0 && (base + i) < flat_hi;
-          else o = o && gl >= 0 && gl < len_in;
-          ok[i] = o;
-          if (o) v[i] = xb[base + i];
-        }
-      }
+    // one row of the window: prologue, hi / lo split, LDS store
+    auto finish_row = [&](const int r, const float (&v)[4], const bool (&ok)[4]) {
       float hi[4], lo[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -161,6 +159,46 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_ge
         pl.x = pack_lo<PREC>(lo[0], lo[1]);
         pl.y = pack_lo<PREC>(lo[2], lo[3]);
         *(uint2*)(A_lo + addr) = pl;
+      }
+    };
+    if constexpr (VEC) {
+      // FOUR rows' loads in flight per thread, unconditional (a row / channel group outside the input reads a clamped, valid address and is zeroed
+      // through ok[]): as `if (inside) v = load` per row every row was its own round trip -- three to six SERIAL ones per chunk, which is what a
+      // launch of few tiles (one utterance per call, the split-K passes) spends its time on
+      auto process_rows = [&](const int rb, const float4 (&t)[NR], const bool (&rin)[NR]) {
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+          const int r = rb + u * RS;
+          if (r >= R) break;
+          const float v[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
+          bool ok[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ok[i] = rin[u] && (c + i) < a.Cin;
+          finish_row(r, v, ok);
+        }
+      };
+      process_rows(tid >> 3, t0, rin0);
+      for (int rb = (tid >> 3) + NR * RS; rb < R; rb += NR * RS) {
+        float4 t[NR];
+        bool rin[NR];
+        load_rows(rb, t, rin);
+        process_rows(rb, t, rin);
+      }
+    } else {
+      for (int r = tid >> 3; r < R; r += kThreads / 8) {
+        const int gl = l0 - a.pad + r;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        bool ok[4] = {false, false, false, false};
+        const int64_t base = (int64_t)a.x_off + (int64_t)gl * a.ldx + c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          bool o = (c + i) < a.Cin;
+          if (a.flat_valid > 0) o = o && (base + i) >= 0 && (base + i) < flat_hi;
+          else o = o && gl >= 0 && gl < len_in;
+          ok[i] = o;
+          if (o) v[i] = xb[base + i];
+        }
+        finish_row(r, v, ok);
       }
     }
   };
@@ -483,7 +521,7 @@ int split_groups(const long wgs, const int nchunks, const int K, const long rows
   if (nchunks < 2) return 0;
   static const int off = getenv("MI355_CONV_SPLIT") ? atoi(getenv("MI355_CONV_SPLIT")) : -1;   // 0 = never split (A/B aid)
   if (off == 0 && !forced) return 0;
-  static const int min_steps = getenv("MI355_CONV_SPLIT_MINSTEPS") ? atoi(getenv("MI355_CONV_SPLIT_MINSTEPS")) : 4;   // A/B knob
+  static const int min_steps = getenv("MI355_CONV_SPLIT_MINSTEPS") ? atoi(getenv("MI355_CONV_SPLIT_MINSTEPS")) : 2;   // A/B knob (round 4, call 15: 2 beats 4 by 0.27 ms on the 7.7 ms one-utterance pass, 1 does not)
   const int min_chunks = K >= min_steps ? 1 : (min_steps + K - 1) / K;       // >= min_steps (chunk, tap) steps per group
   int ks = forced;                                            // > 0: that many groups; -1: the rule's count whatever the tile count; 0: the rule
   if (ks <= 0) {
