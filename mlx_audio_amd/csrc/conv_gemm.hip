@@ -521,7 +521,9 @@ int split_groups(const long wgs, const int nchunks, const int K, const long rows
   if (nchunks < 2) return 0;
   static const int off = getenv("MI355_CONV_SPLIT") ? atoi(getenv("MI355_CONV_SPLIT")) : -1;   // 0 = never split (A/B aid)
   if (off == 0 && !forced) return 0;
-  static const int min_steps = getenv("MI355_CONV_SPLIT_MINSTEPS") ? atoi(getenv("MI355_CONV_SPLIT_MINSTEPS")) : 2;   // A/B knob (round 4, call 15: 2 beats 4 by 0.27 ms on the 7.7 ms one-utterance pass, 1 does not)
+  static const int min_steps = getenv("MI355_CONV_SPLIT_MINSTEPS") ? atoi(getenv("MI355_CONV_SPLIT_MINSTEPS")) : 4;   // A/B knob.  Round 4, calls 15 / 18: 2 is 0.27 ms faster on the 7.7 ms one-utterance pass (1 is not), but a different grouping between a
+  // batch and a lone utterance moves F0 by 5e-6 relative, which is enough to wrap a harmonic phase feature (atan2 at +-pi) in the free-running
+  // batch-vs-single tests (tools/diag_batch_single.py): kept at 4 until those tests inject the source
   const int min_chunks = K >= min_steps ? 1 : (min_steps + K - 1) / K;       // >= min_steps (chunk, tap) steps per group
   int ks = forced;                                            // > 0: that many groups; -1: the rule's count whatever the tile count; 0: the rule
   if (ks <= 0) {

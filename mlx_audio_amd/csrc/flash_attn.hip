@@ -26,6 +26,7 @@
 // Visibility of key j for query i of item b (len_q / len_k = valid rows, queries are the LAST len_q positions):
 //   k_start <= j < len_k,  causal: j <= i + (len_k - len_q),  window W > 0: j > i + (len_k - len_q) - W.
 // Invisible keys get probability exactly 0 (the reference adds -1e9 / -inf style masks: identical after softmax).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -481,61 +482,96 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
   const bool pf_act = lane < half_dh;
   const int pf_i0 = pf_act ? (a.rope_mode == 1 ? 2 * lane : lane) : 0, pf_i1 = pf_act ? (a.rope_mode == 1 ? 2 * lane + 1 : lane + half_dh) : 0;
   const float* const pf_dummy = a.q + (int64_t)b * a.q_bstride + (int64_t)qi * a.ldq + h * DH;
-  const float* const pf_nwp = fused ? (wave == 0 ? a.q_norm_w : a.k_norm_w) : nullptr;
-  const bool pf_has_nw = pf_nwp != nullptr, pf_has_rope = fused && a.rope_cos != nullptr;
+  const bool pf_has_qnw = fused && a.q_norm_w != nullptr, pf_has_knw = fused && a.k_norm_w != nullptr, pf_has_rope = fused && a.rope_cos != nullptr;
   int pf_pos = 0;
   if (pf_has_rope) {
     pf_pos = (a.lens_k ? len_k - 1 : a.rope_pos) - (a.k_start ? a.k_start[b] : 0);   // slot caches: every item is at its own position
     pf_pos = pf_pos < 0 ? 0 : (pf_pos >= a.rope_rows ? a.rope_rows - 1 : pf_pos);
   }
-  const float pf_nw0 = (pf_has_nw ? pf_nwp : pf_dummy)[pf_i0], pf_nw1 = (pf_has_nw ? pf_nwp : pf_dummy)[pf_i1];
+  const float pf_qnw0 = (pf_has_qnw ? a.q_norm_w : pf_dummy)[pf_i0], pf_qnw1 = (pf_has_qnw ? a.q_norm_w : pf_dummy)[pf_i1];
+  const float pf_knw0 = (pf_has_knw ? a.k_norm_w : pf_dummy)[pf_i0], pf_knw1 = (pf_has_knw ? a.k_norm_w : pf_dummy)[pf_i1];
   const float pf_cos = (pf_has_rope ? a.rope_cos + (int64_t)pf_pos * half_dh : pf_dummy)[pf_act ? lane : 0];
   const float pf_sin = (pf_has_rope ? a.rope_sin + (int64_t)pf_pos * half_dh : pf_dummy)[pf_act ? lane : 0];
   if (!fused) {
     for (int t = tid; t < DH; t += NW * 64) qs[t] = a.q[(int64_t)b * a.q_bstride + (int64_t)qi * a.ldq + h * DH + t] * qsc;
   } else {
-    for (int t = tid; t < DH; t += NW * 64) {
-      const int64_t iq = (int64_t)b * a.q_bstride + (int64_t)qi * a.ldq + h * DH + t, ik = (int64_t)b * a.new_bstride + g * DH + t;
-      float q0 = a.q[iq], k0 = a.new_k[ik], v0 = a.new_v[ik];
-      // rows pipeline: the projection arrives as K-group slabs (summed in slab order: deterministic); four slabs' loads in flight at a time
-      int sl = 1;
-      for (; sl + 4 <= a.in_kgroups; sl += 4) {
-        float tq[4], tk[4], tv[4];
+    // NT elements per thread (2 for the one-wave workgroup at DH = 128), every load of a stage requested before the first is used; the scales /
+    // biases of an fp8 / biased projection come unconditionally too (an absent one reads q and is dropped by a select)
+    constexpr int NT = (DH + NW * 64 - 1) / (NW * 64);
+    int64_t iq[NT], ik[NT];
+    int tt[NT];
+    float q0[NT], k0[NT], v0[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int t = tid + j * NW * 64;
+      tt[j] = t < DH ? t : DH - 1;
+      iq[j] = (int64_t)b * a.q_bstride + (int64_t)qi * a.ldq + h * DH + tt[j];
+      ik[j] = (int64_t)b * a.new_bstride + g * DH + tt[j];
+      q0[j] = a.q[iq[j]]; k0[j] = a.new_k[ik[j]]; v0[j] = a.new_v[ik[j]];
+    }
+    const bool has_ws = a.q_wscale != nullptr, has_qb = a.q_bias != nullptr, has_kb = a.k_bias != nullptr, has_vb = a.v_bias != nullptr;
+    float wq[NT], wk[NT], wv[NT], bq[NT], bk[NT], bv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      wq[j] = (has_ws ? a.q_wscale + h * DH : pf_dummy)[tt[j]]; wk[j] = (has_ws ? a.k_wscale + g * DH : pf_dummy)[tt[j]];
+      wv[j] = (has_ws ? a.v_wscale + g * DH : pf_dummy)[tt[j]];
+      bq[j] = (has_qb ? a.q_bias + h * DH : pf_dummy)[tt[j]]; bk[j] = (has_kb ? a.k_bias + g * DH : pf_dummy)[tt[j]];
+      bv[j] = (has_vb ? a.v_bias + g * DH : pf_dummy)[tt[j]];
+    }
+    // rows pipeline: the projection arrives as K-group slabs (summed in slab order: deterministic); four slabs' loads in flight at a time
+    int sl = 1;
+    for (; sl + 4 <= a.in_kgroups; sl += 4) {
+      float tq[NT][4], tk[NT][4], tv[NT][4];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          tq[u] = a.q[iq + (sl + u) * a.in_kg_stride];
-          tk[u] = a.new_k[ik + (sl + u) * a.in_kg_stride];
-          tv[u] = a.new_v[ik + (sl + u) * a.in_kg_stride];
+          tq[j][u] = a.q[iq[j] + (sl + u) * a.in_kg_stride];
+          tk[j][u] = a.new_k[ik[j] + (sl + u) * a.in_kg_stride];
+          tv[j][u] = a.new_v[ik[j] + (sl + u) * a.in_kg_stride];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { q0 += tq[u]; k0 += tk[u]; v0 += tv[u]; }
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { q0[j] += tq[j][u]; k0[j] += tk[j][u]; v0[j] += tv[j][u]; }
+    }
+    for (; sl < a.in_kgroups; ++sl) {
+      float tq[NT], tk[NT], tv[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        tq[j] = a.q[iq[j] + sl * a.in_kg_stride]; tk[j] = a.new_k[ik[j] + sl * a.in_kg_stride]; tv[j] = a.new_v[ik[j] + sl * a.in_kg_stride];
       }
-      for (; sl < a.in_kgroups; ++sl) {
-        q0 += a.q[iq + sl * a.in_kg_stride];
-        k0 += a.new_k[ik + sl * a.in_kg_stride];
-        v0 += a.new_v[ik + sl * a.in_kg_stride];
-      }
-      if (a.q_wscale) { q0 *= a.q_wscale[h * DH + t]; k0 *= a.k_wscale[g * DH + t]; v0 *= a.v_wscale[g * DH + t]; }
-      if (a.q_bias) q0 += a.q_bias[h * DH + t];
-      if (a.k_bias) k0 += a.k_bias[g * DH + t];
-      if (a.v_bias) v0 += a.v_bias[g * DH + t];
-      qs[t] = q0;
-      ks_new[t] = k0;
-      vs_new[t] = kv_round<KVT>(v0);   // as the cache will hold it (the reference attends over the cache)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) { q0[j] += tq[j]; k0[j] += tk[j]; v0[j] += tv[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int t = tid + j * NW * 64;
+      if (t >= DH) continue;
+      float qv = q0[j], kv2 = k0[j], vv2 = v0[j];
+      if (has_ws) { qv *= wq[j]; kv2 *= wk[j]; vv2 *= wv[j]; }
+      if (has_qb) qv += bq[j];
+      if (has_kb) kv2 += bk[j];
+      if (has_vb) vv2 += bv[j];
+      qs[t] = qv;
+      ks_new[t] = kv2;
+      vs_new[t] = kv_round<KVT>(vv2);   // as the cache will hold it (the reference attends over the cache)
     }
     __syncthreads();
-    if (wave < 2) {  // wave 0: q, wave 1: k -- the arithmetic of head_norm_rope_kernel (transformer.hip), same order
-      float* vec = wave == 0 ? qs : ks_new;
-      const float* nw = wave == 0 ? a.q_norm_w : a.k_norm_w;
+    // q and k: the arithmetic of head_norm_rope_kernel (transformer.hip), same order.  Four-wave workgroups give q to wave 0 and k to wave 1;
+    // the one-wave workgroup of short key ranges does both
+    auto norm_rope = [&](float* vec, const bool is_q) {
+      const bool has_nw = is_q ? pf_has_qnw : pf_has_knw;
+      const float nw0 = is_q ? pf_qnw0 : pf_knw0, nw1 = is_q ? pf_qnw1 : pf_knw1;
       constexpr int half = DH / 2;
       const bool act = lane < half;
       const int i0 = a.rope_mode == 1 ? 2 * lane : lane, i1 = a.rope_mode == 1 ? 2 * lane + 1 : lane + half;
       float x0 = 0.f, x1 = 0.f;
       if (act) { x0 = vec[i0]; x1 = vec[i1]; }
-      if (nw) {
+      if (has_nw) {
         const float ss = wave_sum(sumsq2(x0, x1));
         const float r = rsqrtf(ss / (float)DH + a.norm_eps);
-        if (act) { x0 = x0 * r * pf_nw0; x1 = x1 * r * pf_nw1; }
+        if (act) { x0 = x0 * r * nw0; x1 = x1 * r * nw1; }
       }
       if (a.rope_cos && act) {
         const float c = pf_cos, sn = pf_sin;
@@ -545,9 +581,16 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
       }
       wave_lds_sync2();
       if (act) {
-        if (wave == 0) { vec[i0] = x0 * qsc; vec[i1] = x1 * qsc; }
+        if (is_q) { vec[i0] = x0 * qsc; vec[i1] = x1 * qsc; }
         else { vec[i0] = kv_round<KVT>(x0); vec[i1] = kv_round<KVT>(x1); }
       }
+    };
+    if constexpr (NW == 1) {
+      norm_rope(qs, true);
+      norm_rope(ks_new, false);
+    } else {
+      if (wave == 0) norm_rope(qs, true);
+      else if (wave == 1) norm_rope(ks_new, false);
     }
   }
   __syncthreads();
@@ -591,7 +634,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
       // The four 16-key passes of a chunk go in groups of PG whose loads are ALL requested before the first is used (as one rolled sequence the
       // passes shared their registers and every pass waited for its own loads: four serial round trips per chunk); a group with no visible key
       // is skipped (wave-uniform) and scores -inf.
-      constexpr int PG = DH == 64 ? 4 : 2;
+      constexpr int PG = DH == 64 ? 4 : (NW == 16 ? 1 : 2);   // (the 1024-thread instantiation has 128 registers per lane)
       const int sub = lane & 3, grp = lane >> 2;
 #pragma unroll
       for (int pg = 0; pg < 4; pg += PG) {
@@ -719,7 +762,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
     for (int i = 0; i < ND; ++i) o[i] = o[i] * alpha + p * vs_new[i * 64 + lane];
     m = m_new;
   }
-  if (fused && wave == 1 && h % (a.heads / a.kv_heads) == 0) {   // one writer per (item, kv head): the processed k and the raw v go into the cache
+  if (fused && wave == (NW > 1 ? 1 : 0) && h % (a.heads / a.kv_heads) == 0) {   // one writer per (item, kv head): the processed k and the raw v go into the cache
     using kvw = typename kv_t<KVT>::type;
     kvw* kdst = (kvw*)a.k + (int64_t)b * a.k_bstride + (a.k_hstride ? (int64_t)g * a.k_hstride : (int64_t)g * DH) + (int64_t)(len_k - 1) * a.ldk;
     kvw* vdst = (kvw*)a.v + (int64_t)b * a.v_bstride + (a.v_hstride ? (int64_t)g * a.v_hstride : (int64_t)g * DH) + (int64_t)(len_k - 1) * a.ldv;
@@ -870,12 +913,18 @@ extern "C" int mi355_flash_attention(const mi355_flash_attn_args* ap, void* stre
     // long key ranges (Whisper cross-attention: 1500 keys) get 16 waves per (query, head): the per-wave key loop is a dependent
     // chain of global loads, so more waves in flight is what shortens it; short ranges keep 4 waves
     const bool wide = a.Tk > 256;
+    // ... and ranges of at most one 64-key chunk (the code predictor / depth decoder steps: <= 32 positions) ONE wave: of four waves three would
+    // only hold registers and meet barriers, and 64 items x 16 heads of them do not fit the chip in one round
+    static const bool one_off = getenv("MI355_ATTN_ONE_WAVE") != nullptr && getenv("MI355_ATTN_ONE_WAVE")[0] == '0';   // A/B knob
+    const bool one = a.Tk <= 64 && nsplit == 1 && !one_off;
 #define MI355_DECODE_CASE(KVT)                                                                                   \
     if (a.dh == 64) {                                                                                            \
       if (wide) hipLaunchKernelGGL((attn_decode_kernel<64, 16, KVT>), grid, dim3(1024), 0, st, a);               \
+      else if (one) hipLaunchKernelGGL((attn_decode_kernel<64, 1, KVT>), grid, dim3(64), 0, st, a);              \
       else hipLaunchKernelGGL((attn_decode_kernel<64, 4, KVT>), grid, dim3(256), 0, st, a);                      \
     } else {                                                                                                     \
       if (wide) hipLaunchKernelGGL((attn_decode_kernel<128, 16, KVT>), grid, dim3(1024), 0, st, a);              \
+      else if (one) hipLaunchKernelGGL((attn_decode_kernel<128, 1, KVT>), grid, dim3(64), 0, st, a);             \
       else hipLaunchKernelGGL((attn_decode_kernel<128, 4, KVT>), grid, dim3(256), 0, st, a);                     \
     }
     if (kvt == 0) { MI355_DECODE_CASE(0) } else if (kvt == 1) { MI355_DECODE_CASE(1) } else { MI355_DECODE_CASE(2) }
