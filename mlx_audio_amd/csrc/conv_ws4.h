@@ -121,6 +121,11 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
     const int wrow0 = (wave - 4) * 8;  // pass i of this wave covers window rows [wrow0 + 32 i, +8): passes entirely past R are skipped
     constexpr int cstride = GEMM ? 64 : 32;
     float4 s0[NLD], s1[NLD];  // two windows in flight: s0 carries the even items, s1 the odd ones
+    // ... and with each window the prologue's per-channel coefficients of ITS chunk (scale, shift, alpha, 1 / beta): loaded inside convertA -- under
+    // `if (a.pre_scale)` with constants on the other side, then alpha behind them -- they were two SERIAL L2 round trips (s_waitcnt vmcnt(0) each) at
+    // the head of every item, ~1.3 us per chunk and producer wave: more than the consumers need for a 3-tap chunk
+    constexpr int NKC = 2 + ((PRE == P_SNAKE || PRE == P_SNAKEBETA) ? 1 : 0) + (PRE == P_SNAKEBETA ? 1 : 0);
+    float4 k0[NKC], k1[NKC];
     struct item_t { int id, ci, b, l0, len_in; };
     auto advance = [&](item_t& it) {  // next (tile, chunk) item of this workgroup; id = -1 past the end
       if (it.ci + 1 < nch) { ++it.ci; return; }
@@ -131,38 +136,48 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
 
     // window row r = prow + 32 i of a chunk: conv mode = input row l0 - pad + r, channels [32 chunk, +32);
     // GEMM mode = input row l0 + (r & 127), channels [64 chunk + 32 (r >> 7), +32)
-    auto loadA = [&](float4 (&areg)[NLD], const item_t& it) {
+    auto loadA = [&](float4 (&areg)[NLD], float4 (&kreg)[NKC], const item_t& it) {
       const int chunk = it.ci, l0 = it.l0;
       const float* xb = xbase + (int64_t)it.b * a.x_bstride;
+      {
+        const int c = chunk * cstride + c4;
+        const float* const safe = (const float*)a.w;   // an absent operand reads the weight image (valid, 16-byte aligned) and is dropped by a select
+        const bool aff = !GEMM && a.pre_scale != nullptr;
+        kreg[0] = *(const float4*)(aff ? a.pre_scale + (int64_t)it.b * a.pre_ld + c : safe);
+        kreg[1] = *(const float4*)(aff ? a.pre_shift + (int64_t)it.b * a.pre_ld + c : safe);
+        if constexpr (PRE == P_SNAKE || PRE == P_SNAKEBETA) kreg[2] = *(const float4*)(a.pre_alpha + c);
+        if constexpr (PRE == P_SNAKEBETA) kreg[3] = *(const float4*)(a.pre_inv_beta + c);
+      }
+      // every pass loads, unconditionally: a pass entirely past the window (wave-uniform) repeats pass 0's address (the same cache lines, never
+      // converted).  With the passes under `if (wrow0 + 32 i < R)` the number of loads per window was unknown to the compiler's wait-count
+      // bookkeeping, and the wait for window j became s_waitcnt vmcnt(0): it also waited for window j + 1, issued half an item earlier -- one
+      // window of prefetch instead of two
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
-        if (GEMM || wrow0 + i * 32 < R) {
-          int gl = GEMM ? l0 + prow + 32 * (i & 3) : l0 - a.pad + prow + 32 * i;
-          int c = chunk * cstride + (GEMM ? 32 * (i >> 2) : 0) + c4;
-          gl = gl < 0 ? 0 : (gl >= a.Lin ? a.Lin - 1 : gl);
-          if (c >= a.Cin) c = 0;
-          areg[i] = *(const float4*)(xb + (int64_t)gl * a.ldx + c);
-        }
+        const int ii = (GEMM || wrow0 + i * 32 < R) ? i : 0;
+        int gl = GEMM ? l0 + prow + 32 * (ii & 3) : l0 - a.pad + prow + 32 * ii;
+        int c = chunk * cstride + (GEMM ? 32 * (ii >> 2) : 0) + c4;
+        gl = gl < 0 ? 0 : (gl >= a.Lin ? a.Lin - 1 : gl);
+        if (c >= a.Cin) c = 0;
+        areg[i] = *(const float4*)(xb + (int64_t)gl * a.ldx + c);
       }
     };
-    auto convertA = [&](const float4 (&areg)[NLD], const item_t& it, char* A_hi) {
+    auto convertA = [&](const float4 (&areg)[NLD], const float4 (&kreg)[NKC], const item_t& it, char* A_hi) {
       const int chunk = it.ci, l0 = it.l0, b = it.b, len_in = it.len_in;
       char* A_lo = A_hi + ABYTES;
       const int c = chunk * cstride + c4;  // GEMM mode (no prologue coefficients): passes 4..7 carry channels c + 32
       float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f}, al[4] = {1.f, 1.f, 1.f, 1.f}, ial[4] = {1.f, 1.f, 1.f, 1.f};
       if constexpr (!GEMM) {
-        if (a.pre_scale) {
-          const float4 s4 = *(const float4*)(a.pre_scale + (int64_t)b * a.pre_ld + c);
-          const float4 h4 = *(const float4*)(a.pre_shift + (int64_t)b * a.pre_ld + c);
-          sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
-          sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
-        }
+        const bool aff = a.pre_scale != nullptr;
+        const float4 s4 = kreg[0], h4 = kreg[1];
+        sc[0] = aff ? s4.x : 1.f; sc[1] = aff ? s4.y : 1.f; sc[2] = aff ? s4.z : 1.f; sc[3] = aff ? s4.w : 1.f;
+        sh[0] = aff ? h4.x : 0.f; sh[1] = aff ? h4.y : 0.f; sh[2] = aff ? h4.z : 0.f; sh[3] = aff ? h4.w : 0.f;
       }
       if constexpr (PRE == P_SNAKE || PRE == P_SNAKEBETA) {
-        const float4 a4 = *(const float4*)(a.pre_alpha + c);
+        const float4 a4 = kreg[2];
         al[0] = a4.x; al[1] = a4.y; al[2] = a4.z; al[3] = a4.w;
         if constexpr (PRE == P_SNAKEBETA) {  // x + sin^2(alpha x) * inv_beta[c]
-          const float4 b4 = *(const float4*)(a.pre_inv_beta + c);
+          const float4 b4 = kreg[3];
           ial[0] = b4.x; ial[1] = b4.y; ial[2] = b4.z; ial[3] = b4.w;
         }
 #pragma unroll
@@ -276,19 +291,19 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
     item_t ib = ia;
     advance(ib);
     constexpr bool work = (ABL & 4) == 0;
-    if (work) loadA(s0, ia);
-    if (work && ib.id >= 0) loadA(s1, ib);
+    if (work) loadA(s0, k0, ia);
+    if (work && ib.id >= 0) loadA(s1, k1, ib);
     while (true) {
-      if (work) convertA(s0, ia, Abase);
+      if (work) convertA(s0, k0, ia, Abase);
       item_t na = ib;
       if (na.id >= 0) advance(na);
-      if (work && na.id >= 0) loadA(s0, na);
+      if (work) loadA(s0, k0, na.id >= 0 ? na : ia);   // past the last item: the current one again (unconditional: see loadA), never converted
       lds_barrier();  // even item staged
       if (ib.id < 0) break;
-      if (work) convertA(s1, ib, Abase + WBYTES);
+      if (work) convertA(s1, k1, ib, Abase + WBYTES);
       item_t nb = na;
       if (nb.id >= 0) advance(nb);
-      if (work && nb.id >= 0) loadA(s1, nb);
+      if (work) loadA(s1, k1, nb.id >= 0 ? nb : ib);
       lds_barrier();  // odd item staged
       if (na.id < 0) break;
       ia = na;
