@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void gemv1_stream_kernel(const mi355_gemv_args
     }
   };
   issue(0, ring0);
-  issue(1, ring1);
+  issue(1, ring1);   // unconditional (G == 1: group 0 again, merged with the request in flight): under `if (G > 1)` the loop's waits degrade to vmcnt(1 / 0)
 #pragma unroll
   for (int it = 0; it < NIT; ++it)
     if (!kin[it]) {
@@ -662,12 +662,19 @@ __global__ __launch_bounds__(256) void gemv1_stream_kernel(const mi355_gemv_args
       mine[c][0] = lane == gi ? t : mine[c][0];
     }
   };
-  for (int gi = 0; gi < G; gi += 2) {
+  // the steady state requests two groups ahead; the last pair is consumed without requesting anything (a repeat of the last group there would be
+  // a second trip to HBM for a non-temporal stream).  Only an odd run of >= 3 groups re-reads one group (its last), once.
+  int gi = 0;
+  for (; gi + 2 < G; gi += 2) {
     consume(ring0, gi);
     issue(gi + 2, ring0);
-    consume(ring1, gi + 1);     // gi + 1 == G: a repeat of the last group, parked in a lane the epilogue does not run
+    __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler sinks these requests behind the second group's arithmetic: nothing would overlap)
+    consume(ring1, gi + 1);
     issue(gi + 3, ring1);
+    __builtin_amdgcn_sched_barrier(0);
   }
+  consume(ring0, gi);
+  if (gi + 1 < G) consume(ring1, gi + 1);
   if (lane < G) gemv_epilogue<1, NC>(a, mine, (g0 + lane) * NC);
 }
 

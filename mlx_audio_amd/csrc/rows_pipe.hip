@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void rows_finish_kernel(const mi355_rows_finis
 // situ for 2 MB of slabs, 370 launches per Qwen3-TTS frame: tools/scan_serial_waits.py counts them) in 24 000 instructions of generated code.
 // Here: whole 8-column pieces, NP of them per thread; EVERY operand is loaded unconditionally before the first use (a null operand is replaced by
 // the slab row -- valid memory -- and dropped by a select), threads past the row clamp to its last piece and only their stores are predicated.
-// mi355_rows_finish dispatches here when the call has this shape (no GLU, no activation, no split destination, aligned operands, <= 4096 outputs).
+// mi355_rows_finish dispatches here when the call has this shape (no GLU, no split destination, aligned operands, <= 4096 outputs).
 template <bool F16, int NP>
 __global__ __launch_bounds__(256) void rows_finish_lean_kernel(const mi355_rows_finish_args a) {
   __shared__ float sred[8];
@@ -458,10 +458,31 @@ __global__ __launch_bounds__(256) void rows_finish_lean_kernel(const mi355_rows_
   }
   float lsum = 0.f;
 #pragma unroll
+  for (int it = 0; it < NP; ++it)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[it][e] = v[it][e] * (has_ws ? wsv[it][e] : 1.f) + (has_b ? bv[it][e] : 0.f);
+  if (a.post_act != MI355_ACT_NONE) {   // one switch around the thread's values (the MLP-in epilogue of a non-gated stack: Whisper's GELU)
+    auto each = [&](auto f) {
+#pragma unroll
+      for (int it = 0; it < NP; ++it)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[it][e] = f(v[it][e]);
+    };
+    switch (a.post_act) {
+      case MI355_ACT_LEAKY: each([&](float x) { return x > 0.f ? x : x * a.post_slope; }); break;
+      case MI355_ACT_GELU: each([](float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }); break;
+      case MI355_ACT_SILU: each([](float x) { return x / (1.0f + expf(-x)); }); break;
+      case MI355_ACT_GELU_TANH: each([](float x) { return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x))); }); break;
+      case MI355_ACT_ELU: each([](float x) { return x > 0.f ? x : expm1f(x); }); break;
+      case MI355_ACT_TANH: each([](float x) { return tanhf(x); }); break;
+      default: break;
+    }
+  }
+#pragma unroll
   for (int it = 0; it < NP; ++it) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float t = (v[it][e] * (has_ws ? wsv[it][e] : 1.f) + (has_b ? bv[it][e] : 0.f)) * (has_cs ? cv[it][e] : 1.f);
+      float t = v[it][e] * (has_cs ? cv[it][e] : 1.f);
       t += has_res ? rv[it][e] : 0.f;
       t *= a.out_scale;
       v[it][e] = live[it] ? t : 0.f;
@@ -591,7 +612,7 @@ extern "C" int mi355_rows_finish(const mi355_rows_finish_args* ap, void* stream)
   {   // the straight-line kernel for the shape the decode stacks use (see rows_finish_lean_kernel)
     static const bool lean_off = getenv("MI355_ROWS_FINISH_OLD") != nullptr && getenv("MI355_ROWS_FINISH_OLD")[0] == '1';   // A/B knob
     auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
-    const bool lean = !lean_off && !a.glu && a.post_act == MI355_ACT_NONE && !a.y2 && No % 8 == 0 && No <= 4096 && al16(a.wscale) && al16(a.bias) &&
+    const bool lean = !lean_off && !a.glu && !a.y2 && No % 8 == 0 && No <= 4096 && al16(a.wscale) && al16(a.bias) &&
                       al16(a.colscale) && al16(a.res) && al16(a.norm_weight) && al16(a.norm_bias) && (!a.res || a.ldr % 4 == 0) &&
                       (!a.y || (al16(a.y) && a.ldy % 4 == 0)) && (!a.yn || (al16(a.yn) && a.ldyn % 4 == 0));
     if (lean) {

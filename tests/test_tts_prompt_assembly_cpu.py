@@ -165,6 +165,11 @@ def test_csm_prompt_frames_and_generate_bookkeeping_match_the_reference():
                 n = min(case["frames"][i], max_frames)
                 return {"frames": [torch.tensor([PT.csm_frame(i, j) for j in range(n)], dtype=torch.int32).reshape(n, K)]}
 
+            def generate_chunks(self, tokens, mask, max_frames, *, chunk, **kw):   # the streaming frame loop: the same frames, a block per interval
+                fr = self.generate(tokens, mask, max_frames, **kw)["frames"][0].to(torch.int64)
+                for j in range(0, fr.shape[0], chunk):
+                    yield fr[None, j:j + chunk]
+
         class Host(Model):
             def _decode_frames(self, frames):
                 return torch.zeros(frames.shape[0] * 1920)
@@ -177,7 +182,9 @@ def test_csm_prompt_frames_and_generate_bookkeeping_match_the_reference():
         m._speaker_prefix_space, m._default_voice_match = case["cfg"]["speaker_prefix_space"], case["cfg"]["voice_match"]
         m._use_default_voice_prompt = False
         m._text_tokenizer = SimpleNamespace(encode=tok.ids)
-        m._audio_tokenizer = SimpleNamespace(encode=lambda x: torch.from_numpy(PT.csm_fake_codes(np.asarray(x)[0, 0]))[None])
+        m._audio_tokenizer = SimpleNamespace(encode=lambda x: torch.from_numpy(PT.csm_fake_codes(np.asarray(x)[0, 0]))[None],
+                                             new_stream=lambda b: SimpleNamespace(batch=b),      # what MimiStreamingDecoder drives (stream=True)
+                                             decode_step=lambda tokens, st: torch.zeros(tokens.shape[0], 1, tokens.shape[2] * 1920))
         kw = dict(case["kw"])
         if "context" in kw:
             kw["context"] = [Segment(speaker=sp, text=t, audio=torch.from_numpy(PT.csm_audio(*au))) for sp, t, au in kw["context"]]
