@@ -569,7 +569,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
       float x0 = 0.f, x1 = 0.f;
       if (act) { x0 = vec[i0]; x1 = vec[i1]; }
       if (has_nw) {
-        const float ss = wave_sum(sumsq2(x0, x1));
+        const float ss = wave_sum_fast(sumsq2(x0, x1));   // (the reduction of head_norm_rope_kernel: the two are held bit-equal)
         const float r = rsqrtf(ss / (float)DH + a.norm_eps);
         if (act) { x0 = x0 * r * nw0; x1 = x1 * r * nw1; }
       }
@@ -676,10 +676,10 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
     wave_lds_sync2();
     const float s = ps[wave][lane];
     wave_lds_sync2();  // every lane has its score before ps is overwritten with the probabilities
-    const float m_new = fmaxf(m, wave_max(s));  // finite: key kb itself is visible
+    const float m_new = fmaxf(m, wave_max_fast(s));  // finite: key kb itself is visible (DPP reductions: every lane of the wave is here)
     const float alpha = exp2f(m - m_new);
     const float p = exp2f(s - m_new);
-    l = l * alpha + wave_sum(p);
+    l = l * alpha + wave_sum_fast(p);
     m = m_new;
     ps[wave][lane] = p;
     wave_lds_sync2();
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const mi355_flash_
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < ND; ++i) t = fmaf(qs[i * 64 + lane], ks_new[i * 64 + lane], t);
-    const float s_new = wave_sum(t);
+    const float s_new = wave_sum_fast(t);
     const float m_new = fmaxf(m, s_new);
     const float alpha = exp2f(m - m_new);   // m = -inf (no cached key visible) -> 0
     const float p = exp2f(s_new - m_new);

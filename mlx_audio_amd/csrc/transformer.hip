@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void head_norm_rope_kernel(const mi355_head_ro
   float x0 = 0.f, x1 = 0.f;
   if (act) { x0 = xr[i0]; x1 = xr[i1]; }
   if (nw) {
-    const float ss = wave_sum(sumsq2(x0, x1));
+    const float ss = wave_sum_fast(sumsq2(x0, x1));   // every lane of the wave is here; the fused decode-attention prologue reduces the same way
     const float r = rsqrtf(ss / (float)a.dh + a.eps);
     if (act) { x0 = x0 * r * nw[i0]; x1 = x1 * r * nw[i1]; }
   }
