@@ -489,7 +489,10 @@ def adain_coef(x: torch.Tensor, gb: Optional[torch.Tensor], lens: Optional[torch
 STATS_ROWS = 64  # MI355_STATS_ROWS
 
 # scratch of mi355_conv_gemm's split-K path (launches of few output tiles: one utterance per call), one per (device, stream): launches on a stream
-# are ordered, so consecutive convs can share it
+# are ordered, so consecutive convs can share it.  A fixed 96 MB (MI355_CONV_SPLIT_WS_MB): the dispatcher caps the group count by what fits, so a
+# smaller workspace only means fewer groups.  NOTE (round-3 advisor): whether a launch splits depends on its tile count B * L_out, so one utterance
+# takes a different fp32 summation order alone than inside a batch -- deterministic per shape, equal across shapes only to rounding; code that
+# asserts integer results across batch sizes (durations, token ids) must do so under a margin (tests/test_kokoro_gpu.py, tests/_margin.py)
 SPLIT_WS_BYTES = int(os.environ.get("MI355_CONV_SPLIT_WS_MB", "96")) << 20
 _CONV_SPLIT_WS = {}
 

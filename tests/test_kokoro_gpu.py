@@ -65,7 +65,10 @@ def test_kokoro_front_end_free_running(setup):
     margin = float(((raw - torch.floor(raw)) - 0.5).abs().min())
     assert float((tg["dur_raw"][0, : len(ids)].cpu() - raw).abs().max()) < 5e-4
     assert margin > 1e-3, "pick another seed: the oracle itself sits on a rounding boundary"
-    assert torch.equal(durs[0].cpu(), pd)  # bit-exact integer path
+    # bit-exact integer path UNDER THE MARGIN ABOVE, not unconditionally: the pre-rounding durations carry fp32 summation-order differences of ~1e-6
+    # relative that depend on the launch size (conv_gemm picks its kernel and its split-K grouping by the tile count B * L_out: csrc/conv_gemm.hip
+    # split_groups), so the same utterance may differ at that level between batch sizes; a value >= 1e-3 from a .5 boundary rounds the same everywhere
+    assert torch.equal(durs[0].cpu(), pd)
     assert outs[0].shape == audio_ref[0].shape == (600 * F,)
 
     def rel(a, b):
@@ -191,8 +194,11 @@ def test_kokoro_canonical_short_sentence_forced_durations(setup):
 def test_kokoro_batch_equals_single(setup):
     """Utterance batching is new (the reference is batch-1): every item of a ragged batch must reproduce
     its single-utterance result.  Not bitwise: conv_gemm picks its kernel by the number of 128 x 128 tiles of a launch (the batch fills the
-    wave-specialised kernel from 128 tiles on, a lone short utterance runs the 4-wave one), and the two add the residual at different ends of
-    the fp32 accumulation chain; the ~1e-7 relative differences per layer reach 2e-5 of the waveform peak at the output (measured 1.7e-5)."""
+    wave-specialised kernel from 128 tiles on, a lone short utterance runs the 4-wave one, launches of few tiles split their K loop over several
+    workgroups), and the variants add in different orders; the ~1e-7 relative differences per layer reach 2e-5 of the waveform peak at the output
+    (measured 1.7e-5).  The comparison is FREE-RUNNING (F0 is not injected), so it also depends on no harmonic phase feature sitting at its +-pi wrap
+    for these inputs: a change of the split grouping moved F0 by 5e-6 relative and wrapped one (round 4, tools/diag_batch_single.py) -- the failure
+    mode to look for first when this test breaks after a kernel-selection change."""
     S, eng, _ = setup
     voice = S.make_voice_pack()
     idl = [S.make_phoneme_ids(n, seed=10 + n) for n in (12, 25, 7)]
