@@ -25,7 +25,33 @@ __global__ __launch_bounds__(256) void fq_extrema_kernel(const mi355_fake_quant_
       fq_coef k[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) k[j] = fq_load_coef(a.pre_scale, a.pre_shift, poff, a.pre_act, a.pre_alpha, 4 * c4 + j < a.C ? 4 * c4 + j : a.C - 1);
-      for (int l = blockIdx.x * rps + ty; l < len; l += gridDim.x * rps) {
+      int l = blockIdx.x * rps + ty;
+      const int lstep = gridDim.x * rps;
+      if (vec) {
+        // four rows' loads in flight per thread (unconditional: a row past the end repeats the last one -- a maximum does not care); as one
+        // load per trip of a rolled loop the sweep ran at a fraction of the HBM rate
+        for (; l < len; l += 4 * lstep) {
+          float4 t[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int lu = l + u * lstep < len ? l + u * lstep : len - 1;
+            t[u] = *(const float4*)(xb + (int64_t)lu * a.ldx + 4 * c4);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float v[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (4 * c4 + j < a.C) {
+                const float tv = fq_pre_value(v[j], k[j], affine, a.pre_act, a.pre_slope);
+                nmn = fmaxf(nmn, -tv);
+                mx = fmaxf(mx, tv);
+              }
+            }
+          }
+        }
+      }
+      for (; l < len; l += lstep) {
         float v[4];
         if (vec) {
           const float4 t = *(const float4*)(xb + (int64_t)l * a.ldx + 4 * c4);
