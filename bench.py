@@ -40,12 +40,19 @@ def parse():
     ap.add_argument("--batch", type=int, default=64,
                     help="utterances per GPU per step (SURVEY 8d batch list: 1 / 8 / 64 / 512; 64 per GPU = 512 over the 8-GPU node; measured on one\n"
                          "MI355X: 122 M samples/s at 32, 140 M at 64, 146 M at 128, 150 M at 256 -- the front end's latency-bound LSTMs amortise)")
-    ap.add_argument("--precision", type=int, default=5,
-                    help="5 = vocoder convs as fp16 hi pass + block-scaled e4m3 lo pass (default; 1.1e-4 of the peak / 85 dB on the canonical sentence), "
-                         "2 = bf16 hi+lo split MFMA everywhere (3e-5), 3 = single fp16 pass in the vocoder (misses the 2e-3 bar), 1 = single bf16 pass")
-    ap.add_argument("--config", choices=["kokoro", "whisper", "qwen3", "csm", "kitten"], default="kokoro",
+    ap.add_argument("--precision", type=int, default=None,
+                    help="default: the mode load_model() / KokoroEngine pick for a bf16 checkpoint (KokoroEngine.default_precision = 5: vocoder convs of >= 7 taps\n"
+                         "as fp16 hi pass + block-scaled e4m3 lo pass; 8.8e-5 of the peak / 85 dB on the canonical sentence x 64, tests/test_kokoro_gpu.py::\n"
+                         "test_kokoro_precision5_batch64_canonical).  2 = bf16 hi+lo split MFMA everywhere (3e-5), 3 = single fp16 pass in the vocoder (misses the\n"
+                         "2e-3 bar), 1 = single bf16 pass.  The default run also reports mode 2 as value_precision2")
+    ap.add_argument("--no-secondary-precision", action="store_true", help="skip the value_precision2 leg")
+    ap.add_argument("--config", choices=["kokoro", "whisper", "qwen3", "csm", "kitten", "dsp"], default="kokoro",
                     help="kokoro = the headline line (BASELINE config[1]); whisper / qwen3 / csm = the secondary lines of SURVEY 8d (BASELINE configs\n"
-                         "[2] / [3] / [4]) with the same JSON schema (tools/bench_{whisper,qwen3,csm}.py run in-process, 1 GPU)")
+                         "[2] / [3] / [4]) with the same JSON schema (tools/bench_{whisper,qwen3,csm}.py run in-process); dsp = the STFT -> mel -> log front end\n"
+                         "against the HBM roofline (tools/bench_dsp.py)")
+    ap.add_argument("--dry-run-gloo", action="store_true",
+                    help="CPU rehearsal of the multi-GPU launch: the self-launcher spawns --gpus N ranks over gloo, every rank runs the REAL sharded step\n"
+                         "(mlx_audio_amd/shard.py: broadcast, all_reduce, all_to_all) around a stand-in engine, rank 0 prints the JSON line (value is not a measurement)")
     ap.add_argument("--ragged", action="store_true",
                     help="utterance lengths drawn from 20..510 tokens with +-35 %% frames-per-token spread instead of the uniform canonical sentence:\n"
                          "shows the load imbalance the frame-count re-balance (mlx_audio_amd/shard.py) is there for; not the headline configuration")
@@ -62,15 +69,17 @@ def parse():
 
 
 def cpu_baseline(S):
-    """The oracle (restated reference, PyTorch-CPU fp32) on this host's cores, bounded to ~10-30 s of CPU work:
-    the canonical utterance if one pass takes < 8 s on this host, else a quarter-length one (F = 66)."""
+    """The oracle (restated reference, PyTorch-CPU fp32) on this host's cores -- BASELINE.md section 3's protocol: ``torch.set_num_threads(nproc)``
+    with nproc = every core this process may run on (stated as ``cores``), 2 warm-ups, median of 10 -- bounded to ~30 s of CPU work: the
+    canonical utterance if the budget allows 10 repetitions of it, else fewer repetitions (``reps`` / ``capped_at`` say so), else a
+    quarter-length utterance (F = 66)."""
     from oracle.kokoro_ref import KokoroRef
 
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 32))  # intra-op threads beyond ~32 only add synchronisation cost for these conv sizes
+    cores = max(1, avail)
     torch.set_num_threads(cores)
     ref = KokoroRef(S.make_kokoro_weights(), S.KOKORO_CONFIG)
     ids = S.make_phoneme_ids(T_TOKENS - 2, seed=0)
@@ -82,16 +91,46 @@ def cpu_baseline(S):
         ref.forward(ids, ref_s, pred_dur=fd)
         return time.perf_counter() - t0
 
-    probe = run(T_TOKENS)  # F = T = 80: also the warm-up
-    frames = F_FRAMES if probe * F_FRAMES / T_TOKENS < 8.0 else 66
-    reps = 3 if probe * frames / T_TOKENS < 4.0 else 1
+    budget = 30.0
+    run(T_TOKENS)           # warm-up 1 (F = 80: allocator, thread pool)
+    probe = run(T_TOKENS)   # warm-up 2, and the probe that sizes the sample
+    est = probe * F_FRAMES / T_TOKENS
+    frames = F_FRAMES if est * 3 <= budget else 66
+    est = probe * frames / T_TOKENS
+    reps = int(max(1, min(10, budget // max(est, 1e-3))))
     times = sorted(run(frames) for _ in range(reps))
     med = times[len(times) // 2]
     samples = frames * 600
-    return {"value": samples / med, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"1 utterance (T=80, F={frames}, {samples} samples), 1 warm-up (F=80) + median of {reps}; restated "
-                      "reference (oracle/kokoro_ref.py, PyTorch-CPU fp32), not MLX",
-            "x_realtime": samples / 24000.0 / med, "host_cores_available": avail}
+    out = {"value": samples / med, "unit": "samples/s", "cores": cores, "kind": "port",
+           "sample": f"1 utterance (T=80, F={frames}, {samples} samples), 2 warm-ups (F=80) + median of {reps}; torch.set_num_threads({cores}); restated "
+                     "reference (oracle/kokoro_ref.py, PyTorch-CPU fp32), not MLX",
+           "x_realtime": samples / 24000.0 / med, "host_cores_available": avail, "reps": reps}
+    if reps < 10 or frames != F_FRAMES:
+        out["capped_at"] = f"{budget:.0f} s of CPU work: {reps} repetition(s) of F={frames} instead of 10 of F={F_FRAMES}"
+    return out
+
+
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """``python bench.py --gpus N`` with N > 1 and no launcher around it: re-exec this command line under ``torch.distributed.run`` (one rank per
+    GPU, rendezvous on 127.0.0.1), exactly the command the driver would have typed; the ranks' rank 0 prints the JSON line on our stdout."""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def run_secondary(args):
@@ -102,11 +141,8 @@ def run_secondary(args):
     mod = importlib.import_module(f"bench_{args.config}")
     # --gpus N: launched like the headline line (torch.distributed.run, one rank per GPU); the tools read RANK / WORLD_SIZE themselves and shard
     # their batch over the ranks through mlx_audio_amd.shard.ShardChannel (requests out in one broadcast, ragged integer results back)
-    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
-        print("bench.py: --gpus > 1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
-        sys.exit(2)
     argv = ["--steps", str(args.steps), "--warmup", str(args.warmup)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
-    if args.config != "kitten":
+    if args.config not in ("kitten", "dsp"):
         argv += ["--gather", args.gather]
     mod.main(argv)
 
@@ -155,30 +191,48 @@ def pmc_traffic(args):
 
 def main():
     args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        return self_launch(args)   # never returns
     if args.config != "kokoro":
         return run_secondary(args)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    dry = args.dry_run_gloo
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    elif args.gpus > 1:
-        print("bench.py: --gpus > 1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
-        sys.exit(2)
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cpu") if dry else torch.device("cuda", local)
+    if not dry:
+        torch.cuda.set_device(dev)
 
-    from mlx_audio_amd import ops
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+
     from mlx_audio_amd.tts.models.kokoro import synthetic as S
-    from mlx_audio_amd.tts.models.kokoro.engine import KokoroEngine
 
     from mlx_audio_amd import shard
 
-    eng = KokoroEngine(S.make_kokoro_weights(), S.KOKORO_CONFIG, device=dev, precision=args.precision)
+    if dry:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from _bench_util import RehearsalEngine
+
+        ops = None
+        eng = RehearsalEngine()
+        args.no_roofline = args.no_latency = args.no_cpu_baseline = args.no_secondary_precision = True
+    else:
+        from mlx_audio_amd import ops
+        from mlx_audio_amd.tts.models.kokoro.engine import KokoroEngine
+
+        eng = KokoroEngine(S.make_kokoro_weights(), S.KOKORO_CONFIG, device=dev, precision=args.precision)
+    args.precision = eng.precision   # None -> the engine's own default (KokoroEngine.default_precision): what load_model() users get
     B = args.batch
     n_total = B * world
     # requests (token ids) are owned by rank 0 and cross ranks inside the step (one broadcast); voice rows, forced durations and SineGen noise
@@ -235,27 +289,61 @@ def main():
         return shard.kokoro_step(ch, eng, requests, voice_rows, 600, forced_durations_of=forced_rows,
                                  wire_dtype=wire, back_kwargs=noise_kw)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        outs = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(fn, warmup, steps):
+        for _ in range(warmup):
+            fn()
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            outs = fn()
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return outs, dt
+
+    outs, dt = timed(step, args.warmup, args.steps)
     if rank == 0:
         assert len(outs) == n_total and all(o.numel() == f_of[i] * 600 for i, o in enumerate(outs))
         assert bool(torch.isfinite(torch.cat([o.reshape(-1) for o in outs])).all())   # one fused check, after the timed region
+
+    # ---- after the timed region (N = 1): the benchmarked step against the SAME utterance run alone, SineGen inputs fixed on both sides
+    batch_check = None
+    if rank == 0 and world == 1 and not dry and not args.ragged:
+        g = torch.Generator(device="cpu").manual_seed(4321)
+        ri1 = torch.rand((1, 9), generator=g).to(dev)
+        nz1 = torch.randn((1, 2 * F_FRAMES * 300, 9), generator=g).to(dev)
+        fixed = lambda items: dict(rand_ini=ri1.expand(len(items), -1).contiguous(), noise=nz1.expand(len(items), -1, -1).contiguous())  # noqa: E731
+        ob = shard.kokoro_step(ch, eng, requests, voice_rows, 600, forced_durations_of=forced_rows, wire_dtype=wire, back_kwargs=fixed)
+        o1, _ = eng.forward([requests[0]], voice[T_TOKENS - 3], forced_durations=[fds[0]], rand_ini=ri1, noise=nz1)
+        sync()
+        peak = float(o1[0].abs().max())
+        diff = float((ob[0].to(torch.float32) - o1[0]).abs().max())
+        # mode 5: the lone utterance leaves generator stage 0 on the 4-wave kernels (fp16 hi + fp16 lo on the same images) while the batch runs the
+        # MX lo pass there, so the two differ by the lo pass's own error (~1e-4 of the peak); the other modes differ by summation order only
+        bar = 4e-4 if args.precision == 5 else 5e-5
+        batch_check = {"max_abs_diff_over_peak": diff / peak, "bar": bar, "what": "utterance 0 of the benchmarked batch step vs the same utterance run alone (free-running, "
+                       "fixed SineGen inputs), max |diff| / peak"}
+        assert diff <= bar * peak, batch_check
+        del ob, o1, nz1
+
+    # ---- the other precision mode on the same workload (N = 1): bf16 hi + lo split everywhere (mode 2), reported as value_precision2
+    p2 = None
+    if rank == 0 and world == 1 and not args.no_secondary_precision and not args.pmc_child and not args.ragged and args.precision != 2:
+        eng_main = eng
+        eng = KokoroEngine(S.make_kokoro_weights(), S.KOKORO_CONFIG, device=dev, precision=2)   # `step` reads the name `eng`
+        _, dt2 = timed(step, min(args.warmup, 2), args.steps)
+        p2 = {"value": sum(f_of) * 600 * args.steps / dt2, "ms_per_step": 1000.0 * dt2 / args.steps}
+        eng = eng_main
+        torch.cuda.empty_cache()
 
     res = None
     if rank == 0:
@@ -265,7 +353,7 @@ def main():
             "metric": "audio samples/sec + real-time factor, Kokoro-82M TTS", "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {2: "bf16 weights x fp32 activations (bf16 hi+lo split MFMA, fp32 accumulate)",
+            "dtype": {0: "none (dry run: stand-in engine)", 2: "bf16 weights x fp32 activations (bf16 hi+lo split MFMA, fp32 accumulate)",
                       3: "fp16 activations x bf16-valued weights in fp16 (single MFMA pass, fp32 accumulate) in the vocoder; hi+lo front end",
                       1: "bf16", 4: "fp16-valued weights x fp32 activations (fp16 hi+lo split MFMA)",
                       5: "bf16 weights x fp32 activations: vocoder convs = fp16 hi pass (v_mfma_f32_32x32x16_f16) + block-scaled e4m3 lo pass "
@@ -281,6 +369,13 @@ def main():
                        "shard_plan_makespan_frames": shard.makespan(f_of, ch.owned), "collectives_per_step": ch.collectives // max(1, args.steps + args.warmup)},
             "x_realtime": value / 24000.0, "rtf_reference_style": 24000.0 / value,
         }
+        if batch_check:
+            res["batch_vs_single"] = batch_check
+        if p2:
+            res["value_precision2"] = p2["value"]
+            res["ms_per_step_precision2"] = p2["ms_per_step"]
+        if dry:
+            res["dry_run"] = "gloo rehearsal on CPU with a stand-in engine: the collectives are the real ones, the value is NOT a measurement"
     # ---- roofline leg (rank 0, N=1 only): one extra instrumented step, events around every conv_gemm launch
     if rank == 0 and world == 1 and not args.no_roofline:
         ops.PROFILE = []
@@ -321,8 +416,9 @@ def main():
             "conv_gemm_ms_per_step": ms, "instrumented_step_ms": e0.elapsed_time(e1),
             "hbm_view": {"algorithmic_GB_per_step": byts / 1e9, "achieved_GBps": byts / (ms * 1e-3) / 1e9,
                          "peak_GBps": HBM_PEAK_GBS, "frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "note": "arithmetic intensity of the conv stack (~330-650 FLOP/B) is above the bf16 ridge (~312), so MFMA is the "
-                    "binding roofline; the HBM view is reported alongside (DESIGN.md)",
+            "note": "intensity of the conv stack AS RUN (fp32 activations in HBM: flops / algorithmic bytes of this line = %.0f FLOP/B) is BELOW the bf16 ridge "
+                    "(2500 TF/s / 8 TB/s = 312 FLOP/B): the k = 3 convs sit on the HBM side (2.8-4.0 TB/s of their bytes), the k >= 7 convs on the MFMA / issue "
+                    "side; `frac` prices the whole set against MFMA, `hbm_view` against HBM (DESIGN.md section 6)" % (flops / max(byts, 1.0)),
         }
     # ---- latency leg (rank 0, N=1 only): ONE canonical utterance at a time, the reference's own configuration (config[0] / [1] synthesise a single
     # sentence); median wall time of the whole request: ids -> waveform on the device, SineGen noise drawn inside, synchronised

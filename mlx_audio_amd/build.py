@@ -34,7 +34,7 @@ def _hipcc() -> str:
 
 def _fingerprint() -> str:
     h = hashlib.sha256()
-    for name in SOURCES + ["common.h", "conv_common.h", "conv_ws4.h"]:
+    for name in SOURCES + ["common.h", "conv_common.h", "conv_ws4.h", "fft_fast.h", "fft_tw.h"]:
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
     with open(HEADER, "rb") as f:

@@ -100,10 +100,10 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(const mi355_conv_ge
         int64_t base = (int64_t)a.x_off + (int64_t)gl * a.ldx + cc;
         if (a.flat_valid > 0) {   // flattened strided conv on 16-byte aligned runs: validity by flat element index, every bound a multiple of 4
           rin[u] = r < R && c < a.Cin && base >= 0 && base + 3 < flat_hi;
-          base = base < 0 ? 0 : (base + 3 < flat_hi ? base : flat_hi - 4);
+          base = base < 0 ? 0 : (base + 3 < flat_hi ? base : (flat_hi >= 4 ? flat_hi - 4 : 0));   // an empty item (flat_hi = 0) reads element 0, dropped by rin
         } else {
           rin[u] = r < R && c < a.Cin && gl >= 0 && gl < len_in;
-          const int glc = gl < 0 ? 0 : (gl < len_in ? gl : len_in - 1);
+          const int glc = gl < 0 ? 0 : (gl < len_in ? gl : (len_in > 0 ? len_in - 1 : 0));   // lens_in[b] == 0: row 0 (inside the allocation), dropped by rin
           base = (int64_t)a.x_off + (int64_t)glc * a.ldx + cc;
         }
         t[u] = *(const float4*)(xb + base);

@@ -9,6 +9,8 @@
 // complex FFT.  A workgroup transforms several frame pairs at once so that all 256 lanes have
 // butterflies even for n_fft = 400.
 #include "common.h"
+#include "fft_fast.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -317,6 +319,52 @@ __global__ __launch_bounds__(256) void kaldi_frames_kernel(const mi355_kaldi_fra
   }
 }
 
+// ---- the register-resident two-pass kernels (fft_fast.h) for the sizes the in-scope front ends use; MI355_FFT_FAST=0 keeps the LDS Stockham
+// kernel for every size (A/B aid).  Persistent grid: as many workgroups as are resident at once (LDS-limited), never more than tiles.
+bool fast_enabled() {  // read per call: the A/B test flips it inside one process
+  const char* e = getenv("MI355_FFT_FAST");
+  return !(e && e[0] == '0');
+}
+int cu_count() {
+  static const int n = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t pr;
+      if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+    }
+    return cus;
+  }();
+  return n;
+}
+template <int N1, int N2, int MODE>
+int launch_fast(const StftCommon& c, int B, float* out, const float* fb, int n_mels, int mel_mode, float* gmax, hipStream_t st, const char* name) {
+  using G = mi355fft::FastGeom<N1, N2>;
+  const size_t lds = G::lds_bytes(MODE == 1);
+  if (int r = set_lds(mi355fft::stft_fast_kernel<N1, N2, MODE>, lds, name)) return r;
+  const int tiles_per_item = (c.n_frames + 2 * G::P - 1) / (2 * G::P);
+  const int64_t total = (int64_t)tiles_per_item * B;
+  MI355_REQUIRE(total < (1ll << 31), "%s: too many tiles", name);
+  const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
+  const int64_t resident = (int64_t)cu_count() * (per_cu > 4 ? 4 : per_cu);
+  const int grid = (int)(total < resident ? total : resident);
+  mi355fft::FastArgs a{c.x, c.ldx, c.L, c.hop, c.window, c.pad_mode, c.n_frames, B, tiles_per_item, (int)total, out, fb, n_mels, mel_mode, gmax};
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL((mi355fft::stft_fast_kernel<N1, N2, MODE>), dim3(grid), dim3(mi355fft::kFastThreads), lds, st, a);
+  MI355_LAUNCH_CHECK(name);
+  return MI355_OK;
+}
+// returns -1 when the size has no fast instantiation
+template <int MODE>
+int try_fast(const StftCommon& c, int B, float* out, const float* fb, int n_mels, int mel_mode, float* gmax, hipStream_t st, const char* name) {
+  if (!fast_enabled() || (MODE == 1 && n_mels > mi355fft::kMaxMels)) return -1;
+  switch (c.n_fft) {
+    case 400: return launch_fast<20, 20, MODE>(c, B, out, fb, n_mels, mel_mode, gmax, st, name);
+    case 512: return launch_fast<16, 32, MODE>(c, B, out, fb, n_mels, mel_mode, gmax, st, name);
+    case 1024: return launch_fast<32, 32, MODE>(c, B, out, fb, n_mels, mel_mode, gmax, st, name);
+    default: return -1;
+  }
+}
+
 }  // namespace
 
 extern "C" int mi355_stft(const mi355_stft_args* ap, void* stream) {
@@ -325,6 +373,11 @@ extern "C" int mi355_stft(const mi355_stft_args* ap, void* stream) {
   MI355_REQUIRE(a.n_fft >= 2 && a.hop > 0 && a.n_frames > 0 && a.B > 0, "stft: bad shape");
   MI355_REQUIRE(a.pad_mode >= 0 && a.pad_mode <= 2, "stft: pad_mode must be 0 (none), 1 (reflect) or 2 (constant)");
   MI355_REQUIRE(a.pad_mode != 1 || a.L > a.n_fft / 2, "stft: input too short for reflect padding");
+  {
+    StftCommon c{a.x, a.ldx, a.L, a.n_fft, a.hop, a.window, a.pad_mode, a.n_frames};
+    const int r = try_fast<0>(c, a.B, a.out, nullptr, 0, 0, nullptr, (hipStream_t)stream, "stft");
+    if (r >= 0) return r;
+  }
   FftPlan pl;
   MI355_REQUIRE(make_plan(a.n_fft, pl), "stft: n_fft=%d has a prime factor > 61", a.n_fft);
   const int pairs = choose_pairs(a.n_fft, 0);
@@ -346,17 +399,22 @@ extern "C" int mi355_logmel(const mi355_logmel_args* ap, void* stream) {
   MI355_REQUIRE(a.mode >= 0 && a.mode <= 3, "logmel: mode must be 0 (whisper), 1 (qwen3), 2 (kaldi fbank) or 3 (vocos)");
   MI355_REQUIRE(a.pad_mode >= 0 && a.pad_mode <= 2, "logmel: bad pad_mode");
   MI355_REQUIRE(a.pad_mode != 1 || a.L > a.n_fft / 2, "logmel: input too short for reflect padding");
+  hipStream_t st = (hipStream_t)stream;
+  if (a.gmax) {
+    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)a.gmax, (int)0xff800000u, a.B, st);
+    MI355_REQUIRE(e == hipSuccess, "logmel: memset failed: %s", hipGetErrorString(e));
+  }
+  {
+    StftCommon c{a.x, a.ldx, a.L, a.n_fft, a.hop, a.window, a.pad_mode, a.n_frames};
+    const int r = try_fast<1>(c, a.B, a.out, a.fb, a.n_mels, a.mode, a.gmax, st, "logmel");
+    if (r >= 0) return r;
+  }
   FftPlan pl;
   MI355_REQUIRE(make_plan(a.n_fft, pl), "logmel: n_fft=%d has a prime factor > 61", a.n_fft);
   const int nb = a.n_fft / 2 + 1;
   const int pairs = choose_pairs(a.n_fft, nb * 4);
   const size_t lds = (size_t)a.n_fft * 8 * (1 + 2 * pairs) + (size_t)2 * pairs * nb * 4;
   if (int r = set_lds(stft_kernel<1>, lds, "logmel")) return r;
-  hipStream_t st = (hipStream_t)stream;
-  if (a.gmax) {
-    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)a.gmax, (int)0xff800000u, a.B, st);
-    MI355_REQUIRE(e == hipSuccess, "logmel: memset failed: %s", hipGetErrorString(e));
-  }
   StftCommon c{a.x, a.ldx, a.L, a.n_fft, a.hop, a.window, a.pad_mode, a.n_frames};
   const int blocks = (a.n_frames + 2 * pairs - 1) / (2 * pairs);
   MI355_CLEAR_ERROR();

@@ -18,9 +18,37 @@
 // dependent chain inside a launch (x load -> statistics -> staging -> reduction), hence: statistics from the staged LDS copy (one read of x),
 // a staging thread owns columns (norm weight / bias loaded once per column: fewer registers, more waves in flight), weights issued first.
 #include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <utility>
 #include "common.h"
 
 namespace {
+
+// Workgroups of 256 threads (one wave per SIMD) the chip holds at once for kernel `kern` on the CURRENT device: workgroups per CU = waves per
+// SIMD = floor(512 / registers allocated in granules of 8), at most 8 (the occupancy API answered 4 for the 224-register instantiation, which
+// the hardware runs at 2: round-2 call 5), times the CU count.  Cached per (kernel address, device): the launchers below take the kernel as a
+// generic-lambda argument, and every instantiation of one kernel template decays to the same function-pointer TYPE, so a `static` inside the
+// lambda is shared by all of them (the first variant launched would size every other variant's grid).
+int resident_workgroups(const void* kern) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, int> cache;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  const auto key = std::make_pair(kern, dev);
+  const auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int per_cu = 2, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, kern) == hipSuccess && fa.numRegs > 0) {
+    per_cu = 512 / (((fa.numRegs + 7) / 8) * 8);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+  }
+  return cache[key] = per_cu * cus;
+}
 
 
 __device__ __forceinline__ float gemv_act(float v, int act, float slope) {
@@ -1002,38 +1030,14 @@ int launch_gemv1(const mi355_gemv_args& a, hipStream_t st) {
     // round trip: 13.9 us for the 33.5 MB gate|up image of the depth decoder, profiles/r2_kernel_stats_csm_bygrid_call11_m1_kernels.txt); the rest
     // of the columns come grid-stride with their weights prefetched
     auto go = [&](auto kern) {
-      static int resident = 0;   // per instantiation (the lambda's body is instantiated per kernel type)
-      if (resident == 0) {
-        // 256-thread workgroups = one wave per SIMD: workgroups per CU = waves per SIMD = floor(512 / registers allocated in granules of 8), at most 8
-        // (the occupancy API answered 4 for the 224-register instantiation, which the hardware runs at 2: call 5)
-        int per_cu = 2, dev = 0, cus = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        hipFuncAttributes fa;
-        if (hipFuncGetAttributes(&fa, (const void*)kern) == hipSuccess && fa.numRegs > 0) {
-          per_cu = 512 / (((fa.numRegs + 7) / 8) * 8);
-          per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
-        }
-        resident = per_cu * cus;
-      }
+      const int resident = resident_workgroups((const void*)kern);   // per kernel ADDRESS and device (see resident_workgroups)
       int blocks = (ngroups + 3) / 4;
       if (blocks > resident) blocks = resident;
       hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, st, a, ngroups);
     };
     static const bool old1 = getenv("MI355_GEMV1_OLD") != nullptr && getenv("MI355_GEMV1_OLD")[0] == '1';   // A/B knob: the grid-stride kernel
     auto gs = [&](auto kern) {
-      static int resident = 0;
-      if (resident == 0) {
-        int per_cu = 2, dev = 0, cus = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        hipFuncAttributes fa;
-        if (hipFuncGetAttributes(&fa, (const void*)kern) == hipSuccess && fa.numRegs > 0) {
-          per_cu = 512 / (((fa.numRegs + 7) / 8) * 8);
-          per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
-        }
-        resident = per_cu * cus;
-      }
+      const int resident = resident_workgroups((const void*)kern);
       // one resident round of waves, every wave the same contiguous run of groups (<= 64: one lane per group for the epilogue)
       int gpw = (ngroups + resident * 4 - 1) / (resident * 4);
       if (gpw > 64) gpw = 64;

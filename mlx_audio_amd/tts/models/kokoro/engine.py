@@ -174,11 +174,24 @@ class KokoroEngine:
         """(width of the decoder blocks, generator input width, asr_res width): fixed in Kokoro (istftnet.py:948-975)."""
         return 1024, 512, 64
 
+    @staticmethod
+    def default_precision(param_dtype, quant_modules: Sequence[str] = ()) -> int:
+        """The mode an engine runs when the caller names none -- the SAME rule for ``load_model()``, ``smoke()``, the tests and ``bench.py``:
+        bf16 checkpoints (Kokoro-82M-bf16, BASELINE config[1]) -> 5 (fp16 hi pass + block-scaled e4m3 lo pass on the >= 7-tap vocoder convs, exact
+        bf16 images elsewhere: 8.8e-5 of the peak / 85 dB on the canonical sentence at 64 utterances against the 2e-3 / 50 dB bar); float32
+        checkpoints -> 4 (fp16 images, fp16 hi + lo); fp16 checkpoints and engines with fake-quantised modules (KittenTTS: the quantising
+        prologue has no MX form) -> 2."""
+        if param_dtype == torch.float32:
+            return 4
+        return 5 if (param_dtype == torch.bfloat16 and not tuple(quant_modules)) else 2
+
     def __init__(self, weights: Dict[str, torch.Tensor], config: dict, device="cuda", param_dtype=torch.bfloat16,
-                 precision: int = 2, quant_modules: Sequence[str] = ()):
+                 precision: Optional[int] = None, quant_modules: Sequence[str] = ()):
         ops.require_gpu()
         self.cfg = config
         self.qmods = tuple(quant_modules)
+        if precision is None:
+            precision = self.default_precision(param_dtype, self.qmods)
         # precision 4: EVERY conv / linear weight as an fp16 image (11 significant bits instead of bf16's 8) with fp16 hi + lo activations -- the mode
         # for float32 checkpoints, whose values a bf16 image would round at 2^-9 (measured against the reference run on a float32 checkpoint:
         # 35-40 dB with bf16 images).  bf16 checkpoints (Kokoro-82M-bf16, BASELINE config[1]) are exact in the default mode 2.  The recurrent LSTM
@@ -227,7 +240,9 @@ class KokoroEngine:
         w = self._wn(pre)
         # precision 5: MX images where the fp16 hi + e4m3 lo arithmetic is the faster one (>= 7 taps on the wave-specialised kernel); every other
         # conv keeps the default mode's bf16 image (exact weights, the cheapest prologue: the 3-tap convs are HBM / VALU bound)
-        mx = self.precision == 5 and pre.startswith("decoder.") and w.dim() == 3 and ops.mx_pays(w.shape[0], w.shape[1], w.shape[2])
+        # (a conv whose input is fake-quantised -- KittenTTS -- keeps its bf16 image: the quantising prologue has no MX form, mi355_conv_gemm rejects it)
+        mx = (self.precision == 5 and pre.startswith("decoder.") and w.dim() == 3 and ops.mx_pays(w.shape[0], w.shape[1], w.shape[2])
+              and not (self.qmods and self._isq(pre)))
         return ops.pack_conv(w, b, self.dev, f16=self._f16(pre), mx=mx)
 
     def _f16(self, pre: str) -> bool:

@@ -127,9 +127,9 @@ class Model:
         pdt = torch.bfloat16 if torch.bfloat16 in dtypes else (torch.float16 if torch.float16 in dtypes else torch.float32)
         cfg = self.config if isinstance(self.config, dict) else self.config.__dict__
         try:
-            # bf16 / fp16 checkpoints are held exactly by the default mode (2); a float32 checkpoint gets fp16 weight images + fp16 hi / lo
-            # activations (4) unless the caller chose a mode
-            prec = self.precision if self.precision is not None else (4 if pdt == torch.float32 else 2)
+            # one rule for every entry point (KokoroEngine.default_precision): bf16 checkpoints -> 5 (the benchmarked mode), fp16 -> 2 (held exactly
+            # by the bf16 hi + lo images), float32 -> 4 (fp16 weight images + fp16 hi / lo activations), unless the caller chose a mode
+            prec = self.precision if self.precision is not None else KokoroEngine.default_precision(pdt)
             self.engine = KokoroEngine({k: v.to(torch.float32) for k, v in w.items()}, cfg, device=self.device,
                                        param_dtype=pdt, precision=prec)
         except KeyError as e:

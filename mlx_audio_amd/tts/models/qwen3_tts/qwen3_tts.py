@@ -465,17 +465,21 @@ class Model:
 
     def _generate_icl(self, text: str, ref_audio, ref_text: str, language: str = "auto", temperature: float = 0.9, max_tokens: int = 4096, top_k: int = 50,
                       top_p: float = 1.0, repetition_penalty: float = 1.5, stream: bool = False, streaming_interval: float = 2.0,
-                      streaming_context_size: int = 25, seed=None, **engine_kw) -> Generator[GenerationResult, None, None]:
+                      streaming_context_size: int = 25, seed=None, prime_stream_with_reference: bool = False,
+                      **engine_kw) -> Generator[GenerationResult, None, None]:
         """``qwen3_tts.py:2200-2510``: the whole text as ONE segment behind the in-context prompt; the frame loop is the engine's (prefill of the
         prompt, then a talker step + 15 code-predictor steps per frame); decode behind the reference codes and cut them off.  ``stream=True``
-        yields chunks of the NEW audio only, decoded by ``streaming_step`` on a state primed with the reference clip's codes."""
+        yields chunks of the NEW audio only, decoded by ``streaming_step`` on a FRESH decoder state fed with the generated codes alone -- the
+        reference's behaviour (qwen3_tts.py:2266-2444: ``reset_streaming_state()`` then ``streaming_step`` per chunk, no priming).
+        ``prime_stream_with_reference=True`` is a deliberate DEVIATION kept behind this flag: the state is first run over the reference clip's
+        codes (their audio dropped), so the first streamed chunk starts with the conv / attention context the one-shot decode gives it."""
         t0 = time.time()
         x, trailing, pad, ref_codes = self._prepare_icl_generation_inputs(text, ref_audio=ref_audio, ref_text=ref_text, language=language)
         if stream:
             blocks = self._frame_loop(x, trailing, pad, max_tokens, temperature=temperature, top_k=top_k, top_p=top_p, repetition_penalty=repetition_penalty,
                                       seed=seed, pad_when_index_clamped=False, chunk=max(1, int(streaming_interval * 12.5)), **engine_kw)
             rc = None if ref_codes is None else torch.as_tensor(ref_codes)[0].t()   # [1, groups, ref_time] -> frames [ref_time, groups]
-            yield from self._stream_blocks(blocks, 0, prime_codes=rc)
+            yield from self._stream_blocks(blocks, 0, prime_codes=rc if prime_stream_with_reference else None)
             return
         out = self._frame_loop(x, trailing, pad, max_tokens, temperature=temperature, top_k=top_k, top_p=top_p, repetition_penalty=repetition_penalty,
                                seed=seed, pad_when_index_clamped=False, **engine_kw)

@@ -745,3 +745,48 @@ def test_compute_fbank_kaldi_matches_oracle(ops, kw):
     # too-short input under snip_edges
     assert tuple(dsp.compute_fbank_kaldi(torch.from_numpy(audio[:100])).shape) == (0, 60)
     assert tuple(dsp.compute_fbank_kaldi(torch.from_numpy(audio[None])[:, :4800], dither=0.0).shape) == (8, 60)   # [1, L] input accepted
+
+
+@pytest.mark.parametrize("n_fft,hop,n_mels,mode,pad_mode,L,B", [
+    (400, 160, 80, 0, 1, 48000, 3),      # Whisper geometry; 301 frames = 12 full tiles of 24 + a ragged one
+    (400, 160, 80, 0, 2, 5000, 2),       # constant padding, short signal (every tile touches an edge)
+    (1024, 256, 128, 1, 0, 12768, 2),    # Qwen3 speaker mel (caller pads): sqrt(|X|^2 + 1e-9), natural log
+    (1024, 256, 100, 3, 1, 24000, 1),    # Vocos mel
+    (512, 512, 23, 2, 0, 512 * 37, 1),   # Kaldi fbank frames (hop = n_fft, no overlap)
+    (512, 128, 60, 2, 1, 9000, 2),
+])
+def test_fast_stft_logmel_equals_lds_stockham_and_oracle(ops, monkeypatch, n_fft, hop, n_mels, mode, pad_mode, L, B):
+    """The register-resident two-pass kernels (csrc/fft_fast.h: n_fft 400 / 512 / 1024) against (i) the numpy restatement of dsp.stft
+    (dsp.py:385-433) and (ii) the LDS Stockham kernel they replace on these sizes (MI355_FFT_FAST=0), for the complex spectrum and for every
+    mel mode; then a DENSE filterbank (no zero spans: the rows do not fit the LDS budget and are read from L2 instead)."""
+    from oracle import dsp_ref
+
+    rng = np.random.default_rng(n_fft + hop + L)
+    x = (rng.standard_normal((B, L)) * np.linspace(0.2, 3.0, L)[None]).astype(np.float32)
+    win = dsp_ref.hanning(n_fft)
+    nfr = (1 + (L + (2 * (n_fft // 2) if pad_mode else 0) - n_fft) // hop)
+    xd, wd = torch.from_numpy(x).to(DEV), torch.from_numpy(win).to(DEV)
+    sr = {400: 16000, 512: 16000, 1024: 24000}[n_fft]
+    fb = dsp_ref.mel_filters(sr, n_fft, n_mels, norm="slaney", mel_scale="slaney")
+    fbd = torch.from_numpy(np.ascontiguousarray(fb)).to(DEV)
+    dense = torch.from_numpy((rng.random((n_mels, n_fft // 2 + 1)) * 1e-2 + 1e-4).astype(np.float32)).to(DEV)
+
+    def run():
+        spec = ops.stft_frames(xd, n_fft, hop, wd, pad_mode, nfr)
+        mel = ops.logmel(xd, n_fft, hop, wd, pad_mode, nfr, fbd, mode)
+        mel_dense = ops.logmel(xd, n_fft, hop, wd, pad_mode, nfr, dense, mode)
+        torch.cuda.synchronize()
+        return spec.cpu().numpy(), mel.cpu().numpy(), mel_dense.cpu().numpy()
+
+    monkeypatch.setenv("MI355_FFT_FAST", "1")
+    s1, m1, d1 = run()
+    monkeypatch.setenv("MI355_FFT_FAST", "0")
+    s0, m0, d0 = run()
+    scale = np.abs(s0).max()
+    assert np.abs(s1 - s0).max() / scale < 2e-6
+    if pad_mode == 1:
+        ref = np.stack([dsp_ref.stft(r, n_fft=n_fft, hop_length=hop, window=win) for r in x])
+        assert ref.shape == s1.shape and np.abs(s1 - ref).max() / scale < 2e-6
+    # log of a sum of powers: compare where the value is above the clamp floor by a margin, at the fp32 level of the power itself elsewhere
+    assert np.isfinite(m1).all() and np.abs(m1 - m0).max() < 2e-4, np.abs(m1 - m0).max()
+    assert np.abs(d1 - d0).max() < 2e-4, np.abs(d1 - d0).max()

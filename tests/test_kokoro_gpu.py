@@ -282,11 +282,13 @@ def test_kokoro_precision5_mx_lo_pass_mode(setup):
     S, eng, ref = setup
     from mlx_audio_amd.tts.models.kokoro.engine import KokoroEngine
 
-    eng5 = KokoroEngine(S.make_kokoro_weights(), S.KOKORO_CONFIG, precision=5)
+    assert eng.precision == 5, "the engine default for a bf16 checkpoint is the benchmarked mode (KokoroEngine.default_precision)"
+    eng5 = eng
+    eng2 = KokoroEngine(S.make_kokoro_weights(), S.KOKORO_CONFIG, precision=2)
     ids = S.make_phoneme_ids(18, seed=5)
     ref_s = S.make_voice_pack()[len(ids) - 3]
     _, d5, t5 = eng5.forward([ids], ref_s, speed=1.3, return_intermediates=True)
-    _, d2, t2 = eng.forward([ids], ref_s, speed=1.3, return_intermediates=True)
+    _, d2, t2 = eng2.forward([ids], ref_s, speed=1.3, return_intermediates=True)
     torch.cuda.synchronize()
     assert torch.equal(d5[0], d2[0]) and torch.equal(t5["f0"], t2["f0"]) and torch.equal(t5["n"], t2["n"])
     ids = S.make_phoneme_ids(78)
@@ -314,3 +316,47 @@ def test_kokoro_precision5_mx_lo_pass_mode(setup):
     err1, snr1 = float((got - audio_ref[0]).abs().max()), snr_db(got, audio_ref[0])
     print(f"kokoro precision=5, one utterance: max_abs_err={err1:.3e} snr={snr1:.1f} dB")
     assert err1 <= 2e-3 * peak and snr1 >= 50.0, (err1, snr1)
+    # the bf16 hi + lo mode (2) stays covered on the same sentence: same bars
+    outs2, _ = eng2.forward([ids], ref_s, forced_durations=[fd], rand_ini=torch.from_numpy(ri), noise=torch.from_numpy(nz), overrides=_teacher(tr))
+    torch.cuda.synchronize()
+    got = outs2[0].cpu()
+    err2, snr2 = float((got - audio_ref[0]).abs().max()), snr_db(got, audio_ref[0])
+    print(f"kokoro precision=2, one utterance: max_abs_err={err2:.3e} snr={snr2:.1f} dB")
+    assert err2 <= 2e-3 * peak and snr2 >= 50.0, (err2, snr2)
+
+
+def test_kokoro_precision5_batch64_canonical(setup):
+    """The BENCHMARKED configuration is the parity-tested one: 64 canonical utterances (T = 80, F = 264) through bench.py's exact call path --
+    ``shard.kokoro_step`` on a ``ShardChannel`` (world 1), the engine in its default mode (5 for a bf16 checkpoint), ``back_kwargs`` carrying the
+    SineGen inputs -- teacher-forced on the oracle's F0 / N / harmonic features, EVERY one of the 64 waveforms against the fp32 oracle at the
+    2e-3 * peak / 50 dB bars.  At this launch size the generator runs conv_ws4_kernel<5, 2, ...> x 36, <2, 2> x 12, <2, 1> x 21 per pass
+    (profiles/r4_kernel_stats_b64_call21.txt): a different instantiation mix from the 4-utterance test above."""
+    S, eng, ref = setup
+    from mlx_audio_amd import shard
+
+    assert eng.precision == 5
+    nb = 64
+    ids = S.make_phoneme_ids(78)
+    voice = S.make_voice_pack()
+    ref_s = voice[len(ids) - 3]
+    fd = S.forced_durations(80, 264)
+    ri, nz = _noise(264, 1234)
+    audio_ref, _, tr = ref.forward(ids, ref_s, pred_dur=fd, rand_ini=ri, noise=nz, return_intermediates=True)
+    dev = eng.dev
+    tea = {k: torch.as_tensor(v).to(dev).expand(nb, *torch.as_tensor(v).shape[1:]).contiguous() for k, v in _teacher(tr).items()}
+    ri_d = torch.from_numpy(ri).to(dev).expand(nb, -1).contiguous()
+    nz_d = torch.from_numpy(nz).to(dev).expand(nb, -1, -1).contiguous()
+    fd_d = fd.to(dev)
+    ch = shard.ShardChannel(dev, None, max_items=nb, max_tokens=512)
+    outs = shard.kokoro_step(ch, eng, [ids] * nb, lambda i, t: voice[t - 3].to(dev), 600, forced_durations_of=lambda i: fd_d,
+                             back_kwargs=lambda items: dict(rand_ini=ri_d[: len(items)], noise=nz_d[: len(items)],
+                                                            overrides={k: v[: len(items)] for k, v in tea.items()}))
+    torch.cuda.synchronize()
+    assert len(outs) == nb
+    peak = float(audio_ref.abs().max())
+    got = torch.stack([o.cpu() for o in outs])
+    err = (got - audio_ref[0][None]).abs().amax(dim=1)
+    snrs = [snr_db(got[b], audio_ref[0]) for b in range(nb)]
+    print(f"kokoro default mode (5), canonical sentence x {nb} through shard.kokoro_step: peak={peak:.3f} worst max_abs_err={float(err.max()):.3e} "
+          f"({float(err.max()) / peak:.2e} of peak) worst snr={min(snrs):.1f} dB; spread over the batch {float((got - got[0:1]).abs().max()):.2e}")
+    assert float(err.max()) <= 2e-3 * peak and min(snrs) >= 50.0, (float(err.max()), min(snrs))

@@ -408,3 +408,34 @@ def test_batch_generate_streaming_follows_the_reference_loop(monkeypatch, n, max
         assert r.samples == new * PT.QWEN3_ICL_UP and np.array_equal(r.audio.numpy(), wav), (b, pos[b], new, ctx)
         pos[b] += new
     assert pos == gen
+
+
+@pytest.mark.parametrize("prime", [False, True])
+def test_icl_streaming_decoder_state_is_fresh_like_the_reference(monkeypatch, prime):
+    """qwen3_tts.py:2266-2444: the reference's in-context STREAM path resets the decoder's streaming state and feeds ``streaming_step`` the newly
+    generated codes only.  Priming the state with the reference clip's codes is this build's opt-in deviation (``prime_stream_with_reference``)."""
+    from mlx_audio_amd.tts.models.qwen3_tts.qwen3_tts import Model
+
+    G = PT.QWEN3_ICL_GROUPS
+    fed = []
+
+    class Dec:
+        def new_stream(self, n):
+            fed.append("new")
+            return {}
+
+        def streaming_step(self, codes, st):
+            fed.append(tuple(codes.shape))
+            return torch.zeros(1, 1, codes.shape[-1] * 4)
+
+    m = object.__new__(Model)
+    m.speech_tokenizer = SimpleNamespace(decoder=Dec())
+    ref_codes = torch.ones(1, G, 9, dtype=torch.int64)
+    monkeypatch.setattr(m, "_prepare_icl_generation_inputs", lambda *a, **k: (torch.zeros(1, 3, 8), None, None, ref_codes), raising=False)
+    monkeypatch.setattr(m, "_frame_loop", lambda *a, **k: iter([{"block": torch.ones(1, 5, G, dtype=torch.int64)},
+                                                                 {"block": torch.ones(1, 2, G, dtype=torch.int64), "last": True}, {"codes": None}]), raising=False)
+    monkeypatch.setattr(m, "_result", lambda wav, seg, n, dt, **kw: (int(wav.shape[0]), n, kw.get("is_final_chunk")), raising=False)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    out = list(m._generate_icl("some text", torch.zeros(100), "words", stream=True, prime_stream_with_reference=prime))
+    assert out == [(20, 5, False), (8, 2, True)]
+    assert fed == (["new", (1, G, 9)] if prime else ["new"]) + [(1, G, 5), (1, G, 2)]

@@ -142,3 +142,24 @@ class Dist:
         if self.dist:
             self.dist.barrier()
             self.dist.destroy_process_group()
+
+
+class RehearsalEngine:
+    """Stand-in with the Kokoro engine's ``front`` / ``back`` contract for ``bench.py --dry-run-gloo``: the multi-rank launch, the request broadcast,
+    the frame-count all_reduce, the re-balance and the waveform all_to_all of mlx_audio_amd/shard.py are the REAL ones (over gloo, CPU tensors);
+    only the arithmetic between them is replaced (frames = the forced durations' sum, 'waveform' = a ramp keyed on the state that crossed the
+    split, so a wrong move would still be visible to a caller that checks it)."""
+    hid, sty = 512, 128
+    precision = 0
+
+    def front(self, ids, ref_s, forced_durations=None, speed=1.0):
+        from mlx_audio_amd.tts.models.kokoro.engine import KokoroFront
+
+        ids = [i.to(torch.int32) for i in ids]
+        d = [torch.zeros((int(i.numel()), self.hid + self.sty), dtype=torch.float32) + float(i.sum() % 7) for i in ids]
+        dur = [f.to(torch.int32).reshape(-1)[: int(i.numel())] for f, i in zip(forced_durations, ids)]
+        return KokoroFront(ids, ref_s.to(torch.float32), d, dur, [int(x.sum()) for x in dur], speed, None)
+
+    def back(self, st, **kw):
+        outs = [torch.arange(st.frames[b] * 600, dtype=torch.float32) * 1e-6 + float(st.d[b][0, 0]) for b in range(len(st.ids))]
+        return outs, st.dur

@@ -1,0 +1,126 @@
+#!/usr/bin/env python
+"""Secondary benchmark line: the mlx_audio.dsp front end on one MI355X -- the first thing north_star
+names: STFT -> |X|^2 -> mel -> log as ONE kernel (csrc/fft_fast.h), against the HBM roofline.
+
+Workloads (SURVEY 8d "dsp"):
+  * whisper: ``default_rng(0).standard_normal(480_000)`` fp32 + 480 000 zero pad per window -> [6000, 80] log-mel (whisper/audio.py:41-82),
+    ``--batch`` windows per step (default 64).  Algorithmic bytes = 3.84 MB in + 1.92 MB out = 5.76 MB per window.
+  * qwen3: the reference fixture ``np.random.seed(42); randn(12000)`` -> [46, 128] (qwen3_tts.py:64-120), ``--batch`` copies.
+One "step" = one pass over the batch (log-mel of every window, including Whisper's global-max clamp pass).  Prints ONE JSON line; the kernel's
+duration comes from events around the launch (ops run on torch's current stream), ``roofline.bound`` = "hbm".  ``--ab`` adds the LDS Stockham
+kernel this one replaces (MI355_FFT_FAST=0) as ``previous_kernel``.  cpu_baseline = the numpy restatement (oracle/dsp_ref.py) on one window.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+HBM_PEAK_GBS = 8000.0
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--case", choices=["whisper", "qwen3"], default="whisper")
+    ap.add_argument("--ab", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", default="rank0", help=argparse.SUPPRESS)
+    args = ap.parse_args(argv)
+
+    from mlx_audio_amd import dsp, ops
+    from oracle import dsp_ref
+
+    dev = torch.device("cuda", 0)
+    B = args.batch
+    if args.case == "whisper":
+        a = np.random.default_rng(0).standard_normal(480_000).astype(np.float32)
+        x1 = np.concatenate([a, np.zeros(480_000, np.float32)])
+        n_fft, hop, n_mels, mode, pad_mode = 400, 160, 80, 0, 1
+        fb = dsp_ref.mel_filters(16000, 400, 80, norm="slaney", mel_scale=None)
+        n_frames = 1 + len(x1) // hop - 1          # centred frames, last one dropped (whisper/audio.py:78)
+        win = dsp_ref.hanning(n_fft)               # the symmetric form (audio.py:72)
+        ref = lambda: dsp_ref.whisper_log_mel(a, padding=480_000)   # noqa: E731
+        alg_bytes = (len(x1) * 4 + n_frames * n_mels * 4) * B
+        what = f"{B} x (480 000 samples of N(0,1) + 480 000 zeros) -> [{n_frames}, 80] log-mel, n_fft 400 / hop 160 (Whisper front end)"
+    else:
+        np.random.seed(42)
+        a = np.random.randn(12000).astype(np.float32)
+        pad = (1024 - 256) // 2
+        x1 = np.concatenate([a[1: pad + 1][::-1], a, a[-(pad + 1): -1][::-1]]).astype(np.float32)
+        n_fft, hop, n_mels, mode, pad_mode = 1024, 256, 128, 1, 0
+        fb = dsp_ref.mel_filters(24000, 1024, 128, 0.0, 12000.0, norm="slaney", mel_scale="slaney")
+        n_frames = 1 + (len(x1) - n_fft) // hop
+        win = dsp_ref.hanning(n_fft)
+        ref = lambda: dsp_ref.qwen3_mel_spectrogram(a)[0]   # noqa: E731
+        alg_bytes = (len(x1) * 4 + n_frames * n_mels * 4) * B
+        what = f"{B} x the reference fixture randn(12000) -> [{n_frames}, 128] mel, n_fft 1024 / hop 256 (Qwen3 speaker-encoder front end)"
+    x = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(x1, (B, len(x1))))).to(dev)
+    wd, fbd = torch.from_numpy(np.ascontiguousarray(win.astype(np.float32))).to(dev), torch.from_numpy(np.ascontiguousarray(fb)).to(dev)
+
+    def step():
+        return ops.logmel(x, n_fft, hop, wd, pad_mode, n_frames, fbd, mode)
+
+    def timed(steps, warmup):
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / steps
+        # kernel-only: events bracketing ONE launch sequence (main kernel + the clamp pass), median of 5
+        ks = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); step(); e1.record()
+            torch.cuda.synchronize()
+            ks.append(e0.elapsed_time(e1))
+        ks.sort()
+        return out, wall, ks[2] * 1e-3
+
+    os.environ["MI355_FFT_FAST"] = "1"
+    out, wall, ksec = timed(args.steps, args.warmup)
+    got = out[0].cpu().numpy()
+    want = ref()
+    err = float(np.abs(got - want).max())
+    assert got.shape == want.shape and err < 2e-4, (got.shape, want.shape, err)
+    windows_per_s = B / wall
+    res = {"metric": f"dsp log-mel front end ({args.case}), windows/s", "value": windows_per_s, "unit": "windows/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": what, "batch": B, "parallelism": "1 gpu"},
+           "max_abs_err_vs_oracle": err,
+           "roofline": {"bound": "hbm", "kernel": "stft_fast_kernel<N1, N2, 1> (+ logmel_finish_kernel for the Whisper clamp)",
+                        "achieved": alg_bytes / ksec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / ksec / 1e9 / HBM_PEAK_GBS,
+                        "traffic": None, "algorithmic_bytes_per_step": alg_bytes, "kernel_ms_per_step": ksec * 1e3,
+                        "note": "algorithmic bytes = samples in (4 B) + log-mel out (4 B x n_mels per frame), SURVEY 8d; the Whisper clamp pass re-reads "
+                                "and re-writes the output once more (not counted as algorithmic)"}}
+    if args.ab:
+        os.environ["MI355_FFT_FAST"] = "0"
+        out0, wall0, k0 = timed(max(2, args.steps // 4), 1)
+        os.environ["MI355_FFT_FAST"] = "1"
+        res["previous_kernel"] = {"kernel": "stft_kernel<1> (LDS Stockham, one frame pair per workgroup)", "ms_per_step": wall0 * 1e3, "kernel_ms_per_step": k0 * 1e3,
+                                  "max_abs_diff_vs_fast": float((out0 - out).abs().max())}
+    if not args.no_cpu_baseline:
+        t0 = time.perf_counter(); ref(); t1 = time.perf_counter() - t0
+        reps = max(1, min(10, int(10.0 / max(t1, 1e-3))))
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); ref(); ts.append(time.perf_counter() - t0)
+        ts.sort()
+        res["cpu_baseline"] = {"value": 1.0 / ts[len(ts) // 2], "unit": "windows/s", "cores": 1, "kind": "port",
+                               "sample": f"1 window, 1 warm-up + median of {reps} (oracle/dsp_ref.py, numpy; numpy's pocketfft is single-threaded)"}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
