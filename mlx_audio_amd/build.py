@@ -23,6 +23,12 @@ SOURCES = ["api.cpp", "conv_gemm.hip", "conv_ws4.hip", "conv_ws4_p4.hip", "conv_
            "decode_rules.hip", "gemv.hip", "gemv_mfma.hip", "gemv_mfma_fp8.hip", "gemm_rows.hip", "rows_pipe.hip", "transformer.hip", "rvq.hip", "ecapa.hip", "sampler.hip", "stack_step.cpp"]
 # per-file extra flags: source.hip mirrors the reference's fp32 op order one rounding at a time
 EXTRA_FLAGS = {"source.hip": ["-ffp-contract=off"]}
+# Every translation unit: no SLP vectorisation.  Under plain -O3 hipcc packs adjacent scalar fp32 adds / multiplies into v_pk_add_f32 / v_pk_mul_f32 /
+# v_pk_fma_f32 with SGPR-pair operands; in the interior epilogue of conv_ws4_kernel that packed code produced RANDOM errors in the fused
+# instance-norm statistics (the M2 term of a few 32-column fragments per launch, different ones every run; identical inputs, stored outputs
+# correct): round 5, tools/diag_conv_stats.py, profiles/r5_diag_conv_stats_variants_call5.txt -- the same source compiled with
+# -fno-slp-vectorize is exact on every run.  (MI355X_MICROARCH.md also prices packed fp32 beside MFMAs as slower than the scalar pair.)
+COMMON_FLAGS = ["-fno-slp-vectorize"]
 
 
 def _hipcc() -> str:
@@ -40,6 +46,7 @@ def _fingerprint() -> str:
     with open(HEADER, "rb") as f:
         h.update(f.read())
     h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
+    h.update(repr(COMMON_FLAGS).encode())
     return h.hexdigest()
 
 
@@ -57,7 +64,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in SOURCES:
         obj = os.path.join(objdir, src.rsplit(".", 1)[0] + ".o")
         objs.append(obj)
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c",
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *COMMON_FLAGS, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c",
                os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)

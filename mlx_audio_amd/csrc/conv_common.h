@@ -260,7 +260,24 @@ __device__ __forceinline__ void conv_epilogue_interior(const mi355_conv_gemm_arg
         const float cl = (float)(MF * 16);
         const float ml = sK[nf] + s1[nf] / cl;
         const float vl = s2[nf] - s1[nf] * s1[nf] / cl;
+#if defined(MI355_VARIANT) && MI355_VARIANT == 2
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         const float cp = cl, mp = __shfl_xor(ml, 32, 64), vp = __shfl_xor(vl, 32, 64);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 4" ::: "memory");
+#elif defined(MI355_VARIANT) && MI355_VARIANT == 3
+        // lanes l and l + 32 through DPP only (row_bcast31 cannot cross halves on gfx9: use readlane-free v_permlane32_swap)
+        float ml_sw = ml, vl_sw = vl;
+        {
+          typedef unsigned uu2 __attribute__((ext_vector_type(2)));
+          const uu2 r0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, ml), __builtin_bit_cast(unsigned, ml), false, false);
+          const uu2 r1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, vl), __builtin_bit_cast(unsigned, vl), false, false);
+          ml_sw = __builtin_bit_cast(float, lane < 32 ? r0[1] : r0[0]);
+          vl_sw = __builtin_bit_cast(float, lane < 32 ? r1[1] : r1[0]);
+        }
+        const float cp = cl, mp = ml_sw, vp = vl_sw;
+#else
+        const float cp = cl, mp = __shfl_xor(ml, 32, 64), vp = __shfl_xor(vl, 32, 64);
+#endif
         const float ct = cl + cp;
         const float dm = mp - ml;
         const float sum = ml * cl + mp * cp;

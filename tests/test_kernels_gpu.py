@@ -449,9 +449,13 @@ def test_layernorm_variants(ops):
     assert torch.equal(xd[:, :, 512:].cpu(), x2[:, :, 512:])
 
 
-@pytest.mark.parametrize("H,In,L,B", [(256, 640, 41, 2), (64, 96, 19, 3)])
-def test_lstm_vs_oracle(ops, H, In, L, B):
+@pytest.mark.parametrize("oct", ["1", "0"])
+@pytest.mark.parametrize("H,In,L,B", [(256, 640, 41, 2), (128, 256, 23, 3), (64, 96, 19, 3)])
+def test_lstm_vs_oracle(ops, monkeypatch, H, In, L, B, oct):
+    """Both recurrence kernels of csrc/lstm.hip: lstm_oct_kernel (the default for H >= 64) and lstm_kernel (MI355_LSTM_OCT=0)."""
     from oracle import kokoro_ref
+
+    monkeypatch.setenv("MI355_LSTM_OCT", oct)
 
     g = torch.Generator().manual_seed(H)
     s = 1 / math.sqrt(H)
@@ -790,3 +794,39 @@ def test_fast_stft_logmel_equals_lds_stockham_and_oracle(ops, monkeypatch, n_fft
     # log of a sum of powers: compare where the value is above the clamp floor by a margin, at the fp32 level of the power itself elsewhere
     assert np.isfinite(m1).all() and np.abs(m1 - m0).max() < 2e-4, np.abs(m1 - m0).max()
     assert np.abs(d1 - d0).max() < 2e-4, np.abs(d1 - d0).max()
+
+
+@pytest.mark.parametrize("L,C,K,prec", [(256, 512, 3, 2), (264, 512, 3, 2), (5280, 256, 7, 5)])
+def test_conv_ws4_fused_statistics_identical_rows_repeatable(ops, L, C, K, prec):
+    """Regression (round 5): B IDENTICAL rows through the wave-specialised kernel (>= 128 tiles) with fused statistics, several launches.  Every row
+    must carry the same partials, run after run, and they must be the statistics of the stored output.  With hipcc's SLP vectoriser on, the interior
+    epilogue's packed-fp32 code (v_pk_fma_f32 with SGPR-pair operands) returned RANDOM M2 terms for a few 32-column fragments per launch; the
+    library is built with -fno-slp-vectorize (mlx_audio_amd/build.py)."""
+    g = torch.Generator().manual_seed(3)
+    B = 64 if L < 1000 else 4
+    w = bf16r(torch.randn(C, K, C, generator=g) / math.sqrt(K * C))
+    bias = torch.randn(C, generator=g) * 0.1
+    pc = ops.pack_conv(w, bias, DEV, mx=prec == 5)
+    x = torch.randn(1, L, C, generator=g).expand(B, -1, -1).contiguous().to(DEV)
+    sc = (torch.rand(1, C, generator=g) + 0.5).expand(B, -1).contiguous().to(DEV)
+    sh = (torch.randn(1, C, generator=g) * 0.1).expand(B, -1).contiguous().to(DEV)
+    lens = torch.full((B,), L, dtype=torch.int32, device=DEV)
+    nblk = (L + 63) // 64
+    first = None
+    for rep in range(4):
+        y = torch.zeros(B, L, C, device=DEV)
+        st = ops.new_stats(B, L, C, DEV)
+        st.fill_(float("nan"))
+        ops.conv_gemm(x, pc, y, pad=(K - 1) // 2, lens_in=lens, lens_out=lens, pre=(sc, sh), pre_act=ops.ACT_LEAKY, pre_slope=0.2, stats=st, precision=prec)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y[0:1].expand_as(y)) and torch.equal(st, st[0:1].expand_as(st)), rep
+        if first is None:
+            first = (y.clone(), st.clone())
+            ref = torch.empty_like(st[0])
+            for e in range(nblk):
+                blk = y[0, e * 64:min(L, (e + 1) * 64)].double()
+                ref[e, :, 0] = blk.sum(0).float()
+                ref[e, :, 1] = ((blk - blk.mean(0, keepdim=True)) ** 2).sum(0).float()
+            assert float((st[0] - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+        else:
+            assert torch.equal(y, first[0]) and torch.equal(st, first[1]), rep

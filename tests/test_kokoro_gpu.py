@@ -360,3 +360,29 @@ def test_kokoro_precision5_batch64_canonical(setup):
     print(f"kokoro default mode (5), canonical sentence x {nb} through shard.kokoro_step: peak={peak:.3f} worst max_abs_err={float(err.max()):.3e} "
           f"({float(err.max()) / peak:.2e} of peak) worst snr={min(snrs):.1f} dB; spread over the batch {float((got - got[0:1]).abs().max()):.2e}")
     assert float(err.max()) <= 2e-3 * peak and min(snrs) >= 50.0, (float(err.max()), min(snrs))
+
+
+def test_kokoro_identical_utterances_identical_waveforms(setup):
+    """Regression (round 5): 16 IDENTICAL canonical utterances in one free-running call (same ids, style, durations, SineGen inputs; 192 tiles per
+    predictor conv: the wave-specialised kernels) -- every row walks the same tiles of the same kernels, so the 16 F0 / N curves and the 16
+    waveforms must be bit-identical, and a second call must reproduce them.  (The fused instance-norm statistics used to come back with random
+    errors at >= 128 tiles: F0 differed by 1e-2 between rows and runs, tools/diag_batch_rows.py.)"""
+    S, eng, _ = setup
+    B = 16
+    ids = S.make_phoneme_ids(78)
+    ref_s = S.make_voice_pack()[len(ids) - 3]
+    fd = S.forced_durations(80, 264)
+    ri, nz = _noise(264, 1234)
+    ri_d = torch.from_numpy(ri).cuda().expand(B, -1).contiguous()
+    nz_d = torch.from_numpy(nz).cuda().expand(B, -1, -1).contiguous()
+    prev = None
+    for rep in range(2):
+        outs, _, tr = eng.forward([ids] * B, ref_s.repeat(B, 1), forced_durations=[fd] * B, rand_ini=ri_d, noise=nz_d, return_intermediates=True)
+        torch.cuda.synchronize()
+        wav = torch.stack(outs)
+        for k in ("f0", "n", "xg", "stage0", "stage1"):
+            assert torch.equal(tr[k], tr[k][0:1].expand_as(tr[k])), (rep, k, float((tr[k] - tr[k][0:1]).abs().max()))
+        assert torch.equal(wav, wav[0:1].expand_as(wav)), (rep, float((wav - wav[0:1]).abs().max()))
+        if prev is not None:
+            assert torch.equal(wav, prev), float((wav - prev).abs().max())
+        prev = wav
