@@ -198,6 +198,7 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
         for (int j = 0; j < 4; ++j)
           fk[j] = fq_load_coef(a.pre_scale, a.pre_shift, (int64_t)b * a.pre_ld, PRE == P_SNAKE ? MI355_ACT_SNAKE : MI355_ACT_NONE, a.pre_alpha, c + j);
       }
+      const bool chan[4] = {c < a.Cin, c + 1 < a.Cin, c + 2 < a.Cin, c + 3 < a.Cin};   // conv mode: the lane's four channels are the same in every pass
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
         if (GEMM || wrow0 + i * 32 < R) {
@@ -226,7 +227,15 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
               } else if constexpr (PRE == P_ELU) {
                 u = u > 0.f ? u : expm1f(u);
               }
-              tt[j] = (rowok && (cb + j) < a.Cin) ? u : 0.f;
+              if constexpr (GEMM) {
+                tt[j] = (rowok && (cb + j) < a.Cin) ? u : 0.f;
+              } else {
+                // the prologue value is computed UNCONDITIONALLY (opaque to the optimiser) and masked by one v_cndmask: left to itself hipcc sinks
+                // the whole affine + sin chain of every element under its own s_and_saveexec / s_cbranch_execz pair (skipping work for padding rows
+                // that almost never occur), i.e. ~10 SALU instructions, two branches and a s_waitcnt per element in the producers' issue stream
+                asm volatile("" : "+v"(u));
+                tt[j] = (rowok && chan[j]) ? u : 0.f;
+              }
             }
             const int addr = PREC == 5 ? r * HP + c4 * 2 : r * 64 + ((((c4 >> 3) ^ ((r >> 2) & 3))) << 4) + ((c4 & 4) << 1);
             uint2 ph;
@@ -236,7 +245,7 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
               typedef float f2_t __attribute__((ext_vector_type(2)));
               float cl[4];
 #pragma unroll
-              for (int j = 0; j < 4; ++j) cl[j] = __builtin_fminf(__builtin_fmaxf(tt[j], -65504.f), 65504.f);
+              for (int j = 0; j < 4; ++j) cl[j] = __builtin_amdgcn_fmed3f(tt[j], -65504.f, 65504.f);   // one v_med3_f32 instead of min + max
               const h2_t ha = __builtin_convertvector((f2_t){cl[0], cl[1]}, h2_t), hb = __builtin_convertvector((f2_t){cl[2], cl[3]}, h2_t);
               ph.x = __builtin_bit_cast(uint32_t, ha);
               ph.y = __builtin_bit_cast(uint32_t, hb);
@@ -264,7 +273,15 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
             if constexpr (PREC == 5) {
               // MX block = the 32 channels of this window row (the 8 lanes ptid & 7): shared exponent = floor(log2(max |lo|)) - 7, so the scaled
               // elements stay below 256 < 448 (no saturation); E8M0 byte 0 (2^-127) for an all-zero / denormal-sized row
-              const float l0 = tt[0] - hi[0], l1 = tt[1] - hi[1], l2 = tt[2] - hi[2], l3 = tt[3] - hi[3];
+              // lo = t - fp16(t) as ONE v_fma_mix_f32 per element (the half operand is read in place: no v_cvt_f32_f16 back to fp32 first); the
+              // product is exact, so this is the same single rounding as the subtraction
+              typedef _Float16 h2x_t __attribute__((ext_vector_type(2)));
+              (void)sizeof(h2x_t);
+              float l0, l1, l2, l3;   // src0 = the half selected by op_sel[0] of the packed word (op_sel_hi[0] = 1: an f16 source), src1 = -1.0, src2 = t (f32)
+              asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(ph.x), "v"(tt[0]));
+              asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(ph.x), "v"(tt[1]));
+              asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l2) : "v"(ph.y), "v"(tt[2]));
+              asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l3) : "v"(ph.y), "v"(tt[3]));
               const float m4 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(l0), __builtin_fabsf(l1)), __builtin_fmaxf(__builtin_fabsf(l2), __builtin_fabsf(l3)));
               uint32_t mb = __builtin_bit_cast(uint32_t, m4);  // non-negative floats order like unsigned integers
               mb = max(mb, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mb, 0xB1, 0xf, 0xf, true));   // quad_perm [1, 0, 3, 2]

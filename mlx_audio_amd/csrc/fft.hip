@@ -341,12 +341,13 @@ int launch_fast(const StftCommon& c, int B, float* out, const float* fb, int n_m
   using G = mi355fft::FastGeom<N1, N2>;
   const size_t lds = G::lds_bytes(MODE == 1);
   if (int r = set_lds(mi355fft::stft_fast_kernel<N1, N2, MODE>, lds, name)) return r;
-  const int tiles_per_item = (c.n_frames + 2 * G::P - 1) / (2 * G::P);
+  const int tiles_per_item = (c.n_frames + 2 * G::PW - 1) / (2 * G::PW);   // tiles of ONE WAVE
   const int64_t total = (int64_t)tiles_per_item * B;
   MI355_REQUIRE(total < (1ll << 31), "%s: too many tiles", name);
   const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
   const int64_t resident = (int64_t)cu_count() * (per_cu > 4 ? 4 : per_cu);
-  const int grid = (int)(total < resident ? total : resident);
+  const int64_t wgs = (total + mi355fft::kFastWaves - 1) / mi355fft::kFastWaves;
+  const int grid = (int)(wgs < resident ? wgs : resident);
   mi355fft::FastArgs a{c.x, c.ldx, c.L, c.hop, c.window, c.pad_mode, c.n_frames, B, tiles_per_item, (int)total, out, fb, n_mels, mel_mode, gmax};
   MI355_CLEAR_ERROR();
   hipLaunchKernelGGL((mi355fft::stft_fast_kernel<N1, N2, MODE>), dim3(grid), dim3(mi355fft::kFastThreads), lds, st, a);

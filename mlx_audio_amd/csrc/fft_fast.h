@@ -85,22 +85,28 @@ __host__ __device__ __forceinline__ void dft(float2 (&v)[N]) {
 }
 
 constexpr int kFastThreads = 256;
-constexpr int kFbCap = 3072;      // floats of compacted filterbank resident in LDS (80 x 201 slaney: ~480; 128 x 513: ~1150)
+constexpr int kFastWaves = kFastThreads / 64;
+constexpr int kFbCap = 1536;      // floats of compacted filterbank resident in LDS (80 x 201 slaney: ~480; 128 x 513: ~1150)
 constexpr int kMaxMels = 256;
 
+// One WAVE owns a tile of PW frame pairs from the first sample load to the last store: all the data it exchanges between phases (the transform
+// buffer, the power rows, the staged output) sit in its own slice of LDS, so the phases are ordered by the wave's own in-order LDS queue plus a
+// wavefront-scope fence -- there is NO workgroup barrier inside the tile loop, and the four waves of a workgroup (and the two workgroups of a CU)
+// drift apart freely: one is waiting for its samples while another is in its butterflies.  (First form of this kernel, round-5 call 1: 12 pairs
+// per 256-lane workgroup with 7 barriers per tile and 81 KB of LDS = ONE workgroup per CU: 0.87 ms for 64 Whisper windows.)
 template <int N1, int N2>
 struct FastGeom {
   static constexpr int N = N1 * N2, NB = N / 2 + 1;
   static constexpr int PR = N2 + 1;                                                     // row pitch of the in-place buffer (complex elements)
   static constexpr int BASE = N1 * PR;
   static constexpr int PITCH = N2 < 32 ? BASE + ((N2 % 32) - (BASE % 32) + 32) % 32 : BASE;  // pair pitch: = N2 (mod 32) when a pair is narrower than a half wave
-  static constexpr int P = kFastThreads / (N1 > N2 ? N1 : N2);                          // frame pairs per tile: one task per lane in both passes
+  static constexpr int PW = 64 / (N1 > N2 ? N1 : N2);                                   // frame pairs per wave tile: one task per lane in both passes
   static constexpr int NBP = NB | 1;                                                    // odd pitch of the power rows
-  static_assert(P * N1 <= kFastThreads && P * N2 <= kFastThreads, "one task per lane per pass");
-  // bytes: twiddles | window | z | (MODE 1: power rows | compact filterbank | spans)
-  static constexpr size_t lds_bytes(bool mel) {
-    return (size_t)N * 8 + (size_t)N * 4 + (size_t)P * PITCH * 8 + (mel ? (size_t)2 * P * NBP * 4 + (size_t)kFbCap * 4 + (size_t)kMaxMels * 12 + 16 : 0);
-  }
+  static_assert(PW >= 1 && PW * N1 <= 64 && PW * N2 <= 64, "one task per lane per pass");
+  static constexpr size_t wave_bytes(bool mel) { return (size_t)PW * PITCH * 8 + (mel ? (size_t)2 * PW * NBP * 4 : 0); }
+  // bytes: twiddles | window | (MODE 1: compact filterbank | spans) | per-wave slices
+  static constexpr size_t table_bytes(bool mel) { return (size_t)N * 8 + (size_t)N * 4 + (mel ? (size_t)kFbCap * 4 + (size_t)kMaxMels * 12 + 16 : 0); }
+  static constexpr size_t lds_bytes(bool mel) { return table_bytes(mel) + kFastWaves * wave_bytes(mel); }
 };
 
 struct FastArgs {
@@ -113,23 +119,30 @@ __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
   if (v >= 0.f) atomicMax((int*)addr, __float_as_int(v));
   else atomicMin((unsigned int*)addr, __float_as_uint(v));
 }
+// order this wave's LDS traffic: everything issued before is visible to every lane of the wave afterwards (no s_barrier)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // MODE 0: complex spectrum out [B, n_frames, NB, 2];  MODE 1: log-mel out [B, n_frames, n_mels]
 template <int N1, int N2, int MODE>
 __global__ __launch_bounds__(kFastThreads) void stft_fast_kernel(const FastArgs c) {
   using G = FastGeom<N1, N2>;
-  constexpr int N = G::N, NB = G::NB, PR = G::PR, PITCH = G::PITCH, P = G::P, NBP = G::NBP;
+  constexpr int N = G::N, NB = G::NB, PR = G::PR, PITCH = G::PITCH, PW = G::PW, NBP = G::NBP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float2* tw = (float2*)smem;                 // W_N^j
   float* win = (float*)(tw + N);
-  float2* z = (float2*)(win + N);             // [P][PITCH]
-  float* pw = (float*)(z + P * PITCH);        // [2 P][NBP]
-  float* fbc = pw + 2 * P * NBP;              // compacted filterbank rows
+  float* fbc = win + N;                       // MODE 1: compacted filterbank rows | spans | flag
   int* span_lo = (int*)(fbc + kFbCap);
   int* span_len = span_lo + kMaxMels;
   int* span_off = span_len + kMaxMels;
   int* flags = span_off + kMaxMels;           // [0]: rows resident in LDS
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  char* wbase = smem + G::table_bytes(MODE == 1) + (size_t)wv * G::wave_bytes(MODE == 1);
+  float2* z = (float2*)wbase;                 // [PW][PITCH]
+  float* pw = (float*)(z + PW * PITCH);       // [2 PW][NBP]
 
   // ---- once per workgroup
   for (int i = tid; i < N; i += kFastThreads) {
@@ -139,7 +152,7 @@ __global__ __launch_bounds__(kFastThreads) void stft_fast_kernel(const FastArgs 
     win[i] = c.window[i];
   }
   if constexpr (MODE == 1) {
-    for (int m = wv; m < c.n_mels; m += kFastThreads / 64) {
+    for (int m = wv; m < c.n_mels; m += kFastWaves) {
       int lo = NB, hi = 0;
       for (int k = lane; k < NB; k += 64)
         if (c.fb[(int64_t)m * NB + k] != 0.f) { lo = min(lo, k); hi = max(hi, k + 1); }
@@ -155,53 +168,72 @@ __global__ __launch_bounds__(kFastThreads) void stft_fast_kernel(const FastArgs 
     }
     __syncthreads();
     if (flags[0]) {
-      for (int m = wv; m < c.n_mels; m += kFastThreads / 64)
+      for (int m = wv; m < c.n_mels; m += kFastWaves)
         for (int j = lane; j < span_len[m]; j += 64) fbc[span_off[m] + j] = c.fb[(int64_t)m * NB + span_lo[m] + j];
     }
   }
   __syncthreads();
   const bool fb_lds = MODE == 1 ? flags[0] != 0 : false;
   const int off = c.pad_mode ? N / 2 : 0;
+  const bool vec4 = (N2 % 4 == 0) && (c.hop % 4 == 0) && (c.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(c.x) & 15) == 0);
+  int max_b = -1;            // Whisper's running maximum: kept per wave while it stays inside one item, one atomic per item change
+  float max_v = -INFINITY;
 
-  for (int tile = blockIdx.x; tile < c.total_tiles; tile += gridDim.x) {
+  for (int tile = blockIdx.x * kFastWaves + wv; tile < c.total_tiles; tile += gridDim.x * kFastWaves) {
     const int b = tile / c.tiles_per_item;
-    const int f0 = (tile - b * c.tiles_per_item) * 2 * P;
+    const int f0 = (tile - b * c.tiles_per_item) * 2 * PW;
     const float* xb = c.x + (int64_t)b * c.ldx;
     // ---- windowed frames: even frame -> re, odd frame -> im, element n = N2 n1 + n2 at [n1][n2] of the pair's padded matrix
-    const bool inner = f0 * c.hop - off >= 0 && (f0 + 2 * P - 1) * c.hop - off + N <= c.L && f0 + 2 * P <= c.n_frames;
-#pragma unroll 4
-    for (int i = tid; i < P * N; i += kFastThreads) {
-      const int pr = i / N, n = i - pr * N;
-      const int n1 = n / N2, n2 = n - n1 * N2;
-      float v[2];
-      if (inner) {  // every sample of the tile is inside the signal: no reflection, no range checks
+    const bool inner = f0 * c.hop - off >= 0 && (f0 + 2 * PW - 1) * c.hop - off + N <= c.L && f0 + 2 * PW <= c.n_frames;
+    if (inner && vec4) {  // every sample of the tile is inside the signal and 16-byte aligned: four samples of both frames per lane and step
+      constexpr int Q = N / 4;
+#pragma unroll 2
+      for (int i = lane; i < PW * Q; i += 64) {
+        const int pr = i / Q, n = (i - pr * Q) * 4;
+        const int n1 = n / N2, n2 = n - n1 * N2;
         const int idx = (f0 + 2 * pr) * c.hop + n - off;
-        v[0] = xb[idx];
-        v[1] = xb[idx + c.hop];
-      } else {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int f = f0 + 2 * pr + h;
-          float s = 0.f;
-          if (f < c.n_frames) {
-            int idx = f * c.hop + n - off;
-            bool ok = true;
-            if (c.pad_mode == 1) {  // reflect
-              if (idx < 0) idx = -idx;
-              if (idx >= c.L) idx = 2 * (c.L - 1) - idx;
-            } else if (idx < 0 || idx >= c.L) ok = false;  // constant pad / out of range
-            if (ok) s = xb[idx];
-          }
-          v[h] = s;
-        }
+        const float4 a = *(const float4*)(xb + idx), bq = *(const float4*)(xb + idx + c.hop), w = *(const float4*)(win + n);
+        float2* dst = z + pr * PITCH + n1 * PR + n2;
+        dst[0] = make_float2(a.x * w.x, bq.x * w.x);
+        dst[1] = make_float2(a.y * w.y, bq.y * w.y);
+        dst[2] = make_float2(a.z * w.z, bq.z * w.z);
+        dst[3] = make_float2(a.w * w.w, bq.w * w.w);
       }
-      const float w = win[n];
-      z[pr * PITCH + n1 * PR + n2] = make_float2(v[0] * w, v[1] * w);
+    } else {
+#pragma unroll 4
+      for (int i = lane; i < PW * N; i += 64) {
+        const int pr = i / N, n = i - pr * N;
+        const int n1 = n / N2, n2 = n - n1 * N2;
+        float v[2];
+        if (inner) {
+          const int idx = (f0 + 2 * pr) * c.hop + n - off;
+          v[0] = xb[idx];
+          v[1] = xb[idx + c.hop];
+        } else {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int f = f0 + 2 * pr + h;
+            float s = 0.f;
+            if (f < c.n_frames) {
+              int idx = f * c.hop + n - off;
+              bool ok = true;
+              if (c.pad_mode == 1) {  // reflect
+                if (idx < 0) idx = -idx;
+                if (idx >= c.L) idx = 2 * (c.L - 1) - idx;
+              } else if (idx < 0 || idx >= c.L) ok = false;  // constant pad / out of range
+              if (ok) s = xb[idx];
+            }
+            v[h] = s;
+          }
+        }
+        const float w = win[n];
+        z[pr * PITCH + n1 * PR + n2] = make_float2(v[0] * w, v[1] * w);
+      }
     }
-    __syncthreads();
+    wave_sync();
     // ---- pass 1: lane (pair, n2): N1-point DFT down column n2, inter-pass twiddle W_N^{n2 k1}, back into the same column
-    if (tid < P * N2) {
-      const int pr = tid / N2, n2 = tid - pr * N2;
+    if (lane < PW * N2) {
+      const int pr = lane / N2, n2 = lane - pr * N2;
       float2* col = z + pr * PITCH + n2;
       float2 v[N1];
 #pragma unroll
@@ -214,28 +246,28 @@ __global__ __launch_bounds__(kFastThreads) void stft_fast_kernel(const FastArgs 
         col[k1 * PR] = make_float2(v[k1].x * w.x - v[k1].y * w.y, v[k1].x * w.y + v[k1].y * w.x);
       }
     }
-    __syncthreads();
+    wave_sync();
     // ---- pass 2: lane (pair, k1): N2-point DFT along row k1; X[k1 + N1 k2] goes back in natural order (all reads before any write)
     {
       float2 u[N2];
-      const bool act = tid < P * N1;
-      const int pr = act ? tid / N1 : 0, k1 = act ? tid - pr * N1 : 0;
+      const bool act = lane < PW * N1;
+      const int pr = act ? lane / N1 : 0, k1 = act ? lane - pr * N1 : 0;
       if (act) {
         const float2* row = z + pr * PITCH + k1 * PR;
 #pragma unroll
         for (int n2 = 0; n2 < N2; ++n2) u[n2] = row[n2];
         dft<N2>(u);
       }
-      __syncthreads();
+      wave_sync();
       if (act) {
         float2* dst = z + pr * PITCH + k1;
 #pragma unroll
         for (int k2 = 0; k2 < N2; ++k2) dst[N1 * k2] = u[k2];
       }
     }
-    __syncthreads();
+    wave_sync();
     // ---- the two real transforms: Xa = (Z[k] + conj Z[N-k]) / 2, Xb = (Z[k] - conj Z[N-k]) / (2i)
-    for (int i = tid; i < P * NB; i += kFastThreads) {
+    for (int i = lane; i < PW * NB; i += 64) {
       const int pr = i / NB, k = i - pr * NB;
       const float2 zk = z[pr * PITCH + k], zc = z[pr * PITCH + (k == 0 ? 0 : N - k)];
       float2 xa = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
@@ -253,14 +285,18 @@ __global__ __launch_bounds__(kFastThreads) void stft_fast_kernel(const FastArgs 
         pw[(2 * pr + 1) * NBP + k] = pb;
       }
     }
-    __syncthreads();
+    wave_sync();
     if constexpr (MODE == 1) {
-      // ---- mel rows over their spans, log, staged as [frame][n_mels + 1] on top of the (now dead) transform buffer
+      // ---- mel rows over their spans, log, staged as [frame][n_mels | 1] on top of the (now dead) transform buffer
       float* stage = (float*)z;
       const int n_mels = c.n_mels, SP = n_mels | 1;
+      if (b != max_b) {
+        if (c.gmax && max_b >= 0 && lane == 0 && max_v > -INFINITY) atomic_max_f32(c.gmax + max_b, max_v);
+        max_b = b; max_v = -INFINITY;
+      }
       float lmax = -INFINITY;
-      for (int task = tid; task < 2 * P * n_mels; task += kFastThreads) {
-        const int m = task / (2 * P), fl = task - m * (2 * P);
+      for (int task = lane; task < 2 * PW * n_mels; task += 64) {
+        const int m = task / (2 * PW), fl = task - m * (2 * PW);
         if (f0 + fl >= c.n_frames) continue;
         const int lo = span_lo[m], len = span_len[m];
         const float* prow = pw + fl * NBP + lo;
@@ -282,17 +318,20 @@ __global__ __launch_bounds__(kFastThreads) void stft_fast_kernel(const FastArgs 
       if (c.gmax) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
-        if (lane == 0 && lmax > -INFINITY) atomic_max_f32(c.gmax + b, lmax);
+        max_v = fmaxf(max_v, lmax);
       }
-      __syncthreads();
-      const int nf = min(2 * P, c.n_frames - f0);
+      wave_sync();
+      const int nf = min(2 * PW, c.n_frames - f0);
       float* dst = c.out + ((int64_t)b * c.n_frames + f0) * n_mels;
-      for (int i = tid; i < nf * n_mels; i += kFastThreads) {
+      for (int i = lane; i < nf * n_mels; i += 64) {
         const int fl = i / n_mels, m = i - fl * n_mels;
         dst[i] = stage[fl * SP + m];
       }
-      __syncthreads();
+      wave_sync();
     }
+  }
+  if constexpr (MODE == 1) {
+    if (c.gmax && max_b >= 0 && lane == 0 && max_v > -INFINITY) atomic_max_f32(c.gmax + max_b, max_v);
   }
 }
 
