@@ -189,22 +189,35 @@ def pmc_traffic(args):
     env = dict(os.environ, TMPDIR="/tmp")
     tot = {}
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, ctr)
-            cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
+        # third pass: MFMA pipe occupancy of the same launches (SQ_VALU_MFMA_BUSY_CYCLES: cycles summed over the 1024 SIMDs; GRBM_GUI_ACTIVE: cycles
+        # summed over the 8 XCDs, so GUI_ACTIVE / 8 is the launch's duration in shader clocks and also gives the clock the chip actually ran at)
+        for ctrs in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE")):
+            out = os.path.join(tmp, ctrs[0])
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", *ctrs, "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
                    "--steps", "1", "--warmup", "1", "--batch", str(args.batch), "--precision", str(args.precision), "--no-roofline",
                    "--no-cpu-baseline"]
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
             dbs = glob.glob(os.path.join(out, "**", "*results.db"), recursive=True)
             if r.returncode != 0 or not dbs:
                 return None
-            per = per_kernel(dbs[0], ctr)
-            vals = [v for k, vs in per.items() if "conv_ws4_kernel" in k or "conv_gemm_kernel" in k for v in vs]
-            tot[ctr] = (sum(vals), len(vals))
+            for ctr in ctrs:
+                per = per_kernel(dbs[0], ctr)
+                vals = [v for k, vs in per.items() if "conv_ws4_kernel" in k or "conv_gemm_kernel" in k for v in vs]
+                tot[ctr] = (sum(vals), len(vals))
+                if ctr in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):   # ... and of the dominant instantiation alone
+                    dom = [v for k, vs in per.items() if "conv_ws4_kernel<5, 2" in k or "conv_ws4_kernel<2, 2" in k for v in vs]
+                    tot[ctr + "_dom"] = (sum(dom), len(dom))
         n = max(tot["FETCH_SIZE"][1], 1)
-        # the child ran warm-up + timed step = 2 steps; both counters saw the same launches
-        return {"bytes_per_launch": (2.0 * tot["FETCH_SIZE"][0] + tot["WRITE_SIZE"][0]) * 1024.0 / n, "launches_counted": n,
-                "fetch_kb_total": tot["FETCH_SIZE"][0], "write_kb_total": tot["WRITE_SIZE"][0]}
+        res = {"bytes_per_launch": (2.0 * tot["FETCH_SIZE"][0] + tot["WRITE_SIZE"][0]) * 1024.0 / n, "launches_counted": n,
+               "fetch_kb_total": tot["FETCH_SIZE"][0], "write_kb_total": tot["WRITE_SIZE"][0]}
+        gui, busy = tot["GRBM_GUI_ACTIVE"][0], tot["SQ_VALU_MFMA_BUSY_CYCLES"][0]
+        if gui > 0:
+            res["mfma_busy_frac"] = busy / (gui / 8.0 * 1024.0)
+        gd, bd = tot["GRBM_GUI_ACTIVE_dom"][0], tot["SQ_VALU_MFMA_BUSY_CYCLES_dom"][0]
+        if gd > 0:
+            res["mfma_busy_frac_dominant"] = bd / (gd / 8.0 * 1024.0)
+        # the child ran warm-up + timed step = 2 steps; every counter saw the same launches
+        return res
     except Exception:
         return None
     finally:
@@ -351,7 +364,7 @@ def main():
 
     # ---- after the timed region (N = 1): the benchmarked step against the SAME utterance run alone, SineGen inputs fixed on both sides
     batch_check = None
-    if rank == 0 and world == 1 and not dry and not args.ragged:
+    if rank == 0 and world == 1 and not dry and not args.ragged and not args.pmc_child:   # (the PMC child passes count the step's own launches only)
         g = torch.Generator(device="cpu").manual_seed(4321)
         ri1 = torch.rand((1, 9), generator=g).to(dev)
         nz1 = torch.randn((1, 2 * F_FRAMES * 300, 9), generator=g).to(dev)
@@ -451,6 +464,10 @@ def main():
                                         "conv_ws4_kernel + conv_gemm_kernel (implicit-GEMM conv1d/convT/linear, v_mfma_f32_32x32x16_bf16)"),
             "achieved": flops / (ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+            "mfma_busy_frac": pmc.get("mfma_busy_frac") if pmc else None,
+            "mfma_busy_frac_dominant_kernel": pmc.get("mfma_busy_frac_dominant") if pmc else None,
+            "mfma_busy_note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) over the conv launches of a third in-run rocprofv3 pass: the share of "
+                              "SIMD-cycles with the matrix pipe busy, at the clock the chip actually ran (DVFS); dominant = conv_ws4_kernel<5, 2, ...> / <2, 2, ...>",
             "traffic_note": "avg HBM bytes per conv launch measured in this run: (2*FETCH_SIZE + WRITE_SIZE)*1024 over %s launches of two rocprofv3 PMC "
                             "child passes; algorithmic avg = %.3e B per launch (inputs + outputs + residual / accumulate reads + weights, each once)" % (
                                 pmc["launches_counted"] if pmc else "no", byts / max(1, len(prof))),

@@ -287,11 +287,17 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
               mb = max(mb, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mb, 0xB1, 0xf, 0xf, true));   // quad_perm [1, 0, 3, 2]
               mb = max(mb, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mb, 0x4E, 0xf, 0xf, true));   // quad_perm [2, 3, 0, 1]
               mb = max(mb, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mb, 0x141, 0xf, 0xf, true));  // row_half_mirror: the other quad of the 8 lanes
-              const int sb = max((int)(mb >> 23) - 7, 0);
-              const float mul = __builtin_bit_cast(float, (uint32_t)(254 - sb) << 23);  // 2^(127 - sb): exact
-              int pk = 0;
-              pk = __builtin_amdgcn_cvt_pk_fp8_f32(l0 * mul, l1 * mul, pk, false);
-              pk = __builtin_amdgcn_cvt_pk_fp8_f32(l2 * mul, l3 * mul, pk, true);
+              // (floor 1, not 0: the scale then is a NORMAL float for the scaled conversion below; a row that small -- padding, lo == 0 -- converts to 0 anyway)
+              const int sb = max((int)(mb >> 23) - 7, 1);
+              // v_cvt_scalef32_pk_fp8_f32 divides both inputs by 2^(exponent of the scale operand - 127) inside the conversion (probed on gfx950:
+              // tools/probes/cvt_scale_probe.hip, profiles/r5_cvt_scale_probe_call9.txt: bit-identical to multiplying by the exact reciprocal first):
+              // four v_mul_f32 and the 254 - sb arithmetic per four elements less in the producers' issue stream
+              typedef short s16x2 __attribute__((ext_vector_type(2)));
+              const float scl = __builtin_bit_cast(float, (uint32_t)sb << 23);   // 2^(sb - 127)
+              s16x2 p8 = {0, 0};
+              p8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(p8, l0, l1, scl, false);
+              p8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(p8, l2, l3, scl, true);
+              const int pk = __builtin_bit_cast(int, p8);
               char* A_l8 = A_hi + ABYTES;
               *(int*)(A_l8 + r * LP + c4) = pk;
               if ((ptid & 7) == 0) *(uint8_t*)(A_l8 + R * LP + r) = (uint8_t)sb;

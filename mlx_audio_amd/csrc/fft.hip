@@ -336,32 +336,39 @@ int cu_count() {
   }();
   return n;
 }
-template <int N1, int N2, int MODE>
-int launch_fast(const StftCommon& c, int B, float* out, const float* fb, int n_mels, int mel_mode, float* gmax, hipStream_t st, const char* name) {
+template <int N1, int N2, int MODE, int WAVES, bool PREF>
+int launch_fast_cfg(const StftCommon& c, int B, float* out, const float* fb, int n_mels, int mel_mode, float* gmax, hipStream_t st, const char* name) {
   using G = mi355fft::FastGeom<N1, N2>;
-  const size_t lds = G::lds_bytes(MODE == 1);
-  if (int r = set_lds(mi355fft::stft_fast_kernel<N1, N2, MODE>, lds, name)) return r;
+  const size_t lds = G::lds_bytes(MODE == 1, WAVES);
+  if (int r = set_lds(mi355fft::stft_fast_kernel<N1, N2, MODE, WAVES, PREF>, lds, name)) return r;
   const int tiles_per_item = (c.n_frames + 2 * G::PW - 1) / (2 * G::PW);   // tiles of ONE WAVE
   const int64_t total = (int64_t)tiles_per_item * B;
   MI355_REQUIRE(total < (1ll << 31), "%s: too many tiles", name);
-  const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
-  const int64_t resident = (int64_t)cu_count() * (per_cu > 4 ? 4 : per_cu);
-  const int64_t wgs = (total + mi355fft::kFastWaves - 1) / mi355fft::kFastWaves;
+  const int by_lds = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
+  const int by_regs = ((PREF ? 2 : 3) * 4) / WAVES > 0 ? ((PREF ? 2 : 3) * 4) / WAVES : 1;   // waves per SIMD x 4 SIMDs / waves per workgroup
+  const int64_t resident = (int64_t)cu_count() * (by_lds < by_regs ? by_lds : by_regs);
+  const int64_t wgs = (total + WAVES - 1) / WAVES;
   const int grid = (int)(wgs < resident ? wgs : resident);
   mi355fft::FastArgs a{c.x, c.ldx, c.L, c.hop, c.window, c.pad_mode, c.n_frames, B, tiles_per_item, (int)total, out, fb, n_mels, mel_mode, gmax};
   MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL((mi355fft::stft_fast_kernel<N1, N2, MODE>), dim3(grid), dim3(mi355fft::kFastThreads), lds, st, a);
+  hipLaunchKernelGGL((mi355fft::stft_fast_kernel<N1, N2, MODE, WAVES, PREF>), dim3(grid), dim3(WAVES * 64), lds, st, a);
   MI355_LAUNCH_CHECK(name);
   return MI355_OK;
+}
+template <int N1, int N2, int MODE>
+int launch_fast(const StftCommon& c, int B, float* out, const float* fb, int n_mels, int mel_mode, float* gmax, hipStream_t st, const char* name) {
+  const char* e = getenv("MI355_FFT_PREFETCH");   // A/B: 1 = four waves per workgroup with the next tile's samples prefetched into registers
+  if (e && e[0] == '1') return launch_fast_cfg<N1, N2, MODE, 4, true>(c, B, out, fb, n_mels, mel_mode, gmax, st, name);
+  return launch_fast_cfg<N1, N2, MODE, 6, false>(c, B, out, fb, n_mels, mel_mode, gmax, st, name);
 }
 // returns -1 when the size has no fast instantiation
 template <int MODE>
 int try_fast(const StftCommon& c, int B, float* out, const float* fb, int n_mels, int mel_mode, float* gmax, hipStream_t st, const char* name) {
   if (!fast_enabled() || (MODE == 1 && n_mels > mi355fft::kMaxMels)) return -1;
   switch (c.n_fft) {
-    case 400: return launch_fast<20, 20, MODE>(c, B, out, fb, n_mels, mel_mode, gmax, st, name);
-    case 512: return launch_fast<16, 32, MODE>(c, B, out, fb, n_mels, mel_mode, gmax, st, name);
-    case 1024: return launch_fast<32, 32, MODE>(c, B, out, fb, n_mels, mel_mode, gmax, st, name);
+    case 400: return (MODE == 1 && !mi355fft::FastGeom<20, 20>::mel_fits(n_mels)) ? -1 : launch_fast<20, 20, MODE>(c, B, out, fb, n_mels, mel_mode, gmax, st, name);
+    case 512: return (MODE == 1 && !mi355fft::FastGeom<16, 32>::mel_fits(n_mels)) ? -1 : launch_fast<16, 32, MODE>(c, B, out, fb, n_mels, mel_mode, gmax, st, name);
+    case 1024: return (MODE == 1 && !mi355fft::FastGeom<32, 32>::mel_fits(n_mels)) ? -1 : launch_fast<32, 32, MODE>(c, B, out, fb, n_mels, mel_mode, gmax, st, name);
     default: return -1;
   }
 }

@@ -84,8 +84,8 @@ __host__ __device__ __forceinline__ void dft(float2 (&v)[N]) {
   }
 }
 
-constexpr int kFastThreads = 256;
-constexpr int kFastWaves = kFastThreads / 64;
+// two configurations of the same kernel (A/B: MI355_FFT_PREFETCH): WAVES = 6 per workgroup without the register prefetch (<= 168 registers: three
+// waves per SIMD, 12 per CU for n_fft = 400) or WAVES = 4 with the next tile's samples prefetched into registers (two waves per SIMD, 8 per CU)
 constexpr int kFbCap = 1536;      // floats of compacted filterbank resident in LDS (80 x 201 slaney: ~480; 128 x 513: ~1150)
 constexpr int kMaxMels = 256;
 
@@ -103,10 +103,16 @@ struct FastGeom {
   static constexpr int PW = 64 / (N1 > N2 ? N1 : N2);                                   // frame pairs per wave tile: one task per lane in both passes
   static constexpr int NBP = NB | 1;                                                    // odd pitch of the power rows
   static_assert(PW >= 1 && PW * N1 <= 64 && PW * N2 <= 64, "one task per lane per pass");
-  static constexpr size_t wave_bytes(bool mel) { return (size_t)PW * PITCH * 8 + (mel ? (size_t)2 * PW * NBP * 4 : 0); }
+  // a wave's slice: the in-place transform buffer; the power rows [2 PW][NBP] and the staged output [2 PW][kMaxMels + 1] are written on top of it
+  // once the spectrum has been read into registers (they must fit: checked below for the instantiated sizes)
+  static constexpr size_t zbytes = (size_t)PW * PITCH * 8;
+  static constexpr size_t pw_floats = (size_t)2 * PW * NBP;
+  static constexpr size_t wave_bytes(bool) { return zbytes; }
+  // does a filterbank of n_mels rows fit (power rows + staged output inside the slice)?  The launcher falls back to the LDS Stockham kernel otherwise
+  static constexpr bool mel_fits(int n_mels) { return pw_floats * 4 + (size_t)2 * PW * (size_t)(n_mels | 1) * 4 <= zbytes; }
   // bytes: twiddles | window | (MODE 1: compact filterbank | spans) | per-wave slices
   static constexpr size_t table_bytes(bool mel) { return (size_t)N * 8 + (size_t)N * 4 + (mel ? (size_t)kFbCap * 4 + (size_t)kMaxMels * 12 + 16 : 0); }
-  static constexpr size_t lds_bytes(bool mel) { return table_bytes(mel) + kFastWaves * wave_bytes(mel); }
+  static constexpr size_t lds_bytes(bool mel, int waves) { return table_bytes(mel) + (size_t)waves * wave_bytes(mel); }
 };
 
 struct FastArgs {
@@ -127,8 +133,9 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // MODE 0: complex spectrum out [B, n_frames, NB, 2];  MODE 1: log-mel out [B, n_frames, n_mels]
-template <int N1, int N2, int MODE>
-__global__ __launch_bounds__(kFastThreads) void stft_fast_kernel(const FastArgs c) {
+template <int N1, int N2, int MODE, int WAVES, bool PREF>
+__global__ __attribute__((amdgpu_flat_work_group_size(WAVES * 64, WAVES * 64), amdgpu_waves_per_eu(PREF ? 2 : 3))) void stft_fast_kernel(const FastArgs c) {
+  constexpr int kFastThreads = WAVES * 64, kFastWaves = WAVES;
   using G = FastGeom<N1, N2>;
   constexpr int N = G::N, NB = G::NB, PR = G::PR, PITCH = G::PITCH, PW = G::PW, NBP = G::NBP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(kFastThreads) void stft_fast_kernel(const FastArgs 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   char* wbase = smem + G::table_bytes(MODE == 1) + (size_t)wv * G::wave_bytes(MODE == 1);
   float2* z = (float2*)wbase;                 // [PW][PITCH]
-  float* pw = (float*)(z + PW * PITCH);       // [2 PW][NBP]
+  float* pw = (float*)wbase;                  // [2 PW][NBP]: on top of z, written after the spectrum is in registers
 
   // ---- once per workgroup
   for (int i = tid; i < N; i += kFastThreads) {
@@ -179,6 +186,21 @@ __global__ __launch_bounds__(kFastThreads) void stft_fast_kernel(const FastArgs 
   int max_b = -1;            // Whisper's running maximum: kept per wave while it stays inside one item, one atomic per item change
   float max_v = -INFINITY;
 
+  constexpr int Q = N / 4, NL = (PW * Q + 63) / 64;   // float4 pieces of a frame, pieces per lane and tile
+  float4 ra[PREF ? NL : 1], rb[PREF ? NL : 1];        // PREF: the tile's samples (even frame | odd frame) in flight / landed
+  bool have = false;
+  auto load_regs = [&](const float* xrow, const int fr0) {
+#pragma unroll
+    for (int q = 0; q < (PREF ? NL : 0); ++q) {
+      const int i = lane + 64 * q;
+      if (i < PW * Q) {
+        const int pr = i / Q, n = (i - pr * Q) * 4;
+        const int idx = (fr0 + 2 * pr) * c.hop + n - off;
+        ra[q] = *(const float4*)(xrow + idx);
+        rb[q] = *(const float4*)(xrow + idx + c.hop);
+      }
+    }
+  };
   for (int tile = blockIdx.x * kFastWaves + wv; tile < c.total_tiles; tile += gridDim.x * kFastWaves) {
     const int b = tile / c.tiles_per_item;
     const int f0 = (tile - b * c.tiles_per_item) * 2 * PW;
@@ -186,20 +208,48 @@ __global__ __launch_bounds__(kFastThreads) void stft_fast_kernel(const FastArgs 
     // ---- windowed frames: even frame -> re, odd frame -> im, element n = N2 n1 + n2 at [n1][n2] of the pair's padded matrix
     const bool inner = f0 * c.hop - off >= 0 && (f0 + 2 * PW - 1) * c.hop - off + N <= c.L && f0 + 2 * PW <= c.n_frames;
     if (inner && vec4) {  // every sample of the tile is inside the signal and 16-byte aligned: four samples of both frames per lane and step
-      constexpr int Q = N / 4;
+      if constexpr (!PREF) {   // straight from memory, two steps in flight
 #pragma unroll 2
-      for (int i = lane; i < PW * Q; i += 64) {
-        const int pr = i / Q, n = (i - pr * Q) * 4;
-        const int n1 = n / N2, n2 = n - n1 * N2;
-        const int idx = (f0 + 2 * pr) * c.hop + n - off;
-        const float4 a = *(const float4*)(xb + idx), bq = *(const float4*)(xb + idx + c.hop), w = *(const float4*)(win + n);
-        float2* dst = z + pr * PITCH + n1 * PR + n2;
-        dst[0] = make_float2(a.x * w.x, bq.x * w.x);
-        dst[1] = make_float2(a.y * w.y, bq.y * w.y);
-        dst[2] = make_float2(a.z * w.z, bq.z * w.z);
-        dst[3] = make_float2(a.w * w.w, bq.w * w.w);
+        for (int i = lane; i < PW * Q; i += 64) {
+          const int pr = i / Q, n = (i - pr * Q) * 4;
+          const int n1 = n / N2, n2 = n - n1 * N2;
+          const int idx = (f0 + 2 * pr) * c.hop + n - off;
+          const float4 a = *(const float4*)(xb + idx), bq = *(const float4*)(xb + idx + c.hop), w = *(const float4*)(win + n);
+          float2* dst = z + pr * PITCH + n1 * PR + n2;
+          dst[0] = make_float2(a.x * w.x, bq.x * w.x);
+          dst[1] = make_float2(a.y * w.y, bq.y * w.y);
+          dst[2] = make_float2(a.z * w.z, bq.z * w.z);
+          dst[3] = make_float2(a.w * w.w, bq.w * w.w);
+        }
+      } else {
+      if (!have) load_regs(xb, f0);   // first tile of this wave / the one before was an edge tile
+#pragma unroll
+      for (int q = 0; q < NL; ++q) {
+        const int i = lane + 64 * q;
+        if (i < PW * Q) {
+          const int pr = i / Q, n = (i - pr * Q) * 4;
+          const int n1 = n / N2, n2 = n - n1 * N2;
+          const float4 a = ra[q], bq = rb[q], w = *(const float4*)(win + n);
+          float2* dst = z + pr * PITCH + n1 * PR + n2;
+          dst[0] = make_float2(a.x * w.x, bq.x * w.x);
+          dst[1] = make_float2(a.y * w.y, bq.y * w.y);
+          dst[2] = make_float2(a.z * w.z, bq.z * w.z);
+          dst[3] = make_float2(a.w * w.w, bq.w * w.w);
+        }
+      }
+      }
+      // the NEXT tile's samples start their trip from HBM now and land while this tile is in its butterflies and mel rows
+      have = false;
+      const int nt = tile + (int)gridDim.x * kFastWaves;
+      if (PREF && nt < c.total_tiles) {
+        const int nb_ = nt / c.tiles_per_item, nf0 = (nt - nb_ * c.tiles_per_item) * 2 * PW;
+        if (nf0 * c.hop - off >= 0 && (nf0 + 2 * PW - 1) * c.hop - off + N <= c.L && nf0 + 2 * PW <= c.n_frames) {
+          load_regs(c.x + (int64_t)nb_ * c.ldx, nf0);
+          have = true;
+        }
       }
     } else {
+      have = false;
 #pragma unroll 4
       for (int i = lane; i < PW * N; i += 64) {
         const int pr = i / N, n = i - pr * N;
@@ -266,29 +316,47 @@ __global__ __launch_bounds__(kFastThreads) void stft_fast_kernel(const FastArgs 
       }
     }
     wave_sync();
-    // ---- the two real transforms: Xa = (Z[k] + conj Z[N-k]) / 2, Xb = (Z[k] - conj Z[N-k]) / (2i)
-    for (int i = lane; i < PW * NB; i += 64) {
-      const int pr = i / NB, k = i - pr * NB;
-      const float2 zk = z[pr * PITCH + k], zc = z[pr * PITCH + (k == 0 ? 0 : N - k)];
-      float2 xa = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
-      float2 xb2 = make_float2(0.5f * (zk.y + zc.y), 0.5f * (zc.x - zk.x));
-      if (k == 0 || 2 * k == N) { xa.y = 0.f; xb2.y = 0.f; }
-      const int fa = f0 + 2 * pr;
-      if constexpr (MODE == 0) {
-        if (fa < c.n_frames) *(float2*)(c.out + (((int64_t)b * c.n_frames + fa) * NB + k) * 2) = xa;
-        if (fa + 1 < c.n_frames) *(float2*)(c.out + (((int64_t)b * c.n_frames + fa + 1) * NB + k) * 2) = xb2;
-      } else {
-        float pa = xa.x * xa.x + xa.y * xa.y, pb = xb2.x * xb2.x + xb2.y * xb2.y;
-        if (c.mel_mode == 1) { pa = sqrtf(pa + 1e-9f); pb = sqrtf(pb + 1e-9f); }
-        else if (c.mel_mode == 3) { pa = sqrtf(pa); pb = sqrtf(pb); }
-        pw[(2 * pr) * NBP + k] = pa;
-        pw[(2 * pr + 1) * NBP + k] = pb;
+    // ---- the two real transforms: Xa = (Z[k] + conj Z[N-k]) / 2, Xb = (Z[k] - conj Z[N-k]) / (2i).  MODE 1: the powers of a lane's bins wait in
+    // registers until every lane has read its spectrum values, then go back on top of the transform buffer as the rows the mel stage reads
+    constexpr int NS = (PW * NB + 63) / 64;
+    float pa_r[MODE == 1 ? NS : 1], pb_r[MODE == 1 ? NS : 1];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      const int i = lane + 64 * q;
+      if (i < PW * NB) {
+        const int pr = i / NB, k = i - pr * NB;
+        const float2 zk = z[pr * PITCH + k], zc = z[pr * PITCH + (k == 0 ? 0 : N - k)];
+        float2 xa = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+        float2 xb2 = make_float2(0.5f * (zk.y + zc.y), 0.5f * (zc.x - zk.x));
+        if (k == 0 || 2 * k == N) { xa.y = 0.f; xb2.y = 0.f; }
+        const int fa = f0 + 2 * pr;
+        if constexpr (MODE == 0) {
+          if (fa < c.n_frames) *(float2*)(c.out + (((int64_t)b * c.n_frames + fa) * NB + k) * 2) = xa;
+          if (fa + 1 < c.n_frames) *(float2*)(c.out + (((int64_t)b * c.n_frames + fa + 1) * NB + k) * 2) = xb2;
+        } else {
+          float pa = xa.x * xa.x + xa.y * xa.y, pb = xb2.x * xb2.x + xb2.y * xb2.y;
+          if (c.mel_mode == 1) { pa = sqrtf(pa + 1e-9f); pb = sqrtf(pb + 1e-9f); }
+          else if (c.mel_mode == 3) { pa = sqrtf(pa); pb = sqrtf(pb); }
+          pa_r[q] = pa; pb_r[q] = pb;
+        }
       }
     }
     wave_sync();
     if constexpr (MODE == 1) {
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        const int i = lane + 64 * q;
+        if (i < PW * NB) {
+          const int pr = i / NB, k = i - pr * NB;
+          pw[(2 * pr) * NBP + k] = pa_r[q];
+          pw[(2 * pr + 1) * NBP + k] = pb_r[q];
+        }
+      }
+      wave_sync();
+    }
+    if constexpr (MODE == 1) {
       // ---- mel rows over their spans, log, staged as [frame][n_mels | 1] on top of the (now dead) transform buffer
-      float* stage = (float*)z;
+      float* stage = pw + G::pw_floats;   // behind the power rows
       const int n_mels = c.n_mels, SP = n_mels | 1;
       if (b != max_b) {
         if (c.gmax && max_b >= 0 && lane == 0 && max_v > -INFINITY) atomic_max_f32(c.gmax + max_b, max_v);
@@ -301,9 +369,13 @@ __global__ __launch_bounds__(kFastThreads) void stft_fast_kernel(const FastArgs 
         const int lo = span_lo[m], len = span_len[m];
         const float* prow = pw + fl * NBP + lo;
         float s = 0.f;
-        if (fb_lds) {
+        if (fb_lds) {   // two running sums (even / odd k): the LDS round trips of consecutive terms overlap instead of chaining through one fma
           const float* frow = fbc + span_off[m];
-          for (int j = 0; j < len; ++j) s = fmaf(prow[j], frow[j], s);
+          float s1 = 0.f;
+          int j = 0;
+          for (; j + 1 < len; j += 2) { s = fmaf(prow[j], frow[j], s); s1 = fmaf(prow[j + 1], frow[j + 1], s1); }
+          if (j < len) s = fmaf(prow[j], frow[j], s);
+          s += s1;
         } else {
           const float* frow = c.fb + (int64_t)m * NB + lo;
           for (int j = 0; j < len; ++j) s = fmaf(prow[j], frow[j], s);

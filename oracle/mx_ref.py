@@ -63,7 +63,8 @@ def quantise_weights(w: np.ndarray) -> np.ndarray:
 
 def split_activation(t: np.ndarray):
     """t [..., C] float32 (C a multiple of 32, zero padded) -> (hi, lo_q) float64: hi = fp16(clamp(t)), lo_q = the MX-quantised residual with one
-    shared exponent per row and 32-channel chunk: floor(log2(max |lo|)) - 7 (byte 0 = 2^-127 when that would go below)."""
+    shared exponent per row and 32-channel chunk: floor(log2(max |lo|)) - 7, floored at byte 1 = 2^-126 (the kernel hands the scale to
+    v_cvt_scalef32_pk_fp8_f32 as a float, which must be a normal number; a row that small converts to zeros anyway)."""
     t = np.asarray(t, dtype=np.float32)
     hi = np.clip(t, -65504.0, 65504.0).astype(np.float16).astype(np.float32)
     lo = (t - hi).astype(np.float32)                        # exact in float32
@@ -72,7 +73,7 @@ def split_activation(t: np.ndarray):
     blk = lo.reshape(*t.shape[:-1], C // 32, 32)
     amax = np.abs(blk).max(axis=-1)
     ef = (amax.view(np.uint32) >> 23).astype(np.int64)      # biased float32 exponent of the block maximum
-    sb = np.maximum(ef - 7, 0)
+    sb = np.maximum(ef - 7, 1)
     scale = np.exp2((sb - 127).astype(np.float64))[..., None]
     q = e4m3_round(blk.astype(np.float64) / scale) * scale
     return hi.astype(np.float64), q.reshape(t.shape)
