@@ -46,6 +46,7 @@ def parse():
                          "test_kokoro_precision5_batch64_canonical).  2 = bf16 hi+lo split MFMA everywhere (3e-5), 3 = single fp16 pass in the vocoder (misses the\n"
                          "2e-3 bar), 1 = single bf16 pass.  The default run also reports mode 2 as value_precision2")
     ap.add_argument("--no-secondary-precision", action="store_true", help="skip the value_precision2 leg")
+    ap.add_argument("--no-batch-check", action="store_true", help="skip the batch-vs-single leg (a kernel trace of the run then holds the step's launches only)")
     ap.add_argument("--config", choices=["kokoro", "whisper", "qwen3", "csm", "kitten", "dsp"], default="kokoro",
                     help="kokoro = the headline line (BASELINE config[1]); whisper / qwen3 / csm = the secondary lines of SURVEY 8d (BASELINE configs\n"
                          "[2] / [3] / [4]) with the same JSON schema (tools/bench_{whisper,qwen3,csm}.py run in-process); dsp = the STFT -> mel -> log front end\n"
@@ -364,7 +365,7 @@ def main():
 
     # ---- after the timed region (N = 1): the benchmarked step against the SAME utterance run alone, SineGen inputs fixed on both sides
     batch_check = None
-    if rank == 0 and world == 1 and not dry and not args.ragged and not args.pmc_child:   # (the PMC child passes count the step's own launches only)
+    if rank == 0 and world == 1 and not dry and not args.ragged and not args.pmc_child and not args.no_batch_check:   # (the PMC child passes count the step's own launches only)
         g = torch.Generator(device="cpu").manual_seed(4321)
         ri1 = torch.rand((1, 9), generator=g).to(dev)
         nz1 = torch.randn((1, 2 * F_FRAMES * 300, 9), generator=g).to(dev)

@@ -380,10 +380,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(WAVES * 64, WAVES * 64), a
           const float* frow = c.fb + (int64_t)m * NB + lo;
           for (int j = 0; j < len; ++j) s = fmaf(prow[j], frow[j], s);
         }
-        float y;
-        if (c.mel_mode == 0) y = log10f(fmaxf(s, 1e-10f));
-        else if (c.mel_mode == 1 || c.mel_mode == 3) y = logf(fmaxf(s, 1e-5f));
-        else y = logf(fmaxf(s, 1e-8f));  // mode 2: Kaldi fbank (dsp.py:994-995)
+        // log through v_log_f32 (log2, 1 ulp; the argument is clamped to a normal number first) times the constant: the library log10f / logf
+        // spend ~25 instructions per value on denormal and special-case handling this argument range cannot reach
+        const float floor_v = c.mel_mode == 0 ? 1e-10f : ((c.mel_mode == 1 || c.mel_mode == 3) ? 1e-5f : 1e-8f);   // mode 2: Kaldi fbank (dsp.py:994-995)
+        const float y = __builtin_amdgcn_logf(fmaxf(s, floor_v)) * (c.mel_mode == 0 ? 0.30102999566398120f : 0.69314718055994531f);
         stage[fl * SP + m] = y;
         lmax = fmaxf(lmax, y);
       }
