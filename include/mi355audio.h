@@ -463,7 +463,9 @@ int mi355_stft(const mi355_stft_args* a, void* stream);
 /* Fused STFT -> power/magnitude -> mel -> log (whisper/audio.py:41-82; qwen3_tts.py:64-120).
  * mode 0 (whisper): p = |X|^2, y = log10(max(mel, 1e-10)) (global max clamp + (y+4)/4 by
  *   mi355_logmel_finish); mode 1 (qwen3): p = sqrt(|X|^2 + 1e-9), y = log(max(mel, 1e-5)); mode 2 (kaldi fbank): p = |X|^2,
- *   y = log(max(mel, 1e-8)); mode 3 (vocos, codec/models/vocos/mel.py:9-33): p = |X|, y = log(max(mel, 1e-5)).
+ *   y = log(max(mel, 1e-8)); mode 3 (vocos, codec/models/vocos/mel.py:9-33): p = |X|, y = log(max(mel, 1e-5));
+ *   mode 4 (NeMo FilterbankFeatures: stt/models/parakeet/audio.py:71-79, vad/models/sortformer/sortformer.py:95-97): p = |X|^2,
+ *   y = log(mel + log_guard).
  * fb: [n_mels, n_fft/2+1] float32.  out [B, n_frames, n_mels]. */
 typedef struct {
   const float* x; int32_t ldx; int32_t L; int32_t B;
@@ -471,6 +473,7 @@ typedef struct {
   const float* fb; int32_t n_mels; int32_t mode;
   float* out;
   float* gmax;  /* [B] running max for mode 0 (must be -inf initialised by the call), nullable */
+  float log_guard;  /* mode 4: the additive guard inside the log (NeMo's log_zero_guard_value, 2^-24) */
 } mi355_logmel_args;
 int mi355_logmel(const mi355_logmel_args* a, void* stream);
 int mi355_logmel_finish(float* y, int64_t n_per_item, const float* gmax, int32_t B, void* stream);

@@ -110,7 +110,7 @@ struct StftCommon {
 // MODE 0: complex spectrum out [B, n_frames, nb, 2];  MODE 1: log-mel out [B, n_frames, n_mels]
 template <int MODE>
 __global__ __launch_bounds__(256) void stft_kernel(StftCommon c, FftPlan pl, int pairs, float* out, const float* fb, int n_mels,
-                                                   int mel_mode, float* gmax) {
+                                                   int mel_mode, float* gmax, float log_guard) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int N = c.n_fft, nb = N / 2 + 1;
   float2* tw = (float2*)smem;
@@ -180,6 +180,7 @@ __global__ __launch_bounds__(256) void stft_kernel(StftCommon c, FftPlan pl, int
         float y;
         if (mel_mode == 0) y = log10f(fmaxf(s, 1e-10f));
         else if (mel_mode == 1 || mel_mode == 3) y = logf(fmaxf(s, 1e-5f));
+        else if (mel_mode == 4) y = logf(s + log_guard);   // NeMo: parakeet/audio.py:78-79
         else y = logf(fmaxf(s, 1e-8f));  // mode 2: Kaldi fbank (dsp.py:994-995)
         out[((int64_t)b * c.n_frames + f) * n_mels + m] = y;
         lmax = fmaxf(lmax, y);
@@ -337,7 +338,7 @@ int cu_count() {
   return n;
 }
 template <int N1, int N2, int MODE, int WAVES, bool PREF>
-int launch_fast_cfg(const StftCommon& c, int B, float* out, const float* fb, int n_mels, int mel_mode, float* gmax, hipStream_t st, const char* name) {
+int launch_fast_cfg(const StftCommon& c, int B, float* out, const float* fb, int n_mels, int mel_mode, float* gmax, float guard, hipStream_t st, const char* name) {
   using G = mi355fft::FastGeom<N1, N2>;
   const size_t lds = G::lds_bytes(MODE == 1, WAVES);
   if (int r = set_lds(mi355fft::stft_fast_kernel<N1, N2, MODE, WAVES, PREF>, lds, name)) return r;
@@ -349,26 +350,26 @@ int launch_fast_cfg(const StftCommon& c, int B, float* out, const float* fb, int
   const int64_t resident = (int64_t)cu_count() * (by_lds < by_regs ? by_lds : by_regs);
   const int64_t wgs = (total + WAVES - 1) / WAVES;
   const int grid = (int)(wgs < resident ? wgs : resident);
-  mi355fft::FastArgs a{c.x, c.ldx, c.L, c.hop, c.window, c.pad_mode, c.n_frames, B, tiles_per_item, (int)total, out, fb, n_mels, mel_mode, gmax};
+  mi355fft::FastArgs a{c.x, c.ldx, c.L, c.hop, c.window, c.pad_mode, c.n_frames, B, tiles_per_item, (int)total, out, fb, n_mels, mel_mode, gmax, guard};
   MI355_CLEAR_ERROR();
   hipLaunchKernelGGL((mi355fft::stft_fast_kernel<N1, N2, MODE, WAVES, PREF>), dim3(grid), dim3(WAVES * 64), lds, st, a);
   MI355_LAUNCH_CHECK(name);
   return MI355_OK;
 }
 template <int N1, int N2, int MODE>
-int launch_fast(const StftCommon& c, int B, float* out, const float* fb, int n_mels, int mel_mode, float* gmax, hipStream_t st, const char* name) {
+int launch_fast(const StftCommon& c, int B, float* out, const float* fb, int n_mels, int mel_mode, float* gmax, float guard, hipStream_t st, const char* name) {
   const char* e = getenv("MI355_FFT_PREFETCH");   // A/B: 1 = four waves per workgroup with the next tile's samples prefetched into registers
-  if (e && e[0] == '1') return launch_fast_cfg<N1, N2, MODE, 4, true>(c, B, out, fb, n_mels, mel_mode, gmax, st, name);
-  return launch_fast_cfg<N1, N2, MODE, 6, false>(c, B, out, fb, n_mels, mel_mode, gmax, st, name);
+  if (e && e[0] == '1') return launch_fast_cfg<N1, N2, MODE, 4, true>(c, B, out, fb, n_mels, mel_mode, gmax, guard, st, name);
+  return launch_fast_cfg<N1, N2, MODE, 6, false>(c, B, out, fb, n_mels, mel_mode, gmax, guard, st, name);
 }
 // returns -1 when the size has no fast instantiation
 template <int MODE>
-int try_fast(const StftCommon& c, int B, float* out, const float* fb, int n_mels, int mel_mode, float* gmax, hipStream_t st, const char* name) {
+int try_fast(const StftCommon& c, int B, float* out, const float* fb, int n_mels, int mel_mode, float* gmax, float guard, hipStream_t st, const char* name) {
   if (!fast_enabled() || (MODE == 1 && n_mels > mi355fft::kMaxMels)) return -1;
   switch (c.n_fft) {
-    case 400: return (MODE == 1 && !mi355fft::FastGeom<20, 20>::mel_fits(n_mels)) ? -1 : launch_fast<20, 20, MODE>(c, B, out, fb, n_mels, mel_mode, gmax, st, name);
-    case 512: return (MODE == 1 && !mi355fft::FastGeom<16, 32>::mel_fits(n_mels)) ? -1 : launch_fast<16, 32, MODE>(c, B, out, fb, n_mels, mel_mode, gmax, st, name);
-    case 1024: return (MODE == 1 && !mi355fft::FastGeom<32, 32>::mel_fits(n_mels)) ? -1 : launch_fast<32, 32, MODE>(c, B, out, fb, n_mels, mel_mode, gmax, st, name);
+    case 400: return (MODE == 1 && !mi355fft::FastGeom<20, 20>::mel_fits(n_mels)) ? -1 : launch_fast<20, 20, MODE>(c, B, out, fb, n_mels, mel_mode, gmax, guard, st, name);
+    case 512: return (MODE == 1 && !mi355fft::FastGeom<16, 32>::mel_fits(n_mels)) ? -1 : launch_fast<16, 32, MODE>(c, B, out, fb, n_mels, mel_mode, gmax, guard, st, name);
+    case 1024: return (MODE == 1 && !mi355fft::FastGeom<32, 32>::mel_fits(n_mels)) ? -1 : launch_fast<32, 32, MODE>(c, B, out, fb, n_mels, mel_mode, gmax, guard, st, name);
     default: return -1;
   }
 }
@@ -383,7 +384,7 @@ extern "C" int mi355_stft(const mi355_stft_args* ap, void* stream) {
   MI355_REQUIRE(a.pad_mode != 1 || a.L > a.n_fft / 2, "stft: input too short for reflect padding");
   {
     StftCommon c{a.x, a.ldx, a.L, a.n_fft, a.hop, a.window, a.pad_mode, a.n_frames};
-    const int r = try_fast<0>(c, a.B, a.out, nullptr, 0, 0, nullptr, (hipStream_t)stream, "stft");
+    const int r = try_fast<0>(c, a.B, a.out, nullptr, 0, 0, nullptr, 0.f, (hipStream_t)stream, "stft");
     if (r >= 0) return r;
   }
   FftPlan pl;
@@ -395,7 +396,7 @@ extern "C" int mi355_stft(const mi355_stft_args* ap, void* stream) {
   const int blocks = (a.n_frames + 2 * pairs - 1) / (2 * pairs);
   MI355_CLEAR_ERROR();
   hipLaunchKernelGGL(stft_kernel<0>, dim3(blocks, a.B), dim3(256), lds, (hipStream_t)stream, c, pl, pairs, a.out,
-                     (const float*)nullptr, 0, 0, (float*)nullptr);
+                     (const float*)nullptr, 0, 0, (float*)nullptr, 0.f);
   MI355_LAUNCH_CHECK("stft");
   return MI355_OK;
 }
@@ -404,7 +405,8 @@ extern "C" int mi355_logmel(const mi355_logmel_args* ap, void* stream) {
   MI355_REQUIRE(ap && ap->x && ap->window && ap->fb && ap->out, "logmel: null tensor");
   const mi355_logmel_args a = *ap;
   MI355_REQUIRE(a.n_fft >= 2 && a.hop > 0 && a.n_frames > 0 && a.B > 0 && a.n_mels > 0, "logmel: bad shape");
-  MI355_REQUIRE(a.mode >= 0 && a.mode <= 3, "logmel: mode must be 0 (whisper), 1 (qwen3), 2 (kaldi fbank) or 3 (vocos)");
+  MI355_REQUIRE(a.mode >= 0 && a.mode <= 4, "logmel: mode must be 0 (whisper), 1 (qwen3), 2 (kaldi fbank), 3 (vocos) or 4 (nemo)");
+  MI355_REQUIRE(a.mode != 4 || a.log_guard > 0.f, "logmel: mode 4 needs a positive log_guard");
   MI355_REQUIRE(a.pad_mode >= 0 && a.pad_mode <= 2, "logmel: bad pad_mode");
   MI355_REQUIRE(a.pad_mode != 1 || a.L > a.n_fft / 2, "logmel: input too short for reflect padding");
   hipStream_t st = (hipStream_t)stream;
@@ -414,7 +416,7 @@ extern "C" int mi355_logmel(const mi355_logmel_args* ap, void* stream) {
   }
   {
     StftCommon c{a.x, a.ldx, a.L, a.n_fft, a.hop, a.window, a.pad_mode, a.n_frames};
-    const int r = try_fast<1>(c, a.B, a.out, a.fb, a.n_mels, a.mode, a.gmax, st, "logmel");
+    const int r = try_fast<1>(c, a.B, a.out, a.fb, a.n_mels, a.mode, a.gmax, a.log_guard, st, "logmel");
     if (r >= 0) return r;
   }
   FftPlan pl;
@@ -426,7 +428,7 @@ extern "C" int mi355_logmel(const mi355_logmel_args* ap, void* stream) {
   StftCommon c{a.x, a.ldx, a.L, a.n_fft, a.hop, a.window, a.pad_mode, a.n_frames};
   const int blocks = (a.n_frames + 2 * pairs - 1) / (2 * pairs);
   MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL(stft_kernel<1>, dim3(blocks, a.B), dim3(256), lds, st, c, pl, pairs, a.out, a.fb, a.n_mels, a.mode, a.gmax);
+  hipLaunchKernelGGL(stft_kernel<1>, dim3(blocks, a.B), dim3(256), lds, st, c, pl, pairs, a.out, a.fb, a.n_mels, a.mode, a.gmax, a.log_guard);
   MI355_LAUNCH_CHECK("logmel");
   return MI355_OK;
 }

@@ -118,7 +118,7 @@ struct FastGeom {
 struct FastArgs {
   const float* x; int ldx; int L; int hop; const float* window; int pad_mode; int n_frames; int B;
   int tiles_per_item; int total_tiles;
-  float* out; const float* fb; int n_mels; int mel_mode; float* gmax;
+  float* out; const float* fb; int n_mels; int mel_mode; float* gmax; float log_guard;
 };
 
 __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
@@ -383,7 +383,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(WAVES * 64, WAVES * 64), a
         // log through v_log_f32 (log2, 1 ulp; the argument is clamped to a normal number first) times the constant: the library log10f / logf
         // spend ~25 instructions per value on denormal and special-case handling this argument range cannot reach
         const float floor_v = c.mel_mode == 0 ? 1e-10f : ((c.mel_mode == 1 || c.mel_mode == 3) ? 1e-5f : 1e-8f);   // mode 2: Kaldi fbank (dsp.py:994-995)
-        const float y = __builtin_amdgcn_logf(fmaxf(s, floor_v)) * (c.mel_mode == 0 ? 0.30102999566398120f : 0.69314718055994531f);
+        const float arg = c.mel_mode == 4 ? s + c.log_guard : fmaxf(s, floor_v);                                  // mode 4: NeMo, ln(mel + guard)
+        const float y = __builtin_amdgcn_logf(arg) * (c.mel_mode == 0 ? 0.30102999566398120f : 0.69314718055994531f);
         stage[fl * SP + m] = y;
         lmax = fmaxf(lmax, y);
       }

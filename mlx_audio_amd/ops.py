@@ -970,7 +970,9 @@ def stft_frames(x: torch.Tensor, n_fft: int, hop: int, window: torch.Tensor, pad
 
 
 def logmel(x: torch.Tensor, n_fft: int, hop: int, window: torch.Tensor, pad_mode: int, n_frames: int, fb: torch.Tensor,
-           mode: int):
+           mode: int, log_guard: float = 0.0, fixed_max: Optional[float] = None):
+    """Fused STFT -> power -> mel -> log (``mi355_logmel``).  ``mode`` 0 clamps to (max - 8) and rescales like Whisper: the maximum is the global one of
+    every item, or ``fixed_max`` when given (Voxtral Realtime's ``global_log_mel_max``); ``mode`` 4 = ln(mel + ``log_guard``) (NeMo)."""
     assert x.dim() == 2 and x.stride(1) == 1 and fb.is_contiguous()
     B, L = x.shape
     n_mels = fb.shape[0]
@@ -978,8 +980,10 @@ def logmel(x: torch.Tensor, n_fft: int, hop: int, window: torch.Tensor, pad_mode
     gmax = torch.empty((B,), dtype=torch.float32, device=x.device) if mode == 0 else None
     _lib.call_struct("mi355_logmel", "mi355_logmel_args", _stream(), x=_ptr(x), ldx=x.stride(0), L=L, B=B, n_fft=n_fft,
                      hop=hop, window=_ptr(window), pad_mode=pad_mode, n_frames=n_frames, fb=_ptr(fb), n_mels=n_mels,
-                     mode=mode, out=_ptr(out), gmax=_ptr(gmax))
+                     mode=mode, out=_ptr(out), gmax=None if fixed_max is not None else _ptr(gmax), log_guard=float(log_guard))
     if mode == 0:
+        if fixed_max is not None:
+            gmax.fill_(float(fixed_max))
         lib = _lib.load()
         rc = lib.mi355_logmel_finish(_ptr(out), n_frames * n_mels, _ptr(gmax), B, _stream())
         _lib.check(rc, "mi355_logmel_finish")

@@ -431,3 +431,91 @@ def compute_fbank_kaldi(waveform, sample_rate: int = 48000, win_len: int = 1920,
     bins, _ = get_mel_banks_kaldi(num_mels, P, float(sample_rate), low_freq, high_freq)
     bins = np.pad(bins, [(0, 0), (0, 1)])
     return np.log(np.maximum(spec @ bins.T.astype(np.float64), 1e-8)).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------ log-mel front ends of four more dsp callers
+# ("the 40-odd dsp.stft / mel_filters callers get the fused mel kernel").  Each restates the reference function it cites and is pinned
+# by tests/test_frontends_cpu.py to what the reference's own source computes over the MLX stand-in (tests/golden/ref_frontends.npz).
+def _centre_pad_window(window: np.ndarray, n_fft: int) -> np.ndarray:
+    """torch.stft / NeMo convention: a window shorter than n_fft sits in the MIDDLE of the frame (parakeet/audio.py:58-69, sortformer.py:79-84)."""
+    if window.shape[0] >= n_fft:
+        return window.astype(F32)
+    left = (n_fft - window.shape[0]) // 2
+    return np.concatenate([np.zeros(left, F32), window.astype(F32), np.zeros(n_fft - window.shape[0] - left, F32)])
+
+
+def _per_feature_norm(x: np.ndarray, axis: int, eps: float = 1e-5) -> np.ndarray:
+    """(x - mean) / (std + eps) along ``axis`` with Bessel's correction (parakeet/audio.py:80-85, sortformer.py:105-112)."""
+    mean = x.mean(axis=axis, keepdims=True, dtype=F32)
+    n = max(x.shape[axis] - 1, 1)
+    var = ((x - mean) ** 2).sum(axis=axis, keepdims=True, dtype=F32) / F32(n)
+    return ((x - mean) / (np.sqrt(var) + F32(eps))).astype(F32)
+
+
+def nemo_log_mel(x, sample_rate=16000, n_fft=512, hop_length=160, win_length=400, n_mels=80, window="hann", preemph=0.97, log_guard=2.0 ** -24) -> np.ndarray:
+    """The NeMo FilterbankFeatures chain both Parakeet and Sortformer restate: pre-emphasis (first sample kept), centred zero padding, centre-padded
+    window, |X|^2, Slaney mel, ln(mel + guard) -> float32 ``[n_frames, n_mels]``."""
+    x = np.asarray(x, dtype=F32)
+    if preemph > 0:
+        x = np.concatenate([x[:1], x[1:] - F32(preemph) * x[:-1]]).astype(F32)
+    fn = {"hann": hanning, "hanning": hanning, "hamming": hamming, "blackman": blackman, "bartlett": bartlett}.get(window, hanning)
+    w = _centre_pad_window(fn(win_length), n_fft)
+    spec = stft(x, n_fft=n_fft, hop_length=hop_length, win_length=n_fft, window=w, pad_mode="constant")
+    power = (np.abs(spec).astype(F32) ** 2).astype(F32)
+    fb = mel_filters(sample_rate, n_fft, n_mels, norm="slaney", mel_scale="slaney")
+    return np.log((power @ fb.T).astype(F32) + F32(log_guard)).astype(F32)
+
+
+def parakeet_log_mel(x, sample_rate=16000, normalize="per_feature", window_size=0.025, window_stride=0.01, window="hann", features=80, n_fft=512,
+                     pad_to=0, pad_value=0.0, preemph=0.97, log_zero_guard_value=2.0 ** -24) -> np.ndarray:
+    """stt/models/parakeet/audio.py:39-94 -> ``[1, n_frames, features]``."""
+    x = np.asarray(x, dtype=F32)
+    if pad_to > 0 and x.shape[-1] < pad_to:
+        x = np.concatenate([x, np.full(pad_to - x.shape[-1], pad_value, F32)])
+    y = nemo_log_mel(x, sample_rate, n_fft, int(window_stride * sample_rate), int(window_size * sample_rate), features, window, preemph, log_zero_guard_value)
+    if normalize == "per_feature":
+        y = _per_feature_norm(y, axis=0)
+    else:
+        y = ((y - y.mean(dtype=F32)) / (y.std(dtype=F32) + F32(1e-5))).astype(F32)
+    return y[None]
+
+
+def sortformer_mel_features(waveform, sample_rate=16000, n_fft=512, hop_length=160, win_length=400, n_mels=80, preemphasis_coeff=0.97,
+                            normalize="per_feature", pad_to=16) -> np.ndarray:
+    """vad/models/sortformer/sortformer.py:43-123 -> ``[batch, n_mels, n_frames (padded to a multiple of pad_to with zeros)]``."""
+    w = np.asarray(waveform, dtype=F32)
+    if w.ndim == 1:
+        w = w[None]
+    feats = np.stack([nemo_log_mel(r, sample_rate, n_fft, hop_length, win_length, n_mels, "hann", preemphasis_coeff).T for r in w])
+    if normalize == "per_feature":
+        feats = _per_feature_norm(feats, axis=2)
+    if pad_to > 0 and feats.shape[2] % pad_to:
+        feats = np.concatenate([feats, np.zeros(feats.shape[:2] + (pad_to - feats.shape[2] % pad_to,), F32)], axis=2)
+    return feats
+
+
+def s3_log_mel(audio, sample_rate=16000, n_mels=128, n_fft=400, hop_length=160, padding=0) -> np.ndarray:
+    """codec/models/s3/utils.py:8-42: Whisper's chain with a PERIODIC Hann window and no frame dropped -> ``[n_mels, n_frames]``."""
+    audio = np.asarray(audio, dtype=F32)
+    if padding > 0:
+        audio = np.concatenate([audio, np.zeros(padding, F32)])
+    spec = stft(audio, window=hanning(n_fft + 1)[:-1], n_fft=n_fft, hop_length=hop_length, win_length=n_fft)
+    mags = (np.abs(spec).astype(F32) ** 2).astype(F32)
+    fb = mel_filters(sample_rate, n_fft, n_mels, norm="slaney", mel_scale="slaney")
+    log_spec = np.log10(np.maximum((fb @ mags.T).astype(F32), F32(1e-10))).astype(F32)
+    log_spec = np.maximum(log_spec, log_spec.max() - F32(8.0))
+    return ((log_spec + F32(4.0)) / F32(4.0)).astype(F32)
+
+
+def voxtral_log_mel(audio, n_mels=128, window_size=400, hop_length=160, sample_rate=16000, global_log_mel_max=1.5) -> np.ndarray:
+    """stt/models/voxtral_realtime/audio.py:21-96: periodic Hann, reflect-centred frames, last frame dropped, Slaney filters up to 8 kHz, FIXED maximum
+    for the clamp -> ``[n_mels, n_frames - 1]``."""
+    audio = np.asarray(audio, dtype=F32)
+    n = np.arange(window_size, dtype=F32)
+    window = (0.5 * (1.0 - np.cos(2.0 * np.pi * n / window_size))).astype(F32)
+    spec = stft(audio, window=window, n_fft=window_size, hop_length=hop_length, win_length=window_size)
+    mags = (np.abs(spec[:-1]).astype(F32) ** 2).astype(F32)
+    fb = mel_filters(sample_rate, window_size, n_mels, 0, 8000, norm="slaney", mel_scale="slaney")
+    log_spec = np.log10(np.maximum((fb @ mags.T).astype(F32), F32(1e-10))).astype(F32)
+    log_spec = np.maximum(log_spec, F32(global_log_mel_max - 8.0))
+    return ((log_spec + F32(4.0)) / F32(4.0)).astype(F32)

@@ -354,6 +354,10 @@ def var(a, axis=None, keepdims=False, ddof=0, stream=None):
     return _wrap(np.var(np.asarray(a), axis=tuple(axis) if isinstance(axis, list) else axis, keepdims=keepdims, ddof=ddof))
 
 
+def std(a, axis=None, keepdims=False, ddof=0, stream=None):
+    return _wrap(np.std(np.asarray(a), axis=tuple(axis) if isinstance(axis, list) else axis, keepdims=keepdims, ddof=ddof))
+
+
 def cumsum(a, axis=None, reverse=False, inclusive=True, stream=None):
     assert not reverse and inclusive
     return _wrap(np.cumsum(np.asarray(a), axis=axis, dtype=np.asarray(a).dtype))
