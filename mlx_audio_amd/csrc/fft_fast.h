@@ -207,6 +207,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(WAVES * 64, WAVES * 64), a
     const float* xb = c.x + (int64_t)b * c.ldx;
     // ---- windowed frames: even frame -> re, odd frame -> im, element n = N2 n1 + n2 at [n1][n2] of the pair's padded matrix
     const bool inner = f0 * c.hop - off >= 0 && (f0 + 2 * PW - 1) * c.hop - off + N <= c.L && f0 + 2 * PW <= c.n_frames;
+    unsigned nzbits = 0;   // OR of the magnitude bits of every sample this lane loads for the tile: zero <=> the whole tile is silence (+0 / -0)
+    auto note4 = [&](const float4 v) {
+      nzbits |= (__float_as_uint(v.x) | __float_as_uint(v.y) | __float_as_uint(v.z) | __float_as_uint(v.w)) << 1;
+    };
     if (inner && vec4) {  // every sample of the tile is inside the signal and 16-byte aligned: four samples of both frames per lane and step
       if constexpr (!PREF) {   // straight from memory, two steps in flight
 #pragma unroll 2
@@ -215,6 +219,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(WAVES * 64, WAVES * 64), a
           const int n1 = n / N2, n2 = n - n1 * N2;
           const int idx = (f0 + 2 * pr) * c.hop + n - off;
           const float4 a = *(const float4*)(xb + idx), bq = *(const float4*)(xb + idx + c.hop), w = *(const float4*)(win + n);
+          note4(a); note4(bq);
           float2* dst = z + pr * PITCH + n1 * PR + n2;
           dst[0] = make_float2(a.x * w.x, bq.x * w.x);
           dst[1] = make_float2(a.y * w.y, bq.y * w.y);
@@ -230,6 +235,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(WAVES * 64, WAVES * 64), a
           const int pr = i / Q, n = (i - pr * Q) * 4;
           const int n1 = n / N2, n2 = n - n1 * N2;
           const float4 a = ra[q], bq = rb[q], w = *(const float4*)(win + n);
+          note4(a); note4(bq);
           float2* dst = z + pr * PITCH + n1 * PR + n2;
           dst[0] = make_float2(a.x * w.x, bq.x * w.x);
           dst[1] = make_float2(a.y * w.y, bq.y * w.y);
@@ -277,8 +283,32 @@ __global__ __attribute__((amdgpu_flat_work_group_size(WAVES * 64, WAVES * 64), a
           }
         }
         const float w = win[n];
+        nzbits |= (__float_as_uint(v[0]) | __float_as_uint(v[1])) << 1;
         z[pr * PITCH + n1 * PR + n2] = make_float2(v[0] * w, v[1] * w);
       }
+    }
+    // ---- a tile of pure silence (Whisper pads every window to 30 s with zeros; a 10 s utterance is two thirds silence): its spectrum is exactly
+    // zero, so every mel row is the clamp floor's logarithm -- the same expression the full path would evaluate on a zero sum, hence bit-identical --
+    // and the transforms are skipped.  Not taken for mode 1 (sqrt(|X|^2 + 1e-9) is not zero on silence).
+    if (__builtin_amdgcn_ballot_w64(nzbits != 0) == 0 && (MODE == 0 || c.mel_mode != 1)) {
+      const int nf = min(2 * PW, c.n_frames - f0);
+      if constexpr (MODE == 0) {
+        float2* dst = (float2*)(c.out + ((int64_t)b * c.n_frames + f0) * NB * 2);
+        for (int i = lane; i < nf * NB; i += 64) dst[i] = make_float2(0.f, 0.f);
+      } else {
+        const float floor_v = c.mel_mode == 0 ? 1e-10f : (c.mel_mode == 3 ? 1e-5f : 1e-8f);
+        const float arg = c.mel_mode == 4 ? 0.f + c.log_guard : fmaxf(0.f, floor_v);
+        const float y0 = __builtin_amdgcn_logf(arg) * (c.mel_mode == 0 ? 0.30102999566398120f : 0.69314718055994531f);
+        if (b != max_b) {
+          if (c.gmax && max_b >= 0 && lane == 0 && max_v > -INFINITY) atomic_max_f32(c.gmax + max_b, max_v);
+          max_b = b; max_v = -INFINITY;
+        }
+        if (nf > 0) max_v = fmaxf(max_v, y0);
+        float* dst = c.out + ((int64_t)b * c.n_frames + f0) * c.n_mels;
+        for (int i = lane; i < nf * c.n_mels; i += 64) dst[i] = y0;
+      }
+      wave_sync();   // the buffer is rewritten by the next tile's loads
+      continue;
     }
     wave_sync();
     // ---- pass 1: lane (pair, n2): N1-point DFT down column n2, inter-pass twiddle W_N^{n2 k1}, back into the same column

@@ -830,3 +830,43 @@ def test_conv_ws4_fused_statistics_identical_rows_repeatable(ops, L, C, K, prec)
             assert float((st[0] - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
         else:
             assert torch.equal(y, first[0]) and torch.equal(st, first[1]), rep
+
+
+@pytest.mark.parametrize("mode,n_fft,hop,n_mels", [(0, 400, 160, 80), (4, 512, 160, 80), (2, 512, 512, 23), (3, 1024, 256, 100), (1, 1024, 256, 128)])
+def test_fast_logmel_silent_tiles_are_bit_identical_to_the_full_path(ops, monkeypatch, mode, n_fft, hop, n_mels):
+    """Tiles whose samples are all zero skip their transforms in csrc/fft_fast.h and write the clamp floor's logarithm directly.  The outputs must be
+    EXACTLY what the full path writes for the same frames: checked by moving the silence (a signal with a silent middle and tail vs the same signal
+    with 1e-30 added everywhere, which defeats the shortcut and changes no power above rounding) and against the LDS Stockham kernel."""
+    from oracle import dsp_ref
+
+    rng = np.random.default_rng(mode)
+    L = 40 * n_fft
+    x = np.zeros((2, L), np.float32)
+    x[0, : 6 * n_fft] = rng.standard_normal(6 * n_fft)
+    x[0, 17 * n_fft: 19 * n_fft + 7] = rng.standard_normal(2 * n_fft + 7) * 0.1
+    x[1, 30 * n_fft:] = rng.standard_normal(10 * n_fft)
+    win = dsp_ref.hanning(n_fft)
+    sr = {400: 16000, 512: 16000, 1024: 24000}[n_fft]
+    fb = torch.from_numpy(np.ascontiguousarray(dsp_ref.mel_filters(sr, n_fft, n_mels, norm="slaney", mel_scale="slaney"))).to(DEV)
+    nfr = 1 + L // hop
+    wd = torch.from_numpy(win).to(DEV)
+
+    def run(sig):
+        y = ops.logmel(torch.from_numpy(sig).to(DEV), n_fft, hop, wd, 1, nfr, fb, mode, log_guard=2.0 ** -24 if mode == 4 else 0.0)
+        spec = ops.stft_frames(torch.from_numpy(sig).to(DEV), n_fft, hop, wd, 1, nfr)
+        torch.cuda.synchronize()
+        return y.cpu().numpy(), spec.cpu().numpy()
+
+    monkeypatch.setenv("MI355_FFT_FAST", "1")
+    y1, s1 = run(x)
+    y2, s2 = run(x + np.float32(1e-30))           # no tile is all-zero any more; powers change by < 1e-50
+    monkeypatch.setenv("MI355_FFT_FAST", "0")
+    y0, s0 = run(x)
+    silent = np.abs(s0).max(axis=2) == 0.0         # frames whose spectrum is exactly zero
+    assert silent.sum() > nfr                      # the test signal really has silent frames
+    assert np.array_equal(y1[silent], y2[silent]), "silent-tile shortcut differs from the full path on silent frames"
+    assert np.abs(y1 - y2).max() < 1e-5 and np.abs(y1 - y0).max() < 2e-4
+    # spectrum: a silent frame that shares its complex transform with a sounding one (two real frames ride one transform) carries the Hermitian split's
+    # rounding residue of its partner (~1e-7 of the partner's magnitude) in the two-pass kernel; frames of all-silent TILES are exact zeros
+    assert np.abs(s1 - s0).max() / np.abs(s0).max() < 2e-6
+    assert (np.abs(s1).max(axis=2) == 0.0).sum() > nfr // 2
