@@ -21,7 +21,43 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 HBM_PEAK_GBS = 8000.0
+
+
+def pmc_traffic(args):
+    """HBM bytes per launch of the fused kernel from the TCC counters, measured in THIS run like bench.py does: two child passes of this command under
+    ``rocprofv3 --kernel-trace --pmc FETCH_SIZE`` / ``WRITE_SIZE``, gfx950 correction bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if shutil.which("rocprofv3") is None or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD") or os.environ.get("ROCP_TOOL_LIBRARIES"):
+        return {"traffic": None}
+    from pmc_traffic import per_kernel
+
+    tmp = tempfile.mkdtemp(prefix="mi355_pmc_dsp_")
+    tot = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--case", args.case,
+                   "--batch", str(args.batch), "--no-cpu-baseline", "--no-pmc"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=180)
+            dbs = glob.glob(os.path.join(out, "**", "*results.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return {"traffic": None}
+            vals = [v for k, vs in per_kernel(dbs[0], ctr).items() if "stft_fast_kernel" in k for v in vs]
+            tot[ctr] = (sum(vals), len(vals))
+        n = max(tot["FETCH_SIZE"][1], 1)
+        t = (2.0 * tot["FETCH_SIZE"][0] + tot["WRITE_SIZE"][0]) * 1024.0 / n
+        return {"traffic": t, "traffic_note": "HBM bytes per launch of stft_fast_kernel: (2*FETCH_SIZE + WRITE_SIZE)*1024 averaged over %d launches of two rocprofv3 PMC child passes "
+                                              "(the clamp pass of the Whisper case is a second kernel and not included)" % n}
+    except Exception:
+        return {"traffic": None}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main(argv=None):
@@ -33,6 +69,8 @@ def main(argv=None):
     ap.add_argument("--ab", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", default="rank0", help=argparse.SUPPRESS)
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two in-run rocprofv3 PMC passes (roofline.traffic is then null)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
 
     from mlx_audio_amd import dsp, ops
@@ -87,6 +125,10 @@ def main(argv=None):
         ks.sort()
         return out, wall, ks[2] * 1e-3
 
+    if args.pmc_child:   # two launches of the step under the counters, nothing else
+        step(); step()
+        torch.cuda.synchronize()
+        return
     os.environ["MI355_FFT_FAST"] = "1"
     out, wall, ksec = timed(args.steps, args.warmup)
     got = out[0].cpu().numpy()
@@ -104,6 +146,8 @@ def main(argv=None):
                         "traffic": None, "algorithmic_bytes_per_step": alg_bytes, "kernel_ms_per_step": ksec * 1e3,
                         "note": "algorithmic bytes = samples in (4 B) + log-mel out (4 B x n_mels per frame), SURVEY 8d; the Whisper clamp pass re-reads "
                                 "and re-writes the output once more (not counted as algorithmic)"}}
+    if not args.no_pmc:
+        res["roofline"].update(pmc_traffic(args))
     if args.case == "whisper":
         # the same shapes with NO silent half (noise over all 60 s): the kernel skips the transforms of tiles whose samples are all zero (Whisper's own
         # 30 s zero padding makes half of SURVEY's workload such tiles), so the dense figure is reported beside the contract workload's
