@@ -5,15 +5,20 @@
 Conventions kept from the reference: decoded audio passes through signed 16-bit samples (the reference decodes with miniaudio to s16,
 ``audio_io.py:339-341``), ``dtype='float32' | 'float64'`` divides by 32768 (``:349-352``), mono comes back 1-D unless ``always_2d`` (``:343-368``),
 ``write`` clips floats to [-1, 1] and scales by 32767 with truncation (``:526-531``), integer input other than int16 is cast, the format is taken
-from the extension (WAV for a ``BytesIO``), unknown formats raise ``ValueError`` (``:601-602``).  Not kept: the compressed containers (mp3 / flac /
-ogg / opus / webm / m4a go through ffmpeg or miniaudio in the reference; neither is part of this image) raise ``RuntimeError`` naming the gap.  A
+from the extension (WAV for a ``BytesIO``), unknown formats raise ``ValueError`` (``:601-602``).  The compressed containers (mp3 / flac / ogg / opus /
+webm / m4a) go through **ffmpeg when one is on PATH**, with the reference's own command lines (ffprobe for rate / channels, ``-f s16le -acodec pcm_s16le``
+to decode, ``audio_io.py:59-187``; raw s16le in, ``-b:a`` / libopus / FLAC-in-Ogg out to encode, ``:405-483``); the reference's second decoder
+(miniaudio, for mp3 / flac / vorbis without ffmpeg) is not part of this build, so without ffmpeg those raise ``RuntimeError`` naming the gap.  A
 ``sample_rate`` different from the file's goes through ``mlx_audio_amd.resample`` (the reference's ``kaiser_best`` polyphase FIR; the reference uses
 miniaudio's converter for upsampling and this FIR for downsampling, ``audio_io.py:318-330``: here one filter serves both directions).
 """
 from __future__ import annotations
 
 import io
+import json
+import shutil
 import struct
+import subprocess
 from pathlib import Path
 from typing import Optional, Tuple, Union
 
@@ -23,11 +28,68 @@ _COMPRESSED = ("flac", "mp3", "ogg", "opus", "vorbis", "webm", "m4a", "aac")
 FileLike = Union[str, Path, io.BytesIO]
 
 
+def _sniff_compressed(buf: bytes) -> Optional[str]:
+    """Container of a byte stream by its magic bytes (audio_io.py:39-56), ``None`` for anything else."""
+    if buf[:4] == b"OggS":
+        return "Ogg"
+    if buf[4:8] == b"ftyp":
+        return "MP4 / M4A"
+    if buf[:4] == b"fLaC":
+        return "FLAC"
+    if buf[:3] == b"ID3" or buf[:2] in (b"\xff\xfb", b"\xff\xfa"):
+        return "MP3"
+    if buf[:4] == b"\x1a\x45\xdf\xa3":
+        return "WebM"
+    return None
+
+
+def _decode_ffmpeg(src: Union[str, Path, bytes], sample_rate: Optional[int], nchannels: Optional[int], kind: str) -> Tuple[np.ndarray, int, int]:
+    """Compressed container -> (int16 samples [frames, channels], rate, channels) through ffprobe + ffmpeg, the reference's way (audio_io.py:59-187):
+    the stream's own rate / channel count unless the caller asks for others (ffmpeg then converts)."""
+    ffmpeg, ffprobe = shutil.which("ffmpeg"), shutil.which("ffprobe")
+    if ffmpeg is None or ffprobe is None:
+        raise RuntimeError(f"{kind} decoding needs ffmpeg / ffprobe on PATH (the reference's miniaudio decoder is not part of this build); convert to WAV first")
+    from_bytes = isinstance(src, (bytes, bytearray))
+    target = "pipe:0" if from_bytes else str(src)
+    probe = subprocess.run([ffprobe, "-v", "quiet", "-print_format", "json", "-show_streams", "-select_streams", "a:0"] + (["-i", target] if from_bytes else [target]),
+                           input=bytes(src) if from_bytes else None, capture_output=True)
+    if probe.returncode != 0:
+        raise RuntimeError(f"ffprobe failed: {probe.stderr.decode(errors='replace')}")
+    streams = json.loads(probe.stdout.decode() or "{}").get("streams")
+    if not streams:
+        raise RuntimeError("No audio streams found in file")
+    rate = int(sample_rate or streams[0].get("sample_rate", 44100))
+    nch = int(nchannels or streams[0].get("channels", 2))
+    dec = subprocess.run([ffmpeg, "-i", target, "-f", "s16le", "-acodec", "pcm_s16le", "-ar", str(rate), "-ac", str(nch), "pipe:1"],
+                         input=bytes(src) if from_bytes else None, capture_output=True)
+    if dec.returncode != 0:
+        raise RuntimeError(f"ffmpeg decoding failed: {dec.stderr.decode(errors='replace')}")
+    pcm = np.frombuffer(dec.stdout, dtype="<i2")
+    return pcm[: pcm.size - pcm.size % nch].reshape(-1, nch), rate, nch
+
+
+def _encode_ffmpeg(pcm: np.ndarray, samplerate: int, nch: int, fmt: str, bitrate: str = "128k") -> bytes:
+    """int16 PCM -> compressed bytes through ffmpeg with the reference's options (audio_io.py:405-483): raw s16le in; mp3 at ``bitrate``; opus / webm on
+    libopus; ogg / vorbis as FLAC inside an Ogg container."""
+    ffmpeg = shutil.which("ffmpeg")
+    if ffmpeg is None:
+        raise RuntimeError(f"{fmt.upper()} encoding needs ffmpeg on PATH; use WAV")
+    cmd = [ffmpeg, "-y", "-f", "s16le", "-ar", str(int(samplerate)), "-ac", str(int(nch)), "-i", "pipe:0"]
+    if fmt == "mp3":
+        cmd += ["-b:a", bitrate]
+    elif fmt in ("opus", "webm"):
+        cmd += ["-c:a", "libopus", "-b:a", bitrate]
+    elif fmt in ("ogg", "vorbis"):
+        cmd += ["-c:a", "flac"]
+    cmd += ["-f", "ogg" if fmt == "vorbis" else ("ipod" if fmt in ("m4a", "aac") else fmt), "pipe:1"]
+    r = subprocess.run(cmd, input=np.ascontiguousarray(pcm).astype("<i2").tobytes(), capture_output=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"ffmpeg encoding failed: {r.stderr.decode(errors='replace')}")
+    return r.stdout
+
+
 def _riff_chunks(buf: bytes):
     if len(buf) < 12 or buf[:4] != b"RIFF" or buf[8:12] != b"WAVE":
-        kind = "Ogg" if buf[:4] == b"OggS" else "MP4 / M4A" if buf[4:8] == b"ftyp" else "FLAC" if buf[:4] == b"fLaC" else "MP3" if buf[:3] == b"ID3" else None
-        if kind:
-            raise RuntimeError(f"{kind} decoding needs ffmpeg / miniaudio, which this build does not contain; convert to WAV first")
         raise ValueError("Unsupported format: not a RIFF / WAVE stream")
     pos = 12
     while pos + 8 <= len(buf):
@@ -78,19 +140,24 @@ def read(file: FileLike, always_2d: bool = False, dtype: str = "float64", sample
         raise ValueError(f"sample_rate must be positive, got {sample_rate}")
     if nchannels is not None and nchannels <= 0:
         raise ValueError(f"nchannels must be positive, got {nchannels}")
+    decoded = None
     if isinstance(file, (str, Path)):
         ext = Path(file).suffix.lstrip(".").lower()
         if ext in _COMPRESSED:
-            raise RuntimeError(f"{ext.upper()} decoding needs ffmpeg / miniaudio, which this build does not contain; convert to WAV first")
-        with open(file, "rb") as f:
-            buf = f.read()
+            decoded = _decode_ffmpeg(file, sample_rate, nchannels, ext.upper())
+        else:
+            with open(file, "rb") as f:
+                buf = f.read()
     elif isinstance(file, io.BytesIO):
         file.seek(0)
         buf = file.read()
         file.seek(0)
     else:
         raise TypeError(f"Unsupported file type: {type(file)}")
-    pcm, rate, nch = _decode_wav(buf)
+    if decoded is None:
+        kind = _sniff_compressed(buf)
+        decoded = _decode_ffmpeg(buf, sample_rate, nchannels, kind) if kind else _decode_wav(buf)
+    pcm, rate, nch = decoded
     x = pcm.astype(np.float64) / 32768.0
     if nchannels is not None and nchannels != nch:
         if nchannels == 1:
@@ -142,7 +209,7 @@ def write(file: FileLike, data, samplerate: int, format: Optional[str] = None) -
                           b"data", len(payload))
         blob = hdr + payload
     elif format in _COMPRESSED:
-        raise RuntimeError(f"{format.upper()} encoding needs ffmpeg, which this build does not contain; use WAV")
+        blob = _encode_ffmpeg(pcm, samplerate, nch, format)
     else:
         raise ValueError(f"Unsupported output format: {format}")
     if isinstance(file, io.BytesIO):

@@ -275,8 +275,6 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
               // elements stay below 256 < 448 (no saturation); E8M0 byte 0 (2^-127) for an all-zero / denormal-sized row
               // lo = t - fp16(t) as ONE v_fma_mix_f32 per element (the half operand is read in place: no v_cvt_f32_f16 back to fp32 first); the
               // product is exact, so this is the same single rounding as the subtraction
-              typedef _Float16 h2x_t __attribute__((ext_vector_type(2)));
-              (void)sizeof(h2x_t);
               float l0, l1, l2, l3;   // src0 = the half selected by op_sel[0] of the packed word (op_sel_hi[0] = 1: an f16 source), src1 = -1.0, src2 = t (f32)
               asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(ph.x), "v"(tt[0]));
               asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(ph.x), "v"(tt[1]));

@@ -211,8 +211,6 @@ __global__ __launch_bounds__(4 * H) void lstm_oct_kernel(const mi355_lstm_args a
   auto dpp = [](const float v, auto ctrl) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true));
   };
-  using C = std::integral_constant<int, 0>;
-  (void)sizeof(C);
 
   for (int st = 0; st < len; ++st) {
     const int tt = dir ? (len - 1 - st) : st;

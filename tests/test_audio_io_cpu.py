@@ -327,3 +327,50 @@ def test_load_audio_and_level_helpers(tmp_path):
     assert 16384 <= len(tr) < len(sil) and isinstance(tr, np.ndarray)
     assert isinstance(trim_silence(torch.from_numpy(sil)), torch.Tensor) and trim_silence(torch.from_numpy(sil)).numel() == len(tr)
     assert trim_silence(sil[:100]) is not None and len(trim_silence(sil[:100])) == 100   # shorter than a frame: returned as is
+
+
+def test_compressed_containers_go_through_ffmpeg_like_the_reference(tmp_path, monkeypatch):
+    """audio_io.py:59-187, 405-483: with ffmpeg on PATH the compressed containers decode through ffprobe + ``ffmpeg -f s16le -acodec pcm_s16le`` and encode
+    from raw s16le with the reference's per-format options.  ffmpeg is not part of the test image: a scripted ``subprocess.run`` stands in and the
+    COMMAND LINES are what is checked."""
+    import json as _json
+    from types import SimpleNamespace
+
+    from mlx_audio_amd import audio_io
+
+    calls = []
+    pcm = (np.arange(48, dtype=np.int16) - 24) * 100                 # 24 stereo frames
+
+    def fake_run(cmd, input=None, capture_output=False):
+        calls.append((list(cmd), input))
+        if cmd[0].endswith("ffprobe"):
+            return SimpleNamespace(returncode=0, stdout=_json.dumps({"streams": [{"sample_rate": "44100", "channels": 2}]}).encode(), stderr=b"")
+        if "pcm_s16le" in cmd:                                       # decode
+            return SimpleNamespace(returncode=0, stdout=pcm.astype("<i2").tobytes(), stderr=b"")
+        return SimpleNamespace(returncode=0, stdout=b"ENCODED:" + bytes(str(len(input)), "ascii"), stderr=b"")
+
+    monkeypatch.setattr(audio_io.shutil, "which", lambda name: f"/usr/bin/{name}")
+    monkeypatch.setattr(audio_io.subprocess, "run", fake_run)
+    # decode from a path: the stream's own rate and channels
+    x, sr = read(tmp_path / "clip.m4a", dtype="int16")
+    assert sr == 44100 and x.shape == (24, 2) and x[:, 0].tolist() == pcm[0::2].tolist()
+    assert calls[0][0][:8] == ["/usr/bin/ffprobe", "-v", "quiet", "-print_format", "json", "-show_streams", "-select_streams", "a:0"] and calls[0][0][-1].endswith("clip.m4a")
+    assert calls[1][0] == ["/usr/bin/ffmpeg", "-i", str(tmp_path / "clip.m4a"), "-f", "s16le", "-acodec", "pcm_s16le", "-ar", "44100", "-ac", "2", "pipe:1"]
+    # decode from bytes (magic bytes pick the path), caller-chosen rate / channels are ffmpeg's to apply
+    calls.clear()
+    read(io.BytesIO(b"fLaC" + b"\0" * 64), sample_rate=16000, nchannels=1)
+    assert calls[0][0][-2:] == ["-i", "pipe:0"] and calls[0][1][:4] == b"fLaC"
+    assert calls[1][0][1:3] == ["-i", "pipe:0"] and calls[1][0][-5:] == ["-ar", "16000", "-ac", "1", "pipe:1"]
+    # encode: per-format options, raw s16le on stdin
+    for fmt, expect in (("mp3", ["-b:a", "128k", "-f", "mp3", "pipe:1"]), ("opus", ["-c:a", "libopus", "-b:a", "128k", "-f", "opus", "pipe:1"]),
+                        ("ogg", ["-c:a", "flac", "-f", "ogg", "pipe:1"]), ("vorbis", ["-c:a", "flac", "-f", "ogg", "pipe:1"]), ("flac", ["-f", "flac", "pipe:1"])):
+        calls.clear()
+        bio = io.BytesIO()
+        write(bio, np.zeros(100, np.float32), 24000, format=fmt)
+        cmd, stdin = calls[0]
+        assert cmd[:10] == ["/usr/bin/ffmpeg", "-y", "-f", "s16le", "-ar", "24000", "-ac", "1", "-i", "pipe:0"] and cmd[10:] == expect, (fmt, cmd)
+        assert len(stdin) == 200 and bio.getvalue() == b"ENCODED:200"
+    # without ffmpeg: loud
+    monkeypatch.setattr(audio_io.shutil, "which", lambda name: None)
+    with pytest.raises(RuntimeError, match="ffmpeg"):
+        read(tmp_path / "clip.m4a")
