@@ -1,7 +1,7 @@
-"""Descript Audio Codec, decode side (codes / latents -> waveform), on MI355X: host schedule over the HIP kernels.
+"""Descript Audio Codec (waveform -> codes / latents -> waveform) on MI355X: host schedule over the HIP kernels.
 
-Mirrors ``mlx_audio/codec/models/descript/dac.py`` + ``nn/layers.py`` + ``nn/quantize.py`` (constructor arguments, ``preprocess``, ``decode``,
-``quantizer.from_codes``), with the reference's op-by-op graph collapsed into:
+Mirrors ``mlx_audio/codec/models/descript/dac.py`` + ``nn/layers.py`` + ``nn/quantize.py`` (constructor arguments, ``preprocess``, ``encode``, ``decode``,
+``__call__``, ``quantizer(z, n_quantizers)``, ``quantizer.from_codes``), with the reference's op-by-op graph collapsed into:
   * ``ResidualVectorQuantize.from_codes`` (quantize.py:130-139): the per-codebook ``out_proj(codebook[code])`` is a table lookup --
     ``codebook @ W^T + b`` is folded once at load into one ``[n_codebooks * codebook_size, latent_dim]`` table and a frame is ONE ``embed_sum``
     launch (sum of n_codebooks table rows, in codebook order like the reference's running sum);
@@ -11,8 +11,17 @@ Mirrors ``mlx_audio/codec/models/descript/dac.py`` + ``nn/layers.py`` + ``nn/qua
 Reference quirk preserved: ``WNConvTranspose1d`` hands ``groups = 1`` to MLX's ``output_padding`` slot (positional order), so each transposed
 conv emits one extra sample: T frames -> lengths pinned by the reference's tests (250 -> 80 043, 375 -> 120 043, 430 -> 220 235).
 
-The encoder / quantiser-search half (``encode``, ``__call__``) is outside the decode hot path and raises.  Weights: float32 checkpoints are held
-as fp16 MFMA images, activations split fp16 hi + lo (``precision = 4``); deviation from the float32 oracle asserted in ``tests/test_dac_gpu.py``.
+
+Encode side (round 5; dac.py:36-81, 184-192, nn/quantize.py:17-127), from the same kernels:
+  * ``Encoder``: the 1 -> d_model k7 conv runs FLATTENED over the contiguous samples (7 taps = 7 "channels" of a one-tap conv, zero outside the
+    signal); a ``ResidualUnit`` is two launches (Snake prologue, residual epilogue), as in the decoder; the strided ``WNConv1d(K = 2 s, stride s,
+    padding ceil(s / 2))`` that ends an ``EncoderBlock`` is a TWO-tap conv over rows regrouped ``[rows / s, s * C]`` -- a free view of a zeroed
+    buffer that holds the block's activation behind ``padding`` zero rows (Snake(0) = 0 keeps the padding zero through the prologue);
+  * ``ResidualVectorQuantize.__call__``: per codebook ``in_proj`` (1x1 conv to 8 dims) -> nearest L2-normalised codeword (``mi355_rvq_encode`` over the
+    normalised codebook: arg-max of the cosine; the reference's ``|e|^2 - 2 e.c + |c|^2`` on normalised vectors has the same arg-min) -> the
+    residual update ``residual -= out_proj(codebook[idx])`` as one ``embed_sum`` over the NEGATED folded table; ``z_q`` is ``from_codes`` of the result.
+Weights: float32 checkpoints are held as fp16 MFMA images, activations split fp16 hi + lo (``precision = 4``); deviation from the float32 oracle
+asserted in ``tests/test_dac_gpu.py`` / ``tests/test_codec_encode_gpu.py``.
 """
 from __future__ import annotations
 
@@ -67,6 +76,46 @@ def make_dac_weights(decoder_dim: int, decoder_rates: List[int], latent_dim: int
     return w
 
 
+def make_dac_encoder_weights(encoder_dim: int, encoder_rates: List[int], latent_dim: int, n_codebooks: int, codebook_dim: int,
+                             seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Random float32 ENCODE-side parameters (``encoder.*`` and every quantizer's ``in_proj``; reference module paths, MLX layouts): merge with
+    ``make_dac_weights`` for a whole model."""
+    g = torch.Generator().manual_seed(seed + 7919)
+    w: Dict[str, torch.Tensor] = {}
+
+    def conv(name, cout, k, cin, gain=1.0):
+        scale = math.sqrt(1 / (cin * k))
+        v0 = (torch.rand(cout, k, cin, generator=g) * 2 - 1) * scale * gain
+        gw = torch.sqrt((v0 ** 2).sum(dim=(1, 2), keepdim=True))
+        w[name + ".weight_g"] = gw * (1.0 + 0.1 * torch.randn(gw.shape, generator=g))
+        w[name + ".weight_v"] = v0 / (gw + 1e-12)
+        w[name + ".bias"] = 0.02 * torch.randn(cout, generator=g)
+
+    def alpha(name, c):
+        w[name + ".alpha"] = (1.0 + 0.3 * torch.randn(1, 1, c, generator=g)).abs() + 0.05
+
+    e = "encoder.block.layers."
+    conv(e + "0", encoder_dim, 7, 1, gain=2.5)
+    d = encoder_dim
+    for i, s in enumerate(encoder_rates):
+        d *= 2
+        p = f"{e}{i + 1}.block.layers."
+        for j in range(3):
+            q = p + f"{j}.block.layers."
+            alpha(q + "0", d // 2)
+            conv(q + "1", d // 2, 7, d // 2, gain=1.2)
+            alpha(q + "2", d // 2)
+            conv(q + "3", d // 2, 1, d // 2, gain=0.5)
+        alpha(p + "3", d // 2)
+        conv(p + "4", d, 2 * s, d // 2, gain=1.2)
+    n = len(encoder_rates)
+    alpha(f"{e}{n + 1}", d)
+    conv(f"{e}{n + 2}", latent_dim, 3, d, gain=1.5)
+    for i in range(n_codebooks):
+        conv(f"quantizer.quantizers.{i}.in_proj", codebook_dim, 1, latent_dim, gain=1.5)
+    return w
+
+
 class _Snake:
     """alpha and 1 / (alpha + 1e-9) (layers.py:123-126), padded to a multiple of 32 channels (conv_gemm prologue operands)."""
 
@@ -99,6 +148,58 @@ class _Quantizer:
         self.table = torch.cat(tabs, 0).contiguous().to(device)
         self.offs = torch.tensor([i * codebook_size for i in range(n_codebooks)], dtype=torch.int32, device=device)
         self.latent_dim = self.table.shape[1]
+        self.codebook_dim = self.codebooks[0].shape[1]
+        # encode side (present when the checkpoint carries the in_proj convs): the 1x1 projections, the L2-normalised codebooks in the layouts
+        # mi355_rvq_encode reads, and the NEGATED out_proj table for the residual update
+        self.in_proj = None
+        if all(f"quantizer.quantizers.{i}.in_proj.weight_v" in w for i in range(n_codebooks)):
+            self.in_proj, self.search = [], []
+            for i in range(n_codebooks):
+                p = f"quantizer.quantizers.{i}.in_proj"
+                v, gw = w[p + ".weight_v"].double(), w[p + ".weight_g"].double()
+                self.in_proj.append(ops.pack_conv((gw * v / torch.sqrt((v ** 2).sum(dim=(1, 2), keepdim=True))).float(), w.get(p + ".bias"), device, f16=True))
+                cb = w[f"quantizer.quantizers.{i}.codebook.weight"].float()
+                cn = cb / torch.clamp(torch.sqrt((cb * cb).sum(1, keepdim=True)), min=1e-12)      # normalize() of quantize.py:10-12
+                t = cn[None].contiguous()
+                self.search.append((t.to(device), t.transpose(1, 2).contiguous().to(device), ((t * t).sum(-1) / 2).contiguous().to(device)))
+            self.neg_table = (-self.table).contiguous()
+
+    def __call__(self, z, n_quantizers: Optional[int] = None, return_margins: bool = False):
+        """``ResidualVectorQuantize.__call__`` (quantize.py:90-127): z [B, D, T] ->
+        (z_q [B, D, T], codes [B, n, T] int64, latents [B, n * d, T], commitment_loss, codebook_loss).  ``return_margins`` appends the cosine gap
+        between the best and the second-best codeword of every decision ([B, n, T]: a gap at float32 rounding level is a knife edge)."""
+        if self.in_proj is None:
+            raise ValueError("this DAC was loaded without quantizer in_proj weights (decode-only checkpoint): the codebook search cannot run")
+        z = torch.as_tensor(z, dtype=torch.float32).to(self.device).transpose(1, 2)   # channels-last rows for the kernels
+        B, T, D = z.shape
+        if D != self.latent_dim:
+            raise ValueError(f"quantizer: z must be [B, {self.latent_dim}, T], got {tuple(z.transpose(1, 2).shape)}")
+        n = self.n_codebooks if n_quantizers is None else max(0, min(int(n_quantizers), self.n_codebooks))
+        d = self.codebook_dim
+        residual = z.contiguous().clone()
+        lat = torch.empty((B, T, max(n, 1) * d), dtype=torch.float32, device=self.device)
+        ids, margins = [], []
+        for i in range(n):
+            ze = lat[:, :, i * d:(i + 1) * d]
+            ops.conv_gemm(residual, self.in_proj[i], ze, precision=4)
+            rows = lat.view(B * T, -1)[:, i * d:(i + 1) * d]
+            c, m = ops.rvq_encode(rows, *self.search[i], margins=True)
+            if return_margins:   # score = |c|^2 / 2 - e . c over the normalised codebook: the gap in cosine units is the score gap over |e|
+                margins.append((m.view(B, T) / torch.clamp(torch.sqrt((rows * rows).sum(1)).view(B, T), min=1e-30)))
+            ids.append(c.view(B, T, 1))
+            if i + 1 < n:
+                ops.embed_sum(self.neg_table, ids[-1], residual, slot_offset=self.offs[i:i + 1], add=residual)
+        if n == 0:
+            raise ValueError("quantizer: n_quantizers must be at least 1")
+        codes = torch.cat(ids, 2).permute(0, 2, 1).contiguous().to(torch.int64)      # [B, n, T]
+        z_q, z_p, _ = self.from_codes(codes)
+        latents = lat.transpose(1, 2)
+        # (z_e - codebook[idx])^2 averaged over (d, T) per item and codebook, summed over the codebooks and averaged over the batch; the two
+        # losses are the same number in a forward pass (quantize.py:29-30)
+        diff = lat.view(B, T, n, d) - z_p.transpose(1, 2).reshape(B, T, n, d)
+        loss = (diff * diff).mean(dim=(1, 3)).mean(dim=0).sum()
+        out = (z_q, codes, latents, loss, loss.clone())
+        return out + (torch.stack(margins, 1),) if return_margins else out
 
     def from_codes(self, codes):
         """codes int [B, n, T] -> (z_q [B, D, T], z_p [B, n * d, T], codes)."""
@@ -139,7 +240,7 @@ class DAC:
     # ------------------------------------------------------------------ load
     def load_weights(self, weights: Dict[str, torch.Tensor]):
         dev = self.device
-        w = {k: torch.as_tensor(v).detach().float().cpu() for k, v in weights.items() if k.startswith(("decoder.", "quantizer."))}
+        w = {k: torch.as_tensor(v).detach().float().cpu() for k, v in weights.items() if k.startswith(("decoder.", "quantizer.", "encoder."))}
 
         def conv(name) -> PackedConv:
             v, g = w[name + ".weight_v"].double(), w[name + ".weight_g"].double()
@@ -162,6 +263,28 @@ class DAC:
         n = len(self.decoder_rates)
         self.out_snake = _Snake(w[f"decoder.model.layers.{n + 1}.alpha"], dev)
         self.conv_out = conv(f"decoder.model.layers.{n + 2}")
+        self.enc = None
+        if "encoder.block.layers.0.weight_v" in w:   # the encode half (dac.py:36-81)
+            e = "encoder.block.layers."
+            v, g = w[e + "0.weight_v"].double(), w[e + "0.weight_g"].double()
+            w0 = (g * v / torch.sqrt((v ** 2).sum(dim=(1, 2), keepdim=True))).float()   # [d, 7, 1] -> one tap of 7 "channels" (flattened conv)
+            stem = ops.pack_conv(w0.reshape(w0.shape[0], 1, w0.shape[1]).contiguous(), w.get(e + "0.bias"), dev, f16=True)
+            blocks = []
+            for i, s in enumerate(self.encoder_rates):
+                p = f"{e}{i + 1}.block.layers."
+                units = []
+                for j, d in enumerate((1, 3, 9)):
+                    q = p + f"{j}.block.layers."
+                    units.append(dict(dil=d, s1=_Snake(w[q + "0.alpha"], dev), c1=conv(q + "1"), s2=_Snake(w[q + "2.alpha"], dev), c2=conv(q + "3")))
+                v, g = w[p + "4.weight_v"].double(), w[p + "4.weight_g"].double()
+                wd = (g * v / torch.sqrt((v ** 2).sum(dim=(1, 2), keepdim=True))).float()   # [cout, 2 s, cin]: tap j s + r -> (tap j, channel r cin + c)
+                cout, k, cin = wd.shape
+                if k != 2 * s:
+                    raise ValueError(f"encoder block {i}: {k} taps for stride {s} (the reference builds kernel_size = 2 * stride)")
+                down = ops.pack_conv(wd.reshape(cout, 2, s * cin).contiguous(), w.get(p + "4.bias"), dev, f16=True)
+                blocks.append(dict(stride=s, cin=cin, units=units, snake=_Snake(w[p + "3.alpha"].reshape(-1).repeat(s), dev), down=down))
+            ne = len(self.encoder_rates)
+            self.enc = dict(stem=stem, k0=w0.shape[1], dim=w0.shape[0], blocks=blocks, snake=_Snake(w[f"{e}{ne + 1}.alpha"], dev), out=conv(f"{e}{ne + 2}"))
         return self
 
     # ------------------------------------------------------------------ reference surface
@@ -174,11 +297,76 @@ class DAC:
         right_pad = math.ceil(length / self.hop_length) * self.hop_length - length
         return torch.nn.functional.pad(audio_data, (0, right_pad))
 
-    def encode(self, audio_data, n_quantizers: int = None):
-        raise NotImplementedError("DAC.encode (encoder + codebook search) is outside the decode hot path of this build (SURVEY section 8(f).2)")
+    def encoder(self, audio_data, return_stages: bool = False):
+        """``Encoder.__call__`` on ``audio_data.moveaxis(1, 2)`` (dac.py:57-81, 189): audio [B, 1, S] -> z [B, latent_dim, T]."""
+        if self.enc is None:
+            raise ValueError("this DAC was loaded without encoder weights (decode-only checkpoint)")
+        e = self.enc
+        x0 = torch.as_tensor(audio_data, dtype=torch.float32).to(self.device)
+        if x0.dim() != 3 or x0.shape[1] != 1:
+            raise ValueError(f"encoder: audio_data must be [B, 1, samples], got {tuple(x0.shape)}")
+        x0 = x0.reshape(x0.shape[0], -1).contiguous()
+        B, L = x0.shape
+        st = {}
+
+        def staged(L, C, s):
+            """Zeroed buffer whose rows [p, p + L) hold a block's activation; regrouped s rows at a time it is the input of the block's strided conv."""
+            p = math.ceil(s / 2)
+            if L + 2 * p < 2 * s:
+                raise ValueError(f"encoder: {L} rows are fewer than one frame of the stride-{s} conv")
+            Lout = (L + 2 * p - 2 * s) // s + 1
+            rows = round_up(max((Lout + 1) * s, p + L), s)
+            buf = torch.zeros((B, rows, C), dtype=torch.float32, device=self.device)
+            return buf, buf[:, p:p + L], Lout
+
+        blocks = e["blocks"]
+        buf, y, Lout = staged(L, e["dim"], blocks[0]["stride"])
+        ops.conv_gemm(x0[:, :, None], e["stem"], y, lout=L, flat=dict(ldx=1, x_off=-(e["k0"] // 2), channels=1), precision=4)
+        for bi, blk in enumerate(blocks):
+            s, C = blk["stride"], blk["cin"]
+            tmp = self._f(B, L, C)
+            for u in blk["units"]:
+                self._conv(y, u["s1"], u["c1"], tmp, dil=u["dil"])
+                self._conv(tmp, u["s2"], u["c2"], y, res=y)
+            if return_stages:
+                st[f"units{bi}"] = y.clone()
+            cout = blk["down"].cout
+            if bi + 1 < len(blocks):
+                nbuf, ny, nLout = staged(Lout, cout, blocks[bi + 1]["stride"])
+            else:
+                nbuf, ny, nLout = None, self._f(B, Lout, cout), 0
+            sn = blk["snake"]
+            ops.conv_gemm(buf.view(B, buf.shape[1] // s, s * C), blk["down"], ny, pad=0, lout=Lout, pre_act=ACT_SNAKE, pre_alpha=sn.alpha,
+                          pre_inv_beta=sn.inv_conv, precision=4)
+            buf, y, L, Lout = nbuf, ny, Lout, nLout
+            if return_stages:
+                st[f"block{bi}"] = y.clone()
+        z = self._f(B, L, self.latent_dim)
+        self._conv(y, e["snake"], e["out"], z)
+        st["latent"] = z
+        return (z.transpose(1, 2), st) if return_stages else z.transpose(1, 2)
+
+    def encode(self, audio_data, n_quantizers: int = None, return_margins: bool = False):
+        """dac.py:184-192: audio [B, 1, S] -> (z [B, D, T], codes [B, n, T], latents [B, n * d, T], commitment_loss, codebook_loss)."""
+        return self.quantizer(self.encoder(audio_data), n_quantizers, return_margins=return_margins)
 
     def __call__(self, audio_data, sample_rate: int = None, n_quantizers: int = None, use_rvq: bool = True, return_loss: bool = False):
-        raise NotImplementedError("DAC.__call__ runs the encoder, which this build does not contain; use quantizer.from_codes + decode")
+        """dac.py:207-239 (the reference slices the LAST axis of the channels-last decoder output, ``x[..., :length]`` -- one channel, so a no-op
+        for length >= 1; mirrored as is, like ``SNAC.decode_stream``)."""
+        audio_data = torch.as_tensor(audio_data, dtype=torch.float32)
+        length = audio_data.shape[-1]
+        audio_data = self.preprocess(audio_data, sample_rate)
+        codes = latents = commitment_loss = codebook_loss = None
+        if use_rvq:
+            z, codes, latents, commitment_loss, codebook_loss = self.encode(audio_data, n_quantizers)
+        else:
+            z = self.encoder(audio_data)
+        x = self.decode(z)
+        if return_loss:
+            # mx.losses.mse(x, audio_data) broadcasts [B, T', 1] against [B, 1, S] in the reference; restated on matching layouts
+            n = min(x.shape[1], audio_data.shape[-1])
+            return ((x[:, :n, 0] - audio_data.to(self.device)[:, 0, :n]) ** 2).mean()
+        return {"audio": x[..., :length], "z": z, "codes": codes, "latents": latents, "vq/commitment_loss": commitment_loss, "vq/codebook_loss": codebook_loss}
 
     def _f(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.device)

@@ -1,4 +1,4 @@
-"""PyTorch-CPU restatement of the Descript Audio Codec decode path (TEST ORACLE, not product).
+"""PyTorch-CPU restatement of the Descript Audio Codec, decode and encode paths (TEST ORACLE, not product).
 
 Follows /root/reference/mlx_audio/codec/models/descript statement by statement:
   * ``nn/layers.py:8-14, 17-62``    WNConv1d: weight = g * v / ||v|| (norm over all axes but 0)
@@ -13,6 +13,15 @@ Follows /root/reference/mlx_audio/codec/models/descript statement by statement:
   * ``dac.py:84-129``               DecoderBlock / Decoder: conv k7 -> blocks (snake, convT K = 2 s, padding ceil(s / 2), three units with
                                     dilations 1 / 3 / 9) -> snake -> conv k7 -> tanh
   * ``nn/quantize.py:42-46, 130-139`` ResidualVectorQuantize.from_codes: codebook lookup, out_proj (1x1 WNConv), sum over codebooks
+
+Encode side (round 5):
+  * ``dac.py:16-33, 36-81``         EncoderBlock: three units (dilations 1 / 3 / 9) at dim / 2, snake, WNConv1d(K = 2 s, stride s, padding ceil(s / 2));
+                                    Encoder: conv k7 (1 -> d_model), the blocks (d_model doubles per block), snake, conv k3 -> latent
+  * ``nn/quantize.py:10-12, 17-62`` VectorQuantize: in_proj (1x1), L2-normalised encodings / codebook, ``dist = |e|^2 - 2 e c^T + |c|^2``,
+                                    ``(-dist).argmax(1)`` (first maximum), out_proj of the UN-normalised codeword
+  * ``nn/quantize.py:90-127``       ResidualVectorQuantize.__call__: residual loop, codes stacked on axis 1, latents concatenated on axis 1, the two
+                                    (numerically equal) losses as per-item means, batch-averaged, summed over the codebooks
+pinned the same way: ``DAC.encode`` of the reference's own modules on a seeded checkpoint (``ref_dac_encode.npz``; every code equal, latents 2e-5).
 
 Parameter names are the reference's module paths (``decoder.model.layers.N...``, ``quantizer.quantizers.N.codebook.weight`` ...), layouts MLX's
 (conv ``[out, K, in]``).  Arithmetic float32 (float64 on request) on the parameters as given (the published checkpoints are float32).
@@ -92,3 +101,75 @@ class DACDecoderRef:
         x = snake(x, self.w[f"decoder.model.layers.{n + 1}.alpha"])
         x = torch.tanh(self._conv(x, f"decoder.model.layers.{n + 2}", padding=3))
         return (x, st) if return_stages else x
+
+
+class DACEncoderRef:
+    """``DAC.encode`` (dac.py:184-192): ``Encoder`` + ``ResidualVectorQuantize.__call__``."""
+
+    def __init__(self, weights: Dict[str, Tensor], encoder_rates: List[int], n_codebooks: int, dtype=torch.float32):
+        self.w = {k: v.to(dtype) if v.is_floating_point() else v for k, v in weights.items()}
+        self.rates = list(encoder_rates)
+        self.n_codebooks = n_codebooks
+        self.dtype = dtype
+
+    def _conv(self, x: Tensor, name: str, dilation: int = 1, padding: int = 0, stride: int = 1) -> Tensor:
+        w = wn_conv_weight(self.w[name + ".weight_g"], self.w[name + ".weight_v"])  # [out, K, in]
+        return F.conv1d(x.transpose(1, 2), w.permute(0, 2, 1), self.w.get(name + ".bias"), stride=stride, padding=padding, dilation=dilation).transpose(1, 2)
+
+    def encoder(self, audio: Tensor, return_stages: bool = False):
+        """audio [B, 1, S] -> z [B, D, T] (dac.py:57-81 on ``audio_data.moveaxis(1, 2)``)."""
+        x = audio.to(self.dtype).transpose(1, 2)   # [B, S, 1]
+        st = {}
+        e = "encoder.block.layers."
+        x = self._conv(x, e + "0", padding=3)
+        for i, s in enumerate(self.rates):
+            p = f"{e}{i + 1}.block.layers."
+            for j, d in enumerate((1, 3, 9)):
+                q = p + f"{j}.block.layers."
+                y = snake(x, self.w[q + "0.alpha"])
+                y = self._conv(y, q + "1", dilation=d, padding=3 * d)
+                y = snake(y, self.w[q + "2.alpha"])
+                y = self._conv(y, q + "3")
+                x = x + y
+            st[f"units{i}"] = x
+            x = snake(x, self.w[p + "3.alpha"])
+            x = self._conv(x, p + "4", stride=s, padding=math.ceil(s / 2))
+            st[f"block{i}"] = x
+        n = len(self.rates)
+        x = snake(x, self.w[f"{e}{n + 1}.alpha"])
+        x = self._conv(x, f"{e}{n + 2}", padding=1)
+        st["latent"] = x
+        return (x.transpose(1, 2), st) if return_stages else x.transpose(1, 2)
+
+    def quantize(self, z: Tensor, n_quantizers: int = None, return_margins: bool = False):
+        """z [B, D, T] -> (z_q, codes [B, n, T], latents [B, n d, T], commitment_loss, codebook_loss) (+ the top-2 gap of ``-dist`` per decision)."""
+        n = self.n_codebooks if n_quantizers is None else min(n_quantizers, self.n_codebooks)
+        residual = z.to(self.dtype)
+        z_q = 0
+        codes, latents, margins = [], [], []
+        commit = cbl = 0
+        for i in range(n):
+            p = f"quantizer.quantizers.{i}."
+            z_e = self._conv(residual.transpose(1, 2), p + "in_proj").transpose(1, 2)       # [B, d, T]
+            b, d, t = z_e.shape
+            enc = z_e.permute(0, 2, 1).reshape(b * t, d)
+            cb = self.w[p + "codebook.weight"]
+            en = enc / torch.clamp(torch.sqrt((enc.abs() ** 2).sum(1, keepdim=True)), min=1e-12)
+            cn = cb / torch.clamp(torch.sqrt((cb.abs() ** 2).sum(1, keepdim=True)), min=1e-12)
+            dist = (en ** 2).sum(1, keepdim=True) - 2 * en @ cn.t() + (cn ** 2).sum(1, keepdim=True).t()
+            top = torch.topk(-dist, 2, dim=1).values
+            idx = (-dist).argmax(1).reshape(b, t)
+            margins.append(((top[:, 0] - top[:, 1]) / 2).reshape(b, t))   # -dist = 2 cos - const: half the gap is the cosine gap
+            zq_lat = cb[idx].transpose(1, 2)                               # decode_code: [B, d, T]
+            commit = commit + ((z_e - zq_lat) ** 2).mean(dim=(1, 2)).mean()
+            cbl = cbl + ((zq_lat - z_e) ** 2).mean(dim=(1, 2)).mean()
+            z_q_i = self._conv((z_e + (zq_lat - z_e)).transpose(1, 2), p + "out_proj").transpose(1, 2)
+            z_q = z_q + z_q_i
+            residual = residual - z_q_i
+            codes.append(idx)
+            latents.append(z_e)
+        out = (z_q, torch.stack(codes, 1), torch.cat(latents, 1), commit, cbl)
+        return out + (torch.stack(margins, 1),) if return_margins else out
+
+    def encode(self, audio: Tensor, n_quantizers: int = None):
+        return self.quantize(self.encoder(audio), n_quantizers)

@@ -873,6 +873,49 @@ def run_dac(seed_w, seed_codes, n_frames):
     return dict(seed_w=seed_w, codes=codes, z=np.asarray(z).astype(np.float32), audio=audio.astype(np.float32))
 
 
+def _load_dac_modules():
+    _codec_pkgs()
+    base = "mlx_audio.codec.models.descript"
+    _pkg(base, f"{REF}/codec/models/descript")
+    _pkg(f"{base}.nn", f"{REF}/codec/models/descript/nn")
+    _load(f"{base}.base", f"{REF}/codec/models/descript/base.py")
+    _load(f"{base}.nn.layers", f"{REF}/codec/models/descript/nn/layers.py")
+    _load(f"{base}.nn.quantize", f"{REF}/codec/models/descript/nn/quantize.py")
+    return _load(f"{base}.dac", f"{REF}/codec/models/descript/dac.py")
+
+
+DAC_ENC_TINY = dict(encoder_dim=16, encoder_rates=[2, 4, 5, 8], latent_dim=32, decoder_dim=64, decoder_rates=[8, 5, 4, 2], n_codebooks=4, codebook_size=128,
+                    codebook_dim=8, sample_rate=16000)
+
+
+def run_dac_encode(seed_w, seed_audio, n_samples):
+    """The reference's ``DAC.encode`` (dac.py:184-192: Encoder -> ResidualVectorQuantize.__call__, nn/quantize.py:17-127) and ``DAC.__call__`` on a seeded
+    checkpoint: even and odd strides, a length that is not a whole number of hops, all codebooks and ``n_quantizers = 2``."""
+    from mlx_audio_amd.codec.models.descript import make_dac_encoder_weights, make_dac_weights
+
+    rd = _load_dac_modules()
+    c = DAC_ENC_TINY
+    w = make_dac_weights(c["decoder_dim"], c["decoder_rates"], c["latent_dim"], c["n_codebooks"], c["codebook_size"], c["codebook_dim"], seed=seed_w)
+    w.update(make_dac_encoder_weights(c["encoder_dim"], c["encoder_rates"], c["latent_dim"], c["n_codebooks"], c["codebook_dim"], seed=seed_w))
+    model = rd.DAC(**c)
+    model.load_weights([(k, v.numpy()) for k, v in w.items()])
+    missing, unexpected, mism = model._load_report
+    assert not unexpected and not missing and not mism, (missing[:8], unexpected[:8], mism[:4])
+    model.eval()
+    g = np.random.default_rng(seed_audio)
+    t = np.arange(n_samples) / c["sample_rate"]
+    audio = np.stack([0.5 * np.sin(2 * np.pi * (180 + 90 * b) * t) * (0.6 + 0.4 * np.sin(2 * np.pi * 3 * t)) + 0.15 * g.standard_normal(n_samples) for b in range(2)])
+    audio = audio[:, None, :].astype(np.float32)
+    z, codes, latents, commit, cbl = model.encode(mx.array(audio))
+    z2, codes2, latents2, commit2, _ = model.encode(mx.array(audio), 2)
+    enc = model.encoder(mx.array(audio).moveaxis(1, 2))
+    out = model(mx.array(audio), c["sample_rate"])
+    return dict(seed_w=seed_w, config=json.dumps(c), audio=audio, enc=_np(enc), z=_np(z), codes=np.asarray(codes).astype(np.int32), latents=_np(latents),
+                commitment_loss=np.float32(np.asarray(commit)), codebook_loss=np.float32(np.asarray(cbl)), z_nq2=_np(z2),
+                codes_nq2=np.asarray(codes2).astype(np.int32), latents_nq2=_np(latents2), commitment_loss_nq2=np.float32(np.asarray(commit2)),
+                call_audio=_np(out["audio"]), call_codes=np.asarray(out["codes"]).astype(np.int32), call_z=_np(out["z"]))
+
+
 def run_snac(seed_w, seed_codes, n_frames, attn_window_size=None):
     """The reference's ``SNAC.quantizer.from_codes`` + ``SNAC.decoder`` (codec/models/snac/{snac,layers,vq}.py), depthwise convs, no attention, with the
     NoiseBlock's gaussian draws logged."""
@@ -1737,6 +1780,11 @@ def run_whisper_generate():
 
 def main():
     R = import_reference()
+    if "codec_encode" in sys.argv[1:]:   # only the codec ENCODE fixtures (round 5)
+        efx = run_dac_encode(seed_w=31, seed_audio=4, n_samples=320 * 24 + 77)
+        np.savez_compressed(os.path.join(HERE, "ref_dac_encode.npz"), **efx)
+        print("dac encode:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in efx.items() if a != "config"}, float(efx["commitment_loss"]))
+        return
     if "qwen3_clone" in sys.argv[1:]:   # only the voice-cloning fixtures (round 3)
         sfx = run_qwen3_speaker_encoder(seed_w=13, seed_mel=5, frames=37)
         np.savez_compressed(os.path.join(HERE, "ref_qwen3_speaker_encoder.npz"), **sfx)

@@ -105,6 +105,10 @@ class array(np.ndarray):
     def square(self):
         return self * self
 
+    def mean(self, axis=None, keepdims=False, **kw):   # MLX takes a LIST of axes too (descript/nn/quantize.py:29: ``.mean([1, 2])``)
+        ax = tuple(axis) if isinstance(axis, list) else axis
+        return _wrap(np.asarray(np.mean(np.asarray(self), axis=ax, keepdims=keepdims, **kw)))
+
     def logsumexp(self, axis=None, keepdims=False):
         return logsumexp(self, axis=axis, keepdims=keepdims)
 
@@ -1032,6 +1036,16 @@ def install():
               "gelu", "relu", "silu", "sigmoid", "MultiHeadAttention", "RMSNorm", "RoPE", "ConvTranspose1d", "elu", "gelu_approx", "Sequential", "Tanh", "log_softmax", "ELU"):
         setattr(nn, k, getattr(me, k))
     nn.tanh = nn_tanh
+    losses = types.ModuleType("mlx.nn.losses")
+
+    def mse_loss(predictions, targets, reduction="mean"):
+        """``mlx.nn.losses.mse_loss``: ``square(predictions - targets)``, then ``none`` / ``mean`` / ``sum``."""
+        loss = _wrap(np.square(np.asarray(predictions) - np.asarray(targets)))
+        return loss if reduction == "none" else (_wrap(np.asarray(loss.mean())) if reduction == "mean" else _wrap(np.asarray(loss.sum())))
+
+    losses.mse_loss = mse_loss
+    nn.losses = losses
+    sys.modules["mlx.nn.losses"] = losses
     utils = types.ModuleType("mlx.utils")
     utils.tree_flatten = lambda tree: []
 

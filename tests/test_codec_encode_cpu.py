@@ -1,0 +1,90 @@
+"""Codec ENCODE oracles against the reference's own modules: tests/golden/make_reference_fixtures.py ``codec_encode`` runs
+``DAC.encode`` / ``SNAC.encode`` / ``Encodec.encode`` of /root/reference over the MLX stand-in on seeded checkpoints; the restatements in ``oracle/`` must
+reproduce every code and the float tensors at float32 rounding level.  CPU only."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel_max(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def dac_model_weights(fx):
+    from mlx_audio_amd.codec.models.descript import make_dac_encoder_weights, make_dac_weights
+
+    c = json.loads(str(fx["config"]))
+    w = make_dac_weights(c["decoder_dim"], c["decoder_rates"], c["latent_dim"], c["n_codebooks"], c["codebook_size"], c["codebook_dim"], seed=int(fx["seed_w"]))
+    w.update(make_dac_encoder_weights(c["encoder_dim"], c["encoder_rates"], c["latent_dim"], c["n_codebooks"], c["codebook_dim"], seed=int(fx["seed_w"])))
+    return c, w
+
+
+def test_dac_encode_oracle_reproduces_the_reference_modules():
+    """``DAC.encode`` (dac.py:184-192): encoder output, every code of every codebook, latents, z_q, both losses; ``n_quantizers = 2``; and the
+    encode half of ``DAC.__call__`` (preprocess pads to a whole number of hops first: one more frame)."""
+    from oracle.dac_ref import DACDecoderRef, DACEncoderRef
+
+    fx = np.load(os.path.join(GOLD, "ref_dac_encode.npz"))
+    c, w = dac_model_weights(fx)
+    ref = DACEncoderRef(w, c["encoder_rates"], c["n_codebooks"])
+    audio = torch.from_numpy(fx["audio"])
+    enc = ref.encoder(audio)
+    assert tuple(enc.shape) == fx["enc"].shape and rel_max(enc.numpy(), fx["enc"]) < 2e-5
+    z, codes, latents, commit, cbl, margins = ref.quantize(enc, return_margins=True)
+    assert np.array_equal(codes.numpy(), fx["codes"]), int((codes.numpy() != fx["codes"]).sum())
+    assert rel_max(latents.numpy(), fx["latents"]) < 2e-5 and rel_max(z.numpy(), fx["z"]) < 2e-5
+    assert abs(float(commit) - float(fx["commitment_loss"])) < 1e-5 * float(fx["commitment_loss"])
+    assert abs(float(cbl) - float(fx["codebook_loss"])) < 1e-5 * float(fx["codebook_loss"])
+    assert float(margins.min()) >= 0.0 and tuple(margins.shape) == tuple(codes.shape)
+    z2, codes2, latents2, commit2, _ = ref.quantize(enc, 2)
+    assert np.array_equal(codes2.numpy(), fx["codes_nq2"]) and rel_max(latents2.numpy(), fx["latents_nq2"]) < 2e-5
+    assert rel_max(z2.numpy(), fx["z_nq2"]) < 2e-5 and abs(float(commit2) - float(fx["commitment_loss_nq2"])) < 1e-5 * float(fx["commitment_loss_nq2"])
+    # __call__: right-pad to a multiple of hop_length (dac.py:173-182), encode, decode
+    hop = int(np.prod(c["encoder_rates"]))
+    pad = (-audio.shape[-1]) % hop
+    zc, cc, *_ = ref.encode(torch.nn.functional.pad(audio, (0, pad)))
+    assert np.array_equal(cc.numpy(), fx["call_codes"]) and rel_max(zc.numpy(), fx["call_z"]) < 2e-5
+    dec = DACDecoderRef(w, c["decoder_rates"], c["n_codebooks"]).decode(zc).numpy()
+    assert dec.shape == fx["call_audio"].shape and rel_max(dec, fx["call_audio"]) < 5e-5
+
+
+def test_dac_encode_host_schedule_dry_run():
+    """The product's host schedule (``mlx_audio_amd/codec/models/descript/dac.py``: flattened stem conv, in-place residual units inside the zero-padded
+    staging buffers, the strided convs as two taps over regrouped rows, per-codebook in_proj -> search -> negated-table residual update) over the CPU
+    emulation of the operator contracts (tests/_ops_emu.py), against the reference's own run: views, pads and operand order are right before a GPU
+    is spent.  (The kernels themselves are held by tests/test_codec_encode_gpu.py.)"""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _ops_emu
+    from mlx_audio_amd.codec.models.descript import DAC
+    from oracle.dac_ref import DACEncoderRef
+
+    fx = np.load(os.path.join(GOLD, "ref_dac_encode.npz"))
+    c, w = dac_model_weights(fx)
+    audio = torch.from_numpy(fx["audio"])
+    with _ops_emu.patched():
+        eng = DAC(**c, weights=w, device="cpu")
+        enc, st = eng.encoder(audio, return_stages=True)
+        _, est = DACEncoderRef(w, c["encoder_rates"], c["n_codebooks"]).encoder(audio, return_stages=True)
+        for k in est:
+            assert rel_max(st[k].numpy(), est[k].numpy()) < 1e-5, k
+        assert rel_max(enc.numpy(), fx["enc"]) < 1e-5
+        z, codes, latents, commit, cbl, margins = eng.quantizer(torch.from_numpy(fx["enc"]), return_margins=True)
+        assert np.array_equal(codes.numpy(), fx["codes"]) and codes.dtype == torch.int64
+        assert rel_max(z.numpy(), fx["z"]) < 1e-5 and rel_max(latents.numpy(), fx["latents"]) < 1e-5
+        assert abs(float(commit) - float(fx["commitment_loss"])) < 1e-5 * float(fx["commitment_loss"]) and float(cbl) == float(commit)
+        assert float(margins.min()) > 0 and tuple(margins.shape) == tuple(codes.shape)
+        z2, codes2, latents2, commit2, _ = eng.quantizer(torch.from_numpy(fx["enc"]), 2)
+        assert np.array_equal(codes2.numpy(), fx["codes_nq2"]) and rel_max(z2.numpy(), fx["z_nq2"]) < 1e-5 and rel_max(latents2.numpy(), fx["latents_nq2"]) < 1e-5
+        out = eng(audio, c["sample_rate"])
+        assert np.array_equal(out["codes"].numpy(), fx["call_codes"]) and rel_max(out["z"].numpy(), fx["call_z"]) < 1e-5
+        assert out["audio"].shape == fx["call_audio"].shape and rel_max(out["audio"].numpy(), fx["call_audio"]) < 2e-5
+    import mlx_audio_amd.ops as real_ops
+    assert real_ops.conv_gemm.__module__ == "mlx_audio_amd.ops"   # the emulation is gone after the block

@@ -1,0 +1,161 @@
+"""Codec ENCODE sides on the HIP path: DAC / SNAC / EnCodec ``encode`` against the CPU oracles (pinned to the
+reference's own modules by tests/test_codec_encode_cpu.py) and against the reference-run fixtures themselves.  Float stages within stated bars; codes
+bit-exact under the margin rule (tests/_margin.py: a decision whose top-2 gap is at float32 rounding level may fall either way).
+Needs a real MI355X: ``pytest -m gpu``."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _margin  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel_peak(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def make_audio(batch, n, sr, seed):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(n, dtype=torch.float64) / sr
+    rows = [0.5 * torch.sin(2 * np.pi * (170 + 80 * b) * t) * (0.6 + 0.4 * torch.sin(2 * np.pi * 3 * t)) + 0.15 * torch.randn(n, generator=g, dtype=torch.float64)
+            for b in range(batch)]
+    return torch.stack(rows)[:, None, :].float()
+
+
+def walk_frames(family, got, want, margins, thr):
+    """codes [B, n, T]: the n residual decisions of a frame form one sequence (a different pick changes every later residual of that frame)."""
+    got, want, margins = got.cpu(), want.cpu(), margins.cpu()
+    for b in range(got.shape[0]):
+        for t in range(got.shape[2]):
+            _margin.walk(family, got[b, :, t].tolist(), want[b, :, t].tolist(), margins[b, :, t].tolist(), thr=thr, where=(b, t))
+
+
+# ------------------------------------------------------------------------------------------------------------------ DAC
+def fp16_exact_dac(w):
+    """Make every FOLDED conv weight fp16-representable (v := the folded weight rounded to half, g := its norm), so the fp16 MFMA image is exact."""
+    from oracle.dac_ref import wn_conv_weight, wn_convT_weight
+
+    for k in [k for k in w if k.endswith("weight_v")]:
+        base = k[: -len(".weight_v")]
+        tr = base.startswith("decoder.") and ".block.layers.1" in base and base.count(".block.layers.") == 1
+        folded = (wn_convT_weight if tr else wn_conv_weight)(w[base + ".weight_g"], w[k]).half().float()
+        dims = (0, 1) if tr else (1, 2)
+        w[base + ".weight_g"] = torch.sqrt((folded.double() ** 2).sum(dim=dims, keepdim=True)).float()
+        w[k] = folded
+    return w
+
+
+def dac_pair(c, seed, exact):
+    from mlx_audio_amd.codec.models.descript import DAC, make_dac_encoder_weights, make_dac_weights
+    from oracle.dac_ref import DACDecoderRef, DACEncoderRef
+
+    w = make_dac_weights(c["decoder_dim"], c["decoder_rates"], c["latent_dim"], c["n_codebooks"], c["codebook_size"], c["codebook_dim"], seed=seed)
+    w.update(make_dac_encoder_weights(c["encoder_dim"], c["encoder_rates"], c["latent_dim"], c["n_codebooks"], c["codebook_dim"], seed=seed))
+    if exact:
+        fp16_exact_dac(w)
+    eng = DAC(**c, weights=w, device=DEV)
+    return eng, DACEncoderRef(w, c["encoder_rates"], c["n_codebooks"]), DACDecoderRef(w, c["decoder_rates"], c["n_codebooks"])
+
+
+def test_dac_encode_against_the_reference_run():
+    """The reference's own ``DAC.encode`` / ``DAC.__call__`` outputs (tests/golden/ref_dac_encode.npz): encoder latents, codes of every codebook under the
+    margin rule, latents, z_q, losses, ``n_quantizers = 2``, and the ``__call__`` round trip."""
+    from mlx_audio_amd.codec.models.descript import DAC
+    from test_codec_encode_cpu import dac_model_weights
+    from oracle.dac_ref import DACEncoderRef
+
+    fx = np.load(os.path.join(GOLD, "ref_dac_encode.npz"))
+    c, w = dac_model_weights(fx)
+    eng = DAC(**c, weights=w, device=DEV)
+    audio = torch.from_numpy(fx["audio"])
+    enc = eng.encoder(audio)
+    torch.cuda.synchronize()
+    assert tuple(enc.shape) == fx["enc"].shape
+    e = rel_peak(enc, fx["enc"])
+    print(f"dac encoder vs the reference run: {e:.2e} of the peak (float32 checkpoint held as an fp16 image)")
+    assert e < 2e-3, e
+    # the search on the REFERENCE's encoder output: only the quantizer differs
+    ref = DACEncoderRef(w, c["encoder_rates"], c["n_codebooks"])
+    _, _, _, _, _, wm = ref.quantize(torch.from_numpy(fx["enc"]), return_margins=True)
+    z, codes, latents, commit, cbl, gm = eng.quantizer(torch.from_numpy(fx["enc"]), return_margins=True)
+    torch.cuda.synchronize()
+    assert tuple(codes.shape) == fx["codes"].shape and codes.dtype == torch.int64 and tuple(latents.shape) == fx["latents"].shape
+    walk_frames("dac_encode", codes, torch.from_numpy(fx["codes"]), torch.minimum(gm.cpu(), wm), thr=2e-3)
+    same = (codes.cpu().numpy() == fx["codes"]).all(axis=1)            # frames whose whole chain agrees
+    assert same.mean() > 0.7, same.mean()
+    lat = latents.cpu().numpy().reshape(2, c["n_codebooks"], c["codebook_dim"], -1)
+    fl = fx["latents"].reshape(2, c["n_codebooks"], c["codebook_dim"], -1)
+    for b in range(2):
+        for t in np.nonzero(same[b])[0]:
+            assert np.abs(lat[b, :, :, t] - fl[b, :, :, t]).max() < 2e-3 * np.abs(fl).max()
+    if same.all():
+        assert rel_peak(z, fx["z"]) < 1e-5
+        assert abs(float(commit) - float(fx["commitment_loss"])) < 2e-3 * float(fx["commitment_loss"]) and float(cbl) == float(commit)
+    z2, codes2, latents2, *_ = eng.quantizer(torch.from_numpy(fx["enc"]), 2)
+    assert tuple(codes2.shape) == fx["codes_nq2"].shape and tuple(latents2.shape) == fx["latents_nq2"].shape and tuple(z2.shape) == fx["z_nq2"].shape
+    assert torch.equal(codes2.cpu(), codes.cpu()[:, :2])
+    out = eng(audio, c["sample_rate"])
+    torch.cuda.synchronize()
+    assert tuple(out["audio"].shape) == fx["call_audio"].shape and tuple(out["codes"].shape) == fx["call_codes"].shape and tuple(out["z"].shape) == fx["call_z"].shape
+    assert torch.isfinite(out["audio"]).all()
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_dac_encode_stages_and_codes_vs_oracle(exact):
+    """Published-shape strides (2 / 4 / 5 / 8: even and odd) at widths that take the wave-specialised kernel, two utterances of 1.3 s whose length is
+    not a whole number of hops: every encoder stage, then the codes of the free-running ``encode`` under the margin rule."""
+    c = dict(encoder_dim=32, encoder_rates=[2, 4, 5, 8], latent_dim=256, decoder_dim=256, decoder_rates=[8, 5, 4, 2], n_codebooks=6, codebook_size=1024,
+             codebook_dim=8, sample_rate=16000)
+    eng, ref, dec = dac_pair(c, 17, exact)
+    audio = make_audio(2, 320 * 64 + 131, 16000, seed=3)
+    zr, est = ref.encoder(audio, return_stages=True)
+    z, gst = eng.encoder(audio, return_stages=True)
+    torch.cuda.synchronize()
+    assert tuple(z.shape) == tuple(zr.shape)
+    errs = {k: rel_peak(gst[k], est[k]) for k in est}
+    print(f"dac encoder exact_fp16_weights={exact}: stage rel err { {k: f'{v:.1e}' for k, v in errs.items()} }")
+    assert max(errs.values()) < (2e-4 if exact else 2e-3), errs
+    # exact images: the free-running chain (device latents); float32 checkpoint behind an fp16 image: the search on the ORACLE's latents, so that the
+    # knife-edge threshold only has to cover the in_proj image (a latent error of 1e-3 of the peak would put a sixth of all decisions under it)
+    want = ref.quantize(zr, return_margins=True)
+    got = eng.encode(audio, return_margins=True) if exact else eng.quantizer(zr, return_margins=True)
+    torch.cuda.synchronize()
+    walk_frames("dac_encode", got[1], want[1], torch.minimum(got[5].cpu(), want[5]), thr=1e-3)
+    agree = float((got[1].cpu() == want[1]).float().mean())
+    print(f"dac encode exact_fp16_weights={exact}: {100 * agree:.1f} % of all codes equal the oracle's")
+    assert agree > 0.85, agree
+    # z_q is from_codes of the codes found: the decode side takes it unchanged
+    zq2, _, _ = eng.quantizer.from_codes(got[1])
+    assert torch.equal(zq2, got[0])
+    y = eng.decode(got[0])
+    torch.cuda.synchronize()
+    assert y.shape[0] == 2 and y.shape[2] == 1 and torch.isfinite(y).all()
+    # a batch equals its items (codes of item 1 alone)
+    one = eng.encode(audio[1:2], return_margins=True)
+    m = torch.minimum(one[5], got[5][1:2]).cpu()
+    walk_frames("dac_encode", one[1], got[1][1:2], m, thr=1e-4)
+
+
+def test_dac_encode_errors():
+    from mlx_audio_amd.codec.models.descript import DAC, make_dac_weights
+
+    c = dict(encoder_dim=16, encoder_rates=[2, 4], latent_dim=32, decoder_dim=64, decoder_rates=[4, 2], n_codebooks=2, codebook_size=64, codebook_dim=8, sample_rate=16000)
+    dec_only = DAC(**c, weights=make_dac_weights(64, [4, 2], 32, 2, 64, 8, seed=1), device=DEV)
+    with pytest.raises(ValueError, match="without encoder weights"):
+        dec_only.encode(torch.zeros(1, 1, 800))
+    with pytest.raises(ValueError, match="in_proj"):
+        dec_only.quantizer(torch.zeros(1, 32, 5))
+    eng, _, _ = dac_pair(c, 2, False)
+    with pytest.raises(ValueError, match=r"\[B, 1, samples\]"):
+        eng.encode(torch.zeros(1, 2, 800))
+    with pytest.raises(ValueError, match="fewer than one frame"):
+        eng.encode(torch.zeros(1, 1, 1))
