@@ -1,7 +1,7 @@
-"""SNAC (multi-scale neural audio codec), decode side (codes -> waveform), on MI355X: host schedule over the HIP kernels.
+"""SNAC (multi-scale neural audio codec; waveform -> codes -> waveform) on MI355X: host schedule over the HIP kernels.
 
-Mirrors ``mlx_audio/codec/models/snac/snac.py`` + ``layers.py`` + ``vq.py`` (constructor arguments, ``preprocess``, ``decode``, ``decode_stream``,
-``quantizer.from_codes``), with the reference's op-by-op graph collapsed into:
+Mirrors ``mlx_audio/codec/models/snac/snac.py`` + ``layers.py`` + ``vq.py`` (constructor arguments, ``preprocess``, ``encode``, ``decode``, ``__call__``,
+``decode_stream``, ``quantizer(z)``, ``quantizer.from_codes``), with the reference's op-by-op graph collapsed into:
   * ``ResidualVectorQuantize.from_codes`` (vq.py:116-137): ``out_proj(codebook[code])`` is folded once at load into one
     ``[n_codebooks * codebook_size, latent_dim]`` table; the coarse levels' ``repeat_interleave(stride)`` becomes an index map, so a frame is ONE
     ``embed_sum`` launch (rows summed in codebook order like the reference's running sum);
@@ -20,9 +20,19 @@ conv emits one extra sample: the reference's test pins 59 / 118 / 236 code frame
 ``attn_window_size`` = ``None`` is the 24 kHz model (the one Orpheus-style TTS uses).  The 32 / 44 kHz models' ``LocalMHA`` (windowed attention between the
 input convs and the first decoder block, attention.py:5-53) is LayerNorm + two GEMMs around one attention launch whose batch items are the windows -- built
 to what the module MEANS: the reference's own transcription expects [B, C, T] data but receives channels-last [B, T, C] and raises (recorded in
-tests/golden/ref_snac_local_mha_probe.json), so this path has no reference output and is held to the oracle's restatement only (PARITY UNPINNED).  The encoder /
-quantiser-search half (``encode``, ``__call__``) is outside the decode hot path and raises.  Weights: float32 checkpoints are held as fp16 MFMA
-images, activations split fp16 hi + lo (``precision = 4``); deviation from the float32 oracle asserted in ``tests/test_snac_gpu.py``.
+tests/golden/ref_snac_local_mha_probe.json), so this path has no reference output and is held to the oracle's restatement only (PARITY UNPINNED).
+
+Encode side (round 5; layers.py:132-156, 236-253, vq.py:10-113, snac.py:88-102), from the same kernels:
+  * ``Encoder``: the 1 -> d_model k7 conv runs FLATTENED over the contiguous samples; an ``EncoderBlock`` is its three ``ResidualUnit``s (depthwise k7
+    on ``mi355_dwconv`` with the Snake prologue, or dense) updating the block's activation in place inside a zeroed staging buffer, then the strided
+    ``WNConv1d(K = 2 s, stride s, padding ceil(s / 2))`` as a TWO-tap conv over that buffer's rows regrouped ``[rows / s, s * C]`` (Snake(0) = 0 keeps
+    the padding rows zero through the prologue); [LocalMHA]; the final k7 conv (depthwise or dense, no Snake in front);
+  * ``ResidualVectorQuantize.__call__``: per level the ``stride``-frame average pool and ``in_proj`` are ONE 1-tap conv over rows regrouped
+    ``[T / s, s * D]`` (weights ``W / s`` tiled s times: the same linear map), then the nearest L2-normalised codeword (``mi355_rvq_encode``), then the
+    residual update ``residual -= repeat_interleave(out_proj(codebook[idx]), s)`` as one ``embed_sum`` over the NEGATED folded table with the
+    level's ids repeated s times; ``z_q`` is ``from_codes`` of the result.
+Weights: float32 checkpoints are held as fp16 MFMA images, activations split fp16 hi + lo (``precision = 4``); deviation from the float32 oracle
+asserted in ``tests/test_snac_gpu.py`` / ``tests/test_codec_encode_gpu.py``.
 """
 from __future__ import annotations
 
@@ -100,6 +110,58 @@ def make_snac_weights(latent_dim: int, decoder_dim: int, decoder_rates: List[int
     return w
 
 
+def make_snac_encoder_weights(encoder_dim: int, encoder_rates: List[int], latent_dim: int, vq_strides: List[int], codebook_dim: int,
+                              depthwise: bool = True, seed: int = 0, attn: bool = False) -> Dict[str, torch.Tensor]:
+    """Random float32 ENCODE-side parameters (``encoder.*`` and every quantizer's ``in_proj``; reference module paths, MLX layouts): merge with
+    ``make_snac_weights`` for a whole model."""
+    g = torch.Generator().manual_seed(seed + 104729)
+    w: Dict[str, torch.Tensor] = {}
+
+    def conv(name, cout, k, cin_g, fan_in, gain=1.0):
+        v0 = (torch.rand(cout, k, cin_g, generator=g) * 2 - 1) * math.sqrt(1 / fan_in) * gain
+        gw = torch.sqrt((v0 ** 2).sum(dim=(1, 2), keepdim=True))
+        w[name + ".weight_g"] = gw * (1.0 + 0.1 * torch.randn(gw.shape, generator=g))
+        w[name + ".weight_v"] = v0 / (gw + 1e-12)
+        w[name + ".bias"] = 0.02 * torch.randn(cout, generator=g)
+
+    def alpha(name, c):
+        w[name + ".alpha"] = (1.0 + 0.3 * torch.randn(1, c, 1, generator=g)).abs() + 0.05
+
+    e = "encoder.block.layers."
+    conv(e + "0", encoder_dim, 7, 1, 7, gain=2.5)
+    d = encoder_dim
+    for i, s in enumerate(encoder_rates):
+        d *= 2
+        p = f"{e}{i + 1}.block.layers."
+        for j in range(3):
+            q = p + f"{j}.block.layers."
+            alpha(q + "0", d // 2)
+            if depthwise:
+                conv(q + "1", d // 2, 7, 1, 7, gain=1.2)
+            else:
+                conv(q + "1", d // 2, 7, d // 2, 7 * (d // 2), gain=1.2)
+            alpha(q + "2", d // 2)
+            conv(q + "3", d // 2, 1, d // 2, d // 2, gain=0.5)
+        alpha(p + "3", d // 2)
+        conv(p + "4", d, 2 * s, d // 2, 2 * s * (d // 2), gain=1.2)
+    nxt = len(encoder_rates) + 1
+    if attn:
+        a = f"{e}{nxt}."
+        w[a + "norm.weight"] = 1.0 + 0.1 * torch.randn(d, generator=g)
+        w[a + "norm.bias"] = 0.05 * torch.randn(d, generator=g)
+        w[a + "to_qkv.weight"] = (torch.rand(3 * d, d, generator=g) * 2 - 1) * math.sqrt(3.0 / d)
+        w[a + "to_out.weight"] = (torch.rand(d, d, generator=g) * 2 - 1) * math.sqrt(1.5 / d)
+        nxt += 1
+    if depthwise:
+        conv(f"{e}{nxt}", d, 7, 1, 7, gain=1.7)
+    else:
+        conv(f"{e}{nxt}", d, 7, d, 7 * d, gain=1.7)
+    assert d == latent_dim, (d, latent_dim)
+    for i in range(len(vq_strides)):
+        conv(f"quantizer.quantizers.{i}.in_proj", codebook_dim, 1, latent_dim, latent_dim, gain=1.5)
+    return w
+
+
 class _Snake:
     """alpha and 1 / (alpha + 1e-9) (layers.py:123-126), padded to a multiple of 32 channels (conv_gemm / dwconv prologue operands)."""
 
@@ -135,6 +197,52 @@ class _Quantizer:
         self.table = torch.cat(tabs, 0).contiguous().to(device)
         self.offs = torch.tensor([i * codebook_size for i in range(self.n_codebooks)], dtype=torch.int32, device=device)
         self.latent_dim = self.table.shape[1]
+        # encode side (present when the checkpoint carries the in_proj convs)
+        self.in_proj = None
+        if all(f"quantizer.quantizers.{i}.in_proj.weight_v" in w for i in range(self.n_codebooks)):
+            self.in_proj, self.search = [], []
+            for i, s in enumerate(self.vq_strides):
+                p = f"quantizer.quantizers.{i}.in_proj"
+                wi = _wn(w, p)                                    # [d, 1, D]
+                # avg_pool(stride s) then in_proj = one tap over rows regrouped s at a time: weights W / s, tiled s times (vq.py:25-32)
+                self.in_proj.append(ops.pack_conv((wi / s).repeat(1, 1, s).contiguous() if s > 1 else wi, w.get(p + ".bias"), device, f16=True))
+                cb = w[f"quantizer.quantizers.{i}.codebook.weight"].float()
+                cn = cb / torch.clamp(torch.sqrt((cb * cb).sum(1, keepdim=True)), min=1e-12)      # normalize() of vq.py:140-143
+                t = cn[None].contiguous()
+                self.search.append((t.to(device), t.transpose(1, 2).contiguous().to(device), ((t * t).sum(-1) / 2).contiguous().to(device)))
+            self.codebook_dim = self.search[0][0].shape[2]
+            self.neg_table = (-self.table).contiguous()
+
+    def __call__(self, z, return_margins: bool = False):
+        """``ResidualVectorQuantize.__call__`` (vq.py:102-113): z [B, D, T] -> (z_q [B, D, T], codes: list of int64 [B, T / stride_i]).
+        ``return_margins`` appends the cosine gap between the best and the second-best codeword of every decision (list of [B, T / stride_i])."""
+        if self.in_proj is None:
+            raise ValueError("this SNAC was loaded without quantizer in_proj weights (decode-only checkpoint): the codebook search cannot run")
+        z = torch.as_tensor(z, dtype=torch.float32).to(self.device).transpose(1, 2)   # channels-last rows for the kernels
+        B, T, D = z.shape
+        if D != self.latent_dim:
+            raise ValueError(f"quantizer: z must be [B, {self.latent_dim}, T], got {tuple(z.transpose(1, 2).shape)}")
+        for s in self.vq_strides:
+            if T % s:
+                raise ValueError(f"quantizer: {T} frames are not a whole number of stride-{s} groups (SNAC.preprocess pads the audio so that they are)")
+        residual = z.contiguous().clone()
+        d = self.codebook_dim
+        codes, margins = [], []
+        for i, s in enumerate(self.vq_strides):
+            Ts = T // s
+            ze = torch.empty((B, Ts, d), dtype=torch.float32, device=self.device)
+            ops.conv_gemm(residual.view(B, Ts, s * D), self.in_proj[i], ze, precision=4)
+            rows = ze.view(B * Ts, d)
+            c, m = ops.rvq_encode(rows, *self.search[i], margins=True)
+            if return_margins:
+                margins.append(m.view(B, Ts) / torch.clamp(torch.sqrt((rows * rows).sum(1)).view(B, Ts), min=1e-30))
+            c = c.view(B, Ts)
+            codes.append(c.to(torch.int64))
+            if i + 1 < self.n_codebooks:
+                ids = (torch.repeat_interleave(c, s, dim=1) if s > 1 else c).reshape(B, T, 1).contiguous()
+                ops.embed_sum(self.neg_table, ids, residual, slot_offset=self.offs[i:i + 1], add=residual)
+        z_q = self.from_codes(codes)
+        return (z_q, codes, margins) if return_margins else (z_q, codes)
 
     def from_codes(self, codes: List[torch.Tensor]) -> torch.Tensor:
         """codes[i] int [B, T / stride_i] -> z_q [B, D, T]."""
@@ -177,7 +285,7 @@ class SNAC:
     # ------------------------------------------------------------------ load
     def load_weights(self, weights: Dict[str, torch.Tensor]):
         dev = self.device
-        w = {k: torch.as_tensor(v).detach().float().cpu() for k, v in weights.items() if k.startswith(("decoder.", "quantizer."))}
+        w = {k: torch.as_tensor(v).detach().float().cpu() for k, v in weights.items() if k.startswith(("decoder.", "quantizer.", "encoder."))}
 
         def conv(name) -> PackedConv:
             return ops.pack_conv(_wn(w, name), w.get(name + ".bias"), dev, f16=True)
@@ -224,6 +332,39 @@ class SNAC:
         n = nxt + len(self.decoder_rates)
         self.out_snake = _Snake(w[f"{m}{n}.alpha"], dev)
         self.conv_out = conv(f"{m}{n + 1}")
+        self.enc = None
+        if "encoder.block.layers.0.weight_v" in w:   # the encode half (layers.py:132-156)
+            e = "encoder.block.layers."
+            w0 = _wn(w, e + "0")                      # [d, 7, 1] -> one tap of 7 "channels" (flattened conv)
+            stem = ops.pack_conv(w0.reshape(w0.shape[0], 1, w0.shape[1]).contiguous(), w.get(e + "0.bias"), dev, f16=True)
+            blocks = []
+            for i, s in enumerate(self.encoder_rates):
+                p = f"{e}{i + 1}.block.layers."
+                units = []
+                for j, d in enumerate((1, 3, 9)):
+                    q = p + f"{j}.block.layers."
+                    units.append(dict(dil=d, s1=_Snake(w[q + "0.alpha"], dev), c1=mid(q + "1"), s2=_Snake(w[q + "2.alpha"], dev), c2=conv(q + "3")))
+                wd = _wn(w, p + "4")                  # [cout, 2 s, cin]: tap j s + r -> (tap j, channel r cin + c)
+                cout, k, cin = wd.shape
+                if k != 2 * s:
+                    raise ValueError(f"encoder block {i}: {k} taps for stride {s} (the reference builds kernel_size = 2 * stride)")
+                blocks.append(dict(stride=s, cin=cin, units=units, snake=_Snake(w[p + "3.alpha"].reshape(-1).repeat(s), dev),
+                                   down=ops.pack_conv(wd.reshape(cout, 2, s * cin).contiguous(), w.get(p + "4.bias"), dev, f16=True)))
+            nxt = len(self.encoder_rates) + 1
+            enc_attn = None
+            if self.attn_window_size is not None:
+                a = f"{e}{nxt}."
+                dh, dm = 64, self.latent_dim
+                if dm % dh:
+                    raise ValueError(f"LocalMHA needs the encoder width ({dm}) to be a multiple of its head size 64")
+                inv = 1.0 / (10000 ** (torch.arange(0, dh, 2, dtype=torch.float32) / dh))
+                ang = torch.arange(self.attn_window_size, dtype=torch.float32)[:, None] * inv[None, :]
+                enc_attn = dict(nw=w[a + "norm.weight"].to(dev), nb=w[a + "norm.bias"].to(dev), dh=dh, heads=dm // dh,
+                                qkv=ops.pack_conv(w[a + "to_qkv.weight"][:, None, :], None, dev, f16=True),
+                                out=ops.pack_conv(w[a + "to_out.weight"][:, None, :], None, dev, f16=True),
+                                cos=torch.cos(ang).contiguous().to(dev), sin=torch.sin(ang).contiguous().to(dev))
+                nxt += 1
+            self.enc = dict(stem=stem, k0=w0.shape[1], dim=w0.shape[0], blocks=blocks, attn=enc_attn, out=mid(f"{e}{nxt}"))
         return self
 
     # ------------------------------------------------------------------ reference surface
@@ -238,11 +379,74 @@ class SNAC:
         right_pad = math.ceil(length / pad_to) * pad_to - length
         return torch.nn.functional.pad(audio_data, (0, right_pad))
 
-    def encode(self, audio_data):
-        raise NotImplementedError("SNAC.encode (encoder + codebook search) is outside the decode hot path of this build (SURVEY section 8(f).2)")
+    def encoder(self, audio_data, return_stages: bool = False):
+        """``Encoder.__call__`` on ``audio_data.moveaxis(1, 2)`` (layers.py:132-156): audio [B, 1, S] -> z [B, latent_dim, T]."""
+        if self.enc is None:
+            raise ValueError("this SNAC was loaded without encoder weights (decode-only checkpoint)")
+        e = self.enc
+        x0 = torch.as_tensor(audio_data, dtype=torch.float32).to(self.device)
+        if x0.dim() != 3 or x0.shape[1] != 1:
+            raise ValueError(f"encoder: audio_data must be [B, 1, samples], got {tuple(x0.shape)}")
+        x0 = x0.reshape(x0.shape[0], -1).contiguous()
+        B, L = x0.shape
+        st = {}
 
-    def __call__(self, audio_data):
-        raise NotImplementedError("SNAC.__call__ runs the encoder, which this build does not contain; use decode(codes)")
+        def staged(L, C, s):
+            """Zeroed buffer whose rows [p, p + L) hold a block's activation; regrouped s rows at a time it is the input of the block's strided conv."""
+            p = math.ceil(s / 2)
+            if L + 2 * p < 2 * s:
+                raise ValueError(f"encoder: {L} rows are fewer than one frame of the stride-{s} conv")
+            Lout = (L + 2 * p - 2 * s) // s + 1
+            rows = round_up(max((Lout + 1) * s, p + L), s)
+            buf = torch.zeros((B, rows, C), dtype=torch.float32, device=self.device)
+            return buf, buf[:, p:p + L], Lout
+
+        blocks = e["blocks"]
+        buf, y, Lout = staged(L, e["dim"], blocks[0]["stride"])
+        ops.conv_gemm(x0[:, :, None], e["stem"], y, lout=L, flat=dict(ldx=1, x_off=-(e["k0"] // 2), channels=1), precision=4)
+        for bi, blk in enumerate(blocks):
+            s, C = blk["stride"], blk["cin"]
+            tmp = self._f(B, L, C)
+            for u in blk["units"]:
+                self._mid(y, u["s1"], u["c1"], tmp, u["dil"])
+                self._conv(tmp, u["s2"], u["c2"], y, res=y)
+            if return_stages:
+                st[f"units{bi}"] = y.clone()
+            cout = blk["down"].cout
+            if bi + 1 < len(blocks):
+                nbuf, ny, nLout = staged(Lout, cout, blocks[bi + 1]["stride"])
+            else:
+                nbuf, ny, nLout = None, self._f(B, Lout, cout), 0
+            sn = blk["snake"]
+            ops.conv_gemm(buf.view(B, buf.shape[1] // s, s * C), blk["down"], ny, pad=0, lout=Lout, pre_act=ACT_SNAKE, pre_alpha=sn.alpha,
+                          pre_inv_beta=sn.inv_conv, precision=4)
+            buf, y, L, Lout = nbuf, ny, Lout, nLout
+            if return_stages:
+                st[f"block{bi}"] = y.clone()
+        if e["attn"] is not None:
+            y = self._local_mha(y, e["attn"])
+            st["attn"] = y
+        z = self._f(B, L, self.latent_dim)
+        if self.depthwise:
+            ops.dwconv(y, e["out"][0], e["out"][1], z, pad=3)
+        else:
+            self._conv(y, None, e["out"], z)
+        st["latent"] = z
+        return (z.transpose(1, 2), st) if return_stages else z.transpose(1, 2)
+
+    def encode(self, audio_data, return_margins: bool = False):
+        """snac.py:96-102: audio [B, 1, S] -> codes (list of int64 [B, T / vq_strides[i]]); the audio is right-padded first (``preprocess``)."""
+        out = self.quantizer(self.encoder(self.preprocess(audio_data)), return_margins=return_margins)
+        return (out[1], out[2]) if return_margins else out[1]
+
+    def __call__(self, audio_data, noises: Optional[List[torch.Tensor]] = None):
+        """snac.py:88-94: (audio_hat, codes).  The reference slices the LAST axis of the channels-last decoder output (``audio_hat[..., :length]``:
+        one channel, so a no-op for length >= 1) -- mirrored as is, like ``decode_stream``."""
+        audio_data = torch.as_tensor(audio_data, dtype=torch.float32)
+        length = audio_data.shape[-1]
+        z_q, codes = self.quantizer(self.encoder(self.preprocess(audio_data)))
+        audio_hat = self.decode_latents(z_q, noises=noises)
+        return audio_hat[..., :length], codes
 
     def _f(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.device)
@@ -276,7 +480,7 @@ class SNAC:
         self._conv(x, None, self.conv_in, h)
         st["conv_in"] = h
         if self.attn is not None:
-            h = self._local_mha(h)
+            h = self._local_mha(h, self.attn)
             st["attn"] = h
         for bi, blk in enumerate(self.blocks):
             s, cout, taps = blk["stride"], blk["cout"], blk["up"].k
@@ -304,11 +508,11 @@ class SNAC:
         self._conv(h, self.out_snake, self.conv_out, out, post_act=ACT_TANH)
         return (out, st) if return_stages else out
 
-    def _local_mha(self, h: torch.Tensor) -> torch.Tensor:
+    def _local_mha(self, h: torch.Tensor, a: dict) -> torch.Tensor:
         """``LocalMHA.__call__`` (attention.py:19-53) on channels-last [B, T, C]: LayerNorm -> to_qkv -> heads of 64 channels, attention INSIDE
         windows of ``attn_window_size`` positions (rotate-half rotary embedding with the position inside the window, no mask) -> to_out + x.  The
         windows are the batch items of one attention launch (a window's rows are contiguous: [B, T, 3C] viewed as [B * windows, window, 3C])."""
-        a, ws = self.attn, self.attn_window_size
+        ws = self.attn_window_size
         B, T, C = h.shape
         if T % ws:
             raise ValueError(f"LocalMHA: {T} positions are not a whole number of windows of {ws} (the reference's reshape fails the same way)")

@@ -1,4 +1,4 @@
-"""PyTorch-CPU restatement of the SNAC decode path (TEST ORACLE, not product).
+"""PyTorch-CPU restatement of the SNAC decode and encode paths (TEST ORACLE, not product).
 
 Follows /root/reference/mlx_audio/codec/models/snac statement by statement:
   * ``layers.py:9-60``      WNConv1d: weight = g * v / ||v|| (norm over all axes but 0), ``mx.conv1d(x, w, stride, padding, dilation, groups)``
@@ -18,6 +18,16 @@ Follows /root/reference/mlx_audio/codec/models/snac statement by statement:
   * ``layers.py:270-295``   DecoderBlock: snake, convT K = 2 s (padding ceil(s / 2)), [NoiseBlock], three units with dilations 1 / 3 / 9
   * ``vq.py:102-137``       ResidualVectorQuantize.from_codes: codebook lookup, out_proj (1x1 WNConv), repeat_interleave(stride), running sum
   * ``snac.py:104-107``     SNAC.decode(codes) = decoder(from_codes(codes).moveaxis(1, 2))
+
+Encode side (round 5):
+  * ``layers.py:132-156``   Encoder: conv k7 (1 -> d_model), EncoderBlocks (d_model doubles per block), [LocalMHA], conv k7 (groups = d_model when depthwise;
+                            NO snake in front of it)
+  * ``layers.py:236-253``   EncoderBlock: three units (dilations 1 / 3 / 9, groups = channels when depthwise) on the INPUT width, snake,
+                            WNConv1d(K = 2 s, stride s, padding ceil(s / 2))
+  * ``vq.py:10-78``         VectorQuantize: average pool over ``stride`` frames (a grouped conv with a 1 / stride kernel), in_proj, L2-normalised nearest
+                            codeword (``(-dist).argmax``), out_proj of the un-normalised codeword, repeat_interleave(stride)
+  * ``vq.py:102-113``       ResidualVectorQuantize.__call__: the residual loop; ``snac.py:96-102`` encode = preprocess (right pad) -> encoder -> codes
+pinned the same way: ``SNAC.encode`` / ``SNAC.__call__`` of the reference's own modules on a seeded checkpoint (``ref_snac_encode.npz``; every code equal).
 
 Parameter names are the reference's module paths (``decoder.model.layers.N...``, ``quantizer.quantizers.N.codebook.weight`` ...), layouts MLX's
 (conv ``[out, K, in / groups]``, transposed conv stored ``[in, K, out]``).  Arithmetic float32 (float64 on request) on the parameters as given.
@@ -145,3 +155,90 @@ class SNACDecoderRef:
         x = snake(x, self.w[f"{m}{n}.alpha"])
         x = torch.tanh(self._conv(x, f"{m}{n + 1}", padding=3))
         return (x, st) if return_stages else x
+
+
+class SNACEncoderRef:
+    """``SNAC.encode`` (snac.py:96-102): preprocess -> ``Encoder`` -> ``ResidualVectorQuantize.__call__``."""
+
+    def __init__(self, weights: Dict[str, Tensor], encoder_rates: List[int], vq_strides: List[int], depthwise: bool = True, dtype=torch.float32,
+                 attn_window_size: Optional[int] = None):
+        self.w = {k: v.to(dtype) if v.is_floating_point() else v for k, v in weights.items()}
+        self.rates, self.vq_strides, self.depthwise, self.dtype, self.attn_window_size = list(encoder_rates), list(vq_strides), depthwise, dtype, attn_window_size
+        self._dec = SNACDecoderRef(weights, [], vq_strides, noise=False, depthwise=depthwise, dtype=dtype, attn_window_size=attn_window_size)
+
+    def _conv(self, x: Tensor, name: str, dilation: int = 1, padding: int = 0, groups: int = 1, stride: int = 1) -> Tensor:
+        w = wn_weight(self.w[name + ".weight_g"], self.w[name + ".weight_v"])  # [out, K, in / groups]
+        return F.conv1d(x.transpose(1, 2), w.permute(0, 2, 1), self.w.get(name + ".bias"), stride=stride, padding=padding, dilation=dilation,
+                        groups=groups).transpose(1, 2)
+
+    def preprocess(self, audio: Tensor) -> Tensor:
+        """snac.py:67-86 (the window size joins the least common multiple when attention is on)."""
+        lcm = self.vq_strides[0]
+        for s in self.vq_strides[1:]:
+            lcm = abs(lcm * s) // math.gcd(lcm, s)
+        if self.attn_window_size:
+            lcm = abs(lcm * self.attn_window_size) // math.gcd(lcm, self.attn_window_size)
+        pad_to = int(torch.tensor(self.rates).prod()) * lcm
+        return F.pad(audio, (0, math.ceil(audio.shape[-1] / pad_to) * pad_to - audio.shape[-1]))
+
+    def encoder(self, audio: Tensor, return_stages: bool = False):
+        """audio [B, 1, S] -> z [B, D, T]."""
+        x = audio.to(self.dtype).transpose(1, 2)
+        st = {}
+        e = "encoder.block.layers."
+        x = self._conv(x, e + "0", padding=3)
+        for i, s in enumerate(self.rates):
+            p = f"{e}{i + 1}.block.layers."
+            C = x.shape[-1]
+            for j, d in enumerate((1, 3, 9)):
+                q = p + f"{j}.block.layers."
+                y = snake(x, self.w[q + "0.alpha"])
+                y = self._conv(y, q + "1", dilation=d, padding=3 * d, groups=C if self.depthwise else 1)
+                y = snake(y, self.w[q + "2.alpha"])
+                y = self._conv(y, q + "3")
+                x = x + y
+            st[f"units{i}"] = x
+            x = snake(x, self.w[p + "3.alpha"])
+            x = self._conv(x, p + "4", stride=s, padding=math.ceil(s / 2))
+            st[f"block{i}"] = x
+        nxt = len(self.rates) + 1
+        if self.attn_window_size is not None:
+            x = self._dec.local_mha(x, f"{e}{nxt}.")
+            st["attn"] = x
+            nxt += 1
+        x = self._conv(x, f"{e}{nxt}", padding=3, groups=x.shape[-1] if self.depthwise else 1)
+        st["latent"] = x
+        return (x.transpose(1, 2), st) if return_stages else x.transpose(1, 2)
+
+    def quantize(self, z: Tensor, return_margins: bool = False):
+        """z [B, D, T] -> (z_q [B, D, T], codes list [B, T / stride_i]) (+ the cosine top-2 gap per decision)."""
+        residual = z.to(self.dtype)
+        z_q = 0
+        codes, margins = [], []
+        for i, s in enumerate(self.vq_strides):
+            p = f"quantizer.quantizers.{i}."
+            x = residual.transpose(1, 2)                                              # [B, T, D]
+            if s > 1:
+                D = x.shape[2]
+                x = F.conv1d(x.transpose(1, 2), torch.ones((D, 1, s), dtype=self.dtype) / s, stride=s, groups=D).transpose(1, 2)
+            z_e = self._conv(x, p + "in_proj").transpose(1, 2)                        # [B, d, T / s]
+            b, d, t = z_e.shape
+            enc = z_e.permute(0, 2, 1).reshape(b * t, d)
+            cb = self.w[p + "codebook.weight"]
+            en = enc / torch.clamp(torch.sqrt((enc.abs() ** 2).sum(1, keepdim=True)), min=1e-12)
+            cn = cb / torch.clamp(torch.sqrt((cb.abs() ** 2).sum(1, keepdim=True)), min=1e-12)
+            dist = (en ** 2).sum(1, keepdim=True) - 2 * en @ cn.t() + (cn ** 2).sum(1, keepdim=True).t()
+            top = torch.topk(-dist, 2, dim=1).values
+            idx = (-dist).argmax(1).reshape(b, t)
+            margins.append(((top[:, 0] - top[:, 1]) / 2).reshape(b, t))
+            zq_lat = cb[idx].transpose(1, 2)
+            z_q_i = self._conv((z_e + (zq_lat - z_e)).transpose(1, 2), p + "out_proj").transpose(1, 2)
+            if s > 1:
+                z_q_i = torch.repeat_interleave(z_q_i, s, dim=2)
+            z_q = z_q + z_q_i
+            residual = residual - z_q_i
+            codes.append(idx)
+        return (z_q, codes, margins) if return_margins else (z_q, codes)
+
+    def encode(self, audio: Tensor):
+        return self.quantize(self.encoder(self.preprocess(audio)))[1]

@@ -951,6 +951,53 @@ def run_snac(seed_w, seed_codes, n_frames, attn_window_size=None):
     return out, cfg
 
 
+SNAC_ENC_TINY = dict(sampling_rate=24000, encoder_dim=8, encoder_rates=[2, 3, 8], decoder_dim=64, decoder_rates=[8, 3, 2], attn_window_size=None, codebook_size=64,
+                     codebook_dim=8, vq_strides=[4, 2, 1], noise=True, depthwise=True)
+
+
+def run_snac_encode(seed_w, seed_audio, n_samples, depthwise=True):
+    """The reference's ``SNAC.encode`` and ``SNAC.__call__`` (snac.py:88-102: preprocess -> Encoder -> ResidualVectorQuantize.__call__, vq.py:10-113) on a
+    seeded checkpoint: even and odd strides, multi-scale levels (strides 4 / 2 / 1), a length that needs the right padding; depthwise or dense k7 convs."""
+    from mlx_audio_amd.codec.models.snac import make_snac_encoder_weights, make_snac_weights
+
+    _codec_pkgs()
+    base = "mlx_audio.codec.models.snac"
+    _pkg(base, f"{REF}/codec/models/snac")
+    _load(f"{base}.attention", f"{REF}/codec/models/snac/attention.py")
+    _load(f"{base}.layers", f"{REF}/codec/models/snac/layers.py")
+    _load(f"{base}.vq", f"{REF}/codec/models/snac/vq.py")
+    rsn = _load(f"{base}.snac", f"{REF}/codec/models/snac/snac.py")
+    cfg = dict(SNAC_ENC_TINY, depthwise=depthwise)
+    latent = cfg["encoder_dim"] * 2 ** len(cfg["encoder_rates"])
+    w = make_snac_weights(latent, cfg["decoder_dim"], cfg["decoder_rates"], cfg["vq_strides"], cfg["codebook_size"], cfg["codebook_dim"], True, depthwise, seed=seed_w)
+    w.update(make_snac_encoder_weights(cfg["encoder_dim"], cfg["encoder_rates"], latent, cfg["vq_strides"], cfg["codebook_dim"], depthwise, seed=seed_w))
+    model = rsn.SNAC(**cfg)
+    model.load_weights([(k, v.numpy()) for k, v in w.items()])
+    missing, unexpected, mism = model._load_report
+    missing = [m for m in missing if ".rel_pos.inv_freq" not in m]
+    assert not unexpected and not missing and not mism, (missing[:8], unexpected[:8], mism[:4])
+    model.eval()
+    g = np.random.default_rng(seed_audio)
+    t = np.arange(n_samples) / cfg["sampling_rate"]
+    audio = np.stack([0.5 * np.sin(2 * np.pi * (200 + 110 * b) * t) * (0.6 + 0.4 * np.sin(2 * np.pi * 2.5 * t)) + 0.15 * g.standard_normal(n_samples) for b in range(2)])
+    audio = audio[:, None, :].astype(np.float32)
+    padded = model.preprocess(mx.array(audio))
+    z = model.encoder(padded.moveaxis(1, 2))
+    z_q, codes = model.quantizer(z)
+    codes2 = model.encode(mx.array(audio))
+    assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(codes, codes2))
+    # SNAC.__call__ (snac.py:88-94) hands the quantizer's [B, D, T] output to the channels-last decoder WITHOUT the moveaxis that decode() applies
+    # (snac.py:106): it raises unless T == D.  Recorded, not pinned.
+    try:
+        model(mx.array(audio))
+        call_error = ""
+    except Exception as e:  # noqa: BLE001
+        call_error = f"{type(e).__name__}: {str(e)[:160]}"
+    out = dict(seed_w=seed_w, config=json.dumps(cfg), audio=audio, padded_len=np.int32(padded.shape[-1]), z=_np(z), z_q=_np(z_q), call_error=call_error)
+    out.update({f"codes{i}": np.asarray(c).astype(np.int32) for i, c in enumerate(codes)})
+    return out
+
+
 def run_snac_local_mha_probe():
     """The reference's SNAC with ``attn_window_size`` set (the 32 / 44 kHz models) CANNOT run its decoder: ``LocalMHA.__call__`` (attention.py:19-23) is a
     line-by-line transcription of the PyTorch module for [B, C, T] data (``B, C, T = x.shape``, ``x.moveaxis(1, 2)``) but the MLX decoder hands it
@@ -1784,6 +1831,10 @@ def main():
         efx = run_dac_encode(seed_w=31, seed_audio=4, n_samples=320 * 24 + 77)
         np.savez_compressed(os.path.join(HERE, "ref_dac_encode.npz"), **efx)
         print("dac encode:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in efx.items() if a != "config"}, float(efx["commitment_loss"]))
+        for dwise in (True, False):
+            sfx = run_snac_encode(seed_w=33, seed_audio=6, n_samples=48 * 4 * 9 + 101, depthwise=dwise)
+            np.savez_compressed(os.path.join(HERE, f"ref_snac_encode_{'dw' if dwise else 'dense'}.npz"), **sfx)
+            print("snac encode:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in sfx.items() if a != "config"})
         return
     if "qwen3_clone" in sys.argv[1:]:   # only the voice-cloning fixtures (round 3)
         sfx = run_qwen3_speaker_encoder(seed_w=13, seed_mel=5, frames=37)

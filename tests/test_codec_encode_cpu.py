@@ -6,6 +6,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -88,3 +89,70 @@ def test_dac_encode_host_schedule_dry_run():
         assert out["audio"].shape == fx["call_audio"].shape and rel_max(out["audio"].numpy(), fx["call_audio"]) < 2e-5
     import mlx_audio_amd.ops as real_ops
     assert real_ops.conv_gemm.__module__ == "mlx_audio_amd.ops"   # the emulation is gone after the block
+
+
+def snac_model_weights(fx):
+    from mlx_audio_amd.codec.models.snac import make_snac_encoder_weights, make_snac_weights
+
+    c = json.loads(str(fx["config"]))
+    latent = c["encoder_dim"] * 2 ** len(c["encoder_rates"])
+    w = make_snac_weights(latent, c["decoder_dim"], c["decoder_rates"], c["vq_strides"], c["codebook_size"], c["codebook_dim"], True, c["depthwise"], seed=int(fx["seed_w"]))
+    w.update(make_snac_encoder_weights(c["encoder_dim"], c["encoder_rates"], latent, c["vq_strides"], c["codebook_dim"], c["depthwise"], seed=int(fx["seed_w"])))
+    return c, w
+
+
+def test_snac_encode_oracle_reproduces_the_reference_modules():
+    """``SNAC.encode`` (snac.py:96-102): padded length, encoder output, every code of the three levels (strides 4 / 2 / 1), z_q -- depthwise and dense."""
+    from oracle.snac_ref import SNACEncoderRef
+
+    for kind in ("dw", "dense"):
+        fx = np.load(os.path.join(GOLD, f"ref_snac_encode_{kind}.npz"))
+        c, w = snac_model_weights(fx)
+        ref = SNACEncoderRef(w, c["encoder_rates"], c["vq_strides"], depthwise=c["depthwise"])
+        audio = torch.from_numpy(fx["audio"])
+        padded = ref.preprocess(audio)
+        assert padded.shape[-1] == int(fx["padded_len"])
+        z = ref.encoder(padded)
+        assert tuple(z.shape) == fx["z"].shape and rel_max(z.numpy(), fx["z"]) < 2e-5
+        z_q, codes, margins = ref.quantize(z, return_margins=True)
+        for i, cd in enumerate(codes):
+            assert np.array_equal(cd.numpy(), fx[f"codes{i}"]), (kind, i)
+            assert tuple(margins[i].shape) == tuple(cd.shape) and float(margins[i].min()) >= 0.0
+        assert rel_max(z_q.numpy(), fx["z_q"]) < 2e-5
+        assert all(np.array_equal(a.numpy(), fx[f"codes{i}"]) for i, a in enumerate(ref.encode(audio)))
+        assert "expected input" in str(fx["call_error"])   # the reference's SNAC.__call__ cannot run (decoder handed [B, D, T]): nothing to pin there
+
+
+def test_snac_encode_host_schedule_dry_run():
+    """The product's SNAC encode schedule (staging buffers, depthwise / dense units, strided convs over regrouped rows, average pool folded into the
+    in_proj tap, negated-table residual update with repeated ids) over tests/_ops_emu.py, against the reference's own run."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _ops_emu
+    from mlx_audio_amd.codec.models.snac import SNAC
+    from oracle.snac_ref import SNACEncoderRef
+
+    for kind in ("dw", "dense"):
+        fx = np.load(os.path.join(GOLD, f"ref_snac_encode_{kind}.npz"))
+        c, w = snac_model_weights(fx)
+        audio = torch.from_numpy(fx["audio"])
+        with _ops_emu.patched():
+            eng = SNAC(**c, weights=w, device="cpu")
+            padded = eng.preprocess(audio)
+            assert padded.shape[-1] == int(fx["padded_len"])
+            z, st = eng.encoder(padded, return_stages=True)
+            _, est = SNACEncoderRef(w, c["encoder_rates"], c["vq_strides"], depthwise=c["depthwise"]).encoder(padded, return_stages=True)
+            for k in est:
+                assert rel_max(st[k].numpy(), est[k].numpy()) < 1e-5, (kind, k)
+            assert rel_max(z.numpy(), fx["z"]) < 1e-5
+            z_q, codes, margins = eng.quantizer(torch.from_numpy(fx["z"]), return_margins=True)
+            for i, cd in enumerate(codes):
+                assert np.array_equal(cd.numpy(), fx[f"codes{i}"]) and cd.dtype == torch.int64, (kind, i)
+                assert float(margins[i].min()) > 0
+            assert rel_max(z_q.numpy(), fx["z_q"]) < 1e-5
+            assert all(np.array_equal(a.numpy(), fx[f"codes{i}"]) for i, a in enumerate(eng.encode(audio)))
+            g = torch.Generator().manual_seed(1)
+            nz = [torch.randn(2, 1, c["decoder_dim"] // 2 ** (i + 1), generator=g) for i in range(len(c["decoder_rates"]))]
+            hat, codes2 = eng(audio, noises=nz)
+            assert hat.shape[0] == 2 and hat.shape[2] == 1 and torch.isfinite(hat).all() and all(torch.equal(a, b) for a, b in zip(codes, codes2))
+            with pytest.raises(ValueError, match="whole number of stride"):
+                eng.quantizer(torch.zeros(1, z.shape[1], 7))

@@ -159,3 +159,98 @@ def test_dac_encode_errors():
         eng.encode(torch.zeros(1, 2, 800))
     with pytest.raises(ValueError, match="fewer than one frame"):
         eng.encode(torch.zeros(1, 1, 1))
+
+
+# ------------------------------------------------------------------------------------------------------------------ SNAC
+def fp16_exact_snac(w):
+    """Every FOLDED conv weight fp16-representable (all SNAC weight norms run over every axis but 0, layers.py:9-15)."""
+    from oracle.snac_ref import wn_weight
+
+    for k in [k for k in w if k.endswith("weight_v")]:
+        base = k[: -len(".weight_v")]
+        folded = wn_weight(w[base + ".weight_g"], w[k]).half().float()
+        w[base + ".weight_g"] = torch.sqrt((folded.double() ** 2).sum(dim=(1, 2), keepdim=True)).float()
+        w[k] = folded
+    return w
+
+
+def walk_levels(family, got, want, gm, wm, thr):
+    """SNAC's levels have different rates: the decisions that depend on one another are (level 0 frame t // s0 ... level n frame t): walk them per finest frame."""
+    strides = [got[-1].shape[1] // g.shape[1] for g in got]
+    for b in range(got[0].shape[0]):
+        for t in range(got[-1].shape[1]):
+            g = [int(got[i][b, t // s]) for i, s in enumerate(strides)]
+            w = [int(want[i][b, t // s]) for i, s in enumerate(strides)]
+            m = [min(float(gm[i][b, t // s]), float(wm[i][b, t // s])) for i, s in enumerate(strides)]
+            _margin.walk(family, g, w, m, thr=thr, where=(b, t))
+
+
+@pytest.mark.parametrize("kind", ["dw", "dense"])
+def test_snac_encode_against_the_reference_run(kind):
+    """The reference's own ``SNAC.encode`` outputs (tests/golden/ref_snac_encode_*.npz): padded length, encoder latents, the codes of the three levels
+    under the margin rule (searched on the reference's latents), z_q."""
+    from mlx_audio_amd.codec.models.snac import SNAC
+    from test_codec_encode_cpu import snac_model_weights
+    from oracle.snac_ref import SNACEncoderRef
+
+    fx = np.load(os.path.join(GOLD, f"ref_snac_encode_{kind}.npz"))
+    c, w = snac_model_weights(fx)
+    eng = SNAC(**c, weights=w, device=DEV)
+    audio = torch.from_numpy(fx["audio"])
+    padded = eng.preprocess(audio)
+    assert padded.shape[-1] == int(fx["padded_len"])
+    z = eng.encoder(padded)
+    torch.cuda.synchronize()
+    e = rel_peak(z, fx["z"])
+    print(f"snac ({kind}) encoder vs the reference run: {e:.2e} of the peak")
+    assert tuple(z.shape) == fx["z"].shape and e < 2e-3, e
+    ref = SNACEncoderRef(w, c["encoder_rates"], c["vq_strides"], depthwise=c["depthwise"])
+    _, wc, wm = ref.quantize(torch.from_numpy(fx["z"]), return_margins=True)
+    z_q, codes, gm = eng.quantizer(torch.from_numpy(fx["z"]), return_margins=True)
+    torch.cuda.synchronize()
+    want = [torch.from_numpy(fx[f"codes{i}"]).long() for i in range(len(codes))]
+    assert all(tuple(a.shape) == tuple(b.shape) and a.dtype == torch.int64 for a, b in zip(codes, want))
+    walk_levels("snac_encode", [x.cpu() for x in codes], want, [x.cpu() for x in gm], wm, thr=2e-3)
+    if all(torch.equal(a.cpu(), b) for a, b in zip(codes, want)):
+        assert rel_peak(z_q, fx["z_q"]) < 1e-5
+    got = eng.encode(audio)
+    assert all(tuple(a.shape) == tuple(b.shape) for a, b in zip(got, want))
+    hat, codes2 = eng(audio)
+    torch.cuda.synchronize()
+    assert hat.shape[0] == 2 and hat.shape[2] == 1 and torch.isfinite(hat).all() and all(torch.equal(a, b) for a, b in zip(got, codes2))
+
+
+@pytest.mark.parametrize("depthwise", [True, False])
+def test_snac_encode_stages_and_codes_vs_oracle(depthwise):
+    """24 kHz-model strides (2 / 4 / 8 / 8) and levels (4 / 2 / 1) at widths that take the wave-specialised kernel, fp16-exact folded weights: every
+    encoder stage, then the free-running codes under the margin rule."""
+    from mlx_audio_amd.codec.models.snac import SNAC, make_snac_encoder_weights, make_snac_weights
+    from oracle.snac_ref import SNACEncoderRef
+
+    c = dict(sampling_rate=24000, encoder_dim=16, encoder_rates=[2, 4, 8, 8], decoder_dim=256, decoder_rates=[8, 8, 4, 2], attn_window_size=None, codebook_size=1024,
+             codebook_dim=8, vq_strides=[4, 2, 1], noise=True, depthwise=depthwise)
+    latent = 256
+    w = make_snac_weights(latent, 256, c["decoder_rates"], c["vq_strides"], 1024, 8, True, depthwise, seed=5)
+    w.update(make_snac_encoder_weights(16, c["encoder_rates"], latent, c["vq_strides"], 8, depthwise, seed=5))
+    fp16_exact_snac(w)
+    eng = SNAC(**c, weights=w, device=DEV)
+    ref = SNACEncoderRef(w, c["encoder_rates"], c["vq_strides"], depthwise=depthwise)
+    audio = make_audio(2, 512 * 4 * 11 + 77, 24000, seed=8)
+    padded = ref.preprocess(audio)
+    assert torch.equal(eng.preprocess(audio), padded) and padded.shape[-1] == 512 * 4 * 12
+    zr, est = ref.encoder(padded, return_stages=True)
+    z, gst = eng.encoder(padded, return_stages=True)
+    torch.cuda.synchronize()
+    errs = {k: rel_peak(gst[k], est[k]) for k in est}
+    print(f"snac encoder depthwise={depthwise}: stage rel err { {k: f'{v:.1e}' for k, v in errs.items()} }")
+    assert max(errs.values()) < 2e-4, errs
+    _, wc, wm = ref.quantize(zr, return_margins=True)
+    got, gm = eng.encode(audio, return_margins=True)
+    torch.cuda.synchronize()
+    walk_levels("snac_encode", [x.cpu() for x in got], wc, [x.cpu() for x in gm], wm, thr=1e-3)
+    agree = float(torch.cat([(a.cpu() == b).float().flatten() for a, b in zip(got, wc)]).mean())
+    print(f"snac encode depthwise={depthwise}: {100 * agree:.1f} % of all codes equal the oracle's (free-running)")
+    assert agree > 0.85, agree
+    y = eng.decode(got)
+    torch.cuda.synchronize()
+    assert y.shape[0] == 2 and y.shape[2] == 1 and torch.isfinite(y).all()
