@@ -1,8 +1,8 @@
-"""EnCodec, decode side (codes -> waveform), on MI355X: host schedule over the HIP kernels.
+"""EnCodec (waveform -> codes -> waveform) on MI355X: host schedule over the HIP kernels.
 
-Mirrors ``mlx_audio/codec/models/encodec/encodec.py`` (``EncodecConfig``, ``preprocess_audio``, ``Encodec.decode`` / ``_decode_frame`` /
-``_linear_overlap_add`` / ``chunk_length`` / ``chunk_stride``, ``quantizer.decode`` / ``get_num_quantizers_for_bandwidth``), with the reference's
-op-by-op graph collapsed into:
+Mirrors ``mlx_audio/codec/models/encodec/encodec.py`` (``EncodecConfig``, ``preprocess_audio``, ``Encodec.encode`` / ``_encode_frame`` / ``decode`` /
+``_decode_frame`` / ``_linear_overlap_add`` / ``chunk_length`` / ``chunk_stride``, ``quantizer.encode`` / ``decode`` /
+``get_num_quantizers_for_bandwidth``), with the reference's op-by-op graph collapsed into:
   * RVQ decode (encodec.py:533-547): a frame is ONE ``embed_sum`` launch over the stacked codebooks (sum of the codebook rows in codebook order);
   * every ``nn.ELU`` is the PROLOGUE of the conv that consumes it; the resnet block's skip and shortcut conv are the residual / accumulate
     operands of its second conv; convs are implicit GEMMs (``mi355_conv_gemm``), the transposed convs (K = 2 stride) run polyphase with a
@@ -12,8 +12,12 @@ op-by-op graph collapsed into:
   * ``EncodecLSTM`` (encodec.py:137-167, 296-306): the x-projection of all time steps is ONE GEMM, the recurrence runs in the native per-step
     loop of ``mi355_lstm_seq`` (csrc/lstm_seq.hip: 2 MB of Wh per layer do not fit the persistent one-CU kernel of the Kokoro LSTMs); the
     reference's own Metal ``lstm`` kernel lives here (its gate order i | f | g | o and its sigmoid are reproduced).
-The encoder / codebook search (``encode``) is outside the decode hot path and raises.  ``norm_type = "time_group_norm"`` (the 48 kHz model's
-GroupNorm after every conv) is not built.  Weights: float32 checkpoints are held as fp16 MFMA images, activations split fp16 hi + lo
+Encode side (round 5; encodec.py:340-389, 445-533, 556-650), from the same kernels: the first conv runs FLATTENED over the (reflect-) padded samples
+(K taps x audio channels = the "channels" of a one-tap conv); a resnet block is conv k3 (ELU prologue) -> shortcut conv -> conv k1 accumulating onto
+it; the strided ``EncodecConv1d(K = 2 r, stride r)`` is a TWO-tap conv over the padded rows regrouped ``[rows / r, r * C]`` (the padding makes the
+row count a whole number of strides by construction, encodec.py:202-210); the LSTM as in the decoder; ``quantizer.encode`` is ONE
+``mi355_rvq_encode`` launch (residual kept on chip across the layers in use for the bandwidth).
+``norm_type = "time_group_norm"`` (the 48 kHz model's GroupNorm after every conv) is not built.  Weights: float32 checkpoints are held as fp16 MFMA images, activations split fp16 hi + lo
 (``precision = 4``); deviation from the float32 oracle asserted in ``tests/test_encodec_gpu.py``.
 """
 from __future__ import annotations
@@ -98,6 +102,24 @@ def decoder_layer_names(c: dict) -> dict:
     return names
 
 
+def encoder_layer_names(c: dict) -> dict:
+    """Module indices of ``EncodecEncoder.layers`` (encodec.py:343-383: the ``nn.ELU`` entries occupy list slots too)."""
+    idx = 1
+    names = dict(conv_in="encoder.layers.0", blocks=[])
+    for _ in c["upsampling_ratios"]:
+        blk = dict(res=[])
+        for _ in range(c["num_residual_layers"]):
+            blk["res"].append(f"encoder.layers.{idx}")
+            idx += 1
+        idx += 1   # nn.ELU()
+        blk["down"] = f"encoder.layers.{idx}"
+        idx += 1
+        names["blocks"].append(blk)
+    names["lstm"] = f"encoder.layers.{idx}"
+    names["conv_out"] = f"encoder.layers.{idx + 2}"
+    return names
+
+
 def _cfg_dict(config) -> dict:
     d = dict(EncodecConfig().__dict__)
     d.update(config if isinstance(config, dict) else config.__dict__)
@@ -149,8 +171,41 @@ def make_encodec_weights(config, seed: int = 0) -> Dict[str, torch.Tensor]:
     return w
 
 
+def make_encodec_encoder_weights(config, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Random float32 ENCODE-side parameters (``encoder.*``; reference module paths, MLX layouts): merge with ``make_encodec_weights`` for a whole model."""
+    c = _cfg_dict(config)
+    g = torch.Generator().manual_seed(seed + 15485863)
+    w: Dict[str, torch.Tensor] = {}
+
+    def conv(name, cout, k, cin, gain=1.0):
+        w[name + ".conv.weight"] = (torch.rand(cout, k, cin, generator=g) * 2 - 1) * math.sqrt(3.0 / (cin * k)) * gain
+        w[name + ".conv.bias"] = 0.02 * torch.randn(cout, generator=g)
+
+    names = encoder_layer_names(c)
+    conv(names["conv_in"], c["num_filters"], c["kernel_size"], c["audio_channels"], gain=2.0)
+    scaling = 1
+    for blk, ratio in zip(names["blocks"], reversed(c["upsampling_ratios"])):
+        cur = scaling * c["num_filters"]
+        for r in blk["res"]:
+            hid = cur // c["compress"]
+            conv(r + ".block.1", hid, c["residual_kernel_size"], cur, gain=1.3)
+            conv(r + ".block.3", cur, 1, hid, gain=0.7)
+            if c["use_conv_shortcut"]:
+                conv(r + ".shortcut", cur, 1, cur, gain=0.9)
+        conv(blk["down"], cur * 2, 2 * ratio, cur, gain=1.2)
+        scaling *= 2
+    dim = scaling * c["num_filters"]
+    for l in range(c["num_lstm_layers"]):
+        p = f"{names['lstm']}.lstm.{l}."
+        w[p + "Wx"] = (torch.rand(4 * dim, dim, generator=g) * 2 - 1) / math.sqrt(dim)
+        w[p + "Wh"] = (torch.rand(4 * dim, dim, generator=g) * 2 - 1) / math.sqrt(dim)
+        w[p + "bias"] = 0.1 * torch.randn(4 * dim, generator=g)
+    conv(names["conv_out"], c["hidden_size"], c["last_kernel_size"], dim, gain=1.5)
+    return w
+
+
 class _Quantizer:
-    """``EncodecResidualVectorQuantizer`` decode side (encodec.py:486-547)."""
+    """``EncodecResidualVectorQuantizer`` (encodec.py:486-547)."""
 
     def __init__(self, w: Dict[str, torch.Tensor], c: dict, device):
         self.codebook_size = c["codebook_size"]
@@ -160,6 +215,9 @@ class _Quantizer:
         self.table = torch.cat(tabs, 0).contiguous().to(device)
         self.offs = torch.tensor([i * self.codebook_size for i in range(self.num_quantizers)], dtype=torch.int32, device=device)
         self.device = device
+        # the layouts mi355_rvq_encode reads: [nq, bins, D], its transpose, |e|^2 / 2 (float32 codebooks as the checkpoint holds them)
+        t = torch.stack(tabs, 0).contiguous()
+        self.search = (t.to(device), t.transpose(1, 2).contiguous().to(device), ((t * t).sum(-1) / 2).contiguous().to(device))
 
     def get_num_quantizers_for_bandwidth(self, bandwidth: Optional[float] = None) -> int:
         bw_per_q = math.log2(self.codebook_size) * self.frame_rate
@@ -168,8 +226,17 @@ class _Quantizer:
             n = int(max(1, math.floor(bandwidth * 1000 / bw_per_q)))
         return n
 
-    def encode(self, embeddings, bandwidth: Optional[float] = None):
-        raise NotImplementedError("EnCodec codebook search (encode) is outside the decode hot path of this build (SURVEY section 8(f).2)")
+    def encode(self, embeddings, bandwidth: Optional[float] = None, return_margins: bool = False):
+        """encodec.py:516-533: embeddings [B, T, codebook_dim] -> codes int64 [B, nq(bandwidth), T]; per layer the nearest codeword by
+        ``-(|x|^2 - 2 x e^T + |e|^2)`` (first maximum), residual -= codeword.  ``return_margins`` adds the top-2 score gap of every decision."""
+        n = min(self.get_num_quantizers_for_bandwidth(bandwidth), self.num_quantizers)   # ``self.layers[:num_quantizers]``: a slice stops at the last layer
+        x = torch.as_tensor(embeddings, dtype=torch.float32).to(self.device).contiguous()
+        B, T, D = x.shape
+        tables, tables_t, c2 = self.search
+        out = ops.rvq_encode(x.view(B * T, D), tables[:n], tables_t[:n], c2[:n], margins=return_margins)
+        c, m = out if return_margins else (out, None)
+        codes = c.view(B, T, n).permute(0, 2, 1).contiguous().to(torch.int64)
+        return (codes, m.view(B, T, n).permute(0, 2, 1)) if return_margins else codes
 
     def decode(self, codes) -> torch.Tensor:
         """codes int [B, nq, T] -> [B, T, codebook_dim]."""
@@ -200,7 +267,7 @@ class Encodec:
     # ------------------------------------------------------------------ load
     def load_weights(self, weights: Dict[str, torch.Tensor], strict: bool = True):
         dev, c = self.device, self.c
-        w = {k: torch.as_tensor(v).detach().float().cpu() for k, v in weights.items() if k.startswith(("decoder.", "quantizer."))}
+        w = {k: torch.as_tensor(v).detach().float().cpu() for k, v in weights.items() if k.startswith(("decoder.", "quantizer.", "encoder."))}
         names = decoder_layer_names(c)
 
         def conv(name) -> PackedConv:
@@ -222,6 +289,28 @@ class Encodec:
                 res.append(dict(c1=conv(r + ".block.1"), c2=conv(r + ".block.3"), sc=conv(r + ".shortcut") if c["use_conv_shortcut"] else None))
             self.blocks.append(dict(ratio=ratio, cout=up_w.shape[0], up=ops.pack_conv_transpose(up_w, w.get(blk["up"] + ".conv.bias"), ratio, dev, f16=True), res=res))
         self.conv_out = conv(names["conv_out"])
+        self.enc = None
+        if "encoder.layers.0.conv.weight" in w:   # the encode half (encodec.py:340-389)
+            en = encoder_layer_names(c)
+            w0 = w[en["conv_in"] + ".conv.weight"]   # [F, K, channels] -> one tap of K * channels "channels" (flattened conv over the padded samples)
+            stem = ops.pack_conv(w0.reshape(w0.shape[0], 1, w0.shape[1] * w0.shape[2]).contiguous(), w.get(en["conv_in"] + ".conv.bias"), dev, f16=True)
+            eblocks = []
+            for blk, ratio in zip(en["blocks"], reversed(c["upsampling_ratios"])):
+                res = []
+                for j, r in enumerate(blk["res"]):
+                    res.append(dict(c1=conv(r + ".block.1"), c2=conv(r + ".block.3"), sc=conv(r + ".shortcut") if c["use_conv_shortcut"] else None,
+                                    dil=c["dilation_growth_rate"] ** j))
+                wd = w[blk["down"] + ".conv.weight"]   # [cout, 2 r, cin]: tap j r + q -> (tap j, channel q cin + ch)
+                cout, k, cin = wd.shape
+                if k != 2 * ratio:
+                    raise ValueError(f"{blk['down']}: {k} taps for stride {ratio} (the reference builds kernel_size = 2 * ratio)")
+                eblocks.append(dict(ratio=ratio, cin=cin, res=res, down=ops.pack_conv(wd.reshape(cout, 2, ratio * cin).contiguous(), w.get(blk["down"] + ".conv.bias"), dev, f16=True)))
+            elstm = []
+            for l in range(c["num_lstm_layers"]):
+                p = f"{en['lstm']}.lstm.{l}."
+                wx = w[p + "Wx"]
+                elstm.append(dict(wx=ops.pack_conv(wx[:, None, :], w.get(p + "bias"), dev, f16=True), wh=ops.pack_rowmajor16(w[p + "Wh"], None, dev, f16=True), H=wx.shape[0] // 4))
+            self.enc = dict(stem=stem, k0=w0.shape[1], blocks=eblocks, lstm=elstm, out=conv(en["conv_out"]))
         return self
 
     # ------------------------------------------------------------------ reference surface
@@ -243,21 +332,113 @@ class Encodec:
             return None
         return max(1, int((1.0 - self.c["overlap"]) * self.chunk_length))
 
+    # ------------------------------------------------------------------ encoder
+    def _encoder(self, x: torch.Tensor, return_stages: bool = False):
+        """x [B, L, audio_channels] -> embeddings [B, T, hidden_size] (encodec.py:340-389)."""
+        if self.enc is None:
+            raise ValueError("this Encodec was loaded without encoder weights (decode-only checkpoint)")
+        c, e = self.c, self.enc
+        x = torch.as_tensor(x, dtype=torch.float32).to(self.device).contiguous()
+        B, L, ch = x.shape
+        if ch != c["audio_channels"]:
+            raise ValueError(f"encoder: {ch} audio channels given, the model has {c['audio_channels']}")
+        st = {}
+        xp = self._padded(x, e["k0"], 1)                                  # [B, L + K - 1, ch]: the taps of a row are contiguous samples
+        h = self._f(B, L, e["stem"].cout)
+        ops.conv_gemm(xp, e["stem"], h, lout=L, flat=dict(ldx=ch, x_off=0, channels=ch), precision=4)
+        st["conv_in"] = h
+        for bi, blk in enumerate(e["blocks"]):
+            r, C = blk["ratio"], blk["cin"]
+            for rb in blk["res"]:
+                hid = self._f(B, L, rb["c1"].cout)
+                self._conv(h, rb["c1"], hid, dilation=rb["dil"], elu=True)
+                out = self._f(B, L, C)
+                if rb["sc"] is not None:
+                    self._conv(h, rb["sc"], out)
+                    self._conv(hid, rb["c2"], out, elu=True, accumulate=True)
+                else:
+                    self._conv(hid, rb["c2"], out, elu=True, res=h)
+                h = out
+            hp = self._padded(h, 2 * r, 1, stride=r)                        # a whole number of strides by construction
+            assert hp.shape[1] % r == 0, (hp.shape, r)
+            rows = hp.shape[1] // r
+            L = rows - 1
+            y = self._f(B, L, blk["down"].cout)
+            ops.conv_gemm(hp.view(B, rows, r * C), blk["down"], y, pad=0, lout=L, pre_act=ACT_ELU, precision=4)   # K = 2 r, stride r as 2 taps of r rows
+            h = y
+            st[f"block{bi}"] = h
+        y = h
+        for l in e["lstm"]:
+            xq = self._f(B, L, 4 * l["H"])
+            ops.conv_gemm(y, l["wx"], xq, precision=4)
+            out = self._f(B, L, l["H"])
+            ops.lstm_seq(xq, l["wh"], out)
+            y = out
+        h = y + h
+        st["lstm"] = h
+        z = self._f(B, L, c["hidden_size"])
+        self._conv(h, e["out"], z, elu=True)
+        st["embeddings"] = z
+        return (z, st) if return_stages else z
+
+    def _encode_frame(self, input_values: torch.Tensor, bandwidth: float, padding_mask: torch.Tensor):
+        """encodec.py:556-583: one chunk -> (codes [B, nq, T], scale [B, 1, 1] or None)."""
+        c = self.c
+        length = input_values.shape[1]
+        duration = length / c["sampling_rate"]
+        if c["chunk_length_s"] is not None and duration > 1e-5 + c["chunk_length_s"]:
+            raise RuntimeError(f"Duration of frame ({duration}) is longer than chunk {c['chunk_length_s']}")
+        scale = None
+        if c["normalize"]:
+            input_values = input_values * padding_mask[..., None].to(input_values.dtype)
+            mono = input_values.sum(dim=2, keepdim=True) / input_values.shape[2]
+            scale = torch.sqrt((mono * mono).mean(dim=1, keepdim=True)) + 1e-8
+            input_values = input_values / scale
+        return self.quantizer.encode(self._encoder(input_values), bandwidth), scale
+
     def encode(self, input_values, padding_mask=None, bandwidth: Optional[float] = None):
-        raise NotImplementedError("Encodec.encode (encoder + codebook search) is outside the decode hot path of this build (SURVEY section 8(f).2)")
+        """encodec.py:585-650: input_values [B, samples, channels] -> (codes int64 [n_chunks, B, nq, T], scales: list of [B, 1, 1] or None)."""
+        c = self.c
+        if bandwidth is None:
+            bandwidth = c["target_bandwidths"][0]
+        if bandwidth not in c["target_bandwidths"]:
+            raise ValueError(f"This model doesn't support the bandwidth {bandwidth}. Select one of {c['target_bandwidths']}.")
+        input_values = torch.as_tensor(input_values, dtype=torch.float32).to(self.device)
+        _, input_length, channels = input_values.shape
+        if channels < 1 or channels > 2:
+            raise ValueError(f"Number of audio channels must be 1 or 2, but got {channels}")
+        chunk_length = self.chunk_length
+        if chunk_length is None:
+            chunk_length = input_length
+            stride = input_length
+        else:
+            stride = self.chunk_stride
+        if padding_mask is None:
+            padding_mask = torch.ones(input_values.shape[:2], dtype=torch.bool, device=self.device)
+        padding_mask = torch.as_tensor(padding_mask).to(self.device)
+        step = chunk_length - stride
+        if (input_length % stride) != step:
+            raise ValueError("The input length is not properly padded for batched chunked encoding. Make sure to pad the input correctly.")
+        frames, scales = [], []
+        for offset in range(0, input_length - step, stride):
+            mask = padding_mask[:, offset:offset + chunk_length].bool()
+            codes, scale = self._encode_frame(input_values[:, offset:offset + chunk_length], bandwidth, mask)
+            frames.append(codes)
+            scales.append(scale)
+        return torch.stack(frames), scales
 
     # ------------------------------------------------------------------ decoder
     def _f(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.device)
 
-    def _padded(self, x: torch.Tensor, kernel_size: int, dilation: int) -> torch.Tensor:
-        """The explicit padding of ``EncodecConv1d`` (stride 1; encodec.py:199-247): x [B, L, C] -> [B, L + (kernel_size - 1) + extra, C]."""
+    def _padded(self, x: torch.Tensor, kernel_size: int, dilation: int, stride: int = 1) -> torch.Tensor:
+        """The explicit padding of ``EncodecConv1d`` (encodec.py:199-247): x [B, L, C] -> [B, L + (kernel_size - stride) + extra, C]."""
         c = self.c
         k_eff = (kernel_size - 1) * dilation + 1
-        padding_total = kernel_size - 1
+        padding_total = kernel_size - stride
         L = x.shape[1]
-        n_frames = int(math.ceil((L - k_eff + padding_total) + 1)) - 1
-        extra = n_frames + k_eff - padding_total - L
+        n_frames = int(math.ceil((L - k_eff + padding_total) / stride + 1)) - 1
+        extra = n_frames * stride + k_eff - padding_total - L
         if c["use_causal_conv"]:
             pl, pr = padding_total, extra
         else:

@@ -1,4 +1,4 @@
-"""PyTorch-CPU restatement of the EnCodec decode path (TEST ORACLE, not product).
+"""PyTorch-CPU restatement of the EnCodec decode and encode paths (TEST ORACLE, not product).
 
 Follows /root/reference/mlx_audio/codec/models/encodec/encodec.py statement by statement:
   * ``:89-167``   LSTM: x @ Wx^T + bias for every step, then per step hidden @ Wh^T (zeros at step 0) + the Metal ``lstm`` kernel: gate chunks
@@ -15,6 +15,10 @@ Follows /root/reference/mlx_audio/codec/models/encodec/encodec.py statement by s
   * ``:391-444``  EncodecDecoder: conv k7 -> LSTM -> per ratio (ELU, convT K = 2 r, resnet blocks) -> ELU -> conv k7
   * ``:447-547``  Euclidean codebooks / RVQ decode: sum of the codebook rows
   * ``:679-777``  Encodec._decode_frame / decode / _linear_overlap_add
+  * ``:340-389``  EncodecEncoder (round 5): conv k7 -> per ratio (reversed) resnet blocks, ELU, conv K = 2 r stride r -> LSTM -> ELU -> conv k7
+  * ``:452-469, 516-533``  Euclidean codebook search ``argmax -(|x|^2 - 2 x e^T + |e|^2)`` and the residual loop of ``quantizer.encode``
+  * ``:556-650``  Encodec._encode_frame (optional loudness normalisation) / encode (chunk loop)
+    -- pinned by ``ref_encodec_encode.npz`` (the reference's own ``Encodec.encode`` run; every code equal)
 Parameter names are the reference's module paths (``decoder.layers.N...``), layouts MLX's (conv ``[out, K, in]``).  ``norm_type = "weight_norm"``
 checkpoints carry folded weights (the reference's modules hold plain ``nn.Conv1d``); ``time_group_norm`` (the 48 kHz model) is not restated.
 Parity status: **pinned to the reference's own modules**: tests/golden/make_reference_fixtures.py runs the reference's ``Encodec.decode`` (over the
@@ -184,3 +188,92 @@ class EncodecDecoderRef:
         if padding_mask is not None and padding_mask.shape[1] < audio.shape[1]:
             audio = audio[:, :padding_mask.shape[1]]
         return audio
+
+    # ------------------------------------------------------------------ encoder (encodec.py:340-389)
+    def encoder(self, x: Tensor, return_stages: bool = False):
+        """x [B, L, channels] -> embeddings [B, T, hidden_size]."""
+        c = self.c
+        st = {}
+        idx = 0
+        h = self.conv(x.to(self.dtype), f"encoder.layers.{idx}", c["kernel_size"])
+        st["conv_in"] = h
+        idx += 1
+        scaling = 1
+        for bi, ratio in enumerate(reversed(c["upsampling_ratios"])):
+            cur = scaling * c["num_filters"]
+            for j in range(c["num_residual_layers"]):
+                h = self.resnet(h, f"encoder.layers.{idx}", cur, [c["dilation_growth_rate"] ** j, 1])
+                idx += 1
+            idx += 1  # nn.ELU()
+            h = self.conv(F.elu(h), f"encoder.layers.{idx}", ratio * 2, stride=ratio)
+            idx += 1
+            st[f"block{bi}"] = h
+            scaling *= 2
+        y = h
+        for l in range(c["num_lstm_layers"]):
+            y = self.lstm(y, f"encoder.layers.{idx}.lstm.{l}")
+        h = y + h
+        st["lstm"] = h
+        idx += 2  # the LSTM, nn.ELU()
+        z = self.conv(F.elu(h), f"encoder.layers.{idx}", c["last_kernel_size"])
+        st["embeddings"] = z
+        return (z, st) if return_stages else z
+
+    def num_quantizers_for_bandwidth(self, bandwidth: Optional[float]) -> int:
+        c = self.c
+        frame_rate = math.ceil(c["sampling_rate"] / int(torch.tensor(c["upsampling_ratios"]).prod()))
+        tb = c.get("target_bandwidths") or [1.5, 3.0, 6.0, 12.0, 24.0]
+        n = int(1000 * tb[-1] // (frame_rate * 10))
+        if bandwidth is not None and bandwidth > 0.0:
+            n = int(max(1, math.floor(bandwidth * 1000 / (math.log2(c["codebook_size"]) * frame_rate))))
+        return n
+
+    def quantizer_encode(self, embeddings: Tensor, bandwidth: Optional[float] = None, return_margins: bool = False):
+        """embeddings [B, T, D] -> codes [B, nq, T] (encodec.py:516-533); margins = top-2 gap of ``dist / 2`` (the score scale of mi355_rvq_encode)."""
+        residual = embeddings.to(self.dtype)
+        codes, margins = [], []
+        for i in range(self.num_quantizers_for_bandwidth(bandwidth)):
+            if f"quantizer.layers.{i}.codebook.embed" not in self.w:   # ``self.layers[:num_quantizers]``: a slice past the end stops at the last layer
+                break
+            embed = self.w[f"quantizer.layers.{i}.codebook.embed"]
+            flat = residual.reshape(-1, residual.shape[-1])
+            dist = -((flat ** 2).sum(1, keepdim=True) - 2 * flat @ embed.t() + (embed.t() ** 2).sum(0, keepdim=True))
+            top = torch.topk(dist, 2, dim=1).values
+            ind = dist.argmax(-1).reshape(residual.shape[:-1])
+            margins.append(((top[:, 0] - top[:, 1]) / 2).reshape(residual.shape[:-1]))
+            residual = residual - embed[ind]
+            codes.append(ind)
+        out = torch.stack(codes, 1)
+        return (out, torch.stack(margins, 1)) if return_margins else out
+
+    def encode_frame(self, x: Tensor, bandwidth: float, mask: Tensor):
+        c = self.c
+        scale = None
+        if c["normalize"]:
+            x = x * mask[..., None].to(x.dtype)
+            mono = x.sum(dim=2, keepdim=True) / x.shape[2]
+            scale = torch.sqrt((mono ** 2).mean(dim=1, keepdim=True)) + 1e-8
+            x = x / scale
+        return self.quantizer_encode(self.encoder(x), bandwidth), scale
+
+    def encode(self, input_values: Tensor, padding_mask: Optional[Tensor] = None, bandwidth: Optional[float] = None):
+        """input_values [B, samples, channels] -> (codes [n_chunks, B, nq, T], scales) (encodec.py:585-650)."""
+        c = self.c
+        tb = c.get("target_bandwidths") or [1.5, 3.0, 6.0, 12.0, 24.0]
+        bandwidth = tb[0] if bandwidth is None else bandwidth
+        n = input_values.shape[1]
+        chunk_length, stride = (n, n) if self.chunk_length is None else (self.chunk_length, self.chunk_stride)
+        if padding_mask is None:
+            padding_mask = torch.ones(input_values.shape[:2], dtype=torch.bool)
+        step = chunk_length - stride
+        if (n % stride) != step:
+            raise ValueError("The input length is not properly padded for batched chunked encoding. Make sure to pad the input correctly.")
+        frames, scales = [], []
+        for off in range(0, n - step, stride):
+            f, s = self.encode_frame(input_values[:, off:off + chunk_length], bandwidth, padding_mask[:, off:off + chunk_length].bool())
+            frames.append(f)
+            scales.append(s)
+        return torch.stack(frames), scales
+
+
+EncodecRef = EncodecDecoderRef   # both halves live on the one class

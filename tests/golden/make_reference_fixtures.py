@@ -1431,6 +1431,49 @@ def run_encodec(seed_w, seed_codes, n_frames):
     return dict(audio=list(np.asarray(audio).shape), nq=int(nq), peak=float(np.abs(np.asarray(audio)).max()), missing=str(missing)[:80])
 
 
+ENCODEC_ENC_STEREO = dict(audio_channels=2, num_filters=8, kernel_size=7, num_residual_layers=1, dilation_growth_rate=2, codebook_size=64, codebook_dim=32,
+                          hidden_size=32, num_lstm_layers=1, residual_kernel_size=3, use_causal_conv=False, normalize=True, pad_mode="reflect",
+                          norm_type="weight_norm", last_kernel_size=7, trim_right_ratio=1.0, compress=2, upsampling_ratios=[5, 2, 2],
+                          target_bandwidths=[18.0, 60.0], sampling_rate=24000, chunk_length_s=0.05, overlap=0.2)
+
+
+def run_encodec_encode(seed_w, seed_audio, cfg_dict, n_samples, tag):
+    """The reference's ``Encodec.encode`` (encodec.py:585-650 -> _encode_frame -> EncodecEncoder -> quantizer.encode) on a seeded checkpoint, batch 1 (the
+    Metal LSTM kernel's index arithmetic, see mlx_shim._metal_kernel): (a) mono, causal, one chunk, both bandwidths; (b) stereo, non-causal, an odd stride, loudness normalisation, overlapping chunks -- input made by the reference's own ``preprocess_audio``."""
+    if "mlx_audio" not in sys.modules:
+        import_reference()
+    if "mlx_audio.codec" not in sys.modules:
+        _pkg("mlx_audio.codec", f"{REF}/codec")
+        _pkg("mlx_audio.codec.models", f"{REF}/codec/models")
+    _pkg("mlx_audio.codec.models.encodec", f"{REF}/codec/models/encodec")
+    E = _load("mlx_audio.codec.models.encodec.encodec", f"{REF}/codec/models/encodec/encodec.py")
+    sys.path.insert(0, ROOT)
+    from mlx_audio_amd.codec.models.encodec.encodec import make_encodec_encoder_weights, make_encodec_weights
+
+    cfg = E.EncodecConfig(**cfg_dict)
+    model = E.Encodec(cfg)
+    w = make_encodec_weights(cfg_dict, seed=seed_w)
+    w.update(make_encodec_encoder_weights(cfg_dict, seed=seed_w))
+    model.load_weights([(k, mx.array(v.numpy())) for k, v in w.items()], strict=True)
+    g = np.random.default_rng(seed_audio)
+    t = np.arange(n_samples) / cfg_dict["sampling_rate"]
+    ch = cfg_dict["audio_channels"]
+    raw = np.stack([0.5 * np.sin(2 * np.pi * (210 + 130 * c) * t) * (0.6 + 0.4 * np.sin(2 * np.pi * 9 * t)) + 0.15 * g.standard_normal(n_samples) for c in range(ch)], axis=1)
+    raw = raw.astype(np.float32)
+    inputs, masks = E.preprocess_audio(mx.array(raw if ch > 1 else raw[:, 0]), cfg_dict["sampling_rate"], model.chunk_length, model.chunk_stride)
+    out = dict(seed_w=seed_w, config=json.dumps(cfg_dict), raw=raw, inputs=_np(inputs), masks=np.asarray(masks).astype(np.bool_))
+    emb = model.encoder(inputs[:, :model.chunk_length] if model.chunk_length else inputs)
+    out["embeddings_chunk0_unnormalised"] = _np(emb)
+    for bw in cfg_dict["target_bandwidths"]:
+        codes, scales = model.encode(inputs, masks, bandwidth=bw)
+        out[f"codes_bw{bw}"] = np.asarray(codes).astype(np.int32)
+        out[f"scales_bw{bw}"] = np.stack([_np(sc) for sc in scales]) if scales[0] is not None else np.zeros(0, np.float32)
+    audio = model.decode(codes, scales, masks)
+    out["decoded"] = _np(audio)
+    np.savez_compressed(os.path.join(HERE, f"ref_encodec_encode_{tag}.npz"), **out)
+    return {a: (v.shape if hasattr(v, "shape") else v) for a, v in out.items() if a != "config"}
+
+
 def run_dataclasses(R):
     """Field names and defaults of the record types that cross the boundary: ``GenerationResult`` / ``BatchGenerationResult`` (tts/models/base.py),
     ``TTSBatchOptions / Item / Event`` (tts/continuous.py), the broker's request / context / chunk records (server_inference.py), Whisper's
@@ -1835,6 +1878,8 @@ def main():
             sfx = run_snac_encode(seed_w=33, seed_audio=6, n_samples=48 * 4 * 9 + 101, depthwise=dwise)
             np.savez_compressed(os.path.join(HERE, f"ref_snac_encode_{'dw' if dwise else 'dense'}.npz"), **sfx)
             print("snac encode:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in sfx.items() if a != "config"})
+        print("encodec encode (mono):", run_encodec_encode(41, 3, ENCODEC_TINY, 16 * 61 + 5, "mono"))
+        print("encodec encode (stereo):", run_encodec_encode(43, 5, ENCODEC_ENC_STEREO, 2600, "stereo"))
         return
     if "qwen3_clone" in sys.argv[1:]:   # only the voice-cloning fixtures (round 3)
         sfx = run_qwen3_speaker_encoder(seed_w=13, seed_mel=5, frames=37)

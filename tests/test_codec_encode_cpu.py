@@ -156,3 +156,72 @@ def test_snac_encode_host_schedule_dry_run():
             assert hat.shape[0] == 2 and hat.shape[2] == 1 and torch.isfinite(hat).all() and all(torch.equal(a, b) for a, b in zip(codes, codes2))
             with pytest.raises(ValueError, match="whole number of stride"):
                 eng.quantizer(torch.zeros(1, z.shape[1], 7))
+
+
+def encodec_model_weights(fx):
+    from mlx_audio_amd.codec.models.encodec import make_encodec_encoder_weights, make_encodec_weights
+
+    c = json.loads(str(fx["config"]))
+    w = make_encodec_weights(c, seed=int(fx["seed_w"]))
+    w.update(make_encodec_encoder_weights(c, seed=int(fx["seed_w"])))
+    return c, w
+
+
+def test_encodec_encode_oracle_reproduces_the_reference_modules():
+    """``Encodec.encode`` (encodec.py:585-650): mono causal one-chunk, and stereo non-causal with loudness normalisation and overlapping chunks; every
+    code at both bandwidths, the scales, the encoder's embeddings, and the decode of those codes."""
+    from oracle.encodec_ref import EncodecRef
+
+    for tag in ("mono", "stereo"):
+        fx = np.load(os.path.join(GOLD, f"ref_encodec_encode_{tag}.npz"))
+        c, w = encodec_model_weights(fx)
+        ref = EncodecRef(w, c)
+        x, m = torch.from_numpy(fx["inputs"]), torch.from_numpy(fx["masks"])
+        chunk = ref.chunk_length or x.shape[1]
+        emb = ref.encoder(x[:, :chunk])
+        assert tuple(emb.shape) == fx["embeddings_chunk0_unnormalised"].shape and rel_max(emb.numpy(), fx["embeddings_chunk0_unnormalised"]) < 3e-5, tag
+        for bw in c["target_bandwidths"]:
+            codes, scales = ref.encode(x, m, bandwidth=bw)
+            assert np.array_equal(codes.numpy(), fx[f"codes_bw{bw}"]), (tag, bw, int((codes.numpy() != fx[f"codes_bw{bw}"]).sum()))
+            if c["normalize"]:
+                assert rel_max(torch.stack(scales).numpy(), fx[f"scales_bw{bw}"]) < 1e-6
+            else:
+                assert all(s is None for s in scales)
+        audio = ref.decode(codes, scales, m).numpy()
+        assert audio.shape == fx["decoded"].shape and rel_max(audio, fx["decoded"]) < 5e-5, tag
+
+
+def test_encodec_encode_host_schedule_dry_run():
+    """The product's EnCodec encode schedule (flattened stem over the reflect-padded samples, resnet blocks, strided convs over the padded rows regrouped,
+    LSTM, one rvq_encode launch per chunk, normalisation and the chunk loop) over tests/_ops_emu.py, against the reference's own run."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _ops_emu
+    from mlx_audio_amd.codec.models.encodec import Encodec
+    from oracle.encodec_ref import EncodecRef
+
+    for tag in ("mono", "stereo"):
+        fx = np.load(os.path.join(GOLD, f"ref_encodec_encode_{tag}.npz"))
+        c, w = encodec_model_weights(fx)
+        x, m = torch.from_numpy(fx["inputs"]), torch.from_numpy(fx["masks"])
+        with _ops_emu.patched():
+            eng = Encodec(c, weights=w, device="cpu")
+            chunk = eng.chunk_length or x.shape[1]
+            emb, st = eng._encoder(x[:, :chunk], return_stages=True)
+            _, est = EncodecRef(w, c).encoder(x[:, :chunk], return_stages=True)
+            for k in est:
+                assert rel_max(st[k].numpy(), est[k].numpy()) < 1e-5, (tag, k)
+            assert rel_max(emb.numpy(), fx["embeddings_chunk0_unnormalised"]) < 3e-5
+            for bw in c["target_bandwidths"]:
+                codes, scales = eng.encode(x, m, bandwidth=bw)
+                assert codes.dtype == torch.int64 and np.array_equal(codes.numpy(), fx[f"codes_bw{bw}"]), (tag, bw)
+                if c["normalize"]:
+                    assert rel_max(torch.stack(scales).numpy(), fx[f"scales_bw{bw}"]) < 1e-6
+            cm, mg = eng.quantizer.encode(emb, c["target_bandwidths"][-1], return_margins=True)
+            assert tuple(mg.shape) == tuple(cm.shape) and float(mg.min()) >= 0
+            audio = eng.decode(codes, scales, m)
+            assert rel_max(audio.numpy(), fx["decoded"]) < 5e-5
+            with pytest.raises(ValueError, match="doesn't support the bandwidth"):
+                eng.encode(x, m, bandwidth=7.0)
+            if eng.chunk_length is not None:
+                with pytest.raises(ValueError, match="not properly padded"):
+                    eng.encode(x[:, :-1], m[:, :-1])

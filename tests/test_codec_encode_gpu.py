@@ -254,3 +254,88 @@ def test_snac_encode_stages_and_codes_vs_oracle(depthwise):
     y = eng.decode(got)
     torch.cuda.synchronize()
     assert y.shape[0] == 2 and y.shape[2] == 1 and torch.isfinite(y).all()
+
+
+# ------------------------------------------------------------------------------------------------------------------ EnCodec
+@pytest.mark.parametrize("tag", ["mono", "stereo"])
+def test_encodec_encode_against_the_reference_run(tag):
+    """The reference's own ``Encodec.encode`` outputs (tests/golden/ref_encodec_encode_*.npz): the encoder's embeddings, then every code of both
+    bandwidths under the margin rule -- mono causal one-chunk, and stereo non-causal with loudness normalisation and overlapping chunks."""
+    from mlx_audio_amd.codec.models.encodec import Encodec
+    from test_codec_encode_cpu import encodec_model_weights
+    from oracle.encodec_ref import EncodecRef
+
+    fx = np.load(os.path.join(GOLD, f"ref_encodec_encode_{tag}.npz"))
+    c, w = encodec_model_weights(fx)
+    eng, ref = Encodec(c, weights=w, device=DEV), EncodecRef(w, c)
+    x, m = torch.from_numpy(fx["inputs"]), torch.from_numpy(fx["masks"])
+    chunk = eng.chunk_length or x.shape[1]
+    emb = eng._encoder(x[:, :chunk])
+    torch.cuda.synchronize()
+    e = rel_peak(emb, fx["embeddings_chunk0_unnormalised"])
+    print(f"encodec ({tag}) encoder vs the reference run: {e:.2e} of the peak")
+    assert tuple(emb.shape) == fx["embeddings_chunk0_unnormalised"].shape and e < 2e-3, e
+    bw = c["target_bandwidths"][-1]
+    want = torch.from_numpy(fx[f"codes_bw{bw}"]).long()                  # [chunks, B, nq, T]
+    codes, scales = eng.encode(x, m, bandwidth=bw)
+    torch.cuda.synchronize()
+    assert tuple(codes.shape) == tuple(want.shape) and codes.dtype == torch.int64
+    if c["normalize"]:
+        assert rel_peak(torch.stack(scales), fx[f"scales_bw{bw}"]) < 1e-5
+    # the oracle's margins per chunk (its codes ARE the fixture's: tests/test_codec_encode_cpu.py), the device's from a second search
+    step = chunk - (eng.chunk_stride or chunk)
+    for ci, off in enumerate(range(0, x.shape[1] - step, eng.chunk_stride or chunk)):
+        xc, mc = x[:, off:off + chunk], m[:, off:off + chunk]
+        if c["normalize"]:
+            xc = xc * mc[..., None].float()
+            mono = xc.sum(dim=2, keepdim=True) / xc.shape[2]
+            xc = xc / (torch.sqrt((mono ** 2).mean(dim=1, keepdim=True)) + 1e-8)
+        er = ref.encoder(xc)
+        wc, wm = ref.quantizer_encode(er, bw, return_margins=True)
+        assert torch.equal(wc, want[ci])
+        gc, gm = eng.quantizer.encode(eng._encoder(xc), bw, return_margins=True)
+        assert torch.equal(gc.cpu(), codes[ci].cpu())
+        thr = 2e-3 * float(er.abs().max()) * 3.0
+        walk_frames("encodec_encode", codes[ci], want[ci], torch.minimum(gm.cpu(), wm), thr=thr)
+    lo = c["target_bandwidths"][0]
+    codes_lo, _ = eng.encode(x, m, bandwidth=lo)
+    assert tuple(codes_lo.shape) == fx[f"codes_bw{lo}"].shape
+    audio = eng.decode(codes, scales, m)
+    torch.cuda.synchronize()
+    assert tuple(audio.shape) == fx["decoded"].shape and torch.isfinite(audio).all()
+
+
+def test_encodec_24khz_encode_stages_and_codes_vs_oracle():
+    """The published 24 kHz configuration (32 filters, ratios 8 / 5 / 4 / 2, two LSTM layers of 512, 1024 x 128 codebooks, 24 kbps = 32 quantizers), weights
+    on the fp16 grid (the image is then exact): every encoder stage against the float32 oracle, then the free-running codes under the margin rule, and the
+    encode -> decode round trip."""
+    from mlx_audio_amd.codec.models.encodec import Encodec, make_encodec_encoder_weights, make_encodec_weights
+    from oracle.encodec_ref import EncodecRef
+
+    c = dict(upsampling_ratios=[8, 5, 4, 2], target_bandwidths=[1.5, 3.0, 6.0, 12.0, 24.0])
+    w = make_encodec_weights(c, seed=9)
+    w.update(make_encodec_encoder_weights(c, seed=9))
+    w = {k: (v.half().float() if v.is_floating_point() and "codebook" not in k else v) for k, v in w.items()}
+    eng, ref = Encodec(c, weights=w, device=DEV), EncodecRef(w, c)
+    x = make_audio(1, 24000 + 123, 24000, seed=4).transpose(1, 2).contiguous()      # [1, samples, 1]
+    er, est = ref.encoder(x, return_stages=True)
+    eg, gst = eng._encoder(x, return_stages=True)
+    torch.cuda.synchronize()
+    errs = {k: rel_peak(gst[k], est[k]) for k in est}
+    print(f"encodec 24 kHz encoder: stage rel err { {k: f'{v:.1e}' for k, v in errs.items()} }")
+    assert tuple(eg.shape) == tuple(er.shape) == (1, 76, 128) and max(errs.values()) < 3e-4, errs
+    wc, wm = ref.quantizer_encode(er, 24.0, return_margins=True)
+    gc, gm = eng.quantizer.encode(eg, 24.0, return_margins=True)
+    torch.cuda.synchronize()
+    assert tuple(gc.shape) == (1, 32, 76)
+    walk_frames("encodec_encode", gc, wc, torch.minimum(gm.cpu(), wm), thr=1e-3 * float(er.abs().max()) * 3.0)
+    agree = float((gc.cpu() == wc).float().mean())
+    print(f"encodec 24 kHz: {100 * agree:.1f} % of all codes equal the oracle's (free-running, 32 layers deep)")
+    assert agree > 0.5, agree
+    codes, scales = eng.encode(x, None, bandwidth=24.0)
+    assert tuple(codes.shape) == (1, 1, 32, 76) and scales == [None] and torch.equal(codes[0].cpu(), gc.cpu())
+    audio = eng.decode(codes, scales)
+    torch.cuda.synchronize()
+    assert tuple(audio.shape) == (1, 76 * 320, 1) and torch.isfinite(audio).all()
+    for bw, nq in ((1.5, 2), (6.0, 8)):
+        assert tuple(eng.encode(x, None, bandwidth=bw)[0].shape) == (1, 1, nq, 76)
