@@ -313,6 +313,25 @@ class Encodec:
             self.enc = dict(stem=stem, k0=w0.shape[1], blocks=eblocks, lstm=elstm, out=conv(en["conv_out"]))
         return self
 
+    @classmethod
+    def from_pretrained(cls, path_or_repo: str, device="cuda:0"):
+        """encodec.py:710-737 for a LOCAL directory (``config.json`` + ``model.safetensors``; no hub here): (model, preprocess_audio partial)."""
+        import functools
+        import json
+        from pathlib import Path
+
+        from safetensors.torch import load_file
+
+        path = Path(path_or_repo)
+        if not path.exists():
+            raise FileNotFoundError(f"{path_or_repo}: Encodec.from_pretrained needs a local directory (no hub access in this build)")
+        with open(path / "config.json", "r") as f:
+            config = json.load(f)
+        config = {k: v for k, v in config.items() if k in EncodecConfig.__dataclass_fields__}
+        model = cls(config, weights=load_file(str(path / "model.safetensors")), device=device)
+        processor = functools.partial(preprocess_audio, sampling_rate=model.sampling_rate, chunk_length=model.chunk_length, chunk_stride=model.chunk_stride)
+        return model, processor
+
     # ------------------------------------------------------------------ reference surface
     @property
     def channels(self):

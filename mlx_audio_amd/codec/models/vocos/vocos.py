@@ -89,9 +89,63 @@ class MelSpectrogramFeatures(FeatureExtractor):
 
 
 class EncodecFeatures(FeatureExtractor):
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError("EncodecFeatures needs the EnCodec encoder, which this build does not contain (SURVEY section 8(f).2); "
-                                  "compute the features elsewhere and call Vocos.decode(features, bandwidth_id=...)")
+    """vocos.py:54-116: EnCodec codes as features -- ``get_encodec_codes`` (preprocess -> ``Encodec.encode`` at ``bandwidths[bandwidth_id]``) and
+    ``get_features_from_codes`` (sum over the quantizers of their codebook rows: one ``embed_sum`` launch over the stacked codebooks).
+
+    The reference downloads the EnCodec checkpoint from the hub by name; there is no hub here, so the model comes in as ``encodec=`` (an
+    ``mlx_audio_amd...encodec.Encodec``; ``preprocessor`` defaults to its ``preprocess_audio`` partial) or ``encodec_model`` names a LOCAL directory
+    (``config.json`` + ``model.safetensors``, ``Encodec.from_pretrained``)."""
+
+    HUB = {"encodec_24khz": "mlx-community/encodec-24khz-float32", "encodec_48khz": "mlx-community/encodec-48khz-float32"}
+
+    def __init__(self, encodec_model: str = "encodec_24khz", bandwidths: List[float] = [1.5, 3.0, 6.0, 12.0], train_codebooks: bool = False,
+                 encodec=None, preprocessor=None, device="cuda:0"):
+        import functools
+        import os
+
+        from ..encodec.encodec import Encodec, preprocess_audio
+
+        if encodec is None:
+            if os.path.isdir(str(encodec_model)):
+                encodec, preprocessor = Encodec.from_pretrained(encodec_model, device=device)
+            elif encodec_model in self.HUB:
+                raise FileNotFoundError(f"EncodecFeatures: '{encodec_model}' is {self.HUB[encodec_model]} on the hub, which is not reachable here; pass "
+                                        "encodec=<Encodec> or a local checkpoint directory as encodec_model")
+            else:
+                raise ValueError(f"Unsupported encodec_model: {encodec_model}. Supported options are 'encodec_24khz' and 'encodec_48khz'.")
+        self.encodec = encodec
+        self.preprocessor = preprocessor or functools.partial(preprocess_audio, sampling_rate=encodec.sampling_rate, chunk_length=encodec.chunk_length,
+                                                              chunk_stride=encodec.chunk_stride)
+        self.num_q = self.encodec.quantizer.get_num_quantizers_for_bandwidth(bandwidth=max(bandwidths))
+        self.bandwidths = list(bandwidths)
+
+    @property
+    def codebook_weights(self) -> torch.Tensor:
+        """The first ``num_q`` codebooks stacked on axis 0 (vocos.py:81-83)."""
+        return self.encodec.quantizer.table[: self.num_q * self.encodec.quantizer.codebook_size]
+
+    def get_encodec_codes(self, audio, bandwidth_id) -> torch.Tensor:
+        """audio [L] / [L, C] -> codes [nq, 1, T] (vocos.py:86-97)."""
+        features, mask = self.preprocessor(audio)
+        if isinstance(bandwidth_id, torch.Tensor):
+            bandwidth_id = int(bandwidth_id.flatten().tolist()[0])
+        elif isinstance(bandwidth_id, list):
+            bandwidth_id = bandwidth_id[0]
+        codes, _ = self.encodec.encode(features, mask, bandwidth=self.bandwidths[bandwidth_id])
+        return codes.reshape(codes.shape[-2], 1, codes.shape[-1])
+
+    def get_features_from_codes(self, codes) -> torch.Tensor:
+        """codes [nq, B, T] -> features [B, T, codebook_dim] (vocos.py:99-108)."""
+        codes = torch.as_tensor(codes)
+        if codes.shape[0] > self.num_q:
+            raise IndexError(f"get_features_from_codes: {codes.shape[0]} quantizers given, the extractor holds {self.num_q}")
+        return self.encodec.quantizer.decode(codes.permute(1, 0, 2))
+
+    def __call__(self, audio, **kwargs):
+        bandwidth_id = kwargs.get("bandwidth_id")
+        if bandwidth_id is None:
+            raise ValueError("The 'bandwidth_id' argument is required")
+        return self.get_features_from_codes(self.get_encodec_codes(audio, bandwidth_id=bandwidth_id))
 
 
 class _Norm:
@@ -208,15 +262,19 @@ class Vocos:
         self.feature_extractor, self.backbone, self.head = feature_extractor, backbone, head
 
     @classmethod
-    def from_hparams(cls, config: dict, weights: Optional[Dict[str, torch.Tensor]] = None, device="cuda:0", seed: int = 0) -> "Vocos":
+    def from_hparams(cls, config: dict, weights: Optional[Dict[str, torch.Tensor]] = None, device="cuda:0", seed: int = 0, encodec=None) -> "Vocos":
         """Model from the hyper-parameters of a Vocos ``config.yaml`` (vocos.py:288-303).  ``weights`` (extra): a parameter dict in the
-        reference's names; omitted, the parameters are random like a freshly constructed reference model."""
+        reference's names; omitted, the parameters are random like a freshly constructed reference model.  ``encodec`` (extra): the EnCodec model of
+        an ``EncodecFeatures`` extractor (the reference fetches it from the hub by name)."""
         ops.require_gpu()
         fe = config["feature_extractor"]
         if "MelSpectrogramFeatures" in fe["class_path"]:
             feature_extractor = MelSpectrogramFeatures(**fe["init_args"])
         elif "EncodecFeatures" in fe["class_path"]:
-            feature_extractor = None  # decode() with external features still works; __call__ raises
+            try:
+                feature_extractor = EncodecFeatures(**fe["init_args"], encodec=encodec, device=device)
+            except FileNotFoundError:   # hub name without a local model: decode() with external features still works; __call__ raises
+                feature_extractor = None
         else:
             raise ValueError(f"unknown feature extractor {fe['class_path']}")
         backbone = VocosBackbone(**config["backbone"]["init_args"])
@@ -257,16 +315,22 @@ class Vocos:
 
     def __call__(self, audio_input, **kwargs: Any):
         if self.feature_extractor is None:
-            raise NotImplementedError("this Vocos was configured with EncodecFeatures, which this build does not contain; use decode(features, bandwidth_id=...)")
+            raise FileNotFoundError("this Vocos was configured with EncodecFeatures by hub name and no EnCodec model was supplied "
+                                    "(from_hparams(..., encodec=<Encodec>)); decode(features, bandwidth_id=...) works without one")
         features = self.feature_extractor(audio_input, **kwargs)
         return self.decode(features, **kwargs)
 
     def get_encodec_codes(self, audio_input, bandwidth_id: int):
-        raise ValueError("This model does not support getting encodec codes.")
+        if not isinstance(self.feature_extractor, EncodecFeatures):
+            raise ValueError("This model does not support getting encodec codes.")
+        return self.feature_extractor.get_encodec_codes(audio_input, bandwidth_id)
 
     def decode(self, features_input, **kwargs: Any):
         x = self.backbone(features_input, **kwargs)
         return self.head(x)
 
     def decode_from_codes(self, codes, **kwargs: Any):
-        raise NotImplementedError("decode_from_codes needs the EnCodec codebooks (EncodecFeatures), which this build does not contain")
+        """vocos.py:372-375: codes [nq, B, T] -> audio."""
+        if not isinstance(self.feature_extractor, EncodecFeatures):
+            raise ValueError("decode_from_codes needs an EncodecFeatures extractor (its codebooks)")
+        return self.decode(self.feature_extractor.get_features_from_codes(codes), **kwargs)

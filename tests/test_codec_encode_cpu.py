@@ -225,3 +225,31 @@ def test_encodec_encode_host_schedule_dry_run():
             if eng.chunk_length is not None:
                 with pytest.raises(ValueError, match="not properly padded"):
                     eng.encode(x[:, :-1], m[:, :-1])
+
+
+def test_vocos_encodec_features_dry_run():
+    """``EncodecFeatures`` (codec/models/vocos/vocos.py:54-116) over the emulated operators: ``get_encodec_codes`` returns the reference run's codes in the
+    [nq, 1, T] layout, ``get_features_from_codes`` is the sum of the codebook rows; hub names without a local model fail loudly."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _ops_emu
+    from mlx_audio_amd.codec.models.encodec import Encodec
+    from mlx_audio_amd.codec.models.vocos import EncodecFeatures
+
+    fx = np.load(os.path.join(GOLD, "ref_encodec_encode_mono.npz"))
+    c, w = encodec_model_weights(fx)
+    with _ops_emu.patched():
+        enc = Encodec(c, weights=w, device="cpu")
+        fe = EncodecFeatures(bandwidths=c["target_bandwidths"], encodec=enc)
+        assert fe.num_q == 6 and tuple(fe.codebook_weights.shape) == (4 * c["codebook_size"], c["codebook_dim"])
+        codes = fe.get_encodec_codes(torch.from_numpy(fx["raw"][:, 0]), bandwidth_id=[1])
+        want = fx["codes_bw60.0"]                                  # [chunks = 1, B = 1, nq, T]
+        assert tuple(codes.shape) == (want.shape[2], 1, want.shape[3]) and np.array_equal(codes[:, 0].numpy(), want[0, 0])
+        feats = fe(torch.from_numpy(fx["raw"][:, 0]), bandwidth_id=torch.tensor([1]))
+        rows = sum(w[f"quantizer.layers.{i}.codebook.embed"][codes[i, 0]] for i in range(codes.shape[0]))
+        assert tuple(feats.shape) == (1, want.shape[3], c["codebook_dim"]) and rel_max(feats[0].numpy(), rows.numpy()) < 1e-6
+        with pytest.raises(ValueError, match="bandwidth_id"):
+            fe(torch.zeros(100))
+    with pytest.raises(FileNotFoundError, match="not reachable"):
+        EncodecFeatures()
+    with pytest.raises(ValueError, match="Unsupported encodec_model"):
+        EncodecFeatures(encodec_model="encodec_16khz")

@@ -339,3 +339,38 @@ def test_encodec_24khz_encode_stages_and_codes_vs_oracle():
     assert tuple(audio.shape) == (1, 76 * 320, 1) and torch.isfinite(audio).all()
     for bw, nq in ((1.5, 2), (6.0, 8)):
         assert tuple(eng.encode(x, None, bandwidth=bw)[0].shape) == (1, 1, nq, 76)
+
+
+def test_vocos_with_encodec_features():
+    """``Vocos`` over ``EncodecFeatures`` (codec/models/vocos/vocos.py:54-116, 350-375): audio -> EnCodec codes -> summed codebook rows -> backbone -> iSTFT.
+    ``__call__`` equals ``decode(features)`` and ``decode_from_codes(codes)``; the codes are the EnCodec engine's own."""
+    from mlx_audio_amd.codec.models.encodec import Encodec
+    from mlx_audio_amd.codec.models.vocos import EncodecFeatures, Vocos
+    from test_codec_encode_cpu import encodec_model_weights
+
+    fx = np.load(os.path.join(GOLD, "ref_encodec_encode_mono.npz"))
+    c, w = encodec_model_weights(fx)
+    enc = Encodec(c, weights=w, device=DEV)
+    cfg = {"feature_extractor": {"class_path": "vocos.feature_extractors.EncodecFeatures", "init_args": {"encodec_model": "encodec_24khz", "bandwidths": c["target_bandwidths"]}},
+           "backbone": {"class_path": "vocos.models.VocosBackbone",
+                        "init_args": {"input_channels": c["codebook_dim"], "dim": 64, "intermediate_dim": 192, "num_layers": 2, "adanorm_num_embeddings": 2}},
+           "head": {"class_path": "vocos.heads.ISTFTHead", "init_args": {"dim": 64, "n_fft": 64, "hop_length": 16, "padding": "same"}}}
+    v = Vocos.from_hparams(cfg, device=DEV, seed=3, encodec=enc)
+    assert isinstance(v.feature_extractor, EncodecFeatures) and v.feature_extractor.num_q == 6   # floor(60 kbps / 9 kbps per layer); the model holds 4
+    audio = torch.from_numpy(fx["raw"][:, 0])
+    bw = torch.tensor([[1.0, 1.0]])                                  # index 1 for the extractor, the conditioning vector of the AdaLayerNorms
+    codes = v.get_encodec_codes(audio, bandwidth_id=bw)
+    want, _ = enc.encode(*v.feature_extractor.preprocessor(audio), bandwidth=c["target_bandwidths"][1])
+    assert tuple(codes.shape) == (4, 1, want.shape[-1]) and torch.equal(codes[:, 0], want[0, 0])
+    feats = v.feature_extractor.get_features_from_codes(codes)
+    rows = sum(w[f"quantizer.layers.{i}.codebook.embed"][codes[i, 0].cpu()] for i in range(4))
+    assert rel_peak(feats[0], rows) < 1e-6
+    y = v(audio, bandwidth_id=bw)
+    y2 = v.decode(feats, bandwidth_id=bw)
+    y3 = v.decode_from_codes(codes, bandwidth_id=bw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all() and y.numel() >= (want.shape[-1] - 1) * 16 and torch.equal(y, y2) and torch.equal(y, y3)
+    none = Vocos.from_hparams(cfg, device=DEV, seed=3)             # hub name, no model: decode works, __call__ is loud
+    assert none.feature_extractor is None and torch.equal(none.decode(feats, bandwidth_id=bw), y)
+    with pytest.raises(FileNotFoundError):
+        none(audio, bandwidth_id=bw)

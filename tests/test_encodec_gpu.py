@@ -102,7 +102,7 @@ def test_encodec_24khz_shapes_chunked_decode_and_batch():
     want = ref_c.decode(chunks, scales)
     assert got.shape == want.shape == (2, 2 * 1600 + 3200, 1)
     assert float((got - want).abs().max()) <= 2e-3 * float(want.abs().max()) and snr_db(got, want) >= 50.0
-    with pytest.raises(NotImplementedError):
-        eng.encode(torch.zeros(1, 100, 1))
+    with pytest.raises(ValueError, match="decode-only"):   # loaded without encoder weights (tests/test_codec_encode_gpu.py has the encode side)
+        eng.encode(torch.zeros(1, 100, 1), bandwidth=eng.c["target_bandwidths"][0])
     with pytest.raises(ValueError):
         eng.decode(torch.zeros(2, 2, 8, 5, dtype=torch.long), [None])

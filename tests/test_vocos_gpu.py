@@ -120,7 +120,11 @@ def test_adanorm_model_decode_batch_and_errors():
     assert snr_db(both[0], got0) > 100.0 and snr_db(both[1], want1) > 80.0
     with pytest.raises(AssertionError):
         eng.decode(feats[:1])                       # AdaLayerNorm without bandwidth_id (vocos.py:259-261)
-    with pytest.raises(NotImplementedError):
-        eng(torch.zeros(24000), bandwidth_id=bw)    # EncodecFeatures is not part of this build: loud, no fallback
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(FileNotFoundError):
+        eng(torch.zeros(24000), bandwidth_id=bw)    # EncodecFeatures by hub name and no EnCodec model supplied: loud, no fallback
+    with pytest.raises(FileNotFoundError):
         EncodecFeatures()
+    with pytest.raises(ValueError):
+        EncodecFeatures(encodec_model="encodec_16khz")
+    with pytest.raises(ValueError):
+        eng.decode_from_codes(torch.zeros(2, 1, 5, dtype=torch.long))
