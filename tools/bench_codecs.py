@@ -54,6 +54,66 @@ def line(name, workload, sr, n_samples, B, wall_ms, dev_ms, roof, dtype):
             "config": {"workload": workload, "batch": B, "samples_per_item": n_samples, "sample_rate": sr}, "x_realtime": total / sr / (dev_ms * 1e-3), "roofline": roof}
 
 
+def enc_line(name, workload, sr, n_samples, B, wall_ms, dev_ms, roof, dtype, frames, n_codes):
+    d = line(name, workload, sr, n_samples, B, wall_ms, dev_ms, roof, dtype)
+    d["metric"] = f"audio samples encoded per second, {name} encode, 1 MI355X"
+    d["config"].update(frames_per_item=frames, codes_per_item=n_codes)
+    if roof is not None:
+        roof["kernel"] = "conv_gemm (all launches of one encode pass: encoder convs, in_proj)"
+    return d
+
+
+def encode_lines(args, dev, g, dt16):
+    """waveform [B, 1, S] -> codes; synthetic weights of the published shapes (encoder halves from make_*_encoder_weights), audio resident in HBM."""
+    B = args.batch
+
+    def audio(sr, hop_multiple):
+        n = int(args.seconds * sr) // hop_multiple * hop_multiple
+        return (0.3 * torch.randn(B, 1, n, generator=g)).to(dev), n
+
+    if args.only in ("", "dac"):
+        from mlx_audio_amd.codec.models.descript import DAC, make_dac_encoder_weights, make_dac_weights
+
+        w = make_dac_weights(1536, [8, 8, 4, 2], 1024, 9, 1024, 8, seed=0)
+        w.update(make_dac_encoder_weights(64, [2, 4, 8, 8], 1024, 9, 8, seed=0))
+        eng = DAC(encoder_dim=64, encoder_rates=[2, 4, 8, 8], decoder_dim=1536, decoder_rates=[8, 8, 4, 2], n_codebooks=9, codebook_size=1024, codebook_dim=8,
+                  sample_rate=44100, weights=w, device=dev)
+        x, n = audio(44100, 512)
+        fn = lambda: eng.encode(x)[1]  # noqa: E731
+        out, wall, dms = timed(fn, args.steps, args.warmup)
+        print(json.dumps(enc_line("DAC 44 kHz (encoder_dim 64, rates 2/4/8/8, latent 1024, 9 codebooks of 1024 x 8)", f"{B} x {n} samples -> codes (encoder + 9-level residual search)",
+                                  44100, n, B, wall, dms, conv_roofline(fn), dt16, int(out.shape[2]), int(out.shape[1] * out.shape[2]))))
+
+    if args.only in ("", "snac"):
+        from mlx_audio_amd.codec.models.snac import SNAC, make_snac_encoder_weights, make_snac_weights
+
+        w = make_snac_weights(768, 1024, [8, 8, 4, 2], [4, 2, 1], 4096, 8, True, True, seed=0)
+        w.update(make_snac_encoder_weights(48, [2, 4, 8, 8], 768, [4, 2, 1], 8, True, seed=0))
+        eng = SNAC(sampling_rate=24000, encoder_dim=48, encoder_rates=[2, 4, 8, 8], decoder_dim=1024, decoder_rates=[8, 8, 4, 2], attn_window_size=None,
+                   codebook_size=4096, codebook_dim=8, vq_strides=[4, 2, 1], noise=True, depthwise=True, weights=w, device=dev)
+        x, n = audio(24000, 512 * 4)
+        fn = lambda: eng.encode(x)  # noqa: E731
+        out, wall, dms = timed(fn, args.steps, args.warmup)
+        print(json.dumps(enc_line("SNAC 24 kHz (encoder_dim 48, rates 2/4/8/8, depthwise, 3 code levels of 4096 x 8)", f"{B} x {n} samples -> codes (encoder + 3-level multi-scale search)",
+                                  24000, n, B, wall, dms, conv_roofline(fn), dt16, int(out[-1].shape[1]), int(sum(c.shape[1] for c in out)))))
+
+    if args.only in ("", "encodec"):
+        from mlx_audio_amd.codec.models.encodec import Encodec, make_encodec_encoder_weights, make_encodec_weights
+
+        c = dict(upsampling_ratios=[8, 5, 4, 2], target_bandwidths=[1.5, 3.0, 6.0, 12.0, 24.0])
+        w = make_encodec_weights(c, seed=0)
+        w.update(make_encodec_encoder_weights(c, seed=0))
+        eng = Encodec(c, weights=w, device=dev)
+        x, n = audio(24000, 320)
+        xin = x.transpose(1, 2).contiguous()          # [B, samples, 1]
+        fn = lambda: eng.encode(xin, None, bandwidth=6.0)[0]  # noqa: E731
+        out, wall, dms = timed(fn, args.steps, args.warmup)
+        T = int(out.shape[-1])
+        print(json.dumps(enc_line("EnCodec 24 kHz (32 filters, rates 2/4/5/8, two 512-wide LSTM layers, 6 kbps = 8 of 32 codebooks)",
+                                  f"{B} x {n} samples -> codes (SEANet encoder; LSTM = {2 * T} per-step launch pairs; one rvq_encode launch)", 24000, n, B, wall, dms,
+                                  conv_roofline(fn), dt16, T, 8 * T)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
@@ -61,11 +121,15 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--only", default="")
+    ap.add_argument("--encode", action="store_true", help="the ENCODE lines instead (round 5): DAC / SNAC / EnCodec waveform -> codes (encoder + residual codebook search)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     B = args.batch
     g = torch.Generator().manual_seed(0)
     dt16 = "fp32 checkpoints held as fp16 MFMA images x fp32 activations (fp16 hi+lo split, fp32 accumulate)"
+
+    if args.encode:
+        return encode_lines(args, dev, g, dt16)
 
     if args.only in ("", "vocos"):
         from mlx_audio_amd.codec.models.vocos import Vocos
