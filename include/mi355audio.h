@@ -807,7 +807,11 @@ typedef struct {
  * Unidirectional LSTM over a whole sequence, any hidden size (EnCodec's two 512-wide layers, codec/models/encodec/encodec.py:89-167: the
  * reference's Metal `lstm` kernel + one matmul per step).  xproj [B, T, 4H] = x @ Wx^T + bias for all steps (the caller's GEMM), gate chunks in the
  * order i | f | g | o; wh: row-major 16-bit image [4H, H] (mi355_pack_rowmajor16_host); h, c [B, H] fp32 state (in: initial, normally zeros; out:
- * final); pre [B, 4H] scratch; out [B, T, H].  Two launches per time step (mi355_gemv with the x-projection row as residual, then the gates).
+ * final); pre [B, 4H] scratch; out [B, T, H].  Two launches per time step (mi355_gemv with the x-projection row as residual, then the gates) --
+ * or ONE (round 5, ABI 32): with gate_interleaved = 1 the rows of `wh` are ordered by hidden unit (row 4 j + g = gate g of unit j instead of the
+ * reference's g H + j), so a 16-row tile of the step's GEMM holds all four gates of four units and the gates, the cell update and the stores of h
+ * are that GEMM's epilogue; h then ping-pongs between `h` and the scratch `h2` (every workgroup reads the whole previous h), the final state ends
+ * up in `h`.  Needs H % 64 == 0; `pre` is not used.
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
   const float* xproj; int64_t xproj_bstride; int32_t ld_xproj;
@@ -815,6 +819,8 @@ typedef struct {
   float* h; float* c; float* pre;
   float* out; int64_t out_bstride; int32_t ld_out;
   int32_t B; int32_t T; int32_t H;
+  int32_t gate_interleaved;   /* 0: wh rows in the reference's i | f | g | o blocks (two launches per step); 1: row 4 j + g (one launch per step) */
+  float* h2;                  /* [B, H] scratch, gate_interleaved = 1 only */
 } mi355_lstm_seq_args;
 int mi355_lstm_seq(const mi355_lstm_seq_args* a, void* stream);
 

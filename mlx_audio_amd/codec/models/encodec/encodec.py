@@ -10,7 +10,8 @@ Mirrors ``mlx_audio/codec/models/encodec/encodec.py`` (``EncodecConfig``, ``prep
   * the reference pads explicitly before every conv (causal: everything on the left; reflect or zero, encodec.py:213-254); reflect padding is
     a gather of the first / last rows here (the padded rows are materialised, the ELU prologue commutes with the gather);
   * ``EncodecLSTM`` (encodec.py:137-167, 296-306): the x-projection of all time steps is ONE GEMM, the recurrence runs in the native per-step
-    loop of ``mi355_lstm_seq`` (csrc/lstm_seq.hip: 2 MB of Wh per layer do not fit the persistent one-CU kernel of the Kokoro LSTMs); the
+    loop of ``mi355_lstm_seq`` (csrc/lstm_seq.hip: 2 MB of Wh per layer do not fit the persistent one-CU kernel of the Kokoro LSTMs) -- ONE launch per
+    step since round 5 (``ops.pack_lstm_seq_wh`` orders the rows of Wh by hidden unit, so the gates are the epilogue of the step's GEMM); the
     reference's own Metal ``lstm`` kernel lives here (its gate order i | f | g | o and its sigmoid are reproduced).
 Encode side (round 5; encodec.py:340-389, 445-533, 556-650), from the same kernels: the first conv runs FLATTENED over the (reflect-) padded samples
 (K taps x audio channels = the "channels" of a one-tap conv); a resnet block is conv k3 (ELU prologue) -> shortcut conv -> conv k1 accumulating onto
@@ -279,7 +280,7 @@ class Encodec:
         for l in range(c["num_lstm_layers"]):
             p = f"{names['lstm']}.lstm.{l}."
             wx = w[p + "Wx"]
-            self.lstm.append(dict(wx=ops.pack_conv(wx[:, None, :], w.get(p + "bias"), dev, f16=True), wh=ops.pack_rowmajor16(w[p + "Wh"], None, dev, f16=True),
+            self.lstm.append(dict(wx=ops.pack_conv(wx[:, None, :], w.get(p + "bias"), dev, f16=True), wh=ops.pack_lstm_seq_wh(w[p + "Wh"], dev, f16=True),
                                   H=wx.shape[0] // 4))
         self.blocks = []
         for blk, ratio in zip(names["blocks"], c["upsampling_ratios"]):
@@ -309,7 +310,7 @@ class Encodec:
             for l in range(c["num_lstm_layers"]):
                 p = f"{en['lstm']}.lstm.{l}."
                 wx = w[p + "Wx"]
-                elstm.append(dict(wx=ops.pack_conv(wx[:, None, :], w.get(p + "bias"), dev, f16=True), wh=ops.pack_rowmajor16(w[p + "Wh"], None, dev, f16=True), H=wx.shape[0] // 4))
+                elstm.append(dict(wx=ops.pack_conv(wx[:, None, :], w.get(p + "bias"), dev, f16=True), wh=ops.pack_lstm_seq_wh(w[p + "Wh"], dev, f16=True), H=wx.shape[0] // 4))
             self.enc = dict(stem=stem, k0=w0.shape[1], blocks=eblocks, lstm=elstm, out=conv(en["conv_out"]))
         return self
 

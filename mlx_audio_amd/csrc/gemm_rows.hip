@@ -72,8 +72,23 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int MR, bool F16>
-__global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mi355_gemv_args a, const int ntiles, const int dbg) {
+// LSTM mode (mi355_lstm_seq with gate-interleaved Wh rows, lstm_seq.hip): the GEMM is one recurrence step pre = h @ Wh^T; its epilogue adds the
+// x-projection row, applies the gates (the reference's Metal kernel: codec/models/encodec/encodec.py:89-134 -- chunks i | f | g | o, sigmoid as
+// 1 / (1 + exp(-|x|)) mirrored for x < 0, precise tanh), updates c in place and stores the new h to the OTHER h buffer (a.y) and to row t of the output
+struct rows_lstm_t {
+  const float* xproj; int64_t xproj_bstride;   // row t of the x-projection of sequence m: xproj + m * xproj_bstride, gate blocks of H
+  float* c;                                     // [B, H]
+  float* out; int64_t out_bstride;              // row t of the output of sequence m
+  int H;
+};
+
+__device__ __forceinline__ float rows_lstm_sigmoid(const float x) {
+  const float y = 1.0f / (1.0f + expf(-fabsf(x)));
+  return x < 0.f ? 1.0f - y : y;
+}
+
+template <int MR, bool F16, bool LSTM = false>
+__global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mi355_gemv_args a, const int ntiles, const int dbg, const rows_lstm_t L) {
   using C = rows_cfg<MR>;
   constexpr int R = C::R, KC = C::KC, SPW = C::SPW, T = C::T, P = C::P;
   constexpr int IMGW = SPW * 8 * R;     // 16-byte pieces per image of ONE wave's window
@@ -260,6 +275,20 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mi355_gemv_args
           const int o = (j * MR + r) * 256 + ii * 16 + ml;
           return (red[o] + red[T * MR * 256 + o]) + (red[2 * T * MR * 256 + o] + red[3 * T * MR * 256 + o]);
         };
+        if constexpr (LSTM) {   // rows of W come as (i, f, g, o) of one hidden unit: the first thread of a quad finishes the unit
+          if (i & 3) continue;
+          const int j = n >> 2;
+          const float* xp = L.xproj + (int64_t)m * L.xproj_bstride + j;
+          const float gi_ = rows_lstm_sigmoid(part(i) + xp[0]), gf = rows_lstm_sigmoid(part(i + 1) + xp[L.H]);
+          const float gg = tanhf(part(i + 2) + xp[2 * L.H]), go = rows_lstm_sigmoid(part(i + 3) + xp[3 * L.H]);
+          const int64_t ci = (int64_t)m * L.H + j;
+          const float cn = gf * L.c[ci] + gi_ * gg;
+          const float hn = go * tanhf(cn);
+          L.c[ci] = cn;
+          a.y[(int64_t)m * a.ldy + j] = hn;
+          L.out[(int64_t)m * L.out_bstride + j] = hn;
+          continue;
+        }
         const float v0 = part(i);
         if (a.glu) {   // rows of W come in (gate, up) pairs: the even thread of a pair finishes both
           if (i & 1) continue;
@@ -277,12 +306,12 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mi355_gemv_args
   }
 }
 
-template <int MR, bool F16>
-int launch_rows(const mi355_gemv_args& a, hipStream_t st) {
+template <int MR, bool F16, bool LSTM = false>
+int launch_rows(const mi355_gemv_args& a, hipStream_t st, const rows_lstm_t L = rows_lstm_t{}) {
   static bool attr_set = false;  // benign race: the attribute is idempotent
   constexpr size_t lds = 64 * 1024;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_rows_kernel<MR, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_rows_kernel<MR, F16, LSTM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     MI355_REQUIRE(e == hipSuccess, "gemv(rows): cannot reserve LDS: %s", hipGetErrorString(e));
     attr_set = true;
   }
@@ -292,7 +321,7 @@ int launch_rows(const mi355_gemv_args& a, hipStream_t st) {
   const int grid = ntiles < cap ? ntiles : cap;
   MI355_CLEAR_ERROR();
   static const int dbg = getenv("MI355_GEMM_ROWS_DBG") ? atoi(getenv("MI355_GEMM_ROWS_DBG")) : 0;   // ablation bits (timing experiments only)
-  hipLaunchKernelGGL((gemm_rows_kernel<MR, F16>), dim3(grid), dim3(256), lds, st, a, ntiles, dbg);
+  hipLaunchKernelGGL((gemm_rows_kernel<MR, F16, LSTM>), dim3(grid), dim3(256), lds, st, a, ntiles, dbg, L);
   MI355_LAUNCH_CHECK("gemv(9..64 rows, matrix pipe)");
   return MI355_OK;
 }
@@ -314,4 +343,14 @@ int mi355_gemm_rows_launch(const mi355_gemv_args& a, hipStream_t st) {
   if (a.M <= 16) return f16 ? launch_rows<1, true>(a, st) : launch_rows<1, false>(a, st);
   if (a.M <= 32) return f16 ? launch_rows<2, true>(a, st) : launch_rows<2, false>(a, st);
   return f16 ? launch_rows<4, true>(a, st) : launch_rows<4, false>(a, st);
+}
+
+// One step of mi355_lstm_seq on gate-interleaved Wh rows (lstm_seq.hip): a = { x = h_in [B, H], w = Wh [4 H, H] (row 4 j + g), y = h_out, ldy = H, M = B, K = H,
+// N = 4 H }; any B in 1..64 (rows >= B of the MFMA column space are staged as zeros and never stored)
+int mi355_gemm_rows_lstm_step(const mi355_gemv_args& a, const float* xproj, int64_t xproj_bstride, float* c, float* out, int64_t out_bstride, hipStream_t st) {
+  const rows_lstm_t L{xproj, xproj_bstride, c, out, out_bstride, a.K};
+  const bool f16 = a.wdtype == MI355_W_F16;
+  if (a.M <= 16) return f16 ? launch_rows<1, true, true>(a, st, L) : launch_rows<1, false, true>(a, st, L);
+  if (a.M <= 32) return f16 ? launch_rows<2, true, true>(a, st, L) : launch_rows<2, false, true>(a, st, L);
+  return f16 ? launch_rows<4, true, true>(a, st, L) : launch_rows<4, false, true>(a, st, L);
 }

@@ -8,6 +8,9 @@
 //               x-projection row rides in as the residual operand, 1..64 sequences per step)
 //   lstm_gates_kernel: c = f * c + i * g,  h = o * tanh(c),  h also stored as row t of the output.
 // T x 2 dependent launches (~3 us each): 750 steps of a 10 s clip cost ~5 ms per layer regardless of the batch.
+// Round 5: ONE launch per step when the caller hands Wh with its rows ordered by hidden unit (gate_interleaved: row 4 j + g) -- a 16-row tile of the
+// step's GEMM then holds all four gates of four units and the gates / cell update / stores are the GEMM's own epilogue (gemm_rows.hip, LSTM mode);
+// h ping-pongs between two buffers because every workgroup of a step reads the whole previous h.
 #include <string.h>
 #include "common.h"
 
@@ -34,6 +37,8 @@ __global__ __launch_bounds__(256) void lstm_gates_kernel(const float* __restrict
 
 }  // namespace
 
+int mi355_gemm_rows_lstm_step(const mi355_gemv_args& a, const float* xproj, int64_t xproj_bstride, float* c, float* out, int64_t out_bstride, hipStream_t st);   // gemm_rows.hip
+
 extern "C" int mi355_lstm_seq(const mi355_lstm_seq_args* ap, void* stream) {
   MI355_REQUIRE(ap && ap->xproj && ap->wh && ap->h && ap->c && ap->pre && ap->out, "lstm_seq: null tensor");
   const mi355_lstm_seq_args a = *ap;
@@ -42,6 +47,26 @@ extern "C" int mi355_lstm_seq(const mi355_lstm_seq_args* ap, void* stream) {
   MI355_REQUIRE(a.ld_xproj >= 4 * a.H && a.ld_out >= a.H && a.xproj_bstride >= (int64_t)a.T * a.ld_xproj && a.out_bstride >= (int64_t)a.T * a.ld_out,
                 "lstm_seq: bad strides");
   hipStream_t st = (hipStream_t)stream;
+  if (a.gate_interleaved) {
+    MI355_REQUIRE(a.h2 && a.H % 64 == 0 && ((uintptr_t)a.wh) % 16 == 0 && ((uintptr_t)a.h) % 16 == 0 && ((uintptr_t)a.h2) % 16 == 0,
+                  "lstm_seq: the one-launch step needs the h2 scratch, H %% 64 == 0 and 16-byte aligned wh / h / h2 (H = %d)", a.H);
+    MI355_REQUIRE(a.wdtype == MI355_W_BF16 || a.wdtype == MI355_W_F16, "lstm_seq: wdtype must be MI355_W_BF16 or MI355_W_F16");
+    float* hin = a.h;
+    float* hout = a.h2;
+    for (int t = 0; t < a.T; ++t) {
+      mi355_gemv_args g;
+      memset(&g, 0, sizeof(g));
+      g.x = hin; g.ldx = a.H; g.M = a.B; g.K = a.H; g.w = a.wh; g.ldw = a.H; g.wdtype = a.wdtype; g.N = 4 * a.H; g.out_scale = 1.f; g.y = hout; g.ldy = a.H;
+      const int rc = mi355_gemm_rows_lstm_step(g, a.xproj + (int64_t)t * a.ld_xproj, a.xproj_bstride, a.c, a.out + (int64_t)t * a.ld_out, a.out_bstride, st);
+      if (rc) return rc;
+      float* tmp = hin; hin = hout; hout = tmp;
+    }
+    if (hin != a.h) {   // an odd number of steps left the final state in the scratch
+      hipError_t e = hipMemcpyAsync(a.h, hin, sizeof(float) * (size_t)a.B * a.H, hipMemcpyDeviceToDevice, st);
+      MI355_REQUIRE(e == hipSuccess, "lstm_seq: copy of the final state failed: %s", hipGetErrorString(e));
+    }
+    return MI355_OK;
+  }
   for (int t = 0; t < a.T; ++t) {
     mi355_gemv_args g;
     memset(&g, 0, sizeof(g));

@@ -144,6 +144,7 @@ class RowMajor16:
     k: int
     f16: bool
     scale: Optional[torch.Tensor] = None  # fp8 image only: per-row power-of-two dequantisation scale [N] fp32 (device)
+    interleaved: bool = False             # recurrent weights of mi355_lstm_seq with their rows ordered by hidden unit (row 4 j + gate): the one-launch step
 
     @property
     def wdtype(self) -> int:
@@ -374,18 +375,34 @@ def pack_lstm_wh_scaled(wh_f: torch.Tensor, wh_b: torch.Tensor, device):
     return img, 2.0 ** -k
 
 
+def pack_lstm_seq_wh(wh: torch.Tensor, device, f16: bool = False) -> RowMajor16:
+    """Recurrent weights ``Wh`` [4H, H] (gate blocks i | f | g | o, the reference's layout) for ``lstm_seq``.  For H % 64 == 0 the rows are re-ordered by
+    hidden unit (row 4 j + g): a 16-row tile of the step's GEMM then holds the four gates of four units and the whole step is ONE launch (gates in the
+    GEMM's epilogue); other sizes keep the block order and the two-launch step.  ``MI355_LSTM_SEQ_FUSED=0`` keeps the block order everywhere (A/B)."""
+    wh = wh.detach().to(torch.float32).cpu()
+    h4, h = wh.shape
+    assert h4 == 4 * h, wh.shape
+    fused = h % 64 == 0 and os.environ.get("MI355_LSTM_SEQ_FUSED", "1") != "0"
+    if fused:
+        wh = wh.view(4, h, h).permute(1, 0, 2).reshape(4 * h, h).contiguous()
+    rm = pack_rowmajor16(wh, None, device, f16=f16)
+    rm.interleaved = fused
+    return rm
+
+
 def lstm_seq(xproj: torch.Tensor, wh: RowMajor16, out: torch.Tensor, h0: Optional[torch.Tensor] = None, c0: Optional[torch.Tensor] = None):
     """Unidirectional LSTM recurrence of any hidden size (``mi355_lstm_seq``): ``xproj`` [B, T, 4H] = x @ Wx^T + b (gate order i | f | g | o), ``wh`` the
-    row-major 16-bit image of Wh [4H, H], ``out`` [B, T, H].  Returns (h_T, c_T)."""
+    row-major 16-bit image of Wh [4H, H] (``pack_lstm_seq_wh``), ``out`` [B, T, H].  Returns (h_T, c_T)."""
     B, T, H4 = xproj.shape
     H = H4 // 4
     assert wh.n == H4 and wh.k == H and wh.scale is None and out.shape == (B, T, H) and xproj.stride(2) == 1 and out.stride(2) == 1
     h = torch.zeros((B, H), dtype=torch.float32, device=xproj.device) if h0 is None else h0.to(torch.float32).contiguous().clone()
     c = torch.zeros((B, H), dtype=torch.float32, device=xproj.device) if c0 is None else c0.to(torch.float32).contiguous().clone()
     pre = torch.empty((B, H4), dtype=torch.float32, device=xproj.device)
+    h2 = torch.empty_like(h) if wh.interleaved else None
     _lib.call_struct("mi355_lstm_seq", "mi355_lstm_seq_args", _stream(), xproj=_ptr(xproj), xproj_bstride=xproj.stride(0), ld_xproj=xproj.stride(1),
                      wh=_ptr(wh.w), wdtype=wh.wdtype, h=_ptr(h), c=_ptr(c), pre=_ptr(pre), out=_ptr(out), out_bstride=out.stride(0), ld_out=out.stride(1),
-                     B=B, T=T, H=H)
+                     B=B, T=T, H=H, gate_interleaved=int(wh.interleaved), h2=_ptr(h2))
     return h, c
 
 

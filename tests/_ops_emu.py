@@ -51,6 +51,10 @@ def pack_rowmajor16(w, bias, device, f16=False):
     return ops.RowMajor16(w.detach().double(), None if bias is None else bias.detach().double(), n, k, f16)
 
 
+def pack_lstm_seq_wh(wh, device, f16=False):
+    return pack_rowmajor16(wh, None, device, f16)   # block order: the emulated recurrence reads Wh as the reference does
+
+
 def conv_gemm(x, pc, y, *, dil=1, pad=0, lens_in=None, lens_out=None, lout=None, pre=None, pre_act=ACT_NONE, pre_slope=0.0, pre_alpha=None,
               post_act=ACT_NONE, post_slope=0.0, res=None, res_shift=0, out_scale=1.0, accumulate=False, up=None, precision=2, tile=0, flat=None,
               use_bias=True, stats=None, pre_inv_beta=None, colscale=None, x_off=0, flatten=False, pre_fq=None):
@@ -182,7 +186,7 @@ def lstm_seq(xproj, wh, out, h0=None, c0=None):
 
 @contextlib.contextmanager
 def patched():
-    names = dict(require_gpu=lambda: None, pack_conv=pack_conv, pack_conv_transpose=pack_conv_transpose, pack_rowmajor16=pack_rowmajor16, conv_gemm=conv_gemm,
+    names = dict(require_gpu=lambda: None, pack_conv=pack_conv, pack_conv_transpose=pack_conv_transpose, pack_rowmajor16=pack_rowmajor16, pack_lstm_seq_wh=pack_lstm_seq_wh, conv_gemm=conv_gemm,
                  embed_sum=embed_sum, rvq_encode=rvq_encode, dwconv=dwconv, lstm_seq=lstm_seq)
     saved = {k: getattr(ops, k) for k in names}
     try:

@@ -22,10 +22,12 @@ def rel_err(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-@pytest.mark.parametrize("B,T,H", [(1, 40, 64), (3, 75, 512), (12, 9, 128)])
+@pytest.mark.parametrize("B,T,H", [(1, 40, 64), (3, 75, 512), (12, 9, 128), (16, 33, 512), (40, 8, 64), (64, 5, 128)])
 def test_lstm_seq_vs_float64(B, T, H):
-    """``mi355_lstm_seq`` (x-projection given, per-step GEMV + the gates of the reference's Metal kernel, encodec.py:89-167) against float64, for the
-    EnCodec width (512: Wh = 2 MB, the case the persistent one-CU LSTM cannot hold), 1..8 sequences (GEMV kernels) and 12 (the 9..64-row kernel)."""
+    """``mi355_lstm_seq`` against float64 (x-projection given; the gates of the reference's Metal kernel, encodec.py:89-167), for the EnCodec width
+    (512: Wh = 2 MB, the case the persistent one-CU LSTM cannot hold), odd and even step counts, 1 .. 64 sequences -- in BOTH forms: the one-launch step
+    (``pack_lstm_seq_wh``: rows of Wh ordered by hidden unit, gates in the step GEMM's epilogue; round 5) and the two-launch step on block-ordered rows
+    (GEMV kernels up to 8 sequences, the 9..64-row kernel above).  The two forms run the same GEMM arithmetic from 9 sequences on: equal to an ulp there."""
     from mlx_audio_amd import ops
     from oracle.encodec_ref import lstm_sigmoid
 
@@ -33,9 +35,6 @@ def test_lstm_seq_vs_float64(B, T, H):
     g = torch.Generator().manual_seed(B + T + H)
     wh = (torch.randn(4 * H, H, generator=g) / math.sqrt(H)).half().float()
     xp = torch.randn(B, T, 4 * H, generator=g)
-    out = torch.empty(B, T, H, device=DEV)
-    hT, cT = ops.lstm_seq(xp.to(DEV), ops.pack_rowmajor16(wh, None, DEV, f16=True), out)
-    torch.cuda.synchronize()
     h, c, exp = torch.zeros(B, H, dtype=torch.float64), torch.zeros(B, H, dtype=torch.float64), []
     for t in range(T):
         gts = h @ wh.double().t() + xp[:, t].double()
@@ -44,7 +43,29 @@ def test_lstm_seq_vs_float64(B, T, H):
         h = o * torch.tanh(c)
         exp.append(h)
     exp = torch.stack(exp, 1)
-    assert rel_err(out, exp) < 2e-5 and rel_err(hT, h) < 2e-5 and rel_err(cT, c) < 2e-5
+    fused = ops.pack_lstm_seq_wh(wh, DEV, f16=True)
+    assert fused.interleaved   # every H here is a multiple of 64
+    res = {}
+    for name, img in (("one launch per step", fused), ("two launches per step", ops.pack_rowmajor16(wh, None, DEV, f16=True))):
+        out = torch.full((B, T, H), float("nan"), device=DEV)
+        hT, cT = ops.lstm_seq(xp.to(DEV), img, out)
+        torch.cuda.synchronize()
+        assert rel_err(out, exp) < 2e-5 and rel_err(hT, h) < 2e-5 and rel_err(cT, c) < 2e-5, (name, rel_err(out, exp), rel_err(hT, h), rel_err(cT, c))
+        res[name] = (out.clone(), hT.clone(), cT.clone())
+    a, b = res["one launch per step"], res["two launches per step"]
+    if B >= 9:   # same GEMM arithmetic; the cell update may contract differently in the two kernels (an ulp)
+        assert all(rel_err(x, y) < 1e-6 for x, y in zip(a, b)), [rel_err(x, y) for x, y in zip(a, b)]
+    # a second call on a carried state continues the sequence (h0 / c0 in, odd number of steps: the final state comes back from the scratch buffer)
+    out2 = torch.empty((B, 3, H), device=DEV)
+    x3 = torch.randn(B, 3, 4 * H, generator=g)
+    h3, c3 = ops.lstm_seq(x3.to(DEV), fused, out2, h0=a[1], c0=a[2])
+    hh, cc = h.clone(), c.clone()
+    for t in range(3):
+        gts = hh @ wh.double().t() + x3[:, t].double()
+        i, f, gg, o = lstm_sigmoid(gts[:, :H]), lstm_sigmoid(gts[:, H:2 * H]), torch.tanh(gts[:, 2 * H:3 * H]), lstm_sigmoid(gts[:, 3 * H:])
+        cc = f * cc + i * gg
+        hh = o * torch.tanh(cc)
+    assert rel_err(h3, hh) < 5e-5 and rel_err(c3, cc) < 5e-5 and rel_err(out2[:, -1], hh) < 5e-5
 
 
 def test_encodec_engine_vs_reference_run():
