@@ -139,10 +139,21 @@ typedef struct {
      the utterance, both joined with 0, as mi355_fake_quant_extrema leaves them; the prologue then ends with the reference's dynamic uint8
      quantise / dequantise of every value (float32 op by op), so the quantised tensor is never materialised.  NULL = no quantisation. */
   const float* pre_fq;
+  /* optional per-block extrema of the STORED output (round 5, ABI 33; KittenTTS): (min, max) per block of MI355_STATS_ROWS output rows and per channel,
+     written (never accumulated) to ext_partial[b][row / MI355_STATS_ROWS][c][0..1], laid out like stats_partial.  The producer of a fake-quantised
+     conv's input thereby hands over what that conv's extrema pass (mi355_fake_quant_extrema: one more read of the whole tensor) would compute: every
+     quantised prologue in use is monotone per channel, so mi355_fake_quant_extrema_from_partials needs only these.  Produced by the quantising-prologue
+     instantiations of the wave-specialised kernel (a fake-quantised model's convs feed fake-quantised convs): a launch with ext_partial set must
+     satisfy mi355_conv_gemm_ext_supported and then always runs on that kernel. */
+  float* ext_partial;     /* nullable; [B, ceil(Lout / MI355_STATS_ROWS), Cout, 2] */
+  int64_t ext_bstride;    /* elements between batch items */
 } mi355_conv_gemm_args;
 #define MI355_STATS_ROWS 64
 
 int mi355_conv_gemm(const mi355_conv_gemm_args* a, void* stream);
+/* 1 = this launch can write ext_partial (pre_fq set, precision 2, plain store, a prologue / epilogue pair the wave-specialised kernel's quantising
+ * instantiations carry, 16-byte aligned channels-last rows); 0 otherwise.  ext_partial itself need not be set in the probe. */
+int mi355_conv_gemm_ext_supported(const mi355_conv_gemm_args* a);
 /* Timeline probe of the wave-specialised kernel (tile code 46128128, tools/conv_timeline.py): device buffer of
  * [ceil(grid / 16)][8][4] uint64 s_memtime stamps (consumer wave 0 of every 16th workgroup, its first 8 tiles: tile start, first window
  * staged, main loop done, stores issued); NULL = off. */
@@ -297,6 +308,13 @@ typedef struct {
   float* y; int64_t y_bstride; int32_t ldy;
   float* minmax;
 } mi355_fake_quant_args;
+/* {-min, max} per utterance of act(scale x + shift) from the per-block, per-channel extrema a producing conv left (mi355_conv_gemm_args.ext_partial):
+ * here x = the partials [B, ceil(L / MI355_STATS_ROWS), C, 2], x_bstride = elements between items (ldx, y unused), everything else as in
+ * mi355_fake_quant_extrema.  Per channel the prologue is evaluated at the channel's min and max (both ends: the affine slope may be negative) -- equal
+ * to the sweep's result whenever the float32 evaluation of the prologue is monotone (always for the affine / LeakyReLU prologues; Snake's
+ * x + sin^2(a x) / a has derivative 1 + sin(2 a x) >= 0 and can round non-monotonically by an ulp where that derivative vanishes, which moves the
+ * quantiser's scale by <= 1e-7 relative). */
+int mi355_fake_quant_extrema_from_partials(const mi355_fake_quant_args* a, void* stream);
 int mi355_fake_quant_u8(const mi355_fake_quant_args* a, void* stream);
 /* Extrema pass alone for a conv that quantises in its prologue (mi355_conv_gemm_args.pre_fq): minmax[b] = {-min, max} of act(scale x + shift)
  * over utterance b's valid rows, joined with 0; y is not touched (may be NULL).  The prologue value is evaluated exactly as the conv prologues

@@ -94,7 +94,10 @@ __device__ __forceinline__ void lds_barrier() {
 // LeakyReLU, 1 = GELU (erf), 2 = SiLU, 3 = GELU-tanh.  The wave-specialised kernel is instantiated per activation: every activation body is
 // inlined once per accumulator element (~14 KB of code each), and the instantiation that carried all of them was 2x the code of the plain one
 // and did not fit the instruction cache (profiles/r1_static_code_size_conv_gemm.txt; now profiles/r2_static_code_size_conv.txt).
-template <int MF, int NF, int WM, int WN, int EPI>
+// EXT (the quantising-prologue instantiations of the wave-specialised kernel only): per 64-row block and channel the (min, max) of the STORED output
+// go to a.ext_partial beside the statistics -- the producer of a fake-quantised conv's input hands over what the consumer's extrema pass would
+// otherwise re-read the whole tensor for (every prologue in use is monotone per channel: mi355_fake_quant_extrema_from_partials).
+template <int MF, int NF, int WM, int WN, int EPI, bool EXT = false>
 __device__ __forceinline__ void conv_epilogue(const mi355_conv_gemm_args& a, f32x16 (&acc)[MF][NF], const int b, const int l0,
                                               const int n0, const int wm, const int wn, const int lane, const int len_out,
                                               const bool folded) {
@@ -107,6 +110,7 @@ __device__ __forceinline__ void conv_epilogue(const mi355_conv_gemm_args& a, f32
   // fused statistics (single pass, shifted by the lane's first stored value K so that s2 - s1^2/n does not cancel)
   float sK[NF], s1[NF], s2[NF];
   int scnt[NF];
+  const bool want_ext = EXT && a.ext_partial != nullptr;
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf) { sK[nf] = 0.f; s1[nf] = 0.f; s2[nf] = 0.f; scnt[nf] = 0; }
 #pragma unroll
@@ -182,6 +186,7 @@ __device__ __forceinline__ void conv_epilogue(const mi355_conv_gemm_args& a, f32
             s2[nf] += d * d;
             ++scnt[nf];
           }
+
         }
       }
     }
@@ -209,6 +214,39 @@ __device__ __forceinline__ void conv_epilogue(const mi355_conv_gemm_args& a, f32
         }
       }
     }
+    if constexpr (EXT) {
+      // edge tiles only (interior tiles take conv_epilogue_interior): the extrema from the values this lane just stored, read back (a thread sees its
+      // own stores) -- whatever epilogue variant produced them, and nothing of the store loop stays live
+      if (want_ext && a.up_s == 0) {
+        const int row0 = l0 + wm * WM;
+        if (row0 < len_out) {
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) {
+            const int n = n0 + wn * WN + nf * 32 + (lane & 31);
+            const int ncl = n < a.Cout ? n : a.Cout - 1;
+            float mn = INFINITY, mx = -INFINITY;
+#pragma unroll 1   // (rolled: edge tiles only -- eight loads in flight per trip are plenty, and the kernel's register budget stays the main loop's)
+            for (int g8 = 0; g8 < MF * 2; ++g8) {
+              float v[8];
+              int us[8];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const int r = (g8 & 1) * 8 + q;
+                us[q] = row0 + (g8 >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                v[q] = yb[(int64_t)(us[q] < len_out ? us[q] : len_out - 1) * a.ldy + ncl];
+              }
+#pragma unroll
+              for (int q = 0; q < 8; ++q)
+                if (us[q] < len_out) { mn = fminf(mn, v[q]); mx = fmaxf(mx, v[q]); }
+            }
+            mn = fminf(mn, __shfl_xor(mn, 32, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (lane < 32 && n < a.Cout)
+              *(float2*)(a.ext_partial + (int64_t)b * a.ext_bstride + ((int64_t)(row0 / MI355_STATS_ROWS) * a.Cout + n) * 2) = make_float2(mn, mx);
+          }
+        }
+      }
+    }
   }
 }
 
@@ -216,7 +254,7 @@ __device__ __forceinline__ void conv_epilogue(const mi355_conv_gemm_args& a, f32
 // epilogue activation, residual / running sum already folded into the accumulators (or absent).  Same arithmetic, in the same order, as
 // conv_epilogue (bias, out_scale, shifted single-pass statistics), so the two paths are bit-identical; what goes away is the per-element
 // clamping, predication and 64-bit address arithmetic: one uniform base pointer + a 32-bit lane offset per store.
-template <int MF, int NF, int WM, int WN>
+template <int MF, int NF, int WM, int WN, bool EXT = false>
 __device__ __forceinline__ void conv_epilogue_interior(const mi355_conv_gemm_args& a, f32x16 (&acc)[MF][NF], const int b, const int l0,
                                                        const int n0, const int wm, const int wn, const int lane) {
   char* yw = (char*)(a.y + (int64_t)b * a.y_bstride + (int64_t)(l0 + wm * WM) * a.ldy + (n0 + wn * WN));  // wave-uniform base
@@ -225,6 +263,7 @@ __device__ __forceinline__ void conv_epilogue_interior(const mi355_conv_gemm_arg
   const bool want_stats = a.stats_partial != nullptr;
   const float oscale = a.out_scale;
   float sK[NF], s1[NF], s2[NF];
+  const bool want_ext = EXT && a.ext_partial != nullptr;
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf) { sK[nf] = 0.f; s1[nf] = 0.f; s2[nf] = 0.f; }
   auto body = [&](auto stats_tag) {
@@ -284,6 +323,32 @@ __device__ __forceinline__ void conv_epilogue_interior(const mi355_conv_gemm_arg
         const float m2 = vl + vp + dm * dm * cl * cp / ct;
         if (lane < 32)
           *(float2*)(a.stats_partial + (int64_t)b * a.stats_bstride + ((int64_t)(row0 / MI355_STATS_ROWS) * a.Cout + n) * 2) = make_float2(sum, m2);
+      }
+    }
+    if constexpr (EXT) {
+      // a second pass over the accumulators (the stored values recomputed: the same two operations), behind the stores and the statistics: nothing of
+      // the store loop stays live here, so the kernel's register budget is the one it had
+      if (want_ext) {
+        const int row0 = l0 + wm * WM;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          const int n = n0 + wn * WN + nf * 32 + (lane & 31);
+          const float bias = a.bias ? a.bias[n] : 0.f;
+          float amn = INFINITY, amx = -INFINITY;   // extrema of the raw accumulators: v = (acc + bias) * oscale is monotone in acc (float32 add / multiply
+#pragma unroll                                      // round monotonically), so the stored values' extrema are that expression at the two ends
+          for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              amn = fminf(amn, acc[mf][nf][r]);
+              amx = fmaxf(amx, acc[mf][nf][r]);
+            }
+          const float e0 = (amn + bias) * oscale, e1 = (amx + bias) * oscale;
+          float mn = fminf(e0, e1), mx = fmaxf(e0, e1);
+          mn = fminf(mn, __shfl_xor(mn, 32, 64));
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          if (lane < 32)
+            *(float2*)(a.ext_partial + (int64_t)b * a.ext_bstride + ((int64_t)(row0 / MI355_STATS_ROWS) * a.Cout + n) * 2) = make_float2(mn, mx);
+        }
       }
     }
   }

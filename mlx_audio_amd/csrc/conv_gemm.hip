@@ -586,6 +586,24 @@ int launch_split_p(const mi355_conv_gemm_args& a, hipStream_t st, const int ks) 
 
 }  // namespace
 
+namespace {
+bool conv_vec_path(const mi355_conv_gemm_args& a) {
+  return (a.flat_valid % 4 == 0) && (a.ldx % 4 == 0) && (a.x_off % 4 == 0) && (a.x_bstride % 4 == 0) && (((uintptr_t)a.x) % 16 == 0);
+}
+// launches that can write per-block extrema: the quantising-prologue instantiations of the wave-specialised kernel (conv_ws4_fq.hip)
+bool conv_ext_supported(const mi355_conv_gemm_args& a) {
+  if (!a.pre_fq || (a.precision != 0 && a.precision != 2) || a.up_s != 0 || a.flat_valid != 0 || a.K == 1) return false;
+  if (a.pre_act != MI355_ACT_NONE && a.pre_act != MI355_ACT_LEAKY && !(a.pre_act == MI355_ACT_SNAKE && !a.pre_inv_beta)) return false;
+  if (a.post_act != MI355_ACT_NONE && a.post_act != MI355_ACT_LEAKY) return false;
+  if (a.Cin < (a.Cout <= 64 ? 32 : 64)) return false;
+  mi355_conv_gemm_args t = a;
+  t.precision = 2;
+  return mi355_conv_ws4_eligible(t, conv_vec_path(a));
+}
+}  // namespace
+
+extern "C" int mi355_conv_gemm_ext_supported(const mi355_conv_gemm_args* ap) { return ap && conv_ext_supported(*ap) ? 1 : 0; }
+
 extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
   MI355_REQUIRE(ap, "conv_gemm: null args");
   mi355_conv_gemm_args a = *ap;
@@ -616,6 +634,12 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
   }
   int tile = a.tile;
   t_mx_lo_slices = 0;
+  if (a.ext_partial) {   // per-block extrema: only the quantising instantiations of the wave-specialised kernel write them -- no other path may take the launch
+    MI355_REQUIRE(conv_ext_supported(a), "conv_gemm: ext_partial needs a launch mi355_conv_gemm_ext_supported accepts (pre_fq, precision 2, plain store, K > 1)");
+    MI355_REQUIRE(a.ext_bstride % 2 == 0 && ((uintptr_t)a.ext_partial) % 8 == 0, "conv_gemm: ext_partial must be 8-byte aligned");
+    static const int ws_feat_e = getenv("MI355_CONV_WS_FEAT") ? atoi(getenv("MI355_CONV_WS_FEAT")) : 0;
+    return mi355_conv_ws4_launch(a, st, ws_feat_e & 3, a.Cout <= 64 ? 64 : 128);
+  }
   if (a.precision == 5) {
     // the wave-specialised kernel takes the launch when it fills the chip (the same rule as the auto choice below) or when asked for by tile
     // code; everything else runs the precision-4 arithmetic of the 4-wave kernels on the image's fp16 slices

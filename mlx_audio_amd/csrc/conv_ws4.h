@@ -702,9 +702,9 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
 #if defined(MI355_VARIANT) && MI355_VARIANT == 1
     if (false) conv_epilogue_interior<MF, NF, WM, WN>(a, acc, b, l0, n0, wm, wn, lane);
 #else
-    if (plain && interior) conv_epilogue_interior<MF, NF, WM, WN>(a, acc, b, l0, n0, wm, wn, lane);
+    if (plain && interior) conv_epilogue_interior<MF, NF, WM, WN, FQ>(a, acc, b, l0, n0, wm, wn, lane);   // FQ instantiations: + per-block extrema (EXT)
 #endif
-    else conv_epilogue<MF, NF, WM, WN, EPI>(a, acc, b, l0, n0, wm, wn, lane, len_out, fold != 0);
+    else conv_epilogue<MF, NF, WM, WN, EPI, FQ>(a, acc, b, l0, n0, wm, wn, lane, len_out, fold != 0);
     if constexpr (DBG) {
       if (dbg && lane == 0 && ntile < 8) dbg[4 * ntile + 3] = __builtin_amdgcn_s_memtime();  // stores issued
     }

@@ -416,8 +416,11 @@ def conv_gemm(x: torch.Tensor, pc: PackedConv, y: torch.Tensor, *, dil: int = 1,
               up: Optional[dict] = None, precision: int = 2, tile: int = 0,
               flat: Optional[dict] = None, use_bias: bool = True, stats: Optional[torch.Tensor] = None,
               pre_inv_beta: Optional[torch.Tensor] = None, colscale: Optional[torch.Tensor] = None, x_off: int = 0,
-              flatten: bool = False, pre_fq: Optional[torch.Tensor] = None):
+              flatten: bool = False, pre_fq: Optional[torch.Tensor] = None, ext: Optional[torch.Tensor] = None):
     """y = epilogue(conv1d(prologue(x)))  -- see mi355_conv_gemm_args in the header.
+
+    ``ext`` ([B, ceil(Lout / 64), Cout, 2] from ``new_ext``): the launch also leaves the per-block, per-channel (min, max) of what it stores, for
+    ``fake_quant_extrema_from_partials`` -- only launches ``conv_ext_supported`` accepts (a quantising prologue on the wave-specialised kernel).
 
     ``flatten``: the caller states that this is a per-row linear layer (K == 1) whose padding rows (rows >= lens[b]) may be
     computed and written like any other row (nothing downstream reads them as valid): ``[B, L, C]`` operands whose items are
@@ -463,6 +466,10 @@ def conv_gemm(x: torch.Tensor, pc: PackedConv, y: torch.Tensor, *, dil: int = 1,
     if up is not None:
         kw.update(up_s=up["s"], up_p=up["p"], up_cout=up["cout"], up_row_off=up.get("row_off", 0),
                   up_Lout=up["lout"], lens_up=_ptr(up.get("lens")))
+    if ext is not None:
+        assert ext.dtype == torch.float32 and ext.dim() == 4 and ext.is_contiguous() and ext.shape[0] == B and ext.shape[2] == pc.cout
+        assert ext.shape[1] >= (kw["Lout"] + STATS_ROWS - 1) // STATS_ROWS
+        kw.update(ext_partial=_ptr(ext), ext_bstride=ext.stride(0))
     if stats is not None:  # [B, ceil(Lout / 64), Cout, 2] float32: per-row-block (sum, M2) of the stored output
         assert stats.dtype == torch.float32 and stats.dim() == 4 and stats.is_contiguous()
         assert stats.shape[0] == B and stats.shape[1] >= (kw["Lout"] + STATS_ROWS - 1) // STATS_ROWS and stats.shape[2] == pc.cout
@@ -525,6 +532,41 @@ def _conv_split_ws(device: torch.device, stream: int) -> torch.Tensor:
 def new_stats(B: int, L: int, C: int, device) -> torch.Tensor:
     """Buffer for the fused instance-norm statistics of a conv output [B, L, C] (see conv_gemm(stats=...))."""
     return torch.empty((B, (L + STATS_ROWS - 1) // STATS_ROWS, C, 2), dtype=torch.float32, device=device)
+
+
+def new_ext(B: int, L: int, C: int, device) -> torch.Tensor:
+    """Buffer for the per-block extrema a conv launch leaves (``conv_gemm(ext=...)``): [B, ceil(L / 64), C, 2] = (min, max)."""
+    return torch.empty((B, (L + STATS_ROWS - 1) // STATS_ROWS, C, 2), dtype=torch.float32, device=device)
+
+
+def conv_ext_supported(x: torch.Tensor, pc: PackedConv, *, B: int, lout: int, dil: int = 1, pre_act: int = ACT_NONE, post_act: int = ACT_NONE,
+                       up: Optional[dict] = None, flat: Optional[dict] = None, precision: int = 2, min_tiles: int = 128) -> bool:
+    """Will ``conv_gemm(..., pre_fq=..., ext=...)`` of this shape be taken by the kernel that writes extrema partials -- AND would the dispatcher have
+    chosen that kernel anyway (at least ``min_tiles`` 128-row tiles: the rule of ``mi355_conv_gemm``'s automatic choice), so that asking for the
+    partials does not change which kernel computes the conv?"""
+    if up is not None or flat is not None or pc.f16 or pc.mx or precision != 2 or pc.k == 1:
+        return False
+    _, _, _, xbs, ldx = _nlc(x)
+    bn = 64 if pc.cout <= 64 else 128
+    if B * ((lout + 127) // 128) * ((pc.cout + bn - 1) // bn) < min_tiles:
+        return False
+    return bool(_lib.call_struct_ret("mi355_conv_gemm_ext_supported", "mi355_conv_gemm_args", x=_ptr(x), x_bstride=xbs, ldx=ldx, Cin=pc.cin, Lin=x.shape[1],
+                                     w=_ptr(pc.w), Cout=pc.cout, K=pc.k, dil=dil, pre_act=pre_act, post_act=post_act, Lout=lout, B=B, precision=2,
+                                     pre_alpha=_ptr(pc.w), pre_fq=_ptr(pc.w), y=_ptr(pc.w)))   # the probe reads shapes, flags and x's alignment; the other pointers only have to be set
+
+
+def fake_quant_extrema_from_partials(ext: torch.Tensor, L: int, *, lens=None, pre=None, pre_act: int = ACT_NONE, pre_slope: float = 0.0,
+                                     pre_alpha: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``[B, 2]`` = {-min, max} of ``act(scale * x + shift)`` per utterance from the per-block, per-channel (min, max) of x that the conv producing x
+    left (``conv_gemm(ext=...)``): what ``fake_quant_extrema`` computes by reading x again."""
+    B, nblk, C, two = ext.shape
+    assert two == 2 and ext.is_contiguous() and nblk >= (L + STATS_ROWS - 1) // STATS_ROWS
+    mm = torch.empty((B, 2), dtype=torch.float32, device=ext.device)
+    sc, sh = pre if pre is not None else (None, None)
+    _lib.call_struct("mi355_fake_quant_extrema_from_partials", "mi355_fake_quant_args", _stream(), x=_ptr(ext), x_bstride=ext.stride(0), ldx=2 * C, C=C, L=L,
+                     lens=_ptr(lens), B=B, pre_scale=_ptr(sc), pre_shift=_ptr(sh), pre_ld=sc.stride(0) if sc is not None else 0, pre_act=pre_act,
+                     pre_slope=pre_slope, pre_alpha=_ptr(pre_alpha), minmax=_ptr(mm))
+    return mm
 
 
 def adain_from_partials(stats: torch.Tensor, L: int, gb: Optional[torch.Tensor], lens: Optional[torch.Tensor] = None, eps: float = 1e-5):

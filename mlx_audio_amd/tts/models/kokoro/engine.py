@@ -205,6 +205,9 @@ class KokoroEngine:
         # KittenTTS activation quantisation: extrema pass + quantiser inside the consuming conv's prologue (False: materialise the quantised tensor
         # with mi355_fake_quant_u8 first -- the round-2 path, kept for A/B runs: MI355_FOLD_QUANT=0)
         self.fold_quant = os.environ.get("MI355_FOLD_QUANT", "1") != "0"
+        # ... and the extrema of a quantised conv's input from the per-block partials the producing conv left, instead of one more read of the tensor (False: every
+        # quantised conv sweeps its input; A/B knob MI355_EXT_PARTIALS=0)
+        self.ext_partials = os.environ.get("MI355_EXT_PARTIALS", "1") != "0"
         self.w = weights
         ist = config["istftnet"]
         self.rates = [int(r) for r in ist["upsample_rates"]]
@@ -399,24 +402,42 @@ class KokoroEngine:
             q = q[:, 0]
         return _StyleProj(plain[:, 0], q)
 
-    def _conv(self, x, pc, y, **kw):
+    def _prec(self, pc) -> int:
         # the weight image decides: fp16-packed weights select 3 themselves (4 in mode 5), MX images 5; bf16 images of modes 3 / 5 (front end) run 2
-        kw.setdefault("precision", 2 if (self.precision == 3 or (self.precision == 5 and not pc.f16)) else self.precision)
+        return 2 if (self.precision == 3 or (self.precision == 5 and not pc.f16)) else self.precision
+
+    def _conv(self, x, pc, y, **kw):
+        kw.setdefault("precision", self._prec(pc))
         return ops.conv_gemm(x, pc, y, **kw)
 
-    def _convq(self, name: str, x, pc, y, *, lens_in=None, pre=None, pre_act=ACT_NONE, pre_slope=0.0, pre_alpha=None, **kw):
+    def _convq(self, name: str, x, pc, y, *, lens_in=None, pre=None, pre_act=ACT_NONE, pre_slope=0.0, pre_alpha=None, ext_in=None, ext_out=None, ret_ext=False, **kw):
         """``_conv`` of module ``name``.  When the module is flagged for activation quantisation (KittenTTS) its input -- INCLUDING the
-        AdaIN / activation prologue the conv would have fused -- is materialised and fake-quantised first (kitten_tts/istftnet.py:131)."""
+        AdaIN / activation prologue the conv would have fused -- is materialised and fake-quantised first (kitten_tts/istftnet.py:131).
+
+        ``ext_in``: per-block, per-channel (min, max) of ``x`` left by the conv that produced it (``ops.new_ext``): the extrema of the prologue's
+        output then come from those (every prologue is monotone per channel) instead of one more read of ``x``.  ``ext_out``: a buffer this launch
+        should leave ITS output's extrema in for the next quantised conv.  ``ret_ext``: return ``(y, ext_out or None)`` -- None where the launch cannot
+        write them (the caller's next conv then sweeps)."""
+        want = ret_ext
+        done = None
         if self.qmods and self._isq(name):
             if self.fold_quant and "flat" not in kw:
-                # one read-only extrema pass; the conv quantises inside its prologue (no materialised tensor)
-                mm = ops.fake_quant_extrema(x, lens=lens_in, pre=pre, pre_act=pre_act, pre_slope=pre_slope, pre_alpha=pre_alpha)
-                return self._conv(x, pc, y, lens_in=lens_in, pre=pre, pre_act=pre_act, pre_slope=pre_slope, pre_alpha=pre_alpha, pre_fq=mm, **kw)
+                if ext_in is not None:
+                    mm = ops.fake_quant_extrema_from_partials(ext_in, x.shape[1], lens=lens_in, pre=pre, pre_act=pre_act, pre_slope=pre_slope, pre_alpha=pre_alpha)
+                else:   # one read-only extrema pass; the conv quantises inside its prologue (no materialised tensor)
+                    mm = ops.fake_quant_extrema(x, lens=lens_in, pre=pre, pre_act=pre_act, pre_slope=pre_slope, pre_alpha=pre_alpha)
+                if ext_out is not None and self.ext_partials and ops.conv_ext_supported(x, pc, B=x.shape[0], lout=kw.get("lout") or y.shape[1], dil=kw.get("dil", 1), pre_act=pre_act,
+                                                                         post_act=kw.get("post_act", ACT_NONE), up=kw.get("up"), precision=self._prec(pc)):
+                    kw["ext"] = done = ext_out
+                self._conv(x, pc, y, lens_in=lens_in, pre=pre, pre_act=pre_act, pre_slope=pre_slope, pre_alpha=pre_alpha, pre_fq=mm, **kw)
+                return (y, done) if want else y
             xq = ops.fake_quant_u8(x, lens=lens_in, pre=pre, pre_act=pre_act, pre_slope=pre_slope, pre_alpha=pre_alpha)
-            return self._conv(xq, pc, y, lens_in=lens_in, **kw)
+            self._conv(xq, pc, y, lens_in=lens_in, **kw)
+            return (y, None) if want else y
         if pre is not None or pre_act != ACT_NONE:
             kw.update(pre=pre, pre_act=pre_act, pre_slope=pre_slope, pre_alpha=pre_alpha)
-        return self._conv(x, pc, y, lens_in=lens_in, **kw)
+        self._conv(x, pc, y, lens_in=lens_in, **kw)
+        return (y, None) if want else y
 
     def _dur_cap(self, bins: int, speed: float) -> int:
         """Upper bound of one predicted duration: the clip (Kokoro), else the sum of ``bins`` sigmoids over the speed (KittenTTS, unclipped)."""
@@ -479,6 +500,12 @@ class KokoroEngine:
         st_cur = x_stats
         st_tmp = ops.new_stats(B, L, C, self.dev) if fuse else None
         st_work = ops.new_stats(B, L, C, self.dev) if fuse else None
+        # KittenTTS activation quantisation: a conv leaves the per-block extrema of its output for the quantised conv that consumes it (the block input
+        # of the first round has no producing conv here: that one sweeps)
+        use_ext = bool(self.qmods) and self.fold_quant and self.ext_partials
+        ex_cur = None
+        ex_tmp = ops.new_ext(B, L, C, self.dev) if use_ext else None
+        ex_work = ops.new_ext(B, L, C, self.dev) if use_ext else None
         for i, dl in enumerate(rb.dils):
             if fuse and st_cur is not None:
                 sc, sh = ops.adain_from_partials(st_cur, L, self._gb(gb_all, rb.adain1[i]), lens)
@@ -486,8 +513,8 @@ class KokoroEngine:
                 sc, sh = ops.adain_coef(cur, self._gb(gb_all, rb.adain1[i]), lens, sums=x_sums[0], reuse=x_sums[1])
             else:
                 sc, sh = ops.adain_coef(cur, self._gb(gb_all, rb.adain1[i]), lens)
-            self._convq(f"{rb.name}.convs1.{i}", cur, rb.convs1[i], tmp, dil=dl, pad=(rb.k * dl - dl) // 2, lens_in=lens, lens_out=lens, pre=(sc, sh),
-                        pre_act=ACT_SNAKE, pre_alpha=rb.alpha1[i], stats=st_tmp)
+            _, ex_t = self._convq(f"{rb.name}.convs1.{i}", cur, rb.convs1[i], tmp, dil=dl, pad=(rb.k * dl - dl) // 2, lens_in=lens, lens_out=lens, pre=(sc, sh),
+                                  pre_act=ACT_SNAKE, pre_alpha=rb.alpha1[i], stats=st_tmp, ext_in=ex_cur, ext_out=ex_tmp, ret_ext=True)
             if fuse:
                 sc, sh = ops.adain_from_partials(st_tmp, L, self._gb(gb_all, rb.adain2[i]), lens)
             else:
@@ -499,11 +526,12 @@ class KokoroEngine:
                 if work is None:
                     work = self._new(B, L, C)
                 dst, acc, scale = work, False, 1.0
-            self._convq(f"{rb.name}.convs2.{i}", tmp, rb.convs2[i], dst, pad=(rb.k - 1) // 2, lens_in=lens, lens_out=lens, pre=(sc, sh),
-                        pre_act=ACT_SNAKE, pre_alpha=rb.alpha2[i], res=cur, accumulate=acc, out_scale=scale,
-                        stats=st_work if (fuse and not last) else None)
+            _, ex_w = self._convq(f"{rb.name}.convs2.{i}", tmp, rb.convs2[i], dst, pad=(rb.k - 1) // 2, lens_in=lens, lens_out=lens, pre=(sc, sh),
+                                  pre_act=ACT_SNAKE, pre_alpha=rb.alpha2[i], res=cur, accumulate=acc, out_scale=scale,
+                                  stats=st_work if (fuse and not last) else None, ext_in=ex_t, ext_out=None if last else ex_work, ret_ext=True)
             cur = dst
             st_cur = st_work if (fuse and not last) else None
+            ex_cur = None if last else ex_w
         return cur
 
     # ------------------------------------------------------------------ forward

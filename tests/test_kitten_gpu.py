@@ -395,3 +395,58 @@ def test_kitten_load_model_call_and_generate(tmp_path):
     # speed prior 0.8 compounds per chunk exactly as the reference rebinds ``speed`` (0.8, 0.64, 0.512): later chunks get slower
     one = list(model.generate("The quick brown fox jumps", voice="kiki", clean_text=False))
     assert len(one) == 1 and one[0].token_count == len("the quick brown fox jumps ,") + 2
+
+
+@pytest.mark.parametrize("cout,pre_act", [(128, "snake"), (64, "leaky"), (256, "none")])
+def test_conv_extrema_partials_replace_the_sweep(cout, pre_act):
+    """Round 5: a quantising conv leaves the per-block, per-channel (min, max) of what it stores (``conv_gemm(ext=...)``); the NEXT quantised conv's
+    extrema come from those (``fake_quant_extrema_from_partials``) instead of one more read of the tensor.  (i) the partials are exactly the block
+    extrema of the stored output (ragged batch: a partly valid block, rows past the length untouched); (ii) the extrema derived from them equal the
+    sweep's ``fake_quant_extrema`` for every prologue (bitwise for the affine / LeakyReLU prologues, to 2 ulp under Snake, whose float32 evaluation can
+    round non-monotonically where its derivative vanishes); (iii) the conv's output does not depend on whether the partials were asked for."""
+    from mlx_audio_amd import ops
+    from mlx_audio_amd.ops import ACT_LEAKY, ACT_NONE, ACT_SNAKE
+
+    g = torch.Generator().manual_seed(cout)
+    B, L, cin, K = 6, 64 * 45 + 21, 128, 3
+    lens = torch.tensor([L, L - 64, 64 * 20 + 5, L - 1, 700, L], dtype=torch.int32)
+    x = torch.randn(B, L, cin, generator=g)
+    w = (torch.randn(cout, K, cin, generator=g) / (cin * K) ** 0.5).bfloat16().float()
+    pc = ops.pack_conv(w, 0.1 * torch.randn(cout, generator=g), DEV)
+    sc, sh = (torch.randn(B, cin, generator=g) * 0.4 + 1).to(DEV), (torch.randn(B, cin, generator=g) * 0.3).to(DEV)
+    alpha = (torch.rand(cin, generator=g) + 0.5).to(DEV)
+    act = dict(snake=ACT_SNAKE, leaky=ACT_LEAKY, none=ACT_NONE)[pre_act]
+    pkw = dict(pre=(sc, sh), pre_act=act, pre_slope=0.2, pre_alpha=alpha if act == ACT_SNAKE else None)
+    xd, ld = x.to(DEV), lens.to(DEV)
+    assert ops.conv_ext_supported(xd, pc, B=B, lout=L, pre_act=act)
+    assert not ops.conv_ext_supported(xd[:1], pc, B=1, lout=L, pre_act=act)          # a launch of few tiles keeps the kernel the dispatcher picks by itself
+    mm = ops.fake_quant_extrema(xd, lens=ld, **pkw)
+    y0, y1 = torch.zeros(B, L, cout, device=DEV), torch.zeros(B, L, cout, device=DEV)
+    ext = ops.new_ext(B, L, cout, DEV)
+    ext.fill_(float("nan"))
+    ops.conv_gemm(xd, pc, y0, pad=1, lens_in=ld, lens_out=ld, pre_fq=mm, **pkw)
+    ops.conv_gemm(xd, pc, y1, pad=1, lens_in=ld, lens_out=ld, pre_fq=mm, ext=ext, **pkw)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    yc, ec = y1.cpu(), ext.cpu()
+    for b in range(B):
+        n = int(lens[b])
+        nb = (n + 63) // 64
+        blocks = torch.nn.functional.pad(yc[b, :n], (0, 0, 0, nb * 64 - n), value=float("nan")).view(nb, 64, cout)
+        lo = torch.where(torch.isnan(blocks), torch.full_like(blocks, float("inf")), blocks).amin(1)
+        hi = torch.where(torch.isnan(blocks), torch.full_like(blocks, float("-inf")), blocks).amax(1)
+        assert torch.equal(ec[b, :nb, :, 0], lo) and torch.equal(ec[b, :nb, :, 1], hi), (b, pre_act)
+        assert torch.isnan(ec[b, nb:]).all()                                            # blocks past the length are not written
+    # the consumer's side: extrema of ITS prologue over y1 from the partials == the sweep over y1
+    sc2, sh2 = (torch.randn(B, cout, generator=g) * 0.4 - 0.2).to(DEV), (torch.randn(B, cout, generator=g) * 0.3).to(DEV)   # slopes of both signs
+    alpha2 = (torch.rand(cout, generator=g) + 0.5).to(DEV)
+    for act2, al in ((ACT_SNAKE, alpha2), (ACT_LEAKY, None), (ACT_NONE, None)):
+        kw2 = dict(pre=(sc2, sh2), pre_act=act2, pre_slope=0.2, pre_alpha=al)
+        sweep = ops.fake_quant_extrema(y1, lens=ld, **kw2).cpu()
+        part = ops.fake_quant_extrema_from_partials(ext, L, lens=ld, **kw2).cpu()
+        if act2 == ACT_SNAKE:
+            assert float(((sweep - part).abs() / sweep.abs().clamp_min(1e-30)).max()) < 3e-7, (sweep, part)
+        else:
+            assert torch.equal(sweep, part), (act2, sweep, part)
+    plain = ops.fake_quant_extrema_from_partials(ext, L, lens=ld).cpu()                  # no prologue at all
+    assert torch.equal(plain, ops.fake_quant_extrema(y1, lens=ld).cpu())
