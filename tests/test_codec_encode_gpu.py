@@ -374,3 +374,33 @@ def test_vocos_with_encodec_features():
     assert none.feature_extractor is None and torch.equal(none.decode(feats, bandwidth_id=bw), y)
     with pytest.raises(FileNotFoundError):
         none(audio, bandwidth_id=bw)
+
+
+# ------------------------------------------------------------------------------------------------------------------ the search kernel
+@pytest.mark.parametrize("D,bins,layers", [(128, 1024, 8), (8, 1024, 1), (256, 2048, 5), (32, 64, 4)])
+def test_rvq_encode_frames_per_workgroup_forms_are_bit_identical(D, bins, layers):
+    """``mi355_rvq_encode`` takes 8 / 4 / 2 frames per workgroup from 4096 / 2048 / 1024 frames on (round 5: the frames of a workgroup share each read of the
+    layer's table) and one below: the same frames searched in one large call and in calls of < 1024 frames give the same codes AND the same margins, bit for
+    bit (a thread walks d in the same order with the same fmaf in every form); and both equal the float32 restatement outside knife edges."""
+    from mlx_audio_amd import ops
+
+    g = torch.Generator().manual_seed(D + bins + layers)
+    tables = (torch.randn(layers, bins, D, generator=g) / torch.arange(1, layers + 1).sqrt()[:, None, None]).contiguous()
+    tt, c2 = tables.transpose(1, 2).contiguous(), ((tables * tables).sum(-1) / 2).contiguous()
+    td, ttd, c2d = tables.to(DEV), tt.to(DEV), c2.to(DEV)
+    for n in (5003, 2500, 1500):
+        x = torch.randn(n, D, generator=g) * 1.5
+        xd = x.to(DEV)
+        big, bm = ops.rvq_encode(xd, td, ttd, c2d, margins=True)
+        parts = [ops.rvq_encode(xd[i:i + 700], td, ttd, c2d, margins=True) for i in range(0, n, 700)]
+        torch.cuda.synchronize()
+        small, sm = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+        assert torch.equal(big, small) and torch.equal(bm, sm), (n, int((big != small).sum()))
+    # against the float32 restatement (first minimum of |e|^2 / 2 - x . e, residual -= e), away from knife edges
+    r = x.clone()
+    for l in range(layers):
+        s = c2[l][None, :] - r @ tt[l]
+        idx = s.argmin(1)
+        clear = bm[:, l].cpu() > 1e-4 * float(s.abs().max())
+        assert torch.equal(big[:, l].cpu()[clear].long(), idx[clear]), l
+        r = r - tables[l][big[:, l].cpu().long()]
