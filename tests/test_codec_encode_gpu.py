@@ -404,3 +404,50 @@ def test_rvq_encode_frames_per_workgroup_forms_are_bit_identical(D, bins, layers
         clear = bm[:, l].cpu() > 1e-4 * float(s.abs().max())
         assert torch.equal(big[:, l].cpu()[clear].long(), idx[clear]), l
         r = r - tables[l][big[:, l].cpu().long()]
+
+
+# ------------------------------------------------------------------------------------------------------------------ edge cases
+def test_codec_encode_edge_cases():
+    """Smallest and ragged shapes of the encode sides: one utterance, exactly one hop, a length that is not a whole number of hops (DAC encodes the raw
+    length, dac.py:184-192: the strided convs floor), SNAC's minimal padded length, EnCodec in a BATCH (the reference's Metal LSTM kernel is only
+    consistent for one sequence; the oracle runs the per-sequence LSTM it means) -- a batch equals its items wherever no knife edge is involved."""
+    from mlx_audio_amd.codec.models.encodec import Encodec
+    from mlx_audio_amd.codec.models.snac import SNAC
+    from test_codec_encode_cpu import encodec_model_weights, snac_model_weights
+    from oracle.encodec_ref import EncodecRef
+    from oracle.snac_ref import SNACEncoderRef
+
+    # DAC
+    c = dict(encoder_dim=32, encoder_rates=[2, 4, 5, 8], latent_dim=64, decoder_dim=64, decoder_rates=[8, 5, 4, 2], n_codebooks=3, codebook_size=256, codebook_dim=8, sample_rate=16000)
+    eng, ref, _ = dac_pair(c, 23, True)
+    for S in (320, 320 * 3 + 1, 320 * 2 + 319):
+        a = make_audio(1, S, 16000, seed=S)
+        want = ref.quantize(ref.encoder(a), return_margins=True)
+        got = eng.encode(a, return_margins=True)
+        torch.cuda.synchronize()
+        assert tuple(got[1].shape) == tuple(want[1].shape) and (S % 320 or got[1].shape[2] == S // 320), (S, tuple(got[1].shape), tuple(want[1].shape))   # 959 samples: 3 frames (each strided conv floors)
+        walk_frames("dac_encode", got[1], want[1], torch.minimum(got[5].cpu(), want[5]), thr=1e-3)
+        assert rel_peak(got[2], want[2]) < 1e-3 or not torch.equal(got[1].cpu(), want[1])
+    # SNAC: the shortest input (one sample) pads to hop * lcm(vq_strides) samples = lcm finest frames
+    fx = np.load(os.path.join(GOLD, "ref_snac_encode_dw.npz"))
+    sc, sw = snac_model_weights(fx)
+    sn, sref = SNAC(**sc, weights=sw, device=DEV), SNACEncoderRef(sw, sc["encoder_rates"], sc["vq_strides"], depthwise=True)
+    one = torch.full((1, 1, 1), 0.25)
+    got, want = sn.encode(one), sref.encode(one)
+    assert [tuple(g.shape) for g in got] == [tuple(w.shape) for w in want] == [(1, 1), (1, 2), (1, 4)]
+    # EnCodec: three utterances at once vs one by one
+    fe = np.load(os.path.join(GOLD, "ref_encodec_encode_mono.npz"))
+    ec, ew = encodec_model_weights(fe)
+    en, eref = Encodec(ec, weights=ew, device=DEV), EncodecRef(ew, ec)
+    x = make_audio(3, 16 * 50 + 7, 24000, seed=2).transpose(1, 2).contiguous()
+    bw = ec["target_bandwidths"][-1]
+    both, _ = en.encode(x, None, bandwidth=bw)
+    torch.cuda.synchronize()
+    assert tuple(both.shape) == (1, 3, 4, 51)
+    for b in range(3):
+        alone, _ = en.encode(x[b:b + 1], None, bandwidth=bw)
+        want, _ = eref.encode(x[b:b + 1], None, bandwidth=bw)
+        eq_batch = float((both[0, b].cpu() == alone[0, 0].cpu()).float().mean())
+        eq_ref = float((alone[0, 0].cpu() == want[0, 0]).float().mean())
+        # a float32 checkpoint behind an fp16 image moves the embeddings by ~5e-4: a flipped code changes every later layer of its frame
+        assert eq_batch > 0.95 and eq_ref > 0.85, (b, eq_batch, eq_ref)
