@@ -165,11 +165,19 @@ __global__ __launch_bounds__(256) void sine_merge_kernel(const mi355_sine_source
   if (!EXTREMA) a.out[(int64_t)b * a.ld_out + t] = tanhf(add_rn(accv, a.lin_b));
   }
   if (EXTREMA) {
+    // 40 000 workgroups x 4 waves hammering the SAME two words per utterance serialised in L2 (the extrema pass took 1.75 ms against 0.2 ms for the
+    // merge pass proper): one pair per workgroup (through the noise buffer, which is done with), and only when it RAISES the stored value -- a maximum
+    // only grows, a stale read is a smaller value and merely lets the atomic run
     nmn = wave_max(nmn);
     mxv = wave_max(mxv);
-    if ((tid & 63) == 0) {
-      atomicMax((int*)a.quant_ws + 2 * b, __float_as_int(nmn));
-      atomicMax((int*)a.quant_ws + 2 * b + 1, __float_as_int(mxv));
+    __syncthreads();
+    if ((tid & 63) == 0) { nzs[2 * (tid >> 6)] = nmn; nzs[2 * (tid >> 6) + 1] = mxv; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int i = 1; i < 4; ++i) { nmn = fmaxf(nmn, nzs[2 * i]); mxv = fmaxf(mxv, nzs[2 * i + 1]); }
+      volatile float* cur = a.quant_ws + 2 * b;
+      if (nmn > cur[0]) atomicMax((int*)a.quant_ws + 2 * b, __float_as_int(nmn));
+      if (mxv > cur[1]) atomicMax((int*)a.quant_ws + 2 * b + 1, __float_as_int(mxv));
     }
   }
 }
