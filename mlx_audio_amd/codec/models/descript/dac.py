@@ -174,10 +174,12 @@ class _Quantizer:
         B, T, D = z.shape
         if D != self.latent_dim:
             raise ValueError(f"quantizer: z must be [B, {self.latent_dim}, T], got {tuple(z.transpose(1, 2).shape)}")
-        n = self.n_codebooks if n_quantizers is None else max(0, min(int(n_quantizers), self.n_codebooks))
+        n = self.n_codebooks if n_quantizers is None else min(int(n_quantizers), self.n_codebooks)
+        if n < 1:
+            raise ValueError("quantizer: n_quantizers must be at least 1")
         d = self.codebook_dim
         residual = z.contiguous().clone()
-        lat = torch.empty((B, T, max(n, 1) * d), dtype=torch.float32, device=self.device)
+        lat = torch.empty((B, T, n * d), dtype=torch.float32, device=self.device)
         ids, margins = [], []
         for i in range(n):
             ze = lat[:, :, i * d:(i + 1) * d]
@@ -189,8 +191,6 @@ class _Quantizer:
             ids.append(c.view(B, T, 1))
             if i + 1 < n:
                 ops.embed_sum(self.neg_table, ids[-1], residual, slot_offset=self.offs[i:i + 1], add=residual)
-        if n == 0:
-            raise ValueError("quantizer: n_quantizers must be at least 1")
         codes = torch.cat(ids, 2).permute(0, 2, 1).contiguous().to(torch.int64)      # [B, n, T]
         z_q, z_p, _ = self.from_codes(codes)
         latents = lat.transpose(1, 2)
