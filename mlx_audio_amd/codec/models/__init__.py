@@ -1,6 +1,6 @@
-"""Codec models of the decode hot path, under the reference's names (``mlx_audio/codec/models/__init__.py``): ``DAC``, ``SNAC``, ``Vocos`` are the
-decode-side engines of this build (same constructor arguments as the reference classes); ``Mimi`` is exposed as its decoder engine
-(``MimiDecoder``: codes -> waveform); ``Encodec`` is the decode side of EnCodec (``Encodec(config).decode``).  The remaining reference exports (EcapaTdnnBackbone, MossAudioTokenizer, NemotronVoiceChatCodec,
+"""Codec models of the hot path, under the reference's names (``mlx_audio/codec/models/__init__.py``): ``DAC``, ``SNAC``, ``Encodec`` and ``Vocos`` are the
+engines of this build (same constructor arguments as the reference classes; ``encode`` and ``decode`` since round 5 -- a checkpoint without encoder weights
+decodes only); ``Mimi`` is exposed as its decoder engine (``MimiDecoder``: codes -> waveform; ``mimi.Mimi`` holds both halves).  The remaining reference exports (EcapaTdnnBackbone, MossAudioTokenizer, NemotronVoiceChatCodec,
 StepAudio2Token2Wav) are outside SURVEY section 8 and raise ``ImportError`` naming that fact instead of an ``AttributeError``.  Resolved lazily so
 that ``import mlx_audio_amd.codec`` stays import-light."""
 import importlib
