@@ -253,3 +253,35 @@ def test_vocos_encodec_features_dry_run():
         EncodecFeatures()
     with pytest.raises(ValueError, match="Unsupported encodec_model"):
         EncodecFeatures(encodec_model="encodec_16khz")
+
+
+def test_encodec_from_pretrained_local_directory(tmp_path):
+    """``Encodec.from_pretrained`` (encodec.py:710-737) on a LOCAL directory (``config.json`` with extra keys + ``model.safetensors``): the model and the
+    ``preprocess_audio`` partial it returns reproduce the reference run's codes; ``EncodecFeatures(encodec_model=<that directory>)`` builds on it; a path
+    that does not exist is a ``FileNotFoundError`` (no hub here)."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _ops_emu
+    from safetensors.torch import save_file
+
+    from mlx_audio_amd.codec.models.encodec import Encodec
+    from mlx_audio_amd.codec.models.vocos import EncodecFeatures
+
+    fx = np.load(os.path.join(GOLD, "ref_encodec_encode_stereo.npz"))
+    c, w = encodec_model_weights(fx)
+    d = tmp_path / "encodec-local"
+    d.mkdir()
+    with open(d / "config.json", "w") as f:
+        json.dump(dict(c, transformers_version="4.x", torch_dtype="float32"), f)     # keys outside EncodecConfig are dropped, like filter_dataclass_fields
+    save_file({k: v.contiguous() for k, v in w.items()}, str(d / "model.safetensors"))
+    with _ops_emu.patched():
+        model, processor = Encodec.from_pretrained(str(d), device="cpu")
+        assert model.chunk_length == int(c["chunk_length_s"] * c["sampling_rate"]) and model.channels == 2
+        inputs, masks = processor(torch.from_numpy(fx["raw"]))
+        assert tuple(inputs.shape) == fx["inputs"].shape and np.array_equal(masks.numpy(), fx["masks"])
+        bw = c["target_bandwidths"][-1]
+        codes, scales = model.encode(inputs, masks, bandwidth=bw)
+        assert np.array_equal(codes.numpy(), fx[f"codes_bw{bw}"])
+        fe = EncodecFeatures(encodec_model=str(d), bandwidths=c["target_bandwidths"], device="cpu")
+        assert fe.encodec.chunk_length == model.chunk_length and fe.num_q >= 1
+    with pytest.raises(FileNotFoundError):
+        Encodec.from_pretrained(str(tmp_path / "missing"), device="cpu")
