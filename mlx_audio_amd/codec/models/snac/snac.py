@@ -369,12 +369,14 @@ class SNAC:
 
     # ------------------------------------------------------------------ reference surface
     def preprocess(self, audio_data):
-        """snac.py:67-86: right-pad to a multiple of hop_length * lcm(vq_strides)."""
+        """snac.py:67-86: right-pad to a multiple of hop_length * lcm(vq_strides [, attn_window_size])."""
         audio_data = torch.as_tensor(audio_data)
         length = audio_data.shape[-1]
         lcm_value = self.vq_strides[0]
         for s in self.vq_strides[1:]:
             lcm_value = abs(lcm_value * s) // math.gcd(lcm_value, s)
+        if self.attn_window_size:   # the windows of LocalMHA must tile the latent frames (snac.py:76-78)
+            lcm_value = abs(lcm_value * self.attn_window_size) // math.gcd(lcm_value, self.attn_window_size)
         pad_to = self.hop_length * lcm_value
         right_pad = math.ceil(length / pad_to) * pad_to - length
         return torch.nn.functional.pad(audio_data, (0, right_pad))

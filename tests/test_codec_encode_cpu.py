@@ -285,3 +285,21 @@ def test_encodec_from_pretrained_local_directory(tmp_path):
         assert fe.encodec.chunk_length == model.chunk_length and fe.num_q >= 1
     with pytest.raises(FileNotFoundError):
         Encodec.from_pretrained(str(tmp_path / "missing"), device="cpu")
+
+
+def test_snac_preprocess_pads_to_the_attention_window_too():
+    """snac.py:67-86: the pad unit is hop_length x lcm(vq_strides) -- and the LocalMHA window joins the least common multiple when the model has one (the
+    44 kHz model: hop 441, strides 8 / 4 / 2 / 1, window 32 -> 441 x 32 samples, not 441 x 8)."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _ops_emu
+    from mlx_audio_amd.codec.models.snac import SNAC, make_snac_weights
+
+    with _ops_emu.patched():
+        w = make_snac_weights(64, 64, [2, 2], [8, 4, 2, 1], 16, 8, True, True, seed=0)
+        plain = SNAC(sampling_rate=44100, encoder_dim=16, encoder_rates=[3, 3, 7, 7], latent_dim=64, decoder_dim=64, decoder_rates=[2, 2], attn_window_size=None,
+                     codebook_size=16, codebook_dim=8, vq_strides=[8, 4, 2, 1], weights=w, device="cpu")
+        assert plain.hop_length == 441 and plain.preprocess(torch.zeros(1, 1, 1000)).shape[-1] == 441 * 8
+        plain.attn_window_size = 32
+        assert plain.preprocess(torch.zeros(1, 1, 1000)).shape[-1] == 441 * 32
+        plain.attn_window_size = 12
+        assert plain.preprocess(torch.zeros(1, 1, 1000)).shape[-1] == 441 * 24

@@ -451,3 +451,34 @@ def test_codec_encode_edge_cases():
         eq_ref = float((alone[0, 0].cpu() == want[0, 0]).float().mean())
         # a float32 checkpoint behind an fp16 image moves the embeddings by ~5e-4: a flipped code changes every later layer of its frame
         assert eq_batch > 0.95 and eq_ref > 0.85, (b, eq_batch, eq_ref)
+
+
+def test_snac_encode_with_local_mha_vs_oracle():
+    """The 32 / 44 kHz SNAC family: ``LocalMHA`` between the last ``EncoderBlock`` and the final conv of the ENCODER (layers.py:148-149).  Like the decoder's
+    (tests/test_snac_gpu.py::test_local_mha_variant_vs_oracle) it is held to the oracle's restatement of what the module means -- the reference's own
+    transcription raises on channels-last data (tests/golden/ref_snac_local_mha_probe.json): PARITY UNPINNED for this one stage."""
+    from mlx_audio_amd.codec.models.snac import SNAC, make_snac_encoder_weights, make_snac_weights
+    from oracle.snac_ref import SNACEncoderRef
+
+    c = dict(sampling_rate=32000, encoder_dim=16, encoder_rates=[2, 4, 8], decoder_dim=128, decoder_rates=[8, 4, 2], attn_window_size=4, codebook_size=256,
+             codebook_dim=8, vq_strides=[4, 2, 1], noise=True, depthwise=True)
+    latent = 128
+    w = make_snac_weights(latent, 128, c["decoder_rates"], c["vq_strides"], 256, 8, True, True, seed=12, attn=True)
+    w.update(make_snac_encoder_weights(16, c["encoder_rates"], latent, c["vq_strides"], 8, True, seed=12, attn=True))
+    fp16_exact_snac(w)
+    for k in [k for k in w if k.endswith(("to_qkv.weight", "to_out.weight"))]:
+        w[k] = w[k].half().float()
+    eng = SNAC(**c, weights=w, device=DEV)
+    ref = SNACEncoderRef(w, c["encoder_rates"], c["vq_strides"], depthwise=True, attn_window_size=4)
+    audio = make_audio(2, 64 * 4 * 7 + 19, 32000, seed=6)
+    padded = ref.preprocess(audio)
+    assert padded.shape[-1] == 64 * 4 * 8     # hop 64 x lcm(strides 4 / 2 / 1, window 4) = 256
+    zr, est = ref.encoder(padded, return_stages=True)
+    z, gst = eng.encoder(padded, return_stages=True)
+    torch.cuda.synchronize()
+    errs = {k: rel_peak(gst[k], est[k]) for k in est}
+    print(f"snac encoder with LocalMHA: stage rel err { {k: f'{v:.1e}' for k, v in errs.items()} }")
+    assert "attn" in errs and max(errs.values()) < 3e-4, errs
+    _, wc, wm = ref.quantize(zr, return_margins=True)
+    got, gm = eng.encode(audio, return_margins=True)
+    walk_levels("snac_encode", [x.cpu() for x in got], wc, [x.cpu() for x in gm], wm, thr=1e-3)
