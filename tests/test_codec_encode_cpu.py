@@ -87,6 +87,13 @@ def test_dac_encode_host_schedule_dry_run():
         out = eng(audio, c["sample_rate"])
         assert np.array_equal(out["codes"].numpy(), fx["call_codes"]) and rel_max(out["z"].numpy(), fx["call_z"]) < 1e-5
         assert out["audio"].shape == fx["call_audio"].shape and rel_max(out["audio"].numpy(), fx["call_audio"]) < 2e-5
+        # use_rvq = False: encoder -> decoder without the quantizer (the reference then leaves codes / latents / losses unbound and raises at its return
+        # statement, dac.py:218-239; here they are None); return_loss = True: a scalar
+        raw = eng(audio, c["sample_rate"], use_rvq=False)
+        assert raw["codes"] is None and raw["latents"] is None and tuple(raw["z"].shape) == fx["call_z"].shape and raw["audio"].shape == fx["call_audio"].shape
+        assert rel_max(raw["z"].numpy(), eng.encoder(eng.preprocess(audio, c["sample_rate"])).numpy()) == 0.0
+        loss = eng(audio, c["sample_rate"], return_loss=True)
+        assert loss.dim() == 0 and float(loss) > 0 and np.isfinite(float(loss))
     import mlx_audio_amd.ops as real_ops
     assert real_ops.conv_gemm.__module__ == "mlx_audio_amd.ops"   # the emulation is gone after the block
 
