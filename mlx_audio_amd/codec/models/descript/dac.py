@@ -233,8 +233,9 @@ class DAC:
         self.hop_length = int(np.prod(encoder_rates))
         self.n_codebooks, self.codebook_size, self.codebook_dim = n_codebooks, codebook_size, codebook_dim
         self.device = torch.device(device)
-        if weights is None:
+        if weights is None:   # a freshly constructed reference model has both halves (the reference's own tests encode with one: codec/tests/test_descript.py)
             weights = make_dac_weights(decoder_dim, self.decoder_rates, self.latent_dim, n_codebooks, codebook_size, codebook_dim, seed)
+            weights.update(make_dac_encoder_weights(encoder_dim, self.encoder_rates, self.latent_dim, n_codebooks, codebook_dim, seed))
         self.load_weights(weights)
 
     # ------------------------------------------------------------------ load

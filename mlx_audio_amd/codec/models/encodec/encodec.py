@@ -263,7 +263,9 @@ class Encodec:
         if self.c["pad_mode"] not in ("reflect", "constant", "zero"):
             raise ValueError(f"pad_mode {self.c['pad_mode']!r}")
         self.device = torch.device(device)
-        self.load_weights(make_encodec_weights(self.c, seed) if weights is None else weights)
+        if weights is None:   # a freshly constructed reference model has both halves (the reference's own test encodes with one: codec/tests/test_encodec.py)
+            weights = {**make_encodec_weights(self.c, seed), **make_encodec_encoder_weights(self.c, seed)}
+        self.load_weights(weights)
 
     # ------------------------------------------------------------------ load
     def load_weights(self, weights: Dict[str, torch.Tensor], strict: bool = True):

@@ -277,9 +277,12 @@ class SNAC:
         self.n_codebooks, self.codebook_size, self.codebook_dim = len(vq_strides), codebook_size, codebook_dim
         self.vq_strides, self.attn_window_size, self.noise, self.depthwise = list(vq_strides), attn_window_size, noise, depthwise
         self.device = torch.device(device)
-        if weights is None:
+        if weights is None:   # a freshly constructed reference model has both halves (the reference's own test encodes with one: codec/tests/test_snac.py)
             weights = make_snac_weights(self.latent_dim, decoder_dim, self.decoder_rates, self.vq_strides, codebook_size, codebook_dim, noise, depthwise, seed,
                                         attn=attn_window_size is not None)
+            if self.latent_dim == encoder_dim * 2 ** len(self.encoder_rates):   # (the encoder ends at that width: a different latent_dim cannot be fed by it)
+                weights.update(make_snac_encoder_weights(encoder_dim, self.encoder_rates, self.latent_dim, self.vq_strides, codebook_dim, depthwise, seed,
+                                                         attn=attn_window_size is not None and self.latent_dim % 64 == 0))
         self.load_weights(weights)
 
     # ------------------------------------------------------------------ load
@@ -352,7 +355,7 @@ class SNAC:
                                    down=ops.pack_conv(wd.reshape(cout, 2, s * cin).contiguous(), w.get(p + "4.bias"), dev, f16=True)))
             nxt = len(self.encoder_rates) + 1
             enc_attn = None
-            if self.attn_window_size is not None:
+            if self.attn_window_size is not None and f"{e}{nxt}.to_qkv.weight" in w:
                 a = f"{e}{nxt}."
                 dh, dm = 64, self.latent_dim
                 if dm % dh:

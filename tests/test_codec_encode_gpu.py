@@ -482,3 +482,57 @@ def test_snac_encode_with_local_mha_vs_oracle():
     _, wc, wm = ref.quantize(zr, return_margins=True)
     got, gm = eng.encode(audio, return_margins=True)
     walk_levels("snac_encode", [x.cpu() for x in got], wc, [x.cpu() for x in gm], wm, thr=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------------------------ the reference's own test files
+@pytest.mark.parametrize("sr,n_samples,enc_rates,dec_rates,nq,frames,out_len", [
+    (16_000, 80_000, [2, 4, 5, 8], [8, 5, 4, 2], 12, 250, 80_043),
+    (24_000, 120_000, [2, 4, 5, 8], [8, 5, 4, 2], 32, 375, 120_043),
+    (44_100, 220_000, [2, 4, 8, 8], [8, 8, 4, 2], 9, 430, 220_235),
+])
+def test_reference_test_descript_as_written(sr, n_samples, enc_rates, dec_rates, nq, frames, out_len):
+    """codec/tests/test_descript.py:13-109, statement for statement (``mx.zeros`` -> ``torch.zeros``): a FRESHLY CONSTRUCTED model -- published widths, both
+    halves -- preprocesses, encodes, decodes with the shapes the reference pins."""
+    from mlx_audio_amd.codec.models.descript import DAC
+
+    audio = torch.zeros((1, 1, n_samples))
+    model = DAC(encoder_dim=64, encoder_rates=enc_rates, decoder_dim=1536, decoder_rates=dec_rates, n_codebooks=nq, codebook_size=1024, codebook_dim=8, sample_rate=sr)
+    x = model.preprocess(audio, sr)
+    z, codes, latents, _, _ = model.encode(x)
+    assert tuple(z.shape) == (1, 1024, frames) and tuple(codes.shape) == (1, nq, frames) and tuple(latents.shape) == (1, 8 * nq, frames)
+    y = model.decode(z).squeeze(-1)
+    assert tuple(y.shape) == (1, out_len) and torch.isfinite(y).all()
+
+
+def test_reference_test_snac_as_written():
+    """codec/tests/test_snac.py:8-38."""
+    from mlx_audio_amd.codec.models.snac import SNAC
+
+    config = {"sampling_rate": 24000, "encoder_dim": 48, "encoder_rates": [2, 4, 8, 8], "decoder_dim": 1024, "decoder_rates": [8, 8, 4, 2], "attn_window_size": None,
+              "codebook_size": 4096, "codebook_dim": 8, "vq_strides": [4, 2, 1], "noise": True, "depthwise": True}
+    audio = torch.zeros((1, 1, 120_000))
+    model = SNAC(**config)
+    codes = model.encode(audio)
+    assert len(codes) == 3 and tuple(codes[0].shape) == (1, 59) and tuple(codes[1].shape) == (1, 118) and tuple(codes[2].shape) == (1, 236)
+    reconstructed = model.decode(codes).squeeze(-1)
+    assert tuple(reconstructed.shape) == (1, 120_907) and torch.isfinite(reconstructed).all()
+
+
+def test_reference_test_encodec_as_written():
+    """codec/tests/test_encodec.py:7-57."""
+    from mlx_audio_amd.codec.models.encodec import Encodec, EncodecConfig
+
+    config = EncodecConfig(audio_channels=1, chunk_length_s=None, codebook_dim=128, codebook_size=1024, compress=2, dilation_growth_rate=2, hidden_size=128,
+                           kernel_size=7, last_kernel_size=7, model_type="encodec", norm_type="weight_norm", normalize=False, num_filters=32, num_lstm_layers=2,
+                           num_residual_layers=1, overlap=None, pad_mode="reflect", residual_kernel_size=3, sampling_rate=24000,
+                           target_bandwidths=[1.5, 3.0, 6.0, 12.0, 24.0], trim_right_ratio=1.0, upsampling_ratios=[8, 5, 4, 2], use_causal_conv=True)
+    model = Encodec(config)
+    audio = torch.zeros((1, 120_000, 1))
+    codes, scales = model.encode(audio)                      # default bandwidth
+    assert tuple(codes.shape) == (1, 1, 2, 375)
+    audio_out = model.decode(codes, scales)
+    assert tuple(audio_out.shape) == (1, 120_000, 1)
+    codes, scales = model.encode(audio, bandwidth=6)         # 6 kbps
+    assert tuple(codes.shape) == (1, 1, 8, 375)
+    audio_out = model.decode(codes, scales)
+    assert tuple(audio_out.shape) == (1, 120_000, 1) and torch.isfinite(audio_out).all()

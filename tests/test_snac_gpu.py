@@ -128,7 +128,10 @@ def test_surface_and_errors_are_loud():
 
     cfg = dict(sampling_rate=24000, encoder_dim=2, encoder_rates=[2, 4, 8, 8], decoder_dim=64, decoder_rates=[4, 2], attn_window_size=None,
                codebook_size=64, codebook_dim=8, vq_strides=[2, 1], noise=True, depthwise=True)
-    eng = SNAC(**cfg, device=DEV)
+    from mlx_audio_amd.codec.models.snac import make_snac_weights
+
+    dec_only = lambda attn=False: make_snac_weights(32, 64, [4, 2], [2, 1], 64, 8, True, True, seed=0, attn=attn)   # noqa: E731  (no encoder.* / in_proj keys)
+    eng = SNAC(**cfg, weights=dec_only(), device=DEV)
     assert eng.hop_length == 512 and eng.latent_dim == 32 and eng.n_codebooks == 2
     with pytest.raises(IndexError):
         eng.quantizer.from_codes([torch.full((1, 2), 64), torch.zeros((1, 4), dtype=torch.long)])
@@ -141,7 +144,7 @@ def test_surface_and_errors_are_loud():
     with pytest.raises(ValueError, match="decode-only"):
         eng(torch.zeros(1, 1, 800))
     with pytest.raises(ValueError):   # LocalMHA: positions must be a whole number of windows
-        SNAC(**{**cfg, "attn_window_size": 32}, device=DEV).decode([torch.zeros((1, 2), dtype=torch.long), torch.zeros((1, 4), dtype=torch.long)])
+        SNAC(**{**cfg, "attn_window_size": 32}, weights=dec_only(attn=True), device=DEV).decode([torch.zeros((1, 2), dtype=torch.long), torch.zeros((1, 4), dtype=torch.long)])
     assert tuple(eng.preprocess(torch.zeros(1, 1, 1000)).shape) == (1, 1, 1024)   # right-pad to hop 512 * lcm(2, 1) (snac.py:67-86)
     # decode_stream (snac.py:109-165): first call decodes as is and keeps the last context_frames codes per level
     codes = [torch.zeros((1, 6), dtype=torch.long), torch.zeros((1, 12), dtype=torch.long)]
