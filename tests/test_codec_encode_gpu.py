@@ -536,3 +536,29 @@ def test_reference_test_encodec_as_written():
     assert tuple(codes.shape) == (1, 1, 8, 375)
     audio_out = model.decode(codes, scales)
     assert tuple(audio_out.shape) == (1, 120_000, 1) and torch.isfinite(audio_out).all()
+
+
+def test_reference_test_vocos_encodec_half_as_written():
+    """codec/tests/test_vocos.py:33-56, 77-92, as written except that the EnCodec model comes in by argument (the reference's ``EncodecFeatures`` downloads
+    it from the hub by name): 120 000 samples -> 24 kHz EnCodec codes at ``bandwidths[3]`` -> summed codebook rows -> AdaLayerNorm backbone -> iSTFT head
+    (n_fft 1280, hop 320, 'same' padding): 119 680 samples both through ``__call__`` and through ``get_encodec_codes`` + ``decode_from_codes``."""
+    from mlx_audio_amd.codec.models.encodec import Encodec, EncodecConfig
+    from mlx_audio_amd.codec.models.vocos import Vocos
+
+    config_encodec = {
+        "feature_extractor": {"class_path": "vocos.feature_extractors.EncodecFeatures",
+                              "init_args": {"encodec_model": "encodec_24khz", "bandwidths": [1.5, 3.0, 6.0, 12.0, 24.0]}},
+        "backbone": {"class_path": "vocos.models.VocosBackbone",
+                     "init_args": {"input_channels": 128, "dim": 384, "intermediate_dim": 1152, "num_layers": 8, "adanorm_num_embeddings": 4}},
+        "head": {"class_path": "vocos.heads.ISTFTHead", "init_args": {"dim": 384, "n_fft": 1280, "hop_length": 320, "padding": "same"}},
+    }
+    encodec_24khz = Encodec(EncodecConfig(upsampling_ratios=[8, 5, 4, 2], target_bandwidths=[1.5, 3.0, 6.0, 12.0, 24.0]))
+    audio = torch.zeros((120_000))
+    model = Vocos.from_hparams(config_encodec, encodec=encodec_24khz)
+    bandwidth_id = [3, 3, 3, 3]
+    reconstructed_audio = model(audio, bandwidth_id=torch.tensor(bandwidth_id)[None, ...])
+    assert tuple(reconstructed_audio.shape) == (119680,)
+    codes = model.get_encodec_codes(audio, bandwidth_id=bandwidth_id)
+    assert tuple(codes.shape) == (16, 1, 375)                     # 12 kbps = 16 codebooks
+    decoded = model.decode_from_codes(codes, bandwidth_id=torch.tensor(bandwidth_id)[None, ...])
+    assert tuple(decoded.shape) == (119680,) and torch.equal(decoded, reconstructed_audio) and torch.isfinite(decoded).all()
