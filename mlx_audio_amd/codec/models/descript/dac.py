@@ -288,6 +288,22 @@ class DAC:
             self.enc = dict(stem=stem, k0=w0.shape[1], dim=w0.shape[0], blocks=blocks, snake=_Snake(w[f"{e}{ne + 1}.alpha"], dev), out=conv(f"{e}{ne + 2}"))
         return self
 
+    @classmethod
+    def from_pretrained(cls, repo_id: str, device="cuda:0") -> "DAC":
+        """dac.py:251-270 for a LOCAL directory (``config.json`` = the constructor's keyword arguments, ``model.safetensors``); the reference's
+        ``fetch_from_hub`` needs the network, which this build does not have."""
+        import json
+        from pathlib import Path
+
+        from safetensors.torch import load_file
+
+        path = Path(repo_id)
+        if not path.exists():
+            raise FileNotFoundError(f"{repo_id}: DAC.from_pretrained needs a local directory (no hub access in this build)")
+        with open(path / "config.json") as f:
+            config = json.load(f)
+        return cls(**config, weights=load_file(str(path / "model.safetensors")), device=device)
+
     # ------------------------------------------------------------------ reference surface
     def preprocess(self, audio_data, sample_rate):
         if sample_rate is None:

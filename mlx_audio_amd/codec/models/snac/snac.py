@@ -370,6 +370,27 @@ class SNAC:
             self.enc = dict(stem=stem, k0=w0.shape[1], dim=w0.shape[0], blocks=blocks, attn=enc_attn, out=mid(f"{e}{nxt}"))
         return self
 
+    @classmethod
+    def from_config(cls, config_path, **kwargs) -> "SNAC":
+        """snac.py:177-182: a model (random parameters, like the reference's) from a ``config.json``."""
+        import json
+
+        with open(config_path, "r") as f:
+            config = json.load(f)
+        return cls(**config, **kwargs)
+
+    @classmethod
+    def from_pretrained(cls, repo_id, device="cuda:0", **kwargs) -> "SNAC":
+        """snac.py:184-201 for a LOCAL directory (``config.json`` + ``model.safetensors``); the reference's ``fetch_from_hub`` needs the network."""
+        from pathlib import Path
+
+        from safetensors.torch import load_file
+
+        path = Path(repo_id)
+        if not path.exists():
+            raise FileNotFoundError(f"{repo_id}: SNAC.from_pretrained needs a local directory (no hub access in this build)")
+        return cls.from_config(path / "config.json", weights=load_file(str(path / "model.safetensors")), device=device, **kwargs)
+
     # ------------------------------------------------------------------ reference surface
     def preprocess(self, audio_data):
         """snac.py:67-86: right-pad to a multiple of hop_length * lcm(vq_strides [, attn_window_size])."""

@@ -310,3 +310,38 @@ def test_snac_preprocess_pads_to_the_attention_window_too():
         assert plain.preprocess(torch.zeros(1, 1, 1000)).shape[-1] == 441 * 32
         plain.attn_window_size = 12
         assert plain.preprocess(torch.zeros(1, 1, 1000)).shape[-1] == 441 * 24
+
+
+def test_dac_and_snac_from_pretrained_local_directories(tmp_path):
+    """``DAC.from_pretrained`` (dac.py:251-270) and ``SNAC.from_config / from_pretrained`` (snac.py:177-201) on LOCAL directories (``config.json`` =
+    the constructor's keyword arguments + ``model.safetensors`` in the reference's parameter names): the loaded models reproduce the reference run's codes."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _ops_emu
+    from safetensors.torch import save_file
+
+    from mlx_audio_amd.codec.models.descript import DAC
+    from mlx_audio_amd.codec.models.snac import SNAC
+
+    fx = np.load(os.path.join(GOLD, "ref_dac_encode.npz"))
+    c, w = dac_model_weights(fx)
+    d = tmp_path / "dac"
+    d.mkdir()
+    json.dump(c, open(d / "config.json", "w"))
+    save_file({k: v.contiguous() for k, v in w.items()}, str(d / "model.safetensors"))
+    fs = np.load(os.path.join(GOLD, "ref_snac_encode_dense.npz"))
+    sc, sw = snac_model_weights(fs)
+    s = tmp_path / "snac"
+    s.mkdir()
+    json.dump(sc, open(s / "config.json", "w"))
+    save_file({k: v.contiguous() for k, v in sw.items()}, str(s / "model.safetensors"))
+    with _ops_emu.patched():
+        dac = DAC.from_pretrained(str(d), device="cpu")
+        _, codes, *_ = dac.encode(torch.from_numpy(fx["audio"]))
+        assert np.array_equal(codes.numpy(), fx["codes"])
+        snac = SNAC.from_pretrained(str(s), device="cpu")
+        assert all(np.array_equal(a.numpy(), fs[f"codes{i}"]) for i, a in enumerate(snac.encode(torch.from_numpy(fs["audio"]))))
+        fresh = SNAC.from_config(s / "config.json", device="cpu")       # random parameters, both halves
+        assert fresh.enc is not None and fresh.quantizer.in_proj is not None and [tuple(x.shape) for x in fresh.encode(torch.zeros(1, 1, 500))] == [(1, 3), (1, 6), (1, 12)]   # 500 -> 576 samples = 12 frames of hop 48
+    for cls in (DAC, SNAC):
+        with pytest.raises(FileNotFoundError):
+            cls.from_pretrained(str(tmp_path / "missing"), device="cpu")
