@@ -33,6 +33,7 @@ import torch
 
 from .... import ops
 from ....ops import ACT_NONE, ACT_SNAKE, ACT_TANH, PackedConv, round_up
+from .base import CodecMixin, DACFile  # noqa: F401
 
 
 def make_dac_weights(decoder_dim: int, decoder_rates: List[int], latent_dim: int, n_codebooks: int, codebook_size: int, codebook_dim: int,
@@ -216,7 +217,7 @@ class _Quantizer:
         return z.transpose(1, 2), z_p.transpose(1, 2), codes
 
 
-class DAC:
+class DAC(CodecMixin):
     def __init__(self, encoder_dim: int = 64, encoder_rates: List[int] = [2, 4, 5, 8], latent_dim: int = None, decoder_dim: int = 1536,
                  decoder_rates: List[int] = [8, 5, 4, 2], n_codebooks: int = 32, codebook_size: int = 1024, codebook_dim: Union[int, list] = 8,
                  sample_rate: int = 44100, weights: Optional[Dict[str, torch.Tensor]] = None, device="cuda:0", seed: int = 0, **kwargs):

@@ -916,6 +916,49 @@ def run_dac_encode(seed_w, seed_audio, n_samples):
                 call_audio=_np(out["audio"]), call_codes=np.asarray(out["codes"]).astype(np.int32), call_z=_np(out["z"]))
 
 
+def run_dac_compress(seed_w, seed_audio):
+    """The reference's ``CodecMixin.compress`` / ``decompress`` (codec/models/descript/base.py:123-231) on the seeded checkpoint of ``run_dac_encode``, with a
+    scripted ``mlx_audio.audio_io.read`` (miniaudio is not in this image): (a) a signal longer than the window (2.3 windows of 0.1 s -> three chunks, the last
+    one zero-padded), (b) a signal shorter than the window (one chunk, ``padding`` True); also what ``get_delay`` / ``get_output_length`` return on this
+    architecture and a ``DACFile`` save / load round trip."""
+    from mlx_audio_amd.codec.models.descript import make_dac_encoder_weights, make_dac_weights
+
+    rd = _load_dac_modules()
+    rb = sys.modules["mlx_audio.codec.models.descript.base"]
+    c = DAC_ENC_TINY
+    w = make_dac_weights(c["decoder_dim"], c["decoder_rates"], c["latent_dim"], c["n_codebooks"], c["codebook_size"], c["codebook_dim"], seed=seed_w)
+    w.update(make_dac_encoder_weights(c["encoder_dim"], c["encoder_rates"], c["latent_dim"], c["n_codebooks"], c["codebook_dim"], seed=seed_w))
+    model = rd.DAC(**c)
+    model.load_weights([(k, v.numpy()) for k, v in w.items()])
+    model.eval()
+    g = np.random.default_rng(seed_audio)
+    sr = c["sample_rate"]
+    out = dict(seed_w=seed_w, config=json.dumps(c), delay=np.int32(model.delay), out_len_1000=np.int32(model.get_output_length(1000)))
+    fake = types.ModuleType("mlx_audio.audio_io")
+    saved = sys.modules.get("mlx_audio.audio_io")
+    try:
+        for tag, n, win in (("long", int(0.23 * sr), 0.1), ("short", int(0.07 * sr), 0.1)):
+            t = np.arange(n) / sr
+            sig = (0.3 * np.sin(2 * np.pi * 220 * t) + 0.05 * g.standard_normal(n)).astype(np.float32)
+            fake.read = lambda path, _s=sig: (_s, sr)
+            sys.modules["mlx_audio.audio_io"] = fake
+            f = model.compress("scripted.wav", win_duration=win)
+            rec = model.decompress(f)
+            out.update({f"{tag}_signal": sig, f"{tag}_codes": np.asarray(f.codes).astype(np.int32), f"{tag}_chunk_length": np.int32(f.chunk_length),
+                        f"{tag}_original_length": np.float64(f.original_length), f"{tag}_input_db": np.float32(np.asarray(f.input_db)), f"{tag}_padding": np.bool_(f.padding),
+                        f"{tag}_channels": np.int32(f.channels), f"{tag}_recons": _np(rec), f"{tag}_win": np.float32(win)})
+            if tag == "long":
+                f2 = model.compress("scripted.wav", win_duration=win, n_quantizers=2)
+                out["long_codes_nq2"] = np.asarray(f2.codes).astype(np.int32)
+    finally:
+        if saved is not None:
+            sys.modules["mlx_audio.audio_io"] = saved
+        else:
+            sys.modules.pop("mlx_audio.audio_io", None)
+    out["padding_after"] = np.bool_(model.padding)
+    return out
+
+
 def run_snac(seed_w, seed_codes, n_frames, attn_window_size=None):
     """The reference's ``SNAC.quantizer.from_codes`` + ``SNAC.decoder`` (codec/models/snac/{snac,layers,vq}.py), depthwise convs, no attention, with the
     NoiseBlock's gaussian draws logged."""
@@ -1874,6 +1917,9 @@ def main():
         efx = run_dac_encode(seed_w=31, seed_audio=4, n_samples=320 * 24 + 77)
         np.savez_compressed(os.path.join(HERE, "ref_dac_encode.npz"), **efx)
         print("dac encode:", {a: (v.shape if hasattr(v, "shape") else v) for a, v in efx.items() if a != "config"}, float(efx["commitment_loss"]))
+        cfx = run_dac_compress(seed_w=31, seed_audio=8)
+        np.savez_compressed(os.path.join(HERE, "ref_dac_compress.npz"), **cfx)
+        print("dac compress:", {a: (v.shape if hasattr(v, "shape") and v.shape else v) for a, v in cfx.items() if a != "config"})
         for dwise in (True, False):
             sfx = run_snac_encode(seed_w=33, seed_audio=6, n_samples=48 * 4 * 9 + 101, depthwise=dwise)
             np.savez_compressed(os.path.join(HERE, f"ref_snac_encode_{'dw' if dwise else 'dense'}.npz"), **sfx)
