@@ -562,3 +562,27 @@ def test_reference_test_vocos_encodec_half_as_written():
     assert tuple(codes.shape) == (16, 1, 375)                     # 12 kbps = 16 codebooks
     decoded = model.decode_from_codes(codes, bandwidth_id=torch.tensor(bandwidth_id)[None, ...])
     assert tuple(decoded.shape) == (119680,) and torch.equal(decoded, reconstructed_audio) and torch.isfinite(decoded).all()
+
+
+def test_dac_compress_decompress_against_the_reference_run():
+    """``DAC.compress`` / ``decompress`` (codec/models/descript/base.py:123-231) on the device against the reference's own run (scripted audio reader,
+    tests/golden/ref_dac_compress.npz): chunking, normalisation, the codes of every chunk under the margin rule, the reconstruction where the codes agree."""
+    from mlx_audio_amd.codec.models.descript import DAC
+    from test_codec_encode_cpu import dac_model_weights
+    from oracle.dac_ref import DACEncoderRef
+
+    fx = np.load(os.path.join(GOLD, "ref_dac_compress.npz"))
+    c, w = dac_model_weights(fx)
+    eng, ref = DAC(**c, weights=w, device=DEV), DACEncoderRef(w, c["encoder_rates"], c["n_codebooks"])
+    for tag in ("long", "short"):
+        f = eng.compress((fx[f"{tag}_signal"], c["sample_rate"]), win_duration=float(fx[f"{tag}_win"]))
+        want = torch.from_numpy(fx[f"{tag}_codes"]).long()
+        assert tuple(f.codes.shape) == tuple(want.shape) and f.chunk_length == int(fx[f"{tag}_chunk_length"]) and f.padding == bool(fx[f"{tag}_padding"])
+        assert abs(f.input_db - float(fx[f"{tag}_input_db"])) < 1e-4 and eng.padding is True
+        same = (f.codes.cpu() == want).all(dim=1)[0]                  # frames whose whole chain agrees (a float32 checkpoint behind an fp16 image)
+        assert float(same.float().mean()) > 0.7, float(same.float().mean())
+        rec = eng.decompress(f)
+        torch.cuda.synchronize()
+        assert tuple(rec.shape) == fx[f"{tag}_recons"].shape and torch.isfinite(rec).all()
+        if bool(same.all()):
+            assert rel_peak(rec, fx[f"{tag}_recons"]) < 2e-3
