@@ -6,8 +6,6 @@ for the duration of a ``with`` block."""
 from __future__ import annotations
 
 import contextlib
-import math
-from typing import Optional
 
 import torch
 

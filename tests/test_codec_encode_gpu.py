@@ -2,7 +2,6 @@
 reference's own modules by tests/test_codec_encode_cpu.py) and against the reference-run fixtures themselves.  Float stages within stated bars; codes
 bit-exact under the margin rule (tests/_margin.py: a decision whose top-2 gap is at float32 rounding level may fall either way).
 Needs a real MI355X: ``pytest -m gpu``."""
-import json
 import os
 import sys
 
