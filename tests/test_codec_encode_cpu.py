@@ -379,3 +379,43 @@ def test_dac_compress_decompress_against_the_reference_run(tmp_path):
         assert np.array_equal(f2.codes.numpy(), fx["long_codes_nq2"])
         with pytest.raises(ValueError, match="does not match the sample rate"):
             eng.compress((fx["short_signal"], 8000))
+
+
+def test_codec_decode_host_schedules_dry_run():
+    """The DECODE schedules of DAC / SNAC / EnCodec (folded lookup tables, Snake / ELU prologues, polyphase transposed convs with their trims, depthwise convs,
+    the noise blocks, the LSTM, the reflect paddings) over the emulated operators against the reference's own ``decode`` runs (tests/golden/ref_{dac,snac,
+    encodec}_tiny.npz) -- the host logic of these rows on the CPU suite; the kernels themselves are held by tests/test_{dac,snac,encodec}_gpu.py."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _ops_emu
+    from mlx_audio_amd.codec.models.descript import DAC, make_dac_weights
+    from mlx_audio_amd.codec.models.encodec import Encodec, make_encodec_weights
+    from mlx_audio_amd.codec.models.snac import SNAC, make_snac_weights
+
+    with _ops_emu.patched():
+        fx = np.load(os.path.join(GOLD, "ref_dac_tiny.npz"))
+        rates, dim, latent, nq, csize, cdim = [8, 5, 4, 2], 64, 32, 3, 128, 8
+        dac = DAC(encoder_dim=16, encoder_rates=[2, 4, 5, 8], latent_dim=latent, decoder_dim=dim, decoder_rates=rates, n_codebooks=nq, codebook_size=csize, codebook_dim=cdim,
+                  sample_rate=16000, weights=make_dac_weights(dim, rates, latent, nq, csize, cdim, seed=int(fx["seed_w"])), device="cpu")
+        z, _, _ = dac.quantizer.from_codes(torch.from_numpy(fx["codes"]).long())
+        assert rel_max(z.numpy(), fx["z"]) < 1e-5
+        audio = dac.decode(z)
+        assert audio.shape == fx["audio"].shape and rel_max(audio.numpy(), fx["audio"]) < 3e-5
+
+        fs = np.load(os.path.join(GOLD, "ref_snac_tiny.npz"), allow_pickle=True)
+        cfg = json.loads(str(fs["config"]))
+        lat = cfg["encoder_dim"] * 2 ** len(cfg["encoder_rates"])
+        snac = SNAC(**cfg, weights=make_snac_weights(lat, cfg["decoder_dim"], cfg["decoder_rates"], cfg["vq_strides"], cfg["codebook_size"], cfg["codebook_dim"], True, True,
+                                                     seed=int(fs["seed_w"])), device="cpu")
+        codes = [torch.from_numpy(fs[f"codes{i}"]).long() for i in range(len(cfg["vq_strides"]))]
+        noises = [torch.from_numpy(fs[f"noise{i}"]) for i in range(int(fs["n_noise"]))]
+        assert rel_max(snac.quantizer.from_codes(codes).numpy(), fs["z"]) < 1e-5
+        a2 = snac.decode(codes, noises=noises)
+        assert a2.shape == fs["audio"].shape and rel_max(a2.numpy(), fs["audio"]) < 3e-5
+
+        fe = np.load(os.path.join(GOLD, "ref_encodec_tiny.npz"))
+        ecfg = json.loads(str(fe["config"]))
+        enc = Encodec(ecfg, weights=make_encodec_weights(ecfg, seed=int(fe["seed_w"])), device="cpu")
+        ecodes = torch.from_numpy(fe["codes"]).long()
+        assert rel_max(enc.quantizer.decode(ecodes[:, 0]).numpy(), fe["embeddings"]) < 1e-6   # (the emulation sums in float64; the kernel's float32 slot order is held bit-exact on the GPU)
+        a3 = enc.decode(ecodes, [None])
+        assert a3.shape == fe["audio"].shape and rel_max(a3.numpy(), fe["audio"]) < 5e-5
