@@ -648,7 +648,7 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
     const long wgs128 = (long)a.B * ((a.Lout + 127) / 128) * ((a.Cout + 127) / 128);
     const bool want = tile % 10000000 == 6128128 || (tile == 0 && !no_ws5 && a.Cout > 64 && wgs128 >= ws_min5 && a.Cin >= 64);
     if (want && mi355_conv_ws4_eligible(a, vec)) {
-      const int rc = mi355_conv_ws4_launch(a, st, tile == 0 ? 0 : (tile / 10000000) & 3);
+      const int rc = mi355_conv_ws4_launch(a, st, tile == 0 ? 0 : (((tile / 10000000) % 10) | ((tile / 100000000) << 4)));   // feature / probe / ablation bits
       if (rc != MI355_ERR_UNSUPPORTED) return rc;
     }
     MI355_REQUIRE(tile % 10000000 != 6128128, "conv_gemm: precision 5 on the wave-specialised tile needs K = 3 (mod 4), a plain / LeakyReLU / Snake prologue, "

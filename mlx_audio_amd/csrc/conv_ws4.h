@@ -49,7 +49,8 @@ struct ws4_geom {
 };
 
 // timeline probe (DBG instantiation only): s_memtime stamps of consumer wave 0 of every 16th workgroup, 4 per tile for its first 8 tiles
-constexpr int kDbgSlots = 34;
+constexpr int kDbgSlots = 48;   // 0..31: 4 stamps x 8 tiles, 32..33: wall clock, 34..41: cycles waited at the chunk barriers per tile (PREC 5 probe),
+                                 // 42..47: producer wave 4: cycles in convertA / at barriers / in loadA, items, first / last stamp (PREC 5 probe)
 
 struct tile_t { int b, l0, n0, len_out, len_in; };
 
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
   static_assert(!FQ || (!GEMM && (PRE == P_NONE || PRE == P_LEAKY || PRE == P_SNAKE)), "quantising prologues: conv mode, none / LeakyReLU / Snake");
   constexpr int BM = 128;
   static_assert(BN == 128 || BN == 64, "tile columns");
-  static_assert(PREC != 5 || (!GEMM && !FQ && !DBG && ABL == 0 && BN == 128), "precision 5: conv mode, 128-column tiles");
+  static_assert(PREC != 5 || (!GEMM && !FQ && BN == 128), "precision 5: conv mode, 128-column tiles");
   constexpr int NLD = GEMM ? 8 : 6;  // window passes of 32 rows per chunk (conv: R <= 192; GEMM mode: R = 256)
   constexpr int NA = a_images<PREC>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -312,23 +313,51 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
     item_t ib = ia;
     advance(ib);
     constexpr bool work = (ABL & 4) == 0;
+    // PREC 5 probe: producer wave 4 of every 16th workgroup sums the cycles it spends converting, at the barriers and issuing loads
+    unsigned long long* pdbg = nullptr;
+    unsigned long long pc_conv = 0, pc_bar = 0, pc_load = 0, pc_items = 0, pc_first = 0, pc_t = 0;
+    if constexpr (DBG && PREC == 5) {
+      if (wave == 4 && (blockIdx.x & 15) == 0 && q.dbg) pdbg = q.dbg + (size_t)(blockIdx.x >> 4) * kDbgSlots;
+      if (pdbg) pc_first = pc_t = __builtin_amdgcn_s_memtime();
+    }
+    auto pstamp = [&](unsigned long long& acc_c) {
+      if constexpr (DBG && PREC == 5) {
+        if (pdbg) { const unsigned long long n = __builtin_amdgcn_s_memtime(); acc_c += n - pc_t; pc_t = n; }
+      }
+    };
     if (work) loadA(s0, k0, ia);
     if (work && ib.id >= 0) loadA(s1, k1, ib);
+    pstamp(pc_load);
     while (true) {
       if (work) convertA(s0, k0, ia, Abase);
+      if constexpr (DBG && PREC == 5) { if (pdbg) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+      pstamp(pc_conv);
       item_t na = ib;
       if (na.id >= 0) advance(na);
       if (work) loadA(s0, k0, na.id >= 0 ? na : ia);   // past the last item: the current one again (unconditional: see loadA), never converted
+      pstamp(pc_load);
       lds_barrier();  // even item staged
+      pstamp(pc_bar);
+      ++pc_items;
       if (ib.id < 0) break;
       if (work) convertA(s1, k1, ib, Abase + WBYTES);
+      if constexpr (DBG && PREC == 5) { if (pdbg) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+      pstamp(pc_conv);
       item_t nb = na;
       if (nb.id >= 0) advance(nb);
       if (work) loadA(s1, k1, nb.id >= 0 ? nb : ib);
+      pstamp(pc_load);
       lds_barrier();  // odd item staged
+      pstamp(pc_bar);
+      ++pc_items;
       if (na.id < 0) break;
       ia = na;
       ib = nb;
+    }
+    if constexpr (DBG && PREC == 5) {
+      if (pdbg && lane_k == 0) {
+        pdbg[42] = pc_conv; pdbg[43] = pc_bar; pdbg[44] = pc_load; pdbg[45] = pc_items; pdbg[46] = pc_first; pdbg[47] = pc_t;
+      }
     }
     return;
   }
@@ -458,8 +487,11 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
       // weight item s: a wave-uniform base (SGPR pair) + the lane's 32-bit offset: no 64-bit VALU address arithmetic, no pointer VGPRs
       const char* wtile = (const char*)a.w + ((int64_t)((n0 >> 5) + wn * NF)) * 2048;
       const uint32_t wlane = (uint32_t)lane * 16u;
-      auto ldW = [&](i32x8 (&w)[2], const int s) {
+      auto ldW = [&](i32x8 (&w)[2], const int s, const bool first = false) {
         const char* src = wtile + (int64_t)(s < last_slice ? s : last_slice) * wstep;
+        if constexpr ((ABL & 1) != 0) {   // timing ablation: only the tile's first weight item is loaded
+          if (!first) { asm volatile("" : "+v"(w[0]), "+v"(w[1]) : "s"(src)); return; }
+        }
 #pragma unroll
         for (int nf = 0; nf < 2; ++nf) {
           const i32x4 lo4 = *(const i32x4*)(src + (2 * nf) * 1024 + wlane), hi4 = *(const i32x4*)(src + (2 * nf + 1) * 1024 + wlane);
@@ -467,7 +499,8 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
         }
       };
       i32x8 w0[2], w1[2];
-      ldW(w0, 0);
+      ldW(w0, 0, true);
+      if constexpr ((ABL & 1) != 0) { w1[0] = w0[0]; w1[1] = w0[1]; }
       // Activation operands: two 8-register tuples.  hi phase: four fragment sets (qa low / high half, qb low / high half = groups 0..3 of a tap), each
       // refilled with the NEXT tap's fragment right behind the MFMAs that read it: a read is four groups (8 MFMAs) ahead of its use.  lo phase:
       // qa = the e4m3 operand of rows 0..31 of the wave's block, qb = rows 32..63, each refilled for the next tap pair behind its two MFMAs.
@@ -495,7 +528,9 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
         const int uoff = jbuf * WBYTES + (mf * 32 + tp * dil) * HP + kk * 32;   // wave-uniform
         int la = lbH;
         asm volatile("" : "+v"(la));   // one add per read, recomputed: a shared (hoisted) address per (group, tap) costs a register each
-        const i32x4 v = *(const i32x4*)(Abase + (la + uoff));
+        i32x4 v;
+        if constexpr ((ABL & 2) != 0) v = (i32x4){la, la, la, la};   // timing ablation: no LDS read
+        else v = *(const i32x4*)(Abase + (la + uoff));
         if (g == 0) set_lo(qa, v);
         else if (g == 1) set_hi(qa, v);
         else if (g == 2) set_lo(qb, v);
@@ -510,9 +545,15 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
         const int ubase = jbuf * WBYTES + ABYTES;
         int la = lbL, ls = lbS;
         asm volatile("" : "+v"(la), "+v"(ls));
-        const i32x4 x0 = *(const i32x4*)(Abase + (la + (ubase + u0 * LP)));
-        const i32x4 x1 = *(const i32x4*)(Abase + (la + (ubase + u1 * LP)));
-        const int sc = (int)*(const uint8_t*)(Abase + (ls + (ubase + R * LP + (hhx ? u1 : u0))));
+        i32x4 x0, x1;
+        int sc;
+        if constexpr ((ABL & 2) != 0) {
+          x0 = (i32x4){la, la, la, la}; x1 = x0; sc = 120 + (ls & 7);   // timing ablation: no LDS read
+        } else {
+          x0 = *(const i32x4*)(Abase + (la + (ubase + u0 * LP)));
+          x1 = *(const i32x4*)(Abase + (la + (ubase + u1 * LP)));
+          sc = (int)*(const uint8_t*)(Abase + (ls + (ubase + R * LP + (hhx ? u1 : u0))));
+        }
         if (mf == 0) { qa = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7); sa = sc; }
         else { qb = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7); sb2 = sc; }
       };
@@ -573,8 +614,22 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
       // One chunk: K hi items, then NP lo items; wa holds item s on entry, wb holds the next chunk's first item on exit (K odd, NP even: the
       // roles of the two register sets swap from chunk to chunk, hence the two instances below).
       int s = 0;
+      unsigned long long bar_wait = 0;
+      bool first_chunk = true;
       auto chunk_body = [&](i32x8 (&wa)[2], i32x8 (&wb)[2]) {
-        lds_barrier();  // the chunk's window is staged behind this barrier (and the producers may refill the buffer just left)
+        if constexpr (DBG) {
+          unsigned long long tb0 = 0;
+          if (dbg) tb0 = __builtin_amdgcn_s_memtime();
+          lds_barrier();
+          if (dbg) {
+            const unsigned long long tb1 = __builtin_amdgcn_s_memtime();
+            bar_wait += tb1 - tb0;
+            if (first_chunk && lane == 0 && ntile < 8) dbg[4 * ntile + 1] = tb1;  // first window staged
+            first_chunk = false;
+          }
+        } else {
+          lds_barrier();  // the chunk's window is staged behind this barrier (and the producers may refill the buffer just left)
+        }
         fresh();
         rdH(0, 0);
         rdH(1, 0);
@@ -604,6 +659,9 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
         chunk_body(w0, w1);
         if (c + 1 >= nch) break;
         chunk_body(w1, w0);
+      }
+      if constexpr (DBG) {
+        if (dbg && lane == 0 && ntile < 8) dbg[34 + ntile] = bar_wait;
       }
       // the tile's last MFMAs are asm statements: 16 passes -> 19 wait states before anything but an MFMA may touch their D
       asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
@@ -804,3 +862,4 @@ int mi355_conv_ws4_p4(const mi355_conv_gemm_args& a, hipStream_t st, int feat, i
 int mi355_conv_ws4_p13(const mi355_conv_gemm_args& a, hipStream_t st, int feat, int bn);
 int mi355_conv_ws4_fq(const mi355_conv_gemm_args& a, hipStream_t st, int feat, int bn);   // quantising prologues (pre_fq), precision 2
 int mi355_conv_ws4_p5(const mi355_conv_gemm_args& a, hipStream_t st, int feat, int bn);   // fp16 hi + MX e4m3 lo (conv mode, 128-column tiles)
+int mi355_conv_ws4_p5_probe(const mi355_conv_gemm_args& a, hipStream_t st, int feat, unsigned long long* dbg);   // its probe / ablation builds

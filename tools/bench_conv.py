@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--ablate", action="store_true", help="timing ablations of the wave-specialised kernel (their results are wrong by design)")
     ap.add_argument("--small", action="store_true", help="the few-row GEMMs of PL-BERT / predictor (rows = B*80): 4-wave tile shapes A/B")
     ap.add_argument("--prec-ab", action="store_true", help="the wave-specialised kernel under precisions 2 (bf16 hi+lo), 3 (one fp16 pass), 4 (fp16 hi+lo) and 5 (fp16 hi + MX e4m3 lo)")
+    ap.add_argument("--pmc5", action="store_true", help="precision-5 wave-specialised kernel only, three shapes, few rounds (for rocprofv3 --pmc passes and power sampling)")
+    ap.add_argument("--loop-seconds", type=float, default=0.0, help="with --pmc5: keep launching the first shape for this long (power / clock sampling by rocm-smi alongside)")
     ap.add_argument("--flat", action="store_true", help="with --small: hand the batch over as ONE item of B*L rows (ops.conv_gemm(flatten=True))")
     args = ap.parse_args()
     from mlx_audio_amd import ops
@@ -53,6 +55,10 @@ def main():
         W = 6128128
         variants = [("ws4", W), ("abl1_noBload", 100000000 + W), ("abl2_noAread", 200000000 + W), ("abl3_noAB", 300000000 + W),
                     ("abl4_noProducer", 400000000 + W), ("abl7_noABP", 700000000 + W)]
+        if args.precision == 5:
+            shapes = [(128, 128, 11, 1, 31681, "snake+res"), (128, 128, 7, 1, 31681, "snake+res"), (128, 128, 11, 5, 31681, "snake"), (256, 256, 11, 1, 5280, "snake+res")]
+            variants = [("ws4", W), ("abl1_noBload", 100000000 + W), ("abl4_noProducer", 400000000 + W), ("abl5_noBload_noProducer", 500000000 + W),
+                        ("ws4_1tile", 80000000 + W), ("ws4_noprio", 10000000 + W)]
     if args.small:
         shapes = [(768, 2304, 1, 1, 80, "plain"), (768, 768, 1, 1, 80, "plain"), (768, 2048, 1, 1, 80, "plain"), (2048, 768, 1, 1, 80, "plain"),
                   (640, 2048, 1, 1, 264, "plain"), (1090, 1024, 3, 1, 264, "leaky"), (1024, 1024, 3, 1, 264, "leaky"), (512, 512, 3, 1, 528, "leaky"),
@@ -61,6 +67,11 @@ def main():
     if args.quick:
         shapes = [(128, 128, 11, 1, 31681, "snake+res"), (128, 128, 3, 1, 31681, "snake+res")]
         variants = [("old64x128", 64128), ("ws4", 6128128)]
+    if args.pmc5:
+        args.precision = 5
+        shapes = [(128, 128, 11, 1, 31681, "snake+res"), (128, 128, 7, 1, 31681, "snake+res"), (256, 256, 11, 1, 5280, "snake+res")]
+        variants = [("ws4", 6128128)]
+        args.rounds = 3
     if args.prec_ab:
         shapes = [s for s in shapes if s[2] % 4 == 3]
         variants = [("p2_bf16_hi_lo", 6128128), ("p3_fp16_one_pass", 6128128), ("p4_fp16_hi_lo", 6128128), ("p5_fp16_hi_mx8_lo", 6128128)]
@@ -71,7 +82,7 @@ def main():
             L, B = L * args.batch, 1
         w = (torch.randn(cout, k, cin) / math.sqrt(k * cin)).to(torch.bfloat16).float()
         bias = torch.randn(cout) * 0.1
-        pc = ops.pack_conv(w, bias, dev, f16=args.precision == 3)
+        pc = ops.pack_conv(w, bias, dev, mx=True) if args.precision == 5 else ops.pack_conv(w, bias, dev, f16=args.precision == 3)
         vprec = {name: args.precision for name, _ in variants}
         vpc = {name: pc for name, _ in variants}
         if args.prec_ab:
@@ -124,6 +135,16 @@ def main():
                 errs[name] = float((got - ref[:ok_rows]).abs().max() / ref.abs().max())
             except Exception as e:  # a variant may not support a shape
                 errs[name] = str(e)[:60]
+        if args.loop_seconds > 0 and (cin, k) == (shapes[0][0], shapes[0][2]):
+            import time
+            t_end = time.time() + args.loop_seconds
+            n = 0
+            while time.time() < t_end:
+                for _ in range(50):
+                    ops.conv_gemm(x[:, :, :cin], vpc["ws4"], y, dil=dil, pad=pad, tile=6128128, precision=vprec["ws4"], **kw)
+                torch.cuda.synchronize()
+                n += 50
+            print(f"# sustained loop: {n} launches in {args.loop_seconds:.1f} s = {args.loop_seconds / n * 1e6:.1f} us per launch", flush=True)
         for _ in range(args.rounds):
             for name, tile in variants:
                 if isinstance(errs[name], str):

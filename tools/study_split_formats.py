@@ -54,6 +54,31 @@ def mx_e4m3(x, dim):
     return q.reshape(*shp[:-1], -1)[..., :C].movedim(-1, dim)
 
 
+def mx_small(x, dim, ebits, mbits):
+    """OCP MX fp6 / fp4 image (e2m3, e3m2, e2m1): one power-of-two scale per 32 elements along ``dim``; shared exponent = floor(log2(amax)) - emax_elem,
+    elements round to nearest even and saturate at the format's maximum."""
+    bias = (1 << (ebits - 1)) - 1
+    emax = (1 << ebits) - 1 - bias            # no inf / nan encodings in fp6 / fp4
+    fmax = (2.0 - 2.0 ** -mbits) * 2.0 ** emax
+    x = x.movedim(dim, -1)
+    shp = x.shape
+    C = shp[-1]
+    pad = (-C) % 32
+    xp = F.pad(x, (0, pad)).reshape(*shp[:-1], -1, 32).double()
+    amax = xp.abs().amax(-1, keepdim=True)
+    e = torch.floor(torch.log2(amax.clamp_min(2.0 ** -126))) - emax
+    scale = torch.exp2(e.clamp(-127.0, 127.0))
+    v = (xp / scale).clamp(-fmax, fmax)
+    ex = torch.floor(torch.log2(v.abs().clamp_min(2.0 ** -40))).clamp_min(1 - bias)   # subnormals share the smallest normal exponent
+    step = torch.exp2(ex - mbits)
+    q = (torch.round(v / step) * step).clamp(-fmax, fmax) * scale     # torch.round = half to even
+    q = torch.where(amax > 0, q, torch.zeros_like(q)).float()
+    return q.reshape(*shp[:-1], -1)[..., :C].movedim(-1, dim)
+
+
+SMALL = {"e2m3": (2, 3), "e3m2": (3, 2), "e2m1": (2, 1)}
+
+
 class Scheme:
     def __init__(self, name, hi, lo):
         self.name, self.hi, self.lo = name, hi, lo
@@ -66,10 +91,14 @@ class Scheme:
         r = x - h
         if self.lo in ("bf16", "fp16"):
             return h, rnd(r, self.lo)
+        if self.lo in SMALL:
+            return h, mx_small(r, 1, *SMALL[self.lo])
         return h, mx_e4m3(r, 1)
 
     def w_lo(self, w):
         """w (C_out, K, C_in / groups): the lo pass's weights"""
+        if self.lo in SMALL:
+            return mx_small(w, 2, *SMALL[self.lo])
         return mx_e4m3(w, 2) if self.lo == "e4m3" else w
 
 
@@ -139,7 +168,10 @@ def main():
                Scheme("bf16 hi + bf16 lo       (precision 2, 2 passes: today)", "bf16", "bf16"),
                Scheme("fp16 hi + fp16 lo       (precision 4, 2 passes)", "fp16", "fp16"),
                Scheme("bf16 hi + MX e4m3 lo    (1 + ~0.46 passes)", "bf16", "e4m3"),
-               Scheme("fp16 hi + MX e4m3 lo    (1 + ~0.46 passes)", "fp16", "e4m3")]
+               Scheme("fp16 hi + MX e4m3 lo    (1 + ~0.46 passes)", "fp16", "e4m3"),
+               Scheme("fp16 hi + MX fp6 e2m3 lo (1 + ~0.27 passes)", "fp16", "e2m3"),
+               Scheme("fp16 hi + MX fp6 e3m2 lo (1 + ~0.27 passes)", "fp16", "e3m2"),
+               Scheme("fp16 hi + MX fp4 e2m1 lo (1 + ~0.27 passes)", "fp16", "e2m1")]
     lines = [f"Kokoro-82M decoder (published widths, seeded parameters), T = {len(ids)} tokens, F = {args.frames} frames = {audio_ref.numel()} samples, peak {peak:.3f}; "
              f"float32 restatement {t_plain:.1f} s on {torch.get_num_threads()} threads",
              "scheme | max-abs / peak | SNR dB | device bars: 2e-3 and 50 dB"]
