@@ -97,8 +97,10 @@ __device__ __forceinline__ void lds_barrier() {
 // EXT (the quantising-prologue instantiations of the wave-specialised kernel only): per 64-row block and channel the (min, max) of the STORED output
 // go to a.ext_partial beside the statistics -- the producer of a fake-quantised conv's input hands over what the consumer's extrema pass would
 // otherwise re-read the whole tensor for (every prologue in use is monotone per channel: mi355_fake_quant_extrema_from_partials).
-template <int MF, int NF, int WM, int WN, int EPI, bool EXT = false>
-__device__ __forceinline__ void conv_epilogue(const mi355_conv_gemm_args& a, f32x16 (&acc)[MF][NF], const int b, const int l0,
+// MT / MO: the caller's accumulator array holds MT row blocks and this call works on blocks MO .. MO + MF - 1 as its blocks 0 .. MF - 1 (the column
+// waves of the precision-5 kernel run the epilogue once per 64-row statistics block).
+template <int MF, int NF, int WM, int WN, int EPI, bool EXT = false, int MT = MF, int MO = 0>
+__device__ __forceinline__ void conv_epilogue(const mi355_conv_gemm_args& a, f32x16 (&acc)[MT][NF], const int b, const int l0,
                                               const int n0, const int wm, const int wn, const int lane, const int len_out,
                                               const bool folded) {
   const int len_up = a.lens_up ? a.lens_up[b] : a.up_Lout;
@@ -158,7 +160,7 @@ __device__ __forceinline__ void conv_epilogue(const mi355_conv_gemm_args& a, f32
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          float v = acc[mf][nf][h * 8 + q] + bias;
+          float v = acc[MO + mf][nf][h * 8 + q] + bias;
           if constexpr (EPI == -1 || EPI == 0) {
             if (a.post_act == MI355_ACT_LEAKY) v = v > 0.f ? v : v * a.post_slope;
           }
@@ -254,14 +256,22 @@ __device__ __forceinline__ void conv_epilogue(const mi355_conv_gemm_args& a, f32
 // epilogue activation, residual / running sum already folded into the accumulators (or absent).  Same arithmetic, in the same order, as
 // conv_epilogue (bias, out_scale, shifted single-pass statistics), so the two paths are bit-identical; what goes away is the per-element
 // clamping, predication and 64-bit address arithmetic: one uniform base pointer + a 32-bit lane offset per store.
-template <int MF, int NF, int WM, int WN, bool EXT = false>
-__device__ __forceinline__ void conv_epilogue_interior(const mi355_conv_gemm_args& a, f32x16 (&acc)[MF][NF], const int b, const int l0,
+template <int MF, int NF, int WM, int WN, bool EXT = false, int MT = MF, int MO = 0>
+__device__ __forceinline__ void conv_epilogue_interior(const mi355_conv_gemm_args& a, f32x16 (&acc)[MT][NF], const int b, const int l0,
                                                        const int n0, const int wm, const int wn, const int lane) {
   char* yw = (char*)(a.y + (int64_t)b * a.y_bstride + (int64_t)(l0 + wm * WM) * a.ldy + (n0 + wn * WN));  // wave-uniform base
   const uint32_t ldb = (uint32_t)a.ldy * 4u;                                                             // row pitch in bytes
   const uint32_t lane_off = (uint32_t)(4 * (lane >> 5)) * ldb + (uint32_t)(lane & 31) * 4u;            // < 4 GB inside the wave block
   const bool want_stats = a.stats_partial != nullptr;
+#if defined(MI355_SLP_PROBE) && MI355_SLP_PROBE == 2   // tools/build_variants.sh: no SGPR (pair) operand in the packed arithmetic
+  float oscale = a.out_scale;
+  asm volatile("" : "+v"(oscale));
+#else
   const float oscale = a.out_scale;
+#endif
+#if defined(MI355_SLP_PROBE) && MI355_SLP_PROBE == 3   // tools/build_variants.sh: a long pad + full drain between the main loop and the first accumulator read
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
   float sK[NF], s1[NF], s2[NF];
   const bool want_ext = EXT && a.ext_partial != nullptr;
 #pragma unroll
@@ -276,7 +286,7 @@ __device__ __forceinline__ void conv_epilogue_interior(const mi355_conv_gemm_arg
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const uint32_t row = mf * 32 + (r & 3) + 8 * (r >> 2);
-          const float v = (acc[mf][nf][r] + bias) * oscale;
+          const float v = (acc[MO + mf][nf][r] + bias) * oscale;
           *(float*)(yw + (lane_off + row * ldb + (uint32_t)(nf * 128))) = v;
           if constexpr (STATS) {
             if (mf == 0 && r == 0) sK[nf] = v;
@@ -296,27 +306,15 @@ __device__ __forceinline__ void conv_epilogue_interior(const mi355_conv_gemm_arg
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) {
         const int n = n0 + wn * WN + nf * 32 + (lane & 31);
+#if defined(MI355_SLP_PROBE) && MI355_SLP_PROBE == 2
+        float cl = (float)(MF * 16);
+        asm volatile("" : "+v"(cl));
+#else
         const float cl = (float)(MF * 16);
+#endif
         const float ml = sK[nf] + s1[nf] / cl;
         const float vl = s2[nf] - s1[nf] * s1[nf] / cl;
-#if defined(MI355_VARIANT) && MI355_VARIANT == 2
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         const float cp = cl, mp = __shfl_xor(ml, 32, 64), vp = __shfl_xor(vl, 32, 64);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 4" ::: "memory");
-#elif defined(MI355_VARIANT) && MI355_VARIANT == 3
-        // lanes l and l + 32 through DPP only (row_bcast31 cannot cross halves on gfx9: use readlane-free v_permlane32_swap)
-        float ml_sw = ml, vl_sw = vl;
-        {
-          typedef unsigned uu2 __attribute__((ext_vector_type(2)));
-          const uu2 r0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, ml), __builtin_bit_cast(unsigned, ml), false, false);
-          const uu2 r1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, vl), __builtin_bit_cast(unsigned, vl), false, false);
-          ml_sw = __builtin_bit_cast(float, lane < 32 ? r0[1] : r0[0]);
-          vl_sw = __builtin_bit_cast(float, lane < 32 ? r1[1] : r1[0]);
-        }
-        const float cp = cl, mp = ml_sw, vp = vl_sw;
-#else
-        const float cp = cl, mp = __shfl_xor(ml, 32, 64), vp = __shfl_xor(vl, 32, 64);
-#endif
         const float ct = cl + cp;
         const float dm = mp - ml;
         const float sum = ml * cl + mp * cp;
@@ -339,8 +337,8 @@ __device__ __forceinline__ void conv_epilogue_interior(const mi355_conv_gemm_arg
           for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              amn = fminf(amn, acc[mf][nf][r]);
-              amx = fmaxf(amx, acc[mf][nf][r]);
+              amn = fminf(amn, acc[MO + mf][nf][r]);
+              amx = fmaxf(amx, acc[MO + mf][nf][r]);
             }
           const float e0 = (amn + bias) * oscale, e1 = (amx + bias) * oscale;
           float mn = fminf(e0, e1), mx = fmaxf(e0, e1);

@@ -84,7 +84,7 @@ __device__ __forceinline__ int next_work(const mi355_conv_gemm_args& a, const ws
 // reads, 4 = the producers only take part in the barriers, 8 = no residual fold and no epilogue.
 // FQ: the prologue ends with the dynamic uint8 fake quantisation of its value (a.pre_fq: the utterance's extrema); the prologue value is then
 // conv_common.h's fq_pre_value, the function the extrema pass evaluated.
-template <int PREC, int PRE, int EPI, bool GEMM, bool DBG = false, int ABL = 0, int BN = 128, bool FQ = false>
+template <int PREC, int PRE, int EPI, bool GEMM, bool DBG = false, int ABL = 0, int BN = 128, bool FQ = false, bool CW = true>
 __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_conv_gemm_args a, const ws4_geom q) {
   static_assert(!FQ || (!GEMM && (PRE == P_NONE || PRE == P_LEAKY || PRE == P_SNAKE)), "quantising prologues: conv mode, none / LeakyReLU / Snake");
   constexpr int BM = 128;
@@ -135,6 +135,12 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
       it.ci = 0; it.b = t.b; it.l0 = t.l0; it.len_in = t.len_in;
     };
 
+    // precision 5: windows that lie inside their utterance in rows and channels take straight-line loads and an unmasked conversion (FASTW)
+    constexpr bool FASTW = PREC == 5;
+    auto interior_window = [&](const item_t& it) {
+      const int r0 = it.l0 - a.pad;
+      return r0 >= 0 && r0 + R <= it.len_in && r0 + R <= a.Lin && it.ci * 32 + 32 <= a.Cin;   // wave-uniform
+    };
     // window row r = prow + 32 i of a chunk: conv mode = input row l0 - pad + r, channels [32 chunk, +32);
     // GEMM mode = input row l0 + (r & 127), channels [64 chunk + 32 (r >> 7), +32)
     auto loadA = [&](float4 (&areg)[NLD], float4 (&kreg)[NKC], const item_t& it) {
@@ -153,6 +159,20 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
       // converted).  With the passes under `if (wrow0 + 32 i < R)` the number of loads per window was unknown to the compiler's wait-count
       // bookkeeping, and the wait for window j became s_waitcnt vmcnt(0): it also waited for window j + 1, issued half an item earlier -- one
       // window of prefetch instead of two
+      if (FASTW && interior_window(it)) {
+        // every row and channel of the window exists (the resblock convs' interior tiles: all but the two edge tiles of an utterance): one wave-uniform
+        // base per pass + ONE 32-bit lane offset, no clamps -- ~6 VALU operations per load less in the producers' issue stream (round 6: the
+        // producers are starved of VALU issue slots, 16 cycles per instruction under the consumers' priority)
+        const char* wb = (const char*)(xb + (int64_t)(l0 - a.pad) * a.ldx + chunk * cstride);
+        const uint32_t loff = ((uint32_t)prow * (uint32_t)a.ldx + (uint32_t)c4) * 4u;
+        const size_t pstep = (size_t)a.ldx * 128u;   // 32 rows
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+          const int ii = (wrow0 + i * 32 < R) ? i : 0;
+          areg[i] = *(const float4*)(wb + ii * pstep + loff);
+        }
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
         const int ii = (GEMM || wrow0 + i * 32 < R) ? i : 0;
@@ -163,7 +183,8 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
         areg[i] = *(const float4*)(xb + (int64_t)gl * a.ldx + c);
       }
     };
-    auto convertA = [&](const float4 (&areg)[NLD], const float4 (&kreg)[NKC], const item_t& it, char* A_hi) {
+    auto convertA_body = [&](const float4 (&areg)[NLD], const float4 (&kreg)[NKC], const item_t& it, char* A_hi, auto mask_tag) {
+      constexpr bool MASK = decltype(mask_tag)::value;   // false: an interior window (FASTW) -- no row / channel masks
       const int chunk = it.ci, l0 = it.l0, b = it.b, len_in = it.len_in;
       char* A_lo = A_hi + ABYTES;
       const int c = chunk * cstride + c4;  // GEMM mode (no prologue coefficients): passes 4..7 carry channels c + 32
@@ -234,8 +255,12 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
                 // the prologue value is computed UNCONDITIONALLY (opaque to the optimiser) and masked by one v_cndmask: left to itself hipcc sinks
                 // the whole affine + sin chain of every element under its own s_and_saveexec / s_cbranch_execz pair (skipping work for padding rows
                 // that almost never occur), i.e. ~10 SALU instructions, two branches and a s_waitcnt per element in the producers' issue stream
-                asm volatile("" : "+v"(u));
-                tt[j] = (rowok && chan[j]) ? u : 0.f;
+                if constexpr (MASK) {
+                  asm volatile("" : "+v"(u));
+                  tt[j] = (rowok && chan[j]) ? u : 0.f;
+                } else {
+                  tt[j] = u;
+                }
               }
             }
             const int addr = PREC == 5 ? r * HP + c4 * 2 : r * 64 + ((((c4 >> 3) ^ ((r >> 2) & 3))) << 4) + ((c4 & 4) << 1);
@@ -281,7 +306,11 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
               asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(ph.x), "v"(tt[1]));
               asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l2) : "v"(ph.y), "v"(tt[2]));
               asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l3) : "v"(ph.y), "v"(tt[3]));
-              const float m4 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(l0), __builtin_fabsf(l1)), __builtin_fmaxf(__builtin_fabsf(l2), __builtin_fabsf(l3)));
+              // max |lo| of the lane's four elements in TWO instructions (source modifiers; left to itself hipcc spends four: it canonicalises each
+              // |x| through v_max_f32 |x|, |x| first).  (The DPP read behind it wants two wait states after a VALU write: hipcc's hazard pass counts an
+              // asm statement's register definitions and pads with its own s_nop 1 -- checked in the generated code.)
+              float m4;
+              asm("v_max3_f32 %0, |%1|, |%2|, |%3|\n\tv_max_f32_e64 %0, %0, |%4|" : "=&v"(m4) : "v"(l0), "v"(l1), "v"(l2), "v"(l3));
               uint32_t mb = __builtin_bit_cast(uint32_t, m4);  // non-negative floats order like unsigned integers
               mb = max(mb, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mb, 0xB1, 0xf, 0xf, true));   // quad_perm [1, 0, 3, 2]
               mb = max(mb, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mb, 0x4E, 0xf, 0xf, true));   // quad_perm [2, 3, 0, 1]
@@ -304,6 +333,13 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
           }
         }
       }
+    };
+
+    auto convertA = [&](const float4 (&areg)[NLD], const float4 (&kreg)[NKC], const item_t& it, char* A_hi) {
+      if constexpr (FASTW) {
+        if (interior_window(it)) { convertA_body(areg, kreg, it, A_hi, std::false_type{}); return; }
+      }
+      convertA_body(areg, kreg, it, A_hi, std::true_type{});
     };
 
     // chunk ci is converted into buffer ci & 1 while the consumers work on chunk ci - 1 (they left that buffer at the barrier that ended
@@ -363,9 +399,11 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
   }
 
   // -------------------------------------------------------------------------------- consumers
-  constexpr int WM = 64, WN = BN / 2, MF = 2, NF = WN / 32;   // BN = 64: every activation fragment feeds one 32-column fragment instead of two
+  // consumer waves over the tile: 2 x 2 blocks of 64 x (BN / 2) -- or, precision 5, four COLUMN waves of 128 rows x 32 columns (see there)
+  constexpr bool COLW = PREC == 5 && CW;   // CW = false: the 2 x 2 layout (A / B aid)
+  constexpr int WM = COLW ? 128 : 64, WN = COLW ? 32 : BN / 2, MF = WM / 32, NF = WN / 32;   // BN = 64: every activation fragment feeds one 32-column fragment instead of two
   constexpr int NB = 2 * NF;                                  // weight fragments of a wave per slice: (nf, kk)
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = COLW ? 0 : wave >> 1, wn = COLW ? wave : wave & 1;
   if (!(q.feat & 1)) __builtin_amdgcn_s_setprio(1);  // MFMA issuers outrank the producers' VALU work (measured +1..8 %)
   const int NTp = ((a.Cout + 127) >> 7) << 2;
   const int64_t wstep = (int64_t)NTp * 2048;
@@ -470,8 +508,186 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
         }
     }
 
-    if constexpr (PREC == 5) {
-      // ---- fp16 hi taps, then the e4m3 lo tap pairs of the chunk: one stream of 16-register weight items, one s_barrier per chunk.
+    if constexpr (PREC == 5 && COLW) {
+      // ---- fp16 hi taps, then the e4m3 lo tap pairs of the chunk: one stream of 8-register weight items, one s_barrier per chunk.
+      // COLUMN-WAVE layout (round 6): consumer wave w owns ALL 128 rows x the 32 columns [32 w, +32) of the tile = four 32x32 accumulators (mf = 0..3).
+      // A weight item is then 8 registers per lane (hi item: the kk 0 and kk 1 fragments of ONE 32-column group; lo item: its 32-byte e4m3 operand)
+      // and no two waves of a workgroup load the same fragment: half the L2 -> L1 -> register traffic of the 2 x 2 layout, whose row-pair waves each
+      // pulled the same 4 KB per tap (round 6 call 1: the weight loads cost 20 % of this kernel; profiles/r6_conv_ws4_p5_ablation_b64_call1.txt).  The
+      // activation fragments (LDS, 4x the L1's bandwidth) are read twice as often instead: 8 per tap and wave, each feeding one MFMA.
+      // Per accumulator element the order of additions is the one of the 2 x 2 layout (chunks, taps, kk 0 then kk 1, then the lo pairs): bit-identical.
+      // Register plan (128 per lane, 64 of them accumulators): two weight items w0 / w1, four 8-register activation tuples qv[0..3]
+      // (hi: group g = the two 32-row fragments mf = 2 (g & 1), + 1 under kk = g >> 1; lo: qv[mf] = the e4m3 operand of rows [32 mf, +32)).
+      typedef int i32x4 __attribute__((ext_vector_type(4)));
+      typedef int i32x8 __attribute__((ext_vector_type(8)));
+      const int K = keff, NP = (K + 1) >> 1, dil = q.tap_rows;   // K = 3 (mod 4): K odd, NP even (the dispatcher's eligibility rule)
+      // E8M0 scale of this wave's 32-column fragment (one per output column, after the last slice of the image)
+      const uint8_t* wsc = (const uint8_t*)a.w + (int64_t)q.nslices * wstep + (n0 + wn * WN) + hl;
+      const int bsc = (int)wsc[0];
+      // weight item s: a wave-uniform base (SGPR pair) + the lane's 32-bit offset: no 64-bit VALU address arithmetic, no pointer VGPRs
+      const char* wtile = (const char*)a.w + ((int64_t)((n0 >> 5) + wn * NF)) * 2048;
+      const uint32_t wlane = (uint32_t)lane * 16u;
+      auto ldW = [&](i32x8& w, const int s, const bool first = false) {
+        const char* src = wtile + (int64_t)(s < last_slice ? s : last_slice) * wstep;
+        if constexpr ((ABL & 1) != 0) {   // timing ablation: only the tile's first weight item is loaded
+          if (!first) { asm volatile("" : "+v"(w) : "s"(src)); return; }
+        }
+        const i32x4 lo4 = *(const i32x4*)(src + wlane), hi4 = *(const i32x4*)(src + 1024 + wlane);
+        w = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+      };
+      i32x8 w0, w1;
+      ldW(w0, 0, true);
+      if constexpr ((ABL & 1) != 0) w1 = w0;
+      i32x8 qv[4];
+      int sv[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[g][e] = 0;
+      // per-item opaque copies of the lane coordinates: LICM otherwise parks partly computed LDS addresses in VGPRs across the whole tile and
+      // the allocator pays for them with an accumulator in scratch; recomputing them costs a handful of VALU operations per 8 MFMAs
+      int hlx = hl, hhx = hh;
+      int lbH = 0, lbL = 0, lbS = 0;   // the lane's byte offsets into the hi / lo planes and the scale bytes; everything else of an address is wave-uniform
+      auto fresh = [&]() {
+        asm volatile("" : "+v"(hlx), "+v"(hhx));
+        lbH = hlx * HP + hhx * 16;
+        lbL = hlx * LP + hhx * 16;
+        lbS = hlx;
+      };
+      auto lo4 = [](const i32x8& v) { return __builtin_bit_cast(bf16x8, (i32x4)__builtin_shufflevector(v, v, 0, 1, 2, 3)); };
+      auto hi4 = [](const i32x8& v) { return __builtin_bit_cast(bf16x8, (i32x4)__builtin_shufflevector(v, v, 4, 5, 6, 7)); };
+      // fragments of group g under tap tp: kk = g >> 1 (16-channel half of the chunk), rows [32 m0, +32) and [32 (m0 + 1), +32), m0 = 2 (g & 1)
+      auto rdH = [&](const int g, const int tp) {
+        const int kk = g >> 1, m0 = 2 * (g & 1);
+        const int uoff = jbuf * WBYTES + (m0 * 32 + tp * dil) * HP + kk * 32;   // wave-uniform
+        int la = lbH;
+        asm volatile("" : "+v"(la));   // one add per group, recomputed: a shared (hoisted) address per (group, tap) costs a register each
+        i32x4 v0, v1;
+        if constexpr ((ABL & 2) != 0) { v0 = (i32x4){la, la, la, la}; v1 = v0; }   // timing ablation: no LDS read
+        else {
+          v0 = *(const i32x4*)(Abase + (la + uoff));
+          v1 = *(const i32x4*)(Abase + (la + uoff) + 32 * HP);
+        }
+        qv[g] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+      };
+      // lo operand of rows [mf * 32, +32) for tap pair p: bytes 0..15 = channels [16 hh, +16) of the row under tap 2 p, bytes 16..31 = the same
+      // channels under tap 2 p + 1 (K is odd: the last pair takes its last tap twice, that half of the weight item is zero, the data stay
+      // finite); scale byte: lanes 0..31 carry K block 0 (tap 2 p), lanes 32..63 K block 1
+      auto rdL = [&](const int mf, const int p) {
+        const int t1 = 2 * p + 1 < K ? 2 * p + 1 : K - 1;
+        const int u0 = mf * 32 + 2 * p * dil, u1 = mf * 32 + t1 * dil;          // wave-uniform row offsets of the two taps
+        const int ubase = jbuf * WBYTES + ABYTES;
+        int la = lbL, ls = lbS;
+        asm volatile("" : "+v"(la), "+v"(ls));
+        i32x4 x0, x1;
+        int sc;
+        if constexpr ((ABL & 2) != 0) {
+          x0 = (i32x4){la, la, la, la}; x1 = x0; sc = 120 + (ls & 7);   // timing ablation: no LDS read
+        } else {
+          x0 = *(const i32x4*)(Abase + (la + (ubase + u0 * LP)));
+          x1 = *(const i32x4*)(Abase + (la + (ubase + u1 * LP)));
+          sc = (int)*(const uint8_t*)(Abase + (ls + (ubase + R * LP + (hhx ? u1 : u0))));
+        }
+        qv[mf] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+        sv[mf] = sc;
+      };
+      auto mmH = [&](const int g, const i32x8& w) {
+        const int kk = g >> 1, m0 = 2 * (g & 1);
+        const bf16x8 bfrag = kk ? hi4(w) : lo4(w);
+        acc[m0][0] = mfma16<PREC>(lo4(qv[g]), bfrag, acc[m0][0]);
+        acc[m0 + 1][0] = mfma16<PREC>(hi4(qv[g]), bfrag, acc[m0 + 1][0]);
+      };
+      auto mmL = [&](const int mf, const i32x8& w) {
+        // (inline asm, accumulator tied in place: with the builtin hipcc picks the three-address form under register pressure -- D in 16 OTHER
+        // registers -- and then shuffles whole accumulators through scratch.  Hazards, which hipcc does not pad for an asm statement: a VALU
+        // result as an operand (the scale byte's mask) wants two wait states = the leading s_nop 1; the next reader of D is always another
+        // MFMA taking it whole as C (0 wait states) until the pad in front of the fold / epilogue below.)
+        asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc[mf][0]) : "v"(qv[mf]), "v"(w), "v"(sv[mf]), "v"(bsc));
+      };
+      // hi tap tp on weight item w (its two fragments are in flight or landed); `last`: the chunk's last hi tap requests the operands of the
+      // first lo tap pair instead of the next tap's fragments
+      auto hi_tap = [&](const int tp, const i32x8& w, auto last) {
+        constexpr bool LAST = decltype(last)::value;
+        fresh();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          mmH(g, w);
+          if constexpr (LAST) rdL(g, 0);
+          else rdH(g, tp + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      // lo tap pair p on weight item w
+      auto lo_pair = [&](const int p, const i32x8& w, const bool more) {
+        fresh();
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+          mmL(mf, w);
+          if (more) rdL(mf, p + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      auto prefetch = [&](i32x8& w, const int s) {
+        ldW(w, s);
+        asm volatile("" ::: "memory");  // keep the prefetch AHEAD of the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      // One chunk: K hi items, then NP lo items; wa holds item s on entry, wb holds the next chunk's first item on exit (K odd, NP even: the
+      // roles of the two register sets swap from chunk to chunk, hence the two instances below).
+      int s = 0;
+      unsigned long long bar_wait = 0;
+      bool first_chunk = true;
+      auto chunk_body = [&](i32x8& wa, i32x8& wb) {
+        if constexpr (DBG) {
+          unsigned long long tb0 = 0;
+          if (dbg) tb0 = __builtin_amdgcn_s_memtime();
+          lds_barrier();
+          if (dbg) {
+            const unsigned long long tb1 = __builtin_amdgcn_s_memtime();
+            bar_wait += tb1 - tb0;
+            if (first_chunk && lane == 0 && ntile < 8) dbg[4 * ntile + 1] = tb1;  // first window staged
+            first_chunk = false;
+          }
+        } else {
+          lds_barrier();  // the chunk's window is staged behind this barrier (and the producers may refill the buffer just left)
+        }
+        fresh();
+        rdH(0, 0);
+        rdH(1, 0);
+        rdH(2, 0);
+        rdH(3, 0);
+        int tp = 0;
+        for (; tp + 1 < K; tp += 2) {
+          prefetch(wb, s + 1);
+          hi_tap(tp, wa, std::false_type{});
+          prefetch(wa, s + 2);
+          hi_tap(tp + 1, wb, std::false_type{});
+          s += 2;
+        }
+        prefetch(wb, s + 1);
+        hi_tap(tp, wa, std::true_type{});
+        s += 1;
+        for (int p = 0; p < NP; p += 2) {
+          prefetch(wa, s + 1);
+          lo_pair(p, wb, true);
+          prefetch(wb, s + 2);
+          lo_pair(p + 1, wa, p + 2 < NP);
+          s += 2;
+        }
+        jbuf ^= 1;
+      };
+      for (int c = 0; c < nch; c += 2) {
+        chunk_body(w0, w1);
+        if (c + 1 >= nch) break;
+        chunk_body(w1, w0);
+      }
+      if constexpr (DBG) {
+        if (dbg && lane == 0 && ntile < 8) dbg[34 + ntile] = bar_wait;
+      }
+      // the tile's last MFMAs are asm statements: 16 passes -> 19 wait states before anything but an MFMA may touch their D
+      asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[2][0]), "+v"(acc[3][0]));
+    } else if constexpr (PREC == 5) {
+      // ---- (the 2 x 2 consumer layout of rounds 4 - 5, kept selectable for same-box A / B: tile code feature bit 1) fp16 hi taps, then the e4m3 lo tap pairs of the chunk: one stream of 16-register weight items, one s_barrier per chunk.
       // Register plan (128 per lane, 64 of them accumulators): two weight items as 8-register tuples w[nf] (hi item: low half = the kk 0 fragment,
       // high half = kk 1; lo item: the 32-byte e4m3 operand of column fragment nf), ONE 8-register activation set `qa` shared by the two phases
       // (hi: its low half is fragment set 0; lo: the whole e4m3 operand) and a 4-register second hi set.
@@ -757,12 +973,19 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
       continue;
     }
     const bool plain = a.up_s == 0 && a.post_act == MI355_ACT_NONE && (fold || (!a.res && !a.accumulate)) && !a.post_colscale;
-#if defined(MI355_VARIANT) && MI355_VARIANT == 1
-    if (false) conv_epilogue_interior<MF, NF, WM, WN>(a, acc, b, l0, n0, wm, wn, lane);
-#else
-    if (plain && interior) conv_epilogue_interior<MF, NF, WM, WN, FQ>(a, acc, b, l0, n0, wm, wn, lane);   // FQ instantiations: + per-block extrema (EXT)
-#endif
-    else conv_epilogue<MF, NF, WM, WN, EPI, FQ>(a, acc, b, l0, n0, wm, wn, lane, len_out, fold != 0);
+    if constexpr (COLW) {
+      // a column wave holds two 64-row statistics blocks: the epilogue of the 2 x 2 layout, once per half (accumulators 2 h, 2 h + 1 as its block h)
+      if (plain && interior) {
+        conv_epilogue_interior<2, NF, 64, WN, FQ, MF, 0>(a, acc, b, l0, n0, 0, wn, lane);
+        conv_epilogue_interior<2, NF, 64, WN, FQ, MF, 2>(a, acc, b, l0, n0, 1, wn, lane);
+      } else {
+        conv_epilogue<2, NF, 64, WN, EPI, FQ, MF, 0>(a, acc, b, l0, n0, 0, wn, lane, len_out, fold != 0);
+        conv_epilogue<2, NF, 64, WN, EPI, FQ, MF, 2>(a, acc, b, l0, n0, 1, wn, lane, len_out, fold != 0);
+      }
+    } else {
+      if (plain && interior) conv_epilogue_interior<MF, NF, WM, WN, FQ>(a, acc, b, l0, n0, wm, wn, lane);   // FQ instantiations: + per-block extrema (EXT)
+      else conv_epilogue<MF, NF, WM, WN, EPI, FQ>(a, acc, b, l0, n0, wm, wn, lane, len_out, fold != 0);
+    }
     if constexpr (DBG) {
       if (dbg && lane == 0 && ntile < 8) dbg[4 * ntile + 3] = __builtin_amdgcn_s_memtime();  // stores issued
     }
@@ -773,7 +996,7 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
 // GEMM mode: pure linear layers (K == 1, no prologue) with at least two 32-channel chunks
 inline bool gemm_mode(const mi355_conv_gemm_args& a) { return a.K == 1 && a.Cin >= 64 && a.pre_act == MI355_ACT_NONE && !a.pre_scale && !a.pre_fq; }
 
-template <int PREC, int PRE, int EPI, bool GEMM, bool DBG = false, int ABL = 0, int BN = 128, bool FQ = false>
+template <int PREC, int PRE, int EPI, bool GEMM, bool DBG = false, int ABL = 0, int BN = 128, bool FQ = false, bool CW = true>
 int launch_ws4(const mi355_conv_gemm_args& a, hipStream_t st, const int feat, unsigned long long* dbg = nullptr) {
   ws4_geom q;
   q.bn = BN;
@@ -816,7 +1039,7 @@ int launch_ws4(const mi355_conv_gemm_args& a, hipStream_t st, const int feat, un
   const int resident = g_ws4_resident > 0 ? ((g_ws4_resident + 7) / 8) * 8 : ((cus * wg_per_cu) / 8) * 8;
   const unsigned grid = (unsigned)((feat & 8) || q.total_ids <= resident ? q.total_ids : resident);  // feat bit 3: one workgroup per tile (A/B aid)
   MI355_CLEAR_ERROR();
-  hipLaunchKernelGGL((conv_ws4_kernel<PREC, PRE, EPI, GEMM, DBG, ABL, BN, FQ>), dim3(grid), dim3(kWs4Threads), lds, st, a, q);
+  hipLaunchKernelGGL((conv_ws4_kernel<PREC, PRE, EPI, GEMM, DBG, ABL, BN, FQ, CW>), dim3(grid), dim3(kWs4Threads), lds, st, a, q);
   MI355_LAUNCH_CHECK("conv_gemm(ws4)");
   return MI355_OK;
 }

@@ -7,6 +7,7 @@ using namespace mi355conv;
 int mi355_conv_ws4_p5(const mi355_conv_gemm_args& a, hipStream_t st, int feat, int bn) {
   const int pre = pre_kind(a), epi = epi_family(a);
   const bool gemm = false;   // K == 1 layers run this kernel in conv mode too (one hi item + one half-empty lo item per chunk)
+  if ((feat & 2) && pre == P_SNAKE && epi == 0) return launch_ws4<5, P_SNAKE, 0, false, false, 0, 128, false, false>(a, st, feat & 9);   // A / B aid: the 2 x 2 consumer layout
   WS4_CASE(5, P_NONE, 0);
   WS4_CASE(5, P_LEAKY, 0);
   WS4_CASE(5, P_SNAKE, 0);

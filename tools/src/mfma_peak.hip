@@ -71,6 +71,29 @@ __global__ __launch_bounds__(256) void mfma_loop(const uint4* __restrict__ src, 
     for (int i = 0; i < NACC; ++i)
 #pragma unroll
       for (int j = 0; j < 16; ++j) total += acc[i][j];
+  } else if constexpr (SHAPE == 5) {  // 32x32x64 fp4 (e2m1) on the block-scaled pipe with unit scales: 16 bytes per operand and lane
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    i32x8 a8[2], b8[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a8[0][j] = ((const int*)&ra[0])[j]; a8[0][j + 4] = 0;
+      a8[1][j] = ((const int*)&ra[1])[j]; a8[1][j + 4] = 0;
+      b8[0][j] = ((const int*)&rb[0])[j]; b8[0][j + 4] = 0;
+      b8[1][j] = ((const int*)&rb[1])[j]; b8[1][j + 4] = 0;
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < NACC; ++i)
+        acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i & 1], b8[(i >> 1) & 1], acc[i], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    }
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) total += acc[i][j];
   } else if constexpr (SHAPE == 4) {  // 32x32x32 int8
     i32x16 acc[NACC];
 #pragma unroll
@@ -138,11 +161,12 @@ int main(int argc, char** argv) {
   }
   hipMemcpy(src8, h8, nsrc * 16, hipMemcpyHostToDevice);
   // cycles of the two 8-bit shapes = what a 2x-rate pipe would need (K = 64 fp8: 64; K = 32 int8: 32); "implied_clock_ghz" for them is that assumption's clock
-  const Shape shapes[5] = {{"v_mfma_f32_32x32x16_bf16", 0, 2.0 * 32 * 32 * 16, 32},
+  const Shape shapes[6] = {{"v_mfma_f32_32x32x16_bf16", 0, 2.0 * 32 * 32 * 16, 32},
                            {"v_mfma_f32_16x16x32_bf16", 1, 2.0 * 16 * 16 * 32, 16},
                            {"v_mfma_f32_32x32x16_f16", 2, 2.0 * 32 * 32 * 16, 32},
                            {"v_mfma_scale_f32_32x32x64_f8f6f4(e4m3, unit scales)", 3, 2.0 * 32 * 32 * 64, 64},
-                           {"v_mfma_i32_32x32x32_i8", 4, 2.0 * 32 * 32 * 32, 32}};
+                           {"v_mfma_i32_32x32x32_i8", 4, 2.0 * 32 * 32 * 32, 32},
+                           {"v_mfma_scale_f32_32x32x64_f8f6f4(fp4 e2m1, unit scales)", 5, 2.0 * 32 * 32 * 64, 32}};
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
@@ -151,7 +175,9 @@ int main(int argc, char** argv) {
   constexpr int NACC = 4;
   int ntargets = argc > 1 ? argc - 1 : 3;
   double targets_default[3] = {2.0, 50.0, 1000.0};
-  for (int si = 0; si < 5; ++si) {
+  const int only = getenv("MI355_MFMA_ONLY") ? atoi(getenv("MI355_MFMA_ONLY")) : -1;   // one shape id only
+  for (int si = 0; si < 6; ++si) {
+    if (only >= 0 && si != only && !(only == 35 && (si == 3 || si == 5 || si == 2))) continue;
     for (int ti = 0; ti < ntargets; ++ti) {
       const double target_ms = argc > 1 ? atof(argv[1 + ti]) : targets_default[ti];
       // iterations for the target duration at a nominal 2.0 GHz: per SIMD, waves x iters x NACC x cycles
@@ -165,6 +191,7 @@ int main(int argc, char** argv) {
         if (si == 2) mfma_loop<2, NACC><<<grid, block>>>(src, sink, iters);
         if (si == 3) mfma_loop<3, NACC><<<grid, block>>>(src8, sink, iters);
         if (si == 4) mfma_loop<4, NACC><<<grid, block>>>(src8, sink, iters);
+        if (si == 5) mfma_loop<5, NACC><<<grid, block>>>(src8, sink, iters);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         hipEventElapsedTime(&last, e0, e1);
