@@ -165,10 +165,12 @@ class _Quantizer:
                 self.search.append((t.to(device), t.transpose(1, 2).contiguous().to(device), ((t * t).sum(-1) / 2).contiguous().to(device)))
             self.neg_table = (-self.table).contiguous()
 
-    def __call__(self, z, n_quantizers: Optional[int] = None, return_margins: bool = False):
+    def __call__(self, z, n_quantizers: Optional[int] = None, return_margins: bool = False, force=None):
         """``ResidualVectorQuantize.__call__`` (quantize.py:90-127): z [B, D, T] ->
         (z_q [B, D, T], codes [B, n, T] int64, latents [B, n * d, T], commitment_loss, codebook_loss).  ``return_margins`` appends the cosine gap
-        between the best and the second-best codeword of every decision ([B, n, T]: a gap at float32 rounding level is a knife edge)."""
+        between the best and the second-best codeword of every decision ([B, n, T]: a gap at float32 rounding level is a knife edge).
+        ``force`` = (mask bool [B, n, T], codes int [B, n, T]): parity-test hook -- where the mask is set the given code replaces the search result
+        (the search still runs, its margin is still reported), so that a residual chain can be re-synchronised with another build's at a knife edge."""
         if self.in_proj is None:
             raise ValueError("this DAC was loaded without quantizer in_proj weights (decode-only checkpoint): the codebook search cannot run")
         z = torch.as_tensor(z, dtype=torch.float32).to(self.device).transpose(1, 2)   # channels-last rows for the kernels
@@ -189,6 +191,9 @@ class _Quantizer:
             c, m = ops.rvq_encode(rows, *self.search[i], margins=True)
             if return_margins:   # score = |c|^2 / 2 - e . c over the normalised codebook: the gap in cosine units is the score gap over |e|
                 margins.append((m.view(B, T) / torch.clamp(torch.sqrt((rows * rows).sum(1)).view(B, T), min=1e-30)))
+            if force is not None:
+                fm, fc = force
+                c = torch.where(torch.as_tensor(fm)[:, i].to(self.device).reshape(B * T, 1), torch.as_tensor(fc)[:, i].to(self.device, torch.int32).reshape(B * T, 1), c)
             ids.append(c.view(B, T, 1))
             if i + 1 < n:
                 ops.embed_sum(self.neg_table, ids[-1], residual, slot_offset=self.offs[i:i + 1], add=residual)
@@ -364,9 +369,9 @@ class DAC(CodecMixin):
         st["latent"] = z
         return (z.transpose(1, 2), st) if return_stages else z.transpose(1, 2)
 
-    def encode(self, audio_data, n_quantizers: int = None, return_margins: bool = False):
+    def encode(self, audio_data, n_quantizers: int = None, return_margins: bool = False, force=None):
         """dac.py:184-192: audio [B, 1, S] -> (z [B, D, T], codes [B, n, T], latents [B, n * d, T], commitment_loss, codebook_loss)."""
-        return self.quantizer(self.encoder(audio_data), n_quantizers, return_margins=return_margins)
+        return self.quantizer(self.encoder(audio_data), n_quantizers, return_margins=return_margins, force=force)
 
     def __call__(self, audio_data, sample_rate: int = None, n_quantizers: int = None, use_rvq: bool = True, return_loss: bool = False):
         """dac.py:207-239 (the reference slices the LAST axis of the channels-last decoder output, ``x[..., :length]`` -- one channel, so a no-op

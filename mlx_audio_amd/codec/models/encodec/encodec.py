@@ -227,13 +227,28 @@ class _Quantizer:
             n = int(max(1, math.floor(bandwidth * 1000 / bw_per_q)))
         return n
 
-    def encode(self, embeddings, bandwidth: Optional[float] = None, return_margins: bool = False):
+    def encode(self, embeddings, bandwidth: Optional[float] = None, return_margins: bool = False, force=None):
         """encodec.py:516-533: embeddings [B, T, codebook_dim] -> codes int64 [B, nq(bandwidth), T]; per layer the nearest codeword by
-        ``-(|x|^2 - 2 x e^T + |e|^2)`` (first maximum), residual -= codeword.  ``return_margins`` adds the top-2 score gap of every decision."""
+        ``-(|x|^2 - 2 x e^T + |e|^2)`` (first maximum), residual -= codeword.  ``return_margins`` adds the top-2 score gap of every decision.
+        ``force`` = (mask bool [B, nq, T], codes int [B, nq, T]): parity-test hook -- the layers run as one launch EACH (the same kernel, the same float32
+        subtraction between them) and where the mask is set the given code replaces the search result before the residual update: re-synchronises the
+        residual chain with another build's at a knife edge.  With an all-false mask the result equals the one-launch path bit for bit (tested)."""
         n = min(self.get_num_quantizers_for_bandwidth(bandwidth), self.num_quantizers)   # ``self.layers[:num_quantizers]``: a slice stops at the last layer
         x = torch.as_tensor(embeddings, dtype=torch.float32).to(self.device).contiguous()
         B, T, D = x.shape
         tables, tables_t, c2 = self.search
+        if force is not None:
+            fm, fc = torch.as_tensor(force[0]).to(self.device), torch.as_tensor(force[1]).to(self.device, torch.int32)
+            r = x.view(B * T, D).clone()
+            cs, ms = [], []
+            for i in range(n):
+                ci, mi = ops.rvq_encode(r, tables[i:i + 1], tables_t[i:i + 1], c2[i:i + 1], margins=True)
+                ci = torch.where(fm[:, i].reshape(B * T, 1), fc[:, i].reshape(B * T, 1), ci)
+                r = r - tables[i][ci.view(-1).long()]
+                cs.append(ci)
+                ms.append(mi)
+            codes = torch.cat(cs, 1).view(B, T, n).permute(0, 2, 1).contiguous().to(torch.int64)
+            return (codes, torch.cat(ms, 1).view(B, T, n).permute(0, 2, 1)) if return_margins else codes
         out = ops.rvq_encode(x.view(B * T, D), tables[:n], tables_t[:n], c2[:n], margins=return_margins)
         c, m = out if return_margins else (out, None)
         codes = c.view(B, T, n).permute(0, 2, 1).contiguous().to(torch.int64)

@@ -213,9 +213,11 @@ class _Quantizer:
             self.codebook_dim = self.search[0][0].shape[2]
             self.neg_table = (-self.table).contiguous()
 
-    def __call__(self, z, return_margins: bool = False):
+    def __call__(self, z, return_margins: bool = False, force=None):
         """``ResidualVectorQuantize.__call__`` (vq.py:102-113): z [B, D, T] -> (z_q [B, D, T], codes: list of int64 [B, T / stride_i]).
-        ``return_margins`` appends the cosine gap between the best and the second-best codeword of every decision (list of [B, T / stride_i])."""
+        ``return_margins`` appends the cosine gap between the best and the second-best codeword of every decision (list of [B, T / stride_i]).
+        ``force`` = (masks, codes), lists of [B, T / stride_i] per level: parity-test hook -- where a mask is set the given code replaces the search result
+        (the search still runs and reports its margin): re-synchronises the residual chain with another build's at a knife edge."""
         if self.in_proj is None:
             raise ValueError("this SNAC was loaded without quantizer in_proj weights (decode-only checkpoint): the codebook search cannot run")
         z = torch.as_tensor(z, dtype=torch.float32).to(self.device).transpose(1, 2)   # channels-last rows for the kernels
@@ -237,6 +239,8 @@ class _Quantizer:
             if return_margins:
                 margins.append(m.view(B, Ts) / torch.clamp(torch.sqrt((rows * rows).sum(1)).view(B, Ts), min=1e-30))
             c = c.view(B, Ts)
+            if force is not None:
+                c = torch.where(torch.as_tensor(force[0][i]).to(self.device), torch.as_tensor(force[1][i]).to(self.device, torch.int32), c)
             codes.append(c.to(torch.int64))
             if i + 1 < self.n_codebooks:
                 ids = (torch.repeat_interleave(c, s, dim=1) if s > 1 else c).reshape(B, T, 1).contiguous()
@@ -460,9 +464,9 @@ class SNAC:
         st["latent"] = z
         return (z.transpose(1, 2), st) if return_stages else z.transpose(1, 2)
 
-    def encode(self, audio_data, return_margins: bool = False):
+    def encode(self, audio_data, return_margins: bool = False, force=None):
         """snac.py:96-102: audio [B, 1, S] -> codes (list of int64 [B, T / vq_strides[i]]); the audio is right-padded first (``preprocess``)."""
-        out = self.quantizer(self.encoder(self.preprocess(audio_data)), return_margins=return_margins)
+        out = self.quantizer(self.encoder(self.preprocess(audio_data)), return_margins=return_margins, force=force)
         return (out[1], out[2]) if return_margins else out[1]
 
     def __call__(self, audio_data, noises: Optional[List[torch.Tensor]] = None):

@@ -23,21 +23,19 @@ import torch
 
 __all__ = ["hanning", "hamming", "blackman", "bartlett", "STR_TO_WINDOW_FN", "stft", "istft", "mel_filters", "ISTFTCache",
            "log_mel_spectrogram", "mel_spectrogram",
-           # host-side level helpers of mlx_audio.dsp (dsp.py:96-382), implemented in .loudness
+           # host-side level helpers of mlx_audio.dsp (dsp.py:96-382): out of the hot-path scope, resolved lazily from .host.loudness
            "integrated_loudness", "lfilter", "normalize_loudness", "normalize_peak"]
 
-from .loudness import (  # noqa: E402,F401  (numpy-only; keeps ``from mlx_audio_amd.dsp import integrated_loudness`` working like the reference)
-    _K_WEIGHT_HIGHPASS_FREQ,
-    _K_WEIGHT_HIGHPASS_Q,
-    _K_WEIGHT_SHELF_FREQ,
-    _K_WEIGHT_SHELF_GAIN_DB,
-    _K_WEIGHT_SHELF_Q,
-    _biquad_coefficients,
-    integrated_loudness,
-    lfilter,
-    normalize_loudness,
-    normalize_peak,
-)
+_HOST_LEVEL_NAMES = ("integrated_loudness", "lfilter", "normalize_loudness", "normalize_peak", "_biquad_coefficients", "_K_WEIGHT_HIGHPASS_FREQ",
+                     "_K_WEIGHT_HIGHPASS_Q", "_K_WEIGHT_SHELF_FREQ", "_K_WEIGHT_SHELF_GAIN_DB", "_K_WEIGHT_SHELF_Q")
+
+
+def __getattr__(name):   # ``from mlx_audio_amd.dsp import integrated_loudness`` keeps working like the reference; the numpy module loads on first use
+    if name in _HOST_LEVEL_NAMES:
+        from .host import loudness
+
+        return getattr(loudness, name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
 
 def _device():

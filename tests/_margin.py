@@ -2,9 +2,10 @@
 
 Two float32 builds of the same network (device kernels vs the CPU oracle) differ by ~1e-4 in the logits, so an arg-max / Gumbel-max decision
 whose top-2 gap is below ``thr`` may legitimately fall either way -- and every later decision of that sequence then runs on a different
-context.  Two remedies: ``walk_resync`` (the autoregressive engines: the test forces the oracle's token at the knife edges, so every other decision
-of the whole sequence is compared) and ``walk`` (families without a forcing hook: a sequence's decisions in generation order up to, not including,
-its first knife-edge decision; the rest is recorded as uncompared).  The session prints the totals (tests/conftest.py: ``pytest_terminal_summary``) so that the fraction of
+context.  Three remedies: ``walk_resync`` (the autoregressive engines: the test forces the oracle's token at the knife edges, so every other decision
+of the whole sequence is compared), ``walk_forced`` (the residual-VQ encoders, round 6: the quantizers' ``force`` hook takes the oracle's code at the
+oracle's knife edges, every other layer of every frame is compared) and ``walk`` (families without a forcing hook: a sequence's decisions in generation
+order up to, not including, its first knife-edge decision; the rest is recorded as uncompared).  The session prints the totals (tests/conftest.py: ``pytest_terminal_summary``) so that the fraction of
 free-running steps hidden behind the rule is a reported number with a bound, not an unknown.  Teacher-forced tests compare every step.
 """
 from typing import Dict, List, Sequence
@@ -28,6 +29,25 @@ def walk_resync(family: str, got: Sequence[int], exp: Sequence[int], margins: Se
         if float(margins[i]) < thr:
             continue
         assert int(got[i]) == int(exp[i]), (family, where, i, int(got[i]), int(exp[i]), float(margins[i]))
+        compared += 1
+    r = REPORT.setdefault(family, [0, 0, 0, 0])
+    r[0] += compared
+    r[1] += n - compared
+    r[2] += int(compared < n)
+    r[3] += 1
+    return compared
+
+
+def walk_forced(family: str, got: Sequence[int], exp: Sequence[int], forced: Sequence[bool], where=None) -> int:
+    """Residual-VQ encode chains run with the oracle's code FORCED wherever ``forced`` is set (the oracle's own knife edges: the engines' ``force`` hook):
+    the residual is re-synchronised there, so EVERY other decision of the chain must agree bit for bit.  Returns the number compared."""
+    n = min(len(got), len(exp), len(forced))
+    compared = 0
+    for i in range(n):
+        if bool(forced[i]):
+            assert int(got[i]) == int(exp[i]), (family, where, i, "a forced code did not come back")
+            continue
+        assert int(got[i]) == int(exp[i]), (family, where, i, int(got[i]), int(exp[i]))
         compared += 1
     r = REPORT.setdefault(family, [0, 0, 0, 0])
     r[0] += compared

@@ -54,7 +54,7 @@ def mx_e4m3(x, dim):
     return q.reshape(*shp[:-1], -1)[..., :C].movedim(-1, dim)
 
 
-def mx_small(x, dim, ebits, mbits):
+def mx_small(x, dim, ebits, mbits, bump=False):
     """OCP MX fp6 / fp4 image (e2m3, e3m2, e2m1): one power-of-two scale per 32 elements along ``dim``; shared exponent = floor(log2(amax)) - emax_elem,
     elements round to nearest even and saturate at the format's maximum."""
     bias = (1 << (ebits - 1)) - 1
@@ -67,6 +67,8 @@ def mx_small(x, dim, ebits, mbits):
     xp = F.pad(x, (0, pad)).reshape(*shp[:-1], -1, 32).double()
     amax = xp.abs().amax(-1, keepdim=True)
     e = torch.floor(torch.log2(amax.clamp_min(2.0 ** -126))) - emax
+    if bump:   # no saturation: one more exponent step whenever amax / 2^e would exceed the format's maximum
+        e = torch.where(amax / torch.exp2(e) > fmax, e + 1.0, e)
     scale = torch.exp2(e.clamp(-127.0, 127.0))
     v = (xp / scale).clamp(-fmax, fmax)
     ex = torch.floor(torch.log2(v.abs().clamp_min(2.0 ** -40))).clamp_min(1 - bias)   # subnormals share the smallest normal exponent
@@ -76,7 +78,7 @@ def mx_small(x, dim, ebits, mbits):
     return q.reshape(*shp[:-1], -1)[..., :C].movedim(-1, dim)
 
 
-SMALL = {"e2m3": (2, 3), "e3m2": (3, 2), "e2m1": (2, 1)}
+SMALL = {"e2m3": (2, 3), "e3m2": (3, 2), "e2m1": (2, 1), "e2m1_bump": (2, 1, True), "e2m1_bump_act": (2, 1, True), "e2m1_bump_w": (2, 1, False)}
 
 
 class Scheme:
@@ -97,6 +99,10 @@ class Scheme:
 
     def w_lo(self, w):
         """w (C_out, K, C_in / groups): the lo pass's weights"""
+        if self.lo == "e2m1_bump_act":
+            return mx_small(w, 2, 2, 1, False)
+        if self.lo == "e2m1_bump_w":
+            return mx_small(w, 2, 2, 1, True)
         if self.lo in SMALL:
             return mx_small(w, 2, *SMALL[self.lo])
         return mx_e4m3(w, 2) if self.lo == "e4m3" else w
@@ -171,7 +177,10 @@ def main():
                Scheme("fp16 hi + MX e4m3 lo    (1 + ~0.46 passes)", "fp16", "e4m3"),
                Scheme("fp16 hi + MX fp6 e2m3 lo (1 + ~0.27 passes)", "fp16", "e2m3"),
                Scheme("fp16 hi + MX fp6 e3m2 lo (1 + ~0.27 passes)", "fp16", "e3m2"),
-               Scheme("fp16 hi + MX fp4 e2m1 lo (1 + ~0.27 passes)", "fp16", "e2m1")]
+               Scheme("fp16 hi + MX fp4 e2m1 lo (1 + ~0.27 passes)", "fp16", "e2m1"),
+               Scheme("fp16 hi + MX fp4 e2m1 lo, no-saturation scales (both)", "fp16", "e2m1_bump"),
+               Scheme("fp16 hi + MX fp4 e2m1 lo, no-saturation scales (activations only)", "fp16", "e2m1_bump_act"),
+               Scheme("fp16 hi + MX fp4 e2m1 lo, no-saturation scales (weights only)", "fp16", "e2m1_bump_w")]
     lines = [f"Kokoro-82M decoder (published widths, seeded parameters), T = {len(ids)} tokens, F = {args.frames} frames = {audio_ref.numel()} samples, peak {peak:.3f}; "
              f"float32 restatement {t_plain:.1f} s on {torch.get_num_threads()} threads",
              "scheme | max-abs / peak | SNR dB | device bars: 2e-3 and 50 dB"]
