@@ -114,7 +114,12 @@ typedef struct {
                               v_mfma_scale_f32_32x32x64_f8f6f4 at twice the 16-bit rate, two taps per instruction, E8M0 scale per window
                               row and 32 channels / per output column: ~15 significant bits of the activation (conv sweep: <= 2e-5 of
                               the peak).  Launches the wave-specialised kernel does not take (few tiles, K % 4 != 3, thin outputs) run
-                              the precision-4 arithmetic on the image's fp16 slices */
+                              the precision-4 arithmetic on the image's fp16 slices,
+                          6 = fp16 hi pass + block-scaled FP4 (OCP e2m1) lo pass on an MX4 image (mi355_pack_conv_weight_mx4_host): as 5
+                              with 4-bit elements on both sides of the lo product -- the matrix pipe runs them at 4x the 16-bit rate (the
+                              lo pass costs ~0.27 of a 16-bit pass instead of ~0.55), the lo planes in LDS and the lo weight stream
+                              halve; ~13 significant bits of the activation (waveform: ~4e-4 of the peak, 70 dB, against the 2e-3 /
+                              50 dB bars: profiles/r6_split_format_study_fp6.txt).  Same eligibility and fallback as 5 */
   int32_t tile;        /* 0 = auto, else BM*1000+BN (128128, 64128, 64064), 6128128 / 7128128 = wave-specialised 8-wave kernels (ws4 / ws3),
                           2064128 / 2064064 (+ 10000000 * groups) = split-K on 64-row tiles (needs split_ws) */
   /* optional instance-norm statistics of the STORED output, fused into the epilogue (plain stores only): per block of
@@ -175,6 +180,10 @@ int mi355_pack_conv_weight_host_dt(const float* w_host, int32_t Cout, int32_t K,
  * by ceil(K / 2) e4m3 tap-pair slices, then one E8M0 scale byte per (padded) output column.  out_host: mi355_packed_conv_weight_mx_bytes bytes. */
 int64_t mi355_packed_conv_weight_mx_bytes(int32_t Cout, int32_t K, int32_t Cin);
 int mi355_pack_conv_weight_mx_host(const float* w_host, int32_t Cout, int32_t K, int32_t Cin, uint8_t* out_host);
+/* The MX4 image of precision 6: the MX image's geometry and byte count (mi355_packed_conv_weight_mx_bytes), the tap-pair slots holding one kilobyte
+ * of e2m1 codes per 32-column group (K block b of the matrix instruction = tap 2 p + b = lane half b) and the column scales of the 4-bit grid
+ * (e[n] = floor(log2(max |w[n]|)) - 2). */
+int mi355_pack_conv_weight_mx4_host(const float* w_host, int32_t Cout, int32_t K, int32_t Cin, uint8_t* out_host);
 
 /* ------------------------------------------------------------------------------------------
  * Instance-norm statistics + AdaIN coefficients.

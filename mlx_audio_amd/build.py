@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libmi355audio.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "mi355audio.h")
-SOURCES = ["api.cpp", "conv_gemm.hip", "conv_ws4.hip", "conv_ws4_p4.hip", "conv_ws4_p13.hip", "conv_ws4_p5.hip", "conv_ws4_p5_probe.hip", "conv_ws4_fq.hip", "conv_quant.hip", "norm.hip", "lstm.hip", "lstm_seq.hip", "attention.hip", "glue.hip", "source.hip", "fft.hip", "flash_attn.hip",
+SOURCES = ["api.cpp", "conv_gemm.hip", "conv_ws4.hip", "conv_ws4_p4.hip", "conv_ws4_p13.hip", "conv_ws4_p5.hip", "conv_ws4_p6.hip", "conv_ws4_p5_probe.hip", "conv_ws4_fq.hip", "conv_quant.hip", "norm.hip", "lstm.hip", "lstm_seq.hip", "attention.hip", "glue.hip", "source.hip", "fft.hip", "flash_attn.hip",
            "decode_rules.hip", "gemv.hip", "gemv_mfma.hip", "gemv_mfma_fp8.hip", "gemm_rows.hip", "rows_pipe.hip", "transformer.hip", "rvq.hip", "ecapa.hip", "sampler.hip", "stack_step.cpp"]
 # per-file extra flags: source.hip mirrors the reference's fp32 op order one rounding at a time
 EXTRA_FLAGS = {"source.hip": ["-ffp-contract=off"]}

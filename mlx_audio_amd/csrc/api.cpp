@@ -17,7 +17,7 @@ void mi355_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* mi355_last_error(void) { return g_err; }
-extern "C" int mi355_abi_version(void) { return 33; }
+extern "C" int mi355_abi_version(void) { return 34; }
 
 extern "C" int mi355_device_info(int dev, char* name, int name_cap, int* cu_count, int* lds_bytes) {
   hipDeviceProp_t p;
@@ -130,6 +130,73 @@ extern "C" int mi355_pack_conv_weight_mx_host(const float* w, int32_t Cout, int3
             }
           }
     o += b / 2;
+  }
+  return MI355_OK;
+}
+
+// ---- MX4 image (precision 6: fp16 hi pass + block-scaled FP4 lo pass).  The MX image's geometry (same byte count, same fp16 tap slices, same slot of
+// NTp x 2 KB per tap PAIR, same trailer of NTp*32 E8M0 column bytes); a pair slot holds, per 32-column group nt, ONE kilobyte of e2m1 codes at
+// ((nt * 2) * 64 + lane) * 16 + j / 2 (low nibble = even j) and one kilobyte of zeros:
+//   n = nt*32 + (lane & 31),  tap = 2 p + (lane >> 5),  c = chunk*32 + j,  j = 0..31
+// (for 4-bit operands v_mfma_scale_f32_32x32x64_f8f6f4 takes a lane's 32 elements as ONE scale block -- probed: tools/src/mfma_fp4_probe.hip,
+// profiles/r6_mfma_fp4_probe_call2.jsonl -- so K block b = tap 2 p + b sits whole in lane half b), value = e2m1(w / 2^e[n]), zero for tap >= K or
+// padding; e[n] = floor(log2(max |w[n, :, :]|)) - 2 (OCP MX: the scaled column maximum lies in [4, 8), elements above 6 saturate), byte = e + 127.
+extern "C" int mi355_pack_conv_weight_mx4_host(const float* w, int32_t Cout, int32_t K, int32_t Cin, uint8_t* out) {
+  MI355_REQUIRE(w && out && Cout > 0 && K > 0 && Cin > 0, "pack_conv_weight_mx4: bad arguments");
+  const int chunks = (Cin + 31) / 32;
+  const int ntp = ((Cout + 127) / 128) * 4;
+  const int np = (K + 1) / 2;
+  uint8_t* scales = out + (size_t)chunks * (K + np) * ntp * 2048;
+  std::vector<float> inv(ntp * 32, 1.0f);
+  for (int n = 0; n < ntp * 32; ++n) {
+    float amax = 0.f;
+    if (n < Cout)
+      for (size_t e = 0; e < (size_t)K * Cin; ++e) {
+        const float v = fabsf(w[(size_t)n * K * Cin + e]);
+        MI355_REQUIRE(v == v && v <= 3.0e38f, "pack_conv_weight_mx4: non-finite weight in output channel %d", n);
+        amax = v > amax ? v : amax;
+      }
+    int e = 0;
+    if (amax > 0.f) {
+      (void)frexpf(amax, &e);   // amax = m * 2^e, m in [0.5, 1): floor(log2(amax)) = e - 1
+      e = e - 1 - 2;
+      if (e < -127) e = -127;
+      if (e > 120) e = 120;
+    }
+    scales[n] = (uint8_t)(e + 127);
+    inv[n] = ldexpf(1.0f, -e);
+  }
+  size_t o = 0;
+  uint16_t* o16 = (uint16_t*)out;
+  for (int ch = 0; ch < chunks; ++ch) {
+    for (int tap = 0; tap < K; ++tap)
+      for (int nt = 0; nt < ntp; ++nt)
+        for (int kk = 0; kk < 2; ++kk)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int n = nt * 32 + (lane & 31);
+            const int c0 = ch * 32 + kk * 16 + (lane >> 5) * 8;
+            for (int j = 0; j < 8; ++j) {
+              const int c = c0 + j;
+              const float v = (n < Cout && c < Cin) ? w[((size_t)n * K + tap) * Cin + c] : 0.0f;
+              o16[o++] = host_f32_to_f16(v);
+            }
+          }
+    uint8_t* o8 = out + o * 2;
+    memset(o8, 0, (size_t)np * ntp * 2048);
+    for (int p = 0; p < np; ++p)
+      for (int nt = 0; nt < ntp; ++nt)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int n = nt * 32 + (lane & 31);
+          const int tap = 2 * p + (lane >> 5);
+          uint8_t* dst = o8 + ((size_t)p * ntp + nt) * 2048 + (size_t)lane * 16;
+          for (int j = 0; j < 32; ++j) {
+            const int c = ch * 32 + j;
+            const float v = (n < Cout && c < Cin && tap < K) ? w[((size_t)n * K + tap) * Cin + c] : 0.0f;
+            const uint8_t code = host_f32_to_e2m1(v * inv[n]);   // power-of-two scaling: exact
+            dst[j >> 1] |= (uint8_t)((j & 1) ? (code << 4) : code);
+          }
+        }
+    o += (size_t)np * ntp * 1024;
   }
   return MI355_OK;
 }

@@ -140,6 +140,25 @@ static inline uint8_t host_f32_to_e4m3(float f) {
   return (uint8_t)(sign | (uint8_t)(((e + 7) << 3) | (ni - 8)));
 }
 
+// host: fp32 -> OCP e2m1 (FP4) code: sign, 2 exponent bits (bias 1), 1 mantissa bit: magnitudes {0, 0.5, 1, 1.5, 2, 3, 4, 6}; round to nearest
+// (ties to the even CODE, as v_cvt_scalef32_pk_fp4_f32 does: probed, profiles/r6_mfma_fp4_probe_call2.jsonl), saturating at +-6; NaN -> +6.
+static inline uint8_t host_f32_to_e2m1(float f) {
+  uint32_t u;
+  __builtin_memcpy(&u, &f, 4);
+  const uint8_t sign = (uint8_t)((u >> 28) & 0x8u);
+  u &= 0x7fffffffu;
+  float ax;
+  __builtin_memcpy(&ax, &u, 4);
+  if (!(ax < 6.0f)) return (uint8_t)(sign | 7u);
+  static const float mag[8] = {0.f, 0.5f, 1.f, 1.5f, 2.f, 3.f, 4.f, 6.f};
+  int c = 0;
+  while (c < 7 && ax > mag[c + 1]) ++c;                 // mag[c] < ax <= mag[c + 1]  (c == 0: 0 <= ax <= 0.5)
+  if (ax <= mag[c]) return (uint8_t)(sign | (uint8_t)c);
+  const float mid = 0.5f * (mag[c] + mag[c + 1]);
+  const int pick = ax < mid ? c : (ax > mid ? c + 1 : ((c & 1) ? c + 1 : c));   // tie: the even code
+  return (uint8_t)(sign | (uint8_t)pick);
+}
+
 // one value into a buffer of element type MI355_KV_F32 / MI355_KV_BF16 / MI355_KV_F16 (index in elements); round to nearest even
 __device__ __forceinline__ void store_kv_elem(void* base, int64_t idx, float v, int dtype) {
   if (dtype == MI355_KV_F32) ((float*)base)[idx] = v;

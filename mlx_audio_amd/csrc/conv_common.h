@@ -20,7 +20,7 @@ __device__ __forceinline__ float gelu_tanh(float x) { return 0.5f * x * (1.0f + 
 // PREC 2 / 4 split the fp32 activation into hi + lo images of the weight's 16-bit type (two MFMAs per fragment)
 template <int PREC>
 __device__ __forceinline__ f32x16 mfma16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
-  if constexpr (PREC >= 3)
+  if constexpr (PREC >= 3)   // (3, 4: fp16 images; 5, 6: the fp16 hi pass of the MX images)
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -35,13 +35,15 @@ constexpr int a_images() { return (PREC == 2 || PREC == 4) ? 2 : 1; }
 // LDS bytes of one staged window of R rows: [hi image R x 80][lo image R x 48][R scale bytes, padded to 16] (padded pitches instead of a swizzle)
 template <int PREC>
 __host__ __device__ constexpr int window_bytes(const int R) {
-  return PREC == 5 ? R * 128 + ((R + 15) & ~15) : a_images<PREC>() * R * 64;   // PREC 5: 80-byte hi rows + 48-byte lo rows (unswizzled, conv_ws4.h)
+  return PREC == 5 ? R * 128 + ((R + 15) & ~15)    // PREC 5: 80-byte hi rows + 48-byte lo rows (unswizzled, conv_ws4.h)
+         : PREC == 6 ? R * 96 + ((R + 15) & ~15)   // PREC 6: 80-byte hi rows + 16-byte FP4 lo rows
+                     : a_images<PREC>() * R * 64;
 }
 // the part of t the first (hi) image carries, as an fp32 value
 template <int PREC>
 __device__ __forceinline__ float split_hi(float t) {
   if constexpr (PREC == 3) return t;
-  else if constexpr (PREC == 4 || PREC == 5) return (float)(_Float16)__builtin_fminf(__builtin_fmaxf(t, -65504.f), 65504.f);
+  else if constexpr (PREC == 4 || PREC == 5 || PREC == 6) return (float)(_Float16)__builtin_fminf(__builtin_fmaxf(t, -65504.f), 65504.f);
   else return bf16_bits_to_f32(f32_to_bf16_bits(t));
 }
 template <int PREC>

@@ -618,8 +618,8 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
   MI355_REQUIRE(!a.up_s || (a.up_cout > 0 && a.Cout % a.up_cout == 0 && a.Cout / a.up_cout == a.up_s),
                 "conv_gemm: polyphase store needs Cout == up_s*up_cout");
   if (a.precision == 0) a.precision = 2;
-  MI355_REQUIRE(a.precision >= 1 && a.precision <= 5, "conv_gemm: precision must be 1 .. 5");
-  MI355_REQUIRE(a.precision != 5 || !a.pre_fq, "conv_gemm: precision 5 has no quantising prologue");
+  MI355_REQUIRE(a.precision >= 1 && a.precision <= 6, "conv_gemm: precision must be 1 .. 6");
+  MI355_REQUIRE((a.precision != 5 && a.precision != 6) || !a.pre_fq, "conv_gemm: precisions 5 / 6 have no quantising prologue");
   MI355_REQUIRE(!a.pre_fq || a.pre_act == MI355_ACT_NONE || a.pre_act == MI355_ACT_LEAKY || (a.pre_act == MI355_ACT_SNAKE && !a.pre_inv_beta),
                 "conv_gemm: a quantising prologue (pre_fq) takes no activation, LeakyReLU or Snake");
   if (a.out_scale == 0.f) a.out_scale = 1.f;
@@ -640,7 +640,7 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
     static const int ws_feat_e = getenv("MI355_CONV_WS_FEAT") ? atoi(getenv("MI355_CONV_WS_FEAT")) : 0;
     return mi355_conv_ws4_launch(a, st, ws_feat_e & 3, a.Cout <= 64 ? 64 : 128);
   }
-  if (a.precision == 5) {
+  if (a.precision == 5 || a.precision == 6) {
     // the wave-specialised kernel takes the launch when it fills the chip (the same rule as the auto choice below) or when asked for by tile
     // code; everything else runs the precision-4 arithmetic of the 4-wave kernels on the image's fp16 slices
     static const long ws_min5 = getenv("MI355_CONV_WS_MIN_TILES") ? atol(getenv("MI355_CONV_WS_MIN_TILES")) : 128;
@@ -651,7 +651,7 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
       const int rc = mi355_conv_ws4_launch(a, st, tile == 0 ? 0 : (((tile / 10000000) % 10) | ((tile / 100000000) << 4)));   // feature / probe / ablation bits
       if (rc != MI355_ERR_UNSUPPORTED) return rc;
     }
-    MI355_REQUIRE(tile % 10000000 != 6128128, "conv_gemm: precision 5 on the wave-specialised tile needs K = 3 (mod 4), a plain / LeakyReLU / Snake prologue, "
+    MI355_REQUIRE(tile % 10000000 != 6128128, "conv_gemm: precisions 5 / 6 on the wave-specialised tile needs K = 3 (mod 4), a plain / LeakyReLU / Snake prologue, "
                   "no epilogue activation beyond LeakyReLU and 16-B aligned channels-last rows");
     t_mx_lo_slices = (a.K + 1) >> 1;
     a.precision = 4;   // (the precision-4 instantiations of the wave-specialised kernel do not know the MX slice layout: mx_image below)

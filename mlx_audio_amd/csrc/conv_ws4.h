@@ -89,7 +89,10 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
   static_assert(!FQ || (!GEMM && (PRE == P_NONE || PRE == P_LEAKY || PRE == P_SNAKE)), "quantising prologues: conv mode, none / LeakyReLU / Snake");
   constexpr int BM = 128;
   static_assert(BN == 128 || BN == 64, "tile columns");
-  static_assert(PREC != 5 || (!GEMM && !FQ && BN == 128), "precision 5: conv mode, 128-column tiles");
+  constexpr bool MXP = PREC == 5 || PREC == 6;   // fp16 hi pass + block-scaled lo pass on an MX image: e4m3 (5) or FP4 e2m1 (6) elements
+  constexpr bool FP4 = PREC == 6;
+  static_assert(!MXP || (!GEMM && !FQ && BN == 128), "precisions 5 / 6: conv mode, 128-column tiles");
+  static_assert(!FP4 || CW, "precision 6: the column-wave consumer layout only");
   constexpr int NLD = GEMM ? 8 : 6;  // window passes of 32 rows per chunk (conv: R <= 192; GEMM mode: R = 256)
   constexpr int NA = a_images<PREC>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -100,7 +103,9 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
   // PREC 5 keeps its planes UNSWIZZLED at padded pitches -- 80-byte hi rows, 48-byte lo rows: 20 r mod 64 / 12 r mod 64 walk the 4-bank groups
   // bijectively over any 16 consecutive row residues, so the 16 lanes of a ds_read_b128 group (rows covering all residues mod 16, one 16-byte piece
   // each) never meet -- and an address is then base + row * pitch: one add per read instead of the ~10 VALU operations of the XOR swizzle
-  constexpr int HP = PREC == 5 ? 80 : 64, LP = 48;
+  // PREC 6: 16-byte lo rows (32 channels x 4 bits) at their natural pitch: a lane reads ONE row's 16 bytes (its scale block = tap 2 p + lane half), and
+  // 16 consecutive rows are 16 distinct 16-byte slots of the 256-byte bank row
+  constexpr int HP = MXP ? 80 : 64, LP = FP4 ? 16 : 48;
   const int ABYTES = R * HP;
   const int WBYTES = window_bytes<PREC>(R);  // one staged window: NA 16-bit images (PREC 5: hi image, e4m3 lo image, scale bytes)
   char* Abase = smem;  // [2 buffers][WBYTES]
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
     };
 
     // precision 5: windows that lie inside their utterance in rows and channels take straight-line loads and an unmasked conversion (FASTW)
-    constexpr bool FASTW = PREC == 5;
+    constexpr bool FASTW = MXP;
     auto interior_window = [&](const item_t& it) {
       const int r0 = it.l0 - a.pad;
       return r0 >= 0 && r0 + R <= it.len_in && r0 + R <= a.Lin && it.ci * 32 + 32 <= a.Cin;   // wave-uniform
@@ -263,10 +268,10 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
                 }
               }
             }
-            const int addr = PREC == 5 ? r * HP + c4 * 2 : r * 64 + ((((c4 >> 3) ^ ((r >> 2) & 3))) << 4) + ((c4 & 4) << 1);
+            const int addr = MXP ? r * HP + c4 * 2 : r * 64 + ((((c4 >> 3) ^ ((r >> 2) & 3))) << 4) + ((c4 & 4) << 1);
             uint2 ph;
             float hi[4];
-            if constexpr (PREC == 5) {  // v_cvt_pk_f16_f32 on the clamped value, v_cvt_f32_f16 back
+            if constexpr (MXP) {  // v_cvt_pk_f16_f32 on the clamped value, v_cvt_f32_f16 back
               typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
               typedef float f2_t __attribute__((ext_vector_type(2)));
               float cl[4];
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
               pl.y = pack_lo<PREC>(tt[2] - hi[2], tt[3] - hi[3]);
               *(uint2*)(A_lo + addr) = pl;
             }
-            if constexpr (PREC == 5) {
+            if constexpr (MXP) {
               // MX block = the 32 channels of this window row (the 8 lanes ptid & 7): shared exponent = floor(log2(max |lo|)) - 7, so the scaled
               // elements stay below 256 < 448 (no saturation); E8M0 byte 0 (2^-127) for an all-zero / denormal-sized row
               // lo = t - fp16(t) as ONE v_fma_mix_f32 per element (the half operand is read in place: no v_cvt_f32_f16 back to fp32 first); the
@@ -316,18 +321,29 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
               mb = max(mb, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mb, 0x4E, 0xf, 0xf, true));   // quad_perm [2, 3, 0, 1]
               mb = max(mb, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mb, 0x141, 0xf, 0xf, true));  // row_half_mirror: the other quad of the 8 lanes
               // (floor 1, not 0: the scale then is a NORMAL float for the scaled conversion below; a row that small -- padding, lo == 0 -- converts to 0 anyway)
-              const int sb = max((int)(mb >> 23) - 7, 1);
+              // PREC 6: the e2m1 grid tops out at 6 = 1.5 x 2^2: shared exponent = floor(log2(max |lo|)) - 2 (OCP MX: a scaled maximum in (6, 8) saturates)
+              const int sb = max((int)(mb >> 23) - (FP4 ? 2 : 7), 1);
               // v_cvt_scalef32_pk_fp8_f32 divides both inputs by 2^(exponent of the scale operand - 127) inside the conversion (probed on gfx950:
               // tools/probes/cvt_scale_probe.hip, profiles/r5_cvt_scale_probe_call9.txt: bit-identical to multiplying by the exact reciprocal first):
               // four v_mul_f32 and the 254 - sb arithmetic per four elements less in the producers' issue stream
               typedef short s16x2 __attribute__((ext_vector_type(2)));
               const float scl = __builtin_bit_cast(float, (uint32_t)sb << 23);   // 2^(sb - 127)
-              s16x2 p8 = {0, 0};
-              p8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(p8, l0, l1, scl, false);
-              p8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(p8, l2, l3, scl, true);
-              const int pk = __builtin_bit_cast(int, p8);
               char* A_l8 = A_hi + ABYTES;
-              *(int*)(A_l8 + r * LP + c4) = pk;
+              if constexpr (FP4) {
+                // v_cvt_scalef32_pk_fp4_f32: src0 -> the low nibble, src1 -> the high nibble of the byte op_sel picks; divides by 2^(exponent of the
+                // scale - 127), nearest with ties to the even code, saturating at +-6 (probed: tools/src/mfma_fp4_probe.hip, r6_mfma_fp4_probe_call2.jsonl).
+                // The lane's four channels are two bytes: nibble j of a row's 16 bytes = channel j of the chunk
+                unsigned p4 = 0;
+                p4 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(p4, l0, l1, scl, 0);
+                p4 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(p4, l2, l3, scl, 1);
+                *(uint16_t*)(A_l8 + r * LP + (c4 >> 1)) = (uint16_t)p4;
+              } else {
+                s16x2 p8 = {0, 0};
+                p8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(p8, l0, l1, scl, false);
+                p8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(p8, l2, l3, scl, true);
+                const int pk = __builtin_bit_cast(int, p8);
+                *(int*)(A_l8 + r * LP + c4) = pk;
+              }
               if ((ptid & 7) == 0) *(uint8_t*)(A_l8 + R * LP + r) = (uint8_t)sb;
             }
           }
@@ -352,12 +368,12 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
     // PREC 5 probe: producer wave 4 of every 16th workgroup sums the cycles it spends converting, at the barriers and issuing loads
     unsigned long long* pdbg = nullptr;
     unsigned long long pc_conv = 0, pc_bar = 0, pc_load = 0, pc_items = 0, pc_first = 0, pc_t = 0;
-    if constexpr (DBG && PREC == 5) {
+    if constexpr (DBG && MXP) {
       if (wave == 4 && (blockIdx.x & 15) == 0 && q.dbg) pdbg = q.dbg + (size_t)(blockIdx.x >> 4) * kDbgSlots;
       if (pdbg) pc_first = pc_t = __builtin_amdgcn_s_memtime();
     }
     auto pstamp = [&](unsigned long long& acc_c) {
-      if constexpr (DBG && PREC == 5) {
+      if constexpr (DBG && MXP) {
         if (pdbg) { const unsigned long long n = __builtin_amdgcn_s_memtime(); acc_c += n - pc_t; pc_t = n; }
       }
     };
@@ -366,7 +382,7 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
     pstamp(pc_load);
     while (true) {
       if (work) convertA(s0, k0, ia, Abase);
-      if constexpr (DBG && PREC == 5) { if (pdbg) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+      if constexpr (DBG && MXP) { if (pdbg) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
       pstamp(pc_conv);
       item_t na = ib;
       if (na.id >= 0) advance(na);
@@ -377,7 +393,7 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
       ++pc_items;
       if (ib.id < 0) break;
       if (work) convertA(s1, k1, ib, Abase + WBYTES);
-      if constexpr (DBG && PREC == 5) { if (pdbg) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+      if constexpr (DBG && MXP) { if (pdbg) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
       pstamp(pc_conv);
       item_t nb = na;
       if (nb.id >= 0) advance(nb);
@@ -390,7 +406,7 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
       ia = na;
       ib = nb;
     }
-    if constexpr (DBG && PREC == 5) {
+    if constexpr (DBG && MXP) {
       if (pdbg && lane_k == 0) {
         pdbg[42] = pc_conv; pdbg[43] = pc_bar; pdbg[44] = pc_load; pdbg[45] = pc_items; pdbg[46] = pc_first; pdbg[47] = pc_t;
       }
@@ -400,7 +416,7 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
 
   // -------------------------------------------------------------------------------- consumers
   // consumer waves over the tile: 2 x 2 blocks of 64 x (BN / 2) -- or, precision 5, four COLUMN waves of 128 rows x 32 columns (see there)
-  constexpr bool COLW = PREC == 5 && CW;   // CW = false: the 2 x 2 layout (A / B aid)
+  constexpr bool COLW = MXP && CW;   // CW = false: the 2 x 2 layout (A / B aid, precision 5 only)
   constexpr int WM = COLW ? 128 : 64, WN = COLW ? 32 : BN / 2, MF = WM / 32, NF = WN / 32;   // BN = 64: every activation fragment feeds one 32-column fragment instead of two
   constexpr int NB = 2 * NF;                                  // weight fragments of a wave per slice: (nf, kk)
   const int wm = COLW ? 0 : wave >> 1, wn = COLW ? wave : wave & 1;
@@ -432,7 +448,7 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
     const char* wfrag = (const char*)a.w + ((int64_t)((n0 >> 5) + wn * NF)) * 2048 + lane * 16;
     auto wptr = [&](const int s) { return wfrag + (int64_t)(s < last_slice ? s : last_slice) * wstep; };
     bf16x8 b0[NB], b1[NB];
-    if constexpr (PREC != 5) {
+    if constexpr (!MXP) {
 #pragma unroll
       for (int f = 0; f < NB; ++f) b0[f] = *(const bf16x8*)(wfrag + f * 1024);
     }
@@ -508,7 +524,7 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
         }
     }
 
-    if constexpr (PREC == 5 && COLW) {
+    if constexpr (MXP && COLW) {
       // ---- fp16 hi taps, then the e4m3 lo tap pairs of the chunk: one stream of 8-register weight items, one s_barrier per chunk.
       // COLUMN-WAVE layout (round 6): consumer wave w owns ALL 128 rows x the 32 columns [32 w, +32) of the tile = four 32x32 accumulators (mf = 0..3).
       // A weight item is then 8 registers per lane (hi item: the kk 0 and kk 1 fragments of ONE 32-column group; lo item: its 32-byte e4m3 operand)
@@ -527,12 +543,17 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
       // weight item s: a wave-uniform base (SGPR pair) + the lane's 32-bit offset: no 64-bit VALU address arithmetic, no pointer VGPRs
       const char* wtile = (const char*)a.w + ((int64_t)((n0 >> 5) + wn * NF)) * 2048;
       const uint32_t wlane = (uint32_t)lane * 16u;
-      auto ldW = [&](i32x8& w, const int s, const bool first = false) {
+      auto ldW = [&](i32x8& w, const int s, const bool first = false, const bool lo_item = false) {
         const char* src = wtile + (int64_t)(s < last_slice ? s : last_slice) * wstep;
         if constexpr ((ABL & 1) != 0) {   // timing ablation: only the tile's first weight item is loaded
           if (!first) { asm volatile("" : "+v"(w) : "s"(src)); return; }
         }
-        const i32x4 lo4 = *(const i32x4*)(src + wlane), hi4 = *(const i32x4*)(src + 1024 + wlane);
+        const i32x4 lo4 = *(const i32x4*)(src + wlane);
+        if (FP4 && lo_item) {   // an FP4 lo item is ONE kilobyte (16 bytes per lane: the 32 channels of tap 2 p + lane half for the lane's column)
+          w = __builtin_shufflevector(lo4, lo4, 0, 1, 2, 3, 4, 5, 6, 7);
+          return;
+        }
+        const i32x4 hi4 = *(const i32x4*)(src + 1024 + wlane);
         w = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
       };
       i32x8 w0, w1;
@@ -551,8 +572,13 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
       auto fresh = [&]() {
         asm volatile("" : "+v"(hlx), "+v"(hhx));
         lbH = hlx * HP + hhx * 16;
-        lbL = hlx * LP + hhx * 16;
-        lbS = hlx;
+        if constexpr (FP4) {   // a lane reads the whole 16-byte row under ITS tap: lane half 1 sits one tap (dil rows) further down
+          lbL = (hlx + hhx * dil) * LP;
+          lbS = hlx + hhx * dil;
+        } else {
+          lbL = hlx * LP + hhx * 16;
+          lbS = hlx;
+        }
       };
       auto lo4 = [](const i32x8& v) { return __builtin_bit_cast(bf16x8, (i32x4)__builtin_shufflevector(v, v, 0, 1, 2, 3)); };
       auto hi4 = [](const i32x8& v) { return __builtin_bit_cast(bf16x8, (i32x4)__builtin_shufflevector(v, v, 4, 5, 6, 7)); };
@@ -581,7 +607,15 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
         asm volatile("" : "+v"(la), "+v"(ls));
         i32x4 x0, x1;
         int sc;
-        if constexpr ((ABL & 2) != 0) {
+        if constexpr (FP4) {
+          // ONE 16-byte read: the lane's row under tap 2 p + lane half (fresh() put the half's tap shift into the lane offset; the odd tap
+          // count's last pair takes its last tap twice: there the shift is taken back, the weight half is zero)
+          const int back = (2 * p + 1 < K) ? 0 : dil;   // wave-uniform
+          if (back) { la -= hhx * back * LP; ls -= hhx * back; }
+          x0 = *(const i32x4*)(Abase + (la + (ubase + u0 * LP)));
+          x1 = x0;
+          sc = (int)*(const uint8_t*)(Abase + (ls + (ubase + R * LP + u0)));
+        } else if constexpr ((ABL & 2) != 0) {
           x0 = (i32x4){la, la, la, la}; x1 = x0; sc = 120 + (ls & 7);   // timing ablation: no LDS read
         } else {
           x0 = *(const i32x4*)(Abase + (la + (ubase + u0 * LP)));
@@ -602,7 +636,12 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
         // registers -- and then shuffles whole accumulators through scratch.  Hazards, which hipcc does not pad for an asm statement: a VALU
         // result as an operand (the scale byte's mask) wants two wait states = the leading s_nop 1; the next reader of D is always another
         // MFMA taking it whole as C (0 wait states) until the pad in front of the fold / epilogue below.)
-        asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc[mf][0]) : "v"(qv[mf]), "v"(w), "v"(sv[mf]), "v"(bsc));
+        if constexpr (FP4) {   // 4-register operands, cbsz / blgp 4 = e2m1 on both sides: 8 passes instead of 16
+          const i32x4 a4 = __builtin_shufflevector(qv[mf], qv[mf], 0, 1, 2, 3), b4 = __builtin_shufflevector(w, w, 0, 1, 2, 3);
+          asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:4" : "+v"(acc[mf][0]) : "v"(a4), "v"(b4), "v"(sv[mf]), "v"(bsc));
+        } else {
+          asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc[mf][0]) : "v"(qv[mf]), "v"(w), "v"(sv[mf]), "v"(bsc));
+        }
       };
       // hi tap tp on weight item w (its two fragments are in flight or landed); `last`: the chunk's last hi tap requests the operands of the
       // first lo tap pair instead of the next tap's fragments
@@ -627,8 +666,8 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
           __builtin_amdgcn_sched_barrier(0);
         }
       };
-      auto prefetch = [&](i32x8& w, const int s) {
-        ldW(w, s);
+      auto prefetch = [&](i32x8& w, const int s, const bool lo_item = false) {
+        ldW(w, s, false, lo_item);
         asm volatile("" ::: "memory");  // keep the prefetch AHEAD of the MFMAs
         __builtin_amdgcn_sched_barrier(0);
       };
@@ -664,15 +703,34 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
           hi_tap(tp + 1, wb, std::false_type{});
           s += 2;
         }
-        prefetch(wb, s + 1);
+        prefetch(wb, s + 1, true);                    // the chunk's first lo item
         hi_tap(tp, wa, std::true_type{});
         s += 1;
-        for (int p = 0; p < NP; p += 2) {
-          prefetch(wa, s + 1);
+        if constexpr (FP4) {
+          // lo items two at a time (NP is even); the LAST two are peeled so that every prefetch knows at compile time whether it fetches a lo item (one
+          // kilobyte per wave under precision 6) or the next chunk's first hi item: a run-time choice between one and two loads would cost the
+          // compiler's wait-count bookkeeping its precision (it then waits for everything in flight)
+          int p = 0;
+          for (; p + 2 < NP; p += 2) {
+            prefetch(wa, s + 1, true);
+            lo_pair(p, wb, true);
+            prefetch(wb, s + 2, true);
+            lo_pair(p + 1, wa, true);
+            s += 2;
+          }
+          prefetch(wa, s + 1, true);
           lo_pair(p, wb, true);
-          prefetch(wb, s + 2);
-          lo_pair(p + 1, wa, p + 2 < NP);
+          prefetch(wb, s + 2, false);                   // the next chunk's first hi item (past the image's end: the last slice again, never used)
+          lo_pair(p + 1, wa, false);
           s += 2;
+        } else {
+          for (int p = 0; p < NP; p += 2) {
+            prefetch(wa, s + 1);
+            lo_pair(p, wb, true);
+            prefetch(wb, s + 2);
+            lo_pair(p + 1, wa, p + 2 < NP);
+            s += 2;
+          }
         }
         jbuf ^= 1;
       };
@@ -1002,7 +1060,7 @@ int launch_ws4(const mi355_conv_gemm_args& a, hipStream_t st, const int feat, un
   q.bn = BN;
   q.gemm = GEMM ? 1 : 0;
   const int chunks32 = (a.Cin + 31) >> 5;
-  q.nslices = chunks32 * (PREC == 5 ? a.K + ((a.K + 1) >> 1) : a.K);
+  q.nslices = chunks32 * ((PREC == 5 || PREC == 6) ? a.K + ((a.K + 1) >> 1) : a.K);
   if (q.gemm) {
     q.nch = (chunks32 + 1) >> 1;
     q.keff = 2;
@@ -1085,4 +1143,5 @@ int mi355_conv_ws4_p4(const mi355_conv_gemm_args& a, hipStream_t st, int feat, i
 int mi355_conv_ws4_p13(const mi355_conv_gemm_args& a, hipStream_t st, int feat, int bn);
 int mi355_conv_ws4_fq(const mi355_conv_gemm_args& a, hipStream_t st, int feat, int bn);   // quantising prologues (pre_fq), precision 2
 int mi355_conv_ws4_p5(const mi355_conv_gemm_args& a, hipStream_t st, int feat, int bn);   // fp16 hi + MX e4m3 lo (conv mode, 128-column tiles)
+int mi355_conv_ws4_p6(const mi355_conv_gemm_args& a, hipStream_t st, int feat, int bn);   // fp16 hi + MX FP4 lo (conv mode, 128-column tiles)
 int mi355_conv_ws4_p5_probe(const mi355_conv_gemm_args& a, hipStream_t st, int feat, unsigned long long* dbg);   // its probe / ablation builds

@@ -22,7 +22,7 @@ extern "C" int mi355_conv_ws4_resident(int wgs) {
 
 bool mi355_conv_ws4_eligible(const mi355_conv_gemm_args& a, bool vec) {
   if (!vec || a.Lin <= 0 || a.flat_valid != 0) return false;   // (flattened strided convs: the producers mask by row, not by flat element index)
-  if (a.precision == 5)   // conv mode only (K == 1 layers included), K odd with an even number of tap pairs, 128-column tiles
+  if (a.precision == 5 || a.precision == 6)   // conv mode only (K == 1 layers included), K odd with an even number of tap pairs, 128-column tiles
     return a.K % 4 == 3 && 128 + (a.K - 1) * a.dil <= 192 && a.Cout > 64 && !a.pre_fq && (pre_kind(a) == P_NONE || pre_kind(a) == P_LEAKY || pre_kind(a) == P_SNAKE) &&
            epi_family(a) == 0;
   if (!gemm_mode(a) && 128 + (a.K - 1) * a.dil > 192) return false;
@@ -77,6 +77,7 @@ int mi355_conv_ws4_launch(const mi355_conv_gemm_args& a, hipStream_t st, int fea
   if (a.pre_fq) rc = a.precision == 2 ? mi355_conv_ws4_fq(a, st, feat & 3, bn) : MI355_ERR_UNSUPPORTED;
   else if (a.precision == 2) rc = mi355_conv_ws4_p2(a, st, feat, g_dbg_buffer, bn);
   else if (a.precision == 4) rc = mi355_conv_ws4_p4(a, st, feat & 3, bn);
+  else if (a.precision == 6) rc = mi355_conv_ws4_p6(a, st, feat & 9, bn);
   else if (a.precision == 5) rc = (feat & ~11) ? mi355_conv_ws4_p5_probe(a, st, feat, g_dbg_buffer) : mi355_conv_ws4_p5(a, st, feat & 11, bn);
   else if (a.precision == 1 || a.precision == 3) rc = mi355_conv_ws4_p13(a, st, feat & 3, bn);
   if (rc == MI355_ERR_UNSUPPORTED)

@@ -76,7 +76,7 @@ class PackedConv:
     k: int
     cin: int
     f16: bool = False  # packed as fp16 for the single-pass fp16 MFMA mode (precision 3)
-    mx: bool = False   # MX image: fp16 tap slices + e4m3 tap-pair slices + E8M0 column scales (precision 5)
+    mx: int = 0        # 1: MX image: fp16 tap slices + e4m3 tap-pair slices + E8M0 column scales (precision 5); 2: MX4 image, FP4 (e2m1) tap-pair slices (precision 6)
 
 
 def mx_eligible(cout: int, k: int, cin: int) -> bool:
@@ -90,8 +90,9 @@ def mx_pays(cout: int, k: int, cin: int) -> bool:
     return mx_eligible(cout, k, cin) and k >= 7
 
 
-def pack_conv(w: torch.Tensor, bias: Optional[torch.Tensor], device, f16: bool = False, mx: bool = False) -> PackedConv:
-    """``w``: float32 CPU tensor ``[Cout, K, Cin]`` (MLX conv layout) or ``[Cout, Cin]`` (linear).  ``mx``: the image of precision 5."""
+def pack_conv(w: torch.Tensor, bias: Optional[torch.Tensor], device, f16: bool = False, mx=False) -> PackedConv:
+    """``w``: float32 CPU tensor ``[Cout, K, Cin]`` (MLX conv layout) or ``[Cout, Cin]`` (linear).  ``mx``: True / 1 = the image of precision 5 (e4m3 lo
+    slices), 2 = the MX4 image of precision 6 (FP4 lo slices)."""
     if w.dim() == 2:
         w = w[:, None, :]
     w = w.detach().to(torch.float32).contiguous().cpu()
@@ -100,11 +101,12 @@ def pack_conv(w: torch.Tensor, bias: Optional[torch.Tensor], device, f16: bool =
     if mx:
         nb = lib.mi355_packed_conv_weight_mx_bytes(cout, k, cin)
         out8 = np.empty(nb, dtype=np.uint8)
-        rc = lib.mi355_pack_conv_weight_mx_host(w.numpy().ctypes.data, cout, k, cin, out8.ctypes.data)
-        _lib.check(rc, "mi355_pack_conv_weight_mx_host")
+        fn = "mi355_pack_conv_weight_mx4_host" if int(mx) == 2 else "mi355_pack_conv_weight_mx_host"
+        rc = getattr(lib, fn)(w.numpy().ctypes.data, cout, k, cin, out8.ctypes.data)
+        _lib.check(rc, fn)
         wd = torch.from_numpy(out8).to(device)
         bd = None if bias is None else bias.detach().to(torch.float32).contiguous().to(device)
-        return PackedConv(wd, bd, cout, k, cin, True, True)
+        return PackedConv(wd, bd, cout, k, cin, True, 2 if int(mx) == 2 else 1)
     n = lib.mi355_packed_conv_weight_elems(cout, k, cin)
     out = np.empty(n, dtype=np.uint16)
     rc = lib.mi355_pack_conv_weight_host_dt(w.numpy().ctypes.data, cout, k, cin, 1 if f16 else 0, out.ctypes.data)
@@ -437,12 +439,12 @@ def conv_gemm(x: torch.Tensor, pc: PackedConv, y: torch.Tensor, *, dil: int = 1,
     By, Ly, Cy, ybs, ldy = _nlc(y)
     assert B == By
     if pc.mx:
-        precision = 5  # the weight image decides
+        precision = 6 if pc.mx == 2 else 5  # the weight image decides
     elif pc.f16:
         if precision not in (3, 4):
-            precision = 4 if precision == 5 else 3  # fp16-packed weights only fit the fp16 MFMA paths (3 single, 4 hi+lo; mode 5 = hi+lo where no MX image exists)
-    elif precision in (3, 4, 5):
-        raise _lib.Mi355Error("conv_gemm: precision 3 / 4 need weights packed with f16=True, precision 5 with mx=True")
+            precision = 4 if precision in (5, 6) else 3  # fp16-packed weights only fit the fp16 MFMA paths (3 single, 4 hi+lo; mode 5 = hi+lo where no MX image exists)
+    elif precision in (3, 4, 5, 6):
+        raise _lib.Mi355Error("conv_gemm: precision 3 / 4 need weights packed with f16=True, precision 5 / 6 with mx=True / mx=2")
     kw = dict(x=_ptr(x), x_bstride=xbs, ldx=ldx, x_off=x_off, Cin=pc.cin, Lin=Lin, lens_in=_ptr(lens_in), flat_valid=0,
               w=_ptr(pc.w), Cout=pc.cout, K=pc.k, dil=dil, pad=pad, pre_act=pre_act, pre_slope=pre_slope,
               pre_alpha=_ptr(pre_alpha), bias=_ptr(pc.bias) if use_bias else None, post_act=post_act,

@@ -244,9 +244,10 @@ class KokoroEngine:
         # precision 5: MX images where the fp16 hi + e4m3 lo arithmetic is the faster one (>= 7 taps on the wave-specialised kernel); every other
         # conv keeps the default mode's bf16 image (exact weights, the cheapest prologue: the 3-tap convs are HBM / VALU bound)
         # (a conv whose input is fake-quantised -- KittenTTS -- keeps its bf16 image: the quantising prologue has no MX form, mi355_conv_gemm rejects it)
-        mx = (self.precision == 5 and pre.startswith("decoder.") and w.dim() == 3 and ops.mx_pays(w.shape[0], w.shape[1], w.shape[2])
+        # precision 6: the same convs on MX4 images (FP4 lo elements: the lo pass at 4x the 16-bit rate of the matrix pipe)
+        mx = (self.precision in (5, 6) and pre.startswith("decoder.") and w.dim() == 3 and ops.mx_pays(w.shape[0], w.shape[1], w.shape[2])
               and not (self.qmods and self._isq(pre)))
-        return ops.pack_conv(w, b, self.dev, f16=self._f16(pre), mx=mx)
+        return ops.pack_conv(w, b, self.dev, f16=self._f16(pre), mx=(2 if self.precision == 6 else 1) if mx else 0)
 
     def _f16(self, pre: str) -> bool:
         """precision 3: the decoder / generator convs (97 % of the FLOPs) run the single-pass fp16 MFMA; the front end
@@ -404,7 +405,7 @@ class KokoroEngine:
 
     def _prec(self, pc) -> int:
         # the weight image decides: fp16-packed weights select 3 themselves (4 in mode 5), MX images 5; bf16 images of modes 3 / 5 (front end) run 2
-        return 2 if (self.precision == 3 or (self.precision == 5 and not pc.f16)) else self.precision
+        return 2 if (self.precision == 3 or (self.precision in (5, 6) and not pc.f16)) else self.precision
 
     def _conv(self, x, pc, y, **kw):
         kw.setdefault("precision", self._prec(pc))

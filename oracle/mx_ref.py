@@ -132,3 +132,117 @@ def pack_mx_image(w: np.ndarray) -> np.ndarray:
                     out[o:o + 1024] = frag.reshape(-1)
     out[chunks * (K + npair) * ntp * 2048:] = (ep + 127).astype(np.uint8)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ precision 6: FP4 (OCP e2m1) lo pass
+# y = sum fp16(t) * w + sum q4(t - fp16(t)) * q4(w): e2m1 elements {0, 0.5, 1, 1.5, 2, 3, 4, 6} (sign + 2 exponent bits, bias 1, + 1 mantissa bit), one E8M0
+# scale per window row and 32-channel chunk for the activations and one per output column for the weights, both chosen as floor(log2(max)) - 2 (OCP MX: the
+# scaled maximum lies in [4, 8), values above 6 saturate); round to nearest, ties to the even CODE (what v_cvt_scalef32_pk_fp4_f32 does: probed on gfx950,
+# profiles/r6_mfma_fp4_probe_call2.jsonl).
+_E2M1 = np.array([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
+
+
+def e2m1_code(v: np.ndarray) -> np.ndarray:
+    """e2m1 code (0..15, bit 3 = sign) of the nearest grid value (ties to the even code), saturating at +-6; float64 in."""
+    v = np.asarray(v, dtype=np.float64)
+    a = np.minimum(np.abs(v), 6.0)
+    d = np.abs(a[..., None] - _E2M1)
+    best = d.min(axis=-1, keepdims=True)
+    cand = d == best
+    lo = cand.argmax(axis=-1)                                   # the lower candidate
+    hi = 7 - cand[..., ::-1].argmax(axis=-1)                    # the upper candidate (== lo unless a tie)
+    code = np.where(lo == hi, lo, np.where(lo % 2 == 0, lo, hi))
+    return (code | (np.signbit(v).astype(np.int64) << 3)).astype(np.uint8)
+
+
+def e2m1_round(v: np.ndarray) -> np.ndarray:
+    c = e2m1_code(v)
+    return np.where(c & 8, -1.0, 1.0) * _E2M1[c & 7]
+
+
+def column_scale_exponents4(w: np.ndarray) -> np.ndarray:
+    """E8M0 exponent e[n] of every output column of w [Cout, K, Cin] for the FP4 image: floor(log2(max |w[n]|)) - 2 (0 for an all-zero column)."""
+    amax = np.abs(w.reshape(w.shape[0], -1)).max(axis=1).astype(np.float64)
+    e = np.zeros(w.shape[0], dtype=np.int64)
+    nz = amax > 0
+    e[nz] = np.floor(np.log2(amax[nz])).astype(np.int64) - 2
+    return np.clip(e, -127, 120)
+
+
+def quantise_weights4(w: np.ndarray) -> np.ndarray:
+    e = column_scale_exponents4(w)
+    sc = np.exp2(e.astype(np.float64))[:, None, None]
+    return e2m1_round(w.astype(np.float64) / sc) * sc
+
+
+def split_activation4(t: np.ndarray):
+    """As split_activation with FP4 residuals: shared exponent per row and 32-channel chunk = (biased float32 exponent of the block maximum) - 2, floored at byte 1."""
+    t = np.asarray(t, dtype=np.float32)
+    hi = np.clip(t, -65504.0, 65504.0).astype(np.float16).astype(np.float32)
+    lo = (t - hi).astype(np.float32)
+    C = t.shape[-1]
+    assert C % 32 == 0
+    blk = lo.reshape(*t.shape[:-1], C // 32, 32)
+    amax = np.abs(blk).max(axis=-1)
+    ef = (amax.view(np.uint32) >> 23).astype(np.int64)
+    sb = np.maximum(ef - 2, 1)
+    scale = np.exp2((sb - 127).astype(np.float64))[..., None]
+    q = e2m1_round(blk.astype(np.float64) / scale) * scale
+    return hi.astype(np.float64), q.reshape(t.shape)
+
+
+def conv_mx4(t: np.ndarray, w: np.ndarray, dil: int, pad: int) -> np.ndarray:
+    """conv_mx by the precision-6 arithmetic."""
+    L, cin = t.shape
+    cout, K, _ = w.shape
+    cp = (cin + 31) // 32 * 32
+    tp = np.zeros((L, cp), dtype=np.float32)
+    tp[:, :cin] = t
+    hi, lo = split_activation4(tp)
+    w16 = w.astype(np.float16).astype(np.float64)
+    wq = quantise_weights4(w)
+    y = np.zeros((L, cout), dtype=np.float64)
+    for k in range(K):
+        off = k * dil - pad
+        lo_r, hi_r = max(0, -off), min(L, L - off)
+        if hi_r <= lo_r:
+            continue
+        rows = slice(lo_r + off, hi_r + off)
+        y[lo_r:hi_r] += hi[rows, :cin] @ w16[:, k, :].T + lo[rows, :cin] @ wq[:, k, :].T
+    return y
+
+
+def pack_mx4_image(w: np.ndarray) -> np.ndarray:
+    """Independent restatement of ``mi355_pack_conv_weight_mx4_host`` (csrc/api.cpp): the MX image's geometry, one kilobyte of e2m1 codes per 32-column
+    group and tap pair (lane l: column l & 31, tap 2 p + (l >> 5), nibble j = channel j of the chunk, low nibble first), the second kilobyte zero."""
+    cout, K, cin = w.shape
+    chunks, ntp, npair = (cin + 31) // 32, (cout + 127) // 128 * 4, (K + 1) // 2
+    e = column_scale_exponents4(w)
+    wp = np.zeros((ntp * 32, 2 * npair, chunks * 32), dtype=np.float64)
+    wp[:cout, :K, :cin] = w
+    ep = np.zeros(ntp * 32, dtype=np.int64)
+    ep[:cout] = e
+    codes = e2m1_code(wp / np.exp2(ep.astype(np.float64))[:, None, None])                   # [N, 2 NP, C]
+    codes[cout:] = 0
+    codes[:, K:] = 0
+    codes[:, :, cin:] = 0
+    h16 = wp[:, :K, :].astype(np.float16).view(np.uint16)
+    out = np.zeros(chunks * (K + npair) * ntp * 2048 + ntp * 32, dtype=np.uint8)
+    lane = np.arange(64)
+    n_of = lane & 31
+    for ch in range(chunks):
+        base = ch * (K + npair) * ntp * 2048
+        for tap in range(K):
+            for nt in range(ntp):
+                for kk in range(2):
+                    c0 = ch * 32 + kk * 16 + (lane >> 5) * 8
+                    frag = h16[nt * 32 + n_of][:, tap][np.arange(64)[:, None], c0[:, None] + np.arange(8)[None, :]]
+                    o = base + ((tap * ntp + nt) * 2 + kk) * 1024
+                    out[o:o + 1024] = frag.astype(np.uint16).reshape(-1).view(np.uint8)
+        for p in range(npair):
+            for nt in range(ntp):
+                c = codes[nt * 32 + n_of, 2 * p + (lane >> 5)][:, ch * 32:ch * 32 + 32]     # [64 lanes, 32 channels]
+                o = base + K * ntp * 2048 + (p * ntp + nt) * 2048
+                out[o:o + 1024] = (c[:, 0::2] | (c[:, 1::2] << 4)).astype(np.uint8).reshape(-1)
+    out[chunks * (K + npair) * ntp * 2048:] = (ep + 127).astype(np.uint8)
+    return out

@@ -329,6 +329,40 @@ def test_kokoro_precision5_mx_lo_pass_mode(setup):
     assert err2 <= 2e-3 * peak and snr2 >= 50.0, (err2, snr2)
 
 
+def test_kokoro_precision6_fp4_lo_pass_mode(setup):
+    """precision=6 (round 6): the >= 7-tap decoder / generator convs as the fp16 hi pass + block-scaled FP4 (e2m1) lo pass on MX4 images -- the lo pass
+    at 4x the 16-bit rate of the matrix pipe.  The SAME bars as every mode (2e-3 * peak, 50 dB), teacher-forced on the oracle's features, canonical
+    sentence x 4 (both generator stages on the wave-specialised kernel) and x 1; the front end (integer path, F0 / N curves) stays bit-identical to
+    mode 2.  Expected from the CPU study of the scheme (profiles/r6_split_format_study_fp6.txt): ~4e-4 of the peak, ~70 dB."""
+    S, eng, ref = setup
+    from mlx_audio_amd.tts.models.kokoro.engine import KokoroEngine
+
+    eng6 = eng if eng.precision == 6 else KokoroEngine(S.make_kokoro_weights(), S.KOKORO_CONFIG, precision=6)
+    eng2 = KokoroEngine(S.make_kokoro_weights(), S.KOKORO_CONFIG, precision=2)
+    ids = S.make_phoneme_ids(18, seed=5)
+    ref_s = S.make_voice_pack()[len(ids) - 3]
+    _, d6, t6 = eng6.forward([ids], ref_s, speed=1.3, return_intermediates=True)
+    _, d2, t2 = eng2.forward([ids], ref_s, speed=1.3, return_intermediates=True)
+    torch.cuda.synchronize()
+    assert torch.equal(d6[0], d2[0]) and torch.equal(t6["f0"], t2["f0"]) and torch.equal(t6["n"], t2["n"])
+    del eng2
+    ids = S.make_phoneme_ids(78)
+    ref_s = S.make_voice_pack()[len(ids) - 3]
+    fd = S.forced_durations(80, 264)
+    ri, nz = _noise(264, 1234)
+    audio_ref, _, tr = ref.forward(ids, ref_s, pred_dur=fd, rand_ini=ri, noise=nz, return_intermediates=True)
+    peak = float(audio_ref.abs().max())
+    for nb in (4, 1):
+        tea = {k: torch.cat([torch.as_tensor(v)] * nb, dim=0) for k, v in _teacher(tr).items()}
+        outs, _ = eng6.forward([ids] * nb, ref_s.repeat(nb, 1), forced_durations=[fd] * nb, rand_ini=torch.from_numpy(np.repeat(ri, nb, axis=0)),
+                               noise=torch.from_numpy(np.repeat(nz, nb, axis=0)), overrides=tea)
+        torch.cuda.synchronize()
+        worst_err = max(float((outs[b].cpu() - audio_ref[0]).abs().max()) for b in range(nb))
+        worst_snr = min(snr_db(outs[b].cpu(), audio_ref[0]) for b in range(nb))
+        print(f"kokoro precision=6 (fp16 hi + MX FP4 lo, canonical sentence x {nb}): peak={peak:.3f} max_abs_err={worst_err:.3e} ({worst_err / peak:.2e} of peak) snr={worst_snr:.1f} dB")
+        assert worst_err <= 2e-3 * peak and worst_snr >= 50.0, (nb, worst_err, worst_snr)
+
+
 def test_kokoro_precision5_batch64_canonical(setup):
     """The BENCHMARKED configuration is the parity-tested one: 64 canonical utterances (T = 80, F = 264) through bench.py's exact call path --
     ``shard.kokoro_step`` on a ``ShardChannel`` (world 1), the engine in its default mode (5 for a bf16 checkpoint), ``back_kwargs`` carrying the

@@ -74,7 +74,7 @@ def main():
         args.rounds = 3
     if args.prec_ab:
         shapes = [s for s in shapes if s[2] % 4 == 3]
-        variants = [("p2_bf16_hi_lo", 6128128), ("p3_fp16_one_pass", 6128128), ("p4_fp16_hi_lo", 6128128), ("p5_fp16_hi_mx8_lo", 6128128)]
+        variants = [("p2_bf16_hi_lo", 6128128), ("p3_fp16_one_pass", 6128128), ("p4_fp16_hi_lo", 6128128), ("p5_fp16_hi_mx8_lo", 6128128), ("p6_fp16_hi_mx4_lo", 6128128)]
     lines = ["cin cout k dil rows fused variant ms tflops_alg GBps_alg maxrel"]
     g = torch.Generator(device=dev).manual_seed(0)
     for cin, cout, k, dil, L, fused in shapes:
@@ -82,13 +82,13 @@ def main():
             L, B = L * args.batch, 1
         w = (torch.randn(cout, k, cin) / math.sqrt(k * cin)).to(torch.bfloat16).float()
         bias = torch.randn(cout) * 0.1
-        pc = ops.pack_conv(w, bias, dev, mx=True) if args.precision == 5 else ops.pack_conv(w, bias, dev, f16=args.precision == 3)
+        pc = ops.pack_conv(w, bias, dev, mx=args.precision - 4) if args.precision in (5, 6) else ops.pack_conv(w, bias, dev, f16=args.precision == 3)
         vprec = {name: args.precision for name, _ in variants}
         vpc = {name: pc for name, _ in variants}
         if args.prec_ab:
-            pc16, pcmx = ops.pack_conv(w, bias, dev, f16=True), ops.pack_conv(w, bias, dev, mx=True)
-            vprec = {"p2_bf16_hi_lo": 2, "p3_fp16_one_pass": 3, "p4_fp16_hi_lo": 4, "p5_fp16_hi_mx8_lo": 5}
-            vpc = {"p2_bf16_hi_lo": pc, "p3_fp16_one_pass": pc16, "p4_fp16_hi_lo": pc16, "p5_fp16_hi_mx8_lo": pcmx}
+            pc16, pcmx, pcmx4 = ops.pack_conv(w, bias, dev, f16=True), ops.pack_conv(w, bias, dev, mx=True), ops.pack_conv(w, bias, dev, mx=2)
+            vprec = {"p2_bf16_hi_lo": 2, "p3_fp16_one_pass": 3, "p4_fp16_hi_lo": 4, "p5_fp16_hi_mx8_lo": 5, "p6_fp16_hi_mx4_lo": 6}
+            vpc = {"p2_bf16_hi_lo": pc, "p3_fp16_one_pass": pc16, "p4_fp16_hi_lo": pc16, "p5_fp16_hi_mx8_lo": pcmx, "p6_fp16_hi_mx4_lo": pcmx4}
         ld = ops.round_up(cin, 32)
         x = torch.randn((B, L, ld), generator=g, device=dev)
         y = torch.zeros((B, L, cout), device=dev)

@@ -179,6 +179,26 @@ def main(argv=None):
                                  "ms_per_launch": ms16,
                                  "fp32_kv_kernel": {"kernel": "flash_attn_kernel<64> (f32 MFMA)", "TFLOPs": fl / (ms32 * 1e-3) / 1e12, "ms_per_launch": ms32}}
 
+    # ---- whole-PHASE rooflines: the line's `roofline` is the phase that takes most of the step, priced on SURVEY section 8(d)'s
+    # figures, not on its best kernel; the per-kernel legs above stay as sub-fields
+    n_here = len(ch.my_items()) if D_.dist else B
+    enc_flop = 0.34e12 * n_here                                    # section 8(d): ~0.34 TFLOP per 30 s window (12 x [1500 x 7.08 M + 2 x 1500^2 x 768] MAC + convs)
+    ntl, nts, nv = dims.n_text_layer, dims.n_text_state, dims.n_vocab
+    w_bytes = 2.0 * (ntl * (6 * nts * nts + 2 * nts * 4 * nts) + nv * nts)                       # 16-bit decoder weights incl. the tied embedding (~0.28 GB)
+    ckv_bytes = 2.0 * ntl * n_here * dims.n_audio_ctx * nts * torch.empty(0, dtype=eng.kv_dtype).element_size()   # cross K | V of every window, every step
+    step_ms = dec_ms / args.decode_steps
+    phases = {
+        "encoder": {"bound": "mfma", "achieved": enc_flop / (enc_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": enc_flop / (enc_ms * 1e-3) / 1e12 / 2500.0,
+                    "ms": enc_ms, "algorithmic_flop": enc_flop, "what": "whole encoder phase (convs, 12 layers) of the step's windows; section 8(d): 0.34 TFLOP per window"},
+        "decode": {"bound": "hbm", "achieved": (w_bytes + ckv_bytes) / (step_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                   "frac": (w_bytes + ckv_bytes) / (step_ms * 1e-3) / 1e9 / 8000.0, "ms_per_token_step": step_ms, "algorithmic_bytes_per_token_step": w_bytes + ckv_bytes,
+                   "what": "whole decode token step: 16-bit decoder weights (%.0f MB) + the cross K | V of the step's windows (%.0f MB), every step" % (w_bytes / 1e6, ckv_bytes / 1e6)},
+    }
+    res["kernel_rooflines"] = {"decode_dominant_kernel": res.pop("roofline"), "logits_gemv": res.pop("logits_roofline", None), "encoder_attention": res.pop("attention_roofline")}
+    dom = "decode" if dec_ms >= enc_ms else "encoder"
+    res["roofline"] = dict(phases[dom], phase=dom, traffic=None, share_of_step=(dec_ms if dom == "decode" else enc_ms) / max(mel_ms + enc_ms + dec_ms, 1e-9))
+    res["phase_rooflines"] = phases
+
     if not args.no_cpu_baseline:
         from oracle.whisper_ref import WhisperRef
 

@@ -9,7 +9,7 @@ generated code of every conv_ws4_kernel<5, ...> instantiation:
   3. no VALU instruction writes an operand register (A, B, scale A, scale B) of a scaled MFMA in the two issue slots in front of it, unless an
      s_nop >= 1 stands between them.
 
-    python tools/check_mx_hazards.py            # compiles csrc/conv_ws4_p5.hip to assembly and audits it; exit code 1 on a finding
+    python tools/check_mx_hazards.py            # compiles csrc/conv_ws4_p5.hip and conv_ws4_p6.hip to assembly and audits it; exit code 1 on a finding
 Every instruction is counted as ONE wait state (an MFMA or a memory instruction occupies more), s_nop N as N + 1: conservative.
 """
 import os
@@ -19,7 +19,8 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "mlx_audio_amd", "csrc", "conv_ws4_p5.hip")
+SRCS = [os.path.join(ROOT, "mlx_audio_amd", "csrc", f) for f in ("conv_ws4_p5.hip", "conv_ws4_p6.hip")]   # e4m3 and FP4 lo passes
+FLAGS = ["-fno-slp-vectorize"]   # the production flags (mlx_audio_amd/build.py: COMMON_FLAGS)
 NEED = 19
 
 
@@ -35,7 +36,7 @@ def regs(tok):
 def parse(path):
     kernels, cur, name = {}, None, None
     for ln in open(path):
-        m = re.match(r"^(_ZN9mi355conv15conv_ws4_kernelILi5E\w+):", ln)
+        m = re.match(r"^(_ZN9mi355conv15conv_ws4_kernelILi[56]E\w+):", ln)
         if m:
             name, cur = m.group(1), []
             kernels[name] = cur
@@ -126,12 +127,14 @@ def audit(name, ins):
 
 
 def main():
+    kernels = {}
     with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "p5.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-S", "--cuda-device-only", SRC, "-o", out],
-                       check=True, stderr=subprocess.DEVNULL)
-        kernels = parse(out)
-    assert kernels, "no conv_ws4_kernel<5, ...> in the assembly"
+        for i, src in enumerate(SRCS):
+            out = os.path.join(td, f"p{i}.s")
+            subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *FLAGS, "-x", "hip", "-S", "--cuda-device-only", src, "-o", out],
+                           check=True, stderr=subprocess.DEVNULL)
+            kernels.update(parse(out))
+    assert any("ILi5E" in k for k in kernels) and any("ILi6E" in k for k in kernels), "no conv_ws4_kernel<5 / 6, ...> in the assembly"
     bad = []
     for name, ins in kernels.items():
         n = sum(1 for s in ins if s.startswith("v_mfma_scale"))
