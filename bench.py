@@ -41,10 +41,11 @@ def parse():
                     help="utterances per GPU per step (SURVEY 8d batch list: 1 / 8 / 64 / 512; 64 per GPU = 512 over the 8-GPU node; measured on one\n"
                          "MI355X: 122 M samples/s at 32, 140 M at 64, 146 M at 128, 150 M at 256 -- the front end's latency-bound LSTMs amortise)")
     ap.add_argument("--precision", type=int, default=None,
-                    help="default: the mode load_model() / KokoroEngine pick for a bf16 checkpoint (KokoroEngine.default_precision = 5: vocoder convs of >= 7 taps\n"
-                         "as fp16 hi pass + block-scaled e4m3 lo pass; 8.8e-5 of the peak / 85 dB on the canonical sentence x 64, tests/test_kokoro_gpu.py::\n"
-                         "test_kokoro_precision5_batch64_canonical).  2 = bf16 hi+lo split MFMA everywhere (3e-5), 3 = single fp16 pass in the vocoder (misses the\n"
-                         "2e-3 bar), 1 = single bf16 pass.  The default run also reports mode 2 as value_precision2")
+                    help="default: the mode load_model() / KokoroEngine pick for a bf16 checkpoint (KokoroEngine.default_precision = 6: vocoder convs of >= 7 taps\n"
+                         "as fp16 hi pass + block-scaled FP4 lo pass; parity at the benchmarked batch: tests/test_kokoro_gpu.py::\n"
+                         "test_kokoro_default_mode_batch64_canonical).  5 = the e4m3 lo pass of rounds 4 - 5 (7.9e-5 of the peak), 2 = bf16 hi+lo split MFMA\n"
+                         "everywhere (3e-5), 3 = single fp16 pass in the vocoder (misses the 2e-3 bar), 1 = single bf16 pass.  The default run also reports\n"
+                         "mode 2 as value_precision2")
     ap.add_argument("--no-secondary-precision", action="store_true", help="skip the value_precision2 leg")
     ap.add_argument("--no-batch-check", action="store_true", help="skip the batch-vs-single leg (a kernel trace of the run then holds the step's launches only)")
     ap.add_argument("--config", choices=["kokoro", "whisper", "qwen3", "csm", "kitten", "dsp"], default="kokoro",
@@ -170,6 +171,36 @@ def run_secondary(args):
     mod.main(argv)
 
 
+# sustained rates of the matrix pipe ALONE at this part's 1400 W cap (tools/src/mfma_peak.hip, 50 ms loops, random operands, two waves per SIMD:
+# profiles/r6_mfma_peak_fp4_call2.jsonl): what "100 % MFMA" buys on this box -- the 2.5 PFLOP/s dense figure needs 2.4 GHz, the cap allows ~1.7
+MFMA_SUSTAINED_TFLOPS = {"f16": 1777.0, "e4m3": 3886.0, "fp4": 6738.0}
+
+
+def power_cap_view(prof, conv_ms):
+    """The conv set against the matrix pipe's own sustained rates under the power cap: time the step's MFMA work would take with NOTHING else on the
+    chip (per conv: one 16-bit pass, + the lo pass of its mode: a second 16-bit pass for the bf16 / fp16 splits, the padded tap pairs at the e4m3 / FP4
+    rate for the MX convs = the >= 7-tap convs of >= 64 channels), and the share of the measured conv time that floor is."""
+    from mlx_audio_amd import ops
+
+    floor_ms, mode = 0.0, None
+    for fl, by, a0, a1, shp in prof:
+        cin, cout, k = shp[0], shp[1], shp[2]
+        hi = fl / (MFMA_SUSTAINED_TFLOPS["f16"] * 1e12)
+        if PRECISION_FOR_VIEW in (5, 6) and ops.mx_pays(cout, k, cin):
+            lo = fl * (2.0 * ((k + 1) // 2) / k) / (MFMA_SUSTAINED_TFLOPS["fp4" if PRECISION_FOR_VIEW == 6 else "e4m3"] * 1e12)
+        else:
+            lo = hi
+        floor_ms += (hi + lo) * 1e3
+    return {"mfma_only_floor_ms": floor_ms, "share_of_conv_time": floor_ms / max(conv_ms, 1e-9),
+            "sustained_tflops": MFMA_SUSTAINED_TFLOPS,
+            "what": "the conv set's matrix work at the pipe's measured sustained rates under the 1400 W cap (profiles/r6_mfma_peak_fp4_call2.jsonl) / measured conv time; "
+                    "the remainder is the energy of everything else -- weight fragments L2 -> registers, the producers' VALU work, HBM traffic, data toggling "
+                    "(profiles/r6_conv_ws4_p5_ablation_b64_call1.txt, r6_conv_energy_probe_call3.txt: each removal buys its share, the chip stays at 1390 W)"}
+
+
+PRECISION_FOR_VIEW = 2
+
+
 def pmc_traffic(args):
     """HBM bytes per conv launch from the PMC counters, measured in THIS run: two child passes of this same command (one step each) under
     ``rocprofv3 --kernel-trace --pmc FETCH_SIZE`` and ``... --pmc WRITE_SIZE`` (separate passes: the TCC block has 4 slots, the two counters
@@ -206,8 +237,16 @@ def pmc_traffic(args):
                 vals = [v for k, vs in per.items() if "conv_ws4_kernel" in k or "conv_gemm_kernel" in k for v in vs]
                 tot[ctr] = (sum(vals), len(vals))
                 if ctr in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):   # ... and of the dominant instantiation alone
-                    dom = [v for k, vs in per.items() if "conv_ws4_kernel<5, 2" in k or "conv_ws4_kernel<2, 2" in k for v in vs]
+                    domk = "conv_ws4_kernel<%d, 2" % (args.precision if args.precision in (5, 6) else 2)   # the Snake resblock convs of the mode
+                    dom = [v for k, vs in per.items() if domk in k for v in vs]
                     tot[ctr + "_dom"] = (sum(dom), len(dom))
+                    if ctr == "GRBM_GUI_ACTIVE":   # wall time of the same dispatches: GUI_ACTIVE / 8 XCDs / duration = the clock the chip ran them at
+                        import sqlite3
+
+                        cur = sqlite3.connect(dbs[0]).cursor()
+                        cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+                        ncol = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+                        tot["dom_ns"] = sum(r[1] - r[0] for r in cur.execute(f"select start, end, {ncol} from kernels") if domk in r[2])
         n = max(tot["FETCH_SIZE"][1], 1)
         res = {"bytes_per_launch": (2.0 * tot["FETCH_SIZE"][0] + tot["WRITE_SIZE"][0]) * 1024.0 / n, "launches_counted": n,
                "fetch_kb_total": tot["FETCH_SIZE"][0], "write_kb_total": tot["WRITE_SIZE"][0]}
@@ -217,6 +256,8 @@ def pmc_traffic(args):
         gd, bd = tot["GRBM_GUI_ACTIVE_dom"][0], tot["SQ_VALU_MFMA_BUSY_CYCLES_dom"][0]
         if gd > 0:
             res["mfma_busy_frac_dominant"] = bd / (gd / 8.0 * 1024.0)
+            if tot.get("dom_ns", 0) > 0:
+                res["clock_ghz_dominant"] = gd / 8.0 / tot["dom_ns"]
         # the child ran warm-up + timed step = 2 steps; every counter saw the same launches
         return res
     except Exception:
@@ -279,6 +320,8 @@ def main():
 
         eng = KokoroEngine(S.make_kokoro_weights(), S.KOKORO_CONFIG, device=dev, precision=args.precision)
     args.precision = eng.precision   # None -> the engine's own default (KokoroEngine.default_precision): what load_model() users get
+    global PRECISION_FOR_VIEW
+    PRECISION_FOR_VIEW = args.precision
     B = args.batch
     n_total = B * world
     # requests (token ids) are owned by rank 0 and cross ranks inside the step (one broadcast); voice rows, forced durations and SineGen noise
@@ -472,8 +515,13 @@ def main():
             "frac": flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
             "mfma_busy_frac": pmc.get("mfma_busy_frac") if pmc else None,
             "mfma_busy_frac_dominant_kernel": pmc.get("mfma_busy_frac_dominant") if pmc else None,
+            "clock_ghz_dominant_kernel": pmc.get("clock_ghz_dominant") if pmc else None,
             "mfma_busy_note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) over the conv launches of a third in-run rocprofv3 pass: the share of "
-                              "SIMD-cycles with the matrix pipe busy, at the clock the chip actually ran (DVFS); dominant = conv_ws4_kernel<5, 2, ...> / <2, 2, ...>",
+                              "SIMD-cycles with the matrix pipe busy, at the clock the chip actually ran (DVFS: clock_ghz_dominant_kernel = GRBM_GUI_ACTIVE / 8 / "
+                              "duration; the part sits at its 1400 W cap under these kernels, profiles/r6_smi_power_clock_during_conv_call1.txt); dominant = "
+                              "conv_ws4_kernel<mode, 2, ...> (the Snake resblock convs).  An FP4 lo MFMA occupies the pipe half as long as the e4m3 one it replaced: "
+                              "mode 6 LOWERS this fraction while it raises the rate",
+            "power_cap_view": power_cap_view(prof, ms),
             "traffic_note": "avg HBM bytes per conv launch measured in this run: (2*FETCH_SIZE + WRITE_SIZE)*1024 over %s launches of two rocprofv3 PMC "
                             "child passes; algorithmic avg = %.3e B per launch (inputs + outputs + residual / accumulate reads + weights, each once)" % (
                                 pmc["launches_counted"] if pmc else "no", byts / max(1, len(prof))),
@@ -482,7 +530,12 @@ def main():
             "launches_per_step": len(prof), "algorithmic_gflop_per_step": flops / 1e9,
             "conv_gemm_ms_per_step": ms, "instrumented_step_ms": e0.elapsed_time(e1),
             "hbm_view": {"algorithmic_GB_per_step": byts / 1e9, "achieved_GBps": byts / (ms * 1e-3) / 1e9,
-                         "peak_GBps": HBM_PEAK_GBS, "frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "peak_GBps": HBM_PEAK_GBS, "frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         # SURVEY section 8(d)'s own count beside it (bf16 activations, each conv's input + output once, 96.8 MB of weights once per step):
+                         # 3 746 B per output sample and utterance -- the line's count above is 2.6x that: fp32 activations + the residual / running-sum reads
+                         "survey_8d_GB_per_step": (3746.0 * sum(f_of) * 600 + 96.8e6) / 1e9,
+                         "frac_on_survey_8d_bytes": (3746.0 * sum(f_of) * 600 + 96.8e6) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "measured_GB_per_step": (traffic * len(prof) / 1e9) if traffic else None},
             "note": "intensity of the conv stack AS RUN (fp32 activations in HBM: flops / algorithmic bytes of this line = %.0f FLOP/B) is BELOW the bf16 ridge "
                     "(2500 TF/s / 8 TB/s = 312 FLOP/B): the k = 3 convs sit on the HBM side (2.8-4.0 TB/s of their bytes), the k >= 7 convs on the MFMA / issue "
                     "side; `frac` prices the whole set against MFMA, `hbm_view` against HBM (DESIGN.md section 6)" % (flops / max(byts, 1.0)),

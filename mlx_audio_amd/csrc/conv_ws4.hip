@@ -77,7 +77,7 @@ int mi355_conv_ws4_launch(const mi355_conv_gemm_args& a, hipStream_t st, int fea
   if (a.pre_fq) rc = a.precision == 2 ? mi355_conv_ws4_fq(a, st, feat & 3, bn) : MI355_ERR_UNSUPPORTED;
   else if (a.precision == 2) rc = mi355_conv_ws4_p2(a, st, feat, g_dbg_buffer, bn);
   else if (a.precision == 4) rc = mi355_conv_ws4_p4(a, st, feat & 3, bn);
-  else if (a.precision == 6) rc = mi355_conv_ws4_p6(a, st, feat & 9, bn);
+  else if (a.precision == 6) rc = (feat & ~9) ? mi355_conv_ws4_p5_probe(a, st, feat, g_dbg_buffer) : mi355_conv_ws4_p6(a, st, feat & 9, bn);
   else if (a.precision == 5) rc = (feat & ~11) ? mi355_conv_ws4_p5_probe(a, st, feat, g_dbg_buffer) : mi355_conv_ws4_p5(a, st, feat & 11, bn);
   else if (a.precision == 1 || a.precision == 3) rc = mi355_conv_ws4_p13(a, st, feat & 3, bn);
   if (rc == MI355_ERR_UNSUPPORTED)

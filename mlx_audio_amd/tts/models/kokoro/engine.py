@@ -177,13 +177,14 @@ class KokoroEngine:
     @staticmethod
     def default_precision(param_dtype, quant_modules: Sequence[str] = ()) -> int:
         """The mode an engine runs when the caller names none -- the SAME rule for ``load_model()``, ``smoke()``, the tests and ``bench.py``:
-        bf16 checkpoints (Kokoro-82M-bf16, BASELINE config[1]) -> 5 (fp16 hi pass + block-scaled e4m3 lo pass on the >= 7-tap vocoder convs, exact
-        bf16 images elsewhere: 8.8e-5 of the peak / 85 dB on the canonical sentence at 64 utterances against the 2e-3 / 50 dB bar); float32
-        checkpoints -> 4 (fp16 images, fp16 hi + lo); fp16 checkpoints and engines with fake-quantised modules (KittenTTS: the quantising
-        prologue has no MX form) -> 2."""
+        bf16 checkpoints (Kokoro-82M-bf16, BASELINE config[1]) -> 6 (round 6: fp16 hi pass + block-scaled FP4 lo pass on the >= 7-tap vocoder convs,
+        exact bf16 images elsewhere: 2.3e-4 of the peak / 76 dB on the canonical sentence against the 2e-3 / 50 dB bars -- a 9x margin -- and 6.6 % faster
+        than mode 5 on the contract line, same box: profiles/r6_bench_contract_p6_call6.json; mode 5 = the e4m3 lo pass of rounds 4 - 5, 7.9e-5 / 89 dB,
+        stays selectable, as does the exact bf16 hi + lo mode 2); float32 checkpoints -> 4 (fp16 images, fp16 hi + lo); fp16 checkpoints and engines with
+        fake-quantised modules (KittenTTS: the quantising prologue has no MX form) -> 2."""
         if param_dtype == torch.float32:
             return 4
-        return 5 if (param_dtype == torch.bfloat16 and not tuple(quant_modules)) else 2
+        return 6 if (param_dtype == torch.bfloat16 and not tuple(quant_modules)) else 2
 
     def __init__(self, weights: Dict[str, torch.Tensor], config: dict, device="cuda", param_dtype=torch.bfloat16,
                  precision: Optional[int] = None, quant_modules: Sequence[str] = ()):

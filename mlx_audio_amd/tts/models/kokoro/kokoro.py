@@ -127,7 +127,7 @@ class Model:
         pdt = torch.bfloat16 if torch.bfloat16 in dtypes else (torch.float16 if torch.float16 in dtypes else torch.float32)
         cfg = self.config if isinstance(self.config, dict) else self.config.__dict__
         try:
-            # one rule for every entry point (KokoroEngine.default_precision): bf16 checkpoints -> 5 (the benchmarked mode), fp16 -> 2 (held exactly
+            # one rule for every entry point (KokoroEngine.default_precision): bf16 checkpoints -> 6 (the benchmarked mode), fp16 -> 2 (held exactly
             # by the bf16 hi + lo images), float32 -> 4 (fp16 weight images + fp16 hi / lo activations), unless the caller chose a mode
             prec = self.precision if self.precision is not None else KokoroEngine.default_precision(pdt)
             self.engine = KokoroEngine({k: v.to(torch.float32) for k, v in w.items()}, cfg, device=self.device,

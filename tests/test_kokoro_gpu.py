@@ -202,7 +202,10 @@ def test_kokoro_batch_equals_single(setup):
     workgroups), and the variants add in different orders; the ~1e-7 relative differences per layer reach 2e-5 of the waveform peak at the output
     (measured 1.7e-5).  The comparison is FREE-RUNNING (F0 is not injected), so it also depends on no harmonic phase feature sitting at its +-pi wrap
     for these inputs: a change of the split grouping moved F0 by 5e-6 relative and wrapped one (round 4, tools/diag_batch_single.py) -- the failure
-    mode to look for first when this test breaks after a kernel-selection change."""
+    mode to look for first when this test breaks after a kernel-selection change.
+    Mode 6 (the default since round 6): the batch's stage-1 launches reach 128 tiles and take the FP4 lo pass while a lone utterance's stay on the 4-wave
+    kernels (fp16 hi + fp16 lo on the same image: MORE exact), so the two differ by the FP4 lo pass's own error -- measured 9.2e-5 of the peak; the bar
+    is 4e-4 there (the mode's error against the oracle is 2.3e-4, bar 2e-3).  The exact modes keep 5e-5."""
     S, eng, _ = setup
     voice = S.make_voice_pack()
     idl = [S.make_phoneme_ids(n, seed=10 + n) for n in (12, 25, 7)]
@@ -221,7 +224,7 @@ def test_kokoro_batch_equals_single(setup):
         torch.cuda.synchronize()
         assert outs[b].shape == o1[0].shape
         d = float((outs[b] - o1[0]).abs().max())
-        assert d <= 5e-5 * float(o1[0].abs().max() + 1), (b, d)
+        assert d <= (4e-4 if eng.precision == 6 else 5e-5) * float(o1[0].abs().max() + 1), (b, d)
 
 
 def test_kokoro_single_pass_bf16_precision_mode(setup):
@@ -286,8 +289,8 @@ def test_kokoro_precision5_mx_lo_pass_mode(setup):
     S, eng, ref = setup
     from mlx_audio_amd.tts.models.kokoro.engine import KokoroEngine
 
-    assert eng.precision == 5, "the engine default for a bf16 checkpoint is the benchmarked mode (KokoroEngine.default_precision)"
-    eng5 = eng
+    assert eng.precision == KokoroEngine.default_precision(torch.bfloat16) == 6, "the engine default for a bf16 checkpoint is the benchmarked mode (KokoroEngine.default_precision)"
+    eng5 = KokoroEngine(S.make_kokoro_weights(), S.KOKORO_CONFIG, precision=5)
     eng2 = KokoroEngine(S.make_kokoro_weights(), S.KOKORO_CONFIG, precision=2)
     ids = S.make_phoneme_ids(18, seed=5)
     ref_s = S.make_voice_pack()[len(ids) - 3]
@@ -363,16 +366,16 @@ def test_kokoro_precision6_fp4_lo_pass_mode(setup):
         assert worst_err <= 2e-3 * peak and worst_snr >= 50.0, (nb, worst_err, worst_snr)
 
 
-def test_kokoro_precision5_batch64_canonical(setup):
+def test_kokoro_default_mode_batch64_canonical(setup):
     """The BENCHMARKED configuration is the parity-tested one: 64 canonical utterances (T = 80, F = 264) through bench.py's exact call path --
-    ``shard.kokoro_step`` on a ``ShardChannel`` (world 1), the engine in its default mode (5 for a bf16 checkpoint), ``back_kwargs`` carrying the
+    ``shard.kokoro_step`` on a ``ShardChannel`` (world 1), the engine in its default mode (6 for a bf16 checkpoint since round 6), ``back_kwargs`` carrying the
     SineGen inputs -- teacher-forced on the oracle's F0 / N / harmonic features, EVERY one of the 64 waveforms against the fp32 oracle at the
     2e-3 * peak / 50 dB bars.  At this launch size the generator runs conv_ws4_kernel<5, 2, ...> x 36, <2, 2> x 12, <2, 1> x 21 per pass
     (profiles/r4_kernel_stats_b64_call21.txt): a different instantiation mix from the 4-utterance test above."""
     S, eng, ref = setup
     from mlx_audio_amd import shard
 
-    assert eng.precision == 5
+    assert eng.precision == 6   # KokoroEngine.default_precision for a bf16 checkpoint (round 6: the FP4 lo pass)
     nb = 64
     ids = S.make_phoneme_ids(78)
     voice = S.make_voice_pack()
@@ -395,7 +398,7 @@ def test_kokoro_precision5_batch64_canonical(setup):
     got = torch.stack([o.cpu() for o in outs])
     err = (got - audio_ref[0][None]).abs().amax(dim=1)
     snrs = [snr_db(got[b], audio_ref[0]) for b in range(nb)]
-    print(f"kokoro default mode (5), canonical sentence x {nb} through shard.kokoro_step: peak={peak:.3f} worst max_abs_err={float(err.max()):.3e} "
+    print(f"kokoro default mode ({eng.precision}), canonical sentence x {nb} through shard.kokoro_step: peak={peak:.3f} worst max_abs_err={float(err.max()):.3e} "
           f"({float(err.max()) / peak:.2e} of peak) worst snr={min(snrs):.1f} dB; spread over the batch {float((got - got[0:1]).abs().max()):.2e}")
     assert float(err.max()) <= 2e-3 * peak and min(snrs) >= 50.0, (float(err.max()), min(snrs))
 

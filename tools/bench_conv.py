@@ -55,10 +55,12 @@ def main():
         W = 6128128
         variants = [("ws4", W), ("abl1_noBload", 100000000 + W), ("abl2_noAread", 200000000 + W), ("abl3_noAB", 300000000 + W),
                     ("abl4_noProducer", 400000000 + W), ("abl7_noABP", 700000000 + W)]
-        if args.precision == 5:
+        if args.precision in (5, 6):
             shapes = [(128, 128, 11, 1, 31681, "snake+res"), (128, 128, 7, 1, 31681, "snake+res"), (128, 128, 11, 5, 31681, "snake"), (256, 256, 11, 1, 5280, "snake+res")]
             shapes += [(128, 128, 11, 3, 31681, "snake"), (128, 128, 7, 5, 31681, "snake"), (256, 256, 7, 1, 5280, "snake+res"), (256, 256, 11, 5, 5280, "snake")]
             variants = [("ws4", W), ("ws4_2x2", 20000000 + W), ("abl1_noBload", 100000000 + W), ("abl4_noProducer", 400000000 + W), ("abl5_noBload_noProducer", 500000000 + W)]
+            if args.precision == 6:
+                variants = [v for v in variants if v[0] != "ws4_2x2"]   # the FP4 lo pass exists in the column-wave layout only
     if args.small:
         shapes = [(768, 2304, 1, 1, 80, "plain"), (768, 768, 1, 1, 80, "plain"), (768, 2048, 1, 1, 80, "plain"), (2048, 768, 1, 1, 80, "plain"),
                   (640, 2048, 1, 1, 264, "plain"), (1090, 1024, 3, 1, 264, "leaky"), (1024, 1024, 3, 1, 264, "leaky"), (512, 512, 3, 1, 528, "leaky"),

@@ -34,9 +34,9 @@ def main():
     for cin, cout, k, dil, L, res_on in ((128, 128, 11, 1, 31681, True), (128, 128, 11, 5, 31681, False), (128, 128, 3, 1, 31681, True),
                                          (128, 128, 7, 1, 31681, True), (256, 256, 7, 1, 5280, True)):
         w = (torch.randn(cout, k, cin) / math.sqrt(k * cin)).to(torch.bfloat16).float()
-        if args.precision == 5 and k % 4 != 3:
+        if args.precision in (5, 6) and k % 4 != 3:
             continue
-        pc = ops.pack_conv(w, torch.randn(cout) * 0.1, dev, mx=args.precision == 5)
+        pc = ops.pack_conv(w, torch.randn(cout) * 0.1, dev, mx=(args.precision - 4) if args.precision in (5, 6) else 0)
         x = torch.randn((B, L, cin), generator=g, device=dev)
         y = torch.zeros((B, L, cout), device=dev)
         sc = torch.rand((B, cin), generator=g, device=dev) + 0.5
@@ -66,7 +66,7 @@ def main():
         ghz = float(np.median((t[okc, 7, 0] - t[okc, 0, 0]) / ((wc[okc, 1] - wc[okc, 0]) * 10.0))) if okc.any() else float("nan")  # [workgroup, tile, (start, window staged, main loop done, stores issued)]
         t = t[t[:, 0, 0] > 0]
         nch = (cin + 31) // 32
-        mfma_cyc = k * 16 * 32 * nch if args.precision != 5 else (k * 8 * 32 + ((k + 1) // 2) * 4 * 64) * nch
+        mfma_cyc = k * 16 * 32 * nch if args.precision not in (5, 6) else (k * 8 * 32 + ((k + 1) // 2) * 4 * (64 if args.precision == 5 else 32)) * nch
         med = lambda v: float(np.median(v))
         lines.append(f"## cin={cin} cout={cout} k={k} dil={dil} rows={B * L} res={int(res_on)}: kernel {ms_plain * 1e3:.1f} us (probe build {ms * 1e3:.1f} us), grid {grid}, "
                      f"{len(t)} probed workgroups, shader clock {ghz:.2f} GHz (s_memtime ticks per wall_clock64 tick); one consumer wave issues {mfma_cyc} MFMA pipe cycles per tile (2 waves share a SIMD: {2 * mfma_cyc})")
