@@ -2,7 +2,10 @@
 """One period of a dependent launch chain from a rocprofv3 rocpd database: the dispatches between two consecutive occurrences of a marker kernel, in start
 order, each with its duration and the idle gap in front of it -- says whether a decode frame is made of kernel time or of gaps, and what it is made of.
 
-    python tools/rocpd_timeline.py DB marker-substring [occurrence-from-the-end=3] [--list] > profiles/<name>.txt
+    python tools/rocpd_timeline.py DB marker-substring [occurrence-from-the-end=3] [--span=N] [--list] > profiles/<name>.txt
+
+--from-start=I: the period starts at the I-th marker occurrence counted from the START of the trace (default: counted back from the end).
+--span=N: the marker fires N times per period (Qwen3-TTS: 16 sampling launches per frame, CSM: 32): the period is N marker occurrences long.
 """
 import collections
 import re
@@ -22,6 +25,7 @@ def main():
     db = sqlite3.connect(args[0])
     marker = args[1]
     back = int(args[2]) if len(args) > 2 else 3
+    span = max([int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--span=")] + [1])
     cur = db.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
@@ -29,12 +33,16 @@ def main():
     gsel = gcol[0] if gcol else "0"
     rows = cur.execute(f"select {name_col}, {gsel}, start, end from kernels order by start").fetchall()
     marks = [i for i, r in enumerate(rows) if marker in r[0]]
-    if len(marks) < back + 1:
+    if len(marks) < back + span:
         print(f"# only {len(marks)} launches match {marker!r}")
         return
     # the marker may fire several times per period (e.g. once per code group): a period = the span between marker occurrences `back * per` apart is
     # left to the caller -- here: from the marker `back + 1` from the end to the one `back` from the end
-    a, b = marks[-back - 1], marks[-back]
+    first = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--from-start=")]
+    if first and first[0] + span < len(marks):
+        a, b = marks[first[0]], marks[first[0] + span]
+    else:
+        a, b = marks[-back - span], marks[-back]
     seg = rows[a + 1:b + 1]
     t0 = rows[a][3]
     busy = sum(r[3] - r[2] for r in seg)
