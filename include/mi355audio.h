@@ -152,6 +152,16 @@ typedef struct {
      satisfy mi355_conv_gemm_ext_supported and then always runs on that kernel. */
   float* ext_partial;     /* nullable; [B, ceil(Lout / MI355_STATS_ROWS), Cout, 2] */
   int64_t ext_bstride;    /* elements between batch items */
+  /* pre-split activations (round 6, ABI 35): the wide linears of the transformer encoders (Whisper: 768 -> 768 / 2304 / 3072 at 96 000 rows) are bound
+     by the producers' fp32 -> hi + lo conversion, which every one of the C_out / 128 column tiles of a row tile repeats
+     (profiles/r6_conv_big_gemm_b64_call11.txt).  A SPLIT tensor has the layout of the fp32 tensor it replaces, each 32-bit word holding the 16-bit hi
+     part of the value (bits 0-15) and the 16-bit lo residual (bits 16-31) in the type of the launch's precision (2: bfloat16, 4: IEEE half) -- exactly
+     the two numbers the fp32 path's prologue would have produced, so both paths give the same bits.  x_split = 2 / 4: x holds split words (same
+     strides; must equal `precision`; no prologue; wave-specialised kernel only: 16-byte aligned rows).  y_split = 2 / 4: the epilogue stores split
+     words of its result instead of floats (for the launch that consumes y; res / accumulate / statistics still work on the float value).  Producers
+     other than a conv epilogue: mi355_split16 (elementwise), mi355_layernorm (split field). */
+  int32_t x_split;
+  int32_t y_split;
 } mi355_conv_gemm_args;
 #define MI355_STATS_ROWS 64
 
@@ -227,8 +237,12 @@ typedef struct {
   float eps;
   int32_t post_act; float post_slope;
   float* y; int64_t y_bstride; int32_t ldy;
+  int32_t y_split;   /* 0, or 2 / 4: y receives SPLIT words (mi355_conv_gemm_args.x_split of the linear that consumes it) instead of floats (ABI 35) */
 } mi355_layernorm_args;
 int mi355_layernorm(const mi355_layernorm_args* a, void* stream);
+/* Elementwise fp32 -> SPLIT words (x_split of mi355_conv_gemm_args; fmt 2 = bfloat16 hi | lo << 16, 4 = IEEE half) over n contiguous values, n a
+ * multiple of 4, both pointers 16-byte aligned; y may alias x.  For activations no conv epilogue / LayerNorm produces (attention outputs). */
+int mi355_split16(const float* x, void* y, int64_t n, int32_t fmt, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Bidirectional LSTM recurrence (the x-projection is a conv_gemm).

@@ -57,6 +57,20 @@ __device__ __forceinline__ uint32_t pack_f16x2(float a, float b) {
   return (uint32_t)__builtin_bit_cast(uint16_t, ha) | ((uint32_t)__builtin_bit_cast(uint16_t, hb) << 16);
 }
 
+// fp32 -> SPLIT word (include/mi355audio.h: x_split / y_split): the 16-bit hi part in bits 0-15 and the 16-bit lo residual in bits 16-31, in IEEE half
+// (fmt 4; the value clamped to +-65504 first) or bfloat16 (fmt 2) -- the two numbers the conv prologue of that precision makes of the value
+__device__ __forceinline__ uint32_t split16_word(float v, int fmt) {
+  if (fmt == 4) {
+    const float c = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+    const _Float16 h = (_Float16)c;
+    const _Float16 l = (_Float16)(c - (float)h);
+    return (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
+  }
+  const uint16_t h = f32_to_bf16_bits(v);
+  const uint16_t l = f32_to_bf16_bits(v - bf16_bits_to_f32(h));
+  return (uint32_t)h | ((uint32_t)l << 16);
+}
+
 // host: fp32 -> IEEE binary16 bits, round-to-nearest-even, saturating to the largest finite value
 static inline uint16_t host_f32_to_f16(float f) {
   uint32_t u;

@@ -182,7 +182,10 @@ __device__ __forceinline__ void conv_epilogue(const mi355_conv_gemm_args& a, f32
             v = gelu_tanh(v);
           }
           v = (v * cscale + rv[q]) * a.out_scale;
-          if (ok[q]) yb[(int64_t)orows[q] * a.ldy + ocol] = v;
+          if (ok[q]) {
+            if (a.y_split) ((uint32_t*)yb)[(int64_t)orows[q] * a.ldy + ocol] = split16_word(v, a.y_split);   // for the launch that consumes y (x_split)
+            else yb[(int64_t)orows[q] * a.ldy + ocol] = v;
+          }
           if (want_stats && ok[q]) {
             sK[nf] = scnt[nf] == 0 ? v : sK[nf];
             const float d = v - sK[nf];

@@ -634,6 +634,20 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
   }
   int tile = a.tile;
   t_mx_lo_slices = 0;
+  if (a.y_split) {
+    MI355_REQUIRE(a.y_split == 2 || a.y_split == 4, "conv_gemm: y_split must be 0, 2 (bfloat16 hi | lo) or 4 (IEEE half hi | lo)");
+    MI355_REQUIRE(!a.accumulate, "conv_gemm: y_split cannot accumulate into y (y holds split words)");
+    a.split_ws = nullptr;   // (the split-K finish kernel stores floats)
+  }
+  if (a.x_split) {   // pre-split activations: the wave-specialised kernel's producers only (whatever the tile count)
+    MI355_REQUIRE(a.x_split == a.precision && (a.precision == 2 || a.precision == 4), "conv_gemm: x_split must equal the launch's precision, 2 or 4");
+    MI355_REQUIRE(a.pre_act == MI355_ACT_NONE && !a.pre_scale && !a.pre_fq, "conv_gemm: a split input takes no prologue");
+    MI355_REQUIRE(!a.ext_partial && mi355_conv_ws4_eligible(a, vec), "conv_gemm: x_split needs 16-byte aligned channels-last rows and a window of <= 192 rows "
+                  "(the wave-specialised kernel)");
+    static const int ws_feat_x = getenv("MI355_CONV_WS_FEAT") ? atoi(getenv("MI355_CONV_WS_FEAT")) : 0;
+    const int rc = a.Cout <= 64 ? mi355_conv_ws4_launch(a, st, ws_feat_x & 3, 64) : mi355_conv_ws4_launch(a, st, tile % 10000000 == 6128128 ? ((tile / 10000000) % 10) : ws_feat_x);
+    return rc;
+  }
   if (a.ext_partial) {   // per-block extrema: only the quantising instantiations of the wave-specialised kernel write them -- no other path may take the launch
     MI355_REQUIRE(conv_ext_supported(a), "conv_gemm: ext_partial needs a launch mi355_conv_gemm_ext_supported accepts (pre_fq, precision 2, plain store, K > 1)");
     MI355_REQUIRE(a.ext_bstride % 2 == 0 && ((uintptr_t)a.ext_partial) % 8 == 0, "conv_gemm: ext_partial must be 8-byte aligned");

@@ -226,6 +226,9 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
           fk[j] = fq_load_coef(a.pre_scale, a.pre_shift, (int64_t)b * a.pre_ld, PRE == P_SNAKE ? MI355_ACT_SNAKE : MI355_ACT_NONE, a.pre_alpha, c + j);
       }
       const bool chan[4] = {c < a.Cin, c + 1 < a.Cin, c + 2 < a.Cin, c + 3 < a.Cin};   // conv mode: the lane's four channels are the same in every pass
+      // a.x_split (wave-uniform): x holds SPLIT words -- hi | lo << 16 of every value, produced once by the layer in front (a conv epilogue, LayerNorm,
+      // mi355_split16) -- so the conversion the C_out / 128 column tiles of a row tile would each repeat is two v_perm_b32 per pair of values
+      const bool xs = PRE == P_NONE && NA == 2 && !FQ && !MXP && a.x_split != 0;
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
         if (GEMM || wrow0 + i * 32 < R) {
@@ -235,6 +238,22 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
             const bool rowok = gl >= 0 && gl < len_in;
             const int cb = c + (GEMM ? 32 * (i >> 2) : 0);
             const float v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
+            if constexpr (PRE == P_NONE && NA == 2 && !FQ && !MXP) {
+              if (xs) {
+                uint32_t w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = (rowok && (cb + j) < a.Cin) ? __builtin_bit_cast(uint32_t, v[j]) : 0u;
+                const int xaddr = r * 64 + ((((c4 >> 3) ^ ((r >> 2) & 3))) << 4) + ((c4 & 4) << 1);
+                uint2 xh, xl;   // v_perm_b32: selector bytes 0-3 pick from the second operand, 4-7 from the first
+                xh.x = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u);
+                xh.y = __builtin_amdgcn_perm(w[3], w[2], 0x05040100u);
+                xl.x = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u);
+                xl.y = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
+                *(uint2*)(A_hi + xaddr) = xh;
+                *(uint2*)(A_lo + xaddr) = xl;
+                continue;
+              }
+            }
             float tt[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -271,12 +290,16 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
             const int addr = MXP ? r * HP + c4 * 2 : r * 64 + ((((c4 >> 3) ^ ((r >> 2) & 3))) << 4) + ((c4 & 4) << 1);
             uint2 ph;
             float hi[4];
-            if constexpr (MXP) {  // v_cvt_pk_f16_f32 on the clamped value, v_cvt_f32_f16 back
+            if constexpr (MXP || PREC == 4) {  // v_cvt_pk_f16_f32 on the clamped value, v_cvt_f32_f16 back
               typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
               typedef float f2_t __attribute__((ext_vector_type(2)));
               float cl[4];
 #pragma unroll
               for (int j = 0; j < 4; ++j) cl[j] = __builtin_amdgcn_fmed3f(tt[j], -65504.f, 65504.f);   // one v_med3_f32 instead of min + max
+              if constexpr (PREC == 4) {   // the lo image is the residual of the CLAMPED value: finite for every input (a value beyond fp16's range is wrong either way)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tt[j] = cl[j];
+              }
               const h2_t ha = __builtin_convertvector((f2_t){cl[0], cl[1]}, h2_t), hb = __builtin_convertvector((f2_t){cl[2], cl[3]}, h2_t);
               ph.x = __builtin_bit_cast(uint32_t, ha);
               ph.y = __builtin_bit_cast(uint32_t, hb);
@@ -295,7 +318,22 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
               hi[3] = __builtin_bit_cast(float, ph.y & 0xffff0000u);
             }
             *(uint2*)(A_hi + addr) = ph;
-            if constexpr (NA == 2) {
+            if constexpr (PREC == 4) {
+              // lo = t - fp16(t) as ONE v_fma_mix_f32 per element (the half operand read in place, see the MX branch below: the product is exact, so
+              // this is the subtraction's single rounding), two elements per v_cvt_pk_f16_f32: 12 VALU operations per four elements instead of ~24
+              // (round 6: the wide linears are bound by this conversion -- profiles/r6_conv_big_gemm_b64_call11.txt)
+              typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+              typedef float f2_t __attribute__((ext_vector_type(2)));
+              float l0, l1, l2, l3;
+              asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(ph.x), "v"(tt[0]));
+              asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(ph.x), "v"(tt[1]));
+              asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l2) : "v"(ph.y), "v"(tt[2]));
+              asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l3) : "v"(ph.y), "v"(tt[3]));
+              uint2 pl;
+              pl.x = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2_t){l0, l1}, h2_t));
+              pl.y = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2_t){l2, l3}, h2_t));
+              *(uint2*)(A_lo + addr) = pl;
+            } else if constexpr (NA == 2) {
               uint2 pl;
               pl.x = pack_lo<PREC>(tt[0] - hi[0], tt[1] - hi[1]);
               pl.y = pack_lo<PREC>(tt[2] - hi[2], tt[3] - hi[3]);
@@ -1030,7 +1068,7 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
       if (tsum == 1.2345e-30f) yb[0] = tsum;  // keeps the MFMAs alive without an epilogue
       continue;
     }
-    const bool plain = a.up_s == 0 && a.post_act == MI355_ACT_NONE && (fold || (!a.res && !a.accumulate)) && !a.post_colscale;
+    const bool plain = a.up_s == 0 && a.post_act == MI355_ACT_NONE && (fold || (!a.res && !a.accumulate)) && !a.post_colscale && !a.y_split;
     if constexpr (COLW) {
       // a column wave holds two 64-row statistics blocks: the epilogue of the 2 x 2 layout, once per half (accumulators 2 h, 2 h + 1 as its block h)
       if (plain && interior) {

@@ -40,7 +40,14 @@ int mi355_conv_ws4_p2(const mi355_conv_gemm_args& a, hipStream_t st, int feat, u
   const bool gemm = gemm_mode(a);
   if (bn == 128 && (feat & 4) && pre == P_SNAKE && epi == 0 && !gemm) return launch_ws4<2, P_SNAKE, 0, false, true>(a, st, feat, dbg);
   if (const int abl = bn == 128 ? feat >> 4 : 0) {  // timing ablations (wrong results by design)
-    MI355_REQUIRE(pre == P_SNAKE && epi == 0 && !gemm, "conv_gemm(ws4): ablation tiles exist for the precision-2 Snake kernel only");
+    if (gemm && epi == 0) {   // GEMM mode (round 6: what bounds the wide linears)
+      switch (abl) {
+        case 1: return launch_ws4<2, P_NONE, 0, true, false, 1>(a, st, feat & 15);
+        case 4: return launch_ws4<2, P_NONE, 0, true, false, 4>(a, st, feat & 15);
+        case 5: return launch_ws4<2, P_NONE, 0, true, false, 5>(a, st, feat & 15);
+      }
+    }
+    MI355_REQUIRE(pre == P_SNAKE && epi == 0 && !gemm, "conv_gemm(ws4): ablation tiles exist for the precision-2 Snake kernel and the plain GEMM mode only");
     switch (abl) {
       case 1: return launch_ws4<2, P_SNAKE, 0, false, false, 1>(a, st, feat & 15);
       case 2: return launch_ws4<2, P_SNAKE, 0, false, false, 2>(a, st, feat & 15);

@@ -206,12 +206,32 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const mi355_layernorm_ar
         if (a.post_act == MI355_ACT_LEAKY) t = t > 0.f ? t : t * a.post_slope;
         o[j] = t;
       }
-      *(float4*)(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
+      if (a.y_split) *(uint4*)(yr + c) = make_uint4(split16_word(o[0], a.y_split), split16_word(o[1], a.y_split), split16_word(o[2], a.y_split), split16_word(o[3], a.y_split));
+      else *(float4*)(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
     }
   }
 }
 
+__global__ __launch_bounds__(256) void split16_kernel(const float* __restrict__ x, uint32_t* __restrict__ y, const int64_t n4, const int fmt) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 t = ((const float4*)x)[i];
+    ((uint4*)y)[i] = make_uint4(split16_word(t.x, fmt), split16_word(t.y, fmt), split16_word(t.z, fmt), split16_word(t.w, fmt));
+  }
+}
+
 }  // namespace
+
+extern "C" int mi355_split16(const float* x, void* y, int64_t n, int32_t fmt, void* stream) {
+  MI355_REQUIRE(x && y && n > 0, "split16: null tensor / empty");
+  MI355_REQUIRE(fmt == 2 || fmt == 4, "split16: fmt must be 2 (bfloat16) or 4 (IEEE half)");
+  MI355_REQUIRE(n % 4 == 0 && ((uintptr_t)x) % 16 == 0 && ((uintptr_t)y) % 16 == 0, "split16: n must be a multiple of 4 and the pointers 16-byte aligned");
+  const int64_t n4 = n / 4;
+  const unsigned grid = (unsigned)(n4 + 255) / 256 > 8192u ? 8192u : (unsigned)((n4 + 255) / 256);
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(split16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (uint32_t*)y, n4, (int)fmt);
+  MI355_LAUNCH_CHECK("split16");
+  return MI355_OK;
+}
 
 extern "C" int mi355_adain_coef(const mi355_adain_coef_args* ap, void* stream) {
   MI355_REQUIRE(ap && ap->x && ap->sums && ap->scale && ap->shift, "adain_coef: null tensor");
@@ -259,6 +279,7 @@ extern "C" int mi355_layernorm(const mi355_layernorm_args* ap, void* stream) {
   MI355_REQUIRE(a.C > 0 && a.C <= 1024 && a.C % 4 == 0, "layernorm: C must be a multiple of 4 and <= 1024 (got %d)", a.C);
   MI355_REQUIRE(a.ldx % 4 == 0 && a.ldy % 4 == 0 && a.x_bstride % 4 == 0 && a.y_bstride % 4 == 0, "layernorm: strides must be multiples of 4");
   MI355_REQUIRE(!a.res || (a.ldr % 4 == 0 && a.res_bstride % 4 == 0), "layernorm: residual strides must be multiples of 4");
+  MI355_REQUIRE(a.y_split == 0 || a.y_split == 2 || a.y_split == 4, "layernorm: y_split must be 0, 2 or 4");
   const int64_t rows = (int64_t)a.B * a.L;
   MI355_CLEAR_ERROR();
   hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);

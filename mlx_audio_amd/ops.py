@@ -418,8 +418,13 @@ def conv_gemm(x: torch.Tensor, pc: PackedConv, y: torch.Tensor, *, dil: int = 1,
               up: Optional[dict] = None, precision: int = 2, tile: int = 0,
               flat: Optional[dict] = None, use_bias: bool = True, stats: Optional[torch.Tensor] = None,
               pre_inv_beta: Optional[torch.Tensor] = None, colscale: Optional[torch.Tensor] = None, x_off: int = 0,
-              flatten: bool = False, pre_fq: Optional[torch.Tensor] = None, ext: Optional[torch.Tensor] = None):
+              flatten: bool = False, pre_fq: Optional[torch.Tensor] = None, ext: Optional[torch.Tensor] = None,
+              x_split: bool = False, y_split: bool = False):
     """y = epilogue(conv1d(prologue(x)))  -- see mi355_conv_gemm_args in the header.
+
+    ``x_split`` / ``y_split``: the float32 tensors ``x`` / ``y`` hold SPLIT words (16-bit hi | lo << 16 of each value in the type of the launch's
+    precision, 2 or 4: ``split16``, ``layernorm(split=...)`` or another launch's ``y_split``) -- the conversion is then done once by the producer
+    instead of once per column tile of this launch.
 
     ``ext`` ([B, ceil(Lout / 64), Cout, 2] from ``new_ext``): the launch also leaves the per-block, per-channel (min, max) of what it stores, for
     ``fake_quant_extrema_from_partials`` -- only launches ``conv_ext_supported`` accepts (a quantising prologue on the wave-specialised kernel).
@@ -434,7 +439,8 @@ def conv_gemm(x: torch.Tensor, pc: PackedConv, y: torch.Tensor, *, dil: int = 1,
             fl = lambda t: t.as_strided((1, t.shape[0] * t.shape[1], t.shape[2]), (t.shape[0] * t.shape[1] * t.stride(1), t.stride(1), 1))
             return conv_gemm(fl(x), pc, fl(y), pre_act=pre_act, pre_slope=pre_slope, pre_alpha=pre_alpha, post_act=post_act,
                              post_slope=post_slope, res=None if res is None else fl(res), out_scale=out_scale, accumulate=accumulate,
-                             precision=precision, tile=tile, use_bias=use_bias, pre_inv_beta=pre_inv_beta, colscale=colscale, x_off=x_off)
+                             precision=precision, tile=tile, use_bias=use_bias, pre_inv_beta=pre_inv_beta, colscale=colscale, x_off=x_off,
+                             x_split=x_split, y_split=y_split)
     B, Lin, Cx, xbs, ldx = _nlc(x)
     By, Ly, Cy, ybs, ldy = _nlc(y)
     assert B == By
@@ -451,6 +457,10 @@ def conv_gemm(x: torch.Tensor, pc: PackedConv, y: torch.Tensor, *, dil: int = 1,
               post_slope=post_slope, out_scale=out_scale, accumulate=int(accumulate), y=_ptr(y), y_bstride=ybs, ldy=ldy,
               Lout=lout if lout is not None else Ly, lens_out=_ptr(lens_out), B=B, precision=precision, tile=tile,
               pre_inv_beta=_ptr(pre_inv_beta), post_colscale=_ptr(colscale))
+    if x_split or y_split:
+        if precision not in (2, 4):
+            raise _lib.Mi355Error("conv_gemm: split activations exist for the hi + lo precisions 2 and 4 only")
+        kw.update(x_split=precision if x_split else 0, y_split=precision if y_split else 0)
     if pre_fq is not None:  # [B, 2] from fake_quant_extrema (same prologue arguments): the prologue ends with the dynamic uint8 fake quantisation
         assert pre_fq.dtype == torch.float32 and pre_fq.shape == (B, 2) and pre_fq.is_contiguous()
         kw.update(pre_fq=_ptr(pre_fq))
@@ -584,16 +594,29 @@ def adain_from_partials(stats: torch.Tensor, L: int, gb: Optional[torch.Tensor],
 
 
 def layernorm(x: torch.Tensor, y: torch.Tensor, *, weight=None, bias=None, ada_gb=None, res=None, eps=1e-5,
-              lens=None, post_act=ACT_NONE, post_slope=0.0):
+              lens=None, post_act=ACT_NONE, post_slope=0.0, split: int = 0):
+    """``split`` = 2 / 4: ``y`` receives SPLIT words (``conv_gemm(..., x_split=True)`` at that precision reads them) instead of floats."""
     B, L, C, xbs, ldx = _nlc(x)
     _, _, _, ybs, ldy = _nlc(y)
     kw = dict(x=_ptr(x), x_bstride=xbs, ldx=ldx, C=C, L=L, lens=_ptr(lens), B=B, weight=_ptr(weight), bias=_ptr(bias),
               ada_gb=_ptr(ada_gb), ada_ld=0 if ada_gb is None else ada_gb.stride(0), eps=eps, post_act=post_act,
-              post_slope=post_slope, y=_ptr(y), y_bstride=ybs, ldy=ldy)
+              post_slope=post_slope, y=_ptr(y), y_bstride=ybs, ldy=ldy, y_split=int(split))
     if res is not None:
         _, _, _, rbs, ldr = _nlc(res)
         kw.update(res=_ptr(res), res_bstride=rbs, ldr=ldr)
     _lib.call_struct("mi355_layernorm", "mi355_layernorm_args", _stream(), **kw)
+    return y
+
+
+def split16(x: torch.Tensor, fmt: int, y: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 -> SPLIT words (16-bit hi | lo << 16; ``fmt`` 2 = bfloat16, 4 = IEEE half) of a contiguous float32 tensor, for ``conv_gemm(..., x_split=True)`` at
+    precision ``fmt``; ``y`` defaults to a fresh tensor (``y is x``: in place).  The words travel in a float32 tensor: read them with ``.view(torch.int32)``."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() % 4 == 0
+    if y is None:
+        y = torch.empty_like(x)
+    assert y.dtype == torch.float32 and y.is_contiguous() and y.numel() == x.numel()
+    lib = _lib.load()
+    _lib.check(lib.mi355_split16(_ptr(x), _ptr(y), x.numel(), int(fmt), _stream()), "mi355_split16")
     return y
 
 

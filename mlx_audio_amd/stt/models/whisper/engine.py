@@ -79,6 +79,10 @@ class WhisperEngine:
         self.dims = dims
         self.device = torch.device(device)
         self.precision = precision
+        # encoder linears on PRE-SPLIT activations (precision 4): LayerNorm / the GELU epilogue / one elementwise pass behind the attention leave the fp16
+        # hi | lo words, so the conversion happens once per value instead of once per 128-column tile of every linear (the producers' VALU work bounds
+        # these launches: profiles/r6_conv_big_gemm_b64_call11.txt).  Same numbers, bit for bit.  MI355_WHISPER_SPLIT=0: A/B knob
+        self.split_acts = precision == 4 and os.environ.get("MI355_WHISPER_SPLIT", "1") != "0"
         self.native_decode = True  # single-token decoder steps run through mi355_stack_decode_step
         # windows per step from which the decoder runs on the rows pipeline (tile images x input planes; stack_step.cpp tall_step); below: the
         # one-row-per-wave / 5..8-row matrix-pipe GEMV kernels.  MI355_WHISPER_ROWS_MIN: A/B knob
@@ -174,7 +178,14 @@ class WhisperEngine:
         kv16 = torch.empty((B, T, 2 * na), dtype=self.kv_dtype, device=self.device) if self.kv_dtype != torch.float32 else None
         att = self._f(B, T, na)
         mid = self._f(B, T, 4 * na)
+        sp = 4 if self.split_acts else 0
+        hbuf = self._f(B, T, na) if sp else None
         for blk in self.enc_blocks:
+            if sp:
+                self._encoder_block_split(blk, x, hbuf, qkv, kv16, att, mid, H, dh)
+                if return_layers:
+                    layers.append(x.clone())
+                continue
             h = self._lnorm(x, blk.attn_ln)
             self._linear(h, blk.qkv, qkv)
             if self.kv_dtype == torch.float32:
@@ -190,6 +201,23 @@ class WhisperEngine:
                 layers.append(x.clone())
         out = self._lnorm(x, self.ln_post)
         return (out, layers) if return_layers else out
+
+    def _encoder_block_split(self, blk, x, h, qkv, kv16, att, mid, H, dh):
+        """One ResidualAttentionBlock of the encoder (whisper.py:397-420) with every linear reading pre-split activations (``split_acts``)."""
+        na = x.shape[2]
+        kw = dict(precision=4, x_split=True)
+        ops.layernorm(x, h, weight=blk.attn_ln.w, bias=blk.attn_ln.b, eps=1e-5, split=4)
+        ops.conv_gemm(h, blk.qkv.pc, qkv, **kw)
+        if self.kv_dtype == torch.float32:
+            ops.flash_attention(qkv[:, :, 0:na], qkv[:, :, na:2 * na], qkv[:, :, 2 * na:], att, heads=H, dh=dh, scale=dh ** -0.5)
+        else:
+            kv16.copy_(qkv[:, :, na:])
+            ops.flash_attention(qkv[:, :, 0:na], kv16[:, :, :na], kv16[:, :, na:], att, heads=H, dh=dh, scale=dh ** -0.5)
+        ops.split16(att, 4, att)
+        ops.conv_gemm(att, blk.out.pc, x, res=x, **kw)
+        ops.layernorm(x, h, weight=blk.mlp_ln.w, bias=blk.mlp_ln.b, eps=1e-5, split=4)
+        ops.conv_gemm(h, blk.mlp1.pc, mid, post_act=ACT_GELU, y_split=True, **kw)
+        ops.conv_gemm(mid, blk.mlp2.pc, x, res=x, **kw)
 
     # ------------------------------------------------------------------ decoder (whisper.py:476-498)
     def new_state(self, xa: torch.Tensor) -> dict:

@@ -246,3 +246,36 @@ def pack_mx4_image(w: np.ndarray) -> np.ndarray:
                 out[o:o + 1024] = (c[:, 0::2] | (c[:, 1::2] << 4)).astype(np.uint8).reshape(-1)
     out[chunks * (K + npair) * ntp * 2048:] = (ep + 127).astype(np.uint8)
     return out
+
+
+# ---- SPLIT words (include/mi355audio.h: mi355_conv_gemm_args.x_split / y_split, mi355_split16) --------------------------------------------------
+def bf16_round_bits(v: np.ndarray) -> np.ndarray:
+    """float32 -> bfloat16 bits (uint16), round to nearest even (finite inputs)."""
+    u = np.asarray(v, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = (u + 0x7fff + ((u >> 16) & 1)) >> 16
+    return r.astype(np.uint16)
+
+
+def split16_words(v: np.ndarray, fmt: int) -> np.ndarray:
+    """The uint32 SPLIT word of every float32 value: bits 0-15 = the 16-bit hi part, bits 16-31 = the 16-bit lo residual, in IEEE half (``fmt`` 4: the value
+    clamped to +-65504 first) or bfloat16 (``fmt`` 2) -- the two numbers the conv prologue of that precision makes of the value (conv_ws4.h convertA)."""
+    v = np.asarray(v, dtype=np.float32)
+    if fmt == 4:
+        c = np.clip(v, -65504.0, 65504.0).astype(np.float32)
+        h = c.astype(np.float16)
+        lo = (c - h.astype(np.float32)).astype(np.float32).astype(np.float16)   # the fp32 difference is exact: one rounding, to half
+        return h.view(np.uint16).astype(np.uint32) | (lo.view(np.uint16).astype(np.uint32) << 16)
+    assert fmt == 2
+    hb = bf16_round_bits(v)
+    hf = (hb.astype(np.uint32) << 16).view(np.float32)
+    lb = bf16_round_bits((v - hf).astype(np.float32))
+    return hb.astype(np.uint32) | (lb.astype(np.uint32) << 16)
+
+
+def split16_value(words: np.ndarray, fmt: int) -> np.ndarray:
+    """hi + lo of SPLIT words, as float64."""
+    w = np.asarray(words, dtype=np.uint32)
+    h16, l16 = (w & 0xffff).astype(np.uint16), (w >> 16).astype(np.uint16)
+    if fmt == 4:
+        return h16.view(np.float16).astype(np.float64) + l16.view(np.float16).astype(np.float64)
+    return (h16.astype(np.uint32) << 16).view(np.float32).astype(np.float64) + (l16.astype(np.uint32) << 16).view(np.float32).astype(np.float64)

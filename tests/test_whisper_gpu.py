@@ -51,6 +51,22 @@ def test_tiny_encoder_layers(tiny):
     assert rel_peak(got3, exp) < 1e-2
 
 
+def test_encoder_on_pre_split_activations_equals_the_float_path(tiny):
+    """engine.split_acts (the default at precision 4): LayerNorm / GELU epilogue / one pass behind the attention leave fp16 hi | lo words and the linears
+    read those -- the same two numbers per value the float path's prologue makes, so only the kernel choice (and with it the accumulation order) may differ."""
+    eng = tiny["eng"]
+    assert eng.split_acts
+    mel = tiny["WS"].make_mel(3, seed=5, n_frames=2 * tiny["dims"].n_audio_ctx)
+    a = eng.encode(mel).clone()
+    eng.split_acts = False
+    try:
+        b = eng.encode(mel).clone()
+    finally:
+        eng.split_acts = True
+    torch.cuda.synchronize()
+    assert rel_peak(a, b) < 1e-5, rel_peak(a, b)   # (measured 2.4e-6: fp32 accumulation order over four layers)
+
+
 def _margin(filtered):
     top2 = torch.topk(filtered, 2, dim=-1).values
     return (top2[:, 0] - top2[:, 1])

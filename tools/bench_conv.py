@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--prec-ab", action="store_true", help="the wave-specialised kernel under precisions 2 (bf16 hi+lo), 3 (one fp16 pass), 4 (fp16 hi+lo) and 5 (fp16 hi + MX e4m3 lo)")
     ap.add_argument("--pmc5", action="store_true", help="precision-5 wave-specialised kernel only, three shapes, few rounds (for rocprofv3 --pmc passes and power sampling)")
     ap.add_argument("--loop-seconds", type=float, default=0.0, help="with --pmc5: keep launching the first shape for this long (power / clock sampling by rocm-smi alongside)")
+    ap.add_argument("--big-gemm", action="store_true", help="the Whisper-small encoder linears at 64 windows (96 000 rows): precisions 2 / 3 / 4 and the GEMM-mode timing ablations")
     ap.add_argument("--flat", action="store_true", help="with --small: hand the batch over as ONE item of B*L rows (ops.conv_gemm(flatten=True))")
     args = ap.parse_args()
     from mlx_audio_amd import ops
@@ -66,6 +67,11 @@ def main():
                   (640, 2048, 1, 1, 264, "plain"), (1090, 1024, 3, 1, 264, "leaky"), (1024, 1024, 3, 1, 264, "leaky"), (512, 512, 3, 1, 528, "leaky"),
                   (512, 512, 5, 1, 80, "plain")]
         variants = [("t64x128", 64128), ("t64x64", 64064), ("ws4_1tile", 86128128), ("ws4", 6128128)]
+    if args.big_gemm:
+        W = 6128128
+        shapes = [(768, 2304, 1, 1, 1500, "plain"), (768, 768, 1, 1, 1500, "plain+res"), (768, 3072, 1, 1, 1500, "plain"), (3072, 768, 1, 1, 1500, "plain+res")]
+        variants = [("p2_bf16_hi_lo", W), ("p3_fp16_one_pass", W), ("p4_fp16_hi_lo", W), ("p2_xsplit", W), ("p4_xsplit", W), ("p4_xsplit_ysplit", W),
+                    ("p2_abl1_noBload", 100000000 + W), ("p2_abl4_noProducer", 400000000 + W), ("p2_abl5_noBload_noProducer", 500000000 + W)]
     if args.quick:
         shapes = [(128, 128, 11, 1, 31681, "snake+res"), (128, 128, 3, 1, 31681, "snake+res")]
         variants = [("old64x128", 64128), ("ws4", 6128128)]
@@ -87,6 +93,10 @@ def main():
         pc = ops.pack_conv(w, bias, dev, mx=args.precision - 4) if args.precision in (5, 6) else ops.pack_conv(w, bias, dev, f16=args.precision == 3)
         vprec = {name: args.precision for name, _ in variants}
         vpc = {name: pc for name, _ in variants}
+        if args.big_gemm:
+            pc16 = ops.pack_conv(w, bias, dev, f16=True)
+            vprec = {name: (3 if name.startswith("p3") else 4 if name.startswith("p4") else 2) for name, _ in variants}
+            vpc = {name: (pc16 if vprec[name] != 2 else pc) for name, _ in variants}
         if args.prec_ab:
             pc16, pcmx, pcmx4 = ops.pack_conv(w, bias, dev, f16=True), ops.pack_conv(w, bias, dev, mx=True), ops.pack_conv(w, bias, dev, mx=2)
             vprec = {"p2_bf16_hi_lo": 2, "p3_fp16_one_pass": 3, "p4_fp16_hi_lo": 4, "p5_fp16_hi_mx8_lo": 5, "p6_fp16_hi_mx4_lo": 6}
@@ -129,11 +139,28 @@ def main():
         ok_rows = n - (k - 1) * dil  # rows whose window stays inside the first n inputs
         times = {name: [] for name, _ in variants}
         errs = {}
+        xsplit = {}   # pre-split copies of the input (the split variants: conversion done once, in front of the launch)
+        for name, _ in variants:
+            if "xsplit" in name and vprec[name] not in xsplit:
+                xsplit[vprec[name]] = ops.split16(x, vprec[name])
+
+        def xin(name):
+            return (xsplit[vprec[name]] if "xsplit" in name else x)[:, :, :cin]
+
+        def vkw(name):
+            return dict(kw, x_split="xsplit" in name, y_split="ysplit" in name) if "split" in name else kw
+
         for name, tile in variants:
             try:
-                ops.conv_gemm(x[:, :, :cin], vpc[name], y, dil=dil, pad=pad, tile=tile, precision=vprec[name], **kw)
+                ops.conv_gemm(xin(name), vpc[name], y, dil=dil, pad=pad, tile=tile, precision=vprec[name], **vkw(name))
                 torch.cuda.synchronize()
-                got = y[0, :ok_rows].double().cpu()
+                if "ysplit" in name:   # the stored words' hi + lo halves against the reference
+                    wds = y[0, :ok_rows].contiguous().view(torch.int32)
+                    halves = torch.stack([wds & 0xffff, (wds >> 16) & 0xffff], 0).to(torch.int16)
+                    hl = halves.view(torch.float16 if vprec[name] == 4 else torch.bfloat16).double().cpu()
+                    got = hl[0] + hl[1]
+                else:
+                    got = y[0, :ok_rows].double().cpu()
                 errs[name] = float((got - ref[:ok_rows]).abs().max() / ref.abs().max())
             except Exception as e:  # a variant may not support a shape
                 errs[name] = str(e)[:60]
@@ -153,7 +180,7 @@ def main():
                     continue
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                ops.conv_gemm(x[:, :, :cin], vpc[name], y, dil=dil, pad=pad, tile=tile, precision=vprec[name], **kw)
+                ops.conv_gemm(xin(name), vpc[name], y, dil=dil, pad=pad, tile=tile, precision=vprec[name], **vkw(name))
                 e1.record()
                 torch.cuda.synchronize()
                 times[name].append(e0.elapsed_time(e1))
@@ -163,7 +190,7 @@ def main():
                 continue
             ms = sorted(times[name])[len(times[name]) // 2]
             lines.append(f"{cin} {cout} {k} {dil} {rows} {fused} {name} {ms:.4f} {flops / ms / 1e9:.1f} {byts / ms / 1e6:.0f} {errs[name]:.2e}")
-        del x, y, res
+        del x, y, res, xsplit
         torch.cuda.empty_cache()
     txt = "\n".join(lines)
     print(txt)
