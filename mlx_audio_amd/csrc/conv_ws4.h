@@ -141,8 +141,16 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
     };
 
     // precision 5: windows that lie inside their utterance in rows and channels take straight-line loads and an unmasked conversion (FASTW)
-    constexpr bool FASTW = MXP;
+    // ... and GEMM mode (round 6): the wide linears' producers are bound by VALU ISSUE slots (they get one every ~16 cycles under the consumers' priority),
+    // and most of their instructions were row / channel masks and address arithmetic, not the conversion (profiles/r6_conv_big_gemm_split_b64_call13.txt)
+    // Same-box A / B (profiles/r6_conv_ab_fastw_b64_call17.txt, r6_conv_big_gemm_fastw_b64_call17.txt): GEMM mode -10 .. -13 %, LeakyReLU convs -6 %, plain
+    // convs -1 %; the Snake convs of the 16-bit splits get SLOWER (+2 .. +8 % at 7 / 11 taps: a second copy of the sin / rcp body in the instruction
+    // cache), so they keep the one masked body -- as do the quantising prologues (KittenTTS' launches are small)
+    constexpr bool FASTW = !FQ && (MXP || GEMM || PRE == P_NONE || PRE == P_LEAKY);
+    const bool fastw_off = !MXP && (q.feat & 2);   // feature bit 1 on the 16-bit-split kernels: masked body only (A / B aid; precision 5: the 2 x 2 layout)
     auto interior_window = [&](const item_t& it) {
+      if (fastw_off) return false;
+      if constexpr (GEMM) return it.l0 + 128 <= it.len_in && it.l0 + 128 <= a.Lin && it.ci * 64 + 64 <= a.Cin;   // wave-uniform
       const int r0 = it.l0 - a.pad;
       return r0 >= 0 && r0 + R <= it.len_in && r0 + R <= a.Lin && it.ci * 32 + 32 <= a.Cin;   // wave-uniform
     };
@@ -168,13 +176,14 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
         // every row and channel of the window exists (the resblock convs' interior tiles: all but the two edge tiles of an utterance): one wave-uniform
         // base per pass + ONE 32-bit lane offset, no clamps -- ~6 VALU operations per load less in the producers' issue stream (round 6: the
         // producers are starved of VALU issue slots, 16 cycles per instruction under the consumers' priority)
-        const char* wb = (const char*)(xb + (int64_t)(l0 - a.pad) * a.ldx + chunk * cstride);
+        const char* wb = (const char*)(xb + (int64_t)(GEMM ? l0 : l0 - a.pad) * a.ldx + chunk * cstride);
         const uint32_t loff = ((uint32_t)prow * (uint32_t)a.ldx + (uint32_t)c4) * 4u;
         const size_t pstep = (size_t)a.ldx * 128u;   // 32 rows
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-          const int ii = (wrow0 + i * 32 < R) ? i : 0;
-          areg[i] = *(const float4*)(wb + ii * pstep + loff);
+          const int ii = (GEMM || wrow0 + i * 32 < R) ? i : 0;
+          if constexpr (GEMM) areg[i] = *(const float4*)(wb + (ii & 3) * pstep + (ii >> 2) * 128 + loff);   // passes 4..7: the second 32 channels of the super-chunk
+          else areg[i] = *(const float4*)(wb + ii * pstep + loff);
         }
         return;
       }
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
               if (xs) {
                 uint32_t w[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) w[j] = (rowok && (cb + j) < a.Cin) ? __builtin_bit_cast(uint32_t, v[j]) : 0u;
+                for (int j = 0; j < 4; ++j) w[j] = (!MASK || (rowok && (cb + j) < a.Cin)) ? __builtin_bit_cast(uint32_t, v[j]) : 0u;
                 const int xaddr = r * 64 + ((((c4 >> 3) ^ ((r >> 2) & 3))) << 4) + ((c4 & 4) << 1);
                 uint2 xh, xl;   // v_perm_b32: selector bytes 0-3 pick from the second operand, 4-7 from the first
                 xh.x = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u);
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
                 u = u > 0.f ? u : expm1f(u);
               }
               if constexpr (GEMM) {
-                tt[j] = (rowok && (cb + j) < a.Cin) ? u : 0.f;
+                tt[j] = (!MASK || (rowok && (cb + j) < a.Cin)) ? u : 0.f;
               } else {
                 // the prologue value is computed UNCONDITIONALLY (opaque to the optimiser) and masked by one v_cndmask: left to itself hipcc sinks
                 // the whole affine + sin chain of every element under its own s_and_saveexec / s_cbranch_execz pair (skipping work for padding rows

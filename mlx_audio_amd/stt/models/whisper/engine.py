@@ -79,9 +79,10 @@ class WhisperEngine:
         self.dims = dims
         self.device = torch.device(device)
         self.precision = precision
-        # encoder linears on PRE-SPLIT activations (precision 4): LayerNorm / the GELU epilogue / one elementwise pass behind the attention leave the fp16
-        # hi | lo words, so the conversion happens once per value instead of once per 128-column tile of every linear (the producers' VALU work bounds
-        # these launches: profiles/r6_conv_big_gemm_b64_call11.txt).  Same numbers, bit for bit.  MI355_WHISPER_SPLIT=0: A/B knob
+        # encoder linears behind a LayerNorm read PRE-SPLIT activations (precision 4): the LayerNorm kernel leaves the fp16 hi | lo words, so the conversion
+        # happens once per value instead of once per 128-column tile of the linear.  Same numbers, bit for bit; measured -3 .. -5 % on those launches
+        # (profiles/r6_conv_big_gemm_fastw_b64_call17.txt).  A conv epilogue can leave the words too (y_split), but that costs the producing launch more
+        # than the consumer gains (+30 %), so the GELU -> mlp2 and attention -> out hand-overs stay float32.  MI355_WHISPER_SPLIT=0: A/B knob
         self.split_acts = precision == 4 and os.environ.get("MI355_WHISPER_SPLIT", "1") != "0"
         self.native_decode = True  # single-token decoder steps run through mi355_stack_decode_step
         # windows per step from which the decoder runs on the rows pipeline (tile images x input planes; stack_step.cpp tall_step); below: the
@@ -203,21 +204,19 @@ class WhisperEngine:
         return (out, layers) if return_layers else out
 
     def _encoder_block_split(self, blk, x, h, qkv, kv16, att, mid, H, dh):
-        """One ResidualAttentionBlock of the encoder (whisper.py:397-420) with every linear reading pre-split activations (``split_acts``)."""
+        """One ResidualAttentionBlock of the encoder (whisper.py:397-420) with the two linears behind a LayerNorm reading pre-split activations (``split_acts``)."""
         na = x.shape[2]
-        kw = dict(precision=4, x_split=True)
         ops.layernorm(x, h, weight=blk.attn_ln.w, bias=blk.attn_ln.b, eps=1e-5, split=4)
-        ops.conv_gemm(h, blk.qkv.pc, qkv, **kw)
+        ops.conv_gemm(h, blk.qkv.pc, qkv, precision=4, x_split=True)
         if self.kv_dtype == torch.float32:
             ops.flash_attention(qkv[:, :, 0:na], qkv[:, :, na:2 * na], qkv[:, :, 2 * na:], att, heads=H, dh=dh, scale=dh ** -0.5)
         else:
             kv16.copy_(qkv[:, :, na:])
             ops.flash_attention(qkv[:, :, 0:na], kv16[:, :, :na], kv16[:, :, na:], att, heads=H, dh=dh, scale=dh ** -0.5)
-        ops.split16(att, 4, att)
-        ops.conv_gemm(att, blk.out.pc, x, res=x, **kw)
+        ops.conv_gemm(att, blk.out.pc, x, res=x, precision=4)
         ops.layernorm(x, h, weight=blk.mlp_ln.w, bias=blk.mlp_ln.b, eps=1e-5, split=4)
-        ops.conv_gemm(h, blk.mlp1.pc, mid, post_act=ACT_GELU, y_split=True, **kw)
-        ops.conv_gemm(mid, blk.mlp2.pc, x, res=x, **kw)
+        ops.conv_gemm(h, blk.mlp1.pc, mid, post_act=ACT_GELU, precision=4, x_split=True)
+        ops.conv_gemm(mid, blk.mlp2.pc, x, res=x, precision=4)
 
     # ------------------------------------------------------------------ decoder (whisper.py:476-498)
     def new_state(self, xa: torch.Tensor) -> dict:

@@ -50,7 +50,7 @@ def main():
     shapes.append((256, 256, 11, 5, 5280, "snake"))
     shapes.append((1090, 1024, 3, 1, 264, "leaky"))
     shapes.append((512, 2560, 2, 1, 529, "plain"))
-    variants = [("old64x128", 64128), ("ws4_1tile", 86128128), ("ws4_noprio", 16128128), ("ws4", 6128128)]
+    variants = [("old64x128", 64128), ("ws4_1tile", 86128128), ("ws4_masked_producers", 26128128), ("ws4", 6128128)]
     if args.ablate:
         shapes = [(128, 128, 11, 1, 31681, "snake+res"), (128, 128, 11, 5, 31681, "snake"), (128, 128, 3, 1, 31681, "snake+res"), (256, 256, 7, 1, 5280, "snake+res")]
         W = 6128128
@@ -70,7 +70,7 @@ def main():
     if args.big_gemm:
         W = 6128128
         shapes = [(768, 2304, 1, 1, 1500, "plain"), (768, 768, 1, 1, 1500, "plain+res"), (768, 3072, 1, 1, 1500, "plain"), (3072, 768, 1, 1, 1500, "plain+res")]
-        variants = [("p2_bf16_hi_lo", W), ("p3_fp16_one_pass", W), ("p4_fp16_hi_lo", W), ("p2_xsplit", W), ("p4_xsplit", W), ("p4_xsplit_ysplit", W),
+        variants = [("p2_bf16_hi_lo", W), ("p3_fp16_one_pass", W), ("p4_fp16_hi_lo", W), ("p2_masked_producers", 20000000 + W), ("p4_masked_producers", 20000000 + W), ("p2_xsplit", W), ("p4_xsplit", W), ("p4_xsplit_ysplit", W),
                     ("p2_abl1_noBload", 100000000 + W), ("p2_abl4_noProducer", 400000000 + W), ("p2_abl5_noBload_noProducer", 500000000 + W)]
     if args.quick:
         shapes = [(128, 128, 11, 1, 31681, "snake+res"), (128, 128, 3, 1, 31681, "snake+res")]
