@@ -357,6 +357,54 @@ __device__ __forceinline__ void conv_epilogue_interior(const mi355_conv_gemm_arg
   }
 }
 
+// Interior-tile epilogue of the POLYPHASE store (conv_transpose as a stride-1 conv with up_s * up_cout columns: column n = phase * up_cout + channel goes to
+// output row u * up_s + phase - up_p): every GEMM row of the tile and every output row it maps to is in range, no epilogue activation, no column scale,
+// no statistics.  Same arithmetic as conv_epilogue (bias, + residual at the OUTPUT row, out_scale), so the two paths are bit-identical; what goes away is
+// the per-element division-free but 64-bit, predicated address arithmetic: one base pointer per 32-column fragment and a 32-bit row step
+// (Kokoro's two upsamplers at 64 utterances: 1.32 + 0.79 ms of the step on the general path, profiles/r6_shape_table_b64_call18.txt).
+template <int MF, int NF, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue_up_interior(const mi355_conv_gemm_args& a, f32x16 (&acc)[MF][NF], const int b, const int l0, const int n0,
+                                                          const int wm, const int wn, const int lane) {
+  const float oscale = a.out_scale;
+  // wave-uniform bases (the output row of the wave block's first GEMM row at phase 0) + one 32-bit lane offset per 32-column fragment
+  const int64_t urow = (int64_t)(l0 + wm * WM) * a.up_s - a.up_p + a.up_row_off;
+  char* yw = (char*)(a.y + (int64_t)b * a.y_bstride + urow * a.ldy);
+  const char* rw = a.res ? (const char*)(a.res + (int64_t)b * a.res_bstride + urow * a.ldr) : nullptr;
+  const uint32_t ystep = (uint32_t)a.up_s * (uint32_t)a.ldy * 4u;   // bytes between the output rows of consecutive GEMM rows (one phase)
+  const uint32_t rstep = (uint32_t)a.up_s * (uint32_t)a.ldr * 4u;
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+    const int n = n0 + wn * WN + nf * 32 + (lane & 31);
+    const int rph = n / a.up_cout, ocol = n - rph * a.up_cout;
+    const float bias = a.bias ? a.bias[ocol] : 0.f;
+    const uint32_t lrow = (uint32_t)(4 * (lane >> 5));
+    const uint32_t yoff = lrow * ystep + ((uint32_t)rph * (uint32_t)a.ldy + (uint32_t)ocol) * 4u;
+    const uint32_t roff = lrow * rstep + ((uint32_t)rph * (uint32_t)a.ldr + (uint32_t)ocol) * 4u;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {   // 8 accumulator rows at a time keeps the live set small
+        float rv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rv[q] = 0.f;
+        if (rw) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int r = h * 8 + q;
+            rv[q] = *(const float*)(rw + (roff + (uint32_t)(mf * 32 + (r & 3) + 8 * (r >> 2)) * rstep));
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int r = h * 8 + q;
+          const float v = ((acc[mf][nf][r] + bias) + rv[q]) * oscale;
+          *(float*)(yw + (yoff + (uint32_t)(mf * 32 + (r & 3) + 8 * (r >> 2)) * ystep)) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  }
+}
+
 }  // namespace mi355conv
 
 // conv_ws4.hip: wave-specialised kernel (tile code 6128128 [+ 10000000 * feature bits for A/B runs]).  `feat` bit 0: consumers at default

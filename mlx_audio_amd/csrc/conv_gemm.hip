@@ -682,7 +682,9 @@ extern "C" int mi355_conv_gemm(const mi355_conv_gemm_args* ap, void* stream) {
     static const bool no_ws = getenv("MI355_CONV_NO_WS") != nullptr;
     static const int ws_feat = getenv("MI355_CONV_WS_FEAT") ? atoi(getenv("MI355_CONV_WS_FEAT")) : 0;
     static const long ws_min = getenv("MI355_CONV_WS_MIN_TILES") ? atol(getenv("MI355_CONV_WS_MIN_TILES")) : 128;
-    if (!no_ws && !mx_image && bn == 128 && wgs128 >= ws_min && a.Cin >= 64 && mi355_conv_ws4_eligible(a, vec)) {
+    // (shallow inputs, C_in < 64: a tile is one chunk of work and an epilogue -- store bound.  From 2048 tiles on the persistent kernel's interior epilogue wins
+    // 2.2x over the 4-wave kernels: Kokoro's 22 -> 128 source conv at 2 M rows 0.60 -> 0.26 ms, profiles/r6_conv_thin_b64_call19.txt)
+    if (!no_ws && !mx_image && bn == 128 && wgs128 >= ws_min && (a.Cin >= 64 || wgs128 >= 2048) && mi355_conv_ws4_eligible(a, vec)) {
       const int rc = mi355_conv_ws4_launch(a, st, ws_feat);
       if (rc != MI355_ERR_UNSUPPORTED) return rc;  // no instantiation for this prologue / epilogue pair: fall through to the 4-wave kernels
     }

@@ -1088,7 +1088,16 @@ __global__ __launch_bounds__(kWs4Threads, 4) void conv_ws4_kernel(const mi355_co
         conv_epilogue<2, NF, 64, WN, EPI, FQ, MF, 2>(a, acc, b, l0, n0, 1, wn, lane, len_out, fold != 0);
       }
     } else {
+      bool up_interior = false;
+      if constexpr (EPI == 0 && !FQ && BN == 128 && PRE == P_LEAKY && !GEMM) {   // polyphase store (the conv_transpose upsamplers behind a LeakyReLU): tiles whose rows all land inside the output
+        if (a.up_s != 0 && interior && a.post_act == MI355_ACT_NONE && !a.accumulate && !a.post_colscale && !a.y_split && !a.stats_partial && a.res_shift == 0 &&
+            (a.up_cout & 31) == 0) {
+          const int len_up = a.lens_up ? a.lens_up[b] : a.up_Lout;
+          up_interior = (int64_t)l0 * a.up_s - a.up_p >= 0 && (int64_t)(l0 + BM - 1) * a.up_s + (a.up_s - 1) - a.up_p < len_up;
+        }
+      }
       if (plain && interior) conv_epilogue_interior<MF, NF, WM, WN, FQ>(a, acc, b, l0, n0, wm, wn, lane);   // FQ instantiations: + per-block extrema (EXT)
+      else if (up_interior) conv_epilogue_up_interior<MF, NF, WM, WN>(a, acc, b, l0, n0, wm, wn, lane);
       else conv_epilogue<MF, NF, WM, WN, EPI, FQ>(a, acc, b, l0, n0, wm, wn, lane, len_out, fold != 0);
     }
     if constexpr (DBG) {

@@ -394,15 +394,18 @@ class KokoroEngine:
 
     def _style_proj(self, s: torch.Tensor, pc: PackedConv, quant: bool) -> _StyleProj:
         """Every ``fc(style)`` of one style vector: one GEMM, and one more from the fake-quantised vector when an AdaIN wants that."""
+        # ONE item of B rows (not B items of one row: that is B row tiles with a single valid row each -- 0.53 ms for the 37 396-column projection of
+        # 64 utterances, profiles/r6_shape_table_b64_call18.txt)
         B = s.shape[0]
-        plain = self._new(B, 1, pc.cout)
-        self._conv(s[:, None, :], pc, plain)
+        plain = self._new(1, B, pc.cout)
+        self._conv(s[None, :, :], pc, plain)
         q = None
         if quant:
-            q = self._new(B, 1, pc.cout)
-            self._conv(ops.fake_quant_u8(s[:, None, :]), pc, q)
-            q = q[:, 0]
-        return _StyleProj(plain[:, 0], q)
+            q = self._new(1, B, pc.cout)
+            sq = ops.fake_quant_u8(s[:, None, :])   # per utterance
+            self._conv(sq.as_strided((1, B, sq.shape[2]), (B * sq.stride(0), sq.stride(0), 1)), pc, q)
+            q = q[0]
+        return _StyleProj(plain[0], q)
 
     def _prec(self, pc) -> int:
         # the weight image decides: fp16-packed weights select 3 themselves (4 in mode 5), MX images 5; bf16 images of modes 3 / 5 (front end) run 2

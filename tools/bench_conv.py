@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--pmc5", action="store_true", help="precision-5 wave-specialised kernel only, three shapes, few rounds (for rocprofv3 --pmc passes and power sampling)")
     ap.add_argument("--loop-seconds", type=float, default=0.0, help="with --pmc5: keep launching the first shape for this long (power / clock sampling by rocm-smi alongside)")
     ap.add_argument("--big-gemm", action="store_true", help="the Whisper-small encoder linears at 64 windows (96 000 rows): precisions 2 / 3 / 4 and the GEMM-mode timing ablations")
+    ap.add_argument("--thin", action="store_true", help="the Kokoro generator's thin / shallow launches (22 -> 128 k = 1, 128 -> 22 k = 7, the flattened noise conv, the upsamplers): tile A/B")
     ap.add_argument("--flat", action="store_true", help="with --small: hand the batch over as ONE item of B*L rows (ops.conv_gemm(flatten=True))")
     args = ap.parse_args()
     from mlx_audio_amd import ops
@@ -67,6 +68,9 @@ def main():
                   (640, 2048, 1, 1, 264, "plain"), (1090, 1024, 3, 1, 264, "leaky"), (1024, 1024, 3, 1, 264, "leaky"), (512, 512, 3, 1, 528, "leaky"),
                   (512, 512, 5, 1, 80, "plain")]
         variants = [("t64x128", 64128), ("t64x64", 64064), ("ws4_1tile", 86128128), ("ws4", 6128128)]
+    if args.thin:
+        shapes = [(22, 128, 1, 1, 31681, "plain"), (128, 22, 7, 1, 31681, "leaky"), (288, 256, 1, 1, 5280, "plain"), (256, 768, 2, 1, 5281, "plain"), (512, 2560, 2, 1, 529, "plain")]
+        variants = [("auto", 0), ("t64x64", 64064), ("t64x128", 64128), ("t128x128", 128128), ("ws4_n64", 6128064), ("ws4_n64_noprio", 16128064), ("ws4", 6128128), ("ws4_noprio", 16128128)]
     if args.big_gemm:
         W = 6128128
         shapes = [(768, 2304, 1, 1, 1500, "plain"), (768, 768, 1, 1, 1500, "plain+res"), (768, 3072, 1, 1, 1500, "plain"), (3072, 768, 1, 1, 1500, "plain+res")]
