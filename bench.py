@@ -426,7 +426,7 @@ def main():
         diff = float((ob[0].to(torch.float32) - o1[0]).abs().max())
         # mode 5: the lone utterance leaves generator stage 0 on the 4-wave kernels (fp16 hi + fp16 lo on the same images) while the batch runs the
         # MX lo pass there, so the two differ by the lo pass's own error (~1e-4 of the peak); the other modes differ by summation order only
-        bar = {5: 4e-4, 6: 1.2e-3}.get(args.precision, 5e-5)   # (mode 6: the FP4 lo pass's own error is ~3x the e4m3 one's)
+        bar = {5: 4e-4, 6: 5e-4}.get(args.precision, 5e-5)   # (mode 6: measured 1.7e-4 -- the FP4 lo pass's own error is ~3x the e4m3 one's; B = 1 and B = 64 take different kernels for generator stage 0)
         batch_check = {"max_abs_diff_over_peak": diff / peak, "bar": bar, "what": "utterance 0 of the benchmarked batch step vs the same utterance run alone (same SineGen inputs, the lone "
                        "run's F0 / N curves injected into the batch), max |diff| / peak"}
         batch_check["ok"] = bool(diff <= bar * peak)   # reported, not fatal: the line's own parity gate is tests/test_kokoro_gpu.py (B = 64, against the oracle)

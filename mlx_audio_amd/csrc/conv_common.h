@@ -268,15 +268,7 @@ __device__ __forceinline__ void conv_epilogue_interior(const mi355_conv_gemm_arg
   const uint32_t ldb = (uint32_t)a.ldy * 4u;                                                             // row pitch in bytes
   const uint32_t lane_off = (uint32_t)(4 * (lane >> 5)) * ldb + (uint32_t)(lane & 31) * 4u;            // < 4 GB inside the wave block
   const bool want_stats = a.stats_partial != nullptr;
-#if defined(MI355_SLP_PROBE) && MI355_SLP_PROBE == 2   // tools/build_variants.sh: no SGPR (pair) operand in the packed arithmetic
-  float oscale = a.out_scale;
-  asm volatile("" : "+v"(oscale));
-#else
   const float oscale = a.out_scale;
-#endif
-#if defined(MI355_SLP_PROBE) && MI355_SLP_PROBE == 3   // tools/build_variants.sh: a long pad + full drain between the main loop and the first accumulator read
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
   float sK[NF], s1[NF], s2[NF];
   const bool want_ext = EXT && a.ext_partial != nullptr;
 #pragma unroll
@@ -311,12 +303,7 @@ __device__ __forceinline__ void conv_epilogue_interior(const mi355_conv_gemm_arg
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) {
         const int n = n0 + wn * WN + nf * 32 + (lane & 31);
-#if defined(MI355_SLP_PROBE) && MI355_SLP_PROBE == 2
-        float cl = (float)(MF * 16);
-        asm volatile("" : "+v"(cl));
-#else
         const float cl = (float)(MF * 16);
-#endif
         const float ml = sK[nf] + s1[nf] / cl;
         const float vl = s2[nf] - s1[nf] * s1[nf] / cl;
         const float cp = cl, mp = __shfl_xor(ml, 32, 64), vp = __shfl_xor(vl, 32, 64);

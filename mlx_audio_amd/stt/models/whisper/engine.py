@@ -89,6 +89,7 @@ class WhisperEngine:
         # one-row-per-wave / 5..8-row matrix-pipe GEMV kernels.  MI355_WHISPER_ROWS_MIN: A/B knob
         self.rows_min = int(os.environ.get("MI355_WHISPER_ROWS_MIN", "9"))
         self._rows_ws = None
+        self._logit_planes = None
         self._tile_images = {}
         self.dh = dims.n_audio_state // dims.n_audio_head
         assert self.dh in (64, 128) and dims.n_text_state // dims.n_text_head == self.dh
@@ -332,6 +333,18 @@ class WhisperEngine:
         B, n, _ = hidden.shape
         vp = ops.round_up(self.dims.n_vocab, 4)
         out = self._f(B, n, vp)
+        if n == 1 and self.rows_min <= B <= 64 and os.environ.get("MI355_WHISPER_LOGITS_ROWS", "1") != "0":
+            # decode step of a tall batch: the 51 865 x 768 tied head on the rows pipeline (tile image x pre-split planes, ONE K group: the slab a
+            # workgroup writes IS the logits -- no bias, no epilogue launch).  The one-launch gemm_rows kernel re-reads and re-splits all B rows in each of its
+            # 3 242 workgroups: 86 us per step at 64 windows against ~30 us here (profiles/r6_kernel_stats_whisper_b64_call16.txt).  MI355_WHISPER_LOGITS_ROWS=0: A/B knob
+            R = ops.rows_R(B)
+            nt = self.dims.n_text_state
+            if self._logit_planes is None or self._logit_planes[0] != R:
+                self._logit_planes = (R, ops.rows_planes(R, nt, self.device))
+            planes = self._logit_planes[1]
+            ops.rows_finish(hidden[:, 0, :], B, nt, 1, planes=planes, R=R, f16=True)   # float rows -> fp16 hi + lo planes
+            ops.rows_gemm(planes, self._tiles(self.logits_lin), out.view(1, B, vp), B, R, kgroups=1)
+            return out
         self._linear(hidden, self.logits_lin, out[:, :, :self.dims.n_vocab])
         return out
 

@@ -33,12 +33,13 @@ def setup():
 
 
 # Free-running spectral-envelope bar (log10 power, mean |diff| over the 80-band log-mel of the whole utterance).  Measured on MI355X in round 2:
-# see the value printed by test_kokoro_front_end_free_running (profiles/r2_kokoro_free_running_call11.txt: 0.1796); the bar is 2x that measurement.
+# see the value printed by test_kokoro_front_end_free_running (profiles/r2_kokoro_free_running_call11.txt: 0.1796); the bar is 1.5x that measurement
+# (round 6; it was 2x: VERDICT r5 weak point 3).
 # What the bar separates (round 5, CPU study pinned by tests/test_oracle_golden.py::test_kokoro_free_running_envelope_bar_is_the_oracle_self_sensitivity):
 # the oracle against ITSELF with its F0 curve perturbed by 1e-5 of the peak (float32 rounding level) scores 0.14 - 0.18 on this metric -- the device's
 # figure -- and 0.24 - 0.33 at 1e-4, 0.37 - 0.40 at 5e-4: the free-running waveform is chaotic in F0 (phase integration), so a sample-level bar cannot exist
-# and this one sits at "an F0 error of about 1e-4 of the peak".  The F0 / N curves themselves are held at 5e-4 relative just above.
-ENV_BAR = 0.36  # measured 0.1796 (call 11)
+# and this one sits at "an F0 error of about 5e-5 of the peak".  The F0 / N curves themselves are held at 5e-4 relative just above.
+ENV_BAR = 0.27  # measured 0.1796 (round 2, call 11)
 
 
 def snr_db(got, ref):
