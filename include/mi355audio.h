@@ -300,6 +300,13 @@ typedef struct {
 } mi355_gather_rows_args;
 int mi355_gather_rows(const mi355_gather_rows_args* a, void* stream);
 
+/* k | v projection rows -> the 16-bit head-major blocks the decode-step attention streams (round 6, ABI 36; stt/models/whisper/whisper.py:360-365: the reference
+ * computes k and v of the cross-attention once per window and caches them in the model's 16-bit dtype).  kv: float32 [B, T, ld] with G * H * dh value columns
+ * (G groups -- k, v -- of H heads); out: [G, B, H, T, dh] of MI355_KV_BF16 / MI355_KV_F16, contiguous; round to nearest even.  One pass (read 4 bytes, write 2
+ * per value) instead of a permute copy and a conversion copy per group.  dh a multiple of 8, ld a multiple of 4, 16-byte aligned pointers. */
+int mi355_kv_head_major16(const float* kv, int64_t kv_bstride, int32_t ld, int32_t B, int32_t T, int32_t G, int32_t H, int32_t dh, void* out, int32_t out_dtype,
+                          void* stream);
+
 /* y[b, l, c] = v[b, c] for l < lens[b] (style broadcast, modules.py:393-395). */
 int mi355_broadcast_rows(const float* v, int32_t ldv, int32_t C, float* y, int64_t y_bstride, int32_t ldy,
                          int32_t L, const int32_t* lens, int32_t B, void* stream);

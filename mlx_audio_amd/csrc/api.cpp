@@ -17,7 +17,7 @@ void mi355_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* mi355_last_error(void) { return g_err; }
-extern "C" int mi355_abi_version(void) { return 35; }
+extern "C" int mi355_abi_version(void) { return 36; }
 
 extern "C" int mi355_device_info(int dev, char* name, int name_cap, int* cu_count, int* lds_bytes) {
   hipDeviceProp_t p;

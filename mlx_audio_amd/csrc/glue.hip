@@ -295,6 +295,49 @@ extern "C" int mi355_gather_rows(const mi355_gather_rows_args* ap, void* stream)
   return MI355_OK;
 }
 
+namespace {
+// one thread = 8 consecutive d of one (g, b, h, t): two float4 in, one 16-byte store out; a block = 32 rows t of one (g, b, h) when dh = 64
+__global__ __launch_bounds__(256) void kv_head_major16_kernel(const float* __restrict__ kv, const int64_t bstride, const int ld, const int B, const int T, const int G, const int H,
+                                                               const int dh, uint4* __restrict__ out, const int bf16) {
+  const int cpr = dh >> 3;                                    // 16-byte pieces per (t, head)
+  const int64_t per_head = (int64_t)T * cpr;
+  const int64_t total = (int64_t)G * B * H * per_head;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t blk = i / per_head;                         // (g * B + b) * H + h
+    const int r = (int)(i - blk * per_head);
+    const int t = r / cpr, c = r - t * cpr;
+    const int h = (int)(blk % H);
+    const int64_t gb = blk / H;
+    const int b = (int)(gb % B), g = (int)(gb / B);
+    const float* src = kv + (int64_t)b * bstride + (int64_t)t * ld + (g * H + h) * dh + c * 8;
+    const float4 v0 = *(const float4*)src, v1 = *(const float4*)(src + 4);
+    uint4 o;
+    if (bf16) {
+      o.x = pack_bf16x2(v0.x, v0.y); o.y = pack_bf16x2(v0.z, v0.w); o.z = pack_bf16x2(v1.x, v1.y); o.w = pack_bf16x2(v1.z, v1.w);
+    } else {
+      o.x = pack_f16x2(v0.x, v0.y); o.y = pack_f16x2(v0.z, v0.w); o.z = pack_f16x2(v1.x, v1.y); o.w = pack_f16x2(v1.z, v1.w);
+    }
+    out[i] = o;
+  }
+}
+}  // namespace
+
+extern "C" int mi355_kv_head_major16(const float* kv, int64_t kv_bstride, int32_t ld, int32_t B, int32_t T, int32_t G, int32_t H, int32_t dh, void* out,
+                                     int32_t out_dtype, void* stream) {
+  MI355_REQUIRE(kv && out, "kv_head_major16: null tensor");
+  MI355_REQUIRE(B > 0 && T > 0 && G > 0 && H > 0 && dh > 0 && dh % 8 == 0, "kv_head_major16: bad shape (dh must be a multiple of 8)");
+  MI355_REQUIRE(out_dtype == MI355_KV_BF16 || out_dtype == MI355_KV_F16, "kv_head_major16: out_dtype must be MI355_KV_BF16 or MI355_KV_F16");
+  MI355_REQUIRE(ld >= G * H * dh && ld % 4 == 0 && kv_bstride % 4 == 0 && ((uintptr_t)kv) % 16 == 0 && ((uintptr_t)out) % 16 == 0,
+                "kv_head_major16: ld must cover G * H * dh and be a multiple of 4; 16-byte aligned pointers");
+  const int64_t total = (int64_t)G * B * H * T * (dh / 8);
+  const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+  MI355_CLEAR_ERROR();
+  hipLaunchKernelGGL(kv_head_major16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, kv, kv_bstride, (int)ld, (int)B, (int)T, (int)G, (int)H, (int)dh, (uint4*)out,
+                     out_dtype == MI355_KV_BF16 ? 1 : 0);
+  MI355_LAUNCH_CHECK("kv_head_major16");
+  return MI355_OK;
+}
+
 extern "C" int mi355_broadcast_rows(const float* v, int32_t ldv, int32_t C, float* y, int64_t y_bstride, int32_t ldy,
                                     int32_t L, const int32_t* lens, int32_t B, void* stream) {
   MI355_REQUIRE(v && y && B > 0 && L > 0 && C > 0, "broadcast_rows: bad arguments");

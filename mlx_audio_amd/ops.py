@@ -758,6 +758,17 @@ def gemv_split_workspace(device, n: int, k: int):
 KV_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}  # MI355_KV_F32 / MI355_KV_BF16 / MI355_KV_F16
 
 
+def kv_head_major16(kv: torch.Tensor, groups: int, heads: int, dh: int, dtype: torch.dtype) -> torch.Tensor:
+    """float32 ``kv[B, T, >= groups * heads * dh]`` (k | v projection rows) -> ``[groups, B, heads, T, dh]`` in ``dtype`` (float16 / bfloat16): the head-major 16-bit
+    blocks the decode-step attention streams, in one pass (``mi355_kv_head_major16``)."""
+    B, T, C, bs, ld = _nlc(kv)
+    assert C >= groups * heads * dh and dtype in (torch.float16, torch.bfloat16)
+    out = torch.empty((groups, B, heads, T, dh), dtype=dtype, device=kv.device)
+    lib = _lib.load()
+    _lib.check(lib.mi355_kv_head_major16(_ptr(kv), bs, ld, B, T, groups, heads, dh, _ptr(out), KV_DTYPES[dtype], _stream()), "mi355_kv_head_major16")
+    return out
+
+
 def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, heads: int, kv_heads: Optional[int] = None,
                     dh: int, scale: Optional[float] = None, causal: bool = False, window: int = 0, lens_q=None, lens_k=None,
                     mode: int = 0, k_start=None, head_major: bool = False, nsplit: int = 0, fused: Optional[dict] = None):

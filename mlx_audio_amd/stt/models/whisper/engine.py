@@ -233,6 +233,11 @@ class WhisperEngine:
             # with heads packed inside 12 KB rows a head's keys are 6 KB apart -- they all land on the same one or two L2 channels
             # ... and in the checkpoint's 16-bit type, as the reference keeps them (whisper.py:360-361: k, v of the cross-attention are computed
             # once in the model dtype and cached): the decode step is bound by streaming these 2 x B x 1500 x n_state values per layer
+            if self.kv_dtype != torch.float32 and dh % 8 == 0:   # one pass: float32 rows -> the two 16-bit head-major blocks
+                blocks = ops.kv_head_major16(ckv, 2, H, dh, self.kv_dtype)
+                st["cross_k"].append(blocks[0])
+                st["cross_v"].append(blocks[1])
+                continue
             st["cross_k"].append(ckv[:, :, :nt].reshape(B, T, H, dh).permute(0, 2, 1, 3).to(self.kv_dtype).contiguous())
             st["cross_v"].append(ckv[:, :, nt:].reshape(B, T, H, dh).permute(0, 2, 1, 3).to(self.kv_dtype).contiguous())
         return st

@@ -863,3 +863,18 @@ def test_rows_pipeline_fp8_tile_image(ops, M, N, K, glu, fused):
         torch.cuda.synchronize()
         got = y.cpu()
     assert rel_err(got, exp) < 3e-5, rel_err(got, exp)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,T,H,dh,pad", [(3, 77, 4, 64, 0), (2, 1500, 12, 64, 0), (2, 33, 2, 128, 32)])
+def test_kv_head_major16_equals_the_permute_and_convert_passes(ops, dt, B, T, H, dh, pad):
+    """mi355_kv_head_major16: the k | v projection rows [B, T, 2 H dh] -> two 16-bit head-major blocks [2, B, H, T, dh] in one pass, element for element what the reference's
+    reshape / transpose / astype leave (whisper.py:360-365)."""
+    g = torch.Generator().manual_seed(T + H)
+    C = 2 * H * dh
+    kv = torch.randn((B, T, C + pad), generator=g).to(DEV)[:, :, :C]
+    got = ops.kv_head_major16(kv, 2, H, dh, dt)
+    torch.cuda.synchronize()
+    exp = kv.reshape(B, T, 2, H, dh).permute(2, 0, 3, 1, 4).to(dt)
+    assert got.shape == (2, B, H, T, dh) and got.is_contiguous()
+    assert torch.equal(got, exp)
