@@ -74,7 +74,7 @@ def main():
     if args.big_gemm:
         W = 6128128
         shapes = [(768, 2304, 1, 1, 1500, "plain"), (768, 768, 1, 1, 1500, "plain+res"), (768, 3072, 1, 1, 1500, "plain"), (3072, 768, 1, 1, 1500, "plain+res")]
-        variants = [("p2_bf16_hi_lo", W), ("p3_fp16_one_pass", W), ("p4_fp16_hi_lo", W), ("p2_masked_producers", 20000000 + W), ("p4_masked_producers", 20000000 + W), ("p2_xsplit", W), ("p4_xsplit", W), ("p4_xsplit_ysplit", W),
+        variants = [("p2_bf16_hi_lo", W), ("p3_fp16_one_pass", W), ("p4_fp16_hi_lo", W), ("p2_masked_producers", 20000000 + W), ("p4_masked_producers", 20000000 + W), ("p4_noprio", 10000000 + W), ("p4_1tile_per_wg", 80000000 + W), ("p2_xsplit", W), ("p4_xsplit", W), ("p4_xsplit_ysplit", W),
                     ("p2_abl1_noBload", 100000000 + W), ("p2_abl4_noProducer", 400000000 + W), ("p2_abl5_noBload_noProducer", 500000000 + W)]
     if args.quick:
         shapes = [(128, 128, 11, 1, 31681, "snake+res"), (128, 128, 3, 1, 31681, "snake+res")]
