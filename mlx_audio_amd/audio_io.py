@@ -81,6 +81,8 @@ def _encode_ffmpeg(pcm: np.ndarray, samplerate: int, nch: int, fmt: str, bitrate
         cmd += ["-c:a", "libopus", "-b:a", bitrate]
     elif fmt in ("ogg", "vorbis"):
         cmd += ["-c:a", "flac"]
+    if fmt in ("m4a", "aac"):   # the MP4-family muxer wants seekable output; on a pipe it needs fragmented output with the moov atom up front
+        cmd += ["-movflags", "frag_keyframe+empty_moov"]
     cmd += ["-f", "ogg" if fmt == "vorbis" else ("ipod" if fmt in ("m4a", "aac") else fmt), "pipe:1"]
     r = subprocess.run(cmd, input=np.ascontiguousarray(pcm).astype("<i2").tobytes(), capture_output=True)
     if r.returncode != 0:

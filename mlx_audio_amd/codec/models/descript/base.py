@@ -78,7 +78,10 @@ class CodecMixin:
             signal, sr = audio_read(audio_path)
         if sr != self.sample_rate:
             raise ValueError(f"Sample rate of the audio signal ({sr}) does not match the sample rate of the model ({self.sample_rate}).")
-        x = torch.as_tensor(np.asarray(signal), dtype=torch.float32).reshape(-1)
+        arr = np.asarray(signal)
+        if arr.ndim > 1 and min(arr.shape) > 1:   # (the reference fails on such input too; flattening [frames, channels] would interleave the channels into one stream)
+            raise ValueError(f"compress() takes a mono signal; got an array of shape {arr.shape} -- encode each channel separately")
+        x = torch.as_tensor(arr, dtype=torch.float32).reshape(-1)
         nt = x.numel()
         duration = nt / sr
         keep = self.padding

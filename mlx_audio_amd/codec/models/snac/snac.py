@@ -209,7 +209,10 @@ class _Quantizer:
                 cb = w[f"quantizer.quantizers.{i}.codebook.weight"].float()
                 cn = cb / torch.clamp(torch.sqrt((cb * cb).sum(1, keepdim=True)), min=1e-12)      # normalize() of vq.py:140-143
                 t = cn[None].contiguous()
-                self.search.append((t.to(device), t.transpose(1, 2).contiguous().to(device), ((t * t).sum(-1) / 2).contiguous().to(device)))
+                # |c|^2 / 2 of an L2-normalised row is the CONSTANT 0.5: with it the arg-min of the score is exactly the arg-max of the cosine whatever |e| is (the float32
+                # rounding spread of a computed |c|^2, ~1e-7, would bias the decision by 1e-7 / |e| for small-norm residual projections: ADVICE r5); an all-zero row keeps 0
+                half = torch.where((cb * cb).sum(1) > 1e-24, torch.full((cb.shape[0],), 0.5), ((t * t).sum(-1) / 2)[0])[None].contiguous()
+                self.search.append((t.to(device), t.transpose(1, 2).contiguous().to(device), half.to(device)))
             self.codebook_dim = self.search[0][0].shape[2]
             self.neg_table = (-self.table).contiguous()
 

@@ -33,3 +33,18 @@ def test_s3_and_voxtral_restatements_match_reference_run():
     a = REF["audio"]
     _close(dsp_ref.s3_log_mel(a, padding=160), REF["s3"], 2e-5)
     _close(dsp_ref.voxtral_log_mel(a), REF["voxtral"], 2e-5)
+
+
+def test_voxtral_mel_rejects_a_foreign_filter_bank():
+    """``compute_mel_spectrogram`` applies its own device copy of the 16 kHz / 0-8000 Hz Slaney bank; a caller's different bank must fail loudly, not be
+    silently replaced (the check runs before any device work)."""
+    import pytest
+    import torch
+
+    from mlx_audio_amd.stt.models.voxtral_realtime import audio as A
+
+    fb = A.compute_mel_filters(128, 400, 16000)
+    with pytest.raises(ValueError, match="differs from the built-in"):
+        A.compute_mel_spectrogram(torch.zeros(1600), fb * 1.01)
+    with pytest.raises(ValueError, match="differs from the built-in"):
+        A.compute_mel_spectrogram(torch.zeros(1600), torch.from_numpy(fb[:, ::-1].copy()))

@@ -832,6 +832,40 @@ def test_conv_ws4_fused_statistics_identical_rows_repeatable(ops, L, C, K, prec)
             assert torch.equal(y, first[0]) and torch.equal(st, first[1]), rep
 
 
+@pytest.mark.parametrize("L,C,K", [(264, 512, 3), (5280, 128, 7)])
+def test_conv_ws4_ext_partials_identical_rows_repeatable(ops, L, C, K):
+    """The same gate for the per-block EXTREMA a quantising conv leaves (ext_partial, round 5): they are produced next to the fused statistics by the same
+    xor-32 exchange pattern.  B identical rows, several launches: every row carries the same (min, max) partials, run after run, and they are the
+    extrema of the stored output."""
+    g = torch.Generator().manual_seed(4)
+    B = 64 if L < 1000 else 4
+    w = bf16r(torch.randn(C, K, C, generator=g) / math.sqrt(K * C))
+    pc = ops.pack_conv(w, torch.randn(C, generator=g) * 0.1, DEV)
+    x = torch.randn(1, L, C, generator=g).expand(B, -1, -1).contiguous().to(DEV)
+    sc = (torch.rand(1, C, generator=g) + 0.5).expand(B, -1).contiguous().to(DEV)
+    sh = (torch.randn(1, C, generator=g) * 0.1).expand(B, -1).contiguous().to(DEV)
+    lens = torch.full((B,), L, dtype=torch.int32, device=DEV)
+    kw = dict(pre=(sc, sh), pre_act=ops.ACT_LEAKY, pre_slope=0.2)
+    assert ops.conv_ext_supported(x, pc, B=B, lout=L, pre_act=ops.ACT_LEAKY)
+    mm = ops.fake_quant_extrema(x, lens=lens, **kw)
+    nblk = (L + 63) // 64
+    first = None
+    for rep in range(4):
+        y = torch.zeros(B, L, C, device=DEV)
+        ext = ops.new_ext(B, L, C, DEV)
+        ext.fill_(float("nan"))
+        ops.conv_gemm(x, pc, y, pad=(K - 1) // 2, lens_in=lens, lens_out=lens, pre_fq=mm, ext=ext, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y[0:1].expand_as(y)) and torch.equal(ext, ext[0:1].expand_as(ext)), rep
+        if first is None:
+            first = (y.clone(), ext.clone())
+            for e in range(nblk):
+                blk = y[0, e * 64:min(L, (e + 1) * 64)]
+                assert torch.equal(ext[0, e, :, 0], blk.min(0).values) and torch.equal(ext[0, e, :, 1], blk.max(0).values), e
+        else:
+            assert torch.equal(y, first[0]) and torch.equal(ext, first[1]), rep
+
+
 @pytest.mark.parametrize("mode,n_fft,hop,n_mels", [(0, 400, 160, 80), (4, 512, 160, 80), (2, 512, 512, 23), (3, 1024, 256, 100), (1, 1024, 256, 128)])
 def test_fast_logmel_silent_tiles_are_bit_identical_to_the_full_path(ops, monkeypatch, mode, n_fft, hop, n_mels):
     """Tiles whose samples are all zero skip their transforms in csrc/fft_fast.h and write the clamp floor's logarithm directly.  The outputs must be
